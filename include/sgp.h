@@ -1,0 +1,307 @@
+/*
+ * sgp.h -- C ABI of the MI355X-native rigid-body stepper that sits behind Substrata's
+ *          PhysicsWorld / PhysicsObject facade.
+ *
+ * Every entry point replaces one piece of the reference's physics facade, which today forwards to
+ * JoltPhysics v5.3.0 (an un-vendored dependency).  Citations are relative to /root/reference.
+ * There is no FFI seam in the reference: the boundary is the C++ class `PhysicsWorld`
+ * (gui_client/PhysicsWorld.h:98-218).  This header is what a thin `PhysicsWorld.cpp` binds instead
+ * of `#include <Jolt/...>`; INTEGRATION.md shows that binding.
+ *
+ * Conventions
+ *   - every function returns an int status: SGP_OK (0) or a negative SGP_ERR_* code; nothing throws;
+ *   - plain pointers and sizes only; all buffers are caller-owned host memory unless a parameter is
+ *     documented as a device pointer;
+ *   - one world per handle; calls on one world are externally synchronised (the reference calls the
+ *     facade from the main thread only, PhysicsWorld.h:135 / GUIClient.cpp:6365-6515);
+ *   - z is up, gravity defaults to (0,0,-9.81)                       (PhysicsWorld.cpp:520);
+ *   - quaternions are (x,y,z,w), same memory order as Quatf / JPH::Quat (JoltUtils.h:48-56);
+ *   - all arithmetic is fp32 (Jolt is built single precision; dt arrives as double and is narrowed,
+ *     PhysicsWorld.cpp:1363).
+ *
+ * There is NO CPU fallback: every function that needs the device returns SGP_ERR_NO_DEVICE when no
+ * gfx950 GPU is usable.
+ */
+#ifndef SGP_H
+#define SGP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGP_ABI_VERSION 1
+
+/* ---- status codes ---------------------------------------------------------------------------- */
+#define SGP_OK                 0
+#define SGP_ERR_INVALID       -1   /* bad argument / NULL handle                                   */
+#define SGP_ERR_NO_DEVICE     -2   /* no usable HIP device (never falls back to the CPU)            */
+#define SGP_ERR_CAPACITY      -3   /* max_bodies exceeded (cf. cMaxBodies, PhysicsWorld.cpp:492)    */
+#define SGP_ERR_HIP           -4   /* a HIP runtime call failed; see sgp_last_error()               */
+#define SGP_ERR_BAD_ID        -5   /* body id is not live                                           */
+#define SGP_ERR_REJECTED      -6   /* addObject's silent rejections (PhysicsWorld.cpp:1178-1189)    */
+
+/* ---- enums (values are ABI) ------------------------------------------------------------------ */
+/* Motion type: JPH::EMotionType as chosen at PhysicsWorld.cpp:1209-1217. */
+#define SGP_MOTION_STATIC      0
+#define SGP_MOTION_KINEMATIC   1
+#define SGP_MOTION_DYNAMIC     2
+
+/* Object layers: namespace Layers, PhysicsWorld.h:67-74; collide matrix PhysicsWorld.cpp:151-189. */
+#define SGP_LAYER_NON_MOVING                 0
+#define SGP_LAYER_MOVING                     1
+#define SGP_LAYER_NON_MOVING_NON_COLLIDABLE  2
+#define SGP_LAYER_MOVING_NON_COLLIDABLE      3
+#define SGP_NUM_LAYERS                       4
+
+/* Shapes the stepper collides natively.  Sizes are FINAL (scale already applied by the caller):
+ *   SPHERE : p[0] = radius                      (unit sphere r=0.5 * scale.x, PhysicsWorld.cpp:1221-1227)
+ *   BOX    : p[0..2] = half extents             (unit cube half 0.5 * scale,  PhysicsWorld.cpp:1249-1255;
+ *                                                ground quad (w/2,w/2,0.5),   PhysicsWorld.cpp:1123)
+ *   CAPSULE: p[0] = radius, p[1] = half height of the cylinder part, axis = local z
+ *                                               (player capsule, PlayerPhysics.cpp:31-32,74)            */
+#define SGP_SHAPE_SPHERE   0
+#define SGP_SHAPE_BOX      1
+#define SGP_SHAPE_CAPSULE  2
+
+#define SGP_INVALID_ID 0xFFFFFFFFu   /* JPH::BodyID() default = invalid (PhysicsObject.h:106)        */
+
+/* ---- settings: Jolt v5.3.0 PhysicsSettings defaults (Substrata never overrides them) ----------- */
+typedef struct sgp_settings {
+	int32_t num_velocity_steps;              /* 10   */
+	int32_t num_position_steps;              /* 2    */
+	float   baumgarte;                       /* 0.2  */
+	float   penetration_slop;                /* 0.02 */
+	float   speculative_contact_distance;    /* 0.02 */
+	float   min_velocity_for_restitution;    /* 1.0  */
+	float   max_penetration_distance;        /* 0.2  */
+	float   time_before_sleep;               /* 0.5  */
+	float   point_velocity_sleep_threshold;  /* 0.03 */
+	float   contact_point_preserve_lambda_max_dist_sq; /* 0.01^2 */
+	float   max_linear_velocity;             /* 500  */
+	float   max_angular_velocity;            /* 0.25*pi*60 */
+	int32_t allow_sleeping;                  /* 1    */
+	int32_t warm_start;                      /* 1    */
+} sgp_settings;
+
+typedef struct sgp_world_desc {
+	uint32_t max_bodies;        /* capacity; reference: 65536 (PhysicsWorld.cpp:492)                 */
+	uint32_t max_body_pairs;    /* 0 = 16*max_bodies+1024; reference: 65536 in flight (:501)          */
+	uint32_t max_manifolds;     /* 0 = 8*max_bodies+1024;  reference: 10240 constraints (:506)        */
+	int32_t  device;            /* HIP device ordinal                                                 */
+	float    gravity[3];        /* (0,0,-9.81)                                                        */
+	float    large_body_radius; /* bodies with bounding radius above this skip the hashed grid; 0 = 4 m */
+	sgp_settings settings;
+} sgp_world_desc;
+
+/* One body, as PhysicsWorld::addObject builds it (PhysicsWorld.cpp:1169-1311). */
+typedef struct sgp_body_desc {
+	float    pos[3];
+	float    rot[4];            /* x,y,z,w */
+	float    lin_vel[3];
+	float    ang_vel[3];
+	int32_t  shape_type;        /* SGP_SHAPE_* */
+	float    shape[4];          /* see SGP_SHAPE_* */
+	int32_t  motion_type;       /* SGP_MOTION_* */
+	int32_t  layer;             /* SGP_LAYER_* */
+	float    mass;              /* clamped to >= 0.001 (PhysicsWorld.cpp:1238); inertia from shape+mass */
+	float    friction;          /* clamped to [0,1] (:1236) */
+	float    restitution;       /* clamped to [0,1] (:1237) */
+	float    gravity_factor;    /* Jolt default 1 */
+	float    linear_damping;    /* Jolt default 0.05 */
+	float    angular_damping;   /* Jolt default 0.05 */
+	int32_t  is_sensor;         /* mIsSensor (:1235) */
+	int32_t  allow_sleeping;    /* Jolt default 1 */
+	int32_t  activate;          /* reference adds with EActivation::DontActivate, then activateObject() */
+	int32_t  use_zero_linear_drag; /* PhysicsObject::use_zero_linear_drag (buoyancy, PhysicsWorld.cpp:1405) */
+	uint64_t userdata;          /* mUserData = (uint64)PhysicsObject* (:1241) */
+} sgp_body_desc;
+
+/* Read-back record for one body (what GUIClient.cpp:6581-6690 pulls per active object). */
+typedef struct sgp_body_state {
+	float    pos[3];
+	float    rot[4];
+	float    lin_vel[3];
+	float    ang_vel[3];
+	uint32_t active;            /* 1 = awake */
+	uint32_t underwater;        /* PhysicsObject::underwater */
+	float    submerged_volume;  /* PhysicsObject::last_submerged_volume */
+	uint32_t id;
+} sgp_body_state;
+
+/* Event kinds for sgp_world_drain_events. */
+#define SGP_EVENT_ACTIVATED         0  /* OnBodyActivated   (PhysicsWorld.cpp:1448-1467)  payload: sgp_body_event    */
+#define SGP_EVENT_DEACTIVATED       1  /* OnBodyDeactivated (PhysicsWorld.cpp:1471-1486)  payload: sgp_body_event    */
+#define SGP_EVENT_ENTERED_WATER     2  /* physicsObjectEnteredWater (:1416-1420)          payload: sgp_body_event    */
+#define SGP_EVENT_CONTACT_ADDED     3  /* OnContactAdded     (:1499-1503)                 payload: sgp_contact_event */
+#define SGP_EVENT_CONTACT_PERSISTED 4  /* OnContactPersisted (:1516-1520)                 payload: sgp_contact_event */
+
+typedef struct sgp_body_event {
+	uint32_t id;
+	uint32_t _pad;
+	uint64_t userdata;
+} sgp_body_event;
+
+/* What GUIClient::contactAdded/Persisted read from JPH::Body / JPH::ContactManifold
+ * (GUIClient.cpp:10588-10632): both linear velocities, mBaseOffset, mRelativeContactPointsOn1. */
+typedef struct sgp_contact_event {
+	uint32_t id1, id2;              /* id1 < id2 */
+	uint64_t userdata1, userdata2;
+	float    lin_vel1[3], lin_vel2[3];
+	float    base_offset[3];        /* = first contact point on body 1 (world) */
+	float    normal[3];             /* from body 1 to body 2 */
+	uint32_t num_points;            /* 1..4 */
+	float    rel_points_on1[4][3];  /* relative to base_offset */
+	float    penetration;           /* max over points, > 0 if overlapping */
+} sgp_contact_event;
+
+typedef struct sgp_ray {
+	float    origin[3];
+	float    dir[3];           /* unit */
+	float    max_t;
+	uint32_t ignore_id;        /* JPH::BodyID ignore_body_id (PhysicsWorld.h:178) */
+	uint32_t collidable_only;  /* traceRayAgainstCollidableObs (PhysicsWorld.cpp:1711-1715) */
+} sgp_ray;
+
+typedef struct sgp_hit {
+	uint32_t id;               /* SGP_INVALID_ID if no hit */
+	float    t;                /* RayTraceResult::hit_t */
+	float    normal[3];        /* RayTraceResult::hit_normal_ws */
+	uint64_t userdata;         /* -> RayTraceResult::hit_object */
+} sgp_hit;
+
+/* Counters of the last step (getDiagnostics, PhysicsWorld.cpp:1578-1604, plus stage sizes). */
+typedef struct sgp_step_stats {
+	uint32_t num_bodies;
+	uint32_t num_active;
+	uint32_t num_pairs;
+	uint32_t num_manifolds;
+	uint32_t num_contact_points;
+	uint32_t num_colours;
+	uint32_t num_colour_rounds;
+	uint32_t num_overflow_constraints;
+	uint32_t pairs_dropped;
+	uint32_t manifolds_dropped;
+	uint32_t num_activated;
+	uint32_t num_deactivated;
+	uint32_t layer_counts[SGP_NUM_LAYERS];
+	uint64_t device_bytes;
+} sgp_step_stats;
+
+/* Per-stage device time of the last profiled step, measured with HIP events on the world's stream. */
+#define SGP_STAGE_APPLY_FORCES   0
+#define SGP_STAGE_BROADPHASE     1
+#define SGP_STAGE_NARROWPHASE    2
+#define SGP_STAGE_SETUP          3   /* islands, colouring, constraint setup + cache match */
+#define SGP_STAGE_SOLVE_VELOCITY 4
+#define SGP_STAGE_INTEGRATE      5   /* the body-array sweep (pose integrate + AABB)  */
+#define SGP_STAGE_SOLVE_POSITION 6
+#define SGP_STAGE_FINALIZE       7   /* AABB refresh, sleep test, islands sleep, buoyancy, events */
+#define SGP_NUM_STAGES           8
+
+typedef struct sgp_step_profile {
+	float    stage_ms[SGP_NUM_STAGES];
+	float    total_ms;
+	float    sweep_kernel_ms;       /* duration of ONE launch of the integrate+AABB body sweep */
+	uint32_t sweep_bodies;          /* bodies that launch advanced */
+	float    solve_kernel_ms_avg;   /* average launch of the velocity-solve kernel */
+	uint32_t solve_launches;
+} sgp_step_profile;
+
+typedef struct sgp_world sgp_world;
+
+/* ---- lifecycle ------------------------------------------------------------------------------- */
+/* PhysicsWorld::init() (PhysicsWorld.cpp:250-273): once per process. Returns the device count found. */
+int  sgp_init(void);
+int  sgp_abi_version(void);
+const char* sgp_last_error(void);
+void sgp_default_settings(sgp_settings* out);
+void sgp_default_world_desc(sgp_world_desc* out);
+void sgp_default_body_desc(sgp_body_desc* out);
+/* PhysicsWorld ctor / dtor (PhysicsWorld.cpp:462-543). */
+int  sgp_world_create(const sgp_world_desc* desc, sgp_world** out);
+int  sgp_world_destroy(sgp_world* w);
+
+/* ---- bodies ---------------------------------------------------------------------------------- */
+/* addObject (PhysicsWorld.cpp:1169-1311).  Returns SGP_ERR_REJECTED for |pos|>1e9 etc. */
+int  sgp_body_add(sgp_world* w, const sgp_body_desc* d, uint32_t* id_out);
+int  sgp_body_add_batch(sgp_world* w, const sgp_body_desc* d, uint32_t n, uint32_t* ids_out);
+/* removeObject (:1315-1339) */
+int  sgp_body_remove(sgp_world* w, uint32_t id);
+/* activateObject (:1342-1346) */
+int  sgp_body_activate(sgp_world* w, uint32_t id);
+/* setObjectLayer (:1349-1353) */
+int  sgp_body_set_layer(sgp_world* w, uint32_t id, int32_t layer);
+/* setNewObToWorldTransform(pos,rot,linvel,angvel) (:607-620); SetPositionRotationAndVelocity. Does not activate. */
+int  sgp_body_set_pose_vel(sgp_world* w, uint32_t id, const float pos[3], const float rot[4],
+                           const float lin_vel[3], const float ang_vel[3]);
+/* setNewObToWorldTransform(pos,rot,scale) (:546-604): zero velocity, new final shape size, activates. */
+int  sgp_body_set_pose_shape(sgp_world* w, uint32_t id, const float pos[3], const float rot[4],
+                             const float shape[4]);
+/* setNewPosition (:623-633): SetPosition, DontActivate. */
+int  sgp_body_set_pos(sgp_world* w, uint32_t id, const float pos[3]);
+/* setLinearAndAngularVelToZero (:649-657) */
+int  sgp_body_set_vel(sgp_world* w, uint32_t id, const float lin_vel[3], const float ang_vel[3]);
+/* moveKinematicObject (:707-722): BodyInterface::MoveKinematic; no-op for non-kinematic bodies. */
+int  sgp_body_move_kinematic(sgp_world* w, uint32_t id, const float target_pos[3], const float target_rot[4], float dt);
+/* BodyInterface::AddForce / AddTorque / AddForce(at point) used by HoverCarPhysics.cpp:113-348, BoatPhysics.cpp:221-267.
+ * Accumulate until the next step, then cleared. Activate the body. */
+int  sgp_body_add_force(sgp_world* w, uint32_t id, const float force[3]);
+int  sgp_body_add_force_at(sgp_world* w, uint32_t id, const float force[3], const float point[3]);
+int  sgp_body_add_torque(sgp_world* w, uint32_t id, const float torque[3]);
+/* getObjectLinearVelocity (:636-646), getPosInJolt (:1625-1632), GUIClient.cpp:6588,6673 read-back. */
+int  sgp_body_get_state(sgp_world* w, const uint32_t* ids, uint32_t n, sgp_body_state* out);
+/* All live bodies in id order [first, first+n). Slots that are not live get id = SGP_INVALID_ID. */
+int  sgp_world_read_states(sgp_world* w, uint32_t first, uint32_t n, sgp_body_state* out);
+/* The per-frame read-back loop (GUIClient.cpp:6581-6690): compacted states of every ACTIVE body. */
+int  sgp_world_read_active(sgp_world* w, sgp_body_state* out, uint32_t cap, uint32_t* n_out);
+
+/* ---- world state ----------------------------------------------------------------------------- */
+/* setWaterBuoyancyEnabled / setWaterZ (PhysicsWorld.h:109-112) */
+int  sgp_world_set_water(sgp_world* w, int enabled, float water_z);
+/* Enable capture of contact added/persisted events (only needed when an event_listener is set). */
+int  sgp_world_set_contact_events(sgp_world* w, int enabled);
+/* think(dt) (PhysicsWorld.cpp:1356-1443): one PhysicsSystem::Update with 1 collision step + buoyancy sweep.
+ * Blocks until the step has finished on the device. */
+int  sgp_world_step(sgp_world* w, float dt);
+/* Same, n steps back to back with a single host sync at the end (GUIClient's sub-step loop, GUIClient.cpp:6382). */
+int  sgp_world_step_n(sgp_world* w, float dt, uint32_t n);
+/* Same as sgp_world_step but brackets every stage with HIP events on the world's stream. */
+int  sgp_world_step_profiled(sgp_world* w, float dt, sgp_step_profile* out);
+int  sgp_world_stats(sgp_world* w, sgp_step_stats* out);
+/* activated_obs / newly_activated_obs maintenance + listener callbacks (PhysicsWorld.h:194-200). */
+int  sgp_world_drain_events(sgp_world* w, int kind, void* out, uint32_t cap, uint32_t* n_out);
+/* getNumObjects (:1635-1638) */
+int  sgp_world_num_bodies(sgp_world* w, uint32_t* n_out);
+
+/* ---- queries --------------------------------------------------------------------------------- */
+/* traceRay / traceRayAgainstCollidableObs / doesRayHitAnything (PhysicsWorld.cpp:1668-1725), batched. */
+int  sgp_raycast(sgp_world* w, const sgp_ray* rays, uint32_t n, sgp_hit* hits_out);
+
+/* ---- multi-GPU tiles: ghost bodies are ordinary kinematic-like bodies owned elsewhere ---- */
+/* Pack the ghost record of every owned body whose AABB, inflated by `margin`, crosses outside [lo,hi). */
+typedef struct sgp_ghost_record {
+	float    pos[3];  float rot[4];  float lin_vel[3];  float ang_vel[3];
+	int32_t  shape_type;  float shape[4];
+	float    mass;  float friction;  float restitution;
+	uint32_t motion_type;
+	uint64_t global_id;
+} sgp_ghost_record;
+int  sgp_world_export_boundary(sgp_world* w, const float lo[3], const float hi[3], float margin,
+                               sgp_ghost_record* out, uint32_t cap, uint32_t* n_out);
+/* Replace this world's ghost set with `n` records (bodies simulated as velocity-driven, infinite mass). */
+int  sgp_world_import_ghosts(sgp_world* w, const sgp_ghost_record* in, uint32_t n);
+
+/* ---- device-resident bulk access (bench / torch plumbing; pointers are HIP device pointers) ---- */
+/* Raw SoA views of the body arrays, valid until the world is destroyed:
+ * which = 0 pos_invmass(float4), 1 rot(float4), 2 lin_vel(float4), 3 ang_vel(float4). */
+int  sgp_world_device_array(sgp_world* w, int which, void** dev_ptr_out, uint32_t* count_out);
+/* hipStream_t the world launches on (as void*). */
+int  sgp_world_stream(sgp_world* w, void** stream_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGP_H */

@@ -1,0 +1,62 @@
+"""ORACLE loader (test infrastructure).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import this module; the product package substrata_amd never does.
+
+Binds oracle/libsgo_oracle.so (plain-C restatement of PhysicsWorld::think, see sgo_oracle.c) to the same thin
+ctypes driver the product uses, so parity tests issue identical calls to both.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+from substrata_amd import abi
+from substrata_amd.world import CWorld
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libsgo_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in ("sgo_oracle.c", "sgo_collide.h", "sgo_math.h")]
+    srcs.append(os.path.join(_HERE, "..", "include", "sgp.h"))
+    if not force and os.path.exists(_LIB_PATH) and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+        return _LIB_PATH
+    subprocess.run(["make", "-C", _HERE, "-B", "libsgo_oracle.so"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        abi.bind(_lib, "sgo_")
+        _lib.sgo_collide_pair.restype = C.c_int
+        _lib.sgo_collide_pair.argtypes = [C.POINTER(abi.BodyDesc), C.POINTER(abi.BodyDesc), C.c_float, C.c_void_p,
+                                          C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
+        _lib.sgo_layers_collide.restype = C.c_int
+        _lib.sgo_layers_collide.argtypes = [C.c_int, C.c_int]
+    return _lib
+
+
+class OracleWorld(CWorld):
+    def __init__(self, **kw):
+        super().__init__(lib(), "sgo_", **kw)
+
+
+def collide_pair(a, b, max_sep=0.02):
+    """Narrow phase of the oracle on two body descs. Returns (normal, p1[np,3], p2[np,3]) or None."""
+    n = np.zeros(3, np.float32)
+    p1 = np.zeros((8, 3), np.float32)
+    p2 = np.zeros((8, 3), np.float32)
+    npts = C.c_int(0)
+    hit = lib().sgo_collide_pair(C.byref(a), C.byref(b), float(max_sep), n.ctypes.data, C.byref(npts), p1.ctypes.data,
+                                 p2.ctypes.data)
+    if not hit:
+        return None
+    return n, p1[:npts.value].copy(), p2[:npts.value].copy()
+
+
+def layers_collide(l1, l2):
+    return bool(lib().sgo_layers_collide(int(l1), int(l2)))

@@ -1,0 +1,1405 @@
+/*
+ * sgo_oracle.c -- THE ORACLE.  Test infrastructure only: nothing under substrata_amd/ may include,
+ * link or call this file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it.
+ *
+ * What it restates.  PhysicsWorld::think(dt)  (/root/reference/gui_client/PhysicsWorld.cpp:1356-1443):
+ *     physics_system->Update((float)dt, cCollisionSteps = 1, ...)          :1359-1363
+ *     then the water-buoyancy sweep over activated dynamic bodies           :1367-1442
+ * The arithmetic of Update() lives in JoltPhysics v5.3.0 (scripts/get_libs.rb:29-40), which is NOT in
+ * /root/reference and not on this machine.  This file therefore restates Jolt's published step
+ * (PhysicsSystem::Update: apply forces -> find collisions -> contact constraints with a contact cache ->
+ * sequential-impulse velocity solve -> integrate -> position solve -> island sleeping) from upstream
+ * knowledge, under exactly the configuration Substrata imposes (all citable):
+ *     gravity (0,0,-9.81) :520, one collision step :1359, layer matrix :151-189, body settings :1229-1243,
+ *     unit sphere r 0.5 / unit cube half 0.5 :1221-1255, buoyancy constants :1384-1410,
+ *     Jolt default PhysicsSettings (Substrata never calls SetPhysicsSettings).
+ *
+ * parity unpinned: the reference holds no golden vectors, KATs or fixtures for this path
+ * (PhysicsWorld::test(), :1754-1825, asserts nothing about dynamics) and Jolt cannot be built here, so this
+ * oracle is pinned only by the analytic known-answer tests in tests/test_oracle_kat.py.
+ *
+ * Ordering contract shared with the device implementation (so that results are comparable to fp32 rounding):
+ *   - the set of body pairs / manifolds is order independent;
+ *   - contact constraints are solved colour by colour; colours come from the deterministic round-based
+ *     greedy colouring below (priority = sgp_mix64(pair key)); constraints of one colour share no movable
+ *     body, so their relative order cannot matter.  This is a legal sequential-impulse order (Jolt itself
+ *     batches large islands into non-conflicting splits, LargeIslandSplitter).
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include "../include/sgp.h"
+#include "sgo_collide.h"
+
+#define SGO_API __attribute__((visibility("default")))
+#define SGO_MAX_COLOURS 64
+#define SGO_OVERFLOW_COLOUR 63
+
+typedef struct {
+	v3 pos; quat rot; v3 linv, angv; v3 force, torque;
+	float inv_mass; v3 inv_inertia;
+	int shape_type; float shape[4];
+	int motion, layer;
+	float friction, restitution, gravity_factor, lin_damp, ang_damp, mass;
+	int is_sensor, allow_sleep, zero_lin_drag;
+	uint64_t userdata;
+	int alive, active;
+	v3 aabb_min, aabb_max;
+	v3 sleep_c[3]; float sleep_r[3]; float sleep_timer;
+	int underwater; float submerged;
+	/* per-step scratch */
+	uint64_t colour_mask; uint64_t claim[2];
+	int island; int can_sleep;
+} sgo_body;
+
+typedef struct {
+	v3 r1, r2;           /* world offsets from the centres of mass to the contact mid point */
+	v3 local1, local2;   /* contact point on 1 / 2 in the body frames (cache matching, position solve) */
+	float bias;
+	float eff_n, eff_t1, eff_t2;
+	float lam_n, lam_t1, lam_t2;
+} sgo_point;
+
+typedef struct {
+	uint32_t a, b;       /* a < b */
+	uint64_t key, prio;
+	v3 n, t1, t2;
+	float friction;
+	int np;
+	int colour;
+	int persisted;
+	sgo_point pt[4];
+} sgo_constraint;
+
+typedef struct { uint32_t a, b; } sgo_pair;
+
+typedef struct sgo_world {
+	sgp_world_desc desc;
+	sgp_settings st;
+	v3 gravity;
+	uint32_t cap, high;          /* capacity, high-water slot count */
+	sgo_body* bodies;
+	uint32_t* free_list; uint32_t n_free;
+	uint32_t n_alive;
+	/* pairs / constraints of the current and previous step */
+	sgo_pair* pairs; uint32_t n_pairs, cap_pairs;
+	sgo_constraint* cons; uint32_t n_cons, cap_cons;
+	sgo_constraint* prev; uint32_t n_prev, cap_prev;
+	uint64_t* prev_keys_sorted; uint32_t* prev_idx_sorted;
+	uint32_t* order;            /* constraint indices sorted by (colour, prio) */
+	int water_enabled; float water_z;
+	int contact_events;
+	sgp_step_stats stats;
+	/* events */
+	sgp_body_event* ev_act; uint32_t n_act, cap_act;
+	sgp_body_event* ev_deact; uint32_t n_deact, cap_deact;
+	sgp_body_event* ev_water; uint32_t n_water, cap_water;
+	sgp_contact_event* ev_added; uint32_t n_added, cap_added;
+	sgp_contact_event* ev_pers; uint32_t n_pers, cap_pers;
+	/* broad-phase scratch */
+	uint64_t* cell_keys; uint32_t* cell_idx; uint32_t* large; uint32_t n_large;
+} sgo_world;
+
+/* ------------------------------------------------------------------------------------------------ */
+/* defaults (Jolt v5.3.0 PhysicsSettings / BodyCreationSettings; UNVERIFIED: upstream)                  */
+
+SGO_API void sgo_default_settings(sgp_settings* s)
+{
+	s->num_velocity_steps = 10;
+	s->num_position_steps = 2;
+	s->baumgarte = 0.2f;
+	s->penetration_slop = 0.02f;
+	s->speculative_contact_distance = 0.02f;
+	s->min_velocity_for_restitution = 1.0f;
+	s->max_penetration_distance = 0.2f;
+	s->time_before_sleep = 0.5f;
+	s->point_velocity_sleep_threshold = 0.03f;
+	s->contact_point_preserve_lambda_max_dist_sq = 0.01f * 0.01f;
+	s->max_linear_velocity = 500.0f;
+	s->max_angular_velocity = 0.25f * 3.14159265358979323846f * 60.0f;
+	s->allow_sleeping = 1;
+	s->warm_start = 1;
+}
+
+SGO_API void sgo_default_world_desc(sgp_world_desc* d)
+{
+	memset(d, 0, sizeof(*d));
+	d->max_bodies = 65536;                 /* PhysicsWorld.cpp:492 */
+	d->gravity[0] = 0.0f; d->gravity[1] = 0.0f; d->gravity[2] = -9.81f; /* :520 */
+	d->large_body_radius = 4.0f;
+	sgo_default_settings(&d->settings);
+}
+
+SGO_API void sgo_default_body_desc(sgp_body_desc* d)
+{
+	memset(d, 0, sizeof(*d));
+	d->rot[3] = 1.0f;
+	d->shape_type = SGP_SHAPE_BOX;
+	d->shape[0] = d->shape[1] = d->shape[2] = 0.5f;   /* unit cube, PhysicsWorld.cpp:1249 */
+	d->motion_type = SGP_MOTION_STATIC;                /* PhysicsObject.cpp:28 */
+	d->layer = SGP_LAYER_NON_MOVING;
+	d->mass = 100.0f; d->friction = 0.5f; d->restitution = 0.3f; /* PhysicsObject.cpp:36-38 */
+	d->gravity_factor = 1.0f;
+	d->linear_damping = 0.05f; d->angular_damping = 0.05f;
+	d->allow_sleeping = 1;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* layer matrix: MyObjectLayerPairFilter, PhysicsWorld.cpp:160-189                                     */
+
+static int layers_collide(int l1, int l2)
+{
+	switch (l1) {
+	case SGP_LAYER_NON_MOVING: return l2 == SGP_LAYER_MOVING;
+	case SGP_LAYER_MOVING: return l2 != SGP_LAYER_NON_MOVING_NON_COLLIDABLE && l2 != SGP_LAYER_MOVING_NON_COLLIDABLE;
+	default: return 0;
+	}
+}
+SGO_API int sgo_layers_collide(int l1, int l2) { return layers_collide(l1, l2); }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* mass properties (Jolt Shape::GetMassProperties scaled to the overridden mass, CalculateInertia)      */
+
+static void mass_properties(int type, const float* p, float mass, float* inv_mass, v3* inv_inertia)
+{
+	v3 I;
+	if (type == SGP_SHAPE_SPHERE) {
+		const float i = 0.4f * mass * p[0] * p[0];
+		I = V3(i, i, i);
+	} else if (type == SGP_SHAPE_BOX) {
+		const float sx = 2.0f * p[0], sy = 2.0f * p[1], sz = 2.0f * p[2];
+		const float k = mass / 12.0f;
+		I = V3(k * (sy * sy + sz * sz), k * (sx * sx + sz * sz), k * (sx * sx + sy * sy));
+	} else {
+		/* capsule along z: cylinder (height H = 2 hh) + two hemispheres, uniform density */
+		const float r = p[0], H = 2.0f * p[1];
+		const float vc = 3.14159265358979323846f * r * r * H;
+		const float vs = (4.0f / 3.0f) * 3.14159265358979323846f * r * r * r;
+		const float mc = mass * vc / (vc + vs), ms = mass * vs / (vc + vs);
+		const float iz = 0.5f * mc * r * r + 0.4f * ms * r * r;
+		const float ix = mc * (3.0f * r * r + H * H) / 12.0f
+		               + ms * (0.4f * r * r + 0.25f * H * H + 0.375f * H * r);
+		I = V3(ix, ix, iz);
+	}
+	*inv_mass = 1.0f / mass;
+	*inv_inertia = V3(1.0f / I.x, 1.0f / I.y, 1.0f / I.z);
+}
+
+static float shape_volume(int type, const float* p)
+{
+	if (type == SGP_SHAPE_SPHERE) return (4.0f / 3.0f) * 3.14159265358979323846f * p[0] * p[0] * p[0];
+	if (type == SGP_SHAPE_BOX) return 8.0f * p[0] * p[1] * p[2];
+	return 3.14159265358979323846f * p[0] * p[0] * (2.0f * p[1]) + (4.0f / 3.0f) * 3.14159265358979323846f * p[0] * p[0] * p[0];
+}
+
+/* Local-space half extents of the shape's AABB (Shape::GetLocalBounds). */
+static v3 shape_local_half(int type, const float* p)
+{
+	if (type == SGP_SHAPE_SPHERE) return V3(p[0], p[0], p[0]);
+	if (type == SGP_SHAPE_BOX) return V3(p[0], p[1], p[2]);
+	return V3(p[0], p[0], p[1] + p[0]);
+}
+
+static float shape_bounding_radius(int type, const float* p)
+{
+	if (type == SGP_SHAPE_SPHERE) return p[0];
+	if (type == SGP_SHAPE_BOX) return sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+	return p[0] + p[1];
+}
+
+static void body_update_aabb(sgo_body* b)
+{
+	v3 e;
+	if (b->shape_type == SGP_SHAPE_SPHERE) e = V3(b->shape[0], b->shape[0], b->shape[0]);
+	else {
+		const m33 R = quat_to_m33(b->rot);
+		if (b->shape_type == SGP_SHAPE_BOX) {
+			const float hx = b->shape[0], hy = b->shape[1], hz = b->shape[2];
+			e = V3(fabsf(R.c0.x) * hx + fabsf(R.c1.x) * hy + fabsf(R.c2.x) * hz,
+			       fabsf(R.c0.y) * hx + fabsf(R.c1.y) * hy + fabsf(R.c2.y) * hz,
+			       fabsf(R.c0.z) * hx + fabsf(R.c1.z) * hy + fabsf(R.c2.z) * hz);
+		} else {
+			const float r = b->shape[0], hh = b->shape[1];
+			e = V3(fabsf(R.c2.x) * hh + r, fabsf(R.c2.y) * hh + r, fabsf(R.c2.z) * hh + r);
+		}
+	}
+	b->aabb_min = v3_sub(b->pos, e);
+	b->aabb_max = v3_add(b->pos, e);
+}
+
+/* Body::GetSleepTestPoints: COM plus two points on the two largest local extents. */
+static void body_sleep_points(const sgo_body* b, v3 out[3])
+{
+	const v3 ext = shape_local_half(b->shape_type, b->shape);
+	const m33 R = quat_to_m33(b->rot);
+	int lowest = 0;
+	if (ext.y < v3_get(ext, lowest)) lowest = 1;
+	if (ext.z < v3_get(ext, lowest)) lowest = 2;
+	const int i1 = lowest == 0 ? 1 : 0;
+	const int i2 = lowest == 2 ? 1 : 2;
+	out[0] = b->pos;
+	out[1] = v3_add(b->pos, v3_scale(m33_col(R, i1), v3_get(ext, i1)));
+	out[2] = v3_add(b->pos, v3_scale(m33_col(R, i2), v3_get(ext, i2)));
+}
+
+static void body_reset_sleep(sgo_body* b)
+{
+	v3 p[3];
+	body_sleep_points(b, p);
+	for (int i = 0; i < 3; ++i) { b->sleep_c[i] = p[i]; b->sleep_r[i] = 0.0f; }
+	b->sleep_timer = 0.0f;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* events                                                                                           */
+
+#define PUSH_EVENT(arr, n, cap, type, val) do { \
+	if ((n) == (cap)) { (cap) = (cap) ? (cap) * 2 : 64; (arr) = (type*)realloc((arr), (size_t)(cap) * sizeof(type)); } \
+	(arr)[(n)++] = (val); } while (0)
+
+static void push_body_event(sgo_world* w, int kind, uint32_t id)
+{
+	sgp_body_event e; e.id = id; e._pad = 0; e.userdata = w->bodies[id].userdata;
+	if (kind == SGP_EVENT_ACTIVATED) PUSH_EVENT(w->ev_act, w->n_act, w->cap_act, sgp_body_event, e);
+	else if (kind == SGP_EVENT_DEACTIVATED) PUSH_EVENT(w->ev_deact, w->n_deact, w->cap_deact, sgp_body_event, e);
+	else PUSH_EVENT(w->ev_water, w->n_water, w->cap_water, sgp_body_event, e);
+}
+
+static void body_activate(sgo_world* w, uint32_t id)
+{
+	sgo_body* b = &w->bodies[id];
+	if (!b->alive || b->motion == SGP_MOTION_STATIC) return;
+	if (!b->active) {
+		b->active = 1;
+		push_body_event(w, SGP_EVENT_ACTIVATED, id);
+	}
+	body_reset_sleep(b);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* lifecycle                                                                                        */
+
+SGO_API int sgo_world_create(const sgp_world_desc* desc, sgo_world** out)
+{
+	if (!desc || !out || desc->max_bodies == 0) return SGP_ERR_INVALID;
+	sgo_world* w = (sgo_world*)calloc(1, sizeof(sgo_world));
+	w->desc = *desc;
+	w->st = desc->settings;
+	w->gravity = V3(desc->gravity[0], desc->gravity[1], desc->gravity[2]);
+	w->cap = desc->max_bodies;
+	w->bodies = (sgo_body*)calloc(w->cap, sizeof(sgo_body));
+	w->free_list = (uint32_t*)malloc(sizeof(uint32_t) * w->cap);
+	w->cell_keys = (uint64_t*)malloc(sizeof(uint64_t) * w->cap);
+	w->cell_idx = (uint32_t*)malloc(sizeof(uint32_t) * w->cap);
+	w->large = (uint32_t*)malloc(sizeof(uint32_t) * w->cap);
+	if (w->desc.large_body_radius <= 0.0f) w->desc.large_body_radius = 4.0f;
+	*out = w;
+	return SGP_OK;
+}
+
+SGO_API int sgo_world_destroy(sgo_world* w)
+{
+	if (!w) return SGP_ERR_INVALID;
+	free(w->bodies); free(w->free_list); free(w->pairs); free(w->cons); free(w->prev);
+	free(w->prev_keys_sorted); free(w->prev_idx_sorted); free(w->order);
+	free(w->ev_act); free(w->ev_deact); free(w->ev_water); free(w->ev_added); free(w->ev_pers);
+	free(w->cell_keys); free(w->cell_idx); free(w->large);
+	free(w);
+	return SGP_OK;
+}
+
+static int finite3(const float* v) { return isfinite(v[0]) && isfinite(v[1]) && isfinite(v[2]); }
+
+/* addObject, PhysicsWorld.cpp:1169-1311 */
+SGO_API int sgo_body_add(sgo_world* w, const sgp_body_desc* d, uint32_t* id_out)
+{
+	if (!w || !d) return SGP_ERR_INVALID;
+	if (!finite3(d->pos) || fabsf(d->pos[0]) > 1.0e9f || fabsf(d->pos[1]) > 1.0e9f || fabsf(d->pos[2]) > 1.0e9f) return SGP_ERR_REJECTED; /* :1178 */
+	if (d->shape_type < 0 || d->shape_type > 2) return SGP_ERR_INVALID;
+	const int nparam = d->shape_type == SGP_SHAPE_BOX ? 3 : (d->shape_type == SGP_SHAPE_SPHERE ? 1 : 2);
+	for (int i = 0; i < nparam; ++i) {
+		const float lim = (d->shape_type == SGP_SHAPE_CAPSULE && i == 1) ? 0.0f : 0.5e-7f; /* |scale| < 1e-7 on a 0.5 unit shape, :1184 */
+		if (!isfinite(d->shape[i]) || d->shape[i] < lim) return SGP_ERR_REJECTED;
+	}
+	uint32_t id;
+	if (w->n_free) id = w->free_list[--w->n_free];
+	else { if (w->high >= w->cap) return SGP_ERR_CAPACITY; id = w->high++; }
+	sgo_body* b = &w->bodies[id];
+	memset(b, 0, sizeof(*b));
+	b->pos = V3(d->pos[0], d->pos[1], d->pos[2]);
+	quat q = { d->rot[0], d->rot[1], d->rot[2], d->rot[3] };
+	b->rot = q;
+	b->linv = V3(d->lin_vel[0], d->lin_vel[1], d->lin_vel[2]);
+	b->angv = V3(d->ang_vel[0], d->ang_vel[1], d->ang_vel[2]);
+	b->shape_type = d->shape_type;
+	memcpy(b->shape, d->shape, sizeof(b->shape));
+	b->motion = d->motion_type; b->layer = d->layer;
+	b->friction = clampf(d->friction, 0.0f, 1.0f);         /* :1236 */
+	b->restitution = clampf(d->restitution, 0.0f, 1.0f);   /* :1237 */
+	b->mass = fmaxf(0.001f, d->mass);                      /* :1238 */
+	b->gravity_factor = d->gravity_factor;
+	b->lin_damp = d->linear_damping; b->ang_damp = d->angular_damping;
+	b->is_sensor = d->is_sensor; b->allow_sleep = d->allow_sleeping; b->zero_lin_drag = d->use_zero_linear_drag;
+	b->userdata = d->userdata;
+	if (b->motion == SGP_MOTION_DYNAMIC) mass_properties(b->shape_type, b->shape, b->mass, &b->inv_mass, &b->inv_inertia);
+	else { b->inv_mass = 0.0f; b->inv_inertia = V3(0.0f, 0.0f, 0.0f); }
+	if (b->motion != SGP_MOTION_DYNAMIC) { /* non-dynamic bodies carry no force */ }
+	b->alive = 1; b->active = 0;
+	body_update_aabb(b);
+	body_reset_sleep(b);
+	w->n_alive++;
+	if (d->activate) body_activate(w, id);
+	if (id_out) *id_out = id;
+	return SGP_OK;
+}
+
+SGO_API int sgo_body_add_batch(sgo_world* w, const sgp_body_desc* d, uint32_t n, uint32_t* ids_out)
+{
+	for (uint32_t i = 0; i < n; ++i) {
+		uint32_t id = SGP_INVALID_ID;
+		const int r = sgo_body_add(w, &d[i], &id);
+		if (r != SGP_OK && r != SGP_ERR_REJECTED) return r;
+		if (ids_out) ids_out[i] = (r == SGP_OK) ? id : SGP_INVALID_ID;
+	}
+	return SGP_OK;
+}
+
+static int live(sgo_world* w, uint32_t id) { return w && id < w->high && w->bodies[id].alive; }
+
+SGO_API int sgo_body_remove(sgo_world* w, uint32_t id)
+{
+	if (!live(w, id)) return SGP_ERR_BAD_ID;
+	w->bodies[id].alive = 0; w->bodies[id].active = 0;
+	w->free_list[w->n_free++] = id;
+	w->n_alive--;
+	return SGP_OK;
+}
+SGO_API int sgo_body_activate(sgo_world* w, uint32_t id) { if (!live(w, id)) return SGP_ERR_BAD_ID; body_activate(w, id); return SGP_OK; }
+SGO_API int sgo_body_set_layer(sgo_world* w, uint32_t id, int32_t layer) { if (!live(w, id)) return SGP_ERR_BAD_ID; w->bodies[id].layer = layer; return SGP_OK; }
+
+SGO_API int sgo_body_set_pose_vel(sgo_world* w, uint32_t id, const float pos[3], const float rot[4], const float lv[3], const float av[3])
+{
+	if (!live(w, id)) return SGP_ERR_BAD_ID;
+	sgo_body* b = &w->bodies[id];
+	b->pos = V3(pos[0], pos[1], pos[2]);
+	quat q = { rot[0], rot[1], rot[2], rot[3] }; b->rot = q;
+	if (b->motion != SGP_MOTION_STATIC) { b->linv = V3(lv[0], lv[1], lv[2]); b->angv = V3(av[0], av[1], av[2]); }
+	body_update_aabb(b);
+	return SGP_OK;
+}
+SGO_API int sgo_body_set_pose_shape(sgo_world* w, uint32_t id, const float pos[3], const float rot[4], const float shape[4])
+{
+	if (!live(w, id)) return SGP_ERR_BAD_ID;
+	sgo_body* b = &w->bodies[id];
+	b->pos = V3(pos[0], pos[1], pos[2]);
+	quat q = { rot[0], rot[1], rot[2], rot[3] }; b->rot = q;
+	b->linv = V3(0, 0, 0); b->angv = V3(0, 0, 0);
+	memcpy(b->shape, shape, sizeof(b->shape));   /* inUpdateMassProperties = false, PhysicsWorld.cpp:579 */
+	body_update_aabb(b);
+	body_activate(w, id);
+	return SGP_OK;
+}
+SGO_API int sgo_body_set_pos(sgo_world* w, uint32_t id, const float pos[3])
+{
+	if (!live(w, id)) return SGP_ERR_BAD_ID;
+	w->bodies[id].pos = V3(pos[0], pos[1], pos[2]);
+	body_update_aabb(&w->bodies[id]);
+	return SGP_OK;
+}
+SGO_API int sgo_body_set_vel(sgo_world* w, uint32_t id, const float lv[3], const float av[3])
+{
+	if (!live(w, id)) return SGP_ERR_BAD_ID;
+	if (w->bodies[id].motion == SGP_MOTION_STATIC) return SGP_OK;
+	w->bodies[id].linv = V3(lv[0], lv[1], lv[2]); w->bodies[id].angv = V3(av[0], av[1], av[2]);
+	return SGP_OK;
+}
+/* MotionProperties::MoveKinematic: velocities that reach the target in dt. Host-side maths (acos), like the product. */
+SGO_API int sgo_body_move_kinematic(sgo_world* w, uint32_t id, const float tp[3], const float tr[4], float dt)
+{
+	if (!live(w, id)) return SGP_ERR_BAD_ID;
+	sgo_body* b = &w->bodies[id];
+	if (b->motion != SGP_MOTION_KINEMATIC || dt <= 0.0f) return SGP_OK;
+	b->linv = v3_scale(v3_sub(V3(tp[0], tp[1], tp[2]), b->pos), 1.0f / dt);
+	quat t = { tr[0], tr[1], tr[2], tr[3] };
+	quat c = { -b->rot.x, -b->rot.y, -b->rot.z, b->rot.w };
+	quat dq = quat_mul(t, c);
+	if (dq.w < 0.0f) { dq.x = -dq.x; dq.y = -dq.y; dq.z = -dq.z; dq.w = -dq.w; }
+	const float sl = sqrtf(dq.x * dq.x + dq.y * dq.y + dq.z * dq.z);
+	if (sl > 1.0e-12f) {
+		const float angle = 2.0f * atan2f(sl, dq.w);
+		b->angv = v3_scale(V3(dq.x / sl, dq.y / sl, dq.z / sl), angle / dt);
+	} else b->angv = V3(0, 0, 0);
+	body_activate(w, id);
+	return SGP_OK;
+}
+SGO_API int sgo_body_add_force(sgo_world* w, uint32_t id, const float f[3])
+{
+	if (!live(w, id)) return SGP_ERR_BAD_ID;
+	sgo_body* b = &w->bodies[id];
+	if (b->motion != SGP_MOTION_DYNAMIC) return SGP_OK;
+	b->force = v3_add(b->force, V3(f[0], f[1], f[2]));
+	body_activate(w, id);
+	return SGP_OK;
+}
+SGO_API int sgo_body_add_torque(sgo_world* w, uint32_t id, const float t[3])
+{
+	if (!live(w, id)) return SGP_ERR_BAD_ID;
+	sgo_body* b = &w->bodies[id];
+	if (b->motion != SGP_MOTION_DYNAMIC) return SGP_OK;
+	b->torque = v3_add(b->torque, V3(t[0], t[1], t[2]));
+	body_activate(w, id);
+	return SGP_OK;
+}
+SGO_API int sgo_body_add_force_at(sgo_world* w, uint32_t id, const float f[3], const float p[3])
+{
+	if (!live(w, id)) return SGP_ERR_BAD_ID;
+	sgo_body* b = &w->bodies[id];
+	if (b->motion != SGP_MOTION_DYNAMIC) return SGP_OK;
+	const v3 F = V3(f[0], f[1], f[2]);
+	b->force = v3_add(b->force, F);
+	b->torque = v3_add(b->torque, v3_cross(v3_sub(V3(p[0], p[1], p[2]), b->pos), F));
+	body_activate(w, id);
+	return SGP_OK;
+}
+
+static void fill_state(const sgo_body* b, uint32_t id, sgp_body_state* s)
+{
+	s->pos[0] = b->pos.x; s->pos[1] = b->pos.y; s->pos[2] = b->pos.z;
+	s->rot[0] = b->rot.x; s->rot[1] = b->rot.y; s->rot[2] = b->rot.z; s->rot[3] = b->rot.w;
+	s->lin_vel[0] = b->linv.x; s->lin_vel[1] = b->linv.y; s->lin_vel[2] = b->linv.z;
+	s->ang_vel[0] = b->angv.x; s->ang_vel[1] = b->angv.y; s->ang_vel[2] = b->angv.z;
+	s->active = (uint32_t)b->active; s->underwater = (uint32_t)b->underwater; s->submerged_volume = b->submerged;
+	s->id = b->alive ? id : SGP_INVALID_ID;
+}
+SGO_API int sgo_body_get_state(sgo_world* w, const uint32_t* ids, uint32_t n, sgp_body_state* out)
+{
+	for (uint32_t i = 0; i < n; ++i) { if (!live(w, ids[i])) return SGP_ERR_BAD_ID; fill_state(&w->bodies[ids[i]], ids[i], &out[i]); }
+	return SGP_OK;
+}
+SGO_API int sgo_world_read_states(sgo_world* w, uint32_t first, uint32_t n, sgp_body_state* out)
+{
+	if (!w || first + n > w->cap) return SGP_ERR_INVALID;
+	for (uint32_t i = 0; i < n; ++i) fill_state(&w->bodies[first + i], first + i, &out[i]);
+	return SGP_OK;
+}
+SGO_API int sgo_world_read_active(sgo_world* w, sgp_body_state* out, uint32_t cap, uint32_t* n_out)
+{
+	uint32_t n = 0;
+	for (uint32_t i = 0; i < w->high; ++i) if (w->bodies[i].alive && w->bodies[i].active) { if (n < cap) fill_state(&w->bodies[i], i, &out[n]); ++n; }
+	*n_out = n;
+	return SGP_OK;
+}
+SGO_API int sgo_world_set_water(sgo_world* w, int enabled, float z) { w->water_enabled = enabled; w->water_z = z; return SGP_OK; }
+SGO_API int sgo_world_set_contact_events(sgo_world* w, int enabled) { w->contact_events = enabled; return SGP_OK; }
+SGO_API int sgo_world_num_bodies(sgo_world* w, uint32_t* n) { *n = w->n_alive; return SGP_OK; }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* broad phase: uniform grid over the small bodies (cell >= largest small-body AABB + margin), large  */
+/* bodies (ground quad, PhysicsWorld.cpp:1123) against everything.  Only the resulting SET matters.   */
+
+static int body_is_active_for_pairs(const sgo_body* b)
+{
+	if (!b->alive) return 0;
+	if (b->motion == SGP_MOTION_DYNAMIC) return b->active;
+	if (b->motion == SGP_MOTION_KINEMATIC) return b->active;
+	return 0;
+}
+
+static int pair_passes(const sgo_world* w, uint32_t i, uint32_t j)
+{
+	const sgo_body* a = &w->bodies[i]; const sgo_body* b = &w->bodies[j];
+	if (!(body_is_active_for_pairs(a) || body_is_active_for_pairs(b))) return 0;
+	if (a->motion != SGP_MOTION_DYNAMIC && b->motion != SGP_MOTION_DYNAMIC) return 0;
+	if (!(layers_collide(a->layer, b->layer))) return 0;
+	const float d = w->st.speculative_contact_distance;
+	if (a->aabb_min.x - d > b->aabb_max.x || b->aabb_min.x - d > a->aabb_max.x) return 0;
+	if (a->aabb_min.y - d > b->aabb_max.y || b->aabb_min.y - d > a->aabb_max.y) return 0;
+	if (a->aabb_min.z - d > b->aabb_max.z || b->aabb_min.z - d > a->aabb_max.z) return 0;
+	return 1;
+}
+
+static void push_pair(sgo_world* w, uint32_t i, uint32_t j)
+{
+	if (w->n_pairs == w->cap_pairs) { w->cap_pairs = w->cap_pairs ? w->cap_pairs * 2 : 1024; w->pairs = (sgo_pair*)realloc(w->pairs, sizeof(sgo_pair) * w->cap_pairs); }
+	sgo_pair p; p.a = i < j ? i : j; p.b = i < j ? j : i;
+	w->pairs[w->n_pairs++] = p;
+}
+
+typedef struct { uint64_t key; uint32_t idx; } keyidx;
+static int cmp_keyidx(const void* a, const void* b)
+{
+	const keyidx* x = (const keyidx*)a; const keyidx* y = (const keyidx*)b;
+	if (x->key < y->key) return -1; if (x->key > y->key) return 1;
+	return (x->idx > y->idx) - (x->idx < y->idx);
+}
+
+static uint64_t cell_key(int64_t cx, int64_t cy, int64_t cz)
+{
+	return ((uint64_t)(cz + (1 << 20)) << 42) | ((uint64_t)(cy + (1 << 20)) << 21) | (uint64_t)(cx + (1 << 20));
+}
+
+static uint32_t lower_bound_key(const keyidx* a, uint32_t n, uint64_t key)
+{
+	uint32_t lo = 0, hi = n;
+	while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if (a[mid].key < key) lo = mid + 1; else hi = mid; }
+	return lo;
+}
+
+static void broad_phase(sgo_world* w)
+{
+	w->n_pairs = 0; w->n_large = 0;
+	const float large_r = w->desc.large_body_radius;
+	float cell = 0.5f;
+	uint32_t n_small = 0;
+	keyidx* ki = (keyidx*)malloc(sizeof(keyidx) * (w->high ? w->high : 1));
+	for (uint32_t i = 0; i < w->high; ++i) {
+		const sgo_body* b = &w->bodies[i];
+		if (!b->alive) continue;
+		if (shape_bounding_radius(b->shape_type, b->shape) > large_r) { w->large[w->n_large++] = i; continue; }
+		const v3 e = v3_sub(b->aabb_max, b->aabb_min);
+		cell = fmaxf(cell, fmaxf(e.x, fmaxf(e.y, e.z)));
+		ki[n_small++].idx = i;
+	}
+	cell += 2.0f * w->st.speculative_contact_distance;
+	for (uint32_t k = 0; k < n_small; ++k) {
+		const sgo_body* b = &w->bodies[ki[k].idx];
+		const v3 c = v3_scale(v3_add(b->aabb_min, b->aabb_max), 0.5f);
+		ki[k].key = cell_key((int64_t)floorf(c.x / cell), (int64_t)floorf(c.y / cell), (int64_t)floorf(c.z / cell));
+	}
+	qsort(ki, n_small, sizeof(keyidx), cmp_keyidx);
+	for (uint32_t k = 0; k < n_small; ++k) {
+		const uint32_t i = ki[k].idx;
+		if (!body_is_active_for_pairs(&w->bodies[i])) continue;
+		const int64_t cx = (int64_t)(ki[k].key & 0x1FFFFF) - (1 << 20);
+		const int64_t cy = (int64_t)((ki[k].key >> 21) & 0x1FFFFF) - (1 << 20);
+		const int64_t cz = (int64_t)((ki[k].key >> 42) & 0x1FFFFF) - (1 << 20);
+		for (int64_t dz = -1; dz <= 1; ++dz) for (int64_t dy = -1; dy <= 1; ++dy) for (int64_t dx = -1; dx <= 1; ++dx) {
+			const uint64_t key = cell_key(cx + dx, cy + dy, cz + dz);
+			for (uint32_t p = lower_bound_key(ki, n_small, key); p < n_small && ki[p].key == key; ++p) {
+				const uint32_t j = ki[p].idx;
+				if (j == i) continue;
+				/* emitted once: by the lower id if both scan, else by the scanning (active) one */
+				if (body_is_active_for_pairs(&w->bodies[j]) && j < i) continue;
+				if (pair_passes(w, i, j)) push_pair(w, i, j);
+			}
+		}
+	}
+	for (uint32_t l = 0; l < w->n_large; ++l) {
+		const uint32_t i = w->large[l];
+		for (uint32_t j = 0; j < w->high; ++j) {
+			if (j == i || !w->bodies[j].alive) continue;
+			/* large-large pairs once */
+			if (shape_bounding_radius(w->bodies[j].shape_type, w->bodies[j].shape) > large_r && j < i) continue;
+			if (pair_passes(w, i, j)) push_pair(w, i, j);
+		}
+	}
+	free(ki);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* contact constraints (Jolt ContactConstraintManager)                                               */
+
+static sgo_shape body_shape_xf(const sgo_body* b)
+{
+	sgo_shape s; s.pos = b->pos; s.R = quat_to_m33(b->rot); s.type = b->shape_type;
+	memcpy(s.p, b->shape, sizeof(s.p));
+	return s;
+}
+
+static int body_movable(const sgo_body* b) { return b->motion == SGP_MOTION_DYNAMIC && b->active; }
+
+/* AxisConstraintPart::CalculateConstraintProperties: 1 / (J M^-1 J^T) */
+static float axis_eff_mass(float im1, sym33 I1, v3 r1, float im2, sym33 I2, v3 r2, v3 axis)
+{
+	float inv = 0.0f;
+	if (im1 > 0.0f) { const v3 c = v3_cross(r1, axis); inv = im1 + v3_dot(sym33_mul(I1, c), c); }
+	if (im2 > 0.0f) { const v3 c = v3_cross(r2, axis); inv = inv + (im2 + v3_dot(sym33_mul(I2, c), c)); }
+	return inv > 0.0f ? 1.0f / inv : 0.0f;
+}
+
+static const sgo_constraint* find_prev(const sgo_world* w, uint64_t key)
+{
+	uint32_t lo = 0, hi = w->n_prev;
+	while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if (w->prev_keys_sorted[mid] < key) lo = mid + 1; else hi = mid; }
+	if (lo < w->n_prev && w->prev_keys_sorted[lo] == key) return &w->prev[w->prev_idx_sorted[lo]];
+	return NULL;
+}
+
+static void emit_contact_event(sgo_world* w, const sgo_constraint* c, const sgo_manifold* m, int persisted)
+{
+	sgp_contact_event e; memset(&e, 0, sizeof(e));
+	const sgo_body* A = &w->bodies[c->a]; const sgo_body* B = &w->bodies[c->b];
+	e.id1 = c->a; e.id2 = c->b; e.userdata1 = A->userdata; e.userdata2 = B->userdata;
+	e.lin_vel1[0] = A->linv.x; e.lin_vel1[1] = A->linv.y; e.lin_vel1[2] = A->linv.z;
+	e.lin_vel2[0] = B->linv.x; e.lin_vel2[1] = B->linv.y; e.lin_vel2[2] = B->linv.z;
+	e.base_offset[0] = m->p1[0].x; e.base_offset[1] = m->p1[0].y; e.base_offset[2] = m->p1[0].z;
+	e.normal[0] = m->n.x; e.normal[1] = m->n.y; e.normal[2] = m->n.z;
+	e.num_points = (uint32_t)m->np;
+	float pen = -3.4e38f;
+	for (int i = 0; i < m->np; ++i) {
+		const v3 r = v3_sub(m->p1[i], m->p1[0]);
+		e.rel_points_on1[i][0] = r.x; e.rel_points_on1[i][1] = r.y; e.rel_points_on1[i][2] = r.z;
+		pen = fmaxf(pen, v3_dot(v3_sub(m->p1[i], m->p2[i]), m->n));
+	}
+	e.penetration = pen;
+	if (persisted) PUSH_EVENT(w->ev_pers, w->n_pers, w->cap_pers, sgp_contact_event, e);
+	else PUSH_EVENT(w->ev_added, w->n_added, w->cap_added, sgp_contact_event, e);
+}
+
+/* Narrow phase + constraint setup for every candidate pair. */
+static void find_contacts(sgo_world* w, float dt)
+{
+	w->n_cons = 0;
+	if (w->cap_cons < w->n_pairs + 1) {
+		w->cap_cons = w->n_pairs + 1024;
+		w->cons = (sgo_constraint*)realloc(w->cons, sizeof(sgo_constraint) * w->cap_cons);
+	}
+	/* pass 1: manifolds + activation of sleeping bodies touched by an active one */
+	sgo_manifold* mans = (sgo_manifold*)malloc(sizeof(sgo_manifold) * (w->n_pairs ? w->n_pairs : 1));
+	uint32_t nm = 0;
+	for (uint32_t p = 0; p < w->n_pairs; ++p) {
+		const uint32_t a = w->pairs[p].a, b = w->pairs[p].b;
+		const sgo_shape sa = body_shape_xf(&w->bodies[a]), sb = body_shape_xf(&w->bodies[b]);
+		sgo_manifold m;
+		if (!sgo_collide(&sa, &sb, w->st.speculative_contact_distance, &m)) continue;
+		sgo_constraint* c = &w->cons[nm];
+		memset(c, 0, sizeof(*c));
+		c->a = a; c->b = b; c->key = ((uint64_t)a << 32) | b; c->prio = sgp_mix64(c->key);
+		c->np = m.np; c->n = m.n;
+		mans[nm++] = m;
+	}
+	w->n_cons = nm;
+	for (uint32_t k = 0; k < nm; ++k) {
+		sgo_body* A = &w->bodies[w->cons[k].a]; sgo_body* B = &w->bodies[w->cons[k].b];
+		if (A->is_sensor || B->is_sensor) continue;
+		const int actA = body_is_active_for_pairs(A), actB = body_is_active_for_pairs(B);
+		if (actA && !actB && B->motion == SGP_MOTION_DYNAMIC) B->can_sleep = -1;   /* mark for wake-up */
+		if (actB && !actA && A->motion == SGP_MOTION_DYNAMIC) A->can_sleep = -1;
+	}
+	for (uint32_t i = 0; i < w->high; ++i) if (w->bodies[i].alive && w->bodies[i].can_sleep == -1) { w->bodies[i].can_sleep = 0; body_activate(w, i); }
+
+	/* pass 2: constraint properties */
+	uint32_t npts = 0, out = 0;
+	for (uint32_t k = 0; k < nm; ++k) {
+		sgo_constraint c = w->cons[k];
+		const sgo_manifold* m = &mans[k];
+		const sgo_body* A = &w->bodies[c.a]; const sgo_body* B = &w->bodies[c.b];
+		const sgo_constraint* pc = find_prev(w, c.key);
+		c.persisted = pc != NULL;
+		if (w->contact_events) emit_contact_event(w, &c, m, c.persisted);
+		if (A->is_sensor || B->is_sensor) continue;
+		const m33 RA = quat_to_m33(A->rot), RB = quat_to_m33(B->rot);
+		const float im1 = body_movable(A) ? A->inv_mass : 0.0f, im2 = body_movable(B) ? B->inv_mass : 0.0f;
+		sym33 I1, I2; memset(&I1, 0, sizeof(I1)); memset(&I2, 0, sizeof(I2));
+		if (im1 > 0.0f) I1 = world_inv_inertia(RA, A->inv_inertia);
+		if (im2 > 0.0f) I2 = world_inv_inertia(RB, B->inv_inertia);
+		c.friction = sqrtf(A->friction * B->friction);
+		const float restitution = fmaxf(A->restitution, B->restitution);
+		c.t1 = v3_normalized_perpendicular(c.n);
+		c.t2 = v3_cross(c.n, c.t1);
+		for (int i = 0; i < c.np; ++i) {
+			sgo_point* pt = &c.pt[i];
+			const v3 p1 = m->p1[i], p2 = m->p2[i];
+			pt->local1 = m33_tmul(RA, v3_sub(p1, A->pos));
+			pt->local2 = m33_tmul(RB, v3_sub(p2, B->pos));
+			pt->lam_n = pt->lam_t1 = pt->lam_t2 = 0.0f;
+			if (pc && w->st.warm_start) {
+				for (int j = 0; j < pc->np; ++j) {
+					if (v3_len_sq(v3_sub(pt->local1, pc->pt[j].local1)) < w->st.contact_point_preserve_lambda_max_dist_sq &&
+					    v3_len_sq(v3_sub(pt->local2, pc->pt[j].local2)) < w->st.contact_point_preserve_lambda_max_dist_sq) {
+						pt->lam_n = pc->pt[j].lam_n; pt->lam_t1 = pc->pt[j].lam_t1; pt->lam_t2 = pc->pt[j].lam_t2;
+						break;
+					}
+				}
+			}
+			const v3 mid = v3_scale(v3_add(p1, p2), 0.5f);
+			pt->r1 = v3_sub(mid, A->pos); pt->r2 = v3_sub(mid, B->pos);
+			/* TemplatedCalculateFrictionAndNonPenetrationConstraintProperties */
+			const v3 va = v3_add(A->linv, v3_cross(A->angv, pt->r1));
+			const v3 vb = v3_add(B->linv, v3_cross(B->angv, pt->r2));
+			const float normal_velocity = v3_dot(v3_sub(vb, va), c.n);
+			const float penetration = v3_dot(v3_sub(p1, p2), c.n);
+			const float spec_bias = fmaxf(0.0f, -penetration / dt);
+			float bias = spec_bias;
+			if (restitution > 0.0f && normal_velocity < -w->st.min_velocity_for_restitution) {
+				if (normal_velocity < -spec_bias) {
+					/* cancel the velocity the constant forces added this step (gravity + accumulated force; forces were
+					   consumed by apply_forces, so only gravity is known here) */
+					v3 rel_acc = V3(0, 0, 0);
+					if (im2 > 0.0f) rel_acc = v3_add(rel_acc, v3_scale(w->gravity, B->gravity_factor));
+					if (im1 > 0.0f) rel_acc = v3_sub(rel_acc, v3_scale(w->gravity, A->gravity_factor));
+					const float force_dv = fminf(0.0f, v3_dot(rel_acc, c.n)) * dt;
+					bias = restitution * (normal_velocity - force_dv);
+				}
+			}
+			pt->bias = bias;
+			pt->eff_n = axis_eff_mass(im1, I1, pt->r1, im2, I2, pt->r2, c.n);
+			pt->eff_t1 = axis_eff_mass(im1, I1, pt->r1, im2, I2, pt->r2, c.t1);
+			pt->eff_t2 = axis_eff_mass(im1, I1, pt->r1, im2, I2, pt->r2, c.t2);
+		}
+		npts += (uint32_t)c.np;
+		w->cons[out++] = c;
+	}
+	w->n_cons = out;
+	w->stats.num_contact_points = npts;
+	free(mans);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* deterministic round-based greedy colouring (see header): shared spec with the device code           */
+
+static void colour_constraints(sgo_world* w)
+{
+	for (uint32_t i = 0; i < w->high; ++i) { w->bodies[i].colour_mask = 0; w->bodies[i].claim[0] = w->bodies[i].claim[1] = ~0ull; }
+	for (uint32_t k = 0; k < w->n_cons; ++k) w->cons[k].colour = -1;
+	uint32_t remaining = w->n_cons, rounds = 0;
+	while (remaining) {
+		const int cur = rounds & 1, nxt = cur ^ 1;
+		/* phase A: claim */
+		for (uint32_t k = 0; k < w->n_cons; ++k) {
+			sgo_constraint* c = &w->cons[k];
+			if (c->colour >= 0) continue;
+			sgo_body* A = &w->bodies[c->a]; sgo_body* B = &w->bodies[c->b];
+			if (body_movable(A) && c->prio < A->claim[cur]) A->claim[cur] = c->prio;
+			if (body_movable(B) && c->prio < B->claim[cur]) B->claim[cur] = c->prio;
+		}
+		/* phase B: winners take the lowest colour free on both bodies */
+		for (uint32_t k = 0; k < w->n_cons; ++k) {
+			sgo_constraint* c = &w->cons[k];
+			if (c->colour >= 0) continue;
+			sgo_body* A = &w->bodies[c->a]; sgo_body* B = &w->bodies[c->b];
+			const int ma = body_movable(A), mb = body_movable(B);
+			const int win = (!ma || A->claim[cur] == c->prio) && (!mb || B->claim[cur] == c->prio);
+			if (win) {
+				const uint64_t used = (ma ? A->colour_mask : 0) | (mb ? B->colour_mask : 0);
+				int col = 0;
+				while (col < SGO_OVERFLOW_COLOUR && ((used >> col) & 1)) ++col;
+				c->colour = col;
+				if (col < SGO_OVERFLOW_COLOUR) {
+					if (ma) A->colour_mask |= 1ull << col;
+					if (mb) B->colour_mask |= 1ull << col;
+				}
+				--remaining;
+			}
+		}
+		/* reset the other claim buffer for the bodies the next round can touch */
+		for (uint32_t k = 0; k < w->n_cons; ++k) {
+			sgo_constraint* c = &w->cons[k];
+			w->bodies[c->a].claim[nxt] = ~0ull; w->bodies[c->b].claim[nxt] = ~0ull;
+		}
+		++rounds;
+	}
+	w->stats.num_colour_rounds = rounds;
+}
+
+static const sgo_world* g_sort_world;
+static int cmp_order(const void* a, const void* b)
+{
+	const sgo_constraint* x = &g_sort_world->cons[*(const uint32_t*)a];
+	const sgo_constraint* y = &g_sort_world->cons[*(const uint32_t*)b];
+	if (x->colour != y->colour) return x->colour - y->colour;
+	if (x->prio < y->prio) return -1; if (x->prio > y->prio) return 1;
+	return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* solver (Jolt ContactConstraintManager::WarmStart / SolveVelocityConstraints / SolvePositionConstraints) */
+
+static void apply_impulse(sgo_body* A, sgo_body* B, float im1, sym33 I1, float im2, sym33 I2, v3 r1, v3 r2, v3 axis, float lambda)
+{
+	if (im1 > 0.0f) {
+		A->linv = v3_sub(A->linv, v3_scale(axis, lambda * im1));
+		A->angv = v3_sub(A->angv, v3_scale(sym33_mul(I1, v3_cross(r1, axis)), lambda));
+	}
+	if (im2 > 0.0f) {
+		B->linv = v3_add(B->linv, v3_scale(axis, lambda * im2));
+		B->angv = v3_add(B->angv, v3_scale(sym33_mul(I2, v3_cross(r2, axis)), lambda));
+	}
+}
+
+static float axis_jv(const sgo_body* A, const sgo_body* B, v3 r1, v3 r2, v3 axis)
+{
+	return v3_dot(axis, v3_sub(A->linv, B->linv)) + v3_dot(v3_cross(r1, axis), A->angv) - v3_dot(v3_cross(r2, axis), B->angv);
+}
+
+static void warm_start_constraint(sgo_world* w, sgo_constraint* c)
+{
+	sgo_body* A = &w->bodies[c->a]; sgo_body* B = &w->bodies[c->b];
+	const float im1 = body_movable(A) ? A->inv_mass : 0.0f, im2 = body_movable(B) ? B->inv_mass : 0.0f;
+	sym33 I1, I2; memset(&I1, 0, sizeof(I1)); memset(&I2, 0, sizeof(I2));
+	if (im1 > 0.0f) I1 = world_inv_inertia(quat_to_m33(A->rot), A->inv_inertia);
+	if (im2 > 0.0f) I2 = world_inv_inertia(quat_to_m33(B->rot), B->inv_inertia);
+	for (int i = 0; i < c->np; ++i) {
+		sgo_point* p = &c->pt[i];
+		if (c->friction > 0.0f) {
+			apply_impulse(A, B, im1, I1, im2, I2, p->r1, p->r2, c->t1, p->lam_t1);
+			apply_impulse(A, B, im1, I1, im2, I2, p->r1, p->r2, c->t2, p->lam_t2);
+		}
+		apply_impulse(A, B, im1, I1, im2, I2, p->r1, p->r2, c->n, p->lam_n);
+	}
+}
+
+static void solve_velocity_constraint(sgo_world* w, sgo_constraint* c)
+{
+	sgo_body* A = &w->bodies[c->a]; sgo_body* B = &w->bodies[c->b];
+	const float im1 = body_movable(A) ? A->inv_mass : 0.0f, im2 = body_movable(B) ? B->inv_mass : 0.0f;
+	sym33 I1, I2; memset(&I1, 0, sizeof(I1)); memset(&I2, 0, sizeof(I2));
+	if (im1 > 0.0f) I1 = world_inv_inertia(quat_to_m33(A->rot), A->inv_inertia);
+	if (im2 > 0.0f) I2 = world_inv_inertia(quat_to_m33(B->rot), B->inv_inertia);
+	/* friction first (uses the normal impulse of the previous iteration), then non-penetration */
+	if (c->friction > 0.0f) {
+		for (int i = 0; i < c->np; ++i) {
+			sgo_point* p = &c->pt[i];
+			if (p->eff_t1 <= 0.0f && p->eff_t2 <= 0.0f) continue;
+			float l1 = p->lam_t1 + p->eff_t1 * axis_jv(A, B, p->r1, p->r2, c->t1);
+			float l2 = p->lam_t2 + p->eff_t2 * axis_jv(A, B, p->r1, p->r2, c->t2);
+			const float max_f = c->friction * p->lam_n;
+			const float tot_sq = l1 * l1 + l2 * l2;
+			if (tot_sq > max_f * max_f) { const float sc = max_f / sqrtf(tot_sq); l1 = l1 * sc; l2 = l2 * sc; }
+			apply_impulse(A, B, im1, I1, im2, I2, p->r1, p->r2, c->t1, l1 - p->lam_t1); p->lam_t1 = l1;
+			apply_impulse(A, B, im1, I1, im2, I2, p->r1, p->r2, c->t2, l2 - p->lam_t2); p->lam_t2 = l2;
+		}
+	}
+	for (int i = 0; i < c->np; ++i) {
+		sgo_point* p = &c->pt[i];
+		if (p->eff_n <= 0.0f) continue;
+		const float jv = axis_jv(A, B, p->r1, p->r2, c->n);
+		const float lambda = p->eff_n * (jv - p->bias);
+		const float nl = fmaxf(p->lam_n + lambda, 0.0f);
+		apply_impulse(A, B, im1, I1, im2, I2, p->r1, p->r2, c->n, nl - p->lam_n);
+		p->lam_n = nl;
+	}
+}
+
+static void solve_position_constraint(sgo_world* w, sgo_constraint* c)
+{
+	sgo_body* A = &w->bodies[c->a]; sgo_body* B = &w->bodies[c->b];
+	const float im1 = body_movable(A) ? A->inv_mass : 0.0f, im2 = body_movable(B) ? B->inv_mass : 0.0f;
+	for (int i = 0; i < c->np; ++i) {
+		sgo_point* p = &c->pt[i];
+		const m33 RA = quat_to_m33(A->rot), RB = quat_to_m33(B->rot);
+		const v3 p1 = v3_add(A->pos, m33_mul(RA, p->local1));
+		const v3 p2 = v3_add(B->pos, m33_mul(RB, p->local2));
+		float sep = v3_dot(v3_sub(p2, p1), c->n) + w->st.penetration_slop;
+		if (sep < 0.0f) {
+			sep = fmaxf(sep, -w->st.max_penetration_distance);
+			const v3 mid = v3_scale(v3_add(p1, p2), 0.5f);
+			const v3 r1 = v3_sub(mid, A->pos), r2 = v3_sub(mid, B->pos);
+			sym33 I1, I2; memset(&I1, 0, sizeof(I1)); memset(&I2, 0, sizeof(I2));
+			if (im1 > 0.0f) I1 = world_inv_inertia(RA, A->inv_inertia);
+			if (im2 > 0.0f) I2 = world_inv_inertia(RB, B->inv_inertia);
+			const float eff = axis_eff_mass(im1, I1, r1, im2, I2, r2, c->n);
+			if (eff <= 0.0f) continue;
+			const float lambda = -eff * w->st.baumgarte * sep;
+			if (im1 > 0.0f) {
+				A->pos = v3_sub(A->pos, v3_scale(c->n, lambda * im1));
+				A->rot = quat_add_rotation_step(A->rot, v3_scale(sym33_mul(I1, v3_cross(r1, c->n)), -lambda));
+			}
+			if (im2 > 0.0f) {
+				B->pos = v3_add(B->pos, v3_scale(c->n, lambda * im2));
+				B->rot = quat_add_rotation_step(B->rot, v3_scale(sym33_mul(I2, v3_cross(r2, c->n)), lambda));
+			}
+		}
+	}
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* islands (union-find, root = smallest body id) and sleeping (Body::UpdateSleepStateInternal)        */
+
+static uint32_t uf_find(sgo_world* w, uint32_t x)
+{
+	while ((uint32_t)w->bodies[x].island != x) { w->bodies[x].island = w->bodies[w->bodies[x].island].island; x = (uint32_t)w->bodies[x].island; }
+	return x;
+}
+
+static void update_sleeping(sgo_world* w, float dt)
+{
+	const float max_movement = w->st.point_velocity_sleep_threshold * w->st.time_before_sleep;
+	for (uint32_t i = 0; i < w->high; ++i) { w->bodies[i].island = (int)i; }
+	for (uint32_t k = 0; k < w->n_cons; ++k) {
+		const sgo_constraint* c = &w->cons[k];
+		if (!body_movable(&w->bodies[c->a]) || !body_movable(&w->bodies[c->b])) continue;
+		const uint32_t ra = uf_find(w, c->a), rb = uf_find(w, c->b);
+		if (ra < rb) w->bodies[rb].island = (int)ra; else if (rb < ra) w->bodies[ra].island = (int)rb;
+	}
+	/* per-body sleep test */
+	for (uint32_t i = 0; i < w->high; ++i) {
+		sgo_body* b = &w->bodies[i];
+		b->can_sleep = 1;
+		if (!b->alive || !body_movable(b)) continue;
+		if (!b->allow_sleep || !w->st.allow_sleeping) { b->can_sleep = 0; continue; }
+		v3 pts[3];
+		body_sleep_points(b, pts);
+		int reset = 0;
+		for (int k = 0; k < 3; ++k) {
+			/* Sphere::EncapsulatePoint */
+			const v3 d = v3_sub(pts[k], b->sleep_c[k]);
+			const float d2 = v3_len_sq(d);
+			if (d2 > b->sleep_r[k] * b->sleep_r[k]) {
+				const float dl = sqrtf(d2);
+				const float nr = 0.5f * (b->sleep_r[k] + dl);
+				b->sleep_c[k] = v3_add(b->sleep_c[k], v3_scale(d, (nr - b->sleep_r[k]) / dl));
+				b->sleep_r[k] = nr;
+			}
+			if (b->sleep_r[k] > max_movement) reset = 1;
+		}
+		if (reset) {
+			for (int k = 0; k < 3; ++k) { b->sleep_c[k] = pts[k]; b->sleep_r[k] = 0.0f; }
+			b->sleep_timer = 0.0f; b->can_sleep = 0;
+		} else {
+			b->sleep_timer += dt;
+			b->can_sleep = b->sleep_timer >= w->st.time_before_sleep;
+		}
+	}
+	/* island AND-reduction into the root's colour_mask scratch (1 = every member can sleep) */
+	for (uint32_t i = 0; i < w->high; ++i) w->bodies[i].colour_mask = 1;
+	for (uint32_t i = 0; i < w->high; ++i) {
+		sgo_body* b = &w->bodies[i];
+		if (!b->alive || !body_movable(b)) continue;
+		if (!b->can_sleep) w->bodies[uf_find(w, i)].colour_mask = 0;
+	}
+	for (uint32_t i = 0; i < w->high; ++i) {
+		sgo_body* b = &w->bodies[i];
+		if (!b->alive || !body_movable(b)) continue;
+		if (w->bodies[uf_find(w, i)].colour_mask) {
+			b->active = 0; b->linv = V3(0, 0, 0); b->angv = V3(0, 0, 0);
+			push_body_event(w, SGP_EVENT_DEACTIVATED, i);
+		}
+	}
+	/* kinematic bodies stay active while they move */
+	for (uint32_t i = 0; i < w->high; ++i) {
+		sgo_body* b = &w->bodies[i];
+		if (b->alive && b->motion == SGP_MOTION_KINEMATIC && b->active && v3_len_sq(b->linv) == 0.0f && v3_len_sq(b->angv) == 0.0f) {
+			b->active = 0; push_body_event(w, SGP_EVENT_DEACTIVATED, i);
+		}
+	}
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* buoyancy sweep, PhysicsWorld.cpp:1367-1442 (Body::GetSubmergedVolume + Body::ApplyBuoyancyImpulse)  */
+
+/* Volume and centroid of the part of a convex polyhedron (box) below the plane z = wz, by slicing the 8
+   corners: uses the exact tetrahedral decomposition of the clipped box. */
+static void box_submerged(const sgo_body* b, float wz, float* vol_out, v3* centroid_out)
+{
+	const m33 R = quat_to_m33(b->rot);
+	const v3 h = V3(b->shape[0], b->shape[1], b->shape[2]);
+	/* Work in the box frame: plane n.x = d with n = R^T (0,0,1), d = wz - pos.z ; submerged part: n.x <= d. */
+	const v3 n = m33_tmul(R, V3(0.0f, 0.0f, 1.0f));
+	const float d = wz - b->pos.z;
+	/* Clip the 6 faces (quads) by the half space and add the cap polygon; accumulate signed tetrahedra from the origin. */
+	float vol = 0.0f; v3 cen = V3(0, 0, 0);
+	v3 cap[24]; int ncap = 0;
+	for (int ax = 0; ax < 3; ++ax) for (int sg = -1; sg <= 1; sg += 2) {
+		const int u = (ax + 1) % 3, v = (ax + 2) % 3;
+		v3 q[4];
+		const float su[4] = { 1, -1, -1, 1 }, sv[4] = { 1, 1, -1, -1 };
+		for (int k = 0; k < 4; ++k) {
+			v3 p = V3(0, 0, 0);
+			v3_set(&p, ax, (float)sg * v3_get(h, ax));
+			/* orient counter-clockwise seen from outside */
+			const int kk = sg > 0 ? k : 3 - k;
+			v3_set(&p, u, su[kk] * v3_get(h, u)); v3_set(&p, v, sv[kk] * v3_get(h, v));
+			q[k] = p;
+		}
+		v3 poly[8]; int np = 0;
+		for (int k = 0; k < 4; ++k) {
+			const v3 a = q[k], c = q[(k + 1) % 4];
+			const float da = v3_dot(n, a) - d, dc = v3_dot(n, c) - d;
+			if (da <= 0.0f) poly[np++] = a;
+			if ((da <= 0.0f) != (dc <= 0.0f)) {
+				const float t = da / (da - dc);
+				const v3 x = v3_add(a, v3_scale(v3_sub(c, a), t));
+				poly[np++] = x;
+				if (ncap < 24) cap[ncap++] = x;
+			}
+		}
+		for (int k = 1; k + 1 < np; ++k) {
+			const float tv = v3_dot(poly[0], v3_cross(poly[k], poly[k + 1])) / 6.0f;
+			vol += tv;
+			cen = v3_add(cen, v3_scale(v3_add(v3_add(poly[0], poly[k]), poly[k + 1]), tv * 0.25f));
+		}
+	}
+	/* cap polygon lies in the plane n.x = d: its tetrahedra with the origin have volume (d/3)*area each; order the
+	   cap points by angle around their mean */
+	if (ncap >= 3) {
+		v3 mean = V3(0, 0, 0);
+		for (int k = 0; k < ncap; ++k) mean = v3_add(mean, cap[k]);
+		mean = v3_scale(mean, 1.0f / (float)ncap);
+		const v3 e1 = v3_normalized_perpendicular(n), e2 = v3_cross(n, e1);
+		float ang[24];
+		for (int k = 0; k < ncap; ++k) { const v3 r = v3_sub(cap[k], mean); ang[k] = atan2f(v3_dot(r, e2), v3_dot(r, e1)); }
+		for (int i = 1; i < ncap; ++i) { const float a = ang[i]; const v3 p = cap[i]; int j = i - 1; while (j >= 0 && ang[j] > a) { ang[j + 1] = ang[j]; cap[j + 1] = cap[j]; --j; } ang[j + 1] = a; cap[j + 1] = p; }
+		for (int k = 0; k < ncap; ++k) {
+			const v3 a = cap[k], c = cap[(k + 1) % ncap];
+			const float tv = v3_dot(mean, v3_cross(a, c)) / 6.0f;
+			vol += tv;
+			cen = v3_add(cen, v3_scale(v3_add(v3_add(mean, a), c), tv * 0.25f));
+		}
+	}
+	*vol_out = vol;
+	*centroid_out = vol > 1.0e-12f ? m33_mul(R, v3_scale(cen, 1.0f / vol)) : V3(0, 0, 0);   /* relative to COM, world axes */
+}
+
+static void sphere_cap_submerged(float r, float depth_of_centre /* wz - centre.z */, float* vol_out, float* cz_out)
+{
+	/* submerged height h in [0, 2r] measured from the bottom of the sphere */
+	const float h = clampf(depth_of_centre + r, 0.0f, 2.0f * r);
+	const float pi = 3.14159265358979323846f;
+	const float vol = pi * h * h * (3.0f * r - h) / 3.0f;
+	/* centroid of a spherical cap of height h, measured from the sphere centre, pointing down */
+	float cz = 0.0f;
+	if (h > 0.0f) { const float k = 2.0f * r - h; cz = -(3.0f * k * k) / (4.0f * (3.0f * r - h)); }
+	*vol_out = vol; *cz_out = cz;
+}
+
+static void submerged_volume(const sgo_body* b, float wz, float* total, float* sub, v3* rel_cob)
+{
+	*total = shape_volume(b->shape_type, b->shape);
+	if (b->shape_type == SGP_SHAPE_BOX) { box_submerged(b, wz, sub, rel_cob); return; }
+	if (b->shape_type == SGP_SHAPE_SPHERE) {
+		float cz; sphere_cap_submerged(b->shape[0], wz - b->pos.z, sub, &cz);
+		*rel_cob = V3(0.0f, 0.0f, cz);
+		return;
+	}
+	/* capsule: approximated (as Jolt does for non-trivial convex shapes) by the fraction of its AABB height under water */
+	{
+		const float zmin = b->aabb_min.z, zmax = b->aabb_max.z;
+		const float f = clampf((wz - zmin) / (zmax - zmin), 0.0f, 1.0f);
+		*sub = *total * f;
+		*rel_cob = V3(0.0f, 0.0f, (zmin + 0.5f * f * (zmax - zmin)) - b->pos.z);
+	}
+}
+
+static void buoyancy_sweep(sgo_world* w, float dt)
+{
+	for (uint32_t i = 0; i < w->high; ++i) {
+		sgo_body* b = &w->bodies[i];
+		if (!b->alive || !b->active || b->motion != SGP_MOTION_DYNAMIC) continue;          /* :1377 */
+		if (b->aabb_min.z < w->water_z) {                                                   /* :1379 */
+			const float fluid_density = 1020.0f;                                            /* :1381 */
+			float total, sub; v3 rc;
+			submerged_volume(b, w->water_z, &total, &sub, &rc);
+			const float buoyancy = fluid_density * total / b->mass;                         /* :1387 */
+			int applied = 0;
+			if (sub > 0.0f) {
+				/* Body::ApplyBuoyancyImpulse */
+				const float inv_mass = b->inv_mass;
+				const float rho = buoyancy / (total * inv_mass);
+				const v3 g = V3(0.0f, 0.0f, -9.81f);                                         /* :1407 */
+				const v3 buoy_imp = v3_scale(g, -rho * sub * b->gravity_factor * dt);
+				const v3 cob_vel = v3_add(b->linv, v3_cross(b->angv, rc));
+				const v3 rel = v3_neg(cob_vel);                                              /* fluid velocity 0, :1406 */
+				const float lin_drag = b->zero_lin_drag ? 0.0f : 0.1f;                      /* :1404 */
+				const v3 size = v3_scale(shape_local_half(b->shape_type, b->shape), 2.0f);
+				const m33 R = quat_to_m33(b->rot);
+				const v3 lrel = m33_tmul(R, rel);
+				const float rl2 = v3_len_sq(lrel);
+				v3 drag_imp = V3(0, 0, 0);
+				if (rl2 > 1.0e-12f) {
+					const float rl = sqrtf(rl2);
+					const v3 dirl = v3_scale(v3_abs(lrel), 1.0f / rl);
+					const float area = (sub / total) * (dirl.x * size.y * size.z + dirl.y * size.x * size.z + dirl.z * size.x * size.y);
+					float dv = 0.5f * rho * rl2 * lin_drag * area * dt * inv_mass;
+					if (dv > rl) dv = rl;
+					drag_imp = v3_scale(rel, dv / (rl * inv_mass));
+				}
+				const v3 dlin = v3_scale(v3_add(drag_imp, buoy_imp), inv_mass);
+				const float l = (size.x + size.y + size.z) / 3.0f;
+				const float ang_drag = 3.0f;                                                 /* :1405 */
+				const v3 drag_ang_imp = v3_scale(b->angv, -ang_drag * sub / total * dt * (l * l) / inv_mass);
+				const sym33 Iw = world_inv_inertia(R, b->inv_inertia);
+				v3 ddrag = sym33_mul(Iw, drag_ang_imp);
+				if (v3_len_sq(ddrag) > v3_len_sq(b->angv)) ddrag = v3_neg(b->angv);
+				const v3 dang = v3_add(ddrag, sym33_mul(Iw, v3_cross(rc, v3_add(buoy_imp, drag_imp))));
+				b->linv = v3_add(b->linv, dlin);
+				b->angv = v3_add(b->angv, dang);
+				applied = 1;
+			}
+			if (applied) {
+				if (!b->underwater) { push_body_event(w, SGP_EVENT_ENTERED_WATER, i); b->underwater = 1; }  /* :1414-1420 */
+				b->submerged = sub;                                                                       /* :1422 */
+			} else { b->underwater = 0; b->submerged = 0.0f; }                                              /* :1426-1427 */
+		} else if (b->underwater) { b->underwater = 0; b->submerged = 0.0f; }                               /* :1432-1436 */
+	}
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* think(dt)                                                                                        */
+
+static int cmp_prev(const void* a, const void* b)
+{
+	const keyidx* x = (const keyidx*)a; const keyidx* y = (const keyidx*)b;
+	return (x->key > y->key) - (x->key < y->key);
+}
+
+SGO_API int sgo_world_step(sgo_world* w, float dt)
+{
+	if (!w || !(dt > 0.0f)) return SGP_ERR_INVALID;
+	memset(&w->stats, 0, sizeof(w->stats));
+
+	/* 1. MotionProperties::ApplyForceTorqueAndDragInternal (JobApplyGravity) */
+	for (uint32_t i = 0; i < w->high; ++i) {
+		sgo_body* b = &w->bodies[i];
+		if (!b->alive || !body_movable(b)) continue;
+		b->linv = v3_add(b->linv, v3_scale(v3_add(v3_scale(w->gravity, b->gravity_factor), v3_scale(b->force, b->inv_mass)), dt));
+		const sym33 Iw = world_inv_inertia(quat_to_m33(b->rot), b->inv_inertia);
+		b->angv = v3_add(b->angv, v3_scale(sym33_mul(Iw, b->torque), dt));
+		b->linv = v3_scale(b->linv, fmaxf(0.0f, 1.0f - b->lin_damp * dt));
+		b->angv = v3_scale(b->angv, fmaxf(0.0f, 1.0f - b->ang_damp * dt));
+		const float l2 = v3_len_sq(b->linv), ml = w->st.max_linear_velocity;
+		if (l2 > ml * ml) b->linv = v3_scale(b->linv, ml / sqrtf(l2));
+		const float a2 = v3_len_sq(b->angv), ma = w->st.max_angular_velocity;
+		if (a2 > ma * ma) b->angv = v3_scale(b->angv, ma / sqrtf(a2));
+		b->force = V3(0, 0, 0); b->torque = V3(0, 0, 0);
+	}
+
+	/* 2-3. broad phase, narrow phase, contact constraints */
+	broad_phase(w);
+	find_contacts(w, dt);
+
+	/* 4. colouring and solve order */
+	colour_constraints(w);
+	w->order = (uint32_t*)realloc(w->order, sizeof(uint32_t) * (w->n_cons ? w->n_cons : 1));
+	for (uint32_t k = 0; k < w->n_cons; ++k) w->order[k] = k;
+	g_sort_world = w;
+	qsort(w->order, w->n_cons, sizeof(uint32_t), cmp_order);
+	int ncol = 0; uint32_t novf = 0;
+	for (uint32_t k = 0; k < w->n_cons; ++k) { if (w->cons[k].colour + 1 > ncol) ncol = w->cons[k].colour + 1; if (w->cons[k].colour == SGO_OVERFLOW_COLOUR) ++novf; }
+
+	/* 5. warm start + velocity iterations */
+	if (w->st.warm_start) for (uint32_t k = 0; k < w->n_cons; ++k) warm_start_constraint(w, &w->cons[w->order[k]]);
+	for (int it = 0; it < w->st.num_velocity_steps; ++it)
+		for (uint32_t k = 0; k < w->n_cons; ++k) solve_velocity_constraint(w, &w->cons[w->order[k]]);
+
+	/* 6. integrate positions (Body::AddPositionStep / AddRotationStep) */
+	for (uint32_t i = 0; i < w->high; ++i) {
+		sgo_body* b = &w->bodies[i];
+		if (!b->alive || !b->active || b->motion == SGP_MOTION_STATIC) continue;
+		if (b->motion == SGP_MOTION_DYNAMIC) {
+			const float l2 = v3_len_sq(b->linv), ml = w->st.max_linear_velocity;
+			if (l2 > ml * ml) b->linv = v3_scale(b->linv, ml / sqrtf(l2));
+			const float a2 = v3_len_sq(b->angv), ma = w->st.max_angular_velocity;
+			if (a2 > ma * ma) b->angv = v3_scale(b->angv, ma / sqrtf(a2));
+		}
+		b->pos = v3_add(b->pos, v3_scale(b->linv, dt));
+		b->rot = quat_add_rotation_step(b->rot, v3_scale(b->angv, dt));
+	}
+
+	/* 7. position iterations */
+	for (int it = 0; it < w->st.num_position_steps; ++it)
+		for (uint32_t k = 0; k < w->n_cons; ++k) solve_position_constraint(w, &w->cons[w->order[k]]);
+
+	/* 8. bounds, sleeping */
+	for (uint32_t i = 0; i < w->high; ++i) { sgo_body* b = &w->bodies[i]; if (b->alive && b->active) body_update_aabb(b); }
+	update_sleeping(w, dt);
+
+	/* 9. buoyancy (Substrata's own sweep after Update) */
+	if (w->water_enabled) buoyancy_sweep(w, dt);
+
+	/* 10. contact cache for the next step */
+	{
+		sgo_constraint* t = w->prev; w->prev = w->cons; w->cons = t;
+		const uint32_t tc = w->cap_prev; w->cap_prev = w->cap_cons; w->cap_cons = tc;
+		w->n_prev = w->n_cons;
+		keyidx* ki = (keyidx*)malloc(sizeof(keyidx) * (w->n_prev ? w->n_prev : 1));
+		for (uint32_t k = 0; k < w->n_prev; ++k) { ki[k].key = w->prev[k].key; ki[k].idx = k; }
+		qsort(ki, w->n_prev, sizeof(keyidx), cmp_prev);
+		w->prev_keys_sorted = (uint64_t*)realloc(w->prev_keys_sorted, sizeof(uint64_t) * (w->n_prev ? w->n_prev : 1));
+		w->prev_idx_sorted = (uint32_t*)realloc(w->prev_idx_sorted, sizeof(uint32_t) * (w->n_prev ? w->n_prev : 1));
+		for (uint32_t k = 0; k < w->n_prev; ++k) { w->prev_keys_sorted[k] = ki[k].key; w->prev_idx_sorted[k] = ki[k].idx; }
+		free(ki);
+	}
+
+	/* stats */
+	w->stats.num_bodies = w->n_alive;
+	for (uint32_t i = 0; i < w->high; ++i) {
+		const sgo_body* b = &w->bodies[i];
+		if (!b->alive) continue;
+		if (b->active) w->stats.num_active++;
+		if (b->layer >= 0 && b->layer < SGP_NUM_LAYERS) w->stats.layer_counts[b->layer]++;
+	}
+	w->stats.num_pairs = w->n_pairs;
+	w->stats.num_manifolds = w->n_prev;
+	w->stats.num_colours = (uint32_t)ncol;
+	w->stats.num_overflow_constraints = novf;
+	w->stats.num_activated = w->n_act;
+	w->stats.num_deactivated = w->n_deact;
+	return SGP_OK;
+}
+
+SGO_API int sgo_world_step_n(sgo_world* w, float dt, uint32_t n)
+{
+	for (uint32_t i = 0; i < n; ++i) { const int r = sgo_world_step(w, dt); if (r != SGP_OK) return r; }
+	return SGP_OK;
+}
+
+SGO_API int sgo_world_stats(sgo_world* w, sgp_step_stats* out) { *out = w->stats; return SGP_OK; }
+
+static int cmp_body_event(const void* a, const void* b)
+{
+	const uint32_t x = ((const sgp_body_event*)a)->id, y = ((const sgp_body_event*)b)->id;
+	return (x > y) - (x < y);
+}
+static int cmp_contact_event(const void* a, const void* b)
+{
+	const sgp_contact_event* x = (const sgp_contact_event*)a; const sgp_contact_event* y = (const sgp_contact_event*)b;
+	if (x->id1 != y->id1) return (x->id1 > y->id1) - (x->id1 < y->id1);
+	return (x->id2 > y->id2) - (x->id2 < y->id2);
+}
+
+SGO_API int sgo_world_drain_events(sgo_world* w, int kind, void* out, uint32_t cap, uint32_t* n_out)
+{
+	if (!w || !n_out) return SGP_ERR_INVALID;
+	if (kind <= SGP_EVENT_ENTERED_WATER) {
+		sgp_body_event* src; uint32_t* n;
+		if (kind == SGP_EVENT_ACTIVATED) { src = w->ev_act; n = &w->n_act; }
+		else if (kind == SGP_EVENT_DEACTIVATED) { src = w->ev_deact; n = &w->n_deact; }
+		else { src = w->ev_water; n = &w->n_water; }
+		qsort(src, *n, sizeof(sgp_body_event), cmp_body_event);
+		const uint32_t m = *n < cap ? *n : cap;
+		if (out && m) memcpy(out, src, sizeof(sgp_body_event) * m);
+		*n_out = *n; *n = 0;
+	} else {
+		sgp_contact_event* src; uint32_t* n;
+		if (kind == SGP_EVENT_CONTACT_ADDED) { src = w->ev_added; n = &w->n_added; } else { src = w->ev_pers; n = &w->n_pers; }
+		qsort(src, *n, sizeof(sgp_contact_event), cmp_contact_event);
+		const uint32_t m = *n < cap ? *n : cap;
+		if (out && m) memcpy(out, src, sizeof(sgp_contact_event) * m);
+		*n_out = *n; *n = 0;
+	}
+	return SGP_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* direct access for unit tests                                                                      */
+
+static sgo_shape shape_from_desc(const sgp_body_desc* d)
+{
+	sgo_shape s;
+	s.pos = V3(d->pos[0], d->pos[1], d->pos[2]);
+	quat q = { d->rot[0], d->rot[1], d->rot[2], d->rot[3] };
+	s.R = quat_to_m33(q);
+	s.type = d->shape_type;
+	memcpy(s.p, d->shape, sizeof(s.p));
+	return s;
+}
+
+/* out: normal[3], np, p1[4][3], p2[4][3].  Returns 1 on contact. */
+SGO_API int sgo_collide_pair(const sgp_body_desc* a, const sgp_body_desc* b, float max_sep, float* normal, int* np, float* p1, float* p2)
+{
+	const sgo_shape sa = shape_from_desc(a), sb = shape_from_desc(b);
+	sgo_manifold m;
+	if (!sgo_collide(&sa, &sb, max_sep, &m)) { *np = 0; return 0; }
+	normal[0] = m.n.x; normal[1] = m.n.y; normal[2] = m.n.z;
+	*np = m.np;
+	for (int i = 0; i < m.np; ++i) {
+		p1[3 * i] = m.p1[i].x; p1[3 * i + 1] = m.p1[i].y; p1[3 * i + 2] = m.p1[i].z;
+		p2[3 * i] = m.p2[i].x; p2[3 * i + 1] = m.p2[i].y; p2[3 * i + 2] = m.p2[i].z;
+	}
+	return 1;
+}
+
+/* Constraints of the step just taken (the contact cache): key a<<32|b, colour, np, lambdas, normal. */
+typedef struct { uint32_t a, b; int32_t colour; int32_t np; float n[3]; float lam_n[4]; float lam_t1[4]; float lam_t2[4]; float bias[4]; } sgo_constraint_dump;
+SGO_API int sgo_world_dump_constraints(sgo_world* w, sgo_constraint_dump* out, uint32_t cap, uint32_t* n_out)
+{
+	*n_out = w->n_prev;
+	for (uint32_t k = 0; k < w->n_prev && k < cap; ++k) {
+		const sgo_constraint* c = &w->prev[w->prev_idx_sorted[k]];
+		sgo_constraint_dump* d = &out[k];
+		memset(d, 0, sizeof(*d));
+		d->a = c->a; d->b = c->b; d->colour = c->colour; d->np = c->np;
+		d->n[0] = c->n.x; d->n[1] = c->n.y; d->n[2] = c->n.z;
+		for (int i = 0; i < c->np; ++i) { d->lam_n[i] = c->pt[i].lam_n; d->lam_t1[i] = c->pt[i].lam_t1; d->lam_t2[i] = c->pt[i].lam_t2; d->bias[i] = c->pt[i].bias; }
+	}
+	return SGP_OK;
+}
+
+/* Ray vs one body (traceRay, PhysicsWorld.cpp:1668-1725).  Returns t or -1. */
+static float ray_body(const sgo_body* b, v3 o, v3 d, float max_t, v3* n_out)
+{
+	const m33 R = quat_to_m33(b->rot);
+	const v3 ol = m33_tmul(R, v3_sub(o, b->pos)), dl = m33_tmul(R, d);
+	if (b->shape_type == SGP_SHAPE_SPHERE) {
+		const float r = b->shape[0];
+		const float B = v3_dot(ol, dl), C = v3_len_sq(ol) - r * r;
+		if (C <= 0.0f) { *n_out = v3_neg(d); return 0.0f; }
+		const float disc = B * B - C;
+		if (disc < 0.0f) return -1.0f;
+		const float t = -B - sqrtf(disc);
+		if (t < 0.0f || t > max_t) return -1.0f;
+		*n_out = m33_mul(R, v3_scale(v3_add(ol, v3_scale(dl, t)), 1.0f / r));
+		return t;
+	}
+	if (b->shape_type == SGP_SHAPE_BOX) {
+		const v3 h = V3(b->shape[0], b->shape[1], b->shape[2]);
+		float t0 = 0.0f, t1 = max_t; int ax = -1; float sg = 0.0f;
+		for (int k = 0; k < 3; ++k) {
+			const float ok = v3_get(ol, k), dk = v3_get(dl, k), hk = v3_get(h, k);
+			if (fabsf(dk) < 1.0e-12f) { if (ok < -hk || ok > hk) return -1.0f; continue; }
+			float ta = (-hk - ok) / dk, tb = (hk - ok) / dk; float s = -1.0f;
+			if (ta > tb) { const float tmp = ta; ta = tb; tb = tmp; s = 1.0f; }
+			if (ta > t0) { t0 = ta; ax = k; sg = s; }
+			if (tb < t1) t1 = tb;
+			if (t0 > t1) return -1.0f;
+		}
+		if (ax < 0) { *n_out = v3_neg(d); return 0.0f; }
+		v3 nl = V3(0, 0, 0); v3_set(&nl, ax, sg);
+		*n_out = m33_mul(R, nl);
+		return t0;
+	}
+	/* capsule along local z: infinite cylinder clipped to |z| <= hh, plus the two end spheres */
+	{
+		const float r = b->shape[0], hh = b->shape[1];
+		float best = -1.0f; v3 bn = V3(0, 0, 0);
+		const float a = dl.x * dl.x + dl.y * dl.y;
+		const float bq = ol.x * dl.x + ol.y * dl.y, c = ol.x * ol.x + ol.y * ol.y - r * r;
+		if (a > 1.0e-12f) {
+			const float disc = bq * bq - a * c;
+			if (disc >= 0.0f) {
+				const float t = (-bq - sqrtf(disc)) / a;
+				const float z = ol.z + dl.z * t;
+				if (t >= 0.0f && t <= max_t && fabsf(z) <= hh) { best = t; bn = V3((ol.x + dl.x * t) / r, (ol.y + dl.y * t) / r, 0.0f); }
+			}
+		}
+		for (int sgn = -1; sgn <= 1; sgn += 2) {
+			const v3 oc = V3(ol.x, ol.y, ol.z - (float)sgn * hh);
+			const float B = v3_dot(oc, dl), C = v3_len_sq(oc) - r * r;
+			const float disc = B * B - C;
+			if (disc < 0.0f) continue;
+			const float t = -B - sqrtf(disc);
+			if (t < 0.0f || t > max_t) continue;
+			if (best < 0.0f || t < best) { best = t; bn = v3_scale(v3_add(oc, v3_scale(dl, t)), 1.0f / r); }
+		}
+		if (best < 0.0f) {
+			/* origin inside? */
+			const v3 q = sgo_closest_on_segment(V3(0, 0, -hh), V3(0, 0, hh), ol);
+			if (v3_len_sq(v3_sub(ol, q)) <= r * r) { *n_out = v3_neg(d); return 0.0f; }
+			return -1.0f;
+		}
+		*n_out = m33_mul(R, bn);
+		return best;
+	}
+}
+
+SGO_API int sgo_raycast(sgo_world* w, const sgp_ray* rays, uint32_t n, sgp_hit* hits)
+{
+	for (uint32_t k = 0; k < n; ++k) {
+		const v3 o = V3(rays[k].origin[0], rays[k].origin[1], rays[k].origin[2]);
+		const v3 d = V3(rays[k].dir[0], rays[k].dir[1], rays[k].dir[2]);
+		float best = rays[k].max_t; uint32_t bid = SGP_INVALID_ID; v3 bn = V3(0, 0, 0);
+		for (uint32_t i = 0; i < w->high; ++i) {
+			const sgo_body* b = &w->bodies[i];
+			if (!b->alive || i == rays[k].ignore_id) continue;
+			if (rays[k].collidable_only && !(b->layer == SGP_LAYER_NON_MOVING || b->layer == SGP_LAYER_MOVING)) continue;
+			v3 nn;
+			const float t = ray_body(b, o, d, best, &nn);
+			if (t >= 0.0f && (t < best || bid == SGP_INVALID_ID) && t <= best) { best = t; bid = i; bn = nn; }
+		}
+		hits[k].id = bid; hits[k].t = bid == SGP_INVALID_ID ? 0.0f : best;
+		hits[k].normal[0] = bn.x; hits[k].normal[1] = bn.y; hits[k].normal[2] = bn.z;
+		hits[k].userdata = bid == SGP_INVALID_ID ? 0 : w->bodies[bid].userdata;
+	}
+	return SGP_OK;
+}

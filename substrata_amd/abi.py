@@ -1,0 +1,170 @@
+"""ctypes mirror of include/sgp.h (the C ABI behind Substrata's PhysicsWorld facade).
+
+Struct layouts, constants and prototypes here must stay in lock-step with include/sgp.h; tests/test_abi.py
+checks sizes/offsets against the compiled library (sgp_abi_sizeof) and that every declared symbol is exported.
+"""
+import ctypes as C
+import numpy as np
+
+ABI_VERSION = 1
+
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_CAPACITY, ERR_HIP, ERR_BAD_ID, ERR_REJECTED = 0, -1, -2, -3, -4, -5, -6
+
+MOTION_STATIC, MOTION_KINEMATIC, MOTION_DYNAMIC = 0, 1, 2
+LAYER_NON_MOVING, LAYER_MOVING, LAYER_NON_MOVING_NON_COLLIDABLE, LAYER_MOVING_NON_COLLIDABLE = 0, 1, 2, 3
+NUM_LAYERS = 4
+SHAPE_SPHERE, SHAPE_BOX, SHAPE_CAPSULE = 0, 1, 2
+INVALID_ID = 0xFFFFFFFF
+
+EVENT_ACTIVATED, EVENT_DEACTIVATED, EVENT_ENTERED_WATER, EVENT_CONTACT_ADDED, EVENT_CONTACT_PERSISTED = 0, 1, 2, 3, 4
+NUM_STAGES = 8
+STAGE_NAMES = ["apply_forces", "broadphase", "narrowphase", "setup", "solve_velocity", "integrate",
+               "solve_position", "finalize"]
+
+f32, i32, u32, u64 = C.c_float, C.c_int32, C.c_uint32, C.c_uint64
+
+
+class Settings(C.Structure):
+    _fields_ = [("num_velocity_steps", i32), ("num_position_steps", i32), ("baumgarte", f32),
+                ("penetration_slop", f32), ("speculative_contact_distance", f32),
+                ("min_velocity_for_restitution", f32), ("max_penetration_distance", f32),
+                ("time_before_sleep", f32), ("point_velocity_sleep_threshold", f32),
+                ("contact_point_preserve_lambda_max_dist_sq", f32), ("max_linear_velocity", f32),
+                ("max_angular_velocity", f32), ("allow_sleeping", i32), ("warm_start", i32)]
+
+
+class WorldDesc(C.Structure):
+    _fields_ = [("max_bodies", u32), ("max_body_pairs", u32), ("max_manifolds", u32), ("device", i32),
+                ("gravity", f32 * 3), ("large_body_radius", f32), ("settings", Settings)]
+
+
+class BodyDesc(C.Structure):
+    _fields_ = [("pos", f32 * 3), ("rot", f32 * 4), ("lin_vel", f32 * 3), ("ang_vel", f32 * 3),
+                ("shape_type", i32), ("shape", f32 * 4), ("motion_type", i32), ("layer", i32),
+                ("mass", f32), ("friction", f32), ("restitution", f32), ("gravity_factor", f32),
+                ("linear_damping", f32), ("angular_damping", f32), ("is_sensor", i32),
+                ("allow_sleeping", i32), ("activate", i32), ("use_zero_linear_drag", i32), ("userdata", u64)]
+
+
+class BodyState(C.Structure):
+    _fields_ = [("pos", f32 * 3), ("rot", f32 * 4), ("lin_vel", f32 * 3), ("ang_vel", f32 * 3),
+                ("active", u32), ("underwater", u32), ("submerged_volume", f32), ("id", u32)]
+
+
+class BodyEvent(C.Structure):
+    _fields_ = [("id", u32), ("_pad", u32), ("userdata", u64)]
+
+
+class ContactEvent(C.Structure):
+    _fields_ = [("id1", u32), ("id2", u32), ("userdata1", u64), ("userdata2", u64),
+                ("lin_vel1", f32 * 3), ("lin_vel2", f32 * 3), ("base_offset", f32 * 3), ("normal", f32 * 3),
+                ("num_points", u32), ("rel_points_on1", (f32 * 3) * 4), ("penetration", f32)]
+
+
+class Ray(C.Structure):
+    _fields_ = [("origin", f32 * 3), ("dir", f32 * 3), ("max_t", f32), ("ignore_id", u32), ("collidable_only", u32)]
+
+
+class Hit(C.Structure):
+    _fields_ = [("id", u32), ("t", f32), ("normal", f32 * 3), ("userdata", u64)]
+
+
+class StepStats(C.Structure):
+    _fields_ = [("num_bodies", u32), ("num_active", u32), ("num_pairs", u32), ("num_manifolds", u32),
+                ("num_contact_points", u32), ("num_colours", u32), ("num_colour_rounds", u32),
+                ("num_overflow_constraints", u32), ("pairs_dropped", u32), ("manifolds_dropped", u32),
+                ("num_activated", u32), ("num_deactivated", u32), ("layer_counts", u32 * NUM_LAYERS),
+                ("device_bytes", u64)]
+
+
+class StepProfile(C.Structure):
+    _fields_ = [("stage_ms", f32 * NUM_STAGES), ("total_ms", f32), ("sweep_kernel_ms", f32),
+                ("sweep_bodies", u32), ("solve_kernel_ms_avg", f32), ("solve_launches", u32)]
+
+
+class GhostRecord(C.Structure):
+    _fields_ = [("pos", f32 * 3), ("rot", f32 * 4), ("lin_vel", f32 * 3), ("ang_vel", f32 * 3),
+                ("shape_type", i32), ("shape", f32 * 4), ("mass", f32), ("friction", f32), ("restitution", f32),
+                ("motion_type", u32), ("global_id", u64)]
+
+
+class ConstraintDump(C.Structure):
+    """Debug/test view of one contact constraint of the last step (not part of the reference facade)."""
+    _fields_ = [("a", u32), ("b", u32), ("colour", i32), ("np", i32), ("n", f32 * 3), ("lam_n", f32 * 4),
+                ("lam_t1", f32 * 4), ("lam_t2", f32 * 4), ("bias", f32 * 4)]
+
+
+STRUCTS = {"sgp_settings": Settings, "sgp_world_desc": WorldDesc, "sgp_body_desc": BodyDesc,
+           "sgp_body_state": BodyState, "sgp_body_event": BodyEvent, "sgp_contact_event": ContactEvent,
+           "sgp_ray": Ray, "sgp_hit": Hit, "sgp_step_stats": StepStats, "sgp_step_profile": StepProfile,
+           "sgp_ghost_record": GhostRecord}
+
+body_desc_dtype = np.dtype(BodyDesc)
+body_state_dtype = np.dtype(BodyState)
+ghost_dtype = np.dtype(GhostRecord)
+contact_event_dtype = np.dtype(ContactEvent)
+body_event_dtype = np.dtype(BodyEvent)
+constraint_dump_dtype = np.dtype(ConstraintDump)
+ray_dtype = np.dtype(Ray)
+hit_dtype = np.dtype(Hit)
+
+P = C.POINTER
+vp = C.c_void_p
+
+# name (without prefix) -> (restype, argtypes); world handle is void*
+PROTOTYPES = {
+    "init": (C.c_int, []),
+    "abi_version": (C.c_int, []),
+    "last_error": (C.c_char_p, []),
+    "default_settings": (None, [P(Settings)]),
+    "default_world_desc": (None, [P(WorldDesc)]),
+    "default_body_desc": (None, [P(BodyDesc)]),
+    "world_create": (C.c_int, [P(WorldDesc), P(vp)]),
+    "world_destroy": (C.c_int, [vp]),
+    "body_add": (C.c_int, [vp, P(BodyDesc), P(u32)]),
+    "body_add_batch": (C.c_int, [vp, vp, u32, vp]),
+    "body_remove": (C.c_int, [vp, u32]),
+    "body_activate": (C.c_int, [vp, u32]),
+    "body_set_layer": (C.c_int, [vp, u32, i32]),
+    "body_set_pose_vel": (C.c_int, [vp, u32, P(f32), P(f32), P(f32), P(f32)]),
+    "body_set_pose_shape": (C.c_int, [vp, u32, P(f32), P(f32), P(f32)]),
+    "body_set_pos": (C.c_int, [vp, u32, P(f32)]),
+    "body_set_vel": (C.c_int, [vp, u32, P(f32), P(f32)]),
+    "body_move_kinematic": (C.c_int, [vp, u32, P(f32), P(f32), f32]),
+    "body_add_force": (C.c_int, [vp, u32, P(f32)]),
+    "body_add_force_at": (C.c_int, [vp, u32, P(f32), P(f32)]),
+    "body_add_torque": (C.c_int, [vp, u32, P(f32)]),
+    "body_get_state": (C.c_int, [vp, vp, u32, vp]),
+    "world_read_states": (C.c_int, [vp, u32, u32, vp]),
+    "world_read_active": (C.c_int, [vp, vp, u32, P(u32)]),
+    "world_set_water": (C.c_int, [vp, C.c_int, f32]),
+    "world_set_contact_events": (C.c_int, [vp, C.c_int]),
+    "world_step": (C.c_int, [vp, f32]),
+    "world_step_n": (C.c_int, [vp, f32, u32]),
+    "world_step_profiled": (C.c_int, [vp, f32, P(StepProfile)]),
+    "world_stats": (C.c_int, [vp, P(StepStats)]),
+    "world_drain_events": (C.c_int, [vp, C.c_int, vp, u32, P(u32)]),
+    "world_num_bodies": (C.c_int, [vp, P(u32)]),
+    "raycast": (C.c_int, [vp, vp, u32, vp]),
+    "world_export_boundary": (C.c_int, [vp, P(f32), P(f32), f32, vp, u32, P(u32)]),
+    "world_import_ghosts": (C.c_int, [vp, vp, u32]),
+    "world_device_array": (C.c_int, [vp, C.c_int, P(vp), P(u32)]),
+    "world_stream": (C.c_int, [vp, P(vp)]),
+    # test/debug helper, not a facade entry point
+    "world_dump_constraints": (C.c_int, [vp, vp, u32, P(u32)]),
+}
+
+
+def bind(lib, prefix, names=None):
+    """Attach argtypes/restype for every prototype the library exports under `prefix`. Returns the bound names."""
+    bound = []
+    for name, (res, args) in PROTOTYPES.items():
+        if names is not None and name not in names:
+            continue
+        fn = getattr(lib, prefix + name, None)
+        if fn is None:
+            continue
+        fn.restype = res
+        fn.argtypes = args
+        bound.append(name)
+    return bound

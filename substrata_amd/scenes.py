@@ -1,0 +1,122 @@
+"""Synthetic inputs for the BASELINE.json configs.  Pure numpy, deterministic (numpy PCG64 streams
+seeded per config).  Every generator returns a structured array of abi.body_desc_dtype ready for add_batch();
+body 0 is always the ground quad (createGroundQuadShape(2000): static box half (1000,1000,0.5) centred at z=-0.5,
+/root/reference/gui_client/PhysicsWorld.cpp:1123-1135, GUIClient.cpp:573-574).
+
+Body parameters are the WorldObject defaults the reference gives scripted objects: mass 50, friction 0.5,
+restitution 0.2 (shared/WorldObject.cpp:119,1268-1270); dynamic, layer MOVING, activated on add.
+"""
+import numpy as np
+from . import abi
+
+
+def _blank(n):
+    d = np.zeros(n, dtype=abi.body_desc_dtype)
+    d["rot"][:, 3] = 1.0
+    d["shape_type"] = abi.SHAPE_BOX
+    d["shape"][:, :3] = 0.5
+    d["motion_type"] = abi.MOTION_STATIC
+    d["layer"] = abi.LAYER_NON_MOVING
+    d["mass"] = 100.0
+    d["friction"] = 0.5
+    d["restitution"] = 0.3
+    d["gravity_factor"] = 1.0
+    d["linear_damping"] = 0.05
+    d["angular_damping"] = 0.05
+    d["allow_sleeping"] = 1
+    return d
+
+
+def ground(width=2000.0, friction=0.5, restitution=0.3):
+    g = _blank(1)
+    g["shape"][0, :3] = (width / 2, width / 2, 0.5)
+    g["pos"][0] = (0.0, 0.0, -0.5)
+    g["friction"] = friction
+    g["restitution"] = restitution
+    return g
+
+
+def dynamic_bodies(n, mass=50.0, friction=0.5, restitution=0.2):
+    d = _blank(n)
+    d["motion_type"] = abi.MOTION_DYNAMIC
+    d["layer"] = abi.LAYER_MOVING
+    d["mass"] = mass
+    d["friction"] = friction
+    d["restitution"] = restitution
+    d["activate"] = 1
+    return d
+
+
+def _random_unit_quats(rng, n):
+    q = rng.standard_normal((n, 4)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    return q.astype(np.float32)
+
+
+def lattice(nx, ny, nz, spacing, z0, seed, jitter=0.05, random_rot=True, origin_centered=True):
+    """nx*ny*nz unit cubes on a lattice, x fastest; xy jitter +-jitter; optional uniformly random orientation."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = nx * ny * nz
+    ix, iy, iz = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    # x fastest ordering
+    idx = np.arange(n)
+    x = (idx % nx).astype(np.float32)
+    y = ((idx // nx) % ny).astype(np.float32)
+    z = (idx // (nx * ny)).astype(np.float32)
+    d = dynamic_bodies(n)
+    ox = (nx - 1) * spacing / 2 if origin_centered else 0.0
+    oy = (ny - 1) * spacing / 2 if origin_centered else 0.0
+    jit = (rng.random((n, 2)).astype(np.float32) * 2 - 1) * np.float32(jitter)
+    d["pos"][:, 0] = x * spacing - ox + jit[:, 0]
+    d["pos"][:, 1] = y * spacing - oy + jit[:, 1]
+    d["pos"][:, 2] = z0 + z * spacing
+    if random_rot:
+        d["rot"] = _random_unit_quats(rng, n)
+    return d, rng
+
+
+def config1_256_boxes():
+    """Config 1: 256 unit cubes, 8x8x4 lattice, spacing 1.5 m, lowest layer centre z=1.0, seed 1."""
+    d, _ = lattice(8, 8, 4, 1.5, 1.0, seed=1)
+    return np.concatenate([ground(), d])
+
+
+def config2_10k_boxes():
+    """Config 2: 10k unit cubes, 25x25x16 lattice, spacing 1.25 m, seed 2."""
+    d, _ = lattice(25, 25, 16, 1.25, 1.0, seed=2)
+    return np.concatenate([ground(), d])
+
+
+def config3_100k_mixed(nx=100, ny=100, nz=10, seed=3):
+    """Config 3: 100k mixed bodies, 100x100x10 lattice, spacing 1.5 m; type = index mod 3 -> box (half 0.5) /
+    sphere (r 0.5) / capsule (half-height 0.65, r 0.3, axis z); uniform scale in [0.5,1.5]; mass = 50*scale^3."""
+    d, rng = lattice(nx, ny, nz, 1.5, 1.0, seed=seed)
+    n = len(d)
+    s = (0.5 + rng.random(n)).astype(np.float32)
+    t = np.arange(n) % 3
+    d["mass"] = 50.0 * s ** 3
+    box = t == 0
+    sph = t == 1
+    cap = t == 2
+    d["shape_type"][box] = abi.SHAPE_BOX
+    d["shape"][box, :3] = (0.5 * s[box])[:, None]
+    d["shape_type"][sph] = abi.SHAPE_SPHERE
+    d["shape"][sph, 0] = 0.5 * s[sph]
+    d["shape"][sph, 1:] = 0
+    d["shape_type"][cap] = abi.SHAPE_CAPSULE
+    d["shape"][cap, 0] = 0.3 * s[cap]
+    d["shape"][cap, 1] = 0.65 * s[cap]
+    d["shape"][cap, 2:] = 0
+    return np.concatenate([ground(), d])
+
+
+def config4_tile(nx, ny, nz, spacing=1.25, seed=4, offset=(0.0, 0.0, 0.0)):
+    """Config 4 building block: one spatial tile of the 1M-box lattice (100^3, spacing 1.25 m)."""
+    d, _ = lattice(nx, ny, nz, spacing, 1.0, seed=seed, origin_centered=False)
+    d["pos"] += np.asarray(offset, dtype=np.float32)
+    return d
+
+
+def small_mixed(n_side=6, layers=3, seed=7):
+    """A small config-3-style scene for parity tests (oracle finishes in seconds)."""
+    return config3_100k_mixed(n_side, n_side, layers, seed)

@@ -1,0 +1,209 @@
+"""Thin numpy/ctypes driver over the C ABI (include/sgp.h).
+
+`CWorld` is ABI plumbing only: it owns no physics.  The product binds it to substrata_amd/libsgp.so (HIP, gfx950);
+the test oracle binds the same class to oracle/libsgo_oracle.so (prefix sgo_) so that parity tests drive both
+sides through identical calls.
+"""
+import ctypes as C
+import numpy as np
+from . import abi
+
+
+class SgpError(RuntimeError):
+    pass
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _f3(v):
+    return np.ascontiguousarray(v, dtype=np.float32).reshape(3)
+
+
+def _f4(v):
+    return np.ascontiguousarray(v, dtype=np.float32).reshape(4)
+
+
+class CWorld:
+    def __init__(self, lib, prefix, max_bodies=65536, gravity=(0.0, 0.0, -9.81), device=0, settings=None,
+                 max_body_pairs=0, max_manifolds=0, large_body_radius=0.0):
+        self._lib, self._p = lib, prefix
+        self._h = C.c_void_p()
+        d = abi.WorldDesc()
+        self._fn("default_world_desc")(C.byref(d))
+        d.max_bodies = int(max_bodies)
+        d.max_body_pairs = int(max_body_pairs)
+        d.max_manifolds = int(max_manifolds)
+        d.device = int(device)
+        d.gravity[:] = gravity
+        if large_body_radius:
+            d.large_body_radius = float(large_body_radius)
+        if settings:
+            for k, v in settings.items():
+                setattr(d.settings, k, v)
+        self.desc = d
+        self._check(self._fn("world_create")(C.byref(d), C.byref(self._h)), "world_create")
+        self.max_bodies = int(max_bodies)
+
+    # -- plumbing -------------------------------------------------------------------------------------------
+    def _fn(self, name):
+        return getattr(self._lib, self._p + name)
+
+    def _check(self, rc, what):
+        if rc != abi.OK:
+            msg = ""
+            fn = getattr(self._lib, self._p + "last_error", None)
+            if fn is not None:
+                m = fn()
+                msg = m.decode() if m else ""
+            raise SgpError(f"{self._p}{what} failed: rc={rc} {msg}")
+
+    def close(self):
+        if self._h:
+            self._fn("world_destroy")(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- bodies ---------------------------------------------------------------------------------------------
+    def default_body_desc(self):
+        d = abi.BodyDesc()
+        self._fn("default_body_desc")(C.byref(d))
+        return d
+
+    def add(self, desc):
+        out = C.c_uint32(abi.INVALID_ID)
+        rc = self._fn("body_add")(self._h, C.byref(desc), C.byref(out))
+        if rc == abi.ERR_REJECTED:
+            return abi.INVALID_ID
+        self._check(rc, "body_add")
+        return out.value
+
+    def add_batch(self, descs):
+        """descs: numpy structured array of abi.body_desc_dtype. Returns ids (uint32; INVALID_ID where rejected)."""
+        descs = np.ascontiguousarray(descs, dtype=abi.body_desc_dtype)
+        ids = np.empty(len(descs), dtype=np.uint32)
+        self._check(self._fn("body_add_batch")(self._h, descs.ctypes.data, len(descs), ids.ctypes.data), "body_add_batch")
+        return ids
+
+    def remove(self, i):
+        self._check(self._fn("body_remove")(self._h, int(i)), "body_remove")
+
+    def activate(self, i):
+        self._check(self._fn("body_activate")(self._h, int(i)), "body_activate")
+
+    def set_layer(self, i, layer):
+        self._check(self._fn("body_set_layer")(self._h, int(i), int(layer)), "body_set_layer")
+
+    def set_pose_vel(self, i, pos, rot, lin_vel=(0, 0, 0), ang_vel=(0, 0, 0)):
+        self._check(self._fn("body_set_pose_vel")(self._h, int(i), _fp(_f3(pos)), _fp(_f4(rot)), _fp(_f3(lin_vel)),
+                                                  _fp(_f3(ang_vel))), "body_set_pose_vel")
+
+    def set_pose_shape(self, i, pos, rot, shape):
+        self._check(self._fn("body_set_pose_shape")(self._h, int(i), _fp(_f3(pos)), _fp(_f4(rot)), _fp(_f4(shape))),
+                    "body_set_pose_shape")
+
+    def set_pos(self, i, pos):
+        self._check(self._fn("body_set_pos")(self._h, int(i), _fp(_f3(pos))), "body_set_pos")
+
+    def set_vel(self, i, lin_vel, ang_vel):
+        self._check(self._fn("body_set_vel")(self._h, int(i), _fp(_f3(lin_vel)), _fp(_f3(ang_vel))), "body_set_vel")
+
+    def move_kinematic(self, i, pos, rot, dt):
+        self._check(self._fn("body_move_kinematic")(self._h, int(i), _fp(_f3(pos)), _fp(_f4(rot)), float(dt)),
+                    "body_move_kinematic")
+
+    def add_force(self, i, f):
+        self._check(self._fn("body_add_force")(self._h, int(i), _fp(_f3(f))), "body_add_force")
+
+    def add_force_at(self, i, f, p):
+        self._check(self._fn("body_add_force_at")(self._h, int(i), _fp(_f3(f)), _fp(_f3(p))), "body_add_force_at")
+
+    def add_torque(self, i, t):
+        self._check(self._fn("body_add_torque")(self._h, int(i), _fp(_f3(t))), "body_add_torque")
+
+    def get_state(self, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        out = np.zeros(len(ids), dtype=abi.body_state_dtype)
+        self._check(self._fn("body_get_state")(self._h, ids.ctypes.data, len(ids), out.ctypes.data), "body_get_state")
+        return out
+
+    def read_states(self, first=0, n=None):
+        n = self.max_bodies - first if n is None else n
+        out = np.zeros(n, dtype=abi.body_state_dtype)
+        self._check(self._fn("world_read_states")(self._h, int(first), int(n), out.ctypes.data), "world_read_states")
+        return out
+
+    def read_active(self, cap=None):
+        cap = self.max_bodies if cap is None else cap
+        out = np.zeros(cap, dtype=abi.body_state_dtype)
+        n = C.c_uint32(0)
+        self._check(self._fn("world_read_active")(self._h, out.ctypes.data, int(cap), C.byref(n)), "world_read_active")
+        return out[:min(n.value, cap)]
+
+    # -- world ----------------------------------------------------------------------------------------------
+    def set_water(self, enabled, z):
+        self._check(self._fn("world_set_water")(self._h, int(bool(enabled)), float(z)), "world_set_water")
+
+    def set_contact_events(self, enabled):
+        self._check(self._fn("world_set_contact_events")(self._h, int(bool(enabled))), "world_set_contact_events")
+
+    def step(self, dt=1.0 / 60.0):
+        self._check(self._fn("world_step")(self._h, float(dt)), "world_step")
+
+    def step_n(self, dt, n):
+        self._check(self._fn("world_step_n")(self._h, float(dt), int(n)), "world_step_n")
+
+    def step_profiled(self, dt=1.0 / 60.0):
+        p = abi.StepProfile()
+        self._check(self._fn("world_step_profiled")(self._h, float(dt), C.byref(p)), "world_step_profiled")
+        return p
+
+    def stats(self):
+        s = abi.StepStats()
+        self._check(self._fn("world_stats")(self._h, C.byref(s)), "world_stats")
+        return s
+
+    def num_bodies(self):
+        n = C.c_uint32(0)
+        self._check(self._fn("world_num_bodies")(self._h, C.byref(n)), "world_num_bodies")
+        return n.value
+
+    def drain_events(self, kind, cap=1 << 16):
+        dt = abi.body_event_dtype if kind <= abi.EVENT_ENTERED_WATER else abi.contact_event_dtype
+        n = C.c_uint32(0)
+        while True:
+            out = np.zeros(cap, dtype=dt)
+            self._check(self._fn("world_drain_events")(self._h, int(kind), out.ctypes.data, int(cap), C.byref(n)),
+                        "world_drain_events")
+            return out[:min(n.value, cap)]
+
+    def raycast(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=abi.ray_dtype)
+        hits = np.zeros(len(rays), dtype=abi.hit_dtype)
+        self._check(self._fn("raycast")(self._h, rays.ctypes.data, len(rays), hits.ctypes.data), "raycast")
+        return hits
+
+    def dump_constraints(self, cap=None):
+        cap = (8 * self.max_bodies + 1024) if cap is None else cap
+        out = np.zeros(cap, dtype=abi.constraint_dump_dtype)
+        n = C.c_uint32(0)
+        self._check(self._fn("world_dump_constraints")(self._h, out.ctypes.data, int(cap), C.byref(n)),
+                    "world_dump_constraints")
+        return out[:min(n.value, cap)]
+
+    def export_boundary(self, lo, hi, margin, cap=1 << 16):
+        out = np.zeros(cap, dtype=abi.ghost_dtype)
+        n = C.c_uint32(0)
+        self._check(self._fn("world_export_boundary")(self._h, _fp(_f3(lo)), _fp(_f3(hi)), float(margin),
+                                                      out.ctypes.data, int(cap), C.byref(n)), "world_export_boundary")
+        return out[:min(n.value, cap)]
+
+    def import_ghosts(self, recs):
+        recs = np.ascontiguousarray(recs, dtype=abi.ghost_dtype)
+        self._check(self._fn("world_import_ghosts")(self._h, recs.ctypes.data, len(recs)), "world_import_ghosts")
