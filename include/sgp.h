@@ -201,13 +201,16 @@ typedef struct sgp_step_stats {
 #define SGP_STAGE_FINALIZE       7   /* AABB refresh, sleep test, islands sleep, buoyancy, events */
 #define SGP_NUM_STAGES           8
 
+#define SGP_NUM_KERNEL_CLASSES 32
 typedef struct sgp_step_profile {
 	float    stage_ms[SGP_NUM_STAGES];
-	float    total_ms;
-	float    sweep_kernel_ms;       /* duration of ONE launch of the integrate+AABB body sweep */
-	uint32_t sweep_bodies;          /* bodies that launch advanced */
-	float    solve_kernel_ms_avg;   /* average launch of the velocity-solve kernel */
-	uint32_t solve_launches;
+	float    total_ms;              /* first launch -> last launch of the step, device time */
+	float    kernel_ms[SGP_NUM_KERNEL_CLASSES];       /* summed launch durations per kernel class (HIP events) */
+	uint32_t kernel_launches[SGP_NUM_KERNEL_CLASSES]; /* launches per class; name: sgp_kernel_class_name() */
+	uint32_t sweep_bodies;          /* body slots one launch of the body-array sweep covers */
+	uint32_t num_constraints;
+	uint32_t num_contact_points;
+	uint32_t num_colours;
 } sgp_step_profile;
 
 typedef struct sgp_world sgp_world;
@@ -271,10 +274,19 @@ int  sgp_world_step_n(sgp_world* w, float dt, uint32_t n);
 /* Same as sgp_world_step but brackets every stage with HIP events on the world's stream. */
 int  sgp_world_step_profiled(sgp_world* w, float dt, sgp_step_profile* out);
 int  sgp_world_stats(sgp_world* w, sgp_step_stats* out);
+/* Name of kernel class k of sgp_step_profile (NULL past the last class). */
+const char* sgp_kernel_class_name(int k);
+/* sizeof() of ABI struct number `which` (order: settings, world_desc, body_desc, body_state, body_event, contact_event,
+ * ray, hit, step_stats, step_profile, ghost_record) so bindings can verify their layout. */
+int  sgp_abi_sizeof(int which);
 /* activated_obs / newly_activated_obs maintenance + listener callbacks (PhysicsWorld.h:194-200). */
 int  sgp_world_drain_events(sgp_world* w, int kind, void* out, uint32_t cap, uint32_t* n_out);
 /* getNumObjects (:1635-1638) */
 int  sgp_world_num_bodies(sgp_world* w, uint32_t* n_out);
+
+/* Debug / test view (not a facade entry point): the contact constraints of the last step, sorted by (a,b).
+ * Record layout: {u32 a,b; i32 colour,np; f32 n[3], lam_n[4], lam_t1[4], lam_t2[4], bias[4]}. */
+int  sgp_world_dump_constraints(sgp_world* w, void* out, uint32_t cap, uint32_t* n_out);
 
 /* ---- queries --------------------------------------------------------------------------------- */
 /* traceRay / traceRayAgainstCollidableObs / doesRayHitAnything (PhysicsWorld.cpp:1668-1725), batched. */

@@ -1028,7 +1028,14 @@ static void box_submerged(const sgo_body* b, float wz, float* vol_out, v3* centr
 		mean = v3_scale(mean, 1.0f / (float)ncap);
 		const v3 e1 = v3_normalized_perpendicular(n), e2 = v3_cross(n, e1);
 		float ang[24];
-		for (int k = 0; k < ncap; ++k) { const v3 r = v3_sub(cap[k], mean); ang[k] = atan2f(v3_dot(r, e2), v3_dot(r, e1)); }
+		for (int k = 0; k < ncap; ++k) {
+			/* monotone pseudo-angle in (-2, 2]: no libm, so the device code orders the points identically */
+			const v3 r = v3_sub(cap[k], mean);
+			const float dx = v3_dot(r, e1), dy = v3_dot(r, e2);
+			const float den = fabsf(dx) + fabsf(dy);
+			const float pa = den > 0.0f ? 1.0f - dx / den : 0.0f;
+			ang[k] = dy < 0.0f ? -pa : pa;
+		}
 		for (int i = 1; i < ncap; ++i) { const float a = ang[i]; const v3 p = cap[i]; int j = i - 1; while (j >= 0 && ang[j] > a) { ang[j + 1] = ang[j]; cap[j + 1] = cap[j]; --j; } ang[j + 1] = a; cap[j + 1] = p; }
 		for (int k = 0; k < ncap; ++k) {
 			const v3 a = cap[k], c = cap[(k + 1) % ncap];

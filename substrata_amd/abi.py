@@ -77,9 +77,13 @@ class StepStats(C.Structure):
                 ("device_bytes", u64)]
 
 
+NUM_KERNEL_CLASSES = 32
+
+
 class StepProfile(C.Structure):
-    _fields_ = [("stage_ms", f32 * NUM_STAGES), ("total_ms", f32), ("sweep_kernel_ms", f32),
-                ("sweep_bodies", u32), ("solve_kernel_ms_avg", f32), ("solve_launches", u32)]
+    _fields_ = [("stage_ms", f32 * NUM_STAGES), ("total_ms", f32), ("kernel_ms", f32 * NUM_KERNEL_CLASSES),
+                ("kernel_launches", u32 * NUM_KERNEL_CLASSES), ("sweep_bodies", u32), ("num_constraints", u32),
+                ("num_contact_points", u32), ("num_colours", u32)]
 
 
 class GhostRecord(C.Structure):
@@ -93,6 +97,9 @@ class ConstraintDump(C.Structure):
     _fields_ = [("a", u32), ("b", u32), ("colour", i32), ("np", i32), ("n", f32 * 3), ("lam_n", f32 * 4),
                 ("lam_t1", f32 * 4), ("lam_t2", f32 * 4), ("bias", f32 * 4)]
 
+
+ABI_SIZEOF_ORDER = ["sgp_settings", "sgp_world_desc", "sgp_body_desc", "sgp_body_state", "sgp_body_event",
+                    "sgp_contact_event", "sgp_ray", "sgp_hit", "sgp_step_stats", "sgp_step_profile", "sgp_ghost_record"]
 
 STRUCTS = {"sgp_settings": Settings, "sgp_world_desc": WorldDesc, "sgp_body_desc": BodyDesc,
            "sgp_body_state": BodyState, "sgp_body_event": BodyEvent, "sgp_contact_event": ContactEvent,
@@ -143,6 +150,8 @@ PROTOTYPES = {
     "world_step_n": (C.c_int, [vp, f32, u32]),
     "world_step_profiled": (C.c_int, [vp, f32, P(StepProfile)]),
     "world_stats": (C.c_int, [vp, P(StepStats)]),
+    "kernel_class_name": (C.c_char_p, [C.c_int]),
+    "abi_sizeof": (C.c_int, [C.c_int]),
     "world_drain_events": (C.c_int, [vp, C.c_int, vp, u32, P(u32)]),
     "world_num_bodies": (C.c_int, [vp, P(u32)]),
     "raycast": (C.c_int, [vp, vp, u32, vp]),

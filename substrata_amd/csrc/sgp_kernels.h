@@ -1,0 +1,198 @@
+// sgp_kernels.h -- device-side data layout + kernel declarations of the gfx950 rigid-body step.
+//
+// One sgp_world owns one set of SoA arrays in HBM (struct DeviceArrays).  Everything a kernel needs is passed as a
+// by-value view (struct DV) so launches carry plain pointers only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/sgp.h"
+
+// ---- body flags (uint32 per body) -----------------------------------------------------------------------------
+#define BF_MOTION_MASK   0x3u        // SGP_MOTION_*
+#define BF_LAYER_SHIFT   2
+#define BF_LAYER_MASK    (0x3u << BF_LAYER_SHIFT)
+#define BF_ALIVE         (1u << 4)
+#define BF_ACTIVE        (1u << 5)
+#define BF_SENSOR        (1u << 6)
+#define BF_ALLOW_SLEEP   (1u << 7)
+#define BF_ZERO_LIN_DRAG (1u << 8)
+#define BF_LARGE         (1u << 9)   // skips the hashed grid (ground quad etc.)
+#define BF_UNDERWATER    (1u << 10)
+#define BF_GHOST         (1u << 11)  // owned by another tile (multi-GPU), simulated as velocity-driven
+#define BF_SHAPE_SHIFT   12
+#define BF_SHAPE_MASK    (0x3u << BF_SHAPE_SHIFT)
+#define BF_WAKE          (1u << 14)  // scratch: touched by an active body this step
+#define BF_CAN_SLEEP     (1u << 15)  // scratch: sleep test result
+
+#define SGP_MAX_COLOURS      64
+#define SGP_OVERFLOW_COLOUR  63
+
+// kernel classes for the per-kernel profile
+enum {
+	KC_APPLY_FORCES = 0, KC_BP_CELL, KC_BP_SCAN, KC_BP_SCATTER, KC_BP_PAIRS, KC_BP_LARGE, KC_NARROWPHASE, KC_WAKE,
+	KC_COLOUR_CLAIM, KC_COLOUR_COMMIT, KC_COLOUR_COUNT, KC_SETUP, KC_WARM_START, KC_SOLVE_VELOCITY,
+	KC_INTEGRATE_POSE, KC_SOLVE_POSITION, KC_FINALIZE, KC_ISLAND_HOOK, KC_ISLAND_FLAG, KC_SLEEP_APPLY, KC_BUOYANCY,
+	KC_CACHE_BUILD, KC_MISC, KC_EDIT, KC_GATHER, KC_COUNT
+};
+
+// Device-side counters of one step (read back once per step).
+struct StepCounters {
+	uint32_t n_pairs;
+	uint32_t n_manifolds;        // narrow-phase hits (incl. sensors)
+	uint32_t n_constraints;      // manifolds that became contact constraints
+	uint32_t n_points;
+	uint32_t n_uncoloured;
+	uint32_t pairs_dropped;
+	uint32_t manifolds_dropped;
+	uint32_t n_active;
+	uint32_t n_read_active;
+	uint32_t n_export;
+	uint32_t pad0;
+	uint32_t colour_count[SGP_MAX_COLOURS];
+	uint32_t colour_fill[SGP_MAX_COLOURS];
+};
+
+// Event counters: NOT cleared at step start (edits between steps also raise activation events); the host drains them.
+struct EventCounters {
+	uint32_t n_activated;
+	uint32_t n_deactivated;
+	uint32_t n_water;
+	uint32_t n_contact_added;
+	uint32_t n_contact_persisted;
+	uint32_t pad[3];
+};
+
+// Host -> device body edit command (applied in order, one thread per body run).
+#define CMD_SET_POS      (1u << 0)
+#define CMD_SET_ROT      (1u << 1)
+#define CMD_SET_VEL      (1u << 2)
+#define CMD_SET_SHAPE    (1u << 3)
+#define CMD_ADD_FORCE    (1u << 4)
+#define CMD_ADD_TORQUE   (1u << 5)
+#define CMD_ADD_FORCE_AT (1u << 6)
+#define CMD_ACTIVATE     (1u << 7)
+#define CMD_SET_LAYER    (1u << 8)
+#define CMD_REMOVE       (1u << 9)
+#define CMD_MOVE_KINEMATIC (1u << 10)
+#define CMD_CREATE       (1u << 11)
+
+struct BodyCmd {
+	uint32_t id;
+	uint32_t ops;
+	float pos[3];      // SET_POS / MOVE_KINEMATIC target / ADD_FORCE_AT point
+	float rot[4];
+	float linv[3];     // SET_VEL / ADD_FORCE(_AT) force
+	float angv[3];     // SET_VEL / ADD_TORQUE torque
+	float shape[4];
+	float dt;          // MOVE_KINEMATIC
+	// CREATE only
+	float inv_mass, mass;
+	float inv_inertia[3];
+	float friction, restitution, gravity_factor, lin_damp, ang_damp;
+	uint32_t flags;
+};
+
+// Constraint (contact manifold) SoA, double buffered (current step / previous step = contact cache).
+struct ConstraintArrays {
+	uint2*    ab;          // body ids, a < b
+	float4*   n_fric;      // normal xyz, combined friction w
+	uint64_t* key;         // a << 32 | b
+	int32_t*  np_col;      // np | colour << 8 | persisted << 16
+	float4*   r1b[4];      // r1 xyz, bias w
+	float4*   r2e[4];      // r2 xyz, eff_n w
+	float4*   lam[4];      // lam_n, lam_t1, lam_t2, -
+	float2*   efft[4];     // eff_t1, eff_t2
+	float4*   loc1[4];     // contact point in body-1 frame
+	float4*   loc2[4];     // contact point in body-2 frame
+};
+
+struct DV {
+	uint32_t n_slots;          // high-water body slot count
+	uint32_t cap_bodies, cap_pairs, cap_manifolds;
+	// bodies
+	float4* pos_im;            // position xyz, inverse mass w (0 unless dynamic)
+	float4* rot;
+	float4* linv;              // xyz, linear damping w
+	float4* angv;              // xyz, angular damping w
+	float4* force;             // xyz, gravity factor w
+	float4* torque;            // xyz, mass w
+	float4* inv_inertia;       // local diagonal xyz, restitution w
+	float4* shape;             // parameters xyz, friction w
+	uint32_t* flags;
+	float4* aabb_min;
+	float4* aabb_max;
+	float4* sleep_s[3];        // sleep test spheres: centre xyz, radius w
+	float*  sleep_timer;
+	float*  submerged;
+	uint64_t* colour_mask;
+	uint64_t* claim[2];
+	uint32_t* island;
+	uint32_t* island_awake;
+	// broad phase
+	uint32_t table_size;       // power of two
+	float    cell_size;
+	uint32_t* cell_hash;       // per body
+	int4*     cell_xyz;        // per body
+	uint32_t* cell_count;      // per bucket (+1)
+	uint32_t* cell_start;      // per bucket (+1), exclusive scan of cell_count
+	uint32_t* cell_fill;
+	uint32_t* sorted_ids;
+	uint32_t* scan_block_sums;
+	const uint32_t* large_ids; uint32_t n_large;
+	uint2*    pairs;
+	// narrow phase output (manifolds, unordered)
+	uint2*    man_ab;
+	float4*   man_n;           // normal xyz, np (as int bits) w
+	float4*   man_p1[4];
+	float4*   man_p2[4];
+	int32_t*  man_colour;      // -1 uncoloured, -2 not a constraint (sensor)
+	uint64_t* man_prio;
+	// constraints
+	ConstraintArrays cur, prev;
+	uint32_t  n_prev;
+	uint64_t* ht_keys; uint32_t* ht_vals; uint32_t ht_size;   // contact cache: pair key -> prev slot
+	uint32_t* colour_start;    // [SGP_MAX_COLOURS + 1]
+	// counters / events
+	StepCounters* ctr;
+	EventCounters* evc;
+	uint32_t* ev_activated; uint32_t* ev_deactivated; uint32_t* ev_water;
+	sgp_contact_event* ev_contacts_added; sgp_contact_event* ev_contacts_persisted; uint32_t cap_contact_events;
+	int contact_events;
+	// settings
+	sgp_settings st;
+	float gx, gy, gz;
+	int water_enabled; float water_z;
+};
+
+// ---- launch wrappers (defined in sgp_kernels.hip) ---------------------------------------------------------------
+void launch_apply_forces(const DV& d, float dt, hipStream_t s);
+void launch_bp_cell(const DV& d, hipStream_t s);
+void launch_bp_scan(const DV& d, hipStream_t s);
+void launch_bp_scatter(const DV& d, hipStream_t s);
+void launch_bp_pairs(const DV& d, hipStream_t s);
+void launch_bp_large(const DV& d, hipStream_t s);
+void launch_narrowphase(const DV& d, uint32_t n_pairs_upper, hipStream_t s);
+void launch_wake(const DV& d, hipStream_t s);
+void launch_colour_claim(const DV& d, uint32_t n_man, uint32_t round, hipStream_t s);
+void launch_colour_commit(const DV& d, uint32_t n_man, uint32_t round, hipStream_t s);
+void launch_colour_count(const DV& d, uint32_t n_man, hipStream_t s);
+struct ColourStarts { uint32_t s[SGP_MAX_COLOURS + 1]; };
+void launch_setup(const DV& d, uint32_t n_man, float dt, const ColourStarts& cs, hipStream_t s);
+void launch_warm_start(const DV& d, uint32_t first, uint32_t count, hipStream_t s);
+void launch_solve_velocity(const DV& d, uint32_t first, uint32_t count, hipStream_t s);
+void launch_solve_velocity_serial(const DV& d, uint32_t first, uint32_t count, int mode, hipStream_t s);
+void launch_integrate_pose(const DV& d, float dt, hipStream_t s);
+void launch_solve_position(const DV& d, uint32_t first, uint32_t count, hipStream_t s);
+void launch_finalize(const DV& d, float dt, hipStream_t s);
+void launch_island_hook(const DV& d, uint32_t n_con, hipStream_t s);
+void launch_island_flag(const DV& d, hipStream_t s);
+void launch_sleep_apply(const DV& d, hipStream_t s);
+void launch_buoyancy(const DV& d, float dt, hipStream_t s);
+void launch_cache_build(const DV& d, uint32_t n_con, hipStream_t s);
+void launch_contact_events(const DV& d, uint32_t n_man, hipStream_t s);
+void launch_apply_cmds(const DV& d, const BodyCmd* cmds, const uint32_t* run_start, uint32_t n_runs, hipStream_t s);
+void launch_gather_states(const DV& d, const uint32_t* ids, uint32_t first, uint32_t n, sgp_body_state* out, hipStream_t s);
+void launch_gather_active(const DV& d, sgp_body_state* out, uint32_t cap, hipStream_t s);
+void launch_dump_constraints(const DV& d, uint32_t n_con, void* out, uint32_t cap, hipStream_t s);
+void launch_raycast(const DV& d, const sgp_ray* rays, uint32_t n, sgp_hit* hits, hipStream_t s);
+void launch_export_boundary(const DV& d, float3 lo, float3 hi, float margin, sgp_ghost_record* out, uint32_t cap, uint32_t* count, hipStream_t s);

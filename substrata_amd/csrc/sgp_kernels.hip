@@ -1,0 +1,1370 @@
+// sgp_kernels.hip -- hand-written gfx950 kernels of the rigid-body step behind PhysicsWorld::think
+// (/root/reference/gui_client/PhysicsWorld.cpp:1356-1443).  Stage map:
+//   k_apply_forces        K8a  MotionProperties::ApplyForceTorqueAndDragInternal
+//   k_bp_*                K2/K3 spatial-hash broad phase (uniform grid, hashed buckets) + layer filter (PhysicsWorld.cpp:160-189)
+//   k_narrowphase         K4   sphere/box/capsule manifolds (sgp_device_collide.h)
+//   k_colour_*, k_setup   K5/K6 contact cache match (warm start), deterministic colouring, constraint properties
+//   k_warm_start, k_solve_velocity  K7  sequential impulses, one colour per launch
+//   k_integrate_pose      K8b  the body-array sweep: x += v dt, q <- rot(w dt) q
+//   k_solve_position      K7b  Baumgarte position iterations
+//   k_finalize, k_island_*, k_sleep_apply  K1 + K9  AABB refresh, sleep spheres, island sleeping
+//   k_buoyancy            A3   Substrata's own water sweep (PhysicsWorld.cpp:1367-1442)
+// All body state is SoA float4 in HBM; every per-body kernel is a coalesced 16 B/lane sweep.
+#include "sgp_kernels.h"
+#include "sgp_device_collide.h"
+
+#define TPB 256
+
+// ---------------------------------------------------------------------------------------------------------------
+// small helpers
+
+SGP_DEV uint32_t f_motion(uint32_t f) { return f & BF_MOTION_MASK; }
+SGP_DEV uint32_t f_layer(uint32_t f) { return (f & BF_LAYER_MASK) >> BF_LAYER_SHIFT; }
+SGP_DEV uint32_t f_shape(uint32_t f) { return (f & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT; }
+SGP_DEV bool f_movable(uint32_t f) { return (f & (BF_ALIVE | BF_ACTIVE)) == (BF_ALIVE | BF_ACTIVE) && f_motion(f) == SGP_MOTION_DYNAMIC; }
+SGP_DEV bool f_active_for_pairs(uint32_t f) { return (f & (BF_ALIVE | BF_ACTIVE)) == (BF_ALIVE | BF_ACTIVE) && f_motion(f) != SGP_MOTION_STATIC; }
+
+// MyObjectLayerPairFilter, PhysicsWorld.cpp:160-189
+SGP_DEV bool layers_collide(uint32_t l1, uint32_t l2)
+{
+	if (l1 == SGP_LAYER_NON_MOVING) return l2 == SGP_LAYER_MOVING;
+	if (l1 == SGP_LAYER_MOVING) return l2 != SGP_LAYER_NON_MOVING_NON_COLLIDABLE && l2 != SGP_LAYER_MOVING_NON_COLLIDABLE;
+	return false;
+}
+
+SGP_DEV v3 shape_local_half(uint32_t type, float4 sh)
+{
+	if (type == SGP_SHAPE_SPHERE) return V3(sh.x, sh.x, sh.x);
+	if (type == SGP_SHAPE_BOX) return V3(sh.x, sh.y, sh.z);
+	return V3(sh.x, sh.x, sh.y + sh.x);
+}
+
+SGP_DEV float shape_volume(uint32_t type, float4 sh)
+{
+	if (type == SGP_SHAPE_SPHERE) return (4.0f / 3.0f) * 3.14159265358979323846f * sh.x * sh.x * sh.x;
+	if (type == SGP_SHAPE_BOX) return 8.0f * sh.x * sh.y * sh.z;
+	return 3.14159265358979323846f * sh.x * sh.x * (2.0f * sh.y) + (4.0f / 3.0f) * 3.14159265358979323846f * sh.x * sh.x * sh.x;
+}
+
+SGP_DEV void compute_aabb(uint32_t type, float4 sh, v3 pos, quat q, v3& mn, v3& mx)
+{
+	v3 e;
+	if (type == SGP_SHAPE_SPHERE) e = V3(sh.x, sh.x, sh.x);
+	else {
+		const m33 R = quat_to_m33(q);
+		if (type == SGP_SHAPE_BOX) {
+			e = V3(fabsf(R.c0.x) * sh.x + fabsf(R.c1.x) * sh.y + fabsf(R.c2.x) * sh.z,
+			       fabsf(R.c0.y) * sh.x + fabsf(R.c1.y) * sh.y + fabsf(R.c2.y) * sh.z,
+			       fabsf(R.c0.z) * sh.x + fabsf(R.c1.z) * sh.y + fabsf(R.c2.z) * sh.z);
+		} else {
+			e = V3(fabsf(R.c2.x) * sh.y + sh.x, fabsf(R.c2.y) * sh.y + sh.x, fabsf(R.c2.z) * sh.y + sh.x);
+		}
+	}
+	mn = v3_sub(pos, e);
+	mx = v3_add(pos, e);
+}
+
+// Body::GetSleepTestPoints
+SGP_DEV void sleep_points(uint32_t type, float4 sh, v3 pos, quat q, v3 out[3])
+{
+	const v3 ext = shape_local_half(type, sh);
+	const m33 R = quat_to_m33(q);
+	int lowest = 0;
+	if (ext.y < v3_get(ext, lowest)) lowest = 1;
+	if (ext.z < v3_get(ext, lowest)) lowest = 2;
+	const int i1 = lowest == 0 ? 1 : 0;
+	const int i2 = lowest == 2 ? 1 : 2;
+	out[0] = pos;
+	out[1] = v3_add(pos, v3_scale(m33_col(R, i1), v3_get(ext, i1)));
+	out[2] = v3_add(pos, v3_scale(m33_col(R, i2), v3_get(ext, i2)));
+}
+
+SGP_DEV void reset_sleep(const DV& d, uint32_t i, uint32_t type, float4 sh, v3 pos, quat q)
+{
+	v3 p[3];
+	sleep_points(type, sh, pos, q, p);
+	d.sleep_s[0][i] = F4(p[0], 0.0f);
+	d.sleep_s[1][i] = F4(p[1], 0.0f);
+	d.sleep_s[2][i] = F4(p[2], 0.0f);
+	d.sleep_timer[i] = 0.0f;
+}
+
+SGP_DEV void push_event(uint32_t* list, uint32_t* counter, uint32_t cap, uint32_t id)
+{
+	const uint32_t k = atomicAdd(counter, 1u);
+	if (k < cap) list[k] = id;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K8a: forces, gravity, damping, velocity clamps (JobApplyGravity)
+
+__global__ void __launch_bounds__(TPB) k_apply_forces(DV d, float dt)
+{
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i >= d.n_slots) return;
+	const uint32_t f = d.flags[i];
+	if (!f_movable(f)) return;
+	const float4 pim = d.pos_im[i], lv4 = d.linv[i], av4 = d.angv[i], F4v = d.force[i], T4 = d.torque[i], II = d.inv_inertia[i];
+	const quat q = Q4(d.rot[i]);
+	const v3 g = V3(d.gx, d.gy, d.gz);
+	v3 lv = V3(lv4), av = V3(av4);
+	lv = v3_add(lv, v3_scale(v3_add(v3_scale(g, F4v.w), v3_scale(V3(F4v), pim.w)), dt));
+	const sym33 Iw = world_inv_inertia(quat_to_m33(q), V3(II));
+	av = v3_add(av, v3_scale(sym33_mul(Iw, V3(T4)), dt));
+	lv = v3_scale(lv, fmaxf(0.0f, 1.0f - lv4.w * dt));
+	av = v3_scale(av, fmaxf(0.0f, 1.0f - av4.w * dt));
+	const float l2 = v3_len_sq(lv), ml = d.st.max_linear_velocity;
+	if (l2 > ml * ml) lv = v3_scale(lv, ml / sqrtf(l2));
+	const float a2 = v3_len_sq(av), ma = d.st.max_angular_velocity;
+	if (a2 > ma * ma) av = v3_scale(av, ma / sqrtf(a2));
+	d.linv[i] = F4(lv, lv4.w);
+	d.angv[i] = F4(av, av4.w);
+	d.force[i] = make_float4(0.0f, 0.0f, 0.0f, F4v.w);
+	d.torque[i] = make_float4(0.0f, 0.0f, 0.0f, T4.w);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K2/K3: broad phase.  Small bodies are binned by AABB centre into cells of edge >= the largest small-body AABB
+// (+ speculative margin), so overlapping bodies always sit in adjacent cells; cells live in a hashed bucket table.
+
+SGP_DEV uint32_t cell_hash_fn(int x, int y, int z, uint32_t mask)
+{
+	return (((uint32_t)x * 73856093u) ^ ((uint32_t)y * 19349663u) ^ ((uint32_t)z * 83492791u)) & mask;
+}
+
+__global__ void __launch_bounds__(TPB) k_bp_cell(DV d)
+{
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i >= d.n_slots) return;
+	const uint32_t f = d.flags[i];
+	uint32_t h = 0xFFFFFFFFu;
+	if ((f & BF_ALIVE) && !(f & BF_LARGE)) {
+		const float4 mn = d.aabb_min[i], mx = d.aabb_max[i];
+		const float inv = 1.0f / d.cell_size;
+		const int cx = (int)floorf((mn.x + mx.x) * 0.5f * inv);
+		const int cy = (int)floorf((mn.y + mx.y) * 0.5f * inv);
+		const int cz = (int)floorf((mn.z + mx.z) * 0.5f * inv);
+		h = cell_hash_fn(cx, cy, cz, d.table_size - 1);
+		d.cell_xyz[i] = make_int4(cx, cy, cz, 0);
+		atomicAdd(&d.cell_count[h], 1u);
+	}
+	d.cell_hash[i] = h;
+}
+
+// exclusive scan of cell_count[0..n) -> cell_start, 3 passes, 1024 elements per block
+__global__ void __launch_bounds__(TPB) k_scan_blocks(const uint32_t* in, uint32_t* out, uint32_t* block_sums, uint32_t n)
+{
+	__shared__ uint32_t wave_sums[TPB / 64];
+	const uint32_t base = (blockIdx.x * TPB + threadIdx.x) * 4;
+	uint32_t v[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) v[k] = (base + k < n) ? in[base + k] : 0u;
+	const uint32_t tsum = v[0] + v[1] + v[2] + v[3];
+	// wave inclusive scan
+	uint32_t x = tsum;
+	const int lane = threadIdx.x & 63;
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off, 64); if (lane >= off) x += y; }
+	const int wave = threadIdx.x >> 6;
+	if (lane == 63) wave_sums[wave] = x;
+	__syncthreads();
+	uint32_t wbase = 0;
+	for (int k = 0; k < wave; ++k) wbase += wave_sums[k];
+	uint32_t excl = wbase + x - tsum;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) { if (base + k < n) out[base + k] = excl; excl += v[k]; }
+	if (threadIdx.x == TPB - 1) block_sums[blockIdx.x] = wbase + x;
+}
+
+__global__ void __launch_bounds__(1024) k_scan_sums(uint32_t* block_sums, uint32_t nb)
+{
+	__shared__ uint32_t wave_sums[16];
+	__shared__ uint32_t carry;
+	if (threadIdx.x == 0) carry = 0;
+	__syncthreads();
+	for (uint32_t start = 0; start < nb; start += 1024) {
+		const uint32_t i = start + threadIdx.x;
+		const uint32_t v = i < nb ? block_sums[i] : 0u;
+		uint32_t x = v;
+		const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+		for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off, 64); if (lane >= off) x += y; }
+		if (lane == 63) wave_sums[wave] = x;
+		__syncthreads();
+		uint32_t wbase = carry;
+		for (int k = 0; k < wave; ++k) wbase += wave_sums[k];
+		if (i < nb) block_sums[i] = wbase + x - v;
+		__syncthreads();
+		if (threadIdx.x == 1023) carry = wbase + x;
+		__syncthreads();
+	}
+}
+
+__global__ void __launch_bounds__(TPB) k_scan_add(uint32_t* out, const uint32_t* block_sums, uint32_t n)
+{
+	const uint32_t base = (blockIdx.x * TPB + threadIdx.x) * 4;
+	const uint32_t add = block_sums[blockIdx.x];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) if (base + k < n) out[base + k] += add;
+}
+
+__global__ void __launch_bounds__(TPB) k_bp_scatter(DV d)
+{
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i >= d.n_slots) return;
+	const uint32_t h = d.cell_hash[i];
+	if (h == 0xFFFFFFFFu) return;
+	const uint32_t slot = d.cell_start[h] + atomicAdd(&d.cell_fill[h], 1u);
+	d.sorted_ids[slot] = i;
+}
+
+SGP_DEV bool pair_passes(const DV& d, uint32_t fi, float4 mni, float4 mxi, uint32_t j)
+{
+	const uint32_t fj = d.flags[j];
+	if (!(fj & BF_ALIVE)) return false;
+	if (f_motion(fi) != SGP_MOTION_DYNAMIC && f_motion(fj) != SGP_MOTION_DYNAMIC) return false;
+	if (!layers_collide(f_layer(fi), f_layer(fj))) return false;
+	const float4 mnj = d.aabb_min[j], mxj = d.aabb_max[j];
+	const float s = d.st.speculative_contact_distance;
+	if (mni.x - s > mxj.x || mnj.x - s > mxi.x) return false;
+	if (mni.y - s > mxj.y || mnj.y - s > mxi.y) return false;
+	if (mni.z - s > mxj.z || mnj.z - s > mxi.z) return false;
+	return true;
+}
+
+SGP_DEV void push_pair(const DV& d, uint32_t i, uint32_t j)
+{
+	const uint32_t k = atomicAdd(&d.ctr->n_pairs, 1u);
+	if (k < d.cap_pairs) d.pairs[k] = make_uint2(i < j ? i : j, i < j ? j : i);
+	else atomicAdd(&d.ctr->pairs_dropped, 1u);
+}
+
+// one thread per ACTIVE small body: scan the 27 neighbouring cells
+__global__ void __launch_bounds__(TPB) k_bp_pairs(DV d)
+{
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i >= d.n_slots) return;
+	const uint32_t fi = d.flags[i];
+	if (!f_active_for_pairs(fi) || (fi & BF_LARGE)) return;
+	const int4 c = d.cell_xyz[i];
+	const float4 mni = d.aabb_min[i], mxi = d.aabb_max[i];
+	const uint32_t mask = d.table_size - 1;
+	for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
+		const int nx = c.x + dx, ny = c.y + dy, nz = c.z + dz;
+		const uint32_t h = cell_hash_fn(nx, ny, nz, mask);
+		const uint32_t b = d.cell_start[h], e = d.cell_start[h + 1];
+		for (uint32_t p = b; p < e; ++p) {
+			const uint32_t j = d.sorted_ids[p];
+			if (j == i) continue;
+			const int4 cj = d.cell_xyz[j];
+			if (cj.x != nx || cj.y != ny || cj.z != nz) continue;     // bucket collision / duplicate bucket
+			// emitted once: by the lower id if both bodies scan, else by the scanning (active) one
+			if (f_active_for_pairs(d.flags[j]) && j < i) continue;
+			if (pair_passes(d, fi, mni, mxi, j)) push_pair(d, i, j);
+		}
+	}
+}
+
+// large bodies (ground quad, PhysicsWorld.cpp:1123) against every body
+__global__ void __launch_bounds__(TPB) k_bp_large(DV d)
+{
+	const uint32_t j = blockIdx.x * TPB + threadIdx.x;
+	if (j >= d.n_slots) return;
+	const uint32_t fj = d.flags[j];
+	if (!(fj & BF_ALIVE)) return;
+	const float4 mnj = d.aabb_min[j], mxj = d.aabb_max[j];
+	for (uint32_t l = 0; l < d.n_large; ++l) {
+		const uint32_t i = d.large_ids[l];
+		if (i == j) continue;
+		const uint32_t fi = d.flags[i];
+		if (!(fi & BF_ALIVE)) continue;
+		if ((fj & BF_LARGE) && j < i) continue;                 // large-large once
+		if (!(f_active_for_pairs(fi) || f_active_for_pairs(fj))) continue;
+		if (pair_passes(d, fj, mnj, mxj, i)) push_pair(d, i, j);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K4: narrow phase, one thread per candidate pair
+
+SGP_DEV sgd_shape load_shape(const DV& d, uint32_t i, uint32_t f)
+{
+	sgd_shape s;
+	s.pos = V3(d.pos_im[i]);
+	s.R = quat_to_m33(Q4(d.rot[i]));
+	s.type = (int)f_shape(f);
+	const float4 sh = d.shape[i];
+	s.p0 = sh.x; s.p1 = sh.y; s.p2 = sh.z;
+	return s;
+}
+
+__global__ void __launch_bounds__(TPB) k_narrowphase(DV d)
+{
+	const uint32_t n = min(d.ctr->n_pairs, d.cap_pairs);
+	for (uint32_t p = blockIdx.x * TPB + threadIdx.x; p < n; p += gridDim.x * TPB) {
+		const uint2 ab = d.pairs[p];
+		const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
+		const sgd_shape sa = load_shape(d, ab.x, fa), sb = load_shape(d, ab.y, fb);
+		sgd_manifold m;
+		if (!sgd_collide(&sa, &sb, d.st.speculative_contact_distance, &m)) continue;
+		const uint32_t slot = atomicAdd(&d.ctr->n_manifolds, 1u);
+		if (slot >= d.cap_manifolds) { atomicAdd(&d.ctr->manifolds_dropped, 1u); continue; }
+		d.man_ab[slot] = ab;
+		d.man_n[slot] = make_float4(m.n.x, m.n.y, m.n.z, __int_as_float(m.np));
+		for (int k = 0; k < 4; ++k) if (k < m.np) { d.man_p1[k][slot] = F4(m.p1[k], 0.0f); d.man_p2[k][slot] = F4(m.p2[k], 0.0f); }
+		d.man_prio[slot] = sgp_mix64(((uint64_t)ab.x << 32) | ab.y);
+		const bool sensor = (fa | fb) & BF_SENSOR;
+		d.man_colour[slot] = sensor ? -2 : -1;
+		if (!sensor) {
+			const bool actA = f_active_for_pairs(fa), actB = f_active_for_pairs(fb);
+			if (actA && !actB && f_motion(fb) == SGP_MOTION_DYNAMIC) atomicOr(&d.flags[ab.y], BF_WAKE);
+			if (actB && !actA && f_motion(fa) == SGP_MOTION_DYNAMIC) atomicOr(&d.flags[ab.x], BF_WAKE);
+		}
+	}
+}
+
+// sleeping bodies touched by an active body wake up (Jolt activates them while finding collisions)
+__global__ void __launch_bounds__(TPB) k_wake(DV d)
+{
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i >= d.n_slots) return;
+	uint32_t f = d.flags[i];
+	if (!(f & BF_WAKE)) return;
+	f &= ~BF_WAKE;
+	if (!(f & BF_ACTIVE)) {
+		f |= BF_ACTIVE;
+		push_event(d.ev_activated, &d.evc->n_activated, d.cap_bodies, i);
+	}
+	d.flags[i] = f;
+	reset_sleep(d, i, f_shape(f), d.shape[i], V3(d.pos_im[i]), Q4(d.rot[i]));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K6: deterministic round-based greedy colouring.  priority = mix64(pair key); per round each uncoloured manifold
+// claims its movable bodies with atomicMin; the manifold that holds both claims takes the lowest colour free on
+// both bodies.  The result depends only on the SET of manifolds (spec: DESIGN.md "Colouring").
+
+__global__ void __launch_bounds__(TPB) k_colour_claim(DV d, uint32_t round)
+{
+	const uint32_t n = min(d.ctr->n_manifolds, d.cap_manifolds);
+	unsigned long long* claim = (unsigned long long*)d.claim[round & 1];
+	for (uint32_t m = blockIdx.x * TPB + threadIdx.x; m < n; m += gridDim.x * TPB) {
+		if (d.man_colour[m] != -1) continue;
+		const uint2 ab = d.man_ab[m];
+		const unsigned long long pr = d.man_prio[m];
+		if (f_movable(d.flags[ab.x])) atomicMin(&claim[ab.x], pr);
+		if (f_movable(d.flags[ab.y])) atomicMin(&claim[ab.y], pr);
+	}
+}
+
+__global__ void __launch_bounds__(TPB) k_colour_commit(DV d, uint32_t round)
+{
+	const uint32_t n = min(d.ctr->n_manifolds, d.cap_manifolds);
+	const uint64_t* claim = d.claim[round & 1];
+	uint64_t* next = d.claim[(round & 1) ^ 1];
+	for (uint32_t m = blockIdx.x * TPB + threadIdx.x; m < n; m += gridDim.x * TPB) {
+		if (d.man_colour[m] != -1) continue;
+		const uint2 ab = d.man_ab[m];
+		const uint64_t pr = d.man_prio[m];
+		const bool ma = f_movable(d.flags[ab.x]), mb = f_movable(d.flags[ab.y]);
+		const bool win = (!ma || claim[ab.x] == pr) && (!mb || claim[ab.y] == pr);
+		if (win) {
+			const uint64_t used = (ma ? d.colour_mask[ab.x] : 0ull) | (mb ? d.colour_mask[ab.y] : 0ull);
+			int col = __ffsll((long long)~used) - 1;
+			if (col < 0 || col > SGP_OVERFLOW_COLOUR) col = SGP_OVERFLOW_COLOUR;
+			d.man_colour[m] = col;
+			if (col < SGP_OVERFLOW_COLOUR) {
+				if (ma) d.colour_mask[ab.x] = d.colour_mask[ab.x] | (1ull << col);
+				if (mb) d.colour_mask[ab.y] = d.colour_mask[ab.y] | (1ull << col);
+			}
+			atomicSub(&d.ctr->n_uncoloured, 1u);
+		}
+		next[ab.x] = ~0ull;
+		next[ab.y] = ~0ull;
+	}
+}
+
+__global__ void __launch_bounds__(TPB) k_colour_init(DV d)
+{
+	// n_uncoloured = number of manifolds that become constraints
+	const uint32_t n = min(d.ctr->n_manifolds, d.cap_manifolds);
+	uint32_t cnt = 0;
+	for (uint32_t m = blockIdx.x * TPB + threadIdx.x; m < n; m += gridDim.x * TPB) if (d.man_colour[m] == -1) ++cnt;
+	if (cnt) atomicAdd(&d.ctr->n_uncoloured, cnt);
+}
+
+__global__ void __launch_bounds__(TPB) k_colour_count(DV d)
+{
+	const uint32_t n = min(d.ctr->n_manifolds, d.cap_manifolds);
+	for (uint32_t m = blockIdx.x * TPB + threadIdx.x; m < n; m += gridDim.x * TPB) {
+		const int c = d.man_colour[m];
+		if (c < 0) continue;
+		atomicAdd(&d.ctr->colour_count[c], 1u);
+		atomicAdd(&d.ctr->n_points, (uint32_t)__float_as_int(d.man_n[m].w));
+		atomicAdd(&d.ctr->n_constraints, 1u);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K5: contact constraint setup (Jolt ContactConstraintManager::TemplatedAddContactConstraint): contact-cache match
+// for warm starting, restitution / speculative bias, effective masses.  Constraints are written colour-sorted.
+
+SGP_DEV float axis_eff_mass(float im1, const sym33& I1, v3 r1, float im2, const sym33& I2, v3 r2, v3 axis)
+{
+	float inv = 0.0f;
+	if (im1 > 0.0f) { const v3 c = v3_cross(r1, axis); inv = im1 + v3_dot(sym33_mul(I1, c), c); }
+	if (im2 > 0.0f) { const v3 c = v3_cross(r2, axis); inv = inv + (im2 + v3_dot(sym33_mul(I2, c), c)); }
+	return inv > 0.0f ? 1.0f / inv : 0.0f;
+}
+
+SGP_DEV uint32_t ht_hash(uint64_t key, uint32_t mask) { return (uint32_t)(sgp_mix64(key) >> 20) & mask; }
+
+SGP_DEV uint32_t cache_find(const DV& d, uint64_t key)
+{
+	if (d.n_prev == 0) return 0xFFFFFFFFu;
+	const uint32_t mask = d.ht_size - 1;
+	uint32_t h = ht_hash(key, mask);
+	for (uint32_t probe = 0; probe < d.ht_size; ++probe) {
+		const uint64_t k = d.ht_keys[h];
+		if (k == key) return d.ht_vals[h];
+		if (k == ~0ull) return 0xFFFFFFFFu;
+		h = (h + 1) & mask;
+	}
+	return 0xFFFFFFFFu;
+}
+
+__global__ void __launch_bounds__(TPB) k_setup(DV d, ColourStarts cs, float dt)
+{
+	const uint32_t n = min(d.ctr->n_manifolds, d.cap_manifolds);
+	for (uint32_t m = blockIdx.x * TPB + threadIdx.x; m < n; m += gridDim.x * TPB) {
+		const int col = d.man_colour[m];
+		if (col < 0) continue;
+		const uint32_t slot = cs.s[col] + atomicAdd(&d.ctr->colour_fill[col], 1u);
+		const uint2 ab = d.man_ab[m];
+		const uint64_t key = ((uint64_t)ab.x << 32) | ab.y;
+		const float4 n4 = d.man_n[m];
+		const int np = __float_as_int(n4.w);
+		const v3 nrm = V3(n4);
+		const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
+		const float4 pa4 = d.pos_im[ab.x], pb4 = d.pos_im[ab.y];
+		const v3 posA = V3(pa4), posB = V3(pb4);
+		const m33 RA = quat_to_m33(Q4(d.rot[ab.x])), RB = quat_to_m33(Q4(d.rot[ab.y]));
+		const float4 iiA = d.inv_inertia[ab.x], iiB = d.inv_inertia[ab.y];
+		const float4 shA = d.shape[ab.x], shB = d.shape[ab.y];
+		const float im1 = f_movable(fa) ? pa4.w : 0.0f, im2 = f_movable(fb) ? pb4.w : 0.0f;
+		sym33 I1 = sym33_zero(), I2 = sym33_zero();
+		if (im1 > 0.0f) I1 = world_inv_inertia(RA, V3(iiA));
+		if (im2 > 0.0f) I2 = world_inv_inertia(RB, V3(iiB));
+		const float friction = sqrtf(shA.w * shB.w);
+		const float restitution = fmaxf(iiA.w, iiB.w);
+		const v3 t1 = v3_normalized_perpendicular(nrm);
+		const v3 t2 = v3_cross(nrm, t1);
+		const v3 lvA = V3(d.linv[ab.x]), avA = V3(d.angv[ab.x]), lvB = V3(d.linv[ab.y]), avB = V3(d.angv[ab.y]);
+		const float gfA = d.force[ab.x].w, gfB = d.force[ab.y].w;
+		const uint32_t fslot = cache_find(d, key);
+		const uint32_t pslot = d.st.warm_start ? fslot : 0xFFFFFFFFu;
+		int pnp = 0;
+		if (pslot != 0xFFFFFFFFu) pnp = d.prev.np_col[pslot] & 0xFF;
+		const v3 g = V3(d.gx, d.gy, d.gz);
+		d.cur.ab[slot] = ab;
+		d.cur.n_fric[slot] = F4(nrm, friction);
+		d.cur.key[slot] = key;
+		d.cur.np_col[slot] = np | (col << 8) | ((fslot != 0xFFFFFFFFu ? 1 : 0) << 16);
+		for (int i = 0; i < 4; ++i) {
+			if (i >= np) break;
+			const v3 p1 = V3(d.man_p1[i][m]), p2 = V3(d.man_p2[i][m]);
+			const v3 local1 = m33_tmul(RA, v3_sub(p1, posA));
+			const v3 local2 = m33_tmul(RB, v3_sub(p2, posB));
+			float lam_n = 0.0f, lam_t1 = 0.0f, lam_t2 = 0.0f;
+			for (int j = 0; j < 4; ++j) {
+				if (j >= pnp) break;
+				const v3 c1 = V3(d.prev.loc1[j][pslot]), c2 = V3(d.prev.loc2[j][pslot]);
+				if (v3_len_sq(v3_sub(local1, c1)) < d.st.contact_point_preserve_lambda_max_dist_sq &&
+				    v3_len_sq(v3_sub(local2, c2)) < d.st.contact_point_preserve_lambda_max_dist_sq) {
+					const float4 pl = d.prev.lam[j][pslot];
+					lam_n = pl.x; lam_t1 = pl.y; lam_t2 = pl.z;
+					break;
+				}
+			}
+			const v3 mid = v3_scale(v3_add(p1, p2), 0.5f);
+			const v3 r1 = v3_sub(mid, posA), r2 = v3_sub(mid, posB);
+			const v3 va = v3_add(lvA, v3_cross(avA, r1));
+			const v3 vb = v3_add(lvB, v3_cross(avB, r2));
+			const float normal_velocity = v3_dot(v3_sub(vb, va), nrm);
+			const float penetration = v3_dot(v3_sub(p1, p2), nrm);
+			const float spec_bias = fmaxf(0.0f, -penetration / dt);
+			float bias = spec_bias;
+			if (restitution > 0.0f && normal_velocity < -d.st.min_velocity_for_restitution) {
+				if (normal_velocity < -spec_bias) {
+					v3 rel_acc = V3(0.0f, 0.0f, 0.0f);
+					if (im2 > 0.0f) rel_acc = v3_add(rel_acc, v3_scale(g, gfB));
+					if (im1 > 0.0f) rel_acc = v3_sub(rel_acc, v3_scale(g, gfA));
+					const float force_dv = fminf(0.0f, v3_dot(rel_acc, nrm)) * dt;
+					bias = restitution * (normal_velocity - force_dv);
+				}
+			}
+			const float eff_n = axis_eff_mass(im1, I1, r1, im2, I2, r2, nrm);
+			const float eff_t1 = axis_eff_mass(im1, I1, r1, im2, I2, r2, t1);
+			const float eff_t2 = axis_eff_mass(im1, I1, r1, im2, I2, r2, t2);
+			d.cur.r1b[i][slot] = F4(r1, bias);
+			d.cur.r2e[i][slot] = F4(r2, eff_n);
+			d.cur.lam[i][slot] = make_float4(lam_n, lam_t1, lam_t2, 0.0f);
+			d.cur.efft[i][slot] = make_float2(eff_t1, eff_t2);
+			d.cur.loc1[i][slot] = F4(local1, 0.0f);
+			d.cur.loc2[i][slot] = F4(local2, 0.0f);
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K7: sequential impulses.  One launch per colour: constraints of a colour share no movable body.
+
+struct BodyVel { v3 lv, av; float lw, aw; };
+
+SGP_DEV void apply_impulse(BodyVel& A, BodyVel& B, float im1, const sym33& I1, float im2, const sym33& I2, v3 r1, v3 r2, v3 axis, float lambda)
+{
+	if (im1 > 0.0f) {
+		A.lv = v3_sub(A.lv, v3_scale(axis, lambda * im1));
+		A.av = v3_sub(A.av, v3_scale(sym33_mul(I1, v3_cross(r1, axis)), lambda));
+	}
+	if (im2 > 0.0f) {
+		B.lv = v3_add(B.lv, v3_scale(axis, lambda * im2));
+		B.av = v3_add(B.av, v3_scale(sym33_mul(I2, v3_cross(r2, axis)), lambda));
+	}
+}
+
+SGP_DEV float axis_jv(const BodyVel& A, const BodyVel& B, v3 r1, v3 r2, v3 axis)
+{
+	return v3_dot(axis, v3_sub(A.lv, B.lv)) + v3_dot(v3_cross(r1, axis), A.av) - v3_dot(v3_cross(r2, axis), B.av);
+}
+
+struct PairCtx { uint2 ab; float im1, im2; sym33 I1, I2; BodyVel A, B; v3 n, t1, t2; float friction; int np; };
+
+SGP_DEV void load_pair(const DV& d, uint32_t slot, PairCtx& c)
+{
+	c.ab = d.cur.ab[slot];
+	const float4 nf = d.cur.n_fric[slot];
+	c.n = V3(nf); c.friction = nf.w;
+	c.np = d.cur.np_col[slot] & 0xFF;
+	const uint32_t fa = d.flags[c.ab.x], fb = d.flags[c.ab.y];
+	const float4 pa = d.pos_im[c.ab.x], pb = d.pos_im[c.ab.y];
+	c.im1 = f_movable(fa) ? pa.w : 0.0f; c.im2 = f_movable(fb) ? pb.w : 0.0f;
+	c.I1 = sym33_zero(); c.I2 = sym33_zero();
+	if (c.im1 > 0.0f) c.I1 = world_inv_inertia(quat_to_m33(Q4(d.rot[c.ab.x])), V3(d.inv_inertia[c.ab.x]));
+	if (c.im2 > 0.0f) c.I2 = world_inv_inertia(quat_to_m33(Q4(d.rot[c.ab.y])), V3(d.inv_inertia[c.ab.y]));
+	const float4 la = d.linv[c.ab.x], aa = d.angv[c.ab.x], lb = d.linv[c.ab.y], ab4 = d.angv[c.ab.y];
+	c.A.lv = V3(la); c.A.av = V3(aa); c.A.lw = la.w; c.A.aw = aa.w;
+	c.B.lv = V3(lb); c.B.av = V3(ab4); c.B.lw = lb.w; c.B.aw = ab4.w;
+}
+
+SGP_DEV void store_pair_vel(const DV& d, const PairCtx& c)
+{
+	if (c.im1 > 0.0f) { d.linv[c.ab.x] = F4(c.A.lv, c.A.lw); d.angv[c.ab.x] = F4(c.A.av, c.A.aw); }
+	if (c.im2 > 0.0f) { d.linv[c.ab.y] = F4(c.B.lv, c.B.lw); d.angv[c.ab.y] = F4(c.B.av, c.B.aw); }
+}
+
+SGP_DEV void warm_start_one(const DV& d, uint32_t slot)
+{
+	PairCtx c;
+	load_pair(d, slot, c);
+	c.t1 = v3_normalized_perpendicular(c.n);
+	c.t2 = v3_cross(c.n, c.t1);
+	for (int i = 0; i < 4; ++i) {
+		if (i >= c.np) break;
+		const v3 r1 = V3(d.cur.r1b[i][slot]), r2 = V3(d.cur.r2e[i][slot]);
+		const float4 l = d.cur.lam[i][slot];
+		if (c.friction > 0.0f) {
+			apply_impulse(c.A, c.B, c.im1, c.I1, c.im2, c.I2, r1, r2, c.t1, l.y);
+			apply_impulse(c.A, c.B, c.im1, c.I1, c.im2, c.I2, r1, r2, c.t2, l.z);
+		}
+		apply_impulse(c.A, c.B, c.im1, c.I1, c.im2, c.I2, r1, r2, c.n, l.x);
+	}
+	store_pair_vel(d, c);
+}
+
+SGP_DEV void solve_velocity_one(const DV& d, uint32_t slot)
+{
+	PairCtx c;
+	load_pair(d, slot, c);
+	c.t1 = v3_normalized_perpendicular(c.n);
+	c.t2 = v3_cross(c.n, c.t1);
+	float4 r1b[4], r2e[4], lam[4];
+	for (int i = 0; i < 4; ++i) {
+		if (i >= c.np) break;
+		r1b[i] = d.cur.r1b[i][slot]; r2e[i] = d.cur.r2e[i][slot]; lam[i] = d.cur.lam[i][slot];
+	}
+	// friction first (uses the normal impulse of the previous iteration), then non-penetration
+	if (c.friction > 0.0f) {
+		for (int i = 0; i < 4; ++i) {
+			if (i >= c.np) break;
+			const float2 et = d.cur.efft[i][slot];
+			if (et.x <= 0.0f && et.y <= 0.0f) continue;
+			const v3 r1 = V3(r1b[i]), r2 = V3(r2e[i]);
+			float l1 = lam[i].y + et.x * axis_jv(c.A, c.B, r1, r2, c.t1);
+			float l2 = lam[i].z + et.y * axis_jv(c.A, c.B, r1, r2, c.t2);
+			const float max_f = c.friction * lam[i].x;
+			const float tot_sq = l1 * l1 + l2 * l2;
+			if (tot_sq > max_f * max_f) { const float sc = max_f / sqrtf(tot_sq); l1 = l1 * sc; l2 = l2 * sc; }
+			apply_impulse(c.A, c.B, c.im1, c.I1, c.im2, c.I2, r1, r2, c.t1, l1 - lam[i].y); lam[i].y = l1;
+			apply_impulse(c.A, c.B, c.im1, c.I1, c.im2, c.I2, r1, r2, c.t2, l2 - lam[i].z); lam[i].z = l2;
+		}
+	}
+	for (int i = 0; i < 4; ++i) {
+		if (i >= c.np) break;
+		const float eff_n = r2e[i].w;
+		if (eff_n <= 0.0f) continue;
+		const v3 r1 = V3(r1b[i]), r2 = V3(r2e[i]);
+		const float jv = axis_jv(c.A, c.B, r1, r2, c.n);
+		const float lambda = eff_n * (jv - r1b[i].w);
+		const float nl = fmaxf(lam[i].x + lambda, 0.0f);
+		apply_impulse(c.A, c.B, c.im1, c.I1, c.im2, c.I2, r1, r2, c.n, nl - lam[i].x);
+		lam[i].x = nl;
+	}
+	for (int i = 0; i < 4; ++i) { if (i >= c.np) break; d.cur.lam[i][slot] = lam[i]; }
+	store_pair_vel(d, c);
+}
+
+SGP_DEV void solve_position_one(const DV& d, uint32_t slot)
+{
+	const uint2 ab = d.cur.ab[slot];
+	const float4 nf = d.cur.n_fric[slot];
+	const v3 nrm = V3(nf);
+	const int np = d.cur.np_col[slot] & 0xFF;
+	const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
+	float4 pa = d.pos_im[ab.x], pb = d.pos_im[ab.y];
+	const float im1 = f_movable(fa) ? pa.w : 0.0f, im2 = f_movable(fb) ? pb.w : 0.0f;
+	quat qa = Q4(d.rot[ab.x]), qb = Q4(d.rot[ab.y]);
+	const v3 iiA = V3(d.inv_inertia[ab.x]), iiB = V3(d.inv_inertia[ab.y]);
+	v3 posA = V3(pa), posB = V3(pb);
+	bool moved = false;
+	for (int i = 0; i < 4; ++i) {
+		if (i >= np) break;
+		const m33 RA = quat_to_m33(qa), RB = quat_to_m33(qb);
+		const v3 p1 = v3_add(posA, m33_mul(RA, V3(d.cur.loc1[i][slot])));
+		const v3 p2 = v3_add(posB, m33_mul(RB, V3(d.cur.loc2[i][slot])));
+		float sep = v3_dot(v3_sub(p2, p1), nrm) + d.st.penetration_slop;
+		if (sep < 0.0f) {
+			sep = fmaxf(sep, -d.st.max_penetration_distance);
+			const v3 mid = v3_scale(v3_add(p1, p2), 0.5f);
+			const v3 r1 = v3_sub(mid, posA), r2 = v3_sub(mid, posB);
+			sym33 I1 = sym33_zero(), I2 = sym33_zero();
+			if (im1 > 0.0f) I1 = world_inv_inertia(RA, iiA);
+			if (im2 > 0.0f) I2 = world_inv_inertia(RB, iiB);
+			const float eff = axis_eff_mass(im1, I1, r1, im2, I2, r2, nrm);
+			if (eff <= 0.0f) continue;
+			const float lambda = -eff * d.st.baumgarte * sep;
+			if (im1 > 0.0f) {
+				posA = v3_sub(posA, v3_scale(nrm, lambda * im1));
+				qa = quat_add_rotation_step(qa, v3_scale(sym33_mul(I1, v3_cross(r1, nrm)), -lambda));
+			}
+			if (im2 > 0.0f) {
+				posB = v3_add(posB, v3_scale(nrm, lambda * im2));
+				qb = quat_add_rotation_step(qb, v3_scale(sym33_mul(I2, v3_cross(r2, nrm)), lambda));
+			}
+			moved = true;
+		}
+	}
+	if (moved) {
+		if (im1 > 0.0f) { d.pos_im[ab.x] = F4(posA, pa.w); d.rot[ab.x] = make_float4(qa.x, qa.y, qa.z, qa.w); }
+		if (im2 > 0.0f) { d.pos_im[ab.y] = F4(posB, pb.w); d.rot[ab.y] = make_float4(qb.x, qb.y, qb.z, qb.w); }
+	}
+}
+
+__global__ void __launch_bounds__(TPB) k_warm_start(DV d, uint32_t first, uint32_t count)
+{
+	const uint32_t t = blockIdx.x * TPB + threadIdx.x;
+	if (t < count) warm_start_one(d, first + t);
+}
+__global__ void __launch_bounds__(TPB) k_solve_velocity(DV d, uint32_t first, uint32_t count)
+{
+	const uint32_t t = blockIdx.x * TPB + threadIdx.x;
+	if (t < count) solve_velocity_one(d, first + t);
+}
+__global__ void __launch_bounds__(TPB) k_solve_position(DV d, uint32_t first, uint32_t count)
+{
+	const uint32_t t = blockIdx.x * TPB + threadIdx.x;
+	if (t < count) solve_position_one(d, first + t);
+}
+
+// Overflow colour (a body with > 63 contacts): one thread, ascending priority (Jolt's non-parallel split).
+__global__ void k_solve_serial(DV d, uint32_t first, uint32_t count, int mode)
+{
+	if (blockIdx.x != 0 || threadIdx.x != 0) return;
+	uint64_t last = 0; bool have_last = false;
+	for (uint32_t it = 0; it < count; ++it) {
+		uint64_t best = ~0ull; uint32_t bslot = first;
+		for (uint32_t k = 0; k < count; ++k) {
+			const uint64_t pr = sgp_mix64(d.cur.key[first + k]);
+			if ((!have_last || pr > last) && pr <= best) { best = pr; bslot = first + k; }
+		}
+		last = best; have_last = true;
+		if (mode == 0) warm_start_one(d, bslot);
+		else if (mode == 1) solve_velocity_one(d, bslot);
+		else solve_position_one(d, bslot);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K8b: THE BODY-ARRAY SWEEP.  x += v dt, q <- normalize(rot(w dt) * q) for every active non-static body.
+
+__global__ void __launch_bounds__(TPB) k_integrate_pose(DV d, float dt)
+{
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i >= d.n_slots) return;
+	const uint32_t f = d.flags[i];
+	if ((f & (BF_ALIVE | BF_ACTIVE)) != (BF_ALIVE | BF_ACTIVE) || f_motion(f) == SGP_MOTION_STATIC) return;
+	float4 lv4 = d.linv[i], av4 = d.angv[i];
+	v3 lv = V3(lv4), av = V3(av4);
+	if (f_motion(f) == SGP_MOTION_DYNAMIC) {
+		const float l2 = v3_len_sq(lv), ml = d.st.max_linear_velocity;
+		bool w = false;
+		if (l2 > ml * ml) { lv = v3_scale(lv, ml / sqrtf(l2)); w = true; }
+		const float a2 = v3_len_sq(av), ma = d.st.max_angular_velocity;
+		if (a2 > ma * ma) { av = v3_scale(av, ma / sqrtf(a2)); w = true; }
+		if (w) { d.linv[i] = F4(lv, lv4.w); d.angv[i] = F4(av, av4.w); }
+	}
+	const float4 p = d.pos_im[i];
+	const v3 np = v3_add(V3(p), v3_scale(lv, dt));
+	const quat q = quat_add_rotation_step(Q4(d.rot[i]), v3_scale(av, dt));
+	d.pos_im[i] = F4(np, p.w);
+	d.rot[i] = make_float4(q.x, q.y, q.z, q.w);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K1 + K9: AABB refresh, sleep test spheres (Body::UpdateSleepStateInternal), island bookkeeping
+
+__global__ void __launch_bounds__(TPB) k_finalize(DV d, float dt)
+{
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i >= d.n_slots) return;
+	d.island[i] = i;
+	d.island_awake[i] = 0;
+	uint32_t f = d.flags[i];
+	if ((f & (BF_ALIVE | BF_ACTIVE)) != (BF_ALIVE | BF_ACTIVE)) return;
+	const uint32_t type = f_shape(f);
+	const float4 sh = d.shape[i];
+	const v3 pos = V3(d.pos_im[i]);
+	const quat q = Q4(d.rot[i]);
+	v3 mn, mx;
+	compute_aabb(type, sh, pos, q, mn, mx);
+	d.aabb_min[i] = F4(mn, 0.0f);
+	d.aabb_max[i] = F4(mx, 0.0f);
+	if (!f_movable(f)) return;
+	bool can_sleep;
+	if (!(f & BF_ALLOW_SLEEP) || !d.st.allow_sleeping) can_sleep = false;
+	else {
+		const float max_movement = d.st.point_velocity_sleep_threshold * d.st.time_before_sleep;
+		v3 pts[3];
+		sleep_points(type, sh, pos, q, pts);
+		bool reset = false;
+		float4 s[3];
+		for (int k = 0; k < 3; ++k) {
+			s[k] = d.sleep_s[k][i];
+			const v3 dd = v3_sub(pts[k], V3(s[k]));
+			const float d2 = v3_len_sq(dd);
+			if (d2 > s[k].w * s[k].w) {
+				const float dl = sqrtf(d2);
+				const float nr = 0.5f * (s[k].w + dl);
+				const v3 c = v3_add(V3(s[k]), v3_scale(dd, (nr - s[k].w) / dl));
+				s[k] = F4(c, nr);
+			}
+			if (s[k].w > max_movement) reset = true;
+		}
+		if (reset) {
+			for (int k = 0; k < 3; ++k) d.sleep_s[k][i] = F4(pts[k], 0.0f);
+			d.sleep_timer[i] = 0.0f;
+			can_sleep = false;
+		} else {
+			for (int k = 0; k < 3; ++k) d.sleep_s[k][i] = s[k];
+			const float t = d.sleep_timer[i] + dt;
+			d.sleep_timer[i] = t;
+			can_sleep = t >= d.st.time_before_sleep;
+		}
+	}
+	f = can_sleep ? (f | BF_CAN_SLEEP) : (f & ~BF_CAN_SLEEP);
+	d.flags[i] = f;
+}
+
+SGP_DEV uint32_t uf_find(const uint32_t* parent, uint32_t x)
+{
+	uint32_t p = parent[x];
+	while (p != x) { x = p; p = parent[x]; }
+	return x;
+}
+
+// union by smaller root id (ECL-CC style hooking): the final root of a component is its smallest body id
+__global__ void __launch_bounds__(TPB) k_island_hook(DV d, uint32_t n_con)
+{
+	const uint32_t k = blockIdx.x * TPB + threadIdx.x;
+	if (k >= n_con) return;
+	const uint2 ab = d.cur.ab[k];
+	if (!f_movable(d.flags[ab.x]) || !f_movable(d.flags[ab.y])) return;
+	uint32_t ra = uf_find(d.island, ab.x), rb = uf_find(d.island, ab.y);
+	while (ra != rb) {
+		const uint32_t hi = ra > rb ? ra : rb, lo = ra > rb ? rb : ra;
+		const uint32_t old = atomicCAS(&d.island[hi], hi, lo);
+		if (old == hi) break;
+		ra = uf_find(d.island, old); rb = uf_find(d.island, lo);
+	}
+}
+
+__global__ void __launch_bounds__(TPB) k_island_flag(DV d)
+{
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i >= d.n_slots) return;
+	const uint32_t f = d.flags[i];
+	if (!f_movable(f)) return;
+	if (!(f & BF_CAN_SLEEP)) d.island_awake[uf_find(d.island, i)] = 1;
+}
+
+__global__ void __launch_bounds__(TPB) k_sleep_apply(DV d)
+{
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i >= d.n_slots) return;
+	uint32_t f = d.flags[i];
+	if (!(f & BF_ALIVE)) return;
+	if (f_movable(f)) {
+		if (d.island_awake[uf_find(d.island, i)] == 0) {
+			f &= ~(BF_ACTIVE | BF_CAN_SLEEP);
+			d.flags[i] = f;
+			d.linv[i] = make_float4(0.0f, 0.0f, 0.0f, d.linv[i].w);
+			d.angv[i] = make_float4(0.0f, 0.0f, 0.0f, d.angv[i].w);
+			push_event(d.ev_deactivated, &d.evc->n_deactivated, d.cap_bodies, i);
+		}
+	} else if (f_motion(f) == SGP_MOTION_KINEMATIC && (f & BF_ACTIVE)) {
+		const v3 lv = V3(d.linv[i]), av = V3(d.angv[i]);
+		if (v3_len_sq(lv) == 0.0f && v3_len_sq(av) == 0.0f) {
+			f &= ~BF_ACTIVE;
+			d.flags[i] = f;
+			push_event(d.ev_deactivated, &d.evc->n_deactivated, d.cap_bodies, i);
+		}
+	}
+	if (f & BF_ACTIVE) atomicAdd(&d.ctr->n_active, 1u);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// A3: water buoyancy sweep, PhysicsWorld.cpp:1367-1442 (Body::GetSubmergedVolume + Body::ApplyBuoyancyImpulse)
+
+SGP_DEV void box_submerged(v3 h, m33 R, float posz, float wz, float* vol_out, v3* centroid_out)
+{
+	const v3 n = m33_tmul(R, V3(0.0f, 0.0f, 1.0f));
+	const float dpl = wz - posz;
+	float vol = 0.0f; v3 cen = V3(0.0f, 0.0f, 0.0f);
+	v3 cap[24]; int ncap = 0;
+	for (int ax = 0; ax < 3; ++ax) for (int sg = -1; sg <= 1; sg += 2) {
+		const int u = (ax + 1) % 3, v = (ax + 2) % 3;
+		v3 q[4];
+		const float su[4] = { 1, -1, -1, 1 }, sv[4] = { 1, 1, -1, -1 };
+		for (int k = 0; k < 4; ++k) {
+			v3 p = V3(0.0f, 0.0f, 0.0f);
+			v3_set(p, ax, (float)sg * v3_get(h, ax));
+			const int kk = sg > 0 ? k : 3 - k;
+			v3_set(p, u, su[kk] * v3_get(h, u)); v3_set(p, v, sv[kk] * v3_get(h, v));
+			q[k] = p;
+		}
+		v3 poly[8]; int np = 0;
+		for (int k = 0; k < 4; ++k) {
+			const v3 a = q[k], c = q[(k + 1) % 4];
+			const float da = v3_dot(n, a) - dpl, dc = v3_dot(n, c) - dpl;
+			if (da <= 0.0f) poly[np++] = a;
+			if ((da <= 0.0f) != (dc <= 0.0f)) {
+				const float t = da / (da - dc);
+				const v3 x = v3_add(a, v3_scale(v3_sub(c, a), t));
+				poly[np++] = x;
+				if (ncap < 24) cap[ncap++] = x;
+			}
+		}
+		for (int k = 1; k + 1 < np; ++k) {
+			const float tv = v3_dot(poly[0], v3_cross(poly[k], poly[k + 1])) / 6.0f;
+			vol += tv;
+			cen = v3_add(cen, v3_scale(v3_add(v3_add(poly[0], poly[k]), poly[k + 1]), tv * 0.25f));
+		}
+	}
+	if (ncap >= 3) {
+		v3 mean = V3(0.0f, 0.0f, 0.0f);
+		for (int k = 0; k < ncap; ++k) mean = v3_add(mean, cap[k]);
+		mean = v3_scale(mean, 1.0f / (float)ncap);
+		const v3 e1 = v3_normalized_perpendicular(n), e2 = v3_cross(n, e1);
+		float ang[24];
+		for (int k = 0; k < ncap; ++k) {
+			const v3 r = v3_sub(cap[k], mean);
+			const float dx = v3_dot(r, e1), dy = v3_dot(r, e2);
+			const float den = fabsf(dx) + fabsf(dy);
+			const float pa = den > 0.0f ? 1.0f - dx / den : 0.0f;
+			ang[k] = dy < 0.0f ? -pa : pa;
+		}
+		for (int i = 1; i < ncap; ++i) { const float a = ang[i]; const v3 p = cap[i]; int j = i - 1; while (j >= 0 && ang[j] > a) { ang[j + 1] = ang[j]; cap[j + 1] = cap[j]; --j; } ang[j + 1] = a; cap[j + 1] = p; }
+		for (int k = 0; k < ncap; ++k) {
+			const v3 a = cap[k], c = cap[(k + 1) % ncap];
+			const float tv = v3_dot(mean, v3_cross(a, c)) / 6.0f;
+			vol += tv;
+			cen = v3_add(cen, v3_scale(v3_add(v3_add(mean, a), c), tv * 0.25f));
+		}
+	}
+	*vol_out = vol;
+	*centroid_out = vol > 1.0e-12f ? m33_mul(R, v3_scale(cen, 1.0f / vol)) : V3(0.0f, 0.0f, 0.0f);
+}
+
+__global__ void __launch_bounds__(TPB) k_buoyancy(DV d, float dt)
+{
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i >= d.n_slots) return;
+	uint32_t f = d.flags[i];
+	if (!f_movable(f)) return;                                                       // :1377
+	const float4 mn = d.aabb_min[i], mx = d.aabb_max[i];
+	if (mn.z < d.water_z) {                                                          // :1379
+		const float fluid_density = 1020.0f;                                         // :1381
+		const uint32_t type = f_shape(f);
+		const float4 sh = d.shape[i];
+		const float4 pim = d.pos_im[i];
+		const v3 pos = V3(pim);
+		const m33 R = quat_to_m33(Q4(d.rot[i]));
+		const float total = shape_volume(type, sh);
+		float sub; v3 rc;
+		if (type == SGP_SHAPE_BOX) box_submerged(V3(sh.x, sh.y, sh.z), R, pos.z, d.water_z, &sub, &rc);
+		else if (type == SGP_SHAPE_SPHERE) {
+			const float r = sh.x;
+			const float h = clampf((d.water_z - pos.z) + r, 0.0f, 2.0f * r);
+			const float pi = 3.14159265358979323846f;
+			sub = pi * h * h * (3.0f * r - h) / 3.0f;
+			float cz = 0.0f;
+			if (h > 0.0f) { const float k = 2.0f * r - h; cz = -(3.0f * k * k) / (4.0f * (3.0f * r - h)); }
+			rc = V3(0.0f, 0.0f, cz);
+		} else {
+			const float fr = clampf((d.water_z - mn.z) / (mx.z - mn.z), 0.0f, 1.0f);
+			sub = total * fr;
+			rc = V3(0.0f, 0.0f, (mn.z + 0.5f * fr * (mx.z - mn.z)) - pos.z);
+		}
+		const float mass = d.torque[i].w;
+		const float buoyancy = fluid_density * total / mass;                         // :1387
+		bool applied = false;
+		if (sub > 0.0f) {
+			const float inv_mass = pim.w;
+			const float rho = buoyancy / (total * inv_mass);
+			const v3 g = V3(0.0f, 0.0f, -9.81f);                                      // :1407
+			const float gf = d.force[i].w;
+			const v3 buoy_imp = v3_scale(g, -rho * sub * gf * dt);
+			float4 lv4 = d.linv[i], av4 = d.angv[i];
+			const v3 lv = V3(lv4), av = V3(av4);
+			const v3 cob_vel = v3_add(lv, v3_cross(av, rc));
+			const v3 rel = v3_neg(cob_vel);
+			const float lin_drag = (f & BF_ZERO_LIN_DRAG) ? 0.0f : 0.1f;             // :1404
+			const v3 size = v3_scale(shape_local_half(type, sh), 2.0f);
+			const v3 lrel = m33_tmul(R, rel);
+			const float rl2 = v3_len_sq(lrel);
+			v3 drag_imp = V3(0.0f, 0.0f, 0.0f);
+			if (rl2 > 1.0e-12f) {
+				const float rl = sqrtf(rl2);
+				const v3 dirl = v3_scale(v3_abs(lrel), 1.0f / rl);
+				const float area = (sub / total) * (dirl.x * size.y * size.z + dirl.y * size.x * size.z + dirl.z * size.x * size.y);
+				float dv = 0.5f * rho * rl2 * lin_drag * area * dt * inv_mass;
+				if (dv > rl) dv = rl;
+				drag_imp = v3_scale(rel, dv / (rl * inv_mass));
+			}
+			const v3 dlin = v3_scale(v3_add(drag_imp, buoy_imp), inv_mass);
+			const float l = (size.x + size.y + size.z) / 3.0f;
+			const float ang_drag = 3.0f;                                             // :1405
+			const v3 drag_ang_imp = v3_scale(av, -ang_drag * sub / total * dt * (l * l) / inv_mass);
+			const sym33 Iw = world_inv_inertia(R, V3(d.inv_inertia[i]));
+			v3 ddrag = sym33_mul(Iw, drag_ang_imp);
+			if (v3_len_sq(ddrag) > v3_len_sq(av)) ddrag = v3_neg(av);
+			const v3 dang = v3_add(ddrag, sym33_mul(Iw, v3_cross(rc, v3_add(buoy_imp, drag_imp))));
+			d.linv[i] = F4(v3_add(lv, dlin), lv4.w);
+			d.angv[i] = F4(v3_add(av, dang), av4.w);
+			applied = true;
+		}
+		if (applied) {
+			if (!(f & BF_UNDERWATER)) { push_event(d.ev_water, &d.evc->n_water, d.cap_bodies, i); f |= BF_UNDERWATER; d.flags[i] = f; }
+			d.submerged[i] = sub;
+		} else { if (f & BF_UNDERWATER) d.flags[i] = f & ~BF_UNDERWATER; d.submerged[i] = 0.0f; }
+	} else if (f & BF_UNDERWATER) { d.flags[i] = f & ~BF_UNDERWATER; d.submerged[i] = 0.0f; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// contact cache (pair key -> constraint slot) for the next step's warm start; contact events
+
+__global__ void __launch_bounds__(TPB) k_cache_build(DV d, uint32_t n_con)
+{
+	const uint32_t k = blockIdx.x * TPB + threadIdx.x;
+	if (k >= n_con) return;
+	const uint64_t key = d.cur.key[k];
+	const uint32_t mask = d.ht_size - 1;
+	uint32_t h = ht_hash(key, mask);
+	for (uint32_t probe = 0; probe < d.ht_size; ++probe) {
+		const unsigned long long old = atomicCAS((unsigned long long*)&d.ht_keys[h], ~0ull, (unsigned long long)key);
+		if (old == ~0ull || old == key) { d.ht_vals[h] = k; return; }
+		h = (h + 1) & mask;
+	}
+}
+
+__global__ void __launch_bounds__(TPB) k_contact_events(DV d)
+{
+	const uint32_t n = min(d.ctr->n_manifolds, d.cap_manifolds);
+	for (uint32_t m = blockIdx.x * TPB + threadIdx.x; m < n; m += gridDim.x * TPB) {
+		const uint2 ab = d.man_ab[m];
+		const uint64_t key = ((uint64_t)ab.x << 32) | ab.y;
+		const bool persisted = cache_find(d, key) != 0xFFFFFFFFu;
+		uint32_t* ctr = persisted ? &d.evc->n_contact_persisted : &d.evc->n_contact_added;
+		const uint32_t k = atomicAdd(ctr, 1u);
+		if (k >= d.cap_contact_events) continue;
+		sgp_contact_event e;
+		e.id1 = ab.x; e.id2 = ab.y; e.userdata1 = 0; e.userdata2 = 0;
+		const float4 la = d.linv[ab.x], lb = d.linv[ab.y];
+		e.lin_vel1[0] = la.x; e.lin_vel1[1] = la.y; e.lin_vel1[2] = la.z;
+		e.lin_vel2[0] = lb.x; e.lin_vel2[1] = lb.y; e.lin_vel2[2] = lb.z;
+		const float4 n4 = d.man_n[m];
+		const int np = __float_as_int(n4.w);
+		const v3 nrm = V3(n4);
+		const v3 base = V3(d.man_p1[0][m]);
+		e.base_offset[0] = base.x; e.base_offset[1] = base.y; e.base_offset[2] = base.z;
+		e.normal[0] = nrm.x; e.normal[1] = nrm.y; e.normal[2] = nrm.z;
+		e.num_points = (uint32_t)np;
+		float pen = -3.4e38f;
+		for (int i = 0; i < 4; ++i) {
+			v3 r = V3(0.0f, 0.0f, 0.0f);
+			if (i < np) {
+				const v3 p1 = V3(d.man_p1[i][m]), p2 = V3(d.man_p2[i][m]);
+				r = v3_sub(p1, base);
+				pen = fmaxf(pen, v3_dot(v3_sub(p1, p2), nrm));
+			}
+			e.rel_points_on1[i][0] = r.x; e.rel_points_on1[i][1] = r.y; e.rel_points_on1[i][2] = r.z;
+		}
+		e.penetration = pen;
+		(persisted ? d.ev_contacts_persisted : d.ev_contacts_added)[k] = e;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host edits: one thread per body, its commands applied in submission order
+
+SGP_DEV void refresh_aabb(const DV& d, uint32_t i, uint32_t f)
+{
+	v3 mn, mx;
+	compute_aabb(f_shape(f), d.shape[i], V3(d.pos_im[i]), Q4(d.rot[i]), mn, mx);
+	d.aabb_min[i] = F4(mn, 0.0f); d.aabb_max[i] = F4(mx, 0.0f);
+}
+
+SGP_DEV uint32_t activate_body(const DV& d, uint32_t i, uint32_t f)
+{
+	if (!(f & BF_ALIVE) || f_motion(f) == SGP_MOTION_STATIC) return f;
+	if (!(f & BF_ACTIVE)) { f |= BF_ACTIVE; push_event(d.ev_activated, &d.evc->n_activated, d.cap_bodies, i); }
+	reset_sleep(d, i, f_shape(f), d.shape[i], V3(d.pos_im[i]), Q4(d.rot[i]));
+	return f;
+}
+
+__global__ void __launch_bounds__(TPB) k_apply_cmds(DV d, const BodyCmd* cmds, const uint32_t* run_start, uint32_t n_runs)
+{
+	const uint32_t r = blockIdx.x * TPB + threadIdx.x;
+	if (r >= n_runs) return;
+	const uint32_t b = run_start[r], e = run_start[r + 1];
+	const uint32_t i = cmds[b].id;
+	uint32_t f = d.flags[i];
+	for (uint32_t k = b; k < e; ++k) {
+		const BodyCmd& c = cmds[k];
+		if (c.ops & CMD_CREATE) {
+			f = c.flags;
+			d.pos_im[i] = make_float4(c.pos[0], c.pos[1], c.pos[2], c.inv_mass);
+			d.rot[i] = make_float4(c.rot[0], c.rot[1], c.rot[2], c.rot[3]);
+			d.linv[i] = make_float4(c.linv[0], c.linv[1], c.linv[2], c.lin_damp);
+			d.angv[i] = make_float4(c.angv[0], c.angv[1], c.angv[2], c.ang_damp);
+			d.force[i] = make_float4(0.0f, 0.0f, 0.0f, c.gravity_factor);
+			d.torque[i] = make_float4(0.0f, 0.0f, 0.0f, c.mass);
+			d.inv_inertia[i] = make_float4(c.inv_inertia[0], c.inv_inertia[1], c.inv_inertia[2], c.restitution);
+			d.shape[i] = make_float4(c.shape[0], c.shape[1], c.shape[2], c.friction);
+			d.submerged[i] = 0.0f;
+			refresh_aabb(d, i, f);
+			reset_sleep(d, i, f_shape(f), d.shape[i], V3(d.pos_im[i]), Q4(d.rot[i]));
+			continue;
+		}
+		if (c.ops & CMD_REMOVE) { f = 0; continue; }
+		if (!(f & BF_ALIVE)) continue;
+		if (c.ops & CMD_SET_LAYER) f = (f & ~BF_LAYER_MASK) | ((c.flags & 0x3u) << BF_LAYER_SHIFT);
+		if (c.ops & CMD_MOVE_KINEMATIC) {
+			// MotionProperties::MoveKinematic: velocities that reach the target in dt
+			if (f_motion(f) == SGP_MOTION_KINEMATIC && c.dt > 0.0f) {
+				const v3 pos = V3(d.pos_im[i]);
+				const quat q = Q4(d.rot[i]);
+				const v3 lv = v3_scale(v3_sub(V3(c.pos[0], c.pos[1], c.pos[2]), pos), 1.0f / c.dt);
+				quat t; t.x = c.rot[0]; t.y = c.rot[1]; t.z = c.rot[2]; t.w = c.rot[3];
+				quat cj; cj.x = -q.x; cj.y = -q.y; cj.z = -q.z; cj.w = q.w;
+				quat dq = quat_mul(t, cj);
+				if (dq.w < 0.0f) { dq.x = -dq.x; dq.y = -dq.y; dq.z = -dq.z; dq.w = -dq.w; }
+				const float sl = sqrtf(dq.x * dq.x + dq.y * dq.y + dq.z * dq.z);
+				v3 av = V3(0.0f, 0.0f, 0.0f);
+				if (sl > 1.0e-12f) { const float angle = 2.0f * atan2f(sl, dq.w); av = v3_scale(V3(dq.x / sl, dq.y / sl, dq.z / sl), angle / c.dt); }
+				d.linv[i] = F4(lv, d.linv[i].w);
+				d.angv[i] = F4(av, d.angv[i].w);
+				f = activate_body(d, i, f);
+			}
+			continue;
+		}
+		bool pose = false;
+		if (c.ops & CMD_SET_POS) { d.pos_im[i] = make_float4(c.pos[0], c.pos[1], c.pos[2], d.pos_im[i].w); pose = true; }
+		if (c.ops & CMD_SET_ROT) { d.rot[i] = make_float4(c.rot[0], c.rot[1], c.rot[2], c.rot[3]); pose = true; }
+		if (c.ops & CMD_SET_SHAPE) { d.shape[i] = make_float4(c.shape[0], c.shape[1], c.shape[2], d.shape[i].w); pose = true; }
+		if ((c.ops & CMD_SET_VEL) && f_motion(f) != SGP_MOTION_STATIC) {
+			d.linv[i] = make_float4(c.linv[0], c.linv[1], c.linv[2], d.linv[i].w);
+			d.angv[i] = make_float4(c.angv[0], c.angv[1], c.angv[2], d.angv[i].w);
+		}
+		if (pose) refresh_aabb(d, i, f);
+		if (f_motion(f) == SGP_MOTION_DYNAMIC) {
+			if (c.ops & CMD_ADD_FORCE) {
+				const float4 F = d.force[i];
+				d.force[i] = F4(v3_add(V3(F), V3(c.linv[0], c.linv[1], c.linv[2])), F.w);
+				f = activate_body(d, i, f);
+			}
+			if (c.ops & CMD_ADD_TORQUE) {
+				const float4 T = d.torque[i];
+				d.torque[i] = F4(v3_add(V3(T), V3(c.angv[0], c.angv[1], c.angv[2])), T.w);
+				f = activate_body(d, i, f);
+			}
+			if (c.ops & CMD_ADD_FORCE_AT) {
+				const v3 Fv = V3(c.linv[0], c.linv[1], c.linv[2]);
+				const float4 F = d.force[i], T = d.torque[i];
+				d.force[i] = F4(v3_add(V3(F), Fv), F.w);
+				d.torque[i] = F4(v3_add(V3(T), v3_cross(v3_sub(V3(c.pos[0], c.pos[1], c.pos[2]), V3(d.pos_im[i])), Fv)), T.w);
+				f = activate_body(d, i, f);
+			}
+		}
+		if (c.ops & CMD_ACTIVATE) f = activate_body(d, i, f);
+	}
+	d.flags[i] = f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// read-back
+
+SGP_DEV void fill_state(const DV& d, uint32_t i, sgp_body_state* s)
+{
+	const float4 p = d.pos_im[i], q = d.rot[i], lv = d.linv[i], av = d.angv[i];
+	const uint32_t f = d.flags[i];
+	s->pos[0] = p.x; s->pos[1] = p.y; s->pos[2] = p.z;
+	s->rot[0] = q.x; s->rot[1] = q.y; s->rot[2] = q.z; s->rot[3] = q.w;
+	s->lin_vel[0] = lv.x; s->lin_vel[1] = lv.y; s->lin_vel[2] = lv.z;
+	s->ang_vel[0] = av.x; s->ang_vel[1] = av.y; s->ang_vel[2] = av.z;
+	s->active = (f & BF_ACTIVE) ? 1u : 0u;
+	s->underwater = (f & BF_UNDERWATER) ? 1u : 0u;
+	s->submerged_volume = d.submerged[i];
+	s->id = (f & BF_ALIVE) ? i : SGP_INVALID_ID;
+}
+
+__global__ void __launch_bounds__(TPB) k_gather_states(DV d, const uint32_t* ids, uint32_t first, uint32_t n, sgp_body_state* out)
+{
+	const uint32_t k = blockIdx.x * TPB + threadIdx.x;
+	if (k >= n) return;
+	const uint32_t i = ids ? ids[k] : first + k;
+	if (i < d.cap_bodies) fill_state(d, i, &out[k]);
+}
+
+__global__ void __launch_bounds__(TPB) k_gather_active(DV d, sgp_body_state* out, uint32_t cap)
+{
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i >= d.n_slots) return;
+	const uint32_t f = d.flags[i];
+	if ((f & (BF_ALIVE | BF_ACTIVE)) != (BF_ALIVE | BF_ACTIVE)) return;
+	const uint32_t k = atomicAdd(&d.ctr->n_read_active, 1u);
+	if (k < cap) fill_state(d, i, &out[k]);
+}
+
+struct ConstraintDumpRec { uint32_t a, b; int32_t colour; int32_t np; float n[3]; float lam_n[4]; float lam_t1[4]; float lam_t2[4]; float bias[4]; };
+
+__global__ void __launch_bounds__(TPB) k_dump_constraints(DV d, uint32_t n_con, ConstraintDumpRec* out, uint32_t cap)
+{
+	// dumps the PREVIOUS buffer: after a step the solved constraints have been swapped into `prev`
+	const uint32_t k = blockIdx.x * TPB + threadIdx.x;
+	if (k >= n_con || k >= cap) return;
+	ConstraintDumpRec r;
+	const uint2 ab = d.prev.ab[k];
+	const int nc = d.prev.np_col[k];
+	const float4 nf = d.prev.n_fric[k];
+	r.a = ab.x; r.b = ab.y; r.colour = (nc >> 8) & 0xFF; r.np = nc & 0xFF;
+	r.n[0] = nf.x; r.n[1] = nf.y; r.n[2] = nf.z;
+	for (int i = 0; i < 4; ++i) {
+		if (i < r.np) { const float4 l = d.prev.lam[i][k]; r.lam_n[i] = l.x; r.lam_t1[i] = l.y; r.lam_t2[i] = l.z; r.bias[i] = d.prev.r1b[i][k].w; }
+		else { r.lam_n[i] = 0; r.lam_t1[i] = 0; r.lam_t2[i] = 0; r.bias[i] = 0; }
+	}
+	out[k] = r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ray queries (traceRay, PhysicsWorld.cpp:1668-1725), one thread per ray, brute force over bodies with an AABB slab test
+
+SGP_DEV float ray_body(uint32_t type, float4 sh, v3 pos, quat q, v3 o, v3 dir, float max_t, v3* n_out)
+{
+	const m33 R = quat_to_m33(q);
+	const v3 ol = m33_tmul(R, v3_sub(o, pos)), dl = m33_tmul(R, dir);
+	if (type == SGP_SHAPE_SPHERE) {
+		const float r = sh.x;
+		const float B = v3_dot(ol, dl), C = v3_len_sq(ol) - r * r;
+		if (C <= 0.0f) { *n_out = v3_neg(dir); return 0.0f; }
+		const float disc = B * B - C;
+		if (disc < 0.0f) return -1.0f;
+		const float t = -B - sqrtf(disc);
+		if (t < 0.0f || t > max_t) return -1.0f;
+		*n_out = m33_mul(R, v3_scale(v3_add(ol, v3_scale(dl, t)), 1.0f / r));
+		return t;
+	}
+	if (type == SGP_SHAPE_BOX) {
+		const v3 h = V3(sh.x, sh.y, sh.z);
+		float t0 = 0.0f, t1 = max_t; int ax = -1; float sg = 0.0f;
+		for (int k = 0; k < 3; ++k) {
+			const float ok = v3_get(ol, k), dk = v3_get(dl, k), hk = v3_get(h, k);
+			if (fabsf(dk) < 1.0e-12f) { if (ok < -hk || ok > hk) return -1.0f; continue; }
+			float ta = (-hk - ok) / dk, tb = (hk - ok) / dk; float s = -1.0f;
+			if (ta > tb) { const float tmp = ta; ta = tb; tb = tmp; s = 1.0f; }
+			if (ta > t0) { t0 = ta; ax = k; sg = s; }
+			if (tb < t1) t1 = tb;
+			if (t0 > t1) return -1.0f;
+		}
+		if (ax < 0) { *n_out = v3_neg(dir); return 0.0f; }
+		v3 nl = V3(0.0f, 0.0f, 0.0f); v3_set(nl, ax, sg);
+		*n_out = m33_mul(R, nl);
+		return t0;
+	}
+	{
+		const float r = sh.x, hh = sh.y;
+		float best = -1.0f; v3 bn = V3(0.0f, 0.0f, 0.0f);
+		const float a = dl.x * dl.x + dl.y * dl.y;
+		const float bq = ol.x * dl.x + ol.y * dl.y, c = ol.x * ol.x + ol.y * ol.y - r * r;
+		if (a > 1.0e-12f) {
+			const float disc = bq * bq - a * c;
+			if (disc >= 0.0f) {
+				const float t = (-bq - sqrtf(disc)) / a;
+				const float z = ol.z + dl.z * t;
+				if (t >= 0.0f && t <= max_t && fabsf(z) <= hh) { best = t; bn = V3((ol.x + dl.x * t) / r, (ol.y + dl.y * t) / r, 0.0f); }
+			}
+		}
+		for (int sgn = -1; sgn <= 1; sgn += 2) {
+			const v3 oc = V3(ol.x, ol.y, ol.z - (float)sgn * hh);
+			const float B = v3_dot(oc, dl), C = v3_len_sq(oc) - r * r;
+			const float disc = B * B - C;
+			if (disc < 0.0f) continue;
+			const float t = -B - sqrtf(disc);
+			if (t < 0.0f || t > max_t) continue;
+			if (best < 0.0f || t < best) { best = t; bn = v3_scale(v3_add(oc, v3_scale(dl, t)), 1.0f / r); }
+		}
+		if (best < 0.0f) {
+			const v3 qq = sgd_closest_on_segment(V3(0.0f, 0.0f, -hh), V3(0.0f, 0.0f, hh), ol);
+			if (v3_len_sq(v3_sub(ol, qq)) <= r * r) { *n_out = v3_neg(dir); return 0.0f; }
+			return -1.0f;
+		}
+		*n_out = m33_mul(R, bn);
+		return best;
+	}
+}
+
+__global__ void __launch_bounds__(64) k_raycast(DV d, const sgp_ray* rays, uint32_t n, sgp_hit* hits)
+{
+	const uint32_t k = blockIdx.x * 64 + threadIdx.x;
+	if (k >= n) return;
+	const sgp_ray ry = rays[k];
+	const v3 o = V3(ry.origin[0], ry.origin[1], ry.origin[2]), dir = V3(ry.dir[0], ry.dir[1], ry.dir[2]);
+	float best = ry.max_t; uint32_t bid = SGP_INVALID_ID; v3 bn = V3(0.0f, 0.0f, 0.0f);
+	for (uint32_t i = 0; i < d.n_slots; ++i) {
+		const uint32_t f = d.flags[i];
+		if (!(f & BF_ALIVE) || i == ry.ignore_id) continue;
+		const uint32_t layer = f_layer(f);
+		if (ry.collidable_only && !(layer == SGP_LAYER_NON_MOVING || layer == SGP_LAYER_MOVING)) continue;
+		// slab test against the world AABB
+		const float4 mn = d.aabb_min[i], mx = d.aabb_max[i];
+		float t0 = 0.0f, t1 = best; bool miss = false;
+		const float oo[3] = { o.x, o.y, o.z }, dd[3] = { dir.x, dir.y, dir.z };
+		const float lo[3] = { mn.x, mn.y, mn.z }, hi[3] = { mx.x, mx.y, mx.z };
+		for (int a = 0; a < 3 && !miss; ++a) {
+			if (fabsf(dd[a]) < 1.0e-12f) { if (oo[a] < lo[a] - 1.0e-4f || oo[a] > hi[a] + 1.0e-4f) miss = true; }
+			else {
+				float ta = (lo[a] - 1.0e-4f - oo[a]) / dd[a], tb = (hi[a] + 1.0e-4f - oo[a]) / dd[a];
+				if (ta > tb) { const float tmp = ta; ta = tb; tb = tmp; }
+				t0 = fmaxf(t0, ta); t1 = fminf(t1, tb);
+				if (t0 > t1) miss = true;
+			}
+		}
+		if (miss) continue;
+		v3 nn;
+		const float t = ray_body(f_shape(f), d.shape[i], V3(d.pos_im[i]), Q4(d.rot[i]), o, dir, best, &nn);
+		if (t >= 0.0f && (t < best || bid == SGP_INVALID_ID) && t <= best) { best = t; bid = i; bn = nn; }
+	}
+	sgp_hit h;
+	h.id = bid; h.t = bid == SGP_INVALID_ID ? 0.0f : best;
+	h.normal[0] = bn.x; h.normal[1] = bn.y; h.normal[2] = bn.z;
+	h.userdata = 0;
+	hits[k] = h;
+}
+
+// multi-GPU tiles: bodies owned by this tile whose inflated AABB pokes outside [lo,hi)
+__global__ void __launch_bounds__(TPB) k_export_boundary(DV d, float3 lo, float3 hi, float margin, sgp_ghost_record* out, uint32_t cap, uint32_t* count)
+{
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i >= d.n_slots) return;
+	const uint32_t f = d.flags[i];
+	if (!(f & BF_ALIVE) || (f & (BF_GHOST | BF_LARGE)) || f_motion(f) == SGP_MOTION_STATIC) return;
+	const float4 mn = d.aabb_min[i], mx = d.aabb_max[i];
+	const bool crosses = mn.x - margin < lo.x || mn.y - margin < lo.y || mn.z - margin < lo.z ||
+	                     mx.x + margin >= hi.x || mx.y + margin >= hi.y || mx.z + margin >= hi.z;
+	if (!crosses) return;
+	const uint32_t k = atomicAdd(count, 1u);
+	if (k >= cap) return;
+	sgp_ghost_record r;
+	const float4 p = d.pos_im[i], q = d.rot[i], lv = d.linv[i], av = d.angv[i], sh = d.shape[i];
+	r.pos[0] = p.x; r.pos[1] = p.y; r.pos[2] = p.z;
+	r.rot[0] = q.x; r.rot[1] = q.y; r.rot[2] = q.z; r.rot[3] = q.w;
+	r.lin_vel[0] = lv.x; r.lin_vel[1] = lv.y; r.lin_vel[2] = lv.z;
+	r.ang_vel[0] = av.x; r.ang_vel[1] = av.y; r.ang_vel[2] = av.z;
+	r.shape_type = (int32_t)f_shape(f);
+	r.shape[0] = sh.x; r.shape[1] = sh.y; r.shape[2] = sh.z; r.shape[3] = 0.0f;
+	r.mass = d.torque[i].w; r.friction = sh.w; r.restitution = d.inv_inertia[i].w;
+	r.motion_type = f_motion(f);
+	r.global_id = i;
+	out[k] = r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// launch wrappers
+
+static inline uint32_t blocks_for(uint32_t n) { return n ? (n + TPB - 1) / TPB : 1; }
+static inline uint32_t stride_grid(uint32_t estimate) { uint32_t b = blocks_for(estimate); if (b < 64) b = 64; if (b > 4096) b = 4096; return b; }
+
+void launch_apply_forces(const DV& d, float dt, hipStream_t s) { hipLaunchKernelGGL(k_apply_forces, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d, dt); }
+void launch_bp_cell(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_bp_cell, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d); }
+void launch_bp_scan(const DV& d, hipStream_t s)
+{
+	const uint32_t n = d.table_size + 1;
+	const uint32_t nb = (n + 1023) / 1024;
+	hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(TPB), 0, s, d.cell_count, d.cell_start, d.scan_block_sums, n);
+	hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, d.scan_block_sums, nb);
+	hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(TPB), 0, s, d.cell_start, d.scan_block_sums, n);
+}
+void launch_bp_scatter(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_bp_scatter, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d); }
+void launch_bp_pairs(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_bp_pairs, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d); }
+void launch_bp_large(const DV& d, hipStream_t s) { if (d.n_large) hipLaunchKernelGGL(k_bp_large, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d); }
+void launch_narrowphase(const DV& d, uint32_t est, hipStream_t s) { hipLaunchKernelGGL(k_narrowphase, dim3(stride_grid(est)), dim3(TPB), 0, s, d); }
+void launch_wake(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_wake, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d); }
+void launch_colour_claim(const DV& d, uint32_t est, uint32_t round, hipStream_t s)
+{
+	if (round == 0) hipLaunchKernelGGL(k_colour_init, dim3(stride_grid(est)), dim3(TPB), 0, s, d);
+	hipLaunchKernelGGL(k_colour_claim, dim3(stride_grid(est)), dim3(TPB), 0, s, d, round);
+}
+void launch_colour_commit(const DV& d, uint32_t est, uint32_t round, hipStream_t s) { hipLaunchKernelGGL(k_colour_commit, dim3(stride_grid(est)), dim3(TPB), 0, s, d, round); }
+void launch_colour_count(const DV& d, uint32_t est, hipStream_t s) { hipLaunchKernelGGL(k_colour_count, dim3(stride_grid(est)), dim3(TPB), 0, s, d); }
+void launch_setup(const DV& d, uint32_t n_man, float dt, const ColourStarts& cs, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_setup, dim3(stride_grid(n_man)), dim3(TPB), 0, s, d, cs, dt);
+}
+void launch_warm_start(const DV& d, uint32_t first, uint32_t count, hipStream_t s) { if (count) hipLaunchKernelGGL(k_warm_start, dim3(blocks_for(count)), dim3(TPB), 0, s, d, first, count); }
+void launch_solve_velocity(const DV& d, uint32_t first, uint32_t count, hipStream_t s) { if (count) hipLaunchKernelGGL(k_solve_velocity, dim3(blocks_for(count)), dim3(TPB), 0, s, d, first, count); }
+void launch_solve_velocity_serial(const DV& d, uint32_t first, uint32_t count, int mode, hipStream_t s) { if (count) hipLaunchKernelGGL(k_solve_serial, dim3(1), dim3(64), 0, s, d, first, count, mode); }
+void launch_integrate_pose(const DV& d, float dt, hipStream_t s) { hipLaunchKernelGGL(k_integrate_pose, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d, dt); }
+void launch_solve_position(const DV& d, uint32_t first, uint32_t count, hipStream_t s) { if (count) hipLaunchKernelGGL(k_solve_position, dim3(blocks_for(count)), dim3(TPB), 0, s, d, first, count); }
+void launch_finalize(const DV& d, float dt, hipStream_t s) { hipLaunchKernelGGL(k_finalize, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d, dt); }
+void launch_island_hook(const DV& d, uint32_t n_con, hipStream_t s) { if (n_con) hipLaunchKernelGGL(k_island_hook, dim3(blocks_for(n_con)), dim3(TPB), 0, s, d, n_con); }
+void launch_island_flag(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_island_flag, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d); }
+void launch_sleep_apply(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_sleep_apply, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d); }
+void launch_buoyancy(const DV& d, float dt, hipStream_t s) { hipLaunchKernelGGL(k_buoyancy, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d, dt); }
+void launch_cache_build(const DV& d, uint32_t n_con, hipStream_t s) { if (n_con) hipLaunchKernelGGL(k_cache_build, dim3(blocks_for(n_con)), dim3(TPB), 0, s, d, n_con); }
+void launch_contact_events(const DV& d, uint32_t est, hipStream_t s) { hipLaunchKernelGGL(k_contact_events, dim3(stride_grid(est)), dim3(TPB), 0, s, d); }
+void launch_apply_cmds(const DV& d, const BodyCmd* cmds, const uint32_t* run_start, uint32_t n_runs, hipStream_t s) { if (n_runs) hipLaunchKernelGGL(k_apply_cmds, dim3(blocks_for(n_runs)), dim3(TPB), 0, s, d, cmds, run_start, n_runs); }
+void launch_gather_states(const DV& d, const uint32_t* ids, uint32_t first, uint32_t n, sgp_body_state* out, hipStream_t s) { if (n) hipLaunchKernelGGL(k_gather_states, dim3(blocks_for(n)), dim3(TPB), 0, s, d, ids, first, n, out); }
+void launch_gather_active(const DV& d, sgp_body_state* out, uint32_t cap, hipStream_t s) { hipLaunchKernelGGL(k_gather_active, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d, out, cap); }
+void launch_dump_constraints(const DV& d, uint32_t n_con, void* out, uint32_t cap, hipStream_t s) { if (n_con) hipLaunchKernelGGL(k_dump_constraints, dim3(blocks_for(n_con)), dim3(TPB), 0, s, d, n_con, (ConstraintDumpRec*)out, cap); }
+void launch_raycast(const DV& d, const sgp_ray* rays, uint32_t n, sgp_hit* hits, hipStream_t s) { if (n) hipLaunchKernelGGL(k_raycast, dim3((n + 63) / 64), dim3(64), 0, s, d, rays, n, hits); }
+void launch_export_boundary(const DV& d, float3 lo, float3 hi, float margin, sgp_ghost_record* out, uint32_t cap, uint32_t* count, hipStream_t s) { hipLaunchKernelGGL(k_export_boundary, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d, lo, hi, margin, out, cap, count); }

@@ -1,0 +1,964 @@
+// sgp_world.hip -- host side of libsgp.so: the C ABI of include/sgp.h over the gfx950 kernels.
+//
+// Replaces what gui_client/PhysicsWorld.cpp does with Jolt: world construction (:462-532), addObject (:1169-1311),
+// setters (:546-722), think (:1356-1443), activation / contact bookkeeping (:1448-1520), ray queries (:1668-1725).
+// The job system / temp allocator adapters (:288-457) have no counterpart: work is HIP launches on one stream,
+// scratch lives in device arenas allocated once per world.
+//
+// There is no CPU compute path in this file: without a HIP device every entry point fails with SGP_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "sgp_kernels.h"
+
+#define SGP_API extern "C" __attribute__((visibility("default")))
+
+static thread_local std::string g_last_error;
+static int g_device_count = -1;
+
+static int fail(int code, const char* what, hipError_t e = hipSuccess)
+{
+	char buf[512];
+	if (e != hipSuccess) snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+	else snprintf(buf, sizeof(buf), "%s", what);
+	g_last_error = buf;
+	return code;
+}
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(SGP_ERR_HIP, #expr, e_); } while (0)
+
+static const char* k_class_names[KC_COUNT] = {
+	"apply_forces", "bp_cell", "bp_scan", "bp_scatter", "bp_pairs", "bp_large", "narrowphase", "wake",
+	"colour_claim", "colour_commit", "colour_count", "setup", "warm_start", "solve_velocity",
+	"integrate_pose", "solve_position", "finalize", "island_hook", "island_flag", "sleep_apply", "buoyancy",
+	"cache_build", "misc", "edit", "gather" };
+
+// ---------------------------------------------------------------------------------------------------------------
+
+struct HostBody {
+	uint32_t flags = 0;          // mirror of the static part of the device flags (alive, motion, layer, shape, large)
+	uint64_t userdata = 0;
+	float bound_radius = 0.0f;
+	bool ghost = false;
+};
+
+struct ProfEvent { int kc; hipEvent_t a, b; };
+
+struct sgp_world {
+	sgp_world_desc desc;
+	int device = 0;
+	hipStream_t stream = nullptr;
+	DV dv;
+	std::vector<void*> allocs;
+	uint64_t device_bytes = 0;
+	// host mirrors
+	std::vector<HostBody> hb;
+	std::vector<uint32_t> free_list;
+	uint32_t high = 0, n_alive = 0;
+	std::vector<uint32_t> large_ids; bool large_dirty = false;
+	uint32_t* d_large = nullptr; uint32_t cap_large = 0;
+	float max_small_radius = 0.0f;
+	std::vector<uint32_t> ghost_ids;
+	// pending edits
+	std::vector<BodyCmd> cmds;
+	// staging
+	void* stage_dev = nullptr; size_t stage_dev_bytes = 0;
+	void* stage_host = nullptr; size_t stage_host_bytes = 0;
+	StepCounters* h_ctr = nullptr; EventCounters* h_evc = nullptr;
+	// events collected on the host until drained
+	std::vector<sgp_body_event> ev_act, ev_deact, ev_water;
+	std::vector<sgp_contact_event> ev_added, ev_pers;
+	// last step
+	sgp_step_stats stats;
+	uint32_t last_pairs = 0, last_manifolds = 0, n_con = 0;
+	uint32_t table_alloc = 0, ht_alloc = 0;
+	// profiling
+	bool profiling = false;
+	std::vector<ProfEvent> prof;
+	std::vector<hipEvent_t> event_pool; size_t event_next = 0;
+	hipEvent_t stage_ev[SGP_NUM_STAGES + 1];
+	bool stage_ev_ok = false;
+};
+
+template <typename T> static int dev_alloc(sgp_world* w, T*& p, size_t n)
+{
+	void* q = nullptr;
+	const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+	hipError_t e = hipMalloc(&q, bytes);
+	if (e != hipSuccess) return fail(SGP_ERR_HIP, "hipMalloc", e);
+	e = hipMemsetAsync(q, 0, bytes, w->stream);
+	if (e != hipSuccess) return fail(SGP_ERR_HIP, "hipMemsetAsync", e);
+	w->allocs.push_back(q);
+	w->device_bytes += bytes;
+	p = (T*)q;
+	return SGP_OK;
+}
+#define DEV_ALLOC(ptr, n) do { int r_ = dev_alloc(w, ptr, n); if (r_ != SGP_OK) return r_; } while (0)
+
+static int ensure_stage(sgp_world* w, size_t bytes)
+{
+	if (bytes > w->stage_dev_bytes) {
+		if (w->stage_dev) { hipStreamSynchronize(w->stream); hipFree(w->stage_dev); w->device_bytes -= w->stage_dev_bytes; }
+		size_t nb = std::max<size_t>(bytes, 1 << 16); nb = nb + nb / 2;
+		HIP_TRY(hipMalloc(&w->stage_dev, nb));
+		w->stage_dev_bytes = nb; w->device_bytes += nb;
+	}
+	if (bytes > w->stage_host_bytes) {
+		if (w->stage_host) { hipStreamSynchronize(w->stream); hipHostFree(w->stage_host); }
+		size_t nb = std::max<size_t>(bytes, 1 << 16); nb = nb + nb / 2;
+		HIP_TRY(hipHostMalloc(&w->stage_host, nb, hipHostMallocDefault));
+		w->stage_host_bytes = nb;
+	}
+	return SGP_OK;
+}
+
+static uint32_t next_pow2(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// defaults (Jolt v5.3.0 PhysicsSettings; Substrata never overrides them)
+
+SGP_API void sgp_default_settings(sgp_settings* s)
+{
+	s->num_velocity_steps = 10;
+	s->num_position_steps = 2;
+	s->baumgarte = 0.2f;
+	s->penetration_slop = 0.02f;
+	s->speculative_contact_distance = 0.02f;
+	s->min_velocity_for_restitution = 1.0f;
+	s->max_penetration_distance = 0.2f;
+	s->time_before_sleep = 0.5f;
+	s->point_velocity_sleep_threshold = 0.03f;
+	s->contact_point_preserve_lambda_max_dist_sq = 0.01f * 0.01f;
+	s->max_linear_velocity = 500.0f;
+	s->max_angular_velocity = 0.25f * 3.14159265358979323846f * 60.0f;
+	s->allow_sleeping = 1;
+	s->warm_start = 1;
+}
+
+SGP_API void sgp_default_world_desc(sgp_world_desc* d)
+{
+	memset(d, 0, sizeof(*d));
+	d->max_bodies = 65536;                                       // PhysicsWorld.cpp:492
+	d->gravity[0] = 0.0f; d->gravity[1] = 0.0f; d->gravity[2] = -9.81f;   // :520
+	d->large_body_radius = 4.0f;
+	sgp_default_settings(&d->settings);
+}
+
+SGP_API void sgp_default_body_desc(sgp_body_desc* d)
+{
+	memset(d, 0, sizeof(*d));
+	d->rot[3] = 1.0f;
+	d->shape_type = SGP_SHAPE_BOX;
+	d->shape[0] = d->shape[1] = d->shape[2] = 0.5f;               // unit cube, PhysicsWorld.cpp:1249
+	d->motion_type = SGP_MOTION_STATIC;                            // PhysicsObject.cpp:28
+	d->layer = SGP_LAYER_NON_MOVING;
+	d->mass = 100.0f; d->friction = 0.5f; d->restitution = 0.3f;   // PhysicsObject.cpp:36-38
+	d->gravity_factor = 1.0f;
+	d->linear_damping = 0.05f; d->angular_damping = 0.05f;
+	d->allow_sleeping = 1;
+}
+
+SGP_API int sgp_abi_version(void) { return SGP_ABI_VERSION; }
+SGP_API const char* sgp_last_error(void) { return g_last_error.c_str(); }
+SGP_API const char* sgp_kernel_class_name(int k) { return (k >= 0 && k < KC_COUNT) ? k_class_names[k] : nullptr; }
+SGP_API int sgp_abi_sizeof(int which)
+{
+	switch (which) {
+	case 0: return (int)sizeof(sgp_settings); case 1: return (int)sizeof(sgp_world_desc); case 2: return (int)sizeof(sgp_body_desc);
+	case 3: return (int)sizeof(sgp_body_state); case 4: return (int)sizeof(sgp_body_event); case 5: return (int)sizeof(sgp_contact_event);
+	case 6: return (int)sizeof(sgp_ray); case 7: return (int)sizeof(sgp_hit); case 8: return (int)sizeof(sgp_step_stats);
+	case 9: return (int)sizeof(sgp_step_profile); case 10: return (int)sizeof(sgp_ghost_record);
+	default: return -1;
+	}
+}
+
+// PhysicsWorld::init(), PhysicsWorld.cpp:250-273: once per process.  Returns the number of HIP devices (>= 1) or an error.
+SGP_API int sgp_init(void)
+{
+	int n = 0;
+	const hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0) { g_device_count = 0; return fail(SGP_ERR_NO_DEVICE, "no HIP device available (there is no CPU fallback)", e); }
+	g_device_count = n;
+	return n;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// world construction, PhysicsWorld.cpp:462-532
+
+static int alloc_constraints(sgp_world* w, ConstraintArrays& c, uint32_t cap)
+{
+	DEV_ALLOC(c.ab, cap); DEV_ALLOC(c.n_fric, cap); DEV_ALLOC(c.key, cap); DEV_ALLOC(c.np_col, cap);
+	for (int k = 0; k < 4; ++k) {
+		DEV_ALLOC(c.r1b[k], cap); DEV_ALLOC(c.r2e[k], cap); DEV_ALLOC(c.lam[k], cap); DEV_ALLOC(c.efft[k], cap);
+		DEV_ALLOC(c.loc1[k], cap); DEV_ALLOC(c.loc2[k], cap);
+	}
+	return SGP_OK;
+}
+
+SGP_API int sgp_world_destroy(sgp_world* w);
+
+SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
+{
+	if (!desc || !out || desc->max_bodies == 0) return fail(SGP_ERR_INVALID, "sgp_world_create: bad arguments");
+	if (g_device_count < 0) sgp_init();
+	if (g_device_count <= 0) return fail(SGP_ERR_NO_DEVICE, "sgp_world_create: no HIP device available (there is no CPU fallback)");
+	if (desc->device < 0 || desc->device >= g_device_count) return fail(SGP_ERR_INVALID, "sgp_world_create: bad device ordinal");
+	sgp_world* w = new sgp_world();
+	w->desc = *desc;
+	w->device = desc->device;
+	if (w->desc.large_body_radius <= 0.0f) w->desc.large_body_radius = 4.0f;
+	if (w->desc.max_body_pairs == 0) w->desc.max_body_pairs = 16u * desc->max_bodies + 1024u;
+	if (w->desc.max_manifolds == 0) w->desc.max_manifolds = 8u * desc->max_bodies + 1024u;
+	memset(&w->dv, 0, sizeof(w->dv));
+	memset(&w->stats, 0, sizeof(w->stats));
+	hipError_t e = hipSetDevice(w->device);
+	if (e != hipSuccess) { delete w; return fail(SGP_ERR_HIP, "hipSetDevice", e); }
+	e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking);
+	if (e != hipSuccess) { delete w; return fail(SGP_ERR_HIP, "hipStreamCreate", e); }
+	*out = w;   // so that DEV_ALLOC failures can be cleaned by the caller via destroy
+	DV& d = w->dv;
+	const uint32_t N = desc->max_bodies, P = w->desc.max_body_pairs, M = w->desc.max_manifolds;
+	d.cap_bodies = N; d.cap_pairs = P; d.cap_manifolds = M;
+	DEV_ALLOC(d.pos_im, N); DEV_ALLOC(d.rot, N); DEV_ALLOC(d.linv, N); DEV_ALLOC(d.angv, N);
+	DEV_ALLOC(d.force, N); DEV_ALLOC(d.torque, N); DEV_ALLOC(d.inv_inertia, N); DEV_ALLOC(d.shape, N);
+	DEV_ALLOC(d.flags, N); DEV_ALLOC(d.aabb_min, N); DEV_ALLOC(d.aabb_max, N);
+	for (int k = 0; k < 3; ++k) DEV_ALLOC(d.sleep_s[k], N);
+	DEV_ALLOC(d.sleep_timer, N); DEV_ALLOC(d.submerged, N);
+	DEV_ALLOC(d.colour_mask, N); DEV_ALLOC(d.claim[0], N); DEV_ALLOC(d.claim[1], N);
+	DEV_ALLOC(d.island, N); DEV_ALLOC(d.island_awake, N);
+	d.table_size = std::max(1024u, next_pow2(2u * N));
+	DEV_ALLOC(d.cell_hash, N); DEV_ALLOC(d.cell_xyz, N);
+	DEV_ALLOC(d.cell_count, d.table_size + 4); DEV_ALLOC(d.cell_start, d.table_size + 4); DEV_ALLOC(d.cell_fill, d.table_size + 4);
+	DEV_ALLOC(d.sorted_ids, N); DEV_ALLOC(d.scan_block_sums, (d.table_size + 1) / 1024 + 2);
+	DEV_ALLOC(d.pairs, P);
+	DEV_ALLOC(d.man_ab, M); DEV_ALLOC(d.man_n, M); DEV_ALLOC(d.man_colour, M); DEV_ALLOC(d.man_prio, M);
+	for (int k = 0; k < 4; ++k) { DEV_ALLOC(d.man_p1[k], M); DEV_ALLOC(d.man_p2[k], M); }
+	{ int r = alloc_constraints(w, d.cur, M); if (r != SGP_OK) return r; }
+	{ int r = alloc_constraints(w, d.prev, M); if (r != SGP_OK) return r; }
+	w->ht_alloc = next_pow2(2u * M);
+	DEV_ALLOC(d.ht_keys, w->ht_alloc); DEV_ALLOC(d.ht_vals, w->ht_alloc);
+	d.ht_size = 1024;
+	DEV_ALLOC(d.ctr, 1); DEV_ALLOC(d.evc, 1);
+	DEV_ALLOC(d.ev_activated, N); DEV_ALLOC(d.ev_deactivated, N); DEV_ALLOC(d.ev_water, N);
+	HIP_TRY(hipHostMalloc((void**)&w->h_ctr, sizeof(StepCounters), hipHostMallocDefault));
+	HIP_TRY(hipHostMalloc((void**)&w->h_evc, sizeof(EventCounters), hipHostMallocDefault));
+	d.st = desc->settings;
+	d.gx = desc->gravity[0]; d.gy = desc->gravity[1]; d.gz = desc->gravity[2];
+	d.cell_size = 1.0f;
+	w->hb.resize(N);
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	return SGP_OK;
+}
+
+SGP_API int sgp_world_destroy(sgp_world* w)
+{
+	if (!w) return fail(SGP_ERR_INVALID, "sgp_world_destroy: NULL");
+	hipSetDevice(w->device);
+	if (w->stream) hipStreamSynchronize(w->stream);
+	for (void* p : w->allocs) hipFree(p);
+	if (w->d_large) hipFree(w->d_large);
+	if (w->stage_dev) hipFree(w->stage_dev);
+	if (w->stage_host) hipHostFree(w->stage_host);
+	if (w->h_ctr) hipHostFree(w->h_ctr);
+	if (w->h_evc) hipHostFree(w->h_evc);
+	for (hipEvent_t ev : w->event_pool) hipEventDestroy(ev);
+	if (w->stage_ev_ok) for (int i = 0; i <= SGP_NUM_STAGES; ++i) hipEventDestroy(w->stage_ev[i]);
+	if (w->stream) hipStreamDestroy(w->stream);
+	delete w;
+	return SGP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// bodies
+
+static void mass_properties(int type, const float* p, float mass, float* inv_mass, float* inv_inertia)
+{
+	// Shape::GetMassProperties scaled to the overridden mass (EOverrideMassProperties::CalculateInertia, PhysicsWorld.cpp:1239)
+	float ix, iy, iz;
+	if (type == SGP_SHAPE_SPHERE) { const float i = 0.4f * mass * p[0] * p[0]; ix = iy = iz = i; }
+	else if (type == SGP_SHAPE_BOX) {
+		const float sx = 2.0f * p[0], sy = 2.0f * p[1], sz = 2.0f * p[2];
+		const float k = mass / 12.0f;
+		ix = k * (sy * sy + sz * sz); iy = k * (sx * sx + sz * sz); iz = k * (sx * sx + sy * sy);
+	} else {
+		const float r = p[0], H = 2.0f * p[1];
+		const float vc = 3.14159265358979323846f * r * r * H;
+		const float vs = (4.0f / 3.0f) * 3.14159265358979323846f * r * r * r;
+		const float mc = mass * vc / (vc + vs), ms = mass * vs / (vc + vs);
+		iz = 0.5f * mc * r * r + 0.4f * ms * r * r;
+		ix = mc * (3.0f * r * r + H * H) / 12.0f + ms * (0.4f * r * r + 0.25f * H * H + 0.375f * H * r);
+		iy = ix;
+	}
+	*inv_mass = 1.0f / mass;
+	inv_inertia[0] = 1.0f / ix; inv_inertia[1] = 1.0f / iy; inv_inertia[2] = 1.0f / iz;
+}
+
+static float bounding_radius(int type, const float* p)
+{
+	if (type == SGP_SHAPE_SPHERE) return p[0];
+	if (type == SGP_SHAPE_BOX) return sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+	return p[0] + p[1];
+}
+
+static inline float clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
+static inline bool finite3(const float* v) { return std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2]); }
+static inline bool live(const sgp_world* w, uint32_t id) { return w && id < w->high && (w->hb[id].flags & BF_ALIVE); }
+
+static void note_radius(sgp_world* w, uint32_t id, float r)
+{
+	HostBody& b = w->hb[id];
+	const bool was_large = b.flags & BF_LARGE;
+	const bool is_large = r > w->desc.large_body_radius;
+	b.bound_radius = r;
+	if (is_large) b.flags |= BF_LARGE; else b.flags &= ~BF_LARGE;
+	if (is_large != was_large || (is_large && (b.flags & BF_ALIVE))) {
+		if (is_large && std::find(w->large_ids.begin(), w->large_ids.end(), id) == w->large_ids.end()) w->large_ids.push_back(id);
+		if (!is_large) w->large_ids.erase(std::remove(w->large_ids.begin(), w->large_ids.end(), id), w->large_ids.end());
+		w->large_dirty = true;
+	}
+	if (!is_large) w->max_small_radius = std::max(w->max_small_radius, r);
+}
+
+static int add_one(sgp_world* w, const sgp_body_desc* d, uint32_t* id_out, bool ghost)
+{
+	if (!finite3(d->pos) || fabsf(d->pos[0]) > 1.0e9f || fabsf(d->pos[1]) > 1.0e9f || fabsf(d->pos[2]) > 1.0e9f) return SGP_ERR_REJECTED;   // :1178
+	if (d->shape_type < 0 || d->shape_type > 2) return fail(SGP_ERR_INVALID, "sgp_body_add: bad shape_type");
+	const int nparam = d->shape_type == SGP_SHAPE_BOX ? 3 : (d->shape_type == SGP_SHAPE_SPHERE ? 1 : 2);
+	for (int i = 0; i < nparam; ++i) {
+		const float lim = (d->shape_type == SGP_SHAPE_CAPSULE && i == 1) ? 0.0f : 0.5e-7f;   // |scale| < 1e-7 on a 0.5 unit shape, :1184
+		if (!std::isfinite(d->shape[i]) || d->shape[i] < lim) return SGP_ERR_REJECTED;
+	}
+	uint32_t id;
+	if (!w->free_list.empty()) { id = w->free_list.back(); w->free_list.pop_back(); }
+	else { if (w->high >= w->dv.cap_bodies) return fail(SGP_ERR_CAPACITY, "sgp_body_add: max_bodies exceeded"); id = w->high++; }
+	BodyCmd c; memset(&c, 0, sizeof(c));
+	c.id = id; c.ops = CMD_CREATE;
+	memcpy(c.pos, d->pos, sizeof(c.pos)); memcpy(c.rot, d->rot, sizeof(c.rot));
+	memcpy(c.linv, d->lin_vel, sizeof(c.linv)); memcpy(c.angv, d->ang_vel, sizeof(c.angv));
+	memcpy(c.shape, d->shape, sizeof(c.shape));
+	c.friction = clamp01(d->friction);                 // :1236
+	c.restitution = clamp01(d->restitution);           // :1237
+	c.mass = std::max(0.001f, d->mass);                // :1238
+	c.gravity_factor = d->gravity_factor; c.lin_damp = d->linear_damping; c.ang_damp = d->angular_damping;
+	if (d->motion_type == SGP_MOTION_DYNAMIC) mass_properties(d->shape_type, d->shape, c.mass, &c.inv_mass, c.inv_inertia);
+	uint32_t f = BF_ALIVE | ((uint32_t)d->motion_type & BF_MOTION_MASK) | (((uint32_t)d->layer & 0x3u) << BF_LAYER_SHIFT) |
+	             (((uint32_t)d->shape_type & 0x3u) << BF_SHAPE_SHIFT);
+	if (d->is_sensor) f |= BF_SENSOR;
+	if (d->allow_sleeping) f |= BF_ALLOW_SLEEP;
+	if (d->use_zero_linear_drag) f |= BF_ZERO_LIN_DRAG;
+	if (ghost) f |= BF_GHOST;
+	HostBody& hb = w->hb[id];
+	hb.flags = f; hb.userdata = d->userdata; hb.ghost = ghost;
+	note_radius(w, id, bounding_radius(d->shape_type, d->shape));
+	c.flags = hb.flags;
+	w->cmds.push_back(c);
+	if (d->activate && d->motion_type != SGP_MOTION_STATIC) { BodyCmd a; memset(&a, 0, sizeof(a)); a.id = id; a.ops = CMD_ACTIVATE; w->cmds.push_back(a); }
+	w->n_alive++;
+	if (id_out) *id_out = id;
+	return SGP_OK;
+}
+
+SGP_API int sgp_body_add(sgp_world* w, const sgp_body_desc* d, uint32_t* id_out)
+{
+	if (!w || !d) return fail(SGP_ERR_INVALID, "sgp_body_add: NULL");
+	if (id_out) *id_out = SGP_INVALID_ID;
+	return add_one(w, d, id_out, false);
+}
+
+SGP_API int sgp_body_add_batch(sgp_world* w, const sgp_body_desc* d, uint32_t n, uint32_t* ids_out)
+{
+	if (!w || (!d && n)) return fail(SGP_ERR_INVALID, "sgp_body_add_batch: NULL");
+	w->cmds.reserve(w->cmds.size() + 2 * (size_t)n);
+	for (uint32_t i = 0; i < n; ++i) {
+		uint32_t id = SGP_INVALID_ID;
+		const int r = add_one(w, &d[i], &id, false);
+		if (r != SGP_OK && r != SGP_ERR_REJECTED) return r;
+		if (ids_out) ids_out[i] = (r == SGP_OK) ? id : SGP_INVALID_ID;
+	}
+	return SGP_OK;
+}
+
+static BodyCmd blank_cmd(uint32_t id, uint32_t ops) { BodyCmd c; memset(&c, 0, sizeof(c)); c.id = id; c.ops = ops; return c; }
+
+SGP_API int sgp_body_remove(sgp_world* w, uint32_t id)
+{
+	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_remove: id not live");
+	if (w->hb[id].flags & BF_LARGE) { w->large_ids.erase(std::remove(w->large_ids.begin(), w->large_ids.end(), id), w->large_ids.end()); w->large_dirty = true; }
+	w->hb[id].flags = 0;
+	w->cmds.push_back(blank_cmd(id, CMD_REMOVE));
+	w->free_list.push_back(id);
+	w->n_alive--;
+	return SGP_OK;
+}
+SGP_API int sgp_body_activate(sgp_world* w, uint32_t id)
+{
+	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_activate: id not live");
+	w->cmds.push_back(blank_cmd(id, CMD_ACTIVATE));
+	return SGP_OK;
+}
+SGP_API int sgp_body_set_layer(sgp_world* w, uint32_t id, int32_t layer)
+{
+	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_set_layer: id not live");
+	BodyCmd c = blank_cmd(id, CMD_SET_LAYER); c.flags = (uint32_t)layer & 0x3u;
+	w->hb[id].flags = (w->hb[id].flags & ~BF_LAYER_MASK) | (((uint32_t)layer & 0x3u) << BF_LAYER_SHIFT);
+	w->cmds.push_back(c);
+	return SGP_OK;
+}
+SGP_API int sgp_body_set_pose_vel(sgp_world* w, uint32_t id, const float pos[3], const float rot[4], const float lv[3], const float av[3])
+{
+	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_set_pose_vel: id not live");
+	BodyCmd c = blank_cmd(id, CMD_SET_POS | CMD_SET_ROT | CMD_SET_VEL);
+	memcpy(c.pos, pos, 12); memcpy(c.rot, rot, 16); memcpy(c.linv, lv, 12); memcpy(c.angv, av, 12);
+	w->cmds.push_back(c);
+	return SGP_OK;
+}
+SGP_API int sgp_body_set_pose_shape(sgp_world* w, uint32_t id, const float pos[3], const float rot[4], const float shape[4])
+{
+	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_set_pose_shape: id not live");
+	BodyCmd c = blank_cmd(id, CMD_SET_POS | CMD_SET_ROT | CMD_SET_VEL | CMD_SET_SHAPE | CMD_ACTIVATE);
+	memcpy(c.pos, pos, 12); memcpy(c.rot, rot, 16); memcpy(c.shape, shape, 16);
+	const int type = (int)((w->hb[id].flags & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT);
+	note_radius(w, id, bounding_radius(type, shape));
+	w->cmds.push_back(c);
+	return SGP_OK;
+}
+SGP_API int sgp_body_set_pos(sgp_world* w, uint32_t id, const float pos[3])
+{
+	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_set_pos: id not live");
+	BodyCmd c = blank_cmd(id, CMD_SET_POS); memcpy(c.pos, pos, 12);
+	w->cmds.push_back(c);
+	return SGP_OK;
+}
+SGP_API int sgp_body_set_vel(sgp_world* w, uint32_t id, const float lv[3], const float av[3])
+{
+	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_set_vel: id not live");
+	BodyCmd c = blank_cmd(id, CMD_SET_VEL); memcpy(c.linv, lv, 12); memcpy(c.angv, av, 12);
+	w->cmds.push_back(c);
+	return SGP_OK;
+}
+SGP_API int sgp_body_move_kinematic(sgp_world* w, uint32_t id, const float tp[3], const float tr[4], float dt)
+{
+	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_move_kinematic: id not live");
+	BodyCmd c = blank_cmd(id, CMD_MOVE_KINEMATIC); memcpy(c.pos, tp, 12); memcpy(c.rot, tr, 16); c.dt = dt;
+	w->cmds.push_back(c);
+	return SGP_OK;
+}
+SGP_API int sgp_body_add_force(sgp_world* w, uint32_t id, const float f[3])
+{
+	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_add_force: id not live");
+	BodyCmd c = blank_cmd(id, CMD_ADD_FORCE); memcpy(c.linv, f, 12);
+	w->cmds.push_back(c);
+	return SGP_OK;
+}
+SGP_API int sgp_body_add_force_at(sgp_world* w, uint32_t id, const float f[3], const float p[3])
+{
+	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_add_force_at: id not live");
+	BodyCmd c = blank_cmd(id, CMD_ADD_FORCE_AT); memcpy(c.linv, f, 12); memcpy(c.pos, p, 12);
+	w->cmds.push_back(c);
+	return SGP_OK;
+}
+SGP_API int sgp_body_add_torque(sgp_world* w, uint32_t id, const float t[3])
+{
+	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_add_torque: id not live");
+	BodyCmd c = blank_cmd(id, CMD_ADD_TORQUE); memcpy(c.angv, t, 12);
+	w->cmds.push_back(c);
+	return SGP_OK;
+}
+
+// Upload the pending edits: grouped by body (submission order kept inside a group), one thread per body.
+static int flush_cmds(sgp_world* w)
+{
+	hipSetDevice(w->device);
+	DV& d = w->dv;
+	d.n_slots = w->high;
+	if (w->large_dirty) {
+		if (w->large_ids.size() > w->cap_large) {
+			if (w->d_large) { hipStreamSynchronize(w->stream); hipFree(w->d_large); }
+			w->cap_large = (uint32_t)w->large_ids.size() * 2 + 16;
+			HIP_TRY(hipMalloc((void**)&w->d_large, sizeof(uint32_t) * w->cap_large));
+		}
+		if (!w->large_ids.empty()) {
+			HIP_TRY(hipMemcpyAsync(w->d_large, w->large_ids.data(), sizeof(uint32_t) * w->large_ids.size(), hipMemcpyHostToDevice, w->stream));
+			HIP_TRY(hipStreamSynchronize(w->stream));   // large_ids is pageable host memory that may change
+		}
+		d.large_ids = w->d_large; d.n_large = (uint32_t)w->large_ids.size();
+		w->large_dirty = false;
+	}
+	d.cell_size = std::max(0.5f, 2.0f * w->max_small_radius) + 2.0f * d.st.speculative_contact_distance;
+	if (w->cmds.empty()) return SGP_OK;
+	const size_t n = w->cmds.size();
+	std::vector<uint32_t> order(n);
+	for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return w->cmds[a].id < w->cmds[b].id; });
+	const size_t cmd_bytes = n * sizeof(BodyCmd);
+	const size_t run_off = (cmd_bytes + 15) & ~size_t(15);
+	const size_t total = run_off + (n + 1) * sizeof(uint32_t);
+	{ int r = ensure_stage(w, total); if (r != SGP_OK) return r; }
+	BodyCmd* hc = (BodyCmd*)w->stage_host;
+	uint32_t* hr = (uint32_t*)((char*)w->stage_host + run_off);
+	uint32_t n_runs = 0;
+	for (size_t i = 0; i < n; ++i) {
+		hc[i] = w->cmds[order[i]];
+		if (i == 0 || hc[i].id != hc[i - 1].id) hr[n_runs++] = (uint32_t)i;
+	}
+	hr[n_runs] = (uint32_t)n;
+	HIP_TRY(hipMemcpyAsync(w->stage_dev, w->stage_host, total, hipMemcpyHostToDevice, w->stream));
+	launch_apply_cmds(d, (const BodyCmd*)w->stage_dev, (const uint32_t*)((char*)w->stage_dev + run_off), n_runs, w->stream);
+	HIP_TRY(hipStreamSynchronize(w->stream));   // the staging buffer is reused by the next call
+	w->cmds.clear();
+	return SGP_OK;
+}
+
+// Pull the device event lists into the host vectors and reset the device counters.
+static int collect_events(sgp_world* w)
+{
+	DV& d = w->dv;
+	HIP_TRY(hipMemcpyAsync(w->h_evc, d.evc, sizeof(EventCounters), hipMemcpyDeviceToHost, w->stream));
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	const EventCounters ec = *w->h_evc;
+	if (!(ec.n_activated | ec.n_deactivated | ec.n_water | ec.n_contact_added | ec.n_contact_persisted)) return SGP_OK;
+	struct L { uint32_t n; uint32_t* dev; std::vector<sgp_body_event>* out; };
+	L lists[3] = { { std::min(ec.n_activated, d.cap_bodies), d.ev_activated, &w->ev_act },
+	               { std::min(ec.n_deactivated, d.cap_bodies), d.ev_deactivated, &w->ev_deact },
+	               { std::min(ec.n_water, d.cap_bodies), d.ev_water, &w->ev_water } };
+	for (L& l : lists) {
+		if (!l.n) continue;
+		{ int r = ensure_stage(w, sizeof(uint32_t) * l.n); if (r != SGP_OK) return r; }
+		HIP_TRY(hipMemcpyAsync(w->stage_host, l.dev, sizeof(uint32_t) * l.n, hipMemcpyDeviceToHost, w->stream));
+		HIP_TRY(hipStreamSynchronize(w->stream));
+		const uint32_t* ids = (const uint32_t*)w->stage_host;
+		for (uint32_t k = 0; k < l.n; ++k) { sgp_body_event e; e.id = ids[k]; e._pad = 0; e.userdata = w->hb[ids[k]].userdata; l.out->push_back(e); }
+	}
+	struct CL { uint32_t n; sgp_contact_event* dev; std::vector<sgp_contact_event>* out; };
+	CL cl[2] = { { std::min(ec.n_contact_added, d.cap_contact_events), d.ev_contacts_added, &w->ev_added },
+	             { std::min(ec.n_contact_persisted, d.cap_contact_events), d.ev_contacts_persisted, &w->ev_pers } };
+	for (CL& l : cl) {
+		if (!l.n) continue;
+		{ int r = ensure_stage(w, sizeof(sgp_contact_event) * l.n); if (r != SGP_OK) return r; }
+		HIP_TRY(hipMemcpyAsync(w->stage_host, l.dev, sizeof(sgp_contact_event) * l.n, hipMemcpyDeviceToHost, w->stream));
+		HIP_TRY(hipStreamSynchronize(w->stream));
+		const sgp_contact_event* src = (const sgp_contact_event*)w->stage_host;
+		for (uint32_t k = 0; k < l.n; ++k) { sgp_contact_event e = src[k]; e.userdata1 = w->hb[e.id1].userdata; e.userdata2 = w->hb[e.id2].userdata; l.out->push_back(e); }
+	}
+	HIP_TRY(hipMemsetAsync(d.evc, 0, sizeof(EventCounters), w->stream));
+	return SGP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// profiling helpers
+
+static hipEvent_t pool_event(sgp_world* w)
+{
+	if (w->event_next == w->event_pool.size()) { hipEvent_t e; hipEventCreate(&e); w->event_pool.push_back(e); }
+	return w->event_pool[w->event_next++];
+}
+struct KScope {
+	sgp_world* w; int kc; hipEvent_t a, b; bool on;
+	KScope(sgp_world* w_, int kc_) : w(w_), kc(kc_), on(w_->profiling) { if (on) { a = pool_event(w); b = pool_event(w); hipEventRecord(a, w->stream); } }
+	~KScope() { if (on) { hipEventRecord(b, w->stream); w->prof.push_back({ kc, a, b }); } }
+};
+#define STAGE_MARK(i) do { if (w->profiling) hipEventRecord(w->stage_ev[i], w->stream); } while (0)
+
+static int read_counters(sgp_world* w)
+{
+	HIP_TRY(hipMemcpyAsync(w->h_ctr, w->dv.ctr, sizeof(StepCounters), hipMemcpyDeviceToHost, w->stream));
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	return SGP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// think(dt), PhysicsWorld.cpp:1356-1443
+
+static int step_impl(sgp_world* w, float dt, bool final_readback)
+{
+	if (!(dt > 0.0f)) return fail(SGP_ERR_INVALID, "sgp_world_step: dt must be > 0");
+	{ int r = flush_cmds(w); if (r != SGP_OK) return r; }
+	DV& d = w->dv;
+	hipStream_t s = w->stream;
+	const uint32_t n = d.n_slots;
+	STAGE_MARK(0);
+	// -- per-step scratch reset
+	{
+		KScope k(w, KC_MISC);
+		HIP_TRY(hipMemsetAsync(d.ctr, 0, sizeof(StepCounters), s));
+		HIP_TRY(hipMemsetAsync(d.cell_count, 0, sizeof(uint32_t) * (d.table_size + 4), s));
+		HIP_TRY(hipMemsetAsync(d.cell_fill, 0, sizeof(uint32_t) * (d.table_size + 4), s));
+		if (n) {
+			HIP_TRY(hipMemsetAsync(d.colour_mask, 0, sizeof(uint64_t) * n, s));
+			HIP_TRY(hipMemsetAsync(d.claim[0], 0xFF, sizeof(uint64_t) * n, s));
+			HIP_TRY(hipMemsetAsync(d.claim[1], 0xFF, sizeof(uint64_t) * n, s));
+		}
+	}
+	if (n == 0) { memset(&w->stats, 0, sizeof(w->stats)); return SGP_OK; }
+	// -- 1. forces
+	{ KScope k(w, KC_APPLY_FORCES); launch_apply_forces(d, dt, s); }
+	STAGE_MARK(1);
+	// -- 2. broad phase
+	{ KScope k(w, KC_BP_CELL); launch_bp_cell(d, s); }
+	{ KScope k(w, KC_BP_SCAN); launch_bp_scan(d, s); }
+	{ KScope k(w, KC_BP_SCATTER); launch_bp_scatter(d, s); }
+	{ KScope k(w, KC_BP_PAIRS); launch_bp_pairs(d, s); }
+	{ KScope k(w, KC_BP_LARGE); launch_bp_large(d, s); }
+	STAGE_MARK(2);
+	// -- 3. narrow phase + wake-ups (+ contact events, which see the velocities before the solve)
+	const uint32_t est_pairs = std::max(w->last_pairs + w->last_pairs / 4 + 1024u, 4u * n);
+	{ KScope k(w, KC_NARROWPHASE); launch_narrowphase(d, est_pairs, s); }
+	{ KScope k(w, KC_WAKE); launch_wake(d, s); }
+	const uint32_t est_man = std::max(w->last_manifolds + w->last_manifolds / 4 + 1024u, 2u * n);
+	if (d.contact_events) { KScope k(w, KC_MISC); launch_contact_events(d, est_man, s); }
+	STAGE_MARK(3);
+	// -- 4. colouring (host polls the uncoloured count between batches of rounds)
+	uint32_t round = 0;
+	for (int batch = 0; batch < 64; ++batch) {
+		const int rounds = batch == 0 ? 8 : 4;
+		for (int r = 0; r < rounds; ++r, ++round) {
+			{ KScope k(w, KC_COLOUR_CLAIM); launch_colour_claim(d, est_man, round, s); }
+			{ KScope k(w, KC_COLOUR_COMMIT); launch_colour_commit(d, est_man, round, s); }
+		}
+		{ int r = read_counters(w); if (r != SGP_OK) return r; }
+		if (w->h_ctr->n_uncoloured == 0) break;
+	}
+	{ KScope k(w, KC_COLOUR_COUNT); launch_colour_count(d, est_man, s); }
+	{ int r = read_counters(w); if (r != SGP_OK) return r; }
+	const StepCounters c1 = *w->h_ctr;
+	const uint32_t n_man = std::min(c1.n_manifolds, d.cap_manifolds);
+	const uint32_t n_con = c1.n_constraints;
+	ColourStarts cs; uint32_t acc = 0; int ncol = 0;
+	for (int c = 0; c < SGP_MAX_COLOURS; ++c) { cs.s[c] = acc; acc += c1.colour_count[c]; if (c1.colour_count[c]) ncol = c + 1; }
+	cs.s[SGP_MAX_COLOURS] = acc;
+	{ KScope k(w, KC_SETUP); launch_setup(d, n_man, dt, cs, s); }
+	STAGE_MARK(4);
+	// -- 5. warm start + velocity iterations, colour by colour
+	const uint32_t n_ovf = c1.colour_count[SGP_OVERFLOW_COLOUR];
+	if (d.st.warm_start) {
+		for (int c = 0; c < SGP_OVERFLOW_COLOUR; ++c) if (c1.colour_count[c]) { KScope k(w, KC_WARM_START); launch_warm_start(d, cs.s[c], c1.colour_count[c], s); }
+		if (n_ovf) { KScope k(w, KC_WARM_START); launch_solve_velocity_serial(d, cs.s[SGP_OVERFLOW_COLOUR], n_ovf, 0, s); }
+	}
+	for (int it = 0; it < d.st.num_velocity_steps; ++it) {
+		for (int c = 0; c < SGP_OVERFLOW_COLOUR; ++c) if (c1.colour_count[c]) { KScope k(w, KC_SOLVE_VELOCITY); launch_solve_velocity(d, cs.s[c], c1.colour_count[c], s); }
+		if (n_ovf) { KScope k(w, KC_SOLVE_VELOCITY); launch_solve_velocity_serial(d, cs.s[SGP_OVERFLOW_COLOUR], n_ovf, 1, s); }
+	}
+	STAGE_MARK(5);
+	// -- 6. the body-array sweep
+	{ KScope k(w, KC_INTEGRATE_POSE); launch_integrate_pose(d, dt, s); }
+	STAGE_MARK(6);
+	// -- 7. position iterations
+	for (int it = 0; it < d.st.num_position_steps; ++it) {
+		for (int c = 0; c < SGP_OVERFLOW_COLOUR; ++c) if (c1.colour_count[c]) { KScope k(w, KC_SOLVE_POSITION); launch_solve_position(d, cs.s[c], c1.colour_count[c], s); }
+		if (n_ovf) { KScope k(w, KC_SOLVE_POSITION); launch_solve_velocity_serial(d, cs.s[SGP_OVERFLOW_COLOUR], n_ovf, 2, s); }
+	}
+	STAGE_MARK(7);
+	// -- 8. bounds, sleeping, buoyancy, contact cache
+	{ KScope k(w, KC_FINALIZE); launch_finalize(d, dt, s); }
+	{ KScope k(w, KC_ISLAND_HOOK); launch_island_hook(d, n_con, s); }
+	{ KScope k(w, KC_ISLAND_FLAG); launch_island_flag(d, s); }
+	{ KScope k(w, KC_SLEEP_APPLY); launch_sleep_apply(d, s); }
+	if (d.water_enabled) { KScope k(w, KC_BUOYANCY); launch_buoyancy(d, dt, s); }
+	{
+		KScope k(w, KC_CACHE_BUILD);
+		d.ht_size = std::min(w->ht_alloc, std::max(1024u, next_pow2(2u * std::max(n_con, 1u))));
+		HIP_TRY(hipMemsetAsync(d.ht_keys, 0xFF, sizeof(uint64_t) * d.ht_size, s));
+		launch_cache_build(d, n_con, s);
+	}
+	std::swap(d.cur, d.prev);
+	d.n_prev = n_con;
+	w->n_con = n_con;
+	STAGE_MARK(8);
+	w->last_pairs = c1.n_pairs; w->last_manifolds = c1.n_manifolds;
+	// -- stats + events
+	sgp_step_stats& st = w->stats;
+	memset(&st, 0, sizeof(st));
+	st.num_bodies = w->n_alive;
+	st.num_pairs = std::min(c1.n_pairs, d.cap_pairs);
+	st.num_manifolds = n_con;
+	st.num_contact_points = c1.n_points;
+	st.num_colours = (uint32_t)ncol;
+	st.num_colour_rounds = round;
+	st.num_overflow_constraints = n_ovf;
+	st.pairs_dropped = c1.pairs_dropped; st.manifolds_dropped = c1.manifolds_dropped;
+	st.device_bytes = w->device_bytes;
+	if (final_readback) {
+		{ int r = read_counters(w); if (r != SGP_OK) return r; }
+		st.num_active = w->h_ctr->n_active;
+		const size_t a0 = w->ev_act.size(), d0 = w->ev_deact.size();
+		{ int r = collect_events(w); if (r != SGP_OK) return r; }
+		st.num_activated = (uint32_t)(w->ev_act.size() - a0);
+		st.num_deactivated = (uint32_t)(w->ev_deact.size() - d0);
+		for (uint32_t i = 0; i < w->high; ++i) if (w->hb[i].flags & BF_ALIVE) st.layer_counts[(w->hb[i].flags & BF_LAYER_MASK) >> BF_LAYER_SHIFT]++;
+	}
+	return SGP_OK;
+}
+
+SGP_API int sgp_world_step(sgp_world* w, float dt)
+{
+	if (!w) return fail(SGP_ERR_INVALID, "sgp_world_step: NULL");
+	hipSetDevice(w->device);
+	w->profiling = false;
+	return step_impl(w, dt, true);
+}
+
+SGP_API int sgp_world_step_n(sgp_world* w, float dt, uint32_t n)
+{
+	if (!w) return fail(SGP_ERR_INVALID, "sgp_world_step_n: NULL");
+	hipSetDevice(w->device);
+	w->profiling = false;
+	for (uint32_t i = 0; i < n; ++i) { const int r = step_impl(w, dt, i + 1 == n); if (r != SGP_OK) return r; }
+	return SGP_OK;
+}
+
+SGP_API int sgp_world_step_profiled(sgp_world* w, float dt, sgp_step_profile* out)
+{
+	if (!w || !out) return fail(SGP_ERR_INVALID, "sgp_world_step_profiled: NULL");
+	hipSetDevice(w->device);
+	if (!w->stage_ev_ok) { for (int i = 0; i <= SGP_NUM_STAGES; ++i) HIP_TRY(hipEventCreate(&w->stage_ev[i])); w->stage_ev_ok = true; }
+	w->profiling = true; w->prof.clear(); w->event_next = 0;
+	const int r = step_impl(w, dt, true);
+	w->profiling = false;
+	if (r != SGP_OK) return r;
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	memset(out, 0, sizeof(*out));
+	if (w->dv.n_slots == 0) return SGP_OK;
+	for (int i = 0; i < SGP_NUM_STAGES; ++i) { float ms = 0.0f; hipEventElapsedTime(&ms, w->stage_ev[i], w->stage_ev[i + 1]); out->stage_ms[i] = ms; }
+	hipEventElapsedTime(&out->total_ms, w->stage_ev[0], w->stage_ev[SGP_NUM_STAGES]);
+	for (const ProfEvent& p : w->prof) { float ms = 0.0f; hipEventElapsedTime(&ms, p.a, p.b); out->kernel_ms[p.kc] += ms; out->kernel_launches[p.kc]++; }
+	out->sweep_bodies = w->dv.n_slots;
+	out->num_constraints = w->stats.num_manifolds;
+	out->num_contact_points = w->stats.num_contact_points;
+	out->num_colours = w->stats.num_colours;
+	return SGP_OK;
+}
+
+SGP_API int sgp_world_stats(sgp_world* w, sgp_step_stats* out)
+{
+	if (!w || !out) return fail(SGP_ERR_INVALID, "sgp_world_stats: NULL");
+	*out = w->stats;
+	out->num_bodies = w->n_alive;
+	out->device_bytes = w->device_bytes;
+	return SGP_OK;
+}
+
+SGP_API int sgp_world_num_bodies(sgp_world* w, uint32_t* n_out)
+{
+	if (!w || !n_out) return fail(SGP_ERR_INVALID, "sgp_world_num_bodies: NULL");
+	*n_out = w->n_alive;
+	return SGP_OK;
+}
+
+SGP_API int sgp_world_set_water(sgp_world* w, int enabled, float z)
+{
+	if (!w) return fail(SGP_ERR_INVALID, "sgp_world_set_water: NULL");
+	w->dv.water_enabled = enabled; w->dv.water_z = z;
+	return SGP_OK;
+}
+
+SGP_API int sgp_world_set_contact_events(sgp_world* w, int enabled)
+{
+	if (!w) return fail(SGP_ERR_INVALID, "sgp_world_set_contact_events: NULL");
+	hipSetDevice(w->device);
+	if (enabled && !w->dv.ev_contacts_added) {
+		w->dv.cap_contact_events = w->dv.cap_manifolds;
+		DEV_ALLOC(w->dv.ev_contacts_added, w->dv.cap_contact_events);
+		DEV_ALLOC(w->dv.ev_contacts_persisted, w->dv.cap_contact_events);
+	}
+	w->dv.contact_events = enabled;
+	return SGP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// read-back
+
+SGP_API int sgp_body_get_state(sgp_world* w, const uint32_t* ids, uint32_t n, sgp_body_state* out)
+{
+	if (!w || (!ids && n) || (!out && n)) return fail(SGP_ERR_INVALID, "sgp_body_get_state: NULL");
+	hipSetDevice(w->device);
+	for (uint32_t i = 0; i < n; ++i) if (!live(w, ids[i])) return fail(SGP_ERR_BAD_ID, "sgp_body_get_state: id not live");
+	{ int r = flush_cmds(w); if (r != SGP_OK) return r; }
+	if (!n) return SGP_OK;
+	const size_t ids_bytes = (sizeof(uint32_t) * n + 15) & ~size_t(15);
+	{ int r = ensure_stage(w, ids_bytes + sizeof(sgp_body_state) * n); if (r != SGP_OK) return r; }
+	memcpy(w->stage_host, ids, sizeof(uint32_t) * n);
+	HIP_TRY(hipMemcpyAsync(w->stage_dev, w->stage_host, sizeof(uint32_t) * n, hipMemcpyHostToDevice, w->stream));
+	sgp_body_state* dout = (sgp_body_state*)((char*)w->stage_dev + ids_bytes);
+	launch_gather_states(w->dv, (const uint32_t*)w->stage_dev, 0, n, dout, w->stream);
+	HIP_TRY(hipMemcpyAsync((char*)w->stage_host + ids_bytes, dout, sizeof(sgp_body_state) * n, hipMemcpyDeviceToHost, w->stream));
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	memcpy(out, (char*)w->stage_host + ids_bytes, sizeof(sgp_body_state) * n);
+	return SGP_OK;
+}
+
+SGP_API int sgp_world_read_states(sgp_world* w, uint32_t first, uint32_t n, sgp_body_state* out)
+{
+	if (!w || (!out && n)) return fail(SGP_ERR_INVALID, "sgp_world_read_states: NULL");
+	if ((uint64_t)first + n > w->dv.cap_bodies) return fail(SGP_ERR_INVALID, "sgp_world_read_states: range exceeds max_bodies");
+	hipSetDevice(w->device);
+	{ int r = flush_cmds(w); if (r != SGP_OK) return r; }
+	if (!n) return SGP_OK;
+	{ int r = ensure_stage(w, sizeof(sgp_body_state) * n); if (r != SGP_OK) return r; }
+	launch_gather_states(w->dv, nullptr, first, n, (sgp_body_state*)w->stage_dev, w->stream);
+	HIP_TRY(hipMemcpyAsync(w->stage_host, w->stage_dev, sizeof(sgp_body_state) * n, hipMemcpyDeviceToHost, w->stream));
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	memcpy(out, w->stage_host, sizeof(sgp_body_state) * n);
+	return SGP_OK;
+}
+
+SGP_API int sgp_world_read_active(sgp_world* w, sgp_body_state* out, uint32_t cap, uint32_t* n_out)
+{
+	if (!w || !n_out) return fail(SGP_ERR_INVALID, "sgp_world_read_active: NULL");
+	hipSetDevice(w->device);
+	{ int r = flush_cmds(w); if (r != SGP_OK) return r; }
+	const uint32_t lim = std::min(cap, w->dv.cap_bodies);
+	{ int r = ensure_stage(w, sizeof(sgp_body_state) * std::max(lim, 1u)); if (r != SGP_OK) return r; }
+	HIP_TRY(hipMemsetAsync(&w->dv.ctr->n_read_active, 0, sizeof(uint32_t), w->stream));
+	launch_gather_active(w->dv, (sgp_body_state*)w->stage_dev, lim, w->stream);
+	{ int r = read_counters(w); if (r != SGP_OK) return r; }
+	const uint32_t n = w->h_ctr->n_read_active;
+	const uint32_t m = std::min(n, lim);
+	if (m && out) {
+		HIP_TRY(hipMemcpyAsync(w->stage_host, w->stage_dev, sizeof(sgp_body_state) * m, hipMemcpyDeviceToHost, w->stream));
+		HIP_TRY(hipStreamSynchronize(w->stream));
+		memcpy(out, w->stage_host, sizeof(sgp_body_state) * m);
+	}
+	*n_out = n;
+	return SGP_OK;
+}
+
+template <typename T, typename Cmp> static void drain(std::vector<T>& v, void* out, uint32_t cap, uint32_t* n_out, Cmp cmp)
+{
+	std::sort(v.begin(), v.end(), cmp);
+	const uint32_t m = std::min<uint32_t>((uint32_t)v.size(), cap);
+	if (out && m) memcpy(out, v.data(), sizeof(T) * m);
+	*n_out = (uint32_t)v.size();
+	v.clear();
+}
+
+SGP_API int sgp_world_drain_events(sgp_world* w, int kind, void* out, uint32_t cap, uint32_t* n_out)
+{
+	if (!w || !n_out) return fail(SGP_ERR_INVALID, "sgp_world_drain_events: NULL");
+	hipSetDevice(w->device);
+	{ int r = flush_cmds(w); if (r != SGP_OK) return r; }
+	{ int r = collect_events(w); if (r != SGP_OK) return r; }
+	auto bcmp = [](const sgp_body_event& a, const sgp_body_event& b) { return a.id < b.id; };
+	auto ccmp = [](const sgp_contact_event& a, const sgp_contact_event& b) { return a.id1 != b.id1 ? a.id1 < b.id1 : a.id2 < b.id2; };
+	switch (kind) {
+	case SGP_EVENT_ACTIVATED: drain(w->ev_act, out, cap, n_out, bcmp); break;
+	case SGP_EVENT_DEACTIVATED: drain(w->ev_deact, out, cap, n_out, bcmp); break;
+	case SGP_EVENT_ENTERED_WATER: drain(w->ev_water, out, cap, n_out, bcmp); break;
+	case SGP_EVENT_CONTACT_ADDED: drain(w->ev_added, out, cap, n_out, ccmp); break;
+	case SGP_EVENT_CONTACT_PERSISTED: drain(w->ev_pers, out, cap, n_out, ccmp); break;
+	default: return fail(SGP_ERR_INVALID, "sgp_world_drain_events: bad kind");
+	}
+	return SGP_OK;
+}
+
+// Test / debug view of the constraints of the last step (sorted by pair key on the host).
+struct DumpRec { uint32_t a, b; int32_t colour; int32_t np; float n[3]; float lam_n[4]; float lam_t1[4]; float lam_t2[4]; float bias[4]; };
+SGP_API int sgp_world_dump_constraints(sgp_world* w, void* out, uint32_t cap, uint32_t* n_out)
+{
+	if (!w || !n_out) return fail(SGP_ERR_INVALID, "sgp_world_dump_constraints: NULL");
+	hipSetDevice(w->device);
+	const uint32_t n = w->n_con;
+	*n_out = n;
+	const uint32_t m = std::min(n, cap);
+	if (!m || !out) return SGP_OK;
+	{ int r = ensure_stage(w, sizeof(DumpRec) * n); if (r != SGP_OK) return r; }
+	launch_dump_constraints(w->dv, n, w->stage_dev, n, w->stream);
+	HIP_TRY(hipMemcpyAsync(w->stage_host, w->stage_dev, sizeof(DumpRec) * n, hipMemcpyDeviceToHost, w->stream));
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	DumpRec* r = (DumpRec*)w->stage_host;
+	std::sort(r, r + n, [](const DumpRec& x, const DumpRec& y) { return x.a != y.a ? x.a < y.a : x.b < y.b; });
+	memcpy(out, r, sizeof(DumpRec) * m);
+	return SGP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ray queries, PhysicsWorld.cpp:1668-1725
+
+SGP_API int sgp_raycast(sgp_world* w, const sgp_ray* rays, uint32_t n, sgp_hit* hits)
+{
+	if (!w || (!rays && n) || (!hits && n)) return fail(SGP_ERR_INVALID, "sgp_raycast: NULL");
+	hipSetDevice(w->device);
+	{ int r = flush_cmds(w); if (r != SGP_OK) return r; }
+	if (!n) return SGP_OK;
+	const size_t rb = (sizeof(sgp_ray) * n + 15) & ~size_t(15);
+	{ int r = ensure_stage(w, rb + sizeof(sgp_hit) * n); if (r != SGP_OK) return r; }
+	memcpy(w->stage_host, rays, sizeof(sgp_ray) * n);
+	HIP_TRY(hipMemcpyAsync(w->stage_dev, w->stage_host, sizeof(sgp_ray) * n, hipMemcpyHostToDevice, w->stream));
+	sgp_hit* dh = (sgp_hit*)((char*)w->stage_dev + rb);
+	launch_raycast(w->dv, (const sgp_ray*)w->stage_dev, n, dh, w->stream);
+	HIP_TRY(hipMemcpyAsync((char*)w->stage_host + rb, dh, sizeof(sgp_hit) * n, hipMemcpyDeviceToHost, w->stream));
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	memcpy(hits, (char*)w->stage_host + rb, sizeof(sgp_hit) * n);
+	for (uint32_t k = 0; k < n; ++k) hits[k].userdata = hits[k].id != SGP_INVALID_ID ? w->hb[hits[k].id].userdata : 0;
+	return SGP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// multi-GPU tiles
+
+SGP_API int sgp_world_export_boundary(sgp_world* w, const float lo[3], const float hi[3], float margin, sgp_ghost_record* out, uint32_t cap, uint32_t* n_out)
+{
+	if (!w || !n_out) return fail(SGP_ERR_INVALID, "sgp_world_export_boundary: NULL");
+	hipSetDevice(w->device);
+	{ int r = flush_cmds(w); if (r != SGP_OK) return r; }
+	const uint32_t lim = std::min(cap, w->dv.cap_bodies);
+	{ int r = ensure_stage(w, sizeof(sgp_ghost_record) * std::max(lim, 1u)); if (r != SGP_OK) return r; }
+	HIP_TRY(hipMemsetAsync(&w->dv.ctr->n_export, 0, sizeof(uint32_t), w->stream));
+	launch_export_boundary(w->dv, make_float3(lo[0], lo[1], lo[2]), make_float3(hi[0], hi[1], hi[2]), margin,
+	                       (sgp_ghost_record*)w->stage_dev, lim, &w->dv.ctr->n_export, w->stream);
+	{ int r = read_counters(w); if (r != SGP_OK) return r; }
+	const uint32_t n = w->h_ctr->n_export, m = std::min(n, lim);
+	if (m && out) {
+		HIP_TRY(hipMemcpyAsync(w->stage_host, w->stage_dev, sizeof(sgp_ghost_record) * m, hipMemcpyDeviceToHost, w->stream));
+		HIP_TRY(hipStreamSynchronize(w->stream));
+		memcpy(out, w->stage_host, sizeof(sgp_ghost_record) * m);
+		// deterministic order for the exchange
+		std::sort(out, out + m, [](const sgp_ghost_record& a, const sgp_ghost_record& b) { return a.global_id < b.global_id; });
+	}
+	*n_out = n;
+	return SGP_OK;
+}
+
+SGP_API int sgp_world_import_ghosts(sgp_world* w, const sgp_ghost_record* in, uint32_t n)
+{
+	if (!w || (!in && n)) return fail(SGP_ERR_INVALID, "sgp_world_import_ghosts: NULL");
+	for (uint32_t id : w->ghost_ids) if (live(w, id)) sgp_body_remove(w, id);
+	w->ghost_ids.clear();
+	for (uint32_t k = 0; k < n; ++k) {
+		sgp_body_desc d; sgp_default_body_desc(&d);
+		memcpy(d.pos, in[k].pos, 12); memcpy(d.rot, in[k].rot, 16); memcpy(d.lin_vel, in[k].lin_vel, 12); memcpy(d.ang_vel, in[k].ang_vel, 12);
+		d.shape_type = in[k].shape_type; memcpy(d.shape, in[k].shape, 16);
+		d.motion_type = SGP_MOTION_KINEMATIC;      // velocity driven, infinite mass for this tile's solve
+		d.layer = SGP_LAYER_MOVING;
+		d.mass = in[k].mass; d.friction = in[k].friction; d.restitution = in[k].restitution;
+		d.activate = 1; d.userdata = in[k].global_id;
+		uint32_t id = SGP_INVALID_ID;
+		const int r = add_one(w, &d, &id, true);
+		if (r == SGP_OK) w->ghost_ids.push_back(id);
+		else if (r != SGP_ERR_REJECTED) return r;
+	}
+	return SGP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+
+SGP_API int sgp_world_device_array(sgp_world* w, int which, void** dev_ptr_out, uint32_t* count_out)
+{
+	if (!w || !dev_ptr_out) return fail(SGP_ERR_INVALID, "sgp_world_device_array: NULL");
+	void* p = nullptr;
+	switch (which) { case 0: p = w->dv.pos_im; break; case 1: p = w->dv.rot; break; case 2: p = w->dv.linv; break; case 3: p = w->dv.angv; break;
+	default: return fail(SGP_ERR_INVALID, "sgp_world_device_array: bad index"); }
+	*dev_ptr_out = p;
+	if (count_out) *count_out = w->high;
+	return SGP_OK;
+}
+
+SGP_API int sgp_world_stream(sgp_world* w, void** stream_out)
+{
+	if (!w || !stream_out) return fail(SGP_ERR_INVALID, "sgp_world_stream: NULL");
+	*stream_out = (void*)w->stream;
+	return SGP_OK;
+}

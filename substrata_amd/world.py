@@ -1,8 +1,8 @@
 """Thin numpy/ctypes driver over the C ABI (include/sgp.h).
 
 `CWorld` is ABI plumbing only: it owns no physics.  The product binds it to substrata_amd/libsgp.so (HIP, gfx950);
-the test oracle binds the same class to oracle/libsgo_oracle.so (prefix sgo_) so that parity tests drive both
-sides through identical calls.
+the test suite binds the same class to its CPU checker library (a different symbol prefix) so that parity tests
+drive both sides through identical calls.
 """
 import ctypes as C
 import numpy as np
