@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- physics steps/sec at fixed dt = 1/60 s, 100k bodies (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one PhysicsWorld::think(1/60) (/root/reference/gui_client/PhysicsWorld.cpp:1356-1443) over the synthetic
+BASELINE config 3 world: 100k mixed box / sphere / capsule bodies (100x100x10 lattice, seed 3, substrata_amd/scenes.py)
+dropped on the ground quad.  All state is resident in HBM before the timed region; every step blocks until the device
+has finished it, like think().  N > 1: weak scaling, one 100k-body tile per GPU side by side (4x2 for 8), one fused RCCL
+all-gather of ghost bodies per step (substrata_amd/tiles.py); value = N x world-steps/s = 100k-body tile-steps per second.
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the world's stream
+(sgp_world_step_profiled); `cpu_baseline` times the CPU oracle (a port, NOT Jolt) on a bounded sample of the same
+workload: the device state after warm-up is copied into the oracle and a few steps are timed on one host core.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+DT = 1.0 / 60.0
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+SWEEP_BYTES_PER_BODY = 188     # integrate + AABB body-array sweep, 112 B read + 76 B written
+# per contact point per velocity iteration: constraint rows 56 B read + 16 B written, plus per manifold 2 x (v,w,pose,inertia) gathers
+SOLVE_BYTES_PER_POINT = 72
+SOLVE_BYTES_PER_MANIFOLD = 2 * (32 + 48 + 4) + 2 * 32 + 28
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=120)
+    ap.add_argument("--bodies", type=int, default=100000, help="bodies per tile (BASELINE: 100k)")
+    ap.add_argument("--cpu-steps", type=int, default=12, help="oracle steps timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=8)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    from substrata_amd import abi, scenes, tiles
+    from substrata_amd.lib import World, init
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n_gpus = args.gpus
+    dist = None
+    if world_size > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        assert world_size == n_gpus, "launch with --nproc-per-node equal to --gpus"
+    elif n_gpus != 1:
+        raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run with N ranks")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    init()
+
+    # ---- world: config 3 tile(s) -------------------------------------------------------------------------------
+    nx = ny = 100
+    nz = max(1, args.bodies // (nx * ny))
+    spacing = 1.5
+    tile_w, tile_d = nx * spacing, ny * spacing
+    lo, hi, origin = tiles.tile_bounds(rank, n_gpus, tile_w, tile_d)
+    descs = scenes.config3_100k_mixed(nx, ny, nz, seed=3 + rank)
+    # tile-local lattice is centred on the origin: move it to the tile's place
+    descs["pos"][1:, 0] += origin[0] + tile_w / 2 - spacing / 2
+    descs["pos"][1:, 1] += origin[1] + tile_d / 2 - spacing / 2
+    n_bodies = len(descs) - 1
+    w = World(max_bodies=len(descs) + 32768, device=local_rank)
+    w.add_batch(descs)
+    ex = tiles.GhostExchange(w, rank, n_gpus, lo, hi, margin=2.0, dist=dist, device=torch.device("cuda", local_rank)) if n_gpus > 1 else None
+
+    def one_step():
+        if ex is not None:
+            ex.exchange()
+        w.step(DT)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    contacts = 0
+    for _ in range(args.steps):
+        one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = w.stats()
+
+    # ---- roofline: HIP events around every launch, same world, steps right after the timed region -----------------
+    names = w.kernel_class_names()
+    ksum = np.zeros(len(names)); klaunch = np.zeros(len(names)); n_prof = max(1, args.profile_steps)
+    pts = cons = 0
+    for _ in range(n_prof):
+        if ex is not None:
+            ex.exchange()
+        p = w.step_profiled(DT)
+        ksum += np.array([p.kernel_ms[k] for k in range(len(names))])
+        klaunch += np.array([p.kernel_launches[k] for k in range(len(names))])
+        pts += p.num_contact_points; cons += p.num_constraints
+        sweep_bodies = p.sweep_bodies
+    k = {nm: i for i, nm in enumerate(names)}
+    sweep_ms = (ksum[k["apply_forces"]] + ksum[k["integrate_pose"]] + ksum[k["finalize"]]) / n_prof
+    sweep_bytes = SWEEP_BYTES_PER_BODY * sweep_bodies
+    sweep_gbs = sweep_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+    sv = k["solve_velocity"]
+    solve_launch_ms = ksum[sv] / max(klaunch[sv], 1)
+    iters = w.desc.settings.num_velocity_steps
+    solve_bytes_per_launch = (SOLVE_BYTES_PER_POINT * pts / n_prof + SOLVE_BYTES_PER_MANIFOLD * cons / n_prof) * iters / max(klaunch[sv] / n_prof, 1)
+    solve_gbs = solve_bytes_per_launch / (solve_launch_ms * 1e-3) / 1e9 if solve_launch_ms > 0 else 0.0
+
+    out = None
+    if rank == 0:
+        steps_per_s = args.steps / elapsed
+        out = {
+            "metric": "physics steps/sec at fixed dt, 100k bodies",
+            "value": steps_per_s * n_gpus,
+            "unit": "steps/s",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1000.0 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE config 3: 100k mixed box/sphere/capsule bodies, 100x100x10 lattice spacing 1.5 m, seed 3, "
+                            "ground quad 2000 m, dt 1/60, Jolt default settings (10 velocity / 2 position iterations), sleeping enabled",
+                "bodies_per_gpu": n_bodies, "tiles": n_gpus, "value_definition": "n_gpus x world steps/s (one 100k-body tile per GPU)",
+                "active_bodies_end": st.num_active, "contact_constraints_end": st.num_manifolds,
+                "contact_points_end": st.num_contact_points, "colours_end": st.num_colours,
+                "ghosts_exported_per_step": (ex.last_exported if ex else 0), "ghosts_imported_per_step": (ex.last_imported if ex else 0),
+                "dropped_pairs_or_manifolds": st.pairs_dropped + st.manifolds_dropped,
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "body-array sweep = k_apply_forces + k_integrate_pose + k_finalize (one launch each per step)",
+                "achieved": sweep_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sweep_gbs / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": sweep_bytes, "launch_ms": sweep_ms, "traffic": None,
+            },
+            "roofline_solver": {
+                "bound": "hbm", "kernel": "k_solve_velocity (dominant by time; one launch per colour per iteration)",
+                "achieved": solve_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": solve_gbs / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": solve_bytes_per_launch, "launch_ms": solve_launch_ms,
+                "launches_per_step": klaunch[sv] / n_prof, "traffic": None,
+            },
+            "kernel_ms_per_step": {names[i]: round(ksum[i] / n_prof, 4) for i in range(len(names)) if klaunch[i]},
+        }
+
+    # ---- CPU baseline: the oracle (a port of the same step, NOT Jolt) on a bounded sample, rank 0 only --------------
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline and args.cpu_steps > 0:
+        from oracle import oracle
+        S = w.read_states(0, len(descs))
+        d2 = descs.copy()
+        d2["pos"] = S["pos"]; d2["rot"] = S["rot"]; d2["lin_vel"] = S["lin_vel"]; d2["ang_vel"] = S["ang_vel"]
+        d2["activate"] = (S["active"] != 0).astype(np.int32)
+        cw = oracle.OracleWorld(max_bodies=len(descs) + 8)
+        cw.add_batch(d2)
+        cw.step(DT)                      # builds the contact cache so the timed steps are warm-started like the device's
+        t1 = time.perf_counter()
+        for _ in range(args.cpu_steps):
+            cw.step(DT)
+        cpu_el = time.perf_counter() - t1
+        cst = cw.stats()
+        out["cpu_baseline"] = {
+            "value": args.cpu_steps / cpu_el, "unit": "steps/s", "cores": 1, "kind": "port",
+            "sample": f"{args.cpu_steps} steps of the same 100k-body world, started from the device state after warm-up + timed region "
+                      f"({cst.num_manifolds} contact constraints, {cst.num_active} active bodies); oracle/sgo_oracle.c, single thread; "
+                      "this is this repo's CPU restatement, not JoltPhysics (absent from the reference tree)",
+            "host_cpus": os.cpu_count(),
+        }
+        cw.close()
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    w.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

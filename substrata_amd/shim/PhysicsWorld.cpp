@@ -1,0 +1,354 @@
+// PhysicsWorld over the sgp C ABI.  Each method follows the reference method of the same name
+// (/root/reference/gui_client/PhysicsWorld.cpp, line ranges in the comments) with Jolt calls replaced by ABI calls.
+#include "PhysicsWorld.h"
+#include <utils/Exception.h>
+#include "../../include/sgp.h"
+#include <algorithm>
+#include <cassert>
+#include <cstring>
+
+static inline float myClamp(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// PhysicsWorld.cpp:250-273
+void PhysicsWorld::init()
+{
+	const int n = sgp_init();
+	if (n <= 0) throw glare::Exception(std::string("PhysicsWorld::init: ") + sgp_last_error());
+}
+
+// PhysicsWorld.cpp:462-532.  task_manager / stack_allocator are accepted for source compatibility and unused: the
+// step runs as HIP launches on one stream, scratch lives in device arenas (no job system, no temp allocator).
+PhysicsWorld::PhysicsWorld(glare::TaskManager* task_manager_, glare::StackAllocator* stack_allocator_)
+:	activated_obs(NULL), newly_activated_obs(NULL), event_listener(NULL), world(NULL),
+	water_buoyancy_enabled(false), water_z(0), task_manager(task_manager_), stack_allocator(stack_allocator_)
+{
+	sgp_world_desc d;
+	sgp_default_world_desc(&d);        // cMaxBodies 65536 (:492), gravity (0,0,-9.81) (:520), Jolt default settings
+	const int r = sgp_world_create(&d, &world);
+	if (r != SGP_OK) { world = NULL; throw glare::Exception(std::string("PhysicsWorld: ") + sgp_last_error()); }
+	id_to_ob.resize(d.max_bodies, NULL);
+}
+
+PhysicsWorld::~PhysicsWorld() { if (world) sgp_world_destroy(world); }
+
+void PhysicsWorld::setWaterBuoyancyEnabled(bool enabled) { water_buoyancy_enabled = enabled; sgp_world_set_water(world, enabled ? 1 : 0, water_z); }
+void PhysicsWorld::setWaterZ(float z) { water_z = z; sgp_world_set_water(world, water_buoyancy_enabled ? 1 : 0, water_z); }
+
+// PhysicsWorld.cpp:1123-1135
+PhysicsShape PhysicsWorld::createGroundQuadShape(float ground_quad_w)
+{
+	PhysicsShape s; s.kind = 1; s.p[0] = ground_quad_w / 2; s.p[1] = ground_quad_w / 2; s.p[2] = 0.5f; s.size_B = sizeof(PhysicsShape);
+	return s;
+}
+PhysicsShape PhysicsWorld::createCapsuleShape(float radius, float half_height)
+{
+	PhysicsShape s; s.kind = 2; s.p[0] = radius; s.p[1] = half_height; s.size_B = sizeof(PhysicsShape);
+	return s;
+}
+
+// PhysicsWorld.cpp:1169-1311
+void PhysicsWorld::addObject(const Reference<PhysicsObject>& object)
+{
+	assert(object->pos.isFinite());
+	if (!object->jolt_body_id.IsInvalid()) return;    // body already built (:1175)
+	sgp_body_desc d;
+	sgp_default_body_desc(&d);
+	for (int i = 0; i < 3; ++i) d.pos[i] = object->pos[i];
+	for (int i = 0; i < 4; ++i) d.rot[i] = object->rot.v[i];
+	if (std::fabs(object->scale.x) < 1.0e-7f || std::fabs(object->scale.y) < 1.0e-7f || std::fabs(object->scale.z) < 1.0e-7f) return;   // :1184
+	const bool moving = object->motion_type == PhysicsObject::MotionType_dynamic || object->motion_type == PhysicsObject::MotionType_kinematic ||
+		object->motion_type == PhysicsObject::MotionType_semi_static;
+	if (moving) d.layer = object->collidable ? SGP_LAYER_MOVING : SGP_LAYER_MOVING_NON_COLLIDABLE;               // :1193-1199
+	else        d.layer = object->collidable ? SGP_LAYER_NON_MOVING : SGP_LAYER_NON_MOVING_NON_COLLIDABLE;       // :1200-1207
+	switch (object->motion_type) {                                                                                // :1209-1217
+	case PhysicsObject::MotionType_dynamic:   d.motion_type = SGP_MOTION_DYNAMIC; break;
+	case PhysicsObject::MotionType_kinematic: d.motion_type = SGP_MOTION_KINEMATIC; break;
+	default:                                  d.motion_type = SGP_MOTION_STATIC; break;
+	}
+	if (object->is_sphere) {              // unit sphere r 0.5, uniform scale = scale.x (:1219-1227)
+		d.shape_type = SGP_SHAPE_SPHERE; d.shape[0] = 0.5f * std::fabs(object->scale.x); d.shape[1] = d.shape[2] = 0;
+	} else if (object->is_cube) {         // unit cube half 0.5, per-axis scale (:1247-1255)
+		d.shape_type = SGP_SHAPE_BOX;
+		d.shape[0] = 0.5f * std::fabs(object->scale.x); d.shape[1] = 0.5f * std::fabs(object->scale.y); d.shape[2] = 0.5f * std::fabs(object->scale.z);
+	} else {                              // object->shape with a ScaledShape decorator (:1275-1287)
+		const PhysicsShape& s = object->shape;
+		if (s.kind < 0) return;           // shape.jolt_shape == NULL (:1278-1279)
+		d.shape_type = s.kind;
+		if (s.kind == 1) { d.shape[0] = s.p[0] * std::fabs(object->scale.x); d.shape[1] = s.p[1] * std::fabs(object->scale.y); d.shape[2] = s.p[2] * std::fabs(object->scale.z); }
+		else if (s.kind == 0) { d.shape[0] = s.p[0] * std::fabs(object->scale.x); }
+		else { d.shape[0] = s.p[0] * std::fabs(object->scale.x); d.shape[1] = s.p[1] * std::fabs(object->scale.z); }
+	}
+	d.is_sensor = object->is_sensor ? 1 : 0;
+	d.friction = myClamp(object->friction, 0.f, 1.f);       // :1236
+	d.restitution = myClamp(object->restitution, 0.f, 1.f); // :1237
+	d.mass = std::max(0.001f, object->mass);                // :1238
+	d.use_zero_linear_drag = object->use_zero_linear_drag ? 1 : 0;
+	d.userdata = (uint64)object.ptr();                      // :1241
+	d.activate = 0;                                          // EActivation::DontActivate (:1243)
+	uint32_t id = SGP_INVALID_ID;
+	if (sgp_body_add(world, &d, &id) != SGP_OK) return;      // silent rejection, as the reference (:1178-1189)
+	object->jolt_body_id = JPH::BodyID(id);
+	if (id < id_to_ob.size()) id_to_ob[id] = object.ptr();
+}
+
+// PhysicsWorld.cpp:1315-1339
+void PhysicsWorld::removeObject(const Reference<PhysicsObject>& object)
+{
+	if (!object->jolt_body_id.IsInvalid()) {
+		const uint32_t id = object->jolt_body_id.GetIndex();
+		sgp_body_remove(world, id);
+		if (id < id_to_ob.size()) id_to_ob[id] = NULL;
+		object->jolt_body_id = JPH::BodyID();
+	}
+	{
+		Lock lock(activated_obs_mutex);
+		activated_obs.erase(object.ptr());
+		newly_activated_obs.erase(object.ptr());
+	}
+}
+
+// PhysicsWorld.cpp:1342-1353
+void PhysicsWorld::activateObject(const Reference<PhysicsObject>& object)
+{
+	if (object->jolt_body_id.IsInvalid()) return;
+	sgp_body_activate(world, object->jolt_body_id.GetIndex());
+	drainActivationEvents();
+}
+void PhysicsWorld::setObjectLayer(const Reference<PhysicsObject>& object, uint8 new_object_layer)
+{
+	if (object->jolt_body_id.IsInvalid()) return;
+	sgp_body_set_layer(world, object->jolt_body_id.GetIndex(), new_object_layer);
+}
+
+// OnBodyActivated / OnBodyDeactivated (:1448-1486): maintain activated_obs / newly_activated_obs.
+void PhysicsWorld::drainActivationEvents()
+{
+	std::vector<sgp_body_event> ev(1024);
+	for (int kind = SGP_EVENT_ACTIVATED; kind <= SGP_EVENT_DEACTIVATED; ++kind) {
+		uint32_t n = 0;
+		// the ABI drains the whole list in one call: size the buffer to the world's capacity
+		ev.resize(id_to_ob.size());
+		sgp_world_drain_events(world, kind, ev.data(), (uint32_t)ev.size(), &n);
+		Lock lock(activated_obs_mutex);
+		for (uint32_t i = 0; i < n && i < ev.size(); ++i) {
+			PhysicsObject* ob = (PhysicsObject*)ev[i].userdata;
+			if (!ob) continue;                                  // inBodyUserData != 0 (:1452,1475)
+			if (kind == SGP_EVENT_ACTIVATED) { activated_obs.insert(ob); newly_activated_obs.insert(ob); }
+			else activated_obs.erase(ob);
+		}
+	}
+}
+
+// PhysicsWorld.cpp:1356-1443
+void PhysicsWorld::think(double dt)
+{
+	sgp_world_set_contact_events(world, event_listener ? 1 : 0);
+	sgp_world_step(world, (float)dt);                            // physics_system->Update((float)dt, 1, ...) (:1363) + buoyancy sweep (:1367-1442)
+	drainActivationEvents();
+
+	if (event_listener) {
+		// OnContactAdded / OnContactPersisted -> event_listener (:1499-1520), delivered on the calling thread
+		std::vector<sgp_contact_event> ce;
+		for (int kind = SGP_EVENT_CONTACT_ADDED; kind <= SGP_EVENT_CONTACT_PERSISTED; ++kind) {
+			uint32_t n = 0;
+			ce.resize(8 * id_to_ob.size() + 1024);
+			sgp_world_drain_events(world, kind, ce.data(), (uint32_t)ce.size(), &n);
+			for (uint32_t i = 0; i < n && i < ce.size(); ++i) {
+				const sgp_contact_event& e = ce[i];
+				JPH::Body b1, b2; JPH::ContactManifold m;
+				b1.lin_vel = JPH::Vec3(e.lin_vel1[0], e.lin_vel1[1], e.lin_vel1[2]); b1.user_data = e.userdata1; b1.id = JPH::BodyID(e.id1);
+				b2.lin_vel = JPH::Vec3(e.lin_vel2[0], e.lin_vel2[1], e.lin_vel2[2]); b2.user_data = e.userdata2; b2.id = JPH::BodyID(e.id2);
+				m.mBaseOffset = JPH::Vec3(e.base_offset[0], e.base_offset[1], e.base_offset[2]);
+				m.mWorldSpaceNormal = JPH::Vec3(e.normal[0], e.normal[1], e.normal[2]);
+				m.mPenetrationDepth = e.penetration;
+				for (uint32_t k = 0; k < e.num_points; ++k) m.mRelativeContactPointsOn1.push_back(JPH::Vec3(e.rel_points_on1[k][0], e.rel_points_on1[k][1], e.rel_points_on1[k][2]));
+				if (kind == SGP_EVENT_CONTACT_ADDED) event_listener->contactAdded(b1, b2, m); else event_listener->contactPersisted(b1, b2, m);
+			}
+		}
+	}
+
+	if (water_buoyancy_enabled) {
+		// underwater / last_submerged_volume / physicsObjectEnteredWater bookkeeping (:1414-1437)
+		std::vector<sgp_body_event> ev(id_to_ob.size());
+		uint32_t n = 0;
+		sgp_world_drain_events(world, SGP_EVENT_ENTERED_WATER, ev.data(), (uint32_t)ev.size(), &n);
+		for (uint32_t i = 0; i < n && i < ev.size(); ++i) {
+			PhysicsObject* ob = (PhysicsObject*)ev[i].userdata;
+			if (ob && event_listener) event_listener->physicsObjectEnteredWater(*ob);
+		}
+		Lock lock(activated_obs_mutex);
+		std::vector<uint32_t> ids; std::vector<PhysicsObject*> obs;
+		for (auto it = activated_obs.begin(); it != activated_obs.end(); ++it) if (!(*it)->jolt_body_id.IsInvalid()) { ids.push_back((*it)->jolt_body_id.GetIndex()); obs.push_back(*it); }
+		std::vector<sgp_body_state> st(ids.size());
+		if (!ids.empty() && sgp_body_get_state(world, ids.data(), (uint32_t)ids.size(), st.data()) == SGP_OK)
+			for (size_t i = 0; i < ids.size(); ++i) { obs[i]->underwater = st[i].underwater != 0; obs[i]->last_submerged_volume = st[i].submerged_volume; }
+	}
+}
+
+// GUIClient.cpp:6581-6690 in one batched read
+void PhysicsWorld::readBackActivatedObjectTransforms()
+{
+	Lock lock(activated_obs_mutex);
+	std::vector<uint32_t> ids; std::vector<PhysicsObject*> obs;
+	for (auto it = activated_obs.begin(); it != activated_obs.end(); ++it) if (!(*it)->jolt_body_id.IsInvalid()) { ids.push_back((*it)->jolt_body_id.GetIndex()); obs.push_back(*it); }
+	if (ids.empty()) return;
+	std::vector<sgp_body_state> st(ids.size());
+	if (sgp_body_get_state(world, ids.data(), (uint32_t)ids.size(), st.data()) != SGP_OK) return;
+	for (size_t i = 0; i < ids.size(); ++i) {
+		obs[i]->pos = Vec4f(st[i].pos[0], st[i].pos[1], st[i].pos[2], 1.f);
+		obs[i]->rot = Quatf(st[i].rot[0], st[i].rot[1], st[i].rot[2], st[i].rot[3]);
+	}
+}
+
+// PhysicsWorld.cpp:546-604
+void PhysicsWorld::setNewObToWorldTransform(PhysicsObject& object, const Vec4f& translation, const Quatf& rot_quat, const Vec4f& scale)
+{
+	assert(translation.isFinite());
+	object.pos = translation; object.rot = rot_quat; object.scale = Vec3f(scale);
+	if (object.jolt_body_id.IsInvalid()) return;
+	float shape[4] = { 0, 0, 0, 0 };
+	if (object.is_sphere) shape[0] = 0.5f * std::fabs(scale[0]);                       // sphere forced to uniform scale (:571-572)
+	else if (object.is_cube) { shape[0] = 0.5f * std::fabs(scale[0]); shape[1] = 0.5f * std::fabs(scale[1]); shape[2] = 0.5f * std::fabs(scale[2]); }
+	else if (object.shape.kind == 1) { shape[0] = object.shape.p[0] * std::fabs(scale[0]); shape[1] = object.shape.p[1] * std::fabs(scale[1]); shape[2] = object.shape.p[2] * std::fabs(scale[2]); }
+	else if (object.shape.kind == 0) shape[0] = object.shape.p[0] * std::fabs(scale[0]);
+	else { shape[0] = object.shape.p[0] * std::fabs(scale[0]); shape[1] = object.shape.p[1] * std::fabs(scale[2]); }
+	sgp_body_set_pose_shape(world, object.jolt_body_id.GetIndex(), translation.x, rot_quat.v.x, shape);   // zero velocity, new scale, ActivateBody (:553-601)
+	drainActivationEvents();
+}
+
+// PhysicsWorld.cpp:607-620
+void PhysicsWorld::setNewObToWorldTransform(PhysicsObject& object, const Vec4f& pos, const Quatf& rot, const Vec4f& linear_vel, const Vec4f& angular_vel)
+{
+	assert(pos.isFinite());
+	object.pos = pos; object.rot = rot;
+	if (!object.jolt_body_id.IsInvalid()) sgp_body_set_pose_vel(world, object.jolt_body_id.GetIndex(), pos.x, rot.v.x, linear_vel.x, angular_vel.x);
+}
+
+// PhysicsWorld.cpp:623-633
+void PhysicsWorld::setNewPosition(PhysicsObject& object, const Vec4f& pos)
+{
+	assert(pos.isFinite());
+	object.pos = pos;
+	if (!object.jolt_body_id.IsInvalid()) sgp_body_set_pos(world, object.jolt_body_id.GetIndex(), pos.x);
+}
+
+// PhysicsWorld.cpp:636-646
+Vec4f PhysicsWorld::getObjectLinearVelocity(const PhysicsObject& object) const
+{
+	if (object.jolt_body_id.IsInvalid()) return Vec4f(0.f);
+	const uint32_t id = object.jolt_body_id.GetIndex();
+	sgp_body_state st;
+	if (sgp_body_get_state(world, &id, 1, &st) != SGP_OK) return Vec4f(0.f);
+	return Vec4f(st.lin_vel[0], st.lin_vel[1], st.lin_vel[2], 0.f);
+}
+
+// PhysicsWorld.cpp:649-657
+void PhysicsWorld::setLinearAndAngularVelToZero(PhysicsObject& object)
+{
+	const float z[3] = { 0, 0, 0 };
+	if (!object.jolt_body_id.IsInvalid()) sgp_body_set_vel(world, object.jolt_body_id.GetIndex(), z, z);
+}
+
+// PhysicsWorld.cpp:660-704 (same construction: columns of R scaled, inverse = S^-1 R^T T^-1)
+void computeToWorldAndToObMatrices(const Vec4f& translation, const Quatf& rot_quat, const Vec4f& scale, Matrix4f& ob_to_world_out, Matrix4f& world_to_ob_out)
+{
+	Vec4f use_scale = scale;
+	for (int i = 0; i < 3; ++i) if (use_scale[i] == 0) use_scale[i] = 1.0e-6f;
+	const Matrix4f rot = rot_quat.toMatrix();
+	Matrix4f ob_to_world;
+	ob_to_world.setColumn(0, rot.getColumn(0) * use_scale[0]);
+	ob_to_world.setColumn(1, rot.getColumn(1) * use_scale[1]);
+	ob_to_world.setColumn(2, rot.getColumn(2) * use_scale[2]);
+	ob_to_world.setColumn(3, setWToOne(translation));
+	const Matrix4f rot_inv = rot.getTranspose();
+	const Vec4f recip_scale = maskWToZero(div(Vec4f(1.f), use_scale));
+	Matrix4f S_inv_R_inv;
+	for (int c = 0; c < 3; ++c) {
+		const Vec4f col = rot_inv.getColumn(c);
+		S_inv_R_inv.setColumn(c, Vec4f(col[0] * recip_scale[0], col[1] * recip_scale[1], col[2] * recip_scale[2], 0.f));
+	}
+	S_inv_R_inv.setColumn(3, Vec4f(0, 0, 0, 1));
+	ob_to_world_out = ob_to_world;
+	world_to_ob_out = rightTranslate(S_inv_R_inv, -translation);
+}
+
+// PhysicsWorld.cpp:707-722
+void PhysicsWorld::moveKinematicObject(PhysicsObject& object, const Vec4f& translation, const Quatf& rot, float dt)
+{
+	if (object.jolt_body_id.IsInvalid()) return;
+	if (object.motion_type != PhysicsObject::MotionType_kinematic) return;     // "Tried to move a non-kinematic object" guard (:713-720)
+	sgp_body_move_kinematic(world, object.jolt_body_id.GetIndex(), translation.x, rot.v.x, dt);
+}
+
+void PhysicsWorld::addForce(PhysicsObject& object, const Vec4f& force) { if (!object.jolt_body_id.IsInvalid()) sgp_body_add_force(world, object.jolt_body_id.GetIndex(), force.x); }
+void PhysicsWorld::addForceAtPoint(PhysicsObject& object, const Vec4f& force, const Vec4f& point) { if (!object.jolt_body_id.IsInvalid()) sgp_body_add_force_at(world, object.jolt_body_id.GetIndex(), force.x, point.x); }
+void PhysicsWorld::addTorque(PhysicsObject& object, const Vec4f& torque) { if (!object.jolt_body_id.IsInvalid()) sgp_body_add_torque(world, object.jolt_body_id.GetIndex(), torque.x); }
+
+void PhysicsWorld::clear() {}    // stub in the reference too (:1523-1526)
+
+// PhysicsWorld.cpp:1529-1604
+PhysicsWorld::MemUsageStats PhysicsWorld::getMemUsageStats() const
+{
+	sgp_step_stats s; memset(&s, 0, sizeof(s));
+	sgp_world_stats(world, &s);
+	MemUsageStats m; m.mem = (size_t)s.device_bytes; m.num_meshes = 0;
+	m.layer_counts.assign(s.layer_counts, s.layer_counts + Layers::NUM_LAYERS);
+	return m;
+}
+std::string PhysicsWorld::getDiagnostics() const
+{
+	sgp_step_stats s; memset(&s, 0, sizeof(s));
+	sgp_world_stats(world, &s);
+	std::string out;
+	out += "Objects: " + std::to_string(s.num_bodies) + "\n";
+	out += "Active bodies: " + std::to_string(s.num_active) + "\n";
+	out += "Body pairs: " + std::to_string(s.num_pairs) + ", contact constraints: " + std::to_string(s.num_manifolds) + ", colours: " + std::to_string(s.num_colours) + "\n";
+	out += "Device mem usage: " + std::to_string(s.device_bytes >> 20) + " MB\n";
+	out += "NON_MOVING layer obs:                " + std::to_string(s.layer_counts[Layers::NON_MOVING]) + "\n";
+	out += "MOVING layer obs:                    " + std::to_string(s.layer_counts[Layers::MOVING]) + "\n";
+	out += "NON_MOVING_NON_COLLIDABLE layer obs: " + std::to_string(s.layer_counts[Layers::NON_MOVING_NON_COLLIDABLE]) + "\n";
+	out += "MOVING_NON_COLLIDABLE layer obs:     " + std::to_string(s.layer_counts[Layers::MOVING_NON_COLLIDABLE]) + "\n";
+	return out;
+}
+std::string PhysicsWorld::getLoadedMeshes() const { return std::string(); }
+
+// PhysicsWorld.cpp:1625-1638
+const Vec4f PhysicsWorld::getPosInJolt(const Reference<PhysicsObject>& object)
+{
+	if (object->jolt_body_id.IsInvalid()) return object->pos;
+	const uint32_t id = object->jolt_body_id.GetIndex();
+	sgp_body_state st;
+	if (sgp_body_get_state(world, &id, 1, &st) != SGP_OK) return object->pos;
+	return Vec4f(st.pos[0], st.pos[1], st.pos[2], 1.f);
+}
+size_t PhysicsWorld::getNumObjects() const { uint32_t n = 0; sgp_world_num_bodies(world, &n); return n; }
+
+// PhysicsWorld.cpp:1668-1725
+static void doTraceRay(sgp_world* world, const Vec4f& origin, const Vec4f& dir, float max_t, JPH::BodyID ignore_body_id, bool collidable_only, RayTraceResult& results_out)
+{
+	results_out.hit_object = NULL;
+	sgp_ray r; memset(&r, 0, sizeof(r));
+	for (int i = 0; i < 3; ++i) { r.origin[i] = origin[i]; r.dir[i] = dir[i]; }
+	r.max_t = max_t; r.ignore_id = ignore_body_id.GetIndex(); r.collidable_only = collidable_only ? 1u : 0u;
+	sgp_hit h;
+	if (sgp_raycast(world, &r, 1, &h) != SGP_OK || h.id == SGP_INVALID_ID) return;
+	if (h.userdata != 0) {                                                       // :1687-1690
+		results_out.hit_object = (PhysicsObject*)h.userdata;
+		results_out.coords = Vec2f(0.f);
+		results_out.hit_t = h.t;
+		results_out.hit_normal_ws = Vec4f(h.normal[0], h.normal[1], h.normal[2], 0.f);
+		results_out.hit_mat_index = 0;
+	}
+}
+void PhysicsWorld::traceRay(const Vec4f& origin, const Vec4f& dir, float max_t, JPH::BodyID ignore_body_id, RayTraceResult& results_out) const
+{ doTraceRay(world, origin, dir, max_t, ignore_body_id, false, results_out); }
+void PhysicsWorld::traceRayAgainstCollidableObs(const Vec4f& origin, const Vec4f& dir, float max_t, JPH::BodyID ignore_body_id, RayTraceResult& results_out) const
+{ doTraceRay(world, origin, dir, max_t, ignore_body_id, true, results_out); }
+bool PhysicsWorld::doesRayHitAnything(const Vec4f& origin, const Vec4f& dir, float max_t) const
+{
+	sgp_ray r; memset(&r, 0, sizeof(r));
+	for (int i = 0; i < 3; ++i) { r.origin[i] = origin[i]; r.dir[i] = dir[i]; }
+	r.max_t = max_t; r.ignore_id = SGP_INVALID_ID;
+	sgp_hit h;
+	return sgp_raycast(world, &r, 1, &h) == SGP_OK && h.id != SGP_INVALID_ID;
+}

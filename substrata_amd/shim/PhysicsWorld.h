@@ -1,0 +1,127 @@
+// PhysicsWorld -- the reference's physics facade (/root/reference/gui_client/PhysicsWorld.h:98-218), same class and
+// method names, same public members (activated_obs_mutex, activated_obs, newly_activated_obs, event_listener), bound to
+// the sgp C ABI (include/sgp.h) instead of JoltPhysics.  Members that exposed raw Jolt objects (physics_system,
+// temp_allocator, job_system: PhysicsWorld.h:204-210) do not exist here; INTEGRATION.md lists what that means for the
+// callers that reach around the facade.
+#pragma once
+#include "PhysicsObject.h"
+#include <maths/Vec4f.h>
+#include <maths/Quat.h>
+#include <maths/vec2.h>
+#include <utils/ThreadSafeRefCounted.h>
+#include <utils/Mutex.h>
+#include <utils/HashSet.h>
+#include <Jolt/JoltLite.h>
+#include <string>
+#include <vector>
+#include <cstdint>
+
+namespace glare { class TaskManager; class StackAllocator; class Allocator; }
+struct sgp_world;
+typedef unsigned char uint8;
+typedef uint64_t uint64;
+
+class RayTraceResult
+{
+public:
+	Vec4f hit_normal_ws;
+	const PhysicsObject* hit_object;
+	float hit_t;
+	unsigned int hit_mat_index;
+	Vec2f coords;
+};
+
+namespace Layers
+{
+	static constexpr uint8 NON_MOVING = 0;
+	static constexpr uint8 MOVING = 1;
+	static constexpr uint8 NON_MOVING_NON_COLLIDABLE = 2;
+	static constexpr uint8 MOVING_NON_COLLIDABLE = 3;
+	static constexpr uint8 NUM_LAYERS = 4;
+};
+
+class PhysicsWorldEventListener
+{
+public:
+	virtual ~PhysicsWorldEventListener() {}
+	virtual void physicsObjectEnteredWater(PhysicsObject& ob) {}
+	// The reference may call these off the main thread; this backend calls them on the caller's thread at the end of think().
+	virtual void contactAdded(const JPH::Body& inBody1, const JPH::Body& inBody2, const JPH::ContactManifold& contact_manifold) {}
+	virtual void contactPersisted(const JPH::Body& inBody1, const JPH::Body& inBody2, const JPH::ContactManifold& contact_manifold) {}
+};
+
+void computeToWorldAndToObMatrices(const Vec4f& translation, const Quatf& rot_quat, const Vec4f& scale, Matrix4f& ob_to_world_out, Matrix4f& world_to_ob_out);
+
+class PhysicsWorld : public ThreadSafeRefCounted
+{
+public:
+	PhysicsWorld(glare::TaskManager* task_manager, glare::StackAllocator* stack_allocator);
+	~PhysicsWorld();
+
+	static void init();
+
+	void setWaterBuoyancyEnabled(bool enabled);
+	bool getWaterBuoyancyEnabled() const { return water_buoyancy_enabled; }
+	void setWaterZ(float water_z);
+	float getWaterZ() const { return water_z; }
+
+	void addObject(const Reference<PhysicsObject>& object);
+	void removeObject(const Reference<PhysicsObject>& object);
+	void activateObject(const Reference<PhysicsObject>& object);
+	void setObjectLayer(const Reference<PhysicsObject>& object, uint8 new_object_layer);
+
+	// Creates a box, centered at (0,0,0), with x and y extent = ground_quad_w, and z extent = 1.
+	static PhysicsShape createGroundQuadShape(float ground_quad_w);
+	// Not in the reference: the capsule the reference builds inline from JPH::CapsuleShape (PlayerPhysics.cpp:74, AvatarGraphics.cpp:150).
+	static PhysicsShape createCapsuleShape(float radius, float half_height);
+
+	void think(double dt);
+
+	void setNewObToWorldTransform(PhysicsObject& object, const Vec4f& translation, const Quatf& rot, const Vec4f& scale);
+	void setNewObToWorldTransform(PhysicsObject& object, const Vec4f& translation, const Quatf& rot, const Vec4f& linear_vel, const Vec4f& angular_vel);
+	void setNewPosition(PhysicsObject& object, const Vec4f& pos);
+	Vec4f getObjectLinearVelocity(const PhysicsObject& object) const;
+	void setLinearAndAngularVelToZero(PhysicsObject& object);
+	void moveKinematicObject(PhysicsObject& object, const Vec4f& translation, const Quatf& rot, float dt);
+	void clear();
+
+	struct MemUsageStats { size_t mem; size_t num_meshes; std::vector<int> layer_counts; };
+	MemUsageStats getMemUsageStats() const;
+	std::string getDiagnostics() const;
+	std::string getLoadedMeshes() const;
+	const Vec4f getPosInJolt(const Reference<PhysicsObject>& object);
+	size_t getNumObjects() const;
+
+	void traceRay(const Vec4f& origin, const Vec4f& dir, float max_t, JPH::BodyID ignore_body_id, RayTraceResult& results_out) const;
+	void traceRayAgainstCollidableObs(const Vec4f& origin, const Vec4f& dir, float max_t, JPH::BodyID ignore_body_id, RayTraceResult& results_out) const;
+	bool doesRayHitAnything(const Vec4f& origin, const Vec4f& dir, float max_t) const;
+
+	// What GUIClient.cpp:6581-6690 does through physics_system->GetBodyInterface(): copy the poses of the activated
+	// objects back into PhysicsObject::pos / rot (one batched device read instead of one Jolt call per object).
+	void readBackActivatedObjectTransforms();
+	// BodyInterface::AddForce / AddTorque / AddForce(at point), used by HoverCarPhysics.cpp:113-348, BoatPhysics.cpp:221-267
+	void addForce(PhysicsObject& object, const Vec4f& force);
+	void addForceAtPoint(PhysicsObject& object, const Vec4f& force, const Vec4f& point);
+	void addTorque(PhysicsObject& object, const Vec4f& torque);
+
+public:
+	mutable Mutex activated_obs_mutex;
+	HashSet<PhysicsObject*> activated_obs GUARDED_BY(activated_obs_mutex);
+	HashSet<PhysicsObject*> newly_activated_obs GUARDED_BY(activated_obs_mutex);
+	PhysicsWorldEventListener* event_listener;
+
+	sgp_world* world;   // the C-ABI handle (in place of physics_system / temp_allocator / job_system)
+
+private:
+	void drainActivationEvents();
+	bool water_buoyancy_enabled;
+	float water_z;
+	glare::TaskManager* task_manager;
+	glare::StackAllocator* stack_allocator;
+	std::vector<PhysicsObject*> id_to_ob;
+};
+
+inline void checkRemoveObAndSetRefToNull(PhysicsWorld& physics_world, Reference<PhysicsObject>& physics_object)
+{
+	if (physics_object) { physics_world.removeObject(physics_object); physics_object = nullptr; }
+}
