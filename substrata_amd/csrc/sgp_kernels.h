@@ -32,7 +32,15 @@ enum {
 	KC_APPLY_FORCES = 0, KC_BP_CELL, KC_BP_SCAN, KC_BP_SCATTER, KC_BP_PAIRS, KC_BP_LARGE, KC_NARROWPHASE, KC_WAKE,
 	KC_COLOUR_CLAIM, KC_COLOUR_COMMIT, KC_COLOUR_COUNT, KC_SETUP, KC_WARM_START, KC_SOLVE_VELOCITY,
 	KC_INTEGRATE_POSE, KC_SOLVE_POSITION, KC_FINALIZE, KC_ISLAND_HOOK, KC_ISLAND_FLAG, KC_SLEEP_APPLY, KC_BUOYANCY,
-	KC_CACHE_BUILD, KC_MISC, KC_EDIT, KC_GATHER, KC_COUNT
+	KC_CACHE_BUILD, KC_MISC, KC_EDIT, KC_GATHER, KC_PREP_BODIES, KC_COUNT
+};
+
+// Dense broad-phase grid of the current step (written by k_bp_grid_params).
+struct BpGrid {
+	int   min_x, min_y, min_z, max_x, max_y, max_z;   // ordered-int encoded float bounds of the small bodies' AABB centres
+	float ox, oy, oz, inv_cell, cell;
+	int   nx, ny, nz;
+	uint32_t n_cells;
 };
 
 // Device-side counters of one step (read back once per step).
@@ -128,9 +136,12 @@ struct DV {
 	uint64_t* claim[2];
 	uint32_t* island;
 	uint32_t* island_awake;
+	float4* sbody;             // per step, 64 B per body (one cache line): [lin vel xyz, EFFECTIVE inverse mass][ang vel xyz, -]
+	                           //   [world inv inertia xx,xy,xz,-][yy,yz,zz,-]; velocities live here during the velocity solve
 	// broad phase
 	uint32_t table_size;       // power of two
-	float    cell_size;
+	float    cell_size;        // requested cell edge = bp_rmax + speculative margin (the grid may coarsen it)
+	float    bp_rmax;          // largest bounding radius of the small bodies: a body's partners have centres within AABB +- (bp_rmax + margin)
 	uint32_t* cell_hash;       // per body
 	int4*     cell_xyz;        // per body
 	uint32_t* cell_count;      // per bucket (+1)
@@ -138,6 +149,9 @@ struct DV {
 	uint32_t* cell_fill;
 	uint32_t* sorted_ids;
 	uint32_t* scan_block_sums;
+	float4*   sorted_min;      // cell-sorted copy: aabb min xyz, flags (bits) w
+	float4*   sorted_max;      // cell-sorted copy: aabb max xyz, body id (bits) w
+	struct BpGrid* grid;       // per-step dense grid parameters (device)
 	const uint32_t* large_ids; uint32_t n_large;
 	uint2*    pairs;
 	// narrow phase output (manifolds, unordered)
@@ -166,6 +180,7 @@ struct DV {
 
 // ---- launch wrappers (defined in sgp_kernels.hip) ---------------------------------------------------------------
 void launch_apply_forces(const DV& d, float dt, hipStream_t s);
+void launch_bp_bounds(const DV& d, hipStream_t s);
 void launch_bp_cell(const DV& d, hipStream_t s);
 void launch_bp_scan(const DV& d, hipStream_t s);
 void launch_bp_scatter(const DV& d, hipStream_t s);
@@ -173,6 +188,7 @@ void launch_bp_pairs(const DV& d, hipStream_t s);
 void launch_bp_large(const DV& d, hipStream_t s);
 void launch_narrowphase(const DV& d, uint32_t n_pairs_upper, hipStream_t s);
 void launch_wake(const DV& d, hipStream_t s);
+void launch_prep_bodies(const DV& d, hipStream_t s);
 void launch_colour_claim(const DV& d, uint32_t n_man, uint32_t round, hipStream_t s);
 void launch_colour_commit(const DV& d, uint32_t n_man, uint32_t round, hipStream_t s);
 void launch_colour_count(const DV& d, uint32_t n_man, hipStream_t s);
@@ -180,12 +196,13 @@ struct ColourStarts { uint32_t s[SGP_MAX_COLOURS + 1]; };
 void launch_setup(const DV& d, uint32_t n_man, float dt, const ColourStarts& cs, hipStream_t s);
 void launch_warm_start(const DV& d, uint32_t first, uint32_t count, hipStream_t s);
 void launch_solve_velocity(const DV& d, uint32_t first, uint32_t count, hipStream_t s);
+void launch_solve_tail(const DV& d, const ColourStarts& cs, int first_colour, int end_colour, int mode, hipStream_t s);
 void launch_solve_velocity_serial(const DV& d, uint32_t first, uint32_t count, int mode, hipStream_t s);
 void launch_integrate_pose(const DV& d, float dt, hipStream_t s);
 void launch_solve_position(const DV& d, uint32_t first, uint32_t count, hipStream_t s);
 void launch_finalize(const DV& d, float dt, hipStream_t s);
 void launch_island_hook(const DV& d, uint32_t n_con, hipStream_t s);
-void launch_island_flag(const DV& d, hipStream_t s);
+void launch_island_flag(const DV& d, uint32_t n_con, hipStream_t s);
 void launch_sleep_apply(const DV& d, hipStream_t s);
 void launch_buoyancy(const DV& d, float dt, hipStream_t s);
 void launch_cache_build(const DV& d, uint32_t n_con, hipStream_t s);

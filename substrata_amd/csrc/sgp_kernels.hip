@@ -124,12 +124,57 @@ __global__ void __launch_bounds__(TPB) k_apply_forces(DV d, float dt)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// K2/K3: broad phase.  Small bodies are binned by AABB centre into cells of edge >= the largest small-body AABB
-// (+ speculative margin), so overlapping bodies always sit in adjacent cells; cells live in a hashed bucket table.
+// K2/K3: broad phase.  Small bodies are binned by AABB centre into a dense grid of cells whose edge is >= the largest
+// small-body AABB (+ speculative margin), so overlapping bodies always sit in adjacent cells.  Bodies are counting-sorted
+// into cell order together with a packed 32-byte AABB record; the pair kernel stages a 4x4x4-cell tile plus its halo in
+// LDS and tests every body of the tile against the 27 neighbouring cells out of LDS.
 
-SGP_DEV uint32_t cell_hash_fn(int x, int y, int z, uint32_t mask)
+SGP_DEV int float_to_ordered(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
+SGP_DEV float ordered_to_float(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
+
+__global__ void __launch_bounds__(TPB) k_bp_bounds(DV d)
 {
-	return (((uint32_t)x * 73856093u) ^ ((uint32_t)y * 19349663u) ^ ((uint32_t)z * 83492791u)) & mask;
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	float mnx = 3.0e38f, mny = 3.0e38f, mnz = 3.0e38f, mxx = -3.0e38f, mxy = -3.0e38f, mxz = -3.0e38f;
+	if (i < d.n_slots) {
+		const uint32_t f = d.flags[i];
+		if ((f & BF_ALIVE) && !(f & BF_LARGE)) {
+			const float4 mn = d.aabb_min[i], mx = d.aabb_max[i];
+			mnx = mxx = (mn.x + mx.x) * 0.5f; mny = mxy = (mn.y + mx.y) * 0.5f; mnz = mxz = (mn.z + mx.z) * 0.5f;
+		}
+	}
+	for (int off = 32; off > 0; off >>= 1) {
+		mnx = fminf(mnx, __shfl_down(mnx, off, 64)); mny = fminf(mny, __shfl_down(mny, off, 64)); mnz = fminf(mnz, __shfl_down(mnz, off, 64));
+		mxx = fmaxf(mxx, __shfl_down(mxx, off, 64)); mxy = fmaxf(mxy, __shfl_down(mxy, off, 64)); mxz = fmaxf(mxz, __shfl_down(mxz, off, 64));
+	}
+	if ((threadIdx.x & 63) == 0 && mnx <= mxx) {
+		atomicMin(&d.grid->min_x, float_to_ordered(mnx)); atomicMin(&d.grid->min_y, float_to_ordered(mny)); atomicMin(&d.grid->min_z, float_to_ordered(mnz));
+		atomicMax(&d.grid->max_x, float_to_ordered(mxx)); atomicMax(&d.grid->max_y, float_to_ordered(mxy)); atomicMax(&d.grid->max_z, float_to_ordered(mxz));
+	}
+}
+
+// one thread: grid origin / dims; the cell edge grows until the dense table fits
+__global__ void k_bp_grid_params(DV d)
+{
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	BpGrid g = *d.grid;
+	float cell = d.cell_size;
+	if (g.min_x > g.max_x) { g.ox = g.oy = g.oz = 0.0f; g.nx = g.ny = g.nz = 1; }
+	else {
+		const float x0 = ordered_to_float(g.min_x), y0 = ordered_to_float(g.min_y), z0 = ordered_to_float(g.min_z);
+		const float x1 = ordered_to_float(g.max_x), y1 = ordered_to_float(g.max_y), z1 = ordered_to_float(g.max_z);
+		for (int it = 0; it < 64; ++it) {
+			const float inv = 1.0f / cell;
+			const float fx = floorf((x1 - x0) * inv) + 1.0f, fy = floorf((y1 - y0) * inv) + 1.0f, fz = floorf((z1 - z0) * inv) + 1.0f;
+			if (fx * fy * fz <= (float)d.table_size && fx < 2.0e9f && fy < 2.0e9f && fz < 2.0e9f) { g.nx = (int)fx; g.ny = (int)fy; g.nz = (int)fz; break; }
+			cell = cell * 1.5f;
+			g.nx = g.ny = g.nz = 1;
+		}
+		g.ox = x0; g.oy = y0; g.oz = z0;
+	}
+	g.cell = cell; g.inv_cell = 1.0f / cell;
+	g.n_cells = (uint32_t)g.nx * (uint32_t)g.ny * (uint32_t)g.nz;
+	*d.grid = g;
 }
 
 __global__ void __launch_bounds__(TPB) k_bp_cell(DV d)
@@ -140,12 +185,12 @@ __global__ void __launch_bounds__(TPB) k_bp_cell(DV d)
 	uint32_t h = 0xFFFFFFFFu;
 	if ((f & BF_ALIVE) && !(f & BF_LARGE)) {
 		const float4 mn = d.aabb_min[i], mx = d.aabb_max[i];
-		const float inv = 1.0f / d.cell_size;
-		const int cx = (int)floorf((mn.x + mx.x) * 0.5f * inv);
-		const int cy = (int)floorf((mn.y + mx.y) * 0.5f * inv);
-		const int cz = (int)floorf((mn.z + mx.z) * 0.5f * inv);
-		h = cell_hash_fn(cx, cy, cz, d.table_size - 1);
-		d.cell_xyz[i] = make_int4(cx, cy, cz, 0);
+		const BpGrid& g = *d.grid;
+		int cx = (int)floorf(((mn.x + mx.x) * 0.5f - g.ox) * g.inv_cell);
+		int cy = (int)floorf(((mn.y + mx.y) * 0.5f - g.oy) * g.inv_cell);
+		int cz = (int)floorf(((mn.z + mx.z) * 0.5f - g.oz) * g.inv_cell);
+		cx = min(max(cx, 0), g.nx - 1); cy = min(max(cy, 0), g.ny - 1); cz = min(max(cz, 0), g.nz - 1);
+		h = ((uint32_t)cz * (uint32_t)g.ny + (uint32_t)cy) * (uint32_t)g.nx + (uint32_t)cx;
 		atomicAdd(&d.cell_count[h], 1u);
 	}
 	d.cell_hash[i] = h;
@@ -215,7 +260,9 @@ __global__ void __launch_bounds__(TPB) k_bp_scatter(DV d)
 	const uint32_t h = d.cell_hash[i];
 	if (h == 0xFFFFFFFFu) return;
 	const uint32_t slot = d.cell_start[h] + atomicAdd(&d.cell_fill[h], 1u);
-	d.sorted_ids[slot] = i;
+	const float4 mn = d.aabb_min[i], mx = d.aabb_max[i];
+	d.sorted_min[slot] = make_float4(mn.x, mn.y, mn.z, __uint_as_float(d.flags[i]));
+	d.sorted_max[slot] = make_float4(mx.x, mx.y, mx.z, __uint_as_float(i));
 }
 
 SGP_DEV bool pair_passes(const DV& d, uint32_t fi, float4 mni, float4 mxi, uint32_t j)
@@ -232,6 +279,18 @@ SGP_DEV bool pair_passes(const DV& d, uint32_t fi, float4 mni, float4 mxi, uint3
 	return true;
 }
 
+// same predicate on two packed records (w of min = flags, w of max = id)
+SGP_DEV bool rec_pair_passes(float spec, float4 mni, float4 mxi, float4 mnj, float4 mxj)
+{
+	const uint32_t fi = __float_as_uint(mni.w), fj = __float_as_uint(mnj.w);
+	if (f_motion(fi) != SGP_MOTION_DYNAMIC && f_motion(fj) != SGP_MOTION_DYNAMIC) return false;
+	if (!layers_collide(f_layer(fi), f_layer(fj))) return false;
+	if (mni.x - spec > mxj.x || mnj.x - spec > mxi.x) return false;
+	if (mni.y - spec > mxj.y || mnj.y - spec > mxi.y) return false;
+	if (mni.z - spec > mxj.z || mnj.z - spec > mxi.z) return false;
+	return true;
+}
+
 SGP_DEV void push_pair(const DV& d, uint32_t i, uint32_t j)
 {
 	const uint32_t k = atomicAdd(&d.ctr->n_pairs, 1u);
@@ -239,28 +298,161 @@ SGP_DEV void push_pair(const DV& d, uint32_t i, uint32_t j)
 	else atomicAdd(&d.ctr->pairs_dropped, 1u);
 }
 
-// one thread per ACTIVE small body: scan the 27 neighbouring cells
+// pair staged in LDS (falls back to the global list when the tile's buffer is full)
+SGP_DEV void stage_pair(const DV& d, uint2* spairs, uint32_t* lcount, uint32_t i, uint32_t j);
+
+#define BP_TILE 4
+#define BP_H 2
+#define BP_HALO (BP_TILE + 2 * BP_H)
+#define BP_HALO_CELLS (BP_HALO * BP_HALO * BP_HALO)
+#define BP_INNER_CELLS (BP_TILE * BP_TILE * BP_TILE)
+#define BP_LDS_CAP 1536
+#define BP_PAIR_CAP 2048
+
+SGP_DEV void stage_pair(const DV& d, uint2* spairs, uint32_t* lcount, uint32_t i, uint32_t j)
+{
+	const uint32_t k = atomicAdd(lcount, 1u);
+	if (k < BP_PAIR_CAP) spairs[k] = make_uint2(i < j ? i : j, i < j ? j : i);
+	else push_pair(d, i, j);
+}
+
+// exclusive scan of n <= 2*TPB values held in LDS (in place), result total returned to every thread
+SGP_DEV uint32_t block_scan_512(uint32_t* a, int n, uint32_t* wave_tot)
+{
+	const int t = threadIdx.x;
+	const uint32_t v0 = (2 * t < n) ? a[2 * t] : 0u, v1 = (2 * t + 1 < n) ? a[2 * t + 1] : 0u;
+	uint32_t x = v0 + v1;
+	const int lane = t & 63, wave = t >> 6;
+	for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off, 64); if (lane >= off) x += y; }
+	if (lane == 63) wave_tot[wave] = x;
+	__syncthreads();
+	uint32_t base = 0, total = 0;
+	for (int k = 0; k < TPB / 64; ++k) { if (k < wave) base += wave_tot[k]; total += wave_tot[k]; }
+	const uint32_t excl = base + x - (v0 + v1);
+	__syncthreads();
+	if (2 * t < n) a[2 * t] = excl;
+	if (2 * t + 1 < n) a[2 * t + 1] = excl + v0;
+	__syncthreads();
+	return total;
+}
+
+// One workgroup per 4x4x4-cell tile.  Cell edge = R_max + margin (R_max = largest small-body bounding radius), so any
+// partner of a body has its centre within 2 cells of the body's own AABB: the tile plus a 2-cell halo (8x8x8 cells = 64
+// contiguous runs of the cell-sorted records) is staged in LDS and every active body of the tile scans only the cells its
+// own AABB (+- R_max + margin) reaches.  A pair is emitted once: by the lower id when both are active, else by the active one.
 __global__ void __launch_bounds__(TPB) k_bp_pairs(DV d)
 {
-	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-	if (i >= d.n_slots) return;
-	const uint32_t fi = d.flags[i];
-	if (!f_active_for_pairs(fi) || (fi & BF_LARGE)) return;
-	const int4 c = d.cell_xyz[i];
-	const float4 mni = d.aabb_min[i], mxi = d.aabb_max[i];
-	const uint32_t mask = d.table_size - 1;
-	for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
-		const int nx = c.x + dx, ny = c.y + dy, nz = c.z + dz;
-		const uint32_t h = cell_hash_fn(nx, ny, nz, mask);
-		const uint32_t b = d.cell_start[h], e = d.cell_start[h + 1];
-		for (uint32_t p = b; p < e; ++p) {
-			const uint32_t j = d.sorted_ids[p];
-			if (j == i) continue;
-			const int4 cj = d.cell_xyz[j];
-			if (cj.x != nx || cj.y != ny || cj.z != nz) continue;     // bucket collision / duplicate bucket
-			// emitted once: by the lower id if both bodies scan, else by the scanning (active) one
-			if (f_active_for_pairs(d.flags[j]) && j < i) continue;
-			if (pair_passes(d, fi, mni, mxi, j)) push_pair(d, i, j);
+	__shared__ float4 smin[BP_LDS_CAP];
+	__shared__ float4 smax[BP_LDS_CAP];
+	__shared__ uint32_t cstart[BP_HALO_CELLS + 1];
+	__shared__ uint32_t gstart[BP_HALO_CELLS];
+	__shared__ uint32_t istart[BP_INNER_CELLS + 1];
+	__shared__ uint32_t wave_tot[TPB / 64];
+	__shared__ uint2 spairs[BP_PAIR_CAP];
+	__shared__ uint32_t lcount, gbase;
+	const BpGrid g = *d.grid;
+	const int tnx = (g.nx + BP_TILE - 1) / BP_TILE, tny = (g.ny + BP_TILE - 1) / BP_TILE, tnz = (g.nz + BP_TILE - 1) / BP_TILE;
+	const uint32_t n_tiles = (uint32_t)tnx * (uint32_t)tny * (uint32_t)tnz;
+	const float spec = d.st.speculative_contact_distance;
+	const float reach = d.bp_rmax + spec;
+	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		const int tx = (int)(tile % (uint32_t)tnx), ty = (int)((tile / (uint32_t)tnx) % (uint32_t)tny), tz = (int)(tile / ((uint32_t)tnx * (uint32_t)tny));
+		const int x0 = tx * BP_TILE - BP_H, y0 = ty * BP_TILE - BP_H, z0 = tz * BP_TILE - BP_H;   // halo origin (cell coords)
+		__syncthreads();
+		// the tile's own cells first: an empty tile is skipped without touching the halo
+		if (threadIdx.x < BP_INNER_CELLS) {
+			const int ix = threadIdx.x % BP_TILE, iy = (threadIdx.x / BP_TILE) % BP_TILE, iz = threadIdx.x / (BP_TILE * BP_TILE);
+			const int x = tx * BP_TILE + ix, y = ty * BP_TILE + iy, z = tz * BP_TILE + iz;
+			uint32_t cnt = 0;
+			if (x < g.nx && y < g.ny && z < g.nz) {
+				const uint32_t lin = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx + (uint32_t)x;
+				cnt = d.cell_start[lin + 1] - d.cell_start[lin];
+			}
+			istart[threadIdx.x] = cnt;
+		}
+		__syncthreads();
+		const uint32_t n_inner = block_scan_512(istart, BP_INNER_CELLS, wave_tot);
+		if (threadIdx.x == 0) istart[BP_INNER_CELLS] = n_inner;
+		if (threadIdx.x == 0) lcount = 0;
+		if (n_inner == 0) continue;
+		// per halo cell: global start and count
+		for (int c = threadIdx.x; c < BP_HALO_CELLS; c += TPB) {
+			const int hx = c % BP_HALO, hy = (c / BP_HALO) % BP_HALO, hz = c / (BP_HALO * BP_HALO);
+			const int x = x0 + hx, y = y0 + hy, z = z0 + hz;
+			uint32_t b = 0, cnt = 0;
+			if (x >= 0 && x < g.nx && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
+				const uint32_t lin = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx + (uint32_t)x;
+				b = d.cell_start[lin]; cnt = d.cell_start[lin + 1] - b;
+			}
+			gstart[c] = b;
+			cstart[c] = cnt;
+		}
+		__syncthreads();
+		const uint32_t total = block_scan_512(cstart, BP_HALO_CELLS, wave_tot);
+		if (threadIdx.x == 0) cstart[BP_HALO_CELLS] = total;
+		__syncthreads();
+		const bool in_lds = total <= BP_LDS_CAP;
+		if (in_lds) {
+			for (uint32_t q = threadIdx.x; q < total; q += TPB) {
+				int lo = 0, hi = BP_HALO_CELLS - 1;
+				while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (cstart[mid] <= q) lo = mid; else hi = mid - 1; }
+				const uint32_t src = gstart[lo] + (q - cstart[lo]);
+				smin[q] = d.sorted_min[src]; smax[q] = d.sorted_max[src];
+			}
+		}
+		__syncthreads();
+		for (uint32_t t = threadIdx.x; t < n_inner; t += TPB) {
+			int lo = 0, hi = BP_INNER_CELLS - 1;
+			while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (istart[mid] <= t) lo = mid; else hi = mid - 1; }
+			const int ic = lo;
+			const uint32_t k = t - istart[ic];
+			const int ix = ic % BP_TILE, iy = (ic / BP_TILE) % BP_TILE, iz = ic / (BP_TILE * BP_TILE);
+			const int hc = ((iz + BP_H) * BP_HALO + (iy + BP_H)) * BP_HALO + (ix + BP_H);
+			const float4 mni = in_lds ? smin[cstart[hc] + k] : d.sorted_min[gstart[hc] + k];
+			const float4 mxi = in_lds ? smax[cstart[hc] + k] : d.sorted_max[gstart[hc] + k];
+			const uint32_t fi = __float_as_uint(mni.w), i = __float_as_uint(mxi.w);
+			if (!f_active_for_pairs(fi)) continue;
+			// cells (halo-local) whose bodies can touch this one
+			int xl = (int)floorf((mni.x - reach - g.ox) * g.inv_cell) - x0, xh = (int)floorf((mxi.x + reach - g.ox) * g.inv_cell) - x0;
+			int yl = (int)floorf((mni.y - reach - g.oy) * g.inv_cell) - y0, yh = (int)floorf((mxi.y + reach - g.oy) * g.inv_cell) - y0;
+			int zl = (int)floorf((mni.z - reach - g.oz) * g.inv_cell) - z0, zh = (int)floorf((mxi.z + reach - g.oz) * g.inv_cell) - z0;
+			// a body clamped into a border cell of the grid keeps scanning its full halo box
+			xl = min(max(xl, 0), ix + BP_H); xh = max(min(xh, BP_HALO - 1), ix + BP_H);
+			yl = min(max(yl, 0), iy + BP_H); yh = max(min(yh, BP_HALO - 1), iy + BP_H);
+			zl = min(max(zl, 0), iz + BP_H); zh = max(min(zh, BP_HALO - 1), iz + BP_H);
+			for (int hz = zl; hz <= zh; ++hz) for (int hy = yl; hy <= yh; ++hy) {
+				const int rb = (hz * BP_HALO + hy) * BP_HALO;
+				if (in_lds) {
+					const uint32_t q0 = cstart[rb + xl], q1 = cstart[rb + xh + 1];
+					for (uint32_t q = q0; q < q1; ++q) {
+						const float4 mnj = smin[q], mxj = smax[q];
+						const uint32_t j = __float_as_uint(mxj.w);
+						if (j == i) continue;
+						if (f_active_for_pairs(__float_as_uint(mnj.w)) && j < i) continue;
+						if (rec_pair_passes(spec, mni, mxi, mnj, mxj)) stage_pair(d, spairs, &lcount, i, j);
+					}
+				} else {
+					for (int c = xl; c <= xh; ++c) {
+						const uint32_t gb = gstart[rb + c], gn = cstart[rb + c + 1] - cstart[rb + c];
+						for (uint32_t q = 0; q < gn; ++q) {
+							const float4 mnj = d.sorted_min[gb + q], mxj = d.sorted_max[gb + q];
+							const uint32_t j = __float_as_uint(mxj.w);
+							if (j == i) continue;
+							if (f_active_for_pairs(__float_as_uint(mnj.w)) && j < i) continue;
+							if (rec_pair_passes(spec, mni, mxi, mnj, mxj)) stage_pair(d, spairs, &lcount, i, j);
+						}
+					}
+				}
+			}
+		}
+		// flush the staged pairs: one global atomic per tile, coalesced stores
+		__syncthreads();
+		const uint32_t n_out = min(lcount, (uint32_t)BP_PAIR_CAP);
+		if (threadIdx.x == 0 && n_out) gbase = atomicAdd(&d.ctr->n_pairs, n_out);
+		__syncthreads();
+		for (uint32_t k = threadIdx.x; k < n_out; k += TPB) {
+			if (gbase + k < d.cap_pairs) d.pairs[gbase + k] = spairs[k];
+			else atomicAdd(&d.ctr->pairs_dropped, 1u);
 		}
 	}
 }
@@ -339,6 +531,29 @@ __global__ void __launch_bounds__(TPB) k_wake(DV d)
 	reset_sleep(d, i, f_shape(f), d.shape[i], V3(d.pos_im[i]), Q4(d.rot[i]));
 }
 
+// Per-step solver record of every body (64 B = one cache line): velocities, the EFFECTIVE inverse mass (0 unless the body
+// is dynamic and awake) and the world-space inverse inertia.  The velocity-phase kernels gather ONE line per body instead
+// of six arrays; velocities stay in this record until k_integrate_pose writes them back.
+__global__ void __launch_bounds__(TPB) k_prep_bodies(DV d)
+{
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i >= d.n_slots) return;
+	const uint32_t f = d.flags[i];
+	float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f), w = v, a = v, b = v;
+	if ((f & BF_ALIVE) && f_motion(f) != SGP_MOTION_STATIC) {
+		const float4 lv = d.linv[i], av = d.angv[i];
+		v = make_float4(lv.x, lv.y, lv.z, 0.0f);
+		w = make_float4(av.x, av.y, av.z, 0.0f);
+		if (f_movable(f)) {
+			const sym33 I = world_inv_inertia(quat_to_m33(Q4(d.rot[i])), V3(d.inv_inertia[i]));
+			v.w = d.pos_im[i].w;
+			a = make_float4(I.xx, I.xy, I.xz, 0.0f);
+			b = make_float4(I.yy, I.yz, I.zz, 0.0f);
+		}
+	}
+	d.sbody[4 * i + 0] = v; d.sbody[4 * i + 1] = w; d.sbody[4 * i + 2] = a; d.sbody[4 * i + 3] = b;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // K6: deterministic round-based greedy colouring.  priority = mix64(pair key); per round each uncoloured manifold
 // claims its movable bodies with atomicMin; the manifold that holds both claims takes the lowest colour free on
@@ -362,6 +577,7 @@ __global__ void __launch_bounds__(TPB) k_colour_commit(DV d, uint32_t round)
 	const uint32_t n = min(d.ctr->n_manifolds, d.cap_manifolds);
 	const uint64_t* claim = d.claim[round & 1];
 	uint64_t* next = d.claim[(round & 1) ^ 1];
+	uint32_t won = 0;
 	for (uint32_t m = blockIdx.x * TPB + threadIdx.x; m < n; m += gridDim.x * TPB) {
 		if (d.man_colour[m] != -1) continue;
 		const uint2 ab = d.man_ab[m];
@@ -377,11 +593,14 @@ __global__ void __launch_bounds__(TPB) k_colour_commit(DV d, uint32_t round)
 				if (ma) d.colour_mask[ab.x] = d.colour_mask[ab.x] | (1ull << col);
 				if (mb) d.colour_mask[ab.y] = d.colour_mask[ab.y] | (1ull << col);
 			}
-			atomicSub(&d.ctr->n_uncoloured, 1u);
+			++won;
 		}
 		next[ab.x] = ~0ull;
 		next[ab.y] = ~0ull;
 	}
+	// one atomic per wave
+	for (int off = 32; off > 0; off >>= 1) won += __shfl_down(won, off, 64);
+	if ((threadIdx.x & 63) == 0 && won) atomicSub(&d.ctr->n_uncoloured, won);
 }
 
 __global__ void __launch_bounds__(TPB) k_colour_init(DV d)
@@ -390,19 +609,27 @@ __global__ void __launch_bounds__(TPB) k_colour_init(DV d)
 	const uint32_t n = min(d.ctr->n_manifolds, d.cap_manifolds);
 	uint32_t cnt = 0;
 	for (uint32_t m = blockIdx.x * TPB + threadIdx.x; m < n; m += gridDim.x * TPB) if (d.man_colour[m] == -1) ++cnt;
-	if (cnt) atomicAdd(&d.ctr->n_uncoloured, cnt);
+	for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+	if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&d.ctr->n_uncoloured, cnt);
 }
 
 __global__ void __launch_bounds__(TPB) k_colour_count(DV d)
 {
+	__shared__ uint32_t hist[SGP_MAX_COLOURS + 2];
+	if (threadIdx.x < SGP_MAX_COLOURS + 2) hist[threadIdx.x] = 0;
+	__syncthreads();
 	const uint32_t n = min(d.ctr->n_manifolds, d.cap_manifolds);
 	for (uint32_t m = blockIdx.x * TPB + threadIdx.x; m < n; m += gridDim.x * TPB) {
 		const int c = d.man_colour[m];
 		if (c < 0) continue;
-		atomicAdd(&d.ctr->colour_count[c], 1u);
-		atomicAdd(&d.ctr->n_points, (uint32_t)__float_as_int(d.man_n[m].w));
-		atomicAdd(&d.ctr->n_constraints, 1u);
+		atomicAdd(&hist[c], 1u);
+		atomicAdd(&hist[SGP_MAX_COLOURS], (uint32_t)__float_as_int(d.man_n[m].w));
+		atomicAdd(&hist[SGP_MAX_COLOURS + 1], 1u);
 	}
+	__syncthreads();
+	if (threadIdx.x < SGP_MAX_COLOURS) { if (hist[threadIdx.x]) atomicAdd(&d.ctr->colour_count[threadIdx.x], hist[threadIdx.x]); }
+	else if (threadIdx.x == SGP_MAX_COLOURS) { if (hist[SGP_MAX_COLOURS]) atomicAdd(&d.ctr->n_points, hist[SGP_MAX_COLOURS]); }
+	else if (threadIdx.x == SGP_MAX_COLOURS + 1) { if (hist[SGP_MAX_COLOURS + 1]) atomicAdd(&d.ctr->n_constraints, hist[SGP_MAX_COLOURS + 1]); }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -435,31 +662,40 @@ SGP_DEV uint32_t cache_find(const DV& d, uint64_t key)
 
 __global__ void __launch_bounds__(TPB) k_setup(DV d, ColourStarts cs, float dt)
 {
+	__shared__ uint32_t hist[SGP_MAX_COLOURS];
+	__shared__ uint32_t base[SGP_MAX_COLOURS];
 	const uint32_t n = min(d.ctr->n_manifolds, d.cap_manifolds);
-	for (uint32_t m = blockIdx.x * TPB + threadIdx.x; m < n; m += gridDim.x * TPB) {
-		const int col = d.man_colour[m];
+	for (uint32_t m0 = blockIdx.x * TPB; m0 < n; m0 += gridDim.x * TPB) {
+		const uint32_t m = m0 + threadIdx.x;
+		// slot allocation: one global atomic per (block, colour) instead of one per manifold
+		if (threadIdx.x < SGP_MAX_COLOURS) hist[threadIdx.x] = 0;
+		__syncthreads();
+		const int col = m < n ? d.man_colour[m] : -1;
+		uint32_t rank = 0;
+		if (col >= 0) rank = atomicAdd(&hist[col], 1u);
+		__syncthreads();
+		if (threadIdx.x < SGP_MAX_COLOURS && hist[threadIdx.x]) base[threadIdx.x] = atomicAdd(&d.ctr->colour_fill[threadIdx.x], hist[threadIdx.x]);
+		__syncthreads();
 		if (col < 0) continue;
-		const uint32_t slot = cs.s[col] + atomicAdd(&d.ctr->colour_fill[col], 1u);
+		const uint32_t slot = cs.s[col] + base[col] + rank;
 		const uint2 ab = d.man_ab[m];
 		const uint64_t key = ((uint64_t)ab.x << 32) | ab.y;
 		const float4 n4 = d.man_n[m];
 		const int np = __float_as_int(n4.w);
 		const v3 nrm = V3(n4);
-		const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
-		const float4 pa4 = d.pos_im[ab.x], pb4 = d.pos_im[ab.y];
-		const v3 posA = V3(pa4), posB = V3(pb4);
+		const v3 posA = V3(d.pos_im[ab.x]), posB = V3(d.pos_im[ab.y]);
 		const m33 RA = quat_to_m33(Q4(d.rot[ab.x])), RB = quat_to_m33(Q4(d.rot[ab.y]));
-		const float4 iiA = d.inv_inertia[ab.x], iiB = d.inv_inertia[ab.y];
-		const float4 shA = d.shape[ab.x], shB = d.shape[ab.y];
-		const float im1 = f_movable(fa) ? pa4.w : 0.0f, im2 = f_movable(fb) ? pb4.w : 0.0f;
-		sym33 I1 = sym33_zero(), I2 = sym33_zero();
-		if (im1 > 0.0f) I1 = world_inv_inertia(RA, V3(iiA));
-		if (im2 > 0.0f) I2 = world_inv_inertia(RB, V3(iiB));
-		const float friction = sqrtf(shA.w * shB.w);
-		const float restitution = fmaxf(iiA.w, iiB.w);
+		const float4 va4 = d.sbody[4 * ab.x], wa4 = d.sbody[4 * ab.x + 1], sa0 = d.sbody[4 * ab.x + 2], sa1 = d.sbody[4 * ab.x + 3];
+		const float4 vb4 = d.sbody[4 * ab.y], wb4 = d.sbody[4 * ab.y + 1], sb0 = d.sbody[4 * ab.y + 2], sb1 = d.sbody[4 * ab.y + 3];
+		const float im1 = va4.w, im2 = vb4.w;
+		sym33 I1, I2;
+		I1.xx = sa0.x; I1.xy = sa0.y; I1.xz = sa0.z; I1.yy = sa1.x; I1.yz = sa1.y; I1.zz = sa1.z;
+		I2.xx = sb0.x; I2.xy = sb0.y; I2.xz = sb0.z; I2.yy = sb1.x; I2.yz = sb1.y; I2.zz = sb1.z;
+		const float friction = sqrtf(d.shape[ab.x].w * d.shape[ab.y].w);
+		const float restitution = fmaxf(d.inv_inertia[ab.x].w, d.inv_inertia[ab.y].w);
 		const v3 t1 = v3_normalized_perpendicular(nrm);
 		const v3 t2 = v3_cross(nrm, t1);
-		const v3 lvA = V3(d.linv[ab.x]), avA = V3(d.angv[ab.x]), lvB = V3(d.linv[ab.y]), avB = V3(d.angv[ab.y]);
+		const v3 lvA = V3(va4), avA = V3(wa4), lvB = V3(vb4), avB = V3(wb4);
 		const float gfA = d.force[ab.x].w, gfB = d.force[ab.y].w;
 		const uint32_t fslot = cache_find(d, key);
 		const uint32_t pslot = d.st.warm_start ? fslot : 0xFFFFFFFFu;
@@ -519,7 +755,7 @@ __global__ void __launch_bounds__(TPB) k_setup(DV d, ColourStarts cs, float dt)
 // ---------------------------------------------------------------------------------------------------------------
 // K7: sequential impulses.  One launch per colour: constraints of a colour share no movable body.
 
-struct BodyVel { v3 lv, av; float lw, aw; };
+struct BodyVel { v3 lv, av; };
 
 SGP_DEV void apply_impulse(BodyVel& A, BodyVel& B, float im1, const sym33& I1, float im2, const sym33& I2, v3 r1, v3 r2, v3 axis, float lambda)
 {
@@ -546,21 +782,21 @@ SGP_DEV void load_pair(const DV& d, uint32_t slot, PairCtx& c)
 	const float4 nf = d.cur.n_fric[slot];
 	c.n = V3(nf); c.friction = nf.w;
 	c.np = d.cur.np_col[slot] & 0xFF;
-	const uint32_t fa = d.flags[c.ab.x], fb = d.flags[c.ab.y];
-	const float4 pa = d.pos_im[c.ab.x], pb = d.pos_im[c.ab.y];
-	c.im1 = f_movable(fa) ? pa.w : 0.0f; c.im2 = f_movable(fb) ? pb.w : 0.0f;
-	c.I1 = sym33_zero(); c.I2 = sym33_zero();
-	if (c.im1 > 0.0f) c.I1 = world_inv_inertia(quat_to_m33(Q4(d.rot[c.ab.x])), V3(d.inv_inertia[c.ab.x]));
-	if (c.im2 > 0.0f) c.I2 = world_inv_inertia(quat_to_m33(Q4(d.rot[c.ab.y])), V3(d.inv_inertia[c.ab.y]));
-	const float4 la = d.linv[c.ab.x], aa = d.angv[c.ab.x], lb = d.linv[c.ab.y], ab4 = d.angv[c.ab.y];
-	c.A.lv = V3(la); c.A.av = V3(aa); c.A.lw = la.w; c.A.aw = aa.w;
-	c.B.lv = V3(lb); c.B.av = V3(ab4); c.B.lw = lb.w; c.B.aw = ab4.w;
+	const float4* pa = d.sbody + 4 * (size_t)c.ab.x;
+	const float4* pb = d.sbody + 4 * (size_t)c.ab.y;
+	const float4 va = pa[0], wa = pa[1], a0 = pa[2], a1 = pa[3];
+	const float4 vb = pb[0], wb = pb[1], b0 = pb[2], b1 = pb[3];
+	c.im1 = va.w; c.im2 = vb.w;
+	c.I1.xx = a0.x; c.I1.xy = a0.y; c.I1.xz = a0.z; c.I1.yy = a1.x; c.I1.yz = a1.y; c.I1.zz = a1.z;
+	c.I2.xx = b0.x; c.I2.xy = b0.y; c.I2.xz = b0.z; c.I2.yy = b1.x; c.I2.yz = b1.y; c.I2.zz = b1.z;
+	c.A.lv = V3(va); c.A.av = V3(wa);
+	c.B.lv = V3(vb); c.B.av = V3(wb);
 }
 
 SGP_DEV void store_pair_vel(const DV& d, const PairCtx& c)
 {
-	if (c.im1 > 0.0f) { d.linv[c.ab.x] = F4(c.A.lv, c.A.lw); d.angv[c.ab.x] = F4(c.A.av, c.A.aw); }
-	if (c.im2 > 0.0f) { d.linv[c.ab.y] = F4(c.B.lv, c.B.lw); d.angv[c.ab.y] = F4(c.B.av, c.B.aw); }
+	if (c.im1 > 0.0f) { d.sbody[4 * (size_t)c.ab.x] = F4(c.A.lv, c.im1); d.sbody[4 * (size_t)c.ab.x + 1] = F4(c.A.av, 0.0f); }
+	if (c.im2 > 0.0f) { d.sbody[4 * (size_t)c.ab.y] = F4(c.B.lv, c.im2); d.sbody[4 * (size_t)c.ab.y + 1] = F4(c.B.av, 0.0f); }
 }
 
 SGP_DEV void warm_start_one(const DV& d, uint32_t slot)
@@ -569,58 +805,63 @@ SGP_DEV void warm_start_one(const DV& d, uint32_t slot)
 	load_pair(d, slot, c);
 	c.t1 = v3_normalized_perpendicular(c.n);
 	c.t2 = v3_cross(c.n, c.t1);
+#pragma unroll
 	for (int i = 0; i < 4; ++i) {
-		if (i >= c.np) break;
-		const v3 r1 = V3(d.cur.r1b[i][slot]), r2 = V3(d.cur.r2e[i][slot]);
-		const float4 l = d.cur.lam[i][slot];
-		if (c.friction > 0.0f) {
-			apply_impulse(c.A, c.B, c.im1, c.I1, c.im2, c.I2, r1, r2, c.t1, l.y);
-			apply_impulse(c.A, c.B, c.im1, c.I1, c.im2, c.I2, r1, r2, c.t2, l.z);
+		if (i < c.np) {
+			const v3 r1 = V3(d.cur.r1b[i][slot]), r2 = V3(d.cur.r2e[i][slot]);
+			const float4 l = d.cur.lam[i][slot];
+			if (c.friction > 0.0f) {
+				apply_impulse(c.A, c.B, c.im1, c.I1, c.im2, c.I2, r1, r2, c.t1, l.y);
+				apply_impulse(c.A, c.B, c.im1, c.I1, c.im2, c.I2, r1, r2, c.t2, l.z);
+			}
+			apply_impulse(c.A, c.B, c.im1, c.I1, c.im2, c.I2, r1, r2, c.n, l.x);
 		}
-		apply_impulse(c.A, c.B, c.im1, c.I1, c.im2, c.I2, r1, r2, c.n, l.x);
 	}
 	store_pair_vel(d, c);
 }
 
+// One contact manifold, one velocity iteration (ContactConstraintManager::SolveVelocityConstraints): friction rows of
+// every point first (they use the normal impulse of the previous iteration), then the non-penetration rows.
+// All per-point state is held in registers: loops are fully unrolled with predicates (no runtime-indexed arrays).
 SGP_DEV void solve_velocity_one(const DV& d, uint32_t slot)
 {
 	PairCtx c;
 	load_pair(d, slot, c);
+	float4 r1b[4], r2e[4], lam[4]; float2 et[4];
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		if (i < c.np) { r1b[i] = d.cur.r1b[i][slot]; r2e[i] = d.cur.r2e[i][slot]; lam[i] = d.cur.lam[i][slot]; et[i] = d.cur.efft[i][slot]; }
+	}
 	c.t1 = v3_normalized_perpendicular(c.n);
 	c.t2 = v3_cross(c.n, c.t1);
-	float4 r1b[4], r2e[4], lam[4];
-	for (int i = 0; i < 4; ++i) {
-		if (i >= c.np) break;
-		r1b[i] = d.cur.r1b[i][slot]; r2e[i] = d.cur.r2e[i][slot]; lam[i] = d.cur.lam[i][slot];
-	}
-	// friction first (uses the normal impulse of the previous iteration), then non-penetration
 	if (c.friction > 0.0f) {
+#pragma unroll
 		for (int i = 0; i < 4; ++i) {
-			if (i >= c.np) break;
-			const float2 et = d.cur.efft[i][slot];
-			if (et.x <= 0.0f && et.y <= 0.0f) continue;
-			const v3 r1 = V3(r1b[i]), r2 = V3(r2e[i]);
-			float l1 = lam[i].y + et.x * axis_jv(c.A, c.B, r1, r2, c.t1);
-			float l2 = lam[i].z + et.y * axis_jv(c.A, c.B, r1, r2, c.t2);
-			const float max_f = c.friction * lam[i].x;
-			const float tot_sq = l1 * l1 + l2 * l2;
-			if (tot_sq > max_f * max_f) { const float sc = max_f / sqrtf(tot_sq); l1 = l1 * sc; l2 = l2 * sc; }
-			apply_impulse(c.A, c.B, c.im1, c.I1, c.im2, c.I2, r1, r2, c.t1, l1 - lam[i].y); lam[i].y = l1;
-			apply_impulse(c.A, c.B, c.im1, c.I1, c.im2, c.I2, r1, r2, c.t2, l2 - lam[i].z); lam[i].z = l2;
+			if (i < c.np && !(et[i].x <= 0.0f && et[i].y <= 0.0f)) {
+				const v3 r1 = V3(r1b[i]), r2 = V3(r2e[i]);
+				float l1 = lam[i].y + et[i].x * axis_jv(c.A, c.B, r1, r2, c.t1);
+				float l2 = lam[i].z + et[i].y * axis_jv(c.A, c.B, r1, r2, c.t2);
+				const float max_f = c.friction * lam[i].x;
+				const float tot_sq = l1 * l1 + l2 * l2;
+				if (tot_sq > max_f * max_f) { const float sc = max_f / sqrtf(tot_sq); l1 = l1 * sc; l2 = l2 * sc; }
+				apply_impulse(c.A, c.B, c.im1, c.I1, c.im2, c.I2, r1, r2, c.t1, l1 - lam[i].y); lam[i].y = l1;
+				apply_impulse(c.A, c.B, c.im1, c.I1, c.im2, c.I2, r1, r2, c.t2, l2 - lam[i].z); lam[i].z = l2;
+			}
 		}
 	}
+#pragma unroll
 	for (int i = 0; i < 4; ++i) {
-		if (i >= c.np) break;
-		const float eff_n = r2e[i].w;
-		if (eff_n <= 0.0f) continue;
-		const v3 r1 = V3(r1b[i]), r2 = V3(r2e[i]);
-		const float jv = axis_jv(c.A, c.B, r1, r2, c.n);
-		const float lambda = eff_n * (jv - r1b[i].w);
-		const float nl = fmaxf(lam[i].x + lambda, 0.0f);
-		apply_impulse(c.A, c.B, c.im1, c.I1, c.im2, c.I2, r1, r2, c.n, nl - lam[i].x);
-		lam[i].x = nl;
+		if (i < c.np && r2e[i].w > 0.0f) {
+			const v3 r1 = V3(r1b[i]), r2 = V3(r2e[i]);
+			const float jv = axis_jv(c.A, c.B, r1, r2, c.n);
+			const float lambda = r2e[i].w * (jv - r1b[i].w);
+			const float nl = fmaxf(lam[i].x + lambda, 0.0f);
+			apply_impulse(c.A, c.B, c.im1, c.I1, c.im2, c.I2, r1, r2, c.n, nl - lam[i].x);
+			lam[i].x = nl;
+		}
 	}
-	for (int i = 0; i < 4; ++i) { if (i >= c.np) break; d.cur.lam[i][slot] = lam[i]; }
+#pragma unroll
+	for (int i = 0; i < 4; ++i) { if (i < c.np) d.cur.lam[i][slot] = lam[i]; }
 	store_pair_vel(d, c);
 }
 
@@ -637,8 +878,9 @@ SGP_DEV void solve_position_one(const DV& d, uint32_t slot)
 	const v3 iiA = V3(d.inv_inertia[ab.x]), iiB = V3(d.inv_inertia[ab.y]);
 	v3 posA = V3(pa), posB = V3(pb);
 	bool moved = false;
+#pragma unroll
 	for (int i = 0; i < 4; ++i) {
-		if (i >= np) break;
+		if (i >= np) continue;
 		const m33 RA = quat_to_m33(qa), RB = quat_to_m33(qb);
 		const v3 p1 = v3_add(posA, m33_mul(RA, V3(d.cur.loc1[i][slot])));
 		const v3 p2 = v3_add(posB, m33_mul(RB, V3(d.cur.loc2[i][slot])));
@@ -686,6 +928,21 @@ __global__ void __launch_bounds__(TPB) k_solve_position(DV d, uint32_t first, ui
 	if (t < count) solve_position_one(d, first + t);
 }
 
+// Tail colours (few constraints each) share ONE launch: a single 512-thread workgroup walks them in colour order with a
+// workgroup barrier in between, which orders them exactly like separate launches but costs ~1 us instead of a launch each.
+__global__ void __launch_bounds__(512) k_solve_tail(DV d, ColourStarts cs, int first_colour, int end_colour, int mode)
+{
+	for (int c = first_colour; c < end_colour; ++c) {
+		const uint32_t b = cs.s[c], e = cs.s[c + 1];
+		for (uint32_t k = b + threadIdx.x; k < e; k += 512) {
+			if (mode == 0) warm_start_one(d, k);
+			else if (mode == 1) solve_velocity_one(d, k);
+			else solve_position_one(d, k);
+		}
+		__syncthreads();
+	}
+}
+
 // Overflow colour (a body with > 63 contacts): one thread, ascending priority (Jolt's non-parallel split).
 __global__ void k_solve_serial(DV d, uint32_t first, uint32_t count, int mode)
 {
@@ -713,16 +970,16 @@ __global__ void __launch_bounds__(TPB) k_integrate_pose(DV d, float dt)
 	if (i >= d.n_slots) return;
 	const uint32_t f = d.flags[i];
 	if ((f & (BF_ALIVE | BF_ACTIVE)) != (BF_ALIVE | BF_ACTIVE) || f_motion(f) == SGP_MOTION_STATIC) return;
-	float4 lv4 = d.linv[i], av4 = d.angv[i];
-	v3 lv = V3(lv4), av = V3(av4);
+	// the solved velocities live in the solver record
+	v3 lv = V3(d.sbody[4 * (size_t)i]), av = V3(d.sbody[4 * (size_t)i + 1]);
 	if (f_motion(f) == SGP_MOTION_DYNAMIC) {
 		const float l2 = v3_len_sq(lv), ml = d.st.max_linear_velocity;
-		bool w = false;
-		if (l2 > ml * ml) { lv = v3_scale(lv, ml / sqrtf(l2)); w = true; }
+		if (l2 > ml * ml) lv = v3_scale(lv, ml / sqrtf(l2));
 		const float a2 = v3_len_sq(av), ma = d.st.max_angular_velocity;
-		if (a2 > ma * ma) { av = v3_scale(av, ma / sqrtf(a2)); w = true; }
-		if (w) { d.linv[i] = F4(lv, lv4.w); d.angv[i] = F4(av, av4.w); }
+		if (a2 > ma * ma) av = v3_scale(av, ma / sqrtf(a2));
 	}
+	d.linv[i] = F4(lv, d.linv[i].w);
+	d.angv[i] = F4(av, d.angv[i].w);
 	const float4 p = d.pos_im[i];
 	const v3 np = v3_add(V3(p), v3_scale(lv, dt));
 	const quat q = quat_add_rotation_step(Q4(d.rot[i]), v3_scale(av, dt));
@@ -792,13 +1049,18 @@ SGP_DEV uint32_t uf_find(const uint32_t* parent, uint32_t x)
 	return x;
 }
 
-// union by smaller root id (ECL-CC style hooking): the final root of a component is its smallest body id
+// Island sleeping without building every island: an island sleeps iff all its members pass the sleep test.  Only
+// bodies that pass it ("sleepy") are united (union by smaller root id, ECL-CC style hooking); a sleepy component is kept
+// awake iff one of its members touches a movable body that failed the test.  Same result as uniting whole islands, but
+// an active pile (few sleepy bodies) does almost no union work.
 __global__ void __launch_bounds__(TPB) k_island_hook(DV d, uint32_t n_con)
 {
 	const uint32_t k = blockIdx.x * TPB + threadIdx.x;
 	if (k >= n_con) return;
 	const uint2 ab = d.cur.ab[k];
-	if (!f_movable(d.flags[ab.x]) || !f_movable(d.flags[ab.y])) return;
+	const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
+	if (!f_movable(fa) || !f_movable(fb)) return;
+	if (!(fa & BF_CAN_SLEEP) || !(fb & BF_CAN_SLEEP)) return;
 	uint32_t ra = uf_find(d.island, ab.x), rb = uf_find(d.island, ab.y);
 	while (ra != rb) {
 		const uint32_t hi = ra > rb ? ra : rb, lo = ra > rb ? rb : ra;
@@ -808,13 +1070,16 @@ __global__ void __launch_bounds__(TPB) k_island_hook(DV d, uint32_t n_con)
 	}
 }
 
-__global__ void __launch_bounds__(TPB) k_island_flag(DV d)
+__global__ void __launch_bounds__(TPB) k_island_flag(DV d, uint32_t n_con)
 {
-	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-	if (i >= d.n_slots) return;
-	const uint32_t f = d.flags[i];
-	if (!f_movable(f)) return;
-	if (!(f & BF_CAN_SLEEP)) d.island_awake[uf_find(d.island, i)] = 1;
+	const uint32_t k = blockIdx.x * TPB + threadIdx.x;
+	if (k >= n_con) return;
+	const uint2 ab = d.cur.ab[k];
+	const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
+	if (!f_movable(fa) || !f_movable(fb)) return;
+	const bool sa = fa & BF_CAN_SLEEP, sb = fb & BF_CAN_SLEEP;
+	if (sa == sb) return;
+	d.island_awake[uf_find(d.island, sa ? ab.x : ab.y)] = 1;
 }
 
 __global__ void __launch_bounds__(TPB) k_sleep_apply(DV d)
@@ -824,7 +1089,7 @@ __global__ void __launch_bounds__(TPB) k_sleep_apply(DV d)
 	uint32_t f = d.flags[i];
 	if (!(f & BF_ALIVE)) return;
 	if (f_movable(f)) {
-		if (d.island_awake[uf_find(d.island, i)] == 0) {
+		if ((f & BF_CAN_SLEEP) && d.island_awake[uf_find(d.island, i)] == 0) {
 			f &= ~(BF_ACTIVE | BF_CAN_SLEEP);
 			d.flags[i] = f;
 			d.linv[i] = make_float4(0.0f, 0.0f, 0.0f, d.linv[i].w);
@@ -1325,6 +1590,11 @@ static inline uint32_t blocks_for(uint32_t n) { return n ? (n + TPB - 1) / TPB :
 static inline uint32_t stride_grid(uint32_t estimate) { uint32_t b = blocks_for(estimate); if (b < 64) b = 64; if (b > 4096) b = 4096; return b; }
 
 void launch_apply_forces(const DV& d, float dt, hipStream_t s) { hipLaunchKernelGGL(k_apply_forces, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d, dt); }
+void launch_bp_bounds(const DV& d, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_bp_bounds, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d);
+	hipLaunchKernelGGL(k_bp_grid_params, dim3(1), dim3(64), 0, s, d);
+}
 void launch_bp_cell(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_bp_cell, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d); }
 void launch_bp_scan(const DV& d, hipStream_t s)
 {
@@ -1335,10 +1605,11 @@ void launch_bp_scan(const DV& d, hipStream_t s)
 	hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(TPB), 0, s, d.cell_start, d.scan_block_sums, n);
 }
 void launch_bp_scatter(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_bp_scatter, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d); }
-void launch_bp_pairs(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_bp_pairs, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d); }
+void launch_bp_pairs(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_bp_pairs, dim3(4096), dim3(TPB), 0, s, d); }
 void launch_bp_large(const DV& d, hipStream_t s) { if (d.n_large) hipLaunchKernelGGL(k_bp_large, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d); }
 void launch_narrowphase(const DV& d, uint32_t est, hipStream_t s) { hipLaunchKernelGGL(k_narrowphase, dim3(stride_grid(est)), dim3(TPB), 0, s, d); }
 void launch_wake(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_wake, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d); }
+void launch_prep_bodies(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_prep_bodies, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d); }
 void launch_colour_claim(const DV& d, uint32_t est, uint32_t round, hipStream_t s)
 {
 	if (round == 0) hipLaunchKernelGGL(k_colour_init, dim3(stride_grid(est)), dim3(TPB), 0, s, d);
@@ -1352,12 +1623,13 @@ void launch_setup(const DV& d, uint32_t n_man, float dt, const ColourStarts& cs,
 }
 void launch_warm_start(const DV& d, uint32_t first, uint32_t count, hipStream_t s) { if (count) hipLaunchKernelGGL(k_warm_start, dim3(blocks_for(count)), dim3(TPB), 0, s, d, first, count); }
 void launch_solve_velocity(const DV& d, uint32_t first, uint32_t count, hipStream_t s) { if (count) hipLaunchKernelGGL(k_solve_velocity, dim3(blocks_for(count)), dim3(TPB), 0, s, d, first, count); }
+void launch_solve_tail(const DV& d, const ColourStarts& cs, int first_colour, int end_colour, int mode, hipStream_t s) { if (end_colour > first_colour) hipLaunchKernelGGL(k_solve_tail, dim3(1), dim3(512), 0, s, d, cs, first_colour, end_colour, mode); }
 void launch_solve_velocity_serial(const DV& d, uint32_t first, uint32_t count, int mode, hipStream_t s) { if (count) hipLaunchKernelGGL(k_solve_serial, dim3(1), dim3(64), 0, s, d, first, count, mode); }
 void launch_integrate_pose(const DV& d, float dt, hipStream_t s) { hipLaunchKernelGGL(k_integrate_pose, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d, dt); }
 void launch_solve_position(const DV& d, uint32_t first, uint32_t count, hipStream_t s) { if (count) hipLaunchKernelGGL(k_solve_position, dim3(blocks_for(count)), dim3(TPB), 0, s, d, first, count); }
 void launch_finalize(const DV& d, float dt, hipStream_t s) { hipLaunchKernelGGL(k_finalize, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d, dt); }
 void launch_island_hook(const DV& d, uint32_t n_con, hipStream_t s) { if (n_con) hipLaunchKernelGGL(k_island_hook, dim3(blocks_for(n_con)), dim3(TPB), 0, s, d, n_con); }
-void launch_island_flag(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_island_flag, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d); }
+void launch_island_flag(const DV& d, uint32_t n_con, hipStream_t s) { if (n_con) hipLaunchKernelGGL(k_island_flag, dim3(blocks_for(n_con)), dim3(TPB), 0, s, d, n_con); }
 void launch_sleep_apply(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_sleep_apply, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d); }
 void launch_buoyancy(const DV& d, float dt, hipStream_t s) { hipLaunchKernelGGL(k_buoyancy, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d, dt); }
 void launch_cache_build(const DV& d, uint32_t n_con, hipStream_t s) { if (n_con) hipLaunchKernelGGL(k_cache_build, dim3(blocks_for(n_con)), dim3(TPB), 0, s, d, n_con); }

@@ -35,7 +35,7 @@ static const char* k_class_names[KC_COUNT] = {
 	"apply_forces", "bp_cell", "bp_scan", "bp_scatter", "bp_pairs", "bp_large", "narrowphase", "wake",
 	"colour_claim", "colour_commit", "colour_count", "setup", "warm_start", "solve_velocity",
 	"integrate_pose", "solve_position", "finalize", "island_hook", "island_flag", "sleep_apply", "buoyancy",
-	"cache_build", "misc", "edit", "gather" };
+	"cache_build", "misc", "edit", "gather", "prep_bodies" };
 
 // ---------------------------------------------------------------------------------------------------------------
 
@@ -68,7 +68,7 @@ struct sgp_world {
 	// staging
 	void* stage_dev = nullptr; size_t stage_dev_bytes = 0;
 	void* stage_host = nullptr; size_t stage_host_bytes = 0;
-	StepCounters* h_ctr = nullptr; EventCounters* h_evc = nullptr;
+	StepCounters* h_ctr = nullptr; EventCounters* h_evc = nullptr; BpGrid* h_grid = nullptr;
 	// events collected on the host until drained
 	std::vector<sgp_body_event> ev_act, ev_deact, ev_water;
 	std::vector<sgp_contact_event> ev_added, ev_pers;
@@ -230,10 +230,11 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	DEV_ALLOC(d.sleep_timer, N); DEV_ALLOC(d.submerged, N);
 	DEV_ALLOC(d.colour_mask, N); DEV_ALLOC(d.claim[0], N); DEV_ALLOC(d.claim[1], N);
 	DEV_ALLOC(d.island, N); DEV_ALLOC(d.island_awake, N);
+	DEV_ALLOC(d.sbody, 4 * (size_t)N);
 	d.table_size = std::max(1024u, next_pow2(2u * N));
 	DEV_ALLOC(d.cell_hash, N); DEV_ALLOC(d.cell_xyz, N);
 	DEV_ALLOC(d.cell_count, d.table_size + 4); DEV_ALLOC(d.cell_start, d.table_size + 4); DEV_ALLOC(d.cell_fill, d.table_size + 4);
-	DEV_ALLOC(d.sorted_ids, N); DEV_ALLOC(d.scan_block_sums, (d.table_size + 1) / 1024 + 2);
+	DEV_ALLOC(d.sorted_ids, N); DEV_ALLOC(d.sorted_min, N); DEV_ALLOC(d.sorted_max, N); DEV_ALLOC(d.grid, 1); DEV_ALLOC(d.scan_block_sums, (d.table_size + 1) / 1024 + 2);
 	DEV_ALLOC(d.pairs, P);
 	DEV_ALLOC(d.man_ab, M); DEV_ALLOC(d.man_n, M); DEV_ALLOC(d.man_colour, M); DEV_ALLOC(d.man_prio, M);
 	for (int k = 0; k < 4; ++k) { DEV_ALLOC(d.man_p1[k], M); DEV_ALLOC(d.man_p2[k], M); }
@@ -246,6 +247,7 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	DEV_ALLOC(d.ev_activated, N); DEV_ALLOC(d.ev_deactivated, N); DEV_ALLOC(d.ev_water, N);
 	HIP_TRY(hipHostMalloc((void**)&w->h_ctr, sizeof(StepCounters), hipHostMallocDefault));
 	HIP_TRY(hipHostMalloc((void**)&w->h_evc, sizeof(EventCounters), hipHostMallocDefault));
+	HIP_TRY(hipHostMalloc((void**)&w->h_grid, sizeof(BpGrid), hipHostMallocDefault));
 	d.st = desc->settings;
 	d.gx = desc->gravity[0]; d.gy = desc->gravity[1]; d.gz = desc->gravity[2];
 	d.cell_size = 1.0f;
@@ -265,6 +267,7 @@ SGP_API int sgp_world_destroy(sgp_world* w)
 	if (w->stage_host) hipHostFree(w->stage_host);
 	if (w->h_ctr) hipHostFree(w->h_ctr);
 	if (w->h_evc) hipHostFree(w->h_evc);
+	if (w->h_grid) hipHostFree(w->h_grid);
 	for (hipEvent_t ev : w->event_pool) hipEventDestroy(ev);
 	if (w->stage_ev_ok) for (int i = 0; i <= SGP_NUM_STAGES; ++i) hipEventDestroy(w->stage_ev[i]);
 	if (w->stream) hipStreamDestroy(w->stream);
@@ -488,7 +491,8 @@ static int flush_cmds(sgp_world* w)
 		d.large_ids = w->d_large; d.n_large = (uint32_t)w->large_ids.size();
 		w->large_dirty = false;
 	}
-	d.cell_size = std::max(0.5f, 2.0f * w->max_small_radius) + 2.0f * d.st.speculative_contact_distance;
+	d.bp_rmax = std::max(0.25f, w->max_small_radius);
+	d.cell_size = d.bp_rmax + d.st.speculative_contact_distance;
 	if (w->cmds.empty()) return SGP_OK;
 	const size_t n = w->cmds.size();
 	std::vector<uint32_t> order(n);
@@ -587,6 +591,12 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 		HIP_TRY(hipMemsetAsync(d.ctr, 0, sizeof(StepCounters), s));
 		HIP_TRY(hipMemsetAsync(d.cell_count, 0, sizeof(uint32_t) * (d.table_size + 4), s));
 		HIP_TRY(hipMemsetAsync(d.cell_fill, 0, sizeof(uint32_t) * (d.table_size + 4), s));
+		{
+			BpGrid g0; memset(&g0, 0, sizeof(g0));
+			g0.min_x = g0.min_y = g0.min_z = 0x7FFFFFFF; g0.max_x = g0.max_y = g0.max_z = (int)0x80000000;
+			*w->h_grid = g0;
+			HIP_TRY(hipMemcpyAsync(d.grid, w->h_grid, sizeof(BpGrid), hipMemcpyHostToDevice, s));
+		}
 		if (n) {
 			HIP_TRY(hipMemsetAsync(d.colour_mask, 0, sizeof(uint64_t) * n, s));
 			HIP_TRY(hipMemsetAsync(d.claim[0], 0xFF, sizeof(uint64_t) * n, s));
@@ -598,7 +608,7 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	{ KScope k(w, KC_APPLY_FORCES); launch_apply_forces(d, dt, s); }
 	STAGE_MARK(1);
 	// -- 2. broad phase
-	{ KScope k(w, KC_BP_CELL); launch_bp_cell(d, s); }
+	{ KScope k(w, KC_BP_CELL); launch_bp_bounds(d, s); launch_bp_cell(d, s); }
 	{ KScope k(w, KC_BP_SCAN); launch_bp_scan(d, s); }
 	{ KScope k(w, KC_BP_SCATTER); launch_bp_scatter(d, s); }
 	{ KScope k(w, KC_BP_PAIRS); launch_bp_pairs(d, s); }
@@ -608,6 +618,7 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	const uint32_t est_pairs = std::max(w->last_pairs + w->last_pairs / 4 + 1024u, 4u * n);
 	{ KScope k(w, KC_NARROWPHASE); launch_narrowphase(d, est_pairs, s); }
 	{ KScope k(w, KC_WAKE); launch_wake(d, s); }
+	{ KScope k(w, KC_PREP_BODIES); launch_prep_bodies(d, s); }
 	const uint32_t est_man = std::max(w->last_manifolds + w->last_manifolds / 4 + 1024u, 2u * n);
 	if (d.contact_events) { KScope k(w, KC_MISC); launch_contact_events(d, est_man, s); }
 	STAGE_MARK(3);
@@ -632,30 +643,36 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	cs.s[SGP_MAX_COLOURS] = acc;
 	{ KScope k(w, KC_SETUP); launch_setup(d, n_man, dt, cs, s); }
 	STAGE_MARK(4);
-	// -- 5. warm start + velocity iterations, colour by colour
+	// -- 5. warm start + velocity iterations, colour by colour; the small tail colours share one launch
 	const uint32_t n_ovf = c1.colour_count[SGP_OVERFLOW_COLOUR];
-	if (d.st.warm_start) {
-		for (int c = 0; c < SGP_OVERFLOW_COLOUR; ++c) if (c1.colour_count[c]) { KScope k(w, KC_WARM_START); launch_warm_start(d, cs.s[c], c1.colour_count[c], s); }
-		if (n_ovf) { KScope k(w, KC_WARM_START); launch_solve_velocity_serial(d, cs.s[SGP_OVERFLOW_COLOUR], n_ovf, 0, s); }
-	}
-	for (int it = 0; it < d.st.num_velocity_steps; ++it) {
-		for (int c = 0; c < SGP_OVERFLOW_COLOUR; ++c) if (c1.colour_count[c]) { KScope k(w, KC_SOLVE_VELOCITY); launch_solve_velocity(d, cs.s[c], c1.colour_count[c], s); }
-		if (n_ovf) { KScope k(w, KC_SOLVE_VELOCITY); launch_solve_velocity_serial(d, cs.s[SGP_OVERFLOW_COLOUR], n_ovf, 1, s); }
-	}
+	int end_colour = 0;
+	for (int c = 0; c < SGP_OVERFLOW_COLOUR; ++c) if (c1.colour_count[c]) end_colour = c + 1;
+	int tail_first = end_colour;
+	while (tail_first > 0 && c1.colour_count[tail_first - 1] <= 256u) --tail_first;
+	if (end_colour - tail_first < 2) tail_first = end_colour;       // a single small colour is cheaper as a normal launch
+	auto solve_pass = [&](int mode, int kc) {
+		for (int c = 0; c < tail_first; ++c) if (c1.colour_count[c]) {
+			KScope k(w, kc);
+			if (mode == 0) launch_warm_start(d, cs.s[c], c1.colour_count[c], s);
+			else if (mode == 1) launch_solve_velocity(d, cs.s[c], c1.colour_count[c], s);
+			else launch_solve_position(d, cs.s[c], c1.colour_count[c], s);
+		}
+		if (end_colour > tail_first) { KScope k(w, kc); launch_solve_tail(d, cs, tail_first, end_colour, mode, s); }
+		if (n_ovf) { KScope k(w, kc); launch_solve_velocity_serial(d, cs.s[SGP_OVERFLOW_COLOUR], n_ovf, mode, s); }
+	};
+	if (d.st.warm_start) solve_pass(0, KC_WARM_START);
+	for (int it = 0; it < d.st.num_velocity_steps; ++it) solve_pass(1, KC_SOLVE_VELOCITY);
 	STAGE_MARK(5);
 	// -- 6. the body-array sweep
 	{ KScope k(w, KC_INTEGRATE_POSE); launch_integrate_pose(d, dt, s); }
 	STAGE_MARK(6);
 	// -- 7. position iterations
-	for (int it = 0; it < d.st.num_position_steps; ++it) {
-		for (int c = 0; c < SGP_OVERFLOW_COLOUR; ++c) if (c1.colour_count[c]) { KScope k(w, KC_SOLVE_POSITION); launch_solve_position(d, cs.s[c], c1.colour_count[c], s); }
-		if (n_ovf) { KScope k(w, KC_SOLVE_POSITION); launch_solve_velocity_serial(d, cs.s[SGP_OVERFLOW_COLOUR], n_ovf, 2, s); }
-	}
+	for (int it = 0; it < d.st.num_position_steps; ++it) solve_pass(2, KC_SOLVE_POSITION);
 	STAGE_MARK(7);
 	// -- 8. bounds, sleeping, buoyancy, contact cache
 	{ KScope k(w, KC_FINALIZE); launch_finalize(d, dt, s); }
 	{ KScope k(w, KC_ISLAND_HOOK); launch_island_hook(d, n_con, s); }
-	{ KScope k(w, KC_ISLAND_FLAG); launch_island_flag(d, s); }
+	{ KScope k(w, KC_ISLAND_FLAG); launch_island_flag(d, n_con, s); }
 	{ KScope k(w, KC_SLEEP_APPLY); launch_sleep_apply(d, s); }
 	if (d.water_enabled) { KScope k(w, KC_BUOYANCY); launch_buoyancy(d, dt, s); }
 	{

@@ -47,4 +47,7 @@ if __name__ == "__main__":
         names = w.kernel_class_names()
         print("  stages ms:", [round(x, 3) for x in p.stage_ms], "total", round(p.total_ms, 3))
         print("  kernels:", {names[k]: (round(p.kernel_ms[k], 3), p.kernel_launches[k]) for k in range(len(names)) if p.kernel_launches[k]})
+        cons = w.dump_constraints()
+        print("  colour histogram:", np.bincount(cons["colour"], minlength=1).tolist())
+        print("  points histogram:", np.bincount(cons["np"], minlength=5).tolist())
         w.close()
