@@ -98,6 +98,9 @@ typedef struct sgo_world {
 	sgp_contact_event* ev_pers; uint32_t n_pers, cap_pers;
 	/* broad-phase scratch */
 	uint64_t* cell_keys; uint32_t* cell_idx; uint32_t* large; uint32_t n_large;
+	/* multi-tile ghosts: global id -> local id, kept sorted by global id */
+	uint64_t* ghost_gid; uint32_t* ghost_lid; uint32_t n_ghosts;
+	int* is_ghost;
 } sgo_world;
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -292,6 +295,7 @@ SGO_API int sgo_world_create(const sgp_world_desc* desc, sgo_world** out)
 	w->cell_keys = (uint64_t*)malloc(sizeof(uint64_t) * w->cap);
 	w->cell_idx = (uint32_t*)malloc(sizeof(uint32_t) * w->cap);
 	w->large = (uint32_t*)malloc(sizeof(uint32_t) * w->cap);
+	w->is_ghost = (int*)calloc(w->cap, sizeof(int));
 	if (w->desc.large_body_radius <= 0.0f) w->desc.large_body_radius = 4.0f;
 	*out = w;
 	return SGP_OK;
@@ -303,7 +307,7 @@ SGO_API int sgo_world_destroy(sgo_world* w)
 	free(w->bodies); free(w->free_list); free(w->pairs); free(w->cons); free(w->prev);
 	free(w->prev_keys_sorted); free(w->prev_idx_sorted); free(w->order);
 	free(w->ev_act); free(w->ev_deact); free(w->ev_water); free(w->ev_added); free(w->ev_pers);
-	free(w->cell_keys); free(w->cell_idx); free(w->large);
+	free(w->cell_keys); free(w->cell_idx); free(w->large); free(w->is_ghost); free(w->ghost_gid); free(w->ghost_lid);
 	free(w);
 	return SGP_OK;
 }
@@ -1275,6 +1279,84 @@ SGO_API int sgo_world_drain_events(sgo_world* w, int kind, void* out, uint32_t c
 		if (out && m) memcpy(out, src, sizeof(sgp_contact_event) * m);
 		*n_out = *n; *n = 0;
 	}
+	return SGP_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* multi-GPU tiles: the same export / import semantics as the device library, so that the tile exchange  */
+/* (substrata_amd/tiles.py) can be exercised on CPU with gloo                                                            */
+
+static int cmp_ghost_rec(const void* a, const void* b)
+{
+	const uint64_t x = ((const sgp_ghost_record*)a)->global_id, y = ((const sgp_ghost_record*)b)->global_id;
+	return (x > y) - (x < y);
+}
+
+SGO_API int sgo_world_export_boundary(sgo_world* w, const float lo[3], const float hi[3], float margin, sgp_ghost_record* out, uint32_t cap, uint32_t* n_out)
+{
+	uint32_t n = 0;
+	const float large_r = w->desc.large_body_radius;
+	for (uint32_t i = 0; i < w->high; ++i) {
+		const sgo_body* b = &w->bodies[i];
+		if (!b->alive || w->is_ghost[i] || b->motion == SGP_MOTION_STATIC) continue;
+		if (shape_bounding_radius(b->shape_type, b->shape) > large_r) continue;
+		const int crosses = b->aabb_min.x - margin < lo[0] || b->aabb_min.y - margin < lo[1] || b->aabb_min.z - margin < lo[2] ||
+		                    b->aabb_max.x + margin >= hi[0] || b->aabb_max.y + margin >= hi[1] || b->aabb_max.z + margin >= hi[2];
+		if (!crosses) continue;
+		if (n < cap) {
+			sgp_ghost_record* r = &out[n];
+			memset(r, 0, sizeof(*r));
+			r->pos[0] = b->pos.x; r->pos[1] = b->pos.y; r->pos[2] = b->pos.z;
+			r->rot[0] = b->rot.x; r->rot[1] = b->rot.y; r->rot[2] = b->rot.z; r->rot[3] = b->rot.w;
+			r->lin_vel[0] = b->linv.x; r->lin_vel[1] = b->linv.y; r->lin_vel[2] = b->linv.z;
+			r->ang_vel[0] = b->angv.x; r->ang_vel[1] = b->angv.y; r->ang_vel[2] = b->angv.z;
+			r->shape_type = b->shape_type; memcpy(r->shape, b->shape, sizeof(r->shape)); r->shape[3] = 0.0f;
+			r->mass = b->mass; r->friction = b->friction; r->restitution = b->restitution;
+			r->motion_type = (uint32_t)b->motion; r->global_id = i;
+		}
+		++n;
+	}
+	*n_out = n;
+	qsort(out, n < cap ? n : cap, sizeof(sgp_ghost_record), cmp_ghost_rec);
+	return SGP_OK;
+}
+
+SGO_API int sgo_world_import_ghosts(sgo_world* w, const sgp_ghost_record* in, uint32_t n)
+{
+	uint64_t* ngid = (uint64_t*)malloc(sizeof(uint64_t) * (n ? n : 1));
+	uint32_t* nlid = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
+	int* kept = (int*)calloc(w->n_ghosts ? w->n_ghosts : 1, sizeof(int));
+	uint32_t nn = 0;
+	for (uint32_t k = 0; k < n; ++k) {
+		int found = -1;
+		for (uint32_t g = 0; g < w->n_ghosts; ++g) if (w->ghost_gid[g] == in[k].global_id && !kept[g] && live(w, w->ghost_lid[g])) { found = (int)g; break; }
+		if (found >= 0) {
+			const uint32_t id = w->ghost_lid[found];
+			kept[found] = 1;
+			sgo_body_set_pose_vel(w, id, in[k].pos, in[k].rot, in[k].lin_vel, in[k].ang_vel);
+			sgo_body_activate(w, id);
+			ngid[nn] = in[k].global_id; nlid[nn] = id; ++nn;
+			continue;
+		}
+		sgp_body_desc d; sgo_default_body_desc(&d);
+		memcpy(d.pos, in[k].pos, 12); memcpy(d.rot, in[k].rot, 16); memcpy(d.lin_vel, in[k].lin_vel, 12); memcpy(d.ang_vel, in[k].ang_vel, 12);
+		d.shape_type = in[k].shape_type; memcpy(d.shape, in[k].shape, 16);
+		d.motion_type = SGP_MOTION_KINEMATIC; d.layer = SGP_LAYER_MOVING;
+		d.mass = in[k].mass; d.friction = in[k].friction; d.restitution = in[k].restitution;
+		d.activate = 1; d.userdata = in[k].global_id;
+		uint32_t id = SGP_INVALID_ID;
+		const int r = sgo_body_add(w, &d, &id);
+		if (r == SGP_OK) { w->is_ghost[id] = 1; ngid[nn] = in[k].global_id; nlid[nn] = id; ++nn; }
+		else if (r != SGP_ERR_REJECTED) { free(ngid); free(nlid); free(kept); return r; }
+	}
+	/* remove the ghosts that left the set, ascending local id */
+	for (uint32_t id = 0; id < w->high; ++id) {
+		int gone = 0;
+		for (uint32_t g = 0; g < w->n_ghosts; ++g) if (w->ghost_lid[g] == id && !kept[g] && live(w, id) && w->is_ghost[id]) { gone = 1; break; }
+		if (gone) { w->is_ghost[id] = 0; sgo_body_remove(w, id); }
+	}
+	free(w->ghost_gid); free(w->ghost_lid); free(kept);
+	w->ghost_gid = ngid; w->ghost_lid = nlid; w->n_ghosts = nn;
 	return SGP_OK;
 }
 

@@ -50,6 +50,9 @@ struct StepCounters {
 	uint32_t n_constraints;      // manifolds that became contact constraints
 	uint32_t n_points;
 	uint32_t n_uncoloured;
+	uint32_t ucount[2];          // sizes of the two uncoloured worklists (round parity)
+	uint32_t rounds_used;        // colouring rounds that found work
+	uint32_t n_colours;          // highest used colour + 1 (overflow colour excluded)
 	uint32_t pairs_dropped;
 	uint32_t manifolds_dropped;
 	uint32_t n_active;
@@ -160,12 +163,13 @@ struct DV {
 	float4*   man_p1[4];
 	float4*   man_p2[4];
 	int32_t*  man_colour;      // -1 uncoloured, -2 not a constraint (sensor)
+	uint32_t* ulist[2];        // worklists of still-uncoloured manifolds, double buffered by round parity
 	uint64_t* man_prio;
 	// constraints
 	ConstraintArrays cur, prev;
 	uint32_t  n_prev;
 	uint64_t* ht_keys; uint32_t* ht_vals; uint32_t ht_size;   // contact cache: pair key -> prev slot
-	uint32_t* colour_start;    // [SGP_MAX_COLOURS + 1]
+	uint32_t* cstarts;         // [SGP_MAX_COLOURS + 1] first constraint slot of every colour (device-side exclusive scan)
 	// counters / events
 	StepCounters* ctr;
 	EventCounters* evc;
@@ -192,14 +196,12 @@ void launch_prep_bodies(const DV& d, hipStream_t s);
 void launch_colour_claim(const DV& d, uint32_t n_man, uint32_t round, hipStream_t s);
 void launch_colour_commit(const DV& d, uint32_t n_man, uint32_t round, hipStream_t s);
 void launch_colour_count(const DV& d, uint32_t n_man, hipStream_t s);
-struct ColourStarts { uint32_t s[SGP_MAX_COLOURS + 1]; };
-void launch_setup(const DV& d, uint32_t n_man, float dt, const ColourStarts& cs, hipStream_t s);
-void launch_warm_start(const DV& d, uint32_t first, uint32_t count, hipStream_t s);
-void launch_solve_velocity(const DV& d, uint32_t first, uint32_t count, hipStream_t s);
-void launch_solve_tail(const DV& d, const ColourStarts& cs, int first_colour, int end_colour, int mode, hipStream_t s);
-void launch_solve_velocity_serial(const DV& d, uint32_t first, uint32_t count, int mode, hipStream_t s);
+void launch_colour_finish(const DV& d, uint32_t first_round, hipStream_t s);
+void launch_setup(const DV& d, uint32_t n_man, float dt, hipStream_t s);
+// mode: 0 warm start, 1 velocity iteration, 2 position iteration.  est = expected constraints of that colour (grid sizing only)
+void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStream_t s);
+void launch_solve_tail(const DV& d, int first_colour, int mode, hipStream_t s);
 void launch_integrate_pose(const DV& d, float dt, hipStream_t s);
-void launch_solve_position(const DV& d, uint32_t first, uint32_t count, hipStream_t s);
 void launch_finalize(const DV& d, float dt, hipStream_t s);
 void launch_island_hook(const DV& d, uint32_t n_con, hipStream_t s);
 void launch_island_flag(const DV& d, uint32_t n_con, hipStream_t s);

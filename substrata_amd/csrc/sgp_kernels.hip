@@ -4,9 +4,9 @@
 //   k_bp_*                K2/K3 spatial-hash broad phase (uniform grid, hashed buckets) + layer filter (PhysicsWorld.cpp:160-189)
 //   k_narrowphase         K4   sphere/box/capsule manifolds (sgp_device_collide.h)
 //   k_colour_*, k_setup   K5/K6 contact cache match (warm start), deterministic colouring, constraint properties
-//   k_warm_start, k_solve_velocity  K7  sequential impulses, one colour per launch
+//   k_solve_colour<0|1>, k_solve_tail  K7  warm start + sequential impulses, one colour per launch
 //   k_integrate_pose      K8b  the body-array sweep: x += v dt, q <- rot(w dt) q
-//   k_solve_position      K7b  Baumgarte position iterations
+//   k_solve_colour<2>     K7b  Baumgarte position iterations
 //   k_finalize, k_island_*, k_sleep_apply  K1 + K9  AABB refresh, sleep spheres, island sleeping
 //   k_buoyancy            A3   Substrata's own water sweep (PhysicsWorld.cpp:1367-1442)
 // All body state is SoA float4 in HBM; every per-body kernel is a coalesced 16 B/lane sweep.
@@ -147,9 +147,15 @@ __global__ void __launch_bounds__(TPB) k_bp_bounds(DV d)
 		mnx = fminf(mnx, __shfl_down(mnx, off, 64)); mny = fminf(mny, __shfl_down(mny, off, 64)); mnz = fminf(mnz, __shfl_down(mnz, off, 64));
 		mxx = fmaxf(mxx, __shfl_down(mxx, off, 64)); mxy = fmaxf(mxy, __shfl_down(mxy, off, 64)); mxz = fmaxf(mxz, __shfl_down(mxz, off, 64));
 	}
-	if ((threadIdx.x & 63) == 0 && mnx <= mxx) {
-		atomicMin(&d.grid->min_x, float_to_ordered(mnx)); atomicMin(&d.grid->min_y, float_to_ordered(mny)); atomicMin(&d.grid->min_z, float_to_ordered(mnz));
-		atomicMax(&d.grid->max_x, float_to_ordered(mxx)); atomicMax(&d.grid->max_y, float_to_ordered(mxy)); atomicMax(&d.grid->max_z, float_to_ordered(mxz));
+	__shared__ float red[6][TPB / 64];
+	if ((threadIdx.x & 63) == 0) { const int wv = threadIdx.x >> 6; red[0][wv] = mnx; red[1][wv] = mny; red[2][wv] = mnz; red[3][wv] = mxx; red[4][wv] = mxy; red[5][wv] = mxz; }
+	__syncthreads();
+	if (threadIdx.x < 6) {
+		float v = red[threadIdx.x][0];
+		for (int k = 1; k < TPB / 64; ++k) v = threadIdx.x < 3 ? fminf(v, red[threadIdx.x][k]) : fmaxf(v, red[threadIdx.x][k]);
+		int* dst = &d.grid->min_x + threadIdx.x;
+		if (threadIdx.x < 3) { if (v < 2.9e38f) atomicMin(dst, float_to_ordered(v)); }
+		else { if (v > -2.9e38f) atomicMax(dst, float_to_ordered(v)); }
 	}
 }
 
@@ -559,12 +565,18 @@ __global__ void __launch_bounds__(TPB) k_prep_bodies(DV d)
 // claims its movable bodies with atomicMin; the manifold that holds both claims takes the lowest colour free on
 // both bodies.  The result depends only on the SET of manifolds (spec: DESIGN.md "Colouring").
 
+// Round 0 walks every manifold; later rounds walk the compacted worklist of still-uncoloured manifolds that the previous
+// commit produced, so the work per round shrinks with the remaining set.
 __global__ void __launch_bounds__(TPB) k_colour_claim(DV d, uint32_t round)
 {
-	const uint32_t n = min(d.ctr->n_manifolds, d.cap_manifolds);
-	unsigned long long* claim = (unsigned long long*)d.claim[round & 1];
-	for (uint32_t m = blockIdx.x * TPB + threadIdx.x; m < n; m += gridDim.x * TPB) {
-		if (d.man_colour[m] != -1) continue;
+	const uint32_t par = round & 1;
+	const uint32_t n = round == 0 ? min(d.ctr->n_manifolds, d.cap_manifolds) : d.ctr->ucount[par];
+	if (blockIdx.x == 0 && threadIdx.x == 0) { d.ctr->ucount[par ^ 1] = 0; if (n) d.ctr->rounds_used = round + 1; }   // commit(round) appends to the other list
+	const uint32_t* list = d.ulist[par];
+	unsigned long long* claim = (unsigned long long*)d.claim[par];
+	for (uint32_t idx = blockIdx.x * TPB + threadIdx.x; idx < n; idx += gridDim.x * TPB) {
+		const uint32_t m = round == 0 ? idx : list[idx];
+		if (round == 0 && d.man_colour[m] != -1) continue;
 		const uint2 ab = d.man_ab[m];
 		const unsigned long long pr = d.man_prio[m];
 		if (f_movable(d.flags[ab.x])) atomicMin(&claim[ab.x], pr);
@@ -574,43 +586,46 @@ __global__ void __launch_bounds__(TPB) k_colour_claim(DV d, uint32_t round)
 
 __global__ void __launch_bounds__(TPB) k_colour_commit(DV d, uint32_t round)
 {
-	const uint32_t n = min(d.ctr->n_manifolds, d.cap_manifolds);
-	const uint64_t* claim = d.claim[round & 1];
-	uint64_t* next = d.claim[(round & 1) ^ 1];
-	uint32_t won = 0;
-	for (uint32_t m = blockIdx.x * TPB + threadIdx.x; m < n; m += gridDim.x * TPB) {
-		if (d.man_colour[m] != -1) continue;
-		const uint2 ab = d.man_ab[m];
-		const uint64_t pr = d.man_prio[m];
-		const bool ma = f_movable(d.flags[ab.x]), mb = f_movable(d.flags[ab.y]);
-		const bool win = (!ma || claim[ab.x] == pr) && (!mb || claim[ab.y] == pr);
-		if (win) {
-			const uint64_t used = (ma ? d.colour_mask[ab.x] : 0ull) | (mb ? d.colour_mask[ab.y] : 0ull);
-			int col = __ffsll((long long)~used) - 1;
-			if (col < 0 || col > SGP_OVERFLOW_COLOUR) col = SGP_OVERFLOW_COLOUR;
-			d.man_colour[m] = col;
-			if (col < SGP_OVERFLOW_COLOUR) {
-				if (ma) d.colour_mask[ab.x] = d.colour_mask[ab.x] | (1ull << col);
-				if (mb) d.colour_mask[ab.y] = d.colour_mask[ab.y] | (1ull << col);
+	const uint32_t par = round & 1;
+	const uint32_t n = round == 0 ? min(d.ctr->n_manifolds, d.cap_manifolds) : d.ctr->ucount[par];
+	const uint32_t* list = d.ulist[par];
+	uint32_t* out = d.ulist[par ^ 1];
+	const uint64_t* claim = d.claim[par];
+	uint64_t* next = d.claim[par ^ 1];
+	const int lane = threadIdx.x & 63;
+	for (uint32_t base = blockIdx.x * TPB; base < n; base += gridDim.x * TPB) {
+		const uint32_t idx = base + threadIdx.x;
+		bool lose = false; uint32_t m = 0;
+		if (idx < n) {
+			m = round == 0 ? idx : list[idx];
+			if (!(round == 0 && d.man_colour[m] != -1)) {
+				const uint2 ab = d.man_ab[m];
+				const uint64_t pr = d.man_prio[m];
+				const bool ma = f_movable(d.flags[ab.x]), mb = f_movable(d.flags[ab.y]);
+				const bool win = (!ma || claim[ab.x] == pr) && (!mb || claim[ab.y] == pr);
+				if (win) {
+					const uint64_t used = (ma ? d.colour_mask[ab.x] : 0ull) | (mb ? d.colour_mask[ab.y] : 0ull);
+					int col = __ffsll((long long)~used) - 1;
+					if (col < 0 || col > SGP_OVERFLOW_COLOUR) col = SGP_OVERFLOW_COLOUR;
+					d.man_colour[m] = col;
+					if (col < SGP_OVERFLOW_COLOUR) {
+						if (ma) d.colour_mask[ab.x] = d.colour_mask[ab.x] | (1ull << col);
+						if (mb) d.colour_mask[ab.y] = d.colour_mask[ab.y] | (1ull << col);
+					}
+				} else lose = true;
+				next[ab.x] = ~0ull;
+				next[ab.y] = ~0ull;
 			}
-			++won;
 		}
-		next[ab.x] = ~0ull;
-		next[ab.y] = ~0ull;
+		// losers go to the next round's worklist: one atomic per wave
+		const unsigned long long mask = __ballot(lose);
+		if (mask) {
+			uint32_t wbase = 0;
+			if (lane == 0) wbase = atomicAdd(&d.ctr->ucount[par ^ 1], (uint32_t)__popcll(mask));
+			wbase = __shfl(wbase, 0, 64);
+			if (lose) out[wbase + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = m;
+		}
 	}
-	// one atomic per wave
-	for (int off = 32; off > 0; off >>= 1) won += __shfl_down(won, off, 64);
-	if ((threadIdx.x & 63) == 0 && won) atomicSub(&d.ctr->n_uncoloured, won);
-}
-
-__global__ void __launch_bounds__(TPB) k_colour_init(DV d)
-{
-	// n_uncoloured = number of manifolds that become constraints
-	const uint32_t n = min(d.ctr->n_manifolds, d.cap_manifolds);
-	uint32_t cnt = 0;
-	for (uint32_t m = blockIdx.x * TPB + threadIdx.x; m < n; m += gridDim.x * TPB) if (d.man_colour[m] == -1) ++cnt;
-	for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
-	if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&d.ctr->n_uncoloured, cnt);
 }
 
 __global__ void __launch_bounds__(TPB) k_colour_count(DV d)
@@ -632,6 +647,72 @@ __global__ void __launch_bounds__(TPB) k_colour_count(DV d)
 	else if (threadIdx.x == SGP_MAX_COLOURS + 1) { if (hist[SGP_MAX_COLOURS + 1]) atomicAdd(&d.ctr->n_constraints, hist[SGP_MAX_COLOURS + 1]); }
 }
 
+// Catch-all: if the planned number of rounds left manifolds uncoloured, ONE workgroup finishes the job with workgroup
+// barriers between the phases (same algorithm, same result; only reached when the plan from the previous step was short).
+__global__ void __launch_bounds__(1024) k_colour_finish(DV d, uint32_t first_round)
+{
+	for (uint32_t round = first_round; round < first_round + 4096u; ++round) {
+		const uint32_t par = round & 1;
+		const uint32_t n = d.ctr->ucount[par];
+		__syncthreads();
+		if (n == 0) return;
+		if (threadIdx.x == 0) { d.ctr->ucount[par ^ 1] = 0; d.ctr->rounds_used = round + 1; }
+		const uint32_t* list = d.ulist[par];
+		uint32_t* out = d.ulist[par ^ 1];
+		unsigned long long* claim = (unsigned long long*)d.claim[par];
+		uint64_t* next = d.claim[par ^ 1];
+		for (uint32_t idx = threadIdx.x; idx < n; idx += 1024) {
+			const uint32_t m = list[idx];
+			const uint2 ab = d.man_ab[m];
+			const unsigned long long pr = d.man_prio[m];
+			if (f_movable(d.flags[ab.x])) atomicMin(&claim[ab.x], pr);
+			if (f_movable(d.flags[ab.y])) atomicMin(&claim[ab.y], pr);
+		}
+		__threadfence();
+		__syncthreads();
+		for (uint32_t idx = threadIdx.x; idx < n; idx += 1024) {
+			const uint32_t m = list[idx];
+			const uint2 ab = d.man_ab[m];
+			const uint64_t pr = d.man_prio[m];
+			const bool ma = f_movable(d.flags[ab.x]), mb = f_movable(d.flags[ab.y]);
+			const bool win = (!ma || claim[ab.x] == pr) && (!mb || claim[ab.y] == pr);
+			if (win) {
+				const uint64_t used = (ma ? d.colour_mask[ab.x] : 0ull) | (mb ? d.colour_mask[ab.y] : 0ull);
+				int col = __ffsll((long long)~used) - 1;
+				if (col < 0 || col > SGP_OVERFLOW_COLOUR) col = SGP_OVERFLOW_COLOUR;
+				d.man_colour[m] = col;
+				if (col < SGP_OVERFLOW_COLOUR) {
+					if (ma) d.colour_mask[ab.x] = d.colour_mask[ab.x] | (1ull << col);
+					if (mb) d.colour_mask[ab.y] = d.colour_mask[ab.y] | (1ull << col);
+				}
+			} else out[atomicAdd(&d.ctr->ucount[par ^ 1], 1u)] = m;
+		}
+		__threadfence();
+		__syncthreads();
+		// reset the claim words this round used (the next round's buffer was reset by the previous commit)
+		for (uint32_t idx = threadIdx.x; idx < n; idx += 1024) {
+			const uint2 ab = d.man_ab[list[idx]];
+			claim[ab.x] = ~0ull; claim[ab.y] = ~0ull;
+			next[ab.x] = ~0ull; next[ab.y] = ~0ull;
+		}
+		__threadfence();
+		__syncthreads();
+	}
+}
+
+// exclusive scan of the colour histogram -> first slot of every colour, on the device (no host round trip)
+__global__ void __launch_bounds__(64) k_colour_scan(DV d)
+{
+	const int c = threadIdx.x;
+	const uint32_t v = d.ctr->colour_count[c];
+	uint32_t x = v;
+	for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off, 64); if (c >= off) x += y; }
+	d.cstarts[c] = x - v;
+	if (c == 63) d.cstarts[64] = x;
+	const unsigned long long used = __ballot(v != 0 && c < SGP_OVERFLOW_COLOUR);
+	if (c == 0) d.ctr->n_colours = used ? 64u - (uint32_t)__clzll(used) : 0u;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // K5: contact constraint setup (Jolt ContactConstraintManager::TemplatedAddContactConstraint): contact-cache match
 // for warm starting, restitution / speculative bias, effective masses.  Constraints are written colour-sorted.
@@ -648,7 +729,6 @@ SGP_DEV uint32_t ht_hash(uint64_t key, uint32_t mask) { return (uint32_t)(sgp_mi
 
 SGP_DEV uint32_t cache_find(const DV& d, uint64_t key)
 {
-	if (d.n_prev == 0) return 0xFFFFFFFFu;
 	const uint32_t mask = d.ht_size - 1;
 	uint32_t h = ht_hash(key, mask);
 	for (uint32_t probe = 0; probe < d.ht_size; ++probe) {
@@ -660,7 +740,7 @@ SGP_DEV uint32_t cache_find(const DV& d, uint64_t key)
 	return 0xFFFFFFFFu;
 }
 
-__global__ void __launch_bounds__(TPB) k_setup(DV d, ColourStarts cs, float dt)
+__global__ void __launch_bounds__(TPB) k_setup(DV d, float dt)
 {
 	__shared__ uint32_t hist[SGP_MAX_COLOURS];
 	__shared__ uint32_t base[SGP_MAX_COLOURS];
@@ -677,7 +757,7 @@ __global__ void __launch_bounds__(TPB) k_setup(DV d, ColourStarts cs, float dt)
 		if (threadIdx.x < SGP_MAX_COLOURS && hist[threadIdx.x]) base[threadIdx.x] = atomicAdd(&d.ctr->colour_fill[threadIdx.x], hist[threadIdx.x]);
 		__syncthreads();
 		if (col < 0) continue;
-		const uint32_t slot = cs.s[col] + base[col] + rank;
+		const uint32_t slot = d.cstarts[col] + base[col] + rank;
 		const uint2 ab = d.man_ab[m];
 		const uint64_t key = ((uint64_t)ab.x << 32) | ab.y;
 		const float4 n4 = d.man_n[m];
@@ -912,41 +992,36 @@ SGP_DEV void solve_position_one(const DV& d, uint32_t slot)
 	}
 }
 
-__global__ void __launch_bounds__(TPB) k_warm_start(DV d, uint32_t first, uint32_t count)
+// One launch = one colour of one pass.  The slot range comes from the device-side colour table, so the host never has
+// to know the counts of the current step; the grid is sized from the previous step and the loop strides over the rest.
+template <int MODE> __global__ void __launch_bounds__(TPB) k_solve_colour(DV d, int colour)
 {
-	const uint32_t t = blockIdx.x * TPB + threadIdx.x;
-	if (t < count) warm_start_one(d, first + t);
-}
-__global__ void __launch_bounds__(TPB) k_solve_velocity(DV d, uint32_t first, uint32_t count)
-{
-	const uint32_t t = blockIdx.x * TPB + threadIdx.x;
-	if (t < count) solve_velocity_one(d, first + t);
-}
-__global__ void __launch_bounds__(TPB) k_solve_position(DV d, uint32_t first, uint32_t count)
-{
-	const uint32_t t = blockIdx.x * TPB + threadIdx.x;
-	if (t < count) solve_position_one(d, first + t);
+	const uint32_t first = d.cstarts[colour], end = d.cstarts[colour + 1];
+	for (uint32_t k = first + blockIdx.x * TPB + threadIdx.x; k < end; k += gridDim.x * TPB) {
+		if (MODE == 0) warm_start_one(d, k);
+		else if (MODE == 1) solve_velocity_one(d, k);
+		else solve_position_one(d, k);
+	}
 }
 
-// Tail colours (few constraints each) share ONE launch: a single 512-thread workgroup walks them in colour order with a
-// workgroup barrier in between, which orders them exactly like separate launches but costs ~1 us instead of a launch each.
-__global__ void __launch_bounds__(512) k_solve_tail(DV d, ColourStarts cs, int first_colour, int end_colour, int mode)
+// Tail colours (few constraints each) share ONE launch: a single 512-thread workgroup walks colours first_colour..62 in
+// order with a workgroup barrier in between (ordered exactly like separate launches), then lane 0 solves the overflow
+// colour 63 (a body with > 63 contacts; Jolt's non-parallel split) serially in ascending priority.  Because it covers
+// every colour from first_colour on, it is also the catch-all when this step uses more colours than the plan expected.
+__global__ void __launch_bounds__(512) k_solve_tail(DV d, int first_colour, int mode)
 {
-	for (int c = first_colour; c < end_colour; ++c) {
-		const uint32_t b = cs.s[c], e = cs.s[c + 1];
+	for (int c = first_colour; c < SGP_OVERFLOW_COLOUR; ++c) {
+		const uint32_t b = d.cstarts[c], e = d.cstarts[c + 1];
+		if (b == e) continue;
 		for (uint32_t k = b + threadIdx.x; k < e; k += 512) {
 			if (mode == 0) warm_start_one(d, k);
 			else if (mode == 1) solve_velocity_one(d, k);
 			else solve_position_one(d, k);
 		}
-		__syncthreads();
+		__syncthreads();      // workgroup scope is enough: all waves of the workgroup share one CU (one L1)
 	}
-}
-
-// Overflow colour (a body with > 63 contacts): one thread, ascending priority (Jolt's non-parallel split).
-__global__ void k_solve_serial(DV d, uint32_t first, uint32_t count, int mode)
-{
-	if (blockIdx.x != 0 || threadIdx.x != 0) return;
+	const uint32_t first = d.cstarts[SGP_OVERFLOW_COLOUR], count = d.cstarts[SGP_OVERFLOW_COLOUR + 1] - first;
+	if (count == 0 || threadIdx.x != 0) return;
 	uint64_t last = 0; bool have_last = false;
 	for (uint32_t it = 0; it < count; ++it) {
 		uint64_t best = ~0ull; uint32_t bslot = first;
@@ -1053,14 +1128,14 @@ SGP_DEV uint32_t uf_find(const uint32_t* parent, uint32_t x)
 // bodies that pass it ("sleepy") are united (union by smaller root id, ECL-CC style hooking); a sleepy component is kept
 // awake iff one of its members touches a movable body that failed the test.  Same result as uniting whole islands, but
 // an active pile (few sleepy bodies) does almost no union work.
-__global__ void __launch_bounds__(TPB) k_island_hook(DV d, uint32_t n_con)
+__global__ void __launch_bounds__(TPB) k_island_hook(DV d)
 {
-	const uint32_t k = blockIdx.x * TPB + threadIdx.x;
-	if (k >= n_con) return;
+	const uint32_t n_con = d.ctr->n_constraints;
+	for (uint32_t k = blockIdx.x * TPB + threadIdx.x; k < n_con; k += gridDim.x * TPB) {
 	const uint2 ab = d.cur.ab[k];
 	const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
-	if (!f_movable(fa) || !f_movable(fb)) return;
-	if (!(fa & BF_CAN_SLEEP) || !(fb & BF_CAN_SLEEP)) return;
+	if (!f_movable(fa) || !f_movable(fb)) continue;
+	if (!(fa & BF_CAN_SLEEP) || !(fb & BF_CAN_SLEEP)) continue;
 	uint32_t ra = uf_find(d.island, ab.x), rb = uf_find(d.island, ab.y);
 	while (ra != rb) {
 		const uint32_t hi = ra > rb ? ra : rb, lo = ra > rb ? rb : ra;
@@ -1068,18 +1143,20 @@ __global__ void __launch_bounds__(TPB) k_island_hook(DV d, uint32_t n_con)
 		if (old == hi) break;
 		ra = uf_find(d.island, old); rb = uf_find(d.island, lo);
 	}
+	}
 }
 
-__global__ void __launch_bounds__(TPB) k_island_flag(DV d, uint32_t n_con)
+__global__ void __launch_bounds__(TPB) k_island_flag(DV d)
 {
-	const uint32_t k = blockIdx.x * TPB + threadIdx.x;
-	if (k >= n_con) return;
-	const uint2 ab = d.cur.ab[k];
-	const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
-	if (!f_movable(fa) || !f_movable(fb)) return;
-	const bool sa = fa & BF_CAN_SLEEP, sb = fb & BF_CAN_SLEEP;
-	if (sa == sb) return;
-	d.island_awake[uf_find(d.island, sa ? ab.x : ab.y)] = 1;
+	const uint32_t n_con = d.ctr->n_constraints;
+	for (uint32_t k = blockIdx.x * TPB + threadIdx.x; k < n_con; k += gridDim.x * TPB) {
+		const uint2 ab = d.cur.ab[k];
+		const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
+		if (!f_movable(fa) || !f_movable(fb)) continue;
+		const bool sa = fa & BF_CAN_SLEEP, sb = fb & BF_CAN_SLEEP;
+		if (sa == sb) continue;
+		d.island_awake[uf_find(d.island, sa ? ab.x : ab.y)] = 1;
+	}
 }
 
 __global__ void __launch_bounds__(TPB) k_sleep_apply(DV d)
@@ -1248,17 +1325,18 @@ __global__ void __launch_bounds__(TPB) k_buoyancy(DV d, float dt)
 // ---------------------------------------------------------------------------------------------------------------
 // contact cache (pair key -> constraint slot) for the next step's warm start; contact events
 
-__global__ void __launch_bounds__(TPB) k_cache_build(DV d, uint32_t n_con)
+__global__ void __launch_bounds__(TPB) k_cache_build(DV d)
 {
-	const uint32_t k = blockIdx.x * TPB + threadIdx.x;
-	if (k >= n_con) return;
-	const uint64_t key = d.cur.key[k];
+	const uint32_t n_con = d.ctr->n_constraints;
 	const uint32_t mask = d.ht_size - 1;
-	uint32_t h = ht_hash(key, mask);
-	for (uint32_t probe = 0; probe < d.ht_size; ++probe) {
-		const unsigned long long old = atomicCAS((unsigned long long*)&d.ht_keys[h], ~0ull, (unsigned long long)key);
-		if (old == ~0ull || old == key) { d.ht_vals[h] = k; return; }
-		h = (h + 1) & mask;
+	for (uint32_t k = blockIdx.x * TPB + threadIdx.x; k < n_con; k += gridDim.x * TPB) {
+		const uint64_t key = d.cur.key[k];
+		uint32_t h = ht_hash(key, mask);
+		for (uint32_t probe = 0; probe < d.ht_size; ++probe) {
+			const unsigned long long old = atomicCAS((unsigned long long*)&d.ht_keys[h], ~0ull, (unsigned long long)key);
+			if (old == ~0ull || old == key) { d.ht_vals[h] = k; break; }
+			h = (h + 1) & mask;
+		}
 	}
 }
 
@@ -1612,27 +1690,32 @@ void launch_wake(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_wake, dim3(b
 void launch_prep_bodies(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_prep_bodies, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d); }
 void launch_colour_claim(const DV& d, uint32_t est, uint32_t round, hipStream_t s)
 {
-	if (round == 0) hipLaunchKernelGGL(k_colour_init, dim3(stride_grid(est)), dim3(TPB), 0, s, d);
 	hipLaunchKernelGGL(k_colour_claim, dim3(stride_grid(est)), dim3(TPB), 0, s, d, round);
 }
 void launch_colour_commit(const DV& d, uint32_t est, uint32_t round, hipStream_t s) { hipLaunchKernelGGL(k_colour_commit, dim3(stride_grid(est)), dim3(TPB), 0, s, d, round); }
-void launch_colour_count(const DV& d, uint32_t est, hipStream_t s) { hipLaunchKernelGGL(k_colour_count, dim3(stride_grid(est)), dim3(TPB), 0, s, d); }
-void launch_setup(const DV& d, uint32_t n_man, float dt, const ColourStarts& cs, hipStream_t s)
+void launch_colour_count(const DV& d, uint32_t est, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_setup, dim3(stride_grid(n_man)), dim3(TPB), 0, s, d, cs, dt);
+	hipLaunchKernelGGL(k_colour_count, dim3(stride_grid(est)), dim3(TPB), 0, s, d);
+	hipLaunchKernelGGL(k_colour_scan, dim3(1), dim3(64), 0, s, d);
 }
-void launch_warm_start(const DV& d, uint32_t first, uint32_t count, hipStream_t s) { if (count) hipLaunchKernelGGL(k_warm_start, dim3(blocks_for(count)), dim3(TPB), 0, s, d, first, count); }
-void launch_solve_velocity(const DV& d, uint32_t first, uint32_t count, hipStream_t s) { if (count) hipLaunchKernelGGL(k_solve_velocity, dim3(blocks_for(count)), dim3(TPB), 0, s, d, first, count); }
-void launch_solve_tail(const DV& d, const ColourStarts& cs, int first_colour, int end_colour, int mode, hipStream_t s) { if (end_colour > first_colour) hipLaunchKernelGGL(k_solve_tail, dim3(1), dim3(512), 0, s, d, cs, first_colour, end_colour, mode); }
-void launch_solve_velocity_serial(const DV& d, uint32_t first, uint32_t count, int mode, hipStream_t s) { if (count) hipLaunchKernelGGL(k_solve_serial, dim3(1), dim3(64), 0, s, d, first, count, mode); }
+void launch_colour_finish(const DV& d, uint32_t first_round, hipStream_t s) { hipLaunchKernelGGL(k_colour_finish, dim3(1), dim3(1024), 0, s, d, first_round); }
+void launch_setup(const DV& d, uint32_t n_man, float dt, hipStream_t s) { hipLaunchKernelGGL(k_setup, dim3(stride_grid(n_man)), dim3(TPB), 0, s, d, dt); }
+void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStream_t s)
+{
+	uint32_t blocks = blocks_for(est + est / 8 + 64);
+	if (blocks > 2048) blocks = 2048;
+	if (mode == 0) hipLaunchKernelGGL(k_solve_colour<0>, dim3(blocks), dim3(TPB), 0, s, d, colour);
+	else if (mode == 1) hipLaunchKernelGGL(k_solve_colour<1>, dim3(blocks), dim3(TPB), 0, s, d, colour);
+	else hipLaunchKernelGGL(k_solve_colour<2>, dim3(blocks), dim3(TPB), 0, s, d, colour);
+}
+void launch_solve_tail(const DV& d, int first_colour, int mode, hipStream_t s) { hipLaunchKernelGGL(k_solve_tail, dim3(1), dim3(512), 0, s, d, first_colour, mode); }
 void launch_integrate_pose(const DV& d, float dt, hipStream_t s) { hipLaunchKernelGGL(k_integrate_pose, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d, dt); }
-void launch_solve_position(const DV& d, uint32_t first, uint32_t count, hipStream_t s) { if (count) hipLaunchKernelGGL(k_solve_position, dim3(blocks_for(count)), dim3(TPB), 0, s, d, first, count); }
 void launch_finalize(const DV& d, float dt, hipStream_t s) { hipLaunchKernelGGL(k_finalize, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d, dt); }
-void launch_island_hook(const DV& d, uint32_t n_con, hipStream_t s) { if (n_con) hipLaunchKernelGGL(k_island_hook, dim3(blocks_for(n_con)), dim3(TPB), 0, s, d, n_con); }
-void launch_island_flag(const DV& d, uint32_t n_con, hipStream_t s) { if (n_con) hipLaunchKernelGGL(k_island_flag, dim3(blocks_for(n_con)), dim3(TPB), 0, s, d, n_con); }
+void launch_island_hook(const DV& d, uint32_t n_con, hipStream_t s) { hipLaunchKernelGGL(k_island_hook, dim3(stride_grid(n_con)), dim3(TPB), 0, s, d); }
+void launch_island_flag(const DV& d, uint32_t n_con, hipStream_t s) { hipLaunchKernelGGL(k_island_flag, dim3(stride_grid(n_con)), dim3(TPB), 0, s, d); }
 void launch_sleep_apply(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_sleep_apply, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d); }
 void launch_buoyancy(const DV& d, float dt, hipStream_t s) { hipLaunchKernelGGL(k_buoyancy, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d, dt); }
-void launch_cache_build(const DV& d, uint32_t n_con, hipStream_t s) { if (n_con) hipLaunchKernelGGL(k_cache_build, dim3(blocks_for(n_con)), dim3(TPB), 0, s, d, n_con); }
+void launch_cache_build(const DV& d, uint32_t n_con, hipStream_t s) { hipLaunchKernelGGL(k_cache_build, dim3(stride_grid(n_con)), dim3(TPB), 0, s, d); }
 void launch_contact_events(const DV& d, uint32_t est, hipStream_t s) { hipLaunchKernelGGL(k_contact_events, dim3(stride_grid(est)), dim3(TPB), 0, s, d); }
 void launch_apply_cmds(const DV& d, const BodyCmd* cmds, const uint32_t* run_start, uint32_t n_runs, hipStream_t s) { if (n_runs) hipLaunchKernelGGL(k_apply_cmds, dim3(blocks_for(n_runs)), dim3(TPB), 0, s, d, cmds, run_start, n_runs); }
 void launch_gather_states(const DV& d, const uint32_t* ids, uint32_t first, uint32_t n, sgp_body_state* out, hipStream_t s) { if (n) hipLaunchKernelGGL(k_gather_states, dim3(blocks_for(n)), dim3(TPB), 0, s, d, ids, first, n, out); }

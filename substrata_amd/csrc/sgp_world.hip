@@ -14,6 +14,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <unordered_map>
 #include "sgp_kernels.h"
 
 #define SGP_API extern "C" __attribute__((visibility("default")))
@@ -62,7 +63,7 @@ struct sgp_world {
 	std::vector<uint32_t> large_ids; bool large_dirty = false;
 	uint32_t* d_large = nullptr; uint32_t cap_large = 0;
 	float max_small_radius = 0.0f;
-	std::vector<uint32_t> ghost_ids;
+	std::unordered_map<uint64_t, uint32_t> ghost_map;      // global id of a ghost -> local body id (stable across steps)
 	// pending edits
 	std::vector<BodyCmd> cmds;
 	// staging
@@ -75,6 +76,8 @@ struct sgp_world {
 	// last step
 	sgp_step_stats stats;
 	uint32_t last_pairs = 0, last_manifolds = 0, n_con = 0;
+	uint32_t plan_rounds = 12;                               // launch plan for the next step (from the last step's counters)
+	uint32_t plan_colour_count[SGP_MAX_COLOURS] = { 0 };
 	uint32_t table_alloc = 0, ht_alloc = 0;
 	// profiling
 	bool profiling = false;
@@ -237,12 +240,14 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	DEV_ALLOC(d.sorted_ids, N); DEV_ALLOC(d.sorted_min, N); DEV_ALLOC(d.sorted_max, N); DEV_ALLOC(d.grid, 1); DEV_ALLOC(d.scan_block_sums, (d.table_size + 1) / 1024 + 2);
 	DEV_ALLOC(d.pairs, P);
 	DEV_ALLOC(d.man_ab, M); DEV_ALLOC(d.man_n, M); DEV_ALLOC(d.man_colour, M); DEV_ALLOC(d.man_prio, M);
+	DEV_ALLOC(d.ulist[0], M); DEV_ALLOC(d.ulist[1], M);
 	for (int k = 0; k < 4; ++k) { DEV_ALLOC(d.man_p1[k], M); DEV_ALLOC(d.man_p2[k], M); }
 	{ int r = alloc_constraints(w, d.cur, M); if (r != SGP_OK) return r; }
 	{ int r = alloc_constraints(w, d.prev, M); if (r != SGP_OK) return r; }
 	w->ht_alloc = next_pow2(2u * M);
 	DEV_ALLOC(d.ht_keys, w->ht_alloc); DEV_ALLOC(d.ht_vals, w->ht_alloc);
-	d.ht_size = 1024;
+	d.ht_size = w->ht_alloc;
+	DEV_ALLOC(d.cstarts, SGP_MAX_COLOURS + 2);
 	DEV_ALLOC(d.ctr, 1); DEV_ALLOC(d.evc, 1);
 	DEV_ALLOC(d.ev_activated, N); DEV_ALLOC(d.ev_deactivated, N); DEV_ALLOC(d.ev_water, N);
 	HIP_TRY(hipHostMalloc((void**)&w->h_ctr, sizeof(StepCounters), hipHostMallocDefault));
@@ -622,43 +627,26 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	const uint32_t est_man = std::max(w->last_manifolds + w->last_manifolds / 4 + 1024u, 2u * n);
 	if (d.contact_events) { KScope k(w, KC_MISC); launch_contact_events(d, est_man, s); }
 	STAGE_MARK(3);
-	// -- 4. colouring (host polls the uncoloured count between batches of rounds)
-	uint32_t round = 0;
-	for (int batch = 0; batch < 64; ++batch) {
-		const int rounds = batch == 0 ? 8 : 4;
-		for (int r = 0; r < rounds; ++r, ++round) {
-			{ KScope k(w, KC_COLOUR_CLAIM); launch_colour_claim(d, est_man, round, s); }
-			{ KScope k(w, KC_COLOUR_COMMIT); launch_colour_commit(d, est_man, round, s); }
-		}
-		{ int r = read_counters(w); if (r != SGP_OK) return r; }
-		if (w->h_ctr->n_uncoloured == 0) break;
+	// -- 4. colouring + constraint setup.  No host round trip: the number of rounds / colours to launch is PLANNED from the
+	//       previous step; catch-all kernels (k_colour_finish, k_solve_tail) keep the result exact when the plan is short.
+	const uint32_t rounds_plan = std::max(w->plan_rounds + 3u, 10u);
+	uint32_t est_unc = est_man;
+	for (uint32_t round = 0; round < rounds_plan; ++round) {
+		{ KScope k(w, KC_COLOUR_CLAIM); launch_colour_claim(d, est_unc, round, s); }
+		{ KScope k(w, KC_COLOUR_COMMIT); launch_colour_commit(d, est_unc, round, s); }
+		if (round >= 1) est_unc = std::max(est_unc - est_unc / 4, 8192u);      // worklists shrink; kernels grid-stride over the rest
 	}
+	{ KScope k(w, KC_COLOUR_COMMIT); launch_colour_finish(d, rounds_plan, s); }
 	{ KScope k(w, KC_COLOUR_COUNT); launch_colour_count(d, est_man, s); }
-	{ int r = read_counters(w); if (r != SGP_OK) return r; }
-	const StepCounters c1 = *w->h_ctr;
-	const uint32_t n_man = std::min(c1.n_manifolds, d.cap_manifolds);
-	const uint32_t n_con = c1.n_constraints;
-	ColourStarts cs; uint32_t acc = 0; int ncol = 0;
-	for (int c = 0; c < SGP_MAX_COLOURS; ++c) { cs.s[c] = acc; acc += c1.colour_count[c]; if (c1.colour_count[c]) ncol = c + 1; }
-	cs.s[SGP_MAX_COLOURS] = acc;
-	{ KScope k(w, KC_SETUP); launch_setup(d, n_man, dt, cs, s); }
+	{ KScope k(w, KC_SETUP); launch_setup(d, est_man, dt, s); }
 	STAGE_MARK(4);
-	// -- 5. warm start + velocity iterations, colour by colour; the small tail colours share one launch
-	const uint32_t n_ovf = c1.colour_count[SGP_OVERFLOW_COLOUR];
-	int end_colour = 0;
-	for (int c = 0; c < SGP_OVERFLOW_COLOUR; ++c) if (c1.colour_count[c]) end_colour = c + 1;
-	int tail_first = end_colour;
-	while (tail_first > 0 && c1.colour_count[tail_first - 1] <= 256u) --tail_first;
-	if (end_colour - tail_first < 2) tail_first = end_colour;       // a single small colour is cheaper as a normal launch
+	// -- 5. warm start + velocity iterations: one launch per planned colour, the rest (small tail colours, overflow colour,
+	//       colours beyond the plan) in one single-workgroup launch
+	int tail_first = 0;
+	while (tail_first < SGP_OVERFLOW_COLOUR && w->plan_colour_count[tail_first] > 256u) ++tail_first;
 	auto solve_pass = [&](int mode, int kc) {
-		for (int c = 0; c < tail_first; ++c) if (c1.colour_count[c]) {
-			KScope k(w, kc);
-			if (mode == 0) launch_warm_start(d, cs.s[c], c1.colour_count[c], s);
-			else if (mode == 1) launch_solve_velocity(d, cs.s[c], c1.colour_count[c], s);
-			else launch_solve_position(d, cs.s[c], c1.colour_count[c], s);
-		}
-		if (end_colour > tail_first) { KScope k(w, kc); launch_solve_tail(d, cs, tail_first, end_colour, mode, s); }
-		if (n_ovf) { KScope k(w, kc); launch_solve_velocity_serial(d, cs.s[SGP_OVERFLOW_COLOUR], n_ovf, mode, s); }
+		for (int c = 0; c < tail_first; ++c) { KScope k(w, kc); launch_solve_colour(d, c, w->plan_colour_count[c], mode, s); }
+		{ KScope k(w, kc); launch_solve_tail(d, tail_first, mode, s); }
 	};
 	if (d.st.warm_start) solve_pass(0, KC_WARM_START);
 	for (int it = 0; it < d.st.num_velocity_steps; ++it) solve_pass(1, KC_SOLVE_VELOCITY);
@@ -670,37 +658,41 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	for (int it = 0; it < d.st.num_position_steps; ++it) solve_pass(2, KC_SOLVE_POSITION);
 	STAGE_MARK(7);
 	// -- 8. bounds, sleeping, buoyancy, contact cache
+	const uint32_t est_con = est_man;
 	{ KScope k(w, KC_FINALIZE); launch_finalize(d, dt, s); }
-	{ KScope k(w, KC_ISLAND_HOOK); launch_island_hook(d, n_con, s); }
-	{ KScope k(w, KC_ISLAND_FLAG); launch_island_flag(d, n_con, s); }
+	{ KScope k(w, KC_ISLAND_HOOK); launch_island_hook(d, est_con, s); }
+	{ KScope k(w, KC_ISLAND_FLAG); launch_island_flag(d, est_con, s); }
 	{ KScope k(w, KC_SLEEP_APPLY); launch_sleep_apply(d, s); }
 	if (d.water_enabled) { KScope k(w, KC_BUOYANCY); launch_buoyancy(d, dt, s); }
 	{
 		KScope k(w, KC_CACHE_BUILD);
-		d.ht_size = std::min(w->ht_alloc, std::max(1024u, next_pow2(2u * std::max(n_con, 1u))));
 		HIP_TRY(hipMemsetAsync(d.ht_keys, 0xFF, sizeof(uint64_t) * d.ht_size, s));
-		launch_cache_build(d, n_con, s);
+		launch_cache_build(d, est_con, s);
 	}
 	std::swap(d.cur, d.prev);
+	STAGE_MARK(8);
+	// -- the ONE host sync of the step: counters, events, and the launch plan for the next step
+	{ int r = read_counters(w); if (r != SGP_OK) return r; }
+	const StepCounters c1 = *w->h_ctr;
+	const uint32_t n_con = c1.n_constraints;
 	d.n_prev = n_con;
 	w->n_con = n_con;
-	STAGE_MARK(8);
 	w->last_pairs = c1.n_pairs; w->last_manifolds = c1.n_manifolds;
-	// -- stats + events
+	w->plan_rounds = c1.rounds_used;
+	for (int c = 0; c < SGP_MAX_COLOURS; ++c) w->plan_colour_count[c] = c1.colour_count[c];
 	sgp_step_stats& st = w->stats;
 	memset(&st, 0, sizeof(st));
 	st.num_bodies = w->n_alive;
 	st.num_pairs = std::min(c1.n_pairs, d.cap_pairs);
 	st.num_manifolds = n_con;
 	st.num_contact_points = c1.n_points;
-	st.num_colours = (uint32_t)ncol;
-	st.num_colour_rounds = round;
-	st.num_overflow_constraints = n_ovf;
+	st.num_colours = c1.n_colours;
+	st.num_colour_rounds = c1.rounds_used;
+	st.num_overflow_constraints = c1.colour_count[SGP_OVERFLOW_COLOUR];
 	st.pairs_dropped = c1.pairs_dropped; st.manifolds_dropped = c1.manifolds_dropped;
 	st.device_bytes = w->device_bytes;
+	st.num_active = c1.n_active;
 	if (final_readback) {
-		{ int r = read_counters(w); if (r != SGP_OK) return r; }
-		st.num_active = w->h_ctr->n_active;
 		const size_t a0 = w->ev_act.size(), d0 = w->ev_deact.size();
 		{ int r = collect_events(w); if (r != SGP_OK) return r; }
 		st.num_activated = (uint32_t)(w->ev_act.size() - a0);
@@ -942,9 +934,20 @@ SGP_API int sgp_world_export_boundary(sgp_world* w, const float lo[3], const flo
 SGP_API int sgp_world_import_ghosts(sgp_world* w, const sgp_ghost_record* in, uint32_t n)
 {
 	if (!w || (!in && n)) return fail(SGP_ERR_INVALID, "sgp_world_import_ghosts: NULL");
-	for (uint32_t id : w->ghost_ids) if (live(w, id)) sgp_body_remove(w, id);
-	w->ghost_ids.clear();
+	// ghosts keep their local id while they stay in the set, so the contact cache (keyed by body ids) keeps warm-starting
+	std::unordered_map<uint64_t, uint32_t> next;
+	next.reserve(n * 2 + 1);
 	for (uint32_t k = 0; k < n; ++k) {
+		auto it = w->ghost_map.find(in[k].global_id);
+		if (it != w->ghost_map.end() && live(w, it->second)) {
+			const uint32_t id = it->second;
+			BodyCmd c = blank_cmd(id, CMD_SET_POS | CMD_SET_ROT | CMD_SET_VEL | CMD_ACTIVATE);
+			memcpy(c.pos, in[k].pos, 12); memcpy(c.rot, in[k].rot, 16); memcpy(c.linv, in[k].lin_vel, 12); memcpy(c.angv, in[k].ang_vel, 12);
+			w->cmds.push_back(c);
+			next[in[k].global_id] = id;
+			w->ghost_map.erase(it);
+			continue;
+		}
 		sgp_body_desc d; sgp_default_body_desc(&d);
 		memcpy(d.pos, in[k].pos, 12); memcpy(d.rot, in[k].rot, 16); memcpy(d.lin_vel, in[k].lin_vel, 12); memcpy(d.ang_vel, in[k].ang_vel, 12);
 		d.shape_type = in[k].shape_type; memcpy(d.shape, in[k].shape, 16);
@@ -954,9 +957,15 @@ SGP_API int sgp_world_import_ghosts(sgp_world* w, const sgp_ghost_record* in, ui
 		d.activate = 1; d.userdata = in[k].global_id;
 		uint32_t id = SGP_INVALID_ID;
 		const int r = add_one(w, &d, &id, true);
-		if (r == SGP_OK) w->ghost_ids.push_back(id);
+		if (r == SGP_OK) next[in[k].global_id] = id;
 		else if (r != SGP_ERR_REJECTED) return r;
 	}
+	// whatever is left in the old map left the ghost set: remove in ascending id order (deterministic free-list order)
+	std::vector<uint32_t> gone;
+	for (auto& kv : w->ghost_map) if (live(w, kv.second)) gone.push_back(kv.second);
+	std::sort(gone.begin(), gone.end());
+	for (uint32_t id : gone) sgp_body_remove(w, id);
+	w->ghost_map.swap(next);
 	return SGP_OK;
 }
 

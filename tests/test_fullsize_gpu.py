@@ -1,0 +1,117 @@
+"""BASELINE-size checks on the GPU: direct oracle parity where the oracle finishes in seconds (config 2 at 10k bodies,
+the first steps of config 3 at 100k), and size-independent properties at full size (run-to-run bit reproducibility,
+valid colouring, no dropped pairs, energy not created, unit quaternions, nothing below the ground)."""
+import numpy as np
+import pytest
+
+from substrata_amd import abi, scenes
+from helpers import DT
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config2_10k_parity_with_oracle(oracle):
+    descs = scenes.config2_10k_boxes()
+    tw = parity.make_twin(oracle, max_bodies=len(descs) + 64)
+    tw.add_batch(descs)
+    for s in range(1, 41):
+        tw.step(DT)
+        if s in (1, 10, 25, 40):
+            d = parity.compare(tw, len(descs))
+            assert d["active_mismatch"] == 0
+            assert d["pos"] <= 1e-4 and d["rot"] <= 1e-4 and d["lin_vel"] <= 1e-3 and d["ang_vel"] <= 1e-3, (s, d)
+    sg, sc = tw.stats()
+    assert (sg.num_pairs, sg.num_manifolds, sg.num_contact_points, sg.num_colours, sg.num_colour_rounds) == \
+           (sc.num_pairs, sc.num_manifolds, sc.num_contact_points, sc.num_colours, sc.num_colour_rounds)
+    assert sg.num_manifolds > 5000
+    tw.close()
+
+
+def test_config3_100k_first_steps_parity_with_oracle(oracle):
+    """100k mixed bodies: neighbours already touch at t=0 (scale up to 1.5 on a 1.5 m lattice), so the first steps
+    exercise every stage at full size.  6 steps of the oracle take ~10 s."""
+    descs = scenes.config3_100k_mixed()
+    tw = parity.make_twin(oracle, max_bodies=len(descs) + 64)
+    tw.add_batch(descs)
+    for s in range(1, 7):
+        tw.step(DT)
+    d = parity.compare(tw, len(descs))
+    assert d["active_mismatch"] == 0
+    assert d["pos"] <= 1e-4 and d["rot"] <= 1e-4 and d["lin_vel"] <= 1e-3 and d["ang_vel"] <= 1e-3, d
+    sg, sc = tw.stats()
+    assert (sg.num_pairs, sg.num_manifolds, sg.num_contact_points, sg.num_colours) == \
+           (sc.num_pairs, sc.num_manifolds, sc.num_contact_points, sc.num_colours)
+    assert sg.num_manifolds > 20000 and sg.pairs_dropped == 0 and sg.manifolds_dropped == 0
+    tw.close()
+
+
+def mechanical_energy(descs, st):
+    m = descs["mass"][1:].astype(np.float64)
+    z = st["pos"][1:, 2].astype(np.float64)
+    v2 = np.sum(st["lin_vel"][1:].astype(np.float64) ** 2, axis=1)
+    return float(np.sum(m * 9.81 * z + 0.5 * m * v2))
+
+
+def test_config3_100k_properties():
+    from substrata_amd.lib import World
+    descs = scenes.config3_100k_mixed()
+    n = len(descs)
+    runs = []
+    for rep in range(2):
+        w = World(max_bodies=n + 64)
+        w.add_batch(descs)
+        e0 = mechanical_energy(descs, w.read_states(0, n))
+        for _ in range(90):
+            w.step(DT)
+        st = w.read_states(0, n)
+        stats = w.stats()
+        cons = w.dump_constraints() if rep == 0 else None
+        runs.append(st)
+        if rep == 0:
+            assert stats.pairs_dropped == 0 and stats.manifolds_dropped == 0
+            assert stats.num_manifolds > 150000 and stats.num_colours <= 40 and stats.num_overflow_constraints == 0
+            for f in ("pos", "rot", "lin_vel", "ang_vel"):
+                assert np.all(np.isfinite(st[f])), f
+            assert np.max(np.abs(np.linalg.norm(st["rot"], axis=1) - 1.0)) < 1e-5
+            # nothing tunnels through the 1 m thick ground slab.  (Light bodies, 6 kg, under a 10-deep pile of bodies up to
+            # 170 kg do get pressed INTO the slab by up to a few dm with 10 PGS iterations -- identical in the oracle.)
+            assert st["pos"][1:, 2].min() > -0.5
+            assert np.mean(st["pos"][1:, 2] < 0.1) < 0.01
+            # no energy is created (restitution < 1, friction, damping); rotational energy only adds to the right-hand side
+            assert mechanical_energy(descs, st) <= e0 * (1.0 + 1e-3)
+            # valid colouring at full size: constraints of one colour never share a movable body
+            movable = st["active"].astype(bool)
+            movable[0] = False
+            assert parity.check_colouring_valid(cons, movable)
+            assert len(cons) == stats.num_manifolds
+            # the contact list has no duplicate pair and is sorted
+            key = cons["a"].astype(np.uint64) << np.uint64(32) | cons["b"].astype(np.uint64)
+            assert np.all(np.diff(key.astype(np.int64)) > 0)
+        w.close()
+    # run-to-run reproducibility: atomics only ever decide ORDER, never a value
+    for f in ("pos", "rot", "lin_vel", "ang_vel"):
+        assert np.array_equal(runs[0][f].view(np.uint32), runs[1][f].view(np.uint32)), f
+
+
+def test_sleeping_at_scale_and_read_active():
+    """10k boxes dropped from 5 cm settle and go to sleep; read_active / events agree with the flags."""
+    from substrata_amd.lib import World
+    g = scenes.ground()
+    d, _ = scenes.lattice(100, 100, 1, 1.5, 0.55, seed=5, jitter=0.0, random_rot=False)
+    descs = np.concatenate([g, d])
+    w = World(max_bodies=len(descs) + 8)
+    w.add_batch(descs)
+    act = w.drain_events(abi.EVENT_ACTIVATED)
+    assert len(act) == 10000
+    for _ in range(100):
+        w.step(DT)
+    st = w.read_states(0, len(descs))
+    assert st["active"][1:].sum() == 0
+    assert len(w.read_active()) == 0
+    deact = w.drain_events(abi.EVENT_DEACTIVATED)
+    assert len(deact) == 10000 and np.array_equal(np.sort(deact["id"]), np.arange(1, 10001))
+    assert np.all(st["lin_vel"] == 0)
+    assert abs(float(st["pos"][1:, 2].mean()) - 0.5) < 0.02
+    assert w.stats().num_pairs == 0            # a sleeping world generates no work
+    w.close()

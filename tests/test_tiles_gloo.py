@@ -1,0 +1,94 @@
+"""The N > 1 path on CPU: two processes (gloo, world_size 2), one tile each, exchanging ghost bodies through
+substrata_amd/tiles.py exactly as bench.py does over RCCL.  The worlds here are oracle worlds (the product has no CPU
+path); the exchange code, the export/import ABI semantics and the tiling are the ones the GPU run uses."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from substrata_amd import abi, scenes, tiles  # noqa: E402
+
+DT = 1.0 / 60.0
+TILE_W = 12.0
+
+
+def scene_for_tile(rank, n_tiles):
+    """A 6x6x2 box lattice per tile (spacing 2 m, so columns straddle the tile border closely) + the ground quad."""
+    lo, hi, origin = tiles.tile_bounds(rank, n_tiles, TILE_W, TILE_W)
+    d, _ = scenes.lattice(6, 6, 2, 2.0, 0.6, seed=11 + rank, jitter=0.05, random_rot=False, origin_centered=False)
+    d["pos"][:, 0] += origin[0] + 1.0
+    d["pos"][:, 1] += origin[1] + 1.0
+    return np.concatenate([scenes.ground(), d]), lo, hi
+
+
+def worker(rank, world_size, port, steps, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    from oracle import oracle
+    descs, lo, hi = scene_for_tile(rank, world_size)
+    w = oracle.OracleWorld(max_bodies=1024)
+    w.add_batch(descs)
+    ex = tiles.GhostExchange(w, rank, world_size, lo, hi, margin=1.5, dist=dist, device=torch.device("cpu"), cap=512)
+    log = []
+    for _ in range(steps):
+        ex.exchange()
+        w.step(DT)
+        log.append((ex.last_exported, ex.last_imported))
+    st = w.read_states(0, 256)
+    np.save(os.path.join(out_dir, f"tile{rank}.npy"), st)
+    np.save(os.path.join(out_dir, f"log{rank}.npy"), np.array(log))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tile_grid_and_bounds():
+    assert tiles.tile_grid(1) == (1, 1) and tiles.tile_grid(2) == (2, 1) and tiles.tile_grid(4) == (2, 2) and tiles.tile_grid(8) == (4, 2)
+    lo, hi, org = tiles.tile_bounds(1, 2, 150.0, 150.0)
+    assert lo[0] == 150.0 and hi[0] > 1e8 and org[0] == 150.0
+    lo, hi, org = tiles.tile_bounds(5, 8, 150.0, 150.0)     # ix=1, iy=1
+    assert (lo[0], hi[0], lo[1]) == (150.0, 300.0, 150.0)
+
+
+def test_select_ghosts_filters_by_region():
+    recs = np.zeros(4, dtype=abi.ghost_dtype)
+    recs["pos"] = [[149.5, 10, 1], [100, 10, 1], [151, 10, 1], [149.5, 400, 1]]
+    lo, hi, _ = tiles.tile_bounds(1, 2, 150.0, 150.0)
+    sel = tiles.select_ghosts(recs, lo, hi, margin=2.0)
+    assert len(sel) == 3 and 100.0 not in sel["pos"][:, 0]
+
+
+@pytest.mark.timeout(300)
+def test_two_tiles_gloo_ghost_exchange(tmp_path, oracle):
+    steps = 150
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(worker, args=(2, port, steps, str(tmp_path)), nprocs=2, join=True)
+    t0, t1 = np.load(tmp_path / "tile0.npy"), np.load(tmp_path / "tile1.npy")
+    l0, l1 = np.load(tmp_path / "log0.npy"), np.load(tmp_path / "log1.npy")
+    # every step each tile exported its border bodies and imported the other tile's
+    assert l0[:, 0].min() > 0 and l1[:, 0].min() > 0
+    assert np.array_equal(l0[:, 1] > 0, l1[:, 0] > 0)
+    # bodies 1..72 are the tile's own; ghosts (kinematic copies) sit above them in the id space
+    own0, own1 = t0[1:73], t1[1:73]
+    assert np.all(own0["id"] != abi.INVALID_ID) and np.all(own1["id"] != abi.INVALID_ID)
+    # the piles settled on the ground on both sides of the border: nothing fell through or exploded
+    for own in (own0, own1):
+        assert own["pos"][:, 2].min() > 0.4 and own["pos"][:, 2].max() < 4.0
+        assert np.abs(own["lin_vel"]).max() < 1.0
+    # ghosts present in tile 0 mirror bodies tile 1 owns (same pose within one step of motion)
+    ghosts0 = t0[73:]
+    ghosts0 = ghosts0[ghosts0["id"] != abi.INVALID_ID]
+    assert len(ghosts0) > 0
+    dmin = np.min(np.linalg.norm(ghosts0["pos"][:, None, :] - own1["pos"][None, :, :], axis=2), axis=1)
+    assert dmin.max() < 0.05
+    # no deep interpenetration across the border: closest centre distance between the two tiles' own boxes
+    dd = np.linalg.norm(own0["pos"][:, None, :] - own1["pos"][None, :, :], axis=2)
+    assert dd.min() > 0.9
