@@ -103,6 +103,20 @@ struct BodyCmd {
 	uint32_t flags;
 };
 
+// Per-step scalars, device resident: kernels read them through DV::sp so that the launch arguments of a step never
+// change and the whole step can be replayed as a hipGraph.  The host writes the pinned copy, a copy node uploads it.
+struct StepParams {
+	float    dt;
+	uint32_t n_slots;          // high-water body slot count
+	uint32_t n_large;
+	float    cell_size;        // requested broad-phase cell edge = bp_rmax + speculative margin (the grid may coarsen it)
+	float    bp_rmax;          // largest bounding radius of the small bodies
+	int      water_enabled; float water_z;
+	int      contact_events;
+	uint32_t parity;           // which of DV::ca[] is the current constraint buffer (the other one is the contact cache)
+	uint32_t pad[7];
+};
+
 // Constraint (contact manifold) SoA, double buffered (current step / previous step = contact cache).
 struct ConstraintArrays {
 	uint2*    ab;          // body ids, a < b
@@ -118,7 +132,7 @@ struct ConstraintArrays {
 };
 
 struct DV {
-	uint32_t n_slots;          // high-water body slot count
+	const StepParams* sp;
 	uint32_t cap_bodies, cap_pairs, cap_manifolds;
 	// bodies
 	float4* pos_im;            // position xyz, inverse mass w (0 unless dynamic)
@@ -143,8 +157,6 @@ struct DV {
 	                           //   [world inv inertia xx,xy,xz,-][yy,yz,zz,-]; velocities live here during the velocity solve
 	// broad phase
 	uint32_t table_size;       // power of two
-	float    cell_size;        // requested cell edge = bp_rmax + speculative margin (the grid may coarsen it)
-	float    bp_rmax;          // largest bounding radius of the small bodies: a body's partners have centres within AABB +- (bp_rmax + margin)
 	uint32_t* cell_hash;       // per body
 	int4*     cell_xyz;        // per body
 	uint32_t* cell_count;      // per bucket (+1)
@@ -155,7 +167,7 @@ struct DV {
 	float4*   sorted_min;      // cell-sorted copy: aabb min xyz, flags (bits) w
 	float4*   sorted_max;      // cell-sorted copy: aabb max xyz, body id (bits) w
 	struct BpGrid* grid;       // per-step dense grid parameters (device)
-	const uint32_t* large_ids; uint32_t n_large;
+	const uint32_t* large_ids;
 	uint2*    pairs;
 	// narrow phase output (manifolds, unordered)
 	uint2*    man_ab;
@@ -166,8 +178,7 @@ struct DV {
 	uint32_t* ulist[2];        // worklists of still-uncoloured manifolds, double buffered by round parity
 	uint64_t* man_prio;
 	// constraints
-	ConstraintArrays cur, prev;
-	uint32_t  n_prev;
+	ConstraintArrays ca[2];    // [sp->parity] = this step's constraints, the other = previous step's (contact cache)
 	uint64_t* ht_keys; uint32_t* ht_vals; uint32_t ht_size;   // contact cache: pair key -> prev slot
 	uint32_t* cstarts;         // [SGP_MAX_COLOURS + 1] first constraint slot of every colour (device-side exclusive scan)
 	// counters / events
@@ -175,43 +186,43 @@ struct DV {
 	EventCounters* evc;
 	uint32_t* ev_activated; uint32_t* ev_deactivated; uint32_t* ev_water;
 	sgp_contact_event* ev_contacts_added; sgp_contact_event* ev_contacts_persisted; uint32_t cap_contact_events;
-	int contact_events;
-	// settings
+	// settings (fixed after world creation)
 	sgp_settings st;
 	float gx, gy, gz;
-	int water_enabled; float water_z;
 };
 
 // ---- launch wrappers (defined in sgp_kernels.hip) ---------------------------------------------------------------
-void launch_apply_forces(const DV& d, float dt, hipStream_t s);
-void launch_bp_bounds(const DV& d, hipStream_t s);
-void launch_bp_cell(const DV& d, hipStream_t s);
+// `nb` = number of body slots the per-body grids must cover (a bucketed upper bound of StepParams::n_slots)
+void launch_step_begin(const DV& d, hipStream_t s);
+void launch_apply_forces(const DV& d, uint32_t nb, hipStream_t s);
+void launch_bp_bounds(const DV& d, uint32_t nb, hipStream_t s);
+void launch_bp_cell(const DV& d, uint32_t nb, hipStream_t s);
 void launch_bp_scan(const DV& d, hipStream_t s);
-void launch_bp_scatter(const DV& d, hipStream_t s);
+void launch_bp_scatter(const DV& d, uint32_t nb, hipStream_t s);
 void launch_bp_pairs(const DV& d, hipStream_t s);
-void launch_bp_large(const DV& d, hipStream_t s);
+void launch_bp_large(const DV& d, uint32_t nb, hipStream_t s);
 void launch_narrowphase(const DV& d, uint32_t n_pairs_upper, hipStream_t s);
-void launch_wake(const DV& d, hipStream_t s);
-void launch_prep_bodies(const DV& d, hipStream_t s);
+void launch_wake(const DV& d, uint32_t nb, hipStream_t s);
+void launch_prep_bodies(const DV& d, uint32_t nb, hipStream_t s);
 void launch_colour_claim(const DV& d, uint32_t n_man, uint32_t round, hipStream_t s);
 void launch_colour_commit(const DV& d, uint32_t n_man, uint32_t round, hipStream_t s);
 void launch_colour_count(const DV& d, uint32_t n_man, hipStream_t s);
 void launch_colour_finish(const DV& d, uint32_t first_round, hipStream_t s);
-void launch_setup(const DV& d, uint32_t n_man, float dt, hipStream_t s);
+void launch_setup(const DV& d, uint32_t n_man, hipStream_t s);
 // mode: 0 warm start, 1 velocity iteration, 2 position iteration.  est = expected constraints of that colour (grid sizing only)
 void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStream_t s);
 void launch_solve_tail(const DV& d, int first_colour, int mode, hipStream_t s);
-void launch_integrate_pose(const DV& d, float dt, hipStream_t s);
-void launch_finalize(const DV& d, float dt, hipStream_t s);
+void launch_integrate_pose(const DV& d, uint32_t nb, hipStream_t s);
+void launch_finalize(const DV& d, uint32_t nb, hipStream_t s);
 void launch_island_hook(const DV& d, uint32_t n_con, hipStream_t s);
 void launch_island_flag(const DV& d, uint32_t n_con, hipStream_t s);
-void launch_sleep_apply(const DV& d, hipStream_t s);
-void launch_buoyancy(const DV& d, float dt, hipStream_t s);
+void launch_sleep_apply(const DV& d, uint32_t nb, hipStream_t s);
+void launch_buoyancy(const DV& d, uint32_t nb, hipStream_t s);
 void launch_cache_build(const DV& d, uint32_t n_con, hipStream_t s);
 void launch_contact_events(const DV& d, uint32_t n_man, hipStream_t s);
 void launch_apply_cmds(const DV& d, const BodyCmd* cmds, const uint32_t* run_start, uint32_t n_runs, hipStream_t s);
 void launch_gather_states(const DV& d, const uint32_t* ids, uint32_t first, uint32_t n, sgp_body_state* out, hipStream_t s);
-void launch_gather_active(const DV& d, sgp_body_state* out, uint32_t cap, hipStream_t s);
-void launch_dump_constraints(const DV& d, uint32_t n_con, void* out, uint32_t cap, hipStream_t s);
+void launch_gather_active(const DV& d, uint32_t nb, sgp_body_state* out, uint32_t cap, hipStream_t s);
+void launch_dump_constraints(const DV& d, uint32_t which, uint32_t n_con, void* out, uint32_t cap, hipStream_t s);
 void launch_raycast(const DV& d, const sgp_ray* rays, uint32_t n, sgp_hit* hits, hipStream_t s);
-void launch_export_boundary(const DV& d, float3 lo, float3 hi, float margin, sgp_ghost_record* out, uint32_t cap, uint32_t* count, hipStream_t s);
+void launch_export_boundary(const DV& d, uint32_t nb, float3 lo, float3 hi, float margin, sgp_ghost_record* out, uint32_t cap, uint32_t* count, hipStream_t s);

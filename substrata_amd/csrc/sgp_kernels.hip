@@ -18,6 +18,9 @@
 // ---------------------------------------------------------------------------------------------------------------
 // small helpers
 
+SGP_DEV const ConstraintArrays& CUR(const DV& d) { return d.ca[d.sp->parity & 1]; }
+SGP_DEV const ConstraintArrays& PRV(const DV& d) { return d.ca[(d.sp->parity & 1) ^ 1]; }
+
 SGP_DEV uint32_t f_motion(uint32_t f) { return f & BF_MOTION_MASK; }
 SGP_DEV uint32_t f_layer(uint32_t f) { return (f & BF_LAYER_MASK) >> BF_LAYER_SHIFT; }
 SGP_DEV uint32_t f_shape(uint32_t f) { return (f & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT; }
@@ -95,13 +98,27 @@ SGP_DEV void push_event(uint32_t* list, uint32_t* counter, uint32_t cap, uint32_
 	if (k < cap) list[k] = id;
 }
 
+// first launch of a step: reset the per-step counters and the grid bounds
+__global__ void __launch_bounds__(TPB) k_step_begin(DV d)
+{
+	uint32_t* c = (uint32_t*)d.ctr;
+	for (uint32_t i = threadIdx.x; i < sizeof(StepCounters) / 4; i += TPB) c[i] = 0;
+	if (threadIdx.x == 0) {
+		BpGrid g;
+		g.min_x = g.min_y = g.min_z = 0x7FFFFFFF; g.max_x = g.max_y = g.max_z = (int)0x80000000;
+		g.ox = g.oy = g.oz = 0.0f; g.inv_cell = 1.0f; g.cell = 1.0f; g.nx = g.ny = g.nz = 1; g.n_cells = 1;
+		*d.grid = g;
+	}
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // K8a: forces, gravity, damping, velocity clamps (JobApplyGravity)
 
-__global__ void __launch_bounds__(TPB) k_apply_forces(DV d, float dt)
+__global__ void __launch_bounds__(TPB) k_apply_forces(DV d)
 {
+	const float dt = d.sp->dt;
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-	if (i >= d.n_slots) return;
+	if (i >= d.sp->n_slots) return;
 	const uint32_t f = d.flags[i];
 	if (!f_movable(f)) return;
 	const float4 pim = d.pos_im[i], lv4 = d.linv[i], av4 = d.angv[i], F4v = d.force[i], T4 = d.torque[i], II = d.inv_inertia[i];
@@ -136,7 +153,7 @@ __global__ void __launch_bounds__(TPB) k_bp_bounds(DV d)
 {
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
 	float mnx = 3.0e38f, mny = 3.0e38f, mnz = 3.0e38f, mxx = -3.0e38f, mxy = -3.0e38f, mxz = -3.0e38f;
-	if (i < d.n_slots) {
+	if (i < d.sp->n_slots) {
 		const uint32_t f = d.flags[i];
 		if ((f & BF_ALIVE) && !(f & BF_LARGE)) {
 			const float4 mn = d.aabb_min[i], mx = d.aabb_max[i];
@@ -164,7 +181,7 @@ __global__ void k_bp_grid_params(DV d)
 {
 	if (threadIdx.x != 0 || blockIdx.x != 0) return;
 	BpGrid g = *d.grid;
-	float cell = d.cell_size;
+	float cell = d.sp->cell_size;
 	if (g.min_x > g.max_x) { g.ox = g.oy = g.oz = 0.0f; g.nx = g.ny = g.nz = 1; }
 	else {
 		const float x0 = ordered_to_float(g.min_x), y0 = ordered_to_float(g.min_y), z0 = ordered_to_float(g.min_z);
@@ -186,7 +203,7 @@ __global__ void k_bp_grid_params(DV d)
 __global__ void __launch_bounds__(TPB) k_bp_cell(DV d)
 {
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-	if (i >= d.n_slots) return;
+	if (i >= d.sp->n_slots) return;
 	const uint32_t f = d.flags[i];
 	uint32_t h = 0xFFFFFFFFu;
 	if ((f & BF_ALIVE) && !(f & BF_LARGE)) {
@@ -262,7 +279,7 @@ __global__ void __launch_bounds__(TPB) k_scan_add(uint32_t* out, const uint32_t*
 __global__ void __launch_bounds__(TPB) k_bp_scatter(DV d)
 {
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-	if (i >= d.n_slots) return;
+	if (i >= d.sp->n_slots) return;
 	const uint32_t h = d.cell_hash[i];
 	if (h == 0xFFFFFFFFu) return;
 	const uint32_t slot = d.cell_start[h] + atomicAdd(&d.cell_fill[h], 1u);
@@ -360,7 +377,7 @@ __global__ void __launch_bounds__(TPB) k_bp_pairs(DV d)
 	const int tnx = (g.nx + BP_TILE - 1) / BP_TILE, tny = (g.ny + BP_TILE - 1) / BP_TILE, tnz = (g.nz + BP_TILE - 1) / BP_TILE;
 	const uint32_t n_tiles = (uint32_t)tnx * (uint32_t)tny * (uint32_t)tnz;
 	const float spec = d.st.speculative_contact_distance;
-	const float reach = d.bp_rmax + spec;
+	const float reach = d.sp->bp_rmax + spec;
 	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
 		const int tx = (int)(tile % (uint32_t)tnx), ty = (int)((tile / (uint32_t)tnx) % (uint32_t)tny), tz = (int)(tile / ((uint32_t)tnx * (uint32_t)tny));
 		const int x0 = tx * BP_TILE - BP_H, y0 = ty * BP_TILE - BP_H, z0 = tz * BP_TILE - BP_H;   // halo origin (cell coords)
@@ -467,11 +484,11 @@ __global__ void __launch_bounds__(TPB) k_bp_pairs(DV d)
 __global__ void __launch_bounds__(TPB) k_bp_large(DV d)
 {
 	const uint32_t j = blockIdx.x * TPB + threadIdx.x;
-	if (j >= d.n_slots) return;
+	if (j >= d.sp->n_slots) return;
 	const uint32_t fj = d.flags[j];
 	if (!(fj & BF_ALIVE)) return;
 	const float4 mnj = d.aabb_min[j], mxj = d.aabb_max[j];
-	for (uint32_t l = 0; l < d.n_large; ++l) {
+	for (uint32_t l = 0; l < d.sp->n_large; ++l) {
 		const uint32_t i = d.large_ids[l];
 		if (i == j) continue;
 		const uint32_t fi = d.flags[i];
@@ -525,7 +542,7 @@ __global__ void __launch_bounds__(TPB) k_narrowphase(DV d)
 __global__ void __launch_bounds__(TPB) k_wake(DV d)
 {
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-	if (i >= d.n_slots) return;
+	if (i >= d.sp->n_slots) return;
 	uint32_t f = d.flags[i];
 	if (!(f & BF_WAKE)) return;
 	f &= ~BF_WAKE;
@@ -543,7 +560,7 @@ __global__ void __launch_bounds__(TPB) k_wake(DV d)
 __global__ void __launch_bounds__(TPB) k_prep_bodies(DV d)
 {
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-	if (i >= d.n_slots) return;
+	if (i >= d.sp->n_slots) return;
 	const uint32_t f = d.flags[i];
 	float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f), w = v, a = v, b = v;
 	if ((f & BF_ALIVE) && f_motion(f) != SGP_MOTION_STATIC) {
@@ -740,8 +757,9 @@ SGP_DEV uint32_t cache_find(const DV& d, uint64_t key)
 	return 0xFFFFFFFFu;
 }
 
-__global__ void __launch_bounds__(TPB) k_setup(DV d, float dt)
+__global__ void __launch_bounds__(TPB) k_setup(DV d)
 {
+	const float dt = d.sp->dt;
 	__shared__ uint32_t hist[SGP_MAX_COLOURS];
 	__shared__ uint32_t base[SGP_MAX_COLOURS];
 	const uint32_t n = min(d.ctr->n_manifolds, d.cap_manifolds);
@@ -780,12 +798,12 @@ __global__ void __launch_bounds__(TPB) k_setup(DV d, float dt)
 		const uint32_t fslot = cache_find(d, key);
 		const uint32_t pslot = d.st.warm_start ? fslot : 0xFFFFFFFFu;
 		int pnp = 0;
-		if (pslot != 0xFFFFFFFFu) pnp = d.prev.np_col[pslot] & 0xFF;
+		if (pslot != 0xFFFFFFFFu) pnp = PRV(d).np_col[pslot] & 0xFF;
 		const v3 g = V3(d.gx, d.gy, d.gz);
-		d.cur.ab[slot] = ab;
-		d.cur.n_fric[slot] = F4(nrm, friction);
-		d.cur.key[slot] = key;
-		d.cur.np_col[slot] = np | (col << 8) | ((fslot != 0xFFFFFFFFu ? 1 : 0) << 16);
+		CUR(d).ab[slot] = ab;
+		CUR(d).n_fric[slot] = F4(nrm, friction);
+		CUR(d).key[slot] = key;
+		CUR(d).np_col[slot] = np | (col << 8) | ((fslot != 0xFFFFFFFFu ? 1 : 0) << 16);
 		for (int i = 0; i < 4; ++i) {
 			if (i >= np) break;
 			const v3 p1 = V3(d.man_p1[i][m]), p2 = V3(d.man_p2[i][m]);
@@ -794,10 +812,10 @@ __global__ void __launch_bounds__(TPB) k_setup(DV d, float dt)
 			float lam_n = 0.0f, lam_t1 = 0.0f, lam_t2 = 0.0f;
 			for (int j = 0; j < 4; ++j) {
 				if (j >= pnp) break;
-				const v3 c1 = V3(d.prev.loc1[j][pslot]), c2 = V3(d.prev.loc2[j][pslot]);
+				const v3 c1 = V3(PRV(d).loc1[j][pslot]), c2 = V3(PRV(d).loc2[j][pslot]);
 				if (v3_len_sq(v3_sub(local1, c1)) < d.st.contact_point_preserve_lambda_max_dist_sq &&
 				    v3_len_sq(v3_sub(local2, c2)) < d.st.contact_point_preserve_lambda_max_dist_sq) {
-					const float4 pl = d.prev.lam[j][pslot];
+					const float4 pl = PRV(d).lam[j][pslot];
 					lam_n = pl.x; lam_t1 = pl.y; lam_t2 = pl.z;
 					break;
 				}
@@ -822,12 +840,12 @@ __global__ void __launch_bounds__(TPB) k_setup(DV d, float dt)
 			const float eff_n = axis_eff_mass(im1, I1, r1, im2, I2, r2, nrm);
 			const float eff_t1 = axis_eff_mass(im1, I1, r1, im2, I2, r2, t1);
 			const float eff_t2 = axis_eff_mass(im1, I1, r1, im2, I2, r2, t2);
-			d.cur.r1b[i][slot] = F4(r1, bias);
-			d.cur.r2e[i][slot] = F4(r2, eff_n);
-			d.cur.lam[i][slot] = make_float4(lam_n, lam_t1, lam_t2, 0.0f);
-			d.cur.efft[i][slot] = make_float2(eff_t1, eff_t2);
-			d.cur.loc1[i][slot] = F4(local1, 0.0f);
-			d.cur.loc2[i][slot] = F4(local2, 0.0f);
+			CUR(d).r1b[i][slot] = F4(r1, bias);
+			CUR(d).r2e[i][slot] = F4(r2, eff_n);
+			CUR(d).lam[i][slot] = make_float4(lam_n, lam_t1, lam_t2, 0.0f);
+			CUR(d).efft[i][slot] = make_float2(eff_t1, eff_t2);
+			CUR(d).loc1[i][slot] = F4(local1, 0.0f);
+			CUR(d).loc2[i][slot] = F4(local2, 0.0f);
 		}
 	}
 }
@@ -858,10 +876,10 @@ struct PairCtx { uint2 ab; float im1, im2; sym33 I1, I2; BodyVel A, B; v3 n, t1,
 
 SGP_DEV void load_pair(const DV& d, uint32_t slot, PairCtx& c)
 {
-	c.ab = d.cur.ab[slot];
-	const float4 nf = d.cur.n_fric[slot];
+	c.ab = CUR(d).ab[slot];
+	const float4 nf = CUR(d).n_fric[slot];
 	c.n = V3(nf); c.friction = nf.w;
-	c.np = d.cur.np_col[slot] & 0xFF;
+	c.np = CUR(d).np_col[slot] & 0xFF;
 	const float4* pa = d.sbody + 4 * (size_t)c.ab.x;
 	const float4* pb = d.sbody + 4 * (size_t)c.ab.y;
 	const float4 va = pa[0], wa = pa[1], a0 = pa[2], a1 = pa[3];
@@ -888,8 +906,8 @@ SGP_DEV void warm_start_one(const DV& d, uint32_t slot)
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
 		if (i < c.np) {
-			const v3 r1 = V3(d.cur.r1b[i][slot]), r2 = V3(d.cur.r2e[i][slot]);
-			const float4 l = d.cur.lam[i][slot];
+			const v3 r1 = V3(CUR(d).r1b[i][slot]), r2 = V3(CUR(d).r2e[i][slot]);
+			const float4 l = CUR(d).lam[i][slot];
 			if (c.friction > 0.0f) {
 				apply_impulse(c.A, c.B, c.im1, c.I1, c.im2, c.I2, r1, r2, c.t1, l.y);
 				apply_impulse(c.A, c.B, c.im1, c.I1, c.im2, c.I2, r1, r2, c.t2, l.z);
@@ -910,7 +928,7 @@ SGP_DEV void solve_velocity_one(const DV& d, uint32_t slot)
 	float4 r1b[4], r2e[4], lam[4]; float2 et[4];
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
-		if (i < c.np) { r1b[i] = d.cur.r1b[i][slot]; r2e[i] = d.cur.r2e[i][slot]; lam[i] = d.cur.lam[i][slot]; et[i] = d.cur.efft[i][slot]; }
+		if (i < c.np) { r1b[i] = CUR(d).r1b[i][slot]; r2e[i] = CUR(d).r2e[i][slot]; lam[i] = CUR(d).lam[i][slot]; et[i] = CUR(d).efft[i][slot]; }
 	}
 	c.t1 = v3_normalized_perpendicular(c.n);
 	c.t2 = v3_cross(c.n, c.t1);
@@ -941,16 +959,16 @@ SGP_DEV void solve_velocity_one(const DV& d, uint32_t slot)
 		}
 	}
 #pragma unroll
-	for (int i = 0; i < 4; ++i) { if (i < c.np) d.cur.lam[i][slot] = lam[i]; }
+	for (int i = 0; i < 4; ++i) { if (i < c.np) CUR(d).lam[i][slot] = lam[i]; }
 	store_pair_vel(d, c);
 }
 
 SGP_DEV void solve_position_one(const DV& d, uint32_t slot)
 {
-	const uint2 ab = d.cur.ab[slot];
-	const float4 nf = d.cur.n_fric[slot];
+	const uint2 ab = CUR(d).ab[slot];
+	const float4 nf = CUR(d).n_fric[slot];
 	const v3 nrm = V3(nf);
-	const int np = d.cur.np_col[slot] & 0xFF;
+	const int np = CUR(d).np_col[slot] & 0xFF;
 	const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
 	float4 pa = d.pos_im[ab.x], pb = d.pos_im[ab.y];
 	const float im1 = f_movable(fa) ? pa.w : 0.0f, im2 = f_movable(fb) ? pb.w : 0.0f;
@@ -962,8 +980,8 @@ SGP_DEV void solve_position_one(const DV& d, uint32_t slot)
 	for (int i = 0; i < 4; ++i) {
 		if (i >= np) continue;
 		const m33 RA = quat_to_m33(qa), RB = quat_to_m33(qb);
-		const v3 p1 = v3_add(posA, m33_mul(RA, V3(d.cur.loc1[i][slot])));
-		const v3 p2 = v3_add(posB, m33_mul(RB, V3(d.cur.loc2[i][slot])));
+		const v3 p1 = v3_add(posA, m33_mul(RA, V3(CUR(d).loc1[i][slot])));
+		const v3 p2 = v3_add(posB, m33_mul(RB, V3(CUR(d).loc2[i][slot])));
 		float sep = v3_dot(v3_sub(p2, p1), nrm) + d.st.penetration_slop;
 		if (sep < 0.0f) {
 			sep = fmaxf(sep, -d.st.max_penetration_distance);
@@ -1026,7 +1044,7 @@ __global__ void __launch_bounds__(512) k_solve_tail(DV d, int first_colour, int 
 	for (uint32_t it = 0; it < count; ++it) {
 		uint64_t best = ~0ull; uint32_t bslot = first;
 		for (uint32_t k = 0; k < count; ++k) {
-			const uint64_t pr = sgp_mix64(d.cur.key[first + k]);
+			const uint64_t pr = sgp_mix64(CUR(d).key[first + k]);
 			if ((!have_last || pr > last) && pr <= best) { best = pr; bslot = first + k; }
 		}
 		last = best; have_last = true;
@@ -1039,10 +1057,11 @@ __global__ void __launch_bounds__(512) k_solve_tail(DV d, int first_colour, int 
 // ---------------------------------------------------------------------------------------------------------------
 // K8b: THE BODY-ARRAY SWEEP.  x += v dt, q <- normalize(rot(w dt) * q) for every active non-static body.
 
-__global__ void __launch_bounds__(TPB) k_integrate_pose(DV d, float dt)
+__global__ void __launch_bounds__(TPB) k_integrate_pose(DV d)
 {
+	const float dt = d.sp->dt;
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-	if (i >= d.n_slots) return;
+	if (i >= d.sp->n_slots) return;
 	const uint32_t f = d.flags[i];
 	if ((f & (BF_ALIVE | BF_ACTIVE)) != (BF_ALIVE | BF_ACTIVE) || f_motion(f) == SGP_MOTION_STATIC) return;
 	// the solved velocities live in the solver record
@@ -1065,10 +1084,11 @@ __global__ void __launch_bounds__(TPB) k_integrate_pose(DV d, float dt)
 // ---------------------------------------------------------------------------------------------------------------
 // K1 + K9: AABB refresh, sleep test spheres (Body::UpdateSleepStateInternal), island bookkeeping
 
-__global__ void __launch_bounds__(TPB) k_finalize(DV d, float dt)
+__global__ void __launch_bounds__(TPB) k_finalize(DV d)
 {
+	const float dt = d.sp->dt;
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-	if (i >= d.n_slots) return;
+	if (i >= d.sp->n_slots) return;
 	d.island[i] = i;
 	d.island_awake[i] = 0;
 	uint32_t f = d.flags[i];
@@ -1132,7 +1152,7 @@ __global__ void __launch_bounds__(TPB) k_island_hook(DV d)
 {
 	const uint32_t n_con = d.ctr->n_constraints;
 	for (uint32_t k = blockIdx.x * TPB + threadIdx.x; k < n_con; k += gridDim.x * TPB) {
-	const uint2 ab = d.cur.ab[k];
+	const uint2 ab = CUR(d).ab[k];
 	const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
 	if (!f_movable(fa) || !f_movable(fb)) continue;
 	if (!(fa & BF_CAN_SLEEP) || !(fb & BF_CAN_SLEEP)) continue;
@@ -1150,7 +1170,7 @@ __global__ void __launch_bounds__(TPB) k_island_flag(DV d)
 {
 	const uint32_t n_con = d.ctr->n_constraints;
 	for (uint32_t k = blockIdx.x * TPB + threadIdx.x; k < n_con; k += gridDim.x * TPB) {
-		const uint2 ab = d.cur.ab[k];
+		const uint2 ab = CUR(d).ab[k];
 		const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
 		if (!f_movable(fa) || !f_movable(fb)) continue;
 		const bool sa = fa & BF_CAN_SLEEP, sb = fb & BF_CAN_SLEEP;
@@ -1162,7 +1182,7 @@ __global__ void __launch_bounds__(TPB) k_island_flag(DV d)
 __global__ void __launch_bounds__(TPB) k_sleep_apply(DV d)
 {
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-	if (i >= d.n_slots) return;
+	if (i >= d.sp->n_slots) return;
 	uint32_t f = d.flags[i];
 	if (!(f & BF_ALIVE)) return;
 	if (f_movable(f)) {
@@ -1247,14 +1267,15 @@ SGP_DEV void box_submerged(v3 h, m33 R, float posz, float wz, float* vol_out, v3
 	*centroid_out = vol > 1.0e-12f ? m33_mul(R, v3_scale(cen, 1.0f / vol)) : V3(0.0f, 0.0f, 0.0f);
 }
 
-__global__ void __launch_bounds__(TPB) k_buoyancy(DV d, float dt)
+__global__ void __launch_bounds__(TPB) k_buoyancy(DV d)
 {
+	const float dt = d.sp->dt;
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-	if (i >= d.n_slots) return;
+	if (i >= d.sp->n_slots) return;
 	uint32_t f = d.flags[i];
 	if (!f_movable(f)) return;                                                       // :1377
 	const float4 mn = d.aabb_min[i], mx = d.aabb_max[i];
-	if (mn.z < d.water_z) {                                                          // :1379
+	if (mn.z < d.sp->water_z) {                                                          // :1379
 		const float fluid_density = 1020.0f;                                         // :1381
 		const uint32_t type = f_shape(f);
 		const float4 sh = d.shape[i];
@@ -1263,17 +1284,17 @@ __global__ void __launch_bounds__(TPB) k_buoyancy(DV d, float dt)
 		const m33 R = quat_to_m33(Q4(d.rot[i]));
 		const float total = shape_volume(type, sh);
 		float sub; v3 rc;
-		if (type == SGP_SHAPE_BOX) box_submerged(V3(sh.x, sh.y, sh.z), R, pos.z, d.water_z, &sub, &rc);
+		if (type == SGP_SHAPE_BOX) box_submerged(V3(sh.x, sh.y, sh.z), R, pos.z, d.sp->water_z, &sub, &rc);
 		else if (type == SGP_SHAPE_SPHERE) {
 			const float r = sh.x;
-			const float h = clampf((d.water_z - pos.z) + r, 0.0f, 2.0f * r);
+			const float h = clampf((d.sp->water_z - pos.z) + r, 0.0f, 2.0f * r);
 			const float pi = 3.14159265358979323846f;
 			sub = pi * h * h * (3.0f * r - h) / 3.0f;
 			float cz = 0.0f;
 			if (h > 0.0f) { const float k = 2.0f * r - h; cz = -(3.0f * k * k) / (4.0f * (3.0f * r - h)); }
 			rc = V3(0.0f, 0.0f, cz);
 		} else {
-			const float fr = clampf((d.water_z - mn.z) / (mx.z - mn.z), 0.0f, 1.0f);
+			const float fr = clampf((d.sp->water_z - mn.z) / (mx.z - mn.z), 0.0f, 1.0f);
 			sub = total * fr;
 			rc = V3(0.0f, 0.0f, (mn.z + 0.5f * fr * (mx.z - mn.z)) - pos.z);
 		}
@@ -1330,7 +1351,7 @@ __global__ void __launch_bounds__(TPB) k_cache_build(DV d)
 	const uint32_t n_con = d.ctr->n_constraints;
 	const uint32_t mask = d.ht_size - 1;
 	for (uint32_t k = blockIdx.x * TPB + threadIdx.x; k < n_con; k += gridDim.x * TPB) {
-		const uint64_t key = d.cur.key[k];
+		const uint64_t key = CUR(d).key[k];
 		uint32_t h = ht_hash(key, mask);
 		for (uint32_t probe = 0; probe < d.ht_size; ++probe) {
 			const unsigned long long old = atomicCAS((unsigned long long*)&d.ht_keys[h], ~0ull, (unsigned long long)key);
@@ -1502,7 +1523,7 @@ __global__ void __launch_bounds__(TPB) k_gather_states(DV d, const uint32_t* ids
 __global__ void __launch_bounds__(TPB) k_gather_active(DV d, sgp_body_state* out, uint32_t cap)
 {
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-	if (i >= d.n_slots) return;
+	if (i >= d.sp->n_slots) return;
 	const uint32_t f = d.flags[i];
 	if ((f & (BF_ALIVE | BF_ACTIVE)) != (BF_ALIVE | BF_ACTIVE)) return;
 	const uint32_t k = atomicAdd(&d.ctr->n_read_active, 1u);
@@ -1511,19 +1532,19 @@ __global__ void __launch_bounds__(TPB) k_gather_active(DV d, sgp_body_state* out
 
 struct ConstraintDumpRec { uint32_t a, b; int32_t colour; int32_t np; float n[3]; float lam_n[4]; float lam_t1[4]; float lam_t2[4]; float bias[4]; };
 
-__global__ void __launch_bounds__(TPB) k_dump_constraints(DV d, uint32_t n_con, ConstraintDumpRec* out, uint32_t cap)
+__global__ void __launch_bounds__(TPB) k_dump_constraints(DV d, uint32_t which, uint32_t n_con, ConstraintDumpRec* out, uint32_t cap)
 {
-	// dumps the PREVIOUS buffer: after a step the solved constraints have been swapped into `prev`
 	const uint32_t k = blockIdx.x * TPB + threadIdx.x;
 	if (k >= n_con || k >= cap) return;
+	const ConstraintArrays& ca = d.ca[which & 1];
 	ConstraintDumpRec r;
-	const uint2 ab = d.prev.ab[k];
-	const int nc = d.prev.np_col[k];
-	const float4 nf = d.prev.n_fric[k];
+	const uint2 ab = ca.ab[k];
+	const int nc = ca.np_col[k];
+	const float4 nf = ca.n_fric[k];
 	r.a = ab.x; r.b = ab.y; r.colour = (nc >> 8) & 0xFF; r.np = nc & 0xFF;
 	r.n[0] = nf.x; r.n[1] = nf.y; r.n[2] = nf.z;
 	for (int i = 0; i < 4; ++i) {
-		if (i < r.np) { const float4 l = d.prev.lam[i][k]; r.lam_n[i] = l.x; r.lam_t1[i] = l.y; r.lam_t2[i] = l.z; r.bias[i] = d.prev.r1b[i][k].w; }
+		if (i < r.np) { const float4 l = ca.lam[i][k]; r.lam_n[i] = l.x; r.lam_t1[i] = l.y; r.lam_t2[i] = l.z; r.bias[i] = ca.r1b[i][k].w; }
 		else { r.lam_n[i] = 0; r.lam_t1[i] = 0; r.lam_t2[i] = 0; r.bias[i] = 0; }
 	}
 	out[k] = r;
@@ -1603,7 +1624,7 @@ __global__ void __launch_bounds__(64) k_raycast(DV d, const sgp_ray* rays, uint3
 	const sgp_ray ry = rays[k];
 	const v3 o = V3(ry.origin[0], ry.origin[1], ry.origin[2]), dir = V3(ry.dir[0], ry.dir[1], ry.dir[2]);
 	float best = ry.max_t; uint32_t bid = SGP_INVALID_ID; v3 bn = V3(0.0f, 0.0f, 0.0f);
-	for (uint32_t i = 0; i < d.n_slots; ++i) {
+	for (uint32_t i = 0; i < d.sp->n_slots; ++i) {
 		const uint32_t f = d.flags[i];
 		if (!(f & BF_ALIVE) || i == ry.ignore_id) continue;
 		const uint32_t layer = f_layer(f);
@@ -1638,7 +1659,7 @@ __global__ void __launch_bounds__(64) k_raycast(DV d, const sgp_ray* rays, uint3
 __global__ void __launch_bounds__(TPB) k_export_boundary(DV d, float3 lo, float3 hi, float margin, sgp_ghost_record* out, uint32_t cap, uint32_t* count)
 {
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-	if (i >= d.n_slots) return;
+	if (i >= d.sp->n_slots) return;
 	const uint32_t f = d.flags[i];
 	if (!(f & BF_ALIVE) || (f & (BF_GHOST | BF_LARGE)) || f_motion(f) == SGP_MOTION_STATIC) return;
 	const float4 mn = d.aabb_min[i], mx = d.aabb_max[i];
@@ -1667,13 +1688,14 @@ __global__ void __launch_bounds__(TPB) k_export_boundary(DV d, float3 lo, float3
 static inline uint32_t blocks_for(uint32_t n) { return n ? (n + TPB - 1) / TPB : 1; }
 static inline uint32_t stride_grid(uint32_t estimate) { uint32_t b = blocks_for(estimate); if (b < 64) b = 64; if (b > 4096) b = 4096; return b; }
 
-void launch_apply_forces(const DV& d, float dt, hipStream_t s) { hipLaunchKernelGGL(k_apply_forces, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d, dt); }
-void launch_bp_bounds(const DV& d, hipStream_t s)
+void launch_step_begin(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(TPB), 0, s, d); }
+void launch_apply_forces(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_apply_forces, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
+void launch_bp_bounds(const DV& d, uint32_t nb, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_bp_bounds, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d);
+	hipLaunchKernelGGL(k_bp_bounds, dim3(blocks_for(nb)), dim3(TPB), 0, s, d);
 	hipLaunchKernelGGL(k_bp_grid_params, dim3(1), dim3(64), 0, s, d);
 }
-void launch_bp_cell(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_bp_cell, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d); }
+void launch_bp_cell(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_bp_cell, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_bp_scan(const DV& d, hipStream_t s)
 {
 	const uint32_t n = d.table_size + 1;
@@ -1682,12 +1704,12 @@ void launch_bp_scan(const DV& d, hipStream_t s)
 	hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, d.scan_block_sums, nb);
 	hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(TPB), 0, s, d.cell_start, d.scan_block_sums, n);
 }
-void launch_bp_scatter(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_bp_scatter, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d); }
+void launch_bp_scatter(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_bp_scatter, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_bp_pairs(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_bp_pairs, dim3(4096), dim3(TPB), 0, s, d); }
-void launch_bp_large(const DV& d, hipStream_t s) { if (d.n_large) hipLaunchKernelGGL(k_bp_large, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d); }
+void launch_bp_large(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_bp_large, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_narrowphase(const DV& d, uint32_t est, hipStream_t s) { hipLaunchKernelGGL(k_narrowphase, dim3(stride_grid(est)), dim3(TPB), 0, s, d); }
-void launch_wake(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_wake, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d); }
-void launch_prep_bodies(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_prep_bodies, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d); }
+void launch_wake(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_wake, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
+void launch_prep_bodies(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_prep_bodies, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_colour_claim(const DV& d, uint32_t est, uint32_t round, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_colour_claim, dim3(stride_grid(est)), dim3(TPB), 0, s, d, round);
@@ -1699,7 +1721,7 @@ void launch_colour_count(const DV& d, uint32_t est, hipStream_t s)
 	hipLaunchKernelGGL(k_colour_scan, dim3(1), dim3(64), 0, s, d);
 }
 void launch_colour_finish(const DV& d, uint32_t first_round, hipStream_t s) { hipLaunchKernelGGL(k_colour_finish, dim3(1), dim3(1024), 0, s, d, first_round); }
-void launch_setup(const DV& d, uint32_t n_man, float dt, hipStream_t s) { hipLaunchKernelGGL(k_setup, dim3(stride_grid(n_man)), dim3(TPB), 0, s, d, dt); }
+void launch_setup(const DV& d, uint32_t n_man, hipStream_t s) { hipLaunchKernelGGL(k_setup, dim3(stride_grid(n_man)), dim3(TPB), 0, s, d); }
 void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStream_t s)
 {
 	uint32_t blocks = blocks_for(est + est / 8 + 64);
@@ -1709,17 +1731,17 @@ void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStr
 	else hipLaunchKernelGGL(k_solve_colour<2>, dim3(blocks), dim3(TPB), 0, s, d, colour);
 }
 void launch_solve_tail(const DV& d, int first_colour, int mode, hipStream_t s) { hipLaunchKernelGGL(k_solve_tail, dim3(1), dim3(512), 0, s, d, first_colour, mode); }
-void launch_integrate_pose(const DV& d, float dt, hipStream_t s) { hipLaunchKernelGGL(k_integrate_pose, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d, dt); }
-void launch_finalize(const DV& d, float dt, hipStream_t s) { hipLaunchKernelGGL(k_finalize, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d, dt); }
+void launch_integrate_pose(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_integrate_pose, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
+void launch_finalize(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_finalize, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_island_hook(const DV& d, uint32_t n_con, hipStream_t s) { hipLaunchKernelGGL(k_island_hook, dim3(stride_grid(n_con)), dim3(TPB), 0, s, d); }
 void launch_island_flag(const DV& d, uint32_t n_con, hipStream_t s) { hipLaunchKernelGGL(k_island_flag, dim3(stride_grid(n_con)), dim3(TPB), 0, s, d); }
-void launch_sleep_apply(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_sleep_apply, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d); }
-void launch_buoyancy(const DV& d, float dt, hipStream_t s) { hipLaunchKernelGGL(k_buoyancy, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d, dt); }
+void launch_sleep_apply(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_sleep_apply, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
+void launch_buoyancy(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_buoyancy, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_cache_build(const DV& d, uint32_t n_con, hipStream_t s) { hipLaunchKernelGGL(k_cache_build, dim3(stride_grid(n_con)), dim3(TPB), 0, s, d); }
 void launch_contact_events(const DV& d, uint32_t est, hipStream_t s) { hipLaunchKernelGGL(k_contact_events, dim3(stride_grid(est)), dim3(TPB), 0, s, d); }
 void launch_apply_cmds(const DV& d, const BodyCmd* cmds, const uint32_t* run_start, uint32_t n_runs, hipStream_t s) { if (n_runs) hipLaunchKernelGGL(k_apply_cmds, dim3(blocks_for(n_runs)), dim3(TPB), 0, s, d, cmds, run_start, n_runs); }
 void launch_gather_states(const DV& d, const uint32_t* ids, uint32_t first, uint32_t n, sgp_body_state* out, hipStream_t s) { if (n) hipLaunchKernelGGL(k_gather_states, dim3(blocks_for(n)), dim3(TPB), 0, s, d, ids, first, n, out); }
-void launch_gather_active(const DV& d, sgp_body_state* out, uint32_t cap, hipStream_t s) { hipLaunchKernelGGL(k_gather_active, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d, out, cap); }
-void launch_dump_constraints(const DV& d, uint32_t n_con, void* out, uint32_t cap, hipStream_t s) { if (n_con) hipLaunchKernelGGL(k_dump_constraints, dim3(blocks_for(n_con)), dim3(TPB), 0, s, d, n_con, (ConstraintDumpRec*)out, cap); }
+void launch_gather_active(const DV& d, uint32_t nb, sgp_body_state* out, uint32_t cap, hipStream_t s) { hipLaunchKernelGGL(k_gather_active, dim3(blocks_for(nb)), dim3(TPB), 0, s, d, out, cap); }
+void launch_dump_constraints(const DV& d, uint32_t which, uint32_t n_con, void* out, uint32_t cap, hipStream_t s) { if (n_con) hipLaunchKernelGGL(k_dump_constraints, dim3(blocks_for(n_con)), dim3(TPB), 0, s, d, which, n_con, (ConstraintDumpRec*)out, cap); }
 void launch_raycast(const DV& d, const sgp_ray* rays, uint32_t n, sgp_hit* hits, hipStream_t s) { if (n) hipLaunchKernelGGL(k_raycast, dim3((n + 63) / 64), dim3(64), 0, s, d, rays, n, hits); }
-void launch_export_boundary(const DV& d, float3 lo, float3 hi, float margin, sgp_ghost_record* out, uint32_t cap, uint32_t* count, hipStream_t s) { hipLaunchKernelGGL(k_export_boundary, dim3(blocks_for(d.n_slots)), dim3(TPB), 0, s, d, lo, hi, margin, out, cap, count); }
+void launch_export_boundary(const DV& d, uint32_t nb, float3 lo, float3 hi, float margin, sgp_ghost_record* out, uint32_t cap, uint32_t* count, hipStream_t s) { hipLaunchKernelGGL(k_export_boundary, dim3(blocks_for(nb)), dim3(TPB), 0, s, d, lo, hi, margin, out, cap, count); }

@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 #include <unordered_map>
+#include <map>
 #include "sgp_kernels.h"
 
 #define SGP_API extern "C" __attribute__((visibility("default")))
@@ -69,7 +70,11 @@ struct sgp_world {
 	// staging
 	void* stage_dev = nullptr; size_t stage_dev_bytes = 0;
 	void* stage_host = nullptr; size_t stage_host_bytes = 0;
-	StepCounters* h_ctr = nullptr; EventCounters* h_evc = nullptr; BpGrid* h_grid = nullptr;
+	StepCounters* h_ctr = nullptr; EventCounters* h_evc = nullptr;
+	StepParams* h_sp = nullptr; StepParams* d_sp = nullptr;      // pinned host copy / device copy of the per-step scalars
+	std::map<std::string, hipGraphExec_t> graphs;              // replayable launch sequences keyed by launch plan
+	std::string last_plan_key; uint32_t plan_repeats = 0; bool use_graphs = true;
+	uint32_t graph_launches = 0, eager_steps = 0;
 	// events collected on the host until drained
 	std::vector<sgp_body_event> ev_act, ev_deact, ev_water;
 	std::vector<sgp_contact_event> ev_added, ev_pers;
@@ -237,25 +242,30 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	d.table_size = std::max(1024u, next_pow2(2u * N));
 	DEV_ALLOC(d.cell_hash, N); DEV_ALLOC(d.cell_xyz, N);
 	DEV_ALLOC(d.cell_count, d.table_size + 4); DEV_ALLOC(d.cell_start, d.table_size + 4); DEV_ALLOC(d.cell_fill, d.table_size + 4);
+	DEV_ALLOC(w->d_large, N); w->cap_large = N; d.large_ids = w->d_large;
 	DEV_ALLOC(d.sorted_ids, N); DEV_ALLOC(d.sorted_min, N); DEV_ALLOC(d.sorted_max, N); DEV_ALLOC(d.grid, 1); DEV_ALLOC(d.scan_block_sums, (d.table_size + 1) / 1024 + 2);
 	DEV_ALLOC(d.pairs, P);
 	DEV_ALLOC(d.man_ab, M); DEV_ALLOC(d.man_n, M); DEV_ALLOC(d.man_colour, M); DEV_ALLOC(d.man_prio, M);
 	DEV_ALLOC(d.ulist[0], M); DEV_ALLOC(d.ulist[1], M);
 	for (int k = 0; k < 4; ++k) { DEV_ALLOC(d.man_p1[k], M); DEV_ALLOC(d.man_p2[k], M); }
-	{ int r = alloc_constraints(w, d.cur, M); if (r != SGP_OK) return r; }
-	{ int r = alloc_constraints(w, d.prev, M); if (r != SGP_OK) return r; }
+	{ int r = alloc_constraints(w, d.ca[0], M); if (r != SGP_OK) return r; }
+	{ int r = alloc_constraints(w, d.ca[1], M); if (r != SGP_OK) return r; }
 	w->ht_alloc = next_pow2(2u * M);
 	DEV_ALLOC(d.ht_keys, w->ht_alloc); DEV_ALLOC(d.ht_vals, w->ht_alloc);
+	HIP_TRY(hipMemsetAsync(d.ht_keys, 0xFF, sizeof(uint64_t) * w->ht_alloc, w->stream));      // empty contact cache
 	d.ht_size = w->ht_alloc;
 	DEV_ALLOC(d.cstarts, SGP_MAX_COLOURS + 2);
 	DEV_ALLOC(d.ctr, 1); DEV_ALLOC(d.evc, 1);
 	DEV_ALLOC(d.ev_activated, N); DEV_ALLOC(d.ev_deactivated, N); DEV_ALLOC(d.ev_water, N);
 	HIP_TRY(hipHostMalloc((void**)&w->h_ctr, sizeof(StepCounters), hipHostMallocDefault));
 	HIP_TRY(hipHostMalloc((void**)&w->h_evc, sizeof(EventCounters), hipHostMallocDefault));
-	HIP_TRY(hipHostMalloc((void**)&w->h_grid, sizeof(BpGrid), hipHostMallocDefault));
+	HIP_TRY(hipHostMalloc((void**)&w->h_sp, sizeof(StepParams), hipHostMallocDefault));
+	memset(w->h_sp, 0, sizeof(StepParams));
+	DEV_ALLOC(w->d_sp, 1);
+	d.sp = w->d_sp;
+	{ const char* e = getenv("SGP_NO_GRAPH"); if (e && e[0] == '1') w->use_graphs = false; }
 	d.st = desc->settings;
 	d.gx = desc->gravity[0]; d.gy = desc->gravity[1]; d.gz = desc->gravity[2];
-	d.cell_size = 1.0f;
 	w->hb.resize(N);
 	HIP_TRY(hipStreamSynchronize(w->stream));
 	return SGP_OK;
@@ -267,12 +277,12 @@ SGP_API int sgp_world_destroy(sgp_world* w)
 	hipSetDevice(w->device);
 	if (w->stream) hipStreamSynchronize(w->stream);
 	for (void* p : w->allocs) hipFree(p);
-	if (w->d_large) hipFree(w->d_large);
 	if (w->stage_dev) hipFree(w->stage_dev);
 	if (w->stage_host) hipHostFree(w->stage_host);
 	if (w->h_ctr) hipHostFree(w->h_ctr);
 	if (w->h_evc) hipHostFree(w->h_evc);
-	if (w->h_grid) hipHostFree(w->h_grid);
+	if (w->h_sp) hipHostFree(w->h_sp);
+	for (auto& kv : w->graphs) hipGraphExecDestroy(kv.second);
 	for (hipEvent_t ev : w->event_pool) hipEventDestroy(ev);
 	if (w->stage_ev_ok) for (int i = 0; i <= SGP_NUM_STAGES; ++i) hipEventDestroy(w->stage_ev[i]);
 	if (w->stream) hipStreamDestroy(w->stream);
@@ -478,26 +488,29 @@ SGP_API int sgp_body_add_torque(sgp_world* w, uint32_t id, const float t[3])
 }
 
 // Upload the pending edits: grouped by body (submission order kept inside a group), one thread per body.
+static int upload_sp(sgp_world* w)
+{
+	StepParams& sp = *w->h_sp;
+	sp.n_slots = w->high;
+	sp.n_large = (uint32_t)w->large_ids.size();
+	sp.bp_rmax = std::max(0.25f, w->max_small_radius);
+	sp.cell_size = sp.bp_rmax + w->dv.st.speculative_contact_distance;
+	HIP_TRY(hipMemcpyAsync(w->d_sp, w->h_sp, sizeof(StepParams), hipMemcpyHostToDevice, w->stream));
+	return SGP_OK;
+}
+
 static int flush_cmds(sgp_world* w)
 {
 	hipSetDevice(w->device);
 	DV& d = w->dv;
-	d.n_slots = w->high;
 	if (w->large_dirty) {
-		if (w->large_ids.size() > w->cap_large) {
-			if (w->d_large) { hipStreamSynchronize(w->stream); hipFree(w->d_large); }
-			w->cap_large = (uint32_t)w->large_ids.size() * 2 + 16;
-			HIP_TRY(hipMalloc((void**)&w->d_large, sizeof(uint32_t) * w->cap_large));
-		}
 		if (!w->large_ids.empty()) {
 			HIP_TRY(hipMemcpyAsync(w->d_large, w->large_ids.data(), sizeof(uint32_t) * w->large_ids.size(), hipMemcpyHostToDevice, w->stream));
 			HIP_TRY(hipStreamSynchronize(w->stream));   // large_ids is pageable host memory that may change
 		}
-		d.large_ids = w->d_large; d.n_large = (uint32_t)w->large_ids.size();
 		w->large_dirty = false;
 	}
-	d.bp_rmax = std::max(0.25f, w->max_small_radius);
-	d.cell_size = d.bp_rmax + d.st.speculative_contact_distance;
+	{ int r = upload_sp(w); if (r != SGP_OK) return r; }
 	if (w->cmds.empty()) return SGP_OK;
 	const size_t n = w->cmds.size();
 	std::vector<uint32_t> order(n);
@@ -581,101 +594,156 @@ static int read_counters(sgp_world* w)
 
 // ---------------------------------------------------------------------------------------------------------------
 // think(dt), PhysicsWorld.cpp:1356-1443
+//
+// A step is (1) a LAUNCH PLAN made on the host from the previous step's counters (how many body slots, colouring rounds
+// and per-colour launches to issue, with bucketed sizes), (2) the launch sequence of that plan -- issued eagerly, or
+// replayed as a hipGraph once the same plan has come up twice -- and (3) ONE host sync that reads the counters back.
+// Nothing in the sequence depends on host knowledge of the CURRENT step: kernels size themselves from device counters,
+// and catch-all kernels (k_colour_finish, k_solve_tail) keep the result exact when the plan under-estimates.
+
+static uint32_t bucket_up(uint32_t x)
+{
+	if (x <= 1024) return 1024;
+	uint32_t p = 1; while ((p << 1) <= x) p <<= 1;        // largest power of two <= x
+	const uint32_t q = p / 4;
+	return ((x + q - 1) / q) * q;                          // steps of 25 %
+}
+
+struct StepPlan {
+	uint32_t nb;                 // body slots covered by the per-body grids
+	uint32_t rounds;             // colouring rounds launched before the catch-all
+	uint32_t est_pairs, est_man;
+	int      tail_first;         // colours [0, tail_first) get their own launch per pass
+	uint32_t colour_est[SGP_MAX_COLOURS];
+	int      water, contact_events, warm_start, vel_iters, pos_iters;
+};
+
+static void make_plan(const sgp_world* w, StepPlan& p)
+{
+	memset(&p, 0, sizeof(p));
+	p.nb = bucket_up(w->high);
+	p.rounds = ((std::max(w->plan_rounds + 3u, 10u) + 3u) / 4u) * 4u;
+	p.est_pairs = bucket_up(std::max(w->last_pairs + w->last_pairs / 8, 4u * w->high));
+	p.est_man = bucket_up(std::max(w->last_manifolds + w->last_manifolds / 8, 2u * w->high));
+	int tf = 0;
+	while (tf < SGP_OVERFLOW_COLOUR && w->plan_colour_count[tf] > 256u) { p.colour_est[tf] = bucket_up(w->plan_colour_count[tf] + w->plan_colour_count[tf] / 8); ++tf; }
+	p.tail_first = tf;
+	p.water = w->h_sp->water_enabled; p.contact_events = w->h_sp->contact_events;
+	p.warm_start = w->dv.st.warm_start; p.vel_iters = w->dv.st.num_velocity_steps; p.pos_iters = w->dv.st.num_position_steps;
+}
+
+static int enqueue_step(sgp_world* w, const StepPlan& p)
+{
+	const DV& d = w->dv;
+	hipStream_t s = w->stream;
+	const uint32_t nb = p.nb;
+	HIP_TRY(hipMemcpyAsync(w->d_sp, w->h_sp, sizeof(StepParams), hipMemcpyHostToDevice, s));
+	STAGE_MARK(0);
+	{
+		KScope k(w, KC_MISC);
+		launch_step_begin(d, s);
+		HIP_TRY(hipMemsetAsync(d.cell_count, 0, sizeof(uint32_t) * (d.table_size + 4), s));
+		HIP_TRY(hipMemsetAsync(d.cell_fill, 0, sizeof(uint32_t) * (d.table_size + 4), s));
+		HIP_TRY(hipMemsetAsync(d.colour_mask, 0, sizeof(uint64_t) * std::min(nb, d.cap_bodies), s));
+		HIP_TRY(hipMemsetAsync(d.claim[0], 0xFF, sizeof(uint64_t) * std::min(nb, d.cap_bodies), s));
+		HIP_TRY(hipMemsetAsync(d.claim[1], 0xFF, sizeof(uint64_t) * std::min(nb, d.cap_bodies), s));
+	}
+	// -- 1. forces
+	{ KScope k(w, KC_APPLY_FORCES); launch_apply_forces(d, nb, s); }
+	STAGE_MARK(1);
+	// -- 2. broad phase
+	{ KScope k(w, KC_BP_CELL); launch_bp_bounds(d, nb, s); launch_bp_cell(d, nb, s); }
+	{ KScope k(w, KC_BP_SCAN); launch_bp_scan(d, s); }
+	{ KScope k(w, KC_BP_SCATTER); launch_bp_scatter(d, nb, s); }
+	{ KScope k(w, KC_BP_PAIRS); launch_bp_pairs(d, s); }
+	{ KScope k(w, KC_BP_LARGE); launch_bp_large(d, nb, s); }
+	STAGE_MARK(2);
+	// -- 3. narrow phase, wake-ups, per-body solver records (+ contact events, which see the velocities before the solve)
+	{ KScope k(w, KC_NARROWPHASE); launch_narrowphase(d, p.est_pairs, s); }
+	{ KScope k(w, KC_WAKE); launch_wake(d, nb, s); }
+	{ KScope k(w, KC_PREP_BODIES); launch_prep_bodies(d, nb, s); }
+	if (p.contact_events) { KScope k(w, KC_MISC); launch_contact_events(d, p.est_man, s); }
+	STAGE_MARK(3);
+	// -- 4. colouring + constraint setup
+	uint32_t est_unc = p.est_man;
+	for (uint32_t round = 0; round < p.rounds; ++round) {
+		{ KScope k(w, KC_COLOUR_CLAIM); launch_colour_claim(d, est_unc, round, s); }
+		{ KScope k(w, KC_COLOUR_COMMIT); launch_colour_commit(d, est_unc, round, s); }
+		if (round >= 1) est_unc = std::max(est_unc - est_unc / 4, 8192u);      // worklists shrink; kernels grid-stride over the rest
+	}
+	{ KScope k(w, KC_COLOUR_COMMIT); launch_colour_finish(d, p.rounds, s); }
+	{ KScope k(w, KC_COLOUR_COUNT); launch_colour_count(d, p.est_man, s); }
+	{ KScope k(w, KC_SETUP); launch_setup(d, p.est_man, s); }
+	STAGE_MARK(4);
+	// -- 5. warm start + velocity iterations: one launch per planned colour, everything else in the single-workgroup tail
+	auto solve_pass = [&](int mode, int kc) {
+		for (int c = 0; c < p.tail_first; ++c) { KScope k(w, kc); launch_solve_colour(d, c, p.colour_est[c], mode, s); }
+		{ KScope k(w, kc); launch_solve_tail(d, p.tail_first, mode, s); }
+	};
+	if (p.warm_start) solve_pass(0, KC_WARM_START);
+	for (int it = 0; it < p.vel_iters; ++it) solve_pass(1, KC_SOLVE_VELOCITY);
+	STAGE_MARK(5);
+	// -- 6. the body-array sweep
+	{ KScope k(w, KC_INTEGRATE_POSE); launch_integrate_pose(d, nb, s); }
+	STAGE_MARK(6);
+	// -- 7. position iterations
+	for (int it = 0; it < p.pos_iters; ++it) solve_pass(2, KC_SOLVE_POSITION);
+	STAGE_MARK(7);
+	// -- 8. bounds, sleeping, buoyancy, contact cache
+	{ KScope k(w, KC_FINALIZE); launch_finalize(d, nb, s); }
+	{ KScope k(w, KC_ISLAND_HOOK); launch_island_hook(d, p.est_man, s); }
+	{ KScope k(w, KC_ISLAND_FLAG); launch_island_flag(d, p.est_man, s); }
+	{ KScope k(w, KC_SLEEP_APPLY); launch_sleep_apply(d, nb, s); }
+	if (p.water) { KScope k(w, KC_BUOYANCY); launch_buoyancy(d, nb, s); }
+	{
+		KScope k(w, KC_CACHE_BUILD);
+		HIP_TRY(hipMemsetAsync(d.ht_keys, 0xFF, sizeof(uint64_t) * d.ht_size, s));
+		launch_cache_build(d, p.est_man, s);
+	}
+	STAGE_MARK(8);
+	HIP_TRY(hipMemcpyAsync(w->h_ctr, d.ctr, sizeof(StepCounters), hipMemcpyDeviceToHost, s));
+	return SGP_OK;
+}
 
 static int step_impl(sgp_world* w, float dt, bool final_readback)
 {
 	if (!(dt > 0.0f)) return fail(SGP_ERR_INVALID, "sgp_world_step: dt must be > 0");
 	{ int r = flush_cmds(w); if (r != SGP_OK) return r; }
 	DV& d = w->dv;
-	hipStream_t s = w->stream;
-	const uint32_t n = d.n_slots;
-	STAGE_MARK(0);
-	// -- per-step scratch reset
-	{
-		KScope k(w, KC_MISC);
-		HIP_TRY(hipMemsetAsync(d.ctr, 0, sizeof(StepCounters), s));
-		HIP_TRY(hipMemsetAsync(d.cell_count, 0, sizeof(uint32_t) * (d.table_size + 4), s));
-		HIP_TRY(hipMemsetAsync(d.cell_fill, 0, sizeof(uint32_t) * (d.table_size + 4), s));
-		{
-			BpGrid g0; memset(&g0, 0, sizeof(g0));
-			g0.min_x = g0.min_y = g0.min_z = 0x7FFFFFFF; g0.max_x = g0.max_y = g0.max_z = (int)0x80000000;
-			*w->h_grid = g0;
-			HIP_TRY(hipMemcpyAsync(d.grid, w->h_grid, sizeof(BpGrid), hipMemcpyHostToDevice, s));
+	if (w->high == 0) { memset(&w->stats, 0, sizeof(w->stats)); return SGP_OK; }
+	w->h_sp->dt = dt;
+	StepPlan plan;
+	make_plan(w, plan);
+	const std::string key((const char*)&plan, sizeof(plan));
+	bool launched = false;
+	if (w->use_graphs && !w->profiling) {
+		auto it = w->graphs.find(key);
+		if (it == w->graphs.end()) {
+			// capture only once the same plan has come up twice in a row (plans churn while a scene is still changing)
+			w->plan_repeats = (key == w->last_plan_key) ? w->plan_repeats + 1 : 0;
+			if (w->plan_repeats >= 1) {
+				if (w->graphs.size() >= 16) { for (auto& kv : w->graphs) hipGraphExecDestroy(kv.second); w->graphs.clear(); }
+				hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+				HIP_TRY(hipStreamBeginCapture(w->stream, hipStreamCaptureModeThreadLocal));
+				const int r = enqueue_step(w, plan);
+				const hipError_t e = hipStreamEndCapture(w->stream, &g);
+				if (r != SGP_OK) { if (g) hipGraphDestroy(g); return r; }
+				if (e != hipSuccess) return fail(SGP_ERR_HIP, "hipStreamEndCapture", e);
+				const hipError_t e2 = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+				hipGraphDestroy(g);
+				if (e2 != hipSuccess) return fail(SGP_ERR_HIP, "hipGraphInstantiate", e2);
+				it = w->graphs.emplace(key, ge).first;
+			}
 		}
-		if (n) {
-			HIP_TRY(hipMemsetAsync(d.colour_mask, 0, sizeof(uint64_t) * n, s));
-			HIP_TRY(hipMemsetAsync(d.claim[0], 0xFF, sizeof(uint64_t) * n, s));
-			HIP_TRY(hipMemsetAsync(d.claim[1], 0xFF, sizeof(uint64_t) * n, s));
-		}
+		if (it != w->graphs.end()) { HIP_TRY(hipGraphLaunch(it->second, w->stream)); launched = true; w->graph_launches++; }
 	}
-	if (n == 0) { memset(&w->stats, 0, sizeof(w->stats)); return SGP_OK; }
-	// -- 1. forces
-	{ KScope k(w, KC_APPLY_FORCES); launch_apply_forces(d, dt, s); }
-	STAGE_MARK(1);
-	// -- 2. broad phase
-	{ KScope k(w, KC_BP_CELL); launch_bp_bounds(d, s); launch_bp_cell(d, s); }
-	{ KScope k(w, KC_BP_SCAN); launch_bp_scan(d, s); }
-	{ KScope k(w, KC_BP_SCATTER); launch_bp_scatter(d, s); }
-	{ KScope k(w, KC_BP_PAIRS); launch_bp_pairs(d, s); }
-	{ KScope k(w, KC_BP_LARGE); launch_bp_large(d, s); }
-	STAGE_MARK(2);
-	// -- 3. narrow phase + wake-ups (+ contact events, which see the velocities before the solve)
-	const uint32_t est_pairs = std::max(w->last_pairs + w->last_pairs / 4 + 1024u, 4u * n);
-	{ KScope k(w, KC_NARROWPHASE); launch_narrowphase(d, est_pairs, s); }
-	{ KScope k(w, KC_WAKE); launch_wake(d, s); }
-	{ KScope k(w, KC_PREP_BODIES); launch_prep_bodies(d, s); }
-	const uint32_t est_man = std::max(w->last_manifolds + w->last_manifolds / 4 + 1024u, 2u * n);
-	if (d.contact_events) { KScope k(w, KC_MISC); launch_contact_events(d, est_man, s); }
-	STAGE_MARK(3);
-	// -- 4. colouring + constraint setup.  No host round trip: the number of rounds / colours to launch is PLANNED from the
-	//       previous step; catch-all kernels (k_colour_finish, k_solve_tail) keep the result exact when the plan is short.
-	const uint32_t rounds_plan = std::max(w->plan_rounds + 3u, 10u);
-	uint32_t est_unc = est_man;
-	for (uint32_t round = 0; round < rounds_plan; ++round) {
-		{ KScope k(w, KC_COLOUR_CLAIM); launch_colour_claim(d, est_unc, round, s); }
-		{ KScope k(w, KC_COLOUR_COMMIT); launch_colour_commit(d, est_unc, round, s); }
-		if (round >= 1) est_unc = std::max(est_unc - est_unc / 4, 8192u);      // worklists shrink; kernels grid-stride over the rest
-	}
-	{ KScope k(w, KC_COLOUR_COMMIT); launch_colour_finish(d, rounds_plan, s); }
-	{ KScope k(w, KC_COLOUR_COUNT); launch_colour_count(d, est_man, s); }
-	{ KScope k(w, KC_SETUP); launch_setup(d, est_man, dt, s); }
-	STAGE_MARK(4);
-	// -- 5. warm start + velocity iterations: one launch per planned colour, the rest (small tail colours, overflow colour,
-	//       colours beyond the plan) in one single-workgroup launch
-	int tail_first = 0;
-	while (tail_first < SGP_OVERFLOW_COLOUR && w->plan_colour_count[tail_first] > 256u) ++tail_first;
-	auto solve_pass = [&](int mode, int kc) {
-		for (int c = 0; c < tail_first; ++c) { KScope k(w, kc); launch_solve_colour(d, c, w->plan_colour_count[c], mode, s); }
-		{ KScope k(w, kc); launch_solve_tail(d, tail_first, mode, s); }
-	};
-	if (d.st.warm_start) solve_pass(0, KC_WARM_START);
-	for (int it = 0; it < d.st.num_velocity_steps; ++it) solve_pass(1, KC_SOLVE_VELOCITY);
-	STAGE_MARK(5);
-	// -- 6. the body-array sweep
-	{ KScope k(w, KC_INTEGRATE_POSE); launch_integrate_pose(d, dt, s); }
-	STAGE_MARK(6);
-	// -- 7. position iterations
-	for (int it = 0; it < d.st.num_position_steps; ++it) solve_pass(2, KC_SOLVE_POSITION);
-	STAGE_MARK(7);
-	// -- 8. bounds, sleeping, buoyancy, contact cache
-	const uint32_t est_con = est_man;
-	{ KScope k(w, KC_FINALIZE); launch_finalize(d, dt, s); }
-	{ KScope k(w, KC_ISLAND_HOOK); launch_island_hook(d, est_con, s); }
-	{ KScope k(w, KC_ISLAND_FLAG); launch_island_flag(d, est_con, s); }
-	{ KScope k(w, KC_SLEEP_APPLY); launch_sleep_apply(d, s); }
-	if (d.water_enabled) { KScope k(w, KC_BUOYANCY); launch_buoyancy(d, dt, s); }
-	{
-		KScope k(w, KC_CACHE_BUILD);
-		HIP_TRY(hipMemsetAsync(d.ht_keys, 0xFF, sizeof(uint64_t) * d.ht_size, s));
-		launch_cache_build(d, est_con, s);
-	}
-	std::swap(d.cur, d.prev);
-	STAGE_MARK(8);
+	w->last_plan_key = key;
+	if (!launched) { const int r = enqueue_step(w, plan); if (r != SGP_OK) return r; w->eager_steps++; }
 	// -- the ONE host sync of the step: counters, events, and the launch plan for the next step
-	{ int r = read_counters(w); if (r != SGP_OK) return r; }
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	w->h_sp->parity ^= 1u;                    // the buffer just solved becomes the contact cache of the next step
 	const StepCounters c1 = *w->h_ctr;
 	const uint32_t n_con = c1.n_constraints;
-	d.n_prev = n_con;
 	w->n_con = n_con;
 	w->last_pairs = c1.n_pairs; w->last_manifolds = c1.n_manifolds;
 	w->plan_rounds = c1.rounds_used;
@@ -730,11 +798,11 @@ SGP_API int sgp_world_step_profiled(sgp_world* w, float dt, sgp_step_profile* ou
 	if (r != SGP_OK) return r;
 	HIP_TRY(hipStreamSynchronize(w->stream));
 	memset(out, 0, sizeof(*out));
-	if (w->dv.n_slots == 0) return SGP_OK;
+	if (w->high == 0) return SGP_OK;
 	for (int i = 0; i < SGP_NUM_STAGES; ++i) { float ms = 0.0f; hipEventElapsedTime(&ms, w->stage_ev[i], w->stage_ev[i + 1]); out->stage_ms[i] = ms; }
 	hipEventElapsedTime(&out->total_ms, w->stage_ev[0], w->stage_ev[SGP_NUM_STAGES]);
 	for (const ProfEvent& p : w->prof) { float ms = 0.0f; hipEventElapsedTime(&ms, p.a, p.b); out->kernel_ms[p.kc] += ms; out->kernel_launches[p.kc]++; }
-	out->sweep_bodies = w->dv.n_slots;
+	out->sweep_bodies = w->high;
 	out->num_constraints = w->stats.num_manifolds;
 	out->num_contact_points = w->stats.num_contact_points;
 	out->num_colours = w->stats.num_colours;
@@ -760,7 +828,7 @@ SGP_API int sgp_world_num_bodies(sgp_world* w, uint32_t* n_out)
 SGP_API int sgp_world_set_water(sgp_world* w, int enabled, float z)
 {
 	if (!w) return fail(SGP_ERR_INVALID, "sgp_world_set_water: NULL");
-	w->dv.water_enabled = enabled; w->dv.water_z = z;
+	w->h_sp->water_enabled = enabled; w->h_sp->water_z = z;
 	return SGP_OK;
 }
 
@@ -772,8 +840,10 @@ SGP_API int sgp_world_set_contact_events(sgp_world* w, int enabled)
 		w->dv.cap_contact_events = w->dv.cap_manifolds;
 		DEV_ALLOC(w->dv.ev_contacts_added, w->dv.cap_contact_events);
 		DEV_ALLOC(w->dv.ev_contacts_persisted, w->dv.cap_contact_events);
+		for (auto& kv : w->graphs) hipGraphExecDestroy(kv.second);
+		w->graphs.clear();
 	}
-	w->dv.contact_events = enabled;
+	w->h_sp->contact_events = enabled;
 	return SGP_OK;
 }
 
@@ -822,7 +892,7 @@ SGP_API int sgp_world_read_active(sgp_world* w, sgp_body_state* out, uint32_t ca
 	const uint32_t lim = std::min(cap, w->dv.cap_bodies);
 	{ int r = ensure_stage(w, sizeof(sgp_body_state) * std::max(lim, 1u)); if (r != SGP_OK) return r; }
 	HIP_TRY(hipMemsetAsync(&w->dv.ctr->n_read_active, 0, sizeof(uint32_t), w->stream));
-	launch_gather_active(w->dv, (sgp_body_state*)w->stage_dev, lim, w->stream);
+	launch_gather_active(w->dv, w->high, (sgp_body_state*)w->stage_dev, lim, w->stream);
 	{ int r = read_counters(w); if (r != SGP_OK) return r; }
 	const uint32_t n = w->h_ctr->n_read_active;
 	const uint32_t m = std::min(n, lim);
@@ -874,7 +944,7 @@ SGP_API int sgp_world_dump_constraints(sgp_world* w, void* out, uint32_t cap, ui
 	const uint32_t m = std::min(n, cap);
 	if (!m || !out) return SGP_OK;
 	{ int r = ensure_stage(w, sizeof(DumpRec) * n); if (r != SGP_OK) return r; }
-	launch_dump_constraints(w->dv, n, w->stage_dev, n, w->stream);
+	launch_dump_constraints(w->dv, (w->h_sp->parity & 1u) ^ 1u, n, w->stage_dev, n, w->stream);
 	HIP_TRY(hipMemcpyAsync(w->stage_host, w->stage_dev, sizeof(DumpRec) * n, hipMemcpyDeviceToHost, w->stream));
 	HIP_TRY(hipStreamSynchronize(w->stream));
 	DumpRec* r = (DumpRec*)w->stage_host;
@@ -916,7 +986,7 @@ SGP_API int sgp_world_export_boundary(sgp_world* w, const float lo[3], const flo
 	const uint32_t lim = std::min(cap, w->dv.cap_bodies);
 	{ int r = ensure_stage(w, sizeof(sgp_ghost_record) * std::max(lim, 1u)); if (r != SGP_OK) return r; }
 	HIP_TRY(hipMemsetAsync(&w->dv.ctr->n_export, 0, sizeof(uint32_t), w->stream));
-	launch_export_boundary(w->dv, make_float3(lo[0], lo[1], lo[2]), make_float3(hi[0], hi[1], hi[2]), margin,
+	launch_export_boundary(w->dv, w->high, make_float3(lo[0], lo[1], lo[2]), make_float3(hi[0], hi[1], hi[2]), margin,
 	                       (sgp_ghost_record*)w->stage_dev, lim, &w->dv.ctr->n_export, w->stream);
 	{ int r = read_counters(w); if (r != SGP_OK) return r; }
 	const uint32_t n = w->h_ctr->n_export, m = std::min(n, lim);
