@@ -29,8 +29,11 @@ DT = 1.0 / 60.0
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 SWEEP_BYTES_PER_BODY = 188     # integrate + AABB body-array sweep, 112 B read + 76 B written
 # per contact point per velocity iteration: constraint rows 56 B read + 16 B written, plus per manifold 2 x (v,w,pose,inertia) gathers
-SOLVE_BYTES_PER_POINT = 72
-SOLVE_BYTES_PER_MANIFOLD = 2 * (32 + 48 + 4) + 2 * 32 + 28
+SOLVE_BYTES_PER_POINT = 72                       # r1b 16 + r2e 16 + lam 16 + efft 8 read, lam 16 written
+SOLVE_BYTES_PER_MANIFOLD = 28 + 2 * 64 + 2 * 32  # ab 8 + normal/friction 16 + np 4; two 64 B solver-body records read, 2 x 32 B velocities written
+# HBM traffic of the three sweep kernels per step at 100k bodies from the rocprofv3 PMC passes in profiles/r01_pmc_hbm_traffic.md
+# (FETCH_SIZE x2 per the gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE): 32.1 MB read + 22.4 MB written
+SWEEP_TRAFFIC_BYTES_PER_BODY_PMC = 545.0
 
 
 def parse():
@@ -39,7 +42,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=120)
     ap.add_argument("--bodies", type=int, default=100000, help="bodies per tile (BASELINE: 100k)")
-    ap.add_argument("--cpu-steps", type=int, default=12, help="oracle steps timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=16, help="oracle steps timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the oracle (0 = min(32, host cpus))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=8)
     return ap.parse_args()
@@ -155,7 +159,9 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "body-array sweep = k_apply_forces + k_integrate_pose + k_finalize (one launch each per step)",
                 "achieved": sweep_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sweep_gbs / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_launch": sweep_bytes, "launch_ms": sweep_ms, "traffic": None,
+                "algorithmic_bytes_per_launch": sweep_bytes, "launch_ms": sweep_ms,
+                "traffic": SWEEP_TRAFFIC_BYTES_PER_BODY_PMC * sweep_bodies,
+                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/r01_pmc_hbm_traffic.md; float4-padded SoA + three passes move 2.9x the algorithmic bytes",
             },
             "roofline_solver": {
                 "bound": "hbm", "kernel": "k_solve_velocity (dominant by time; one launch per colour per iteration)",
@@ -173,6 +179,8 @@ def main():
         d2 = descs.copy()
         d2["pos"] = S["pos"]; d2["rot"] = S["rot"]; d2["lin_vel"] = S["lin_vel"]; d2["ang_vel"] = S["ang_vel"]
         d2["activate"] = (S["active"] != 0).astype(np.int32)
+        threads = args.cpu_threads or min(32, os.cpu_count() or 1)
+        threads = oracle.set_threads(threads)
         cw = oracle.OracleWorld(max_bodies=len(descs) + 8)
         cw.add_batch(d2)
         cw.step(DT)                      # builds the contact cache so the timed steps are warm-started like the device's
@@ -181,11 +189,16 @@ def main():
             cw.step(DT)
         cpu_el = time.perf_counter() - t1
         cst = cw.stats()
+        oracle.set_threads(1)
+        t2 = time.perf_counter()
+        for _ in range(2):
+            cw.step(DT)
+        cpu1 = 2 / (time.perf_counter() - t2)
         out["cpu_baseline"] = {
-            "value": args.cpu_steps / cpu_el, "unit": "steps/s", "cores": 1, "kind": "port",
+            "value": args.cpu_steps / cpu_el, "unit": "steps/s", "cores": threads, "kind": "port",
             "sample": f"{args.cpu_steps} steps of the same 100k-body world, started from the device state after warm-up + timed region "
-                      f"({cst.num_manifolds} contact constraints, {cst.num_active} active bodies); oracle/sgo_oracle.c, single thread; "
-                      "this is this repo's CPU restatement, not JoltPhysics (absent from the reference tree)",
+                      f"({cst.num_manifolds} contact constraints, {cst.num_active} active bodies); oracle/sgo_oracle.c with {threads} OpenMP "
+                      f"threads (single thread: {cpu1:.2f} steps/s); this is this repo's CPU restatement, not JoltPhysics (absent from the reference tree)",
             "host_cpus": os.cpu_count(),
         }
         cw.close()

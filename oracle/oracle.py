@@ -37,6 +37,8 @@ def lib():
                                           C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
         _lib.sgo_layers_collide.restype = C.c_int
         _lib.sgo_layers_collide.argtypes = [C.c_int, C.c_int]
+        _lib.sgo_set_threads.restype = C.c_int
+        _lib.sgo_set_threads.argtypes = [C.c_int]
     return _lib
 
 
@@ -56,6 +58,11 @@ def collide_pair(a, b, max_sep=0.02):
     if not hit:
         return None
     return n, p1[:npts.value].copy(), p2[:npts.value].copy()
+
+
+def set_threads(n):
+    """OpenMP threads for the order-independent loops of the oracle (cpu_baseline timing only; tests use 1)."""
+    return int(lib().sgo_set_threads(int(n)))
 
 
 def layers_collide(l1, l2):

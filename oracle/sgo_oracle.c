@@ -28,6 +28,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include "../include/sgp.h"
 #include "sgo_collide.h"
 
@@ -146,6 +149,23 @@ SGO_API void sgo_default_body_desc(sgp_body_desc* d)
 	d->linear_damping = 0.05f; d->angular_damping = 0.05f;
 	d->allow_sleeping = 1;
 }
+
+/* Optional multi-core mode for the cpu_baseline timing (bench.py): the loops over bodies, pairs and the constraints of one
+   colour are order independent (see the ordering contract above), so they are plain OpenMP parallel-for loops and give the
+   same bits as the single-thread run.  Tests run with 1 thread. */
+static int g_threads = 1;
+SGO_API int sgo_set_threads(int n)
+{
+#ifdef _OPENMP
+	if (n < 1) n = 1;
+	g_threads = n;
+	omp_set_num_threads(n);
+	return n;
+#else
+	(void)n; return 1;
+#endif
+}
+SGO_API int sgo_get_threads(void) { return g_threads; }
 
 /* ------------------------------------------------------------------------------------------------ */
 /* layer matrix: MyObjectLayerPairFilter, PhysicsWorld.cpp:160-189                                     */
@@ -571,22 +591,33 @@ static void broad_phase(sgo_world* w)
 		ki[k].key = cell_key((int64_t)floorf(c.x / cell), (int64_t)floorf(c.y / cell), (int64_t)floorf(c.z / cell));
 	}
 	qsort(ki, n_small, sizeof(keyidx), cmp_keyidx);
-	for (uint32_t k = 0; k < n_small; ++k) {
-		const uint32_t i = ki[k].idx;
-		if (!body_is_active_for_pairs(&w->bodies[i])) continue;
-		const int64_t cx = (int64_t)(ki[k].key & 0x1FFFFF) - (1 << 20);
-		const int64_t cy = (int64_t)((ki[k].key >> 21) & 0x1FFFFF) - (1 << 20);
-		const int64_t cz = (int64_t)((ki[k].key >> 42) & 0x1FFFFF) - (1 << 20);
-		for (int64_t dz = -1; dz <= 1; ++dz) for (int64_t dy = -1; dy <= 1; ++dy) for (int64_t dx = -1; dx <= 1; ++dx) {
-			const uint64_t key = cell_key(cx + dx, cy + dy, cz + dz);
-			for (uint32_t p = lower_bound_key(ki, n_small, key); p < n_small && ki[p].key == key; ++p) {
-				const uint32_t j = ki[p].idx;
-				if (j == i) continue;
-				/* emitted once: by the lower id if both scan, else by the scanning (active) one */
-				if (body_is_active_for_pairs(&w->bodies[j]) && j < i) continue;
-				if (pair_passes(w, i, j)) push_pair(w, i, j);
+	#pragma omp parallel if (g_threads > 1)
+	{
+		sgo_pair* loc = NULL; uint32_t nloc = 0, caploc = 0;
+		#pragma omp for schedule(dynamic, 256) nowait
+		for (uint32_t k = 0; k < n_small; ++k) {
+			const uint32_t i = ki[k].idx;
+			if (!body_is_active_for_pairs(&w->bodies[i])) continue;
+			const int64_t cx = (int64_t)(ki[k].key & 0x1FFFFF) - (1 << 20);
+			const int64_t cy = (int64_t)((ki[k].key >> 21) & 0x1FFFFF) - (1 << 20);
+			const int64_t cz = (int64_t)((ki[k].key >> 42) & 0x1FFFFF) - (1 << 20);
+			for (int64_t dz = -1; dz <= 1; ++dz) for (int64_t dy = -1; dy <= 1; ++dy) for (int64_t dx = -1; dx <= 1; ++dx) {
+				const uint64_t key = cell_key(cx + dx, cy + dy, cz + dz);
+				for (uint32_t p = lower_bound_key(ki, n_small, key); p < n_small && ki[p].key == key; ++p) {
+					const uint32_t j = ki[p].idx;
+					if (j == i) continue;
+					/* emitted once: by the lower id if both scan, else by the scanning (active) one */
+					if (body_is_active_for_pairs(&w->bodies[j]) && j < i) continue;
+					if (pair_passes(w, i, j)) {
+						if (nloc == caploc) { caploc = caploc ? caploc * 2 : 1024; loc = (sgo_pair*)realloc(loc, sizeof(sgo_pair) * caploc); }
+						loc[nloc].a = i < j ? i : j; loc[nloc].b = i < j ? j : i; ++nloc;
+					}
+				}
 			}
 		}
+		#pragma omp critical
+		{ for (uint32_t q = 0; q < nloc; ++q) push_pair(w, loc[q].a, loc[q].b); }
+		free(loc);
 	}
 	for (uint32_t l = 0; l < w->n_large; ++l) {
 		const uint32_t i = w->large[l];
@@ -650,6 +681,65 @@ static void emit_contact_event(sgo_world* w, const sgo_constraint* c, const sgo_
 	else PUSH_EVENT(w->ev_added, w->n_added, w->cap_added, sgp_contact_event, e);
 }
 
+/* Constraint properties of manifold k (TemplatedAddContactConstraint); returns 0 for sensor pairs. Same arithmetic as the loop in find_contacts. */
+static int setup_constraint(sgo_world* w, uint32_t k, const sgo_manifold* m, float dt, uint32_t* npts)
+{
+	sgo_constraint c = w->cons[k];
+	const sgo_body* A = &w->bodies[c.a]; const sgo_body* B = &w->bodies[c.b];
+	const sgo_constraint* pc = find_prev(w, c.key);
+	c.persisted = pc != NULL;
+	if (A->is_sensor || B->is_sensor) return 0;
+	const m33 RA = quat_to_m33(A->rot), RB = quat_to_m33(B->rot);
+	const float im1 = body_movable(A) ? A->inv_mass : 0.0f, im2 = body_movable(B) ? B->inv_mass : 0.0f;
+	sym33 I1, I2; memset(&I1, 0, sizeof(I1)); memset(&I2, 0, sizeof(I2));
+	if (im1 > 0.0f) I1 = world_inv_inertia(RA, A->inv_inertia);
+	if (im2 > 0.0f) I2 = world_inv_inertia(RB, B->inv_inertia);
+	c.friction = sqrtf(A->friction * B->friction);
+	const float restitution = fmaxf(A->restitution, B->restitution);
+	c.t1 = v3_normalized_perpendicular(c.n);
+	c.t2 = v3_cross(c.n, c.t1);
+	for (int i = 0; i < c.np; ++i) {
+		sgo_point* pt = &c.pt[i];
+		const v3 p1 = m->p1[i], p2 = m->p2[i];
+		pt->local1 = m33_tmul(RA, v3_sub(p1, A->pos));
+		pt->local2 = m33_tmul(RB, v3_sub(p2, B->pos));
+		pt->lam_n = pt->lam_t1 = pt->lam_t2 = 0.0f;
+		if (pc && w->st.warm_start) {
+			for (int j = 0; j < pc->np; ++j) {
+				if (v3_len_sq(v3_sub(pt->local1, pc->pt[j].local1)) < w->st.contact_point_preserve_lambda_max_dist_sq &&
+				    v3_len_sq(v3_sub(pt->local2, pc->pt[j].local2)) < w->st.contact_point_preserve_lambda_max_dist_sq) {
+					pt->lam_n = pc->pt[j].lam_n; pt->lam_t1 = pc->pt[j].lam_t1; pt->lam_t2 = pc->pt[j].lam_t2;
+					break;
+				}
+			}
+		}
+		const v3 mid = v3_scale(v3_add(p1, p2), 0.5f);
+		pt->r1 = v3_sub(mid, A->pos); pt->r2 = v3_sub(mid, B->pos);
+		const v3 va = v3_add(A->linv, v3_cross(A->angv, pt->r1));
+		const v3 vb = v3_add(B->linv, v3_cross(B->angv, pt->r2));
+		const float normal_velocity = v3_dot(v3_sub(vb, va), c.n);
+		const float penetration = v3_dot(v3_sub(p1, p2), c.n);
+		const float spec_bias = fmaxf(0.0f, -penetration / dt);
+		float bias = spec_bias;
+		if (restitution > 0.0f && normal_velocity < -w->st.min_velocity_for_restitution) {
+			if (normal_velocity < -spec_bias) {
+				v3 rel_acc = V3(0, 0, 0);
+				if (im2 > 0.0f) rel_acc = v3_add(rel_acc, v3_scale(w->gravity, B->gravity_factor));
+				if (im1 > 0.0f) rel_acc = v3_sub(rel_acc, v3_scale(w->gravity, A->gravity_factor));
+				const float force_dv = fminf(0.0f, v3_dot(rel_acc, c.n)) * dt;
+				bias = restitution * (normal_velocity - force_dv);
+			}
+		}
+		pt->bias = bias;
+		pt->eff_n = axis_eff_mass(im1, I1, pt->r1, im2, I2, pt->r2, c.n);
+		pt->eff_t1 = axis_eff_mass(im1, I1, pt->r1, im2, I2, pt->r2, c.t1);
+		pt->eff_t2 = axis_eff_mass(im1, I1, pt->r1, im2, I2, pt->r2, c.t2);
+	}
+	*npts = (uint32_t)c.np;
+	w->cons[k] = c;
+	return 1;
+}
+
 /* Narrow phase + constraint setup for every candidate pair. */
 static void find_contacts(sgo_world* w, float dt)
 {
@@ -660,18 +750,24 @@ static void find_contacts(sgo_world* w, float dt)
 	}
 	/* pass 1: manifolds + activation of sleeping bodies touched by an active one */
 	sgo_manifold* mans = (sgo_manifold*)malloc(sizeof(sgo_manifold) * (w->n_pairs ? w->n_pairs : 1));
-	uint32_t nm = 0;
+	unsigned char* hit = (unsigned char*)malloc(w->n_pairs ? w->n_pairs : 1);
+	#pragma omp parallel for schedule(static, 256) if (g_threads > 1)
 	for (uint32_t p = 0; p < w->n_pairs; ++p) {
 		const uint32_t a = w->pairs[p].a, b = w->pairs[p].b;
 		const sgo_shape sa = body_shape_xf(&w->bodies[a]), sb = body_shape_xf(&w->bodies[b]);
-		sgo_manifold m;
-		if (!sgo_collide(&sa, &sb, w->st.speculative_contact_distance, &m)) continue;
+		hit[p] = (unsigned char)sgo_collide(&sa, &sb, w->st.speculative_contact_distance, &mans[p]);
+	}
+	uint32_t nm = 0;
+	for (uint32_t p = 0; p < w->n_pairs; ++p) {
+		if (!hit[p]) continue;
+		const uint32_t a = w->pairs[p].a, b = w->pairs[p].b;
 		sgo_constraint* c = &w->cons[nm];
 		memset(c, 0, sizeof(*c));
 		c->a = a; c->b = b; c->key = ((uint64_t)a << 32) | b; c->prio = sgp_mix64(c->key);
-		c->np = m.np; c->n = m.n;
-		mans[nm++] = m;
+		c->np = mans[p].np; c->n = mans[p].n;
+		mans[nm++] = mans[p];
 	}
+	free(hit);
 	w->n_cons = nm;
 	for (uint32_t k = 0; k < nm; ++k) {
 		sgo_body* A = &w->bodies[w->cons[k].a]; sgo_body* B = &w->bodies[w->cons[k].b];
@@ -682,8 +778,19 @@ static void find_contacts(sgo_world* w, float dt)
 	}
 	for (uint32_t i = 0; i < w->high; ++i) if (w->bodies[i].alive && w->bodies[i].can_sleep == -1) { w->bodies[i].can_sleep = 0; body_activate(w, i); }
 
-	/* pass 2: constraint properties */
+	/* pass 2: constraint properties (independent per constraint: parallel unless contact events must be emitted in order) */
 	uint32_t npts = 0, out = 0;
+	if (g_threads > 1 && !w->contact_events) {
+		unsigned char* keep = (unsigned char*)malloc(nm ? nm : 1);
+		#pragma omp parallel for schedule(static, 128) reduction(+:npts)
+		for (uint32_t k = 0; k < nm; ++k) { uint32_t np1 = 0; keep[k] = (unsigned char)setup_constraint(w, k, &mans[k], dt, &np1); npts += np1; }
+		for (uint32_t k = 0; k < nm; ++k) if (keep[k]) w->cons[out++] = w->cons[k];
+		free(keep);
+		w->n_cons = out;
+		w->stats.num_contact_points = npts;
+		free(mans);
+		return;
+	}
 	for (uint32_t k = 0; k < nm; ++k) {
 		sgo_constraint c = w->cons[k];
 		const sgo_manifold* m = &mans[k];
@@ -759,15 +866,18 @@ static void colour_constraints(sgo_world* w)
 	uint32_t remaining = w->n_cons, rounds = 0;
 	while (remaining) {
 		const int cur = rounds & 1, nxt = cur ^ 1;
-		/* phase A: claim */
+		/* phase A: claim (atomic min per body; the outcome is order independent) */
+		#pragma omp parallel for schedule(static, 512) if (g_threads > 1)
 		for (uint32_t k = 0; k < w->n_cons; ++k) {
 			sgo_constraint* c = &w->cons[k];
 			if (c->colour >= 0) continue;
 			sgo_body* A = &w->bodies[c->a]; sgo_body* B = &w->bodies[c->b];
-			if (body_movable(A) && c->prio < A->claim[cur]) A->claim[cur] = c->prio;
-			if (body_movable(B) && c->prio < B->claim[cur]) B->claim[cur] = c->prio;
+			if (body_movable(A)) { uint64_t cur_v = __atomic_load_n(&A->claim[cur], __ATOMIC_RELAXED); while (c->prio < cur_v && !__atomic_compare_exchange_n(&A->claim[cur], &cur_v, c->prio, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} }
+			if (body_movable(B)) { uint64_t cur_v = __atomic_load_n(&B->claim[cur], __ATOMIC_RELAXED); while (c->prio < cur_v && !__atomic_compare_exchange_n(&B->claim[cur], &cur_v, c->prio, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} }
 		}
-		/* phase B: winners take the lowest colour free on both bodies */
+		/* phase B: winners take the lowest colour free on both bodies (a body has at most one winner per round) */
+		uint32_t won = 0;
+		#pragma omp parallel for schedule(static, 512) reduction(+:won) if (g_threads > 1)
 		for (uint32_t k = 0; k < w->n_cons; ++k) {
 			sgo_constraint* c = &w->cons[k];
 			if (c->colour >= 0) continue;
@@ -783,10 +893,12 @@ static void colour_constraints(sgo_world* w)
 					if (ma) A->colour_mask |= 1ull << col;
 					if (mb) B->colour_mask |= 1ull << col;
 				}
-				--remaining;
+				++won;
 			}
 		}
+		remaining -= won;
 		/* reset the other claim buffer for the bodies the next round can touch */
+		#pragma omp parallel for schedule(static, 512) if (g_threads > 1)
 		for (uint32_t k = 0; k < w->n_cons; ++k) {
 			sgo_constraint* c = &w->cons[k];
 			w->bodies[c->a].claim[nxt] = ~0ull; w->bodies[c->b].claim[nxt] = ~0ull;
@@ -1150,6 +1262,7 @@ SGO_API int sgo_world_step(sgo_world* w, float dt)
 	memset(&w->stats, 0, sizeof(w->stats));
 
 	/* 1. MotionProperties::ApplyForceTorqueAndDragInternal (JobApplyGravity) */
+	#pragma omp parallel for schedule(static, 1024) if (g_threads > 1)
 	for (uint32_t i = 0; i < w->high; ++i) {
 		sgo_body* b = &w->bodies[i];
 		if (!b->alive || !body_movable(b)) continue;
@@ -1178,12 +1291,29 @@ SGO_API int sgo_world_step(sgo_world* w, float dt)
 	int ncol = 0; uint32_t novf = 0;
 	for (uint32_t k = 0; k < w->n_cons; ++k) { if (w->cons[k].colour + 1 > ncol) ncol = w->cons[k].colour + 1; if (w->cons[k].colour == SGO_OVERFLOW_COLOUR) ++novf; }
 
+	/* colour segments of the solve order: constraints of one colour (except the overflow colour) share no movable body, so a
+	   segment may be walked in any order or in parallel without changing a single bit */
+	uint32_t seg[SGO_MAX_COLOURS + 1];
+	{
+		uint32_t k = 0;
+		for (int c = 0; c < SGO_MAX_COLOURS; ++c) { seg[c] = k; while (k < w->n_cons && w->cons[w->order[k]].colour == c) ++k; }
+		seg[SGO_MAX_COLOURS] = k;
+	}
+	#define SOLVE_PASS(fn) do { \
+		for (int c_ = 0; c_ < SGO_MAX_COLOURS; ++c_) { \
+			const uint32_t b_ = seg[c_], e_ = seg[c_ + 1]; \
+			if (c_ != SGO_OVERFLOW_COLOUR && g_threads > 1 && e_ - b_ > 64) { \
+				_Pragma("omp parallel for schedule(static, 64)") \
+				for (uint32_t k_ = b_; k_ < e_; ++k_) fn(w, &w->cons[w->order[k_]]); \
+			} else for (uint32_t k_ = b_; k_ < e_; ++k_) fn(w, &w->cons[w->order[k_]]); \
+		} } while (0)
+
 	/* 5. warm start + velocity iterations */
-	if (w->st.warm_start) for (uint32_t k = 0; k < w->n_cons; ++k) warm_start_constraint(w, &w->cons[w->order[k]]);
-	for (int it = 0; it < w->st.num_velocity_steps; ++it)
-		for (uint32_t k = 0; k < w->n_cons; ++k) solve_velocity_constraint(w, &w->cons[w->order[k]]);
+	if (w->st.warm_start) SOLVE_PASS(warm_start_constraint);
+	for (int it = 0; it < w->st.num_velocity_steps; ++it) SOLVE_PASS(solve_velocity_constraint);
 
 	/* 6. integrate positions (Body::AddPositionStep / AddRotationStep) */
+	#pragma omp parallel for schedule(static, 1024) if (g_threads > 1)
 	for (uint32_t i = 0; i < w->high; ++i) {
 		sgo_body* b = &w->bodies[i];
 		if (!b->alive || !b->active || b->motion == SGP_MOTION_STATIC) continue;
@@ -1198,10 +1328,10 @@ SGO_API int sgo_world_step(sgo_world* w, float dt)
 	}
 
 	/* 7. position iterations */
-	for (int it = 0; it < w->st.num_position_steps; ++it)
-		for (uint32_t k = 0; k < w->n_cons; ++k) solve_position_constraint(w, &w->cons[w->order[k]]);
+	for (int it = 0; it < w->st.num_position_steps; ++it) SOLVE_PASS(solve_position_constraint);
 
 	/* 8. bounds, sleeping */
+	#pragma omp parallel for schedule(static, 1024) if (g_threads > 1)
 	for (uint32_t i = 0; i < w->high; ++i) { sgo_body* b = &w->bodies[i]; if (b->alive && b->active) body_update_aabb(b); }
 	update_sleeping(w, dt);
 
