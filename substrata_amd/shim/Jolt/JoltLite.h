@@ -51,4 +51,78 @@ namespace JPH
 		std::vector<Vec3> mRelativeContactPointsOn1;
 	};
 	class ContactSettings {};
+
+	class Quat
+	{
+	public:
+		Quat() : x(0), y(0), z(0), w(1) {}
+		Quat(float x_, float y_, float z_, float w_) : x(x_), y(y_), z(z_), w(w_) {}
+		float GetX() const { return x; } float GetY() const { return y; } float GetZ() const { return z; } float GetW() const { return w; }
+		Quat Conjugated() const { return Quat(-x, -y, -z, w); }
+		Vec3 operator*(const Vec3& v) const   // rotate
+		{
+			const float tx = 2 * (y * v.z - z * v.y), ty = 2 * (z * v.x - x * v.z), tz = 2 * (x * v.y - y * v.x);
+			return Vec3(v.x + w * tx + (y * tz - z * ty), v.y + w * ty + (z * tx - x * tz), v.z + w * tz + (x * ty - y * tx));
+		}
+		float x, y, z, w;
+	};
+	// column-major rotation + translation, the part of JPH::Mat44 the controllers read
+	class Mat44
+	{
+	public:
+		Vec3 GetAxisX() const { return c[0]; } Vec3 GetAxisY() const { return c[1]; } Vec3 GetAxisZ() const { return c[2]; }
+		Vec3 GetTranslation() const { return c[3]; }
+		Vec3 GetColumn3(int i) const { return c[i]; }
+		Vec3 operator*(const Vec3& v) const { return c[0] * v.x + c[1] * v.y + c[2] * v.z + c[3]; }
+		Vec3 Multiply3x3(const Vec3& v) const { return c[0] * v.x + c[1] * v.y + c[2] * v.z; }
+		Vec3 c[4];
+	};
+	enum class EActivation { Activate, DontActivate };
+}
+
+struct sgp_world;
+
+namespace JPH
+{
+	// JPH::BodyInterface look-alike: the calls HoverCarPhysics.cpp:113-348,425-480, BoatPhysics.cpp:35-49,134-267,367-385 and
+	// GUIClient.cpp:6577-6673 make through physics_world.physics_system->GetBodyInterface(), forwarded to the sgp C ABI.
+	// Getters share one cached read-back per body between world mutations (invalidate() is called by PhysicsWorld::think and setters).
+	class BodyInterface
+	{
+	public:
+		explicit BodyInterface(sgp_world* w) : world(w), cached_id(0xFFFFFFFFu) {}
+		void ActivateBody(const BodyID& id);
+		void AddForce(const BodyID& id, const Vec3& force);
+		void AddForce(const BodyID& id, const Vec3& force, const RVec3& point);
+		void AddTorque(const BodyID& id, const Vec3& torque);
+		RVec3 GetPosition(const BodyID& id) const;
+		RVec3 GetCenterOfMassPosition(const BodyID& id) const;
+		Quat GetRotation(const BodyID& id) const;
+		void GetPositionAndRotation(const BodyID& id, RVec3& pos_out, Quat& rot_out) const;
+		Mat44 GetWorldTransform(const BodyID& id) const;
+		Vec3 GetLinearVelocity(const BodyID& id) const;
+		Vec3 GetAngularVelocity(const BodyID& id) const;
+		void GetLinearAndAngularVelocity(const BodyID& id, Vec3& lin_out, Vec3& ang_out) const;
+		Vec3 GetPointVelocity(const BodyID& id, const RVec3& point) const;
+		void SetLinearAndAngularVelocity(const BodyID& id, const Vec3& lin, const Vec3& ang);
+		bool IsActive(const BodyID& id) const;
+		void invalidate() const { cached_id = 0xFFFFFFFFu; }
+	private:
+		void fetch(const BodyID& id) const;
+		sgp_world* world;
+		mutable uint32_t cached_id;
+		mutable float st_pos[3], st_rot[4], st_lv[3], st_av[3];
+		mutable bool st_active;
+	};
+
+	class PhysicsSystem
+	{
+	public:
+		explicit PhysicsSystem(sgp_world* w) : body_interface(w) {}
+		BodyInterface& GetBodyInterface() { return body_interface; }
+		const BodyInterface& GetBodyInterface() const { return body_interface; }
+		Vec3 GetGravity() const { return Vec3(0, 0, -9.81f); }   // PhysicsWorld.cpp:520
+	private:
+		BodyInterface body_interface;
+	};
 }

@@ -27,9 +27,10 @@ PhysicsWorld::PhysicsWorld(glare::TaskManager* task_manager_, glare::StackAlloca
 	const int r = sgp_world_create(&d, &world);
 	if (r != SGP_OK) { world = NULL; throw glare::Exception(std::string("PhysicsWorld: ") + sgp_last_error()); }
 	id_to_ob.resize(d.max_bodies, NULL);
+	physics_system = new JPH::PhysicsSystem(world);
 }
 
-PhysicsWorld::~PhysicsWorld() { if (world) sgp_world_destroy(world); }
+PhysicsWorld::~PhysicsWorld() { delete physics_system; if (world) sgp_world_destroy(world); }
 
 void PhysicsWorld::setWaterBuoyancyEnabled(bool enabled) { water_buoyancy_enabled = enabled; sgp_world_set_water(world, enabled ? 1 : 0, water_z); }
 void PhysicsWorld::setWaterZ(float z) { water_z = z; sgp_world_set_water(world, water_buoyancy_enabled ? 1 : 0, water_z); }
@@ -143,6 +144,7 @@ void PhysicsWorld::drainActivationEvents()
 void PhysicsWorld::think(double dt)
 {
 	sgp_world_set_contact_events(world, event_listener ? 1 : 0);
+	physics_system->GetBodyInterface().invalidate();
 	sgp_world_step(world, (float)dt);                            // physics_system->Update((float)dt, 1, ...) (:1363) + buoyancy sweep (:1367-1442)
 	drainActivationEvents();
 
@@ -352,3 +354,46 @@ bool PhysicsWorld::doesRayHitAnything(const Vec4f& origin, const Vec4f& dir, flo
 	sgp_hit h;
 	return sgp_raycast(world, &r, 1, &h) == SGP_OK && h.id != SGP_INVALID_ID;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// JPH::BodyInterface look-alike over the C ABI (declared in Jolt/JoltLite.h)
+
+void JPH::BodyInterface::fetch(const BodyID& id) const
+{
+	const uint32_t i = id.GetIndex();
+	if (i == cached_id) return;
+	sgp_body_state st;
+	memset(&st, 0, sizeof(st)); st.rot[3] = 1.f;
+	if (!id.IsInvalid()) sgp_body_get_state(world, &i, 1, &st);
+	for (int k = 0; k < 3; ++k) { st_pos[k] = st.pos[k]; st_lv[k] = st.lin_vel[k]; st_av[k] = st.ang_vel[k]; }
+	for (int k = 0; k < 4; ++k) st_rot[k] = st.rot[k];
+	st_active = st.active != 0;
+	cached_id = i;
+}
+void JPH::BodyInterface::ActivateBody(const BodyID& id) { if (!id.IsInvalid()) { sgp_body_activate(world, id.GetIndex()); invalidate(); } }
+void JPH::BodyInterface::AddForce(const BodyID& id, const Vec3& f) { if (!id.IsInvalid()) sgp_body_add_force(world, id.GetIndex(), &f.x); }
+void JPH::BodyInterface::AddForce(const BodyID& id, const Vec3& f, const RVec3& p) { if (!id.IsInvalid()) sgp_body_add_force_at(world, id.GetIndex(), &f.x, &p.x); }
+void JPH::BodyInterface::AddTorque(const BodyID& id, const Vec3& t) { if (!id.IsInvalid()) sgp_body_add_torque(world, id.GetIndex(), &t.x); }
+JPH::RVec3 JPH::BodyInterface::GetPosition(const BodyID& id) const { fetch(id); return RVec3(st_pos[0], st_pos[1], st_pos[2]); }
+JPH::RVec3 JPH::BodyInterface::GetCenterOfMassPosition(const BodyID& id) const { return GetPosition(id); }   // primitives: COM = shape origin
+JPH::Quat JPH::BodyInterface::GetRotation(const BodyID& id) const { fetch(id); return Quat(st_rot[0], st_rot[1], st_rot[2], st_rot[3]); }
+void JPH::BodyInterface::GetPositionAndRotation(const BodyID& id, RVec3& p, Quat& r) const { p = GetPosition(id); r = GetRotation(id); }
+JPH::Mat44 JPH::BodyInterface::GetWorldTransform(const BodyID& id) const
+{
+	const Quat q = GetRotation(id);
+	Mat44 m;
+	m.c[0] = q * Vec3(1, 0, 0); m.c[1] = q * Vec3(0, 1, 0); m.c[2] = q * Vec3(0, 0, 1); m.c[3] = GetPosition(id);
+	return m;
+}
+JPH::Vec3 JPH::BodyInterface::GetLinearVelocity(const BodyID& id) const { fetch(id); return Vec3(st_lv[0], st_lv[1], st_lv[2]); }
+JPH::Vec3 JPH::BodyInterface::GetAngularVelocity(const BodyID& id) const { fetch(id); return Vec3(st_av[0], st_av[1], st_av[2]); }
+void JPH::BodyInterface::GetLinearAndAngularVelocity(const BodyID& id, Vec3& l, Vec3& a) const { l = GetLinearVelocity(id); a = GetAngularVelocity(id); }
+JPH::Vec3 JPH::BodyInterface::GetPointVelocity(const BodyID& id, const RVec3& p) const
+{
+	fetch(id);
+	const Vec3 r(p.x - st_pos[0], p.y - st_pos[1], p.z - st_pos[2]);
+	return Vec3(st_lv[0] + (st_av[1] * r.z - st_av[2] * r.y), st_lv[1] + (st_av[2] * r.x - st_av[0] * r.z), st_lv[2] + (st_av[0] * r.y - st_av[1] * r.x));
+}
+void JPH::BodyInterface::SetLinearAndAngularVelocity(const BodyID& id, const Vec3& l, const Vec3& a) { if (!id.IsInvalid()) { sgp_body_set_vel(world, id.GetIndex(), &l.x, &a.x); invalidate(); } }
+bool JPH::BodyInterface::IsActive(const BodyID& id) const { fetch(id); return st_active; }

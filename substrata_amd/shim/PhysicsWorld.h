@@ -110,7 +110,8 @@ public:
 	HashSet<PhysicsObject*> newly_activated_obs GUARDED_BY(activated_obs_mutex);
 	PhysicsWorldEventListener* event_listener;
 
-	sgp_world* world;   // the C-ABI handle (in place of physics_system / temp_allocator / job_system)
+	sgp_world* world;                   // the C-ABI handle (in place of temp_allocator / job_system)
+	JPH::PhysicsSystem* physics_system; // look-alike carrying GetBodyInterface() for the controllers that reach around the facade (PhysicsWorld.h:204)
 
 private:
 	void drainActivationEvents();

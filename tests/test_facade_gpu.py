@@ -12,12 +12,12 @@ from helpers import DT
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def build_facade_exe(tmp_path):
+def build_facade_exe(tmp_path, src="facade_scene.cpp"):
     build.build()
     build_shim.build()
-    exe = str(tmp_path / "facade_scene")
+    exe = str(tmp_path / src.replace(".cpp", ""))
     lib_dir = os.path.join(ROOT, "substrata_amd")
-    cmd = ["g++", "-O2", "-std=c++17", "-I", os.path.join(lib_dir, "shim"), os.path.join(ROOT, "tests", "cpp", "facade_scene.cpp"),
+    cmd = ["g++", "-O2", "-std=c++17", "-I", os.path.join(lib_dir, "shim"), os.path.join(ROOT, "tests", "cpp", src),
            "-o", exe, "-L", lib_dir, "-lsgp_shim", "-lsgp", f"-Wl,-rpath,{lib_dir}"]
     subprocess.run(cmd, check=True)
     return exe
@@ -26,6 +26,17 @@ def build_facade_exe(tmp_path):
 def test_facade_compiles_without_gpu(tmp_path):
     """CPU check: the facade and a GUIClient-style caller compile and link against libsgp.so (no run)."""
     assert os.path.exists(build_facade_exe(tmp_path))
+    assert os.path.exists(build_facade_exe(tmp_path, "hover_controller.cpp"))
+
+
+@pytest.mark.gpu
+def test_hover_controller_through_body_interface(tmp_path):
+    """A HoverCarPhysics-shaped controller drives a body through physics_system->GetBodyInterface() (AddForce, AddTorque,
+    GetWorldTransform, GetLinearVelocity ...): the body settles at the spring's target height and has yawed."""
+    exe = build_facade_exe(tmp_path, "hover_controller.cpp")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
 
 
 @pytest.mark.gpu
