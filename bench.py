@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the oracle (0 = min(32, host cpus))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=8)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for single-GPU dry runs of the tile exchange)")
+    ap.add_argument("--share-gpu", action="store_true", help="dry run: every rank uses cuda:0 (needs --backend gloo)")
     return ap.parse_args()
 
 
@@ -60,10 +62,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     n_gpus = args.gpus
     dist = None
+    if args.share_gpu:
+        local_rank = 0
     if world_size > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
         assert world_size == n_gpus, "launch with --nproc-per-node equal to --gpus"
     elif n_gpus != 1:
         raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run with N ranks")
@@ -84,7 +91,8 @@ def main():
     n_bodies = len(descs) - 1
     w = World(max_bodies=len(descs) + 32768, device=local_rank)
     w.add_batch(descs)
-    ex = tiles.GhostExchange(w, rank, n_gpus, lo, hi, margin=2.0, dist=dist, device=torch.device("cuda", local_rank)) if n_gpus > 1 else None
+    xdev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")
+    ex = tiles.GhostExchange(w, rank, n_gpus, lo, hi, margin=2.0, dist=dist, device=xdev) if n_gpus > 1 else None
 
     def one_step():
         if ex is not None:
@@ -106,7 +114,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = w.stats()

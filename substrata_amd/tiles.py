@@ -3,10 +3,10 @@
 The path shards by space.  Each rank OWNS the bodies created in its tile and simulates them dynamically; bodies whose
 AABB (inflated by the ghost margin) pokes out of the owner's tile are exported once per sub-step and imported by every
 rank whose tile (inflated by the margin) they touch, where they are simulated as velocity-driven infinite-mass ghosts
-(kinematic bodies) for that step.  The only collective is one variable-length all-gather of ghost records per step
-(torch.distributed: backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).  Ghost traffic is
-~1e3-1e4 records x 104 B per rank, so the exchange is latency- not bandwidth-bound: it is fused into ONE collective
-(counts ride in the same padded buffer).  No migration in this round: a body stays owned by the tile it was created in.
+(kinematic bodies) for that step.  The only collectives are, per step, one all-gather of the record counts (8 B per rank) and
+one all-gather of the ghost records padded to the largest count (torch.distributed: backend "nccl" = RCCL over xGMI on the
+GPU box, "gloo" in the CPU tests).  Ghost traffic is ~1e3-1e4 records x 104 B per rank, so the exchange is latency- not
+bandwidth-bound.  No migration in this round: a body stays owned by the tile it was created in.
 """
 import numpy as np
 
@@ -47,7 +47,7 @@ def select_ghosts(recs, lo, hi, margin, radius_pad=1.5):
 
 
 class GhostExchange:
-    """One fused all-gather of boundary records per step."""
+    """Per step: one tiny all-gather of the record counts, then one all-gather of the records padded to the largest count."""
 
     def __init__(self, world, rank, n_tiles, lo, hi, margin, dist=None, device=None, cap=1 << 16):
         self.world, self.rank, self.n = world, rank, n_tiles
@@ -58,9 +58,10 @@ class GhostExchange:
         if dist is not None:
             import torch
             self.torch = torch
-            # slot 0 of every rank's block carries its record count
-            self.send = torch.zeros((cap + 1) * REC, dtype=torch.uint8, device=device)
-            self.recv = torch.zeros(n_tiles * (cap + 1) * REC, dtype=torch.uint8, device=device)
+            self.cnt_send = torch.zeros(1, dtype=torch.int64, device=device)
+            self.cnt_recv = torch.zeros(n_tiles, dtype=torch.int64, device=device)
+            self.send = torch.zeros(cap * REC, dtype=torch.uint8, device=device)
+            self.recv = torch.zeros(n_tiles * cap * REC, dtype=torch.uint8, device=device)
 
     def exchange(self):
         recs = self.world.export_boundary(self.lo, self.hi, self.margin, cap=self.cap)
@@ -70,20 +71,24 @@ class GhostExchange:
             self.world.import_ghosts(recs[:0])
             return
         torch = self.torch
-        buf = np.zeros((self.cap + 1) * REC, dtype=np.uint8)
-        buf[:8] = np.frombuffer(np.uint64(len(recs)).tobytes(), dtype=np.uint8)
+        self.cnt_send[0] = len(recs)
+        self.dist.all_gather_into_tensor(self.cnt_recv, self.cnt_send)
+        counts = self.cnt_recv.cpu().numpy()
+        maxc = int(counts.max())
+        if maxc == 0:
+            self.last_imported = 0
+            self.world.import_ghosts(recs[:0])
+            return
+        nbytes = maxc * REC
         if len(recs):
-            buf[REC:REC + len(recs) * REC] = recs.view(np.uint8).reshape(-1)
-        self.send.copy_(torch.from_numpy(buf), non_blocking=False)
-        self.dist.all_gather_into_tensor(self.recv, self.send)
-        allb = self.recv.cpu().numpy().reshape(self.n, (self.cap + 1) * REC)
+            self.send[:len(recs) * REC].copy_(torch.from_numpy(recs.view(np.uint8).reshape(-1).copy()))
+        self.dist.all_gather_into_tensor(self.recv[:self.n * nbytes], self.send[:nbytes])
+        allb = self.recv[:self.n * nbytes].cpu().numpy().reshape(self.n, nbytes)
         parts = []
         for r in range(self.n):
-            if r == self.rank:
-                continue
-            cnt = int(np.frombuffer(allb[r, :8].tobytes(), dtype=np.uint64)[0])
-            if cnt:
-                parts.append(np.frombuffer(allb[r, REC:REC + cnt * REC].tobytes(), dtype=abi.ghost_dtype))
+            c = int(counts[r])
+            if r != self.rank and c:
+                parts.append(np.frombuffer(allb[r, :c * REC].tobytes(), dtype=abi.ghost_dtype))
         others = np.concatenate(parts) if parts else np.zeros(0, dtype=abi.ghost_dtype)
         mine = select_ghosts(others, self.lo, self.hi, self.margin)
         self.last_imported = len(mine)
