@@ -1614,6 +1614,7 @@ SGO_API int sgo_raycast(sgo_world* w, const sgp_ray* rays, uint32_t n, sgp_hit* 
 			if (rays[k].collidable_only && !(b->layer == SGP_LAYER_NON_MOVING || b->layer == SGP_LAYER_MOVING)) continue;
 			v3 nn;
 			const float t = ray_body(b, o, d, best, &nn);
+			/* closest hit; on equal t the lower body id wins (ids are visited in ascending order) */
 			if (t >= 0.0f && (t < best || bid == SGP_INVALID_ID) && t <= best) { best = t; bid = i; bn = nn; }
 		}
 		hits[k].id = bid; hits[k].t = bid == SGP_INVALID_ID ? 0.0f : best;

@@ -1617,40 +1617,103 @@ SGP_DEV float ray_body(uint32_t type, float4 sh, v3 pos, quat q, v3 o, v3 dir, f
 	}
 }
 
+SGP_DEV bool ray_aabb(v3 o, v3 dir, float4 mn, float4 mx, float tmax)
+{
+	float t0 = 0.0f, t1 = tmax;
+	const float oo[3] = { o.x, o.y, o.z }, dd[3] = { dir.x, dir.y, dir.z };
+	const float lo[3] = { mn.x, mn.y, mn.z }, hi[3] = { mx.x, mx.y, mx.z };
+#pragma unroll
+	for (int a = 0; a < 3; ++a) {
+		if (fabsf(dd[a]) < 1.0e-12f) { if (oo[a] < lo[a] - 1.0e-4f || oo[a] > hi[a] + 1.0e-4f) return false; }
+		else {
+			float ta = (lo[a] - 1.0e-4f - oo[a]) / dd[a], tb = (hi[a] + 1.0e-4f - oo[a]) / dd[a];
+			if (ta > tb) { const float tmp = ta; ta = tb; tb = tmp; }
+			t0 = fmaxf(t0, ta); t1 = fminf(t1, tb);
+			if (t0 > t1) return false;
+		}
+	}
+	return true;
+}
+
+struct RayBest { float t; uint32_t id; v3 n; };
+
+SGP_DEV void ray_test_body(const DV& d, const sgp_ray& ry, v3 o, v3 dir, uint32_t i, RayBest& best)
+{
+	if (i == ry.ignore_id) return;
+	const uint32_t f = d.flags[i];
+	if (!(f & BF_ALIVE)) return;
+	const uint32_t layer = f_layer(f);
+	if (ry.collidable_only && !(layer == SGP_LAYER_NON_MOVING || layer == SGP_LAYER_MOVING)) return;
+	if (!ray_aabb(o, dir, d.aabb_min[i], d.aabb_max[i], best.t)) return;
+	v3 nn;
+	const float t = ray_body(f_shape(f), d.shape[i], V3(d.pos_im[i]), Q4(d.rot[i]), o, dir, best.t, &nn);
+	// closest hit; ties go to the lower body id so the result does not depend on the traversal order
+	if (t >= 0.0f && t <= best.t && (t < best.t || best.id == SGP_INVALID_ID || i < best.id)) { best.t = t; best.id = i; best.n = nn; }
+}
+
+// traceRay (PhysicsWorld.cpp:1668-1725), batched: one thread per ray.  Large bodies (ground quad ...) are tested directly;
+// small bodies through a 3D-DDA walk of the broad-phase cell grid (bodies are binned by centre and reach at most one cell
+// beyond it, so every visited cell also looks at its 26 neighbours), stopping once the cell entry distance passes the best hit.
 __global__ void __launch_bounds__(64) k_raycast(DV d, const sgp_ray* rays, uint32_t n, sgp_hit* hits)
 {
 	const uint32_t k = blockIdx.x * 64 + threadIdx.x;
 	if (k >= n) return;
 	const sgp_ray ry = rays[k];
 	const v3 o = V3(ry.origin[0], ry.origin[1], ry.origin[2]), dir = V3(ry.dir[0], ry.dir[1], ry.dir[2]);
-	float best = ry.max_t; uint32_t bid = SGP_INVALID_ID; v3 bn = V3(0.0f, 0.0f, 0.0f);
-	for (uint32_t i = 0; i < d.sp->n_slots; ++i) {
-		const uint32_t f = d.flags[i];
-		if (!(f & BF_ALIVE) || i == ry.ignore_id) continue;
-		const uint32_t layer = f_layer(f);
-		if (ry.collidable_only && !(layer == SGP_LAYER_NON_MOVING || layer == SGP_LAYER_MOVING)) continue;
-		// slab test against the world AABB
-		const float4 mn = d.aabb_min[i], mx = d.aabb_max[i];
-		float t0 = 0.0f, t1 = best; bool miss = false;
+	RayBest best; best.t = ry.max_t; best.id = SGP_INVALID_ID; best.n = V3(0.0f, 0.0f, 0.0f);
+	for (uint32_t l = 0; l < d.sp->n_large; ++l) ray_test_body(d, ry, o, dir, d.large_ids[l], best);
+	const BpGrid g = *d.grid;
+	if (g.n_cells > 0 && g.min_x <= g.max_x) {
+		// clip the ray to the grid box inflated by one cell (bodies reach one cell beyond their centre cell)
+		const float c = g.cell;
+		const v3 lo = V3(g.ox - c, g.oy - c, g.oz - c);
+		const v3 hi = V3(g.ox + ((float)g.nx + 1.0f) * c, g.oy + ((float)g.ny + 1.0f) * c, g.oz + ((float)g.nz + 1.0f) * c);
+		float t0 = 0.0f, t1 = best.t; bool miss = false;
 		const float oo[3] = { o.x, o.y, o.z }, dd[3] = { dir.x, dir.y, dir.z };
-		const float lo[3] = { mn.x, mn.y, mn.z }, hi[3] = { mx.x, mx.y, mx.z };
+		const float bl[3] = { lo.x, lo.y, lo.z }, bh[3] = { hi.x, hi.y, hi.z };
 		for (int a = 0; a < 3 && !miss; ++a) {
-			if (fabsf(dd[a]) < 1.0e-12f) { if (oo[a] < lo[a] - 1.0e-4f || oo[a] > hi[a] + 1.0e-4f) miss = true; }
+			if (fabsf(dd[a]) < 1.0e-12f) { if (oo[a] < bl[a] || oo[a] > bh[a]) miss = true; }
 			else {
-				float ta = (lo[a] - 1.0e-4f - oo[a]) / dd[a], tb = (hi[a] + 1.0e-4f - oo[a]) / dd[a];
+				float ta = (bl[a] - oo[a]) / dd[a], tb = (bh[a] - oo[a]) / dd[a];
 				if (ta > tb) { const float tmp = ta; ta = tb; tb = tmp; }
 				t0 = fmaxf(t0, ta); t1 = fminf(t1, tb);
 				if (t0 > t1) miss = true;
 			}
 		}
-		if (miss) continue;
-		v3 nn;
-		const float t = ray_body(f_shape(f), d.shape[i], V3(d.pos_im[i]), Q4(d.rot[i]), o, dir, best, &nn);
-		if (t >= 0.0f && (t < best || bid == SGP_INVALID_ID) && t <= best) { best = t; bid = i; bn = nn; }
+		if (!miss) {
+			// DDA over cells (cell coordinates may run one cell outside the grid on each side)
+			const v3 p0 = v3_add(o, v3_scale(dir, t0));
+			int cx = (int)floorf((p0.x - g.ox) * g.inv_cell), cy = (int)floorf((p0.y - g.oy) * g.inv_cell), cz = (int)floorf((p0.z - g.oz) * g.inv_cell);
+			cx = min(max(cx, -1), g.nx); cy = min(max(cy, -1), g.ny); cz = min(max(cz, -1), g.nz);
+			const int sx = dir.x > 0.0f ? 1 : -1, sy = dir.y > 0.0f ? 1 : -1, sz = dir.z > 0.0f ? 1 : -1;
+			const float inf = 3.0e38f;
+			const float tdx = fabsf(dir.x) > 1.0e-12f ? c / fabsf(dir.x) : inf, tdy = fabsf(dir.y) > 1.0e-12f ? c / fabsf(dir.y) : inf, tdz = fabsf(dir.z) > 1.0e-12f ? c / fabsf(dir.z) : inf;
+			float tmx = fabsf(dir.x) > 1.0e-12f ? ((g.ox + (float)(cx + (sx > 0 ? 1 : 0)) * c) - o.x) / dir.x : inf;
+			float tmy = fabsf(dir.y) > 1.0e-12f ? ((g.oy + (float)(cy + (sy > 0 ? 1 : 0)) * c) - o.y) / dir.y : inf;
+			float tmz = fabsf(dir.z) > 1.0e-12f ? ((g.oz + (float)(cz + (sz > 0 ? 1 : 0)) * c) - o.z) / dir.z : inf;
+			float t_enter = t0;
+			for (int iter = 0; iter < 100000; ++iter) {
+				if (t_enter - 2.0f * c > best.t) break;           // nothing nearer can come from cells this far along the ray
+				for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) {
+					const int y = cy + dy, z = cz + dz;
+					if (y < 0 || y >= g.ny || z < 0 || z >= g.nz) continue;
+					const int xa = max(cx - 1, 0), xb = min(cx + 1, g.nx - 1);
+					if (xa > xb) continue;
+					const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
+					const uint32_t q0 = d.cell_start[row + (uint32_t)xa], q1 = d.cell_start[row + (uint32_t)xb + 1];
+					for (uint32_t q = q0; q < q1; ++q) ray_test_body(d, ry, o, dir, __float_as_uint(d.sorted_max[q].w), best);
+				}
+				// next cell
+				if (tmx <= tmy && tmx <= tmz) { t_enter = tmx; tmx += tdx; cx += sx; if (cx < -1 || cx > g.nx) break; }
+				else if (tmy <= tmz) { t_enter = tmy; tmy += tdy; cy += sy; if (cy < -1 || cy > g.ny) break; }
+				else { t_enter = tmz; tmz += tdz; cz += sz; if (cz < -1 || cz > g.nz) break; }
+				if (t_enter > t1) break;
+			}
+		}
 	}
 	sgp_hit h;
-	h.id = bid; h.t = bid == SGP_INVALID_ID ? 0.0f : best;
-	h.normal[0] = bn.x; h.normal[1] = bn.y; h.normal[2] = bn.z;
+	h.id = best.id; h.t = best.id == SGP_INVALID_ID ? 0.0f : best.t;
+	h.normal[0] = best.n.x; h.normal[1] = best.n.y; h.normal[2] = best.n.z;
 	h.userdata = 0;
 	hits[k] = h;
 }

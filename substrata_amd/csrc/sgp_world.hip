@@ -75,6 +75,7 @@ struct sgp_world {
 	std::map<std::string, hipGraphExec_t> graphs;              // replayable launch sequences keyed by launch plan
 	std::string last_plan_key; uint32_t plan_repeats = 0; bool use_graphs = true;
 	uint32_t graph_launches = 0, eager_steps = 0;
+	bool grid_valid = false;                                   // the broad-phase grid matches the current poses (ray queries reuse it)
 	// events collected on the host until drained
 	std::vector<sgp_body_event> ev_act, ev_deact, ev_water;
 	std::vector<sgp_contact_event> ev_added, ev_pers;
@@ -512,6 +513,7 @@ static int flush_cmds(sgp_world* w)
 	}
 	{ int r = upload_sp(w); if (r != SGP_OK) return r; }
 	if (w->cmds.empty()) return SGP_OK;
+	w->grid_valid = false;
 	const size_t n = w->cmds.size();
 	std::vector<uint32_t> order(n);
 	for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
@@ -742,6 +744,7 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	// -- the ONE host sync of the step: counters, events, and the launch plan for the next step
 	HIP_TRY(hipStreamSynchronize(w->stream));
 	w->h_sp->parity ^= 1u;                    // the buffer just solved becomes the contact cache of the next step
+	w->grid_valid = false;                    // bodies moved after the broad phase of this step
 	const StepCounters c1 = *w->h_ctr;
 	const uint32_t n_con = c1.n_constraints;
 	w->n_con = n_con;
@@ -962,6 +965,15 @@ SGP_API int sgp_raycast(sgp_world* w, const sgp_ray* rays, uint32_t n, sgp_hit* 
 	hipSetDevice(w->device);
 	{ int r = flush_cmds(w); if (r != SGP_OK) return r; }
 	if (!n) return SGP_OK;
+	if (!w->grid_valid && w->high) {
+		// poses changed since the grid was built (a step integrates after its broad phase; edits move bodies): re-bin
+		const DV& d = w->dv; hipStream_t s = w->stream; const uint32_t nb = w->high;
+		launch_step_begin(d, s);
+		HIP_TRY(hipMemsetAsync(d.cell_count, 0, sizeof(uint32_t) * (d.table_size + 4), s));
+		HIP_TRY(hipMemsetAsync(d.cell_fill, 0, sizeof(uint32_t) * (d.table_size + 4), s));
+		launch_bp_bounds(d, nb, s); launch_bp_cell(d, nb, s); launch_bp_scan(d, s); launch_bp_scatter(d, nb, s);
+		w->grid_valid = true;
+	}
 	const size_t rb = (sizeof(sgp_ray) * n + 15) & ~size_t(15);
 	{ int r = ensure_stage(w, rb + sizeof(sgp_hit) * n); if (r != SGP_OK) return r; }
 	memcpy(w->stage_host, rays, sizeof(sgp_ray) * n);
