@@ -52,6 +52,7 @@ typedef struct {
 	int underwater; float submerged;
 	/* per-step scratch */
 	uint64_t colour_mask; uint64_t claim[2];
+	int movable_prev, movable_cur;   /* movable (dynamic and awake) when the previous / this step coloured its constraints */
 	int island; int can_sleep;
 } sgo_body;
 
@@ -861,9 +862,26 @@ static void find_contacts(sgo_world* w, float dt)
 
 static void colour_constraints(sgo_world* w)
 {
-	for (uint32_t i = 0; i < w->high; ++i) { w->bodies[i].colour_mask = 0; w->bodies[i].claim[0] = w->bodies[i].claim[1] = ~0ull; }
-	for (uint32_t k = 0; k < w->n_cons; ++k) w->cons[k].colour = -1;
-	uint32_t remaining = w->n_cons, rounds = 0;
+	for (uint32_t i = 0; i < w->high; ++i) {
+		sgo_body* b = &w->bodies[i];
+		b->colour_mask = 0; b->claim[0] = b->claim[1] = ~0ull;
+		b->movable_prev = b->movable_cur; b->movable_cur = b->alive && body_movable(b);
+	}
+	/* Colour inheritance through the contact cache: a persisted manifold keeps last step's colour when both of its movable
+	   bodies were already movable when that colour was chosen (then last step's proper colouring guarantees that no two
+	   inheritors sharing a movable body carry the same colour).  Only the other manifolds go through the rounds below. */
+	uint32_t remaining = 0, rounds = 0;
+	for (uint32_t k = 0; k < w->n_cons; ++k) {
+		sgo_constraint* c = &w->cons[k];
+		c->colour = -1;
+		const sgo_constraint* pc = find_prev(w, c->key);
+		sgo_body* A = &w->bodies[c->a]; sgo_body* B = &w->bodies[c->b];
+		if (pc && pc->colour >= 0 && pc->colour < SGO_OVERFLOW_COLOUR && (!A->movable_cur || A->movable_prev) && (!B->movable_cur || B->movable_prev)) {
+			c->colour = pc->colour;
+			if (A->movable_cur) A->colour_mask |= 1ull << c->colour;
+			if (B->movable_cur) B->colour_mask |= 1ull << c->colour;
+		} else ++remaining;
+	}
 	while (remaining) {
 		const int cur = rounds & 1, nxt = cur ^ 1;
 		/* phase A: claim (atomic min per body; the outcome is order independent) */

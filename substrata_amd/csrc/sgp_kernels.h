@@ -23,6 +23,8 @@
 #define BF_SHAPE_MASK    (0x3u << BF_SHAPE_SHIFT)
 #define BF_WAKE          (1u << 14)  // scratch: touched by an active body this step
 #define BF_CAN_SLEEP     (1u << 15)  // scratch: sleep test result
+#define BF_MOVABLE_PREV  (1u << 16)  // movable (dynamic and awake) when the PREVIOUS step coloured its constraints
+#define BF_MOVABLE_CUR   (1u << 17)  // same, this step
 
 #define SGP_MAX_COLOURS      64
 #define SGP_OVERFLOW_COLOUR  63
@@ -204,6 +206,7 @@ void launch_bp_large(const DV& d, uint32_t nb, hipStream_t s);
 void launch_narrowphase(const DV& d, uint32_t n_pairs_upper, hipStream_t s);
 void launch_wake(const DV& d, uint32_t nb, hipStream_t s);
 void launch_prep_bodies(const DV& d, uint32_t nb, hipStream_t s);
+void launch_colour_inherit(const DV& d, uint32_t n_man, hipStream_t s);
 void launch_colour_claim(const DV& d, uint32_t n_man, uint32_t round, hipStream_t s);
 void launch_colour_commit(const DV& d, uint32_t n_man, uint32_t round, hipStream_t s);
 void launch_colour_count(const DV& d, uint32_t n_man, hipStream_t s);

@@ -575,6 +575,11 @@ __global__ void __launch_bounds__(TPB) k_prep_bodies(DV d)
 		}
 	}
 	d.sbody[4 * i + 0] = v; d.sbody[4 * i + 1] = w; d.sbody[4 * i + 2] = a; d.sbody[4 * i + 3] = b;
+	// remember whether the body was movable when the previous step coloured its constraints (colour inheritance)
+	uint32_t nf = f & ~(BF_MOVABLE_PREV | BF_MOVABLE_CUR);
+	if (f & BF_MOVABLE_CUR) nf |= BF_MOVABLE_PREV;
+	if (f_movable(f)) nf |= BF_MOVABLE_CUR;
+	if (nf != f) d.flags[i] = nf;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -582,23 +587,52 @@ __global__ void __launch_bounds__(TPB) k_prep_bodies(DV d)
 // claims its movable bodies with atomicMin; the manifold that holds both claims takes the lowest colour free on
 // both bodies.  The result depends only on the SET of manifolds (spec: DESIGN.md "Colouring").
 
+SGP_DEV uint32_t cache_find(const DV& d, uint64_t key);
+
+// Colour inheritance through the contact cache: a persisted manifold keeps last step's colour when both of its movable
+// bodies were already movable when that colour was chosen (last step's proper colouring then guarantees that no two
+// inheritors sharing a movable body carry the same colour).  Only the remaining manifolds go through the rounds.
+__global__ void __launch_bounds__(TPB) k_colour_inherit(DV d)
+{
+	const uint32_t n = min(d.ctr->n_manifolds, d.cap_manifolds);
+	for (uint32_t m = blockIdx.x * TPB + threadIdx.x; m < n; m += gridDim.x * TPB) {
+		if (d.man_colour[m] != -1) continue;
+		const uint2 ab = d.man_ab[m];
+		const uint32_t ps = cache_find(d, ((uint64_t)ab.x << 32) | ab.y);
+		if (ps == 0xFFFFFFFFu) continue;
+		const int pc = (PRV(d).np_col[ps] >> 8) & 0xFF;
+		if (pc >= SGP_OVERFLOW_COLOUR) continue;
+		const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
+		const bool ma = fa & BF_MOVABLE_CUR, mb = fb & BF_MOVABLE_CUR;
+		if ((ma && !(fa & BF_MOVABLE_PREV)) || (mb && !(fb & BF_MOVABLE_PREV))) continue;
+		d.man_colour[m] = pc;
+		if (ma) atomicOr((unsigned long long*)&d.colour_mask[ab.x], 1ull << pc);
+		if (mb) atomicOr((unsigned long long*)&d.colour_mask[ab.y], 1ull << pc);
+	}
+}
+
 // Round 0 walks every manifold; later rounds walk the compacted worklist of still-uncoloured manifolds that the previous
 // commit produced, so the work per round shrinks with the remaining set.
 __global__ void __launch_bounds__(TPB) k_colour_claim(DV d, uint32_t round)
 {
 	const uint32_t par = round & 1;
 	const uint32_t n = round == 0 ? min(d.ctr->n_manifolds, d.cap_manifolds) : d.ctr->ucount[par];
-	if (blockIdx.x == 0 && threadIdx.x == 0) { d.ctr->ucount[par ^ 1] = 0; if (n) d.ctr->rounds_used = round + 1; }   // commit(round) appends to the other list
+	if (blockIdx.x == 0 && threadIdx.x == 0) d.ctr->ucount[par ^ 1] = 0;      // commit(round) appends to the other list
 	const uint32_t* list = d.ulist[par];
 	unsigned long long* claim = (unsigned long long*)d.claim[par];
+	bool saw = false;
 	for (uint32_t idx = blockIdx.x * TPB + threadIdx.x; idx < n; idx += gridDim.x * TPB) {
 		const uint32_t m = round == 0 ? idx : list[idx];
 		if (round == 0 && d.man_colour[m] != -1) continue;
+		saw = true;
 		const uint2 ab = d.man_ab[m];
 		const unsigned long long pr = d.man_prio[m];
 		if (f_movable(d.flags[ab.x])) atomicMin(&claim[ab.x], pr);
 		if (f_movable(d.flags[ab.y])) atomicMin(&claim[ab.y], pr);
 	}
+	// a round counts when it found an uncoloured manifold
+	const unsigned long long any = __ballot(saw);
+	if (any && (threadIdx.x & 63) == 0) atomicMax(&d.ctr->rounds_used, round + 1);
 }
 
 __global__ void __launch_bounds__(TPB) k_colour_commit(DV d, uint32_t round)
@@ -1773,6 +1807,7 @@ void launch_bp_large(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelG
 void launch_narrowphase(const DV& d, uint32_t est, hipStream_t s) { hipLaunchKernelGGL(k_narrowphase, dim3(stride_grid(est)), dim3(TPB), 0, s, d); }
 void launch_wake(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_wake, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_prep_bodies(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_prep_bodies, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
+void launch_colour_inherit(const DV& d, uint32_t est, hipStream_t s) { hipLaunchKernelGGL(k_colour_inherit, dim3(stride_grid(est)), dim3(TPB), 0, s, d); }
 void launch_colour_claim(const DV& d, uint32_t est, uint32_t round, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_colour_claim, dim3(stride_grid(est)), dim3(TPB), 0, s, d, round);

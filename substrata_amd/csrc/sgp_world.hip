@@ -624,7 +624,7 @@ static void make_plan(const sgp_world* w, StepPlan& p)
 {
 	memset(&p, 0, sizeof(p));
 	p.nb = bucket_up(w->high);
-	p.rounds = ((std::max(w->plan_rounds + 3u, 10u) + 3u) / 4u) * 4u;
+	p.rounds = ((std::max(w->plan_rounds + 3u, 6u) + 3u) / 4u) * 4u;
 	p.est_pairs = bucket_up(std::max(w->last_pairs + w->last_pairs / 8, 4u * w->high));
 	p.est_man = bucket_up(std::max(w->last_manifolds + w->last_manifolds / 8, 2u * w->high));
 	int tf = 0;
@@ -667,6 +667,7 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 	if (p.contact_events) { KScope k(w, KC_MISC); launch_contact_events(d, p.est_man, s); }
 	STAGE_MARK(3);
 	// -- 4. colouring + constraint setup
+	{ KScope k(w, KC_COLOUR_CLAIM); launch_colour_inherit(d, p.est_man, s); }
 	uint32_t est_unc = p.est_man;
 	for (uint32_t round = 0; round < p.rounds; ++round) {
 		{ KScope k(w, KC_COLOUR_CLAIM); launch_colour_claim(d, est_unc, round, s); }
