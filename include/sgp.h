@@ -254,6 +254,17 @@ int  sgp_body_move_kinematic(sgp_world* w, uint32_t id, const float target_pos[3
 int  sgp_body_add_force(sgp_world* w, uint32_t id, const float force[3]);
 int  sgp_body_add_force_at(sgp_world* w, uint32_t id, const float force[3], const float point[3]);
 int  sgp_body_add_torque(sgp_world* w, uint32_t id, const float torque[3]);
+/* Batched form of setNewObToWorldTransform(pos,rot,linvel,angvel) for network physics snapshots (GUIClient.cpp:7474-7478 inserts
+ * one snapshot per object per frame; n objects here cost one upload + one kernel). */
+typedef struct sgp_pose_vel { float pos[3]; float rot[4]; float lin_vel[3]; float ang_vel[3]; } sgp_pose_vel;
+int  sgp_body_set_pose_vel_batch(sgp_world* w, const uint32_t* ids, const sgp_pose_vel* recs, uint32_t n);
+
+/* ObjectPhysicsTransformUpdate payload (Protocol.h:120, written at GUIClient.cpp:7637-7650): little endian,
+ * uid u64 | pos 3 x f64 | rot 4 x f32 (x,y,z,w) | lin vel 3 x f32 | ang vel 3 x f32 | client time f64  = 80 bytes. */
+#define SGP_PHYSICS_UPDATE_BYTES 80
+int  sgp_physics_update_encode(uint64_t uid, const sgp_body_state* st, double client_time, uint8_t out[SGP_PHYSICS_UPDATE_BYTES]);
+int  sgp_physics_update_decode(const uint8_t in[SGP_PHYSICS_UPDATE_BYTES], uint64_t* uid_out, sgp_pose_vel* rec_out, double* client_time_out);
+
 /* getObjectLinearVelocity (:636-646), getPosInJolt (:1625-1632), GUIClient.cpp:6588,6673 read-back. */
 int  sgp_body_get_state(sgp_world* w, const uint32_t* ids, uint32_t n, sgp_body_state* out);
 /* All live bodies in id order [first, first+n). Slots that are not live get id = SGP_INVALID_ID. */

@@ -51,6 +51,13 @@ class BodyState(C.Structure):
                 ("active", u32), ("underwater", u32), ("submerged_volume", f32), ("id", u32)]
 
 
+class PoseVel(C.Structure):
+    _fields_ = [("pos", f32 * 3), ("rot", f32 * 4), ("lin_vel", f32 * 3), ("ang_vel", f32 * 3)]
+
+
+PHYSICS_UPDATE_BYTES = 80
+
+
 class BodyEvent(C.Structure):
     _fields_ = [("id", u32), ("_pad", u32), ("userdata", u64)]
 
@@ -114,6 +121,7 @@ body_event_dtype = np.dtype(BodyEvent)
 constraint_dump_dtype = np.dtype(ConstraintDump)
 ray_dtype = np.dtype(Ray)
 hit_dtype = np.dtype(Hit)
+pose_vel_dtype = np.dtype(PoseVel)
 
 P = C.POINTER
 vp = C.c_void_p
@@ -135,6 +143,9 @@ PROTOTYPES = {
     "body_set_layer": (C.c_int, [vp, u32, i32]),
     "body_set_pose_vel": (C.c_int, [vp, u32, P(f32), P(f32), P(f32), P(f32)]),
     "body_set_pose_shape": (C.c_int, [vp, u32, P(f32), P(f32), P(f32)]),
+    "body_set_pose_vel_batch": (C.c_int, [vp, vp, vp, u32]),
+    "physics_update_encode": (C.c_int, [u64, P(BodyState), C.c_double, vp]),
+    "physics_update_decode": (C.c_int, [vp, P(u64), P(PoseVel), P(C.c_double)]),
     "body_set_pos": (C.c_int, [vp, u32, P(f32)]),
     "body_set_vel": (C.c_int, [vp, u32, P(f32), P(f32)]),
     "body_move_kinematic": (C.c_int, [vp, u32, P(f32), P(f32), f32]),

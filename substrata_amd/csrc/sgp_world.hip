@@ -435,6 +435,47 @@ SGP_API int sgp_body_set_pose_vel(sgp_world* w, uint32_t id, const float pos[3],
 	w->cmds.push_back(c);
 	return SGP_OK;
 }
+SGP_API int sgp_body_set_pose_vel_batch(sgp_world* w, const uint32_t* ids, const sgp_pose_vel* recs, uint32_t n)
+{
+	if (!w || ((!ids || !recs) && n)) return fail(SGP_ERR_INVALID, "sgp_body_set_pose_vel_batch: NULL");
+	for (uint32_t i = 0; i < n; ++i) if (!live(w, ids[i])) return fail(SGP_ERR_BAD_ID, "sgp_body_set_pose_vel_batch: id not live");
+	w->cmds.reserve(w->cmds.size() + n);
+	for (uint32_t i = 0; i < n; ++i) {
+		BodyCmd c = blank_cmd(ids[i], CMD_SET_POS | CMD_SET_ROT | CMD_SET_VEL);
+		memcpy(c.pos, recs[i].pos, 12); memcpy(c.rot, recs[i].rot, 16); memcpy(c.linv, recs[i].lin_vel, 12); memcpy(c.angv, recs[i].ang_vel, 12);
+		w->cmds.push_back(c);
+	}
+	return SGP_OK;
+}
+
+// ObjectPhysicsTransformUpdate payload, GUIClient.cpp:7637-7650 (host-side byte packing; x86-64 / little endian)
+SGP_API int sgp_physics_update_encode(uint64_t uid, const sgp_body_state* st, double client_time, uint8_t out[SGP_PHYSICS_UPDATE_BYTES])
+{
+	if (!st || !out) return fail(SGP_ERR_INVALID, "sgp_physics_update_encode: NULL");
+	uint8_t* p = out;
+	memcpy(p, &uid, 8); p += 8;
+	for (int i = 0; i < 3; ++i) { const double v = (double)st->pos[i]; memcpy(p, &v, 8); p += 8; }   // Vec3d world_ob->pos
+	memcpy(p, st->rot, 16); p += 16;
+	memcpy(p, st->lin_vel, 12); p += 12;
+	memcpy(p, st->ang_vel, 12); p += 12;
+	memcpy(p, &client_time, 8);
+	return SGP_OK;
+}
+SGP_API int sgp_physics_update_decode(const uint8_t in[SGP_PHYSICS_UPDATE_BYTES], uint64_t* uid_out, sgp_pose_vel* rec, double* client_time_out)
+{
+	if (!in || !rec) return fail(SGP_ERR_INVALID, "sgp_physics_update_decode: NULL");
+	const uint8_t* p = in;
+	if (uid_out) memcpy(uid_out, p, 8);
+	p += 8;
+	for (int i = 0; i < 3; ++i) { double v; memcpy(&v, p, 8); p += 8; rec->pos[i] = (float)v; }
+	memcpy(rec->rot, p, 16); p += 16;
+	memcpy(rec->lin_vel, p, 12); p += 12;
+	memcpy(rec->ang_vel, p, 12); p += 12;
+	if (client_time_out) memcpy(client_time_out, p, 8);
+	for (int i = 0; i < 3; ++i) if (!std::isfinite(rec->pos[i]) || !std::isfinite(rec->lin_vel[i]) || !std::isfinite(rec->ang_vel[i])) return fail(SGP_ERR_REJECTED, "sgp_physics_update_decode: non-finite field");
+	return SGP_OK;
+}
+
 SGP_API int sgp_body_set_pose_shape(sgp_world* w, uint32_t id, const float pos[3], const float rot[4], const float shape[4])
 {
 	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_set_pose_shape: id not live");

@@ -104,6 +104,17 @@ class CWorld:
         self._check(self._fn("body_set_pose_vel")(self._h, int(i), _fp(_f3(pos)), _fp(_f4(rot)), _fp(_f3(lin_vel)),
                                                   _fp(_f3(ang_vel))), "body_set_pose_vel")
 
+    def set_pose_vel_batch(self, ids, recs):
+        """Insert many physics snapshots at once (recs: structured array of abi.pose_vel_dtype)."""
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        recs = np.ascontiguousarray(recs, dtype=abi.pose_vel_dtype)
+        fn = getattr(self._lib, self._p + "body_set_pose_vel_batch", None)
+        if fn is None:      # the CPU checker has no batched entry point
+            for i, r in zip(ids, recs):
+                self.set_pose_vel(int(i), r["pos"], r["rot"], r["lin_vel"], r["ang_vel"])
+            return
+        self._check(fn(self._h, ids.ctypes.data, recs.ctypes.data, len(ids)), "body_set_pose_vel_batch")
+
     def set_pose_shape(self, i, pos, rot, shape):
         self._check(self._fn("body_set_pose_shape")(self._h, int(i), _fp(_f3(pos)), _fp(_f4(rot)), _fp(_f4(shape))),
                     "body_set_pose_shape")
