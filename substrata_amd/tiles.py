@@ -6,7 +6,8 @@ rank whose tile (inflated by the margin) they touch, where they are simulated as
 (kinematic bodies) for that step.  The only collectives are, per step, one all-gather of the record counts (8 B per rank) and
 one all-gather of the ghost records padded to the largest count (torch.distributed: backend "nccl" = RCCL over xGMI on the
 GPU box, "gloo" in the CPU tests).  Ghost traffic is ~1e3-1e4 records x 104 B per rank, so the exchange is latency- not
-bandwidth-bound.  No migration in this round: a body stays owned by the tile it was created in.
+bandwidth-bound.  Ownership migrates: when the centre of an owned body has left the tile, the owner removes it and the tile
+that now contains the centre re-creates it as a dynamic body from the same record (its contact-cache entries restart).
 """
 import numpy as np
 
@@ -36,6 +37,29 @@ def tile_bounds(rank, n_tiles, tile_w, tile_d):
     return lo, hi, origin
 
 
+def inside(recs, lo, hi):
+    """Mask of records whose centre lies in [lo, hi)."""
+    if len(recs) == 0:
+        return np.zeros(0, dtype=bool)
+    p = recs["pos"]
+    return np.all(p >= lo, axis=1) & np.all(p < hi, axis=1)
+
+
+def records_to_descs(recs):
+    """Body descs for immigrants: dynamic, awake, layer MOVING, Jolt default damping / gravity factor."""
+    d = np.zeros(len(recs), dtype=abi.body_desc_dtype)
+    for f in ("pos", "rot", "lin_vel", "ang_vel", "shape_type", "shape", "mass", "friction", "restitution"):
+        d[f] = recs[f]
+    d["motion_type"] = abi.MOTION_DYNAMIC
+    d["layer"] = abi.LAYER_MOVING
+    d["gravity_factor"] = 1.0
+    d["linear_damping"] = 0.05
+    d["angular_damping"] = 0.05
+    d["allow_sleeping"] = 1
+    d["activate"] = 1
+    return d
+
+
 def select_ghosts(recs, lo, hi, margin, radius_pad=1.5):
     """Records (from other ranks) that can touch the region [lo - margin, hi + margin)."""
     if len(recs) == 0:
@@ -55,6 +79,8 @@ class GhostExchange:
         self.dist, self.device, self.cap = dist, device, cap
         self.last_exported = 0
         self.last_imported = 0
+        self.last_emigrated = 0
+        self.last_immigrated = 0
         if dist is not None:
             import torch
             self.torch = torch
@@ -65,7 +91,14 @@ class GhostExchange:
 
     def exchange(self):
         recs = self.world.export_boundary(self.lo, self.hi, self.margin, cap=self.cap)
+        # owned DYNAMIC bodies whose centre has left the tile emigrate: removed here, re-created by the tile that contains them
+        local_ids = (recs["global_id"] & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        emigrant = ~inside(recs, self.lo, self.hi) & (recs["motion_type"] == abi.MOTION_DYNAMIC) if self.n > 1 else np.zeros(len(recs), bool)
+        for i in local_ids[emigrant]:
+            self.world.remove(int(i))
+        self.last_emigrated = int(emigrant.sum())
         recs["global_id"] = recs["global_id"] | (np.uint64(self.rank) << np.uint64(40))
+        recs["motion_type"] = np.where(emigrant, np.uint32(abi.MOTION_DYNAMIC | 0x100), recs["motion_type"])   # bit 8 = "take ownership"
         self.last_exported = len(recs)
         if self.dist is None or self.n == 1:
             self.world.import_ghosts(recs[:0])
@@ -90,6 +123,12 @@ class GhostExchange:
             if r != self.rank and c:
                 parts.append(np.frombuffer(allb[r, :c * REC].tobytes(), dtype=abi.ghost_dtype))
         others = np.concatenate(parts) if parts else np.zeros(0, dtype=abi.ghost_dtype)
-        mine = select_ghosts(others, self.lo, self.hi, self.margin)
+        take = (others["motion_type"] & 0x100) != 0
+        immigrants = others[take & inside(others, self.lo, self.hi)]
+        ghosts = others[~take].copy()
+        mine = select_ghosts(ghosts, self.lo, self.hi, self.margin)
         self.last_imported = len(mine)
+        self.last_immigrated = len(immigrants)
         self.world.import_ghosts(mine)
+        if len(immigrants):
+            self.world.add_batch(records_to_descs(immigrants))

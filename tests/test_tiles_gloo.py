@@ -29,6 +29,37 @@ def scene_for_tile(rank, n_tiles):
     return np.concatenate([scenes.ground(), d]), lo, hi
 
 
+def migration_worker(rank, world_size, port, steps, out_dir):
+    """Tile 0 owns one sphere rolling in +x across the border at x = TILE_W; tile 1 must take it over."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    from oracle import oracle
+    lo, hi, origin = tiles.tile_bounds(rank, world_size, TILE_W, TILE_W)
+    descs = scenes.ground()
+    if rank == 0:
+        b = scenes.dynamic_bodies(1)
+        b["shape_type"] = abi.SHAPE_SPHERE
+        b["shape"][0] = (0.5, 0, 0, 0)
+        b["pos"][0] = (TILE_W - 3.0, 5.0, 0.5)
+        b["lin_vel"][0] = (4.0, 0.0, 0.0)
+        descs = np.concatenate([descs, b])
+    w = oracle.OracleWorld(max_bodies=64)
+    w.add_batch(descs)
+    ex = tiles.GhostExchange(w, rank, world_size, lo, hi, margin=1.5, dist=dist, device=torch.device("cpu"), cap=64)
+    emig = immig = 0
+    for _ in range(steps):
+        ex.exchange()
+        emig += ex.last_emigrated
+        immig += ex.last_immigrated
+        w.step(DT)
+    st = w.read_states(0, 8)
+    np.save(os.path.join(out_dir, f"mig{rank}.npy"), st)
+    np.save(os.path.join(out_dir, f"migcount{rank}.npy"), np.array([emig, immig, w.num_bodies()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def worker(rank, world_size, port, steps, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -92,3 +123,18 @@ def test_two_tiles_gloo_ghost_exchange(tmp_path, oracle):
     # no deep interpenetration across the border: closest centre distance between the two tiles' own boxes
     dd = np.linalg.norm(own0["pos"][:, None, :] - own1["pos"][None, :, :], axis=2)
     assert dd.min() > 0.9
+
+
+@pytest.mark.timeout(300)
+def test_ownership_migrates_across_the_tile_border(tmp_path, oracle):
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(migration_worker, args=(2, port, 120, str(tmp_path)), nprocs=2, join=True)
+    c0, c1 = np.load(tmp_path / "migcount0.npy"), np.load(tmp_path / "migcount1.npy")
+    assert c0[0] == 1 and c1[1] == 1                    # emigrated once from tile 0, immigrated once into tile 1
+    s1 = np.load(tmp_path / "mig1.npy")
+    own = s1[(s1["id"] != abi.INVALID_ID)]
+    ball = own[np.argmax(own["pos"][:, 0])]
+    # it kept rolling: well past the border, still moving in +x, still on the ground
+    assert ball["pos"][0] > TILE_W + 1.0 and ball["lin_vel"][0] > 1.0 and abs(ball["pos"][2] - 0.5) < 0.05
+    # tile 0 now only holds its ground quad plus (at most) a ghost copy while the ball is still near the border
+    assert c0[2] <= 2
