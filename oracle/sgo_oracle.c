@@ -689,7 +689,9 @@ static int setup_constraint(sgo_world* w, uint32_t k, const sgo_manifold* m, flo
 	const sgo_body* A = &w->bodies[c.a]; const sgo_body* B = &w->bodies[c.b];
 	const sgo_constraint* pc = find_prev(w, c.key);
 	c.persisted = pc != NULL;
-	if (A->is_sensor || B->is_sensor) return 0;
+	/* a sensor pair (mIsSensor, PhysicsWorld.cpp:1235) stays in the contact list with zero points: no response, but the pair is
+	   cached so that the next step reports OnContactPersisted instead of OnContactAdded */
+	if (A->is_sensor || B->is_sensor) c.np = 0;
 	const m33 RA = quat_to_m33(A->rot), RB = quat_to_m33(B->rot);
 	const float im1 = body_movable(A) ? A->inv_mass : 0.0f, im2 = body_movable(B) ? B->inv_mass : 0.0f;
 	sym33 I1, I2; memset(&I1, 0, sizeof(I1)); memset(&I2, 0, sizeof(I2));
@@ -793,64 +795,9 @@ static void find_contacts(sgo_world* w, float dt)
 		return;
 	}
 	for (uint32_t k = 0; k < nm; ++k) {
-		sgo_constraint c = w->cons[k];
-		const sgo_manifold* m = &mans[k];
-		const sgo_body* A = &w->bodies[c.a]; const sgo_body* B = &w->bodies[c.b];
-		const sgo_constraint* pc = find_prev(w, c.key);
-		c.persisted = pc != NULL;
-		if (w->contact_events) emit_contact_event(w, &c, m, c.persisted);
-		if (A->is_sensor || B->is_sensor) continue;
-		const m33 RA = quat_to_m33(A->rot), RB = quat_to_m33(B->rot);
-		const float im1 = body_movable(A) ? A->inv_mass : 0.0f, im2 = body_movable(B) ? B->inv_mass : 0.0f;
-		sym33 I1, I2; memset(&I1, 0, sizeof(I1)); memset(&I2, 0, sizeof(I2));
-		if (im1 > 0.0f) I1 = world_inv_inertia(RA, A->inv_inertia);
-		if (im2 > 0.0f) I2 = world_inv_inertia(RB, B->inv_inertia);
-		c.friction = sqrtf(A->friction * B->friction);
-		const float restitution = fmaxf(A->restitution, B->restitution);
-		c.t1 = v3_normalized_perpendicular(c.n);
-		c.t2 = v3_cross(c.n, c.t1);
-		for (int i = 0; i < c.np; ++i) {
-			sgo_point* pt = &c.pt[i];
-			const v3 p1 = m->p1[i], p2 = m->p2[i];
-			pt->local1 = m33_tmul(RA, v3_sub(p1, A->pos));
-			pt->local2 = m33_tmul(RB, v3_sub(p2, B->pos));
-			pt->lam_n = pt->lam_t1 = pt->lam_t2 = 0.0f;
-			if (pc && w->st.warm_start) {
-				for (int j = 0; j < pc->np; ++j) {
-					if (v3_len_sq(v3_sub(pt->local1, pc->pt[j].local1)) < w->st.contact_point_preserve_lambda_max_dist_sq &&
-					    v3_len_sq(v3_sub(pt->local2, pc->pt[j].local2)) < w->st.contact_point_preserve_lambda_max_dist_sq) {
-						pt->lam_n = pc->pt[j].lam_n; pt->lam_t1 = pc->pt[j].lam_t1; pt->lam_t2 = pc->pt[j].lam_t2;
-						break;
-					}
-				}
-			}
-			const v3 mid = v3_scale(v3_add(p1, p2), 0.5f);
-			pt->r1 = v3_sub(mid, A->pos); pt->r2 = v3_sub(mid, B->pos);
-			/* TemplatedCalculateFrictionAndNonPenetrationConstraintProperties */
-			const v3 va = v3_add(A->linv, v3_cross(A->angv, pt->r1));
-			const v3 vb = v3_add(B->linv, v3_cross(B->angv, pt->r2));
-			const float normal_velocity = v3_dot(v3_sub(vb, va), c.n);
-			const float penetration = v3_dot(v3_sub(p1, p2), c.n);
-			const float spec_bias = fmaxf(0.0f, -penetration / dt);
-			float bias = spec_bias;
-			if (restitution > 0.0f && normal_velocity < -w->st.min_velocity_for_restitution) {
-				if (normal_velocity < -spec_bias) {
-					/* cancel the velocity the constant forces added this step (gravity + accumulated force; forces were
-					   consumed by apply_forces, so only gravity is known here) */
-					v3 rel_acc = V3(0, 0, 0);
-					if (im2 > 0.0f) rel_acc = v3_add(rel_acc, v3_scale(w->gravity, B->gravity_factor));
-					if (im1 > 0.0f) rel_acc = v3_sub(rel_acc, v3_scale(w->gravity, A->gravity_factor));
-					const float force_dv = fminf(0.0f, v3_dot(rel_acc, c.n)) * dt;
-					bias = restitution * (normal_velocity - force_dv);
-				}
-			}
-			pt->bias = bias;
-			pt->eff_n = axis_eff_mass(im1, I1, pt->r1, im2, I2, pt->r2, c.n);
-			pt->eff_t1 = axis_eff_mass(im1, I1, pt->r1, im2, I2, pt->r2, c.t1);
-			pt->eff_t2 = axis_eff_mass(im1, I1, pt->r1, im2, I2, pt->r2, c.t2);
-		}
-		npts += (uint32_t)c.np;
-		w->cons[out++] = c;
+		if (w->contact_events) emit_contact_event(w, &w->cons[k], &mans[k], find_prev(w, w->cons[k].key) != NULL);
+		uint32_t np1 = 0;
+		if (setup_constraint(w, k, &mans[k], dt, &np1)) { npts += np1; w->cons[out++] = w->cons[k]; }
 	}
 	w->n_cons = out;
 	w->stats.num_contact_points = npts;

@@ -525,11 +525,13 @@ __global__ void __launch_bounds__(TPB) k_narrowphase(DV d)
 		const uint32_t slot = atomicAdd(&d.ctr->n_manifolds, 1u);
 		if (slot >= d.cap_manifolds) { atomicAdd(&d.ctr->manifolds_dropped, 1u); continue; }
 		d.man_ab[slot] = ab;
-		d.man_n[slot] = make_float4(m.n.x, m.n.y, m.n.z, __int_as_float(m.np));
+		const bool sensor = (fa | fb) & BF_SENSOR;
+		// bit 8 = sensor pair (mIsSensor, PhysicsWorld.cpp:1235): reported in the contact events, kept in the contact list
+		// (so that it is 'persisted' next step) but with zero points for the solver
+		d.man_n[slot] = make_float4(m.n.x, m.n.y, m.n.z, __int_as_float(m.np | (sensor ? 0x100 : 0)));
 		for (int k = 0; k < 4; ++k) if (k < m.np) { d.man_p1[k][slot] = F4(m.p1[k], 0.0f); d.man_p2[k][slot] = F4(m.p2[k], 0.0f); }
 		d.man_prio[slot] = sgp_mix64(((uint64_t)ab.x << 32) | ab.y);
-		const bool sensor = (fa | fb) & BF_SENSOR;
-		d.man_colour[slot] = sensor ? -2 : -1;
+		d.man_colour[slot] = -1;
 		if (!sensor) {
 			const bool actA = f_active_for_pairs(fa), actB = f_active_for_pairs(fb);
 			if (actA && !actB && f_motion(fb) == SGP_MOTION_DYNAMIC) atomicOr(&d.flags[ab.y], BF_WAKE);
@@ -689,7 +691,7 @@ __global__ void __launch_bounds__(TPB) k_colour_count(DV d)
 		const int c = d.man_colour[m];
 		if (c < 0) continue;
 		atomicAdd(&hist[c], 1u);
-		atomicAdd(&hist[SGP_MAX_COLOURS], (uint32_t)__float_as_int(d.man_n[m].w));
+		{ const int npb = __float_as_int(d.man_n[m].w); atomicAdd(&hist[SGP_MAX_COLOURS], (npb & 0x100) ? 0u : (uint32_t)(npb & 0xFF)); }
 		atomicAdd(&hist[SGP_MAX_COLOURS + 1], 1u);
 	}
 	__syncthreads();
@@ -813,7 +815,8 @@ __global__ void __launch_bounds__(TPB) k_setup(DV d)
 		const uint2 ab = d.man_ab[m];
 		const uint64_t key = ((uint64_t)ab.x << 32) | ab.y;
 		const float4 n4 = d.man_n[m];
-		const int np = __float_as_int(n4.w);
+		const int npb = __float_as_int(n4.w);
+		const int np = (npb & 0x100) ? 0 : (npb & 0xFF);          // sensor pairs carry no points
 		const v3 nrm = V3(n4);
 		const v3 posA = V3(d.pos_im[ab.x]), posB = V3(d.pos_im[ab.y]);
 		const m33 RA = quat_to_m33(Q4(d.rot[ab.x])), RB = quat_to_m33(Q4(d.rot[ab.y]));
@@ -1411,7 +1414,7 @@ __global__ void __launch_bounds__(TPB) k_contact_events(DV d)
 		e.lin_vel1[0] = la.x; e.lin_vel1[1] = la.y; e.lin_vel1[2] = la.z;
 		e.lin_vel2[0] = lb.x; e.lin_vel2[1] = lb.y; e.lin_vel2[2] = lb.z;
 		const float4 n4 = d.man_n[m];
-		const int np = __float_as_int(n4.w);
+		const int np = __float_as_int(n4.w) & 0xFF;
 		const v3 nrm = V3(n4);
 		const v3 base = V3(d.man_p1[0][m]);
 		e.base_offset[0] = base.x; e.base_offset[1] = base.y; e.base_offset[2] = base.z;

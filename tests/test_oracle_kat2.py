@@ -1,0 +1,129 @@
+"""More closed-form answers pinning the oracle's dynamics (friction cone, rotational inertia, impulse direction).
+All analytic; none needs the reference (which holds no physics fixtures)."""
+import numpy as np
+import pytest
+
+from substrata_amd import abi
+from helpers import DT, add_ground, dyn, quat_axis_angle
+
+G = 9.81
+
+
+def tilted_world(oracle, theta):
+    """Gravity tilted by theta about y: equivalent to a ground plane inclined by theta."""
+    return oracle.OracleWorld(max_bodies=64, gravity=(G * np.sin(theta), 0.0, -G * np.cos(theta)))
+
+
+@pytest.mark.parametrize("theta_deg,slides", [(20.0, False), (35.0, True)])
+def test_friction_cone_on_incline(oracle, theta_deg, slides):
+    """mu = 0.5: a box holds on a 20 deg incline (tan 20 = 0.36 < mu) and slides on 35 deg (tan 35 = 0.70 > mu) with
+    a = g (sin t - mu cos t)."""
+    th = np.radians(theta_deg)
+    w = tilted_world(oracle, th)
+    add_ground(w, friction=0.5, restitution=0.0)
+    i = dyn(w, pos=(0, 0, 0.5), friction=0.5, restitution=0.0, lin_damp=0.0, ang_damp=0.0, allow_sleeping=0, shape=(1.0, 1.0, 0.5))
+    n = 90
+    for _ in range(n):
+        w.step(DT)
+    s = w.get_state([i])[0]
+    if not slides:
+        assert abs(s["pos"][0]) < 0.02 and np.linalg.norm(s["lin_vel"]) < 0.02
+    else:
+        a = G * (np.sin(th) - 0.5 * np.cos(th))
+        t = n * DT
+        assert abs(s["lin_vel"][0] - a * t) <= 0.05 * a * t
+        assert abs(s["pos"][0] - 0.5 * a * t * t) <= 0.08 * 0.5 * a * t * t
+    w.close()
+
+
+def test_sphere_slip_to_roll_transition(oracle):
+    """A sphere launched sliding (no spin) on a rough plane ends up rolling without slipping at v = 5/7 v0
+    (I = 2/5 m r^2), independent of mu."""
+    w = oracle.OracleWorld(max_bodies=64)
+    add_ground(w, friction=0.6, restitution=0.0)
+    v0 = 7.0
+    i = dyn(w, abi.SHAPE_SPHERE, (0.5,), pos=(0, 0, 0.5), lin_vel=(v0, 0, 0), friction=0.6, restitution=0.0,
+            lin_damp=0.0, ang_damp=0.0, allow_sleeping=0)
+    for _ in range(150):
+        w.step(DT)
+    s = w.get_state([i])[0]
+    assert abs(s["lin_vel"][0] - 5.0) < 0.1                      # 5/7 * 7
+    assert abs(s["ang_vel"][1] - s["lin_vel"][0] / 0.5) < 0.2     # rolling: omega_y = v / r
+    w.close()
+
+
+def test_oblique_elastic_sphere_collision(oracle):
+    """Equal spheres, restitution 1, friction 0, zero gravity: the normal components of velocity are exchanged, the
+    tangential ones untouched; momentum and kinetic energy are conserved."""
+    w = oracle.OracleWorld(max_bodies=16, gravity=(0, 0, 0))
+    a = dyn(w, abi.SHAPE_SPHERE, (0.5,), pos=(-2.0, 0.5, 0), lin_vel=(4, 0, 0), restitution=1.0, friction=0.0, lin_damp=0.0, ang_damp=0.0, allow_sleeping=0)
+    b = dyn(w, abi.SHAPE_SPHERE, (0.5,), pos=(0.0, 0.0, 0), lin_vel=(0, 0, 0), restitution=1.0, friction=0.0, lin_damp=0.0, ang_damp=0.0, allow_sleeping=0)
+    for _ in range(90):
+        w.step(DT)
+    s = w.get_state([a, b])
+    va, vb = s["lin_vel"][0].astype(np.float64), s["lin_vel"][1].astype(np.float64)
+    assert np.allclose(va + vb, (4, 0, 0), atol=1e-4)                               # momentum
+    assert abs(0.5 * (va @ va + vb @ vb) - 0.5 * 16.0) < 0.02 * 8.0                 # kinetic energy (per unit mass)
+    # contact normal at impact: centres 1 m apart with lateral offset 0.5 -> n = (cos 30, -sin 30): b leaves along n
+    n = np.array([np.cos(np.radians(30)), -np.sin(np.radians(30)), 0.0])
+    assert np.allclose(vb / np.linalg.norm(vb), n, atol=0.03)
+    assert abs(np.linalg.norm(vb) - 4 * np.cos(np.radians(30))) < 0.1
+    assert abs(va @ vb) < 0.15                                                       # equal masses leave at right angles
+    assert np.allclose(s["ang_vel"], 0, atol=1e-5)                                   # frictionless: no spin
+    w.close()
+
+
+@pytest.mark.parametrize("tilt_deg,falls", [(20.0, False), (32.0, True)])
+def test_box_tipping_threshold(oracle, tilt_deg, falls):
+    """A 1 x 1 x 2 box balanced on an edge falls back if its COM is inside the support (tilt < atan(0.5/1) = 26.6 deg)
+    and topples if it is beyond."""
+    w = oracle.OracleWorld(max_bodies=16)
+    add_ground(w, friction=1.0, restitution=0.0)
+    t = np.radians(tilt_deg)
+    # rotate about the y axis through the bottom edge at x = +0.5: place the centre accordingly
+    hx, hz = 0.5, 1.0
+    cx = 0.5 - (hx * np.cos(t) - hz * np.sin(t))
+    cz = hx * np.sin(t) + hz * np.cos(t)
+    i = dyn(w, shape=(0.5, 0.5, 1.0), pos=(cx, 0, cz + 0.001), rot=quat_axis_angle((0, 1, 0), t), friction=1.0, restitution=0.0, allow_sleeping=0)
+    for _ in range(240):
+        w.step(DT)
+    s = w.get_state([i])[0]
+    up_z = 1 - 2 * (s["rot"][0] ** 2 + s["rot"][1] ** 2)          # z component of the body's z axis
+    if falls:
+        assert abs(up_z) < 0.2 and abs(s["pos"][2] - 0.5) < 0.05   # lying on its long side
+    else:
+        assert up_z > 0.98 and abs(s["pos"][2] - 1.0) < 0.05       # back upright
+    w.close()
+
+
+def test_kinematic_and_static_do_not_collide(oracle):
+    """Pairs without a dynamic body are never generated (Jolt: kinematic vs non-dynamic do not collide by default)."""
+    w = oracle.OracleWorld(max_bodies=16)
+    add_ground(w)
+    k = dyn(w, pos=(0, 0, 0.3), motion=abi.MOTION_KINEMATIC, lin_vel=(0, 0, -1.0))
+    for _ in range(30):
+        w.step(DT)
+    s = w.get_state([k])[0]
+    assert abs(s["pos"][2] - (0.3 - 0.5)) < 1e-4 and w.stats().num_pairs == 0
+    w.close()
+
+
+def test_sensor_reports_contacts_without_response(oracle):
+    w = oracle.OracleWorld(max_bodies=16)
+    w.set_contact_events(True)
+    add_ground(w)
+    sensor = dyn(w, pos=(0, 0, 1.0), motion=abi.MOTION_STATIC, layer=abi.LAYER_NON_MOVING, sensor=1, activate=0)
+    ball = dyn(w, abi.SHAPE_SPHERE, (0.25,), pos=(0, 0, 3.0), allow_sleeping=0)
+    hit = pers = 0
+    for _ in range(90):
+        w.step(DT)
+        ev = w.drain_events(abi.EVENT_CONTACT_ADDED)
+        hit += int(np.any((ev["id1"] == sensor) & (ev["id2"] == ball)))
+        ev = w.drain_events(abi.EVENT_CONTACT_PERSISTED)
+        pers += int(np.any((ev["id1"] == sensor) & (ev["id2"] == ball)))
+    s = w.get_state([ball])[0]
+    # 'added' when the overlap begins (again after the small bounce off the ground takes the ball out of the sensor's
+    # speculative margin), 'persisted' on every other step of the overlap
+    assert 1 <= hit <= 3 and pers >= 40
+    assert abs(s["pos"][2] - 0.25) < 0.03            # fell straight through the sensor and rests on the ground
+    w.close()

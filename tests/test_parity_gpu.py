@@ -253,3 +253,32 @@ def test_empty_world_and_rejections(oracle):
     with pytest.raises(SgpError):
         tw.gpu.add(tw.gpu.default_body_desc())
     tw.close()
+
+
+def test_incline_roll_sensor_scene(oracle):
+    """Tilted gravity (friction cone), a sphere going from slip to roll, a box tipping over, and a sensor volume with its
+    contact events: device vs oracle."""
+    th = np.radians(35.0)
+    tw = parity.make_twin(oracle, max_bodies=64, gravity=(9.81 * np.sin(th), 0.0, -9.81 * np.cos(th)))
+    tw.set_contact_events(True)
+    for w in (tw.gpu, tw.cpu):
+        add_ground(w, friction=0.5, restitution=0.0)
+        dyn(w, pos=(0, 0, 0.5), friction=0.5, restitution=0.0, allow_sleeping=0, shape=(1.0, 1.0, 0.5))
+        dyn(w, abi.SHAPE_SPHERE, (0.5,), pos=(0, 4, 0.5), lin_vel=(7, 0, 0), friction=0.6, restitution=0.0, allow_sleeping=0)
+        dyn(w, shape=(0.5, 0.5, 1.0), pos=(0, 8, 1.2), rot=quat_axis_angle((0, 1, 0), 0.5), friction=1.0, allow_sleeping=0)
+        dyn(w, pos=(6, 4, 1.0), motion=abi.MOTION_STATIC, layer=abi.LAYER_NON_MOVING, sensor=1, activate=0, shape=(2.0, 2.0, 1.0))
+        dyn(w, abi.SHAPE_CAPSULE, (0.3, 0.65), pos=(2, 12, 1.0), rot=quat_axis_angle((1, 0, 0), 1.2), allow_sleeping=0)
+    added = pers = 0
+    for _ in range(150):
+        tw.step(DT)
+        for kind in (abi.EVENT_CONTACT_ADDED, abi.EVENT_CONTACT_PERSISTED):
+            eg, ec = tw.drain_events(kind)
+            assert np.array_equal(eg["id1"], ec["id1"]) and np.array_equal(eg["id2"], ec["id2"]) and np.array_equal(eg["num_points"], ec["num_points"])
+            if kind == abi.EVENT_CONTACT_ADDED:
+                added += int(np.sum(eg["id1"] == 4) + np.sum(eg["id2"] == 4))
+            else:
+                pers += int(np.sum(eg["id1"] == 4) + np.sum(eg["id2"] == 4))
+    d = parity.compare(tw, 6)
+    assert d["pos"] <= POS_TOL and d["rot"] <= POS_TOL and d["lin_vel"] <= VEL_TOL and d["ang_vel"] <= VEL_TOL, d
+    assert added >= 1 and pers >= 5          # the rolling sphere crossed the sensor volume
+    tw.close()
