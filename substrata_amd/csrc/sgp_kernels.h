@@ -134,7 +134,7 @@ struct ConstraintArrays {
 };
 
 struct DV {
-	const StepParams* sp;
+	StepParams* sp;
 	uint32_t cap_bodies, cap_pairs, cap_manifolds;
 	// bodies
 	float4* pos_im;            // position xyz, inverse mass w (0 unless dynamic)
@@ -195,7 +195,11 @@ struct DV {
 
 // ---- launch wrappers (defined in sgp_kernels.hip) ---------------------------------------------------------------
 // `nb` = number of body slots the per-body grids must cover (a bucketed upper bound of StepParams::n_slots)
-void launch_step_begin(const DV& d, hipStream_t s);
+// first / last launch of a step: per-step scalars in by value + scratch reset; counters out to host-mapped memory
+void launch_step_begin(const DV& d, const StepParams& sp, uint32_t nb, bool reset_step_scratch, hipStream_t s);
+void launch_set_params(const DV& d, const StepParams& sp, hipStream_t s);
+void launch_step_end(const DV& d, StepCounters* host_mapped, EventCounters* host_events, hipStream_t s);
+void launch_fill_u64(uint64_t* p, uint64_t v, size_t n, hipStream_t s);
 void launch_apply_forces(const DV& d, uint32_t nb, hipStream_t s);
 void launch_bp_bounds(const DV& d, uint32_t nb, hipStream_t s);
 void launch_bp_cell(const DV& d, uint32_t nb, hipStream_t s);

@@ -11,6 +11,7 @@
 //   k_buoyancy            A3   Substrata's own water sweep (PhysicsWorld.cpp:1367-1442)
 // All body state is SoA float4 in HBM; every per-body kernel is a coalesced 16 B/lane sweep.
 #include "sgp_kernels.h"
+#include <algorithm>
 #include "sgp_device_collide.h"
 
 #define TPB 256
@@ -98,17 +99,42 @@ SGP_DEV void push_event(uint32_t* list, uint32_t* counter, uint32_t cap, uint32_
 	if (k < cap) list[k] = id;
 }
 
-// first launch of a step: reset the per-step counters and the grid bounds
-__global__ void __launch_bounds__(TPB) k_step_begin(DV d)
+// First launch of a step: the per-step scalars arrive BY VALUE (no upload node), the per-step counters, grid bounds and
+// scratch arrays are reset by this one grid-stride kernel (instead of half a dozen runtime memset nodes).
+__global__ void __launch_bounds__(TPB) k_step_begin(DV d, StepParams sp, uint32_t nb, int reset_scratch)
 {
-	uint32_t* c = (uint32_t*)d.ctr;
-	for (uint32_t i = threadIdx.x; i < sizeof(StepCounters) / 4; i += TPB) c[i] = 0;
-	if (threadIdx.x == 0) {
+	const uint32_t tid = blockIdx.x * TPB + threadIdx.x, stride = gridDim.x * TPB;
+	if (tid == 0) {
+		*d.sp = sp;
 		BpGrid g;
 		g.min_x = g.min_y = g.min_z = 0x7FFFFFFF; g.max_x = g.max_y = g.max_z = (int)0x80000000;
 		g.ox = g.oy = g.oz = 0.0f; g.inv_cell = 1.0f; g.cell = 1.0f; g.nx = g.ny = g.nz = 1; g.n_cells = 1;
 		*d.grid = g;
 	}
+	uint32_t* c = (uint32_t*)d.ctr;
+	for (uint32_t i = tid; i < sizeof(StepCounters) / 4; i += stride) c[i] = 0;
+	for (uint32_t i = tid; i < d.table_size + 4; i += stride) { d.cell_count[i] = 0; d.cell_fill[i] = 0; }
+	if (reset_scratch) {
+		const uint32_t n = min(nb, d.cap_bodies);
+		for (uint32_t i = tid; i < n; i += stride) { d.colour_mask[i] = 0ull; d.claim[0][i] = ~0ull; d.claim[1][i] = ~0ull; }
+	}
+}
+
+// Between steps (after adds / edits): refresh the device copy of the per-step scalars only.
+__global__ void k_set_params(DV d, StepParams sp) { if (threadIdx.x == 0 && blockIdx.x == 0) *d.sp = sp; }
+
+// Last launch of a step: the counters go straight into host-mapped pinned memory (no copy node).
+__global__ void __launch_bounds__(TPB) k_step_end(DV d, StepCounters* host_mapped, EventCounters* host_events)
+{
+	const uint32_t* src = (const uint32_t*)d.ctr;
+	uint32_t* dst = (uint32_t*)host_mapped;
+	for (uint32_t i = threadIdx.x; i < sizeof(StepCounters) / 4; i += TPB) dst[i] = src[i];
+	if (threadIdx.x < sizeof(EventCounters) / 4) ((uint32_t*)host_events)[threadIdx.x] = ((const uint32_t*)d.evc)[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(TPB) k_fill_u64(uint64_t* p, uint64_t v, size_t n)
+{
+	for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (size_t)gridDim.x * TPB) p[i] = v;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1065,8 +1091,13 @@ template <int MODE> __global__ void __launch_bounds__(TPB) k_solve_colour(DV d, 
 // every colour from first_colour on, it is also the catch-all when this step uses more colours than the plan expected.
 __global__ void __launch_bounds__(512) k_solve_tail(DV d, int first_colour, int mode)
 {
+	// the colour table in LDS: one coalesced load instead of a dependent global load per (mostly empty) colour
+	__shared__ uint32_t cs[SGP_MAX_COLOURS + 1];
+	if (threadIdx.x <= SGP_MAX_COLOURS) cs[threadIdx.x] = d.cstarts[threadIdx.x];
+	__syncthreads();
+	if (cs[first_colour] == cs[SGP_MAX_COLOURS]) return;          // nothing from first_colour on (incl. the overflow colour)
 	for (int c = first_colour; c < SGP_OVERFLOW_COLOUR; ++c) {
-		const uint32_t b = d.cstarts[c], e = d.cstarts[c + 1];
+		const uint32_t b = cs[c], e = cs[c + 1];
 		if (b == e) continue;
 		for (uint32_t k = b + threadIdx.x; k < e; k += 512) {
 			if (mode == 0) warm_start_one(d, k);
@@ -1075,7 +1106,7 @@ __global__ void __launch_bounds__(512) k_solve_tail(DV d, int first_colour, int 
 		}
 		__syncthreads();      // workgroup scope is enough: all waves of the workgroup share one CU (one L1)
 	}
-	const uint32_t first = d.cstarts[SGP_OVERFLOW_COLOUR], count = d.cstarts[SGP_OVERFLOW_COLOUR + 1] - first;
+	const uint32_t first = cs[SGP_OVERFLOW_COLOUR], count = cs[SGP_OVERFLOW_COLOUR + 1] - first;
 	if (count == 0 || threadIdx.x != 0) return;
 	uint64_t last = 0; bool have_last = false;
 	for (uint32_t it = 0; it < count; ++it) {
@@ -1788,7 +1819,21 @@ __global__ void __launch_bounds__(TPB) k_export_boundary(DV d, float3 lo, float3
 static inline uint32_t blocks_for(uint32_t n) { return n ? (n + TPB - 1) / TPB : 1; }
 static inline uint32_t stride_grid(uint32_t estimate) { uint32_t b = blocks_for(estimate); if (b < 64) b = 64; if (b > 4096) b = 4096; return b; }
 
-void launch_step_begin(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(TPB), 0, s, d); }
+void launch_step_begin(const DV& d, const StepParams& sp, uint32_t nb, bool reset_step_scratch, hipStream_t s)
+{
+	const uint32_t work = std::max(d.table_size + 4, reset_step_scratch ? nb : 0u);
+	uint32_t blocks = (work + TPB * 4 - 1) / (TPB * 4);
+	if (blocks < 1) blocks = 1; if (blocks > 1024) blocks = 1024;
+	hipLaunchKernelGGL(k_step_begin, dim3(blocks), dim3(TPB), 0, s, d, sp, nb, reset_step_scratch ? 1 : 0);
+}
+void launch_set_params(const DV& d, const StepParams& sp, hipStream_t s) { hipLaunchKernelGGL(k_set_params, dim3(1), dim3(64), 0, s, d, sp); }
+void launch_step_end(const DV& d, StepCounters* host_mapped, EventCounters* host_events, hipStream_t s) { hipLaunchKernelGGL(k_step_end, dim3(1), dim3(TPB), 0, s, d, host_mapped, host_events); }
+void launch_fill_u64(uint64_t* p, uint64_t v, size_t n, hipStream_t s)
+{
+	size_t blocks = (n + TPB * 8 - 1) / (TPB * 8);
+	if (blocks < 1) blocks = 1; if (blocks > 2048) blocks = 2048;
+	hipLaunchKernelGGL(k_fill_u64, dim3((uint32_t)blocks), dim3(TPB), 0, s, p, v, n);
+}
 void launch_apply_forces(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_apply_forces, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_bp_bounds(const DV& d, uint32_t nb, hipStream_t s)
 {

@@ -70,11 +70,13 @@ struct sgp_world {
 	// staging
 	void* stage_dev = nullptr; size_t stage_dev_bytes = 0;
 	void* stage_host = nullptr; size_t stage_host_bytes = 0;
-	StepCounters* h_ctr = nullptr; EventCounters* h_evc = nullptr;
+	StepCounters* h_ctr = nullptr; StepCounters* h_ctr_dev = nullptr; EventCounters* h_evc = nullptr; EventCounters* h_evc_dev = nullptr;
+	bool dirty_since_step = true;                              // an edit was flushed since the last step (or no step yet)
+	uint32_t last_active = 0xFFFFFFFFu;
 	StepParams* h_sp = nullptr; StepParams* d_sp = nullptr;      // pinned host copy / device copy of the per-step scalars
 	std::map<std::string, hipGraphExec_t> graphs;              // replayable launch sequences keyed by launch plan
 	std::string last_plan_key; uint32_t plan_repeats = 0; bool use_graphs = true;
-	uint32_t graph_launches = 0, eager_steps = 0;
+	uint32_t graph_launches = 0, eager_steps = 0, idle_steps = 0;
 	bool grid_valid = false;                                   // the broad-phase grid matches the current poses (ray queries reuse it)
 	// events collected on the host until drained
 	std::vector<sgp_body_event> ev_act, ev_deact, ev_water;
@@ -258,8 +260,10 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	DEV_ALLOC(d.cstarts, SGP_MAX_COLOURS + 2);
 	DEV_ALLOC(d.ctr, 1); DEV_ALLOC(d.evc, 1);
 	DEV_ALLOC(d.ev_activated, N); DEV_ALLOC(d.ev_deactivated, N); DEV_ALLOC(d.ev_water, N);
-	HIP_TRY(hipHostMalloc((void**)&w->h_ctr, sizeof(StepCounters), hipHostMallocDefault));
-	HIP_TRY(hipHostMalloc((void**)&w->h_evc, sizeof(EventCounters), hipHostMallocDefault));
+	HIP_TRY(hipHostMalloc((void**)&w->h_ctr, sizeof(StepCounters), hipHostMallocMapped));
+	HIP_TRY(hipHostGetDevicePointer((void**)&w->h_ctr_dev, w->h_ctr, 0));
+	HIP_TRY(hipHostMalloc((void**)&w->h_evc, sizeof(EventCounters), hipHostMallocMapped));
+	HIP_TRY(hipHostGetDevicePointer((void**)&w->h_evc_dev, w->h_evc, 0));
 	HIP_TRY(hipHostMalloc((void**)&w->h_sp, sizeof(StepParams), hipHostMallocDefault));
 	memset(w->h_sp, 0, sizeof(StepParams));
 	DEV_ALLOC(w->d_sp, 1);
@@ -537,7 +541,7 @@ static int upload_sp(sgp_world* w)
 	sp.n_large = (uint32_t)w->large_ids.size();
 	sp.bp_rmax = std::max(0.25f, w->max_small_radius);
 	sp.cell_size = sp.bp_rmax + w->dv.st.speculative_contact_distance;
-	HIP_TRY(hipMemcpyAsync(w->d_sp, w->h_sp, sizeof(StepParams), hipMemcpyHostToDevice, w->stream));
+	launch_set_params(w->dv, *w->h_sp, w->stream);
 	return SGP_OK;
 }
 
@@ -555,6 +559,7 @@ static int flush_cmds(sgp_world* w)
 	{ int r = upload_sp(w); if (r != SGP_OK) return r; }
 	if (w->cmds.empty()) return SGP_OK;
 	w->grid_valid = false;
+	w->dirty_since_step = true;
 	const size_t n = w->cmds.size();
 	std::vector<uint32_t> order(n);
 	for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
@@ -579,11 +584,13 @@ static int flush_cmds(sgp_world* w)
 }
 
 // Pull the device event lists into the host vectors and reset the device counters.
-static int collect_events(sgp_world* w)
+static int collect_events(sgp_world* w, bool counters_fresh = false)
 {
 	DV& d = w->dv;
-	HIP_TRY(hipMemcpyAsync(w->h_evc, d.evc, sizeof(EventCounters), hipMemcpyDeviceToHost, w->stream));
-	HIP_TRY(hipStreamSynchronize(w->stream));
+	if (!counters_fresh) {
+		HIP_TRY(hipMemcpyAsync(w->h_evc, d.evc, sizeof(EventCounters), hipMemcpyDeviceToHost, w->stream));
+		HIP_TRY(hipStreamSynchronize(w->stream));
+	}
 	const EventCounters ec = *w->h_evc;
 	if (!(ec.n_activated | ec.n_deactivated | ec.n_water | ec.n_contact_added | ec.n_contact_persisted)) return SGP_OK;
 	struct L { uint32_t n; uint32_t* dev; std::vector<sgp_body_event>* out; };
@@ -659,6 +666,7 @@ struct StepPlan {
 	int      tail_first;         // colours [0, tail_first) get their own launch per pass
 	uint32_t colour_est[SGP_MAX_COLOURS];
 	int      water, contact_events, warm_start, vel_iters, pos_iters;
+	StepParams sp;               // by-value kernel argument of the first launch: part of the key of a captured graph
 };
 
 static void make_plan(const sgp_world* w, StepPlan& p)
@@ -673,6 +681,7 @@ static void make_plan(const sgp_world* w, StepPlan& p)
 	p.tail_first = tf;
 	p.water = w->h_sp->water_enabled; p.contact_events = w->h_sp->contact_events;
 	p.warm_start = w->dv.st.warm_start; p.vel_iters = w->dv.st.num_velocity_steps; p.pos_iters = w->dv.st.num_position_steps;
+	p.sp = *w->h_sp;
 }
 
 static int enqueue_step(sgp_world* w, const StepPlan& p)
@@ -680,17 +689,8 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 	const DV& d = w->dv;
 	hipStream_t s = w->stream;
 	const uint32_t nb = p.nb;
-	HIP_TRY(hipMemcpyAsync(w->d_sp, w->h_sp, sizeof(StepParams), hipMemcpyHostToDevice, s));
 	STAGE_MARK(0);
-	{
-		KScope k(w, KC_MISC);
-		launch_step_begin(d, s);
-		HIP_TRY(hipMemsetAsync(d.cell_count, 0, sizeof(uint32_t) * (d.table_size + 4), s));
-		HIP_TRY(hipMemsetAsync(d.cell_fill, 0, sizeof(uint32_t) * (d.table_size + 4), s));
-		HIP_TRY(hipMemsetAsync(d.colour_mask, 0, sizeof(uint64_t) * std::min(nb, d.cap_bodies), s));
-		HIP_TRY(hipMemsetAsync(d.claim[0], 0xFF, sizeof(uint64_t) * std::min(nb, d.cap_bodies), s));
-		HIP_TRY(hipMemsetAsync(d.claim[1], 0xFF, sizeof(uint64_t) * std::min(nb, d.cap_bodies), s));
-	}
+	{ KScope k(w, KC_MISC); launch_step_begin(d, *w->h_sp, nb, true, s); }
 	// -- 1. forces
 	{ KScope k(w, KC_APPLY_FORCES); launch_apply_forces(d, nb, s); }
 	STAGE_MARK(1);
@@ -741,11 +741,11 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 	if (p.water) { KScope k(w, KC_BUOYANCY); launch_buoyancy(d, nb, s); }
 	{
 		KScope k(w, KC_CACHE_BUILD);
-		HIP_TRY(hipMemsetAsync(d.ht_keys, 0xFF, sizeof(uint64_t) * d.ht_size, s));
+		launch_fill_u64(d.ht_keys, ~0ull, d.ht_size, s);
 		launch_cache_build(d, p.est_man, s);
 	}
 	STAGE_MARK(8);
-	HIP_TRY(hipMemcpyAsync(w->h_ctr, d.ctr, sizeof(StepCounters), hipMemcpyDeviceToHost, s));
+	launch_step_end(d, w->h_ctr_dev, w->h_evc_dev, s);
 	return SGP_OK;
 }
 
@@ -755,6 +755,17 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	{ int r = flush_cmds(w); if (r != SGP_OK) return r; }
 	DV& d = w->dv;
 	if (w->high == 0) { memset(&w->stats, 0, sizeof(w->stats)); return SGP_OK; }
+	if (w->last_active == 0 && !w->dirty_since_step && !w->profiling) {
+		// every body is asleep / static and nothing was edited since the last step: the step is the identity (no forces act on
+		// sleeping bodies, no pair has an active member), exactly what PhysicsSystem::Update costs with an empty active list
+		sgp_step_stats& st = w->stats;
+		const uint32_t nb_ = st.num_bodies;
+		uint32_t lc[SGP_NUM_LAYERS]; memcpy(lc, st.layer_counts, sizeof(lc));
+		memset(&st, 0, sizeof(st));
+		st.num_bodies = nb_; memcpy(st.layer_counts, lc, sizeof(lc)); st.device_bytes = w->device_bytes;
+		w->idle_steps++;
+		return SGP_OK;
+	}
 	w->h_sp->dt = dt;
 	StepPlan plan;
 	make_plan(w, plan);
@@ -787,6 +798,8 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	HIP_TRY(hipStreamSynchronize(w->stream));
 	w->h_sp->parity ^= 1u;                    // the buffer just solved becomes the contact cache of the next step
 	w->grid_valid = false;                    // bodies moved after the broad phase of this step
+	w->dirty_since_step = false;
+	w->last_active = w->h_ctr->n_active;
 	const StepCounters c1 = *w->h_ctr;
 	const uint32_t n_con = c1.n_constraints;
 	w->n_con = n_con;
@@ -807,7 +820,7 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	st.num_active = c1.n_active;
 	if (final_readback) {
 		const size_t a0 = w->ev_act.size(), d0 = w->ev_deact.size();
-		{ int r = collect_events(w); if (r != SGP_OK) return r; }
+		{ int r = collect_events(w, /*counters_fresh=*/true); if (r != SGP_OK) return r; }
 		st.num_activated = (uint32_t)(w->ev_act.size() - a0);
 		st.num_deactivated = (uint32_t)(w->ev_deact.size() - d0);
 		for (uint32_t i = 0; i < w->high; ++i) if (w->hb[i].flags & BF_ALIVE) st.layer_counts[(w->hb[i].flags & BF_LAYER_MASK) >> BF_LAYER_SHIFT]++;
@@ -874,6 +887,7 @@ SGP_API int sgp_world_set_water(sgp_world* w, int enabled, float z)
 {
 	if (!w) return fail(SGP_ERR_INVALID, "sgp_world_set_water: NULL");
 	w->h_sp->water_enabled = enabled; w->h_sp->water_z = z;
+	w->dirty_since_step = true;
 	return SGP_OK;
 }
 
@@ -1010,9 +1024,7 @@ SGP_API int sgp_raycast(sgp_world* w, const sgp_ray* rays, uint32_t n, sgp_hit* 
 	if (!w->grid_valid && w->high) {
 		// poses changed since the grid was built (a step integrates after its broad phase; edits move bodies): re-bin
 		const DV& d = w->dv; hipStream_t s = w->stream; const uint32_t nb = w->high;
-		launch_step_begin(d, s);
-		HIP_TRY(hipMemsetAsync(d.cell_count, 0, sizeof(uint32_t) * (d.table_size + 4), s));
-		HIP_TRY(hipMemsetAsync(d.cell_fill, 0, sizeof(uint32_t) * (d.table_size + 4), s));
+		launch_step_begin(d, *w->h_sp, nb, false, s);
 		launch_bp_bounds(d, nb, s); launch_bp_cell(d, nb, s); launch_bp_scan(d, s); launch_bp_scatter(d, nb, s);
 		w->grid_valid = true;
 	}
