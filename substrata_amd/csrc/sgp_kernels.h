@@ -51,7 +51,7 @@ struct StepCounters {
 	uint32_t n_manifolds;        // narrow-phase hits (incl. sensors)
 	uint32_t n_constraints;      // manifolds that became contact constraints
 	uint32_t n_points;
-	uint32_t n_uncoloured;
+	uint32_t pad_unused;
 	uint32_t ucount[2];          // sizes of the two uncoloured worklists (round parity)
 	uint32_t rounds_used;        // colouring rounds that found work
 	uint32_t n_colours;          // highest used colour + 1 (overflow colour excluded)
@@ -159,12 +159,10 @@ struct DV {
 	                           //   [world inv inertia xx,xy,xz,-][yy,yz,zz,-]; velocities live here during the velocity solve
 	// broad phase
 	uint32_t table_size;       // power of two
-	uint32_t* cell_hash;       // per body
-	int4*     cell_xyz;        // per body
+	uint32_t* cell_hash;       // per body: linear cell index in the dense grid (0xFFFFFFFF = not binned)
 	uint32_t* cell_count;      // per bucket (+1)
 	uint32_t* cell_start;      // per bucket (+1), exclusive scan of cell_count
 	uint32_t* cell_fill;
-	uint32_t* sorted_ids;
 	uint32_t* scan_block_sums;
 	float4*   sorted_min;      // cell-sorted copy: aabb min xyz, flags (bits) w
 	float4*   sorted_max;      // cell-sorted copy: aabb max xyz, body id (bits) w

@@ -243,10 +243,10 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	DEV_ALLOC(d.island, N); DEV_ALLOC(d.island_awake, N);
 	DEV_ALLOC(d.sbody, 4 * (size_t)N);
 	d.table_size = std::max(1024u, next_pow2(2u * N));
-	DEV_ALLOC(d.cell_hash, N); DEV_ALLOC(d.cell_xyz, N);
+	DEV_ALLOC(d.cell_hash, N);
 	DEV_ALLOC(d.cell_count, d.table_size + 4); DEV_ALLOC(d.cell_start, d.table_size + 4); DEV_ALLOC(d.cell_fill, d.table_size + 4);
 	DEV_ALLOC(w->d_large, N); w->cap_large = N; d.large_ids = w->d_large;
-	DEV_ALLOC(d.sorted_ids, N); DEV_ALLOC(d.sorted_min, N); DEV_ALLOC(d.sorted_max, N); DEV_ALLOC(d.grid, 1); DEV_ALLOC(d.scan_block_sums, (d.table_size + 1) / 1024 + 2);
+	DEV_ALLOC(d.sorted_min, N); DEV_ALLOC(d.sorted_max, N); DEV_ALLOC(d.grid, 1); DEV_ALLOC(d.scan_block_sums, (d.table_size + 1) / 1024 + 2);
 	DEV_ALLOC(d.pairs, P);
 	DEV_ALLOC(d.man_ab, M); DEV_ALLOC(d.man_n, M); DEV_ALLOC(d.man_colour, M); DEV_ALLOC(d.man_prio, M);
 	DEV_ALLOC(d.ulist[0], M); DEV_ALLOC(d.ulist[1], M);
