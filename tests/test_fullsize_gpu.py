@@ -15,7 +15,7 @@ def test_config2_10k_parity_with_oracle(oracle):
     descs = scenes.config2_10k_boxes()
     tw = parity.make_twin(oracle, max_bodies=len(descs) + 64)
     tw.add_batch(descs)
-    for s in range(1, 41):
+    for s in range(1, 121):
         tw.step(DT)
         if s in (1, 10, 25, 40):
             d = parity.compare(tw, len(descs))
@@ -28,22 +28,50 @@ def test_config2_10k_parity_with_oracle(oracle):
     tw.close()
 
 
-def test_config3_100k_first_steps_parity_with_oracle(oracle):
-    """100k mixed bodies: neighbours already touch at t=0 (scale up to 1.5 on a 1.5 m lattice), so the first steps
-    exercise every stage at full size.  6 steps of the oracle take ~10 s."""
+def test_config3_100k_parity_with_oracle_120_steps(oracle):
+    """100k mixed bodies: neighbours already touch at t=0 (scale up to 1.5 on a 1.5 m lattice), so every stage runs at
+    full size from the first step.  The oracle runs its order-independent loops on 16 threads (bit-identical to its
+    single-thread run, tests/test_oracle_threads.py) so that 120 steps take seconds."""
+    import os
     descs = scenes.config3_100k_mixed()
-    tw = parity.make_twin(oracle, max_bodies=len(descs) + 64)
-    tw.add_batch(descs)
-    for s in range(1, 7):
-        tw.step(DT)
-    d = parity.compare(tw, len(descs))
-    assert d["active_mismatch"] == 0
-    assert d["pos"] <= 1e-4 and d["rot"] <= 1e-4 and d["lin_vel"] <= 1e-3 and d["ang_vel"] <= 1e-3, d
-    sg, sc = tw.stats()
-    assert (sg.num_pairs, sg.num_manifolds, sg.num_contact_points, sg.num_colours) == \
-           (sc.num_pairs, sc.num_manifolds, sc.num_contact_points, sc.num_colours)
-    assert sg.num_manifolds > 20000 and sg.pairs_dropped == 0 and sg.manifolds_dropped == 0
-    tw.close()
+    oracle.set_threads(min(16, os.cpu_count() or 1))
+    try:
+        tw = parity.make_twin(oracle, max_bodies=len(descs) + 64)
+        tw.add_batch(descs)
+        for s in range(1, 121):
+            tw.step(DT)
+            if s in (1, 6, 20, 40, 80, 120):
+                d = parity.compare(tw, len(descs))
+                assert d["active_mismatch"] == 0
+                assert d["pos"] <= 1e-4 and d["rot"] <= 1e-4 and d["lin_vel"] <= 1e-3 and d["ang_vel"] <= 1e-3, (s, d)
+                sg, sc = tw.stats()
+                assert (sg.num_pairs, sg.num_manifolds, sg.num_contact_points, sg.num_colours, sg.num_colour_rounds) == \
+                       (sc.num_pairs, sc.num_manifolds, sc.num_contact_points, sc.num_colours, sc.num_colour_rounds), s
+        assert sg.num_manifolds > 50000 and sg.pairs_dropped == 0 and sg.manifolds_dropped == 0
+        print("config3 100k, 120 steps: bit exact =", d["bit_exact"])
+        tw.close()
+    finally:
+        oracle.set_threads(1)
+
+
+def test_graph_replay_and_eager_launch_give_identical_bits():
+    """The captured hipGraph of a launch plan and the eager launch sequence are the same kernels with the same arguments."""
+    import subprocess, sys, os, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np\n"
+            "from substrata_amd import scenes; from substrata_amd.lib import World\n"
+            "d = scenes.config2_10k_boxes(); w = World(max_bodies=len(d) + 8); w.add_batch(d)\n"
+            "[w.step(1 / 60) for _ in range(80)]\n"
+            "np.save(sys.argv[1], w.read_states(0, len(d)))\n") % root
+    outs = []
+    with tempfile.TemporaryDirectory() as td:
+        for flag in ("0", "1"):
+            out = os.path.join(td, f"s{flag}.npy")
+            env = dict(os.environ, SGP_NO_GRAPH=flag)
+            subprocess.run([sys.executable, "-c", code, out], check=True, env=env, timeout=300)
+            outs.append(np.load(out))
+    for f in ("pos", "rot", "lin_vel", "ang_vel", "active"):
+        assert np.array_equal(outs[0][f], outs[1][f]), f
 
 
 def mechanical_energy(descs, st):
