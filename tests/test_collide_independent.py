@@ -1,0 +1,157 @@
+"""Independent validation of the narrow phase (oracle/sgo_collide.h) that does NOT share formulas with it.
+
+For convex shapes A, B the signed penetration is  min over unit d of  overlap(d) = h_A(d) + h_B(-d)  (h = support
+function): positive = depth of the minimum-translation separation, negative = -distance.  Support functions of a
+sphere / box / capsule are one-liners in numpy, so this is a brute-force reference: sample the sphere of directions,
+refine the best candidates with a generic optimiser, and require that
+  * the oracle reports a contact exactly when min overlap > -max_sep (outside a small dead band),
+  * the overlap along the oracle's normal is (near-)minimal: no direction separates the shapes with less motion,
+  * the deepest contact point's penetration equals the overlap along the oracle's normal,
+  * every contact point lies on (or within tolerance of) its own shape, and the manifold is symmetric under A<->B.
+Shapes and size ranges are those of the BASELINE configs (/root/reference/gui_client/PhysicsWorld.cpp:1221-1255)."""
+import numpy as np
+import pytest
+from scipy.optimize import minimize
+
+from substrata_amd import abi
+from test_oracle_collide import desc, pen
+
+MAX_SEP = 0.02
+
+
+def quat_to_mat(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+class Shape:
+    def __init__(self, kind, p, pos, rot):
+        self.kind, self.p, self.pos, self.R = kind, np.asarray(p, float), np.asarray(pos, float), quat_to_mat(rot)
+        self.rot = rot
+
+    def support(self, d):
+        """h(d) for unit directions d[...,3] (world space)."""
+        dl = d @ self.R                       # R^T d
+        c = d @ self.pos
+        if self.kind == abi.SHAPE_SPHERE:
+            return c + self.p[0]
+        if self.kind == abi.SHAPE_BOX:
+            return c + np.abs(dl) @ self.p[:3]
+        return c + self.p[0] + self.p[1] * np.abs(dl[..., 2])     # capsule: axis = local z, p = (radius, half height)
+
+    def signed_dist(self, x):
+        """Signed distance of world point x to the surface (negative inside)."""
+        l = (np.asarray(x, float) - self.pos) @ self.R
+        if self.kind == abi.SHAPE_SPHERE:
+            return np.linalg.norm(l) - self.p[0]
+        if self.kind == abi.SHAPE_BOX:
+            q = np.abs(l) - self.p[:3]
+            return np.linalg.norm(np.maximum(q, 0)) + min(q.max(), 0.0)
+        zc = np.clip(l[2], -self.p[1], self.p[1])
+        return np.linalg.norm(l - np.array([0, 0, zc])) - self.p[0]
+
+    def desc(self):
+        return desc(self.kind, tuple(self.p), tuple(self.pos), tuple(self.rot))
+
+
+def overlap(a, b, d):
+    return a.support(d) + b.support(-d)
+
+
+_rng = np.random.default_rng(7)
+_DIRS = _rng.normal(size=(20000, 3))
+_DIRS /= np.linalg.norm(_DIRS, axis=1, keepdims=True)
+
+
+def min_overlap(a, b, seeds=()):
+    """Brute-force min over the unit sphere: dense sampling + local refinement of the best few (and of the given seeds)."""
+    o = overlap(a, b, _DIRS)
+    cand = [_DIRS[i] for i in np.argsort(o)[:6]] + [np.asarray(s, float) for s in seeds]
+    best = (o.min(), _DIRS[o.argmin()])
+
+    def f(v):
+        n = np.linalg.norm(v)
+        return overlap(a, b, v / n) if n > 1e-9 else 1e9
+
+    for c in cand:
+        r = minimize(f, c, method="Nelder-Mead", options={"xatol": 1e-7, "fatol": 1e-9, "maxiter": 600})
+        if r.fun < best[0]:
+            best = (r.fun, r.x / np.linalg.norm(r.x))
+    return best
+
+
+def rand_quat(rng):
+    q = rng.normal(size=4)
+    return tuple(q / np.linalg.norm(q))
+
+
+def rand_shape(rng, kind, pos):
+    if kind == abi.SHAPE_SPHERE:
+        p = (rng.uniform(0.2, 0.75), 0, 0)
+    elif kind == abi.SHAPE_BOX:
+        p = tuple(rng.uniform(0.2, 0.75, size=3))
+    else:
+        p = (rng.uniform(0.15, 0.4), rng.uniform(0.2, 0.8), 0)
+    return Shape(kind, p, pos, rand_quat(rng))
+
+
+KINDS = [abi.SHAPE_SPHERE, abi.SHAPE_BOX, abi.SHAPE_CAPSULE]
+NAMES = {abi.SHAPE_SPHERE: "sphere", abi.SHAPE_BOX: "box", abi.SHAPE_CAPSULE: "capsule"}
+
+
+def place_near_contact(rng, a, kind_b, target):
+    """B at a random direction from A, moved along that direction until min overlap ~= target (bisection on the brute-force value)."""
+    u = rng.normal(size=3)
+    u /= np.linalg.norm(u)
+    b = rand_shape(rng, kind_b, a.pos)
+    lo, hi = 0.0, 4.0
+    for _ in range(40):
+        mid = 0.5 * (lo + hi)
+        b.pos = a.pos + u * mid
+        if overlap(a, b, _DIRS).min() > target:
+            lo = mid
+        else:
+            hi = mid
+    b.pos = a.pos + u * hi
+    return b
+
+
+@pytest.mark.parametrize("ka", KINDS, ids=[NAMES[k] for k in KINDS])
+@pytest.mark.parametrize("kb", KINDS, ids=[NAMES[k] for k in KINDS])
+def test_manifold_against_brute_force_support_functions(oracle, ka, kb):
+    rng = np.random.default_rng(100 + 10 * ka + kb)
+    checked = 0
+    for trial in range(40):
+        a = rand_shape(rng, ka, rng.uniform(-3, 3, size=3))
+        target = rng.choice([-0.015, -0.005, 0.0, 0.005, 0.02, 0.05, 0.1])     # speculative gap ... solid penetration
+        b = place_near_contact(rng, a, kb, target)
+        hit = oracle.collide_pair(a.desc(), b.desc(), MAX_SEP)
+        ref, dref = min_overlap(a, b, seeds=() if hit is None else (hit[0],))
+        if ref < -MAX_SEP - 2e-3:
+            assert hit is None, (trial, ref)
+            continue
+        if ref < -MAX_SEP + 2e-3:
+            continue                                         # dead band around the speculative margin
+        assert hit is not None, (trial, ref)
+        n, p1, p2 = hit
+        n = n.astype(float)
+        assert abs(np.linalg.norm(n) - 1) < 1e-5
+        along_n = float(overlap(a, b, n))
+        # (1) the oracle's axis is a minimum-translation axis: nothing found by brute force beats it by more than 1 mm
+        assert along_n <= ref + 1e-3, (trial, NAMES[ka], NAMES[kb], along_n, ref, n, dref)
+        # (2) deepest reported penetration == overlap along that axis
+        pens = pen(n, p1.astype(float), p2.astype(float))
+        assert abs(pens.max() - along_n) < 2e-4, (trial, pens, along_n)
+        # (3) all points within the speculative margin, and on their own shape
+        assert (pens > -MAX_SEP - 1e-4).all()
+        for q1, q2 in zip(p1, p2):
+            assert abs(a.signed_dist(q1)) < 2e-3 + max(0.0, along_n), (trial, a.signed_dist(q1))
+            assert abs(b.signed_dist(q2)) < 2e-3 + max(0.0, along_n), (trial, b.signed_dist(q2))
+        # (4) swapping the operands mirrors the manifold
+        hit2 = oracle.collide_pair(b.desc(), a.desc(), MAX_SEP)
+        assert hit2 is not None and len(hit2[1]) == len(p1)
+        assert abs(float(overlap(b, a, hit2[0].astype(float))) - along_n) < 1e-4
+        checked += 1
+    assert checked >= 25
