@@ -288,7 +288,7 @@ int  sgp_world_stats(sgp_world* w, sgp_step_stats* out);
 /* Name of kernel class k of sgp_step_profile (NULL past the last class). */
 const char* sgp_kernel_class_name(int k);
 /* sizeof() of ABI struct number `which` (order: settings, world_desc, body_desc, body_state, body_event, contact_event,
- * ray, hit, step_stats, step_profile, ghost_record) so bindings can verify their layout. */
+ * ray, hit, step_stats, step_profile, ghost_record, vehicle_desc, vehicle_input, vehicle_state) so bindings can verify their layout. */
 int  sgp_abi_sizeof(int which);
 /* activated_obs / newly_activated_obs maintenance + listener callbacks (PhysicsWorld.h:194-200). */
 int  sgp_world_drain_events(sgp_world* w, int kind, void* out, uint32_t cap, uint32_t* n_out);
@@ -302,6 +302,74 @@ int  sgp_world_dump_constraints(sgp_world* w, void* out, uint32_t cap, uint32_t*
 /* ---- queries --------------------------------------------------------------------------------- */
 /* traceRay / traceRayAgainstCollidableObs / doesRayHitAnything (PhysicsWorld.cpp:1668-1725), batched. */
 int  sgp_raycast(sgp_world* w, const sgp_ray* rays, uint32_t n, sgp_hit* hits_out);
+
+/* ---- wheeled vehicles --------------------------------------------------------
+ * Replaces JPH::VehicleConstraint + JPH::WheeledVehicleController + JPH::VehicleCollisionTesterCastSphere as CarPhysics
+ * sets them up (gui_client/CarPhysics.cpp:62,94-231; script defaults gui_client/Scripting.cpp:315-346).  A vehicle is
+ * attached to an existing dynamic body (the chassis; body origin = centre of mass).  Each step, before the forces:
+ * one sphere cast per wheel, tyre slip -> friction, engine / clutch / gearbox / differential, brakes, anti-roll bars;
+ * then 4 axis rows per wheel (suspension spring, max-up stop, longitudinal, lateral) are solved with the contact
+ * constraints (before them in every iteration).  Field names follow JPH::WheelSettingsWV / VehicleEngineSettings /
+ * VehicleTransmissionSettings / VehicleDifferentialSettings; sgp_default_vehicle_desc() fills Jolt's defaults. */
+#define SGP_MAX_WHEELS 4
+#define SGP_MAX_GEARS  8
+typedef struct sgp_wheel_desc {
+	float position[3];            /* mPosition: suspension attachment point, chassis frame                       */
+	float suspension_dir[3];      /* mSuspensionDirection (default (0,0,-1))                                      */
+	float steering_axis[3];       /* mSteeringAxis (0,0,1)                                                        */
+	float wheel_up[3];            /* mWheelUp (0,0,1)                                                             */
+	float wheel_forward[3];       /* mWheelForward (0,1,0)                                                        */
+	float suspension_min_length, suspension_max_length, suspension_preload;   /* 0.3, 0.5, 0                     */
+	float spring_frequency, spring_damping;                                   /* 1.5 Hz, 0.5                     */
+	float radius, width;                                                      /* 0.3, 0.1                        */
+	float inertia, angular_damping;                                           /* 0.9 kg m^2, 0.2                 */
+	float max_steer_angle, max_brake_torque, max_handbrake_torque;            /* 70 deg, 1500, 4000 N m          */
+	float longitudinal_friction[3][2];   /* (slip ratio, friction): (0,0) (0.06,1.2) (0.2,1)                      */
+	float lateral_friction[3][2];        /* (slip angle in degrees, friction): (0,0) (3,1.2) (20,1)               */
+} sgp_wheel_desc;
+typedef struct sgp_differential_desc { int32_t left_wheel, right_wheel; float differential_ratio, left_right_split, limited_slip_ratio, engine_torque_ratio; } sgp_differential_desc;
+typedef struct sgp_anti_roll_bar_desc { int32_t left_wheel, right_wheel; float stiffness; } sgp_anti_roll_bar_desc;
+typedef struct sgp_vehicle_desc {
+	uint32_t body;                /* chassis body id                                                              */
+	uint32_t num_wheels;          /* 1..SGP_MAX_WHEELS                                                            */
+	sgp_wheel_desc wheels[SGP_MAX_WHEELS];
+	float up[3], forward[3];      /* VehicleConstraintSettings::mUp / mForward, chassis frame                      */
+	float cast_radius;            /* VehicleCollisionTesterCastSphere radius (CarPhysics: 0.5 * wheel width); 0 = ray */
+	float max_slope_angle;        /* hits steeper than this against world +z are ignored (80 deg)                  */
+	float engine_max_torque, engine_min_rpm, engine_max_rpm, engine_inertia, engine_angular_damping;   /* 500, 1000, 6000, 0.5, 0.2 */
+	float engine_torque_curve[3][2];     /* (rpm / max rpm, torque fraction): (0,0.8) (0.66,1) (1,0.8)             */
+	uint32_t num_gears, num_reverse_gears;
+	float gear_ratios[SGP_MAX_GEARS], reverse_gear_ratios[SGP_MAX_GEARS];    /* 2.66 1.78 1.3 1.0 0.74 / -2.9     */
+	float switch_time, clutch_release_time, switch_latency, shift_up_rpm, shift_down_rpm, clutch_strength;   /* .5 .3 .5 4000 2000 10 */
+	uint32_t num_differentials;
+	sgp_differential_desc differentials[2];
+	float differential_limited_slip_ratio;   /* 1.4 */
+	uint32_t num_anti_roll_bars;
+	sgp_anti_roll_bar_desc anti_roll_bars[2];
+} sgp_vehicle_desc;
+/* WheeledVehicleController::SetDriverInput(forward, right, brake, hand brake) (CarPhysics.cpp:366-367) */
+typedef struct sgp_vehicle_input { float forward, right, brake, hand_brake; } sgp_vehicle_input;
+/* What CarPhysics reads back from JPH::Wheel (CarPhysics.cpp:405-470) and the controller (BikePhysics.cpp:707) */
+typedef struct sgp_wheel_state {
+	float suspension_length, steer_angle, rotation_angle, angular_velocity;
+	int32_t has_contact; uint32_t contact_body;
+	float contact_position[3], contact_normal[3], contact_longitudinal[3], contact_lateral[3], contact_point_velocity[3];
+	float suspension_lambda, longitudinal_lambda, lateral_lambda;
+	float longitudinal_slip, lateral_slip;
+} sgp_wheel_state;
+typedef struct sgp_vehicle_state {
+	sgp_wheel_state wheels[SGP_MAX_WHEELS];
+	float engine_rpm; int32_t current_gear; float clutch_friction; int32_t active;
+} sgp_vehicle_state;
+void sgp_default_vehicle_desc(sgp_vehicle_desc* d);         /* Jolt defaults + CarPhysics' 4-wheel FWD layout, Scripting.cpp defaults */
+int  sgp_vehicle_create(sgp_world* w, const sgp_vehicle_desc* d, uint32_t* vehicle_id_out);   /* AddConstraint + AddStepListener, CarPhysics.cpp:224-226 */
+int  sgp_vehicle_destroy(sgp_world* w, uint32_t vehicle_id);                                  /* RemoveConstraint / RemoveStepListener, :258-262 */
+int  sgp_vehicle_set_input(sgp_world* w, uint32_t vehicle_id, const sgp_vehicle_input* in);
+int  sgp_vehicle_set_inputs(sgp_world* w, uint32_t first_vehicle_id, uint32_t n, const sgp_vehicle_input* in);
+int  sgp_vehicle_get_state(sgp_world* w, uint32_t vehicle_id, sgp_vehicle_state* out);
+int  sgp_vehicle_get_states(sgp_world* w, uint32_t first_vehicle_id, uint32_t n, sgp_vehicle_state* out);
+/* vehicleSummoned(): GetEngine().SetCurrentRPM / Wheel::SetAngularVelocity (CarPhysics.cpp:266-272) */
+int  sgp_vehicle_reset_drivetrain(sgp_world* w, uint32_t vehicle_id, float engine_rpm, float wheel_angular_velocity);
 
 /* ---- multi-GPU tiles: ghost bodies are ordinary kinematic-like bodies owned elsewhere ---- */
 /* Pack the ghost record of every owned body whose AABB, inflated by `margin`, crosses outside [lo,hi). */

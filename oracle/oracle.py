@@ -18,7 +18,7 @@ _lib = None
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("sgo_oracle.c", "sgo_collide.h", "sgo_math.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("sgo_oracle.c", "sgo_collide.h", "sgo_vehicle.h", "sgo_math.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "sgp.h"))
     if not force and os.path.exists(_LIB_PATH) and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return _LIB_PATH
@@ -58,6 +58,19 @@ def collide_pair(a, b, max_sep=0.02):
     if not hit:
         return None
     return n, p1[:npts.value].copy(), p2[:npts.value].copy()
+
+
+def cast_sphere(body, origin, direction, max_t, radius):
+    """Sphere cast of the oracle against one body desc. Returns (t, normal, point) or None."""
+    o = np.asarray(origin, np.float32)
+    d = np.asarray(direction, np.float32)
+    n = np.zeros(3, np.float32)
+    p = np.zeros(3, np.float32)
+    f = lib().sgo_cast_sphere
+    f.restype = C.c_float
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    t = f(C.addressof(body), o.ctypes.data, d.ctypes.data, float(max_t), float(radius), n.ctypes.data, p.ctypes.data)
+    return None if t < 0 else (float(t), n, p)
 
 
 def set_threads(n):

@@ -33,6 +33,7 @@
 #endif
 #include "../include/sgp.h"
 #include "sgo_collide.h"
+#include "sgo_vehicle.h"
 
 #define SGO_API __attribute__((visibility("default")))
 #define SGO_MAX_COLOURS 64
@@ -105,6 +106,8 @@ typedef struct sgo_world {
 	/* multi-tile ghosts: global id -> local id, kept sorted by global id */
 	uint64_t* ghost_gid; uint32_t* ghost_lid; uint32_t n_ghosts;
 	int* is_ghost;
+	/* wheeled vehicles (sgo_vehicle.h) */
+	sgo_vehicle* vehicles; uint32_t n_vehicles, cap_vehicles;
 } sgo_world;
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -329,6 +332,7 @@ SGO_API int sgo_world_destroy(sgo_world* w)
 	free(w->prev_keys_sorted); free(w->prev_idx_sorted); free(w->order);
 	free(w->ev_act); free(w->ev_deact); free(w->ev_water); free(w->ev_added); free(w->ev_pers);
 	free(w->cell_keys); free(w->cell_idx); free(w->large); free(w->is_ghost); free(w->ghost_gid); free(w->ghost_lid);
+	free(w->vehicles);
 	free(w);
 	return SGP_OK;
 }
@@ -1215,6 +1219,242 @@ static void buoyancy_sweep(sgo_world* w, float dt)
 /* ------------------------------------------------------------------------------------------------ */
 /* think(dt)                                                                                        */
 
+
+/* ------------------------------------------------------------------------------------------------ */
+/* wheeled vehicles: world-side glue around sgo_vehicle.h                                              */
+
+SGO_API void sgo_default_vehicle_desc(sgp_vehicle_desc* d)
+{
+	memset(d, 0, sizeof(*d));
+	d->body = SGP_INVALID_ID;
+	d->num_wheels = 4;
+	for (int i = 0; i < 4; ++i) {
+		sgp_wheel_desc* w = &d->wheels[i];
+		const int front = i < 2, left = (i % 2) == 0;
+		w->position[0] = left ? -0.8f : 0.8f; w->position[1] = front ? 1.3f : -1.3f; w->position[2] = 0.15f;
+		w->suspension_dir[2] = -1.0f; w->steering_axis[2] = 1.0f; w->wheel_up[2] = 1.0f; w->wheel_forward[1] = 1.0f;
+		w->suspension_min_length = 0.2f; w->suspension_max_length = 0.5f; w->suspension_preload = 0.0f;   /* Scripting.cpp:326-330 */
+		w->spring_frequency = 2.0f; w->spring_damping = 0.5f;                                            /* :335-339 */
+		w->radius = 0.42f; w->width = 0.16f;                                                             /* :320-324 */
+		w->inertia = 0.9f; w->angular_damping = 0.2f;
+		w->max_steer_angle = front ? 0.78525f : 0.0f;                                                    /* :342, CarPhysics.cpp:127,153 */
+		w->max_brake_torque = 1500.0f; w->max_handbrake_torque = front ? 0.0f : 4000.0f;                 /* :347-348, CarPhysics.cpp:129,155 */
+		const float lf[3][2] = { { 0.0f, 0.0f }, { 0.06f, 1.2f }, { 0.2f, 1.0f } };
+		const float tf[3][2] = { { 0.0f, 0.0f }, { 3.0f, 1.2f }, { 20.0f, 1.0f } };
+		memcpy(w->longitudinal_friction, lf, sizeof(lf)); memcpy(w->lateral_friction, tf, sizeof(tf));
+	}
+	d->up[2] = 1.0f; d->forward[1] = 1.0f;
+	d->cast_radius = 0.08f;                                                                            /* CarPhysics.cpp:62 */
+	d->max_slope_angle = 80.0f * 3.14159265358979323846f / 180.0f;
+	d->engine_max_torque = 500.0f; d->engine_min_rpm = 1000.0f; d->engine_max_rpm = 6000.0f; d->engine_inertia = 0.5f; d->engine_angular_damping = 0.2f;
+	const float ec[3][2] = { { 0.0f, 0.8f }, { 0.66f, 1.0f }, { 1.0f, 0.8f } };
+	memcpy(d->engine_torque_curve, ec, sizeof(ec));
+	d->num_gears = 5; d->num_reverse_gears = 1;
+	const float gr[5] = { 2.66f, 1.78f, 1.3f, 1.0f, 0.74f };
+	memcpy(d->gear_ratios, gr, sizeof(gr)); d->reverse_gear_ratios[0] = -2.9f;
+	d->switch_time = 0.5f; d->clutch_release_time = 0.3f; d->switch_latency = 0.5f; d->shift_up_rpm = 4000.0f; d->shift_down_rpm = 2000.0f; d->clutch_strength = 10.0f;
+	d->num_differentials = 1;                                                                          /* front wheel drive, CarPhysics.cpp:191-194 */
+	d->differentials[0].left_wheel = 0; d->differentials[0].right_wheel = 1;
+	d->differentials[0].differential_ratio = 3.42f; d->differentials[0].left_right_split = 0.5f; d->differentials[0].limited_slip_ratio = 1.4f; d->differentials[0].engine_torque_ratio = 1.0f;
+	d->differentials[1] = d->differentials[0]; d->differentials[1].left_wheel = 2; d->differentials[1].right_wheel = 3;
+	d->differential_limited_slip_ratio = 1.4f;
+	d->num_anti_roll_bars = 2;                                                                         /* CarPhysics.cpp:217-221 */
+	d->anti_roll_bars[0].left_wheel = 0; d->anti_roll_bars[0].right_wheel = 1; d->anti_roll_bars[0].stiffness = 1000.0f;
+	d->anti_roll_bars[1].left_wheel = 2; d->anti_roll_bars[1].right_wheel = 3; d->anti_roll_bars[1].stiffness = 1000.0f;
+}
+
+static v3 v3_from(const float* p) { return V3(p[0], p[1], p[2]); }
+
+static int vehicle_desc_valid(const sgp_vehicle_desc* d)
+{
+	if (d->num_wheels < 1 || d->num_wheels > SGP_MAX_WHEELS) return 0;
+	if (d->num_gears < 1 || d->num_gears > SGP_MAX_GEARS || d->num_reverse_gears < 1 || d->num_reverse_gears > SGP_MAX_GEARS) return 0;
+	if (d->num_differentials > 2 || d->num_anti_roll_bars > 2) return 0;
+	for (uint32_t k = 0; k < d->num_differentials; ++k) {
+		if (d->differentials[k].left_wheel >= (int)d->num_wheels || d->differentials[k].right_wheel >= (int)d->num_wheels) return 0;
+		if (!(d->differentials[k].limited_slip_ratio > 1.0f)) return 0;
+	}
+	for (uint32_t k = 0; k < d->num_anti_roll_bars; ++k) {
+		const sgp_anti_roll_bar_desc* r = &d->anti_roll_bars[k];
+		if (r->left_wheel < 0 || r->right_wheel < 0 || r->left_wheel >= (int)d->num_wheels || r->right_wheel >= (int)d->num_wheels) return 0;
+	}
+	for (uint32_t i = 0; i < d->num_wheels; ++i) {
+		const sgp_wheel_desc* w = &d->wheels[i];
+		if (!(w->radius > 0.0f) || !(w->inertia > 0.0f) || !(w->suspension_max_length >= w->suspension_min_length) || !(w->suspension_min_length >= 0.0f)) return 0;
+	}
+	if (!(d->engine_inertia > 0.0f) || !(d->engine_max_rpm > 0.0f) || !(d->clutch_release_time > 0.0f) || !(d->differential_limited_slip_ratio > 1.0f)) return 0;
+	return 1;
+}
+
+static void vehicle_from_desc(sgo_vehicle* v, const sgp_vehicle_desc* d)
+{
+	memset(v, 0, sizeof(*v));
+	v->body = d->body; v->alive = 1; v->num_wheels = (int)d->num_wheels;
+	for (int i = 0; i < v->num_wheels; ++i) {
+		sgo_wheel* w = &v->wheels[i]; const sgp_wheel_desc* s = &d->wheels[i];
+		w->position = v3_from(s->position); w->suspension_dir = v3_from(s->suspension_dir); w->steering_axis = v3_from(s->steering_axis);
+		w->wheel_up = v3_from(s->wheel_up); w->wheel_forward = v3_from(s->wheel_forward);
+		w->sus_min = s->suspension_min_length; w->sus_max = s->suspension_max_length; w->sus_preload = s->suspension_preload;
+		w->spring_freq = s->spring_frequency; w->spring_damp = s->spring_damping;
+		w->radius = s->radius; w->width = s->width; w->inertia = s->inertia; w->ang_damping = s->angular_damping;
+		w->max_steer = s->max_steer_angle; w->max_brake_torque = s->max_brake_torque; w->max_handbrake_torque = s->max_handbrake_torque;
+		memcpy(w->long_fric, s->longitudinal_friction, sizeof(w->long_fric)); memcpy(w->lat_fric, s->lateral_friction, sizeof(w->lat_fric));
+		w->suspension_length = w->sus_max; w->contact_body = SGP_INVALID_ID;
+	}
+	v->up = v3_from(d->up); v->forward = v3_from(d->forward);
+	v->cast_radius = d->cast_radius;
+	{ float sn, cs; sgp_sincos_poly(d->max_slope_angle, &sn, &cs); v->cos_max_slope = cs; }
+	v->engine_max_torque = d->engine_max_torque; v->engine_min_rpm = d->engine_min_rpm; v->engine_max_rpm = d->engine_max_rpm;
+	v->engine_inertia = d->engine_inertia; v->engine_ang_damping = d->engine_angular_damping;
+	memcpy(v->engine_curve, d->engine_torque_curve, sizeof(v->engine_curve));
+	v->engine_rpm = d->engine_min_rpm;
+	v->num_gears = (int)d->num_gears; v->num_reverse_gears = (int)d->num_reverse_gears;
+	memcpy(v->gear_ratios, d->gear_ratios, sizeof(v->gear_ratios)); memcpy(v->reverse_gear_ratios, d->reverse_gear_ratios, sizeof(v->reverse_gear_ratios));
+	v->switch_time = d->switch_time; v->clutch_release_time = d->clutch_release_time; v->switch_latency = d->switch_latency;
+	v->shift_up_rpm = d->shift_up_rpm; v->shift_down_rpm = d->shift_down_rpm; v->clutch_strength = d->clutch_strength;
+	v->current_gear = 0; v->clutch_friction = 1.0f;
+	v->num_differentials = (int)d->num_differentials;
+	for (int k = 0; k < v->num_differentials; ++k) {
+		const sgp_differential_desc* s = &d->differentials[k];
+		v->differentials[k].left = s->left_wheel; v->differentials[k].right = s->right_wheel; v->differentials[k].ratio = s->differential_ratio;
+		v->differentials[k].left_right_split = s->left_right_split; v->differentials[k].limited_slip_ratio = s->limited_slip_ratio;
+		v->differentials[k].engine_torque_ratio = s->engine_torque_ratio;
+	}
+	v->differential_limited_slip_ratio = d->differential_limited_slip_ratio;
+	v->num_anti_roll_bars = (int)d->num_anti_roll_bars;
+	for (int k = 0; k < v->num_anti_roll_bars; ++k) {
+		v->anti_roll_bars[k].left = d->anti_roll_bars[k].left_wheel; v->anti_roll_bars[k].right = d->anti_roll_bars[k].right_wheel;
+		v->anti_roll_bars[k].stiffness = d->anti_roll_bars[k].stiffness;
+	}
+}
+
+SGO_API int sgo_vehicle_create(sgo_world* w, const sgp_vehicle_desc* d, uint32_t* id_out)
+{
+	if (!w || !d || !id_out) return SGP_ERR_INVALID;
+	if (!live(w, d->body) || w->bodies[d->body].motion != SGP_MOTION_DYNAMIC) return SGP_ERR_BAD_ID;
+	if (!vehicle_desc_valid(d)) return SGP_ERR_INVALID;
+	uint32_t id = w->n_vehicles;
+	for (uint32_t k = 0; k < w->n_vehicles; ++k) if (!w->vehicles[k].alive) { id = k; break; }     /* lowest free slot */
+	if (id == w->n_vehicles) {
+		if (w->n_vehicles == w->cap_vehicles) { w->cap_vehicles = w->cap_vehicles ? w->cap_vehicles * 2 : 16; w->vehicles = (sgo_vehicle*)realloc(w->vehicles, sizeof(sgo_vehicle) * w->cap_vehicles); }
+		w->n_vehicles++;
+	}
+	vehicle_from_desc(&w->vehicles[id], d);
+	*id_out = id;
+	return SGP_OK;
+}
+
+static int vehicle_live(sgo_world* w, uint32_t id) { return w && id < w->n_vehicles && w->vehicles[id].alive; }
+
+SGO_API int sgo_vehicle_destroy(sgo_world* w, uint32_t id) { if (!vehicle_live(w, id)) return SGP_ERR_BAD_ID; w->vehicles[id].alive = 0; return SGP_OK; }
+
+SGO_API int sgo_vehicle_set_inputs(sgo_world* w, uint32_t first, uint32_t n, const sgp_vehicle_input* in)
+{
+	for (uint32_t k = 0; k < n; ++k) {
+		if (!vehicle_live(w, first + k)) return SGP_ERR_BAD_ID;
+		sgo_vehicle* v = &w->vehicles[first + k];
+		v->in_forward = clampf(in[k].forward, -1.0f, 1.0f); v->in_right = clampf(in[k].right, -1.0f, 1.0f);
+		v->in_brake = clampf(in[k].brake, 0.0f, 1.0f); v->in_handbrake = clampf(in[k].hand_brake, 0.0f, 1.0f);
+		/* "On user input, assure that the car is active" (CarPhysics.cpp:362-363) */
+		if ((v->in_forward != 0.0f || v->in_right != 0.0f || v->in_brake != 0.0f || v->in_handbrake != 0.0f) && live(w, v->body)) body_activate(w, v->body);
+	}
+	return SGP_OK;
+}
+SGO_API int sgo_vehicle_set_input(sgo_world* w, uint32_t id, const sgp_vehicle_input* in) { return sgo_vehicle_set_inputs(w, id, 1, in); }
+
+static void vec_out(float* o, v3 v) { o[0] = v.x; o[1] = v.y; o[2] = v.z; }
+SGO_API int sgo_vehicle_get_states(sgo_world* w, uint32_t first, uint32_t n, sgp_vehicle_state* out)
+{
+	for (uint32_t k = 0; k < n; ++k) {
+		if (!vehicle_live(w, first + k)) return SGP_ERR_BAD_ID;
+		const sgo_vehicle* v = &w->vehicles[first + k];
+		sgp_vehicle_state* s = &out[k];
+		memset(s, 0, sizeof(*s));
+		for (int i = 0; i < v->num_wheels; ++i) {
+			const sgo_wheel* wh = &v->wheels[i]; sgp_wheel_state* ws = &s->wheels[i];
+			ws->suspension_length = wh->suspension_length; ws->steer_angle = wh->steer_angle; ws->rotation_angle = wh->angle; ws->angular_velocity = wh->angular_velocity;
+			ws->has_contact = wh->has_contact; ws->contact_body = wh->has_contact ? wh->contact_body : SGP_INVALID_ID;
+			if (wh->has_contact) {
+				vec_out(ws->contact_position, wh->contact_pos); vec_out(ws->contact_normal, wh->contact_normal);
+				vec_out(ws->contact_longitudinal, wh->contact_long); vec_out(ws->contact_lateral, wh->contact_lat); vec_out(ws->contact_point_velocity, wh->contact_point_vel);
+			}
+			ws->suspension_lambda = wh->suspension.lambda + wh->max_up.lambda; ws->longitudinal_lambda = wh->longitudinal.lambda; ws->lateral_lambda = wh->lateral.lambda;
+			ws->longitudinal_slip = wh->long_slip; ws->lateral_slip = wh->lat_slip;
+		}
+		s->engine_rpm = v->engine_rpm; s->current_gear = v->current_gear; s->clutch_friction = v->clutch_friction; s->active = v->active;
+	}
+	return SGP_OK;
+}
+SGO_API int sgo_vehicle_get_state(sgo_world* w, uint32_t id, sgp_vehicle_state* out) { return sgo_vehicle_get_states(w, id, 1, out); }
+
+SGO_API int sgo_vehicle_reset_drivetrain(sgo_world* w, uint32_t id, float rpm, float wheel_w)
+{
+	if (!vehicle_live(w, id)) return SGP_ERR_BAD_ID;
+	sgo_vehicle* v = &w->vehicles[id];
+	v->engine_rpm = rpm;
+	for (int i = 0; i < v->num_wheels; ++i) v->wheels[i].angular_velocity = wheel_w;
+	return SGP_OK;
+}
+
+static sgo_chassis chassis_load(const sgo_body* b)
+{
+	sgo_chassis c;
+	c.pos = b->pos; c.rot = b->rot; c.v = b->linv; c.w = b->angv;
+	c.im = b->inv_mass; c.inv_inertia_local = b->inv_inertia;
+	c.I = world_inv_inertia(quat_to_m33(b->rot), b->inv_inertia);
+	return c;
+}
+
+/* VehicleConstraint::OnStep for every vehicle whose chassis is awake.  The cast visits every body (closest accepted hit; on
+   equal distance the lower body id wins) -- the device walks the broad-phase grid instead and must find the same hit. */
+static void vehicles_pre_step(sgo_world* w, float dt)
+{
+	for (uint32_t k = 0; k < w->n_vehicles; ++k) {
+		sgo_vehicle* v = &w->vehicles[k];
+		if (!v->alive) continue;
+		v->active = live(w, v->body) && body_movable(&w->bodies[v->body]);
+		if (!v->active) continue;
+		sgo_body* b = &w->bodies[v->body];
+		sgo_chassis c = chassis_load(b);
+		sgo_vehicle_pre_a(v, &c);
+		for (int i = 0; i < v->num_wheels; ++i) {
+			sgo_wheel* wh = &v->wheels[i];
+			float best = wh->cast_len; uint32_t bid = SGP_INVALID_ID; v3 bn = V3(0, 0, 0), bp = V3(0, 0, 0);
+			for (uint32_t j = 0; j < w->high; ++j) {
+				const sgo_body* o = &w->bodies[j];
+				if (!o->alive || j == v->body || o->is_sensor) continue;
+				if (!(o->layer == SGP_LAYER_NON_MOVING || o->layer == SGP_LAYER_MOVING)) continue;      /* tester object layer MOVING, CarPhysics.cpp:62 */
+				v3 n, p;
+				const float t = sgo_cast_sphere_body(o->shape_type, o->shape, o->pos, quat_to_m33(o->rot), wh->cast_origin, wh->cast_dir, best, v->cast_radius, &n, &p);
+				if (t < 0.0f || n.z < v->cos_max_slope) continue;
+				if (t < best || bid == SGP_INVALID_ID) { best = t; bid = j; bn = n; bp = p; }
+			}
+			if (bid != SGP_INVALID_ID) {
+				const sgo_body* o = &w->bodies[bid];
+				const v3 gv = o->motion == SGP_MOTION_STATIC ? V3(0, 0, 0) : v3_add(o->linv, v3_cross(o->angv, v3_sub(bp, o->pos)));
+				sgo_vehicle_set_hit(v, i, bid, best, bn, bp, gv, o->friction);
+			}
+		}
+		if (sgo_vehicle_pre_b(v, &c, dt)) b->sleep_timer = 0.0f;
+		b->linv = c.v; b->angv = c.w;
+	}
+}
+
+/* mode 0 warm start, 1 velocity iteration, 2 position iteration */
+static void vehicles_solve(sgo_world* w, int mode)
+{
+	for (uint32_t k = 0; k < w->n_vehicles; ++k) {
+		sgo_vehicle* v = &w->vehicles[k];
+		if (!v->alive || !v->active) continue;
+		sgo_body* b = &w->bodies[v->body];
+		sgo_chassis c = chassis_load(b);
+		if (mode == 0) sgo_vehicle_warm_start(v, &c);
+		else if (mode == 1) sgo_vehicle_solve_velocity(v, &c);
+		else sgo_vehicle_solve_position(v, &c, w->st.baumgarte);
+		if (mode == 2) { b->pos = c.pos; b->rot = c.rot; } else { b->linv = c.v; b->angv = c.w; }
+	}
+}
+
 static int cmp_prev(const void* a, const void* b)
 {
 	const keyidx* x = (const keyidx*)a; const keyidx* y = (const keyidx*)b;
@@ -1225,6 +1465,9 @@ SGO_API int sgo_world_step(sgo_world* w, float dt)
 {
 	if (!w || !(dt > 0.0f)) return SGP_ERR_INVALID;
 	memset(&w->stats, 0, sizeof(w->stats));
+
+	/* 0. step listeners: VehicleConstraint::OnStep (wheel casts, controller, row setup) */
+	vehicles_pre_step(w, dt);
 
 	/* 1. MotionProperties::ApplyForceTorqueAndDragInternal (JobApplyGravity) */
 	#pragma omp parallel for schedule(static, 1024) if (g_threads > 1)
@@ -1274,8 +1517,9 @@ SGO_API int sgo_world_step(sgo_world* w, float dt)
 		} } while (0)
 
 	/* 5. warm start + velocity iterations */
-	if (w->st.warm_start) SOLVE_PASS(warm_start_constraint);
-	for (int it = 0; it < w->st.num_velocity_steps; ++it) SOLVE_PASS(solve_velocity_constraint);
+	/* (non-contact constraints -- here: the vehicles -- go first in every pass, as in PhysicsSystem::JobSolveVelocityConstraints) */
+	if (w->st.warm_start) { vehicles_solve(w, 0); SOLVE_PASS(warm_start_constraint); }
+	for (int it = 0; it < w->st.num_velocity_steps; ++it) { vehicles_solve(w, 1); SOLVE_PASS(solve_velocity_constraint); }
 
 	/* 6. integrate positions (Body::AddPositionStep / AddRotationStep) */
 	#pragma omp parallel for schedule(static, 1024) if (g_threads > 1)
@@ -1293,7 +1537,7 @@ SGO_API int sgo_world_step(sgo_world* w, float dt)
 	}
 
 	/* 7. position iterations */
-	for (int it = 0; it < w->st.num_position_steps; ++it) SOLVE_PASS(solve_position_constraint);
+	for (int it = 0; it < w->st.num_position_steps; ++it) { vehicles_solve(w, 2); SOLVE_PASS(solve_position_constraint); }
 
 	/* 8. bounds, sleeping */
 	#pragma omp parallel for schedule(static, 1024) if (g_threads > 1)
@@ -1482,6 +1726,16 @@ SGO_API int sgo_collide_pair(const sgp_body_desc* a, const sgp_body_desc* b, flo
 		p2[3 * i] = m.p2[i].x; p2[3 * i + 1] = m.p2[i].y; p2[3 * i + 2] = m.p2[i].z;
 	}
 	return 1;
+}
+
+/* Sphere cast against one body desc (test hook for sgo_cast_sphere_body). Returns t or -1. */
+SGO_API float sgo_cast_sphere(const sgp_body_desc* b, const float o[3], const float d[3], float max_t, float rs, float* n_out, float* p_out)
+{
+	const quat q = { b->rot[0], b->rot[1], b->rot[2], b->rot[3] };
+	v3 n = V3(0, 0, 0), p = V3(0, 0, 0);
+	const float t = sgo_cast_sphere_body(b->shape_type, b->shape, V3(b->pos[0], b->pos[1], b->pos[2]), quat_to_m33(q), V3(o[0], o[1], o[2]), V3(d[0], d[1], d[2]), max_t, rs, &n, &p);
+	n_out[0] = n.x; n_out[1] = n.y; n_out[2] = n.z; p_out[0] = p.x; p_out[1] = p.y; p_out[2] = p.z;
+	return t;
 }
 
 /* Constraints of the step just taken (the contact cache): key a<<32|b, colour, np, lambdas, normal. */

@@ -105,13 +105,65 @@ class ConstraintDump(C.Structure):
                 ("lam_t1", f32 * 4), ("lam_t2", f32 * 4), ("bias", f32 * 4)]
 
 
+MAX_WHEELS, MAX_GEARS = 4, 8
+
+
+class WheelDesc(C.Structure):
+    _fields_ = [("position", f32 * 3), ("suspension_dir", f32 * 3), ("steering_axis", f32 * 3), ("wheel_up", f32 * 3),
+                ("wheel_forward", f32 * 3), ("suspension_min_length", f32), ("suspension_max_length", f32),
+                ("suspension_preload", f32), ("spring_frequency", f32), ("spring_damping", f32), ("radius", f32),
+                ("width", f32), ("inertia", f32), ("angular_damping", f32), ("max_steer_angle", f32),
+                ("max_brake_torque", f32), ("max_handbrake_torque", f32), ("longitudinal_friction", (f32 * 2) * 3),
+                ("lateral_friction", (f32 * 2) * 3)]
+
+
+class DifferentialDesc(C.Structure):
+    _fields_ = [("left_wheel", i32), ("right_wheel", i32), ("differential_ratio", f32), ("left_right_split", f32),
+                ("limited_slip_ratio", f32), ("engine_torque_ratio", f32)]
+
+
+class AntiRollBarDesc(C.Structure):
+    _fields_ = [("left_wheel", i32), ("right_wheel", i32), ("stiffness", f32)]
+
+
+class VehicleDesc(C.Structure):
+    _fields_ = [("body", u32), ("num_wheels", u32), ("wheels", WheelDesc * MAX_WHEELS), ("up", f32 * 3),
+                ("forward", f32 * 3), ("cast_radius", f32), ("max_slope_angle", f32), ("engine_max_torque", f32),
+                ("engine_min_rpm", f32), ("engine_max_rpm", f32), ("engine_inertia", f32),
+                ("engine_angular_damping", f32), ("engine_torque_curve", (f32 * 2) * 3), ("num_gears", u32),
+                ("num_reverse_gears", u32), ("gear_ratios", f32 * MAX_GEARS), ("reverse_gear_ratios", f32 * MAX_GEARS),
+                ("switch_time", f32), ("clutch_release_time", f32), ("switch_latency", f32), ("shift_up_rpm", f32),
+                ("shift_down_rpm", f32), ("clutch_strength", f32), ("num_differentials", u32),
+                ("differentials", DifferentialDesc * 2), ("differential_limited_slip_ratio", f32),
+                ("num_anti_roll_bars", u32), ("anti_roll_bars", AntiRollBarDesc * 2)]
+
+
+class VehicleInput(C.Structure):
+    _fields_ = [("forward", f32), ("right", f32), ("brake", f32), ("hand_brake", f32)]
+
+
+class WheelState(C.Structure):
+    _fields_ = [("suspension_length", f32), ("steer_angle", f32), ("rotation_angle", f32), ("angular_velocity", f32),
+                ("has_contact", i32), ("contact_body", u32), ("contact_position", f32 * 3), ("contact_normal", f32 * 3),
+                ("contact_longitudinal", f32 * 3), ("contact_lateral", f32 * 3), ("contact_point_velocity", f32 * 3),
+                ("suspension_lambda", f32), ("longitudinal_lambda", f32), ("lateral_lambda", f32),
+                ("longitudinal_slip", f32), ("lateral_slip", f32)]
+
+
+class VehicleState(C.Structure):
+    _fields_ = [("wheels", WheelState * MAX_WHEELS), ("engine_rpm", f32), ("current_gear", i32),
+                ("clutch_friction", f32), ("active", i32)]
+
+
 ABI_SIZEOF_ORDER = ["sgp_settings", "sgp_world_desc", "sgp_body_desc", "sgp_body_state", "sgp_body_event",
-                    "sgp_contact_event", "sgp_ray", "sgp_hit", "sgp_step_stats", "sgp_step_profile", "sgp_ghost_record"]
+                    "sgp_contact_event", "sgp_ray", "sgp_hit", "sgp_step_stats", "sgp_step_profile", "sgp_ghost_record",
+                    "sgp_vehicle_desc", "sgp_vehicle_input", "sgp_vehicle_state"]
 
 STRUCTS = {"sgp_settings": Settings, "sgp_world_desc": WorldDesc, "sgp_body_desc": BodyDesc,
            "sgp_body_state": BodyState, "sgp_body_event": BodyEvent, "sgp_contact_event": ContactEvent,
            "sgp_ray": Ray, "sgp_hit": Hit, "sgp_step_stats": StepStats, "sgp_step_profile": StepProfile,
-           "sgp_ghost_record": GhostRecord}
+           "sgp_ghost_record": GhostRecord, "sgp_vehicle_desc": VehicleDesc, "sgp_vehicle_input": VehicleInput,
+           "sgp_vehicle_state": VehicleState}
 
 body_desc_dtype = np.dtype(BodyDesc)
 body_state_dtype = np.dtype(BodyState)
@@ -122,6 +174,8 @@ constraint_dump_dtype = np.dtype(ConstraintDump)
 ray_dtype = np.dtype(Ray)
 hit_dtype = np.dtype(Hit)
 pose_vel_dtype = np.dtype(PoseVel)
+vehicle_input_dtype = np.dtype(VehicleInput)
+vehicle_state_dtype = np.dtype(VehicleState)
 
 P = C.POINTER
 vp = C.c_void_p
@@ -170,6 +224,14 @@ PROTOTYPES = {
     "world_import_ghosts": (C.c_int, [vp, vp, u32]),
     "world_device_array": (C.c_int, [vp, C.c_int, P(vp), P(u32)]),
     "world_stream": (C.c_int, [vp, P(vp)]),
+    "default_vehicle_desc": (None, [P(VehicleDesc)]),
+    "vehicle_create": (C.c_int, [vp, P(VehicleDesc), P(u32)]),
+    "vehicle_destroy": (C.c_int, [vp, u32]),
+    "vehicle_set_input": (C.c_int, [vp, u32, P(VehicleInput)]),
+    "vehicle_set_inputs": (C.c_int, [vp, u32, u32, vp]),
+    "vehicle_get_state": (C.c_int, [vp, u32, P(VehicleState)]),
+    "vehicle_get_states": (C.c_int, [vp, u32, u32, vp]),
+    "vehicle_reset_drivetrain": (C.c_int, [vp, u32, f32, f32]),
     # test/debug helper, not a facade entry point
     "world_dump_constraints": (C.c_int, [vp, vp, u32, P(u32)]),
 }

@@ -200,6 +200,42 @@ class CWorld:
         self._check(self._fn("raycast")(self._h, rays.ctypes.data, len(rays), hits.ctypes.data), "raycast")
         return hits
 
+    # -- wheeled vehicles ---------------------------------------------------------------------------------------
+    def default_vehicle_desc(self, body=None):
+        d = abi.VehicleDesc()
+        self._fn("default_vehicle_desc")(C.byref(d))
+        if body is not None:
+            d.body = int(body)
+        return d
+
+    def vehicle_create(self, desc):
+        out = C.c_uint32(abi.INVALID_ID)
+        self._check(self._fn("vehicle_create")(self._h, C.byref(desc), C.byref(out)), "vehicle_create")
+        return out.value
+
+    def vehicle_destroy(self, vid):
+        self._check(self._fn("vehicle_destroy")(self._h, int(vid)), "vehicle_destroy")
+
+    def vehicle_set_input(self, vid, forward=0.0, right=0.0, brake=0.0, hand_brake=0.0):
+        i = abi.VehicleInput(float(forward), float(right), float(brake), float(hand_brake))
+        self._check(self._fn("vehicle_set_input")(self._h, int(vid), C.byref(i)), "vehicle_set_input")
+
+    def vehicle_set_inputs(self, first, inputs):
+        inputs = np.ascontiguousarray(inputs, dtype=abi.vehicle_input_dtype)
+        self._check(self._fn("vehicle_set_inputs")(self._h, int(first), len(inputs), inputs.ctypes.data), "vehicle_set_inputs")
+
+    def vehicle_get_state(self, vid):
+        return self.vehicle_get_states(vid, 1)[0]
+
+    def vehicle_get_states(self, first, n):
+        out = np.zeros(n, dtype=abi.vehicle_state_dtype)
+        self._check(self._fn("vehicle_get_states")(self._h, int(first), int(n), out.ctypes.data), "vehicle_get_states")
+        return out
+
+    def vehicle_reset_drivetrain(self, vid, engine_rpm=0.0, wheel_angular_velocity=0.0):
+        self._check(self._fn("vehicle_reset_drivetrain")(self._h, int(vid), float(engine_rpm), float(wheel_angular_velocity)),
+                    "vehicle_reset_drivetrain")
+
     def dump_constraints(self, cap=None):
         cap = (8 * self.max_bodies + 1024) if cap is None else cap
         out = np.zeros(cap, dtype=abi.constraint_dump_dtype)

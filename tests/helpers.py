@@ -38,3 +38,13 @@ def quat_axis_angle(axis, angle):
     axis = axis / np.linalg.norm(axis)
     s = np.sin(angle / 2)
     return (axis[0] * s, axis[1] * s, axis[2] * s, np.cos(angle / 2))
+
+
+def add_car(w, pos=(0, 0, 0.75), rot=(0, 0, 0, 1), mass=1200.0, friction=0.5, desc_edit=None):
+    """Chassis box (hull extents of the default car script, Scripting.cpp:369-377, as a box: x right, y forward, z up) plus the
+    default 4-wheel vehicle.  Returns (body id, vehicle id)."""
+    body = dyn(w, shape=(0.9, 2.0, 0.25, 0.0), pos=pos, rot=rot, mass=mass, friction=friction, restitution=0.0)
+    vd = w.default_vehicle_desc(body)
+    if desc_edit is not None:
+        desc_edit(vd)
+    return body, w.vehicle_create(vd)
