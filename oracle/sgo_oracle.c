@@ -398,6 +398,7 @@ static int live(sgo_world* w, uint32_t id) { return w && id < w->high && w->bodi
 SGO_API int sgo_body_remove(sgo_world* w, uint32_t id)
 {
 	if (!live(w, id)) return SGP_ERR_BAD_ID;
+	for (uint32_t k = 0; k < w->n_vehicles; ++k) if (w->vehicles[k].alive && w->vehicles[k].body == id) w->vehicles[k].alive = 0;   /* a vehicle does not outlive its chassis */
 	w->bodies[id].alive = 0; w->bodies[id].active = 0;
 	w->free_list[w->n_free++] = id;
 	w->n_alive--;

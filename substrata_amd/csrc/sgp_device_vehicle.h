@@ -1,0 +1,615 @@
+// sgp_device_vehicle.h -- gfx950 wheeled vehicle constraint: per-vehicle arithmetic (device code only).
+//
+// Role of JPH::VehicleConstraint + JPH::WheeledVehicleController + JPH::VehicleCollisionTesterCastSphere behind CarPhysics
+// (/root/reference/gui_client/CarPhysics.cpp:62,94-231; defaults /root/reference/gui_client/Scripting.cpp:315-346):
+// per wheel one sphere cast along the suspension, tyre slip -> friction, engine / clutch / gearbox / differential, brakes,
+// anti-roll bars, then 4 axis rows per wheel (soft suspension spring, hard max-up stop, longitudinal, lateral).
+// One thread owns one vehicle; vehicles never share a chassis and treat the body under a wheel as kinematic (its contact
+// point velocity is sampled at cast time), so the vehicle phases need no colouring.
+// The arithmetic (expression order included) is the contract checked by tests/test_vehicle_parity_gpu.py against the CPU
+// oracle; no libm call sits on this path (polynomial sin/cos/acos).
+#pragma once
+#include "sgp_device_math.h"
+
+#define SGD_MAX_WHEELS 4
+#define SGD_MAX_GEARS 8
+#define SGD_VEH_PI 3.14159265358979323846f
+
+// one row J = [-axis, -(r1 x axis)] against a kinematic second body (Jolt AxisConstraintPart + SpringPart)
+struct sgd_axis_part {
+	v3 r1xa;            // r1 x axis
+	v3 iI_r1xa;         // I1^-1 (r1 x axis)
+	float eff;          // effective mass (incl. spring softness)
+	float softness, bias;
+	float lambda;
+	int active;
+};
+
+struct sgd_wheel {
+	// settings (JPH::WheelSettingsWV)
+	v3 position, suspension_dir, steering_axis, wheel_up, wheel_forward;
+	float sus_min, sus_max, sus_preload, spring_freq, spring_damp;
+	float radius, width, inertia, ang_damping, max_steer, max_brake_torque, max_handbrake_torque;
+	float long_fric[3][2], lat_fric[3][2];
+	// state (JPH::Wheel / WheelWV)
+	float angular_velocity, angle, steer_angle, suspension_length;
+	int has_contact; uint32_t contact_body;
+	v3 contact_pos, contact_normal, contact_long, contact_lat, contact_point_vel;
+	float axle_plane_constant;
+	float anti_roll_impulse, brake_impulse;
+	float long_slip, lat_slip, comb_long_fric, comb_lat_fric;
+	float ground_friction;
+	sgd_axis_part suspension, max_up, longitudinal, lateral;
+	// cast request of this step (filled by pre_a, consumed by the world's cast loop)
+	v3 cast_origin, cast_dir; float cast_len;
+};
+
+struct sgd_differential { int left, right; float ratio, left_right_split, limited_slip_ratio, engine_torque_ratio; };
+struct sgd_anti_roll_bar { int left, right; float stiffness; };
+
+struct sgd_vehicle {
+	uint32_t body;
+	int alive, active;                 // active = chassis was awake when this step's pre-step ran
+	int num_wheels;
+	sgd_wheel wheels[SGD_MAX_WHEELS];
+	v3 up, forward;                    // chassis frame
+	float cast_radius, cos_max_slope;
+	// engine (JPH::VehicleEngineSettings)
+	float engine_max_torque, engine_min_rpm, engine_max_rpm, engine_inertia, engine_ang_damping;
+	float engine_curve[3][2];
+	float engine_rpm;
+	// transmission (auto)
+	int num_gears, num_reverse_gears;
+	float gear_ratios[SGD_MAX_GEARS], reverse_gear_ratios[SGD_MAX_GEARS];
+	float switch_time, clutch_release_time, switch_latency, shift_up_rpm, shift_down_rpm, clutch_strength;
+	int current_gear; float clutch_friction, gear_switch_time_left, clutch_release_time_left, gear_switch_latency_time_left;
+	// differentials, anti-roll bars
+	int num_differentials; sgd_differential differentials[2]; float differential_limited_slip_ratio;
+	int num_anti_roll_bars; sgd_anti_roll_bar anti_roll_bars[2];
+	// driver input
+	float in_forward, in_right, in_brake, in_handbrake;
+};
+
+// chassis state as the vehicle rows see it
+struct sgd_chassis { v3 pos; quat rot; v3 v, w; float im; v3 inv_inertia_local; sym33 I; };
+
+SGP_DEV static float sgd_curve3(const float c[3][2], float x)
+{
+	if (x <= c[0][0]) return c[0][1];
+	if (x <= c[1][0]) return c[0][1] + (c[1][1] - c[0][1]) * ((x - c[0][0]) / (c[1][0] - c[0][0]));
+	if (x <= c[2][0]) return c[1][1] + (c[2][1] - c[1][1]) * ((x - c[1][0]) / (c[2][0] - c[1][0]));
+	return c[2][1];
+}
+
+// acos on [0,1] (Abramowitz & Stegun 4.4.45, |err| < 7e-5 rad)
+SGP_DEV static float sgd_acos01(float x)
+{
+	const float xc = clampf(x, 0.0f, 1.0f);
+	float p = -0.0187293f;
+	p = p * xc + 0.0742610f;
+	p = p * xc - 0.2121144f;
+	p = p * xc + 1.5707288f;
+	return p * sqrtf(1.0f - xc);
+}
+
+SGP_DEV static v3 sgd_rotate_about(v3 axis_unit, float angle, v3 v)
+{
+	float s, c;
+	sgp_sincos_poly(0.5f * angle, &s, &c);
+	const quat q = { axis_unit.x * s, axis_unit.y * s, axis_unit.z * s, c };
+	return m33_mul(quat_to_m33(q), v);
+}
+
+SGP_DEV static v3 sgd_chassis_point_vel(const sgd_chassis* c, v3 p)
+{
+	return v3_add(c->v, v3_cross(c->w, v3_sub(p, c->pos)));
+}
+
+// ---- rays and sphere casts against the three primitives (VehicleCollisionTesterCastSphere; also traceRay) ------------------
+
+SGP_DEV static float sgd_ray_sphere(v3 oc, v3 d, float r, float max_t, v3* n_out)
+{
+	const float B = v3_dot(oc, d), C = v3_len_sq(oc) - r * r;
+	if (C <= 0.0f) { *n_out = v3_neg(d); return 0.0f; }
+	const float disc = B * B - C;
+	if (disc < 0.0f) return -1.0f;
+	const float t = -B - sqrtf(disc);
+	if (t < 0.0f || t > max_t) return -1.0f;
+	*n_out = v3_scale(v3_add(oc, v3_scale(d, t)), 1.0f / r);
+	return t;
+}
+
+SGP_DEV static float sgd_ray_box(v3 ol, v3 dl, v3 h, float max_t, v3* n_out)
+{
+	float t0 = 0.0f, t1 = max_t; int ax = -1; float sg = 0.0f;
+	for (int k = 0; k < 3; ++k) {
+		const float ok = v3_get(ol, k), dk = v3_get(dl, k), hk = v3_get(h, k);
+		if (fabsf(dk) < 1.0e-12f) { if (ok < -hk || ok > hk) return -1.0f; continue; }
+		float ta = (-hk - ok) / dk, tb = (hk - ok) / dk; float s = -1.0f;
+		if (ta > tb) { const float tmp = ta; ta = tb; tb = tmp; s = 1.0f; }
+		if (ta > t0) { t0 = ta; ax = k; sg = s; }
+		if (tb < t1) t1 = tb;
+		if (t0 > t1) return -1.0f;
+	}
+	if (ax < 0) { *n_out = v3_neg(dl); return 0.0f; }
+	v3 nl = V3(0, 0, 0); v3_set(nl, ax, sg);
+	*n_out = nl;
+	return t0;
+}
+
+// capsule along z through the origin: radius r, half height hh
+SGP_DEV static float sgd_ray_capsule_z(v3 ol, v3 dl, float r, float hh, float max_t, v3* n_out)
+{
+	float best = -1.0f; v3 bn = V3(0, 0, 0);
+	const float a = dl.x * dl.x + dl.y * dl.y;
+	const float bq = ol.x * dl.x + ol.y * dl.y, c = ol.x * ol.x + ol.y * ol.y - r * r;
+	if (a > 1.0e-12f) {
+		const float disc = bq * bq - a * c;
+		if (disc >= 0.0f) {
+			const float t = (-bq - sqrtf(disc)) / a;
+			const float z = ol.z + dl.z * t;
+			if (t >= 0.0f && t <= max_t && fabsf(z) <= hh) { best = t; bn = V3((ol.x + dl.x * t) / r, (ol.y + dl.y * t) / r, 0.0f); }
+		}
+	}
+	for (int sgn = -1; sgn <= 1; sgn += 2) {
+		const v3 oc = V3(ol.x, ol.y, ol.z - (float)sgn * hh);
+		const float B = v3_dot(oc, dl), C = v3_len_sq(oc) - r * r;
+		const float disc = B * B - C;
+		if (disc < 0.0f) continue;
+		const float t = -B - sqrtf(disc);
+		if (t < 0.0f || t > max_t) continue;
+		if (best < 0.0f || t < best) { best = t; bn = v3_scale(v3_add(oc, v3_scale(dl, t)), 1.0f / r); }
+	}
+	if (best < 0.0f) {
+		const float zc = clampf(ol.z, -hh, hh);
+		const v3 dq = V3(ol.x, ol.y, ol.z - zc);
+		if (v3_len_sq(dq) <= r * r) { *n_out = v3_neg(dl); return 0.0f; }
+		return -1.0f;
+	}
+	*n_out = bn;
+	return best;
+}
+
+SGP_DEV static v3 sgd_perm_to_z(v3 v, int axis) // coordinates permuted so that `axis` becomes z
+{
+	return axis == 0 ? V3(v.y, v.z, v.x) : (axis == 1 ? V3(v.z, v.x, v.y) : v);
+}
+SGP_DEV static v3 sgd_perm_from_z(v3 v, int axis)
+{
+	return axis == 0 ? V3(v.z, v.x, v.y) : (axis == 1 ? V3(v.y, v.z, v.x) : v);
+}
+
+/* A sphere of radius rs whose centre moves from o along the unit direction d for at most max_t, against one body
+   (shape type / parameters p, pose pos + R).  Returns the travel distance at first touch (0 if it starts overlapping) or -1;
+   n_out = world normal at the touch point on the body (towards the sphere), p_out = world touch point on the body.
+   Box: the Minkowski sum box (+) ball is covered exactly by 3 boxes grown along one axis each plus 12 edge capsules. */
+SGP_DEV static float sgd_cast_sphere_body(int type, const float* p, v3 pos, m33 R, v3 o, v3 d, float max_t, float rs, v3* n_out, v3* p_out)
+{
+	const v3 ol = m33_tmul(R, v3_sub(o, pos)), dl = m33_tmul(R, d);
+	float t = -1.0f; v3 nl = V3(0, 0, 0);
+	if (type == SGP_SHAPE_SPHERE) {
+		t = sgd_ray_sphere(ol, dl, p[0] + rs, max_t, &nl);
+	} else if (type == SGP_SHAPE_CAPSULE) {
+		t = sgd_ray_capsule_z(ol, dl, p[0] + rs, p[1], max_t, &nl);
+	} else {
+		const v3 h = V3(p[0], p[1], p[2]);
+		float lim = max_t;
+		if (rs <= 0.0f) {
+			t = sgd_ray_box(ol, dl, h, lim, &nl);
+		} else {
+			for (int k = 0; k < 3; ++k) {
+				v3 hk = h; v3_set(hk, k, v3_get(h, k) + rs);
+				v3 nn;
+				const float tk = sgd_ray_box(ol, dl, hk, lim, &nn);
+				if (tk >= 0.0f && (t < 0.0f || tk < t)) { t = tk; nl = nn; lim = tk; }
+			}
+			for (int axis = 0; axis < 3; ++axis) {
+				const int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
+				for (int s1 = -1; s1 <= 1; s1 += 2) for (int s2 = -1; s2 <= 1; s2 += 2) {
+					v3 c = V3(0, 0, 0);
+					v3_set(c, a1, (float)s1 * v3_get(h, a1)); v3_set(c, a2, (float)s2 * v3_get(h, a2));
+					v3 nn;
+					const float tk = sgd_ray_capsule_z(sgd_perm_to_z(v3_sub(ol, c), axis), sgd_perm_to_z(dl, axis), rs, v3_get(h, axis), lim, &nn);
+					if (tk >= 0.0f && (t < 0.0f || tk < t)) { t = tk; nl = sgd_perm_from_z(nn, axis); lim = tk; }
+				}
+			}
+		}
+	}
+	if (t < 0.0f) return -1.0f;
+	const v3 n = m33_mul(R, nl);
+	*n_out = n;
+	*p_out = v3_sub(v3_add(o, v3_scale(d, t)), v3_scale(n, rs));
+	return t;
+}
+
+// ---- axis rows ------------------------------------------------------------------------------------------------------------------
+
+SGP_DEV static void sgd_part_deactivate(sgd_axis_part* p) { p->active = 0; p->lambda = 0.0f; p->eff = 0.0f; p->softness = 0.0f; p->bias = 0.0f; }
+
+// hard row, or soft row when stiffness > 0 (Jolt SpringPart::CalculateSpringPropertiesWithStiffnessAndDamping)
+SGP_DEV static void sgd_part_setup(sgd_axis_part* p, const sgd_chassis* c, v3 r1, v3 axis, float dt, float C, float stiffness, float damping)
+{
+	p->r1xa = v3_cross(r1, axis);
+	p->iI_r1xa = sym33_mul(c->I, p->r1xa);
+	const float inv_eff = c->im + v3_dot(p->r1xa, p->iI_r1xa);
+	if (!(inv_eff > 0.0f)) { sgd_part_deactivate(p); return; }
+	if (stiffness > 0.0f) {
+		p->softness = 1.0f / (dt * (damping + dt * stiffness));
+		p->bias = dt * stiffness * p->softness * C;
+		p->eff = 1.0f / (inv_eff + p->softness);
+	} else {
+		p->softness = 0.0f; p->bias = 0.0f;
+		p->eff = 1.0f / inv_eff;
+	}
+	p->active = 1;
+}
+
+SGP_DEV static void sgd_part_apply(const sgd_axis_part* p, sgd_chassis* c, v3 axis, float lambda)
+{
+	c->v = v3_sub(c->v, v3_scale(axis, lambda * c->im));
+	c->w = v3_sub(c->w, v3_scale(p->iI_r1xa, lambda));
+}
+
+SGP_DEV static void sgd_part_solve(sgd_axis_part* p, sgd_chassis* c, v3 ground_vel, v3 axis, float lo, float hi)
+{
+	const float jv = v3_dot(axis, v3_sub(c->v, ground_vel)) + v3_dot(p->r1xa, c->w);
+	const float lambda = p->eff * (jv - (p->softness * p->lambda + p->bias));
+	const float nl = clampf(p->lambda + lambda, lo, hi);
+	sgd_part_apply(p, c, axis, nl - p->lambda);
+	p->lambda = nl;
+}
+
+// ---- pre-step, part A: steering angle and the cast request of every wheel (VehicleConstraint::OnStep, first half) ------
+
+SGP_DEV static void sgd_vehicle_pre_a(sgd_vehicle* v, const sgd_chassis* c)
+{
+	const m33 R = quat_to_m33(c->rot);
+	for (int i = 0; i < v->num_wheels; ++i) {
+		sgd_wheel* w = &v->wheels[i];
+		w->steer_angle = -v->in_right * w->max_steer;                       // WheeledVehicleController::PreCollide
+		w->cast_origin = v3_add(c->pos, m33_mul(R, w->position));
+		w->cast_dir = m33_mul(R, w->suspension_dir);
+		w->cast_len = w->sus_max + w->radius - v->cast_radius;
+		w->has_contact = 0; w->contact_body = 0xFFFFFFFFu;
+	}
+}
+
+// The world's cast loop reports the accepted hit of wheel i (distance t along the cast).
+SGP_DEV static void sgd_vehicle_set_hit(sgd_vehicle* v, int i, uint32_t body, float t, v3 n, v3 p, v3 ground_point_vel, float ground_friction)
+{
+	sgd_wheel* w = &v->wheels[i];
+	w->has_contact = 1; w->contact_body = body;
+	w->contact_normal = n; w->contact_pos = p; w->contact_point_vel = ground_point_vel; w->ground_friction = ground_friction;
+	w->suspension_length = fmaxf(0.0f, t + v->cast_radius - w->radius);
+}
+
+// ---- pre-step, part B: everything after the casts ---------------------------------------------------------------------------
+
+SGP_DEV static float sgd_gear_ratio(const sgd_vehicle* v)
+{
+	if (v->current_gear < 0) return v->reverse_gear_ratios[-v->current_gear - 1];
+	if (v->current_gear == 0) return 0.0f;
+	return v->gear_ratios[v->current_gear - 1];
+}
+
+SGP_DEV static void sgd_transmission_update(sgd_vehicle* v, float dt, float rpm, float forward_input, int can_shift_up)
+{
+	const int old_gear = v->current_gear;
+	if (v->current_gear == 0 && forward_input > 0.0f) v->current_gear = 1;
+	else if (v->current_gear == 0 && forward_input < 0.0f) v->current_gear = -1;
+	else if (v->gear_switch_latency_time_left == 0.0f) {
+		if (can_shift_up && rpm > v->shift_up_rpm) {
+			if (v->current_gear < 0) { if (v->current_gear > -v->num_reverse_gears) v->current_gear--; }
+			else { if (v->current_gear < v->num_gears) v->current_gear++; }
+		} else if (rpm < v->shift_down_rpm) {
+			if (v->current_gear < 0) { const int max_gear = forward_input != 0.0f ? -1 : 0; if (v->current_gear < max_gear) v->current_gear++; }
+			else { const int min_gear = forward_input != 0.0f ? 1 : 0; if (v->current_gear > min_gear) v->current_gear--; }
+		}
+	}
+	if (old_gear != v->current_gear) {
+		v->gear_switch_time_left = old_gear != 0 ? v->switch_time : 0.0f;
+		v->clutch_release_time_left = v->clutch_release_time;
+		v->gear_switch_latency_time_left = v->switch_latency;
+		v->clutch_friction = 0.0f;
+	} else if (v->gear_switch_time_left > 0.0f) {
+		v->gear_switch_time_left = fmaxf(0.0f, v->gear_switch_time_left - dt);
+		v->clutch_friction = 0.0f;
+	} else if (v->clutch_release_time_left > 0.0f) {
+		v->clutch_release_time_left = fmaxf(0.0f, v->clutch_release_time_left - dt);
+		v->clutch_friction = 1.0f - v->clutch_release_time_left / v->clutch_release_time;
+	} else {
+		v->clutch_friction = 1.0f;
+		v->gear_switch_latency_time_left = fmaxf(0.0f, v->gear_switch_latency_time_left - dt);
+	}
+}
+
+// VehicleDifferentialSettings::CalculateTorqueRatio
+SGP_DEV static void sgd_differential_split(const sgd_differential* d, float wl, float wr, float* fl, float* fr)
+{
+	*fl = 1.0f - d->left_right_split; *fr = d->left_right_split;
+	if (d->limited_slip_ratio < 3.0e38f) {
+		const float ol = fmaxf(1.0e-3f, fabsf(wl)), orr = fmaxf(1.0e-3f, fabsf(wr));
+		const float omin = fminf(ol, orr), omax = fmaxf(ol, orr);
+		const float alpha = fminf((omax / omin - 1.0f) / (d->limited_slip_ratio - 1.0f), 1.0f);
+		const float oma = 1.0f - alpha;
+		if (ol < orr) { *fl = *fl * oma + alpha; *fr = *fr * oma; }
+		else { *fl = *fl * oma; *fr = *fr * oma + alpha; }
+	}
+}
+
+// Returns 1 when the chassis' sleep timer must be reset (wheels still spinning).
+SGP_DEV static int sgd_vehicle_pre_b(sgd_vehicle* v, sgd_chassis* c, float dt)
+{
+	const m33 R = quat_to_m33(c->rot);
+	const int nw = v->num_wheels;
+	// contact frames
+	for (int i = 0; i < nw; ++i) {
+		sgd_wheel* w = &v->wheels[i];
+		if (!w->has_contact) { w->suspension_length = w->sus_max; continue; }
+		w->axle_plane_constant = v3_dot(w->contact_normal, v3_add(w->cast_origin, v3_scale(w->cast_dir, w->suspension_length)));
+		const v3 steering_axis = m33_mul(R, w->steering_axis);
+		const v3 forward = sgd_rotate_about(steering_axis, w->steer_angle, m33_mul(R, w->wheel_forward));
+		v3 lat = v3_cross(forward, w->contact_normal);
+		const float ll = v3_len(lat);
+		lat = ll > 1.0e-12f ? v3_scale(lat, 1.0f / ll) : V3(0, 0, 0);
+		w->contact_lat = lat;
+		w->contact_long = v3_cross(w->contact_normal, lat);
+	}
+	// anti-roll bars: impulse from the suspension length difference, applied to the chassis at the two contact points
+	for (int i = 0; i < nw; ++i) v->wheels[i].anti_roll_impulse = 0.0f;
+	for (int k = 0; k < v->num_anti_roll_bars; ++k) {
+		sgd_wheel* lw = &v->wheels[v->anti_roll_bars[k].left]; sgd_wheel* rw = &v->wheels[v->anti_roll_bars[k].right];
+		if (lw->has_contact && rw->has_contact) {
+			const float impulse = (rw->suspension_length - lw->suspension_length) * v->anti_roll_bars[k].stiffness * dt;
+			lw->anti_roll_impulse = -impulse; rw->anti_roll_impulse = impulse;
+		}
+	}
+	for (int i = 0; i < nw; ++i) {
+		sgd_wheel* w = &v->wheels[i];
+		if (!w->has_contact || w->anti_roll_impulse == 0.0f) continue;
+		const v3 J = v3_scale(w->contact_normal, w->anti_roll_impulse);
+		c->v = v3_add(c->v, v3_scale(J, c->im));
+		c->w = v3_add(c->w, sym33_mul(c->I, v3_cross(v3_sub(w->contact_pos, c->pos), J)));
+	}
+
+	// ---- WheeledVehicleController::PostCollide ----
+	const float old_rpm = v->engine_rpm;
+	// WheelWV::Update: spin damping, rotation angle, slip -> tyre friction
+	for (int i = 0; i < nw; ++i) {
+		sgd_wheel* w = &v->wheels[i];
+		w->angular_velocity = w->angular_velocity * fmaxf(0.0f, 1.0f - w->ang_damping * dt);
+		w->angle = w->angle + w->angular_velocity * dt;
+		if (w->angle > 2.0f * SGD_VEH_PI) w->angle = w->angle - 2.0f * SGD_VEH_PI;
+		else if (w->angle < -2.0f * SGD_VEH_PI) w->angle = w->angle + 2.0f * SGD_VEH_PI;
+		if (w->has_contact) {
+			v3 rel = v3_sub(sgd_chassis_point_vel(c, w->contact_pos), w->contact_point_vel);
+			rel = v3_sub(rel, v3_scale(w->contact_normal, v3_dot(w->contact_normal, rel)));
+			const float rel_long = v3_dot(rel, w->contact_long);
+			const float denom = (rel_long < 0.0f ? -1.0f : 1.0f) * fmaxf(1.0e-3f, fabsf(rel_long));
+			w->long_slip = fabsf((w->angular_velocity * w->radius - rel_long) / denom);
+			const float long_fr = sgd_curve3(w->long_fric, w->long_slip);
+			const float rel_len = v3_len(rel);
+			w->lat_slip = rel_len < 1.0e-3f ? 0.0f : sgd_acos01(fabsf(rel_long) / rel_len);
+			const float lat_fr = sgd_curve3(w->lat_fric, w->lat_slip * (180.0f / SGD_VEH_PI));
+			w->comb_long_fric = sqrtf(long_fr * w->ground_friction);           // default VehicleConstraint combine function
+			w->comb_lat_fric = sqrtf(lat_fr * w->ground_friction);
+		} else {
+			w->long_slip = 0.0f; w->lat_slip = 0.0f; w->comb_long_fric = 0.0f; w->comb_lat_fric = 0.0f;
+		}
+	}
+	float forward_input = fabsf(v->in_forward) * v->clutch_friction;                 // auto transmission: no throttle while switching
+	v->engine_rpm = v->engine_rpm * fmaxf(0.0f, 1.0f - v->engine_ang_damping * dt); // VehicleEngine::ApplyDamping
+	const float engine_torque = forward_input * v->engine_max_torque * sgd_curve3(v->engine_curve, v->engine_rpm / v->engine_max_rpm);
+
+	// driven differentials and their share of the clutch torque (limited slip between differentials)
+	float dd_omega[2], dd_ratio[2]; int dd_idx[2]; int ndd = 0;
+	float omin = 3.0e38f, omax = 0.0f;
+	for (int k = 0; k < v->num_differentials; ++k) {
+		const sgd_differential* d = &v->differentials[k];
+		float avg = 0.0f; int cnt = 0;
+		if (d->left >= 0) { avg = avg + v->wheels[d->left].angular_velocity; ++cnt; }
+		if (d->right >= 0) { avg = avg + v->wheels[d->right].angular_velocity; ++cnt; }
+		if (cnt > 0) {
+			avg = fabsf(avg * d->ratio / (float)cnt);
+			dd_omega[ndd] = avg; dd_ratio[ndd] = d->engine_torque_ratio; dd_idx[ndd] = k; ++ndd;
+			omin = fminf(omin, avg); omax = fmaxf(omax, avg);
+		}
+	}
+	if (v->differential_limited_slip_ratio < 3.0e38f && omax > omin) {
+		float tf[2]; float sum = 0.0f;
+		for (int k = 0; k < ndd; ++k) { tf[k] = (omax - dd_omega[k]) / (omax - omin); sum = sum + tf[k]; }
+		for (int k = 0; k < ndd; ++k) tf[k] = tf[k] / sum;
+		const float lo = fmaxf(1.0e-3f, omin), hi = fmaxf(1.0e-3f, omax);
+		const float alpha = fminf((hi / lo - 1.0f) / (v->differential_limited_slip_ratio - 1.0f), 1.0f);
+		for (int k = 0; k < ndd; ++k) dd_ratio[k] = (1.0f - alpha) * dd_ratio[k] + alpha * tf[k];
+	}
+	// driven wheels: engine->wheel speed ratio and torque fraction
+	const float trans_ratio = sgd_gear_ratio(v);
+	int dw[4]; float dw_ratio[4], dw_frac[4]; int ndw = 0;
+	for (int k = 0; k < ndd; ++k) {
+		const sgd_differential* d = &v->differentials[dd_idx[k]];
+		const float ratio = trans_ratio * d->ratio;
+		if (d->left >= 0 && d->right >= 0) {
+			float fl, fr;
+			sgd_differential_split(d, v->wheels[d->left].angular_velocity, v->wheels[d->right].angular_velocity, &fl, &fr);
+			dw[ndw] = d->left; dw_ratio[ndw] = ratio; dw_frac[ndw] = dd_ratio[k] * fl; ++ndw;
+			dw[ndw] = d->right; dw_ratio[ndw] = ratio; dw_frac[ndw] = dd_ratio[k] * fr; ++ndw;
+		} else if (d->left >= 0) { dw[ndw] = d->left; dw_ratio[ndw] = ratio; dw_frac[ndw] = dd_ratio[k]; ++ndw; }
+		else if (d->right >= 0) { dw[ndw] = d->right; dw_ratio[ndw] = ratio; dw_frac[ndw] = dd_ratio[k]; ++ndw; }
+	}
+	// implicit clutch:  tc = tcs (we' - mean_j R_j ww_j'),  we' = we + dt (te - tc)/Ie,  ww_i' = ww_i + dt R_i F_i tc / Iw_i
+	const float rpm_to_w = 2.0f * SGD_VEH_PI / 60.0f, w_to_rpm = 60.0f / (2.0f * SGD_VEH_PI);
+	int solved = 0;
+	if (ndw > 0) {
+		const float tcs = trans_ratio != 0.0f ? v->clutch_friction * v->clutch_strength : 0.0f;
+		if (tcs > 0.0f) {
+			const float we = v->engine_rpm * rpm_to_w;
+			float s0 = 0.0f, bsum = 0.0f;
+			for (int k = 0; k < ndw; ++k) {
+				const sgd_wheel* w = &v->wheels[dw[k]];
+				s0 = s0 + dw_ratio[k] * w->angular_velocity;
+				bsum = bsum + dw_ratio[k] * dw_ratio[k] * dw_frac[k] / w->inertia;
+			}
+			const float inv_m = 1.0f / (float)ndw;
+			s0 = s0 * inv_m;
+			const float A = dt / v->engine_inertia, B = dt * bsum * inv_m;
+			const float tc = tcs * (we + A * engine_torque - s0) / (1.0f + tcs * (A + B));
+			v->engine_rpm = (we + A * (engine_torque - tc)) * w_to_rpm;
+			for (int k = 0; k < ndw; ++k) {
+				sgd_wheel* w = &v->wheels[dw[k]];
+				w->angular_velocity = w->angular_velocity + dt * dw_ratio[k] * dw_frac[k] * tc / w->inertia;
+			}
+			solved = 1;
+		}
+	}
+	if (!solved) v->engine_rpm = v->engine_rpm + w_to_rpm * engine_torque * dt / v->engine_inertia;   // VehicleEngine::ApplyTorque
+	v->engine_rpm = clampf(v->engine_rpm, v->engine_min_rpm, v->engine_max_rpm);
+
+	int slipping = 0;
+	for (int k = 0; k < ndw; ++k) {
+		const sgd_wheel* w = &v->wheels[dw[k]];
+		if (dw_frac[k] > 0.0f && (!w->has_contact || w->long_slip > 0.1f)) slipping = 1;
+	}
+	sgd_transmission_update(v, dt, v->engine_rpm, v->in_forward, !slipping && v->engine_rpm >= old_rpm);
+
+	// brakes
+	for (int i = 0; i < nw; ++i) {
+		sgd_wheel* w = &v->wheels[i];
+		const float brake_torque = v->in_brake * w->max_brake_torque + v->in_handbrake * w->max_handbrake_torque;
+		w->brake_impulse = 0.0f;
+		if (brake_torque > 0.0f) {
+			const float to_lock = fabsf(w->angular_velocity) * w->inertia / dt;
+			if (brake_torque > to_lock) {
+				w->angular_velocity = 0.0f;
+				w->brake_impulse = (brake_torque - to_lock) * dt / w->radius;
+			} else {
+				w->angular_velocity = w->angular_velocity + (w->angular_velocity < 0.0f ? 1.0f : -1.0f) * brake_torque * dt / w->inertia;
+			}
+		}
+	}
+
+	// ---- VehicleConstraint::SetupVelocityConstraint ----
+	for (int i = 0; i < nw; ++i) {
+		sgd_wheel* w = &v->wheels[i];
+		if (!w->has_contact) {
+			sgd_part_deactivate(&w->suspension); sgd_part_deactivate(&w->max_up); sgd_part_deactivate(&w->longitudinal); sgd_part_deactivate(&w->lateral);
+			continue;
+		}
+		const v3 r1 = v3_sub(w->contact_pos, c->pos);
+		const v3 neg_n = v3_neg(w->contact_normal);
+		float lam;
+		if (w->sus_max > w->sus_min) {
+			// spring stiffness from frequency / damping ratio and the effective mass at the average suspension point
+			const v3 fp = v3_add(w->position, v3_scale(w->suspension_dir, 0.5f * (w->sus_min + w->sus_max)));
+			const v3 fxu = v3_cross(fp, v3_neg(v->up));
+			const v3 il = c->inv_inertia_local;
+			const float eff_mass = 1.0f / (c->im + (fxu.x * il.x * fxu.x + fxu.y * il.y * fxu.y + fxu.z * il.z * fxu.z));
+			const float omega = 2.0f * SGD_VEH_PI * w->spring_freq;
+			const float stiffness = eff_mass * (omega * omega);
+			const float damping = 2.0f * eff_mass * w->spring_damp * omega;
+			const float Cc = w->suspension_length - w->sus_max - w->sus_preload;
+			lam = w->suspension.lambda;
+			sgd_part_setup(&w->suspension, c, r1, neg_n, dt, Cc, stiffness, damping);
+			if (w->suspension.active) w->suspension.lambda = lam;
+		} else sgd_part_deactivate(&w->suspension);
+		if (w->suspension_length < w->sus_min) {
+			lam = w->max_up.lambda;
+			sgd_part_setup(&w->max_up, c, r1, neg_n, dt, 0.0f, 0.0f, 0.0f);
+			if (w->max_up.active) w->max_up.lambda = lam;
+			w->suspension_length = w->sus_min;
+		} else sgd_part_deactivate(&w->max_up);
+		// the longitudinal row (engine / brake force) is never warm started: its impulse starts from zero every step
+		sgd_part_setup(&w->longitudinal, c, r1, v3_neg(w->contact_long), dt, 0.0f, 0.0f, 0.0f);
+		w->longitudinal.lambda = 0.0f;
+		lam = w->lateral.lambda;
+		sgd_part_setup(&w->lateral, c, r1, v3_neg(w->contact_lat), dt, 0.0f, 0.0f, 0.0f);
+		if (w->lateral.active) w->lateral.lambda = lam;
+	}
+	int spinning = 0;
+	for (int i = 0; i < nw; ++i) if (fabsf(v->wheels[i].angular_velocity) > 10.0f * SGD_VEH_PI / 180.0f) spinning = 1;
+	return spinning;
+}
+
+// VehicleConstraint::WarmStartVelocityConstraint
+SGP_DEV static void sgd_vehicle_warm_start(sgd_vehicle* v, sgd_chassis* c)
+{
+	for (int i = 0; i < v->num_wheels; ++i) {
+		sgd_wheel* w = &v->wheels[i];
+		if (!w->has_contact) continue;
+		if (w->suspension.active) sgd_part_apply(&w->suspension, c, v3_neg(w->contact_normal), w->suspension.lambda);
+		if (w->max_up.active) sgd_part_apply(&w->max_up, c, v3_neg(w->contact_normal), w->max_up.lambda);
+		if (w->lateral.active) sgd_part_apply(&w->lateral, c, v3_neg(w->contact_lat), w->lateral.lambda);
+	}
+}
+
+// VehicleConstraint::SolveVelocityConstraint + WheeledVehicleController::SolveLongitudinalAndLateralConstraints
+SGP_DEV static void sgd_vehicle_solve_velocity(sgd_vehicle* v, sgd_chassis* c)
+{
+	const int nw = v->num_wheels;
+	for (int i = 0; i < nw; ++i) {
+		sgd_wheel* w = &v->wheels[i];
+		if (!w->has_contact) continue;
+		const v3 neg_n = v3_neg(w->contact_normal);
+		if (w->suspension.active) sgd_part_solve(&w->suspension, c, w->contact_point_vel, neg_n, 0.0f, 3.0e38f);   // pushes, never pulls
+		if (w->max_up.active) sgd_part_solve(&w->max_up, c, w->contact_point_vel, neg_n, 0.0f, 3.0e38f);
+	}
+	float max_lat[SGD_MAX_WHEELS];
+	for (int i = 0; i < nw; ++i) {
+		sgd_wheel* w = &v->wheels[i];
+		max_lat[i] = 0.0f;
+		if (!w->has_contact) continue;
+		const float sus_lambda = w->suspension.lambda + w->max_up.lambda;
+		const float max_long = w->comb_long_fric * sus_lambda;
+		max_lat[i] = w->comb_lat_fric * sus_lambda;
+		if (!w->longitudinal.active) continue;
+		const v3 rel = v3_sub(sgd_chassis_point_vel(c, w->contact_pos), w->contact_point_vel);
+		const float rel_long = v3_dot(rel, w->contact_long);
+		if (w->brake_impulse != 0.0f) {
+			const float bi = fminf(w->brake_impulse, max_long);
+			float lo, hi;
+			if (rel_long >= 0.0f) { lo = -bi; hi = 0.0f; } else { lo = 0.0f; hi = bi; }
+			sgd_part_solve(&w->longitudinal, c, w->contact_point_vel, v3_neg(w->contact_long), lo, hi);
+		} else {
+			// impulse that brings the contact patch speed to the rolling speed of the wheel within this step
+			const float desired_w = rel_long / w->radius;
+			const float lin_imp = (w->angular_velocity - desired_w) * w->inertia / w->radius;
+			const float prev = w->longitudinal.lambda;
+			const float lim = clampf(prev + lin_imp, -max_long, max_long);
+			sgd_part_solve(&w->longitudinal, c, w->contact_point_vel, v3_neg(w->contact_long), lim, lim);
+			w->angular_velocity = w->angular_velocity - (w->longitudinal.lambda - prev) * w->radius / w->inertia;
+		}
+	}
+	for (int i = 0; i < nw; ++i) {
+		sgd_wheel* w = &v->wheels[i];
+		if (!w->has_contact || !w->lateral.active) continue;
+		sgd_part_solve(&w->lateral, c, w->contact_point_vel, v3_neg(w->contact_lat), -max_lat[i], max_lat[i]);
+	}
+}
+
+/* VehicleConstraint::SolvePositionConstraint: the axle at minimum suspension length must stay on the outer side of the plane
+   through the axle position at cast time.  Works on the chassis pose (c->pos, c->rot); c->I is recomputed from the pose. */
+SGP_DEV static void sgd_vehicle_solve_position(sgd_vehicle* v, sgd_chassis* c, float baumgarte)
+{
+	for (int i = 0; i < v->num_wheels; ++i) {
+		sgd_wheel* w = &v->wheels[i];
+		if (!w->has_contact) continue;
+		const m33 R = quat_to_m33(c->rot);
+		const v3 ws_dir = m33_mul(R, w->suspension_dir);
+		const v3 ws_pos = v3_add(c->pos, m33_mul(R, w->position));
+		const v3 min_pos = v3_add(ws_pos, v3_scale(ws_dir, w->sus_min));
+		const float err = v3_dot(w->contact_normal, min_pos) - w->axle_plane_constant;
+		if (err < 0.0f) {
+			const v3 axis = v3_neg(w->contact_normal);
+			const v3 r1 = v3_sub(w->contact_pos, c->pos);
+			const sym33 I = world_inv_inertia(R, c->inv_inertia_local);
+			const v3 r1xa = v3_cross(r1, axis);
+			const v3 iI = sym33_mul(I, r1xa);
+			const float inv_eff = c->im + v3_dot(r1xa, iI);
+			if (!(inv_eff > 0.0f)) continue;
+			const float lambda = -(1.0f / inv_eff) * baumgarte * err;
+			c->pos = v3_sub(c->pos, v3_scale(axis, lambda * c->im));
+			c->rot = quat_add_rotation_step(c->rot, v3_scale(iI, -lambda));
+		}
+	}
+}
+

@@ -34,7 +34,7 @@ enum {
 	KC_APPLY_FORCES = 0, KC_BP_CELL, KC_BP_SCAN, KC_BP_SCATTER, KC_BP_PAIRS, KC_BP_LARGE, KC_NARROWPHASE, KC_WAKE,
 	KC_COLOUR_CLAIM, KC_COLOUR_COMMIT, KC_COLOUR_COUNT, KC_SETUP, KC_WARM_START, KC_SOLVE_VELOCITY,
 	KC_INTEGRATE_POSE, KC_SOLVE_POSITION, KC_FINALIZE, KC_ISLAND_HOOK, KC_ISLAND_FLAG, KC_SLEEP_APPLY, KC_BUOYANCY,
-	KC_CACHE_BUILD, KC_MISC, KC_EDIT, KC_GATHER, KC_PREP_BODIES, KC_COUNT
+	KC_CACHE_BUILD, KC_MISC, KC_EDIT, KC_GATHER, KC_PREP_BODIES, KC_VEHICLE, KC_COUNT
 };
 
 // Dense broad-phase grid of the current step (written by k_bp_grid_params).
@@ -186,6 +186,8 @@ struct DV {
 	EventCounters* evc;
 	uint32_t* ev_activated; uint32_t* ev_deactivated; uint32_t* ev_water;
 	sgp_contact_event* ev_contacts_added; sgp_contact_event* ev_contacts_persisted; uint32_t cap_contact_events;
+	// wheeled vehicles (sgp_device_vehicle.h): AoS, one record per vehicle slot
+	struct sgd_vehicle* vehicles; uint32_t n_vehicles; const sgp_vehicle_input* vehicle_inputs;
 	// settings (fixed after world creation)
 	sgp_settings st;
 	float gx, gy, gz;
@@ -229,5 +231,7 @@ void launch_apply_cmds(const DV& d, const BodyCmd* cmds, const uint32_t* run_sta
 void launch_gather_states(const DV& d, const uint32_t* ids, uint32_t first, uint32_t n, sgp_body_state* out, hipStream_t s);
 void launch_gather_active(const DV& d, uint32_t nb, sgp_body_state* out, uint32_t cap, hipStream_t s);
 void launch_dump_constraints(const DV& d, uint32_t which, uint32_t n_con, void* out, uint32_t cap, hipStream_t s);
+void launch_vehicle_pre(const DV& d, hipStream_t s);
+void launch_vehicle_solve(const DV& d, int mode, hipStream_t s);      // mode as launch_solve_colour
 void launch_raycast(const DV& d, const sgp_ray* rays, uint32_t n, sgp_hit* hits, hipStream_t s);
 void launch_export_boundary(const DV& d, uint32_t nb, float3 lo, float3 hi, float margin, sgp_ghost_record* out, uint32_t cap, uint32_t* count, hipStream_t s);

@@ -13,6 +13,7 @@
 #include "sgp_kernels.h"
 #include <algorithm>
 #include "sgp_device_collide.h"
+#include "sgp_device_vehicle.h"
 
 #define TPB 256
 
@@ -1786,6 +1787,113 @@ __global__ void __launch_bounds__(64) k_raycast(DV d, const sgp_ray* rays, uint3
 	hits[k] = h;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Wheeled vehicles (sgp_device_vehicle.h): one thread per vehicle.  Vehicles never share a chassis and apply no impulse to
+// the body under a wheel, so each phase is race free without colouring; it runs as its own launch before the contact colours
+// of the same pass (PhysicsSystem solves non-contact constraints first).
+
+SGP_DEV void veh_cast_test(const DV& d, const sgd_vehicle* v, v3 o, v3 dir, float rs, uint32_t j, float& best, uint32_t& bid, v3& bn, v3& bp)
+{
+	if (j == v->body) return;
+	const uint32_t f = d.flags[j];
+	if (!(f & BF_ALIVE) || (f & BF_SENSOR)) return;
+	const uint32_t layer = f_layer(f);
+	if (!(layer == SGP_LAYER_NON_MOVING || layer == SGP_LAYER_MOVING)) return;            // tester object layer MOVING, CarPhysics.cpp:62
+	const float4 mn = d.aabb_min[j], mx = d.aabb_max[j];
+	const float e = rs + 1.0e-3f;
+	if (!ray_aabb(o, dir, make_float4(mn.x - e, mn.y - e, mn.z - e, 0.0f), make_float4(mx.x + e, mx.y + e, mx.z + e, 0.0f), best)) return;
+	const float4 sh = d.shape[j];
+	const float prm[3] = { sh.x, sh.y, sh.z };
+	v3 n, p;
+	const float t = sgd_cast_sphere_body((int)f_shape(f), prm, V3(d.pos_im[j]), quat_to_m33(Q4(d.rot[j])), o, dir, best, rs, &n, &p);
+	if (t < 0.0f || n.z < v->cos_max_slope) return;
+	// closest accepted hit; on equal distance the lower body id wins (the oracle visits ids in ascending order)
+	if (t < best || bid == SGP_INVALID_ID || (t == best && j < bid)) { best = t; bid = j; bn = n; bp = p; }
+}
+
+SGP_DEV sgd_chassis veh_chassis_pose_vel(const DV& d, uint32_t b)
+{
+	sgd_chassis c;
+	const float4 p = d.pos_im[b];
+	c.pos = V3(p); c.rot = Q4(d.rot[b]); c.v = V3(d.linv[b]); c.w = V3(d.angv[b]);
+	c.im = p.w; c.inv_inertia_local = V3(d.inv_inertia[b]);
+	c.I = world_inv_inertia(quat_to_m33(c.rot), c.inv_inertia_local);
+	return c;
+}
+
+// VehicleConstraint::OnStep for every vehicle whose chassis is awake: runs after this step's broad-phase grid is built (the
+// wheel casts walk it) and before the forces are applied.
+__global__ void __launch_bounds__(64) k_vehicle_pre(DV d)
+{
+	const uint32_t k = blockIdx.x * 64 + threadIdx.x;
+	if (k >= d.n_vehicles) return;
+	sgd_vehicle* v = &d.vehicles[k];
+	if (!v->alive) return;
+	const sgp_vehicle_input in = d.vehicle_inputs[k];
+	v->in_forward = in.forward; v->in_right = in.right; v->in_brake = in.brake; v->in_handbrake = in.hand_brake;
+	const uint32_t b = v->body;
+	const int active = (b < d.sp->n_slots && f_movable(d.flags[b])) ? 1 : 0;
+	v->active = active;
+	if (!active) return;
+	sgd_chassis c = veh_chassis_pose_vel(d, b);
+	sgd_vehicle_pre_a(v, &c);
+	const BpGrid g = *d.grid;
+	const float rs = v->cast_radius;
+	for (int i = 0; i < v->num_wheels; ++i) {
+		sgd_wheel* wh = &v->wheels[i];
+		const v3 o = wh->cast_origin, dir = wh->cast_dir;
+		float best = wh->cast_len; uint32_t bid = SGP_INVALID_ID; v3 bn = V3(0.0f, 0.0f, 0.0f), bp = bn;
+		for (uint32_t l = 0; l < d.sp->n_large; ++l) veh_cast_test(d, v, o, dir, rs, d.large_ids[l], best, bid, bn, bp);
+		if (g.n_cells > 0 && g.min_x <= g.max_x) {
+			// cells overlapped by the swept sphere's box, one more cell each side (bodies are binned by centre and reach at most one cell beyond it)
+			const v3 e = v3_add(o, v3_scale(dir, wh->cast_len));
+			const float m = rs + 1.0e-3f;
+			const int x0 = max((int)floorf((fminf(o.x, e.x) - m - g.ox) * g.inv_cell) - 1, 0), x1 = min((int)floorf((fmaxf(o.x, e.x) + m - g.ox) * g.inv_cell) + 1, g.nx - 1);
+			const int y0 = max((int)floorf((fminf(o.y, e.y) - m - g.oy) * g.inv_cell) - 1, 0), y1 = min((int)floorf((fmaxf(o.y, e.y) + m - g.oy) * g.inv_cell) + 1, g.ny - 1);
+			const int z0 = max((int)floorf((fminf(o.z, e.z) - m - g.oz) * g.inv_cell) - 1, 0), z1 = min((int)floorf((fmaxf(o.z, e.z) + m - g.oz) * g.inv_cell) + 1, g.nz - 1);
+			if (x0 <= x1) for (int z = z0; z <= z1; ++z) for (int y = y0; y <= y1; ++y) {
+				const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
+				const uint32_t q0 = d.cell_start[row + (uint32_t)x0], q1 = d.cell_start[row + (uint32_t)x1 + 1];
+				for (uint32_t q = q0; q < q1; ++q) veh_cast_test(d, v, o, dir, rs, __float_as_uint(d.sorted_max[q].w), best, bid, bn, bp);
+			}
+		}
+		if (bid != SGP_INVALID_ID) {
+			const uint32_t fo = d.flags[bid];
+			v3 gv = V3(0.0f, 0.0f, 0.0f);
+			if (f_motion(fo) != SGP_MOTION_STATIC) gv = v3_add(V3(d.linv[bid]), v3_cross(V3(d.angv[bid]), v3_sub(bp, V3(d.pos_im[bid]))));
+			sgd_vehicle_set_hit(v, i, bid, best, bn, bp, gv, d.shape[bid].w);
+		}
+	}
+	if (sgd_vehicle_pre_b(v, &c, d.sp->dt)) d.sleep_timer[b] = 0.0f;
+	const float4 lv = d.linv[b], av = d.angv[b];
+	d.linv[b] = F4(c.v, lv.w); d.angv[b] = F4(c.w, av.w);
+}
+
+// MODE 0 warm start, 1 velocity iteration (velocities live in the per-step solver records), 2 position iteration (poses)
+template <int MODE> __global__ void __launch_bounds__(64) k_vehicle_solve(DV d)
+{
+	const uint32_t k = blockIdx.x * 64 + threadIdx.x;
+	if (k >= d.n_vehicles) return;
+	sgd_vehicle* v = &d.vehicles[k];
+	if (!v->alive || !v->active) return;
+	const uint32_t b = v->body;
+	sgd_chassis c;
+	const float4 p = d.pos_im[b];
+	c.pos = V3(p); c.rot = Q4(d.rot[b]); c.inv_inertia_local = V3(d.inv_inertia[b]);
+	if (MODE == 2) {
+		c.im = p.w; c.v = V3(0.0f, 0.0f, 0.0f); c.w = c.v; c.I = sym33_zero();
+		sgd_vehicle_solve_position(v, &c, d.st.baumgarte);
+		d.pos_im[b] = F4(c.pos, p.w);
+		d.rot[b] = make_float4(c.rot.x, c.rot.y, c.rot.z, c.rot.w);
+	} else {
+		const float4 s0 = d.sbody[4 * b + 0], s1 = d.sbody[4 * b + 1], s2 = d.sbody[4 * b + 2], s3 = d.sbody[4 * b + 3];
+		c.v = V3(s0); c.im = s0.w; c.w = V3(s1);
+		c.I.xx = s2.x; c.I.xy = s2.y; c.I.xz = s2.z; c.I.yy = s3.x; c.I.yz = s3.y; c.I.zz = s3.z;
+		if (MODE == 0) sgd_vehicle_warm_start(v, &c); else sgd_vehicle_solve_velocity(v, &c);
+		d.sbody[4 * b + 0] = F4(c.v, s0.w); d.sbody[4 * b + 1] = F4(c.w, s1.w);
+	}
+}
+
 // multi-GPU tiles: bodies owned by this tile whose inflated AABB pokes outside [lo,hi)
 __global__ void __launch_bounds__(TPB) k_export_boundary(DV d, float3 lo, float3 hi, float margin, sgp_ghost_record* out, uint32_t cap, uint32_t* count)
 {
@@ -1889,5 +1997,14 @@ void launch_apply_cmds(const DV& d, const BodyCmd* cmds, const uint32_t* run_sta
 void launch_gather_states(const DV& d, const uint32_t* ids, uint32_t first, uint32_t n, sgp_body_state* out, hipStream_t s) { if (n) hipLaunchKernelGGL(k_gather_states, dim3(blocks_for(n)), dim3(TPB), 0, s, d, ids, first, n, out); }
 void launch_gather_active(const DV& d, uint32_t nb, sgp_body_state* out, uint32_t cap, hipStream_t s) { hipLaunchKernelGGL(k_gather_active, dim3(blocks_for(nb)), dim3(TPB), 0, s, d, out, cap); }
 void launch_dump_constraints(const DV& d, uint32_t which, uint32_t n_con, void* out, uint32_t cap, hipStream_t s) { if (n_con) hipLaunchKernelGGL(k_dump_constraints, dim3(blocks_for(n_con)), dim3(TPB), 0, s, d, which, n_con, (ConstraintDumpRec*)out, cap); }
+void launch_vehicle_pre(const DV& d, hipStream_t s) { if (d.n_vehicles) hipLaunchKernelGGL(k_vehicle_pre, dim3((d.n_vehicles + 63) / 64), dim3(64), 0, s, d); }
+void launch_vehicle_solve(const DV& d, int mode, hipStream_t s)
+{
+	if (!d.n_vehicles) return;
+	const dim3 g((d.n_vehicles + 63) / 64), b(64);
+	if (mode == 0) hipLaunchKernelGGL(k_vehicle_solve<0>, g, b, 0, s, d);
+	else if (mode == 1) hipLaunchKernelGGL(k_vehicle_solve<1>, g, b, 0, s, d);
+	else hipLaunchKernelGGL(k_vehicle_solve<2>, g, b, 0, s, d);
+}
 void launch_raycast(const DV& d, const sgp_ray* rays, uint32_t n, sgp_hit* hits, hipStream_t s) { if (n) hipLaunchKernelGGL(k_raycast, dim3((n + 63) / 64), dim3(64), 0, s, d, rays, n, hits); }
 void launch_export_boundary(const DV& d, uint32_t nb, float3 lo, float3 hi, float margin, sgp_ghost_record* out, uint32_t cap, uint32_t* count, hipStream_t s) { hipLaunchKernelGGL(k_export_boundary, dim3(blocks_for(nb)), dim3(TPB), 0, s, d, lo, hi, margin, out, cap, count); }

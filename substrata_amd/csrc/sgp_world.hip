@@ -17,6 +17,7 @@
 #include <unordered_map>
 #include <map>
 #include "sgp_kernels.h"
+#include "sgp_device_vehicle.h"
 
 #define SGP_API extern "C" __attribute__((visibility("default")))
 
@@ -37,7 +38,7 @@ static const char* k_class_names[KC_COUNT] = {
 	"apply_forces", "bp_cell", "bp_scan", "bp_scatter", "bp_pairs", "bp_large", "narrowphase", "wake",
 	"colour_claim", "colour_commit", "colour_count", "setup", "warm_start", "solve_velocity",
 	"integrate_pose", "solve_position", "finalize", "island_hook", "island_flag", "sleep_apply", "buoyancy",
-	"cache_build", "misc", "edit", "gather", "prep_bodies" };
+	"cache_build", "misc", "edit", "gather", "prep_bodies", "vehicle" };
 
 // ---------------------------------------------------------------------------------------------------------------
 
@@ -78,6 +79,9 @@ struct sgp_world {
 	std::string last_plan_key; uint32_t plan_repeats = 0; bool use_graphs = true;
 	uint32_t graph_launches = 0, eager_steps = 0, idle_steps = 0;
 	bool grid_valid = false;                                   // the broad-phase grid matches the current poses (ray queries reuse it)
+	// wheeled vehicles: device records (AoS) + host mirror of what the ABI needs without a read-back
+	sgd_vehicle* d_vehicles = nullptr; sgp_vehicle_input* d_veh_inputs = nullptr; uint32_t cap_vehicles = 0, n_vehicles = 0;
+	std::vector<uint8_t> veh_alive; std::vector<uint32_t> veh_body; std::vector<sgp_vehicle_input> veh_inputs; bool veh_inputs_dirty = false;
 	// events collected on the host until drained
 	std::vector<sgp_body_event> ev_act, ev_deact, ev_water;
 	std::vector<sgp_contact_event> ev_added, ev_pers;
@@ -183,6 +187,7 @@ SGP_API int sgp_abi_sizeof(int which)
 	case 3: return (int)sizeof(sgp_body_state); case 4: return (int)sizeof(sgp_body_event); case 5: return (int)sizeof(sgp_contact_event);
 	case 6: return (int)sizeof(sgp_ray); case 7: return (int)sizeof(sgp_hit); case 8: return (int)sizeof(sgp_step_stats);
 	case 9: return (int)sizeof(sgp_step_profile); case 10: return (int)sizeof(sgp_ghost_record);
+	case 11: return (int)sizeof(sgp_vehicle_desc); case 12: return (int)sizeof(sgp_vehicle_input); case 13: return (int)sizeof(sgp_vehicle_state);
 	default: return -1;
 	}
 }
@@ -211,6 +216,7 @@ static int alloc_constraints(sgp_world* w, ConstraintArrays& c, uint32_t cap)
 }
 
 SGP_API int sgp_world_destroy(sgp_world* w);
+SGP_API int sgp_vehicle_destroy(sgp_world* w, uint32_t id);
 
 SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 {
@@ -283,6 +289,8 @@ SGP_API int sgp_world_destroy(sgp_world* w)
 	if (w->stream) hipStreamSynchronize(w->stream);
 	for (void* p : w->allocs) hipFree(p);
 	if (w->stage_dev) hipFree(w->stage_dev);
+	if (w->d_vehicles) hipFree(w->d_vehicles);
+	if (w->d_veh_inputs) hipFree(w->d_veh_inputs);
 	if (w->stage_host) hipHostFree(w->stage_host);
 	if (w->h_ctr) hipHostFree(w->h_ctr);
 	if (w->h_evc) hipHostFree(w->h_evc);
@@ -410,6 +418,7 @@ static BodyCmd blank_cmd(uint32_t id, uint32_t ops) { BodyCmd c; memset(&c, 0, s
 SGP_API int sgp_body_remove(sgp_world* w, uint32_t id)
 {
 	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_remove: id not live");
+	for (uint32_t v = 0; v < w->n_vehicles; ++v) if (w->veh_alive[v] && w->veh_body[v] == id) sgp_vehicle_destroy(w, v);   // a vehicle does not outlive its chassis
 	if (w->hb[id].flags & BF_LARGE) { w->large_ids.erase(std::remove(w->large_ids.begin(), w->large_ids.end(), id), w->large_ids.end()); w->large_dirty = true; }
 	w->hb[id].flags = 0;
 	w->cmds.push_back(blank_cmd(id, CMD_REMOVE));
@@ -666,6 +675,7 @@ struct StepPlan {
 	int      tail_first;         // colours [0, tail_first) get their own launch per pass
 	uint32_t colour_est[SGP_MAX_COLOURS];
 	int      water, contact_events, warm_start, vel_iters, pos_iters;
+	uint32_t n_vehicles;
 	StepParams sp;               // by-value kernel argument of the first launch: part of the key of a captured graph
 };
 
@@ -681,6 +691,7 @@ static void make_plan(const sgp_world* w, StepPlan& p)
 	p.tail_first = tf;
 	p.water = w->h_sp->water_enabled; p.contact_events = w->h_sp->contact_events;
 	p.warm_start = w->dv.st.warm_start; p.vel_iters = w->dv.st.num_velocity_steps; p.pos_iters = w->dv.st.num_position_steps;
+	p.n_vehicles = w->n_vehicles;
 	p.sp = *w->h_sp;
 }
 
@@ -691,13 +702,14 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 	const uint32_t nb = p.nb;
 	STAGE_MARK(0);
 	{ KScope k(w, KC_MISC); launch_step_begin(d, *w->h_sp, nb, true, s); }
-	// -- 1. forces
-	{ KScope k(w, KC_APPLY_FORCES); launch_apply_forces(d, nb, s); }
 	STAGE_MARK(1);
-	// -- 2. broad phase
+	// -- 1/2. broad-phase grid of the current poses (forces do not move bodies), then the step listeners that query it
+	//         (VehicleConstraint::OnStep: wheel casts), then forces, then the pair search
 	{ KScope k(w, KC_BP_CELL); launch_bp_bounds(d, nb, s); launch_bp_cell(d, nb, s); }
 	{ KScope k(w, KC_BP_SCAN); launch_bp_scan(d, s); }
 	{ KScope k(w, KC_BP_SCATTER); launch_bp_scatter(d, nb, s); }
+	if (p.n_vehicles) { KScope k(w, KC_VEHICLE); launch_vehicle_pre(d, s); }
+	{ KScope k(w, KC_APPLY_FORCES); launch_apply_forces(d, nb, s); }
 	{ KScope k(w, KC_BP_PAIRS); launch_bp_pairs(d, s); }
 	{ KScope k(w, KC_BP_LARGE); launch_bp_large(d, nb, s); }
 	STAGE_MARK(2);
@@ -721,6 +733,7 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 	STAGE_MARK(4);
 	// -- 5. warm start + velocity iterations: one launch per planned colour, everything else in the single-workgroup tail
 	auto solve_pass = [&](int mode, int kc) {
+		if (p.n_vehicles) { KScope k(w, KC_VEHICLE); launch_vehicle_solve(d, mode, s); }      // non-contact constraints first
 		for (int c = 0; c < p.tail_first; ++c) { KScope k(w, kc); launch_solve_colour(d, c, p.colour_est[c], mode, s); }
 		{ KScope k(w, kc); launch_solve_tail(d, p.tail_first, mode, s); }
 	};
@@ -765,6 +778,10 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 		st.num_bodies = nb_; memcpy(st.layer_counts, lc, sizeof(lc)); st.device_bytes = w->device_bytes;
 		w->idle_steps++;
 		return SGP_OK;
+	}
+	if (w->veh_inputs_dirty && w->n_vehicles) {
+		HIP_TRY(hipMemcpyAsync(w->d_veh_inputs, w->veh_inputs.data(), sizeof(sgp_vehicle_input) * w->n_vehicles, hipMemcpyHostToDevice, w->stream));
+		w->veh_inputs_dirty = false;
 	}
 	w->h_sp->dt = dt;
 	StepPlan plan;
@@ -903,6 +920,250 @@ SGP_API int sgp_world_set_contact_events(sgp_world* w, int enabled)
 		w->graphs.clear();
 	}
 	w->h_sp->contact_events = enabled;
+	return SGP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// wheeled vehicles (VehicleConstraint + WheeledVehicleController, CarPhysics.cpp:94-231)
+
+static void invalidate_graphs(sgp_world* w)
+{
+	for (auto& kv : w->graphs) hipGraphExecDestroy(kv.second);
+	w->graphs.clear();
+	w->last_plan_key.clear(); w->plan_repeats = 0;
+}
+
+SGP_API void sgp_default_vehicle_desc(sgp_vehicle_desc* d)
+{
+	memset(d, 0, sizeof(*d));
+	d->body = SGP_INVALID_ID;
+	d->num_wheels = 4;
+	for (int i = 0; i < 4; ++i) {
+		sgp_wheel_desc* w = &d->wheels[i];
+		const bool front = i < 2, left = (i % 2) == 0;
+		w->position[0] = left ? -0.8f : 0.8f; w->position[1] = front ? 1.3f : -1.3f; w->position[2] = 0.15f;
+		w->suspension_dir[2] = -1.0f; w->steering_axis[2] = 1.0f; w->wheel_up[2] = 1.0f; w->wheel_forward[1] = 1.0f;
+		w->suspension_min_length = 0.2f; w->suspension_max_length = 0.5f; w->suspension_preload = 0.0f;     // Scripting.cpp:326-330
+		w->spring_frequency = 2.0f; w->spring_damping = 0.5f;                                              // :335-339
+		w->radius = 0.42f; w->width = 0.16f;                                                               // :320-324
+		w->inertia = 0.9f; w->angular_damping = 0.2f;                                                      // JPH::WheelSettingsWV defaults
+		w->max_steer_angle = front ? 0.78525f : 0.0f;                                                      // :342, CarPhysics.cpp:127,153
+		w->max_brake_torque = 1500.0f; w->max_handbrake_torque = front ? 0.0f : 4000.0f;                   // :347-348, CarPhysics.cpp:129,155
+		const float lf[3][2] = { { 0.0f, 0.0f }, { 0.06f, 1.2f }, { 0.2f, 1.0f } };
+		const float tf[3][2] = { { 0.0f, 0.0f }, { 3.0f, 1.2f }, { 20.0f, 1.0f } };
+		memcpy(w->longitudinal_friction, lf, sizeof(lf)); memcpy(w->lateral_friction, tf, sizeof(tf));
+	}
+	d->up[2] = 1.0f; d->forward[1] = 1.0f;
+	d->cast_radius = 0.08f;                                                                              // 0.5 * front_wheel_width, CarPhysics.cpp:62
+	d->max_slope_angle = 80.0f * 3.14159265358979323846f / 180.0f;
+	d->engine_max_torque = 500.0f; d->engine_min_rpm = 1000.0f; d->engine_max_rpm = 6000.0f; d->engine_inertia = 0.5f; d->engine_angular_damping = 0.2f;
+	const float ec[3][2] = { { 0.0f, 0.8f }, { 0.66f, 1.0f }, { 1.0f, 0.8f } };
+	memcpy(d->engine_torque_curve, ec, sizeof(ec));
+	d->num_gears = 5; d->num_reverse_gears = 1;
+	const float gr[5] = { 2.66f, 1.78f, 1.3f, 1.0f, 0.74f };
+	memcpy(d->gear_ratios, gr, sizeof(gr)); d->reverse_gear_ratios[0] = -2.9f;
+	d->switch_time = 0.5f; d->clutch_release_time = 0.3f; d->switch_latency = 0.5f; d->shift_up_rpm = 4000.0f; d->shift_down_rpm = 2000.0f; d->clutch_strength = 10.0f;
+	d->num_differentials = 1;                                                                            // front wheel drive, CarPhysics.cpp:191-194
+	d->differentials[0].left_wheel = 0; d->differentials[0].right_wheel = 1;
+	d->differentials[0].differential_ratio = 3.42f; d->differentials[0].left_right_split = 0.5f; d->differentials[0].limited_slip_ratio = 1.4f; d->differentials[0].engine_torque_ratio = 1.0f;
+	d->differentials[1] = d->differentials[0]; d->differentials[1].left_wheel = 2; d->differentials[1].right_wheel = 3;
+	d->differential_limited_slip_ratio = 1.4f;
+	d->num_anti_roll_bars = 2;                                                                           // CarPhysics.cpp:217-221
+	d->anti_roll_bars[0].left_wheel = 0; d->anti_roll_bars[0].right_wheel = 1; d->anti_roll_bars[0].stiffness = 1000.0f;
+	d->anti_roll_bars[1].left_wheel = 2; d->anti_roll_bars[1].right_wheel = 3; d->anti_roll_bars[1].stiffness = 1000.0f;
+}
+
+static bool vehicle_desc_valid(const sgp_vehicle_desc* d)
+{
+	if (d->num_wheels < 1 || d->num_wheels > SGP_MAX_WHEELS) return false;
+	if (d->num_gears < 1 || d->num_gears > SGP_MAX_GEARS || d->num_reverse_gears < 1 || d->num_reverse_gears > SGP_MAX_GEARS) return false;
+	if (d->num_differentials > 2 || d->num_anti_roll_bars > 2) return false;
+	for (uint32_t k = 0; k < d->num_differentials; ++k) {
+		if (d->differentials[k].left_wheel >= (int)d->num_wheels || d->differentials[k].right_wheel >= (int)d->num_wheels) return false;
+		if (!(d->differentials[k].limited_slip_ratio > 1.0f)) return false;
+	}
+	for (uint32_t k = 0; k < d->num_anti_roll_bars; ++k) {
+		const sgp_anti_roll_bar_desc* r = &d->anti_roll_bars[k];
+		if (r->left_wheel < 0 || r->right_wheel < 0 || r->left_wheel >= (int)d->num_wheels || r->right_wheel >= (int)d->num_wheels) return false;
+	}
+	for (uint32_t i = 0; i < d->num_wheels; ++i) {
+		const sgp_wheel_desc* w = &d->wheels[i];
+		if (!(w->radius > 0.0f) || !(w->inertia > 0.0f) || !(w->suspension_max_length >= w->suspension_min_length) || !(w->suspension_min_length >= 0.0f)) return false;
+	}
+	if (!(d->engine_inertia > 0.0f) || !(d->engine_max_rpm > 0.0f) || !(d->clutch_release_time > 0.0f) || !(d->differential_limited_slip_ratio > 1.0f)) return false;
+	return true;
+}
+
+// cos(max slope) by the same fixed polynomial the kernels use for their trigonometry (|x| <= 1.5)
+static float host_cos_poly(float x)
+{
+	if (fabsf(x) > 1.5f) return cosf(x);
+	const float x2 = x * x;
+	float pc = 2.08767569878681e-9f;
+	pc = pc * x2 - 2.75573192239859e-7f;
+	pc = pc * x2 + 2.48015873015873e-5f;
+	pc = pc * x2 - 1.38888888888889e-3f;
+	pc = pc * x2 + 4.16666666666667e-2f;
+	pc = pc * x2 - 0.5f;
+	pc = pc * x2 + 1.0f;
+	return pc;
+}
+
+static v3 hv3(const float* p) { v3 r; r.x = p[0]; r.y = p[1]; r.z = p[2]; return r; }
+
+static void vehicle_record_from_desc(sgd_vehicle* v, const sgp_vehicle_desc* d)
+{
+	memset(v, 0, sizeof(*v));
+	v->body = d->body; v->alive = 1; v->num_wheels = (int)d->num_wheels;
+	for (int i = 0; i < v->num_wheels; ++i) {
+		sgd_wheel* w = &v->wheels[i]; const sgp_wheel_desc* s = &d->wheels[i];
+		w->position = hv3(s->position); w->suspension_dir = hv3(s->suspension_dir); w->steering_axis = hv3(s->steering_axis);
+		w->wheel_up = hv3(s->wheel_up); w->wheel_forward = hv3(s->wheel_forward);
+		w->sus_min = s->suspension_min_length; w->sus_max = s->suspension_max_length; w->sus_preload = s->suspension_preload;
+		w->spring_freq = s->spring_frequency; w->spring_damp = s->spring_damping;
+		w->radius = s->radius; w->width = s->width; w->inertia = s->inertia; w->ang_damping = s->angular_damping;
+		w->max_steer = s->max_steer_angle; w->max_brake_torque = s->max_brake_torque; w->max_handbrake_torque = s->max_handbrake_torque;
+		memcpy(w->long_fric, s->longitudinal_friction, sizeof(w->long_fric)); memcpy(w->lat_fric, s->lateral_friction, sizeof(w->lat_fric));
+		w->suspension_length = w->sus_max; w->contact_body = SGP_INVALID_ID;
+	}
+	v->up = hv3(d->up); v->forward = hv3(d->forward);
+	v->cast_radius = d->cast_radius;
+	v->cos_max_slope = host_cos_poly(d->max_slope_angle);
+	v->engine_max_torque = d->engine_max_torque; v->engine_min_rpm = d->engine_min_rpm; v->engine_max_rpm = d->engine_max_rpm;
+	v->engine_inertia = d->engine_inertia; v->engine_ang_damping = d->engine_angular_damping;
+	memcpy(v->engine_curve, d->engine_torque_curve, sizeof(v->engine_curve));
+	v->engine_rpm = d->engine_min_rpm;
+	v->num_gears = (int)d->num_gears; v->num_reverse_gears = (int)d->num_reverse_gears;
+	memcpy(v->gear_ratios, d->gear_ratios, sizeof(v->gear_ratios)); memcpy(v->reverse_gear_ratios, d->reverse_gear_ratios, sizeof(v->reverse_gear_ratios));
+	v->switch_time = d->switch_time; v->clutch_release_time = d->clutch_release_time; v->switch_latency = d->switch_latency;
+	v->shift_up_rpm = d->shift_up_rpm; v->shift_down_rpm = d->shift_down_rpm; v->clutch_strength = d->clutch_strength;
+	v->current_gear = 0; v->clutch_friction = 1.0f;
+	v->num_differentials = (int)d->num_differentials;
+	for (int k = 0; k < v->num_differentials; ++k) {
+		const sgp_differential_desc* s = &d->differentials[k];
+		v->differentials[k].left = s->left_wheel; v->differentials[k].right = s->right_wheel; v->differentials[k].ratio = s->differential_ratio;
+		v->differentials[k].left_right_split = s->left_right_split; v->differentials[k].limited_slip_ratio = s->limited_slip_ratio;
+		v->differentials[k].engine_torque_ratio = s->engine_torque_ratio;
+	}
+	v->differential_limited_slip_ratio = d->differential_limited_slip_ratio;
+	v->num_anti_roll_bars = (int)d->num_anti_roll_bars;
+	for (int k = 0; k < v->num_anti_roll_bars; ++k) {
+		v->anti_roll_bars[k].left = d->anti_roll_bars[k].left_wheel; v->anti_roll_bars[k].right = d->anti_roll_bars[k].right_wheel;
+		v->anti_roll_bars[k].stiffness = d->anti_roll_bars[k].stiffness;
+	}
+}
+
+static inline bool vehicle_live(const sgp_world* w, uint32_t id) { return w && id < w->n_vehicles && w->veh_alive[id]; }
+
+SGP_API int sgp_vehicle_create(sgp_world* w, const sgp_vehicle_desc* d, uint32_t* id_out)
+{
+	if (!w || !d || !id_out) return fail(SGP_ERR_INVALID, "sgp_vehicle_create: NULL");
+	if (!live(w, d->body) || (w->hb[d->body].flags & BF_MOTION_MASK) != SGP_MOTION_DYNAMIC) return fail(SGP_ERR_BAD_ID, "sgp_vehicle_create: the chassis must be a live dynamic body");
+	if (!vehicle_desc_valid(d)) return fail(SGP_ERR_INVALID, "sgp_vehicle_create: bad vehicle description");
+	hipSetDevice(w->device);
+	uint32_t id = w->n_vehicles;
+	for (uint32_t k = 0; k < w->n_vehicles; ++k) if (!w->veh_alive[k]) { id = k; break; }     // lowest free slot
+	if (id == w->n_vehicles) {
+		if (w->n_vehicles == w->cap_vehicles) {
+			// grow the device arrays (the step's captured graphs carry the old pointers)
+			const uint32_t nc = w->cap_vehicles ? w->cap_vehicles * 2 : 64;
+			sgd_vehicle* nv = nullptr; sgp_vehicle_input* ni = nullptr;
+			HIP_TRY(hipMalloc((void**)&nv, sizeof(sgd_vehicle) * nc));
+			HIP_TRY(hipMalloc((void**)&ni, sizeof(sgp_vehicle_input) * nc));
+			HIP_TRY(hipMemsetAsync(nv, 0, sizeof(sgd_vehicle) * nc, w->stream));
+			HIP_TRY(hipMemsetAsync(ni, 0, sizeof(sgp_vehicle_input) * nc, w->stream));
+			if (w->n_vehicles) HIP_TRY(hipMemcpyAsync(nv, w->d_vehicles, sizeof(sgd_vehicle) * w->n_vehicles, hipMemcpyDeviceToDevice, w->stream));
+			HIP_TRY(hipStreamSynchronize(w->stream));
+			if (w->d_vehicles) { hipFree(w->d_vehicles); hipFree(w->d_veh_inputs); w->device_bytes -= (sizeof(sgd_vehicle) + sizeof(sgp_vehicle_input)) * w->cap_vehicles; }
+			w->d_vehicles = nv; w->d_veh_inputs = ni; w->cap_vehicles = nc;
+			w->device_bytes += (sizeof(sgd_vehicle) + sizeof(sgp_vehicle_input)) * nc;
+			w->veh_inputs_dirty = true;
+		}
+		w->n_vehicles++;
+		w->veh_alive.push_back(0); w->veh_body.push_back(SGP_INVALID_ID); w->veh_inputs.push_back(sgp_vehicle_input{ 0.0f, 0.0f, 0.0f, 0.0f });
+	}
+	sgd_vehicle rec;
+	vehicle_record_from_desc(&rec, d);
+	HIP_TRY(hipMemcpyAsync(&w->d_vehicles[id], &rec, sizeof(rec), hipMemcpyHostToDevice, w->stream));
+	HIP_TRY(hipStreamSynchronize(w->stream));                  // `rec` lives on this stack frame
+	w->veh_alive[id] = 1; w->veh_body[id] = d->body; w->veh_inputs[id] = sgp_vehicle_input{ 0.0f, 0.0f, 0.0f, 0.0f }; w->veh_inputs_dirty = true;
+	w->dv.vehicles = w->d_vehicles; w->dv.vehicle_inputs = w->d_veh_inputs; w->dv.n_vehicles = w->n_vehicles;
+	invalidate_graphs(w);
+	w->dirty_since_step = true;
+	*id_out = id;
+	return SGP_OK;
+}
+
+SGP_API int sgp_vehicle_destroy(sgp_world* w, uint32_t id)
+{
+	if (!vehicle_live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_vehicle_destroy: id not live");
+	hipSetDevice(w->device);
+	const int zero = 0;
+	HIP_TRY(hipMemcpyAsync((char*)&w->d_vehicles[id] + offsetof(sgd_vehicle, alive), &zero, sizeof(int), hipMemcpyHostToDevice, w->stream));
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	w->veh_alive[id] = 0;
+	return SGP_OK;
+}
+
+SGP_API int sgp_vehicle_set_inputs(sgp_world* w, uint32_t first, uint32_t n, const sgp_vehicle_input* in)
+{
+	if (!w || (!in && n)) return fail(SGP_ERR_INVALID, "sgp_vehicle_set_inputs: NULL");
+	for (uint32_t k = 0; k < n; ++k) if (!vehicle_live(w, first + k)) return fail(SGP_ERR_BAD_ID, "sgp_vehicle_set_inputs: id not live");
+	auto cl = [](float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); };
+	for (uint32_t k = 0; k < n; ++k) {
+		sgp_vehicle_input c = { cl(in[k].forward, -1.0f, 1.0f), cl(in[k].right, -1.0f, 1.0f), cl(in[k].brake, 0.0f, 1.0f), cl(in[k].hand_brake, 0.0f, 1.0f) };
+		w->veh_inputs[first + k] = c;
+		// "On user input, assure that the car is active" (CarPhysics.cpp:362-363)
+		if ((c.forward != 0.0f || c.right != 0.0f || c.brake != 0.0f || c.hand_brake != 0.0f) && live(w, w->veh_body[first + k])) w->cmds.push_back(blank_cmd(w->veh_body[first + k], CMD_ACTIVATE));
+	}
+	w->veh_inputs_dirty = true;
+	return SGP_OK;
+}
+SGP_API int sgp_vehicle_set_input(sgp_world* w, uint32_t id, const sgp_vehicle_input* in) { return sgp_vehicle_set_inputs(w, id, 1, in); }
+
+static void hvec_out(float* o, v3 v) { o[0] = v.x; o[1] = v.y; o[2] = v.z; }
+
+SGP_API int sgp_vehicle_get_states(sgp_world* w, uint32_t first, uint32_t n, sgp_vehicle_state* out)
+{
+	if (!w || (!out && n)) return fail(SGP_ERR_INVALID, "sgp_vehicle_get_states: NULL");
+	for (uint32_t k = 0; k < n; ++k) if (!vehicle_live(w, first + k)) return fail(SGP_ERR_BAD_ID, "sgp_vehicle_get_states: id not live");
+	if (!n) return SGP_OK;
+	hipSetDevice(w->device);
+	std::vector<sgd_vehicle> recs(n);
+	HIP_TRY(hipMemcpyAsync(recs.data(), &w->d_vehicles[first], sizeof(sgd_vehicle) * n, hipMemcpyDeviceToHost, w->stream));
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	for (uint32_t k = 0; k < n; ++k) {
+		const sgd_vehicle* v = &recs[k];
+		sgp_vehicle_state* s = &out[k];
+		memset(s, 0, sizeof(*s));
+		for (int i = 0; i < v->num_wheels; ++i) {
+			const sgd_wheel* wh = &v->wheels[i]; sgp_wheel_state* ws = &s->wheels[i];
+			ws->suspension_length = wh->suspension_length; ws->steer_angle = wh->steer_angle; ws->rotation_angle = wh->angle; ws->angular_velocity = wh->angular_velocity;
+			ws->has_contact = wh->has_contact; ws->contact_body = wh->has_contact ? wh->contact_body : SGP_INVALID_ID;
+			if (wh->has_contact) {
+				hvec_out(ws->contact_position, wh->contact_pos); hvec_out(ws->contact_normal, wh->contact_normal);
+				hvec_out(ws->contact_longitudinal, wh->contact_long); hvec_out(ws->contact_lateral, wh->contact_lat); hvec_out(ws->contact_point_velocity, wh->contact_point_vel);
+			}
+			ws->suspension_lambda = wh->suspension.lambda + wh->max_up.lambda; ws->longitudinal_lambda = wh->longitudinal.lambda; ws->lateral_lambda = wh->lateral.lambda;
+			ws->longitudinal_slip = wh->long_slip; ws->lateral_slip = wh->lat_slip;
+		}
+		s->engine_rpm = v->engine_rpm; s->current_gear = v->current_gear; s->clutch_friction = v->clutch_friction; s->active = v->active;
+	}
+	return SGP_OK;
+}
+SGP_API int sgp_vehicle_get_state(sgp_world* w, uint32_t id, sgp_vehicle_state* out) { return sgp_vehicle_get_states(w, id, 1, out); }
+
+SGP_API int sgp_vehicle_reset_drivetrain(sgp_world* w, uint32_t id, float rpm, float wheel_w)
+{
+	if (!vehicle_live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_vehicle_reset_drivetrain: id not live");
+	hipSetDevice(w->device);
+	sgd_vehicle rec;
+	HIP_TRY(hipMemcpyAsync(&rec, &w->d_vehicles[id], sizeof(rec), hipMemcpyDeviceToHost, w->stream));
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	rec.engine_rpm = rpm;
+	for (int i = 0; i < rec.num_wheels; ++i) rec.wheels[i].angular_velocity = wheel_w;
+	HIP_TRY(hipMemcpyAsync(&w->d_vehicles[id], &rec, sizeof(rec), hipMemcpyHostToDevice, w->stream));
+	HIP_TRY(hipStreamSynchronize(w->stream));
 	return SGP_OK;
 }
 

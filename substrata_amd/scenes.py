@@ -120,3 +120,42 @@ def config4_tile(nx, ny, nz, spacing=1.25, seed=4, offset=(0.0, 0.0, 0.0)):
 def small_mixed(n_side=6, layers=3, seed=7):
     """A small config-3-style scene for parity tests (oracle finishes in seconds)."""
     return config3_100k_mixed(n_side, n_side, layers, seed)
+
+
+CAR_HALF_EXTENTS = (0.9, 2.0, 0.25)      # default car hull of the reference (Scripting.cpp:369-386: x +-0.9, up +-0.25 (roof 0.7), forward +-2) as a box;
+CAR_MASS = 1200.0                        # x right, y forward, z up.  The reference has no default car mass (it uses ob->mass).
+
+
+def config5_cars_debris(cars_side=32, n_debris=50000, spacing=8.0, seed=5):
+    """BASELINE config 5: cars_side^2 cars on a grid (spacing 8 m) + n_debris unit boxes scattered at z in [0.5, 3].
+    Returns (descs, car_body_ids): descs[0] is the ground, descs[1 : 1 + cars] the chassis bodies (box stand-in for the 12-point
+    hull), the rest debris.  Vehicles are created per chassis with World.default_vehicle_desc(body) (CarPhysics' 4-wheel FWD
+    layout with the Scripting.cpp:315-346 defaults); drive them with config5_inputs()."""
+    rng = np.random.default_rng(seed)
+    n_cars = cars_side * cars_side
+    cars = dynamic_bodies(n_cars, mass=CAR_MASS, friction=0.5, restitution=0.0)
+    ix, iy = np.meshgrid(np.arange(cars_side), np.arange(cars_side), indexing="ij")
+    cars["pos"][:, 0] = (ix.ravel() - 0.5 * (cars_side - 1)) * spacing
+    cars["pos"][:, 1] = (iy.ravel() - 0.5 * (cars_side - 1)) * spacing
+    cars["pos"][:, 2] = 0.8
+    cars["shape"][:, :3] = CAR_HALF_EXTENTS
+    half = 0.5 * cars_side * spacing
+    deb = dynamic_bodies(n_debris)
+    pts = np.empty((0, 3), np.float32)
+    while len(pts) < n_debris:                      # scatter, keeping the cars' footprints (+ margin) clear
+        p = rng.uniform([-half, -half, 0.5], [half, half, 3.0], size=(n_debris, 3)).astype(np.float32)
+        fx = np.abs(((p[:, 0] + half) % spacing) - 0.5 * spacing)
+        fy = np.abs(((p[:, 1] + half) % spacing) - 0.5 * spacing)
+        pts = np.concatenate([pts, p[(fx > 1.9) | (fy > 3.0)]])
+    deb["pos"] = pts[:n_debris]
+    deb["rot"] = _random_unit_quats(rng, n_debris)
+    descs = np.concatenate([ground(), cars, deb])
+    return descs, np.arange(1, 1 + n_cars, dtype=np.uint32)
+
+
+def config5_inputs(n_cars, t):
+    """Driver input of config 5 at time t: forward = 1, steer = sin(0.5 t + car id)."""
+    inp = np.zeros(n_cars, dtype=abi.vehicle_input_dtype)
+    inp["forward"] = 1.0
+    inp["right"] = np.sin(0.5 * t + np.arange(n_cars)).astype(np.float32)
+    return inp

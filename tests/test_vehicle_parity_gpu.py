@@ -1,0 +1,104 @@
+"""GPU-vs-oracle parity of the wheeled vehicle path (sgp_vehicle_*, replacing JPH::VehicleConstraint +
+WheeledVehicleController as CarPhysics uses them, /root/reference/gui_client/CarPhysics.cpp:94-231): the same cars, inputs and
+debris on both sides; chassis / debris states and the drivetrain state must agree to fp32 rounding (in practice bit for bit)."""
+import numpy as np
+import pytest
+
+from substrata_amd import abi, scenes
+from helpers import DT, add_car
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+def vehicle_diff(sg, sc):
+    out = {}
+    for f in ("engine_rpm", "clutch_friction"):
+        out[f] = float(np.max(np.abs(sg[f] - sc[f])))
+    assert np.array_equal(sg["current_gear"], sc["current_gear"]) and np.array_equal(sg["active"], sc["active"])
+    wg, wc = sg["wheels"], sc["wheels"]
+    assert np.array_equal(wg["has_contact"], wc["has_contact"]) and np.array_equal(wg["contact_body"], wc["contact_body"])
+    for f in ("suspension_length", "steer_angle", "rotation_angle", "angular_velocity", "contact_position", "contact_normal",
+              "suspension_lambda", "longitudinal_lambda", "lateral_lambda", "longitudinal_slip", "lateral_slip"):
+        out[f] = float(np.max(np.abs(wg[f] - wc[f])))
+    out["inexact_fields"] = [f for f in ("suspension_length", "steer_angle", "rotation_angle", "angular_velocity", "suspension_lambda",
+                                         "longitudinal_lambda", "lateral_lambda", "longitudinal_slip", "lateral_slip", "contact_position", "contact_normal")
+                             if not np.array_equal(wg[f], wc[f])]              # (value equality: -0.0 == +0.0)
+    out["bit_exact"] = not out["inexact_fields"] and out["engine_rpm"] == 0.0
+    return out
+
+
+def drive(tw, ncars, s):
+    t = s * DT
+    inp = np.zeros(ncars, dtype=abi.vehicle_input_dtype)
+    for k in range(ncars):
+        inp[k]["forward"] = 1.0 if (s // 120 + k) % 3 != 2 else -1.0
+        inp[k]["right"] = np.sin(0.5 * t + k)
+        inp[k]["brake"] = 1.0 if (s // 90 + k) % 5 == 4 else 0.0
+        inp[k]["hand_brake"] = 1.0 if (s // 150 + k) % 7 == 6 else 0.0
+    tw.vehicle_set_inputs(0, inp)
+
+
+def test_cars_and_debris_match_oracle(oracle):
+    tw = parity.make_twin(oracle, max_bodies=2048)
+    descs, car_ids = scenes.config5_cars_debris(cars_side=3, n_debris=400, seed=11)
+    ncars = len(car_ids)
+    descs["pos"][1:1 + ncars, 2] += 0.1 * np.arange(ncars)            # staggered drops
+    tw.add_batch(descs)
+    for b in car_ids:
+        vg, vc = tw.vehicle_create(tw.gpu.default_vehicle_desc(int(b)))
+        assert vg == vc
+    debris = descs[1 + ncars:]
+    n = 1 + ncars + len(debris)
+    for s in range(360):
+        if s % 15 == 0:
+            drive(tw, ncars, s)
+        tw.step(DT)
+        if s in (0, 30, 120, 240, 359):
+            d = parity.compare(tw, n)
+            assert d["active_mismatch"] == 0, (s, d)
+            assert d["pos"] <= 2e-4 and d["rot"] <= 2e-4 and d["lin_vel"] <= 2e-3 and d["ang_vel"] <= 2e-3, (s, d)
+            sg, sc = tw.vehicle_get_states(0, ncars)
+            vd = vehicle_diff(sg, sc)
+            assert vd["engine_rpm"] <= 0.5 and vd["angular_velocity"] <= 1e-2 and vd["suspension_length"] <= 1e-4, (s, vd)
+    assert vd["bit_exact"] and d["bit_exact"]
+    print("cars+debris 360 steps: bodies bit exact =", d["bit_exact"], " vehicles bit exact =", vd["bit_exact"], vd["inexact_fields"],
+          {k: v for k, v in vd.items() if isinstance(v, float) and v > 0})
+    sg, _ = tw.vehicle_get_states(0, ncars)
+    assert (np.abs(sg["wheels"]["angular_velocity"]) > 1.0).any() and (sg["current_gear"] != 0).any()
+    # the cars went somewhere
+    st = tw.gpu.read_states(1, ncars)
+    assert np.max(np.abs(st["lin_vel"])) > 1.0
+    tw.close()
+
+
+def test_vehicle_lifecycle_and_errors():
+    from substrata_amd.lib import World
+    from substrata_amd.world import SgpError
+    w = World(max_bodies=64)
+    w.add_batch(scenes.ground())
+    body, vid = add_car(w)
+    assert vid == 0
+    with pytest.raises(SgpError):
+        w.vehicle_create(w.default_vehicle_desc(0))               # the ground is not dynamic
+    bad = w.default_vehicle_desc(body); bad.num_wheels = 9
+    with pytest.raises(SgpError):
+        w.vehicle_create(bad)
+    b2, v2 = add_car(w, pos=(10, 0, 0.8))
+    assert v2 == 1
+    w.step(DT)
+    w.vehicle_destroy(vid)
+    with pytest.raises(SgpError):
+        w.vehicle_get_state(vid)
+    b3, v3 = add_car(w, pos=(20, 0, 0.8))
+    assert v3 == 0                                                # lowest free slot is reused
+    w.remove(b2)                                                  # a vehicle does not outlive its chassis
+    with pytest.raises(SgpError):
+        w.vehicle_set_input(v2, forward=1.0)
+    for _ in range(30):
+        w.step(DT)
+    vs = w.vehicle_get_state(v3)
+    assert vs["active"] == 1 and all(x["has_contact"] == 1 for x in vs["wheels"])
+    w.vehicle_reset_drivetrain(v3, 0.0, 0.0)
+    assert w.vehicle_get_state(v3)["engine_rpm"] == 0.0
+    w.close()
