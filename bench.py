@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=120)
     ap.add_argument("--bodies", type=int, default=100000, help="bodies per tile (BASELINE: 100k)")
+    ap.add_argument("--workload", default="config3", choices=["config3", "config5"],
+                    help="config3 = the bench line (100k mixed bodies); config5 = 1k cars + 50k debris (extra measurement, N=1 only)")
     ap.add_argument("--cpu-steps", type=int, default=16, help="oracle steps timed for cpu_baseline (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the oracle (0 = min(32, host cpus))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -88,15 +90,26 @@ def main():
     # tile-local lattice is centred on the origin: move it to the tile's place
     descs["pos"][1:, 0] += origin[0] + tile_w / 2 - spacing / 2
     descs["pos"][1:, 1] += origin[1] + tile_d / 2 - spacing / 2
+    car_ids = []
+    if args.workload == "config5":
+        if n_gpus != 1:
+            raise SystemExit("--workload config5 is a single-GPU measurement")
+        descs, car_ids = scenes.config5_cars_debris()
     n_bodies = len(descs) - 1
     w = World(max_bodies=len(descs) + 32768, device=local_rank)
     w.add_batch(descs)
+    for b in car_ids:
+        w.vehicle_create(w.default_vehicle_desc(int(b)))
+    sim_step = [0]
     xdev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")
     ex = tiles.GhostExchange(w, rank, n_gpus, lo, hi, margin=2.0, dist=dist, device=xdev) if n_gpus > 1 else None
 
     def one_step():
         if ex is not None:
             ex.exchange()
+        if len(car_ids):                 # driver input arrives every frame (CarPhysics::update -> SetDriverInput)
+            w.vehicle_set_inputs(0, scenes.config5_inputs(len(car_ids), sim_step[0] * DT))
+        sim_step[0] += 1
         w.step(DT)
 
     def barrier():
@@ -145,7 +158,7 @@ def main():
     if rank == 0:
         steps_per_s = args.steps / elapsed
         out = {
-            "metric": "physics steps/sec at fixed dt, 100k bodies",
+            "metric": "physics steps/sec at fixed dt, 100k bodies" if args.workload == "config3" else "physics steps/sec at fixed dt, 1k cars + 50k debris",
             "value": steps_per_s * n_gpus,
             "unit": "steps/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -156,8 +169,11 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE config 3: 100k mixed box/sphere/capsule bodies, 100x100x10 lattice spacing 1.5 m, seed 3, "
-                            "ground quad 2000 m, dt 1/60, Jolt default settings (10 velocity / 2 position iterations), sleeping enabled",
+                "workload": ("BASELINE config 3: 100k mixed box/sphere/capsule bodies, 100x100x10 lattice spacing 1.5 m, seed 3, "
+                             "ground quad 2000 m, dt 1/60, Jolt default settings (10 velocity / 2 position iterations), sleeping enabled")
+                            if args.workload == "config3" else
+                            ("BASELINE config 5: 1024 cars (32x32 grid, spacing 8 m; chassis = box stand-in for the 12-point hull, 1200 kg, 4 wheels, "
+                             "FWD, Scripting.cpp defaults; input forward=1, steer=sin(0.5t+id) refreshed every step) + 50k unit-box debris, seed 5, dt 1/60"),
                 "bodies_per_gpu": n_bodies, "tiles": n_gpus, "value_definition": "n_gpus x world steps/s (one 100k-body tile per GPU)",
                 "active_bodies_end": st.num_active, "contact_constraints_end": st.num_manifolds,
                 "contact_points_end": st.num_contact_points, "colours_end": st.num_colours,
@@ -191,6 +207,10 @@ def main():
         threads = oracle.set_threads(threads)
         cw = oracle.OracleWorld(max_bodies=len(descs) + 8)
         cw.add_batch(d2)
+        for b in car_ids:                # (drivetrain state starts fresh on the CPU side: same cost per step, not the same trajectory)
+            cw.vehicle_create(cw.default_vehicle_desc(int(b)))
+        if len(car_ids):
+            cw.vehicle_set_inputs(0, scenes.config5_inputs(len(car_ids), sim_step[0] * DT))
         cw.step(DT)                      # builds the contact cache so the timed steps are warm-started like the device's
         t1 = time.perf_counter()
         for _ in range(args.cpu_steps):
@@ -204,7 +224,7 @@ def main():
         cpu1 = 2 / (time.perf_counter() - t2)
         out["cpu_baseline"] = {
             "value": args.cpu_steps / cpu_el, "unit": "steps/s", "cores": threads, "kind": "port",
-            "sample": f"{args.cpu_steps} steps of the same 100k-body world, started from the device state after warm-up + timed region "
+            "sample": f"{args.cpu_steps} steps of the same {n_bodies}-body world, started from the device state after warm-up + timed region "
                       f"({cst.num_manifolds} contact constraints, {cst.num_active} active bodies); oracle/sgo_oracle.c with {threads} OpenMP "
                       f"threads (single thread: {cpu1:.2f} steps/s); this is this repo's CPU restatement, not JoltPhysics (absent from the reference tree)",
             "host_cpus": os.cpu_count(),

@@ -1406,25 +1406,41 @@ static sgo_chassis chassis_load(const sgo_body* b)
 	return c;
 }
 
-/* VehicleConstraint::OnStep for every vehicle whose chassis is awake.  The cast visits every body (closest accepted hit; on
-   equal distance the lower body id wins) -- the device walks the broad-phase grid instead and must find the same hit. */
+/* VehicleConstraint::OnStep for every vehicle whose chassis is awake, in two sweeps so that the result does not depend on the
+   order of the vehicles: (A) all wheel casts (read-only on the bodies), (B) controller + row setup (writes the own chassis only).
+   The cast visits every body (closest accepted hit; on equal distance the lower body id wins) -- the device walks the
+   broad-phase grid instead and must find the same hit. */
 static void vehicles_pre_step(sgo_world* w, float dt)
 {
+	if (w->n_vehicles == 0) return;
+	/* dense copy of the candidate bounds for the conservative reject (one cache-friendly stream instead of the body records) */
+	float* bounds = (float*)malloc(sizeof(float) * 6 * (w->high ? w->high : 1));
+	for (uint32_t j = 0; j < w->high; ++j) {
+		const sgo_body* o = &w->bodies[j];
+		const int cand = o->alive && !o->is_sensor && (o->layer == SGP_LAYER_NON_MOVING || o->layer == SGP_LAYER_MOVING);   /* tester object layer MOVING, CarPhysics.cpp:62 */
+		float* bb = &bounds[6 * j];
+		if (cand) { bb[0] = o->aabb_min.x; bb[1] = o->aabb_min.y; bb[2] = o->aabb_min.z; bb[3] = o->aabb_max.x; bb[4] = o->aabb_max.y; bb[5] = o->aabb_max.z; }
+		else { bb[0] = bb[1] = bb[2] = 1.0f; bb[3] = bb[4] = bb[5] = -1.0f; }                          /* empty box: never overlaps */
+	}
+	#pragma omp parallel for schedule(dynamic, 4) if (g_threads > 1)
 	for (uint32_t k = 0; k < w->n_vehicles; ++k) {
 		sgo_vehicle* v = &w->vehicles[k];
 		if (!v->alive) continue;
 		v->active = live(w, v->body) && body_movable(&w->bodies[v->body]);
 		if (!v->active) continue;
-		sgo_body* b = &w->bodies[v->body];
-		sgo_chassis c = chassis_load(b);
+		const sgo_chassis c = chassis_load(&w->bodies[v->body]);
 		sgo_vehicle_pre_a(v, &c);
 		for (int i = 0; i < v->num_wheels; ++i) {
 			sgo_wheel* wh = &v->wheels[i];
 			float best = wh->cast_len; uint32_t bid = SGP_INVALID_ID; v3 bn = V3(0, 0, 0), bp = V3(0, 0, 0);
+			const v3 e = v3_add(wh->cast_origin, v3_scale(wh->cast_dir, wh->cast_len));
+			const float m = v->cast_radius + 1.0e-3f;
+			const v3 lo = v3_sub(v3_min(wh->cast_origin, e), V3(m, m, m)), hi = v3_add(v3_max(wh->cast_origin, e), V3(m, m, m));
 			for (uint32_t j = 0; j < w->high; ++j) {
+				const float* bb = &bounds[6 * j];
+				if (bb[3] < lo.x || bb[0] > hi.x || bb[4] < lo.y || bb[1] > hi.y || bb[5] < lo.z || bb[2] > hi.z) continue;
+				if (j == v->body) continue;
 				const sgo_body* o = &w->bodies[j];
-				if (!o->alive || j == v->body || o->is_sensor) continue;
-				if (!(o->layer == SGP_LAYER_NON_MOVING || o->layer == SGP_LAYER_MOVING)) continue;      /* tester object layer MOVING, CarPhysics.cpp:62 */
 				v3 n, p;
 				const float t = sgo_cast_sphere_body(o->shape_type, o->shape, o->pos, quat_to_m33(o->rot), wh->cast_origin, wh->cast_dir, best, v->cast_radius, &n, &p);
 				if (t < 0.0f || n.z < v->cos_max_slope) continue;
@@ -1436,6 +1452,13 @@ static void vehicles_pre_step(sgo_world* w, float dt)
 				sgo_vehicle_set_hit(v, i, bid, best, bn, bp, gv, o->friction);
 			}
 		}
+	}
+	free(bounds);
+	for (uint32_t k = 0; k < w->n_vehicles; ++k) {
+		sgo_vehicle* v = &w->vehicles[k];
+		if (!v->alive || !v->active) continue;
+		sgo_body* b = &w->bodies[v->body];
+		sgo_chassis c = chassis_load(b);
 		if (sgo_vehicle_pre_b(v, &c, dt)) b->sleep_timer = 0.0f;
 		b->linv = c.v; b->angv = c.w;
 	}

@@ -1206,13 +1206,17 @@ __global__ void __launch_bounds__(TPB) k_finalize(DV d)
 	d.flags[i] = f;
 }
 
+// Union-find over the sleepy bodies, linked by a random priority (a bijective hash of the body id) instead of by id: the
+// body ids of a lattice-like pile are spatially ordered, and "smaller id wins" then builds parent chains as long as a row of
+// the pile; with random priorities the expected depth is logarithmic.  Which member ends up as the root of a component is
+// irrelevant (only the per-component awake flag is read), so this does not change any result.
+SGP_DEV uint32_t uf_prio(uint32_t x) { uint32_t h = x * 0x9E3779B1u; h ^= h >> 15; h *= 0x85EBCA6Bu; h ^= h >> 13; return h; }
 SGP_DEV uint32_t uf_find(const uint32_t* parent, uint32_t x)
 {
 	uint32_t p = parent[x];
 	while (p != x) { x = p; p = parent[x]; }
 	return x;
 }
-
 // Island sleeping without building every island: an island sleeps iff all its members pass the sleep test.  Only
 // bodies that pass it ("sleepy") are united (union by smaller root id, ECL-CC style hooking); a sleepy component is kept
 // awake iff one of its members touches a movable body that failed the test.  Same result as uniting whole islands, but
@@ -1227,7 +1231,8 @@ __global__ void __launch_bounds__(TPB) k_island_hook(DV d)
 	if (!(fa & BF_CAN_SLEEP) || !(fb & BF_CAN_SLEEP)) continue;
 	uint32_t ra = uf_find(d.island, ab.x), rb = uf_find(d.island, ab.y);
 	while (ra != rb) {
-		const uint32_t hi = ra > rb ? ra : rb, lo = ra > rb ? rb : ra;
+		const bool a_hi = uf_prio(ra) > uf_prio(rb);
+		const uint32_t hi = a_hi ? ra : rb, lo = a_hi ? rb : ra;
 		const uint32_t old = atomicCAS(&d.island[hi], hi, lo);
 		if (old == hi) break;
 		ra = uf_find(d.island, old); rb = uf_find(d.island, lo);
@@ -1822,8 +1827,10 @@ SGP_DEV sgd_chassis veh_chassis_pose_vel(const DV& d, uint32_t b)
 }
 
 // VehicleConstraint::OnStep for every vehicle whose chassis is awake: runs after this step's broad-phase grid is built (the
-// wheel casts walk it) and before the forces are applied.
-__global__ void __launch_bounds__(64) k_vehicle_pre(DV d)
+// wheel casts walk it) and before the forces are applied.  Two launches so that no vehicle reads a chassis velocity another
+// vehicle is updating: (A) k_vehicle_cast -- wheel casts, read-only on the bodies; (B) k_vehicle_controller -- tyres,
+// drivetrain, row setup, anti-roll impulses on the own chassis.
+__global__ void __launch_bounds__(64) k_vehicle_cast(DV d)
 {
 	const uint32_t k = blockIdx.x * 64 + threadIdx.x;
 	if (k >= d.n_vehicles) return;
@@ -1864,6 +1871,16 @@ __global__ void __launch_bounds__(64) k_vehicle_pre(DV d)
 			sgd_vehicle_set_hit(v, i, bid, best, bn, bp, gv, d.shape[bid].w);
 		}
 	}
+}
+
+__global__ void __launch_bounds__(64) k_vehicle_controller(DV d)
+{
+	const uint32_t k = blockIdx.x * 64 + threadIdx.x;
+	if (k >= d.n_vehicles) return;
+	sgd_vehicle* v = &d.vehicles[k];
+	if (!v->alive || !v->active) return;
+	const uint32_t b = v->body;
+	sgd_chassis c = veh_chassis_pose_vel(d, b);
 	if (sgd_vehicle_pre_b(v, &c, d.sp->dt)) d.sleep_timer[b] = 0.0f;
 	const float4 lv = d.linv[b], av = d.angv[b];
 	d.linv[b] = F4(c.v, lv.w); d.angv[b] = F4(c.w, av.w);
@@ -1997,7 +2014,12 @@ void launch_apply_cmds(const DV& d, const BodyCmd* cmds, const uint32_t* run_sta
 void launch_gather_states(const DV& d, const uint32_t* ids, uint32_t first, uint32_t n, sgp_body_state* out, hipStream_t s) { if (n) hipLaunchKernelGGL(k_gather_states, dim3(blocks_for(n)), dim3(TPB), 0, s, d, ids, first, n, out); }
 void launch_gather_active(const DV& d, uint32_t nb, sgp_body_state* out, uint32_t cap, hipStream_t s) { hipLaunchKernelGGL(k_gather_active, dim3(blocks_for(nb)), dim3(TPB), 0, s, d, out, cap); }
 void launch_dump_constraints(const DV& d, uint32_t which, uint32_t n_con, void* out, uint32_t cap, hipStream_t s) { if (n_con) hipLaunchKernelGGL(k_dump_constraints, dim3(blocks_for(n_con)), dim3(TPB), 0, s, d, which, n_con, (ConstraintDumpRec*)out, cap); }
-void launch_vehicle_pre(const DV& d, hipStream_t s) { if (d.n_vehicles) hipLaunchKernelGGL(k_vehicle_pre, dim3((d.n_vehicles + 63) / 64), dim3(64), 0, s, d); }
+void launch_vehicle_pre(const DV& d, hipStream_t s)
+{
+	if (!d.n_vehicles) return;
+	hipLaunchKernelGGL(k_vehicle_cast, dim3((d.n_vehicles + 63) / 64), dim3(64), 0, s, d);
+	hipLaunchKernelGGL(k_vehicle_controller, dim3((d.n_vehicles + 63) / 64), dim3(64), 0, s, d);
+}
 void launch_vehicle_solve(const DV& d, int mode, hipStream_t s)
 {
 	if (!d.n_vehicles) return;

@@ -74,6 +74,54 @@ def test_graph_replay_and_eager_launch_give_identical_bits():
         assert np.array_equal(outs[0][f], outs[1][f]), f
 
 
+def test_config5_1k_cars_50k_debris(oracle):
+    """BASELINE config 5 at full size: parity with the oracle over the first steps (every wheel cast, the drivetrains and the
+    debris contacts), then a longer GPU-only run with physical invariants."""
+    import os
+    from substrata_amd import abi
+    descs, car_ids = scenes.config5_cars_debris()
+    nc = len(car_ids)
+    oracle.set_threads(min(16, os.cpu_count() or 1))
+    try:
+        tw = parity.make_twin(oracle, max_bodies=len(descs) + 64)
+        tw.add_batch(descs)
+        for b in car_ids:
+            tw.vehicle_create(tw.gpu.default_vehicle_desc(int(b)))
+        for s in range(1, 25):
+            tw.vehicle_set_inputs(0, scenes.config5_inputs(nc, s * DT))
+            tw.step(DT)
+            if s in (1, 8, 24):
+                d = parity.compare(tw, len(descs))
+                assert d["active_mismatch"] == 0
+                assert d["pos"] <= 1e-4 and d["rot"] <= 1e-4 and d["lin_vel"] <= 1e-3 and d["ang_vel"] <= 1e-3, (s, d)
+                vg, vc = tw.vehicle_get_states(0, nc)
+                assert np.array_equal(vg["wheels"]["contact_body"], vc["wheels"]["contact_body"])
+                assert np.array_equal(vg["wheels"]["angular_velocity"], vc["wheels"]["angular_velocity"])
+                assert np.array_equal(vg["engine_rpm"], vc["engine_rpm"]) and np.array_equal(vg["current_gear"], vc["current_gear"])
+        print("config5, 24 steps: bit exact =", d["bit_exact"])
+        assert (vg["wheels"]["has_contact"] == 1).mean() > 0.9
+    finally:
+        oracle.set_threads(1)
+    w = tw.gpu
+    for s in range(25, 300):
+        w.vehicle_set_inputs(0, scenes.config5_inputs(nc, s * DT))
+        w.step(DT)
+    st = w.read_states(0, len(descs))
+    cars = st[1:1 + nc]
+    assert np.isfinite(st["pos"]).all() and np.isfinite(st["lin_vel"]).all()
+    assert (cars["pos"][:, 2] > 0.3).all() and (cars["pos"][:, 2] < 3.0).all()          # on their wheels / on debris, not through the ground
+    # (the debris field is dense -- 0.76 one-metre boxes per m^2 -- so the cars mostly shove boxes around rather than travel)
+    moved = np.linalg.norm(cars["pos"][:, :2] - descs["pos"][1:1 + nc, :2], axis=1)
+    assert np.median(moved) > 0.5 and moved.max() < 100.0
+    assert (st["pos"][1 + nc:, 2] > 0.2).all()                                            # debris rests on the ground
+    vs = w.vehicle_get_states(0, nc)
+    assert (vs["current_gear"] >= 1).all() and (vs["engine_rpm"] >= 1000).all() and (vs["engine_rpm"] <= 6000).all()
+    assert np.median(np.abs(vs["wheels"]["angular_velocity"][:, :2])) > 5.0               # driven wheels turn
+    sg = w.stats()
+    assert sg.pairs_dropped == 0 and sg.manifolds_dropped == 0
+    tw.close()
+
+
 def mechanical_energy(descs, st):
     m = descs["mass"][1:].astype(np.float64)
     z = st["pos"][1:, 2].astype(np.float64)
