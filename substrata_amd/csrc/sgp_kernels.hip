@@ -1826,89 +1826,128 @@ SGP_DEV sgd_chassis veh_chassis_pose_vel(const DV& d, uint32_t b)
 	return c;
 }
 
+// One wave owns one vehicle: the 64 lanes stage the vehicle record (~2.3 KB) between HBM/L2 and LDS in a few coalesced
+// bursts, and the sequential per-vehicle arithmetic then runs out of LDS instead of paying a global round trip per field.
+SGP_DEV void veh_stage_in(sgd_vehicle* sv, const sgd_vehicle* gv)
+{
+	const uint32_t* src = (const uint32_t*)gv; uint32_t* dst = (uint32_t*)sv;
+	for (uint32_t i = threadIdx.x; i < sizeof(sgd_vehicle) / 4; i += 64) dst[i] = src[i];
+	__syncthreads();
+}
+SGP_DEV void veh_stage_out(sgd_vehicle* gv, const sgd_vehicle* sv)
+{
+	__syncthreads();
+	const uint32_t* src = (const uint32_t*)sv; uint32_t* dst = (uint32_t*)gv;
+	for (uint32_t i = threadIdx.x; i < sizeof(sgd_vehicle) / 4; i += 64) dst[i] = src[i];
+}
+
 // VehicleConstraint::OnStep for every vehicle whose chassis is awake: runs after this step's broad-phase grid is built (the
 // wheel casts walk it) and before the forces are applied.  Two launches so that no vehicle reads a chassis velocity another
 // vehicle is updating: (A) k_vehicle_cast -- wheel casts, read-only on the bodies; (B) k_vehicle_controller -- tyres,
 // drivetrain, row setup, anti-roll impulses on the own chassis.
+// Cast: 16 lanes per wheel share the candidate list (large bodies + the grid cells under the swept sphere); each lane keeps its
+// closest accepted hit and a butterfly reduction takes the lexicographic (distance, body id) minimum, which does not depend
+// on how the candidates were dealt to the lanes.
 __global__ void __launch_bounds__(64) k_vehicle_cast(DV d)
 {
-	const uint32_t k = blockIdx.x * 64 + threadIdx.x;
-	if (k >= d.n_vehicles) return;
-	sgd_vehicle* v = &d.vehicles[k];
-	if (!v->alive) return;
-	const sgp_vehicle_input in = d.vehicle_inputs[k];
-	v->in_forward = in.forward; v->in_right = in.right; v->in_brake = in.brake; v->in_handbrake = in.hand_brake;
-	const uint32_t b = v->body;
-	const int active = (b < d.sp->n_slots && f_movable(d.flags[b])) ? 1 : 0;
-	v->active = active;
-	if (!active) return;
-	sgd_chassis c = veh_chassis_pose_vel(d, b);
-	sgd_vehicle_pre_a(v, &c);
-	const BpGrid g = *d.grid;
-	const float rs = v->cast_radius;
-	for (int i = 0; i < v->num_wheels; ++i) {
-		sgd_wheel* wh = &v->wheels[i];
-		const v3 o = wh->cast_origin, dir = wh->cast_dir;
-		float best = wh->cast_len; uint32_t bid = SGP_INVALID_ID; v3 bn = V3(0.0f, 0.0f, 0.0f), bp = bn;
-		for (uint32_t l = 0; l < d.sp->n_large; ++l) veh_cast_test(d, v, o, dir, rs, d.large_ids[l], best, bid, bn, bp);
-		if (g.n_cells > 0 && g.min_x <= g.max_x) {
-			// cells overlapped by the swept sphere's box, one more cell each side (bodies are binned by centre and reach at most one cell beyond it)
-			const v3 e = v3_add(o, v3_scale(dir, wh->cast_len));
-			const float m = rs + 1.0e-3f;
-			const int x0 = max((int)floorf((fminf(o.x, e.x) - m - g.ox) * g.inv_cell) - 1, 0), x1 = min((int)floorf((fmaxf(o.x, e.x) + m - g.ox) * g.inv_cell) + 1, g.nx - 1);
-			const int y0 = max((int)floorf((fminf(o.y, e.y) - m - g.oy) * g.inv_cell) - 1, 0), y1 = min((int)floorf((fmaxf(o.y, e.y) + m - g.oy) * g.inv_cell) + 1, g.ny - 1);
-			const int z0 = max((int)floorf((fminf(o.z, e.z) - m - g.oz) * g.inv_cell) - 1, 0), z1 = min((int)floorf((fmaxf(o.z, e.z) + m - g.oz) * g.inv_cell) + 1, g.nz - 1);
-			if (x0 <= x1) for (int z = z0; z <= z1; ++z) for (int y = y0; y <= y1; ++y) {
-				const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
-				const uint32_t q0 = d.cell_start[row + (uint32_t)x0], q1 = d.cell_start[row + (uint32_t)x1 + 1];
-				for (uint32_t q = q0; q < q1; ++q) veh_cast_test(d, v, o, dir, rs, __float_as_uint(d.sorted_max[q].w), best, bid, bn, bp);
+	__shared__ sgd_vehicle sv;
+	const uint32_t k = blockIdx.x;
+	sgd_vehicle* gv = &d.vehicles[k];
+	if (!gv->alive) return;
+	veh_stage_in(&sv, gv);
+	if (threadIdx.x == 0) {
+		const sgp_vehicle_input in = d.vehicle_inputs[k];
+		sv.in_forward = in.forward; sv.in_right = in.right; sv.in_brake = in.brake; sv.in_handbrake = in.hand_brake;
+		const uint32_t b = sv.body;
+		sv.active = (b < d.sp->n_slots && f_movable(d.flags[b])) ? 1 : 0;
+		if (sv.active) { const sgd_chassis c = veh_chassis_pose_vel(d, b); sgd_vehicle_pre_a(&sv, &c); }
+	}
+	__syncthreads();
+	if (sv.active) {
+		const int wi = (int)(threadIdx.x >> 4); const uint32_t sub = threadIdx.x & 15u;
+		float best = 0.0f; uint32_t bid = SGP_INVALID_ID; v3 bn = V3(0.0f, 0.0f, 0.0f), bp = bn;
+		if (wi < sv.num_wheels) {
+			const sgd_wheel* wh = &sv.wheels[wi];
+			const v3 o = wh->cast_origin, dir = wh->cast_dir;
+			const float rs = sv.cast_radius;
+			best = wh->cast_len;
+			for (uint32_t l = sub; l < d.sp->n_large; l += 16) veh_cast_test(d, &sv, o, dir, rs, d.large_ids[l], best, bid, bn, bp);
+			const BpGrid g = *d.grid;
+			if (g.n_cells > 0 && g.min_x <= g.max_x) {
+				// cells overlapped by the swept sphere's box, one more cell each side (bodies are binned by centre and reach at most one cell beyond it)
+				const v3 e = v3_add(o, v3_scale(dir, wh->cast_len));
+				const float m = rs + 1.0e-3f;
+				const int x0 = max((int)floorf((fminf(o.x, e.x) - m - g.ox) * g.inv_cell) - 1, 0), x1 = min((int)floorf((fmaxf(o.x, e.x) + m - g.ox) * g.inv_cell) + 1, g.nx - 1);
+				const int y0 = max((int)floorf((fminf(o.y, e.y) - m - g.oy) * g.inv_cell) - 1, 0), y1 = min((int)floorf((fmaxf(o.y, e.y) + m - g.oy) * g.inv_cell) + 1, g.ny - 1);
+				const int z0 = max((int)floorf((fminf(o.z, e.z) - m - g.oz) * g.inv_cell) - 1, 0), z1 = min((int)floorf((fmaxf(o.z, e.z) + m - g.oz) * g.inv_cell) + 1, g.nz - 1);
+				if (x0 <= x1) for (int z = z0; z <= z1; ++z) for (int y = y0; y <= y1; ++y) {
+					const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
+					const uint32_t q0 = d.cell_start[row + (uint32_t)x0], q1 = d.cell_start[row + (uint32_t)x1 + 1];
+					for (uint32_t q = q0 + sub; q < q1; q += 16) veh_cast_test(d, &sv, o, dir, rs, __float_as_uint(d.sorted_max[q].w), best, bid, bn, bp);
+				}
 			}
 		}
-		if (bid != SGP_INVALID_ID) {
+		// (distance, id) minimum over the 16 lanes of the wheel; lanes without a hit carry id = invalid
+#pragma unroll
+		for (int off = 8; off >= 1; off >>= 1) {
+			const float ot = __shfl_xor(best, off, 16); const uint32_t oid = __shfl_xor(bid, off, 16);
+			const float onx = __shfl_xor(bn.x, off, 16), ony = __shfl_xor(bn.y, off, 16), onz = __shfl_xor(bn.z, off, 16);
+			const float opx = __shfl_xor(bp.x, off, 16), opy = __shfl_xor(bp.y, off, 16), opz = __shfl_xor(bp.z, off, 16);
+			const bool take = oid != SGP_INVALID_ID && (bid == SGP_INVALID_ID || ot < best || (ot == best && oid < bid));
+			if (take) { best = ot; bid = oid; bn = V3(onx, ony, onz); bp = V3(opx, opy, opz); }
+		}
+		if (wi < sv.num_wheels && sub == 0 && bid != SGP_INVALID_ID) {
 			const uint32_t fo = d.flags[bid];
-			v3 gv = V3(0.0f, 0.0f, 0.0f);
-			if (f_motion(fo) != SGP_MOTION_STATIC) gv = v3_add(V3(d.linv[bid]), v3_cross(V3(d.angv[bid]), v3_sub(bp, V3(d.pos_im[bid]))));
-			sgd_vehicle_set_hit(v, i, bid, best, bn, bp, gv, d.shape[bid].w);
+			v3 gvel = V3(0.0f, 0.0f, 0.0f);
+			if (f_motion(fo) != SGP_MOTION_STATIC) gvel = v3_add(V3(d.linv[bid]), v3_cross(V3(d.angv[bid]), v3_sub(bp, V3(d.pos_im[bid]))));
+			sgd_vehicle_set_hit(&sv, wi, bid, best, bn, bp, gvel, d.shape[bid].w);
 		}
 	}
+	veh_stage_out(gv, &sv);
 }
 
 __global__ void __launch_bounds__(64) k_vehicle_controller(DV d)
 {
-	const uint32_t k = blockIdx.x * 64 + threadIdx.x;
-	if (k >= d.n_vehicles) return;
-	sgd_vehicle* v = &d.vehicles[k];
-	if (!v->alive || !v->active) return;
-	const uint32_t b = v->body;
-	sgd_chassis c = veh_chassis_pose_vel(d, b);
-	if (sgd_vehicle_pre_b(v, &c, d.sp->dt)) d.sleep_timer[b] = 0.0f;
-	const float4 lv = d.linv[b], av = d.angv[b];
-	d.linv[b] = F4(c.v, lv.w); d.angv[b] = F4(c.w, av.w);
+	__shared__ sgd_vehicle sv;
+	sgd_vehicle* gv = &d.vehicles[blockIdx.x];
+	if (!gv->alive || !gv->active) return;
+	veh_stage_in(&sv, gv);
+	if (threadIdx.x == 0) {
+		const uint32_t b = sv.body;
+		sgd_chassis c = veh_chassis_pose_vel(d, b);
+		if (sgd_vehicle_pre_b(&sv, &c, d.sp->dt)) d.sleep_timer[b] = 0.0f;
+		const float4 lv = d.linv[b], av = d.angv[b];
+		d.linv[b] = F4(c.v, lv.w); d.angv[b] = F4(c.w, av.w);
+	}
+	veh_stage_out(gv, &sv);
 }
 
 // MODE 0 warm start, 1 velocity iteration (velocities live in the per-step solver records), 2 position iteration (poses)
 template <int MODE> __global__ void __launch_bounds__(64) k_vehicle_solve(DV d)
 {
-	const uint32_t k = blockIdx.x * 64 + threadIdx.x;
-	if (k >= d.n_vehicles) return;
-	sgd_vehicle* v = &d.vehicles[k];
-	if (!v->alive || !v->active) return;
-	const uint32_t b = v->body;
-	sgd_chassis c;
-	const float4 p = d.pos_im[b];
-	c.pos = V3(p); c.rot = Q4(d.rot[b]); c.inv_inertia_local = V3(d.inv_inertia[b]);
-	if (MODE == 2) {
-		c.im = p.w; c.v = V3(0.0f, 0.0f, 0.0f); c.w = c.v; c.I = sym33_zero();
-		sgd_vehicle_solve_position(v, &c, d.st.baumgarte);
-		d.pos_im[b] = F4(c.pos, p.w);
-		d.rot[b] = make_float4(c.rot.x, c.rot.y, c.rot.z, c.rot.w);
-	} else {
-		const float4 s0 = d.sbody[4 * b + 0], s1 = d.sbody[4 * b + 1], s2 = d.sbody[4 * b + 2], s3 = d.sbody[4 * b + 3];
-		c.v = V3(s0); c.im = s0.w; c.w = V3(s1);
-		c.I.xx = s2.x; c.I.xy = s2.y; c.I.xz = s2.z; c.I.yy = s3.x; c.I.yz = s3.y; c.I.zz = s3.z;
-		if (MODE == 0) sgd_vehicle_warm_start(v, &c); else sgd_vehicle_solve_velocity(v, &c);
-		d.sbody[4 * b + 0] = F4(c.v, s0.w); d.sbody[4 * b + 1] = F4(c.w, s1.w);
+	__shared__ sgd_vehicle sv;
+	sgd_vehicle* gv = &d.vehicles[blockIdx.x];
+	if (!gv->alive || !gv->active) return;
+	veh_stage_in(&sv, gv);
+	if (threadIdx.x == 0) {
+		const uint32_t b = sv.body;
+		sgd_chassis c;
+		const float4 p = d.pos_im[b];
+		c.pos = V3(p); c.rot = Q4(d.rot[b]); c.inv_inertia_local = V3(d.inv_inertia[b]);
+		if (MODE == 2) {
+			c.im = p.w; c.v = V3(0.0f, 0.0f, 0.0f); c.w = c.v; c.I = sym33_zero();
+			sgd_vehicle_solve_position(&sv, &c, d.st.baumgarte);
+			d.pos_im[b] = F4(c.pos, p.w);
+			d.rot[b] = make_float4(c.rot.x, c.rot.y, c.rot.z, c.rot.w);
+		} else {
+			const float4 s0 = d.sbody[4 * b + 0], s1 = d.sbody[4 * b + 1], s2 = d.sbody[4 * b + 2], s3 = d.sbody[4 * b + 3];
+			c.v = V3(s0); c.im = s0.w; c.w = V3(s1);
+			c.I.xx = s2.x; c.I.xy = s2.y; c.I.xz = s2.z; c.I.yy = s3.x; c.I.yz = s3.y; c.I.zz = s3.z;
+			if (MODE == 0) sgd_vehicle_warm_start(&sv, &c); else sgd_vehicle_solve_velocity(&sv, &c);
+			d.sbody[4 * b + 0] = F4(c.v, s0.w); d.sbody[4 * b + 1] = F4(c.w, s1.w);
+		}
 	}
+	if (MODE == 1) veh_stage_out(gv, &sv);        // only the velocity iteration changes the record (row impulses, wheel spin)
 }
 
 // multi-GPU tiles: bodies owned by this tile whose inflated AABB pokes outside [lo,hi)
@@ -2017,13 +2056,13 @@ void launch_dump_constraints(const DV& d, uint32_t which, uint32_t n_con, void* 
 void launch_vehicle_pre(const DV& d, hipStream_t s)
 {
 	if (!d.n_vehicles) return;
-	hipLaunchKernelGGL(k_vehicle_cast, dim3((d.n_vehicles + 63) / 64), dim3(64), 0, s, d);
-	hipLaunchKernelGGL(k_vehicle_controller, dim3((d.n_vehicles + 63) / 64), dim3(64), 0, s, d);
+	hipLaunchKernelGGL(k_vehicle_cast, dim3(d.n_vehicles), dim3(64), 0, s, d);
+	hipLaunchKernelGGL(k_vehicle_controller, dim3(d.n_vehicles), dim3(64), 0, s, d);
 }
 void launch_vehicle_solve(const DV& d, int mode, hipStream_t s)
 {
 	if (!d.n_vehicles) return;
-	const dim3 g((d.n_vehicles + 63) / 64), b(64);
+	const dim3 g(d.n_vehicles), b(64);                     // one wave per vehicle
 	if (mode == 0) hipLaunchKernelGGL(k_vehicle_solve<0>, g, b, 0, s, d);
 	else if (mode == 1) hipLaunchKernelGGL(k_vehicle_solve<1>, g, b, 0, s, d);
 	else hipLaunchKernelGGL(k_vehicle_solve<2>, g, b, 0, s, d);
