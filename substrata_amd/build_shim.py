@@ -16,7 +16,7 @@ def flags():
 
 def build(force=False, verbose=False):
     srcs = [os.path.join(SHIM, s) for s in SOURCES]
-    deps = srcs + [os.path.join(SHIM, h) for h in ("PhysicsWorld.h", "PhysicsObject.h")]
+    deps = srcs + [os.path.join(SHIM, h) for h in ("PhysicsWorld.h", "PhysicsObject.h", "Jolt/JoltLite.h", "Jolt/JoltVehicleLite.h")]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
         return LIB
     cmd = ["g++"] + flags() + ["-shared"] + srcs + ["-o", LIB, "-L", HERE, "-lsgp", "-Wl,-rpath,$ORIGIN"]

@@ -115,14 +115,26 @@ namespace JPH
 		mutable bool st_active;
 	};
 
+	class VehicleConstraint;      // Jolt/JoltVehicleLite.h
+	class PhysicsStepListener;
+
 	class PhysicsSystem
 	{
 	public:
-		explicit PhysicsSystem(sgp_world* w) : body_interface(w) {}
+		explicit PhysicsSystem(sgp_world* w) : world(w), body_interface(w), step_serial(0) {}
 		BodyInterface& GetBodyInterface() { return body_interface; }
 		const BodyInterface& GetBodyInterface() const { return body_interface; }
 		Vec3 GetGravity() const { return Vec3(0, 0, -9.81f); }   // PhysicsWorld.cpp:520
+		// CarPhysics.cpp:224-226,258-262: the vehicle constraint is both a constraint and a step listener in Jolt; here the
+		// constraint registration creates / destroys the device-side vehicle and the listener calls are no-ops.
+		void AddConstraint(VehicleConstraint* c);
+		void RemoveConstraint(VehicleConstraint* c);
+		template <class T> void AddStepListener(T*) {}
+		template <class T> void RemoveStepListener(T*) {}
+		void onStep() { ++step_serial; body_interface.invalidate(); }       // called by PhysicsWorld::think
+		sgp_world* world;
 	private:
 		BodyInterface body_interface;
+		uint64_t step_serial;
 	};
 }

@@ -1,6 +1,7 @@
 // PhysicsWorld over the sgp C ABI.  Each method follows the reference method of the same name
 // (/root/reference/gui_client/PhysicsWorld.cpp, line ranges in the comments) with Jolt calls replaced by ABI calls.
 #include "PhysicsWorld.h"
+#include <Jolt/JoltVehicleLite.h>
 #include <utils/Exception.h>
 #include "../../include/sgp.h"
 #include <algorithm>
@@ -144,8 +145,8 @@ void PhysicsWorld::drainActivationEvents()
 void PhysicsWorld::think(double dt)
 {
 	sgp_world_set_contact_events(world, event_listener ? 1 : 0);
-	physics_system->GetBodyInterface().invalidate();
 	sgp_world_step(world, (float)dt);                            // physics_system->Update((float)dt, 1, ...) (:1363) + buoyancy sweep (:1367-1442)
+	physics_system->onStep();                                   // cached body / vehicle read-backs are stale now
 	drainActivationEvents();
 
 	if (event_listener) {
@@ -397,3 +398,21 @@ JPH::Vec3 JPH::BodyInterface::GetPointVelocity(const BodyID& id, const RVec3& p)
 }
 void JPH::BodyInterface::SetLinearAndAngularVelocity(const BodyID& id, const Vec3& l, const Vec3& a) { if (!id.IsInvalid()) { sgp_body_set_vel(world, id.GetIndex(), &l.x, &a.x); invalidate(); } }
 bool JPH::BodyInterface::IsActive(const BodyID& id) const { fetch(id); return st_active; }
+
+
+// ---- JPH::PhysicsSystem constraint registration (vehicles) -----------------------------------------------------------
+void JPH::PhysicsSystem::AddConstraint(VehicleConstraint* c)
+{
+	if (!c) return;
+	sgp_vehicle_desc d;
+	c->fillDesc(d);
+	uint32_t id = 0xFFFFFFFFu;
+	if (sgp_vehicle_create(world, &d, &id) != SGP_OK) throw glare::Exception(std::string("Error creating vehicle: ") + sgp_last_error());
+	c->bind(world, id, &step_serial);
+}
+void JPH::PhysicsSystem::RemoveConstraint(VehicleConstraint* c)
+{
+	if (!c || !c->world) return;
+	sgp_vehicle_destroy(world, c->GetVehicleID());
+	c->unbind();
+}

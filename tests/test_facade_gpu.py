@@ -27,6 +27,7 @@ def test_facade_compiles_without_gpu(tmp_path):
     """CPU check: the facade and a GUIClient-style caller compile and link against libsgp.so (no run)."""
     assert os.path.exists(build_facade_exe(tmp_path))
     assert os.path.exists(build_facade_exe(tmp_path, "hover_controller.cpp"))
+    assert os.path.exists(build_facade_exe(tmp_path, "car_controller.cpp"))
 
 
 @pytest.mark.gpu
@@ -34,6 +35,16 @@ def test_hover_controller_through_body_interface(tmp_path):
     """A HoverCarPhysics-shaped controller drives a body through physics_system->GetBodyInterface() (AddForce, AddTorque,
     GetWorldTransform, GetLinearVelocity ...): the body settles at the spring's target height and has yawed."""
     exe = build_facade_exe(tmp_path, "hover_controller.cpp")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_car_controller_through_vehicle_constraint(tmp_path):
+    """A CarPhysics-shaped caller builds JPH::VehicleConstraintSettings / WheelSettingsWV / WheeledVehicleControllerSettings as
+    CarPhysics.cpp:94-231 does, registers the constraint, drives (throttle, steer right, brake) and reads the wheels back."""
+    exe = build_facade_exe(tmp_path, "car_controller.cpp")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     print(r.stdout)
     assert r.returncode == 0, r.stdout + r.stderr
