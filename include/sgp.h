@@ -313,6 +313,8 @@ int  sgp_raycast(sgp_world* w, const sgp_ray* rays, uint32_t n, sgp_hit* hits_ou
  * VehicleTransmissionSettings / VehicleDifferentialSettings; sgp_default_vehicle_desc() fills Jolt's defaults. */
 #define SGP_MAX_WHEELS 4
 #define SGP_MAX_GEARS  8
+#define SGP_VEHICLE_CONTROLLER_WHEELED     0   /* JPH::WheeledVehicleController (CarPhysics)                        */
+#define SGP_VEHICLE_CONTROLLER_MOTORCYCLE  1   /* JPH::MotorcycleController (BikePhysics): + lean spring, lean steering limit */
 typedef struct sgp_wheel_desc {
 	float position[3];            /* mPosition: suspension attachment point, chassis frame                       */
 	float suspension_dir[3];      /* mSuspensionDirection (default (0,0,-1))                                      */
@@ -346,6 +348,13 @@ typedef struct sgp_vehicle_desc {
 	float differential_limited_slip_ratio;   /* 1.4 */
 	uint32_t num_anti_roll_bars;
 	sgp_anti_roll_bar_desc anti_roll_bars[2];
+	/* JPH::MotorcycleControllerSettings (BikePhysics.cpp:197-205); ignored for SGP_VEHICLE_CONTROLLER_WHEELED */
+	uint32_t controller_type;                /* SGP_VEHICLE_CONTROLLER_*                                            */
+	float max_lean_angle;                    /* mMaxLeanAngle 45 deg                                               */
+	float lean_spring_constant, lean_spring_damping;                       /* 5000, 1000                            */
+	float lean_spring_integration_coefficient, lean_spring_integration_decay;   /* 0, 4                              */
+	float lean_smoothing_factor;             /* 0.8                                                                */
+	uint32_t lean_steering_limit;            /* mEnableLeanSteeringLimit (1)                                       */
 } sgp_vehicle_desc;
 /* WheeledVehicleController::SetDriverInput(forward, right, brake, hand brake) (CarPhysics.cpp:366-367) */
 typedef struct sgp_vehicle_input { float forward, right, brake, hand_brake; } sgp_vehicle_input;
@@ -368,6 +377,8 @@ int  sgp_vehicle_set_input(sgp_world* w, uint32_t vehicle_id, const sgp_vehicle_
 int  sgp_vehicle_set_inputs(sgp_world* w, uint32_t first_vehicle_id, uint32_t n, const sgp_vehicle_input* in);
 int  sgp_vehicle_get_state(sgp_world* w, uint32_t vehicle_id, sgp_vehicle_state* out);
 int  sgp_vehicle_get_states(sgp_world* w, uint32_t first_vehicle_id, uint32_t n, sgp_vehicle_state* out);
+/* MotorcycleController::EnableLeanController (BikePhysics.cpp:493,617) */
+int  sgp_vehicle_enable_lean_controller(sgp_world* w, uint32_t vehicle_id, int enabled);
 /* vehicleSummoned(): GetEngine().SetCurrentRPM / Wheel::SetAngularVelocity (CarPhysics.cpp:266-272) */
 int  sgp_vehicle_reset_drivetrain(sgp_world* w, uint32_t vehicle_id, float engine_rpm, float wheel_angular_velocity);
 

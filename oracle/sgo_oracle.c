@@ -1262,6 +1262,9 @@ SGO_API void sgo_default_vehicle_desc(sgp_vehicle_desc* d)
 	d->num_anti_roll_bars = 2;                                                                         /* CarPhysics.cpp:217-221 */
 	d->anti_roll_bars[0].left_wheel = 0; d->anti_roll_bars[0].right_wheel = 1; d->anti_roll_bars[0].stiffness = 1000.0f;
 	d->anti_roll_bars[1].left_wheel = 2; d->anti_roll_bars[1].right_wheel = 3; d->anti_roll_bars[1].stiffness = 1000.0f;
+	d->controller_type = SGP_VEHICLE_CONTROLLER_WHEELED;
+	d->max_lean_angle = 45.0f * 3.14159265358979323846f / 180.0f; d->lean_spring_constant = 5000.0f; d->lean_spring_damping = 1000.0f;   /* JPH::MotorcycleControllerSettings defaults */
+	d->lean_spring_integration_coefficient = 0.0f; d->lean_spring_integration_decay = 4.0f; d->lean_smoothing_factor = 0.8f; d->lean_steering_limit = 1;
 }
 
 static v3 v3_from(const float* p) { return V3(p[0], p[1], p[2]); }
@@ -1284,6 +1287,8 @@ static int vehicle_desc_valid(const sgp_vehicle_desc* d)
 		if (!(w->radius > 0.0f) || !(w->inertia > 0.0f) || !(w->suspension_max_length >= w->suspension_min_length) || !(w->suspension_min_length >= 0.0f)) return 0;
 	}
 	if (!(d->engine_inertia > 0.0f) || !(d->engine_max_rpm > 0.0f) || !(d->clutch_release_time > 0.0f) || !(d->differential_limited_slip_ratio > 1.0f)) return 0;
+	if (d->controller_type != SGP_VEHICLE_CONTROLLER_WHEELED && d->controller_type != SGP_VEHICLE_CONTROLLER_MOTORCYCLE) return 0;
+	if (d->controller_type == SGP_VEHICLE_CONTROLLER_MOTORCYCLE && !(d->max_lean_angle > 0.0f && d->max_lean_angle < 1.5f)) return 0;
 	return 1;
 }
 
@@ -1327,6 +1332,14 @@ static void vehicle_from_desc(sgo_vehicle* v, const sgp_vehicle_desc* d)
 		v->anti_roll_bars[k].left = d->anti_roll_bars[k].left_wheel; v->anti_roll_bars[k].right = d->anti_roll_bars[k].right_wheel;
 		v->anti_roll_bars[k].stiffness = d->anti_roll_bars[k].stiffness;
 	}
+	v->is_motorcycle = d->controller_type == SGP_VEHICLE_CONTROLLER_MOTORCYCLE;
+	v->lean_enabled = v->is_motorcycle; v->lean_steering_limit = d->lean_steering_limit != 0;
+	v->max_lean_angle = d->max_lean_angle;
+	{ float sn, cs; sgp_sincos_poly(d->max_lean_angle, &sn, &cs); v->tan_max_lean = sn / cs; }
+	v->lean_spring_constant = d->lean_spring_constant; v->lean_spring_damping = d->lean_spring_damping;
+	v->lean_integration_coefficient = d->lean_spring_integration_coefficient; v->lean_integration_decay = d->lean_spring_integration_decay;
+	v->lean_smoothing = d->lean_smoothing_factor;
+	v->target_lean = V3(0.0f, 0.0f, 1.0f);
 }
 
 SGO_API int sgo_vehicle_create(sgo_world* w, const sgp_vehicle_desc* d, uint32_t* id_out)
@@ -1341,6 +1354,7 @@ SGO_API int sgo_vehicle_create(sgo_world* w, const sgp_vehicle_desc* d, uint32_t
 		w->n_vehicles++;
 	}
 	vehicle_from_desc(&w->vehicles[id], d);
+	w->vehicles[id].gravity_len = v3_len(w->gravity);
 	*id_out = id;
 	return SGP_OK;
 }
@@ -1388,6 +1402,13 @@ SGO_API int sgo_vehicle_get_states(sgo_world* w, uint32_t first, uint32_t n, sgp
 }
 SGO_API int sgo_vehicle_get_state(sgo_world* w, uint32_t id, sgp_vehicle_state* out) { return sgo_vehicle_get_states(w, id, 1, out); }
 
+SGO_API int sgo_vehicle_enable_lean_controller(sgo_world* w, uint32_t id, int enabled)
+{
+	if (!vehicle_live(w, id)) return SGP_ERR_BAD_ID;
+	w->vehicles[id].lean_enabled = w->vehicles[id].is_motorcycle && enabled;
+	return SGP_OK;
+}
+
 SGO_API int sgo_vehicle_reset_drivetrain(sgo_world* w, uint32_t id, float rpm, float wheel_w)
 {
 	if (!vehicle_live(w, id)) return SGP_ERR_BAD_ID;
@@ -1429,7 +1450,7 @@ static void vehicles_pre_step(sgo_world* w, float dt)
 		v->active = live(w, v->body) && body_movable(&w->bodies[v->body]);
 		if (!v->active) continue;
 		const sgo_chassis c = chassis_load(&w->bodies[v->body]);
-		sgo_vehicle_pre_a(v, &c);
+		sgo_vehicle_pre_a(v, &c, dt);
 		for (int i = 0; i < v->num_wheels; ++i) {
 			sgo_wheel* wh = &v->wheels[i];
 			float best = wh->cast_len; uint32_t bid = SGP_INVALID_ID; v3 bn = V3(0, 0, 0), bp = V3(0, 0, 0);
@@ -1465,7 +1486,7 @@ static void vehicles_pre_step(sgo_world* w, float dt)
 }
 
 /* mode 0 warm start, 1 velocity iteration, 2 position iteration */
-static void vehicles_solve(sgo_world* w, int mode)
+static void vehicles_solve(sgo_world* w, int mode, float dt)
 {
 	for (uint32_t k = 0; k < w->n_vehicles; ++k) {
 		sgo_vehicle* v = &w->vehicles[k];
@@ -1473,7 +1494,7 @@ static void vehicles_solve(sgo_world* w, int mode)
 		sgo_body* b = &w->bodies[v->body];
 		sgo_chassis c = chassis_load(b);
 		if (mode == 0) sgo_vehicle_warm_start(v, &c);
-		else if (mode == 1) sgo_vehicle_solve_velocity(v, &c);
+		else if (mode == 1) sgo_vehicle_solve_velocity(v, &c, dt);
 		else sgo_vehicle_solve_position(v, &c, w->st.baumgarte);
 		if (mode == 2) { b->pos = c.pos; b->rot = c.rot; } else { b->linv = c.v; b->angv = c.w; }
 	}
@@ -1542,8 +1563,8 @@ SGO_API int sgo_world_step(sgo_world* w, float dt)
 
 	/* 5. warm start + velocity iterations */
 	/* (non-contact constraints -- here: the vehicles -- go first in every pass, as in PhysicsSystem::JobSolveVelocityConstraints) */
-	if (w->st.warm_start) { vehicles_solve(w, 0); SOLVE_PASS(warm_start_constraint); }
-	for (int it = 0; it < w->st.num_velocity_steps; ++it) { vehicles_solve(w, 1); SOLVE_PASS(solve_velocity_constraint); }
+	if (w->st.warm_start) { vehicles_solve(w, 0, dt); SOLVE_PASS(warm_start_constraint); }
+	for (int it = 0; it < w->st.num_velocity_steps; ++it) { vehicles_solve(w, 1, dt); SOLVE_PASS(solve_velocity_constraint); }
 
 	/* 6. integrate positions (Body::AddPositionStep / AddRotationStep) */
 	#pragma omp parallel for schedule(static, 1024) if (g_threads > 1)
@@ -1561,7 +1582,7 @@ SGO_API int sgo_world_step(sgo_world* w, float dt)
 	}
 
 	/* 7. position iterations */
-	for (int it = 0; it < w->st.num_position_steps; ++it) { vehicles_solve(w, 2); SOLVE_PASS(solve_position_constraint); }
+	for (int it = 0; it < w->st.num_position_steps; ++it) { vehicles_solve(w, 2, dt); SOLVE_PASS(solve_position_constraint); }
 
 	/* 8. bounds, sleeping */
 	#pragma omp parallel for schedule(static, 1024) if (g_threads > 1)

@@ -19,7 +19,9 @@
  *   - anti-roll bar impulses are applied to the chassis in the pre-step;
  *   - the (m+1)x(m+1) implicit clutch system is solved in closed form (same linear system);
  *   - acos of the slip angle uses a fixed polynomial, the wheel angle wraps by subtraction (no libm on the step path);
- *   - no pitch/roll limit (CarPhysics leaves mMaxPitchRollAngle at its default pi = off), no motorcycle lean controller.
+ *   - no pitch/roll limit (CarPhysics / BikePhysics leave mMaxPitchRollAngle at its default pi = off);
+ *   - the motorcycle lean spring is solved implicitly in its damping term (see sgo_vehicle_solve_velocity);
+ *   - VehicleCollisionTesterCastCylinder (BikePhysics.cpp:227) is served by the sphere cast with the half wheel width as radius.
  */
 #ifndef SGO_VEHICLE_H
 #define SGO_VEHICLE_H
@@ -83,6 +85,11 @@ typedef struct {
 	int num_anti_roll_bars; sgo_anti_roll_bar anti_roll_bars[2];
 	/* driver input */
 	float in_forward, in_right, in_brake, in_handbrake;
+	/* JPH::MotorcycleController (BikePhysics.cpp:197-205): lean spring towards the direction of the ground reaction */
+	int is_motorcycle, lean_enabled, lean_steering_limit;
+	float max_lean_angle, tan_max_lean, lean_spring_constant, lean_spring_damping, lean_integration_coefficient, lean_integration_decay, lean_smoothing;
+	float gravity_len;
+	v3 target_lean; float lean_integrated_delta, lean_applied_impulse;
 } sgo_vehicle;
 
 /* chassis state as the vehicle rows see it */
@@ -105,6 +112,17 @@ static inline float sgo_acos01(float x)
 	p = p * xc - 0.2121144f;
 	p = p * xc + 1.5707288f;
 	return p * sqrtf(1.0f - xc);
+}
+
+/* acos on [-1,1] and asin on [0,1] from the same polynomial */
+static inline float sgo_acos11(float x) { return x >= 0.0f ? sgo_acos01(x) : SGO_VEH_PI - sgo_acos01(-x); }
+static inline float sgo_asin01(float x) { return 0.5f * SGO_VEH_PI - sgo_acos01(x); }
+static inline float sgo_signf(float x) { return x < 0.0f ? -1.0f : 1.0f; }
+static inline v3 sgo_normalized_or(v3 v, v3 fallback)
+{
+	const float l2 = v3_len_sq(v);
+	if (l2 <= 1.0e-24f) return fallback;
+	return v3_scale(v, 1.0f / sqrtf(l2));
 }
 
 static inline v3 sgo_rotate_about(v3 axis_unit, float angle, v3 v)
@@ -276,12 +294,59 @@ static inline void sgo_part_solve(sgo_axis_part* p, sgo_chassis* c, v3 ground_ve
 
 /* ---- pre-step, part A: steering angle and the cast request of every wheel (VehicleConstraint::OnStep, first half) ------ */
 
-static inline void sgo_vehicle_pre_a(sgo_vehicle* v, const sgo_chassis* c)
+static inline void sgo_vehicle_pre_a(sgo_vehicle* v, const sgo_chassis* c, float dt)
 {
 	const m33 R = quat_to_m33(c->rot);
+	float lean_max_steer_factor = 0.0f, velocity_sq = 0.0f;
+	if (v->is_motorcycle) {
+		/* MotorcycleController::PreCollide: the wheels still hold the contacts and impulses of the previous step here */
+		const v3 forward = m33_mul(R, v->forward);
+		const v3 world_up = V3(0.0f, 0.0f, 1.0f);
+		if (v->lean_enabled) {
+			v3 tl = V3(0, 0, 0);
+			for (int i = 0; i < v->num_wheels; ++i) {
+				const sgo_wheel* w = &v->wheels[i];
+				if (w->has_contact) tl = v3_add(tl, v3_add(v3_scale(w->contact_normal, w->suspension.lambda + w->max_up.lambda), v3_scale(w->contact_lat, w->lateral.lambda)));
+			}
+			tl = sgo_normalized_or(tl, world_up);
+			v->target_lean = v3_add(v3_scale(v->target_lean, v->lean_smoothing), v3_scale(tl, 1.0f - v->lean_smoothing));
+			v->target_lean = v3_sub(v->target_lean, v3_scale(forward, v3_dot(v->target_lean, forward)));       /* lean sideways only */
+			v->target_lean = sgo_normalized_or(v->target_lean, world_up);
+			v3 adj_up = v3_sub(world_up, v3_scale(forward, v3_dot(world_up, forward)));
+			adj_up = sgo_normalized_or(adj_up, world_up);
+			const float w_angle = -sgo_signf(v3_dot(v3_cross(v->target_lean, adj_up), forward)) * sgo_acos11(clampf(v3_dot(v->target_lean, adj_up), -1.0f, 1.0f));
+			if (fabsf(w_angle) > v->max_lean_angle) v->target_lean = sgo_rotate_about(forward, sgo_signf(w_angle) * v->max_lean_angle, adj_up);
+			const v3 up = m33_mul(R, v->up);
+			const float d_angle = -sgo_signf(v3_dot(v3_cross(v->target_lean, up), forward)) * sgo_acos11(clampf(v3_dot(v->target_lean, up), -1.0f, 1.0f));
+			v->lean_integrated_delta = v->lean_integrated_delta + d_angle * dt;
+		} else {
+			v->target_lean = world_up;
+			v->lean_integrated_delta = 0.0f;
+		}
+		/* steering limit: SteerAngle <= asin(WheelBase tan(MaxLean) g / (v^2 cos(caster))) */
+		float lo = 3.0e38f, hi = -3.0e38f;
+		for (int i = 0; i < v->num_wheels; ++i) {
+			const sgo_wheel* w = &v->wheels[i];
+			const float val = v3_dot(v3_add(w->position, v3_scale(w->suspension_dir, w->sus_max)), v->forward);
+			lo = fminf(lo, val); hi = fmaxf(hi, val);
+		}
+		lean_max_steer_factor = (hi - lo) * v->tan_max_lean * v->gravity_len;
+		const float vel = v3_dot(c->v, forward);
+		velocity_sq = vel * vel;
+		v->lean_applied_impulse = 0.0f;
+	}
 	for (int i = 0; i < v->num_wheels; ++i) {
 		sgo_wheel* w = &v->wheels[i];
 		w->steer_angle = -v->in_right * w->max_steer;                       /* WheeledVehicleController::PreCollide */
+		if (v->is_motorcycle && w->max_steer != 0.0f) {
+			const float cos_caster = v3_dot(w->steering_axis, v->up);
+			float steer = fabsf(v->in_right) * w->max_steer;
+			if (v->lean_steering_limit && velocity_sq > 1.0e-6f && cos_caster > 1.0e-6f) {
+				const float arg = lean_max_steer_factor / (velocity_sq * cos_caster);
+				if (arg < 1.0f) steer = fminf(steer, sgo_asin01(arg));
+			}
+			w->steer_angle = -sgo_signf(v->in_right) * steer;
+		}
 		w->cast_origin = v3_add(c->pos, m33_mul(R, w->position));
 		w->cast_dir = m33_mul(R, w->suspension_dir);
 		w->cast_len = w->sus_max + w->radius - v->cast_radius;
@@ -558,7 +623,7 @@ static inline void sgo_vehicle_warm_start(sgo_vehicle* v, sgo_chassis* c)
 }
 
 /* VehicleConstraint::SolveVelocityConstraint + WheeledVehicleController::SolveLongitudinalAndLateralConstraints */
-static inline void sgo_vehicle_solve_velocity(sgo_vehicle* v, sgo_chassis* c)
+static inline void sgo_vehicle_solve_velocity(sgo_vehicle* v, sgo_chassis* c, float dt)
 {
 	const int nw = v->num_wheels;
 	for (int i = 0; i < nw; ++i) {
@@ -598,6 +663,41 @@ static inline void sgo_vehicle_solve_velocity(sgo_vehicle* v, sgo_chassis* c)
 		sgo_wheel* w = &v->wheels[i];
 		if (!w->has_contact || !w->lateral.active) continue;
 		sgo_part_solve(&w->lateral, c, w->contact_point_vel, v3_neg(w->contact_lat), -max_lat[i], max_lat[i]);
+	}
+	if (v->is_motorcycle && v->lean_enabled) {
+		/* MotorcycleController::SolveLongitudinalAndLateralConstraints: lean spring (PID on the angle to the target lean), only
+		   with every wheel loaded; the matching linear impulse keeps the contact patches from being swept sideways */
+		int all_in_contact = 1;
+		for (int i = 0; i < nw; ++i) if (!v->wheels[i].has_contact || !(v->wheels[i].suspension.lambda + v->wheels[i].max_up.lambda > 0.0f)) all_in_contact = 0;
+		if (all_in_contact) {
+			const m33 R = quat_to_m33(c->rot);
+			const v3 forward = m33_mul(R, v->forward), up = m33_mul(R, v->up);
+			const float d_angle = -sgo_signf(v3_dot(v3_cross(v->target_lean, up), forward)) * sgo_acos11(clampf(v3_dot(v->target_lean, up), -1.0f, 1.0f));
+			const float ddt_angle = v3_dot(c->w, forward);
+			/* Jolt re-evaluates  total = (K d - D w.f + Ki integral) dt  with the current angular velocity every iteration and applies
+			   the difference to what it applied before: a fixed-point iteration that only converges while D dt (f.I^-1 f) < 1.  Here the
+			   same fixed point is solved for directly (w.f without the lean impulse = ddt_angle - (f.I^-1 f) applied), which is its
+			   limit when it converges and stays stable when it would not. */
+			const v3 If = sym33_mul(c->I, forward);
+			const float iff = v3_dot(forward, If);
+			const float wf0 = ddt_angle - iff * v->lean_applied_impulse;
+			const float total = (v->lean_spring_constant * d_angle - v->lean_spring_damping * wf0 + v->lean_integration_coefficient * v->lean_integrated_delta) * dt
+			                    / (1.0f + v->lean_spring_damping * dt * iff);
+			const v3 old_w = c->w;
+			c->w = v3_add(c->w, v3_scale(If, total - v->lean_applied_impulse));
+			v->lean_applied_impulse = total;
+			const v3 dw = v3_sub(c->w, old_w);
+			v3 lin_acc = V3(0, 0, 0); float total_lambda = 0.0f;
+			for (int i = 0; i < nw; ++i) {
+				const sgo_wheel* w = &v->wheels[i];
+				const float lam = w->suspension.lambda + w->max_up.lambda;
+				total_lambda = total_lambda + lam;
+				lin_acc = v3_add(lin_acc, v3_scale(v3_cross(dw, v3_sub(w->contact_pos, c->pos)), lam));
+			}
+			c->v = v3_sub(c->v, v3_scale(lin_acc, 1.0f / total_lambda));      /* impulse -acc / (lambda im), times im */
+		} else {
+			v->lean_integrated_delta = v->lean_integrated_delta * fmaxf(0.0f, 1.0f - v->lean_integration_decay * dt);
+		}
 	}
 }
 

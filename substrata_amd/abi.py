@@ -106,6 +106,7 @@ class ConstraintDump(C.Structure):
 
 
 MAX_WHEELS, MAX_GEARS = 4, 8
+VEHICLE_CONTROLLER_WHEELED, VEHICLE_CONTROLLER_MOTORCYCLE = 0, 1
 
 
 class WheelDesc(C.Structure):
@@ -135,7 +136,10 @@ class VehicleDesc(C.Structure):
                 ("switch_time", f32), ("clutch_release_time", f32), ("switch_latency", f32), ("shift_up_rpm", f32),
                 ("shift_down_rpm", f32), ("clutch_strength", f32), ("num_differentials", u32),
                 ("differentials", DifferentialDesc * 2), ("differential_limited_slip_ratio", f32),
-                ("num_anti_roll_bars", u32), ("anti_roll_bars", AntiRollBarDesc * 2)]
+                ("num_anti_roll_bars", u32), ("anti_roll_bars", AntiRollBarDesc * 2), ("controller_type", u32),
+                ("max_lean_angle", f32), ("lean_spring_constant", f32), ("lean_spring_damping", f32),
+                ("lean_spring_integration_coefficient", f32), ("lean_spring_integration_decay", f32),
+                ("lean_smoothing_factor", f32), ("lean_steering_limit", u32)]
 
 
 class VehicleInput(C.Structure):
@@ -232,6 +236,7 @@ PROTOTYPES = {
     "vehicle_get_state": (C.c_int, [vp, u32, P(VehicleState)]),
     "vehicle_get_states": (C.c_int, [vp, u32, u32, vp]),
     "vehicle_reset_drivetrain": (C.c_int, [vp, u32, f32, f32]),
+    "vehicle_enable_lean_controller": (C.c_int, [vp, u32, C.c_int]),
     # test/debug helper, not a facade entry point
     "world_dump_constraints": (C.c_int, [vp, vp, u32, P(u32)]),
 }

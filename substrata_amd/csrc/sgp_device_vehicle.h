@@ -1,13 +1,14 @@
 // sgp_device_vehicle.h -- gfx950 wheeled vehicle constraint: per-vehicle arithmetic (device code only).
 //
-// Role of JPH::VehicleConstraint + JPH::WheeledVehicleController + JPH::VehicleCollisionTesterCastSphere behind CarPhysics
-// (/root/reference/gui_client/CarPhysics.cpp:62,94-231; defaults /root/reference/gui_client/Scripting.cpp:315-346):
-// per wheel one sphere cast along the suspension, tyre slip -> friction, engine / clutch / gearbox / differential, brakes,
-// anti-roll bars, then 4 axis rows per wheel (soft suspension spring, hard max-up stop, longitudinal, lateral).
-// One thread owns one vehicle; vehicles never share a chassis and treat the body under a wheel as kinematic (its contact
+// Role of JPH::VehicleConstraint + JPH::WheeledVehicleController / MotorcycleController + the sphere-cast collision tester behind
+// CarPhysics and BikePhysics (/root/reference/gui_client/CarPhysics.cpp:62,94-231; BikePhysics.cpp:124-227; defaults
+// /root/reference/gui_client/Scripting.cpp:315-346): per wheel one sphere cast along the suspension, tyre slip -> friction,
+// engine / clutch / gearbox / differential, brakes, anti-roll bars, then 4 axis rows per wheel (soft suspension spring, hard
+// max-up stop, longitudinal, lateral) and, for motorcycles, the lean spring.
+// One wave owns one vehicle; vehicles never share a chassis and treat the body under a wheel as kinematic (its contact
 // point velocity is sampled at cast time), so the vehicle phases need no colouring.
 // The arithmetic (expression order included) is the contract checked by tests/test_vehicle_parity_gpu.py against the CPU
-// oracle; no libm call sits on this path (polynomial sin/cos/acos).
+// oracle; no libm call sits on this path (polynomial sin/cos/acos).  Regenerate with tools/derive_device_vehicle.py.
 #pragma once
 #include "sgp_device_math.h"
 
@@ -68,6 +69,11 @@ struct sgd_vehicle {
 	int num_anti_roll_bars; sgd_anti_roll_bar anti_roll_bars[2];
 	// driver input
 	float in_forward, in_right, in_brake, in_handbrake;
+	// JPH::MotorcycleController (BikePhysics.cpp:197-205): lean spring towards the direction of the ground reaction
+	int is_motorcycle, lean_enabled, lean_steering_limit;
+	float max_lean_angle, tan_max_lean, lean_spring_constant, lean_spring_damping, lean_integration_coefficient, lean_integration_decay, lean_smoothing;
+	float gravity_len;
+	v3 target_lean; float lean_integrated_delta, lean_applied_impulse;
 };
 
 // chassis state as the vehicle rows see it
@@ -90,6 +96,17 @@ SGP_DEV static float sgd_acos01(float x)
 	p = p * xc - 0.2121144f;
 	p = p * xc + 1.5707288f;
 	return p * sqrtf(1.0f - xc);
+}
+
+// acos on [-1,1] and asin on [0,1] from the same polynomial
+SGP_DEV static float sgd_acos11(float x) { return x >= 0.0f ? sgd_acos01(x) : SGD_VEH_PI - sgd_acos01(-x); }
+SGP_DEV static float sgd_asin01(float x) { return 0.5f * SGD_VEH_PI - sgd_acos01(x); }
+SGP_DEV static float sgd_signf(float x) { return x < 0.0f ? -1.0f : 1.0f; }
+SGP_DEV static v3 sgd_normalized_or(v3 v, v3 fallback)
+{
+	const float l2 = v3_len_sq(v);
+	if (l2 <= 1.0e-24f) return fallback;
+	return v3_scale(v, 1.0f / sqrtf(l2));
 }
 
 SGP_DEV static v3 sgd_rotate_about(v3 axis_unit, float angle, v3 v)
@@ -261,12 +278,59 @@ SGP_DEV static void sgd_part_solve(sgd_axis_part* p, sgd_chassis* c, v3 ground_v
 
 // ---- pre-step, part A: steering angle and the cast request of every wheel (VehicleConstraint::OnStep, first half) ------
 
-SGP_DEV static void sgd_vehicle_pre_a(sgd_vehicle* v, const sgd_chassis* c)
+SGP_DEV static void sgd_vehicle_pre_a(sgd_vehicle* v, const sgd_chassis* c, float dt)
 {
 	const m33 R = quat_to_m33(c->rot);
+	float lean_max_steer_factor = 0.0f, velocity_sq = 0.0f;
+	if (v->is_motorcycle) {
+		// MotorcycleController::PreCollide: the wheels still hold the contacts and impulses of the previous step here
+		const v3 forward = m33_mul(R, v->forward);
+		const v3 world_up = V3(0.0f, 0.0f, 1.0f);
+		if (v->lean_enabled) {
+			v3 tl = V3(0, 0, 0);
+			for (int i = 0; i < v->num_wheels; ++i) {
+				const sgd_wheel* w = &v->wheels[i];
+				if (w->has_contact) tl = v3_add(tl, v3_add(v3_scale(w->contact_normal, w->suspension.lambda + w->max_up.lambda), v3_scale(w->contact_lat, w->lateral.lambda)));
+			}
+			tl = sgd_normalized_or(tl, world_up);
+			v->target_lean = v3_add(v3_scale(v->target_lean, v->lean_smoothing), v3_scale(tl, 1.0f - v->lean_smoothing));
+			v->target_lean = v3_sub(v->target_lean, v3_scale(forward, v3_dot(v->target_lean, forward)));       // lean sideways only
+			v->target_lean = sgd_normalized_or(v->target_lean, world_up);
+			v3 adj_up = v3_sub(world_up, v3_scale(forward, v3_dot(world_up, forward)));
+			adj_up = sgd_normalized_or(adj_up, world_up);
+			const float w_angle = -sgd_signf(v3_dot(v3_cross(v->target_lean, adj_up), forward)) * sgd_acos11(clampf(v3_dot(v->target_lean, adj_up), -1.0f, 1.0f));
+			if (fabsf(w_angle) > v->max_lean_angle) v->target_lean = sgd_rotate_about(forward, sgd_signf(w_angle) * v->max_lean_angle, adj_up);
+			const v3 up = m33_mul(R, v->up);
+			const float d_angle = -sgd_signf(v3_dot(v3_cross(v->target_lean, up), forward)) * sgd_acos11(clampf(v3_dot(v->target_lean, up), -1.0f, 1.0f));
+			v->lean_integrated_delta = v->lean_integrated_delta + d_angle * dt;
+		} else {
+			v->target_lean = world_up;
+			v->lean_integrated_delta = 0.0f;
+		}
+		// steering limit: SteerAngle <= asin(WheelBase tan(MaxLean) g / (v^2 cos(caster)))
+		float lo = 3.0e38f, hi = -3.0e38f;
+		for (int i = 0; i < v->num_wheels; ++i) {
+			const sgd_wheel* w = &v->wheels[i];
+			const float val = v3_dot(v3_add(w->position, v3_scale(w->suspension_dir, w->sus_max)), v->forward);
+			lo = fminf(lo, val); hi = fmaxf(hi, val);
+		}
+		lean_max_steer_factor = (hi - lo) * v->tan_max_lean * v->gravity_len;
+		const float vel = v3_dot(c->v, forward);
+		velocity_sq = vel * vel;
+		v->lean_applied_impulse = 0.0f;
+	}
 	for (int i = 0; i < v->num_wheels; ++i) {
 		sgd_wheel* w = &v->wheels[i];
 		w->steer_angle = -v->in_right * w->max_steer;                       // WheeledVehicleController::PreCollide
+		if (v->is_motorcycle && w->max_steer != 0.0f) {
+			const float cos_caster = v3_dot(w->steering_axis, v->up);
+			float steer = fabsf(v->in_right) * w->max_steer;
+			if (v->lean_steering_limit && velocity_sq > 1.0e-6f && cos_caster > 1.0e-6f) {
+				const float arg = lean_max_steer_factor / (velocity_sq * cos_caster);
+				if (arg < 1.0f) steer = fminf(steer, sgd_asin01(arg));
+			}
+			w->steer_angle = -sgd_signf(v->in_right) * steer;
+		}
 		w->cast_origin = v3_add(c->pos, m33_mul(R, w->position));
 		w->cast_dir = m33_mul(R, w->suspension_dir);
 		w->cast_len = w->sus_max + w->radius - v->cast_radius;
@@ -543,7 +607,7 @@ SGP_DEV static void sgd_vehicle_warm_start(sgd_vehicle* v, sgd_chassis* c)
 }
 
 // VehicleConstraint::SolveVelocityConstraint + WheeledVehicleController::SolveLongitudinalAndLateralConstraints
-SGP_DEV static void sgd_vehicle_solve_velocity(sgd_vehicle* v, sgd_chassis* c)
+SGP_DEV static void sgd_vehicle_solve_velocity(sgd_vehicle* v, sgd_chassis* c, float dt)
 {
 	const int nw = v->num_wheels;
 	for (int i = 0; i < nw; ++i) {
@@ -583,6 +647,41 @@ SGP_DEV static void sgd_vehicle_solve_velocity(sgd_vehicle* v, sgd_chassis* c)
 		sgd_wheel* w = &v->wheels[i];
 		if (!w->has_contact || !w->lateral.active) continue;
 		sgd_part_solve(&w->lateral, c, w->contact_point_vel, v3_neg(w->contact_lat), -max_lat[i], max_lat[i]);
+	}
+	if (v->is_motorcycle && v->lean_enabled) {
+		/* MotorcycleController::SolveLongitudinalAndLateralConstraints: lean spring (PID on the angle to the target lean), only
+		   with every wheel loaded; the matching linear impulse keeps the contact patches from being swept sideways */
+		int all_in_contact = 1;
+		for (int i = 0; i < nw; ++i) if (!v->wheels[i].has_contact || !(v->wheels[i].suspension.lambda + v->wheels[i].max_up.lambda > 0.0f)) all_in_contact = 0;
+		if (all_in_contact) {
+			const m33 R = quat_to_m33(c->rot);
+			const v3 forward = m33_mul(R, v->forward), up = m33_mul(R, v->up);
+			const float d_angle = -sgd_signf(v3_dot(v3_cross(v->target_lean, up), forward)) * sgd_acos11(clampf(v3_dot(v->target_lean, up), -1.0f, 1.0f));
+			const float ddt_angle = v3_dot(c->w, forward);
+			/* Jolt re-evaluates  total = (K d - D w.f + Ki integral) dt  with the current angular velocity every iteration and applies
+			   the difference to what it applied before: a fixed-point iteration that only converges while D dt (f.I^-1 f) < 1.  Here the
+			   same fixed point is solved for directly (w.f without the lean impulse = ddt_angle - (f.I^-1 f) applied), which is its
+			   limit when it converges and stays stable when it would not. */
+			const v3 If = sym33_mul(c->I, forward);
+			const float iff = v3_dot(forward, If);
+			const float wf0 = ddt_angle - iff * v->lean_applied_impulse;
+			const float total = (v->lean_spring_constant * d_angle - v->lean_spring_damping * wf0 + v->lean_integration_coefficient * v->lean_integrated_delta) * dt
+			                    / (1.0f + v->lean_spring_damping * dt * iff);
+			const v3 old_w = c->w;
+			c->w = v3_add(c->w, v3_scale(If, total - v->lean_applied_impulse));
+			v->lean_applied_impulse = total;
+			const v3 dw = v3_sub(c->w, old_w);
+			v3 lin_acc = V3(0, 0, 0); float total_lambda = 0.0f;
+			for (int i = 0; i < nw; ++i) {
+				const sgd_wheel* w = &v->wheels[i];
+				const float lam = w->suspension.lambda + w->max_up.lambda;
+				total_lambda = total_lambda + lam;
+				lin_acc = v3_add(lin_acc, v3_scale(v3_cross(dw, v3_sub(w->contact_pos, c->pos)), lam));
+			}
+			c->v = v3_sub(c->v, v3_scale(lin_acc, 1.0f / total_lambda));      // impulse -acc / (lambda im), times im
+		} else {
+			v->lean_integrated_delta = v->lean_integrated_delta * fmaxf(0.0f, 1.0f - v->lean_integration_decay * dt);
+		}
 	}
 }
 

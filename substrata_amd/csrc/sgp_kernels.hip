@@ -1860,7 +1860,7 @@ __global__ void __launch_bounds__(64) k_vehicle_cast(DV d)
 		sv.in_forward = in.forward; sv.in_right = in.right; sv.in_brake = in.brake; sv.in_handbrake = in.hand_brake;
 		const uint32_t b = sv.body;
 		sv.active = (b < d.sp->n_slots && f_movable(d.flags[b])) ? 1 : 0;
-		if (sv.active) { const sgd_chassis c = veh_chassis_pose_vel(d, b); sgd_vehicle_pre_a(&sv, &c); }
+		if (sv.active) { const sgd_chassis c = veh_chassis_pose_vel(d, b); sgd_vehicle_pre_a(&sv, &c, d.sp->dt); }
 	}
 	__syncthreads();
 	if (sv.active) {
@@ -1943,7 +1943,7 @@ template <int MODE> __global__ void __launch_bounds__(64) k_vehicle_solve(DV d)
 			const float4 s0 = d.sbody[4 * b + 0], s1 = d.sbody[4 * b + 1], s2 = d.sbody[4 * b + 2], s3 = d.sbody[4 * b + 3];
 			c.v = V3(s0); c.im = s0.w; c.w = V3(s1);
 			c.I.xx = s2.x; c.I.xy = s2.y; c.I.xz = s2.z; c.I.yy = s3.x; c.I.yz = s3.y; c.I.zz = s3.z;
-			if (MODE == 0) sgd_vehicle_warm_start(&sv, &c); else sgd_vehicle_solve_velocity(&sv, &c);
+			if (MODE == 0) sgd_vehicle_warm_start(&sv, &c); else sgd_vehicle_solve_velocity(&sv, &c, d.sp->dt);
 			d.sbody[4 * b + 0] = F4(c.v, s0.w); d.sbody[4 * b + 1] = F4(c.w, s1.w);
 		}
 	}

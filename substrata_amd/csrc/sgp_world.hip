@@ -971,6 +971,9 @@ SGP_API void sgp_default_vehicle_desc(sgp_vehicle_desc* d)
 	d->num_anti_roll_bars = 2;                                                                           // CarPhysics.cpp:217-221
 	d->anti_roll_bars[0].left_wheel = 0; d->anti_roll_bars[0].right_wheel = 1; d->anti_roll_bars[0].stiffness = 1000.0f;
 	d->anti_roll_bars[1].left_wheel = 2; d->anti_roll_bars[1].right_wheel = 3; d->anti_roll_bars[1].stiffness = 1000.0f;
+	d->controller_type = SGP_VEHICLE_CONTROLLER_WHEELED;
+	d->max_lean_angle = 45.0f * 3.14159265358979323846f / 180.0f; d->lean_spring_constant = 5000.0f; d->lean_spring_damping = 1000.0f;   // JPH::MotorcycleControllerSettings defaults
+	d->lean_spring_integration_coefficient = 0.0f; d->lean_spring_integration_decay = 4.0f; d->lean_smoothing_factor = 0.8f; d->lean_steering_limit = 1;
 }
 
 static bool vehicle_desc_valid(const sgp_vehicle_desc* d)
@@ -991,6 +994,8 @@ static bool vehicle_desc_valid(const sgp_vehicle_desc* d)
 		if (!(w->radius > 0.0f) || !(w->inertia > 0.0f) || !(w->suspension_max_length >= w->suspension_min_length) || !(w->suspension_min_length >= 0.0f)) return false;
 	}
 	if (!(d->engine_inertia > 0.0f) || !(d->engine_max_rpm > 0.0f) || !(d->clutch_release_time > 0.0f) || !(d->differential_limited_slip_ratio > 1.0f)) return false;
+	if (d->controller_type != SGP_VEHICLE_CONTROLLER_WHEELED && d->controller_type != SGP_VEHICLE_CONTROLLER_MOTORCYCLE) return false;
+	if (d->controller_type == SGP_VEHICLE_CONTROLLER_MOTORCYCLE && !(d->max_lean_angle > 0.0f && d->max_lean_angle < 1.5f)) return false;
 	return true;
 }
 
@@ -1007,6 +1012,19 @@ static float host_cos_poly(float x)
 	pc = pc * x2 - 0.5f;
 	pc = pc * x2 + 1.0f;
 	return pc;
+}
+
+static float host_sin_poly(float x)
+{
+	if (fabsf(x) > 1.5f) return sinf(x);
+	const float x2 = x * x;
+	float ps = -2.50521083854417e-8f;
+	ps = ps * x2 + 2.75573192239859e-6f;
+	ps = ps * x2 - 1.98412698412698e-4f;
+	ps = ps * x2 + 8.33333333333333e-3f;
+	ps = ps * x2 - 1.66666666666667e-1f;
+	ps = ps * x2 + 1.0f;
+	return ps * x;
 }
 
 static v3 hv3(const float* p) { v3 r; r.x = p[0]; r.y = p[1]; r.z = p[2]; return r; }
@@ -1051,6 +1069,14 @@ static void vehicle_record_from_desc(sgd_vehicle* v, const sgp_vehicle_desc* d)
 		v->anti_roll_bars[k].left = d->anti_roll_bars[k].left_wheel; v->anti_roll_bars[k].right = d->anti_roll_bars[k].right_wheel;
 		v->anti_roll_bars[k].stiffness = d->anti_roll_bars[k].stiffness;
 	}
+	v->is_motorcycle = d->controller_type == SGP_VEHICLE_CONTROLLER_MOTORCYCLE;
+	v->lean_enabled = v->is_motorcycle; v->lean_steering_limit = d->lean_steering_limit != 0;
+	v->max_lean_angle = d->max_lean_angle;
+	v->tan_max_lean = host_sin_poly(d->max_lean_angle) / host_cos_poly(d->max_lean_angle);
+	v->lean_spring_constant = d->lean_spring_constant; v->lean_spring_damping = d->lean_spring_damping;
+	v->lean_integration_coefficient = d->lean_spring_integration_coefficient; v->lean_integration_decay = d->lean_spring_integration_decay;
+	v->lean_smoothing = d->lean_smoothing_factor;
+	v->target_lean.x = 0.0f; v->target_lean.y = 0.0f; v->target_lean.z = 1.0f;
 }
 
 static inline bool vehicle_live(const sgp_world* w, uint32_t id) { return w && id < w->n_vehicles && w->veh_alive[id]; }
@@ -1084,6 +1110,7 @@ SGP_API int sgp_vehicle_create(sgp_world* w, const sgp_vehicle_desc* d, uint32_t
 	}
 	sgd_vehicle rec;
 	vehicle_record_from_desc(&rec, d);
+	rec.gravity_len = sqrtf(w->dv.gx * w->dv.gx + w->dv.gy * w->dv.gy + w->dv.gz * w->dv.gz);
 	HIP_TRY(hipMemcpyAsync(&w->d_vehicles[id], &rec, sizeof(rec), hipMemcpyHostToDevice, w->stream));
 	HIP_TRY(hipStreamSynchronize(w->stream));                  // `rec` lives on this stack frame
 	w->veh_alive[id] = 1; w->veh_body[id] = d->body; w->veh_inputs[id] = sgp_vehicle_input{ 0.0f, 0.0f, 0.0f, 0.0f }; w->veh_inputs_dirty = true;
@@ -1152,6 +1179,21 @@ SGP_API int sgp_vehicle_get_states(sgp_world* w, uint32_t first, uint32_t n, sgp
 	return SGP_OK;
 }
 SGP_API int sgp_vehicle_get_state(sgp_world* w, uint32_t id, sgp_vehicle_state* out) { return sgp_vehicle_get_states(w, id, 1, out); }
+
+SGP_API int sgp_vehicle_enable_lean_controller(sgp_world* w, uint32_t id, int enabled)
+{
+	if (!vehicle_live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_vehicle_enable_lean_controller: id not live");
+	hipSetDevice(w->device);
+	sgd_vehicle rec;
+	HIP_TRY(hipMemcpyAsync(&rec, &w->d_vehicles[id], sizeof(rec), hipMemcpyDeviceToHost, w->stream));
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	const int on = (rec.is_motorcycle && enabled) ? 1 : 0;
+	if (on != rec.lean_enabled) {
+		HIP_TRY(hipMemcpyAsync((char*)&w->d_vehicles[id] + offsetof(sgd_vehicle, lean_enabled), &on, sizeof(int), hipMemcpyHostToDevice, w->stream));
+		HIP_TRY(hipStreamSynchronize(w->stream));
+	}
+	return SGP_OK;
+}
 
 SGP_API int sgp_vehicle_reset_drivetrain(sgp_world* w, uint32_t id, float rpm, float wheel_w)
 {

@@ -5,7 +5,7 @@
 //   WheeledVehicleController::SetDriverInput                                          -> sgp_vehicle_set_input
 //   Wheel getters, VehicleEngine::GetCurrentRPM                                       -> sgp_vehicle_get_state (one read-back per step)
 // Differences a maintainer must know: the chassis is an existing box / sphere / capsule body (no
-// ConvexHullShape / OffsetCenterOfMassShape yet); VehicleCollisionTesterCastCylinder and MotorcycleController are absent.
+// ConvexHullShape / OffsetCenterOfMassShape yet); VehicleCollisionTesterCastCylinder is served by the sphere cast.
 #pragma once
 #include "JoltLite.h"
 #include "../../../include/sgp.h"
@@ -102,6 +102,13 @@ namespace JPH
 		std::vector<VehicleDifferentialSettings> mDifferentials;
 		float mDifferentialLimitedSlipRatio = 1.4f;
 	};
+	// BikePhysics.cpp:197-205
+	class MotorcycleControllerSettings : public WheeledVehicleControllerSettings
+	{
+	public:
+		float mMaxLeanAngle = DegreesToRadians(45.0f), mLeanSpringConstant = 5000.0f, mLeanSpringDamping = 1000.0f;
+		float mLeanSpringIntegrationCoefficient = 0.0f, mLeanSpringIntegrationCoefficientDecay = 4.0f, mLeanSmoothingFactor = 0.8f;
+	};
 	class VehicleConstraintSettings
 	{
 	public:
@@ -112,7 +119,7 @@ namespace JPH
 		Ref<VehicleControllerSettings> mController;
 	};
 
-	class VehicleCollisionTester { public: virtual ~VehicleCollisionTester() {} virtual float castRadius() const { return 0.0f; } };
+	class VehicleCollisionTester { public: virtual ~VehicleCollisionTester() {} virtual float castRadius(float /*wheel_width*/) const { return 0.0f; } };
 	class VehicleCollisionTesterRay : public VehicleCollisionTester
 	{
 	public:
@@ -123,8 +130,17 @@ namespace JPH
 	{
 	public:
 		VehicleCollisionTesterCastSphere(ObjectLayer, float radius, const Vec3& = Vec3(0, 1, 0), float max_slope = DegreesToRadians(80.0f)) : mRadius(radius), mMaxSlopeAngle(max_slope) {}
-		float castRadius() const override { return mRadius; }
+		float castRadius(float) const override { return mRadius; }
 		float mRadius, mMaxSlopeAngle;
+	};
+	// BikePhysics.cpp:227.  Served by the sphere cast with the half wheel width as radius (exact on flat ground; a kerb is met by the
+	// tyre's centre line rather than by its full radius).
+	class VehicleCollisionTesterCastCylinder : public VehicleCollisionTester
+	{
+	public:
+		VehicleCollisionTesterCastCylinder(ObjectLayer, float convex_radius_fraction = 0.1f) : mConvexRadiusFraction(convex_radius_fraction) {}
+		float castRadius(float wheel_width) const override { return 0.5f * wheel_width; }
+		float mConvexRadiusFraction;
 	};
 
 	class VehicleConstraint;
@@ -173,9 +189,17 @@ namespace JPH
 		VehicleEngine& GetEngine() { return engine; }
 		const VehicleEngine& GetEngine() const { return engine; }
 		int GetCurrentGear() const;
-	private:
+	protected:
 		friend class VehicleConstraint;
 		VehicleConstraint* owner = nullptr; VehicleEngine engine;
+	};
+	class MotorcycleController : public WheeledVehicleController
+	{
+	public:
+		void EnableLeanController(bool enable);                  // BikePhysics.cpp:493,617
+		bool IsLeanControllerEnabled() const { return lean_enabled; }
+	private:
+		bool lean_enabled = true;
 	};
 
 	// Bound to a world by PhysicsSystem::AddConstraint (CarPhysics.cpp:224-226).
@@ -188,7 +212,7 @@ namespace JPH
 			for (size_t i = 0; i < wheels.size(); ++i) { wheels[i].owner = this; wheels[i].index = (int)i; wheels[i].settings = settings.mWheels[i].GetPtr(); }
 			controller.owner = this; controller.engine.owner = this;
 		}
-		void SetVehicleCollisionTester(const VehicleCollisionTester* t) { cast_radius = t ? t->castRadius() : 0.0f; }
+		void SetVehicleCollisionTester(const VehicleCollisionTester* t) { cast_radius = t ? t->castRadius(settings.mWheels.empty() ? 0.0f : settings.mWheels[0]->mWidth) : 0.0f; }
 		VehicleController* GetController() { return &controller; }
 		const VehicleController* GetController() const { return &controller; }
 		Wheel* GetWheel(uint i) { return &wheels[i]; }
@@ -257,6 +281,12 @@ namespace JPH
 				d.differentials[k].left_right_split = s.mLeftRightSplit; d.differentials[k].limited_slip_ratio = s.mLimitedSlipRatio; d.differentials[k].engine_torque_ratio = s.mEngineTorqueRatio;
 			}
 			d.differential_limited_slip_ratio = c->mDifferentialLimitedSlipRatio;
+			if (const MotorcycleControllerSettings* m = dynamic_cast<const MotorcycleControllerSettings*>(c)) {
+				d.controller_type = SGP_VEHICLE_CONTROLLER_MOTORCYCLE;
+				d.max_lean_angle = m->mMaxLeanAngle; d.lean_spring_constant = m->mLeanSpringConstant; d.lean_spring_damping = m->mLeanSpringDamping;
+				d.lean_spring_integration_coefficient = m->mLeanSpringIntegrationCoefficient; d.lean_spring_integration_decay = m->mLeanSpringIntegrationCoefficientDecay;
+				d.lean_smoothing_factor = m->mLeanSmoothingFactor;
+			}
 			d.num_anti_roll_bars = (uint32_t)settings.mAntiRollBars.size();
 			for (uint32_t k = 0; k < d.num_anti_roll_bars && k < 2; ++k) {
 				d.anti_roll_bars[k].left_wheel = settings.mAntiRollBars[k].mLeftWheel; d.anti_roll_bars[k].right_wheel = settings.mAntiRollBars[k].mRightWheel;
@@ -274,10 +304,10 @@ namespace JPH
 	private:
 		static void put(float* o, const Vec3& v) { o[0] = v.x; o[1] = v.y; o[2] = v.z; }
 		BodyID body_id; VehicleConstraintSettings settings; float cast_radius = 0.0f;
-		std::vector<Wheel> wheels; WheeledVehicleController controller;
+		std::vector<Wheel> wheels; MotorcycleController controller;    // (a WheeledVehicleController for cars; the lean part is inert then)
 		uint32_t vehicle_id = 0xFFFFFFFFu; const uint64_t* step_serial = nullptr;
 		mutable uint64_t cached_serial = ~0ull; mutable sgp_vehicle_state cached = {};
-		friend class Wheel; friend class VehicleEngine; friend class WheeledVehicleController;
+		friend class Wheel; friend class VehicleEngine; friend class WheeledVehicleController; friend class MotorcycleController;
 	};
 
 	inline const sgp_wheel_state& Wheel::st() const { return owner->state().wheels[index]; }
@@ -285,6 +315,12 @@ namespace JPH
 	inline float VehicleEngine::GetCurrentRPM() const { return owner->state().engine_rpm; }
 	inline void VehicleEngine::SetCurrentRPM(float rpm) { if (owner->world) { sgp_vehicle_reset_drivetrain(owner->world, owner->GetVehicleID(), rpm, owner->state().wheels[0].angular_velocity); owner->cached_serial = ~0ull; } }
 	inline int WheeledVehicleController::GetCurrentGear() const { return owner->state().current_gear; }
+	inline void MotorcycleController::EnableLeanController(bool enable)
+	{
+		if (enable == lean_enabled || !owner->world) { lean_enabled = enable; return; }
+		lean_enabled = enable;
+		sgp_vehicle_enable_lean_controller(owner->world, owner->GetVehicleID(), enable ? 1 : 0);
+	}
 	inline void WheeledVehicleController::SetDriverInput(float f, float r, float b, float h)
 	{
 		if (!owner->world) return;

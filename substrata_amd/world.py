@@ -232,6 +232,9 @@ class CWorld:
         self._check(self._fn("vehicle_get_states")(self._h, int(first), int(n), out.ctypes.data), "vehicle_get_states")
         return out
 
+    def vehicle_enable_lean_controller(self, vid, enabled=True):
+        self._check(self._fn("vehicle_enable_lean_controller")(self._h, int(vid), int(bool(enabled))), "vehicle_enable_lean_controller")
+
     def vehicle_reset_drivetrain(self, vid, engine_rpm=0.0, wheel_angular_velocity=0.0):
         self._check(self._fn("vehicle_reset_drivetrain")(self._h, int(vid), float(engine_rpm), float(wheel_angular_velocity)),
                     "vehicle_reset_drivetrain")

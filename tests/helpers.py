@@ -48,3 +48,45 @@ def add_car(w, pos=(0, 0, 0.75), rot=(0, 0, 0, 1), mass=1200.0, friction=0.5, de
     if desc_edit is not None:
         desc_edit(vd)
     return body, w.vehicle_create(vd)
+
+
+def bike_vehicle_desc(w, body):
+    """The two-wheel MotorcycleController setup of BikePhysics (/root/reference/gui_client/BikePhysics.cpp:124-227): raked front
+    fork, rear-wheel drive through a 0/1 differential, 6 gears, lean spring 2000 / 500 / 2000, max lean 60 deg.  The reference's
+    centre-of-mass offset of -0.15 m is expressed by raising the wheel attachment points by 0.15 m."""
+    vd = w.default_vehicle_desc(body)
+    vd.num_wheels = 2
+    axis = np.array([0.0, -1.87, 2.37]); axis /= np.linalg.norm(axis)
+    wr, ww = 3.856 / 2 * 0.18, 0.94 * 0.18
+    f, r = vd.wheels[0], vd.wheels[1]
+    f.position[:] = (0.0, 0.65, 0.15); f.suspension_dir[:] = tuple(-axis); f.steering_axis[:] = tuple(axis); f.wheel_up[:] = tuple(axis)
+    f.wheel_forward[:] = (0, 1, 0)
+    f.suspension_min_length, f.suspension_max_length, f.spring_frequency, f.spring_damping = 0.1, 0.35, 2.0, 0.5
+    f.radius, f.width, f.max_steer_angle, f.max_handbrake_torque, f.max_brake_torque, f.inertia = wr, ww, np.radians(30), 40000.0, 500.0, 0.63
+    r.position[:] = (0.0, -0.88, 0.15); r.suspension_dir[:] = (0, 0, -1); r.steering_axis[:] = (0, 0, 1); r.wheel_up[:] = (0, 0, 1)
+    r.wheel_forward[:] = (0, 1, 0)
+    r.suspension_min_length, r.suspension_max_length, r.spring_frequency, r.spring_damping = 0.1, 0.3, 2.5, 0.5
+    r.radius, r.width, r.max_steer_angle, r.max_handbrake_torque, r.max_brake_torque, r.inertia = wr, ww, 0.0, 0.0, 700.0, 0.9
+    for wh in (f, r):
+        for k, y in enumerate((15.0, 8.0, 3.0)):
+            wh.longitudinal_friction[k][1] = y
+        for k, m in enumerate((5.0, 3.0, 2.0)):
+            wh.lateral_friction[k][1] *= m
+    vd.cast_radius = 0.5 * ww
+    vd.controller_type = abi.VEHICLE_CONTROLLER_MOTORCYCLE
+    vd.lean_spring_constant, vd.lean_spring_damping, vd.lean_spring_integration_coefficient = 2000.0, 500.0, 2000.0
+    vd.lean_smoothing_factor, vd.max_lean_angle = 0.9, np.radians(60)
+    vd.num_differentials = 1
+    vd.differentials[0].left_wheel, vd.differentials[0].right_wheel, vd.differentials[0].left_right_split = 0, 1, 1.0
+    vd.engine_max_torque, vd.engine_max_rpm, vd.engine_inertia = 390.0, 10000.0, 0.2
+    vd.num_gears = 6
+    for k, g in enumerate((2.27, 1.63, 1.3, 1.09, 0.96, 0.88)):
+        vd.gear_ratios[k] = g
+    vd.shift_down_rpm, vd.shift_up_rpm, vd.switch_time = 5000.0, 9000.0, 0.2
+    vd.num_anti_roll_bars = 0
+    return vd
+
+
+def add_bike(w, pos=(0, 0, 0.7), rot=(0, 0, 0, 1), mass=200.0):
+    body = dyn(w, shape=(1.7 / 2 * 0.18, 9.0 / 2 * 0.18, 3.2 / 2 * 0.18, 0.0), pos=pos, rot=rot, mass=mass, friction=0.5, restitution=0.0)
+    return body, w.vehicle_create(bike_vehicle_desc(w, body))

@@ -28,6 +28,7 @@ def test_facade_compiles_without_gpu(tmp_path):
     assert os.path.exists(build_facade_exe(tmp_path))
     assert os.path.exists(build_facade_exe(tmp_path, "hover_controller.cpp"))
     assert os.path.exists(build_facade_exe(tmp_path, "car_controller.cpp"))
+    assert os.path.exists(build_facade_exe(tmp_path, "bike_controller.cpp"))
 
 
 @pytest.mark.gpu
@@ -45,6 +46,16 @@ def test_car_controller_through_vehicle_constraint(tmp_path):
     """A CarPhysics-shaped caller builds JPH::VehicleConstraintSettings / WheelSettingsWV / WheeledVehicleControllerSettings as
     CarPhysics.cpp:94-231 does, registers the constraint, drives (throttle, steer right, brake) and reads the wheels back."""
     exe = build_facade_exe(tmp_path, "car_controller.cpp")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_bike_controller_through_motorcycle_controller(tmp_path):
+    """A BikePhysics-shaped caller (MotorcycleControllerSettings, raked fork, CastCylinder tester, EnableLeanController): the bike stays
+    upright on the straight, leans right in the right-hand turn, shifts up."""
+    exe = build_facade_exe(tmp_path, "bike_controller.cpp")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     print(r.stdout)
     assert r.returncode == 0, r.stdout + r.stderr

@@ -212,3 +212,48 @@ def test_sphere_cast_against_brute_force(oracle):
         assert abs(np.linalg.norm(n) - 1) < 1e-4 and n @ d < 1e-3
         checked += 1
     assert checked > 150
+
+
+def roll_deg(q):
+    """Roll of the chassis about its forward axis, positive = leaning to its right (x right, y forward, z up)."""
+    x, y, z, w = [float(c) for c in q]
+    up = np.array([2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y)])
+    fw = np.array([2 * (x * y - w * z), 1 - 2 * (x * x + z * z), 2 * (y * z + w * x)])
+    rt = np.cross(fw, [0, 0, 1.0]); rt /= np.linalg.norm(rt)
+    return float(np.degrees(np.arcsin(np.clip(up @ rt, -1, 1))))
+
+
+def test_motorcycle_lean_controller(oracle):
+    """JPH::MotorcycleController as BikePhysics sets it up (BikePhysics.cpp:124-227): the lean spring keeps the two-wheeler upright,
+    leans it into a turn (towards the ground reaction), the lean steering limit shrinks the steering angle with speed, and
+    without the controller (EnableLeanController(false), :617) the bike falls over."""
+    from helpers import add_bike
+    w = oracle.OracleWorld(max_bodies=16)
+    add_ground(w, friction=1.0)
+    b, v = add_bike(w)
+    rolls, steer = [], []
+    for s in range(600):
+        w.vehicle_set_input(v, forward=0.5 if s > 30 else 0.0, right=0.5 if 300 <= s < 480 else 0.0)
+        w.step(DT)
+        st = w.get_state([b])[0]
+        rolls.append(roll_deg(st["rot"])); steer.append(float(w.vehicle_get_state(v)["wheels"][0]["steer_angle"]))
+    rolls = np.array(rolls)
+    assert np.abs(rolls[:300]).max() < 2.0                                  # upright while accelerating in a straight line
+    assert 15.0 < rolls[420:480].mean() < 60.0                              # leans right in the right-hand turn, below the 60 deg cap
+    assert abs(rolls[-1]) < 8.0                                             # and comes back up
+    st = w.get_state([b])[0]
+    assert st["pos"][0] > 20.0 and st["lin_vel"][0] > 5.0                   # turned right
+    assert st["pos"][2] > 0.3
+    vs = w.vehicle_get_state(v)
+    assert vs["current_gear"] >= 2 and all(x["has_contact"] == 1 for x in vs["wheels"][:2])
+    # lean steering limit: at ~45 m/s the allowed steering angle is far below 0.5 * 30 deg
+    assert 0.0 < -min(steer[300:480]) < 0.05
+    # rear-wheel drive: all the engine torque goes to wheel 1 (left_right_split = 1)
+    w2 = oracle.OracleWorld(max_bodies=16)
+    add_ground(w2, friction=1.0)
+    b2, v2 = add_bike(w2)
+    w2.vehicle_enable_lean_controller(v2, False)
+    for s in range(200):
+        w2.vehicle_set_input(v2, forward=0.5 if s > 30 else 0.0)
+        w2.step(DT)
+    assert abs(roll_deg(w2.get_state([b2])[0]["rot"])) > 60.0               # on its side

@@ -49,7 +49,21 @@ def test_cars_and_debris_match_oracle(oracle):
         vg, vc = tw.vehicle_create(tw.gpu.default_vehicle_desc(int(b)))
         assert vg == vc
     debris = descs[1 + ncars:]
-    n = 1 + ncars + len(debris)
+    # two motorcycles (MotorcycleController: lean spring, lean steering limit) riding through the same field
+    from helpers import bike_vehicle_desc
+    nbikes = 2
+    for k in range(nbikes):
+        bd = scenes.dynamic_bodies(1, mass=200.0, friction=0.5, restitution=0.0)
+        bd["shape"][0, :3] = (1.7 / 2 * 0.18, 9.0 / 2 * 0.18, 3.2 / 2 * 0.18)
+        bd["pos"][0] = (-16.0 + 3.0 * k, -16.0, 0.7)
+        ig, ic = tw.add_batch(bd)
+        bg = int(ig[0])
+        assert bg == int(ic[0])
+        vg, vc = tw.vehicle_create(bike_vehicle_desc(tw.gpu, bg))
+        assert vg == vc == ncars + k
+    ncars_only = ncars
+    ncars += nbikes
+    n = 1 + ncars + len(debris)                # (bikes were added after the debris: same count)
     for s in range(360):
         if s % 15 == 0:
             drive(tw, ncars, s)
