@@ -100,7 +100,7 @@ class GhostExchange:
         recs["global_id"] = recs["global_id"] | (np.uint64(self.rank) << np.uint64(40))
         recs["motion_type"] = np.where(emigrant, np.uint32(abi.MOTION_DYNAMIC | 0x100), recs["motion_type"])   # bit 8 = "take ownership"
         self.last_exported = len(recs)
-        if self.dist is None or self.n == 1:
+        if self.dist is None:
             self.world.import_ghosts(recs[:0])
             return
         torch = self.torch
