@@ -938,7 +938,9 @@ SGP_DEV float axis_jv(const BodyVel& A, const BodyVel& B, v3 r1, v3 r2, v3 axis)
 
 struct PairCtx { uint2 ab; float im1, im2; sym33 I1, I2; BodyVel A, B; v3 n, t1, t2; float friction; int np; };
 
-SGP_DEV void load_pair(const DV& d, uint32_t slot, PairCtx& c)
+// `vel` / VS: where the velocity half of the per-body solver record lives -- the global record itself (vel = d.sbody, VS = 4) or
+// the LDS copy of the small-world kernel (VS = 2).  The inverse-inertia half is read-only during the solve and stays global.
+template <int VS> SGP_DEV void load_pair(const DV& d, uint32_t slot, PairCtx& c, const float4* vel)
 {
 	c.ab = CUR(d).ab[slot];
 	const float4 nf = CUR(d).n_fric[slot];
@@ -946,8 +948,9 @@ SGP_DEV void load_pair(const DV& d, uint32_t slot, PairCtx& c)
 	c.np = CUR(d).np_col[slot] & 0xFF;
 	const float4* pa = d.sbody + 4 * (size_t)c.ab.x;
 	const float4* pb = d.sbody + 4 * (size_t)c.ab.y;
-	const float4 va = pa[0], wa = pa[1], a0 = pa[2], a1 = pa[3];
-	const float4 vb = pb[0], wb = pb[1], b0 = pb[2], b1 = pb[3];
+	const float4 a0 = pa[2], a1 = pa[3], b0 = pb[2], b1 = pb[3];
+	const float4 va = vel[VS * (size_t)c.ab.x], wa = vel[VS * (size_t)c.ab.x + 1];
+	const float4 vb = vel[VS * (size_t)c.ab.y], wb = vel[VS * (size_t)c.ab.y + 1];
 	c.im1 = va.w; c.im2 = vb.w;
 	c.I1.xx = a0.x; c.I1.xy = a0.y; c.I1.xz = a0.z; c.I1.yy = a1.x; c.I1.yz = a1.y; c.I1.zz = a1.z;
 	c.I2.xx = b0.x; c.I2.xy = b0.y; c.I2.xz = b0.z; c.I2.yy = b1.x; c.I2.yz = b1.y; c.I2.zz = b1.z;
@@ -955,16 +958,16 @@ SGP_DEV void load_pair(const DV& d, uint32_t slot, PairCtx& c)
 	c.B.lv = V3(vb); c.B.av = V3(wb);
 }
 
-SGP_DEV void store_pair_vel(const DV& d, const PairCtx& c)
+template <int VS> SGP_DEV void store_pair_vel(const PairCtx& c, float4* vel)
 {
-	if (c.im1 > 0.0f) { d.sbody[4 * (size_t)c.ab.x] = F4(c.A.lv, c.im1); d.sbody[4 * (size_t)c.ab.x + 1] = F4(c.A.av, 0.0f); }
-	if (c.im2 > 0.0f) { d.sbody[4 * (size_t)c.ab.y] = F4(c.B.lv, c.im2); d.sbody[4 * (size_t)c.ab.y + 1] = F4(c.B.av, 0.0f); }
+	if (c.im1 > 0.0f) { vel[VS * (size_t)c.ab.x] = F4(c.A.lv, c.im1); vel[VS * (size_t)c.ab.x + 1] = F4(c.A.av, 0.0f); }
+	if (c.im2 > 0.0f) { vel[VS * (size_t)c.ab.y] = F4(c.B.lv, c.im2); vel[VS * (size_t)c.ab.y + 1] = F4(c.B.av, 0.0f); }
 }
 
-SGP_DEV void warm_start_one(const DV& d, uint32_t slot)
+template <int VS> SGP_DEV void warm_start_one_t(const DV& d, uint32_t slot, float4* vel)
 {
 	PairCtx c;
-	load_pair(d, slot, c);
+	load_pair<VS>(d, slot, c, vel);
 	c.t1 = v3_normalized_perpendicular(c.n);
 	c.t2 = v3_cross(c.n, c.t1);
 #pragma unroll
@@ -979,16 +982,17 @@ SGP_DEV void warm_start_one(const DV& d, uint32_t slot)
 			apply_impulse(c.A, c.B, c.im1, c.I1, c.im2, c.I2, r1, r2, c.n, l.x);
 		}
 	}
-	store_pair_vel(d, c);
+	store_pair_vel<VS>(c, vel);
 }
+SGP_DEV void warm_start_one(const DV& d, uint32_t slot) { warm_start_one_t<4>(d, slot, d.sbody); }
 
 // One contact manifold, one velocity iteration (ContactConstraintManager::SolveVelocityConstraints): friction rows of
 // every point first (they use the normal impulse of the previous iteration), then the non-penetration rows.
 // All per-point state is held in registers: loops are fully unrolled with predicates (no runtime-indexed arrays).
-SGP_DEV void solve_velocity_one(const DV& d, uint32_t slot)
+template <int VS> SGP_DEV void solve_velocity_one_t(const DV& d, uint32_t slot, float4* vel)
 {
 	PairCtx c;
-	load_pair(d, slot, c);
+	load_pair<VS>(d, slot, c, vel);
 	float4 r1b[4], r2e[4], lam[4]; float2 et[4];
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
@@ -1024,8 +1028,9 @@ SGP_DEV void solve_velocity_one(const DV& d, uint32_t slot)
 	}
 #pragma unroll
 	for (int i = 0; i < 4; ++i) { if (i < c.np) CUR(d).lam[i][slot] = lam[i]; }
-	store_pair_vel(d, c);
+	store_pair_vel<VS>(c, vel);
 }
+SGP_DEV void solve_velocity_one(const DV& d, uint32_t slot) { solve_velocity_one_t<4>(d, slot, d.sbody); }
 
 SGP_DEV void solve_position_one(const DV& d, uint32_t slot)
 {
@@ -1121,6 +1126,51 @@ __global__ void __launch_bounds__(512) k_solve_tail(DV d, int first_colour, int 
 		else if (mode == 1) solve_velocity_one(d, bslot);
 		else solve_position_one(d, bslot);
 	}
+}
+
+// Small worlds (every colour in the tail, <= SMALL_LDS_BODIES body slots, no vehicles -- i.e. a typical Substrata scene of a
+// few hundred awake bodies): the warm start and ALL velocity iterations in ONE launch of one workgroup.  The velocity half of
+// the solver records lives in LDS for the whole solve (a phase then costs an LDS gather instead of a dependent global one);
+// phases are ordered exactly like the separate launches they replace (colour by colour, workgroup barrier in between, overflow
+// colour serially by priority), so the result is bit-identical.
+#define SMALL_LDS_BODIES 2048
+__global__ void __launch_bounds__(512) k_solve_small(DV d, int warm_start, int iterations)
+{
+	__shared__ float4 sv[2 * SMALL_LDS_BODIES];        // 64 KB: [lin vel, effective inverse mass][ang vel, -] per body slot
+	__shared__ uint32_t cs[SGP_MAX_COLOURS + 1];
+	const uint32_t n = min(d.sp->n_slots, (uint32_t)SMALL_LDS_BODIES);
+	if (threadIdx.x <= SGP_MAX_COLOURS) cs[threadIdx.x] = d.cstarts[threadIdx.x];
+	for (uint32_t i = threadIdx.x; i < 2 * n; i += 512) sv[i] = d.sbody[4 * (size_t)(i >> 1) + (i & 1)];
+	__syncthreads();
+	if (cs[0] != cs[SGP_MAX_COLOURS]) {
+		for (int pass = warm_start ? -1 : 0; pass < iterations; ++pass) {
+			for (int c = 0; c < SGP_OVERFLOW_COLOUR; ++c) {
+				const uint32_t b = cs[c], e = cs[c + 1];
+				if (b == e) continue;
+				for (uint32_t k = b + threadIdx.x; k < e; k += 512) {
+					if (pass < 0) warm_start_one_t<2>(d, k, sv); else solve_velocity_one_t<2>(d, k, sv);
+				}
+				__syncthreads();
+			}
+			const uint32_t first = cs[SGP_OVERFLOW_COLOUR], count = cs[SGP_OVERFLOW_COLOUR + 1] - first;
+			if (count != 0) {
+				if (threadIdx.x == 0) {
+					uint64_t last = 0; bool have_last = false;
+					for (uint32_t it = 0; it < count; ++it) {
+						uint64_t best = ~0ull; uint32_t bslot = first;
+						for (uint32_t k = 0; k < count; ++k) {
+							const uint64_t pr = sgp_mix64(CUR(d).key[first + k]);
+							if ((!have_last || pr > last) && pr <= best) { best = pr; bslot = first + k; }
+						}
+						last = best; have_last = true;
+						if (pass < 0) warm_start_one_t<2>(d, bslot, sv); else solve_velocity_one_t<2>(d, bslot, sv);
+					}
+				}
+				__syncthreads();
+			}
+		}
+	}
+	for (uint32_t i = threadIdx.x; i < 2 * n; i += 512) d.sbody[4 * (size_t)(i >> 1) + (i & 1)] = sv[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2041,6 +2091,7 @@ void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStr
 	else hipLaunchKernelGGL(k_solve_colour<2>, dim3(blocks), dim3(TPB), 0, s, d, colour);
 }
 void launch_solve_tail(const DV& d, int first_colour, int mode, hipStream_t s) { hipLaunchKernelGGL(k_solve_tail, dim3(1), dim3(512), 0, s, d, first_colour, mode); }
+void launch_solve_small(const DV& d, int warm_start, int iterations, hipStream_t s) { hipLaunchKernelGGL(k_solve_small, dim3(1), dim3(512), 0, s, d, warm_start, iterations); }
 void launch_integrate_pose(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_integrate_pose, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_finalize(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_finalize, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_island_hook(const DV& d, uint32_t n_con, hipStream_t s) { hipLaunchKernelGGL(k_island_hook, dim3(stride_grid(n_con)), dim3(TPB), 0, s, d); }

@@ -16,6 +16,7 @@
 #include <vector>
 #include <unordered_map>
 #include <map>
+#include <chrono>
 #include "sgp_kernels.h"
 #include "sgp_device_vehicle.h"
 
@@ -76,7 +77,7 @@ struct sgp_world {
 	uint32_t last_active = 0xFFFFFFFFu;
 	StepParams* h_sp = nullptr; StepParams* d_sp = nullptr;      // pinned host copy / device copy of the per-step scalars
 	std::map<std::string, hipGraphExec_t> graphs;              // replayable launch sequences keyed by launch plan
-	std::string last_plan_key; uint32_t plan_repeats = 0; bool use_graphs = true;
+	std::string last_plan_key; uint32_t plan_repeats = 0; bool use_graphs = true; bool use_small_world = true;
 	uint32_t graph_launches = 0, eager_steps = 0, idle_steps = 0;
 	bool grid_valid = false;                                   // the broad-phase grid matches the current poses (ray queries reuse it)
 	// wheeled vehicles: device records (AoS) + host mirror of what the ABI needs without a read-back
@@ -275,6 +276,7 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	DEV_ALLOC(w->d_sp, 1);
 	d.sp = w->d_sp;
 	{ const char* e = getenv("SGP_NO_GRAPH"); if (e && e[0] == '1') w->use_graphs = false; }
+	{ const char* e = getenv("SGP_NO_SMALL_WORLD"); if (e && e[0] == '1') w->use_small_world = false; }
 	d.st = desc->settings;
 	d.gx = desc->gravity[0]; d.gy = desc->gravity[1]; d.gz = desc->gravity[2];
 	w->hb.resize(N);
@@ -676,6 +678,7 @@ struct StepPlan {
 	uint32_t colour_est[SGP_MAX_COLOURS];
 	int      water, contact_events, warm_start, vel_iters, pos_iters;
 	uint32_t n_vehicles;
+	int      small_world;        // warm start + velocity iterations as ONE single-workgroup launch (k_solve_small)
 	StepParams sp;               // by-value kernel argument of the first launch: part of the key of a captured graph
 };
 
@@ -692,6 +695,7 @@ static void make_plan(const sgp_world* w, StepPlan& p)
 	p.water = w->h_sp->water_enabled; p.contact_events = w->h_sp->contact_events;
 	p.warm_start = w->dv.st.warm_start; p.vel_iters = w->dv.st.num_velocity_steps; p.pos_iters = w->dv.st.num_position_steps;
 	p.n_vehicles = w->n_vehicles;
+	p.small_world = (tf == 0 && w->high <= SGP_SMALL_WORLD_BODIES && w->n_vehicles == 0 && w->use_small_world) ? 1 : 0;
 	p.sp = *w->h_sp;
 }
 
@@ -737,8 +741,11 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 		for (int c = 0; c < p.tail_first; ++c) { KScope k(w, kc); launch_solve_colour(d, c, p.colour_est[c], mode, s); }
 		{ KScope k(w, kc); launch_solve_tail(d, p.tail_first, mode, s); }
 	};
-	if (p.warm_start) solve_pass(0, KC_WARM_START);
-	for (int it = 0; it < p.vel_iters; ++it) solve_pass(1, KC_SOLVE_VELOCITY);
+	if (p.small_world) { KScope k(w, KC_SOLVE_VELOCITY); launch_solve_small(d, p.warm_start, p.vel_iters, s); }
+	else {
+		if (p.warm_start) solve_pass(0, KC_WARM_START);
+		for (int it = 0; it < p.vel_iters; ++it) solve_pass(1, KC_SOLVE_VELOCITY);
+	}
 	STAGE_MARK(5);
 	// -- 6. the body-array sweep
 	{ KScope k(w, KC_INTEGRATE_POSE); launch_integrate_pose(d, nb, s); }
@@ -783,6 +790,10 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 		HIP_TRY(hipMemcpyAsync(w->d_veh_inputs, w->veh_inputs.data(), sizeof(sgp_vehicle_input) * w->n_vehicles, hipMemcpyHostToDevice, w->stream));
 		w->veh_inputs_dirty = false;
 	}
+	static const bool timing = getenv("SGP_TIMING") != nullptr;
+	static double t_acc[4] = { 0, 0, 0, 0 }; static int t_n = 0;
+	auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const double tt0 = timing ? now() : 0.0;
 	w->h_sp->dt = dt;
 	StepPlan plan;
 	make_plan(w, plan);
@@ -812,7 +823,9 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	w->last_plan_key = key;
 	if (!launched) { const int r = enqueue_step(w, plan); if (r != SGP_OK) return r; w->eager_steps++; }
 	// -- the ONE host sync of the step: counters, events, and the launch plan for the next step
+	const double tt1 = timing ? now() : 0.0;
 	HIP_TRY(hipStreamSynchronize(w->stream));
+	const double tt2 = timing ? now() : 0.0;
 	w->h_sp->parity ^= 1u;                    // the buffer just solved becomes the contact cache of the next step
 	w->grid_valid = false;                    // bodies moved after the broad phase of this step
 	w->dirty_since_step = false;
@@ -841,6 +854,11 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 		st.num_activated = (uint32_t)(w->ev_act.size() - a0);
 		st.num_deactivated = (uint32_t)(w->ev_deact.size() - d0);
 		for (uint32_t i = 0; i < w->high; ++i) if (w->hb[i].flags & BF_ALIVE) st.layer_counts[(w->hb[i].flags & BF_LAYER_MASK) >> BF_LAYER_SHIFT]++;
+	}
+	if (timing) {
+		const double tt3 = now();
+		t_acc[0] += tt1 - tt0; t_acc[1] += tt2 - tt1; t_acc[2] += tt3 - tt2; t_n++;
+		if (t_n == 500) { fprintf(stderr, "[sgp timing] enqueue %.1f us  sync wait %.1f us  post %.1f us\n", t_acc[0] / t_n, t_acc[1] / t_n, t_acc[2] / t_n); t_acc[0] = t_acc[1] = t_acc[2] = 0; t_n = 0; }
 	}
 	return SGP_OK;
 }

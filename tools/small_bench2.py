@@ -1,0 +1,26 @@
+"""Developer probe: where a small world's step time goes (config 1 while active, 256 boxes kept awake)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from substrata_amd import scenes
+from substrata_amd.lib import World
+descs = scenes.config1_256_boxes()
+descs["allow_sleeping"] = 0
+for graphs in ("0", "1"):
+    os.environ["SGP_NO_GRAPH"] = graphs
+    w = World(max_bodies=len(descs) + 64)
+    w.add_batch(descs)
+    for _ in range(200):
+        w.step(1 / 60)
+    t = time.perf_counter(); n = 500
+    for _ in range(n):
+        w.step(1 / 60)
+    el = time.perf_counter() - t
+    st = w.stats()
+    p = w.step_profiled(1 / 60)
+    names = w.kernel_class_names()
+    nl = sum(p.kernel_launches[k] for k in range(len(names)))
+    print(f"SGP_NO_GRAPH={graphs}: {1000 * el / n:.3f} ms/step wall; active {st.num_active} manifolds {st.num_manifolds} colours {st.num_colours}; launches {nl}; GPU span of a profiled step {p.total_ms:.3f} ms")
+    print("   ", {names[k]: (round(p.kernel_ms[k], 3), p.kernel_launches[k]) for k in range(len(names)) if p.kernel_launches[k]})
+    w.close()
