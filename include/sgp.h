@@ -184,7 +184,7 @@ typedef struct sgp_step_stats {
 	uint32_t num_overflow_constraints;
 	uint32_t pairs_dropped;
 	uint32_t manifolds_dropped;
-	uint32_t num_activated;
+	uint32_t num_activated;      /* activation / deactivation events raised since the end of the previous step */
 	uint32_t num_deactivated;
 	uint32_t layer_counts[SGP_NUM_LAYERS];
 	uint64_t device_bytes;

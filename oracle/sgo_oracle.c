@@ -106,6 +106,7 @@ typedef struct sgo_world {
 	/* multi-tile ghosts: global id -> local id, kept sorted by global id */
 	uint64_t* ghost_gid; uint32_t* ghost_lid; uint32_t n_ghosts;
 	int* is_ghost;
+	uint64_t tot_act, tot_deact, rep_act, rep_deact;   /* running totals of (de)activation events / totals already reported in stats */
 	/* wheeled vehicles (sgo_vehicle.h) */
 	sgo_vehicle* vehicles; uint32_t n_vehicles, cap_vehicles;
 } sgo_world;
@@ -287,8 +288,8 @@ static void body_reset_sleep(sgo_body* b)
 static void push_body_event(sgo_world* w, int kind, uint32_t id)
 {
 	sgp_body_event e; e.id = id; e._pad = 0; e.userdata = w->bodies[id].userdata;
-	if (kind == SGP_EVENT_ACTIVATED) PUSH_EVENT(w->ev_act, w->n_act, w->cap_act, sgp_body_event, e);
-	else if (kind == SGP_EVENT_DEACTIVATED) PUSH_EVENT(w->ev_deact, w->n_deact, w->cap_deact, sgp_body_event, e);
+	if (kind == SGP_EVENT_ACTIVATED) { PUSH_EVENT(w->ev_act, w->n_act, w->cap_act, sgp_body_event, e); w->tot_act++; }
+	else if (kind == SGP_EVENT_DEACTIVATED) { PUSH_EVENT(w->ev_deact, w->n_deact, w->cap_deact, sgp_body_event, e); w->tot_deact++; }
 	else PUSH_EVENT(w->ev_water, w->n_water, w->cap_water, sgp_body_event, e);
 }
 
@@ -1618,8 +1619,9 @@ SGO_API int sgo_world_step(sgo_world* w, float dt)
 	w->stats.num_manifolds = w->n_prev;
 	w->stats.num_colours = (uint32_t)ncol;
 	w->stats.num_overflow_constraints = novf;
-	w->stats.num_activated = w->n_act;
-	w->stats.num_deactivated = w->n_deact;
+	/* activation events raised since the end of the previous step (edits between steps included) */
+	w->stats.num_activated = (uint32_t)(w->tot_act - w->rep_act); w->rep_act = w->tot_act;
+	w->stats.num_deactivated = (uint32_t)(w->tot_deact - w->rep_deact); w->rep_deact = w->tot_deact;
 	return SGP_OK;
 }
 
