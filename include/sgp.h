@@ -236,6 +236,8 @@ int  sgp_body_remove(sgp_world* w, uint32_t id);
 /* activateObject (:1342-1346) */
 int  sgp_body_activate(sgp_world* w, uint32_t id);
 /* setObjectLayer (:1349-1353) */
+/* Body::GetShape()->GetVolume() through GetBodyLockInterface().TryGetBody() (BoatPhysics.cpp:40-43) */
+int  sgp_body_get_volume(sgp_world* w, uint32_t id, float* volume_out);
 int  sgp_body_set_layer(sgp_world* w, uint32_t id, int32_t layer);
 /* setNewObToWorldTransform(pos,rot,linvel,angvel) (:607-620); SetPositionRotationAndVelocity. Does not activate. */
 int  sgp_body_set_pose_vel(sgp_world* w, uint32_t id, const float pos[3], const float rot[4],

@@ -406,6 +406,7 @@ SGO_API int sgo_body_remove(sgo_world* w, uint32_t id)
 	return SGP_OK;
 }
 SGO_API int sgo_body_activate(sgo_world* w, uint32_t id) { if (!live(w, id)) return SGP_ERR_BAD_ID; body_activate(w, id); return SGP_OK; }
+SGO_API int sgo_body_get_volume(sgo_world* w, uint32_t id, float* out) { if (!live(w, id) || !out) return SGP_ERR_BAD_ID; *out = shape_volume(w->bodies[id].shape_type, w->bodies[id].shape); return SGP_OK; }
 SGO_API int sgo_body_set_layer(sgo_world* w, uint32_t id, int32_t layer) { if (!live(w, id)) return SGP_ERR_BAD_ID; w->bodies[id].layer = layer; return SGP_OK; }
 
 SGO_API int sgo_body_set_pose_vel(sgo_world* w, uint32_t id, const float pos[3], const float rot[4], const float lv[3], const float av[3])

@@ -199,6 +199,7 @@ PROTOTYPES = {
     "body_remove": (C.c_int, [vp, u32]),
     "body_activate": (C.c_int, [vp, u32]),
     "body_set_layer": (C.c_int, [vp, u32, i32]),
+    "body_get_volume": (C.c_int, [vp, u32, P(f32)]),
     "body_set_pose_vel": (C.c_int, [vp, u32, P(f32), P(f32), P(f32), P(f32)]),
     "body_set_pose_shape": (C.c_int, [vp, u32, P(f32), P(f32), P(f32)]),
     "body_set_pose_vel_batch": (C.c_int, [vp, vp, vp, u32]),

@@ -47,6 +47,7 @@ struct HostBody {
 	uint32_t flags = 0;          // mirror of the static part of the device flags (alive, motion, layer, shape, large)
 	uint64_t userdata = 0;
 	float bound_radius = 0.0f;
+	float volume = 0.0f;         // Shape::GetVolume of the current shape
 	bool ghost = false;
 };
 
@@ -341,6 +342,14 @@ static inline float clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f
 static inline bool finite3(const float* v) { return std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2]); }
 static inline bool live(const sgp_world* w, uint32_t id) { return w && id < w->high && (w->hb[id].flags & BF_ALIVE); }
 
+static float host_shape_volume(int type, const float* p)
+{
+	const float pi = 3.14159265358979323846f;
+	if (type == SGP_SHAPE_SPHERE) return (4.0f / 3.0f) * pi * p[0] * p[0] * p[0];
+	if (type == SGP_SHAPE_BOX) return 8.0f * p[0] * p[1] * p[2];
+	return pi * p[0] * p[0] * (2.0f * p[1]) + (4.0f / 3.0f) * pi * p[0] * p[0] * p[0];
+}
+
 static void note_radius(sgp_world* w, uint32_t id, float r)
 {
 	HostBody& b = w->hb[id];
@@ -387,6 +396,7 @@ static int add_one(sgp_world* w, const sgp_body_desc* d, uint32_t* id_out, bool 
 	HostBody& hb = w->hb[id];
 	hb.flags = f; hb.userdata = d->userdata; hb.ghost = ghost;
 	note_radius(w, id, bounding_radius(d->shape_type, d->shape));
+	hb.volume = host_shape_volume(d->shape_type, d->shape);
 	c.flags = hb.flags;
 	w->cmds.push_back(c);
 	if (d->activate && d->motion_type != SGP_MOTION_STATIC) { BodyCmd a; memset(&a, 0, sizeof(a)); a.id = id; a.ops = CMD_ACTIVATE; w->cmds.push_back(a); }
@@ -432,6 +442,13 @@ SGP_API int sgp_body_activate(sgp_world* w, uint32_t id)
 {
 	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_activate: id not live");
 	w->cmds.push_back(blank_cmd(id, CMD_ACTIVATE));
+	return SGP_OK;
+}
+// Body::GetShape()->GetVolume() (BoatPhysics.cpp:40-43)
+SGP_API int sgp_body_get_volume(sgp_world* w, uint32_t id, float* volume_out)
+{
+	if (!live(w, id) || !volume_out) return fail(SGP_ERR_BAD_ID, "sgp_body_get_volume: id not live");
+	*volume_out = w->hb[id].volume;
 	return SGP_OK;
 }
 SGP_API int sgp_body_set_layer(sgp_world* w, uint32_t id, int32_t layer)
@@ -498,6 +515,7 @@ SGP_API int sgp_body_set_pose_shape(sgp_world* w, uint32_t id, const float pos[3
 	memcpy(c.pos, pos, 12); memcpy(c.rot, rot, 16); memcpy(c.shape, shape, 16);
 	const int type = (int)((w->hb[id].flags & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT);
 	note_radius(w, id, bounding_radius(type, shape));
+	w->hb[id].volume = host_shape_volume(type, shape);
 	w->cmds.push_back(c);
 	return SGP_OK;
 }

@@ -33,10 +33,13 @@ namespace JPH
 	private:
 		uint32_t id;
 	};
+	class Shape { public: float GetVolume() const { return volume; } float volume = 0; };
 	// What the listeners read from a body during a contact callback.
 	class Body
 	{
 	public:
+		const Shape* GetShape() const { return &shape; }
+		Shape shape;
 		Vec3 GetLinearVelocity() const { return lin_vel; }
 		uint64_t GetUserData() const { return user_data; }
 		BodyID GetID() const { return id; }
@@ -115,13 +118,24 @@ namespace JPH
 		mutable bool st_active;
 	};
 
+	// GetBodyLockInterface().TryGetBody(id)->GetShape()->GetVolume()  (BoatPhysics.cpp:40-43)
+	class BodyLockInterface
+	{
+	public:
+		explicit BodyLockInterface(sgp_world* w) : world(w) {}
+		Body* TryGetBody(const BodyID& id) const;          // valid until the next TryGetBody call
+	private:
+		sgp_world* world; mutable Body scratch;
+	};
+
 	class VehicleConstraint;      // Jolt/JoltVehicleLite.h
 	class PhysicsStepListener;
 
 	class PhysicsSystem
 	{
 	public:
-		explicit PhysicsSystem(sgp_world* w) : world(w), body_interface(w), step_serial(0) {}
+		explicit PhysicsSystem(sgp_world* w) : world(w), body_interface(w), body_lock_interface(w), step_serial(0) {}
+		const BodyLockInterface& GetBodyLockInterface() const { return body_lock_interface; }
 		BodyInterface& GetBodyInterface() { return body_interface; }
 		const BodyInterface& GetBodyInterface() const { return body_interface; }
 		Vec3 GetGravity() const { return Vec3(0, 0, -9.81f); }   // PhysicsWorld.cpp:520
@@ -135,6 +149,7 @@ namespace JPH
 		sgp_world* world;
 	private:
 		BodyInterface body_interface;
+		BodyLockInterface body_lock_interface;
 		uint64_t step_serial;
 	};
 }

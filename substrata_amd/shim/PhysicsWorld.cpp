@@ -416,3 +416,14 @@ void JPH::PhysicsSystem::RemoveConstraint(VehicleConstraint* c)
 	sgp_vehicle_destroy(world, c->GetVehicleID());
 	c->unbind();
 }
+
+JPH::Body* JPH::BodyLockInterface::TryGetBody(const BodyID& id) const
+{
+	float vol = 0.f;
+	if (id.IsInvalid() || sgp_body_get_volume(world, id.GetIndex(), &vol) != SGP_OK) return nullptr;
+	sgp_body_state st;
+	const uint32_t i = id.GetIndex();
+	if (sgp_body_get_state(world, &i, 1, &st) != SGP_OK) return nullptr;
+	scratch.id = id; scratch.shape.volume = vol; scratch.lin_vel = Vec3(st.lin_vel[0], st.lin_vel[1], st.lin_vel[2]);
+	return &scratch;
+}

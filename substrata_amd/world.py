@@ -97,6 +97,11 @@ class CWorld:
     def activate(self, i):
         self._check(self._fn("body_activate")(self._h, int(i)), "body_activate")
 
+    def get_volume(self, i):
+        v = C.c_float(0.0)
+        self._check(self._fn("body_get_volume")(self._h, int(i), C.byref(v)), "body_get_volume")
+        return v.value
+
     def set_layer(self, i, layer):
         self._check(self._fn("body_set_layer")(self._h, int(i), int(layer)), "body_set_layer")
 

@@ -38,6 +38,11 @@ int main()
 		bi.GetLinearAndAngularVelocity(car->jolt_body_id, lv, av);
 		const float yaw = 2.f * std::atan2(q.GetZ(), q.GetW());
 		printf("z %.4f vz %.4f yaw %.4f wz %.4f active %d\n", p.GetZ(), lv.GetZ(), yaw, av.GetZ(), (int)bi.IsActive(car->jolt_body_id));
+		// BoatPhysics.cpp:40-43: shape volume through the body lock interface (2 x 4 x 1 box)
+		const JPH::Body* locked = world->physics_system->GetBodyLockInterface().TryGetBody(car->jolt_body_id);
+		const float volume = locked ? locked->GetShape()->GetVolume() : -1.f;
+		printf("volume %.3f\n", volume);
+		if (std::fabs(volume - 8.f) > 1e-4f) return 3;
 		const bool ok = std::fabs(p.GetZ() - target_z) < 0.05f && std::fabs(lv.GetZ()) < 0.05f && yaw > 0.3f;
 		return ok ? 0 : 1;
 	} catch (glare::Exception& e) { fprintf(stderr, "glare::Exception: %s\n", e.what().c_str()); return 2; }
