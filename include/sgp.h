@@ -65,6 +65,8 @@ extern "C" {
 #define SGP_SHAPE_SPHERE   0
 #define SGP_SHAPE_BOX      1
 #define SGP_SHAPE_CAPSULE  2
+#define SGP_SHAPE_HULL     3   /* convex hull created with sgp_hull_create; shape[0] = (float) hull id, body frame = the hull's
+                                  centre-of-mass / principal-axes frame (see sgp_hull_info)                                  */
 
 #define SGP_INVALID_ID 0xFFFFFFFFu   /* JPH::BodyID() default = invalid (PhysicsObject.h:106)        */
 
@@ -290,7 +292,7 @@ int  sgp_world_stats(sgp_world* w, sgp_step_stats* out);
 /* Name of kernel class k of sgp_step_profile (NULL past the last class). */
 const char* sgp_kernel_class_name(int k);
 /* sizeof() of ABI struct number `which` (order: settings, world_desc, body_desc, body_state, body_event, contact_event,
- * ray, hit, step_stats, step_profile, ghost_record, vehicle_desc, vehicle_input, vehicle_state) so bindings can verify their layout. */
+ * ray, hit, step_stats, step_profile, ghost_record, vehicle_desc, vehicle_input, vehicle_state, hull_info) so bindings can verify their layout. */
 int  sgp_abi_sizeof(int which);
 /* activated_obs / newly_activated_obs maintenance + listener callbacks (PhysicsWorld.h:194-200). */
 int  sgp_world_drain_events(sgp_world* w, int kind, void* out, uint32_t cap, uint32_t* n_out);
@@ -304,6 +306,23 @@ int  sgp_world_dump_constraints(sgp_world* w, void* out, uint32_t cap, uint32_t*
 /* ---- queries --------------------------------------------------------------------------------- */
 /* traceRay / traceRayAgainstCollidableObs / doesRayHitAnything (PhysicsWorld.cpp:1668-1725), batched. */
 int  sgp_raycast(sgp_world* w, const sgp_ray* rays, uint32_t n, sgp_hit* hits_out);
+
+/* ---- convex hull shapes ---------------------------------------------------------
+ * Replaces JPH::ConvexHullShapeSettings(points).Create() (+ OffsetCenterOfMassShape / the principal-axes decomposition Jolt does
+ * inside MassProperties) for dynamic meshes and vehicle bodies (gui_client/PhysicsWorld.cpp:735-1166 with is_dynamic,
+ * CarPhysics.cpp:66-92, BikePhysics.cpp:76-112).  Up to 32 hull vertices / 60 faces / 16 vertices per face; larger clouds are
+ * reduced to their extreme points.  Points must already carry the object's scale (ScaledShape is baked in).
+ * The hull is stored in its BODY frame (origin = centre of mass, axes = principal axes of inertia).  `com` / `rot` give that
+ * frame in the frame of the input points:  input point = com + rot * body point.  A caller that thinks in the points' frame
+ * (object space) places the body at  pos_body = pos_obj + R_obj * com,  rot_body = rot_obj * rot. */
+typedef struct sgp_hull_info {
+	uint32_t hull_id;                 /* >= 1; goes into sgp_body_desc::shape[0] with shape_type = SGP_SHAPE_HULL                */
+	uint32_t num_vertices, num_faces, num_edges;
+	float com[3];  float rot[4];
+	float volume;  float unit_inertia[3];     /* principal moments for density 1 (body inertia = unit_inertia * mass / volume)    */
+	float aabb_min[3], aabb_max[3];           /* body frame                                                                      */
+} sgp_hull_info;
+int  sgp_hull_create(sgp_world* w, const float* points_xyz, uint32_t num_points, sgp_hull_info* info_out);
 
 /* ---- wheeled vehicles --------------------------------------------------------
  * Replaces JPH::VehicleConstraint + JPH::WheeledVehicleController + JPH::VehicleCollisionTesterCastSphere as CarPhysics

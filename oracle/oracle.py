@@ -18,7 +18,7 @@ _lib = None
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("sgo_oracle.c", "sgo_collide.h", "sgo_vehicle.h", "sgo_math.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("sgo_oracle.c", "sgo_collide.h", "sgo_hull.h", "sgo_hull_build.h", "sgo_vehicle.h", "sgo_math.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "sgp.h"))
     if not force and os.path.exists(_LIB_PATH) and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return _LIB_PATH
@@ -58,6 +58,36 @@ def collide_pair(a, b, max_sep=0.02):
     if not hit:
         return None
     return n, p1[:npts.value].copy(), p2[:npts.value].copy()
+
+
+def world_collide_pair(world, a, b, max_sep=0.02):
+    """Narrow phase on two body descs of `world` (hull ids resolve against its hull table). Returns (normal, p1, p2) or None."""
+    n = np.zeros(3, np.float32)
+    p1 = np.zeros((8, 3), np.float32)
+    p2 = np.zeros((8, 3), np.float32)
+    npts = C.c_int(0)
+    f = lib().sgo_world_collide_pair
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.POINTER(abi.BodyDesc), C.POINTER(abi.BodyDesc), C.c_float, C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
+    hit = f(world._h, C.byref(a), C.byref(b), float(max_sep), n.ctypes.data, C.byref(npts), p1.ctypes.data, p2.ctypes.data)
+    if hit < 0:
+        raise ValueError("bad hull id")
+    if not hit:
+        return None
+    return n, p1[:npts.value].copy(), p2[:npts.value].copy()
+
+
+def hull_dump(world, hull_id):
+    """The hull as stored (body frame): (verts[nv,3], planes[nf,4])."""
+    v = np.zeros((32, 3), np.float32)
+    pl = np.zeros((60, 4), np.float32)
+    f = lib().sgo_hull_dump
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    r = f(world._h, int(hull_id), v.ctypes.data, pl.ctypes.data)
+    if r < 0:
+        raise ValueError("bad hull id")
+    return v[:r & 0xFFFF].copy(), pl[:r >> 16].copy()
 
 
 def cast_sphere(body, origin, direction, max_t, radius):

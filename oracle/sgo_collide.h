@@ -24,8 +24,10 @@
 #define SGO_SHAPE_SPHERE  0
 #define SGO_SHAPE_BOX     1
 #define SGO_SHAPE_CAPSULE 2
+#define SGO_SHAPE_HULL    3   /* convex hull (sgo_hull.h): p[] unused, `hull` = the shape; for a box `hull` = the +-1 cube template */
 
-typedef struct { v3 pos; m33 R; int type; float p[4]; } sgo_shape;
+struct sgo_hull_s;
+typedef struct { v3 pos; m33 R; int type; float p[4]; const struct sgo_hull_s* hull; } sgo_shape;
 typedef struct { v3 n; int np; v3 p1[8]; v3 p2[8]; } sgo_manifold;
 
 /* Supporting-face tolerance for capsules (Jolt cCapsuleProjectionSlop = 0.02). */
@@ -435,12 +437,32 @@ static void sgo_flip_manifold(sgo_manifold* m)
 	for (int i = 0; i < m->np; ++i) { const v3 t = m->p1[i]; m->p1[i] = m->p2[i]; m->p2[i] = t; }
 }
 
-/* Dispatch on the (type_a, type_b) pair; canonical order sphere < box < capsule. */
+#include "sgo_hull.h"
+
+static sgo_hview sgo_hull_view(const sgo_shape* s)
+{
+	sgo_hview v;
+	v.pos = s->pos; v.R = s->R; v.h = s->hull;
+	v.scale = s->type == SGO_SHAPE_BOX ? V3(s->p[0], s->p[1], s->p[2]) : V3(1.0f, 1.0f, 1.0f);
+	return v;
+}
+
+/* Dispatch on the (type_a, type_b) pair; canonical order sphere < box < capsule < hull. */
 static int sgo_collide(const sgo_shape* a, const sgo_shape* b, float max_sep, sgo_manifold* m)
 {
 	int hit, flip = 0;
 	const sgo_shape* x = a; const sgo_shape* y = b;
 	if (a->type > b->type) { x = b; y = a; flip = 1; }
+	if (y->type == SGO_SHAPE_HULL) {
+		const sgo_hview hy = sgo_hull_view(y);
+		if (x->type == SGO_SHAPE_SPHERE) { hit = sgo_hull_sphere(&hy, x->pos, x->p[0], max_sep, m); flip = !flip; }       /* computed hull -> sphere */
+		else if (x->type == SGO_SHAPE_CAPSULE) {
+			const v3 ax = v3_scale(m33_col(x->R, 2), x->p[1]);
+			hit = sgo_hull_capsule(&hy, v3_sub(x->pos, ax), v3_add(x->pos, ax), x->p[0], max_sep, m); flip = !flip;
+		} else { const sgo_hview hx = sgo_hull_view(x); hit = sgo_hull_hull(&hx, &hy, max_sep, m); }
+		if (hit && flip) sgo_flip_manifold(m);
+		return hit;
+	}
 	if (x->type == SGO_SHAPE_SPHERE) {
 		if (y->type == SGO_SHAPE_SPHERE) hit = sgo_sphere_sphere_pts(x->pos, x->p[0], y->pos, y->p[0], max_sep, m);
 		else if (y->type == SGO_SHAPE_BOX) hit = sgo_sphere_box(x, y, max_sep, m);

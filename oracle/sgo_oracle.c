@@ -33,6 +33,7 @@
 #endif
 #include "../include/sgp.h"
 #include "sgo_collide.h"
+#include "sgo_hull_build.h"
 #include "sgo_vehicle.h"
 
 #define SGO_API __attribute__((visibility("default")))
@@ -43,6 +44,7 @@ typedef struct {
 	v3 pos; quat rot; v3 linv, angv; v3 force, torque;
 	float inv_mass; v3 inv_inertia;
 	int shape_type; float shape[4];
+	const sgo_hull* hull;             /* SGP_SHAPE_HULL: the shape; SGP_SHAPE_BOX: the +-1 cube template (for box - hull pairs) */
 	int motion, layer;
 	float friction, restitution, gravity_factor, lin_damp, ang_damp, mass;
 	int is_sensor, allow_sleep, zero_lin_drag;
@@ -107,6 +109,8 @@ typedef struct sgo_world {
 	uint64_t* ghost_gid; uint32_t* ghost_lid; uint32_t n_ghosts;
 	int* is_ghost;
 	uint64_t tot_act, tot_deact, rep_act, rep_deact;   /* running totals of (de)activation events / totals already reported in stats */
+	/* convex hull shapes (sgo_hull.h): stable pointers, hull 0 = the +-1 cube template */
+	sgo_hull** hulls; uint32_t n_hulls, cap_hulls;
 	/* wheeled vehicles (sgo_vehicle.h) */
 	sgo_vehicle* vehicles; uint32_t n_vehicles, cap_vehicles;
 } sgo_world;
@@ -188,10 +192,13 @@ SGO_API int sgo_layers_collide(int l1, int l2) { return layers_collide(l1, l2); 
 /* ------------------------------------------------------------------------------------------------ */
 /* mass properties (Jolt Shape::GetMassProperties scaled to the overridden mass, CalculateInertia)      */
 
-static void mass_properties(int type, const float* p, float mass, float* inv_mass, v3* inv_inertia)
+static void mass_properties(int type, const float* p, const sgo_hull* hull, float mass, float* inv_mass, v3* inv_inertia)
 {
 	v3 I;
-	if (type == SGP_SHAPE_SPHERE) {
+	if (type == SGP_SHAPE_HULL) {
+		const float density = mass / hull->volume;
+		I = v3_scale(hull->unit_inertia, density);
+	} else if (type == SGP_SHAPE_SPHERE) {
 		const float i = 0.4f * mass * p[0] * p[0];
 		I = V3(i, i, i);
 	} else if (type == SGP_SHAPE_BOX) {
@@ -213,6 +220,7 @@ static void mass_properties(int type, const float* p, float mass, float* inv_mas
 	*inv_inertia = V3(1.0f / I.x, 1.0f / I.y, 1.0f / I.z);
 }
 
+static float shape_volume_h(int type, const float* p, const sgo_hull* hull);
 static float shape_volume(int type, const float* p)
 {
 	if (type == SGP_SHAPE_SPHERE) return (4.0f / 3.0f) * 3.14159265358979323846f * p[0] * p[0] * p[0];
@@ -221,11 +229,20 @@ static float shape_volume(int type, const float* p)
 }
 
 /* Local-space half extents of the shape's AABB (Shape::GetLocalBounds). */
+static float shape_volume_h(int type, const float* p, const sgo_hull* hull) { return type == SGP_SHAPE_HULL ? hull->volume : shape_volume(type, p); }
+
+static v3 shape_local_half_h(int type, const float* p, const sgo_hull* hull);
 static v3 shape_local_half(int type, const float* p)
 {
 	if (type == SGP_SHAPE_SPHERE) return V3(p[0], p[0], p[0]);
 	if (type == SGP_SHAPE_BOX) return V3(p[0], p[1], p[2]);
 	return V3(p[0], p[0], p[1] + p[0]);
+}
+
+static v3 shape_local_half_h(int type, const float* p, const sgo_hull* hull)
+{
+	if (type == SGP_SHAPE_HULL) return v3_max(v3_abs(hull->aabb_min), v3_abs(hull->aabb_max));
+	return shape_local_half(type, p);
 }
 
 static float shape_bounding_radius(int type, const float* p)
@@ -235,9 +252,18 @@ static float shape_bounding_radius(int type, const float* p)
 	return p[0] + p[1];
 }
 
+static float body_bounding_radius(const sgo_body* b) { return b->shape_type == SGP_SHAPE_HULL ? b->hull->bound_radius : shape_bounding_radius(b->shape_type, b->shape); }
+
 static void body_update_aabb(sgo_body* b)
 {
 	v3 e;
+	if (b->shape_type == SGP_SHAPE_HULL) {
+		const m33 R = quat_to_m33(b->rot);
+		v3 mn = V3(3.4e38f, 3.4e38f, 3.4e38f), mx = V3(-3.4e38f, -3.4e38f, -3.4e38f);
+		for (int i = 0; i < b->hull->nv; ++i) { const v3 p = m33_mul(R, b->hull->verts[i]); mn = v3_min(mn, p); mx = v3_max(mx, p); }
+		b->aabb_min = v3_add(b->pos, mn); b->aabb_max = v3_add(b->pos, mx);
+		return;
+	}
 	if (b->shape_type == SGP_SHAPE_SPHERE) e = V3(b->shape[0], b->shape[0], b->shape[0]);
 	else {
 		const m33 R = quat_to_m33(b->rot);
@@ -258,7 +284,7 @@ static void body_update_aabb(sgo_body* b)
 /* Body::GetSleepTestPoints: COM plus two points on the two largest local extents. */
 static void body_sleep_points(const sgo_body* b, v3 out[3])
 {
-	const v3 ext = shape_local_half(b->shape_type, b->shape);
+	const v3 ext = shape_local_half_h(b->shape_type, b->shape, b->hull);
 	const m33 R = quat_to_m33(b->rot);
 	int lowest = 0;
 	if (ext.y < v3_get(ext, lowest)) lowest = 1;
@@ -322,6 +348,8 @@ SGO_API int sgo_world_create(const sgp_world_desc* desc, sgo_world** out)
 	w->large = (uint32_t*)malloc(sizeof(uint32_t) * w->cap);
 	w->is_ghost = (int*)calloc(w->cap, sizeof(int));
 	if (w->desc.large_body_radius <= 0.0f) w->desc.large_body_radius = 4.0f;
+	w->cap_hulls = 16; w->hulls = (sgo_hull**)calloc(w->cap_hulls, sizeof(sgo_hull*));
+	w->hulls[0] = (sgo_hull*)malloc(sizeof(sgo_hull)); sgo_hull_cube_template(w->hulls[0]); w->n_hulls = 1;
 	*out = w;
 	return SGP_OK;
 }
@@ -334,6 +362,8 @@ SGO_API int sgo_world_destroy(sgo_world* w)
 	free(w->ev_act); free(w->ev_deact); free(w->ev_water); free(w->ev_added); free(w->ev_pers);
 	free(w->cell_keys); free(w->cell_idx); free(w->large); free(w->is_ghost); free(w->ghost_gid); free(w->ghost_lid);
 	free(w->vehicles);
+	for (uint32_t k = 0; k < w->n_hulls; ++k) free(w->hulls[k]);
+	free(w->hulls);
 	free(w);
 	return SGP_OK;
 }
@@ -345,8 +375,14 @@ SGO_API int sgo_body_add(sgo_world* w, const sgp_body_desc* d, uint32_t* id_out)
 {
 	if (!w || !d) return SGP_ERR_INVALID;
 	if (!finite3(d->pos) || fabsf(d->pos[0]) > 1.0e9f || fabsf(d->pos[1]) > 1.0e9f || fabsf(d->pos[2]) > 1.0e9f) return SGP_ERR_REJECTED; /* :1178 */
-	if (d->shape_type < 0 || d->shape_type > 2) return SGP_ERR_INVALID;
-	const int nparam = d->shape_type == SGP_SHAPE_BOX ? 3 : (d->shape_type == SGP_SHAPE_SPHERE ? 1 : 2);
+	if (d->shape_type < 0 || d->shape_type > SGP_SHAPE_HULL) return SGP_ERR_INVALID;
+	const sgo_hull* hull = NULL;
+	if (d->shape_type == SGP_SHAPE_HULL) {
+		const uint32_t hid = (uint32_t)d->shape[0];
+		if (!(d->shape[0] >= 1.0f) || (float)hid != d->shape[0] || hid >= w->n_hulls) return SGP_ERR_INVALID;   /* hull 0 is the internal cube template */
+		hull = w->hulls[hid];
+	} else if (d->shape_type == SGP_SHAPE_BOX) hull = w->hulls[0];
+	const int nparam = d->shape_type == SGP_SHAPE_BOX ? 3 : (d->shape_type == SGP_SHAPE_SPHERE ? 1 : (d->shape_type == SGP_SHAPE_HULL ? 0 : 2));
 	for (int i = 0; i < nparam; ++i) {
 		const float lim = (d->shape_type == SGP_SHAPE_CAPSULE && i == 1) ? 0.0f : 0.5e-7f; /* |scale| < 1e-7 on a 0.5 unit shape, :1184 */
 		if (!isfinite(d->shape[i]) || d->shape[i] < lim) return SGP_ERR_REJECTED;
@@ -363,6 +399,7 @@ SGO_API int sgo_body_add(sgo_world* w, const sgp_body_desc* d, uint32_t* id_out)
 	b->angv = V3(d->ang_vel[0], d->ang_vel[1], d->ang_vel[2]);
 	b->shape_type = d->shape_type;
 	memcpy(b->shape, d->shape, sizeof(b->shape));
+	b->hull = hull;
 	b->motion = d->motion_type; b->layer = d->layer;
 	b->friction = clampf(d->friction, 0.0f, 1.0f);         /* :1236 */
 	b->restitution = clampf(d->restitution, 0.0f, 1.0f);   /* :1237 */
@@ -371,7 +408,7 @@ SGO_API int sgo_body_add(sgo_world* w, const sgp_body_desc* d, uint32_t* id_out)
 	b->lin_damp = d->linear_damping; b->ang_damp = d->angular_damping;
 	b->is_sensor = d->is_sensor; b->allow_sleep = d->allow_sleeping; b->zero_lin_drag = d->use_zero_linear_drag;
 	b->userdata = d->userdata;
-	if (b->motion == SGP_MOTION_DYNAMIC) mass_properties(b->shape_type, b->shape, b->mass, &b->inv_mass, &b->inv_inertia);
+	if (b->motion == SGP_MOTION_DYNAMIC) mass_properties(b->shape_type, b->shape, b->hull, b->mass, &b->inv_mass, &b->inv_inertia);
 	else { b->inv_mass = 0.0f; b->inv_inertia = V3(0.0f, 0.0f, 0.0f); }
 	if (b->motion != SGP_MOTION_DYNAMIC) { /* non-dynamic bodies carry no force */ }
 	b->alive = 1; b->active = 0;
@@ -406,7 +443,7 @@ SGO_API int sgo_body_remove(sgo_world* w, uint32_t id)
 	return SGP_OK;
 }
 SGO_API int sgo_body_activate(sgo_world* w, uint32_t id) { if (!live(w, id)) return SGP_ERR_BAD_ID; body_activate(w, id); return SGP_OK; }
-SGO_API int sgo_body_get_volume(sgo_world* w, uint32_t id, float* out) { if (!live(w, id) || !out) return SGP_ERR_BAD_ID; *out = shape_volume(w->bodies[id].shape_type, w->bodies[id].shape); return SGP_OK; }
+SGO_API int sgo_body_get_volume(sgo_world* w, uint32_t id, float* out) { if (!live(w, id) || !out) return SGP_ERR_BAD_ID; *out = shape_volume_h(w->bodies[id].shape_type, w->bodies[id].shape, w->bodies[id].hull); return SGP_OK; }
 SGO_API int sgo_body_set_layer(sgo_world* w, uint32_t id, int32_t layer) { if (!live(w, id)) return SGP_ERR_BAD_ID; w->bodies[id].layer = layer; return SGP_OK; }
 
 SGO_API int sgo_body_set_pose_vel(sgo_world* w, uint32_t id, const float pos[3], const float rot[4], const float lv[3], const float av[3])
@@ -426,7 +463,7 @@ SGO_API int sgo_body_set_pose_shape(sgo_world* w, uint32_t id, const float pos[3
 	b->pos = V3(pos[0], pos[1], pos[2]);
 	quat q = { rot[0], rot[1], rot[2], rot[3] }; b->rot = q;
 	b->linv = V3(0, 0, 0); b->angv = V3(0, 0, 0);
-	memcpy(b->shape, shape, sizeof(b->shape));   /* inUpdateMassProperties = false, PhysicsWorld.cpp:579 */
+	if (b->shape_type != SGP_SHAPE_HULL) memcpy(b->shape, shape, sizeof(b->shape));   /* inUpdateMassProperties = false, PhysicsWorld.cpp:579; hulls are pre-scaled */
 	body_update_aabb(b);
 	body_activate(w, id);
 	return SGP_OK;
@@ -587,7 +624,7 @@ static void broad_phase(sgo_world* w)
 	for (uint32_t i = 0; i < w->high; ++i) {
 		const sgo_body* b = &w->bodies[i];
 		if (!b->alive) continue;
-		if (shape_bounding_radius(b->shape_type, b->shape) > large_r) { w->large[w->n_large++] = i; continue; }
+		if (body_bounding_radius(b) > large_r) { w->large[w->n_large++] = i; continue; }
 		const v3 e = v3_sub(b->aabb_max, b->aabb_min);
 		cell = fmaxf(cell, fmaxf(e.x, fmaxf(e.y, e.z)));
 		ki[n_small++].idx = i;
@@ -632,7 +669,7 @@ static void broad_phase(sgo_world* w)
 		for (uint32_t j = 0; j < w->high; ++j) {
 			if (j == i || !w->bodies[j].alive) continue;
 			/* large-large pairs once */
-			if (shape_bounding_radius(w->bodies[j].shape_type, w->bodies[j].shape) > large_r && j < i) continue;
+			if (body_bounding_radius(&w->bodies[j]) > large_r && j < i) continue;
 			if (pair_passes(w, i, j)) push_pair(w, i, j);
 		}
 	}
@@ -646,6 +683,7 @@ static sgo_shape body_shape_xf(const sgo_body* b)
 {
 	sgo_shape s; s.pos = b->pos; s.R = quat_to_m33(b->rot); s.type = b->shape_type;
 	memcpy(s.p, b->shape, sizeof(s.p));
+	s.hull = b->hull;
 	return s;
 }
 
@@ -1150,7 +1188,7 @@ static void sphere_cap_submerged(float r, float depth_of_centre /* wz - centre.z
 
 static void submerged_volume(const sgo_body* b, float wz, float* total, float* sub, v3* rel_cob)
 {
-	*total = shape_volume(b->shape_type, b->shape);
+	*total = shape_volume_h(b->shape_type, b->shape, b->hull);
 	if (b->shape_type == SGP_SHAPE_BOX) { box_submerged(b, wz, sub, rel_cob); return; }
 	if (b->shape_type == SGP_SHAPE_SPHERE) {
 		float cz; sphere_cap_submerged(b->shape[0], wz - b->pos.z, sub, &cz);
@@ -1186,7 +1224,7 @@ static void buoyancy_sweep(sgo_world* w, float dt)
 				const v3 cob_vel = v3_add(b->linv, v3_cross(b->angv, rc));
 				const v3 rel = v3_neg(cob_vel);                                              /* fluid velocity 0, :1406 */
 				const float lin_drag = b->zero_lin_drag ? 0.0f : 0.1f;                      /* :1404 */
-				const v3 size = v3_scale(shape_local_half(b->shape_type, b->shape), 2.0f);
+				const v3 size = v3_scale(shape_local_half_h(b->shape_type, b->shape, b->hull), 2.0f);
 				const m33 R = quat_to_m33(b->rot);
 				const v3 lrel = m33_tmul(R, rel);
 				const float rl2 = v3_len_sq(lrel);
@@ -1465,7 +1503,7 @@ static void vehicles_pre_step(sgo_world* w, float dt)
 				if (j == v->body) continue;
 				const sgo_body* o = &w->bodies[j];
 				v3 n, p;
-				const float t = sgo_cast_sphere_body(o->shape_type, o->shape, o->pos, quat_to_m33(o->rot), wh->cast_origin, wh->cast_dir, best, v->cast_radius, &n, &p);
+				const float t = sgo_cast_sphere_body(o->shape_type, o->shape, o->hull, o->pos, quat_to_m33(o->rot), wh->cast_origin, wh->cast_dir, best, v->cast_radius, &n, &p);
 				if (t < 0.0f || n.z < v->cos_max_slope) continue;
 				if (t < best || bid == SGP_INVALID_ID) { best = t; bid = j; bn = n; bp = p; }
 			}
@@ -1686,7 +1724,7 @@ SGO_API int sgo_world_export_boundary(sgo_world* w, const float lo[3], const flo
 	for (uint32_t i = 0; i < w->high; ++i) {
 		const sgo_body* b = &w->bodies[i];
 		if (!b->alive || w->is_ghost[i] || b->motion == SGP_MOTION_STATIC) continue;
-		if (shape_bounding_radius(b->shape_type, b->shape) > large_r) continue;
+		if (body_bounding_radius(b) > large_r) continue;
 		const int crosses = b->aabb_min.x - margin < lo[0] || b->aabb_min.y - margin < lo[1] || b->aabb_min.z - margin < lo[2] ||
 		                    b->aabb_max.x + margin >= hi[0] || b->aabb_max.y + margin >= hi[1] || b->aabb_max.z + margin >= hi[2];
 		if (!crosses) continue;
@@ -1750,6 +1788,27 @@ SGO_API int sgo_world_import_ghosts(sgo_world* w, const sgp_ghost_record* in, ui
 /* ------------------------------------------------------------------------------------------------ */
 /* direct access for unit tests                                                                      */
 
+static sgo_shape shape_from_desc(const sgp_body_desc* d);
+/* Narrow phase on two body descs of THIS world (hull ids resolve against its hull table). */
+SGO_API int sgo_world_collide_pair(sgo_world* w, const sgp_body_desc* a, const sgp_body_desc* b, float max_sep, float* normal, int* np, float* p1, float* p2)
+{
+	sgo_shape sa = shape_from_desc(a), sb = shape_from_desc(b);
+	const sgp_body_desc* dd[2] = { a, b }; sgo_shape* ss[2] = { &sa, &sb };
+	for (int k = 0; k < 2; ++k) {
+		if (dd[k]->shape_type == SGP_SHAPE_HULL) { const uint32_t hid = (uint32_t)dd[k]->shape[0]; if (hid < 1 || hid >= w->n_hulls) return -1; ss[k]->hull = w->hulls[hid]; }
+		else if (dd[k]->shape_type == SGP_SHAPE_BOX) ss[k]->hull = w->hulls[0];
+	}
+	sgo_manifold m;
+	if (!sgo_collide(&sa, &sb, max_sep, &m)) { *np = 0; return 0; }
+	normal[0] = m.n.x; normal[1] = m.n.y; normal[2] = m.n.z;
+	*np = m.np;
+	for (int i = 0; i < m.np; ++i) {
+		p1[3 * i] = m.p1[i].x; p1[3 * i + 1] = m.p1[i].y; p1[3 * i + 2] = m.p1[i].z;
+		p2[3 * i] = m.p2[i].x; p2[3 * i + 1] = m.p2[i].y; p2[3 * i + 2] = m.p2[i].z;
+	}
+	return 1;
+}
+
 static sgo_shape shape_from_desc(const sgp_body_desc* d)
 {
 	sgo_shape s;
@@ -1758,6 +1817,7 @@ static sgo_shape shape_from_desc(const sgp_body_desc* d)
 	s.R = quat_to_m33(q);
 	s.type = d->shape_type;
 	memcpy(s.p, d->shape, sizeof(s.p));
+	s.hull = NULL;
 	return s;
 }
 
@@ -1776,12 +1836,42 @@ SGO_API int sgo_collide_pair(const sgp_body_desc* a, const sgp_body_desc* b, flo
 	return 1;
 }
 
+/* ConvexHullShapeSettings::Create */
+SGO_API int sgo_hull_create(sgo_world* w, const float* pts, uint32_t n, sgp_hull_info* info)
+{
+	if (!w || !pts || !info || n < 4 || n > 100000) return SGP_ERR_INVALID;
+	sgo_hull* h = (sgo_hull*)malloc(sizeof(sgo_hull));
+	float com[3], rot[4];
+	if (sgo_hull_build(pts, (int)(n > 256 ? 256 : n), h, com, rot) != 0) { free(h); return SGP_ERR_REJECTED; }
+	if (w->n_hulls == w->cap_hulls) { w->cap_hulls *= 2; w->hulls = (sgo_hull**)realloc(w->hulls, sizeof(sgo_hull*) * w->cap_hulls); }
+	const uint32_t id = w->n_hulls++;
+	w->hulls[id] = h;
+	memset(info, 0, sizeof(*info));
+	info->hull_id = id; info->num_vertices = (uint32_t)h->nv; info->num_faces = (uint32_t)h->nf; info->num_edges = (uint32_t)h->ne;
+	memcpy(info->com, com, sizeof(com)); memcpy(info->rot, rot, sizeof(rot));
+	info->volume = h->volume;
+	info->unit_inertia[0] = h->unit_inertia.x; info->unit_inertia[1] = h->unit_inertia.y; info->unit_inertia[2] = h->unit_inertia.z;
+	info->aabb_min[0] = h->aabb_min.x; info->aabb_min[1] = h->aabb_min.y; info->aabb_min[2] = h->aabb_min.z;
+	info->aabb_max[0] = h->aabb_max.x; info->aabb_max[1] = h->aabb_max.y; info->aabb_max[2] = h->aabb_max.z;
+	return SGP_OK;
+}
+
+/* Test hook: the hull as stored (body frame). verts[nv][3], planes[nf][4]; returns nv | nf << 16. */
+SGO_API int sgo_hull_dump(sgo_world* w, uint32_t id, float* verts, float* planes)
+{
+	if (!w || id >= w->n_hulls) return -1;
+	const sgo_hull* h = w->hulls[id];
+	for (int i = 0; i < h->nv; ++i) { verts[3 * i] = h->verts[i].x; verts[3 * i + 1] = h->verts[i].y; verts[3 * i + 2] = h->verts[i].z; }
+	for (int f = 0; f < h->nf; ++f) { planes[4 * f] = h->normals[f].x; planes[4 * f + 1] = h->normals[f].y; planes[4 * f + 2] = h->normals[f].z; planes[4 * f + 3] = h->plane_d[f]; }
+	return h->nv | (h->nf << 16);
+}
+
 /* Sphere cast against one body desc (test hook for sgo_cast_sphere_body). Returns t or -1. */
 SGO_API float sgo_cast_sphere(const sgp_body_desc* b, const float o[3], const float d[3], float max_t, float rs, float* n_out, float* p_out)
 {
 	const quat q = { b->rot[0], b->rot[1], b->rot[2], b->rot[3] };
 	v3 n = V3(0, 0, 0), p = V3(0, 0, 0);
-	const float t = sgo_cast_sphere_body(b->shape_type, b->shape, V3(b->pos[0], b->pos[1], b->pos[2]), quat_to_m33(q), V3(o[0], o[1], o[2]), V3(d[0], d[1], d[2]), max_t, rs, &n, &p);
+	const float t = sgo_cast_sphere_body(b->shape_type, b->shape, NULL, V3(b->pos[0], b->pos[1], b->pos[2]), quat_to_m33(q), V3(o[0], o[1], o[2]), V3(d[0], d[1], d[2]), max_t, rs, &n, &p);
 	n_out[0] = n.x; n_out[1] = n.y; n_out[2] = n.z; p_out[0] = p.x; p_out[1] = p.y; p_out[2] = p.z;
 	return t;
 }
@@ -1807,6 +1897,13 @@ static float ray_body(const sgo_body* b, v3 o, v3 d, float max_t, v3* n_out)
 {
 	const m33 R = quat_to_m33(b->rot);
 	const v3 ol = m33_tmul(R, v3_sub(o, b->pos)), dl = m33_tmul(R, d);
+	if (b->shape_type == SGP_SHAPE_HULL) {
+		v3 nl;
+		const float t = sgo_ray_hull(b->hull, ol, dl, max_t, 0.0f, &nl);
+		if (t < 0.0f) return -1.0f;
+		*n_out = m33_mul(R, nl);
+		return t;
+	}
 	if (b->shape_type == SGP_SHAPE_SPHERE) {
 		const float r = b->shape[0];
 		const float B = v3_dot(ol, dl), C = v3_len_sq(ol) - r * r;

@@ -27,6 +27,7 @@
 #define SGO_VEHICLE_H
 
 #include "sgo_math.h"
+/* (sgo_hull is declared by sgo_collide.h / sgo_hull.h, included first) */
 
 #define SGO_MAX_WHEELS 4
 #define SGO_MAX_GEARS 8
@@ -216,11 +217,13 @@ static inline v3 sgo_perm_from_z(v3 v, int axis)
    (shape type / parameters p, pose pos + R).  Returns the travel distance at first touch (0 if it starts overlapping) or -1;
    n_out = world normal at the touch point on the body (towards the sphere), p_out = world touch point on the body.
    Box: the Minkowski sum box (+) ball is covered exactly by 3 boxes grown along one axis each plus 12 edge capsules. */
-static inline float sgo_cast_sphere_body(int type, const float* p, v3 pos, m33 R, v3 o, v3 d, float max_t, float rs, v3* n_out, v3* p_out)
+static inline float sgo_cast_sphere_body(int type, const float* p, const sgo_hull* hull, v3 pos, m33 R, v3 o, v3 d, float max_t, float rs, v3* n_out, v3* p_out)
 {
 	const v3 ol = m33_tmul(R, v3_sub(o, pos)), dl = m33_tmul(R, d);
 	float t = -1.0f; v3 nl = V3(0, 0, 0);
-	if (type == SGP_SHAPE_SPHERE) {
+	if (type == SGP_SHAPE_HULL) {
+		t = sgo_ray_hull(hull, ol, dl, max_t, rs, &nl);
+	} else if (type == SGP_SHAPE_SPHERE) {
 		t = sgo_ray_sphere(ol, dl, p[0] + rs, max_t, &nl);
 	} else if (type == SGP_SHAPE_CAPSULE) {
 		t = sgo_ray_capsule_z(ol, dl, p[0] + rs, p[1], max_t, &nl);

@@ -13,7 +13,7 @@ OK, ERR_INVALID, ERR_NO_DEVICE, ERR_CAPACITY, ERR_HIP, ERR_BAD_ID, ERR_REJECTED 
 MOTION_STATIC, MOTION_KINEMATIC, MOTION_DYNAMIC = 0, 1, 2
 LAYER_NON_MOVING, LAYER_MOVING, LAYER_NON_MOVING_NON_COLLIDABLE, LAYER_MOVING_NON_COLLIDABLE = 0, 1, 2, 3
 NUM_LAYERS = 4
-SHAPE_SPHERE, SHAPE_BOX, SHAPE_CAPSULE = 0, 1, 2
+SHAPE_SPHERE, SHAPE_BOX, SHAPE_CAPSULE, SHAPE_HULL = 0, 1, 2, 3
 INVALID_ID = 0xFFFFFFFF
 
 EVENT_ACTIVATED, EVENT_DEACTIVATED, EVENT_ENTERED_WATER, EVENT_CONTACT_ADDED, EVENT_CONTACT_PERSISTED = 0, 1, 2, 3, 4
@@ -159,15 +159,20 @@ class VehicleState(C.Structure):
                 ("clutch_friction", f32), ("active", i32)]
 
 
+class HullInfo(C.Structure):
+    _fields_ = [("hull_id", u32), ("num_vertices", u32), ("num_faces", u32), ("num_edges", u32), ("com", f32 * 3), ("rot", f32 * 4),
+                ("volume", f32), ("unit_inertia", f32 * 3), ("aabb_min", f32 * 3), ("aabb_max", f32 * 3)]
+
+
 ABI_SIZEOF_ORDER = ["sgp_settings", "sgp_world_desc", "sgp_body_desc", "sgp_body_state", "sgp_body_event",
                     "sgp_contact_event", "sgp_ray", "sgp_hit", "sgp_step_stats", "sgp_step_profile", "sgp_ghost_record",
-                    "sgp_vehicle_desc", "sgp_vehicle_input", "sgp_vehicle_state"]
+                    "sgp_vehicle_desc", "sgp_vehicle_input", "sgp_vehicle_state", "sgp_hull_info"]
 
 STRUCTS = {"sgp_settings": Settings, "sgp_world_desc": WorldDesc, "sgp_body_desc": BodyDesc,
            "sgp_body_state": BodyState, "sgp_body_event": BodyEvent, "sgp_contact_event": ContactEvent,
            "sgp_ray": Ray, "sgp_hit": Hit, "sgp_step_stats": StepStats, "sgp_step_profile": StepProfile,
            "sgp_ghost_record": GhostRecord, "sgp_vehicle_desc": VehicleDesc, "sgp_vehicle_input": VehicleInput,
-           "sgp_vehicle_state": VehicleState}
+           "sgp_vehicle_state": VehicleState, "sgp_hull_info": HullInfo}
 
 body_desc_dtype = np.dtype(BodyDesc)
 body_state_dtype = np.dtype(BodyState)
@@ -229,6 +234,7 @@ PROTOTYPES = {
     "world_import_ghosts": (C.c_int, [vp, vp, u32]),
     "world_device_array": (C.c_int, [vp, C.c_int, P(vp), P(u32)]),
     "world_stream": (C.c_int, [vp, P(vp)]),
+    "hull_create": (C.c_int, [vp, vp, u32, P(HullInfo)]),
     "default_vehicle_desc": (None, [P(VehicleDesc)]),
     "vehicle_create": (C.c_int, [vp, P(VehicleDesc), P(u32)]),
     "vehicle_destroy": (C.c_int, [vp, u32]),

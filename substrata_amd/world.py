@@ -205,6 +205,15 @@ class CWorld:
         self._check(self._fn("raycast")(self._h, rays.ctypes.data, len(rays), hits.ctypes.data), "raycast")
         return hits
 
+    # -- convex hulls ---------------------------------------------------------------------------------------------
+    def hull_create(self, points):
+        """ConvexHullShapeSettings(points).Create(): returns abi.HullInfo (hull_id for body descs, com / rot = body frame in the
+        frame of the points)."""
+        pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+        info = abi.HullInfo()
+        self._check(self._fn("hull_create")(self._h, pts.ctypes.data, len(pts), C.byref(info)), "hull_create")
+        return info
+
     # -- wheeled vehicles ---------------------------------------------------------------------------------------
     def default_vehicle_desc(self, body=None):
         d = abi.VehicleDesc()

@@ -27,9 +27,10 @@ def quat_to_mat(q):
 
 
 class Shape:
-    def __init__(self, kind, p, pos, rot):
+    def __init__(self, kind, p, pos, rot, hull=None):
         self.kind, self.p, self.pos, self.R = kind, np.asarray(p, float), np.asarray(pos, float), quat_to_mat(rot)
         self.rot = rot
+        self.hull = hull              # (hull id, verts[nv,3], planes[nf,4]) in the body frame, for abi.SHAPE_HULL
 
     def support(self, d):
         """h(d) for unit directions d[...,3] (world space)."""
@@ -39,6 +40,8 @@ class Shape:
             return c + self.p[0]
         if self.kind == abi.SHAPE_BOX:
             return c + np.abs(dl) @ self.p[:3]
+        if self.kind == abi.SHAPE_HULL:
+            return c + (dl @ self.hull[1].astype(float).T).max(axis=-1)
         return c + self.p[0] + self.p[1] * np.abs(dl[..., 2])     # capsule: axis = local z, p = (radius, half height)
 
     def signed_dist(self, x):
@@ -49,10 +52,15 @@ class Shape:
         if self.kind == abi.SHAPE_BOX:
             q = np.abs(l) - self.p[:3]
             return np.linalg.norm(np.maximum(q, 0)) + min(q.max(), 0.0)
+        if self.kind == abi.SHAPE_HULL:                       # exact inside and in front of a face (all the tests need)
+            pl = self.hull[2].astype(float)
+            return float((pl[:, :3] @ l - pl[:, 3]).max())
         zc = np.clip(l[2], -self.p[1], self.p[1])
         return np.linalg.norm(l - np.array([0, 0, zc])) - self.p[0]
 
     def desc(self):
+        if self.kind == abi.SHAPE_HULL:
+            return desc(self.kind, (float(self.hull[0]),), tuple(self.pos), tuple(self.rot))
         return desc(self.kind, tuple(self.p), tuple(self.pos), tuple(self.rot))
 
 
@@ -87,7 +95,36 @@ def rand_quat(rng):
     return tuple(q / np.linalg.norm(q))
 
 
-def rand_shape(rng, kind, pos):
+_HULL_WORLD = {}
+
+
+def hull_world(oracle):
+    """One oracle world that owns the hull shapes of this module."""
+    if "w" not in _HULL_WORLD:
+        _HULL_WORLD["w"] = oracle.OracleWorld(max_bodies=8)
+    return _HULL_WORLD["w"]
+
+
+def rand_hull(rng, oracle):
+    """A random convex polytope: 8-14 points on an ellipsoid; read back in its body frame."""
+    w = hull_world(oracle)
+    n = int(rng.integers(8, 15))
+    pts = rng.normal(size=(n, 3)); pts /= np.linalg.norm(pts, axis=1, keepdims=True)
+    pts *= rng.uniform(0.3, 0.8, size=3)
+    info = w.hull_create(pts)
+    v, pl = oracle.hull_dump(w, info.hull_id)
+    return (info.hull_id, v, pl)
+
+
+def collide(oracle, a, b, max_sep):
+    if abi.SHAPE_HULL in (a.kind, b.kind):
+        return oracle.world_collide_pair(hull_world(oracle), a.desc(), b.desc(), max_sep)
+    return oracle.collide_pair(a.desc(), b.desc(), max_sep)
+
+
+def rand_shape(rng, kind, pos, oracle=None):
+    if kind == abi.SHAPE_HULL:
+        return Shape(kind, (0, 0, 0), pos, rand_quat(rng), hull=rand_hull(rng, oracle))
     if kind == abi.SHAPE_SPHERE:
         p = (rng.uniform(0.2, 0.75), 0, 0)
     elif kind == abi.SHAPE_BOX:
@@ -97,15 +134,15 @@ def rand_shape(rng, kind, pos):
     return Shape(kind, p, pos, rand_quat(rng))
 
 
-KINDS = [abi.SHAPE_SPHERE, abi.SHAPE_BOX, abi.SHAPE_CAPSULE]
-NAMES = {abi.SHAPE_SPHERE: "sphere", abi.SHAPE_BOX: "box", abi.SHAPE_CAPSULE: "capsule"}
+KINDS = [abi.SHAPE_SPHERE, abi.SHAPE_BOX, abi.SHAPE_CAPSULE, abi.SHAPE_HULL]
+NAMES = {abi.SHAPE_SPHERE: "sphere", abi.SHAPE_BOX: "box", abi.SHAPE_CAPSULE: "capsule", abi.SHAPE_HULL: "hull"}
 
 
-def place_near_contact(rng, a, kind_b, target):
+def place_near_contact(rng, a, kind_b, target, oracle=None):
     """B at a random direction from A, moved along that direction until min overlap ~= target (bisection on the brute-force value)."""
     u = rng.normal(size=3)
     u /= np.linalg.norm(u)
-    b = rand_shape(rng, kind_b, a.pos)
+    b = rand_shape(rng, kind_b, a.pos, oracle)
     lo, hi = 0.0, 4.0
     for _ in range(40):
         mid = 0.5 * (lo + hi)
@@ -124,10 +161,10 @@ def test_manifold_against_brute_force_support_functions(oracle, ka, kb):
     rng = np.random.default_rng(100 + 10 * ka + kb)
     checked = 0
     for trial in range(40):
-        a = rand_shape(rng, ka, rng.uniform(-3, 3, size=3))
+        a = rand_shape(rng, ka, rng.uniform(-3, 3, size=3), oracle)
         target = rng.choice([-0.015, -0.005, 0.0, 0.005, 0.02, 0.05, 0.1])     # speculative gap ... solid penetration
-        b = place_near_contact(rng, a, kb, target)
-        hit = oracle.collide_pair(a.desc(), b.desc(), MAX_SEP)
+        b = place_near_contact(rng, a, kb, target, oracle)
+        hit = collide(oracle, a, b, MAX_SEP)
         ref, dref = min_overlap(a, b, seeds=() if hit is None else (hit[0],))
         if ref < -MAX_SEP - 2e-3:
             assert hit is None, (trial, ref)
@@ -143,14 +180,20 @@ def test_manifold_against_brute_force_support_functions(oracle, ka, kb):
         assert along_n <= ref + 1e-3, (trial, NAMES[ka], NAMES[kb], along_n, ref, n, dref)
         # (2) deepest reported penetration == overlap along that axis
         pens = pen(n, p1.astype(float), p2.astype(float))
-        assert abs(pens.max() - along_n) < 2e-4, (trial, pens, along_n)
+        # (for general polytopes the clipped incident face can miss the single deepest vertex by a hair -- the usual price of
+        #  supporting-face clipping, also in Jolt's ManifoldBetweenTwoFaces -- so hulls get 3 mm; the reported depth never exceeds the true one)
+        tol2 = 3e-3 if abi.SHAPE_HULL in (ka, kb) else 2e-4
+        assert abs(pens.max() - along_n) < tol2 and pens.max() <= along_n + 2e-4, (trial, pens, along_n)
         # (3) all points within the speculative margin, and on their own shape
         assert (pens > -MAX_SEP - 1e-4).all()
+        # (a speculative hull contact whose closest features are an edge / a vertex is reported on the plane of the reference face,
+        #  possibly a little outside the face polygon)
+        tol3 = 2e-2 if (abi.SHAPE_HULL in (ka, kb) and along_n < 0.0) else tol2
         for q1, q2 in zip(p1, p2):
-            assert abs(a.signed_dist(q1)) < 2e-3 + max(0.0, along_n), (trial, a.signed_dist(q1))
-            assert abs(b.signed_dist(q2)) < 2e-3 + max(0.0, along_n), (trial, b.signed_dist(q2))
+            assert abs(a.signed_dist(q1)) < 2e-3 + tol3 + max(0.0, along_n), (trial, a.signed_dist(q1))
+            assert abs(b.signed_dist(q2)) < 2e-3 + tol3 + max(0.0, along_n), (trial, b.signed_dist(q2))
         # (4) swapping the operands mirrors the manifold
-        hit2 = oracle.collide_pair(b.desc(), a.desc(), MAX_SEP)
+        hit2 = collide(oracle, b, a, MAX_SEP)
         assert hit2 is not None and len(hit2[1]) == len(p1)
         assert abs(float(overlap(b, a, hit2[0].astype(float))) - along_n) < 1e-4
         checked += 1

@@ -1,0 +1,127 @@
+"""Convex hull shapes in the oracle (oracle/sgo_hull.h, sgo_hull_build.h): the role of JPH::ConvexHullShapeSettings::Create and of
+the hull collision paths Substrata's dynamic meshes and vehicle bodies use (/root/reference/gui_client/PhysicsWorld.cpp:735-1166,
+CarPhysics.cpp:66-92).  Builder: topology, volume / centre of mass / inertia against closed forms, body frame = principal frame.
+Dynamics: a hull cube behaves like the native box, hulls come to rest on their faces, a ray hits the right face."""
+import numpy as np
+import pytest
+
+from substrata_amd import abi, scenes
+from helpers import DT, add_ground, dyn, quat_axis_angle
+from test_collide_independent import quat_to_mat
+
+CAR_HULL = [(-0.9, -0.25, -2.0), (-0.9, -0.25, 2.0), (-0.9, 0.25, -2.0), (-0.9, 0.25, 2.0), (0.9, -0.25, -2.0), (0.9, -0.25, 2.0),
+            (0.9, 0.25, -2.0), (0.9, 0.25, 2.0), (0.9, 0.7, 0.6), (-0.9, 0.7, 0.6), (0.9, 0.7, -1.2), (-0.9, 0.7, -1.2)]   # Scripting.cpp:369-386
+
+
+def hull_body(w, info, pos_obj=(0, 0, 1), rot_obj=(0, 0, 0, 1), **kw):
+    """Body for a hull whose points were given in object space: the body frame sits at com / rot of the object frame."""
+    Ro = quat_to_mat(rot_obj)
+    pos = np.asarray(pos_obj, float) + Ro @ np.asarray(info.com[:], float)
+    qo = np.asarray(rot_obj, float); qh = np.asarray(info.rot[:], float)
+    x1, y1, z1, w1 = qo; x2, y2, z2, w2 = qh
+    rot = (w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2, w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2)
+    return dyn(w, shape_type=abi.SHAPE_HULL, shape=(float(info.hull_id), 0, 0, 0), pos=tuple(pos), rot=rot, **kw)
+
+
+def test_builder_topology_and_mass_properties(oracle):
+    w = oracle.OracleWorld(max_bodies=8)
+    # box 2 x 4 x 6: Euler, volume, inertia = V/12 (b^2 + c^2) ...
+    pts = [(x, y, z) for x in (-1, 1) for y in (-2, 2) for z in (-3, 3)]
+    b = w.hull_create(pts + [(0, 0, 0), (0.5, 0.5, 0.5)])                     # interior points are dropped
+    assert (b.num_vertices, b.num_faces, b.num_edges) == (8, 6, 12)
+    assert np.isclose(b.volume, 48.0, rtol=1e-6) and np.allclose(b.com[:], 0, atol=1e-6)
+    assert np.allclose(sorted(b.unit_inertia[:]), sorted([48 / 12 * (16 + 36), 48 / 12 * (4 + 36), 48 / 12 * (4 + 16)]), rtol=1e-5)
+    # tetrahedron: V = 1/6, com = mean of the vertices, 4 faces, 6 edges
+    t = w.hull_create([(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1)])
+    assert (t.num_vertices, t.num_faces, t.num_edges) == (4, 4, 6)
+    assert np.isclose(t.volume, 1 / 6, rtol=1e-6) and np.allclose(t.com[:], 0.25, atol=1e-6)
+    # a translated and rotated copy of a generic hull: same volume and principal moments, com / rot follow the motion
+    rng = np.random.default_rng(2)
+    P = rng.normal(size=(14, 3)) * (0.5, 0.8, 1.3)
+    h0 = w.hull_create(P)
+    q = quat_axis_angle((1, 2, 3), 0.7); R = quat_to_mat(q); T = np.array([3.0, -2.0, 5.0])
+    h1 = w.hull_create(P @ R.T + T)
+    assert (h0.num_vertices, h0.num_faces, h0.num_edges) == (h1.num_vertices, h1.num_faces, h1.num_edges)
+    assert h0.num_vertices - h0.num_edges + h0.num_faces == 2
+    assert np.isclose(h0.volume, h1.volume, rtol=1e-5)
+    assert np.allclose(sorted(h0.unit_inertia[:]), sorted(h1.unit_inertia[:]), rtol=1e-4)
+    assert np.allclose(R @ np.asarray(h0.com[:]) + T, h1.com[:], atol=1e-5)
+    # the stored hull is in the body frame: its centroid-of-volume is the origin and the products of inertia vanish
+    v, pl = oracle.hull_dump(w, h0.hull_id)
+    assert len(v) == h0.num_vertices and len(pl) == h0.num_faces
+    assert np.allclose(np.linalg.norm(pl[:, :3], axis=1), 1, atol=1e-5)
+    assert ((v @ pl[:, :3].T) <= pl[:, 3] + 1e-5).all()                       # every vertex inside every plane
+    back = v.astype(float) @ quat_to_mat(h0.rot[:]).T + np.asarray(h0.com[:])
+    assert all(np.min(np.linalg.norm(P - b_, axis=1)) < 1e-5 for b_ in back)   # body frame -> input frame reproduces input points
+    # car hull of the reference: 12 points, centre of mass above the floor pan and behind the middle
+    c = w.hull_create(CAR_HULL)
+    assert (c.num_vertices, c.num_faces, c.num_edges) == (12, 8, 18)
+    assert abs(c.com[0]) < 1e-6 and 0.1 < c.com[1] < 0.25 and -0.2 < c.com[2] < 0.0
+    # degenerate clouds are rejected
+    from substrata_amd.world import SgpError
+    with pytest.raises(SgpError):
+        w.hull_create([(0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0)])          # flat
+    with pytest.raises(SgpError):
+        w.hull_create([(0, 0, 0), (1, 0, 0), (2, 0, 0)])
+    # many points: reduced to <= 32 extreme points, still a closed polytope close to the sphere they came from
+    S = rng.normal(size=(500, 3)); S /= np.linalg.norm(S, axis=1, keepdims=True)
+    s = w.hull_create(S)
+    assert s.num_vertices <= 32 and s.num_vertices - s.num_edges + s.num_faces == 2
+    assert 0.6 * 4.19 < s.volume < 4.19
+
+
+def test_hull_cube_behaves_like_the_native_box(oracle):
+    """The same drop with a box body and with a hull built from the box's corners: same rest state to solver tolerance."""
+    res = []
+    for use_hull in (False, True):
+        w = oracle.OracleWorld(max_bodies=16)
+        add_ground(w)
+        q = quat_axis_angle((1, 1, 0), 0.5)
+        if use_hull:
+            info = w.hull_create([(x, y, z) for x in (-0.5, 0.5) for y in (-0.5, 0.5) for z in (-0.5, 0.5)])
+            b = hull_body(w, info, pos_obj=(0, 0, 2.0), rot_obj=q, mass=50.0)
+        else:
+            b = dyn(w, pos=(0, 0, 2.0), rot=q, mass=50.0)
+        for _ in range(400):
+            w.step(DT)
+        st = w.get_state([b])[0]
+        res.append(st)
+        assert abs(st["pos"][2] - 0.5) < 0.025 and st["active"] == 0            # resting on a face (within the slop), asleep
+        w.close()
+    assert np.linalg.norm(res[0]["pos"] - res[1]["pos"]) < 0.25                 # tumbled to a nearby spot
+
+
+def test_hulls_rest_on_faces_and_stack(oracle):
+    w = oracle.OracleWorld(max_bodies=32)
+    add_ground(w)
+    car = w.hull_create(CAR_HULL)
+    # model space of the car script is y-up: rotate +90 deg about x so that y -> z
+    q = quat_axis_angle((1, 0, 0), np.pi / 2)
+    b_car = hull_body(w, car, pos_obj=(0, 0, 1.0), rot_obj=q, mass=1200.0, restitution=0.0)
+    tet = w.hull_create([(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1)])
+    b_tet = hull_body(w, tet, pos_obj=(5, 0, 0.5), rot_obj=quat_axis_angle((1, 0.3, 0.2), 1.1), mass=20.0)
+    wedge = w.hull_create([(-1, -0.5, 0), (1, -0.5, 0), (-1, 0.5, 0), (1, 0.5, 0), (-1, -0.5, 0.6), (-1, 0.5, 0.6)])
+    b_w = hull_body(w, wedge, pos_obj=(10, 0, 0.05), mass=80.0)
+    b_box = dyn(w, pos=(10.3, 0, 1.2), mass=30.0, friction=1.0)              # a native box sliding / resting on the wedge's slope
+    b_sph = dyn(w, shape_type=abi.SHAPE_SPHERE, shape=(0.3, 0, 0, 0), pos=(0, 0.0, 2.4), mass=10.0)   # lands on the car's roof
+    b_cap = dyn(w, shape_type=abi.SHAPE_CAPSULE, shape=(0.2, 0.4, 0, 0), pos=(0, 1.2, 1.6), rot=quat_axis_angle((1, 0, 0), np.pi / 2), mass=10.0)   # lies on the bonnet
+    for _ in range(600):
+        w.step(DT)
+    st = {k: w.get_state([i])[0] for k, i in dict(car=b_car, tet=b_tet, wedge=b_w, box=b_box, sph=b_sph, cap=b_cap).items()}
+    assert all(np.isfinite(s["pos"]).all() for s in st.values())
+    # car: floor pan (model y = -0.25) on the ground: object origin at z = 0.25 -> com z = 0.25 + com_y
+    assert abs(st["car"]["pos"][2] - (0.25 + car.com[1])) < 0.03 and st["car"]["active"] == 0
+    # tetrahedron: on one of its faces: com height = distance from com to a face
+    v, pl = oracle.hull_dump(w, tet.hull_id)
+    assert min(abs(st["tet"]["pos"][2] - d) for d in pl[:, 3]) < 0.03 and st["tet"]["active"] == 0
+    assert abs(st["wedge"]["pos"][2] - (-w.hull_create([(-1, -0.5, 0), (1, -0.5, 0), (-1, 0.5, 0), (1, 0.5, 0), (-1, -0.5, 0.6), (-1, 0.5, 0.6)]).aabb_min[2])) < 0.2
+    assert st["box"]["pos"][2] > 0.45                                          # on the ground or on the slope, not inside anything
+    # sphere and capsule came to rest on top of the car (above the floor pan, below where they started)
+    assert 0.5 < st["sph"]["pos"][2] < 2.0 and 0.4 < st["cap"]["pos"][2] < 1.6
+    # rays: straight down onto the roof of the car, and a miss beside it
+    rays = np.zeros(2, dtype=abi.ray_dtype)
+    rays["origin"] = [(0.0, 0.0, 5.0), (3.0, 0.0, 5.0)]; rays["dir"] = (0, 0, -1); rays["max_t"] = 10.0; rays["ignore_id"] = abi.INVALID_ID
+    w.remove(b_sph); w.remove(b_cap)
+    hits = w.raycast(rays)
+    assert hits[0]["id"] == b_car and abs((5.0 - hits[0]["t"]) - (0.25 + 0.7)) < 0.04 and hits[0]["normal"][2] > 0.99
+    assert hits[1]["id"] == 0
