@@ -16,7 +16,9 @@
 #define SGD_SHAPE_CAPSULE 2
 #define SGD_CAPSULE_SLOP 0.02f
 
-struct sgd_shape { v3 pos; m33 R; int type; float p0, p1, p2; };
+#define SGD_SHAPE_HULL    3   // convex hull (sgp_device_hull.h): `hull` = the shape; for a box `hull` = the +-1 cube template
+struct sgd_hull_s;
+struct sgd_shape { v3 pos; m33 R; int type; float p0, p1, p2; const sgd_hull_s* hull; };
 struct sgd_manifold { v3 n; int np; v3 p1[8]; v3 p2[8]; };
 
 SGP_DEV static int sgd_sphere_sphere_pts(v3 ca, float ra, v3 cb, float rb, float max_sep, sgd_manifold* m)
@@ -424,6 +426,32 @@ SGP_DEV static void sgd_flip_manifold(sgd_manifold* m)
 }
 
 /* Dispatch on the (type_a, type_b) pair; canonical order sphere < box < capsule. */
+#include "sgp_device_hull.h"
+
+SGP_DEV static sgd_hview sgd_hull_view(const sgd_shape* s)
+{
+	sgd_hview v;
+	v.pos = s->pos; v.R = s->R; v.h = s->hull;
+	v.scale = s->type == SGD_SHAPE_BOX ? V3(s->p0, s->p1, s->p2) : V3(1.0f, 1.0f, 1.0f);
+	return v;
+}
+
+// pairs with a convex hull (canonical order sphere < box < capsule < hull); run by k_narrowphase_hull only
+SGP_DEV static int sgd_collide_hull(const sgd_shape* a, const sgd_shape* b, float max_sep, sgd_manifold* m)
+{
+	int hit, flip = 0;
+	const sgd_shape* x = a; const sgd_shape* y = b;
+	if (a->type > b->type) { x = b; y = a; flip = 1; }
+	const sgd_hview hy = sgd_hull_view(y);
+	if (x->type == SGD_SHAPE_SPHERE) { hit = sgd_hull_sphere(&hy, x->pos, x->p0, max_sep, m); flip = !flip; }       // computed hull -> sphere
+	else if (x->type == SGD_SHAPE_CAPSULE) {
+		const v3 ax = v3_scale(m33_col(x->R, 2), x->p1);
+		hit = sgd_hull_capsule(&hy, v3_sub(x->pos, ax), v3_add(x->pos, ax), x->p0, max_sep, m); flip = !flip;
+	} else { const sgd_hview hx = sgd_hull_view(x); hit = sgd_hull_hull(&hx, &hy, max_sep, m); }
+	if (hit && flip) sgd_flip_manifold(m);
+	return hit;
+}
+
 SGP_DEV static int sgd_collide(const sgd_shape* a, const sgd_shape* b, float max_sep, sgd_manifold* m)
 {
 	int hit, flip = 0;

@@ -1,0 +1,337 @@
+// sgp_device_hull.h -- gfx950 convex hull shapes: hull - hull / box / sphere / capsule manifolds, rays (device code only).
+//
+// Role of JPH::ConvexHullShape in CollideShape / CastRay for the dynamic meshes and vehicle bodies Substrata creates
+// (/root/reference/gui_client/PhysicsWorld.cpp:735-1166 with is_dynamic, CarPhysics.cpp:66-92, BikePhysics.cpp:76-112): separating
+// axis test over face normals and edge pairs + reference / incident face clipping (<= 4 points) instead of GJK/EPA.
+// A hull is stored in its body frame (origin = centre of mass, axes = principal axes); a box is the +-1 cube template scaled.
+// Included by sgp_device_collide.h after sgd_manifold / sgd_closest_on_segment.  Regenerate with tools/derive_device_vehicle.py.
+#pragma once
+#include "sgp_device_math.h"
+
+#define SGD_HULL_MAX_VERTS 32
+#define SGD_HULL_MAX_FACES 60
+#define SGD_HULL_MAX_EDGES 90
+#define SGD_HULL_MAX_FACE_IDX 180
+#define SGD_HULL_MAX_FACE_VERTS 16
+#define SGD_HULL_CLIP_CAP 24
+
+struct sgd_hull_s {
+	int nv, nf, ne, is_box_template;
+	v3 verts[SGD_HULL_MAX_VERTS];
+	v3 normals[SGD_HULL_MAX_FACES]; float plane_d[SGD_HULL_MAX_FACES];       // inside: n.x <= d
+	unsigned char face_start[SGD_HULL_MAX_FACES + 1]; unsigned char face_idx[SGD_HULL_MAX_FACE_IDX];   // CCW seen from outside
+	unsigned char edge_a[SGD_HULL_MAX_EDGES], edge_b[SGD_HULL_MAX_EDGES];
+	v3 aabb_min, aabb_max;
+	float bound_radius, volume;
+	v3 unit_inertia;                   // principal moments for density 1
+};
+typedef struct sgd_hull_s sgd_hull;
+
+// a hull (or the cube template scaled to a box) placed in the world
+struct sgd_hview { v3 pos; m33 R; v3 scale; const sgd_hull* h; };
+
+SGP_DEV static v3 sgd_hv_local(const sgd_hview* v, int i) { const v3 p = v->h->verts[i]; return V3(p.x * v->scale.x, p.y * v->scale.y, p.z * v->scale.z); }
+SGP_DEV static v3 sgd_hv_world(const sgd_hview* v, int i) { return v3_add(v->pos, m33_mul(v->R, sgd_hv_local(v, i))); }
+SGP_DEV static v3 sgd_hv_normal(const sgd_hview* v, int f) { return m33_mul(v->R, v->h->normals[f]); }
+SGP_DEV static float sgd_hv_plane_d(const sgd_hview* v, int f)
+{
+	if (v->h->is_box_template) { const v3 n = v->h->normals[f]; return fabsf(n.x) * v->scale.x + fabsf(n.y) * v->scale.y + fabsf(n.z) * v->scale.z; }
+	return v->h->plane_d[f];
+}
+// min / max over the vertices of w . x (world direction w)
+SGP_DEV static float sgd_hv_proj_min(const sgd_hview* v, v3 w)
+{
+	const v3 l = m33_tmul(v->R, w);
+	float best = 3.4e38f;
+	for (int i = 0; i < v->h->nv; ++i) { const float d = v3_dot(l, sgd_hv_local(v, i)); if (d < best) best = d; }
+	return v3_dot(w, v->pos) + best;
+}
+SGP_DEV static float sgd_hv_proj_max(const sgd_hview* v, v3 w)
+{
+	const v3 l = m33_tmul(v->R, w);
+	float best = -3.4e38f;
+	for (int i = 0; i < v->h->nv; ++i) { const float d = v3_dot(l, sgd_hv_local(v, i)); if (d > best) best = d; }
+	return v3_dot(w, v->pos) + best;
+}
+
+// Clip a world-space polygon against the half space (p - a) . side <= 0.
+SGP_DEV static int sgd_hull_clip(const v3* in, int n, v3 a, v3 side, v3* out)
+{
+	int m = 0;
+	for (int i = 0; i < n; ++i) {
+		const v3 p = in[i], q = in[(i + 1) % n];
+		const float dp = v3_dot(v3_sub(p, a), side), dq = v3_dot(v3_sub(q, a), side);
+		if (dp <= 0.0f) { if (m < SGD_HULL_CLIP_CAP) out[m++] = p; }
+		if ((dp <= 0.0f) != (dq <= 0.0f)) {
+			const float t = dp / (dp - dq);
+			if (m < SGD_HULL_CLIP_CAP) out[m++] = v3_add(p, v3_scale(v3_sub(q, p), t));
+		}
+	}
+	return m;
+}
+
+/* Keep at most 4 of np (<= SGD_HULL_CLIP_CAP) contact points: deepest, farthest from it, the extremes either side of that chord
+   (same rule as sgd_reduce_manifold).  Writes the survivors to the manifold. */
+SGP_DEV static void sgd_hull_reduce(v3 n, const v3* p1, const v3* p2, int np, sgd_manifold* m)
+{
+	m->n = n;
+	if (np <= 4) { for (int i = 0; i < np; ++i) { m->p1[i] = p1[i]; m->p2[i] = p2[i]; } m->np = np; return; }
+	int i0 = 0; float best = -3.4e38f;
+	for (int i = 0; i < np; ++i) { const float pen = v3_dot(v3_sub(p1[i], p2[i]), n); if (pen > best) { best = pen; i0 = i; } }
+	int i1 = i0; best = -1.0f;
+	for (int i = 0; i < np; ++i) { const float d2 = v3_len_sq(v3_sub(p1[i], p1[i0])); if (d2 > best) { best = d2; i1 = i; } }
+	const v3 e = v3_sub(p1[i1], p1[i0]);
+	int i2 = -1, i3 = -1; float amax = 0.0f, amin = 0.0f;
+	for (int i = 0; i < np; ++i) {
+		if (i == i0 || i == i1) continue;
+		const float area = v3_dot(v3_cross(e, v3_sub(p1[i], p1[i0])), n);
+		if (area > amax) { amax = area; i2 = i; }
+		if (area < amin) { amin = area; i3 = i; }
+	}
+	int k = 0;
+	m->p1[k] = p1[i0]; m->p2[k] = p2[i0]; ++k;
+	if (i1 != i0) { m->p1[k] = p1[i1]; m->p2[k] = p2[i1]; ++k; }
+	if (i2 >= 0) { m->p1[k] = p1[i2]; m->p2[k] = p2[i2]; ++k; }
+	if (i3 >= 0) { m->p1[k] = p1[i3]; m->p2[k] = p2[i3]; ++k; }
+	m->np = k;
+}
+
+// closest points of two segments (a0,a1), (b0,b1)
+SGP_DEV static void sgd_seg_seg_closest(v3 a0, v3 a1, v3 b0, v3 b1, v3* pa, v3* pb)
+{
+	const v3 d1 = v3_sub(a1, a0), d2 = v3_sub(b1, b0), r = v3_sub(a0, b0);
+	const float a = v3_dot(d1, d1), e = v3_dot(d2, d2), f = v3_dot(d2, r);
+	float s = 0.0f, t = 0.0f;
+	if (a > 1.0e-12f && e > 1.0e-12f) {
+		const float c = v3_dot(d1, r), b = v3_dot(d1, d2);
+		const float den = a * e - b * b;
+		if (den > 1.0e-12f) s = clampf((b * f - c * e) / den, 0.0f, 1.0f);
+		t = (b * s + f) / e;
+		if (t < 0.0f) { t = 0.0f; s = clampf(-c / a, 0.0f, 1.0f); }
+		else if (t > 1.0f) { t = 1.0f; s = clampf((b - c) / a, 0.0f, 1.0f); }
+	} else if (a > 1.0e-12f) { s = clampf(-v3_dot(d1, r) / a, 0.0f, 1.0f); }
+	else if (e > 1.0e-12f) { t = clampf(f / e, 0.0f, 1.0f); }
+	*pa = v3_add(a0, v3_scale(d1, s));
+	*pb = v3_add(b0, v3_scale(d2, t));
+}
+
+// A, B = hull views (either may be the scaled cube template): SAT + clipping.  Normal from A to B.
+SGP_DEV static int sgd_hull_hull(const sgd_hview* A, const sgd_hview* B, float max_sep, sgd_manifold* m)
+{
+	float sA = -3.4e38f, sB = -3.4e38f; int fA = 0, fB = 0;
+	for (int f = 0; f < A->h->nf; ++f) {
+		const v3 n = sgd_hv_normal(A, f);
+		const float s = sgd_hv_proj_min(B, n) - (v3_dot(n, A->pos) + sgd_hv_plane_d(A, f));
+		if (s > max_sep) return 0;
+		if (s > sA) { sA = s; fA = f; }
+	}
+	for (int f = 0; f < B->h->nf; ++f) {
+		const v3 n = sgd_hv_normal(B, f);
+		const float s = sgd_hv_proj_min(A, n) - (v3_dot(n, B->pos) + sgd_hv_plane_d(B, f));
+		if (s > max_sep) return 0;
+		if (s > sB) { sB = s; fB = f; }
+	}
+	const v3 T = v3_sub(B->pos, A->pos);
+	float sE = -3.4e38f; int eA = -1, eB = -1; v3 nE = V3(0, 0, 0);
+	for (int i = 0; i < A->h->ne; ++i) {
+		const v3 da = m33_mul(A->R, v3_sub(sgd_hv_local(A, A->h->edge_b[i]), sgd_hv_local(A, A->h->edge_a[i])));
+		const float la = v3_len_sq(da);
+		for (int j = 0; j < B->h->ne; ++j) {
+			const v3 db = m33_mul(B->R, v3_sub(sgd_hv_local(B, B->h->edge_b[j]), sgd_hv_local(B, B->h->edge_a[j])));
+			v3 ax = v3_cross(da, db);
+			const float l2 = v3_len_sq(ax);
+			if (l2 < 1.0e-6f * la * v3_len_sq(db)) continue;
+			ax = v3_scale(ax, 1.0f / sqrtf(l2));
+			if (v3_dot(ax, T) < 0.0f) ax = v3_neg(ax);
+			const float s = sgd_hv_proj_min(B, ax) - sgd_hv_proj_max(A, ax);
+			if (s > max_sep) return 0;
+			if (s > sE) {
+				// parallel edges give the same axis: only the pair that actually supports the two hulls along it is the contact
+				const v3 a0 = sgd_hv_world(A, A->h->edge_a[i]), b0 = sgd_hv_world(B, B->h->edge_a[j]);
+				const float s_edge = v3_dot(ax, b0) - v3_dot(ax, a0);        // (both ends of an edge project alike: ax is perpendicular to it)
+				if (s_edge - s > 1.0e-4f) continue;
+				sE = s; eA = i; eB = j; nE = ax;
+			}
+		}
+	}
+	const float sF = fmaxf(sA, sB);
+	if (eA >= 0 && sE > sF + 1.0e-3f) {
+		v3 pa, pb;
+		sgd_seg_seg_closest(sgd_hv_world(A, A->h->edge_a[eA]), sgd_hv_world(A, A->h->edge_b[eA]),
+		                    sgd_hv_world(B, B->h->edge_a[eB]), sgd_hv_world(B, B->h->edge_b[eB]), &pa, &pb);
+		m->n = nE; m->np = 1; m->p1[0] = pa; m->p2[0] = pb;
+		return 1;
+	}
+	// face contact: reference hull X owns the axis, the most anti-parallel face of Y is clipped against X's face
+	const int refA = !(sB > sA + 1.0e-4f);
+	const sgd_hview* X = refA ? A : B; const sgd_hview* Y = refA ? B : A;
+	const int fX = refA ? fA : fB;
+	const v3 nref = sgd_hv_normal(X, fX);
+	int fY = 0; float bestd = 3.4e38f;
+	for (int f = 0; f < Y->h->nf; ++f) { const float d = v3_dot(nref, sgd_hv_normal(Y, f)); if (d < bestd) { bestd = d; fY = f; } }
+	v3 poly[SGD_HULL_CLIP_CAP], tmp[SGD_HULL_CLIP_CAP];
+	int np = 0;
+	for (int k = Y->h->face_start[fY]; k < Y->h->face_start[fY + 1]; ++k) poly[np++] = sgd_hv_world(Y, Y->h->face_idx[k]);
+	const int x0 = X->h->face_start[fX], x1 = X->h->face_start[fX + 1];
+	for (int k = x0; k < x1 && np > 0; ++k) {
+		const v3 a = sgd_hv_world(X, X->h->face_idx[k]);
+		const v3 b = sgd_hv_world(X, X->h->face_idx[k + 1 < x1 ? k + 1 : x0]);
+		const v3 side = v3_cross(v3_sub(b, a), nref);
+		np = sgd_hull_clip(poly, np, a, side, tmp);
+		for (int i = 0; i < np; ++i) poly[i] = tmp[i];
+	}
+	const float off = v3_dot(nref, X->pos) + sgd_hv_plane_d(X, fX);
+	v3 q1[SGD_HULL_CLIP_CAP], q2[SGD_HULL_CLIP_CAP];
+	int cnt = 0;
+	for (int i = 0; i < np; ++i) {
+		const float sep = v3_dot(nref, poly[i]) - off;
+		if (sep <= max_sep) {
+			const v3 pr = v3_sub(poly[i], v3_scale(nref, sep));      // on X's face
+			if (refA) { q1[cnt] = pr; q2[cnt] = poly[i]; } else { q1[cnt] = poly[i]; q2[cnt] = pr; }
+			++cnt;
+		}
+	}
+	if (cnt == 0) {
+		/* nothing of the incident face lies over the reference face (the closest features are an edge / a vertex of X): fall back
+		   to the support vertex of Y along the axis */
+		int bi = 0; float bp = 3.4e38f;
+		for (int i = 0; i < Y->h->nv; ++i) { const float pr = v3_dot(nref, sgd_hv_world(Y, i)); if (pr < bp) { bp = pr; bi = i; } }
+		const float sep = bp - off;
+		if (sep > max_sep) return 0;
+		const v3 py = sgd_hv_world(Y, bi), px = v3_sub(py, v3_scale(nref, sep));
+		if (refA) { q1[0] = px; q2[0] = py; } else { q1[0] = py; q2[0] = px; }
+		cnt = 1;
+	}
+	sgd_hull_reduce(refA ? nref : v3_neg(nref), q1, q2, cnt, m);
+	return 1;
+}
+
+/* Closest point on the hull surface to the hull-local point l (scale 1 hulls only).  Returns the signed distance (negative
+   inside), the closest point q and the outward direction n at q (unit). */
+SGP_DEV static float sgd_hull_closest(const sgd_hull* h, v3 l, v3* q_out, v3* n_out)
+{
+	float smax = -3.4e38f; int fmax = 0;
+	for (int f = 0; f < h->nf; ++f) { const float s = v3_dot(h->normals[f], l) - h->plane_d[f]; if (s > smax) { smax = s; fmax = f; } }
+	if (smax <= 0.0f) {
+		*n_out = h->normals[fmax];
+		*q_out = v3_sub(l, v3_scale(h->normals[fmax], smax));
+		return smax;
+	}
+	float best = 3.4e38f; v3 bq = l;
+	for (int f = 0; f < h->nf; ++f) {
+		const v3 n = h->normals[f];
+		const float s = v3_dot(n, l) - h->plane_d[f];
+		if (s <= 0.0f) continue;
+		const v3 p = v3_sub(l, v3_scale(n, s));
+		const int k0 = h->face_start[f], k1 = h->face_start[f + 1];
+		int inside = 1;
+		for (int k = k0; k < k1; ++k) {
+			const v3 a = h->verts[h->face_idx[k]], b = h->verts[h->face_idx[k + 1 < k1 ? k + 1 : k0]];
+			if (v3_dot(v3_cross(v3_sub(b, a), n), v3_sub(p, a)) > 0.0f) { inside = 0; break; }
+		}
+		if (inside) { const float d2 = s * s; if (d2 < best) { best = d2; bq = p; } continue; }
+		for (int k = k0; k < k1; ++k) {
+			const v3 a = h->verts[h->face_idx[k]], b = h->verts[h->face_idx[k + 1 < k1 ? k + 1 : k0]];
+			const v3 c = sgd_closest_on_segment(a, b, l);
+			const float d2 = v3_len_sq(v3_sub(l, c));
+			if (d2 < best) { best = d2; bq = c; }
+		}
+	}
+	const float dist = sqrtf(best);
+	*q_out = bq;
+	*n_out = dist > 1.0e-12f ? v3_scale(v3_sub(l, bq), 1.0f / dist) : h->normals[fmax];
+	return dist;
+}
+
+// hull H (scale 1) vs sphere: normal from the hull to the sphere
+SGP_DEV static int sgd_hull_sphere(const sgd_hview* H, v3 c, float r, float max_sep, sgd_manifold* m)
+{
+	const v3 l = m33_tmul(H->R, v3_sub(c, H->pos));
+	v3 q, n;
+	const float d = sgd_hull_closest(H->h, l, &q, &n);
+	if (d - r > max_sep) return 0;
+	const v3 nw = m33_mul(H->R, n);
+	m->n = nw; m->np = 1;
+	m->p1[0] = v3_add(H->pos, m33_mul(H->R, q));
+	m->p2[0] = v3_sub(c, v3_scale(nw, r));
+	return 1;
+}
+
+// hull H (scale 1) vs capsule (end points e0, e1 of the axis, radius r): normal from the hull to the capsule
+SGP_DEV static int sgd_hull_capsule(const sgd_hview* H, v3 e0, v3 e1, float r, float max_sep, sgd_manifold* m)
+{
+	const v3 s0 = m33_tmul(H->R, v3_sub(e0, H->pos)), s1 = m33_tmul(H->R, v3_sub(e1, H->pos));
+	const v3 d = v3_sub(s1, s0);
+	// the distance to a convex set is convex along the segment: fixed-count ternary search
+	float lo = 0.0f, hi = 1.0f;
+	v3 q, n;
+	for (int it = 0; it < 40; ++it) {
+		const float t1 = lo + (hi - lo) * (1.0f / 3.0f), t2 = hi - (hi - lo) * (1.0f / 3.0f);
+		const float f1 = sgd_hull_closest(H->h, v3_add(s0, v3_scale(d, t1)), &q, &n);
+		const float f2 = sgd_hull_closest(H->h, v3_add(s0, v3_scale(d, t2)), &q, &n);
+		if (f1 <= f2) hi = t2; else lo = t1;
+	}
+	const float ts = 0.5f * (lo + hi);
+	const v3 S = v3_add(s0, v3_scale(d, ts));
+	const float dist = sgd_hull_closest(H->h, S, &q, &n);
+	if (dist - r > max_sep) return 0;
+	m->n = m33_mul(H->R, n); m->np = 1;
+	m->p1[0] = v3_add(H->pos, m33_mul(H->R, q));
+	m->p2[0] = v3_add(H->pos, m33_mul(H->R, v3_sub(S, v3_scale(n, r))));
+	// axis (nearly) parallel to the supporting face: both ends of the overlap between the axis and that face
+	const float dl = v3_len(d);
+	if (dl > 1.0e-6f && dist > 0.0f && fabsf(v3_dot(n, d)) < SGD_CAPSULE_SLOP * dl) {
+		int fb = 0; float bd = -3.4e38f;
+		for (int f = 0; f < H->h->nf; ++f) { const float dd = v3_dot(H->h->normals[f], n); if (dd > bd) { bd = dd; fb = f; } }
+		if (bd > 0.95f) {
+			const v3 nf = H->h->normals[fb];
+			float t0 = 0.0f, t1 = 1.0f; int ok = 1;
+			const int k0 = H->h->face_start[fb], k1 = H->h->face_start[fb + 1];
+			for (int k = k0; k < k1 && ok; ++k) {
+				const v3 a = H->h->verts[H->h->face_idx[k]], b = H->h->verts[H->h->face_idx[k + 1 < k1 ? k + 1 : k0]];
+				const v3 side = v3_cross(v3_sub(b, a), nf);
+				const float g0 = v3_dot(side, v3_sub(s0, a)), gd = v3_dot(side, d);
+				if (fabsf(gd) < 1.0e-12f) { if (g0 > 0.0f) ok = 0; }
+				else { const float tk = -g0 / gd; if (gd > 0.0f) { if (tk < t1) t1 = tk; } else { if (tk > t0) t0 = tk; } if (t0 > t1) ok = 0; }
+			}
+			if (ok && (t1 - t0) * dl > 1.0e-4f) {
+				const float tt[2] = { t0, t1 };
+				v3 a1[2], a2[2]; int np = 0;
+				for (int i = 0; i < 2; ++i) {
+					const v3 P = v3_add(s0, v3_scale(d, tt[i]));
+					const float sep = v3_dot(nf, P) - H->h->plane_d[fb] - r;
+					if (sep <= max_sep) {
+						a1[np] = v3_sub(P, v3_scale(nf, v3_dot(nf, P) - H->h->plane_d[fb]));
+						a2[np] = v3_sub(P, v3_scale(n, r));
+						++np;
+					}
+				}
+				if (np == 2) {
+					m->np = 2;
+					for (int i = 0; i < 2; ++i) { m->p1[i] = v3_add(H->pos, m33_mul(H->R, a1[i])); m->p2[i] = v3_add(H->pos, m33_mul(H->R, a2[i])); }
+				}
+			}
+		}
+	}
+	return 1;
+}
+
+/* ray against a hull (scale 1) grown by `grow` along every face normal, hull-local: clip against every face plane.  Returns t
+   or -1; normal of the entry face (-dl when the origin is inside).  grow > 0 serves the sphere cast of the wheel tester: the
+   planes-only offset is the Minkowski sum with a ball except near edges and corners, where it is slightly larger. */
+SGP_DEV static float sgd_ray_hull(const sgd_hull* h, v3 ol, v3 dl, float max_t, float grow, v3* n_out)
+{
+	float t0 = 0.0f, t1 = max_t; int fin = -1;
+	for (int f = 0; f < h->nf; ++f) {
+		const v3 n = h->normals[f];
+		const float den = v3_dot(n, dl), num = (h->plane_d[f] + grow) - v3_dot(n, ol);
+		if (fabsf(den) < 1.0e-12f) { if (num < 0.0f) return -1.0f; continue; }
+		const float t = num / den;
+		if (den < 0.0f) { if (t > t0) { t0 = t; fin = f; } } else { if (t < t1) t1 = t; }
+		if (t0 > t1) return -1.0f;
+	}
+	if (fin < 0) { *n_out = v3_neg(dl); return 0.0f; }
+	*n_out = h->normals[fin];
+	return t0;
+}
+

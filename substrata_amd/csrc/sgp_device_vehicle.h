@@ -10,7 +10,7 @@
 // The arithmetic (expression order included) is the contract checked by tests/test_vehicle_parity_gpu.py against the CPU
 // oracle; no libm call sits on this path (polynomial sin/cos/acos).  Regenerate with tools/derive_device_vehicle.py.
 #pragma once
-#include "sgp_device_math.h"
+#include "sgp_device_collide.h"     // sgd_hull (wheel casts against hull bodies)
 
 #define SGD_MAX_WHEELS 4
 #define SGD_MAX_GEARS 8
@@ -200,11 +200,13 @@ SGP_DEV static v3 sgd_perm_from_z(v3 v, int axis)
    (shape type / parameters p, pose pos + R).  Returns the travel distance at first touch (0 if it starts overlapping) or -1;
    n_out = world normal at the touch point on the body (towards the sphere), p_out = world touch point on the body.
    Box: the Minkowski sum box (+) ball is covered exactly by 3 boxes grown along one axis each plus 12 edge capsules. */
-SGP_DEV static float sgd_cast_sphere_body(int type, const float* p, v3 pos, m33 R, v3 o, v3 d, float max_t, float rs, v3* n_out, v3* p_out)
+SGP_DEV static float sgd_cast_sphere_body(int type, const float* p, const sgd_hull* hull, v3 pos, m33 R, v3 o, v3 d, float max_t, float rs, v3* n_out, v3* p_out)
 {
 	const v3 ol = m33_tmul(R, v3_sub(o, pos)), dl = m33_tmul(R, d);
 	float t = -1.0f; v3 nl = V3(0, 0, 0);
-	if (type == SGP_SHAPE_SPHERE) {
+	if (type == SGP_SHAPE_HULL) {
+		t = sgd_ray_hull(hull, ol, dl, max_t, rs, &nl);
+	} else if (type == SGP_SHAPE_SPHERE) {
 		t = sgd_ray_sphere(ol, dl, p[0] + rs, max_t, &nl);
 	} else if (type == SGP_SHAPE_CAPSULE) {
 		t = sgd_ray_capsule_z(ol, dl, p[0] + rs, p[1], max_t, &nl);

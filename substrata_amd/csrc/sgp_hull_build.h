@@ -1,0 +1,212 @@
+// sgp_hull_build.h -- HOST side of the convex hull shapes: hull from a point cloud, volume / centre of mass / inertia, body frame.
+//
+// Role of JPH::ConvexHullShapeSettings::Create + MassProperties (+ OffsetCenterOfMassShape) (/root/reference/gui_client/
+// CarPhysics.cpp:66-92, BikePhysics.cpp:76-112): brute-force supporting planes for <= 32 hull vertices, signed-tetrahedra mass
+// properties, Jacobi principal axes; double precision, rounded to float once.  Regenerate with tools/derive_device_vehicle.py.
+#pragma once
+#include <math.h>
+#include <string.h>
+#include "sgp_device_collide.h"     // sgd_hull
+
+static inline v3 sgh_v3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+
+struct sgh_d3 { double x, y, z; };
+static inline sgh_d3 sgh_d3_sub(sgh_d3 a, sgh_d3 b) { sgh_d3 r = { a.x - b.x, a.y - b.y, a.z - b.z }; return r; }
+static inline sgh_d3 sgh_d3_cross(sgh_d3 a, sgh_d3 b) { sgh_d3 r = { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; return r; }
+static inline double sgh_d3_dot(sgh_d3 a, sgh_d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// Jacobi eigen-decomposition of a symmetric 3x3 matrix: a -> diagonal, v = eigenvectors (columns).
+static inline void sgh_jacobi3(double a[3][3], double v[3][3])
+{
+	for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) v[i][j] = i == j ? 1.0 : 0.0;
+	for (int sweep = 0; sweep < 64; ++sweep) {
+		const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
+		if (off < 1.0e-14 * (fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]) + 1.0e-300)) break;
+		for (int p = 0; p < 2; ++p) for (int q = p + 1; q < 3; ++q) {
+			if (fabs(a[p][q]) < 1.0e-300) continue;
+			const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+			const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+			const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+			for (int k = 0; k < 3; ++k) { const double akp = a[k][p], akq = a[k][q]; a[k][p] = c * akp - s * akq; a[k][q] = s * akp + c * akq; }
+			for (int k = 0; k < 3; ++k) { const double apk = a[p][k], aqk = a[q][k]; a[p][k] = c * apk - s * aqk; a[q][k] = s * apk + c * aqk; }
+			for (int k = 0; k < 3; ++k) { const double vkp = v[k][p], vkq = v[k][q]; v[k][p] = c * vkp - s * vkq; v[k][q] = s * vkp + c * vkq; }
+		}
+	}
+}
+
+/* Returns 0 on success.  com_out / rot_out (quaternion xyzw): body frame expressed in the input frame, i.e.
+   input point = com + rot * body point. */
+static inline int sgd_hull_build(const float* pts_in, int n_in, sgd_hull* h, float com_out[3], float rot_out[4])
+{
+	memset(h, 0, sizeof(*h));
+	if (n_in < 4) return -1;
+	// 1. unique points
+	sgh_d3 pts[256]; int n = 0;
+	double ext = 0.0;
+	for (int i = 0; i < n_in; ++i) for (int k = 0; k < 3; ++k) { if (!isfinite(pts_in[3 * i + k])) return -1; ext = fmax(ext, fabs((double)pts_in[3 * i + k])); }
+	if (!(ext > 0.0)) return -1;
+	const double eps = 1.0e-5 * ext;
+	for (int i = 0; i < n_in && n < 256; ++i) {
+		const sgh_d3 p = { pts_in[3 * i], pts_in[3 * i + 1], pts_in[3 * i + 2] };
+		int dup = 0;
+		for (int j = 0; j < n; ++j) { const sgh_d3 d = sgh_d3_sub(p, pts[j]); if (sgh_d3_dot(d, d) < eps * eps) { dup = 1; break; } }
+		if (!dup) pts[n++] = p;
+	}
+	// 2. too many: keep the extreme points along a fixed set of directions (Fibonacci sphere)
+	if (n > SGD_HULL_MAX_VERTS) {
+		unsigned char keep[256]; memset(keep, 0, sizeof(keep)); int kept = 0;
+		for (int kk = 0; kk < 2 * SGD_HULL_MAX_VERTS && kept < SGD_HULL_MAX_VERTS; ++kk) {
+			const int k = (kk * 37) % (2 * SGD_HULL_MAX_VERTS);       // visit the directions spread over the whole sphere, not pole to pole
+			const double z = 1.0 - (2.0 * k + 1.0) / (2.0 * SGD_HULL_MAX_VERTS), rr = sqrt(1.0 - z * z), ph = k * 2.399963229728653;
+			const sgh_d3 dir = { rr * cos(ph), rr * sin(ph), z };
+			int bi = 0; double bd = -1.0e300;
+			for (int i = 0; i < n; ++i) { const double d = sgh_d3_dot(dir, pts[i]); if (d > bd) { bd = d; bi = i; } }
+			if (!keep[bi]) { keep[bi] = 1; ++kept; }
+		}
+		int m = 0;
+		for (int i = 0; i < n; ++i) if (keep[i]) pts[m++] = pts[i];
+		n = m;
+	}
+	if (n < 4) return -1;
+	// 3. faces: every supporting plane through three points; face = all points on that plane
+	unsigned int masks[SGD_HULL_MAX_FACES]; sgh_d3 fn[SGD_HULL_MAX_FACES]; double fd[SGD_HULL_MAX_FACES]; int nf = 0;
+	for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) for (int k = j + 1; k < n; ++k) {
+		sgh_d3 nn = sgh_d3_cross(sgh_d3_sub(pts[j], pts[i]), sgh_d3_sub(pts[k], pts[i]));
+		const double len = sqrt(sgh_d3_dot(nn, nn));
+		if (len < 1.0e-9 * ext * ext) continue;
+		nn.x /= len; nn.y /= len; nn.z /= len;
+		const double d0 = sgh_d3_dot(nn, pts[i]);
+		double mx = 0.0, mn = 0.0;
+		for (int q = 0; q < n; ++q) { const double s = sgh_d3_dot(nn, pts[q]) - d0; if (s > mx) mx = s; if (s < mn) mn = s; }
+		if (mx > eps && mn < -eps) continue;                 // points on both sides: not a supporting plane
+		if (mx > eps) { nn.x = -nn.x; nn.y = -nn.y; nn.z = -nn.z; }
+		const double dd = sgh_d3_dot(nn, pts[i]);
+		unsigned int mask = 0; int cnt = 0;
+		for (int q = 0; q < n; ++q) if (fabs(sgh_d3_dot(nn, pts[q]) - dd) <= eps) { mask |= 1u << q; ++cnt; }
+		if (cnt < 3) continue;
+		int known = 0;
+		for (int f = 0; f < nf; ++f) if (masks[f] == mask) { known = 1; break; }
+		if (known) continue;
+		if (nf == SGD_HULL_MAX_FACES || cnt > SGD_HULL_MAX_FACE_VERTS) return -2;
+		masks[nf] = mask; fn[nf] = nn; fd[nf] = dd; ++nf;
+	}
+	if (nf < 4) return -1;                                   // flat or degenerate cloud
+	// 4. drop interior points, order each face counter-clockwise seen from outside
+	unsigned int used = 0;
+	for (int f = 0; f < nf; ++f) used |= masks[f];
+	int remap[SGD_HULL_MAX_VERTS]; int nv = 0;
+	sgh_d3 hv[SGD_HULL_MAX_VERTS];
+	for (int q = 0; q < n; ++q) { if (used & (1u << q)) { remap[q] = nv; hv[nv++] = pts[q]; } else remap[q] = -1; }
+	int fstart[SGD_HULL_MAX_FACES + 1]; int fidx[SGD_HULL_MAX_FACE_IDX]; int nidx = 0;
+	for (int f = 0; f < nf; ++f) {
+		int ids[SGD_HULL_MAX_FACE_VERTS]; int cnt = 0;
+		sgh_d3 c = { 0, 0, 0 };
+		for (int q = 0; q < n; ++q) if (masks[f] & (1u << q)) { ids[cnt++] = remap[q]; c.x += pts[q].x; c.y += pts[q].y; c.z += pts[q].z; }
+		c.x /= cnt; c.y /= cnt; c.z /= cnt;
+		sgh_d3 u = sgh_d3_sub(hv[ids[0]], c);
+		const double ul = sqrt(sgh_d3_dot(u, u)); u.x /= ul; u.y /= ul; u.z /= ul;
+		const sgh_d3 w = sgh_d3_cross(fn[f], u);
+		double ang[SGD_HULL_MAX_FACE_VERTS];
+		for (int k = 0; k < cnt; ++k) { const sgh_d3 r = sgh_d3_sub(hv[ids[k]], c); ang[k] = atan2(sgh_d3_dot(r, w), sgh_d3_dot(r, u)); }
+		for (int a = 1; a < cnt; ++a) { const int id = ids[a]; const double av = ang[a]; int b = a - 1; while (b >= 0 && ang[b] > av) { ids[b + 1] = ids[b]; ang[b + 1] = ang[b]; --b; } ids[b + 1] = id; ang[b + 1] = av; }
+		if (nidx + cnt > SGD_HULL_MAX_FACE_IDX) return -2;
+		fstart[f] = nidx;
+		for (int k = 0; k < cnt; ++k) fidx[nidx++] = ids[k];
+	}
+	fstart[nf] = nidx;
+	// 5. volume, centre of mass, inertia about the origin (signed tetrahedra of the fan-triangulated faces)
+	double vol = 0.0; sgh_d3 cm = { 0, 0, 0 };
+	double xx = 0, yy = 0, zz = 0, xy = 0, xz = 0, yz = 0;
+	for (int f = 0; f < nf; ++f) {
+		for (int k = fstart[f] + 1; k + 1 < fstart[f + 1]; ++k) {
+			const sgh_d3 a = hv[fidx[fstart[f]]], b = hv[fidx[k]], c = hv[fidx[k + 1]];
+			const double det = sgh_d3_dot(a, sgh_d3_cross(b, c));
+			vol += det / 6.0;
+			cm.x += det / 24.0 * (a.x + b.x + c.x); cm.y += det / 24.0 * (a.y + b.y + c.y); cm.z += det / 24.0 * (a.z + b.z + c.z);
+			xx += det / 60.0 * (a.x * a.x + b.x * b.x + c.x * c.x + a.x * b.x + a.x * c.x + b.x * c.x);
+			yy += det / 60.0 * (a.y * a.y + b.y * b.y + c.y * c.y + a.y * b.y + a.y * c.y + b.y * c.y);
+			zz += det / 60.0 * (a.z * a.z + b.z * b.z + c.z * c.z + a.z * b.z + a.z * c.z + b.z * c.z);
+			xy += det / 120.0 * (2 * a.x * a.y + 2 * b.x * b.y + 2 * c.x * c.y + a.x * b.y + a.y * b.x + a.x * c.y + a.y * c.x + b.x * c.y + b.y * c.x);
+			xz += det / 120.0 * (2 * a.x * a.z + 2 * b.x * b.z + 2 * c.x * c.z + a.x * b.z + a.z * b.x + a.x * c.z + a.z * c.x + b.x * c.z + b.z * c.x);
+			yz += det / 120.0 * (2 * a.y * a.z + 2 * b.y * b.z + 2 * c.y * c.z + a.y * b.z + a.z * b.y + a.y * c.z + a.z * c.y + b.y * c.z + b.z * c.y);
+		}
+	}
+	if (!(vol > 1.0e-12 * ext * ext * ext)) return -1;
+	cm.x /= vol; cm.y /= vol; cm.z /= vol;
+	// second moments about the centre of mass, then the inertia tensor
+	xx -= vol * cm.x * cm.x; yy -= vol * cm.y * cm.y; zz -= vol * cm.z * cm.z;
+	xy -= vol * cm.x * cm.y; xz -= vol * cm.x * cm.z; yz -= vol * cm.y * cm.z;
+	double I[3][3] = { { yy + zz, -xy, -xz }, { -xy, xx + zz, -yz }, { -xz, -yz, xx + yy } }, V[3][3];
+	sgh_jacobi3(I, V);
+	// right-handed frame
+	{
+		const sgh_d3 c0 = { V[0][0], V[1][0], V[2][0] }, c1 = { V[0][1], V[1][1], V[2][1] }, c2 = { V[0][2], V[1][2], V[2][2] };
+		if (sgh_d3_dot(sgh_d3_cross(c0, c1), c2) < 0.0) { V[0][2] = -V[0][2]; V[1][2] = -V[1][2]; V[2][2] = -V[2][2]; }
+	}
+	// 6. into the body frame
+	h->nv = nv; h->nf = nf;
+	float bmin[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, bmax[3] = { -3.4e38f, -3.4e38f, -3.4e38f }; float br = 0.0f;
+	for (int i = 0; i < nv; ++i) {
+		const sgh_d3 r = sgh_d3_sub(hv[i], cm);
+		const double lx = V[0][0] * r.x + V[1][0] * r.y + V[2][0] * r.z, ly = V[0][1] * r.x + V[1][1] * r.y + V[2][1] * r.z, lz = V[0][2] * r.x + V[1][2] * r.y + V[2][2] * r.z;
+		h->verts[i] = sgh_v3((float)lx, (float)ly, (float)lz);
+		const float c[3] = { (float)lx, (float)ly, (float)lz };
+		for (int k = 0; k < 3; ++k) { if (c[k] < bmin[k]) bmin[k] = c[k]; if (c[k] > bmax[k]) bmax[k] = c[k]; }
+		const float rl = sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]); if (rl > br) br = rl;
+	}
+	for (int f = 0; f < nf; ++f) {
+		const sgh_d3 nn = fn[f];
+		h->normals[f] = sgh_v3((float)(V[0][0] * nn.x + V[1][0] * nn.y + V[2][0] * nn.z), (float)(V[0][1] * nn.x + V[1][1] * nn.y + V[2][1] * nn.z), (float)(V[0][2] * nn.x + V[1][2] * nn.y + V[2][2] * nn.z));
+		h->plane_d[f] = (float)(fd[f] - sgh_d3_dot(nn, cm));
+		h->face_start[f] = (unsigned char)fstart[f];
+	}
+	h->face_start[nf] = (unsigned char)fstart[nf];
+	for (int k = 0; k < nidx; ++k) h->face_idx[k] = (unsigned char)fidx[k];
+	// 7. edges: every consecutive pair of a face loop, once
+	int ne = 0;
+	for (int f = 0; f < nf; ++f) for (int k = fstart[f]; k < fstart[f + 1]; ++k) {
+		const int a = fidx[k], b = fidx[k + 1 < fstart[f + 1] ? k + 1 : fstart[f]];
+		const int lo = a < b ? a : b, hi = a < b ? b : a;
+		int known = 0;
+		for (int e = 0; e < ne; ++e) if (h->edge_a[e] == lo && h->edge_b[e] == hi) { known = 1; break; }
+		if (known) continue;
+		if (ne == SGD_HULL_MAX_EDGES) return -2;
+		h->edge_a[ne] = (unsigned char)lo; h->edge_b[ne] = (unsigned char)hi; ++ne;
+	}
+	h->ne = ne;
+	h->aabb_min = sgh_v3(bmin[0], bmin[1], bmin[2]); h->aabb_max = sgh_v3(bmax[0], bmax[1], bmax[2]);
+	h->bound_radius = br; h->volume = (float)vol;
+	h->unit_inertia = sgh_v3((float)I[0][0], (float)I[1][1], (float)I[2][2]);
+	com_out[0] = (float)cm.x; com_out[1] = (float)cm.y; com_out[2] = (float)cm.z;
+	// rotation matrix (columns = principal axes) -> quaternion
+	{
+		const double m00 = V[0][0], m11 = V[1][1], m22 = V[2][2];
+		double qw, qx, qy, qz;
+		const double tr = m00 + m11 + m22;
+		if (tr > 0.0) { const double s = sqrt(tr + 1.0) * 2.0; qw = 0.25 * s; qx = (V[2][1] - V[1][2]) / s; qy = (V[0][2] - V[2][0]) / s; qz = (V[1][0] - V[0][1]) / s; }
+		else if (m00 > m11 && m00 > m22) { const double s = sqrt(1.0 + m00 - m11 - m22) * 2.0; qw = (V[2][1] - V[1][2]) / s; qx = 0.25 * s; qy = (V[0][1] + V[1][0]) / s; qz = (V[0][2] + V[2][0]) / s; }
+		else if (m11 > m22) { const double s = sqrt(1.0 + m11 - m00 - m22) * 2.0; qw = (V[0][2] - V[2][0]) / s; qx = (V[0][1] + V[1][0]) / s; qy = 0.25 * s; qz = (V[1][2] + V[2][1]) / s; }
+		else { const double s = sqrt(1.0 + m22 - m00 - m11) * 2.0; qw = (V[1][0] - V[0][1]) / s; qx = (V[0][2] + V[2][0]) / s; qy = (V[1][2] + V[2][1]) / s; qz = 0.25 * s; }
+		rot_out[0] = (float)qx; rot_out[1] = (float)qy; rot_out[2] = (float)qz; rot_out[3] = (float)qw;
+	}
+	return 0;
+}
+
+// The +-1 cube every box is a scaled copy of (hull id 0 of every world).
+static inline void sgd_hull_cube_template(sgd_hull* h)
+{
+	float pts[24]; int k = 0;
+	for (int x = -1; x <= 1; x += 2) for (int y = -1; y <= 1; y += 2) for (int z = -1; z <= 1; z += 2) { pts[k++] = (float)x; pts[k++] = (float)y; pts[k++] = (float)z; }
+	float com[3], rot[4];
+	sgd_hull_build(pts, 8, h, com, rot);
+	// exact axis-aligned data regardless of what the eigen solver returned for the degenerate (isotropic) inertia
+	k = 0;
+	for (int i = 0; i < h->nv; ++i) { h->verts[i] = sgh_v3(h->verts[i].x < 0 ? -1.0f : 1.0f, h->verts[i].y < 0 ? -1.0f : 1.0f, h->verts[i].z < 0 ? -1.0f : 1.0f); }
+	for (int f = 0; f < h->nf; ++f) {
+		v3 n = h->normals[f];
+		n = sgh_v3(fabsf(n.x) > 0.5f ? (n.x < 0 ? -1.0f : 1.0f) : 0.0f, fabsf(n.y) > 0.5f ? (n.y < 0 ? -1.0f : 1.0f) : 0.0f, fabsf(n.z) > 0.5f ? (n.z < 0 ? -1.0f : 1.0f) : 0.0f);
+		h->normals[f] = n; h->plane_d[f] = 1.0f;
+	}
+	h->is_box_template = 1;
+}
+

@@ -51,7 +51,7 @@ struct StepCounters {
 	uint32_t n_manifolds;        // narrow-phase hits (incl. sensors)
 	uint32_t n_constraints;      // manifolds that became contact constraints
 	uint32_t n_points;
-	uint32_t pad_unused;
+	uint32_t n_hull_pairs;       // pairs with a convex hull, deferred to k_narrowphase_hull
 	uint32_t ucount[2];          // sizes of the two uncoloured worklists (round parity)
 	uint32_t rounds_used;        // colouring rounds that found work
 	uint32_t n_colours;          // highest used colour + 1 (overflow colour excluded)
@@ -186,6 +186,9 @@ struct DV {
 	EventCounters* evc;
 	uint32_t* ev_activated; uint32_t* ev_deactivated; uint32_t* ev_water;
 	sgp_contact_event* ev_contacts_added; sgp_contact_event* ev_contacts_persisted; uint32_t cap_contact_events;
+	// convex hull shapes (sgp_device_hull.h): fixed-capacity table, hull 0 = the +-1 cube template every box is a scaled copy of
+	const struct sgd_hull_s* hulls; uint32_t n_hulls;
+	uint2* hull_pairs; uint32_t cap_hull_pairs;
 	// wheeled vehicles (sgp_device_vehicle.h): AoS, one record per vehicle slot
 	struct sgd_vehicle* vehicles; uint32_t n_vehicles; const sgp_vehicle_input* vehicle_inputs;
 	// settings (fixed after world creation)
@@ -208,6 +211,8 @@ void launch_bp_scatter(const DV& d, uint32_t nb, hipStream_t s);
 void launch_bp_pairs(const DV& d, hipStream_t s);
 void launch_bp_large(const DV& d, uint32_t nb, hipStream_t s);
 void launch_narrowphase(const DV& d, uint32_t n_pairs_upper, hipStream_t s);
+void launch_narrowphase_hull(const DV& d, hipStream_t s);     // only worlds with hull shapes
+#define SGP_MAX_HULLS 256
 void launch_wake(const DV& d, uint32_t nb, hipStream_t s);
 void launch_prep_bodies(const DV& d, uint32_t nb, hipStream_t s);
 void launch_colour_inherit(const DV& d, uint32_t n_man, hipStream_t s);

@@ -37,23 +37,41 @@ SGP_DEV bool layers_collide(uint32_t l1, uint32_t l2)
 	return false;
 }
 
-SGP_DEV v3 shape_local_half(uint32_t type, float4 sh)
+SGP_DEV const sgd_hull* body_hull(const DV& d, float4 sh) { return &d.hulls[(uint32_t)sh.x]; }
+
+SGP_DEV v3 shape_local_half(const DV& d, uint32_t type, float4 sh)
 {
+	if (type == SGP_SHAPE_HULL) {
+		const sgd_hull* h = body_hull(d, sh);
+		return V3(fmaxf(fabsf(h->aabb_min.x), fabsf(h->aabb_max.x)), fmaxf(fabsf(h->aabb_min.y), fabsf(h->aabb_max.y)), fmaxf(fabsf(h->aabb_min.z), fabsf(h->aabb_max.z)));
+	}
 	if (type == SGP_SHAPE_SPHERE) return V3(sh.x, sh.x, sh.x);
 	if (type == SGP_SHAPE_BOX) return V3(sh.x, sh.y, sh.z);
 	return V3(sh.x, sh.x, sh.y + sh.x);
 }
 
-SGP_DEV float shape_volume(uint32_t type, float4 sh)
+SGP_DEV float shape_volume(const DV& d, uint32_t type, float4 sh)
 {
+	if (type == SGP_SHAPE_HULL) return body_hull(d, sh)->volume;
 	if (type == SGP_SHAPE_SPHERE) return (4.0f / 3.0f) * 3.14159265358979323846f * sh.x * sh.x * sh.x;
 	if (type == SGP_SHAPE_BOX) return 8.0f * sh.x * sh.y * sh.z;
 	return 3.14159265358979323846f * sh.x * sh.x * (2.0f * sh.y) + (4.0f / 3.0f) * 3.14159265358979323846f * sh.x * sh.x * sh.x;
 }
 
-SGP_DEV void compute_aabb(uint32_t type, float4 sh, v3 pos, quat q, v3& mn, v3& mx)
+SGP_DEV void compute_aabb(const DV& d, uint32_t type, float4 sh, v3 pos, quat q, v3& mn, v3& mx)
 {
 	v3 e;
+	if (type == SGP_SHAPE_HULL) {
+		const sgd_hull* h = body_hull(d, sh);
+		const m33 R = quat_to_m33(q);
+		v3 lo = V3(3.4e38f, 3.4e38f, 3.4e38f), hi = V3(-3.4e38f, -3.4e38f, -3.4e38f);
+		for (int i = 0; i < h->nv; ++i) {
+			const v3 p = m33_mul(R, h->verts[i]);
+			lo = V3(fminf(lo.x, p.x), fminf(lo.y, p.y), fminf(lo.z, p.z)); hi = V3(fmaxf(hi.x, p.x), fmaxf(hi.y, p.y), fmaxf(hi.z, p.z));
+		}
+		mn = v3_add(pos, lo); mx = v3_add(pos, hi);
+		return;
+	}
 	if (type == SGP_SHAPE_SPHERE) e = V3(sh.x, sh.x, sh.x);
 	else {
 		const m33 R = quat_to_m33(q);
@@ -70,9 +88,9 @@ SGP_DEV void compute_aabb(uint32_t type, float4 sh, v3 pos, quat q, v3& mn, v3& 
 }
 
 // Body::GetSleepTestPoints
-SGP_DEV void sleep_points(uint32_t type, float4 sh, v3 pos, quat q, v3 out[3])
+SGP_DEV void sleep_points(const DV& d, uint32_t type, float4 sh, v3 pos, quat q, v3 out[3])
 {
-	const v3 ext = shape_local_half(type, sh);
+	const v3 ext = shape_local_half(d, type, sh);
 	const m33 R = quat_to_m33(q);
 	int lowest = 0;
 	if (ext.y < v3_get(ext, lowest)) lowest = 1;
@@ -87,7 +105,7 @@ SGP_DEV void sleep_points(uint32_t type, float4 sh, v3 pos, quat q, v3 out[3])
 SGP_DEV void reset_sleep(const DV& d, uint32_t i, uint32_t type, float4 sh, v3 pos, quat q)
 {
 	v3 p[3];
-	sleep_points(type, sh, pos, q, p);
+	sleep_points(d, type, sh, pos, q, p);
 	d.sleep_s[0][i] = F4(p[0], 0.0f);
 	d.sleep_s[1][i] = F4(p[1], 0.0f);
 	d.sleep_s[2][i] = F4(p[2], 0.0f);
@@ -537,7 +555,27 @@ SGP_DEV sgd_shape load_shape(const DV& d, uint32_t i, uint32_t f)
 	s.type = (int)f_shape(f);
 	const float4 sh = d.shape[i];
 	s.p0 = sh.x; s.p1 = sh.y; s.p2 = sh.z;
+	s.hull = s.type == SGP_SHAPE_HULL ? body_hull(d, sh) : (s.type == SGP_SHAPE_BOX ? &d.hulls[0] : nullptr);
 	return s;
+}
+
+SGP_DEV void emit_manifold(const DV& d, uint2 ab, uint32_t fa, uint32_t fb, const sgd_manifold& m)
+{
+	const uint32_t slot = atomicAdd(&d.ctr->n_manifolds, 1u);
+	if (slot >= d.cap_manifolds) { atomicAdd(&d.ctr->manifolds_dropped, 1u); return; }
+	d.man_ab[slot] = ab;
+	const bool sensor = (fa | fb) & BF_SENSOR;
+	// bit 8 = sensor pair (mIsSensor, PhysicsWorld.cpp:1235): reported in the contact events, kept in the contact list
+	// (so that it is 'persisted' next step) but with zero points for the solver
+	d.man_n[slot] = make_float4(m.n.x, m.n.y, m.n.z, __int_as_float(m.np | (sensor ? 0x100 : 0)));
+	for (int k = 0; k < 4; ++k) if (k < m.np) { d.man_p1[k][slot] = F4(m.p1[k], 0.0f); d.man_p2[k][slot] = F4(m.p2[k], 0.0f); }
+	d.man_prio[slot] = sgp_mix64(((uint64_t)ab.x << 32) | ab.y);
+	d.man_colour[slot] = -1;
+	if (!sensor) {
+		const bool actA = f_active_for_pairs(fa), actB = f_active_for_pairs(fb);
+		if (actA && !actB && f_motion(fb) == SGP_MOTION_DYNAMIC) atomicOr(&d.flags[ab.y], BF_WAKE);
+		if (actB && !actA && f_motion(fa) == SGP_MOTION_DYNAMIC) atomicOr(&d.flags[ab.x], BF_WAKE);
+	}
 }
 
 __global__ void __launch_bounds__(TPB) k_narrowphase(DV d)
@@ -546,24 +584,31 @@ __global__ void __launch_bounds__(TPB) k_narrowphase(DV d)
 	for (uint32_t p = blockIdx.x * TPB + threadIdx.x; p < n; p += gridDim.x * TPB) {
 		const uint2 ab = d.pairs[p];
 		const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
+		if (f_shape(fa) == SGP_SHAPE_HULL || f_shape(fb) == SGP_SHAPE_HULL) {
+			// the polytope paths (clip buffers in scratch, long loops) live in their own kernel so that they do not cost the
+			// sphere / box / capsule pairs registers or scratch
+			const uint32_t k = atomicAdd(&d.ctr->n_hull_pairs, 1u);
+			if (k < d.cap_hull_pairs) d.hull_pairs[k] = ab; else atomicAdd(&d.ctr->pairs_dropped, 1u);
+			continue;
+		}
 		const sgd_shape sa = load_shape(d, ab.x, fa), sb = load_shape(d, ab.y, fb);
 		sgd_manifold m;
 		if (!sgd_collide(&sa, &sb, d.st.speculative_contact_distance, &m)) continue;
-		const uint32_t slot = atomicAdd(&d.ctr->n_manifolds, 1u);
-		if (slot >= d.cap_manifolds) { atomicAdd(&d.ctr->manifolds_dropped, 1u); continue; }
-		d.man_ab[slot] = ab;
-		const bool sensor = (fa | fb) & BF_SENSOR;
-		// bit 8 = sensor pair (mIsSensor, PhysicsWorld.cpp:1235): reported in the contact events, kept in the contact list
-		// (so that it is 'persisted' next step) but with zero points for the solver
-		d.man_n[slot] = make_float4(m.n.x, m.n.y, m.n.z, __int_as_float(m.np | (sensor ? 0x100 : 0)));
-		for (int k = 0; k < 4; ++k) if (k < m.np) { d.man_p1[k][slot] = F4(m.p1[k], 0.0f); d.man_p2[k][slot] = F4(m.p2[k], 0.0f); }
-		d.man_prio[slot] = sgp_mix64(((uint64_t)ab.x << 32) | ab.y);
-		d.man_colour[slot] = -1;
-		if (!sensor) {
-			const bool actA = f_active_for_pairs(fa), actB = f_active_for_pairs(fb);
-			if (actA && !actB && f_motion(fb) == SGP_MOTION_DYNAMIC) atomicOr(&d.flags[ab.y], BF_WAKE);
-			if (actB && !actA && f_motion(fa) == SGP_MOTION_DYNAMIC) atomicOr(&d.flags[ab.x], BF_WAKE);
-		}
+		emit_manifold(d, ab, fa, fb, m);
+	}
+}
+
+// pairs with a convex hull (hull - hull / box / sphere / capsule): one thread per pair
+__global__ void __launch_bounds__(64) k_narrowphase_hull(DV d)
+{
+	const uint32_t n = min(d.ctr->n_hull_pairs, d.cap_hull_pairs);
+	for (uint32_t p = blockIdx.x * 64 + threadIdx.x; p < n; p += gridDim.x * 64) {
+		const uint2 ab = d.hull_pairs[p];
+		const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
+		const sgd_shape sa = load_shape(d, ab.x, fa), sb = load_shape(d, ab.y, fb);
+		sgd_manifold m;
+		if (!sgd_collide_hull(&sa, &sb, d.st.speculative_contact_distance, &m)) continue;
+		emit_manifold(d, ab, fa, fb, m);
 	}
 }
 
@@ -1217,7 +1262,7 @@ __global__ void __launch_bounds__(TPB) k_finalize(DV d)
 	const v3 pos = V3(d.pos_im[i]);
 	const quat q = Q4(d.rot[i]);
 	v3 mn, mx;
-	compute_aabb(type, sh, pos, q, mn, mx);
+	compute_aabb(d, type, sh, pos, q, mn, mx);
 	d.aabb_min[i] = F4(mn, 0.0f);
 	d.aabb_max[i] = F4(mx, 0.0f);
 	if (!f_movable(f)) return;
@@ -1226,7 +1271,7 @@ __global__ void __launch_bounds__(TPB) k_finalize(DV d)
 	else {
 		const float max_movement = d.st.point_velocity_sleep_threshold * d.st.time_before_sleep;
 		v3 pts[3];
-		sleep_points(type, sh, pos, q, pts);
+		sleep_points(d, type, sh, pos, q, pts);
 		bool reset = false;
 		float4 s[3];
 		for (int k = 0; k < 3; ++k) {
@@ -1406,7 +1451,7 @@ __global__ void __launch_bounds__(TPB) k_buoyancy(DV d)
 		const float4 pim = d.pos_im[i];
 		const v3 pos = V3(pim);
 		const m33 R = quat_to_m33(Q4(d.rot[i]));
-		const float total = shape_volume(type, sh);
+		const float total = shape_volume(d, type, sh);
 		float sub; v3 rc;
 		if (type == SGP_SHAPE_BOX) box_submerged(V3(sh.x, sh.y, sh.z), R, pos.z, d.sp->water_z, &sub, &rc);
 		else if (type == SGP_SHAPE_SPHERE) {
@@ -1436,7 +1481,7 @@ __global__ void __launch_bounds__(TPB) k_buoyancy(DV d)
 			const v3 cob_vel = v3_add(lv, v3_cross(av, rc));
 			const v3 rel = v3_neg(cob_vel);
 			const float lin_drag = (f & BF_ZERO_LIN_DRAG) ? 0.0f : 0.1f;             // :1404
-			const v3 size = v3_scale(shape_local_half(type, sh), 2.0f);
+			const v3 size = v3_scale(shape_local_half(d, type, sh), 2.0f);
 			const v3 lrel = m33_tmul(R, rel);
 			const float rl2 = v3_len_sq(lrel);
 			v3 drag_imp = V3(0.0f, 0.0f, 0.0f);
@@ -1528,7 +1573,7 @@ __global__ void __launch_bounds__(TPB) k_contact_events(DV d)
 SGP_DEV void refresh_aabb(const DV& d, uint32_t i, uint32_t f)
 {
 	v3 mn, mx;
-	compute_aabb(f_shape(f), d.shape[i], V3(d.pos_im[i]), Q4(d.rot[i]), mn, mx);
+	compute_aabb(d, f_shape(f), d.shape[i], V3(d.pos_im[i]), Q4(d.rot[i]), mn, mx);
 	d.aabb_min[i] = F4(mn, 0.0f); d.aabb_max[i] = F4(mx, 0.0f);
 }
 
@@ -1677,10 +1722,17 @@ __global__ void __launch_bounds__(TPB) k_dump_constraints(DV d, uint32_t which, 
 // ---------------------------------------------------------------------------------------------------------------
 // ray queries (traceRay, PhysicsWorld.cpp:1668-1725), one thread per ray, brute force over bodies with an AABB slab test
 
-SGP_DEV float ray_body(uint32_t type, float4 sh, v3 pos, quat q, v3 o, v3 dir, float max_t, v3* n_out)
+SGP_DEV float ray_body(const DV& d, uint32_t type, float4 sh, v3 pos, quat q, v3 o, v3 dir, float max_t, v3* n_out)
 {
 	const m33 R = quat_to_m33(q);
 	const v3 ol = m33_tmul(R, v3_sub(o, pos)), dl = m33_tmul(R, dir);
+	if (type == SGP_SHAPE_HULL) {
+		v3 nl;
+		const float t = sgd_ray_hull(body_hull(d, sh), ol, dl, max_t, 0.0f, &nl);
+		if (t < 0.0f) return -1.0f;
+		*n_out = m33_mul(R, nl);
+		return t;
+	}
 	if (type == SGP_SHAPE_SPHERE) {
 		const float r = sh.x;
 		const float B = v3_dot(ol, dl), C = v3_len_sq(ol) - r * r;
@@ -1770,7 +1822,7 @@ SGP_DEV void ray_test_body(const DV& d, const sgp_ray& ry, v3 o, v3 dir, uint32_
 	if (ry.collidable_only && !(layer == SGP_LAYER_NON_MOVING || layer == SGP_LAYER_MOVING)) return;
 	if (!ray_aabb(o, dir, d.aabb_min[i], d.aabb_max[i], best.t)) return;
 	v3 nn;
-	const float t = ray_body(f_shape(f), d.shape[i], V3(d.pos_im[i]), Q4(d.rot[i]), o, dir, best.t, &nn);
+	const float t = ray_body(d, f_shape(f), d.shape[i], V3(d.pos_im[i]), Q4(d.rot[i]), o, dir, best.t, &nn);
 	// closest hit; ties go to the lower body id so the result does not depend on the traversal order
 	if (t >= 0.0f && t <= best.t && (t < best.t || best.id == SGP_INVALID_ID || i < best.id)) { best.t = t; best.id = i; best.n = nn; }
 }
@@ -1860,7 +1912,7 @@ SGP_DEV void veh_cast_test(const DV& d, const sgd_vehicle* v, v3 o, v3 dir, floa
 	const float4 sh = d.shape[j];
 	const float prm[3] = { sh.x, sh.y, sh.z };
 	v3 n, p;
-	const float t = sgd_cast_sphere_body((int)f_shape(f), prm, V3(d.pos_im[j]), quat_to_m33(Q4(d.rot[j])), o, dir, best, rs, &n, &p);
+	const float t = sgd_cast_sphere_body((int)f_shape(f), prm, f_shape(f) == SGP_SHAPE_HULL ? body_hull(d, sh) : nullptr, V3(d.pos_im[j]), quat_to_m33(Q4(d.rot[j])), o, dir, best, rs, &n, &p);
 	if (t < 0.0f || n.z < v->cos_max_slope) return;
 	// closest accepted hit; on equal distance the lower body id wins (the oracle visits ids in ascending order)
 	if (t < best || bid == SGP_INVALID_ID || (t == best && j < bid)) { best = t; bid = j; bn = n; bp = p; }
@@ -2067,6 +2119,7 @@ void launch_bp_scatter(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKerne
 void launch_bp_pairs(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_bp_pairs, dim3(4096), dim3(TPB), 0, s, d); }
 void launch_bp_large(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_bp_large, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_narrowphase(const DV& d, uint32_t est, hipStream_t s) { hipLaunchKernelGGL(k_narrowphase, dim3(stride_grid(est)), dim3(TPB), 0, s, d); }
+void launch_narrowphase_hull(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_narrowphase_hull, dim3(256), dim3(64), 0, s, d); }
 void launch_wake(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_wake, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_prep_bodies(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_prep_bodies, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_colour_inherit(const DV& d, uint32_t est, hipStream_t s) { hipLaunchKernelGGL(k_colour_inherit, dim3(stride_grid(est)), dim3(TPB), 0, s, d); }

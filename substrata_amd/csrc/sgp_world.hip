@@ -19,6 +19,7 @@
 #include <chrono>
 #include "sgp_kernels.h"
 #include "sgp_device_vehicle.h"
+#include "sgp_hull_build.h"
 
 #define SGP_API extern "C" __attribute__((visibility("default")))
 
@@ -81,6 +82,8 @@ struct sgp_world {
 	std::string last_plan_key; uint32_t plan_repeats = 0; bool use_graphs = true; bool use_small_world = true;
 	uint32_t graph_launches = 0, eager_steps = 0, idle_steps = 0;
 	bool grid_valid = false;                                   // the broad-phase grid matches the current poses (ray queries reuse it)
+	// convex hull shapes: host copies of the device table (mass properties, radii) -- hull 0 is the +-1 cube template
+	std::vector<sgd_hull> hulls; sgd_hull* d_hulls = nullptr;
 	// wheeled vehicles: device records (AoS) + host mirror of what the ABI needs without a read-back
 	sgd_vehicle* d_vehicles = nullptr; sgp_vehicle_input* d_veh_inputs = nullptr; uint32_t cap_vehicles = 0, n_vehicles = 0;
 	std::vector<uint8_t> veh_alive; std::vector<uint32_t> veh_body; std::vector<sgp_vehicle_input> veh_inputs; bool veh_inputs_dirty = false;
@@ -190,6 +193,7 @@ SGP_API int sgp_abi_sizeof(int which)
 	case 6: return (int)sizeof(sgp_ray); case 7: return (int)sizeof(sgp_hit); case 8: return (int)sizeof(sgp_step_stats);
 	case 9: return (int)sizeof(sgp_step_profile); case 10: return (int)sizeof(sgp_ghost_record);
 	case 11: return (int)sizeof(sgp_vehicle_desc); case 12: return (int)sizeof(sgp_vehicle_input); case 13: return (int)sizeof(sgp_vehicle_state);
+	case 14: return (int)sizeof(sgp_hull_info);
 	default: return -1;
 	}
 }
@@ -254,6 +258,14 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	DEV_ALLOC(d.cell_hash, N);
 	DEV_ALLOC(d.cell_count, d.table_size + 4); DEV_ALLOC(d.cell_start, d.table_size + 4); DEV_ALLOC(d.cell_fill, d.table_size + 4);
 	DEV_ALLOC(w->d_large, N); w->cap_large = N; d.large_ids = w->d_large;
+	DEV_ALLOC(w->d_hulls, SGP_MAX_HULLS); d.hulls = w->d_hulls;
+	d.cap_hull_pairs = P / 4 + 1024; DEV_ALLOC(d.hull_pairs, d.cap_hull_pairs);
+	{
+		sgd_hull cube; sgd_hull_cube_template(&cube);
+		w->hulls.push_back(cube);
+		HIP_TRY(hipMemcpyAsync(&w->d_hulls[0], &w->hulls[0], sizeof(sgd_hull), hipMemcpyHostToDevice, w->stream));
+		d.n_hulls = 1;
+	}
 	DEV_ALLOC(d.sorted_min, N); DEV_ALLOC(d.sorted_max, N); DEV_ALLOC(d.grid, 1); DEV_ALLOC(d.scan_block_sums, (d.table_size + 1) / 1024 + 2);
 	DEV_ALLOC(d.pairs, P);
 	DEV_ALLOC(d.man_ab, M); DEV_ALLOC(d.man_n, M); DEV_ALLOC(d.man_colour, M); DEV_ALLOC(d.man_prio, M);
@@ -368,8 +380,14 @@ static void note_radius(sgp_world* w, uint32_t id, float r)
 static int add_one(sgp_world* w, const sgp_body_desc* d, uint32_t* id_out, bool ghost)
 {
 	if (!finite3(d->pos) || fabsf(d->pos[0]) > 1.0e9f || fabsf(d->pos[1]) > 1.0e9f || fabsf(d->pos[2]) > 1.0e9f) return SGP_ERR_REJECTED;   // :1178
-	if (d->shape_type < 0 || d->shape_type > 2) return fail(SGP_ERR_INVALID, "sgp_body_add: bad shape_type");
-	const int nparam = d->shape_type == SGP_SHAPE_BOX ? 3 : (d->shape_type == SGP_SHAPE_SPHERE ? 1 : 2);
+	if (d->shape_type < 0 || d->shape_type > SGP_SHAPE_HULL) return fail(SGP_ERR_INVALID, "sgp_body_add: bad shape_type");
+	const sgd_hull* hull = nullptr;
+	if (d->shape_type == SGP_SHAPE_HULL) {
+		const uint32_t hid = (uint32_t)d->shape[0];
+		if (!(d->shape[0] >= 1.0f) || (float)hid != d->shape[0] || hid >= w->hulls.size()) return fail(SGP_ERR_INVALID, "sgp_body_add: bad hull id");
+		hull = &w->hulls[hid];
+	}
+	const int nparam = d->shape_type == SGP_SHAPE_BOX ? 3 : (d->shape_type == SGP_SHAPE_SPHERE ? 1 : (d->shape_type == SGP_SHAPE_HULL ? 0 : 2));
 	for (int i = 0; i < nparam; ++i) {
 		const float lim = (d->shape_type == SGP_SHAPE_CAPSULE && i == 1) ? 0.0f : 0.5e-7f;   // |scale| < 1e-7 on a 0.5 unit shape, :1184
 		if (!std::isfinite(d->shape[i]) || d->shape[i] < lim) return SGP_ERR_REJECTED;
@@ -386,7 +404,14 @@ static int add_one(sgp_world* w, const sgp_body_desc* d, uint32_t* id_out, bool 
 	c.restitution = clamp01(d->restitution);           // :1237
 	c.mass = std::max(0.001f, d->mass);                // :1238
 	c.gravity_factor = d->gravity_factor; c.lin_damp = d->linear_damping; c.ang_damp = d->angular_damping;
-	if (d->motion_type == SGP_MOTION_DYNAMIC) mass_properties(d->shape_type, d->shape, c.mass, &c.inv_mass, c.inv_inertia);
+	if (d->motion_type == SGP_MOTION_DYNAMIC) {
+		if (hull) {
+			// MassProperties of the hull scaled to the overridden mass; the body frame already is the principal frame
+			const float density = c.mass / hull->volume;
+			c.inv_mass = 1.0f / c.mass;
+			c.inv_inertia[0] = 1.0f / (hull->unit_inertia.x * density); c.inv_inertia[1] = 1.0f / (hull->unit_inertia.y * density); c.inv_inertia[2] = 1.0f / (hull->unit_inertia.z * density);
+		} else mass_properties(d->shape_type, d->shape, c.mass, &c.inv_mass, c.inv_inertia);
+	}
 	uint32_t f = BF_ALIVE | ((uint32_t)d->motion_type & BF_MOTION_MASK) | (((uint32_t)d->layer & 0x3u) << BF_LAYER_SHIFT) |
 	             (((uint32_t)d->shape_type & 0x3u) << BF_SHAPE_SHIFT);
 	if (d->is_sensor) f |= BF_SENSOR;
@@ -395,8 +420,8 @@ static int add_one(sgp_world* w, const sgp_body_desc* d, uint32_t* id_out, bool 
 	if (ghost) f |= BF_GHOST;
 	HostBody& hb = w->hb[id];
 	hb.flags = f; hb.userdata = d->userdata; hb.ghost = ghost;
-	note_radius(w, id, bounding_radius(d->shape_type, d->shape));
-	hb.volume = host_shape_volume(d->shape_type, d->shape);
+	note_radius(w, id, hull ? hull->bound_radius : bounding_radius(d->shape_type, d->shape));
+	hb.volume = hull ? hull->volume : host_shape_volume(d->shape_type, d->shape);
 	c.flags = hb.flags;
 	w->cmds.push_back(c);
 	if (d->activate && d->motion_type != SGP_MOTION_STATIC) { BodyCmd a; memset(&a, 0, sizeof(a)); a.id = id; a.ops = CMD_ACTIVATE; w->cmds.push_back(a); }
@@ -514,8 +539,11 @@ SGP_API int sgp_body_set_pose_shape(sgp_world* w, uint32_t id, const float pos[3
 	BodyCmd c = blank_cmd(id, CMD_SET_POS | CMD_SET_ROT | CMD_SET_VEL | CMD_SET_SHAPE | CMD_ACTIVATE);
 	memcpy(c.pos, pos, 12); memcpy(c.rot, rot, 16); memcpy(c.shape, shape, 16);
 	const int type = (int)((w->hb[id].flags & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT);
-	note_radius(w, id, bounding_radius(type, shape));
-	w->hb[id].volume = host_shape_volume(type, shape);
+	if (type == SGP_SHAPE_HULL) c.ops &= ~CMD_SET_SHAPE;          // hulls are pre-scaled: only the pose changes
+	else {
+		note_radius(w, id, bounding_radius(type, shape));
+		w->hb[id].volume = host_shape_volume(type, shape);
+	}
 	w->cmds.push_back(c);
 	return SGP_OK;
 }
@@ -696,6 +724,7 @@ struct StepPlan {
 	uint32_t colour_est[SGP_MAX_COLOURS];
 	int      water, contact_events, warm_start, vel_iters, pos_iters;
 	uint32_t n_vehicles;
+	int      has_hulls;          // some body may be a convex hull: run the hull-pair narrow phase
 	int      small_world;        // warm start + velocity iterations as ONE single-workgroup launch (k_solve_small)
 	StepParams sp;               // by-value kernel argument of the first launch: part of the key of a captured graph
 };
@@ -713,6 +742,7 @@ static void make_plan(const sgp_world* w, StepPlan& p)
 	p.water = w->h_sp->water_enabled; p.contact_events = w->h_sp->contact_events;
 	p.warm_start = w->dv.st.warm_start; p.vel_iters = w->dv.st.num_velocity_steps; p.pos_iters = w->dv.st.num_position_steps;
 	p.n_vehicles = w->n_vehicles;
+	p.has_hulls = w->hulls.size() > 1 ? 1 : 0;
 	p.small_world = (tf == 0 && w->high <= SGP_SMALL_WORLD_BODIES && w->n_vehicles == 0 && w->use_small_world) ? 1 : 0;
 	p.sp = *w->h_sp;
 }
@@ -736,7 +766,7 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 	{ KScope k(w, KC_BP_LARGE); launch_bp_large(d, nb, s); }
 	STAGE_MARK(2);
 	// -- 3. narrow phase, wake-ups, per-body solver records (+ contact events, which see the velocities before the solve)
-	{ KScope k(w, KC_NARROWPHASE); launch_narrowphase(d, p.est_pairs, s); }
+	{ KScope k(w, KC_NARROWPHASE); launch_narrowphase(d, p.est_pairs, s); if (p.has_hulls) launch_narrowphase_hull(d, s); }
 	{ KScope k(w, KC_WAKE); launch_wake(d, nb, s); }
 	{ KScope k(w, KC_PREP_BODIES); launch_prep_bodies(d, nb, s); }
 	if (p.contact_events) { KScope k(w, KC_MISC); launch_contact_events(d, p.est_man, s); }
@@ -956,6 +986,35 @@ SGP_API int sgp_world_set_contact_events(sgp_world* w, int enabled)
 		w->graphs.clear();
 	}
 	w->h_sp->contact_events = enabled;
+	return SGP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// convex hull shapes (ConvexHullShapeSettings::Create, CarPhysics.cpp:66-78)
+
+static void invalidate_graphs(sgp_world* w);
+
+SGP_API int sgp_hull_create(sgp_world* w, const float* pts, uint32_t n, sgp_hull_info* info)
+{
+	if (!w || !pts || !info || n < 4 || n > 100000) return fail(SGP_ERR_INVALID, "sgp_hull_create: bad arguments");
+	if (w->hulls.size() >= SGP_MAX_HULLS) return fail(SGP_ERR_CAPACITY, "sgp_hull_create: hull table full");
+	hipSetDevice(w->device);
+	sgd_hull h;
+	float com[3], rot[4];
+	if (sgd_hull_build(pts, (int)(n > 256 ? 256 : n), &h, com, rot) != 0) return fail(SGP_ERR_REJECTED, "sgp_hull_create: degenerate point cloud or too many faces");
+	const uint32_t id = (uint32_t)w->hulls.size();
+	w->hulls.push_back(h);
+	HIP_TRY(hipMemcpyAsync(&w->d_hulls[id], &w->hulls[id], sizeof(sgd_hull), hipMemcpyHostToDevice, w->stream));
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	w->dv.n_hulls = (uint32_t)w->hulls.size();
+	invalidate_graphs(w);                        // DV travels by value in the captured launches
+	memset(info, 0, sizeof(*info));
+	info->hull_id = id; info->num_vertices = (uint32_t)h.nv; info->num_faces = (uint32_t)h.nf; info->num_edges = (uint32_t)h.ne;
+	memcpy(info->com, com, sizeof(com)); memcpy(info->rot, rot, sizeof(rot));
+	info->volume = h.volume;
+	info->unit_inertia[0] = h.unit_inertia.x; info->unit_inertia[1] = h.unit_inertia.y; info->unit_inertia[2] = h.unit_inertia.z;
+	info->aabb_min[0] = h.aabb_min.x; info->aabb_min[1] = h.aabb_min.y; info->aabb_min[2] = h.aabb_min.z;
+	info->aabb_max[0] = h.aabb_max.x; info->aabb_max[1] = h.aabb_max.y; info->aabb_max[2] = h.aabb_max.z;
 	return SGP_OK;
 }
 
