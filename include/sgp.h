@@ -323,6 +323,9 @@ typedef struct sgp_hull_info {
 	float aabb_min[3], aabb_max[3];           /* body frame                                                                      */
 } sgp_hull_info;
 int  sgp_hull_create(sgp_world* w, const float* points_xyz, uint32_t num_points, sgp_hull_info* info_out);
+/* The same wrapped in JPH::OffsetCenterOfMassShapeSettings(com_offset, hull) (PhysicsWorld.cpp:1138-1153, CarPhysics.cpp:76-78,
+ * BikePhysics.cpp:103-105): the body's centre of mass sits at hull centre of mass + com_offset (frame of the points). */
+int  sgp_hull_create_com(sgp_world* w, const float* points_xyz, uint32_t num_points, const float com_offset[3], sgp_hull_info* info_out);
 
 /* ---- wheeled vehicles --------------------------------------------------------
  * Replaces JPH::VehicleConstraint + JPH::WheeledVehicleController + JPH::VehicleCollisionTesterCastSphere as CarPhysics

@@ -1837,12 +1837,12 @@ SGO_API int sgo_collide_pair(const sgp_body_desc* a, const sgp_body_desc* b, flo
 }
 
 /* ConvexHullShapeSettings::Create */
-SGO_API int sgo_hull_create(sgo_world* w, const float* pts, uint32_t n, sgp_hull_info* info)
+SGO_API int sgo_hull_create_com(sgo_world* w, const float* pts, uint32_t n, const float* com_offset, sgp_hull_info* info)
 {
 	if (!w || !pts || !info || n < 4 || n > 100000) return SGP_ERR_INVALID;
 	sgo_hull* h = (sgo_hull*)malloc(sizeof(sgo_hull));
 	float com[3], rot[4];
-	if (sgo_hull_build(pts, (int)(n > 256 ? 256 : n), h, com, rot) != 0) { free(h); return SGP_ERR_REJECTED; }
+	if (sgo_hull_build(pts, (int)(n > 256 ? 256 : n), com_offset, h, com, rot) != 0) { free(h); return SGP_ERR_REJECTED; }
 	if (w->n_hulls == w->cap_hulls) { w->cap_hulls *= 2; w->hulls = (sgo_hull**)realloc(w->hulls, sizeof(sgo_hull*) * w->cap_hulls); }
 	const uint32_t id = w->n_hulls++;
 	w->hulls[id] = h;
@@ -1855,6 +1855,8 @@ SGO_API int sgo_hull_create(sgo_world* w, const float* pts, uint32_t n, sgp_hull
 	info->aabb_max[0] = h->aabb_max.x; info->aabb_max[1] = h->aabb_max.y; info->aabb_max[2] = h->aabb_max.z;
 	return SGP_OK;
 }
+
+SGO_API int sgo_hull_create(sgo_world* w, const float* pts, uint32_t n, sgp_hull_info* info) { return sgo_hull_create_com(w, pts, n, NULL, info); }
 
 /* Test hook: the hull as stored (body frame). verts[nv][3], planes[nf][4]; returns nv | nf << 16. */
 SGO_API int sgo_hull_dump(sgo_world* w, uint32_t id, float* verts, float* planes)

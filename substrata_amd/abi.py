@@ -235,6 +235,7 @@ PROTOTYPES = {
     "world_device_array": (C.c_int, [vp, C.c_int, P(vp), P(u32)]),
     "world_stream": (C.c_int, [vp, P(vp)]),
     "hull_create": (C.c_int, [vp, vp, u32, P(HullInfo)]),
+    "hull_create_com": (C.c_int, [vp, vp, u32, P(f32), P(HullInfo)]),
     "default_vehicle_desc": (None, [P(VehicleDesc)]),
     "vehicle_create": (C.c_int, [vp, P(VehicleDesc), P(u32)]),
     "vehicle_destroy": (C.c_int, [vp, u32]),

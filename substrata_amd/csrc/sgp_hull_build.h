@@ -35,8 +35,9 @@ static inline void sgh_jacobi3(double a[3][3], double v[3][3])
 }
 
 /* Returns 0 on success.  com_out / rot_out (quaternion xyzw): body frame expressed in the input frame, i.e.
-   input point = com + rot * body point. */
-static inline int sgd_hull_build(const float* pts_in, int n_in, sgd_hull* h, float com_out[3], float rot_out[4])
+   input point = com + rot * body point.  com_offset (may be NULL): JPH::OffsetCenterOfMassShape -- the body's centre of mass is
+   moved by this vector (input frame) away from the hull's own; the inertia is taken about the moved point. */
+static inline int sgd_hull_build(const float* pts_in, int n_in, const float* com_offset, sgd_hull* h, float com_out[3], float rot_out[4])
 {
 	memset(h, 0, sizeof(*h));
 	if (n_in < 4) return -1;
@@ -133,9 +134,15 @@ static inline int sgd_hull_build(const float* pts_in, int n_in, sgd_hull* h, flo
 	}
 	if (!(vol > 1.0e-12 * ext * ext * ext)) return -1;
 	cm.x /= vol; cm.y /= vol; cm.z /= vol;
-	// second moments about the centre of mass, then the inertia tensor
+	// second moments about the centre of mass (of the hull's own mass distribution)
 	xx -= vol * cm.x * cm.x; yy -= vol * cm.y * cm.y; zz -= vol * cm.z * cm.z;
 	xy -= vol * cm.x * cm.y; xz -= vol * cm.x * cm.z; yz -= vol * cm.y * cm.z;
+	if (com_offset) {
+		// the body origin moves to cm + o: second moments about it gain vol * o o^T (parallel axis theorem)
+		const sgh_d3 o = { com_offset[0], com_offset[1], com_offset[2] };
+		xx += vol * o.x * o.x; yy += vol * o.y * o.y; zz += vol * o.z * o.z; xy += vol * o.x * o.y; xz += vol * o.x * o.z; yz += vol * o.y * o.z;
+		cm.x += o.x; cm.y += o.y; cm.z += o.z;
+	}
 	double I[3][3] = { { yy + zz, -xy, -xz }, { -xy, xx + zz, -yz }, { -xz, -yz, xx + yy } }, V[3][3];
 	sgh_jacobi3(I, V);
 	// right-handed frame
@@ -198,7 +205,7 @@ static inline void sgd_hull_cube_template(sgd_hull* h)
 	float pts[24]; int k = 0;
 	for (int x = -1; x <= 1; x += 2) for (int y = -1; y <= 1; y += 2) for (int z = -1; z <= 1; z += 2) { pts[k++] = (float)x; pts[k++] = (float)y; pts[k++] = (float)z; }
 	float com[3], rot[4];
-	sgd_hull_build(pts, 8, h, com, rot);
+	sgd_hull_build(pts, 8, NULL, h, com, rot);
 	// exact axis-aligned data regardless of what the eigen solver returned for the degenerate (isotropic) inertia
 	k = 0;
 	for (int i = 0; i < h->nv; ++i) { h->verts[i] = sgh_v3(h->verts[i].x < 0 ? -1.0f : 1.0f, h->verts[i].y < 0 ? -1.0f : 1.0f, h->verts[i].z < 0 ? -1.0f : 1.0f); }

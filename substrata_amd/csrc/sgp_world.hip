@@ -994,14 +994,14 @@ SGP_API int sgp_world_set_contact_events(sgp_world* w, int enabled)
 
 static void invalidate_graphs(sgp_world* w);
 
-SGP_API int sgp_hull_create(sgp_world* w, const float* pts, uint32_t n, sgp_hull_info* info)
+SGP_API int sgp_hull_create_com(sgp_world* w, const float* pts, uint32_t n, const float* com_offset, sgp_hull_info* info)
 {
 	if (!w || !pts || !info || n < 4 || n > 100000) return fail(SGP_ERR_INVALID, "sgp_hull_create: bad arguments");
 	if (w->hulls.size() >= SGP_MAX_HULLS) return fail(SGP_ERR_CAPACITY, "sgp_hull_create: hull table full");
 	hipSetDevice(w->device);
 	sgd_hull h;
 	float com[3], rot[4];
-	if (sgd_hull_build(pts, (int)(n > 256 ? 256 : n), &h, com, rot) != 0) return fail(SGP_ERR_REJECTED, "sgp_hull_create: degenerate point cloud or too many faces");
+	if (sgd_hull_build(pts, (int)(n > 256 ? 256 : n), com_offset, &h, com, rot) != 0) return fail(SGP_ERR_REJECTED, "sgp_hull_create: degenerate point cloud or too many faces");
 	const uint32_t id = (uint32_t)w->hulls.size();
 	w->hulls.push_back(h);
 	HIP_TRY(hipMemcpyAsync(&w->d_hulls[id], &w->hulls[id], sizeof(sgd_hull), hipMemcpyHostToDevice, w->stream));
@@ -1017,6 +1017,8 @@ SGP_API int sgp_hull_create(sgp_world* w, const float* pts, uint32_t n, sgp_hull
 	info->aabb_max[0] = h.aabb_max.x; info->aabb_max[1] = h.aabb_max.y; info->aabb_max[2] = h.aabb_max.z;
 	return SGP_OK;
 }
+
+SGP_API int sgp_hull_create(sgp_world* w, const float* pts, uint32_t n, sgp_hull_info* info) { return sgp_hull_create_com(w, pts, n, nullptr, info); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // wheeled vehicles (VehicleConstraint + WheeledVehicleController, CarPhysics.cpp:94-231)

@@ -40,6 +40,10 @@ namespace JPH
 	public:
 		const Shape* GetShape() const { return &shape; }
 		Shape shape;
+		// Where the simulated body frame (centre of mass, principal axes) sits in the object's shape space; identity except for convex
+		// hulls.  Jolt hides this inside the body; PhysicsWorld::getJoltBody() fills it in and VehicleConstraint uses it to express the
+		// wheel settings (given in shape space, like JPH::WheelSettings::mPosition) in the body frame.
+		Vec3 com_offset; float frame_rot[4] = { 0, 0, 0, 1 };
 		Vec3 GetLinearVelocity() const { return lin_vel; }
 		uint64_t GetUserData() const { return user_data; }
 		BodyID GetID() const { return id; }

@@ -206,7 +206,8 @@ namespace JPH
 	class VehicleConstraint
 	{
 	public:
-		VehicleConstraint(const Body& body, const VehicleConstraintSettings& s) : body_id(body.GetID()), settings(s)
+		VehicleConstraint(const Body& body, const VehicleConstraintSettings& s) : body_id(body.GetID()), settings(s),
+			frame_com(body.com_offset), frame_rot(body.frame_rot[0], body.frame_rot[1], body.frame_rot[2], body.frame_rot[3])
 		{
 			wheels.resize(settings.mWheels.size());
 			for (size_t i = 0; i < wheels.size(); ++i) { wheels[i].owner = this; wheels[i].index = (int)i; wheels[i].settings = settings.mWheels[i].GetPtr(); }
@@ -252,8 +253,10 @@ namespace JPH
 			for (uint32_t i = 0; i < d.num_wheels && i < SGP_MAX_WHEELS; ++i) {
 				const WheelSettingsWV* s = dynamic_cast<const WheelSettingsWV*>(settings.mWheels[i].GetPtr());
 				sgp_wheel_desc& w = d.wheels[i];
-				put(w.position, s->mPosition); put(w.suspension_dir, s->mSuspensionDirection); put(w.steering_axis, s->mSteeringAxis);
-				put(w.wheel_up, s->mWheelUp); put(w.wheel_forward, s->mWheelForward);
+				// shape space -> body frame (centre of mass / principal axes of a hull chassis)
+				const Quat inv = frame_rot.Conjugated();
+				put(w.position, inv * (s->mPosition - frame_com)); put(w.suspension_dir, inv * s->mSuspensionDirection); put(w.steering_axis, inv * s->mSteeringAxis);
+				put(w.wheel_up, inv * s->mWheelUp); put(w.wheel_forward, inv * s->mWheelForward);
 				w.suspension_min_length = s->mSuspensionMinLength; w.suspension_max_length = s->mSuspensionMaxLength; w.suspension_preload = s->mSuspensionPreloadLength;
 				w.spring_frequency = s->mSuspensionSpring.mFrequency; w.spring_damping = s->mSuspensionSpring.mDamping;
 				w.radius = s->mRadius; w.width = s->mWidth; w.inertia = s->mInertia; w.angular_damping = s->mAngularDamping;
@@ -263,7 +266,7 @@ namespace JPH
 					w.lateral_friction[k][0] = s->mLateralFriction.mPoints[k].mX; w.lateral_friction[k][1] = s->mLateralFriction.mPoints[k].mY;
 				}
 			}
-			put(d.up, settings.mUp); put(d.forward, settings.mForward);
+			put(d.up, frame_rot.Conjugated() * settings.mUp); put(d.forward, frame_rot.Conjugated() * settings.mForward);
 			d.cast_radius = cast_radius;
 			const WheeledVehicleControllerSettings* c = dynamic_cast<const WheeledVehicleControllerSettings*>(settings.mController.GetPtr());
 			d.engine_max_torque = c->mEngine.mMaxTorque; d.engine_min_rpm = c->mEngine.mMinRPM; d.engine_max_rpm = c->mEngine.mMaxRPM;
@@ -303,7 +306,7 @@ namespace JPH
 		sgp_world* world = nullptr;
 	private:
 		static void put(float* o, const Vec3& v) { o[0] = v.x; o[1] = v.y; o[2] = v.z; }
-		BodyID body_id; VehicleConstraintSettings settings; float cast_radius = 0.0f;
+		BodyID body_id; VehicleConstraintSettings settings; Vec3 frame_com; Quat frame_rot; float cast_radius = 0.0f;
 		std::vector<Wheel> wheels; MotorcycleController controller;    // (a WheeledVehicleController for cars; the lean part is inert then)
 		uint32_t vehicle_id = 0xFFFFFFFFu; const uint64_t* step_serial = nullptr;
 		mutable uint64_t cached_serial = ~0ull; mutable sgp_vehicle_state cached = {};

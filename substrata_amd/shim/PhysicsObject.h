@@ -4,6 +4,8 @@
 // the primitive, because this backend collides spheres, boxes and capsules natively (SURVEY.md 8f lists mesh /
 // hull / height-field shapes as "next").
 #pragma once
+#include <memory>
+#include <vector>
 #include <maths/Vec4f.h>
 #include <maths/Quat.h>
 #include <maths/vec3.h>
@@ -17,14 +19,27 @@
 class RayTraceResult;
 
 // Role of PhysicsShape (PhysicsObject.h:33-44).  kind: -1 none, 0 sphere (p0 = r), 1 box (p = half extents), 2 capsule (p0 = r, p1 = half height)
+// Points of a convex hull shape (what createJoltShapeFor...Mesh(..., is_dynamic = true) hands to JPH::ConvexHullShapeSettings) plus
+// the device-side hulls already built from them, one per (world, object scale): the shape is shared between bodies like a
+// JPH::Ref<JPH::Shape>, the scale is baked into the hull the way JPH::ScaledShape applies it.
+struct sgp_world;
+struct PhysicsHullData
+{
+	struct Instance { sgp_world* world; float scale[3]; uint32_t hull_id; float com[3]; float rot[4]; float aabb_min[3], aabb_max[3]; };
+	std::vector<float> points;          // xyz, object space, unscaled
+	float com_offset[3] = { 0, 0, 0 };  // OffsetCenterOfMassShape: moves the centre of mass away from the hull's own (object space, unscaled)
+	std::vector<Instance> instances;
+};
+
 class PhysicsShape
 {
 public:
 	PhysicsShape() : kind(-1), size_B(0) { p[0] = p[1] = p[2] = p[3] = 0.f; }
 	js::AABBox getAABBOS() const;
-	int kind;
+	int kind;                            // 0 sphere, 1 box, 2 capsule, 3 convex hull (hull != null)
 	float p[4];
 	size_t size_B;
+	std::shared_ptr<PhysicsHullData> hull;
 };
 
 class PhysicsObject : public ThreadSafeRefCounted
@@ -54,6 +69,11 @@ public:
 	Vec4f pos;
 	Quatf rot;
 	Vec3f scale;
+
+	// Hull bodies live in the hull's centre-of-mass / principal-axes frame (what OffsetCenterOfMassShape and the inertia rotation
+	// hide inside Jolt): body pos = pos + rot * body_com_os, body rot = rot * body_rot_os.  Identity for every other shape.
+	Vec4f body_com_os;
+	Quatf body_rot_os;
 
 	Vec4f smooth_translation;
 	Quatf smooth_rotation;

@@ -48,6 +48,64 @@ PhysicsShape PhysicsWorld::createCapsuleShape(float radius, float half_height)
 	return s;
 }
 
+PhysicsShape PhysicsWorld::createConvexHullShape(const std::vector<Vec3f>& points)
+{
+	if (points.size() < 4) throw glare::Exception("Error building Jolt shape: a convex hull needs at least 4 points");
+	PhysicsShape s; s.kind = 3;
+	s.hull = std::make_shared<PhysicsHullData>();
+	s.hull->points.reserve(points.size() * 3);
+	for (size_t i = 0; i < points.size(); ++i) { s.hull->points.push_back(points[i].x); s.hull->points.push_back(points[i].y); s.hull->points.push_back(points[i].z); }
+	s.size_B = sizeof(PhysicsShape) + s.hull->points.size() * sizeof(float);
+	return s;
+}
+
+PhysicsShape PhysicsWorld::createCOMOffsetShapeForShape(const PhysicsShape& original_shape, const Vec4f& COM_offset)
+{
+	if (original_shape.kind != 3 || !original_shape.hull) throw glare::Exception("Error building Jolt shape: centre-of-mass offsets are implemented for convex hull shapes only");
+	PhysicsShape s = original_shape;
+	s.hull = std::make_shared<PhysicsHullData>();
+	s.hull->points = original_shape.hull->points;
+	for (int i = 0; i < 3; ++i) s.hull->com_offset[i] = original_shape.hull->com_offset[i] + COM_offset[i];
+	return s;
+}
+
+// The device-side hull of `shape` for this world and object scale (JPH::ScaledShape baked into the points), built on first use.
+static const PhysicsHullData::Instance* hullInstance(sgp_world* world, const PhysicsShape& shape, const Vec3f& scale)
+{
+	PhysicsHullData& h = *shape.hull;
+	for (size_t i = 0; i < h.instances.size(); ++i) {
+		const PhysicsHullData::Instance& in = h.instances[i];
+		if (in.world == world && in.scale[0] == scale.x && in.scale[1] == scale.y && in.scale[2] == scale.z) return &in;
+	}
+	std::vector<float> pts(h.points);
+	for (size_t i = 0; i + 2 < pts.size(); i += 3) { pts[i] *= scale.x; pts[i + 1] *= scale.y; pts[i + 2] *= scale.z; }
+	sgp_hull_info info;
+	const float off[3] = { h.com_offset[0] * scale.x, h.com_offset[1] * scale.y, h.com_offset[2] * scale.z };
+	if (sgp_hull_create_com(world, pts.data(), (uint32_t)(pts.size() / 3), off, &info) != SGP_OK) return nullptr;
+	PhysicsHullData::Instance in;
+	in.world = world; in.scale[0] = scale.x; in.scale[1] = scale.y; in.scale[2] = scale.z; in.hull_id = info.hull_id;
+	memcpy(in.com, info.com, sizeof(in.com)); memcpy(in.rot, info.rot, sizeof(in.rot));
+	memcpy(in.aabb_min, info.aabb_min, sizeof(in.aabb_min)); memcpy(in.aabb_max, info.aabb_max, sizeof(in.aabb_max));
+	h.instances.push_back(in);
+	return &h.instances.back();
+}
+
+// object pose <-> body pose (identity unless the body is a hull: body frame = centre of mass / principal axes)
+static inline void toBodyPose(const PhysicsObject& ob, const Vec4f& pos, const Quatf& rot, float pos_out[3], float rot_out[4])
+{
+	const Vec4f p = pos + rot.rotateVector(maskWToZero(ob.body_com_os));
+	const Quatf q = rot * ob.body_rot_os;
+	for (int i = 0; i < 3; ++i) pos_out[i] = p[i];
+	for (int i = 0; i < 4; ++i) rot_out[i] = q.v[i];
+}
+static inline void toObjectPose(const PhysicsObject& ob, const float body_pos[3], const float body_rot[4], Vec4f& pos_out, Quatf& rot_out)
+{
+	const Quatf qb(body_rot[0], body_rot[1], body_rot[2], body_rot[3]);
+	rot_out = qb * ob.body_rot_os.conjugate();
+	const Vec4f c = rot_out.rotateVector(maskWToZero(ob.body_com_os));
+	pos_out = Vec4f(body_pos[0] - c[0], body_pos[1] - c[1], body_pos[2] - c[2], 1.f);
+}
+
 // PhysicsWorld.cpp:1169-1311
 void PhysicsWorld::addObject(const Reference<PhysicsObject>& object)
 {
@@ -76,6 +134,14 @@ void PhysicsWorld::addObject(const Reference<PhysicsObject>& object)
 		const PhysicsShape& s = object->shape;
 		if (s.kind < 0) return;           // shape.jolt_shape == NULL (:1278-1279)
 		d.shape_type = s.kind;
+		if (s.kind == 3) {
+			const PhysicsHullData::Instance* in = s.hull ? hullInstance(world, s, object->scale) : nullptr;
+			if (!in) return;              // (silent, like every other rejected add)
+			d.shape[0] = (float)in->hull_id; d.shape[1] = d.shape[2] = 0;
+			object->body_com_os = Vec4f(in->com[0], in->com[1], in->com[2], 0.f);
+			object->body_rot_os = Quatf(in->rot[0], in->rot[1], in->rot[2], in->rot[3]);
+			toBodyPose(*object, object->pos, object->rot, d.pos, d.rot);
+		} else
 		if (s.kind == 1) { d.shape[0] = s.p[0] * std::fabs(object->scale.x); d.shape[1] = s.p[1] * std::fabs(object->scale.y); d.shape[2] = s.p[2] * std::fabs(object->scale.z); }
 		else if (s.kind == 0) { d.shape[0] = s.p[0] * std::fabs(object->scale.x); }
 		else { d.shape[0] = s.p[0] * std::fabs(object->scale.x); d.shape[1] = s.p[1] * std::fabs(object->scale.z); }
@@ -91,6 +157,15 @@ void PhysicsWorld::addObject(const Reference<PhysicsObject>& object)
 	if (sgp_body_add(world, &d, &id) != SGP_OK) return;      // silent rejection, as the reference (:1178-1189)
 	object->jolt_body_id = JPH::BodyID(id);
 	if (id < id_to_ob.size()) id_to_ob[id] = object.ptr();
+}
+
+JPH::Body PhysicsWorld::getJoltBody(const PhysicsObject& object) const
+{
+	JPH::Body b;
+	b.id = object.jolt_body_id; b.user_data = (uint64)&object;
+	b.com_offset = JPH::Vec3(object.body_com_os[0], object.body_com_os[1], object.body_com_os[2]);
+	for (int i = 0; i < 4; ++i) b.frame_rot[i] = object.body_rot_os.v[i];
+	return b;
 }
 
 // PhysicsWorld.cpp:1315-1339
@@ -198,8 +273,7 @@ void PhysicsWorld::readBackActivatedObjectTransforms()
 	std::vector<sgp_body_state> st(ids.size());
 	if (sgp_body_get_state(world, ids.data(), (uint32_t)ids.size(), st.data()) != SGP_OK) return;
 	for (size_t i = 0; i < ids.size(); ++i) {
-		obs[i]->pos = Vec4f(st[i].pos[0], st[i].pos[1], st[i].pos[2], 1.f);
-		obs[i]->rot = Quatf(st[i].rot[0], st[i].rot[1], st[i].rot[2], st[i].rot[3]);
+		toObjectPose(*obs[i], st[i].pos, st[i].rot, obs[i]->pos, obs[i]->rot);
 	}
 }
 
@@ -215,7 +289,9 @@ void PhysicsWorld::setNewObToWorldTransform(PhysicsObject& object, const Vec4f& 
 	else if (object.shape.kind == 1) { shape[0] = object.shape.p[0] * std::fabs(scale[0]); shape[1] = object.shape.p[1] * std::fabs(scale[1]); shape[2] = object.shape.p[2] * std::fabs(scale[2]); }
 	else if (object.shape.kind == 0) shape[0] = object.shape.p[0] * std::fabs(scale[0]);
 	else { shape[0] = object.shape.p[0] * std::fabs(scale[0]); shape[1] = object.shape.p[1] * std::fabs(scale[2]); }
-	sgp_body_set_pose_shape(world, object.jolt_body_id.GetIndex(), translation.x, rot_quat.v.x, shape);   // zero velocity, new scale, ActivateBody (:553-601)
+	float bp[3], br[4];
+	toBodyPose(object, translation, rot_quat, bp, br);       // (a hull keeps the scale it was added with: its points are pre-scaled)
+	sgp_body_set_pose_shape(world, object.jolt_body_id.GetIndex(), bp, br, shape);   // zero velocity, new scale, ActivateBody (:553-601)
 	drainActivationEvents();
 }
 
@@ -224,7 +300,10 @@ void PhysicsWorld::setNewObToWorldTransform(PhysicsObject& object, const Vec4f& 
 {
 	assert(pos.isFinite());
 	object.pos = pos; object.rot = rot;
-	if (!object.jolt_body_id.IsInvalid()) sgp_body_set_pose_vel(world, object.jolt_body_id.GetIndex(), pos.x, rot.v.x, linear_vel.x, angular_vel.x);
+	if (object.jolt_body_id.IsInvalid()) return;
+	float bp[3], br[4];
+	toBodyPose(object, pos, rot, bp, br);
+	sgp_body_set_pose_vel(world, object.jolt_body_id.GetIndex(), bp, br, linear_vel.x, angular_vel.x);
 }
 
 // PhysicsWorld.cpp:623-633
@@ -232,7 +311,10 @@ void PhysicsWorld::setNewPosition(PhysicsObject& object, const Vec4f& pos)
 {
 	assert(pos.isFinite());
 	object.pos = pos;
-	if (!object.jolt_body_id.IsInvalid()) sgp_body_set_pos(world, object.jolt_body_id.GetIndex(), pos.x);
+	if (object.jolt_body_id.IsInvalid()) return;
+	float bp[3], br[4];
+	toBodyPose(object, pos, object.rot, bp, br);
+	sgp_body_set_pos(world, object.jolt_body_id.GetIndex(), bp);
 }
 
 // PhysicsWorld.cpp:636-646
@@ -280,7 +362,9 @@ void PhysicsWorld::moveKinematicObject(PhysicsObject& object, const Vec4f& trans
 {
 	if (object.jolt_body_id.IsInvalid()) return;
 	if (object.motion_type != PhysicsObject::MotionType_kinematic) return;     // "Tried to move a non-kinematic object" guard (:713-720)
-	sgp_body_move_kinematic(world, object.jolt_body_id.GetIndex(), translation.x, rot.v.x, dt);
+	float bp[3], br[4];
+	toBodyPose(object, translation, rot, bp, br);
+	sgp_body_move_kinematic(world, object.jolt_body_id.GetIndex(), bp, br, dt);
 }
 
 void PhysicsWorld::addForce(PhysicsObject& object, const Vec4f& force) { if (!object.jolt_body_id.IsInvalid()) sgp_body_add_force(world, object.jolt_body_id.GetIndex(), force.x); }
@@ -322,7 +406,9 @@ const Vec4f PhysicsWorld::getPosInJolt(const Reference<PhysicsObject>& object)
 	const uint32_t id = object->jolt_body_id.GetIndex();
 	sgp_body_state st;
 	if (sgp_body_get_state(world, &id, 1, &st) != SGP_OK) return object->pos;
-	return Vec4f(st.pos[0], st.pos[1], st.pos[2], 1.f);
+	Vec4f p; Quatf q;
+	toObjectPose(*object, st.pos, st.rot, p, q);
+	return p;
 }
 size_t PhysicsWorld::getNumObjects() const { uint32_t n = 0; sgp_world_num_bodies(world, &n); return n; }
 

@@ -74,6 +74,18 @@ public:
 	static PhysicsShape createGroundQuadShape(float ground_quad_w);
 	// Not in the reference: the capsule the reference builds inline from JPH::CapsuleShape (PlayerPhysics.cpp:74, AvatarGraphics.cpp:150).
 	static PhysicsShape createCapsuleShape(float radius, float half_height);
+	// The convex hull createJoltShapeForIndigoMesh / createJoltShapeForBatchedMesh build for a dynamic mesh (PhysicsWorld.cpp:735-1166:
+	// JPH::ConvexHullShapeSettings over the mesh vertices) and CarPhysics / BikePhysics build for their bodies (CarPhysics.cpp:66-78);
+	// the mesh containers themselves (glare-core) are not part of this tree, so the builder takes the vertex positions.
+	// Throws glare::Exception("Error building Jolt shape: ...") for fewer than 4 points; a degenerate cloud is reported when the
+	// shape is first added to a world.
+	static PhysicsShape createConvexHullShape(const std::vector<Vec3f>& points);
+	// PhysicsWorld.cpp:1138-1153 (OffsetCenterOfMassShapeSettings); implemented for convex hull shapes.
+	static PhysicsShape createCOMOffsetShapeForShape(const PhysicsShape& original_shape, const Vec4f& COM_offset);
+
+	// What body_interface.CreateBody(...) hands CarPhysics / BikePhysics (CarPhysics.cpp:84-88): the body an already added object is
+	// simulated as, for constructing a JPH::VehicleConstraint on it.
+	JPH::Body getJoltBody(const PhysicsObject& object) const;
 
 	void think(double dt);
 

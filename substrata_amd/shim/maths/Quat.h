@@ -19,6 +19,18 @@ public:
 		m.setColumn(2, Vec4f(2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y), 0));
 		return m;
 	}
+	Quat conjugate() const { return Quat(-v[0], -v[1], -v[2], v[3]); }
+	Quat operator*(const Quat& b) const            // Hamilton product: (this * b) rotates by b first, then by this
+	{
+		const T ax = v[0], ay = v[1], az = v[2], aw = v[3], bx = b.v[0], by = b.v[1], bz = b.v[2], bw = b.v[3];
+		return Quat(aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz);
+	}
+	Vec4f rotateVector(const Vec4f& p) const
+	{
+		const T x = v[0], y = v[1], z = v[2], w = v[3];
+		const T tx = 2 * (y * p[2] - z * p[1]), ty = 2 * (z * p[0] - x * p[2]), tz = 2 * (x * p[1] - y * p[0]);
+		return Vec4f(p[0] + w * tx + (y * tz - z * ty), p[1] + w * ty + (z * tx - x * tz), p[2] + w * tz + (x * ty - y * tx), p[3]);
+	}
 	Vec4f v;
 };
 typedef Quat<float> Quatf;

@@ -206,12 +206,15 @@ class CWorld:
         return hits
 
     # -- convex hulls ---------------------------------------------------------------------------------------------
-    def hull_create(self, points):
-        """ConvexHullShapeSettings(points).Create(): returns abi.HullInfo (hull_id for body descs, com / rot = body frame in the
-        frame of the points)."""
+    def hull_create(self, points, com_offset=None):
+        """ConvexHullShapeSettings(points).Create() (wrapped in OffsetCenterOfMassShape when com_offset is given): returns
+        abi.HullInfo (hull_id for body descs, com / rot = body frame in the frame of the points)."""
         pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
         info = abi.HullInfo()
-        self._check(self._fn("hull_create")(self._h, pts.ctypes.data, len(pts), C.byref(info)), "hull_create")
+        if com_offset is None:
+            self._check(self._fn("hull_create")(self._h, pts.ctypes.data, len(pts), C.byref(info)), "hull_create")
+        else:
+            self._check(self._fn("hull_create_com")(self._h, pts.ctypes.data, len(pts), _fp(_f3(com_offset)), C.byref(info)), "hull_create_com")
         return info
 
     # -- wheeled vehicles ---------------------------------------------------------------------------------------

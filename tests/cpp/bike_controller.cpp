@@ -65,7 +65,7 @@ int main()
 		controller_settings->mTransmission.mGearRatios = { 2.27f, 1.63f, 1.3f, 1.09f, 0.96f, 0.88f };
 		controller_settings->mTransmission.mSwitchTime = 0.2f;
 
-		JPH::Body bike_body; bike_body.id = bike->jolt_body_id;
+		const JPH::Body bike_body = world->getJoltBody(*bike);
 		JPH::Ref<JPH::VehicleConstraint> vehicle_constraint = new JPH::VehicleConstraint(bike_body, vehicle);
 		world->physics_system->AddConstraint(vehicle_constraint);
 		world->physics_system->AddStepListener(vehicle_constraint.GetPtr());

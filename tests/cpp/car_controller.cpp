@@ -16,9 +16,17 @@ int main()
 		Reference<PhysicsObject> ground = new PhysicsObject(true, PhysicsWorld::createGroundQuadShape(2000.f), nullptr, 0);
 		ground->pos = Vec4f(0, 0, -0.5f, 1);
 		world->addObject(ground);
-		// chassis: a box with the extents of the default hull (Scripting.cpp:369-377), z up / y forward
-		Reference<PhysicsObject> car = new PhysicsObject(true);
-		car->is_cube = true; car->scale = Vec3f(1.8f, 4.0f, 0.5f); car->pos = Vec4f(0, 0, 0.8f, 1); car->mass = 1200.f; car->restitution = 0.f;
+		// chassis: the default convex hull of the car script (Scripting.cpp:369-386), here already in z-up / y-forward space
+		const float x_half_w = 0.9f, up_half_w = 0.25f, fwd_half_w = 2.0f;
+		std::vector<Vec3f> convex_hull_pts;
+		for (int sx = -1; sx <= 1; sx += 2) for (int su = -1; su <= 1; su += 2) for (int sf = -1; sf <= 1; sf += 2)
+			convex_hull_pts.push_back(Vec3f(sx * x_half_w, sf * fwd_half_w, su * up_half_w));
+		convex_hull_pts.push_back(Vec3f(x_half_w, 0.6f, 0.7f)); convex_hull_pts.push_back(Vec3f(-x_half_w, 0.6f, 0.7f));     // roof
+		convex_hull_pts.push_back(Vec3f(x_half_w, -1.2f, 0.7f)); convex_hull_pts.push_back(Vec3f(-x_half_w, -1.2f, 0.7f));
+		// CarPhysics.cpp:76-78: the hull wrapped in an OffsetCenterOfMassShape (object->centre_of_mass_offset_os; here 0.2 m down)
+		const PhysicsShape car_body_shape = PhysicsWorld::createCOMOffsetShapeForShape(PhysicsWorld::createConvexHullShape(convex_hull_pts), Vec4f(0, 0, -0.2f, 0));
+		Reference<PhysicsObject> car = new PhysicsObject(true, car_body_shape, nullptr, 0);
+		car->pos = Vec4f(0, 0, 0.8f, 1); car->mass = 1200.f; car->restitution = 0.f;
 		car->motion_type = PhysicsObject::MotionType_dynamic;
 		world->addObject(car);
 		world->activateObject(car);
@@ -57,7 +65,7 @@ int main()
 		vehicle.mAntiRollBars[0].mLeftWheel = 0; vehicle.mAntiRollBars[0].mRightWheel = 1;
 		vehicle.mAntiRollBars[1].mLeftWheel = 2; vehicle.mAntiRollBars[1].mRightWheel = 3;
 
-		JPH::Body chassis_body; chassis_body.id = car->jolt_body_id;
+		const JPH::Body chassis_body = world->getJoltBody(*car);           // (CarPhysics: jolt_body = body_interface.CreateBody(...), :84)
 		JPH::Ref<JPH::VehicleConstraint> vehicle_constraint = new JPH::VehicleConstraint(chassis_body, vehicle);
 		vehicle_constraint->SetVehicleCollisionTester(tester);
 		world->physics_system->AddConstraint(vehicle_constraint);
@@ -91,6 +99,7 @@ int main()
 		}
 		JPH::RVec3 p; JPH::Quat q;
 		body_interface.GetPositionAndRotation(car->jolt_body_id, p, q);
+		world->readBackActivatedObjectTransforms();
 		const JPH::Vec3 v = body_interface.GetLinearVelocity(car->jolt_body_id);
 		const float yaw = 2.f * std::atan2(q.GetZ(), q.GetW());
 		const JPH::Wheel* w0 = vehicle_constraint->GetWheel(0);
@@ -100,7 +109,7 @@ int main()
 		bool ok = std::sqrt(p.GetX() * p.GetX() + p.GetY() * p.GetY()) > 5.f && p.GetY() > 2.f && p.GetX() > 0.5f   // drove off and turned right (+x)
 			&& std::fabs(yaw) > 0.2f                          // (full lock for two seconds: it comes round a long way)
 			&& std::sqrt(v.LengthSq()) < 0.3f                // braked to a stop
-			&& std::fabs(p.GetZ() - 0.70f) < 0.05f && w0->HasContact()
+			&& std::fabs(car->pos[2] - 0.70f) < 0.05f && w0->HasContact()   // object origin (hull space), read back by the facade
 			&& w0->GetSuspensionLength() > sus_min && w0->GetSuspensionLength() < sus_max
 			&& skid_frames > 10;                             // the front wheels spun on launch
 		// vehicleSummoned() (:266-272)

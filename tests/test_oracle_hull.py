@@ -125,3 +125,34 @@ def test_hulls_rest_on_faces_and_stack(oracle):
     hits = w.raycast(rays)
     assert hits[0]["id"] == b_car and abs((5.0 - hits[0]["t"]) - (0.25 + 0.7)) < 0.04 and hits[0]["normal"][2] > 0.99
     assert hits[1]["id"] == 0
+
+
+def test_centre_of_mass_offset(oracle):
+    """OffsetCenterOfMassShape: the body frame moves by the offset, the inertia about it grows by the parallel-axis term."""
+    w = oracle.OracleWorld(max_bodies=8)
+    pts = [(x, y, z) for x in (-1, 1) for y in (-2, 2) for z in (-0.5, 0.5)]
+    a = w.hull_create(pts)
+    b = w.hull_create(pts, com_offset=(0.0, 0.0, -0.4))
+    assert np.allclose(np.array(b.com[:]) - np.array(a.com[:]), (0, 0, -0.4), atol=1e-6)
+    assert np.isclose(a.volume, b.volume)
+    Ia, Ib = np.array(a.unit_inertia[:]), np.array(b.unit_inertia[:])
+    assert np.allclose(sorted(Ib), sorted(Ia + a.volume * 0.16 * np.array([1, 1, 0])), rtol=1e-5)
+    # a lower centre of mass makes the same shape harder to tip: tilt both by 50 degrees about y (balance point of the plain box
+    # is atan(1 / 0.5) = 63 deg; with the lowered com it is atan(1 / 0.1) = 84 deg) and check both fall back; at 70 degrees only
+    # the lowered one does
+    for tilt, expect_upright in ((50.0, (True, True)), (70.0, (False, True))):
+        for info, exp in zip((a, b), expect_upright):
+            w2 = oracle.OracleWorld(max_bodies=8)
+            add_ground(w2, friction=1.0)
+            i2 = w2.hull_create(pts, com_offset=None if info is a else (0.0, 0.0, -0.4))
+            q = quat_axis_angle((0, 1, 0), np.radians(tilt))
+            # place the lowest corner on the ground
+            R = quat_to_mat(q)
+            zmin = min((R @ np.array(p))[2] for p in pts)
+            body = hull_body(w2, i2, pos_obj=(0, 0, -zmin + 0.01), rot_obj=q, mass=100.0, friction=1.0, restitution=0.0)
+            for _ in range(300):
+                w2.step(DT)
+            st = w2.get_state([body])[0]
+            up = quat_to_mat(st["rot"]) @ quat_to_mat(i2.rot[:]).T @ np.array([0, 0, 1.0])        # object z axis in the world
+            assert (up[2] > 0.9) == exp, (tilt, info is a, up)
+            w2.close()
