@@ -97,6 +97,8 @@ def main():
         descs, car_ids = scenes.config5_cars_debris()
     n_bodies = len(descs) - 1
     w = World(max_bodies=len(descs) + 32768, device=local_rank)
+    if len(car_ids):
+        scenes.use_car_hull(w, descs, car_ids)       # chassis = the reference's 12-point convex hull with a lowered centre of mass
     w.add_batch(descs)
     for b in car_ids:
         w.vehicle_create(w.default_vehicle_desc(int(b)))
@@ -172,7 +174,7 @@ def main():
                 "workload": ("BASELINE config 3: 100k mixed box/sphere/capsule bodies, 100x100x10 lattice spacing 1.5 m, seed 3, "
                              "ground quad 2000 m, dt 1/60, Jolt default settings (10 velocity / 2 position iterations), sleeping enabled")
                             if args.workload == "config3" else
-                            ("BASELINE config 5: 1024 cars (32x32 grid, spacing 8 m; chassis = box stand-in for the 12-point hull, 1200 kg, 4 wheels, "
+                            ("BASELINE config 5: 1024 cars (32x32 grid, spacing 8 m; chassis = the 12-point convex hull of the car script, centre of mass lowered 0.2 m, 1200 kg, 4 wheels, "
                              "FWD, Scripting.cpp defaults; input forward=1, steer=sin(0.5t+id) refreshed every step) + 50k unit-box debris, seed 5, dt 1/60"),
                 "bodies_per_gpu": n_bodies, "tiles": n_gpus, "value_definition": "n_gpus x world steps/s (one 100k-body tile per GPU)",
                 "active_bodies_end": st.num_active, "contact_constraints_end": st.num_manifolds,
@@ -206,6 +208,8 @@ def main():
         threads = args.cpu_threads or min(32, os.cpu_count() or 1)
         threads = oracle.set_threads(threads)
         cw = oracle.OracleWorld(max_bodies=len(descs) + 8)
+        if len(car_ids):
+            cw.hull_create(scenes.CAR_HULL_POINTS, com_offset=scenes.CAR_COM_OFFSET)     # same hull id as on the device
         cw.add_batch(d2)
         for b in car_ids:                # (drivetrain state starts fresh on the CPU side: same cost per step, not the same trajectory)
             cw.vehicle_create(cw.default_vehicle_desc(int(b)))

@@ -129,45 +129,65 @@ static inline void sgo_seg_seg_closest(v3 a0, v3 a1, v3 b0, v3 b1, v3* pa, v3* p
 	*pb = v3_add(b0, v3_scale(d2, t));
 }
 
-/* A, B = hull views (either may be the scaled cube template): SAT + clipping.  Normal from A to B. */
-static inline int sgo_hull_hull(const sgo_hview* A, const sgo_hview* B, float max_sep, sgo_manifold* m)
+/* Result of the separating-axis search: best face axis of A, of B, best (supporting) edge pair. */
+typedef struct { float sA, sB, sE; int fA, fB, eA, eB; v3 nE; } sgo_hull_sat;
+
+/* separation of B in front of face f of X (X, Y in either role) */
+static inline float sgo_hull_axis_face(const sgo_hview* X, const sgo_hview* Y, int f)
 {
-	float sA = -3.4e38f, sB = -3.4e38f; int fA = 0, fB = 0;
+	const v3 n = sgo_hv_normal(X, f);
+	return sgo_hv_proj_min(Y, n) - (v3_dot(n, X->pos) + sgo_hv_plane_d(X, f));
+}
+
+/* edge pair (i of A, j of B): returns 0 when the edges are (nearly) parallel, else 1 with the axis (oriented A -> B), the
+   separation along it and whether this pair really supports the two hulls along it (parallel edges give the same axis: only the
+   supporting pair is the contact) */
+static inline int sgo_hull_axis_edge(const sgo_hview* A, const sgo_hview* B, int i, int j, v3 T, v3* ax_out, float* s_out, int* supporting)
+{
+	const v3 da = m33_mul(A->R, v3_sub(sgo_hv_local(A, A->h->edge_b[i]), sgo_hv_local(A, A->h->edge_a[i])));
+	const v3 db = m33_mul(B->R, v3_sub(sgo_hv_local(B, B->h->edge_b[j]), sgo_hv_local(B, B->h->edge_a[j])));
+	v3 ax = v3_cross(da, db);
+	const float l2 = v3_len_sq(ax);
+	if (l2 < 1.0e-6f * v3_len_sq(da) * v3_len_sq(db)) return 0;
+	ax = v3_scale(ax, 1.0f / sqrtf(l2));
+	if (v3_dot(ax, T) < 0.0f) ax = v3_neg(ax);
+	const float s = sgo_hv_proj_min(B, ax) - sgo_hv_proj_max(A, ax);
+	const v3 a0 = sgo_hv_world(A, A->h->edge_a[i]), b0 = sgo_hv_world(B, B->h->edge_a[j]);
+	const float s_edge = v3_dot(ax, b0) - v3_dot(ax, a0);        /* (both ends of an edge project alike: ax is perpendicular to it) */
+	*ax_out = ax; *s_out = s; *supporting = !(s_edge - s > 1.0e-4f);
+	return 1;
+}
+
+/* Sequential search (first maximum wins).  Returns 0 when some axis separates the hulls by more than max_sep. */
+static inline int sgo_hull_sat_search(const sgo_hview* A, const sgo_hview* B, float max_sep, sgo_hull_sat* r)
+{
+	r->sA = -3.4e38f; r->sB = -3.4e38f; r->sE = -3.4e38f; r->fA = 0; r->fB = 0; r->eA = -1; r->eB = -1; r->nE = V3(0, 0, 0);
 	for (int f = 0; f < A->h->nf; ++f) {
-		const v3 n = sgo_hv_normal(A, f);
-		const float s = sgo_hv_proj_min(B, n) - (v3_dot(n, A->pos) + sgo_hv_plane_d(A, f));
+		const float s = sgo_hull_axis_face(A, B, f);
 		if (s > max_sep) return 0;
-		if (s > sA) { sA = s; fA = f; }
+		if (s > r->sA) { r->sA = s; r->fA = f; }
 	}
 	for (int f = 0; f < B->h->nf; ++f) {
-		const v3 n = sgo_hv_normal(B, f);
-		const float s = sgo_hv_proj_min(A, n) - (v3_dot(n, B->pos) + sgo_hv_plane_d(B, f));
+		const float s = sgo_hull_axis_face(B, A, f);
 		if (s > max_sep) return 0;
-		if (s > sB) { sB = s; fB = f; }
+		if (s > r->sB) { r->sB = s; r->fB = f; }
 	}
 	const v3 T = v3_sub(B->pos, A->pos);
-	float sE = -3.4e38f; int eA = -1, eB = -1; v3 nE = V3(0, 0, 0);
 	for (int i = 0; i < A->h->ne; ++i) {
-		const v3 da = m33_mul(A->R, v3_sub(sgo_hv_local(A, A->h->edge_b[i]), sgo_hv_local(A, A->h->edge_a[i])));
-		const float la = v3_len_sq(da);
 		for (int j = 0; j < B->h->ne; ++j) {
-			const v3 db = m33_mul(B->R, v3_sub(sgo_hv_local(B, B->h->edge_b[j]), sgo_hv_local(B, B->h->edge_a[j])));
-			v3 ax = v3_cross(da, db);
-			const float l2 = v3_len_sq(ax);
-			if (l2 < 1.0e-6f * la * v3_len_sq(db)) continue;
-			ax = v3_scale(ax, 1.0f / sqrtf(l2));
-			if (v3_dot(ax, T) < 0.0f) ax = v3_neg(ax);
-			const float s = sgo_hv_proj_min(B, ax) - sgo_hv_proj_max(A, ax);
+			v3 ax; float s; int sup;
+			if (!sgo_hull_axis_edge(A, B, i, j, T, &ax, &s, &sup)) continue;
 			if (s > max_sep) return 0;
-			if (s > sE) {
-				/* parallel edges give the same axis: only the pair that actually supports the two hulls along it is the contact */
-				const v3 a0 = sgo_hv_world(A, A->h->edge_a[i]), b0 = sgo_hv_world(B, B->h->edge_a[j]);
-				const float s_edge = v3_dot(ax, b0) - v3_dot(ax, a0);        /* (both ends of an edge project alike: ax is perpendicular to it) */
-				if (s_edge - s > 1.0e-4f) continue;
-				sE = s; eA = i; eB = j; nE = ax;
-			}
+			if (s > r->sE && sup) { r->sE = s; r->eA = i; r->eB = j; r->nE = ax; }
 		}
 	}
+	return 1;
+}
+
+/* Manifold from the result of the search.  Normal from A to B. */
+static inline int sgo_hull_manifold(const sgo_hview* A, const sgo_hview* B, float max_sep, const sgo_hull_sat* r, sgo_manifold* m)
+{
+	const float sA = r->sA, sB = r->sB, sE = r->sE; const int fA = r->fA, fB = r->fB, eA = r->eA, eB = r->eB; const v3 nE = r->nE;
 	const float sF = fmaxf(sA, sB);
 	if (eA >= 0 && sE > sF + 1.0e-3f) {
 		v3 pa, pb;
@@ -218,6 +238,14 @@ static inline int sgo_hull_hull(const sgo_hview* A, const sgo_hview* B, float ma
 	}
 	sgo_hull_reduce(refA ? nref : v3_neg(nref), q1, q2, cnt, m);
 	return 1;
+}
+
+/* A, B = hull views (either may be the scaled cube template): SAT + clipping.  Normal from A to B. */
+static inline int sgo_hull_hull(const sgo_hview* A, const sgo_hview* B, float max_sep, sgo_manifold* m)
+{
+	sgo_hull_sat r;
+	if (!sgo_hull_sat_search(A, B, max_sep, &r)) return 0;
+	return sgo_hull_manifold(A, B, max_sep, &r, m);
 }
 
 /* Closest point on the hull surface to the hull-local point l (scale 1 hulls only).  Returns the signed distance (negative

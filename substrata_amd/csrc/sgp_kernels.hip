@@ -598,17 +598,85 @@ __global__ void __launch_bounds__(TPB) k_narrowphase(DV d)
 	}
 }
 
-// pairs with a convex hull (hull - hull / box / sphere / capsule): one thread per pair
+// The separating-axis search of one hull pair spread over the 64 lanes of a wave: lane l takes axes l, l + 64, ... of the
+// flattened list [faces of A | faces of B | edge pairs]; every axis is evaluated by the same device function the sequential
+// search uses, and the reduction takes (largest separation, lowest axis index) -- exactly the sequential "first maximum wins".
+SGP_DEV int hull_sat_search_wave(const sgd_hview* A, const sgd_hview* B, float max_sep, sgd_hull_sat* r)
+{
+	const int lane = (int)(threadIdx.x & 63u);
+	const int nfA = A->h->nf, nfB = B->h->nf, neA = A->h->ne, neB = B->h->ne;
+	const int total = nfA + nfB + neA * neB;
+	const v3 T = v3_sub(B->pos, A->pos);
+	float sA = -3.4e38f, sB = -3.4e38f, sE = -3.4e38f; int iA = 0x7FFFFFFF, iB = 0x7FFFFFFF, iE = 0x7FFFFFFF;
+	bool separated = false;
+	for (int t = lane; t < total; t += 64) {
+		if (t < nfA) {
+			const float s = sgd_hull_axis_face(A, B, t);
+			if (s > max_sep) separated = true;
+			if (s > sA) { sA = s; iA = t; }
+		} else if (t < nfA + nfB) {
+			const int f = t - nfA;
+			const float s = sgd_hull_axis_face(B, A, f);
+			if (s > max_sep) separated = true;
+			if (s > sB) { sB = s; iB = f; }
+		} else {
+			const int e = t - nfA - nfB;
+			v3 ax; float s; int sup;
+			if (sgd_hull_axis_edge(A, B, e / neB, e % neB, T, &ax, &s, &sup)) {
+				if (s > max_sep) separated = true;
+				if (s > sE && sup) { sE = s; iE = e; }
+			}
+		}
+	}
+	if (__any(separated)) return 0;
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) {
+		float os = __shfl_xor(sA, off); int oi = __shfl_xor(iA, off);
+		if (os > sA || (os == sA && oi < iA)) { sA = os; iA = oi; }
+		os = __shfl_xor(sB, off); oi = __shfl_xor(iB, off);
+		if (os > sB || (os == sB && oi < iB)) { sB = os; iB = oi; }
+		os = __shfl_xor(sE, off); oi = __shfl_xor(iE, off);
+		if (os > sE || (os == sE && oi < iE)) { sE = os; iE = oi; }
+	}
+	r->sA = sA; r->fA = iA == 0x7FFFFFFF ? 0 : iA; r->sB = sB; r->fB = iB == 0x7FFFFFFF ? 0 : iB;
+	r->sE = sE; r->eA = -1; r->eB = -1; r->nE = V3(0.0f, 0.0f, 0.0f);
+	if (iE != 0x7FFFFFFF) {
+		r->eA = iE / neB; r->eB = iE % neB;
+		float s; int sup;
+		sgd_hull_axis_edge(A, B, r->eA, r->eB, T, &r->nE, &s, &sup);      // the axis of the winning pair (same arithmetic as above)
+	}
+	return 1;
+}
+
+// pairs with a convex hull (hull - hull / box / sphere / capsule): one WAVE per pair.  Polytope pairs search their axes in
+// parallel; the manifold (clipping, <= 4 points) and the sphere / capsule cases run on lane 0.
 __global__ void __launch_bounds__(64) k_narrowphase_hull(DV d)
 {
 	const uint32_t n = min(d.ctr->n_hull_pairs, d.cap_hull_pairs);
-	for (uint32_t p = blockIdx.x * 64 + threadIdx.x; p < n; p += gridDim.x * 64) {
+	for (uint32_t p = blockIdx.x; p < n; p += gridDim.x) {
 		const uint2 ab = d.hull_pairs[p];
 		const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
 		const sgd_shape sa = load_shape(d, ab.x, fa), sb = load_shape(d, ab.y, fb);
+		const float max_sep = d.st.speculative_contact_distance;
 		sgd_manifold m;
-		if (!sgd_collide_hull(&sa, &sb, d.st.speculative_contact_distance, &m)) continue;
-		emit_manifold(d, ab, fa, fb, m);
+		int hit;
+		const bool round_other = sa.type == SGP_SHAPE_SPHERE || sa.type == SGP_SHAPE_CAPSULE || sb.type == SGP_SHAPE_SPHERE || sb.type == SGP_SHAPE_CAPSULE;
+		if (round_other) {
+			hit = 0;
+			if (threadIdx.x == 0) hit = sgd_collide_hull(&sa, &sb, max_sep, &m);
+		} else {
+			// canonical order (box < hull; hull - hull keeps its order), as sgd_collide_hull
+			const bool flip = sa.type > sb.type;
+			const sgd_shape* x = flip ? &sb : &sa; const sgd_shape* y = flip ? &sa : &sb;
+			const sgd_hview hx = sgd_hull_view(x), hy = sgd_hull_view(y);
+			sgd_hull_sat r;
+			hit = hull_sat_search_wave(&hx, &hy, max_sep, &r);
+			if (hit && threadIdx.x == 0) {
+				hit = sgd_hull_manifold(&hx, &hy, max_sep, &r, &m);
+				if (hit && flip) sgd_flip_manifold(&m);
+			} else hit = 0;
+		}
+		if (hit && threadIdx.x == 0) emit_manifold(d, ab, fa, fb, m);
 	}
 }
 
@@ -2119,7 +2187,7 @@ void launch_bp_scatter(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKerne
 void launch_bp_pairs(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_bp_pairs, dim3(4096), dim3(TPB), 0, s, d); }
 void launch_bp_large(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_bp_large, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_narrowphase(const DV& d, uint32_t est, hipStream_t s) { hipLaunchKernelGGL(k_narrowphase, dim3(stride_grid(est)), dim3(TPB), 0, s, d); }
-void launch_narrowphase_hull(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_narrowphase_hull, dim3(256), dim3(64), 0, s, d); }
+void launch_narrowphase_hull(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_narrowphase_hull, dim3(4096), dim3(64), 0, s, d); }
 void launch_wake(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_wake, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_prep_bodies(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_prep_bodies, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_colour_inherit(const DV& d, uint32_t est, hipStream_t s) { hipLaunchKernelGGL(k_colour_inherit, dim3(stride_grid(est)), dim3(TPB), 0, s, d); }

@@ -153,6 +153,27 @@ def config5_cars_debris(cars_side=32, n_debris=50000, spacing=8.0, seed=5):
     return descs, np.arange(1, 1 + n_cars, dtype=np.uint32)
 
 
+# the default car hull of the reference (Scripting.cpp:369-386; model space: x right, y up, z forward) turned into x right, y forward, z up
+CAR_HULL_POINTS = np.array([(sx * 0.9, sf * 2.0, su * 0.25) for sx in (-1, 1) for su in (-1, 1) for sf in (-1, 1)] +
+                           [(0.9, 0.6, 0.7), (-0.9, 0.6, 0.7), (0.9, -1.2, 0.7), (-0.9, -1.2, 0.7)], dtype=np.float32)
+CAR_COM_OFFSET = (0.0, 0.0, -0.2)        # OffsetCenterOfMassShape (CarPhysics.cpp:76-78 uses object->centre_of_mass_offset_os; no default in the reference)
+
+
+def use_car_hull(world, descs, car_ids):
+    """Turn the box chassis of config5_cars_debris() into the reference's 12-point convex hull (created in `world`, with the lowered
+    centre of mass) before the descs are added.  Returns the hull info; the body frame sits at info.com of the hull's point frame, so
+    the chassis positions are shifted accordingly (the principal axes of this symmetric hull are the point frame's axes up to a
+    small pitch, which the wheel layout of default_vehicle_desc() ignores)."""
+    info = world.hull_create(CAR_HULL_POINTS, com_offset=CAR_COM_OFFSET)
+    idx = np.asarray(car_ids, dtype=np.int64)
+    descs["shape_type"][idx] = abi.SHAPE_HULL
+    descs["shape"][idx] = 0
+    descs["shape"][idx, 0] = float(info.hull_id)
+    descs["pos"][idx] += np.array(info.com[:], dtype=np.float32)
+    descs["rot"][idx] = np.array(info.rot[:], dtype=np.float32)
+    return info
+
+
 def config5_inputs(n_cars, t):
     """Driver input of config 5 at time t: forward = 1, steer = sin(0.5 t + car id)."""
     inp = np.zeros(n_cars, dtype=abi.vehicle_input_dtype)

@@ -84,6 +84,9 @@ def test_config5_1k_cars_50k_debris(oracle):
     oracle.set_threads(min(16, os.cpu_count() or 1))
     try:
         tw = parity.make_twin(oracle, max_bodies=len(descs) + 64)
+        d_cpu = descs.copy()
+        ig = scenes.use_car_hull(tw.gpu, descs, car_ids); ic = scenes.use_car_hull(tw.cpu, d_cpu, car_ids)
+        assert ig.hull_id == ic.hull_id and np.array_equal(descs["pos"], d_cpu["pos"])
         tw.add_batch(descs)
         for b in car_ids:
             tw.vehicle_create(tw.gpu.default_vehicle_desc(int(b)))
@@ -109,7 +112,7 @@ def test_config5_1k_cars_50k_debris(oracle):
     st = w.read_states(0, len(descs))
     cars = st[1:1 + nc]
     assert np.isfinite(st["pos"]).all() and np.isfinite(st["lin_vel"]).all()
-    assert (cars["pos"][:, 2] > 0.3).all() and (cars["pos"][:, 2] < 3.0).all()          # on their wheels / on debris, not through the ground
+    assert (cars["pos"][:, 2] > 0.2).all() and (cars["pos"][:, 2] < 3.0).all()          # on their wheels / on debris / on their side, not through the ground
     # (the debris field is dense -- 0.76 one-metre boxes per m^2 -- so the cars mostly shove boxes around rather than travel)
     moved = np.linalg.norm(cars["pos"][:, :2] - descs["pos"][1:1 + nc, :2], axis=1)
     assert np.median(moved) > 0.5 and moved.max() < 100.0
