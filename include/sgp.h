@@ -292,7 +292,8 @@ int  sgp_world_stats(sgp_world* w, sgp_step_stats* out);
 /* Name of kernel class k of sgp_step_profile (NULL past the last class). */
 const char* sgp_kernel_class_name(int k);
 /* sizeof() of ABI struct number `which` (order: settings, world_desc, body_desc, body_state, body_event, contact_event,
- * ray, hit, step_stats, step_profile, ghost_record, vehicle_desc, vehicle_input, vehicle_state, hull_info) so bindings can verify their layout. */
+ * ray, hit, step_stats, step_profile, ghost_record, vehicle_desc, vehicle_input, vehicle_state, hull_info, capsule_query,
+ * query_contact) so bindings can verify their layout. */
 int  sgp_abi_sizeof(int which);
 /* activated_obs / newly_activated_obs maintenance + listener callbacks (PhysicsWorld.h:194-200). */
 int  sgp_world_drain_events(sgp_world* w, int kind, void* out, uint32_t cap, uint32_t* n_out);
@@ -405,6 +406,36 @@ int  sgp_vehicle_get_states(sgp_world* w, uint32_t first_vehicle_id, uint32_t n,
 int  sgp_vehicle_enable_lean_controller(sgp_world* w, uint32_t vehicle_id, int enabled);
 /* vehicleSummoned(): GetEngine().SetCurrentRPM / Wheel::SetAngularVelocity (CarPhysics.cpp:266-272) */
 int  sgp_vehicle_reset_drivetrain(sgp_world* w, uint32_t vehicle_id, float engine_rpm, float wheel_angular_velocity);
+
+/* ---- shape queries for the character controller ----------------------------------------------------
+ * What JPH::CharacterVirtual asks the world every update (PlayerPhysics.cpp:64-90,258-353,477-481): every body within reach of
+ * the character's capsule (CollideShape with a maximum separation) and a swept test of its path.  The controller itself (plane
+ * constraints, sliding, ground state, stairs) is host code on top of these two batched queries (shim/Jolt/JoltCharacterLite.h). */
+typedef struct sgp_capsule_query {
+	float    pos[3];            /* centre of the capsule                                                            */
+	float    rot[4];            /* the capsule axis is the local z axis                                             */
+	float    radius, half_height;
+	float    max_separation;    /* report surfaces closer than this (predictive contact distance + character padding) */
+	uint32_t ignore_id;         /* JPH::IgnoreSingleBodyFilter (PlayerPhysics.cpp:477)                             */
+	uint32_t collidable_only;   /* PlayerPhysicsObjectLayerFilter (PlayerPhysics.cpp:240-249)                      */
+} sgp_capsule_query;
+typedef struct sgp_query_contact {
+	uint32_t query;             /* index of the query                                                              */
+	uint32_t body;
+	float    point[3];          /* on the body                                                                     */
+	float    normal[3];         /* from the body towards the capsule                                               */
+	float    distance;          /* separation along the normal; negative = penetration depth                       */
+	float    point_velocity[3]; /* velocity of the body at `point`                                                 */
+	uint32_t motion_type;       /* SGP_MOTION_*                                                                    */
+	uint32_t is_sensor;
+	float    inv_mass;          /* 0 unless dynamic                                                                */
+	uint32_t pad;
+	uint64_t userdata;
+} sgp_query_contact;
+/* Contacts come back sorted by (query, body, point). n_out may exceed cap (then only the first cap are written). */
+int  sgp_collide_capsules(sgp_world* w, const sgp_capsule_query* queries, uint32_t n, sgp_query_contact* out, uint32_t cap, uint32_t* n_out);
+/* Sphere casts (rays with thickness): hit.t = distance travelled by the centre until first touch, hit.normal at the touch point. */
+int  sgp_spherecast(sgp_world* w, const sgp_ray* rays, const float* radii, uint32_t n, sgp_hit* hits_out);
 
 /* ---- multi-GPU tiles: ghost bodies are ordinary kinematic-like bodies owned elsewhere ---- */
 /* Pack the ghost record of every owned body whose AABB, inflated by `margin`, crosses outside [lo,hi). */

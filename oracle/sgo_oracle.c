@@ -1894,6 +1894,79 @@ SGO_API int sgo_world_dump_constraints(sgo_world* w, sgo_constraint_dump* out, u
 	return SGP_OK;
 }
 
+/* CharacterVirtual's CollideShape: every body within max_separation of a capsule (brute force over the bodies whose bounds
+   overlap the capsule's). */
+static int cmp_query_contact(const void* a, const void* b)
+{
+	const sgp_query_contact* x = (const sgp_query_contact*)a; const sgp_query_contact* y = (const sgp_query_contact*)b;
+	if (x->query != y->query) return x->query < y->query ? -1 : 1;
+	if (x->body != y->body) return x->body < y->body ? -1 : 1;
+	return x->pad < y->pad ? -1 : (x->pad > y->pad ? 1 : 0);
+}
+SGO_API int sgo_collide_capsules(sgo_world* w, const sgp_capsule_query* qs, uint32_t n, sgp_query_contact* out, uint32_t cap, uint32_t* n_out)
+{
+	uint32_t cnt = 0;
+	for (uint32_t k = 0; k < n; ++k) {
+		const sgp_capsule_query* q = &qs[k];
+		sgo_shape sc; memset(&sc, 0, sizeof(sc));
+		sc.pos = V3(q->pos[0], q->pos[1], q->pos[2]);
+		const quat qq = { q->rot[0], q->rot[1], q->rot[2], q->rot[3] };
+		sc.R = quat_to_m33(qq); sc.type = SGO_SHAPE_CAPSULE; sc.p[0] = q->radius; sc.p[1] = q->half_height; sc.hull = NULL;
+		const v3 ax = v3_scale(sc.R.c2, q->half_height);
+		const float e = q->radius + q->max_separation;
+		const v3 ext = V3(fabsf(ax.x) + e, fabsf(ax.y) + e, fabsf(ax.z) + e);
+		const v3 lo = v3_sub(sc.pos, ext), hi = v3_add(sc.pos, ext);
+		for (uint32_t j = 0; j < w->high; ++j) {
+			const sgo_body* b = &w->bodies[j];
+			if (!b->alive || j == q->ignore_id) continue;
+			if (q->collidable_only && !(b->layer == SGP_LAYER_NON_MOVING || b->layer == SGP_LAYER_MOVING)) continue;
+			if (b->aabb_max.x < lo.x || b->aabb_min.x > hi.x || b->aabb_max.y < lo.y || b->aabb_min.y > hi.y || b->aabb_max.z < lo.z || b->aabb_min.z > hi.z) continue;
+			const sgo_shape sb = body_shape_xf(b);
+			sgo_manifold m;
+			if (!sgo_collide(&sb, &sc, q->max_separation, &m)) continue;        /* normal from the body to the capsule */
+			for (int i = 0; i < m.np; ++i) {
+				if (cnt < cap) {
+					sgp_query_contact* c = &out[cnt];
+					memset(c, 0, sizeof(*c));
+					c->query = k; c->body = j; c->pad = (uint32_t)i;
+					c->point[0] = m.p1[i].x; c->point[1] = m.p1[i].y; c->point[2] = m.p1[i].z;
+					c->normal[0] = m.n.x; c->normal[1] = m.n.y; c->normal[2] = m.n.z;
+					c->distance = v3_dot(v3_sub(m.p2[i], m.p1[i]), m.n);
+					const v3 pv = b->motion == SGP_MOTION_STATIC ? V3(0, 0, 0) : v3_add(b->linv, v3_cross(b->angv, v3_sub(m.p1[i], b->pos)));
+					c->point_velocity[0] = pv.x; c->point_velocity[1] = pv.y; c->point_velocity[2] = pv.z;
+					c->motion_type = (uint32_t)b->motion; c->is_sensor = (uint32_t)b->is_sensor; c->inv_mass = b->inv_mass; c->userdata = b->userdata;
+				}
+				++cnt;
+			}
+		}
+	}
+	*n_out = cnt;
+	qsort(out, cnt < cap ? cnt : cap, sizeof(sgp_query_contact), cmp_query_contact);
+	for (uint32_t i = 0; i < (cnt < cap ? cnt : cap); ++i) out[i].pad = 0;
+	return SGP_OK;
+}
+
+SGO_API int sgo_spherecast(sgo_world* w, const sgp_ray* rays, const float* radii, uint32_t n, sgp_hit* hits)
+{
+	for (uint32_t k = 0; k < n; ++k) {
+		const v3 o = V3(rays[k].origin[0], rays[k].origin[1], rays[k].origin[2]);
+		const v3 d = V3(rays[k].dir[0], rays[k].dir[1], rays[k].dir[2]);
+		float best = rays[k].max_t; uint32_t bid = SGP_INVALID_ID; v3 bn = V3(0, 0, 0);
+		for (uint32_t i = 0; i < w->high; ++i) {
+			const sgo_body* b = &w->bodies[i];
+			if (!b->alive || i == rays[k].ignore_id || b->is_sensor) continue;
+			if (rays[k].collidable_only && !(b->layer == SGP_LAYER_NON_MOVING || b->layer == SGP_LAYER_MOVING)) continue;
+			v3 nn, pp;
+			const float t = sgo_cast_sphere_body(b->shape_type, b->shape, b->hull, b->pos, quat_to_m33(b->rot), o, d, best, radii[k], &nn, &pp);
+			if (t >= 0.0f && (t < best || bid == SGP_INVALID_ID) && t <= best) { best = t; bid = i; bn = nn; }
+		}
+		hits[k].id = bid; hits[k].t = bid == SGP_INVALID_ID ? 0.0f : best;
+		hits[k].normal[0] = bn.x; hits[k].normal[1] = bn.y; hits[k].normal[2] = bn.z;
+		hits[k].userdata = bid == SGP_INVALID_ID ? 0 : w->bodies[bid].userdata;
+	}
+	return SGP_OK;
+}
+
 /* Ray vs one body (traceRay, PhysicsWorld.cpp:1668-1725).  Returns t or -1. */
 static float ray_body(const sgo_body* b, v3 o, v3 d, float max_t, v3* n_out)
 {

@@ -164,15 +164,28 @@ class HullInfo(C.Structure):
                 ("volume", f32), ("unit_inertia", f32 * 3), ("aabb_min", f32 * 3), ("aabb_max", f32 * 3)]
 
 
+class CapsuleQuery(C.Structure):
+    _fields_ = [("pos", f32 * 3), ("rot", f32 * 4), ("radius", f32), ("half_height", f32), ("max_separation", f32),
+                ("ignore_id", u32), ("collidable_only", u32)]
+
+
+class QueryContact(C.Structure):
+    _fields_ = [("query", u32), ("body", u32), ("point", f32 * 3), ("normal", f32 * 3), ("distance", f32),
+                ("point_velocity", f32 * 3), ("motion_type", u32), ("is_sensor", u32), ("inv_mass", f32), ("pad", u32),
+                ("userdata", u64)]
+
+
 ABI_SIZEOF_ORDER = ["sgp_settings", "sgp_world_desc", "sgp_body_desc", "sgp_body_state", "sgp_body_event",
                     "sgp_contact_event", "sgp_ray", "sgp_hit", "sgp_step_stats", "sgp_step_profile", "sgp_ghost_record",
-                    "sgp_vehicle_desc", "sgp_vehicle_input", "sgp_vehicle_state", "sgp_hull_info"]
+                    "sgp_vehicle_desc", "sgp_vehicle_input", "sgp_vehicle_state", "sgp_hull_info",
+                    "sgp_capsule_query", "sgp_query_contact"]
 
 STRUCTS = {"sgp_settings": Settings, "sgp_world_desc": WorldDesc, "sgp_body_desc": BodyDesc,
            "sgp_body_state": BodyState, "sgp_body_event": BodyEvent, "sgp_contact_event": ContactEvent,
            "sgp_ray": Ray, "sgp_hit": Hit, "sgp_step_stats": StepStats, "sgp_step_profile": StepProfile,
            "sgp_ghost_record": GhostRecord, "sgp_vehicle_desc": VehicleDesc, "sgp_vehicle_input": VehicleInput,
-           "sgp_vehicle_state": VehicleState, "sgp_hull_info": HullInfo}
+           "sgp_vehicle_state": VehicleState, "sgp_hull_info": HullInfo, "sgp_capsule_query": CapsuleQuery,
+           "sgp_query_contact": QueryContact}
 
 body_desc_dtype = np.dtype(BodyDesc)
 body_state_dtype = np.dtype(BodyState)
@@ -185,6 +198,8 @@ hit_dtype = np.dtype(Hit)
 pose_vel_dtype = np.dtype(PoseVel)
 vehicle_input_dtype = np.dtype(VehicleInput)
 vehicle_state_dtype = np.dtype(VehicleState)
+capsule_query_dtype = np.dtype(CapsuleQuery)
+query_contact_dtype = np.dtype(QueryContact)
 
 P = C.POINTER
 vp = C.c_void_p
@@ -230,6 +245,8 @@ PROTOTYPES = {
     "world_drain_events": (C.c_int, [vp, C.c_int, vp, u32, P(u32)]),
     "world_num_bodies": (C.c_int, [vp, P(u32)]),
     "raycast": (C.c_int, [vp, vp, u32, vp]),
+    "collide_capsules": (C.c_int, [vp, vp, u32, vp, u32, P(u32)]),
+    "spherecast": (C.c_int, [vp, vp, vp, u32, vp]),
     "world_export_boundary": (C.c_int, [vp, P(f32), P(f32), f32, vp, u32, P(u32)]),
     "world_import_ghosts": (C.c_int, [vp, vp, u32]),
     "world_device_array": (C.c_int, [vp, C.c_int, P(vp), P(u32)]),

@@ -242,4 +242,6 @@ void launch_dump_constraints(const DV& d, uint32_t which, uint32_t n_con, void* 
 void launch_vehicle_pre(const DV& d, hipStream_t s);
 void launch_vehicle_solve(const DV& d, int mode, hipStream_t s);      // mode as launch_solve_colour
 void launch_raycast(const DV& d, const sgp_ray* rays, uint32_t n, sgp_hit* hits, hipStream_t s);
+void launch_collide_capsules(const DV& d, const sgp_capsule_query* q, uint32_t n, sgp_query_contact* out, uint32_t cap, uint32_t* count, hipStream_t s);
+void launch_spherecast(const DV& d, const sgp_ray* rays, const float* radii, uint32_t n, sgp_hit* hits, hipStream_t s);
 void launch_export_boundary(const DV& d, uint32_t nb, float3 lo, float3 hi, float margin, sgp_ghost_record* out, uint32_t cap, uint32_t* count, hipStream_t s);

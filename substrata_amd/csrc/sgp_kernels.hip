@@ -2120,6 +2120,113 @@ template <int MODE> __global__ void __launch_bounds__(64) k_vehicle_solve(DV d)
 	if (MODE == 1) veh_stage_out(gv, &sv);        // only the velocity iteration changes the record (row impulses, wheel spin)
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Shape queries of the character controller (JPH::CharacterVirtual: CollideShape with a maximum separation, swept test).
+
+SGP_DEV void capsule_query_body(const DV& d, const sgp_capsule_query& q, uint32_t k, const sgd_shape& sc, v3 lo, v3 hi, uint32_t j, sgp_query_contact* out, uint32_t cap, uint32_t* count)
+{
+	if (j == q.ignore_id) return;
+	const uint32_t f = d.flags[j];
+	if (!(f & BF_ALIVE)) return;
+	const uint32_t layer = f_layer(f);
+	if (q.collidable_only && !(layer == SGP_LAYER_NON_MOVING || layer == SGP_LAYER_MOVING)) return;
+	const float4 mn = d.aabb_min[j], mx = d.aabb_max[j];
+	if (mx.x < lo.x || mn.x > hi.x || mx.y < lo.y || mn.y > hi.y || mx.z < lo.z || mn.z > hi.z) return;
+	const sgd_shape sb = load_shape(d, j, f);
+	sgd_manifold m;
+	const int hit = sb.type == SGP_SHAPE_HULL ? sgd_collide_hull(&sb, &sc, q.max_separation, &m) : sgd_collide(&sb, &sc, q.max_separation, &m);   // normal: body -> capsule
+	if (!hit) return;
+	for (int i = 0; i < m.np; ++i) {
+		const uint32_t slot = atomicAdd(count, 1u);
+		if (slot >= cap) continue;
+		sgp_query_contact c;
+		c.query = k; c.body = j; c.pad = (uint32_t)i;
+		c.point[0] = m.p1[i].x; c.point[1] = m.p1[i].y; c.point[2] = m.p1[i].z;
+		c.normal[0] = m.n.x; c.normal[1] = m.n.y; c.normal[2] = m.n.z;
+		c.distance = v3_dot(v3_sub(m.p2[i], m.p1[i]), m.n);
+		v3 pv = V3(0.0f, 0.0f, 0.0f);
+		if (f_motion(f) != SGP_MOTION_STATIC) pv = v3_add(V3(d.linv[j]), v3_cross(V3(d.angv[j]), v3_sub(m.p1[i], V3(d.pos_im[j]))));
+		c.point_velocity[0] = pv.x; c.point_velocity[1] = pv.y; c.point_velocity[2] = pv.z;
+		c.motion_type = f_motion(f); c.is_sensor = (f & BF_SENSOR) ? 1u : 0u; c.inv_mass = d.pos_im[j].w; c.userdata = 0;
+		out[slot] = c;
+	}
+}
+
+// one thread per query capsule: large bodies directly, the rest through the broad-phase cells its bounds reach
+__global__ void __launch_bounds__(64) k_collide_capsules(DV d, const sgp_capsule_query* qs, uint32_t n, sgp_query_contact* out, uint32_t cap, uint32_t* count)
+{
+	const uint32_t k = blockIdx.x * 64 + threadIdx.x;
+	if (k >= n) return;
+	const sgp_capsule_query q = qs[k];
+	sgd_shape sc;
+	sc.pos = V3(q.pos[0], q.pos[1], q.pos[2]);
+	quat qq; qq.x = q.rot[0]; qq.y = q.rot[1]; qq.z = q.rot[2]; qq.w = q.rot[3];
+	sc.R = quat_to_m33(qq); sc.type = SGP_SHAPE_CAPSULE; sc.p0 = q.radius; sc.p1 = q.half_height; sc.p2 = 0.0f; sc.hull = nullptr;
+	const v3 ax = v3_scale(sc.R.c2, q.half_height);
+	const float e = q.radius + q.max_separation;
+	const v3 ext = V3(fabsf(ax.x) + e, fabsf(ax.y) + e, fabsf(ax.z) + e);
+	const v3 lo = v3_sub(sc.pos, ext), hi = v3_add(sc.pos, ext);
+	for (uint32_t l = 0; l < d.sp->n_large; ++l) capsule_query_body(d, q, k, sc, lo, hi, d.large_ids[l], out, cap, count);
+	const BpGrid g = *d.grid;
+	if (g.n_cells > 0 && g.min_x <= g.max_x) {
+		const int x0 = max((int)floorf((lo.x - g.ox) * g.inv_cell) - 1, 0), x1 = min((int)floorf((hi.x - g.ox) * g.inv_cell) + 1, g.nx - 1);
+		const int y0 = max((int)floorf((lo.y - g.oy) * g.inv_cell) - 1, 0), y1 = min((int)floorf((hi.y - g.oy) * g.inv_cell) + 1, g.ny - 1);
+		const int z0 = max((int)floorf((lo.z - g.oz) * g.inv_cell) - 1, 0), z1 = min((int)floorf((hi.z - g.oz) * g.inv_cell) + 1, g.nz - 1);
+		if (x0 <= x1) for (int z = z0; z <= z1; ++z) for (int y = y0; y <= y1; ++y) {
+			const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
+			const uint32_t c0 = d.cell_start[row + (uint32_t)x0], c1 = d.cell_start[row + (uint32_t)x1 + 1];
+			for (uint32_t c = c0; c < c1; ++c) capsule_query_body(d, q, k, sc, lo, hi, __float_as_uint(d.sorted_max[c].w), out, cap, count);
+		}
+	}
+}
+
+SGP_DEV void spherecast_body(const DV& d, const sgp_ray& ry, float rs, v3 o, v3 dir, uint32_t j, RayBest& best)
+{
+	if (j == ry.ignore_id) return;
+	const uint32_t f = d.flags[j];
+	if (!(f & BF_ALIVE) || (f & BF_SENSOR)) return;
+	const uint32_t layer = f_layer(f);
+	if (ry.collidable_only && !(layer == SGP_LAYER_NON_MOVING || layer == SGP_LAYER_MOVING)) return;
+	const float4 mn = d.aabb_min[j], mx = d.aabb_max[j];
+	const float e = rs + 1.0e-3f;
+	if (!ray_aabb(o, dir, make_float4(mn.x - e, mn.y - e, mn.z - e, 0.0f), make_float4(mx.x + e, mx.y + e, mx.z + e, 0.0f), best.t)) return;
+	const float4 sh = d.shape[j];
+	const float prm[3] = { sh.x, sh.y, sh.z };
+	v3 n, p;
+	const float t = sgd_cast_sphere_body((int)f_shape(f), prm, f_shape(f) == SGP_SHAPE_HULL ? body_hull(d, sh) : nullptr, V3(d.pos_im[j]), quat_to_m33(Q4(d.rot[j])), o, dir, best.t, rs, &n, &p);
+	if (t >= 0.0f && t <= best.t && (t < best.t || best.id == SGP_INVALID_ID || j < best.id)) { best.t = t; best.id = j; best.n = n; }
+}
+
+// one thread per cast; cells under the swept sphere's bounds (casts are short: a character's step)
+__global__ void __launch_bounds__(64) k_spherecast(DV d, const sgp_ray* rays, const float* radii, uint32_t n, sgp_hit* hits)
+{
+	const uint32_t k = blockIdx.x * 64 + threadIdx.x;
+	if (k >= n) return;
+	const sgp_ray ry = rays[k];
+	const float rs = radii[k];
+	const v3 o = V3(ry.origin[0], ry.origin[1], ry.origin[2]), dir = V3(ry.dir[0], ry.dir[1], ry.dir[2]);
+	RayBest best; best.t = ry.max_t; best.id = SGP_INVALID_ID; best.n = V3(0.0f, 0.0f, 0.0f);
+	for (uint32_t l = 0; l < d.sp->n_large; ++l) spherecast_body(d, ry, rs, o, dir, d.large_ids[l], best);
+	const BpGrid g = *d.grid;
+	if (g.n_cells > 0 && g.min_x <= g.max_x) {
+		const v3 e = v3_add(o, v3_scale(dir, ry.max_t));
+		const float m = rs + 1.0e-3f;
+		const int x0 = max((int)floorf((fminf(o.x, e.x) - m - g.ox) * g.inv_cell) - 1, 0), x1 = min((int)floorf((fmaxf(o.x, e.x) + m - g.ox) * g.inv_cell) + 1, g.nx - 1);
+		const int y0 = max((int)floorf((fminf(o.y, e.y) - m - g.oy) * g.inv_cell) - 1, 0), y1 = min((int)floorf((fmaxf(o.y, e.y) + m - g.oy) * g.inv_cell) + 1, g.ny - 1);
+		const int z0 = max((int)floorf((fminf(o.z, e.z) - m - g.oz) * g.inv_cell) - 1, 0), z1 = min((int)floorf((fmaxf(o.z, e.z) + m - g.oz) * g.inv_cell) + 1, g.nz - 1);
+		if (x0 <= x1) for (int z = z0; z <= z1; ++z) for (int y = y0; y <= y1; ++y) {
+			const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
+			const uint32_t c0 = d.cell_start[row + (uint32_t)x0], c1 = d.cell_start[row + (uint32_t)x1 + 1];
+			for (uint32_t c = c0; c < c1; ++c) spherecast_body(d, ry, rs, o, dir, __float_as_uint(d.sorted_max[c].w), best);
+		}
+	}
+	sgp_hit h;
+	h.id = best.id; h.t = best.id == SGP_INVALID_ID ? 0.0f : best.t;
+	h.normal[0] = best.n.x; h.normal[1] = best.n.y; h.normal[2] = best.n.z;
+	h.userdata = 0;
+	hits[k] = h;
+}
+
 // multi-GPU tiles: bodies owned by this tile whose inflated AABB pokes outside [lo,hi)
 __global__ void __launch_bounds__(TPB) k_export_boundary(DV d, float3 lo, float3 hi, float margin, sgp_ghost_record* out, uint32_t cap, uint32_t* count)
 {
@@ -2240,4 +2347,6 @@ void launch_vehicle_solve(const DV& d, int mode, hipStream_t s)
 	else hipLaunchKernelGGL(k_vehicle_solve<2>, g, b, 0, s, d);
 }
 void launch_raycast(const DV& d, const sgp_ray* rays, uint32_t n, sgp_hit* hits, hipStream_t s) { if (n) hipLaunchKernelGGL(k_raycast, dim3((n + 63) / 64), dim3(64), 0, s, d, rays, n, hits); }
+void launch_collide_capsules(const DV& d, const sgp_capsule_query* q, uint32_t n, sgp_query_contact* out, uint32_t cap, uint32_t* count, hipStream_t s) { if (n) hipLaunchKernelGGL(k_collide_capsules, dim3((n + 63) / 64), dim3(64), 0, s, d, q, n, out, cap, count); }
+void launch_spherecast(const DV& d, const sgp_ray* rays, const float* radii, uint32_t n, sgp_hit* hits, hipStream_t s) { if (n) hipLaunchKernelGGL(k_spherecast, dim3((n + 63) / 64), dim3(64), 0, s, d, rays, radii, n, hits); }
 void launch_export_boundary(const DV& d, uint32_t nb, float3 lo, float3 hi, float margin, sgp_ghost_record* out, uint32_t cap, uint32_t* count, hipStream_t s) { hipLaunchKernelGGL(k_export_boundary, dim3(blocks_for(nb)), dim3(TPB), 0, s, d, lo, hi, margin, out, cap, count); }

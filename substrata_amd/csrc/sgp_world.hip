@@ -193,7 +193,7 @@ SGP_API int sgp_abi_sizeof(int which)
 	case 6: return (int)sizeof(sgp_ray); case 7: return (int)sizeof(sgp_hit); case 8: return (int)sizeof(sgp_step_stats);
 	case 9: return (int)sizeof(sgp_step_profile); case 10: return (int)sizeof(sgp_ghost_record);
 	case 11: return (int)sizeof(sgp_vehicle_desc); case 12: return (int)sizeof(sgp_vehicle_input); case 13: return (int)sizeof(sgp_vehicle_state);
-	case 14: return (int)sizeof(sgp_hull_info);
+	case 14: return (int)sizeof(sgp_hull_info); case 15: return (int)sizeof(sgp_capsule_query); case 16: return (int)sizeof(sgp_query_contact);
 	default: return -1;
 	}
 }
@@ -1437,6 +1437,72 @@ SGP_API int sgp_raycast(sgp_world* w, const sgp_ray* rays, uint32_t n, sgp_hit* 
 	HIP_TRY(hipMemcpyAsync((char*)w->stage_host + rb, dh, sizeof(sgp_hit) * n, hipMemcpyDeviceToHost, w->stream));
 	HIP_TRY(hipStreamSynchronize(w->stream));
 	memcpy(hits, (char*)w->stage_host + rb, sizeof(sgp_hit) * n);
+	for (uint32_t k = 0; k < n; ++k) hits[k].userdata = hits[k].id != SGP_INVALID_ID ? w->hb[hits[k].id].userdata : 0;
+	return SGP_OK;
+}
+
+static int ensure_query_grid(sgp_world* w)
+{
+	if (!w->grid_valid && w->high) {
+		// poses changed since the grid was built (a step integrates after its broad phase; edits move bodies): re-bin
+		const DV& d = w->dv; hipStream_t s = w->stream; const uint32_t nb = w->high;
+		launch_step_begin(d, *w->h_sp, nb, false, s);
+		launch_bp_bounds(d, nb, s); launch_bp_cell(d, nb, s); launch_bp_scan(d, s); launch_bp_scatter(d, nb, s);
+		w->grid_valid = true;
+	}
+	return SGP_OK;
+}
+
+// CharacterVirtual's CollideShape (PlayerPhysics.cpp:258-353): contacts of capsules with everything within max_separation
+SGP_API int sgp_collide_capsules(sgp_world* w, const sgp_capsule_query* qs, uint32_t n, sgp_query_contact* out, uint32_t cap, uint32_t* n_out)
+{
+	if (!w || (!qs && n) || (!out && cap) || !n_out) return fail(SGP_ERR_INVALID, "sgp_collide_capsules: NULL");
+	hipSetDevice(w->device);
+	{ int r = flush_cmds(w); if (r != SGP_OK) return r; }
+	*n_out = 0;
+	if (!n) return SGP_OK;
+	ensure_query_grid(w);
+	const size_t qb = (sizeof(sgp_capsule_query) * n + 15) & ~size_t(15);
+	const size_t ob = sizeof(sgp_query_contact) * std::max(cap, 1u);
+	{ int r = ensure_stage(w, qb + ob + 16); if (r != SGP_OK) return r; }
+	memcpy(w->stage_host, qs, sizeof(sgp_capsule_query) * n);
+	HIP_TRY(hipMemcpyAsync(w->stage_dev, w->stage_host, sizeof(sgp_capsule_query) * n, hipMemcpyHostToDevice, w->stream));
+	sgp_query_contact* dout = (sgp_query_contact*)((char*)w->stage_dev + qb);
+	uint32_t* dcount = (uint32_t*)((char*)w->stage_dev + qb + ob);
+	HIP_TRY(hipMemsetAsync(dcount, 0, sizeof(uint32_t), w->stream));
+	launch_collide_capsules(w->dv, (const sgp_capsule_query*)w->stage_dev, n, dout, cap, dcount, w->stream);
+	HIP_TRY(hipMemcpyAsync((char*)w->stage_host + qb, dout, ob + 16, hipMemcpyDeviceToHost, w->stream));
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	const uint32_t cnt = *(const uint32_t*)((char*)w->stage_host + qb + ob);
+	const uint32_t m = std::min(cnt, cap);
+	sgp_query_contact* h = (sgp_query_contact*)((char*)w->stage_host + qb);
+	std::sort(h, h + m, [](const sgp_query_contact& a, const sgp_query_contact& b) {
+		if (a.query != b.query) return a.query < b.query;
+		if (a.body != b.body) return a.body < b.body;
+		return a.pad < b.pad; });
+	for (uint32_t i = 0; i < m; ++i) { h[i].pad = 0; h[i].userdata = w->hb[h[i].body].userdata; }
+	memcpy(out, h, sizeof(sgp_query_contact) * m);
+	*n_out = cnt;
+	return SGP_OK;
+}
+
+SGP_API int sgp_spherecast(sgp_world* w, const sgp_ray* rays, const float* radii, uint32_t n, sgp_hit* hits)
+{
+	if (!w || (n && (!rays || !radii || !hits))) return fail(SGP_ERR_INVALID, "sgp_spherecast: NULL");
+	hipSetDevice(w->device);
+	{ int r = flush_cmds(w); if (r != SGP_OK) return r; }
+	if (!n) return SGP_OK;
+	ensure_query_grid(w);
+	const size_t rb = (sizeof(sgp_ray) * n + 15) & ~size_t(15), fb = (sizeof(float) * n + 15) & ~size_t(15);
+	{ int r = ensure_stage(w, rb + fb + sizeof(sgp_hit) * n); if (r != SGP_OK) return r; }
+	memcpy(w->stage_host, rays, sizeof(sgp_ray) * n);
+	memcpy((char*)w->stage_host + rb, radii, sizeof(float) * n);
+	HIP_TRY(hipMemcpyAsync(w->stage_dev, w->stage_host, rb + sizeof(float) * n, hipMemcpyHostToDevice, w->stream));
+	sgp_hit* dh = (sgp_hit*)((char*)w->stage_dev + rb + fb);
+	launch_spherecast(w->dv, (const sgp_ray*)w->stage_dev, (const float*)((char*)w->stage_dev + rb), n, dh, w->stream);
+	HIP_TRY(hipMemcpyAsync((char*)w->stage_host + rb + fb, dh, sizeof(sgp_hit) * n, hipMemcpyDeviceToHost, w->stream));
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	memcpy(hits, (char*)w->stage_host + rb + fb, sizeof(sgp_hit) * n);
 	for (uint32_t k = 0; k < n; ++k) hits[k].userdata = hits[k].id != SGP_INVALID_ID ? w->hb[hits[k].id].userdata : 0;
 	return SGP_OK;
 }

@@ -256,6 +256,20 @@ class CWorld:
         self._check(self._fn("vehicle_reset_drivetrain")(self._h, int(vid), float(engine_rpm), float(wheel_angular_velocity)),
                     "vehicle_reset_drivetrain")
 
+    def collide_capsules(self, queries, cap=4096):
+        queries = np.ascontiguousarray(queries, dtype=abi.capsule_query_dtype)
+        out = np.zeros(cap, dtype=abi.query_contact_dtype)
+        n = C.c_uint32(0)
+        self._check(self._fn("collide_capsules")(self._h, queries.ctypes.data, len(queries), out.ctypes.data, int(cap), C.byref(n)), "collide_capsules")
+        return out[:min(n.value, cap)]
+
+    def spherecast(self, rays, radii):
+        rays = np.ascontiguousarray(rays, dtype=abi.ray_dtype)
+        radii = np.ascontiguousarray(np.broadcast_to(np.asarray(radii, dtype=np.float32), (len(rays),)), dtype=np.float32)
+        hits = np.zeros(len(rays), dtype=abi.hit_dtype)
+        self._check(self._fn("spherecast")(self._h, rays.ctypes.data, radii.ctypes.data, len(rays), hits.ctypes.data), "spherecast")
+        return hits
+
     def dump_constraints(self, cap=None):
         cap = (8 * self.max_bodies + 1024) if cap is None else cap
         out = np.zeros(cap, dtype=abi.constraint_dump_dtype)
