@@ -132,6 +132,11 @@ namespace JPH
 		sgp_world* world; mutable Body scratch;
 	};
 
+	class BroadPhaseLayerFilter {};
+	class ObjectLayerFilter { public: virtual ~ObjectLayerFilter() {} virtual bool ShouldCollide(uint16_t) const { return true; } };
+	class DefaultBroadPhaseLayerFilter : public BroadPhaseLayerFilter {};
+	class DefaultObjectLayerFilter : public ObjectLayerFilter {};
+
 	class VehicleConstraint;      // Jolt/JoltVehicleLite.h
 	class PhysicsStepListener;
 
@@ -150,6 +155,10 @@ namespace JPH
 		template <class T> void AddStepListener(T*) {}
 		template <class T> void RemoveStepListener(T*) {}
 		void onStep() { ++step_serial; body_interface.invalidate(); }       // called by PhysicsWorld::think
+		// filter factories CharacterVirtual callers pass through (PlayerPhysics.cpp:106-114,344-346): the character queries always use the
+		// MOVING object layer's collision set, so these are placeholders
+		DefaultBroadPhaseLayerFilter GetDefaultBroadPhaseLayerFilter(uint16_t) const { return DefaultBroadPhaseLayerFilter(); }
+		DefaultObjectLayerFilter GetDefaultLayerFilter(uint16_t) const { return DefaultObjectLayerFilter(); }
 		sgp_world* world;
 	private:
 		BodyInterface body_interface;
