@@ -65,6 +65,9 @@ extern "C" {
 #define SGP_SHAPE_SPHERE   0
 #define SGP_SHAPE_BOX      1
 #define SGP_SHAPE_CAPSULE  2
+#define SGP_SHAPE_MESH     4   /* static triangle mesh created with sgp_mesh_create; shape[0] = (float) mesh id; static bodies only.
+                                  A mesh body occupies three consecutive body ids (the id returned + two internal aliases that carry
+                                  the second and third contact manifold of a body touching the mesh from several sides)             */
 #define SGP_SHAPE_HULL     3   /* convex hull created with sgp_hull_create; shape[0] = (float) hull id, body frame = the hull's
                                   centre-of-mass / principal-axes frame (see sgp_hull_info)                                  */
 
@@ -293,7 +296,7 @@ int  sgp_world_stats(sgp_world* w, sgp_step_stats* out);
 const char* sgp_kernel_class_name(int k);
 /* sizeof() of ABI struct number `which` (order: settings, world_desc, body_desc, body_state, body_event, contact_event,
  * ray, hit, step_stats, step_profile, ghost_record, vehicle_desc, vehicle_input, vehicle_state, hull_info, capsule_query,
- * query_contact) so bindings can verify their layout. */
+ * query_contact, mesh_info) so bindings can verify their layout. */
 int  sgp_abi_sizeof(int which);
 /* activated_obs / newly_activated_obs maintenance + listener callbacks (PhysicsWorld.h:194-200). */
 int  sgp_world_drain_events(sgp_world* w, int kind, void* out, uint32_t cap, uint32_t* n_out);
@@ -327,6 +330,18 @@ int  sgp_hull_create(sgp_world* w, const float* points_xyz, uint32_t num_points,
 /* The same wrapped in JPH::OffsetCenterOfMassShapeSettings(com_offset, hull) (PhysicsWorld.cpp:1138-1153, CarPhysics.cpp:76-78,
  * BikePhysics.cpp:103-105): the body's centre of mass sits at hull centre of mass + com_offset (frame of the points). */
 int  sgp_hull_create_com(sgp_world* w, const float* points_xyz, uint32_t num_points, const float com_offset[3], sgp_hull_info* info_out);
+
+/* ---- static triangle meshes ---------------------------------------------------
+ * Replaces JPH::MeshShapeSettings(vertices, triangles).Create() for static mesh objects and -- through a triangulated grid --
+ * JPH::HeightFieldShapeSettings for the terrain (gui_client/PhysicsWorld.cpp:735-1166 with is_dynamic = false, :1020-1120;
+ * TerrainSystem.cpp:1300).  Vertices must already carry the object's scale.  Front faces (counter-clockwise) collide, back
+ * faces do not.  Mesh bodies are static, live in the mesh's own frame (no centre-of-mass shift) and take three body ids. */
+typedef struct sgp_mesh_info {
+	uint32_t mesh_id;                 /* >= 1; goes into sgp_body_desc::shape[0] with shape_type = SGP_SHAPE_MESH */
+	uint32_t num_vertices, num_triangles, num_nodes;
+	float aabb_min[3], aabb_max[3];
+} sgp_mesh_info;
+int  sgp_mesh_create(sgp_world* w, const float* vertices_xyz, uint32_t num_vertices, const uint32_t* indices, uint32_t num_triangles, sgp_mesh_info* info_out);
 
 /* ---- wheeled vehicles --------------------------------------------------------
  * Replaces JPH::VehicleConstraint + JPH::WheeledVehicleController + JPH::VehicleCollisionTesterCastSphere as CarPhysics

@@ -18,7 +18,7 @@ _lib = None
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("sgo_oracle.c", "sgo_collide.h", "sgo_hull.h", "sgo_hull_build.h", "sgo_vehicle.h", "sgo_math.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("sgo_oracle.c", "sgo_collide.h", "sgo_hull.h", "sgo_hull_build.h", "sgo_mesh.h", "sgo_vehicle.h", "sgo_math.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "sgp.h"))
     if not force and os.path.exists(_LIB_PATH) and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return _LIB_PATH

@@ -24,6 +24,7 @@
 #define SGO_SHAPE_SPHERE  0
 #define SGO_SHAPE_BOX     1
 #define SGO_SHAPE_CAPSULE 2
+#define SGO_SHAPE_MESH    4   /* static triangle mesh (sgo_mesh.h): collided per triangle by the world, never through sgo_collide */
 #define SGO_SHAPE_HULL    3   /* convex hull (sgo_hull.h): p[] unused, `hull` = the shape; for a box `hull` = the +-1 cube template */
 
 struct sgo_hull_s;

@@ -1,0 +1,113 @@
+/*
+ * sgo_mesh.h -- ORACLE (test infrastructure only): static triangle-mesh shapes.
+ *
+ * What it restates.  Substrata gives every static mesh object a JPH::MeshShape and the terrain a JPH::HeightFieldShape
+ * (/root/reference/gui_client/PhysicsWorld.cpp:735-1166 createJoltShapeFor...Mesh with is_dynamic = false,
+ * createJoltHeightFieldShape :1020-1120; TerrainSystem.cpp:1300).  Jolt (v5.3.0, not in the tree) walks the mesh's tree with the
+ * other shape's bounds and collides the convex shape with every triangle it reaches (back faces ignored), each hit becoming a
+ * manifold; manifolds of one body pair with similar normals are merged and pruned to 4 points.  Restated from upstream
+ * knowledge (parity unpinned; pinned by tests/test_oracle_mesh.py):
+ *   - a triangle is collided as a thin convex hull (3 vertices, front and back face, 3 edges) with the hull routines of
+ *     sgo_hull.h (SAT + clipping for boxes / hulls, closest point for spheres / capsules); contacts whose normal points to the
+ *     triangle's back side are dropped;
+ *   - the triangles reached by a body are taken in index order; their manifolds are grouped by normal (within ~18 degrees of the
+ *     group's first normal), at most 3 groups per body pair, each group pruned to 4 points -- a body in a corner of the mesh
+ *     keeps one constraint per wall.  The groups are carried by the mesh body and its two alias body slots, so that the
+ *     (body a, body b) constraint key needs no sub-shape part.
+ * Not restated: Jolt's active-edge flags (contacts on edges shared by coplanar triangles keep their edge normal here).
+ */
+#ifndef SGO_MESH_H
+#define SGO_MESH_H
+
+#include "sgo_hull.h"
+
+#define SGO_MESH_MAX_GROUPS 3
+#define SGO_MESH_GROUP_COS 0.95f
+
+/* the thin hull of one triangle; vertices relative to the centroid (mesh frame) */
+static inline void sgo_tri_hull(v3 a, v3 b, v3 c, sgo_hull* h, v3* centroid_out, v3* normal_out)
+{
+	const v3 cen = v3_scale(v3_add(v3_add(a, b), c), 1.0f / 3.0f);
+	v3 n = v3_cross(v3_sub(b, a), v3_sub(c, a));
+	const float l = v3_len(n);
+	n = l > 1.0e-20f ? v3_scale(n, 1.0f / l) : V3(0.0f, 0.0f, 1.0f);
+	h->nv = 3; h->nf = 2; h->ne = 3; h->is_box_template = 0;
+	h->verts[0] = v3_sub(a, cen); h->verts[1] = v3_sub(b, cen); h->verts[2] = v3_sub(c, cen);
+	h->normals[0] = n; h->plane_d[0] = v3_dot(n, h->verts[0]);
+	h->normals[1] = v3_neg(n); h->plane_d[1] = -h->plane_d[0];
+	h->face_start[0] = 0; h->face_start[1] = 3; h->face_start[2] = 6;
+	h->face_idx[0] = 0; h->face_idx[1] = 1; h->face_idx[2] = 2;          /* counter-clockwise seen from +n */
+	h->face_idx[3] = 0; h->face_idx[4] = 2; h->face_idx[5] = 1;
+	h->edge_a[0] = 0; h->edge_b[0] = 1; h->edge_a[1] = 1; h->edge_b[1] = 2; h->edge_a[2] = 0; h->edge_b[2] = 2;
+	*centroid_out = cen; *normal_out = n;
+}
+
+typedef struct { v3 n; int np; v3 p_mesh[SGO_HULL_CLIP_CAP]; v3 p_body[SGO_HULL_CLIP_CAP]; } sgo_mesh_group;
+typedef struct { int ng; sgo_mesh_group g[SGO_MESH_MAX_GROUPS]; } sgo_mesh_contacts;
+
+/* m: manifold of one triangle, normal from the triangle to the body, p1 on the triangle, p2 on the body */
+static inline void sgo_mesh_add(sgo_mesh_contacts* mc, const sgo_manifold* m)
+{
+	int gi = -1;
+	for (int k = 0; k < mc->ng; ++k) if (v3_dot(mc->g[k].n, m->n) >= SGO_MESH_GROUP_COS) { gi = k; break; }
+	if (gi < 0) {
+		if (mc->ng == SGO_MESH_MAX_GROUPS) return;
+		gi = mc->ng++;
+		mc->g[gi].n = m->n; mc->g[gi].np = 0;
+	}
+	sgo_mesh_group* g = &mc->g[gi];
+	for (int i = 0; i < m->np; ++i) {
+		if (g->np == SGO_HULL_CLIP_CAP) break;
+		/* the same point reached through two triangles that share it (an edge or a vertex of the mesh) counts once */
+		int dup = 0;
+		for (int j = 0; j < g->np; ++j) if (v3_len_sq(v3_sub(g->p_body[j], m->p2[i])) < 1.0e-8f) { dup = 1; break; }
+		if (dup) continue;
+		g->p_mesh[g->np] = m->p1[i]; g->p_body[g->np] = m->p2[i]; g->np++;
+	}
+}
+
+/* X against one triangle (world-space view T of its thin hull, world normal nt).  Normal of the result: triangle -> X. */
+static inline int sgo_collide_tri(const sgo_shape* X, const sgo_hview* T, v3 nt, float max_sep, sgo_manifold* m)
+{
+	int hit;
+	if (X->type == SGO_SHAPE_SPHERE) hit = sgo_hull_sphere(T, X->pos, X->p[0], max_sep, m);
+	else if (X->type == SGO_SHAPE_CAPSULE) {
+		const v3 ax = v3_scale(m33_col(X->R, 2), X->p[1]);
+		hit = sgo_hull_capsule(T, v3_sub(X->pos, ax), v3_add(X->pos, ax), X->p[0], max_sep, m);
+	} else {
+		sgo_hview hx;
+		hx.pos = X->pos; hx.R = X->R; hx.h = X->hull;
+		hx.scale = X->type == SGO_SHAPE_BOX ? V3(X->p[0], X->p[1], X->p[2]) : V3(1.0f, 1.0f, 1.0f);
+		hit = sgo_hull_hull(T, &hx, max_sep, m);
+	}
+	if (!hit) return 0;
+	if (v3_dot(m->n, nt) < 0.0f) return 0;                   /* reached from the back side */
+	return 1;
+}
+
+/* the groups as manifolds (normal mesh -> body, p1 on the mesh, p2 on the body), each pruned to <= 4 points */
+static inline int sgo_mesh_finish(const sgo_mesh_contacts* mc, sgo_manifold* out)
+{
+	for (int k = 0; k < mc->ng; ++k) sgo_hull_reduce(mc->g[k].n, mc->g[k].p_mesh, mc->g[k].p_body, mc->g[k].np, &out[k]);
+	return mc->ng;
+}
+
+/* ray against one triangle (Moeller-Trumbore, front face only): t or -1 */
+static inline float sgo_ray_tri(v3 o, v3 d, v3 a, v3 b, v3 c, float max_t)
+{
+	const v3 e1 = v3_sub(b, a), e2 = v3_sub(c, a);
+	const v3 pv = v3_cross(d, e2);
+	const float det = v3_dot(e1, pv);
+	if (det < 1.0e-12f) return -1.0f;                          /* parallel or hitting the back face */
+	const v3 tv = v3_sub(o, a);
+	const float u = v3_dot(tv, pv);
+	if (u < 0.0f || u > det) return -1.0f;
+	const v3 qv = v3_cross(tv, e1);
+	const float vv = v3_dot(d, qv);
+	if (vv < 0.0f || u + vv > det) return -1.0f;
+	const float t = v3_dot(e2, qv) / det;
+	if (t < 0.0f || t > max_t) return -1.0f;
+	return t;
+}
+
+#endif

@@ -34,6 +34,7 @@
 #include "../include/sgp.h"
 #include "sgo_collide.h"
 #include "sgo_hull_build.h"
+#include "sgo_mesh.h"
 #include "sgo_vehicle.h"
 
 #define SGO_API __attribute__((visibility("default")))
@@ -44,6 +45,8 @@ typedef struct {
 	v3 pos; quat rot; v3 linv, angv; v3 force, torque;
 	float inv_mass; v3 inv_inertia;
 	int shape_type; float shape[4];
+	const struct sgo_mesh_s* mesh;    /* SGP_SHAPE_MESH: the triangles (mesh frame = body frame) */
+	int is_alias;                     /* internal second / third slot of a mesh body: carries contact manifolds only */
 	const sgo_hull* hull;             /* SGP_SHAPE_HULL: the shape; SGP_SHAPE_BOX: the +-1 cube template (for box - hull pairs) */
 	int motion, layer;
 	float friction, restitution, gravity_factor, lin_damp, ang_damp, mass;
@@ -80,6 +83,8 @@ typedef struct {
 
 typedef struct { uint32_t a, b; } sgo_pair;
 
+typedef struct sgo_mesh_s { uint32_t nv, nt; v3* verts; uint32_t* tris; v3 aabb_min, aabb_max; float bound_radius; } sgo_mesh;
+
 typedef struct sgo_world {
 	sgp_world_desc desc;
 	sgp_settings st;
@@ -109,6 +114,7 @@ typedef struct sgo_world {
 	uint64_t* ghost_gid; uint32_t* ghost_lid; uint32_t n_ghosts;
 	int* is_ghost;
 	uint64_t tot_act, tot_deact, rep_act, rep_deact;   /* running totals of (de)activation events / totals already reported in stats */
+	sgo_mesh** meshes; uint32_t n_meshes, cap_meshes;      /* static triangle meshes; id 0 unused */
 	/* convex hull shapes (sgo_hull.h): stable pointers, hull 0 = the +-1 cube template */
 	sgo_hull** hulls; uint32_t n_hulls, cap_hulls;
 	/* wheeled vehicles (sgo_vehicle.h) */
@@ -229,7 +235,7 @@ static float shape_volume(int type, const float* p)
 }
 
 /* Local-space half extents of the shape's AABB (Shape::GetLocalBounds). */
-static float shape_volume_h(int type, const float* p, const sgo_hull* hull) { return type == SGP_SHAPE_HULL ? hull->volume : shape_volume(type, p); }
+static float shape_volume_h(int type, const float* p, const sgo_hull* hull) { return type == SGP_SHAPE_MESH ? 0.0f : (type == SGP_SHAPE_HULL ? hull->volume : shape_volume(type, p)); }
 
 static v3 shape_local_half_h(int type, const float* p, const sgo_hull* hull);
 static v3 shape_local_half(int type, const float* p)
@@ -241,6 +247,7 @@ static v3 shape_local_half(int type, const float* p)
 
 static v3 shape_local_half_h(int type, const float* p, const sgo_hull* hull)
 {
+	if (type == SGP_SHAPE_MESH) return V3(1.0f, 1.0f, 1.0f);      /* (static: never asked for sleep points) */
 	if (type == SGP_SHAPE_HULL) return v3_max(v3_abs(hull->aabb_min), v3_abs(hull->aabb_max));
 	return shape_local_half(type, p);
 }
@@ -252,11 +259,23 @@ static float shape_bounding_radius(int type, const float* p)
 	return p[0] + p[1];
 }
 
-static float body_bounding_radius(const sgo_body* b) { return b->shape_type == SGP_SHAPE_HULL ? b->hull->bound_radius : shape_bounding_radius(b->shape_type, b->shape); }
+/* mesh bodies always count as large (tested against every body instead of being binned) */
+static float body_bounding_radius(const sgo_body* b) { if (b->shape_type == SGP_SHAPE_MESH) return 3.0e38f; return b->shape_type == SGP_SHAPE_HULL ? b->hull->bound_radius : shape_bounding_radius(b->shape_type, b->shape); }
 
 static void body_update_aabb(sgo_body* b)
 {
 	v3 e;
+	if (b->shape_type == SGP_SHAPE_MESH) {
+		/* corners of the mesh's local bounds */
+		const m33 R = quat_to_m33(b->rot);
+		v3 mn = V3(3.4e38f, 3.4e38f, 3.4e38f), mx = V3(-3.4e38f, -3.4e38f, -3.4e38f);
+		for (int k = 0; k < 8; ++k) {
+			const v3 c = V3((k & 1) ? b->mesh->aabb_max.x : b->mesh->aabb_min.x, (k & 2) ? b->mesh->aabb_max.y : b->mesh->aabb_min.y, (k & 4) ? b->mesh->aabb_max.z : b->mesh->aabb_min.z);
+			const v3 p = m33_mul(R, c); mn = v3_min(mn, p); mx = v3_max(mx, p);
+		}
+		b->aabb_min = v3_add(b->pos, mn); b->aabb_max = v3_add(b->pos, mx);
+		return;
+	}
 	if (b->shape_type == SGP_SHAPE_HULL) {
 		const m33 R = quat_to_m33(b->rot);
 		v3 mn = V3(3.4e38f, 3.4e38f, 3.4e38f), mx = V3(-3.4e38f, -3.4e38f, -3.4e38f);
@@ -350,6 +369,7 @@ SGO_API int sgo_world_create(const sgp_world_desc* desc, sgo_world** out)
 	if (w->desc.large_body_radius <= 0.0f) w->desc.large_body_radius = 4.0f;
 	w->cap_hulls = 16; w->hulls = (sgo_hull**)calloc(w->cap_hulls, sizeof(sgo_hull*));
 	w->hulls[0] = (sgo_hull*)malloc(sizeof(sgo_hull)); sgo_hull_cube_template(w->hulls[0]); w->n_hulls = 1;
+	w->cap_meshes = 16; w->meshes = (sgo_mesh**)calloc(w->cap_meshes, sizeof(sgo_mesh*)); w->n_meshes = 1;
 	*out = w;
 	return SGP_OK;
 }
@@ -364,6 +384,8 @@ SGO_API int sgo_world_destroy(sgo_world* w)
 	free(w->vehicles);
 	for (uint32_t k = 0; k < w->n_hulls; ++k) free(w->hulls[k]);
 	free(w->hulls);
+	for (uint32_t k = 1; k < w->n_meshes; ++k) { free(w->meshes[k]->verts); free(w->meshes[k]->tris); free(w->meshes[k]); }
+	free(w->meshes);
 	free(w);
 	return SGP_OK;
 }
@@ -375,20 +397,32 @@ SGO_API int sgo_body_add(sgo_world* w, const sgp_body_desc* d, uint32_t* id_out)
 {
 	if (!w || !d) return SGP_ERR_INVALID;
 	if (!finite3(d->pos) || fabsf(d->pos[0]) > 1.0e9f || fabsf(d->pos[1]) > 1.0e9f || fabsf(d->pos[2]) > 1.0e9f) return SGP_ERR_REJECTED; /* :1178 */
-	if (d->shape_type < 0 || d->shape_type > SGP_SHAPE_HULL) return SGP_ERR_INVALID;
+	if (d->shape_type < 0 || d->shape_type > SGP_SHAPE_MESH) return SGP_ERR_INVALID;
 	const sgo_hull* hull = NULL;
+	const sgo_mesh* mesh = NULL;
+	if (d->shape_type == SGP_SHAPE_MESH) {
+		const uint32_t mid = (uint32_t)d->shape[0];
+		if (!(d->shape[0] >= 1.0f) || (float)mid != d->shape[0] || mid >= w->n_meshes) return SGP_ERR_INVALID;
+		if (d->motion_type != SGP_MOTION_STATIC) return SGP_ERR_INVALID;       /* JPH::MeshShape: static bodies only */
+		mesh = w->meshes[mid];
+	}
 	if (d->shape_type == SGP_SHAPE_HULL) {
 		const uint32_t hid = (uint32_t)d->shape[0];
 		if (!(d->shape[0] >= 1.0f) || (float)hid != d->shape[0] || hid >= w->n_hulls) return SGP_ERR_INVALID;   /* hull 0 is the internal cube template */
 		hull = w->hulls[hid];
 	} else if (d->shape_type == SGP_SHAPE_BOX) hull = w->hulls[0];
-	const int nparam = d->shape_type == SGP_SHAPE_BOX ? 3 : (d->shape_type == SGP_SHAPE_SPHERE ? 1 : (d->shape_type == SGP_SHAPE_HULL ? 0 : 2));
+	const int nparam = d->shape_type == SGP_SHAPE_BOX ? 3 : (d->shape_type == SGP_SHAPE_SPHERE ? 1 : ((d->shape_type == SGP_SHAPE_HULL || d->shape_type == SGP_SHAPE_MESH) ? 0 : 2));
 	for (int i = 0; i < nparam; ++i) {
 		const float lim = (d->shape_type == SGP_SHAPE_CAPSULE && i == 1) ? 0.0f : 0.5e-7f; /* |scale| < 1e-7 on a 0.5 unit shape, :1184 */
 		if (!isfinite(d->shape[i]) || d->shape[i] < lim) return SGP_ERR_REJECTED;
 	}
 	uint32_t id;
-	if (w->n_free) id = w->free_list[--w->n_free];
+	if (mesh) {
+		/* three consecutive fresh slots: the body and its two aliases */
+		if (w->high + 3 > w->cap) return SGP_ERR_CAPACITY;
+		id = w->high; w->high += 3;
+	}
+	else if (w->n_free) id = w->free_list[--w->n_free];
 	else { if (w->high >= w->cap) return SGP_ERR_CAPACITY; id = w->high++; }
 	sgo_body* b = &w->bodies[id];
 	memset(b, 0, sizeof(*b));
@@ -400,6 +434,7 @@ SGO_API int sgo_body_add(sgo_world* w, const sgp_body_desc* d, uint32_t* id_out)
 	b->shape_type = d->shape_type;
 	memcpy(b->shape, d->shape, sizeof(b->shape));
 	b->hull = hull;
+	b->mesh = mesh;
 	b->motion = d->motion_type; b->layer = d->layer;
 	b->friction = clampf(d->friction, 0.0f, 1.0f);         /* :1236 */
 	b->restitution = clampf(d->restitution, 0.0f, 1.0f);   /* :1237 */
@@ -415,6 +450,7 @@ SGO_API int sgo_body_add(sgo_world* w, const sgp_body_desc* d, uint32_t* id_out)
 	body_update_aabb(b);
 	body_reset_sleep(b);
 	w->n_alive++;
+	if (mesh) for (uint32_t k = 1; k <= 2; ++k) { w->bodies[id + k] = *b; w->bodies[id + k].is_alias = 1; }
 	if (d->activate) body_activate(w, id);
 	if (id_out) *id_out = id;
 	return SGP_OK;
@@ -437,8 +473,9 @@ SGO_API int sgo_body_remove(sgo_world* w, uint32_t id)
 {
 	if (!live(w, id)) return SGP_ERR_BAD_ID;
 	for (uint32_t k = 0; k < w->n_vehicles; ++k) if (w->vehicles[k].alive && w->vehicles[k].body == id) w->vehicles[k].alive = 0;   /* a vehicle does not outlive its chassis */
-	w->bodies[id].alive = 0; w->bodies[id].active = 0;
-	w->free_list[w->n_free++] = id;
+	if (w->bodies[id].is_alias) return SGP_ERR_BAD_ID;
+	const int nslots = w->bodies[id].shape_type == SGP_SHAPE_MESH ? 3 : 1;
+	for (int k = 0; k < nslots; ++k) { w->bodies[id + k].alive = 0; w->bodies[id + k].active = 0; w->bodies[id + k].is_alias = 0; w->free_list[w->n_free++] = id + k; }
 	w->n_alive--;
 	return SGP_OK;
 }
@@ -623,7 +660,7 @@ static void broad_phase(sgo_world* w)
 	keyidx* ki = (keyidx*)malloc(sizeof(keyidx) * (w->high ? w->high : 1));
 	for (uint32_t i = 0; i < w->high; ++i) {
 		const sgo_body* b = &w->bodies[i];
-		if (!b->alive) continue;
+		if (!b->alive || b->is_alias) continue;
 		if (body_bounding_radius(b) > large_r) { w->large[w->n_large++] = i; continue; }
 		const v3 e = v3_sub(b->aabb_max, b->aabb_min);
 		cell = fmaxf(cell, fmaxf(e.x, fmaxf(e.y, e.z)));
@@ -667,7 +704,7 @@ static void broad_phase(sgo_world* w)
 	for (uint32_t l = 0; l < w->n_large; ++l) {
 		const uint32_t i = w->large[l];
 		for (uint32_t j = 0; j < w->high; ++j) {
-			if (j == i || !w->bodies[j].alive) continue;
+			if (j == i || !w->bodies[j].alive || w->bodies[j].is_alias) continue;
 			/* large-large pairs once */
 			if (body_bounding_radius(&w->bodies[j]) > large_r && j < i) continue;
 			if (pair_passes(w, i, j)) push_pair(w, i, j);
@@ -711,6 +748,8 @@ static void emit_contact_event(sgo_world* w, const sgo_constraint* c, const sgo_
 	sgp_contact_event e; memset(&e, 0, sizeof(e));
 	const sgo_body* A = &w->bodies[c->a]; const sgo_body* B = &w->bodies[c->b];
 	e.id1 = c->a; e.id2 = c->b; e.userdata1 = A->userdata; e.userdata2 = B->userdata;
+	while (e.id1 > 0 && w->bodies[e.id1].is_alias) --e.id1;      /* a mesh body's alias slots report as the mesh body */
+	while (e.id2 > 0 && w->bodies[e.id2].is_alias) --e.id2;
 	e.lin_vel1[0] = A->linv.x; e.lin_vel1[1] = A->linv.y; e.lin_vel1[2] = A->linv.z;
 	e.lin_vel2[0] = B->linv.x; e.lin_vel2[1] = B->linv.y; e.lin_vel2[2] = B->linv.z;
 	e.base_offset[0] = m->p1[0].x; e.base_offset[1] = m->p1[0].y; e.base_offset[2] = m->p1[0].z;
@@ -789,31 +828,51 @@ static int setup_constraint(sgo_world* w, uint32_t k, const sgo_manifold* m, flo
 }
 
 /* Narrow phase + constraint setup for every candidate pair. */
+static int collide_with_mesh(const sgo_body* M, const sgo_shape* X, v3 lo, v3 hi, float max_sep, sgo_manifold* out);
+
 static void find_contacts(sgo_world* w, float dt)
 {
 	w->n_cons = 0;
-	if (w->cap_cons < w->n_pairs + 1) {
-		w->cap_cons = w->n_pairs + 1024;
+	/* pass 1: manifolds + activation of sleeping bodies touched by an active one.  A pair with a mesh body yields up to three
+	   manifolds (groups of triangle contacts with similar normals), carried by the mesh body and its two alias slots. */
+	if (w->cap_cons < 3 * w->n_pairs + 1) {
+		w->cap_cons = 3 * w->n_pairs + 1024;
 		w->cons = (sgo_constraint*)realloc(w->cons, sizeof(sgo_constraint) * w->cap_cons);
 	}
-	/* pass 1: manifolds + activation of sleeping bodies touched by an active one */
-	sgo_manifold* mans = (sgo_manifold*)malloc(sizeof(sgo_manifold) * (w->n_pairs ? w->n_pairs : 1));
+	sgo_manifold* mans = (sgo_manifold*)malloc(sizeof(sgo_manifold) * (w->n_pairs ? 3 * w->n_pairs : 1));
 	unsigned char* hit = (unsigned char*)malloc(w->n_pairs ? w->n_pairs : 1);
 	#pragma omp parallel for schedule(static, 256) if (g_threads > 1)
 	for (uint32_t p = 0; p < w->n_pairs; ++p) {
 		const uint32_t a = w->pairs[p].a, b = w->pairs[p].b;
-		const sgo_shape sa = body_shape_xf(&w->bodies[a]), sb = body_shape_xf(&w->bodies[b]);
-		hit[p] = (unsigned char)sgo_collide(&sa, &sb, w->st.speculative_contact_distance, &mans[p]);
+		const sgo_body* A = &w->bodies[a]; const sgo_body* B = &w->bodies[b];
+		if (A->shape_type == SGP_SHAPE_MESH || B->shape_type == SGP_SHAPE_MESH) {
+			hit[p] = 0;
+			if (A->shape_type == SGP_SHAPE_MESH && B->shape_type == SGP_SHAPE_MESH) continue;       /* (both static anyway) */
+			const sgo_body* M = A->shape_type == SGP_SHAPE_MESH ? A : B; const sgo_body* X = M == A ? B : A;
+			const sgo_shape sx = body_shape_xf(X);
+			hit[p] = (unsigned char)collide_with_mesh(M, &sx, X->aabb_min, X->aabb_max, w->st.speculative_contact_distance, &mans[3 * p]);
+			continue;
+		}
+		const sgo_shape sa = body_shape_xf(A), sb = body_shape_xf(B);
+		hit[p] = (unsigned char)sgo_collide(&sa, &sb, w->st.speculative_contact_distance, &mans[3 * p]);
 	}
 	uint32_t nm = 0;
 	for (uint32_t p = 0; p < w->n_pairs; ++p) {
-		if (!hit[p]) continue;
-		const uint32_t a = w->pairs[p].a, b = w->pairs[p].b;
-		sgo_constraint* c = &w->cons[nm];
-		memset(c, 0, sizeof(*c));
-		c->a = a; c->b = b; c->key = ((uint64_t)a << 32) | b; c->prio = sgp_mix64(c->key);
-		c->np = mans[p].np; c->n = mans[p].n;
-		mans[nm++] = mans[p];
+		for (int g = 0; g < hit[p]; ++g) {
+			uint32_t a = w->pairs[p].a, b = w->pairs[p].b;
+			sgo_manifold m = mans[3 * p + g];
+			const int mesh_a = w->bodies[a].shape_type == SGP_SHAPE_MESH, mesh_b = w->bodies[b].shape_type == SGP_SHAPE_MESH;
+			if (mesh_a || mesh_b) {
+				/* the manifold runs mesh -> body; the constraint runs lower id -> higher id, with the mesh's g-th slot */
+				const uint32_t mid = (mesh_a ? a : b) + (uint32_t)g, xid = mesh_a ? b : a;
+				if (mid < xid) { a = mid; b = xid; } else { a = xid; b = mid; sgo_flip_manifold(&m); }
+			}
+			sgo_constraint* c = &w->cons[nm];
+			memset(c, 0, sizeof(*c));
+			c->a = a; c->b = b; c->key = ((uint64_t)a << 32) | b; c->prio = sgp_mix64(c->key);
+			c->np = m.np; c->n = m.n;
+			mans[nm++] = m;           /* (nm <= 3 p + g: compaction never overtakes the read position) */
+		}
 	}
 	free(hit);
 	w->n_cons = nm;
@@ -1478,7 +1537,7 @@ static void vehicles_pre_step(sgo_world* w, float dt)
 	float* bounds = (float*)malloc(sizeof(float) * 6 * (w->high ? w->high : 1));
 	for (uint32_t j = 0; j < w->high; ++j) {
 		const sgo_body* o = &w->bodies[j];
-		const int cand = o->alive && !o->is_sensor && (o->layer == SGP_LAYER_NON_MOVING || o->layer == SGP_LAYER_MOVING);   /* tester object layer MOVING, CarPhysics.cpp:62 */
+		const int cand = o->alive && !o->is_alias && o->shape_type != SGP_SHAPE_MESH && !o->is_sensor && (o->layer == SGP_LAYER_NON_MOVING || o->layer == SGP_LAYER_MOVING);   /* tester object layer MOVING, CarPhysics.cpp:62 */
 		float* bb = &bounds[6 * j];
 		if (cand) { bb[0] = o->aabb_min.x; bb[1] = o->aabb_min.y; bb[2] = o->aabb_min.z; bb[3] = o->aabb_max.x; bb[4] = o->aabb_max.y; bb[5] = o->aabb_max.z; }
 		else { bb[0] = bb[1] = bb[2] = 1.0f; bb[3] = bb[4] = bb[5] = -1.0f; }                          /* empty box: never overlaps */
@@ -1650,7 +1709,7 @@ SGO_API int sgo_world_step(sgo_world* w, float dt)
 	w->stats.num_bodies = w->n_alive;
 	for (uint32_t i = 0; i < w->high; ++i) {
 		const sgo_body* b = &w->bodies[i];
-		if (!b->alive) continue;
+		if (!b->alive || b->is_alias) continue;
 		if (b->active) w->stats.num_active++;
 		if (b->layer >= 0 && b->layer < SGP_NUM_LAYERS) w->stats.layer_counts[b->layer]++;
 	}
@@ -1836,6 +1895,50 @@ SGO_API int sgo_collide_pair(const sgp_body_desc* a, const sgp_body_desc* b, flo
 	return 1;
 }
 
+/* MeshShapeSettings::Create */
+SGO_API int sgo_mesh_create(sgo_world* w, const float* verts, uint32_t nv, const uint32_t* idx, uint32_t nt, sgp_mesh_info* info)
+{
+	if (!w || !verts || !idx || !info || nv < 3 || nt < 1) return SGP_ERR_INVALID;
+	for (uint32_t k = 0; k < 3 * nt; ++k) if (idx[k] >= nv) return SGP_ERR_INVALID;
+	for (uint32_t k = 0; k < 3 * nv; ++k) if (!isfinite(verts[k])) return SGP_ERR_INVALID;
+	sgo_mesh* m = (sgo_mesh*)calloc(1, sizeof(sgo_mesh));
+	m->nv = nv; m->nt = nt;
+	m->verts = (v3*)malloc(sizeof(v3) * nv); m->tris = (uint32_t*)malloc(sizeof(uint32_t) * 3 * nt);
+	memcpy(m->tris, idx, sizeof(uint32_t) * 3 * nt);
+	v3 mn = V3(3.4e38f, 3.4e38f, 3.4e38f), mx = V3(-3.4e38f, -3.4e38f, -3.4e38f); float br = 0.0f;
+	for (uint32_t k = 0; k < nv; ++k) { const v3 p = V3(verts[3 * k], verts[3 * k + 1], verts[3 * k + 2]); m->verts[k] = p; mn = v3_min(mn, p); mx = v3_max(mx, p); br = fmaxf(br, v3_len(p)); }
+	m->aabb_min = mn; m->aabb_max = mx; m->bound_radius = br;
+	if (w->n_meshes == w->cap_meshes) { w->cap_meshes *= 2; w->meshes = (sgo_mesh**)realloc(w->meshes, sizeof(sgo_mesh*) * w->cap_meshes); }
+	const uint32_t id = w->n_meshes++;
+	w->meshes[id] = m;
+	memset(info, 0, sizeof(*info));
+	info->mesh_id = id; info->num_vertices = nv; info->num_triangles = nt; info->num_nodes = 0;
+	info->aabb_min[0] = mn.x; info->aabb_min[1] = mn.y; info->aabb_min[2] = mn.z; info->aabb_max[0] = mx.x; info->aabb_max[1] = mx.y; info->aabb_max[2] = mx.z;
+	return SGP_OK;
+}
+
+/* Every triangle of mesh body M whose world bounds come within max_sep of the world bounds [lo,hi]; collides X with each in index
+   order and groups the manifolds (sgo_mesh.h).  Returns the number of groups; normals point from the mesh to X. */
+static int collide_with_mesh(const sgo_body* M, const sgo_shape* X, v3 lo, v3 hi, float max_sep, sgo_manifold* out)
+{
+	const m33 R = quat_to_m33(M->rot);
+	sgo_mesh_contacts mc; mc.ng = 0;
+	const v3 e = V3(max_sep, max_sep, max_sep);
+	const v3 qlo = v3_sub(lo, e), qhi = v3_add(hi, e);
+	for (uint32_t t = 0; t < M->mesh->nt; ++t) {
+		const v3 a = M->mesh->verts[M->mesh->tris[3 * t]], b = M->mesh->verts[M->mesh->tris[3 * t + 1]], c = M->mesh->verts[M->mesh->tris[3 * t + 2]];
+		const v3 wa = v3_add(M->pos, m33_mul(R, a)), wb = v3_add(M->pos, m33_mul(R, b)), wc = v3_add(M->pos, m33_mul(R, c));
+		const v3 tmin = v3_min(v3_min(wa, wb), wc), tmax = v3_max(v3_max(wa, wb), wc);
+		if (tmax.x < qlo.x || tmin.x > qhi.x || tmax.y < qlo.y || tmin.y > qhi.y || tmax.z < qlo.z || tmin.z > qhi.z) continue;
+		sgo_hull th; v3 cen, n;
+		sgo_tri_hull(a, b, c, &th, &cen, &n);
+		sgo_hview T; T.pos = v3_add(M->pos, m33_mul(R, cen)); T.R = R; T.scale = V3(1.0f, 1.0f, 1.0f); T.h = &th;
+		sgo_manifold m;
+		if (sgo_collide_tri(X, &T, m33_mul(R, n), max_sep, &m)) sgo_mesh_add(&mc, &m);
+	}
+	return sgo_mesh_finish(&mc, out);
+}
+
 /* ConvexHullShapeSettings::Create */
 SGO_API int sgo_hull_create_com(sgo_world* w, const float* pts, uint32_t n, const float* com_offset, sgp_hull_info* info)
 {
@@ -1918,17 +2021,19 @@ SGO_API int sgo_collide_capsules(sgo_world* w, const sgp_capsule_query* qs, uint
 		const v3 lo = v3_sub(sc.pos, ext), hi = v3_add(sc.pos, ext);
 		for (uint32_t j = 0; j < w->high; ++j) {
 			const sgo_body* b = &w->bodies[j];
-			if (!b->alive || j == q->ignore_id) continue;
+			if (!b->alive || b->is_alias || j == q->ignore_id) continue;
 			if (q->collidable_only && !(b->layer == SGP_LAYER_NON_MOVING || b->layer == SGP_LAYER_MOVING)) continue;
 			if (b->aabb_max.x < lo.x || b->aabb_min.x > hi.x || b->aabb_max.y < lo.y || b->aabb_min.y > hi.y || b->aabb_max.z < lo.z || b->aabb_min.z > hi.z) continue;
 			const sgo_shape sb = body_shape_xf(b);
-			sgo_manifold m;
-			if (!sgo_collide(&sb, &sc, q->max_separation, &m)) continue;        /* normal from the body to the capsule */
+			sgo_manifold mm[SGO_MESH_MAX_GROUPS]; int ng;
+			if (b->shape_type == SGP_SHAPE_MESH) ng = collide_with_mesh(b, &sc, lo, hi, q->max_separation, mm);
+			else ng = sgo_collide(&sb, &sc, q->max_separation, &mm[0]) ? 1 : 0;        /* normal from the body to the capsule */
+			for (int g = 0; g < ng; ++g) { const sgo_manifold m = mm[g];
 			for (int i = 0; i < m.np; ++i) {
 				if (cnt < cap) {
 					sgp_query_contact* c = &out[cnt];
 					memset(c, 0, sizeof(*c));
-					c->query = k; c->body = j; c->pad = (uint32_t)i;
+					c->query = k; c->body = j; c->pad = (uint32_t)(4 * g + i);
 					c->point[0] = m.p1[i].x; c->point[1] = m.p1[i].y; c->point[2] = m.p1[i].z;
 					c->normal[0] = m.n.x; c->normal[1] = m.n.y; c->normal[2] = m.n.z;
 					c->distance = v3_dot(v3_sub(m.p2[i], m.p1[i]), m.n);
@@ -1937,6 +2042,7 @@ SGO_API int sgo_collide_capsules(sgo_world* w, const sgp_capsule_query* qs, uint
 					c->motion_type = (uint32_t)b->motion; c->is_sensor = (uint32_t)b->is_sensor; c->inv_mass = b->inv_mass; c->userdata = b->userdata;
 				}
 				++cnt;
+			}
 			}
 		}
 	}
@@ -1954,7 +2060,7 @@ SGO_API int sgo_spherecast(sgo_world* w, const sgp_ray* rays, const float* radii
 		float best = rays[k].max_t; uint32_t bid = SGP_INVALID_ID; v3 bn = V3(0, 0, 0);
 		for (uint32_t i = 0; i < w->high; ++i) {
 			const sgo_body* b = &w->bodies[i];
-			if (!b->alive || i == rays[k].ignore_id || b->is_sensor) continue;
+			if (!b->alive || b->is_alias || b->shape_type == SGP_SHAPE_MESH || i == rays[k].ignore_id || b->is_sensor) continue;
 			if (rays[k].collidable_only && !(b->layer == SGP_LAYER_NON_MOVING || b->layer == SGP_LAYER_MOVING)) continue;
 			v3 nn, pp;
 			const float t = sgo_cast_sphere_body(b->shape_type, b->shape, b->hull, b->pos, quat_to_m33(b->rot), o, d, best, radii[k], &nn, &pp);
@@ -1972,6 +2078,18 @@ static float ray_body(const sgo_body* b, v3 o, v3 d, float max_t, v3* n_out)
 {
 	const m33 R = quat_to_m33(b->rot);
 	const v3 ol = m33_tmul(R, v3_sub(o, b->pos)), dl = m33_tmul(R, d);
+	if (b->shape_type == SGP_SHAPE_MESH) {
+		/* closest front-facing triangle; on equal distance the lower triangle index wins */
+		float best = max_t; int hit = 0; v3 bn = V3(0, 0, 0);
+		for (uint32_t t = 0; t < b->mesh->nt; ++t) {
+			const v3 pa = b->mesh->verts[b->mesh->tris[3 * t]], pb = b->mesh->verts[b->mesh->tris[3 * t + 1]], pc = b->mesh->verts[b->mesh->tris[3 * t + 2]];
+			const float tt = sgo_ray_tri(ol, dl, pa, pb, pc, best);
+			if (tt >= 0.0f && (tt < best || !hit)) { best = tt; hit = 1; const v3 nn = v3_cross(v3_sub(pb, pa), v3_sub(pc, pa)); bn = v3_scale(nn, 1.0f / v3_len(nn)); }
+		}
+		if (!hit) return -1.0f;
+		*n_out = m33_mul(R, bn);
+		return best;
+	}
 	if (b->shape_type == SGP_SHAPE_HULL) {
 		v3 nl;
 		const float t = sgo_ray_hull(b->hull, ol, dl, max_t, 0.0f, &nl);
@@ -2049,7 +2167,7 @@ SGO_API int sgo_raycast(sgo_world* w, const sgp_ray* rays, uint32_t n, sgp_hit* 
 		float best = rays[k].max_t; uint32_t bid = SGP_INVALID_ID; v3 bn = V3(0, 0, 0);
 		for (uint32_t i = 0; i < w->high; ++i) {
 			const sgo_body* b = &w->bodies[i];
-			if (!b->alive || i == rays[k].ignore_id) continue;
+			if (!b->alive || b->is_alias || i == rays[k].ignore_id) continue;
 			if (rays[k].collidable_only && !(b->layer == SGP_LAYER_NON_MOVING || b->layer == SGP_LAYER_MOVING)) continue;
 			v3 nn;
 			const float t = ray_body(b, o, d, best, &nn);

@@ -13,7 +13,7 @@ OK, ERR_INVALID, ERR_NO_DEVICE, ERR_CAPACITY, ERR_HIP, ERR_BAD_ID, ERR_REJECTED 
 MOTION_STATIC, MOTION_KINEMATIC, MOTION_DYNAMIC = 0, 1, 2
 LAYER_NON_MOVING, LAYER_MOVING, LAYER_NON_MOVING_NON_COLLIDABLE, LAYER_MOVING_NON_COLLIDABLE = 0, 1, 2, 3
 NUM_LAYERS = 4
-SHAPE_SPHERE, SHAPE_BOX, SHAPE_CAPSULE, SHAPE_HULL = 0, 1, 2, 3
+SHAPE_SPHERE, SHAPE_BOX, SHAPE_CAPSULE, SHAPE_HULL, SHAPE_MESH = 0, 1, 2, 3, 4
 INVALID_ID = 0xFFFFFFFF
 
 EVENT_ACTIVATED, EVENT_DEACTIVATED, EVENT_ENTERED_WATER, EVENT_CONTACT_ADDED, EVENT_CONTACT_PERSISTED = 0, 1, 2, 3, 4
@@ -164,6 +164,10 @@ class HullInfo(C.Structure):
                 ("volume", f32), ("unit_inertia", f32 * 3), ("aabb_min", f32 * 3), ("aabb_max", f32 * 3)]
 
 
+class MeshInfo(C.Structure):
+    _fields_ = [("mesh_id", u32), ("num_vertices", u32), ("num_triangles", u32), ("num_nodes", u32), ("aabb_min", f32 * 3), ("aabb_max", f32 * 3)]
+
+
 class CapsuleQuery(C.Structure):
     _fields_ = [("pos", f32 * 3), ("rot", f32 * 4), ("radius", f32), ("half_height", f32), ("max_separation", f32),
                 ("ignore_id", u32), ("collidable_only", u32)]
@@ -178,14 +182,14 @@ class QueryContact(C.Structure):
 ABI_SIZEOF_ORDER = ["sgp_settings", "sgp_world_desc", "sgp_body_desc", "sgp_body_state", "sgp_body_event",
                     "sgp_contact_event", "sgp_ray", "sgp_hit", "sgp_step_stats", "sgp_step_profile", "sgp_ghost_record",
                     "sgp_vehicle_desc", "sgp_vehicle_input", "sgp_vehicle_state", "sgp_hull_info",
-                    "sgp_capsule_query", "sgp_query_contact"]
+                    "sgp_capsule_query", "sgp_query_contact", "sgp_mesh_info"]
 
 STRUCTS = {"sgp_settings": Settings, "sgp_world_desc": WorldDesc, "sgp_body_desc": BodyDesc,
            "sgp_body_state": BodyState, "sgp_body_event": BodyEvent, "sgp_contact_event": ContactEvent,
            "sgp_ray": Ray, "sgp_hit": Hit, "sgp_step_stats": StepStats, "sgp_step_profile": StepProfile,
            "sgp_ghost_record": GhostRecord, "sgp_vehicle_desc": VehicleDesc, "sgp_vehicle_input": VehicleInput,
            "sgp_vehicle_state": VehicleState, "sgp_hull_info": HullInfo, "sgp_capsule_query": CapsuleQuery,
-           "sgp_query_contact": QueryContact}
+           "sgp_query_contact": QueryContact, "sgp_mesh_info": MeshInfo}
 
 body_desc_dtype = np.dtype(BodyDesc)
 body_state_dtype = np.dtype(BodyState)
@@ -251,6 +255,7 @@ PROTOTYPES = {
     "world_import_ghosts": (C.c_int, [vp, vp, u32]),
     "world_device_array": (C.c_int, [vp, C.c_int, P(vp), P(u32)]),
     "world_stream": (C.c_int, [vp, P(vp)]),
+    "mesh_create": (C.c_int, [vp, vp, u32, vp, u32, P(MeshInfo)]),
     "hull_create": (C.c_int, [vp, vp, u32, P(HullInfo)]),
     "hull_create_com": (C.c_int, [vp, vp, u32, P(f32), P(HullInfo)]),
     "default_vehicle_desc": (None, [P(VehicleDesc)]),

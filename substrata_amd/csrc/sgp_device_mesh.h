@@ -1,0 +1,98 @@
+// sgp_device_mesh.h -- gfx950 static triangle meshes: per-triangle collision (a triangle is a thin 3-vertex hull), grouping of the
+// triangle manifolds of one body pair by normal (<= 3 groups, <= 4 points each), ray - triangle (device code only).
+//
+// Role of JPH::MeshShape / HeightFieldShape in CollideShape / CastRay for Substrata's static meshes and terrain
+// (/root/reference/gui_client/PhysicsWorld.cpp:735-1166 with is_dynamic = false, :1020-1120; TerrainSystem.cpp:1300).
+// Included after sgp_device_collide.h.  Regenerate with tools/derive_device_vehicle.py.
+#pragma once
+#include "sgp_device_collide.h"
+
+#define SGD_MESH_MAX_GROUPS 3
+#define SGD_MESH_GROUP_COS 0.95f
+
+// the thin hull of one triangle; vertices relative to the centroid (mesh frame)
+SGP_DEV static void sgd_tri_hull(v3 a, v3 b, v3 c, sgd_hull* h, v3* centroid_out, v3* normal_out)
+{
+	const v3 cen = v3_scale(v3_add(v3_add(a, b), c), 1.0f / 3.0f);
+	v3 n = v3_cross(v3_sub(b, a), v3_sub(c, a));
+	const float l = v3_len(n);
+	n = l > 1.0e-20f ? v3_scale(n, 1.0f / l) : V3(0.0f, 0.0f, 1.0f);
+	h->nv = 3; h->nf = 2; h->ne = 3; h->is_box_template = 0;
+	h->verts[0] = v3_sub(a, cen); h->verts[1] = v3_sub(b, cen); h->verts[2] = v3_sub(c, cen);
+	h->normals[0] = n; h->plane_d[0] = v3_dot(n, h->verts[0]);
+	h->normals[1] = v3_neg(n); h->plane_d[1] = -h->plane_d[0];
+	h->face_start[0] = 0; h->face_start[1] = 3; h->face_start[2] = 6;
+	h->face_idx[0] = 0; h->face_idx[1] = 1; h->face_idx[2] = 2;          // counter-clockwise seen from +n
+	h->face_idx[3] = 0; h->face_idx[4] = 2; h->face_idx[5] = 1;
+	h->edge_a[0] = 0; h->edge_b[0] = 1; h->edge_a[1] = 1; h->edge_b[1] = 2; h->edge_a[2] = 0; h->edge_b[2] = 2;
+	*centroid_out = cen; *normal_out = n;
+}
+
+struct sgd_mesh_group { v3 n; int np; v3 p_mesh[SGD_HULL_CLIP_CAP]; v3 p_body[SGD_HULL_CLIP_CAP]; };
+struct sgd_mesh_contacts { int ng; sgd_mesh_group g[SGD_MESH_MAX_GROUPS]; };
+
+// m: manifold of one triangle, normal from the triangle to the body, p1 on the triangle, p2 on the body
+SGP_DEV static void sgd_mesh_add(sgd_mesh_contacts* mc, const sgd_manifold* m)
+{
+	int gi = -1;
+	for (int k = 0; k < mc->ng; ++k) if (v3_dot(mc->g[k].n, m->n) >= SGD_MESH_GROUP_COS) { gi = k; break; }
+	if (gi < 0) {
+		if (mc->ng == SGD_MESH_MAX_GROUPS) return;
+		gi = mc->ng++;
+		mc->g[gi].n = m->n; mc->g[gi].np = 0;
+	}
+	sgd_mesh_group* g = &mc->g[gi];
+	for (int i = 0; i < m->np; ++i) {
+		if (g->np == SGD_HULL_CLIP_CAP) break;
+		// the same point reached through two triangles that share it (an edge or a vertex of the mesh) counts once
+		int dup = 0;
+		for (int j = 0; j < g->np; ++j) if (v3_len_sq(v3_sub(g->p_body[j], m->p2[i])) < 1.0e-8f) { dup = 1; break; }
+		if (dup) continue;
+		g->p_mesh[g->np] = m->p1[i]; g->p_body[g->np] = m->p2[i]; g->np++;
+	}
+}
+
+// X against one triangle (world-space view T of its thin hull, world normal nt).  Normal of the result: triangle -> X.
+SGP_DEV static int sgd_collide_tri(const sgd_shape* X, const sgd_hview* T, v3 nt, float max_sep, sgd_manifold* m)
+{
+	int hit;
+	if (X->type == SGD_SHAPE_SPHERE) hit = sgd_hull_sphere(T, X->pos, X->p0, max_sep, m);
+	else if (X->type == SGD_SHAPE_CAPSULE) {
+		const v3 ax = v3_scale(m33_col(X->R, 2), X->p1);
+		hit = sgd_hull_capsule(T, v3_sub(X->pos, ax), v3_add(X->pos, ax), X->p0, max_sep, m);
+	} else {
+		sgd_hview hx;
+		hx.pos = X->pos; hx.R = X->R; hx.h = X->hull;
+		hx.scale = X->type == SGD_SHAPE_BOX ? V3(X->p0, X->p1, X->p2) : V3(1.0f, 1.0f, 1.0f);
+		hit = sgd_hull_hull(T, &hx, max_sep, m);
+	}
+	if (!hit) return 0;
+	if (v3_dot(m->n, nt) < 0.0f) return 0;                   // reached from the back side
+	return 1;
+}
+
+// the groups as manifolds (normal mesh -> body, p1 on the mesh, p2 on the body), each pruned to <= 4 points
+SGP_DEV static int sgd_mesh_finish(const sgd_mesh_contacts* mc, sgd_manifold* out)
+{
+	for (int k = 0; k < mc->ng; ++k) sgd_hull_reduce(mc->g[k].n, mc->g[k].p_mesh, mc->g[k].p_body, mc->g[k].np, &out[k]);
+	return mc->ng;
+}
+
+// ray against one triangle (Moeller-Trumbore, front face only): t or -1
+SGP_DEV static float sgd_ray_tri(v3 o, v3 d, v3 a, v3 b, v3 c, float max_t)
+{
+	const v3 e1 = v3_sub(b, a), e2 = v3_sub(c, a);
+	const v3 pv = v3_cross(d, e2);
+	const float det = v3_dot(e1, pv);
+	if (det < 1.0e-12f) return -1.0f;                          // parallel or hitting the back face
+	const v3 tv = v3_sub(o, a);
+	const float u = v3_dot(tv, pv);
+	if (u < 0.0f || u > det) return -1.0f;
+	const v3 qv = v3_cross(tv, e1);
+	const float vv = v3_dot(d, qv);
+	if (vv < 0.0f || u + vv > det) return -1.0f;
+	const float t = v3_dot(e2, qv) / det;
+	if (t < 0.0f || t > max_t) return -1.0f;
+	return t;
+}
+

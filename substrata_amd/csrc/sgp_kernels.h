@@ -19,8 +19,9 @@
 #define BF_LARGE         (1u << 9)   // skips the hashed grid (ground quad etc.)
 #define BF_UNDERWATER    (1u << 10)
 #define BF_GHOST         (1u << 11)  // owned by another tile (multi-GPU), simulated as velocity-driven
-#define BF_SHAPE_SHIFT   12
-#define BF_SHAPE_MASK    (0x3u << BF_SHAPE_SHIFT)
+#define BF_SHAPE_SHIFT   18          // SGP_SHAPE_* (3 bits)
+#define BF_SHAPE_MASK    (0x7u << BF_SHAPE_SHIFT)
+#define BF_ALIAS         (1u << 21)  // second / third slot of a static mesh body: carries contact manifolds only (never binned, never queried)
 #define BF_WAKE          (1u << 14)  // scratch: touched by an active body this step
 #define BF_CAN_SLEEP     (1u << 15)  // scratch: sleep test result
 #define BF_MOVABLE_PREV  (1u << 16)  // movable (dynamic and awake) when the PREVIOUS step coloured its constraints
@@ -45,6 +46,12 @@ struct BpGrid {
 	uint32_t n_cells;
 };
 
+// One static triangle mesh in the pools.
+struct MeshHeader { uint32_t vert_off, nv, tri_off, nt, node_off, n_nodes; float mnx, mny, mnz, mxx, mxy, mxz; };
+// Node of a mesh's bounding-volume tree (node 0 = root).  Inner node (count == 0): children `left`, `right`.  Leaf: triangles
+// [left, left + count) of the mesh's tree-ordered triangle array (uint4.w of a triangle = its index in the caller's order).
+struct MeshNode { float mnx, mny, mnz; uint32_t left; float mxx, mxy, mxz; uint32_t right; uint32_t count; uint32_t pad[3]; };
+
 // Device-side counters of one step (read back once per step).
 struct StepCounters {
 	uint32_t n_pairs;
@@ -60,7 +67,7 @@ struct StepCounters {
 	uint32_t n_active;
 	uint32_t n_read_active;
 	uint32_t n_export;
-	uint32_t pad0;
+	uint32_t n_mesh_pairs;       // pairs with a static mesh, deferred to k_narrowphase_mesh
 	uint32_t colour_count[SGP_MAX_COLOURS];
 	uint32_t colour_fill[SGP_MAX_COLOURS];
 };
@@ -189,6 +196,10 @@ struct DV {
 	// convex hull shapes (sgp_device_hull.h): fixed-capacity table, hull 0 = the +-1 cube template every box is a scaled copy of
 	const struct sgd_hull_s* hulls; uint32_t n_hulls;
 	uint2* hull_pairs; uint32_t cap_hull_pairs;
+	// static triangle meshes: headers + pooled vertices / triangles / tree nodes (mesh frame = body frame)
+	const struct MeshHeader* meshes; uint32_t n_meshes;
+	const float4* mesh_verts; const uint4* mesh_tris; const struct MeshNode* mesh_nodes;
+	uint2* mesh_pairs; uint32_t cap_mesh_pairs;
 	// wheeled vehicles (sgp_device_vehicle.h): AoS, one record per vehicle slot
 	struct sgd_vehicle* vehicles; uint32_t n_vehicles; const sgp_vehicle_input* vehicle_inputs;
 	// settings (fixed after world creation)
@@ -212,6 +223,8 @@ void launch_bp_pairs(const DV& d, hipStream_t s);
 void launch_bp_large(const DV& d, uint32_t nb, hipStream_t s);
 void launch_narrowphase(const DV& d, uint32_t n_pairs_upper, hipStream_t s);
 void launch_narrowphase_hull(const DV& d, hipStream_t s);     // only worlds with hull shapes
+void launch_narrowphase_mesh(const DV& d, hipStream_t s);     // only worlds with mesh shapes
+#define SGP_MAX_MESHES 1024
 #define SGP_MAX_HULLS 256
 void launch_wake(const DV& d, uint32_t nb, hipStream_t s);
 void launch_prep_bodies(const DV& d, uint32_t nb, hipStream_t s);

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include "sgp_device_collide.h"
 #include "sgp_device_vehicle.h"
+#include "sgp_device_mesh.h"
 
 #define TPB 256
 
@@ -41,6 +42,7 @@ SGP_DEV const sgd_hull* body_hull(const DV& d, float4 sh) { return &d.hulls[(uin
 
 SGP_DEV v3 shape_local_half(const DV& d, uint32_t type, float4 sh)
 {
+	if (type == SGP_SHAPE_MESH) return V3(1.0f, 1.0f, 1.0f);        // (static: never asked for sleep points)
 	if (type == SGP_SHAPE_HULL) {
 		const sgd_hull* h = body_hull(d, sh);
 		return V3(fmaxf(fabsf(h->aabb_min.x), fabsf(h->aabb_max.x)), fmaxf(fabsf(h->aabb_min.y), fabsf(h->aabb_max.y)), fmaxf(fabsf(h->aabb_min.z), fabsf(h->aabb_max.z)));
@@ -52,6 +54,7 @@ SGP_DEV v3 shape_local_half(const DV& d, uint32_t type, float4 sh)
 
 SGP_DEV float shape_volume(const DV& d, uint32_t type, float4 sh)
 {
+	if (type == SGP_SHAPE_MESH) return 0.0f;
 	if (type == SGP_SHAPE_HULL) return body_hull(d, sh)->volume;
 	if (type == SGP_SHAPE_SPHERE) return (4.0f / 3.0f) * 3.14159265358979323846f * sh.x * sh.x * sh.x;
 	if (type == SGP_SHAPE_BOX) return 8.0f * sh.x * sh.y * sh.z;
@@ -61,6 +64,18 @@ SGP_DEV float shape_volume(const DV& d, uint32_t type, float4 sh)
 SGP_DEV void compute_aabb(const DV& d, uint32_t type, float4 sh, v3 pos, quat q, v3& mn, v3& mx)
 {
 	v3 e;
+	if (type == SGP_SHAPE_MESH) {
+		const MeshHeader mh = d.meshes[(uint32_t)sh.x];
+		const m33 R = quat_to_m33(q);
+		v3 lo = V3(3.4e38f, 3.4e38f, 3.4e38f), hi = V3(-3.4e38f, -3.4e38f, -3.4e38f);
+		for (int k = 0; k < 8; ++k) {
+			const v3 c = V3((k & 1) ? mh.mxx : mh.mnx, (k & 2) ? mh.mxy : mh.mny, (k & 4) ? mh.mxz : mh.mnz);
+			const v3 p = m33_mul(R, c);
+			lo = V3(fminf(lo.x, p.x), fminf(lo.y, p.y), fminf(lo.z, p.z)); hi = V3(fmaxf(hi.x, p.x), fmaxf(hi.y, p.y), fmaxf(hi.z, p.z));
+		}
+		mn = v3_add(pos, lo); mx = v3_add(pos, hi);
+		return;
+	}
 	if (type == SGP_SHAPE_HULL) {
 		const sgd_hull* h = body_hull(d, sh);
 		const m33 R = quat_to_m33(q);
@@ -584,6 +599,11 @@ __global__ void __launch_bounds__(TPB) k_narrowphase(DV d)
 	for (uint32_t p = blockIdx.x * TPB + threadIdx.x; p < n; p += gridDim.x * TPB) {
 		const uint2 ab = d.pairs[p];
 		const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
+		if (f_shape(fa) == SGP_SHAPE_MESH || f_shape(fb) == SGP_SHAPE_MESH) {
+			const uint32_t k = atomicAdd(&d.ctr->n_mesh_pairs, 1u);
+			if (k < d.cap_mesh_pairs) d.mesh_pairs[k] = ab; else atomicAdd(&d.ctr->pairs_dropped, 1u);
+			continue;
+		}
 		if (f_shape(fa) == SGP_SHAPE_HULL || f_shape(fb) == SGP_SHAPE_HULL) {
 			// the polytope paths (clip buffers in scratch, long loops) live in their own kernel so that they do not cost the
 			// sphere / box / capsule pairs registers or scratch
@@ -595,6 +615,98 @@ __global__ void __launch_bounds__(TPB) k_narrowphase(DV d)
 		sgd_manifold m;
 		if (!sgd_collide(&sa, &sb, d.st.speculative_contact_distance, &m)) continue;
 		emit_manifold(d, ab, fa, fb, m);
+	}
+}
+
+// ---- static triangle meshes ----------------------------------------------------------------------------------------
+#define MESH_CAND_CAP 192
+
+// Triangles of mesh body M (header mh, pose pos / R) whose tree leaves overlap the mesh-local box [llo, lhi]: indices (caller's order)
+// into cand[], ascending.  Returns the count (capped; *overflow set).
+SGP_DEV int mesh_candidates(const DV& d, const MeshHeader& mh, v3 llo, v3 lhi, uint32_t* cand, bool* overflow)
+{
+	int n = 0; *overflow = false;
+	uint32_t stack[48]; int sp = 0;
+	stack[sp++] = 0;
+	while (sp > 0) {
+		const MeshNode nd = d.mesh_nodes[mh.node_off + stack[--sp]];
+		if (nd.mxx < llo.x || nd.mnx > lhi.x || nd.mxy < llo.y || nd.mny > lhi.y || nd.mxz < llo.z || nd.mnz > lhi.z) continue;
+		if (nd.count == 0) { if (sp + 2 <= 48) { stack[sp++] = nd.left; stack[sp++] = nd.right; } else *overflow = true; continue; }
+		for (uint32_t k = 0; k < nd.count; ++k) {
+			if (n == MESH_CAND_CAP) { *overflow = true; break; }
+			cand[n++] = nd.left + k;                     // position in the tree-ordered triangle array
+		}
+	}
+	// order by the triangle's index in the caller's order (what the sequential reference walks): insertion sort on (orig, pos)
+	for (int i = 1; i < n; ++i) {
+		const uint32_t pos = cand[i]; const uint32_t key = d.mesh_tris[mh.tri_off + pos].w;
+		int j = i - 1;
+		while (j >= 0 && d.mesh_tris[mh.tri_off + cand[j]].w > key) { cand[j + 1] = cand[j]; --j; }
+		cand[j + 1] = pos;
+	}
+	return n;
+}
+
+// X against mesh body M: every triangle whose world bounds come within max_sep of [lo, hi], in index order, manifolds grouped by normal.
+// Returns the number of groups (manifolds mesh -> X).  Sequential (one thread).
+SGP_DEV int collide_with_mesh(const DV& d, uint32_t mbody, const sgd_shape& X, v3 lo, v3 hi, float max_sep, sgd_manifold* out, bool* dropped)
+{
+	const float4 msh = d.shape[mbody];
+	const MeshHeader mh = d.meshes[(uint32_t)msh.x];
+	const v3 mpos = V3(d.pos_im[mbody]); const m33 R = quat_to_m33(Q4(d.rot[mbody]));
+	const v3 e = V3(max_sep, max_sep, max_sep);
+	const v3 qlo = v3_sub(lo, e), qhi = v3_add(hi, e);
+	// the query box in the mesh frame (bounds of its 8 corners), a little generous
+	v3 llo = V3(3.4e38f, 3.4e38f, 3.4e38f), lhi = V3(-3.4e38f, -3.4e38f, -3.4e38f);
+	for (int k = 0; k < 8; ++k) {
+		const v3 c = V3((k & 1) ? qhi.x : qlo.x, (k & 2) ? qhi.y : qlo.y, (k & 4) ? qhi.z : qlo.z);
+		const v3 l = m33_tmul(R, v3_sub(c, mpos));
+		llo = V3(fminf(llo.x, l.x), fminf(llo.y, l.y), fminf(llo.z, l.z)); lhi = V3(fmaxf(lhi.x, l.x), fmaxf(lhi.y, l.y), fmaxf(lhi.z, l.z));
+	}
+	const float pad = 1.0e-4f * (1.0f + fabsf(llo.x) + fabsf(llo.y) + fabsf(llo.z) + fabsf(lhi.x) + fabsf(lhi.y) + fabsf(lhi.z));
+	llo = v3_sub(llo, V3(pad, pad, pad)); lhi = v3_add(lhi, V3(pad, pad, pad));
+	uint32_t cand[MESH_CAND_CAP];
+	const int nc = mesh_candidates(d, mh, llo, lhi, cand, dropped);
+	sgd_mesh_contacts mc; mc.ng = 0;
+	for (int k = 0; k < nc; ++k) {
+		const uint4 tri = d.mesh_tris[mh.tri_off + cand[k]];
+		const v3 a = V3(d.mesh_verts[mh.vert_off + tri.x]), b = V3(d.mesh_verts[mh.vert_off + tri.y]), c = V3(d.mesh_verts[mh.vert_off + tri.z]);
+		const v3 wa = v3_add(mpos, m33_mul(R, a)), wb = v3_add(mpos, m33_mul(R, b)), wc = v3_add(mpos, m33_mul(R, c));
+		const v3 tmin = V3(fminf(fminf(wa.x, wb.x), wc.x), fminf(fminf(wa.y, wb.y), wc.y), fminf(fminf(wa.z, wb.z), wc.z));
+		const v3 tmax = V3(fmaxf(fmaxf(wa.x, wb.x), wc.x), fmaxf(fmaxf(wa.y, wb.y), wc.y), fmaxf(fmaxf(wa.z, wb.z), wc.z));
+		if (tmax.x < qlo.x || tmin.x > qhi.x || tmax.y < qlo.y || tmin.y > qhi.y || tmax.z < qlo.z || tmin.z > qhi.z) continue;
+		sgd_hull th; v3 cen, n;
+		sgd_tri_hull(a, b, c, &th, &cen, &n);
+		sgd_hview T; T.pos = v3_add(mpos, m33_mul(R, cen)); T.R = R; T.scale = V3(1.0f, 1.0f, 1.0f); T.h = &th;
+		sgd_manifold m;
+		if (sgd_collide_tri(&X, &T, m33_mul(R, n), max_sep, &m)) sgd_mesh_add(&mc, &m);
+	}
+	return sgd_mesh_finish(&mc, out);
+}
+
+// pairs with a static mesh: one thread per pair (sequential walk in triangle-index order, as the reference)
+__global__ void __launch_bounds__(64) k_narrowphase_mesh(DV d)
+{
+	const uint32_t n = min(d.ctr->n_mesh_pairs, d.cap_mesh_pairs);
+	for (uint32_t p = blockIdx.x * 64 + threadIdx.x; p < n; p += gridDim.x * 64) {
+		const uint2 ab = d.mesh_pairs[p];
+		const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
+		const bool mesh_a = f_shape(fa) == SGP_SHAPE_MESH, mesh_b = f_shape(fb) == SGP_SHAPE_MESH;
+		if (mesh_a && mesh_b) continue;
+		const uint32_t mid = mesh_a ? ab.x : ab.y, xid = mesh_a ? ab.y : ab.x;
+		const uint32_t fx = mesh_a ? fb : fa;
+		const sgd_shape sx = load_shape(d, xid, fx);
+		sgd_manifold mm[SGD_MESH_MAX_GROUPS]; bool dropped = false;
+		const int ng = collide_with_mesh(d, mid, sx, V3(d.aabb_min[xid]), V3(d.aabb_max[xid]), d.st.speculative_contact_distance, mm, &dropped);
+		if (dropped) atomicAdd(&d.ctr->manifolds_dropped, 1u);
+		for (int g = 0; g < ng; ++g) {
+			// the manifold runs mesh -> body; the constraint runs lower id -> higher id, with the mesh's g-th slot
+			const uint32_t alias = mid + (uint32_t)g;
+			sgd_manifold m = mm[g];
+			uint2 key;
+			if (alias < xid) key = make_uint2(alias, xid); else { key = make_uint2(xid, alias); sgd_flip_manifold(&m); }
+			emit_manifold(d, key, d.flags[key.x], d.flags[key.y], m);
+		}
 	}
 }
 
@@ -1794,6 +1906,40 @@ SGP_DEV float ray_body(const DV& d, uint32_t type, float4 sh, v3 pos, quat q, v3
 {
 	const m33 R = quat_to_m33(q);
 	const v3 ol = m33_tmul(R, v3_sub(o, pos)), dl = m33_tmul(R, dir);
+	if (type == SGP_SHAPE_MESH) {
+		// closest front-facing triangle; on equal distance the lower triangle index (caller's order) wins
+		const MeshHeader mh = d.meshes[(uint32_t)sh.x];
+		float best = max_t; uint32_t best_idx = 0xFFFFFFFFu; v3 bn = V3(0.0f, 0.0f, 0.0f);
+		const v3 inv = V3(fabsf(dl.x) > 1.0e-12f ? 1.0f / dl.x : 3.0e38f, fabsf(dl.y) > 1.0e-12f ? 1.0f / dl.y : 3.0e38f, fabsf(dl.z) > 1.0e-12f ? 1.0f / dl.z : 3.0e38f);
+		uint32_t stack[48]; int sp = 0;
+		stack[sp++] = 0;
+		while (sp > 0) {
+			const MeshNode nd = d.mesh_nodes[mh.node_off + stack[--sp]];
+			// slab test against the node box grown a little (never rejects a triangle the exact test would accept)
+			const float g = 1.0e-4f * (1.0f + fabsf(nd.mxx) + fabsf(nd.mxy) + fabsf(nd.mxz) + fabsf(nd.mnx) + fabsf(nd.mny) + fabsf(nd.mnz));
+			float t0 = 0.0f, t1 = best; bool miss = false;
+			const float lo3[3] = { nd.mnx - g, nd.mny - g, nd.mnz - g }, hi3[3] = { nd.mxx + g, nd.mxy + g, nd.mxz + g };
+			const float o3[3] = { ol.x, ol.y, ol.z }, d3[3] = { dl.x, dl.y, dl.z }, i3[3] = { inv.x, inv.y, inv.z };
+			for (int a = 0; a < 3 && !miss; ++a) {
+				if (fabsf(d3[a]) <= 1.0e-12f) { if (o3[a] < lo3[a] || o3[a] > hi3[a]) miss = true; }
+				else { float ta = (lo3[a] - o3[a]) * i3[a], tb = (hi3[a] - o3[a]) * i3[a]; if (ta > tb) { const float tmp = ta; ta = tb; tb = tmp; } t0 = fmaxf(t0, ta - g); t1 = fminf(t1, tb + g); if (t0 > t1) miss = true; }
+			}
+			if (miss) continue;
+			if (nd.count == 0) { if (sp + 2 <= 48) { stack[sp++] = nd.left; stack[sp++] = nd.right; } continue; }
+			for (uint32_t k = 0; k < nd.count; ++k) {
+				const uint4 tri = d.mesh_tris[mh.tri_off + nd.left + k];
+				const v3 pa = V3(d.mesh_verts[mh.vert_off + tri.x]), pb = V3(d.mesh_verts[mh.vert_off + tri.y]), pc = V3(d.mesh_verts[mh.vert_off + tri.z]);
+				const float tt = sgd_ray_tri(ol, dl, pa, pb, pc, best);
+				if (tt >= 0.0f && (tt < best || best_idx == 0xFFFFFFFFu || (tt == best && tri.w < best_idx))) {
+					best = tt; best_idx = tri.w;
+					const v3 nn = v3_cross(v3_sub(pb, pa), v3_sub(pc, pa)); bn = v3_scale(nn, 1.0f / v3_len(nn));
+				}
+			}
+		}
+		if (best_idx == 0xFFFFFFFFu) return -1.0f;
+		*n_out = m33_mul(R, bn);
+		return best;
+	}
 	if (type == SGP_SHAPE_HULL) {
 		v3 nl;
 		const float t = sgd_ray_hull(body_hull(d, sh), ol, dl, max_t, 0.0f, &nl);
@@ -1885,7 +2031,7 @@ SGP_DEV void ray_test_body(const DV& d, const sgp_ray& ry, v3 o, v3 dir, uint32_
 {
 	if (i == ry.ignore_id) return;
 	const uint32_t f = d.flags[i];
-	if (!(f & BF_ALIVE)) return;
+	if (!(f & BF_ALIVE) || (f & BF_ALIAS)) return;
 	const uint32_t layer = f_layer(f);
 	if (ry.collidable_only && !(layer == SGP_LAYER_NON_MOVING || layer == SGP_LAYER_MOVING)) return;
 	if (!ray_aabb(o, dir, d.aabb_min[i], d.aabb_max[i], best.t)) return;
@@ -1971,7 +2117,7 @@ SGP_DEV void veh_cast_test(const DV& d, const sgd_vehicle* v, v3 o, v3 dir, floa
 {
 	if (j == v->body) return;
 	const uint32_t f = d.flags[j];
-	if (!(f & BF_ALIVE) || (f & BF_SENSOR)) return;
+	if (!(f & BF_ALIVE) || (f & (BF_SENSOR | BF_ALIAS)) || f_shape(f) == SGP_SHAPE_MESH) return;
 	const uint32_t layer = f_layer(f);
 	if (!(layer == SGP_LAYER_NON_MOVING || layer == SGP_LAYER_MOVING)) return;            // tester object layer MOVING, CarPhysics.cpp:62
 	const float4 mn = d.aabb_min[j], mx = d.aabb_max[j];
@@ -2127,20 +2273,21 @@ SGP_DEV void capsule_query_body(const DV& d, const sgp_capsule_query& q, uint32_
 {
 	if (j == q.ignore_id) return;
 	const uint32_t f = d.flags[j];
-	if (!(f & BF_ALIVE)) return;
+	if (!(f & BF_ALIVE) || (f & BF_ALIAS)) return;
 	const uint32_t layer = f_layer(f);
 	if (q.collidable_only && !(layer == SGP_LAYER_NON_MOVING || layer == SGP_LAYER_MOVING)) return;
 	const float4 mn = d.aabb_min[j], mx = d.aabb_max[j];
 	if (mx.x < lo.x || mn.x > hi.x || mx.y < lo.y || mn.y > hi.y || mx.z < lo.z || mn.z > hi.z) return;
 	const sgd_shape sb = load_shape(d, j, f);
-	sgd_manifold m;
-	const int hit = sb.type == SGP_SHAPE_HULL ? sgd_collide_hull(&sb, &sc, q.max_separation, &m) : sgd_collide(&sb, &sc, q.max_separation, &m);   // normal: body -> capsule
-	if (!hit) return;
+	sgd_manifold mm[SGD_MESH_MAX_GROUPS]; int ng; bool dropped = false;
+	if (sb.type == SGP_SHAPE_MESH) ng = collide_with_mesh(d, j, sc, lo, hi, q.max_separation, mm, &dropped);
+	else ng = (sb.type == SGP_SHAPE_HULL ? sgd_collide_hull(&sb, &sc, q.max_separation, &mm[0]) : sgd_collide(&sb, &sc, q.max_separation, &mm[0])) ? 1 : 0;   // normal: body -> capsule
+	for (int g = 0; g < ng; ++g) { const sgd_manifold& m = mm[g];
 	for (int i = 0; i < m.np; ++i) {
 		const uint32_t slot = atomicAdd(count, 1u);
 		if (slot >= cap) continue;
 		sgp_query_contact c;
-		c.query = k; c.body = j; c.pad = (uint32_t)i;
+		c.query = k; c.body = j; c.pad = (uint32_t)(4 * g + i);
 		c.point[0] = m.p1[i].x; c.point[1] = m.p1[i].y; c.point[2] = m.p1[i].z;
 		c.normal[0] = m.n.x; c.normal[1] = m.n.y; c.normal[2] = m.n.z;
 		c.distance = v3_dot(v3_sub(m.p2[i], m.p1[i]), m.n);
@@ -2149,6 +2296,7 @@ SGP_DEV void capsule_query_body(const DV& d, const sgp_capsule_query& q, uint32_
 		c.point_velocity[0] = pv.x; c.point_velocity[1] = pv.y; c.point_velocity[2] = pv.z;
 		c.motion_type = f_motion(f); c.is_sensor = (f & BF_SENSOR) ? 1u : 0u; c.inv_mass = d.pos_im[j].w; c.userdata = 0;
 		out[slot] = c;
+	}
 	}
 }
 
@@ -2184,7 +2332,7 @@ SGP_DEV void spherecast_body(const DV& d, const sgp_ray& ry, float rs, v3 o, v3 
 {
 	if (j == ry.ignore_id) return;
 	const uint32_t f = d.flags[j];
-	if (!(f & BF_ALIVE) || (f & BF_SENSOR)) return;
+	if (!(f & BF_ALIVE) || (f & (BF_SENSOR | BF_ALIAS)) || f_shape(f) == SGP_SHAPE_MESH) return;
 	const uint32_t layer = f_layer(f);
 	if (ry.collidable_only && !(layer == SGP_LAYER_NON_MOVING || layer == SGP_LAYER_MOVING)) return;
 	const float4 mn = d.aabb_min[j], mx = d.aabb_max[j];
@@ -2295,6 +2443,7 @@ void launch_bp_pairs(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_bp_pairs
 void launch_bp_large(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_bp_large, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_narrowphase(const DV& d, uint32_t est, hipStream_t s) { hipLaunchKernelGGL(k_narrowphase, dim3(stride_grid(est)), dim3(TPB), 0, s, d); }
 void launch_narrowphase_hull(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_narrowphase_hull, dim3(4096), dim3(64), 0, s, d); }
+void launch_narrowphase_mesh(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_narrowphase_mesh, dim3(1024), dim3(64), 0, s, d); }
 void launch_wake(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_wake, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_prep_bodies(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_prep_bodies, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_colour_inherit(const DV& d, uint32_t est, hipStream_t s) { hipLaunchKernelGGL(k_colour_inherit, dim3(stride_grid(est)), dim3(TPB), 0, s, d); }

@@ -82,6 +82,10 @@ struct sgp_world {
 	std::string last_plan_key; uint32_t plan_repeats = 0; bool use_graphs = true; bool use_small_world = true;
 	uint32_t graph_launches = 0, eager_steps = 0, idle_steps = 0;
 	bool grid_valid = false;                                   // the broad-phase grid matches the current poses (ray queries reuse it)
+	// static triangle meshes: host-side headers + pools mirrored on the device (grown on demand)
+	std::vector<MeshHeader> meshes; std::vector<float4> mesh_verts; std::vector<uint4> mesh_tris; std::vector<MeshNode> mesh_nodes;
+	MeshHeader* d_meshes = nullptr; float4* d_mesh_verts = nullptr; uint4* d_mesh_tris = nullptr; MeshNode* d_mesh_nodes = nullptr;
+	size_t cap_mesh_verts = 0, cap_mesh_tris = 0, cap_mesh_nodes = 0;
 	// convex hull shapes: host copies of the device table (mass properties, radii) -- hull 0 is the +-1 cube template
 	std::vector<sgd_hull> hulls; sgd_hull* d_hulls = nullptr;
 	// wheeled vehicles: device records (AoS) + host mirror of what the ABI needs without a read-back
@@ -193,7 +197,7 @@ SGP_API int sgp_abi_sizeof(int which)
 	case 6: return (int)sizeof(sgp_ray); case 7: return (int)sizeof(sgp_hit); case 8: return (int)sizeof(sgp_step_stats);
 	case 9: return (int)sizeof(sgp_step_profile); case 10: return (int)sizeof(sgp_ghost_record);
 	case 11: return (int)sizeof(sgp_vehicle_desc); case 12: return (int)sizeof(sgp_vehicle_input); case 13: return (int)sizeof(sgp_vehicle_state);
-	case 14: return (int)sizeof(sgp_hull_info); case 15: return (int)sizeof(sgp_capsule_query); case 16: return (int)sizeof(sgp_query_contact);
+	case 14: return (int)sizeof(sgp_hull_info); case 15: return (int)sizeof(sgp_capsule_query); case 16: return (int)sizeof(sgp_query_contact); case 17: return (int)sizeof(sgp_mesh_info);
 	default: return -1;
 	}
 }
@@ -258,6 +262,8 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	DEV_ALLOC(d.cell_hash, N);
 	DEV_ALLOC(d.cell_count, d.table_size + 4); DEV_ALLOC(d.cell_start, d.table_size + 4); DEV_ALLOC(d.cell_fill, d.table_size + 4);
 	DEV_ALLOC(w->d_large, N); w->cap_large = N; d.large_ids = w->d_large;
+	DEV_ALLOC(w->d_meshes, SGP_MAX_MESHES); d.meshes = w->d_meshes; d.n_meshes = 1; w->meshes.push_back(MeshHeader{});
+	d.cap_mesh_pairs = P / 4 + 1024; DEV_ALLOC(d.mesh_pairs, d.cap_mesh_pairs);
 	DEV_ALLOC(w->d_hulls, SGP_MAX_HULLS); d.hulls = w->d_hulls;
 	d.cap_hull_pairs = P / 4 + 1024; DEV_ALLOC(d.hull_pairs, d.cap_hull_pairs);
 	{
@@ -304,6 +310,9 @@ SGP_API int sgp_world_destroy(sgp_world* w)
 	if (w->stream) hipStreamSynchronize(w->stream);
 	for (void* p : w->allocs) hipFree(p);
 	if (w->stage_dev) hipFree(w->stage_dev);
+	if (w->d_mesh_verts) hipFree(w->d_mesh_verts);
+	if (w->d_mesh_tris) hipFree(w->d_mesh_tris);
+	if (w->d_mesh_nodes) hipFree(w->d_mesh_nodes);
 	if (w->d_vehicles) hipFree(w->d_vehicles);
 	if (w->d_veh_inputs) hipFree(w->d_veh_inputs);
 	if (w->stage_host) hipHostFree(w->stage_host);
@@ -380,20 +389,31 @@ static void note_radius(sgp_world* w, uint32_t id, float r)
 static int add_one(sgp_world* w, const sgp_body_desc* d, uint32_t* id_out, bool ghost)
 {
 	if (!finite3(d->pos) || fabsf(d->pos[0]) > 1.0e9f || fabsf(d->pos[1]) > 1.0e9f || fabsf(d->pos[2]) > 1.0e9f) return SGP_ERR_REJECTED;   // :1178
-	if (d->shape_type < 0 || d->shape_type > SGP_SHAPE_HULL) return fail(SGP_ERR_INVALID, "sgp_body_add: bad shape_type");
+	if (d->shape_type < 0 || d->shape_type > SGP_SHAPE_MESH) return fail(SGP_ERR_INVALID, "sgp_body_add: bad shape_type");
 	const sgd_hull* hull = nullptr;
+	const bool is_mesh = d->shape_type == SGP_SHAPE_MESH;
+	if (is_mesh) {
+		const uint32_t mid = (uint32_t)d->shape[0];
+		if (!(d->shape[0] >= 1.0f) || (float)mid != d->shape[0] || mid >= w->meshes.size()) return fail(SGP_ERR_INVALID, "sgp_body_add: bad mesh id");
+		if (d->motion_type != SGP_MOTION_STATIC) return fail(SGP_ERR_INVALID, "sgp_body_add: mesh shapes are for static bodies only");
+	}
 	if (d->shape_type == SGP_SHAPE_HULL) {
 		const uint32_t hid = (uint32_t)d->shape[0];
 		if (!(d->shape[0] >= 1.0f) || (float)hid != d->shape[0] || hid >= w->hulls.size()) return fail(SGP_ERR_INVALID, "sgp_body_add: bad hull id");
 		hull = &w->hulls[hid];
 	}
-	const int nparam = d->shape_type == SGP_SHAPE_BOX ? 3 : (d->shape_type == SGP_SHAPE_SPHERE ? 1 : (d->shape_type == SGP_SHAPE_HULL ? 0 : 2));
+	const int nparam = d->shape_type == SGP_SHAPE_BOX ? 3 : (d->shape_type == SGP_SHAPE_SPHERE ? 1 : ((d->shape_type == SGP_SHAPE_HULL || is_mesh) ? 0 : 2));
 	for (int i = 0; i < nparam; ++i) {
 		const float lim = (d->shape_type == SGP_SHAPE_CAPSULE && i == 1) ? 0.0f : 0.5e-7f;   // |scale| < 1e-7 on a 0.5 unit shape, :1184
 		if (!std::isfinite(d->shape[i]) || d->shape[i] < lim) return SGP_ERR_REJECTED;
 	}
 	uint32_t id;
-	if (!w->free_list.empty()) { id = w->free_list.back(); w->free_list.pop_back(); }
+	if (is_mesh) {
+		// three consecutive fresh slots: the body and its two aliases (second / third contact manifold of a pair)
+		if (w->high + 3 > w->dv.cap_bodies) return fail(SGP_ERR_CAPACITY, "sgp_body_add: max_bodies exceeded");
+		id = w->high; w->high += 3;
+	}
+	else if (!w->free_list.empty()) { id = w->free_list.back(); w->free_list.pop_back(); }
 	else { if (w->high >= w->dv.cap_bodies) return fail(SGP_ERR_CAPACITY, "sgp_body_add: max_bodies exceeded"); id = w->high++; }
 	BodyCmd c; memset(&c, 0, sizeof(c));
 	c.id = id; c.ops = CMD_CREATE;
@@ -413,17 +433,23 @@ static int add_one(sgp_world* w, const sgp_body_desc* d, uint32_t* id_out, bool 
 		} else mass_properties(d->shape_type, d->shape, c.mass, &c.inv_mass, c.inv_inertia);
 	}
 	uint32_t f = BF_ALIVE | ((uint32_t)d->motion_type & BF_MOTION_MASK) | (((uint32_t)d->layer & 0x3u) << BF_LAYER_SHIFT) |
-	             (((uint32_t)d->shape_type & 0x3u) << BF_SHAPE_SHIFT);
+	             (((uint32_t)d->shape_type & 0x7u) << BF_SHAPE_SHIFT);
 	if (d->is_sensor) f |= BF_SENSOR;
 	if (d->allow_sleeping) f |= BF_ALLOW_SLEEP;
 	if (d->use_zero_linear_drag) f |= BF_ZERO_LIN_DRAG;
 	if (ghost) f |= BF_GHOST;
 	HostBody& hb = w->hb[id];
 	hb.flags = f; hb.userdata = d->userdata; hb.ghost = ghost;
-	note_radius(w, id, hull ? hull->bound_radius : bounding_radius(d->shape_type, d->shape));
-	hb.volume = hull ? hull->volume : host_shape_volume(d->shape_type, d->shape);
+	note_radius(w, id, is_mesh ? 3.0e38f : (hull ? hull->bound_radius : bounding_radius(d->shape_type, d->shape)));   // (meshes always go through the large-body list)
+	hb.volume = is_mesh ? 0.0f : (hull ? hull->volume : host_shape_volume(d->shape_type, d->shape));
 	c.flags = hb.flags;
 	w->cmds.push_back(c);
+	if (is_mesh) for (uint32_t k = 1; k <= 2; ++k) {
+		// aliases: same pose and material, flagged large (so never binned) but absent from the large-body list (so never paired or queried)
+		BodyCmd a = c; a.id = id + k; a.flags = hb.flags | BF_ALIAS | BF_LARGE;
+		HostBody& ha = w->hb[id + k]; ha.flags = a.flags; ha.userdata = d->userdata; ha.ghost = false; ha.bound_radius = 0.0f; ha.volume = 0.0f;
+		w->cmds.push_back(a);
+	}
 	if (d->activate && d->motion_type != SGP_MOTION_STATIC) { BodyCmd a; memset(&a, 0, sizeof(a)); a.id = id; a.ops = CMD_ACTIVATE; w->cmds.push_back(a); }
 	w->n_alive++;
 	if (id_out) *id_out = id;
@@ -457,9 +483,9 @@ SGP_API int sgp_body_remove(sgp_world* w, uint32_t id)
 	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_remove: id not live");
 	for (uint32_t v = 0; v < w->n_vehicles; ++v) if (w->veh_alive[v] && w->veh_body[v] == id) sgp_vehicle_destroy(w, v);   // a vehicle does not outlive its chassis
 	if (w->hb[id].flags & BF_LARGE) { w->large_ids.erase(std::remove(w->large_ids.begin(), w->large_ids.end(), id), w->large_ids.end()); w->large_dirty = true; }
-	w->hb[id].flags = 0;
-	w->cmds.push_back(blank_cmd(id, CMD_REMOVE));
-	w->free_list.push_back(id);
+	if (w->hb[id].flags & BF_ALIAS) return fail(SGP_ERR_BAD_ID, "sgp_body_remove: id not live");
+	const uint32_t nslots = ((w->hb[id].flags & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT) == SGP_SHAPE_MESH ? 3u : 1u;
+	for (uint32_t k = 0; k < nslots; ++k) { w->hb[id + k].flags = 0; w->cmds.push_back(blank_cmd(id + k, CMD_REMOVE)); w->free_list.push_back(id + k); }
 	w->n_alive--;
 	return SGP_OK;
 }
@@ -671,7 +697,10 @@ static int collect_events(sgp_world* w, bool counters_fresh = false)
 		HIP_TRY(hipMemcpyAsync(w->stage_host, l.dev, sizeof(sgp_contact_event) * l.n, hipMemcpyDeviceToHost, w->stream));
 		HIP_TRY(hipStreamSynchronize(w->stream));
 		const sgp_contact_event* src = (const sgp_contact_event*)w->stage_host;
-		for (uint32_t k = 0; k < l.n; ++k) { sgp_contact_event e = src[k]; e.userdata1 = w->hb[e.id1].userdata; e.userdata2 = w->hb[e.id2].userdata; l.out->push_back(e); }
+		for (uint32_t k = 0; k < l.n; ++k) { sgp_contact_event e = src[k];
+			while (e.id1 > 0 && (w->hb[e.id1].flags & BF_ALIAS)) --e.id1;       // a mesh body's alias slots report as the mesh body
+			while (e.id2 > 0 && (w->hb[e.id2].flags & BF_ALIAS)) --e.id2;
+			e.userdata1 = w->hb[e.id1].userdata; e.userdata2 = w->hb[e.id2].userdata; l.out->push_back(e); }
 	}
 	HIP_TRY(hipMemsetAsync(d.evc, 0, sizeof(EventCounters), w->stream));
 	return SGP_OK;
@@ -724,6 +753,7 @@ struct StepPlan {
 	uint32_t colour_est[SGP_MAX_COLOURS];
 	int      water, contact_events, warm_start, vel_iters, pos_iters;
 	uint32_t n_vehicles;
+	int      has_meshes;         // some body may be a static triangle mesh: run the mesh-pair narrow phase
 	int      has_hulls;          // some body may be a convex hull: run the hull-pair narrow phase
 	int      small_world;        // warm start + velocity iterations as ONE single-workgroup launch (k_solve_small)
 	StepParams sp;               // by-value kernel argument of the first launch: part of the key of a captured graph
@@ -743,6 +773,7 @@ static void make_plan(const sgp_world* w, StepPlan& p)
 	p.warm_start = w->dv.st.warm_start; p.vel_iters = w->dv.st.num_velocity_steps; p.pos_iters = w->dv.st.num_position_steps;
 	p.n_vehicles = w->n_vehicles;
 	p.has_hulls = w->hulls.size() > 1 ? 1 : 0;
+	p.has_meshes = w->meshes.size() > 1 ? 1 : 0;
 	p.small_world = (tf == 0 && w->high <= SGP_SMALL_WORLD_BODIES && w->n_vehicles == 0 && w->use_small_world) ? 1 : 0;
 	p.sp = *w->h_sp;
 }
@@ -766,7 +797,7 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 	{ KScope k(w, KC_BP_LARGE); launch_bp_large(d, nb, s); }
 	STAGE_MARK(2);
 	// -- 3. narrow phase, wake-ups, per-body solver records (+ contact events, which see the velocities before the solve)
-	{ KScope k(w, KC_NARROWPHASE); launch_narrowphase(d, p.est_pairs, s); if (p.has_hulls) launch_narrowphase_hull(d, s); }
+	{ KScope k(w, KC_NARROWPHASE); launch_narrowphase(d, p.est_pairs, s); if (p.has_hulls) launch_narrowphase_hull(d, s); if (p.has_meshes) launch_narrowphase_mesh(d, s); }
 	{ KScope k(w, KC_WAKE); launch_wake(d, nb, s); }
 	{ KScope k(w, KC_PREP_BODIES); launch_prep_bodies(d, nb, s); }
 	if (p.contact_events) { KScope k(w, KC_MISC); launch_contact_events(d, p.est_man, s); }
@@ -901,7 +932,7 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 		{ int r = collect_events(w, /*counters_fresh=*/true); if (r != SGP_OK) return r; }
 		st.num_activated = (uint32_t)(w->ev_act.size() - a0);
 		st.num_deactivated = (uint32_t)(w->ev_deact.size() - d0);
-		for (uint32_t i = 0; i < w->high; ++i) if (w->hb[i].flags & BF_ALIVE) st.layer_counts[(w->hb[i].flags & BF_LAYER_MASK) >> BF_LAYER_SHIFT]++;
+		for (uint32_t i = 0; i < w->high; ++i) if ((w->hb[i].flags & (BF_ALIVE | BF_ALIAS)) == BF_ALIVE) st.layer_counts[(w->hb[i].flags & BF_LAYER_MASK) >> BF_LAYER_SHIFT]++;
 	}
 	if (timing) {
 		const double tt3 = now();
@@ -986,6 +1017,94 @@ SGP_API int sgp_world_set_contact_events(sgp_world* w, int enabled)
 		w->graphs.clear();
 	}
 	w->h_sp->contact_events = enabled;
+	return SGP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// static triangle meshes (MeshShapeSettings::Create, PhysicsWorld.cpp:735-1166 with is_dynamic = false)
+
+static void invalidate_graphs(sgp_world* w);
+
+template <typename T> static int grow_pool(sgp_world* w, T*& dev, size_t& cap, size_t need, size_t used_before)
+{
+	if (need <= cap) return SGP_OK;
+	size_t nc = std::max<size_t>(need + need / 2, 4096);
+	T* nd = nullptr;
+	HIP_TRY(hipMalloc((void**)&nd, sizeof(T) * nc));
+	if (dev && used_before) HIP_TRY(hipMemcpyAsync(nd, dev, sizeof(T) * used_before, hipMemcpyDeviceToDevice, w->stream));
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	if (dev) { hipFree(dev); w->device_bytes -= sizeof(T) * cap; }
+	dev = nd; cap = nc; w->device_bytes += sizeof(T) * nc;
+	return SGP_OK;
+}
+
+// median-split tree over the triangles [first, first + count) of `order`; returns the node index
+static uint32_t build_mesh_node(std::vector<MeshNode>& nodes, size_t node_base, std::vector<uint32_t>& order, const std::vector<float>& cen, const std::vector<float>& tmin, const std::vector<float>& tmax, uint32_t first, uint32_t count)
+{
+	const uint32_t me = (uint32_t)(nodes.size() - node_base);
+	nodes.push_back(MeshNode{});
+	float mn[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, mx[3] = { -3.4e38f, -3.4e38f, -3.4e38f }, cmn[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, cmx[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
+	for (uint32_t k = first; k < first + count; ++k) for (int a = 0; a < 3; ++a) {
+		const uint32_t t = order[k];
+		mn[a] = std::min(mn[a], tmin[3 * t + a]); mx[a] = std::max(mx[a], tmax[3 * t + a]);
+		cmn[a] = std::min(cmn[a], cen[3 * t + a]); cmx[a] = std::max(cmx[a], cen[3 * t + a]);
+	}
+	MeshNode nd{};
+	nd.mnx = mn[0]; nd.mny = mn[1]; nd.mnz = mn[2]; nd.mxx = mx[0]; nd.mxy = mx[1]; nd.mxz = mx[2];
+	int axis = 0; if (cmx[1] - cmn[1] > cmx[axis] - cmn[axis]) axis = 1; if (cmx[2] - cmn[2] > cmx[axis] - cmn[axis]) axis = 2;
+	if (count <= 4 || !(cmx[axis] - cmn[axis] > 0.0f)) { nd.left = first; nd.right = 0; nd.count = count; nodes[node_base + me] = nd; return me; }
+	const uint32_t mid = first + count / 2;
+	std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count, [&](uint32_t x, uint32_t y) { return cen[3 * x + axis] < cen[3 * y + axis] || (cen[3 * x + axis] == cen[3 * y + axis] && x < y); });
+	nd.count = 0;
+	nd.left = build_mesh_node(nodes, node_base, order, cen, tmin, tmax, first, mid - first);
+	nd.right = build_mesh_node(nodes, node_base, order, cen, tmin, tmax, mid, first + count - mid);
+	nodes[node_base + me] = nd;
+	return me;
+}
+
+SGP_API int sgp_mesh_create(sgp_world* w, const float* verts, uint32_t nv, const uint32_t* idx, uint32_t nt, sgp_mesh_info* info)
+{
+	if (!w || !verts || !idx || !info || nv < 3 || nt < 1) return fail(SGP_ERR_INVALID, "sgp_mesh_create: bad arguments");
+	if (w->meshes.size() >= SGP_MAX_MESHES) return fail(SGP_ERR_CAPACITY, "sgp_mesh_create: mesh table full");
+	for (uint32_t k = 0; k < 3 * nt; ++k) if (idx[k] >= nv) return fail(SGP_ERR_INVALID, "sgp_mesh_create: vertex index out of range");
+	for (uint32_t k = 0; k < 3 * nv; ++k) if (!std::isfinite(verts[k])) return fail(SGP_ERR_INVALID, "sgp_mesh_create: non-finite vertex");
+	hipSetDevice(w->device);
+	MeshHeader mh{};
+	mh.vert_off = (uint32_t)w->mesh_verts.size(); mh.nv = nv; mh.tri_off = (uint32_t)w->mesh_tris.size(); mh.nt = nt; mh.node_off = (uint32_t)w->mesh_nodes.size();
+	float mn[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, mx[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
+	for (uint32_t k = 0; k < nv; ++k) {
+		w->mesh_verts.push_back(make_float4(verts[3 * k], verts[3 * k + 1], verts[3 * k + 2], 0.0f));
+		for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], verts[3 * k + a]); mx[a] = std::max(mx[a], verts[3 * k + a]); }
+	}
+	mh.mnx = mn[0]; mh.mny = mn[1]; mh.mnz = mn[2]; mh.mxx = mx[0]; mh.mxy = mx[1]; mh.mxz = mx[2];
+	std::vector<float> cen(3 * (size_t)nt), tmin(3 * (size_t)nt), tmax(3 * (size_t)nt);
+	std::vector<uint32_t> order(nt);
+	for (uint32_t t = 0; t < nt; ++t) {
+		order[t] = t;
+		for (int a = 0; a < 3; ++a) {
+			const float p0 = verts[3 * idx[3 * t] + a], p1 = verts[3 * idx[3 * t + 1] + a], p2 = verts[3 * idx[3 * t + 2] + a];
+			cen[3 * t + a] = (p0 + p1 + p2) * (1.0f / 3.0f); tmin[3 * t + a] = std::min(p0, std::min(p1, p2)); tmax[3 * t + a] = std::max(p0, std::max(p1, p2));
+		}
+	}
+	build_mesh_node(w->mesh_nodes, mh.node_off, order, cen, tmin, tmax, 0, nt);
+	mh.n_nodes = (uint32_t)(w->mesh_nodes.size() - mh.node_off);
+	for (uint32_t k = 0; k < nt; ++k) { const uint32_t t = order[k]; w->mesh_tris.push_back(make_uint4(idx[3 * t], idx[3 * t + 1], idx[3 * t + 2], t)); }
+	// upload (pools may move: captured graphs carry the old pointers)
+	{ int r = grow_pool(w, w->d_mesh_verts, w->cap_mesh_verts, w->mesh_verts.size(), mh.vert_off); if (r != SGP_OK) return r; }
+	{ int r = grow_pool(w, w->d_mesh_tris, w->cap_mesh_tris, w->mesh_tris.size(), mh.tri_off); if (r != SGP_OK) return r; }
+	{ int r = grow_pool(w, w->d_mesh_nodes, w->cap_mesh_nodes, w->mesh_nodes.size(), mh.node_off); if (r != SGP_OK) return r; }
+	HIP_TRY(hipMemcpyAsync(w->d_mesh_verts + mh.vert_off, w->mesh_verts.data() + mh.vert_off, sizeof(float4) * nv, hipMemcpyHostToDevice, w->stream));
+	HIP_TRY(hipMemcpyAsync(w->d_mesh_tris + mh.tri_off, w->mesh_tris.data() + mh.tri_off, sizeof(uint4) * nt, hipMemcpyHostToDevice, w->stream));
+	HIP_TRY(hipMemcpyAsync(w->d_mesh_nodes + mh.node_off, w->mesh_nodes.data() + mh.node_off, sizeof(MeshNode) * mh.n_nodes, hipMemcpyHostToDevice, w->stream));
+	const uint32_t id = (uint32_t)w->meshes.size();
+	w->meshes.push_back(mh);
+	HIP_TRY(hipMemcpyAsync(&w->d_meshes[id], &w->meshes[id], sizeof(MeshHeader), hipMemcpyHostToDevice, w->stream));
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	w->dv.mesh_verts = w->d_mesh_verts; w->dv.mesh_tris = w->d_mesh_tris; w->dv.mesh_nodes = w->d_mesh_nodes; w->dv.n_meshes = (uint32_t)w->meshes.size();
+	invalidate_graphs(w);
+	memset(info, 0, sizeof(*info));
+	info->mesh_id = id; info->num_vertices = nv; info->num_triangles = nt; info->num_nodes = mh.n_nodes;
+	memcpy(info->aabb_min, mn, sizeof(mn)); memcpy(info->aabb_max, mx, sizeof(mx));
 	return SGP_OK;
 }
 

@@ -205,6 +205,15 @@ class CWorld:
         self._check(self._fn("raycast")(self._h, rays.ctypes.data, len(rays), hits.ctypes.data), "raycast")
         return hits
 
+    # -- static triangle meshes -------------------------------------------------------------------------------------
+    def mesh_create(self, vertices, triangles):
+        """MeshShapeSettings(vertices, triangles).Create(): returns abi.MeshInfo (mesh_id for static body descs)."""
+        v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
+        t = np.ascontiguousarray(triangles, dtype=np.uint32).reshape(-1, 3)
+        info = abi.MeshInfo()
+        self._check(self._fn("mesh_create")(self._h, v.ctypes.data, len(v), t.ctypes.data, len(t), C.byref(info)), "mesh_create")
+        return info
+
     # -- convex hulls ---------------------------------------------------------------------------------------------
     def hull_create(self, points, com_offset=None):
         """ConvexHullShapeSettings(points).Create() (wrapped in OffsetCenterOfMassShape when com_offset is given): returns

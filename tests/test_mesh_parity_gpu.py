@@ -1,0 +1,112 @@
+"""GPU-vs-oracle parity with static triangle-mesh bodies (sgp_mesh_create + SGP_SHAPE_MESH; the role of JPH::MeshShape /
+HeightFieldShape for Substrata's static meshes and terrain, /root/reference/gui_client/PhysicsWorld.cpp:735-1166, TerrainSystem.cpp:1300):
+a triangulated terrain and a walled room, spheres / boxes / capsules / hulls dropped on them, rays and capsule queries."""
+import numpy as np
+import pytest
+
+from substrata_amd import abi, scenes
+from helpers import DT
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+def grid_mesh(n, size, height_fn):
+    xs = np.linspace(-size, size, n)
+    V = np.array([(x, y, height_fn(x, y)) for y in xs for x in xs], np.float32)
+    T = []
+    for j in range(n - 1):
+        for i in range(n - 1):
+            a = j * n + i; b = a + 1; c = a + n; d = c + 1
+            T += [(a, b, d), (a, d, c)]
+    return V, np.array(T, np.uint32)
+
+
+def room_mesh(half, height):
+    """An open box seen from inside: floor + four walls (normals pointing inwards)."""
+    h, z = half, height
+    V = np.array([(-h, -h, 0), (h, -h, 0), (h, h, 0), (-h, h, 0), (-h, -h, z), (h, -h, z), (h, h, z), (-h, h, z)], np.float32)
+    T = [(0, 1, 2), (0, 2, 3),                 # floor, +z
+         (0, 4, 5), (0, 5, 1),                 # wall y = -h, normal +y
+         (1, 5, 6), (1, 6, 2),                 # wall x = +h, normal -x
+         (2, 6, 7), (2, 7, 3),                 # wall y = +h, normal -y
+         (3, 7, 4), (3, 4, 0)]                 # wall x = -h, normal +x
+    return V, np.array(T, np.uint32)
+
+
+def mesh_body(info, pos=(0, 0, 0), rot=(0, 0, 0, 1)):
+    d = scenes._blank(1)
+    d["shape_type"] = abi.SHAPE_MESH; d["shape"][0] = 0; d["shape"][0, 0] = float(info.mesh_id)
+    d["pos"][0] = pos; d["rot"][0] = rot
+    return d
+
+
+def test_terrain_and_room_match_oracle(oracle):
+    rng = np.random.default_rng(21)
+    tw = parity.make_twin(oracle, max_bodies=1024)
+    V, T = grid_mesh(33, 16.0, lambda x, y: 0.6 * np.sin(0.5 * x) * np.cos(0.4 * y) + 0.01 * (x * x + y * y))
+    ig, ic = tw.mesh_create(V, T)
+    assert (ig.mesh_id, ig.num_triangles) == (ic.mesh_id, ic.num_triangles) == (1, 2048)
+    mg, mc = tw.add_batch(mesh_body(ig))
+    assert int(mg[0]) == int(mc[0]) == 0
+    Vr, Tr = room_mesh(3.0, 12.0)
+    rg, rc = tw.mesh_create(Vr, Tr)
+    q = (0, 0, np.sin(0.2), np.cos(0.2))
+    mg2, mc2 = tw.add_batch(mesh_body(rg, pos=(30.0, 0.0, 0.0), rot=q))           # a second, rotated mesh body far from the terrain
+    assert int(mg2[0]) == int(mc2[0]) == 3                                       # (ids 1, 2 are the terrain's alias slots)
+    hg, hc = tw.hull_create(rng.normal(size=(12, 3)) * 0.5)
+    n_dyn = 0
+    for centre, count in (((0.0, 0.0), 90), ((30.0, 0.0), 40)):
+        d = scenes.dynamic_bodies(count)
+        kinds = rng.integers(0, 4, size=count)
+        d["shape_type"] = np.where(kinds == 3, abi.SHAPE_HULL, kinds)
+        d["shape"][:, :3] = 0.4
+        d["shape"][kinds == 2, 1] = 0.5; d["shape"][kinds == 2, 0] = 0.25
+        d["shape"][kinds == 3, 0] = float(hg.hull_id); d["shape"][kinds == 3, 1:] = 0
+        spread = 9.0 if count == 90 else 2.0
+        d["pos"] = np.column_stack([rng.uniform(centre[0] - spread, centre[0] + spread, count), rng.uniform(centre[1] - spread, centre[1] + spread, count), rng.uniform(2.5, 9.0, count)])
+        quat = rng.normal(size=(count, 4)); quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+        d["rot"] = quat
+        d["lin_vel"][:, :2] = rng.uniform(-2, 2, size=(count, 2))
+        tw.add_batch(d)
+        n_dyn += count
+    total = 6 + n_dyn
+    for s in range(1, 481):
+        tw.step(DT)
+        if s in (1, 60, 180, 300, 480):
+            d = parity.compare(tw, total)
+            assert d["active_mismatch"] == 0, (s, d)
+            assert d["pos"] <= 2e-4 and d["rot"] <= 2e-4 and d["lin_vel"] <= 2e-3 and d["ang_vel"] <= 2e-3, (s, d)
+            sg, sc = tw.stats()
+            assert (sg.num_pairs, sg.num_manifolds, sg.num_contact_points) == (sc.num_pairs, sc.num_manifolds, sc.num_contact_points), s
+            assert sg.manifolds_dropped == 0
+    print("mesh terrain + room, 480 steps: bit exact =", d["bit_exact"])
+    st = tw.gpu.read_states(6, n_dyn)
+    assert np.isfinite(st["pos"]).all()
+    terrain_z = lambda x, y: 0.6 * np.sin(0.5 * x) * np.cos(0.4 * y) + 0.01 * (x * x + y * y)
+    on_terrain = st[:90]
+    assert (on_terrain["pos"][:, 2] > terrain_z(on_terrain["pos"][:, 0], on_terrain["pos"][:, 1]) - 0.05).all()     # nothing fell through
+    in_room = st[90:]
+    c, s_ = np.cos(-0.4), np.sin(-0.4)                                                      # room frame
+    lx = c * (in_room["pos"][:, 0] - 30.0) - s_ * in_room["pos"][:, 1]; ly = s_ * (in_room["pos"][:, 0] - 30.0) + c * in_room["pos"][:, 1]
+    assert (np.abs(lx) < 3.0).all() and (np.abs(ly) < 3.0).all() and (in_room["pos"][:, 2] > 0.1).all()     # the walls held them
+    # rays
+    rays = np.zeros(512, dtype=abi.ray_dtype)
+    rays["origin"] = np.column_stack([rng.uniform(-15, 34, 512), rng.uniform(-15, 15, 512), rng.uniform(5, 12, 512)])
+    dd = rng.normal(size=(512, 3)) * (0.6, 0.6, 0.2) + (0, 0, -1.0); dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+    rays["dir"] = dd; rays["max_t"] = 40.0; rays["ignore_id"] = abi.INVALID_ID
+    rg_, rc_ = tw.raycast(rays)
+    assert np.array_equal(rg_["id"], rc_["id"]) and (rg_["id"] == 0).sum() > 100 and (rg_["id"] == 3).sum() > 5
+    assert np.max(np.abs(rg_["t"] - rc_["t"])) <= 1e-4 and np.max(np.abs(rg_["normal"] - rc_["normal"])) <= 1e-5
+    # capsule queries against the meshes (the character controller's CollideShape)
+    qy = np.zeros(128, dtype=abi.capsule_query_dtype)
+    px = rng.uniform(-12, 12, 128); py = rng.uniform(-12, 12, 128)
+    qy["pos"] = np.column_stack([px, py, terrain_z(px, py) + rng.uniform(0.85, 1.1, 128)])
+    qy["pos"][:16] = [(30.0 + 2.6 * np.cos(a), 2.6 * np.sin(a), 0.97) for a in np.linspace(0, 6.2, 16)]     # along the room's walls
+    qy["rot"] = (0, 0, 0, 1); qy["radius"] = 0.3; qy["half_height"] = 0.65; qy["max_separation"] = 0.12; qy["ignore_id"] = abi.INVALID_ID; qy["collidable_only"] = 1
+    cg, cc = tw.collide_capsules(qy)
+    assert len(cg) == len(cc) and len(cg) > 60
+    assert np.array_equal(cg["query"], cc["query"]) and np.array_equal(cg["body"], cc["body"])
+    for f in ("point", "normal", "distance"):
+        assert np.max(np.abs(cg[f] - cc[f])) <= 1e-5, f
+    tw.close()

@@ -38,6 +38,17 @@ HULL_HDR = '''// sgp_device_hull.h -- gfx950 convex hull shapes: hull - hull / b
 
 '''
 
+MESH_HDR = '''// sgp_device_mesh.h -- gfx950 static triangle meshes: per-triangle collision (a triangle is a thin 3-vertex hull), grouping of the
+// triangle manifolds of one body pair by normal (<= 3 groups, <= 4 points each), ray - triangle (device code only).
+//
+// Role of JPH::MeshShape / HeightFieldShape in CollideShape / CastRay for Substrata's static meshes and terrain
+// (/root/reference/gui_client/PhysicsWorld.cpp:735-1166 with is_dynamic = false, :1020-1120; TerrainSystem.cpp:1300).
+// Included after sgp_device_collide.h.  Regenerate with tools/derive_device_vehicle.py.
+#pragma once
+#include "sgp_device_collide.h"
+
+'''
+
 BUILD_HDR = '''// sgp_hull_build.h -- HOST side of the convex hull shapes: hull from a point cloud, volume / centre of mass / inertia, body frame.
 //
 // Role of JPH::ConvexHullShapeSettings::Create + MassProperties (+ OffsetCenterOfMassShape) (/root/reference/gui_client/
@@ -70,6 +81,10 @@ def main():
     s = open(os.path.join(ROOT, "oracle", "sgo_hull.h")).read()
     body = rewrite(s[s.index('#define SGO_HULL_MAX_VERTS'):s.rindex('#endif')])
     open(os.path.join(csrc, "sgp_device_hull.h"), "w").write(HULL_HDR + body)
+    s = open(os.path.join(ROOT, "oracle", "sgo_mesh.h")).read()
+    body = rewrite(s[s.index('#define SGO_MESH_MAX_GROUPS'):s.rindex('#endif')])
+    body = re.sub(r'->p\[(\d)\]', r'->p\1', body)          # the device shape record names its parameters p0, p1, p2
+    open(os.path.join(csrc, "sgp_device_mesh.h"), "w").write(MESH_HDR + body)
     # host-side builder: plain host functions (no __device__), host constructor for v3
     s = open(os.path.join(ROOT, "oracle", "sgo_hull_build.h")).read()
     body = s[s.index('typedef struct { double x, y, z; } sgo_d3;'):s.rindex('#endif')]
