@@ -20,6 +20,7 @@
 #define SGO_MESH_H
 
 #include "sgo_hull.h"
+/* (sgo_ray_sphere / sgo_ray_capsule_z come from sgo_vehicle.h, included before this header) */
 
 #define SGO_MESH_MAX_GROUPS 3
 #define SGO_MESH_GROUP_COS 0.95f
@@ -108,6 +109,50 @@ static inline float sgo_ray_tri(v3 o, v3 d, v3 a, v3 b, v3 c, float max_t)
 	const float t = v3_dot(e2, qv) / det;
 	if (t < 0.0f || t > max_t) return -1.0f;
 	return t;
+}
+
+/* ray against a capsule with end points a, b and radius r (any orientation): t or -1, normal at the hit */
+static inline float sgo_ray_capsule_seg(v3 o, v3 d, v3 a, v3 b, float r, float max_t, v3* n_out)
+{
+	const v3 ab = v3_sub(b, a);
+	const float len = v3_len(ab);
+	if (len < 1.0e-12f) { const float t = sgo_ray_sphere(v3_sub(o, a), d, r, max_t, n_out); return t; }
+	const v3 ez = v3_scale(ab, 1.0f / len);
+	const v3 ex = v3_normalized_perpendicular(ez);
+	const v3 ey = v3_cross(ez, ex);
+	const v3 mid = v3_scale(v3_add(a, b), 0.5f);
+	const v3 ro = v3_sub(o, mid);
+	const v3 ol = V3(v3_dot(ro, ex), v3_dot(ro, ey), v3_dot(ro, ez)), dl = V3(v3_dot(d, ex), v3_dot(d, ey), v3_dot(d, ez));
+	v3 nl;
+	const float t = sgo_ray_capsule_z(ol, dl, r, 0.5f * len, max_t, &nl);
+	if (t < 0.0f) return -1.0f;
+	*n_out = v3_add(v3_add(v3_scale(ex, nl.x), v3_scale(ey, nl.y)), v3_scale(ez, nl.z));
+	return t;
+}
+
+/* A sphere of radius rs moving from o along d against the FRONT of triangle (a, b, c): the face plane moved out by rs, plus the
+   three edges as capsules (they cover the vertices too).  Returns the travel distance or -1; n_out = normal at the touch point. */
+static inline float sgo_cast_sphere_tri(v3 o, v3 d, v3 a, v3 b, v3 c, float max_t, float rs, v3* n_out)
+{
+	v3 nt = v3_cross(v3_sub(b, a), v3_sub(c, a));
+	const float l = v3_len(nt);
+	if (l < 1.0e-20f) return -1.0f;
+	nt = v3_scale(nt, 1.0f / l);
+	float best = -1.0f; v3 bn = nt; float lim = max_t;
+	const v3 off = v3_scale(nt, rs);
+	const float tf = sgo_ray_tri(o, d, v3_add(a, off), v3_add(b, off), v3_add(c, off), lim);
+	if (tf >= 0.0f) { best = tf; bn = nt; lim = tf; }
+	if (rs > 0.0f) {
+		const v3 ea[3] = { a, b, c }, eb[3] = { b, c, a };
+		for (int k = 0; k < 3; ++k) {
+			v3 nn = nt;
+			const float tk = sgo_ray_capsule_seg(o, d, ea[k], eb[k], rs, lim, &nn);
+			if (tk >= 0.0f && v3_dot(nn, nt) >= 0.0f && (best < 0.0f || tk < best)) { best = tk; bn = nn; lim = tk; }
+		}
+	}
+	if (best < 0.0f) return -1.0f;
+	*n_out = bn;
+	return best;
 }
 
 #endif

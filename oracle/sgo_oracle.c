@@ -34,8 +34,8 @@
 #include "../include/sgp.h"
 #include "sgo_collide.h"
 #include "sgo_hull_build.h"
-#include "sgo_mesh.h"
 #include "sgo_vehicle.h"
+#include "sgo_mesh.h"
 
 #define SGO_API __attribute__((visibility("default")))
 #define SGO_MAX_COLOURS 64
@@ -1530,6 +1530,8 @@ static sgo_chassis chassis_load(const sgo_body* b)
    order of the vehicles: (A) all wheel casts (read-only on the bodies), (B) controller + row setup (writes the own chassis only).
    The cast visits every body (closest accepted hit; on equal distance the lower body id wins) -- the device walks the
    broad-phase grid instead and must find the same hit. */
+static float cast_sphere_mesh(const sgo_body* M, v3 o, v3 d, float max_t, float rs, v3* n_out, v3* p_out);
+
 static void vehicles_pre_step(sgo_world* w, float dt)
 {
 	if (w->n_vehicles == 0) return;
@@ -1537,7 +1539,7 @@ static void vehicles_pre_step(sgo_world* w, float dt)
 	float* bounds = (float*)malloc(sizeof(float) * 6 * (w->high ? w->high : 1));
 	for (uint32_t j = 0; j < w->high; ++j) {
 		const sgo_body* o = &w->bodies[j];
-		const int cand = o->alive && !o->is_alias && o->shape_type != SGP_SHAPE_MESH && !o->is_sensor && (o->layer == SGP_LAYER_NON_MOVING || o->layer == SGP_LAYER_MOVING);   /* tester object layer MOVING, CarPhysics.cpp:62 */
+		const int cand = o->alive && !o->is_alias && !o->is_sensor && (o->layer == SGP_LAYER_NON_MOVING || o->layer == SGP_LAYER_MOVING);   /* tester object layer MOVING, CarPhysics.cpp:62 */
 		float* bb = &bounds[6 * j];
 		if (cand) { bb[0] = o->aabb_min.x; bb[1] = o->aabb_min.y; bb[2] = o->aabb_min.z; bb[3] = o->aabb_max.x; bb[4] = o->aabb_max.y; bb[5] = o->aabb_max.z; }
 		else { bb[0] = bb[1] = bb[2] = 1.0f; bb[3] = bb[4] = bb[5] = -1.0f; }                          /* empty box: never overlaps */
@@ -1562,7 +1564,8 @@ static void vehicles_pre_step(sgo_world* w, float dt)
 				if (j == v->body) continue;
 				const sgo_body* o = &w->bodies[j];
 				v3 n, p;
-				const float t = sgo_cast_sphere_body(o->shape_type, o->shape, o->hull, o->pos, quat_to_m33(o->rot), wh->cast_origin, wh->cast_dir, best, v->cast_radius, &n, &p);
+				const float t = o->shape_type == SGP_SHAPE_MESH ? cast_sphere_mesh(o, wh->cast_origin, wh->cast_dir, best, v->cast_radius, &n, &p)
+				                                                : sgo_cast_sphere_body(o->shape_type, o->shape, o->hull, o->pos, quat_to_m33(o->rot), wh->cast_origin, wh->cast_dir, best, v->cast_radius, &n, &p);
 				if (t < 0.0f || n.z < v->cos_max_slope) continue;
 				if (t < best || bid == SGP_INVALID_ID) { best = t; bid = j; bn = n; bp = p; }
 			}
@@ -1939,6 +1942,25 @@ static int collide_with_mesh(const sgo_body* M, const sgo_shape* X, v3 lo, v3 hi
 	return sgo_mesh_finish(&mc, out);
 }
 
+/* swept sphere against mesh body M: closest front-side touch; on equal distance the lower triangle index wins */
+static float cast_sphere_mesh(const sgo_body* M, v3 o, v3 d, float max_t, float rs, v3* n_out, v3* p_out)
+{
+	const m33 R = quat_to_m33(M->rot);
+	const v3 ol = m33_tmul(R, v3_sub(o, M->pos)), dl = m33_tmul(R, d);
+	float best = max_t; int hit = 0; v3 bn = V3(0, 0, 0);
+	for (uint32_t t = 0; t < M->mesh->nt; ++t) {
+		const v3 a = M->mesh->verts[M->mesh->tris[3 * t]], b = M->mesh->verts[M->mesh->tris[3 * t + 1]], c = M->mesh->verts[M->mesh->tris[3 * t + 2]];
+		v3 nn;
+		const float tt = sgo_cast_sphere_tri(ol, dl, a, b, c, best, rs, &nn);
+		if (tt >= 0.0f && (tt < best || !hit)) { best = tt; hit = 1; bn = nn; }
+	}
+	if (!hit) return -1.0f;
+	const v3 n = m33_mul(R, bn);
+	*n_out = n;
+	*p_out = v3_sub(v3_add(o, v3_scale(d, best)), v3_scale(n, rs));
+	return best;
+}
+
 /* ConvexHullShapeSettings::Create */
 SGO_API int sgo_hull_create_com(sgo_world* w, const float* pts, uint32_t n, const float* com_offset, sgp_hull_info* info)
 {
@@ -2060,10 +2082,11 @@ SGO_API int sgo_spherecast(sgo_world* w, const sgp_ray* rays, const float* radii
 		float best = rays[k].max_t; uint32_t bid = SGP_INVALID_ID; v3 bn = V3(0, 0, 0);
 		for (uint32_t i = 0; i < w->high; ++i) {
 			const sgo_body* b = &w->bodies[i];
-			if (!b->alive || b->is_alias || b->shape_type == SGP_SHAPE_MESH || i == rays[k].ignore_id || b->is_sensor) continue;
+			if (!b->alive || b->is_alias || i == rays[k].ignore_id || b->is_sensor) continue;
 			if (rays[k].collidable_only && !(b->layer == SGP_LAYER_NON_MOVING || b->layer == SGP_LAYER_MOVING)) continue;
 			v3 nn, pp;
-			const float t = sgo_cast_sphere_body(b->shape_type, b->shape, b->hull, b->pos, quat_to_m33(b->rot), o, d, best, radii[k], &nn, &pp);
+			const float t = b->shape_type == SGP_SHAPE_MESH ? cast_sphere_mesh(b, o, d, best, radii[k], &nn, &pp)
+			                                                : sgo_cast_sphere_body(b->shape_type, b->shape, b->hull, b->pos, quat_to_m33(b->rot), o, d, best, radii[k], &nn, &pp);
 			if (t >= 0.0f && (t < best || bid == SGP_INVALID_ID) && t <= best) { best = t; bid = i; bn = nn; }
 		}
 		hits[k].id = bid; hits[k].t = bid == SGP_INVALID_ID ? 0.0f : best;

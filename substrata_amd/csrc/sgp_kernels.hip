@@ -2113,11 +2113,48 @@ __global__ void __launch_bounds__(64) k_raycast(DV d, const sgp_ray* rays, uint3
 // the body under a wheel, so each phase is race free without colouring; it runs as its own launch before the contact colours
 // of the same pass (PhysicsSystem solves non-contact constraints first).
 
+// swept sphere against mesh body j: closest front-side touch; on equal distance the lower triangle index (caller's order) wins
+SGP_DEV float cast_sphere_mesh(const DV& d, uint32_t j, v3 o, v3 dir, float max_t, float rs, v3* n_out, v3* p_out)
+{
+	const MeshHeader mh = d.meshes[(uint32_t)d.shape[j].x];
+	const v3 mpos = V3(d.pos_im[j]); const m33 R = quat_to_m33(Q4(d.rot[j]));
+	const v3 ol = m33_tmul(R, v3_sub(o, mpos)), dl = m33_tmul(R, dir);
+	float best = max_t; uint32_t best_idx = 0xFFFFFFFFu; v3 bn = V3(0.0f, 0.0f, 0.0f);
+	uint32_t stack[48]; int sp = 0;
+	stack[sp++] = 0;
+	while (sp > 0) {
+		const MeshNode nd = d.mesh_nodes[mh.node_off + stack[--sp]];
+		// slab test of the centre's path against the node box grown by the sphere radius (+ a little)
+		const float g = rs + 1.0e-4f * (1.0f + fabsf(nd.mxx) + fabsf(nd.mxy) + fabsf(nd.mxz) + fabsf(nd.mnx) + fabsf(nd.mny) + fabsf(nd.mnz));
+		float t0 = 0.0f, t1 = best; bool miss = false;
+		const float lo3[3] = { nd.mnx - g, nd.mny - g, nd.mnz - g }, hi3[3] = { nd.mxx + g, nd.mxy + g, nd.mxz + g };
+		const float o3[3] = { ol.x, ol.y, ol.z }, d3[3] = { dl.x, dl.y, dl.z };
+		for (int a = 0; a < 3 && !miss; ++a) {
+			if (fabsf(d3[a]) <= 1.0e-12f) { if (o3[a] < lo3[a] || o3[a] > hi3[a]) miss = true; }
+			else { float ta = (lo3[a] - o3[a]) / d3[a], tb = (hi3[a] - o3[a]) / d3[a]; if (ta > tb) { const float tmp = ta; ta = tb; tb = tmp; } t0 = fmaxf(t0, ta - 1.0e-4f); t1 = fminf(t1, tb + 1.0e-4f); if (t0 > t1) miss = true; }
+		}
+		if (miss) continue;
+		if (nd.count == 0) { if (sp + 2 <= 48) { stack[sp++] = nd.left; stack[sp++] = nd.right; } continue; }
+		for (uint32_t k = 0; k < nd.count; ++k) {
+			const uint4 tri = d.mesh_tris[mh.tri_off + nd.left + k];
+			const v3 pa = V3(d.mesh_verts[mh.vert_off + tri.x]), pb = V3(d.mesh_verts[mh.vert_off + tri.y]), pc = V3(d.mesh_verts[mh.vert_off + tri.z]);
+			v3 nn;
+			const float tt = sgd_cast_sphere_tri(ol, dl, pa, pb, pc, best, rs, &nn);
+			if (tt >= 0.0f && (tt < best || best_idx == 0xFFFFFFFFu || (tt == best && tri.w < best_idx))) { best = tt; best_idx = tri.w; bn = nn; }
+		}
+	}
+	if (best_idx == 0xFFFFFFFFu) return -1.0f;
+	const v3 n = m33_mul(R, bn);
+	*n_out = n;
+	*p_out = v3_sub(v3_add(o, v3_scale(dir, best)), v3_scale(n, rs));
+	return best;
+}
+
 SGP_DEV void veh_cast_test(const DV& d, const sgd_vehicle* v, v3 o, v3 dir, float rs, uint32_t j, float& best, uint32_t& bid, v3& bn, v3& bp)
 {
 	if (j == v->body) return;
 	const uint32_t f = d.flags[j];
-	if (!(f & BF_ALIVE) || (f & (BF_SENSOR | BF_ALIAS)) || f_shape(f) == SGP_SHAPE_MESH) return;
+	if (!(f & BF_ALIVE) || (f & (BF_SENSOR | BF_ALIAS))) return;
 	const uint32_t layer = f_layer(f);
 	if (!(layer == SGP_LAYER_NON_MOVING || layer == SGP_LAYER_MOVING)) return;            // tester object layer MOVING, CarPhysics.cpp:62
 	const float4 mn = d.aabb_min[j], mx = d.aabb_max[j];
@@ -2126,7 +2163,8 @@ SGP_DEV void veh_cast_test(const DV& d, const sgd_vehicle* v, v3 o, v3 dir, floa
 	const float4 sh = d.shape[j];
 	const float prm[3] = { sh.x, sh.y, sh.z };
 	v3 n, p;
-	const float t = sgd_cast_sphere_body((int)f_shape(f), prm, f_shape(f) == SGP_SHAPE_HULL ? body_hull(d, sh) : nullptr, V3(d.pos_im[j]), quat_to_m33(Q4(d.rot[j])), o, dir, best, rs, &n, &p);
+	const float t = f_shape(f) == SGP_SHAPE_MESH ? cast_sphere_mesh(d, j, o, dir, best, rs, &n, &p)
+	              : sgd_cast_sphere_body((int)f_shape(f), prm, f_shape(f) == SGP_SHAPE_HULL ? body_hull(d, sh) : nullptr, V3(d.pos_im[j]), quat_to_m33(Q4(d.rot[j])), o, dir, best, rs, &n, &p);
 	if (t < 0.0f || n.z < v->cos_max_slope) return;
 	// closest accepted hit; on equal distance the lower body id wins (the oracle visits ids in ascending order)
 	if (t < best || bid == SGP_INVALID_ID || (t == best && j < bid)) { best = t; bid = j; bn = n; bp = p; }
@@ -2332,7 +2370,7 @@ SGP_DEV void spherecast_body(const DV& d, const sgp_ray& ry, float rs, v3 o, v3 
 {
 	if (j == ry.ignore_id) return;
 	const uint32_t f = d.flags[j];
-	if (!(f & BF_ALIVE) || (f & (BF_SENSOR | BF_ALIAS)) || f_shape(f) == SGP_SHAPE_MESH) return;
+	if (!(f & BF_ALIVE) || (f & (BF_SENSOR | BF_ALIAS))) return;
 	const uint32_t layer = f_layer(f);
 	if (ry.collidable_only && !(layer == SGP_LAYER_NON_MOVING || layer == SGP_LAYER_MOVING)) return;
 	const float4 mn = d.aabb_min[j], mx = d.aabb_max[j];
@@ -2341,7 +2379,8 @@ SGP_DEV void spherecast_body(const DV& d, const sgp_ray& ry, float rs, v3 o, v3 
 	const float4 sh = d.shape[j];
 	const float prm[3] = { sh.x, sh.y, sh.z };
 	v3 n, p;
-	const float t = sgd_cast_sphere_body((int)f_shape(f), prm, f_shape(f) == SGP_SHAPE_HULL ? body_hull(d, sh) : nullptr, V3(d.pos_im[j]), quat_to_m33(Q4(d.rot[j])), o, dir, best.t, rs, &n, &p);
+	const float t = f_shape(f) == SGP_SHAPE_MESH ? cast_sphere_mesh(d, j, o, dir, best.t, rs, &n, &p)
+	              : sgd_cast_sphere_body((int)f_shape(f), prm, f_shape(f) == SGP_SHAPE_HULL ? body_hull(d, sh) : nullptr, V3(d.pos_im[j]), quat_to_m33(Q4(d.rot[j])), o, dir, best.t, rs, &n, &p);
 	if (t >= 0.0f && t <= best.t && (t < best.t || best.id == SGP_INVALID_ID || j < best.id)) { best.t = t; best.id = j; best.n = n; }
 }
 

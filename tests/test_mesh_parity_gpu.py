@@ -98,6 +98,12 @@ def test_terrain_and_room_match_oracle(oracle):
     rg_, rc_ = tw.raycast(rays)
     assert np.array_equal(rg_["id"], rc_["id"]) and (rg_["id"] == 0).sum() > 100 and (rg_["id"] == 3).sum() > 5
     assert np.max(np.abs(rg_["t"] - rc_["t"])) <= 1e-4 and np.max(np.abs(rg_["normal"] - rc_["normal"])) <= 1e-5
+    # sphere casts (wheel tester / character sweep) against the meshes and the bodies lying on them
+    radii = rng.choice([0.0, 0.08, 0.3], size=512).astype(np.float32)
+    rays["max_t"] = rng.uniform(2.0, 25.0, size=512)
+    sg_, sc_ = tw.spherecast(rays, radii)
+    assert np.array_equal(sg_["id"], sc_["id"]) and (sg_["id"] == 0).sum() > 60
+    assert np.max(np.abs(sg_["t"] - sc_["t"])) <= 1e-4 and np.max(np.abs(sg_["normal"] - sc_["normal"])) <= 1e-4
     # capsule queries against the meshes (the character controller's CollideShape)
     qy = np.zeros(128, dtype=abi.capsule_query_dtype)
     px = rng.uniform(-12, 12, 128); py = rng.uniform(-12, 12, 128)
@@ -109,4 +115,34 @@ def test_terrain_and_room_match_oracle(oracle):
     assert np.array_equal(cg["query"], cc["query"]) and np.array_equal(cg["body"], cc["body"])
     for f in ("point", "normal", "distance"):
         assert np.max(np.abs(cg[f] - cc[f])) <= 1e-5, f
+    tw.close()
+
+
+def test_car_on_mesh_terrain_matches_oracle(oracle):
+    """A car (hull chassis, four wheel casts per step) driving over a triangulated terrain: wheels find the mesh, GPU == oracle."""
+    from helpers import add_car
+    tw = parity.make_twin(oracle, max_bodies=256)
+    V, T = grid_mesh(41, 40.0, lambda x, y: 0.4 * np.sin(0.3 * x) * np.sin(0.25 * y))
+    ig, ic = tw.mesh_create(V, T)
+    tw.add_batch(mesh_body(ig))
+    ids = []
+    for w in (tw.gpu, tw.cpu):
+        ids.append(add_car(w, pos=(0.0, -20.0, 1.3)))
+    assert ids[0] == ids[1]
+    body, vid = ids[0]
+    for s in range(1, 421):
+        if s == 60:
+            tw.vehicle_set_input(vid, 1.0, 0.0, 0.0, 0.0)
+        if s == 240:
+            tw.vehicle_set_input(vid, 1.0, 0.4, 0.0, 0.0)
+        tw.step(DT)
+        if s % 60 == 0:
+            d = parity.compare(tw, body + 1)
+            assert d["active_mismatch"] == 0 and d["pos"] <= 2e-4 and d["lin_vel"] <= 2e-3, (s, d)
+            vg, vc = tw.vehicle_get_states(vid, 1)
+            assert np.array_equal(vg["wheels"]["contact_body"], vc["wheels"]["contact_body"]) and np.array_equal(vg["wheels"]["angular_velocity"], vc["wheels"]["angular_velocity"])
+    st = tw.gpu.get_state([body])[0]
+    vs = tw.gpu.vehicle_get_state(vid)
+    print("car on terrain: pos", np.round(st["pos"], 2), "bit exact =", d["bit_exact"])
+    assert st["pos"][1] > -10.0 and 0.2 < st["pos"][2] < 2.0 and (vs["wheels"]["contact_body"][:4] == 0).sum() >= 2
     tw.close()
