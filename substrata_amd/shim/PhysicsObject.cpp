@@ -8,6 +8,11 @@ js::AABBox PhysicsShape::getAABBOS() const
 	if (kind == 0) h = Vec4f(p[0], p[0], p[0], 0.f);
 	else if (kind == 1) h = Vec4f(p[0], p[1], p[2], 0.f);
 	else if (kind == 2) h = Vec4f(p[0], p[0], p[0] + p[1], 0.f);
+	else if (kind == 4 && mesh && !mesh->vertices.empty()) {
+		Vec4f mn(1e30f), mx(-1e30f);
+		for (size_t i = 0; i + 2 < mesh->vertices.size(); i += 3) for (int k = 0; k < 3; ++k) { const float c = mesh->vertices[i + k]; if (c < mn[k]) mn[k] = c; if (c > mx[k]) mx[k] = c; }
+		return js::AABBox(setWToOne(mn), setWToOne(mx));
+	}
 	else if (kind == 3 && hull && !hull->points.empty()) {
 		Vec4f mn(1e30f), mx(-1e30f);
 		for (size_t i = 0; i + 2 < hull->points.size(); i += 3) for (int k = 0; k < 3; ++k) { const float c = hull->points[i + k]; if (c < mn[k]) mn[k] = c; if (c > mx[k]) mx[k] = c; }

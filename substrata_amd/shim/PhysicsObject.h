@@ -31,15 +31,26 @@ struct PhysicsHullData
 	std::vector<Instance> instances;
 };
 
+// Triangles of a static mesh shape (what createJoltShapeFor...Mesh(..., is_dynamic = false) hands to JPH::MeshShapeSettings, and the
+// triangulated samples of a height field) plus the device-side meshes built from them, one per (world, object scale).
+struct PhysicsMeshData
+{
+	struct Instance { sgp_world* world; float scale[3]; uint32_t mesh_id; };
+	std::vector<float> vertices;        // xyz, object space, unscaled
+	std::vector<uint32_t> indices;      // 3 per triangle, counter-clockwise = front
+	std::vector<Instance> instances;
+};
+
 class PhysicsShape
 {
 public:
 	PhysicsShape() : kind(-1), size_B(0) { p[0] = p[1] = p[2] = p[3] = 0.f; }
 	js::AABBox getAABBOS() const;
-	int kind;                            // 0 sphere, 1 box, 2 capsule, 3 convex hull (hull != null)
+	int kind;                            // 0 sphere, 1 box, 2 capsule, 3 convex hull (hull != null), 4 static triangle mesh (mesh != null)
 	float p[4];
 	size_t size_B;
 	std::shared_ptr<PhysicsHullData> hull;
+	std::shared_ptr<PhysicsMeshData> mesh;
 };
 
 class PhysicsObject : public ThreadSafeRefCounted

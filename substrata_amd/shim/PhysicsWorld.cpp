@@ -59,6 +59,51 @@ PhysicsShape PhysicsWorld::createConvexHullShape(const std::vector<Vec3f>& point
 	return s;
 }
 
+PhysicsShape PhysicsWorld::createMeshShape(const std::vector<Vec3f>& vertices, const std::vector<uint32>& triangle_indices)
+{
+	if (vertices.size() < 3 || triangle_indices.size() < 3 || triangle_indices.size() % 3 != 0) throw glare::Exception("Error building Jolt shape: a mesh needs vertices and whole triangles");
+	for (size_t i = 0; i < triangle_indices.size(); ++i) if (triangle_indices[i] >= vertices.size()) throw glare::Exception("Error building Jolt shape: triangle index out of range");
+	PhysicsShape s; s.kind = 4;
+	s.mesh = std::make_shared<PhysicsMeshData>();
+	for (size_t i = 0; i < vertices.size(); ++i) { s.mesh->vertices.push_back(vertices[i].x); s.mesh->vertices.push_back(vertices[i].y); s.mesh->vertices.push_back(vertices[i].z); }
+	s.mesh->indices.assign(triangle_indices.begin(), triangle_indices.end());
+	s.size_B = sizeof(PhysicsShape) + s.mesh->vertices.size() * sizeof(float) + s.mesh->indices.size() * sizeof(uint32_t);
+	return s;
+}
+
+PhysicsShape PhysicsWorld::createJoltHeightFieldShape(int vert_res, const std::vector<float>& heightfield, int width, float quad_w)
+{
+	if (width < 2 || vert_res > width || (size_t)width * (size_t)width > heightfield.size()) throw glare::Exception("Error building Jolt heightfield shape: bad sample count");
+	const float z_offset = -quad_w * (float)(width - 1);
+	std::vector<Vec3f> verts; std::vector<uint32> tris;
+	verts.reserve((size_t)width * width);
+	for (int z = 0; z < width; ++z) for (int x = 0; x < width; ++x) verts.push_back(Vec3f(quad_w * (float)x, heightfield[(size_t)z * width + x], quad_w * (float)z + z_offset));
+	for (int z = 0; z + 1 < width; ++z) for (int x = 0; x + 1 < width; ++x) {
+		const uint32 a = (uint32)(z * width + x), b = a + 1, c = a + (uint32)width, d = c + 1;      // a (x,z)  b (x+1,z)  c (x,z+1)  d (x+1,z+1)
+		tris.push_back(a); tris.push_back(c); tris.push_back(d);          // facing +y
+		tris.push_back(a); tris.push_back(d); tris.push_back(b);
+	}
+	return createMeshShape(verts, tris);
+}
+
+static const PhysicsMeshData::Instance* meshInstance(sgp_world* world, const PhysicsShape& shape, const Vec3f& scale)
+{
+	PhysicsMeshData& m = *shape.mesh;
+	for (size_t i = 0; i < m.instances.size(); ++i) {
+		const PhysicsMeshData::Instance& in = m.instances[i];
+		if (in.world == world && in.scale[0] == scale.x && in.scale[1] == scale.y && in.scale[2] == scale.z) return &in;
+	}
+	std::vector<float> v(m.vertices);
+	for (size_t i = 0; i + 2 < v.size(); i += 3) { v[i] *= scale.x; v[i + 1] *= scale.y; v[i + 2] *= scale.z; }
+	std::vector<uint32_t> idx(m.indices);
+	if (scale.x * scale.y * scale.z < 0.f) for (size_t i = 0; i + 2 < idx.size(); i += 3) std::swap(idx[i + 1], idx[i + 2]);      // a mirroring scale turns the triangles inside out
+	sgp_mesh_info info;
+	if (sgp_mesh_create(world, v.data(), (uint32_t)(v.size() / 3), idx.data(), (uint32_t)(idx.size() / 3), &info) != SGP_OK) return nullptr;
+	PhysicsMeshData::Instance in; in.world = world; in.scale[0] = scale.x; in.scale[1] = scale.y; in.scale[2] = scale.z; in.mesh_id = info.mesh_id;
+	m.instances.push_back(in);
+	return &m.instances.back();
+}
+
 PhysicsShape PhysicsWorld::createCOMOffsetShapeForShape(const PhysicsShape& original_shape, const Vec4f& COM_offset)
 {
 	if (original_shape.kind != 3 || !original_shape.hull) throw glare::Exception("Error building Jolt shape: centre-of-mass offsets are implemented for convex hull shapes only");
@@ -134,7 +179,13 @@ void PhysicsWorld::addObject(const Reference<PhysicsObject>& object)
 		const PhysicsShape& s = object->shape;
 		if (s.kind < 0) return;           // shape.jolt_shape == NULL (:1278-1279)
 		d.shape_type = s.kind;
-		if (s.kind == 3) {
+		if (s.kind == 4) {
+			// JPH::MeshShape: static (or kinematic) bodies only -- the reference builds a mesh shape exactly when the object is not dynamic
+			if (d.motion_type != SGP_MOTION_STATIC) return;
+			const PhysicsMeshData::Instance* in = s.mesh ? meshInstance(world, s, object->scale) : nullptr;
+			if (!in) return;
+			d.shape[0] = (float)in->mesh_id; d.shape[1] = d.shape[2] = 0;
+		} else if (s.kind == 3) {
 			const PhysicsHullData::Instance* in = s.hull ? hullInstance(world, s, object->scale) : nullptr;
 			if (!in) return;              // (silent, like every other rejected add)
 			d.shape[0] = (float)in->hull_id; d.shape[1] = d.shape[2] = 0;

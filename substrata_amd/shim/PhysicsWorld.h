@@ -20,6 +20,7 @@ namespace glare { class TaskManager; class StackAllocator; class Allocator; }
 struct sgp_world;
 typedef unsigned char uint8;
 typedef uint64_t uint64;
+typedef uint32_t uint32;
 
 class RayTraceResult
 {
@@ -80,6 +81,12 @@ public:
 	// Throws glare::Exception("Error building Jolt shape: ...") for fewer than 4 points; a degenerate cloud is reported when the
 	// shape is first added to a world.
 	static PhysicsShape createConvexHullShape(const std::vector<Vec3f>& points);
+	// The triangle mesh createJoltShapeForIndigoMesh / createJoltShapeForBatchedMesh build for a static object (PhysicsWorld.cpp:735-1017:
+	// JPH::MeshShapeSettings over the mesh's vertices and triangles); takes the arrays because the mesh containers are glare-core types.
+	static PhysicsShape createMeshShape(const std::vector<Vec3f>& vertices, const std::vector<uint32>& triangle_indices);
+	// PhysicsWorld.cpp:1086-1119: a heightfield.getWidth() x getWidth() grid of heights (row-major, sample (x, z) at [z * width + x]) in Jolt's
+	// y-up shape space: vertex = (quad_w * x, height, quad_w * z - quad_w * (width - 1)); triangulated here (two triangles per cell, facing +y).
+	static PhysicsShape createJoltHeightFieldShape(int vert_res, const std::vector<float>& heightfield, int width, float quad_w);
 	// PhysicsWorld.cpp:1138-1153 (OffsetCenterOfMassShapeSettings); implemented for convex hull shapes.
 	static PhysicsShape createCOMOffsetShapeForShape(const PhysicsShape& original_shape, const Vec4f& COM_offset);
 

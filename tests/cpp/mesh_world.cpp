@@ -1,0 +1,91 @@
+// A small "real world" through the facade: a height-field terrain (createJoltHeightFieldShape, the way TerrainSystem.cpp:1300 builds its
+// chunks; y-up shape space turned upright by the object's rotation), a static mesh building (createMeshShape, what
+// createJoltShapeForBatchedMesh gives a static object), dynamic boxes / spheres / a hull dropped on both, the player walking up the
+// terrain and into the building's wall, rays against the meshes.
+#include <PhysicsWorld.h>
+#include <Jolt/JoltCharacterLite.h>
+#include <utils/Exception.h>
+#include <cstdio>
+#include <cmath>
+
+static float terrainHeight(float x, float y) { return 0.8f * std::sin(0.25f * x) * std::cos(0.2f * y) + 0.05f * x; }
+
+int main()
+{
+	try {
+		PhysicsWorld::init();
+		Reference<PhysicsWorld> world = new PhysicsWorld(nullptr, nullptr);
+		// height field: 64 x 64 samples, 1 m quads.  Shape space (X, height, Z - 63); the object rotation maps y -> z (up), z -> -y,
+		// so world x = X, world y = 63 - Z... = sample z index counted downwards from the object's origin
+		const int W = 64; const float quad_w = 1.0f;
+		std::vector<float> heights((size_t)W * W);
+		for (int z = 0; z < W; ++z) for (int x = 0; x < W; ++x) heights[(size_t)z * W + x] = terrainHeight((float)x * quad_w - 32.f, 31.f - (float)z * quad_w + 0.f);
+		Reference<PhysicsObject> terrain = new PhysicsObject(true, PhysicsWorld::createJoltHeightFieldShape(W, heights, W, quad_w), nullptr, 0);
+		terrain->rot = Quatf::fromAxisAndAngle(Vec4f(1, 0, 0, 0), 1.5707963f);          // y-up shape space -> z-up world
+		terrain->pos = Vec4f(-32.f, -32.f, 0.f, 1);                                      // world x = X - 32, world y = -(Z - 63) - 32 = 31 - z index
+		world->addObject(terrain);
+		// a building: an open box (floor + 4 walls, normals outwards) 6 x 6 x 4 at (10, 10)
+		std::vector<Vec3f> bv; std::vector<uint32> bt;
+		const float h = 3.f, z0 = -2.f, z1 = 6.f;
+		const float cx[4] = { -h, h, h, -h }, cy[4] = { -h, -h, h, h };
+		for (int i = 0; i < 4; ++i) { bv.push_back(Vec3f(cx[i], cy[i], z0)); bv.push_back(Vec3f(cx[i], cy[i], z1)); }
+		for (int i = 0; i < 4; ++i) { const uint32 a = 2 * i, b = 2 * ((i + 1) % 4); bt.push_back(a); bt.push_back(b); bt.push_back(b + 1); bt.push_back(a); bt.push_back(b + 1); bt.push_back(a + 1); }   // outward-facing walls
+		bt.push_back(1); bt.push_back(3); bt.push_back(5); bt.push_back(1); bt.push_back(5); bt.push_back(7);                                                                                          // roof, facing up
+		Reference<PhysicsObject> building = new PhysicsObject(true, PhysicsWorld::createMeshShape(bv, bt), nullptr, 0);
+		building->pos = Vec4f(10.f, 10.f, 0.f, 1);
+		world->addObject(building);
+
+		// things falling on the terrain and on the building's roof
+		std::vector<Reference<PhysicsObject>> obs;
+		for (int i = 0; i < 12; ++i) {
+			Reference<PhysicsObject> ob = new PhysicsObject(true);
+			if (i % 3 == 0) ob->is_sphere = true; else ob->is_cube = true;
+			ob->scale = Vec3f(0.8f); ob->mass = 20.f; ob->motion_type = PhysicsObject::MotionType_dynamic;
+			const float px = (i < 6) ? (-10.f + 3.5f * i) : (8.5f + 0.9f * (i - 6)), py = (i < 6) ? (-6.f + 2.f * i) : 10.f;
+			ob->pos = Vec4f(px, py, (i < 6 ? terrainHeight(px, py) : z1) + 3.f + 0.5f * i, 1);
+			world->addObject(ob); world->activateObject(ob); obs.push_back(ob);
+		}
+		for (int s = 0; s < 420; ++s) world->think(1.0 / 60.0);
+		world->readBackActivatedObjectTransforms();
+		bool ok = true;
+		for (int i = 0; i < 12; ++i) {
+			const Vec4f p = world->getPosInJolt(obs[i]);
+			const float floor_z = (i < 6) ? terrainHeight(p[0], p[1]) : ((std::fabs(p[0] - 10.f) < 3.f && std::fabs(p[1] - 10.f) < 3.f) ? z1 : terrainHeight(p[0], p[1]));
+			const bool fine = p[2] > floor_z + 0.25f && p[2] < floor_z + 1.2f;
+			if (!fine) { printf("object %d at %.2f %.2f %.2f, surface %.2f\n", i, p[0], p[1], p[2], floor_z); ok = false; }
+		}
+		// rays: down onto the terrain, sideways into the building's wall (hit from outside), from inside the building (back faces: no hit on the wall)
+		RayTraceResult r;
+		world->traceRay(Vec4f(-5, 3, 20, 1), Vec4f(0, 0, -1, 0), 100.f, JPH::BodyID(), r);
+		ok = ok && r.hit_object == terrain.ptr() && std::fabs((20.f - r.hit_t) - terrainHeight(-5, 3)) < 0.15f && r.hit_normal_ws[2] > 0.8f;
+		world->traceRay(Vec4f(0, 10, 3, 1), Vec4f(1, 0, 0, 0), 100.f, JPH::BodyID(), r);
+		ok = ok && r.hit_object == building.ptr() && std::fabs(r.hit_t - 7.f) < 1e-3f && r.hit_normal_ws[0] < -0.99f;
+		world->traceRay(Vec4f(10, 10, 3, 1), Vec4f(1, 0, 0, 0), 2.9f, JPH::BodyID(), r);
+		ok = ok && r.hit_object == NULL;
+		printf("rays ok %d\n", (int)ok);
+
+		// the player: starts on the terrain west of the building, walks east (+x, uphill on average) into its wall
+		struct P : public JPH::CharacterContactListener {} listener;
+		JPH::CharRef<JPH::CharacterShape> shape = JPH::RotatedTranslatedShapeSettings(JPH::Vec3(0, 0, 0.65f + 0.3f), JPH::Quat(), new JPH::CapsuleShape(0.65f, 0.3f)).Create().Get();
+		JPH::CharRef<JPH::CharacterVirtualSettings> cs = new JPH::CharacterVirtualSettings();
+		cs->mShape = shape; cs->mUp = JPH::Vec3(0, 0, 1); cs->mSupportingVolume = JPH::Plane(JPH::Vec3(0, 0, 1), -0.3f); cs->mMaxStrength = 1000;
+		JPH::CharacterVirtual player(cs, JPH::Vec3(-8.f, 10.f, terrainHeight(-8.f, 10.f) + 1.5f), JPH::Quat(), world->physics_system);
+		player.SetListener(&listener);
+		JPH::TempAllocator ta; JPH::CharacterVirtual::ExtendedUpdateSettings ext; ext.mStickToFloorStepDown = JPH::Vec3(0, 0, -0.5f); ext.mWalkStairsStepUp = JPH::Vec3(0, 0, 0.4f);
+		float max_err = 0;
+		for (int s = 0; s < 600; ++s) {
+			JPH::Vec3 vel = player.GetLinearVelocity();
+			if (player.IsSupported()) vel = JPH::Vec3(3, 0, 0) + player.GetGroundVelocity(); else vel = vel + JPH::Vec3(3, 0, 0) * (1.f / 60.f);
+			vel = vel + JPH::Vec3(0, 0, -9.81f / 60.f);
+			player.SetLinearVelocity(vel);
+			player.ExtendedUpdate(1.f / 60.f, world->physics_system->GetGravity(), ext, world->physics_system->GetDefaultBroadPhaseLayerFilter(1), world->physics_system->GetDefaultLayerFilter(1), JPH::BodyFilter(), JPH::ShapeFilter(), ta);
+			world->think(1.0 / 60.0);
+			const JPH::Vec3 pp = player.GetPosition();
+			if (s > 60 && player.IsSupported() && pp.x < 6.5f) max_err = std::fmax(max_err, std::fabs(pp.z - terrainHeight(pp.x, pp.y)));
+		}
+		const JPH::Vec3 pp = player.GetPosition();
+		printf("player at %.2f %.2f %.2f (terrain %.2f)  max height error while walking %.3f\n", pp.x, pp.y, pp.z, terrainHeight(pp.x, pp.y), max_err);
+		ok = ok && std::fabs(pp.x - (7.f - 0.3f)) < 0.08f && std::fabs(pp.y - 10.f) < 0.3f && max_err < 0.12f && player.IsSupported();
+		return ok ? 0 : 1;
+	} catch (glare::Exception& e) { fprintf(stderr, "glare::Exception: %s\n", e.what().c_str()); return 2; }
+}

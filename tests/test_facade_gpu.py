@@ -30,6 +30,7 @@ def test_facade_compiles_without_gpu(tmp_path):
     assert os.path.exists(build_facade_exe(tmp_path, "car_controller.cpp"))
     assert os.path.exists(build_facade_exe(tmp_path, "bike_controller.cpp"))
     assert os.path.exists(build_facade_exe(tmp_path, "player_controller.cpp"))
+    assert os.path.exists(build_facade_exe(tmp_path, "mesh_world.cpp"))
 
 
 @pytest.mark.gpu
@@ -67,6 +68,16 @@ def test_player_controller_through_character_virtual(tmp_path):
     """A PlayerPhysics-shaped caller on the JPH::CharacterVirtual look-alike: lands, walks at the commanded speed, takes a 0.3 m step,
     sticks to the floor going down, stops at a wall, jumps, refuses a 66 degree slope, rides a moving platform, pushes a crate."""
     exe = build_facade_exe(tmp_path, "player_controller.cpp")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_mesh_world_through_the_facade(tmp_path):
+    """Height-field terrain + static mesh building built through the facade's shape builders; objects rest on them, rays hit their
+    front faces only, the player follows the terrain and stops at the building's wall."""
+    exe = build_facade_exe(tmp_path, "mesh_world.cpp")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     print(r.stdout)
     assert r.returncode == 0, r.stdout + r.stderr
