@@ -134,6 +134,19 @@ def main():
         elapsed = float(t.item())
     st = w.stats()
 
+    # ---- the application's real loop: every step followed by the read-back of the active bodies' poses ------
+    # (GUIClient walks activated_obs after think(), GUIClient.cpp:6581-6723).  Reported next to the headline, never as `value`.
+    n_rb = min(args.steps, 60)
+    barrier()
+    rb_buf = np.empty(n_bodies + 8, dtype=abi.body_state_dtype)
+    t1 = time.perf_counter()
+    for _ in range(n_rb):
+        one_step()
+        active_states = w.read_active(out=rb_buf)
+    barrier()
+    readback_steps_per_s = n_rb / (time.perf_counter() - t1) if n_rb else 0.0
+    n_read_back = len(active_states) if n_rb else 0
+
     # ---- roofline: HIP events around every launch, same world, steps right after the timed region -----------------
     names = w.kernel_class_names()
     ksum = np.zeros(len(names)); klaunch = np.zeros(len(names)); n_prof = max(1, args.profile_steps)
@@ -181,6 +194,7 @@ def main():
                 "contact_points_end": st.num_contact_points, "colours_end": st.num_colours,
                 "ghosts_exported_per_step": (ex.last_exported if ex else 0), "ghosts_imported_per_step": (ex.last_imported if ex else 0),
                 "dropped_pairs_or_manifolds": st.pairs_dropped + st.manifolds_dropped,
+                "steps_per_s_with_active_pose_readback": readback_steps_per_s * n_gpus, "bodies_read_back_per_step": n_read_back,
             },
             "roofline": {
                 "bound": "hbm", "kernel": "body-array sweep = k_apply_forces + k_integrate_pose + k_finalize (one launch each per step)",

@@ -155,9 +155,13 @@ class CWorld:
         self._check(self._fn("world_read_states")(self._h, int(first), int(n), out.ctypes.data), "world_read_states")
         return out
 
-    def read_active(self, cap=None):
-        cap = self.max_bodies if cap is None else cap
-        out = np.zeros(cap, dtype=abi.body_state_dtype)
+    def read_active(self, cap=None, out=None):
+        """States of the active bodies (the application's per-frame read-back).  `out`: a reusable caller-owned record array."""
+        if out is not None:
+            cap = len(out)
+        else:
+            cap = self.max_bodies if cap is None else cap
+            out = np.zeros(cap, dtype=abi.body_state_dtype)
         n = C.c_uint32(0)
         self._check(self._fn("world_read_active")(self._h, out.ctypes.data, int(cap), C.byref(n)), "world_read_active")
         return out[:min(n.value, cap)]
