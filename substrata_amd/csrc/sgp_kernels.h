@@ -27,6 +27,7 @@
 #define BF_MOVABLE_PREV  (1u << 16)  // movable (dynamic and awake) when the PREVIOUS step coloured its constraints
 #define BF_MOVABLE_CUR   (1u << 17)  // same, this step
 
+#define SGP_ISLAND_MARK_ROUNDS 3   // marking rounds before the island union-find (k_island_mark)
 #define SGP_MAX_COLOURS      64
 #define SGP_OVERFLOW_COLOUR  63
 
@@ -162,6 +163,7 @@ struct DV {
 	uint64_t* claim[2];
 	uint32_t* island;
 	uint32_t* island_awake;
+	uint32_t* awake_mark;      // per body: 1 = sleepy but known to stay awake this step (k_island_mark)
 	float4* sbody;             // per step, 64 B per body (one cache line): [lin vel xyz, EFFECTIVE inverse mass][ang vel xyz, -]
 	                           //   [world inv inertia xx,xy,xz,-][yy,yz,zz,-]; velocities live here during the velocity solve
 	// broad phase
@@ -242,6 +244,7 @@ void launch_solve_tail(const DV& d, int first_colour, int mode, hipStream_t s);
 void launch_solve_small(const DV& d, int warm_start, int iterations, hipStream_t s);
 void launch_integrate_pose(const DV& d, uint32_t nb, hipStream_t s);
 void launch_finalize(const DV& d, uint32_t nb, hipStream_t s);
+void launch_island_mark(const DV& d, uint32_t n_con, hipStream_t s);
 void launch_island_hook(const DV& d, uint32_t n_con, hipStream_t s);
 void launch_island_flag(const DV& d, uint32_t n_con, hipStream_t s);
 void launch_sleep_apply(const DV& d, uint32_t nb, hipStream_t s);

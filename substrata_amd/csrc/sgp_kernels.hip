@@ -1435,6 +1435,7 @@ __global__ void __launch_bounds__(TPB) k_finalize(DV d)
 	if (i >= d.sp->n_slots) return;
 	d.island[i] = i;
 	d.island_awake[i] = 0;
+	d.awake_mark[i] = 0;
 	uint32_t f = d.flags[i];
 	if ((f & (BF_ALIVE | BF_ACTIVE)) != (BF_ALIVE | BF_ACTIVE)) return;
 	const uint32_t type = f_shape(f);
@@ -1492,6 +1493,26 @@ SGP_DEV uint32_t uf_find(const uint32_t* parent, uint32_t x)
 	while (p != x) { x = p; p = parent[x]; }
 	return x;
 }
+// Marking rounds before the union-find.  A sleepy body that touches a movable body which failed the sleep test, or a sleepy body
+// already marked, is certainly awake: k_island_mark propagates that along the constraints for a few rounds (plain stores of 1; a
+// round also sees marks made earlier in the same launch, so a mark usually travels several hops per round).  Every mark is a true
+// "stays awake", so the exact union-find below only has to process what is still unmarked -- in a jittering pile, where awake
+// bodies are spread everywhere, that is almost nothing, instead of one giant component of a hundred thousand sleepy bodies; an island
+// that really is about to sleep, or one whose only awake member is many hops away, still goes through the union-find, which
+// yields the same set of sleepers as before.
+__global__ void __launch_bounds__(TPB) k_island_mark(DV d)
+{
+	const uint32_t n_con = d.ctr->n_constraints;
+	for (uint32_t k = blockIdx.x * TPB + threadIdx.x; k < n_con; k += gridDim.x * TPB) {
+		const uint2 ab = CUR(d).ab[k];
+		const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
+		if (!f_movable(fa) || !f_movable(fb)) continue;
+		const bool ka = !(fa & BF_CAN_SLEEP) || d.awake_mark[ab.x], kb = !(fb & BF_CAN_SLEEP) || d.awake_mark[ab.y];
+		if (ka == kb) continue;
+		d.awake_mark[ka ? ab.y : ab.x] = 1;
+	}
+}
+
 // Island sleeping without building every island: an island sleeps iff all its members pass the sleep test.  Only
 // bodies that pass it ("sleepy") are united (union by smaller root id, ECL-CC style hooking); a sleepy component is kept
 // awake iff one of its members touches a movable body that failed the test.  Same result as uniting whole islands, but
@@ -1504,6 +1525,7 @@ __global__ void __launch_bounds__(TPB) k_island_hook(DV d)
 	const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
 	if (!f_movable(fa) || !f_movable(fb)) continue;
 	if (!(fa & BF_CAN_SLEEP) || !(fb & BF_CAN_SLEEP)) continue;
+	if (d.awake_mark[ab.x] || d.awake_mark[ab.y]) continue;      // a marked body is known to stay awake; flag pass handles the edge
 	uint32_t ra = uf_find(d.island, ab.x), rb = uf_find(d.island, ab.y);
 	while (ra != rb) {
 		const bool a_hi = uf_prio(ra) > uf_prio(rb);
@@ -1522,7 +1544,8 @@ __global__ void __launch_bounds__(TPB) k_island_flag(DV d)
 		const uint2 ab = CUR(d).ab[k];
 		const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
 		if (!f_movable(fa) || !f_movable(fb)) continue;
-		const bool sa = fa & BF_CAN_SLEEP, sb = fb & BF_CAN_SLEEP;
+		// "undecided" = sleepy and not marked awake by k_island_mark; an undecided body next to a decided-awake one keeps its component up
+		const bool sa = (fa & BF_CAN_SLEEP) && !d.awake_mark[ab.x], sb = (fb & BF_CAN_SLEEP) && !d.awake_mark[ab.y];
 		if (sa == sb) continue;
 		d.island_awake[uf_find(d.island, sa ? ab.x : ab.y)] = 1;
 	}
@@ -1535,7 +1558,7 @@ __global__ void __launch_bounds__(TPB) k_sleep_apply(DV d)
 	uint32_t f = d.flags[i];
 	if (!(f & BF_ALIVE)) return;
 	if (f_movable(f)) {
-		if ((f & BF_CAN_SLEEP) && d.island_awake[uf_find(d.island, i)] == 0) {
+		if ((f & BF_CAN_SLEEP) && !d.awake_mark[i] && d.island_awake[uf_find(d.island, i)] == 0) {
 			f &= ~(BF_ACTIVE | BF_CAN_SLEEP);
 			d.flags[i] = f;
 			d.linv[i] = make_float4(0.0f, 0.0f, 0.0f, d.linv[i].w);
@@ -2510,6 +2533,7 @@ void launch_solve_tail(const DV& d, int first_colour, int mode, hipStream_t s) {
 void launch_solve_small(const DV& d, int warm_start, int iterations, hipStream_t s) { hipLaunchKernelGGL(k_solve_small, dim3(1), dim3(512), 0, s, d, warm_start, iterations); }
 void launch_integrate_pose(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_integrate_pose, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_finalize(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_finalize, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
+void launch_island_mark(const DV& d, uint32_t n_con, hipStream_t s) { hipLaunchKernelGGL(k_island_mark, dim3(stride_grid(n_con)), dim3(TPB), 0, s, d); }
 void launch_island_hook(const DV& d, uint32_t n_con, hipStream_t s) { hipLaunchKernelGGL(k_island_hook, dim3(stride_grid(n_con)), dim3(TPB), 0, s, d); }
 void launch_island_flag(const DV& d, uint32_t n_con, hipStream_t s) { hipLaunchKernelGGL(k_island_flag, dim3(stride_grid(n_con)), dim3(TPB), 0, s, d); }
 void launch_sleep_apply(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_sleep_apply, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }

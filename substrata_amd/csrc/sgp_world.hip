@@ -256,7 +256,7 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	for (int k = 0; k < 3; ++k) DEV_ALLOC(d.sleep_s[k], N);
 	DEV_ALLOC(d.sleep_timer, N); DEV_ALLOC(d.submerged, N);
 	DEV_ALLOC(d.colour_mask, N); DEV_ALLOC(d.claim[0], N); DEV_ALLOC(d.claim[1], N);
-	DEV_ALLOC(d.island, N); DEV_ALLOC(d.island_awake, N);
+	DEV_ALLOC(d.island, N); DEV_ALLOC(d.island_awake, N); DEV_ALLOC(d.awake_mark, N);
 	DEV_ALLOC(d.sbody, 4 * (size_t)N);
 	d.table_size = std::max(1024u, next_pow2(2u * N));
 	DEV_ALLOC(d.cell_hash, N);
@@ -834,6 +834,7 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 	STAGE_MARK(7);
 	// -- 8. bounds, sleeping, buoyancy, contact cache
 	{ KScope k(w, KC_FINALIZE); launch_finalize(d, nb, s); }
+	for (int r = 0; r < SGP_ISLAND_MARK_ROUNDS; ++r) { KScope k(w, KC_ISLAND_HOOK); launch_island_mark(d, p.est_man, s); }
 	{ KScope k(w, KC_ISLAND_HOOK); launch_island_hook(d, p.est_man, s); }
 	{ KScope k(w, KC_ISLAND_FLAG); launch_island_flag(d, p.est_man, s); }
 	{ KScope k(w, KC_SLEEP_APPLY); launch_sleep_apply(d, nb, s); }
