@@ -1263,11 +1263,13 @@ SGP_DEV void solve_position_one(const DV& d, uint32_t slot)
 	const float4 nf = CUR(d).n_fric[slot];
 	const v3 nrm = V3(nf);
 	const int np = CUR(d).np_col[slot] & 0xFF;
-	const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
-	float4 pa = d.pos_im[ab.x], pb = d.pos_im[ab.y];
-	const float im1 = f_movable(fa) ? pa.w : 0.0f, im2 = f_movable(fb) ? pb.w : 0.0f;
-	quat qa = Q4(d.rot[ab.x]), qb = Q4(d.rot[ab.y]);
-	const v3 iiA = V3(d.inv_inertia[ab.x]), iiB = V3(d.inv_inertia[ab.y]);
+	// pose half of the solver records (written by k_integrate_pose): one line per body
+	float4* ra = d.sbody + 4 * (size_t)ab.x;
+	float4* rb = d.sbody + 4 * (size_t)ab.y;
+	const float4 pa = ra[0], pb = rb[0];
+	const float im1 = pa.w, im2 = pb.w;                 // effective: 0 unless dynamic and awake
+	quat qa = Q4(ra[1]), qb = Q4(rb[1]);
+	const v3 iiA = V3(ra[2]), iiB = V3(rb[2]);
 	v3 posA = V3(pa), posB = V3(pb);
 	bool moved = false;
 #pragma unroll
@@ -1299,8 +1301,8 @@ SGP_DEV void solve_position_one(const DV& d, uint32_t slot)
 		}
 	}
 	if (moved) {
-		if (im1 > 0.0f) { d.pos_im[ab.x] = F4(posA, pa.w); d.rot[ab.x] = make_float4(qa.x, qa.y, qa.z, qa.w); }
-		if (im2 > 0.0f) { d.pos_im[ab.y] = F4(posB, pb.w); d.rot[ab.y] = make_float4(qb.x, qb.y, qb.z, qb.w); }
+		if (im1 > 0.0f) { ra[0] = F4(posA, pa.w); ra[1] = make_float4(qa.x, qa.y, qa.z, qa.w); }
+		if (im2 > 0.0f) { rb[0] = F4(posB, pb.w); rb[1] = make_float4(qb.x, qb.y, qb.z, qb.w); }
 	}
 }
 
@@ -1407,22 +1409,32 @@ __global__ void __launch_bounds__(TPB) k_integrate_pose(DV d)
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
 	if (i >= d.sp->n_slots) return;
 	const uint32_t f = d.flags[i];
-	if ((f & (BF_ALIVE | BF_ACTIVE)) != (BF_ALIVE | BF_ACTIVE) || f_motion(f) == SGP_MOTION_STATIC) return;
-	// the solved velocities live in the solver record
-	v3 lv = V3(d.sbody[4 * (size_t)i]), av = V3(d.sbody[4 * (size_t)i + 1]);
-	if (f_motion(f) == SGP_MOTION_DYNAMIC) {
-		const float l2 = v3_len_sq(lv), ml = d.st.max_linear_velocity;
-		if (l2 > ml * ml) lv = v3_scale(lv, ml / sqrtf(l2));
-		const float a2 = v3_len_sq(av), ma = d.st.max_angular_velocity;
-		if (a2 > ma * ma) av = v3_scale(av, ma / sqrtf(a2));
+	if (!(f & BF_ALIVE)) return;
+	float4 p = d.pos_im[i], r = d.rot[i];
+	if ((f & BF_ACTIVE) && f_motion(f) != SGP_MOTION_STATIC) {
+		// the solved velocities live in the solver record
+		v3 lv = V3(d.sbody[4 * (size_t)i]), av = V3(d.sbody[4 * (size_t)i + 1]);
+		if (f_motion(f) == SGP_MOTION_DYNAMIC) {
+			const float l2 = v3_len_sq(lv), ml = d.st.max_linear_velocity;
+			if (l2 > ml * ml) lv = v3_scale(lv, ml / sqrtf(l2));
+			const float a2 = v3_len_sq(av), ma = d.st.max_angular_velocity;
+			if (a2 > ma * ma) av = v3_scale(av, ma / sqrtf(a2));
+		}
+		d.linv[i] = F4(lv, d.linv[i].w);
+		d.angv[i] = F4(av, d.angv[i].w);
+		const v3 np = v3_add(V3(p), v3_scale(lv, dt));
+		const quat q = quat_add_rotation_step(Q4(r), v3_scale(av, dt));
+		p = F4(np, p.w);
+		r = make_float4(q.x, q.y, q.z, q.w);
+		d.pos_im[i] = p;
+		d.rot[i] = r;
 	}
-	d.linv[i] = F4(lv, d.linv[i].w);
-	d.angv[i] = F4(av, d.angv[i].w);
-	const float4 p = d.pos_im[i];
-	const v3 np = v3_add(V3(p), v3_scale(lv, dt));
-	const quat q = quat_add_rotation_step(Q4(d.rot[i]), v3_scale(av, dt));
-	d.pos_im[i] = F4(np, p.w);
-	d.rot[i] = make_float4(q.x, q.y, q.z, q.w);
+	// From here to k_finalize the solver record holds the POSE half of the body (the velocities have gone back to their arrays):
+	// [position, effective inverse mass][rotation][local inverse inertia diagonal].  The position iterations gather and update this one
+	// line per body instead of four arrays; k_finalize copies the corrected poses of the movable bodies back.
+	d.sbody[4 * (size_t)i] = make_float4(p.x, p.y, p.z, f_movable(f) ? p.w : 0.0f);
+	d.sbody[4 * (size_t)i + 1] = r;
+	d.sbody[4 * (size_t)i + 2] = d.inv_inertia[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1440,8 +1452,13 @@ __global__ void __launch_bounds__(TPB) k_finalize(DV d)
 	if ((f & (BF_ALIVE | BF_ACTIVE)) != (BF_ALIVE | BF_ACTIVE)) return;
 	const uint32_t type = f_shape(f);
 	const float4 sh = d.shape[i];
-	const v3 pos = V3(d.pos_im[i]);
-	const quat q = Q4(d.rot[i]);
+	float4 p4, r4;
+	if (f_movable(f)) {      // the position iterations corrected the pose in the solver record: write it back
+		p4 = d.sbody[4 * (size_t)i]; r4 = d.sbody[4 * (size_t)i + 1];
+		d.pos_im[i] = p4; d.rot[i] = r4;
+	} else { p4 = d.pos_im[i]; r4 = d.rot[i]; }
+	const v3 pos = V3(p4);
+	const quat q = Q4(r4);
 	v3 mn, mx;
 	compute_aabb(d, type, sh, pos, q, mn, mx);
 	d.aabb_min[i] = F4(mn, 0.0f);
@@ -2312,10 +2329,16 @@ template <int MODE> __global__ void __launch_bounds__(64) k_vehicle_solve(DV d)
 		const float4 p = d.pos_im[b];
 		c.pos = V3(p); c.rot = Q4(d.rot[b]); c.inv_inertia_local = V3(d.inv_inertia[b]);
 		if (MODE == 2) {
+			// between k_integrate_pose and k_finalize the pose being corrected is the one in the solver record (k_finalize copies it back
+			// for movable bodies; anything else keeps its pose arrays authoritative)
+			const bool mv = f_movable(d.flags[b]);
+			if (mv) { c.pos = V3(d.sbody[4 * b + 0]); c.rot = Q4(d.sbody[4 * b + 1]); }
 			c.im = p.w; c.v = V3(0.0f, 0.0f, 0.0f); c.w = c.v; c.I = sym33_zero();
 			sgd_vehicle_solve_position(&sv, &c, d.st.baumgarte);
-			d.pos_im[b] = F4(c.pos, p.w);
-			d.rot[b] = make_float4(c.rot.x, c.rot.y, c.rot.z, c.rot.w);
+			const float4 r4 = make_float4(c.rot.x, c.rot.y, c.rot.z, c.rot.w);
+			if (!mv) { d.pos_im[b] = F4(c.pos, p.w); d.rot[b] = r4; }
+			d.sbody[4 * b + 0] = F4(c.pos, mv ? p.w : 0.0f);
+			d.sbody[4 * b + 1] = r4;
 		} else {
 			const float4 s0 = d.sbody[4 * b + 0], s1 = d.sbody[4 * b + 1], s2 = d.sbody[4 * b + 2], s3 = d.sbody[4 * b + 3];
 			c.v = V3(s0); c.im = s0.w; c.w = V3(s1);

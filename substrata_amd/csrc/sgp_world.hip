@@ -79,7 +79,7 @@ struct sgp_world {
 	uint32_t last_active = 0xFFFFFFFFu;
 	StepParams* h_sp = nullptr; StepParams* d_sp = nullptr;      // pinned host copy / device copy of the per-step scalars
 	std::map<std::string, hipGraphExec_t> graphs;              // replayable launch sequences keyed by launch plan
-	std::string last_plan_key; uint32_t plan_repeats = 0; bool use_graphs = true; bool use_small_world = true;
+	std::string last_plan_key; uint32_t plan_repeats = 0; bool use_graphs = true; bool use_small_world = true; uint32_t tail_threshold = 256;
 	uint32_t graph_launches = 0, eager_steps = 0, idle_steps = 0;
 	bool grid_valid = false;                                   // the broad-phase grid matches the current poses (ray queries reuse it)
 	// static triangle meshes: host-side headers + pools mirrored on the device (grown on demand)
@@ -296,6 +296,7 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	d.sp = w->d_sp;
 	{ const char* e = getenv("SGP_NO_GRAPH"); if (e && e[0] == '1') w->use_graphs = false; }
 	{ const char* e = getenv("SGP_NO_SMALL_WORLD"); if (e && e[0] == '1') w->use_small_world = false; }
+	{ const char* e = getenv("SGP_TAIL_THRESHOLD"); if (e && atoi(e) > 0) w->tail_threshold = (uint32_t)atoi(e); }
 	d.st = desc->settings;
 	d.gx = desc->gravity[0]; d.gy = desc->gravity[1]; d.gz = desc->gravity[2];
 	w->hb.resize(N);
@@ -767,7 +768,7 @@ static void make_plan(const sgp_world* w, StepPlan& p)
 	p.est_pairs = bucket_up(std::max(w->last_pairs + w->last_pairs / 8, 4u * w->high));
 	p.est_man = bucket_up(std::max(w->last_manifolds + w->last_manifolds / 8, 2u * w->high));
 	int tf = 0;
-	while (tf < SGP_OVERFLOW_COLOUR && w->plan_colour_count[tf] > 256u) { p.colour_est[tf] = bucket_up(w->plan_colour_count[tf] + w->plan_colour_count[tf] / 8); ++tf; }
+	while (tf < SGP_OVERFLOW_COLOUR && w->plan_colour_count[tf] > w->tail_threshold) { p.colour_est[tf] = bucket_up(w->plan_colour_count[tf] + w->plan_colour_count[tf] / 8); ++tf; }
 	p.tail_first = tf;
 	p.water = w->h_sp->water_enabled; p.contact_events = w->h_sp->contact_events;
 	p.warm_start = w->dv.st.warm_start; p.vel_iters = w->dv.st.num_velocity_steps; p.pos_iters = w->dv.st.num_position_steps;
