@@ -1308,10 +1308,11 @@ SGP_DEV void solve_position_one(const DV& d, uint32_t slot)
 
 // One launch = one colour of one pass.  The slot range comes from the device-side colour table, so the host never has
 // to know the counts of the current step; the grid is sized from the previous step and the loop strides over the rest.
-template <int MODE> __global__ void __launch_bounds__(TPB) k_solve_colour(DV d, int colour)
+#define SOLVE_TPB 64      // one wave per workgroup: a colour of ~17k constraints then spreads over all 256 CUs instead of 67 of them
+template <int MODE> __global__ void __launch_bounds__(SOLVE_TPB) k_solve_colour(DV d, int colour)
 {
 	const uint32_t first = d.cstarts[colour], end = d.cstarts[colour + 1];
-	for (uint32_t k = first + blockIdx.x * TPB + threadIdx.x; k < end; k += gridDim.x * TPB) {
+	for (uint32_t k = first + blockIdx.x * SOLVE_TPB + threadIdx.x; k < end; k += gridDim.x * SOLVE_TPB) {
 		if (MODE == 0) warm_start_one(d, k);
 		else if (MODE == 1) solve_velocity_one(d, k);
 		else solve_position_one(d, k);
@@ -2546,11 +2547,11 @@ void launch_colour_finish(const DV& d, uint32_t first_round, hipStream_t s) { hi
 void launch_setup(const DV& d, uint32_t n_man, hipStream_t s) { hipLaunchKernelGGL(k_setup, dim3(stride_grid(n_man)), dim3(TPB), 0, s, d); }
 void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStream_t s)
 {
-	uint32_t blocks = blocks_for(est + est / 8 + 64);
-	if (blocks > 2048) blocks = 2048;
-	if (mode == 0) hipLaunchKernelGGL(k_solve_colour<0>, dim3(blocks), dim3(TPB), 0, s, d, colour);
-	else if (mode == 1) hipLaunchKernelGGL(k_solve_colour<1>, dim3(blocks), dim3(TPB), 0, s, d, colour);
-	else hipLaunchKernelGGL(k_solve_colour<2>, dim3(blocks), dim3(TPB), 0, s, d, colour);
+	uint32_t blocks = (est + est / 8 + 64 + SOLVE_TPB - 1) / SOLVE_TPB;
+	if (blocks > 8192) blocks = 8192;
+	if (mode == 0) hipLaunchKernelGGL(k_solve_colour<0>, dim3(blocks), dim3(SOLVE_TPB), 0, s, d, colour);
+	else if (mode == 1) hipLaunchKernelGGL(k_solve_colour<1>, dim3(blocks), dim3(SOLVE_TPB), 0, s, d, colour);
+	else hipLaunchKernelGGL(k_solve_colour<2>, dim3(blocks), dim3(SOLVE_TPB), 0, s, d, colour);
 }
 void launch_solve_tail(const DV& d, int first_colour, int mode, hipStream_t s) { hipLaunchKernelGGL(k_solve_tail, dim3(1), dim3(512), 0, s, d, first_colour, mode); }
 void launch_solve_small(const DV& d, int warm_start, int iterations, hipStream_t s) { hipLaunchKernelGGL(k_solve_small, dim3(1), dim3(512), 0, s, d, warm_start, iterations); }
