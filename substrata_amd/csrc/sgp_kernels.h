@@ -160,6 +160,7 @@ struct DV {
 	float*  sleep_timer;
 	float*  submerged;
 	uint64_t* colour_mask;
+	uint32_t* body_con;        // [body][colour] -> 2 * constraint slot + side, valid where colour_mask[body] has the bit (k_setup)
 	uint64_t* claim[2];
 	uint32_t* island;
 	uint32_t* island_awake;
@@ -238,6 +239,7 @@ void launch_colour_finish(const DV& d, uint32_t first_round, hipStream_t s);
 void launch_setup(const DV& d, uint32_t n_man, hipStream_t s);
 // mode: 0 warm start, 1 velocity iteration, 2 position iteration.  est = expected constraints of that colour (grid sizing only)
 void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStream_t s);
+void launch_warm_bodies(const DV& d, uint32_t nb, hipStream_t s);
 void launch_solve_tail(const DV& d, int first_colour, int mode, hipStream_t s);
 // small worlds: warm start + all velocity iterations in one single-workgroup launch (needs n_slots <= SGP_SMALL_WORLD_BODIES)
 #define SGP_SMALL_WORLD_BODIES 2048

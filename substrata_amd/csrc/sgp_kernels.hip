@@ -1090,6 +1090,12 @@ __global__ void __launch_bounds__(TPB) k_setup(DV d)
 		if (pslot != 0xFFFFFFFFu) pnp = PRV(d).np_col[pslot] & 0xFF;
 		const v3 g = V3(d.gx, d.gy, d.gz);
 		CUR(d).ab[slot] = ab;
+		// (body, colour) -> constraint: a proper colouring gives every movable body at most one constraint per colour, so this
+		// table needs no clearing -- its valid entries are exactly the bits of colour_mask[body] (read by k_warm_bodies)
+		if (col < SGP_OVERFLOW_COLOUR) {
+			if (im1 > 0.0f) d.body_con[(size_t)ab.x * SGP_MAX_COLOURS + col] = slot * 2u;
+			if (im2 > 0.0f) d.body_con[(size_t)ab.y * SGP_MAX_COLOURS + col] = slot * 2u + 1u;
+		}
 		CUR(d).n_fric[slot] = F4(nrm, friction);
 		CUR(d).key[slot] = key;
 		CUR(d).np_col[slot] = np | (col << 8) | ((fslot != 0xFFFFFFFFu ? 1 : 0) << 16);
@@ -1210,6 +1216,56 @@ template <int VS> SGP_DEV void warm_start_one_t(const DV& d, uint32_t slot, floa
 	store_pair_vel<VS>(c, vel);
 }
 SGP_DEV void warm_start_one(const DV& d, uint32_t slot) { warm_start_one_t<4>(d, slot, d.sbody); }
+
+// Warm start, one thread per BODY instead of one launch per colour.  A warm-start impulse depends only on its own constraint (cached
+// lambdas, axes, lever arms) and on the inverse mass / inertia of the body it is applied to -- not on any velocity -- so what the
+// colour-by-colour order does to one body is a fixed sequence of additions: its constraints in ascending colour (a body has at most one
+// per colour), each contributing friction t1, friction t2, normal per point exactly as warm_start_one_t applies them.  This kernel
+// replays that sequence per body from the (body, colour) table written by k_setup; same operations in the same order, hence the same
+// bits, in one launch.  Constraints of the overflow colour come last in the order and are still applied serially by k_solve_tail.
+__global__ void __launch_bounds__(TPB) k_warm_bodies(DV d)
+{
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i >= d.sp->n_slots) return;
+	uint64_t mask = d.colour_mask[i] & ~(1ull << SGP_OVERFLOW_COLOUR);
+	if (!mask) return;
+	float4* rec = d.sbody + 4 * (size_t)i;
+	const float4 v4 = rec[0], w4 = rec[1], a0 = rec[2], a1 = rec[3];
+	const float im = v4.w;
+	if (!(im > 0.0f)) return;
+	sym33 I; I.xx = a0.x; I.xy = a0.y; I.xz = a0.z; I.yy = a1.x; I.yz = a1.y; I.zz = a1.z;
+	v3 lv = V3(v4), av = V3(w4);
+	while (mask) {
+		const int col = __ffsll((long long)mask) - 1;
+		mask &= mask - 1;
+		const uint32_t e = d.body_con[(size_t)i * SGP_MAX_COLOURS + col];
+		const uint32_t slot = e >> 1;
+		const bool second = e & 1u;
+		const float4 nf = CUR(d).n_fric[slot];
+		const int np = CUR(d).np_col[slot] & 0xFF;
+		const v3 n = V3(nf);
+		const v3 t1 = v3_normalized_perpendicular(n);
+		const v3 t2 = v3_cross(n, t1);
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			if (k < np) {
+				const v3 r = second ? V3(CUR(d).r2e[k][slot]) : V3(CUR(d).r1b[k][slot]);
+				const float4 l = CUR(d).lam[k][slot];
+				// apply_impulse, one side: body 1 subtracts, body 2 adds
+				if (nf.w > 0.0f) {
+					if (second) { lv = v3_add(lv, v3_scale(t1, l.y * im)); av = v3_add(av, v3_scale(sym33_mul(I, v3_cross(r, t1)), l.y)); }
+					else        { lv = v3_sub(lv, v3_scale(t1, l.y * im)); av = v3_sub(av, v3_scale(sym33_mul(I, v3_cross(r, t1)), l.y)); }
+					if (second) { lv = v3_add(lv, v3_scale(t2, l.z * im)); av = v3_add(av, v3_scale(sym33_mul(I, v3_cross(r, t2)), l.z)); }
+					else        { lv = v3_sub(lv, v3_scale(t2, l.z * im)); av = v3_sub(av, v3_scale(sym33_mul(I, v3_cross(r, t2)), l.z)); }
+				}
+				if (second) { lv = v3_add(lv, v3_scale(n, l.x * im)); av = v3_add(av, v3_scale(sym33_mul(I, v3_cross(r, n)), l.x)); }
+				else        { lv = v3_sub(lv, v3_scale(n, l.x * im)); av = v3_sub(av, v3_scale(sym33_mul(I, v3_cross(r, n)), l.x)); }
+			}
+		}
+	}
+	rec[0] = F4(lv, im);
+	rec[1] = F4(av, 0.0f);
+}
 
 // One contact manifold, one velocity iteration (ContactConstraintManager::SolveVelocityConstraints): friction rows of
 // every point first (they use the normal impulse of the previous iteration), then the non-penetration rows.
@@ -2553,6 +2609,7 @@ void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStr
 	else if (mode == 1) hipLaunchKernelGGL(k_solve_colour<1>, dim3(blocks), dim3(SOLVE_TPB), 0, s, d, colour);
 	else hipLaunchKernelGGL(k_solve_colour<2>, dim3(blocks), dim3(SOLVE_TPB), 0, s, d, colour);
 }
+void launch_warm_bodies(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_warm_bodies, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_solve_tail(const DV& d, int first_colour, int mode, hipStream_t s) { hipLaunchKernelGGL(k_solve_tail, dim3(1), dim3(512), 0, s, d, first_colour, mode); }
 void launch_solve_small(const DV& d, int warm_start, int iterations, hipStream_t s) { hipLaunchKernelGGL(k_solve_small, dim3(1), dim3(512), 0, s, d, warm_start, iterations); }
 void launch_integrate_pose(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_integrate_pose, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }

@@ -255,7 +255,7 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	DEV_ALLOC(d.flags, N); DEV_ALLOC(d.aabb_min, N); DEV_ALLOC(d.aabb_max, N);
 	for (int k = 0; k < 3; ++k) DEV_ALLOC(d.sleep_s[k], N);
 	DEV_ALLOC(d.sleep_timer, N); DEV_ALLOC(d.submerged, N);
-	DEV_ALLOC(d.colour_mask, N); DEV_ALLOC(d.claim[0], N); DEV_ALLOC(d.claim[1], N);
+	DEV_ALLOC(d.colour_mask, N); DEV_ALLOC(d.body_con, (size_t)N * SGP_MAX_COLOURS); DEV_ALLOC(d.claim[0], N); DEV_ALLOC(d.claim[1], N);
 	DEV_ALLOC(d.island, N); DEV_ALLOC(d.island_awake, N); DEV_ALLOC(d.awake_mark, N);
 	DEV_ALLOC(d.sbody, 4 * (size_t)N);
 	d.table_size = std::max(1024u, next_pow2(2u * N));
@@ -823,7 +823,12 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 	};
 	if (p.small_world) { KScope k(w, KC_SOLVE_VELOCITY); launch_solve_small(d, p.warm_start, p.vel_iters, s); }
 	else {
-		if (p.warm_start) solve_pass(0, KC_WARM_START);
+		if (p.warm_start) {
+			// vehicle rows first, then every contact constraint of the regular colours (one launch, by body), then the overflow colour
+			if (p.n_vehicles) { KScope k(w, KC_VEHICLE); launch_vehicle_solve(d, 0, s); }
+			{ KScope k(w, KC_WARM_START); launch_warm_bodies(d, nb, s); }
+			{ KScope k(w, KC_WARM_START); launch_solve_tail(d, SGP_OVERFLOW_COLOUR, 0, s); }
+		}
 		for (int it = 0; it < p.vel_iters; ++it) solve_pass(1, KC_SOLVE_VELOCITY);
 	}
 	STAGE_MARK(5);
