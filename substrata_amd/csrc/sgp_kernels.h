@@ -27,6 +27,7 @@
 #define BF_MOVABLE_PREV  (1u << 16)  // movable (dynamic and awake) when the PREVIOUS step coloured its constraints
 #define BF_MOVABLE_CUR   (1u << 17)  // same, this step
 
+#define SGP_SMALL_COLOURING_MANIFOLDS 4096   // at most this many manifolds last step: colouring rounds run inside one workgroup
 #define SGP_ISLAND_MARK_ROUNDS 3   // marking rounds before the island union-find (k_island_mark)
 #define SGP_MAX_COLOURS      64
 #define SGP_OVERFLOW_COLOUR  63
@@ -188,6 +189,8 @@ struct DV {
 	uint32_t* ulist[2];        // worklists of still-uncoloured manifolds, double buffered by round parity
 	uint64_t* man_prio;
 	// constraints
+	float4* rows;              // velocity-iteration rows, [point 0..3][axis n,t1,t2][4][cap_manifolds] (k_setup): r1 x axis (w: bias for n),
+	                           //   r2 x axis (w: effective mass of the axis), I1 (r1 x axis), I2 (r2 x axis)
 	ConstraintArrays ca[2];    // [sp->parity] = this step's constraints, the other = previous step's (contact cache)
 	uint64_t* ht_keys; uint32_t* ht_vals; uint32_t ht_size;   // contact cache: pair key -> prev slot
 	uint32_t* cstarts;         // [SGP_MAX_COLOURS + 1] first constraint slot of every colour (device-side exclusive scan)
@@ -235,10 +238,11 @@ void launch_colour_inherit(const DV& d, uint32_t n_man, hipStream_t s);
 void launch_colour_claim(const DV& d, uint32_t n_man, uint32_t round, hipStream_t s);
 void launch_colour_commit(const DV& d, uint32_t n_man, uint32_t round, hipStream_t s);
 void launch_colour_count(const DV& d, uint32_t n_man, hipStream_t s);
-void launch_colour_finish(const DV& d, uint32_t first_round, hipStream_t s);
+void launch_colour_finish(const DV& d, uint32_t first_round, int build_list, hipStream_t s);
 void launch_setup(const DV& d, uint32_t n_man, hipStream_t s);
 // mode: 0 warm start, 1 velocity iteration, 2 position iteration.  est = expected constraints of that colour (grid sizing only)
 void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStream_t s);
+void launch_solve_probe(const DV& d, int variant, int colour, uint32_t est, hipStream_t s);
 void launch_warm_bodies(const DV& d, uint32_t nb, hipStream_t s);
 void launch_solve_tail(const DV& d, int first_colour, int mode, hipStream_t s);
 // small worlds: warm start + all velocity iterations in one single-workgroup launch (needs n_slots <= SGP_SMALL_WORLD_BODIES)

@@ -954,8 +954,18 @@ __global__ void __launch_bounds__(TPB) k_colour_count(DV d)
 
 // Catch-all: if the planned number of rounds left manifolds uncoloured, ONE workgroup finishes the job with workgroup
 // barriers between the phases (same algorithm, same result; only reached when the plan from the previous step was short).
-__global__ void __launch_bounds__(1024) k_colour_finish(DV d, uint32_t first_round)
+__global__ void __launch_bounds__(1024) k_colour_finish(DV d, uint32_t first_round, int build_list)
 {
+	// small worlds skip the per-round launches altogether: this workgroup collects the manifolds that did not inherit a colour and runs
+	// every round itself (same algorithm, same colours: the outcome of a round does not depend on the order of the worklist)
+	if (build_list) {
+		if (threadIdx.x == 0) d.ctr->ucount[first_round & 1] = 0;
+		__syncthreads();
+		const uint32_t nm = min(d.ctr->n_manifolds, d.cap_manifolds);
+		for (uint32_t m = threadIdx.x; m < nm; m += 1024) if (d.man_colour[m] == -1) d.ulist[first_round & 1][atomicAdd(&d.ctr->ucount[first_round & 1], 1u)] = m;
+		__threadfence();
+		__syncthreads();
+	}
 	for (uint32_t round = first_round; round < first_round + 4096u; ++round) {
 		const uint32_t par = round & 1;
 		const uint32_t n = d.ctr->ucount[par];
@@ -1028,6 +1038,19 @@ SGP_DEV float axis_eff_mass(float im1, const sym33& I1, v3 r1, float im2, const 
 	if (im1 > 0.0f) { const v3 c = v3_cross(r1, axis); inv = im1 + v3_dot(sym33_mul(I1, c), c); }
 	if (im2 > 0.0f) { const v3 c = v3_cross(r2, axis); inv = inv + (im2 + v3_dot(sym33_mul(I2, c), c)); }
 	return inv > 0.0f ? 1.0f / inv : 0.0f;
+}
+
+// rows of one (point, axis) for the velocity iterations: the two lever-arm cross products and their inverse-inertia images
+SGP_DEV float4* axis_rows(const DV& d, uint32_t slot, int point, int axis) { return d.rows + (size_t)((point * 3 + axis) * 4) * d.cap_manifolds + slot; }
+SGP_DEV void write_axis_rows(const DV& d, uint32_t slot, int point, int axis, v3 r1, v3 r2, v3 a, const sym33& I1, const sym33& I2, float w0, float w1)
+{
+	const v3 c1 = v3_cross(r1, a), c2 = v3_cross(r2, a);
+	float4* p = axis_rows(d, slot, point, axis);
+	const size_t st = d.cap_manifolds;
+	p[0] = F4(c1, w0);
+	p[st] = F4(c2, w1);
+	p[2 * st] = F4(sym33_mul(I1, c1), 0.0f);
+	p[3 * st] = F4(sym33_mul(I2, c2), 0.0f);
 }
 
 SGP_DEV uint32_t ht_hash(uint64_t key, uint32_t mask) { return (uint32_t)(sgp_mix64(key) >> 20) & mask; }
@@ -1135,6 +1158,10 @@ __global__ void __launch_bounds__(TPB) k_setup(DV d)
 			const float eff_n = axis_eff_mass(im1, I1, r1, im2, I2, r2, nrm);
 			const float eff_t1 = axis_eff_mass(im1, I1, r1, im2, I2, r2, t1);
 			const float eff_t2 = axis_eff_mass(im1, I1, r1, im2, I2, r2, t2);
+			// what every velocity iteration would otherwise recompute per axis (Jolt's AxisConstraintPart keeps the same products)
+			write_axis_rows(d, slot, i, 0, r1, r2, nrm, I1, I2, bias, eff_n);
+			write_axis_rows(d, slot, i, 1, r1, r2, t1, I1, I2, 0.0f, eff_t1);
+			write_axis_rows(d, slot, i, 2, r1, r2, t2, I1, I2, 0.0f, eff_t2);
 			CUR(d).r1b[i][slot] = F4(r1, bias);
 			CUR(d).r2e[i][slot] = F4(r2, eff_n);
 			CUR(d).lam[i][slot] = make_float4(lam_n, lam_t1, lam_t2, 0.0f);
@@ -1269,47 +1296,85 @@ __global__ void __launch_bounds__(TPB) k_warm_bodies(DV d)
 
 // One contact manifold, one velocity iteration (ContactConstraintManager::SolveVelocityConstraints): friction rows of
 // every point first (they use the normal impulse of the previous iteration), then the non-penetration rows.
-// All per-point state is held in registers: loops are fully unrolled with predicates (no runtime-indexed arrays).
+// The lever-arm products of every (point, axis) come precomputed from k_setup (axis_rows); they are the very values the expressions
+// cross(r, axis) and I (r x axis) would yield here, so the arithmetic -- and every bit of the result -- is that of the plain
+// formulation (apply_impulse / axis_jv above, which the warm start and the oracle use), at less than half the instructions.
+struct AxisRows { float4 c1, c2, i1, i2; };      // r1 x axis (w: bias), r2 x axis (w: effective mass), I1 (r1 x axis), I2 (r2 x axis)
+
+SGP_DEV AxisRows load_axis_rows(const DV& d, uint32_t slot, int point, int axis)
+{
+	const float4* p = axis_rows(d, slot, point, axis);
+	const size_t st = d.cap_manifolds;
+	AxisRows r; r.c1 = p[0]; r.c2 = p[st]; r.i1 = p[2 * st]; r.i2 = p[3 * st];
+	return r;
+}
+
+SGP_DEV float rows_jv(const BodyVel& A, const BodyVel& B, v3 axis, const AxisRows& r)
+{
+	return v3_dot(axis, v3_sub(A.lv, B.lv)) + v3_dot(V3(r.c1), A.av) - v3_dot(V3(r.c2), B.av);
+}
+
+SGP_DEV void rows_apply(BodyVel& A, BodyVel& B, float im1, float im2, v3 axis, const AxisRows& r, float lambda)
+{
+	if (im1 > 0.0f) {
+		A.lv = v3_sub(A.lv, v3_scale(axis, lambda * im1));
+		A.av = v3_sub(A.av, v3_scale(V3(r.i1), lambda));
+	}
+	if (im2 > 0.0f) {
+		B.lv = v3_add(B.lv, v3_scale(axis, lambda * im2));
+		B.av = v3_add(B.av, v3_scale(V3(r.i2), lambda));
+	}
+}
+
 template <int VS> SGP_DEV void solve_velocity_one_t(const DV& d, uint32_t slot, float4* vel)
 {
-	PairCtx c;
-	load_pair<VS>(d, slot, c, vel);
-	float4 r1b[4], r2e[4], lam[4]; float2 et[4];
+	const uint2 ab = CUR(d).ab[slot];
+	const float4 nf = CUR(d).n_fric[slot];
+	const int np = CUR(d).np_col[slot] & 0xFF;
+	const float4 va = vel[VS * (size_t)ab.x], wa = vel[VS * (size_t)ab.x + 1];
+	const float4 vb = vel[VS * (size_t)ab.y], wb = vel[VS * (size_t)ab.y + 1];
+	AxisRows rn[4], rt1[4], rt2[4]; float4 lam[4];
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
-		if (i < c.np) { r1b[i] = CUR(d).r1b[i][slot]; r2e[i] = CUR(d).r2e[i][slot]; lam[i] = CUR(d).lam[i][slot]; et[i] = CUR(d).efft[i][slot]; }
+		if (i < np) {
+			rn[i] = load_axis_rows(d, slot, i, 0); rt1[i] = load_axis_rows(d, slot, i, 1); rt2[i] = load_axis_rows(d, slot, i, 2);
+			lam[i] = CUR(d).lam[i][slot];
+		}
 	}
-	c.t1 = v3_normalized_perpendicular(c.n);
-	c.t2 = v3_cross(c.n, c.t1);
-	if (c.friction > 0.0f) {
+	const float im1 = va.w, im2 = vb.w, friction = nf.w;
+	BodyVel A, B;
+	A.lv = V3(va); A.av = V3(wa); B.lv = V3(vb); B.av = V3(wb);
+	const v3 n = V3(nf);
+	const v3 t1 = v3_normalized_perpendicular(n);
+	const v3 t2 = v3_cross(n, t1);
+	if (friction > 0.0f) {
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
-			if (i < c.np && !(et[i].x <= 0.0f && et[i].y <= 0.0f)) {
-				const v3 r1 = V3(r1b[i]), r2 = V3(r2e[i]);
-				float l1 = lam[i].y + et[i].x * axis_jv(c.A, c.B, r1, r2, c.t1);
-				float l2 = lam[i].z + et[i].y * axis_jv(c.A, c.B, r1, r2, c.t2);
-				const float max_f = c.friction * lam[i].x;
+			if (i < np && !(rt1[i].c2.w <= 0.0f && rt2[i].c2.w <= 0.0f)) {
+				float l1 = lam[i].y + rt1[i].c2.w * rows_jv(A, B, t1, rt1[i]);
+				float l2 = lam[i].z + rt2[i].c2.w * rows_jv(A, B, t2, rt2[i]);
+				const float max_f = friction * lam[i].x;
 				const float tot_sq = l1 * l1 + l2 * l2;
 				if (tot_sq > max_f * max_f) { const float sc = max_f / sqrtf(tot_sq); l1 = l1 * sc; l2 = l2 * sc; }
-				apply_impulse(c.A, c.B, c.im1, c.I1, c.im2, c.I2, r1, r2, c.t1, l1 - lam[i].y); lam[i].y = l1;
-				apply_impulse(c.A, c.B, c.im1, c.I1, c.im2, c.I2, r1, r2, c.t2, l2 - lam[i].z); lam[i].z = l2;
+				rows_apply(A, B, im1, im2, t1, rt1[i], l1 - lam[i].y); lam[i].y = l1;
+				rows_apply(A, B, im1, im2, t2, rt2[i], l2 - lam[i].z); lam[i].z = l2;
 			}
 		}
 	}
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
-		if (i < c.np && r2e[i].w > 0.0f) {
-			const v3 r1 = V3(r1b[i]), r2 = V3(r2e[i]);
-			const float jv = axis_jv(c.A, c.B, r1, r2, c.n);
-			const float lambda = r2e[i].w * (jv - r1b[i].w);
+		if (i < np && rn[i].c2.w > 0.0f) {
+			const float jv = rows_jv(A, B, n, rn[i]);
+			const float lambda = rn[i].c2.w * (jv - rn[i].c1.w);
 			const float nl = fmaxf(lam[i].x + lambda, 0.0f);
-			apply_impulse(c.A, c.B, c.im1, c.I1, c.im2, c.I2, r1, r2, c.n, nl - lam[i].x);
+			rows_apply(A, B, im1, im2, n, rn[i], nl - lam[i].x);
 			lam[i].x = nl;
 		}
 	}
 #pragma unroll
-	for (int i = 0; i < 4; ++i) { if (i < c.np) CUR(d).lam[i][slot] = lam[i]; }
-	store_pair_vel<VS>(c, vel);
+	for (int i = 0; i < 4; ++i) { if (i < np) CUR(d).lam[i][slot] = lam[i]; }
+	if (im1 > 0.0f) { vel[VS * (size_t)ab.x] = F4(A.lv, im1); vel[VS * (size_t)ab.x + 1] = F4(A.av, 0.0f); }
+	if (im2 > 0.0f) { vel[VS * (size_t)ab.y] = F4(B.lv, im2); vel[VS * (size_t)ab.y + 1] = F4(B.av, 0.0f); }
 }
 SGP_DEV void solve_velocity_one(const DV& d, uint32_t slot) { solve_velocity_one_t<4>(d, slot, d.sbody); }
 
@@ -1373,6 +1438,43 @@ template <int MODE> __global__ void __launch_bounds__(SOLVE_TPB) k_solve_colour(
 		else if (MODE == 1) solve_velocity_one(d, k);
 		else solve_position_one(d, k);
 	}
+}
+
+// Timing probe (not part of the step; sgp_debug_time_solve, tools/solve_probe.py): the velocity-iteration launch of one colour with parts
+// of its body removed, to see where a launch's time goes.  V0 full; V1 every load and store but no row arithmetic; V2 the header and the
+// two body records only; V3 the colour range only.
+template <int V> __global__ void __launch_bounds__(SOLVE_TPB) k_solve_probe(DV d, int colour)
+{
+	const uint32_t first = d.cstarts[colour], end = d.cstarts[colour + 1];
+	for (uint32_t k = first + blockIdx.x * SOLVE_TPB + threadIdx.x; k < end; k += gridDim.x * SOLVE_TPB) {
+		if (V == 0) solve_velocity_one(d, k);
+		else if (V == 1) {
+			PairCtx c;
+			load_pair<4>(d, k, c, d.sbody);
+			float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+			for (int i = 0; i < 4; ++i) if (i < c.np) {
+				const float4 a = CUR(d).r1b[i][k], b = CUR(d).r2e[i][k], l = CUR(d).lam[i][k]; const float2 e = CUR(d).efft[i][k];
+				acc.x += a.x + b.x + l.x + e.x;
+				CUR(d).lam[i][k] = l;
+			}
+			if (acc.x == 12345.678f) c.A.lv.x += 1.0f;
+			store_pair_vel<4>(c, d.sbody);
+		} else if (V == 2) {
+			PairCtx c;
+			load_pair<4>(d, k, c, d.sbody);
+			store_pair_vel<4>(c, d.sbody);
+		}
+	}
+}
+void launch_solve_probe(const DV& d, int variant, int colour, uint32_t est, hipStream_t s)
+{
+	uint32_t blocks = (est + est / 8 + 64 + SOLVE_TPB - 1) / SOLVE_TPB;
+	if (blocks > 8192) blocks = 8192;
+	if (variant == 0) hipLaunchKernelGGL(k_solve_probe<0>, dim3(blocks), dim3(SOLVE_TPB), 0, s, d, colour);
+	else if (variant == 1) hipLaunchKernelGGL(k_solve_probe<1>, dim3(blocks), dim3(SOLVE_TPB), 0, s, d, colour);
+	else if (variant == 2) hipLaunchKernelGGL(k_solve_probe<2>, dim3(blocks), dim3(SOLVE_TPB), 0, s, d, colour);
+	else hipLaunchKernelGGL(k_solve_probe<3>, dim3(blocks), dim3(SOLVE_TPB), 0, s, d, colour);
 }
 
 // Tail colours (few constraints each) share ONE launch: a single 512-thread workgroup walks colours first_colour..62 in
@@ -2599,7 +2701,7 @@ void launch_colour_count(const DV& d, uint32_t est, hipStream_t s)
 	hipLaunchKernelGGL(k_colour_count, dim3(stride_grid(est)), dim3(TPB), 0, s, d);
 	hipLaunchKernelGGL(k_colour_scan, dim3(1), dim3(64), 0, s, d);
 }
-void launch_colour_finish(const DV& d, uint32_t first_round, hipStream_t s) { hipLaunchKernelGGL(k_colour_finish, dim3(1), dim3(1024), 0, s, d, first_round); }
+void launch_colour_finish(const DV& d, uint32_t first_round, int build_list, hipStream_t s) { hipLaunchKernelGGL(k_colour_finish, dim3(1), dim3(1024), 0, s, d, first_round, build_list); }
 void launch_setup(const DV& d, uint32_t n_man, hipStream_t s) { hipLaunchKernelGGL(k_setup, dim3(stride_grid(n_man)), dim3(TPB), 0, s, d); }
 void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStream_t s)
 {

@@ -277,6 +277,7 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	DEV_ALLOC(d.man_ab, M); DEV_ALLOC(d.man_n, M); DEV_ALLOC(d.man_colour, M); DEV_ALLOC(d.man_prio, M);
 	DEV_ALLOC(d.ulist[0], M); DEV_ALLOC(d.ulist[1], M);
 	for (int k = 0; k < 4; ++k) { DEV_ALLOC(d.man_p1[k], M); DEV_ALLOC(d.man_p2[k], M); }
+	DEV_ALLOC(d.rows, (size_t)48 * M);
 	{ int r = alloc_constraints(w, d.ca[0], M); if (r != SGP_OK) return r; }
 	{ int r = alloc_constraints(w, d.ca[1], M); if (r != SGP_OK) return r; }
 	w->ht_alloc = next_pow2(2u * M);
@@ -756,6 +757,7 @@ struct StepPlan {
 	uint32_t n_vehicles;
 	int      has_meshes;         // some body may be a static triangle mesh: run the mesh-pair narrow phase
 	int      has_hulls;          // some body may be a convex hull: run the hull-pair narrow phase
+	int      small_colouring;    // the whole colouring in one single-workgroup launch (k_colour_finish builds its own worklist)
 	int      small_world;        // warm start + velocity iterations as ONE single-workgroup launch (k_solve_small)
 	StepParams sp;               // by-value kernel argument of the first launch: part of the key of a captured graph
 };
@@ -775,6 +777,7 @@ static void make_plan(const sgp_world* w, StepPlan& p)
 	p.n_vehicles = w->n_vehicles;
 	p.has_hulls = w->hulls.size() > 1 ? 1 : 0;
 	p.has_meshes = w->meshes.size() > 1 ? 1 : 0;
+	p.small_colouring = (w->last_manifolds <= SGP_SMALL_COLOURING_MANIFOLDS && w->high <= SGP_SMALL_WORLD_BODIES) ? 1 : 0;
 	p.small_world = (tf == 0 && w->high <= SGP_SMALL_WORLD_BODIES && w->n_vehicles == 0 && w->use_small_world) ? 1 : 0;
 	p.sp = *w->h_sp;
 }
@@ -805,13 +808,18 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 	STAGE_MARK(3);
 	// -- 4. colouring + constraint setup
 	{ KScope k(w, KC_COLOUR_CLAIM); launch_colour_inherit(d, p.est_man, s); }
-	uint32_t est_unc = p.est_man;
-	for (uint32_t round = 0; round < p.rounds; ++round) {
-		{ KScope k(w, KC_COLOUR_CLAIM); launch_colour_claim(d, est_unc, round, s); }
-		{ KScope k(w, KC_COLOUR_COMMIT); launch_colour_commit(d, est_unc, round, s); }
-		if (round >= 1) est_unc = std::max(est_unc - est_unc / 4, 8192u);      // worklists shrink; kernels grid-stride over the rest
+	if (p.small_colouring) {
+		// few manifolds: one workgroup runs every colouring round (no per-round launches)
+		KScope k(w, KC_COLOUR_COMMIT); launch_colour_finish(d, 0, 1, s);
+	} else {
+		uint32_t est_unc = p.est_man;
+		for (uint32_t round = 0; round < p.rounds; ++round) {
+			{ KScope k(w, KC_COLOUR_CLAIM); launch_colour_claim(d, est_unc, round, s); }
+			{ KScope k(w, KC_COLOUR_COMMIT); launch_colour_commit(d, est_unc, round, s); }
+			if (round >= 1) est_unc = std::max(est_unc - est_unc / 4, 8192u);      // worklists shrink; kernels grid-stride over the rest
+		}
+		{ KScope k(w, KC_COLOUR_COMMIT); launch_colour_finish(d, p.rounds, 0, s); }
 	}
-	{ KScope k(w, KC_COLOUR_COMMIT); launch_colour_finish(d, p.rounds, s); }
 	{ KScope k(w, KC_COLOUR_COUNT); launch_colour_count(d, p.est_man, s); }
 	{ KScope k(w, KC_SETUP); launch_setup(d, p.est_man, s); }
 	STAGE_MARK(4);
@@ -985,6 +993,26 @@ SGP_API int sgp_world_step_profiled(sgp_world* w, float dt, sgp_step_profile* ou
 	out->num_constraints = w->stats.num_manifolds;
 	out->num_contact_points = w->stats.num_contact_points;
 	out->num_colours = w->stats.num_colours;
+	return SGP_OK;
+}
+
+// Timing probe (tools/solve_probe.py; not declared in include/sgp.h): average time of `reps` back-to-back launches of the velocity
+// iteration of one colour, full (variant 0) or with parts removed (see k_solve_probe).  Leaves the velocities of the world perturbed.
+SGP_API int sgp_debug_time_solve(sgp_world* w, int variant, int colour, int reps, float* us_out, uint32_t* count_out)
+{
+	if (!w || !us_out || colour < 0 || colour >= SGP_OVERFLOW_COLOUR) return fail(SGP_ERR_INVALID, "sgp_debug_time_solve");
+	hipSetDevice(w->device);
+	hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+	const uint32_t est = w->plan_colour_count[colour];
+	for (int r = 0; r < 3; ++r) launch_solve_probe(w->dv, variant, colour, est, w->stream);
+	HIP_TRY(hipEventRecord(e0, w->stream));
+	for (int r = 0; r < reps; ++r) launch_solve_probe(w->dv, variant, colour, est, w->stream);
+	HIP_TRY(hipEventRecord(e1, w->stream));
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	float ms = 0.0f; HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+	hipEventDestroy(e0); hipEventDestroy(e1);
+	*us_out = 1000.0f * ms / (float)reps;
+	if (count_out) *count_out = est;
 	return SGP_OK;
 }
 
