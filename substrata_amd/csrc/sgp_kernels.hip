@@ -1326,55 +1326,79 @@ SGP_DEV void rows_apply(BodyVel& A, BodyVel& B, float im1, float im2, v3 axis, c
 	}
 }
 
-template <int VS> SGP_DEV void solve_velocity_one_t(const DV& d, uint32_t slot, float4* vel)
+// A constraint held in registers: loaded once (con_load), iterated any number of times (con_solve_velocity: only the two bodies'
+// velocities are gathered and scattered), lambdas written back at the end (con_store).  solve_velocity_one_t is the three in a row; the
+// single-workgroup kernels (tail colours, small worlds) keep the record across their colour phases / iterations instead of re-reading it.
+struct ConReg { uint2 ab; float4 nf; int np_col; AxisRows rn[4], rt1[4], rt2[4]; float4 lam[4]; };
+
+SGP_DEV void con_load(const DV& d, uint32_t slot, ConReg& r)
 {
-	const uint2 ab = CUR(d).ab[slot];
-	const float4 nf = CUR(d).n_fric[slot];
-	const int np = CUR(d).np_col[slot] & 0xFF;
-	const float4 va = vel[VS * (size_t)ab.x], wa = vel[VS * (size_t)ab.x + 1];
-	const float4 vb = vel[VS * (size_t)ab.y], wb = vel[VS * (size_t)ab.y + 1];
-	AxisRows rn[4], rt1[4], rt2[4]; float4 lam[4];
+	r.ab = CUR(d).ab[slot];
+	r.nf = CUR(d).n_fric[slot];
+	r.np_col = CUR(d).np_col[slot];
+	const int np = r.np_col & 0xFF;
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
 		if (i < np) {
-			rn[i] = load_axis_rows(d, slot, i, 0); rt1[i] = load_axis_rows(d, slot, i, 1); rt2[i] = load_axis_rows(d, slot, i, 2);
-			lam[i] = CUR(d).lam[i][slot];
+			r.rn[i] = load_axis_rows(d, slot, i, 0); r.rt1[i] = load_axis_rows(d, slot, i, 1); r.rt2[i] = load_axis_rows(d, slot, i, 2);
+			r.lam[i] = CUR(d).lam[i][slot];
 		}
 	}
-	const float im1 = va.w, im2 = vb.w, friction = nf.w;
+}
+
+SGP_DEV void con_store(const DV& d, uint32_t slot, const ConReg& r)
+{
+	const int np = r.np_col & 0xFF;
+#pragma unroll
+	for (int i = 0; i < 4; ++i) { if (i < np) CUR(d).lam[i][slot] = r.lam[i]; }
+}
+
+template <int VS> SGP_DEV void con_solve_velocity(ConReg& r, float4* vel)
+{
+	const uint2 ab = r.ab;
+	const int np = r.np_col & 0xFF;
+	const float4 va = vel[VS * (size_t)ab.x], wa = vel[VS * (size_t)ab.x + 1];
+	const float4 vb = vel[VS * (size_t)ab.y], wb = vel[VS * (size_t)ab.y + 1];
+	const float im1 = va.w, im2 = vb.w, friction = r.nf.w;
 	BodyVel A, B;
 	A.lv = V3(va); A.av = V3(wa); B.lv = V3(vb); B.av = V3(wb);
-	const v3 n = V3(nf);
+	const v3 n = V3(r.nf);
 	const v3 t1 = v3_normalized_perpendicular(n);
 	const v3 t2 = v3_cross(n, t1);
 	if (friction > 0.0f) {
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
-			if (i < np && !(rt1[i].c2.w <= 0.0f && rt2[i].c2.w <= 0.0f)) {
-				float l1 = lam[i].y + rt1[i].c2.w * rows_jv(A, B, t1, rt1[i]);
-				float l2 = lam[i].z + rt2[i].c2.w * rows_jv(A, B, t2, rt2[i]);
-				const float max_f = friction * lam[i].x;
+			if (i < np && !(r.rt1[i].c2.w <= 0.0f && r.rt2[i].c2.w <= 0.0f)) {
+				float l1 = r.lam[i].y + r.rt1[i].c2.w * rows_jv(A, B, t1, r.rt1[i]);
+				float l2 = r.lam[i].z + r.rt2[i].c2.w * rows_jv(A, B, t2, r.rt2[i]);
+				const float max_f = friction * r.lam[i].x;
 				const float tot_sq = l1 * l1 + l2 * l2;
 				if (tot_sq > max_f * max_f) { const float sc = max_f / sqrtf(tot_sq); l1 = l1 * sc; l2 = l2 * sc; }
-				rows_apply(A, B, im1, im2, t1, rt1[i], l1 - lam[i].y); lam[i].y = l1;
-				rows_apply(A, B, im1, im2, t2, rt2[i], l2 - lam[i].z); lam[i].z = l2;
+				rows_apply(A, B, im1, im2, t1, r.rt1[i], l1 - r.lam[i].y); r.lam[i].y = l1;
+				rows_apply(A, B, im1, im2, t2, r.rt2[i], l2 - r.lam[i].z); r.lam[i].z = l2;
 			}
 		}
 	}
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
-		if (i < np && rn[i].c2.w > 0.0f) {
-			const float jv = rows_jv(A, B, n, rn[i]);
-			const float lambda = rn[i].c2.w * (jv - rn[i].c1.w);
-			const float nl = fmaxf(lam[i].x + lambda, 0.0f);
-			rows_apply(A, B, im1, im2, n, rn[i], nl - lam[i].x);
-			lam[i].x = nl;
+		if (i < np && r.rn[i].c2.w > 0.0f) {
+			const float jv = rows_jv(A, B, n, r.rn[i]);
+			const float lambda = r.rn[i].c2.w * (jv - r.rn[i].c1.w);
+			const float nl = fmaxf(r.lam[i].x + lambda, 0.0f);
+			rows_apply(A, B, im1, im2, n, r.rn[i], nl - r.lam[i].x);
+			r.lam[i].x = nl;
 		}
 	}
-#pragma unroll
-	for (int i = 0; i < 4; ++i) { if (i < np) CUR(d).lam[i][slot] = lam[i]; }
 	if (im1 > 0.0f) { vel[VS * (size_t)ab.x] = F4(A.lv, im1); vel[VS * (size_t)ab.x + 1] = F4(A.av, 0.0f); }
 	if (im2 > 0.0f) { vel[VS * (size_t)ab.y] = F4(B.lv, im2); vel[VS * (size_t)ab.y + 1] = F4(B.av, 0.0f); }
+}
+
+template <int VS> SGP_DEV void solve_velocity_one_t(const DV& d, uint32_t slot, float4* vel)
+{
+	ConReg r;
+	con_load(d, slot, r);
+	con_solve_velocity<VS>(r, vel);
+	con_store(d, slot, r);
 }
 SGP_DEV void solve_velocity_one(const DV& d, uint32_t slot) { solve_velocity_one_t<4>(d, slot, d.sbody); }
 
@@ -1488,6 +1512,21 @@ __global__ void __launch_bounds__(512) k_solve_tail(DV d, int first_colour, int 
 	if (threadIdx.x <= SGP_MAX_COLOURS) cs[threadIdx.x] = d.cstarts[threadIdx.x];
 	__syncthreads();
 	if (cs[first_colour] == cs[SGP_MAX_COLOURS]) return;          // nothing from first_colour on (incl. the overflow colour)
+	const uint32_t tail_n = cs[SGP_OVERFLOW_COLOUR] - cs[first_colour];
+	if (mode == 1 && tail_n <= 512u) {
+		// one constraint per thread, read once up front (all loads in flight together); a colour phase is then only the velocity gather,
+		// the arithmetic and the scatter.  Phases and their order are those of the loop below.
+		const uint32_t slot = cs[first_colour] + threadIdx.x;
+		const bool mine = threadIdx.x < tail_n;
+		ConReg r; int my_col = -1;
+		if (mine) { con_load(d, slot, r); my_col = (r.np_col >> 8) & 0xFF; }
+		for (int c = first_colour; c < SGP_OVERFLOW_COLOUR; ++c) {
+			if (cs[c] == cs[c + 1]) continue;
+			if (my_col == c) con_solve_velocity<4>(r, d.sbody);
+			__syncthreads();
+		}
+		if (mine) con_store(d, slot, r);
+	} else
 	for (int c = first_colour; c < SGP_OVERFLOW_COLOUR; ++c) {
 		const uint32_t b = cs[c], e = cs[c + 1];
 		if (b == e) continue;
@@ -1528,6 +1567,32 @@ __global__ void __launch_bounds__(512) k_solve_small(DV d, int warm_start, int i
 	if (threadIdx.x <= SGP_MAX_COLOURS) cs[threadIdx.x] = d.cstarts[threadIdx.x];
 	for (uint32_t i = threadIdx.x; i < 2 * n; i += 512) sv[i] = d.sbody[4 * (size_t)(i >> 1) + (i & 1)];
 	__syncthreads();
+	const uint32_t all_n = cs[SGP_OVERFLOW_COLOUR];
+	if (all_n != 0 && all_n <= 512u && cs[SGP_OVERFLOW_COLOUR] == cs[SGP_MAX_COLOURS]) {
+		// at most one constraint per thread and no overflow colour: the constraint lives in registers for the whole solve (read once,
+		// lambdas written once), the velocities in LDS; a phase is an LDS gather, the arithmetic and an LDS scatter.  Same phases in
+		// the same order as the general path below.
+		const uint32_t slot = threadIdx.x;
+		const bool mine = slot < all_n;
+		if (warm_start) {
+			for (int c = 0; c < SGP_OVERFLOW_COLOUR; ++c) {
+				const uint32_t b = cs[c], e = cs[c + 1];
+				if (b == e) continue;
+				if (slot >= b && slot < e) warm_start_one_t<2>(d, slot, sv);
+				__syncthreads();
+			}
+		}
+		ConReg r; int my_col = -1;
+		if (mine) { con_load(d, slot, r); my_col = (r.np_col >> 8) & 0xFF; }
+		for (int pass = 0; pass < iterations; ++pass) {
+			for (int c = 0; c < SGP_OVERFLOW_COLOUR; ++c) {
+				if (cs[c] == cs[c + 1]) continue;
+				if (my_col == c) con_solve_velocity<2>(r, sv);
+				__syncthreads();
+			}
+		}
+		if (mine) con_store(d, slot, r);
+	} else
 	if (cs[0] != cs[SGP_MAX_COLOURS]) {
 		for (int pass = warm_start ? -1 : 0; pass < iterations; ++pass) {
 			for (int c = 0; c < SGP_OVERFLOW_COLOUR; ++c) {
