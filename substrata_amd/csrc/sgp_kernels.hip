@@ -1408,7 +1408,7 @@ SGP_DEV void solve_position_one(const DV& d, uint32_t slot)
 	const float4 nf = CUR(d).n_fric[slot];
 	const v3 nrm = V3(nf);
 	const int np = CUR(d).np_col[slot] & 0xFF;
-	// pose half of the solver records (written by k_integrate_pose): one line per body
+	// pose half of the solver records (written by k_prep_pose): one line per body
 	float4* ra = d.sbody + 4 * (size_t)ab.x;
 	float4* rb = d.sbody + 4 * (size_t)ab.y;
 	const float4 pa = ra[0], pb = rb[0];
@@ -1633,31 +1633,37 @@ __global__ void __launch_bounds__(TPB) k_integrate_pose(DV d)
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
 	if (i >= d.sp->n_slots) return;
 	const uint32_t f = d.flags[i];
-	if (!(f & BF_ALIVE)) return;
-	float4 p = d.pos_im[i], r = d.rot[i];
-	if ((f & BF_ACTIVE) && f_motion(f) != SGP_MOTION_STATIC) {
-		// the solved velocities live in the solver record
-		v3 lv = V3(d.sbody[4 * (size_t)i]), av = V3(d.sbody[4 * (size_t)i + 1]);
-		if (f_motion(f) == SGP_MOTION_DYNAMIC) {
-			const float l2 = v3_len_sq(lv), ml = d.st.max_linear_velocity;
-			if (l2 > ml * ml) lv = v3_scale(lv, ml / sqrtf(l2));
-			const float a2 = v3_len_sq(av), ma = d.st.max_angular_velocity;
-			if (a2 > ma * ma) av = v3_scale(av, ma / sqrtf(a2));
-		}
-		d.linv[i] = F4(lv, d.linv[i].w);
-		d.angv[i] = F4(av, d.angv[i].w);
-		const v3 np = v3_add(V3(p), v3_scale(lv, dt));
-		const quat q = quat_add_rotation_step(Q4(r), v3_scale(av, dt));
-		p = F4(np, p.w);
-		r = make_float4(q.x, q.y, q.z, q.w);
-		d.pos_im[i] = p;
-		d.rot[i] = r;
+	if ((f & (BF_ALIVE | BF_ACTIVE)) != (BF_ALIVE | BF_ACTIVE) || f_motion(f) == SGP_MOTION_STATIC) return;
+	// the solved velocities live in the solver record
+	v3 lv = V3(d.sbody[4 * (size_t)i]), av = V3(d.sbody[4 * (size_t)i + 1]);
+	if (f_motion(f) == SGP_MOTION_DYNAMIC) {
+		const float l2 = v3_len_sq(lv), ml = d.st.max_linear_velocity;
+		if (l2 > ml * ml) lv = v3_scale(lv, ml / sqrtf(l2));
+		const float a2 = v3_len_sq(av), ma = d.st.max_angular_velocity;
+		if (a2 > ma * ma) av = v3_scale(av, ma / sqrtf(a2));
 	}
-	// From here to k_finalize the solver record holds the POSE half of the body (the velocities have gone back to their arrays):
-	// [position, effective inverse mass][rotation][local inverse inertia diagonal].  The position iterations gather and update this one
-	// line per body instead of four arrays; k_finalize copies the corrected poses of the movable bodies back.
+	d.linv[i] = F4(lv, d.linv[i].w);
+	d.angv[i] = F4(av, d.angv[i].w);
+	const float4 p = d.pos_im[i];
+	const v3 np = v3_add(V3(p), v3_scale(lv, dt));
+	const quat q = quat_add_rotation_step(Q4(d.rot[i]), v3_scale(av, dt));
+	d.pos_im[i] = F4(np, p.w);
+	d.rot[i] = make_float4(q.x, q.y, q.z, q.w);
+}
+
+// Per-body record of the POSITION iterations (the counterpart of k_prep_bodies): from here to k_finalize the solver record holds
+// [position, effective inverse mass][rotation][local inverse inertia diagonal] (the velocities have gone back to their arrays).  The
+// position iterations gather and update this one line per body instead of four arrays; k_finalize copies the corrected poses of the
+// movable bodies back.
+__global__ void __launch_bounds__(TPB) k_prep_pose(DV d)
+{
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i >= d.sp->n_slots) return;
+	const uint32_t f = d.flags[i];
+	if (!(f & BF_ALIVE)) return;
+	const float4 p = d.pos_im[i];
 	d.sbody[4 * (size_t)i] = make_float4(p.x, p.y, p.z, f_movable(f) ? p.w : 0.0f);
-	d.sbody[4 * (size_t)i + 1] = r;
+	d.sbody[4 * (size_t)i + 1] = d.rot[i];
 	d.sbody[4 * (size_t)i + 2] = d.inv_inertia[i];
 }
 
@@ -2553,7 +2559,7 @@ template <int MODE> __global__ void __launch_bounds__(64) k_vehicle_solve(DV d)
 		const float4 p = d.pos_im[b];
 		c.pos = V3(p); c.rot = Q4(d.rot[b]); c.inv_inertia_local = V3(d.inv_inertia[b]);
 		if (MODE == 2) {
-			// between k_integrate_pose and k_finalize the pose being corrected is the one in the solver record (k_finalize copies it back
+			// between k_prep_pose and k_finalize the pose being corrected is the one in the solver record (k_finalize copies it back
 			// for movable bodies; anything else keeps its pose arrays authoritative)
 			const bool mv = f_movable(d.flags[b]);
 			if (mv) { c.pos = V3(d.sbody[4 * b + 0]); c.rot = Q4(d.sbody[4 * b + 1]); }
@@ -2779,6 +2785,7 @@ void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStr
 void launch_warm_bodies(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_warm_bodies, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_solve_tail(const DV& d, int first_colour, int mode, hipStream_t s) { hipLaunchKernelGGL(k_solve_tail, dim3(1), dim3(512), 0, s, d, first_colour, mode); }
 void launch_solve_small(const DV& d, int warm_start, int iterations, hipStream_t s) { hipLaunchKernelGGL(k_solve_small, dim3(1), dim3(512), 0, s, d, warm_start, iterations); }
+void launch_prep_pose(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_prep_pose, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_integrate_pose(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_integrate_pose, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_finalize(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_finalize, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_island_mark(const DV& d, uint32_t n_con, hipStream_t s) { hipLaunchKernelGGL(k_island_mark, dim3(stride_grid(n_con)), dim3(TPB), 0, s, d); }

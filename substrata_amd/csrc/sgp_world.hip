@@ -842,6 +842,7 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 	STAGE_MARK(5);
 	// -- 6. the body-array sweep
 	{ KScope k(w, KC_INTEGRATE_POSE); launch_integrate_pose(d, nb, s); }
+	{ KScope k(w, KC_PREP_BODIES); launch_prep_pose(d, nb, s); }      // k_finalize reads the poses of the movable bodies from this record
 	STAGE_MARK(6);
 	// -- 7. position iterations
 	for (int it = 0; it < p.pos_iters; ++it) solve_pass(2, KC_SOLVE_POSITION);
