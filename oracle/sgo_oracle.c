@@ -1643,8 +1643,11 @@ SGO_API int sgo_world_step(sgo_world* w, float dt)
 	for (uint32_t k = 0; k < w->n_cons; ++k) w->order[k] = k;
 	g_sort_world = w;
 	qsort(w->order, w->n_cons, sizeof(uint32_t), cmp_order);
-	int ncol = 0; uint32_t novf = 0;
-	for (uint32_t k = 0; k < w->n_cons; ++k) { if (w->cons[k].colour + 1 > ncol) ncol = w->cons[k].colour + 1; if (w->cons[k].colour == SGO_OVERFLOW_COLOUR) ++novf; }
+	int ncol = 0, nreg = 0; uint32_t novf = 0;
+	for (uint32_t k = 0; k < w->n_cons; ++k) {
+		if (w->cons[k].colour + 1 > ncol) ncol = w->cons[k].colour + 1;
+		if (w->cons[k].colour == SGO_OVERFLOW_COLOUR) ++novf; else if (w->cons[k].colour + 1 > nreg) nreg = w->cons[k].colour + 1;
+	}
 
 	/* colour segments of the solve order: constraints of one colour (except the overflow colour) share no movable body, so a
 	   segment may be walked in any order or in parallel without changing a single bit */
@@ -1718,7 +1721,7 @@ SGO_API int sgo_world_step(sgo_world* w, float dt)
 	}
 	w->stats.num_pairs = w->n_pairs;
 	w->stats.num_manifolds = w->n_prev;
-	w->stats.num_colours = (uint32_t)ncol;
+	w->stats.num_colours = (uint32_t)nreg;      /* regular colours only, like the device's colour table; the overflow colour is num_overflow_constraints */
 	w->stats.num_overflow_constraints = novf;
 	/* activation events raised since the end of the previous step (edits between steps included) */
 	w->stats.num_activated = (uint32_t)(w->tot_act - w->rep_act); w->rep_act = w->tot_act;
