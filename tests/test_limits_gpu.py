@@ -1,0 +1,70 @@
+"""Edge cases of the world's extent and capacities, HIP path against the oracle (and, where the outcome cannot be bit-exact, sanity)."""
+import numpy as np
+import pytest
+
+from substrata_amd import abi, scenes
+from helpers import DT
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+def two_piles(offset):
+    a, _ = scenes.lattice(5, 5, 3, 1.2, 0.8, seed=21)
+    b, _ = scenes.lattice(5, 5, 3, 1.2, 0.8, seed=22)
+    b["pos"][:, 0] += offset[0]; b["pos"][:, 1] += offset[1]; b["pos"][:, 2] += offset[2]
+    return np.concatenate([scenes.ground(width=2000.0), a, b])
+
+
+def test_two_piles_far_apart_and_a_body_falling_away(oracle):
+    """The broad-phase grid spans the bounds of all small bodies: two piles 900 m apart (both on the 2000 m ground quad) plus one body
+    that has left the ground and keeps falling stretch it over hundreds of metres, so the cell size must coarsen without losing pairs."""
+    descs = two_piles((900.0, -300.0, 0.0))
+    runaway = scenes.dynamic_bodies(1)
+    runaway["pos"][0] = (1500.0, 0.0, 5.0)          # beyond the ground quad: falls forever
+    runaway["allow_sleeping"] = 0
+    descs = np.concatenate([descs, runaway])
+    tw = parity.make_twin(oracle, max_bodies=512)
+    tw.add_batch(descs)
+    for s in range(1, 301):
+        tw.step(DT)
+        if s % 50 == 0:
+            sg, sc = tw.gpu.stats(), tw.cpu.stats()
+            assert (sg.num_pairs, sg.num_manifolds, sg.num_contact_points) == (sc.num_pairs, sc.num_manifolds, sc.num_contact_points), s
+            assert sg.pairs_dropped == 0 and sg.manifolds_dropped == 0
+            d = parity.compare(tw, len(descs))
+            assert d["bit_exact"] and d["active_mismatch"] == 0, (s, d)
+    st = tw.gpu.read_states(0, len(descs))
+    assert st["pos"][-1, 2] < -100.0                                  # the runaway is far below by now
+    assert np.all(st["pos"][1:-1, 2] > 0.2)                           # both piles rest on the ground
+    tw.close()
+
+
+def test_pair_and_manifold_capacity_overflow_is_counted_not_fatal():
+    """More contacts than max_manifolds: the excess is dropped and counted (SURVEY: the reference's cMaxContactConstraints behaves the same
+    way -- Jolt drops contacts beyond its buffer), the step neither crashes nor corrupts the rest."""
+    from substrata_amd.lib import World
+    descs = scenes.config2_10k_boxes()
+    w = World(max_bodies=len(descs) + 16, max_manifolds=4096, max_body_pairs=200000)
+    w.add_batch(descs)
+    dropped = 0
+    for _ in range(150):
+        w.step(DT)
+        st = w.stats()
+        dropped = max(dropped, st.manifolds_dropped)
+        assert st.num_manifolds <= 4096
+    assert dropped > 0
+    s = w.read_states(0, len(descs))
+    assert np.all(np.isfinite(s["pos"])) and np.all(np.isfinite(s["lin_vel"]))
+    w.close()
+    # the same with the pair buffer as the bottleneck
+    w = World(max_bodies=len(descs) + 16, max_body_pairs=8192)
+    w.add_batch(descs)
+    dropped = 0
+    for _ in range(100):
+        w.step(DT)
+        dropped = max(dropped, w.stats().pairs_dropped)
+    assert dropped > 0
+    s = w.read_states(0, len(descs))
+    assert np.all(np.isfinite(s["pos"]))
+    w.close()
