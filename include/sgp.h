@@ -465,6 +465,21 @@ int  sgp_world_export_boundary(sgp_world* w, const float lo[3], const float hi[3
                                sgp_ghost_record* out, uint32_t cap, uint32_t* n_out);
 /* Replace this world's ghost set with `n` records (bodies simulated as velocity-driven, infinite mass). */
 int  sgp_world_import_ghosts(sgp_world* w, const sgp_ghost_record* in, uint32_t n);
+/* Host-side routing of one tile's exported records (pure functions, no world, no device): the per-step bookkeeping of the exchange
+ * in substrata_amd/tiles.py, which numpy on 100-byte records is too slow for.
+ * sgp_tiles_route: `boxes` holds n_tiles x (lo xyz, hi xyz).  A record goes to every OTHER tile whose region grown by `pad` contains its
+ * centre; `send_out` receives the records grouped by destination in rank order (`send_counts[r]` each; a record can appear under several
+ * destinations; cap = capacity of send_out in records, exceeded -> SGP_ERR_CAPACITY).  Owned DYNAMIC bodies whose centre has left
+ * boxes[my_rank] emigrate: their records carry SGP_GHOST_TAKE_OWNERSHIP in motion_type and the low 32 bits of their global ids (the
+ * local body ids) are listed in `emigrant_ids`.  `rank_tag` is OR-ed into bits 40.. of every global_id. */
+#define SGP_GHOST_TAKE_OWNERSHIP 0x100u
+int  sgp_tiles_route(const sgp_ghost_record* recs, uint32_t n, uint32_t my_rank, const float* boxes, uint32_t n_tiles, float pad,
+                     sgp_ghost_record* send_out, uint32_t cap, uint32_t* send_counts,
+                     uint32_t* emigrant_ids, uint32_t emigrant_cap, uint32_t* n_emigrants);
+/* sgp_tiles_split: what arrived at a tile -> ghosts (records without the flag) and immigrants (flagged records whose centre lies in
+ * [lo,hi); flagged records addressed to another tile are dropped).  Both outputs need room for n records. */
+int  sgp_tiles_split(const sgp_ghost_record* in, uint32_t n, const float lo[3], const float hi[3],
+                     sgp_ghost_record* ghosts_out, uint32_t* n_ghosts, sgp_ghost_record* immigrants_out, uint32_t* n_immigrants);
 
 /* ---- device-resident bulk access (bench / torch plumbing; pointers are HIP device pointers) ---- */
 /* Raw SoA views of the body arrays, valid until the world is destroyed:

@@ -253,6 +253,8 @@ PROTOTYPES = {
     "spherecast": (C.c_int, [vp, vp, vp, u32, vp]),
     "world_export_boundary": (C.c_int, [vp, P(f32), P(f32), f32, vp, u32, P(u32)]),
     "world_import_ghosts": (C.c_int, [vp, vp, u32]),
+    "tiles_route": (C.c_int, [vp, u32, u32, vp, u32, f32, vp, u32, vp, vp, u32, P(u32)]),
+    "tiles_split": (C.c_int, [vp, u32, vp, vp, vp, P(u32), vp, P(u32)]),
     "world_device_array": (C.c_int, [vp, C.c_int, P(vp), P(u32)]),
     "world_stream": (C.c_int, [vp, P(vp)]),
     "mesh_create": (C.c_int, [vp, vp, u32, vp, u32, P(MeshInfo)]),

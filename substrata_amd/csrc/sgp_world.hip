@@ -1680,9 +1680,21 @@ SGP_API int sgp_world_export_boundary(sgp_world* w, const float lo[3], const flo
 	if (m && out) {
 		HIP_TRY(hipMemcpyAsync(w->stage_host, w->stage_dev, sizeof(sgp_ghost_record) * m, hipMemcpyDeviceToHost, w->stream));
 		HIP_TRY(hipStreamSynchronize(w->stream));
-		memcpy(out, w->stage_host, sizeof(sgp_ghost_record) * m);
-		// deterministic order for the exchange
-		std::sort(out, out + m, [](const sgp_ghost_record& a, const sgp_ghost_record& b) { return a.global_id < b.global_id; });
+		// deterministic order for the exchange: ascending id (sort 12-byte keys, then move each 96-byte record once)
+		// (LSD radix sort of the 32-bit local ids, 3 passes of 11 bits: a comparison sort of a few thousand keys costs more than the
+		// kernel and the copies together)
+		const sgp_ghost_record* src = (const sgp_ghost_record*)w->stage_host;
+		std::vector<uint32_t> idx(m), tmp(m);
+		for (uint32_t k = 0; k < m; ++k) idx[k] = k;
+		for (int pass = 0; pass < 3; ++pass) {
+			uint32_t hist[2049] = { 0 };
+			const int sh = 11 * pass;
+			for (uint32_t k = 0; k < m; ++k) ++hist[(((uint32_t)src[idx[k]].global_id >> sh) & 2047u) + 1];
+			for (int b = 0; b < 2048; ++b) hist[b + 1] += hist[b];
+			for (uint32_t k = 0; k < m; ++k) tmp[hist[((uint32_t)src[idx[k]].global_id >> sh) & 2047u]++] = idx[k];
+			idx.swap(tmp);
+		}
+		for (uint32_t k = 0; k < m; ++k) out[k] = src[idx[k]];
 	}
 	*n_out = n;
 	return SGP_OK;
@@ -1723,6 +1735,62 @@ SGP_API int sgp_world_import_ghosts(sgp_world* w, const sgp_ghost_record* in, ui
 	std::sort(gone.begin(), gone.end());
 	for (uint32_t id : gone) sgp_body_remove(w, id);
 	w->ghost_map.swap(next);
+	return SGP_OK;
+}
+
+// ---- host-side routing of exported records (tiles.py) -------------------------------------------------------------------------
+
+static inline bool in_box(const float* p, const float* lo, const float* hi, float pad)
+{
+	return p[0] >= lo[0] - pad && p[0] < hi[0] + pad && p[1] >= lo[1] - pad && p[1] < hi[1] + pad && p[2] >= lo[2] - pad && p[2] < hi[2] + pad;
+}
+
+SGP_API int sgp_tiles_route(const sgp_ghost_record* recs, uint32_t n, uint32_t my_rank, const float* boxes, uint32_t n_tiles, float pad,
+                            sgp_ghost_record* send_out, uint32_t cap, uint32_t* send_counts,
+                            uint32_t* emigrant_ids, uint32_t emigrant_cap, uint32_t* n_emigrants)
+{
+	if ((!recs && n) || !boxes || !send_counts || !n_emigrants || my_rank >= n_tiles) return fail(SGP_ERR_INVALID, "sgp_tiles_route: bad arguments");
+	const float* mylo = boxes + 6 * (size_t)my_rank; const float* myhi = mylo + 3;
+	// flags per record: emigrant?
+	std::vector<uint8_t> emig(n, 0);
+	uint32_t ne = 0;
+	for (uint32_t k = 0; k < n; ++k) {
+		if (n_tiles > 1 && (recs[k].motion_type & 0xFFu) == SGP_MOTION_DYNAMIC && !in_box(recs[k].pos, mylo, myhi, 0.0f)) {
+			emig[k] = 1;
+			if (ne < emigrant_cap && emigrant_ids) emigrant_ids[ne] = (uint32_t)(recs[k].global_id & 0xFFFFFFFFull);
+			++ne;
+		}
+	}
+	*n_emigrants = ne;
+	if (ne > emigrant_cap) return fail(SGP_ERR_CAPACITY, "sgp_tiles_route: emigrant list too small");
+	uint32_t w = 0;
+	for (uint32_t r = 0; r < n_tiles; ++r) {
+		send_counts[r] = 0;
+		if (r == my_rank) continue;
+		const float* lo = boxes + 6 * (size_t)r; const float* hi = lo + 3;
+		for (uint32_t k = 0; k < n; ++k) {
+			if (!in_box(recs[k].pos, lo, hi, pad)) continue;
+			if (w >= cap || !send_out) return fail(SGP_ERR_CAPACITY, "sgp_tiles_route: send buffer too small");
+			sgp_ghost_record o = recs[k];
+			o.global_id |= (uint64_t)my_rank << 40;
+			if (emig[k]) o.motion_type = SGP_MOTION_DYNAMIC | SGP_GHOST_TAKE_OWNERSHIP;
+			send_out[w++] = o;
+			++send_counts[r];
+		}
+	}
+	return SGP_OK;
+}
+
+SGP_API int sgp_tiles_split(const sgp_ghost_record* in, uint32_t n, const float lo[3], const float hi[3],
+                            sgp_ghost_record* ghosts_out, uint32_t* n_ghosts, sgp_ghost_record* immigrants_out, uint32_t* n_immigrants)
+{
+	if ((!in && n) || !lo || !hi || !n_ghosts || !n_immigrants || (n && (!ghosts_out || !immigrants_out))) return fail(SGP_ERR_INVALID, "sgp_tiles_split: bad arguments");
+	uint32_t g = 0, m = 0;
+	for (uint32_t k = 0; k < n; ++k) {
+		if (in[k].motion_type & SGP_GHOST_TAKE_OWNERSHIP) { if (in_box(in[k].pos, lo, hi, 0.0f)) immigrants_out[m++] = in[k]; }
+		else ghosts_out[g++] = in[k];
+	}
+	*n_ghosts = g; *n_immigrants = m;
 	return SGP_OK;
 }
 

@@ -3,12 +3,14 @@
 The path shards by space.  Each rank OWNS the bodies created in its tile and simulates them dynamically; bodies whose
 AABB (inflated by the ghost margin) pokes out of the owner's tile are exported once per sub-step and imported by every
 rank whose tile (inflated by the margin) they touch, where they are simulated as velocity-driven infinite-mass ghosts
-(kinematic bodies) for that step.  The only collectives are, per step, one all-gather of the record counts (8 B per rank) and
-one all-gather of the ghost records padded to the largest count (torch.distributed: backend "nccl" = RCCL over xGMI on the
-GPU box, "gloo" in the CPU tests).  Ghost traffic is ~1e3-1e4 records x 104 B per rank, so the exchange is latency- not
-bandwidth-bound.  Ownership migrates: when the centre of an owned body has left the tile, the owner removes it and the tile
+(kinematic bodies) for that step.  The only collectives are, per step, one all-gather of the per-destination record counts (8 B x
+tiles per rank) and one all-to-all-v of the ghost records -- each record goes only to the tiles it can touch -- (torch.distributed:
+backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).  Ghost traffic is ~1e3-1e4 records x 96 B per rank, so the
+exchange is latency- not bandwidth-bound; the per-record routing is done by two C helpers (sgp_tiles_route / sgp_tiles_split).  Ownership migrates: when the centre of an owned body has left the tile, the owner removes it and the tile
 that now contains the centre re-creates it as a dynamic body from the same record (its contact-cache entries restart).
 """
+import ctypes as C
+
 import numpy as np
 
 from . import abi
@@ -70,65 +72,134 @@ def select_ghosts(recs, lo, hi, margin, radius_pad=1.5):
     return recs[m]
 
 
-class GhostExchange:
-    """Per step: one tiny all-gather of the record counts, then one all-gather of the records padded to the largest count."""
+GHOST_TAKE_OWNERSHIP = 0x100       # sgp.h SGP_GHOST_TAKE_OWNERSHIP
 
-    def __init__(self, world, rank, n_tiles, lo, hi, margin, dist=None, device=None, cap=1 << 16):
+
+def _routing_lib():
+    """The host-side routing helpers (sgp_tiles_route / sgp_tiles_split) live in libsgp.so; they touch neither a world nor the device."""
+    from .lib import load
+    return load()
+
+
+def route(recs, rank, boxes, pad, cap=None):
+    """Group one tile's exported records by destination tile (sgp_tiles_route).  Returns (send records grouped in rank order,
+    per-destination counts, local ids of the emigrants)."""
+    n_tiles = len(boxes)
+    cap = max(64, 3 * len(recs)) if cap is None else cap
+    while True:
+        send = np.empty(cap, dtype=abi.ghost_dtype)
+        counts = np.zeros(n_tiles, dtype=np.uint32)
+        emig = np.empty(max(16, len(recs)), dtype=np.uint32)
+        n_emig = C.c_uint32(0)
+        recs = np.ascontiguousarray(recs)
+        boxes32 = np.ascontiguousarray(boxes, dtype=np.float32)
+        rc = _routing_lib().sgp_tiles_route(recs.ctypes.data, len(recs), int(rank), boxes32.ctypes.data, n_tiles, float(pad),
+                                            send.ctypes.data, cap, counts.ctypes.data, emig.ctypes.data, len(emig), C.byref(n_emig))
+        if rc == abi.ERR_CAPACITY and cap < 64 * max(64, len(recs)):
+            cap *= 4
+            continue
+        if rc != 0:
+            raise RuntimeError(f"sgp_tiles_route failed ({rc})")
+        return send[:int(counts.sum())], counts, emig[:n_emig.value].copy()
+
+
+def split(recs, lo, hi):
+    """What arrived at a tile -> (ghosts, immigrants) (sgp_tiles_split)."""
+    n = len(recs)
+    ghosts = np.empty(max(n, 1), dtype=abi.ghost_dtype)
+    immigrants = np.empty(max(n, 1), dtype=abi.ghost_dtype)
+    ng, ni = C.c_uint32(0), C.c_uint32(0)
+    recs = np.ascontiguousarray(recs)
+    lo32, hi32 = np.ascontiguousarray(lo, dtype=np.float32), np.ascontiguousarray(hi, dtype=np.float32)
+    rc = _routing_lib().sgp_tiles_split(recs.ctypes.data, n, lo32.ctypes.data, hi32.ctypes.data, ghosts.ctypes.data, C.byref(ng),
+                                        immigrants.ctypes.data, C.byref(ni))
+    if rc != 0:
+        raise RuntimeError(f"sgp_tiles_split failed ({rc})")
+    return ghosts[:ng.value], immigrants[:ni.value]
+
+
+class GhostExchange:
+    """Per step: one small all-gather (every rank's per-destination record counts) and one all-to-all-v of the ghost records, each
+    record travelling only to the tiles whose region (grown by margin + radius_pad) contains it.  With RCCL the all-to-all-v is the
+    grouped ncclSend/ncclRecv exchange over xGMI; the CPU tests run the same code over gloo."""
+
+    def __init__(self, world, rank, n_tiles, lo, hi, margin, dist=None, device=None, cap=1 << 16, radius_pad=1.5):
         self.world, self.rank, self.n = world, rank, n_tiles
-        self.lo, self.hi, self.margin = lo, hi, float(margin)
+        self.lo, self.hi, self.margin = np.asarray(lo, np.float32), np.asarray(hi, np.float32), float(margin)
+        self.pad = float(margin) + float(radius_pad)
         self.dist, self.device, self.cap = dist, device, cap
         self.last_exported = 0
+        self.last_sent = 0
         self.last_imported = 0
         self.last_emigrated = 0
         self.last_immigrated = 0
+        self.boxes = np.concatenate([self.lo, self.hi])[None, :].astype(np.float32)
         if dist is not None:
             import torch
             self.torch = torch
-            self.cnt_send = torch.zeros(1, dtype=torch.int64, device=device)
-            self.cnt_recv = torch.zeros(n_tiles, dtype=torch.int64, device=device)
-            self.send = torch.zeros(cap * REC, dtype=torch.uint8, device=device)
-            self.recv = torch.zeros(n_tiles * cap * REC, dtype=torch.uint8, device=device)
+            on_gpu = device is not None and torch.device(device).type == "cuda"
+            self.on_gpu = on_gpu
+            # every tile's region, once
+            mine = torch.from_numpy(self.boxes[0].copy()).to(device)
+            allb = torch.zeros(n_tiles * 6, dtype=torch.float32, device=device)
+            dist.all_gather_into_tensor(allb, mine)
+            self.boxes = allb.cpu().numpy().reshape(n_tiles, 6)
+            self.cnt_send = torch.zeros(n_tiles, dtype=torch.int64, device=device)
+            self.cnt_recv = torch.zeros(n_tiles * n_tiles, dtype=torch.int64, device=device)
+            self._grow(cap)
+
+    def _grow(self, cap):
+        torch = self.torch
+        self.cap = cap
+        self.send_host = torch.zeros(cap * REC, dtype=torch.uint8, pin_memory=self.on_gpu)
+        self.recv_host = torch.zeros(cap * REC, dtype=torch.uint8, pin_memory=self.on_gpu)
+        self.send_dev = torch.zeros(cap * REC, dtype=torch.uint8, device=self.device) if self.on_gpu else self.send_host
+        self.recv_dev = torch.zeros(cap * REC, dtype=torch.uint8, device=self.device) if self.on_gpu else self.recv_host
 
     def exchange(self):
-        recs = self.world.export_boundary(self.lo, self.hi, self.margin, cap=self.cap)
-        # owned DYNAMIC bodies whose centre has left the tile emigrate: removed here, re-created by the tile that contains them
-        local_ids = (recs["global_id"] & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-        emigrant = ~inside(recs, self.lo, self.hi) & (recs["motion_type"] == abi.MOTION_DYNAMIC) if self.n > 1 else np.zeros(len(recs), bool)
-        for i in local_ids[emigrant]:
-            self.world.remove(int(i))
-        self.last_emigrated = int(emigrant.sum())
-        recs["global_id"] = recs["global_id"] | (np.uint64(self.rank) << np.uint64(40))
-        recs["motion_type"] = np.where(emigrant, np.uint32(abi.MOTION_DYNAMIC | 0x100), recs["motion_type"])   # bit 8 = "take ownership"
+        cap = max(1 << 14, 2 * self.last_exported)
+        recs = self.world.export_boundary(self.lo, self.hi, self.margin, cap=cap)
+        if len(recs) == cap:      # more boundary bodies than expected: ask again with room for every body
+            recs = self.world.export_boundary(self.lo, self.hi, self.margin, cap=1 << 22)
         self.last_exported = len(recs)
-        if self.dist is None:
-            self.world.import_ghosts(recs[:0])
-            return
+        if self.dist is None or self.n == 1:
+            # a single tile: nobody to talk to (the collectives still run when a process group is given, so that the one-rank RCCL
+            # test exercises them)
+            if self.dist is None:
+                self.world.import_ghosts(recs[:0])
+                self.last_imported = self.last_emigrated = self.last_immigrated = self.last_sent = 0
+                return
+        send, counts, emigrants = route(recs, self.rank, self.boxes, self.pad)
+        # owned DYNAMIC bodies whose centre has left the tile emigrate: removed here, re-created by the tile that contains them
+        for i in emigrants:
+            self.world.remove(int(i))
+        self.last_emigrated = len(emigrants)
+        self.last_sent = len(send)
         torch = self.torch
-        self.cnt_send[0] = len(recs)
+        self.cnt_send.copy_(torch.from_numpy(counts.astype(np.int64)))
         self.dist.all_gather_into_tensor(self.cnt_recv, self.cnt_send)
-        counts = self.cnt_recv.cpu().numpy()
-        maxc = int(counts.max())
-        if maxc == 0:
-            self.last_imported = 0
+        matrix = self.cnt_recv.cpu().numpy().reshape(self.n, self.n)          # [source][destination]
+        recv_counts = matrix[:, self.rank]
+        n_send, n_recv = int(counts.sum()), int(recv_counts.sum())
+        if max(n_send, n_recv) > self.cap:
+            self._grow(2 * max(n_send, n_recv))
+        if int(matrix.sum()) == 0:
+            self.last_imported = self.last_immigrated = 0
             self.world.import_ghosts(recs[:0])
             return
-        nbytes = maxc * REC
-        if len(recs):
-            self.send[:len(recs) * REC].copy_(torch.from_numpy(recs.view(np.uint8).reshape(-1).copy()))
-        self.dist.all_gather_into_tensor(self.recv[:self.n * nbytes], self.send[:nbytes])
-        allb = self.recv[:self.n * nbytes].cpu().numpy().reshape(self.n, nbytes)
-        parts = []
-        for r in range(self.n):
-            c = int(counts[r])
-            if r != self.rank and c:
-                parts.append(np.frombuffer(allb[r, :c * REC].tobytes(), dtype=abi.ghost_dtype))
-        others = np.concatenate(parts) if parts else np.zeros(0, dtype=abi.ghost_dtype)
-        take = (others["motion_type"] & 0x100) != 0
-        immigrants = others[take & inside(others, self.lo, self.hi)]
-        ghosts = others[~take].copy()
-        mine = select_ghosts(ghosts, self.lo, self.hi, self.margin)
-        self.last_imported = len(mine)
+        if n_send:
+            self.send_host[:n_send * REC].copy_(torch.from_numpy(send.view(np.uint8).reshape(-1)))
+            if self.on_gpu:
+                self.send_dev[:n_send * REC].copy_(self.send_host[:n_send * REC], non_blocking=True)
+        self.dist.all_to_all_single(self.recv_dev[:n_recv * REC], self.send_dev[:n_send * REC],
+                                    output_split_sizes=[int(c) * REC for c in recv_counts],
+                                    input_split_sizes=[int(c) * REC for c in counts])
+        if self.on_gpu:
+            self.recv_host[:n_recv * REC].copy_(self.recv_dev[:n_recv * REC])
+        arrived = np.frombuffer(self.recv_host[:n_recv * REC].numpy(), dtype=abi.ghost_dtype) if n_recv else recs[:0]
+        ghosts, immigrants = split(arrived, self.lo, self.hi)
+        self.last_imported = len(ghosts)
         self.last_immigrated = len(immigrants)
-        self.world.import_ghosts(mine)
+        self.world.import_ghosts(ghosts)
         if len(immigrants):
             self.world.add_batch(records_to_descs(immigrants))

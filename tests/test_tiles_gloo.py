@@ -138,3 +138,100 @@ def test_ownership_migrates_across_the_tile_border(tmp_path, oracle):
     assert ball["pos"][0] > TILE_W + 1.0 and ball["lin_vel"][0] > 1.0 and abs(ball["pos"][2] - 0.5) < 0.05
     # tile 0 now only holds its ground quad plus (at most) a ghost copy while the ball is still near the border
     assert c0[2] <= 2
+
+
+def test_route_and_split_match_a_numpy_reference():
+    """sgp_tiles_route / sgp_tiles_split (the C helpers behind GhostExchange) against the plain numpy statement of the same rules."""
+    rng = np.random.default_rng(5)
+    n_tiles, w = 8, 30.0
+    boxes = np.array([np.concatenate(tiles.tile_bounds(r, n_tiles, w, w)[:2]) for r in range(n_tiles)], np.float32)
+    for rank in (0, 5):
+        lo, hi = boxes[rank, :3], boxes[rank, 3:]
+        n = 3000
+        recs = np.zeros(n, dtype=abi.ghost_dtype)
+        recs["pos"] = rng.uniform(-10, 130, (n, 3)).astype(np.float32) * np.float32([1, 0.55, 0.05])
+        recs["motion_type"] = rng.choice([abi.MOTION_DYNAMIC, abi.MOTION_KINEMATIC], n, p=[0.9, 0.1])
+        recs["global_id"] = np.arange(n, dtype=np.uint64) * 3 + 1
+        send, counts, emig = tiles.route(recs, rank, boxes, pad=3.5)
+        inside_own = tiles.inside(recs, lo, hi)
+        want_emig = ~inside_own & (recs["motion_type"] == abi.MOTION_DYNAMIC)
+        assert np.array_equal(np.sort(emig), np.sort((recs["global_id"][want_emig] & np.uint64(0xFFFFFFFF)).astype(np.uint32)))
+        off = 0
+        for r in range(n_tiles):
+            if r == rank:
+                assert counts[r] == 0
+                continue
+            m = np.all(recs["pos"] >= boxes[r, :3] - np.float32(3.5), axis=1) & np.all(recs["pos"] < boxes[r, 3:] + np.float32(3.5), axis=1)
+            part = send[off:off + counts[r]]
+            off += counts[r]
+            assert counts[r] == m.sum()
+            assert np.array_equal(part["global_id"], recs["global_id"][m] | (np.uint64(rank) << np.uint64(40)))
+            assert np.array_equal((part["motion_type"] & tiles.GHOST_TAKE_OWNERSHIP) != 0, want_emig[m])
+            assert np.array_equal(part["pos"], recs["pos"][m])
+        assert off == len(send)
+        # receiving side, as tile 1 would see what `rank` sent it
+        part = send[:counts[0]] if rank != 0 else send[:counts[1]]
+        dst = 0 if rank != 0 else 1
+        ghosts, immigrants = tiles.split(part, boxes[dst, :3], boxes[dst, 3:])
+        take = (part["motion_type"] & tiles.GHOST_TAKE_OWNERSHIP) != 0
+        assert np.array_equal(ghosts["global_id"], part["global_id"][~take])
+        assert np.array_equal(immigrants["global_id"], part["global_id"][take & tiles.inside(part, boxes[dst, :3], boxes[dst, 3:])])
+    # empty input
+    send, counts, emig = tiles.route(np.zeros(0, dtype=abi.ghost_dtype), 0, boxes, pad=3.5)
+    assert len(send) == 0 and counts.sum() == 0 and len(emig) == 0
+
+
+def corner_worker(rank, world_size, port, steps, out_dir):
+    """2 x 2 tiles; tile 0 owns a small pile sitting right at the common corner, so its bodies are ghosts in all three other tiles, and
+    tile 3 owns a box that slides across the corner region into tile 0 (migration with four ranks)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    from oracle import oracle
+    lo, hi, origin = tiles.tile_bounds(rank, world_size, TILE_W, TILE_W)
+    descs = scenes.ground()
+    if rank == 0:
+        b = scenes.dynamic_bodies(4)
+        b["pos"] = np.float32([[TILE_W - 0.7, TILE_W - 0.7, 0.5], [TILE_W - 0.7, TILE_W - 1.9, 0.5], [TILE_W - 1.9, TILE_W - 0.7, 0.5], [TILE_W - 0.7, TILE_W - 0.7, 1.6]])
+        descs = np.concatenate([descs, b])
+    if rank == 3:
+        b = scenes.dynamic_bodies(1)
+        b["pos"][0] = (TILE_W + 3.0, TILE_W + 3.0, 0.5)
+        b["lin_vel"][0] = (-3.0, -3.0, 0.0)
+        b["friction"] = 0.0
+        descs = np.concatenate([descs, b])
+    w = oracle.OracleWorld(max_bodies=64)
+    w.add_batch(descs)
+    ex = tiles.GhostExchange(w, rank, world_size, lo, hi, margin=1.5, dist=dist, device=torch.device("cpu"), cap=64)
+    log = []
+    for _ in range(steps):
+        ex.exchange()
+        log.append((ex.last_exported, ex.last_sent, ex.last_imported, ex.last_emigrated, ex.last_immigrated))
+        w.step(DT)
+    np.save(os.path.join(out_dir, f"corner{rank}.npy"), np.array(log))
+    np.save(os.path.join(out_dir, f"cornerstate{rank}.npy"), w.read_states(0, 32))
+    np.save(os.path.join(out_dir, f"cornercount{rank}.npy"), np.array([w.num_bodies()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_four_tiles_corner_bodies_reach_all_neighbours(tmp_path, oracle):
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(corner_worker, args=(4, port, 90, str(tmp_path)), nprocs=4, join=True)
+    logs = [np.load(tmp_path / f"corner{r}.npy") for r in range(4)]
+    # step 0: tile 0 exports its 4 corner bodies; each goes to all three other tiles (12 records sent), which import 4 ghosts each
+    # (+ tile 3's slider is not yet near anybody)
+    assert logs[0][0, 0] == 4 and logs[0][0, 1] == 12
+    for r in (1, 2, 3):
+        assert logs[r][0, 2] == 4
+    # the slider left tile 3 (it runs into the ghosts of the corner pile there and is deflected); every emigration was matched by
+    # exactly one immigration somewhere, and no body was lost or duplicated: 5 dynamic bodies are owned in total at the end
+    assert logs[3][:, 3].sum() >= 1
+    assert sum(int(l[:, 3].sum()) for l in logs) == sum(int(l[:, 4].sum()) for l in logs)
+    owned = sum(int(np.load(tmp_path / f"cornercount{r}.npy")[0]) - 1 - int(logs[r][-1, 2]) for r in range(4))
+    assert owned == 5
+    for r in range(4):
+        st = np.load(tmp_path / f"cornerstate{r}.npy")
+        own = st[st["id"] != abi.INVALID_ID]
+        assert own["pos"][:, 2].min() > -0.6 and np.abs(own["lin_vel"]).max() < 8.0      # nothing fell through or exploded

@@ -1,6 +1,6 @@
 """The tile exchange on the RCCL path (torch.distributed backend "nccl"), as far as one GPU allows: a one-rank process group
-runs the same two all-gathers (counts, padded records) on device tensors that the N-rank bench runs over xGMI.  The N > 1 logic
-(ghost selection, migration) is covered on CPU by tests/test_tiles_gloo.py."""
+runs the same collectives (all-gather of the count matrix, all-to-all-v of the records) on device tensors that the N-rank bench runs
+over xGMI.  The N > 1 logic (routing, ghost selection, migration) is covered on CPU by tests/test_tiles_gloo.py (2 and 4 ranks)."""
 import os
 
 import numpy as np
@@ -32,11 +32,16 @@ def test_exchange_collectives_on_rccl_single_rank():
             w.step(DT)
             dist.barrier()
         torch.cuda.synchronize()
-        assert ex.last_exported > 50 and ex.last_imported == 0          # nobody else to import from
-        assert int(ex.cnt_recv[0].item()) == ex.last_exported
-        # the padded records came back through the collective unchanged
+        assert ex.last_exported > 50 and ex.last_imported == 0 and ex.last_sent == 0      # nobody else to send to or import from
+        assert int(ex.cnt_recv.sum().item()) == 0
         rec = w.export_boundary(lo, hi, 2.0)
         assert len(rec) > 50
+        # the all-to-all-v itself, with a non-empty payload to self, on the device buffers the exchange uses
+        n = 64 * tiles.REC
+        ex.send_dev[:n].copy_(torch.arange(n, dtype=torch.int64, device=ex.send_dev.device).to(torch.uint8))
+        dist.all_to_all_single(ex.recv_dev[:n], ex.send_dev[:n], output_split_sizes=[n], input_split_sizes=[n])
+        torch.cuda.synchronize()
+        assert torch.equal(ex.recv_dev[:n], ex.send_dev[:n])
         w.close()
     finally:
         dist.destroy_process_group()
