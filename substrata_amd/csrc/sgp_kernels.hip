@@ -391,6 +391,7 @@ SGP_DEV void stage_pair(const DV& d, uint2* spairs, uint32_t* lcount, uint32_t i
 #define BP_INNER_CELLS (BP_TILE * BP_TILE * BP_TILE)
 #define BP_LDS_CAP 1536
 #define BP_PAIR_CAP 2048
+#define BP_SPLIT 4
 
 SGP_DEV void stage_pair(const DV& d, uint2* spairs, uint32_t* lcount, uint32_t i, uint32_t j)
 {
@@ -484,7 +485,11 @@ __global__ void __launch_bounds__(TPB) k_bp_pairs(DV d)
 			}
 		}
 		__syncthreads();
-		for (uint32_t t = threadIdx.x; t < n_inner; t += TPB) {
+		// BP_SPLIT threads share one body: each takes every BP_SPLIT-th (z, y) row of the cells the body reaches (a tile holds far
+		// fewer bodies than the workgroup has threads, and the candidate loop is the long part)
+		for (uint32_t tt = threadIdx.x; tt < n_inner * BP_SPLIT; tt += TPB) {
+			const uint32_t t = tt / BP_SPLIT;
+			const int sub = (int)(tt % BP_SPLIT);
 			int lo = 0, hi = BP_INNER_CELLS - 1;
 			while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (istart[mid] <= t) lo = mid; else hi = mid - 1; }
 			const int ic = lo;
@@ -503,7 +508,9 @@ __global__ void __launch_bounds__(TPB) k_bp_pairs(DV d)
 			xl = min(max(xl, 0), ix + BP_H); xh = max(min(xh, BP_HALO - 1), ix + BP_H);
 			yl = min(max(yl, 0), iy + BP_H); yh = max(min(yh, BP_HALO - 1), iy + BP_H);
 			zl = min(max(zl, 0), iz + BP_H); zh = max(min(zh, BP_HALO - 1), iz + BP_H);
-			for (int hz = zl; hz <= zh; ++hz) for (int hy = yl; hy <= yh; ++hy) {
+			const int ny_rows = yh - yl + 1, n_rows = (zh - zl + 1) * ny_rows;
+			for (int row = sub; row < n_rows; row += BP_SPLIT) {
+				const int hz = zl + row / ny_rows, hy = yl + row % ny_rows;
 				const int rb = (hz * BP_HALO + hy) * BP_HALO;
 				if (in_lds) {
 					const uint32_t q0 = cstart[rb + xl], q1 = cstart[rb + xh + 1];
