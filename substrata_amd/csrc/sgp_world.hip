@@ -68,7 +68,10 @@ struct sgp_world {
 	std::vector<uint32_t> large_ids; bool large_dirty = false;
 	uint32_t* d_large = nullptr; uint32_t cap_large = 0;
 	float max_small_radius = 0.0f;
-	std::unordered_map<uint64_t, uint32_t> ghost_map;      // global id of a ghost -> local body id (stable across steps)
+	uint32_t last_export = 0;                              // records the previous sgp_world_export_boundary produced
+	std::vector<uint64_t> sort_a, sort_b;                  // scratch of its radix sort
+	std::unordered_map<uint64_t, uint64_t> ghost_map;      // global id of a ghost -> generation << 32 | local body id (stable across steps)
+	uint32_t ghost_gen = 0;
 	// pending edits
 	std::vector<BodyCmd> cmds;
 	// staging
@@ -1675,26 +1678,33 @@ SGP_API int sgp_world_export_boundary(sgp_world* w, const float lo[3], const flo
 	HIP_TRY(hipMemsetAsync(&w->dv.ctr->n_export, 0, sizeof(uint32_t), w->stream));
 	launch_export_boundary(w->dv, w->high, make_float3(lo[0], lo[1], lo[2]), make_float3(hi[0], hi[1], hi[2]), margin,
 	                       (sgp_ghost_record*)w->stage_dev, lim, &w->dv.ctr->n_export, w->stream);
+	// one sync in the common case: the counters and as many records as the previous call produced (+ 25 %) come back together
+	uint32_t guess = out ? std::min(lim, w->last_export + w->last_export / 4 + 64u) : 0u;
+	if (guess) HIP_TRY(hipMemcpyAsync(w->stage_host, w->stage_dev, sizeof(sgp_ghost_record) * guess, hipMemcpyDeviceToHost, w->stream));
 	{ int r = read_counters(w); if (r != SGP_OK) return r; }
 	const uint32_t n = w->h_ctr->n_export, m = std::min(n, lim);
+	w->last_export = n;
 	if (m && out) {
-		HIP_TRY(hipMemcpyAsync(w->stage_host, w->stage_dev, sizeof(sgp_ghost_record) * m, hipMemcpyDeviceToHost, w->stream));
-		HIP_TRY(hipStreamSynchronize(w->stream));
-		// deterministic order for the exchange: ascending id (sort 12-byte keys, then move each 96-byte record once)
-		// (LSD radix sort of the 32-bit local ids, 3 passes of 11 bits: a comparison sort of a few thousand keys costs more than the
-		// kernel and the copies together)
+		if (m > guess) {
+			HIP_TRY(hipMemcpyAsync((char*)w->stage_host + sizeof(sgp_ghost_record) * guess, (char*)w->stage_dev + sizeof(sgp_ghost_record) * guess,
+			                       sizeof(sgp_ghost_record) * (m - guess), hipMemcpyDeviceToHost, w->stream));
+			HIP_TRY(hipStreamSynchronize(w->stream));
+		}
+		// deterministic order for the exchange: ascending local id.  LSD radix sort of (id, index) pairs, 3 passes of 11 bits (a comparison
+		// sort of a few thousand keys costs more than the kernel and the copies together), then every 96-byte record moves once.
 		const sgp_ghost_record* src = (const sgp_ghost_record*)w->stage_host;
-		std::vector<uint32_t> idx(m), tmp(m);
-		for (uint32_t k = 0; k < m; ++k) idx[k] = k;
+		std::vector<uint64_t>& a = w->sort_a; std::vector<uint64_t>& b = w->sort_b;
+		a.resize(m); b.resize(m);
+		for (uint32_t k = 0; k < m; ++k) a[k] = ((uint64_t)(uint32_t)src[k].global_id << 32) | k;
 		for (int pass = 0; pass < 3; ++pass) {
 			uint32_t hist[2049] = { 0 };
-			const int sh = 11 * pass;
-			for (uint32_t k = 0; k < m; ++k) ++hist[(((uint32_t)src[idx[k]].global_id >> sh) & 2047u) + 1];
-			for (int b = 0; b < 2048; ++b) hist[b + 1] += hist[b];
-			for (uint32_t k = 0; k < m; ++k) tmp[hist[((uint32_t)src[idx[k]].global_id >> sh) & 2047u]++] = idx[k];
-			idx.swap(tmp);
+			const int sh = 32 + 11 * pass;
+			for (uint32_t k = 0; k < m; ++k) ++hist[((a[k] >> sh) & 2047u) + 1];
+			for (int q = 0; q < 2048; ++q) hist[q + 1] += hist[q];
+			for (uint32_t k = 0; k < m; ++k) b[hist[(a[k] >> sh) & 2047u]++] = a[k];
+			a.swap(b);
 		}
-		for (uint32_t k = 0; k < m; ++k) out[k] = src[idx[k]];
+		for (uint32_t k = 0; k < m; ++k) out[k] = src[(uint32_t)a[k]];
 	}
 	*n_out = n;
 	return SGP_OK;
@@ -1703,18 +1713,18 @@ SGP_API int sgp_world_export_boundary(sgp_world* w, const float lo[3], const flo
 SGP_API int sgp_world_import_ghosts(sgp_world* w, const sgp_ghost_record* in, uint32_t n)
 {
 	if (!w || (!in && n)) return fail(SGP_ERR_INVALID, "sgp_world_import_ghosts: NULL");
-	// ghosts keep their local id while they stay in the set, so the contact cache (keyed by body ids) keeps warm-starting
-	std::unordered_map<uint64_t, uint32_t> next;
-	next.reserve(n * 2 + 1);
+	// ghosts keep their local id while they stay in the set, so the contact cache (keyed by body ids) keeps warm-starting.
+	// ghost_map: global id -> (local id, generation of the last import that contained it)
+	const uint32_t gen = ++w->ghost_gen;
+	w->cmds.reserve(w->cmds.size() + n);
 	for (uint32_t k = 0; k < n; ++k) {
 		auto it = w->ghost_map.find(in[k].global_id);
-		if (it != w->ghost_map.end() && live(w, it->second)) {
-			const uint32_t id = it->second;
+		if (it != w->ghost_map.end() && live(w, (uint32_t)it->second)) {
+			const uint32_t id = (uint32_t)it->second;
 			BodyCmd c = blank_cmd(id, CMD_SET_POS | CMD_SET_ROT | CMD_SET_VEL | CMD_ACTIVATE);
 			memcpy(c.pos, in[k].pos, 12); memcpy(c.rot, in[k].rot, 16); memcpy(c.linv, in[k].lin_vel, 12); memcpy(c.angv, in[k].ang_vel, 12);
 			w->cmds.push_back(c);
-			next[in[k].global_id] = id;
-			w->ghost_map.erase(it);
+			it->second = ((uint64_t)gen << 32) | id;
 			continue;
 		}
 		sgp_body_desc d; sgp_default_body_desc(&d);
@@ -1726,15 +1736,17 @@ SGP_API int sgp_world_import_ghosts(sgp_world* w, const sgp_ghost_record* in, ui
 		d.activate = 1; d.userdata = in[k].global_id;
 		uint32_t id = SGP_INVALID_ID;
 		const int r = add_one(w, &d, &id, true);
-		if (r == SGP_OK) next[in[k].global_id] = id;
+		if (r == SGP_OK) w->ghost_map[in[k].global_id] = ((uint64_t)gen << 32) | id;
 		else if (r != SGP_ERR_REJECTED) return r;
 	}
-	// whatever is left in the old map left the ghost set: remove in ascending id order (deterministic free-list order)
+	// whatever was not refreshed by this import left the ghost set: remove in ascending id order (deterministic free-list order)
 	std::vector<uint32_t> gone;
-	for (auto& kv : w->ghost_map) if (live(w, kv.second)) gone.push_back(kv.second);
+	for (auto it = w->ghost_map.begin(); it != w->ghost_map.end();) {
+		if ((uint32_t)(it->second >> 32) != gen) { if (live(w, (uint32_t)it->second)) gone.push_back((uint32_t)it->second); it = w->ghost_map.erase(it); }
+		else ++it;
+	}
 	std::sort(gone.begin(), gone.end());
 	for (uint32_t id : gone) sgp_body_remove(w, id);
-	w->ghost_map.swap(next);
 	return SGP_OK;
 }
 
