@@ -824,6 +824,8 @@ __global__ void __launch_bounds__(TPB) k_prep_bodies(DV d)
 	if (i >= d.sp->n_slots) return;
 	const uint32_t f = d.flags[i];
 	float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f), w = v, a = v, b = v;
+	// material of the body in the spare lanes of the record (k_setup then needs no other per-body array for it): friction, restitution
+	if (f & BF_ALIVE) { a.w = d.shape[i].w; b.w = d.inv_inertia[i].w; }
 	if ((f & BF_ALIVE) && f_motion(f) != SGP_MOTION_STATIC) {
 		const float4 lv = d.linv[i], av = d.angv[i];
 		v = make_float4(lv.x, lv.y, lv.z, 0.0f);
@@ -831,8 +833,8 @@ __global__ void __launch_bounds__(TPB) k_prep_bodies(DV d)
 		if (f_movable(f)) {
 			const sym33 I = world_inv_inertia(quat_to_m33(Q4(d.rot[i])), V3(d.inv_inertia[i]));
 			v.w = d.pos_im[i].w;
-			a = make_float4(I.xx, I.xy, I.xz, 0.0f);
-			b = make_float4(I.yy, I.yz, I.zz, 0.0f);
+			a = make_float4(I.xx, I.xy, I.xz, a.w);
+			b = make_float4(I.yy, I.yz, I.zz, b.w);
 		}
 	}
 	d.sbody[4 * i + 0] = v; d.sbody[4 * i + 1] = w; d.sbody[4 * i + 2] = a; d.sbody[4 * i + 3] = b;
@@ -1108,12 +1110,11 @@ __global__ void __launch_bounds__(TPB) k_setup(DV d)
 		sym33 I1, I2;
 		I1.xx = sa0.x; I1.xy = sa0.y; I1.xz = sa0.z; I1.yy = sa1.x; I1.yz = sa1.y; I1.zz = sa1.z;
 		I2.xx = sb0.x; I2.xy = sb0.y; I2.xz = sb0.z; I2.yy = sb1.x; I2.yz = sb1.y; I2.zz = sb1.z;
-		const float friction = sqrtf(d.shape[ab.x].w * d.shape[ab.y].w);
-		const float restitution = fmaxf(d.inv_inertia[ab.x].w, d.inv_inertia[ab.y].w);
+		const float friction = sqrtf(sa0.w * sb0.w);               // per-body friction / restitution ride in the solver records (k_prep_bodies)
+		const float restitution = fmaxf(sa1.w, sb1.w);
 		const v3 t1 = v3_normalized_perpendicular(nrm);
 		const v3 t2 = v3_cross(nrm, t1);
 		const v3 lvA = V3(va4), avA = V3(wa4), lvB = V3(vb4), avB = V3(wb4);
-		const float gfA = d.force[ab.x].w, gfB = d.force[ab.y].w;
 		const uint32_t fslot = cache_find(d, key);
 		const uint32_t pslot = d.st.warm_start ? fslot : 0xFFFFFFFFu;
 		int pnp = 0;
@@ -1156,8 +1157,8 @@ __global__ void __launch_bounds__(TPB) k_setup(DV d)
 			if (restitution > 0.0f && normal_velocity < -d.st.min_velocity_for_restitution) {
 				if (normal_velocity < -spec_bias) {
 					v3 rel_acc = V3(0.0f, 0.0f, 0.0f);
-					if (im2 > 0.0f) rel_acc = v3_add(rel_acc, v3_scale(g, gfB));
-					if (im1 > 0.0f) rel_acc = v3_sub(rel_acc, v3_scale(g, gfA));
+					if (im2 > 0.0f) rel_acc = v3_add(rel_acc, v3_scale(g, d.force[ab.y].w));      // gravity factors: only bouncing contacts get here
+					if (im1 > 0.0f) rel_acc = v3_sub(rel_acc, v3_scale(g, d.force[ab.x].w));
 					const float force_dv = fminf(0.0f, v3_dot(rel_acc, nrm)) * dt;
 					bias = restitution * (normal_velocity - force_dv);
 				}
