@@ -1,6 +1,7 @@
 // PhysicsWorld over the sgp C ABI.  Each method follows the reference method of the same name
 // (/root/reference/gui_client/PhysicsWorld.cpp, line ranges in the comments) with Jolt calls replaced by ABI calls.
 #include "PhysicsWorld.h"
+#include <cmath>
 #include <Jolt/JoltVehicleLite.h>
 #include <utils/Exception.h>
 #include "../../include/sgp.h"
@@ -102,6 +103,29 @@ static const PhysicsMeshData::Instance* meshInstance(sgp_world* world, const Phy
 	PhysicsMeshData::Instance in; in.world = world; in.scale[0] = scale.x; in.scale[1] = scale.y; in.scale[2] = scale.z; in.mesh_id = info.mesh_id;
 	m.instances.push_back(in);
 	return &m.instances.back();
+}
+
+// PhysicsWorld.cpp:1155-1166: RotatedTranslatedShape(translation, identity, ScaledShape(shape, scale)) -- a point p of the original
+// shape ends up at translation + scale * p.  The decorators are baked into a new vertex list (GUIClient uses this on the unit quad /
+// unit cube for text objects and splat bounds, GUIClient.cpp:2117,4807).
+PhysicsShape PhysicsWorld::createScaledAndTranslatedShapeForShape(const PhysicsShape& original_shape, const Vec3f& translation, const Vec3f& scale)
+{
+	if (!(std::fabs(scale.x) > 0.f && std::fabs(scale.y) > 0.f && std::fabs(scale.z) > 0.f)) throw glare::Exception("Error building Jolt shape: degenerate scale");
+	PhysicsShape s = original_shape;
+	const float sc[3] = { scale.x, scale.y, scale.z }, tr[3] = { translation.x, translation.y, translation.z };
+	if (original_shape.kind == 3 && original_shape.hull) {
+		s.hull = std::make_shared<PhysicsHullData>();
+		s.hull->points = original_shape.hull->points;
+		for (size_t i = 0; i < s.hull->points.size(); ++i) s.hull->points[i] = tr[i % 3] + sc[i % 3] * s.hull->points[i];
+		for (int i = 0; i < 3; ++i) s.hull->com_offset[i] = sc[i] * original_shape.hull->com_offset[i];
+	} else if (original_shape.kind == 4 && original_shape.mesh) {
+		s.mesh = std::make_shared<PhysicsMeshData>();
+		s.mesh->vertices = original_shape.mesh->vertices;
+		for (size_t i = 0; i < s.mesh->vertices.size(); ++i) s.mesh->vertices[i] = tr[i % 3] + sc[i % 3] * s.mesh->vertices[i];
+		s.mesh->indices = original_shape.mesh->indices;
+		if (scale.x * scale.y * scale.z < 0.f) for (size_t i = 0; i + 2 < s.mesh->indices.size(); i += 3) std::swap(s.mesh->indices[i + 1], s.mesh->indices[i + 2]);
+	} else throw glare::Exception("Error building Jolt shape: scale / translate decorators are implemented for convex hull and mesh shapes");
+	return s;
 }
 
 PhysicsShape PhysicsWorld::createCOMOffsetShapeForShape(const PhysicsShape& original_shape, const Vec4f& COM_offset)

@@ -89,6 +89,7 @@ public:
 	static PhysicsShape createJoltHeightFieldShape(int vert_res, const std::vector<float>& heightfield, int width, float quad_w);
 	// PhysicsWorld.cpp:1138-1153 (OffsetCenterOfMassShapeSettings); implemented for convex hull shapes.
 	static PhysicsShape createCOMOffsetShapeForShape(const PhysicsShape& original_shape, const Vec4f& COM_offset);
+	static PhysicsShape createScaledAndTranslatedShapeForShape(const PhysicsShape& shape, const Vec3f& translation, const Vec3f& scale);      // PhysicsWorld.h:133
 
 	// What body_interface.CreateBody(...) hands CarPhysics / BikePhysics (CarPhysics.cpp:84-88): the body an already added object is
 	// simulated as, for constructing a JPH::VehicleConstraint on it.

@@ -62,6 +62,26 @@ int main()
 		ok = ok && r.hit_object == building.ptr() && std::fabs(r.hit_t - 7.f) < 1e-3f && r.hit_normal_ws[0] < -0.99f;
 		world->traceRay(Vec4f(10, 10, 3, 1), Vec4f(1, 0, 0, 0), 2.9f, JPH::BodyID(), r);
 		ok = ok && r.hit_object == NULL;
+		// a decorated unit cube, as GUIClient builds for splat bounds (createScaledAndTranslatedShapeForShape(unit_cube_shape, aabb_min, aabb_span),
+		// GUIClient.cpp:4807): the [0,1]^3 cube mesh mapped onto the box [(-1,-2,0), (1,2,1.5)] of an object floating at (-12, 12, 8)
+		{
+			std::vector<Vec3f> cv; std::vector<uint32> ct;
+			for (int i = 0; i < 8; ++i) cv.push_back(Vec3f((float)(i & 1), (float)((i >> 1) & 1), (float)((i >> 2) & 1)));
+			const uint32 quads[6][4] = { { 0, 2, 3, 1 }, { 4, 5, 7, 6 }, { 0, 1, 5, 4 }, { 2, 6, 7, 3 }, { 0, 4, 6, 2 }, { 1, 3, 7, 5 } };      // outward-facing
+			for (int q = 0; q < 6; ++q) { ct.push_back(quads[q][0]); ct.push_back(quads[q][1]); ct.push_back(quads[q][2]); ct.push_back(quads[q][0]); ct.push_back(quads[q][2]); ct.push_back(quads[q][3]); }
+			const PhysicsShape unit_cube = PhysicsWorld::createMeshShape(cv, ct);
+			Reference<PhysicsObject> bounds = new PhysicsObject(true, PhysicsWorld::createScaledAndTranslatedShapeForShape(unit_cube, Vec3f(-1.f, -2.f, 0.f), Vec3f(2.f, 4.f, 1.5f)), nullptr, 0);
+			bounds->pos = Vec4f(-12.f, 12.f, 8.f, 1);
+			world->addObject(bounds);
+			world->traceRay(Vec4f(-12.5f, 13.5f, 30, 1), Vec4f(0, 0, -1, 0), 100.f, JPH::BodyID(), r);
+			const bool top = r.hit_object == bounds.ptr() && std::fabs(r.hit_t - (30.f - 9.5f)) < 1e-3f && r.hit_normal_ws[2] > 0.99f;
+			world->traceRay(Vec4f(-20.f, 13.9f, 8.7f, 1), Vec4f(1, 0, 0, 0), 100.f, JPH::BodyID(), r);
+			const bool side = r.hit_object == bounds.ptr() && std::fabs(r.hit_t - 7.f) < 1e-3f && r.hit_normal_ws[0] < -0.99f;
+			world->traceRay(Vec4f(-20.f, 14.1f, 8.7f, 1), Vec4f(1, 0, 0, 0), 12.f, JPH::BodyID(), r);      // just past its +y face: misses it
+			const bool miss = r.hit_object != bounds.ptr();
+			if (!(top && side && miss)) printf("decorated cube: top %d side %d miss %d\n", (int)top, (int)side, (int)miss);
+			ok = ok && top && side && miss;
+		}
 		printf("rays ok %d\n", (int)ok);
 
 		// the player: starts on the terrain west of the building, walks east (+x, uphill on average) into its wall
