@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cassert>
 #include <cstring>
+#include <cstdio>
 
 static inline float myClamp(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
@@ -486,6 +487,32 @@ const Vec4f PhysicsWorld::getPosInJolt(const Reference<PhysicsObject>& object)
 	return p;
 }
 size_t PhysicsWorld::getNumObjects() const { uint32_t n = 0; sgp_world_num_bodies(world, &n); return n; }
+
+// PhysicsWorld.cpp:1728-1739 (debug): every body slot's state, raw
+void PhysicsWorld::writeJoltSnapshotToDisk(const std::string& path)
+{
+	sgp_step_stats st; memset(&st, 0, sizeof(st));
+	sgp_world_stats(world, &st);
+	const uint32_t n = (uint32_t)id_to_ob.size();
+	std::vector<sgp_body_state> states(n);
+	if (n && sgp_world_read_states(world, 0, n, states.data()) != SGP_OK) return;
+	FILE* f = fopen(path.c_str(), "wb");
+	if (!f) return;
+	const char magic[8] = { 'S', 'G', 'P', 'S', 'N', 'A', 'P', '1' };
+	const uint32_t header[2] = { n, (uint32_t)sizeof(sgp_body_state) };
+	fwrite(magic, 1, 8, f); fwrite(header, sizeof(uint32_t), 2, f);
+	if (n) fwrite(states.data(), sizeof(sgp_body_state), n, f);
+	fclose(f);
+}
+
+// PhysicsWorld.cpp:725-732
+size_t PhysicsWorld::computeSizeBForShape(const PhysicsShape& shape)
+{
+	size_t b = sizeof(PhysicsShape);
+	if (shape.hull) b += shape.hull->points.size() * sizeof(float);
+	if (shape.mesh) b += shape.mesh->vertices.size() * sizeof(float) + shape.mesh->indices.size() * sizeof(uint32_t);
+	return b;
+}
 
 // PhysicsWorld.cpp:1668-1725
 static void doTraceRay(sgp_world* world, const Vec4f& origin, const Vec4f& dir, float max_t, JPH::BodyID ignore_body_id, bool collidable_only, RayTraceResult& results_out)

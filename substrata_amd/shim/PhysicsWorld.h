@@ -112,6 +112,11 @@ public:
 	const Vec4f getPosInJolt(const Reference<PhysicsObject>& object);
 	size_t getNumObjects() const;
 
+	// Debug helpers (PhysicsWorld.h:187-189).  The snapshot is this library's own flat dump (a header + one sgp_body_state per body slot),
+	// not Jolt's PhysicsScene stream; computeSizeBForShape reports the bytes the shape description holds.
+	void writeJoltSnapshotToDisk(const std::string& path);
+	static size_t computeSizeBForShape(const PhysicsShape& shape);
+
 	void traceRay(const Vec4f& origin, const Vec4f& dir, float max_t, JPH::BodyID ignore_body_id, RayTraceResult& results_out) const;
 	void traceRayAgainstCollidableObs(const Vec4f& origin, const Vec4f& dir, float max_t, JPH::BodyID ignore_body_id, RayTraceResult& results_out) const;
 	bool doesRayHitAnything(const Vec4f& origin, const Vec4f& dir, float max_t) const;

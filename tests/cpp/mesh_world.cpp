@@ -7,6 +7,7 @@
 #include <utils/Exception.h>
 #include <cstdio>
 #include <cmath>
+#include <string>
 
 static float terrainHeight(float x, float y) { return 0.8f * std::sin(0.25f * x) * std::cos(0.2f * y) + 0.05f * x; }
 
@@ -81,6 +82,13 @@ int main()
 			const bool miss = r.hit_object != bounds.ptr();
 			if (!(top && side && miss)) printf("decorated cube: top %d side %d miss %d\n", (int)top, (int)side, (int)miss);
 			ok = ok && top && side && miss;
+		}
+		{      // debug helpers of the facade (PhysicsWorld.h:187-189)
+			world->writeJoltSnapshotToDisk("/tmp/sgp_mesh_world.snap");
+			FILE* f = fopen("/tmp/sgp_mesh_world.snap", "rb");
+			char magic[9] = { 0 }; const bool snap = f && fread(magic, 1, 8, f) == 8 && std::string(magic) == "SGPSNAP1";
+			if (f) fclose(f);
+			ok = ok && snap && PhysicsWorld::computeSizeBForShape(building->shape) > sizeof(PhysicsShape);
 		}
 		printf("rays ok %d\n", (int)ok);
 
