@@ -3,6 +3,7 @@
 #pragma once
 #include <cstdint>
 #include <vector>
+#include <cmath>
 namespace JPH
 {
 	typedef unsigned int uint;
@@ -15,7 +16,13 @@ namespace JPH
 		Vec3 operator+(const Vec3& o) const { return Vec3(x + o.x, y + o.y, z + o.z); }
 		Vec3 operator-(const Vec3& o) const { return Vec3(x - o.x, y - o.y, z - o.z); }
 		Vec3 operator*(float f) const { return Vec3(x * f, y * f, z * f); }
+		Vec3 operator/(float f) const { return Vec3(x / f, y / f, z / f); }
+		Vec3 operator-() const { return Vec3(-x, -y, -z); }
+		float Dot(const Vec3& o) const { return x * o.x + y * o.y + z * o.z; }
+		Vec3 Cross(const Vec3& o) const { return Vec3(y * o.z - z * o.y, z * o.x - x * o.z, x * o.y - y * o.x); }
 		float LengthSq() const { return x * x + y * y + z * z; }
+		float Length() const { return std::sqrt(LengthSq()); }
+		Vec3 Normalized() const { const float l = Length(); return Vec3(x / l, y / l, z / l); }
 		float x, y, z;
 	};
 	typedef Vec3 RVec3;

@@ -31,6 +31,7 @@ def test_facade_compiles_without_gpu(tmp_path):
     assert os.path.exists(build_facade_exe(tmp_path, "bike_controller.cpp"))
     assert os.path.exists(build_facade_exe(tmp_path, "player_controller.cpp"))
     assert os.path.exists(build_facade_exe(tmp_path, "mesh_world.cpp"))
+    assert os.path.exists(build_facade_exe(tmp_path, "boat_controller.cpp"))
 
 
 @pytest.mark.gpu
@@ -38,6 +39,16 @@ def test_hover_controller_through_body_interface(tmp_path):
     """A HoverCarPhysics-shaped controller drives a body through physics_system->GetBodyInterface() (AddForce, AddTorque,
     GetWorldTransform, GetLinearVelocity ...): the body settles at the spring's target height and has yawed."""
     exe = build_facade_exe(tmp_path, "hover_controller.cpp")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_boat_controller_on_the_buoyancy_sweep(tmp_path):
+    """A BoatPhysics-shaped controller: a box hull floats at its density ratio on think()'s buoyancy sweep, is driven by a thrust applied
+    at the propellor point, slowed by drag scaled with PhysicsObject::last_submerged_volume, and turned by a rudder force."""
+    exe = build_facade_exe(tmp_path, "boat_controller.cpp")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     print(r.stdout)
     assert r.returncode == 0, r.stdout + r.stderr
