@@ -535,6 +535,28 @@ void PhysicsWorld::traceRay(const Vec4f& origin, const Vec4f& dir, float max_t, 
 { doTraceRay(world, origin, dir, max_t, ignore_body_id, false, results_out); }
 void PhysicsWorld::traceRayAgainstCollidableObs(const Vec4f& origin, const Vec4f& dir, float max_t, JPH::BodyID ignore_body_id, RayTraceResult& results_out) const
 { doTraceRay(world, origin, dir, max_t, ignore_body_id, true, results_out); }
+void PhysicsWorld::traceRays(const std::vector<RayQuery>& rays, std::vector<RayTraceResult>& results_out) const
+{
+	results_out.resize(rays.size());
+	if (rays.empty()) return;
+	std::vector<sgp_ray> rs(rays.size()); std::vector<sgp_hit> hs(rays.size());
+	memset(rs.data(), 0, sizeof(sgp_ray) * rs.size());
+	for (size_t k = 0; k < rays.size(); ++k) {
+		for (int i = 0; i < 3; ++i) { rs[k].origin[i] = rays[k].origin[i]; rs[k].dir[i] = rays[k].dir[i]; }
+		rs[k].max_t = rays[k].max_t; rs[k].ignore_id = rays[k].ignore_body_id.GetIndex(); rs[k].collidable_only = rays[k].collidable_only ? 1u : 0u;
+	}
+	const bool ok = sgp_raycast(world, rs.data(), (uint32_t)rs.size(), hs.data()) == SGP_OK;
+	for (size_t k = 0; k < rays.size(); ++k) {
+		RayTraceResult& r = results_out[k];
+		r.hit_object = NULL;
+		if (!ok || hs[k].id == SGP_INVALID_ID || hs[k].userdata == 0) continue;
+		r.hit_object = (PhysicsObject*)hs[k].userdata;
+		r.coords = Vec2f(0.f);
+		r.hit_t = hs[k].t;
+		r.hit_normal_ws = Vec4f(hs[k].normal[0], hs[k].normal[1], hs[k].normal[2], 0.f);
+		r.hit_mat_index = 0;
+	}
+}
 bool PhysicsWorld::doesRayHitAnything(const Vec4f& origin, const Vec4f& dir, float max_t) const
 {
 	sgp_ray r; memset(&r, 0, sizeof(r));

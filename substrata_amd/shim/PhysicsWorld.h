@@ -121,6 +121,12 @@ public:
 	void traceRayAgainstCollidableObs(const Vec4f& origin, const Vec4f& dir, float max_t, JPH::BodyID ignore_body_id, RayTraceResult& results_out) const;
 	bool doesRayHitAnything(const Vec4f& origin, const Vec4f& dir, float max_t) const;
 
+	// Extension (not in the reference): many rays in ONE device launch.  A single traceRay costs a kernel launch and a host sync
+	// (tens of microseconds) however cheap the ray; ParticleManager::think (ParticleManager.cpp:145-274) traces one ray per particle,
+	// up to 2048 per frame, so its loop should collect the rays, call this once and then react to the results.
+	struct RayQuery { Vec4f origin, dir; float max_t; JPH::BodyID ignore_body_id; bool collidable_only; };
+	void traceRays(const std::vector<RayQuery>& rays, std::vector<RayTraceResult>& results_out) const;
+
 	// What GUIClient.cpp:6581-6690 does through physics_system->GetBodyInterface(): copy the poses of the activated
 	// objects back into PhysicsObject::pos / rot (one batched device read instead of one Jolt call per object).
 	void readBackActivatedObjectTransforms();

@@ -55,6 +55,16 @@ def test_boat_controller_on_the_buoyancy_sweep(tmp_path):
 
 
 @pytest.mark.gpu
+def test_particle_rays_serial_and_batched(tmp_path):
+    """A ParticleManager-shaped loop (one traceRay per particle per frame, 2048 particles) against the batched extension traceRays():
+    identical results; the printed timings document what the per-call latency costs."""
+    exe = build_facade_exe(tmp_path, "particle_rays.cpp")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
 def test_car_controller_through_vehicle_constraint(tmp_path):
     """A CarPhysics-shaped caller builds JPH::VehicleConstraintSettings / WheelSettingsWV / WheeledVehicleControllerSettings as
     CarPhysics.cpp:94-231 does, registers the constraint, drives (throttle, steer right, brake) and reads the wheels back."""
