@@ -1589,11 +1589,18 @@ SGP_API int sgp_raycast(sgp_world* w, const sgp_ray* rays, uint32_t n, sgp_hit* 
 	const size_t rb = (sizeof(sgp_ray) * n + 15) & ~size_t(15);
 	{ int r = ensure_stage(w, rb + sizeof(sgp_hit) * n); if (r != SGP_OK) return r; }
 	memcpy(w->stage_host, rays, sizeof(sgp_ray) * n);
-	HIP_TRY(hipMemcpyAsync(w->stage_dev, w->stage_host, sizeof(sgp_ray) * n, hipMemcpyHostToDevice, w->stream));
-	sgp_hit* dh = (sgp_hit*)((char*)w->stage_dev + rb);
-	launch_raycast(w->dv, (const sgp_ray*)w->stage_dev, n, dh, w->stream);
-	HIP_TRY(hipMemcpyAsync((char*)w->stage_host + rb, dh, sizeof(sgp_hit) * n, hipMemcpyDeviceToHost, w->stream));
-	HIP_TRY(hipStreamSynchronize(w->stream));
+	if (n <= 64) {
+		// a handful of rays (the facade's traceRay is n = 1): the kernel reads them from, and writes the hits to, the pinned host buffer
+		// directly -- one launch and one sync instead of two copies around it
+		launch_raycast(w->dv, (const sgp_ray*)w->stage_host, n, (sgp_hit*)((char*)w->stage_host + rb), w->stream);
+		HIP_TRY(hipStreamSynchronize(w->stream));
+	} else {
+		HIP_TRY(hipMemcpyAsync(w->stage_dev, w->stage_host, sizeof(sgp_ray) * n, hipMemcpyHostToDevice, w->stream));
+		sgp_hit* dh = (sgp_hit*)((char*)w->stage_dev + rb);
+		launch_raycast(w->dv, (const sgp_ray*)w->stage_dev, n, dh, w->stream);
+		HIP_TRY(hipMemcpyAsync((char*)w->stage_host + rb, dh, sizeof(sgp_hit) * n, hipMemcpyDeviceToHost, w->stream));
+		HIP_TRY(hipStreamSynchronize(w->stream));
+	}
 	memcpy(hits, (char*)w->stage_host + rb, sizeof(sgp_hit) * n);
 	for (uint32_t k = 0; k < n; ++k) hits[k].userdata = hits[k].id != SGP_INVALID_ID ? w->hb[hits[k].id].userdata : 0;
 	return SGP_OK;
