@@ -1806,10 +1806,19 @@ __global__ void __launch_bounds__(TPB) k_island_flag(DV d)
 	}
 }
 
+SGP_DEV void sleep_apply_one(const DV& d, uint32_t i, bool& active);
 __global__ void __launch_bounds__(TPB) k_sleep_apply(DV d)
 {
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-	if (i >= d.sp->n_slots) return;
+	bool active = false;
+	if (i < d.sp->n_slots) sleep_apply_one(d, i, active);
+	// one atomic per wave for the active-body count (100k single-address atomics cost more than the rest of the kernel)
+	const unsigned long long m = __ballot(active);
+	if (m && (threadIdx.x & 63) == 0) atomicAdd(&d.ctr->n_active, (uint32_t)__popcll(m));
+}
+
+SGP_DEV void sleep_apply_one(const DV& d, uint32_t i, bool& active)
+{
 	uint32_t f = d.flags[i];
 	if (!(f & BF_ALIVE)) return;
 	if (f_movable(f)) {
@@ -1828,7 +1837,7 @@ __global__ void __launch_bounds__(TPB) k_sleep_apply(DV d)
 			push_event(d.ev_deactivated, &d.evc->n_deactivated, d.cap_bodies, i);
 		}
 	}
-	if (f & BF_ACTIVE) atomicAdd(&d.ctr->n_active, 1u);
+	active = (f & BF_ACTIVE) != 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
