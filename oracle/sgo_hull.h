@@ -259,7 +259,7 @@ static inline float sgo_hull_closest(const sgo_hull* h, v3 l, v3* q_out, v3* n_o
 		*q_out = v3_sub(l, v3_scale(h->normals[fmax], smax));
 		return smax;
 	}
-	float best = 3.4e38f; v3 bq = l;
+	float best = 3.4e38f; v3 bq = l; int on_face = -1;
 	for (int f = 0; f < h->nf; ++f) {
 		const v3 n = h->normals[f];
 		const float s = v3_dot(n, l) - h->plane_d[f];
@@ -271,17 +271,24 @@ static inline float sgo_hull_closest(const sgo_hull* h, v3 l, v3* q_out, v3* n_o
 			const v3 a = h->verts[h->face_idx[k]], b = h->verts[h->face_idx[k + 1 < k1 ? k + 1 : k0]];
 			if (v3_dot(v3_cross(v3_sub(b, a), n), v3_sub(p, a)) > 0.0f) { inside = 0; break; }
 		}
-		if (inside) { const float d2 = s * s; if (d2 < best) { best = d2; bq = p; } continue; }
+		if (inside) { const float d2 = s * s; if (d2 < best) { best = d2; bq = p; on_face = f; } continue; }
 		for (int k = k0; k < k1; ++k) {
 			const v3 a = h->verts[h->face_idx[k]], b = h->verts[h->face_idx[k + 1 < k1 ? k + 1 : k0]];
 			const v3 c = sgo_closest_on_segment(a, b, l);
 			const float d2 = v3_len_sq(v3_sub(l, c));
-			if (d2 < best) { best = d2; bq = c; }
+			if (d2 < best) { best = d2; bq = c; on_face = -1; }
 		}
 	}
 	const float dist = sqrtf(best);
 	*q_out = bq;
-	*n_out = dist > 1.0e-12f ? v3_scale(v3_sub(l, bq), 1.0f / dist) : h->normals[fmax];
+	/* over a face the direction IS the face normal: l - q would cancel to nothing once the distance drops below the rounding of l
+	   (the distance itself, taken from the plane equation, stays accurate) -- and a zero direction poisons the whole solve */
+	if (on_face >= 0) *n_out = h->normals[on_face];
+	else {
+		const v3 v = v3_sub(l, bq);
+		const float len = v3_len(v);
+		*n_out = len > 1.0e-12f ? v3_scale(v, 1.0f / len) : h->normals[fmax];
+	}
 	return dist;
 }
 

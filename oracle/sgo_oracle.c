@@ -861,6 +861,7 @@ static void find_contacts(sgo_world* w, float dt)
 		for (int g = 0; g < hit[p]; ++g) {
 			uint32_t a = w->pairs[p].a, b = w->pairs[p].b;
 			sgo_manifold m = mans[3 * p + g];
+			if (!(v3_len_sq(m.n) > 0.25f)) continue;          /* safety net: a manifold without a direction (or with a NaN one) is dropped, never solved */
 			const int mesh_a = w->bodies[a].shape_type == SGP_SHAPE_MESH, mesh_b = w->bodies[b].shape_type == SGP_SHAPE_MESH;
 			if (mesh_a || mesh_b) {
 				/* the manifold runs mesh -> body; the constraint runs lower id -> higher id, with the mesh's g-th slot */
@@ -1532,6 +1533,30 @@ static sgo_chassis chassis_load(const sgo_body* b)
    broad-phase grid instead and must find the same hit. */
 static float cast_sphere_mesh(const sgo_body* M, v3 o, v3 d, float max_t, float rs, v3* n_out, v3* p_out);
 
+/* Slab test of a ray against a box, the broad-phase filter in front of every swept-sphere test (same arithmetic as the device's
+ * ray_aabb; it is part of the result because the planes-only swept-sphere test of hulls and boxes is generous at their corners). */
+static int ray_aabb(v3 o, v3 dir, v3 mn, v3 mx, float tmax)
+{
+	float t0 = 0.0f, t1 = tmax;
+	const float oo[3] = { o.x, o.y, o.z }, dd[3] = { dir.x, dir.y, dir.z };
+	const float lo[3] = { mn.x, mn.y, mn.z }, hi[3] = { mx.x, mx.y, mx.z };
+	for (int a = 0; a < 3; ++a) {
+		if (fabsf(dd[a]) < 1.0e-12f) { if (oo[a] < lo[a] - 1.0e-4f || oo[a] > hi[a] + 1.0e-4f) return 0; }
+		else {
+			float ta = (lo[a] - 1.0e-4f - oo[a]) / dd[a], tb = (hi[a] + 1.0e-4f - oo[a]) / dd[a];
+			if (ta > tb) { const float tmp = ta; ta = tb; tb = tmp; }
+			t0 = fmaxf(t0, ta); t1 = fminf(t1, tb);
+			if (t0 > t1) return 0;
+		}
+	}
+	return 1;
+}
+static int cast_reaches_bounds(const sgo_body* b, v3 o, v3 dir, float rs, float best)
+{
+	const float e = rs + 1.0e-3f;
+	return ray_aabb(o, dir, V3(b->aabb_min.x - e, b->aabb_min.y - e, b->aabb_min.z - e), V3(b->aabb_max.x + e, b->aabb_max.y + e, b->aabb_max.z + e), best);
+}
+
 static void vehicles_pre_step(sgo_world* w, float dt)
 {
 	if (w->n_vehicles == 0) return;
@@ -1563,6 +1588,7 @@ static void vehicles_pre_step(sgo_world* w, float dt)
 				if (bb[3] < lo.x || bb[0] > hi.x || bb[4] < lo.y || bb[1] > hi.y || bb[5] < lo.z || bb[2] > hi.z) continue;
 				if (j == v->body) continue;
 				const sgo_body* o = &w->bodies[j];
+				if (!cast_reaches_bounds(o, wh->cast_origin, wh->cast_dir, v->cast_radius, wh->cast_len)) continue;      /* full length, not `best`: the answer must not depend on the visiting order */
 				v3 n, p;
 				const float t = o->shape_type == SGP_SHAPE_MESH ? cast_sphere_mesh(o, wh->cast_origin, wh->cast_dir, best, v->cast_radius, &n, &p)
 				                                                : sgo_cast_sphere_body(o->shape_type, o->shape, o->hull, o->pos, quat_to_m33(o->rot), wh->cast_origin, wh->cast_dir, best, v->cast_radius, &n, &p);
@@ -1608,13 +1634,39 @@ static int cmp_prev(const void* a, const void* b)
 	return (x->key > y->key) - (x->key < y->key);
 }
 
+/* Debugging aid: with SGO_NAN_TRACE=1 in the environment, reports the first stage of a step after which some body's state is not finite. */
+static void nan_trace(sgo_world* w, const char* stage)
+{
+	static int enabled = -1, reported = 0;
+	if (enabled < 0) { const char* e = getenv("SGO_NAN_TRACE"); enabled = (e && e[0] == '1') ? 1 : 0; }
+	if (!enabled || reported) return;
+	for (uint32_t k = 0; (stage[0] == '4' || stage[0] == '5') && k < w->n_cons; ++k) {
+		const sgo_constraint* c = &w->cons[k];
+		float s = c->n.x + c->n.y + c->n.z + c->t1.x + c->t1.y + c->t1.z + c->friction;
+		for (int i = 0; i < c->np; ++i) s += c->pt[i].r1.x + c->pt[i].r1.y + c->pt[i].r1.z + c->pt[i].r2.x + c->pt[i].r2.y + c->pt[i].r2.z + c->pt[i].bias + c->pt[i].eff_n + c->pt[i].eff_t1 + c->pt[i].eff_t2 + c->pt[i].lam_n + c->pt[i].lam_t1 + c->pt[i].lam_t2;
+		if (!(s - s == 0.0f)) {
+			fprintf(stderr, "[sgo nan trace] constraint (%u shape %d, %u shape %d) not finite after stage '%s': n %g %g %g t1 %g %g %g np %d", c->a, w->bodies[c->a].shape_type, c->b, w->bodies[c->b].shape_type, stage, c->n.x, c->n.y, c->n.z, c->t1.x, c->t1.y, c->t1.z, c->np);
+			for (int i = 0; i < c->np; ++i) fprintf(stderr, " | r1 %g %g %g bias %g eff %g %g %g lam %g %g %g", c->pt[i].r1.x, c->pt[i].r1.y, c->pt[i].r1.z, c->pt[i].bias, c->pt[i].eff_n, c->pt[i].eff_t1, c->pt[i].eff_t2, c->pt[i].lam_n, c->pt[i].lam_t1, c->pt[i].lam_t2);
+			fprintf(stderr, "\n"); reported = 1; return;
+		}
+	}
+	for (uint32_t i = 0; i < w->high; ++i) {
+		const sgo_body* b = &w->bodies[i];
+		if (!b->alive) continue;
+		const float s = b->pos.x + b->pos.y + b->pos.z + b->linv.x + b->linv.y + b->linv.z + b->angv.x + b->angv.y + b->angv.z + b->rot.x + b->rot.y + b->rot.z + b->rot.w;
+		if (!(s - s == 0.0f)) { fprintf(stderr, "[sgo nan trace] body %u not finite after stage '%s' (linv %g %g %g angv %g %g %g)\n", i, stage, b->linv.x, b->linv.y, b->linv.z, b->angv.x, b->angv.y, b->angv.z); reported = 1; return; }
+	}
+}
+
 SGO_API int sgo_world_step(sgo_world* w, float dt)
 {
 	if (!w || !(dt > 0.0f)) return SGP_ERR_INVALID;
 	memset(&w->stats, 0, sizeof(w->stats));
 
 	/* 0. step listeners: VehicleConstraint::OnStep (wheel casts, controller, row setup) */
+	nan_trace(w, "edits before the step");
 	vehicles_pre_step(w, dt);
+	nan_trace(w, "0 vehicle pre-step");
 
 	/* 1. MotionProperties::ApplyForceTorqueAndDragInternal (JobApplyGravity) */
 	#pragma omp parallel for schedule(static, 1024) if (g_threads > 1)
@@ -1637,6 +1689,7 @@ SGO_API int sgo_world_step(sgo_world* w, float dt)
 	broad_phase(w);
 	find_contacts(w, dt);
 
+	nan_trace(w, "1-3 forces, collision");
 	/* 4. colouring and solve order */
 	colour_constraints(w);
 	w->order = (uint32_t*)realloc(w->order, sizeof(uint32_t) * (w->n_cons ? w->n_cons : 1));
@@ -1666,11 +1719,13 @@ SGO_API int sgo_world_step(sgo_world* w, float dt)
 			} else for (uint32_t k_ = b_; k_ < e_; ++k_) fn(w, &w->cons[w->order[k_]]); \
 		} } while (0)
 
+	nan_trace(w, "4 colouring, setup");
 	/* 5. warm start + velocity iterations */
 	/* (non-contact constraints -- here: the vehicles -- go first in every pass, as in PhysicsSystem::JobSolveVelocityConstraints) */
 	if (w->st.warm_start) { vehicles_solve(w, 0, dt); SOLVE_PASS(warm_start_constraint); }
 	for (int it = 0; it < w->st.num_velocity_steps; ++it) { vehicles_solve(w, 1, dt); SOLVE_PASS(solve_velocity_constraint); }
 
+	nan_trace(w, "5 warm start + velocity iterations");
 	/* 6. integrate positions (Body::AddPositionStep / AddRotationStep) */
 	#pragma omp parallel for schedule(static, 1024) if (g_threads > 1)
 	for (uint32_t i = 0; i < w->high; ++i) {
@@ -1686,17 +1741,21 @@ SGO_API int sgo_world_step(sgo_world* w, float dt)
 		b->rot = quat_add_rotation_step(b->rot, v3_scale(b->angv, dt));
 	}
 
+	nan_trace(w, "6 integrate");
 	/* 7. position iterations */
 	for (int it = 0; it < w->st.num_position_steps; ++it) { vehicles_solve(w, 2, dt); SOLVE_PASS(solve_position_constraint); }
 
+	nan_trace(w, "7 position iterations");
 	/* 8. bounds, sleeping */
 	#pragma omp parallel for schedule(static, 1024) if (g_threads > 1)
 	for (uint32_t i = 0; i < w->high; ++i) { sgo_body* b = &w->bodies[i]; if (b->alive && b->active) body_update_aabb(b); }
 	update_sleeping(w, dt);
 
+	nan_trace(w, "8 bounds, sleeping");
 	/* 9. buoyancy (Substrata's own sweep after Update) */
 	if (w->water_enabled) buoyancy_sweep(w, dt);
 
+	nan_trace(w, "9 buoyancy");
 	/* 10. contact cache for the next step */
 	{
 		sgo_constraint* t = w->prev; w->prev = w->cons; w->cons = t;
@@ -2087,6 +2146,7 @@ SGO_API int sgo_spherecast(sgo_world* w, const sgp_ray* rays, const float* radii
 			const sgo_body* b = &w->bodies[i];
 			if (!b->alive || b->is_alias || i == rays[k].ignore_id || b->is_sensor) continue;
 			if (rays[k].collidable_only && !(b->layer == SGP_LAYER_NON_MOVING || b->layer == SGP_LAYER_MOVING)) continue;
+			if (!cast_reaches_bounds(b, o, d, radii[k], rays[k].max_t)) continue;
 			v3 nn, pp;
 			const float t = b->shape_type == SGP_SHAPE_MESH ? cast_sphere_mesh(b, o, d, best, radii[k], &nn, &pp)
 			                                                : sgo_cast_sphere_body(b->shape_type, b->shape, b->hull, b->pos, quat_to_m33(b->rot), o, d, best, radii[k], &nn, &pp);

@@ -583,6 +583,7 @@ SGP_DEV sgd_shape load_shape(const DV& d, uint32_t i, uint32_t f)
 
 SGP_DEV void emit_manifold(const DV& d, uint2 ab, uint32_t fa, uint32_t fb, const sgd_manifold& m)
 {
+	if (!(v3_len_sq(m.n) > 0.25f)) return;          // safety net: a manifold without a direction (or with a NaN one) is dropped, never solved
 	const uint32_t slot = atomicAdd(&d.ctr->n_manifolds, 1u);
 	if (slot >= d.cap_manifolds) { atomicAdd(&d.ctr->manifolds_dropped, 1u); return; }
 	d.man_ab[slot] = ab;
@@ -2437,7 +2438,7 @@ SGP_DEV float cast_sphere_mesh(const DV& d, uint32_t j, v3 o, v3 dir, float max_
 	return best;
 }
 
-SGP_DEV void veh_cast_test(const DV& d, const sgd_vehicle* v, v3 o, v3 dir, float rs, uint32_t j, float& best, uint32_t& bid, v3& bn, v3& bp)
+SGP_DEV void veh_cast_test(const DV& d, const sgd_vehicle* v, v3 o, v3 dir, float rs, float cast_len, uint32_t j, float& best, uint32_t& bid, v3& bn, v3& bp)
 {
 	if (j == v->body) return;
 	const uint32_t f = d.flags[j];
@@ -2446,7 +2447,9 @@ SGP_DEV void veh_cast_test(const DV& d, const sgd_vehicle* v, v3 o, v3 dir, floa
 	if (!(layer == SGP_LAYER_NON_MOVING || layer == SGP_LAYER_MOVING)) return;            // tester object layer MOVING, CarPhysics.cpp:62
 	const float4 mn = d.aabb_min[j], mx = d.aabb_max[j];
 	const float e = rs + 1.0e-3f;
-	if (!ray_aabb(o, dir, make_float4(mn.x - e, mn.y - e, mn.z - e, 0.0f), make_float4(mx.x + e, mx.y + e, mx.z + e, 0.0f), best)) return;
+	// the bounds filter uses the full cast length, not the best hit so far: the planes-only swept-sphere test of boxes and hulls can report a
+	// touch just outside the inflated bounds (it is generous at corners), and the answer must not depend on the order of the candidates
+	if (!ray_aabb(o, dir, make_float4(mn.x - e, mn.y - e, mn.z - e, 0.0f), make_float4(mx.x + e, mx.y + e, mx.z + e, 0.0f), cast_len)) return;
 	const float4 sh = d.shape[j];
 	const float prm[3] = { sh.x, sh.y, sh.z };
 	v3 n, p;
@@ -2512,7 +2515,7 @@ __global__ void __launch_bounds__(64) k_vehicle_cast(DV d)
 			const v3 o = wh->cast_origin, dir = wh->cast_dir;
 			const float rs = sv.cast_radius;
 			best = wh->cast_len;
-			for (uint32_t l = sub; l < d.sp->n_large; l += 16) veh_cast_test(d, &sv, o, dir, rs, d.large_ids[l], best, bid, bn, bp);
+			for (uint32_t l = sub; l < d.sp->n_large; l += 16) veh_cast_test(d, &sv, o, dir, rs, wh->cast_len, d.large_ids[l], best, bid, bn, bp);
 			const BpGrid g = *d.grid;
 			if (g.n_cells > 0 && g.min_x <= g.max_x) {
 				// cells overlapped by the swept sphere's box, one more cell each side (bodies are binned by centre and reach at most one cell beyond it)
@@ -2524,7 +2527,7 @@ __global__ void __launch_bounds__(64) k_vehicle_cast(DV d)
 				if (x0 <= x1) for (int z = z0; z <= z1; ++z) for (int y = y0; y <= y1; ++y) {
 					const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
 					const uint32_t q0 = d.cell_start[row + (uint32_t)x0], q1 = d.cell_start[row + (uint32_t)x1 + 1];
-					for (uint32_t q = q0 + sub; q < q1; q += 16) veh_cast_test(d, &sv, o, dir, rs, __float_as_uint(d.sorted_max[q].w), best, bid, bn, bp);
+					for (uint32_t q = q0 + sub; q < q1; q += 16) veh_cast_test(d, &sv, o, dir, rs, wh->cast_len, __float_as_uint(d.sorted_max[q].w), best, bid, bn, bp);
 				}
 			}
 		}
@@ -2668,7 +2671,7 @@ SGP_DEV void spherecast_body(const DV& d, const sgp_ray& ry, float rs, v3 o, v3 
 	if (ry.collidable_only && !(layer == SGP_LAYER_NON_MOVING || layer == SGP_LAYER_MOVING)) return;
 	const float4 mn = d.aabb_min[j], mx = d.aabb_max[j];
 	const float e = rs + 1.0e-3f;
-	if (!ray_aabb(o, dir, make_float4(mn.x - e, mn.y - e, mn.z - e, 0.0f), make_float4(mx.x + e, mx.y + e, mx.z + e, 0.0f), best.t)) return;
+	if (!ray_aabb(o, dir, make_float4(mn.x - e, mn.y - e, mn.z - e, 0.0f), make_float4(mx.x + e, mx.y + e, mx.z + e, 0.0f), ry.max_t)) return;      // full length: see veh_cast_test
 	const float4 sh = d.shape[j];
 	const float prm[3] = { sh.x, sh.y, sh.z };
 	v3 n, p;

@@ -96,3 +96,29 @@ def test_back_faces_do_not_collide_and_queries(oracle):
         w.add_batch(bad)
     w.remove(mid)
     assert w.num_bodies() == 1
+
+
+def test_capsule_axis_grazing_a_far_triangle_keeps_a_unit_normal(oracle):
+    """Regression (found by tools/fuzz_parity.py, seed 19): with the capsule's axis a hair above a triangle far from the origin, the closest
+    point on the face equals the axis point after rounding, so 'axis point minus closest point' cancels to zero while the distance (from the
+    plane equation) does not; the contact normal must still be the face normal, not a zero vector that turns into NaNs in the solver."""
+    w = oracle.OracleWorld(max_bodies=64)
+    V = [(6.9, -6.9, 0.39), (9.7, -6.9, 0.33), (9.7, -4.15, 0.48), (6.9, -4.15, 0.45)]
+    mid, _ = add_mesh(w, V, [(0, 1, 2), (0, 2, 3)])
+    worst = 1.0
+    for k in range(60):
+        # a tilted capsule whose lower axis end sits 1e-7 .. 1e-2 m above the plane of the first triangle
+        lift = 10.0 ** (-7 + 5 * k / 59.0)
+        c = dyn(w, shape_type=abi.SHAPE_CAPSULE, shape=(0.15, 0.26, 0, 0), pos=(8.9, -5.6, 0.41 + 0.26 * np.cos(0.7) + lift),
+                rot=quat_axis_angle((1, 0.3, 0), 0.7), mass=2.6)
+        for _ in range(3):
+            w.step(DT)
+        st = w.get_state([c])[0]
+        assert np.all(np.isfinite(st["pos"])) and np.all(np.isfinite(st["lin_vel"])) and np.all(np.isfinite(st["ang_vel"])), (k, lift)
+        cons = w.dump_constraints()
+        for con in cons:
+            nrm = float(np.linalg.norm(con["n"]))
+            worst = min(worst, nrm)
+            assert abs(nrm - 1.0) < 1e-3, (k, lift, con["n"])
+        w.remove(c)
+    assert worst > 0.999

@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Randomised differential test: the HIP path against the oracle on random scenes and random call sequences.
+
+Each seed builds a scene from every shape kind the product knows (boxes, spheres, capsules, convex hulls, optionally a static triangle
+terrain and a walled mesh pen), sensors, a kinematic mover, optionally a car, then interleaves steps with random facade-level calls
+(teleports with velocities, forces, removals, additions, layer changes, activation, water on/off, contact events) and with queries (rays,
+sphere casts, capsule contacts).  After every checkpoint the two worlds must agree bit for bit (states, statistics, query answers).
+
+    python tools/fuzz_parity.py --seeds 0-49 --steps 240        (on the GPU box)
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from substrata_amd import abi, scenes          # noqa: E402
+from helpers import DT, add_car, quat_axis_angle  # noqa: E402
+import parity                                  # noqa: E402
+
+
+def terrain(rng, n=14, size=36.0):
+    xs = np.linspace(-size / 2, size / 2, n)
+    k = rng.uniform(0.15, 0.4, 2); amp = rng.uniform(0.2, 0.9)
+    v = np.array([[x, y, amp * (np.sin(k[0] * x) + np.cos(k[1] * y)) - 0.2] for y in xs for x in xs], np.float32)
+    t = []
+    for j in range(n - 1):
+        for i in range(n - 1):
+            a, b, c, d = j * n + i, j * n + i + 1, (j + 1) * n + i, (j + 1) * n + i + 1
+            t += [[a, b, d], [a, d, c]]
+    return v, np.array(t, np.uint32)
+
+
+def random_hull_points(rng):
+    n = int(rng.integers(6, 20))
+    p = rng.normal(size=(n, 3)) * rng.uniform(0.25, 0.6, 3)
+    return p.astype(np.float32)
+
+
+def run_seed(oracle, seed, steps, verbose=False):
+    rng = np.random.default_rng(seed)
+    tw = parity.make_twin(oracle, max_bodies=2048)
+    use_mesh = rng.random() < 0.6
+    use_car = rng.random() < 0.5
+    ground = scenes.ground()
+    if use_mesh:
+        ground["pos"][0, 2] = -3.0          # the mesh is the floor; the quad far below catches what leaves it
+    tw.add_batch(ground)
+    if use_mesh:
+        v, t = terrain(rng)
+        mg, mc = tw.mesh_create(v, t)
+        assert mg.mesh_id == mc.mesh_id
+        m = scenes.dynamic_bodies(1)
+        m["motion_type"] = abi.MOTION_STATIC; m["layer"] = abi.LAYER_NON_MOVING
+        m["shape_type"] = abi.SHAPE_MESH; m["shape"][0] = (float(mg.mesh_id), 0, 0, 0)
+        m["pos"][0] = (0, 0, 0)
+        ig, ic = tw.add_batch(m)
+        assert np.array_equal(ig, ic)
+    hulls = []
+    for _ in range(int(rng.integers(0, 4))):
+        hg, hc = tw.hull_create(random_hull_points(rng))
+        assert hg.hull_id == hc.hull_id
+        hulls.append(hg)
+    n = int(rng.integers(40, 160))
+    d = scenes.dynamic_bodies(n)
+    d["pos"] = rng.uniform([-8, -8, 1.0], [8, 8, 9.0], size=(n, 3)).astype(np.float32)
+    q = rng.normal(size=(n, 4)); d["rot"] = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    kind = rng.integers(0, 4 if hulls else 3, n)
+    scale = rng.uniform(0.3, 1.2, n).astype(np.float32)
+    for i in range(n):
+        if kind[i] == 0:
+            d["shape_type"][i] = abi.SHAPE_BOX; d["shape"][i, :3] = scale[i] * rng.uniform(0.4, 1.0, 3)
+        elif kind[i] == 1:
+            d["shape_type"][i] = abi.SHAPE_SPHERE; d["shape"][i, :3] = (scale[i] * 0.6, 0, 0)
+        elif kind[i] == 2:
+            d["shape_type"][i] = abi.SHAPE_CAPSULE; d["shape"][i, :3] = (scale[i] * 0.35, scale[i] * 0.6, 0)
+        else:
+            h = hulls[int(rng.integers(len(hulls)))]
+            d["shape_type"][i] = abi.SHAPE_HULL; d["shape"][i] = (float(h.hull_id), 0, 0, 0)
+            d["pos"][i] -= 0  # hull bodies are placed by their body frame; fine for a random scene
+    d["mass"] = (20.0 * scale ** 3 + 1.0).astype(np.float32)
+    d["friction"] = rng.uniform(0.0, 1.0, n).astype(np.float32)
+    d["restitution"] = rng.choice([0.0, 0.2, 0.6], n).astype(np.float32)
+    d["lin_vel"] = rng.uniform(-2, 2, (n, 3)).astype(np.float32)
+    d["is_sensor"] = (rng.random(n) < 0.04).astype(d["is_sensor"].dtype)
+    d["allow_sleeping"] = (rng.random(n) < 0.9).astype(d["allow_sleeping"].dtype)
+    ig, ic = tw.add_batch(d)
+    assert np.array_equal(ig, ic)
+    live = [int(x) for x in ig if x != abi.INVALID_ID]
+    kin = scenes.dynamic_bodies(1)
+    kin["motion_type"] = abi.MOTION_KINEMATIC; kin["shape"][0, :3] = (1.5, 0.4, 0.6); kin["pos"][0] = (-10.0, 0.0, 1.2)
+    kg, kc = tw.add_batch(kin); kid = int(kg[0]); assert kid == int(kc[0])
+    vid = None
+    if use_car:
+        (cb, vg), (cb2, vc) = add_car(tw.gpu, pos=(9.0, -9.0, 2.0)), add_car(tw.cpu, pos=(9.0, -9.0, 2.0))
+        assert cb == cb2 and vg == vc
+        vid = vg
+    tw.set_contact_events(int(rng.random() < 0.5))
+    water = False
+    for s in range(1, steps + 1):
+        r = rng.random()
+        if r < 0.04 and live:                                   # teleport with velocities
+            i = int(rng.choice(live))
+            qq = rng.normal(size=4); qq /= np.linalg.norm(qq)
+            tw.set_pose_vel(i, tuple(rng.uniform([-6, -6, 2], [6, 6, 8])), tuple(qq), tuple(rng.uniform(-4, 4, 3)), tuple(rng.uniform(-3, 3, 3)))
+        elif r < 0.08 and live:                                 # forces
+            i = int(rng.choice(live)); tw.activate(i)
+            tw.add_force(i, tuple(rng.uniform(-3000, 3000, 3))); tw.add_torque(i, tuple(rng.uniform(-200, 200, 3)))
+            tw.add_force_at(i, tuple(rng.uniform(-500, 500, 3)), tuple(rng.uniform(-5, 5, 3)))
+        elif r < 0.10 and len(live) > 10:                       # removal
+            i = int(rng.choice(live)); live.remove(i); tw.remove(i)
+        elif r < 0.13:                                          # additions (slots get reused)
+            nb = scenes.dynamic_bodies(2)
+            nb["pos"] = rng.uniform([-5, -5, 5], [5, 5, 9], size=(2, 3)).astype(np.float32)
+            nb["shape_type"] = [abi.SHAPE_SPHERE, abi.SHAPE_BOX]; nb["shape"][0, :3] = (0.4, 0, 0); nb["shape"][1, :3] = (0.3, 0.5, 0.2)
+            ag, ac = tw.add_batch(nb); assert np.array_equal(ag, ac)
+            live += [int(x) for x in ag if x != abi.INVALID_ID]
+        elif r < 0.15 and live:                                 # layer change
+            i = int(rng.choice(live)); tw.set_layer(i, int(rng.choice([abi.LAYER_MOVING, abi.LAYER_MOVING_NON_COLLIDABLE])))
+        elif r < 0.16:
+            water = not water; tw.set_water(int(water), float(rng.uniform(0.0, 1.5)))
+        tw.move_kinematic(kid, (float(-10.0 + 18.0 * (0.5 - 0.5 * np.cos(s * 0.03))), 0.0, 1.2), quat_axis_angle((0, 0, 1), 0.01 * s), DT)
+        if vid is not None:
+            inp = dict(forward=float(np.float32(np.sin(0.02 * s) > -0.3)), right=float(np.float32(0.5 * np.sin(0.05 * s))), brake=float(s % 120 > 100))
+            tw.vehicle_set_input(vid, **inp)
+        tw.step(DT)
+        if s % 40 == 0 or s == steps:
+            sg, sc = tw.stats()
+            tg = (sg.num_pairs, sg.num_manifolds, sg.num_contact_points, sg.num_colours, sg.num_active, sg.num_overflow_constraints)
+            tc = (sc.num_pairs, sc.num_manifolds, sc.num_contact_points, sc.num_colours, sc.num_active, sc.num_overflow_constraints)
+            assert tg == tc, (seed, s, "stats (pairs, manifolds, points, colours, active, overflow)", tg, tc)
+            hi = tw.gpu.num_bodies() + 64
+            dd = parity.state_diff(tw.gpu.read_states(0, 2048), tw.cpu.read_states(0, 2048))
+            assert dd["bit_exact"] and dd["active_mismatch"] == 0, (seed, s, dd)
+            # queries
+            rays = np.zeros(24, dtype=abi.ray_dtype)
+            rays["origin"] = rng.uniform([-9, -9, 3], [9, 9, 10], (24, 3)); dirv = rng.normal(size=(24, 3)); dirv[:, 2] = -np.abs(dirv[:, 2]) - 0.3
+            rays["dir"] = dirv / np.linalg.norm(dirv, axis=1, keepdims=True); rays["max_t"] = 30.0; rays["ignore_id"] = abi.INVALID_ID
+            hg, hc = tw.raycast(rays)
+            assert np.array_equal(hg["id"], hc["id"]) and np.array_equal(hg["t"].view(np.uint32), hc["t"].view(np.uint32)), (seed, s, "rays")
+            radii = rng.uniform(0.1, 0.5, 24).astype(np.float32)
+            cg, cc = tw.spherecast(rays, radii)
+            if not (np.array_equal(cg["id"], cc["id"]) and np.array_equal(cg["t"].view(np.uint32), cc["t"].view(np.uint32))):
+                bad = np.flatnonzero((cg["id"] != cc["id"]) | (cg["t"].view(np.uint32) != cc["t"].view(np.uint32)))
+                info = []
+                for k in bad[:4]:
+                    ids = [int(cg["id"][k]), int(cc["id"][k])]
+                    sts = tw.gpu.get_state([i for i in ids if i != abi.INVALID_ID])
+                    info.append((int(k), ids, float(cg["t"][k]), float(cc["t"][k]), float(radii[k]), [int(x) for x in sts["shape_type"]] if "shape_type" in sts.dtype.names else None,
+                                 rays["origin"][k].tolist(), rays["dir"][k].tolist()))
+                raise AssertionError((seed, s, "casts", info))
+            for ev in (abi.EVENT_CONTACT_ADDED, abi.EVENT_CONTACT_PERSISTED, abi.EVENT_ACTIVATED, abi.EVENT_DEACTIVATED):
+                eg, ec = tw.drain_events(ev)
+                assert len(eg) == len(ec), (seed, s, "events", ev)
+    st = tw.gpu.stats()
+    if verbose:
+        print(f"seed {seed}: mesh {use_mesh} car {use_car} hulls {len(hulls)} bodies {tw.gpu.num_bodies()} manifolds {st.num_manifolds} colours {st.num_colours}: ok")
+    tw.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", default="0-19")
+    ap.add_argument("--steps", type=int, default=240)
+    args = ap.parse_args()
+    lo, _, hi = args.seeds.partition("-")
+    seeds = range(int(lo), int(hi or lo) + 1)
+    from oracle import oracle
+    oracle.build()
+    failed = []
+    for seed in seeds:
+        try:
+            run_seed(oracle, seed, args.steps, verbose=True)
+        except AssertionError as e:
+            print(f"seed {seed}: MISMATCH {str(e)[:300]}")
+            failed.append(seed)
+    print(f"{len(seeds) - len(failed)} of {len(seeds)} seeds bit-exact; failed: {failed}")
+    return 1 if failed else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
