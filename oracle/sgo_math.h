@@ -31,7 +31,10 @@ static inline void v3_set(v3* a, int i, float v) { if (i == 0) a->x = v; else if
 static inline v3 v3_abs(v3 a) { return V3(fabsf(a.x), fabsf(a.y), fabsf(a.z)); }
 static inline v3 v3_min(v3 a, v3 b) { return V3(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)); }
 static inline v3 v3_max(v3 a, v3 b) { return V3(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)); }
-static inline float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+/* comparisons, not fminf / fmaxf: for operands that compare equal (+0 and -0, e.g. a friction limit of zero) those may return either one, and the
+   choice differs between processors; this form returns the same bits everywhere */
+static inline float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static inline float max0f(float v) { return v > 0.0f ? v : 0.0f; }
 
 /* Rotation matrix of a unit quaternion (columns = rotated basis vectors). */
 static inline m33 quat_to_m33(quat q)

@@ -1051,7 +1051,7 @@ static void solve_velocity_constraint(sgo_world* w, sgo_constraint* c)
 		if (p->eff_n <= 0.0f) continue;
 		const float jv = axis_jv(A, B, p->r1, p->r2, c->n);
 		const float lambda = p->eff_n * (jv - p->bias);
-		const float nl = fmaxf(p->lam_n + lambda, 0.0f);
+		const float nl = max0f(p->lam_n + lambda);
 		apply_impulse(A, B, im1, I1, im2, I2, p->r1, p->r2, c->n, nl - p->lam_n);
 		p->lam_n = nl;
 	}

@@ -28,7 +28,10 @@ SGP_DEV float v3_len(v3 a) { return sqrtf(v3_dot(a, a)); }
 SGP_DEV float v3_get(v3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 SGP_DEV void v3_set(v3& a, int i, float v) { if (i == 0) a.x = v; else if (i == 1) a.y = v; else a.z = v; }
 SGP_DEV v3 v3_abs(v3 a) { return V3(fabsf(a.x), fabsf(a.y), fabsf(a.z)); }
-SGP_DEV float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+/* comparisons, not fminf / fmaxf: for operands that compare equal (+0 and -0, e.g. a friction limit of zero) those may return either one, and the
+   choice differs between processors; this form returns the same bits everywhere */
+SGP_DEV float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+SGP_DEV float max0f(float v) { return v > 0.0f ? v : 0.0f; }
 
 SGP_DEV m33 quat_to_m33(quat q)
 {

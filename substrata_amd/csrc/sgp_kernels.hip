@@ -1393,7 +1393,7 @@ template <int VS> SGP_DEV void con_solve_velocity(ConReg& r, float4* vel)
 		if (i < np && r.rn[i].c2.w > 0.0f) {
 			const float jv = rows_jv(A, B, n, r.rn[i]);
 			const float lambda = r.rn[i].c2.w * (jv - r.rn[i].c1.w);
-			const float nl = fmaxf(r.lam[i].x + lambda, 0.0f);
+			const float nl = max0f(r.lam[i].x + lambda);
 			rows_apply(A, B, im1, im2, n, r.rn[i], nl - r.lam[i].x);
 			r.lam[i].x = nl;
 		}

@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from substrata_amd import abi, scenes          # noqa: E402
-from helpers import DT, add_car, quat_axis_angle  # noqa: E402
+from helpers import DT, add_car, add_bike, quat_axis_angle  # noqa: E402
 import parity                                  # noqa: E402
 
 
@@ -91,14 +91,20 @@ def run_seed(oracle, seed, steps, verbose=False):
     ig, ic = tw.add_batch(d)
     assert np.array_equal(ig, ic)
     live = [int(x) for x in ig if x != abi.INVALID_ID]
+    kind_of = {int(x): int(d["shape_type"][k]) for k, x in enumerate(ig) if x != abi.INVALID_ID}
     kin = scenes.dynamic_bodies(1)
     kin["motion_type"] = abi.MOTION_KINEMATIC; kin["shape"][0, :3] = (1.5, 0.4, 0.6); kin["pos"][0] = (-10.0, 0.0, 1.2)
     kg, kc = tw.add_batch(kin); kid = int(kg[0]); assert kid == int(kc[0])
     vid = None
+    vids = []
     if use_car:
         (cb, vg), (cb2, vc) = add_car(tw.gpu, pos=(9.0, -9.0, 2.0)), add_car(tw.cpu, pos=(9.0, -9.0, 2.0))
         assert cb == cb2 and vg == vc
-        vid = vg
+        vid = vg; vids.append(vg)
+    if rng.random() < 0.3:
+        (bb, vg), (bb2, vc) = add_bike(tw.gpu, pos=(-9.0, 9.0, 2.0)), add_bike(tw.cpu, pos=(-9.0, 9.0, 2.0))
+        assert bb == bb2 and vg == vc
+        vids.append(vg)
     tw.set_contact_events(int(rng.random() < 0.5))
     water = False
     for s in range(1, steps + 1):
@@ -119,14 +125,26 @@ def run_seed(oracle, seed, steps, verbose=False):
             nb["shape_type"] = [abi.SHAPE_SPHERE, abi.SHAPE_BOX]; nb["shape"][0, :3] = (0.4, 0, 0); nb["shape"][1, :3] = (0.3, 0.5, 0.2)
             ag, ac = tw.add_batch(nb); assert np.array_equal(ag, ac)
             live += [int(x) for x in ag if x != abi.INVALID_ID]
+            for k, x in enumerate(ag):
+                if x != abi.INVALID_ID:
+                    kind_of[int(x)] = int(nb["shape_type"][k])
         elif r < 0.15 and live:                                 # layer change
             i = int(rng.choice(live)); tw.set_layer(i, int(rng.choice([abi.LAYER_MOVING, abi.LAYER_MOVING_NON_COLLIDABLE])))
         elif r < 0.16:
             water = not water; tw.set_water(int(water), float(rng.uniform(0.0, 1.5)))
+        elif r < 0.18 and live:                                 # setNewObToWorldTransform with a new scale (primitive shapes)
+            i = int(rng.choice(live))
+            stt = tw.gpu.get_state([i])[0]
+            if kind_of.get(i) == abi.SHAPE_BOX:
+                tw.set_pose_shape(i, tuple(stt["pos"]), tuple(stt["rot"]), tuple(rng.uniform(0.2, 0.9, 3)) + (0.0,))
+            elif kind_of.get(i) == abi.SHAPE_SPHERE:
+                tw.set_pose_shape(i, tuple(stt["pos"]), tuple(stt["rot"]), (float(rng.uniform(0.2, 0.7)), 0.0, 0.0, 0.0))
+        elif r < 0.20 and live:
+            i = int(rng.choice(live)); tw.set_vel(i, tuple(rng.uniform(-5, 5, 3)), tuple(rng.uniform(-4, 4, 3)))
         tw.move_kinematic(kid, (float(-10.0 + 18.0 * (0.5 - 0.5 * np.cos(s * 0.03))), 0.0, 1.2), quat_axis_angle((0, 0, 1), 0.01 * s), DT)
-        if vid is not None:
-            inp = dict(forward=float(np.float32(np.sin(0.02 * s) > -0.3)), right=float(np.float32(0.5 * np.sin(0.05 * s))), brake=float(s % 120 > 100))
-            tw.vehicle_set_input(vid, **inp)
+        for k, v in enumerate(vids):
+            inp = dict(forward=float(np.float32(np.sin(0.02 * s + k) > -0.3)), right=float(np.float32(0.5 * np.sin(0.05 * s + 2 * k))), brake=float((s + 40 * k) % 120 > 100))
+            tw.vehicle_set_input(v, **inp)
         tw.step(DT)
         if s % 40 == 0 or s == steps:
             sg, sc = tw.stats()
@@ -153,6 +171,26 @@ def run_seed(oracle, seed, steps, verbose=False):
                     info.append((int(k), ids, float(cg["t"][k]), float(cc["t"][k]), float(radii[k]), [int(x) for x in sts["shape_type"]] if "shape_type" in sts.dtype.names else None,
                                  rays["origin"][k].tolist(), rays["dir"][k].tolist()))
                 raise AssertionError((seed, s, "casts", info))
+            qs = np.zeros(6, dtype=abi.capsule_query_dtype)
+            qs["pos"] = rng.uniform([-8, -8, 0.3], [8, 8, 3.0], (6, 3)); qq = rng.normal(size=(6, 4)); qs["rot"] = qq / np.linalg.norm(qq, axis=1, keepdims=True)
+            qs["radius"] = 0.3; qs["half_height"] = 0.65; qs["max_separation"] = 0.1; qs["ignore_id"] = abi.INVALID_ID
+            kg, kc = tw.collide_capsules(qs)
+            assert len(kg) == len(kc) and np.array_equal(kg["body"], kc["body"]) and np.array_equal(kg["distance"].view(np.uint32), kc["distance"].view(np.uint32)) \
+                and np.array_equal(kg["normal"].view(np.uint32), kc["normal"].view(np.uint32)), (seed, s, "capsule queries")
+            for v in vids:
+                vg_, vc_ = tw.vehicle_get_state(v)
+                if vg_.tobytes() != vc_.tobytes():
+                    diffs = []
+                    for name in vg_.dtype.names:
+                        if name == "wheels":
+                            for wi in range(len(vg_["wheels"])):
+                                for wn in vg_["wheels"].dtype.names:
+                                    a, b = vg_["wheels"][wi][wn], vc_["wheels"][wi][wn]
+                                    if np.asarray(a).tobytes() != np.asarray(b).tobytes():
+                                        diffs.append((f"wheel{wi}.{wn}", np.asarray(a).tolist(), np.asarray(b).tolist()))
+                        elif np.asarray(vg_[name]).tobytes() != np.asarray(vc_[name]).tobytes():
+                            diffs.append((name, np.asarray(vg_[name]).tolist(), np.asarray(vc_[name]).tolist()))
+                    raise AssertionError((seed, s, "vehicle state", v, diffs[:6]))
             for ev in (abi.EVENT_CONTACT_ADDED, abi.EVENT_CONTACT_PERSISTED, abi.EVENT_ACTIVATED, abi.EVENT_DEACTIVATED):
                 eg, ec = tw.drain_events(ev)
                 assert len(eg) == len(ec), (seed, s, "events", ev)
