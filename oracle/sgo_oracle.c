@@ -532,7 +532,7 @@ SGO_API int sgo_body_move_kinematic(sgo_world* w, uint32_t id, const float tp[3]
 	if (dq.w < 0.0f) { dq.x = -dq.x; dq.y = -dq.y; dq.z = -dq.z; dq.w = -dq.w; }
 	const float sl = sqrtf(dq.x * dq.x + dq.y * dq.y + dq.z * dq.z);
 	if (sl > 1.0e-12f) {
-		const float angle = 2.0f * atan2f(sl, dq.w);
+		const float angle = sgo_quat_angle(sl, dq.w);
 		b->angv = v3_scale(V3(dq.x / sl, dq.y / sl, dq.z / sl), angle / dt);
 	} else b->angv = V3(0, 0, 0);
 	body_activate(w, id);

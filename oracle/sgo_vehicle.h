@@ -119,6 +119,16 @@ static inline float sgo_acos01(float x)
 static inline float sgo_acos11(float x) { return x >= 0.0f ? sgo_acos01(x) : SGO_VEH_PI - sgo_acos01(-x); }
 static inline float sgo_asin01(float x) { return 0.5f * SGO_VEH_PI - sgo_acos01(x); }
 static inline float sgo_signf(float x) { return x < 0.0f ? -1.0f : 1.0f; }
+/* Rotation angle of a unit quaternion with vector part of length sl >= 0 and scalar part w >= 0 (2 atan2(sl, w)) without libm, whose
+   atan2f differs in the last bit between processors: the asin series where it converges fast, the acos polynomial elsewhere. */
+static inline float sgo_quat_angle(float sl, float w)
+{
+	if (sl < 0.25f) {
+		const float x2 = sl * sl;
+		return 2.0f * (sl * (1.0f + x2 * (0.16666667f + x2 * (0.075f + x2 * (0.044642857f + x2 * 0.030381944f)))));
+	}
+	return 2.0f * sgo_acos11(clampf(w, -1.0f, 1.0f));
+}
 static inline v3 sgo_normalized_or(v3 v, v3 fallback)
 {
 	const float l2 = v3_len_sq(v);

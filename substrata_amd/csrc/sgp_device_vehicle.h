@@ -102,6 +102,16 @@ SGP_DEV static float sgd_acos01(float x)
 SGP_DEV static float sgd_acos11(float x) { return x >= 0.0f ? sgd_acos01(x) : SGD_VEH_PI - sgd_acos01(-x); }
 SGP_DEV static float sgd_asin01(float x) { return 0.5f * SGD_VEH_PI - sgd_acos01(x); }
 SGP_DEV static float sgd_signf(float x) { return x < 0.0f ? -1.0f : 1.0f; }
+/* Rotation angle of a unit quaternion with vector part of length sl >= 0 and scalar part w >= 0 (2 atan2(sl, w)) without libm, whose
+   atan2f differs in the last bit between processors: the asin series where it converges fast, the acos polynomial elsewhere. */
+SGP_DEV static float sgd_quat_angle(float sl, float w)
+{
+	if (sl < 0.25f) {
+		const float x2 = sl * sl;
+		return 2.0f * (sl * (1.0f + x2 * (0.16666667f + x2 * (0.075f + x2 * (0.044642857f + x2 * 0.030381944f)))));
+	}
+	return 2.0f * sgd_acos11(clampf(w, -1.0f, 1.0f));
+}
 SGP_DEV static v3 sgd_normalized_or(v3 v, v3 fallback)
 {
 	const float l2 = v3_len_sq(v);

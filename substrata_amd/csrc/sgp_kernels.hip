@@ -2092,7 +2092,7 @@ __global__ void __launch_bounds__(TPB) k_apply_cmds(DV d, const BodyCmd* cmds, c
 				if (dq.w < 0.0f) { dq.x = -dq.x; dq.y = -dq.y; dq.z = -dq.z; dq.w = -dq.w; }
 				const float sl = sqrtf(dq.x * dq.x + dq.y * dq.y + dq.z * dq.z);
 				v3 av = V3(0.0f, 0.0f, 0.0f);
-				if (sl > 1.0e-12f) { const float angle = 2.0f * atan2f(sl, dq.w); av = v3_scale(V3(dq.x / sl, dq.y / sl, dq.z / sl), angle / c.dt); }
+				if (sl > 1.0e-12f) { const float angle = sgd_quat_angle(sl, dq.w); av = v3_scale(V3(dq.x / sl, dq.y / sl, dq.z / sl), angle / c.dt); }
 				d.linv[i] = F4(lv, d.linv[i].w);
 				d.angv[i] = F4(av, d.angv[i].w);
 				f = activate_body(d, i, f);
