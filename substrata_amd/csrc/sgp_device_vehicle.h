@@ -167,6 +167,13 @@ SGP_DEV static float sgd_ray_box(v3 ol, v3 dl, v3 h, float max_t, v3* n_out)
 // capsule along z through the origin: radius r, half height hh
 SGP_DEV static float sgd_ray_capsule_z(v3 ol, v3 dl, float r, float hh, float max_t, v3* n_out)
 {
+	/* starting inside comes first: from the inside, the ray would otherwise "enter" the far cap's sphere at a point in the capsule's
+	   interior, and whether that counted depended on max_t (found by tools/fuzz_parity.py) */
+	{
+		const float zc = clampf(ol.z, -hh, hh);
+		const v3 dq = V3(ol.x, ol.y, ol.z - zc);
+		if (v3_len_sq(dq) <= r * r) { *n_out = v3_neg(dl); return 0.0f; }
+	}
 	float best = -1.0f; v3 bn = V3(0, 0, 0);
 	const float a = dl.x * dl.x + dl.y * dl.y;
 	const float bq = ol.x * dl.x + ol.y * dl.y, c = ol.x * ol.x + ol.y * ol.y - r * r;
@@ -187,12 +194,7 @@ SGP_DEV static float sgd_ray_capsule_z(v3 ol, v3 dl, float r, float hh, float ma
 		if (t < 0.0f || t > max_t) continue;
 		if (best < 0.0f || t < best) { best = t; bn = v3_scale(v3_add(oc, v3_scale(dl, t)), 1.0f / r); }
 	}
-	if (best < 0.0f) {
-		const float zc = clampf(ol.z, -hh, hh);
-		const v3 dq = V3(ol.x, ol.y, ol.z - zc);
-		if (v3_len_sq(dq) <= r * r) { *n_out = v3_neg(dl); return 0.0f; }
-		return -1.0f;
-	}
+	if (best < 0.0f) return -1.0f;
 	*n_out = bn;
 	return best;
 }
