@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsgp.so")
 SOURCES = ["sgp_kernels.hip", "sgp_world.hip"]
-HEADERS = ["sgp_kernels.h", "sgp_device_math.h", "sgp_device_collide.h", os.path.join("..", "..", "include", "sgp.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "sgp.h")]      # every header: several are generated
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
 
