@@ -1,7 +1,10 @@
 """Randomised differential test (tools/fuzz_parity.py): random scenes of every shape kind, random facade calls and queries, HIP path
-against the oracle, bit for bit.  The seeds kept here are the ones that found bugs (stale statistics, a sphere-cast bounds filter the
-oracle lacked and whose use of the running best made the answer order-dependent, a zero contact normal from cancellation) plus a few more;
-run `python tools/fuzz_parity.py --seeds 0-199` for a wider sweep."""
+against the oracle, bit for bit (body states, step statistics, rays, sphere casts, capsule queries, vehicle read-backs, event counts).
+The seeds kept here are the ones that found bugs -- a sphere-cast bounds filter the oracle lacked and whose use of the running best made the
+answer order-dependent (0, 1, 4, 7, 10, 31), a zero contact normal from cancellation that turned into NaNs (19), fminf / fmaxf returning
+either of +0 / -0 (220), libm's atan2f in moveKinematicObject differing in the last bit between host and device (590, at 360 steps), a
+capsule ray that depended on max_t when it started inside (1272, 1383) -- plus two more; `python tools/fuzz_parity.py --seeds 0-999 --steps 420`
+is the wide sweep (1000+ seeds ran clean at the end of round 1)."""
 import os
 import sys
 
@@ -12,7 +15,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", [0, 1, 4, 7, 10, 19, 31, 42, 77])
-def test_random_scene_and_calls_stay_bit_exact(oracle, seed):
+@pytest.mark.parametrize("seed,steps", [(0, 240), (1, 240), (4, 240), (7, 240), (10, 240), (19, 240), (31, 240), (42, 240), (77, 240),
+                                        (220, 300), (590, 360), (1272, 420), (1383, 420)])
+def test_random_scene_and_calls_stay_bit_exact(oracle, seed, steps):
     import fuzz_parity
-    fuzz_parity.run_seed(oracle, seed, 240)
+    fuzz_parity.run_seed(oracle, seed, steps)
