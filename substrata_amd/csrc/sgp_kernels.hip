@@ -2102,7 +2102,10 @@ __global__ void __launch_bounds__(TPB) k_apply_cmds(DV d, const BodyCmd* cmds, c
 		bool pose = false;
 		if (c.ops & CMD_SET_POS) { d.pos_im[i] = make_float4(c.pos[0], c.pos[1], c.pos[2], d.pos_im[i].w); pose = true; }
 		if (c.ops & CMD_SET_ROT) { d.rot[i] = make_float4(c.rot[0], c.rot[1], c.rot[2], c.rot[3]); pose = true; }
-		if (c.ops & CMD_SET_SHAPE) { d.shape[i] = make_float4(c.shape[0], c.shape[1], c.shape[2], d.shape[i].w); pose = true; }
+		if (c.ops & CMD_SET_SHAPE) {
+			d.shape[i] = make_float4(c.shape[0], c.shape[1], c.shape[2], d.shape[i].w); pose = true;
+			f = (f & ~BF_LARGE) | (c.flags & BF_LARGE);      // a new scale can move the body across the broad phase's large-body radius (host: note_radius)
+		}
 		if ((c.ops & CMD_SET_VEL) && f_motion(f) != SGP_MOTION_STATIC) {
 			d.linv[i] = make_float4(c.linv[0], c.linv[1], c.linv[2], d.linv[i].w);
 			d.angv[i] = make_float4(c.angv[0], c.angv[1], c.angv[2], d.angv[i].w);

@@ -574,6 +574,7 @@ SGP_API int sgp_body_set_pose_shape(sgp_world* w, uint32_t id, const float pos[3
 	else {
 		note_radius(w, id, bounding_radius(type, shape));
 		w->hb[id].volume = host_shape_volume(type, shape);
+		c.flags = w->hb[id].flags & BF_LARGE;      // the device copy of the flag follows the host's
 	}
 	w->cmds.push_back(c);
 	return SGP_OK;

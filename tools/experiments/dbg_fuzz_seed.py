@@ -39,8 +39,11 @@ def run():
                     print("  desc:", state["descs"].get(int(i)))
             state["prev"] = stg
             sg, sc = tw.gpu.stats(), tw.cpu.stats()
-            tg = (sg.num_pairs, sg.num_manifolds, sg.num_contact_points, sg.num_colours)
-            tc = (sc.num_pairs, sc.num_manifolds, sc.num_contact_points, sc.num_colours)
+            tg = (sg.num_manifolds, sg.num_contact_points, sg.num_colours)
+            tc = (sc.num_manifolds, sc.num_contact_points, sc.num_colours)
+            if sg.num_pairs != sc.num_pairs and not state.get("pairs_reported"):
+                state["pairs_reported"] = True
+                print("pair counts differ first at step", state["n"], sg.num_pairs, sc.num_pairs)
             if tg != tc:
                 print("first stats mismatch at step", state["n"], tg, tc)
                 cg, cc = tw.gpu.dump_constraints(), tw.cpu.dump_constraints()
@@ -49,14 +52,14 @@ def run():
                 ids = sorted({x for p in (pc ^ pg) for x in p})[:12]
                 st = tw.gpu.read_states(0, 2048); sc2 = tw.cpu.read_states(0, 2048)
                 for i in ids:
-                    print(i, "gpu pos", st["pos"][i], "active", st["active"][i], "| cpu pos", sc2["pos"][i], "active", sc2["active"][i])
+                    print(i, state["descs"].get(int(i)), "gpu pos", st["pos"][i], "active", st["active"][i], "| cpu pos", sc2["pos"][i], "active", sc2["active"][i])
                 raise Stop()
             return None, None
         tw.step = both_step
         return tw
     parity.make_twin = mk
     try:
-        fz.run_seed(oracle, 19, 200, verbose=True)
+        fz.run_seed(oracle, int(sys.argv[1]), int(sys.argv[2]), verbose=True)
     except Stop:
         pass
 run()

@@ -1,1 +1,4 @@
-for s in 300 314 318 377 398 412 424 480 482 519 528 531 541 559 570 581 590 595 598; do timeout 300 python tools/fuzz_parity.py --seeds $s-$s --steps 360 2>&1 | grep -E "MISMATCH" | cut -c1-300; done; echo done
+#!/bin/bash
+# usage: rerun_seeds.sh <steps> seed seed ...
+steps=$1; shift
+for s in "$@"; do timeout 300 python tools/fuzz_parity.py --seeds $s-$s --steps $steps 2>&1 | grep -E "MISMATCH" | cut -c1-400; done; echo done

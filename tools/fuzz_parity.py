@@ -43,7 +43,10 @@ def random_hull_points(rng):
 
 def run_seed(oracle, seed, steps, verbose=False):
     rng = np.random.default_rng(seed)
+    # both launch plans of small worlds get their share (the product reads the switch when the world is created)
+    os.environ["SGP_NO_SMALL_WORLD"] = "1" if rng.random() < 0.4 else "0"
     tw = parity.make_twin(oracle, max_bodies=2048)
+    os.environ.pop("SGP_NO_SMALL_WORLD", None)
     use_mesh = rng.random() < 0.6
     use_car = rng.random() < 0.5
     ground = scenes.ground()
@@ -65,9 +68,10 @@ def run_seed(oracle, seed, steps, verbose=False):
         hg, hc = tw.hull_create(random_hull_points(rng))
         assert hg.hull_id == hc.hull_id
         hulls.append(hg)
-    n = int(rng.integers(40, 160))
+    big = rng.random() < 0.2                        # one scene in five is crowded: deeper piles, more colours, bodies with many contacts
+    n = int(rng.integers(500, 1300)) if big else int(rng.integers(40, 160))
     d = scenes.dynamic_bodies(n)
-    d["pos"] = rng.uniform([-8, -8, 1.0], [8, 8, 9.0], size=(n, 3)).astype(np.float32)
+    d["pos"] = rng.uniform([-8, -8, 1.0], [8, 8, 25.0 if big else 9.0], size=(n, 3)).astype(np.float32)
     q = rng.normal(size=(n, 4)); d["rot"] = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
     kind = rng.integers(0, 4 if hulls else 3, n)
     scale = rng.uniform(0.3, 1.2, n).astype(np.float32)
@@ -82,6 +86,10 @@ def run_seed(oracle, seed, steps, verbose=False):
             h = hulls[int(rng.integers(len(hulls)))]
             d["shape_type"][i] = abi.SHAPE_HULL; d["shape"][i] = (float(h.hull_id), 0, 0, 0)
             d["pos"][i] -= 0  # hull bodies are placed by their body frame; fine for a random scene
+    for i in rng.choice(n, size=int(rng.integers(0, 3)), replace=False):      # bodies beyond the broad phase's large-body radius
+        d["shape_type"][i] = abi.SHAPE_BOX; d["shape"][i, :3] = (float(rng.uniform(3.5, 6.0)), float(rng.uniform(2.0, 5.0)), 0.3); scale[i] = 3.0
+        d["pos"][i, 2] = 0.6 + 0.7 * float(rng.random())
+        d["rot"][i] = (0, 0, 0, 1)
     d["mass"] = (20.0 * scale ** 3 + 1.0).astype(np.float32)
     d["friction"] = rng.uniform(0.0, 1.0, n).astype(np.float32)
     d["restitution"] = rng.choice([0.0, 0.2, 0.6], n).astype(np.float32)
