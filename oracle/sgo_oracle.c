@@ -1560,6 +1560,9 @@ static int cast_reaches_bounds(const sgo_body* b, v3 o, v3 dir, float rs, float 
 static void vehicles_pre_step(sgo_world* w, float dt)
 {
 	if (w->n_vehicles == 0) return;
+	/* debugging aid: SGO_WHEEL_TRACE="<step>,<wheel>" prints the candidates of that wheel of vehicle 0 in that call of this function */
+	static int dbg_calls = 0; int dbg_wheel = -1; const int dbg_step_now = ++dbg_calls;
+	{ const char* e = getenv("SGO_WHEEL_TRACE"); if (e) { int st_ = 0, wh_ = 0; if (sscanf(e, "%d,%d", &st_, &wh_) == 2 && st_ == dbg_step_now) dbg_wheel = wh_; } }
 	/* dense copy of the candidate bounds for the conservative reject (one cache-friendly stream instead of the body records) */
 	float* bounds = (float*)malloc(sizeof(float) * 6 * (w->high ? w->high : 1));
 	for (uint32_t j = 0; j < w->high; ++j) {
@@ -1581,17 +1584,22 @@ static void vehicles_pre_step(sgo_world* w, float dt)
 			sgo_wheel* wh = &v->wheels[i];
 			float best = wh->cast_len; uint32_t bid = SGP_INVALID_ID; v3 bn = V3(0, 0, 0), bp = V3(0, 0, 0);
 			const v3 e = v3_add(wh->cast_origin, v3_scale(wh->cast_dir, wh->cast_len));
-			const float m = v->cast_radius + 1.0e-3f;
+			/* cheap reject only; it must never be stricter than the slab test below (which allows 1e-4 of slack and is the filter the device
+			   applies), so it gets a wider margin -- a wheel 8e-5 m beside a hull's bounds once made the two disagree (tools/fuzz_parity.py) */
+			const float m = v->cast_radius + 2.0e-3f;
 			const v3 lo = v3_sub(v3_min(wh->cast_origin, e), V3(m, m, m)), hi = v3_add(v3_max(wh->cast_origin, e), V3(m, m, m));
 			for (uint32_t j = 0; j < w->high; ++j) {
 				const float* bb = &bounds[6 * j];
+				if (dbg_wheel >= 0 && i == dbg_wheel && getenv("SGO_WHEEL_TRACE_BODY") && (int)j == atoi(getenv("SGO_WHEEL_TRACE_BODY"))) fprintf(stderr, "[sgo wheel trace] body %u bounds %g %g %g .. %g %g %g | segment box %g %g %g .. %g %g %g | alive %d sensor %d layer %d alias %d shape %d\n", j, bb[0], bb[1], bb[2], bb[3], bb[4], bb[5], lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, w->bodies[j].alive, w->bodies[j].is_sensor, w->bodies[j].layer, w->bodies[j].is_alias, w->bodies[j].shape_type);
 				if (bb[3] < lo.x || bb[0] > hi.x || bb[4] < lo.y || bb[1] > hi.y || bb[5] < lo.z || bb[2] > hi.z) continue;
 				if (j == v->body) continue;
 				const sgo_body* o = &w->bodies[j];
+				if (dbg_wheel >= 0 && i == dbg_wheel) fprintf(stderr, "[sgo wheel trace] step %d body %u: in segment box; reaches bounds %d; origin %g %g %g dir %g %g %g len %g aabb %g %g %g .. %g %g %g\n", dbg_step_now, j, cast_reaches_bounds(o, wh->cast_origin, wh->cast_dir, v->cast_radius, wh->cast_len), wh->cast_origin.x, wh->cast_origin.y, wh->cast_origin.z, wh->cast_dir.x, wh->cast_dir.y, wh->cast_dir.z, wh->cast_len, o->aabb_min.x, o->aabb_min.y, o->aabb_min.z, o->aabb_max.x, o->aabb_max.y, o->aabb_max.z);
 				if (!cast_reaches_bounds(o, wh->cast_origin, wh->cast_dir, v->cast_radius, wh->cast_len)) continue;      /* full length, not `best`: the answer must not depend on the visiting order */
 				v3 n, p;
 				const float t = o->shape_type == SGP_SHAPE_MESH ? cast_sphere_mesh(o, wh->cast_origin, wh->cast_dir, best, v->cast_radius, &n, &p)
 				                                                : sgo_cast_sphere_body(o->shape_type, o->shape, o->hull, o->pos, quat_to_m33(o->rot), wh->cast_origin, wh->cast_dir, best, v->cast_radius, &n, &p);
+				if (dbg_wheel >= 0 && i == dbg_wheel) fprintf(stderr, "[sgo wheel trace]   body %u: t %g n %g %g %g (best so far %g)\n", j, t, n.x, n.y, n.z, best);
 				if (t < 0.0f || n.z < v->cos_max_slope) continue;
 				if (t < best || bid == SGP_INVALID_ID) { best = t; bid = j; bn = n; bp = p; }
 			}

@@ -1522,7 +1522,7 @@ __global__ void __launch_bounds__(512) k_solve_tail(DV d, int first_colour, int 
 	__syncthreads();
 	if (cs[first_colour] == cs[SGP_MAX_COLOURS]) return;          // nothing from first_colour on (incl. the overflow colour)
 	const uint32_t tail_n = cs[SGP_OVERFLOW_COLOUR] - cs[first_colour];
-	if (mode == 1 && tail_n <= 512u) {
+	if (mode == 1 && tail_n <= 512u && !(d.dbg_flags & 1u)) {
 		// one constraint per thread, read once up front (all loads in flight together); a colour phase is then only the velocity gather,
 		// the arithmetic and the scatter.  Phases and their order are those of the loop below.
 		const uint32_t slot = cs[first_colour] + threadIdx.x;
