@@ -2222,6 +2222,10 @@ static float ray_body(const sgo_body* b, v3 o, v3 d, float max_t, v3* n_out)
 	/* capsule along local z: infinite cylinder clipped to |z| <= hh, plus the two end spheres */
 	{
 		const float r = b->shape[0], hh = b->shape[1];
+		{	/* starting inside comes first (else an interior cap-sphere entry can win, depending on max_t; see sgo_ray_capsule_z) */
+			const v3 q = sgo_closest_on_segment(V3(0, 0, -hh), V3(0, 0, hh), ol);
+			if (v3_len_sq(v3_sub(ol, q)) <= r * r) { *n_out = v3_neg(d); return 0.0f; }
+		}
 		float best = -1.0f; v3 bn = V3(0, 0, 0);
 		const float a = dl.x * dl.x + dl.y * dl.y;
 		const float bq = ol.x * dl.x + ol.y * dl.y, c = ol.x * ol.x + ol.y * ol.y - r * r;
@@ -2242,12 +2246,7 @@ static float ray_body(const sgo_body* b, v3 o, v3 d, float max_t, v3* n_out)
 			if (t < 0.0f || t > max_t) continue;
 			if (best < 0.0f || t < best) { best = t; bn = v3_scale(v3_add(oc, v3_scale(dl, t)), 1.0f / r); }
 		}
-		if (best < 0.0f) {
-			/* origin inside? */
-			const v3 q = sgo_closest_on_segment(V3(0, 0, -hh), V3(0, 0, hh), ol);
-			if (v3_len_sq(v3_sub(ol, q)) <= r * r) { *n_out = v3_neg(d); return 0.0f; }
-			return -1.0f;
-		}
+		if (best < 0.0f) return -1.0f;
 		*n_out = m33_mul(R, bn);
 		return best;
 	}

@@ -2268,6 +2268,10 @@ SGP_DEV float ray_body(const DV& d, uint32_t type, float4 sh, v3 pos, quat q, v3
 	}
 	{
 		const float r = sh.x, hh = sh.y;
+		{      // starting inside comes first (else an interior cap-sphere entry can win, depending on max_t; see sgd_ray_capsule_z)
+			const v3 qq = sgd_closest_on_segment(V3(0.0f, 0.0f, -hh), V3(0.0f, 0.0f, hh), ol);
+			if (v3_len_sq(v3_sub(ol, qq)) <= r * r) { *n_out = v3_neg(dir); return 0.0f; }
+		}
 		float best = -1.0f; v3 bn = V3(0.0f, 0.0f, 0.0f);
 		const float a = dl.x * dl.x + dl.y * dl.y;
 		const float bq = ol.x * dl.x + ol.y * dl.y, c = ol.x * ol.x + ol.y * ol.y - r * r;
@@ -2288,11 +2292,7 @@ SGP_DEV float ray_body(const DV& d, uint32_t type, float4 sh, v3 pos, quat q, v3
 			if (t < 0.0f || t > max_t) continue;
 			if (best < 0.0f || t < best) { best = t; bn = v3_scale(v3_add(oc, v3_scale(dl, t)), 1.0f / r); }
 		}
-		if (best < 0.0f) {
-			const v3 qq = sgd_closest_on_segment(V3(0.0f, 0.0f, -hh), V3(0.0f, 0.0f, hh), ol);
-			if (v3_len_sq(v3_sub(ol, qq)) <= r * r) { *n_out = v3_neg(dir); return 0.0f; }
-			return -1.0f;
-		}
+		if (best < 0.0f) return -1.0f;
 		*n_out = m33_mul(R, bn);
 		return best;
 	}

@@ -1,6 +1,7 @@
 """Randomised differential test (tools/fuzz_parity.py): random scenes of every shape kind, random facade calls and queries, HIP path
 against the oracle, bit for bit (body states, step statistics, rays, sphere casts, capsule queries, vehicle read-backs, event counts).
-The seeds kept here are the ones that found bugs -- a sphere-cast bounds filter the oracle lacked and whose use of the running best made the
+The seeds kept here are the ones that found bugs with the generator of that moment (it has grown since, so today they are simply thirteen
+scenes; the bugs themselves are fixed and, where a small case exists, pinned by unit tests) -- a sphere-cast bounds filter the oracle lacked and whose use of the running best made the
 answer order-dependent (0, 1, 4, 7, 10, 31), a zero contact normal from cancellation that turned into NaNs (19), fminf / fmaxf returning
 either of +0 / -0 (220), libm's atan2f in moveKinematicObject differing in the last bit between host and device (590, at 360 steps), a
 capsule ray that depended on max_t when it started inside (1272, 1383) -- plus two more; `python tools/fuzz_parity.py --seeds 0-999 --steps 420`

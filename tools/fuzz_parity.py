@@ -167,7 +167,9 @@ def run_seed(oracle, seed, steps, verbose=False):
             rays["origin"] = rng.uniform([-9, -9, 3], [9, 9, 10], (24, 3)); dirv = rng.normal(size=(24, 3)); dirv[:, 2] = -np.abs(dirv[:, 2]) - 0.3
             rays["dir"] = dirv / np.linalg.norm(dirv, axis=1, keepdims=True); rays["max_t"] = 30.0; rays["ignore_id"] = abi.INVALID_ID
             hg, hc = tw.raycast(rays)
-            assert np.array_equal(hg["id"], hc["id"]) and np.array_equal(hg["t"].view(np.uint32), hc["t"].view(np.uint32)), (seed, s, "rays")
+            if not (np.array_equal(hg["id"], hc["id"]) and np.array_equal(hg["t"].view(np.uint32), hc["t"].view(np.uint32))):
+                badr = np.flatnonzero((hg["id"] != hc["id"]) | (hg["t"].view(np.uint32) != hc["t"].view(np.uint32)))
+                raise AssertionError((seed, s, "rays", [(int(k), int(hg["id"][k]), float(hg["t"][k]), int(hc["id"][k]), float(hc["t"][k]), rays["origin"][k].tolist(), rays["dir"][k].tolist()) for k in badr[:3]]))
             radii = rng.uniform(0.1, 0.5, 24).astype(np.float32)
             cg, cc = tw.spherecast(rays, radii)
             if not (np.array_equal(cg["id"], cc["id"]) and np.array_equal(cg["t"].view(np.uint32), cc["t"].view(np.uint32))):
