@@ -31,7 +31,7 @@ SWEEP_BYTES_PER_BODY = 188     # integrate + AABB body-array swe
 # per contact point per velocity iteration: 12 precomputed row vectors (3 axes x 4 float4) + lambdas read, lambdas written
 SOLVE_BYTES_PER_POINT = 12 * 16 + 16 + 16
 SOLVE_BYTES_PER_MANIFOLD = 28 + 2 * 32 + 2 * 32  # ab 8 + normal/friction 16 + np 4; the velocity halves of two solver-body records read and written
-# HBM traffic of the three sweep kernels per step at 100k bodies from the rocprofv3 PMC passes in profiles/r01l_pmc_hbm_traffic.md
+# HBM traffic of the three sweep kernels per step at 100k bodies from the rocprofv3 PMC passes in profiles/r01m_pmc_hbm_traffic.md
 # (FETCH_SIZE x2 per the gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE): 35.4 MB read + 26.0 MB written per step
 SWEEP_TRAFFIC_BYTES_PER_BODY_PMC = 614.0
 
@@ -201,7 +201,7 @@ def main():
                 "achieved": sweep_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sweep_gbs / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_launch": sweep_bytes, "launch_ms": sweep_ms,
                 "traffic": SWEEP_TRAFFIC_BYTES_PER_BODY_PMC * sweep_bodies,
-                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/r01l_pmc_hbm_traffic.md (tools/collect_pmc.sh); float4-padded SoA, the pose read by all three passes, sleep-test spheres and the pose write-back move 3.3x the algorithmic bytes",
+                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/r01m_pmc_hbm_traffic.md (tools/collect_pmc.sh); float4-padded SoA, the pose read by all three passes, sleep-test spheres and the pose write-back move 3.3x the algorithmic bytes",
             },
             "roofline_solver": {
                 "bound": "hbm", "kernel": "k_solve_velocity (dominant by time; one launch per colour per iteration)",
