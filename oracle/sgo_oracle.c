@@ -1813,7 +1813,12 @@ static int cmp_contact_event(const void* a, const void* b)
 {
 	const sgp_contact_event* x = (const sgp_contact_event*)a; const sgp_contact_event* y = (const sgp_contact_event*)b;
 	if (x->id1 != y->id1) return (x->id1 > y->id1) - (x->id1 < y->id1);
-	return (x->id2 > y->id2) - (x->id2 < y->id2);
+	if (x->id2 != y->id2) return (x->id2 > y->id2) - (x->id2 < y->id2);
+	/* several events of one pair (the manifolds of a body against a mesh, or several steps drained together): a total order, so that
+	   the result does not depend on the sort or on the arrival order */
+	for (int k = 0; k < 3; ++k) if (x->base_offset[k] != y->base_offset[k]) return (x->base_offset[k] > y->base_offset[k]) - (x->base_offset[k] < y->base_offset[k]);
+	for (int k = 0; k < 3; ++k) if (x->normal[k] != y->normal[k]) return (x->normal[k] > y->normal[k]) - (x->normal[k] < y->normal[k]);
+	return (x->penetration > y->penetration) - (x->penetration < y->penetration);
 }
 
 SGO_API int sgo_world_drain_events(sgo_world* w, int kind, void* out, uint32_t cap, uint32_t* n_out)

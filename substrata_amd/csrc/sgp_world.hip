@@ -1540,7 +1540,14 @@ SGP_API int sgp_world_drain_events(sgp_world* w, int kind, void* out, uint32_t c
 	{ int r = flush_cmds(w); if (r != SGP_OK) return r; }
 	{ int r = collect_events(w); if (r != SGP_OK) return r; }
 	auto bcmp = [](const sgp_body_event& a, const sgp_body_event& b) { return a.id < b.id; };
-	auto ccmp = [](const sgp_contact_event& a, const sgp_contact_event& b) { return a.id1 != b.id1 ? a.id1 < b.id1 : a.id2 < b.id2; };
+	// total order (a pair can have several events: the manifolds of a body against a mesh, or several steps drained together)
+	auto ccmp = [](const sgp_contact_event& a, const sgp_contact_event& b) {
+		if (a.id1 != b.id1) return a.id1 < b.id1;
+		if (a.id2 != b.id2) return a.id2 < b.id2;
+		for (int k = 0; k < 3; ++k) if (a.base_offset[k] != b.base_offset[k]) return a.base_offset[k] < b.base_offset[k];
+		for (int k = 0; k < 3; ++k) if (a.normal[k] != b.normal[k]) return a.normal[k] < b.normal[k];
+		return a.penetration < b.penetration;
+	};
 	switch (kind) {
 	case SGP_EVENT_ACTIVATED: drain(w->ev_act, out, cap, n_out, bcmp); break;
 	case SGP_EVENT_DEACTIVATED: drain(w->ev_deact, out, cap, n_out, bcmp); break;

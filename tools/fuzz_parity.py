@@ -55,6 +55,18 @@ def run_seed(oracle, seed, steps, verbose=False):
     tw.add_batch(ground)
     if use_mesh:
         v, t = terrain(rng)
+        if rng.random() < 0.5:      # a pen: four inward-facing walls around the middle of the terrain (corners give several manifolds per body)
+            w_, h_ = float(rng.uniform(5.0, 8.0)), 4.0
+            base = len(v)
+            corners = [(-w_, -w_), (w_, -w_), (w_, w_), (-w_, w_)]
+            wv = [(x, y, z) for (x, y) in corners for z in (-1.0, h_)]
+            v = np.concatenate([v, np.array(wv, np.float32)])
+            tt = []
+            for k in range(4):
+                a0, a1 = base + 2 * k, base + 2 * k + 1
+                b0, b1 = base + 2 * ((k + 1) % 4), base + 2 * ((k + 1) % 4) + 1
+                tt += [[a0, a1, b1], [a0, b1, b0]]          # facing the inside of the pen
+            t = np.concatenate([t, np.array(tt, np.uint32)])
         mg, mc = tw.mesh_create(v, t)
         assert mg.mesh_id == mc.mesh_id
         m = scenes.dynamic_bodies(1)
@@ -65,7 +77,9 @@ def run_seed(oracle, seed, steps, verbose=False):
         assert np.array_equal(ig, ic)
     hulls = []
     for _ in range(int(rng.integers(0, 4))):
-        hg, hc = tw.hull_create(random_hull_points(rng))
+        pts_ = random_hull_points(rng)
+        off_ = tuple(rng.uniform(-0.1, 0.1, 3)) if rng.random() < 0.4 else None
+        hg, hc = tw.hull_create(pts_, off_)
         assert hg.hull_id == hc.hull_id
         hulls.append(hg)
     big = rng.random() < 0.2                        # one scene in five is crowded: deeper piles, more colours, bodies with many contacts
@@ -149,11 +163,27 @@ def run_seed(oracle, seed, steps, verbose=False):
                 tw.set_pose_shape(i, tuple(stt["pos"]), tuple(stt["rot"]), (float(rng.uniform(0.2, 0.7)), 0.0, 0.0, 0.0))
         elif r < 0.20 and live:
             i = int(rng.choice(live)); tw.set_vel(i, tuple(rng.uniform(-5, 5, 3)), tuple(rng.uniform(-4, 4, 3)))
+        elif r < 0.22 and len(live) > 8:                        # a burst of network snapshots (batched setNewObToWorldTransform)
+            ids_ = rng.choice(live, size=6, replace=False).astype(np.uint32)
+            recs_ = np.zeros(6, dtype=abi.pose_vel_dtype)
+            recs_["pos"] = rng.uniform([-6, -6, 1.5], [6, 6, 7], (6, 3)); qq = rng.normal(size=(6, 4)); recs_["rot"] = qq / np.linalg.norm(qq, axis=1, keepdims=True)
+            recs_["lin_vel"] = rng.uniform(-3, 3, (6, 3)); recs_["ang_vel"] = rng.uniform(-2, 2, (6, 3))
+            tw.set_pose_vel_batch(ids_, recs_)
         tw.move_kinematic(kid, (float(-10.0 + 18.0 * (0.5 - 0.5 * np.cos(s * 0.03))), 0.0, 1.2), quat_axis_angle((0, 0, 1), 0.01 * s), DT)
         for k, v in enumerate(vids):
             inp = dict(forward=float(np.float32(np.sin(0.02 * s + k) > -0.3)), right=float(np.float32(0.5 * np.sin(0.05 * s + 2 * k))), brake=float((s + 40 * k) % 120 > 100))
             tw.vehicle_set_input(v, **inp)
         tw.step(DT)
+        for ev in (abi.EVENT_CONTACT_ADDED, abi.EVENT_CONTACT_PERSISTED, abi.EVENT_ACTIVATED, abi.EVENT_DEACTIVATED, abi.EVENT_ENTERED_WATER):
+            eg, ec = tw.drain_events(ev)
+            assert len(eg) == len(ec), (seed, s, "event count", ev, len(eg), len(ec))
+            if len(eg):      # the events of THIS step, same payloads (both sides deliver them sorted by body ids)
+                for f in eg.dtype.names:
+                    if f.startswith("userdata"):
+                        continue
+                    if not np.array_equal(np.ascontiguousarray(eg[f]).view(np.uint8), np.ascontiguousarray(ec[f]).view(np.uint8)):
+                        k = int(np.flatnonzero((np.ascontiguousarray(eg[f]).reshape(len(eg), -1) != np.ascontiguousarray(ec[f]).reshape(len(ec), -1)).any(axis=1))[0])
+                        raise AssertionError((seed, s, "event payload", ev, f, k, {n_: np.asarray(eg[n_][k]).tolist() for n_ in eg.dtype.names}, {n_: np.asarray(ec[n_][k]).tolist() for n_ in ec.dtype.names}))
         if s % 40 == 0 or s == steps:
             sg, sc = tw.stats()
             tg = (sg.num_pairs, sg.num_manifolds, sg.num_contact_points, sg.num_colours, sg.num_active, sg.num_overflow_constraints)
@@ -201,9 +231,6 @@ def run_seed(oracle, seed, steps, verbose=False):
                         elif np.asarray(vg_[name]).tobytes() != np.asarray(vc_[name]).tobytes():
                             diffs.append((name, np.asarray(vg_[name]).tolist(), np.asarray(vc_[name]).tolist()))
                     raise AssertionError((seed, s, "vehicle state", v, diffs[:6]))
-            for ev in (abi.EVENT_CONTACT_ADDED, abi.EVENT_CONTACT_PERSISTED, abi.EVENT_ACTIVATED, abi.EVENT_DEACTIVATED):
-                eg, ec = tw.drain_events(ev)
-                assert len(eg) == len(ec), (seed, s, "events", ev)
     st = tw.gpu.stats()
     if verbose:
         print(f"seed {seed}: mesh {use_mesh} car {use_car} hulls {len(hulls)} bodies {tw.gpu.num_bodies()} manifolds {st.num_manifolds} colours {st.num_colours}: ok")
