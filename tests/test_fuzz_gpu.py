@@ -21,3 +21,11 @@ pytestmark = pytest.mark.gpu
 def test_random_scene_and_calls_stay_bit_exact(oracle, seed, steps):
     import fuzz_parity
     fuzz_parity.run_seed(oracle, seed, steps)
+
+
+@pytest.mark.parametrize("seed", [3, 11, 217])
+def test_random_tiles_stay_bit_exact_and_lose_no_body(oracle, seed):
+    """tools/fuzz_tiles.py: 2 or 4 adjacent tiles in one process, random piles thrown across the borders (dozens of ownership
+    migrations), ghosts handed over by direct calls; HIP worlds against oracle worlds bit for bit, body count conserved."""
+    import fuzz_tiles
+    fuzz_tiles.run_seed(oracle, seed, 240)
