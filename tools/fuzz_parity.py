@@ -120,8 +120,19 @@ def run_seed(oracle, seed, steps, verbose=False):
     vid = None
     vids = []
     if use_car:
-        (cb, vg), (cb2, vc) = add_car(tw.gpu, pos=(9.0, -9.0, 2.0)), add_car(tw.cpu, pos=(9.0, -9.0, 2.0))
-        assert cb == cb2 and vg == vc
+        if rng.random() < 0.5:      # the reference's hull chassis with its lowered centre of mass (what config 5 uses)
+            cd = scenes.dynamic_bodies(1, mass=1200.0)
+            cd["pos"][0] = (9.0, -9.0, 2.0); cd["restitution"] = 0.0
+            cdx = cd.copy(); ih2 = scenes.use_car_hull(tw.gpu, cdx, [0]); cdy = cd.copy(); ih3 = scenes.use_car_hull(tw.cpu, cdy, [0])
+            assert ih2.hull_id == ih3.hull_id
+            bg = tw.gpu.add_batch(cdx); bc = tw.cpu.add_batch(cdy)
+            assert np.array_equal(bg, bc)
+            cb = int(bg[0])
+            vg = tw.gpu.vehicle_create(tw.gpu.default_vehicle_desc(cb)); vc = tw.cpu.vehicle_create(tw.cpu.default_vehicle_desc(cb))
+            assert vg == vc
+        else:
+            (cb, vg), (cb2, vc) = add_car(tw.gpu, pos=(9.0, -9.0, 2.0)), add_car(tw.cpu, pos=(9.0, -9.0, 2.0))
+            assert cb == cb2 and vg == vc
         vid = vg; vids.append(vg)
     if rng.random() < 0.3:
         (bb, vg), (bb2, vc) = add_bike(tw.gpu, pos=(-9.0, 9.0, 2.0)), add_bike(tw.cpu, pos=(-9.0, 9.0, 2.0))
