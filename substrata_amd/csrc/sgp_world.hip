@@ -1688,6 +1688,8 @@ SGP_API int sgp_world_export_boundary(sgp_world* w, const float lo[3], const flo
 {
 	if (!w || !n_out) return fail(SGP_ERR_INVALID, "sgp_world_export_boundary: NULL");
 	hipSetDevice(w->device);
+	static const bool timing = getenv("SGP_TIMING") != nullptr;
+	const auto t0 = std::chrono::steady_clock::now();
 	{ int r = flush_cmds(w); if (r != SGP_OK) return r; }
 	const uint32_t lim = std::min(cap, w->dv.cap_bodies);
 	{ int r = ensure_stage(w, sizeof(sgp_ghost_record) * std::max(lim, 1u)); if (r != SGP_OK) return r; }
@@ -1700,6 +1702,7 @@ SGP_API int sgp_world_export_boundary(sgp_world* w, const float lo[3], const flo
 	{ int r = read_counters(w); if (r != SGP_OK) return r; }
 	const uint32_t n = w->h_ctr->n_export, m = std::min(n, lim);
 	w->last_export = n;
+	const auto t1 = std::chrono::steady_clock::now();
 	if (m && out) {
 		if (m > guess) {
 			HIP_TRY(hipMemcpyAsync((char*)w->stage_host + sizeof(sgp_ghost_record) * guess, (char*)w->stage_dev + sizeof(sgp_ghost_record) * guess,
@@ -1722,6 +1725,7 @@ SGP_API int sgp_world_export_boundary(sgp_world* w, const float lo[3], const flo
 		}
 		for (uint32_t k = 0; k < m; ++k) out[k] = src[(uint32_t)a[k]];
 	}
+	if (timing) { const auto t2 = std::chrono::steady_clock::now(); fprintf(stderr, "[sgp timing] export_boundary: device part %.1f us, sort + copy of %u records %.1f us\n", std::chrono::duration<double, std::micro>(t1 - t0).count(), m, std::chrono::duration<double, std::micro>(t2 - t1).count()); }
 	*n_out = n;
 	return SGP_OK;
 }

@@ -292,7 +292,7 @@ class CWorld:
         return out[:min(n.value, cap)]
 
     def export_boundary(self, lo, hi, margin, cap=1 << 16):
-        out = np.zeros(cap, dtype=abi.ghost_dtype)
+        out = np.empty(cap, dtype=abi.ghost_dtype)          # only the records the call fills in are returned
         n = C.c_uint32(0)
         self._check(self._fn("world_export_boundary")(self._h, _fp(_f3(lo)), _fp(_f3(hi)), float(margin),
                                                       out.ctypes.data, int(cap), C.byref(n)), "world_export_boundary")
