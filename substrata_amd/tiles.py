@@ -177,20 +177,28 @@ class GhostExchange:
         self.last_sent = len(send)
         torch = self.torch
         self.cnt_send.copy_(torch.from_numpy(counts.astype(np.int64)))
-        self.dist.all_gather_into_tensor(self.cnt_recv, self.cnt_send)
-        matrix = self.cnt_recv.cpu().numpy().reshape(self.n, self.n)          # [source][destination]
-        recv_counts = matrix[:, self.rank]
-        n_send, n_recv = int(counts.sum()), int(recv_counts.sum())
-        if max(n_send, n_recv) > self.cap:
-            self._grow(2 * max(n_send, n_recv))
-        if int(matrix.sum()) == 0:
-            self.last_imported = self.last_immigrated = 0
-            self.world.import_ghosts(recs[:0])
-            return
+        pending = self.dist.all_gather_into_tensor(self.cnt_recv, self.cnt_send, async_op=True)
+        # while the counts travel: stage this tile's records for the all-to-all-v
+        n_send = int(counts.sum())
+        if n_send > self.cap:
+            self._grow(2 * n_send)
         if n_send:
             self.send_host[:n_send * REC].copy_(torch.from_numpy(send.view(np.uint8).reshape(-1)))
             if self.on_gpu:
                 self.send_dev[:n_send * REC].copy_(self.send_host[:n_send * REC], non_blocking=True)
+        pending.wait()
+        matrix = self.cnt_recv.cpu().numpy().reshape(self.n, self.n)          # [source][destination]
+        recv_counts = matrix[:, self.rank]
+        n_recv = int(recv_counts.sum())
+        if n_recv > self.cap:
+            keep = self.send_dev[:n_send * REC].clone() if n_send else None
+            self._grow(2 * max(n_send, n_recv))
+            if n_send:
+                self.send_dev[:n_send * REC].copy_(keep)
+        if int(matrix.sum()) == 0:
+            self.last_imported = self.last_immigrated = 0
+            self.world.import_ghosts(recs[:0])
+            return
         self.dist.all_to_all_single(self.recv_dev[:n_recv * REC], self.send_dev[:n_send * REC],
                                     output_split_sizes=[int(c) * REC for c in recv_counts],
                                     input_split_sizes=[int(c) * REC for c in counts])
