@@ -165,6 +165,7 @@ struct DV {
 	uint64_t* claim[2];
 	uint32_t* island;
 	uint32_t* island_awake;
+	uint32_t* export_counts;   // per 256-body block: bodies the tile export picks (k_export_count)
 	uint32_t* awake_mark;      // per body: 1 = sleepy but known to stay awake this step (k_island_mark)
 	float4* sbody;             // per step, 64 B per body (one cache line): [lin vel xyz, EFFECTIVE inverse mass][ang vel xyz, -]
 	                           //   [world inv inertia xx,xy,xz,-][yy,yz,zz,-]; velocities live here during the velocity solve

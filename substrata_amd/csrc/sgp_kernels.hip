@@ -2714,22 +2714,59 @@ __global__ void __launch_bounds__(64) k_spherecast(DV d, const sgp_ray* rays, co
 }
 
 // multi-GPU tiles: bodies owned by this tile whose inflated AABB pokes outside [lo,hi)
+// Export in ASCENDING BODY ID without a sort: pass 1 counts the qualifying bodies of every 256-body block, pass 2 gives each block the sum
+// of the counts before it and each qualifying thread its rank inside the block (wave ballots), so record k of the output is the k-th
+// qualifying body.  (The exchange wants a deterministic order; the host used to sort a few thousand 96-byte records every step.)
+SGP_DEV bool export_qualifies(const DV& d, uint32_t i, float3 lo, float3 hi, float margin, uint32_t& f_out)
+{
+	if (i >= d.sp->n_slots) return false;
+	const uint32_t f = d.flags[i];
+	f_out = f;
+	if (!(f & BF_ALIVE) || (f & (BF_GHOST | BF_LARGE)) || f_motion(f) == SGP_MOTION_STATIC) return false;
+	const float4 mn = d.aabb_min[i], mx = d.aabb_max[i];
+	return mn.x - margin < lo.x || mn.y - margin < lo.y || mn.z - margin < lo.z ||
+	       mx.x + margin >= hi.x || mx.y + margin >= hi.y || mx.z + margin >= hi.z;
+}
+
+__global__ void __launch_bounds__(TPB) k_export_count(DV d, float3 lo, float3 hi, float margin)
+{
+	__shared__ uint32_t wsum[TPB / 64];
+	uint32_t f;
+	const bool q = export_qualifies(d, blockIdx.x * TPB + threadIdx.x, lo, hi, margin, f);
+	const unsigned long long m = __ballot(q);
+	if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+	__syncthreads();
+	if (threadIdx.x == 0) { uint32_t t = 0; for (int k = 0; k < TPB / 64; ++k) t += wsum[k]; d.export_counts[blockIdx.x] = t; }
+}
+
 __global__ void __launch_bounds__(TPB) k_export_boundary(DV d, float3 lo, float3 hi, float margin, sgp_ghost_record* out, uint32_t cap, uint32_t* count)
 {
+	__shared__ uint32_t part[TPB];
+	__shared__ uint32_t wsum[TPB / 64];
+	// blocks before this one
+	uint32_t acc = 0;
+	for (uint32_t b = threadIdx.x; b < blockIdx.x; b += TPB) acc += d.export_counts[b];
+	part[threadIdx.x] = acc;
+	__syncthreads();
+	for (int off = TPB / 2; off > 0; off >>= 1) { if (threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off]; __syncthreads(); }
+	const uint32_t base = part[0];
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-	if (i >= d.sp->n_slots) return;
-	const uint32_t f = d.flags[i];
-	if (!(f & BF_ALIVE) || (f & (BF_GHOST | BF_LARGE)) || f_motion(f) == SGP_MOTION_STATIC) return;
-	const float4 mn = d.aabb_min[i], mx = d.aabb_max[i];
-	const bool crosses = mn.x - margin < lo.x || mn.y - margin < lo.y || mn.z - margin < lo.z ||
-	                     mx.x + margin >= hi.x || mx.y + margin >= hi.y || mx.z + margin >= hi.z;
-	if (!crosses) return;
-	const uint32_t k = atomicAdd(count, 1u);
+	uint32_t f = 0;
+	const bool q = export_qualifies(d, i, lo, hi, margin, f);
+	const unsigned long long m = __ballot(q);
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	if (lane == 0) wsum[wv] = (uint32_t)__popcll(m);
+	__syncthreads();
+	uint32_t wbase = 0, total = 0;
+	for (int k = 0; k < TPB / 64; ++k) { if (k < wv) wbase += wsum[k]; total += wsum[k]; }
+	if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *count = base + total;      // the last block knows the grand total
+	if (!q) return;
+	const uint32_t k = base + wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 	if (k >= cap) return;
 	sgp_ghost_record r;
-	const float4 p = d.pos_im[i], q = d.rot[i], lv = d.linv[i], av = d.angv[i], sh = d.shape[i];
+	const float4 p = d.pos_im[i], qq = d.rot[i], lv = d.linv[i], av = d.angv[i], sh = d.shape[i];
 	r.pos[0] = p.x; r.pos[1] = p.y; r.pos[2] = p.z;
-	r.rot[0] = q.x; r.rot[1] = q.y; r.rot[2] = q.z; r.rot[3] = q.w;
+	r.rot[0] = qq.x; r.rot[1] = qq.y; r.rot[2] = qq.z; r.rot[3] = qq.w;
 	r.lin_vel[0] = lv.x; r.lin_vel[1] = lv.y; r.lin_vel[2] = lv.z;
 	r.ang_vel[0] = av.x; r.ang_vel[1] = av.y; r.ang_vel[2] = av.z;
 	r.shape_type = (int32_t)f_shape(f);
@@ -2839,4 +2876,9 @@ void launch_vehicle_solve(const DV& d, int mode, hipStream_t s)
 void launch_raycast(const DV& d, const sgp_ray* rays, uint32_t n, sgp_hit* hits, hipStream_t s) { if (n) hipLaunchKernelGGL(k_raycast, dim3((n + 63) / 64), dim3(64), 0, s, d, rays, n, hits); }
 void launch_collide_capsules(const DV& d, const sgp_capsule_query* q, uint32_t n, sgp_query_contact* out, uint32_t cap, uint32_t* count, hipStream_t s) { if (n) hipLaunchKernelGGL(k_collide_capsules, dim3((n + 63) / 64), dim3(64), 0, s, d, q, n, out, cap, count); }
 void launch_spherecast(const DV& d, const sgp_ray* rays, const float* radii, uint32_t n, sgp_hit* hits, hipStream_t s) { if (n) hipLaunchKernelGGL(k_spherecast, dim3((n + 63) / 64), dim3(64), 0, s, d, rays, radii, n, hits); }
-void launch_export_boundary(const DV& d, uint32_t nb, float3 lo, float3 hi, float margin, sgp_ghost_record* out, uint32_t cap, uint32_t* count, hipStream_t s) { hipLaunchKernelGGL(k_export_boundary, dim3(blocks_for(nb)), dim3(TPB), 0, s, d, lo, hi, margin, out, cap, count); }
+void launch_export_boundary(const DV& d, uint32_t nb, float3 lo, float3 hi, float margin, sgp_ghost_record* out, uint32_t cap, uint32_t* count, hipStream_t s)
+{
+	const uint32_t blocks = blocks_for(nb);
+	hipLaunchKernelGGL(k_export_count, dim3(blocks), dim3(TPB), 0, s, d, lo, hi, margin);
+	hipLaunchKernelGGL(k_export_boundary, dim3(blocks), dim3(TPB), 0, s, d, lo, hi, margin, out, cap, count);
+}

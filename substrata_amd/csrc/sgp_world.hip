@@ -259,7 +259,7 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	for (int k = 0; k < 3; ++k) DEV_ALLOC(d.sleep_s[k], N);
 	DEV_ALLOC(d.sleep_timer, N); DEV_ALLOC(d.submerged, N);
 	DEV_ALLOC(d.colour_mask, N); DEV_ALLOC(d.body_con, (size_t)N * SGP_MAX_COLOURS); DEV_ALLOC(d.claim[0], N); DEV_ALLOC(d.claim[1], N);
-	DEV_ALLOC(d.island, N); DEV_ALLOC(d.island_awake, N); DEV_ALLOC(d.awake_mark, N);
+	DEV_ALLOC(d.island, N); DEV_ALLOC(d.island_awake, N); DEV_ALLOC(d.awake_mark, N); DEV_ALLOC(d.export_counts, N / 256 + 2);
 	DEV_ALLOC(d.sbody, 4 * (size_t)N);
 	d.table_size = std::max(1024u, next_pow2(2u * N));
 	DEV_ALLOC(d.cell_hash, N);
@@ -1693,7 +1693,6 @@ SGP_API int sgp_world_export_boundary(sgp_world* w, const float lo[3], const flo
 	{ int r = flush_cmds(w); if (r != SGP_OK) return r; }
 	const uint32_t lim = std::min(cap, w->dv.cap_bodies);
 	{ int r = ensure_stage(w, sizeof(sgp_ghost_record) * std::max(lim, 1u)); if (r != SGP_OK) return r; }
-	HIP_TRY(hipMemsetAsync(&w->dv.ctr->n_export, 0, sizeof(uint32_t), w->stream));
 	launch_export_boundary(w->dv, w->high, make_float3(lo[0], lo[1], lo[2]), make_float3(hi[0], hi[1], hi[2]), margin,
 	                       (sgp_ghost_record*)w->stage_dev, lim, &w->dv.ctr->n_export, w->stream);
 	// one sync in the common case: the counters and as many records as the previous call produced (+ 25 %) come back together
@@ -1709,21 +1708,8 @@ SGP_API int sgp_world_export_boundary(sgp_world* w, const float lo[3], const flo
 			                       sizeof(sgp_ghost_record) * (m - guess), hipMemcpyDeviceToHost, w->stream));
 			HIP_TRY(hipStreamSynchronize(w->stream));
 		}
-		// deterministic order for the exchange: ascending local id.  LSD radix sort of (id, index) pairs, 3 passes of 11 bits (a comparison
-		// sort of a few thousand keys costs more than the kernel and the copies together), then every 96-byte record moves once.
-		const sgp_ghost_record* src = (const sgp_ghost_record*)w->stage_host;
-		std::vector<uint64_t>& a = w->sort_a; std::vector<uint64_t>& b = w->sort_b;
-		a.resize(m); b.resize(m);
-		for (uint32_t k = 0; k < m; ++k) a[k] = ((uint64_t)(uint32_t)src[k].global_id << 32) | k;
-		for (int pass = 0; pass < 3; ++pass) {
-			uint32_t hist[2049] = { 0 };
-			const int sh = 32 + 11 * pass;
-			for (uint32_t k = 0; k < m; ++k) ++hist[((a[k] >> sh) & 2047u) + 1];
-			for (int q = 0; q < 2048; ++q) hist[q + 1] += hist[q];
-			for (uint32_t k = 0; k < m; ++k) b[hist[(a[k] >> sh) & 2047u]++] = a[k];
-			a.swap(b);
-		}
-		for (uint32_t k = 0; k < m; ++k) out[k] = src[(uint32_t)a[k]];
+		// the kernel wrote the records in ascending body id (k_export_count + k_export_boundary): the order of the exchange is deterministic
+		memcpy(out, w->stage_host, sizeof(sgp_ghost_record) * m);
 	}
 	if (timing) { const auto t2 = std::chrono::steady_clock::now(); fprintf(stderr, "[sgp timing] export_boundary: device part %.1f us, sort + copy of %u records %.1f us\n", std::chrono::duration<double, std::micro>(t1 - t0).count(), m, std::chrono::duration<double, std::micro>(t2 - t1).count()); }
 	*n_out = n;
