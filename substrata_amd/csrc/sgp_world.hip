@@ -72,6 +72,7 @@ struct sgp_world {
 	std::vector<uint64_t> sort_a, sort_b;                  // scratch of its radix sort
 	std::unordered_map<uint64_t, uint64_t> ghost_map;      // global id of a ghost -> generation << 32 | local body id (stable across steps)
 	uint32_t ghost_gen = 0;
+	std::vector<std::pair<uint64_t, uint32_t>> ghost_seq;   // (global id, local id) of the previous import, in its order (fast path of the next one)
 	// pending edits
 	std::vector<BodyCmd> cmds;
 	// staging
@@ -651,9 +652,13 @@ static int flush_cmds(sgp_world* w)
 	w->grid_valid = false;
 	w->dirty_since_step = true;
 	const size_t n = w->cmds.size();
+	// commands of one body must be adjacent and in call order (k_apply_cmds walks runs): a stable sort by id -- skipped when the queue is
+	// already ordered, which is what a per-step refresh of thousands of ghosts or snapshots looks like
 	std::vector<uint32_t> order(n);
 	for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
-	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return w->cmds[a].id < w->cmds[b].id; });
+	bool ordered = true;
+	for (size_t i = 1; i < n && ordered; ++i) ordered = w->cmds[i - 1].id <= w->cmds[i].id;
+	if (!ordered) std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return w->cmds[a].id < w->cmds[b].id; });
 	const size_t cmd_bytes = n * sizeof(BodyCmd);
 	const size_t run_off = (cmd_bytes + 15) & ~size_t(15);
 	const size_t total = run_off + (n + 1) * sizeof(uint32_t);
@@ -1721,9 +1726,24 @@ SGP_API int sgp_world_import_ghosts(sgp_world* w, const sgp_ghost_record* in, ui
 	if (!w || (!in && n)) return fail(SGP_ERR_INVALID, "sgp_world_import_ghosts: NULL");
 	// ghosts keep their local id while they stay in the set, so the contact cache (keyed by body ids) keeps warm-starting.
 	// ghost_map: global id -> (local id, generation of the last import that contained it)
-	const uint32_t gen = ++w->ghost_gen;
 	w->cmds.reserve(w->cmds.size() + n);
+	// the usual case: the same ghosts as in the previous import, in the same order -- no hashing, just refresh their poses
+	if (n == w->ghost_seq.size() && n > 0) {
+		bool same = true;
+		for (uint32_t k = 0; k < n && same; ++k) same = in[k].global_id == w->ghost_seq[k].first && live(w, w->ghost_seq[k].second);
+		if (same) {
+			for (uint32_t k = 0; k < n; ++k) {
+				BodyCmd c = blank_cmd(w->ghost_seq[k].second, CMD_SET_POS | CMD_SET_ROT | CMD_SET_VEL | CMD_ACTIVATE);
+				memcpy(c.pos, in[k].pos, 12); memcpy(c.rot, in[k].rot, 16); memcpy(c.linv, in[k].lin_vel, 12); memcpy(c.angv, in[k].ang_vel, 12);
+				w->cmds.push_back(c);
+			}
+			return SGP_OK;
+		}
+	}
+	const uint32_t gen = ++w->ghost_gen;
+	w->ghost_seq.assign(n, std::pair<uint64_t, uint32_t>(0, SGP_INVALID_ID));
 	for (uint32_t k = 0; k < n; ++k) {
+		w->ghost_seq[k].first = in[k].global_id;
 		auto it = w->ghost_map.find(in[k].global_id);
 		if (it != w->ghost_map.end() && live(w, (uint32_t)it->second)) {
 			const uint32_t id = (uint32_t)it->second;
@@ -1731,6 +1751,7 @@ SGP_API int sgp_world_import_ghosts(sgp_world* w, const sgp_ghost_record* in, ui
 			memcpy(c.pos, in[k].pos, 12); memcpy(c.rot, in[k].rot, 16); memcpy(c.linv, in[k].lin_vel, 12); memcpy(c.angv, in[k].ang_vel, 12);
 			w->cmds.push_back(c);
 			it->second = ((uint64_t)gen << 32) | id;
+			w->ghost_seq[k].second = id;
 			continue;
 		}
 		sgp_body_desc d; sgp_default_body_desc(&d);
@@ -1742,7 +1763,7 @@ SGP_API int sgp_world_import_ghosts(sgp_world* w, const sgp_ghost_record* in, ui
 		d.activate = 1; d.userdata = in[k].global_id;
 		uint32_t id = SGP_INVALID_ID;
 		const int r = add_one(w, &d, &id, true);
-		if (r == SGP_OK) w->ghost_map[in[k].global_id] = ((uint64_t)gen << 32) | id;
+		if (r == SGP_OK) { w->ghost_map[in[k].global_id] = ((uint64_t)gen << 32) | id; w->ghost_seq[k].second = id; }
 		else if (r != SGP_ERR_REJECTED) return r;
 	}
 	// whatever was not refreshed by this import left the ghost set: remove in ascending id order (deterministic free-list order)
