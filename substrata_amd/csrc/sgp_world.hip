@@ -69,7 +69,6 @@ struct sgp_world {
 	uint32_t* d_large = nullptr; uint32_t cap_large = 0;
 	float max_small_radius = 0.0f;
 	uint32_t last_export = 0;                              // records the previous sgp_world_export_boundary produced
-	std::vector<uint64_t> sort_a, sort_b;                  // scratch of its radix sort
 	std::unordered_map<uint64_t, uint64_t> ghost_map;      // global id of a ghost -> generation << 32 | local body id (stable across steps)
 	uint32_t ghost_gen = 0;
 	std::vector<std::pair<uint64_t, uint32_t>> ghost_seq;   // (global id, local id) of the previous import, in its order (fast path of the next one)
