@@ -367,6 +367,10 @@ static float bounding_radius(int type, const float* p)
 
 static inline float clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
 static inline bool finite3(const float* v) { return std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2]); }
+static inline bool finite4(const float* v) { return finite3(v) && std::isfinite(v[3]); }
+// The reference only asserts finite inputs in debug builds (PhysicsWorld.cpp:548-556,625,710); a NaN that gets into one body spreads through
+// every contact it touches, so the setters refuse it outright.
+#define REQUIRE_FINITE(cond, what) do { if (!(cond)) return fail(SGP_ERR_INVALID, what ": non-finite argument"); } while (0)
 static inline bool live(const sgp_world* w, uint32_t id) { return w && id < w->high && (w->hb[id].flags & BF_ALIVE); }
 
 static float host_shape_volume(int type, const float* p)
@@ -518,6 +522,7 @@ SGP_API int sgp_body_set_layer(sgp_world* w, uint32_t id, int32_t layer)
 }
 SGP_API int sgp_body_set_pose_vel(sgp_world* w, uint32_t id, const float pos[3], const float rot[4], const float lv[3], const float av[3])
 {
+	REQUIRE_FINITE(pos && rot && lv && av && finite3(pos) && finite4(rot) && finite3(lv) && finite3(av), "sgp_body_set_pose_vel");
 	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_set_pose_vel: id not live");
 	BodyCmd c = blank_cmd(id, CMD_SET_POS | CMD_SET_ROT | CMD_SET_VEL);
 	memcpy(c.pos, pos, 12); memcpy(c.rot, rot, 16); memcpy(c.linv, lv, 12); memcpy(c.angv, av, 12);
@@ -528,6 +533,7 @@ SGP_API int sgp_body_set_pose_vel_batch(sgp_world* w, const uint32_t* ids, const
 {
 	if (!w || ((!ids || !recs) && n)) return fail(SGP_ERR_INVALID, "sgp_body_set_pose_vel_batch: NULL");
 	for (uint32_t i = 0; i < n; ++i) if (!live(w, ids[i])) return fail(SGP_ERR_BAD_ID, "sgp_body_set_pose_vel_batch: id not live");
+	for (uint32_t i = 0; i < n; ++i) REQUIRE_FINITE(finite3(recs[i].pos) && finite4(recs[i].rot) && finite3(recs[i].lin_vel) && finite3(recs[i].ang_vel), "sgp_body_set_pose_vel_batch");
 	w->cmds.reserve(w->cmds.size() + n);
 	for (uint32_t i = 0; i < n; ++i) {
 		BodyCmd c = blank_cmd(ids[i], CMD_SET_POS | CMD_SET_ROT | CMD_SET_VEL);
@@ -567,6 +573,7 @@ SGP_API int sgp_physics_update_decode(const uint8_t in[SGP_PHYSICS_UPDATE_BYTES]
 
 SGP_API int sgp_body_set_pose_shape(sgp_world* w, uint32_t id, const float pos[3], const float rot[4], const float shape[4])
 {
+	REQUIRE_FINITE(pos && rot && shape && finite3(pos) && finite4(rot) && finite4(shape), "sgp_body_set_pose_shape");
 	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_set_pose_shape: id not live");
 	BodyCmd c = blank_cmd(id, CMD_SET_POS | CMD_SET_ROT | CMD_SET_VEL | CMD_SET_SHAPE | CMD_ACTIVATE);
 	memcpy(c.pos, pos, 12); memcpy(c.rot, rot, 16); memcpy(c.shape, shape, 16);
@@ -582,6 +589,7 @@ SGP_API int sgp_body_set_pose_shape(sgp_world* w, uint32_t id, const float pos[3
 }
 SGP_API int sgp_body_set_pos(sgp_world* w, uint32_t id, const float pos[3])
 {
+	REQUIRE_FINITE(pos && finite3(pos), "sgp_body_set_pos");
 	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_set_pos: id not live");
 	BodyCmd c = blank_cmd(id, CMD_SET_POS); memcpy(c.pos, pos, 12);
 	w->cmds.push_back(c);
@@ -589,6 +597,7 @@ SGP_API int sgp_body_set_pos(sgp_world* w, uint32_t id, const float pos[3])
 }
 SGP_API int sgp_body_set_vel(sgp_world* w, uint32_t id, const float lv[3], const float av[3])
 {
+	REQUIRE_FINITE(lv && av && finite3(lv) && finite3(av), "sgp_body_set_vel");
 	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_set_vel: id not live");
 	BodyCmd c = blank_cmd(id, CMD_SET_VEL); memcpy(c.linv, lv, 12); memcpy(c.angv, av, 12);
 	w->cmds.push_back(c);
@@ -596,6 +605,7 @@ SGP_API int sgp_body_set_vel(sgp_world* w, uint32_t id, const float lv[3], const
 }
 SGP_API int sgp_body_move_kinematic(sgp_world* w, uint32_t id, const float tp[3], const float tr[4], float dt)
 {
+	REQUIRE_FINITE(tp && tr && finite3(tp) && finite4(tr) && std::isfinite(dt), "sgp_body_move_kinematic");
 	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_move_kinematic: id not live");
 	BodyCmd c = blank_cmd(id, CMD_MOVE_KINEMATIC); memcpy(c.pos, tp, 12); memcpy(c.rot, tr, 16); c.dt = dt;
 	w->cmds.push_back(c);
@@ -603,6 +613,7 @@ SGP_API int sgp_body_move_kinematic(sgp_world* w, uint32_t id, const float tp[3]
 }
 SGP_API int sgp_body_add_force(sgp_world* w, uint32_t id, const float f[3])
 {
+	REQUIRE_FINITE(f && finite3(f), "sgp_body_add_force");
 	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_add_force: id not live");
 	BodyCmd c = blank_cmd(id, CMD_ADD_FORCE); memcpy(c.linv, f, 12);
 	w->cmds.push_back(c);
@@ -610,6 +621,7 @@ SGP_API int sgp_body_add_force(sgp_world* w, uint32_t id, const float f[3])
 }
 SGP_API int sgp_body_add_force_at(sgp_world* w, uint32_t id, const float f[3], const float p[3])
 {
+	REQUIRE_FINITE(f && p && finite3(f) && finite3(p), "sgp_body_add_force_at");
 	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_add_force_at: id not live");
 	BodyCmd c = blank_cmd(id, CMD_ADD_FORCE_AT); memcpy(c.linv, f, 12); memcpy(c.pos, p, 12);
 	w->cmds.push_back(c);
@@ -617,6 +629,7 @@ SGP_API int sgp_body_add_force_at(sgp_world* w, uint32_t id, const float f[3], c
 }
 SGP_API int sgp_body_add_torque(sgp_world* w, uint32_t id, const float t[3])
 {
+	REQUIRE_FINITE(t && finite3(t), "sgp_body_add_torque");
 	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_add_torque: id not live");
 	BodyCmd c = blank_cmd(id, CMD_ADD_TORQUE); memcpy(c.angv, t, 12);
 	w->cmds.push_back(c);

@@ -252,6 +252,18 @@ def test_empty_world_and_rejections(oracle):
         tw.gpu.add(tw.gpu.default_body_desc())
     with pytest.raises(SgpError):
         tw.gpu.add(tw.gpu.default_body_desc())
+    # non-finite arguments are refused by every setter (the reference asserts them, PhysicsWorld.cpp:548-556) and leave the world untouched
+    nan = float("nan")
+    for call in (lambda: tw.gpu.set_pose_vel(0, (nan, 0, 0), (0, 0, 0, 1)), lambda: tw.gpu.set_pose_vel(0, (0, 0, 1), (0, 0, nan, 1)),
+                 lambda: tw.gpu.set_vel(0, (0, float("inf"), 0), (0, 0, 0)), lambda: tw.gpu.set_pos(0, (0, nan, 0)),
+                 lambda: tw.gpu.add_force(0, (nan, 0, 0)), lambda: tw.gpu.add_torque(0, (0, 0, nan)), lambda: tw.gpu.add_force_at(0, (1, 0, 0), (nan, 0, 0)),
+                 lambda: tw.gpu.move_kinematic(0, (0, 0, nan), (0, 0, 0, 1), DT), lambda: tw.gpu.set_pose_shape(0, (0, 0, 1), (0, 0, 0, 1), (nan, 0.5, 0.5, 0))):
+        with pytest.raises(SgpError):
+            call()
+    for _ in range(5):
+        tw.gpu.step(DT)
+    st = tw.gpu.read_states(0, 16)
+    assert np.all(np.isfinite(st["pos"])) and np.all(np.isfinite(st["lin_vel"]))
     tw.close()
 
 
