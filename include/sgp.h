@@ -245,6 +245,8 @@ int  sgp_body_activate(sgp_world* w, uint32_t id);
 int  sgp_body_get_volume(sgp_world* w, uint32_t id, float* volume_out);
 int  sgp_body_set_layer(sgp_world* w, uint32_t id, int32_t layer);
 /* setNewObToWorldTransform(pos,rot,linvel,angvel) (:607-620); SetPositionRotationAndVelocity. Does not activate. */
+/* Every setter below returns SGP_ERR_INVALID for a non-finite argument and leaves the body untouched (the reference asserts finite
+ * inputs, PhysicsWorld.cpp:548-556,625,710). */
 int  sgp_body_set_pose_vel(sgp_world* w, uint32_t id, const float pos[3], const float rot[4],
                            const float lin_vel[3], const float ang_vel[3]);
 /* setNewObToWorldTransform(pos,rot,scale) (:546-604): zero velocity, new final shape size, activates. */
