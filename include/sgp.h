@@ -240,13 +240,13 @@ int  sgp_body_add_batch(sgp_world* w, const sgp_body_desc* d, uint32_t n, uint32
 int  sgp_body_remove(sgp_world* w, uint32_t id);
 /* activateObject (:1342-1346) */
 int  sgp_body_activate(sgp_world* w, uint32_t id);
-/* setObjectLayer (:1349-1353) */
 /* Body::GetShape()->GetVolume() through GetBodyLockInterface().TryGetBody() (BoatPhysics.cpp:40-43) */
 int  sgp_body_get_volume(sgp_world* w, uint32_t id, float* volume_out);
+/* setObjectLayer (:1349-1353) */
 int  sgp_body_set_layer(sgp_world* w, uint32_t id, int32_t layer);
-/* setNewObToWorldTransform(pos,rot,linvel,angvel) (:607-620); SetPositionRotationAndVelocity. Does not activate. */
 /* Every setter below returns SGP_ERR_INVALID for a non-finite argument and leaves the body untouched (the reference asserts finite
  * inputs, PhysicsWorld.cpp:548-556,625,710). */
+/* setNewObToWorldTransform(pos,rot,linvel,angvel) (:607-620); SetPositionRotationAndVelocity. Does not activate. */
 int  sgp_body_set_pose_vel(sgp_world* w, uint32_t id, const float pos[3], const float rot[4],
                            const float lin_vel[3], const float ang_vel[3]);
 /* setNewObToWorldTransform(pos,rot,scale) (:546-604): zero velocity, new final shape size, activates. */
