@@ -98,6 +98,9 @@ struct EventCounters {
 #define CMD_MOVE_KINEMATIC (1u << 10)
 #define CMD_CREATE       (1u << 11)
 
+// Per-step pose refresh of an existing ghost body (tiles): what a SET_POS | SET_ROT | SET_VEL | ACTIVATE command does, in 56 bytes
+struct GhostRefresh { uint32_t id; float pos[3]; float rot[4]; float linv[3]; float angv[3]; };
+
 struct BodyCmd {
 	uint32_t id;
 	uint32_t ops;
@@ -260,6 +263,7 @@ void launch_sleep_apply(const DV& d, uint32_t nb, hipStream_t s);
 void launch_buoyancy(const DV& d, uint32_t nb, hipStream_t s);
 void launch_cache_build(const DV& d, uint32_t n_con, hipStream_t s);
 void launch_contact_events(const DV& d, uint32_t n_man, hipStream_t s);
+void launch_ghost_refresh(const DV& d, const GhostRefresh* recs, uint32_t n, hipStream_t s);
 void launch_apply_cmds(const DV& d, const BodyCmd* cmds, const uint32_t* run_start, uint32_t n_runs, hipStream_t s);
 void launch_gather_states(const DV& d, const uint32_t* ids, uint32_t first, uint32_t n, sgp_body_state* out, hipStream_t s);
 void launch_gather_active(const DV& d, uint32_t nb, sgp_body_state* out, uint32_t cap, hipStream_t s);

@@ -2053,6 +2053,27 @@ SGP_DEV uint32_t activate_body(const DV& d, uint32_t i, uint32_t f)
 	return f;
 }
 
+// The ghosts of a tile are refreshed every step with the poses their owners exported: same effect, in the same order, as the
+// SET_POS | SET_ROT | SET_VEL | ACTIVATE command of k_apply_cmds, without the 136-byte command record and the run detection.
+__global__ void __launch_bounds__(TPB) k_ghost_refresh(DV d, const GhostRefresh* recs, uint32_t n)
+{
+	const uint32_t k = blockIdx.x * TPB + threadIdx.x;
+	if (k >= n) return;
+	const GhostRefresh c = recs[k];
+	const uint32_t i = c.id;
+	uint32_t f = d.flags[i];
+	if (!(f & BF_ALIVE)) return;
+	d.pos_im[i] = make_float4(c.pos[0], c.pos[1], c.pos[2], d.pos_im[i].w);
+	d.rot[i] = make_float4(c.rot[0], c.rot[1], c.rot[2], c.rot[3]);
+	if (f_motion(f) != SGP_MOTION_STATIC) {
+		d.linv[i] = make_float4(c.linv[0], c.linv[1], c.linv[2], d.linv[i].w);
+		d.angv[i] = make_float4(c.angv[0], c.angv[1], c.angv[2], d.angv[i].w);
+	}
+	refresh_aabb(d, i, f);
+	f = activate_body(d, i, f);
+	d.flags[i] = f;
+}
+
 __global__ void __launch_bounds__(TPB) k_apply_cmds(DV d, const BodyCmd* cmds, const uint32_t* run_start, uint32_t n_runs)
 {
 	const uint32_t r = blockIdx.x * TPB + threadIdx.x;
@@ -2855,6 +2876,7 @@ void launch_sleep_apply(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKern
 void launch_buoyancy(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_buoyancy, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_cache_build(const DV& d, uint32_t n_con, hipStream_t s) { hipLaunchKernelGGL(k_cache_build, dim3(stride_grid(n_con)), dim3(TPB), 0, s, d); }
 void launch_contact_events(const DV& d, uint32_t est, hipStream_t s) { hipLaunchKernelGGL(k_contact_events, dim3(stride_grid(est)), dim3(TPB), 0, s, d); }
+void launch_ghost_refresh(const DV& d, const GhostRefresh* recs, uint32_t n, hipStream_t s) { if (n) hipLaunchKernelGGL(k_ghost_refresh, dim3(blocks_for(n)), dim3(TPB), 0, s, d, recs, n); }
 void launch_apply_cmds(const DV& d, const BodyCmd* cmds, const uint32_t* run_start, uint32_t n_runs, hipStream_t s) { if (n_runs) hipLaunchKernelGGL(k_apply_cmds, dim3(blocks_for(n_runs)), dim3(TPB), 0, s, d, cmds, run_start, n_runs); }
 void launch_gather_states(const DV& d, const uint32_t* ids, uint32_t first, uint32_t n, sgp_body_state* out, hipStream_t s) { if (n) hipLaunchKernelGGL(k_gather_states, dim3(blocks_for(n)), dim3(TPB), 0, s, d, ids, first, n, out); }
 void launch_gather_active(const DV& d, uint32_t nb, sgp_body_state* out, uint32_t cap, hipStream_t s) { hipLaunchKernelGGL(k_gather_active, dim3(blocks_for(nb)), dim3(TPB), 0, s, d, out, cap); }

@@ -71,6 +71,7 @@ struct sgp_world {
 	uint32_t last_export = 0;                              // records the previous sgp_world_export_boundary produced
 	std::unordered_map<uint64_t, uint64_t> ghost_map;      // global id of a ghost -> generation << 32 | local body id (stable across steps)
 	uint32_t ghost_gen = 0;
+	std::vector<GhostRefresh> ghost_refresh;               // pose refreshes of existing ghosts queued by the last import (uploaded by flush_cmds)
 	std::vector<std::pair<uint64_t, uint32_t>> ghost_seq;   // (global id, local id) of the previous import, in its order (fast path of the next one)
 	// pending edits
 	std::vector<BodyCmd> cmds;
@@ -660,6 +661,18 @@ static int flush_cmds(sgp_world* w)
 		w->large_dirty = false;
 	}
 	{ int r = upload_sp(w); if (r != SGP_OK) return r; }
+	if (!w->ghost_refresh.empty()) {
+		// ghosts never appear in the command queue while their set is unchanged, so the order against the commands below does not matter
+		const size_t bytes = w->ghost_refresh.size() * sizeof(GhostRefresh);
+		{ int r = ensure_stage(w, bytes); if (r != SGP_OK) return r; }
+		memcpy(w->stage_host, w->ghost_refresh.data(), bytes);
+		HIP_TRY(hipMemcpyAsync(w->stage_dev, w->stage_host, bytes, hipMemcpyHostToDevice, w->stream));
+		launch_ghost_refresh(d, (const GhostRefresh*)w->stage_dev, (uint32_t)w->ghost_refresh.size(), w->stream);
+		HIP_TRY(hipStreamSynchronize(w->stream));   // the staging buffer is reused below / by the next call
+		w->ghost_refresh.clear();
+		w->grid_valid = false;
+		w->dirty_since_step = true;
+	}
 	if (w->cmds.empty()) return SGP_OK;
 	w->grid_valid = false;
 	w->dirty_since_step = true;
@@ -1744,14 +1757,17 @@ SGP_API int sgp_world_import_ghosts(sgp_world* w, const sgp_ghost_record* in, ui
 		bool same = true;
 		for (uint32_t k = 0; k < n && same; ++k) same = in[k].global_id == w->ghost_seq[k].first && live(w, w->ghost_seq[k].second);
 		if (same) {
+			// a later import before the next flush supersedes an earlier one: the refresh list holds one record per ghost
+			w->ghost_refresh.resize(n);
 			for (uint32_t k = 0; k < n; ++k) {
-				BodyCmd c = blank_cmd(w->ghost_seq[k].second, CMD_SET_POS | CMD_SET_ROT | CMD_SET_VEL | CMD_ACTIVATE);
+				GhostRefresh& c = w->ghost_refresh[k];
+				c.id = w->ghost_seq[k].second;
 				memcpy(c.pos, in[k].pos, 12); memcpy(c.rot, in[k].rot, 16); memcpy(c.linv, in[k].lin_vel, 12); memcpy(c.angv, in[k].ang_vel, 12);
-				w->cmds.push_back(c);
 			}
 			return SGP_OK;
 		}
 	}
+	w->ghost_refresh.clear();
 	const uint32_t gen = ++w->ghost_gen;
 	w->ghost_seq.assign(n, std::pair<uint64_t, uint32_t>(0, SGP_INVALID_ID));
 	for (uint32_t k = 0; k < n; ++k) {
