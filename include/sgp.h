@@ -294,6 +294,9 @@ int  sgp_world_step_n(sgp_world* w, float dt, uint32_t n);
 /* Same as sgp_world_step but brackets every stage with HIP events on the world's stream. */
 int  sgp_world_step_profiled(sgp_world* w, float dt, sgp_step_profile* out);
 int  sgp_world_stats(sgp_world* w, sgp_step_stats* out);
+/* How the steps so far were issued: replayed as a captured hipGraph, launched eagerly, or skipped because nothing was awake
+ * (diagnostic; any pointer may be NULL). */
+int  sgp_world_launch_counts(sgp_world* w, uint32_t* graph_replays_out, uint32_t* eager_steps_out, uint32_t* idle_steps_out);
 /* Name of kernel class k of sgp_step_profile (NULL past the last class). */
 const char* sgp_kernel_class_name(int k);
 /* sizeof() of ABI struct number `which` (order: settings, world_desc, body_desc, body_state, body_event, contact_event,

@@ -468,6 +468,12 @@ SGO_API int sgo_body_add_batch(sgo_world* w, const sgp_body_desc* d, uint32_t n,
 }
 
 static int live(sgo_world* w, uint32_t id) { return w && id < w->high && w->bodies[id].alive; }
+/* a static mesh body owns the two alias slots behind it (second / third contact manifold of a pair): they share its pose */
+static void sync_mesh_aliases(sgo_world* w, uint32_t id)
+{
+	if (w->bodies[id].shape_type != SGP_SHAPE_MESH || w->bodies[id].is_alias) return;
+	for (int k = 1; k <= 2; ++k) { w->bodies[id + k].pos = w->bodies[id].pos; w->bodies[id + k].rot = w->bodies[id].rot; }
+}
 
 SGO_API int sgo_body_remove(sgo_world* w, uint32_t id)
 {
@@ -491,6 +497,7 @@ SGO_API int sgo_body_set_pose_vel(sgo_world* w, uint32_t id, const float pos[3],
 	quat q = { rot[0], rot[1], rot[2], rot[3] }; b->rot = q;
 	if (b->motion != SGP_MOTION_STATIC) { b->linv = V3(lv[0], lv[1], lv[2]); b->angv = V3(av[0], av[1], av[2]); }
 	body_update_aabb(b);
+	sync_mesh_aliases(w, id);
 	return SGP_OK;
 }
 SGO_API int sgo_body_set_pose_shape(sgo_world* w, uint32_t id, const float pos[3], const float rot[4], const float shape[4])
@@ -500,8 +507,9 @@ SGO_API int sgo_body_set_pose_shape(sgo_world* w, uint32_t id, const float pos[3
 	b->pos = V3(pos[0], pos[1], pos[2]);
 	quat q = { rot[0], rot[1], rot[2], rot[3] }; b->rot = q;
 	b->linv = V3(0, 0, 0); b->angv = V3(0, 0, 0);
-	if (b->shape_type != SGP_SHAPE_HULL) memcpy(b->shape, shape, sizeof(b->shape));   /* inUpdateMassProperties = false, PhysicsWorld.cpp:579; hulls are pre-scaled */
+	if (b->shape_type != SGP_SHAPE_HULL && b->shape_type != SGP_SHAPE_MESH) memcpy(b->shape, shape, sizeof(b->shape));   /* inUpdateMassProperties = false, PhysicsWorld.cpp:579; hulls and meshes are pre-scaled */
 	body_update_aabb(b);
+	sync_mesh_aliases(w, id);
 	body_activate(w, id);
 	return SGP_OK;
 }
@@ -510,6 +518,7 @@ SGO_API int sgo_body_set_pos(sgo_world* w, uint32_t id, const float pos[3])
 	if (!live(w, id)) return SGP_ERR_BAD_ID;
 	w->bodies[id].pos = V3(pos[0], pos[1], pos[2]);
 	body_update_aabb(&w->bodies[id]);
+	sync_mesh_aliases(w, id);
 	return SGP_OK;
 }
 SGO_API int sgo_body_set_vel(sgo_world* w, uint32_t id, const float lv[3], const float av[3])

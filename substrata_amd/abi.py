@@ -244,6 +244,7 @@ PROTOTYPES = {
     "world_step_n": (C.c_int, [vp, f32, u32]),
     "world_step_profiled": (C.c_int, [vp, f32, P(StepProfile)]),
     "world_stats": (C.c_int, [vp, P(StepStats)]),
+    "world_launch_counts": (C.c_int, [vp, P(u32), P(u32), P(u32)]),
     "kernel_class_name": (C.c_char_p, [C.c_int]),
     "abi_sizeof": (C.c_int, [C.c_int]),
     "world_drain_events": (C.c_int, [vp, C.c_int, vp, u32, P(u32)]),

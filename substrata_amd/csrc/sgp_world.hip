@@ -83,7 +83,7 @@ struct sgp_world {
 	uint32_t last_active = 0xFFFFFFFFu;
 	StepParams* h_sp = nullptr; StepParams* d_sp = nullptr;      // pinned host copy / device copy of the per-step scalars
 	std::map<std::string, hipGraphExec_t> graphs;              // replayable launch sequences keyed by launch plan
-	std::string last_plan_key; uint32_t plan_repeats = 0; bool use_graphs = true; bool use_small_world = true; uint32_t tail_threshold = 256;
+	std::string last_plan_key[2]; uint32_t plan_repeats[2] = { 0, 0 }; bool use_graphs = true;   // per buffer parity: StepParams (by value in the first launch) flips parity every step bool use_small_world = true; uint32_t tail_threshold = 256;
 	uint32_t graph_launches = 0, eager_steps = 0, idle_steps = 0;
 	bool grid_valid = false;                                   // the broad-phase grid matches the current poses (ray queries reuse it)
 	// static triangle meshes: host-side headers + pools mirrored on the device (grown on demand)
@@ -488,6 +488,13 @@ SGP_API int sgp_body_add_batch(sgp_world* w, const sgp_body_desc* d, uint32_t n,
 }
 
 static BodyCmd blank_cmd(uint32_t id, uint32_t ops) { BodyCmd c; memset(&c, 0, sizeof(c)); c.id = id; c.ops = ops; return c; }
+static inline bool is_mesh_body(const sgp_world* w, uint32_t id) { return ((w->hb[id].flags & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT) == SGP_SHAPE_MESH && !(w->hb[id].flags & BF_ALIAS); }
+// queue a pose edit; a static mesh body owns the two alias slots behind it (second / third contact manifold of a pair), which share its pose
+static void push_pose_cmd(sgp_world* w, const BodyCmd& c)
+{
+	w->cmds.push_back(c);
+	if (is_mesh_body(w, c.id)) for (uint32_t k = 1; k <= 2; ++k) { BodyCmd a = c; a.id = c.id + k; a.ops &= (CMD_SET_POS | CMD_SET_ROT); w->cmds.push_back(a); }
+}
 
 SGP_API int sgp_body_remove(sgp_world* w, uint32_t id)
 {
@@ -527,7 +534,7 @@ SGP_API int sgp_body_set_pose_vel(sgp_world* w, uint32_t id, const float pos[3],
 	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_set_pose_vel: id not live");
 	BodyCmd c = blank_cmd(id, CMD_SET_POS | CMD_SET_ROT | CMD_SET_VEL);
 	memcpy(c.pos, pos, 12); memcpy(c.rot, rot, 16); memcpy(c.linv, lv, 12); memcpy(c.angv, av, 12);
-	w->cmds.push_back(c);
+	push_pose_cmd(w, c);
 	return SGP_OK;
 }
 SGP_API int sgp_body_set_pose_vel_batch(sgp_world* w, const uint32_t* ids, const sgp_pose_vel* recs, uint32_t n)
@@ -539,7 +546,7 @@ SGP_API int sgp_body_set_pose_vel_batch(sgp_world* w, const uint32_t* ids, const
 	for (uint32_t i = 0; i < n; ++i) {
 		BodyCmd c = blank_cmd(ids[i], CMD_SET_POS | CMD_SET_ROT | CMD_SET_VEL);
 		memcpy(c.pos, recs[i].pos, 12); memcpy(c.rot, recs[i].rot, 16); memcpy(c.linv, recs[i].lin_vel, 12); memcpy(c.angv, recs[i].ang_vel, 12);
-		w->cmds.push_back(c);
+		push_pose_cmd(w, c);
 	}
 	return SGP_OK;
 }
@@ -579,13 +586,13 @@ SGP_API int sgp_body_set_pose_shape(sgp_world* w, uint32_t id, const float pos[3
 	BodyCmd c = blank_cmd(id, CMD_SET_POS | CMD_SET_ROT | CMD_SET_VEL | CMD_SET_SHAPE | CMD_ACTIVATE);
 	memcpy(c.pos, pos, 12); memcpy(c.rot, rot, 16); memcpy(c.shape, shape, 16);
 	const int type = (int)((w->hb[id].flags & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT);
-	if (type == SGP_SHAPE_HULL) c.ops &= ~CMD_SET_SHAPE;          // hulls are pre-scaled: only the pose changes
+	if (type == SGP_SHAPE_HULL || type == SGP_SHAPE_MESH) c.ops &= ~CMD_SET_SHAPE;          // hulls and meshes are pre-scaled (shape.x = table id): only the pose changes
 	else {
 		note_radius(w, id, bounding_radius(type, shape));
 		w->hb[id].volume = host_shape_volume(type, shape);
 		c.flags = w->hb[id].flags & BF_LARGE;      // the device copy of the flag follows the host's
 	}
-	w->cmds.push_back(c);
+	push_pose_cmd(w, c);
 	return SGP_OK;
 }
 SGP_API int sgp_body_set_pos(sgp_world* w, uint32_t id, const float pos[3])
@@ -593,7 +600,7 @@ SGP_API int sgp_body_set_pos(sgp_world* w, uint32_t id, const float pos[3])
 	REQUIRE_FINITE(pos && finite3(pos), "sgp_body_set_pos");
 	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_set_pos: id not live");
 	BodyCmd c = blank_cmd(id, CMD_SET_POS); memcpy(c.pos, pos, 12);
-	w->cmds.push_back(c);
+	push_pose_cmd(w, c);
 	return SGP_OK;
 }
 SGP_API int sgp_body_set_vel(sgp_world* w, uint32_t id, const float lv[3], const float av[3])
@@ -932,9 +939,11 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	if (w->use_graphs && !w->profiling) {
 		auto it = w->graphs.find(key);
 		if (it == w->graphs.end()) {
-			// capture only once the same plan has come up twice in a row (plans churn while a scene is still changing)
-			w->plan_repeats = (key == w->last_plan_key) ? w->plan_repeats + 1 : 0;
-			if (w->plan_repeats >= 1) {
+			// capture only once the same plan has come up twice in a row for this buffer parity (plans churn while a scene is still
+			// changing; the parity is part of the by-value StepParams, so a plan alternates between two keys)
+			const uint32_t par = w->h_sp->parity & 1u;
+			w->plan_repeats[par] = (key == w->last_plan_key[par]) ? w->plan_repeats[par] + 1 : 0;
+			if (w->plan_repeats[par] >= 1) {
 				if (w->graphs.size() >= 16) { for (auto& kv : w->graphs) hipGraphExecDestroy(kv.second); w->graphs.clear(); }
 				hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
 				HIP_TRY(hipStreamBeginCapture(w->stream, hipStreamCaptureModeThreadLocal));
@@ -950,7 +959,7 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 		}
 		if (it != w->graphs.end()) { HIP_TRY(hipGraphLaunch(it->second, w->stream)); launched = true; w->graph_launches++; }
 	}
-	w->last_plan_key = key;
+	w->last_plan_key[w->h_sp->parity & 1u] = key;
 	if (!launched) { const int r = enqueue_step(w, plan); if (r != SGP_OK) return r; w->eager_steps++; }
 	// -- the ONE host sync of the step: counters, events, and the launch plan for the next step
 	const double tt1 = timing ? now() : 0.0;
@@ -1058,6 +1067,15 @@ SGP_API int sgp_world_stats(sgp_world* w, sgp_step_stats* out)
 	*out = w->stats;
 	out->num_bodies = w->n_alive;
 	out->device_bytes = w->device_bytes;
+	return SGP_OK;
+}
+
+SGP_API int sgp_world_launch_counts(sgp_world* w, uint32_t* graph_replays_out, uint32_t* eager_steps_out, uint32_t* idle_steps_out)
+{
+	if (!w) return fail(SGP_ERR_INVALID, "sgp_world_launch_counts: NULL");
+	if (graph_replays_out) *graph_replays_out = w->graph_launches;
+	if (eager_steps_out) *eager_steps_out = w->eager_steps;
+	if (idle_steps_out) *idle_steps_out = w->idle_steps;
 	return SGP_OK;
 }
 

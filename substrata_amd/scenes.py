@@ -110,6 +110,35 @@ def config3_100k_mixed(nx=100, ny=100, nz=10, seed=3):
     return np.concatenate([ground(), d])
 
 
+CONFIG4_SPACING = 1.25
+
+
+def config4_1m_boxes(n=100, seed=4, spacing=CONFIG4_SPACING):
+    """Config 4: n^3 unit cubes (1M at n = 100) on an n x n x n lattice, spacing 1.25 m, lowest layer centre z = 1.0, seed 4 (SURVEY 8d);
+    body 0 is the ground quad.  The lattice is centred on the origin in x and y."""
+    d, _ = lattice(n, n, n, spacing, 1.0, seed=seed)
+    return np.concatenate([ground(), d])
+
+
+def config4_world_box(n=100, spacing=CONFIG4_SPACING):
+    """The box the 3-D tiles of config 4 split: the lattice's extent (lo corner, size), z from the ground plane."""
+    w = n * spacing
+    return np.array([-w / 2, -w / 2, 0.0], np.float32), np.array([w, w, w], np.float32)
+
+
+def config4_tile_descs(rank, n_tiles, n=100, seed=4, spacing=CONFIG4_SPACING):
+    """What tile `rank` of the n_tiles-way 3-D split (tiles.tile_grid: 2x1x1 / 2x2x1 / 2x2x2) owns of config 4: its own ground quad
+    (body 0 of every tile world) + the lattice bodies whose centre lies in the tile.  Returns (descs, lo, hi) with the tile's region."""
+    from . import tiles
+    full = config4_1m_boxes(n, seed, spacing)
+    origin, size = config4_world_box(n, spacing)
+    tx, ty, tz = tiles.tile_grid(n_tiles)
+    lo, hi, _ = tiles.tile_bounds(rank, n_tiles, size[0] / tx, size[1] / ty, size[2] / tz, origin=origin)
+    p = full["pos"][1:]
+    mine = np.all(p >= lo, axis=1) & np.all(p < hi, axis=1)
+    return np.concatenate([full[:1], full[1:][mine]]), lo, hi
+
+
 def config4_tile(nx, ny, nz, spacing=1.25, seed=4, offset=(0.0, 0.0, 0.0)):
     """Config 4 building block: one spatial tile of the 1M-box lattice (100^3, spacing 1.25 m)."""
     d, _ = lattice(nx, ny, nz, spacing, 1.0, seed=seed, origin_centered=False)

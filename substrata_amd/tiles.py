@@ -19,24 +19,42 @@ REC = abi.ghost_dtype.itemsize
 
 
 def tile_grid(n_tiles):
-    """2-D tiling (the settled pile is shallow in z): 1 -> 1x1, 2 -> 2x1, 4 -> 2x2, 8 -> 4x2."""
-    tx = 1
-    while tx * tx < n_tiles:
-        tx *= 2
-    ty = max(1, n_tiles // tx)
-    assert tx * ty == n_tiles, "tile count must be a power of two"
-    return tx, ty
+    """3-D tiling of the world box (north_star): 1 -> 1x1x1, 2 -> 2x1x1, 4 -> 2x2x1, 8 -> 2x2x2; beyond that the
+    axes keep doubling in turn (x, y, z)."""
+    g = [1, 1, 1]
+    axis = 0
+    n = 1
+    while n < n_tiles:
+        g[axis] *= 2
+        n *= 2
+        axis = (axis + 1) % 3
+    assert n == n_tiles, "tile count must be a power of two"
+    return tuple(g)
 
 
-def tile_bounds(rank, n_tiles, tile_w, tile_d):
-    """Axis-aligned region [lo, hi) of tile `rank`; z is unbounded."""
-    tx, ty = tile_grid(n_tiles)
-    ix, iy = rank % tx, rank // tx
+def tile_coords(rank, grid):
+    """(ix, iy, iz) of tile `rank`: x fastest."""
+    tx, ty, tz = grid
+    return rank % tx, (rank // tx) % ty, rank // (tx * ty)
+
+
+def tile_bounds(rank, n_tiles, tile_w, tile_d, tile_h=None, grid=None, origin=(0.0, 0.0, 0.0)):
+    """Axis-aligned region [lo, hi) of tile `rank` in a grid of tile_w x tile_d x tile_h tiles starting at `origin`; the outer
+    faces of the grid are unbounded (a body that leaves the world box stays with the nearest tile).  tile_h = None: the grid must
+    be flat (one tile in z, unbounded in z) -- pass grid=(tx, ty, 1) for a side-by-side layout of more than 4 tiles.
+    Returns (lo, hi, corner of the tile)."""
+    tx, ty, tz = grid if grid is not None else tile_grid(n_tiles)
+    assert tx * ty * tz == n_tiles
+    assert tile_h is not None or tz == 1, "a z split needs a tile height"
+    ix, iy, iz = tile_coords(rank, (tx, ty, tz))
     big = 1.0e9
-    lo = np.array([ix * tile_w if ix > 0 else -big, iy * tile_d if iy > 0 else -big, -big], dtype=np.float32)
-    hi = np.array([(ix + 1) * tile_w if ix < tx - 1 else big, (iy + 1) * tile_d if iy < ty - 1 else big, big], dtype=np.float32)
-    origin = np.array([ix * tile_w, iy * tile_d, 0.0], dtype=np.float32)
-    return lo, hi, origin
+    ox, oy, oz = (float(v) for v in origin)
+    th = float(tile_h) if tile_h is not None else 0.0
+    lo = np.array([ox + ix * tile_w if ix > 0 else -big, oy + iy * tile_d if iy > 0 else -big, oz + iz * th if iz > 0 else -big], dtype=np.float32)
+    hi = np.array([ox + (ix + 1) * tile_w if ix < tx - 1 else big, oy + (iy + 1) * tile_d if iy < ty - 1 else big,
+                   oz + (iz + 1) * th if iz < tz - 1 else big], dtype=np.float32)
+    corner = np.array([ox + ix * tile_w, oy + iy * tile_d, oz + iz * th], dtype=np.float32)
+    return lo, hi, corner
 
 
 def inside(recs, lo, hi):
@@ -116,6 +134,30 @@ def split(recs, lo, hi):
     if rc != 0:
         raise RuntimeError(f"sgp_tiles_split failed ({rc})")
     return ghosts[:ng.value], immigrants[:ni.value]
+
+
+def exchange_in_process(worlds, boxes, margin, log=None, radius_pad=1.5):
+    """What GhostExchange does across ranks, for N tile worlds living in ONE process (tests, tools/fuzz_tiles.py, and a single-GPU
+    dry run of a multi-tile world): export -> route -> [hand over] -> split -> import / immigrate, in rank order."""
+    n = len(worlds)
+    sent = []
+    for r, w in enumerate(worlds):
+        recs = w.export_boundary(boxes[r, :3], boxes[r, 3:], margin, cap=max(1 << 14, 4 * w.num_bodies()))
+        send, counts, emig = route(recs, r, boxes, margin + radius_pad)
+        for i in emig:
+            w.remove(int(i))
+        off = [0] + [int(x) for x in np.cumsum(counts)]
+        sent.append([send[off[d]:off[d + 1]] for d in range(n)])
+        if log is not None:
+            log.append(("export", r, len(recs), [int(c) for c in counts], len(emig)))
+    for r, w in enumerate(worlds):
+        arrived = np.concatenate([sent[src][r] for src in range(n)]) if n > 1 else sent[0][0][:0]
+        ghosts, immigrants = split(arrived, boxes[r, :3], boxes[r, 3:])
+        w.import_ghosts(ghosts)
+        if len(immigrants):
+            w.add_batch(records_to_descs(immigrants))
+        if log is not None:
+            log.append(("import", r, len(ghosts), len(immigrants)))
 
 
 class GhostExchange:

@@ -189,6 +189,12 @@ class CWorld:
         self._check(self._fn("world_stats")(self._h, C.byref(s)), "world_stats")
         return s
 
+    def launch_counts(self):
+        """(graph replays, eager steps, idle steps) so far -- product library only."""
+        g, e, i = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        self._check(self._fn("world_launch_counts")(self._h, C.byref(g), C.byref(e), C.byref(i)), "world_launch_counts")
+        return g.value, e.value, i.value
+
     def num_bodies(self):
         n = C.c_uint32(0)
         self._check(self._fn("world_num_bodies")(self._h, C.byref(n)), "world_num_bodies")

@@ -1,0 +1,124 @@
+"""BASELINE config 4 (1M boxes, 100^3 lattice, spacing 1.25 m, 2x2x2 spatial tiles).
+
+(i)  the full 1M-box world on ONE GPU: size-independent properties (nothing dropped, valid colouring, finite state, no energy
+     created, run-to-run bit equality);
+(ii) the 2x2x2 split on a scaled-down lattice, eight tile worlds in one process, HIP against oracle tiles bit for bit, with bodies
+     falling through the z faces of the tiling (ownership migrates downwards) -- the tile path of the named config measured against
+     the oracle like every other part of the step;
+(iii) the two-process z-split over gloo lives in tests/test_tiles_gloo.py (CPU).
+"""
+import numpy as np
+import pytest
+
+from substrata_amd import abi, scenes, tiles
+from helpers import DT
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+def colouring_valid(cons, movable):
+    """Vectorised parity.check_colouring_valid: no two constraints of one (non-overflow) colour share a movable body."""
+    c = cons[cons["colour"] != 63]
+    keys = []
+    for side in ("a", "b"):
+        m = movable[c[side]]
+        keys.append(c["colour"][m].astype(np.int64) << np.int64(32) | c[side][m].astype(np.int64))
+    k = np.concatenate(keys)
+    return len(np.unique(k)) == len(k)
+
+
+def potential_energy(descs, st):
+    return float(np.sum(descs["mass"][1:].astype(np.float64) * 9.81 * st["pos"][1:, 2].astype(np.float64)))
+
+
+def kinetic_energy(descs, st):
+    return float(np.sum(0.5 * descs["mass"][1:].astype(np.float64) * np.sum(st["lin_vel"][1:].astype(np.float64) ** 2, axis=1)))
+
+
+@pytest.mark.timeout(1500)
+def test_config4_1m_boxes_single_gpu_properties():
+    from substrata_amd.lib import World
+    descs = scenes.config4_1m_boxes()
+    n = len(descs)
+    assert n == 1_000_001
+    runs = []
+    for rep in range(2):
+        w = World(max_bodies=n + 64)
+        w.add_batch(descs)
+        e0 = potential_energy(descs, w.read_states(0, n))
+        for _ in range(48):
+            w.step(DT)
+        st = w.read_states(0, n)
+        stats = w.stats()
+        runs.append(st)
+        if rep == 0:
+            cons = w.dump_constraints(cap=stats.num_manifolds + 1024)
+            assert stats.num_bodies == n and stats.pairs_dropped == 0 and stats.manifolds_dropped == 0
+            # the lowest layers have landed on the ground and on each other
+            assert stats.num_manifolds > 10000 and stats.num_overflow_constraints == 0 and stats.num_colours <= 40
+            for f in ("pos", "rot", "lin_vel", "ang_vel"):
+                assert np.all(np.isfinite(st[f])), f
+            assert np.max(np.abs(np.linalg.norm(st["rot"], axis=1) - 1.0)) < 1e-5
+            assert st["pos"][1:, 2].min() > -0.5
+            # free fall above the contact front: the top layer is still exactly on the closed-form semi-implicit Euler path
+            top = st["pos"][-100:, 2]
+            v, z = 0.0, float(descs["pos"][-1, 2])
+            for _ in range(48):
+                v = np.float32(np.float32(v + np.float32(-9.81) * np.float32(DT)) * np.float32(1.0 - 0.05 * DT))
+                z = np.float32(z + v * np.float32(DT))
+            assert np.max(np.abs(top - z)) < 2e-3
+            assert potential_energy(descs, st) + kinetic_energy(descs, st) <= e0 * (1.0 + 1e-4)
+            movable = st["active"].astype(bool)
+            movable[0] = False
+            assert len(cons) == stats.num_manifolds
+            assert colouring_valid(cons, movable)
+            key = cons["a"].astype(np.uint64) << np.uint64(32) | cons["b"].astype(np.uint64)
+            assert np.all(np.diff(key.astype(np.int64)) > 0)
+        w.close()
+    for f in ("pos", "rot", "lin_vel", "ang_vel"):
+        assert np.array_equal(runs[0][f].view(np.uint32), runs[1][f].view(np.uint32)), f
+
+
+@pytest.mark.timeout(900)
+def test_config4_scaled_down_2x2x2_tiles_against_oracle(oracle):
+    """n = 8 lattice (512 boxes) split 2x2x2: the four upper tiles own the upper half of the tower, which falls through the z = 5 m
+    faces into the lower tiles.  Eight HIP worlds and eight oracle worlds go through the same exchange; states must agree bit for bit,
+    no body may be lost or duplicated, and every upper-tile body must have changed owner by the end."""
+    from substrata_amd.lib import World
+    n, n_tiles = 8, 8
+    assert tiles.tile_grid(n_tiles) == (2, 2, 2)
+    tile_descs, boxes = [], []
+    for r in range(n_tiles):
+        d, lo, hi = scenes.config4_tile_descs(r, n_tiles, n=n)
+        tile_descs.append(d); boxes.append(np.concatenate([lo, hi]))
+    boxes = np.array(boxes, np.float32)
+    total = sum(len(d) - 1 for d in tile_descs)
+    assert total == n ** 3 and all(len(d) - 1 == n ** 3 // 8 for d in tile_descs)
+    cap = 2048
+    gpu = [World(max_bodies=cap) for _ in range(n_tiles)]
+    cpu = [oracle.OracleWorld(max_bodies=cap) for _ in range(n_tiles)]
+    for r in range(n_tiles):
+        assert np.array_equal(gpu[r].add_batch(tile_descs[r]), cpu[r].add_batch(tile_descs[r]))
+    margin = 2.0                       # ghost margin = 1 cell (2 m)
+    migrated_down = 0
+    for s in range(1, 181):
+        lg, lc = [], []
+        tiles.exchange_in_process(gpu, boxes, margin, lg)
+        tiles.exchange_in_process(cpu, boxes, margin, lc)
+        assert lg == lc, (s, [a for a, b in zip(lg, lc) if a != b][:3], [b for a, b in zip(lg, lc) if a != b][:3])
+        migrated_down += sum(e[4] for e in lg if e[0] == "export" and e[1] >= 4)
+        for r in range(n_tiles):
+            gpu[r].step(DT); cpu[r].step(DT)
+        if s % 30 == 0:
+            for r in range(n_tiles):
+                dd = parity.state_diff(gpu[r].read_states(0, cap), cpu[r].read_states(0, cap))
+                assert dd["bit_exact"] and dd["active_mismatch"] == 0, (s, r, dd)
+            owned = sum(gpu[r].num_bodies() - 1 - [e for e in lg if e[0] == "import" and e[1] == r][0][2] for r in range(n_tiles))
+            assert owned == total, (s, owned, total)
+    # the upper half of the tower (4 upper tiles x 64 bodies) fell through the z faces
+    assert migrated_down >= n ** 3 // 2
+    upper_owned = sum(gpu[r].num_bodies() - 1 - [e for e in lg if e[0] == "import" and e[1] == r][0][2] for r in range(4, 8))
+    assert upper_owned == 0
+    for w in gpu + cpu:
+        w.close()

@@ -82,11 +82,25 @@ def worker(rank, world_size, port, steps, out_dir):
 
 
 def test_tile_grid_and_bounds():
-    assert tiles.tile_grid(1) == (1, 1) and tiles.tile_grid(2) == (2, 1) and tiles.tile_grid(4) == (2, 2) and tiles.tile_grid(8) == (4, 2)
+    # SURVEY 8(e) / north_star: 2x1x1, 2x2x1, 2x2x2
+    assert tiles.tile_grid(1) == (1, 1, 1) and tiles.tile_grid(2) == (2, 1, 1) and tiles.tile_grid(4) == (2, 2, 1) and tiles.tile_grid(8) == (2, 2, 2)
     lo, hi, org = tiles.tile_bounds(1, 2, 150.0, 150.0)
-    assert lo[0] == 150.0 and hi[0] > 1e8 and org[0] == 150.0
-    lo, hi, org = tiles.tile_bounds(5, 8, 150.0, 150.0)     # ix=1, iy=1
+    assert lo[0] == 150.0 and hi[0] > 1e8 and org[0] == 150.0 and lo[2] < -1e8 and hi[2] > 1e8
+    lo, hi, org = tiles.tile_bounds(5, 8, 150.0, 150.0, grid=(4, 2, 1))     # flat side-by-side layout: ix=1, iy=1
     assert (lo[0], hi[0], lo[1]) == (150.0, 300.0, 150.0)
+    # the 2x2x2 split of a box that starts at (-10, -10, 0): rank 7 = upper (+x, +y) octant, rank 1 = lower (+x, -y)
+    lo, hi, org = tiles.tile_bounds(7, 8, 10.0, 10.0, 20.0, origin=(-10.0, -10.0, 0.0))
+    assert tuple(lo) == (0.0, 0.0, 20.0) and all(hi > 1e8) and tuple(org) == (0.0, 0.0, 20.0)
+    lo, hi, org = tiles.tile_bounds(1, 8, 10.0, 10.0, 20.0, origin=(-10.0, -10.0, 0.0))
+    assert lo[0] == 0.0 and lo[1] < -1e8 and lo[2] < -1e8 and hi[0] > 1e8 and hi[1] == 0.0 and hi[2] == 20.0
+    # every point belongs to exactly one tile
+    rng = np.random.default_rng(0)
+    pts = rng.uniform(-30, 50, size=(2000, 3)).astype(np.float32)
+    owners = np.zeros(len(pts), int)
+    for r in range(8):
+        lo, hi, _ = tiles.tile_bounds(r, 8, 10.0, 10.0, 20.0, origin=(-10.0, -10.0, 0.0))
+        owners += (np.all(pts >= lo, axis=1) & np.all(pts < hi, axis=1)).astype(int)
+    assert np.all(owners == 1)
 
 
 def test_select_ghosts_filters_by_region():
@@ -144,7 +158,7 @@ def test_route_and_split_match_a_numpy_reference():
     """sgp_tiles_route / sgp_tiles_split (the C helpers behind GhostExchange) against the plain numpy statement of the same rules."""
     rng = np.random.default_rng(5)
     n_tiles, w = 8, 30.0
-    boxes = np.array([np.concatenate(tiles.tile_bounds(r, n_tiles, w, w)[:2]) for r in range(n_tiles)], np.float32)
+    boxes = np.array([np.concatenate(tiles.tile_bounds(r, n_tiles, w, w, grid=(4, 2, 1))[:2]) for r in range(n_tiles)], np.float32)
     for rank in (0, 5):
         lo, hi = boxes[rank, :3], boxes[rank, 3:]
         n = 3000
@@ -235,3 +249,57 @@ def test_four_tiles_corner_bodies_reach_all_neighbours(tmp_path, oracle):
         st = np.load(tmp_path / f"cornerstate{r}.npy")
         own = st[st["id"] != abi.INVALID_ID]
         assert own["pos"][:, 2].min() > -0.6 and np.abs(own["lin_vel"]).max() < 8.0      # nothing fell through or exploded
+
+
+def zsplit_worker(rank, world_size, port, steps, out_dir):
+    """A z split (grid 1 x 1 x 2, the third axis of the 2x2x2 tiling of config 4): the upper tile owns a short column of boxes that
+    falls through the z face onto a 2 x 2 base the lower tile owns."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    from oracle import oracle
+    lo, hi, origin = tiles.tile_bounds(rank, world_size, TILE_W, TILE_W, 3.0, grid=(1, 1, 2))
+    descs = scenes.ground()
+    if rank == 0:
+        b = scenes.dynamic_bodies(4)
+        b["pos"] = np.float32([[5.0, 5.0, 0.5], [6.02, 5.0, 0.5], [5.0, 6.02, 0.5], [6.02, 6.02, 0.5]])
+    else:
+        b = scenes.dynamic_bodies(3)
+        b["pos"] = np.float32([[5.5, 5.5, 4.0], [5.52, 5.5, 5.5], [5.5, 5.52, 7.0]])
+    descs = np.concatenate([descs, b])
+    w = oracle.OracleWorld(max_bodies=64)
+    w.add_batch(descs)
+    ex = tiles.GhostExchange(w, rank, world_size, lo, hi, margin=2.0, dist=dist, device=torch.device("cpu"), cap=64)
+    log = []
+    for _ in range(steps):
+        ex.exchange()
+        log.append((ex.last_exported, ex.last_sent, ex.last_imported, ex.last_emigrated, ex.last_immigrated))
+        w.step(DT)
+    st = w.read_states(0, 32)
+    np.save(os.path.join(out_dir, f"z{rank}.npy"), st)
+    np.save(os.path.join(out_dir, f"zlog{rank}.npy"), np.array(log))
+    np.save(os.path.join(out_dir, f"zcount{rank}.npy"), np.array([w.num_bodies(), ex.last_imported]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_tiles_split_in_z_bodies_fall_through_the_face(tmp_path, oracle):
+    lo, hi, org = tiles.tile_bounds(1, 2, TILE_W, TILE_W, 3.0, grid=(1, 1, 2))
+    assert lo[2] == 3.0 and hi[2] > 1e8 and lo[0] < -1e8 and org[2] == 3.0
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(zsplit_worker, args=(2, port, 200, str(tmp_path)), nprocs=2, join=True)
+    l0, l1 = np.load(tmp_path / "zlog0.npy"), np.load(tmp_path / "zlog1.npy")
+    c0, c1 = np.load(tmp_path / "zcount0.npy"), np.load(tmp_path / "zcount1.npy")
+    # all three boxes of the upper tile emigrated through the z = 3 face, and the lower tile took every one of them
+    assert l1[:, 3].sum() == 3 and l0[:, 4].sum() == 3 and l0[:, 3].sum() == 0
+    # before it crossed, the lowest falling box was a ghost in the lower tile (imported across the z face)
+    assert l0[:, 2].max() >= 1
+    s0 = np.load(tmp_path / "z0.npy")
+    own = s0[s0["id"] != abi.INVALID_ID][1:]
+    assert c0[0] - c0[1] == 1 + 7                        # ground + 4 base boxes + 3 immigrants (ghost copies excluded)
+    assert c1[0] - c1[1] == 1                            # the upper tile is left with its ground quad
+    dyn = own[np.argsort(own["pos"][:, 2])][:7]
+    # the column came to rest on the base: nothing fell through, nothing is still moving fast
+    assert dyn["pos"][:, 2].min() > 0.45 and dyn["pos"][:, 2].max() < 4.2
+    assert np.abs(dyn["lin_vel"]).max() < 2.0 and np.all(np.isfinite(dyn["pos"]))     # (the top box may still be sliding off the pile)
