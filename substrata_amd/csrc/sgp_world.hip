@@ -83,7 +83,8 @@ struct sgp_world {
 	uint32_t last_active = 0xFFFFFFFFu;
 	StepParams* h_sp = nullptr; StepParams* d_sp = nullptr;      // pinned host copy / device copy of the per-step scalars
 	std::map<std::string, hipGraphExec_t> graphs;              // replayable launch sequences keyed by launch plan
-	std::string last_plan_key[2]; uint32_t plan_repeats[2] = { 0, 0 }; bool use_graphs = true;   // per buffer parity: StepParams (by value in the first launch) flips parity every step bool use_small_world = true; uint32_t tail_threshold = 256;
+	std::string last_plan_key[2]; uint32_t plan_repeats[2] = { 0, 0 };   // per buffer parity: StepParams (by value in the first launch) flips parity every step
+	bool use_graphs = true; bool use_small_world = true; uint32_t tail_threshold = 256;
 	uint32_t graph_launches = 0, eager_steps = 0, idle_steps = 0;
 	bool grid_valid = false;                                   // the broad-phase grid matches the current poses (ray queries reuse it)
 	// static triangle meshes: host-side headers + pools mirrored on the device (grown on demand)
@@ -1235,7 +1236,7 @@ static void invalidate_graphs(sgp_world* w)
 {
 	for (auto& kv : w->graphs) hipGraphExecDestroy(kv.second);
 	w->graphs.clear();
-	w->last_plan_key.clear(); w->plan_repeats = 0;
+	for (int k = 0; k < 2; ++k) { w->last_plan_key[k].clear(); w->plan_repeats[k] = 0; }
 }
 
 SGP_API void sgp_default_vehicle_desc(sgp_vehicle_desc* d)
