@@ -174,7 +174,13 @@ typedef struct sgp_hit {
 	uint32_t id;               /* SGP_INVALID_ID if no hit */
 	float    t;                /* RayTraceResult::hit_t */
 	float    normal[3];        /* RayTraceResult::hit_normal_ws */
+	uint32_t triangle;         /* mesh hits (ray casts): index of the triangle in the caller's order; SGP_INVALID_ID otherwise            */
 	uint64_t userdata;         /* -> RayTraceResult::hit_object */
+	uint32_t material;         /* mesh hits: the triangle's user data = material index, MeshShape::GetTriangleUserData
+	                              (PhysicsWorld.cpp:1700-1704 -> RayTraceResult::hit_mat_index); 0 otherwise                               */
+	float    bary[2];          /* mesh hits: barycentric coordinates (u, v) of the hit, point = (1 - u - v) a + u b + v c; 0 otherwise.
+	                              (The reference leaves RayTraceResult::coords at 0, :1693; the facade does the same.)                     */
+	uint32_t _pad;
 } sgp_hit;
 
 /* Counters of the last step (getDiagnostics, PhysicsWorld.cpp:1578-1604, plus stage sizes). */
@@ -305,6 +311,8 @@ const char* sgp_kernel_class_name(int k);
 int  sgp_abi_sizeof(int which);
 /* activated_obs / newly_activated_obs maintenance + listener callbacks (PhysicsWorld.h:194-200). */
 int  sgp_world_drain_events(sgp_world* w, int kind, void* out, uint32_t cap, uint32_t* n_out);
+/* Body::GetUserData() of a live body (what JPH::BodyLockRead users read, PlayerPhysics.cpp:519-530); host-side lookup, no device access. */
+int  sgp_body_get_userdata(sgp_world* w, uint32_t id, uint64_t* userdata_out);
 /* getNumObjects (:1635-1638) */
 int  sgp_world_num_bodies(sgp_world* w, uint32_t* n_out);
 
@@ -347,6 +355,10 @@ typedef struct sgp_mesh_info {
 	float aabb_min[3], aabb_max[3];
 } sgp_mesh_info;
 int  sgp_mesh_create(sgp_world* w, const float* vertices_xyz, uint32_t num_vertices, const uint32_t* indices, uint32_t num_triangles, sgp_mesh_info* info_out);
+/* The same with one user-data word per triangle (JPH::IndexedTriangle::mMaterialIndex / MeshShape::GetTriangleUserData: the reference
+ * stores the batch's material index there, PhysicsWorld.cpp:1032-1060), reported by ray hits.  NULL = all 0. */
+int  sgp_mesh_create_with_materials(sgp_world* w, const float* vertices_xyz, uint32_t num_vertices, const uint32_t* indices, uint32_t num_triangles,
+                                    const uint32_t* triangle_materials, sgp_mesh_info* info_out);
 
 /* ---- wheeled vehicles --------------------------------------------------------
  * Replaces JPH::VehicleConstraint + JPH::WheeledVehicleController + JPH::VehicleCollisionTesterCastSphere as CarPhysics

@@ -93,8 +93,9 @@ static inline int sgo_mesh_finish(const sgo_mesh_contacts* mc, sgo_manifold* out
 	return mc->ng;
 }
 
-/* ray against one triangle (Moeller-Trumbore, front face only): t or -1 */
-static inline float sgo_ray_tri(v3 o, v3 d, v3 a, v3 b, v3 c, float max_t)
+/* ray against one triangle (Moeller-Trumbore, front face only): t or -1; uv_out (may be NULL) = barycentric coordinates of the hit,
+   point = (1 - u - v) a + u b + v c */
+static inline float sgo_ray_tri_uv(v3 o, v3 d, v3 a, v3 b, v3 c, float max_t, float* uv_out)
 {
 	const v3 e1 = v3_sub(b, a), e2 = v3_sub(c, a);
 	const v3 pv = v3_cross(d, e2);
@@ -108,8 +109,10 @@ static inline float sgo_ray_tri(v3 o, v3 d, v3 a, v3 b, v3 c, float max_t)
 	if (vv < 0.0f || u + vv > det) return -1.0f;
 	const float t = v3_dot(e2, qv) / det;
 	if (t < 0.0f || t > max_t) return -1.0f;
+	if (uv_out) { uv_out[0] = u / det; uv_out[1] = vv / det; }
 	return t;
 }
+static inline float sgo_ray_tri(v3 o, v3 d, v3 a, v3 b, v3 c, float max_t) { return sgo_ray_tri_uv(o, d, a, b, c, max_t, (float*)0); }
 
 /* ray against a capsule with end points a, b and radius r (any orientation): t or -1, normal at the hit */
 static inline float sgo_ray_capsule_seg(v3 o, v3 d, v3 a, v3 b, float r, float max_t, v3* n_out)

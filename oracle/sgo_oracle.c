@@ -83,7 +83,7 @@ typedef struct {
 
 typedef struct { uint32_t a, b; } sgo_pair;
 
-typedef struct sgo_mesh_s { uint32_t nv, nt; v3* verts; uint32_t* tris; v3 aabb_min, aabb_max; float bound_radius; } sgo_mesh;
+typedef struct sgo_mesh_s { uint32_t nv, nt; v3* verts; uint32_t* tris; uint32_t* mats; v3 aabb_min, aabb_max; float bound_radius; } sgo_mesh;
 
 typedef struct sgo_world {
 	sgp_world_desc desc;
@@ -1983,7 +1983,9 @@ SGO_API int sgo_collide_pair(const sgp_body_desc* a, const sgp_body_desc* b, flo
 }
 
 /* MeshShapeSettings::Create */
-SGO_API int sgo_mesh_create(sgo_world* w, const float* verts, uint32_t nv, const uint32_t* idx, uint32_t nt, sgp_mesh_info* info)
+SGO_API int sgo_mesh_create_with_materials(sgo_world* w, const float* verts, uint32_t nv, const uint32_t* idx, uint32_t nt, const uint32_t* mats, sgp_mesh_info* info);
+SGO_API int sgo_mesh_create(sgo_world* w, const float* verts, uint32_t nv, const uint32_t* idx, uint32_t nt, sgp_mesh_info* info) { return sgo_mesh_create_with_materials(w, verts, nv, idx, nt, NULL, info); }
+SGO_API int sgo_mesh_create_with_materials(sgo_world* w, const float* verts, uint32_t nv, const uint32_t* idx, uint32_t nt, const uint32_t* mats, sgp_mesh_info* info)
 {
 	if (!w || !verts || !idx || !info || nv < 3 || nt < 1) return SGP_ERR_INVALID;
 	for (uint32_t k = 0; k < 3 * nt; ++k) if (idx[k] >= nv) return SGP_ERR_INVALID;
@@ -1992,6 +1994,8 @@ SGO_API int sgo_mesh_create(sgo_world* w, const float* verts, uint32_t nv, const
 	m->nv = nv; m->nt = nt;
 	m->verts = (v3*)malloc(sizeof(v3) * nv); m->tris = (uint32_t*)malloc(sizeof(uint32_t) * 3 * nt);
 	memcpy(m->tris, idx, sizeof(uint32_t) * 3 * nt);
+	m->mats = (uint32_t*)calloc(nt, sizeof(uint32_t));
+	if (mats) memcpy(m->mats, mats, sizeof(uint32_t) * nt);
 	v3 mn = V3(3.4e38f, 3.4e38f, 3.4e38f), mx = V3(-3.4e38f, -3.4e38f, -3.4e38f); float br = 0.0f;
 	for (uint32_t k = 0; k < nv; ++k) { const v3 p = V3(verts[3 * k], verts[3 * k + 1], verts[3 * k + 2]); m->verts[k] = p; mn = v3_min(mn, p); mx = v3_max(mx, p); br = fmaxf(br, v3_len(p)); }
 	m->aabb_min = mn; m->aabb_max = mx; m->bound_radius = br;
@@ -2174,25 +2178,33 @@ SGO_API int sgo_spherecast(sgo_world* w, const sgp_ray* rays, const float* radii
 			                                                : sgo_cast_sphere_body(b->shape_type, b->shape, b->hull, b->pos, quat_to_m33(b->rot), o, d, best, radii[k], &nn, &pp);
 			if (t >= 0.0f && (t < best || bid == SGP_INVALID_ID) && t <= best) { best = t; bid = i; bn = nn; }
 		}
+		memset(&hits[k], 0, sizeof(hits[k]));
 		hits[k].id = bid; hits[k].t = bid == SGP_INVALID_ID ? 0.0f : best;
 		hits[k].normal[0] = bn.x; hits[k].normal[1] = bn.y; hits[k].normal[2] = bn.z;
+		hits[k].triangle = SGP_INVALID_ID;
 		hits[k].userdata = bid == SGP_INVALID_ID ? 0 : w->bodies[bid].userdata;
 	}
 	return SGP_OK;
 }
 
 /* Ray vs one body (traceRay, PhysicsWorld.cpp:1668-1725).  Returns t or -1. */
-static float ray_body(const sgo_body* b, v3 o, v3 d, float max_t, v3* n_out)
+typedef struct { uint32_t tri, mat; float u, v; } ray_sub;      /* which triangle of a mesh a ray hit, its user data, barycentrics */
+static float ray_body(const sgo_body* b, v3 o, v3 d, float max_t, v3* n_out, ray_sub* sub)
 {
 	const m33 R = quat_to_m33(b->rot);
 	const v3 ol = m33_tmul(R, v3_sub(o, b->pos)), dl = m33_tmul(R, d);
+	sub->tri = SGP_INVALID_ID; sub->mat = 0; sub->u = 0.0f; sub->v = 0.0f;
 	if (b->shape_type == SGP_SHAPE_MESH) {
 		/* closest front-facing triangle; on equal distance the lower triangle index wins */
 		float best = max_t; int hit = 0; v3 bn = V3(0, 0, 0);
 		for (uint32_t t = 0; t < b->mesh->nt; ++t) {
 			const v3 pa = b->mesh->verts[b->mesh->tris[3 * t]], pb = b->mesh->verts[b->mesh->tris[3 * t + 1]], pc = b->mesh->verts[b->mesh->tris[3 * t + 2]];
-			const float tt = sgo_ray_tri(ol, dl, pa, pb, pc, best);
-			if (tt >= 0.0f && (tt < best || !hit)) { best = tt; hit = 1; const v3 nn = v3_cross(v3_sub(pb, pa), v3_sub(pc, pa)); bn = v3_scale(nn, 1.0f / v3_len(nn)); }
+			float uv[2];
+			const float tt = sgo_ray_tri_uv(ol, dl, pa, pb, pc, best, uv);
+			if (tt >= 0.0f && (tt < best || !hit)) {
+				best = tt; hit = 1; const v3 nn = v3_cross(v3_sub(pb, pa), v3_sub(pc, pa)); bn = v3_scale(nn, 1.0f / v3_len(nn));
+				sub->tri = t; sub->mat = b->mesh->mats[t]; sub->u = uv[0]; sub->v = uv[1];
+			}
 		}
 		if (!hit) return -1.0f;
 		*n_out = m33_mul(R, bn);
@@ -2272,17 +2284,20 @@ SGO_API int sgo_raycast(sgo_world* w, const sgp_ray* rays, uint32_t n, sgp_hit* 
 		const v3 o = V3(rays[k].origin[0], rays[k].origin[1], rays[k].origin[2]);
 		const v3 d = V3(rays[k].dir[0], rays[k].dir[1], rays[k].dir[2]);
 		float best = rays[k].max_t; uint32_t bid = SGP_INVALID_ID; v3 bn = V3(0, 0, 0);
+		ray_sub bsub; bsub.tri = SGP_INVALID_ID; bsub.mat = 0; bsub.u = bsub.v = 0.0f;
 		for (uint32_t i = 0; i < w->high; ++i) {
 			const sgo_body* b = &w->bodies[i];
 			if (!b->alive || b->is_alias || i == rays[k].ignore_id) continue;
 			if (rays[k].collidable_only && !(b->layer == SGP_LAYER_NON_MOVING || b->layer == SGP_LAYER_MOVING)) continue;
-			v3 nn;
-			const float t = ray_body(b, o, d, best, &nn);
+			v3 nn; ray_sub sub;
+			const float t = ray_body(b, o, d, best, &nn, &sub);
 			/* closest hit; on equal t the lower body id wins (ids are visited in ascending order) */
-			if (t >= 0.0f && (t < best || bid == SGP_INVALID_ID) && t <= best) { best = t; bid = i; bn = nn; }
+			if (t >= 0.0f && (t < best || bid == SGP_INVALID_ID) && t <= best) { best = t; bid = i; bn = nn; bsub = sub; }
 		}
+		memset(&hits[k], 0, sizeof(hits[k]));
 		hits[k].id = bid; hits[k].t = bid == SGP_INVALID_ID ? 0.0f : best;
 		hits[k].normal[0] = bn.x; hits[k].normal[1] = bn.y; hits[k].normal[2] = bn.z;
+		hits[k].triangle = bsub.tri; hits[k].material = bsub.mat; hits[k].bary[0] = bsub.u; hits[k].bary[1] = bsub.v;
 		hits[k].userdata = bid == SGP_INVALID_ID ? 0 : w->bodies[bid].userdata;
 	}
 	return SGP_OK;

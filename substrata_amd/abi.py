@@ -73,7 +73,7 @@ class Ray(C.Structure):
 
 
 class Hit(C.Structure):
-    _fields_ = [("id", u32), ("t", f32), ("normal", f32 * 3), ("userdata", u64)]
+    _fields_ = [("id", u32), ("t", f32), ("normal", f32 * 3), ("triangle", u32), ("userdata", u64), ("material", u32), ("bary", f32 * 2), ("_pad", u32)]
 
 
 class StepStats(C.Structure):
@@ -224,6 +224,7 @@ PROTOTYPES = {
     "body_activate": (C.c_int, [vp, u32]),
     "body_set_layer": (C.c_int, [vp, u32, i32]),
     "body_get_volume": (C.c_int, [vp, u32, P(f32)]),
+    "body_get_userdata": (C.c_int, [vp, u32, P(u64)]),
     "body_set_pose_vel": (C.c_int, [vp, u32, P(f32), P(f32), P(f32), P(f32)]),
     "body_set_pose_shape": (C.c_int, [vp, u32, P(f32), P(f32), P(f32)]),
     "body_set_pose_vel_batch": (C.c_int, [vp, vp, vp, u32]),
@@ -259,6 +260,7 @@ PROTOTYPES = {
     "world_device_array": (C.c_int, [vp, C.c_int, P(vp), P(u32)]),
     "world_stream": (C.c_int, [vp, P(vp)]),
     "mesh_create": (C.c_int, [vp, vp, u32, vp, u32, P(MeshInfo)]),
+    "mesh_create_with_materials": (C.c_int, [vp, vp, u32, vp, u32, vp, P(MeshInfo)]),
     "hull_create": (C.c_int, [vp, vp, u32, P(HullInfo)]),
     "hull_create_com": (C.c_int, [vp, vp, u32, P(f32), P(HullInfo)]),
     "default_vehicle_desc": (None, [P(VehicleDesc)]),

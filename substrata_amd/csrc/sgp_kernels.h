@@ -209,7 +209,7 @@ struct DV {
 	uint2* hull_pairs; uint32_t cap_hull_pairs;
 	// static triangle meshes: headers + pooled vertices / triangles / tree nodes (mesh frame = body frame)
 	const struct MeshHeader* meshes; uint32_t n_meshes;
-	const float4* mesh_verts; const uint4* mesh_tris; const struct MeshNode* mesh_nodes;
+	const float4* mesh_verts; const uint4* mesh_tris; const uint32_t* mesh_tri_mat; const struct MeshNode* mesh_nodes;     // mesh_tri_mat: user data (material index) per tree-ordered triangle
 	uint2* mesh_pairs; uint32_t cap_mesh_pairs;
 	// wheeled vehicles (sgp_device_vehicle.h): AoS, one record per vehicle slot
 	struct sgd_vehicle* vehicles; uint32_t n_vehicles; const sgp_vehicle_input* vehicle_inputs;

@@ -2214,10 +2214,13 @@ __global__ void __launch_bounds__(TPB) k_dump_constraints(DV d, uint32_t which, 
 // ---------------------------------------------------------------------------------------------------------------
 // ray queries (traceRay, PhysicsWorld.cpp:1668-1725), one thread per ray, brute force over bodies with an AABB slab test
 
-SGP_DEV float ray_body(const DV& d, uint32_t type, float4 sh, v3 pos, quat q, v3 o, v3 dir, float max_t, v3* n_out)
+struct RaySub { uint32_t tri, mat; float u, v; };      // which triangle of a mesh a ray hit, its user data, barycentrics
+
+SGP_DEV float ray_body(const DV& d, uint32_t type, float4 sh, v3 pos, quat q, v3 o, v3 dir, float max_t, v3* n_out, RaySub* sub)
 {
 	const m33 R = quat_to_m33(q);
 	const v3 ol = m33_tmul(R, v3_sub(o, pos)), dl = m33_tmul(R, dir);
+	sub->tri = SGP_INVALID_ID; sub->mat = 0; sub->u = 0.0f; sub->v = 0.0f;
 	if (type == SGP_SHAPE_MESH) {
 		// closest front-facing triangle; on equal distance the lower triangle index (caller's order) wins
 		const MeshHeader mh = d.meshes[(uint32_t)sh.x];
@@ -2241,10 +2244,12 @@ SGP_DEV float ray_body(const DV& d, uint32_t type, float4 sh, v3 pos, quat q, v3
 			for (uint32_t k = 0; k < nd.count; ++k) {
 				const uint4 tri = d.mesh_tris[mh.tri_off + nd.left + k];
 				const v3 pa = V3(d.mesh_verts[mh.vert_off + tri.x]), pb = V3(d.mesh_verts[mh.vert_off + tri.y]), pc = V3(d.mesh_verts[mh.vert_off + tri.z]);
-				const float tt = sgd_ray_tri(ol, dl, pa, pb, pc, best);
+				float uv[2];
+				const float tt = sgd_ray_tri_uv(ol, dl, pa, pb, pc, best, uv);
 				if (tt >= 0.0f && (tt < best || best_idx == 0xFFFFFFFFu || (tt == best && tri.w < best_idx))) {
 					best = tt; best_idx = tri.w;
 					const v3 nn = v3_cross(v3_sub(pb, pa), v3_sub(pc, pa)); bn = v3_scale(nn, 1.0f / v3_len(nn));
+					sub->tri = tri.w; sub->mat = d.mesh_tri_mat[mh.tri_off + nd.left + k]; sub->u = uv[0]; sub->v = uv[1];
 				}
 			}
 		}
@@ -2337,7 +2342,7 @@ SGP_DEV bool ray_aabb(v3 o, v3 dir, float4 mn, float4 mx, float tmax)
 	return true;
 }
 
-struct RayBest { float t; uint32_t id; v3 n; };
+struct RayBest { float t; uint32_t id; v3 n; RaySub sub; };
 
 SGP_DEV void ray_test_body(const DV& d, const sgp_ray& ry, v3 o, v3 dir, uint32_t i, RayBest& best)
 {
@@ -2347,10 +2352,10 @@ SGP_DEV void ray_test_body(const DV& d, const sgp_ray& ry, v3 o, v3 dir, uint32_
 	const uint32_t layer = f_layer(f);
 	if (ry.collidable_only && !(layer == SGP_LAYER_NON_MOVING || layer == SGP_LAYER_MOVING)) return;
 	if (!ray_aabb(o, dir, d.aabb_min[i], d.aabb_max[i], best.t)) return;
-	v3 nn;
-	const float t = ray_body(d, f_shape(f), d.shape[i], V3(d.pos_im[i]), Q4(d.rot[i]), o, dir, best.t, &nn);
+	v3 nn; RaySub sub;
+	const float t = ray_body(d, f_shape(f), d.shape[i], V3(d.pos_im[i]), Q4(d.rot[i]), o, dir, best.t, &nn, &sub);
 	// closest hit; ties go to the lower body id so the result does not depend on the traversal order
-	if (t >= 0.0f && t <= best.t && (t < best.t || best.id == SGP_INVALID_ID || i < best.id)) { best.t = t; best.id = i; best.n = nn; }
+	if (t >= 0.0f && t <= best.t && (t < best.t || best.id == SGP_INVALID_ID || i < best.id)) { best.t = t; best.id = i; best.n = nn; best.sub = sub; }
 }
 
 // traceRay (PhysicsWorld.cpp:1668-1725), batched: one thread per ray.  Large bodies (ground quad ...) are tested directly;
@@ -2363,6 +2368,7 @@ __global__ void __launch_bounds__(64) k_raycast(DV d, const sgp_ray* rays, uint3
 	const sgp_ray ry = rays[k];
 	const v3 o = V3(ry.origin[0], ry.origin[1], ry.origin[2]), dir = V3(ry.dir[0], ry.dir[1], ry.dir[2]);
 	RayBest best; best.t = ry.max_t; best.id = SGP_INVALID_ID; best.n = V3(0.0f, 0.0f, 0.0f);
+	best.sub.tri = SGP_INVALID_ID; best.sub.mat = 0; best.sub.u = best.sub.v = 0.0f;
 	for (uint32_t l = 0; l < d.sp->n_large; ++l) ray_test_body(d, ry, o, dir, d.large_ids[l], best);
 	const BpGrid g = *d.grid;
 	if (g.n_cells > 0 && g.min_x <= g.max_x) {
@@ -2416,6 +2422,7 @@ __global__ void __launch_bounds__(64) k_raycast(DV d, const sgp_ray* rays, uint3
 	sgp_hit h;
 	h.id = best.id; h.t = best.id == SGP_INVALID_ID ? 0.0f : best.t;
 	h.normal[0] = best.n.x; h.normal[1] = best.n.y; h.normal[2] = best.n.z;
+	h.triangle = best.sub.tri; h.material = best.sub.mat; h.bary[0] = best.sub.u; h.bary[1] = best.sub.v; h._pad = 0;
 	h.userdata = 0;
 	hits[k] = h;
 }
@@ -2730,6 +2737,7 @@ __global__ void __launch_bounds__(64) k_spherecast(DV d, const sgp_ray* rays, co
 	sgp_hit h;
 	h.id = best.id; h.t = best.id == SGP_INVALID_ID ? 0.0f : best.t;
 	h.normal[0] = best.n.x; h.normal[1] = best.n.y; h.normal[2] = best.n.z;
+	h.triangle = SGP_INVALID_ID; h.material = 0; h.bary[0] = h.bary[1] = 0.0f; h._pad = 0;
 	h.userdata = 0;
 	hits[k] = h;
 }

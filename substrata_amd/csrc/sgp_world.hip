@@ -88,9 +88,9 @@ struct sgp_world {
 	uint32_t graph_launches = 0, eager_steps = 0, idle_steps = 0;
 	bool grid_valid = false;                                   // the broad-phase grid matches the current poses (ray queries reuse it)
 	// static triangle meshes: host-side headers + pools mirrored on the device (grown on demand)
-	std::vector<MeshHeader> meshes; std::vector<float4> mesh_verts; std::vector<uint4> mesh_tris; std::vector<MeshNode> mesh_nodes;
-	MeshHeader* d_meshes = nullptr; float4* d_mesh_verts = nullptr; uint4* d_mesh_tris = nullptr; MeshNode* d_mesh_nodes = nullptr;
-	size_t cap_mesh_verts = 0, cap_mesh_tris = 0, cap_mesh_nodes = 0;
+	std::vector<MeshHeader> meshes; std::vector<float4> mesh_verts; std::vector<uint4> mesh_tris; std::vector<uint32_t> mesh_tri_mat; std::vector<MeshNode> mesh_nodes;
+	MeshHeader* d_meshes = nullptr; float4* d_mesh_verts = nullptr; uint4* d_mesh_tris = nullptr; uint32_t* d_mesh_tri_mat = nullptr; MeshNode* d_mesh_nodes = nullptr;
+	size_t cap_mesh_verts = 0, cap_mesh_tris = 0, cap_mesh_tri_mat = 0, cap_mesh_nodes = 0;
 	// convex hull shapes: host copies of the device table (mass properties, radii) -- hull 0 is the +-1 cube template
 	std::vector<sgd_hull> hulls; sgd_hull* d_hulls = nullptr;
 	// wheeled vehicles: device records (AoS) + host mirror of what the ABI needs without a read-back
@@ -320,6 +320,7 @@ SGP_API int sgp_world_destroy(sgp_world* w)
 	if (w->stage_dev) hipFree(w->stage_dev);
 	if (w->d_mesh_verts) hipFree(w->d_mesh_verts);
 	if (w->d_mesh_tris) hipFree(w->d_mesh_tris);
+	if (w->d_mesh_tri_mat) hipFree(w->d_mesh_tri_mat);
 	if (w->d_mesh_nodes) hipFree(w->d_mesh_nodes);
 	if (w->d_vehicles) hipFree(w->d_vehicles);
 	if (w->d_veh_inputs) hipFree(w->d_veh_inputs);
@@ -519,6 +520,14 @@ SGP_API int sgp_body_get_volume(sgp_world* w, uint32_t id, float* volume_out)
 {
 	if (!live(w, id) || !volume_out) return fail(SGP_ERR_BAD_ID, "sgp_body_get_volume: id not live");
 	*volume_out = w->hb[id].volume;
+	return SGP_OK;
+}
+SGP_API int sgp_body_get_userdata(sgp_world* w, uint32_t id, uint64_t* userdata_out)
+{
+	if (!live(w, id) || !userdata_out) return fail(SGP_ERR_BAD_ID, "sgp_body_get_userdata: id not live");
+	uint32_t b = id;
+	while (b > 0 && (w->hb[b].flags & BF_ALIAS)) --b;          // an alias slot reports as the body it belongs to
+	*userdata_out = w->hb[b].userdata;
 	return SGP_OK;
 }
 SGP_API int sgp_body_set_layer(sgp_world* w, uint32_t id, int32_t layer)
@@ -1152,7 +1161,12 @@ static uint32_t build_mesh_node(std::vector<MeshNode>& nodes, size_t node_base, 
 	return me;
 }
 
+SGP_API int sgp_mesh_create_with_materials(sgp_world* w, const float* verts, uint32_t nv, const uint32_t* idx, uint32_t nt, const uint32_t* tri_mats, sgp_mesh_info* info);
 SGP_API int sgp_mesh_create(sgp_world* w, const float* verts, uint32_t nv, const uint32_t* idx, uint32_t nt, sgp_mesh_info* info)
+{
+	return sgp_mesh_create_with_materials(w, verts, nv, idx, nt, nullptr, info);
+}
+SGP_API int sgp_mesh_create_with_materials(sgp_world* w, const float* verts, uint32_t nv, const uint32_t* idx, uint32_t nt, const uint32_t* tri_mats, sgp_mesh_info* info)
 {
 	if (!w || !verts || !idx || !info || nv < 3 || nt < 1) return fail(SGP_ERR_INVALID, "sgp_mesh_create: bad arguments");
 	if (w->meshes.size() >= SGP_MAX_MESHES) return fail(SGP_ERR_CAPACITY, "sgp_mesh_create: mesh table full");
@@ -1178,19 +1192,21 @@ SGP_API int sgp_mesh_create(sgp_world* w, const float* verts, uint32_t nv, const
 	}
 	build_mesh_node(w->mesh_nodes, mh.node_off, order, cen, tmin, tmax, 0, nt);
 	mh.n_nodes = (uint32_t)(w->mesh_nodes.size() - mh.node_off);
-	for (uint32_t k = 0; k < nt; ++k) { const uint32_t t = order[k]; w->mesh_tris.push_back(make_uint4(idx[3 * t], idx[3 * t + 1], idx[3 * t + 2], t)); }
+	for (uint32_t k = 0; k < nt; ++k) { const uint32_t t = order[k]; w->mesh_tris.push_back(make_uint4(idx[3 * t], idx[3 * t + 1], idx[3 * t + 2], t)); w->mesh_tri_mat.push_back(tri_mats ? tri_mats[t] : 0u); }
 	// upload (pools may move: captured graphs carry the old pointers)
 	{ int r = grow_pool(w, w->d_mesh_verts, w->cap_mesh_verts, w->mesh_verts.size(), mh.vert_off); if (r != SGP_OK) return r; }
 	{ int r = grow_pool(w, w->d_mesh_tris, w->cap_mesh_tris, w->mesh_tris.size(), mh.tri_off); if (r != SGP_OK) return r; }
+	{ int r = grow_pool(w, w->d_mesh_tri_mat, w->cap_mesh_tri_mat, w->mesh_tri_mat.size(), mh.tri_off); if (r != SGP_OK) return r; }
 	{ int r = grow_pool(w, w->d_mesh_nodes, w->cap_mesh_nodes, w->mesh_nodes.size(), mh.node_off); if (r != SGP_OK) return r; }
 	HIP_TRY(hipMemcpyAsync(w->d_mesh_verts + mh.vert_off, w->mesh_verts.data() + mh.vert_off, sizeof(float4) * nv, hipMemcpyHostToDevice, w->stream));
 	HIP_TRY(hipMemcpyAsync(w->d_mesh_tris + mh.tri_off, w->mesh_tris.data() + mh.tri_off, sizeof(uint4) * nt, hipMemcpyHostToDevice, w->stream));
+	HIP_TRY(hipMemcpyAsync(w->d_mesh_tri_mat + mh.tri_off, w->mesh_tri_mat.data() + mh.tri_off, sizeof(uint32_t) * nt, hipMemcpyHostToDevice, w->stream));
 	HIP_TRY(hipMemcpyAsync(w->d_mesh_nodes + mh.node_off, w->mesh_nodes.data() + mh.node_off, sizeof(MeshNode) * mh.n_nodes, hipMemcpyHostToDevice, w->stream));
 	const uint32_t id = (uint32_t)w->meshes.size();
 	w->meshes.push_back(mh);
 	HIP_TRY(hipMemcpyAsync(&w->d_meshes[id], &w->meshes[id], sizeof(MeshHeader), hipMemcpyHostToDevice, w->stream));
 	HIP_TRY(hipStreamSynchronize(w->stream));
-	w->dv.mesh_verts = w->d_mesh_verts; w->dv.mesh_tris = w->d_mesh_tris; w->dv.mesh_nodes = w->d_mesh_nodes; w->dv.n_meshes = (uint32_t)w->meshes.size();
+	w->dv.mesh_verts = w->d_mesh_verts; w->dv.mesh_tris = w->d_mesh_tris; w->dv.mesh_tri_mat = w->d_mesh_tri_mat; w->dv.mesh_nodes = w->d_mesh_nodes; w->dv.n_meshes = (uint32_t)w->meshes.size();
 	invalidate_graphs(w);
 	memset(info, 0, sizeof(*info));
 	info->mesh_id = id; info->num_vertices = nv; info->num_triangles = nt; info->num_nodes = mh.n_nodes;

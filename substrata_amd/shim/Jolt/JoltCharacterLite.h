@@ -22,7 +22,6 @@
 namespace JPH
 {
 	typedef Vec3 Vec3Arg; typedef Vec3 RVec3Arg; typedef Quat QuatArg;
-	class SubShapeID { public: uint32_t GetValue() const { return 0; } };
 	class PhysicsMaterial {};
 	class TempAllocator {};
 	class BodyFilter { public: virtual ~BodyFilter() {} virtual uint32_t ignored() const { return 0xFFFFFFFFu; } };

@@ -4,8 +4,7 @@
 //   PhysicsSystem::AddConstraint(VehicleConstraint*)                                  -> sgp_vehicle_create
 //   WheeledVehicleController::SetDriverInput                                          -> sgp_vehicle_set_input
 //   Wheel getters, VehicleEngine::GetCurrentRPM                                       -> sgp_vehicle_get_state (one read-back per step)
-// Differences a maintainer must know: the chassis is an existing box / sphere / capsule body (no
-// ConvexHullShape / OffsetCenterOfMassShape yet); VehicleCollisionTesterCastCylinder is served by the sphere cast.
+// Differences a maintainer must know: VehicleCollisionTesterCastCylinder is served by the sphere cast.
 #pragma once
 #include "JoltLite.h"
 #include "../../../include/sgp.h"
@@ -19,23 +18,6 @@ namespace JPH
 	static const float JPH_PI = 3.14159265358979323846f;
 	inline float DegreesToRadians(float d) { return d * (JPH_PI / 180.0f); }
 
-	// intrusive-pointer stand-in (JPH::Ref): shared ownership is all CarPhysics relies on
-	template <class T> class Ref
-	{
-	public:
-		Ref() {}
-		Ref(T* p) : ptr(p) {}
-		template <class U> Ref(const Ref<U>& o) : ptr(o.shared()) {}
-		T* operator->() const { return ptr.get(); }
-		T& operator*() const { return *ptr; }
-		T* GetPtr() const { return ptr.get(); }
-		operator T*() const { return ptr.get(); }
-		Ref& operator=(T* p) { ptr.reset(p); return *this; }
-		const std::shared_ptr<T>& shared() const { return ptr; }
-	private:
-		std::shared_ptr<T> ptr;
-	};
-
 	class LinearCurve
 	{
 	public:
@@ -46,10 +28,9 @@ namespace JPH
 
 	struct SpringSettings { float mFrequency = 1.5f, mDamping = 0.5f; };
 
-	class WheelSettings
+	class WheelSettings : public RefTargetBase
 	{
 	public:
-		virtual ~WheelSettings() {}
 		Vec3 mPosition = Vec3(0, 0, 0);
 		Vec3 mSuspensionDirection = Vec3(0, -1, 0), mSteeringAxis = Vec3(0, 1, 0), mWheelUp = Vec3(0, 1, 0), mWheelForward = Vec3(0, 0, 1);
 		float mSuspensionMinLength = 0.3f, mSuspensionMaxLength = 0.5f, mSuspensionPreloadLength = 0.0f;
@@ -93,7 +74,7 @@ namespace JPH
 	};
 	class VehicleAntiRollBar { public: int mLeftWheel = 0, mRightWheel = 1; float mStiffness = 1000.0f; };
 
-	class VehicleControllerSettings { public: virtual ~VehicleControllerSettings() {} };
+	class VehicleControllerSettings : public RefTargetBase {};
 	class WheeledVehicleControllerSettings : public VehicleControllerSettings
 	{
 	public:
@@ -119,7 +100,7 @@ namespace JPH
 		Ref<VehicleControllerSettings> mController;
 	};
 
-	class VehicleCollisionTester { public: virtual ~VehicleCollisionTester() {} virtual float castRadius(float /*wheel_width*/) const { return 0.0f; } };
+	class VehicleCollisionTester : public RefTargetBase { public: virtual float castRadius(float /*wheel_width*/) const { return 0.0f; } };
 	class VehicleCollisionTesterRay : public VehicleCollisionTester
 	{
 	public:
@@ -203,7 +184,7 @@ namespace JPH
 	};
 
 	// Bound to a world by PhysicsSystem::AddConstraint (CarPhysics.cpp:224-226).
-	class VehicleConstraint
+	class VehicleConstraint : public RefTargetBase, public PhysicsStepListener
 	{
 	public:
 		VehicleConstraint(const Body& body, const VehicleConstraintSettings& s) : body_id(body.GetID()), settings(s),
@@ -241,6 +222,9 @@ namespace JPH
 			m.c[3] = ws->mPosition + ws->mSuspensionDirection * w->GetSuspensionLength();
 			return m;
 		}
+		// Jolt: VehicleConstraint::GetWheelWorldTransform = body world transform (shape space -> world) * GetWheelLocalTransform
+		// (CarPhysics.cpp:405-470 keeps this variant commented next to the local one; BikePhysics uses the same pair).
+		Mat44 GetWheelWorldTransform(uint i, const Vec3& wheel_right, const Vec3& wheel_up) const;
 		BodyID GetVehicleBodyID() const { return body_id; }
 		uint32_t GetVehicleID() const { return vehicle_id; }
 
@@ -313,6 +297,18 @@ namespace JPH
 		friend class Wheel; friend class VehicleEngine; friend class WheeledVehicleController; friend class MotorcycleController;
 	};
 
+	inline Mat44 VehicleConstraint::GetWheelWorldTransform(uint i, const Vec3& wheel_right, const Vec3& wheel_up) const
+	{
+		const Mat44 local = GetWheelLocalTransform(i, wheel_right, wheel_up);
+		if (!world) return local;
+		// chassis pose of the BODY frame -> pose of the shape space the wheel settings are expressed in
+		sgp_body_state st; const uint32_t id = body_id.GetIndex();
+		if (sgp_body_get_state(world, &id, 1, &st) != SGP_OK) return local;
+		const Quat qb(st.rot[0], st.rot[1], st.rot[2], st.rot[3]);
+		const Quat q = qb * frame_rot.Conjugated();
+		const Vec3 t = Vec3(st.pos[0], st.pos[1], st.pos[2]) - q * frame_com;
+		return Mat44::sRotationTranslation(q, t) * local;
+	}
 	inline const sgp_wheel_state& Wheel::st() const { return owner->state().wheels[index]; }
 	inline void Wheel::SetAngularVelocity(float w) { if (owner->world) { sgp_vehicle_reset_drivetrain(owner->world, owner->GetVehicleID(), owner->state().engine_rpm, w); owner->cached_serial = ~0ull; } }
 	inline float VehicleEngine::GetCurrentRPM() const { return owner->state().engine_rpm; }

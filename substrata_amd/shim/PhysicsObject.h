@@ -38,6 +38,7 @@ struct PhysicsMeshData
 	struct Instance { sgp_world* world; float scale[3]; uint32_t mesh_id; };
 	std::vector<float> vertices;        // xyz, object space, unscaled
 	std::vector<uint32_t> indices;      // 3 per triangle, counter-clockwise = front
+	std::vector<uint32_t> materials;    // per triangle: the material index a ray hit reports (JPH::IndexedTriangle::mMaterialIndex, PhysicsWorld.cpp:1032-1060); empty = all 0
 	std::vector<Instance> instances;
 };
 

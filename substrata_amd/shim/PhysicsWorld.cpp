@@ -61,15 +61,25 @@ PhysicsShape PhysicsWorld::createConvexHullShape(const std::vector<Vec3f>& point
 	return s;
 }
 
-PhysicsShape PhysicsWorld::createMeshShape(const std::vector<Vec3f>& vertices, const std::vector<uint32>& triangle_indices)
+PhysicsShape PhysicsWorld::createMeshShape(const std::vector<Vec3f>& vertices, const std::vector<uint32>& triangle_indices,
+	const std::vector<uint32>* triangle_materials, const std::vector<bool>* create_tris_for_mat)
 {
 	if (vertices.size() < 3 || triangle_indices.size() < 3 || triangle_indices.size() % 3 != 0) throw glare::Exception("Error building Jolt shape: a mesh needs vertices and whole triangles");
 	for (size_t i = 0; i < triangle_indices.size(); ++i) if (triangle_indices[i] >= vertices.size()) throw glare::Exception("Error building Jolt shape: triangle index out of range");
+	const size_t num_tris = triangle_indices.size() / 3;
+	if (triangle_materials && triangle_materials->size() != num_tris) throw glare::Exception("Error building Jolt shape: one material index per triangle expected");
 	PhysicsShape s; s.kind = 4;
 	s.mesh = std::make_shared<PhysicsMeshData>();
 	for (size_t i = 0; i < vertices.size(); ++i) { s.mesh->vertices.push_back(vertices[i].x); s.mesh->vertices.push_back(vertices[i].y); s.mesh->vertices.push_back(vertices[i].z); }
-	s.mesh->indices.assign(triangle_indices.begin(), triangle_indices.end());
-	s.size_B = sizeof(PhysicsShape) + s.mesh->vertices.size() * sizeof(float) + s.mesh->indices.size() * sizeof(uint32_t);
+	for (size_t t = 0; t < num_tris; ++t) {
+		const uint32 mat = triangle_materials ? (*triangle_materials)[t] : 0;
+		// PhysicsWorld.cpp:1028: if(!create_tris_for_mat || (material_index >= create_tris_for_mat->size()) || (*create_tris_for_mat)[material_index])
+		if (create_tris_for_mat && mat < create_tris_for_mat->size() && !(*create_tris_for_mat)[mat]) continue;
+		for (int k = 0; k < 3; ++k) s.mesh->indices.push_back(triangle_indices[3 * t + k]);
+		if (triangle_materials) s.mesh->materials.push_back(mat);
+	}
+	if (s.mesh->indices.empty()) throw glare::Exception("Error building Jolt shape: no triangles left after the material filter");
+	s.size_B = sizeof(PhysicsShape) + s.mesh->vertices.size() * sizeof(float) + (s.mesh->indices.size() + s.mesh->materials.size()) * sizeof(uint32_t);
 	return s;
 }
 
@@ -100,7 +110,8 @@ static const PhysicsMeshData::Instance* meshInstance(sgp_world* world, const Phy
 	std::vector<uint32_t> idx(m.indices);
 	if (scale.x * scale.y * scale.z < 0.f) for (size_t i = 0; i + 2 < idx.size(); i += 3) std::swap(idx[i + 1], idx[i + 2]);      // a mirroring scale turns the triangles inside out
 	sgp_mesh_info info;
-	if (sgp_mesh_create(world, v.data(), (uint32_t)(v.size() / 3), idx.data(), (uint32_t)(idx.size() / 3), &info) != SGP_OK) return nullptr;
+	if (sgp_mesh_create_with_materials(world, v.data(), (uint32_t)(v.size() / 3), idx.data(), (uint32_t)(idx.size() / 3),
+		m.materials.size() == idx.size() / 3 ? m.materials.data() : nullptr, &info) != SGP_OK) return nullptr;
 	PhysicsMeshData::Instance in; in.world = world; in.scale[0] = scale.x; in.scale[1] = scale.y; in.scale[2] = scale.z; in.mesh_id = info.mesh_id;
 	m.instances.push_back(in);
 	return &m.instances.back();
@@ -124,6 +135,7 @@ PhysicsShape PhysicsWorld::createScaledAndTranslatedShapeForShape(const PhysicsS
 		s.mesh->vertices = original_shape.mesh->vertices;
 		for (size_t i = 0; i < s.mesh->vertices.size(); ++i) s.mesh->vertices[i] = tr[i % 3] + sc[i % 3] * s.mesh->vertices[i];
 		s.mesh->indices = original_shape.mesh->indices;
+		s.mesh->materials = original_shape.mesh->materials;
 		if (scale.x * scale.y * scale.z < 0.f) for (size_t i = 0; i + 2 < s.mesh->indices.size(); i += 3) std::swap(s.mesh->indices[i + 1], s.mesh->indices[i + 2]);
 	} else throw glare::Exception("Error building Jolt shape: scale / translate decorators are implemented for convex hull and mesh shapes");
 	return s;
@@ -180,7 +192,15 @@ static inline void toObjectPose(const PhysicsObject& ob, const float body_pos[3]
 void PhysicsWorld::addObject(const Reference<PhysicsObject>& object)
 {
 	assert(object->pos.isFinite());
-	if (!object->jolt_body_id.IsInvalid()) return;    // body already built (:1175)
+	if (!object->jolt_body_id.IsInvalid()) {          // body already built (:1175), e.g. by CarPhysics through BodyInterface::CreateBody
+		if (const JPH::BodyInterface::Frame* f = physics_system->GetBodyInterface().getFrame(object->jolt_body_id)) {
+			object->body_com_os = Vec4f(f->com.x, f->com.y, f->com.z, 0.f);
+			object->body_rot_os = Quatf(f->rot.x, f->rot.y, f->rot.z, f->rot.w);
+		}
+		const uint32_t bid = object->jolt_body_id.GetIndex();
+		if (bid < id_to_ob.size()) id_to_ob[bid] = object.ptr();
+		return;
+	}
 	sgp_body_desc d;
 	sgp_default_body_desc(&d);
 	for (int i = 0; i < 3; ++i) d.pos[i] = object->pos[i];
@@ -233,6 +253,10 @@ void PhysicsWorld::addObject(const Reference<PhysicsObject>& object)
 	if (sgp_body_add(world, &d, &id) != SGP_OK) return;      // silent rejection, as the reference (:1178-1189)
 	object->jolt_body_id = JPH::BodyID(id);
 	if (id < id_to_ob.size()) id_to_ob[id] = object.ptr();
+	// the look-alike BodyInterface answers in the shape's space: it needs the body frame of hull bodies
+	if (object->shape.kind == 3 && !object->is_sphere && !object->is_cube)
+		physics_system->GetBodyInterface().setFrame(object->jolt_body_id, JPH::Vec3(object->body_com_os[0], object->body_com_os[1], object->body_com_os[2]),
+			JPH::Quat(object->body_rot_os.v[0], object->body_rot_os.v[1], object->body_rot_os.v[2], object->body_rot_os.v[3]));
 }
 
 JPH::Body PhysicsWorld::getJoltBody(const PhysicsObject& object) const
@@ -249,7 +273,9 @@ void PhysicsWorld::removeObject(const Reference<PhysicsObject>& object)
 {
 	if (!object->jolt_body_id.IsInvalid()) {
 		const uint32_t id = object->jolt_body_id.GetIndex();
-		sgp_body_remove(world, id);
+		if (physics_system->GetBodyInterface().IsAdded(object->jolt_body_id)) { physics_system->GetBodyInterface().RemoveBody(object->jolt_body_id); physics_system->GetBodyInterface().DestroyBody(object->jolt_body_id); }
+		else sgp_body_remove(world, id);
+		physics_system->GetBodyInterface().clearFrame(object->jolt_body_id);
 		if (id < id_to_ob.size()) id_to_ob[id] = NULL;
 		object->jolt_body_id = JPH::BodyID();
 	}
@@ -357,8 +383,20 @@ void PhysicsWorld::readBackActivatedObjectTransforms()
 void PhysicsWorld::setNewObToWorldTransform(PhysicsObject& object, const Vec4f& translation, const Quatf& rot_quat, const Vec4f& scale)
 {
 	assert(translation.isFinite());
+	const Vec3f old_scale = object.scale;
 	object.pos = translation; object.rot = rot_quat; object.scale = Vec3f(scale);
 	if (object.jolt_body_id.IsInvalid()) return;
+	if (!object.is_sphere && !object.is_cube && (object.shape.kind == 3 || object.shape.kind == 4) &&
+		(old_scale.x != object.scale.x || old_scale.y != object.scale.y || old_scale.z != object.scale.z)) {
+		// JPH::ScaledShape swap (:562-601): hulls and meshes carry their scale baked into the device-side shape, so a new scale means the
+		// shape instance of that scale (built on first use) and a body made from it; like the reference the body ends up activated with
+		// zero velocity.  The PhysicsObject keeps its identity (userdata), only its body id changes.
+		Reference<PhysicsObject> ref(&object);
+		removeObject(ref);
+		addObject(ref);
+		if (!object.jolt_body_id.IsInvalid()) { sgp_body_activate(world, object.jolt_body_id.GetIndex()); drainActivationEvents(); }
+		return;
+	}
 	float shape[4] = { 0, 0, 0, 0 };
 	if (object.is_sphere) shape[0] = 0.5f * std::fabs(scale[0]);                       // sphere forced to uniform scale (:571-572)
 	else if (object.is_cube) { shape[0] = 0.5f * std::fabs(scale[0]); shape[1] = 0.5f * std::fabs(scale[1]); shape[2] = 0.5f * std::fabs(scale[2]); }
@@ -528,7 +566,7 @@ static void doTraceRay(sgp_world* world, const Vec4f& origin, const Vec4f& dir, 
 		results_out.coords = Vec2f(0.f);
 		results_out.hit_t = h.t;
 		results_out.hit_normal_ws = Vec4f(h.normal[0], h.normal[1], h.normal[2], 0.f);
-		results_out.hit_mat_index = 0;
+		results_out.hit_mat_index = h.material;                                 // mesh_shape->GetTriangleUserData(...) for mesh shapes, else 0 (:1698-1704)
 	}
 }
 void PhysicsWorld::traceRay(const Vec4f& origin, const Vec4f& dir, float max_t, JPH::BodyID ignore_body_id, RayTraceResult& results_out) const
@@ -554,7 +592,7 @@ void PhysicsWorld::traceRays(const std::vector<RayQuery>& rays, std::vector<RayT
 		r.coords = Vec2f(0.f);
 		r.hit_t = hs[k].t;
 		r.hit_normal_ws = Vec4f(hs[k].normal[0], hs[k].normal[1], hs[k].normal[2], 0.f);
-		r.hit_mat_index = 0;
+		r.hit_mat_index = hs[k].material;
 	}
 }
 bool PhysicsWorld::doesRayHitAnything(const Vec4f& origin, const Vec4f& dir, float max_t) const
@@ -586,9 +624,23 @@ void JPH::BodyInterface::ActivateBody(const BodyID& id) { if (!id.IsInvalid()) {
 void JPH::BodyInterface::AddForce(const BodyID& id, const Vec3& f) { if (!id.IsInvalid()) sgp_body_add_force(world, id.GetIndex(), &f.x); }
 void JPH::BodyInterface::AddForce(const BodyID& id, const Vec3& f, const RVec3& p) { if (!id.IsInvalid()) sgp_body_add_force_at(world, id.GetIndex(), &f.x, &p.x); }
 void JPH::BodyInterface::AddTorque(const BodyID& id, const Vec3& t) { if (!id.IsInvalid()) sgp_body_add_torque(world, id.GetIndex(), &t.x); }
-JPH::RVec3 JPH::BodyInterface::GetPosition(const BodyID& id) const { fetch(id); return RVec3(st_pos[0], st_pos[1], st_pos[2]); }
-JPH::RVec3 JPH::BodyInterface::GetCenterOfMassPosition(const BodyID& id) const { return GetPosition(id); }   // primitives: COM = shape origin
-JPH::Quat JPH::BodyInterface::GetRotation(const BodyID& id) const { fetch(id); return Quat(st_rot[0], st_rot[1], st_rot[2], st_rot[3]); }
+// Position / rotation of the SHAPE's origin and axes, like Jolt: a hull body is simulated in its centre-of-mass / principal-axes frame
+// (frames), so  rot_shape = rot_body * frame.rot^-1,  pos_shape = pos_body - rot_shape * frame.com.
+JPH::Quat JPH::BodyInterface::GetRotation(const BodyID& id) const
+{
+	fetch(id);
+	const Quat qb(st_rot[0], st_rot[1], st_rot[2], st_rot[3]);
+	const Frame* f = getFrame(id);
+	return f ? qb * f->rot.Conjugated() : qb;
+}
+JPH::RVec3 JPH::BodyInterface::GetPosition(const BodyID& id) const
+{
+	fetch(id);
+	const RVec3 pb(st_pos[0], st_pos[1], st_pos[2]);
+	const Frame* f = getFrame(id);
+	return f ? pb - GetRotation(id) * f->com : pb;
+}
+JPH::RVec3 JPH::BodyInterface::GetCenterOfMassPosition(const BodyID& id) const { fetch(id); return RVec3(st_pos[0], st_pos[1], st_pos[2]); }   // the body frame's origin IS the centre of mass
 void JPH::BodyInterface::GetPositionAndRotation(const BodyID& id, RVec3& p, Quat& r) const { p = GetPosition(id); r = GetRotation(id); }
 JPH::Mat44 JPH::BodyInterface::GetWorldTransform(const BodyID& id) const
 {
@@ -609,6 +661,68 @@ JPH::Vec3 JPH::BodyInterface::GetPointVelocity(const BodyID& id, const RVec3& p)
 void JPH::BodyInterface::SetLinearAndAngularVelocity(const BodyID& id, const Vec3& l, const Vec3& a) { if (!id.IsInvalid()) { sgp_body_set_vel(world, id.GetIndex(), &l.x, &a.x); invalidate(); } }
 bool JPH::BodyInterface::IsActive(const BodyID& id) const { fetch(id); return st_active; }
 
+void JPH::BodyInterface::setFrame(const BodyID& id, const Vec3& com, const Quat& rot) { Frame f; f.com = com; f.rot = rot; frames[id.GetIndex()] = f; }
+void JPH::BodyInterface::clearFrame(const BodyID& id) { frames.erase(id.GetIndex()); }
+const JPH::BodyInterface::Frame* JPH::BodyInterface::getFrame(const BodyID& id) const { auto it = frames.find(id.GetIndex()); return it == frames.end() ? nullptr : &it->second; }
+JPH::BodyInterface::~BodyInterface() { for (auto& kv : bodies) delete kv.second; }
+
+// CarPhysics.cpp:80-90 / BikePhysics.cpp:107-121
+JPH::Body* JPH::BodyInterface::CreateBody(const BodyCreationSettings& s)
+{
+	const Shape* shape = s.GetShape();
+	if (!shape || shape->kind < 0) return nullptr;
+	sgp_body_desc d;
+	sgp_default_body_desc(&d);
+	d.shape_type = shape->kind;
+	Vec3 com(0, 0, 0); Quat frot(0, 0, 0, 1);
+	if (shape->kind == 3) {
+		sgp_hull_info info;
+		if (sgp_hull_create_com(world, shape->hull_points.data(), (uint32_t)(shape->hull_points.size() / 3), shape->com_offset, &info) != SGP_OK) return nullptr;
+		d.shape[0] = (float)info.hull_id;
+		com = Vec3(info.com[0], info.com[1], info.com[2]); frot = Quat(info.rot[0], info.rot[1], info.rot[2], info.rot[3]);
+	} else { d.shape[0] = shape->p[0]; d.shape[1] = shape->p[1]; d.shape[2] = shape->p[2]; }
+	const Vec3 pb = s.mPosition + s.mRotation * com;
+	const Quat qb = s.mRotation * frot;
+	d.pos[0] = pb.x; d.pos[1] = pb.y; d.pos[2] = pb.z;
+	d.rot[0] = qb.x; d.rot[1] = qb.y; d.rot[2] = qb.z; d.rot[3] = qb.w;
+	d.lin_vel[0] = s.mLinearVelocity.x; d.lin_vel[1] = s.mLinearVelocity.y; d.lin_vel[2] = s.mLinearVelocity.z;
+	d.ang_vel[0] = s.mAngularVelocity.x; d.ang_vel[1] = s.mAngularVelocity.y; d.ang_vel[2] = s.mAngularVelocity.z;
+	d.motion_type = s.mMotionType == EMotionType::Dynamic ? SGP_MOTION_DYNAMIC : (s.mMotionType == EMotionType::Kinematic ? SGP_MOTION_KINEMATIC : SGP_MOTION_STATIC);
+	d.layer = (int32_t)s.mObjectLayer;
+	d.is_sensor = s.mIsSensor ? 1 : 0; d.allow_sleeping = s.mAllowSleeping ? 1 : 0;
+	d.friction = s.mFriction; d.restitution = s.mRestitution; d.linear_damping = s.mLinearDamping; d.angular_damping = s.mAngularDamping; d.gravity_factor = s.mGravityFactor;
+	// EOverrideMassProperties::CalculateInertia: the given mass, inertia from the shape (the only mode the callers use; without an override
+	// Jolt derives the mass from the shape's volume at density 1000)
+	if (s.mOverrideMassProperties != EOverrideMassProperties::CalculateMassAndInertia && s.mMassPropertiesOverride.mMass > 0.0f) d.mass = s.mMassPropertiesOverride.mMass;
+	else if (shape->kind != 3) d.mass = 1000.0f * shape->volume;
+	d.userdata = s.mUserData;
+	d.activate = 0;
+	uint32_t id = SGP_INVALID_ID;
+	if (sgp_body_add(world, &d, &id) != SGP_OK || id == SGP_INVALID_ID) return nullptr;
+	Body* b = new Body;
+	b->id = BodyID(id); b->user_data = s.mUserData; b->is_sensor = s.mIsSensor;
+	b->shape.kind = shape->kind; b->shape.p[0] = shape->p[0]; b->shape.p[1] = shape->p[1]; b->shape.p[2] = shape->p[2];
+	float vol = shape->volume; sgp_body_get_volume(world, id, &vol); b->shape.volume = vol;
+	b->com_offset = com; b->frame_rot[0] = frot.x; b->frame_rot[1] = frot.y; b->frame_rot[2] = frot.z; b->frame_rot[3] = frot.w;
+	bodies[id] = b;
+	if (shape->kind == 3) setFrame(b->id, com, frot);
+	invalidate();
+	return b;
+}
+void JPH::BodyInterface::AddBody(const BodyID& id, EActivation activation)
+{
+	if (id.IsInvalid()) return;
+	if (activation == EActivation::Activate) sgp_body_activate(world, id.GetIndex());
+	invalidate();
+}
+void JPH::BodyInterface::RemoveBody(const BodyID& id) { if (!id.IsInvalid()) { sgp_body_remove(world, id.GetIndex()); invalidate(); } }
+void JPH::BodyInterface::DestroyBody(const BodyID& id)
+{
+	auto it = bodies.find(id.GetIndex());
+	if (it != bodies.end()) { delete it->second; bodies.erase(it); }
+	clearFrame(id);
+}
+
 
 // ---- JPH::PhysicsSystem constraint registration (vehicles) -----------------------------------------------------------
 void JPH::PhysicsSystem::AddConstraint(VehicleConstraint* c)
@@ -627,13 +741,16 @@ void JPH::PhysicsSystem::RemoveConstraint(VehicleConstraint* c)
 	c->unbind();
 }
 
-JPH::Body* JPH::BodyLockInterface::TryGetBody(const BodyID& id) const
+bool JPH::BodyLockInterface::fill(const BodyID& id, Body& out) const
 {
 	float vol = 0.f;
-	if (id.IsInvalid() || sgp_body_get_volume(world, id.GetIndex(), &vol) != SGP_OK) return nullptr;
+	if (id.IsInvalid() || sgp_body_get_volume(world, id.GetIndex(), &vol) != SGP_OK) return false;
 	sgp_body_state st;
 	const uint32_t i = id.GetIndex();
-	if (sgp_body_get_state(world, &i, 1, &st) != SGP_OK) return nullptr;
-	scratch.id = id; scratch.shape.volume = vol; scratch.lin_vel = Vec3(st.lin_vel[0], st.lin_vel[1], st.lin_vel[2]);
-	return &scratch;
+	if (sgp_body_get_state(world, &i, 1, &st) != SGP_OK) return false;
+	uint64_t ud = 0; sgp_body_get_userdata(world, i, &ud);
+	out.id = id; out.shape.volume = vol; out.lin_vel = Vec3(st.lin_vel[0], st.lin_vel[1], st.lin_vel[2]); out.user_data = ud;
+	return true;
 }
+JPH::Body* JPH::BodyLockInterface::TryGetBody(const BodyID& id) const { return fill(id, scratch) ? &scratch : nullptr; }
+JPH::BodyLockRead::BodyLockRead(const BodyLockInterface& iface, const BodyID& id) : ok(iface.fill(id, body)) {}

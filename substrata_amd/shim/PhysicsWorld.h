@@ -83,7 +83,12 @@ public:
 	static PhysicsShape createConvexHullShape(const std::vector<Vec3f>& points);
 	// The triangle mesh createJoltShapeForIndigoMesh / createJoltShapeForBatchedMesh build for a static object (PhysicsWorld.cpp:735-1017:
 	// JPH::MeshShapeSettings over the mesh's vertices and triangles); takes the arrays because the mesh containers are glare-core types.
-	static PhysicsShape createMeshShape(const std::vector<Vec3f>& vertices, const std::vector<uint32>& triangle_indices);
+	// triangle_materials (optional, one per triangle): the material index of the triangle's batch, returned as RayTraceResult::hit_mat_index
+	// (PhysicsWorld.cpp:1032-1060,1700-1704).  create_tris_for_mat (optional): "should physics triangles be created for this material?" --
+	// triangles of a material whose entry is false are left out (PhysicsWorld.h:124-125, .cpp:1028; MeshBuilding.cpp:392-393); materials
+	// beyond the vector's size are kept, like the reference.
+	static PhysicsShape createMeshShape(const std::vector<Vec3f>& vertices, const std::vector<uint32>& triangle_indices,
+		const std::vector<uint32>* triangle_materials = nullptr, const std::vector<bool>* create_tris_for_mat = nullptr);
 	// PhysicsWorld.cpp:1086-1119: a heightfield.getWidth() x getWidth() grid of heights (row-major, sample (x, z) at [z * width + x]) in Jolt's
 	// y-up shape space: vertex = (quad_w * x, height, quad_w * z - quad_w * (width - 1)); triangulated here (two triangles per cell, facing +y).
 	static PhysicsShape createJoltHeightFieldShape(int vert_res, const std::vector<float>& heightfield, int width, float quad_w);

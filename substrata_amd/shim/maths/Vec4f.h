@@ -26,3 +26,4 @@ inline Vec4f setWToOne(const Vec4f& v) { return Vec4f(v[0], v[1], v[2], 1.f); }
 inline float dot(const Vec4f& a, const Vec4f& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
 inline Vec4f div(const Vec4f& a, const Vec4f& b) { return Vec4f(a[0] / b[0], a[1] / b[1], a[2] / b[2], a[3] / b[3]); }
 inline Vec4f normalise(const Vec4f& v) { return v * (1.f / v.length()); }
+inline Vec4f crossProduct(const Vec4f& a, const Vec4f& b) { return Vec4f(a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0], 0.f); }

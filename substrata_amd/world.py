@@ -216,12 +216,18 @@ class CWorld:
         return hits
 
     # -- static triangle meshes -------------------------------------------------------------------------------------
-    def mesh_create(self, vertices, triangles):
-        """MeshShapeSettings(vertices, triangles).Create(): returns abi.MeshInfo (mesh_id for static body descs)."""
+    def mesh_create(self, vertices, triangles, materials=None):
+        """MeshShapeSettings(vertices, triangles).Create(): returns abi.MeshInfo (mesh_id for static body descs).  `materials`: one
+        user-data word per triangle (the material index ray hits report)."""
         v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
         t = np.ascontiguousarray(triangles, dtype=np.uint32).reshape(-1, 3)
         info = abi.MeshInfo()
-        self._check(self._fn("mesh_create")(self._h, v.ctypes.data, len(v), t.ctypes.data, len(t), C.byref(info)), "mesh_create")
+        if materials is None:
+            self._check(self._fn("mesh_create")(self._h, v.ctypes.data, len(v), t.ctypes.data, len(t), C.byref(info)), "mesh_create")
+        else:
+            m = np.ascontiguousarray(materials, dtype=np.uint32).reshape(len(t))
+            self._check(self._fn("mesh_create_with_materials")(self._h, v.ctypes.data, len(v), t.ctypes.data, len(t), m.ctypes.data, C.byref(info)),
+                        "mesh_create_with_materials")
         return info
 
     # -- convex hulls ---------------------------------------------------------------------------------------------

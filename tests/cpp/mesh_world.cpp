@@ -32,9 +32,18 @@ int main()
 		for (int i = 0; i < 4; ++i) { bv.push_back(Vec3f(cx[i], cy[i], z0)); bv.push_back(Vec3f(cx[i], cy[i], z1)); }
 		for (int i = 0; i < 4; ++i) { const uint32 a = 2 * i, b = 2 * ((i + 1) % 4); bt.push_back(a); bt.push_back(b); bt.push_back(b + 1); bt.push_back(a); bt.push_back(b + 1); bt.push_back(a + 1); }   // outward-facing walls
 		bt.push_back(1); bt.push_back(3); bt.push_back(5); bt.push_back(1); bt.push_back(5); bt.push_back(7);                                                                                          // roof, facing up
-		Reference<PhysicsObject> building = new PhysicsObject(true, PhysicsWorld::createMeshShape(bv, bt), nullptr, 0);
+		// per-triangle material indices, as createJoltShapeForBatchedMesh stores them from the mesh batches (PhysicsWorld.cpp:1032-1060): wall i -> i + 1, roof -> 5
+		std::vector<uint32> bmat;
+		for (int i = 0; i < 4; ++i) { bmat.push_back(i + 1); bmat.push_back(i + 1); }
+		bmat.push_back(5); bmat.push_back(5);
+		Reference<PhysicsObject> building = new PhysicsObject(true, PhysicsWorld::createMeshShape(bv, bt, &bmat), nullptr, 0);
 		building->pos = Vec4f(10.f, 10.f, 0.f, 1);
 		world->addObject(building);
+		// the same mesh with create_tris_for_mat[5] = false (MeshBuilding.cpp:392-393): no roof triangles
+		std::vector<bool> create_tris_for_mat(6, true); create_tris_for_mat[5] = false;
+		Reference<PhysicsObject> roofless = new PhysicsObject(true, PhysicsWorld::createMeshShape(bv, bt, &bmat, &create_tris_for_mat), nullptr, 0);
+		roofless->pos = Vec4f(-20.f, -20.f, 0.f, 1);
+		world->addObject(roofless);
 
 		// things falling on the terrain and on the building's roof
 		std::vector<Reference<PhysicsObject>> obs;
@@ -61,8 +70,47 @@ int main()
 		ok = ok && r.hit_object == terrain.ptr() && std::fabs((20.f - r.hit_t) - terrainHeight(-5, 3)) < 0.15f && r.hit_normal_ws[2] > 0.8f;
 		world->traceRay(Vec4f(0, 10, 3, 1), Vec4f(1, 0, 0, 0), 100.f, JPH::BodyID(), r);
 		ok = ok && r.hit_object == building.ptr() && std::fabs(r.hit_t - 7.f) < 1e-3f && r.hit_normal_ws[0] < -0.99f;
+		ok = ok && r.hit_mat_index == 4 && r.coords.x == 0.f && r.coords.y == 0.f;      // the -x wall is wall 3 -> material 4; coords stay 0 like the reference (:1693)
 		world->traceRay(Vec4f(10, 10, 3, 1), Vec4f(1, 0, 0, 0), 2.9f, JPH::BodyID(), r);
 		ok = ok && r.hit_object == NULL;
+		world->traceRay(Vec4f(10, 10, 30, 1), Vec4f(0, 0, -1, 0), 100.f, JPH::BodyID(), r);
+		ok = ok && r.hit_object == building.ptr() && r.hit_mat_index == 5 && std::fabs(r.hit_t - 24.f) < 1e-3f;      // the roof
+		world->traceRay(Vec4f(10, 1, 3, 1), Vec4f(0, 1, 0, 0), 100.f, JPH::BodyID(), r);
+		ok = ok && r.hit_object == building.ptr() && r.hit_mat_index == 1;                                           // the -y wall is wall 0 -> material 1
+		world->traceRay(Vec4f(-5, 3, 20, 1), Vec4f(0, 0, -1, 0), 100.f, JPH::BodyID(), r);
+		ok = ok && r.hit_object == terrain.ptr() && r.hit_mat_index == 0;                                            // no material array -> 0
+		// the roofless copy: a ray from above goes through where the roof would be and lands on the terrain; its walls are still there
+		world->traceRay(Vec4f(-20, -20, 30, 1), Vec4f(0, 0, -1, 0), 100.f, JPH::BodyID(), r);
+		ok = ok && r.hit_object == terrain.ptr();
+		world->traceRay(Vec4f(-30, -20, 3, 1), Vec4f(1, 0, 0, 0), 100.f, JPH::BodyID(), r);
+		ok = ok && r.hit_object == roofless.ptr() && r.hit_mat_index == 4 && std::fabs(r.hit_t - 7.f) < 1e-3f;
+		if (!ok) printf("material / filter rays failed\n");
+		{
+			// moving a static mesh object keeps it collidable (setNewObToWorldTransform, :546-604): the roofless building goes to (-20, 20), a ray finds
+			// its wall there and no longer at the old place, and a box dropped onto the rim of a wall ... lands on the wall's top edge or beside it,
+			// so instead drop a box INSIDE: it must come to rest on the terrain between the walls and stay inside them when pushed
+			world->setNewObToWorldTransform(*roofless, Vec4f(-20.f, 20.f, 0.f, 1), Quatf::identity(), Vec4f(1.f, 1.f, 1.f, 0));
+			world->traceRay(Vec4f(-30, 20, 3, 1), Vec4f(1, 0, 0, 0), 100.f, JPH::BodyID(), r);
+			const bool moved = r.hit_object == roofless.ptr() && std::fabs(r.hit_t - 7.f) < 1e-3f && r.hit_mat_index == 4;
+			world->traceRay(Vec4f(-30, -20, 3, 1), Vec4f(1, 0, 0, 0), 100.f, JPH::BodyID(), r);
+			const bool gone = r.hit_object != roofless.ptr();
+			// a ball thrown at the moved wall from outside bounces off it (the wall's collision moved with the object)
+			Reference<PhysicsObject> ball = new PhysicsObject(true);
+			ball->is_sphere = true; ball->scale = Vec3f(0.6f); ball->mass = 5.f; ball->motion_type = PhysicsObject::MotionType_dynamic; ball->restitution = 0.5f;
+			ball->pos = Vec4f(-27.f, 20.f, 4.f, 1);
+			world->addObject(ball); world->activateObject(ball);
+			world->setNewObToWorldTransform(*ball, ball->pos, Quatf::identity(), Vec4f(12.f, 0, 2.f, 0), Vec4f(0.f));
+			float max_x = -1e9f;
+			for (int s = 0; s < 45; ++s) { world->think(1.0 / 60.0); max_x = std::fmax(max_x, world->getPosInJolt(ball)[0]); }
+			const bool bounced = max_x < -23.f + 0.05f && max_x > -23.6f && world->getObjectLinearVelocity(*ball)[0] < 0.f;
+			// a scale change swaps the shape instance (JPH::ScaledShape, :562-601): twice as large, the wall is met 3 m earlier
+			world->setNewObToWorldTransform(*roofless, Vec4f(-20.f, 20.f, 0.f, 1), Quatf::identity(), Vec4f(2.f, 2.f, 2.f, 0));
+			world->traceRay(Vec4f(-30, 20, 3, 1), Vec4f(1, 0, 0, 0), 100.f, JPH::BodyID(), r);
+			const bool scaled = r.hit_object == roofless.ptr() && std::fabs(r.hit_t - 4.f) < 1e-3f && r.hit_mat_index == 4;
+			if (!(moved && gone && bounced && scaled)) printf("moved mesh: moved %d gone %d bounced %d (max x %.3f) scaled %d\n", (int)moved, (int)gone, (int)bounced, max_x, (int)scaled);
+			ok = ok && moved && gone && bounced && scaled;
+			world->removeObject(ball);
+		}
 		// a decorated unit cube, as GUIClient builds for splat bounds (createScaledAndTranslatedShapeForShape(unit_cube_shape, aabb_min, aabb_span),
 		// GUIClient.cpp:4807): the [0,1]^3 cube mesh mapped onto the box [(-1,-2,0), (1,2,1.5)] of an object floating at (-12, 12, 8)
 		{

@@ -28,6 +28,7 @@ def test_facade_compiles_without_gpu(tmp_path):
     assert os.path.exists(build_facade_exe(tmp_path))
     assert os.path.exists(build_facade_exe(tmp_path, "hover_controller.cpp"))
     assert os.path.exists(build_facade_exe(tmp_path, "car_controller.cpp"))
+    assert os.path.exists(build_facade_exe(tmp_path, "car_physics_sequence.cpp"))
     assert os.path.exists(build_facade_exe(tmp_path, "bike_controller.cpp"))
     assert os.path.exists(build_facade_exe(tmp_path, "player_controller.cpp"))
     assert os.path.exists(build_facade_exe(tmp_path, "mesh_world.cpp"))
@@ -72,6 +73,19 @@ def test_car_controller_through_vehicle_constraint(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     print(r.stdout)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_car_physics_call_sequence(tmp_path):
+    """The statements of CarPhysics.cpp:55-231 (constructor), :299-470 (update) and :258-272 (destructor) against the look-alike headers:
+    ConvexHullShapeSettings -> OffsetCenterOfMassShapeSettings -> BodyCreationSettings -> BodyInterface::CreateBody / AddBody,
+    GetWorldTransform + StoreFloat4x4, the righting torque through Quat::sRotation / Conjugated / GetAxisAngle, GetWheelLocalTransform /
+    GetWheelWorldTransform, BodyLockRead, SubShapeID::PopID.  The car drives, is flipped, rights itself."""
+    exe = build_facade_exe(tmp_path, "car_physics_sequence.cpp")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "car_physics_sequence: ok" in r.stdout
 
 
 @pytest.mark.gpu

@@ -45,7 +45,8 @@ def test_terrain_and_room_match_oracle(oracle):
     rng = np.random.default_rng(21)
     tw = parity.make_twin(oracle, max_bodies=1024)
     V, T = grid_mesh(33, 16.0, lambda x, y: 0.6 * np.sin(0.5 * x) * np.cos(0.4 * y) + 0.01 * (x * x + y * y))
-    ig, ic = tw.mesh_create(V, T)
+    terrain_mats = (np.arange(len(T), dtype=np.uint32) * 2654435761 >> 7) % 5          # per-triangle material index (user data)
+    ig, ic = tw.mesh_create(V, T, materials=terrain_mats)
     assert (ig.mesh_id, ig.num_triangles) == (ic.mesh_id, ic.num_triangles) == (1, 2048)
     mg, mc = tw.add_batch(mesh_body(ig))
     assert int(mg[0]) == int(mc[0]) == 0
@@ -98,6 +99,16 @@ def test_terrain_and_room_match_oracle(oracle):
     rg_, rc_ = tw.raycast(rays)
     assert np.array_equal(rg_["id"], rc_["id"]) and (rg_["id"] == 0).sum() > 100 and (rg_["id"] == 3).sum() > 5
     assert np.max(np.abs(rg_["t"] - rc_["t"])) <= 1e-4 and np.max(np.abs(rg_["normal"] - rc_["normal"])) <= 1e-5
+    # which triangle was hit, its material (MeshShape::GetTriangleUserData -> RayTraceResult::hit_mat_index) and the barycentrics: bit for bit
+    on_terrain = rg_["id"] == 0
+    assert np.array_equal(rg_["triangle"], rc_["triangle"]) and np.array_equal(rg_["material"], rc_["material"])
+    assert np.array_equal(rg_["bary"].view(np.uint32), rc_["bary"].view(np.uint32))
+    assert np.array_equal(rg_["material"][on_terrain], terrain_mats[rg_["triangle"][on_terrain]]) and len(np.unique(rg_["material"][on_terrain])) == 5
+    assert np.all(rg_["triangle"][(rg_["id"] != 0) & (rg_["id"] != 3)] == abi.INVALID_ID)
+    # the hit point rebuilt from the barycentrics lies on the ray
+    tri = T[rg_["triangle"][on_terrain]]; u = rg_["bary"][on_terrain][:, :1]; v = rg_["bary"][on_terrain][:, 1:]
+    pt = (1 - u - v) * V[tri[:, 0]] + u * V[tri[:, 1]] + v * V[tri[:, 2]]
+    assert np.max(np.abs(pt - (rays["origin"][on_terrain] + rays["dir"][on_terrain] * rg_["t"][on_terrain][:, None]))) < 2e-4
     # sphere casts (wheel tester / character sweep) against the meshes and the bodies lying on them
     radii = rng.choice([0.0, 0.08, 0.3], size=512).astype(np.float32)
     rays["max_t"] = rng.uniform(2.0, 25.0, size=512)

@@ -122,3 +122,38 @@ def test_capsule_axis_grazing_a_far_triangle_keeps_a_unit_normal(oracle):
             assert abs(nrm - 1.0) < 1e-3, (k, lift, con["n"])
         w.remove(c)
     assert worst > 0.999
+
+
+def test_ray_hit_reports_triangle_material_and_barycentrics(oracle):
+    """MeshShape::GetTriangleUserData through the ray hit (-> RayTraceResult::hit_mat_index, PhysicsWorld.cpp:1698-1704) + the
+    barycentric coordinates of the hit, known answers on a two-triangle quad carrying materials 7 and 9."""
+    w = oracle.OracleWorld(max_bodies=16)
+    V = np.float32([(0, 0, 0), (4, 0, 0), (4, 4, 0), (0, 4, 0)])
+    T = np.uint32([(0, 1, 2), (0, 2, 3)])
+    info = w.mesh_create(V, T, materials=[7, 9])
+    d = scenes._blank(1)
+    d["shape_type"] = abi.SHAPE_MESH; d["shape"][0] = 0; d["shape"][0, 0] = float(info.mesh_id); d["pos"][0] = (10, 20, 1)
+    mid = int(w.add_batch(d)[0])
+    sph = scenes.dynamic_bodies(1); sph["shape_type"] = abi.SHAPE_SPHERE; sph["shape"][0] = (0.5, 0, 0, 0); sph["pos"][0] = (50, 50, 5)
+    sid = int(w.add_batch(sph)[0])
+    rays = np.zeros(4, dtype=abi.ray_dtype)
+    # point (3, 1) lies in triangle 0 = (a=(0,0), b=(4,0), c=(4,4)): p = a + u (b - a) + v (c - a) -> v = 1/4, u = 3/4 - 1/4 = 1/2
+    # point (1, 3) lies in triangle 1 = (a=(0,0), b=(4,4), c=(0,4)): u = 1/4, v = 1/2
+    rays["origin"] = [(13, 21, 6), (11, 23, 6), (50, 50, 9), (13, 21, -3)]
+    rays["dir"] = [(0, 0, -1), (0, 0, -1), (0, 0, -1), (0, 0, 1)]
+    rays["max_t"] = 20.0; rays["ignore_id"] = abi.INVALID_ID
+    h = w.raycast(rays)
+    assert h[0]["id"] == mid and h[0]["triangle"] == 0 and h[0]["material"] == 7 and np.allclose(h[0]["bary"], (0.5, 0.25), atol=1e-6) and abs(h[0]["t"] - 5.0) < 1e-6
+    assert h[1]["id"] == mid and h[1]["triangle"] == 1 and h[1]["material"] == 9 and np.allclose(h[1]["bary"], (0.25, 0.5), atol=1e-6)
+    # a primitive: no triangle, material 0, coordinates 0
+    assert h[2]["id"] == sid and h[2]["triangle"] == abi.INVALID_ID and h[2]["material"] == 0 and np.all(h[2]["bary"] == 0)
+    # from below: back faces are not hit
+    assert h[3]["id"] == abi.INVALID_ID and h[3]["triangle"] == abi.INVALID_ID
+    # without a material array every triangle reports 0
+    info2 = w.mesh_create(V, T)
+    d["shape"][0, 0] = float(info2.mesh_id); d["pos"][0] = (-30, 0, 0)
+    mid2 = int(w.add_batch(d)[0])
+    r = np.zeros(1, dtype=abi.ray_dtype); r["origin"] = (-29, 3, 4); r["dir"] = (0, 0, -1); r["max_t"] = 10; r["ignore_id"] = abi.INVALID_ID
+    h2 = w.raycast(r)
+    assert h2[0]["id"] == mid2 and h2[0]["triangle"] == 1 and h2[0]["material"] == 0
+    w.close()
