@@ -180,7 +180,7 @@ typedef struct sgp_hit {
 	                              (PhysicsWorld.cpp:1700-1704 -> RayTraceResult::hit_mat_index); 0 otherwise                               */
 	float    bary[2];          /* mesh hits: barycentric coordinates (u, v) of the hit, point = (1 - u - v) a + u b + v c; 0 otherwise.
 	                              (The reference leaves RayTraceResult::coords at 0, :1693; the facade does the same.)                     */
-	uint32_t _pad;
+	uint32_t sub_shape;        /* compound bodies (sgp_body_add_compound): index of the child that was hit, `id` is the compound's id; 0 otherwise */
 } sgp_hit;
 
 /* Counters of the last step (getDiagnostics, PhysicsWorld.cpp:1578-1604, plus stage sizes). */
@@ -311,6 +311,25 @@ const char* sgp_kernel_class_name(int k);
 int  sgp_abi_sizeof(int which);
 /* activated_obs / newly_activated_obs maintenance + listener callbacks (PhysicsWorld.h:194-200). */
 int  sgp_world_drain_events(sgp_world* w, int kind, void* out, uint32_t cap, uint32_t* n_out);
+/* ---- static compound bodies ---------------------------------------------------
+ * Replaces JPH::StaticCompoundShapeSettings::AddShape(position, rotation, shape, user data) x n + Create() as MeshBuilding.cpp:396-407
+ * uses it for portals (the arch mesh + a thin box across the opening).  The compound is a STATIC body made of n child shapes, each with
+ * a pose in the compound's frame; every child occupies its own body slot(s) (world pose = compound pose o child pose, all children share
+ * the desc's material, layer and userdata), so the broad phase, narrow phase and queries need no notion of a sub-shape.  The id returned
+ * (= the first child's slot) stands for the whole compound: pose setters, layer changes and removal act on every child; ray hits,
+ * capsule-query contacts and contact events report this id, with the child index in `sub_shape` where the struct has one.  `base` gives
+ * pose, layer, friction, restitution, sensor flag and userdata; its shape fields are ignored; motion_type must be SGP_MOTION_STATIC. */
+typedef struct sgp_compound_child {
+	int32_t shape_type;         /* SGP_SHAPE_SPHERE / BOX / CAPSULE / HULL / MESH */
+	float   shape[4];           /* as sgp_body_desc::shape */
+	float   pos[3];             /* of the child's body frame in the compound's frame */
+	float   rot[4];
+} sgp_compound_child;
+#define SGP_MAX_COMPOUND_CHILDREN 64
+int  sgp_body_add_compound(sgp_world* w, const sgp_body_desc* base, const sgp_compound_child* children, uint32_t num_children, uint32_t* id_out);
+/* Number of children of compound `id` (0 = not a compound). */
+int  sgp_body_compound_size(sgp_world* w, uint32_t id, uint32_t* num_children_out);
+
 /* Body::GetUserData() of a live body (what JPH::BodyLockRead users read, PlayerPhysics.cpp:519-530); host-side lookup, no device access. */
 int  sgp_body_get_userdata(sgp_world* w, uint32_t id, uint64_t* userdata_out);
 /* getNumObjects (:1635-1638) */
@@ -461,7 +480,8 @@ typedef struct sgp_query_contact {
 	uint32_t motion_type;       /* SGP_MOTION_*                                                                    */
 	uint32_t is_sensor;
 	float    inv_mass;          /* 0 unless dynamic                                                                */
-	uint32_t pad;
+	uint32_t sub_shape;         /* compound bodies: index of the touched child (`body` is the compound's id); 0 otherwise
+	                               -> JPH::SubShapeID of CharacterContactListener::OnContactAdded (GUIClient.cpp:6484-6486)   */
 	uint64_t userdata;
 } sgp_query_contact;
 /* Contacts come back sorted by (query, body, point). n_out may exceed cap (then only the first cap are written). */

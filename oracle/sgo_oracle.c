@@ -47,6 +47,10 @@ typedef struct {
 	int shape_type; float shape[4];
 	const struct sgo_mesh_s* mesh;    /* SGP_SHAPE_MESH: the triangles (mesh frame = body frame) */
 	int is_alias;                     /* internal second / third slot of a mesh body: carries contact manifolds only */
+	uint32_t comp_root, comp_child;   /* child of a static compound body: the compound's id (= first child's slot) and the child's index; root = SGP_INVALID_ID otherwise */
+	float comp_local_pos[3], comp_local_rot[4];   /* ... and its pose in the compound's frame */
+	float comp_pos[3], comp_rot[4];   /* (on the first child) the compound's own pose */
+	uint32_t comp_n;                  /* (on the first child) number of children */
 	const sgo_hull* hull;             /* SGP_SHAPE_HULL: the shape; SGP_SHAPE_BOX: the +-1 cube template (for box - hull pairs) */
 	int motion, layer;
 	float friction, restitution, gravity_factor, lin_damp, ang_damp, mass;
@@ -447,6 +451,7 @@ SGO_API int sgo_body_add(sgo_world* w, const sgp_body_desc* d, uint32_t* id_out)
 	else { b->inv_mass = 0.0f; b->inv_inertia = V3(0.0f, 0.0f, 0.0f); }
 	if (b->motion != SGP_MOTION_DYNAMIC) { /* non-dynamic bodies carry no force */ }
 	b->alive = 1; b->active = 0;
+	b->comp_root = SGP_INVALID_ID;
 	body_update_aabb(b);
 	body_reset_sleep(b);
 	w->n_alive++;
@@ -468,6 +473,89 @@ SGO_API int sgo_body_add_batch(sgo_world* w, const sgp_body_desc* d, uint32_t n,
 }
 
 static int live(sgo_world* w, uint32_t id) { return w && id < w->high && w->bodies[id].alive; }
+
+/* ---- static compound bodies (StaticCompoundShapeSettings, MeshBuilding.cpp:396-407): one body slot per child ---------------------- */
+static void compound_child_pose(const float P[3], const float R[4], const float lp[3], const float lr[4], float pos_out[3], float rot_out[4])
+{
+	const float x = R[0], y = R[1], z = R[2], w_ = R[3];
+	const float vx = lp[0], vy = lp[1], vz = lp[2];
+	const float tx = 2.0f * (y * vz - z * vy), ty = 2.0f * (z * vx - x * vz), tz = 2.0f * (x * vy - y * vx);
+	pos_out[0] = P[0] + (vx + w_ * tx + (y * tz - z * ty));
+	pos_out[1] = P[1] + (vy + w_ * ty + (z * tx - x * tz));
+	pos_out[2] = P[2] + (vz + w_ * tz + (x * ty - y * tx));
+	const float ox = lr[0], oy = lr[1], oz = lr[2], ow = lr[3];
+	rot_out[0] = w_ * ox + x * ow + y * oz - z * oy;
+	rot_out[1] = w_ * oy - x * oz + y * ow + z * ox;
+	rot_out[2] = w_ * oz + x * oy - y * ox + z * ow;
+	rot_out[3] = w_ * ow - x * ox - y * oy - z * oz;
+}
+static int is_compound_child(const sgo_world* w, uint32_t id) { return w->bodies[id].comp_root != SGP_INVALID_ID && w->bodies[id].comp_root != id; }
+static int is_compound(const sgo_world* w, uint32_t id) { return w->bodies[id].comp_root == id; }
+/* the slots of compound `root`'s children, in child order (children are found by their back reference) */
+static uint32_t compound_children(const sgo_world* w, uint32_t root, uint32_t* ids)
+{
+	const uint32_t n = w->bodies[root].comp_n;
+	for (uint32_t i = 0; i < w->high; ++i) { const sgo_body* b = &w->bodies[i]; if (b->alive && !b->is_alias && b->comp_root == root && b->comp_child < n) ids[b->comp_child] = i; }
+	return n;
+}
+static uint32_t compound_id_of(const sgo_world* w, uint32_t id, uint32_t* sub)
+{
+	const sgo_body* b = &w->bodies[id];
+	if (b->comp_root == SGP_INVALID_ID) { if (sub) *sub = 0; return id; }
+	if (sub) *sub = b->comp_child;
+	return b->comp_root;
+}
+SGO_API int sgo_body_remove(sgo_world* w, uint32_t id);
+SGO_API int sgo_body_add_compound(sgo_world* w, const sgp_body_desc* base, const sgp_compound_child* children, uint32_t n, uint32_t* id_out)
+{
+	if (!w || !base || !children || !id_out) return SGP_ERR_INVALID;
+	*id_out = SGP_INVALID_ID;
+	if (n < 1 || n > SGP_MAX_COMPOUND_CHILDREN) return SGP_ERR_INVALID;
+	if (base->motion_type != SGP_MOTION_STATIC) return SGP_ERR_INVALID;
+	if (!finite3(base->pos) || !isfinite(base->rot[0]) || !isfinite(base->rot[1]) || !isfinite(base->rot[2]) || !isfinite(base->rot[3])) return SGP_ERR_REJECTED;
+	for (uint32_t k = 0; k < n; ++k) for (int a = 0; a < 4; ++a) if ((a < 3 && !isfinite(children[k].pos[a])) || !isfinite(children[k].rot[a])) return SGP_ERR_INVALID;
+	uint32_t ids[SGP_MAX_COMPOUND_CHILDREN];
+	for (uint32_t k = 0; k < n; ++k) {
+		sgp_body_desc d = *base;
+		d.shape_type = children[k].shape_type; memcpy(d.shape, children[k].shape, sizeof(d.shape));
+		compound_child_pose(base->pos, base->rot, children[k].pos, children[k].rot, d.pos, d.rot);
+		d.activate = 0;
+		const int r = sgo_body_add(w, &d, &ids[k]);
+		if (r != SGP_OK) { for (uint32_t j = 0; j < k; ++j) sgo_body_remove(w, ids[j]); return r; }
+	}
+	for (uint32_t k = 0; k < n; ++k) {
+		sgo_body* b = &w->bodies[ids[k]];
+		b->comp_root = ids[0]; b->comp_child = k;
+		memcpy(b->comp_local_pos, children[k].pos, 12); memcpy(b->comp_local_rot, children[k].rot, 16);
+		if (b->shape_type == SGP_SHAPE_MESH) for (int a = 1; a <= 2; ++a) { w->bodies[ids[k] + a].comp_root = SGP_INVALID_ID; }
+	}
+	sgo_body* r0 = &w->bodies[ids[0]];
+	r0->comp_n = n; memcpy(r0->comp_pos, base->pos, 12); memcpy(r0->comp_rot, base->rot, 16);
+	w->n_alive -= (n - 1);
+	*id_out = ids[0];
+	return SGP_OK;
+}
+SGO_API int sgo_body_compound_size(sgo_world* w, uint32_t id, uint32_t* n_out)
+{
+	if (!live(w, id) || !n_out) return SGP_ERR_BAD_ID;
+	*n_out = is_compound(w, id) ? w->bodies[id].comp_n : 0u;
+	return SGP_OK;
+}
+static int set_pose_one(sgo_world* w, uint32_t id, const float pos[3], const float rot[4]);
+/* a pose edit of a compound: every child gets the compound's new pose composed with its own.  rot == NULL keeps the rotation. */
+static void compound_set_pose(sgo_world* w, uint32_t root, const float pos[3], const float* rot)
+{
+	sgo_body* r0 = &w->bodies[root];
+	memcpy(r0->comp_pos, pos, 12); if (rot) memcpy(r0->comp_rot, rot, 16);
+	uint32_t ids[SGP_MAX_COMPOUND_CHILDREN];
+	const uint32_t n = compound_children(w, root, ids);
+	for (uint32_t k = 0; k < n; ++k) {
+		float p[3], q[4];
+		sgo_body* b = &w->bodies[ids[k]];
+		compound_child_pose(r0->comp_pos, r0->comp_rot, b->comp_local_pos, b->comp_local_rot, p, q);
+		set_pose_one(w, ids[k], p, q);
+	}
+}
 /* a static mesh body owns the two alias slots behind it (second / third contact manifold of a pair): they share its pose */
 static void sync_mesh_aliases(sgo_world* w, uint32_t id)
 {
@@ -480,6 +568,13 @@ SGO_API int sgo_body_remove(sgo_world* w, uint32_t id)
 	if (!live(w, id)) return SGP_ERR_BAD_ID;
 	for (uint32_t k = 0; k < w->n_vehicles; ++k) if (w->vehicles[k].alive && w->vehicles[k].body == id) w->vehicles[k].alive = 0;   /* a vehicle does not outlive its chassis */
 	if (w->bodies[id].is_alias) return SGP_ERR_BAD_ID;
+	if (is_compound_child(w, id)) return SGP_ERR_BAD_ID;
+	if (is_compound(w, id)) {
+		uint32_t ids[SGP_MAX_COMPOUND_CHILDREN];
+		const uint32_t n = compound_children(w, id, ids);
+		for (uint32_t k = 0; k < n; ++k) w->bodies[ids[k]].comp_root = SGP_INVALID_ID;
+		for (uint32_t k = 1; k < n; ++k) { const int r = sgo_body_remove(w, ids[k]); if (r != SGP_OK) return r; w->n_alive++; }
+	}
 	const int nslots = w->bodies[id].shape_type == SGP_SHAPE_MESH ? 3 : 1;
 	for (int k = 0; k < nslots; ++k) { w->bodies[id + k].alive = 0; w->bodies[id + k].active = 0; w->bodies[id + k].is_alias = 0; w->free_list[w->n_free++] = id + k; }
 	w->n_alive--;
@@ -487,11 +582,27 @@ SGO_API int sgo_body_remove(sgo_world* w, uint32_t id)
 }
 SGO_API int sgo_body_activate(sgo_world* w, uint32_t id) { if (!live(w, id)) return SGP_ERR_BAD_ID; body_activate(w, id); return SGP_OK; }
 SGO_API int sgo_body_get_volume(sgo_world* w, uint32_t id, float* out) { if (!live(w, id) || !out) return SGP_ERR_BAD_ID; *out = shape_volume_h(w->bodies[id].shape_type, w->bodies[id].shape, w->bodies[id].hull); return SGP_OK; }
-SGO_API int sgo_body_set_layer(sgo_world* w, uint32_t id, int32_t layer) { if (!live(w, id)) return SGP_ERR_BAD_ID; w->bodies[id].layer = layer; return SGP_OK; }
+SGO_API int sgo_body_set_layer(sgo_world* w, uint32_t id, int32_t layer)
+{
+	if (!live(w, id) || is_compound_child(w, id)) return SGP_ERR_BAD_ID;
+	if (is_compound(w, id)) { uint32_t ids[SGP_MAX_COMPOUND_CHILDREN]; const uint32_t n = compound_children(w, id, ids); for (uint32_t k = 0; k < n; ++k) w->bodies[ids[k]].layer = layer; return SGP_OK; }
+	w->bodies[id].layer = layer;
+	return SGP_OK;
+}
 
+static int set_pose_one(sgo_world* w, uint32_t id, const float pos[3], const float rot[4])
+{
+	sgo_body* b = &w->bodies[id];
+	b->pos = V3(pos[0], pos[1], pos[2]);
+	quat q = { rot[0], rot[1], rot[2], rot[3] }; b->rot = q;
+	body_update_aabb(b);
+	sync_mesh_aliases(w, id);
+	return SGP_OK;
+}
 SGO_API int sgo_body_set_pose_vel(sgo_world* w, uint32_t id, const float pos[3], const float rot[4], const float lv[3], const float av[3])
 {
-	if (!live(w, id)) return SGP_ERR_BAD_ID;
+	if (!live(w, id) || is_compound_child(w, id)) return SGP_ERR_BAD_ID;
+	if (is_compound(w, id)) { compound_set_pose(w, id, pos, rot); return SGP_OK; }
 	sgo_body* b = &w->bodies[id];
 	b->pos = V3(pos[0], pos[1], pos[2]);
 	quat q = { rot[0], rot[1], rot[2], rot[3] }; b->rot = q;
@@ -502,7 +613,8 @@ SGO_API int sgo_body_set_pose_vel(sgo_world* w, uint32_t id, const float pos[3],
 }
 SGO_API int sgo_body_set_pose_shape(sgo_world* w, uint32_t id, const float pos[3], const float rot[4], const float shape[4])
 {
-	if (!live(w, id)) return SGP_ERR_BAD_ID;
+	if (!live(w, id) || is_compound_child(w, id)) return SGP_ERR_BAD_ID;
+	if (is_compound(w, id)) { compound_set_pose(w, id, pos, rot); return SGP_OK; }
 	sgo_body* b = &w->bodies[id];
 	b->pos = V3(pos[0], pos[1], pos[2]);
 	quat q = { rot[0], rot[1], rot[2], rot[3] }; b->rot = q;
@@ -515,7 +627,8 @@ SGO_API int sgo_body_set_pose_shape(sgo_world* w, uint32_t id, const float pos[3
 }
 SGO_API int sgo_body_set_pos(sgo_world* w, uint32_t id, const float pos[3])
 {
-	if (!live(w, id)) return SGP_ERR_BAD_ID;
+	if (!live(w, id) || is_compound_child(w, id)) return SGP_ERR_BAD_ID;
+	if (is_compound(w, id)) { compound_set_pose(w, id, pos, NULL); return SGP_OK; }
 	w->bodies[id].pos = V3(pos[0], pos[1], pos[2]);
 	body_update_aabb(&w->bodies[id]);
 	sync_mesh_aliases(w, id);
@@ -759,6 +872,7 @@ static void emit_contact_event(sgo_world* w, const sgo_constraint* c, const sgo_
 	e.id1 = c->a; e.id2 = c->b; e.userdata1 = A->userdata; e.userdata2 = B->userdata;
 	while (e.id1 > 0 && w->bodies[e.id1].is_alias) --e.id1;      /* a mesh body's alias slots report as the mesh body */
 	while (e.id2 > 0 && w->bodies[e.id2].is_alias) --e.id2;
+	e.id1 = compound_id_of(w, e.id1, NULL); e.id2 = compound_id_of(w, e.id2, NULL);      /* a compound's children report as the compound */
 	e.lin_vel1[0] = A->linv.x; e.lin_vel1[1] = A->linv.y; e.lin_vel1[2] = A->linv.z;
 	e.lin_vel2[0] = B->linv.x; e.lin_vel2[1] = B->linv.y; e.lin_vel2[2] = B->linv.z;
 	e.base_offset[0] = m->p1[0].x; e.base_offset[1] = m->p1[0].y; e.base_offset[2] = m->p1[0].z;
@@ -2114,7 +2228,7 @@ static int cmp_query_contact(const void* a, const void* b)
 	const sgp_query_contact* x = (const sgp_query_contact*)a; const sgp_query_contact* y = (const sgp_query_contact*)b;
 	if (x->query != y->query) return x->query < y->query ? -1 : 1;
 	if (x->body != y->body) return x->body < y->body ? -1 : 1;
-	return x->pad < y->pad ? -1 : (x->pad > y->pad ? 1 : 0);
+	return x->sub_shape < y->sub_shape ? -1 : (x->sub_shape > y->sub_shape ? 1 : 0);      /* (the point index, until the final pass below) */
 }
 SGO_API int sgo_collide_capsules(sgo_world* w, const sgp_capsule_query* qs, uint32_t n, sgp_query_contact* out, uint32_t cap, uint32_t* n_out)
 {
@@ -2143,7 +2257,7 @@ SGO_API int sgo_collide_capsules(sgo_world* w, const sgp_capsule_query* qs, uint
 				if (cnt < cap) {
 					sgp_query_contact* c = &out[cnt];
 					memset(c, 0, sizeof(*c));
-					c->query = k; c->body = j; c->pad = (uint32_t)(4 * g + i);
+					c->query = k; c->body = j; c->sub_shape = (uint32_t)(4 * g + i);
 					c->point[0] = m.p1[i].x; c->point[1] = m.p1[i].y; c->point[2] = m.p1[i].z;
 					c->normal[0] = m.n.x; c->normal[1] = m.n.y; c->normal[2] = m.n.z;
 					c->distance = v3_dot(v3_sub(m.p2[i], m.p1[i]), m.n);
@@ -2158,7 +2272,7 @@ SGO_API int sgo_collide_capsules(sgo_world* w, const sgp_capsule_query* qs, uint
 	}
 	*n_out = cnt;
 	qsort(out, cnt < cap ? cnt : cap, sizeof(sgp_query_contact), cmp_query_contact);
-	for (uint32_t i = 0; i < (cnt < cap ? cnt : cap); ++i) out[i].pad = 0;
+	for (uint32_t i = 0; i < (cnt < cap ? cnt : cap); ++i) out[i].body = compound_id_of(w, out[i].body, &out[i].sub_shape);       /* a compound's children report as the compound */
 	return SGP_OK;
 }
 
@@ -2183,6 +2297,7 @@ SGO_API int sgo_spherecast(sgo_world* w, const sgp_ray* rays, const float* radii
 		hits[k].normal[0] = bn.x; hits[k].normal[1] = bn.y; hits[k].normal[2] = bn.z;
 		hits[k].triangle = SGP_INVALID_ID;
 		hits[k].userdata = bid == SGP_INVALID_ID ? 0 : w->bodies[bid].userdata;
+		if (bid != SGP_INVALID_ID) hits[k].id = compound_id_of(w, bid, &hits[k].sub_shape);
 	}
 	return SGP_OK;
 }
@@ -2299,6 +2414,7 @@ SGO_API int sgo_raycast(sgo_world* w, const sgp_ray* rays, uint32_t n, sgp_hit* 
 		hits[k].normal[0] = bn.x; hits[k].normal[1] = bn.y; hits[k].normal[2] = bn.z;
 		hits[k].triangle = bsub.tri; hits[k].material = bsub.mat; hits[k].bary[0] = bsub.u; hits[k].bary[1] = bsub.v;
 		hits[k].userdata = bid == SGP_INVALID_ID ? 0 : w->bodies[bid].userdata;
+		if (bid != SGP_INVALID_ID) hits[k].id = compound_id_of(w, bid, &hits[k].sub_shape);
 	}
 	return SGP_OK;
 }

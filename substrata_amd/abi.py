@@ -73,7 +73,7 @@ class Ray(C.Structure):
 
 
 class Hit(C.Structure):
-    _fields_ = [("id", u32), ("t", f32), ("normal", f32 * 3), ("triangle", u32), ("userdata", u64), ("material", u32), ("bary", f32 * 2), ("_pad", u32)]
+    _fields_ = [("id", u32), ("t", f32), ("normal", f32 * 3), ("triangle", u32), ("userdata", u64), ("material", u32), ("bary", f32 * 2), ("sub_shape", u32)]
 
 
 class StepStats(C.Structure):
@@ -173,9 +173,13 @@ class CapsuleQuery(C.Structure):
                 ("ignore_id", u32), ("collidable_only", u32)]
 
 
+class CompoundChild(C.Structure):
+    _fields_ = [("shape_type", i32), ("shape", f32 * 4), ("pos", f32 * 3), ("rot", f32 * 4)]
+
+
 class QueryContact(C.Structure):
     _fields_ = [("query", u32), ("body", u32), ("point", f32 * 3), ("normal", f32 * 3), ("distance", f32),
-                ("point_velocity", f32 * 3), ("motion_type", u32), ("is_sensor", u32), ("inv_mass", f32), ("pad", u32),
+                ("point_velocity", f32 * 3), ("motion_type", u32), ("is_sensor", u32), ("inv_mass", f32), ("sub_shape", u32),
                 ("userdata", u64)]
 
 
@@ -204,6 +208,7 @@ vehicle_input_dtype = np.dtype(VehicleInput)
 vehicle_state_dtype = np.dtype(VehicleState)
 capsule_query_dtype = np.dtype(CapsuleQuery)
 query_contact_dtype = np.dtype(QueryContact)
+compound_child_dtype = np.dtype(CompoundChild)
 
 P = C.POINTER
 vp = C.c_void_p
@@ -220,6 +225,8 @@ PROTOTYPES = {
     "world_destroy": (C.c_int, [vp]),
     "body_add": (C.c_int, [vp, P(BodyDesc), P(u32)]),
     "body_add_batch": (C.c_int, [vp, vp, u32, vp]),
+    "body_add_compound": (C.c_int, [vp, P(BodyDesc), vp, u32, P(u32)]),
+    "body_compound_size": (C.c_int, [vp, u32, P(u32)]),
     "body_remove": (C.c_int, [vp, u32]),
     "body_activate": (C.c_int, [vp, u32]),
     "body_set_layer": (C.c_int, [vp, u32, i32]),

@@ -2422,7 +2422,7 @@ __global__ void __launch_bounds__(64) k_raycast(DV d, const sgp_ray* rays, uint3
 	sgp_hit h;
 	h.id = best.id; h.t = best.id == SGP_INVALID_ID ? 0.0f : best.t;
 	h.normal[0] = best.n.x; h.normal[1] = best.n.y; h.normal[2] = best.n.z;
-	h.triangle = best.sub.tri; h.material = best.sub.mat; h.bary[0] = best.sub.u; h.bary[1] = best.sub.v; h._pad = 0;
+	h.triangle = best.sub.tri; h.material = best.sub.mat; h.bary[0] = best.sub.u; h.bary[1] = best.sub.v; h.sub_shape = 0;
 	h.userdata = 0;
 	hits[k] = h;
 }
@@ -2652,7 +2652,7 @@ SGP_DEV void capsule_query_body(const DV& d, const sgp_capsule_query& q, uint32_
 		const uint32_t slot = atomicAdd(count, 1u);
 		if (slot >= cap) continue;
 		sgp_query_contact c;
-		c.query = k; c.body = j; c.pad = (uint32_t)(4 * g + i);
+		c.query = k; c.body = j; c.sub_shape = (uint32_t)(4 * g + i);      // point index for the host's sort; the host then stores the compound child index here
 		c.point[0] = m.p1[i].x; c.point[1] = m.p1[i].y; c.point[2] = m.p1[i].z;
 		c.normal[0] = m.n.x; c.normal[1] = m.n.y; c.normal[2] = m.n.z;
 		c.distance = v3_dot(v3_sub(m.p2[i], m.p1[i]), m.n);
@@ -2737,7 +2737,7 @@ __global__ void __launch_bounds__(64) k_spherecast(DV d, const sgp_ray* rays, co
 	sgp_hit h;
 	h.id = best.id; h.t = best.id == SGP_INVALID_ID ? 0.0f : best.t;
 	h.normal[0] = best.n.x; h.normal[1] = best.n.y; h.normal[2] = best.n.z;
-	h.triangle = SGP_INVALID_ID; h.material = 0; h.bary[0] = h.bary[1] = 0.0f; h._pad = 0;
+	h.triangle = SGP_INVALID_ID; h.material = 0; h.bary[0] = h.bary[1] = 0.0f; h.sub_shape = 0;
 	h.userdata = 0;
 	hits[k] = h;
 }

@@ -50,7 +50,12 @@ struct HostBody {
 	float bound_radius = 0.0f;
 	float volume = 0.0f;         // Shape::GetVolume of the current shape
 	bool ghost = false;
+	uint32_t comp_root = SGP_INVALID_ID;   // child of a static compound body: slot of the compound (= its first child), else invalid
+	uint32_t comp_child = 0;               // index among the compound's children
 };
+
+// A static compound body (sgp_body_add_compound): the slots of its children and their poses in the compound's frame
+struct CompoundRec { std::vector<uint32_t> ids; std::vector<sgp_compound_child> children; float pos[3]; float rot[4]; };
 
 struct ProfEvent { int kc; hipEvent_t a, b; };
 
@@ -73,6 +78,7 @@ struct sgp_world {
 	uint32_t ghost_gen = 0;
 	std::vector<GhostRefresh> ghost_refresh;               // pose refreshes of existing ghosts queued by the last import (uploaded by flush_cmds)
 	std::vector<std::pair<uint64_t, uint32_t>> ghost_seq;   // (global id, local id) of the previous import, in its order (fast path of the next one)
+	std::unordered_map<uint32_t, CompoundRec> compounds;    // compound id (= first child's slot) -> record
 	// pending edits
 	std::vector<BodyCmd> cmds;
 	// staging
@@ -452,7 +458,7 @@ static int add_one(sgp_world* w, const sgp_body_desc* d, uint32_t* id_out, bool 
 	if (d->use_zero_linear_drag) f |= BF_ZERO_LIN_DRAG;
 	if (ghost) f |= BF_GHOST;
 	HostBody& hb = w->hb[id];
-	hb.flags = f; hb.userdata = d->userdata; hb.ghost = ghost;
+	hb.flags = f; hb.userdata = d->userdata; hb.ghost = ghost; hb.comp_root = SGP_INVALID_ID; hb.comp_child = 0;
 	note_radius(w, id, is_mesh ? 3.0e38f : (hull ? hull->bound_radius : bounding_radius(d->shape_type, d->shape)));   // (meshes always go through the large-body list)
 	hb.volume = is_mesh ? 0.0f : (hull ? hull->volume : host_shape_volume(d->shape_type, d->shape));
 	c.flags = hb.flags;
@@ -460,7 +466,7 @@ static int add_one(sgp_world* w, const sgp_body_desc* d, uint32_t* id_out, bool 
 	if (is_mesh) for (uint32_t k = 1; k <= 2; ++k) {
 		// aliases: same pose and material, flagged large (so never binned) but absent from the large-body list (so never paired or queried)
 		BodyCmd a = c; a.id = id + k; a.flags = hb.flags | BF_ALIAS | BF_LARGE;
-		HostBody& ha = w->hb[id + k]; ha.flags = a.flags; ha.userdata = d->userdata; ha.ghost = false; ha.bound_radius = 0.0f; ha.volume = 0.0f;
+		HostBody& ha = w->hb[id + k]; ha.flags = a.flags; ha.userdata = d->userdata; ha.ghost = false; ha.bound_radius = 0.0f; ha.volume = 0.0f; ha.comp_root = SGP_INVALID_ID; ha.comp_child = 0;
 		w->cmds.push_back(a);
 	}
 	if (d->activate && d->motion_type != SGP_MOTION_STATIC) { BodyCmd a; memset(&a, 0, sizeof(a)); a.id = id; a.ops = CMD_ACTIVATE; w->cmds.push_back(a); }
@@ -489,18 +495,106 @@ SGP_API int sgp_body_add_batch(sgp_world* w, const sgp_body_desc* d, uint32_t n,
 	return SGP_OK;
 }
 
+// world pose of a compound's child: pos = P + R * p_k, rot = R * q_k (plain float arithmetic, written out so that the CPU checker can state the same operations)
+static void compound_child_pose(const float P[3], const float R[4], const sgp_compound_child& c, float pos_out[3], float rot_out[4])
+{
+	const float x = R[0], y = R[1], z = R[2], w_ = R[3];
+	const float vx = c.pos[0], vy = c.pos[1], vz = c.pos[2];
+	const float tx = 2.0f * (y * vz - z * vy), ty = 2.0f * (z * vx - x * vz), tz = 2.0f * (x * vy - y * vx);
+	pos_out[0] = P[0] + (vx + w_ * tx + (y * tz - z * ty));
+	pos_out[1] = P[1] + (vy + w_ * ty + (z * tx - x * tz));
+	pos_out[2] = P[2] + (vz + w_ * tz + (x * ty - y * tx));
+	const float ox = c.rot[0], oy = c.rot[1], oz = c.rot[2], ow = c.rot[3];
+	rot_out[0] = w_ * ox + x * ow + y * oz - z * oy;
+	rot_out[1] = w_ * oy - x * oz + y * ow + z * ox;
+	rot_out[2] = w_ * oz + x * oy - y * ox + z * ow;
+	rot_out[3] = w_ * ow - x * ox - y * oy - z * oz;
+}
+static inline bool is_compound_child(const sgp_world* w, uint32_t id) { return w->hb[id].comp_root != SGP_INVALID_ID && w->hb[id].comp_root != id; }
+static inline CompoundRec* compound_of(sgp_world* w, uint32_t id) { auto it = w->compounds.find(id); return it == w->compounds.end() ? nullptr : &it->second; }
+
+SGP_API int sgp_body_remove(sgp_world* w, uint32_t id);
+SGP_API int sgp_body_add_compound(sgp_world* w, const sgp_body_desc* base, const sgp_compound_child* children, uint32_t n, uint32_t* id_out)
+{
+	if (!w || !base || !children || !id_out) return fail(SGP_ERR_INVALID, "sgp_body_add_compound: NULL");
+	*id_out = SGP_INVALID_ID;
+	if (n < 1 || n > SGP_MAX_COMPOUND_CHILDREN) return fail(SGP_ERR_INVALID, "sgp_body_add_compound: 1..64 children");
+	if (base->motion_type != SGP_MOTION_STATIC) return fail(SGP_ERR_INVALID, "sgp_body_add_compound: compound bodies are static (JPH::StaticCompoundShape on a static object)");
+	if (!finite3(base->pos) || !finite4(base->rot)) return SGP_ERR_REJECTED;
+	for (uint32_t k = 0; k < n; ++k) if (!finite3(children[k].pos) || !finite4(children[k].rot)) return fail(SGP_ERR_INVALID, "sgp_body_add_compound: non-finite child pose");
+	CompoundRec rec;
+	memcpy(rec.pos, base->pos, 12); memcpy(rec.rot, base->rot, 16);
+	for (uint32_t k = 0; k < n; ++k) {
+		sgp_body_desc d = *base;
+		d.shape_type = children[k].shape_type; memcpy(d.shape, children[k].shape, 16);
+		compound_child_pose(base->pos, base->rot, children[k], d.pos, d.rot);
+		d.activate = 0;
+		uint32_t cid = SGP_INVALID_ID;
+		const int r = add_one(w, &d, &cid, false);
+		if (r != SGP_OK) {                  // all or nothing
+			for (uint32_t j = 0; j < rec.ids.size(); ++j) { w->hb[rec.ids[j]].comp_root = SGP_INVALID_ID; sgp_body_remove(w, rec.ids[j]); }
+			return r;
+		}
+		rec.ids.push_back(cid); rec.children.push_back(children[k]);
+	}
+	const uint32_t root = rec.ids[0];
+	for (uint32_t k = 0; k < n; ++k) { w->hb[rec.ids[k]].comp_root = root; w->hb[rec.ids[k]].comp_child = k; }
+	w->n_alive -= (n - 1);                 // one object, however many slots
+	w->compounds[root] = std::move(rec);
+	*id_out = root;
+	return SGP_OK;
+}
+SGP_API int sgp_body_compound_size(sgp_world* w, uint32_t id, uint32_t* n_out)
+{
+	if (!live(w, id) || !n_out) return fail(SGP_ERR_BAD_ID, "sgp_body_compound_size: id not live");
+	const CompoundRec* c = compound_of(w, id);
+	*n_out = c ? (uint32_t)c->ids.size() : 0u;
+	return SGP_OK;
+}
+
 static BodyCmd blank_cmd(uint32_t id, uint32_t ops) { BodyCmd c; memset(&c, 0, sizeof(c)); c.id = id; c.ops = ops; return c; }
 static inline bool is_mesh_body(const sgp_world* w, uint32_t id) { return ((w->hb[id].flags & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT) == SGP_SHAPE_MESH && !(w->hb[id].flags & BF_ALIAS); }
 // queue a pose edit; a static mesh body owns the two alias slots behind it (second / third contact manifold of a pair), which share its pose
-static void push_pose_cmd(sgp_world* w, const BodyCmd& c)
+static void push_pose_cmd_one(sgp_world* w, const BodyCmd& c)
 {
 	w->cmds.push_back(c);
 	if (is_mesh_body(w, c.id)) for (uint32_t k = 1; k <= 2; ++k) { BodyCmd a = c; a.id = c.id + k; a.ops &= (CMD_SET_POS | CMD_SET_ROT); w->cmds.push_back(a); }
 }
+// ... and a compound moves all its children: each gets the compound's new pose composed with its own
+static void push_pose_cmd(sgp_world* w, const BodyCmd& c)
+{
+	CompoundRec* rec = compound_of(w, c.id);
+	if (!rec) { push_pose_cmd_one(w, c); return; }
+	if (c.ops & CMD_SET_POS) memcpy(rec->pos, c.pos, 12);
+	if (c.ops & CMD_SET_ROT) memcpy(rec->rot, c.rot, 16);
+	for (size_t k = 0; k < rec->ids.size(); ++k) {
+		BodyCmd a = c; a.id = rec->ids[k];
+		a.ops &= ~(CMD_SET_SHAPE | CMD_SET_VEL);
+		if (c.ops & (CMD_SET_POS | CMD_SET_ROT)) { a.ops |= CMD_SET_POS | CMD_SET_ROT; compound_child_pose(rec->pos, rec->rot, rec->children[k], a.pos, a.rot); }
+		push_pose_cmd_one(w, a);
+	}
+}
+// compound ids reported by queries and events: a child's slot -> the compound's id (+ the child index)
+static inline uint32_t compound_id_of(const sgp_world* w, uint32_t id, uint32_t* sub_out)
+{
+	const HostBody& b = w->hb[id];
+	if (b.comp_root == SGP_INVALID_ID) { if (sub_out) *sub_out = 0; return id; }
+	if (sub_out) *sub_out = b.comp_child;
+	return b.comp_root;
+}
+#define REJECT_COMPOUND_CHILD(what) do { if (is_compound_child(w, id)) return fail(SGP_ERR_BAD_ID, what ": the id is a child slot of a compound body; use the compound's id"); } while (0)
 
 SGP_API int sgp_body_remove(sgp_world* w, uint32_t id)
 {
 	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_remove: id not live");
+	if (is_compound_child(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_remove: a compound's child is removed with the compound");
+	if (CompoundRec* c = compound_of(w, id)) {
+		const std::vector<uint32_t> ids = c->ids;
+		w->compounds.erase(id);
+		for (uint32_t k : ids) w->hb[k].comp_root = SGP_INVALID_ID;
+		for (size_t k = 1; k < ids.size(); ++k) { const int r = sgp_body_remove(w, ids[k]); if (r != SGP_OK) return r; w->n_alive++; }
+		// (falls through: the first child's slot is removed like any body and accounts for the one object)
+	}
 	for (uint32_t v = 0; v < w->n_vehicles; ++v) if (w->veh_alive[v] && w->veh_body[v] == id) sgp_vehicle_destroy(w, v);   // a vehicle does not outlive its chassis
 	if (w->hb[id].flags & BF_LARGE) { w->large_ids.erase(std::remove(w->large_ids.begin(), w->large_ids.end(), id), w->large_ids.end()); w->large_dirty = true; }
 	if (w->hb[id].flags & BF_ALIAS) return fail(SGP_ERR_BAD_ID, "sgp_body_remove: id not live");
@@ -533,15 +627,22 @@ SGP_API int sgp_body_get_userdata(sgp_world* w, uint32_t id, uint64_t* userdata_
 SGP_API int sgp_body_set_layer(sgp_world* w, uint32_t id, int32_t layer)
 {
 	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_set_layer: id not live");
-	BodyCmd c = blank_cmd(id, CMD_SET_LAYER); c.flags = (uint32_t)layer & 0x3u;
-	w->hb[id].flags = (w->hb[id].flags & ~BF_LAYER_MASK) | (((uint32_t)layer & 0x3u) << BF_LAYER_SHIFT);
-	w->cmds.push_back(c);
+	REJECT_COMPOUND_CHILD("sgp_body_set_layer");
+	const CompoundRec* rec = compound_of(w, id);
+	const size_t n = rec ? rec->ids.size() : 1;
+	for (size_t k = 0; k < n; ++k) {
+		const uint32_t b = rec ? rec->ids[k] : id;
+		BodyCmd c = blank_cmd(b, CMD_SET_LAYER); c.flags = (uint32_t)layer & 0x3u;
+		w->hb[b].flags = (w->hb[b].flags & ~BF_LAYER_MASK) | (((uint32_t)layer & 0x3u) << BF_LAYER_SHIFT);
+		w->cmds.push_back(c);
+	}
 	return SGP_OK;
 }
 SGP_API int sgp_body_set_pose_vel(sgp_world* w, uint32_t id, const float pos[3], const float rot[4], const float lv[3], const float av[3])
 {
 	REQUIRE_FINITE(pos && rot && lv && av && finite3(pos) && finite4(rot) && finite3(lv) && finite3(av), "sgp_body_set_pose_vel");
 	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_set_pose_vel: id not live");
+	REJECT_COMPOUND_CHILD("sgp_body_set_pose_vel");
 	BodyCmd c = blank_cmd(id, CMD_SET_POS | CMD_SET_ROT | CMD_SET_VEL);
 	memcpy(c.pos, pos, 12); memcpy(c.rot, rot, 16); memcpy(c.linv, lv, 12); memcpy(c.angv, av, 12);
 	push_pose_cmd(w, c);
@@ -593,10 +694,11 @@ SGP_API int sgp_body_set_pose_shape(sgp_world* w, uint32_t id, const float pos[3
 {
 	REQUIRE_FINITE(pos && rot && shape && finite3(pos) && finite4(rot) && finite4(shape), "sgp_body_set_pose_shape");
 	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_set_pose_shape: id not live");
+	REJECT_COMPOUND_CHILD("sgp_body_set_pose_shape");
 	BodyCmd c = blank_cmd(id, CMD_SET_POS | CMD_SET_ROT | CMD_SET_VEL | CMD_SET_SHAPE | CMD_ACTIVATE);
 	memcpy(c.pos, pos, 12); memcpy(c.rot, rot, 16); memcpy(c.shape, shape, 16);
 	const int type = (int)((w->hb[id].flags & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT);
-	if (type == SGP_SHAPE_HULL || type == SGP_SHAPE_MESH) c.ops &= ~CMD_SET_SHAPE;          // hulls and meshes are pre-scaled (shape.x = table id): only the pose changes
+	if (type == SGP_SHAPE_HULL || type == SGP_SHAPE_MESH || compound_of(w, id)) c.ops &= ~CMD_SET_SHAPE;          // hulls, meshes and compounds are pre-scaled (shape.x = table id): only the pose changes
 	else {
 		note_radius(w, id, bounding_radius(type, shape));
 		w->hb[id].volume = host_shape_volume(type, shape);
@@ -609,6 +711,7 @@ SGP_API int sgp_body_set_pos(sgp_world* w, uint32_t id, const float pos[3])
 {
 	REQUIRE_FINITE(pos && finite3(pos), "sgp_body_set_pos");
 	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_set_pos: id not live");
+	REJECT_COMPOUND_CHILD("sgp_body_set_pos");
 	BodyCmd c = blank_cmd(id, CMD_SET_POS); memcpy(c.pos, pos, 12);
 	push_pose_cmd(w, c);
 	return SGP_OK;
@@ -754,6 +857,7 @@ static int collect_events(sgp_world* w, bool counters_fresh = false)
 		for (uint32_t k = 0; k < l.n; ++k) { sgp_contact_event e = src[k];
 			while (e.id1 > 0 && (w->hb[e.id1].flags & BF_ALIAS)) --e.id1;       // a mesh body's alias slots report as the mesh body
 			while (e.id2 > 0 && (w->hb[e.id2].flags & BF_ALIAS)) --e.id2;
+			e.id1 = compound_id_of(w, e.id1, nullptr); e.id2 = compound_id_of(w, e.id2, nullptr);   // a compound's children report as the compound
 			e.userdata1 = w->hb[e.id1].userdata; e.userdata2 = w->hb[e.id2].userdata; l.out->push_back(e); }
 	}
 	HIP_TRY(hipMemsetAsync(d.evc, 0, sizeof(EventCounters), w->stream));
@@ -1676,7 +1780,11 @@ SGP_API int sgp_raycast(sgp_world* w, const sgp_ray* rays, uint32_t n, sgp_hit* 
 		HIP_TRY(hipStreamSynchronize(w->stream));
 	}
 	memcpy(hits, (char*)w->stage_host + rb, sizeof(sgp_hit) * n);
-	for (uint32_t k = 0; k < n; ++k) hits[k].userdata = hits[k].id != SGP_INVALID_ID ? w->hb[hits[k].id].userdata : 0;
+	for (uint32_t k = 0; k < n; ++k) {
+		hits[k].userdata = hits[k].id != SGP_INVALID_ID ? w->hb[hits[k].id].userdata : 0;
+		hits[k].sub_shape = 0;
+		if (hits[k].id != SGP_INVALID_ID) hits[k].id = compound_id_of(w, hits[k].id, &hits[k].sub_shape);
+	}
 	return SGP_OK;
 }
 
@@ -1718,8 +1826,8 @@ SGP_API int sgp_collide_capsules(sgp_world* w, const sgp_capsule_query* qs, uint
 	std::sort(h, h + m, [](const sgp_query_contact& a, const sgp_query_contact& b) {
 		if (a.query != b.query) return a.query < b.query;
 		if (a.body != b.body) return a.body < b.body;
-		return a.pad < b.pad; });
-	for (uint32_t i = 0; i < m; ++i) { h[i].pad = 0; h[i].userdata = w->hb[h[i].body].userdata; }
+		return a.sub_shape < b.sub_shape; });         // (the kernel leaves the contact's point index in this field)
+	for (uint32_t i = 0; i < m; ++i) { h[i].userdata = w->hb[h[i].body].userdata; h[i].body = compound_id_of(w, h[i].body, &h[i].sub_shape); }
 	memcpy(out, h, sizeof(sgp_query_contact) * m);
 	*n_out = cnt;
 	return SGP_OK;
@@ -1742,7 +1850,11 @@ SGP_API int sgp_spherecast(sgp_world* w, const sgp_ray* rays, const float* radii
 	HIP_TRY(hipMemcpyAsync((char*)w->stage_host + rb + fb, dh, sizeof(sgp_hit) * n, hipMemcpyDeviceToHost, w->stream));
 	HIP_TRY(hipStreamSynchronize(w->stream));
 	memcpy(hits, (char*)w->stage_host + rb + fb, sizeof(sgp_hit) * n);
-	for (uint32_t k = 0; k < n; ++k) hits[k].userdata = hits[k].id != SGP_INVALID_ID ? w->hb[hits[k].id].userdata : 0;
+	for (uint32_t k = 0; k < n; ++k) {
+		hits[k].userdata = hits[k].id != SGP_INVALID_ID ? w->hb[hits[k].id].userdata : 0;
+		hits[k].sub_shape = 0;
+		if (hits[k].id != SGP_INVALID_ID) hits[k].id = compound_id_of(w, hits[k].id, &hits[k].sub_shape);
+	}
 	return SGP_OK;
 }
 

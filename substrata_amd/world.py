@@ -91,6 +91,21 @@ class CWorld:
         self._check(self._fn("body_add_batch")(self._h, descs.ctypes.data, len(descs), ids.ctypes.data), "body_add_batch")
         return ids
 
+    def add_compound(self, base_desc, children):
+        """StaticCompoundShapeSettings::AddShape x n + Create on a static body (MeshBuilding.cpp:396-407).  base_desc: one record of
+        abi.body_desc_dtype (pose, layer, material, userdata); children: array of abi.compound_child_dtype.  Returns the compound's id."""
+        base = np.ascontiguousarray(base_desc, dtype=abi.body_desc_dtype).reshape(-1)[:1].copy()
+        ch = np.ascontiguousarray(children, dtype=abi.compound_child_dtype)
+        out = C.c_uint32(abi.INVALID_ID)
+        self._check(self._fn("body_add_compound")(self._h, C.cast(base.ctypes.data, C.POINTER(abi.BodyDesc)), ch.ctypes.data, len(ch), C.byref(out)),
+                    "body_add_compound")
+        return out.value
+
+    def compound_size(self, i):
+        n = C.c_uint32(0)
+        self._check(self._fn("body_compound_size")(self._h, int(i), C.byref(n)), "body_compound_size")
+        return n.value
+
     def remove(self, i):
         self._check(self._fn("body_remove")(self._h, int(i)), "body_remove")
 
