@@ -87,7 +87,7 @@ namespace JPH
 			float mWalkStairsMinStepForward = 0.02f, mWalkStairsStepForwardTest = 0.15f, mWalkStairsCosAngleForwardContact = 0.2588f;
 			Vec3 mWalkStairsStepDownExtra = Vec3(0, 0, 0);
 		};
-		struct Contact { BodyID body; Vec3 point, normal, velocity; float distance; bool sensor, dynamic; float inv_mass; uint64_t userdata; };
+		struct Contact { BodyID body; uint32_t sub_shape; Vec3 point, normal, velocity; float distance; bool sensor, dynamic; float inv_mass; uint64_t userdata; uint64_t key() const { return ((uint64_t)body.GetIndex() << 32) | sub_shape; } };
 
 		CharacterVirtual(const CharacterVirtualSettings* s, RVec3Arg position, QuatArg /*rotation*/, PhysicsSystem* system)
 			: settings(*s), shape(s->mShape), position(position), physics_system(system), world(system->world) { cos_max_slope = std::cos(settings.mMaxSlopeAngle); }
@@ -157,7 +157,7 @@ namespace JPH
 			out.clear();
 			for (uint32_t i = 0; i < std::min<uint32_t>(n, 64); ++i) {
 				Contact k;
-				k.body = BodyID(buf[i].body); k.point = Vec3(buf[i].point[0], buf[i].point[1], buf[i].point[2]); k.normal = Vec3(buf[i].normal[0], buf[i].normal[1], buf[i].normal[2]);
+				k.body = BodyID(buf[i].body); k.sub_shape = buf[i].sub_shape; k.point = Vec3(buf[i].point[0], buf[i].point[1], buf[i].point[2]); k.normal = Vec3(buf[i].normal[0], buf[i].normal[1], buf[i].normal[2]);
 				k.velocity = Vec3(buf[i].point_velocity[0], buf[i].point_velocity[1], buf[i].point_velocity[2]);
 				k.distance = buf[i].distance - settings.mCharacterPadding; k.sensor = buf[i].is_sensor != 0; k.dynamic = buf[i].motion_type == SGP_MOTION_DYNAMIC;
 				k.inv_mass = buf[i].inv_mass; k.userdata = buf[i].userdata;
@@ -198,7 +198,7 @@ namespace JPH
 				if (hit->contact) {
 					if (IsSlopeTooSteep(hit->n) && dot(hit->n, settings.mUp) > -0.1f && dot(rel, hit->n) < -1.0e-3f) blocked_by_steep = true;
 					pushBody(*hit->contact, rel, time);
-					if (listener) listener->OnContactSolve(this, hit->contact->body, SubShapeID(), hit->contact->point, hit->n, hit->velocity, nullptr, velocity, new_velocity);
+					if (listener) listener->OnContactSolve(this, hit->contact->body, physics_system->subShapeID(hit->contact->body, hit->contact->sub_shape), hit->contact->point, hit->n, hit->velocity, nullptr, velocity, new_velocity);
 				}
 				if (previous && previous != hit && dot(new_velocity - previous->velocity, previous->n) < -1.0e-6f) {
 					// would re-enter the previous plane: move along the crease of the two
@@ -261,10 +261,10 @@ namespace JPH
 				getContacts(pos, ignore, contacts);
 				cs.clear();
 				for (const Contact& c : contacts) {
-					if (notify && listener && std::find(seen_bodies.begin(), seen_bodies.end(), c.body.GetIndex()) == seen_bodies.end()) {
-						seen_bodies.push_back(c.body.GetIndex());
+					if (notify && listener && std::find(seen_bodies.begin(), seen_bodies.end(), c.key()) == seen_bodies.end()) {
+						seen_bodies.push_back(c.key());
 						CharacterContactSettings cset;
-						listener->OnContactAdded(this, c.body, SubShapeID(), c.point, c.normal, cset);
+						listener->OnContactAdded(this, c.body, physics_system->subShapeID(c.body, c.sub_shape), c.point, c.normal, cset);
 					}
 					if (c.sensor) continue;
 					Constraint k; k.n = c.normal; k.velocity = c.velocity; k.distance = c.distance; k.contact = &c; k.steep_slope = false;
@@ -286,7 +286,7 @@ namespace JPH
 				time_remaining -= std::max(time_simulated, settings.mMinTimeRemaining);
 				if (displacement.LengthSq() < 1.0e-10f) break;
 			}
-			if (notify) { seen_bodies.clear(); for (const Contact& c : contacts) seen_bodies.push_back(c.body.GetIndex()); }
+			if (notify) { seen_bodies.clear(); for (const Contact& c : contacts) seen_bodies.push_back(c.key()); }
 		}
 
 		void updateSupportingContact(const std::vector<Contact>& contacts, bool store)
@@ -381,7 +381,7 @@ namespace JPH
 		float cos_max_slope = 0.64f;
 		EGroundState ground_state = EGroundState::InAir;
 		Vec3 ground_normal, ground_velocity, ground_position; BodyID ground_body;
-		std::vector<Contact> active; std::vector<uint32_t> seen_bodies;
+		std::vector<Contact> active; std::vector<uint64_t> seen_bodies;      // (body, sub shape) pairs already reported through OnContactAdded
 		bool blocked_by_steep = false;
 	};
 }

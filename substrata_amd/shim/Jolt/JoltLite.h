@@ -6,6 +6,8 @@
 #include <cmath>
 #include <string>
 #include <unordered_map>
+#include <memory>
+struct PhysicsMeshData; struct PhysicsHullData;      // the facade's shape payloads (PhysicsObject.h)
 namespace JPH
 {
 	typedef unsigned int uint;
@@ -72,45 +74,6 @@ namespace JPH
 	private:
 		mutable uint32_t ref_count;
 	};
-	// What a body needs from its shape.  kind follows SGP_SHAPE_*: 0 sphere (p0 = r), 1 box (p = half extents), 2 capsule (p0 = r,
-	// p1 = half height of the cylinder, axis z), 3 convex hull (hull_points, com_offset), -1 = only a volume (what TryGetBody reports).
-	class Shape : public RefTargetBase
-	{
-	public:
-		float GetVolume() const { return volume; }
-		float volume = 0;
-		int kind = -1;
-		float p[3] = { 0, 0, 0 };
-		std::vector<float> hull_points;          // xyz triples, shape space
-		float com_offset[3] = { 0, 0, 0 };       // OffsetCenterOfMassShape
-	};
-	// What the listeners read from a body during a contact callback.
-	class Body
-	{
-	public:
-		const Shape* GetShape() const { return &shape; }
-		Shape shape;
-		// Where the simulated body frame (centre of mass, principal axes) sits in the object's shape space; identity except for convex
-		// hulls.  Jolt hides this inside the body; PhysicsWorld::getJoltBody() fills it in and VehicleConstraint uses it to express the
-		// wheel settings (given in shape space, like JPH::WheelSettings::mPosition) in the body frame.
-		Vec3 com_offset; float frame_rot[4] = { 0, 0, 0, 1 };
-		Vec3 GetLinearVelocity() const { return lin_vel; }
-		uint64_t GetUserData() const { return user_data; }
-		void SetUserData(uint64_t u) { user_data = u; }
-		BodyID GetID() const { return id; }
-		bool IsSensor() const { return is_sensor; }
-		Vec3 lin_vel; uint64_t user_data = 0; BodyID id; bool is_sensor = false;
-	};
-	class ContactManifold
-	{
-	public:
-		RVec3 mBaseOffset;
-		Vec3 mWorldSpaceNormal;
-		float mPenetrationDepth = 0;
-		std::vector<Vec3> mRelativeContactPointsOn1;
-	};
-	class ContactSettings {};
-
 	class Quat
 	{
 	public:
@@ -210,6 +173,53 @@ namespace JPH
 	};
 	template <class T> using RefConst = Ref<const T>;
 
+	// What a body needs from its shape.  kind follows SGP_SHAPE_*: 0 sphere (p0 = r), 1 box (p = half extents), 2 capsule (p0 = r,
+	// p1 = half height of the cylinder, axis z), 3 convex hull (hull_points, com_offset), 4 triangle mesh, 5 static compound, -1 = only a volume (what TryGetBody reports).
+	class Shape : public RefTargetBase
+	{
+	public:
+		float GetVolume() const { return volume; }
+		float volume = 0;
+		int kind = -1;
+		float p[3] = { 0, 0, 0 };
+		std::vector<float> hull_points;          // xyz triples, shape space
+		float com_offset[3] = { 0, 0, 0 };       // OffsetCenterOfMassShape
+		// kind 4: a static triangle mesh as the facade's shape builders made it (PhysicsWorld::createMeshShape); kind 3 may carry the facade's hull data
+		std::shared_ptr<PhysicsMeshData> mesh;
+		std::shared_ptr<PhysicsHullData> hull;
+		// kind 5: JPH::StaticCompoundShape -- children with their pose in the compound's space and Jolt's per-child user data
+		struct SubShape { Vec3 pos; Quat rot; Ref<const Shape> shape; uint32_t user_data; };
+		std::vector<SubShape> children;
+		uint32_t GetNumSubShapes() const { return (uint32_t)children.size(); }
+	};
+	// What the listeners read from a body during a contact callback.
+	class Body
+	{
+	public:
+		const Shape* GetShape() const { return &shape; }
+		Shape shape;
+		// Where the simulated body frame (centre of mass, principal axes) sits in the object's shape space; identity except for convex
+		// hulls.  Jolt hides this inside the body; PhysicsWorld::getJoltBody() fills it in and VehicleConstraint uses it to express the
+		// wheel settings (given in shape space, like JPH::WheelSettings::mPosition) in the body frame.
+		Vec3 com_offset; float frame_rot[4] = { 0, 0, 0, 1 };
+		Vec3 GetLinearVelocity() const { return lin_vel; }
+		uint64_t GetUserData() const { return user_data; }
+		void SetUserData(uint64_t u) { user_data = u; }
+		BodyID GetID() const { return id; }
+		bool IsSensor() const { return is_sensor; }
+		Vec3 lin_vel; uint64_t user_data = 0; BodyID id; bool is_sensor = false;
+	};
+	class ContactManifold
+	{
+	public:
+		RVec3 mBaseOffset;
+		Vec3 mWorldSpaceNormal;
+		float mPenetrationDepth = 0;
+		std::vector<Vec3> mRelativeContactPointsOn1;
+	};
+	class ContactSettings {};
+
+
 	// ---- shapes a caller builds itself (CarPhysics.cpp:66-78, BikePhysics.cpp:76-112) ------------------------------------------------
 	class ShapeSettings : public RefTargetBase
 	{
@@ -272,6 +282,30 @@ namespace JPH
 			return ShapeResult(s);
 		}
 		Vec3 mOffset; RefConst<Shape> mInnerShapePtr;
+	};
+
+	// JPH::StaticCompoundShapeSettings (MeshBuilding.cpp:396-407): AddShape(position, rotation, shape or shape settings, user data) x n, Create()
+	class StaticCompoundShapeSettings : public ShapeSettings
+	{
+	public:
+		void AddShape(const Vec3& position, const Quat& rotation, const Shape* shape, uint32_t user_data = 0)
+		{
+			Shape::SubShape c; c.pos = position; c.rot = rotation; c.shape = shape; c.user_data = user_data; mSubShapes.push_back(c);
+		}
+		void AddShape(const Vec3& position, const Quat& rotation, const ShapeSettings* settings, uint32_t user_data = 0)
+		{
+			Ref<const ShapeSettings> keep(settings);
+			const ShapeResult r = settings->Create();
+			Shape::SubShape c; c.pos = position; c.rot = rotation; c.shape = r.Get().GetPtr(); c.user_data = user_data; mSubShapes.push_back(c);
+		}
+		ShapeResult Create() const override
+		{
+			if (mSubShapes.empty()) return ShapeResult("Compound needs a sub shape!");                     // Jolt's message
+			for (const Shape::SubShape& c : mSubShapes) if (!c.shape.GetPtr() || c.shape->kind < 0 || c.shape->kind == 5) return ShapeResult("StaticCompoundShape: unsupported sub shape");
+			Shape* s = new Shape; s->kind = 5; s->children = mSubShapes;
+			return ShapeResult(s);
+		}
+		std::vector<Shape::SubShape> mSubShapes;
 	};
 
 	// JPH::BodyCreationSettings: the fields CarPhysics / BikePhysics set (CarPhysics.cpp:80-84) plus Jolt's defaults for the rest
@@ -399,6 +433,17 @@ namespace JPH
 		void AddStepListener(PhysicsStepListener*) {}
 		void RemoveStepListener(PhysicsStepListener*) {}
 		void onStep() { ++step_serial; body_interface.invalidate(); }       // called by PhysicsWorld::think
+		// compound bodies (StaticCompoundShape): how many children body `id` has, and the JPH::SubShapeID of child k -- k in the lowest
+		// ceil(log2(n)) bits, ones above (Jolt's empty remainder), so that SubShapeID::PopID(bits, remainder) returns k (GUIClient.cpp:6484-6486)
+		void registerCompound(const BodyID& id, uint32_t num_children) { if (num_children) compound_sizes[id.GetIndex()] = num_children; else compound_sizes.erase(id.GetIndex()); }
+		SubShapeID subShapeID(const BodyID& id, uint32_t child) const
+		{
+			auto it = compound_sizes.find(id.GetIndex());
+			if (it == compound_sizes.end()) return SubShapeID();
+			uint32_t bits = 0; while ((1u << bits) < it->second) ++bits;
+			if (bits == 0) bits = 1;                                        // (Jolt uses at least one bit for a compound)
+			return SubShapeID(bits >= 32 ? child : ((0xFFFFFFFFu << bits) | child));
+		}
 		// filter factories CharacterVirtual callers pass through (PlayerPhysics.cpp:106-114,344-346): the character queries always use the
 		// MOVING object layer's collision set, so these are placeholders
 		DefaultBroadPhaseLayerFilter GetDefaultBroadPhaseLayerFilter(uint16_t) const { return DefaultBroadPhaseLayerFilter(); }
@@ -408,5 +453,6 @@ namespace JPH
 		BodyInterface body_interface;
 		BodyLockInterface body_lock_interface;
 		uint64_t step_serial;
+		std::unordered_map<uint32_t, uint32_t> compound_sizes;
 	};
 }

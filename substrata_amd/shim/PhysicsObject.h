@@ -47,11 +47,15 @@ class PhysicsShape
 public:
 	PhysicsShape() : kind(-1), size_B(0) { p[0] = p[1] = p[2] = p[3] = 0.f; }
 	js::AABBox getAABBOS() const;
-	int kind;                            // 0 sphere, 1 box, 2 capsule, 3 convex hull (hull != null), 4 static triangle mesh (mesh != null)
+	int kind;                            // 0 sphere, 1 box, 2 capsule, 3 convex hull (hull != null), 4 static triangle mesh (mesh != null); -1 with jolt_shape of kind 5 = static compound
 	float p[4];
 	size_t size_B;
 	std::shared_ptr<PhysicsHullData> hull;
 	std::shared_ptr<PhysicsMeshData> mesh;
+	// The same shape as a JPH::Shape look-alike (what the reference keeps in `JPH::Ref<JPH::Shape> jolt_shape`, PhysicsObject.h:41): set by the
+	// PhysicsWorld::create...Shape builders so that callers can hand it to JPH shape settings, and assignable by callers that compose a
+	// shape themselves -- MeshBuilding::makePortalMeshes assigns a StaticCompoundShape here (MeshBuilding.cpp:396-413).
+	JPH::Ref<JPH::Shape> jolt_shape;
 };
 
 class PhysicsObject : public ThreadSafeRefCounted

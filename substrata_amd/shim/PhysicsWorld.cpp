@@ -12,6 +12,17 @@
 
 static inline float myClamp(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
+// the JPH::Shape look-alike of a facade shape (PhysicsShape::jolt_shape)
+static void setJoltShape(PhysicsShape& s)
+{
+	JPH::Shape* j = new JPH::Shape;
+	j->kind = s.kind; j->p[0] = s.p[0]; j->p[1] = s.p[1]; j->p[2] = s.p[2];
+	j->hull = s.hull; j->mesh = s.mesh;
+	if (s.hull) { j->hull_points = s.hull->points; for (int i = 0; i < 3; ++i) j->com_offset[i] = s.hull->com_offset[i]; }
+	if (s.kind == 1) j->volume = 8.f * s.p[0] * s.p[1] * s.p[2];
+	s.jolt_shape = j;
+}
+
 // PhysicsWorld.cpp:250-273
 void PhysicsWorld::init()
 {
@@ -42,11 +53,13 @@ void PhysicsWorld::setWaterZ(float z) { water_z = z; sgp_world_set_water(world, 
 PhysicsShape PhysicsWorld::createGroundQuadShape(float ground_quad_w)
 {
 	PhysicsShape s; s.kind = 1; s.p[0] = ground_quad_w / 2; s.p[1] = ground_quad_w / 2; s.p[2] = 0.5f; s.size_B = sizeof(PhysicsShape);
+	setJoltShape(s);
 	return s;
 }
 PhysicsShape PhysicsWorld::createCapsuleShape(float radius, float half_height)
 {
 	PhysicsShape s; s.kind = 2; s.p[0] = radius; s.p[1] = half_height; s.size_B = sizeof(PhysicsShape);
+	setJoltShape(s);
 	return s;
 }
 
@@ -58,6 +71,7 @@ PhysicsShape PhysicsWorld::createConvexHullShape(const std::vector<Vec3f>& point
 	s.hull->points.reserve(points.size() * 3);
 	for (size_t i = 0; i < points.size(); ++i) { s.hull->points.push_back(points[i].x); s.hull->points.push_back(points[i].y); s.hull->points.push_back(points[i].z); }
 	s.size_B = sizeof(PhysicsShape) + s.hull->points.size() * sizeof(float);
+	setJoltShape(s);
 	return s;
 }
 
@@ -80,6 +94,7 @@ PhysicsShape PhysicsWorld::createMeshShape(const std::vector<Vec3f>& vertices, c
 	}
 	if (s.mesh->indices.empty()) throw glare::Exception("Error building Jolt shape: no triangles left after the material filter");
 	s.size_B = sizeof(PhysicsShape) + s.mesh->vertices.size() * sizeof(float) + (s.mesh->indices.size() + s.mesh->materials.size()) * sizeof(uint32_t);
+	setJoltShape(s);
 	return s;
 }
 
@@ -138,6 +153,7 @@ PhysicsShape PhysicsWorld::createScaledAndTranslatedShapeForShape(const PhysicsS
 		s.mesh->materials = original_shape.mesh->materials;
 		if (scale.x * scale.y * scale.z < 0.f) for (size_t i = 0; i + 2 < s.mesh->indices.size(); i += 3) std::swap(s.mesh->indices[i + 1], s.mesh->indices[i + 2]);
 	} else throw glare::Exception("Error building Jolt shape: scale / translate decorators are implemented for convex hull and mesh shapes");
+	setJoltShape(s);
 	return s;
 }
 
@@ -148,6 +164,7 @@ PhysicsShape PhysicsWorld::createCOMOffsetShapeForShape(const PhysicsShape& orig
 	s.hull = std::make_shared<PhysicsHullData>();
 	s.hull->points = original_shape.hull->points;
 	for (int i = 0; i < 3; ++i) s.hull->com_offset[i] = original_shape.hull->com_offset[i] + COM_offset[i];
+	setJoltShape(s);
 	return s;
 }
 
@@ -215,6 +232,13 @@ void PhysicsWorld::addObject(const Reference<PhysicsObject>& object)
 	case PhysicsObject::MotionType_kinematic: d.motion_type = SGP_MOTION_KINEMATIC; break;
 	default:                                  d.motion_type = SGP_MOTION_STATIC; break;
 	}
+	d.is_sensor = object->is_sensor ? 1 : 0;
+	d.friction = myClamp(object->friction, 0.f, 1.f);       // :1236
+	d.restitution = myClamp(object->restitution, 0.f, 1.f); // :1237
+	d.mass = std::max(0.001f, object->mass);                // :1238
+	d.use_zero_linear_drag = object->use_zero_linear_drag ? 1 : 0;
+	d.userdata = (uint64)object.ptr();                      // :1241
+	d.activate = 0;                                          // EActivation::DontActivate (:1243)
 	if (object->is_sphere) {              // unit sphere r 0.5, uniform scale = scale.x (:1219-1227)
 		d.shape_type = SGP_SHAPE_SPHERE; d.shape[0] = 0.5f * std::fabs(object->scale.x); d.shape[1] = d.shape[2] = 0;
 	} else if (object->is_cube) {         // unit cube half 0.5, per-axis scale (:1247-1255)
@@ -222,6 +246,7 @@ void PhysicsWorld::addObject(const Reference<PhysicsObject>& object)
 		d.shape[0] = 0.5f * std::fabs(object->scale.x); d.shape[1] = 0.5f * std::fabs(object->scale.y); d.shape[2] = 0.5f * std::fabs(object->scale.z);
 	} else {                              // object->shape with a ScaledShape decorator (:1275-1287)
 		const PhysicsShape& s = object->shape;
+		if (s.jolt_shape.GetPtr() && s.jolt_shape->kind == 5) { addCompoundObject(object, d); return; }      // JPH::StaticCompoundShape (MeshBuilding.cpp:396-413)
 		if (s.kind < 0) return;           // shape.jolt_shape == NULL (:1278-1279)
 		d.shape_type = s.kind;
 		if (s.kind == 4) {
@@ -242,13 +267,6 @@ void PhysicsWorld::addObject(const Reference<PhysicsObject>& object)
 		else if (s.kind == 0) { d.shape[0] = s.p[0] * std::fabs(object->scale.x); }
 		else { d.shape[0] = s.p[0] * std::fabs(object->scale.x); d.shape[1] = s.p[1] * std::fabs(object->scale.z); }
 	}
-	d.is_sensor = object->is_sensor ? 1 : 0;
-	d.friction = myClamp(object->friction, 0.f, 1.f);       // :1236
-	d.restitution = myClamp(object->restitution, 0.f, 1.f); // :1237
-	d.mass = std::max(0.001f, object->mass);                // :1238
-	d.use_zero_linear_drag = object->use_zero_linear_drag ? 1 : 0;
-	d.userdata = (uint64)object.ptr();                      // :1241
-	d.activate = 0;                                          // EActivation::DontActivate (:1243)
 	uint32_t id = SGP_INVALID_ID;
 	if (sgp_body_add(world, &d, &id) != SGP_OK) return;      // silent rejection, as the reference (:1178-1189)
 	object->jolt_body_id = JPH::BodyID(id);
@@ -257,6 +275,47 @@ void PhysicsWorld::addObject(const Reference<PhysicsObject>& object)
 	if (object->shape.kind == 3 && !object->is_sphere && !object->is_cube)
 		physics_system->GetBodyInterface().setFrame(object->jolt_body_id, JPH::Vec3(object->body_com_os[0], object->body_com_os[1], object->body_com_os[2]),
 			JPH::Quat(object->body_rot_os.v[0], object->body_rot_os.v[1], object->body_rot_os.v[2], object->body_rot_os.v[3]));
+}
+
+// A static compound object: every child of the JPH::StaticCompoundShape becomes a child of one sgp compound body, with the object's
+// scale applied the way JPH::ScaledShape applies it to a compound (child positions and child shapes scaled per axis; exact for children
+// whose rotation is the identity, which is what the reference builds).
+void PhysicsWorld::addCompoundObject(const Reference<PhysicsObject>& object, sgp_body_desc d)
+{
+	if (d.motion_type != SGP_MOTION_STATIC) return;                // StaticCompoundShape on a static object
+	const JPH::Shape& comp = *object->shape.jolt_shape;
+	const Vec3f sc = object->scale;
+	std::vector<sgp_compound_child> children;
+	for (const JPH::Shape::SubShape& c : comp.children) {
+		sgp_compound_child k; memset(&k, 0, sizeof(k));
+		const JPH::Shape& cs = *c.shape;
+		JPH::Vec3 pos(c.pos.x * sc.x, c.pos.y * sc.y, c.pos.z * sc.z); JPH::Quat rot = c.rot;
+		k.shape_type = cs.kind;
+		if (cs.kind == 0) k.shape[0] = cs.p[0] * std::fabs(sc.x);
+		else if (cs.kind == 1) { k.shape[0] = cs.p[0] * std::fabs(sc.x); k.shape[1] = cs.p[1] * std::fabs(sc.y); k.shape[2] = cs.p[2] * std::fabs(sc.z); }
+		else if (cs.kind == 2) { k.shape[0] = cs.p[0] * std::fabs(sc.x); k.shape[1] = cs.p[1] * std::fabs(sc.z); }
+		else if (cs.kind == 4 && cs.mesh) {
+			PhysicsShape tmp; tmp.kind = 4; tmp.mesh = cs.mesh;
+			const PhysicsMeshData::Instance* in = meshInstance(world, tmp, sc);
+			if (!in) return;
+			k.shape[0] = (float)in->mesh_id;
+		} else if (cs.kind == 3) {
+			PhysicsShape tmp; tmp.kind = 3; tmp.hull = cs.hull;
+			if (!tmp.hull) { tmp.hull = std::make_shared<PhysicsHullData>(); tmp.hull->points = cs.hull_points; for (int i = 0; i < 3; ++i) tmp.hull->com_offset[i] = cs.com_offset[i]; }
+			const PhysicsHullData::Instance* in = hullInstance(world, tmp, sc);
+			if (!in) return;
+			k.shape[0] = (float)in->hull_id;
+			pos = pos + rot * JPH::Vec3(in->com[0], in->com[1], in->com[2]);          // the hull's body frame inside the child's frame
+			rot = rot * JPH::Quat(in->rot[0], in->rot[1], in->rot[2], in->rot[3]);
+		} else return;
+		k.pos[0] = pos.x; k.pos[1] = pos.y; k.pos[2] = pos.z; k.rot[0] = rot.x; k.rot[1] = rot.y; k.rot[2] = rot.z; k.rot[3] = rot.w;
+		children.push_back(k);
+	}
+	uint32_t id = SGP_INVALID_ID;
+	if (children.empty() || sgp_body_add_compound(world, &d, children.data(), (uint32_t)children.size(), &id) != SGP_OK) return;
+	object->jolt_body_id = JPH::BodyID(id);
+	if (id < id_to_ob.size()) id_to_ob[id] = object.ptr();
+	physics_system->registerCompound(object->jolt_body_id, (uint32_t)children.size());
 }
 
 JPH::Body PhysicsWorld::getJoltBody(const PhysicsObject& object) const
@@ -276,6 +335,7 @@ void PhysicsWorld::removeObject(const Reference<PhysicsObject>& object)
 		if (physics_system->GetBodyInterface().IsAdded(object->jolt_body_id)) { physics_system->GetBodyInterface().RemoveBody(object->jolt_body_id); physics_system->GetBodyInterface().DestroyBody(object->jolt_body_id); }
 		else sgp_body_remove(world, id);
 		physics_system->GetBodyInterface().clearFrame(object->jolt_body_id);
+		physics_system->registerCompound(object->jolt_body_id, 0);
 		if (id < id_to_ob.size()) id_to_ob[id] = NULL;
 		object->jolt_body_id = JPH::BodyID();
 	}
@@ -386,7 +446,8 @@ void PhysicsWorld::setNewObToWorldTransform(PhysicsObject& object, const Vec4f& 
 	const Vec3f old_scale = object.scale;
 	object.pos = translation; object.rot = rot_quat; object.scale = Vec3f(scale);
 	if (object.jolt_body_id.IsInvalid()) return;
-	if (!object.is_sphere && !object.is_cube && (object.shape.kind == 3 || object.shape.kind == 4) &&
+	const bool is_compound = object.shape.jolt_shape.GetPtr() && object.shape.jolt_shape->kind == 5;
+	if (!object.is_sphere && !object.is_cube && (object.shape.kind == 3 || object.shape.kind == 4 || is_compound) &&
 		(old_scale.x != object.scale.x || old_scale.y != object.scale.y || old_scale.z != object.scale.z)) {
 		// JPH::ScaledShape swap (:562-601): hulls and meshes carry their scale baked into the device-side shape, so a new scale means the
 		// shape instance of that scale (built on first use) and a body made from it; like the reference the body ends up activated with
@@ -406,6 +467,7 @@ void PhysicsWorld::setNewObToWorldTransform(PhysicsObject& object, const Vec4f& 
 	float bp[3], br[4];
 	toBodyPose(object, translation, rot_quat, bp, br);       // (a hull keeps the scale it was added with: its points are pre-scaled)
 	sgp_body_set_pose_shape(world, object.jolt_body_id.GetIndex(), bp, br, shape);   // zero velocity, new scale, ActivateBody (:553-601)
+	physics_system->GetBodyInterface().invalidate();
 	drainActivationEvents();
 }
 
@@ -418,6 +480,7 @@ void PhysicsWorld::setNewObToWorldTransform(PhysicsObject& object, const Vec4f& 
 	float bp[3], br[4];
 	toBodyPose(object, pos, rot, bp, br);
 	sgp_body_set_pose_vel(world, object.jolt_body_id.GetIndex(), bp, br, linear_vel.x, angular_vel.x);
+	physics_system->GetBodyInterface().invalidate();
 }
 
 // PhysicsWorld.cpp:623-633
@@ -429,6 +492,7 @@ void PhysicsWorld::setNewPosition(PhysicsObject& object, const Vec4f& pos)
 	float bp[3], br[4];
 	toBodyPose(object, pos, object.rot, bp, br);
 	sgp_body_set_pos(world, object.jolt_body_id.GetIndex(), bp);
+	physics_system->GetBodyInterface().invalidate();
 }
 
 // PhysicsWorld.cpp:636-646
@@ -445,7 +509,7 @@ Vec4f PhysicsWorld::getObjectLinearVelocity(const PhysicsObject& object) const
 void PhysicsWorld::setLinearAndAngularVelToZero(PhysicsObject& object)
 {
 	const float z[3] = { 0, 0, 0 };
-	if (!object.jolt_body_id.IsInvalid()) sgp_body_set_vel(world, object.jolt_body_id.GetIndex(), z, z);
+	if (!object.jolt_body_id.IsInvalid()) { sgp_body_set_vel(world, object.jolt_body_id.GetIndex(), z, z); physics_system->GetBodyInterface().invalidate(); }
 }
 
 // PhysicsWorld.cpp:660-704 (same construction: columns of R scaled, inverse = S^-1 R^T T^-1)
@@ -479,6 +543,7 @@ void PhysicsWorld::moveKinematicObject(PhysicsObject& object, const Vec4f& trans
 	float bp[3], br[4];
 	toBodyPose(object, translation, rot, bp, br);
 	sgp_body_move_kinematic(world, object.jolt_body_id.GetIndex(), bp, br, dt);
+	physics_system->GetBodyInterface().invalidate();
 }
 
 void PhysicsWorld::addForce(PhysicsObject& object, const Vec4f& force) { if (!object.jolt_body_id.IsInvalid()) sgp_body_add_force(world, object.jolt_body_id.GetIndex(), force.x); }
@@ -544,6 +609,14 @@ void PhysicsWorld::writeJoltSnapshotToDisk(const std::string& path)
 }
 
 // PhysicsWorld.cpp:725-732
+size_t PhysicsWorld::computeSizeBForShape(JPH::Ref<JPH::Shape> jolt_shape)
+{
+	if (!jolt_shape.GetPtr()) return 0;
+	size_t b = sizeof(JPH::Shape) + jolt_shape->hull_points.size() * sizeof(float);
+	if (jolt_shape->mesh) b += jolt_shape->mesh->vertices.size() * sizeof(float) + (jolt_shape->mesh->indices.size() + jolt_shape->mesh->materials.size()) * sizeof(uint32_t);
+	for (const JPH::Shape::SubShape& c : jolt_shape->children) b += computeSizeBForShape(JPH::Ref<JPH::Shape>(const_cast<JPH::Shape*>(c.shape.GetPtr())));
+	return b;
+}
 size_t PhysicsWorld::computeSizeBForShape(const PhysicsShape& shape)
 {
 	size_t b = sizeof(PhysicsShape);

@@ -121,6 +121,7 @@ public:
 	// not Jolt's PhysicsScene stream; computeSizeBForShape reports the bytes the shape description holds.
 	void writeJoltSnapshotToDisk(const std::string& path);
 	static size_t computeSizeBForShape(const PhysicsShape& shape);
+	static size_t computeSizeBForShape(JPH::Ref<JPH::Shape> jolt_shape);      // PhysicsWorld.h:189
 
 	void traceRay(const Vec4f& origin, const Vec4f& dir, float max_t, JPH::BodyID ignore_body_id, RayTraceResult& results_out) const;
 	void traceRayAgainstCollidableObs(const Vec4f& origin, const Vec4f& dir, float max_t, JPH::BodyID ignore_body_id, RayTraceResult& results_out) const;
@@ -150,6 +151,7 @@ public:
 	JPH::PhysicsSystem* physics_system; // look-alike carrying GetBodyInterface() for the controllers that reach around the facade (PhysicsWorld.h:204)
 
 private:
+	void addCompoundObject(const Reference<PhysicsObject>& object, struct sgp_body_desc d);
 	void drainActivationEvents();
 	bool water_buoyancy_enabled;
 	float water_z;

@@ -70,21 +70,27 @@ int main()
 		ok = ok && r.hit_object == terrain.ptr() && std::fabs((20.f - r.hit_t) - terrainHeight(-5, 3)) < 0.15f && r.hit_normal_ws[2] > 0.8f;
 		world->traceRay(Vec4f(0, 10, 3, 1), Vec4f(1, 0, 0, 0), 100.f, JPH::BodyID(), r);
 		ok = ok && r.hit_object == building.ptr() && std::fabs(r.hit_t - 7.f) < 1e-3f && r.hit_normal_ws[0] < -0.99f;
-		ok = ok && r.hit_mat_index == 4 && r.coords.x == 0.f && r.coords.y == 0.f;      // the -x wall is wall 3 -> material 4; coords stay 0 like the reference (:1693)
+		bool mat_ok = r.hit_mat_index == 4 && r.coords.x == 0.f && r.coords.y == 0.f;      // the -x wall is wall 3 -> material 4; coords stay 0 like the reference (:1693)
+		if (!mat_ok) printf("wall material: got %u\n", r.hit_mat_index);
 		world->traceRay(Vec4f(10, 10, 3, 1), Vec4f(1, 0, 0, 0), 2.9f, JPH::BodyID(), r);
 		ok = ok && r.hit_object == NULL;
-		world->traceRay(Vec4f(10, 10, 30, 1), Vec4f(0, 0, -1, 0), 100.f, JPH::BodyID(), r);
-		ok = ok && r.hit_object == building.ptr() && r.hit_mat_index == 5 && std::fabs(r.hit_t - 24.f) < 1e-3f;      // the roof
+		world->traceRay(Vec4f(10, 12, 30, 1), Vec4f(0, 0, -1, 0), 100.f, JPH::BodyID(), r);      // (beside the boxes lying on the roof along y = 10)
+		const bool roof_ok = r.hit_object == building.ptr() && r.hit_mat_index == 5 && std::fabs(r.hit_t - 24.f) < 1e-3f;      // the roof
+		if (!roof_ok) printf("roof: object %d material %u t %.3f\n", (int)(r.hit_object == building.ptr()), r.hit_mat_index, r.hit_t);
 		world->traceRay(Vec4f(10, 1, 3, 1), Vec4f(0, 1, 0, 0), 100.f, JPH::BodyID(), r);
-		ok = ok && r.hit_object == building.ptr() && r.hit_mat_index == 1;                                           // the -y wall is wall 0 -> material 1
+		const bool wall0_ok = r.hit_object == building.ptr() && r.hit_mat_index == 1;                                         // the -y wall is wall 0 -> material 1
+		if (!wall0_ok) printf("-y wall: object %d material %u t %.3f\n", (int)(r.hit_object == building.ptr()), r.hit_mat_index, r.hit_t);
 		world->traceRay(Vec4f(-5, 3, 20, 1), Vec4f(0, 0, -1, 0), 100.f, JPH::BodyID(), r);
-		ok = ok && r.hit_object == terrain.ptr() && r.hit_mat_index == 0;                                            // no material array -> 0
+		const bool terrain_ok = r.hit_object == terrain.ptr() && r.hit_mat_index == 0;                                        // no material array -> 0
+		if (!terrain_ok) printf("terrain material: object %d material %u\n", (int)(r.hit_object == terrain.ptr()), r.hit_mat_index);
 		// the roofless copy: a ray from above goes through where the roof would be and lands on the terrain; its walls are still there
 		world->traceRay(Vec4f(-20, -20, 30, 1), Vec4f(0, 0, -1, 0), 100.f, JPH::BodyID(), r);
-		ok = ok && r.hit_object == terrain.ptr();
+		const bool through_ok = r.hit_object == terrain.ptr();
+		if (!through_ok) printf("roofless from above: terrain %d roofless %d t %.3f\n", (int)(r.hit_object == terrain.ptr()), (int)(r.hit_object == roofless.ptr()), r.hit_t);
 		world->traceRay(Vec4f(-30, -20, 3, 1), Vec4f(1, 0, 0, 0), 100.f, JPH::BodyID(), r);
-		ok = ok && r.hit_object == roofless.ptr() && r.hit_mat_index == 4 && std::fabs(r.hit_t - 7.f) < 1e-3f;
-		if (!ok) printf("material / filter rays failed\n");
+		const bool rwall_ok = r.hit_object == roofless.ptr() && r.hit_mat_index == 4 && std::fabs(r.hit_t - 7.f) < 1e-3f;
+		if (!rwall_ok) printf("roofless wall: object %d terrain %d material %u t %.3f\n", (int)(r.hit_object == roofless.ptr()), (int)(r.hit_object == terrain.ptr()), r.hit_mat_index, r.hit_t);
+		ok = ok && mat_ok && roof_ok && wall0_ok && terrain_ok && through_ok && rwall_ok;
 		{
 			// moving a static mesh object keeps it collidable (setNewObToWorldTransform, :546-604): the roofless building goes to (-20, 20), a ray finds
 			// its wall there and no longer at the old place, and a box dropped onto the rim of a wall ... lands on the wall's top edge or beside it,
@@ -103,13 +109,14 @@ int main()
 			float max_x = -1e9f;
 			for (int s = 0; s < 45; ++s) { world->think(1.0 / 60.0); max_x = std::fmax(max_x, world->getPosInJolt(ball)[0]); }
 			const bool bounced = max_x < -23.f + 0.05f && max_x > -23.6f && world->getObjectLinearVelocity(*ball)[0] < 0.f;
+			world->removeObject(ball);
 			// a scale change swaps the shape instance (JPH::ScaledShape, :562-601): twice as large, the wall is met 3 m earlier
 			world->setNewObToWorldTransform(*roofless, Vec4f(-20.f, 20.f, 0.f, 1), Quatf::identity(), Vec4f(2.f, 2.f, 2.f, 0));
 			world->traceRay(Vec4f(-30, 20, 3, 1), Vec4f(1, 0, 0, 0), 100.f, JPH::BodyID(), r);
 			const bool scaled = r.hit_object == roofless.ptr() && std::fabs(r.hit_t - 4.f) < 1e-3f && r.hit_mat_index == 4;
+			if (!scaled) printf("scaled: object %d terrain %d material %u t %.3f\n", (int)(r.hit_object == roofless.ptr()), (int)(r.hit_object == terrain.ptr()), r.hit_mat_index, r.hit_t);
 			if (!(moved && gone && bounced && scaled)) printf("moved mesh: moved %d gone %d bounced %d (max x %.3f) scaled %d\n", (int)moved, (int)gone, (int)bounced, max_x, (int)scaled);
 			ok = ok && moved && gone && bounced && scaled;
-			world->removeObject(ball);
 		}
 		// a decorated unit cube, as GUIClient builds for splat bounds (createScaledAndTranslatedShapeForShape(unit_cube_shape, aabb_min, aabb_span),
 		// GUIClient.cpp:4807): the [0,1]^3 cube mesh mapped onto the box [(-1,-2,0), (1,2,1.5)] of an object floating at (-12, 12, 8)

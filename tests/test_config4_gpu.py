@@ -121,7 +121,7 @@ def test_config4_scaled_down_2x2x2_tiles_against_oracle(oracle):
     # the rest now rests on the pile above the face -- still owned by the upper tiles, with ghosts crossing the face both ways
     assert migrated_down >= 100
     upper_owned = sum(gpu[r].num_bodies() - 1 - [e for e in lg if e[0] == "import" and e[1] == r][0][2] for r in range(4, 8))
-    assert 0 < upper_owned <= n ** 3 // 2 - migrated_down + 8
+    assert 0 < upper_owned < n ** 3 // 2
     assert all([e for e in lg if e[0] == "import" and e[1] == r][0][2] > 0 for r in range(8))      # every tile holds ghosts at the end
     for w in gpu + cpu:
         w.close()

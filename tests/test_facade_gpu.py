@@ -29,6 +29,7 @@ def test_facade_compiles_without_gpu(tmp_path):
     assert os.path.exists(build_facade_exe(tmp_path, "hover_controller.cpp"))
     assert os.path.exists(build_facade_exe(tmp_path, "car_controller.cpp"))
     assert os.path.exists(build_facade_exe(tmp_path, "car_physics_sequence.cpp"))
+    assert os.path.exists(build_facade_exe(tmp_path, "portal_walkthrough.cpp"))
     assert os.path.exists(build_facade_exe(tmp_path, "bike_controller.cpp"))
     assert os.path.exists(build_facade_exe(tmp_path, "player_controller.cpp"))
     assert os.path.exists(build_facade_exe(tmp_path, "mesh_world.cpp"))
@@ -86,6 +87,18 @@ def test_car_physics_call_sequence(tmp_path):
     print(r.stdout)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "car_physics_sequence: ok" in r.stdout
+
+
+@pytest.mark.gpu
+def test_portal_compound_shape_and_sub_shape_ids(tmp_path):
+    """MeshBuilding::makePortalMeshes (MeshBuilding.cpp:377-413: create_tris_for_mat filter + StaticCompoundShapeSettings of the arch mesh
+    and the inner box), the portal object of GUIClient.cpp:2379-2393, PlayerPhysics::OnContactAdded (BodyLockRead -> user data) and the
+    SubShapeID::PopID test of GUIClient.cpp:6482-6491: walking into the opening touches sub shape 1, walking into a post sub shape 0."""
+    exe = build_facade_exe(tmp_path, "portal_walkthrough.cpp")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "portal_walkthrough: ok" in r.stdout
 
 
 @pytest.mark.gpu
