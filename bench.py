@@ -409,6 +409,27 @@ def main():
             "contact_constraints": cst.num_manifolds, "host_cpus": os.cpu_count(),
         }
         cw.close()
+        # B1: real JoltPhysics v5.3.0 through oracle/_ref/oracle_jolt, only where a maintainer has built it (SGP_JOLT_DIR=...
+        # make -C oracle jolt_ref); the same snapshot, primitives only.  When present it becomes cpu_baseline (kind "reference") and the port
+        # is kept next to it.
+        jolt_bin = os.path.join(ROOT, "oracle", "_ref", "oracle_jolt")
+        if os.path.exists(jolt_bin) and not len(car_ids):
+            import subprocess
+            import tempfile
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import jolt_ref_io
+            with tempfile.TemporaryDirectory() as td:
+                scene, dump = os.path.join(td, "s.bin"), os.path.join(td, "d.bin")
+                jolt_ref_io.write_scene(scene, snap)
+                n_j = max(args.cpu_steps, 16)
+                r = subprocess.run([jolt_bin, scene, dump, "--steps", str(n_j), "--dt", repr(DT), "--checkpoints", str(n_j)], capture_output=True, text=True)
+                if r.returncode == 0:
+                    t = json.loads(r.stdout.strip().splitlines()[-1])
+                    out["cpu_baseline_port"] = out["cpu_baseline"]
+                    out["cpu_baseline"] = {"value": t["steps_per_s"], "unit": "steps/s", "cores": t["threads"], "kind": "reference",
+                                           "sample": f"{n_j} steps of the same snapshot through JoltPhysics {t.get('jolt')} (oracle/jolt_ref/oracle_jolt.cpp: PhysicsWorld's "
+                                                     f"constructor / addObject / think over the real Jolt API, JobSystemThreadPool with {t['threads']} threads)",
+                                           "host_cpus": os.cpu_count()}
     else:
         out["cpu_baseline"] = None
 
