@@ -347,7 +347,7 @@ int  sgp_raycast(sgp_world* w, const sgp_ray* rays, uint32_t n, sgp_hit* hits_ou
  * Replaces JPH::ConvexHullShapeSettings(points).Create() (+ OffsetCenterOfMassShape / the principal-axes decomposition Jolt does
  * inside MassProperties) for dynamic meshes and vehicle bodies (gui_client/PhysicsWorld.cpp:735-1166 with is_dynamic,
  * CarPhysics.cpp:66-92, BikePhysics.cpp:76-112).  Up to 32 hull vertices / 60 faces / 16 vertices per face; larger clouds are
- * reduced to their extreme points.  Points must already carry the object's scale (ScaledShape is baked in).
+ * reduced to their extreme points (every input point takes part, up to 100000).  Points must already carry the object's scale (ScaledShape is baked in).
  * The hull is stored in its BODY frame (origin = centre of mass, axes = principal axes of inertia).  `com` / `rot` give that
  * frame in the frame of the input points:  input point = com + rot * body point.  A caller that thinks in the points' frame
  * (object space) places the body at  pos_body = pos_obj + R_obj * com,  rot_body = rot_obj * rot. */
@@ -362,6 +362,8 @@ int  sgp_hull_create(sgp_world* w, const float* points_xyz, uint32_t num_points,
 /* The same wrapped in JPH::OffsetCenterOfMassShapeSettings(com_offset, hull) (PhysicsWorld.cpp:1138-1153, CarPhysics.cpp:76-78,
  * BikePhysics.cpp:103-105): the body's centre of mass sits at hull centre of mass + com_offset (frame of the points). */
 int  sgp_hull_create_com(sgp_world* w, const float* points_xyz, uint32_t num_points, const float com_offset[3], sgp_hull_info* info_out);
+/* The last JPH::Ref<JPH::Shape> to the hull going away: its id becomes reusable.  SGP_ERR_REJECTED while a body still uses it. */
+int  sgp_hull_destroy(sgp_world* w, uint32_t hull_id);
 
 /* ---- static triangle meshes ---------------------------------------------------
  * Replaces JPH::MeshShapeSettings(vertices, triangles).Create() for static mesh objects and -- through a triangulated grid --
@@ -374,6 +376,9 @@ typedef struct sgp_mesh_info {
 	float aabb_min[3], aabb_max[3];
 } sgp_mesh_info;
 int  sgp_mesh_create(sgp_world* w, const float* vertices_xyz, uint32_t num_vertices, const uint32_t* indices, uint32_t num_triangles, sgp_mesh_info* info_out);
+/* The last JPH::Ref<JPH::Shape> to the mesh going away: its id and its vertex / triangle / node storage become reusable (Substrata streams
+ * static meshes in and out as the camera moves).  SGP_ERR_REJECTED while a body still uses it. */
+int  sgp_mesh_destroy(sgp_world* w, uint32_t mesh_id);
 /* The same with one user-data word per triangle (JPH::IndexedTriangle::mMaterialIndex / MeshShape::GetTriangleUserData: the reference
  * stores the batch's material index there, PhysicsWorld.cpp:1032-1060), reported by ray hits.  NULL = all 0. */
 int  sgp_mesh_create_with_materials(sgp_world* w, const float* vertices_xyz, uint32_t num_vertices, const uint32_t* indices, uint32_t num_triangles,

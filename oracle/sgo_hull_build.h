@@ -53,6 +53,30 @@ static inline int sgo_hull_build(const float* pts_in, int n_in, const float* com
 	for (int i = 0; i < n_in; ++i) for (int k = 0; k < 3; ++k) { if (!isfinite(pts_in[3 * i + k])) return -1; ext = fmax(ext, fabs((double)pts_in[3 * i + k])); }
 	if (!(ext > 0.0)) return -1;
 	const double eps = 1.0e-5 * ext;
+	if (n_in > 256) {
+		/* a large cloud (a dynamic mesh with thousands of vertices): the extreme points of ALL input points along the fixed directions of
+		   step 2 plus the six axis directions -- every vertex takes part, wherever it sits in the array */
+		int cand[2 * SGO_HULL_MAX_VERTS + 6]; int nc = 0;
+		for (int kk = 0; kk < 2 * SGO_HULL_MAX_VERTS + 6 && nc < SGO_HULL_MAX_VERTS; ++kk) {
+			sgo_d3 dir;
+			if (kk < 6) { dir.x = dir.y = dir.z = 0.0; const double sg = (kk & 1) ? -1.0 : 1.0; if (kk / 2 == 0) dir.x = sg; else if (kk / 2 == 1) dir.y = sg; else dir.z = sg; }
+			else {
+				const int k = ((kk - 6) * 37) % (2 * SGO_HULL_MAX_VERTS);
+				const double z = 1.0 - (2.0 * k + 1.0) / (2.0 * SGO_HULL_MAX_VERTS), rr = sqrt(1.0 - z * z), ph = k * 2.399963229728653;
+				dir.x = rr * cos(ph); dir.y = rr * sin(ph); dir.z = z;
+			}
+			int bi = 0; double bd = -1.0e300;
+			for (int i = 0; i < n_in; ++i) { const double d = dir.x * pts_in[3 * i] + dir.y * pts_in[3 * i + 1] + dir.z * pts_in[3 * i + 2]; if (d > bd) { bd = d; bi = i; } }
+			int seen = 0;
+			for (int j = 0; j < nc; ++j) {
+				const sgo_d3 a = { pts_in[3 * bi], pts_in[3 * bi + 1], pts_in[3 * bi + 2] }, b = { pts_in[3 * cand[j]], pts_in[3 * cand[j] + 1], pts_in[3 * cand[j] + 2] };
+				const sgo_d3 d = sgo_d3_sub(a, b);
+				if (cand[j] == bi || sgo_d3_dot(d, d) < eps * eps) { seen = 1; break; }
+			}
+			if (!seen) cand[nc++] = bi;
+		}
+		for (int j = 0; j < nc; ++j) { const sgo_d3 p = { pts_in[3 * cand[j]], pts_in[3 * cand[j] + 1], pts_in[3 * cand[j] + 2] }; pts[n++] = p; }
+	} else
 	for (int i = 0; i < n_in && n < 256; ++i) {
 		const sgo_d3 p = { pts_in[3 * i], pts_in[3 * i + 1], pts_in[3 * i + 2] };
 		int dup = 0;

@@ -96,6 +96,8 @@ typedef struct sgo_world {
 	uint32_t cap, high;          /* capacity, high-water slot count */
 	sgo_body* bodies;
 	uint32_t* free_list; uint32_t n_free;
+	uint32_t* free_triples; uint32_t n_free_triples;      /* first slot of freed (mesh body + 2 alias) triples: the next mesh body reuses one */
+	uint32_t* free_mesh_ids; uint32_t n_free_mesh_ids; uint32_t* free_hull_ids; uint32_t n_free_hull_ids;      /* ids of destroyed shapes (reused last-in first-out) */
 	uint32_t n_alive;
 	/* pairs / constraints of the current and previous step */
 	sgo_pair* pairs; uint32_t n_pairs, cap_pairs;
@@ -366,6 +368,8 @@ SGO_API int sgo_world_create(const sgp_world_desc* desc, sgo_world** out)
 	w->cap = desc->max_bodies;
 	w->bodies = (sgo_body*)calloc(w->cap, sizeof(sgo_body));
 	w->free_list = (uint32_t*)malloc(sizeof(uint32_t) * w->cap);
+	w->free_triples = (uint32_t*)malloc(sizeof(uint32_t) * (w->cap / 3 + 1)); w->n_free_triples = 0;
+	w->free_mesh_ids = NULL; w->n_free_mesh_ids = 0; w->free_hull_ids = NULL; w->n_free_hull_ids = 0;
 	w->cell_keys = (uint64_t*)malloc(sizeof(uint64_t) * w->cap);
 	w->cell_idx = (uint32_t*)malloc(sizeof(uint32_t) * w->cap);
 	w->large = (uint32_t*)malloc(sizeof(uint32_t) * w->cap);
@@ -381,14 +385,14 @@ SGO_API int sgo_world_create(const sgp_world_desc* desc, sgo_world** out)
 SGO_API int sgo_world_destroy(sgo_world* w)
 {
 	if (!w) return SGP_ERR_INVALID;
-	free(w->bodies); free(w->free_list); free(w->pairs); free(w->cons); free(w->prev);
+	free(w->bodies); free(w->free_list); free(w->free_triples); free(w->free_mesh_ids); free(w->free_hull_ids); free(w->pairs); free(w->cons); free(w->prev);
 	free(w->prev_keys_sorted); free(w->prev_idx_sorted); free(w->order);
 	free(w->ev_act); free(w->ev_deact); free(w->ev_water); free(w->ev_added); free(w->ev_pers);
 	free(w->cell_keys); free(w->cell_idx); free(w->large); free(w->is_ghost); free(w->ghost_gid); free(w->ghost_lid);
 	free(w->vehicles);
-	for (uint32_t k = 0; k < w->n_hulls; ++k) free(w->hulls[k]);
+	for (uint32_t k = 0; k < w->n_hulls; ++k) free(w->hulls[k]);       /* (free(NULL) for destroyed hulls) */
 	free(w->hulls);
-	for (uint32_t k = 1; k < w->n_meshes; ++k) { free(w->meshes[k]->verts); free(w->meshes[k]->tris); free(w->meshes[k]); }
+	for (uint32_t k = 1; k < w->n_meshes; ++k) if (w->meshes[k]) { free(w->meshes[k]->verts); free(w->meshes[k]->tris); free(w->meshes[k]->mats); free(w->meshes[k]); }
 	free(w->meshes);
 	free(w);
 	return SGP_OK;
@@ -406,13 +410,13 @@ SGO_API int sgo_body_add(sgo_world* w, const sgp_body_desc* d, uint32_t* id_out)
 	const sgo_mesh* mesh = NULL;
 	if (d->shape_type == SGP_SHAPE_MESH) {
 		const uint32_t mid = (uint32_t)d->shape[0];
-		if (!(d->shape[0] >= 1.0f) || (float)mid != d->shape[0] || mid >= w->n_meshes) return SGP_ERR_INVALID;
+		if (!(d->shape[0] >= 1.0f) || (float)mid != d->shape[0] || mid >= w->n_meshes || !w->meshes[mid]) return SGP_ERR_INVALID;
 		if (d->motion_type != SGP_MOTION_STATIC) return SGP_ERR_INVALID;       /* JPH::MeshShape: static bodies only */
 		mesh = w->meshes[mid];
 	}
 	if (d->shape_type == SGP_SHAPE_HULL) {
 		const uint32_t hid = (uint32_t)d->shape[0];
-		if (!(d->shape[0] >= 1.0f) || (float)hid != d->shape[0] || hid >= w->n_hulls) return SGP_ERR_INVALID;   /* hull 0 is the internal cube template */
+		if (!(d->shape[0] >= 1.0f) || (float)hid != d->shape[0] || hid >= w->n_hulls || !w->hulls[hid]) return SGP_ERR_INVALID;   /* hull 0 is the internal cube template */
 		hull = w->hulls[hid];
 	} else if (d->shape_type == SGP_SHAPE_BOX) hull = w->hulls[0];
 	const int nparam = d->shape_type == SGP_SHAPE_BOX ? 3 : (d->shape_type == SGP_SHAPE_SPHERE ? 1 : ((d->shape_type == SGP_SHAPE_HULL || d->shape_type == SGP_SHAPE_MESH) ? 0 : 2));
@@ -422,9 +426,9 @@ SGO_API int sgo_body_add(sgo_world* w, const sgp_body_desc* d, uint32_t* id_out)
 	}
 	uint32_t id;
 	if (mesh) {
-		/* three consecutive fresh slots: the body and its two aliases */
-		if (w->high + 3 > w->cap) return SGP_ERR_CAPACITY;
-		id = w->high; w->high += 3;
+		/* three consecutive slots: the body and its two aliases -- a triple a removed mesh body left behind, else fresh ones */
+		if (w->n_free_triples) id = w->free_triples[--w->n_free_triples];
+		else { if (w->high + 3 > w->cap) return SGP_ERR_CAPACITY; id = w->high; w->high += 3; }
 	}
 	else if (w->n_free) id = w->free_list[--w->n_free];
 	else { if (w->high >= w->cap) return SGP_ERR_CAPACITY; id = w->high++; }
@@ -576,7 +580,8 @@ SGO_API int sgo_body_remove(sgo_world* w, uint32_t id)
 		for (uint32_t k = 1; k < n; ++k) { const int r = sgo_body_remove(w, ids[k]); if (r != SGP_OK) return r; w->n_alive++; }
 	}
 	const int nslots = w->bodies[id].shape_type == SGP_SHAPE_MESH ? 3 : 1;
-	for (int k = 0; k < nslots; ++k) { w->bodies[id + k].alive = 0; w->bodies[id + k].active = 0; w->bodies[id + k].is_alias = 0; w->free_list[w->n_free++] = id + k; }
+	for (int k = 0; k < nslots; ++k) { w->bodies[id + k].alive = 0; w->bodies[id + k].active = 0; w->bodies[id + k].is_alias = 0; }
+	if (nslots == 3) w->free_triples[w->n_free_triples++] = id; else w->free_list[w->n_free++] = id;
 	w->n_alive--;
 	return SGP_OK;
 }
@@ -2113,12 +2118,40 @@ SGO_API int sgo_mesh_create_with_materials(sgo_world* w, const float* verts, uin
 	v3 mn = V3(3.4e38f, 3.4e38f, 3.4e38f), mx = V3(-3.4e38f, -3.4e38f, -3.4e38f); float br = 0.0f;
 	for (uint32_t k = 0; k < nv; ++k) { const v3 p = V3(verts[3 * k], verts[3 * k + 1], verts[3 * k + 2]); m->verts[k] = p; mn = v3_min(mn, p); mx = v3_max(mx, p); br = fmaxf(br, v3_len(p)); }
 	m->aabb_min = mn; m->aabb_max = mx; m->bound_radius = br;
-	if (w->n_meshes == w->cap_meshes) { w->cap_meshes *= 2; w->meshes = (sgo_mesh**)realloc(w->meshes, sizeof(sgo_mesh*) * w->cap_meshes); }
-	const uint32_t id = w->n_meshes++;
+	uint32_t id;
+	if (w->n_free_mesh_ids) id = w->free_mesh_ids[--w->n_free_mesh_ids];
+	else {
+		if (w->n_meshes == w->cap_meshes) { w->cap_meshes *= 2; w->meshes = (sgo_mesh**)realloc(w->meshes, sizeof(sgo_mesh*) * w->cap_meshes); }
+		id = w->n_meshes++;
+	}
 	w->meshes[id] = m;
 	memset(info, 0, sizeof(*info));
 	info->mesh_id = id; info->num_vertices = nv; info->num_triangles = nt; info->num_nodes = 0;
 	info->aabb_min[0] = mn.x; info->aabb_min[1] = mn.y; info->aabb_min[2] = mn.z; info->aabb_max[0] = mx.x; info->aabb_max[1] = mx.y; info->aabb_max[2] = mx.z;
+	return SGP_OK;
+}
+
+static int shape_in_use(const sgo_world* w, int type, const void* p)
+{
+	for (uint32_t i = 0; i < w->high; ++i) { const sgo_body* b = &w->bodies[i]; if (b->alive && !b->is_alias && b->shape_type == type && (type == SGP_SHAPE_MESH ? (const void*)b->mesh : (const void*)b->hull) == p) return 1; }
+	return 0;
+}
+SGO_API int sgo_mesh_destroy(sgo_world* w, uint32_t id)
+{
+	if (!w || id < 1 || id >= w->n_meshes || !w->meshes[id]) return SGP_ERR_BAD_ID;
+	if (shape_in_use(w, SGP_SHAPE_MESH, w->meshes[id])) return SGP_ERR_REJECTED;
+	free(w->meshes[id]->verts); free(w->meshes[id]->tris); free(w->meshes[id]->mats); free(w->meshes[id]); w->meshes[id] = NULL;
+	w->free_mesh_ids = (uint32_t*)realloc(w->free_mesh_ids, sizeof(uint32_t) * (w->n_free_mesh_ids + 1));
+	w->free_mesh_ids[w->n_free_mesh_ids++] = id;
+	return SGP_OK;
+}
+SGO_API int sgo_hull_destroy(sgo_world* w, uint32_t id)
+{
+	if (!w || id < 1 || id >= w->n_hulls || !w->hulls[id]) return SGP_ERR_BAD_ID;
+	if (shape_in_use(w, SGP_SHAPE_HULL, w->hulls[id])) return SGP_ERR_REJECTED;
+	free(w->hulls[id]); w->hulls[id] = NULL;
+	w->free_hull_ids = (uint32_t*)realloc(w->free_hull_ids, sizeof(uint32_t) * (w->n_free_hull_ids + 1));
+	w->free_hull_ids[w->n_free_hull_ids++] = id;
 	return SGP_OK;
 }
 
@@ -2169,9 +2202,13 @@ SGO_API int sgo_hull_create_com(sgo_world* w, const float* pts, uint32_t n, cons
 	if (!w || !pts || !info || n < 4 || n > 100000) return SGP_ERR_INVALID;
 	sgo_hull* h = (sgo_hull*)malloc(sizeof(sgo_hull));
 	float com[3], rot[4];
-	if (sgo_hull_build(pts, (int)(n > 256 ? 256 : n), com_offset, h, com, rot) != 0) { free(h); return SGP_ERR_REJECTED; }
-	if (w->n_hulls == w->cap_hulls) { w->cap_hulls *= 2; w->hulls = (sgo_hull**)realloc(w->hulls, sizeof(sgo_hull*) * w->cap_hulls); }
-	const uint32_t id = w->n_hulls++;
+	if (sgo_hull_build(pts, (int)n, com_offset, h, com, rot) != 0) { free(h); return SGP_ERR_REJECTED; }
+	uint32_t id;
+	if (w->n_free_hull_ids) id = w->free_hull_ids[--w->n_free_hull_ids];
+	else {
+		if (w->n_hulls == w->cap_hulls) { w->cap_hulls *= 2; w->hulls = (sgo_hull**)realloc(w->hulls, sizeof(sgo_hull*) * w->cap_hulls); }
+		id = w->n_hulls++;
+	}
 	w->hulls[id] = h;
 	memset(info, 0, sizeof(*info));
 	info->hull_id = id; info->num_vertices = (uint32_t)h->nv; info->num_faces = (uint32_t)h->nf; info->num_edges = (uint32_t)h->ne;

@@ -235,8 +235,6 @@ void launch_bp_large(const DV& d, uint32_t nb, hipStream_t s);
 void launch_narrowphase(const DV& d, uint32_t n_pairs_upper, hipStream_t s);
 void launch_narrowphase_hull(const DV& d, hipStream_t s);     // only worlds with hull shapes
 void launch_narrowphase_mesh(const DV& d, hipStream_t s);     // only worlds with mesh shapes
-#define SGP_MAX_MESHES 1024
-#define SGP_MAX_HULLS 256
 void launch_wake(const DV& d, uint32_t nb, hipStream_t s);
 void launch_prep_bodies(const DV& d, uint32_t nb, hipStream_t s);
 void launch_colour_inherit(const DV& d, uint32_t n_man, hipStream_t s);

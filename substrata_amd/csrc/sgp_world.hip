@@ -50,6 +50,7 @@ struct HostBody {
 	float bound_radius = 0.0f;
 	float volume = 0.0f;         // Shape::GetVolume of the current shape
 	bool ghost = false;
+	uint32_t shape_ref = 0;                // the mesh / hull id the body references (0 = none): keeps sgp_mesh_destroy / sgp_hull_destroy honest
 	uint32_t comp_root = SGP_INVALID_ID;   // child of a static compound body: slot of the compound (= its first child), else invalid
 	uint32_t comp_child = 0;               // index among the compound's children
 };
@@ -97,6 +98,11 @@ struct sgp_world {
 	std::vector<MeshHeader> meshes; std::vector<float4> mesh_verts; std::vector<uint4> mesh_tris; std::vector<uint32_t> mesh_tri_mat; std::vector<MeshNode> mesh_nodes;
 	MeshHeader* d_meshes = nullptr; float4* d_mesh_verts = nullptr; uint4* d_mesh_tris = nullptr; uint32_t* d_mesh_tri_mat = nullptr; MeshNode* d_mesh_nodes = nullptr;
 	size_t cap_mesh_verts = 0, cap_mesh_tris = 0, cap_mesh_tri_mat = 0, cap_mesh_nodes = 0;
+	// shape lifecycle: bodies referencing each mesh / hull, ids and pool ranges of destroyed shapes waiting for reuse, table capacities (grown on demand)
+	std::vector<uint32_t> mesh_refs, hull_refs, free_mesh_ids, free_hull_ids;
+	std::vector<std::pair<uint32_t, uint32_t>> free_vert_ranges, free_tri_ranges, free_node_ranges;      // (offset, length)
+	size_t cap_mesh_table = 0, cap_hull_table = 0;
+	std::vector<uint32_t> free_triples;                   // first slot of freed (mesh body + 2 alias) slot triples
 	// convex hull shapes: host copies of the device table (mass properties, radii) -- hull 0 is the +-1 cube template
 	std::vector<sgd_hull> hulls; sgd_hull* d_hulls = nullptr;
 	// wheeled vehicles: device records (AoS) + host mirror of what the ABI needs without a read-back
@@ -273,13 +279,15 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	DEV_ALLOC(d.cell_hash, N);
 	DEV_ALLOC(d.cell_count, d.table_size + 4); DEV_ALLOC(d.cell_start, d.table_size + 4); DEV_ALLOC(d.cell_fill, d.table_size + 4);
 	DEV_ALLOC(w->d_large, N); w->cap_large = N; d.large_ids = w->d_large;
-	DEV_ALLOC(w->d_meshes, SGP_MAX_MESHES); d.meshes = w->d_meshes; d.n_meshes = 1; w->meshes.push_back(MeshHeader{});
+	{ void* q = nullptr; w->cap_mesh_table = 256; HIP_TRY(hipMalloc(&q, sizeof(MeshHeader) * w->cap_mesh_table)); HIP_TRY(hipMemsetAsync(q, 0, sizeof(MeshHeader) * w->cap_mesh_table, w->stream)); w->d_meshes = (MeshHeader*)q; w->device_bytes += sizeof(MeshHeader) * w->cap_mesh_table; }
+	d.meshes = w->d_meshes; d.n_meshes = 1; w->meshes.push_back(MeshHeader{}); w->mesh_refs.push_back(0);
 	d.cap_mesh_pairs = P / 4 + 1024; DEV_ALLOC(d.mesh_pairs, d.cap_mesh_pairs);
-	DEV_ALLOC(w->d_hulls, SGP_MAX_HULLS); d.hulls = w->d_hulls;
+	{ void* q = nullptr; w->cap_hull_table = 64; HIP_TRY(hipMalloc(&q, sizeof(sgd_hull) * w->cap_hull_table)); HIP_TRY(hipMemsetAsync(q, 0, sizeof(sgd_hull) * w->cap_hull_table, w->stream)); w->d_hulls = (sgd_hull*)q; w->device_bytes += sizeof(sgd_hull) * w->cap_hull_table; }
+	d.hulls = w->d_hulls;
 	d.cap_hull_pairs = P / 4 + 1024; DEV_ALLOC(d.hull_pairs, d.cap_hull_pairs);
 	{
 		sgd_hull cube; sgd_hull_cube_template(&cube);
-		w->hulls.push_back(cube);
+		w->hulls.push_back(cube); w->hull_refs.push_back(1);      // (the cube template is never destroyed)
 		HIP_TRY(hipMemcpyAsync(&w->d_hulls[0], &w->hulls[0], sizeof(sgd_hull), hipMemcpyHostToDevice, w->stream));
 		d.n_hulls = 1;
 	}
@@ -324,6 +332,8 @@ SGP_API int sgp_world_destroy(sgp_world* w)
 	if (w->stream) hipStreamSynchronize(w->stream);
 	for (void* p : w->allocs) hipFree(p);
 	if (w->stage_dev) hipFree(w->stage_dev);
+	if (w->d_meshes) hipFree(w->d_meshes);
+	if (w->d_hulls) hipFree(w->d_hulls);
 	if (w->d_mesh_verts) hipFree(w->d_mesh_verts);
 	if (w->d_mesh_tris) hipFree(w->d_mesh_tris);
 	if (w->d_mesh_tri_mat) hipFree(w->d_mesh_tri_mat);
@@ -415,10 +425,12 @@ static int add_one(sgp_world* w, const sgp_body_desc* d, uint32_t* id_out, bool 
 		const uint32_t mid = (uint32_t)d->shape[0];
 		if (!(d->shape[0] >= 1.0f) || (float)mid != d->shape[0] || mid >= w->meshes.size()) return fail(SGP_ERR_INVALID, "sgp_body_add: bad mesh id");
 		if (d->motion_type != SGP_MOTION_STATIC) return fail(SGP_ERR_INVALID, "sgp_body_add: mesh shapes are for static bodies only");
+		if (w->meshes[mid].nt == 0) return fail(SGP_ERR_INVALID, "sgp_body_add: the mesh has been destroyed");
 	}
 	if (d->shape_type == SGP_SHAPE_HULL) {
 		const uint32_t hid = (uint32_t)d->shape[0];
 		if (!(d->shape[0] >= 1.0f) || (float)hid != d->shape[0] || hid >= w->hulls.size()) return fail(SGP_ERR_INVALID, "sgp_body_add: bad hull id");
+		if (w->hulls[hid].nv == 0) return fail(SGP_ERR_INVALID, "sgp_body_add: the hull has been destroyed");
 		hull = &w->hulls[hid];
 	}
 	const int nparam = d->shape_type == SGP_SHAPE_BOX ? 3 : (d->shape_type == SGP_SHAPE_SPHERE ? 1 : ((d->shape_type == SGP_SHAPE_HULL || is_mesh) ? 0 : 2));
@@ -428,9 +440,10 @@ static int add_one(sgp_world* w, const sgp_body_desc* d, uint32_t* id_out, bool 
 	}
 	uint32_t id;
 	if (is_mesh) {
-		// three consecutive fresh slots: the body and its two aliases (second / third contact manifold of a pair)
-		if (w->high + 3 > w->dv.cap_bodies) return fail(SGP_ERR_CAPACITY, "sgp_body_add: max_bodies exceeded");
-		id = w->high; w->high += 3;
+		// three consecutive slots: the body and its two aliases (second / third contact manifold of a pair) -- the triple a removed mesh body
+		// left behind, else fresh ones
+		if (!w->free_triples.empty()) { id = w->free_triples.back(); w->free_triples.pop_back(); }
+		else { if (w->high + 3 > w->dv.cap_bodies) return fail(SGP_ERR_CAPACITY, "sgp_body_add: max_bodies exceeded"); id = w->high; w->high += 3; }
 	}
 	else if (!w->free_list.empty()) { id = w->free_list.back(); w->free_list.pop_back(); }
 	else { if (w->high >= w->dv.cap_bodies) return fail(SGP_ERR_CAPACITY, "sgp_body_add: max_bodies exceeded"); id = w->high++; }
@@ -459,6 +472,8 @@ static int add_one(sgp_world* w, const sgp_body_desc* d, uint32_t* id_out, bool 
 	if (ghost) f |= BF_GHOST;
 	HostBody& hb = w->hb[id];
 	hb.flags = f; hb.userdata = d->userdata; hb.ghost = ghost; hb.comp_root = SGP_INVALID_ID; hb.comp_child = 0;
+	hb.shape_ref = (is_mesh || d->shape_type == SGP_SHAPE_HULL) ? (uint32_t)d->shape[0] : 0u;
+	if (is_mesh) w->mesh_refs[hb.shape_ref]++; else if (hb.shape_ref) w->hull_refs[hb.shape_ref]++;
 	note_radius(w, id, is_mesh ? 3.0e38f : (hull ? hull->bound_radius : bounding_radius(d->shape_type, d->shape)));   // (meshes always go through the large-body list)
 	hb.volume = is_mesh ? 0.0f : (hull ? hull->volume : host_shape_volume(d->shape_type, d->shape));
 	c.flags = hb.flags;
@@ -598,8 +613,11 @@ SGP_API int sgp_body_remove(sgp_world* w, uint32_t id)
 	for (uint32_t v = 0; v < w->n_vehicles; ++v) if (w->veh_alive[v] && w->veh_body[v] == id) sgp_vehicle_destroy(w, v);   // a vehicle does not outlive its chassis
 	if (w->hb[id].flags & BF_LARGE) { w->large_ids.erase(std::remove(w->large_ids.begin(), w->large_ids.end(), id), w->large_ids.end()); w->large_dirty = true; }
 	if (w->hb[id].flags & BF_ALIAS) return fail(SGP_ERR_BAD_ID, "sgp_body_remove: id not live");
-	const uint32_t nslots = ((w->hb[id].flags & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT) == SGP_SHAPE_MESH ? 3u : 1u;
-	for (uint32_t k = 0; k < nslots; ++k) { w->hb[id + k].flags = 0; w->cmds.push_back(blank_cmd(id + k, CMD_REMOVE)); w->free_list.push_back(id + k); }
+	const bool was_mesh = ((w->hb[id].flags & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT) == SGP_SHAPE_MESH;
+	if (w->hb[id].shape_ref) { if (was_mesh) w->mesh_refs[w->hb[id].shape_ref]--; else w->hull_refs[w->hb[id].shape_ref]--; w->hb[id].shape_ref = 0; }
+	const uint32_t nslots = was_mesh ? 3u : 1u;
+	for (uint32_t k = 0; k < nslots; ++k) { w->hb[id + k].flags = 0; w->cmds.push_back(blank_cmd(id + k, CMD_REMOVE)); }
+	if (was_mesh) w->free_triples.push_back(id); else w->free_list.push_back(id);       // a triple stays a triple: the next mesh body reuses it
 	w->n_alive--;
 	return SGP_OK;
 }
@@ -1265,6 +1283,39 @@ static uint32_t build_mesh_node(std::vector<MeshNode>& nodes, size_t node_base, 
 	return me;
 }
 
+// first-fit from the ranges destroyed shapes gave back, else the end of the pool
+static uint32_t take_range(std::vector<std::pair<uint32_t, uint32_t>>& free_ranges, uint32_t len, size_t pool_end)
+{
+	for (size_t k = 0; k < free_ranges.size(); ++k) if (free_ranges[k].second >= len) {
+		const uint32_t off = free_ranges[k].first;
+		if (free_ranges[k].second == len) free_ranges.erase(free_ranges.begin() + (long)k); else { free_ranges[k].first += len; free_ranges[k].second -= len; }
+		return off;
+	}
+	return (uint32_t)pool_end;
+}
+static void give_range(std::vector<std::pair<uint32_t, uint32_t>>& free_ranges, uint32_t off, uint32_t len)
+{
+	if (!len) return;
+	free_ranges.push_back(std::make_pair(off, len));
+	std::sort(free_ranges.begin(), free_ranges.end());
+	for (size_t k = 0; k + 1 < free_ranges.size();) {       // merge neighbours
+		if (free_ranges[k].first + free_ranges[k].second == free_ranges[k + 1].first) { free_ranges[k].second += free_ranges[k + 1].second; free_ranges.erase(free_ranges.begin() + (long)k + 1); } else ++k;
+	}
+}
+template <typename T> static int grow_table(sgp_world* w, T*& dev, size_t& cap, size_t need)
+{
+	if (need <= cap) return SGP_OK;
+	const size_t nc = std::max(need, 2 * cap);
+	T* nd = nullptr;
+	HIP_TRY(hipMalloc((void**)&nd, sizeof(T) * nc));
+	HIP_TRY(hipMemsetAsync(nd, 0, sizeof(T) * nc, w->stream));
+	HIP_TRY(hipMemcpyAsync(nd, dev, sizeof(T) * cap, hipMemcpyDeviceToDevice, w->stream));
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	hipFree(dev); w->device_bytes += sizeof(T) * (nc - cap);
+	dev = nd; cap = nc;
+	return SGP_OK;
+}
+
 SGP_API int sgp_mesh_create_with_materials(sgp_world* w, const float* verts, uint32_t nv, const uint32_t* idx, uint32_t nt, const uint32_t* tri_mats, sgp_mesh_info* info);
 SGP_API int sgp_mesh_create(sgp_world* w, const float* verts, uint32_t nv, const uint32_t* idx, uint32_t nt, sgp_mesh_info* info)
 {
@@ -1273,15 +1324,18 @@ SGP_API int sgp_mesh_create(sgp_world* w, const float* verts, uint32_t nv, const
 SGP_API int sgp_mesh_create_with_materials(sgp_world* w, const float* verts, uint32_t nv, const uint32_t* idx, uint32_t nt, const uint32_t* tri_mats, sgp_mesh_info* info)
 {
 	if (!w || !verts || !idx || !info || nv < 3 || nt < 1) return fail(SGP_ERR_INVALID, "sgp_mesh_create: bad arguments");
-	if (w->meshes.size() >= SGP_MAX_MESHES) return fail(SGP_ERR_CAPACITY, "sgp_mesh_create: mesh table full");
 	for (uint32_t k = 0; k < 3 * nt; ++k) if (idx[k] >= nv) return fail(SGP_ERR_INVALID, "sgp_mesh_create: vertex index out of range");
 	for (uint32_t k = 0; k < 3 * nv; ++k) if (!std::isfinite(verts[k])) return fail(SGP_ERR_INVALID, "sgp_mesh_create: non-finite vertex");
 	hipSetDevice(w->device);
 	MeshHeader mh{};
-	mh.vert_off = (uint32_t)w->mesh_verts.size(); mh.nv = nv; mh.tri_off = (uint32_t)w->mesh_tris.size(); mh.nt = nt; mh.node_off = (uint32_t)w->mesh_nodes.size();
+	mh.nv = nv; mh.nt = nt;
+	mh.vert_off = take_range(w->free_vert_ranges, nv, w->mesh_verts.size());
+	mh.tri_off = take_range(w->free_tri_ranges, nt, w->mesh_tris.size());
+	if (w->mesh_verts.size() < (size_t)mh.vert_off + nv) w->mesh_verts.resize((size_t)mh.vert_off + nv);
+	if (w->mesh_tris.size() < (size_t)mh.tri_off + nt) { w->mesh_tris.resize((size_t)mh.tri_off + nt); w->mesh_tri_mat.resize((size_t)mh.tri_off + nt); }
 	float mn[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, mx[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
 	for (uint32_t k = 0; k < nv; ++k) {
-		w->mesh_verts.push_back(make_float4(verts[3 * k], verts[3 * k + 1], verts[3 * k + 2], 0.0f));
+		w->mesh_verts[mh.vert_off + k] = make_float4(verts[3 * k], verts[3 * k + 1], verts[3 * k + 2], 0.0f);
 		for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], verts[3 * k + a]); mx[a] = std::max(mx[a], verts[3 * k + a]); }
 	}
 	mh.mnx = mn[0]; mh.mny = mn[1]; mh.mnz = mn[2]; mh.mxx = mx[0]; mh.mxy = mx[1]; mh.mxz = mx[2];
@@ -1294,20 +1348,29 @@ SGP_API int sgp_mesh_create_with_materials(sgp_world* w, const float* verts, uin
 			cen[3 * t + a] = (p0 + p1 + p2) * (1.0f / 3.0f); tmin[3 * t + a] = std::min(p0, std::min(p1, p2)); tmax[3 * t + a] = std::max(p0, std::max(p1, p2));
 		}
 	}
-	build_mesh_node(w->mesh_nodes, mh.node_off, order, cen, tmin, tmax, 0, nt);
-	mh.n_nodes = (uint32_t)(w->mesh_nodes.size() - mh.node_off);
-	for (uint32_t k = 0; k < nt; ++k) { const uint32_t t = order[k]; w->mesh_tris.push_back(make_uint4(idx[3 * t], idx[3 * t + 1], idx[3 * t + 2], t)); w->mesh_tri_mat.push_back(tri_mats ? tri_mats[t] : 0u); }
+	{      // the tree is built aside (its size is not known beforehand), then placed in a freed range or at the end of the node pool
+		std::vector<MeshNode> nodes;
+		build_mesh_node(nodes, 0, order, cen, tmin, tmax, 0, nt);
+		mh.n_nodes = (uint32_t)nodes.size();
+		mh.node_off = take_range(w->free_node_ranges, mh.n_nodes, w->mesh_nodes.size());
+		if (w->mesh_nodes.size() < (size_t)mh.node_off + mh.n_nodes) w->mesh_nodes.resize((size_t)mh.node_off + mh.n_nodes);
+		std::copy(nodes.begin(), nodes.end(), w->mesh_nodes.begin() + mh.node_off);
+	}
+	for (uint32_t k = 0; k < nt; ++k) { const uint32_t t = order[k]; w->mesh_tris[mh.tri_off + k] = make_uint4(idx[3 * t], idx[3 * t + 1], idx[3 * t + 2], t); w->mesh_tri_mat[mh.tri_off + k] = tri_mats ? tri_mats[t] : 0u; }
 	// upload (pools may move: captured graphs carry the old pointers)
-	{ int r = grow_pool(w, w->d_mesh_verts, w->cap_mesh_verts, w->mesh_verts.size(), mh.vert_off); if (r != SGP_OK) return r; }
-	{ int r = grow_pool(w, w->d_mesh_tris, w->cap_mesh_tris, w->mesh_tris.size(), mh.tri_off); if (r != SGP_OK) return r; }
-	{ int r = grow_pool(w, w->d_mesh_tri_mat, w->cap_mesh_tri_mat, w->mesh_tri_mat.size(), mh.tri_off); if (r != SGP_OK) return r; }
-	{ int r = grow_pool(w, w->d_mesh_nodes, w->cap_mesh_nodes, w->mesh_nodes.size(), mh.node_off); if (r != SGP_OK) return r; }
+	{ int r = grow_pool(w, w->d_mesh_verts, w->cap_mesh_verts, w->mesh_verts.size(), w->cap_mesh_verts); if (r != SGP_OK) return r; }
+	{ int r = grow_pool(w, w->d_mesh_tris, w->cap_mesh_tris, w->mesh_tris.size(), w->cap_mesh_tris); if (r != SGP_OK) return r; }
+	{ int r = grow_pool(w, w->d_mesh_tri_mat, w->cap_mesh_tri_mat, w->mesh_tri_mat.size(), w->cap_mesh_tri_mat); if (r != SGP_OK) return r; }
+	{ int r = grow_pool(w, w->d_mesh_nodes, w->cap_mesh_nodes, w->mesh_nodes.size(), w->cap_mesh_nodes); if (r != SGP_OK) return r; }
 	HIP_TRY(hipMemcpyAsync(w->d_mesh_verts + mh.vert_off, w->mesh_verts.data() + mh.vert_off, sizeof(float4) * nv, hipMemcpyHostToDevice, w->stream));
 	HIP_TRY(hipMemcpyAsync(w->d_mesh_tris + mh.tri_off, w->mesh_tris.data() + mh.tri_off, sizeof(uint4) * nt, hipMemcpyHostToDevice, w->stream));
 	HIP_TRY(hipMemcpyAsync(w->d_mesh_tri_mat + mh.tri_off, w->mesh_tri_mat.data() + mh.tri_off, sizeof(uint32_t) * nt, hipMemcpyHostToDevice, w->stream));
 	HIP_TRY(hipMemcpyAsync(w->d_mesh_nodes + mh.node_off, w->mesh_nodes.data() + mh.node_off, sizeof(MeshNode) * mh.n_nodes, hipMemcpyHostToDevice, w->stream));
-	const uint32_t id = (uint32_t)w->meshes.size();
-	w->meshes.push_back(mh);
+	uint32_t id;
+	if (!w->free_mesh_ids.empty()) { id = w->free_mesh_ids.back(); w->free_mesh_ids.pop_back(); w->meshes[id] = mh; w->mesh_refs[id] = 0; }
+	else { id = (uint32_t)w->meshes.size(); w->meshes.push_back(mh); w->mesh_refs.push_back(0); }
+	{ int r = grow_table(w, w->d_meshes, w->cap_mesh_table, w->meshes.size()); if (r != SGP_OK) return r; }
+	w->dv.meshes = w->d_meshes;
 	HIP_TRY(hipMemcpyAsync(&w->d_meshes[id], &w->meshes[id], sizeof(MeshHeader), hipMemcpyHostToDevice, w->stream));
 	HIP_TRY(hipStreamSynchronize(w->stream));
 	w->dv.mesh_verts = w->d_mesh_verts; w->dv.mesh_tris = w->d_mesh_tris; w->dv.mesh_tri_mat = w->d_mesh_tri_mat; w->dv.mesh_nodes = w->d_mesh_nodes; w->dv.n_meshes = (uint32_t)w->meshes.size();
@@ -1315,6 +1378,21 @@ SGP_API int sgp_mesh_create_with_materials(sgp_world* w, const float* verts, uin
 	memset(info, 0, sizeof(*info));
 	info->mesh_id = id; info->num_vertices = nv; info->num_triangles = nt; info->num_nodes = mh.n_nodes;
 	memcpy(info->aabb_min, mn, sizeof(mn)); memcpy(info->aabb_max, mx, sizeof(mx));
+	return SGP_OK;
+}
+
+// JPH::Ref<JPH::Shape> going out of scope: the mesh's table slot and pool ranges become reusable.  Refused while a body still uses it.
+SGP_API int sgp_mesh_destroy(sgp_world* w, uint32_t id)
+{
+	if (!w || id < 1 || id >= w->meshes.size() || w->meshes[id].nt == 0) return fail(SGP_ERR_BAD_ID, "sgp_mesh_destroy: no such mesh");
+	if (w->mesh_refs[id] != 0) return fail(SGP_ERR_REJECTED, "sgp_mesh_destroy: a body still uses the mesh");
+	hipSetDevice(w->device);
+	const MeshHeader mh = w->meshes[id];
+	give_range(w->free_vert_ranges, mh.vert_off, mh.nv); give_range(w->free_tri_ranges, mh.tri_off, mh.nt); give_range(w->free_node_ranges, mh.node_off, mh.n_nodes);
+	w->meshes[id] = MeshHeader{};
+	HIP_TRY(hipMemcpyAsync(&w->d_meshes[id], &w->meshes[id], sizeof(MeshHeader), hipMemcpyHostToDevice, w->stream));
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	w->free_mesh_ids.push_back(id);
 	return SGP_OK;
 }
 
@@ -1326,13 +1404,15 @@ static void invalidate_graphs(sgp_world* w);
 SGP_API int sgp_hull_create_com(sgp_world* w, const float* pts, uint32_t n, const float* com_offset, sgp_hull_info* info)
 {
 	if (!w || !pts || !info || n < 4 || n > 100000) return fail(SGP_ERR_INVALID, "sgp_hull_create: bad arguments");
-	if (w->hulls.size() >= SGP_MAX_HULLS) return fail(SGP_ERR_CAPACITY, "sgp_hull_create: hull table full");
 	hipSetDevice(w->device);
 	sgd_hull h;
 	float com[3], rot[4];
-	if (sgd_hull_build(pts, (int)(n > 256 ? 256 : n), com_offset, &h, com, rot) != 0) return fail(SGP_ERR_REJECTED, "sgp_hull_create: degenerate point cloud or too many faces");
-	const uint32_t id = (uint32_t)w->hulls.size();
-	w->hulls.push_back(h);
+	if (sgd_hull_build(pts, (int)n, com_offset, &h, com, rot) != 0) return fail(SGP_ERR_REJECTED, "sgp_hull_create: degenerate point cloud or too many faces");
+	uint32_t id;
+	if (!w->free_hull_ids.empty()) { id = w->free_hull_ids.back(); w->free_hull_ids.pop_back(); w->hulls[id] = h; w->hull_refs[id] = 0; }
+	else { id = (uint32_t)w->hulls.size(); w->hulls.push_back(h); w->hull_refs.push_back(0); }
+	{ int r = grow_table(w, w->d_hulls, w->cap_hull_table, w->hulls.size()); if (r != SGP_OK) return r; }
+	w->dv.hulls = w->d_hulls;
 	HIP_TRY(hipMemcpyAsync(&w->d_hulls[id], &w->hulls[id], sizeof(sgd_hull), hipMemcpyHostToDevice, w->stream));
 	HIP_TRY(hipStreamSynchronize(w->stream));
 	w->dv.n_hulls = (uint32_t)w->hulls.size();
@@ -1348,6 +1428,18 @@ SGP_API int sgp_hull_create_com(sgp_world* w, const float* pts, uint32_t n, cons
 }
 
 SGP_API int sgp_hull_create(sgp_world* w, const float* pts, uint32_t n, sgp_hull_info* info) { return sgp_hull_create_com(w, pts, n, nullptr, info); }
+SGP_API int sgp_hull_destroy(sgp_world* w, uint32_t id)
+{
+	if (!w || id < 1 || id >= w->hulls.size() || w->hulls[id].nv == 0) return fail(SGP_ERR_BAD_ID, "sgp_hull_destroy: no such hull");
+	if (w->hull_refs[id] != 0) return fail(SGP_ERR_REJECTED, "sgp_hull_destroy: a body still uses the hull");
+	for (uint32_t v = 0; v < w->n_vehicles; ++v) (void)v;
+	hipSetDevice(w->device);
+	memset(&w->hulls[id], 0, sizeof(sgd_hull));
+	HIP_TRY(hipMemcpyAsync(&w->d_hulls[id], &w->hulls[id], sizeof(sgd_hull), hipMemcpyHostToDevice, w->stream));
+	HIP_TRY(hipStreamSynchronize(w->stream));
+	w->free_hull_ids.push_back(id);
+	return SGP_OK;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // wheeled vehicles (VehicleConstraint + WheeledVehicleController, CarPhysics.cpp:94-231)

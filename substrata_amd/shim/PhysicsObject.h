@@ -6,6 +6,7 @@
 #pragma once
 #include <memory>
 #include <vector>
+#include <functional>
 #include <maths/Vec4f.h>
 #include <maths/Quat.h>
 #include <maths/vec3.h>
@@ -25,7 +26,7 @@ class RayTraceResult;
 struct sgp_world;
 struct PhysicsHullData
 {
-	struct Instance { sgp_world* world; float scale[3]; uint32_t hull_id; float com[3]; float rot[4]; float aabb_min[3], aabb_max[3]; };
+	struct Instance { sgp_world* world; float scale[3]; uint32_t hull_id; float com[3]; float rot[4]; float aabb_min[3], aabb_max[3]; uint32_t users; };
 	std::vector<float> points;          // xyz, object space, unscaled
 	float com_offset[3] = { 0, 0, 0 };  // OffsetCenterOfMassShape: moves the centre of mass away from the hull's own (object space, unscaled)
 	std::vector<Instance> instances;
@@ -35,7 +36,7 @@ struct PhysicsHullData
 // triangulated samples of a height field) plus the device-side meshes built from them, one per (world, object scale).
 struct PhysicsMeshData
 {
-	struct Instance { sgp_world* world; float scale[3]; uint32_t mesh_id; };
+	struct Instance { sgp_world* world; float scale[3]; uint32_t mesh_id; uint32_t users; };      // users = bodies made from it; destroyed with the last one
 	std::vector<float> vertices;        // xyz, object space, unscaled
 	std::vector<uint32_t> indices;      // 3 per triangle, counter-clockwise = front
 	std::vector<uint32_t> materials;    // per triangle: the material index a ray hit reports (JPH::IndexedTriangle::mMaterialIndex, PhysicsWorld.cpp:1032-1060); empty = all 0
@@ -108,6 +109,10 @@ public:
 	float mass;
 	float friction;
 	float restitution;
+
+	// device-side shape instances (mesh / hull of this object's scale) the object's body holds: released, and destroyed with their last
+	// user, when the body is removed -- the role of the JPH::Ref<JPH::Shape> a Jolt body keeps on its shape
+	std::vector<std::function<void()>> shape_instance_releases;
 };
 
 typedef Reference<PhysicsObject> PhysicsObjectRef;

@@ -12,6 +12,38 @@
 
 static inline float myClamp(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
+// A shape or body the device side refused (capacity, degenerate geometry): the reference would go on silently without the object's collision
+// (addObject has no error path, PhysicsWorld.cpp:1178-1189); this backend says so once per kind on stderr so that a world outgrowing its
+// capacities does not just lose collision quietly.
+static void reportShapeFailure(const char* what)
+{
+	static int reported = 0;
+	if (reported++ < 8) fprintf(stderr, "PhysicsWorld: could not create %s: %s\n", what, sgp_last_error());
+}
+// the body of `object` now uses the device-side instance: remembered on the object so that removeObject can give it back
+static void holdMeshInstance(PhysicsObject& object, const std::shared_ptr<PhysicsMeshData>& data, PhysicsMeshData::Instance* in)
+{
+	in->users++;
+	sgp_world* world = in->world; const uint32_t id = in->mesh_id;
+	object.shape_instance_releases.push_back([data, world, id]() {
+		for (size_t i = 0; i < data->instances.size(); ++i) if (data->instances[i].world == world && data->instances[i].mesh_id == id) {
+			if (--data->instances[i].users == 0) { sgp_mesh_destroy(world, id); data->instances.erase(data->instances.begin() + (long)i); }
+			return;
+		}
+	});
+}
+static void holdHullInstance(PhysicsObject& object, const std::shared_ptr<PhysicsHullData>& data, PhysicsHullData::Instance* in)
+{
+	in->users++;
+	sgp_world* world = in->world; const uint32_t id = in->hull_id;
+	object.shape_instance_releases.push_back([data, world, id]() {
+		for (size_t i = 0; i < data->instances.size(); ++i) if (data->instances[i].world == world && data->instances[i].hull_id == id) {
+			if (--data->instances[i].users == 0) { sgp_hull_destroy(world, id); data->instances.erase(data->instances.begin() + (long)i); }
+			return;
+		}
+	});
+}
+
 // the JPH::Shape look-alike of a facade shape (PhysicsShape::jolt_shape)
 static void setJoltShape(PhysicsShape& s)
 {
@@ -113,11 +145,11 @@ PhysicsShape PhysicsWorld::createJoltHeightFieldShape(int vert_res, const std::v
 	return createMeshShape(verts, tris);
 }
 
-static const PhysicsMeshData::Instance* meshInstance(sgp_world* world, const PhysicsShape& shape, const Vec3f& scale)
+static PhysicsMeshData::Instance* meshInstance(sgp_world* world, const PhysicsShape& shape, const Vec3f& scale)
 {
 	PhysicsMeshData& m = *shape.mesh;
 	for (size_t i = 0; i < m.instances.size(); ++i) {
-		const PhysicsMeshData::Instance& in = m.instances[i];
+		PhysicsMeshData::Instance& in = m.instances[i];
 		if (in.world == world && in.scale[0] == scale.x && in.scale[1] == scale.y && in.scale[2] == scale.z) return &in;
 	}
 	std::vector<float> v(m.vertices);
@@ -126,8 +158,8 @@ static const PhysicsMeshData::Instance* meshInstance(sgp_world* world, const Phy
 	if (scale.x * scale.y * scale.z < 0.f) for (size_t i = 0; i + 2 < idx.size(); i += 3) std::swap(idx[i + 1], idx[i + 2]);      // a mirroring scale turns the triangles inside out
 	sgp_mesh_info info;
 	if (sgp_mesh_create_with_materials(world, v.data(), (uint32_t)(v.size() / 3), idx.data(), (uint32_t)(idx.size() / 3),
-		m.materials.size() == idx.size() / 3 ? m.materials.data() : nullptr, &info) != SGP_OK) return nullptr;
-	PhysicsMeshData::Instance in; in.world = world; in.scale[0] = scale.x; in.scale[1] = scale.y; in.scale[2] = scale.z; in.mesh_id = info.mesh_id;
+		m.materials.size() == idx.size() / 3 ? m.materials.data() : nullptr, &info) != SGP_OK) { reportShapeFailure("mesh"); return nullptr; }
+	PhysicsMeshData::Instance in; in.world = world; in.scale[0] = scale.x; in.scale[1] = scale.y; in.scale[2] = scale.z; in.mesh_id = info.mesh_id; in.users = 0;
 	m.instances.push_back(in);
 	return &m.instances.back();
 }
@@ -169,19 +201,20 @@ PhysicsShape PhysicsWorld::createCOMOffsetShapeForShape(const PhysicsShape& orig
 }
 
 // The device-side hull of `shape` for this world and object scale (JPH::ScaledShape baked into the points), built on first use.
-static const PhysicsHullData::Instance* hullInstance(sgp_world* world, const PhysicsShape& shape, const Vec3f& scale)
+static PhysicsHullData::Instance* hullInstance(sgp_world* world, const PhysicsShape& shape, const Vec3f& scale)
 {
 	PhysicsHullData& h = *shape.hull;
 	for (size_t i = 0; i < h.instances.size(); ++i) {
-		const PhysicsHullData::Instance& in = h.instances[i];
+		PhysicsHullData::Instance& in = h.instances[i];
 		if (in.world == world && in.scale[0] == scale.x && in.scale[1] == scale.y && in.scale[2] == scale.z) return &in;
 	}
 	std::vector<float> pts(h.points);
 	for (size_t i = 0; i + 2 < pts.size(); i += 3) { pts[i] *= scale.x; pts[i + 1] *= scale.y; pts[i + 2] *= scale.z; }
 	sgp_hull_info info;
 	const float off[3] = { h.com_offset[0] * scale.x, h.com_offset[1] * scale.y, h.com_offset[2] * scale.z };
-	if (sgp_hull_create_com(world, pts.data(), (uint32_t)(pts.size() / 3), off, &info) != SGP_OK) return nullptr;
+	if (sgp_hull_create_com(world, pts.data(), (uint32_t)(pts.size() / 3), off, &info) != SGP_OK) { reportShapeFailure("convex hull"); return nullptr; }
 	PhysicsHullData::Instance in;
+	in.users = 0;
 	in.world = world; in.scale[0] = scale.x; in.scale[1] = scale.y; in.scale[2] = scale.z; in.hull_id = info.hull_id;
 	memcpy(in.com, info.com, sizeof(in.com)); memcpy(in.rot, info.rot, sizeof(in.rot));
 	memcpy(in.aabb_min, info.aabb_min, sizeof(in.aabb_min)); memcpy(in.aabb_max, info.aabb_max, sizeof(in.aabb_max));
@@ -239,6 +272,7 @@ void PhysicsWorld::addObject(const Reference<PhysicsObject>& object)
 	d.use_zero_linear_drag = object->use_zero_linear_drag ? 1 : 0;
 	d.userdata = (uint64)object.ptr();                      // :1241
 	d.activate = 0;                                          // EActivation::DontActivate (:1243)
+	PhysicsMeshData::Instance* mesh_in = nullptr; PhysicsHullData::Instance* hull_in = nullptr;
 	if (object->is_sphere) {              // unit sphere r 0.5, uniform scale = scale.x (:1219-1227)
 		d.shape_type = SGP_SHAPE_SPHERE; d.shape[0] = 0.5f * std::fabs(object->scale.x); d.shape[1] = d.shape[2] = 0;
 	} else if (object->is_cube) {         // unit cube half 0.5, per-axis scale (:1247-1255)
@@ -252,12 +286,14 @@ void PhysicsWorld::addObject(const Reference<PhysicsObject>& object)
 		if (s.kind == 4) {
 			// JPH::MeshShape: static (or kinematic) bodies only -- the reference builds a mesh shape exactly when the object is not dynamic
 			if (d.motion_type != SGP_MOTION_STATIC) return;
-			const PhysicsMeshData::Instance* in = s.mesh ? meshInstance(world, s, object->scale) : nullptr;
+			PhysicsMeshData::Instance* in = s.mesh ? meshInstance(world, s, object->scale) : nullptr;
 			if (!in) return;
+			mesh_in = in;
 			d.shape[0] = (float)in->mesh_id; d.shape[1] = d.shape[2] = 0;
 		} else if (s.kind == 3) {
-			const PhysicsHullData::Instance* in = s.hull ? hullInstance(world, s, object->scale) : nullptr;
+			PhysicsHullData::Instance* in = s.hull ? hullInstance(world, s, object->scale) : nullptr;
 			if (!in) return;              // (silent, like every other rejected add)
+			hull_in = in;
 			d.shape[0] = (float)in->hull_id; d.shape[1] = d.shape[2] = 0;
 			object->body_com_os = Vec4f(in->com[0], in->com[1], in->com[2], 0.f);
 			object->body_rot_os = Quatf(in->rot[0], in->rot[1], in->rot[2], in->rot[3]);
@@ -268,7 +304,10 @@ void PhysicsWorld::addObject(const Reference<PhysicsObject>& object)
 		else { d.shape[0] = s.p[0] * std::fabs(object->scale.x); d.shape[1] = s.p[1] * std::fabs(object->scale.z); }
 	}
 	uint32_t id = SGP_INVALID_ID;
-	if (sgp_body_add(world, &d, &id) != SGP_OK) return;      // silent rejection, as the reference (:1178-1189)
+	const int add_rc = sgp_body_add(world, &d, &id);
+	if (add_rc != SGP_OK) { if (add_rc == SGP_ERR_CAPACITY) reportShapeFailure("body"); return; }      // silent rejection of bad input, as the reference (:1178-1189)
+	if (mesh_in) holdMeshInstance(*object, object->shape.mesh, mesh_in);
+	if (hull_in) holdHullInstance(*object, object->shape.hull, hull_in);
 	object->jolt_body_id = JPH::BodyID(id);
 	if (id < id_to_ob.size()) id_to_ob[id] = object.ptr();
 	// the look-alike BodyInterface answers in the shape's space: it needs the body frame of hull bodies
@@ -286,6 +325,7 @@ void PhysicsWorld::addCompoundObject(const Reference<PhysicsObject>& object, sgp
 	const JPH::Shape& comp = *object->shape.jolt_shape;
 	const Vec3f sc = object->scale;
 	std::vector<sgp_compound_child> children;
+	std::vector<std::pair<std::shared_ptr<PhysicsMeshData>, uint32_t>> held_meshes; std::vector<std::pair<std::shared_ptr<PhysicsHullData>, uint32_t>> held_hulls;
 	for (const JPH::Shape::SubShape& c : comp.children) {
 		sgp_compound_child k; memset(&k, 0, sizeof(k));
 		const JPH::Shape& cs = *c.shape;
@@ -296,14 +336,16 @@ void PhysicsWorld::addCompoundObject(const Reference<PhysicsObject>& object, sgp
 		else if (cs.kind == 2) { k.shape[0] = cs.p[0] * std::fabs(sc.x); k.shape[1] = cs.p[1] * std::fabs(sc.z); }
 		else if (cs.kind == 4 && cs.mesh) {
 			PhysicsShape tmp; tmp.kind = 4; tmp.mesh = cs.mesh;
-			const PhysicsMeshData::Instance* in = meshInstance(world, tmp, sc);
+			PhysicsMeshData::Instance* in = meshInstance(world, tmp, sc);
 			if (!in) return;
+			held_meshes.push_back(std::make_pair(cs.mesh, in->mesh_id));
 			k.shape[0] = (float)in->mesh_id;
 		} else if (cs.kind == 3) {
 			PhysicsShape tmp; tmp.kind = 3; tmp.hull = cs.hull;
 			if (!tmp.hull) { tmp.hull = std::make_shared<PhysicsHullData>(); tmp.hull->points = cs.hull_points; for (int i = 0; i < 3; ++i) tmp.hull->com_offset[i] = cs.com_offset[i]; }
-			const PhysicsHullData::Instance* in = hullInstance(world, tmp, sc);
+			PhysicsHullData::Instance* in = hullInstance(world, tmp, sc);
 			if (!in) return;
+			held_hulls.push_back(std::make_pair(tmp.hull, in->hull_id));
 			k.shape[0] = (float)in->hull_id;
 			pos = pos + rot * JPH::Vec3(in->com[0], in->com[1], in->com[2]);          // the hull's body frame inside the child's frame
 			rot = rot * JPH::Quat(in->rot[0], in->rot[1], in->rot[2], in->rot[3]);
@@ -312,7 +354,9 @@ void PhysicsWorld::addCompoundObject(const Reference<PhysicsObject>& object, sgp
 		children.push_back(k);
 	}
 	uint32_t id = SGP_INVALID_ID;
-	if (children.empty() || sgp_body_add_compound(world, &d, children.data(), (uint32_t)children.size(), &id) != SGP_OK) return;
+	if (children.empty() || sgp_body_add_compound(world, &d, children.data(), (uint32_t)children.size(), &id) != SGP_OK) { reportShapeFailure("compound body"); return; }
+	for (auto& hm : held_meshes) for (PhysicsMeshData::Instance& in : hm.first->instances) if (in.world == world && in.mesh_id == hm.second) { holdMeshInstance(*object, hm.first, &in); break; }
+	for (auto& hh : held_hulls) for (PhysicsHullData::Instance& in : hh.first->instances) if (in.world == world && in.hull_id == hh.second) { holdHullInstance(*object, hh.first, &in); break; }
 	object->jolt_body_id = JPH::BodyID(id);
 	if (id < id_to_ob.size()) id_to_ob[id] = object.ptr();
 	physics_system->registerCompound(object->jolt_body_id, (uint32_t)children.size());
@@ -336,6 +380,8 @@ void PhysicsWorld::removeObject(const Reference<PhysicsObject>& object)
 		else sgp_body_remove(world, id);
 		physics_system->GetBodyInterface().clearFrame(object->jolt_body_id);
 		physics_system->registerCompound(object->jolt_body_id, 0);
+		for (auto& release : object->shape_instance_releases) release();
+		object->shape_instance_releases.clear();
 		if (id < id_to_ob.size()) id_to_ob[id] = NULL;
 		object->jolt_body_id = JPH::BodyID();
 	}

@@ -245,6 +245,12 @@ class CWorld:
                         "mesh_create_with_materials")
         return info
 
+    def mesh_destroy(self, mesh_id):
+        self._check(self._fn("mesh_destroy")(self._h, int(mesh_id)), "mesh_destroy")
+
+    def hull_destroy(self, hull_id):
+        self._check(self._fn("hull_destroy")(self._h, int(hull_id)), "hull_destroy")
+
     # -- convex hulls ---------------------------------------------------------------------------------------------
     def hull_create(self, points, com_offset=None):
         """ConvexHullShapeSettings(points).Create() (wrapped in OffsetCenterOfMassShape when com_offset is given): returns

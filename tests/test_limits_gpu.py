@@ -68,3 +68,41 @@ def test_pair_and_manifold_capacity_overflow_is_counted_not_fatal():
     s = w.read_states(0, len(descs))
     assert np.all(np.isfinite(s["pos"]))
     w.close()
+
+
+def test_streaming_static_meshes_through_a_small_world(oracle):
+    """Mesh bodies streamed in and out of a world with room for only a handful (Substrata's normal life): slot triples, mesh ids and mesh
+    storage are reused -- the HIP world hands out the same ids as the oracle for hundreds of cycles, bodies keep colliding with whatever
+    mesh currently sits in a reused slot, and device memory stops growing."""
+    from test_mesh_parity_gpu import grid_mesh, mesh_body
+    rng = np.random.default_rng(9)
+    tw = parity.make_twin(oracle, max_bodies=64)
+    tw.add_batch(scenes.ground())
+    balls = scenes.dynamic_bodies(6); balls["shape_type"] = abi.SHAPE_SPHERE; balls["shape"][:, 0] = 0.3; balls["shape"][:, 1:] = 0
+    balls["pos"] = [(x, y, 4.0) for x in (-2, 0, 2) for y in (-1, 1)]; balls["restitution"] = 0.6
+    tw.add_batch(balls)
+    live = []
+    bytes_after_warmup = None
+    for cycle in range(150):
+        n = int(rng.integers(9, 21))
+        V, T = grid_mesh(n, 4.0, lambda x, y, c=cycle: 1.0 + 0.3 * np.sin(0.7 * x + c) * np.cos(0.5 * y))
+        ig, ic = tw.mesh_create(V, T, materials=np.arange(len(T), dtype=np.uint32) % 7)
+        assert ig.mesh_id == ic.mesh_id
+        bg, bc = tw.add_batch(mesh_body(ig, pos=(0.0, 0.0, 0.2 * (cycle % 3))))
+        assert int(bg[0]) == int(bc[0])
+        live.append((int(bg[0]), ig.mesh_id))
+        for _ in range(4):
+            tw.step(DT)
+        if len(live) > 3:                     # stream the oldest out
+            body, mesh = live.pop(0)
+            tw.remove(body); tw.mesh_destroy(mesh)
+        if cycle % 25 == 24:
+            d = parity.compare(tw, 64)
+            assert d["bit_exact"] and d["active_mismatch"] == 0, (cycle, d)
+            if cycle == 49:
+                bytes_after_warmup = tw.gpu.stats().device_bytes
+    assert max(b for b, _ in live) < 7 + 4 * 3                         # slots were reused: ground + 6 balls + at most 4 live triples
+    assert tw.gpu.stats().device_bytes == bytes_after_warmup           # the mesh pools reached their steady size
+    st = tw.gpu.read_states(1, 6)
+    assert np.all(st["pos"][:, 2] > 0.9)                               # the balls are still carried by the current terrain
+    tw.close()

@@ -156,3 +156,22 @@ def test_centre_of_mass_offset(oracle):
             up = quat_to_mat(st["rot"]) @ quat_to_mat(i2.rot[:]).T @ np.array([0, 0, 1.0])        # object z axis in the world
             assert (up[2] > 0.9) == exp, (tilt, info is a, up)
             w2.close()
+
+
+def test_large_point_cloud_uses_every_vertex(oracle):
+    """A dynamic mesh with thousands of vertices (ConvexHullShapeSettings takes all of them, PhysicsWorld.cpp:1062-1080): the hull must span the
+    whole cloud even when its far end only shows up late in the vertex array -- not just the first 256 vertices."""
+    rng = np.random.default_rng(5)
+    near = rng.uniform(-0.2, 0.2, size=(3000, 3)).astype(np.float32)                   # a small clump first ...
+    far = np.float32([(sx * 2.0, sy * 1.0, sz * 0.5) for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)])      # ... the box corners that define the extent last
+    pts = np.concatenate([near, far])
+    w = oracle.OracleWorld(max_bodies=8)
+    info = w.hull_create(pts)
+    assert info.num_vertices >= 8 and info.num_vertices <= 32
+    ext = np.array(info.aabb_max[:]) - np.array(info.aabb_min[:])
+    assert np.allclose(np.sort(ext), [1.0, 2.0, 4.0], atol=1e-3)
+    assert abs(info.volume - 8.0) < 1e-2                                               # the clump is inside the box
+    # and the same cloud shuffled gives the same solid
+    info2 = w.hull_create(pts[rng.permutation(len(pts))])
+    assert abs(info2.volume - info.volume) < 1e-4
+    w.close()

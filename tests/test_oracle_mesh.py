@@ -157,3 +157,42 @@ def test_ray_hit_reports_triangle_material_and_barycentrics(oracle):
     h2 = w.raycast(r)
     assert h2[0]["id"] == mid2 and h2[0]["triangle"] == 1 and h2[0]["material"] == 0
     w.close()
+
+
+def test_streaming_meshes_in_and_out_reuses_slots_and_ids(oracle):
+    """Substrata streams static meshes in and out as the camera moves: body slots (a mesh body takes three), mesh ids and mesh storage must
+    all come back, or a long session ends in SGP_ERR_CAPACITY with a nearly empty world."""
+    from substrata_amd.world import SgpError
+    w = oracle.OracleWorld(max_bodies=16)                 # room for 5 mesh bodies at most
+    w.add_batch(scenes.ground())
+    ids_seen, mesh_ids_seen = set(), set()
+    for cycle in range(60):
+        mid, info = add_mesh(w, QUAD_V, QUAD_T, pos=(float(cycle), 0, 5.0))
+        mid2, info2 = add_mesh(w, QUAD_V, QUAD_T, pos=(float(cycle), 50, 5.0))
+        ids_seen |= {mid, mid2}; mesh_ids_seen |= {info.mesh_id, info2.mesh_id}
+        r = np.zeros(1, dtype=abi.ray_dtype); r["origin"] = (float(cycle), 50, 9); r["dir"] = (0, 0, -1); r["max_t"] = 20; r["ignore_id"] = abi.INVALID_ID
+        assert w.raycast(r)[0]["id"] == mid2
+        with pytest.raises(SgpError):
+            w.mesh_destroy(info.mesh_id)                  # still in use
+        w.remove(mid); w.remove(mid2)
+        w.mesh_destroy(info.mesh_id); w.mesh_destroy(info2.mesh_id)
+        with pytest.raises(SgpError):
+            w.mesh_destroy(info.mesh_id)                  # already gone
+    assert len(ids_seen) == 2 and len(mesh_ids_seen) == 2 and w.num_bodies() == 1
+    # a body cannot be made from a destroyed mesh
+    d = scenes._blank(1); d["shape_type"] = abi.SHAPE_MESH; d["shape"][0] = 0; d["shape"][0, 0] = float(info.mesh_id)
+    with pytest.raises(SgpError):
+        w.add_batch(d)
+    # hulls: the same life cycle
+    rng = np.random.default_rng(0)
+    hull_ids = set()
+    for cycle in range(40):
+        hi = w.hull_create(rng.normal(size=(10, 3)))
+        hull_ids.add(hi.hull_id)
+        b = scenes.dynamic_bodies(1); b["shape_type"] = abi.SHAPE_HULL; b["shape"][0] = 0; b["shape"][0, 0] = float(hi.hull_id); b["pos"][0] = (0, 0, 3)
+        bid = int(w.add_batch(b)[0])
+        with pytest.raises(SgpError):
+            w.hull_destroy(hi.hull_id)
+        w.remove(bid); w.hull_destroy(hi.hull_id)
+    assert len(hull_ids) == 1
+    w.close()
