@@ -501,8 +501,17 @@ typedef struct sgp_ghost_record {
 	int32_t  shape_type;  float shape[4];
 	float    mass;  float friction;  float restitution;
 	uint32_t motion_type;
-	uint64_t global_id;
+	uint64_t global_id;          /* owner's local body id | owner's rank << 40 */
+	/* the rest of the body's description: what an ownership migration needs to re-create the body as it was (128 bytes in all) */
+	uint64_t userdata;           /* mUserData = the caller's PhysicsObject*: events and ray hits of the new owner keep reporting the same object */
+	float    gravity_factor;  float linear_damping;  float angular_damping;
+	uint32_t flags;              /* SGP_GHOST_FLAG_*: layer in bits 0-1, then is_sensor, allow_sleeping, use_zero_linear_drag */
+	uint32_t _pad[2];
 } sgp_ghost_record;
+#define SGP_GHOST_FLAG_LAYER_MASK   0x3u
+#define SGP_GHOST_FLAG_SENSOR       (1u << 2)
+#define SGP_GHOST_FLAG_ALLOW_SLEEP  (1u << 3)
+#define SGP_GHOST_FLAG_ZERO_DRAG    (1u << 4)
 int  sgp_world_export_boundary(sgp_world* w, const float lo[3], const float hi[3], float margin,
                                sgp_ghost_record* out, uint32_t cap, uint32_t* n_out);
 /* Replace this world's ghost set with `n` records (bodies simulated as velocity-driven, infinite mass). */

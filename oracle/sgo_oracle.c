@@ -2003,6 +2003,8 @@ SGO_API int sgo_world_export_boundary(sgo_world* w, const float lo[3], const flo
 			r->shape_type = b->shape_type; memcpy(r->shape, b->shape, sizeof(r->shape)); r->shape[3] = 0.0f;
 			r->mass = b->mass; r->friction = b->friction; r->restitution = b->restitution;
 			r->motion_type = (uint32_t)b->motion; r->global_id = i;
+			r->userdata = b->userdata; r->gravity_factor = b->gravity_factor; r->linear_damping = b->lin_damp; r->angular_damping = b->ang_damp;
+			r->flags = ((uint32_t)b->layer & SGP_GHOST_FLAG_LAYER_MASK) | (b->is_sensor ? SGP_GHOST_FLAG_SENSOR : 0u) | (b->allow_sleep ? SGP_GHOST_FLAG_ALLOW_SLEEP : 0u) | (b->zero_lin_drag ? SGP_GHOST_FLAG_ZERO_DRAG : 0u);
 		}
 		++n;
 	}

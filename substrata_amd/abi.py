@@ -96,7 +96,11 @@ class StepProfile(C.Structure):
 class GhostRecord(C.Structure):
     _fields_ = [("pos", f32 * 3), ("rot", f32 * 4), ("lin_vel", f32 * 3), ("ang_vel", f32 * 3),
                 ("shape_type", i32), ("shape", f32 * 4), ("mass", f32), ("friction", f32), ("restitution", f32),
-                ("motion_type", u32), ("global_id", u64)]
+                ("motion_type", u32), ("global_id", u64), ("userdata", u64), ("gravity_factor", f32), ("linear_damping", f32),
+                ("angular_damping", f32), ("flags", u32), ("_pad", u32 * 2)]
+
+
+GHOST_FLAG_LAYER_MASK, GHOST_FLAG_SENSOR, GHOST_FLAG_ALLOW_SLEEP, GHOST_FLAG_ZERO_DRAG = 0x3, 1 << 2, 1 << 3, 1 << 4
 
 
 class ConstraintDump(C.Structure):

@@ -115,6 +115,8 @@ struct BodyCmd {
 	float inv_inertia[3];
 	float friction, restitution, gravity_factor, lin_damp, ang_damp;
 	uint32_t flags;
+	uint32_t pad_;
+	uint64_t userdata;
 };
 
 // Per-step scalars, device resident: kernels read them through DV::sp so that the launch arguments of a step never
@@ -163,6 +165,7 @@ struct DV {
 	float4* sleep_s[3];        // sleep test spheres: centre xyz, radius w
 	float*  sleep_timer;
 	float*  submerged;
+	uint64_t* userdata;        // mUserData of the body (the caller's PhysicsObject*): travels with the body when its ownership migrates to another tile
 	uint64_t* colour_mask;
 	uint32_t* body_con;        // [body][colour] -> 2 * constraint slot + side, valid where colour_mask[body] has the bit (k_setup)
 	uint64_t* claim[2];

@@ -2094,6 +2094,7 @@ __global__ void __launch_bounds__(TPB) k_apply_cmds(DV d, const BodyCmd* cmds, c
 			d.inv_inertia[i] = make_float4(c.inv_inertia[0], c.inv_inertia[1], c.inv_inertia[2], c.restitution);
 			d.shape[i] = make_float4(c.shape[0], c.shape[1], c.shape[2], c.friction);
 			d.submerged[i] = 0.0f;
+			d.userdata[i] = c.userdata;
 			refresh_aabb(d, i, f);
 			reset_sleep(d, i, f_shape(f), d.shape[i], V3(d.pos_im[i]), Q4(d.rot[i]));
 			continue;
@@ -2757,6 +2758,15 @@ SGP_DEV bool export_qualifies(const DV& d, uint32_t i, float3 lo, float3 hi, flo
 	       mx.x + margin >= hi.x || mx.y + margin >= hi.y || mx.z + margin >= hi.z;
 }
 
+// the part of the record only an ownership migration reads: user data, layer + flags, damping, gravity factor
+SGP_DEV void fill_ghost_desc(const DV& d, uint32_t i, uint32_t f, sgp_ghost_record& r)
+{
+	r.userdata = d.userdata[i];
+	r.gravity_factor = d.force[i].w; r.linear_damping = d.linv[i].w; r.angular_damping = d.angv[i].w;
+	r.flags = f_layer(f) | ((f & BF_SENSOR) ? SGP_GHOST_FLAG_SENSOR : 0u) | ((f & BF_ALLOW_SLEEP) ? SGP_GHOST_FLAG_ALLOW_SLEEP : 0u) | ((f & BF_ZERO_LIN_DRAG) ? SGP_GHOST_FLAG_ZERO_DRAG : 0u);
+	r._pad[0] = 0; r._pad[1] = 0;
+}
+
 __global__ void __launch_bounds__(TPB) k_export_count(DV d, float3 lo, float3 hi, float margin)
 {
 	__shared__ uint32_t wsum[TPB / 64];
@@ -2803,6 +2813,7 @@ __global__ void __launch_bounds__(TPB) k_export_boundary(DV d, float3 lo, float3
 	r.mass = d.torque[i].w; r.friction = sh.w; r.restitution = d.inv_inertia[i].w;
 	r.motion_type = f_motion(f);
 	r.global_id = i;
+	fill_ghost_desc(d, i, f, r);
 	out[k] = r;
 }
 

@@ -271,7 +271,7 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	DEV_ALLOC(d.force, N); DEV_ALLOC(d.torque, N); DEV_ALLOC(d.inv_inertia, N); DEV_ALLOC(d.shape, N);
 	DEV_ALLOC(d.flags, N); DEV_ALLOC(d.aabb_min, N); DEV_ALLOC(d.aabb_max, N);
 	for (int k = 0; k < 3; ++k) DEV_ALLOC(d.sleep_s[k], N);
-	DEV_ALLOC(d.sleep_timer, N); DEV_ALLOC(d.submerged, N);
+	DEV_ALLOC(d.sleep_timer, N); DEV_ALLOC(d.submerged, N); DEV_ALLOC(d.userdata, N);
 	DEV_ALLOC(d.colour_mask, N); DEV_ALLOC(d.body_con, (size_t)N * SGP_MAX_COLOURS); DEV_ALLOC(d.claim[0], N); DEV_ALLOC(d.claim[1], N);
 	DEV_ALLOC(d.island, N); DEV_ALLOC(d.island_awake, N); DEV_ALLOC(d.awake_mark, N); DEV_ALLOC(d.export_counts, N / 256 + 2);
 	DEV_ALLOC(d.sbody, 4 * (size_t)N);
@@ -456,6 +456,7 @@ static int add_one(sgp_world* w, const sgp_body_desc* d, uint32_t* id_out, bool 
 	c.restitution = clamp01(d->restitution);           // :1237
 	c.mass = std::max(0.001f, d->mass);                // :1238
 	c.gravity_factor = d->gravity_factor; c.lin_damp = d->linear_damping; c.ang_damp = d->angular_damping;
+	c.userdata = d->userdata;
 	if (d->motion_type == SGP_MOTION_DYNAMIC) {
 		if (hull) {
 			// MassProperties of the hull scaled to the overridden mass; the body frame already is the principal frame

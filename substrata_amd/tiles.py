@@ -66,16 +66,19 @@ def inside(recs, lo, hi):
 
 
 def records_to_descs(recs):
-    """Body descs for immigrants: dynamic, awake, layer MOVING, Jolt default damping / gravity factor."""
+    """Body descs for immigrants: the body exactly as its previous owner described it (user data, layer, sensor / sleeping / drag flags,
+    damping, gravity factor travel in the record), dynamic and awake."""
     d = np.zeros(len(recs), dtype=abi.body_desc_dtype)
-    for f in ("pos", "rot", "lin_vel", "ang_vel", "shape_type", "shape", "mass", "friction", "restitution"):
+    for f in ("pos", "rot", "lin_vel", "ang_vel", "shape_type", "shape", "mass", "friction", "restitution", "userdata", "gravity_factor"):
         d[f] = recs[f]
+    d["linear_damping"] = recs["linear_damping"]
+    d["angular_damping"] = recs["angular_damping"]
+    fl = recs["flags"]
     d["motion_type"] = abi.MOTION_DYNAMIC
-    d["layer"] = abi.LAYER_MOVING
-    d["gravity_factor"] = 1.0
-    d["linear_damping"] = 0.05
-    d["angular_damping"] = 0.05
-    d["allow_sleeping"] = 1
+    d["layer"] = fl & abi.GHOST_FLAG_LAYER_MASK
+    d["is_sensor"] = (fl & abi.GHOST_FLAG_SENSOR) != 0
+    d["allow_sleeping"] = (fl & abi.GHOST_FLAG_ALLOW_SLEEP) != 0
+    d["use_zero_linear_drag"] = (fl & abi.GHOST_FLAG_ZERO_DRAG) != 0
     d["activate"] = 1
     return d
 
