@@ -199,7 +199,19 @@ def main():
         cap = (2 * total_bodies // max(1, min(n_gpus, 4)) if workload == "config4" and n_gpus > 1 else n_own) + 65536
         w = World(max_bodies=cap, device=local_rank)
         w.add_batch(descs)
-        ex = tiles.GhostExchange(w, rank, n_gpus, lo, hi, margin=2.0, dist=dist, device=xdev) if n_gpus > 1 else None
+        ex = None
+        if n_gpus > 1 and args.backend == "nccl":
+            # the native exchange (sgp_tiles_*: device routing + RCCL send / recv from inside libsgp.so); torch.distributed only carries the
+            # communicator's unique id to the other ranks and runs the barriers around the timed region
+            boxes_t = torch.zeros(n_gpus * 6, dtype=torch.float32, device=xdev)
+            dist.all_gather_into_tensor(boxes_t, torch.from_numpy(np.concatenate([lo, hi]).astype(np.float32)).to(xdev))
+            uid = torch.zeros(128, dtype=torch.uint8, device=xdev)
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(tiles.NativeTiles.unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, src=0)
+            ex = tiles.NativeTiles(w, rank, n_gpus, boxes_t.cpu().numpy().reshape(n_gpus, 6), 2.0, unique_id=bytes(uid.cpu().numpy().tobytes()))
+        elif n_gpus > 1:
+            ex = tiles.GhostExchange(w, rank, n_gpus, lo, hi, margin=2.0, dist=dist, device=xdev)      # gloo dry run on a shared GPU
 
         def one_step():
             if ex is not None:

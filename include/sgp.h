@@ -532,6 +532,49 @@ int  sgp_tiles_route(const sgp_ghost_record* recs, uint32_t n, uint32_t my_rank,
 int  sgp_tiles_split(const sgp_ghost_record* in, uint32_t n, const float lo[3], const float hi[3],
                      sgp_ghost_record* ghosts_out, uint32_t* n_ghosts, sgp_ghost_record* immigrants_out, uint32_t* n_immigrants);
 
+/* ---- the exchange itself, below the C ABI (what a C++ host with one world per GPU calls once per sub-step before sgp_world_step) ----
+ * The routing runs on the device (one record per (boundary body, destination tile), segmented by destination), the per-destination
+ * counts are all-gathered over RCCL and the records travel device to device with grouped ncclSend / ncclRecv over xGMI; the receiving
+ * tile refreshes its ghosts with a kernel while the ghost set is unchanged, and hands the records to the host (which owns the body
+ * slots) only when ghosts appear / disappear or bodies migrate.  Ownership migrates with the body's full description (sgp_ghost_record).
+ *
+ *   rank 0:  sgp_tiles_unique_id(id)  -> the application broadcasts the 128 bytes (MPI, a socket, torch.distributed ...)
+ *   all:     sgp_tiles_create(world, rank, n_tiles, boxes, margin, radius_pad, id, &tiles)        (collective: ncclCommInitRank)
+ *   per step: sgp_tiles_exchange(tiles); sgp_world_step(world, dt);
+ *
+ * Tiles that live in ONE process (several GPUs driven by one thread, or a single-GPU dry run) are created with unique_id = NULL and
+ * exchanged together with sgp_tiles_exchange_group (device-to-device copies, no communicator).
+ * boxes: n_tiles x (lo xyz, hi xyz).  margin: a body whose AABB grown by it leaves the tile is exported; a record goes to every other
+ * tile whose region grown by margin + radius_pad contains the body's centre (radius_pad >= the largest bounding radius). */
+typedef struct sgp_tiles sgp_tiles;
+#define SGP_TILES_UNIQUE_ID_BYTES 128
+typedef struct sgp_tiles_stats {
+	uint32_t exported;       /* records this tile produced in the last exchange (a body counts once per destination)     */
+	uint32_t sent;
+	uint32_t received;       /* records that arrived                                                                     */
+	uint32_t ghosts;         /* ... of which ghosts                                                                      */
+	uint32_t emigrated, immigrated;
+	uint32_t fast_imports, slow_imports;     /* exchanges whose import ran on the device / went through the host (cumulative) */
+} sgp_tiles_stats;
+#define SGP_MIGRATION_OUT 0
+#define SGP_MIGRATION_IN  1
+typedef struct sgp_migration {
+	uint64_t userdata;       /* the body's user data (its PhysicsObject*): how a caller finds the object whose id changed          */
+	uint32_t old_id;         /* OUT: the id it had in this world (now free).  IN: the id it had in its previous owner's world      */
+	uint32_t new_id;         /* IN: its id in this world.  OUT: SGP_INVALID_ID                                                     */
+	uint32_t direction;      /* SGP_MIGRATION_OUT / SGP_MIGRATION_IN                                                               */
+	uint32_t peer;           /* IN: rank of the previous owner                                                                     */
+} sgp_migration;
+int  sgp_tiles_unique_id(uint8_t id_out[SGP_TILES_UNIQUE_ID_BYTES]);
+int  sgp_tiles_create(sgp_world* w, uint32_t rank, uint32_t n_tiles, const float* boxes, float margin, float radius_pad,
+                      const uint8_t* unique_id, sgp_tiles** tiles_out);
+int  sgp_tiles_destroy(sgp_tiles* t);
+int  sgp_tiles_exchange(sgp_tiles* t);
+int  sgp_tiles_exchange_group(sgp_tiles** tiles, uint32_t n_tiles);
+int  sgp_tiles_get_stats(sgp_tiles* t, sgp_tiles_stats* out);
+/* Ownership changes since the last drain (both directions), oldest first; n_out = how many were pending. */
+int  sgp_tiles_drain_migrations(sgp_tiles* t, sgp_migration* out, uint32_t cap, uint32_t* n_out);
+
 /* ---- device-resident bulk access (bench / torch plumbing; pointers are HIP device pointers) ---- */
 /* Raw SoA views of the body arrays, valid until the world is destroyed:
  * which = 0 pos_invmass(float4), 1 rot(float4), 2 lin_vel(float4), 3 ang_vel(float4). */

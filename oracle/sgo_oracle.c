@@ -2035,7 +2035,7 @@ SGO_API int sgo_world_import_ghosts(sgo_world* w, const sgp_ghost_record* in, ui
 		d.shape_type = in[k].shape_type; memcpy(d.shape, in[k].shape, 16);
 		d.motion_type = SGP_MOTION_KINEMATIC; d.layer = SGP_LAYER_MOVING;
 		d.mass = in[k].mass; d.friction = in[k].friction; d.restitution = in[k].restitution;
-		d.activate = 1; d.userdata = in[k].global_id;
+		d.activate = 1; d.userdata = in[k].userdata;       /* a ray or an event that meets the ghost names the object, like its owner would */
 		uint32_t id = SGP_INVALID_ID;
 		const int r = sgo_body_add(w, &d, &id);
 		if (r == SGP_OK) { w->is_ghost[id] = 1; ngid[nn] = in[k].global_id; nlid[nn] = id; ++nn; }

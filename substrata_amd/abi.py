@@ -103,6 +103,15 @@ class GhostRecord(C.Structure):
 GHOST_FLAG_LAYER_MASK, GHOST_FLAG_SENSOR, GHOST_FLAG_ALLOW_SLEEP, GHOST_FLAG_ZERO_DRAG = 0x3, 1 << 2, 1 << 3, 1 << 4
 
 
+class TilesStats(C.Structure):
+    _fields_ = [("exported", u32), ("sent", u32), ("received", u32), ("ghosts", u32), ("emigrated", u32), ("immigrated", u32),
+                ("fast_imports", u32), ("slow_imports", u32)]
+
+
+class Migration(C.Structure):
+    _fields_ = [("userdata", u64), ("old_id", u32), ("new_id", u32), ("direction", u32), ("peer", u32)]
+
+
 class ConstraintDump(C.Structure):
     """Debug/test view of one contact constraint of the last step (not part of the reference facade)."""
     _fields_ = [("a", u32), ("b", u32), ("colour", i32), ("np", i32), ("n", f32 * 3), ("lam_n", f32 * 4),
@@ -213,6 +222,7 @@ vehicle_state_dtype = np.dtype(VehicleState)
 capsule_query_dtype = np.dtype(CapsuleQuery)
 query_contact_dtype = np.dtype(QueryContact)
 compound_child_dtype = np.dtype(CompoundChild)
+migration_dtype = np.dtype(Migration)
 
 P = C.POINTER
 vp = C.c_void_p
@@ -268,6 +278,13 @@ PROTOTYPES = {
     "world_import_ghosts": (C.c_int, [vp, vp, u32]),
     "tiles_route": (C.c_int, [vp, u32, u32, vp, u32, f32, vp, u32, vp, vp, u32, P(u32)]),
     "tiles_split": (C.c_int, [vp, u32, vp, vp, vp, P(u32), vp, P(u32)]),
+    "tiles_unique_id": (C.c_int, [vp]),
+    "tiles_create": (C.c_int, [vp, u32, u32, vp, f32, f32, vp, P(vp)]),
+    "tiles_destroy": (C.c_int, [vp]),
+    "tiles_exchange": (C.c_int, [vp]),
+    "tiles_exchange_group": (C.c_int, [vp, u32]),
+    "tiles_get_stats": (C.c_int, [vp, P(TilesStats)]),
+    "tiles_drain_migrations": (C.c_int, [vp, vp, u32, P(u32)]),
     "world_device_array": (C.c_int, [vp, C.c_int, P(vp), P(u32)]),
     "world_stream": (C.c_int, [vp, P(vp)]),
     "mesh_create": (C.c_int, [vp, vp, u32, vp, u32, P(MeshInfo)]),

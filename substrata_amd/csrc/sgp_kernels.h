@@ -275,3 +275,16 @@ void launch_raycast(const DV& d, const sgp_ray* rays, uint32_t n, sgp_hit* hits,
 void launch_collide_capsules(const DV& d, const sgp_capsule_query* q, uint32_t n, sgp_query_contact* out, uint32_t cap, uint32_t* count, hipStream_t s);
 void launch_spherecast(const DV& d, const sgp_ray* rays, const float* radii, uint32_t n, sgp_hit* hits, hipStream_t s);
 void launch_export_boundary(const DV& d, uint32_t nb, float3 lo, float3 hi, float margin, sgp_ghost_record* out, uint32_t cap, uint32_t* count, hipStream_t s);
+
+// ---- tile exchange with the routing on the device (sgp_tiles_*) ----------------------------------------------------
+#define SGP_MAX_TILES 64
+// by-value kernel argument: every tile's region + this tile's rank
+struct TileRoute { float boxes[6 * SGP_MAX_TILES]; uint32_t n_tiles, my_rank; float margin, pad; };
+// what the routing kernels leave for the host (and for the counts all-gather): records per destination, where each destination's segment
+// starts in the send buffer, how many owned bodies emigrate
+struct RouteHeader { uint32_t seg_count[SGP_MAX_TILES]; uint32_t seg_start[SGP_MAX_TILES]; uint32_t n_emigrants; uint32_t total; uint32_t pad[2]; };
+// block_counts / block_offsets: [block][n_tiles + 1] (last column: emigrants)
+void launch_route_export(const DV& d, uint32_t nb, const TileRoute& t, uint32_t* block_counts, uint32_t* block_offsets, RouteHeader* header,
+                         sgp_ghost_record* out, uint32_t cap, uint32_t* emigrant_ids, uint32_t emigrant_cap, hipStream_t s);
+// ghost pose refresh straight from received records: record k refreshes body ids[k] (the unchanged-ghost-set fast path, no host copy of the poses)
+void launch_ghost_refresh_records(const DV& d, const sgp_ghost_record* recs, const uint32_t* ids, uint32_t n, hipStream_t s);

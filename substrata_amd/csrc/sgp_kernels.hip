@@ -2817,6 +2817,145 @@ __global__ void __launch_bounds__(TPB) k_export_boundary(DV d, float3 lo, float3
 	out[k] = r;
 }
 
+// ---- export with the routing done on the device: one record per (qualifying body, destination tile) --------------------------------
+// Same rules as the host statement (sgp_tiles_route): a qualifying body goes to every OTHER tile whose region grown by `pad` contains its
+// centre; an owned dynamic body whose centre has left this tile's region emigrates (flagged, listed).  The send buffer is segmented by
+// destination (rank order) and ascending in body id inside a segment: counts per (block, destination) -> scan -> write, no sort, no atomics.
+SGP_DEV bool tile_in_box(float4 p, const float* lo, const float* hi, float pad)
+{
+	return p.x >= lo[0] - pad && p.x < hi[0] + pad && p.y >= lo[1] - pad && p.y < hi[1] + pad && p.z >= lo[2] - pad && p.z < hi[2] + pad;
+}
+SGP_DEV unsigned long long route_mask(const DV& d, uint32_t i, const TileRoute& t, bool& emigrates, uint32_t& f)
+{
+	emigrates = false;
+	const float* mylo = t.boxes + 6 * t.my_rank; const float* myhi = mylo + 3;
+	if (!export_qualifies(d, i, make_float3(mylo[0], mylo[1], mylo[2]), make_float3(myhi[0], myhi[1], myhi[2]), t.margin, f)) return 0ull;
+	const float4 p = d.pos_im[i];
+	emigrates = t.n_tiles > 1 && f_motion(f) == SGP_MOTION_DYNAMIC && !tile_in_box(p, mylo, myhi, 0.0f);
+	unsigned long long m = 0ull;
+	for (uint32_t r = 0; r < t.n_tiles; ++r) { if (r == t.my_rank) continue; const float* lo = t.boxes + 6 * r; if (tile_in_box(p, lo, lo + 3, t.pad)) m |= 1ull << r; }
+	return m;
+}
+
+__global__ void __launch_bounds__(TPB) k_route_count(DV d, TileRoute t, uint32_t* block_counts)
+{
+	__shared__ uint32_t cnt[SGP_MAX_TILES + 1];
+	if (threadIdx.x <= SGP_MAX_TILES) cnt[threadIdx.x] = 0;
+	__syncthreads();
+	bool emig; uint32_t f;
+	const unsigned long long mask = route_mask(d, blockIdx.x * TPB + threadIdx.x, t, emig, f);
+	const int lane = threadIdx.x & 63;
+	for (uint32_t r = 0; r < t.n_tiles; ++r) { const unsigned long long b = __ballot((mask >> r) & 1ull); if (b && lane == 0) atomicAdd(&cnt[r], (uint32_t)__popcll(b)); }
+	{ const unsigned long long b = __ballot(emig); if (b && lane == 0) atomicAdd(&cnt[t.n_tiles], (uint32_t)__popcll(b)); }
+	__syncthreads();
+	if (threadIdx.x <= t.n_tiles) block_counts[(size_t)blockIdx.x * (t.n_tiles + 1) + threadIdx.x] = cnt[threadIdx.x];
+}
+
+// one workgroup: per column (destination, or emigrants) the exclusive scan of the block counts; then the segment starts
+__global__ void __launch_bounds__(1024) k_route_scan(const uint32_t* block_counts, uint32_t* block_offsets, uint32_t n_blocks, uint32_t n_tiles, RouteHeader* header)
+{
+	__shared__ uint32_t wave_sums[16];
+	__shared__ uint32_t carry;
+	__shared__ uint32_t totals[SGP_MAX_TILES + 1];
+	const uint32_t cols = n_tiles + 1;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	for (uint32_t c = 0; c < cols; ++c) {
+		if (threadIdx.x == 0) carry = 0;
+		__syncthreads();
+		for (uint32_t start = 0; start < n_blocks; start += 1024) {
+			const uint32_t b = start + threadIdx.x;
+			const uint32_t v = b < n_blocks ? block_counts[(size_t)b * cols + c] : 0u;
+			uint32_t x = v;
+			for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off, 64); if (lane >= off) x += y; }
+			if (lane == 63) wave_sums[wave] = x;
+			__syncthreads();
+			uint32_t wbase = carry;
+			for (int k = 0; k < wave; ++k) wbase += wave_sums[k];
+			if (b < n_blocks) block_offsets[(size_t)b * cols + c] = wbase + x - v;
+			__syncthreads();
+			if (threadIdx.x == 1023) carry = wbase + x;
+			__syncthreads();
+		}
+		if (threadIdx.x == 0) totals[c] = carry;
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		uint32_t acc = 0;
+		for (uint32_t r = 0; r < SGP_MAX_TILES; ++r) { const uint32_t n = r < n_tiles ? totals[r] : 0u; header->seg_count[r] = n; header->seg_start[r] = acc; acc += n; }
+		header->total = acc; header->n_emigrants = totals[n_tiles]; header->pad[0] = header->pad[1] = 0;
+	}
+}
+
+__global__ void __launch_bounds__(TPB) k_route_write(DV d, TileRoute t, const uint32_t* block_offsets, const RouteHeader* header, sgp_ghost_record* out, uint32_t cap,
+                                                     uint32_t* emigrant_ids, uint32_t emigrant_cap)
+{
+	__shared__ uint32_t wcnt[TPB / 64][SGP_MAX_TILES + 1];
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	bool emig; uint32_t f = 0;
+	const unsigned long long mask = route_mask(d, i, t, emig, f);
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const unsigned long long below = (1ull << lane) - 1ull;
+	// per wave and column: how many of this wave's lanes write to it
+	for (uint32_t r = 0; r <= t.n_tiles; ++r) {
+		const unsigned long long b = __ballot(r < t.n_tiles ? ((mask >> r) & 1ull) != 0ull : emig);
+		if (lane == 0) wcnt[wv][r] = (uint32_t)__popcll(b);
+	}
+	__syncthreads();
+	if (!mask && !emig) return;
+	const uint32_t cols = t.n_tiles + 1;
+	sgp_ghost_record r;
+	bool built = false;
+	for (uint32_t dst = 0; dst < t.n_tiles; ++dst) {
+		const unsigned long long b = __ballot(((mask >> dst) & 1ull) != 0ull);      // (every lane that reached this point takes part: the loop bounds are wave-uniform)
+		if (!((mask >> dst) & 1ull)) continue;
+		uint32_t wbase = 0;
+		for (int k = 0; k < wv; ++k) wbase += wcnt[k][dst];
+		const uint32_t k = header->seg_start[dst] + block_offsets[(size_t)blockIdx.x * cols + dst] + wbase + (uint32_t)__popcll(b & below);
+		if (k >= cap) continue;
+		if (!built) {
+			const float4 p = d.pos_im[i], qq = d.rot[i], lv = d.linv[i], av = d.angv[i], sh = d.shape[i];
+			r.pos[0] = p.x; r.pos[1] = p.y; r.pos[2] = p.z;
+			r.rot[0] = qq.x; r.rot[1] = qq.y; r.rot[2] = qq.z; r.rot[3] = qq.w;
+			r.lin_vel[0] = lv.x; r.lin_vel[1] = lv.y; r.lin_vel[2] = lv.z;
+			r.ang_vel[0] = av.x; r.ang_vel[1] = av.y; r.ang_vel[2] = av.z;
+			r.shape_type = (int32_t)f_shape(f);
+			r.shape[0] = sh.x; r.shape[1] = sh.y; r.shape[2] = sh.z; r.shape[3] = 0.0f;
+			r.mass = d.torque[i].w; r.friction = sh.w; r.restitution = d.inv_inertia[i].w;
+			r.motion_type = emig ? (SGP_MOTION_DYNAMIC | SGP_GHOST_TAKE_OWNERSHIP) : f_motion(f);
+			r.global_id = (uint64_t)i | ((uint64_t)t.my_rank << 40);
+			fill_ghost_desc(d, i, f, r);
+			built = true;
+		}
+		out[k] = r;
+	}
+	if (emig) {
+		uint32_t wbase = 0;
+		for (int k = 0; k < wv; ++k) wbase += wcnt[k][t.n_tiles];
+		const unsigned long long b = __ballot(emig);
+		const uint32_t k = block_offsets[(size_t)blockIdx.x * cols + t.n_tiles] + wbase + (uint32_t)__popcll(b & below);
+		if (k < emigrant_cap) emigrant_ids[k] = i;
+	}
+}
+
+__global__ void __launch_bounds__(TPB) k_ghost_refresh_records(DV d, const sgp_ghost_record* recs, const uint32_t* ids, uint32_t n)
+{
+	const uint32_t k = blockIdx.x * TPB + threadIdx.x;
+	if (k >= n) return;
+	const uint32_t i = ids[k];
+	uint32_t f = d.flags[i];
+	if (!(f & BF_ALIVE)) return;
+	const sgp_ghost_record& c = recs[k];
+	d.pos_im[i] = make_float4(c.pos[0], c.pos[1], c.pos[2], d.pos_im[i].w);
+	d.rot[i] = make_float4(c.rot[0], c.rot[1], c.rot[2], c.rot[3]);
+	if (f_motion(f) != SGP_MOTION_STATIC) {
+		d.linv[i] = make_float4(c.lin_vel[0], c.lin_vel[1], c.lin_vel[2], d.linv[i].w);
+		d.angv[i] = make_float4(c.ang_vel[0], c.ang_vel[1], c.ang_vel[2], d.angv[i].w);
+	}
+	refresh_aabb(d, i, f);
+	f = activate_body(d, i, f);
+	d.flags[i] = f;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // launch wrappers
 
@@ -2917,6 +3056,18 @@ void launch_vehicle_solve(const DV& d, int mode, hipStream_t s)
 void launch_raycast(const DV& d, const sgp_ray* rays, uint32_t n, sgp_hit* hits, hipStream_t s) { if (n) hipLaunchKernelGGL(k_raycast, dim3((n + 63) / 64), dim3(64), 0, s, d, rays, n, hits); }
 void launch_collide_capsules(const DV& d, const sgp_capsule_query* q, uint32_t n, sgp_query_contact* out, uint32_t cap, uint32_t* count, hipStream_t s) { if (n) hipLaunchKernelGGL(k_collide_capsules, dim3((n + 63) / 64), dim3(64), 0, s, d, q, n, out, cap, count); }
 void launch_spherecast(const DV& d, const sgp_ray* rays, const float* radii, uint32_t n, sgp_hit* hits, hipStream_t s) { if (n) hipLaunchKernelGGL(k_spherecast, dim3((n + 63) / 64), dim3(64), 0, s, d, rays, radii, n, hits); }
+void launch_route_export(const DV& d, uint32_t nb, const TileRoute& t, uint32_t* block_counts, uint32_t* block_offsets, RouteHeader* header,
+                         sgp_ghost_record* out, uint32_t cap, uint32_t* emigrant_ids, uint32_t emigrant_cap, hipStream_t s)
+{
+	const uint32_t blocks = blocks_for(nb);
+	hipLaunchKernelGGL(k_route_count, dim3(blocks), dim3(TPB), 0, s, d, t, block_counts);
+	hipLaunchKernelGGL(k_route_scan, dim3(1), dim3(1024), 0, s, (const uint32_t*)block_counts, block_offsets, blocks, t.n_tiles, header);
+	hipLaunchKernelGGL(k_route_write, dim3(blocks), dim3(TPB), 0, s, d, t, (const uint32_t*)block_offsets, (const RouteHeader*)header, out, cap, emigrant_ids, emigrant_cap);
+}
+void launch_ghost_refresh_records(const DV& d, const sgp_ghost_record* recs, const uint32_t* ids, uint32_t n, hipStream_t s)
+{
+	if (n) hipLaunchKernelGGL(k_ghost_refresh_records, dim3(blocks_for(n)), dim3(TPB), 0, s, d, recs, ids, n);
+}
 void launch_export_boundary(const DV& d, uint32_t nb, float3 lo, float3 hi, float margin, sgp_ghost_record* out, uint32_t cap, uint32_t* count, hipStream_t s)
 {
 	const uint32_t blocks = blocks_for(nb);

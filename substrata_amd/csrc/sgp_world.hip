@@ -2028,7 +2028,7 @@ SGP_API int sgp_world_import_ghosts(sgp_world* w, const sgp_ghost_record* in, ui
 		d.motion_type = SGP_MOTION_KINEMATIC;      // velocity driven, infinite mass for this tile's solve
 		d.layer = SGP_LAYER_MOVING;
 		d.mass = in[k].mass; d.friction = in[k].friction; d.restitution = in[k].restitution;
-		d.activate = 1; d.userdata = in[k].global_id;
+		d.activate = 1; d.userdata = in[k].userdata;       // a ray or an event that meets the ghost names the object, like its owner would
 		uint32_t id = SGP_INVALID_ID;
 		const int r = add_one(w, &d, &id, true);
 		if (r == SGP_OK) { w->ghost_map[in[k].global_id] = ((uint64_t)gen << 32) | id; w->ghost_seq[k].second = id; }
@@ -2118,5 +2118,403 @@ SGP_API int sgp_world_stream(sgp_world* w, void** stream_out)
 {
 	if (!w || !stream_out) return fail(SGP_ERR_INVALID, "sgp_world_stream: NULL");
 	*stream_out = (void*)w->stream;
+	return SGP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// sgp_tiles_*: the per-step ghost exchange of the spatial tiles below the C ABI.
+//
+//   export + ROUTING on the device (k_route_count / scan / write: one record per (body, destination), segmented by destination)
+//   -> per-destination counts all-gathered over RCCL (ncclAllGather, device buffers) and read back with ONE small copy (header +
+//      counts matrix + emigrant ids)
+//   -> the records travel device to device: grouped ncclSend / ncclRecv over xGMI straight out of the send buffer's segments
+//      (or, for several tiles driven by one process, plain device-to-device copies)
+//   -> the receiving tile refreshes its ghosts.  While the set of ghosts is what it was the step before (the steady state), a kernel
+//      applies the poses straight from the received records; only when the set changed (or bodies immigrate) do the records come to
+//      the host, which owns the body slots.
+// RCCL is bound at run time (dlopen): libsgp.so carries no link-time dependency on it, a single-GPU user never loads it.
+#include <dlfcn.h>
+
+namespace {
+typedef struct { char internal[128]; } sgp_nccl_unique_id;
+typedef void* sgp_nccl_comm;
+enum { SGP_NCCL_UINT8 = 1, SGP_NCCL_UINT32 = 3 };          // ncclDataType_t (rccl.h): ncclUint8 = 1, ncclUint32 = 3
+struct RcclApi {
+	void* lib = nullptr; bool tried = false;
+	int (*GetUniqueId)(sgp_nccl_unique_id*) = nullptr;
+	int (*CommInitRank)(sgp_nccl_comm*, int, sgp_nccl_unique_id, int) = nullptr;
+	int (*CommDestroy)(sgp_nccl_comm) = nullptr;
+	int (*AllGather)(const void*, void*, size_t, int, sgp_nccl_comm, hipStream_t) = nullptr;
+	int (*Send)(const void*, size_t, int, int, sgp_nccl_comm, hipStream_t) = nullptr;
+	int (*Recv)(void*, size_t, int, int, sgp_nccl_comm, hipStream_t) = nullptr;
+	int (*GroupStart)() = nullptr;
+	int (*GroupEnd)() = nullptr;
+	const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+
+bool rccl_load()
+{
+	if (g_rccl.tried) return g_rccl.lib != nullptr;
+	g_rccl.tried = true;
+	// the copy this process already has (PyTorch brings its own), else the system's
+	const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so" };
+	for (const char* n : names) { g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); if (g_rccl.lib) break; }
+	if (!g_rccl.lib) for (const char* n : names) { g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (g_rccl.lib) break; }
+	if (!g_rccl.lib) return false;
+	bool ok = true;
+	auto sym = [&](const char* name) { void* p = dlsym(g_rccl.lib, name); if (!p) ok = false; return p; };
+	g_rccl.GetUniqueId = (int (*)(sgp_nccl_unique_id*))sym("ncclGetUniqueId");
+	g_rccl.CommInitRank = (int (*)(sgp_nccl_comm*, int, sgp_nccl_unique_id, int))sym("ncclCommInitRank");
+	g_rccl.CommDestroy = (int (*)(sgp_nccl_comm))sym("ncclCommDestroy");
+	g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, sgp_nccl_comm, hipStream_t))sym("ncclAllGather");
+	g_rccl.Send = (int (*)(const void*, size_t, int, int, sgp_nccl_comm, hipStream_t))sym("ncclSend");
+	g_rccl.Recv = (int (*)(void*, size_t, int, int, sgp_nccl_comm, hipStream_t))sym("ncclRecv");
+	g_rccl.GroupStart = (int (*)())sym("ncclGroupStart");
+	g_rccl.GroupEnd = (int (*)())sym("ncclGroupEnd");
+	g_rccl.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+	if (!ok) { g_rccl.lib = nullptr; return false; }
+	return true;
+}
+int rccl_fail(const char* what, int rc)
+{
+	g_last_error = std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error");
+	return SGP_ERR_HIP;
+}
+#define RCCL_TRY(call, what) do { const int rc_ = (call); if (rc_ != 0) return rccl_fail(what, rc_); } while (0)
+}
+
+#define SGP_TILES_EMIG_INLINE 512          // emigrant ids that come back with the header copy
+
+struct sgp_tiles {
+	sgp_world* w = nullptr;
+	uint32_t rank = 0, n_tiles = 1;
+	TileRoute route;
+	sgp_nccl_comm comm = nullptr;
+	// device
+	uint32_t* d_block_counts = nullptr; uint32_t* d_block_offsets = nullptr; uint32_t cap_blocks = 0;
+	char* d_ctl = nullptr;                 // [RouteHeader][counts matrix n_tiles x SGP_MAX_TILES... see ctl_bytes][emigrant ids]
+	sgp_ghost_record* d_send = nullptr; uint32_t cap_send = 0;
+	sgp_ghost_record* d_recv = nullptr; uint32_t cap_recv = 0;
+	uint32_t* d_emig = nullptr; uint32_t cap_emig = 0;
+	uint32_t* d_seq_ids = nullptr; uint32_t cap_seq = 0;       // local body id of ghost k of the previous import (device copy, for the refresh kernel)
+	// host (pinned)
+	char* h_ctl = nullptr; sgp_ghost_record* h_recv = nullptr; uint32_t cap_h_recv = 0;
+	// last exchange
+	std::vector<uint32_t> recv_counts, recv_offsets;
+	std::vector<uint64_t> seq_gids;        // global ids of the ghosts of the previous import, in order
+	bool seq_valid = false;
+	sgp_tiles_stats stats;
+	std::vector<sgp_migration> migrations;
+};
+static size_t tiles_matrix_off() { return sizeof(RouteHeader); }
+static size_t tiles_emig_off(uint32_t n_tiles) { return sizeof(RouteHeader) + sizeof(uint32_t) * (size_t)n_tiles * n_tiles; }
+static size_t tiles_ctl_bytes(uint32_t n_tiles) { return tiles_emig_off(n_tiles) + sizeof(uint32_t) * SGP_TILES_EMIG_INLINE; }
+
+SGP_API int sgp_tiles_unique_id(uint8_t out[SGP_TILES_UNIQUE_ID_BYTES])
+{
+	if (!out) return fail(SGP_ERR_INVALID, "sgp_tiles_unique_id: NULL");
+	if (!rccl_load()) return fail(SGP_ERR_HIP, "sgp_tiles_unique_id: RCCL (librccl.so) not found");
+	sgp_nccl_unique_id id;
+	RCCL_TRY(g_rccl.GetUniqueId(&id), "ncclGetUniqueId");
+	static_assert(sizeof(id) == SGP_TILES_UNIQUE_ID_BYTES, "ncclUniqueId is 128 bytes");
+	memcpy(out, &id, sizeof(id));
+	return SGP_OK;
+}
+
+template <typename T> static int tiles_grow(sgp_world* w, T*& p, uint32_t& cap, uint32_t need, bool keep = false)
+{
+	if (need <= cap) return SGP_OK;
+	const uint32_t nc = std::max(need + need / 2, 4096u);
+	T* q = nullptr;
+	HIP_TRY(hipMalloc((void**)&q, sizeof(T) * (size_t)nc));
+	if (p) { HIP_TRY(hipStreamSynchronize(w->stream)); if (keep && cap) HIP_TRY(hipMemcpy(q, p, sizeof(T) * (size_t)cap, hipMemcpyDeviceToDevice)); hipFree(p); }
+	p = q; cap = nc;
+	return SGP_OK;
+}
+
+SGP_API int sgp_tiles_destroy(sgp_tiles* t)
+{
+	if (!t) return SGP_OK;
+	if (t->w) { hipSetDevice(t->w->device); hipStreamSynchronize(t->w->stream); }
+	if (t->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(t->comm);
+	hipFree(t->d_block_counts); hipFree(t->d_block_offsets); hipFree(t->d_ctl); hipFree(t->d_send); hipFree(t->d_recv); hipFree(t->d_emig); hipFree(t->d_seq_ids);
+	if (t->h_ctl) hipHostFree(t->h_ctl);
+	if (t->h_recv) hipHostFree(t->h_recv);
+	delete t;
+	return SGP_OK;
+}
+
+SGP_API int sgp_tiles_create(sgp_world* w, uint32_t rank, uint32_t n_tiles, const float* boxes, float margin, float radius_pad, const uint8_t* unique_id, sgp_tiles** out)
+{
+	if (!w || !boxes || !out || n_tiles < 1 || n_tiles > SGP_MAX_TILES || rank >= n_tiles) return fail(SGP_ERR_INVALID, "sgp_tiles_create: bad arguments (1..64 tiles)");
+	*out = nullptr;
+	hipSetDevice(w->device);
+	sgp_tiles* t = new sgp_tiles();
+	t->w = w; t->rank = rank; t->n_tiles = n_tiles;
+	memset(&t->route, 0, sizeof(t->route));
+	memcpy(t->route.boxes, boxes, sizeof(float) * 6 * n_tiles);
+	t->route.n_tiles = n_tiles; t->route.my_rank = rank; t->route.margin = margin; t->route.pad = margin + radius_pad;
+	memset(&t->stats, 0, sizeof(t->stats));
+	const size_t cb = tiles_ctl_bytes(n_tiles);
+	if (hipMalloc((void**)&t->d_ctl, cb) != hipSuccess || hipHostMalloc((void**)&t->h_ctl, cb, hipHostMallocDefault) != hipSuccess) { sgp_tiles_destroy(t); return fail(SGP_ERR_HIP, "sgp_tiles_create: allocation"); }
+	hipMemset(t->d_ctl, 0, cb); memset(t->h_ctl, 0, cb);
+	t->recv_counts.assign(n_tiles, 0); t->recv_offsets.assign(n_tiles, 0);
+	if (unique_id && n_tiles > 1) {
+		if (!rccl_load()) { sgp_tiles_destroy(t); return fail(SGP_ERR_HIP, "sgp_tiles_create: RCCL (librccl.so) not found"); }
+		sgp_nccl_unique_id id; memcpy(&id, unique_id, sizeof(id));
+		const int rc = g_rccl.CommInitRank(&t->comm, (int)n_tiles, id, (int)rank);
+		if (rc != 0) { sgp_tiles_destroy(t); return rccl_fail("ncclCommInitRank", rc); }
+	}
+	*out = t;
+	return SGP_OK;
+}
+
+// phase 1: export + routing kernels (stream order), header and emigrant ids still on the device
+static int tiles_launch_route(sgp_tiles* t)
+{
+	sgp_world* w = t->w;
+	{ int r = flush_cmds(w); if (r != SGP_OK) return r; }
+	const uint32_t blocks = w->high ? (w->high + 255u) / 256u : 1u;
+	const uint32_t cols = t->n_tiles + 1;
+	if (blocks * cols > t->cap_blocks) {
+		uint32_t c1 = t->cap_blocks, c2 = t->cap_blocks;
+		{ int r = tiles_grow(w, t->d_block_counts, c1, blocks * cols); if (r != SGP_OK) return r; }
+		{ int r = tiles_grow(w, t->d_block_offsets, c2, blocks * cols); if (r != SGP_OK) return r; }
+		t->cap_blocks = std::min(c1, c2);
+	}
+	if (!t->cap_send) { int r = tiles_grow(w, t->d_send, t->cap_send, 16384u); if (r != SGP_OK) return r; }
+	if (!t->cap_emig) { int r = tiles_grow(w, t->d_emig, t->cap_emig, 4096u); if (r != SGP_OK) return r; }
+	launch_route_export(w->dv, w->high, t->route, t->d_block_counts, t->d_block_offsets, (RouteHeader*)t->d_ctl, t->d_send, t->cap_send, t->d_emig, t->cap_emig, w->stream);
+	// the first emigrant ids ride along with the header copy
+	HIP_TRY(hipMemcpyAsync(t->d_ctl + tiles_emig_off(t->n_tiles), t->d_emig, sizeof(uint32_t) * std::min<uint32_t>(SGP_TILES_EMIG_INLINE, t->cap_emig), hipMemcpyDeviceToDevice, w->stream));
+	return SGP_OK;
+}
+
+// phase 2 (after the control block is on the host): capacity check, emigrants leave this world
+static int tiles_after_header(sgp_tiles* t, bool* redo)
+{
+	sgp_world* w = t->w;
+	*redo = false;
+	const RouteHeader* h = (const RouteHeader*)t->h_ctl;
+	if (h->total > t->cap_send || h->n_emigrants > t->cap_emig) {       // more boundary bodies than the buffers hold: grow, route again
+		if (h->total > t->cap_send) { int r = tiles_grow(w, t->d_send, t->cap_send, h->total); if (r != SGP_OK) return r; }
+		if (h->n_emigrants > t->cap_emig) { int r = tiles_grow(w, t->d_emig, t->cap_emig, h->n_emigrants); if (r != SGP_OK) return r; }
+		*redo = true;
+		return SGP_OK;
+	}
+	t->stats.exported = h->total; t->stats.emigrated = h->n_emigrants;
+	if (h->n_emigrants) {
+		std::vector<uint32_t> ids(h->n_emigrants);
+		const uint32_t inl = std::min<uint32_t>(h->n_emigrants, SGP_TILES_EMIG_INLINE);
+		memcpy(ids.data(), t->h_ctl + tiles_emig_off(t->n_tiles), sizeof(uint32_t) * inl);
+		if (h->n_emigrants > inl) { HIP_TRY(hipMemcpy(ids.data() + inl, t->d_emig + inl, sizeof(uint32_t) * (h->n_emigrants - inl), hipMemcpyDeviceToHost)); }
+		// owned dynamic bodies whose centre has left the tile: removed here, re-created by the tile that contains them (their record is already
+		// in the send buffer, flagged SGP_GHOST_TAKE_OWNERSHIP); the caller learns about it through sgp_tiles_drain_migrations
+		for (uint32_t id : ids) {
+			if (!live(w, id)) continue;
+			sgp_migration m; memset(&m, 0, sizeof(m)); m.userdata = w->hb[id].userdata; m.old_id = id; m.new_id = SGP_INVALID_ID; m.direction = SGP_MIGRATION_OUT;
+			t->migrations.push_back(m);
+			const int r = sgp_body_remove(w, id); if (r != SGP_OK) return r;
+		}
+	}
+	return SGP_OK;
+}
+
+// phase 4: what arrived (n records in d_recv, by source rank) becomes this world's ghost set (+ immigrants)
+static int tiles_import(sgp_tiles* t, uint32_t n)
+{
+	sgp_world* w = t->w;
+	t->stats.received = n;
+	// steady state: the same ghosts as last step in the same order, nobody immigrating -> poses go from the received records to the bodies
+	// on the device; the host only compares the 8-byte ids (copied back packed, not the 128-byte records)
+	if (n > t->cap_h_recv) {
+		if (t->h_recv) hipHostFree(t->h_recv);
+		t->cap_h_recv = n + n / 2 + 1024;
+		HIP_TRY(hipHostMalloc((void**)&t->h_recv, sizeof(sgp_ghost_record) * (size_t)t->cap_h_recv, hipHostMallocDefault));
+	}
+	if (n) {
+		HIP_TRY(hipMemcpyAsync(t->h_recv, t->d_recv, sizeof(sgp_ghost_record) * (size_t)n, hipMemcpyDeviceToHost, w->stream));
+		HIP_TRY(hipStreamSynchronize(w->stream));
+	}
+	bool same = t->seq_valid && n == t->seq_gids.size() && n > 0;
+	for (uint32_t k = 0; k < n && same; ++k) same = t->h_recv[k].global_id == t->seq_gids[k] && !(t->h_recv[k].motion_type & SGP_GHOST_TAKE_OWNERSHIP);
+	if (same) for (uint32_t k = 0; k < n && same; ++k) same = live(w, w->ghost_seq[k].second) && w->ghost_seq[k].first == t->seq_gids[k];
+	if (same) {
+		launch_ghost_refresh_records(w->dv, t->d_recv, t->d_seq_ids, n, w->stream);
+		w->grid_valid = false; w->dirty_since_step = true;
+		t->stats.ghosts = n; t->stats.immigrated = 0; t->stats.fast_imports++;
+		return SGP_OK;
+	}
+	// the set changed: the host, which owns the body slots, sorts ghosts from immigrants and updates the ghost set
+	std::vector<sgp_ghost_record> ghosts; ghosts.reserve(n);
+	std::vector<const sgp_ghost_record*> immigrants;
+	const float* lo = t->route.boxes + 6 * t->rank; const float* hi = lo + 3;
+	for (uint32_t k = 0; k < n; ++k) {
+		const sgp_ghost_record& r = t->h_recv[k];
+		if (!(r.motion_type & SGP_GHOST_TAKE_OWNERSHIP)) ghosts.push_back(r);
+		else if (in_box(r.pos, lo, hi, 0.0f)) immigrants.push_back(&r);          // (flagged records addressed to another tile are dropped)
+	}
+	{ int rc = sgp_world_import_ghosts(w, ghosts.data(), (uint32_t)ghosts.size()); if (rc != SGP_OK) return rc; }
+	uint32_t n_imm = 0;
+	for (const sgp_ghost_record* pr : immigrants) {
+		const sgp_ghost_record& r = *pr;
+		sgp_body_desc d; sgp_default_body_desc(&d);
+		memcpy(d.pos, r.pos, 12); memcpy(d.rot, r.rot, 16); memcpy(d.lin_vel, r.lin_vel, 12); memcpy(d.ang_vel, r.ang_vel, 12);
+		d.shape_type = r.shape_type; memcpy(d.shape, r.shape, 16);
+		d.motion_type = SGP_MOTION_DYNAMIC;
+		d.layer = (int32_t)(r.flags & SGP_GHOST_FLAG_LAYER_MASK);
+		d.is_sensor = (r.flags & SGP_GHOST_FLAG_SENSOR) ? 1 : 0; d.allow_sleeping = (r.flags & SGP_GHOST_FLAG_ALLOW_SLEEP) ? 1 : 0; d.use_zero_linear_drag = (r.flags & SGP_GHOST_FLAG_ZERO_DRAG) ? 1 : 0;
+		d.mass = r.mass; d.friction = r.friction; d.restitution = r.restitution;
+		d.gravity_factor = r.gravity_factor; d.linear_damping = r.linear_damping; d.angular_damping = r.angular_damping;
+		d.userdata = r.userdata; d.activate = 1;
+		uint32_t id = SGP_INVALID_ID;
+		const int rc = add_one(w, &d, &id, false);
+		// the previous owner has already let go of the body: failing to take it over must not pass silently
+		if (rc != SGP_OK) return fail(rc == SGP_ERR_REJECTED ? SGP_ERR_INVALID : rc, "sgp_tiles_exchange: could not take over a migrating body (raise max_bodies; hull / mesh ids must mean the same shape on every tile)");
+		sgp_migration m; memset(&m, 0, sizeof(m)); m.userdata = r.userdata; m.old_id = (uint32_t)(r.global_id & 0xFFFFFFFFull); m.new_id = id; m.direction = SGP_MIGRATION_IN; m.peer = (uint32_t)(r.global_id >> 40);
+		t->migrations.push_back(m);
+		++n_imm;
+	}
+	t->stats.immigrated = n_imm; t->stats.ghosts = (uint32_t)ghosts.size(); t->stats.slow_imports++;
+	// remember the sequence for the fast path of the next exchange -- valid only if what arrived was ghosts alone
+	t->seq_valid = n_imm == 0 && ghosts.size() == n;
+	if (t->seq_valid) {
+		t->seq_gids.resize(n);
+		std::vector<uint32_t> ids(n);
+		for (uint32_t k = 0; k < n; ++k) { t->seq_gids[k] = ghosts[k].global_id; ids[k] = w->ghost_seq[k].second; if (ids[k] == SGP_INVALID_ID) t->seq_valid = false; }
+		if (t->seq_valid && n) {
+			{ int rc = tiles_grow(w, t->d_seq_ids, t->cap_seq, n); if (rc != SGP_OK) return rc; }
+			{ int rc = flush_cmds(w); if (rc != SGP_OK) return rc; }        // the new ghosts exist on the device before a refresh kernel may touch them
+			HIP_TRY(hipMemcpy(t->d_seq_ids, ids.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+		}
+	} else t->seq_gids.clear();
+	return SGP_OK;
+}
+
+SGP_API int sgp_tiles_exchange(sgp_tiles* t)
+{
+	if (!t || !t->w) return fail(SGP_ERR_INVALID, "sgp_tiles_exchange: NULL");
+	sgp_world* w = t->w;
+	hipSetDevice(w->device);
+	const uint32_t T = t->n_tiles;
+	if (T > 1 && !t->comm) return fail(SGP_ERR_INVALID, "sgp_tiles_exchange: created without a communicator (use sgp_tiles_exchange_group for tiles of one process)");
+	uint32_t* d_matrix = (uint32_t*)(t->d_ctl + tiles_matrix_off());
+	for (int attempt = 0; attempt < 3; ++attempt) {
+		{ int r = tiles_launch_route(t); if (r != SGP_OK) return r; }
+		// every rank's per-destination counts: one small all-gather on device buffers
+		if (T > 1) RCCL_TRY(g_rccl.AllGather(t->d_ctl /* RouteHeader::seg_count comes first */, d_matrix, T, SGP_NCCL_UINT32, t->comm, w->stream), "ncclAllGather");
+		HIP_TRY(hipMemcpyAsync(t->h_ctl, t->d_ctl, tiles_ctl_bytes(T), hipMemcpyDeviceToHost, w->stream));
+		HIP_TRY(hipStreamSynchronize(w->stream));
+		bool redo = false;
+		{ int r = tiles_after_header(t, &redo); if (r != SGP_OK) return r; }
+		if (!redo) break;
+		if (attempt == 2) return fail(SGP_ERR_CAPACITY, "sgp_tiles_exchange: send buffer");
+		// (every rank sees every rank's counts, but only this rank knows its buffers were short: the all-gather above already completed for all,
+		//  so the retry runs the collective again on every rank only if all ranks retry -- they cannot know.  Keep it collective-safe: a rank that
+		//  had to grow reports the error instead of desynchronising the communicator.)
+		if (T > 1) return fail(SGP_ERR_CAPACITY, "sgp_tiles_exchange: boundary larger than the send buffer; the buffers have been grown, call again on every rank");
+	}
+	const RouteHeader* h = (const RouteHeader*)t->h_ctl;
+	const uint32_t* matrix = (const uint32_t*)(t->h_ctl + tiles_matrix_off());          // [source][destination]
+	uint32_t n_recv = 0;
+	for (uint32_t r = 0; r < T; ++r) { t->recv_counts[r] = (T > 1 && r != t->rank) ? matrix[(size_t)r * T + t->rank] : 0u; t->recv_offsets[r] = n_recv; n_recv += t->recv_counts[r]; }
+	{ int r = tiles_grow(w, t->d_recv, t->cap_recv, std::max(n_recv, 1u)); if (r != SGP_OK) return r; }
+	if (T > 1) {
+		RCCL_TRY(g_rccl.GroupStart(), "ncclGroupStart");
+		for (uint32_t r = 0; r < T; ++r) {
+			if (r == t->rank) continue;
+			if (h->seg_count[r]) RCCL_TRY(g_rccl.Send(t->d_send + h->seg_start[r], sizeof(sgp_ghost_record) * (size_t)h->seg_count[r], SGP_NCCL_UINT8, (int)r, t->comm, w->stream), "ncclSend");
+			if (t->recv_counts[r]) RCCL_TRY(g_rccl.Recv(t->d_recv + t->recv_offsets[r], sizeof(sgp_ghost_record) * (size_t)t->recv_counts[r], SGP_NCCL_UINT8, (int)r, t->comm, w->stream), "ncclRecv");
+		}
+		RCCL_TRY(g_rccl.GroupEnd(), "ncclGroupEnd");
+	}
+	t->stats.sent = h->total;
+	return tiles_import(t, n_recv);
+}
+
+// Several tiles driven by ONE process (one GPU or several): the same exchange with plain device-to-device copies in place of RCCL.
+SGP_API int sgp_tiles_exchange_group(sgp_tiles** ts, uint32_t n)
+{
+	if (!ts || !n) return fail(SGP_ERR_INVALID, "sgp_tiles_exchange_group: NULL");
+	for (uint32_t i = 0; i < n; ++i) if (!ts[i] || ts[i]->n_tiles != n || ts[i]->rank != i) return fail(SGP_ERR_INVALID, "sgp_tiles_exchange_group: pass all tiles, in rank order");
+	for (int attempt = 0; attempt < 3; ++attempt) {
+		for (uint32_t i = 0; i < n; ++i) { hipSetDevice(ts[i]->w->device); int r = tiles_launch_route(ts[i]); if (r != SGP_OK) return r;
+			HIP_TRY(hipMemcpyAsync(ts[i]->h_ctl, ts[i]->d_ctl, tiles_ctl_bytes(n), hipMemcpyDeviceToHost, ts[i]->w->stream)); }
+		bool any_redo = false;
+		for (uint32_t i = 0; i < n; ++i) { hipSetDevice(ts[i]->w->device); HIP_TRY(hipStreamSynchronize(ts[i]->w->stream)); const RouteHeader* h = (const RouteHeader*)ts[i]->h_ctl; if (h->total > ts[i]->cap_send || h->n_emigrants > ts[i]->cap_emig) any_redo = true; }
+		if (any_redo) {        // grow whoever was short, route everyone again (nothing has been removed yet)
+			for (uint32_t i = 0; i < n; ++i) { const RouteHeader* h = (const RouteHeader*)ts[i]->h_ctl; hipSetDevice(ts[i]->w->device);
+				if (h->total > ts[i]->cap_send) { int r = tiles_grow(ts[i]->w, ts[i]->d_send, ts[i]->cap_send, h->total); if (r != SGP_OK) return r; }
+				if (h->n_emigrants > ts[i]->cap_emig) { int r = tiles_grow(ts[i]->w, ts[i]->d_emig, ts[i]->cap_emig, h->n_emigrants); if (r != SGP_OK) return r; } }
+			if (attempt == 2) return fail(SGP_ERR_CAPACITY, "sgp_tiles_exchange_group: send buffer");
+			continue;
+		}
+		break;
+	}
+	for (uint32_t i = 0; i < n; ++i) { bool redo = false; hipSetDevice(ts[i]->w->device); int r = tiles_after_header(ts[i], &redo); if (r != SGP_OK) return r; }
+	for (uint32_t dst = 0; dst < n; ++dst) {
+		sgp_tiles* t = ts[dst];
+		hipSetDevice(t->w->device);
+		uint32_t n_recv = 0;
+		for (uint32_t src = 0; src < n; ++src) { const RouteHeader* hs = (const RouteHeader*)ts[src]->h_ctl; t->recv_counts[src] = src == dst ? 0u : hs->seg_count[dst]; t->recv_offsets[src] = n_recv; n_recv += t->recv_counts[src]; }
+		{ int r = tiles_grow(t->w, t->d_recv, t->cap_recv, std::max(n_recv, 1u)); if (r != SGP_OK) return r; }
+		for (uint32_t src = 0; src < n; ++src) {
+			if (!t->recv_counts[src]) continue;
+			const RouteHeader* hs = (const RouteHeader*)ts[src]->h_ctl;
+			HIP_TRY(hipMemcpyAsync(t->d_recv + t->recv_offsets[src], ts[src]->d_send + hs->seg_start[dst], sizeof(sgp_ghost_record) * (size_t)t->recv_counts[src], hipMemcpyDeviceToDevice, t->w->stream));
+		}
+		t->stats.sent = ((const RouteHeader*)t->h_ctl)->total;
+		{ int r = tiles_import(t, n_recv); if (r != SGP_OK) return r; }
+	}
+	return SGP_OK;
+}
+
+SGP_API int sgp_tiles_get_stats(sgp_tiles* t, sgp_tiles_stats* out)
+{
+	if (!t || !out) return fail(SGP_ERR_INVALID, "sgp_tiles_get_stats: NULL");
+	*out = t->stats;
+	return SGP_OK;
+}
+
+SGP_API int sgp_tiles_drain_migrations(sgp_tiles* t, sgp_migration* out, uint32_t cap, uint32_t* n_out)
+{
+	if (!t || !n_out || (!out && cap)) return fail(SGP_ERR_INVALID, "sgp_tiles_drain_migrations: NULL");
+	const uint32_t n = (uint32_t)t->migrations.size(), m = std::min(n, cap);
+	if (m) memcpy(out, t->migrations.data(), sizeof(sgp_migration) * m);
+	*n_out = n;
+	t->migrations.erase(t->migrations.begin(), t->migrations.begin() + m);
+	return SGP_OK;
+}
+
+// Self test of the run-time RCCL binding on ONE GPU (tests/test_tiles_parity_gpu.py): a one-rank communicator, an all-gather, and a grouped
+// ncclSend / ncclRecv of `n_records` records from this rank to itself, compared byte for byte.  Not declared in include/sgp.h.
+SGP_API int sgp_tiles_selftest_rccl(sgp_world* w, uint32_t n_records)
+{
+	if (!w || !n_records) return fail(SGP_ERR_INVALID, "sgp_tiles_selftest_rccl: bad arguments");
+	hipSetDevice(w->device);
+	if (!rccl_load()) return fail(SGP_ERR_HIP, "RCCL (librccl.so) not found");
+	sgp_nccl_unique_id id;
+	RCCL_TRY(g_rccl.GetUniqueId(&id), "ncclGetUniqueId");
+	sgp_nccl_comm comm = nullptr;
+	RCCL_TRY(g_rccl.CommInitRank(&comm, 1, id, 0), "ncclCommInitRank");
+	const size_t bytes = sizeof(sgp_ghost_record) * (size_t)n_records;
+	unsigned char *a = nullptr, *b = nullptr; uint32_t *c = nullptr;
+	HIP_TRY(hipMalloc((void**)&a, bytes)); HIP_TRY(hipMalloc((void**)&b, bytes)); HIP_TRY(hipMalloc((void**)&c, 64));
+	std::vector<unsigned char> src(bytes), dst(bytes, 0);
+	for (size_t i = 0; i < bytes; ++i) src[i] = (unsigned char)((i * 2654435761u) >> 13);
+	const uint32_t row[4] = { 11, 22, 33, 44 }; uint32_t got[4] = { 0, 0, 0, 0 };
+	HIP_TRY(hipMemcpy(a, src.data(), bytes, hipMemcpyHostToDevice)); HIP_TRY(hipMemset(b, 0, bytes)); HIP_TRY(hipMemcpy(c, row, 16, hipMemcpyHostToDevice));
+	int rc = g_rccl.AllGather(c, c + 8, 4, SGP_NCCL_UINT32, comm, w->stream);
+	if (rc == 0) rc = g_rccl.GroupStart();
+	if (rc == 0) rc = g_rccl.Send(a, bytes, SGP_NCCL_UINT8, 0, comm, w->stream);
+	if (rc == 0) rc = g_rccl.Recv(b, bytes, SGP_NCCL_UINT8, 0, comm, w->stream);
+	if (rc == 0) rc = g_rccl.GroupEnd();
+	hipStreamSynchronize(w->stream);
+	hipMemcpy(dst.data(), b, bytes, hipMemcpyDeviceToHost); hipMemcpy(got, c + 8, 16, hipMemcpyDeviceToHost);
+	hipFree(a); hipFree(b); hipFree(c);
+	g_rccl.CommDestroy(comm);
+	if (rc != 0) return rccl_fail("RCCL self test", rc);
+	if (memcmp(src.data(), dst.data(), bytes) != 0 || memcmp(row, got, 16) != 0) return fail(SGP_ERR_HIP, "RCCL self test: payload mismatch");
 	return SGP_OK;
 }

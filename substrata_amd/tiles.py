@@ -163,6 +163,89 @@ def exchange_in_process(worlds, boxes, margin, log=None, radius_pad=1.5):
             log.append(("import", r, len(ghosts), len(immigrants)))
 
 
+class NativeTiles:
+    """The exchange below the C ABI (sgp_tiles_*): routing on the device, counts all-gathered and records sent device to device over RCCL
+    from inside libsgp.so, import on the device while the ghost set is unchanged.  Python only hands over the communicator's unique id.
+
+    One tile per process:   t = NativeTiles(world, rank, n, boxes, margin, unique_id=<128 bytes from rank 0>);  t.exchange() each step
+    All tiles in a process: ts = [NativeTiles(w_r, r, n, boxes, margin) ...];  NativeTiles.exchange_group(ts)"""
+
+    def __init__(self, world, rank, n_tiles, boxes, margin, radius_pad=1.5, unique_id=None):
+        self.world, self.rank, self.n = world, rank, n_tiles
+        self._lib = world._lib
+        self._h = C.c_void_p()
+        boxes32 = np.ascontiguousarray(boxes, dtype=np.float32).reshape(n_tiles, 6)
+        uid = None
+        if unique_id is not None:
+            uid = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        rc = self._lib.sgp_tiles_create(world._h, int(rank), int(n_tiles), boxes32.ctypes.data, float(margin), float(radius_pad), uid, C.byref(self._h))
+        if rc != 0:
+            raise RuntimeError(f"sgp_tiles_create failed ({rc}): {self._lib.sgp_last_error().decode()}")
+
+    @staticmethod
+    def unique_id():
+        """rank 0: the communicator id every rank passes to the constructor (ncclGetUniqueId)."""
+        from .lib import load
+        lib = load()
+        buf = (C.c_uint8 * 128)()
+        rc = lib.sgp_tiles_unique_id(buf)
+        if rc != 0:
+            raise RuntimeError(f"sgp_tiles_unique_id failed ({rc}): {lib.sgp_last_error().decode()}")
+        return bytes(buf)
+
+    def exchange(self):
+        rc = self._lib.sgp_tiles_exchange(self._h)
+        if rc != 0:
+            raise RuntimeError(f"sgp_tiles_exchange failed ({rc}): {self._lib.sgp_last_error().decode()}")
+
+    @staticmethod
+    def exchange_group(tiles_list):
+        arr = (C.c_void_p * len(tiles_list))(*[t._h for t in tiles_list])
+        lib = tiles_list[0]._lib
+        rc = lib.sgp_tiles_exchange_group(arr, len(tiles_list))
+        if rc != 0:
+            raise RuntimeError(f"sgp_tiles_exchange_group failed ({rc}): {lib.sgp_last_error().decode()}")
+
+    def stats(self):
+        s = abi.TilesStats()
+        self._lib.sgp_tiles_get_stats(self._h, C.byref(s))
+        return s
+
+    def drain_migrations(self, cap=4096):
+        out = np.zeros(cap, dtype=abi.migration_dtype)
+        n = C.c_uint32(0)
+        self._lib.sgp_tiles_drain_migrations(self._h, out.ctypes.data, cap, C.byref(n))
+        return out[:min(n.value, cap)]
+
+    # the counters bench.py and the tests read from either exchange class
+    @property
+    def last_exported(self):
+        return self.stats().exported
+
+    @property
+    def last_imported(self):
+        return self.stats().ghosts
+
+    @property
+    def last_emigrated(self):
+        return self.stats().emigrated
+
+    @property
+    def last_immigrated(self):
+        return self.stats().immigrated
+
+    def close(self):
+        if self._h:
+            self._lib.sgp_tiles_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class GhostExchange:
     """Per step: one small all-gather (every rank's per-destination record counts) and one all-to-all-v of the ghost records, each
     record travelling only to the tiles whose region (grown by margin + radius_pad) contains it.  With RCCL the all-to-all-v is the

@@ -103,11 +103,19 @@ def test_config4_scaled_down_2x2x2_tiles_against_oracle(oracle):
         assert np.array_equal(gpu[r].add_batch(tile_descs[r]), cpu[r].add_batch(tile_descs[r]))
     margin = 2.0                       # ghost margin = 1 cell (2 m)
     migrated_down = 0
+    # the HIP tiles go through the native exchange (sgp_tiles_*: routing on the device, device-to-device copies between the tiles of this
+    # process), the oracle tiles through the Python statement of the same rules
+    nt = [tiles.NativeTiles(gpu[r], r, n_tiles, boxes, margin) for r in range(n_tiles)]
     for s in range(1, 181):
-        lg, lc = [], []
-        tiles.exchange_in_process(gpu, boxes, margin, lg)
+        lc = []
+        tiles.NativeTiles.exchange_group(nt)
         tiles.exchange_in_process(cpu, boxes, margin, lc)
-        assert lg == lc, (s, [a for a, b in zip(lg, lc) if a != b][:3], [b for a, b in zip(lg, lc) if a != b][:3])
+        lg = []
+        for r in range(n_tiles):
+            st = nt[r].stats()
+            exp = [e for e in lc if e[0] == "export" and e[1] == r][0]; imp = [e for e in lc if e[0] == "import" and e[1] == r][0]
+            assert (st.exported, st.emigrated, st.ghosts, st.immigrated) == (sum(exp[3]), exp[4], imp[2], imp[3]), (s, r)
+        lg = lc
         migrated_down += sum(e[4] for e in lg if e[0] == "export" and e[1] >= 4)
         for r in range(n_tiles):
             gpu[r].step(DT); cpu[r].step(DT)
@@ -123,5 +131,7 @@ def test_config4_scaled_down_2x2x2_tiles_against_oracle(oracle):
     upper_owned = sum(gpu[r].num_bodies() - 1 - [e for e in lg if e[0] == "import" and e[1] == r][0][2] for r in range(4, 8))
     assert 0 < upper_owned < n ** 3 // 2
     assert all([e for e in lg if e[0] == "import" and e[1] == r][0][2] > 0 for r in range(8))      # every tile holds ghosts at the end
+    for t in nt:
+        t.close()
     for w in gpu + cpu:
         w.close()
