@@ -76,7 +76,8 @@ struct sgp_world {
 	float max_small_radius = 0.0f;
 	uint32_t last_export = 0;                              // records the previous sgp_world_export_boundary produced
 	std::unordered_map<uint64_t, uint64_t> ghost_map;      // global id of a ghost -> generation << 32 | local body id (stable across steps)
-	uint32_t ghost_gen = 0;
+	uint32_t ghost_gen = 0; bool ghost_map_stale = false; uint64_t ghost_seq_version = 1;      // version: bumped whenever ghost_seq changes (a device copy of the ids knows whether it is current)
+	//      // ghost_map is rebuilt from ghost_seq when the general import path needs it
 	std::vector<GhostRefresh> ghost_refresh;               // pose refreshes of existing ghosts queued by the last import (uploaded by flush_cmds)
 	std::vector<std::pair<uint64_t, uint32_t>> ghost_seq;   // (global id, local id) of the previous import, in its order (fast path of the next one)
 	std::unordered_map<uint32_t, CompoundRec> compounds;    // compound id (= first child's slot) -> record
@@ -1986,17 +1987,54 @@ SGP_API int sgp_world_export_boundary(sgp_world* w, const float lo[3], const flo
 	return SGP_OK;
 }
 
-SGP_API int sgp_world_import_ghosts(sgp_world* w, const sgp_ghost_record* in, uint32_t n)
+// Where the poses of an import come from when the records are already on the device (sgp_tiles_*): the device copy of the records and a
+// device array for the local body id of every record (grown here); surviving ghosts are then refreshed by ONE kernel, not by commands.
+struct GhostDeviceSource { const sgp_ghost_record* d_recs; uint32_t** d_ids; uint32_t* cap_ids; uint64_t* ids_version; };
+
+static int upload_ghost_ids(sgp_world* w, const GhostDeviceSource* dev)
 {
-	if (!w || (!in && n)) return fail(SGP_ERR_INVALID, "sgp_world_import_ghosts: NULL");
+	const uint32_t n = (uint32_t)w->ghost_seq.size();
+	std::vector<uint32_t> ids(n);
+	for (uint32_t k = 0; k < n; ++k) ids[k] = w->ghost_seq[k].second;
+	if (n > *dev->cap_ids) {
+		if (*dev->d_ids) { HIP_TRY(hipStreamSynchronize(w->stream)); hipFree(*dev->d_ids); }
+		*dev->cap_ids = n + n / 2 + 1024;
+		HIP_TRY(hipMalloc((void**)dev->d_ids, sizeof(uint32_t) * (size_t)*dev->cap_ids));
+	}
+	if (n) { HIP_TRY(hipMemcpyAsync(*dev->d_ids, ids.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, w->stream)); HIP_TRY(hipStreamSynchronize(w->stream)); }      // (`ids` is pageable memory going out of scope)
+	*dev->ids_version = w->ghost_seq_version;
+	return SGP_OK;
+}
+
+static int make_ghost(sgp_world* w, const sgp_ghost_record& r, uint32_t* id_out)
+{
+	sgp_body_desc d; sgp_default_body_desc(&d);
+	memcpy(d.pos, r.pos, 12); memcpy(d.rot, r.rot, 16); memcpy(d.lin_vel, r.lin_vel, 12); memcpy(d.ang_vel, r.ang_vel, 12);
+	d.shape_type = r.shape_type; memcpy(d.shape, r.shape, 16);
+	d.motion_type = SGP_MOTION_KINEMATIC;      // velocity driven, infinite mass for this tile's solve
+	d.layer = SGP_LAYER_MOVING;
+	d.mass = r.mass; d.friction = r.friction; d.restitution = r.restitution;
+	d.activate = 1; d.userdata = r.userdata;       // a ray or an event that meets the ghost names the object, like its owner would
+	*id_out = SGP_INVALID_ID;
+	return add_one(w, &d, id_out, true);
+}
+
+static int import_ghosts_impl(sgp_world* w, const sgp_ghost_record* in, uint32_t n, const GhostDeviceSource* dev)
+{
 	// ghosts keep their local id while they stay in the set, so the contact cache (keyed by body ids) keeps warm-starting.
-	// ghost_map: global id -> (local id, generation of the last import that contained it)
-	w->cmds.reserve(w->cmds.size() + n);
-	// the usual case: the same ghosts as in the previous import, in the same order -- no hashing, just refresh their poses
+	// ghost_seq: (global id, local id) of the previous import, in its order
+	// 1. the usual case: the same ghosts as in the previous import, in the same order -- no bookkeeping, just refresh their poses
 	if (n == w->ghost_seq.size() && n > 0) {
 		bool same = true;
 		for (uint32_t k = 0; k < n && same; ++k) same = in[k].global_id == w->ghost_seq[k].first && live(w, w->ghost_seq[k].second);
 		if (same) {
+			if (dev) {
+				{ int r = flush_cmds(w); if (r != SGP_OK) return r; }
+				if (*dev->ids_version != w->ghost_seq_version) { int r = upload_ghost_ids(w, dev); if (r != SGP_OK) return r; }      // (the set was last changed by an import that did not come through here)
+				launch_ghost_refresh_records(w->dv, dev->d_recs, *dev->d_ids, n, w->stream);
+				w->grid_valid = false; w->dirty_since_step = true;
+				return SGP_OK;
+			}
 			// a later import before the next flush supersedes an earlier one: the refresh list holds one record per ghost
 			w->ghost_refresh.resize(n);
 			for (uint32_t k = 0; k < n; ++k) {
@@ -2008,41 +2046,96 @@ SGP_API int sgp_world_import_ghosts(sgp_world* w, const sgp_ghost_record* in, ui
 		}
 	}
 	w->ghost_refresh.clear();
-	const uint32_t gen = ++w->ghost_gen;
-	w->ghost_seq.assign(n, std::pair<uint64_t, uint32_t>(0, SGP_INVALID_ID));
-	for (uint32_t k = 0; k < n; ++k) {
-		w->ghost_seq[k].first = in[k].global_id;
-		auto it = w->ghost_map.find(in[k].global_id);
-		if (it != w->ghost_map.end() && live(w, (uint32_t)it->second)) {
-			const uint32_t id = (uint32_t)it->second;
-			BodyCmd c = blank_cmd(id, CMD_SET_POS | CMD_SET_ROT | CMD_SET_VEL | CMD_ACTIVATE);
-			memcpy(c.pos, in[k].pos, 12); memcpy(c.rot, in[k].rot, 16); memcpy(c.linv, in[k].lin_vel, 12); memcpy(c.angv, in[k].ang_vel, 12);
-			w->cmds.push_back(c);
-			it->second = ((uint64_t)gen << 32) | id;
-			w->ghost_seq[k].second = id;
-			continue;
-		}
-		sgp_body_desc d; sgp_default_body_desc(&d);
-		memcpy(d.pos, in[k].pos, 12); memcpy(d.rot, in[k].rot, 16); memcpy(d.lin_vel, in[k].lin_vel, 12); memcpy(d.ang_vel, in[k].ang_vel, 12);
-		d.shape_type = in[k].shape_type; memcpy(d.shape, in[k].shape, 16);
-		d.motion_type = SGP_MOTION_KINEMATIC;      // velocity driven, infinite mass for this tile's solve
-		d.layer = SGP_LAYER_MOVING;
-		d.mass = in[k].mass; d.friction = in[k].friction; d.restitution = in[k].restitution;
-		d.activate = 1; d.userdata = in[k].userdata;       // a ray or an event that meets the ghost names the object, like its owner would
-		uint32_t id = SGP_INVALID_ID;
-		const int r = add_one(w, &d, &id, true);
-		if (r == SGP_OK) { w->ghost_map[in[k].global_id] = ((uint64_t)gen << 32) | id; w->ghost_seq[k].second = id; }
-		else if (r != SGP_ERR_REJECTED) return r;
-	}
-	// whatever was not refreshed by this import left the ghost set: remove in ascending id order (deterministic free-list order)
+	w->cmds.reserve(w->cmds.size() + n);
+	std::vector<std::pair<uint64_t, uint32_t>> seq(n, std::pair<uint64_t, uint32_t>(0, SGP_INVALID_ID));
 	std::vector<uint32_t> gone;
-	for (auto it = w->ghost_map.begin(); it != w->ghost_map.end();) {
-		if ((uint32_t)(it->second >> 32) != gen) { if (live(w, (uint32_t)it->second)) gone.push_back((uint32_t)it->second); it = w->ghost_map.erase(it); }
-		else ++it;
+	auto refresh_cmd = [&](uint32_t id, const sgp_ghost_record& r) {
+		if (dev) return;                       // refreshed from the device copy of the records below
+		BodyCmd c = blank_cmd(id, CMD_SET_POS | CMD_SET_ROT | CMD_SET_VEL | CMD_ACTIVATE);
+		memcpy(c.pos, r.pos, 12); memcpy(c.rot, r.rot, 16); memcpy(c.linv, r.lin_vel, 12); memcpy(c.angv, r.ang_vel, 12);
+		w->cmds.push_back(c);
+	};
+	// 2. both the old and the new sequence ascending in global id (what every exchange produces: by source rank, then by the source's body
+	//    id): a two-pointer diff finds who stayed, who is new and who left, without hashing.  New ghosts take their slots in record order,
+	//    leavers are removed afterwards in ascending id order -- the same allocation order as the general path below.
+	bool ascending = true;
+	for (uint32_t k = 1; k < n && ascending; ++k) ascending = in[k - 1].global_id < in[k].global_id;
+	for (size_t k = 1; k < w->ghost_seq.size() && ascending; ++k) ascending = w->ghost_seq[k - 1].first < w->ghost_seq[k].first;
+	if (ascending) {
+		const std::vector<std::pair<uint64_t, uint32_t>>& old = w->ghost_seq;
+		size_t i = 0, j = 0;
+		while (i < n || j < old.size()) {
+			if (j == old.size() || (i < n && in[i].global_id < old[j].first)) {
+				uint32_t id; const int r = make_ghost(w, in[i], &id);
+				if (r != SGP_OK && r != SGP_ERR_REJECTED) return r;
+				seq[i] = std::make_pair(in[i].global_id, r == SGP_OK ? id : SGP_INVALID_ID); ++i;
+			} else if (i == n || old[j].first < in[i].global_id) {
+				if (old[j].second != SGP_INVALID_ID && live(w, old[j].second)) gone.push_back(old[j].second);
+				++j;
+			} else {
+				uint32_t id = old[j].second;
+				if (id != SGP_INVALID_ID && live(w, id)) refresh_cmd(id, in[i]);
+				else { const int r = make_ghost(w, in[i], &id); if (r != SGP_OK && r != SGP_ERR_REJECTED) return r; if (r != SGP_OK) id = SGP_INVALID_ID; }
+				seq[i] = std::make_pair(in[i].global_id, id); ++i; ++j;
+			}
+		}
+		w->ghost_map_stale = true;
+	} else {
+		// 3. general: hash map global id -> (generation of the last import that contained it, local id)
+		if (w->ghost_map_stale) {
+			w->ghost_map.clear();
+			for (const auto& e : w->ghost_seq) if (e.second != SGP_INVALID_ID) w->ghost_map[e.first] = ((uint64_t)w->ghost_gen << 32) | e.second;
+			w->ghost_map_stale = false;
+		}
+		const uint32_t gen = ++w->ghost_gen;
+		for (uint32_t k = 0; k < n; ++k) {
+			seq[k].first = in[k].global_id;
+			auto it = w->ghost_map.find(in[k].global_id);
+			if (it != w->ghost_map.end() && live(w, (uint32_t)it->second)) {
+				const uint32_t id = (uint32_t)it->second;
+				refresh_cmd(id, in[k]);
+				it->second = ((uint64_t)gen << 32) | id;
+				seq[k].second = id;
+				continue;
+			}
+			uint32_t id; const int r = make_ghost(w, in[k], &id);
+			if (r == SGP_OK) { w->ghost_map[in[k].global_id] = ((uint64_t)gen << 32) | id; seq[k].second = id; }
+			else if (r != SGP_ERR_REJECTED) return r;
+		}
+		// whatever was not refreshed by this import left the ghost set
+		for (auto it = w->ghost_map.begin(); it != w->ghost_map.end();) {
+			if ((uint32_t)(it->second >> 32) != gen) { if (live(w, (uint32_t)it->second)) gone.push_back((uint32_t)it->second); it = w->ghost_map.erase(it); }
+			else ++it;
+		}
 	}
+	// leavers: removed in ascending id order (deterministic free-list order)
 	std::sort(gone.begin(), gone.end());
 	for (uint32_t id : gone) sgp_body_remove(w, id);
+	w->ghost_seq.swap(seq);
+	w->ghost_seq_version++;
+	if (dev && n) {
+		// new ghosts and removals reach the device first, then ONE kernel gives every ghost of the set its pose from the received records
+		std::vector<uint32_t> ids(n);
+		bool all = true;
+		for (uint32_t k = 0; k < n; ++k) { ids[k] = w->ghost_seq[k].second; if (ids[k] == SGP_INVALID_ID) all = false; }
+		{ int r = flush_cmds(w); if (r != SGP_OK) return r; }
+		if (!all) {          // a rejected record (non-finite pose ...): its slot in the id array points at the ground-truth "no body" -> refresh the rest by commands
+			for (uint32_t k = 0; k < n; ++k) if (ids[k] != SGP_INVALID_ID) { BodyCmd c = blank_cmd(ids[k], CMD_SET_POS | CMD_SET_ROT | CMD_SET_VEL | CMD_ACTIVATE);
+				memcpy(c.pos, in[k].pos, 12); memcpy(c.rot, in[k].rot, 16); memcpy(c.linv, in[k].lin_vel, 12); memcpy(c.angv, in[k].ang_vel, 12); w->cmds.push_back(c); }
+			return SGP_OK;
+		}
+		{ int r = upload_ghost_ids(w, dev); if (r != SGP_OK) return r; }
+		launch_ghost_refresh_records(w->dv, dev->d_recs, *dev->d_ids, n, w->stream);
+		w->grid_valid = false; w->dirty_since_step = true;
+	}
 	return SGP_OK;
+}
+
+SGP_API int sgp_world_import_ghosts(sgp_world* w, const sgp_ghost_record* in, uint32_t n)
+{
+	if (!w || (!in && n)) return fail(SGP_ERR_INVALID, "sgp_world_import_ghosts: NULL");
+	hipSetDevice(w->device);
+	return import_ghosts_impl(w, in, n, nullptr);
 }
 
 // ---- host-side routing of exported records (tiles.py) -------------------------------------------------------------------------
@@ -2197,7 +2290,7 @@ struct sgp_tiles {
 	sgp_ghost_record* d_send = nullptr; uint32_t cap_send = 0;
 	sgp_ghost_record* d_recv = nullptr; uint32_t cap_recv = 0;
 	uint32_t* d_emig = nullptr; uint32_t cap_emig = 0;
-	uint32_t* d_seq_ids = nullptr; uint32_t cap_seq = 0;       // local body id of ghost k of the previous import (device copy, for the refresh kernel)
+	uint32_t* d_seq_ids = nullptr; uint32_t cap_seq = 0; uint64_t ids_version = 0;      // local body id of ghost k of the current ghost set (device copy, for the refresh kernel)
 	// host (pinned)
 	char* h_ctl = nullptr; sgp_ghost_record* h_recv = nullptr; uint32_t cap_h_recv = 0;
 	// last exchange
@@ -2337,25 +2430,30 @@ static int tiles_import(sgp_tiles* t, uint32_t n)
 		HIP_TRY(hipMemcpyAsync(t->h_recv, t->d_recv, sizeof(sgp_ghost_record) * (size_t)n, hipMemcpyDeviceToHost, w->stream));
 		HIP_TRY(hipStreamSynchronize(w->stream));
 	}
-	bool same = t->seq_valid && n == t->seq_gids.size() && n > 0;
-	for (uint32_t k = 0; k < n && same; ++k) same = t->h_recv[k].global_id == t->seq_gids[k] && !(t->h_recv[k].motion_type & SGP_GHOST_TAKE_OWNERSHIP);
-	if (same) for (uint32_t k = 0; k < n && same; ++k) same = live(w, w->ghost_seq[k].second) && w->ghost_seq[k].first == t->seq_gids[k];
-	if (same) {
-		launch_ghost_refresh_records(w->dv, t->d_recv, t->d_seq_ids, n, w->stream);
-		w->grid_valid = false; w->dirty_since_step = true;
-		t->stats.ghosts = n; t->stats.immigrated = 0; t->stats.fast_imports++;
+	// who is a ghost, who immigrates (flagged records addressed to another tile are dropped)
+	const float* lo = t->route.boxes + 6 * t->rank; const float* hi = lo + 3;
+	bool plain = true;
+	for (uint32_t k = 0; k < n && plain; ++k) plain = !(t->h_recv[k].motion_type & SGP_GHOST_TAKE_OWNERSHIP);
+	const size_t seq_before = w->ghost_seq.size();
+	if (plain) {
+		// ghosts only: the poses stay on the device -- the host compares global ids (and creates / removes the few bodies that entered or left
+		// the set), one kernel refreshes every ghost from the received records
+		bool unchanged = n == seq_before && n > 0;
+		for (uint32_t k = 0; k < n && unchanged; ++k) unchanged = t->h_recv[k].global_id == w->ghost_seq[k].first;
+		GhostDeviceSource dev = { t->d_recv, &t->d_seq_ids, &t->cap_seq, &t->ids_version };
+		{ int rc = import_ghosts_impl(w, t->h_recv, n, &dev); if (rc != SGP_OK) return rc; }
+		t->stats.ghosts = n; t->stats.immigrated = 0;
+		if (unchanged) t->stats.fast_imports++; else t->stats.slow_imports++;
 		return SGP_OK;
 	}
-	// the set changed: the host, which owns the body slots, sorts ghosts from immigrants and updates the ghost set
 	std::vector<sgp_ghost_record> ghosts; ghosts.reserve(n);
 	std::vector<const sgp_ghost_record*> immigrants;
-	const float* lo = t->route.boxes + 6 * t->rank; const float* hi = lo + 3;
 	for (uint32_t k = 0; k < n; ++k) {
 		const sgp_ghost_record& r = t->h_recv[k];
 		if (!(r.motion_type & SGP_GHOST_TAKE_OWNERSHIP)) ghosts.push_back(r);
-		else if (in_box(r.pos, lo, hi, 0.0f)) immigrants.push_back(&r);          // (flagged records addressed to another tile are dropped)
+		else if (in_box(r.pos, lo, hi, 0.0f)) immigrants.push_back(&r);
 	}
-	{ int rc = sgp_world_import_ghosts(w, ghosts.data(), (uint32_t)ghosts.size()); if (rc != SGP_OK) return rc; }
+	{ int rc = import_ghosts_impl(w, ghosts.data(), (uint32_t)ghosts.size(), nullptr); if (rc != SGP_OK) return rc; }
 	uint32_t n_imm = 0;
 	for (const sgp_ghost_record* pr : immigrants) {
 		const sgp_ghost_record& r = *pr;
@@ -2377,18 +2475,6 @@ static int tiles_import(sgp_tiles* t, uint32_t n)
 		++n_imm;
 	}
 	t->stats.immigrated = n_imm; t->stats.ghosts = (uint32_t)ghosts.size(); t->stats.slow_imports++;
-	// remember the sequence for the fast path of the next exchange -- valid only if what arrived was ghosts alone
-	t->seq_valid = n_imm == 0 && ghosts.size() == n;
-	if (t->seq_valid) {
-		t->seq_gids.resize(n);
-		std::vector<uint32_t> ids(n);
-		for (uint32_t k = 0; k < n; ++k) { t->seq_gids[k] = ghosts[k].global_id; ids[k] = w->ghost_seq[k].second; if (ids[k] == SGP_INVALID_ID) t->seq_valid = false; }
-		if (t->seq_valid && n) {
-			{ int rc = tiles_grow(w, t->d_seq_ids, t->cap_seq, n); if (rc != SGP_OK) return rc; }
-			{ int rc = flush_cmds(w); if (rc != SGP_OK) return rc; }        // the new ghosts exist on the device before a refresh kernel may touch them
-			HIP_TRY(hipMemcpy(t->d_seq_ids, ids.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
-		}
-	} else t->seq_gids.clear();
 	return SGP_OK;
 }
 
