@@ -228,7 +228,7 @@ void launch_step_begin(const DV& d, const StepParams& sp, uint32_t nb, bool rese
 void launch_set_params(const DV& d, const StepParams& sp, hipStream_t s);
 void launch_step_end(const DV& d, StepCounters* host_mapped, EventCounters* host_events, hipStream_t s);
 void launch_fill_u64(uint64_t* p, uint64_t v, size_t n, hipStream_t s);
-void launch_apply_forces(const DV& d, uint32_t nb, hipStream_t s);
+void launch_pre_solve(const DV& d, uint32_t nb, hipStream_t s);      // wake-ups + forces + per-step solver records (after the narrow phase)
 void launch_bp_bounds(const DV& d, uint32_t nb, hipStream_t s);
 void launch_bp_cell(const DV& d, uint32_t nb, hipStream_t s);
 void launch_bp_scan(const DV& d, hipStream_t s);
@@ -238,8 +238,6 @@ void launch_bp_large(const DV& d, uint32_t nb, hipStream_t s);
 void launch_narrowphase(const DV& d, uint32_t n_pairs_upper, hipStream_t s);
 void launch_narrowphase_hull(const DV& d, hipStream_t s);     // only worlds with hull shapes
 void launch_narrowphase_mesh(const DV& d, hipStream_t s);     // only worlds with mesh shapes
-void launch_wake(const DV& d, uint32_t nb, hipStream_t s);
-void launch_prep_bodies(const DV& d, uint32_t nb, hipStream_t s);
 void launch_colour_inherit(const DV& d, uint32_t n_man, hipStream_t s);
 void launch_colour_claim(const DV& d, uint32_t n_man, uint32_t round, hipStream_t s);
 void launch_colour_commit(const DV& d, uint32_t n_man, uint32_t round, hipStream_t s);
@@ -254,7 +252,6 @@ void launch_solve_tail(const DV& d, int first_colour, int mode, hipStream_t s);
 // small worlds: warm start + all velocity iterations in one single-workgroup launch (needs n_slots <= SGP_SMALL_WORLD_BODIES)
 #define SGP_SMALL_WORLD_BODIES 2048
 void launch_solve_small(const DV& d, int warm_start, int iterations, hipStream_t s);
-void launch_prep_pose(const DV& d, uint32_t nb, hipStream_t s);
 void launch_integrate_pose(const DV& d, uint32_t nb, hipStream_t s);
 void launch_finalize(const DV& d, uint32_t nb, hipStream_t s);
 void launch_island_mark(const DV& d, uint32_t n_con, hipStream_t s);

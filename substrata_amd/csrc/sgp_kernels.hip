@@ -1,6 +1,6 @@
 // sgp_kernels.hip -- hand-written gfx950 kernels of the rigid-body step behind PhysicsWorld::think
 // (/root/reference/gui_client/PhysicsWorld.cpp:1356-1443).  Stage map:
-//   k_apply_forces        K8a  MotionProperties::ApplyForceTorqueAndDragInternal
+//   k_pre_solve           K8a  MotionProperties::ApplyForceTorqueAndDragInternal (+ wake-ups, per-step solver records)
 //   k_bp_*                K2/K3 spatial-hash broad phase (uniform grid, hashed buckets) + layer filter (PhysicsWorld.cpp:160-189)
 //   k_narrowphase         K4   sphere/box/capsule manifolds (sgp_device_collide.h)
 //   k_colour_*, k_setup   K5/K6 contact cache match (warm start), deterministic colouring, constraint properties
@@ -169,35 +169,6 @@ __global__ void __launch_bounds__(TPB) k_step_end(DV d, StepCounters* host_mappe
 __global__ void __launch_bounds__(TPB) k_fill_u64(uint64_t* p, uint64_t v, size_t n)
 {
 	for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (size_t)gridDim.x * TPB) p[i] = v;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// K8a: forces, gravity, damping, velocity clamps (JobApplyGravity)
-
-__global__ void __launch_bounds__(TPB) k_apply_forces(DV d)
-{
-	const float dt = d.sp->dt;
-	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-	if (i >= d.sp->n_slots) return;
-	const uint32_t f = d.flags[i];
-	if (!f_movable(f)) return;
-	const float4 pim = d.pos_im[i], lv4 = d.linv[i], av4 = d.angv[i], F4v = d.force[i], T4 = d.torque[i], II = d.inv_inertia[i];
-	const quat q = Q4(d.rot[i]);
-	const v3 g = V3(d.gx, d.gy, d.gz);
-	v3 lv = V3(lv4), av = V3(av4);
-	lv = v3_add(lv, v3_scale(v3_add(v3_scale(g, F4v.w), v3_scale(V3(F4v), pim.w)), dt));
-	const sym33 Iw = world_inv_inertia(quat_to_m33(q), V3(II));
-	av = v3_add(av, v3_scale(sym33_mul(Iw, V3(T4)), dt));
-	lv = v3_scale(lv, fmaxf(0.0f, 1.0f - lv4.w * dt));
-	av = v3_scale(av, fmaxf(0.0f, 1.0f - av4.w * dt));
-	const float l2 = v3_len_sq(lv), ml = d.st.max_linear_velocity;
-	if (l2 > ml * ml) lv = v3_scale(lv, ml / sqrtf(l2));
-	const float a2 = v3_len_sq(av), ma = d.st.max_angular_velocity;
-	if (a2 > ma * ma) av = v3_scale(av, ma / sqrtf(a2));
-	d.linv[i] = F4(lv, lv4.w);
-	d.angv[i] = F4(av, av4.w);
-	d.force[i] = make_float4(0.0f, 0.0f, 0.0f, F4v.w);
-	d.torque[i] = make_float4(0.0f, 0.0f, 0.0f, T4.w);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -800,50 +771,67 @@ __global__ void __launch_bounds__(64) k_narrowphase_hull(DV d)
 	}
 }
 
-// sleeping bodies touched by an active body wake up (Jolt activates them while finding collisions)
-__global__ void __launch_bounds__(TPB) k_wake(DV d)
+// Per-step solver record of every body (64 B = one cache line): velocities, the EFFECTIVE inverse mass (0 unless the body is dynamic and
+// awake) and the world-space inverse inertia.  The velocity-phase kernels gather ONE line per body instead of six arrays.
+// THE BODY-ARRAY SWEEP, part 1 of 3 (k_pre_solve, then k_integrate_pose, then k_finalize): what used to be three passes over the bodies
+// (k_wake, k_apply_forces, k_prep_bodies) in one.  Per body: wake it if an active body touched it this step; apply gravity / forces /
+// damping / velocity clamps if it was movable when the step began (Jolt applies gravity before it finds collisions, so a body woken during
+// this step gets none); write its per-step solver record.  The velocities computed here go straight into the record -- nothing reads the
+// velocity arrays again before k_integrate rewrites them from the record.
+__global__ void __launch_bounds__(TPB) k_pre_solve(DV d)
 {
+	const float dt = d.sp->dt;
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
 	if (i >= d.sp->n_slots) return;
-	uint32_t f = d.flags[i];
-	if (!(f & BF_WAKE)) return;
-	f &= ~BF_WAKE;
-	if (!(f & BF_ACTIVE)) {
-		f |= BF_ACTIVE;
-		push_event(d.ev_activated, &d.evc->n_activated, d.cap_bodies, i);
-	}
-	d.flags[i] = f;
-	reset_sleep(d, i, f_shape(f), d.shape[i], V3(d.pos_im[i]), Q4(d.rot[i]));
-}
-
-// Per-step solver record of every body (64 B = one cache line): velocities, the EFFECTIVE inverse mass (0 unless the body
-// is dynamic and awake) and the world-space inverse inertia.  The velocity-phase kernels gather ONE line per body instead
-// of six arrays; velocities stay in this record until k_integrate_pose writes them back.
-__global__ void __launch_bounds__(TPB) k_prep_bodies(DV d)
-{
-	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-	if (i >= d.sp->n_slots) return;
-	const uint32_t f = d.flags[i];
+	const uint32_t f0 = d.flags[i];
+	uint32_t f = f0;
 	float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f), w = v, a = v, b = v;
+	if (!(f & BF_ALIVE)) { d.sbody[4 * i + 0] = v; d.sbody[4 * i + 1] = w; d.sbody[4 * i + 2] = a; d.sbody[4 * i + 3] = b; return; }
+	const bool was_movable = f_movable(f);
+	const float4 sh = d.shape[i], II = d.inv_inertia[i];
+	// sleeping bodies touched by an active body wake up (Jolt activates them while finding collisions)
+	if (f & BF_WAKE) {
+		f &= ~BF_WAKE;
+		if (!(f & BF_ACTIVE)) { f |= BF_ACTIVE; push_event(d.ev_activated, &d.evc->n_activated, d.cap_bodies, i); }
+		reset_sleep(d, i, f_shape(f), sh, V3(d.pos_im[i]), Q4(d.rot[i]));
+	}
 	// material of the body in the spare lanes of the record (k_setup then needs no other per-body array for it): friction, restitution
-	if (f & BF_ALIVE) { a.w = d.shape[i].w; b.w = d.inv_inertia[i].w; }
-	if ((f & BF_ALIVE) && f_motion(f) != SGP_MOTION_STATIC) {
-		const float4 lv = d.linv[i], av = d.angv[i];
-		v = make_float4(lv.x, lv.y, lv.z, 0.0f);
-		w = make_float4(av.x, av.y, av.z, 0.0f);
+	a.w = sh.w; b.w = II.w;
+	if (f_motion(f) != SGP_MOTION_STATIC) {
+		const float4 lv4 = d.linv[i], av4 = d.angv[i];
+		v3 lv = V3(lv4), av = V3(av4);
 		if (f_movable(f)) {
-			const sym33 I = world_inv_inertia(quat_to_m33(Q4(d.rot[i])), V3(d.inv_inertia[i]));
-			v.w = d.pos_im[i].w;
-			a = make_float4(I.xx, I.xy, I.xz, a.w);
-			b = make_float4(I.yy, I.yz, I.zz, b.w);
+			const float im = d.pos_im[i].w;
+			const sym33 Iw = world_inv_inertia(quat_to_m33(Q4(d.rot[i])), V3(II));
+			if (was_movable) {
+				// K8a: forces, gravity, damping, velocity clamps (JobApplyGravity)
+				const float4 F4v = d.force[i], T4 = d.torque[i];
+				const v3 g = V3(d.gx, d.gy, d.gz);
+				lv = v3_add(lv, v3_scale(v3_add(v3_scale(g, F4v.w), v3_scale(V3(F4v), im)), dt));
+				av = v3_add(av, v3_scale(sym33_mul(Iw, V3(T4)), dt));
+				lv = v3_scale(lv, fmaxf(0.0f, 1.0f - lv4.w * dt));
+				av = v3_scale(av, fmaxf(0.0f, 1.0f - av4.w * dt));
+				const float l2 = v3_len_sq(lv), ml = d.st.max_linear_velocity;
+				if (l2 > ml * ml) lv = v3_scale(lv, ml / sqrtf(l2));
+				const float a2 = v3_len_sq(av), ma = d.st.max_angular_velocity;
+				if (a2 > ma * ma) av = v3_scale(av, ma / sqrtf(a2));
+				// the accumulators are cleared only when something was accumulated
+				if (F4v.x != 0.0f || F4v.y != 0.0f || F4v.z != 0.0f) d.force[i] = make_float4(0.0f, 0.0f, 0.0f, F4v.w);
+				if (T4.x != 0.0f || T4.y != 0.0f || T4.z != 0.0f) d.torque[i] = make_float4(0.0f, 0.0f, 0.0f, T4.w);
+			}
+			v.w = im;
+			a = make_float4(Iw.xx, Iw.xy, Iw.xz, a.w);
+			b = make_float4(Iw.yy, Iw.yz, Iw.zz, b.w);
 		}
+		v.x = lv.x; v.y = lv.y; v.z = lv.z;
+		w.x = av.x; w.y = av.y; w.z = av.z;
 	}
 	d.sbody[4 * i + 0] = v; d.sbody[4 * i + 1] = w; d.sbody[4 * i + 2] = a; d.sbody[4 * i + 3] = b;
 	// remember whether the body was movable when the previous step coloured its constraints (colour inheritance)
 	uint32_t nf = f & ~(BF_MOVABLE_PREV | BF_MOVABLE_CUR);
 	if (f & BF_MOVABLE_CUR) nf |= BF_MOVABLE_PREV;
 	if (f_movable(f)) nf |= BF_MOVABLE_CUR;
-	if (nf != f) d.flags[i] = nf;
+	if (nf != f0) d.flags[i] = nf;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1052,15 +1040,16 @@ SGP_DEV float axis_eff_mass(float im1, const sym33& I1, v3 r1, float im2, const 
 
 // rows of one (point, axis) for the velocity iterations: the two lever-arm cross products and their inverse-inertia images
 SGP_DEV float4* axis_rows(const DV& d, uint32_t slot, int point, int axis) { return d.rows + (size_t)((point * 3 + axis) * 4) * d.cap_manifolds + slot; }
-SGP_DEV void write_axis_rows(const DV& d, uint32_t slot, int point, int axis, v3 r1, v3 r2, v3 a, const sym33& I1, const sym33& I2, float w0, float w1)
+// (w2, w3: spare lanes of the two inverse-inertia rows; point 0 carries the first tangent there, see k_setup)
+SGP_DEV void write_axis_rows(const DV& d, uint32_t slot, int point, int axis, v3 r1, v3 r2, v3 a, const sym33& I1, const sym33& I2, float w0, float w1, float w2 = 0.0f, float w3 = 0.0f)
 {
 	const v3 c1 = v3_cross(r1, a), c2 = v3_cross(r2, a);
 	float4* p = axis_rows(d, slot, point, axis);
 	const size_t st = d.cap_manifolds;
 	p[0] = F4(c1, w0);
 	p[st] = F4(c2, w1);
-	p[2 * st] = F4(sym33_mul(I1, c1), 0.0f);
-	p[3 * st] = F4(sym33_mul(I2, c2), 0.0f);
+	p[2 * st] = F4(sym33_mul(I1, c1), w2);
+	p[3 * st] = F4(sym33_mul(I2, c2), w3);
 }
 
 SGP_DEV uint32_t ht_hash(uint64_t key, uint32_t mask) { return (uint32_t)(sgp_mix64(key) >> 20) & mask; }
@@ -1111,7 +1100,7 @@ __global__ void __launch_bounds__(TPB) k_setup(DV d)
 		sym33 I1, I2;
 		I1.xx = sa0.x; I1.xy = sa0.y; I1.xz = sa0.z; I1.yy = sa1.x; I1.yz = sa1.y; I1.zz = sa1.z;
 		I2.xx = sb0.x; I2.xy = sb0.y; I2.xz = sb0.z; I2.yy = sb1.x; I2.yz = sb1.y; I2.zz = sb1.z;
-		const float friction = sqrtf(sa0.w * sb0.w);               // per-body friction / restitution ride in the solver records (k_prep_bodies)
+		const float friction = sqrtf(sa0.w * sb0.w);               // per-body friction / restitution ride in the solver records (k_pre_solve)
 		const float restitution = fmaxf(sa1.w, sb1.w);
 		const v3 t1 = v3_normalized_perpendicular(nrm);
 		const v3 t2 = v3_cross(nrm, t1);
@@ -1168,8 +1157,10 @@ __global__ void __launch_bounds__(TPB) k_setup(DV d)
 			const float eff_t1 = axis_eff_mass(im1, I1, r1, im2, I2, r2, t1);
 			const float eff_t2 = axis_eff_mass(im1, I1, r1, im2, I2, r2, t2);
 			// what every velocity iteration would otherwise recompute per axis (Jolt's AxisConstraintPart keeps the same products)
-			write_axis_rows(d, slot, i, 0, r1, r2, nrm, I1, I2, bias, eff_n);
-			write_axis_rows(d, slot, i, 1, r1, r2, t1, I1, I2, 0.0f, eff_t1);
+			// point 0 also carries the first tangent (spare lanes of its rows): the velocity iterations then need no square root and no division
+			// to rebuild the friction basis from the normal -- same function, same input, computed once instead of ten times
+			write_axis_rows(d, slot, i, 0, r1, r2, nrm, I1, I2, bias, eff_n, i == 0 ? t1.x : 0.0f, i == 0 ? t1.y : 0.0f);
+			write_axis_rows(d, slot, i, 1, r1, r2, t1, I1, I2, 0.0f, eff_t1, i == 0 ? t1.z : 0.0f);
 			write_axis_rows(d, slot, i, 2, r1, r2, t2, I1, I2, 0.0f, eff_t2);
 			CUR(d).r1b[i][slot] = F4(r1, bias);
 			CUR(d).r2e[i][slot] = F4(r2, eff_n);
@@ -1366,13 +1357,14 @@ template <int VS> SGP_DEV void con_solve_velocity(ConReg& r, float4* vel)
 {
 	const uint2 ab = r.ab;
 	const int np = r.np_col & 0xFF;
+	if (np == 0) return;                    // a sensor pair: kept in the contact list, nothing to solve
 	const float4 va = vel[VS * (size_t)ab.x], wa = vel[VS * (size_t)ab.x + 1];
 	const float4 vb = vel[VS * (size_t)ab.y], wb = vel[VS * (size_t)ab.y + 1];
 	const float im1 = va.w, im2 = vb.w, friction = r.nf.w;
 	BodyVel A, B;
 	A.lv = V3(va); A.av = V3(wa); B.lv = V3(vb); B.av = V3(wb);
 	const v3 n = V3(r.nf);
-	const v3 t1 = v3_normalized_perpendicular(n);
+	const v3 t1 = V3(r.rn[0].i1.w, r.rn[0].i2.w, r.rt1[0].i1.w);      // = v3_normalized_perpendicular(n), stored by k_setup (np >= 1 here)
 	const v3 t2 = v3_cross(n, t1);
 	if (friction > 0.0f) {
 #pragma unroll
@@ -1417,7 +1409,7 @@ SGP_DEV void solve_position_one(const DV& d, uint32_t slot)
 	const float4 nf = CUR(d).n_fric[slot];
 	const v3 nrm = V3(nf);
 	const int np = CUR(d).np_col[slot] & 0xFF;
-	// pose half of the solver records (written by k_prep_pose): one line per body
+	// pose half of the solver records (written by k_integrate_pose): one line per body
 	float4* ra = d.sbody + 4 * (size_t)ab.x;
 	float4* rb = d.sbody + 4 * (size_t)ab.y;
 	const float4 pa = ra[0], pb = rb[0];
@@ -1426,10 +1418,10 @@ SGP_DEV void solve_position_one(const DV& d, uint32_t slot)
 	const v3 iiA = V3(ra[2]), iiB = V3(rb[2]);
 	v3 posA = V3(pa), posB = V3(pb);
 	bool moved = false;
+	m33 RA = quat_to_m33(qa), RB = quat_to_m33(qb);          // recomputed below only after a correction turned a body (same values as computing them per point)
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
 		if (i >= np) continue;
-		const m33 RA = quat_to_m33(qa), RB = quat_to_m33(qb);
 		const v3 p1 = v3_add(posA, m33_mul(RA, V3(CUR(d).loc1[i][slot])));
 		const v3 p2 = v3_add(posB, m33_mul(RB, V3(CUR(d).loc2[i][slot])));
 		float sep = v3_dot(v3_sub(p2, p1), nrm) + d.st.penetration_slop;
@@ -1638,41 +1630,36 @@ __global__ void __launch_bounds__(512) k_solve_small(DV d, int warm_start, int i
 
 __global__ void __launch_bounds__(TPB) k_integrate_pose(DV d)
 {
+	// part 2 of 3 of the body-array sweep: the solved velocities go back to their arrays, the pose advances, and the solver record turns into
+	// the pose record of the position iterations [position, effective inverse mass][rotation][local inverse inertia diagonal] (was k_prep_pose).
+	// A movable body's new pose lives in that record until k_finalize writes it to the pose arrays (after the position iterations corrected
+	// it); the arrays themselves are only written here for bodies the position iterations cannot move (kinematic ones).
 	const float dt = d.sp->dt;
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
 	if (i >= d.sp->n_slots) return;
 	const uint32_t f = d.flags[i];
-	if ((f & (BF_ALIVE | BF_ACTIVE)) != (BF_ALIVE | BF_ACTIVE) || f_motion(f) == SGP_MOTION_STATIC) return;
-	// the solved velocities live in the solver record
-	v3 lv = V3(d.sbody[4 * (size_t)i]), av = V3(d.sbody[4 * (size_t)i + 1]);
-	if (f_motion(f) == SGP_MOTION_DYNAMIC) {
-		const float l2 = v3_len_sq(lv), ml = d.st.max_linear_velocity;
-		if (l2 > ml * ml) lv = v3_scale(lv, ml / sqrtf(l2));
-		const float a2 = v3_len_sq(av), ma = d.st.max_angular_velocity;
-		if (a2 > ma * ma) av = v3_scale(av, ma / sqrtf(a2));
-	}
-	d.linv[i] = F4(lv, d.linv[i].w);
-	d.angv[i] = F4(av, d.angv[i].w);
-	const float4 p = d.pos_im[i];
-	const v3 np = v3_add(V3(p), v3_scale(lv, dt));
-	const quat q = quat_add_rotation_step(Q4(d.rot[i]), v3_scale(av, dt));
-	d.pos_im[i] = F4(np, p.w);
-	d.rot[i] = make_float4(q.x, q.y, q.z, q.w);
-}
-
-// Per-body record of the POSITION iterations (the counterpart of k_prep_bodies): from here to k_finalize the solver record holds
-// [position, effective inverse mass][rotation][local inverse inertia diagonal] (the velocities have gone back to their arrays).  The
-// position iterations gather and update this one line per body instead of four arrays; k_finalize copies the corrected poses of the
-// movable bodies back.
-__global__ void __launch_bounds__(TPB) k_prep_pose(DV d)
-{
-	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-	if (i >= d.sp->n_slots) return;
-	const uint32_t f = d.flags[i];
 	if (!(f & BF_ALIVE)) return;
-	const float4 p = d.pos_im[i];
-	d.sbody[4 * (size_t)i] = make_float4(p.x, p.y, p.z, f_movable(f) ? p.w : 0.0f);
-	d.sbody[4 * (size_t)i + 1] = d.rot[i];
+	float4 p = d.pos_im[i], r4 = d.rot[i];
+	const bool movable = f_movable(f);
+	if ((f & BF_ACTIVE) && f_motion(f) != SGP_MOTION_STATIC) {
+		// the solved velocities live in the solver record
+		v3 lv = V3(d.sbody[4 * (size_t)i]), av = V3(d.sbody[4 * (size_t)i + 1]);
+		if (f_motion(f) == SGP_MOTION_DYNAMIC) {
+			const float l2 = v3_len_sq(lv), ml = d.st.max_linear_velocity;
+			if (l2 > ml * ml) lv = v3_scale(lv, ml / sqrtf(l2));
+			const float a2 = v3_len_sq(av), ma = d.st.max_angular_velocity;
+			if (a2 > ma * ma) av = v3_scale(av, ma / sqrtf(a2));
+		}
+		d.linv[i] = F4(lv, d.linv[i].w);
+		d.angv[i] = F4(av, d.angv[i].w);
+		const v3 np = v3_add(V3(p), v3_scale(lv, dt));
+		const quat q = quat_add_rotation_step(Q4(r4), v3_scale(av, dt));
+		p = F4(np, p.w);
+		r4 = make_float4(q.x, q.y, q.z, q.w);
+		if (!movable) { d.pos_im[i] = p; d.rot[i] = r4; }
+	}
+	d.sbody[4 * (size_t)i] = make_float4(p.x, p.y, p.z, movable ? p.w : 0.0f);
+	d.sbody[4 * (size_t)i + 1] = r4;
 	d.sbody[4 * (size_t)i + 2] = d.inv_inertia[i];
 }
 
@@ -2010,7 +1997,7 @@ __global__ void __launch_bounds__(TPB) k_contact_events(DV d)
 		if (k >= d.cap_contact_events) continue;
 		sgp_contact_event e;
 		e.id1 = ab.x; e.id2 = ab.y; e.userdata1 = 0; e.userdata2 = 0;
-		const float4 la = d.linv[ab.x], lb = d.linv[ab.y];
+		const float4 la = d.sbody[4 * (size_t)ab.x], lb = d.sbody[4 * (size_t)ab.y];      // velocities after gravity, before the solve (k_pre_solve)
 		e.lin_vel1[0] = la.x; e.lin_vel1[1] = la.y; e.lin_vel1[2] = la.z;
 		e.lin_vel2[0] = lb.x; e.lin_vel2[1] = lb.y; e.lin_vel2[2] = lb.z;
 		const float4 n4 = d.man_n[m];
@@ -2611,7 +2598,7 @@ template <int MODE> __global__ void __launch_bounds__(64) k_vehicle_solve(DV d)
 		const float4 p = d.pos_im[b];
 		c.pos = V3(p); c.rot = Q4(d.rot[b]); c.inv_inertia_local = V3(d.inv_inertia[b]);
 		if (MODE == 2) {
-			// between k_prep_pose and k_finalize the pose being corrected is the one in the solver record (k_finalize copies it back
+			// between k_integrate_pose and k_finalize the pose being corrected is the one in the solver record (k_finalize copies it back
 			// for movable bodies; anything else keeps its pose arrays authoritative)
 			const bool mv = f_movable(d.flags[b]);
 			if (mv) { c.pos = V3(d.sbody[4 * b + 0]); c.rot = Q4(d.sbody[4 * b + 1]); }
@@ -2977,7 +2964,7 @@ void launch_fill_u64(uint64_t* p, uint64_t v, size_t n, hipStream_t s)
 	if (blocks < 1) blocks = 1; if (blocks > 2048) blocks = 2048;
 	hipLaunchKernelGGL(k_fill_u64, dim3((uint32_t)blocks), dim3(TPB), 0, s, p, v, n);
 }
-void launch_apply_forces(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_apply_forces, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
+void launch_pre_solve(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_pre_solve, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_bp_bounds(const DV& d, uint32_t nb, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_bp_bounds, dim3(blocks_for(nb)), dim3(TPB), 0, s, d);
@@ -2998,8 +2985,6 @@ void launch_bp_large(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelG
 void launch_narrowphase(const DV& d, uint32_t est, hipStream_t s) { hipLaunchKernelGGL(k_narrowphase, dim3(stride_grid(est)), dim3(TPB), 0, s, d); }
 void launch_narrowphase_hull(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_narrowphase_hull, dim3(4096), dim3(64), 0, s, d); }
 void launch_narrowphase_mesh(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_narrowphase_mesh, dim3(1024), dim3(64), 0, s, d); }
-void launch_wake(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_wake, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
-void launch_prep_bodies(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_prep_bodies, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_colour_inherit(const DV& d, uint32_t est, hipStream_t s) { hipLaunchKernelGGL(k_colour_inherit, dim3(stride_grid(est)), dim3(TPB), 0, s, d); }
 void launch_colour_claim(const DV& d, uint32_t est, uint32_t round, hipStream_t s)
 {
@@ -3024,7 +3009,6 @@ void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStr
 void launch_warm_bodies(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_warm_bodies, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_solve_tail(const DV& d, int first_colour, int mode, hipStream_t s) { hipLaunchKernelGGL(k_solve_tail, dim3(1), dim3(512), 0, s, d, first_colour, mode); }
 void launch_solve_small(const DV& d, int warm_start, int iterations, hipStream_t s) { hipLaunchKernelGGL(k_solve_small, dim3(1), dim3(512), 0, s, d, warm_start, iterations); }
-void launch_prep_pose(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_prep_pose, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_integrate_pose(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_integrate_pose, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_finalize(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_finalize, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_island_mark(const DV& d, uint32_t n_con, hipStream_t s) { hipLaunchKernelGGL(k_island_mark, dim3(stride_grid(n_con)), dim3(TPB), 0, s, d); }

@@ -972,14 +972,12 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 	{ KScope k(w, KC_BP_SCAN); launch_bp_scan(d, s); }
 	{ KScope k(w, KC_BP_SCATTER); launch_bp_scatter(d, nb, s); }
 	if (p.n_vehicles) { KScope k(w, KC_VEHICLE); launch_vehicle_pre(d, s); }
-	{ KScope k(w, KC_APPLY_FORCES); launch_apply_forces(d, nb, s); }
 	{ KScope k(w, KC_BP_PAIRS); launch_bp_pairs(d, s); }
 	{ KScope k(w, KC_BP_LARGE); launch_bp_large(d, nb, s); }
 	STAGE_MARK(2);
 	// -- 3. narrow phase, wake-ups, per-body solver records (+ contact events, which see the velocities before the solve)
 	{ KScope k(w, KC_NARROWPHASE); launch_narrowphase(d, p.est_pairs, s); if (p.has_hulls) launch_narrowphase_hull(d, s); if (p.has_meshes) launch_narrowphase_mesh(d, s); }
-	{ KScope k(w, KC_WAKE); launch_wake(d, nb, s); }
-	{ KScope k(w, KC_PREP_BODIES); launch_prep_bodies(d, nb, s); }
+	{ KScope k(w, KC_APPLY_FORCES); launch_pre_solve(d, nb, s); }      // sweep 1/3: wake-ups, forces, per-step solver records
 	if (p.contact_events) { KScope k(w, KC_MISC); launch_contact_events(d, p.est_man, s); }
 	STAGE_MARK(3);
 	// -- 4. colouring + constraint setup
@@ -1018,7 +1016,6 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 	STAGE_MARK(5);
 	// -- 6. the body-array sweep
 	{ KScope k(w, KC_INTEGRATE_POSE); launch_integrate_pose(d, nb, s); }
-	{ KScope k(w, KC_PREP_BODIES); launch_prep_pose(d, nb, s); }      // k_finalize reads the poses of the movable bodies from this record
 	STAGE_MARK(6);
 	// -- 7. position iterations
 	for (int it = 0; it < p.pos_iters; ++it) solve_pass(2, KC_SOLVE_POSITION);
