@@ -1353,7 +1353,7 @@ SGP_DEV void con_store(const DV& d, uint32_t slot, const ConReg& r)
 	for (int i = 0; i < 4; ++i) { if (i < np) CUR(d).lam[i][slot] = r.lam[i]; }
 }
 
-template <int VS> SGP_DEV void con_solve_velocity(ConReg& r, float4* vel)
+template <int VS> SGP_DEV void con_solve_velocity(ConReg& r, float4* vel, uint32_t dbg = 0)
 {
 	const uint2 ab = r.ab;
 	const int np = r.np_col & 0xFF;
@@ -1364,7 +1364,7 @@ template <int VS> SGP_DEV void con_solve_velocity(ConReg& r, float4* vel)
 	BodyVel A, B;
 	A.lv = V3(va); A.av = V3(wa); B.lv = V3(vb); B.av = V3(wb);
 	const v3 n = V3(r.nf);
-	const v3 t1 = V3(r.rn[0].i1.w, r.rn[0].i2.w, r.rt1[0].i1.w);      // = v3_normalized_perpendicular(n), stored by k_setup (np >= 1 here)
+	const v3 t1 = (dbg & 2u) ? v3_normalized_perpendicular(n) : V3(r.rn[0].i1.w, r.rn[0].i2.w, r.rt1[0].i1.w);      // = v3_normalized_perpendicular(n), stored by k_setup (np >= 1 here)
 	const v3 t2 = v3_cross(n, t1);
 	if (friction > 0.0f) {
 #pragma unroll
@@ -1398,7 +1398,7 @@ template <int VS> SGP_DEV void solve_velocity_one_t(const DV& d, uint32_t slot, 
 {
 	ConReg r;
 	con_load(d, slot, r);
-	con_solve_velocity<VS>(r, vel);
+	con_solve_velocity<VS>(r, vel, d.dbg_flags);
 	con_store(d, slot, r);
 }
 SGP_DEV void solve_velocity_one(const DV& d, uint32_t slot) { solve_velocity_one_t<4>(d, slot, d.sbody); }
@@ -1438,10 +1438,12 @@ SGP_DEV void solve_position_one(const DV& d, uint32_t slot)
 			if (im1 > 0.0f) {
 				posA = v3_sub(posA, v3_scale(nrm, lambda * im1));
 				qa = quat_add_rotation_step(qa, v3_scale(sym33_mul(I1, v3_cross(r1, nrm)), -lambda));
+				RA = quat_to_m33(qa);
 			}
 			if (im2 > 0.0f) {
 				posB = v3_add(posB, v3_scale(nrm, lambda * im2));
 				qb = quat_add_rotation_step(qb, v3_scale(sym33_mul(I2, v3_cross(r2, nrm)), lambda));
+				RB = quat_to_m33(qb);
 			}
 			moved = true;
 		}
@@ -1523,7 +1525,7 @@ __global__ void __launch_bounds__(512) k_solve_tail(DV d, int first_colour, int 
 		if (mine) { con_load(d, slot, r); my_col = (r.np_col >> 8) & 0xFF; }
 		for (int c = first_colour; c < SGP_OVERFLOW_COLOUR; ++c) {
 			if (cs[c] == cs[c + 1]) continue;
-			if (my_col == c) con_solve_velocity<4>(r, d.sbody);
+			if (my_col == c) con_solve_velocity<4>(r, d.sbody, d.dbg_flags);
 			__syncthreads();
 		}
 		if (mine) con_store(d, slot, r);
@@ -1588,7 +1590,7 @@ __global__ void __launch_bounds__(512) k_solve_small(DV d, int warm_start, int i
 		for (int pass = 0; pass < iterations; ++pass) {
 			for (int c = 0; c < SGP_OVERFLOW_COLOUR; ++c) {
 				if (cs[c] == cs[c + 1]) continue;
-				if (my_col == c) con_solve_velocity<2>(r, sv);
+				if (my_col == c) con_solve_velocity<2>(r, sv, d.dbg_flags);
 				__syncthreads();
 			}
 		}

@@ -6,7 +6,7 @@ from . import abi
 from .world import CWorld, SgpError
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsgp.so")
+LIB_PATH = os.environ.get("SGP_LIB_PATH") or os.path.join(_HERE, "libsgp.so")      # SGP_LIB_PATH: A/B runs against another build of the same ABI
 _lib = None
 _devices = None
 
