@@ -16,7 +16,8 @@ def flags():
 
 def build(force=False, verbose=False):
     srcs = [os.path.join(SHIM, s) for s in SOURCES]
-    deps = srcs + [os.path.join(SHIM, h) for h in ("PhysicsWorld.h", "PhysicsObject.h", "Jolt/JoltLite.h", "Jolt/JoltVehicleLite.h")]
+    deps = srcs + [os.path.join(SHIM, h) for h in ("PhysicsWorld.h", "PhysicsObject.h", "Jolt/JoltLite.h", "Jolt/JoltVehicleLite.h", "Jolt/JoltCharacterLite.h")]
+    deps += [os.path.join(HERE, "..", "include", "sgp.h"), os.path.join(HERE, "libsgp.so")]      # the C ABI's structs are compiled into the facade
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
         return LIB
     cmd = ["g++"] + flags() + ["-shared"] + srcs + ["-o", LIB, "-L", HERE, "-lsgp", "-Wl,-rpath,$ORIGIN"]

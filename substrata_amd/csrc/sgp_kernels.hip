@@ -937,13 +937,16 @@ __global__ void __launch_bounds__(TPB) k_colour_count(DV d)
 	if (threadIdx.x < SGP_MAX_COLOURS + 2) hist[threadIdx.x] = 0;
 	__syncthreads();
 	const uint32_t n = min(d.ctr->n_manifolds, d.cap_manifolds);
+	uint32_t my_points = 0, my_cons = 0;          // the two totals are summed per thread and reduced per wave: one LDS atomic per wave, not per manifold
 	for (uint32_t m = blockIdx.x * TPB + threadIdx.x; m < n; m += gridDim.x * TPB) {
 		const int c = d.man_colour[m];
 		if (c < 0) continue;
 		atomicAdd(&hist[c], 1u);
-		{ const int npb = __float_as_int(d.man_n[m].w); atomicAdd(&hist[SGP_MAX_COLOURS], (npb & 0x100) ? 0u : (uint32_t)(npb & 0xFF)); }
-		atomicAdd(&hist[SGP_MAX_COLOURS + 1], 1u);
+		{ const int npb = __float_as_int(d.man_n[m].w); my_points += (npb & 0x100) ? 0u : (uint32_t)(npb & 0xFF); }
+		my_cons += 1u;
 	}
+	for (int off = 32; off > 0; off >>= 1) { my_points += __shfl_down(my_points, off, 64); my_cons += __shfl_down(my_cons, off, 64); }
+	if ((threadIdx.x & 63) == 0) { if (my_points) atomicAdd(&hist[SGP_MAX_COLOURS], my_points); if (my_cons) atomicAdd(&hist[SGP_MAX_COLOURS + 1], my_cons); }
 	__syncthreads();
 	if (threadIdx.x < SGP_MAX_COLOURS) { if (hist[threadIdx.x]) atomicAdd(&d.ctr->colour_count[threadIdx.x], hist[threadIdx.x]); }
 	else if (threadIdx.x == SGP_MAX_COLOURS) { if (hist[SGP_MAX_COLOURS]) atomicAdd(&d.ctr->n_points, hist[SGP_MAX_COLOURS]); }

@@ -1,5 +1,7 @@
 """Summarise rocprofv3 --pmc counter_collection.csv files: per-kernel mean counter value per launch (last steps only).
-Usage: python tools/pmc_summary.py <fetch_csv> <write_csv> [out.md]
+Usage: python tools/pmc_summary.py <fetch_csv> <write_csv> [out.md] [out.json bodies]
+(out.json: the two figures bench.py puts into roofline.traffic / roofline_solver.traffic -- bytes per body of the three body-sweep kernels,
+bytes per launch of a velocity-iteration colour launch; `bodies` = body slots the sweep covers)
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB (x1024 = bytes).  Per MI355X_MICROARCH.md (HBM section), on gfx950
 FETCH_SIZE counts 64 B per 128-B request for wide coalesced streams, i.e. reads exactly 1/2 of a 16 B/lane stream: the
 `read_x2` column applies that correction; WRITE_SIZE is uncalibrated and reported as is."""
@@ -33,6 +35,21 @@ def main():
     if len(sys.argv) > 3:
         open(sys.argv[3], "w").write(txt + "\n")
     print(txt)
+    if len(sys.argv) > 5:
+        import json
+        bodies = int(sys.argv[5])
+
+        def per_launch(name):
+            fv = fetch.get(name, [0.0]); wv = write.get(name, [0.0])
+            fv = fv[len(fv) // 2:]; wv = wv[len(wv) // 2:]
+            return sum(fv) / len(fv) * 1024 * 2 + sum(wv) / len(wv) * 1024
+        sweep = sum(per_launch(k) for k in ("k_pre_solve", "k_integrate_pose", "k_finalize"))
+        out = {"sweep_bytes_per_body": sweep / bodies, "solve_velocity_bytes_per_launch": per_launch("void k_solve_colour<1>"),
+               "bodies": bodies,
+               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, eager launches), tools/collect_pmc.sh + tools/pmc_summary.py: "
+                         "FETCH_SIZE KiB x 1024 x 2 (gfx950 correction) + WRITE_SIZE KiB x 1024, mean over the second half of each kernel's launches"}
+        json.dump(out, open(sys.argv[4], "w"), indent=1)
+        print(json.dumps(out))
 
 
 if __name__ == "__main__":
