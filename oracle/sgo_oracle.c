@@ -132,20 +132,23 @@ typedef struct sgo_world {
 
 SGO_API void sgo_default_settings(sgp_settings* s)
 {
-	s->num_velocity_steps = 10;
-	s->num_position_steps = 2;
-	s->baumgarte = 0.2f;
-	s->penetration_slop = 0.02f;
-	s->speculative_contact_distance = 0.02f;
-	s->min_velocity_for_restitution = 1.0f;
-	s->max_penetration_distance = 0.2f;
-	s->time_before_sleep = 0.5f;
-	s->point_velocity_sleep_threshold = 0.03f;
-	s->contact_point_preserve_lambda_max_dist_sq = 0.01f * 0.01f;
-	s->max_linear_velocity = 500.0f;
-	s->max_angular_velocity = 0.25f * 3.14159265358979323846f * 60.0f;
-	s->allow_sleeping = 1;
-	s->warm_start = 1;
+	/* Jolt v5.3.0 Jolt/Physics/PhysicsSettings.h, restated from memory: Jolt's sources are not in /root/reference (scripts/get_libs.rb:29-40
+	   fetches them at build time), so none of these could be checked here.  oracle/jolt_ref/oracle_jolt.cpp prints the real values when it
+	   can be built. */
+	s->num_velocity_steps = 10;                                      /* mNumVelocitySteps             UNVERIFIED: upstream */
+	s->num_position_steps = 2;                                       /* mNumPositionSteps             UNVERIFIED: upstream */
+	s->baumgarte = 0.2f;                                             /* mBaumgarte                    UNVERIFIED: upstream */
+	s->penetration_slop = 0.02f;                                     /* mPenetrationSlop              UNVERIFIED: upstream */
+	s->speculative_contact_distance = 0.02f;                         /* mSpeculativeContactDistance   UNVERIFIED: upstream */
+	s->min_velocity_for_restitution = 1.0f;                          /* mMinVelocityForRestitution    UNVERIFIED: upstream */
+	s->max_penetration_distance = 0.2f;                              /* mMaxPenetrationDistance       UNVERIFIED: upstream */
+	s->time_before_sleep = 0.5f;                                     /* mTimeBeforeSleep              UNVERIFIED: upstream */
+	s->point_velocity_sleep_threshold = 0.03f;                       /* mPointVelocitySleepThreshold  UNVERIFIED: upstream */
+	s->contact_point_preserve_lambda_max_dist_sq = 0.01f * 0.01f;    /* mContactPointPreserveLambdaMaxDistSq  UNVERIFIED: upstream */
+	s->max_linear_velocity = 500.0f;                                 /* BodyCreationSettings::mMaxLinearVelocity   UNVERIFIED: upstream */
+	s->max_angular_velocity = 0.25f * 3.14159265358979323846f * 60.0f; /* BodyCreationSettings::mMaxAngularVelocity  UNVERIFIED: upstream */
+	s->allow_sleeping = 1;                                           /* mAllowSleeping                UNVERIFIED: upstream */
+	s->warm_start = 1;                                               /* mConstraintWarmStart          UNVERIFIED: upstream */
 }
 
 SGO_API void sgo_default_world_desc(sgp_world_desc* d)
@@ -166,9 +169,9 @@ SGO_API void sgo_default_body_desc(sgp_body_desc* d)
 	d->motion_type = SGP_MOTION_STATIC;                /* PhysicsObject.cpp:28 */
 	d->layer = SGP_LAYER_NON_MOVING;
 	d->mass = 100.0f; d->friction = 0.5f; d->restitution = 0.3f; /* PhysicsObject.cpp:36-38 */
-	d->gravity_factor = 1.0f;
-	d->linear_damping = 0.05f; d->angular_damping = 0.05f;
-	d->allow_sleeping = 1;
+	d->gravity_factor = 1.0f;                          /* BodyCreationSettings::mGravityFactor          UNVERIFIED: upstream */
+	d->linear_damping = 0.05f; d->angular_damping = 0.05f;   /* mLinearDamping, mAngularDamping            UNVERIFIED: upstream */
+	d->allow_sleeping = 1;                             /* mAllowSleeping                                UNVERIFIED: upstream */
 }
 
 /* Optional multi-core mode for the cpu_baseline timing (bench.py): the loops over bodies, pairs and the constraints of one
@@ -909,8 +912,8 @@ static int setup_constraint(sgo_world* w, uint32_t k, const sgo_manifold* m, flo
 	sym33 I1, I2; memset(&I1, 0, sizeof(I1)); memset(&I2, 0, sizeof(I2));
 	if (im1 > 0.0f) I1 = world_inv_inertia(RA, A->inv_inertia);
 	if (im2 > 0.0f) I2 = world_inv_inertia(RB, B->inv_inertia);
-	c.friction = sqrtf(A->friction * B->friction);
-	const float restitution = fmaxf(A->restitution, B->restitution);
+	c.friction = sqrtf(A->friction * B->friction);                      /* ContactConstraintManager's default combine: geometric mean   UNVERIFIED: upstream */
+	const float restitution = fmaxf(A->restitution, B->restitution);    /* ... and the larger restitution                                UNVERIFIED: upstream */
 	c.t1 = v3_normalized_perpendicular(c.n);
 	c.t2 = v3_cross(c.n, c.t1);
 	for (int i = 0; i < c.np; ++i) {
