@@ -70,6 +70,19 @@ def parse():
     return ap.parse_args()
 
 
+def single_gpu_reference(workload, lattice):
+    """The same workload on ONE GPU, from the committed log (strong scaling is measured against this, not against the N = 1 bench line,
+    which is config 3)."""
+    if workload != "config4" or lattice != 100:
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02c_bench_config4_1gpu.log")) as f:
+            j = json.loads([l for l in f if l.startswith("{")][-1])
+        return {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "source": "profiles/r02c_bench_config4_1gpu.log (bench.py --workload config4, one MI355X)"}
+    except (OSError, ValueError, IndexError, KeyError):
+        return None
+
+
 def load_pmc():
     try:
         with open(PMC_FILE) as f:
@@ -200,6 +213,7 @@ def main():
         w = World(max_bodies=cap, device=local_rank)
         w.add_batch(descs)
         ex = None
+        exchange_kind = "none (one tile)"
         if n_gpus > 1 and args.backend == "nccl":
             # the native exchange (sgp_tiles_*: device routing + RCCL send / recv from inside libsgp.so); torch.distributed only carries the
             # communicator's unique id to the other ranks and runs the barriers around the timed region
@@ -209,9 +223,26 @@ def main():
             if rank == 0:
                 uid.copy_(torch.frombuffer(bytearray(tiles.NativeTiles.unique_id()), dtype=torch.uint8))
             dist.broadcast(uid, src=0)
-            ex = tiles.NativeTiles(w, rank, n_gpus, boxes_t.cpu().numpy().reshape(n_gpus, 6), 2.0, unique_id=bytes(uid.cpu().numpy().tobytes()))
+            # (a rank that cannot set the native exchange up -- RCCL missing or refusing the communicator -- must not leave the others hanging in
+            # ncclCommInitRank: every rank reports, and all of them switch to the torch.distributed exchange together; the line says which ran)
+            try:
+                ex = tiles.NativeTiles(w, rank, n_gpus, boxes_t.cpu().numpy().reshape(n_gpus, 6), 2.0, unique_id=bytes(uid.cpu().numpy().tobytes()))
+                ok = 1
+            except Exception as e:      # noqa: BLE001
+                print(f"[bench rank {rank}] native tile exchange unavailable: {e}", file=sys.stderr, flush=True)
+                ex, ok = None, 0
+            okt = torch.tensor([ok], dtype=torch.int32, device=xdev)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            if int(okt.item()) == 0:
+                if ex is not None:
+                    ex.close()
+                ex = tiles.GhostExchange(w, rank, n_gpus, lo, hi, margin=2.0, dist=dist, device=xdev)
+                exchange_kind = "torch.distributed all-to-all of ghost records (tiles.GhostExchange): the native sgp_tiles_* exchange could not be set up"
+            else:
+                exchange_kind = "sgp_tiles_exchange: device routing + RCCL grouped send/recv inside libsgp.so"
         elif n_gpus > 1:
             ex = tiles.GhostExchange(w, rank, n_gpus, lo, hi, margin=2.0, dist=dist, device=xdev)      # gloo dry run on a shared GPU
+            exchange_kind = f"torch.distributed ({args.backend}) all-to-all of ghost records (tiles.GhostExchange), dry run"
 
         def one_step():
             if ex is not None:
@@ -254,7 +285,8 @@ def main():
                 "dtype": "f32", "data": "synthetic",
                 "config": {
                     "workload": workload_text, "total_bodies": total_bodies, "tiles": n_gpus, "value_definition": value_definition,
-                    "untimed_settle_steps": SETTLE_STEPS_TILED,
+                    "untimed_settle_steps": SETTLE_STEPS_TILED, "exchange": exchange_kind,
+                    "single_gpu_reference": single_gpu_reference(workload, args.lattice),
                     "owned_bodies_per_tile": [int(v) for v in allv[:, 0]], "contact_constraints_per_tile": [int(v) for v in allv[:, 1]],
                     "active_bodies_per_tile": [int(v) for v in allv[:, 2]],
                     "ghosts_exported_per_tile": [int(v) for v in allv[:, 3]], "ghosts_imported_per_tile": [int(v) for v in allv[:, 4]],
