@@ -524,7 +524,7 @@ __global__ void __launch_bounds__(TPB) k_bp_large(DV d)
 	const uint32_t j = blockIdx.x * TPB + threadIdx.x;
 	if (j >= d.sp->n_slots) return;
 	const uint32_t fj = d.flags[j];
-	if (!(fj & BF_ALIVE)) return;
+	if (!(fj & BF_ALIVE) || (fj & BF_ALIAS)) return;      // (a mesh body's alias slots only carry manifolds: they never pair)
 	const float4 mnj = d.aabb_min[j], mxj = d.aabb_max[j];
 	for (uint32_t l = 0; l < d.sp->n_large; ++l) {
 		const uint32_t i = d.large_ids[l];

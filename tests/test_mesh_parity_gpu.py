@@ -157,3 +157,40 @@ def test_car_on_mesh_terrain_matches_oracle(oracle):
     print("car on terrain: pos", np.round(st["pos"], 2), "bit exact =", d["bit_exact"])
     assert st["pos"][1] > -10.0 and 0.2 < st["pos"][2] < 2.0 and (vs["wheels"]["contact_body"][:4] == 0).sum() >= 2
     tw.close()
+
+
+def test_mesh_added_after_a_large_dynamic_body_matches_oracle(oracle):
+    """A static mesh body streamed in AFTER (so: with a higher id than) a dynamic body that is itself beyond the large-body radius, the big box
+    lying across it.  Both go through the large-body pair kernel; the mesh body's two alias slots must not pair with the box (found by the
+    fuzzer in round 2: with the mesh at the higher id the large-large rule let the aliases through, three manifolds became up to nine)."""
+    import compound_scene as cs
+    tw = parity.make_twin(oracle, max_bodies=256)
+    tw.add_batch(scenes.ground())
+    big = scenes.dynamic_bodies(1, mass=500.0)
+    big["shape_type"] = abi.SHAPE_BOX; big["shape"][0, :3] = (5.0, 3.0, 0.3); big["pos"][0] = (0.0, 0.0, 2.2); big["restitution"] = 0.0
+    small = scenes.dynamic_bodies(6)
+    small["pos"] = [(-3 + 1.2 * k, 4.5, 1.0) for k in range(6)]
+    ig, ic = tw.add_batch(np.concatenate([big, small])); assert np.array_equal(ig, ic)
+    tw.set_contact_events(1)
+    for _ in range(5):
+        tw.step(DT)
+    V, T = cs.box_mesh((-1.0, -0.7, 0.0), (1.0, 0.7, 1.4))
+    mg, mc = tw.mesh_create(V, T, np.arange(len(T), dtype=np.uint32) % 3); assert mg.mesh_id == mc.mesh_id
+    mb = scenes.dynamic_bodies(1)
+    mb["motion_type"] = abi.MOTION_STATIC; mb["layer"] = abi.LAYER_NON_MOVING
+    mb["shape_type"] = abi.SHAPE_MESH; mb["shape"][0] = (float(mg.mesh_id), 0, 0, 0); mb["pos"][0] = (0.5, 0.2, 0.0)
+    jg, jc = tw.add_batch(mb); assert np.array_equal(jg, jc) and int(jg[0]) > int(ig[0])
+    touched = False
+    for s in range(1, 181):
+        tw.step(DT)
+        sg, sc = tw.stats()
+        assert (sg.num_pairs, sg.num_manifolds, sg.num_contact_points) == (sc.num_pairs, sc.num_manifolds, sc.num_contact_points), s
+        for ev in (abi.EVENT_CONTACT_ADDED, abi.EVENT_CONTACT_PERSISTED):
+            eg, ec = tw.drain_events(ev)
+            assert len(eg) == len(ec), (s, ev)
+            touched |= any(int(e["id2"]) == int(jg[0]) or int(e["id1"]) == int(jg[0]) for e in eg)
+        if s % 30 == 0:
+            d = parity.state_diff(tw.gpu.read_states(0, 64), tw.cpu.read_states(0, 64))
+            assert d["bit_exact"] and d["active_mismatch"] == 0, (s, d)
+    assert touched                                          # the big box did come to rest on the mesh
+    tw.close()

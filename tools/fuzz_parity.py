@@ -67,7 +67,8 @@ def run_seed(oracle, seed, steps, verbose=False):
                 b0, b1 = base + 2 * ((k + 1) % 4), base + 2 * ((k + 1) % 4) + 1
                 tt += [[a0, a1, b1], [a0, b1, b0]]          # facing the inside of the pen
             t = np.concatenate([t, np.array(tt, np.uint32)])
-        mg, mc = tw.mesh_create(v, t)
+        mats = rng.integers(0, 5, len(t)).astype(np.uint32) if rng.random() < 0.6 and not os.environ.get("FUZZ_NO_MATS") else None      # material index per triangle (ray hits report it)
+        mg, mc = tw.mesh_create(v, t, mats)
         assert mg.mesh_id == mc.mesh_id
         m = scenes.dynamic_bodies(1)
         m["motion_type"] = abi.MOTION_STATIC; m["layer"] = abi.LAYER_NON_MOVING
@@ -82,6 +83,37 @@ def run_seed(oracle, seed, steps, verbose=False):
         hg, hc = tw.hull_create(pts_, off_)
         assert hg.hull_id == hc.hull_id
         hulls.append(hg)
+    # static compounds (StaticCompoundShape): random children -- boxes, spheres, capsules, a hull, a small mesh -- around the arena
+    compounds = []
+    for _ in range(0 if os.environ.get("FUZZ_NO_COMPOUND") else int(rng.integers(0, 3))):
+        nch = int(rng.integers(1, 5))
+        ch = np.zeros(nch, dtype=abi.compound_child_dtype)
+        qq = rng.normal(size=(nch, 4)); ch["rot"] = (qq / np.linalg.norm(qq, axis=1, keepdims=True)).astype(np.float32)
+        ch["pos"] = rng.uniform([-1.5, -1.5, 0.0], [1.5, 1.5, 2.0], (nch, 3)).astype(np.float32)
+        for k in range(nch):
+            kk = int(rng.integers(0, 5))
+            if kk == 0:
+                ch["shape_type"][k] = abi.SHAPE_BOX; ch["shape"][k, :3] = rng.uniform(0.2, 0.9, 3)
+            elif kk == 1:
+                ch["shape_type"][k] = abi.SHAPE_SPHERE; ch["shape"][k, 0] = rng.uniform(0.2, 0.7)
+            elif kk == 2:
+                ch["shape_type"][k] = abi.SHAPE_CAPSULE; ch["shape"][k, :2] = (rng.uniform(0.15, 0.4), rng.uniform(0.2, 0.8))
+            elif kk == 3 and hulls:
+                ch["shape_type"][k] = abi.SHAPE_HULL; ch["shape"][k, 0] = float(hulls[int(rng.integers(len(hulls)))].hull_id)
+            else:
+                import compound_scene as cs_
+                bv, bt = cs_.box_mesh((-0.6, -0.4, 0.0), (0.6, 0.4, float(rng.uniform(0.3, 1.2))))
+                cmg, cmc = tw.mesh_create(bv, bt, np.arange(len(bt), dtype=np.uint32) % 3)
+                assert cmg.mesh_id == cmc.mesh_id
+                ch["shape_type"][k] = abi.SHAPE_MESH; ch["shape"][k, 0] = float(cmg.mesh_id); ch["rot"][k] = (0, 0, 0, 1)
+        base = scenes._blank(1)
+        base["pos"][0] = tuple(rng.uniform([-7, -7, 0.0], [7, 7, 0.6])); qb = rng.normal(size=4); qb[:2] *= 0.1; base["rot"][0] = qb / np.linalg.norm(qb)
+        base["friction"] = 0.6; base["restitution"] = 0.1; base["userdata"] = 5000 + len(compounds)
+        cg_, cc_ = tw.add_compound(base, ch)
+        assert cg_ == cc_, (seed, "compound id", cg_, cc_)
+        if cg_ != abi.INVALID_ID:
+            compounds.append(cg_)
+    stream = None                                   # a streamed-in static mesh object: added, later removed and its shape destroyed, then another
     big = rng.random() < 0.2                        # one scene in five is crowded: deeper piles, more colours, bodies with many contacts
     n = int(rng.integers(500, 1300)) if big else int(rng.integers(40, 160))
     d = scenes.dynamic_bodies(n)
@@ -174,7 +206,31 @@ def run_seed(oracle, seed, steps, verbose=False):
                 tw.set_pose_shape(i, tuple(stt["pos"]), tuple(stt["rot"]), (float(rng.uniform(0.2, 0.7)), 0.0, 0.0, 0.0))
         elif r < 0.20 and live:
             i = int(rng.choice(live)); tw.set_vel(i, tuple(rng.uniform(-5, 5, 3)), tuple(rng.uniform(-4, 4, 3)))
-        elif r < 0.22 and len(live) > 8:                        # a burst of network snapshots (batched setNewObToWorldTransform)
+        elif r < 0.235 and compounds and rng.random() < 0.5:    # a compound is moved (every child follows) or removed
+            cid = int(rng.choice(compounds))
+            if rng.random() < 0.3:
+                compounds.remove(cid); tw.remove(cid)
+            else:
+                qq = rng.normal(size=4); qq[:2] *= 0.1; qq /= np.linalg.norm(qq)
+                tw.set_pose_vel(cid, tuple(rng.uniform([-7, -7, 0.0], [7, 7, 0.8])), tuple(qq), (0, 0, 0), (0, 0, 0))
+        elif r < 0.25 and not os.environ.get("FUZZ_NO_STREAM"):   # streaming: a static mesh object comes and goes (shape ids and body slots get reused)
+            import compound_scene as cs_
+            if stream is None:
+                bv, bt = cs_.box_mesh((-1.0, -0.7, 0.0), (1.0, 0.7, float(rng.uniform(0.4, 1.5))))
+                smg, smc = tw.mesh_create(bv, bt, np.arange(len(bt), dtype=np.uint32) % 4)
+                assert smg.mesh_id == smc.mesh_id
+                mb = scenes.dynamic_bodies(1)
+                mb["motion_type"] = abi.MOTION_STATIC; mb["layer"] = abi.LAYER_NON_MOVING
+                mb["shape_type"] = abi.SHAPE_MESH; mb["shape"][0] = (float(smg.mesh_id), 0, 0, 0)
+                mb["pos"][0] = tuple(rng.uniform([-6, -6, 0.0], [6, 6, 0.5]))
+                sg_, sc_ = tw.add_batch(mb); assert np.array_equal(sg_, sc_)
+                if sg_[0] != abi.INVALID_ID:
+                    stream = (int(sg_[0]), int(smg.mesh_id))
+                else:
+                    tw.mesh_destroy(int(smg.mesh_id))
+            else:
+                tw.remove(stream[0]); tw.mesh_destroy(stream[1]); stream = None
+        elif r < 0.27 and len(live) > 8:                        # a burst of network snapshots (batched setNewObToWorldTransform)
             ids_ = rng.choice(live, size=6, replace=False).astype(np.uint32)
             recs_ = np.zeros(6, dtype=abi.pose_vel_dtype)
             recs_["pos"] = rng.uniform([-6, -6, 1.5], [6, 6, 7], (6, 3)); qq = rng.normal(size=(6, 4)); recs_["rot"] = qq / np.linalg.norm(qq, axis=1, keepdims=True)
@@ -187,7 +243,10 @@ def run_seed(oracle, seed, steps, verbose=False):
         tw.step(DT)
         for ev in (abi.EVENT_CONTACT_ADDED, abi.EVENT_CONTACT_PERSISTED, abi.EVENT_ACTIVATED, abi.EVENT_DEACTIVATED, abi.EVENT_ENTERED_WATER):
             eg, ec = tw.drain_events(ev)
-            assert len(eg) == len(ec), (seed, s, "event count", ev, len(eg), len(ec))
+            if len(eg) != len(ec):
+                def brief(e):
+                    return [tuple(int(e[n_][k]) for n_ in e.dtype.names if n_ in ("id", "id1", "id2", "body", "a", "b", "kind", "type")) for k in range(min(len(e), 12))]
+                raise AssertionError((seed, s, "event count", ev, len(eg), len(ec), eg.dtype.names, brief(eg), brief(ec), "stream", stream, "compounds", compounds))
             if len(eg):      # the events of THIS step, same payloads (both sides deliver them sorted by body ids)
                 for f in eg.dtype.names:
                     if f.startswith("userdata"):
@@ -211,6 +270,10 @@ def run_seed(oracle, seed, steps, verbose=False):
             if not (np.array_equal(hg["id"], hc["id"]) and np.array_equal(hg["t"].view(np.uint32), hc["t"].view(np.uint32))):
                 badr = np.flatnonzero((hg["id"] != hc["id"]) | (hg["t"].view(np.uint32) != hc["t"].view(np.uint32)))
                 raise AssertionError((seed, s, "rays", [(int(k), int(hg["id"][k]), float(hg["t"][k]), int(hc["id"][k]), float(hc["t"][k]), rays["origin"][k].tolist(), rays["dir"][k].tolist()) for k in badr[:3]]))
+            for f in ("normal", "triangle", "material", "bary", "sub_shape", "userdata"):      # what traceRay hands back besides the distance
+                if not np.array_equal(np.ascontiguousarray(hg[f]).view(np.uint8), np.ascontiguousarray(hc[f]).view(np.uint8)):
+                    k = int(np.flatnonzero((np.ascontiguousarray(hg[f]).reshape(len(hg), -1) != np.ascontiguousarray(hc[f]).reshape(len(hc), -1)).any(axis=1))[0])
+                    raise AssertionError((seed, s, "ray hit field", f, k, {n_: np.asarray(hg[n_][k]).tolist() for n_ in hg.dtype.names}, {n_: np.asarray(hc[n_][k]).tolist() for n_ in hc.dtype.names}))
             radii = rng.uniform(0.1, 0.5, 24).astype(np.float32)
             cg, cc = tw.spherecast(rays, radii)
             if not (np.array_equal(cg["id"], cc["id"]) and np.array_equal(cg["t"].view(np.uint32), cc["t"].view(np.uint32))):
@@ -227,7 +290,7 @@ def run_seed(oracle, seed, steps, verbose=False):
             qs["radius"] = 0.3; qs["half_height"] = 0.65; qs["max_separation"] = 0.1; qs["ignore_id"] = abi.INVALID_ID
             kg, kc = tw.collide_capsules(qs)
             assert len(kg) == len(kc) and np.array_equal(kg["body"], kc["body"]) and np.array_equal(kg["distance"].view(np.uint32), kc["distance"].view(np.uint32)) \
-                and np.array_equal(kg["normal"].view(np.uint32), kc["normal"].view(np.uint32)), (seed, s, "capsule queries")
+                and np.array_equal(kg["normal"].view(np.uint32), kc["normal"].view(np.uint32)) and np.array_equal(kg["sub_shape"], kc["sub_shape"]), (seed, s, "capsule queries")
             for v in vids:
                 vg_, vc_ = tw.vehicle_get_state(v)
                 if vg_.tobytes() != vc_.tobytes():
