@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised differential test of the tile path: N adjacent tiles in ONE process (1 x 2 or 2 x 2), ghosts handed over by direct calls
 (export -> route -> split -> import, what GhostExchange does across ranks), HIP worlds against oracle worlds, bit for bit.  Random piles
-of primitive bodies straddle the tile borders, some are thrown across them (ownership migrates), some are removed or teleported.
+of primitive bodies straddle the tile borders, some are thrown across them (ownership migrates), some are removed, teleported or kicked in
+mid-run.  Odd seeds exchange the HIP worlds through the native path (sgp_tiles_exchange_group: routing kernels, device-to-device copies,
+device-side ghost refresh) while the oracle worlds go through the Python statement of the rules; every third seed stacks the tiles in z.
 
     python tools/fuzz_tiles.py --seeds 0-49 --steps 240        (on the GPU box)
 """
@@ -22,7 +24,8 @@ import parity                                  # noqa: E402
 TILE_W = 10.0
 
 
-def exchange(worlds, boxes, margin, log):
+def exchange(worlds, boxes, margin, log, moved=None):
+    """moved (optional): per tile, [ids that left, ids that arrived] -- how the caller keeps track of which bodies a tile owns."""
     n = len(worlds)
     sent = []
     for r, w in enumerate(worlds):
@@ -30,6 +33,8 @@ def exchange(worlds, boxes, margin, log):
         send, counts, emig = tiles.route(recs, r, boxes, margin + 1.5)
         for i in emig:
             w.remove(int(i))
+        if moved is not None:
+            moved[r][0] += [int(i) for i in emig]
         off = [0] + [int(x) for x in np.cumsum(counts)]
         sent.append([send[off[d]:off[d + 1]] for d in range(n)])
         log.append(("export", r, len(recs), [int(c) for c in counts], len(emig)))
@@ -38,7 +43,9 @@ def exchange(worlds, boxes, margin, log):
         ghosts, immigrants = tiles.split(arrived, boxes[r, :3], boxes[r, 3:])
         w.import_ghosts(ghosts)
         if len(immigrants):
-            w.add_batch(tiles.records_to_descs(immigrants))
+            new_ids = w.add_batch(tiles.records_to_descs(immigrants))
+            if moved is not None:
+                moved[r][1] += [int(i) for i in new_ids if i != abi.INVALID_ID]
         log.append(("import", r, len(ghosts), len(immigrants)))
 
 
@@ -46,18 +53,22 @@ def run_seed(oracle, seed, steps, verbose=False):
     from substrata_amd.lib import World
     rng = np.random.default_rng(seed)
     n_tiles = int(rng.choice([2, 4]))
-    boxes = np.array([np.concatenate(tiles.tile_bounds(r, n_tiles, TILE_W, TILE_W)[:2]) for r in range(n_tiles)], np.float32)
+    native = seed % 2 == 1
+    grid = (1, 1, 2) if (seed % 3 == 2 and n_tiles == 2) else ((2, 1, 2) if (seed % 3 == 2) else None)      # tiles stacked in z (faces at z = 3)
+    tb = lambda r: tiles.tile_bounds(r, n_tiles, TILE_W, TILE_W, 3.0 if grid else None, grid=grid)      # noqa: E731
+    boxes = np.array([np.concatenate(tb(r)[:2]) for r in range(n_tiles)], np.float32)
     span = TILE_W * (2 if n_tiles >= 2 else 1)
     gpu = [World(max_bodies=2048) for _ in range(n_tiles)]
     cpu = [oracle.OracleWorld(max_bodies=2048) for _ in range(n_tiles)]
     total = 0
+    own = []
     for r in range(n_tiles):
-        lo, hi, origin = tiles.tile_bounds(r, n_tiles, TILE_W, TILE_W)
+        lo, hi, origin = tb(r)
         n = int(rng.integers(30, 120))
         d = scenes.dynamic_bodies(n)
         d["pos"][:, 0] = origin[0] + rng.uniform(0.3, TILE_W - 0.3, n)
         d["pos"][:, 1] = origin[1] + rng.uniform(0.3, TILE_W - 0.3, n)
-        d["pos"][:, 2] = rng.uniform(0.6, 6.0, n)
+        d["pos"][:, 2] = rng.uniform(max(float(lo[2]), 0.0) + 0.6, min(float(hi[2]), 6.2) - 0.2, n)
         q = rng.normal(size=(n, 4)); d["rot"] = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
         kind = rng.integers(0, 3, n); sc = rng.uniform(0.3, 0.9, n)
         for i in range(n):
@@ -69,13 +80,50 @@ def run_seed(oracle, seed, steps, verbose=False):
         descs = np.concatenate([scenes.ground(), d])
         ig = gpu[r].add_batch(descs); ic = cpu[r].add_batch(descs)
         assert np.array_equal(ig, ic)
+        own.append(set(int(i) for i in ig[1:] if i != abi.INVALID_ID))
         total += n
+    nt = [tiles.NativeTiles(gpu[r], r, n_tiles, boxes, 1.5) for r in range(n_tiles)] if native else None
     migrated = 0
     for s in range(1, steps + 1):
+        # edits between steps, applied to both worlds of a tile: removal, teleport inside the tile, a kick
+        if rng.random() < 0.25:
+            r = int(rng.integers(n_tiles))
+            if len(own[r]) > 5:
+                i = int(rng.choice(sorted(own[r])))
+                what = rng.random()
+                if what < 0.3:
+                    gpu[r].remove(i); cpu[r].remove(i); own[r].discard(i); total -= 1
+                elif what < 0.6:
+                    lo_, hi_ = boxes[r, :3], boxes[r, 3:]
+                    xl, xh = max(float(lo_[0]), 0.0) + 1.0, min(float(hi_[0]), span) - 1.0
+                    yl, yh = max(float(lo_[1]), 0.0) + 1.0, min(float(hi_[1]), span) - 1.0
+                    zl, zh = max(float(lo_[2]), 0.0) + 0.8, min(float(hi_[2]), 6.0) - 0.3
+                    p_ = (float(rng.uniform(xl, max(xl + 0.1, xh))), float(rng.uniform(yl, max(yl + 0.1, yh))), float(rng.uniform(zl, max(zl + 0.1, zh))))
+                    qq = rng.normal(size=4); qq /= np.linalg.norm(qq)
+                    v_ = tuple(float(x) for x in rng.uniform(-3, 3, 3)); w_ = tuple(float(x) for x in rng.uniform(-2, 2, 3))
+                    gpu[r].set_pose_vel(i, p_, tuple(qq), v_, w_); cpu[r].set_pose_vel(i, p_, tuple(qq), v_, w_)
+                else:
+                    v_ = tuple(float(x) for x in rng.uniform(-6, 6, 3)); w_ = tuple(float(x) for x in rng.uniform(-3, 3, 3))
+                    gpu[r].set_vel(i, v_, w_); cpu[r].set_vel(i, v_, w_)
         lg, lc = [], []
-        exchange(gpu, boxes, 1.5, lg)
-        exchange(cpu, boxes, 1.5, lc)
+        moved = [[[], []] for _ in range(n_tiles)]
+        exchange(cpu, boxes, 1.5, lc, moved)
+        if native:
+            tiles.NativeTiles.exchange_group(nt)
+            for r in range(n_tiles):
+                st = nt[r].stats()
+                exp = [e for e in lc if e[0] == "export" and e[1] == r][0]; imp = [e for e in lc if e[0] == "import" and e[1] == r][0]
+                assert (st.exported, st.emigrated, st.ghosts, st.immigrated) == (sum(exp[3]), exp[4], imp[2], imp[3]), (seed, s, r, "native exchange counts",
+                                                                                                                         (st.exported, st.emigrated, st.ghosts, st.immigrated), exp, imp)
+                mg = nt[r].drain_migrations()
+                assert sorted(int(m["old_id"]) for m in mg if m["direction"] == 0) == sorted(moved[r][0]), (seed, s, r, "emigrant ids")
+                assert sorted(int(m["new_id"]) for m in mg if m["direction"] == 1) == sorted(moved[r][1]), (seed, s, r, "immigrant ids")
+            lg = lc
+        else:
+            exchange(gpu, boxes, 1.5, lg)
         assert lg == lc, (seed, s, "exchange logs differ", [a for a, b in zip(lg, lc) if a != b][:3], [b for a, b in zip(lg, lc) if a != b][:3])
+        for r in range(n_tiles):
+            own[r] -= set(moved[r][0]); own[r] |= set(moved[r][1])
         migrated += sum(e[4] for e in lg if e[0] == "export")
         for r in range(n_tiles):
             gpu[r].step(DT); cpu[r].step(DT)
@@ -87,7 +135,10 @@ def run_seed(oracle, seed, steps, verbose=False):
             owned = sum(gpu[r].num_bodies() - 1 - [e for e in lg if e[0] == "import" and e[1] == r][0][2] for r in range(n_tiles))
             assert owned == total, (seed, s, "owned bodies", owned, total)
     if verbose:
-        print(f"seed {seed}: {n_tiles} tiles, {total} bodies, {migrated} migrations: ok")
+        print(f"seed {seed}: {n_tiles} tiles{' stacked in z' if grid else ''}, {'native' if native else 'python'} exchange, {total} bodies, {migrated} migrations: ok")
+    if nt:
+        for t in nt:
+            t.close()
     for w in gpu + cpu:
         w.close()
 
