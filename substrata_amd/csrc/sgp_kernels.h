@@ -31,6 +31,7 @@
 #define SGP_ISLAND_MARK_ROUNDS 3   // marking rounds before the island union-find (k_island_mark)
 #define SGP_MAX_COLOURS      64
 #define SGP_OVERFLOW_COLOUR  63
+#define SGP_COLOUR_WIDE_MIN  2048u   // a colouring round with fewer uncoloured manifolds than this runs inside k_colour_finish (one workgroup)
 
 // kernel classes for the per-kernel profile
 enum {
@@ -61,6 +62,7 @@ struct StepCounters {
 	uint32_t n_constraints;      // manifolds that became contact constraints
 	uint32_t n_points;
 	uint32_t n_hull_pairs;       // pairs with a convex hull, deferred to k_narrowphase_hull
+	uint32_t n_hull_work;        // ... of which survive the separating-axis search (work items of k_narrowphase_hull_manifold)
 	uint32_t ucount[2];          // sizes of the two uncoloured worklists (round parity)
 	uint32_t rounds_used;        // colouring rounds that found work
 	uint32_t n_colours;          // highest used colour + 1 (overflow colour excluded)
@@ -70,6 +72,7 @@ struct StepCounters {
 	uint32_t n_read_active;
 	uint32_t n_export;
 	uint32_t n_mesh_pairs;       // pairs with a static mesh, deferred to k_narrowphase_mesh
+	uint32_t round_n[32];        // uncoloured manifolds at the start of colouring round r (the host plans the next step's wide rounds from it)
 	uint32_t colour_count[SGP_MAX_COLOURS];
 	uint32_t colour_fill[SGP_MAX_COLOURS];
 };
@@ -210,6 +213,7 @@ struct DV {
 	// convex hull shapes (sgp_device_hull.h): fixed-capacity table, hull 0 = the +-1 cube template every box is a scaled copy of
 	const struct sgd_hull_s* hulls; uint32_t n_hulls;
 	uint2* hull_pairs; uint32_t cap_hull_pairs;
+	struct HullWork* hull_work;      // [cap_hull_pairs] pair + result of the axis search
 	// static triangle meshes: headers + pooled vertices / triangles / tree nodes (mesh frame = body frame)
 	const struct MeshHeader* meshes; uint32_t n_meshes;
 	const float4* mesh_verts; const uint4* mesh_tris; const uint32_t* mesh_tri_mat; const struct MeshNode* mesh_nodes;     // mesh_tri_mat: user data (material index) per tree-ordered triangle

@@ -739,8 +739,14 @@ SGP_DEV int hull_sat_search_wave(const sgd_hview* A, const sgd_hview* B, float m
 	return 1;
 }
 
-// pairs with a convex hull (hull - hull / box / sphere / capsule): one WAVE per pair.  Polytope pairs search their axes in
-// parallel; the manifold (clipping, <= 4 points) and the sphere / capsule cases run on lane 0.
+// pairs with a convex hull (hull - hull / box / sphere / capsule), in two launches:
+//   k_narrowphase_hull       one WAVE per pair: polytope pairs search their separating axes in parallel (faces of both hulls and all edge pairs
+//                            across the 64 lanes); a pair that survives, and every hull - sphere / capsule pair, becomes a work item;
+//   k_narrowphase_hull_manifold  one THREAD per work item: the manifold (reference / incident face, clipping, reduction to <= 4 points), the
+//                            sphere / capsule cases.  These are sequential by nature; with a thread per item 64 of them share a wave instead of
+//                            each idling 63 lanes of its own.
+struct HullWork { uint2 ab; sgd_hull_sat r; uint32_t round_other; };
+
 __global__ void __launch_bounds__(64) k_narrowphase_hull(DV d)
 {
 	const uint32_t n = min(d.ctr->n_hull_pairs, d.cap_hull_pairs);
@@ -749,25 +755,43 @@ __global__ void __launch_bounds__(64) k_narrowphase_hull(DV d)
 		const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
 		const sgd_shape sa = load_shape(d, ab.x, fa), sb = load_shape(d, ab.y, fb);
 		const float max_sep = d.st.speculative_contact_distance;
-		sgd_manifold m;
-		int hit;
-		const bool round_other = sa.type == SGP_SHAPE_SPHERE || sa.type == SGP_SHAPE_CAPSULE || sb.type == SGP_SHAPE_SPHERE || sb.type == SGP_SHAPE_CAPSULE;
-		if (round_other) {
-			hit = 0;
-			if (threadIdx.x == 0) hit = sgd_collide_hull(&sa, &sb, max_sep, &m);
-		} else {
+		HullWork wk; wk.ab = ab;
+		wk.round_other = (sa.type == SGP_SHAPE_SPHERE || sa.type == SGP_SHAPE_CAPSULE || sb.type == SGP_SHAPE_SPHERE || sb.type == SGP_SHAPE_CAPSULE) ? 1u : 0u;
+		int hit = 1;
+		if (!wk.round_other) {
 			// canonical order (box < hull; hull - hull keeps its order), as sgd_collide_hull
 			const bool flip = sa.type > sb.type;
 			const sgd_shape* x = flip ? &sb : &sa; const sgd_shape* y = flip ? &sa : &sb;
 			const sgd_hview hx = sgd_hull_view(x), hy = sgd_hull_view(y);
-			sgd_hull_sat r;
-			hit = hull_sat_search_wave(&hx, &hy, max_sep, &r);
-			if (hit && threadIdx.x == 0) {
-				hit = sgd_hull_manifold(&hx, &hy, max_sep, &r, &m);
-				if (hit && flip) sgd_flip_manifold(&m);
-			} else hit = 0;
+			hit = hull_sat_search_wave(&hx, &hy, max_sep, &wk.r);
+		} else memset(&wk.r, 0, sizeof(wk.r));
+		if (hit && threadIdx.x == 0) {
+			const uint32_t k = atomicAdd(&d.ctr->n_hull_work, 1u);      // (<= n_hull_pairs <= cap_hull_pairs: the list cannot overflow)
+			d.hull_work[k] = wk;
 		}
-		if (hit && threadIdx.x == 0) emit_manifold(d, ab, fa, fb, m);
+	}
+}
+
+__global__ void __launch_bounds__(64) k_narrowphase_hull_manifold(DV d)
+{
+	const uint32_t n = min(d.ctr->n_hull_work, d.cap_hull_pairs);
+	for (uint32_t k = blockIdx.x * 64 + threadIdx.x; k < n; k += gridDim.x * 64) {
+		const HullWork wk = d.hull_work[k];
+		const uint2 ab = wk.ab;
+		const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
+		const sgd_shape sa = load_shape(d, ab.x, fa), sb = load_shape(d, ab.y, fb);
+		const float max_sep = d.st.speculative_contact_distance;
+		sgd_manifold m;
+		int hit;
+		if (wk.round_other) hit = sgd_collide_hull(&sa, &sb, max_sep, &m);
+		else {
+			const bool flip = sa.type > sb.type;
+			const sgd_shape* x = flip ? &sb : &sa; const sgd_shape* y = flip ? &sa : &sb;
+			const sgd_hview hx = sgd_hull_view(x), hy = sgd_hull_view(y);
+			hit = sgd_hull_manifold(&hx, &hy, max_sep, &wk.r, &m);
+			if (hit && flip) sgd_flip_manifold(&m);
+		}
+		if (hit) emit_manifold(d, ab, fa, fb, m);
 	}
 }
 
@@ -869,7 +893,7 @@ __global__ void __launch_bounds__(TPB) k_colour_claim(DV d, uint32_t round)
 {
 	const uint32_t par = round & 1;
 	const uint32_t n = round == 0 ? min(d.ctr->n_manifolds, d.cap_manifolds) : d.ctr->ucount[par];
-	if (blockIdx.x == 0 && threadIdx.x == 0) d.ctr->ucount[par ^ 1] = 0;      // commit(round) appends to the other list
+	if (blockIdx.x == 0 && threadIdx.x == 0) { d.ctr->ucount[par ^ 1] = 0; if (round >= 1 && round < 32) d.ctr->round_n[round] = n; }      // commit(round) appends to the other list
 	const uint32_t* list = d.ulist[par];
 	unsigned long long* claim = (unsigned long long*)d.claim[par];
 	bool saw = false;
@@ -972,7 +996,7 @@ __global__ void __launch_bounds__(1024) k_colour_finish(DV d, uint32_t first_rou
 		const uint32_t n = d.ctr->ucount[par];
 		__syncthreads();
 		if (n == 0) return;
-		if (threadIdx.x == 0) { d.ctr->ucount[par ^ 1] = 0; d.ctr->rounds_used = round + 1; }
+		if (threadIdx.x == 0) { d.ctr->ucount[par ^ 1] = 0; d.ctr->rounds_used = round + 1; if (round < 32) d.ctr->round_n[round] = n; }
 		const uint32_t* list = d.ulist[par];
 		uint32_t* out = d.ulist[par ^ 1];
 		unsigned long long* claim = (unsigned long long*)d.claim[par];
@@ -2988,7 +3012,11 @@ void launch_bp_scatter(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKerne
 void launch_bp_pairs(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_bp_pairs, dim3(4096), dim3(TPB), 0, s, d); }
 void launch_bp_large(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_bp_large, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_narrowphase(const DV& d, uint32_t est, hipStream_t s) { hipLaunchKernelGGL(k_narrowphase, dim3(stride_grid(est)), dim3(TPB), 0, s, d); }
-void launch_narrowphase_hull(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_narrowphase_hull, dim3(4096), dim3(64), 0, s, d); }
+void launch_narrowphase_hull(const DV& d, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_narrowphase_hull, dim3(4096), dim3(64), 0, s, d);
+	hipLaunchKernelGGL(k_narrowphase_hull_manifold, dim3(1024), dim3(64), 0, s, d);
+}
 void launch_narrowphase_mesh(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_narrowphase_mesh, dim3(1024), dim3(64), 0, s, d); }
 void launch_colour_inherit(const DV& d, uint32_t est, hipStream_t s) { hipLaunchKernelGGL(k_colour_inherit, dim3(stride_grid(est)), dim3(TPB), 0, s, d); }
 void launch_colour_claim(const DV& d, uint32_t est, uint32_t round, hipStream_t s)

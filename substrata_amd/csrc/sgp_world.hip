@@ -116,6 +116,7 @@ struct sgp_world {
 	sgp_step_stats stats;
 	uint32_t last_pairs = 0, last_manifolds = 0, n_con = 0;
 	uint32_t plan_rounds = 12;                               // launch plan for the next step (from the last step's counters)
+	uint32_t plan_round_n[32] = { 0, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u };      // uncoloured manifolds at the start of each round of the last step (no history yet: eight wide rounds)
 	uint32_t plan_colour_count[SGP_MAX_COLOURS] = { 0 };
 	uint32_t table_alloc = 0, ht_alloc = 0;
 	// profiling
@@ -286,6 +287,7 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	{ void* q = nullptr; w->cap_hull_table = 64; HIP_TRY(hipMalloc(&q, sizeof(sgd_hull) * w->cap_hull_table)); HIP_TRY(hipMemsetAsync(q, 0, sizeof(sgd_hull) * w->cap_hull_table, w->stream)); w->d_hulls = (sgd_hull*)q; w->device_bytes += sizeof(sgd_hull) * w->cap_hull_table; }
 	d.hulls = w->d_hulls;
 	d.cap_hull_pairs = P / 4 + 1024; DEV_ALLOC(d.hull_pairs, d.cap_hull_pairs);
+	{ void* hw = nullptr; const size_t bytes = (size_t)d.cap_hull_pairs * 64; HIP_TRY(hipMalloc(&hw, bytes)); w->allocs.push_back(hw); w->device_bytes += bytes; d.hull_work = (HullWork*)hw; }      // sizeof(HullWork) = 56
 	{
 		sgd_hull cube; sgd_hull_cube_template(&cube);
 		w->hulls.push_back(cube); w->hull_refs.push_back(1);      // (the cube template is never destroyed)
@@ -942,7 +944,15 @@ static void make_plan(const sgp_world* w, StepPlan& p)
 {
 	memset(&p, 0, sizeof(p));
 	p.nb = bucket_up(w->high);
-	p.rounds = ((std::max(w->plan_rounds + 3u, 6u) + 3u) / 4u) * 4u;
+	// colouring: a round gets launches of its own (claim + commit over the whole chip) while the previous step still had more than a
+	// workgroup's worth of uncoloured manifolds at its start; the remaining rounds -- typically a few hundred manifolds, then a few dozen --
+	// run inside the single-workgroup k_colour_finish, which also catches whatever a short plan leaves over
+	{
+		uint32_t r = 1;
+		while (r < 16u && r < w->plan_rounds && w->plan_round_n[r] > SGP_COLOUR_WIDE_MIN) ++r;
+		static const uint32_t steps[] = { 1, 2, 3, 4, 6, 8, 12, 16 };
+		p.rounds = 16; for (uint32_t k : steps) if (k >= r) { p.rounds = k; break; }
+	}
 	p.est_pairs = bucket_up(std::max(w->last_pairs + w->last_pairs / 8, 4u * w->high));
 	p.est_man = bucket_up(std::max(w->last_manifolds + w->last_manifolds / 8, 2u * w->high));
 	int tf = 0;
@@ -1105,6 +1115,7 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	w->n_con = n_con;
 	w->last_pairs = c1.n_pairs; w->last_manifolds = c1.n_manifolds;
 	w->plan_rounds = c1.rounds_used;
+	memcpy(w->plan_round_n, c1.round_n, sizeof(w->plan_round_n));
 	for (int c = 0; c < SGP_MAX_COLOURS; ++c) w->plan_colour_count[c] = c1.colour_count[c];
 	sgp_step_stats& st = w->stats;
 	memset(&st, 0, sizeof(st));
@@ -1128,7 +1139,12 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	if (timing) {
 		const double tt3 = now();
 		t_acc[0] += tt1 - tt0; t_acc[1] += tt2 - tt1; t_acc[2] += tt3 - tt2; t_n++;
-		if (t_n == 500) { fprintf(stderr, "[sgp timing] enqueue %.1f us  sync wait %.1f us  post %.1f us\n", t_acc[0] / t_n, t_acc[1] / t_n, t_acc[2] / t_n); t_acc[0] = t_acc[1] = t_acc[2] = 0; t_n = 0; }
+		if (t_n == 500 || t_n == 100) {
+			fprintf(stderr, "[sgp timing] enqueue %.1f us  sync wait %.1f us  post %.1f us; colouring: %u rounds used, %u planned wide, uncoloured at round start:", t_acc[0] / t_n, t_acc[1] / t_n, t_acc[2] / t_n, c1.rounds_used, plan.rounds);
+			for (uint32_t r = 1; r < std::min(c1.rounds_used + 1u, 32u); ++r) fprintf(stderr, " %u", c1.round_n[r]);
+			fprintf(stderr, "\n");
+			if (t_n == 500) { t_acc[0] = t_acc[1] = t_acc[2] = 0; t_n = 0; }
+		}
 	}
 	return SGP_OK;
 }
