@@ -89,6 +89,10 @@ typedef struct sgp_settings {
 	float   max_angular_velocity;            /* 0.25*pi*60 */
 	int32_t allow_sleeping;                  /* 1    */
 	int32_t warm_start;                      /* 1    */
+	/* the body-pair contact cache: a pair whose relative pose moved less than this since its manifold was last computed reuses the manifold */
+	int32_t use_body_pair_contact_cache;                 /* 1                  */
+	float   body_pair_cache_max_delta_position_sq;       /* 0.001^2            */
+	float   body_pair_cache_cos_max_delta_rotation_div2; /* cos(2 deg / 2)     */
 } sgp_settings;
 
 typedef struct sgp_world_desc {
@@ -198,6 +202,8 @@ typedef struct sgp_step_stats {
 	uint32_t num_activated;      /* activation / deactivation events raised since the end of the previous step */
 	uint32_t num_deactivated;
 	uint32_t layer_counts[SGP_NUM_LAYERS];
+	uint32_t num_cached_manifolds;       /* manifolds taken from the body-pair contact cache instead of a collision test */
+	uint32_t reserved_;
 	uint64_t device_bytes;
 } sgp_step_stats;
 

@@ -64,6 +64,7 @@ typedef struct {
 	uint64_t colour_mask; uint64_t claim[2];
 	int movable_prev, movable_cur;   /* movable (dynamic and awake) when the previous / this step coloured its constraints */
 	int island; int can_sleep;
+	int cache_invalid;               /* created or reshaped since the last step: its pairs do not reuse cached manifolds (Body::InvalidateContactCache) */
 } sgo_body;
 
 typedef struct {
@@ -82,6 +83,9 @@ typedef struct {
 	int np;
 	int colour;
 	int persisted;
+	/* body-pair contact cache (ContactConstraintManager::GetContactsFromCache): pose of body 2 relative to body 1 and the normal in body 2's
+	   frame WHEN THE MANIFOLD WAS COMPUTED; a reused manifold keeps them, so slow drift ends the reuse */
+	v3 dpos; quat drot; v3 nloc2; int reused;
 	sgo_point pt[4];
 } sgo_constraint;
 
@@ -149,6 +153,9 @@ SGO_API void sgo_default_settings(sgp_settings* s)
 	s->max_angular_velocity = 0.25f * 3.14159265358979323846f * 60.0f; /* BodyCreationSettings::mMaxAngularVelocity  UNVERIFIED: upstream */
 	s->allow_sleeping = 1;                                           /* mAllowSleeping                UNVERIFIED: upstream */
 	s->warm_start = 1;                                               /* mConstraintWarmStart          UNVERIFIED: upstream */
+	s->use_body_pair_contact_cache = 1;                              /* mUseBodyPairContactCache      UNVERIFIED: upstream */
+	s->body_pair_cache_max_delta_position_sq = 0.001f * 0.001f;      /* mBodyPairCacheMaxDeltaPositionSq         UNVERIFIED: upstream */
+	s->body_pair_cache_cos_max_delta_rotation_div2 = 0.99984769515639123915701155881391f;   /* mBodyPairCacheCosMaxDeltaRotationDiv2 = cos(2 deg / 2)   UNVERIFIED: upstream */
 }
 
 SGO_API void sgo_default_world_desc(sgp_world_desc* d)
@@ -453,6 +460,7 @@ SGO_API int sgo_body_add(sgo_world* w, const sgp_body_desc* d, uint32_t* id_out)
 	b->gravity_factor = d->gravity_factor;
 	b->lin_damp = d->linear_damping; b->ang_damp = d->angular_damping;
 	b->is_sensor = d->is_sensor; b->allow_sleep = d->allow_sleeping; b->zero_lin_drag = d->use_zero_linear_drag;
+	b->cache_invalid = 1;
 	b->userdata = d->userdata;
 	if (b->motion == SGP_MOTION_DYNAMIC) mass_properties(b->shape_type, b->shape, b->hull, b->mass, &b->inv_mass, &b->inv_inertia);
 	else { b->inv_mass = 0.0f; b->inv_inertia = V3(0.0f, 0.0f, 0.0f); }
@@ -627,7 +635,7 @@ SGO_API int sgo_body_set_pose_shape(sgo_world* w, uint32_t id, const float pos[3
 	b->pos = V3(pos[0], pos[1], pos[2]);
 	quat q = { rot[0], rot[1], rot[2], rot[3] }; b->rot = q;
 	b->linv = V3(0, 0, 0); b->angv = V3(0, 0, 0);
-	if (b->shape_type != SGP_SHAPE_HULL && b->shape_type != SGP_SHAPE_MESH) memcpy(b->shape, shape, sizeof(b->shape));   /* inUpdateMassProperties = false, PhysicsWorld.cpp:579; hulls and meshes are pre-scaled */
+	if (b->shape_type != SGP_SHAPE_HULL && b->shape_type != SGP_SHAPE_MESH) { memcpy(b->shape, shape, sizeof(b->shape)); b->cache_invalid = 1; }   /* inUpdateMassProperties = false, PhysicsWorld.cpp:579; hulls and meshes are pre-scaled */
 	body_update_aabb(b);
 	sync_mesh_aliases(w, id);
 	body_activate(w, id);
@@ -897,6 +905,39 @@ static void emit_contact_event(sgo_world* w, const sgo_constraint* c, const sgo_
 	else PUSH_EVENT(w->ev_added, w->n_added, w->cap_added, sgp_contact_event, e);
 }
 
+/* pose of body 2 relative to body 1: centre of mass offset in body 1's frame, conj(q1) * q2 */
+static void pair_relative_pose(const sgo_body* A, const sgo_body* B, v3* dpos, quat* drot)
+{
+	*dpos = m33_tmul(quat_to_m33(A->rot), v3_sub(B->pos, A->pos));
+	const quat ca = { -A->rot.x, -A->rot.y, -A->rot.z, A->rot.w };
+	*drot = quat_mul(ca, B->rot);
+}
+
+/* ContactConstraintManager::GetContactsFromCache for one pair of non-mesh bodies: 1 = *m is last step's manifold carried to the bodies'
+   current poses.  (Jolt also caches pairs WITHOUT contacts and skips their collision test; here only pairs that had a manifold are cached.
+   Sensor pairs are always re-tested: their cached entry holds no points.)   UNVERIFIED: upstream */
+static int reuse_cached_manifold(const sgo_world* w, uint32_t a, uint32_t b, sgo_manifold* m)
+{
+	if (!w->st.use_body_pair_contact_cache) return 0;
+	const sgo_body* A = &w->bodies[a]; const sgo_body* B = &w->bodies[b];
+	if (A->cache_invalid || B->cache_invalid || A->is_sensor || B->is_sensor) return 0;
+	/* polytope pairs only (box / hull against box / hull): a deviation from Jolt, which caches every pair -- a sphere or capsule contact is
+	   recomputed every step (cheap, and the same answer); see DESIGN.md */
+	if (!((A->shape_type == SGP_SHAPE_BOX || A->shape_type == SGP_SHAPE_HULL) && (B->shape_type == SGP_SHAPE_BOX || B->shape_type == SGP_SHAPE_HULL))) return 0;
+	const sgo_constraint* pc = find_prev(w, ((uint64_t)a << 32) | b);
+	if (!pc) return 0;
+	v3 dpos; quat drot;
+	pair_relative_pose(A, B, &dpos, &drot);
+	if (!(v3_len_sq(v3_sub(dpos, pc->dpos)) <= w->st.body_pair_cache_max_delta_position_sq)) return 0;
+	const float dq = drot.x * pc->drot.x + drot.y * pc->drot.y + drot.z * pc->drot.z + drot.w * pc->drot.w;
+	if (!(fabsf(dq) >= w->st.body_pair_cache_cos_max_delta_rotation_div2)) return 0;
+	const m33 RA = quat_to_m33(A->rot), RB = quat_to_m33(B->rot);
+	m->np = pc->np;
+	m->n = m33_mul(RB, pc->nloc2);
+	for (int i = 0; i < pc->np; ++i) { m->p1[i] = v3_add(A->pos, m33_mul(RA, pc->pt[i].local1)); m->p2[i] = v3_add(B->pos, m33_mul(RB, pc->pt[i].local2)); }
+	return 1;
+}
+
 /* Constraint properties of manifold k (TemplatedAddContactConstraint); returns 0 for sensor pairs. Same arithmetic as the loop in find_contacts. */
 static int setup_constraint(sgo_world* w, uint32_t k, const sgo_manifold* m, float dt, uint32_t* npts)
 {
@@ -916,11 +957,14 @@ static int setup_constraint(sgo_world* w, uint32_t k, const sgo_manifold* m, flo
 	const float restitution = fmaxf(A->restitution, B->restitution);    /* ... and the larger restitution                                UNVERIFIED: upstream */
 	c.t1 = v3_normalized_perpendicular(c.n);
 	c.t2 = v3_cross(c.n, c.t1);
+	if (c.reused && pc) { c.dpos = pc->dpos; c.drot = pc->drot; c.nloc2 = pc->nloc2; }
+	else { c.reused = 0; pair_relative_pose(A, B, &c.dpos, &c.drot); c.nloc2 = m33_tmul(RB, c.n); }
 	for (int i = 0; i < c.np; ++i) {
 		sgo_point* pt = &c.pt[i];
 		const v3 p1 = m->p1[i], p2 = m->p2[i];
 		pt->local1 = m33_tmul(RA, v3_sub(p1, A->pos));
 		pt->local2 = m33_tmul(RB, v3_sub(p2, B->pos));
+		if (c.reused) { pt->local1 = pc->pt[i].local1; pt->local2 = pc->pt[i].local2; }      /* the cached body-space points themselves: no drift from re-deriving them */
 		pt->lam_n = pt->lam_t1 = pt->lam_t2 = 0.0f;
 		if (pc && w->st.warm_start) {
 			for (int j = 0; j < pc->np; ++j) {
@@ -972,6 +1016,7 @@ static void find_contacts(sgo_world* w, float dt)
 	}
 	sgo_manifold* mans = (sgo_manifold*)malloc(sizeof(sgo_manifold) * (w->n_pairs ? 3 * w->n_pairs : 1));
 	unsigned char* hit = (unsigned char*)malloc(w->n_pairs ? w->n_pairs : 1);
+	unsigned char* reused = (unsigned char*)calloc(w->n_pairs ? w->n_pairs : 1, 1);
 	#pragma omp parallel for schedule(static, 256) if (g_threads > 1)
 	for (uint32_t p = 0; p < w->n_pairs; ++p) {
 		const uint32_t a = w->pairs[p].a, b = w->pairs[p].b;
@@ -984,6 +1029,10 @@ static void find_contacts(sgo_world* w, float dt)
 			hit[p] = (unsigned char)collide_with_mesh(M, &sx, X->aabb_min, X->aabb_max, w->st.speculative_contact_distance, &mans[3 * p]);
 			continue;
 		}
+		/* the body-pair contact cache: both bodies where they were (relative to each other) when the cached manifold was computed ->
+		   the manifold is rebuilt from its body-space points instead of running the collision test */
+		reused[p] = 0;
+		if (reuse_cached_manifold(w, a, b, &mans[3 * p])) { hit[p] = 1; reused[p] = 1; continue; }
 		const sgo_shape sa = body_shape_xf(A), sb = body_shape_xf(B);
 		hit[p] = (unsigned char)sgo_collide(&sa, &sb, w->st.speculative_contact_distance, &mans[3 * p]);
 	}
@@ -1002,11 +1051,11 @@ static void find_contacts(sgo_world* w, float dt)
 			sgo_constraint* c = &w->cons[nm];
 			memset(c, 0, sizeof(*c));
 			c->a = a; c->b = b; c->key = ((uint64_t)a << 32) | b; c->prio = sgp_mix64(c->key);
-			c->np = m.np; c->n = m.n;
+			c->np = m.np; c->n = m.n; c->reused = reused[p];
 			mans[nm++] = m;           /* (nm <= 3 p + g: compaction never overtakes the read position) */
 		}
 	}
-	free(hit);
+	free(hit); free(reused);
 	w->n_cons = nm;
 	for (uint32_t k = 0; k < nm; ++k) {
 		sgo_body* A = &w->bodies[w->cons[k].a]; sgo_body* B = &w->bodies[w->cons[k].b];
@@ -1890,6 +1939,8 @@ SGO_API int sgo_world_step(sgo_world* w, float dt)
 	for (uint32_t i = 0; i < w->high; ++i) { sgo_body* b = &w->bodies[i]; if (b->alive && b->active) body_update_aabb(b); }
 	update_sleeping(w, dt);
 
+	for (uint32_t i = 0; i < w->high; ++i) w->bodies[i].cache_invalid = 0;      /* every live body has now been through a step with its present shape */
+
 	nan_trace(w, "8 bounds, sleeping");
 	/* 9. buoyancy (Substrata's own sweep after Update) */
 	if (w->water_enabled) buoyancy_sweep(w, dt);
@@ -1921,6 +1972,7 @@ SGO_API int sgo_world_step(sgo_world* w, float dt)
 	w->stats.num_manifolds = w->n_prev;
 	w->stats.num_colours = (uint32_t)nreg;      /* regular colours only, like the device's colour table; the overflow colour is num_overflow_constraints */
 	w->stats.num_overflow_constraints = novf;
+	{ uint32_t nr = 0; for (uint32_t k = 0; k < w->n_prev; ++k) nr += (uint32_t)w->prev[k].reused; w->stats.num_cached_manifolds = nr; }
 	/* activation events raised since the end of the previous step (edits between steps included) */
 	w->stats.num_activated = (uint32_t)(w->tot_act - w->rep_act); w->rep_act = w->tot_act;
 	w->stats.num_deactivated = (uint32_t)(w->tot_deact - w->rep_deact); w->rep_deact = w->tot_deact;

@@ -30,7 +30,8 @@ class Settings(C.Structure):
                 ("min_velocity_for_restitution", f32), ("max_penetration_distance", f32),
                 ("time_before_sleep", f32), ("point_velocity_sleep_threshold", f32),
                 ("contact_point_preserve_lambda_max_dist_sq", f32), ("max_linear_velocity", f32),
-                ("max_angular_velocity", f32), ("allow_sleeping", i32), ("warm_start", i32)]
+                ("max_angular_velocity", f32), ("allow_sleeping", i32), ("warm_start", i32), ("use_body_pair_contact_cache", i32),
+                ("body_pair_cache_max_delta_position_sq", f32), ("body_pair_cache_cos_max_delta_rotation_div2", f32)]
 
 
 class WorldDesc(C.Structure):
@@ -81,7 +82,7 @@ class StepStats(C.Structure):
                 ("num_contact_points", u32), ("num_colours", u32), ("num_colour_rounds", u32),
                 ("num_overflow_constraints", u32), ("pairs_dropped", u32), ("manifolds_dropped", u32),
                 ("num_activated", u32), ("num_deactivated", u32), ("layer_counts", u32 * NUM_LAYERS),
-                ("device_bytes", u64)]
+                ("num_cached_manifolds", u32), ("reserved_", u32), ("device_bytes", u64)]
 
 
 NUM_KERNEL_CLASSES = 32

@@ -19,6 +19,7 @@
 #define BF_LARGE         (1u << 9)   // skips the hashed grid (ground quad etc.)
 #define BF_UNDERWATER    (1u << 10)
 #define BF_GHOST         (1u << 11)  // owned by another tile (multi-GPU), simulated as velocity-driven
+#define BF_CACHE_INVALID (1u << 12)  // created or reshaped since the last step: its pairs do not reuse cached manifolds (cleared by k_pre_solve)
 #define BF_SHAPE_SHIFT   18          // SGP_SHAPE_* (3 bits)
 #define BF_SHAPE_MASK    (0x7u << BF_SHAPE_SHIFT)
 #define BF_ALIAS         (1u << 21)  // second / third slot of a static mesh body: carries contact manifolds only (never binned, never queried)
@@ -31,6 +32,8 @@
 #define SGP_ISLAND_MARK_ROUNDS 3   // marking rounds before the island union-find (k_island_mark)
 #define SGP_MAX_COLOURS      64
 #define SGP_OVERFLOW_COLOUR  63
+#define MAN_PREV_NONE   0x7FFFFFFFu
+#define MAN_PREV_REUSED 0x80000000u
 #define SGP_COLOUR_WIDE_MIN  2048u   // a colouring round with fewer uncoloured manifolds than this runs inside k_colour_finish (one workgroup)
 
 // kernel classes for the per-kernel profile
@@ -62,6 +65,7 @@ struct StepCounters {
 	uint32_t n_constraints;      // manifolds that became contact constraints
 	uint32_t n_points;
 	uint32_t n_hull_pairs;       // pairs with a convex hull, deferred to k_narrowphase_hull
+	uint32_t n_cached;           // manifolds taken from the body-pair contact cache
 	uint32_t n_hull_work;        // ... of which survive the separating-axis search (work items of k_narrowphase_hull_manifold)
 	uint32_t ucount[2];          // sizes of the two uncoloured worklists (round parity)
 	uint32_t rounds_used;        // colouring rounds that found work
@@ -148,6 +152,10 @@ struct ConstraintArrays {
 	float2*   efft[4];     // eff_t1, eff_t2
 	float4*   loc1[4];     // contact point in body-1 frame
 	float4*   loc2[4];     // contact point in body-2 frame
+	// body-pair contact cache: pose of body 2 relative to body 1 and the normal in body 2's frame WHEN THE MANIFOLD WAS COMPUTED
+	float4*   cdp;         // relative position (in body 1's frame) xyz, normal-in-2 x
+	float4*   cdr;         // relative rotation conj(q1) * q2
+	float2*   cnl;         // normal-in-2 y, z
 };
 
 struct DV {
@@ -198,6 +206,8 @@ struct DV {
 	int32_t*  man_colour;      // -1 uncoloured, -2 not a constraint (sensor)
 	uint32_t* ulist[2];        // worklists of still-uncoloured manifolds, double buffered by round parity
 	uint64_t* man_prio;
+	uint32_t* man_prev;        // slot of the same pair's constraint in the previous step's buffer (MAN_PREV_NONE if none), bit 31: the manifold was
+	                           // taken from the body-pair contact cache (k_narrowphase) -- one hash look-up per manifold, shared by every later kernel
 	// constraints
 	uint32_t dbg_flags;        // SGP_DEBUG_FLAGS (developer switches): bit 0 = tail kernel without its register-resident path
 	float4* rows;              // velocity-iteration rows, [point 0..3][axis n,t1,t2][4][cap_manifolds] (k_setup): r1 x axis (w: bias for n),

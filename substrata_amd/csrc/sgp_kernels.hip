@@ -345,9 +345,10 @@ SGP_DEV bool rec_pair_passes(float spec, float4 mni, float4 mxi, float4 mnj, flo
 	return true;
 }
 
+SGP_DEV uint32_t wave_alloc(uint32_t* counter);
 SGP_DEV void push_pair(const DV& d, uint32_t i, uint32_t j)
 {
-	const uint32_t k = atomicAdd(&d.ctr->n_pairs, 1u);
+	const uint32_t k = wave_alloc(&d.ctr->n_pairs);      // (one atomic per wave: the ground quad alone pairs with every body)
 	if (k < d.cap_pairs) d.pairs[k] = make_uint2(i < j ? i : j, i < j ? j : i);
 	else atomicAdd(&d.ctr->pairs_dropped, 1u);
 }
@@ -552,10 +553,25 @@ SGP_DEV sgd_shape load_shape(const DV& d, uint32_t i, uint32_t f)
 	return s;
 }
 
-SGP_DEV void emit_manifold(const DV& d, uint2 ab, uint32_t fa, uint32_t fb, const sgd_manifold& m)
+SGP_DEV uint32_t cache_find(const DV& d, uint64_t key);
+#define MAN_PREV_LOOKUP 0xFFFFFFFFu
+// Every lane that calls this (the lanes active at the call) gets its own index from *counter: one atomic per wave instead of one per lane
+// (hundreds of thousands of atomics on ONE address serialise in L2: that, not the collision arithmetic, bounded the narrow phase).
+SGP_DEV uint32_t wave_alloc(uint32_t* counter)
+{
+	const unsigned long long act = __ballot(1);
+	const int lane = (int)(threadIdx.x & 63u), leader = __ffsll((long long)act) - 1;
+	uint32_t base = 0;
+	if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(act));
+	base = __shfl(base, leader, 64);
+	return base + (uint32_t)__popcll(act & ((1ull << lane) - 1ull));
+}
+// prev: the pair's slot in the previous step's constraint buffer if the caller already looked it up (| MAN_PREV_REUSED for a manifold taken
+// from the contact cache), MAN_PREV_LOOKUP to leave the look-up to k_colour_inherit
+SGP_DEV void emit_manifold(const DV& d, uint2 ab, uint32_t fa, uint32_t fb, const sgd_manifold& m, uint32_t prev = MAN_PREV_LOOKUP)
 {
 	if (!(v3_len_sq(m.n) > 0.25f)) return;          // safety net: a manifold without a direction (or with a NaN one) is dropped, never solved
-	const uint32_t slot = atomicAdd(&d.ctr->n_manifolds, 1u);
+	const uint32_t slot = wave_alloc(&d.ctr->n_manifolds);
 	if (slot >= d.cap_manifolds) { atomicAdd(&d.ctr->manifolds_dropped, 1u); return; }
 	d.man_ab[slot] = ab;
 	const bool sensor = (fa | fb) & BF_SENSOR;
@@ -564,12 +580,47 @@ SGP_DEV void emit_manifold(const DV& d, uint2 ab, uint32_t fa, uint32_t fb, cons
 	d.man_n[slot] = make_float4(m.n.x, m.n.y, m.n.z, __int_as_float(m.np | (sensor ? 0x100 : 0)));
 	for (int k = 0; k < 4; ++k) if (k < m.np) { d.man_p1[k][slot] = F4(m.p1[k], 0.0f); d.man_p2[k][slot] = F4(m.p2[k], 0.0f); }
 	d.man_prio[slot] = sgp_mix64(((uint64_t)ab.x << 32) | ab.y);
+	d.man_prev[slot] = prev;          // (MAN_PREV_LOOKUP: k_colour_inherit -- a light kernel that hides the hash probe's latency -- resolves it)
 	d.man_colour[slot] = -1;
 	if (!sensor) {
 		const bool actA = f_active_for_pairs(fa), actB = f_active_for_pairs(fb);
 		if (actA && !actB && f_motion(fb) == SGP_MOTION_DYNAMIC) atomicOr(&d.flags[ab.y], BF_WAKE);
 		if (actB && !actA && f_motion(fa) == SGP_MOTION_DYNAMIC) atomicOr(&d.flags[ab.x], BF_WAKE);
 	}
+}
+
+// pose of body 2 relative to body 1: centre of mass offset in body 1's frame, conj(q1) * q2
+SGP_DEV void pair_relative_pose(v3 posA, quat qA, v3 posB, quat qB, v3* dpos, quat* drot)
+{
+	*dpos = m33_tmul(quat_to_m33(qA), v3_sub(posB, posA));
+	quat ca; ca.x = -qA.x; ca.y = -qA.y; ca.z = -qA.z; ca.w = qA.w;
+	*drot = quat_mul(ca, qB);
+}
+
+// The body-pair contact cache (ContactConstraintManager::GetContactsFromCache) for one pair of non-mesh bodies: true = *m is last step's
+// manifold carried to the bodies' current poses -- the two bodies sit, relative to each other, where they sat when it was computed (within
+// 1 mm and 2 degrees), so the collision test is skipped.  *prev: the pair's slot in last step's constraints (MAN_PREV_NONE if it had none),
+// found with the one hash look-up every later kernel shares.
+SGP_DEV bool reuse_cached_manifold(const DV& d, uint2 ab, uint32_t fa, uint32_t fb, sgd_manifold* m, uint32_t* prev)
+{
+	const uint32_t ps = cache_find(d, ((uint64_t)ab.x << 32) | ab.y);
+	*prev = ps == 0xFFFFFFFFu ? MAN_PREV_NONE : ps;
+	if (ps == 0xFFFFFFFFu || !d.st.use_body_pair_contact_cache || ((fa | fb) & (BF_CACHE_INVALID | BF_SENSOR))) return false;
+	const v3 posA = V3(d.pos_im[ab.x]), posB = V3(d.pos_im[ab.y]);
+	const quat qA = Q4(d.rot[ab.x]), qB = Q4(d.rot[ab.y]);
+	v3 dpos; quat drot;
+	pair_relative_pose(posA, qA, posB, qB, &dpos, &drot);
+	const float4 cdp = PRV(d).cdp[ps], cdr = PRV(d).cdr[ps];
+	if (!(v3_len_sq(v3_sub(dpos, V3(cdp))) <= d.st.body_pair_cache_max_delta_position_sq)) return false;
+	const float dq = drot.x * cdr.x + drot.y * cdr.y + drot.z * cdr.z + drot.w * cdr.w;
+	if (!(fabsf(dq) >= d.st.body_pair_cache_cos_max_delta_rotation_div2)) return false;
+	const m33 RA = quat_to_m33(qA), RB = quat_to_m33(qB);
+	const float2 cnl = PRV(d).cnl[ps];
+	m->np = PRV(d).np_col[ps] & 0xFF;
+	m->n = m33_mul(RB, V3(cdp.w, cnl.x, cnl.y));
+	for (int i = 0; i < 4; ++i) if (i < m->np) { m->p1[i] = v3_add(posA, m33_mul(RA, V3(PRV(d).loc1[i][ps]))); m->p2[i] = v3_add(posB, m33_mul(RB, V3(PRV(d).loc2[i][ps]))); }
+	*prev = ps | MAN_PREV_REUSED;
+	return true;
 }
 
 __global__ void __launch_bounds__(TPB) k_narrowphase(DV d)
@@ -579,21 +630,27 @@ __global__ void __launch_bounds__(TPB) k_narrowphase(DV d)
 		const uint2 ab = d.pairs[p];
 		const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
 		if (f_shape(fa) == SGP_SHAPE_MESH || f_shape(fb) == SGP_SHAPE_MESH) {
-			const uint32_t k = atomicAdd(&d.ctr->n_mesh_pairs, 1u);
+			const uint32_t k = wave_alloc(&d.ctr->n_mesh_pairs);
 			if (k < d.cap_mesh_pairs) d.mesh_pairs[k] = ab; else atomicAdd(&d.ctr->pairs_dropped, 1u);
 			continue;
 		}
+		sgd_manifold m;
+		uint32_t prev = MAN_PREV_LOOKUP;
+		// the contact cache is consulted for polytope pairs only (box / hull against box / hull): their separating-axis test and clipping cost
+		// more than the gather of a cached manifold, and they are the pairs whose resting contacts a frozen manifold keeps from jittering; a
+		// sphere or capsule contact is recomputed (a few dozen instructions, the same answer every step)
+		const bool polytopes = (f_shape(fa) == SGP_SHAPE_BOX || f_shape(fa) == SGP_SHAPE_HULL) && (f_shape(fb) == SGP_SHAPE_BOX || f_shape(fb) == SGP_SHAPE_HULL);
+		if (polytopes && reuse_cached_manifold(d, ab, fa, fb, &m, &prev)) { emit_manifold(d, ab, fa, fb, m, prev); continue; }
 		if (f_shape(fa) == SGP_SHAPE_HULL || f_shape(fb) == SGP_SHAPE_HULL) {
 			// the polytope paths (clip buffers in scratch, long loops) live in their own kernel so that they do not cost the
 			// sphere / box / capsule pairs registers or scratch
-			const uint32_t k = atomicAdd(&d.ctr->n_hull_pairs, 1u);
+			const uint32_t k = wave_alloc(&d.ctr->n_hull_pairs);
 			if (k < d.cap_hull_pairs) d.hull_pairs[k] = ab; else atomicAdd(&d.ctr->pairs_dropped, 1u);
 			continue;
 		}
 		const sgd_shape sa = load_shape(d, ab.x, fa), sb = load_shape(d, ab.y, fb);
-		sgd_manifold m;
 		if (!sgd_collide(&sa, &sb, d.st.speculative_contact_distance, &m)) continue;
-		emit_manifold(d, ab, fa, fb, m);
+		emit_manifold(d, ab, fa, fb, m, prev);
 	}
 }
 
@@ -852,7 +909,7 @@ __global__ void __launch_bounds__(TPB) k_pre_solve(DV d)
 	}
 	d.sbody[4 * i + 0] = v; d.sbody[4 * i + 1] = w; d.sbody[4 * i + 2] = a; d.sbody[4 * i + 3] = b;
 	// remember whether the body was movable when the previous step coloured its constraints (colour inheritance)
-	uint32_t nf = f & ~(BF_MOVABLE_PREV | BF_MOVABLE_CUR);
+	uint32_t nf = f & ~(BF_MOVABLE_PREV | BF_MOVABLE_CUR | BF_CACHE_INVALID);      // (the narrow phase of this step has seen the flag)
 	if (f & BF_MOVABLE_CUR) nf |= BF_MOVABLE_PREV;
 	if (f_movable(f)) nf |= BF_MOVABLE_CUR;
 	if (nf != f0) d.flags[i] = nf;
@@ -872,10 +929,13 @@ __global__ void __launch_bounds__(TPB) k_colour_inherit(DV d)
 {
 	const uint32_t n = min(d.ctr->n_manifolds, d.cap_manifolds);
 	for (uint32_t m = blockIdx.x * TPB + threadIdx.x; m < n; m += gridDim.x * TPB) {
-		if (d.man_colour[m] != -1) continue;
 		const uint2 ab = d.man_ab[m];
-		const uint32_t ps = cache_find(d, ((uint64_t)ab.x << 32) | ab.y);
-		if (ps == 0xFFFFFFFFu) continue;
+		// the one hash probe per manifold (unless the narrow phase already made it for a contact-cache attempt): every later kernel reads man_prev
+		uint32_t mp = d.man_prev[m];
+		if (mp == MAN_PREV_LOOKUP) { const uint32_t f = cache_find(d, ((uint64_t)ab.x << 32) | ab.y); mp = f == 0xFFFFFFFFu ? MAN_PREV_NONE : f; d.man_prev[m] = mp; }
+		if (d.man_colour[m] != -1) continue;
+		const uint32_t ps = mp & ~MAN_PREV_REUSED;
+		if (ps == MAN_PREV_NONE) continue;
 		const int pc = (PRV(d).np_col[ps] >> 8) & 0xFF;
 		if (pc >= SGP_OVERFLOW_COLOUR) continue;
 		const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
@@ -1111,6 +1171,12 @@ __global__ void __launch_bounds__(TPB) k_setup(DV d)
 		__syncthreads();
 		if (threadIdx.x < SGP_MAX_COLOURS && hist[threadIdx.x]) base[threadIdx.x] = atomicAdd(&d.ctr->colour_fill[threadIdx.x], hist[threadIdx.x]);
 		__syncthreads();
+		{
+			// statistics: constraints whose manifold came from the body-pair contact cache (one atomic per wave)
+			const bool ru = col >= 0 && (d.man_prev[m] & MAN_PREV_REUSED);
+			const unsigned long long bm = __ballot(ru);
+			if (bm && (threadIdx.x & 63) == 0) atomicAdd(&d.ctr->n_cached, (uint32_t)__popcll(bm));
+		}
 		if (col < 0) continue;
 		const uint32_t slot = d.cstarts[col] + base[col] + rank;
 		const uint2 ab = d.man_ab[m];
@@ -1132,7 +1198,9 @@ __global__ void __launch_bounds__(TPB) k_setup(DV d)
 		const v3 t1 = v3_normalized_perpendicular(nrm);
 		const v3 t2 = v3_cross(nrm, t1);
 		const v3 lvA = V3(va4), avA = V3(wa4), lvB = V3(vb4), avB = V3(wb4);
-		const uint32_t fslot = cache_find(d, key);
+		const uint32_t mprev = d.man_prev[m];
+		const bool reused = mprev & MAN_PREV_REUSED;                 // the manifold came from the body-pair contact cache
+		const uint32_t fslot = (mprev & ~MAN_PREV_REUSED) == MAN_PREV_NONE ? 0xFFFFFFFFu : (mprev & ~MAN_PREV_REUSED);
 		const uint32_t pslot = d.st.warm_start ? fslot : 0xFFFFFFFFu;
 		int pnp = 0;
 		if (pslot != 0xFFFFFFFFu) pnp = PRV(d).np_col[pslot] & 0xFF;
@@ -1147,11 +1215,23 @@ __global__ void __launch_bounds__(TPB) k_setup(DV d)
 		CUR(d).n_fric[slot] = F4(nrm, friction);
 		CUR(d).key[slot] = key;
 		CUR(d).np_col[slot] = np | (col << 8) | ((fslot != 0xFFFFFFFFu ? 1 : 0) << 16);
+		// body-pair contact cache: a fresh manifold records where the bodies are relative to each other now; a reused one keeps the record of
+		// the step its points were computed in (slow drift then ends the reuse)
+		if (reused) { CUR(d).cdp[slot] = PRV(d).cdp[fslot]; CUR(d).cdr[slot] = PRV(d).cdr[fslot]; CUR(d).cnl[slot] = PRV(d).cnl[fslot]; }
+		else {
+			v3 dpos; quat drot;
+			pair_relative_pose(posA, Q4(d.rot[ab.x]), posB, Q4(d.rot[ab.y]), &dpos, &drot);
+			const v3 nl = m33_tmul(RB, nrm);
+			CUR(d).cdp[slot] = make_float4(dpos.x, dpos.y, dpos.z, nl.x);
+			CUR(d).cdr[slot] = make_float4(drot.x, drot.y, drot.z, drot.w);
+			CUR(d).cnl[slot] = make_float2(nl.y, nl.z);
+		}
 		for (int i = 0; i < 4; ++i) {
 			if (i >= np) break;
 			const v3 p1 = V3(d.man_p1[i][m]), p2 = V3(d.man_p2[i][m]);
-			const v3 local1 = m33_tmul(RA, v3_sub(p1, posA));
-			const v3 local2 = m33_tmul(RB, v3_sub(p2, posB));
+			v3 local1 = m33_tmul(RA, v3_sub(p1, posA));
+			v3 local2 = m33_tmul(RB, v3_sub(p2, posB));
+			if (reused) { local1 = V3(PRV(d).loc1[i][fslot]); local2 = V3(PRV(d).loc2[i][fslot]); }      // the cached body-space points themselves: no drift from re-deriving them
 			float lam_n = 0.0f, lam_t1 = 0.0f, lam_t2 = 0.0f;
 			for (int j = 0; j < 4; ++j) {
 				if (j >= pnp) break;
@@ -2020,7 +2100,7 @@ __global__ void __launch_bounds__(TPB) k_contact_events(DV d)
 	for (uint32_t m = blockIdx.x * TPB + threadIdx.x; m < n; m += gridDim.x * TPB) {
 		const uint2 ab = d.man_ab[m];
 		const uint64_t key = ((uint64_t)ab.x << 32) | ab.y;
-		const bool persisted = cache_find(d, key) != 0xFFFFFFFFu;
+		const bool persisted = (d.man_prev[m] & ~MAN_PREV_REUSED) != MAN_PREV_NONE;
 		uint32_t* ctr = persisted ? &d.evc->n_contact_persisted : &d.evc->n_contact_added;
 		const uint32_t k = atomicAdd(ctr, 1u);
 		if (k >= d.cap_contact_events) continue;
@@ -2100,7 +2180,7 @@ __global__ void __launch_bounds__(TPB) k_apply_cmds(DV d, const BodyCmd* cmds, c
 	for (uint32_t k = b; k < e; ++k) {
 		const BodyCmd& c = cmds[k];
 		if (c.ops & CMD_CREATE) {
-			f = c.flags;
+			f = c.flags | BF_CACHE_INVALID;
 			d.pos_im[i] = make_float4(c.pos[0], c.pos[1], c.pos[2], c.inv_mass);
 			d.rot[i] = make_float4(c.rot[0], c.rot[1], c.rot[2], c.rot[3]);
 			d.linv[i] = make_float4(c.linv[0], c.linv[1], c.linv[2], c.lin_damp);
@@ -2142,7 +2222,7 @@ __global__ void __launch_bounds__(TPB) k_apply_cmds(DV d, const BodyCmd* cmds, c
 		if (c.ops & CMD_SET_ROT) { d.rot[i] = make_float4(c.rot[0], c.rot[1], c.rot[2], c.rot[3]); pose = true; }
 		if (c.ops & CMD_SET_SHAPE) {
 			d.shape[i] = make_float4(c.shape[0], c.shape[1], c.shape[2], d.shape[i].w); pose = true;
-			f = (f & ~BF_LARGE) | (c.flags & BF_LARGE);      // a new scale can move the body across the broad phase's large-body radius (host: note_radius)
+			f = ((f & ~BF_LARGE) | (c.flags & BF_LARGE)) | BF_CACHE_INVALID;      // a new scale can move the body across the broad phase's large-body radius (host: note_radius)
 		}
 		if ((c.ops & CMD_SET_VEL) && f_motion(f) != SGP_MOTION_STATIC) {
 			d.linv[i] = make_float4(c.linv[0], c.linv[1], c.linv[2], d.linv[i].w);
@@ -3011,7 +3091,10 @@ void launch_bp_scan(const DV& d, hipStream_t s)
 void launch_bp_scatter(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_bp_scatter, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_bp_pairs(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_bp_pairs, dim3(4096), dim3(TPB), 0, s, d); }
 void launch_bp_large(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_bp_large, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
-void launch_narrowphase(const DV& d, uint32_t est, hipStream_t s) { hipLaunchKernelGGL(k_narrowphase, dim3(stride_grid(est)), dim3(TPB), 0, s, d); }
+void launch_narrowphase(const DV& d, uint32_t est, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_narrowphase, dim3(stride_grid(est)), dim3(TPB), 0, s, d);
+}
 void launch_narrowphase_hull(const DV& d, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_narrowphase_hull, dim3(4096), dim3(64), 0, s, d);

@@ -180,6 +180,9 @@ SGP_API void sgp_default_settings(sgp_settings* s)
 	s->max_angular_velocity = 0.25f * 3.14159265358979323846f * 60.0f;
 	s->allow_sleeping = 1;
 	s->warm_start = 1;
+	s->use_body_pair_contact_cache = 1;
+	s->body_pair_cache_max_delta_position_sq = 0.001f * 0.001f;
+	s->body_pair_cache_cos_max_delta_rotation_div2 = 0.99984769515639123915701155881391f;
 }
 
 SGP_API void sgp_default_world_desc(sgp_world_desc* d)
@@ -237,6 +240,7 @@ SGP_API int sgp_init(void)
 static int alloc_constraints(sgp_world* w, ConstraintArrays& c, uint32_t cap)
 {
 	DEV_ALLOC(c.ab, cap); DEV_ALLOC(c.n_fric, cap); DEV_ALLOC(c.key, cap); DEV_ALLOC(c.np_col, cap);
+	DEV_ALLOC(c.cdp, cap); DEV_ALLOC(c.cdr, cap); DEV_ALLOC(c.cnl, cap);
 	for (int k = 0; k < 4; ++k) {
 		DEV_ALLOC(c.r1b[k], cap); DEV_ALLOC(c.r2e[k], cap); DEV_ALLOC(c.lam[k], cap); DEV_ALLOC(c.efft[k], cap);
 		DEV_ALLOC(c.loc1[k], cap); DEV_ALLOC(c.loc2[k], cap);
@@ -296,7 +300,7 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	}
 	DEV_ALLOC(d.sorted_min, N); DEV_ALLOC(d.sorted_max, N); DEV_ALLOC(d.grid, 1); DEV_ALLOC(d.scan_block_sums, (d.table_size + 1) / 1024 + 2);
 	DEV_ALLOC(d.pairs, P);
-	DEV_ALLOC(d.man_ab, M); DEV_ALLOC(d.man_n, M); DEV_ALLOC(d.man_colour, M); DEV_ALLOC(d.man_prio, M);
+	DEV_ALLOC(d.man_ab, M); DEV_ALLOC(d.man_n, M); DEV_ALLOC(d.man_colour, M); DEV_ALLOC(d.man_prio, M); DEV_ALLOC(d.man_prev, M);
 	DEV_ALLOC(d.ulist[0], M); DEV_ALLOC(d.ulist[1], M);
 	for (int k = 0; k < 4; ++k) { DEV_ALLOC(d.man_p1[k], M); DEV_ALLOC(d.man_p2[k], M); }
 	DEV_ALLOC(d.rows, (size_t)48 * M);
@@ -988,10 +992,11 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 	// -- 3. narrow phase, wake-ups, per-body solver records (+ contact events, which see the velocities before the solve)
 	{ KScope k(w, KC_NARROWPHASE); launch_narrowphase(d, p.est_pairs, s); if (p.has_hulls) launch_narrowphase_hull(d, s); if (p.has_meshes) launch_narrowphase_mesh(d, s); }
 	{ KScope k(w, KC_APPLY_FORCES); launch_pre_solve(d, nb, s); }      // sweep 1/3: wake-ups, forces, per-step solver records
-	if (p.contact_events) { KScope k(w, KC_MISC); launch_contact_events(d, p.est_man, s); }
 	STAGE_MARK(3);
-	// -- 4. colouring + constraint setup
+	// -- 4. colouring + constraint setup (k_colour_inherit also resolves every manifold's slot in the previous step's constraints, which the
+	//       contact events -- added or persisted? -- and the set-up read)
 	{ KScope k(w, KC_COLOUR_CLAIM); launch_colour_inherit(d, p.est_man, s); }
+	if (p.contact_events) { KScope k(w, KC_MISC); launch_contact_events(d, p.est_man, s); }
 	if (p.small_colouring) {
 		// few manifolds: one workgroup runs every colouring round (no per-round launches)
 		KScope k(w, KC_COLOUR_COMMIT); launch_colour_finish(d, 0, 1, s);
@@ -1126,6 +1131,7 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	st.num_colours = c1.n_colours;
 	st.num_colour_rounds = c1.rounds_used;
 	st.num_overflow_constraints = c1.colour_count[SGP_OVERFLOW_COLOUR];
+	st.num_cached_manifolds = c1.n_cached;
 	st.pairs_dropped = c1.pairs_dropped; st.manifolds_dropped = c1.manifolds_dropped;
 	st.device_bytes = w->device_bytes;
 	st.num_active = c1.n_active;

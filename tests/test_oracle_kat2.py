@@ -127,3 +127,35 @@ def test_sensor_reports_contacts_without_response(oracle):
     assert 1 <= hit <= 3 and pers >= 40
     assert abs(s["pos"][2] - 0.25) < 0.03            # fell straight through the sensor and rests on the ground
     w.close()
+
+
+def test_body_pair_contact_cache_reuses_resting_box_manifolds(oracle):
+    """ContactConstraintManager::GetContactsFromCache as restated here: a box resting on a box keeps its manifold while the two have not moved
+    relative to each other by more than 1 mm / 2 degrees since it was computed; a nudge beyond that (or switching the setting off) sends the
+    pair through the collision test again; sphere contacts are never taken from the cache (polytope pairs only)."""
+    def scene(use):
+        w = oracle.OracleWorld(max_bodies=64, settings={"use_body_pair_contact_cache": use})
+        add_ground(w)
+        a = dyn(w, pos=(0, 0, 0.5), restitution=0.0, allow_sleeping=0)
+        b = dyn(w, pos=(0.1, 0.05, 1.5), restitution=0.0, allow_sleeping=0)
+        s = dyn(w, abi.SHAPE_SPHERE, (0.5,), pos=(3, 0, 0.5), restitution=0.0, allow_sleeping=0)
+        return w, a, b, s
+    w, a, b, s = scene(1)
+    for _ in range(120):
+        w.step(DT)
+    st = w.stats()
+    assert st.num_manifolds == 3 and st.num_cached_manifolds == 2          # ground-box and box-box reused, the sphere's contact recomputed
+    # a nudge of 5 mm: the upper pair is re-collided once, then cached again
+    p = w.get_state([b])[0]
+    w.set_pose_vel(b, (float(p["pos"][0]) + 0.005, float(p["pos"][1]), float(p["pos"][2])), tuple(float(x) for x in p["rot"]), (0, 0, 0), (0, 0, 0))
+    w.step(DT)
+    assert w.stats().num_cached_manifolds == 1
+    for _ in range(30):
+        w.step(DT)
+    assert w.stats().num_cached_manifolds == 2
+    w.close()
+    w, a, b, s = scene(0)
+    for _ in range(120):
+        w.step(DT)
+    assert w.stats().num_cached_manifolds == 0 and w.stats().num_manifolds == 3
+    w.close()

@@ -294,3 +294,27 @@ def test_incline_roll_sensor_scene(oracle):
     assert d["pos"] <= POS_TOL and d["rot"] <= POS_TOL and d["lin_vel"] <= VEL_TOL and d["ang_vel"] <= VEL_TOL, d
     assert added >= 1 and pers >= 5          # the rolling sphere crossed the sensor volume
     tw.close()
+
+
+@pytest.mark.parametrize("use_cache", [0, 1])
+def test_body_pair_contact_cache_on_and_off(oracle, use_cache):
+    """The body-pair contact cache (manifolds of resting polytope pairs reused instead of recomputed) on both sides of the comparison, and the
+    same scene with the setting off: bit-exact either way, the same number of manifolds taken from the cache, and a teleported box is
+    re-collided on both sides in the same step."""
+    descs = scenes.config1_256_boxes()
+    tw = parity.make_twin(oracle, max_bodies=1024, settings={"use_body_pair_contact_cache": use_cache})
+    ig, ic = tw.add_batch(descs)
+    seen = 0
+    for s in range(1, 201):
+        if s == 150:       # a box lifted by 4 mm: its pairs leave the cache for a step
+            st = tw.gpu.get_state([int(ig[40])])[0]
+            tw.set_pose_vel(int(ig[40]), (float(st["pos"][0]), float(st["pos"][1]), float(st["pos"][2]) + 0.004), tuple(float(x) for x in st["rot"]), (0, 0, 0), (0, 0, 0))
+        tw.step(DT)
+        sg, sc = tw.stats()
+        assert (sg.num_manifolds, sg.num_contact_points, sg.num_cached_manifolds) == (sc.num_manifolds, sc.num_contact_points, sc.num_cached_manifolds), s
+        seen = max(seen, sg.num_cached_manifolds)
+        if s % 50 == 0:
+            d = parity.compare(tw, len(descs))
+            assert d["bit_exact"] and d["active_mismatch"] == 0, (s, d)
+    assert (seen > 100) if use_cache else (seen == 0)
+    tw.close()

@@ -291,15 +291,18 @@ def test_two_tiles_split_in_z_bodies_fall_through_the_face(tmp_path, oracle):
     mp.spawn(zsplit_worker, args=(2, port, 200, str(tmp_path)), nprocs=2, join=True)
     l0, l1 = np.load(tmp_path / "zlog0.npy"), np.load(tmp_path / "zlog1.npy")
     c0, c1 = np.load(tmp_path / "zcount0.npy"), np.load(tmp_path / "zcount1.npy")
-    # all three boxes of the upper tile emigrated through the z = 3 face, and the lower tile took every one of them
-    assert l1[:, 3].sum() == 3 and l0[:, 4].sum() == 3 and l0[:, 3].sum() == 0
+    # the boxes of the upper tile that came to rest below the z = 3 face emigrated through it, and the lower tile took every one of them.
+    # (With the body-pair contact cache the column stands: its top box rests at z = 3.5 and stays with the upper tile; without it the
+    # column used to sway apart and all three ended up below the face.)
+    k = int(l1[:, 3].sum())
+    assert k in (2, 3) and l0[:, 4].sum() == k and l0[:, 3].sum() == 0
     # before it crossed, the lowest falling box was a ghost in the lower tile (imported across the z face)
     assert l0[:, 2].max() >= 1
-    s0 = np.load(tmp_path / "z0.npy")
-    own = s0[s0["id"] != abi.INVALID_ID][1:]
-    assert c0[0] - c0[1] == 1 + 7                        # ground + 4 base boxes + 3 immigrants (ghost copies excluded)
-    assert c1[0] - c1[1] == 1                            # the upper tile is left with its ground quad
-    dyn = own[np.argsort(own["pos"][:, 2])][:7]
+    s0, s1 = np.load(tmp_path / "z0.npy"), np.load(tmp_path / "z1.npy")
+    assert c0[0] - c0[1] == 1 + 4 + k                    # ground + 4 base boxes + the immigrants (ghost copies excluded)
+    assert c1[0] - c1[1] == 1 + (3 - k)                  # the upper tile keeps its ground quad and what still rests above the face
+    own0 = s0[s0["id"] != abi.INVALID_ID][1:]
+    dyn = own0[np.argsort(own0["pos"][:, 2])][:4 + k]
     # the column came to rest on the base: nothing fell through, nothing is still moving fast
     assert dyn["pos"][:, 2].min() > 0.45 and dyn["pos"][:, 2].max() < 4.2
     assert np.abs(dyn["lin_vel"]).max() < 2.0 and np.all(np.isfinite(dyn["pos"]))     # (the top box may still be sliding off the pile)

@@ -256,9 +256,9 @@ def run_seed(oracle, seed, steps, verbose=False):
                         raise AssertionError((seed, s, "event payload", ev, f, k, {n_: np.asarray(eg[n_][k]).tolist() for n_ in eg.dtype.names}, {n_: np.asarray(ec[n_][k]).tolist() for n_ in ec.dtype.names}))
         if s % 40 == 0 or s == steps:
             sg, sc = tw.stats()
-            tg = (sg.num_pairs, sg.num_manifolds, sg.num_contact_points, sg.num_colours, sg.num_active, sg.num_overflow_constraints)
-            tc = (sc.num_pairs, sc.num_manifolds, sc.num_contact_points, sc.num_colours, sc.num_active, sc.num_overflow_constraints)
-            assert tg == tc, (seed, s, "stats (pairs, manifolds, points, colours, active, overflow)", tg, tc)
+            tg = (sg.num_pairs, sg.num_manifolds, sg.num_contact_points, sg.num_colours, sg.num_active, sg.num_overflow_constraints, sg.num_cached_manifolds)
+            tc = (sc.num_pairs, sc.num_manifolds, sc.num_contact_points, sc.num_colours, sc.num_active, sc.num_overflow_constraints, sc.num_cached_manifolds)
+            assert tg == tc, (seed, s, "stats (pairs, manifolds, points, colours, active, overflow, cached)", tg, tc)
             hi = tw.gpu.num_bodies() + 64
             dd = parity.state_diff(tw.gpu.read_states(0, 2048), tw.cpu.read_states(0, 2048))
             assert dd["bit_exact"] and dd["active_mismatch"] == 0, (seed, s, dd)
