@@ -568,10 +568,12 @@ SGP_DEV uint32_t wave_alloc(uint32_t* counter)
 }
 // prev: the pair's slot in the previous step's constraint buffer if the caller already looked it up (| MAN_PREV_REUSED for a manifold taken
 // from the contact cache), MAN_PREV_LOOKUP to leave the look-up to k_colour_inherit
-SGP_DEV void emit_manifold(const DV& d, uint2 ab, uint32_t fa, uint32_t fb, const sgd_manifold& m, uint32_t prev = MAN_PREV_LOOKUP)
+// safety net: a manifold without a direction (or with a NaN one) is dropped, never solved
+SGP_DEV bool manifold_ok(const sgd_manifold& m) { return v3_len_sq(m.n) > 0.25f; }
+
+// the manifold goes to slot `slot` of the step's manifold list (the caller allocated it)
+SGP_DEV void emit_manifold_at(const DV& d, uint32_t slot, uint2 ab, uint32_t fa, uint32_t fb, const sgd_manifold& m, uint32_t prev)
 {
-	if (!(v3_len_sq(m.n) > 0.25f)) return;          // safety net: a manifold without a direction (or with a NaN one) is dropped, never solved
-	const uint32_t slot = wave_alloc(&d.ctr->n_manifolds);
 	if (slot >= d.cap_manifolds) { atomicAdd(&d.ctr->manifolds_dropped, 1u); return; }
 	d.man_ab[slot] = ab;
 	const bool sensor = (fa | fb) & BF_SENSOR;
@@ -587,6 +589,12 @@ SGP_DEV void emit_manifold(const DV& d, uint2 ab, uint32_t fa, uint32_t fb, cons
 		if (actA && !actB && f_motion(fb) == SGP_MOTION_DYNAMIC) atomicOr(&d.flags[ab.y], BF_WAKE);
 		if (actB && !actA && f_motion(fa) == SGP_MOTION_DYNAMIC) atomicOr(&d.flags[ab.x], BF_WAKE);
 	}
+}
+// ... with the slot taken here: one atomic per wave (the kernels with few manifolds per wave: hulls, meshes)
+SGP_DEV void emit_manifold(const DV& d, uint2 ab, uint32_t fa, uint32_t fb, const sgd_manifold& m, uint32_t prev = MAN_PREV_LOOKUP)
+{
+	if (!manifold_ok(m)) return;
+	emit_manifold_at(d, wave_alloc(&d.ctr->n_manifolds), ab, fa, fb, m, prev);
 }
 
 // pose of body 2 relative to body 1: centre of mass offset in body 1's frame, conj(q1) * q2
@@ -623,34 +631,60 @@ SGP_DEV bool reuse_cached_manifold(const DV& d, uint2 ab, uint32_t fa, uint32_t 
 	return true;
 }
 
+// Every atomic on the one manifold counter costs ~12 ns however many lanes it serves (same-address atomics serialise in L2): with one per wave
+// the 9k wave-iterations of config 3 spent 110 of the kernel's 230 us queueing for it (measured with parts of the output switched off: no output 108 us, slot allocated but nothing written 224 us, full 230 us).  The
+// workgroup therefore allocates the slots of all its manifolds of an iteration with ONE atomic.
 __global__ void __launch_bounds__(TPB) k_narrowphase(DV d)
 {
+	__shared__ uint32_t s_wave_cnt[TPB / 64];
+	__shared__ uint32_t s_base;
 	const uint32_t n = min(d.ctr->n_pairs, d.cap_pairs);
-	for (uint32_t p = blockIdx.x * TPB + threadIdx.x; p < n; p += gridDim.x * TPB) {
-		const uint2 ab = d.pairs[p];
-		const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
-		if (f_shape(fa) == SGP_SHAPE_MESH || f_shape(fb) == SGP_SHAPE_MESH) {
-			const uint32_t k = wave_alloc(&d.ctr->n_mesh_pairs);
-			if (k < d.cap_mesh_pairs) d.mesh_pairs[k] = ab; else atomicAdd(&d.ctr->pairs_dropped, 1u);
-			continue;
-		}
+	const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+	for (uint32_t p0 = blockIdx.x * TPB; p0 < n; p0 += gridDim.x * TPB) {
+		const uint32_t p = p0 + threadIdx.x;
+		bool have = false;
+		uint2 ab = make_uint2(0u, 0u); uint32_t fa = 0, fb = 0;
 		sgd_manifold m;
 		uint32_t prev = MAN_PREV_LOOKUP;
-		// the contact cache is consulted for polytope pairs only (box / hull against box / hull): their separating-axis test and clipping cost
-		// more than the gather of a cached manifold, and they are the pairs whose resting contacts a frozen manifold keeps from jittering; a
-		// sphere or capsule contact is recomputed (a few dozen instructions, the same answer every step)
-		const bool polytopes = (f_shape(fa) == SGP_SHAPE_BOX || f_shape(fa) == SGP_SHAPE_HULL) && (f_shape(fb) == SGP_SHAPE_BOX || f_shape(fb) == SGP_SHAPE_HULL);
-		if (polytopes && reuse_cached_manifold(d, ab, fa, fb, &m, &prev)) { emit_manifold(d, ab, fa, fb, m, prev); continue; }
-		if (f_shape(fa) == SGP_SHAPE_HULL || f_shape(fb) == SGP_SHAPE_HULL) {
-			// the polytope paths (clip buffers in scratch, long loops) live in their own kernel so that they do not cost the
-			// sphere / box / capsule pairs registers or scratch
-			const uint32_t k = wave_alloc(&d.ctr->n_hull_pairs);
-			if (k < d.cap_hull_pairs) d.hull_pairs[k] = ab; else atomicAdd(&d.ctr->pairs_dropped, 1u);
-			continue;
+		if (p < n) {
+			ab = d.pairs[p];
+			fa = d.flags[ab.x]; fb = d.flags[ab.y];
+			if (f_shape(fa) == SGP_SHAPE_MESH || f_shape(fb) == SGP_SHAPE_MESH) {
+				const uint32_t k = wave_alloc(&d.ctr->n_mesh_pairs);
+				if (k < d.cap_mesh_pairs) d.mesh_pairs[k] = ab; else atomicAdd(&d.ctr->pairs_dropped, 1u);
+			} else {
+				// the contact cache is consulted for polytope pairs only (box / hull against box / hull): their separating-axis test and clipping
+				// cost more than the gather of a cached manifold, and they are the pairs whose resting contacts a frozen manifold keeps from
+				// jittering; a sphere or capsule contact is recomputed (a few dozen instructions, the same answer every step)
+				const bool polytopes = (f_shape(fa) == SGP_SHAPE_BOX || f_shape(fa) == SGP_SHAPE_HULL) && (f_shape(fb) == SGP_SHAPE_BOX || f_shape(fb) == SGP_SHAPE_HULL);
+				if (polytopes && reuse_cached_manifold(d, ab, fa, fb, &m, &prev)) have = true;
+				else if (f_shape(fa) == SGP_SHAPE_HULL || f_shape(fb) == SGP_SHAPE_HULL) {
+					// the polytope paths (clip buffers in scratch, long loops) live in their own kernel so that they do not cost the
+					// sphere / box / capsule pairs registers or scratch
+					const uint32_t k = wave_alloc(&d.ctr->n_hull_pairs);
+					if (k < d.cap_hull_pairs) d.hull_pairs[k] = ab; else atomicAdd(&d.ctr->pairs_dropped, 1u);
+				} else {
+					const sgd_shape sa = load_shape(d, ab.x, fa), sb = load_shape(d, ab.y, fb);
+					have = sgd_collide(&sa, &sb, d.st.speculative_contact_distance, &m) != 0;
+				}
+				have = have && manifold_ok(m);
+			}
 		}
-		const sgd_shape sa = load_shape(d, ab.x, fa), sb = load_shape(d, ab.y, fb);
-		if (!sgd_collide(&sa, &sb, d.st.speculative_contact_distance, &m)) continue;
-		emit_manifold(d, ab, fa, fb, m, prev);
+		const unsigned long long hm = __ballot(have);
+		if (lane == 0) s_wave_cnt[wave] = (uint32_t)__popcll(hm);
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			uint32_t tot = 0;
+			for (int k = 0; k < TPB / 64; ++k) tot += s_wave_cnt[k];
+			s_base = tot ? atomicAdd(&d.ctr->n_manifolds, tot) : 0u;
+		}
+		__syncthreads();
+		if (have) {
+			uint32_t slot = s_base + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+			for (int k = 0; k < wave; ++k) slot += s_wave_cnt[k];
+			emit_manifold_at(d, slot, ab, fa, fb, m, prev);
+		}
+		__syncthreads();
 	}
 }
 
