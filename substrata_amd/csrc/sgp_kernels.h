@@ -66,7 +66,6 @@ struct StepCounters {
 	uint32_t n_points;
 	uint32_t n_hull_pairs;       // pairs with a convex hull, deferred to k_narrowphase_hull
 	uint32_t n_cached;           // manifolds taken from the body-pair contact cache
-	uint32_t n_hull_work;        // ... of which survive the separating-axis search (work items of k_narrowphase_hull_manifold)
 	uint32_t ucount[2];          // sizes of the two uncoloured worklists (round parity)
 	uint32_t rounds_used;        // colouring rounds that found work
 	uint32_t n_colours;          // highest used colour + 1 (overflow colour excluded)

@@ -856,18 +856,18 @@ __global__ void __launch_bounds__(64) k_narrowphase_hull(DV d)
 			const sgd_hview hx = sgd_hull_view(x), hy = sgd_hull_view(y);
 			hit = hull_sat_search_wave(&hx, &hy, max_sep, &wk.r);
 		} else memset(&wk.r, 0, sizeof(wk.r));
-		if (hit && threadIdx.x == 0) {
-			const uint32_t k = atomicAdd(&d.ctr->n_hull_work, 1u);      // (<= n_hull_pairs <= cap_hull_pairs: the list cannot overflow)
-			d.hull_work[k] = wk;
-		}
+		// work item p (no list to append to: one counter shared by ten thousand waves would cost more than the search)
+		if (!hit) wk.round_other = 2u;
+		if (threadIdx.x == 0) d.hull_work[p] = wk;
 	}
 }
 
 __global__ void __launch_bounds__(64) k_narrowphase_hull_manifold(DV d)
 {
-	const uint32_t n = min(d.ctr->n_hull_work, d.cap_hull_pairs);
+	const uint32_t n = min(d.ctr->n_hull_pairs, d.cap_hull_pairs);
 	for (uint32_t k = blockIdx.x * 64 + threadIdx.x; k < n; k += gridDim.x * 64) {
 		const HullWork wk = d.hull_work[k];
+		if (wk.round_other == 2u) continue;            // separated: nothing to do
 		const uint2 ab = wk.ab;
 		const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
 		const sgd_shape sa = load_shape(d, ab.x, fa), sb = load_shape(d, ab.y, fb);
@@ -1051,24 +1051,26 @@ __global__ void __launch_bounds__(TPB) k_colour_commit(DV d, uint32_t round)
 
 __global__ void __launch_bounds__(TPB) k_colour_count(DV d)
 {
-	__shared__ uint32_t hist[SGP_MAX_COLOURS + 2];
-	if (threadIdx.x < SGP_MAX_COLOURS + 2) hist[threadIdx.x] = 0;
+	__shared__ uint32_t hist[SGP_MAX_COLOURS + 3];
+	if (threadIdx.x < SGP_MAX_COLOURS + 3) hist[threadIdx.x] = 0;
 	__syncthreads();
 	const uint32_t n = min(d.ctr->n_manifolds, d.cap_manifolds);
-	uint32_t my_points = 0, my_cons = 0;          // the two totals are summed per thread and reduced per wave: one LDS atomic per wave, not per manifold
+	uint32_t my_points = 0, my_cons = 0, my_cached = 0;          // the totals are summed per thread and reduced per wave: one LDS atomic per wave, not per manifold
 	for (uint32_t m = blockIdx.x * TPB + threadIdx.x; m < n; m += gridDim.x * TPB) {
 		const int c = d.man_colour[m];
 		if (c < 0) continue;
 		atomicAdd(&hist[c], 1u);
 		{ const int npb = __float_as_int(d.man_n[m].w); my_points += (npb & 0x100) ? 0u : (uint32_t)(npb & 0xFF); }
 		my_cons += 1u;
+		my_cached += (d.man_prev[m] & MAN_PREV_REUSED) ? 1u : 0u;      // (statistics: manifolds taken from the body-pair contact cache)
 	}
-	for (int off = 32; off > 0; off >>= 1) { my_points += __shfl_down(my_points, off, 64); my_cons += __shfl_down(my_cons, off, 64); }
-	if ((threadIdx.x & 63) == 0) { if (my_points) atomicAdd(&hist[SGP_MAX_COLOURS], my_points); if (my_cons) atomicAdd(&hist[SGP_MAX_COLOURS + 1], my_cons); }
+	for (int off = 32; off > 0; off >>= 1) { my_points += __shfl_down(my_points, off, 64); my_cons += __shfl_down(my_cons, off, 64); my_cached += __shfl_down(my_cached, off, 64); }
+	if ((threadIdx.x & 63) == 0) { if (my_points) atomicAdd(&hist[SGP_MAX_COLOURS], my_points); if (my_cons) atomicAdd(&hist[SGP_MAX_COLOURS + 1], my_cons); if (my_cached) atomicAdd(&hist[SGP_MAX_COLOURS + 2], my_cached); }
 	__syncthreads();
 	if (threadIdx.x < SGP_MAX_COLOURS) { if (hist[threadIdx.x]) atomicAdd(&d.ctr->colour_count[threadIdx.x], hist[threadIdx.x]); }
 	else if (threadIdx.x == SGP_MAX_COLOURS) { if (hist[SGP_MAX_COLOURS]) atomicAdd(&d.ctr->n_points, hist[SGP_MAX_COLOURS]); }
 	else if (threadIdx.x == SGP_MAX_COLOURS + 1) { if (hist[SGP_MAX_COLOURS + 1]) atomicAdd(&d.ctr->n_constraints, hist[SGP_MAX_COLOURS + 1]); }
+	else if (threadIdx.x == SGP_MAX_COLOURS + 2) { if (hist[SGP_MAX_COLOURS + 2]) atomicAdd(&d.ctr->n_cached, hist[SGP_MAX_COLOURS + 2]); }
 }
 
 // Catch-all: if the planned number of rounds left manifolds uncoloured, ONE workgroup finishes the job with workgroup
@@ -1205,12 +1207,6 @@ __global__ void __launch_bounds__(TPB) k_setup(DV d)
 		__syncthreads();
 		if (threadIdx.x < SGP_MAX_COLOURS && hist[threadIdx.x]) base[threadIdx.x] = atomicAdd(&d.ctr->colour_fill[threadIdx.x], hist[threadIdx.x]);
 		__syncthreads();
-		{
-			// statistics: constraints whose manifold came from the body-pair contact cache (one atomic per wave)
-			const bool ru = col >= 0 && (d.man_prev[m] & MAN_PREV_REUSED);
-			const unsigned long long bm = __ballot(ru);
-			if (bm && (threadIdx.x & 63) == 0) atomicAdd(&d.ctr->n_cached, (uint32_t)__popcll(bm));
-		}
 		if (col < 0) continue;
 		const uint32_t slot = d.cstarts[col] + base[col] + rank;
 		const uint2 ab = d.man_ab[m];
@@ -1937,15 +1933,32 @@ __global__ void __launch_bounds__(TPB) k_island_flag(DV d)
 	}
 }
 
+// Workgroup-wide allocation from ONE counter with one atomic: returns this thread's index if `want` (every thread of the workgroup must call it).
+// Same-address atomics serialise at ~12 ns each in L2, so a per-wave atomic (1.5k of them for 100k bodies) is already ~20 us.
+SGP_DEV uint32_t block_alloc(uint32_t* counter, bool want)
+{
+	__shared__ uint32_t s_cnt[TPB / 64];
+	__shared__ uint32_t s_b;
+	const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+	const unsigned long long m = __ballot(want);
+	if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(m);
+	__syncthreads();
+	if (threadIdx.x == 0) { uint32_t tot = 0; for (int k = 0; k < TPB / 64; ++k) tot += s_cnt[k]; s_b = tot ? atomicAdd(counter, tot) : 0u; }
+	__syncthreads();
+	uint32_t idx = s_b + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+	for (int k = 0; k < wave; ++k) idx += s_cnt[k];
+	__syncthreads();
+	return idx;
+}
+
 SGP_DEV void sleep_apply_one(const DV& d, uint32_t i, bool& active);
 __global__ void __launch_bounds__(TPB) k_sleep_apply(DV d)
 {
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
 	bool active = false;
 	if (i < d.sp->n_slots) sleep_apply_one(d, i, active);
-	// one atomic per wave for the active-body count (100k single-address atomics cost more than the rest of the kernel)
-	const unsigned long long m = __ballot(active);
-	if (m && (threadIdx.x & 63) == 0) atomicAdd(&d.ctr->n_active, (uint32_t)__popcll(m));
+	// one atomic per workgroup for the active-body count
+	block_alloc(&d.ctr->n_active, active);
 }
 
 SGP_DEV void sleep_apply_one(const DV& d, uint32_t i, bool& active)
@@ -2135,8 +2148,9 @@ __global__ void __launch_bounds__(TPB) k_contact_events(DV d)
 		const uint2 ab = d.man_ab[m];
 		const uint64_t key = ((uint64_t)ab.x << 32) | ab.y;
 		const bool persisted = (d.man_prev[m] & ~MAN_PREV_REUSED) != MAN_PREV_NONE;
-		uint32_t* ctr = persisted ? &d.evc->n_contact_persisted : &d.evc->n_contact_added;
-		const uint32_t k = atomicAdd(ctr, 1u);
+		// one atomic per wave and list (the lanes here are the loop's active lanes; wave_alloc serves those that call it together)
+		uint32_t k;
+		if (persisted) k = wave_alloc(&d.evc->n_contact_persisted); else k = wave_alloc(&d.evc->n_contact_added);
 		if (k >= d.cap_contact_events) continue;
 		sgp_contact_event e;
 		e.id1 = ab.x; e.id2 = ab.y; e.userdata1 = 0; e.userdata2 = 0;
@@ -2315,11 +2329,10 @@ __global__ void __launch_bounds__(TPB) k_gather_states(DV d, const uint32_t* ids
 __global__ void __launch_bounds__(TPB) k_gather_active(DV d, sgp_body_state* out, uint32_t cap)
 {
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-	if (i >= d.sp->n_slots) return;
-	const uint32_t f = d.flags[i];
-	if ((f & (BF_ALIVE | BF_ACTIVE)) != (BF_ALIVE | BF_ACTIVE)) return;
-	const uint32_t k = atomicAdd(&d.ctr->n_read_active, 1u);
-	if (k < cap) fill_state(d, i, &out[k]);
+	const uint32_t f = i < d.sp->n_slots ? d.flags[i] : 0u;
+	const bool want = (f & (BF_ALIVE | BF_ACTIVE)) == (BF_ALIVE | BF_ACTIVE);
+	const uint32_t k = block_alloc(&d.ctr->n_read_active, want);      // one atomic per workgroup
+	if (want && k < cap) fill_state(d, i, &out[k]);
 }
 
 struct ConstraintDumpRec { uint32_t a, b; int32_t colour; int32_t np; float n[3]; float lam_n[4]; float lam_t1[4]; float lam_t2[4]; float bias[4]; };
@@ -3143,7 +3156,8 @@ void launch_colour_claim(const DV& d, uint32_t est, uint32_t round, hipStream_t 
 void launch_colour_commit(const DV& d, uint32_t est, uint32_t round, hipStream_t s) { hipLaunchKernelGGL(k_colour_commit, dim3(stride_grid(est)), dim3(TPB), 0, s, d, round); }
 void launch_colour_count(const DV& d, uint32_t est, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_colour_count, dim3(stride_grid(est)), dim3(TPB), 0, s, d);
+	// (few workgroups, each looping: a workgroup ends with one global atomic per colour it saw, and atomics on one address serialise)
+	hipLaunchKernelGGL(k_colour_count, dim3(std::min(stride_grid(est), 512u)), dim3(TPB), 0, s, d);
 	hipLaunchKernelGGL(k_colour_scan, dim3(1), dim3(64), 0, s, d);
 }
 void launch_colour_finish(const DV& d, uint32_t first_round, int build_list, hipStream_t s) { hipLaunchKernelGGL(k_colour_finish, dim3(1), dim3(1024), 0, s, d, first_round, build_list); }
