@@ -205,6 +205,7 @@ struct DV {
 	int32_t*  man_colour;      // -1 uncoloured, -2 not a constraint (sensor)
 	uint32_t* ulist[2];        // worklists of still-uncoloured manifolds, double buffered by round parity
 	uint64_t* man_prio;
+	uint32_t* man_slot;        // constraint slot of the manifold (k_setup_slots)
 	uint32_t* man_prev;        // slot of the same pair's constraint in the previous step's buffer (MAN_PREV_NONE if none), bit 31: the manifold was
 	                           // taken from the body-pair contact cache (k_narrowphase) -- one hash look-up per manifold, shared by every later kernel
 	// constraints

@@ -520,21 +520,25 @@ __global__ void __launch_bounds__(TPB) k_bp_pairs(DV d)
 }
 
 // large bodies (ground quad, PhysicsWorld.cpp:1123) against every body
+SGP_DEV uint32_t block_alloc(uint32_t* counter, bool want);
 __global__ void __launch_bounds__(TPB) k_bp_large(DV d)
 {
 	const uint32_t j = blockIdx.x * TPB + threadIdx.x;
-	if (j >= d.sp->n_slots) return;
-	const uint32_t fj = d.flags[j];
-	if (!(fj & BF_ALIVE) || (fj & BF_ALIAS)) return;      // (a mesh body's alias slots only carry manifolds: they never pair)
-	const float4 mnj = d.aabb_min[j], mxj = d.aabb_max[j];
+	const uint32_t fj = j < d.sp->n_slots ? d.flags[j] : 0u;
+	const bool live_j = (fj & BF_ALIVE) && !(fj & BF_ALIAS);      // (a mesh body's alias slots only carry manifolds: they never pair)
+	float4 mnj = make_float4(0.0f, 0.0f, 0.0f, 0.0f), mxj = mnj;
+	if (live_j) { mnj = d.aabb_min[j]; mxj = d.aabb_max[j]; }
 	for (uint32_t l = 0; l < d.sp->n_large; ++l) {
 		const uint32_t i = d.large_ids[l];
-		if (i == j) continue;
-		const uint32_t fi = d.flags[i];
-		if (!(fi & BF_ALIVE)) continue;
-		if ((fj & BF_LARGE) && j < i) continue;                 // large-large once
-		if (!(f_active_for_pairs(fi) || f_active_for_pairs(fj))) continue;
-		if (pair_passes(d, fj, mnj, mxj, i)) push_pair(d, i, j);
+		bool pair = false;
+		if (live_j && i != j) {
+			const uint32_t fi = d.flags[i];
+			pair = (fi & BF_ALIVE) && !((fj & BF_LARGE) && j < i)                 // large-large once
+			       && (f_active_for_pairs(fi) || f_active_for_pairs(fj)) && pair_passes(d, fj, mnj, mxj, i);
+		}
+		// the ground quad alone pairs with every body: one atomic per workgroup on the pair counter, not one per wave
+		const uint32_t k = block_alloc(&d.ctr->n_pairs, pair);
+		if (pair) { if (k < d.cap_pairs) d.pairs[k] = make_uint2(i < j ? i : j, i < j ? j : i); else atomicAdd(&d.ctr->pairs_dropped, 1u); }
 	}
 }
 
@@ -1190,25 +1194,45 @@ SGP_DEV uint32_t cache_find(const DV& d, uint64_t key)
 	return 0xFFFFFFFFu;
 }
 
-__global__ void __launch_bounds__(TPB) k_setup(DV d)
+// Constraint slot of every manifold (colour-sorted layout): a light kernel of its own, each workgroup taking SLOTS_PER_THREAD x TPB manifolds
+// per global atomic and colour -- the set-up kernel proper is heavy (218 VGPRs) and would otherwise queue for the per-colour fill counters
+// once per 256 manifolds.
+#define SLOTS_PER_THREAD 8
+__global__ void __launch_bounds__(TPB) k_setup_slots(DV d)
 {
-	const float dt = d.sp->dt;
 	__shared__ uint32_t hist[SGP_MAX_COLOURS];
 	__shared__ uint32_t base[SGP_MAX_COLOURS];
 	const uint32_t n = min(d.ctr->n_manifolds, d.cap_manifolds);
-	for (uint32_t m0 = blockIdx.x * TPB; m0 < n; m0 += gridDim.x * TPB) {
-		const uint32_t m = m0 + threadIdx.x;
-		// slot allocation: one global atomic per (block, colour) instead of one per manifold
+	for (uint32_t c0 = blockIdx.x * TPB * SLOTS_PER_THREAD; c0 < n; c0 += gridDim.x * TPB * SLOTS_PER_THREAD) {
 		if (threadIdx.x < SGP_MAX_COLOURS) hist[threadIdx.x] = 0;
 		__syncthreads();
-		const int col = m < n ? d.man_colour[m] : -1;
-		uint32_t rank = 0;
-		if (col >= 0) rank = atomicAdd(&hist[col], 1u);
+		int cols[SLOTS_PER_THREAD]; uint32_t ranks[SLOTS_PER_THREAD];
+#pragma unroll
+		for (int j = 0; j < SLOTS_PER_THREAD; ++j) {
+			const uint32_t m = c0 + (uint32_t)j * TPB + threadIdx.x;
+			cols[j] = m < n ? d.man_colour[m] : -1;
+			ranks[j] = cols[j] >= 0 ? atomicAdd(&hist[cols[j]], 1u) : 0u;
+		}
 		__syncthreads();
 		if (threadIdx.x < SGP_MAX_COLOURS && hist[threadIdx.x]) base[threadIdx.x] = atomicAdd(&d.ctr->colour_fill[threadIdx.x], hist[threadIdx.x]);
 		__syncthreads();
+#pragma unroll
+		for (int j = 0; j < SLOTS_PER_THREAD; ++j) {
+			const uint32_t m = c0 + (uint32_t)j * TPB + threadIdx.x;
+			if (cols[j] >= 0) d.man_slot[m] = d.cstarts[cols[j]] + base[cols[j]] + ranks[j];
+		}
+		__syncthreads();
+	}
+}
+
+__global__ void __launch_bounds__(TPB) k_setup(DV d)
+{
+	const float dt = d.sp->dt;
+	const uint32_t n = min(d.ctr->n_manifolds, d.cap_manifolds);
+	for (uint32_t m = blockIdx.x * TPB + threadIdx.x; m < n; m += gridDim.x * TPB) {
+		const int col = d.man_colour[m];
 		if (col < 0) continue;
-		const uint32_t slot = d.cstarts[col] + base[col] + rank;
+		const uint32_t slot = d.man_slot[m];
 		const uint2 ab = d.man_ab[m];
 		const uint64_t key = ((uint64_t)ab.x << 32) | ab.y;
 		const float4 n4 = d.man_n[m];
@@ -3161,7 +3185,11 @@ void launch_colour_count(const DV& d, uint32_t est, hipStream_t s)
 	hipLaunchKernelGGL(k_colour_scan, dim3(1), dim3(64), 0, s, d);
 }
 void launch_colour_finish(const DV& d, uint32_t first_round, int build_list, hipStream_t s) { hipLaunchKernelGGL(k_colour_finish, dim3(1), dim3(1024), 0, s, d, first_round, build_list); }
-void launch_setup(const DV& d, uint32_t n_man, hipStream_t s) { hipLaunchKernelGGL(k_setup, dim3(stride_grid(n_man)), dim3(TPB), 0, s, d); }
+void launch_setup(const DV& d, uint32_t n_man, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_setup_slots, dim3(std::max(64u, std::min(4096u, (n_man + TPB * SLOTS_PER_THREAD - 1) / (TPB * SLOTS_PER_THREAD)))), dim3(TPB), 0, s, d);
+	hipLaunchKernelGGL(k_setup, dim3(stride_grid(n_man)), dim3(TPB), 0, s, d);
+}
 void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStream_t s)
 {
 	uint32_t blocks = (est + est / 8 + 64 + SOLVE_TPB - 1) / SOLVE_TPB;
