@@ -1185,7 +1185,8 @@ static void apply_impulse(sgo_body* A, sgo_body* B, float im1, sym33 I1, float i
 
 static float axis_jv(const sgo_body* A, const sgo_body* B, v3 r1, v3 r2, v3 axis)
 {
-	return v3_dot(axis, v3_sub(A->linv, B->linv)) + v3_dot(v3_cross(r1, axis), A->angv) - v3_dot(v3_cross(r2, axis), B->angv);
+	/* each body's share first, then the difference (the device computes the two shares on two lanes) */
+	return (v3_dot(axis, A->linv) + v3_dot(v3_cross(r1, axis), A->angv)) - (v3_dot(axis, B->linv) + v3_dot(v3_cross(r2, axis), B->angv));
 }
 
 static void warm_start_constraint(sgo_world* w, sgo_constraint* c)

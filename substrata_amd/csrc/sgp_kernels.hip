@@ -1370,7 +1370,7 @@ SGP_DEV void apply_impulse(BodyVel& A, BodyVel& B, float im1, const sym33& I1, f
 
 SGP_DEV float axis_jv(const BodyVel& A, const BodyVel& B, v3 r1, v3 r2, v3 axis)
 {
-	return v3_dot(axis, v3_sub(A.lv, B.lv)) + v3_dot(v3_cross(r1, axis), A.av) - v3_dot(v3_cross(r2, axis), B.av);
+	return (v3_dot(axis, A.lv) + v3_dot(v3_cross(r1, axis), A.av)) - (v3_dot(axis, B.lv) + v3_dot(v3_cross(r2, axis), B.av));
 }
 
 struct PairCtx { uint2 ab; float im1, im2; sym33 I1, I2; BodyVel A, B; v3 n, t1, t2; float friction; int np; };
@@ -1490,7 +1490,7 @@ SGP_DEV AxisRows load_axis_rows(const DV& d, uint32_t slot, int point, int axis)
 
 SGP_DEV float rows_jv(const BodyVel& A, const BodyVel& B, v3 axis, const AxisRows& r)
 {
-	return v3_dot(axis, v3_sub(A.lv, B.lv)) + v3_dot(V3(r.c1), A.av) - v3_dot(V3(r.c2), B.av);
+	return (v3_dot(axis, A.lv) + v3_dot(V3(r.c1), A.av)) - (v3_dot(axis, B.lv) + v3_dot(V3(r.c2), B.av));      // each body's share, then the difference
 }
 
 SGP_DEV void rows_apply(BodyVel& A, BodyVel& B, float im1, float im2, v3 axis, const AxisRows& r, float lambda)
@@ -1505,82 +1505,135 @@ SGP_DEV void rows_apply(BodyVel& A, BodyVel& B, float im1, float im2, v3 axis, c
 	}
 }
 
-// A constraint held in registers: loaded once (con_load), iterated any number of times (con_solve_velocity: only the two bodies'
-// velocities are gathered and scattered), lambdas written back at the end (con_store).  solve_velocity_one_t is the three in a row; the
-// single-workgroup kernels (tail colours, small worlds) keep the record across their colour phases / iterations instead of re-reading it.
-struct ConReg { uint2 ab; float4 nf; int np_col; AxisRows rn[4], rt1[4], rt2[4]; float4 lam[4]; };
+// VELOCITY ITERATIONS: TWO LANES PER CONSTRAINT.  The arithmetic of one constraint is a dependent chain (every row reads the velocities the
+// row before it wrote), and a launch -- or a colour phase of the single-workgroup kernels -- lasts as long as that chain in its slowest wave.
+// Lane `side` (0 / 1 = body 1 / body 2 of the constraint; the two lanes are neighbours) holds its own body's velocities and its own
+// body's half of every row; per row it computes its body's share of J v, swaps shares with its neighbour (one cross-lane move), computes
+// the same impulse as its neighbour from the same operands, and applies it to its own body: a little over half the instructions per lane,
+// and half the registers.  (The summation order of J v -- each body's share first, then the difference -- is that of the oracle's axis_jv.)
+//
+// A constraint half in registers: loaded once (half_load), iterated any number of times (half_solve: only this lane's body's velocities
+// are gathered and scattered), lambdas written back at the end by lane 0 (half_store).
+struct ConHalf {
+	uint32_t body;          // this lane's body
+	float4 nf; int np_col;
+	float4 c[4][3];         // r x axis of this lane's body for (point, axis n / t1 / t2)
+	float4 iv[4][3];        // I (r x axis) of this lane's body
+	float  eff[4][3];       // effective mass of the row (both lanes)
+	float  bias[4];         // of the normal row (both lanes)
+	v3     t1;              // first friction direction (both lanes)
+	float4 lam[4];
+};
 
-SGP_DEV void con_load(const DV& d, uint32_t slot, ConReg& r)
+SGP_DEV void half_load_rows(const DV& d, uint32_t slot, int side, ConHalf& h)
 {
-	r.ab = CUR(d).ab[slot];
-	r.nf = CUR(d).n_fric[slot];
-	r.np_col = CUR(d).np_col[slot];
-	const int np = r.np_col & 0xFF;
+	const int np = h.np_col & 0xFF;
+	const size_t st = d.cap_manifolds;
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
 		if (i < np) {
-			r.rn[i] = load_axis_rows(d, slot, i, 0); r.rt1[i] = load_axis_rows(d, slot, i, 1); r.rt2[i] = load_axis_rows(d, slot, i, 2);
-			r.lam[i] = CUR(d).lam[i][slot];
+#pragma unroll
+			for (int a = 0; a < 3; ++a) {
+				const float4* p = axis_rows(d, slot, i, a);
+				h.c[i][a] = p[(size_t)side * st];               // lane 0: r1 x axis (w: bias of the normal row); lane 1: r2 x axis (w: effective mass)
+				h.iv[i][a] = p[(size_t)(2 + side) * st];         // I1 (r1 x axis) / I2 (r2 x axis) (w of point 0: the stored tangent, see k_setup)
+			}
+			h.lam[i] = CUR(d).lam[i][slot];
 		}
+	}
+	// what the other lane holds in its .w components: effective masses (lane 1), the bias (lane 0), the tangent (x, z: lane 0; y: lane 1)
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		if (i < np) {
+#pragma unroll
+			for (int a = 0; a < 3; ++a) { const float mine = h.c[i][a].w, other = __shfl_xor(mine, 1, 64); h.eff[i][a] = side ? mine : other; if (a == 0) h.bias[i] = side ? other : mine; }
+		}
+	}
+	if (np > 0) {
+		const float a0 = h.iv[0][0].w, b0 = __shfl_xor(a0, 1, 64), a1 = h.iv[0][1].w, b1 = __shfl_xor(a1, 1, 64);
+		h.t1 = V3(side ? b0 : a0, side ? a0 : b0, side ? b1 : a1);
 	}
 }
 
-SGP_DEV void con_store(const DV& d, uint32_t slot, const ConReg& r)
+SGP_DEV void half_load(const DV& d, uint32_t slot, int side, ConHalf& h)
 {
-	const int np = r.np_col & 0xFF;
-#pragma unroll
-	for (int i = 0; i < 4; ++i) { if (i < np) CUR(d).lam[i][slot] = r.lam[i]; }
+	const uint2 ab = CUR(d).ab[slot];
+	h.body = side ? ab.y : ab.x;
+	h.nf = CUR(d).n_fric[slot];
+	h.np_col = CUR(d).np_col[slot];
+	half_load_rows(d, slot, side, h);
 }
 
-template <int VS> SGP_DEV void con_solve_velocity(ConReg& r, float4* vel, uint32_t dbg = 0)
+SGP_DEV void half_store(const DV& d, uint32_t slot, int side, const ConHalf& h)
 {
-	const uint2 ab = r.ab;
-	const int np = r.np_col & 0xFF;
+	if (side) return;
+	const int np = h.np_col & 0xFF;
+#pragma unroll
+	for (int i = 0; i < 4; ++i) { if (i < np) CUR(d).lam[i][slot] = h.lam[i]; }
+}
+
+// this body's share of J v for one row, the neighbour's share, their difference (share of body 1 minus share of body 2: identical on both lanes)
+SGP_DEV float half_jv(v3 lv, v3 av, v3 axis, float4 c, int side)
+{
+	const float mine = v3_dot(axis, lv) + v3_dot(V3(c), av);
+	const float other = __shfl_xor(mine, 1, 64);
+	return side ? other - mine : mine - other;
+}
+SGP_DEV void half_apply(v3& lv, v3& av, float im, v3 axis, float4 iv, float lambda, int side)
+{
+	if (!(im > 0.0f)) return;
+	if (side) { lv = v3_add(lv, v3_scale(axis, lambda * im)); av = v3_add(av, v3_scale(V3(iv), lambda)); }
+	else      { lv = v3_sub(lv, v3_scale(axis, lambda * im)); av = v3_sub(av, v3_scale(V3(iv), lambda)); }
+}
+
+// One contact manifold, one velocity iteration (ContactConstraintManager::SolveVelocityConstraints): friction rows of every point first (they
+// use the normal impulse of the previous iteration), then the non-penetration rows.  Both lanes of the constraint must call this together.
+// `vel` / VS: where the velocity half of the per-body solver record lives (the global record: d.sbody, VS = 4; an LDS copy: VS = 2).
+template <int VS> SGP_DEV void half_solve(ConHalf& h, int side, float4* vel, uint32_t dbg = 0)
+{
+	const int np = h.np_col & 0xFF;
 	if (np == 0) return;                    // a sensor pair: kept in the contact list, nothing to solve
-	const float4 va = vel[VS * (size_t)ab.x], wa = vel[VS * (size_t)ab.x + 1];
-	const float4 vb = vel[VS * (size_t)ab.y], wb = vel[VS * (size_t)ab.y + 1];
-	const float im1 = va.w, im2 = vb.w, friction = r.nf.w;
-	BodyVel A, B;
-	A.lv = V3(va); A.av = V3(wa); B.lv = V3(vb); B.av = V3(wb);
-	const v3 n = V3(r.nf);
-	const v3 t1 = (dbg & 2u) ? v3_normalized_perpendicular(n) : V3(r.rn[0].i1.w, r.rn[0].i2.w, r.rt1[0].i1.w);      // = v3_normalized_perpendicular(n), stored by k_setup (np >= 1 here)
+	const float4 v4 = vel[VS * (size_t)h.body], w4 = vel[VS * (size_t)h.body + 1];
+	const float im = v4.w, friction = h.nf.w;
+	v3 lv = V3(v4), av = V3(w4);
+	const v3 n = V3(h.nf);
+	const v3 t1 = (dbg & 2u) ? v3_normalized_perpendicular(n) : h.t1;      // = v3_normalized_perpendicular(n), stored by k_setup
 	const v3 t2 = v3_cross(n, t1);
 	if (friction > 0.0f) {
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
-			if (i < np && !(r.rt1[i].c2.w <= 0.0f && r.rt2[i].c2.w <= 0.0f)) {
-				float l1 = r.lam[i].y + r.rt1[i].c2.w * rows_jv(A, B, t1, r.rt1[i]);
-				float l2 = r.lam[i].z + r.rt2[i].c2.w * rows_jv(A, B, t2, r.rt2[i]);
-				const float max_f = friction * r.lam[i].x;
+			if (i < np && !(h.eff[i][1] <= 0.0f && h.eff[i][2] <= 0.0f)) {
+				float l1 = h.lam[i].y + h.eff[i][1] * half_jv(lv, av, t1, h.c[i][1], side);
+				float l2 = h.lam[i].z + h.eff[i][2] * half_jv(lv, av, t2, h.c[i][2], side);
+				const float max_f = friction * h.lam[i].x;
 				const float tot_sq = l1 * l1 + l2 * l2;
 				if (tot_sq > max_f * max_f) { const float sc = max_f / sqrtf(tot_sq); l1 = l1 * sc; l2 = l2 * sc; }
-				rows_apply(A, B, im1, im2, t1, r.rt1[i], l1 - r.lam[i].y); r.lam[i].y = l1;
-				rows_apply(A, B, im1, im2, t2, r.rt2[i], l2 - r.lam[i].z); r.lam[i].z = l2;
+				half_apply(lv, av, im, t1, h.iv[i][1], l1 - h.lam[i].y, side); h.lam[i].y = l1;
+				half_apply(lv, av, im, t2, h.iv[i][2], l2 - h.lam[i].z, side); h.lam[i].z = l2;
 			}
 		}
 	}
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
-		if (i < np && r.rn[i].c2.w > 0.0f) {
-			const float jv = rows_jv(A, B, n, r.rn[i]);
-			const float lambda = r.rn[i].c2.w * (jv - r.rn[i].c1.w);
-			const float nl = max0f(r.lam[i].x + lambda);
-			rows_apply(A, B, im1, im2, n, r.rn[i], nl - r.lam[i].x);
-			r.lam[i].x = nl;
+		if (i < np && h.eff[i][0] > 0.0f) {
+			const float jv = half_jv(lv, av, n, h.c[i][0], side);
+			const float lambda = h.eff[i][0] * (jv - h.bias[i]);
+			const float nl = max0f(h.lam[i].x + lambda);
+			half_apply(lv, av, im, n, h.iv[i][0], nl - h.lam[i].x, side);
+			h.lam[i].x = nl;
 		}
 	}
-	if (im1 > 0.0f) { vel[VS * (size_t)ab.x] = F4(A.lv, im1); vel[VS * (size_t)ab.x + 1] = F4(A.av, 0.0f); }
-	if (im2 > 0.0f) { vel[VS * (size_t)ab.y] = F4(B.lv, im2); vel[VS * (size_t)ab.y + 1] = F4(B.av, 0.0f); }
+	if (im > 0.0f) { vel[VS * (size_t)h.body] = F4(lv, im); vel[VS * (size_t)h.body + 1] = F4(av, 0.0f); }
 }
 
-template <int VS> SGP_DEV void solve_velocity_one_t(const DV& d, uint32_t slot, float4* vel)
+// load + one iteration + store: what a colour launch does per constraint (lanes 2k and 2k + 1 of a wave call it with the same slot)
+template <int VS> SGP_DEV void solve_velocity_pair_t(const DV& d, uint32_t slot, int side, float4* vel)
 {
-	ConReg r;
-	con_load(d, slot, r);
-	con_solve_velocity<VS>(r, vel, d.dbg_flags);
-	con_store(d, slot, r);
+	ConHalf h;
+	half_load(d, slot, side, h);
+	half_solve<VS>(h, side, vel, d.dbg_flags);
+	half_store(d, slot, side, h);
 }
-SGP_DEV void solve_velocity_one(const DV& d, uint32_t slot) { solve_velocity_one_t<4>(d, slot, d.sbody); }
 
 SGP_DEV void solve_position_one(const DV& d, uint32_t slot)
 {
@@ -1636,13 +1689,19 @@ SGP_DEV void solve_position_one(const DV& d, uint32_t slot)
 // One launch = one colour of one pass.  The slot range comes from the device-side colour table, so the host never has
 // to know the counts of the current step; the grid is sized from the previous step and the loop strides over the rest.
 #define SOLVE_TPB 64      // one wave per workgroup: a colour of ~17k constraints then spreads over all 256 CUs instead of 67 of them
-template <int MODE> __global__ void __launch_bounds__(SOLVE_TPB) k_solve_colour(DV d, int colour)
+// (velocity iterations: two neighbouring lanes per constraint, half_solve; workgroups of two waves, so that a colour is as many workgroups
+// as it was with one lane per constraint -- twice as many one-wave workgroups took ~1 us longer to dispatch per launch)
+#define SOLVE_VEL_TPB 128
+template <int MODE> __global__ void __launch_bounds__(MODE == 1 ? SOLVE_VEL_TPB : SOLVE_TPB) k_solve_colour(DV d, int colour)
 {
 	const uint32_t first = d.cstarts[colour], end = d.cstarts[colour + 1];
+	if (MODE == 1) {
+		const int side = (int)(threadIdx.x & 1u);
+		for (uint32_t k = first + ((blockIdx.x * SOLVE_VEL_TPB + threadIdx.x) >> 1); k < end; k += gridDim.x * (SOLVE_VEL_TPB / 2)) solve_velocity_pair_t<4>(d, k, side, d.sbody);
+		return;
+	}
 	for (uint32_t k = first + blockIdx.x * SOLVE_TPB + threadIdx.x; k < end; k += gridDim.x * SOLVE_TPB) {
-		if (MODE == 0) warm_start_one(d, k);
-		else if (MODE == 1) solve_velocity_one(d, k);
-		else solve_position_one(d, k);
+		if (MODE == 0) warm_start_one(d, k); else solve_position_one(d, k);
 	}
 }
 
@@ -1652,9 +1711,12 @@ template <int MODE> __global__ void __launch_bounds__(SOLVE_TPB) k_solve_colour(
 template <int V> __global__ void __launch_bounds__(SOLVE_TPB) k_solve_probe(DV d, int colour)
 {
 	const uint32_t first = d.cstarts[colour], end = d.cstarts[colour + 1];
+	if (V == 0) {
+		for (uint32_t k = first + ((blockIdx.x * SOLVE_TPB + threadIdx.x) >> 1); k < end; k += gridDim.x * (SOLVE_TPB / 2)) solve_velocity_pair_t<4>(d, k, (int)(threadIdx.x & 1u), d.sbody);
+		return;
+	}
 	for (uint32_t k = first + blockIdx.x * SOLVE_TPB + threadIdx.x; k < end; k += gridDim.x * SOLVE_TPB) {
-		if (V == 0) solve_velocity_one(d, k);
-		else if (V == 1) {
+		if (V == 1) {
 			PairCtx c;
 			load_pair<4>(d, k, c, d.sbody);
 			float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1676,6 +1738,7 @@ template <int V> __global__ void __launch_bounds__(SOLVE_TPB) k_solve_probe(DV d
 void launch_solve_probe(const DV& d, int variant, int colour, uint32_t est, hipStream_t s)
 {
 	uint32_t blocks = (est + est / 8 + 64 + SOLVE_TPB - 1) / SOLVE_TPB;
+	if (variant == 0) blocks *= 2;      // two lanes per constraint
 	if (blocks > 8192) blocks = 8192;
 	if (variant == 0) hipLaunchKernelGGL(k_solve_probe<0>, dim3(blocks), dim3(SOLVE_TPB), 0, s, d, colour);
 	else if (variant == 1) hipLaunchKernelGGL(k_solve_probe<1>, dim3(blocks), dim3(SOLVE_TPB), 0, s, d, colour);
@@ -1683,10 +1746,24 @@ void launch_solve_probe(const DV& d, int variant, int colour, uint32_t est, hipS
 	else hipLaunchKernelGGL(k_solve_probe<3>, dim3(blocks), dim3(SOLVE_TPB), 0, s, d, colour);
 }
 
-// Tail colours (few constraints each) share ONE launch: a single 512-thread workgroup walks colours first_colour..62 in
-// order with a workgroup barrier in between (ordered exactly like separate launches), then lane 0 solves the overflow
+// Tail colours (few constraints each) share ONE launch: a single workgroup walks colours first_colour..62 in
+// order with a workgroup barrier in between (ordered exactly like separate launches), then solves the overflow
 // colour 63 (a body with > 63 contacts; Jolt's non-parallel split) serially in ascending priority.  Because it covers
 // every colour from first_colour on, it is also the catch-all when this step uses more colours than the plan expected.
+// k_solve_tail: warm start of the overflow colour (mode 0) and position iterations (mode 2), one thread per constraint;
+// k_solve_tail_vel: velocity iterations, two lanes per constraint (768 threads = 384 constraints per phase).
+SGP_DEV uint32_t overflow_next(const DV& d, uint32_t first, uint32_t count, uint64_t& last, bool& have_last)
+{
+	// the overflow constraint with the lowest priority above `last` (selection by scanning: the overflow colour is rare and short)
+	uint64_t best = ~0ull; uint32_t bslot = first;
+	for (uint32_t k = 0; k < count; ++k) {
+		const uint64_t pr = sgp_mix64(CUR(d).key[first + k]);
+		if ((!have_last || pr > last) && pr <= best) { best = pr; bslot = first + k; }
+	}
+	last = best; have_last = true;
+	return bslot;
+}
+
 __global__ void __launch_bounds__(512) k_solve_tail(DV d, int first_colour, int mode)
 {
 	// the colour table in LDS: one coalesced load instead of a dependent global load per (mostly empty) colour
@@ -1694,28 +1771,11 @@ __global__ void __launch_bounds__(512) k_solve_tail(DV d, int first_colour, int 
 	if (threadIdx.x <= SGP_MAX_COLOURS) cs[threadIdx.x] = d.cstarts[threadIdx.x];
 	__syncthreads();
 	if (cs[first_colour] == cs[SGP_MAX_COLOURS]) return;          // nothing from first_colour on (incl. the overflow colour)
-	const uint32_t tail_n = cs[SGP_OVERFLOW_COLOUR] - cs[first_colour];
-	if (mode == 1 && tail_n <= 512u && !(d.dbg_flags & 1u)) {
-		// one constraint per thread, read once up front (all loads in flight together); a colour phase is then only the velocity gather,
-		// the arithmetic and the scatter.  Phases and their order are those of the loop below.
-		const uint32_t slot = cs[first_colour] + threadIdx.x;
-		const bool mine = threadIdx.x < tail_n;
-		ConReg r; int my_col = -1;
-		if (mine) { con_load(d, slot, r); my_col = (r.np_col >> 8) & 0xFF; }
-		for (int c = first_colour; c < SGP_OVERFLOW_COLOUR; ++c) {
-			if (cs[c] == cs[c + 1]) continue;
-			if (my_col == c) con_solve_velocity<4>(r, d.sbody, d.dbg_flags);
-			__syncthreads();
-		}
-		if (mine) con_store(d, slot, r);
-	} else
 	for (int c = first_colour; c < SGP_OVERFLOW_COLOUR; ++c) {
 		const uint32_t b = cs[c], e = cs[c + 1];
 		if (b == e) continue;
 		for (uint32_t k = b + threadIdx.x; k < e; k += 512) {
-			if (mode == 0) warm_start_one(d, k);
-			else if (mode == 1) solve_velocity_one(d, k);
-			else solve_position_one(d, k);
+			if (mode == 0) warm_start_one(d, k); else solve_position_one(d, k);
 		}
 		__syncthreads();      // workgroup scope is enough: all waves of the workgroup share one CU (one L1)
 	}
@@ -1723,15 +1783,47 @@ __global__ void __launch_bounds__(512) k_solve_tail(DV d, int first_colour, int 
 	if (count == 0 || threadIdx.x != 0) return;
 	uint64_t last = 0; bool have_last = false;
 	for (uint32_t it = 0; it < count; ++it) {
-		uint64_t best = ~0ull; uint32_t bslot = first;
-		for (uint32_t k = 0; k < count; ++k) {
-			const uint64_t pr = sgp_mix64(CUR(d).key[first + k]);
-			if ((!have_last || pr > last) && pr <= best) { best = pr; bslot = first + k; }
+		const uint32_t bslot = overflow_next(d, first, count, last, have_last);
+		if (mode == 0) warm_start_one(d, bslot); else solve_position_one(d, bslot);
+	}
+}
+
+#define TAIL_VEL_TPB 768    // 384 constraints per phase; 3 waves per SIMD (a constraint half needs ~150 registers)
+__global__ void __launch_bounds__(TAIL_VEL_TPB) k_solve_tail_vel(DV d, int first_colour)
+{
+	__shared__ uint32_t cs[SGP_MAX_COLOURS + 1];
+	if (threadIdx.x <= SGP_MAX_COLOURS) cs[threadIdx.x] = d.cstarts[threadIdx.x];
+	__syncthreads();
+	if (cs[first_colour] == cs[SGP_MAX_COLOURS]) return;
+	const int side = (int)(threadIdx.x & 1u);
+	const uint32_t pair = threadIdx.x >> 1;
+	const uint32_t tail_n = cs[SGP_OVERFLOW_COLOUR] - cs[first_colour];
+	if (tail_n <= TAIL_VEL_TPB / 2 && !(d.dbg_flags & 1u)) {
+		// one constraint per lane pair, read once up front (all loads in flight together); a colour phase is then only the velocity gather,
+		// the arithmetic and the scatter.  Phases and their order are those of the loop below.
+		const uint32_t slot = cs[first_colour] + pair;
+		const bool mine = pair < tail_n;
+		ConHalf h; int my_col = -1;
+		if (mine) { half_load(d, slot, side, h); my_col = (h.np_col >> 8) & 0xFF; }
+		for (int c = first_colour; c < SGP_OVERFLOW_COLOUR; ++c) {
+			if (cs[c] == cs[c + 1]) continue;
+			if (my_col == c) half_solve<4>(h, side, d.sbody, d.dbg_flags);
+			__syncthreads();
 		}
-		last = best; have_last = true;
-		if (mode == 0) warm_start_one(d, bslot);
-		else if (mode == 1) solve_velocity_one(d, bslot);
-		else solve_position_one(d, bslot);
+		if (mine) half_store(d, slot, side, h);
+	} else
+	for (int c = first_colour; c < SGP_OVERFLOW_COLOUR; ++c) {
+		const uint32_t b = cs[c], e = cs[c + 1];
+		if (b == e) continue;
+		for (uint32_t k = b + pair; k < e; k += TAIL_VEL_TPB / 2) solve_velocity_pair_t<4>(d, k, side, d.sbody);
+		__syncthreads();
+	}
+	const uint32_t first = cs[SGP_OVERFLOW_COLOUR], count = cs[SGP_OVERFLOW_COLOUR + 1] - first;
+	if (count == 0 || threadIdx.x >= 2) return;                   // lanes 0 and 1: the two sides of one constraint at a time
+	uint64_t last = 0; bool have_last = false;
+	for (uint32_t it = 0; it < count; ++it) {
+		const uint32_t bslot = overflow_next(d, first, count, last, have_last);
+		solve_velocity_pair_t<4>(d, bslot, side, d.sbody);
 	}
 }
 
@@ -1741,69 +1833,66 @@ __global__ void __launch_bounds__(512) k_solve_tail(DV d, int first_colour, int 
 // phases are ordered exactly like the separate launches they replace (colour by colour, workgroup barrier in between, overflow
 // colour serially by priority), so the result is bit-identical.
 #define SMALL_LDS_BODIES 2048
-__global__ void __launch_bounds__(512) k_solve_small(DV d, int warm_start, int iterations)
+#define SMALL_TPB 768       // velocity iterations take two lanes per constraint: 384 constraints per phase (12 waves: 3 per SIMD leaves a constraint half its ~150 registers)
+__global__ void __launch_bounds__(SMALL_TPB) k_solve_small(DV d, int warm_start, int iterations)
 {
 	__shared__ float4 sv[2 * SMALL_LDS_BODIES];        // 64 KB: [lin vel, effective inverse mass][ang vel, -] per body slot
 	__shared__ uint32_t cs[SGP_MAX_COLOURS + 1];
 	const uint32_t n = min(d.sp->n_slots, (uint32_t)SMALL_LDS_BODIES);
 	if (threadIdx.x <= SGP_MAX_COLOURS) cs[threadIdx.x] = d.cstarts[threadIdx.x];
-	for (uint32_t i = threadIdx.x; i < 2 * n; i += 512) sv[i] = d.sbody[4 * (size_t)(i >> 1) + (i & 1)];
+	for (uint32_t i = threadIdx.x; i < 2 * n; i += SMALL_TPB) sv[i] = d.sbody[4 * (size_t)(i >> 1) + (i & 1)];
 	__syncthreads();
+	const int side = (int)(threadIdx.x & 1u);
+	const uint32_t pair = threadIdx.x >> 1;
 	const uint32_t all_n = cs[SGP_OVERFLOW_COLOUR];
-	if (all_n != 0 && all_n <= 512u && cs[SGP_OVERFLOW_COLOUR] == cs[SGP_MAX_COLOURS]) {
-		// at most one constraint per thread and no overflow colour: the constraint lives in registers for the whole solve (read once,
+	if (all_n != 0 && all_n <= SMALL_TPB / 2 && cs[SGP_OVERFLOW_COLOUR] == cs[SGP_MAX_COLOURS]) {
+		// at most one constraint per lane pair and no overflow colour: the constraint lives in registers for the whole solve (read once,
 		// lambdas written once), the velocities in LDS; a phase is an LDS gather, the arithmetic and an LDS scatter.  Same phases in
 		// the same order as the general path below.
-		const uint32_t slot = threadIdx.x;
+		const uint32_t slot = pair;
 		const bool mine = slot < all_n;
 		if (warm_start) {
 			for (int c = 0; c < SGP_OVERFLOW_COLOUR; ++c) {
 				const uint32_t b = cs[c], e = cs[c + 1];
 				if (b == e) continue;
-				if (slot >= b && slot < e) warm_start_one_t<2>(d, slot, sv);
+				if (side == 0 && slot >= b && slot < e) warm_start_one_t<2>(d, slot, sv);      // (the warm start is one thread per constraint)
 				__syncthreads();
 			}
 		}
-		ConReg r; int my_col = -1;
-		if (mine) { con_load(d, slot, r); my_col = (r.np_col >> 8) & 0xFF; }
+		ConHalf h; int my_col = -1;
+		if (mine) { half_load(d, slot, side, h); my_col = (h.np_col >> 8) & 0xFF; }
 		for (int pass = 0; pass < iterations; ++pass) {
 			for (int c = 0; c < SGP_OVERFLOW_COLOUR; ++c) {
 				if (cs[c] == cs[c + 1]) continue;
-				if (my_col == c) con_solve_velocity<2>(r, sv, d.dbg_flags);
+				if (my_col == c) half_solve<2>(h, side, sv, d.dbg_flags);
 				__syncthreads();
 			}
 		}
-		if (mine) con_store(d, slot, r);
+		if (mine) half_store(d, slot, side, h);
 	} else
 	if (cs[0] != cs[SGP_MAX_COLOURS]) {
 		for (int pass = warm_start ? -1 : 0; pass < iterations; ++pass) {
 			for (int c = 0; c < SGP_OVERFLOW_COLOUR; ++c) {
 				const uint32_t b = cs[c], e = cs[c + 1];
 				if (b == e) continue;
-				for (uint32_t k = b + threadIdx.x; k < e; k += 512) {
-					if (pass < 0) warm_start_one_t<2>(d, k, sv); else solve_velocity_one_t<2>(d, k, sv);
-				}
+				if (pass < 0) { for (uint32_t k = b + threadIdx.x; k < e; k += SMALL_TPB) warm_start_one_t<2>(d, k, sv); }
+				else { for (uint32_t k = b + pair; k < e; k += SMALL_TPB / 2) solve_velocity_pair_t<2>(d, k, side, sv); }
 				__syncthreads();
 			}
 			const uint32_t first = cs[SGP_OVERFLOW_COLOUR], count = cs[SGP_OVERFLOW_COLOUR + 1] - first;
 			if (count != 0) {
-				if (threadIdx.x == 0) {
+				if (threadIdx.x < 2) {                     // lanes 0 and 1: the two sides of one constraint at a time (the warm start: lane 0 alone)
 					uint64_t last = 0; bool have_last = false;
 					for (uint32_t it = 0; it < count; ++it) {
-						uint64_t best = ~0ull; uint32_t bslot = first;
-						for (uint32_t k = 0; k < count; ++k) {
-							const uint64_t pr = sgp_mix64(CUR(d).key[first + k]);
-							if ((!have_last || pr > last) && pr <= best) { best = pr; bslot = first + k; }
-						}
-						last = best; have_last = true;
-						if (pass < 0) warm_start_one_t<2>(d, bslot, sv); else solve_velocity_one_t<2>(d, bslot, sv);
+						const uint32_t bslot = overflow_next(d, first, count, last, have_last);
+						if (pass < 0) { if (side == 0) warm_start_one_t<2>(d, bslot, sv); } else solve_velocity_pair_t<2>(d, bslot, side, sv);
 					}
 				}
 				__syncthreads();
 			}
 		}
 	}
-	for (uint32_t i = threadIdx.x; i < 2 * n; i += 512) d.sbody[4 * (size_t)(i >> 1) + (i & 1)] = sv[i];
+	for (uint32_t i = threadIdx.x; i < 2 * n; i += SMALL_TPB) d.sbody[4 * (size_t)(i >> 1) + (i & 1)] = sv[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -3210,15 +3299,19 @@ void launch_setup(const DV& d, uint32_t n_man, hipStream_t s)
 }
 void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStream_t s)
 {
-	uint32_t blocks = (est + est / 8 + 64 + SOLVE_TPB - 1) / SOLVE_TPB;
+	uint32_t blocks = (est + est / 8 + 64 + SOLVE_TPB - 1) / SOLVE_TPB;      // 64 constraints per workgroup in every mode (velocity: 128 threads)
 	if (blocks > 8192) blocks = 8192;
 	if (mode == 0) hipLaunchKernelGGL(k_solve_colour<0>, dim3(blocks), dim3(SOLVE_TPB), 0, s, d, colour);
-	else if (mode == 1) hipLaunchKernelGGL(k_solve_colour<1>, dim3(blocks), dim3(SOLVE_TPB), 0, s, d, colour);
+	else if (mode == 1) hipLaunchKernelGGL(k_solve_colour<1>, dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour);
 	else hipLaunchKernelGGL(k_solve_colour<2>, dim3(blocks), dim3(SOLVE_TPB), 0, s, d, colour);
 }
 void launch_warm_bodies(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_warm_bodies, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
-void launch_solve_tail(const DV& d, int first_colour, int mode, hipStream_t s) { hipLaunchKernelGGL(k_solve_tail, dim3(1), dim3(512), 0, s, d, first_colour, mode); }
-void launch_solve_small(const DV& d, int warm_start, int iterations, hipStream_t s) { hipLaunchKernelGGL(k_solve_small, dim3(1), dim3(512), 0, s, d, warm_start, iterations); }
+void launch_solve_tail(const DV& d, int first_colour, int mode, hipStream_t s)
+{
+	if (mode == 1) hipLaunchKernelGGL(k_solve_tail_vel, dim3(1), dim3(TAIL_VEL_TPB), 0, s, d, first_colour);
+	else hipLaunchKernelGGL(k_solve_tail, dim3(1), dim3(512), 0, s, d, first_colour, mode);
+}
+void launch_solve_small(const DV& d, int warm_start, int iterations, hipStream_t s) { hipLaunchKernelGGL(k_solve_small, dim3(1), dim3(SMALL_TPB), 0, s, d, warm_start, iterations); }
 void launch_integrate_pose(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_integrate_pose, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_finalize(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_finalize, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_island_mark(const DV& d, uint32_t n_con, hipStream_t s) { hipLaunchKernelGGL(k_island_mark, dim3(stride_grid(n_con)), dim3(TPB), 0, s, d); }
