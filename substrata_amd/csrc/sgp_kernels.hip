@@ -1686,23 +1686,75 @@ SGP_DEV void solve_position_one(const DV& d, uint32_t slot)
 	}
 }
 
+// The position iteration of one manifold on TWO LANES (side 0 / 1 = body 1 / body 2, neighbouring lanes, both must call it): each lane carries
+// its own body's pose, computes its own contact point and its own share of the effective mass, swaps them with its neighbour, and corrects
+// its own body.  Same operands, same operations as solve_position_one (the effective mass is share of body 1 + share of body 2 there too),
+// hence the same bits -- at about half the instructions per lane, which is what a position launch is made of (4700 of them per manifold).
+SGP_DEV void solve_position_pair(const DV& d, uint32_t slot, int side)
+{
+	const uint2 ab = CUR(d).ab[slot];
+	const float4 nf = CUR(d).n_fric[slot];
+	const v3 nrm = V3(nf);
+	const int np = CUR(d).np_col[slot] & 0xFF;
+	float4* rec = d.sbody + 4 * (size_t)(side ? ab.y : ab.x);      // pose half of this lane's body's solver record (k_integrate_pose)
+	const float4 p4 = rec[0];
+	const float im = p4.w;                                          // effective: 0 unless dynamic and awake
+	quat q = Q4(rec[1]);
+	const v3 ii = V3(rec[2]);
+	v3 pos = V3(p4);
+	bool moved = false;
+	m33 R = quat_to_m33(q);
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		if (i >= np) continue;
+		const v3 mine = v3_add(pos, m33_mul(R, V3(side ? CUR(d).loc2[i][slot] : CUR(d).loc1[i][slot])));
+		const v3 other = V3(__shfl_xor(mine.x, 1, 64), __shfl_xor(mine.y, 1, 64), __shfl_xor(mine.z, 1, 64));
+		const v3 p1 = side ? other : mine, p2 = side ? mine : other;
+		float sep = v3_dot(v3_sub(p2, p1), nrm) + d.st.penetration_slop;
+		if (sep < 0.0f) {
+			sep = fmaxf(sep, -d.st.max_penetration_distance);
+			const v3 mid = v3_scale(v3_add(p1, p2), 0.5f);
+			const v3 r = v3_sub(mid, pos);
+			// this body's share of the inverse effective mass (axis_eff_mass: im + (I (r x n)) . (r x n), 0 for a body that cannot move)
+			v3 Ic = V3(0.0f, 0.0f, 0.0f);
+			float share = 0.0f;
+			if (im > 0.0f) { const v3 c = v3_cross(r, nrm); Ic = sym33_mul(world_inv_inertia(R, ii), c); share = im + v3_dot(Ic, c); }
+			const float oshare = __shfl_xor(share, 1, 64);
+			const float s1 = side ? oshare : share, s2 = side ? share : oshare;
+			// (axis_eff_mass adds body 2's share to body 1's only when body 2 can move, and starts from it when body 1 cannot: x + 0 and 0 + x are exact)
+			const float inv = s1 + s2;
+			const float eff = inv > 0.0f ? 1.0f / inv : 0.0f;
+			if (eff <= 0.0f) continue;
+			const float lambda = -eff * d.st.baumgarte * sep;
+			if (im > 0.0f) {
+				if (side) { pos = v3_add(pos, v3_scale(nrm, lambda * im)); q = quat_add_rotation_step(q, v3_scale(Ic, lambda)); }
+				else      { pos = v3_sub(pos, v3_scale(nrm, lambda * im)); q = quat_add_rotation_step(q, v3_scale(Ic, -lambda)); }
+				R = quat_to_m33(q);
+			}
+			moved = true;
+		}
+	}
+	if (moved && im > 0.0f) { rec[0] = F4(pos, im); rec[1] = make_float4(q.x, q.y, q.z, q.w); }
+}
+
 // One launch = one colour of one pass.  The slot range comes from the device-side colour table, so the host never has
 // to know the counts of the current step; the grid is sized from the previous step and the loop strides over the rest.
 #define SOLVE_TPB 64      // one wave per workgroup: a colour of ~17k constraints then spreads over all 256 CUs instead of 67 of them
 // (velocity iterations: two neighbouring lanes per constraint, half_solve; workgroups of two waves, so that a colour is as many workgroups
 // as it was with one lane per constraint -- twice as many one-wave workgroups took ~1 us longer to dispatch per launch)
 #define SOLVE_VEL_TPB 128
-template <int MODE> __global__ void __launch_bounds__(MODE == 1 ? SOLVE_VEL_TPB : SOLVE_TPB) k_solve_colour(DV d, int colour)
+template <int MODE> __global__ void __launch_bounds__(MODE != 0 ? SOLVE_VEL_TPB : SOLVE_TPB) k_solve_colour(DV d, int colour)
 {
 	const uint32_t first = d.cstarts[colour], end = d.cstarts[colour + 1];
-	if (MODE == 1) {
+	if (MODE != 0) {
+		// velocity and position iterations: two neighbouring lanes per constraint
 		const int side = (int)(threadIdx.x & 1u);
-		for (uint32_t k = first + ((blockIdx.x * SOLVE_VEL_TPB + threadIdx.x) >> 1); k < end; k += gridDim.x * (SOLVE_VEL_TPB / 2)) solve_velocity_pair_t<4>(d, k, side, d.sbody);
+		for (uint32_t k = first + ((blockIdx.x * SOLVE_VEL_TPB + threadIdx.x) >> 1); k < end; k += gridDim.x * (SOLVE_VEL_TPB / 2)) {
+			if (MODE == 1) solve_velocity_pair_t<4>(d, k, side, d.sbody); else solve_position_pair(d, k, side);
+		}
 		return;
 	}
-	for (uint32_t k = first + blockIdx.x * SOLVE_TPB + threadIdx.x; k < end; k += gridDim.x * SOLVE_TPB) {
-		if (MODE == 0) warm_start_one(d, k); else solve_position_one(d, k);
-	}
+	for (uint32_t k = first + blockIdx.x * SOLVE_TPB + threadIdx.x; k < end; k += gridDim.x * SOLVE_TPB) warm_start_one(d, k);
 }
 
 // Timing probe (not part of the step; sgp_debug_time_solve, tools/solve_probe.py): the velocity-iteration launch of one colour with parts
@@ -1789,7 +1841,7 @@ __global__ void __launch_bounds__(512) k_solve_tail(DV d, int first_colour, int 
 }
 
 #define TAIL_VEL_TPB 768    // 384 constraints per phase; 3 waves per SIMD (a constraint half needs ~150 registers)
-__global__ void __launch_bounds__(TAIL_VEL_TPB) k_solve_tail_vel(DV d, int first_colour)
+__global__ void __launch_bounds__(TAIL_VEL_TPB) k_solve_tail_vel(DV d, int first_colour, int mode)
 {
 	__shared__ uint32_t cs[SGP_MAX_COLOURS + 1];
 	if (threadIdx.x <= SGP_MAX_COLOURS) cs[threadIdx.x] = d.cstarts[threadIdx.x];
@@ -1798,7 +1850,7 @@ __global__ void __launch_bounds__(TAIL_VEL_TPB) k_solve_tail_vel(DV d, int first
 	const int side = (int)(threadIdx.x & 1u);
 	const uint32_t pair = threadIdx.x >> 1;
 	const uint32_t tail_n = cs[SGP_OVERFLOW_COLOUR] - cs[first_colour];
-	if (tail_n <= TAIL_VEL_TPB / 2 && !(d.dbg_flags & 1u)) {
+	if (mode == 1 && tail_n <= TAIL_VEL_TPB / 2 && !(d.dbg_flags & 1u)) {
 		// one constraint per lane pair, read once up front (all loads in flight together); a colour phase is then only the velocity gather,
 		// the arithmetic and the scatter.  Phases and their order are those of the loop below.
 		const uint32_t slot = cs[first_colour] + pair;
@@ -1815,7 +1867,7 @@ __global__ void __launch_bounds__(TAIL_VEL_TPB) k_solve_tail_vel(DV d, int first
 	for (int c = first_colour; c < SGP_OVERFLOW_COLOUR; ++c) {
 		const uint32_t b = cs[c], e = cs[c + 1];
 		if (b == e) continue;
-		for (uint32_t k = b + pair; k < e; k += TAIL_VEL_TPB / 2) solve_velocity_pair_t<4>(d, k, side, d.sbody);
+		for (uint32_t k = b + pair; k < e; k += TAIL_VEL_TPB / 2) { if (mode == 1) solve_velocity_pair_t<4>(d, k, side, d.sbody); else solve_position_pair(d, k, side); }
 		__syncthreads();
 	}
 	const uint32_t first = cs[SGP_OVERFLOW_COLOUR], count = cs[SGP_OVERFLOW_COLOUR + 1] - first;
@@ -1823,7 +1875,7 @@ __global__ void __launch_bounds__(TAIL_VEL_TPB) k_solve_tail_vel(DV d, int first
 	uint64_t last = 0; bool have_last = false;
 	for (uint32_t it = 0; it < count; ++it) {
 		const uint32_t bslot = overflow_next(d, first, count, last, have_last);
-		solve_velocity_pair_t<4>(d, bslot, side, d.sbody);
+		if (mode == 1) solve_velocity_pair_t<4>(d, bslot, side, d.sbody); else solve_position_pair(d, bslot, side);
 	}
 }
 
@@ -3303,12 +3355,12 @@ void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStr
 	if (blocks > 8192) blocks = 8192;
 	if (mode == 0) hipLaunchKernelGGL(k_solve_colour<0>, dim3(blocks), dim3(SOLVE_TPB), 0, s, d, colour);
 	else if (mode == 1) hipLaunchKernelGGL(k_solve_colour<1>, dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour);
-	else hipLaunchKernelGGL(k_solve_colour<2>, dim3(blocks), dim3(SOLVE_TPB), 0, s, d, colour);
+	else hipLaunchKernelGGL(k_solve_colour<2>, dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour);
 }
 void launch_warm_bodies(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_warm_bodies, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_solve_tail(const DV& d, int first_colour, int mode, hipStream_t s)
 {
-	if (mode == 1) hipLaunchKernelGGL(k_solve_tail_vel, dim3(1), dim3(TAIL_VEL_TPB), 0, s, d, first_colour);
+	if (mode == 1) hipLaunchKernelGGL(k_solve_tail_vel, dim3(1), dim3(TAIL_VEL_TPB), 0, s, d, first_colour, mode);      // (position passes of the tail: one thread per constraint measured faster, 30 against 37 us)
 	else hipLaunchKernelGGL(k_solve_tail, dim3(1), dim3(512), 0, s, d, first_colour, mode);
 }
 void launch_solve_small(const DV& d, int warm_start, int iterations, hipStream_t s) { hipLaunchKernelGGL(k_solve_small, dim3(1), dim3(SMALL_TPB), 0, s, d, warm_start, iterations); }
