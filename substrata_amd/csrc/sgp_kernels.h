@@ -265,7 +265,7 @@ void launch_warm_bodies(const DV& d, uint32_t nb, hipStream_t s);
 void launch_solve_tail(const DV& d, int first_colour, int mode, hipStream_t s);
 // small worlds: warm start + all velocity iterations in one single-workgroup launch (needs n_slots <= SGP_SMALL_WORLD_BODIES)
 #define SGP_SMALL_WORLD_BODIES 2048
-void launch_solve_small(const DV& d, int warm_start, int iterations, hipStream_t s);
+void launch_solve_small(const DV& d, int warm_start, int iterations, int lane_pairs, hipStream_t s);      // lane_pairs: two lanes per constraint (<= 384 constraints stay in registers), else one (<= 512)
 void launch_integrate_pose(const DV& d, uint32_t nb, hipStream_t s);
 void launch_finalize(const DV& d, uint32_t nb, hipStream_t s);
 void launch_island_mark(const DV& d, uint32_t n_con, hipStream_t s);

@@ -1517,12 +1517,12 @@ SGP_DEV void rows_apply(BodyVel& A, BodyVel& B, float im1, float im2, v3 axis, c
 struct ConHalf {
 	uint32_t body;          // this lane's body
 	float4 nf; int np_col;
-	float4 c[4][3];         // r x axis of this lane's body for (point, axis n / t1 / t2)
-	float4 iv[4][3];        // I (r x axis) of this lane's body
+	v3     c[4][3];         // r x axis of this lane's body for (point, axis n / t1 / t2)
+	v3     iv[4][3];        // I (r x axis) of this lane's body
 	float  eff[4][3];       // effective mass of the row (both lanes)
 	float  bias[4];         // of the normal row (both lanes)
 	v3     t1;              // first friction direction (both lanes)
-	float4 lam[4];
+	v3     lam[4];          // accumulated impulses n, t1, t2
 };
 
 SGP_DEV void half_load_rows(const DV& d, uint32_t slot, int side, ConHalf& h)
@@ -1535,23 +1535,21 @@ SGP_DEV void half_load_rows(const DV& d, uint32_t slot, int side, ConHalf& h)
 #pragma unroll
 			for (int a = 0; a < 3; ++a) {
 				const float4* p = axis_rows(d, slot, i, a);
-				h.c[i][a] = p[(size_t)side * st];               // lane 0: r1 x axis (w: bias of the normal row); lane 1: r2 x axis (w: effective mass)
-				h.iv[i][a] = p[(size_t)(2 + side) * st];         // I1 (r1 x axis) / I2 (r2 x axis) (w of point 0: the stored tangent, see k_setup)
+				const float4 c4 = p[(size_t)side * st];          // lane 0: r1 x axis (w: bias of the normal row); lane 1: r2 x axis (w: effective mass)
+				const float4 i4 = p[(size_t)(2 + side) * st];    // I1 (r1 x axis) / I2 (r2 x axis) (w of point 0: the stored tangent, see k_setup)
+				h.c[i][a] = V3(c4); h.iv[i][a] = V3(i4);
+				// what the other lane holds in its .w components: effective masses (lane 1), the bias (lane 0), the tangent (x, z: lane 0; y: lane 1)
+				const float ow = __shfl_xor(c4.w, 1, 64);
+				h.eff[i][a] = side ? c4.w : ow;
+				if (a == 0) h.bias[i] = side ? ow : c4.w;
+				if (i == 0 && a < 2) {
+					const float oi = __shfl_xor(i4.w, 1, 64);
+					if (a == 0) { h.t1.x = side ? oi : i4.w; h.t1.y = side ? i4.w : oi; } else h.t1.z = side ? oi : i4.w;
+				}
 			}
-			h.lam[i] = CUR(d).lam[i][slot];
+			const float4 l4 = CUR(d).lam[i][slot];
+			h.lam[i] = V3(l4);
 		}
-	}
-	// what the other lane holds in its .w components: effective masses (lane 1), the bias (lane 0), the tangent (x, z: lane 0; y: lane 1)
-#pragma unroll
-	for (int i = 0; i < 4; ++i) {
-		if (i < np) {
-#pragma unroll
-			for (int a = 0; a < 3; ++a) { const float mine = h.c[i][a].w, other = __shfl_xor(mine, 1, 64); h.eff[i][a] = side ? mine : other; if (a == 0) h.bias[i] = side ? other : mine; }
-		}
-	}
-	if (np > 0) {
-		const float a0 = h.iv[0][0].w, b0 = __shfl_xor(a0, 1, 64), a1 = h.iv[0][1].w, b1 = __shfl_xor(a1, 1, 64);
-		h.t1 = V3(side ? b0 : a0, side ? a0 : b0, side ? b1 : a1);
 	}
 }
 
@@ -1569,21 +1567,21 @@ SGP_DEV void half_store(const DV& d, uint32_t slot, int side, const ConHalf& h)
 	if (side) return;
 	const int np = h.np_col & 0xFF;
 #pragma unroll
-	for (int i = 0; i < 4; ++i) { if (i < np) CUR(d).lam[i][slot] = h.lam[i]; }
+	for (int i = 0; i < 4; ++i) { if (i < np) CUR(d).lam[i][slot] = F4(h.lam[i], 0.0f); }
 }
 
 // this body's share of J v for one row, the neighbour's share, their difference (share of body 1 minus share of body 2: identical on both lanes)
-SGP_DEV float half_jv(v3 lv, v3 av, v3 axis, float4 c, int side)
+SGP_DEV float half_jv(v3 lv, v3 av, v3 axis, v3 c, int side)
 {
-	const float mine = v3_dot(axis, lv) + v3_dot(V3(c), av);
+	const float mine = v3_dot(axis, lv) + v3_dot(c, av);
 	const float other = __shfl_xor(mine, 1, 64);
 	return side ? other - mine : mine - other;
 }
-SGP_DEV void half_apply(v3& lv, v3& av, float im, v3 axis, float4 iv, float lambda, int side)
+SGP_DEV void half_apply(v3& lv, v3& av, float im, v3 axis, v3 iv, float lambda, int side)
 {
 	if (!(im > 0.0f)) return;
-	if (side) { lv = v3_add(lv, v3_scale(axis, lambda * im)); av = v3_add(av, v3_scale(V3(iv), lambda)); }
-	else      { lv = v3_sub(lv, v3_scale(axis, lambda * im)); av = v3_sub(av, v3_scale(V3(iv), lambda)); }
+	if (side) { lv = v3_add(lv, v3_scale(axis, lambda * im)); av = v3_add(av, v3_scale(iv, lambda)); }
+	else      { lv = v3_sub(lv, v3_scale(axis, lambda * im)); av = v3_sub(av, v3_scale(iv, lambda)); }
 }
 
 // One contact manifold, one velocity iteration (ContactConstraintManager::SolveVelocityConstraints): friction rows of every point first (they
@@ -1841,7 +1839,7 @@ __global__ void __launch_bounds__(512) k_solve_tail(DV d, int first_colour, int 
 }
 
 #define TAIL_VEL_TPB 768    // 384 constraints per phase; 3 waves per SIMD (a constraint half needs ~150 registers)
-__global__ void __launch_bounds__(TAIL_VEL_TPB) k_solve_tail_vel(DV d, int first_colour, int mode)
+__global__ void __launch_bounds__(TAIL_VEL_TPB) k_solve_tail_vel(DV d, int first_colour)
 {
 	__shared__ uint32_t cs[SGP_MAX_COLOURS + 1];
 	if (threadIdx.x <= SGP_MAX_COLOURS) cs[threadIdx.x] = d.cstarts[threadIdx.x];
@@ -1850,7 +1848,7 @@ __global__ void __launch_bounds__(TAIL_VEL_TPB) k_solve_tail_vel(DV d, int first
 	const int side = (int)(threadIdx.x & 1u);
 	const uint32_t pair = threadIdx.x >> 1;
 	const uint32_t tail_n = cs[SGP_OVERFLOW_COLOUR] - cs[first_colour];
-	if (mode == 1 && tail_n <= TAIL_VEL_TPB / 2 && !(d.dbg_flags & 1u)) {
+	if (tail_n <= TAIL_VEL_TPB / 2 && !(d.dbg_flags & 1u)) {
 		// one constraint per lane pair, read once up front (all loads in flight together); a colour phase is then only the velocity gather,
 		// the arithmetic and the scatter.  Phases and their order are those of the loop below.
 		const uint32_t slot = cs[first_colour] + pair;
@@ -1867,7 +1865,7 @@ __global__ void __launch_bounds__(TAIL_VEL_TPB) k_solve_tail_vel(DV d, int first
 	for (int c = first_colour; c < SGP_OVERFLOW_COLOUR; ++c) {
 		const uint32_t b = cs[c], e = cs[c + 1];
 		if (b == e) continue;
-		for (uint32_t k = b + pair; k < e; k += TAIL_VEL_TPB / 2) { if (mode == 1) solve_velocity_pair_t<4>(d, k, side, d.sbody); else solve_position_pair(d, k, side); }
+		for (uint32_t k = b + pair; k < e; k += TAIL_VEL_TPB / 2) solve_velocity_pair_t<4>(d, k, side, d.sbody);
 		__syncthreads();
 	}
 	const uint32_t first = cs[SGP_OVERFLOW_COLOUR], count = cs[SGP_OVERFLOW_COLOUR + 1] - first;
@@ -1875,7 +1873,7 @@ __global__ void __launch_bounds__(TAIL_VEL_TPB) k_solve_tail_vel(DV d, int first
 	uint64_t last = 0; bool have_last = false;
 	for (uint32_t it = 0; it < count; ++it) {
 		const uint32_t bslot = overflow_next(d, first, count, last, have_last);
-		if (mode == 1) solve_velocity_pair_t<4>(d, bslot, side, d.sbody); else solve_position_pair(d, bslot, side);
+		solve_velocity_pair_t<4>(d, bslot, side, d.sbody);
 	}
 }
 
@@ -1945,6 +1943,150 @@ __global__ void __launch_bounds__(SMALL_TPB) k_solve_small(DV d, int warm_start,
 		}
 	}
 	for (uint32_t i = threadIdx.x; i < 2 * n; i += SMALL_TPB) d.sbody[4 * (size_t)(i >> 1) + (i & 1)] = sv[i];
+}
+
+// The small-world solve with ONE THREAD PER CONSTRAINT (512 threads, the constraint's ~240 registers in one lane): for worlds of 385..512
+// constraints, which the lane-pair kernel above cannot keep in registers (768 threads x 2 lanes = 384 constraints) and would re-read from
+// memory in every phase (measured on 427 constraints: 0.36 ms against 0.26 ms for this kernel; below 385 the lane pairs win by 4-8 %).
+// Same phases, same operands, same operations: the two kernels produce the same bits.
+// A constraint held in registers: loaded once (con_load), iterated any number of times (con_solve_velocity: only the two bodies'
+// velocities are gathered and scattered), lambdas written back at the end (con_store).  solve_velocity_one_t is the three in a row; the
+// single-workgroup kernels (tail colours, small worlds) keep the record across their colour phases / iterations instead of re-reading it.
+struct ConReg { uint2 ab; float4 nf; int np_col; AxisRows rn[4], rt1[4], rt2[4]; float4 lam[4]; };
+
+SGP_DEV void con_load(const DV& d, uint32_t slot, ConReg& r)
+{
+	r.ab = CUR(d).ab[slot];
+	r.nf = CUR(d).n_fric[slot];
+	r.np_col = CUR(d).np_col[slot];
+	const int np = r.np_col & 0xFF;
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		if (i < np) {
+			r.rn[i] = load_axis_rows(d, slot, i, 0); r.rt1[i] = load_axis_rows(d, slot, i, 1); r.rt2[i] = load_axis_rows(d, slot, i, 2);
+			r.lam[i] = CUR(d).lam[i][slot];
+		}
+	}
+}
+
+SGP_DEV void con_store(const DV& d, uint32_t slot, const ConReg& r)
+{
+	const int np = r.np_col & 0xFF;
+#pragma unroll
+	for (int i = 0; i < 4; ++i) { if (i < np) CUR(d).lam[i][slot] = r.lam[i]; }
+}
+
+template <int VS> SGP_DEV void con_solve_velocity(ConReg& r, float4* vel, uint32_t dbg = 0)
+{
+	const uint2 ab = r.ab;
+	const int np = r.np_col & 0xFF;
+	if (np == 0) return;                    // a sensor pair: kept in the contact list, nothing to solve
+	const float4 va = vel[VS * (size_t)ab.x], wa = vel[VS * (size_t)ab.x + 1];
+	const float4 vb = vel[VS * (size_t)ab.y], wb = vel[VS * (size_t)ab.y + 1];
+	const float im1 = va.w, im2 = vb.w, friction = r.nf.w;
+	BodyVel A, B;
+	A.lv = V3(va); A.av = V3(wa); B.lv = V3(vb); B.av = V3(wb);
+	const v3 n = V3(r.nf);
+	const v3 t1 = (dbg & 2u) ? v3_normalized_perpendicular(n) : V3(r.rn[0].i1.w, r.rn[0].i2.w, r.rt1[0].i1.w);      // = v3_normalized_perpendicular(n), stored by k_setup (np >= 1 here)
+	const v3 t2 = v3_cross(n, t1);
+	if (friction > 0.0f) {
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			if (i < np && !(r.rt1[i].c2.w <= 0.0f && r.rt2[i].c2.w <= 0.0f)) {
+				float l1 = r.lam[i].y + r.rt1[i].c2.w * rows_jv(A, B, t1, r.rt1[i]);
+				float l2 = r.lam[i].z + r.rt2[i].c2.w * rows_jv(A, B, t2, r.rt2[i]);
+				const float max_f = friction * r.lam[i].x;
+				const float tot_sq = l1 * l1 + l2 * l2;
+				if (tot_sq > max_f * max_f) { const float sc = max_f / sqrtf(tot_sq); l1 = l1 * sc; l2 = l2 * sc; }
+				rows_apply(A, B, im1, im2, t1, r.rt1[i], l1 - r.lam[i].y); r.lam[i].y = l1;
+				rows_apply(A, B, im1, im2, t2, r.rt2[i], l2 - r.lam[i].z); r.lam[i].z = l2;
+			}
+		}
+	}
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		if (i < np && r.rn[i].c2.w > 0.0f) {
+			const float jv = rows_jv(A, B, n, r.rn[i]);
+			const float lambda = r.rn[i].c2.w * (jv - r.rn[i].c1.w);
+			const float nl = max0f(r.lam[i].x + lambda);
+			rows_apply(A, B, im1, im2, n, r.rn[i], nl - r.lam[i].x);
+			r.lam[i].x = nl;
+		}
+	}
+	if (im1 > 0.0f) { vel[VS * (size_t)ab.x] = F4(A.lv, im1); vel[VS * (size_t)ab.x + 1] = F4(A.av, 0.0f); }
+	if (im2 > 0.0f) { vel[VS * (size_t)ab.y] = F4(B.lv, im2); vel[VS * (size_t)ab.y + 1] = F4(B.av, 0.0f); }
+}
+
+template <int VS> SGP_DEV void solve_velocity_one_t(const DV& d, uint32_t slot, float4* vel)
+{
+	ConReg r;
+	con_load(d, slot, r);
+	con_solve_velocity<VS>(r, vel, d.dbg_flags);
+	con_store(d, slot, r);
+}
+__global__ void __launch_bounds__(512) k_solve_small_single(DV d, int warm_start, int iterations)
+{
+	__shared__ float4 sv[2 * SMALL_LDS_BODIES];        // 64 KB: [lin vel, effective inverse mass][ang vel, -] per body slot
+	__shared__ uint32_t cs[SGP_MAX_COLOURS + 1];
+	const uint32_t n = min(d.sp->n_slots, (uint32_t)SMALL_LDS_BODIES);
+	if (threadIdx.x <= SGP_MAX_COLOURS) cs[threadIdx.x] = d.cstarts[threadIdx.x];
+	for (uint32_t i = threadIdx.x; i < 2 * n; i += 512) sv[i] = d.sbody[4 * (size_t)(i >> 1) + (i & 1)];
+	__syncthreads();
+	const uint32_t all_n = cs[SGP_OVERFLOW_COLOUR];
+	if (all_n != 0 && all_n <= 512u && cs[SGP_OVERFLOW_COLOUR] == cs[SGP_MAX_COLOURS]) {
+		// at most one constraint per thread and no overflow colour: the constraint lives in registers for the whole solve (read once,
+		// lambdas written once), the velocities in LDS; a phase is an LDS gather, the arithmetic and an LDS scatter.  Same phases in
+		// the same order as the general path below.
+		const uint32_t slot = threadIdx.x;
+		const bool mine = slot < all_n;
+		if (warm_start) {
+			for (int c = 0; c < SGP_OVERFLOW_COLOUR; ++c) {
+				const uint32_t b = cs[c], e = cs[c + 1];
+				if (b == e) continue;
+				if (slot >= b && slot < e) warm_start_one_t<2>(d, slot, sv);
+				__syncthreads();
+			}
+		}
+		ConReg r; int my_col = -1;
+		if (mine) { con_load(d, slot, r); my_col = (r.np_col >> 8) & 0xFF; }
+		for (int pass = 0; pass < iterations; ++pass) {
+			for (int c = 0; c < SGP_OVERFLOW_COLOUR; ++c) {
+				if (cs[c] == cs[c + 1]) continue;
+				if (my_col == c) con_solve_velocity<2>(r, sv, d.dbg_flags);
+				__syncthreads();
+			}
+		}
+		if (mine) con_store(d, slot, r);
+	} else
+	if (cs[0] != cs[SGP_MAX_COLOURS]) {
+		for (int pass = warm_start ? -1 : 0; pass < iterations; ++pass) {
+			for (int c = 0; c < SGP_OVERFLOW_COLOUR; ++c) {
+				const uint32_t b = cs[c], e = cs[c + 1];
+				if (b == e) continue;
+				for (uint32_t k = b + threadIdx.x; k < e; k += 512) {
+					if (pass < 0) warm_start_one_t<2>(d, k, sv); else solve_velocity_one_t<2>(d, k, sv);
+				}
+				__syncthreads();
+			}
+			const uint32_t first = cs[SGP_OVERFLOW_COLOUR], count = cs[SGP_OVERFLOW_COLOUR + 1] - first;
+			if (count != 0) {
+				if (threadIdx.x == 0) {
+					uint64_t last = 0; bool have_last = false;
+					for (uint32_t it = 0; it < count; ++it) {
+						uint64_t best = ~0ull; uint32_t bslot = first;
+						for (uint32_t k = 0; k < count; ++k) {
+							const uint64_t pr = sgp_mix64(CUR(d).key[first + k]);
+							if ((!have_last || pr > last) && pr <= best) { best = pr; bslot = first + k; }
+						}
+						last = best; have_last = true;
+						if (pass < 0) warm_start_one_t<2>(d, bslot, sv); else solve_velocity_one_t<2>(d, bslot, sv);
+					}
+				}
+				__syncthreads();
+			}
+		}
+	}
+	for (uint32_t i = threadIdx.x; i < 2 * n; i += 512) d.sbody[4 * (size_t)(i >> 1) + (i & 1)] = sv[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -3360,10 +3502,14 @@ void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStr
 void launch_warm_bodies(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_warm_bodies, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_solve_tail(const DV& d, int first_colour, int mode, hipStream_t s)
 {
-	if (mode == 1) hipLaunchKernelGGL(k_solve_tail_vel, dim3(1), dim3(TAIL_VEL_TPB), 0, s, d, first_colour, mode);      // (position passes of the tail: one thread per constraint measured faster, 30 against 37 us)
+	if (mode == 1) hipLaunchKernelGGL(k_solve_tail_vel, dim3(1), dim3(TAIL_VEL_TPB), 0, s, d, first_colour);      // (position passes of the tail: one thread per constraint measured faster, 30 against 37 us)
 	else hipLaunchKernelGGL(k_solve_tail, dim3(1), dim3(512), 0, s, d, first_colour, mode);
 }
-void launch_solve_small(const DV& d, int warm_start, int iterations, hipStream_t s) { hipLaunchKernelGGL(k_solve_small, dim3(1), dim3(SMALL_TPB), 0, s, d, warm_start, iterations); }
+void launch_solve_small(const DV& d, int warm_start, int iterations, int lane_pairs, hipStream_t s)
+{
+	if (lane_pairs) hipLaunchKernelGGL(k_solve_small, dim3(1), dim3(SMALL_TPB), 0, s, d, warm_start, iterations);
+	else hipLaunchKernelGGL(k_solve_small_single, dim3(1), dim3(512), 0, s, d, warm_start, iterations);
+}
 void launch_integrate_pose(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_integrate_pose, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_finalize(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_finalize, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_island_mark(const DV& d, uint32_t n_con, hipStream_t s) { hipLaunchKernelGGL(k_island_mark, dim3(stride_grid(n_con)), dim3(TPB), 0, s, d); }

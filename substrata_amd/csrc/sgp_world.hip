@@ -941,6 +941,7 @@ struct StepPlan {
 	int      has_hulls;          // some body may be a convex hull: run the hull-pair narrow phase
 	int      small_colouring;    // the whole colouring in one single-workgroup launch (k_colour_finish builds its own worklist)
 	int      small_world;        // warm start + velocity iterations as ONE single-workgroup launch (k_solve_small)
+	int      small_pairs;        // ... with two lanes per constraint (the previous step had <= 384 constraints), else one thread per constraint
 	StepParams sp;               // by-value kernel argument of the first launch: part of the key of a captured graph
 };
 
@@ -969,6 +970,7 @@ static void make_plan(const sgp_world* w, StepPlan& p)
 	p.has_meshes = w->meshes.size() > 1 ? 1 : 0;
 	p.small_colouring = (w->last_manifolds <= SGP_SMALL_COLOURING_MANIFOLDS && w->high <= SGP_SMALL_WORLD_BODIES) ? 1 : 0;
 	p.small_world = (tf == 0 && w->high <= SGP_SMALL_WORLD_BODIES && w->n_vehicles == 0 && w->use_small_world) ? 1 : 0;
+	p.small_pairs = (w->n_con <= 384u || w->n_con > 512u) ? 1 : 0;
 	p.sp = *w->h_sp;
 }
 
@@ -1018,7 +1020,7 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 		for (int c = 0; c < p.tail_first; ++c) { KScope k(w, kc); launch_solve_colour(d, c, p.colour_est[c], mode, s); }
 		{ KScope k(w, kc); launch_solve_tail(d, p.tail_first, mode, s); }
 	};
-	if (p.small_world) { KScope k(w, KC_SOLVE_VELOCITY); launch_solve_small(d, p.warm_start, p.vel_iters, s); }
+	if (p.small_world) { KScope k(w, KC_SOLVE_VELOCITY); launch_solve_small(d, p.warm_start, p.vel_iters, p.small_pairs, s); }
 	else {
 		if (p.warm_start) {
 			// vehicle rows first, then every contact constraint of the regular colours (one launch, by body), then the overflow colour

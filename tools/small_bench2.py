@@ -5,7 +5,8 @@ sys.path.insert(0, ROOT)
 import numpy as np
 from substrata_amd import scenes
 from substrata_amd.lib import World
-descs = scenes.config1_256_boxes()
+layers = int(os.environ.get("SMALL_LAYERS", "4"))      # 8 x 8 x layers boxes (4 = BASELINE config 1)
+descs = np.concatenate([scenes.ground(), scenes.lattice(8, 8, layers, 1.5, 1.0, seed=1)[0]])
 descs["allow_sleeping"] = 0
 for graphs in ("0", "1"):
     os.environ["SGP_NO_GRAPH"] = graphs
