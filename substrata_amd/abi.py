@@ -82,7 +82,8 @@ class StepStats(C.Structure):
                 ("num_contact_points", u32), ("num_colours", u32), ("num_colour_rounds", u32),
                 ("num_overflow_constraints", u32), ("pairs_dropped", u32), ("manifolds_dropped", u32),
                 ("num_activated", u32), ("num_deactivated", u32), ("layer_counts", u32 * NUM_LAYERS),
-                ("num_cached_manifolds", u32), ("reserved_", u32), ("device_bytes", u64)]
+                ("num_cached_manifolds", u32), ("num_component_constraints", u32), ("num_catch_all_constraints", u32),
+                ("reserved_", u32), ("device_bytes", u64)]
 
 
 NUM_KERNEL_CLASSES = 32

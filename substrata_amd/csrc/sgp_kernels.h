@@ -75,6 +75,11 @@ struct StepCounters {
 	uint32_t n_read_active;
 	uint32_t n_export;
 	uint32_t n_mesh_pairs;       // pairs with a static mesh, deferred to k_narrowphase_mesh
+	uint32_t hc_class[9];        // high-colour components per size class (k_hc_alloc)
+	uint32_t hc_entries;         // entries of the component list (classes padded to whole workgroups)
+	uint32_t hc_n;               // constraints of the high colours
+	uint32_t hc_n_big;           // ... of them in components too large for a workgroup (solved by the catch-all)
+	uint32_t hc_done;            // workgroups of the running solve launch that have finished (the last one runs the catch-all and clears it)
 	uint32_t round_n[32];        // uncoloured manifolds at the start of colouring round r (the host plans the next step's wide rounds from it)
 	uint32_t colour_count[SGP_MAX_COLOURS];
 	uint32_t colour_fill[SGP_MAX_COLOURS];
@@ -208,6 +213,14 @@ struct DV {
 	uint32_t* man_slot;        // constraint slot of the manifold (k_setup_slots)
 	uint32_t* man_prev;        // slot of the same pair's constraint in the previous step's buffer (MAN_PREV_NONE if none), bit 31: the manifold was
 	                           // taken from the body-pair contact cache (k_narrowphase) -- one hash look-up per manifold, shared by every later kernel
+	// high colours by connected component (k_hc_*)
+	uint32_t* hc_root;         // [cap_bodies] union-find parent (bodies of the high colours that can move)
+	uint32_t* hc_count;        // [cap_bodies] constraints of the component (at its root)
+	uint32_t* hc_base;         // [cap_bodies] class << 28 | index within the class (at its root), HC_BIG: catch-all
+	uint32_t* hc_rank;         // [cap_manifolds] rank of the constraint within its component
+	uint32_t* hc_list;         // constraint slot per lane pair of the solve launch (k_hc_scatter) ...
+	uint2*    hc_entry;        // ... ordered by colour within a workgroup's share, with the constraint's np_col (k_hc_sort): what k_solve_hc reads
+	uint32_t  cap_hc_list;
 	// constraints
 	uint32_t dbg_flags;        // SGP_DEBUG_FLAGS (developer switches): bit 0 = tail kernel without its register-resident path
 	float4* rows;              // velocity-iteration rows, [point 0..3][axis n,t1,t2][4][cap_manifolds] (k_setup): r1 x axis (w: bias for n),
@@ -265,6 +278,8 @@ void launch_warm_bodies(const DV& d, uint32_t nb, hipStream_t s);
 void launch_solve_tail(const DV& d, int first_colour, int mode, hipStream_t s);
 // small worlds: warm start + all velocity iterations in one single-workgroup launch (needs n_slots <= SGP_SMALL_WORLD_BODIES)
 #define SGP_SMALL_WORLD_BODIES 2048
+void launch_hc_build(const DV& d, int first_colour, uint32_t est, hipStream_t s);      // components of the colours >= first_colour (after launch_setup)
+void launch_solve_hc(const DV& d, int first_colour, uint32_t est, int mode, hipStream_t s);   // one pass over them + the overflow colour
 void launch_solve_small(const DV& d, int warm_start, int iterations, int lane_pairs, hipStream_t s);      // lane_pairs: two lanes per constraint (<= 384 constraints stay in registers), else one (<= 512)
 void launch_integrate_pose(const DV& d, uint32_t nb, hipStream_t s);
 void launch_finalize(const DV& d, uint32_t nb, hipStream_t s);

@@ -964,6 +964,7 @@ __global__ void __launch_bounds__(TPB) k_pre_solve(DV d)
 		w.x = av.x; w.y = av.y; w.z = av.z;
 	}
 	d.sbody[4 * i + 0] = v; d.sbody[4 * i + 1] = w; d.sbody[4 * i + 2] = a; d.sbody[4 * i + 3] = b;
+	d.hc_root[i] = i; d.hc_count[i] = 0u;      // every body a component of its own (k_hc_hook joins them along the high-colour constraints)
 	// remember whether the body was movable when the previous step coloured its constraints (colour inheritance)
 	uint32_t nf = f & ~(BF_MOVABLE_PREV | BF_MOVABLE_CUR | BF_CACHE_INVALID);      // (the narrow phase of this step has seen the flag)
 	if (f & BF_MOVABLE_CUR) nf |= BF_MOVABLE_PREV;
@@ -989,7 +990,7 @@ __global__ void __launch_bounds__(TPB) k_colour_inherit(DV d)
 		// the one hash probe per manifold (unless the narrow phase already made it for a contact-cache attempt): every later kernel reads man_prev
 		uint32_t mp = d.man_prev[m];
 		if (mp == MAN_PREV_LOOKUP) { const uint32_t f = cache_find(d, ((uint64_t)ab.x << 32) | ab.y); mp = f == 0xFFFFFFFFu ? MAN_PREV_NONE : f; d.man_prev[m] = mp; }
-		if (d.man_colour[m] != -1) continue;
+		if (d.man_colour[m] != -1) continue;      // (debug bit 2: no colour inheritance -- every manifold goes through the rounds)
 		const uint32_t ps = mp & ~MAN_PREV_REUSED;
 		if (ps == MAN_PREV_NONE) continue;
 		const int pc = (PRV(d).np_col[ps] >> 8) & 0xFF;
@@ -1553,14 +1554,15 @@ SGP_DEV void half_load_rows(const DV& d, uint32_t slot, int side, ConHalf& h)
 	}
 }
 
-SGP_DEV void half_load(const DV& d, uint32_t slot, int side, ConHalf& h)
+SGP_DEV void half_load_np(const DV& d, uint32_t slot, int side, int np_col, ConHalf& h)      // (np_col already known: the row loads need not wait for it)
 {
 	const uint2 ab = CUR(d).ab[slot];
 	h.body = side ? ab.y : ab.x;
 	h.nf = CUR(d).n_fric[slot];
-	h.np_col = CUR(d).np_col[slot];
+	h.np_col = np_col;
 	half_load_rows(d, slot, side, h);
 }
+SGP_DEV void half_load(const DV& d, uint32_t slot, int side, ConHalf& h) { half_load_np(d, slot, side, CUR(d).np_col[slot], h); }
 
 SGP_DEV void half_store(const DV& d, uint32_t slot, int side, const ConHalf& h)
 {
@@ -1688,13 +1690,26 @@ SGP_DEV void solve_position_one(const DV& d, uint32_t slot)
 // its own body's pose, computes its own contact point and its own share of the effective mass, swaps them with its neighbour, and corrects
 // its own body.  Same operands, same operations as solve_position_one (the effective mass is share of body 1 + share of body 2 there too),
 // hence the same bits -- at about half the instructions per lane, which is what a position launch is made of (4700 of them per manifold).
+SGP_DEV void solve_position_pair_at(const DV& d, uint32_t slot, int side, float4* rec);
 SGP_DEV void solve_position_pair(const DV& d, uint32_t slot, int side)
 {
 	const uint2 ab = CUR(d).ab[slot];
-	const float4 nf = CUR(d).n_fric[slot];
-	const v3 nrm = V3(nf);
-	const int np = CUR(d).np_col[slot] & 0xFF;
-	float4* rec = d.sbody + 4 * (size_t)(side ? ab.y : ab.x);      // pose half of this lane's body's solver record (k_integrate_pose)
+	solve_position_pair_at(d, slot, side, d.sbody + 4 * (size_t)(side ? ab.y : ab.x));      // pose half of this lane's body's solver record (k_integrate_pose)
+}
+// What a position iteration reads of the constraint itself (this lane's side): loaded once, iterated any number of times.
+struct PosHalf { float4 nf; int np; v3 loc[4]; };
+SGP_DEV void pos_half_load(const DV& d, uint32_t slot, int side, int np_col, PosHalf& ph)
+{
+	ph.nf = CUR(d).n_fric[slot];
+	ph.np = np_col & 0xFF;
+#pragma unroll
+	for (int i = 0; i < 4; ++i) if (i < ph.np) ph.loc[i] = V3(side ? CUR(d).loc2[i][slot] : CUR(d).loc1[i][slot]);
+}
+// (rec: where this lane's body's record lives -- the global one, or a workgroup's copy in LDS)
+SGP_DEV void pos_half_solve(const DV& d, const PosHalf& ph, int side, float4* rec)
+{
+	const v3 nrm = V3(ph.nf);
+	const int np = ph.np;
 	const float4 p4 = rec[0];
 	const float im = p4.w;                                          // effective: 0 unless dynamic and awake
 	quat q = Q4(rec[1]);
@@ -1705,7 +1720,7 @@ SGP_DEV void solve_position_pair(const DV& d, uint32_t slot, int side)
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
 		if (i >= np) continue;
-		const v3 mine = v3_add(pos, m33_mul(R, V3(side ? CUR(d).loc2[i][slot] : CUR(d).loc1[i][slot])));
+		const v3 mine = v3_add(pos, m33_mul(R, ph.loc[i]));
 		const v3 other = V3(__shfl_xor(mine.x, 1, 64), __shfl_xor(mine.y, 1, 64), __shfl_xor(mine.z, 1, 64));
 		const v3 p1 = side ? other : mine, p2 = side ? mine : other;
 		float sep = v3_dot(v3_sub(p2, p1), nrm) + d.st.penetration_slop;
@@ -1733,6 +1748,12 @@ SGP_DEV void solve_position_pair(const DV& d, uint32_t slot, int side)
 		}
 	}
 	if (moved && im > 0.0f) { rec[0] = F4(pos, im); rec[1] = make_float4(q.x, q.y, q.z, q.w); }
+}
+SGP_DEV void solve_position_pair_at(const DV& d, uint32_t slot, int side, float4* rec)
+{
+	PosHalf ph;
+	pos_half_load(d, slot, side, CUR(d).np_col[slot], ph);
+	pos_half_solve(d, ph, side, rec);
 }
 
 // One launch = one colour of one pass.  The slot range comes from the device-side colour table, so the host never has
@@ -1874,6 +1895,228 @@ __global__ void __launch_bounds__(TAIL_VEL_TPB) k_solve_tail_vel(DV d, int first
 	for (uint32_t it = 0; it < count; ++it) {
 		const uint32_t bslot = overflow_next(d, first, count, last, have_last);
 		solve_velocity_pair_t<4>(d, bslot, side, d.sbody);
+	}
+}
+
+// ---- high colours by connected component ----------------------------------------------------------------------------------------
+// The colour histogram of a pile is geometric: the first few colours hold almost every constraint, colour after colour the rest halves
+// (config 3: 47k, 42k, ... 9k, 5.6k, 3.4k, 2k, 1.1k ...), yet every one of them costs a launch per pass.  The constraints of colours
+// >= K form a sparse sub-graph of the contact graph that falls apart into thousands of small connected components (config 3, K = 10:
+// 18k constraints in 6k components of at most 61 constraints).  Components share no body that can move, so each can be solved on its
+// own, its constraints in colour order, while the other components run -- which is exactly the order of operations per body that the
+// colour-by-colour launches produce.  So: label the components once per step (union-find over the bodies with an inverse mass), lay
+// them out in size classes (1, 2, 4 .. 128 constraints, aligned so that a workgroup of 128 lane pairs holds whole components), and
+// replace the launches of ALL colours >= K of a pass by ONE launch in which a workgroup walks those colours over the constraints in
+// its registers.  Bit-identical for every K (K is a launch-plan knob, chosen on the host from the previous step's histogram);
+// a component of more than 128 constraints and the overflow colour go through the serial catch-all at the end of the same launch.
+SGP_DEV uint32_t uf_prio(uint32_t x);
+SGP_DEV uint32_t uf_find(const uint32_t* parent, uint32_t x);
+#define HC_CLASSES 9                  // component size classes: 1 << class constraints
+#define HC_WG_PAIRS 256               // lane pairs (= constraints) per workgroup (8 waves: 2 per SIMD, a constraint half keeps its ~150 registers)
+#define HC_TPB (2 * HC_WG_PAIRS)
+#define HC_BIG 0xFFFFFFFFu
+#define HC_NONE 0xFFFFFFFFu
+#define NPCOL_CATCH_ALL (1 << 17)     // np_col: the constraint's component is too large for a workgroup
+
+SGP_DEV bool hc_can_move(const DV& d, uint32_t body) { return d.sbody[4 * (size_t)body].w > 0.0f; }      // effective inverse mass of the step (k_pre_solve)
+
+// (1) a constraint between two bodies that can move joins their components (k_pre_solve made every body a component of its own);
+//     the slot list is cleared to "no constraint"
+__global__ void __launch_bounds__(TPB) k_hc_hook(DV d, int first_colour)
+{
+	const uint32_t b = d.cstarts[first_colour], e = d.cstarts[SGP_OVERFLOW_COLOUR];
+	const uint32_t tid = blockIdx.x * TPB + threadIdx.x, stride = gridDim.x * TPB;
+	const uint32_t lim = min(2u * (e - b) + HC_CLASSES * HC_WG_PAIRS, d.cap_hc_list);
+	for (uint32_t i = tid; i < lim; i += stride) d.hc_list[i] = HC_NONE;
+	for (uint32_t k = b + tid; k < e; k += stride) {
+		const uint2 ab = CUR(d).ab[k];
+		if (!hc_can_move(d, ab.x) || !hc_can_move(d, ab.y)) continue;
+		uint32_t ra = uf_find(d.hc_root, ab.x), rb = uf_find(d.hc_root, ab.y);
+		while (ra != rb) {
+			const bool a_hi = uf_prio(ra) > uf_prio(rb);
+			const uint32_t hi = a_hi ? ra : rb, lo = a_hi ? rb : ra;
+			const uint32_t old = atomicCAS(&d.hc_root[hi], hi, lo);
+			if (old == hi) break;
+			ra = uf_find(d.hc_root, old); rb = uf_find(d.hc_root, lo);
+		}
+	}
+}
+SGP_DEV uint32_t hc_root_of(const DV& d, uint2 ab)
+{
+	const uint32_t x = hc_can_move(d, ab.x) ? ab.x : (hc_can_move(d, ab.y) ? ab.y : HC_NONE);
+	return x == HC_NONE ? HC_NONE : uf_find(d.hc_root, x);
+}
+// (2) size of every component, and each constraint's rank within its component
+__global__ void __launch_bounds__(TPB) k_hc_count(DV d, int first_colour)
+{
+	const uint32_t b = d.cstarts[first_colour], e = d.cstarts[SGP_OVERFLOW_COLOUR];
+	for (uint32_t k = b + blockIdx.x * TPB + threadIdx.x; k < e; k += gridDim.x * TPB) {
+		const uint32_t r = hc_root_of(d, CUR(d).ab[k]);
+		d.hc_rank[k] = r == HC_NONE ? 0u : atomicAdd(&d.hc_count[r], 1u);
+	}
+}
+// (3) the first constraint of a component takes the component's place in its size class (one atomic per wave and class)
+__global__ void __launch_bounds__(TPB) k_hc_alloc(DV d, int first_colour)
+{
+	const uint32_t b = d.cstarts[first_colour], e = d.cstarts[SGP_OVERFLOW_COLOUR];
+	const int lane = (int)(threadIdx.x & 63u);
+	for (uint32_t k0 = b + blockIdx.x * TPB; k0 < e; k0 += gridDim.x * TPB) {          // (uniform per workgroup: the ballots below need whole waves)
+		const uint32_t k = k0 + threadIdx.x;
+		uint32_t r = HC_NONE, size = 0;
+		if (k < e && d.hc_rank[k] == 0u) { r = hc_root_of(d, CUR(d).ab[k]); if (r != HC_NONE) size = d.hc_count[r]; }
+		const bool lead = r != HC_NONE;
+		int cls = -1;
+		if (lead) {
+			if (size > (uint32_t)HC_WG_PAIRS) d.hc_base[r] = HC_BIG;
+			else cls = size <= 1u ? 0 : 32 - __clz((int)(size - 1u));
+		}
+#pragma unroll
+		for (int c = 0; c < HC_CLASSES; ++c) {
+			const unsigned long long m = __ballot(cls == c);
+			if (m == 0ull) continue;
+			const int leader = __ffsll((long long)m) - 1;
+			uint32_t base = 0;
+			if (lane == leader) base = atomicAdd(&d.ctr->hc_class[c], (uint32_t)__popcll(m));
+			base = __shfl(base, leader, 64);
+			if (cls == c) d.hc_base[r] = ((uint32_t)c << 28) | (base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
+		}
+	}
+}
+// first list entry of a size class: the classes follow each other, each padded to whole workgroups
+SGP_DEV uint32_t hc_class_first(const DV& d, int cls)
+{
+	uint32_t first = 0;
+	for (int c = 0; c < cls; ++c) first += ((d.ctr->hc_class[c] << c) + (HC_WG_PAIRS - 1)) & ~(uint32_t)(HC_WG_PAIRS - 1);
+	return first;
+}
+// (4) every constraint goes to its component's place in the list (entry = lane pair of the solve launch), or is marked for the catch-all
+__global__ void __launch_bounds__(TPB) k_hc_scatter(DV d, int first_colour)
+{
+	const uint32_t b = d.cstarts[first_colour], e = d.cstarts[SGP_OVERFLOW_COLOUR];
+	if (blockIdx.x == 0 && threadIdx.x == 0) { d.ctr->hc_entries = hc_class_first(d, HC_CLASSES); d.ctr->hc_n = e - b; }
+	for (uint32_t k = b + blockIdx.x * TPB + threadIdx.x; k < e; k += gridDim.x * TPB) {
+		const uint32_t r = hc_root_of(d, CUR(d).ab[k]);
+		const uint32_t place = r == HC_NONE ? HC_BIG : d.hc_base[r];
+		uint32_t at = HC_NONE;
+		if (place != HC_BIG) {
+			const int cls = (int)(place >> 28);
+			at = hc_class_first(d, cls) + ((place & 0x0FFFFFFFu) << cls) + d.hc_rank[k];
+		}
+		if (at < d.cap_hc_list) d.hc_list[at] = k;          // (the list has room for every constraint rounded up to its class: at is always inside)
+		else { CUR(d).np_col[k] |= NPCOL_CATCH_ALL; wave_alloc(&d.ctr->hc_n_big); }
+	}
+}
+
+// One pass over every constraint of colours >= first_colour (and the overflow colour).  MODE 1: velocity iteration, 2: position iteration.
+// (5) within a workgroup's share of the list (which constraint sits on which lane pair is free), order the constraints by colour: a wave then
+//     holds one or two colours and runs one or two phases of the pass, instead of every wave running every phase for a few lanes each
+__global__ void __launch_bounds__(HC_WG_PAIRS) k_hc_sort(DV d)
+{
+	__shared__ uint32_t s_cnt[SGP_MAX_COLOURS], s_first[SGP_MAX_COLOURS];
+	__shared__ uint2 s_slot[HC_WG_PAIRS];
+	const uint32_t entries = d.ctr->hc_entries;
+	for (uint32_t e0 = blockIdx.x * HC_WG_PAIRS; e0 < entries; e0 += gridDim.x * HC_WG_PAIRS) {
+		if (threadIdx.x < SGP_MAX_COLOURS) s_cnt[threadIdx.x] = 0u;
+		__syncthreads();
+		const uint32_t slot = d.hc_list[e0 + threadIdx.x];
+		const int npc = slot != HC_NONE ? CUR(d).np_col[slot] : 0;
+		const int col = slot != HC_NONE ? ((npc >> 8) & 0xFF) : SGP_MAX_COLOURS - 1;      // (unused lane pairs last)
+		const uint32_t rank = atomicAdd(&s_cnt[col], 1u);
+		__syncthreads();
+		if (threadIdx.x < 64) {
+			const uint32_t v = s_cnt[threadIdx.x];
+			uint32_t x = v;
+			for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off, 64); if ((int)threadIdx.x >= off) x += y; }
+			s_first[threadIdx.x] = x - v;
+		}
+		__syncthreads();
+		s_slot[s_first[col] + rank] = make_uint2(slot, (uint32_t)npc);
+		__syncthreads();
+		d.hc_entry[e0 + threadIdx.x] = s_slot[threadIdx.x];      // what the solve launches read: slot + its point count and colour
+		__syncthreads();
+	}
+}
+
+// A workgroup's components own their movable bodies, so their solver records live in LDS for the whole pass (read once, written once; a
+// colour phase is an LDS gather, the arithmetic and an LDS scatter): HC_TABLE hash slots keyed by body id, filled by the lanes themselves.
+#define HC_TABLE 1024                 // >= 2 x the bodies a workgroup can meet (one per lane)
+template <int MODE> __global__ void __launch_bounds__(HC_TPB) k_solve_hc(DV d, int first_colour)
+{
+	constexpr int RS = MODE == 1 ? 2 : 3;      // float4 per body: velocity half (lin + inverse mass, ang) / pose half (pos + inverse mass, rot, inertia)
+	__shared__ float4 s_rec[HC_TABLE * RS];
+	__shared__ uint32_t s_key[HC_TABLE];
+	__shared__ unsigned long long s_present;
+	__shared__ uint32_t s_ticket;
+	const int side = (int)(threadIdx.x & 1u);
+	const uint32_t pair = threadIdx.x >> 1;
+	const uint32_t entries = d.ctr->hc_entries;
+	const int n_colours = (int)d.ctr->n_colours;
+	for (uint32_t e0 = blockIdx.x * HC_WG_PAIRS; e0 < entries; e0 += gridDim.x * HC_WG_PAIRS) {
+		__syncthreads();      // (everyone is done with the previous round's table and mask)
+		for (uint32_t i = threadIdx.x; i < HC_TABLE; i += HC_TPB) s_key[i] = HC_NONE;
+		if (threadIdx.x == 0) s_present = 0ull;
+		__syncthreads();
+		const uint2 entry = d.hc_entry[e0 + pair];
+		const uint32_t slot = entry.x;
+		const bool mine = slot != HC_NONE;
+		ConHalf h; PosHalf ph; int my_col = -1;
+		uint32_t body = HC_NONE, at = 0; bool owner = false;
+		if (mine) {
+			my_col = ((int)entry.y >> 8) & 0xFF;
+			if (MODE == 1) { half_load_np(d, slot, side, (int)entry.y, h); body = h.body; }
+			else { const uint2 ab = CUR(d).ab[slot]; body = side ? ab.y : ab.x; pos_half_load(d, slot, side, (int)entry.y, ph); }
+			if (side == 0) atomicOr(&s_present, 1ull << my_col);
+			// this body's LDS slot; the lane that claims it brings the record in
+			at = uf_prio(body) & (HC_TABLE - 1);
+			for (;;) {
+				const uint32_t old = atomicCAS(&s_key[at], HC_NONE, body);
+				if (old == HC_NONE) { owner = true; break; }
+				if (old == body) break;
+				at = (at + 1) & (HC_TABLE - 1);
+			}
+			if (owner) {
+				const float4* g = d.sbody + 4 * (size_t)body;
+#pragma unroll
+				for (int i = 0; i < RS; ++i) s_rec[RS * at + i] = g[i];
+			}
+			if (MODE == 1) h.body = at;
+		}
+		__syncthreads();
+		const unsigned long long present = s_present;
+		for (int c = first_colour; c < n_colours; ++c) {
+			if (!((present >> c) & 1ull)) continue;
+			if (my_col == c) { if (MODE == 1) half_solve<2>(h, side, s_rec, d.dbg_flags); else pos_half_solve(d, ph, side, s_rec + RS * at); }
+			__syncthreads();
+		}
+		if (MODE == 1 && mine) half_store(d, slot, side, h);
+		if (owner && s_rec[RS * at].w > 0.0f) {
+			float4* g = d.sbody + 4 * (size_t)body;
+			g[0] = s_rec[RS * at]; g[1] = s_rec[RS * at + 1];
+		}
+	}
+	// catch-all: components too large for a workgroup and the overflow colour, by the last workgroup to finish (nothing to do: no ticket either)
+	const uint32_t n_big = d.ctr->hc_n_big;
+	const uint32_t ofirst = d.cstarts[SGP_OVERFLOW_COLOUR], ocount = d.cstarts[SGP_OVERFLOW_COLOUR + 1] - ofirst;
+	if (n_big == 0u && ocount == 0u) return;
+	__syncthreads();
+	if (threadIdx.x == 0) { __threadfence(); s_ticket = atomicAdd(&d.ctr->hc_done, 1u); }
+	__syncthreads();
+	if (s_ticket != gridDim.x - 1u) return;
+	if (threadIdx.x == 0) d.ctr->hc_done = 0u;      // for the next launch
+	__threadfence();          // what the other workgroups wrote (and this compute unit may still hold older copies of)
+	for (int c = first_colour; c < n_colours && n_big != 0u; ++c) {
+		const uint32_t cb = d.cstarts[c], ce = d.cstarts[c + 1];
+		for (uint32_t k = cb + pair; k < ce; k += HC_WG_PAIRS) {
+			if (!(CUR(d).np_col[k] & NPCOL_CATCH_ALL)) continue;
+			if (MODE == 1) solve_velocity_pair_t<4>(d, k, side, d.sbody); else solve_position_pair(d, k, side);
+		}
+		__syncthreads();
+	}
+	if (ocount == 0u || threadIdx.x >= 2u) return;               // lanes 0 and 1: the two sides of one constraint at a time
+	uint64_t last = 0; bool have_last = false;
+	for (uint32_t it = 0; it < ocount; ++it) {
+		const uint32_t bslot = overflow_next(d, ofirst, ocount, last, have_last);
+		if (MODE == 1) solve_velocity_pair_t<4>(d, bslot, side, d.sbody); else solve_position_pair(d, bslot, side);
 	}
 }
 
@@ -3504,6 +3747,22 @@ void launch_solve_tail(const DV& d, int first_colour, int mode, hipStream_t s)
 {
 	if (mode == 1) hipLaunchKernelGGL(k_solve_tail_vel, dim3(1), dim3(TAIL_VEL_TPB), 0, s, d, first_colour);      // (position passes of the tail: one thread per constraint measured faster, 30 against 37 us)
 	else hipLaunchKernelGGL(k_solve_tail, dim3(1), dim3(512), 0, s, d, first_colour, mode);
+}
+void launch_hc_build(const DV& d, int first_colour, uint32_t est, hipStream_t s)
+{
+	const uint32_t blocks = std::max(1u, std::min(1024u, (est + est / 8 + TPB - 1) / TPB));
+	hipLaunchKernelGGL(k_hc_hook, dim3(blocks), dim3(TPB), 0, s, d, first_colour);
+	hipLaunchKernelGGL(k_hc_count, dim3(blocks), dim3(TPB), 0, s, d, first_colour);
+	hipLaunchKernelGGL(k_hc_alloc, dim3(blocks), dim3(TPB), 0, s, d, first_colour);
+	hipLaunchKernelGGL(k_hc_scatter, dim3(blocks), dim3(TPB), 0, s, d, first_colour);
+	hipLaunchKernelGGL(k_hc_sort, dim3(std::max(1u, std::min(2048u, (2u * est + HC_CLASSES * HC_WG_PAIRS) / HC_WG_PAIRS))), dim3(HC_WG_PAIRS), 0, s, d);
+}
+void launch_solve_hc(const DV& d, int first_colour, uint32_t est, int mode, hipStream_t s)
+{
+	// list entries: a component of n constraints takes the next power of two (< 2 n), plus the padding of the classes
+	const uint32_t blocks = std::max(1u, std::min(2048u, (2u * est + HC_CLASSES * HC_WG_PAIRS) / HC_WG_PAIRS));
+	if (mode == 1) hipLaunchKernelGGL(k_solve_hc<1>, dim3(blocks), dim3(HC_TPB), 0, s, d, first_colour);
+	else hipLaunchKernelGGL(k_solve_hc<2>, dim3(blocks), dim3(HC_TPB), 0, s, d, first_colour);
 }
 void launch_solve_small(const DV& d, int warm_start, int iterations, int lane_pairs, hipStream_t s)
 {

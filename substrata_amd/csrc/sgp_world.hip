@@ -93,6 +93,7 @@ struct sgp_world {
 	std::map<std::string, hipGraphExec_t> graphs;              // replayable launch sequences keyed by launch plan
 	std::string last_plan_key[2]; uint32_t plan_repeats[2] = { 0, 0 };   // per buffer parity: StepParams (by value in the first launch) flips parity every step
 	bool use_graphs = true; bool use_small_world = true; uint32_t tail_threshold = 256;
+	bool use_components = true; uint32_t hc_budget = 160; uint32_t hc_bump = 0; uint32_t hc_calm = 0; uint32_t hc_retry_after = 64; bool hc_retrying = false;      // high colours by component: share of the constraints (per mille), plan correction
 	uint32_t graph_launches = 0, eager_steps = 0, idle_steps = 0;
 	bool grid_valid = false;                                   // the broad-phase grid matches the current poses (ray queries reuse it)
 	// static triangle meshes: host-side headers + pools mirrored on the device (grown on demand)
@@ -301,6 +302,8 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	DEV_ALLOC(d.sorted_min, N); DEV_ALLOC(d.sorted_max, N); DEV_ALLOC(d.grid, 1); DEV_ALLOC(d.scan_block_sums, (d.table_size + 1) / 1024 + 2);
 	DEV_ALLOC(d.pairs, P);
 	DEV_ALLOC(d.man_ab, M); DEV_ALLOC(d.man_n, M); DEV_ALLOC(d.man_colour, M); DEV_ALLOC(d.man_prio, M); DEV_ALLOC(d.man_prev, M); DEV_ALLOC(d.man_slot, M);
+	DEV_ALLOC(d.hc_root, N); DEV_ALLOC(d.hc_count, N); DEV_ALLOC(d.hc_base, N); DEV_ALLOC(d.hc_rank, M);
+	d.cap_hc_list = 2u * M + 4096u; DEV_ALLOC(d.hc_list, d.cap_hc_list); DEV_ALLOC(d.hc_entry, d.cap_hc_list);
 	DEV_ALLOC(d.ulist[0], M); DEV_ALLOC(d.ulist[1], M);
 	for (int k = 0; k < 4; ++k) { DEV_ALLOC(d.man_p1[k], M); DEV_ALLOC(d.man_p2[k], M); }
 	DEV_ALLOC(d.rows, (size_t)48 * M);
@@ -324,6 +327,7 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	{ const char* e = getenv("SGP_NO_GRAPH"); if (e && e[0] == '1') w->use_graphs = false; }
 	{ const char* e = getenv("SGP_NO_SMALL_WORLD"); if (e && e[0] == '1') w->use_small_world = false; }
 	{ const char* e = getenv("SGP_DEBUG_FLAGS"); w->dv.dbg_flags = e ? (uint32_t)atoi(e) : 0u; }
+	{ const char* e = getenv("SGP_HC_BUDGET"); if (e) { const int v = atoi(e); if (v <= 0) w->use_components = false; else w->hc_budget = (uint32_t)v; } }
 	{ const char* e = getenv("SGP_TAIL_THRESHOLD"); if (e && atoi(e) > 0) w->tail_threshold = (uint32_t)atoi(e); }
 	d.st = desc->settings;
 	d.gx = desc->gravity[0]; d.gy = desc->gravity[1]; d.gz = desc->gravity[2];
@@ -941,6 +945,8 @@ struct StepPlan {
 	int      has_hulls;          // some body may be a convex hull: run the hull-pair narrow phase
 	int      small_colouring;    // the whole colouring in one single-workgroup launch (k_colour_finish builds its own worklist)
 	int      small_world;        // warm start + velocity iterations as ONE single-workgroup launch (k_solve_small)
+	int      hc_first;           // colours >= hc_first (<= tail_first) are solved by connected component, one launch per pass; -1: off (tail kernel)
+	uint32_t hc_est;             // their constraints (previous step)
 	int      small_pairs;        // ... with two lanes per constraint (the previous step had <= 384 constraints), else one thread per constraint
 	StepParams sp;               // by-value kernel argument of the first launch: part of the key of a captured graph
 };
@@ -971,6 +977,21 @@ static void make_plan(const sgp_world* w, StepPlan& p)
 	p.small_colouring = (w->last_manifolds <= SGP_SMALL_COLOURING_MANIFOLDS && w->high <= SGP_SMALL_WORLD_BODIES) ? 1 : 0;
 	p.small_world = (tf == 0 && w->high <= SGP_SMALL_WORLD_BODIES && w->n_vehicles == 0 && w->use_small_world) ? 1 : 0;
 	p.small_pairs = (w->n_con <= 384u || w->n_con > 512u) ? 1 : 0;
+	p.hc_first = -1;
+	if (!p.small_world && w->use_components && w->n_con != 0) {      // (no histogram yet: the tail kernel takes whatever the first step brings)
+		// the high colours: as many of the last colours as hold at most hc_budget (per mille) of the constraints -- few enough that the
+		// sub-graph they form is far below its percolation threshold and falls apart into small components (measured: DESIGN.md section 8)
+		uint64_t total = 0, sum = 0;
+		for (int c = 0; c < SGP_OVERFLOW_COLOUR; ++c) total += w->plan_colour_count[c];
+		for (int c = tf; c < SGP_OVERFLOW_COLOUR; ++c) sum += w->plan_colour_count[c];
+		int k = tf;
+		while (k > 0 && (sum + w->plan_colour_count[k - 1]) * 1000u <= total * w->hc_budget) sum += w->plan_colour_count[--k];
+		k = std::min(tf, k + (int)w->hc_bump);
+		sum = 0; for (int c = k; c < SGP_OVERFLOW_COLOUR; ++c) sum += w->plan_colour_count[c];
+		p.hc_first = k;
+		p.hc_est = bucket_up((uint32_t)sum + (uint32_t)(sum / 8));
+		p.tail_first = k;
+	}
 	p.sp = *w->h_sp;
 }
 
@@ -1013,12 +1034,14 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 	}
 	{ KScope k(w, KC_COLOUR_COUNT); launch_colour_count(d, p.est_man, s); }
 	{ KScope k(w, KC_SETUP); launch_setup(d, p.est_man, s); }
+	if (p.hc_first >= 0) { KScope k(w, KC_SETUP); launch_hc_build(d, p.hc_first, p.hc_est, s); }
 	STAGE_MARK(4);
 	// -- 5. warm start + velocity iterations: one launch per planned colour, everything else in the single-workgroup tail
 	auto solve_pass = [&](int mode, int kc) {
 		if (p.n_vehicles) { KScope k(w, KC_VEHICLE); launch_vehicle_solve(d, mode, s); }      // non-contact constraints first
 		for (int c = 0; c < p.tail_first; ++c) { KScope k(w, kc); launch_solve_colour(d, c, p.colour_est[c], mode, s); }
-		{ KScope k(w, kc); launch_solve_tail(d, p.tail_first, mode, s); }
+		if (p.hc_first >= 0) { KScope k(w, kc); launch_solve_hc(d, p.hc_first, p.hc_est, mode, s); }      // colours >= tail_first by component + overflow colour
+		else { KScope k(w, kc); launch_solve_tail(d, p.tail_first, mode, s); }
 	};
 	if (p.small_world) { KScope k(w, KC_SOLVE_VELOCITY); launch_solve_small(d, p.warm_start, p.vel_iters, p.small_pairs, s); }
 	else {
@@ -1124,6 +1147,14 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	w->plan_rounds = c1.rounds_used;
 	memcpy(w->plan_round_n, c1.round_n, sizeof(w->plan_round_n));
 	for (int c = 0; c < SGP_MAX_COLOURS; ++c) w->plan_colour_count[c] = c1.colour_count[c];
+	// components too large for a workgroup went through the serial catch-all: take fewer colours next time (and try more again later)
+	// (the catch-all costs more per pass than the launch of one more colour: any such component is one too many; how long to wait before trying
+	// again doubles every time the retry fails at once)
+	if (c1.hc_n_big > 0u) {
+		if (w->hc_bump < (uint32_t)SGP_OVERFLOW_COLOUR) w->hc_bump++;
+		if (w->hc_retrying && w->hc_calm < 8u && w->hc_retry_after < 65536u) w->hc_retry_after *= 2u;
+		w->hc_calm = 0; w->hc_retrying = false;
+	} else if (w->hc_bump && ++w->hc_calm >= w->hc_retry_after) { w->hc_bump--; w->hc_calm = 0; w->hc_retrying = true; }
 	sgp_step_stats& st = w->stats;
 	memset(&st, 0, sizeof(st));
 	st.num_bodies = w->n_alive;
@@ -1134,6 +1165,7 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	st.num_colour_rounds = c1.rounds_used;
 	st.num_overflow_constraints = c1.colour_count[SGP_OVERFLOW_COLOUR];
 	st.num_cached_manifolds = c1.n_cached;
+	st.num_component_constraints = c1.hc_n; st.num_catch_all_constraints = c1.hc_n_big;
 	st.pairs_dropped = c1.pairs_dropped; st.manifolds_dropped = c1.manifolds_dropped;
 	st.device_bytes = w->device_bytes;
 	st.num_active = c1.n_active;

@@ -45,8 +45,12 @@ def run_seed(oracle, seed, steps, verbose=False):
     rng = np.random.default_rng(seed)
     # both launch plans of small worlds get their share (the product reads the switch when the world is created)
     os.environ["SGP_NO_SMALL_WORLD"] = "1" if rng.random() < 0.4 else "0"
+    # ... and of the large ones: colours with launches of their own (threshold), the rest by connected component (budget in per mille; 0 = tail kernel)
+    os.environ["SGP_TAIL_THRESHOLD"] = str(int(rng.choice([2, 8, 256])))
+    os.environ["SGP_HC_BUDGET"] = str(int(rng.choice([0, 160, 400, 1000])))
     tw = parity.make_twin(oracle, max_bodies=2048)
-    os.environ.pop("SGP_NO_SMALL_WORLD", None)
+    for k in ("SGP_NO_SMALL_WORLD", "SGP_TAIL_THRESHOLD", "SGP_HC_BUDGET"):
+        os.environ.pop(k, None)
     use_mesh = rng.random() < 0.6
     use_car = rng.random() < 0.5
     ground = scenes.ground()

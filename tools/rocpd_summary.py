@@ -12,10 +12,14 @@ def main():
     rows = cur.execute(f"select {name_col}, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
                        f"from kernels group by {name_col} order by sum(end-start) desc").fetchall()
     total = sum(r[2] for r in rows) or 1
-    lines = ["| kernel | calls | total_ms | avg_us | min_us | max_us | % |", "|---|---|---|---|---|---|---|"]
+    med = {}
+    for n, dur in cur.execute(f"select {name_col}, end-start from kernels"):
+        med.setdefault(n, []).append(dur)
+    lines = ["| kernel | calls | total_ms | avg_us | median_us | min_us | max_us | % |", "|---|---|---|---|---|---|---|---|"]
     for n, c, s, a, mn, mx in rows:
         short = n.split("(")[0]
-        lines.append(f"| {short} | {c} | {s / 1e6:.3f} | {a / 1e3:.2f} | {mn / 1e3:.2f} | {mx / 1e3:.2f} | {100.0 * s / total:.1f} |")
+        m = sorted(med[n])[len(med[n]) // 2]
+        lines.append(f"| {short} | {c} | {s / 1e6:.3f} | {a / 1e3:.2f} | {m / 1e3:.2f} | {mn / 1e3:.2f} | {mx / 1e3:.2f} | {100.0 * s / total:.1f} |")
     txt = "\n".join(lines)
     if len(sys.argv) > 2:
         open(sys.argv[2], "w").write(txt + "\n")
