@@ -219,7 +219,7 @@ struct DV {
 	uint32_t* hc_base;         // [cap_bodies] class << 28 | index within the class (at its root), HC_BIG: catch-all
 	uint32_t* hc_rank;         // [cap_manifolds] rank of the constraint within its component
 	uint32_t* hc_list;         // constraint slot per lane pair of the solve launch (k_hc_scatter) ...
-	uint2*    hc_entry;        // ... ordered by colour within a workgroup's share, with the constraint's np_col (k_hc_sort): what k_solve_hc reads
+	uint4*    hc_entry;        // ... ordered by colour within a workgroup's share, with the constraint's np_col and bodies (k_hc_sort): what k_solve_hc reads
 	uint32_t  cap_hc_list;
 	// constraints
 	uint32_t dbg_flags;        // SGP_DEBUG_FLAGS (developer switches): bit 0 = tail kernel without its register-resident path

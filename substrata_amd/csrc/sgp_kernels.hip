@@ -1532,7 +1532,9 @@ SGP_DEV void half_load_rows(const DV& d, uint32_t slot, int side, ConHalf& h)
 	const size_t st = d.cap_manifolds;
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
-		if (i < np) {
+		// (point 0 is read without waiting for the point count -- the slot's rows exist whatever they hold, and only a sensor pair has none
+		// to use: one dependent load level less for the nine constraints in ten that have a single point)
+		if (i == 0 || i < np) {
 #pragma unroll
 			for (int a = 0; a < 3; ++a) {
 				const float4* p = axis_rows(d, slot, i, a);
@@ -1554,15 +1556,18 @@ SGP_DEV void half_load_rows(const DV& d, uint32_t slot, int side, ConHalf& h)
 	}
 }
 
-SGP_DEV void half_load_np(const DV& d, uint32_t slot, int side, int np_col, ConHalf& h)      // (np_col already known: the row loads need not wait for it)
+SGP_DEV void half_load_known(const DV& d, uint32_t slot, int side, int np_col, uint32_t body, ConHalf& h)      // (header already known: nothing here waits for it)
 {
-	const uint2 ab = CUR(d).ab[slot];
-	h.body = side ? ab.y : ab.x;
+	h.body = body;
 	h.nf = CUR(d).n_fric[slot];
 	h.np_col = np_col;
 	half_load_rows(d, slot, side, h);
 }
-SGP_DEV void half_load(const DV& d, uint32_t slot, int side, ConHalf& h) { half_load_np(d, slot, side, CUR(d).np_col[slot], h); }
+SGP_DEV void half_load(const DV& d, uint32_t slot, int side, ConHalf& h)
+{
+	const uint2 ab = CUR(d).ab[slot];
+	half_load_known(d, slot, side, CUR(d).np_col[slot], side ? ab.y : ab.x, h);
+}
 
 SGP_DEV void half_store(const DV& d, uint32_t slot, int side, const ConHalf& h)
 {
@@ -1703,7 +1708,7 @@ SGP_DEV void pos_half_load(const DV& d, uint32_t slot, int side, int np_col, Pos
 	ph.nf = CUR(d).n_fric[slot];
 	ph.np = np_col & 0xFF;
 #pragma unroll
-	for (int i = 0; i < 4; ++i) if (i < ph.np) ph.loc[i] = V3(side ? CUR(d).loc2[i][slot] : CUR(d).loc1[i][slot]);
+	for (int i = 0; i < 4; ++i) if (i == 0 || i < ph.np) ph.loc[i] = V3(side ? CUR(d).loc2[i][slot] : CUR(d).loc1[i][slot]);      // (point 0: without waiting for the count)
 }
 // (rec: where this lane's body's record lives -- the global one, or a workgroup's copy in LDS)
 SGP_DEV void pos_half_solve(const DV& d, const PosHalf& ph, int side, float4* rec)
@@ -1970,16 +1975,15 @@ __global__ void __launch_bounds__(TPB) k_hc_alloc(DV d, int first_colour)
 			if (size > (uint32_t)HC_WG_PAIRS) d.hc_base[r] = HC_BIG;
 			else cls = size <= 1u ? 0 : 32 - __clz((int)(size - 1u));
 		}
+		// one atomic per (wave, class), all of a wave's classes in flight together: the first lane of each class asks for its class
+		unsigned long long mine_m = 0ull;
 #pragma unroll
-		for (int c = 0; c < HC_CLASSES; ++c) {
-			const unsigned long long m = __ballot(cls == c);
-			if (m == 0ull) continue;
-			const int leader = __ffsll((long long)m) - 1;
-			uint32_t base = 0;
-			if (lane == leader) base = atomicAdd(&d.ctr->hc_class[c], (uint32_t)__popcll(m));
-			base = __shfl(base, leader, 64);
-			if (cls == c) d.hc_base[r] = ((uint32_t)c << 28) | (base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
-		}
+		for (int c = 0; c < HC_CLASSES; ++c) { const unsigned long long m = __ballot(cls == c); if (cls == c) mine_m = m; }
+		const int leader = mine_m ? __ffsll((long long)mine_m) - 1 : lane;
+		uint32_t base = 0;
+		if (cls >= 0 && lane == leader) base = atomicAdd(&d.ctr->hc_class[cls], (uint32_t)__popcll(mine_m));
+		base = __shfl(base, leader, 64);
+		if (cls >= 0) d.hc_base[r] = ((uint32_t)cls << 28) | (base + (uint32_t)__popcll(mine_m & ((1ull << lane) - 1ull)));
 	}
 }
 // first list entry of a size class: the classes follow each other, each padded to whole workgroups
@@ -2013,13 +2017,14 @@ __global__ void __launch_bounds__(TPB) k_hc_scatter(DV d, int first_colour)
 __global__ void __launch_bounds__(HC_WG_PAIRS) k_hc_sort(DV d)
 {
 	__shared__ uint32_t s_cnt[SGP_MAX_COLOURS], s_first[SGP_MAX_COLOURS];
-	__shared__ uint2 s_slot[HC_WG_PAIRS];
+	__shared__ uint4 s_slot[HC_WG_PAIRS];
 	const uint32_t entries = d.ctr->hc_entries;
 	for (uint32_t e0 = blockIdx.x * HC_WG_PAIRS; e0 < entries; e0 += gridDim.x * HC_WG_PAIRS) {
 		if (threadIdx.x < SGP_MAX_COLOURS) s_cnt[threadIdx.x] = 0u;
 		__syncthreads();
 		const uint32_t slot = d.hc_list[e0 + threadIdx.x];
 		const int npc = slot != HC_NONE ? CUR(d).np_col[slot] : 0;
+		const uint2 ab = slot != HC_NONE ? CUR(d).ab[slot] : make_uint2(0u, 0u);
 		const int col = slot != HC_NONE ? ((npc >> 8) & 0xFF) : SGP_MAX_COLOURS - 1;      // (unused lane pairs last)
 		const uint32_t rank = atomicAdd(&s_cnt[col], 1u);
 		__syncthreads();
@@ -2030,9 +2035,9 @@ __global__ void __launch_bounds__(HC_WG_PAIRS) k_hc_sort(DV d)
 			s_first[threadIdx.x] = x - v;
 		}
 		__syncthreads();
-		s_slot[s_first[col] + rank] = make_uint2(slot, (uint32_t)npc);
+		s_slot[s_first[col] + rank] = make_uint4(slot, (uint32_t)npc, ab.x, ab.y);
 		__syncthreads();
-		d.hc_entry[e0 + threadIdx.x] = s_slot[threadIdx.x];      // what the solve launches read: slot + its point count and colour
+		d.hc_entry[e0 + threadIdx.x] = s_slot[threadIdx.x];      // what the solve launches read: slot, its point count and colour, its two bodies
 		__syncthreads();
 	}
 }
@@ -2056,15 +2061,15 @@ template <int MODE> __global__ void __launch_bounds__(HC_TPB) k_solve_hc(DV d, i
 		for (uint32_t i = threadIdx.x; i < HC_TABLE; i += HC_TPB) s_key[i] = HC_NONE;
 		if (threadIdx.x == 0) s_present = 0ull;
 		__syncthreads();
-		const uint2 entry = d.hc_entry[e0 + pair];
+		const uint4 entry = d.hc_entry[e0 + pair];
 		const uint32_t slot = entry.x;
 		const bool mine = slot != HC_NONE;
 		ConHalf h; PosHalf ph; int my_col = -1;
 		uint32_t body = HC_NONE, at = 0; bool owner = false;
 		if (mine) {
 			my_col = ((int)entry.y >> 8) & 0xFF;
-			if (MODE == 1) { half_load_np(d, slot, side, (int)entry.y, h); body = h.body; }
-			else { const uint2 ab = CUR(d).ab[slot]; body = side ? ab.y : ab.x; pos_half_load(d, slot, side, (int)entry.y, ph); }
+			body = side ? entry.w : entry.z;
+			if (MODE == 1) half_load_known(d, slot, side, (int)entry.y, body, h); else pos_half_load(d, slot, side, (int)entry.y, ph);
 			if (side == 0) atomicOr(&s_present, 1ull << my_col);
 			// this body's LDS slot; the lane that claims it brings the record in
 			at = uf_prio(body) & (HC_TABLE - 1);
