@@ -125,7 +125,11 @@ def rooflines(prof, n_prof, vel_iters, pmc):
     solve_bytes_per_launch = (SOLVE_BYTES_PER_POINT * prof["pts"] + SOLVE_BYTES_PER_MANIFOLD * prof["cons"]) * vel_iters / launches
     solve_gbs = solve_bytes_per_launch / (solve_launch_ms * 1e-3) / 1e9 if solve_launch_ms > 0 else 0.0
     sweep_traffic = pmc.get("sweep_bytes_per_body")
+    # a pass = one launch per planned colour + (when the plan solves the high colours by component) one launch for all of those
     solve_traffic = pmc.get("solve_velocity_bytes_per_launch")
+    comp_traffic = pmc.get("solve_components_bytes_per_launch")
+    if solve_traffic and comp_traffic and launches > vel_iters:
+        solve_traffic = (solve_traffic * (launches - vel_iters) + comp_traffic * vel_iters) / launches
     roof = {
         "bound": "hbm", "kernel": "body-array sweep (K8 integrate + K1 AABB + sleep test): kernel classes " + " + ".join(sweep_classes),
         "achieved": sweep_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sweep_gbs / HBM_PEAK_GBS,
@@ -134,7 +138,7 @@ def rooflines(prof, n_prof, vel_iters, pmc):
         "traffic_source": pmc.get("source", "none: run tools/collect_pmc.sh on the GPU box"),
     }
     roof_solver = {
-        "bound": "hbm", "kernel": "velocity iterations (dominant by time)",
+        "bound": "hbm", "kernel": "velocity iterations (dominant by time): k_solve_colour<1> per planned colour + k_solve_hc<1> for the rest, averaged per launch",
         "achieved": solve_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": solve_gbs / HBM_PEAK_GBS,
         "algorithmic_bytes_per_launch": solve_bytes_per_launch, "launch_ms": solve_launch_ms,
         "launches_per_step": klaunch[sv] / n_prof, "traffic": solve_traffic,

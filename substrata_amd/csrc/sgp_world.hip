@@ -93,7 +93,10 @@ struct sgp_world {
 	std::map<std::string, hipGraphExec_t> graphs;              // replayable launch sequences keyed by launch plan
 	std::string last_plan_key[2]; uint32_t plan_repeats[2] = { 0, 0 };   // per buffer parity: StepParams (by value in the first launch) flips parity every step
 	bool use_graphs = true; bool use_small_world = true; uint32_t tail_threshold = 256;
-	bool use_components = true; uint32_t hc_budget = 160; uint32_t hc_bump = 0; uint32_t hc_calm = 0; uint32_t hc_retry_after = 64; bool hc_retrying = false;      // high colours by component: share of the constraints (per mille), plan correction
+	// high colours by component: share of the constraints they may hold (per mille; SGP_HC_BUDGET, 0 = off), and the plan's correction of it
+	// (one colour fewer after a step that left a component to the catch-all; retried after hc_retry_after calm steps, doubling on failure)
+	bool use_components = true; uint32_t hc_budget = 160; uint32_t hc_bump = 0; uint32_t hc_calm = 0; uint32_t hc_retry_after = 64; bool hc_retrying = false;
+	bool plan_seen = false;         // a step has run: plan_colour_count etc. describe the previous step
 	uint32_t graph_launches = 0, eager_steps = 0, idle_steps = 0;
 	bool grid_valid = false;                                   // the broad-phase grid matches the current poses (ray queries reuse it)
 	// static triangle meshes: host-side headers + pools mirrored on the device (grown on demand)
@@ -968,6 +971,11 @@ static void make_plan(const sgp_world* w, StepPlan& p)
 	p.est_man = bucket_up(std::max(w->last_manifolds + w->last_manifolds / 8, 2u * w->high));
 	int tf = 0;
 	while (tf < SGP_OVERFLOW_COLOUR && w->plan_colour_count[tf] > w->tail_threshold) { p.colour_est[tf] = bucket_up(w->plan_colour_count[tf] + w->plan_colour_count[tf] / 8); ++tf; }
+	if (tf == 0 && !w->plan_seen && w->high > SGP_SMALL_WORLD_BODIES) {
+		// no histogram yet (first step of a large world): rather a dozen launches that may find their colour empty (3 us each) than
+		// every constraint of a freshly loaded scene in the single-workgroup tail (100k bodies: 4 ms per pass)
+		for (; tf < 12; ++tf) p.colour_est[tf] = bucket_up(w->high / 2u);
+	}
 	p.tail_first = tf;
 	p.water = w->h_sp->water_enabled; p.contact_events = w->h_sp->contact_events;
 	p.warm_start = w->dv.st.warm_start; p.vel_iters = w->dv.st.num_velocity_steps; p.pos_iters = w->dv.st.num_position_steps;
@@ -1147,6 +1155,7 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	w->plan_rounds = c1.rounds_used;
 	memcpy(w->plan_round_n, c1.round_n, sizeof(w->plan_round_n));
 	for (int c = 0; c < SGP_MAX_COLOURS; ++c) w->plan_colour_count[c] = c1.colour_count[c];
+	w->plan_seen = true;
 	// components too large for a workgroup went through the serial catch-all: take fewer colours next time (and try more again later)
 	// (the catch-all costs more per pass than the launch of one more colour: any such component is one too many; how long to wait before trying
 	// again doubles every time the retry fails at once)

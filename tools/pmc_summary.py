@@ -45,6 +45,8 @@ def main():
             return sum(fv) / len(fv) * 1024 * 2 + sum(wv) / len(wv) * 1024
         sweep = sum(per_launch(k) for k in ("k_pre_solve", "k_integrate_pose", "k_finalize"))
         out = {"sweep_bytes_per_body": sweep / bodies, "solve_velocity_bytes_per_launch": per_launch("void k_solve_colour<1>"),
+               # the one launch per pass that takes every colour from the plan's hc_first on (0 if the run never used it)
+               "solve_components_bytes_per_launch": per_launch("void k_solve_hc<1>") if "void k_solve_hc<1>" in fetch else 0.0,
                "bodies": bodies,
                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, eager launches), tools/collect_pmc.sh + tools/pmc_summary.py: "
                          "FETCH_SIZE KiB x 1024 x 2 (gfx950 correction) + WRITE_SIZE KiB x 1024, mean over the second half of each kernel's launches"}
