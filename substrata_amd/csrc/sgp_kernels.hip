@@ -2012,6 +2012,29 @@ __global__ void __launch_bounds__(TPB) k_hc_scatter(DV d, int first_colour)
 }
 
 // One pass over every constraint of colours >= first_colour (and the overflow colour).  MODE 1: velocity iteration, 2: position iteration.
+// Probe (launch plan, every so often): would the colours >= first_colour -- one more than the plan uses now -- still fall apart into components
+// a workgroup can hold?  Counts the constraints that would not (hc_probe_big); k_hc_init then resets the union-find for the real build.
+__global__ void __launch_bounds__(TPB) k_hc_init(DV d, int first_colour)
+{
+	const uint32_t b = d.cstarts[first_colour], e = d.cstarts[SGP_OVERFLOW_COLOUR];
+	for (uint32_t k = b + blockIdx.x * TPB + threadIdx.x; k < e; k += gridDim.x * TPB) {
+		const uint2 ab = CUR(d).ab[k];
+		if (hc_can_move(d, ab.x)) { d.hc_root[ab.x] = ab.x; d.hc_count[ab.x] = 0u; }
+		if (hc_can_move(d, ab.y)) { d.hc_root[ab.y] = ab.y; d.hc_count[ab.y] = 0u; }
+	}
+}
+__global__ void __launch_bounds__(TPB) k_hc_probe(DV d, int first_colour)
+{
+	const uint32_t b = d.cstarts[first_colour], e = d.cstarts[SGP_OVERFLOW_COLOUR];
+	for (uint32_t k = b + blockIdx.x * TPB + threadIdx.x; k < e; k += gridDim.x * TPB) {
+		if (d.hc_rank[k] != 0u) continue;
+		const uint32_t r = hc_root_of(d, CUR(d).ab[k]);
+		if (r == HC_NONE) continue;
+		const uint32_t size = d.hc_count[r];
+		if (size > (uint32_t)HC_WG_PAIRS) atomicAdd(&d.ctr->hc_probe_big, size);
+	}
+}
+
 // (5) within a workgroup's share of the list (which constraint sits on which lane pair is free), order the constraints by colour: a wave then
 //     holds one or two colours and runs one or two phases of the pass, instead of every wave running every phase for a few lanes each
 __global__ void __launch_bounds__(HC_WG_PAIRS) k_hc_sort(DV d)
@@ -3761,6 +3784,15 @@ void launch_hc_build(const DV& d, int first_colour, uint32_t est, hipStream_t s)
 	hipLaunchKernelGGL(k_hc_alloc, dim3(blocks), dim3(TPB), 0, s, d, first_colour);
 	hipLaunchKernelGGL(k_hc_scatter, dim3(blocks), dim3(TPB), 0, s, d, first_colour);
 	hipLaunchKernelGGL(k_hc_sort, dim3(std::max(1u, std::min(2048u, (2u * est + HC_CLASSES * HC_WG_PAIRS) / HC_WG_PAIRS))), dim3(HC_WG_PAIRS), 0, s, d);
+}
+void launch_hc_probe(const DV& d, int probe_colour, uint32_t probe_est, int first_colour, uint32_t est, hipStream_t s)
+{
+	const uint32_t pb = std::max(1u, std::min(1024u, (probe_est + probe_est / 8 + TPB - 1) / TPB));
+	hipLaunchKernelGGL(k_hc_hook, dim3(pb), dim3(TPB), 0, s, d, probe_colour);
+	hipLaunchKernelGGL(k_hc_count, dim3(pb), dim3(TPB), 0, s, d, probe_colour);
+	hipLaunchKernelGGL(k_hc_probe, dim3(pb), dim3(TPB), 0, s, d, probe_colour);
+	hipLaunchKernelGGL(k_hc_init, dim3(pb), dim3(TPB), 0, s, d, probe_colour);      // (every body the probe touched, i.e. also every body of the real build)
+	(void)first_colour; (void)est;
 }
 void launch_solve_hc(const DV& d, int first_colour, uint32_t est, int mode, hipStream_t s)
 {

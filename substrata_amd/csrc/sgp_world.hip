@@ -94,8 +94,9 @@ struct sgp_world {
 	std::string last_plan_key[2]; uint32_t plan_repeats[2] = { 0, 0 };   // per buffer parity: StepParams (by value in the first launch) flips parity every step
 	bool use_graphs = true; bool use_small_world = true; uint32_t tail_threshold = 256;
 	// high colours by component: share of the constraints they may hold (per mille; SGP_HC_BUDGET, 0 = off), and the plan's correction of it
-	// (one colour fewer after a step that left a component to the catch-all; retried after hc_retry_after calm steps, doubling on failure)
-	bool use_components = true; uint32_t hc_budget = 160; uint32_t hc_bump = 0; uint32_t hc_calm = 0; uint32_t hc_retry_after = 64; bool hc_retrying = false;
+	// hc_k: the first colour that goes to the components (-1: not chosen yet -> the budget rule).  One colour fewer after a step that left a
+	// component to the catch-all; one more after a probe (component sizes computed for hc_k - 1 without using them) found that it fits.
+	bool use_components = true; uint32_t hc_budget = 160; int hc_k = -1; uint32_t hc_probe_in = 8, hc_probe_gap = 16;
 	bool plan_seen = false;         // a step has run: plan_colour_count etc. describe the previous step
 	uint32_t graph_launches = 0, eager_steps = 0, idle_steps = 0;
 	bool grid_valid = false;                                   // the broad-phase grid matches the current poses (ray queries reuse it)
@@ -950,6 +951,8 @@ struct StepPlan {
 	int      small_world;        // warm start + velocity iterations as ONE single-workgroup launch (k_solve_small)
 	int      hc_first;           // colours >= hc_first (<= tail_first) are solved by connected component, one launch per pass; -1: off (tail kernel)
 	uint32_t hc_est;             // their constraints (previous step)
+	int      hc_probe;           // >= 0: this step also computes the component sizes for hc_probe = hc_first - 1 (not used for solving)
+	uint32_t hc_probe_est;
 	int      small_pairs;        // ... with two lanes per constraint (the previous step had <= 384 constraints), else one thread per constraint
 	StepParams sp;               // by-value kernel argument of the first launch: part of the key of a captured graph
 };
@@ -993,11 +996,19 @@ static void make_plan(const sgp_world* w, StepPlan& p)
 		for (int c = 0; c < SGP_OVERFLOW_COLOUR; ++c) total += w->plan_colour_count[c];
 		for (int c = tf; c < SGP_OVERFLOW_COLOUR; ++c) sum += w->plan_colour_count[c];
 		int k = tf;
-		while (k > 0 && (sum + w->plan_colour_count[k - 1]) * 1000u <= total * w->hc_budget) sum += w->plan_colour_count[--k];
-		k = std::min(tf, k + (int)w->hc_bump);
+		// first guess: as many of the last colours as hold at most hc_budget (per mille) of the constraints; never more than twice that
+		const uint64_t budget = w->hc_k < 0 ? w->hc_budget : std::min<uint64_t>(2u * w->hc_budget, 1000u);
+		while (k > 0 && (sum + w->plan_colour_count[k - 1]) * 1000u <= total * budget) sum += w->plan_colour_count[--k];
+		if (w->hc_k >= 0) k = std::min(tf, std::max(k, w->hc_k));
 		sum = 0; for (int c = k; c < SGP_OVERFLOW_COLOUR; ++c) sum += w->plan_colour_count[c];
 		p.hc_first = k;
 		p.hc_est = bucket_up((uint32_t)sum + (uint32_t)(sum / 8));
+		p.hc_probe = -1;
+		if (w->hc_k >= 0 && w->hc_probe_in == 0 && k > 0 && (sum + w->plan_colour_count[k - 1]) * 1000u <= total * budget) {
+			p.hc_probe = k - 1;
+			const uint64_t ps = sum + w->plan_colour_count[k - 1];
+			p.hc_probe_est = bucket_up((uint32_t)ps + (uint32_t)(ps / 8));
+		}
 		p.tail_first = k;
 	}
 	p.sp = *w->h_sp;
@@ -1042,6 +1053,7 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 	}
 	{ KScope k(w, KC_COLOUR_COUNT); launch_colour_count(d, p.est_man, s); }
 	{ KScope k(w, KC_SETUP); launch_setup(d, p.est_man, s); }
+	if (p.hc_first >= 0 && p.hc_probe >= 0) { KScope k(w, KC_SETUP); launch_hc_probe(d, p.hc_probe, p.hc_probe_est, p.hc_first, p.hc_est, s); }
 	if (p.hc_first >= 0) { KScope k(w, KC_SETUP); launch_hc_build(d, p.hc_first, p.hc_est, s); }
 	STAGE_MARK(4);
 	// -- 5. warm start + velocity iterations: one launch per planned colour, everything else in the single-workgroup tail
@@ -1156,14 +1168,18 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	memcpy(w->plan_round_n, c1.round_n, sizeof(w->plan_round_n));
 	for (int c = 0; c < SGP_MAX_COLOURS; ++c) w->plan_colour_count[c] = c1.colour_count[c];
 	w->plan_seen = true;
-	// components too large for a workgroup went through the serial catch-all: take fewer colours next time (and try more again later)
-	// (the catch-all costs more per pass than the launch of one more colour: any such component is one too many; how long to wait before trying
-	// again doubles every time the retry fails at once)
-	if (c1.hc_n_big > 0u) {
-		if (w->hc_bump < (uint32_t)SGP_OVERFLOW_COLOUR) w->hc_bump++;
-		if (w->hc_retrying && w->hc_calm < 8u && w->hc_retry_after < 65536u) w->hc_retry_after *= 2u;
-		w->hc_calm = 0; w->hc_retrying = false;
-	} else if (w->hc_bump && ++w->hc_calm >= w->hc_retry_after) { w->hc_bump--; w->hc_calm = 0; w->hc_retrying = true; }
+	// the launch plan's first component colour: one colour fewer after a step that left a component to the serial catch-all (which costs
+	// more per pass than the launch of one more colour); one more when this step's probe found that the next colour's components fit too
+	// (probes get rarer while they fail, up to one in 1024 steps; a success is followed up at once)
+	if (plan.hc_first >= 0) {
+		int k = plan.hc_first;
+		if (c1.hc_n_big > 0u) { k = std::min(k + 1, (int)SGP_OVERFLOW_COLOUR - 1); w->hc_probe_gap = 64; w->hc_probe_in = 64; }
+		else if (plan.hc_probe >= 0) {
+			if (c1.hc_probe_big == 0u) { k = plan.hc_probe; w->hc_probe_gap = 16; w->hc_probe_in = 2; }
+			else { w->hc_probe_gap = std::min(2u * w->hc_probe_gap, 1024u); w->hc_probe_in = w->hc_probe_gap; }
+		} else if (w->hc_probe_in) w->hc_probe_in--;
+		w->hc_k = k;
+	}
 	sgp_step_stats& st = w->stats;
 	memset(&st, 0, sizeof(st));
 	st.num_bodies = w->n_alive;
