@@ -1764,9 +1764,10 @@ SGP_DEV void solve_position_pair_at(const DV& d, uint32_t slot, int side, float4
 // One launch = one colour of one pass.  The slot range comes from the device-side colour table, so the host never has
 // to know the counts of the current step; the grid is sized from the previous step and the loop strides over the rest.
 #define SOLVE_TPB 64      // one wave per workgroup: a colour of ~17k constraints then spreads over all 256 CUs instead of 67 of them
-// (velocity iterations: two neighbouring lanes per constraint, half_solve; workgroups of two waves, so that a colour is as many workgroups
-// as it was with one lane per constraint -- twice as many one-wave workgroups took ~1 us longer to dispatch per launch)
-#define SOLVE_VEL_TPB 128
+// (velocity and position iterations: two neighbouring lanes per constraint; workgroups of four waves = 128 constraints.  Measured on config 3:
+// one-wave workgroups dispatch ~1 us longer per launch than two-wave ones, two-wave ones another 0.15 us longer than four-wave ones; eight
+// waves are as fast for the velocity launches and slower for the position launches)
+#define SOLVE_VEL_TPB 256
 template <int MODE> __global__ void __launch_bounds__(MODE != 0 ? SOLVE_VEL_TPB : SOLVE_TPB) k_solve_colour(DV d, int colour)
 {
 	const uint32_t first = d.cstarts[colour], end = d.cstarts[colour + 1];
@@ -3764,7 +3765,8 @@ void launch_setup(const DV& d, uint32_t n_man, hipStream_t s)
 }
 void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStream_t s)
 {
-	uint32_t blocks = (est + est / 8 + 64 + SOLVE_TPB - 1) / SOLVE_TPB;      // 64 constraints per workgroup in every mode (velocity: 128 threads)
+	uint32_t blocks = (est + est / 8 + 64 + SOLVE_TPB - 1) / SOLVE_TPB;      // warm start: one thread per constraint, one wave per workgroup
+	if (mode != 0) blocks = (est + est / 8 + 64 + SOLVE_VEL_TPB / 2 - 1) / (SOLVE_VEL_TPB / 2);
 	if (blocks > 8192) blocks = 8192;
 	if (mode == 0) hipLaunchKernelGGL(k_solve_colour<0>, dim3(blocks), dim3(SOLVE_TPB), 0, s, d, colour);
 	else if (mode == 1) hipLaunchKernelGGL(k_solve_colour<1>, dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour);

@@ -96,7 +96,7 @@ struct sgp_world {
 	// high colours by component: share of the constraints they may hold (per mille; SGP_HC_BUDGET, 0 = off), and the plan's correction of it
 	// hc_k: the first colour that goes to the components (-1: not chosen yet -> the budget rule).  One colour fewer after a step that left a
 	// component to the catch-all; one more after a probe (component sizes computed for hc_k - 1 without using them) found that it fits.
-	bool use_components = true; uint32_t hc_budget = 160; int hc_k = -1; uint32_t hc_probe_in = 8, hc_probe_gap = 16;
+	bool use_components = true; uint32_t hc_budget = 160; uint32_t n_cus = 256; int hc_k = -1; uint32_t hc_bump = 1, hc_since_bump = 0xFFFFu; uint32_t hc_probe_in = 8, hc_probe_gap = 16;
 	bool plan_seen = false;         // a step has run: plan_colour_count etc. describe the previous step
 	uint32_t graph_launches = 0, eager_steps = 0, idle_steps = 0;
 	bool grid_valid = false;                                   // the broad-phase grid matches the current poses (ray queries reuse it)
@@ -332,6 +332,7 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	{ const char* e = getenv("SGP_NO_SMALL_WORLD"); if (e && e[0] == '1') w->use_small_world = false; }
 	{ const char* e = getenv("SGP_DEBUG_FLAGS"); w->dv.dbg_flags = e ? (uint32_t)atoi(e) : 0u; }
 	{ const char* e = getenv("SGP_HC_BUDGET"); if (e) { const int v = atoi(e); if (v <= 0) w->use_components = false; else w->hc_budget = (uint32_t)v; } }
+	{ int dev = 0, cus = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) w->n_cus = (uint32_t)cus; }
 	{ const char* e = getenv("SGP_TAIL_THRESHOLD"); if (e && atoi(e) > 0) w->tail_threshold = (uint32_t)atoi(e); }
 	d.st = desc->settings;
 	d.gx = desc->gravity[0]; d.gy = desc->gravity[1]; d.gz = desc->gravity[2];
@@ -998,13 +999,16 @@ static void make_plan(const sgp_world* w, StepPlan& p)
 		int k = tf;
 		// first guess: as many of the last colours as hold at most hc_budget (per mille) of the constraints; never more than twice that
 		const uint64_t budget = w->hc_k < 0 ? w->hc_budget : std::min<uint64_t>(2u * w->hc_budget, 1000u);
-		while (k > 0 && (sum + w->plan_colour_count[k - 1]) * 1000u <= total * budget) sum += w->plan_colour_count[--k];
+		// ... and never more than one round of workgroups can hold (a workgroup per compute unit: the launch replaces launches that are bound by
+		// latency, not throughput -- at a million bodies a colour of 400k constraints is better off in its own, coalesced launch)
+		const uint64_t fits = (uint64_t)w->n_cus * 256u * 18u / 25u;      // 256 lane pairs per workgroup, ~0.72 constraints per list entry
+		while (k > 0 && (sum + w->plan_colour_count[k - 1]) * 1000u <= total * budget && sum + w->plan_colour_count[k - 1] <= fits) sum += w->plan_colour_count[--k];
 		if (w->hc_k >= 0) k = std::min(tf, std::max(k, w->hc_k));
 		sum = 0; for (int c = k; c < SGP_OVERFLOW_COLOUR; ++c) sum += w->plan_colour_count[c];
 		p.hc_first = k;
 		p.hc_est = bucket_up((uint32_t)sum + (uint32_t)(sum / 8));
 		p.hc_probe = -1;
-		if (w->hc_k >= 0 && w->hc_probe_in == 0 && k > 0 && (sum + w->plan_colour_count[k - 1]) * 1000u <= total * budget) {
+		if (w->hc_k >= 0 && w->hc_probe_in == 0 && k > 0 && (sum + w->plan_colour_count[k - 1]) * 1000u <= total * budget && sum + w->plan_colour_count[k - 1] <= fits) {
 			p.hc_probe = k - 1;
 			const uint64_t ps = sum + w->plan_colour_count[k - 1];
 			p.hc_probe_est = bucket_up((uint32_t)ps + (uint32_t)(ps / 8));
@@ -1173,12 +1177,18 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	// (probes get rarer while they fail, up to one in 1024 steps; a success is followed up at once)
 	if (plan.hc_first >= 0) {
 		int k = plan.hc_first;
-		if (c1.hc_n_big > 0u) { k = std::min(k + 1, (int)SGP_OVERFLOW_COLOUR - 1); w->hc_probe_gap = 64; w->hc_probe_in = 64; }
+		if (c1.hc_n_big > 0u) {
+			// (a scene that keeps growing -- a tower coming down -- outruns single steps: the stride doubles while catch-alls follow each other closely)
+			w->hc_bump = (w->hc_since_bump < 32u) ? std::min(2u * w->hc_bump, 8u) : 1u;
+			w->hc_since_bump = 0;
+			k = std::min(k + (int)w->hc_bump, (int)SGP_OVERFLOW_COLOUR - 1); w->hc_probe_gap = 64; w->hc_probe_in = 64;
+		}
 		else if (plan.hc_probe >= 0) {
-			if (c1.hc_probe_big == 0u) { k = plan.hc_probe; w->hc_probe_gap = 16; w->hc_probe_in = 2; }
+			if (c1.hc_probe_big == 0u) { k = plan.hc_probe; w->hc_probe_gap = 16; w->hc_probe_in = 16; }
 			else { w->hc_probe_gap = std::min(2u * w->hc_probe_gap, 1024u); w->hc_probe_in = w->hc_probe_gap; }
 		} else if (w->hc_probe_in) w->hc_probe_in--;
 		w->hc_k = k;
+		if (w->hc_since_bump < 0xFFFFu) w->hc_since_bump++;
 	}
 	sgp_step_stats& st = w->stats;
 	memset(&st, 0, sizeof(st));
