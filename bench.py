@@ -376,12 +376,12 @@ def main():
     if not args.no_readback_leg:
         n_rb = max(1, min(args.steps, 60))
         w = leg_world()
-        rb_buf = np.empty(n_bodies + 8, dtype=abi.body_state_dtype)
+        # (sgp_world_read_active_view: the records in the library's pinned host buffer, which a caller's loop reads once -- no second copy)
         barrier()
         t1 = time.perf_counter()
         for _ in range(n_rb):
             one_step(w)
-            active_states = w.read_active(out=rb_buf)
+            active_states = w.read_active_view()
         barrier()
         readback_steps_per_s = n_rb / (time.perf_counter() - t1)
         n_read_back = len(active_states)

@@ -294,6 +294,9 @@ int  sgp_body_get_state(sgp_world* w, const uint32_t* ids, uint32_t n, sgp_body_
 int  sgp_world_read_states(sgp_world* w, uint32_t first, uint32_t n, sgp_body_state* out);
 /* The per-frame read-back loop (GUIClient.cpp:6581-6690): compacted states of every ACTIVE body. */
 int  sgp_world_read_active(sgp_world* w, sgp_body_state* out, uint32_t cap, uint32_t* n_out);
+/* The same without the copy into the caller's buffer: *view_out points at the library's pinned host buffer holding *n_out records, valid until
+ * the next call on this world that reads states back (the loop at GUIClient.cpp:6581-6690 only reads each record once). */
+int  sgp_world_read_active_view(sgp_world* w, const sgp_body_state** view_out, uint32_t* n_out);
 
 /* ---- world state ----------------------------------------------------------------------------- */
 /* setWaterBuoyancyEnabled / setWaterZ (PhysicsWorld.h:109-112) */

@@ -262,6 +262,7 @@ PROTOTYPES = {
     "body_get_state": (C.c_int, [vp, vp, u32, vp]),
     "world_read_states": (C.c_int, [vp, u32, u32, vp]),
     "world_read_active": (C.c_int, [vp, vp, u32, P(u32)]),
+    "world_read_active_view": (C.c_int, [vp, P(vp), P(u32)]),
     "world_set_water": (C.c_int, [vp, C.c_int, f32]),
     "world_set_contact_events": (C.c_int, [vp, C.c_int]),
     "world_step": (C.c_int, [vp, f32]),

@@ -1854,24 +1854,47 @@ SGP_API int sgp_world_read_states(sgp_world* w, uint32_t first, uint32_t n, sgp_
 	return SGP_OK;
 }
 
-SGP_API int sgp_world_read_active(sgp_world* w, sgp_body_state* out, uint32_t cap, uint32_t* n_out)
+// The compacted states of the active bodies land in the pinned staging buffer with ONE host sync: the gather, the counters and a copy sized
+// from the previous step's active count (+ slack) are queued together; only a count above that estimate costs a second copy.
+static int read_active_to_stage(sgp_world* w, uint32_t cap, uint32_t* n_out, uint32_t* m_out)
 {
-	if (!w || !n_out) return fail(SGP_ERR_INVALID, "sgp_world_read_active: NULL");
 	hipSetDevice(w->device);
 	{ int r = flush_cmds(w); if (r != SGP_OK) return r; }
 	const uint32_t lim = std::min(cap, w->dv.cap_bodies);
 	{ int r = ensure_stage(w, sizeof(sgp_body_state) * std::max(lim, 1u)); if (r != SGP_OK) return r; }
 	HIP_TRY(hipMemsetAsync(&w->dv.ctr->n_read_active, 0, sizeof(uint32_t), w->stream));
 	launch_gather_active(w->dv, w->high, (sgp_body_state*)w->stage_dev, lim, w->stream);
-	{ int r = read_counters(w); if (r != SGP_OK) return r; }
+	const uint32_t guess = std::min(lim, w->last_active + w->last_active / 16u + 256u);
+	if (guess) HIP_TRY(hipMemcpyAsync(w->stage_host, w->stage_dev, sizeof(sgp_body_state) * guess, hipMemcpyDeviceToHost, w->stream));
+	{ int r = read_counters(w); if (r != SGP_OK) return r; }      // (the one sync)
 	const uint32_t n = w->h_ctr->n_read_active;
 	const uint32_t m = std::min(n, lim);
-	if (m && out) {
-		HIP_TRY(hipMemcpyAsync(w->stage_host, w->stage_dev, sizeof(sgp_body_state) * m, hipMemcpyDeviceToHost, w->stream));
+	if (m > guess) {
+		HIP_TRY(hipMemcpyAsync((char*)w->stage_host + sizeof(sgp_body_state) * guess, (char*)w->stage_dev + sizeof(sgp_body_state) * guess,
+		                       sizeof(sgp_body_state) * (m - guess), hipMemcpyDeviceToHost, w->stream));
 		HIP_TRY(hipStreamSynchronize(w->stream));
-		memcpy(out, w->stage_host, sizeof(sgp_body_state) * m);
 	}
+	*n_out = n; *m_out = m;
+	return SGP_OK;
+}
+
+SGP_API int sgp_world_read_active(sgp_world* w, sgp_body_state* out, uint32_t cap, uint32_t* n_out)
+{
+	if (!w || !n_out) return fail(SGP_ERR_INVALID, "sgp_world_read_active: NULL");
+	uint32_t n = 0, m = 0;
+	{ int r = read_active_to_stage(w, out ? cap : 0u, &n, &m); if (r != SGP_OK) return r; }
+	if (m && out) memcpy(out, w->stage_host, sizeof(sgp_body_state) * m);
 	*n_out = n;
+	return SGP_OK;
+}
+
+SGP_API int sgp_world_read_active_view(sgp_world* w, const sgp_body_state** view_out, uint32_t* n_out)
+{
+	if (!w || !view_out || !n_out) return fail(SGP_ERR_INVALID, "sgp_world_read_active_view: NULL");
+	uint32_t n = 0, m = 0;
+	{ int r = read_active_to_stage(w, w->dv.cap_bodies, &n, &m); if (r != SGP_OK) return r; }
+	*view_out = (const sgp_body_state*)w->stage_host;
+	*n_out = m;
 	return SGP_OK;
 }
 

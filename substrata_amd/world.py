@@ -181,6 +181,19 @@ class CWorld:
         self._check(self._fn("world_read_active")(self._h, out.ctypes.data, int(cap), C.byref(n)), "world_read_active")
         return out[:min(n.value, cap)]
 
+    def read_active_view(self):
+        """States of the active bodies as a read-only view of the library's pinned host buffer (no copy into a caller buffer);
+        valid until the next read-back call on this world."""
+        ptr = C.c_void_p(0)
+        n = C.c_uint32(0)
+        self._check(self._fn("world_read_active_view")(self._h, C.byref(ptr), C.byref(n)), "world_read_active_view")
+        if n.value == 0:
+            return np.zeros(0, dtype=abi.body_state_dtype)
+        buf = (C.c_char * (n.value * abi.body_state_dtype.itemsize)).from_address(ptr.value)
+        a = np.frombuffer(buf, dtype=abi.body_state_dtype, count=n.value)
+        a.flags.writeable = False
+        return a
+
     # -- world ----------------------------------------------------------------------------------------------
     def set_water(self, enabled, z):
         self._check(self._fn("world_set_water")(self._h, int(bool(enabled)), float(z)), "world_set_water")

@@ -189,12 +189,46 @@ def test_sleeping_at_scale_and_read_active():
         w.step(DT)
     st = w.read_states(0, len(descs))
     assert st["active"][1:].sum() == 0
-    assert len(w.read_active()) == 0
+    assert len(w.read_active()) == 0 and len(w.read_active_view()) == 0
     deact = w.drain_events(abi.EVENT_DEACTIVATED)
     assert len(deact) == 10000 and np.array_equal(np.sort(deact["id"]), np.arange(1, 10001))
     assert np.all(st["lin_vel"] == 0)
     assert abs(float(st["pos"][1:, 2].mean()) - 0.5) < 0.02
     assert w.stats().num_pairs == 0            # a sleeping world generates no work
+    w.close()
+
+
+def test_read_active_copy_and_view_agree_with_read_states():
+    """The per-frame read-back of the active bodies: the copying call and the pinned-buffer view return the same records (as a set: the
+    compaction order is not part of the contract) and they are the active rows of read_states -- also right after the active count jumped
+    (the one-sync path sizes its copy from the previous step's count)."""
+    from substrata_amd.lib import World
+    g = scenes.ground()
+    d, _ = scenes.lattice(40, 40, 2, 1.5, 0.55, seed=7, jitter=0.0, random_rot=False)
+    descs = np.concatenate([g, d])
+    d["activate"] = 0                                  # a second batch, asleep until something hits it
+    d["pos"][:, 0] += 200.0
+    w = World(max_bodies=2 * len(descs) + 8)
+    w.add_batch(descs)
+    w.add_batch(d)
+    counts = []
+    for s in range(12):
+        w.step(DT)
+        if s == 6:                                     # wake the sleeping batch: the active count more than doubles between two read-backs
+            for i in range(len(descs), len(descs) + len(d)):
+                w.activate(i)
+        a = w.read_active().copy()
+        v = np.array(w.read_active_view())
+        st = w.read_states(0, len(descs) + len(d))
+        want = st[(st["id"] != abi.INVALID_ID) & (st["active"] != 0)]
+        assert len(a) == len(v) == len(want), (s, len(a), len(v), len(want))
+        counts.append(len(want))
+        for got in (a, v):
+            o = np.argsort(got["id"])
+            assert np.array_equal(got["id"][o], want["id"])
+            for f in ("pos", "rot", "lin_vel", "ang_vel"):
+                assert np.array_equal(got[f][o].view(np.uint32), want[f].view(np.uint32)), (s, f)
+    assert counts[0] == 3200 and counts[-1] == 6400, counts
     w.close()
 
 
