@@ -96,7 +96,7 @@ struct sgp_world {
 	// high colours by component: share of the constraints they may hold (per mille; SGP_HC_BUDGET, 0 = off), and the plan's correction of it
 	// hc_k: the first colour that goes to the components (-1: not chosen yet -> the budget rule).  One colour fewer after a step that left a
 	// component to the catch-all; one more after a probe (component sizes computed for hc_k - 1 without using them) found that it fits.
-	bool use_components = true; uint32_t hc_budget = 160; uint32_t n_cus = 256; int hc_k = -1; uint32_t hc_bump = 1, hc_since_bump = 0xFFFFu; uint32_t hc_probe_in = 8, hc_probe_gap = 16;
+	bool use_components = true; uint32_t hc_budget = 160; uint32_t n_cus = 256; uint32_t hc_min_colours = 4; int hc_k = -1; uint32_t hc_bump = 1, hc_since_bump = 0xFFFFu; uint32_t hc_probe_in = 8, hc_probe_gap = 16;
 	bool plan_seen = false;         // a step has run: plan_colour_count etc. describe the previous step
 	uint32_t graph_launches = 0, eager_steps = 0, idle_steps = 0;
 	bool grid_valid = false;                                   // the broad-phase grid matches the current poses (ray queries reuse it)
@@ -333,6 +333,7 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	{ const char* e = getenv("SGP_DEBUG_FLAGS"); w->dv.dbg_flags = e ? (uint32_t)atoi(e) : 0u; }
 	{ const char* e = getenv("SGP_HC_BUDGET"); if (e) { const int v = atoi(e); if (v <= 0) w->use_components = false; else w->hc_budget = (uint32_t)v; } }
 	{ int dev = 0, cus = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) w->n_cus = (uint32_t)cus; }
+	{ const char* e = getenv("SGP_HC_MIN_COLOURS"); if (e && atoi(e) >= 0) w->hc_min_colours = (uint32_t)atoi(e); }
 	{ const char* e = getenv("SGP_TAIL_THRESHOLD"); if (e && atoi(e) > 0) w->tail_threshold = (uint32_t)atoi(e); }
 	d.st = desc->settings;
 	d.gx = desc->gravity[0]; d.gy = desc->gravity[1]; d.gz = desc->gravity[2];
@@ -997,8 +998,9 @@ static void make_plan(const sgp_world* w, StepPlan& p)
 		for (int c = 0; c < SGP_OVERFLOW_COLOUR; ++c) total += w->plan_colour_count[c];
 		for (int c = tf; c < SGP_OVERFLOW_COLOUR; ++c) sum += w->plan_colour_count[c];
 		int k = tf;
-		// first guess: as many of the last colours as hold at most hc_budget (per mille) of the constraints; never more than twice that
-		const uint64_t budget = w->hc_k < 0 ? w->hc_budget : std::min<uint64_t>(2u * w->hc_budget, 1000u);
+		// first guess: as many of the last colours as hold at most hc_budget (per mille) of the constraints; probes may take it further (a world of
+		// scattered objects is all small components: every colour goes to them)
+		const uint64_t budget = w->hc_k < 0 ? w->hc_budget : 1000u;
 		// ... and never more than one round of workgroups can hold (a workgroup per compute unit: the launch replaces launches that are bound by
 		// latency, not throughput -- at a million bodies a colour of 400k constraints is better off in its own, coalesced launch)
 		const uint64_t fits = (uint64_t)w->n_cus * 256u * 18u / 25u;      // 256 lane pairs per workgroup, ~0.72 constraints per list entry
@@ -1014,6 +1016,11 @@ static void make_plan(const sgp_world* w, StepPlan& p)
 			p.hc_probe_est = bucket_up((uint32_t)ps + (uint32_t)(ps / 8));
 		}
 		p.tail_first = k;
+		// the component launch has a price of its own (the build, 40 us per step; a launch of ~14 us before its first phase): it pays when it
+		// replaces several launches -- a world of scattered objects with two or three colours is better off with those launches and the tail
+		int used = 0;
+		for (int c = k; c < SGP_OVERFLOW_COLOUR; ++c) used += w->plan_colour_count[c] != 0u;
+		if (used < (int)w->hc_min_colours) { p.hc_first = -1; p.hc_probe = -1; p.hc_est = 0; p.hc_probe_est = 0; p.tail_first = tf; }
 	}
 	p.sp = *w->h_sp;
 }

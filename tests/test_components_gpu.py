@@ -13,7 +13,7 @@ import parity
 
 pytestmark = pytest.mark.gpu
 
-ENV = ("SGP_NO_SMALL_WORLD", "SGP_TAIL_THRESHOLD", "SGP_HC_BUDGET")
+ENV = ("SGP_NO_SMALL_WORLD", "SGP_TAIL_THRESHOLD", "SGP_HC_BUDGET", "SGP_HC_MIN_COLOURS")
 
 
 def pile_scene(n_side=6, layers=14):

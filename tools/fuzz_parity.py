@@ -48,8 +48,9 @@ def run_seed(oracle, seed, steps, verbose=False):
     # ... and of the large ones: colours with launches of their own (threshold), the rest by connected component (budget in per mille; 0 = tail kernel)
     os.environ["SGP_TAIL_THRESHOLD"] = str(int(rng.choice([2, 8, 256])))
     os.environ["SGP_HC_BUDGET"] = str(int(rng.choice([0, 160, 400, 1000])))
+    os.environ["SGP_HC_MIN_COLOURS"] = str(int(rng.choice([0, 0, 4])))      # (0: the component launch even where it replaces a single colour)
     tw = parity.make_twin(oracle, max_bodies=2048)
-    for k in ("SGP_NO_SMALL_WORLD", "SGP_TAIL_THRESHOLD", "SGP_HC_BUDGET"):
+    for k in ("SGP_NO_SMALL_WORLD", "SGP_TAIL_THRESHOLD", "SGP_HC_BUDGET", "SGP_HC_MIN_COLOURS"):
         os.environ.pop(k, None)
     use_mesh = rng.random() < 0.6
     use_car = rng.random() < 0.5
