@@ -42,7 +42,7 @@ def test_plate_with_more_than_63_contacts(oracle, small_world):
         else:
             os.environ["SGP_NO_SMALL_WORLD"] = old
     tw.add_batch(descs)
-    seen_overflow = 0
+    seen_overflow = by_component = 0
     for s in range(1, 181):
         tw.step(DT)
         if s % 20 == 0 or s == 1:
@@ -50,9 +50,12 @@ def test_plate_with_more_than_63_contacts(oracle, small_world):
             assert (sg.num_manifolds, sg.num_contact_points, sg.num_colours, sg.num_overflow_constraints) == \
                    (sc.num_manifolds, sc.num_contact_points, sc.num_colours, sc.num_overflow_constraints), s
             seen_overflow = max(seen_overflow, sg.num_overflow_constraints)
+            by_component = max(by_component, sg.num_component_constraints)
             d = parity.compare(tw, len(descs))
             assert d["bit_exact"] and d["active_mismatch"] == 0, (s, d)
     assert seen_overflow > 0, "the scene never produced an overflow constraint"
+    # the general launch plan solves the overflow colour in the catch-all of the component launch, the small-world kernel on its own
+    assert (by_component > 0) == (not small_world), by_component
     # the pile has settled on the plate
     st = tw.gpu.read_states(0, len(descs))
     assert np.all(st["pos"][2:, 2] > 0.6) and np.all(np.abs(st["lin_vel"][1:]).max(axis=1) < 1.0)
