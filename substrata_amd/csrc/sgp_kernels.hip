@@ -2743,7 +2743,6 @@ __global__ void __launch_bounds__(TPB) k_contact_events(DV d)
 	const uint32_t n = min(d.ctr->n_manifolds, d.cap_manifolds);
 	for (uint32_t m = blockIdx.x * TPB + threadIdx.x; m < n; m += gridDim.x * TPB) {
 		const uint2 ab = d.man_ab[m];
-		const uint64_t key = ((uint64_t)ab.x << 32) | ab.y;
 		const bool persisted = (d.man_prev[m] & ~MAN_PREV_REUSED) != MAN_PREV_NONE;
 		// one atomic per wave and list (the lanes here are the loop's active lanes; wave_alloc serves those that call it together)
 		uint32_t k;
