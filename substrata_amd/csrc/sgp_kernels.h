@@ -79,6 +79,7 @@ struct StepCounters {
 	uint32_t hc_entries;         // entries of the component list (classes padded to whole workgroups)
 	uint32_t hc_n;               // constraints of the high colours
 	uint32_t hc_n_big;           // ... of them in components too large for a workgroup (solved by the catch-all)
+	uint32_t bp_dense;           // some tile's halo held more records than the small instance of k_bp_pairs stages in LDS
 	uint32_t hc_probe_big;       // launch-plan probe: constraints of components too large for a workgroup if one more colour went to the components
 	uint32_t hc_done;            // workgroups of the running solve launch that have finished (the last one runs the catch-all and clears it)
 	uint32_t round_n[32];        // uncoloured manifolds at the start of colouring round r (the host plans the next step's wide rounds from it)
@@ -261,7 +262,7 @@ void launch_bp_bounds(const DV& d, uint32_t nb, hipStream_t s);
 void launch_bp_cell(const DV& d, uint32_t nb, hipStream_t s);
 void launch_bp_scan(const DV& d, hipStream_t s);
 void launch_bp_scatter(const DV& d, uint32_t nb, hipStream_t s);
-void launch_bp_pairs(const DV& d, hipStream_t s);
+void launch_bp_pairs(const DV& d, int small_lds, hipStream_t s);      // small_lds: the instance with room for 4 workgroups per compute unit (sparse scenes)
 void launch_bp_large(const DV& d, uint32_t nb, hipStream_t s);
 void launch_narrowphase(const DV& d, uint32_t n_pairs_upper, hipStream_t s);
 void launch_narrowphase_hull(const DV& d, hipStream_t s);     // only worlds with hull shapes

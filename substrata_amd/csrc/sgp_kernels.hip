@@ -356,21 +356,28 @@ SGP_DEV void push_pair(const DV& d, uint32_t i, uint32_t j)
 }
 
 // pair staged in LDS (falls back to the global list when the tile's buffer is full)
-SGP_DEV void stage_pair(const DV& d, uint2* spairs, uint32_t* lcount, uint32_t i, uint32_t j);
+template <int PCAP> SGP_DEV void stage_pair(const DV& d, uint2* spairs, uint32_t* lcount, uint32_t i, uint32_t j);
 
 #define BP_TILE 4
 #define BP_H 2
 #define BP_HALO (BP_TILE + 2 * BP_H)
 #define BP_HALO_CELLS (BP_HALO * BP_HALO * BP_HALO)
 #define BP_INNER_CELLS (BP_TILE * BP_TILE * BP_TILE)
-#define BP_LDS_CAP 1536
-#define BP_PAIR_CAP 2048
+// LDS capacities of k_bp_pairs (records of a tile's halo, staged pairs): two instances.  The workgroups of this kernel spend two thirds of their
+// cycles waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.67: staging loads and barriers), so how many of them a compute unit holds decides the
+// launch: 70 KB of LDS = 2 workgroups per CU, 33 KB = 4 (config 3: 130 -> 81 us).  The small instance serves scenes whose halos hold at most
+// BP_LDS_CAP_SMALL records (k_bp_pairs reports a larger one in StepCounters::bp_dense, the next step's plan then takes the large instance);
+// a halo above the instance's capacity is read from global memory either way.
+#define BP_LDS_CAP_SMALL 640
+#define BP_PAIR_CAP_SMALL 1024
+#define BP_LDS_CAP_LARGE 1536
+#define BP_PAIR_CAP_LARGE 2048
 #define BP_SPLIT 4
 
-SGP_DEV void stage_pair(const DV& d, uint2* spairs, uint32_t* lcount, uint32_t i, uint32_t j)
+template <int PCAP> SGP_DEV void stage_pair(const DV& d, uint2* spairs, uint32_t* lcount, uint32_t i, uint32_t j)
 {
 	const uint32_t k = atomicAdd(lcount, 1u);
-	if (k < BP_PAIR_CAP) spairs[k] = make_uint2(i < j ? i : j, i < j ? j : i);
+	if (k < (uint32_t)PCAP) spairs[k] = make_uint2(i < j ? i : j, i < j ? j : i);
 	else push_pair(d, i, j);
 }
 
@@ -398,7 +405,7 @@ SGP_DEV uint32_t block_scan_512(uint32_t* a, int n, uint32_t* wave_tot)
 // partner of a body has its centre within 2 cells of the body's own AABB: the tile plus a 2-cell halo (8x8x8 cells = 64
 // contiguous runs of the cell-sorted records) is staged in LDS and every active body of the tile scans only the cells its
 // own AABB (+- R_max + margin) reaches.  A pair is emitted once: by the lower id when both are active, else by the active one.
-__global__ void __launch_bounds__(TPB) k_bp_pairs(DV d)
+template <int BP_LDS_CAP, int BP_PAIR_CAP> __global__ void __launch_bounds__(TPB) k_bp_pairs(DV d)
 {
 	__shared__ float4 smin[BP_LDS_CAP];
 	__shared__ float4 smax[BP_LDS_CAP];
@@ -449,7 +456,8 @@ __global__ void __launch_bounds__(TPB) k_bp_pairs(DV d)
 		const uint32_t total = block_scan_512(cstart, BP_HALO_CELLS, wave_tot);
 		if (threadIdx.x == 0) cstart[BP_HALO_CELLS] = total;
 		__syncthreads();
-		const bool in_lds = total <= BP_LDS_CAP;
+		const bool in_lds = total <= (uint32_t)BP_LDS_CAP;
+		if (threadIdx.x == 0 && total > (uint32_t)BP_LDS_CAP_SMALL) d.ctr->bp_dense = 1u;      // (plain store of the same value from every such tile)
 		if (in_lds) {
 			for (uint32_t q = threadIdx.x; q < total; q += TPB) {
 				int lo = 0, hi = BP_HALO_CELLS - 1;
@@ -493,7 +501,7 @@ __global__ void __launch_bounds__(TPB) k_bp_pairs(DV d)
 						const uint32_t j = __float_as_uint(mxj.w);
 						if (j == i) continue;
 						if (f_active_for_pairs(__float_as_uint(mnj.w)) && j < i) continue;
-						if (rec_pair_passes(spec, mni, mxi, mnj, mxj)) stage_pair(d, spairs, &lcount, i, j);
+						if (rec_pair_passes(spec, mni, mxi, mnj, mxj)) stage_pair<BP_PAIR_CAP>(d, spairs, &lcount, i, j);
 					}
 				} else {
 					for (int c = xl; c <= xh; ++c) {
@@ -503,7 +511,7 @@ __global__ void __launch_bounds__(TPB) k_bp_pairs(DV d)
 							const uint32_t j = __float_as_uint(mxj.w);
 							if (j == i) continue;
 							if (f_active_for_pairs(__float_as_uint(mnj.w)) && j < i) continue;
-							if (rec_pair_passes(spec, mni, mxi, mnj, mxj)) stage_pair(d, spairs, &lcount, i, j);
+							if (rec_pair_passes(spec, mni, mxi, mnj, mxj)) stage_pair<BP_PAIR_CAP>(d, spairs, &lcount, i, j);
 						}
 					}
 				}
@@ -3732,7 +3740,11 @@ void launch_bp_scan(const DV& d, hipStream_t s)
 	hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(TPB), 0, s, d.cell_start, d.scan_block_sums, n);
 }
 void launch_bp_scatter(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_bp_scatter, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
-void launch_bp_pairs(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_bp_pairs, dim3(4096), dim3(TPB), 0, s, d); }      // (fewer workgroups walking several tiles each were slower: 512 -> 159 us against 132 us, the tiles are uneven)
+void launch_bp_pairs(const DV& d, int small_lds, hipStream_t s)
+{
+	if (small_lds) hipLaunchKernelGGL((k_bp_pairs<BP_LDS_CAP_SMALL, BP_PAIR_CAP_SMALL>), dim3(4096), dim3(TPB), 0, s, d);
+	else hipLaunchKernelGGL((k_bp_pairs<BP_LDS_CAP_LARGE, BP_PAIR_CAP_LARGE>), dim3(4096), dim3(TPB), 0, s, d);
+}      // (fewer workgroups walking several tiles each were slower: 512 -> 159 us against 132 us, the tiles are uneven)
 void launch_bp_large(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_bp_large, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_narrowphase(const DV& d, uint32_t est, hipStream_t s)
 {

@@ -97,6 +97,7 @@ struct sgp_world {
 	// hc_k: the first colour that goes to the components (-1: not chosen yet -> the budget rule).  One colour fewer after a step that left a
 	// component to the catch-all; one more after a probe (component sizes computed for hc_k - 1 without using them) found that it fits.
 	bool use_components = true; uint32_t hc_budget = 160; uint32_t n_cus = 256; uint32_t hc_min_colours = 4; int hc_k = -1; uint32_t hc_bump = 1, hc_since_bump = 0xFFFFu; uint32_t hc_probe_in = 8, hc_probe_gap = 16;
+	bool bp_dense_last = false;     // the previous step's broad phase met a halo too large for the small instance of k_bp_pairs
 	bool plan_seen = false;         // a step has run: plan_colour_count etc. describe the previous step
 	uint32_t graph_launches = 0, eager_steps = 0, idle_steps = 0;
 	bool grid_valid = false;                                   // the broad-phase grid matches the current poses (ray queries reuse it)
@@ -951,6 +952,7 @@ struct StepPlan {
 	int      has_hulls;          // some body may be a convex hull: run the hull-pair narrow phase
 	int      small_colouring;    // the whole colouring in one single-workgroup launch (k_colour_finish builds its own worklist)
 	int      small_world;        // warm start + velocity iterations as ONE single-workgroup launch (k_solve_small)
+	int      bp_small;           // k_bp_pairs instance with the small LDS footprint (the previous step met no dense halo)
 	int      hc_first;           // colours >= hc_first (<= tail_first) are solved by connected component, one launch per pass; -1: off (tail kernel)
 	uint32_t hc_est;             // their constraints (previous step)
 	int      hc_probe;           // >= 0: this step also computes the component sizes for hc_probe = hc_first - 1 (not used for solving)
@@ -990,6 +992,7 @@ static void make_plan(const sgp_world* w, StepPlan& p)
 	p.small_colouring = (w->last_manifolds <= SGP_SMALL_COLOURING_MANIFOLDS && w->high <= SGP_SMALL_WORLD_BODIES) ? 1 : 0;
 	p.small_world = (tf == 0 && w->high <= SGP_SMALL_WORLD_BODIES && w->n_vehicles == 0 && w->use_small_world) ? 1 : 0;
 	p.small_pairs = (w->n_con <= 384u || w->n_con > 512u) ? 1 : 0;
+	p.bp_small = w->bp_dense_last ? 0 : 1;
 	p.hc_first = -1;
 	if (!p.small_world && w->use_components && w->n_con != 0) {      // (no histogram yet: the tail kernel takes whatever the first step brings)
 		// the high colours: as many of the last colours as hold at most hc_budget (per mille) of the constraints -- few enough that the
@@ -1039,7 +1042,7 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 	{ KScope k(w, KC_BP_SCAN); launch_bp_scan(d, s); }
 	{ KScope k(w, KC_BP_SCATTER); launch_bp_scatter(d, nb, s); }
 	if (p.n_vehicles) { KScope k(w, KC_VEHICLE); launch_vehicle_pre(d, s); }
-	{ KScope k(w, KC_BP_PAIRS); launch_bp_pairs(d, s); }
+	{ KScope k(w, KC_BP_PAIRS); launch_bp_pairs(d, p.bp_small, s); }
 	{ KScope k(w, KC_BP_LARGE); launch_bp_large(d, nb, s); }
 	STAGE_MARK(2);
 	// -- 3. narrow phase, wake-ups, per-body solver records (+ contact events, which see the velocities before the solve)
@@ -1179,6 +1182,7 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	memcpy(w->plan_round_n, c1.round_n, sizeof(w->plan_round_n));
 	for (int c = 0; c < SGP_MAX_COLOURS; ++c) w->plan_colour_count[c] = c1.colour_count[c];
 	w->plan_seen = true;
+	w->bp_dense_last = c1.bp_dense != 0u;
 	// the launch plan's first component colour: one colour fewer after a step that left a component to the serial catch-all (which costs
 	// more per pass than the launch of one more colour); one more when this step's probe found that the next colour's components fit too
 	// (probes get rarer while they fail, up to one in 1024 steps; a success is followed up at once)
