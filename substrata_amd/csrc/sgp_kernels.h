@@ -202,6 +202,7 @@ struct DV {
 	float4*   sorted_min;      // cell-sorted copy: aabb min xyz, flags (bits) w
 	float4*   sorted_max;      // cell-sorted copy: aabb max xyz, body id (bits) w
 	struct BpGrid* grid;       // per-step dense grid parameters (device)
+	uint32_t* grid_cells_used; // cells of the most recent grid (what the next step has to clear of the cell tables)
 	const uint32_t* large_ids;
 	uint2*    pairs;
 	// narrow phase output (manifolds, unordered)

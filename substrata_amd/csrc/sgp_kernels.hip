@@ -147,7 +147,9 @@ __global__ void __launch_bounds__(TPB) k_step_begin(DV d, StepParams sp, uint32_
 	}
 	uint32_t* c = (uint32_t*)d.ctr;
 	for (uint32_t i = tid; i < sizeof(StepCounters) / 4; i += stride) c[i] = 0;
-	for (uint32_t i = tid; i < d.table_size + 4; i += stride) { d.cell_count[i] = 0; d.cell_fill[i] = 0; }
+	// the cell tables: only what the previous grid used (everything above it is still zero; the table has room for far more cells than a step uses)
+	const uint32_t used = min(*d.grid_cells_used, d.table_size) + 4u;
+	for (uint32_t i = tid; i < used; i += stride) { d.cell_count[i] = 0; d.cell_fill[i] = 0; }
 	if (reset_scratch) {
 		const uint32_t n = min(nb, d.cap_bodies);
 		for (uint32_t i = tid; i < n; i += stride) { d.colour_mask[i] = 0ull; d.claim[0][i] = ~0ull; d.claim[1][i] = ~0ull; }
@@ -231,6 +233,7 @@ __global__ void k_bp_grid_params(DV d)
 	g.cell = cell; g.inv_cell = 1.0f / cell;
 	g.n_cells = (uint32_t)g.nx * (uint32_t)g.ny * (uint32_t)g.nz;
 	*d.grid = g;
+	*d.grid_cells_used = g.n_cells;
 }
 
 __global__ void __launch_bounds__(TPB) k_bp_cell(DV d)
@@ -253,9 +256,11 @@ __global__ void __launch_bounds__(TPB) k_bp_cell(DV d)
 }
 
 // exclusive scan of cell_count[0..n) -> cell_start, 3 passes, 1024 elements per block
-__global__ void __launch_bounds__(TPB) k_scan_blocks(const uint32_t* in, uint32_t* out, uint32_t* block_sums, uint32_t n)
+__global__ void __launch_bounds__(TPB) k_scan_blocks(const uint32_t* in, uint32_t* out, uint32_t* block_sums, uint32_t n_cap, const uint32_t* n_live)
 {
 	__shared__ uint32_t wave_sums[TPB / 64];
+	const uint32_t n = min(n_cap, *n_live + 1u);          // (the cells of this step's grid + the end sentinel; the launch covers the table's capacity)
+	if (blockIdx.x * (TPB * 4u) >= n) { if (threadIdx.x == TPB - 1) block_sums[blockIdx.x] = 0u; return; }
 	const uint32_t base = (blockIdx.x * TPB + threadIdx.x) * 4;
 	uint32_t v[4];
 #pragma unroll
@@ -277,8 +282,9 @@ __global__ void __launch_bounds__(TPB) k_scan_blocks(const uint32_t* in, uint32_
 	if (threadIdx.x == TPB - 1) block_sums[blockIdx.x] = wbase + x;
 }
 
-__global__ void __launch_bounds__(1024) k_scan_sums(uint32_t* block_sums, uint32_t nb)
+__global__ void __launch_bounds__(1024) k_scan_sums(uint32_t* block_sums, uint32_t nb_cap, uint32_t n_cap, const uint32_t* n_live)
 {
+	const uint32_t nb = min(nb_cap, (min(n_cap, *n_live + 1u) + TPB * 4u - 1u) / (TPB * 4u));      // (the blocks that hold cells of this step's grid)
 	__shared__ uint32_t wave_sums[16];
 	__shared__ uint32_t carry;
 	if (threadIdx.x == 0) carry = 0;
@@ -301,8 +307,10 @@ __global__ void __launch_bounds__(1024) k_scan_sums(uint32_t* block_sums, uint32
 	}
 }
 
-__global__ void __launch_bounds__(TPB) k_scan_add(uint32_t* out, const uint32_t* block_sums, uint32_t n)
+__global__ void __launch_bounds__(TPB) k_scan_add(uint32_t* out, const uint32_t* block_sums, uint32_t n_cap, const uint32_t* n_live)
 {
+	const uint32_t n = min(n_cap, *n_live + 1u);
+	if (blockIdx.x * (TPB * 4u) >= n) return;
 	const uint32_t base = (blockIdx.x * TPB + threadIdx.x) * 4;
 	const uint32_t add = block_sums[blockIdx.x];
 #pragma unroll
@@ -3735,9 +3743,9 @@ void launch_bp_scan(const DV& d, hipStream_t s)
 {
 	const uint32_t n = d.table_size + 1;
 	const uint32_t nb = (n + 1023) / 1024;
-	hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(TPB), 0, s, d.cell_count, d.cell_start, d.scan_block_sums, n);
-	hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, d.scan_block_sums, nb);
-	hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(TPB), 0, s, d.cell_start, d.scan_block_sums, n);
+	hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(TPB), 0, s, d.cell_count, d.cell_start, d.scan_block_sums, n, d.grid_cells_used);
+	hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, d.scan_block_sums, nb, n, d.grid_cells_used);
+	hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(TPB), 0, s, d.cell_start, d.scan_block_sums, n, d.grid_cells_used);
 }
 void launch_bp_scatter(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_bp_scatter, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_bp_pairs(const DV& d, int small_lds, hipStream_t s)

@@ -287,7 +287,10 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	DEV_ALLOC(d.colour_mask, N); DEV_ALLOC(d.body_con, (size_t)N * SGP_MAX_COLOURS); DEV_ALLOC(d.claim[0], N); DEV_ALLOC(d.claim[1], N);
 	DEV_ALLOC(d.island, N); DEV_ALLOC(d.island_awake, N); DEV_ALLOC(d.awake_mark, N); DEV_ALLOC(d.export_counts, N / 256 + 2);
 	DEV_ALLOC(d.sbody, 4 * (size_t)N);
-	d.table_size = std::max(1024u, next_pow2(2u * N));
+	// cells of the broad-phase grid: room for 16 per body slot (clearing and scanning follow the cells a step's grid really has, not this capacity).  The grid covers the bounds of all small bodies with cells of R_max + margin and coarsens them
+	// (x 1.5) until it fits this table: a pile that has spread out (config 2 after its tower fell: 60 x 60 x 10 m of 1 m cells) then lands in
+	// cells with several bodies each and k_bp_pairs scans hundreds of candidates per body (0.23 ms for 10k boxes with 2 cells per slot, 0.02 ms with 8 or more).
+	{ const char* e = getenv("SGP_GRID_CELLS_PER_BODY"); const uint32_t per = e && atoi(e) > 0 ? (uint32_t)atoi(e) : 16u; d.table_size = std::max(1024u, next_pow2(per * N)); }
 	DEV_ALLOC(d.cell_hash, N);
 	DEV_ALLOC(d.cell_count, d.table_size + 4); DEV_ALLOC(d.cell_start, d.table_size + 4); DEV_ALLOC(d.cell_fill, d.table_size + 4);
 	DEV_ALLOC(w->d_large, N); w->cap_large = N; d.large_ids = w->d_large;
@@ -304,7 +307,7 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 		HIP_TRY(hipMemcpyAsync(&w->d_hulls[0], &w->hulls[0], sizeof(sgd_hull), hipMemcpyHostToDevice, w->stream));
 		d.n_hulls = 1;
 	}
-	DEV_ALLOC(d.sorted_min, N); DEV_ALLOC(d.sorted_max, N); DEV_ALLOC(d.grid, 1); DEV_ALLOC(d.scan_block_sums, (d.table_size + 1) / 1024 + 2);
+	DEV_ALLOC(d.sorted_min, N); DEV_ALLOC(d.sorted_max, N); DEV_ALLOC(d.grid, 1); DEV_ALLOC(d.grid_cells_used, 1); DEV_ALLOC(d.scan_block_sums, (d.table_size + 1) / 1024 + 2);
 	DEV_ALLOC(d.pairs, P);
 	DEV_ALLOC(d.man_ab, M); DEV_ALLOC(d.man_n, M); DEV_ALLOC(d.man_colour, M); DEV_ALLOC(d.man_prio, M); DEV_ALLOC(d.man_prev, M); DEV_ALLOC(d.man_slot, M);
 	DEV_ALLOC(d.hc_root, N); DEV_ALLOC(d.hc_count, N); DEV_ALLOC(d.hc_base, N); DEV_ALLOC(d.hc_rank, M);
