@@ -373,10 +373,10 @@ template <int PCAP> SGP_DEV void stage_pair(const DV& d, uint2* spairs, uint32_t
 #define BP_INNER_CELLS (BP_TILE * BP_TILE * BP_TILE)
 // LDS capacities of k_bp_pairs (records of a tile's halo, staged pairs): two instances.  The workgroups of this kernel spend two thirds of their
 // cycles waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.67: staging loads and barriers), so how many of them a compute unit holds decides the
-// launch: 70 KB of LDS = 2 workgroups per CU, 33 KB = 4 (config 3: 130 -> 81 us).  The small instance serves scenes whose halos hold at most
+// launch: 70 KB of LDS = 2 workgroups per CU, 37 KB = 4 (config 3: 130 -> 83 us; its halos hold 500-640 records).  The small instance serves scenes whose halos hold at most
 // BP_LDS_CAP_SMALL records (k_bp_pairs reports a larger one in StepCounters::bp_dense, the next step's plan then takes the large instance);
 // a halo above the instance's capacity is read from global memory either way.
-#define BP_LDS_CAP_SMALL 640
+#define BP_LDS_CAP_SMALL 768
 #define BP_PAIR_CAP_SMALL 1024
 #define BP_LDS_CAP_LARGE 1536
 #define BP_PAIR_CAP_LARGE 2048
