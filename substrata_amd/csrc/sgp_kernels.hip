@@ -672,7 +672,9 @@ SGP_DEV bool reuse_cached_manifold(const DV& d, uint2 ab, uint32_t fa, uint32_t 
 // Every atomic on the one manifold counter costs ~12 ns however many lanes it serves (same-address atomics serialise in L2): with one per wave
 // the 9k wave-iterations of config 3 spent 110 of the kernel's 230 us queueing for it (measured with parts of the output switched off: no output 108 us, slot allocated but nothing written 224 us, full 230 us).  The
 // workgroup therefore allocates the slots of all its manifolds of an iteration with ONE atomic.
-__global__ void __launch_bounds__(TPB) k_narrowphase(DV d)
+// (at least four waves per SIMD: the kernel waits for its gathers three cycles in four, and 128 instead of 157 registers per lane -- a few spills to
+// scratch -- buy a third more waves to wait with: 138 -> 116 us at config 3; five waves: 143 us, six: 178 us)
+__global__ void __launch_bounds__(TPB, 4) k_narrowphase(DV d)
 {
 	__shared__ uint32_t s_wave_cnt[TPB / 64];
 	__shared__ uint32_t s_base;
@@ -876,7 +878,7 @@ SGP_DEV int hull_sat_search_wave(const sgd_hview* A, const sgd_hview* B, float m
 //                            each idling 63 lanes of its own.
 struct HullWork { uint2 ab; sgd_hull_sat r; uint32_t round_other; };
 
-__global__ void __launch_bounds__(64) k_narrowphase_hull(DV d)
+__global__ void __launch_bounds__(64, 3) k_narrowphase_hull(DV d)
 {
 	const uint32_t n = min(d.ctr->n_hull_pairs, d.cap_hull_pairs);
 	for (uint32_t p = blockIdx.x; p < n; p += gridDim.x) {
@@ -900,7 +902,7 @@ __global__ void __launch_bounds__(64) k_narrowphase_hull(DV d)
 	}
 }
 
-__global__ void __launch_bounds__(64) k_narrowphase_hull_manifold(DV d)
+__global__ void __launch_bounds__(64, 3) k_narrowphase_hull_manifold(DV d)
 {
 	const uint32_t n = min(d.ctr->n_hull_pairs, d.cap_hull_pairs);
 	for (uint32_t k = blockIdx.x * 64 + threadIdx.x; k < n; k += gridDim.x * 64) {
