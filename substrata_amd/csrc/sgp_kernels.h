@@ -282,7 +282,7 @@ void launch_solve_tail(const DV& d, int first_colour, int mode, hipStream_t s);
 // small worlds: warm start + all velocity iterations in one single-workgroup launch (needs n_slots <= SGP_SMALL_WORLD_BODIES)
 #define SGP_SMALL_WORLD_BODIES 2048
 void launch_hc_build(const DV& d, int first_colour, uint32_t est, hipStream_t s);      // components of the colours >= first_colour (after launch_setup)
-void launch_hc_probe(const DV& d, int probe_colour, uint32_t probe_est, int first_colour, uint32_t est, hipStream_t s);      // before launch_hc_build: component sizes if the components started at probe_colour
+void launch_hc_probe(const DV& d, int probe_colour, uint32_t probe_est, hipStream_t s);      // before launch_hc_build: component sizes if the components started at probe_colour
 void launch_solve_hc(const DV& d, int first_colour, uint32_t est, int mode, hipStream_t s);   // one pass over them + the overflow colour
 void launch_solve_small(const DV& d, int warm_start, int iterations, int lane_pairs, hipStream_t s);      // lane_pairs: two lanes per constraint (<= 384 constraints stay in registers), else one (<= 512)
 void launch_integrate_pose(const DV& d, uint32_t nb, hipStream_t s);

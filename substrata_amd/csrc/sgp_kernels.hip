@@ -3808,14 +3808,13 @@ void launch_hc_build(const DV& d, int first_colour, uint32_t est, hipStream_t s)
 	hipLaunchKernelGGL(k_hc_scatter, dim3(blocks), dim3(TPB), 0, s, d, first_colour);
 	hipLaunchKernelGGL(k_hc_sort, dim3(std::max(1u, std::min(2048u, (2u * est + HC_CLASSES * HC_WG_PAIRS) / HC_WG_PAIRS))), dim3(HC_WG_PAIRS), 0, s, d);
 }
-void launch_hc_probe(const DV& d, int probe_colour, uint32_t probe_est, int first_colour, uint32_t est, hipStream_t s)
+void launch_hc_probe(const DV& d, int probe_colour, uint32_t probe_est, hipStream_t s)
 {
 	const uint32_t pb = std::max(1u, std::min(1024u, (probe_est + probe_est / 8 + TPB - 1) / TPB));
 	hipLaunchKernelGGL(k_hc_hook, dim3(pb), dim3(TPB), 0, s, d, probe_colour);
 	hipLaunchKernelGGL(k_hc_count, dim3(pb), dim3(TPB), 0, s, d, probe_colour);
 	hipLaunchKernelGGL(k_hc_probe, dim3(pb), dim3(TPB), 0, s, d, probe_colour);
 	hipLaunchKernelGGL(k_hc_init, dim3(pb), dim3(TPB), 0, s, d, probe_colour);      // (every body the probe touched, i.e. also every body of the real build)
-	(void)first_colour; (void)est;
 }
 void launch_solve_hc(const DV& d, int first_colour, uint32_t est, int mode, hipStream_t s)
 {

@@ -1070,7 +1070,7 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 	}
 	{ KScope k(w, KC_COLOUR_COUNT); launch_colour_count(d, p.est_man, s); }
 	{ KScope k(w, KC_SETUP); launch_setup(d, p.est_man, s); }
-	if (p.hc_first >= 0 && p.hc_probe >= 0) { KScope k(w, KC_SETUP); launch_hc_probe(d, p.hc_probe, p.hc_probe_est, p.hc_first, p.hc_est, s); }
+	if (p.hc_first >= 0 && p.hc_probe >= 0) { KScope k(w, KC_SETUP); launch_hc_probe(d, p.hc_probe, p.hc_probe_est, s); }
 	if (p.hc_first >= 0) { KScope k(w, KC_SETUP); launch_hc_build(d, p.hc_first, p.hc_est, s); }
 	STAGE_MARK(4);
 	// -- 5. warm start + velocity iterations: one launch per planned colour, everything else in the single-workgroup tail
