@@ -1220,9 +1220,10 @@ SGP_DEV uint32_t ht_hash(uint64_t key, uint32_t mask) { return (uint32_t)(sgp_mi
 
 SGP_DEV uint32_t cache_find(const DV& d, uint64_t key)
 {
-	const uint32_t mask = d.ht_size - 1;
+	const uint32_t size = *d.ht_cur;          // (the part of the table the last rebuild used: k_cache_clear)
+	const uint32_t mask = size - 1;
 	uint32_t h = ht_hash(key, mask);
-	for (uint32_t probe = 0; probe < d.ht_size; ++probe) {
+	for (uint32_t probe = 0; probe < size; ++probe) {
 		const uint64_t k = d.ht_keys[h];
 		if (k == key) return d.ht_vals[h];
 		if (k == ~0ull) return 0xFFFFFFFFu;
@@ -2741,14 +2742,31 @@ __global__ void __launch_bounds__(TPB) k_buoyancy(DV d)
 // ---------------------------------------------------------------------------------------------------------------
 // contact cache (pair key -> constraint slot) for the next step's warm start; contact events
 
+// The table is allocated for the world's manifold capacity, but a step uses (and clears) only the power of two that holds four times its
+// constraints: 8 MB instead of 33 MB per step at config 3, and a table that stays in the caches between the rebuild and the next step's probes.
+SGP_DEV uint32_t cache_table_size(const DV& d)
+{
+	const uint32_t want = 4u * max(d.ctr->n_constraints, 256u);
+	uint32_t size = 1024u;
+	while (size < want && size < d.ht_size) size <<= 1;
+	return min(size, d.ht_size);
+}
+__global__ void __launch_bounds__(TPB) k_cache_clear(DV d)
+{
+	const uint32_t size = cache_table_size(d);
+	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < size; i += gridDim.x * TPB) d.ht_keys[i] = ~0ull;
+	if (blockIdx.x == 0 && threadIdx.x == 0) *d.ht_cur = size;
+}
+
 __global__ void __launch_bounds__(TPB) k_cache_build(DV d)
 {
 	const uint32_t n_con = d.ctr->n_constraints;
-	const uint32_t mask = d.ht_size - 1;
+	const uint32_t size = *d.ht_cur;
+	const uint32_t mask = size - 1;
 	for (uint32_t k = blockIdx.x * TPB + threadIdx.x; k < n_con; k += gridDim.x * TPB) {
 		const uint64_t key = CUR(d).key[k];
 		uint32_t h = ht_hash(key, mask);
-		for (uint32_t probe = 0; probe < d.ht_size; ++probe) {
+		for (uint32_t probe = 0; probe < size; ++probe) {
 			const unsigned long long old = atomicCAS((unsigned long long*)&d.ht_keys[h], ~0ull, (unsigned long long)key);
 			if (old == ~0ull || old == key) { d.ht_vals[h] = k; break; }
 			h = (h + 1) & mask;
@@ -3837,7 +3855,11 @@ void launch_island_hook(const DV& d, uint32_t n_con, hipStream_t s) { hipLaunchK
 void launch_island_flag(const DV& d, uint32_t n_con, hipStream_t s) { hipLaunchKernelGGL(k_island_flag, dim3(stride_grid(n_con)), dim3(TPB), 0, s, d); }
 void launch_sleep_apply(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_sleep_apply, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_buoyancy(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_buoyancy, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
-void launch_cache_build(const DV& d, uint32_t n_con, hipStream_t s) { hipLaunchKernelGGL(k_cache_build, dim3(stride_grid(n_con)), dim3(TPB), 0, s, d); }
+void launch_cache_build(const DV& d, uint32_t n_con, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_cache_clear, dim3(std::max(64u, std::min(1024u, n_con / 256u))), dim3(TPB), 0, s, d);
+	hipLaunchKernelGGL(k_cache_build, dim3(stride_grid(n_con)), dim3(TPB), 0, s, d);
+}
 void launch_contact_events(const DV& d, uint32_t est, hipStream_t s) { hipLaunchKernelGGL(k_contact_events, dim3(stride_grid(est)), dim3(TPB), 0, s, d); }
 void launch_ghost_refresh(const DV& d, const GhostRefresh* recs, uint32_t n, hipStream_t s) { if (n) hipLaunchKernelGGL(k_ghost_refresh, dim3(blocks_for(n)), dim3(TPB), 0, s, d, recs, n); }
 void launch_apply_cmds(const DV& d, const BodyCmd* cmds, const uint32_t* run_start, uint32_t n_runs, hipStream_t s) { if (n_runs) hipLaunchKernelGGL(k_apply_cmds, dim3(blocks_for(n_runs)), dim3(TPB), 0, s, d, cmds, run_start, n_runs); }

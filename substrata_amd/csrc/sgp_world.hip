@@ -321,6 +321,8 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	DEV_ALLOC(d.ht_keys, w->ht_alloc); DEV_ALLOC(d.ht_vals, w->ht_alloc);
 	HIP_TRY(hipMemsetAsync(d.ht_keys, 0xFF, sizeof(uint64_t) * w->ht_alloc, w->stream));      // empty contact cache
 	d.ht_size = w->ht_alloc;
+	DEV_ALLOC(d.ht_cur, 1);
+	{ static const uint32_t first = 1024u; HIP_TRY(hipMemcpyAsync(d.ht_cur, &first, sizeof(first), hipMemcpyHostToDevice, w->stream)); }      // (an empty table: any size will do)
 	DEV_ALLOC(d.cstarts, SGP_MAX_COLOURS + 2);
 	DEV_ALLOC(d.ctr, 1); DEV_ALLOC(d.evc, 1);
 	DEV_ALLOC(d.ev_activated, N); DEV_ALLOC(d.ev_deactivated, N); DEV_ALLOC(d.ev_water, N);
@@ -1106,7 +1108,6 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 	if (p.water) { KScope k(w, KC_BUOYANCY); launch_buoyancy(d, nb, s); }
 	{
 		KScope k(w, KC_CACHE_BUILD);
-		launch_fill_u64(d.ht_keys, ~0ull, d.ht_size, s);
 		launch_cache_build(d, p.est_man, s);
 	}
 	STAGE_MARK(8);
