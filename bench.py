@@ -376,12 +376,13 @@ def main():
     if not args.no_readback_leg:
         n_rb = max(1, min(args.steps, 60))
         w = leg_world()
-        # (sgp_world_read_active_view: the records in the library's pinned host buffer, which a caller's loop reads once -- no second copy)
+        # (sgp_world_read_active_poses_view: id + position + rotation per active body -- all GUIClient's loop reads, GetPositionAndRotation at
+        # GUIClient.cpp:6586-6588 -- in the library's pinned host buffer, which a caller's loop reads once: no second copy)
         barrier()
         t1 = time.perf_counter()
         for _ in range(n_rb):
             one_step(w)
-            active_states = w.read_active_view()
+            active_states = w.read_active_poses_view()
         barrier()
         readback_steps_per_s = n_rb / (time.perf_counter() - t1)
         n_read_back = len(active_states)

@@ -297,6 +297,13 @@ int  sgp_world_read_active(sgp_world* w, sgp_body_state* out, uint32_t cap, uint
 /* The same without the copy into the caller's buffer: *view_out points at the library's pinned host buffer holding *n_out records, valid until
  * the next call on this world that reads states back (the loop at GUIClient.cpp:6581-6690 only reads each record once). */
 int  sgp_world_read_active_view(sgp_world* w, const sgp_body_state** view_out, uint32_t* n_out);
+/* ... and with nothing but what that loop reads per activated body (GetPositionAndRotation, GUIClient.cpp:6586-6588): 32 bytes instead of 68. */
+typedef struct sgp_body_pose {
+	float    pos[3];
+	uint32_t id;
+	float    rot[4];            /* x, y, z, w */
+} sgp_body_pose;
+int  sgp_world_read_active_poses_view(sgp_world* w, const sgp_body_pose** view_out, uint32_t* n_out);
 
 /* ---- world state ----------------------------------------------------------------------------- */
 /* setWaterBuoyancyEnabled / setWaterZ (PhysicsWorld.h:109-112) */

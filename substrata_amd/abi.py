@@ -52,6 +52,10 @@ class BodyState(C.Structure):
                 ("active", u32), ("underwater", u32), ("submerged_volume", f32), ("id", u32)]
 
 
+class BodyPose(C.Structure):
+    _fields_ = [("pos", f32 * 3), ("id", u32), ("rot", f32 * 4)]
+
+
 class PoseVel(C.Structure):
     _fields_ = [("pos", f32 * 3), ("rot", f32 * 4), ("lin_vel", f32 * 3), ("ang_vel", f32 * 3)]
 
@@ -212,6 +216,7 @@ STRUCTS = {"sgp_settings": Settings, "sgp_world_desc": WorldDesc, "sgp_body_desc
 
 body_desc_dtype = np.dtype(BodyDesc)
 body_state_dtype = np.dtype(BodyState)
+body_pose_dtype = np.dtype(BodyPose)
 ghost_dtype = np.dtype(GhostRecord)
 contact_event_dtype = np.dtype(ContactEvent)
 body_event_dtype = np.dtype(BodyEvent)
@@ -263,6 +268,7 @@ PROTOTYPES = {
     "world_read_states": (C.c_int, [vp, u32, u32, vp]),
     "world_read_active": (C.c_int, [vp, vp, u32, P(u32)]),
     "world_read_active_view": (C.c_int, [vp, P(vp), P(u32)]),
+    "world_read_active_poses_view": (C.c_int, [vp, P(vp), P(u32)]),
     "world_set_water": (C.c_int, [vp, C.c_int, f32]),
     "world_set_contact_events": (C.c_int, [vp, C.c_int]),
     "world_step": (C.c_int, [vp, f32]),

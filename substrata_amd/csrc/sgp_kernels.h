@@ -299,6 +299,7 @@ void launch_ghost_refresh(const DV& d, const GhostRefresh* recs, uint32_t n, hip
 void launch_apply_cmds(const DV& d, const BodyCmd* cmds, const uint32_t* run_start, uint32_t n_runs, hipStream_t s);
 void launch_gather_states(const DV& d, const uint32_t* ids, uint32_t first, uint32_t n, sgp_body_state* out, hipStream_t s);
 void launch_gather_active(const DV& d, uint32_t nb, sgp_body_state* out, uint32_t cap, hipStream_t s);
+void launch_gather_active_poses(const DV& d, uint32_t nb, void* out, uint32_t cap, hipStream_t s);      // sgp_body_pose records (32 B)
 void launch_dump_constraints(const DV& d, uint32_t which, uint32_t n_con, void* out, uint32_t cap, hipStream_t s);
 void launch_vehicle_pre(const DV& d, hipStream_t s);
 void launch_vehicle_solve(const DV& d, int mode, hipStream_t s);      // mode as launch_solve_colour

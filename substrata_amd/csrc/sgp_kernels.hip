@@ -2967,6 +2967,20 @@ __global__ void __launch_bounds__(TPB) k_gather_active(DV d, sgp_body_state* out
 	if (want && k < cap) fill_state(d, i, &out[k]);
 }
 
+// poses only (two float4 per body: position + id, rotation): what the caller's per-frame loop reads
+__global__ void __launch_bounds__(TPB) k_gather_active_poses(DV d, float4* out, uint32_t cap)
+{
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	const uint32_t f = i < d.sp->n_slots ? d.flags[i] : 0u;
+	const bool want = (f & (BF_ALIVE | BF_ACTIVE)) == (BF_ALIVE | BF_ACTIVE);
+	const uint32_t k = block_alloc(&d.ctr->n_read_active, want);      // one atomic per workgroup
+	if (want && k < cap) {
+		const float4 p = d.pos_im[i];
+		out[2 * (size_t)k] = make_float4(p.x, p.y, p.z, __uint_as_float(i));
+		out[2 * (size_t)k + 1] = d.rot[i];
+	}
+}
+
 struct ConstraintDumpRec { uint32_t a, b; int32_t colour; int32_t np; float n[3]; float lam_n[4]; float lam_t1[4]; float lam_t2[4]; float bias[4]; };
 
 __global__ void __launch_bounds__(TPB) k_dump_constraints(DV d, uint32_t which, uint32_t n_con, ConstraintDumpRec* out, uint32_t cap)
@@ -3864,6 +3878,7 @@ void launch_contact_events(const DV& d, uint32_t est, hipStream_t s) { hipLaunch
 void launch_ghost_refresh(const DV& d, const GhostRefresh* recs, uint32_t n, hipStream_t s) { if (n) hipLaunchKernelGGL(k_ghost_refresh, dim3(blocks_for(n)), dim3(TPB), 0, s, d, recs, n); }
 void launch_apply_cmds(const DV& d, const BodyCmd* cmds, const uint32_t* run_start, uint32_t n_runs, hipStream_t s) { if (n_runs) hipLaunchKernelGGL(k_apply_cmds, dim3(blocks_for(n_runs)), dim3(TPB), 0, s, d, cmds, run_start, n_runs); }
 void launch_gather_states(const DV& d, const uint32_t* ids, uint32_t first, uint32_t n, sgp_body_state* out, hipStream_t s) { if (n) hipLaunchKernelGGL(k_gather_states, dim3(blocks_for(n)), dim3(TPB), 0, s, d, ids, first, n, out); }
+void launch_gather_active_poses(const DV& d, uint32_t nb, void* out, uint32_t cap, hipStream_t s) { hipLaunchKernelGGL(k_gather_active_poses, dim3(blocks_for(nb)), dim3(TPB), 0, s, d, (float4*)out, cap); }
 void launch_gather_active(const DV& d, uint32_t nb, sgp_body_state* out, uint32_t cap, hipStream_t s) { hipLaunchKernelGGL(k_gather_active, dim3(blocks_for(nb)), dim3(TPB), 0, s, d, out, cap); }
 void launch_dump_constraints(const DV& d, uint32_t which, uint32_t n_con, void* out, uint32_t cap, hipStream_t s) { if (n_con) hipLaunchKernelGGL(k_dump_constraints, dim3(blocks_for(n_con)), dim3(TPB), 0, s, d, which, n_con, (ConstraintDumpRec*)out, cap); }
 void launch_vehicle_pre(const DV& d, hipStream_t s)

@@ -1871,22 +1871,24 @@ SGP_API int sgp_world_read_states(sgp_world* w, uint32_t first, uint32_t n, sgp_
 
 // The compacted states of the active bodies land in the pinned staging buffer with ONE host sync: the gather, the counters and a copy sized
 // from the previous step's active count (+ slack) are queued together; only a count above that estimate costs a second copy.
-static int read_active_to_stage(sgp_world* w, uint32_t cap, uint32_t* n_out, uint32_t* m_out)
+static int read_active_to_stage(sgp_world* w, uint32_t cap, uint32_t* n_out, uint32_t* m_out, bool poses_only = false)
 {
+	const size_t rec = poses_only ? sizeof(sgp_body_pose) : sizeof(sgp_body_state);
 	hipSetDevice(w->device);
 	{ int r = flush_cmds(w); if (r != SGP_OK) return r; }
 	const uint32_t lim = std::min(cap, w->dv.cap_bodies);
-	{ int r = ensure_stage(w, sizeof(sgp_body_state) * std::max(lim, 1u)); if (r != SGP_OK) return r; }
+	{ int r = ensure_stage(w, rec * std::max(lim, 1u)); if (r != SGP_OK) return r; }
 	HIP_TRY(hipMemsetAsync(&w->dv.ctr->n_read_active, 0, sizeof(uint32_t), w->stream));
-	launch_gather_active(w->dv, w->high, (sgp_body_state*)w->stage_dev, lim, w->stream);
+	if (poses_only) launch_gather_active_poses(w->dv, w->high, w->stage_dev, lim, w->stream);
+	else launch_gather_active(w->dv, w->high, (sgp_body_state*)w->stage_dev, lim, w->stream);
 	const uint32_t guess = std::min(lim, w->last_active + w->last_active / 16u + 256u);
-	if (guess) HIP_TRY(hipMemcpyAsync(w->stage_host, w->stage_dev, sizeof(sgp_body_state) * guess, hipMemcpyDeviceToHost, w->stream));
+	if (guess) HIP_TRY(hipMemcpyAsync(w->stage_host, w->stage_dev, rec * guess, hipMemcpyDeviceToHost, w->stream));
 	{ int r = read_counters(w); if (r != SGP_OK) return r; }      // (the one sync)
 	const uint32_t n = w->h_ctr->n_read_active;
 	const uint32_t m = std::min(n, lim);
 	if (m > guess) {
-		HIP_TRY(hipMemcpyAsync((char*)w->stage_host + sizeof(sgp_body_state) * guess, (char*)w->stage_dev + sizeof(sgp_body_state) * guess,
-		                       sizeof(sgp_body_state) * (m - guess), hipMemcpyDeviceToHost, w->stream));
+		HIP_TRY(hipMemcpyAsync((char*)w->stage_host + rec * guess, (char*)w->stage_dev + rec * guess,
+		                       rec * (m - guess), hipMemcpyDeviceToHost, w->stream));
 		HIP_TRY(hipStreamSynchronize(w->stream));
 	}
 	*n_out = n; *m_out = m;
@@ -1909,6 +1911,16 @@ SGP_API int sgp_world_read_active_view(sgp_world* w, const sgp_body_state** view
 	uint32_t n = 0, m = 0;
 	{ int r = read_active_to_stage(w, w->dv.cap_bodies, &n, &m); if (r != SGP_OK) return r; }
 	*view_out = (const sgp_body_state*)w->stage_host;
+	*n_out = m;
+	return SGP_OK;
+}
+
+SGP_API int sgp_world_read_active_poses_view(sgp_world* w, const sgp_body_pose** view_out, uint32_t* n_out)
+{
+	if (!w || !view_out || !n_out) return fail(SGP_ERR_INVALID, "sgp_world_read_active_poses_view: NULL");
+	uint32_t n = 0, m = 0;
+	{ int r = read_active_to_stage(w, w->dv.cap_bodies, &n, &m, true); if (r != SGP_OK) return r; }
+	*view_out = (const sgp_body_pose*)w->stage_host;
 	*n_out = m;
 	return SGP_OK;
 }

@@ -194,6 +194,19 @@ class CWorld:
         a.flags.writeable = False
         return a
 
+    def read_active_poses_view(self):
+        """Id, position and rotation of the active bodies (32-byte records) as a read-only view of the library's pinned host buffer;
+        valid until the next read-back call on this world."""
+        ptr = C.c_void_p(0)
+        n = C.c_uint32(0)
+        self._check(self._fn("world_read_active_poses_view")(self._h, C.byref(ptr), C.byref(n)), "world_read_active_poses_view")
+        if n.value == 0:
+            return np.zeros(0, dtype=abi.body_pose_dtype)
+        buf = (C.c_char * (n.value * abi.body_pose_dtype.itemsize)).from_address(ptr.value)
+        a = np.frombuffer(buf, dtype=abi.body_pose_dtype, count=n.value)
+        a.flags.writeable = False
+        return a
+
     # -- world ----------------------------------------------------------------------------------------------
     def set_water(self, enabled, z):
         self._check(self._fn("world_set_water")(self._h, int(bool(enabled)), float(z)), "world_set_water")

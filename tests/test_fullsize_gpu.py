@@ -189,7 +189,7 @@ def test_sleeping_at_scale_and_read_active():
         w.step(DT)
     st = w.read_states(0, len(descs))
     assert st["active"][1:].sum() == 0
-    assert len(w.read_active()) == 0 and len(w.read_active_view()) == 0
+    assert len(w.read_active()) == 0 and len(w.read_active_view()) == 0 and len(w.read_active_poses_view()) == 0
     deact = w.drain_events(abi.EVENT_DEACTIVATED)
     assert len(deact) == 10000 and np.array_equal(np.sort(deact["id"]), np.arange(1, 10001))
     assert np.all(st["lin_vel"] == 0)
@@ -228,6 +228,12 @@ def test_read_active_copy_and_view_agree_with_read_states():
             assert np.array_equal(got["id"][o], want["id"])
             for f in ("pos", "rot", "lin_vel", "ang_vel"):
                 assert np.array_equal(got[f][o].view(np.uint32), want[f].view(np.uint32)), (s, f)
+        pz = np.array(w.read_active_poses_view())          # the 32-byte records: id, position, rotation
+        assert len(pz) == len(want)
+        o = np.argsort(pz["id"])
+        assert np.array_equal(pz["id"][o], want["id"])
+        for f in ("pos", "rot"):
+            assert np.array_equal(pz[f][o].view(np.uint32), want[f].view(np.uint32)), (s, f)
     assert counts[0] == 3200 and counts[-1] == 6400, counts
     w.close()
 
