@@ -14,7 +14,9 @@
 #include <utils/ThreadSafeRefCounted.h>
 #include <utils/Reference.h>
 #include <physics/jscol_aabbox.h>
-#include <Jolt/JoltLite.h>
+#include <Jolt/Jolt.h>
+#include <Jolt/Physics/Body/BodyID.h>
+#include <Jolt/Physics/Collision/Shape/Shape.h>
 #include <cstddef>
 
 class RayTraceResult;

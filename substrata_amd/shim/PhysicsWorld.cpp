@@ -2,7 +2,9 @@
 // (/root/reference/gui_client/PhysicsWorld.cpp, line ranges in the comments) with Jolt calls replaced by ABI calls.
 #include "PhysicsWorld.h"
 #include <cmath>
-#include <Jolt/JoltVehicleLite.h>
+#include <Jolt/Physics/Vehicle/VehicleConstraint.h>
+#include <Jolt/Physics/Vehicle/WheeledVehicleController.h>
+#include <Jolt/Physics/Vehicle/MotorcycleController.h>
 #include <utils/Exception.h>
 #include "../../include/sgp.h"
 #include <algorithm>

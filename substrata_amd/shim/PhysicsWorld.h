@@ -11,7 +11,11 @@
 #include <utils/ThreadSafeRefCounted.h>
 #include <utils/Mutex.h>
 #include <utils/HashSet.h>
-#include <Jolt/JoltLite.h>
+#include <Jolt/Jolt.h>
+#include <Jolt/Physics/Body/BodyID.h>
+#include <Jolt/Physics/Body/BodyActivationListener.h>
+#include <Jolt/Physics/Collision/ContactListener.h>
+#include <Jolt/Physics/PhysicsSystem.h>
 #include <string>
 #include <vector>
 #include <cstdint>

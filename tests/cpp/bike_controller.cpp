@@ -1,9 +1,19 @@
 // A BikePhysics-shaped caller (gui_client/BikePhysics.cpp:124-227,395-617): two WheelSettingsWV (raked front fork), a
 // MotorcycleControllerSettings with the reference's lean-spring constants, rear-wheel drive through the 0/1 differential, six
 // gears, VehicleCollisionTesterCastCylinder; per sub-step SetDriverInput + EnableLeanController(true) as while a rider is seated.
-#include <PhysicsWorld.h>
-#include <Jolt/JoltVehicleLite.h>
+#include "PhysicsWorld.h"
+#include "JoltUtils.h"
 #include <utils/Exception.h>
+#include <Jolt/Jolt.h>
+#include <Jolt/Physics/Collision/ObjectLayer.h>
+#include <Jolt/Physics/Vehicle/VehicleConstraint.h>
+#include <Jolt/Physics/PhysicsSystem.h>
+#include <Jolt/Physics/Body/BodyCreationSettings.h>
+#include <Jolt/Physics/Vehicle/WheeledVehicleController.h>
+#include <Jolt/Physics/Vehicle/MotorcycleController.h>
+#include <Jolt/Physics/Collision/Shape/BoxShape.h>
+#include <Jolt/Physics/Collision/Shape/OffsetCenterOfMassShape.h>
+#include <Jolt/Physics/Collision/Shape/ConvexHullShape.h>
 #include <cstdio>
 #include <cmath>
 

@@ -3,8 +3,11 @@
 // physics_system->GetBodyInterface(), thrust applied at the propellor point while it is under water (AddForce(id, F, point)), a rudder
 // force at the same point proportional to the forward speed, and quadratic water drag scaled by
 // PhysicsObject::last_submerged_volume / shape volume (the field think() maintains, PhysicsWorld.cpp:1414-1437); then think().
-#include <PhysicsWorld.h>
+#include "PhysicsWorld.h"
+#include "JoltUtils.h"
 #include <utils/Exception.h>
+#include <Jolt/Jolt.h>
+#include <Jolt/Physics/PhysicsSystem.h>
 #include <cstdio>
 #include <cmath>
 

@@ -2,9 +2,20 @@
 // CarPhysics does (four WheelSettingsWV, front-wheel-drive differential, two anti-roll bars, engine torque / max RPM, a
 // VehicleCollisionTesterCastSphere of half the wheel width), registers the constraint with the physics system, then every
 // sub-step passes driver input to the WheeledVehicleController, steps PhysicsWorld::think() and reads the wheels back.
-#include <PhysicsWorld.h>
-#include <Jolt/JoltVehicleLite.h>
+#include "PhysicsWorld.h"
+#include "JoltUtils.h"
 #include <utils/Exception.h>
+#include <Jolt/Jolt.h>
+#include <Jolt/Physics/Collision/ObjectLayer.h>
+#include <Jolt/Physics/Vehicle/VehicleConstraint.h>
+#include <Jolt/Physics/PhysicsSystem.h>
+#include <Jolt/Physics/Collision/Shape/CapsuleShape.h>
+#include <Jolt/Physics/Collision/Shape/RotatedTranslatedShape.h>
+#include <Jolt/Physics/Collision/Shape/BoxShape.h>
+#include <Jolt/Physics/Collision/Shape/OffsetCenterOfMassShape.h>
+#include <Jolt/Physics/Vehicle/WheeledVehicleController.h>
+#include <Jolt/Physics/Body/BodyCreationSettings.h>
+#include <Jolt/Physics/Collision/Shape/ConvexHullShape.h>
 #include <cstdio>
 #include <cmath>
 

@@ -6,17 +6,24 @@
 //   GetWheelWorldTransform}, PhysicsSystem::{AddConstraint, AddStepListener, RemoveConstraint, RemoveStepListener}.
 // Only the engine-side inputs CarPhysics takes from other subsystems (script settings, animation joints, the WorldObject) are
 // replaced by local constants (Scripting.cpp:315-348,369-386).
-#include <PhysicsWorld.h>
-#include <Jolt/JoltVehicleLite.h>
+#include "PhysicsWorld.h"
+#include "JoltUtils.h"
 #include <utils/Exception.h>
+#include <Jolt/Jolt.h>
+#include <Jolt/Physics/Collision/ObjectLayer.h>
+#include <Jolt/Physics/Vehicle/VehicleConstraint.h>
+#include <Jolt/Physics/PhysicsSystem.h>
+#include <Jolt/Physics/Collision/Shape/CapsuleShape.h>
+#include <Jolt/Physics/Collision/Shape/RotatedTranslatedShape.h>
+#include <Jolt/Physics/Collision/Shape/BoxShape.h>
+#include <Jolt/Physics/Collision/Shape/OffsetCenterOfMassShape.h>
+#include <Jolt/Physics/Vehicle/WheeledVehicleController.h>
+#include <Jolt/Physics/Body/BodyCreationSettings.h>
+#include <Jolt/Physics/Collision/Shape/ConvexHullShape.h>
 #include <cstdio>
 #include <cmath>
 #include <vector>
 
-static inline JPH::Vec3 toJoltVec3(const Vec4f& v) { return JPH::Vec3(v[0], v[1], v[2]); }
-static inline JPH::Vec3 toJoltVec3(const Vec3f& v) { return JPH::Vec3(v.x, v.y, v.z); }
-static inline JPH::Quat toJoltQuat(const Quatf& q) { return JPH::Quat(q.v[0], q.v[1], q.v[2], q.v[3]); }
-static inline Vec4f toVec4fVec(const JPH::Vec3& v) { return Vec4f(v.GetX(), v.GetY(), v.GetZ(), 0.f); }
 
 struct ScriptSettings        // Scripting.cpp:315-348 defaults
 {

@@ -1,7 +1,7 @@
 // Drives a scene through the C++ PhysicsWorld facade exactly the way GUIClient does (GUIClient.cpp:3026-3057, 6365-6690):
 // new PhysicsObject -> fill fields -> addObject -> activateObject -> think() in a sub-step loop -> read activated_obs.
 // Usage: facade_scene <scene.bin (sgp_body_desc[])> <steps> <out.bin (sgp_body_state-like floats)>
-#include <PhysicsWorld.h>
+#include "PhysicsWorld.h"
 #include <utils/Exception.h>
 #include "../../include/sgp.h"
 #include <cstdio>

@@ -1,8 +1,13 @@
 // A HoverCarPhysics-shaped controller (HoverCarPhysics.cpp:113-348): every sub-step it reads the body's transform and
 // velocities through physics_world.physics_system->GetBodyInterface(), applies a hover force (spring to a target height +
 // damping) and a yaw torque, exactly the call pattern of the reference controller, then PhysicsWorld::think().
-#include <PhysicsWorld.h>
+#include "PhysicsWorld.h"
+#include "JoltUtils.h"
 #include <utils/Exception.h>
+#include <Jolt/Jolt.h>
+#include <Jolt/Physics/Collision/ObjectLayer.h>
+#include <Jolt/Physics/Vehicle/VehicleConstraint.h>
+#include <Jolt/Physics/PhysicsSystem.h>
 #include <cstdio>
 #include <cmath>
 

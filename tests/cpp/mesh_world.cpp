@@ -2,9 +2,16 @@
 // chunks; y-up shape space turned upright by the object's rotation), a static mesh building (createMeshShape, what
 // createJoltShapeForBatchedMesh gives a static object), dynamic boxes / spheres / a hull dropped on both, the player walking up the
 // terrain and into the building's wall, rays against the meshes.
-#include <PhysicsWorld.h>
-#include <Jolt/JoltCharacterLite.h>
+#include "PhysicsWorld.h"
+#include "JoltUtils.h"
 #include <utils/Exception.h>
+#include <Jolt/Jolt.h>
+#include <Jolt/Physics/Collision/ObjectLayer.h>
+#include <Jolt/Physics/Character/Character.h>
+#include <Jolt/Physics/Character/CharacterVirtual.h>
+#include <Jolt/Physics/PhysicsSystem.h>
+#include <Jolt/Physics/Collision/Shape/CapsuleShape.h>
+#include <Jolt/Physics/Collision/Shape/RotatedTranslatedShape.h>
 #include <cstdio>
 #include <cmath>
 #include <string>

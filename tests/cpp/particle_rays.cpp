@@ -2,7 +2,7 @@
 // (traceRay(pos, vel, dt, JPH::BodyID(), results)), bounces off what it hits, else advances.  Run twice over the same particles: through the
 // reference's one-ray-per-call facade method and through the batched extension traceRays(); the results must be identical, and the time
 // of both is printed (a single traceRay is a kernel launch + a host sync).
-#include <PhysicsWorld.h>
+#include "PhysicsWorld.h"
 #include <utils/Exception.h>
 #include <chrono>
 #include <cstdio>

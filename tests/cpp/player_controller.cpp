@@ -3,9 +3,16 @@
 // sphere, max strength 1000), driven every frame by the velocity rule of PlayerPhysics::update (on ground: desired + ground
 // velocity; in the air: accelerate; gravity always; jump through the ground normal) and ExtendedUpdate with the reference's
 // stick-to-floor (0.5 m) and stair (0.4 m) settings, while PhysicsWorld::think steps the world around it.
-#include <PhysicsWorld.h>
-#include <Jolt/JoltCharacterLite.h>
+#include "PhysicsWorld.h"
+#include "JoltUtils.h"
 #include <utils/Exception.h>
+#include <Jolt/Jolt.h>
+#include <Jolt/Physics/Collision/ObjectLayer.h>
+#include <Jolt/Physics/Character/Character.h>
+#include <Jolt/Physics/Character/CharacterVirtual.h>
+#include <Jolt/Physics/PhysicsSystem.h>
+#include <Jolt/Physics/Collision/Shape/CapsuleShape.h>
+#include <Jolt/Physics/Collision/Shape/RotatedTranslatedShape.h>
 #include <cstdio>
 #include <cmath>
 #include <cstdlib>

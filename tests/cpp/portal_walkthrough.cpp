@@ -5,9 +5,16 @@
 //   PlayerPhysics::OnContactAdded (PlayerPhysics.cpp:519-533): BodyLockRead -> user data -> contacted_events {object, sub shape id, position}
 //   GUIClient (GUIClient.cpp:6482-6491): contacted_events[z].sub_shape_id.PopID(1, remainder) == 1  <=>  the inner plane collider was touched
 // The statements are the reference's; portal.bmesh (absent from the tree) is replaced by a synthetic arch with the same four materials.
-#include <PhysicsWorld.h>
-#include <Jolt/JoltCharacterLite.h>
+#include "PhysicsWorld.h"
+#include "JoltUtils.h"
 #include <utils/Exception.h>
+#include <Jolt/Jolt.h>
+#include <Jolt/Physics/Collision/ObjectLayer.h>
+#include <Jolt/Physics/Character/Character.h>
+#include <Jolt/Physics/Character/CharacterVirtual.h>
+#include <Jolt/Physics/PhysicsSystem.h>
+#include <Jolt/Physics/Collision/Shape/CapsuleShape.h>
+#include <Jolt/Physics/Collision/Shape/RotatedTranslatedShape.h>
 #include <cstdio>
 #include <cmath>
 #include <vector>

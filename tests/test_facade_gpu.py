@@ -36,6 +36,64 @@ def test_facade_compiles_without_gpu(tmp_path):
     assert os.path.exists(build_facade_exe(tmp_path, "boat_controller.cpp"))
 
 
+# What the reference's callers include from Jolt and from the facade (grep '#include' of the files named; gui_client/ of the reference).
+# Committed as data: /root/reference is not read at test time.  SURVEY 8b Tier 2: the callers must compile unmodified, so every one
+# of these paths has to exist under substrata_amd/shim, and the caller-shaped tests must include these and nothing of our own naming.
+REFERENCE_CALLER_INCLUDES = {
+    "PhysicsObject.h": ["Jolt/Jolt.h", "Jolt/Physics/Body/BodyID.h", "Jolt/Physics/Collision/Shape/Shape.h"],
+    "PhysicsWorld.h": ["Jolt/Jolt.h", "Jolt/Physics/Body/BodyID.h", "Jolt/Physics/Body/BodyActivationListener.h", "Jolt/Physics/Collision/ContactListener.h"],
+    "PlayerPhysics.h+cpp": ["Jolt/Jolt.h", "Jolt/Physics/Collision/ObjectLayer.h", "Jolt/Physics/Character/Character.h", "Jolt/Physics/Character/CharacterVirtual.h",
+                            "Jolt/Physics/PhysicsSystem.h", "Jolt/Physics/Collision/Shape/CapsuleShape.h", "Jolt/Physics/Collision/Shape/RotatedTranslatedShape.h"],
+    "CarPhysics.h+cpp": ["Jolt/Jolt.h", "Jolt/Physics/Collision/ObjectLayer.h", "Jolt/Physics/Vehicle/VehicleConstraint.h", "Jolt/Physics/PhysicsSystem.h",
+                         "Jolt/Physics/Collision/Shape/CapsuleShape.h", "Jolt/Physics/Collision/Shape/RotatedTranslatedShape.h", "Jolt/Physics/Collision/Shape/BoxShape.h",
+                         "Jolt/Physics/Collision/Shape/OffsetCenterOfMassShape.h", "Jolt/Physics/Vehicle/WheeledVehicleController.h",
+                         "Jolt/Physics/Body/BodyCreationSettings.h", "Jolt/Physics/Collision/Shape/ConvexHullShape.h"],
+    "BikePhysics.h+cpp": ["Jolt/Jolt.h", "Jolt/Physics/Collision/ObjectLayer.h", "Jolt/Physics/Vehicle/VehicleConstraint.h", "Jolt/Physics/PhysicsSystem.h",
+                          "Jolt/Physics/Body/BodyCreationSettings.h", "Jolt/Physics/Vehicle/WheeledVehicleController.h", "Jolt/Physics/Vehicle/MotorcycleController.h",
+                          "Jolt/Physics/Collision/Shape/BoxShape.h", "Jolt/Physics/Collision/Shape/OffsetCenterOfMassShape.h", "Jolt/Physics/Collision/Shape/ConvexHullShape.h"],
+    "HoverCarPhysics.h+cpp": ["Jolt/Jolt.h", "Jolt/Physics/Collision/ObjectLayer.h", "Jolt/Physics/Vehicle/VehicleConstraint.h", "Jolt/Physics/PhysicsSystem.h"],
+    "BoatPhysics.h+cpp": ["Jolt/Jolt.h", "Jolt/Physics/PhysicsSystem.h"],
+    "MeshBuilding.cpp": ["Jolt/Jolt.h", "Jolt/Physics/Collision/Shape/Shape.h", "Jolt/Physics/Collision/Shape/CompoundShape.h",
+                         "Jolt/Physics/Collision/Shape/StaticCompoundShape.h", "Jolt/Physics/Collision/Shape/BoxShape.h"],
+    "AvatarGraphics.cpp": ["Jolt/Physics/PhysicsSystem.h", "Jolt/Physics/Collision/Shape/CapsuleShape.h", "Jolt/Physics/Body/BodyCreationSettings.h"],
+    "GUIClient.cpp": ["Jolt/Physics/PhysicsSystem.h"],
+}
+# which reference caller each caller-shaped test stands for
+CALLER_OF_TEST = {
+    "car_controller.cpp": "CarPhysics.h+cpp", "car_physics_sequence.cpp": "CarPhysics.h+cpp", "bike_controller.cpp": "BikePhysics.h+cpp",
+    "player_controller.cpp": "PlayerPhysics.h+cpp", "mesh_world.cpp": "PlayerPhysics.h+cpp", "portal_walkthrough.cpp": "PlayerPhysics.h+cpp",
+    "hover_controller.cpp": "HoverCarPhysics.h+cpp", "boat_controller.cpp": "BoatPhysics.h+cpp",
+}
+# the conversion helpers of gui_client/JoltUtils.h:14-64 that the callers use by name
+JOLT_UTILS_NAMES = ["toJoltVec3", "toVec3f", "toVec4fVec", "toVec4fPos", "toJoltQuat", "toQuat", "toMatrix4f"]
+
+
+def test_jolt_include_paths_exist_and_are_what_the_tests_use():
+    """Tier 2 of the boundary: every Jolt header path a reference caller includes exists under shim/, each compiles on its own with
+    -I shim only, the caller-shaped tests include exactly their caller's Jolt paths (no *Lite.h, no local conversion helpers) and
+    "JoltUtils.h" carries the reference's helper names."""
+    import re
+    shim = os.path.join(ROOT, "substrata_amd", "shim")
+    paths = sorted({p for v in REFERENCE_CALLER_INCLUDES.values() for p in v})
+    for p in paths:
+        assert os.path.exists(os.path.join(shim, p)), p
+    probe = "".join(f"#include <{p}>\n" for p in paths) + '#include "JoltUtils.h"\n#include "PhysicsWorld.h"\nint main() { return 0; }\n'
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", shim, "-x", "c++", "-"], input=probe, text=True, capture_output=True)
+    assert r.returncode == 0, r.stderr
+    for p in paths:                                                     # and each one alone
+        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", shim, "-x", "c++", "-"], input=f"#include <{p}>\n", text=True, capture_output=True)
+        assert r.returncode == 0, (p, r.stderr)
+    utils = open(os.path.join(shim, "JoltUtils.h")).read()
+    for name in JOLT_UTILS_NAMES:
+        assert re.search(rf"\b{name}\(", utils), name
+    for test, caller in CALLER_OF_TEST.items():
+        src = open(os.path.join(ROOT, "tests", "cpp", test)).read()
+        jolt = re.findall(r"#include <(Jolt/[^>]+)>", src)
+        assert sorted(jolt) == sorted(REFERENCE_CALLER_INCLUDES[caller]), (test, jolt)
+        assert "Lite.h" not in src and '#include "JoltUtils.h"' in src and '#include "PhysicsWorld.h"' in src
+        assert not re.search(r"^\s*(static\s+)?inline\s+\S+\s+to(Jolt|Vec|Quat|Matrix)\w*\(", src, re.M), test
+
+
 @pytest.mark.gpu
 def test_hover_controller_through_body_interface(tmp_path):
     """A HoverCarPhysics-shaped controller drives a body through physics_system->GetBodyInterface() (AddForce, AddTorque,
