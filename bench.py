@@ -21,8 +21,9 @@ substrata_amd/scenes.py) dropped on the ground quad.  The measured state is PINN
     The simulation is deterministic, so every GPU leg walks through the very same states; `checks` in the JSON asserts it.
 
 N > 1: BASELINE config 4, the 1M-box lattice (100^3, spacing 1.25 m, seed 4) STRONG-scaled over N spatial tiles of the 3-D grid
-2x1x1 / 2x2x1 / 2x2x2 (substrata_amd/tiles.py), one process per GPU, ghost bodies exchanged once per step (RCCL all-gather of the
-counts + all-to-all-v of the records); value = steps/s of the whole 1M-body world.  (`--workload config3` at N > 1 keeps the round-1
+2x1x1 / 2x2x1 / 2x2x2 (substrata_amd/tiles.py), one process per GPU, ghost bodies exchanged once per step by sgp_tiles_exchange (RCCL
+all-gather of the counts + grouped send / recv of the records, issued inside libsgp.so; the run fails if that cannot be set up -- there is
+no second transport); value = steps/s of the whole 1M-body world.  (`--workload config3` at N > 1 keeps the round-1
 weak-scaling layout, one 100k tile per GPU side by side; `--workload config4` at N = 1 runs the whole 1M world on one GPU.)
 
 Prints ONE JSON line (rank 0).
@@ -65,8 +66,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-readback-leg", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=8)
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for single-GPU dry runs of the tile exchange)")
-    ap.add_argument("--share-gpu", action="store_true", help="dry run: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--force-comm", action="store_true", help="N = 1 with --workload config4: build the process group and the RCCL communicator anyway "
+                    "(one rank), so that a one-GPU box runs the very code path of N > 1")
     return ap.parse_args()
 
 
@@ -158,15 +159,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     n_gpus = args.gpus
     dist = None
-    if args.share_gpu:
-        local_rank = 0
-    if world_size > 1:
+    if world_size > 1 or args.force_comm:
         import torch.distributed as dist
+        if args.force_comm and world_size == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
-        if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=args.backend)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))      # "nccl" IS RCCL on ROCm
         assert world_size == n_gpus, "launch with --nproc-per-node equal to --gpus"
     elif n_gpus != 1:
         raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run with N ranks")
@@ -178,7 +177,7 @@ def main():
         workload = "config3" if n_gpus == 1 else "config4"
     if workload == "config5" and n_gpus != 1:
         raise SystemExit("--workload config5 is a single-GPU measurement")
-    xdev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")
+    xdev = torch.device("cuda", local_rank)
     pmc = load_pmc()
 
     def barrier():
@@ -218,35 +217,33 @@ def main():
         w.add_batch(descs)
         ex = None
         exchange_kind = "none (one tile)"
-        if n_gpus > 1 and args.backend == "nccl":
+        if n_gpus > 1 or args.force_comm:
             # the native exchange (sgp_tiles_*: device routing + RCCL send / recv from inside libsgp.so); torch.distributed only carries the
-            # communicator's unique id to the other ranks and runs the barriers around the timed region
+            # communicator's unique id to the other ranks and runs the barriers around the timed region.  There is no other transport: a
+            # rank that cannot set the exchange up says so, every rank learns of it (so nobody is left waiting in ncclCommInitRank's peers'
+            # collectives), and the run ends with an error instead of a number measured on something else.
             boxes_t = torch.zeros(n_gpus * 6, dtype=torch.float32, device=xdev)
             dist.all_gather_into_tensor(boxes_t, torch.from_numpy(np.concatenate([lo, hi]).astype(np.float32)).to(xdev))
             uid = torch.zeros(128, dtype=torch.uint8, device=xdev)
+            err = ""
             if rank == 0:
-                uid.copy_(torch.frombuffer(bytearray(tiles.NativeTiles.unique_id()), dtype=torch.uint8))
+                try:
+                    uid.copy_(torch.frombuffer(bytearray(tiles.NativeTiles.unique_id()), dtype=torch.uint8))
+                except Exception as e:      # noqa: BLE001
+                    err = f"ncclGetUniqueId: {e}"
             dist.broadcast(uid, src=0)
-            # (a rank that cannot set the native exchange up -- RCCL missing or refusing the communicator -- must not leave the others hanging in
-            # ncclCommInitRank: every rank reports, and all of them switch to the torch.distributed exchange together; the line says which ran)
-            try:
-                ex = tiles.NativeTiles(w, rank, n_gpus, boxes_t.cpu().numpy().reshape(n_gpus, 6), 2.0, unique_id=bytes(uid.cpu().numpy().tobytes()))
-                ok = 1
-            except Exception as e:      # noqa: BLE001
-                print(f"[bench rank {rank}] native tile exchange unavailable: {e}", file=sys.stderr, flush=True)
-                ex, ok = None, 0
-            okt = torch.tensor([ok], dtype=torch.int32, device=xdev)
+            if not err:
+                try:
+                    ex = tiles.NativeTiles(w, rank, n_gpus, boxes_t.cpu().numpy().reshape(n_gpus, 6), 2.0, unique_id=bytes(uid.cpu().numpy().tobytes()))
+                except Exception as e:      # noqa: BLE001
+                    err = str(e)
+            okt = torch.tensor([0 if err else 1], dtype=torch.int32, device=xdev)
             dist.all_reduce(okt, op=dist.ReduceOp.MIN)
             if int(okt.item()) == 0:
-                if ex is not None:
-                    ex.close()
-                ex = tiles.GhostExchange(w, rank, n_gpus, lo, hi, margin=2.0, dist=dist, device=xdev)
-                exchange_kind = "torch.distributed all-to-all of ghost records (tiles.GhostExchange): the native sgp_tiles_* exchange could not be set up"
-            else:
-                exchange_kind = "sgp_tiles_exchange: device routing + RCCL grouped send/recv inside libsgp.so"
-        elif n_gpus > 1:
-            ex = tiles.GhostExchange(w, rank, n_gpus, lo, hi, margin=2.0, dist=dist, device=xdev)      # gloo dry run on a shared GPU
-            exchange_kind = f"torch.distributed ({args.backend}) all-to-all of ghost records (tiles.GhostExchange), dry run"
+                print(f"[bench rank {rank}] native tile exchange (sgp_tiles_create over RCCL) failed: {err or 'on another rank'}", file=sys.stderr, flush=True)
+                raise SystemExit(f"bench.py --gpus {n_gpus}: the sgp_tiles_* exchange could not be set up on every rank; there is no fallback transport")
+            exchange_kind = "sgp_tiles_exchange: device routing + RCCL all-gather of counts + grouped send/recv inside libsgp.so"
+
 
         def one_step():
             if ex is not None:
@@ -257,12 +254,14 @@ def main():
             one_step()
         for _ in range(args.warmup):
             one_step()
+        ex_before = ex.stats() if ex is not None else None
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             one_step()
         barrier()
         elapsed = time.perf_counter() - t0
+        ex_after = ex.stats() if ex is not None else None
         if dist is not None:
             t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -271,8 +270,11 @@ def main():
         n_prof = max(1, args.profile_steps)
         prof = profile_leg(w, n_prof, exchange=(ex.exchange if ex is not None else None))
         roof, roof_solver, kernel_ms = rooflines(prof, n_prof, w.desc.settings.num_velocity_steps, pmc)
+        ex_ms = ((ex_after.total_exchange_ms - ex_before.total_exchange_ms) / max(1, ex_after.exchanges - ex_before.exchanges)) if ex is not None else 0.0
         local = np.array([w.num_bodies() - 1 - (ex.last_imported if ex else 0), st.num_manifolds, st.num_active,
-                          ex.last_exported if ex else 0, ex.last_imported if ex else 0, st.pairs_dropped + st.manifolds_dropped], dtype=np.float64)
+                          ex.last_exported if ex else 0, ex.last_imported if ex else 0, st.pairs_dropped + st.manifolds_dropped,
+                          ex_ms, ex_after.comm_ranks if ex else 0, ex_after.comm_init_ms if ex else 0.0,
+                          (ex_after.route_retries if ex else 0), (ex_after.slow_imports - ex_before.slow_imports) if ex else 0], dtype=np.float64)
         if dist is not None:
             allv = torch.zeros(n_gpus * len(local), dtype=torch.float64, device=xdev)
             dist.all_gather_into_tensor(allv, torch.from_numpy(local).to(xdev))
@@ -295,6 +297,9 @@ def main():
                     "active_bodies_per_tile": [int(v) for v in allv[:, 2]],
                     "ghosts_exported_per_tile": [int(v) for v in allv[:, 3]], "ghosts_imported_per_tile": [int(v) for v in allv[:, 4]],
                     "dropped_pairs_or_manifolds": int(allv[:, 5].sum()),
+                    "exchange_ms_per_step_per_tile": [round(float(v), 4) for v in allv[:, 6]],
+                    "rccl_ranks_seen_per_tile": [int(v) for v in allv[:, 7]], "nccl_comm_init_ms_per_tile": [round(float(v), 1) for v in allv[:, 8]],
+                    "route_retries_per_tile": [int(v) for v in allv[:, 9]], "host_side_imports_in_timed_steps_per_tile": [int(v) for v in allv[:, 10]],
                     "body_steps_per_s": steps_per_s * total_bodies,
                 },
                 "roofline": roof, "roofline_solver": roof_solver, "kernel_ms_per_step": kernel_ms, "cpu_baseline": None,

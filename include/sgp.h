@@ -288,14 +288,46 @@ int  sgp_body_set_pose_vel_batch(sgp_world* w, const uint32_t* ids, const sgp_po
 int  sgp_physics_update_encode(uint64_t uid, const sgp_body_state* st, double client_time, uint8_t out[SGP_PHYSICS_UPDATE_BYTES]);
 int  sgp_physics_update_decode(const uint8_t in[SGP_PHYSICS_UPDATE_BYTES], uint64_t* uid_out, sgp_pose_vel* rec_out, double* client_time_out);
 
+/* ---- network physics snapshots: the de-jitter buffer in front of the step -------------------------------------
+ * What the reference keeps per WorldObject (shared/WorldObject.h:540-566: a ring of HISTORY_BUF_SIZE = 4 snapshots, next_snapshot_i,
+ * next_insertable_snapshot_i, transmission_time_offset) and does with it:
+ *   receive    ClientThread.cpp:736-792   an ObjectPhysicsTransformUpdate from the object's physics owner goes into slot next_snapshot_i % 4
+ *   ownership  ClientThread.cpp:957-975   ObjectPhysicsOwnershipTaken: transmission_time_offset = global time now - the sender's time of the
+ *                                         change (a renewal only sets it when it is still 0); a change of owner drops the queued snapshots
+ *   playback   GUIClient.cpp:7462-7493    once per frame and object: the oldest snapshot not yet inserted is due when
+ *                                         global_time >= client_time + transmission_time_offset + padding_delay (0.1 s); it is then fed to
+ *                                         setNewObToWorldTransform(pos, rot, lin vel, ang vel) -- here: returned for ONE batched
+ *                                         sgp_body_set_pose_vel_batch.  At most one snapshot per object and poll, in arrival order; a ring
+ *                                         that overflowed (more than 4 pending) plays back what its slots hold now, exactly as the reference's.
+ *   expiry     GUIClient.cpp:7443-7452    an object whose last snapshot arrived more than 1 s ago leaves the active set
+ * Host-side state only (no device work); one queue serves any number of objects, keyed by their 64-bit uid. */
+typedef struct sgp_snapshot_queue sgp_snapshot_queue;
+#define SGP_SNAPSHOT_HISTORY 4
+int  sgp_snapshot_queue_create(sgp_snapshot_queue** out);
+int  sgp_snapshot_queue_destroy(sgp_snapshot_queue* q);
+/* receive: a wire record (sgp_physics_update_decode) or an already decoded one; local_time = the receiver's clock at arrival */
+int  sgp_snapshot_queue_push_wire(sgp_snapshot_queue* q, const uint8_t msg[SGP_PHYSICS_UPDATE_BYTES], double local_time);
+int  sgp_snapshot_queue_push(sgp_snapshot_queue* q, uint64_t uid, const sgp_pose_vel* rec, double client_time, double local_time);
+/* ObjectPhysicsOwnershipTaken for uid */
+int  sgp_snapshot_queue_ownership(sgp_snapshot_queue* q, uint64_t uid, double global_time_now, double ownership_change_global_time, int renewal);
+/* playback: the snapshots due at global_time, at most one per object, ascending uid; *n_out = how many were due (<= cap are written and consumed) */
+int  sgp_snapshot_queue_poll(sgp_snapshot_queue* q, double global_time, double padding_delay,
+                             uint64_t* uids_out, sgp_pose_vel* recs_out, uint32_t cap, uint32_t* n_out);
+/* expiry: forget the objects whose last snapshot arrived before local_time_now - max_age (reference: 1.0 s); *n_out = objects still tracked */
+int  sgp_snapshot_queue_expire(sgp_snapshot_queue* q, double local_time_now, double max_age, uint32_t* n_out);
+/* inspection (tests): ring indices and offset of one object; SGP_ERR_BAD_ID when the uid is not tracked */
+int  sgp_snapshot_queue_peek(sgp_snapshot_queue* q, uint64_t uid, uint32_t* next_snapshot_i, uint32_t* next_insertable_snapshot_i, double* transmission_time_offset);
+
 /* getObjectLinearVelocity (:636-646), getPosInJolt (:1625-1632), GUIClient.cpp:6588,6673 read-back. */
 int  sgp_body_get_state(sgp_world* w, const uint32_t* ids, uint32_t n, sgp_body_state* out);
 /* All live bodies in id order [first, first+n). Slots that are not live get id = SGP_INVALID_ID. */
 int  sgp_world_read_states(sgp_world* w, uint32_t first, uint32_t n, sgp_body_state* out);
 /* The per-frame read-back loop (GUIClient.cpp:6581-6690): compacted states of every ACTIVE body. */
 int  sgp_world_read_active(sgp_world* w, sgp_body_state* out, uint32_t cap, uint32_t* n_out);
-/* The same without the copy into the caller's buffer: *view_out points at the library's pinned host buffer holding *n_out records, valid until
- * the next call on this world that reads states back (the loop at GUIClient.cpp:6581-6690 only reads each record once). */
+/* The same without the copy into the caller's buffer: *view_out points at a pinned host buffer of the library holding *n_out records.  The
+ * buffer belongs to the two *_view calls alone: it stays valid and unchanged across steps, ray casts, queries and state reads, until the next
+ * sgp_world_read_active_view / sgp_world_read_active_poses_view on this world or sgp_world_destroy (the loop at GUIClient.cpp:6581-6690
+ * reads each record once, and may trace rays while it does). */
 int  sgp_world_read_active_view(sgp_world* w, const sgp_body_state** view_out, uint32_t* n_out);
 /* ... and with nothing but what that loop reads per activated body (GetPositionAndRotation, GUIClient.cpp:6586-6588): 32 bytes instead of 68. */
 typedef struct sgp_body_pose {
@@ -573,6 +605,11 @@ typedef struct sgp_tiles_stats {
 	uint32_t ghosts;         /* ... of which ghosts                                                                      */
 	uint32_t emigrated, immigrated;
 	uint32_t fast_imports, slow_imports;     /* exchanges whose import ran on the device / went through the host (cumulative) */
+	uint32_t route_retries;  /* exchanges that had to grow this tile's send / emigrant buffers and route again (local, no extra collective) */
+	uint32_t comm_ranks;     /* ranks ncclCommCount reports for this tile's communicator (0: no communicator, e.g. tiles of one process) */
+	uint32_t exchanges;      /* sgp_tiles_exchange calls so far                                                           */
+	float    comm_init_ms;   /* wall time of ncclCommInitRank                                                             */
+	float    last_exchange_ms, total_exchange_ms;    /* host wall time of sgp_tiles_exchange: the last call, all calls    */
 } sgp_tiles_stats;
 #define SGP_MIGRATION_OUT 0
 #define SGP_MIGRATION_IN  1

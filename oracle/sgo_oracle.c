@@ -2089,7 +2089,12 @@ SGO_API int sgo_world_import_ghosts(sgo_world* w, const sgp_ghost_record* in, ui
 		sgp_body_desc d; sgo_default_body_desc(&d);
 		memcpy(d.pos, in[k].pos, 12); memcpy(d.rot, in[k].rot, 16); memcpy(d.lin_vel, in[k].lin_vel, 12); memcpy(d.ang_vel, in[k].ang_vel, 12);
 		d.shape_type = in[k].shape_type; memcpy(d.shape, in[k].shape, 16);
-		d.motion_type = SGP_MOTION_KINEMATIC; d.layer = SGP_LAYER_MOVING;
+		d.motion_type = SGP_MOTION_KINEMATIC;
+		/* layer and sensor flag of the original body (a sensor near the border is a sensor next door too); a kinematic ghost lives on a moving layer */
+		d.layer = (int32_t)(in[k].flags & SGP_GHOST_FLAG_LAYER_MASK);
+		if (d.layer == SGP_LAYER_NON_MOVING) d.layer = SGP_LAYER_MOVING;
+		if (d.layer == SGP_LAYER_NON_MOVING_NON_COLLIDABLE) d.layer = SGP_LAYER_MOVING_NON_COLLIDABLE;
+		d.is_sensor = (in[k].flags & SGP_GHOST_FLAG_SENSOR) ? 1 : 0;
 		d.mass = in[k].mass; d.friction = in[k].friction; d.restitution = in[k].restitution;
 		d.activate = 1; d.userdata = in[k].userdata;       /* a ray or an event that meets the ghost names the object, like its owner would */
 		uint32_t id = SGP_INVALID_ID;

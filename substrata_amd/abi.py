@@ -111,7 +111,8 @@ GHOST_FLAG_LAYER_MASK, GHOST_FLAG_SENSOR, GHOST_FLAG_ALLOW_SLEEP, GHOST_FLAG_ZER
 
 class TilesStats(C.Structure):
     _fields_ = [("exported", u32), ("sent", u32), ("received", u32), ("ghosts", u32), ("emigrated", u32), ("immigrated", u32),
-                ("fast_imports", u32), ("slow_imports", u32)]
+                ("fast_imports", u32), ("slow_imports", u32), ("route_retries", u32), ("comm_ranks", u32), ("exchanges", u32),
+                ("comm_init_ms", f32), ("last_exchange_ms", f32), ("total_exchange_ms", f32)]
 
 
 class Migration(C.Structure):
@@ -258,6 +259,14 @@ PROTOTYPES = {
     "body_set_pose_vel_batch": (C.c_int, [vp, vp, vp, u32]),
     "physics_update_encode": (C.c_int, [u64, P(BodyState), C.c_double, vp]),
     "physics_update_decode": (C.c_int, [vp, P(u64), P(PoseVel), P(C.c_double)]),
+    "snapshot_queue_create": (C.c_int, [P(vp)]),
+    "snapshot_queue_destroy": (C.c_int, [vp]),
+    "snapshot_queue_push_wire": (C.c_int, [vp, vp, C.c_double]),
+    "snapshot_queue_push": (C.c_int, [vp, u64, P(PoseVel), C.c_double, C.c_double]),
+    "snapshot_queue_ownership": (C.c_int, [vp, u64, C.c_double, C.c_double, C.c_int]),
+    "snapshot_queue_poll": (C.c_int, [vp, C.c_double, C.c_double, vp, vp, u32, P(u32)]),
+    "snapshot_queue_expire": (C.c_int, [vp, C.c_double, C.c_double, P(u32)]),
+    "snapshot_queue_peek": (C.c_int, [vp, u64, P(u32), P(u32), P(C.c_double)]),
     "body_set_pos": (C.c_int, [vp, u32, P(f32)]),
     "body_set_vel": (C.c_int, [vp, u32, P(f32), P(f32)]),
     "body_move_kinematic": (C.c_int, [vp, u32, P(f32), P(f32), f32]),

@@ -319,4 +319,5 @@ struct RouteHeader { uint32_t seg_count[SGP_MAX_TILES]; uint32_t seg_start[SGP_M
 void launch_route_export(const DV& d, uint32_t nb, const TileRoute& t, uint32_t* block_counts, uint32_t* block_offsets, RouteHeader* header,
                          sgp_ghost_record* out, uint32_t cap, uint32_t* emigrant_ids, uint32_t emigrant_cap, hipStream_t s);
 // ghost pose refresh straight from received records: record k refreshes body ids[k] (the unchanged-ghost-set fast path, no host copy of the poses)
+void launch_pack_ghost_keys(const sgp_ghost_record* recs, uint32_t n, void* out_uint4, hipStream_t s);
 void launch_ghost_refresh_records(const DV& d, const sgp_ghost_record* recs, const uint32_t* ids, uint32_t n, hipStream_t s);

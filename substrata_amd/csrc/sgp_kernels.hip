@@ -3620,9 +3620,18 @@ SGP_DEV unsigned long long route_mask(const DV& d, uint32_t i, const TileRoute& 
 	const float* mylo = t.boxes + 6 * t.my_rank; const float* myhi = mylo + 3;
 	if (!export_qualifies(d, i, make_float3(mylo[0], mylo[1], mylo[2]), make_float3(myhi[0], myhi[1], myhi[2]), t.margin, f)) return 0ull;
 	const float4 p = d.pos_im[i];
-	emigrates = t.n_tiles > 1 && f_motion(f) == SGP_MOTION_DYNAMIC && !tile_in_box(p, mylo, myhi, 0.0f);
+	// an owned dynamic body emigrates only when another tile's own (unpadded) region contains its centre: where the caller's boxes leave a gap
+	// nobody would accept the body, so it stays with its current owner instead of vanishing
+	const bool left = t.n_tiles > 1 && f_motion(f) == SGP_MOTION_DYNAMIC && !tile_in_box(p, mylo, myhi, 0.0f);
+	bool taker = false;
 	unsigned long long m = 0ull;
-	for (uint32_t r = 0; r < t.n_tiles; ++r) { if (r == t.my_rank) continue; const float* lo = t.boxes + 6 * r; if (tile_in_box(p, lo, lo + 3, t.pad)) m |= 1ull << r; }
+	for (uint32_t r = 0; r < t.n_tiles; ++r) {
+		if (r == t.my_rank) continue;
+		const float* lo = t.boxes + 6 * r;
+		if (tile_in_box(p, lo, lo + 3, t.pad)) m |= 1ull << r;
+		if (left && tile_in_box(p, lo, lo + 3, 0.0f)) taker = true;
+	}
+	emigrates = left && taker;
 	return m;
 }
 
@@ -3743,6 +3752,16 @@ __global__ void __launch_bounds__(TPB) k_ghost_refresh_records(DV d, const sgp_g
 	refresh_aabb(d, i, f);
 	f = activate_body(d, i, f);
 	d.flags[i] = f;
+}
+
+// What the host needs of a received record to decide whether the ghost set changed: its global id and whether it asks for a change of ownership
+// (16 B instead of the 128 B record).
+__global__ void __launch_bounds__(TPB) k_pack_ghost_keys(const sgp_ghost_record* recs, uint32_t n, uint4* out)
+{
+	const uint32_t k = blockIdx.x * TPB + threadIdx.x;
+	if (k >= n) return;
+	const uint64_t g = recs[k].global_id;
+	out[k] = make_uint4((uint32_t)g, (uint32_t)(g >> 32), recs[k].motion_type, 0u);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -3905,6 +3924,10 @@ void launch_route_export(const DV& d, uint32_t nb, const TileRoute& t, uint32_t*
 	hipLaunchKernelGGL(k_route_count, dim3(blocks), dim3(TPB), 0, s, d, t, block_counts);
 	hipLaunchKernelGGL(k_route_scan, dim3(1), dim3(1024), 0, s, (const uint32_t*)block_counts, block_offsets, blocks, t.n_tiles, header);
 	hipLaunchKernelGGL(k_route_write, dim3(blocks), dim3(TPB), 0, s, d, t, (const uint32_t*)block_offsets, (const RouteHeader*)header, out, cap, emigrant_ids, emigrant_cap);
+}
+void launch_pack_ghost_keys(const sgp_ghost_record* recs, uint32_t n, void* out, hipStream_t s)
+{
+	if (n) hipLaunchKernelGGL(k_pack_ghost_keys, dim3(blocks_for(n)), dim3(TPB), 0, s, recs, n, (uint4*)out);
 }
 void launch_ghost_refresh_records(const DV& d, const sgp_ghost_record* recs, const uint32_t* ids, uint32_t n, hipStream_t s)
 {

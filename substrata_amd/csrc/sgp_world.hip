@@ -86,6 +86,7 @@ struct sgp_world {
 	// staging
 	void* stage_dev = nullptr; size_t stage_dev_bytes = 0;
 	void* stage_host = nullptr; size_t stage_host_bytes = 0;
+	void* view_host = nullptr; size_t view_host_bytes = 0;       // pinned buffer of sgp_world_read_active[_poses]_view only
 	StepCounters* h_ctr = nullptr; StepCounters* h_ctr_dev = nullptr; EventCounters* h_evc = nullptr; EventCounters* h_evc_dev = nullptr;
 	bool dirty_since_step = true;                              // an edit was flushed since the last step (or no step yet)
 	uint32_t last_active = 0xFFFFFFFFu;
@@ -364,6 +365,7 @@ SGP_API int sgp_world_destroy(sgp_world* w)
 	if (w->d_vehicles) hipFree(w->d_vehicles);
 	if (w->d_veh_inputs) hipFree(w->d_veh_inputs);
 	if (w->stage_host) hipHostFree(w->stage_host);
+	if (w->view_host) hipHostFree(w->view_host);
 	if (w->h_ctr) hipHostFree(w->h_ctr);
 	if (w->h_evc) hipHostFree(w->h_evc);
 	if (w->h_sp) hipHostFree(w->h_sp);
@@ -694,6 +696,7 @@ SGP_API int sgp_body_set_pose_vel_batch(sgp_world* w, const uint32_t* ids, const
 {
 	if (!w || ((!ids || !recs) && n)) return fail(SGP_ERR_INVALID, "sgp_body_set_pose_vel_batch: NULL");
 	for (uint32_t i = 0; i < n; ++i) if (!live(w, ids[i])) return fail(SGP_ERR_BAD_ID, "sgp_body_set_pose_vel_batch: id not live");
+	for (uint32_t i = 0; i < n; ++i) if (is_compound_child(w, ids[i])) return fail(SGP_ERR_BAD_ID, "sgp_body_set_pose_vel_batch: an id is a child slot of a compound body; use the compound's id");
 	for (uint32_t i = 0; i < n; ++i) REQUIRE_FINITE(finite3(recs[i].pos) && finite4(recs[i].rot) && finite3(recs[i].lin_vel) && finite3(recs[i].ang_vel), "sgp_body_set_pose_vel_batch");
 	w->cmds.reserve(w->cmds.size() + n);
 	for (uint32_t i = 0; i < n; ++i) {
@@ -1537,7 +1540,6 @@ SGP_API int sgp_hull_destroy(sgp_world* w, uint32_t id)
 {
 	if (!w || id < 1 || id >= w->hulls.size() || w->hulls[id].nv == 0) return fail(SGP_ERR_BAD_ID, "sgp_hull_destroy: no such hull");
 	if (w->hull_refs[id] != 0) return fail(SGP_ERR_REJECTED, "sgp_hull_destroy: a body still uses the hull");
-	for (uint32_t v = 0; v < w->n_vehicles; ++v) (void)v;
 	hipSetDevice(w->device);
 	memset(&w->hulls[id], 0, sizeof(sgd_hull));
 	HIP_TRY(hipMemcpyAsync(&w->d_hulls[id], &w->hulls[id], sizeof(sgd_hull), hipMemcpyHostToDevice, w->stream));
@@ -1871,23 +1873,35 @@ SGP_API int sgp_world_read_states(sgp_world* w, uint32_t first, uint32_t n, sgp_
 
 // The compacted states of the active bodies land in the pinned staging buffer with ONE host sync: the gather, the counters and a copy sized
 // from the previous step's active count (+ slack) are queued together; only a count above that estimate costs a second copy.
-static int read_active_to_stage(sgp_world* w, uint32_t cap, uint32_t* n_out, uint32_t* m_out, bool poses_only = false)
+// (to_view: the records land in the pinned buffer that only the *_view entry points use, so that a ray cast, a state query or any other call that
+//  stages data through stage_host cannot overwrite -- or reallocate -- what a caller is still iterating over)
+static int read_active_to_stage(sgp_world* w, uint32_t cap, uint32_t* n_out, uint32_t* m_out, bool poses_only = false, bool to_view = false)
 {
 	const size_t rec = poses_only ? sizeof(sgp_body_pose) : sizeof(sgp_body_state);
 	hipSetDevice(w->device);
 	{ int r = flush_cmds(w); if (r != SGP_OK) return r; }
 	const uint32_t lim = std::min(cap, w->dv.cap_bodies);
 	{ int r = ensure_stage(w, rec * std::max(lim, 1u)); if (r != SGP_OK) return r; }
+	void* host_dst = w->stage_host;
+	if (to_view) {
+		const size_t need = rec * std::max(lim, 1u);
+		if (need > w->view_host_bytes) {
+			if (w->view_host) { hipStreamSynchronize(w->stream); hipHostFree(w->view_host); w->view_host = nullptr; w->view_host_bytes = 0; }
+			HIP_TRY(hipHostMalloc(&w->view_host, need, hipHostMallocDefault));
+			w->view_host_bytes = need;
+		}
+		host_dst = w->view_host;
+	}
 	HIP_TRY(hipMemsetAsync(&w->dv.ctr->n_read_active, 0, sizeof(uint32_t), w->stream));
 	if (poses_only) launch_gather_active_poses(w->dv, w->high, w->stage_dev, lim, w->stream);
 	else launch_gather_active(w->dv, w->high, (sgp_body_state*)w->stage_dev, lim, w->stream);
 	const uint32_t guess = std::min(lim, w->last_active + w->last_active / 16u + 256u);
-	if (guess) HIP_TRY(hipMemcpyAsync(w->stage_host, w->stage_dev, rec * guess, hipMemcpyDeviceToHost, w->stream));
+	if (guess) HIP_TRY(hipMemcpyAsync(host_dst, w->stage_dev, rec * guess, hipMemcpyDeviceToHost, w->stream));
 	{ int r = read_counters(w); if (r != SGP_OK) return r; }      // (the one sync)
 	const uint32_t n = w->h_ctr->n_read_active;
 	const uint32_t m = std::min(n, lim);
 	if (m > guess) {
-		HIP_TRY(hipMemcpyAsync((char*)w->stage_host + rec * guess, (char*)w->stage_dev + rec * guess,
+		HIP_TRY(hipMemcpyAsync((char*)host_dst + rec * guess, (char*)w->stage_dev + rec * guess,
 		                       rec * (m - guess), hipMemcpyDeviceToHost, w->stream));
 		HIP_TRY(hipStreamSynchronize(w->stream));
 	}
@@ -1909,8 +1923,8 @@ SGP_API int sgp_world_read_active_view(sgp_world* w, const sgp_body_state** view
 {
 	if (!w || !view_out || !n_out) return fail(SGP_ERR_INVALID, "sgp_world_read_active_view: NULL");
 	uint32_t n = 0, m = 0;
-	{ int r = read_active_to_stage(w, w->dv.cap_bodies, &n, &m); if (r != SGP_OK) return r; }
-	*view_out = (const sgp_body_state*)w->stage_host;
+	{ int r = read_active_to_stage(w, w->dv.cap_bodies, &n, &m, false, true); if (r != SGP_OK) return r; }
+	*view_out = (const sgp_body_state*)w->view_host;
 	*n_out = m;
 	return SGP_OK;
 }
@@ -1919,8 +1933,8 @@ SGP_API int sgp_world_read_active_poses_view(sgp_world* w, const sgp_body_pose**
 {
 	if (!w || !view_out || !n_out) return fail(SGP_ERR_INVALID, "sgp_world_read_active_poses_view: NULL");
 	uint32_t n = 0, m = 0;
-	{ int r = read_active_to_stage(w, w->dv.cap_bodies, &n, &m, true); if (r != SGP_OK) return r; }
-	*view_out = (const sgp_body_pose*)w->stage_host;
+	{ int r = read_active_to_stage(w, w->dv.cap_bodies, &n, &m, true, true); if (r != SGP_OK) return r; }
+	*view_out = (const sgp_body_pose*)w->view_host;
 	*n_out = m;
 	return SGP_OK;
 }
@@ -2150,7 +2164,11 @@ static int make_ghost(sgp_world* w, const sgp_ghost_record& r, uint32_t* id_out)
 	memcpy(d.pos, r.pos, 12); memcpy(d.rot, r.rot, 16); memcpy(d.lin_vel, r.lin_vel, 12); memcpy(d.ang_vel, r.ang_vel, 12);
 	d.shape_type = r.shape_type; memcpy(d.shape, r.shape, 16);
 	d.motion_type = SGP_MOTION_KINEMATIC;      // velocity driven, infinite mass for this tile's solve
-	d.layer = SGP_LAYER_MOVING;
+	// layer and sensor flag of the original: a sensor or a non-collidable body near the border must not become a solid obstacle next door
+	d.layer = (int32_t)(r.flags & SGP_GHOST_FLAG_LAYER_MASK);
+	if (d.layer == SGP_LAYER_NON_MOVING) d.layer = SGP_LAYER_MOVING;                               // (a kinematic ghost lives on a moving layer)
+	if (d.layer == SGP_LAYER_NON_MOVING_NON_COLLIDABLE) d.layer = SGP_LAYER_MOVING_NON_COLLIDABLE;
+	d.is_sensor = (r.flags & SGP_GHOST_FLAG_SENSOR) ? 1 : 0;
 	d.mass = r.mass; d.friction = r.friction; d.restitution = r.restitution;
 	d.activate = 1; d.userdata = r.userdata;       // a ray or an event that meets the ghost names the object, like its owner would
 	*id_out = SGP_INVALID_ID;
@@ -2293,7 +2311,9 @@ SGP_API int sgp_tiles_route(const sgp_ghost_record* recs, uint32_t n, uint32_t m
 	std::vector<uint8_t> emig(n, 0);
 	uint32_t ne = 0;
 	for (uint32_t k = 0; k < n; ++k) {
-		if (n_tiles > 1 && (recs[k].motion_type & 0xFFu) == SGP_MOTION_DYNAMIC && !in_box(recs[k].pos, mylo, myhi, 0.0f)) {
+		bool taker = false;      // (same rule as route_mask on the device: without a tile that contains the centre the body stays where it is)
+		for (uint32_t r = 0; r < n_tiles && !taker; ++r) if (r != my_rank) taker = in_box(recs[k].pos, boxes + 6 * (size_t)r, boxes + 6 * (size_t)r + 3, 0.0f);
+		if (n_tiles > 1 && taker && (recs[k].motion_type & 0xFFu) == SGP_MOTION_DYNAMIC && !in_box(recs[k].pos, mylo, myhi, 0.0f)) {
 			emig[k] = 1;
 			if (ne < emigrant_cap && emigrant_ids) emigrant_ids[ne] = (uint32_t)(recs[k].global_id & 0xFFFFFFFFull);
 			++ne;
@@ -2381,8 +2401,44 @@ struct RcclApi {
 	int (*GroupStart)() = nullptr;
 	int (*GroupEnd)() = nullptr;
 	const char* (*GetErrorString)(int) = nullptr;
+	int (*CommCount)(sgp_nccl_comm, int*) = nullptr;
 };
 RcclApi g_rccl;
+
+// The prototypes above are hand-declared so that libsgp.so builds and loads without RCCL.  Where <rccl/rccl.h> is installed at build time
+// they are checked against it: same number of parameters, every parameter and the result of the same size and kind (pointer / integer or
+// enum / class passed by value), and the enumerators this file passes as integers.  A mismatch is a compile error, not a first-run surprise.
+#if __has_include(<rccl/rccl.h>)
+}
+#include <rccl/rccl.h>
+#include <type_traits>
+namespace {
+template <class A, class B> constexpr bool sgp_abi_same_arg()
+{
+	return sizeof(A) == sizeof(B) && std::is_pointer<A>::value == std::is_pointer<B>::value && std::is_class<A>::value == std::is_class<B>::value &&
+	       (std::is_integral<A>::value || std::is_enum<A>::value) == (std::is_integral<B>::value || std::is_enum<B>::value);
+}
+template <class F, class G> struct sgp_abi_same : std::false_type {};
+template <class R, class... A, class S, class... B> struct sgp_abi_same<R (*)(A...), S (*)(B...)>
+{
+	template <bool same_arity, class Dummy = void> struct args { static constexpr bool value = false; };
+	template <class Dummy> struct args<true, Dummy> { static constexpr bool value = (sgp_abi_same_arg<A, B>() && ... && true); };
+	static constexpr bool value = sgp_abi_same_arg<R, S>() && args<sizeof...(A) == sizeof...(B)>::value;
+};
+#define SGP_CHECK_RCCL(member, fn) static_assert(sgp_abi_same<decltype(RcclApi::member), decltype(&fn)>::value, "hand-declared prototype of " #fn " does not match <rccl/rccl.h>")
+SGP_CHECK_RCCL(GetUniqueId, ncclGetUniqueId);
+SGP_CHECK_RCCL(CommInitRank, ncclCommInitRank);
+SGP_CHECK_RCCL(CommDestroy, ncclCommDestroy);
+SGP_CHECK_RCCL(AllGather, ncclAllGather);
+SGP_CHECK_RCCL(Send, ncclSend);
+SGP_CHECK_RCCL(Recv, ncclRecv);
+SGP_CHECK_RCCL(GroupStart, ncclGroupStart);
+SGP_CHECK_RCCL(GroupEnd, ncclGroupEnd);
+SGP_CHECK_RCCL(GetErrorString, ncclGetErrorString);
+SGP_CHECK_RCCL(CommCount, ncclCommCount);
+static_assert(sizeof(ncclUniqueId) == sizeof(sgp_nccl_unique_id) && NCCL_UNIQUE_ID_BYTES == SGP_TILES_UNIQUE_ID_BYTES, "ncclUniqueId is 128 bytes");
+static_assert((int)ncclUint8 == SGP_NCCL_UINT8 && (int)ncclUint32 == SGP_NCCL_UINT32 && (int)ncclSuccess == 0, "ncclDataType_t / ncclResult_t values");
+#endif
 
 bool rccl_load()
 {
@@ -2405,6 +2461,7 @@ bool rccl_load()
 	g_rccl.GroupEnd = (int (*)())sym("ncclGroupEnd");
 	g_rccl.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
 	if (!ok) { g_rccl.lib = nullptr; return false; }
+	g_rccl.CommCount = (int (*)(sgp_nccl_comm, int*))dlsym(g_rccl.lib, "ncclCommCount");      // optional: only reported in sgp_tiles_stats
 	return true;
 }
 int rccl_fail(const char* what, int rc)
@@ -2431,6 +2488,7 @@ struct sgp_tiles {
 	uint32_t* d_seq_ids = nullptr; uint32_t cap_seq = 0; uint64_t ids_version = 0;      // local body id of ghost k of the current ghost set (device copy, for the refresh kernel)
 	// host (pinned)
 	char* h_ctl = nullptr; sgp_ghost_record* h_recv = nullptr; uint32_t cap_h_recv = 0;
+	uint4* d_keys = nullptr; uint32_t cap_keys = 0; void* h_keys = nullptr; uint32_t cap_h_keys = 0;      // (global id, ownership flag) of the received records
 	// last exchange
 	std::vector<uint32_t> recv_counts, recv_offsets;
 	std::vector<uint64_t> seq_gids;        // global ids of the ghosts of the previous import, in order
@@ -2472,6 +2530,8 @@ SGP_API int sgp_tiles_destroy(sgp_tiles* t)
 	hipFree(t->d_block_counts); hipFree(t->d_block_offsets); hipFree(t->d_ctl); hipFree(t->d_send); hipFree(t->d_recv); hipFree(t->d_emig); hipFree(t->d_seq_ids);
 	if (t->h_ctl) hipHostFree(t->h_ctl);
 	if (t->h_recv) hipHostFree(t->h_recv);
+	if (t->h_keys) hipHostFree(t->h_keys);
+	hipFree(t->d_keys);
 	delete t;
 	return SGP_OK;
 }
@@ -2491,11 +2551,16 @@ SGP_API int sgp_tiles_create(sgp_world* w, uint32_t rank, uint32_t n_tiles, cons
 	if (hipMalloc((void**)&t->d_ctl, cb) != hipSuccess || hipHostMalloc((void**)&t->h_ctl, cb, hipHostMallocDefault) != hipSuccess) { sgp_tiles_destroy(t); return fail(SGP_ERR_HIP, "sgp_tiles_create: allocation"); }
 	hipMemset(t->d_ctl, 0, cb); memset(t->h_ctl, 0, cb);
 	t->recv_counts.assign(n_tiles, 0); t->recv_offsets.assign(n_tiles, 0);
-	if (unique_id && n_tiles > 1) {
+	if (unique_id) {      // (a one-tile communicator is legal: it lets a single GPU run the whole collective path, bench.py --force-comm)
 		if (!rccl_load()) { sgp_tiles_destroy(t); return fail(SGP_ERR_HIP, "sgp_tiles_create: RCCL (librccl.so) not found"); }
 		sgp_nccl_unique_id id; memcpy(&id, unique_id, sizeof(id));
+		const auto t0 = std::chrono::steady_clock::now();
 		const int rc = g_rccl.CommInitRank(&t->comm, (int)n_tiles, id, (int)rank);
 		if (rc != 0) { sgp_tiles_destroy(t); return rccl_fail("ncclCommInitRank", rc); }
+		t->stats.comm_init_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+		int seen = 0;
+		if (g_rccl.CommCount && g_rccl.CommCount(t->comm, &seen) == 0) t->stats.comm_ranks = (uint32_t)seen;
+		if (t->stats.comm_ranks && t->stats.comm_ranks != n_tiles) { sgp_tiles_destroy(t); return fail(SGP_ERR_HIP, "sgp_tiles_create: the RCCL communicator does not have one rank per tile"); }
 	}
 	*out = t;
 	return SGP_OK;
@@ -2558,7 +2623,32 @@ static int tiles_import(sgp_tiles* t, uint32_t n)
 	sgp_world* w = t->w;
 	t->stats.received = n;
 	// steady state: the same ghosts as last step in the same order, nobody immigrating -> poses go from the received records to the bodies
-	// on the device; the host only compares the 8-byte ids (copied back packed, not the 128-byte records)
+	// on the device; the host only sees 16 bytes per record (global id + ownership flag, packed by a kernel), not the 128-byte records
+	struct GhostKey { uint64_t global_id; uint32_t motion_type, pad; };
+	if (n) {
+		{ int r = tiles_grow(w, t->d_keys, t->cap_keys, n); if (r != SGP_OK) return r; }
+		if (n > t->cap_h_keys) {
+			if (t->h_keys) hipHostFree(t->h_keys);
+			t->cap_h_keys = n + n / 2 + 1024;
+			HIP_TRY(hipHostMalloc((void**)&t->h_keys, 16 * (size_t)t->cap_h_keys, hipHostMallocDefault));
+		}
+		launch_pack_ghost_keys(t->d_recv, n, t->d_keys, w->stream);
+		HIP_TRY(hipMemcpyAsync(t->h_keys, t->d_keys, 16 * (size_t)n, hipMemcpyDeviceToHost, w->stream));
+		HIP_TRY(hipStreamSynchronize(w->stream));
+		const GhostKey* keys = (const GhostKey*)t->h_keys;
+		bool same = n == w->ghost_seq.size();
+		for (uint32_t k = 0; k < n && same; ++k) same = !(keys[k].motion_type & SGP_GHOST_TAKE_OWNERSHIP) && keys[k].global_id == w->ghost_seq[k].first && live(w, w->ghost_seq[k].second);
+		if (same) {
+			{ int r = flush_cmds(w); if (r != SGP_OK) return r; }
+			GhostDeviceSource dev = { t->d_recv, &t->d_seq_ids, &t->cap_seq, &t->ids_version };
+			if (t->ids_version != w->ghost_seq_version) { int r = upload_ghost_ids(w, &dev); if (r != SGP_OK) return r; }
+			launch_ghost_refresh_records(w->dv, t->d_recv, t->d_seq_ids, n, w->stream);
+			w->grid_valid = false; w->dirty_since_step = true;
+			t->stats.ghosts = n; t->stats.immigrated = 0; t->stats.fast_imports++;
+			return SGP_OK;
+		}
+	}
+	// the set changed (or bodies immigrate): the records themselves come to the host, which owns the body slots
 	if (n > t->cap_h_recv) {
 		if (t->h_recv) hipHostFree(t->h_recv);
 		t->cap_h_recv = n + n / 2 + 1024;
@@ -2622,22 +2712,24 @@ SGP_API int sgp_tiles_exchange(sgp_tiles* t)
 	sgp_world* w = t->w;
 	hipSetDevice(w->device);
 	const uint32_t T = t->n_tiles;
+	const auto t_begin = std::chrono::steady_clock::now();
+	struct Stamp { sgp_tiles* t; std::chrono::steady_clock::time_point t0; ~Stamp() { t->stats.last_exchange_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); t->stats.exchanges++; t->stats.total_exchange_ms += t->stats.last_exchange_ms; } } stamp = { t, t_begin };
 	if (T > 1 && !t->comm) return fail(SGP_ERR_INVALID, "sgp_tiles_exchange: created without a communicator (use sgp_tiles_exchange_group for tiles of one process)");
 	uint32_t* d_matrix = (uint32_t*)(t->d_ctl + tiles_matrix_off());
+	// Routing is local and its COUNTS do not depend on the buffer sizes, so the all-gather runs exactly once per exchange; a rank whose
+	// send / emigrant buffers were too small grows them and re-runs only its own routing kernels -- the other ranks never notice, and no rank
+	// can return between the all-gather and the matching send / recv (which would leave its peers waiting in ncclRecv for ever).
 	for (int attempt = 0; attempt < 3; ++attempt) {
 		{ int r = tiles_launch_route(t); if (r != SGP_OK) return r; }
 		// every rank's per-destination counts: one small all-gather on device buffers
-		if (T > 1) RCCL_TRY(g_rccl.AllGather(t->d_ctl /* RouteHeader::seg_count comes first */, d_matrix, T, SGP_NCCL_UINT32, t->comm, w->stream), "ncclAllGather");
+		if (t->comm && attempt == 0) RCCL_TRY(g_rccl.AllGather(t->d_ctl /* RouteHeader::seg_count comes first */, d_matrix, T, SGP_NCCL_UINT32, t->comm, w->stream), "ncclAllGather");
 		HIP_TRY(hipMemcpyAsync(t->h_ctl, t->d_ctl, tiles_ctl_bytes(T), hipMemcpyDeviceToHost, w->stream));
 		HIP_TRY(hipStreamSynchronize(w->stream));
 		bool redo = false;
 		{ int r = tiles_after_header(t, &redo); if (r != SGP_OK) return r; }
 		if (!redo) break;
-		if (attempt == 2) return fail(SGP_ERR_CAPACITY, "sgp_tiles_exchange: send buffer");
-		// (every rank sees every rank's counts, but only this rank knows its buffers were short: the all-gather above already completed for all,
-		//  so the retry runs the collective again on every rank only if all ranks retry -- they cannot know.  Keep it collective-safe: a rank that
-		//  had to grow reports the error instead of desynchronising the communicator.)
-		if (T > 1) return fail(SGP_ERR_CAPACITY, "sgp_tiles_exchange: boundary larger than the send buffer; the buffers have been grown, call again on every rank");
+		t->stats.route_retries++;
+		if (attempt == 2) return fail(SGP_ERR_CAPACITY, "sgp_tiles_exchange: send buffer");      // (unreachable: the second attempt has the sizes the first one reported)
 	}
 	const RouteHeader* h = (const RouteHeader*)t->h_ctl;
 	const uint32_t* matrix = (const uint32_t*)(t->h_ctl + tiles_matrix_off());          // [source][destination]
@@ -2740,5 +2832,93 @@ SGP_API int sgp_tiles_selftest_rccl(sgp_world* w, uint32_t n_records)
 	g_rccl.CommDestroy(comm);
 	if (rc != 0) return rccl_fail("RCCL self test", rc);
 	if (memcmp(src.data(), dst.data(), bytes) != 0 || memcmp(row, got, 16) != 0) return fail(SGP_ERR_HIP, "RCCL self test: payload mismatch");
+	return SGP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Network physics snapshots: the de-jitter ring and the insertion schedule (include/sgp.h has the reference map).  Host-side state only.
+#include <map>
+struct SnapshotRing {
+	struct Entry { sgp_pose_vel rec; double client_time, local_time; };
+	Entry slots[SGP_SNAPSHOT_HISTORY];
+	uint32_t next_snapshot_i = 0, next_insertable_snapshot_i = 0;
+	double transmission_time_offset = 0.0;
+};
+struct sgp_snapshot_queue { std::map<uint64_t, SnapshotRing> rings; };      // ordered: the playback order is ascending uid, deterministic
+
+SGP_API int sgp_snapshot_queue_create(sgp_snapshot_queue** out)
+{
+	if (!out) return fail(SGP_ERR_INVALID, "sgp_snapshot_queue_create: NULL");
+	*out = new sgp_snapshot_queue();
+	return SGP_OK;
+}
+SGP_API int sgp_snapshot_queue_destroy(sgp_snapshot_queue* q) { delete q; return SGP_OK; }
+
+SGP_API int sgp_snapshot_queue_push(sgp_snapshot_queue* q, uint64_t uid, const sgp_pose_vel* rec, double client_time, double local_time)
+{
+	if (!q || !rec) return fail(SGP_ERR_INVALID, "sgp_snapshot_queue_push: NULL");
+	REQUIRE_FINITE(finite3(rec->pos) && finite4(rec->rot) && finite3(rec->lin_vel) && finite3(rec->ang_vel), "sgp_snapshot_queue_push");
+	SnapshotRing& r = q->rings[uid];
+	SnapshotRing::Entry& e = r.slots[r.next_snapshot_i % (uint32_t)SGP_SNAPSHOT_HISTORY];      // the oldest slot is overwritten, pending or not
+	e.rec = *rec; e.client_time = client_time; e.local_time = local_time;
+	r.next_snapshot_i++;
+	return SGP_OK;
+}
+SGP_API int sgp_snapshot_queue_push_wire(sgp_snapshot_queue* q, const uint8_t msg[SGP_PHYSICS_UPDATE_BYTES], double local_time)
+{
+	if (!q || !msg) return fail(SGP_ERR_INVALID, "sgp_snapshot_queue_push_wire: NULL");
+	uint64_t uid = 0; sgp_pose_vel rec; double t = 0.0;
+	{ const int r = sgp_physics_update_decode(msg, &uid, &rec, &t); if (r != SGP_OK) return r; }
+	return sgp_snapshot_queue_push(q, uid, &rec, t, local_time);
+}
+
+SGP_API int sgp_snapshot_queue_ownership(sgp_snapshot_queue* q, uint64_t uid, double global_time_now, double ownership_change_global_time, int renewal)
+{
+	if (!q) return fail(SGP_ERR_INVALID, "sgp_snapshot_queue_ownership: NULL");
+	SnapshotRing& r = q->rings[uid];
+	const double offset = global_time_now - ownership_change_global_time;      // receiver's clock minus sender's clock at the same event
+	if (renewal) { if (r.transmission_time_offset == 0.0) r.transmission_time_offset = offset; }
+	else { r.transmission_time_offset = offset; r.next_insertable_snapshot_i = r.next_snapshot_i; }      // a new owner: what the old one queued is void
+	return SGP_OK;
+}
+
+SGP_API int sgp_snapshot_queue_poll(sgp_snapshot_queue* q, double global_time, double padding_delay, uint64_t* uids_out, sgp_pose_vel* recs_out, uint32_t cap, uint32_t* n_out)
+{
+	if (!q || !n_out || (cap && (!uids_out || !recs_out))) return fail(SGP_ERR_INVALID, "sgp_snapshot_queue_poll: NULL");
+	uint32_t n = 0;
+	for (auto& kv : q->rings) {
+		SnapshotRing& r = kv.second;
+		if (!(r.next_insertable_snapshot_i < r.next_snapshot_i)) continue;                       // nothing pending
+		const SnapshotRing::Entry& e = r.slots[r.next_insertable_snapshot_i % (uint32_t)SGP_SNAPSHOT_HISTORY];
+		const double desired_insertion_time = e.client_time + r.transmission_time_offset + padding_delay;
+		if (!(global_time >= desired_insertion_time)) continue;
+		if (n < cap) { uids_out[n] = kv.first; recs_out[n] = e.rec; r.next_insertable_snapshot_i++; }      // (beyond cap: stays pending, reported in *n_out)
+		++n;
+	}
+	*n_out = n;
+	return SGP_OK;
+}
+
+SGP_API int sgp_snapshot_queue_expire(sgp_snapshot_queue* q, double local_time_now, double max_age, uint32_t* n_out)
+{
+	if (!q) return fail(SGP_ERR_INVALID, "sgp_snapshot_queue_expire: NULL");
+	for (auto it = q->rings.begin(); it != q->rings.end();) {
+		const SnapshotRing& r = it->second;
+		const bool has_any = r.next_snapshot_i > 0;
+		const double last = has_any ? r.slots[(r.next_snapshot_i - 1) % (uint32_t)SGP_SNAPSHOT_HISTORY].local_time : -1.0e300;
+		if (has_any && local_time_now - last > max_age) it = q->rings.erase(it); else ++it;
+	}
+	if (n_out) *n_out = (uint32_t)q->rings.size();
+	return SGP_OK;
+}
+
+SGP_API int sgp_snapshot_queue_peek(sgp_snapshot_queue* q, uint64_t uid, uint32_t* next_snapshot_i, uint32_t* next_insertable_snapshot_i, double* transmission_time_offset)
+{
+	if (!q) return fail(SGP_ERR_INVALID, "sgp_snapshot_queue_peek: NULL");
+	auto it = q->rings.find(uid);
+	if (it == q->rings.end()) return fail(SGP_ERR_BAD_ID, "sgp_snapshot_queue_peek: uid not tracked");
+	if (next_snapshot_i) *next_snapshot_i = it->second.next_snapshot_i;
+	if (next_insertable_snapshot_i) *next_insertable_snapshot_i = it->second.next_insertable_snapshot_i;
+	if (transmission_time_offset) *transmission_time_offset = it->second.transmission_time_offset;
 	return SGP_OK;
 }

@@ -2,6 +2,8 @@
 import ctypes as C
 import os
 
+import numpy as np
+
 from . import abi
 from .world import CWorld, SgpError
 
@@ -50,3 +52,61 @@ class World(CWorld):
                 break
             names.append(s.decode())
         return names
+
+
+class SnapshotQueue:
+    """De-jitter rings + insertion schedule of the network physics snapshots (sgp_snapshot_queue_*, include/sgp.h): host-side state, one
+    queue for any number of objects keyed by uid.  poll() returns what is due now as (uids, pose_vel records) for ONE
+    World.set_pose_vel_batch call."""
+
+    PADDING_DELAY = 0.1       # GUIClient.cpp:7465
+
+    def __init__(self):
+        self._lib = load()
+        self._h = C.c_void_p()
+        rc = self._lib.sgp_snapshot_queue_create(C.byref(self._h))
+        self._check(rc)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise SgpError(f"sgp_snapshot_queue call failed ({rc}): {self._lib.sgp_last_error().decode()}")
+
+    def push_wire(self, msg, local_time):
+        buf = (C.c_uint8 * abi.PHYSICS_UPDATE_BYTES).from_buffer_copy(bytes(msg))
+        self._check(self._lib.sgp_snapshot_queue_push_wire(self._h, buf, float(local_time)))
+
+    def push(self, uid, rec, client_time, local_time):
+        r = abi.PoseVel.from_buffer_copy(np.asarray(rec, dtype=abi.pose_vel_dtype).tobytes())
+        self._check(self._lib.sgp_snapshot_queue_push(self._h, int(uid), C.byref(r), float(client_time), float(local_time)))
+
+    def ownership(self, uid, global_time_now, ownership_change_global_time, renewal=False):
+        self._check(self._lib.sgp_snapshot_queue_ownership(self._h, int(uid), float(global_time_now), float(ownership_change_global_time), 1 if renewal else 0))
+
+    def poll(self, global_time, padding_delay=PADDING_DELAY, cap=4096):
+        uids = np.zeros(cap, dtype=np.uint64)
+        recs = np.zeros(cap, dtype=abi.pose_vel_dtype)
+        n = C.c_uint32(0)
+        self._check(self._lib.sgp_snapshot_queue_poll(self._h, float(global_time), float(padding_delay), uids.ctypes.data, recs.ctypes.data, cap, C.byref(n)))
+        m = min(n.value, cap)
+        return uids[:m], recs[:m], n.value
+
+    def expire(self, local_time_now, max_age=1.0):
+        n = C.c_uint32(0)
+        self._check(self._lib.sgp_snapshot_queue_expire(self._h, float(local_time_now), float(max_age), C.byref(n)))
+        return n.value
+
+    def peek(self, uid):
+        a, b, off = C.c_uint32(0), C.c_uint32(0), C.c_double(0)
+        self._check(self._lib.sgp_snapshot_queue_peek(self._h, int(uid), C.byref(a), C.byref(b), C.byref(off)))
+        return a.value, b.value, off.value
+
+    def close(self):
+        if self._h:
+            self._lib.sgp_snapshot_queue_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

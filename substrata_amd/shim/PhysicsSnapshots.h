@@ -7,6 +7,7 @@
 #include "../../include/sgp.h"
 #include <vector>
 #include <cstring>
+#include <algorithm>
 
 struct PhysicsSnapshot     // WorldObject::Snapshot, shared/WorldObject.h:553-561
 {
@@ -70,3 +71,63 @@ inline void insertPhysicsSnapshots(PhysicsWorld& world, const std::vector<Physic
 	}
 	if (!ids.empty()) sgp_body_set_pose_vel_batch(world.world, ids.data(), recs.data(), (uint32_t)ids.size());
 }
+
+// The de-jitter buffer and its playback schedule for many objects at once: WorldObject::snapshots / next_snapshot_i /
+// next_insertable_snapshot_i / transmission_time_offset (shared/WorldObject.h:540-566), filled the way ClientThread does
+// (ClientThread.cpp:736-792 receive, :957-975 ownership) and drained the way GUIClient::timerEvent does (GUIClient.cpp:7462-7493:
+// global_time >= client_time + transmission_time_offset + 0.1 s, one snapshot per object and frame) -- with all the snapshots that are
+// due in a frame going into the physics world through ONE batched call instead of one setNewObToWorldTransform per object.
+class PhysicsSnapshotQueue
+{
+public:
+	PhysicsSnapshotQueue() : q(nullptr) { sgp_snapshot_queue_create(&q); }
+	~PhysicsSnapshotQueue() { sgp_snapshot_queue_destroy(q); }
+	PhysicsSnapshotQueue(const PhysicsSnapshotQueue&) = delete;
+	PhysicsSnapshotQueue& operator=(const PhysicsSnapshotQueue&) = delete;
+
+	// ClientThread, Protocol::ObjectPhysicsTransformUpdate: the 80 payload bytes as they came off the wire
+	bool receive(const uint8_t msg[SGP_PHYSICS_UPDATE_BYTES], double local_time) { return sgp_snapshot_queue_push_wire(q, msg, local_time) == SGP_OK; }
+	// ClientThread, Protocol::ObjectPhysicsOwnershipTaken
+	void ownershipTaken(uint64 uid, double global_time_now, double last_physics_ownership_change_global_time, bool renewal)
+	{
+		sgp_snapshot_queue_ownership(q, uid, global_time_now, last_physics_ownership_change_global_time, renewal ? 1 : 0);
+	}
+	// GUIClient::timerEvent: everything that is due at global_time goes into the world; `lookup(uid)` returns the object's PhysicsObject* (or
+	// null when it has none).  Returns the number of snapshots inserted.
+	template <class Lookup> size_t insertDue(PhysicsWorld& world, double global_time, Lookup lookup, double padding_delay = 0.1)
+	{
+		uint32_t n = 0;
+		uids.resize(std::max<size_t>(uids.size(), 256)); recs.resize(uids.size());
+		for (;;) {
+			sgp_snapshot_queue_poll(q, global_time, padding_delay, uids.data(), recs.data(), (uint32_t)uids.size(), &n);
+			if (n <= uids.size()) break;
+			// more objects due than the buffers held: the first ones were consumed, take them, then ask again with room for the rest
+			applyBatch(world, uids.size(), lookup);
+			uids.resize(n); recs.resize(n);
+		}
+		applyBatch(world, n, lookup);
+		return n;
+	}
+	// objects that have not been heard of for a second leave the active set (GUIClient.cpp:7443-7452)
+	uint32_t expire(double local_time_now, double max_age = 1.0) { uint32_t n = 0; sgp_snapshot_queue_expire(q, local_time_now, max_age, &n); return n; }
+	sgp_snapshot_queue* handle() const { return q; }
+
+private:
+	template <class Lookup> void applyBatch(PhysicsWorld& world, size_t n, Lookup lookup)
+	{
+		std::vector<PhysicsObject*> obs; std::vector<PhysicsSnapshot> snaps;
+		for (size_t i = 0; i < n; ++i) {
+			PhysicsObject* ob = lookup(uids[i]);
+			if (!ob) continue;
+			const sgp_pose_vel& r = recs[i];
+			PhysicsSnapshot s;
+			s.pos = Vec4f(r.pos[0], r.pos[1], r.pos[2], 1.f); s.rotation = Quatf(r.rot[0], r.rot[1], r.rot[2], r.rot[3]);
+			s.linear_vel = Vec4f(r.lin_vel[0], r.lin_vel[1], r.lin_vel[2], 0.f); s.angular_vel = Vec4f(r.ang_vel[0], r.ang_vel[1], r.ang_vel[2], 0.f);
+			s.client_time = 0; s.local_time = 0;
+			obs.push_back(ob); snaps.push_back(s);
+		}
+		insertPhysicsSnapshots(world, obs, snaps);
+	}
+	sgp_snapshot_queue* q;
+	std::vector<uint64_t> uids; std::vector<sgp_pose_vel> recs;
+};

@@ -13,6 +13,7 @@ import pytest
 from substrata_amd import abi, scenes, tiles
 from helpers import DT
 import parity
+import ghost_exchange
 
 pytestmark = pytest.mark.gpu
 
@@ -109,7 +110,7 @@ def test_config4_scaled_down_2x2x2_tiles_against_oracle(oracle):
     for s in range(1, 181):
         lc = []
         tiles.NativeTiles.exchange_group(nt)
-        tiles.exchange_in_process(cpu, boxes, margin, lc)
+        ghost_exchange.exchange_in_process(cpu, boxes, margin, lc)
         lg = []
         for r in range(n_tiles):
             st = nt[r].stats()

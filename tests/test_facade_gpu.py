@@ -34,6 +34,7 @@ def test_facade_compiles_without_gpu(tmp_path):
     assert os.path.exists(build_facade_exe(tmp_path, "player_controller.cpp"))
     assert os.path.exists(build_facade_exe(tmp_path, "mesh_world.cpp"))
     assert os.path.exists(build_facade_exe(tmp_path, "boat_controller.cpp"))
+    assert os.path.exists(build_facade_exe(tmp_path, "snapshot_stream.cpp"))
 
 
 # What the reference's callers include from Jolt and from the facade (grep '#include' of the files named; gui_client/ of the reference).
@@ -221,3 +222,12 @@ def test_facade_config1_matches_oracle(tmp_path, oracle):
     assert int(kv["contacts_added"]) > 100 and int(kv["persisted"]) > 1000 and int(kv["ray_hit"]) == 1
     assert "after remove: objects 0" in r.stdout
     w.close()
+
+
+@pytest.mark.gpu
+def test_snapshot_stream_through_the_dejitter_queue(tmp_path):
+    """PhysicsSnapshotQueue (shim/PhysicsSnapshots.h): 32 remote-owned boxes follow their owner's jittered 80-byte stream through the ring of
+    4 and the 0.1 s playback delay, batched insertion, smoothing offsets bounded."""
+    exe = build_facade_exe(tmp_path, "snapshot_stream.cpp")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -15,6 +15,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from substrata_amd import abi, scenes, tiles  # noqa: E402
+import ghost_exchange  # noqa: E402
 
 DT = 1.0 / 60.0
 TILE_W = 12.0
@@ -46,7 +47,7 @@ def migration_worker(rank, world_size, port, steps, out_dir):
         descs = np.concatenate([descs, b])
     w = oracle.OracleWorld(max_bodies=64)
     w.add_batch(descs)
-    ex = tiles.GhostExchange(w, rank, world_size, lo, hi, margin=1.5, dist=dist, device=torch.device("cpu"), cap=64)
+    ex = ghost_exchange.GhostExchange(w, rank, world_size, lo, hi, margin=1.5, dist=dist, device=torch.device("cpu"), cap=64)
     emig = immig = 0
     for _ in range(steps):
         ex.exchange()
@@ -68,7 +69,7 @@ def worker(rank, world_size, port, steps, out_dir):
     descs, lo, hi = scene_for_tile(rank, world_size)
     w = oracle.OracleWorld(max_bodies=1024)
     w.add_batch(descs)
-    ex = tiles.GhostExchange(w, rank, world_size, lo, hi, margin=1.5, dist=dist, device=torch.device("cpu"), cap=512)
+    ex = ghost_exchange.GhostExchange(w, rank, world_size, lo, hi, margin=1.5, dist=dist, device=torch.device("cpu"), cap=512)
     log = []
     for _ in range(steps):
         ex.exchange()
@@ -216,7 +217,7 @@ def corner_worker(rank, world_size, port, steps, out_dir):
         descs = np.concatenate([descs, b])
     w = oracle.OracleWorld(max_bodies=64)
     w.add_batch(descs)
-    ex = tiles.GhostExchange(w, rank, world_size, lo, hi, margin=1.5, dist=dist, device=torch.device("cpu"), cap=64)
+    ex = ghost_exchange.GhostExchange(w, rank, world_size, lo, hi, margin=1.5, dist=dist, device=torch.device("cpu"), cap=64)
     log = []
     for _ in range(steps):
         ex.exchange()
@@ -269,7 +270,7 @@ def zsplit_worker(rank, world_size, port, steps, out_dir):
     descs = np.concatenate([descs, b])
     w = oracle.OracleWorld(max_bodies=64)
     w.add_batch(descs)
-    ex = tiles.GhostExchange(w, rank, world_size, lo, hi, margin=2.0, dist=dist, device=torch.device("cpu"), cap=64)
+    ex = ghost_exchange.GhostExchange(w, rank, world_size, lo, hi, margin=2.0, dist=dist, device=torch.device("cpu"), cap=64)
     log = []
     for _ in range(steps):
         ex.exchange()
@@ -306,3 +307,29 @@ def test_two_tiles_split_in_z_bodies_fall_through_the_face(tmp_path, oracle):
     # the column came to rest on the base: nothing fell through, nothing is still moving fast
     assert dyn["pos"][:, 2].min() > 0.45 and dyn["pos"][:, 2].max() < 4.2
     assert np.abs(dyn["lin_vel"]).max() < 2.0 and np.all(np.isfinite(dyn["pos"]))     # (the top box may still be sliding off the pile)
+
+
+def test_sensor_ghost_is_a_sensor_next_door():
+    """Oracle tiles, one process: a sensor box and a non-collidable box of tile 0 overlap a resting box of tile 1 across the border.  Their ghosts
+    carry the layer and the sensor flag of the originals (sgp_ghost_record.flags), so the resting box is not pushed."""
+    from oracle import oracle
+    TILE_W = 12.0
+    boxes = np.array([np.concatenate(tiles.tile_bounds(r, 2, TILE_W, TILE_W)[:2]) for r in range(2)], np.float32)
+    a = scenes.dynamic_bodies(2)
+    a["shape_type"] = abi.SHAPE_BOX; a["shape"][:, :3] = 0.5
+    a["pos"][0] = (TILE_W - 0.1, 6.0, 0.5); a["is_sensor"][0] = 1
+    a["pos"][1] = (TILE_W - 0.2, 6.0, 1.6); a["layer"][1] = abi.LAYER_MOVING_NON_COLLIDABLE
+    a["gravity_factor"][:] = 0.0
+    b = scenes.dynamic_bodies(1)
+    b["shape_type"] = abi.SHAPE_BOX; b["shape"][0] = (0.5, 0.5, 0.5, 0); b["pos"][0] = (TILE_W + 0.7, 6.0, 0.5)
+    ws = [oracle.OracleWorld(max_bodies=64) for _ in range(2)]
+    ws[0].add_batch(np.concatenate([scenes.ground(), a])); ws[1].add_batch(np.concatenate([scenes.ground(), b]))
+    for _ in range(60):
+        ghost_exchange.exchange_in_process(ws, boxes, 1.5)
+        for w in ws:
+            w.step(1.0 / 60.0)
+    assert ws[1].num_bodies() == 4                       # ground + box + two ghosts
+    rest = ws[1].get_state([1])[0]
+    assert abs(float(rest["pos"][0]) - (TILE_W + 0.7)) < 1e-3 and abs(float(rest["pos"][1]) - 6.0) < 1e-3
+    for w in ws:
+        w.close()

@@ -132,6 +132,109 @@ def test_two_tiles_native_exchange_against_oracle(oracle):
         w.close()
 
 
+def sensor_border_scene(rank):
+    """Tile 1 holds a box at rest next to the border; tile 0 holds a SENSOR box and a box on the non-collidable moving layer, both overlapping it
+    across the border.  If their ghosts were solid (the round-2 behaviour) they would shove the resting box away."""
+    lo, hi, origin = tiles.tile_bounds(rank, 2, TILE_W, TILE_W)
+    if rank == 1:
+        d = scenes.dynamic_bodies(1)
+        d["shape_type"] = abi.SHAPE_BOX; d["shape"][0] = (0.5, 0.5, 0.5, 0)
+        d["pos"][0] = (TILE_W + 0.7, 6.0, 0.5)
+    else:
+        d = scenes.dynamic_bodies(2)
+        d["shape_type"] = abi.SHAPE_BOX; d["shape"][:, :3] = 0.5
+        d["pos"][0] = (TILE_W - 0.1, 6.0, 0.5); d["is_sensor"][0] = 1
+        d["pos"][1] = (TILE_W - 0.2, 6.0, 1.6); d["layer"][1] = abi.LAYER_MOVING_NON_COLLIDABLE
+        d["gravity_factor"][:] = 0.0            # they hover where they are
+    return np.concatenate([scenes.ground(), d]), lo, hi
+
+
+def test_sensor_and_non_collidable_ghosts_are_not_solid(oracle):
+    from substrata_amd.lib import World
+    scenes_, boxes = [], []
+    for r in range(2):
+        d, lo, hi = sensor_border_scene(r)
+        scenes_.append(d); boxes.append(np.concatenate([lo, hi]))
+    boxes = np.array(boxes, np.float32)
+    gpu = [World(max_bodies=64) for _ in range(2)]
+    cpu = [oracle.OracleWorld(max_bodies=64) for _ in range(2)]
+    for r in range(2):
+        gpu[r].add_batch(scenes_[r]); cpu[r].add_batch(scenes_[r])
+    nt = [tiles.NativeTiles(gpu[r], r, 2, boxes, 1.5) for r in range(2)]
+    for s in range(1, 61):
+        lc = []
+        tiles.NativeTiles.exchange_group(nt)
+        exchange(cpu, boxes, 1.5, lc)
+        for r in range(2):
+            gpu[r].step(DT); cpu[r].step(DT)
+    assert nt[1].stats().ghosts == 2                       # both hovering boxes are ghosts in tile 1 ...
+    for r in range(2):
+        d = parity.state_diff(gpu[r].read_states(0, 64), cpu[r].read_states(0, 64))
+        assert d["bit_exact"] and d["active_mismatch"] == 0, (r, d)
+    rest = gpu[1].get_state([1])[0]                         # ... and the resting box has not been pushed by either
+    assert abs(float(rest["pos"][0]) - (TILE_W + 0.7)) < 1e-3 and abs(float(rest["pos"][1]) - 6.0) < 1e-3
+    for t in nt:
+        t.close()
+    for w in gpu + cpu:
+        w.close()
+
+
+def test_boxes_with_a_gap_keep_their_bodies():
+    """sgp_tiles_create takes arbitrary boxes.  A dynamic body whose centre leaves its tile into a region NO tile covers must stay with its
+    owner (it used to be removed by the owner and accepted by nobody)."""
+    from substrata_amd.lib import World
+    boxes = np.float32([[-1e9, -1e9, -1e9, 5.0, 1e9, 1e9], [8.0, -1e9, -1e9, 1e9, 1e9, 1e9]])      # a 3 m gap between x = 5 and x = 8
+    gpu = [World(max_bodies=64) for _ in range(2)]
+    d = scenes.dynamic_bodies(1)
+    d["shape_type"] = abi.SHAPE_SPHERE; d["shape"][0] = (0.5, 0, 0, 0); d["pos"][0] = (4.0, 0.0, 0.5); d["lin_vel"][0] = (4.0, 0, 0); d["friction"] = 0.0
+    gpu[0].add_batch(np.concatenate([scenes.ground(), d])); gpu[1].add_batch(scenes.ground())
+    nt = [tiles.NativeTiles(gpu[r], r, 2, boxes, 1.0) for r in range(2)]
+    owners = []
+    for s in range(90):
+        tiles.NativeTiles.exchange_group(nt)
+        owned = [w.num_bodies() - 1 - t.stats().ghosts for w, t in zip(gpu, nt)]
+        assert sum(owned) == 1, (s, owned)               # never lost, never duplicated
+        owners.append(owned.index(1))
+        for w in gpu:
+            w.step(DT)
+    assert owners[0] == 0 and owners[-1] == 1            # it crossed the gap with tile 0 and was handed over once tile 1's region held it
+    for t in nt:
+        t.close()
+    for w in gpu:
+        w.close()
+
+
+def test_route_retry_with_a_small_send_buffer(oracle):
+    """More boundary bodies than the first send buffer holds (16384 records): the exchange grows the buffer and routes again on its own --
+    in the RCCL form without a second all-gather and without returning to the caller -- and the result is what the oracle tiles get."""
+    from substrata_amd.lib import World
+    n = 18000
+    boxes = np.float32([[-1e9, -1e9, -1e9, 0.0, 1e9, 1e9], [0.0, -1e9, -1e9, 1e9, 1e9, 1e9]])
+    d = scenes.dynamic_bodies(n)
+    d["shape_type"] = abi.SHAPE_SPHERE; d["shape"][:, 0] = 0.2
+    k = np.arange(n)
+    d["pos"][:, 0] = -0.5; d["pos"][:, 1] = 0.5 * (k % 150); d["pos"][:, 2] = 0.3 + 0.5 * (k // 150)
+    d["gravity_factor"] = 0.0
+    gpu = [World(max_bodies=2 * n + 64) for _ in range(2)]
+    cpu = [oracle.OracleWorld(max_bodies=2 * n + 64) for _ in range(2)]
+    for ws in (gpu, cpu):
+        ws[0].add_batch(np.concatenate([scenes.ground(), d])); ws[1].add_batch(scenes.ground())
+    nt = [tiles.NativeTiles(gpu[r], r, 2, boxes, 1.0) for r in range(2)]
+    for s in range(3):
+        lc = []
+        tiles.NativeTiles.exchange_group(nt)
+        exchange(cpu, boxes, 1.0, lc)
+        for r in range(2):
+            gpu[r].step(DT); cpu[r].step(DT)
+    assert nt[1].stats().ghosts == n
+    dd = parity.state_diff(gpu[1].read_states(0, n + 8), cpu[1].read_states(0, n + 8))
+    assert dd["bit_exact"], dd
+    for t in nt:
+        t.close()
+    for w in gpu + cpu:
+        w.close()
+
+
 def test_rccl_binding_self_test():
     """The RCCL entry points libsgp.so binds at run time (ncclGetUniqueId, CommInitRank, AllGather, grouped Send / Recv), as far as one GPU
     allows: a one-rank communicator, a counts all-gather and a grouped send/recv of records to itself, checked byte for byte."""

@@ -8,6 +8,7 @@ import pytest
 
 from substrata_amd import scenes, tiles
 from helpers import DT
+import ghost_exchange
 
 pytestmark = pytest.mark.gpu
 
@@ -26,7 +27,7 @@ def test_exchange_collectives_on_rccl_single_rank():
         w.add_batch(descs)
         # a finite tile inside the scene so that boundary records exist
         lo = np.array([-8.0, -8.0, -1e9], np.float32); hi = np.array([8.0, 8.0, 1e9], np.float32)
-        ex = tiles.GhostExchange(w, 0, 1, lo, hi, margin=2.0, dist=dist, device=torch.device("cuda", 0))
+        ex = ghost_exchange.GhostExchange(w, 0, 1, lo, hi, margin=2.0, dist=dist, device=torch.device("cuda", 0))
         for _ in range(5):
             ex.exchange()
             w.step(DT)

@@ -1,8 +1,8 @@
-"""The production exchange (substrata_amd/tiles.py GhostExchange over torch.distributed) with REAL device worlds in two processes: both
-ranks put their tile on cuda:0 (one GPU is all a test box has), the collectives run over gloo, and every rank also runs the oracle on the
-same tile through a second GhostExchange; after every 20 steps the device tile must equal the oracle tile bit for bit.  Together with
-tests/test_tiles_rccl_gpu.py (the same collectives on RCCL with one rank) this covers everything of the N-GPU bench path except RCCL
-between distinct GPUs."""
+"""REAL device worlds in two processes driven through the host statement of the exchange rules (tests/ghost_exchange.py GhostExchange over
+torch.distributed / gloo -- test infrastructure; the product's exchange is sgp_tiles_*, covered by tests/test_tiles_parity_gpu.py and
+test_config4_gpu.py): both ranks put their tile on cuda:0 (one GPU is all a test box has), and every rank also runs the oracle on the same
+tile through a second GhostExchange; after every 20 steps the device tile must equal the oracle tile bit for bit.  What this adds to the
+in-process tests: the worlds of a tile world really live in different processes (export / import / migration through the C ABI only)."""
 import os
 import sys
 
@@ -29,6 +29,7 @@ def worker(rank, world_size, port, steps, out_dir):
     from substrata_amd.lib import World, init
     from oracle import oracle
     import parity
+    import ghost_exchange
     init()
     lo, hi, origin = tiles.tile_bounds(rank, world_size, TILE_W, TILE_W)
     d, _ = scenes.lattice(6, 6, 3, 1.9, 0.6, seed=41 + rank, jitter=0.08, random_rot=True, origin_centered=False)
@@ -40,8 +41,8 @@ def worker(rank, world_size, port, steps, out_dir):
     descs = np.concatenate([scenes.ground(), d])
     g = World(max_bodies=1024, device=0); c = oracle.OracleWorld(max_bodies=1024)
     g.add_batch(descs); c.add_batch(descs)
-    exg = tiles.GhostExchange(g, rank, world_size, lo, hi, margin=1.5, dist=dist, device=torch.device("cpu"), cap=256)
-    exc = tiles.GhostExchange(c, rank, world_size, lo, hi, margin=1.5, dist=dist, device=torch.device("cpu"), cap=256)
+    exg = ghost_exchange.GhostExchange(g, rank, world_size, lo, hi, margin=1.5, dist=dist, device=torch.device("cpu"), cap=256)
+    exc = ghost_exchange.GhostExchange(c, rank, world_size, lo, hi, margin=1.5, dist=dist, device=torch.device("cpu"), cap=256)
     ok = True; migrated = 0; imported = 0
     for s in range(1, steps + 1):
         exg.exchange(); exc.exchange()

@@ -5,6 +5,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, torch.distributed as dist
 from substrata_amd import scenes, tiles
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'tests'))
+import ghost_exchange
 from substrata_amd.lib import World, init
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
 torch.cuda.set_device(0)
@@ -15,7 +17,7 @@ w = World(max_bodies=len(descs) + 4096); w.add_batch(descs)
 for _ in range(200): w.step(1 / 60)
 # a tile boundary through the pile on two sides (like an interior tile of a 4x2 grid has)
 lo = np.array([float(descs["pos"][1:, 0].min()) - 0.2, float(descs["pos"][1:, 1].min()) - 0.2, -1e9], np.float32); hi = np.array([1e9, 1e9, 1e9], np.float32)
-ex = tiles.GhostExchange(w, 0, 1, lo, hi, margin=2.0, dist=dist, device=torch.device("cuda", 0))
+ex = ghost_exchange.GhostExchange(w, 0, 1, lo, hi, margin=2.0, dist=dist, device=torch.device("cuda", 0))
 for _ in range(10): ex.exchange(); w.step(1 / 60)
 torch.cuda.synchronize()
 t0 = time.perf_counter(); n = 100
