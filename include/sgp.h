@@ -631,8 +631,8 @@ int  sgp_tiles_get_stats(sgp_tiles* t, sgp_tiles_stats* out);
 int  sgp_tiles_drain_migrations(sgp_tiles* t, sgp_migration* out, uint32_t cap, uint32_t* n_out);
 
 /* ---- device-resident bulk access (bench / torch plumbing; pointers are HIP device pointers) ---- */
-/* Raw SoA views of the body arrays, valid until the world is destroyed:
- * which = 0 pos_invmass(float4), 1 rot(float4), 2 lin_vel(float4), 3 ang_vel(float4). */
+/* Raw views of the body records, valid until the world is destroyed; record i = two float4 at [2 i], [2 i + 1]:
+ * which = 0 pose: (position xyz, inverse mass) (rotation quaternion xyzw); 1 velocity: (linear velocity xyz, -) (angular velocity xyz, -). */
 int  sgp_world_device_array(sgp_world* w, int which, void** dev_ptr_out, uint32_t* count_out);
 /* hipStream_t the world launches on (as void*). */
 int  sgp_world_stream(sgp_world* w, void** stream_out);

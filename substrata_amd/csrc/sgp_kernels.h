@@ -19,6 +19,7 @@
 #define BF_LARGE         (1u << 9)   // skips the hashed grid (ground quad etc.)
 #define BF_UNDERWATER    (1u << 10)
 #define BF_GHOST         (1u << 11)  // owned by another tile (multi-GPU), simulated as velocity-driven
+#define BF_HAS_FORCE     (1u << 13)  // force / torque accumulators hold something: k_pre_solve reads and clears them
 #define BF_CACHE_INVALID (1u << 12)  // created or reshaped since the last step: its pairs do not reuse cached manifolds (cleared by k_pre_solve)
 #define BF_SHAPE_SHIFT   18          // SGP_SHAPE_* (3 bits)
 #define BF_SHAPE_MASK    (0x7u << BF_SHAPE_SHIFT)
@@ -168,14 +169,15 @@ struct DV {
 	StepParams* sp;
 	uint32_t cap_bodies, cap_pairs, cap_manifolds;
 	// bodies
-	float4* pos_im;            // position xyz, inverse mass w (0 unless dynamic)
-	float4* rot;
-	float4* linv;              // xyz, linear damping w
-	float4* angv;              // xyz, angular damping w
-	float4* force;             // xyz, gravity factor w
-	float4* torque;            // xyz, mass w
-	float4* inv_inertia;       // local diagonal xyz, restitution w
-	float4* shape;             // parameters xyz, friction w
+	// Per-body state as 32-byte records (two float4 each, record i at [2 i], [2 i + 1]): a sweep kernel streams exactly the records it needs and a
+	// constraint gathers one 32 B record per body and purpose, instead of one float4 from each of several arrays.
+	float4* pose;              // [position xyz, inverse mass (0 unless dynamic)] [rotation quaternion]; the position iterations correct it in place
+	float4* vel;               // [linear velocity xyz, EFFECTIVE inverse mass of the step (0 unless dynamic and awake; k_pre_solve)] [angular velocity xyz, -]:
+	                           //   THE velocity storage, and the record the velocity iterations gather and scatter
+	float4* prop;              // [local inverse inertia diagonal xyz, restitution] [shape parameters xyz, friction]
+	float4* dyn;               // one float4 per body: linear damping, angular damping, gravity factor, inverse mass (again; k_pre_solve reads nothing else of the pose)
+	float4* force;             // accumulated force xyz, - (read only for bodies flagged BF_HAS_FORCE)
+	float4* torque;            // accumulated torque xyz, mass w
 	uint32_t* flags;
 	float4* aabb_min;
 	float4* aabb_max;
@@ -190,8 +192,6 @@ struct DV {
 	uint32_t* island_awake;
 	uint32_t* export_counts;   // per 256-body block: bodies the tile export picks (k_export_count)
 	uint32_t* awake_mark;      // per body: 1 = sleepy but known to stay awake this step (k_island_mark)
-	float4* sbody;             // per step, 64 B per body (one cache line): [lin vel xyz, EFFECTIVE inverse mass][ang vel xyz, -]
-	                           //   [world inv inertia xx,xy,xz,-][yy,yz,zz,-]; velocities live here during the velocity solve
 	// broad phase
 	uint32_t table_size;       // power of two
 	uint32_t* cell_hash;       // per body: linear cell index in the dense grid (0xFFFFFFFF = not binned)

@@ -582,10 +582,10 @@ __global__ void __launch_bounds__(TPB) k_bp_large(DV d)
 SGP_DEV sgd_shape load_shape(const DV& d, uint32_t i, uint32_t f)
 {
 	sgd_shape s;
-	s.pos = V3(d.pos_im[i]);
-	s.R = quat_to_m33(Q4(d.rot[i]));
+	s.pos = V3(d.pose[2 * (size_t)i]);
+	s.R = quat_to_m33(Q4(d.pose[2 * (size_t)i + 1]));
 	s.type = (int)f_shape(f);
-	const float4 sh = d.shape[i];
+	const float4 sh = d.prop[2 * (size_t)i + 1];
 	s.p0 = sh.x; s.p1 = sh.y; s.p2 = sh.z;
 	s.hull = s.type == SGP_SHAPE_HULL ? body_hull(d, sh) : (s.type == SGP_SHAPE_BOX ? &d.hulls[0] : nullptr);
 	return s;
@@ -652,8 +652,8 @@ SGP_DEV bool reuse_cached_manifold(const DV& d, uint2 ab, uint32_t fa, uint32_t 
 	const uint32_t ps = cache_find(d, ((uint64_t)ab.x << 32) | ab.y);
 	*prev = ps == 0xFFFFFFFFu ? MAN_PREV_NONE : ps;
 	if (ps == 0xFFFFFFFFu || !d.st.use_body_pair_contact_cache || ((fa | fb) & (BF_CACHE_INVALID | BF_SENSOR))) return false;
-	const v3 posA = V3(d.pos_im[ab.x]), posB = V3(d.pos_im[ab.y]);
-	const quat qA = Q4(d.rot[ab.x]), qB = Q4(d.rot[ab.y]);
+	const v3 posA = V3(d.pose[2 * (size_t)ab.x]), posB = V3(d.pose[2 * (size_t)ab.y]);
+	const quat qA = Q4(d.pose[2 * (size_t)ab.x + 1]), qB = Q4(d.pose[2 * (size_t)ab.y + 1]);
 	v3 dpos; quat drot;
 	pair_relative_pose(posA, qA, posB, qB, &dpos, &drot);
 	const float4 cdp = PRV(d).cdp[ps], cdr = PRV(d).cdr[ps];
@@ -761,9 +761,9 @@ SGP_DEV int mesh_candidates(const DV& d, const MeshHeader& mh, v3 llo, v3 lhi, u
 // Returns the number of groups (manifolds mesh -> X).  Sequential (one thread).
 SGP_DEV int collide_with_mesh(const DV& d, uint32_t mbody, const sgd_shape& X, v3 lo, v3 hi, float max_sep, sgd_manifold* out, bool* dropped)
 {
-	const float4 msh = d.shape[mbody];
+	const float4 msh = d.prop[2 * (size_t)mbody + 1];
 	const MeshHeader mh = d.meshes[(uint32_t)msh.x];
-	const v3 mpos = V3(d.pos_im[mbody]); const m33 R = quat_to_m33(Q4(d.rot[mbody]));
+	const v3 mpos = V3(d.pose[2 * (size_t)mbody]); const m33 R = quat_to_m33(Q4(d.pose[2 * (size_t)mbody + 1]));
 	const v3 e = V3(max_sep, max_sep, max_sep);
 	const v3 qlo = v3_sub(lo, e), qhi = v3_add(hi, e);
 	// the query box in the mesh frame (bounds of its 8 corners), a little generous
@@ -926,13 +926,14 @@ __global__ void __launch_bounds__(64, 3) k_narrowphase_hull_manifold(DV d)
 	}
 }
 
-// Per-step solver record of every body (64 B = one cache line): velocities, the EFFECTIVE inverse mass (0 unless the body is dynamic and
-// awake) and the world-space inverse inertia.  The velocity-phase kernels gather ONE line per body instead of six arrays.
-// THE BODY-ARRAY SWEEP, part 1 of 3 (k_pre_solve, then k_integrate_pose, then k_finalize): what used to be three passes over the bodies
-// (k_wake, k_apply_forces, k_prep_bodies) in one.  Per body: wake it if an active body touched it this step; apply gravity / forces /
-// damping / velocity clamps if it was movable when the step began (Jolt applies gravity before it finds collisions, so a body woken during
-// this step gets none); write its per-step solver record.  The velocities computed here go straight into the record -- nothing reads the
-// velocity arrays again before k_integrate rewrites them from the record.
+// THE BODY-ARRAY SWEEP, part 1 of 3 (k_pre_solve, then k_integrate_pose, then k_finalize).  Per body: wake it if an active body touched it this
+// step; apply gravity / forces / damping / velocity clamps if it was movable when the step began (Jolt applies gravity before it finds
+// collisions, so a body woken during this step gets none); leave the result in the body's velocity record together with the EFFECTIVE inverse
+// mass of this step (0 unless dynamic and awake) -- the record the velocity iterations gather.  Nothing else is copied: the world-space inverse
+// inertia and the material are derived by the kernels that need them (k_setup, the warm start) from the pose and property records they gather
+// anyway.  A body that is asleep or static costs its 4 flag bytes: its velocity record already says (0, 0, 0 | 0) (k_sleep_apply, creation).
+// Traffic per awake body: flags 4 + velocity record 32 + dyn 16 read, velocity record 32 + component scratch 8 written = 92 B
+// (round 2: 205 B, of which 64 B were the per-step solver record this layout no longer has).
 __global__ void __launch_bounds__(TPB) k_pre_solve(DV d)
 {
 	const float dt = d.sp->dt;
@@ -940,48 +941,47 @@ __global__ void __launch_bounds__(TPB) k_pre_solve(DV d)
 	if (i >= d.sp->n_slots) return;
 	const uint32_t f0 = d.flags[i];
 	uint32_t f = f0;
-	float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f), w = v, a = v, b = v;
-	if (!(f & BF_ALIVE)) { d.sbody[4 * i + 0] = v; d.sbody[4 * i + 1] = w; d.sbody[4 * i + 2] = a; d.sbody[4 * i + 3] = b; return; }
+	if (!(f & BF_ALIVE)) return;
 	const bool was_movable = f_movable(f);
-	const float4 sh = d.shape[i], II = d.inv_inertia[i];
 	// sleeping bodies touched by an active body wake up (Jolt activates them while finding collisions)
 	if (f & BF_WAKE) {
 		f &= ~BF_WAKE;
 		if (!(f & BF_ACTIVE)) { f |= BF_ACTIVE; push_event(d.ev_activated, &d.evc->n_activated, d.cap_bodies, i); }
-		reset_sleep(d, i, f_shape(f), sh, V3(d.pos_im[i]), Q4(d.rot[i]));
+		reset_sleep(d, i, f_shape(f), d.prop[2 * (size_t)i + 1], V3(d.pose[2 * (size_t)i]), Q4(d.pose[2 * (size_t)i + 1]));
 	}
-	// material of the body in the spare lanes of the record (k_setup then needs no other per-body array for it): friction, restitution
-	a.w = sh.w; b.w = II.w;
-	if (f_motion(f) != SGP_MOTION_STATIC) {
-		const float4 lv4 = d.linv[i], av4 = d.angv[i];
+	if ((f & BF_ACTIVE) && f_motion(f) != SGP_MOTION_STATIC) {
+		const float4 lv4 = d.vel[2 * (size_t)i], av4 = d.vel[2 * (size_t)i + 1];
+		const float4 dy = d.dyn[i];                                    // linear damping, angular damping, gravity factor, inverse mass
 		v3 lv = V3(lv4), av = V3(av4);
+		float im = 0.0f;
 		if (f_movable(f)) {
-			const float im = d.pos_im[i].w;
-			const sym33 Iw = world_inv_inertia(quat_to_m33(Q4(d.rot[i])), V3(II));
+			im = dy.w;
 			if (was_movable) {
 				// K8a: forces, gravity, damping, velocity clamps (JobApplyGravity)
-				const float4 F4v = d.force[i], T4 = d.torque[i];
+				v3 F = V3(0.0f, 0.0f, 0.0f), T = F;
+				sym33 Iw = sym33_zero();
+				if (f & BF_HAS_FORCE) {                                      // the accumulators hold something: read them, clear them
+					const float4 F4v = d.force[i], T4 = d.torque[i];
+					F = V3(F4v); T = V3(T4);
+					Iw = world_inv_inertia(quat_to_m33(Q4(d.pose[2 * (size_t)i + 1])), V3(d.prop[2 * (size_t)i]));
+					d.force[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+					d.torque[i] = make_float4(0.0f, 0.0f, 0.0f, T4.w);
+					f &= ~BF_HAS_FORCE;
+				}
 				const v3 g = V3(d.gx, d.gy, d.gz);
-				lv = v3_add(lv, v3_scale(v3_add(v3_scale(g, F4v.w), v3_scale(V3(F4v), im)), dt));
-				av = v3_add(av, v3_scale(sym33_mul(Iw, V3(T4)), dt));
-				lv = v3_scale(lv, fmaxf(0.0f, 1.0f - lv4.w * dt));
-				av = v3_scale(av, fmaxf(0.0f, 1.0f - av4.w * dt));
+				lv = v3_add(lv, v3_scale(v3_add(v3_scale(g, dy.z), v3_scale(F, im)), dt));
+				av = v3_add(av, v3_scale(sym33_mul(Iw, T), dt));
+				lv = v3_scale(lv, fmaxf(0.0f, 1.0f - dy.x * dt));
+				av = v3_scale(av, fmaxf(0.0f, 1.0f - dy.y * dt));
 				const float l2 = v3_len_sq(lv), ml = d.st.max_linear_velocity;
 				if (l2 > ml * ml) lv = v3_scale(lv, ml / sqrtf(l2));
 				const float a2 = v3_len_sq(av), ma = d.st.max_angular_velocity;
 				if (a2 > ma * ma) av = v3_scale(av, ma / sqrtf(a2));
-				// the accumulators are cleared only when something was accumulated
-				if (F4v.x != 0.0f || F4v.y != 0.0f || F4v.z != 0.0f) d.force[i] = make_float4(0.0f, 0.0f, 0.0f, F4v.w);
-				if (T4.x != 0.0f || T4.y != 0.0f || T4.z != 0.0f) d.torque[i] = make_float4(0.0f, 0.0f, 0.0f, T4.w);
 			}
-			v.w = im;
-			a = make_float4(Iw.xx, Iw.xy, Iw.xz, a.w);
-			b = make_float4(Iw.yy, Iw.yz, Iw.zz, b.w);
 		}
-		v.x = lv.x; v.y = lv.y; v.z = lv.z;
-		w.x = av.x; w.y = av.y; w.z = av.z;
+		d.vel[2 * (size_t)i] = F4(lv, im);
+		d.vel[2 * (size_t)i + 1] = F4(av, 0.0f);
 	}
-	d.sbody[4 * i + 0] = v; d.sbody[4 * i + 1] = w; d.sbody[4 * i + 2] = a; d.sbody[4 * i + 3] = b;
 	d.hc_root[i] = i; d.hc_count[i] = 0u;      // every body a component of its own (k_hc_hook joins them along the high-colour constraints)
 	// remember whether the body was movable when the previous step coloured its constraints (colour inheritance)
 	uint32_t nf = f & ~(BF_MOVABLE_PREV | BF_MOVABLE_CUR | BF_CACHE_INVALID);      // (the narrow phase of this step has seen the flag)
@@ -1277,16 +1277,17 @@ __global__ void __launch_bounds__(TPB) k_setup(DV d)
 		const int npb = __float_as_int(n4.w);
 		const int np = (npb & 0x100) ? 0 : (npb & 0xFF);          // sensor pairs carry no points
 		const v3 nrm = V3(n4);
-		const v3 posA = V3(d.pos_im[ab.x]), posB = V3(d.pos_im[ab.y]);
-		const m33 RA = quat_to_m33(Q4(d.rot[ab.x])), RB = quat_to_m33(Q4(d.rot[ab.y]));
-		const float4 va4 = d.sbody[4 * ab.x], wa4 = d.sbody[4 * ab.x + 1], sa0 = d.sbody[4 * ab.x + 2], sa1 = d.sbody[4 * ab.x + 3];
-		const float4 vb4 = d.sbody[4 * ab.y], wb4 = d.sbody[4 * ab.y + 1], sb0 = d.sbody[4 * ab.y + 2], sb1 = d.sbody[4 * ab.y + 3];
+		// per body: pose record, velocity record (velocities after gravity + the effective inverse mass: k_pre_solve), property record
+		const float4 pa4 = d.pose[2 * (size_t)ab.x], qa4 = d.pose[2 * (size_t)ab.x + 1], pb4 = d.pose[2 * (size_t)ab.y], qb4 = d.pose[2 * (size_t)ab.y + 1];
+		const float4 va4 = d.vel[2 * (size_t)ab.x], wa4 = d.vel[2 * (size_t)ab.x + 1], vb4 = d.vel[2 * (size_t)ab.y], wb4 = d.vel[2 * (size_t)ab.y + 1];
+		const float4 ia4 = d.prop[2 * (size_t)ab.x], sa4 = d.prop[2 * (size_t)ab.x + 1], ib4 = d.prop[2 * (size_t)ab.y], sb4 = d.prop[2 * (size_t)ab.y + 1];
+		const v3 posA = V3(pa4), posB = V3(pb4);
+		const m33 RA = quat_to_m33(Q4(qa4)), RB = quat_to_m33(Q4(qb4));
 		const float im1 = va4.w, im2 = vb4.w;
-		sym33 I1, I2;
-		I1.xx = sa0.x; I1.xy = sa0.y; I1.xz = sa0.z; I1.yy = sa1.x; I1.yz = sa1.y; I1.zz = sa1.z;
-		I2.xx = sb0.x; I2.xy = sb0.y; I2.xz = sb0.z; I2.yy = sb1.x; I2.yz = sb1.y; I2.zz = sb1.z;
-		const float friction = sqrtf(sa0.w * sb0.w);               // per-body friction / restitution ride in the solver records (k_pre_solve)
-		const float restitution = fmaxf(sa1.w, sb1.w);
+		// world-space inverse inertia of the bodies that can move (the others never use theirs)
+		const sym33 I1 = im1 > 0.0f ? world_inv_inertia(RA, V3(ia4)) : sym33_zero(), I2 = im2 > 0.0f ? world_inv_inertia(RB, V3(ib4)) : sym33_zero();
+		const float friction = sqrtf(sa4.w * sb4.w);
+		const float restitution = fmaxf(ia4.w, ib4.w);
 		const v3 t1 = v3_normalized_perpendicular(nrm);
 		const v3 t2 = v3_cross(nrm, t1);
 		const v3 lvA = V3(va4), avA = V3(wa4), lvB = V3(vb4), avB = V3(wb4);
@@ -1312,7 +1313,7 @@ __global__ void __launch_bounds__(TPB) k_setup(DV d)
 		if (reused) { CUR(d).cdp[slot] = PRV(d).cdp[fslot]; CUR(d).cdr[slot] = PRV(d).cdr[fslot]; CUR(d).cnl[slot] = PRV(d).cnl[fslot]; }
 		else {
 			v3 dpos; quat drot;
-			pair_relative_pose(posA, Q4(d.rot[ab.x]), posB, Q4(d.rot[ab.y]), &dpos, &drot);
+			pair_relative_pose(posA, Q4(qa4), posB, Q4(qb4), &dpos, &drot);
 			const v3 nl = m33_tmul(RB, nrm);
 			CUR(d).cdp[slot] = make_float4(dpos.x, dpos.y, dpos.z, nl.x);
 			CUR(d).cdr[slot] = make_float4(drot.x, drot.y, drot.z, drot.w);
@@ -1346,8 +1347,8 @@ __global__ void __launch_bounds__(TPB) k_setup(DV d)
 			if (restitution > 0.0f && normal_velocity < -d.st.min_velocity_for_restitution) {
 				if (normal_velocity < -spec_bias) {
 					v3 rel_acc = V3(0.0f, 0.0f, 0.0f);
-					if (im2 > 0.0f) rel_acc = v3_add(rel_acc, v3_scale(g, d.force[ab.y].w));      // gravity factors: only bouncing contacts get here
-					if (im1 > 0.0f) rel_acc = v3_sub(rel_acc, v3_scale(g, d.force[ab.x].w));
+					if (im2 > 0.0f) rel_acc = v3_add(rel_acc, v3_scale(g, d.dyn[ab.y].z));      // gravity factors: only bouncing contacts get here
+					if (im1 > 0.0f) rel_acc = v3_sub(rel_acc, v3_scale(g, d.dyn[ab.x].z));
 					const float force_dv = fminf(0.0f, v3_dot(rel_acc, nrm)) * dt;
 					bias = restitution * (normal_velocity - force_dv);
 				}
@@ -1395,22 +1396,23 @@ SGP_DEV float axis_jv(const BodyVel& A, const BodyVel& B, v3 r1, v3 r2, v3 axis)
 
 struct PairCtx { uint2 ab; float im1, im2; sym33 I1, I2; BodyVel A, B; v3 n, t1, t2; float friction; int np; };
 
-// `vel` / VS: where the velocity half of the per-body solver record lives -- the global record itself (vel = d.sbody, VS = 4) or
-// the LDS copy of the small-world kernel (VS = 2).  The inverse-inertia half is read-only during the solve and stays global.
+// `vel` / VS: where the velocity records live -- the global array (vel = d.vel) or a workgroup's copy in LDS; VS = float4 per record (2).
+// The world-space inverse inertia is derived here from the pose and property records (read-only during the solve).
+SGP_DEV sym33 body_world_inv_inertia(const DV& d, uint32_t body)
+{
+	return world_inv_inertia(quat_to_m33(Q4(d.pose[2 * (size_t)body + 1])), V3(d.prop[2 * (size_t)body]));
+}
 template <int VS> SGP_DEV void load_pair(const DV& d, uint32_t slot, PairCtx& c, const float4* vel)
 {
 	c.ab = CUR(d).ab[slot];
 	const float4 nf = CUR(d).n_fric[slot];
 	c.n = V3(nf); c.friction = nf.w;
 	c.np = CUR(d).np_col[slot] & 0xFF;
-	const float4* pa = d.sbody + 4 * (size_t)c.ab.x;
-	const float4* pb = d.sbody + 4 * (size_t)c.ab.y;
-	const float4 a0 = pa[2], a1 = pa[3], b0 = pb[2], b1 = pb[3];
 	const float4 va = vel[VS * (size_t)c.ab.x], wa = vel[VS * (size_t)c.ab.x + 1];
 	const float4 vb = vel[VS * (size_t)c.ab.y], wb = vel[VS * (size_t)c.ab.y + 1];
 	c.im1 = va.w; c.im2 = vb.w;
-	c.I1.xx = a0.x; c.I1.xy = a0.y; c.I1.xz = a0.z; c.I1.yy = a1.x; c.I1.yz = a1.y; c.I1.zz = a1.z;
-	c.I2.xx = b0.x; c.I2.xy = b0.y; c.I2.xz = b0.z; c.I2.yy = b1.x; c.I2.yz = b1.y; c.I2.zz = b1.z;
+	c.I1 = c.im1 > 0.0f ? body_world_inv_inertia(d, c.ab.x) : sym33_zero();
+	c.I2 = c.im2 > 0.0f ? body_world_inv_inertia(d, c.ab.y) : sym33_zero();
 	c.A.lv = V3(va); c.A.av = V3(wa);
 	c.B.lv = V3(vb); c.B.av = V3(wb);
 }
@@ -1441,7 +1443,7 @@ template <int VS> SGP_DEV void warm_start_one_t(const DV& d, uint32_t slot, floa
 	}
 	store_pair_vel<VS>(c, vel);
 }
-SGP_DEV void warm_start_one(const DV& d, uint32_t slot) { warm_start_one_t<4>(d, slot, d.sbody); }
+SGP_DEV void warm_start_one(const DV& d, uint32_t slot) { warm_start_one_t<2>(d, slot, d.vel); }
 
 // Warm start, one thread per BODY instead of one launch per colour.  A warm-start impulse depends only on its own constraint (cached
 // lambdas, axes, lever arms) and on the inverse mass / inertia of the body it is applied to -- not on any velocity -- so what the
@@ -1455,11 +1457,11 @@ __global__ void __launch_bounds__(TPB) k_warm_bodies(DV d)
 	if (i >= d.sp->n_slots) return;
 	uint64_t mask = d.colour_mask[i] & ~(1ull << SGP_OVERFLOW_COLOUR);
 	if (!mask) return;
-	float4* rec = d.sbody + 4 * (size_t)i;
-	const float4 v4 = rec[0], w4 = rec[1], a0 = rec[2], a1 = rec[3];
+	float4* rec = d.vel + 2 * (size_t)i;
+	const float4 v4 = rec[0], w4 = rec[1];
 	const float im = v4.w;
 	if (!(im > 0.0f)) return;
-	sym33 I; I.xx = a0.x; I.xy = a0.y; I.xz = a0.z; I.yy = a1.x; I.yz = a1.y; I.zz = a1.z;
+	const sym33 I = body_world_inv_inertia(d, i);
 	v3 lv = V3(v4), av = V3(w4);
 	while (mask) {
 		const int col = __ffsll((long long)mask) - 1;
@@ -1612,7 +1614,7 @@ SGP_DEV void half_apply(v3& lv, v3& av, float im, v3 axis, v3 iv, float lambda, 
 
 // One contact manifold, one velocity iteration (ContactConstraintManager::SolveVelocityConstraints): friction rows of every point first (they
 // use the normal impulse of the previous iteration), then the non-penetration rows.  Both lanes of the constraint must call this together.
-// `vel` / VS: where the velocity half of the per-body solver record lives (the global record: d.sbody, VS = 4; an LDS copy: VS = 2).
+// `vel` / VS: where the velocity records live (the global array d.vel or an LDS copy; VS = 2 float4 per record).
 template <int VS> SGP_DEV void half_solve(ConHalf& h, int side, float4* vel, uint32_t dbg = 0)
 {
 	const int np = h.np_col & 0xFF;
@@ -1665,13 +1667,13 @@ SGP_DEV void solve_position_one(const DV& d, uint32_t slot)
 	const float4 nf = CUR(d).n_fric[slot];
 	const v3 nrm = V3(nf);
 	const int np = CUR(d).np_col[slot] & 0xFF;
-	// pose half of the solver records (written by k_integrate_pose): one line per body
-	float4* ra = d.sbody + 4 * (size_t)ab.x;
-	float4* rb = d.sbody + 4 * (size_t)ab.y;
+	// the pose records themselves (k_integrate_pose advanced them; the corrections are made in place) + the local inverse inertia
+	float4* ra = d.pose + 2 * (size_t)ab.x;
+	float4* rb = d.pose + 2 * (size_t)ab.y;
 	const float4 pa = ra[0], pb = rb[0];
-	const float im1 = pa.w, im2 = pb.w;                 // effective: 0 unless dynamic and awake
+	const float im1 = pa.w, im2 = pb.w;                 // 0 unless dynamic (and a dynamic body in a constraint is awake: touched sleepers are woken by k_pre_solve)
 	quat qa = Q4(ra[1]), qb = Q4(rb[1]);
-	const v3 iiA = V3(ra[2]), iiB = V3(rb[2]);
+	const v3 iiA = V3(d.prop[2 * (size_t)ab.x]), iiB = V3(d.prop[2 * (size_t)ab.y]);
 	v3 posA = V3(pa), posB = V3(pb);
 	bool moved = false;
 	m33 RA = quat_to_m33(qa), RB = quat_to_m33(qb);          // recomputed below only after a correction turned a body (same values as computing them per point)
@@ -1714,11 +1716,12 @@ SGP_DEV void solve_position_one(const DV& d, uint32_t slot)
 // its own body's pose, computes its own contact point and its own share of the effective mass, swaps them with its neighbour, and corrects
 // its own body.  Same operands, same operations as solve_position_one (the effective mass is share of body 1 + share of body 2 there too),
 // hence the same bits -- at about half the instructions per lane, which is what a position launch is made of (4700 of them per manifold).
-SGP_DEV void solve_position_pair_at(const DV& d, uint32_t slot, int side, float4* rec);
+SGP_DEV void solve_position_pair_at(const DV& d, uint32_t slot, int side, float4* rec, v3 ii);
 SGP_DEV void solve_position_pair(const DV& d, uint32_t slot, int side)
 {
 	const uint2 ab = CUR(d).ab[slot];
-	solve_position_pair_at(d, slot, side, d.sbody + 4 * (size_t)(side ? ab.y : ab.x));      // pose half of this lane's body's solver record (k_integrate_pose)
+	const uint32_t body = side ? ab.y : ab.x;
+	solve_position_pair_at(d, slot, side, d.pose + 2 * (size_t)body, V3(d.prop[2 * (size_t)body]));      // this lane's body's pose record + its local inverse inertia
 }
 // What a position iteration reads of the constraint itself (this lane's side): loaded once, iterated any number of times.
 struct PosHalf { float4 nf; int np; v3 loc[4]; };
@@ -1729,15 +1732,14 @@ SGP_DEV void pos_half_load(const DV& d, uint32_t slot, int side, int np_col, Pos
 #pragma unroll
 	for (int i = 0; i < 4; ++i) if (i == 0 || i < ph.np) ph.loc[i] = V3(side ? CUR(d).loc2[i][slot] : CUR(d).loc1[i][slot]);      // (point 0: without waiting for the count)
 }
-// (rec: where this lane's body's record lives -- the global one, or a workgroup's copy in LDS)
-SGP_DEV void pos_half_solve(const DV& d, const PosHalf& ph, int side, float4* rec)
+// (rec: where this lane's body's pose record lives -- the global one, or a workgroup's copy in LDS; ii: its local inverse inertia diagonal)
+SGP_DEV void pos_half_solve(const DV& d, const PosHalf& ph, int side, float4* rec, v3 ii)
 {
 	const v3 nrm = V3(ph.nf);
 	const int np = ph.np;
 	const float4 p4 = rec[0];
-	const float im = p4.w;                                          // effective: 0 unless dynamic and awake
+	const float im = p4.w;                                          // 0 unless dynamic (see solve_position_one)
 	quat q = Q4(rec[1]);
-	const v3 ii = V3(rec[2]);
 	v3 pos = V3(p4);
 	bool moved = false;
 	m33 R = quat_to_m33(q);
@@ -1773,11 +1775,11 @@ SGP_DEV void pos_half_solve(const DV& d, const PosHalf& ph, int side, float4* re
 	}
 	if (moved && im > 0.0f) { rec[0] = F4(pos, im); rec[1] = make_float4(q.x, q.y, q.z, q.w); }
 }
-SGP_DEV void solve_position_pair_at(const DV& d, uint32_t slot, int side, float4* rec)
+SGP_DEV void solve_position_pair_at(const DV& d, uint32_t slot, int side, float4* rec, v3 ii)
 {
 	PosHalf ph;
 	pos_half_load(d, slot, side, CUR(d).np_col[slot], ph);
-	pos_half_solve(d, ph, side, rec);
+	pos_half_solve(d, ph, side, rec, ii);
 }
 
 // One launch = one colour of one pass.  The slot range comes from the device-side colour table, so the host never has
@@ -1794,7 +1796,7 @@ template <int MODE> __global__ void __launch_bounds__(MODE != 0 ? SOLVE_VEL_TPB 
 		// velocity and position iterations: two neighbouring lanes per constraint
 		const int side = (int)(threadIdx.x & 1u);
 		for (uint32_t k = first + ((blockIdx.x * SOLVE_VEL_TPB + threadIdx.x) >> 1); k < end; k += gridDim.x * (SOLVE_VEL_TPB / 2)) {
-			if (MODE == 1) solve_velocity_pair_t<4>(d, k, side, d.sbody); else solve_position_pair(d, k, side);
+			if (MODE == 1) solve_velocity_pair_t<2>(d, k, side, d.vel); else solve_position_pair(d, k, side);
 		}
 		return;
 	}
@@ -1808,13 +1810,13 @@ template <int V> __global__ void __launch_bounds__(SOLVE_TPB) k_solve_probe(DV d
 {
 	const uint32_t first = d.cstarts[colour], end = d.cstarts[colour + 1];
 	if (V == 0) {
-		for (uint32_t k = first + ((blockIdx.x * SOLVE_TPB + threadIdx.x) >> 1); k < end; k += gridDim.x * (SOLVE_TPB / 2)) solve_velocity_pair_t<4>(d, k, (int)(threadIdx.x & 1u), d.sbody);
+		for (uint32_t k = first + ((blockIdx.x * SOLVE_TPB + threadIdx.x) >> 1); k < end; k += gridDim.x * (SOLVE_TPB / 2)) solve_velocity_pair_t<2>(d, k, (int)(threadIdx.x & 1u), d.vel);
 		return;
 	}
 	for (uint32_t k = first + blockIdx.x * SOLVE_TPB + threadIdx.x; k < end; k += gridDim.x * SOLVE_TPB) {
 		if (V == 1) {
 			PairCtx c;
-			load_pair<4>(d, k, c, d.sbody);
+			load_pair<2>(d, k, c, d.vel);
 			float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
 			for (int i = 0; i < 4; ++i) if (i < c.np) {
@@ -1823,11 +1825,11 @@ template <int V> __global__ void __launch_bounds__(SOLVE_TPB) k_solve_probe(DV d
 				CUR(d).lam[i][k] = l;
 			}
 			if (acc.x == 12345.678f) c.A.lv.x += 1.0f;
-			store_pair_vel<4>(c, d.sbody);
+			store_pair_vel<2>(c, d.vel);
 		} else if (V == 2) {
 			PairCtx c;
-			load_pair<4>(d, k, c, d.sbody);
-			store_pair_vel<4>(c, d.sbody);
+			load_pair<2>(d, k, c, d.vel);
+			store_pair_vel<2>(c, d.vel);
 		}
 	}
 }
@@ -1903,7 +1905,7 @@ __global__ void __launch_bounds__(TAIL_VEL_TPB) k_solve_tail_vel(DV d, int first
 		if (mine) { half_load(d, slot, side, h); my_col = (h.np_col >> 8) & 0xFF; }
 		for (int c = first_colour; c < SGP_OVERFLOW_COLOUR; ++c) {
 			if (cs[c] == cs[c + 1]) continue;
-			if (my_col == c) half_solve<4>(h, side, d.sbody, d.dbg_flags);
+			if (my_col == c) half_solve<2>(h, side, d.vel, d.dbg_flags);
 			__syncthreads();
 		}
 		if (mine) half_store(d, slot, side, h);
@@ -1911,7 +1913,7 @@ __global__ void __launch_bounds__(TAIL_VEL_TPB) k_solve_tail_vel(DV d, int first
 	for (int c = first_colour; c < SGP_OVERFLOW_COLOUR; ++c) {
 		const uint32_t b = cs[c], e = cs[c + 1];
 		if (b == e) continue;
-		for (uint32_t k = b + pair; k < e; k += TAIL_VEL_TPB / 2) solve_velocity_pair_t<4>(d, k, side, d.sbody);
+		for (uint32_t k = b + pair; k < e; k += TAIL_VEL_TPB / 2) solve_velocity_pair_t<2>(d, k, side, d.vel);
 		__syncthreads();
 	}
 	const uint32_t first = cs[SGP_OVERFLOW_COLOUR], count = cs[SGP_OVERFLOW_COLOUR + 1] - first;
@@ -1919,7 +1921,7 @@ __global__ void __launch_bounds__(TAIL_VEL_TPB) k_solve_tail_vel(DV d, int first
 	uint64_t last = 0; bool have_last = false;
 	for (uint32_t it = 0; it < count; ++it) {
 		const uint32_t bslot = overflow_next(d, first, count, last, have_last);
-		solve_velocity_pair_t<4>(d, bslot, side, d.sbody);
+		solve_velocity_pair_t<2>(d, bslot, side, d.vel);
 	}
 }
 
@@ -1943,7 +1945,7 @@ SGP_DEV uint32_t uf_find(const uint32_t* parent, uint32_t x);
 #define HC_NONE 0xFFFFFFFFu
 #define NPCOL_CATCH_ALL (1 << 17)     // np_col: the constraint's component is too large for a workgroup
 
-SGP_DEV bool hc_can_move(const DV& d, uint32_t body) { return d.sbody[4 * (size_t)body].w > 0.0f; }      // effective inverse mass of the step (k_pre_solve)
+SGP_DEV bool hc_can_move(const DV& d, uint32_t body) { return d.vel[2 * (size_t)body].w > 0.0f; }      // effective inverse mass of the step (k_pre_solve)
 
 // (1) a constraint between two bodies that can move joins their components (k_pre_solve made every body a component of its own);
 //     the slot list is cleared to "no constraint"
@@ -2123,9 +2125,9 @@ template <int MODE> __global__ void __launch_bounds__(HC_TPB) k_solve_hc(DV d, i
 				at = (at + 1) & (HC_TABLE - 1);
 			}
 			if (owner) {
-				const float4* g = d.sbody + 4 * (size_t)body;
-#pragma unroll
-				for (int i = 0; i < RS; ++i) s_rec[RS * at + i] = g[i];
+				const float4* g = (MODE == 1 ? d.vel : d.pose) + 2 * (size_t)body;
+				s_rec[RS * at] = g[0]; s_rec[RS * at + 1] = g[1];
+				if (MODE != 1) s_rec[RS * at + 2] = d.prop[2 * (size_t)body];
 			}
 			if (MODE == 1) h.body = at;
 		}
@@ -2133,12 +2135,12 @@ template <int MODE> __global__ void __launch_bounds__(HC_TPB) k_solve_hc(DV d, i
 		const unsigned long long present = s_present;
 		for (int c = first_colour; c < n_colours; ++c) {
 			if (!((present >> c) & 1ull)) continue;
-			if (my_col == c) { if (MODE == 1) half_solve<2>(h, side, s_rec, d.dbg_flags); else pos_half_solve(d, ph, side, s_rec + RS * at); }
+			if (my_col == c) { if (MODE == 1) half_solve<2>(h, side, s_rec, d.dbg_flags); else pos_half_solve(d, ph, side, s_rec + RS * at, V3(s_rec[RS * at + 2])); }
 			__syncthreads();
 		}
 		if (MODE == 1 && mine) half_store(d, slot, side, h);
 		if (owner && s_rec[RS * at].w > 0.0f) {
-			float4* g = d.sbody + 4 * (size_t)body;
+			float4* g = (MODE == 1 ? d.vel : d.pose) + 2 * (size_t)body;
 			g[0] = s_rec[RS * at]; g[1] = s_rec[RS * at + 1];
 		}
 	}
@@ -2156,7 +2158,7 @@ template <int MODE> __global__ void __launch_bounds__(HC_TPB) k_solve_hc(DV d, i
 		const uint32_t cb = d.cstarts[c], ce = d.cstarts[c + 1];
 		for (uint32_t k = cb + pair; k < ce; k += HC_WG_PAIRS) {
 			if (!(CUR(d).np_col[k] & NPCOL_CATCH_ALL)) continue;
-			if (MODE == 1) solve_velocity_pair_t<4>(d, k, side, d.sbody); else solve_position_pair(d, k, side);
+			if (MODE == 1) solve_velocity_pair_t<2>(d, k, side, d.vel); else solve_position_pair(d, k, side);
 		}
 		__syncthreads();
 	}
@@ -2164,7 +2166,7 @@ template <int MODE> __global__ void __launch_bounds__(HC_TPB) k_solve_hc(DV d, i
 	uint64_t last = 0; bool have_last = false;
 	for (uint32_t it = 0; it < ocount; ++it) {
 		const uint32_t bslot = overflow_next(d, ofirst, ocount, last, have_last);
-		if (MODE == 1) solve_velocity_pair_t<4>(d, bslot, side, d.sbody); else solve_position_pair(d, bslot, side);
+		if (MODE == 1) solve_velocity_pair_t<2>(d, bslot, side, d.vel); else solve_position_pair(d, bslot, side);
 	}
 }
 
@@ -2181,7 +2183,7 @@ __global__ void __launch_bounds__(SMALL_TPB) k_solve_small(DV d, int warm_start,
 	__shared__ uint32_t cs[SGP_MAX_COLOURS + 1];
 	const uint32_t n = min(d.sp->n_slots, (uint32_t)SMALL_LDS_BODIES);
 	if (threadIdx.x <= SGP_MAX_COLOURS) cs[threadIdx.x] = d.cstarts[threadIdx.x];
-	for (uint32_t i = threadIdx.x; i < 2 * n; i += SMALL_TPB) sv[i] = d.sbody[4 * (size_t)(i >> 1) + (i & 1)];
+	for (uint32_t i = threadIdx.x; i < 2 * n; i += SMALL_TPB) sv[i] = d.vel[i];
 	__syncthreads();
 	const int side = (int)(threadIdx.x & 1u);
 	const uint32_t pair = threadIdx.x >> 1;
@@ -2233,7 +2235,7 @@ __global__ void __launch_bounds__(SMALL_TPB) k_solve_small(DV d, int warm_start,
 			}
 		}
 	}
-	for (uint32_t i = threadIdx.x; i < 2 * n; i += SMALL_TPB) d.sbody[4 * (size_t)(i >> 1) + (i & 1)] = sv[i];
+	for (uint32_t i = threadIdx.x; i < 2 * n; i += SMALL_TPB) d.vel[i] = sv[i];
 }
 
 // The small-world solve with ONE THREAD PER CONSTRAINT (512 threads, the constraint's ~240 registers in one lane): for worlds of 385..512
@@ -2321,7 +2323,7 @@ __global__ void __launch_bounds__(512) k_solve_small_single(DV d, int warm_start
 	__shared__ uint32_t cs[SGP_MAX_COLOURS + 1];
 	const uint32_t n = min(d.sp->n_slots, (uint32_t)SMALL_LDS_BODIES);
 	if (threadIdx.x <= SGP_MAX_COLOURS) cs[threadIdx.x] = d.cstarts[threadIdx.x];
-	for (uint32_t i = threadIdx.x; i < 2 * n; i += 512) sv[i] = d.sbody[4 * (size_t)(i >> 1) + (i & 1)];
+	for (uint32_t i = threadIdx.x; i < 2 * n; i += 512) sv[i] = d.vel[i];
 	__syncthreads();
 	const uint32_t all_n = cs[SGP_OVERFLOW_COLOUR];
 	if (all_n != 0 && all_n <= 512u && cs[SGP_OVERFLOW_COLOUR] == cs[SGP_MAX_COLOURS]) {
@@ -2377,7 +2379,7 @@ __global__ void __launch_bounds__(512) k_solve_small_single(DV d, int warm_start
 			}
 		}
 	}
-	for (uint32_t i = threadIdx.x; i < 2 * n; i += 512) d.sbody[4 * (size_t)(i >> 1) + (i & 1)] = sv[i];
+	for (uint32_t i = threadIdx.x; i < 2 * n; i += 512) d.vel[i] = sv[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2385,42 +2387,38 @@ __global__ void __launch_bounds__(512) k_solve_small_single(DV d, int warm_start
 
 __global__ void __launch_bounds__(TPB) k_integrate_pose(DV d)
 {
-	// part 2 of 3 of the body-array sweep: the solved velocities go back to their arrays, the pose advances, and the solver record turns into
-	// the pose record of the position iterations [position, effective inverse mass][rotation][local inverse inertia diagonal] (was k_prep_pose).
-	// A movable body's new pose lives in that record until k_finalize writes it to the pose arrays (after the position iterations corrected
-	// it); the arrays themselves are only written here for bodies the position iterations cannot move (kinematic ones).
+	// part 2 of 3 of the body-array sweep: the pose of every active non-static body advances by its solved velocities, in place; the position
+	// iterations then correct the pose records directly.  Traffic per body: flags 4 + velocity record 32 + pose record 32 read, pose record 32
+	// written = 100 B (round 2: 213 B -- it also copied the velocities back to their arrays and built a 48 B pose record per body).
 	const float dt = d.sp->dt;
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
 	if (i >= d.sp->n_slots) return;
 	const uint32_t f = d.flags[i];
-	if (!(f & BF_ALIVE)) return;
-	float4 p = d.pos_im[i], r4 = d.rot[i];
-	const bool movable = f_movable(f);
-	if ((f & BF_ACTIVE) && f_motion(f) != SGP_MOTION_STATIC) {
-		// the solved velocities live in the solver record
-		v3 lv = V3(d.sbody[4 * (size_t)i]), av = V3(d.sbody[4 * (size_t)i + 1]);
-		if (f_motion(f) == SGP_MOTION_DYNAMIC) {
-			const float l2 = v3_len_sq(lv), ml = d.st.max_linear_velocity;
-			if (l2 > ml * ml) lv = v3_scale(lv, ml / sqrtf(l2));
-			const float a2 = v3_len_sq(av), ma = d.st.max_angular_velocity;
-			if (a2 > ma * ma) av = v3_scale(av, ma / sqrtf(a2));
-		}
-		d.linv[i] = F4(lv, d.linv[i].w);
-		d.angv[i] = F4(av, d.angv[i].w);
-		const v3 np = v3_add(V3(p), v3_scale(lv, dt));
-		const quat q = quat_add_rotation_step(Q4(r4), v3_scale(av, dt));
-		p = F4(np, p.w);
-		r4 = make_float4(q.x, q.y, q.z, q.w);
-		if (!movable) { d.pos_im[i] = p; d.rot[i] = r4; }
+	if ((f & (BF_ALIVE | BF_ACTIVE)) != (BF_ALIVE | BF_ACTIVE) || f_motion(f) == SGP_MOTION_STATIC) return;
+	const float4 v4 = d.vel[2 * (size_t)i], w4 = d.vel[2 * (size_t)i + 1];
+	float4 p = d.pose[2 * (size_t)i], r4 = d.pose[2 * (size_t)i + 1];
+	v3 lv = V3(v4), av = V3(w4);
+	if (f_motion(f) == SGP_MOTION_DYNAMIC) {
+		const float l2 = v3_len_sq(lv), ml = d.st.max_linear_velocity;
+		const float a2 = v3_len_sq(av), ma = d.st.max_angular_velocity;
+		const bool cl = l2 > ml * ml, ca = a2 > ma * ma;
+		if (cl) lv = v3_scale(lv, ml / sqrtf(l2));
+		if (ca) av = v3_scale(av, ma / sqrtf(a2));
+		if (cl) d.vel[2 * (size_t)i] = F4(lv, v4.w);                       // (only a clamped velocity changes)
+		if (ca) d.vel[2 * (size_t)i + 1] = F4(av, w4.w);
 	}
-	d.sbody[4 * (size_t)i] = make_float4(p.x, p.y, p.z, movable ? p.w : 0.0f);
-	d.sbody[4 * (size_t)i + 1] = r4;
-	d.sbody[4 * (size_t)i + 2] = d.inv_inertia[i];
+	const v3 np = v3_add(V3(p), v3_scale(lv, dt));
+	const quat q = quat_add_rotation_step(Q4(r4), v3_scale(av, dt));
+	d.pose[2 * (size_t)i] = F4(np, p.w);
+	d.pose[2 * (size_t)i + 1] = make_float4(q.x, q.y, q.z, q.w);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // K1 + K9: AABB refresh, sleep test spheres (Body::UpdateSleepStateInternal), island bookkeeping
 
+// part 3 of 3 of the body-array sweep.  Traffic per awake body: flags 4 + pose record 32 + property record 32 + three sleep spheres 48 + timer 4
+// read, AABB 32 + timer 4 + island scratch 6 written (+ a sphere that grew, + the flags when the sleep verdict changed) = 162 B
+// (round 2: 269 B -- it also wrote the pose back from the solver record and rewrote every sphere and the flags every step).
 __global__ void __launch_bounds__(TPB) k_finalize(DV d)
 {
 	const float dt = d.sp->dt;
@@ -2432,12 +2430,8 @@ __global__ void __launch_bounds__(TPB) k_finalize(DV d)
 	uint32_t f = d.flags[i];
 	if ((f & (BF_ALIVE | BF_ACTIVE)) != (BF_ALIVE | BF_ACTIVE)) return;
 	const uint32_t type = f_shape(f);
-	const float4 sh = d.shape[i];
-	float4 p4, r4;
-	if (f_movable(f)) {      // the position iterations corrected the pose in the solver record: write it back
-		p4 = d.sbody[4 * (size_t)i]; r4 = d.sbody[4 * (size_t)i + 1];
-		d.pos_im[i] = p4; d.rot[i] = r4;
-	} else { p4 = d.pos_im[i]; r4 = d.rot[i]; }
+	const float4 sh = d.prop[2 * (size_t)i + 1];
+	const float4 p4 = d.pose[2 * (size_t)i], r4 = d.pose[2 * (size_t)i + 1];      // (the position iterations corrected the pose records in place)
 	const v3 pos = V3(p4);
 	const quat q = Q4(r4);
 	v3 mn, mx;
@@ -2453,11 +2447,13 @@ __global__ void __launch_bounds__(TPB) k_finalize(DV d)
 		sleep_points(d, type, sh, pos, q, pts);
 		bool reset = false;
 		float4 s[3];
+		bool grew[3];
 		for (int k = 0; k < 3; ++k) {
 			s[k] = d.sleep_s[k][i];
 			const v3 dd = v3_sub(pts[k], V3(s[k]));
 			const float d2 = v3_len_sq(dd);
-			if (d2 > s[k].w * s[k].w) {
+			grew[k] = d2 > s[k].w * s[k].w;
+			if (grew[k]) {
 				const float dl = sqrtf(d2);
 				const float nr = 0.5f * (s[k].w + dl);
 				const v3 c = v3_add(V3(s[k]), v3_scale(dd, (nr - s[k].w) / dl));
@@ -2470,14 +2466,14 @@ __global__ void __launch_bounds__(TPB) k_finalize(DV d)
 			d.sleep_timer[i] = 0.0f;
 			can_sleep = false;
 		} else {
-			for (int k = 0; k < 3; ++k) d.sleep_s[k][i] = s[k];
+			for (int k = 0; k < 3; ++k) if (grew[k]) d.sleep_s[k][i] = s[k];      // (a test point still inside its sphere leaves the sphere as it is)
 			const float t = d.sleep_timer[i] + dt;
 			d.sleep_timer[i] = t;
 			can_sleep = t >= d.st.time_before_sleep;
 		}
 	}
-	f = can_sleep ? (f | BF_CAN_SLEEP) : (f & ~BF_CAN_SLEEP);
-	d.flags[i] = f;
+	const uint32_t nf = can_sleep ? (f | BF_CAN_SLEEP) : (f & ~BF_CAN_SLEEP);
+	if (nf != f) d.flags[i] = nf;
 }
 
 // Union-find over the sleepy bodies, linked by a random priority (a bijective hash of the body id) instead of by id: the
@@ -2585,12 +2581,13 @@ SGP_DEV void sleep_apply_one(const DV& d, uint32_t i, bool& active)
 		if ((f & BF_CAN_SLEEP) && !d.awake_mark[i] && d.island_awake[uf_find(d.island, i)] == 0) {
 			f &= ~(BF_ACTIVE | BF_CAN_SLEEP);
 			d.flags[i] = f;
-			d.linv[i] = make_float4(0.0f, 0.0f, 0.0f, d.linv[i].w);
-			d.angv[i] = make_float4(0.0f, 0.0f, 0.0f, d.angv[i].w);
+			// (the record of a body that is not awake reads (0, 0, 0 | effective inverse mass 0): k_pre_solve then has nothing to write for it)
+			d.vel[2 * (size_t)i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			d.vel[2 * (size_t)i + 1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 			push_event(d.ev_deactivated, &d.evc->n_deactivated, d.cap_bodies, i);
 		}
 	} else if (f_motion(f) == SGP_MOTION_KINEMATIC && (f & BF_ACTIVE)) {
-		const v3 lv = V3(d.linv[i]), av = V3(d.angv[i]);
+		const v3 lv = V3(d.vel[2 * (size_t)i]), av = V3(d.vel[2 * (size_t)i + 1]);
 		if (v3_len_sq(lv) == 0.0f && v3_len_sq(av) == 0.0f) {
 			f &= ~BF_ACTIVE;
 			d.flags[i] = f;
@@ -2674,10 +2671,10 @@ __global__ void __launch_bounds__(TPB) k_buoyancy(DV d)
 	if (mn.z < d.sp->water_z) {                                                          // :1379
 		const float fluid_density = 1020.0f;                                         // :1381
 		const uint32_t type = f_shape(f);
-		const float4 sh = d.shape[i];
-		const float4 pim = d.pos_im[i];
+		const float4 sh = d.prop[2 * (size_t)i + 1];
+		const float4 pim = d.pose[2 * (size_t)i];
 		const v3 pos = V3(pim);
-		const m33 R = quat_to_m33(Q4(d.rot[i]));
+		const m33 R = quat_to_m33(Q4(d.pose[2 * (size_t)i + 1]));
 		const float total = shape_volume(d, type, sh);
 		float sub; v3 rc;
 		if (type == SGP_SHAPE_BOX) box_submerged(V3(sh.x, sh.y, sh.z), R, pos.z, d.sp->water_z, &sub, &rc);
@@ -2701,9 +2698,9 @@ __global__ void __launch_bounds__(TPB) k_buoyancy(DV d)
 			const float inv_mass = pim.w;
 			const float rho = buoyancy / (total * inv_mass);
 			const v3 g = V3(0.0f, 0.0f, -9.81f);                                      // :1407
-			const float gf = d.force[i].w;
+			const float gf = d.dyn[i].z;
 			const v3 buoy_imp = v3_scale(g, -rho * sub * gf * dt);
-			float4 lv4 = d.linv[i], av4 = d.angv[i];
+			float4 lv4 = d.vel[2 * (size_t)i], av4 = d.vel[2 * (size_t)i + 1];
 			const v3 lv = V3(lv4), av = V3(av4);
 			const v3 cob_vel = v3_add(lv, v3_cross(av, rc));
 			const v3 rel = v3_neg(cob_vel);
@@ -2724,12 +2721,12 @@ __global__ void __launch_bounds__(TPB) k_buoyancy(DV d)
 			const float l = (size.x + size.y + size.z) / 3.0f;
 			const float ang_drag = 3.0f;                                             // :1405
 			const v3 drag_ang_imp = v3_scale(av, -ang_drag * sub / total * dt * (l * l) / inv_mass);
-			const sym33 Iw = world_inv_inertia(R, V3(d.inv_inertia[i]));
+			const sym33 Iw = world_inv_inertia(R, V3(d.prop[2 * (size_t)i]));
 			v3 ddrag = sym33_mul(Iw, drag_ang_imp);
 			if (v3_len_sq(ddrag) > v3_len_sq(av)) ddrag = v3_neg(av);
 			const v3 dang = v3_add(ddrag, sym33_mul(Iw, v3_cross(rc, v3_add(buoy_imp, drag_imp))));
-			d.linv[i] = F4(v3_add(lv, dlin), lv4.w);
-			d.angv[i] = F4(v3_add(av, dang), av4.w);
+			d.vel[2 * (size_t)i] = F4(v3_add(lv, dlin), lv4.w);
+			d.vel[2 * (size_t)i + 1] = F4(v3_add(av, dang), av4.w);
 			applied = true;
 		}
 		if (applied) {
@@ -2786,7 +2783,7 @@ __global__ void __launch_bounds__(TPB) k_contact_events(DV d)
 		if (k >= d.cap_contact_events) continue;
 		sgp_contact_event e;
 		e.id1 = ab.x; e.id2 = ab.y; e.userdata1 = 0; e.userdata2 = 0;
-		const float4 la = d.sbody[4 * (size_t)ab.x], lb = d.sbody[4 * (size_t)ab.y];      // velocities after gravity, before the solve (k_pre_solve)
+		const float4 la = d.vel[2 * (size_t)ab.x], lb = d.vel[2 * (size_t)ab.y];      // velocities after gravity, before the solve (k_pre_solve)
 		e.lin_vel1[0] = la.x; e.lin_vel1[1] = la.y; e.lin_vel1[2] = la.z;
 		e.lin_vel2[0] = lb.x; e.lin_vel2[1] = lb.y; e.lin_vel2[2] = lb.z;
 		const float4 n4 = d.man_n[m];
@@ -2817,7 +2814,7 @@ __global__ void __launch_bounds__(TPB) k_contact_events(DV d)
 SGP_DEV void refresh_aabb(const DV& d, uint32_t i, uint32_t f)
 {
 	v3 mn, mx;
-	compute_aabb(d, f_shape(f), d.shape[i], V3(d.pos_im[i]), Q4(d.rot[i]), mn, mx);
+	compute_aabb(d, f_shape(f), d.prop[2 * (size_t)i + 1], V3(d.pose[2 * (size_t)i]), Q4(d.pose[2 * (size_t)i + 1]), mn, mx);
 	d.aabb_min[i] = F4(mn, 0.0f); d.aabb_max[i] = F4(mx, 0.0f);
 }
 
@@ -2825,7 +2822,7 @@ SGP_DEV uint32_t activate_body(const DV& d, uint32_t i, uint32_t f)
 {
 	if (!(f & BF_ALIVE) || f_motion(f) == SGP_MOTION_STATIC) return f;
 	if (!(f & BF_ACTIVE)) { f |= BF_ACTIVE; push_event(d.ev_activated, &d.evc->n_activated, d.cap_bodies, i); }
-	reset_sleep(d, i, f_shape(f), d.shape[i], V3(d.pos_im[i]), Q4(d.rot[i]));
+	reset_sleep(d, i, f_shape(f), d.prop[2 * (size_t)i + 1], V3(d.pose[2 * (size_t)i]), Q4(d.pose[2 * (size_t)i + 1]));
 	return f;
 }
 
@@ -2839,11 +2836,11 @@ __global__ void __launch_bounds__(TPB) k_ghost_refresh(DV d, const GhostRefresh*
 	const uint32_t i = c.id;
 	uint32_t f = d.flags[i];
 	if (!(f & BF_ALIVE)) return;
-	d.pos_im[i] = make_float4(c.pos[0], c.pos[1], c.pos[2], d.pos_im[i].w);
-	d.rot[i] = make_float4(c.rot[0], c.rot[1], c.rot[2], c.rot[3]);
+	d.pose[2 * (size_t)i] = make_float4(c.pos[0], c.pos[1], c.pos[2], d.pose[2 * (size_t)i].w);
+	d.pose[2 * (size_t)i + 1] = make_float4(c.rot[0], c.rot[1], c.rot[2], c.rot[3]);
 	if (f_motion(f) != SGP_MOTION_STATIC) {
-		d.linv[i] = make_float4(c.linv[0], c.linv[1], c.linv[2], d.linv[i].w);
-		d.angv[i] = make_float4(c.angv[0], c.angv[1], c.angv[2], d.angv[i].w);
+		d.vel[2 * (size_t)i] = make_float4(c.linv[0], c.linv[1], c.linv[2], d.vel[2 * (size_t)i].w);
+		d.vel[2 * (size_t)i + 1] = make_float4(c.angv[0], c.angv[1], c.angv[2], d.vel[2 * (size_t)i + 1].w);
 	}
 	refresh_aabb(d, i, f);
 	f = activate_body(d, i, f);
@@ -2861,18 +2858,19 @@ __global__ void __launch_bounds__(TPB) k_apply_cmds(DV d, const BodyCmd* cmds, c
 		const BodyCmd& c = cmds[k];
 		if (c.ops & CMD_CREATE) {
 			f = c.flags | BF_CACHE_INVALID;
-			d.pos_im[i] = make_float4(c.pos[0], c.pos[1], c.pos[2], c.inv_mass);
-			d.rot[i] = make_float4(c.rot[0], c.rot[1], c.rot[2], c.rot[3]);
-			d.linv[i] = make_float4(c.linv[0], c.linv[1], c.linv[2], c.lin_damp);
-			d.angv[i] = make_float4(c.angv[0], c.angv[1], c.angv[2], c.ang_damp);
-			d.force[i] = make_float4(0.0f, 0.0f, 0.0f, c.gravity_factor);
+			d.pose[2 * (size_t)i] = make_float4(c.pos[0], c.pos[1], c.pos[2], c.inv_mass);
+			d.pose[2 * (size_t)i + 1] = make_float4(c.rot[0], c.rot[1], c.rot[2], c.rot[3]);
+			d.vel[2 * (size_t)i] = make_float4(c.linv[0], c.linv[1], c.linv[2], 0.0f);        // (effective inverse mass: set by k_pre_solve once the body is awake)
+			d.vel[2 * (size_t)i + 1] = make_float4(c.angv[0], c.angv[1], c.angv[2], 0.0f);
+			d.dyn[i] = make_float4(c.lin_damp, c.ang_damp, c.gravity_factor, c.inv_mass);
+			d.force[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 			d.torque[i] = make_float4(0.0f, 0.0f, 0.0f, c.mass);
-			d.inv_inertia[i] = make_float4(c.inv_inertia[0], c.inv_inertia[1], c.inv_inertia[2], c.restitution);
-			d.shape[i] = make_float4(c.shape[0], c.shape[1], c.shape[2], c.friction);
+			d.prop[2 * (size_t)i] = make_float4(c.inv_inertia[0], c.inv_inertia[1], c.inv_inertia[2], c.restitution);
+			d.prop[2 * (size_t)i + 1] = make_float4(c.shape[0], c.shape[1], c.shape[2], c.friction);
 			d.submerged[i] = 0.0f;
 			d.userdata[i] = c.userdata;
 			refresh_aabb(d, i, f);
-			reset_sleep(d, i, f_shape(f), d.shape[i], V3(d.pos_im[i]), Q4(d.rot[i]));
+			reset_sleep(d, i, f_shape(f), d.prop[2 * (size_t)i + 1], V3(d.pose[2 * (size_t)i]), Q4(d.pose[2 * (size_t)i + 1]));
 			continue;
 		}
 		if (c.ops & CMD_REMOVE) { f = 0; continue; }
@@ -2881,8 +2879,8 @@ __global__ void __launch_bounds__(TPB) k_apply_cmds(DV d, const BodyCmd* cmds, c
 		if (c.ops & CMD_MOVE_KINEMATIC) {
 			// MotionProperties::MoveKinematic: velocities that reach the target in dt
 			if (f_motion(f) == SGP_MOTION_KINEMATIC && c.dt > 0.0f) {
-				const v3 pos = V3(d.pos_im[i]);
-				const quat q = Q4(d.rot[i]);
+				const v3 pos = V3(d.pose[2 * (size_t)i]);
+				const quat q = Q4(d.pose[2 * (size_t)i + 1]);
 				const v3 lv = v3_scale(v3_sub(V3(c.pos[0], c.pos[1], c.pos[2]), pos), 1.0f / c.dt);
 				quat t; t.x = c.rot[0]; t.y = c.rot[1]; t.z = c.rot[2]; t.w = c.rot[3];
 				quat cj; cj.x = -q.x; cj.y = -q.y; cj.z = -q.z; cj.w = q.w;
@@ -2891,41 +2889,41 @@ __global__ void __launch_bounds__(TPB) k_apply_cmds(DV d, const BodyCmd* cmds, c
 				const float sl = sqrtf(dq.x * dq.x + dq.y * dq.y + dq.z * dq.z);
 				v3 av = V3(0.0f, 0.0f, 0.0f);
 				if (sl > 1.0e-12f) { const float angle = sgd_quat_angle(sl, dq.w); av = v3_scale(V3(dq.x / sl, dq.y / sl, dq.z / sl), angle / c.dt); }
-				d.linv[i] = F4(lv, d.linv[i].w);
-				d.angv[i] = F4(av, d.angv[i].w);
+				d.vel[2 * (size_t)i] = F4(lv, d.vel[2 * (size_t)i].w);
+				d.vel[2 * (size_t)i + 1] = F4(av, d.vel[2 * (size_t)i + 1].w);
 				f = activate_body(d, i, f);
 			}
 			continue;
 		}
 		bool pose = false;
-		if (c.ops & CMD_SET_POS) { d.pos_im[i] = make_float4(c.pos[0], c.pos[1], c.pos[2], d.pos_im[i].w); pose = true; }
-		if (c.ops & CMD_SET_ROT) { d.rot[i] = make_float4(c.rot[0], c.rot[1], c.rot[2], c.rot[3]); pose = true; }
+		if (c.ops & CMD_SET_POS) { d.pose[2 * (size_t)i] = make_float4(c.pos[0], c.pos[1], c.pos[2], d.pose[2 * (size_t)i].w); pose = true; }
+		if (c.ops & CMD_SET_ROT) { d.pose[2 * (size_t)i + 1] = make_float4(c.rot[0], c.rot[1], c.rot[2], c.rot[3]); pose = true; }
 		if (c.ops & CMD_SET_SHAPE) {
-			d.shape[i] = make_float4(c.shape[0], c.shape[1], c.shape[2], d.shape[i].w); pose = true;
+			d.prop[2 * (size_t)i + 1] = make_float4(c.shape[0], c.shape[1], c.shape[2], d.prop[2 * (size_t)i + 1].w); pose = true;
 			f = ((f & ~BF_LARGE) | (c.flags & BF_LARGE)) | BF_CACHE_INVALID;      // a new scale can move the body across the broad phase's large-body radius (host: note_radius)
 		}
 		if ((c.ops & CMD_SET_VEL) && f_motion(f) != SGP_MOTION_STATIC) {
-			d.linv[i] = make_float4(c.linv[0], c.linv[1], c.linv[2], d.linv[i].w);
-			d.angv[i] = make_float4(c.angv[0], c.angv[1], c.angv[2], d.angv[i].w);
+			d.vel[2 * (size_t)i] = make_float4(c.linv[0], c.linv[1], c.linv[2], d.vel[2 * (size_t)i].w);
+			d.vel[2 * (size_t)i + 1] = make_float4(c.angv[0], c.angv[1], c.angv[2], d.vel[2 * (size_t)i + 1].w);
 		}
 		if (pose) refresh_aabb(d, i, f);
 		if (f_motion(f) == SGP_MOTION_DYNAMIC) {
 			if (c.ops & CMD_ADD_FORCE) {
 				const float4 F = d.force[i];
 				d.force[i] = F4(v3_add(V3(F), V3(c.linv[0], c.linv[1], c.linv[2])), F.w);
-				f = activate_body(d, i, f);
+				f = activate_body(d, i, f) | BF_HAS_FORCE;
 			}
 			if (c.ops & CMD_ADD_TORQUE) {
 				const float4 T = d.torque[i];
 				d.torque[i] = F4(v3_add(V3(T), V3(c.angv[0], c.angv[1], c.angv[2])), T.w);
-				f = activate_body(d, i, f);
+				f = activate_body(d, i, f) | BF_HAS_FORCE;
 			}
 			if (c.ops & CMD_ADD_FORCE_AT) {
 				const v3 Fv = V3(c.linv[0], c.linv[1], c.linv[2]);
 				const float4 F = d.force[i], T = d.torque[i];
 				d.force[i] = F4(v3_add(V3(F), Fv), F.w);
-				d.torque[i] = F4(v3_add(V3(T), v3_cross(v3_sub(V3(c.pos[0], c.pos[1], c.pos[2]), V3(d.pos_im[i])), Fv)), T.w);
-				f = activate_body(d, i, f);
+				d.torque[i] = F4(v3_add(V3(T), v3_cross(v3_sub(V3(c.pos[0], c.pos[1], c.pos[2]), V3(d.pose[2 * (size_t)i])), Fv)), T.w);
+				f = activate_body(d, i, f) | BF_HAS_FORCE;
 			}
 		}
 		if (c.ops & CMD_ACTIVATE) f = activate_body(d, i, f);
@@ -2938,7 +2936,7 @@ __global__ void __launch_bounds__(TPB) k_apply_cmds(DV d, const BodyCmd* cmds, c
 
 SGP_DEV void fill_state(const DV& d, uint32_t i, sgp_body_state* s)
 {
-	const float4 p = d.pos_im[i], q = d.rot[i], lv = d.linv[i], av = d.angv[i];
+	const float4 p = d.pose[2 * (size_t)i], q = d.pose[2 * (size_t)i + 1], lv = d.vel[2 * (size_t)i], av = d.vel[2 * (size_t)i + 1];
 	const uint32_t f = d.flags[i];
 	s->pos[0] = p.x; s->pos[1] = p.y; s->pos[2] = p.z;
 	s->rot[0] = q.x; s->rot[1] = q.y; s->rot[2] = q.z; s->rot[3] = q.w;
@@ -2975,9 +2973,9 @@ __global__ void __launch_bounds__(TPB) k_gather_active_poses(DV d, float4* out, 
 	const bool want = (f & (BF_ALIVE | BF_ACTIVE)) == (BF_ALIVE | BF_ACTIVE);
 	const uint32_t k = block_alloc(&d.ctr->n_read_active, want);      // one atomic per workgroup
 	if (want && k < cap) {
-		const float4 p = d.pos_im[i];
+		const float4 p = d.pose[2 * (size_t)i];
 		out[2 * (size_t)k] = make_float4(p.x, p.y, p.z, __uint_as_float(i));
-		out[2 * (size_t)k + 1] = d.rot[i];
+		out[2 * (size_t)k + 1] = d.pose[2 * (size_t)i + 1];
 	}
 }
 
@@ -3143,7 +3141,7 @@ SGP_DEV void ray_test_body(const DV& d, const sgp_ray& ry, v3 o, v3 dir, uint32_
 	if (ry.collidable_only && !(layer == SGP_LAYER_NON_MOVING || layer == SGP_LAYER_MOVING)) return;
 	if (!ray_aabb(o, dir, d.aabb_min[i], d.aabb_max[i], best.t)) return;
 	v3 nn; RaySub sub;
-	const float t = ray_body(d, f_shape(f), d.shape[i], V3(d.pos_im[i]), Q4(d.rot[i]), o, dir, best.t, &nn, &sub);
+	const float t = ray_body(d, f_shape(f), d.prop[2 * (size_t)i + 1], V3(d.pose[2 * (size_t)i]), Q4(d.pose[2 * (size_t)i + 1]), o, dir, best.t, &nn, &sub);
 	// closest hit; ties go to the lower body id so the result does not depend on the traversal order
 	if (t >= 0.0f && t <= best.t && (t < best.t || best.id == SGP_INVALID_ID || i < best.id)) { best.t = t; best.id = i; best.n = nn; best.sub = sub; }
 }
@@ -3225,8 +3223,8 @@ __global__ void __launch_bounds__(64) k_raycast(DV d, const sgp_ray* rays, uint3
 // swept sphere against mesh body j: closest front-side touch; on equal distance the lower triangle index (caller's order) wins
 SGP_DEV float cast_sphere_mesh(const DV& d, uint32_t j, v3 o, v3 dir, float max_t, float rs, v3* n_out, v3* p_out)
 {
-	const MeshHeader mh = d.meshes[(uint32_t)d.shape[j].x];
-	const v3 mpos = V3(d.pos_im[j]); const m33 R = quat_to_m33(Q4(d.rot[j]));
+	const MeshHeader mh = d.meshes[(uint32_t)d.prop[2 * (size_t)j + 1].x];
+	const v3 mpos = V3(d.pose[2 * (size_t)j]); const m33 R = quat_to_m33(Q4(d.pose[2 * (size_t)j + 1]));
 	const v3 ol = m33_tmul(R, v3_sub(o, mpos)), dl = m33_tmul(R, dir);
 	float best = max_t; uint32_t best_idx = 0xFFFFFFFFu; v3 bn = V3(0.0f, 0.0f, 0.0f);
 	uint32_t stack[48]; int sp = 0;
@@ -3271,11 +3269,11 @@ SGP_DEV void veh_cast_test(const DV& d, const sgd_vehicle* v, v3 o, v3 dir, floa
 	// the bounds filter uses the full cast length, not the best hit so far: the planes-only swept-sphere test of boxes and hulls can report a
 	// touch just outside the inflated bounds (it is generous at corners), and the answer must not depend on the order of the candidates
 	if (!ray_aabb(o, dir, make_float4(mn.x - e, mn.y - e, mn.z - e, 0.0f), make_float4(mx.x + e, mx.y + e, mx.z + e, 0.0f), cast_len)) return;
-	const float4 sh = d.shape[j];
+	const float4 sh = d.prop[2 * (size_t)j + 1];
 	const float prm[3] = { sh.x, sh.y, sh.z };
 	v3 n, p;
 	const float t = f_shape(f) == SGP_SHAPE_MESH ? cast_sphere_mesh(d, j, o, dir, best, rs, &n, &p)
-	              : sgd_cast_sphere_body((int)f_shape(f), prm, f_shape(f) == SGP_SHAPE_HULL ? body_hull(d, sh) : nullptr, V3(d.pos_im[j]), quat_to_m33(Q4(d.rot[j])), o, dir, best, rs, &n, &p);
+	              : sgd_cast_sphere_body((int)f_shape(f), prm, f_shape(f) == SGP_SHAPE_HULL ? body_hull(d, sh) : nullptr, V3(d.pose[2 * (size_t)j]), quat_to_m33(Q4(d.pose[2 * (size_t)j + 1])), o, dir, best, rs, &n, &p);
 	if (t < 0.0f || n.z < v->cos_max_slope) return;
 	// closest accepted hit; on equal distance the lower body id wins (the oracle visits ids in ascending order)
 	if (t < best || bid == SGP_INVALID_ID || (t == best && j < bid)) { best = t; bid = j; bn = n; bp = p; }
@@ -3284,9 +3282,9 @@ SGP_DEV void veh_cast_test(const DV& d, const sgd_vehicle* v, v3 o, v3 dir, floa
 SGP_DEV sgd_chassis veh_chassis_pose_vel(const DV& d, uint32_t b)
 {
 	sgd_chassis c;
-	const float4 p = d.pos_im[b];
-	c.pos = V3(p); c.rot = Q4(d.rot[b]); c.v = V3(d.linv[b]); c.w = V3(d.angv[b]);
-	c.im = p.w; c.inv_inertia_local = V3(d.inv_inertia[b]);
+	const float4 p = d.pose[2 * (size_t)b];
+	c.pos = V3(p); c.rot = Q4(d.pose[2 * (size_t)b + 1]); c.v = V3(d.vel[2 * (size_t)b]); c.w = V3(d.vel[2 * (size_t)b + 1]);
+	c.im = p.w; c.inv_inertia_local = V3(d.prop[2 * (size_t)b]);
 	c.I = world_inv_inertia(quat_to_m33(c.rot), c.inv_inertia_local);
 	return c;
 }
@@ -3364,8 +3362,8 @@ __global__ void __launch_bounds__(64) k_vehicle_cast(DV d)
 		if (wi < sv.num_wheels && sub == 0 && bid != SGP_INVALID_ID) {
 			const uint32_t fo = d.flags[bid];
 			v3 gvel = V3(0.0f, 0.0f, 0.0f);
-			if (f_motion(fo) != SGP_MOTION_STATIC) gvel = v3_add(V3(d.linv[bid]), v3_cross(V3(d.angv[bid]), v3_sub(bp, V3(d.pos_im[bid]))));
-			sgd_vehicle_set_hit(&sv, wi, bid, best, bn, bp, gvel, d.shape[bid].w);
+			if (f_motion(fo) != SGP_MOTION_STATIC) gvel = v3_add(V3(d.vel[2 * (size_t)bid]), v3_cross(V3(d.vel[2 * (size_t)bid + 1]), v3_sub(bp, V3(d.pose[2 * (size_t)bid]))));
+			sgd_vehicle_set_hit(&sv, wi, bid, best, bn, bp, gvel, d.prop[2 * (size_t)bid + 1].w);
 		}
 	}
 	veh_stage_out(gv, &sv);
@@ -3381,8 +3379,8 @@ __global__ void __launch_bounds__(64) k_vehicle_controller(DV d)
 		const uint32_t b = sv.body;
 		sgd_chassis c = veh_chassis_pose_vel(d, b);
 		if (sgd_vehicle_pre_b(&sv, &c, d.sp->dt)) d.sleep_timer[b] = 0.0f;
-		const float4 lv = d.linv[b], av = d.angv[b];
-		d.linv[b] = F4(c.v, lv.w); d.angv[b] = F4(c.w, av.w);
+		const float4 lv = d.vel[2 * (size_t)b], av = d.vel[2 * (size_t)b + 1];
+		d.vel[2 * (size_t)b] = F4(c.v, lv.w); d.vel[2 * (size_t)b + 1] = F4(c.w, av.w);
 	}
 	veh_stage_out(gv, &sv);
 }
@@ -3397,25 +3395,20 @@ template <int MODE> __global__ void __launch_bounds__(64) k_vehicle_solve(DV d)
 	if (threadIdx.x == 0) {
 		const uint32_t b = sv.body;
 		sgd_chassis c;
-		const float4 p = d.pos_im[b];
-		c.pos = V3(p); c.rot = Q4(d.rot[b]); c.inv_inertia_local = V3(d.inv_inertia[b]);
+		const float4 p = d.pose[2 * (size_t)b];
+		c.pos = V3(p); c.rot = Q4(d.pose[2 * (size_t)b + 1]); c.inv_inertia_local = V3(d.prop[2 * (size_t)b]);
 		if (MODE == 2) {
-			// between k_integrate_pose and k_finalize the pose being corrected is the one in the solver record (k_finalize copies it back
-			// for movable bodies; anything else keeps its pose arrays authoritative)
-			const bool mv = f_movable(d.flags[b]);
-			if (mv) { c.pos = V3(d.sbody[4 * b + 0]); c.rot = Q4(d.sbody[4 * b + 1]); }
+			// the position iterations correct the pose record in place
 			c.im = p.w; c.v = V3(0.0f, 0.0f, 0.0f); c.w = c.v; c.I = sym33_zero();
 			sgd_vehicle_solve_position(&sv, &c, d.st.baumgarte);
-			const float4 r4 = make_float4(c.rot.x, c.rot.y, c.rot.z, c.rot.w);
-			if (!mv) { d.pos_im[b] = F4(c.pos, p.w); d.rot[b] = r4; }
-			d.sbody[4 * b + 0] = F4(c.pos, mv ? p.w : 0.0f);
-			d.sbody[4 * b + 1] = r4;
+			d.pose[2 * (size_t)b] = F4(c.pos, p.w);
+			d.pose[2 * (size_t)b + 1] = make_float4(c.rot.x, c.rot.y, c.rot.z, c.rot.w);
 		} else {
-			const float4 s0 = d.sbody[4 * b + 0], s1 = d.sbody[4 * b + 1], s2 = d.sbody[4 * b + 2], s3 = d.sbody[4 * b + 3];
-			c.v = V3(s0); c.im = s0.w; c.w = V3(s1);
-			c.I.xx = s2.x; c.I.xy = s2.y; c.I.xz = s2.z; c.I.yy = s3.x; c.I.yz = s3.y; c.I.zz = s3.z;
+			const float4 s0 = d.vel[2 * (size_t)b], s1 = d.vel[2 * (size_t)b + 1];
+			c.v = V3(s0); c.im = s0.w; c.w = V3(s1);                  // (s0.w: the effective inverse mass of this step, k_pre_solve)
+			c.I = c.im > 0.0f ? world_inv_inertia(quat_to_m33(c.rot), c.inv_inertia_local) : sym33_zero();
 			if (MODE == 0) sgd_vehicle_warm_start(&sv, &c); else sgd_vehicle_solve_velocity(&sv, &c, d.sp->dt);
-			d.sbody[4 * b + 0] = F4(c.v, s0.w); d.sbody[4 * b + 1] = F4(c.w, s1.w);
+			d.vel[2 * (size_t)b] = F4(c.v, s0.w); d.vel[2 * (size_t)b + 1] = F4(c.w, s1.w);
 		}
 	}
 	if (MODE == 1) veh_stage_out(gv, &sv);        // only the velocity iteration changes the record (row impulses, wheel spin)
@@ -3447,9 +3440,9 @@ SGP_DEV void capsule_query_body(const DV& d, const sgp_capsule_query& q, uint32_
 		c.normal[0] = m.n.x; c.normal[1] = m.n.y; c.normal[2] = m.n.z;
 		c.distance = v3_dot(v3_sub(m.p2[i], m.p1[i]), m.n);
 		v3 pv = V3(0.0f, 0.0f, 0.0f);
-		if (f_motion(f) != SGP_MOTION_STATIC) pv = v3_add(V3(d.linv[j]), v3_cross(V3(d.angv[j]), v3_sub(m.p1[i], V3(d.pos_im[j]))));
+		if (f_motion(f) != SGP_MOTION_STATIC) pv = v3_add(V3(d.vel[2 * (size_t)j]), v3_cross(V3(d.vel[2 * (size_t)j + 1]), v3_sub(m.p1[i], V3(d.pose[2 * (size_t)j]))));
 		c.point_velocity[0] = pv.x; c.point_velocity[1] = pv.y; c.point_velocity[2] = pv.z;
-		c.motion_type = f_motion(f); c.is_sensor = (f & BF_SENSOR) ? 1u : 0u; c.inv_mass = d.pos_im[j].w; c.userdata = 0;
+		c.motion_type = f_motion(f); c.is_sensor = (f & BF_SENSOR) ? 1u : 0u; c.inv_mass = d.pose[2 * (size_t)j].w; c.userdata = 0;
 		out[slot] = c;
 	}
 	}
@@ -3493,11 +3486,11 @@ SGP_DEV void spherecast_body(const DV& d, const sgp_ray& ry, float rs, v3 o, v3 
 	const float4 mn = d.aabb_min[j], mx = d.aabb_max[j];
 	const float e = rs + 1.0e-3f;
 	if (!ray_aabb(o, dir, make_float4(mn.x - e, mn.y - e, mn.z - e, 0.0f), make_float4(mx.x + e, mx.y + e, mx.z + e, 0.0f), ry.max_t)) return;      // full length: see veh_cast_test
-	const float4 sh = d.shape[j];
+	const float4 sh = d.prop[2 * (size_t)j + 1];
 	const float prm[3] = { sh.x, sh.y, sh.z };
 	v3 n, p;
 	const float t = f_shape(f) == SGP_SHAPE_MESH ? cast_sphere_mesh(d, j, o, dir, best.t, rs, &n, &p)
-	              : sgd_cast_sphere_body((int)f_shape(f), prm, f_shape(f) == SGP_SHAPE_HULL ? body_hull(d, sh) : nullptr, V3(d.pos_im[j]), quat_to_m33(Q4(d.rot[j])), o, dir, best.t, rs, &n, &p);
+	              : sgd_cast_sphere_body((int)f_shape(f), prm, f_shape(f) == SGP_SHAPE_HULL ? body_hull(d, sh) : nullptr, V3(d.pose[2 * (size_t)j]), quat_to_m33(Q4(d.pose[2 * (size_t)j + 1])), o, dir, best.t, rs, &n, &p);
 	if (t >= 0.0f && t <= best.t && (t < best.t || best.id == SGP_INVALID_ID || j < best.id)) { best.t = t; best.id = j; best.n = n; }
 }
 
@@ -3551,7 +3544,8 @@ SGP_DEV bool export_qualifies(const DV& d, uint32_t i, float3 lo, float3 hi, flo
 SGP_DEV void fill_ghost_desc(const DV& d, uint32_t i, uint32_t f, sgp_ghost_record& r)
 {
 	r.userdata = d.userdata[i];
-	r.gravity_factor = d.force[i].w; r.linear_damping = d.linv[i].w; r.angular_damping = d.angv[i].w;
+	const float4 dy = d.dyn[i];
+	r.gravity_factor = dy.z; r.linear_damping = dy.x; r.angular_damping = dy.y;
 	r.flags = f_layer(f) | ((f & BF_SENSOR) ? SGP_GHOST_FLAG_SENSOR : 0u) | ((f & BF_ALLOW_SLEEP) ? SGP_GHOST_FLAG_ALLOW_SLEEP : 0u) | ((f & BF_ZERO_LIN_DRAG) ? SGP_GHOST_FLAG_ZERO_DRAG : 0u);
 	r._pad[0] = 0; r._pad[1] = 0;
 }
@@ -3592,14 +3586,14 @@ __global__ void __launch_bounds__(TPB) k_export_boundary(DV d, float3 lo, float3
 	const uint32_t k = base + wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 	if (k >= cap) return;
 	sgp_ghost_record r;
-	const float4 p = d.pos_im[i], qq = d.rot[i], lv = d.linv[i], av = d.angv[i], sh = d.shape[i];
+	const float4 p = d.pose[2 * (size_t)i], qq = d.pose[2 * (size_t)i + 1], lv = d.vel[2 * (size_t)i], av = d.vel[2 * (size_t)i + 1], sh = d.prop[2 * (size_t)i + 1];
 	r.pos[0] = p.x; r.pos[1] = p.y; r.pos[2] = p.z;
 	r.rot[0] = qq.x; r.rot[1] = qq.y; r.rot[2] = qq.z; r.rot[3] = qq.w;
 	r.lin_vel[0] = lv.x; r.lin_vel[1] = lv.y; r.lin_vel[2] = lv.z;
 	r.ang_vel[0] = av.x; r.ang_vel[1] = av.y; r.ang_vel[2] = av.z;
 	r.shape_type = (int32_t)f_shape(f);
 	r.shape[0] = sh.x; r.shape[1] = sh.y; r.shape[2] = sh.z; r.shape[3] = 0.0f;
-	r.mass = d.torque[i].w; r.friction = sh.w; r.restitution = d.inv_inertia[i].w;
+	r.mass = d.torque[i].w; r.friction = sh.w; r.restitution = d.prop[2 * (size_t)i].w;
 	r.motion_type = f_motion(f);
 	r.global_id = i;
 	fill_ghost_desc(d, i, f, r);
@@ -3619,7 +3613,7 @@ SGP_DEV unsigned long long route_mask(const DV& d, uint32_t i, const TileRoute& 
 	emigrates = false;
 	const float* mylo = t.boxes + 6 * t.my_rank; const float* myhi = mylo + 3;
 	if (!export_qualifies(d, i, make_float3(mylo[0], mylo[1], mylo[2]), make_float3(myhi[0], myhi[1], myhi[2]), t.margin, f)) return 0ull;
-	const float4 p = d.pos_im[i];
+	const float4 p = d.pose[2 * (size_t)i];
 	// an owned dynamic body emigrates only when another tile's own (unpadded) region contains its centre: where the caller's boxes leave a gap
 	// nobody would accept the body, so it stays with its current owner instead of vanishing
 	const bool left = t.n_tiles > 1 && f_motion(f) == SGP_MOTION_DYNAMIC && !tile_in_box(p, mylo, myhi, 0.0f);
@@ -3711,14 +3705,14 @@ __global__ void __launch_bounds__(TPB) k_route_write(DV d, TileRoute t, const ui
 		const uint32_t k = header->seg_start[dst] + block_offsets[(size_t)blockIdx.x * cols + dst] + wbase + (uint32_t)__popcll(b & below);
 		if (k >= cap) continue;
 		if (!built) {
-			const float4 p = d.pos_im[i], qq = d.rot[i], lv = d.linv[i], av = d.angv[i], sh = d.shape[i];
+			const float4 p = d.pose[2 * (size_t)i], qq = d.pose[2 * (size_t)i + 1], lv = d.vel[2 * (size_t)i], av = d.vel[2 * (size_t)i + 1], sh = d.prop[2 * (size_t)i + 1];
 			r.pos[0] = p.x; r.pos[1] = p.y; r.pos[2] = p.z;
 			r.rot[0] = qq.x; r.rot[1] = qq.y; r.rot[2] = qq.z; r.rot[3] = qq.w;
 			r.lin_vel[0] = lv.x; r.lin_vel[1] = lv.y; r.lin_vel[2] = lv.z;
 			r.ang_vel[0] = av.x; r.ang_vel[1] = av.y; r.ang_vel[2] = av.z;
 			r.shape_type = (int32_t)f_shape(f);
 			r.shape[0] = sh.x; r.shape[1] = sh.y; r.shape[2] = sh.z; r.shape[3] = 0.0f;
-			r.mass = d.torque[i].w; r.friction = sh.w; r.restitution = d.inv_inertia[i].w;
+			r.mass = d.torque[i].w; r.friction = sh.w; r.restitution = d.prop[2 * (size_t)i].w;
 			r.motion_type = emig ? (SGP_MOTION_DYNAMIC | SGP_GHOST_TAKE_OWNERSHIP) : f_motion(f);
 			r.global_id = (uint64_t)i | ((uint64_t)t.my_rank << 40);
 			fill_ghost_desc(d, i, f, r);
@@ -3743,11 +3737,11 @@ __global__ void __launch_bounds__(TPB) k_ghost_refresh_records(DV d, const sgp_g
 	uint32_t f = d.flags[i];
 	if (!(f & BF_ALIVE)) return;
 	const sgp_ghost_record& c = recs[k];
-	d.pos_im[i] = make_float4(c.pos[0], c.pos[1], c.pos[2], d.pos_im[i].w);
-	d.rot[i] = make_float4(c.rot[0], c.rot[1], c.rot[2], c.rot[3]);
+	d.pose[2 * (size_t)i] = make_float4(c.pos[0], c.pos[1], c.pos[2], d.pose[2 * (size_t)i].w);
+	d.pose[2 * (size_t)i + 1] = make_float4(c.rot[0], c.rot[1], c.rot[2], c.rot[3]);
 	if (f_motion(f) != SGP_MOTION_STATIC) {
-		d.linv[i] = make_float4(c.lin_vel[0], c.lin_vel[1], c.lin_vel[2], d.linv[i].w);
-		d.angv[i] = make_float4(c.ang_vel[0], c.ang_vel[1], c.ang_vel[2], d.angv[i].w);
+		d.vel[2 * (size_t)i] = make_float4(c.lin_vel[0], c.lin_vel[1], c.lin_vel[2], d.vel[2 * (size_t)i].w);
+		d.vel[2 * (size_t)i + 1] = make_float4(c.ang_vel[0], c.ang_vel[1], c.ang_vel[2], d.vel[2 * (size_t)i + 1].w);
 	}
 	refresh_aabb(d, i, f);
 	f = activate_body(d, i, f);

@@ -280,14 +280,13 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	DV& d = w->dv;
 	const uint32_t N = desc->max_bodies, P = w->desc.max_body_pairs, M = w->desc.max_manifolds;
 	d.cap_bodies = N; d.cap_pairs = P; d.cap_manifolds = M;
-	DEV_ALLOC(d.pos_im, N); DEV_ALLOC(d.rot, N); DEV_ALLOC(d.linv, N); DEV_ALLOC(d.angv, N);
-	DEV_ALLOC(d.force, N); DEV_ALLOC(d.torque, N); DEV_ALLOC(d.inv_inertia, N); DEV_ALLOC(d.shape, N);
+	DEV_ALLOC(d.pose, 2 * (size_t)N); DEV_ALLOC(d.vel, 2 * (size_t)N); DEV_ALLOC(d.prop, 2 * (size_t)N); DEV_ALLOC(d.dyn, N);
+	DEV_ALLOC(d.force, N); DEV_ALLOC(d.torque, N);
 	DEV_ALLOC(d.flags, N); DEV_ALLOC(d.aabb_min, N); DEV_ALLOC(d.aabb_max, N);
 	for (int k = 0; k < 3; ++k) DEV_ALLOC(d.sleep_s[k], N);
 	DEV_ALLOC(d.sleep_timer, N); DEV_ALLOC(d.submerged, N); DEV_ALLOC(d.userdata, N);
 	DEV_ALLOC(d.colour_mask, N); DEV_ALLOC(d.body_con, (size_t)N * SGP_MAX_COLOURS); DEV_ALLOC(d.claim[0], N); DEV_ALLOC(d.claim[1], N);
 	DEV_ALLOC(d.island, N); DEV_ALLOC(d.island_awake, N); DEV_ALLOC(d.awake_mark, N); DEV_ALLOC(d.export_counts, N / 256 + 2);
-	DEV_ALLOC(d.sbody, 4 * (size_t)N);
 	// cells of the broad-phase grid: room for 16 per body slot (clearing and scanning follow the cells a step's grid really has, not this capacity).  The grid covers the bounds of all small bodies with cells of R_max + margin and coarsens them
 	// (x 1.5) until it fits this table: a pile that has spread out (config 2 after its tower fell: 60 x 60 x 10 m of 1 m cells) then lands in
 	// cells with several bodies each and k_bp_pairs scans hundreds of candidates per body (0.23 ms for 10k boxes with 2 cells per slot, 0.02 ms with 8 or more).
@@ -2358,7 +2357,7 @@ SGP_API int sgp_world_device_array(sgp_world* w, int which, void** dev_ptr_out, 
 {
 	if (!w || !dev_ptr_out) return fail(SGP_ERR_INVALID, "sgp_world_device_array: NULL");
 	void* p = nullptr;
-	switch (which) { case 0: p = w->dv.pos_im; break; case 1: p = w->dv.rot; break; case 2: p = w->dv.linv; break; case 3: p = w->dv.angv; break;
+	switch (which) { case 0: p = w->dv.pose; break; case 1: p = w->dv.vel; break;
 	default: return fail(SGP_ERR_INVALID, "sgp_world_device_array: bad index"); }
 	*dev_ptr_out = p;
 	if (count_out) *count_out = w->high;

@@ -51,7 +51,7 @@ int main()
 		std::sort(wire.begin(), wire.end(), [](const InFlight& a, const InFlight& b) { return a.arrival < b.arrival; });
 		size_t cursor = 0, inserted = 0, biggest = 0;
 		double now = skew;
-		float worst_jump = 0.f;
+		float worst_jump = 0.f, worst = 0.f;
 		for (int frame = 0; frame < 200; ++frame) {
 			now += 1.0 / 60.0;
 			while (cursor < wire.size() && wire[cursor].arrival <= now) { queue.receive(wire[cursor].msg, wire[cursor].arrival); ++cursor; }
@@ -66,17 +66,17 @@ int main()
 				obs[i]->pos = Vec4f(p.GetX(), p.GetY(), p.GetZ(), 1.f);
 				worst_jump = std::max(worst_jump, obs[i]->smooth_translation.length());
 				obs[i]->smooth_translation = obs[i]->smooth_translation * 0.9f;
+				// while the stream runs every box follows its owner: at our time `now` the owner's clock shows now - skew, and playback lags by
+				// the 0.1 s padding (between snapshots the box coasts on the snapshot's velocity, minus a little ground friction)
+				const double t_owner = now + 1.0 / 60.0 - skew - 0.1;
+				if (t_owner > 0.5 && t_owner < 2.9) {
+					const float v = 1.f + (float)i / 16.f;
+					worst = std::max(worst, std::fabs(obs[i]->pos[1] - v * (float)t_owner));
+				}
 			}
 		}
-		// every box has followed its owner: at our time `now` the owner's clock shows now - skew; playback lags by the 0.1 s padding
-		float worst = 0.f;
-		for (int i = 0; i < N; ++i) {
-			const float v = 1.f + (float)i / 16.f;
-			const float expect_y = v * (float)std::min(3.0, now - skew - 0.1);
-			worst = std::max(worst, std::fabs(obs[i]->pos[1] - expect_y));
-		}
 		printf("inserted %zu snapshots (largest batch %zu), worst |y - owner's y| %.3f m, largest smoothing offset %.3f m, tracked %u\n", inserted, biggest, worst, worst_jump, queue.expire(now));
-		const bool ok = inserted == (size_t)(30 * N) && biggest >= 8 && worst < 0.35f && worst_jump < 0.5f;
+		const bool ok = inserted == (size_t)(30 * N) && biggest >= 8 && worst < 0.25f && worst_jump < 0.5f;
 		return ok ? 0 : 1;
 	} catch (glare::Exception& e) { fprintf(stderr, "glare::Exception: %s\n", e.what().c_str()); return 2; }
 }
