@@ -83,6 +83,8 @@ struct StepCounters {
 	uint32_t bp_dense;           // some tile's halo held more records than the small instance of k_bp_pairs stages in LDS
 	uint32_t hc_probe_big;       // launch-plan probe: constraints of components too large for a workgroup if one more colour went to the components
 	uint32_t hc_done;            // workgroups of the running solve launch that have finished (the last one runs the catch-all and clears it)
+	uint32_t ts_error;           // tile solver: a tile gave up waiting for a neighbour (k_step_end copies ts_flags[0])
+	uint32_t ts_all_adjacent;    // tile solver: some body was touched by more than four tiles
 	uint32_t round_n[32];        // uncoloured manifolds at the start of colouring round r (the host plans the next step's wide rounds from it)
 	uint32_t colour_count[SGP_MAX_COLOURS];
 	uint32_t colour_fill[SGP_MAX_COLOURS];
@@ -192,6 +194,20 @@ struct DV {
 	uint32_t* island_awake;
 	uint32_t* export_counts;   // per 256-body block: bodies the tile export picks (k_export_count)
 	uint32_t* awake_mark;      // per body: 1 = sleepy but known to stay awake this step (k_island_mark)
+	// tile solver (k_ts_*): ts_nt tiles = workgroups of the one resident velocity-iteration launch, a ts_gx x ts_gy grid over the world (0: unavailable)
+	uint32_t ts_nt, ts_gx, ts_gy;
+	uint8_t*  body_tile;       // tile of every body (k_ts_label)
+	uint64_t* body_tiles4;     // up to four tile ids (16 bits each, 0xFFFF free): the tiles whose constraints touch the body this step
+	uint8_t*  man_tile;        // tile of every manifold's constraint
+	uint32_t* ts_count;        // [colour * ts_nt + tile] constraints; ts_start: their first slot (+ 1 entry: the total); ts_fill: scratch of the slot assignment
+	uint32_t* ts_start;
+	uint32_t* ts_fill;
+	uint32_t* ts_adj;          // [tile][8]: bit U set = this tile and tile U touch a common body
+	uint64_t* ts_wait;         // [tile]: colours in which the tile touches a shared body (it waits for its neighbours before those phases)
+	uint32_t* ts_epoch;        // [tile * 32]: phases the tile has completed (one 128 B line per tile)
+	uint32_t* ts_flags;        // [0] a tile gave up waiting (the step fails), [1] some body is touched by more than four tiles (all tiles neighbours)
+	uint16_t* ts_at;           // [2 * slot + side]: where that side's body lives during the launch: LDS slot, TS_AT_SHARED or TS_AT_IMMOVABLE
+	uint8_t*  ts_side;         // [2 * slot + side]: 0 immovable, 1 private to the constraint's tile, 2 shared
 	// broad phase
 	uint32_t table_size;       // power of two
 	uint32_t* cell_hash;       // per body: linear cell index in the dense grid (0xFFFFFFFF = not binned)
@@ -275,6 +291,10 @@ void launch_colour_commit(const DV& d, uint32_t n_man, uint32_t round, hipStream
 void launch_colour_count(const DV& d, uint32_t n_man, hipStream_t s);
 void launch_colour_finish(const DV& d, uint32_t first_round, int build_list, hipStream_t s);
 void launch_setup(const DV& d, uint32_t n_man, hipStream_t s);
+void launch_ts_label(const DV& d, uint32_t nb, hipStream_t s);
+void launch_colour_count_ts(const DV& d, uint32_t n_man, hipStream_t s);
+void launch_setup_ts(const DV& d, uint32_t n_man, hipStream_t s);
+void launch_ts_solve(const DV& d, int passes, hipStream_t s);
 // mode: 0 warm start, 1 velocity iteration, 2 position iteration.  est = expected constraints of that colour (grid sizing only)
 void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStream_t s);
 void launch_solve_probe(const DV& d, int variant, int colour, uint32_t est, hipStream_t s);

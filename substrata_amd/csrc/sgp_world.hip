@@ -94,6 +94,8 @@ struct sgp_world {
 	std::map<std::string, hipGraphExec_t> graphs;              // replayable launch sequences keyed by launch plan
 	std::string last_plan_key[2]; uint32_t plan_repeats[2] = { 0, 0 };   // per buffer parity: StepParams (by value in the first launch) flips parity every step
 	bool use_graphs = true; bool use_small_world = true; uint32_t tail_threshold = 256;
+	int use_tile_solver = 0;            // SGP_TILE_SOLVER: 0 off, 1 on where the plan finds it applicable (k_ts_solve)
+	uint32_t ts_min_constraints = 16384;
 	// high colours by component: share of the constraints they may hold (per mille; SGP_HC_BUDGET, 0 = off), and the plan's correction of it
 	// hc_k: the first colour that goes to the components (-1: not chosen yet -> the budget rule).  One colour fewer after a step that left a
 	// component to the catch-all; one more after a probe (component sizes computed for hc_k - 1 without using them) found that it fits.
@@ -311,6 +313,20 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	DEV_ALLOC(d.pairs, P);
 	DEV_ALLOC(d.man_ab, M); DEV_ALLOC(d.man_n, M); DEV_ALLOC(d.man_colour, M); DEV_ALLOC(d.man_prio, M); DEV_ALLOC(d.man_prev, M); DEV_ALLOC(d.man_slot, M);
 	DEV_ALLOC(d.hc_root, N); DEV_ALLOC(d.hc_count, N); DEV_ALLOC(d.hc_base, N); DEV_ALLOC(d.hc_rank, M);
+	// tile solver: one workgroup per compute unit must be resident, so the tile grid follows the device (256 CUs: 16 x 16)
+	{
+		int dev = 0, cus = 0;
+		if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+		d.ts_nt = 0; d.ts_gx = d.ts_gy = 0;
+		if (cus >= 256) { d.ts_nt = 256; d.ts_gx = 16; d.ts_gy = 16; } else if (cus >= 128) { d.ts_nt = 128; d.ts_gx = 16; d.ts_gy = 8; } else if (cus >= 64) { d.ts_nt = 64; d.ts_gx = 8; d.ts_gy = 8; }
+		if (d.ts_nt) {
+			const size_t E = (size_t)SGP_MAX_COLOURS * d.ts_nt;
+			DEV_ALLOC(d.body_tile, N); DEV_ALLOC(d.body_tiles4, N); DEV_ALLOC(d.man_tile, M);
+			DEV_ALLOC(d.ts_count, E + 1); DEV_ALLOC(d.ts_start, E + 1); DEV_ALLOC(d.ts_fill, E + 1);
+			DEV_ALLOC(d.ts_adj, (size_t)d.ts_nt * 8); DEV_ALLOC(d.ts_wait, d.ts_nt); DEV_ALLOC(d.ts_epoch, (size_t)d.ts_nt * 32); DEV_ALLOC(d.ts_flags, 4);
+			DEV_ALLOC(d.ts_at, 2 * (size_t)M); DEV_ALLOC(d.ts_side, 2 * (size_t)M);
+		}
+	}
 	d.cap_hc_list = 2u * M + 4096u; DEV_ALLOC(d.hc_list, d.cap_hc_list); DEV_ALLOC(d.hc_entry, d.cap_hc_list);
 	DEV_ALLOC(d.ulist[0], M); DEV_ALLOC(d.ulist[1], M);
 	for (int k = 0; k < 4; ++k) { DEV_ALLOC(d.man_p1[k], M); DEV_ALLOC(d.man_p2[k], M); }
@@ -337,6 +353,8 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	{ const char* e = getenv("SGP_NO_GRAPH"); if (e && e[0] == '1') w->use_graphs = false; }
 	{ const char* e = getenv("SGP_NO_SMALL_WORLD"); if (e && e[0] == '1') w->use_small_world = false; }
 	{ const char* e = getenv("SGP_DEBUG_FLAGS"); w->dv.dbg_flags = e ? (uint32_t)atoi(e) : 0u; }
+	{ const char* e = getenv("SGP_TILE_SOLVER"); if (e) w->use_tile_solver = atoi(e); }
+	{ const char* e = getenv("SGP_TS_MIN_CONSTRAINTS"); if (e && atoi(e) >= 0) w->ts_min_constraints = (uint32_t)atoi(e); }
 	{ const char* e = getenv("SGP_HC_BUDGET"); if (e) { const int v = atoi(e); if (v <= 0) w->use_components = false; else w->hc_budget = (uint32_t)v; } }
 	{ int dev = 0, cus = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) w->n_cus = (uint32_t)cus; }
 	{ const char* e = getenv("SGP_HC_MIN_COLOURS"); if (e && atoi(e) >= 0) w->hc_min_colours = (uint32_t)atoi(e); }
@@ -964,6 +982,7 @@ struct StepPlan {
 	uint32_t hc_est;             // their constraints (previous step)
 	int      hc_probe;           // >= 0: this step also computes the component sizes for hc_probe = hc_first - 1 (not used for solving)
 	uint32_t hc_probe_est;
+	int      tile_solver;        // all velocity iterations in the one resident launch of the tile solver (k_ts_solve)
 	int      small_pairs;        // ... with two lanes per constraint (the previous step had <= 384 constraints), else one thread per constraint
 	StepParams sp;               // by-value kernel argument of the first launch: part of the key of a captured graph
 };
@@ -1032,6 +1051,11 @@ static void make_plan(const sgp_world* w, StepPlan& p)
 		for (int c = k; c < SGP_OVERFLOW_COLOUR; ++c) used += w->plan_colour_count[c] != 0u;
 		if (used < (int)w->hc_min_colours) { p.hc_first = -1; p.hc_probe = -1; p.hc_est = 0; p.hc_probe_est = 0; p.tail_first = tf; }
 	}
+	// the tile solver: a pile large enough that its colour launches are bound by latency, small enough that a tile's bodies fit its LDS table
+	// (the table takes what fits and leaves the rest in global memory, so the bound is about speed, not correctness), no vehicle rows between
+	// the passes, and enough body slots for k_ts_label's grid to clear the (colour, tile) histogram
+	p.tile_solver = (w->use_tile_solver && w->dv.ts_nt && !p.small_world && w->n_vehicles == 0 && p.vel_iters > 0 && w->n_con >= w->ts_min_constraints &&
+	                 w->high >= SGP_MAX_COLOURS * w->dv.ts_nt && w->last_active <= w->dv.ts_nt * 1536u) ? w->use_tile_solver : 0;      // (2: debugging aid -- the tile order of the slots, solved by the colour launches)
 	p.sp = *w->h_sp;
 }
 
@@ -1072,8 +1096,13 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 		}
 		{ KScope k(w, KC_COLOUR_COMMIT); launch_colour_finish(d, p.rounds, 0, s); }
 	}
-	{ KScope k(w, KC_COLOUR_COUNT); launch_colour_count(d, p.est_man, s); }
-	{ KScope k(w, KC_SETUP); launch_setup(d, p.est_man, s); }
+	if (p.tile_solver) {
+		{ KScope k(w, KC_COLOUR_COUNT); launch_ts_label(d, nb, s); launch_colour_count_ts(d, p.est_man, s); }
+		{ KScope k(w, KC_SETUP); launch_setup_ts(d, p.est_man, s); }
+	} else {
+		{ KScope k(w, KC_COLOUR_COUNT); launch_colour_count(d, p.est_man, s); }
+		{ KScope k(w, KC_SETUP); launch_setup(d, p.est_man, s); }
+	}
 	if (p.hc_first >= 0 && p.hc_probe >= 0) { KScope k(w, KC_SETUP); launch_hc_probe(d, p.hc_probe, p.hc_probe_est, s); }
 	if (p.hc_first >= 0) { KScope k(w, KC_SETUP); launch_hc_build(d, p.hc_first, p.hc_est, s); }
 	STAGE_MARK(4);
@@ -1092,7 +1121,8 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 			{ KScope k(w, KC_WARM_START); launch_warm_bodies(d, nb, s); }
 			{ KScope k(w, KC_WARM_START); launch_solve_tail(d, SGP_OVERFLOW_COLOUR, 0, s); }
 		}
-		for (int it = 0; it < p.vel_iters; ++it) solve_pass(1, KC_SOLVE_VELOCITY);
+		if (p.tile_solver == 1) { KScope k(w, KC_SOLVE_VELOCITY); launch_ts_solve(d, p.vel_iters, s); }
+		else for (int it = 0; it < p.vel_iters; ++it) solve_pass(1, KC_SOLVE_VELOCITY);
 	}
 	STAGE_MARK(5);
 	// -- 6. the body-array sweep
@@ -1182,6 +1212,7 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	w->last_active = w->h_ctr->n_active;
 	const StepCounters c1 = *w->h_ctr;
 	const uint32_t n_con = c1.n_constraints;
+	if (plan.tile_solver && c1.ts_error) return fail(SGP_ERR_HIP, "sgp_world_step: the tile solver timed out waiting for a neighbouring tile (a workgroup of the resident launch was not running); set SGP_TILE_SOLVER=0");
 	w->n_con = n_con;
 	w->last_pairs = c1.n_pairs; w->last_manifolds = c1.n_manifolds;
 	w->plan_rounds = c1.rounds_used;
@@ -1218,6 +1249,7 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	st.num_overflow_constraints = c1.colour_count[SGP_OVERFLOW_COLOUR];
 	st.num_cached_manifolds = c1.n_cached;
 	st.num_component_constraints = c1.hc_n; st.num_catch_all_constraints = c1.hc_n_big;
+	st.tile_solver = plan.tile_solver ? (c1.ts_all_adjacent ? 2u : 1u) : 0u;
 	st.pairs_dropped = c1.pairs_dropped; st.manifolds_dropped = c1.manifolds_dropped;
 	st.device_bytes = w->device_bytes;
 	st.num_active = c1.n_active;
