@@ -294,7 +294,7 @@ void launch_setup(const DV& d, uint32_t n_man, hipStream_t s);
 void launch_ts_label(const DV& d, uint32_t nb, hipStream_t s);
 void launch_colour_count_ts(const DV& d, uint32_t n_man, hipStream_t s);
 void launch_setup_ts(const DV& d, uint32_t n_man, hipStream_t s);
-void launch_ts_solve(const DV& d, int passes, hipStream_t s);
+void launch_ts_solve(const DV& d, int passes, int colour_end, hipStream_t s);      // colours < colour_end, `passes` times
 // mode: 0 warm start, 1 velocity iteration, 2 position iteration.  est = expected constraints of that colour (grid sizing only)
 void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStream_t s);
 void launch_solve_probe(const DV& d, int variant, int colour, uint32_t est, hipStream_t s);

@@ -3918,7 +3918,7 @@ __global__ void __launch_bounds__(TPB) k_setup_slots_ts(DV d)
 	}
 }
 
-__global__ void __launch_bounds__(TS_TPB) k_ts_solve(DV d, int passes)
+__global__ void __launch_bounds__(TS_TPB) k_ts_solve(DV d, int passes, int colour_end)
 {
 	__shared__ float4 s_rec[2 * TS_TABLE];
 	__shared__ uint32_t s_key[TS_TABLE];
@@ -3935,7 +3935,7 @@ __global__ void __launch_bounds__(TS_TPB) k_ts_solve(DV d, int passes)
 		const uint32_t e = threadIdx.x * NT + T;
 		const uint32_t b = d.ts_start[e], cnt = d.ts_start[e + 1] - b;
 		s_base[threadIdx.x] = b; s_cnt[threadIdx.x] = cnt;
-		const unsigned long long pres = __ballot(cnt != 0u);
+		const unsigned long long pres = __ballot(cnt != 0u && (int)threadIdx.x < colour_end);      // (colours >= colour_end are somebody else's: the component launch)
 		if (threadIdx.x == 0) { s_present = pres; s_waitmask = all_adjacent ? ~0ull : d.ts_wait[T]; s_ok = 1; }
 	}
 	__syncthreads();
@@ -4135,10 +4135,10 @@ void launch_setup_ts(const DV& d, uint32_t n_man, hipStream_t s)
 	hipLaunchKernelGGL(k_setup_slots_ts, dim3(stride_grid(n_man)), dim3(TPB), 0, s, d);
 	hipLaunchKernelGGL(k_setup, dim3(stride_grid(n_man)), dim3(TPB), 0, s, d);
 }
-void launch_ts_solve(const DV& d, int passes, hipStream_t s)
+void launch_ts_solve(const DV& d, int passes, int colour_end, hipStream_t s)
 {
 	hipMemsetAsync(d.ts_epoch, 0, sizeof(uint32_t) * 32u * d.ts_nt, s);      // (a memset node of the captured graph: every polled word starts from zero in every step)
-	hipLaunchKernelGGL(k_ts_solve, dim3(d.ts_nt), dim3(TS_TPB), 0, s, d, passes);
+	hipLaunchKernelGGL(k_ts_solve, dim3(d.ts_nt), dim3(TS_TPB), 0, s, d, passes, colour_end);
 }
 void launch_colour_finish(const DV& d, uint32_t first_round, int build_list, hipStream_t s) { hipLaunchKernelGGL(k_colour_finish, dim3(1), dim3(1024), 0, s, d, first_round, build_list); }
 void launch_setup(const DV& d, uint32_t n_man, hipStream_t s)

@@ -1121,7 +1121,14 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 			{ KScope k(w, KC_WARM_START); launch_warm_bodies(d, nb, s); }
 			{ KScope k(w, KC_WARM_START); launch_solve_tail(d, SGP_OVERFLOW_COLOUR, 0, s); }
 		}
-		if (p.tile_solver == 1) { KScope k(w, KC_SOLVE_VELOCITY); launch_ts_solve(d, p.vel_iters, s); }
+		if (p.tile_solver == 1) { KScope k(w, KC_SOLVE_VELOCITY); launch_ts_solve(d, p.vel_iters, SGP_MAX_COLOURS, s); }
+		else if (p.tile_solver == 3 && p.hc_first >= 0) {
+			// the big colours of a pass in the resident tile launch, the sparse high colours by connected component (one launch each per pass)
+			for (int it = 0; it < p.vel_iters; ++it) {
+				{ KScope k(w, KC_SOLVE_VELOCITY); launch_ts_solve(d, 1, p.tail_first, s); }
+				{ KScope k(w, KC_SOLVE_VELOCITY); launch_solve_hc(d, p.hc_first, p.hc_est, 1, s); }
+			}
+		}
 		else for (int it = 0; it < p.vel_iters; ++it) solve_pass(1, KC_SOLVE_VELOCITY);
 	}
 	STAGE_MARK(5);
