@@ -384,6 +384,17 @@ int  sgp_body_compound_size(sgp_world* w, uint32_t id, uint32_t* num_children_ou
 int  sgp_body_get_userdata(sgp_world* w, uint32_t id, uint64_t* userdata_out);
 /* getNumObjects (:1635-1638) */
 int  sgp_world_num_bodies(sgp_world* w, uint32_t* n_out);
+/* The counters PhysicsWorld::getDiagnostics prints (PhysicsWorld.cpp:1578-1604: JPH::BodyManager::BodyStats + the mesh count of getMemUsageStats). */
+typedef struct sgp_body_counts {
+	uint32_t num_bodies, max_bodies;
+	uint32_t num_static, num_dynamic, num_kinematic;
+	uint32_t num_active_dynamic, num_active_kinematic;
+	uint32_t num_meshes;             /* live triangle-mesh shapes */
+	uint32_t num_hulls;              /* live convex-hull shapes   */
+	uint32_t reserved_;
+	uint64_t shape_bytes;            /* device bytes held by the mesh and hull tables */
+} sgp_body_counts;
+int  sgp_world_body_counts(sgp_world* w, sgp_body_counts* out);
 
 /* Debug / test view (not a facade entry point): the contact constraints of the last step, sorted by (a,b).
  * Record layout: {u32 a,b; i32 colour,np; f32 n[3], lam_n[4], lam_t1[4], lam_t2[4], bias[4]}. */

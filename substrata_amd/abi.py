@@ -115,6 +115,12 @@ class TilesStats(C.Structure):
                 ("comm_init_ms", f32), ("last_exchange_ms", f32), ("total_exchange_ms", f32)]
 
 
+class BodyCounts(C.Structure):
+    _fields_ = [("num_bodies", u32), ("max_bodies", u32), ("num_static", u32), ("num_dynamic", u32), ("num_kinematic", u32),
+                ("num_active_dynamic", u32), ("num_active_kinematic", u32), ("num_meshes", u32), ("num_hulls", u32), ("reserved_", u32),
+                ("shape_bytes", u64)]
+
+
 class Migration(C.Structure):
     _fields_ = [("userdata", u64), ("old_id", u32), ("new_id", u32), ("direction", u32), ("peer", u32)]
 
@@ -289,6 +295,7 @@ PROTOTYPES = {
     "abi_sizeof": (C.c_int, [C.c_int]),
     "world_drain_events": (C.c_int, [vp, C.c_int, vp, u32, P(u32)]),
     "world_num_bodies": (C.c_int, [vp, P(u32)]),
+    "world_body_counts": (C.c_int, [vp, P(BodyCounts)]),
     "raycast": (C.c_int, [vp, vp, u32, vp]),
     "collide_capsules": (C.c_int, [vp, vp, u32, vp, u32, P(u32)]),
     "spherecast": (C.c_int, [vp, vp, vp, u32, vp]),

@@ -1977,6 +1977,33 @@ SGP_API int sgp_world_read_active_poses_view(sgp_world* w, const sgp_body_pose**
 	return SGP_OK;
 }
 
+SGP_API int sgp_world_body_counts(sgp_world* w, sgp_body_counts* out)
+{
+	if (!w || !out) return fail(SGP_ERR_INVALID, "sgp_world_body_counts: NULL");
+	memset(out, 0, sizeof(*out));
+	out->max_bodies = w->dv.cap_bodies;
+	for (uint32_t i = 0; i < w->high; ++i) {
+		const uint32_t f = w->hb[i].flags;
+		if ((f & (BF_ALIVE | BF_ALIAS)) != BF_ALIVE) continue;
+		out->num_bodies++;
+		const uint32_t m = f & BF_MOTION_MASK;
+		if (m == SGP_MOTION_STATIC) out->num_static++; else if (m == SGP_MOTION_DYNAMIC) out->num_dynamic++; else out->num_kinematic++;
+	}
+	// who is awake lives on the device: one read-back of the active ids
+	uint32_t n = 0, m = 0;
+	{ int r = read_active_to_stage(w, w->dv.cap_bodies, &n, &m, true); if (r != SGP_OK) return r; }
+	const sgp_body_pose* poses = (const sgp_body_pose*)w->stage_host;
+	for (uint32_t k = 0; k < m; ++k) {
+		const uint32_t id = poses[k].id;
+		if (id >= w->high) continue;
+		const uint32_t mt = w->hb[id].flags & BF_MOTION_MASK;
+		if (mt == SGP_MOTION_DYNAMIC) out->num_active_dynamic++; else if (mt == SGP_MOTION_KINEMATIC) out->num_active_kinematic++;
+	}
+	for (size_t k = 1; k < w->meshes.size(); ++k) if (w->meshes[k].nt != 0) { out->num_meshes++; out->shape_bytes += sizeof(MeshHeader) + 16ull * w->meshes[k].nv + 16ull * w->meshes[k].nt + sizeof(MeshNode) * (uint64_t)w->meshes[k].n_nodes; }
+	for (size_t k = 1; k < w->hulls.size(); ++k) if (w->hulls[k].nv != 0) { out->num_hulls++; out->shape_bytes += sizeof(sgd_hull); }
+	return SGP_OK;
+}
+
 template <typename T, typename Cmp> static void drain(std::vector<T>& v, void* out, uint32_t cap, uint32_t* n_out, Cmp cmp)
 {
 	std::sort(v.begin(), v.end(), cmp);

@@ -560,27 +560,27 @@ void PhysicsWorld::setLinearAndAngularVelToZero(PhysicsObject& object)
 	if (!object.jolt_body_id.IsInvalid()) { sgp_body_set_vel(world, object.jolt_body_id.GetIndex(), z, z); physics_system->GetBodyInterface().invalidate(); }
 }
 
-// PhysicsWorld.cpp:660-704 (same construction: columns of R scaled, inverse = S^-1 R^T T^-1)
+// Object-to-world and world-to-object matrices of a pose with a (possibly non-uniform) scale; same contract as the free function of
+// PhysicsWorld.cpp:660-704 (a zero scale component is replaced by 1e-6 so that the inverse exists).  Written element-wise:
+//   M = [ R diag(s) | t ],   M^-1 = [ diag(1/s) R^T | -diag(1/s) R^T t ]
 void computeToWorldAndToObMatrices(const Vec4f& translation, const Quatf& rot_quat, const Vec4f& scale, Matrix4f& ob_to_world_out, Matrix4f& world_to_ob_out)
 {
-	Vec4f use_scale = scale;
-	for (int i = 0; i < 3; ++i) if (use_scale[i] == 0) use_scale[i] = 1.0e-6f;
-	const Matrix4f rot = rot_quat.toMatrix();
-	Matrix4f ob_to_world;
-	ob_to_world.setColumn(0, rot.getColumn(0) * use_scale[0]);
-	ob_to_world.setColumn(1, rot.getColumn(1) * use_scale[1]);
-	ob_to_world.setColumn(2, rot.getColumn(2) * use_scale[2]);
-	ob_to_world.setColumn(3, setWToOne(translation));
-	const Matrix4f rot_inv = rot.getTranspose();
-	const Vec4f recip_scale = maskWToZero(div(Vec4f(1.f), use_scale));
-	Matrix4f S_inv_R_inv;
-	for (int c = 0; c < 3; ++c) {
-		const Vec4f col = rot_inv.getColumn(c);
-		S_inv_R_inv.setColumn(c, Vec4f(col[0] * recip_scale[0], col[1] * recip_scale[1], col[2] * recip_scale[2], 0.f));
+	float sc[3], inv_sc[3];
+	for (int k = 0; k < 3; ++k) { sc[k] = scale[k] != 0.f ? scale[k] : 1.0e-6f; inv_sc[k] = 1.f / sc[k]; }
+	const Matrix4f R = rot_quat.toMatrix();
+	Matrix4f fwd = Matrix4f::identity(), inv = Matrix4f::identity();
+	for (int col = 0; col < 3; ++col)
+		for (int row = 0; row < 3; ++row) {
+			const float r = R.e[col * 4 + row];
+			fwd.e[col * 4 + row] = r * sc[col];              // column `col` of R, stretched by that axis' scale
+			inv.e[row * 4 + col] = r * inv_sc[col];          // (R^T) with row `col` divided by the same scale
+		}
+	for (int row = 0; row < 3; ++row) {
+		fwd.e[12 + row] = translation[row];
+		inv.e[12 + row] = -(inv.e[row] * translation[0] + inv.e[4 + row] * translation[1] + inv.e[8 + row] * translation[2]);
 	}
-	S_inv_R_inv.setColumn(3, Vec4f(0, 0, 0, 1));
-	ob_to_world_out = ob_to_world;
-	world_to_ob_out = rightTranslate(S_inv_R_inv, -translation);
+	ob_to_world_out = fwd;
+	world_to_ob_out = inv;
 }
 
 // PhysicsWorld.cpp:707-722
@@ -605,26 +605,54 @@ PhysicsWorld::MemUsageStats PhysicsWorld::getMemUsageStats() const
 {
 	sgp_step_stats s; memset(&s, 0, sizeof(s));
 	sgp_world_stats(world, &s);
-	MemUsageStats m; m.mem = (size_t)s.device_bytes; m.num_meshes = 0;
+	sgp_body_counts c; memset(&c, 0, sizeof(c));
+	sgp_world_body_counts(world, &c);
+	MemUsageStats m; m.mem = (size_t)c.shape_bytes; m.num_meshes = c.num_meshes;      // (the reference sums the bytes of the shapes in use, :1553)
 	m.layer_counts.assign(s.layer_counts, s.layer_counts + Layers::NUM_LAYERS);
 	return m;
 }
+static std::string niceByteSize(size_t x)
+{
+	char buf[64];
+	if (x < 1024) snprintf(buf, sizeof(buf), "%zu B", x);
+	else if (x < (1u << 20)) snprintf(buf, sizeof(buf), "%.3f KB", (double)x / 1024.0);
+	else if (x < (1u << 30)) snprintf(buf, sizeof(buf), "%.3f MB", (double)x / 1048576.0);
+	else snprintf(buf, sizeof(buf), "%.3f GB", (double)x / 1073741824.0);
+	return buf;
+}
+// the counters of the reference's diagnostics window, under its labels (PhysicsWorld.cpp:1578-1604), followed by this backend's own
 std::string PhysicsWorld::getDiagnostics() const
 {
-	sgp_step_stats s; memset(&s, 0, sizeof(s));
-	sgp_world_stats(world, &s);
-	std::string out;
-	out += "Objects: " + std::to_string(s.num_bodies) + "\n";
-	out += "Active bodies: " + std::to_string(s.num_active) + "\n";
-	out += "Body pairs: " + std::to_string(s.num_pairs) + ", contact constraints: " + std::to_string(s.num_manifolds) + ", colours: " + std::to_string(s.num_colours) + "\n";
-	out += "Device mem usage: " + std::to_string(s.device_bytes >> 20) + " MB\n";
-	out += "NON_MOVING layer obs:                " + std::to_string(s.layer_counts[Layers::NON_MOVING]) + "\n";
-	out += "MOVING layer obs:                    " + std::to_string(s.layer_counts[Layers::MOVING]) + "\n";
-	out += "NON_MOVING_NON_COLLIDABLE layer obs: " + std::to_string(s.layer_counts[Layers::NON_MOVING_NON_COLLIDABLE]) + "\n";
-	out += "MOVING_NON_COLLIDABLE layer obs:     " + std::to_string(s.layer_counts[Layers::MOVING_NON_COLLIDABLE]) + "\n";
-	return out;
+	const MemUsageStats stats = getMemUsageStats();
+	sgp_step_stats st; memset(&st, 0, sizeof(st));
+	sgp_world_stats(world, &st);
+	sgp_body_counts c; memset(&c, 0, sizeof(c));
+	sgp_world_body_counts(world, &c);
+	std::string s;
+	s += "Jolt bodies: " + std::to_string(c.num_bodies) + "\n";
+	s += "max bodies: " + std::to_string(c.max_bodies) + "\n";
+	s += "num static bodies: " + std::to_string(c.num_static) + "\n";
+	s += "num dynamic bodies: " + std::to_string(c.num_dynamic) + "\n";
+	s += "num active dynamic bodies: " + std::to_string(c.num_active_dynamic) + "\n";
+	s += "num kinematic bodies: " + std::to_string(c.num_kinematic) + "\n";
+	s += "num active kinematic bodies: " + std::to_string(c.num_active_kinematic) + "\n";
+	{
+		Lock lock(activated_obs_mutex);
+		s += "Active bodies: " + std::to_string(activated_obs.size()) + "\n";
+	}
+	s += "Meshes:  " + std::to_string(stats.num_meshes) + "\n";
+	s += "mem usage: " + niceByteSize(stats.mem) + "\n";
+	s += "NON_MOVING layer obs:                " + std::to_string(stats.layer_counts[Layers::NON_MOVING]) + "\n";
+	s += "MOVING layer obs:                    " + std::to_string(stats.layer_counts[Layers::MOVING]) + "\n";
+	s += "NON_MOVING_NON_COLLIDABLE layer obs: " + std::to_string(stats.layer_counts[Layers::NON_MOVING_NON_COLLIDABLE]) + "\n";
+	s += "MOVING_NON_COLLIDABLE layer obs:     " + std::to_string(stats.layer_counts[Layers::MOVING_NON_COLLIDABLE]) + "\n";
+	// (not in the reference: what the device step saw last)
+	s += "convex hull shapes: " + std::to_string(c.num_hulls) + "\n";
+	s += "body pairs: " + std::to_string(st.num_pairs) + ", contact constraints: " + std::to_string(st.num_manifolds) + ", colours: " + std::to_string(st.num_colours) + "\n";
+	s += "device mem usage: " + niceByteSize((size_t)st.device_bytes) + "\n";
+	return s;
 }
-std::string PhysicsWorld::getLoadedMeshes() const { return std::string(); }
+std::string PhysicsWorld::getLoadedMeshes() const { return std::string(); }      // (the reference's body is commented out too: it returns "", :1607-1622)
 
 // PhysicsWorld.cpp:1625-1638
 const Vec4f PhysicsWorld::getPosInJolt(const Reference<PhysicsObject>& object)

@@ -11,6 +11,9 @@
 #include <utils/ThreadSafeRefCounted.h>
 #include <utils/Mutex.h>
 #include <utils/HashSet.h>
+#include <utils/Array2D.h>
+#include <utils/Exception.h>
+#include <cstring>
 #include <Jolt/Jolt.h>
 #include <Jolt/Physics/Body/BodyID.h>
 #include <Jolt/Physics/Body/BodyActivationListener.h>
@@ -96,6 +99,80 @@ public:
 	// PhysicsWorld.cpp:1086-1119: a heightfield.getWidth() x getWidth() grid of heights (row-major, sample (x, z) at [z * width + x]) in Jolt's
 	// y-up shape space: vertex = (quad_w * x, height, quad_w * z - quad_w * (width - 1)); triangulated here (two triangles per cell, facing +y).
 	static PhysicsShape createJoltHeightFieldShape(int vert_res, const std::vector<float>& heightfield, int width, float quad_w);
+	// ---- the reference's own builder signatures (PhysicsWorld.h:122-127).  Indigo::Mesh, BatchedMesh and js::Vector are glare-core / indigo
+	// types that are not part of this tree, so the three mesh builders are templates over ANY type exposing the members the reference's code
+	// reads (PhysicsWorld.cpp:735-866, 868-1084); with the real headers on the include path the callers' statements -- ModelLoading.cpp:1175,
+	// 1686, MeshBuilding.cpp:148,374 -- compile as written.  They reduce to the array builders above.
+	//   Indigo::Mesh:  vert_positions[i].{x,y,z}; triangles[i].{vertex_indices[3], tri_mat_index}; quads[i].{vertex_indices[4], mat_index}
+	//   BatchedMesh:   vertexSize(), numVerts(), numIndices(), findAttribute(VertAttribute_Position) -> {component_type, offset_B}, vertex_data,
+	//                  aabb_os.{min_, span()} (uint16 positions are dequantised over it), index_data, index_type, batches[b].{indices_start,
+	//                  num_indices, material_index}.  Skinned meshes (joints + weights + animation_data.joint_nodes) are built in their bind
+	//                  pose here; the reference applies the joint matrices first (PhysicsWorld.cpp:885-947).
+	template <class IndigoMeshT>
+	static PhysicsShape createJoltShapeForIndigoMesh(const IndigoMeshT& mesh, bool build_dynamic_physics_ob, glare::Allocator* mem_allocator = nullptr)
+	{
+		(void)mem_allocator;
+		std::vector<Vec3f> verts(mesh.vert_positions.size());
+		for (size_t i = 0; i < verts.size(); ++i) verts[i] = Vec3f(mesh.vert_positions[i].x, mesh.vert_positions[i].y, mesh.vert_positions[i].z);
+		if (build_dynamic_physics_ob) return createConvexHullShape(verts);      // Jolt has no dynamic triangle meshes: the convex hull of the vertices
+		std::vector<uint32> tris; std::vector<uint32> mats;
+		tris.reserve(3 * (mesh.triangles.size() + 2 * mesh.quads.size())); mats.reserve(mesh.triangles.size() + 2 * mesh.quads.size());
+		for (size_t i = 0; i < mesh.triangles.size(); ++i) {
+			for (int k = 0; k < 3; ++k) tris.push_back((uint32)mesh.triangles[i].vertex_indices[k]);
+			mats.push_back((uint32)mesh.triangles[i].tri_mat_index);
+		}
+		for (size_t i = 0; i < mesh.quads.size(); ++i) {       // a quad = the triangles (0, 1, 2) and (0, 2, 3), both with the quad's material
+			const auto& q = mesh.quads[i];
+			const uint32 a = (uint32)q.vertex_indices[0], b = (uint32)q.vertex_indices[1], c = (uint32)q.vertex_indices[2], d = (uint32)q.vertex_indices[3];
+			tris.insert(tris.end(), { a, b, c, a, c, d });
+			mats.push_back((uint32)q.mat_index); mats.push_back((uint32)q.mat_index);
+		}
+		return createMeshShape(verts, tris, &mats);
+	}
+	template <class BatchedMeshT, class BoolVectorT = std::vector<bool>>
+	static PhysicsShape createJoltShapeForBatchedMesh(const BatchedMeshT& mesh, bool build_dynamic_physics_ob, glare::Allocator* mem_allocator = nullptr,
+		const BoolVectorT* create_tris_for_mat = nullptr)
+	{
+		(void)mem_allocator;
+		const size_t vert_size_B = mesh.vertexSize(), num_verts = mesh.numVerts();
+		const auto* pos_attr = mesh.findAttribute(BatchedMeshT::VertAttribute_Position);
+		if (!pos_attr) throw glare::Exception("Pos attribute not present.");
+		if (!(pos_attr->component_type == BatchedMeshT::ComponentType_Float || pos_attr->component_type == BatchedMeshT::ComponentType_UInt16))
+			throw glare::Exception("PhysicsWorld::createJoltShapeForBatchedMesh(): Pos attribute must have float or uint16 type.");
+		const bool pos_is_float = pos_attr->component_type == BatchedMeshT::ComponentType_Float;
+		const Vec4f span = mesh.aabb_os.span(), lo = mesh.aabb_os.min_;
+		std::vector<Vec3f> verts(num_verts);
+		const unsigned char* src = (const unsigned char*)mesh.vertex_data.data();
+		for (size_t i = 0; i < num_verts; ++i) {
+			const unsigned char* p = src + pos_attr->offset_B + i * vert_size_B;
+			if (pos_is_float) { float f[3]; memcpy(f, p, 12); verts[i] = Vec3f(f[0], f[1], f[2]); }
+			else { uint16_t q[3]; memcpy(q, p, 6); verts[i] = Vec3f(lo[0] + span[0] / 65535.f * (float)q[0], lo[1] + span[1] / 65535.f * (float)q[1], lo[2] + span[2] / 65535.f * (float)q[2]); }
+		}
+		if (build_dynamic_physics_ob) return createConvexHullShape(verts);
+		std::vector<uint32> tris, mats;
+		const unsigned char* idx = (const unsigned char*)mesh.index_data.data();
+		for (size_t b = 0; b < mesh.batches.size(); ++b) {
+			const uint32 mat_index = (uint32)mesh.batches[b].material_index;
+			// "should physics triangles be created for this material?" -- materials beyond the vector are kept (PhysicsWorld.cpp:1028)
+			if (create_tris_for_mat && mat_index < create_tris_for_mat->size() && !(*create_tris_for_mat)[mat_index]) continue;
+			const size_t i_begin = mesh.batches[b].indices_start, i_end = i_begin + mesh.batches[b].num_indices / 3 * 3;
+			for (size_t i = i_begin; i < i_end; ++i) {
+				uint32 v;
+				if (mesh.index_type == BatchedMeshT::ComponentType_UInt8) v = idx[i];
+				else if (mesh.index_type == BatchedMeshT::ComponentType_UInt16) { uint16_t t; memcpy(&t, idx + 2 * i, 2); v = t; }
+				else if (mesh.index_type == BatchedMeshT::ComponentType_UInt32) memcpy(&v, idx + 4 * i, 4);
+				else throw glare::Exception("Invalid index type.");
+				tris.push_back(v);
+			}
+			mats.insert(mats.end(), (i_end - i_begin) / 3, mat_index);
+		}
+		return createMeshShape(verts, tris, &mats);
+	}
+	// PhysicsWorld.h:127 / .cpp:1086-1119: heightfield.getWidth() samples per side (vert_res <= width), Jolt's y-up shape space
+	static PhysicsShape createJoltHeightFieldShape(int vert_res, const Array2D<float>& heightfield, float quad_w)
+	{
+		return createJoltHeightFieldShape(vert_res, std::vector<float>(heightfield.getData(), heightfield.getData() + heightfield.getWidth() * heightfield.getHeight()), (int)heightfield.getWidth(), quad_w);
+	}
 	// PhysicsWorld.cpp:1138-1153 (OffsetCenterOfMassShapeSettings); implemented for convex hull shapes.
 	static PhysicsShape createCOMOffsetShapeForShape(const PhysicsShape& original_shape, const Vec4f& COM_offset);
 	static PhysicsShape createScaledAndTranslatedShapeForShape(const PhysicsShape& shape, const Vec3f& translation, const Vec3f& scale);      // PhysicsWorld.h:133

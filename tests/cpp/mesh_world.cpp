@@ -15,6 +15,47 @@
 #include <cstdio>
 #include <cmath>
 #include <string>
+#include <vector>
+#include <algorithm>
+#include <cstring>
+
+// Stand-ins with the members the reference's builders read from glare-core's BatchedMesh and indigo's Indigo::Mesh (absent from this tree);
+// the builders are called with the reference's own signatures (PhysicsWorld.h:122-127).
+struct TestBatchedMesh
+{
+	enum ComponentType { ComponentType_Float, ComponentType_Half, ComponentType_UInt8, ComponentType_UInt16, ComponentType_UInt32, ComponentType_PackedNormal };
+	enum VertAttributeType { VertAttribute_Position, VertAttribute_Normal, VertAttribute_Joints, VertAttribute_Weights };
+	struct VertAttribute { VertAttributeType type; ComponentType component_type; size_t offset_B; };
+	struct IndicesBatch { uint32 indices_start, num_indices, material_index; };
+	struct Bounds { Vec4f min_, max_; Vec4f span() const { return max_ - min_; } };
+	std::vector<VertAttribute> vert_attributes; std::vector<IndicesBatch> batches; std::vector<uint8_t> vertex_data, index_data;
+	ComponentType index_type = ComponentType_UInt16; Bounds aabb_os; size_t vert_size = 0;
+	size_t vertexSize() const { return vert_size; }
+	size_t numVerts() const { return vert_size ? vertex_data.size() / vert_size : 0; }
+	size_t numIndices() const { return index_data.size() / (index_type == ComponentType_UInt8 ? 1 : (index_type == ComponentType_UInt16 ? 2 : 4)); }
+	const VertAttribute* findAttribute(VertAttributeType t) const { for (const VertAttribute& a : vert_attributes) if (a.type == t) return &a; return nullptr; }
+};
+// quantised uint16 positions over the bounds (what BatchedMesh files usually hold), uint16 indices, one batch per material
+static TestBatchedMesh makeBatchedMesh(const std::vector<Vec3f>& v, const std::vector<uint32>& tris, const std::vector<uint32>& tri_mats, const Vec4f& lo, const Vec4f& hi)
+{
+	TestBatchedMesh m;
+	m.vert_size = 8; m.vert_attributes.push_back({ TestBatchedMesh::VertAttribute_Position, TestBatchedMesh::ComponentType_UInt16, 0 });
+	m.aabb_os.min_ = lo; m.aabb_os.max_ = hi;
+	m.vertex_data.resize(v.size() * 8);
+	for (size_t i = 0; i < v.size(); ++i) for (int k = 0; k < 3; ++k) { const uint16_t q = (uint16_t)std::lround((v[i][k] - lo[k]) / (hi[k] - lo[k]) * 65535.f); memcpy(&m.vertex_data[i * 8 + 2 * k], &q, 2); }
+	uint32 max_mat = 0; for (uint32 x : tri_mats) max_mat = std::max(max_mat, x);
+	for (uint32 mat = 0; mat <= max_mat; ++mat) {
+		TestBatchedMesh::IndicesBatch b = { (uint32)(m.index_data.size() / 2), 0, mat };
+		for (size_t t = 0; t < tri_mats.size(); ++t) if (tri_mats[t] == mat) for (int k = 0; k < 3; ++k) { const uint16_t ix = (uint16_t)tris[3 * t + k]; m.index_data.push_back((uint8_t)(ix & 0xFF)); m.index_data.push_back((uint8_t)(ix >> 8)); b.num_indices++; }
+		if (b.num_indices) m.batches.push_back(b);
+	}
+	return m;
+}
+struct TestIndigoMesh
+{
+	struct V3 { float x, y, z; }; struct Triangle { uint32 vertex_indices[3]; uint32 uv_indices[3]; uint32 tri_mat_index; }; struct Quad { uint32 vertex_indices[4]; uint32 uv_indices[4]; uint32 mat_index; };
+	std::vector<V3> vert_positions; std::vector<Triangle> triangles; std::vector<Quad> quads;
+};
 
 static float terrainHeight(float x, float y) { return 0.8f * std::sin(0.25f * x) * std::cos(0.2f * y) + 0.05f * x; }
 
@@ -26,9 +67,9 @@ int main()
 		// height field: 64 x 64 samples, 1 m quads.  Shape space (X, height, Z - 63); the object rotation maps y -> z (up), z -> -y,
 		// so world x = X, world y = 63 - Z... = sample z index counted downwards from the object's origin
 		const int W = 64; const float quad_w = 1.0f;
-		std::vector<float> heights((size_t)W * W);
-		for (int z = 0; z < W; ++z) for (int x = 0; x < W; ++x) heights[(size_t)z * W + x] = terrainHeight((float)x * quad_w - 32.f, 31.f - (float)z * quad_w + 0.f);
-		Reference<PhysicsObject> terrain = new PhysicsObject(true, PhysicsWorld::createJoltHeightFieldShape(W, heights, W, quad_w), nullptr, 0);
+		Array2D<float> heights(W, W);                                                    // (TerrainSystem.cpp:1300: createJoltHeightFieldShape(res, heightfield, quad_w))
+		for (int z = 0; z < W; ++z) for (int x = 0; x < W; ++x) heights.elem(x, z) = terrainHeight((float)x * quad_w - 32.f, 31.f - (float)z * quad_w + 0.f);
+		Reference<PhysicsObject> terrain = new PhysicsObject(true, PhysicsWorld::createJoltHeightFieldShape(W, heights, quad_w), nullptr, 0);
 		terrain->rot = Quatf::fromAxisAndAngle(Vec4f(1, 0, 0, 0), 1.5707963f);          // y-up shape space -> z-up world
 		terrain->pos = Vec4f(-32.f, -32.f, 0.f, 1);                                      // world x = X - 32, world y = -(Z - 63) - 32 = 31 - z index
 		world->addObject(terrain);
@@ -43,12 +84,15 @@ int main()
 		std::vector<uint32> bmat;
 		for (int i = 0; i < 4; ++i) { bmat.push_back(i + 1); bmat.push_back(i + 1); }
 		bmat.push_back(5); bmat.push_back(5);
-		Reference<PhysicsObject> building = new PhysicsObject(true, PhysicsWorld::createMeshShape(bv, bt, &bmat), nullptr, 0);
+		// ... as a BatchedMesh (uint16 positions quantised over its bounds, one index batch per material), through the reference's signature
+		// (ModelLoading.cpp:1686: createJoltShapeForBatchedMesh(*batched_mesh, /*is dynamic=*/false, mem_allocator))
+		const TestBatchedMesh building_mesh = makeBatchedMesh(bv, bt, bmat, Vec4f(-h, -h, z0, 1), Vec4f(h, h, z1, 1));
+		Reference<PhysicsObject> building = new PhysicsObject(true, PhysicsWorld::createJoltShapeForBatchedMesh(building_mesh, /*build_dynamic_physics_ob=*/false, /*mem_allocator=*/nullptr), nullptr, 0);
 		building->pos = Vec4f(10.f, 10.f, 0.f, 1);
 		world->addObject(building);
 		// the same mesh with create_tris_for_mat[5] = false (MeshBuilding.cpp:392-393): no roof triangles
 		std::vector<bool> create_tris_for_mat(6, true); create_tris_for_mat[5] = false;
-		Reference<PhysicsObject> roofless = new PhysicsObject(true, PhysicsWorld::createMeshShape(bv, bt, &bmat, &create_tris_for_mat), nullptr, 0);
+		Reference<PhysicsObject> roofless = new PhysicsObject(true, PhysicsWorld::createJoltShapeForBatchedMesh(building_mesh, false, nullptr, &create_tris_for_mat), nullptr, 0);
 		roofless->pos = Vec4f(-20.f, -20.f, 0.f, 1);
 		world->addObject(roofless);
 
@@ -132,7 +176,21 @@ int main()
 			for (int i = 0; i < 8; ++i) cv.push_back(Vec3f((float)(i & 1), (float)((i >> 1) & 1), (float)((i >> 2) & 1)));
 			const uint32 quads[6][4] = { { 0, 2, 3, 1 }, { 4, 5, 7, 6 }, { 0, 1, 5, 4 }, { 2, 6, 7, 3 }, { 0, 4, 6, 2 }, { 1, 3, 7, 5 } };      // outward-facing
 			for (int q = 0; q < 6; ++q) { ct.push_back(quads[q][0]); ct.push_back(quads[q][1]); ct.push_back(quads[q][2]); ct.push_back(quads[q][0]); ct.push_back(quads[q][2]); ct.push_back(quads[q][3]); }
-			const PhysicsShape unit_cube = PhysicsWorld::createMeshShape(cv, ct);
+			// (MeshBuilding.cpp:148: createJoltShapeForIndigoMesh(*indigo_mesh, /*build_dynamic_physics_ob=*/false) -- the cube as six quads)
+			TestIndigoMesh cube_mesh;
+			for (const Vec3f& v : cv) cube_mesh.vert_positions.push_back({ v.x, v.y, v.z });
+			for (int q = 0; q < 6; ++q) { TestIndigoMesh::Quad qd = {}; for (int k = 0; k < 4; ++k) qd.vertex_indices[k] = quads[q][k]; qd.mat_index = (uint32)q; cube_mesh.quads.push_back(qd); }
+			const PhysicsShape unit_cube = PhysicsWorld::createJoltShapeForIndigoMesh(cube_mesh, /*build_dynamic_physics_ob=*/false);
+			// ... and the same mesh as a DYNAMIC object: the convex hull of its vertices (PhysicsWorld.cpp:746-768)
+			{
+				Reference<PhysicsObject> crate = new PhysicsObject(true, PhysicsWorld::createJoltShapeForIndigoMesh(cube_mesh, /*build_dynamic_physics_ob=*/true), nullptr, 0);
+				crate->motion_type = PhysicsObject::MotionType_dynamic; crate->mass = 30.f; crate->pos = Vec4f(40.f, 40.f, 20.f, 1);
+				world->addObject(crate); world->activateObject(crate);
+				for (int k = 0; k < 30; ++k) world->think(1.0 / 60.0);
+				const bool fell = world->getPosInJolt(crate)[2] < 19.f;
+				if (!fell) printf("dynamic hull of the cube mesh did not fall\n");
+				ok = ok && fell;
+			}
 			Reference<PhysicsObject> bounds = new PhysicsObject(true, PhysicsWorld::createScaledAndTranslatedShapeForShape(unit_cube, Vec3f(-1.f, -2.f, 0.f), Vec3f(2.f, 4.f, 1.5f)), nullptr, 0);
 			bounds->pos = Vec4f(-12.f, 12.f, 8.f, 1);
 			world->addObject(bounds);
@@ -151,6 +209,32 @@ int main()
 			char magic[9] = { 0 }; const bool snap = f && fread(magic, 1, 8, f) == 8 && std::string(magic) == "SGPSNAP1";
 			if (f) fclose(f);
 			ok = ok && snap && PhysicsWorld::computeSizeBForShape(building->shape) > sizeof(PhysicsShape);
+		}
+		{      // computeToWorldAndToObMatrices (PhysicsWorld.cpp:660-704): the two matrices are each other's inverse, also with a zero scale component
+			Matrix4f a, b;
+			const Quatf q = Quatf::fromAxisAndAngle(normalise(Vec4f(0.3f, -0.5f, 0.8f, 0)), 1.1f);
+			computeToWorldAndToObMatrices(Vec4f(3.f, -2.f, 7.f, 1), q, Vec4f(2.f, 0.5f, 1.5f, 0), a, b);
+			const Matrix4f prod = a * b;
+			float err = 0;
+			for (int i = 0; i < 16; ++i) err = std::fmax(err, std::fabs(prod.e[i] - ((i % 5 == 0) ? 1.f : 0.f)));
+			const Vec4f back = b * (a * Vec4f(0.25f, -1.f, 2.f, 1));
+			Matrix4f c0, c1;
+			computeToWorldAndToObMatrices(Vec4f(0, 0, 0, 1), Quatf::identity(), Vec4f(1.f, 0.f, 1.f, 0), c0, c1);
+			const bool mats = err < 1e-5f && std::fabs(back[0] - 0.25f) < 1e-5f && std::fabs(back[1] + 1.f) < 1e-5f && std::fabs(back[2] - 2.f) < 1e-5f && c0.e[5] == 1.0e-6f && std::isfinite(c1.e[5]);
+			if (!mats) printf("computeToWorldAndToObMatrices: err %g\n", err);
+			ok = ok && mats;
+		}
+		{      // the diagnostics window's counters under the reference's labels (PhysicsWorld.cpp:1578-1604)
+			const std::string diag = world->getDiagnostics();
+			const char* labels[] = { "Jolt bodies: ", "max bodies: ", "num static bodies: ", "num dynamic bodies: ", "num active dynamic bodies: ", "num kinematic bodies: ",
+				"num active kinematic bodies: ", "Active bodies: ", "Meshes:  ", "mem usage: ", "NON_MOVING layer obs:                ", "MOVING layer obs:                    ",
+				"NON_MOVING_NON_COLLIDABLE layer obs: ", "MOVING_NON_COLLIDABLE layer obs:     " };
+			size_t at = 0; bool labels_ok = true;
+			for (const char* l : labels) { const size_t f = diag.find(l, at); if (f == std::string::npos) { labels_ok = false; printf("diagnostics lack '%s'\n", l); break; } at = f; }
+			const PhysicsWorld::MemUsageStats mu = world->getMemUsageStats();
+			const bool counts_ok = mu.num_meshes >= 4 && mu.mem > 0 && diag.find("num static bodies: 0") == std::string::npos && world->getLoadedMeshes().empty();
+			if (!counts_ok) printf("diagnostics:\n%s", diag.c_str());
+			ok = ok && labels_ok && counts_ok;
 		}
 		printf("rays ok %d\n", (int)ok);
 
