@@ -938,10 +938,14 @@ __global__ void __launch_bounds__(64, 3) k_narrowphase_hull_manifold(DV d)
 // (round 2: 205 B, of which 64 B were the per-step solver record this layout no longer has).
 __global__ void __launch_bounds__(TPB) k_pre_solve(DV d)
 {
-	const float dt = d.sp->dt;
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-	if (i >= d.sp->n_slots) return;
+	if (i >= d.cap_bodies) return;
+	// everything an awake body needs is requested at once, next to the flags that say whether it is needed (one memory round trip instead of two)
 	const uint32_t f0 = d.flags[i];
+	const float4 lv4 = d.vel[2 * (size_t)i], av4 = d.vel[2 * (size_t)i + 1];
+	const float4 dy = d.dyn[i];                                        // linear damping, angular damping, gravity factor, inverse mass
+	const float dt = d.sp->dt;
+	if (i >= d.sp->n_slots) return;
 	uint32_t f = f0;
 	if (!(f & BF_ALIVE)) return;
 	const bool was_movable = f_movable(f);
@@ -952,8 +956,6 @@ __global__ void __launch_bounds__(TPB) k_pre_solve(DV d)
 		reset_sleep(d, i, f_shape(f), d.prop[2 * (size_t)i + 1], V3(d.pose[2 * (size_t)i]), Q4(d.pose[2 * (size_t)i + 1]));
 	}
 	if ((f & BF_ACTIVE) && f_motion(f) != SGP_MOTION_STATIC) {
-		const float4 lv4 = d.vel[2 * (size_t)i], av4 = d.vel[2 * (size_t)i + 1];
-		const float4 dy = d.dyn[i];                                    // linear damping, angular damping, gravity factor, inverse mass
 		v3 lv = V3(lv4), av = V3(av4);
 		float im = 0.0f;
 		if (f_movable(f)) {
@@ -2399,13 +2401,14 @@ __global__ void __launch_bounds__(TPB) k_integrate_pose(DV d)
 	// part 2 of 3 of the body-array sweep: the pose of every active non-static body advances by its solved velocities, in place; the position
 	// iterations then correct the pose records directly.  Traffic per body: flags 4 + velocity record 32 + pose record 32 read, pose record 32
 	// written = 100 B (round 2: 213 B -- it also copied the velocities back to their arrays and built a 48 B pose record per body).
-	const float dt = d.sp->dt;
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-	if (i >= d.sp->n_slots) return;
-	const uint32_t f = d.flags[i];
-	if ((f & (BF_ALIVE | BF_ACTIVE)) != (BF_ALIVE | BF_ACTIVE) || f_motion(f) == SGP_MOTION_STATIC) return;
+	if (i >= d.cap_bodies) return;
+	const uint32_t f = d.flags[i];                                      // (flags and records requested together: one memory round trip)
 	const float4 v4 = d.vel[2 * (size_t)i], w4 = d.vel[2 * (size_t)i + 1];
 	float4 p = d.pose[2 * (size_t)i], r4 = d.pose[2 * (size_t)i + 1];
+	const float dt = d.sp->dt;
+	if (i >= d.sp->n_slots) return;
+	if ((f & (BF_ALIVE | BF_ACTIVE)) != (BF_ALIVE | BF_ACTIVE) || f_motion(f) == SGP_MOTION_STATIC) return;
 	v3 lv = V3(v4), av = V3(w4);
 	if (f_motion(f) == SGP_MOTION_DYNAMIC) {
 		const float l2 = v3_len_sq(lv), ml = d.st.max_linear_velocity;
@@ -2430,17 +2433,21 @@ __global__ void __launch_bounds__(TPB) k_integrate_pose(DV d)
 // (round 2: 269 B -- it also wrote the pose back from the solver record and rewrote every sphere and the flags every step).
 __global__ void __launch_bounds__(TPB) k_finalize(DV d)
 {
-	const float dt = d.sp->dt;
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i >= d.cap_bodies) return;
+	uint32_t f = d.flags[i];                                            // (flags and records requested together: one memory round trip)
+	const float4 sh = d.prop[2 * (size_t)i + 1];
+	const float4 p4 = d.pose[2 * (size_t)i], r4 = d.pose[2 * (size_t)i + 1];      // (the position iterations corrected the pose records in place)
+	float4 s[3];
+	for (int k = 0; k < 3; ++k) s[k] = d.sleep_s[k][i];
+	const float timer = d.sleep_timer[i];
+	const float dt = d.sp->dt;
 	if (i >= d.sp->n_slots) return;
 	d.island[i] = i;
 	d.island_awake[i] = 0;
 	d.awake_mark[i] = 0;
-	uint32_t f = d.flags[i];
 	if ((f & (BF_ALIVE | BF_ACTIVE)) != (BF_ALIVE | BF_ACTIVE)) return;
 	const uint32_t type = f_shape(f);
-	const float4 sh = d.prop[2 * (size_t)i + 1];
-	const float4 p4 = d.pose[2 * (size_t)i], r4 = d.pose[2 * (size_t)i + 1];      // (the position iterations corrected the pose records in place)
 	const v3 pos = V3(p4);
 	const quat q = Q4(r4);
 	v3 mn, mx;
@@ -2455,10 +2462,8 @@ __global__ void __launch_bounds__(TPB) k_finalize(DV d)
 		v3 pts[3];
 		sleep_points(d, type, sh, pos, q, pts);
 		bool reset = false;
-		float4 s[3];
 		bool grew[3];
 		for (int k = 0; k < 3; ++k) {
-			s[k] = d.sleep_s[k][i];
 			const v3 dd = v3_sub(pts[k], V3(s[k]));
 			const float d2 = v3_len_sq(dd);
 			grew[k] = d2 > s[k].w * s[k].w;
@@ -2476,7 +2481,7 @@ __global__ void __launch_bounds__(TPB) k_finalize(DV d)
 			can_sleep = false;
 		} else {
 			for (int k = 0; k < 3; ++k) if (grew[k]) d.sleep_s[k][i] = s[k];      // (a test point still inside its sphere leaves the sphere as it is)
-			const float t = d.sleep_timer[i] + dt;
+			const float t = timer + dt;
 			d.sleep_timer[i] = t;
 			can_sleep = t >= d.st.time_before_sleep;
 		}
