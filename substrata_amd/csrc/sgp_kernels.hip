@@ -1504,6 +1504,12 @@ __global__ void __launch_bounds__(TPB) k_warm_bodies(DV d)
 // The lever-arm products of every (point, axis) come precomputed from k_setup (axis_rows); they are the very values the expressions
 // cross(r, axis) and I (r x axis) would yield here, so the arithmetic -- and every bit of the result -- is that of the plain
 // formulation (apply_impulse / axis_jv above, which the warm start and the oracle use), at less than half the instructions.
+// The value the neighbouring lane (lane ^ 1) holds: a DPP quad permutation [1, 0, 3, 2] -- a register move modifier, where __shfl_xor compiles to
+// ds_bpermute_b32, a round trip through the LDS crossbar that sat on the dependent chain of every row of every constraint.
+SGP_DEV float lane_swap1(float x)
+{
+	return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));
+}
 struct AxisRows { float4 c1, c2, i1, i2; };      // r1 x axis (w: bias), r2 x axis (w: effective mass), I1 (r1 x axis), I2 (r2 x axis)
 
 SGP_DEV AxisRows load_axis_rows(const DV& d, uint32_t slot, int point, int axis)
@@ -1567,11 +1573,11 @@ SGP_DEV void half_load_rows(const DV& d, uint32_t slot, int side, ConHalf& h)
 				const float4 i4 = p[(size_t)(2 + side) * st];    // I1 (r1 x axis) / I2 (r2 x axis) (w of point 0: the stored tangent, see k_setup)
 				h.c[i][a] = V3(c4); h.iv[i][a] = V3(i4);
 				// what the other lane holds in its .w components: effective masses (lane 1), the bias (lane 0), the tangent (x, z: lane 0; y: lane 1)
-				const float ow = __shfl_xor(c4.w, 1, 64);
+				const float ow = lane_swap1(c4.w);
 				h.eff[i][a] = side ? c4.w : ow;
 				if (a == 0) h.bias[i] = side ? ow : c4.w;
 				if (i == 0 && a < 2) {
-					const float oi = __shfl_xor(i4.w, 1, 64);
+					const float oi = lane_swap1(i4.w);
 					if (a == 0) { h.t1.x = side ? oi : i4.w; h.t1.y = side ? i4.w : oi; } else h.t1.z = side ? oi : i4.w;
 				}
 			}
@@ -1606,7 +1612,7 @@ SGP_DEV void half_store(const DV& d, uint32_t slot, int side, const ConHalf& h)
 SGP_DEV float half_jv(v3 lv, v3 av, v3 axis, v3 c, int side)
 {
 	const float mine = v3_dot(axis, lv) + v3_dot(c, av);
-	const float other = __shfl_xor(mine, 1, 64);
+	const float other = lane_swap1(mine);
 	return side ? other - mine : mine - other;
 }
 SGP_DEV void half_apply(v3& lv, v3& av, float im, v3 axis, v3 iv, float lambda, int side)
@@ -1758,7 +1764,7 @@ SGP_DEV void pos_half_solve(const DV& d, const PosHalf& ph, int side, float4* re
 	for (int i = 0; i < 4; ++i) {
 		if (i >= np) continue;
 		const v3 mine = v3_add(pos, m33_mul(R, ph.loc[i]));
-		const v3 other = V3(__shfl_xor(mine.x, 1, 64), __shfl_xor(mine.y, 1, 64), __shfl_xor(mine.z, 1, 64));
+		const v3 other = V3(lane_swap1(mine.x), lane_swap1(mine.y), lane_swap1(mine.z));
 		const v3 p1 = side ? other : mine, p2 = side ? mine : other;
 		float sep = v3_dot(v3_sub(p2, p1), nrm) + d.st.penetration_slop;
 		if (sep < 0.0f) {
@@ -1769,7 +1775,7 @@ SGP_DEV void pos_half_solve(const DV& d, const PosHalf& ph, int side, float4* re
 			v3 Ic = V3(0.0f, 0.0f, 0.0f);
 			float share = 0.0f;
 			if (im > 0.0f) { const v3 c = v3_cross(r, nrm); Ic = sym33_mul(world_inv_inertia(R, ii), c); share = im + v3_dot(Ic, c); }
-			const float oshare = __shfl_xor(share, 1, 64);
+			const float oshare = lane_swap1(share);
 			const float s1 = side ? oshare : share, s2 = side ? share : oshare;
 			// (axis_eff_mass adds body 2's share to body 1's only when body 2 can move, and starts from it when body 1 cannot: x + 0 and 0 + x are exact)
 			const float inv = s1 + s2;
