@@ -143,6 +143,17 @@ static inline float sgo_cast_sphere_tri(v3 o, v3 d, v3 a, v3 b, v3 c, float max_
 	nt = v3_scale(nt, 1.0f / l);
 	float best = -1.0f; v3 bn = nt; float lim = max_t;
 	const v3 off = v3_scale(nt, rs);
+	if (rs > 0.0f && v3_dot(d, nt) < 0.0f) {
+		/* the sphere STARTS in touch with the face's interior (centre less than rs in front of the plane, its foot point inside the triangle)
+		   and moves into it: that is a hit at distance 0 (JPH::CastShape reports fraction 0 for an initial overlap); the offset-plane test
+		   below only sees a centre that is still in front of the offset plane */
+		const float h = v3_dot(v3_sub(o, a), nt);
+		if (h >= 0.0f && h < rs) {
+			const v3 q = v3_sub(o, v3_scale(nt, h));
+			const float e0 = v3_dot(v3_cross(v3_sub(b, a), v3_sub(q, a)), nt), e1 = v3_dot(v3_cross(v3_sub(c, b), v3_sub(q, b)), nt), e2 = v3_dot(v3_cross(v3_sub(a, c), v3_sub(q, c)), nt);
+			if (e0 >= 0.0f && e1 >= 0.0f && e2 >= 0.0f) { *n_out = nt; return 0.0f; }
+		}
+	}
 	const float tf = sgo_ray_tri(o, d, v3_add(a, off), v3_add(b, off), v3_add(c, off), lim);
 	if (tf >= 0.0f) { best = tf; bn = nt; lim = tf; }
 	if (rs > 0.0f) {

@@ -84,6 +84,13 @@ def test_back_faces_do_not_collide_and_queries(oracle):
     r2 = rays[:1].copy(); r2["origin"] = (10.3, 0, 9)
     c2 = w.spherecast(r2, [0.5])
     assert c2[0]["id"] == mid and abs(c2[0]["t"] - (4.0 - np.sqrt(0.25 - 0.09))) < 1e-4 and c2[0]["normal"][0] > 0.5
+    # a sphere that STARTS in touch with the face's interior and moves into it is a hit at distance 0 (JPH::CastShape: fraction 0 on initial
+    # overlap); moving away from the face it is not, and just out of reach (centre one radius + a little above) it is an ordinary hit
+    r3 = rays[:3].copy(); r3["origin"] = [(1, 1, 5.3), (1, 1, 5.3), (1, 1, 5.6)]; r3["dir"] = [(0, 0, -1), (0, 0, 1), (0, 0, -1)]
+    c3 = w.spherecast(r3, [0.5, 0.5, 0.5])
+    assert c3[0]["id"] == mid and c3[0]["t"] == 0.0 and c3[0]["normal"][2] > 0.999
+    assert c3[1]["id"] == abi.INVALID_ID
+    assert c3[2]["id"] == mid and abs(c3[2]["t"] - 0.1) < 1e-5
     # capsule query: standing on the floor with the controller's margins
     q = np.zeros(1, dtype=abi.capsule_query_dtype)
     q["pos"] = (2, 2, 5.0 + 0.95 + 0.02); q["rot"] = (0, 0, 0, 1); q["radius"] = 0.3; q["half_height"] = 0.65; q["max_separation"] = 0.12; q["ignore_id"] = abi.INVALID_ID
