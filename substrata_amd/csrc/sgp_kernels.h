@@ -146,7 +146,8 @@ struct StepParams {
 	int      water_enabled; float water_z;
 	int      contact_events;
 	uint32_t parity;           // which of DV::ca[] is the current constraint buffer (the other one is the contact cache)
-	uint32_t pad[7];
+	uint32_t compact_rows;     // 1: the velocity rows hold only r x axis (96 B per point); I (r x axis) is recomputed by the lane that needs it (bandwidth-bound worlds)
+	uint32_t pad[6];
 };
 
 // Constraint (contact manifold) SoA, double buffered (current step / previous step = contact cache).

@@ -1216,6 +1216,7 @@ SGP_DEV void write_axis_rows(const DV& d, uint32_t slot, int point, int axis, v3
 	const size_t st = d.cap_manifolds;
 	p[0] = F4(c1, w0);
 	p[st] = F4(c2, w1);
+	if (d.sp->compact_rows) return;                  // (a million-body world streams its rows from HBM in every pass: half the bytes, a few flops more)
 	p[2 * st] = F4(sym33_mul(I1, c1), w2);
 	p[3 * st] = F4(sym33_mul(I2, c2), w3);
 }
@@ -1561,6 +1562,27 @@ SGP_DEV void half_load_rows(const DV& d, uint32_t slot, int side, ConHalf& h)
 {
 	const int np = h.np_col & 0xFF;
 	const size_t st = d.cap_manifolds;
+	if (d.sp->compact_rows) {
+		// compact rows: r x axis only; this lane rebuilds I (r x axis) from its body's pose and inertia records -- the same function of the same
+		// operands k_setup evaluates for the full rows, hence the same bits
+		const sym33 I = body_world_inv_inertia(d, h.body);
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			if (i == 0 || i < np) {
+#pragma unroll
+				for (int a = 0; a < 3; ++a) {
+					const float4 c4 = axis_rows(d, slot, i, a)[(size_t)side * st];
+					h.c[i][a] = V3(c4); h.iv[i][a] = sym33_mul(I, V3(c4));
+					const float ow = lane_swap1(c4.w);
+					h.eff[i][a] = side ? c4.w : ow;
+					if (a == 0) h.bias[i] = side ? ow : c4.w;
+				}
+				h.lam[i] = V3(CUR(d).lam[i][slot]);
+			}
+		}
+		h.t1 = v3_normalized_perpendicular(V3(h.nf));
+		return;
+	}
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
 		// (point 0 is read without waiting for the point count -- the slot's rows exist whatever they hold, and only a sensor pair has none
