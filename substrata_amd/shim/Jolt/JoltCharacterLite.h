@@ -77,10 +77,15 @@ namespace JPH
 		float mMinTimeRemaining = 1.0e-4f;
 	};
 
-	class CharacterVirtual
+	// (Jolt declares the ground state in CharacterBase, which Character and CharacterVirtual derive from: PlayerPhysics.cpp:226-233 names it there)
+	class CharacterBase
 	{
 	public:
 		enum class EGroundState { OnGround, OnSteepGround, NotSupported, InAir };
+	};
+	class CharacterVirtual : public CharacterBase
+	{
+	public:
 		struct ExtendedUpdateSettings
 		{
 			Vec3 mStickToFloorStepDown = Vec3(0, -0.5f, 0), mWalkStairsStepUp = Vec3(0, 0.4f, 0);

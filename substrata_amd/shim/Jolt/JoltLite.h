@@ -43,6 +43,20 @@ namespace JPH
 	inline Vec3 operator*(float f, const Vec3& v) { return Vec3(v.x * f, v.y * f, v.z * f); }
 	struct Float3 { float x, y, z; };
 	struct Float4 { float x, y, z, w; };
+	// Jolt/Math/Math.h: the scalar helpers the controllers use (BikePhysics.cpp:442,939)
+	static const float JPH_PI = 3.14159265358979323846f;
+	inline float DegreesToRadians(float d) { return d * (JPH_PI / 180.0f); }
+	inline float RadiansToDegrees(float r) { return r * (180.0f / JPH_PI); }
+	template <class T> inline T Square(T v) { return v * v; }
+	// the four floats a Quat is made from (JoltUtils.h:50 builds a Quat from one)
+	class Vec4
+	{
+	public:
+		Vec4() : x(0), y(0), z(0), w(0) {}
+		Vec4(float x_, float y_, float z_, float w_) : x(x_), y(y_), z(z_), w(w_) {}
+		float GetX() const { return x; } float GetY() const { return y; } float GetZ() const { return z; } float GetW() const { return w; }
+		float x, y, z, w;
+	};
 	typedef Vec3 Vec3Arg_; // (Vec3Arg / RVec3Arg proper are declared in JoltCharacterLite.h)
 	typedef Vec3 RVec3;
 	class BodyID
@@ -79,6 +93,7 @@ namespace JPH
 	public:
 		Quat() : x(0), y(0), z(0), w(1) {}
 		Quat(float x_, float y_, float z_, float w_) : x(x_), y(y_), z(z_), w(w_) {}
+		explicit Quat(const Vec4& v) : x(v.x), y(v.y), z(v.z), w(v.w) {}
 		float GetX() const { return x; } float GetY() const { return y; } float GetZ() const { return z; } float GetW() const { return w; }
 		Quat Conjugated() const { return Quat(-x, -y, -z, w); }
 		static Quat sIdentity() { return Quat(0, 0, 0, 1); }

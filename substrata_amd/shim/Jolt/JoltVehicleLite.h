@@ -15,8 +15,7 @@
 namespace JPH
 {
 	typedef uint16_t ObjectLayer;
-	static const float JPH_PI = 3.14159265358979323846f;
-	inline float DegreesToRadians(float d) { return d * (JPH_PI / 180.0f); }
+
 
 	class LinearCurve
 	{
