@@ -88,6 +88,11 @@ struct StepCounters {
 	uint32_t round_n[32];        // uncoloured manifolds at the start of colouring round r (the host plans the next step's wide rounds from it)
 	uint32_t colour_count[SGP_MAX_COLOURS];
 	uint32_t colour_fill[SGP_MAX_COLOURS];
+	// (colour, point-count class) buckets: a colour's slots are laid out by point count (4, 3, 2, <= 1 points: the longest first) so that a wave holds manifolds of one
+	// length -- a wave runs as long as its longest manifold, and unsorted nearly every wave of a mixed pile held a four-point one
+	uint32_t cnp_count[SGP_MAX_COLOURS * 4];
+	uint32_t cnp_start[SGP_MAX_COLOURS * 4];
+	uint32_t cnp_fill[SGP_MAX_COLOURS * 4];
 };
 
 // Event counters: NOT cleared at step start (edits between steps also raise activation events); the host drains them.

@@ -1097,7 +1097,9 @@ __global__ void __launch_bounds__(TPB) k_colour_commit(DV d, uint32_t round)
 __global__ void __launch_bounds__(TPB) k_colour_count(DV d)
 {
 	__shared__ uint32_t hist[SGP_MAX_COLOURS + 3];
+	__shared__ uint32_t hist4[SGP_MAX_COLOURS * 4];
 	if (threadIdx.x < SGP_MAX_COLOURS + 3) hist[threadIdx.x] = 0;
+	hist4[threadIdx.x] = 0;                                   // (TPB = 256 = 64 colours x 4 classes)
 	__syncthreads();
 	const uint32_t n = min(d.ctr->n_manifolds, d.cap_manifolds);
 	uint32_t my_points = 0, my_cons = 0, my_cached = 0;          // the totals are summed per thread and reduced per wave: one LDS atomic per wave, not per manifold
@@ -1105,13 +1107,14 @@ __global__ void __launch_bounds__(TPB) k_colour_count(DV d)
 		const int c = d.man_colour[m];
 		if (c < 0) continue;
 		atomicAdd(&hist[c], 1u);
-		{ const int npb = __float_as_int(d.man_n[m].w); my_points += (npb & 0x100) ? 0u : (uint32_t)(npb & 0xFF); }
+		{ const int npb = __float_as_int(d.man_n[m].w); const uint32_t np = (npb & 0x100) ? 0u : (uint32_t)(npb & 0xFF); my_points += np; atomicAdd(&hist4[c * 4 + (np <= 1u ? 3u : 4u - np)], 1u); }      // (class 0 = four points ... class 3 = at most one: the long manifolds get the first slots, so their waves start first)
 		my_cons += 1u;
 		my_cached += (d.man_prev[m] & MAN_PREV_REUSED) ? 1u : 0u;      // (statistics: manifolds taken from the body-pair contact cache)
 	}
 	for (int off = 32; off > 0; off >>= 1) { my_points += __shfl_down(my_points, off, 64); my_cons += __shfl_down(my_cons, off, 64); my_cached += __shfl_down(my_cached, off, 64); }
 	if ((threadIdx.x & 63) == 0) { if (my_points) atomicAdd(&hist[SGP_MAX_COLOURS], my_points); if (my_cons) atomicAdd(&hist[SGP_MAX_COLOURS + 1], my_cons); if (my_cached) atomicAdd(&hist[SGP_MAX_COLOURS + 2], my_cached); }
 	__syncthreads();
+	if (hist4[threadIdx.x]) atomicAdd(&d.ctr->cnp_count[threadIdx.x], hist4[threadIdx.x]);
 	if (threadIdx.x < SGP_MAX_COLOURS) { if (hist[threadIdx.x]) atomicAdd(&d.ctr->colour_count[threadIdx.x], hist[threadIdx.x]); }
 	else if (threadIdx.x == SGP_MAX_COLOURS) { if (hist[SGP_MAX_COLOURS]) atomicAdd(&d.ctr->n_points, hist[SGP_MAX_COLOURS]); }
 	else if (threadIdx.x == SGP_MAX_COLOURS + 1) { if (hist[SGP_MAX_COLOURS + 1]) atomicAdd(&d.ctr->n_constraints, hist[SGP_MAX_COLOURS + 1]); }
@@ -1182,16 +1185,27 @@ __global__ void __launch_bounds__(1024) k_colour_finish(DV d, uint32_t first_rou
 }
 
 // exclusive scan of the colour histogram -> first slot of every colour, on the device (no host round trip)
-__global__ void __launch_bounds__(64) k_colour_scan(DV d)
+__global__ void __launch_bounds__(256) k_colour_scan(DV d)
 {
-	const int c = threadIdx.x;
-	const uint32_t v = d.ctr->colour_count[c];
+	// buckets in (colour, point-count class) order: the start of a colour is the start of its first class
+	__shared__ uint32_t wsum[4];
+	const int b = threadIdx.x, lane = b & 63, wave = b >> 6;
+	const uint32_t v = d.ctr->cnp_count[b];
 	uint32_t x = v;
-	for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off, 64); if (c >= off) x += y; }
-	d.cstarts[c] = x - v;
-	if (c == 63) d.cstarts[64] = x;
-	const unsigned long long used = __ballot(v != 0 && c < SGP_OVERFLOW_COLOUR);
-	if (c == 0) d.ctr->n_colours = used ? 64u - (uint32_t)__clzll(used) : 0u;
+	for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off, 64); if (lane >= off) x += y; }
+	if (lane == 63) wsum[wave] = x;
+	__syncthreads();
+	uint32_t base = 0;
+	for (int k = 0; k < wave; ++k) base += wsum[k];
+	const uint32_t start = base + x - v;
+	d.ctr->cnp_start[b] = start;
+	if ((b & 3) == 0) d.cstarts[b >> 2] = start;
+	if (b == 255) d.cstarts[SGP_MAX_COLOURS] = start + v;
+	if (b < 64) {
+		const uint32_t cv = d.ctr->colour_count[b];
+		const unsigned long long used = __ballot(cv != 0 && b < SGP_OVERFLOW_COLOUR);
+		if (b == 0) d.ctr->n_colours = used ? 64u - (uint32_t)__clzll(used) : 0u;
+	}
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1243,26 +1257,32 @@ SGP_DEV uint32_t cache_find(const DV& d, uint64_t key)
 #define SLOTS_PER_THREAD 8
 __global__ void __launch_bounds__(TPB) k_setup_slots(DV d)
 {
-	__shared__ uint32_t hist[SGP_MAX_COLOURS];
-	__shared__ uint32_t base[SGP_MAX_COLOURS];
+	__shared__ uint32_t hist[SGP_MAX_COLOURS * 4];
+	__shared__ uint32_t base[SGP_MAX_COLOURS * 4];
 	const uint32_t n = min(d.ctr->n_manifolds, d.cap_manifolds);
 	for (uint32_t c0 = blockIdx.x * TPB * SLOTS_PER_THREAD; c0 < n; c0 += gridDim.x * TPB * SLOTS_PER_THREAD) {
-		if (threadIdx.x < SGP_MAX_COLOURS) hist[threadIdx.x] = 0;
+		hist[threadIdx.x] = 0;                                 // (TPB = 256 buckets: colour x point-count class)
 		__syncthreads();
-		int cols[SLOTS_PER_THREAD]; uint32_t ranks[SLOTS_PER_THREAD];
+		int bins[SLOTS_PER_THREAD]; uint32_t ranks[SLOTS_PER_THREAD];
 #pragma unroll
 		for (int j = 0; j < SLOTS_PER_THREAD; ++j) {
 			const uint32_t m = c0 + (uint32_t)j * TPB + threadIdx.x;
-			cols[j] = m < n ? d.man_colour[m] : -1;
-			ranks[j] = cols[j] >= 0 ? atomicAdd(&hist[cols[j]], 1u) : 0u;
+			const int col = m < n ? d.man_colour[m] : -1;
+			bins[j] = -1;
+			if (col >= 0) {
+				const int npb = __float_as_int(d.man_n[m].w);
+				const uint32_t np = (npb & 0x100) ? 0u : (uint32_t)(npb & 0xFF);
+				bins[j] = col * 4 + (int)(np <= 1u ? 3u : 4u - np);
+			}
+			ranks[j] = bins[j] >= 0 ? atomicAdd(&hist[bins[j]], 1u) : 0u;
 		}
 		__syncthreads();
-		if (threadIdx.x < SGP_MAX_COLOURS && hist[threadIdx.x]) base[threadIdx.x] = atomicAdd(&d.ctr->colour_fill[threadIdx.x], hist[threadIdx.x]);
+		if (hist[threadIdx.x]) base[threadIdx.x] = atomicAdd(&d.ctr->cnp_fill[threadIdx.x], hist[threadIdx.x]);
 		__syncthreads();
 #pragma unroll
 		for (int j = 0; j < SLOTS_PER_THREAD; ++j) {
 			const uint32_t m = c0 + (uint32_t)j * TPB + threadIdx.x;
-			if (cols[j] >= 0) d.man_slot[m] = d.cstarts[cols[j]] + base[cols[j]] + ranks[j];
+			if (bins[j] >= 0) d.man_slot[m] = d.ctr->cnp_start[bins[j]] + base[bins[j]] + ranks[j];
 		}
 		__syncthreads();
 	}
@@ -4154,7 +4174,7 @@ void launch_colour_count(const DV& d, uint32_t est, hipStream_t s)
 	// few, looping workgroups: every workgroup ends with one global atomic per colour, and those queue per colour (config 3: 512 workgroups 21 us,
 	// 256: 13 us, 128: 11 us, 64: 15 us); more of them only where there is enough to count (a million bodies)
 	hipLaunchKernelGGL(k_colour_count, dim3(std::min(std::max(stride_grid(est) / 8u, 128u), 512u)), dim3(TPB), 0, s, d);
-	hipLaunchKernelGGL(k_colour_scan, dim3(1), dim3(64), 0, s, d);
+	hipLaunchKernelGGL(k_colour_scan, dim3(1), dim3(256), 0, s, d);
 }
 void launch_ts_label(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_ts_label, dim3(blocks_for(std::max(nb, SGP_MAX_COLOURS * d.ts_nt))), dim3(TPB), 0, s, d); }
 void launch_colour_count_ts(const DV& d, uint32_t est, hipStream_t s)
