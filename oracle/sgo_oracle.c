@@ -62,6 +62,7 @@ typedef struct {
 	int underwater; float submerged;
 	/* per-step scratch */
 	uint64_t colour_mask; uint64_t claim[2];
+	int chassis;                       /* chassis of a live vehicle (set by colour_constraints): its contacts do not take colour 0 */
 	int movable_prev, movable_cur;   /* movable (dynamic and awake) when the previous / this step coloured its constraints */
 	int island; int can_sleep;
 	int cache_invalid;               /* created or reshaped since the last step: its pairs do not reuse cached manifolds (Body::InvalidateContactCache) */
@@ -1098,7 +1099,12 @@ static void colour_constraints(sgo_world* w)
 		sgo_body* b = &w->bodies[i];
 		b->colour_mask = 0; b->claim[0] = b->claim[1] = ~0ull;
 		b->movable_prev = b->movable_cur; b->movable_cur = b->alive && body_movable(b);
+		b->chassis = 0;
 	}
+	/* Colour 0 of a vehicle's chassis is the vehicle's own: its rows are solved before the contacts in every pass (non-contact constraints first,
+	   as in PhysicsSystem's solve), and the device solves them in the same launch as the first contact colour -- so no contact of a chassis takes
+	   colour 0.  The order a sequential solve visits the rows of any one body in is unchanged by this: vehicle, then contacts by colour. */
+	for (uint32_t k = 0; k < w->n_vehicles; ++k) if (w->vehicles[k].alive && w->vehicles[k].body < w->high) w->bodies[w->vehicles[k].body].chassis = 1;
 	/* Colour inheritance through the contact cache: a persisted manifold keeps last step's colour when both of its movable
 	   bodies were already movable when that colour was chosen (then last step's proper colouring guarantees that no two
 	   inheritors sharing a movable body carry the same colour).  Only the other manifolds go through the rounds below. */
@@ -1108,7 +1114,8 @@ static void colour_constraints(sgo_world* w)
 		c->colour = -1;
 		const sgo_constraint* pc = find_prev(w, c->key);
 		sgo_body* A = &w->bodies[c->a]; sgo_body* B = &w->bodies[c->b];
-		if (pc && pc->colour >= 0 && pc->colour < SGO_OVERFLOW_COLOUR && (!A->movable_cur || A->movable_prev) && (!B->movable_cur || B->movable_prev)) {
+		if (pc && pc->colour >= 0 && pc->colour < SGO_OVERFLOW_COLOUR && (!A->movable_cur || A->movable_prev) && (!B->movable_cur || B->movable_prev)
+		    && !(pc->colour == 0 && ((A->movable_cur && A->chassis) || (B->movable_cur && B->chassis)))) {
 			c->colour = pc->colour;
 			if (A->movable_cur) A->colour_mask |= 1ull << c->colour;
 			if (B->movable_cur) B->colour_mask |= 1ull << c->colour;
@@ -1135,7 +1142,7 @@ static void colour_constraints(sgo_world* w)
 			const int ma = body_movable(A), mb = body_movable(B);
 			const int win = (!ma || A->claim[cur] == c->prio) && (!mb || B->claim[cur] == c->prio);
 			if (win) {
-				const uint64_t used = (ma ? A->colour_mask : 0) | (mb ? B->colour_mask : 0);
+				const uint64_t used = (ma ? A->colour_mask | (uint64_t)A->chassis : 0) | (mb ? B->colour_mask | (uint64_t)B->chassis : 0);
 				int col = 0;
 				while (col < SGO_OVERFLOW_COLOUR && ((used >> col) & 1)) ++col;
 				c->colour = col;

@@ -23,6 +23,7 @@
 #define BF_CACHE_INVALID (1u << 12)  // created or reshaped since the last step: its pairs do not reuse cached manifolds (cleared by k_pre_solve)
 #define BF_SHAPE_SHIFT   18          // SGP_SHAPE_* (3 bits)
 #define BF_SHAPE_MASK    (0x7u << BF_SHAPE_SHIFT)
+#define BF_CHASSIS       (1u << 22)  // chassis of a live vehicle: colour 0 of the contact colouring is the vehicle's own (its rows are solved next to the first contact colour)
 #define BF_ALIAS         (1u << 21)  // second / third slot of a static mesh body: carries contact manifolds only (never binned, never queried)
 #define BF_WAKE          (1u << 14)  // scratch: touched by an active body this step
 #define BF_CAN_SLEEP     (1u << 15)  // scratch: sleep test result
@@ -118,6 +119,7 @@ struct EventCounters {
 #define CMD_REMOVE       (1u << 9)
 #define CMD_MOVE_KINEMATIC (1u << 10)
 #define CMD_CREATE       (1u << 11)
+#define CMD_SET_CHASSIS  (1u << 12)   // flags & BF_CHASSIS = the new value
 
 // Per-step pose refresh of an existing ghost body (tiles): what a SET_POS | SET_ROT | SET_VEL | ACTIVATE command does, in 56 bytes
 struct GhostRefresh { uint32_t id; float pos[3]; float rot[4]; float linv[3]; float angv[3]; };
@@ -269,6 +271,8 @@ struct DV {
 	uint2* mesh_pairs; uint32_t cap_mesh_pairs;
 	// wheeled vehicles (sgp_device_vehicle.h): AoS, one record per vehicle slot
 	struct sgd_vehicle* vehicles; uint32_t n_vehicles; const sgp_vehicle_input* vehicle_inputs;
+	// the rows of the step as the solver passes read them (k_vehicle_controller exports, veh_quad_solve consumes): 16 chunks per wheel, [chunk][4 vehicle + wheel]; 5 float4 per vehicle
+	float4* veh_rows; float4* veh_head; uint32_t veh_cap;
 	// settings (fixed after world creation)
 	sgp_settings st;
 	float gx, gy, gz;
@@ -328,7 +332,8 @@ void launch_gather_active(const DV& d, uint32_t nb, sgp_body_state* out, uint32_
 void launch_gather_active_poses(const DV& d, uint32_t nb, void* out, uint32_t cap, hipStream_t s);      // sgp_body_pose records (32 B)
 void launch_dump_constraints(const DV& d, uint32_t which, uint32_t n_con, void* out, uint32_t cap, hipStream_t s);
 void launch_vehicle_pre(const DV& d, hipStream_t s);
-void launch_vehicle_solve(const DV& d, int mode, hipStream_t s);      // mode as launch_solve_colour
+void launch_vehicle_solve(const DV& d, int mode, hipStream_t s);
+void launch_solve_colour_veh(const DV& d, int colour, uint32_t est, int mode, hipStream_t s);      // a contact colour whose first workgroups solve the vehicles' rows (mode 1, 2)      // mode as launch_solve_colour
 void launch_raycast(const DV& d, const sgp_ray* rays, uint32_t n, sgp_hit* hits, hipStream_t s);
 void launch_collide_capsules(const DV& d, const sgp_capsule_query* q, uint32_t n, sgp_query_contact* out, uint32_t cap, uint32_t* count, hipStream_t s);
 void launch_spherecast(const DV& d, const sgp_ray* rays, const float* radii, uint32_t n, sgp_hit* hits, hipStream_t s);

@@ -594,6 +594,9 @@ SGP_DEV sgd_shape load_shape(const DV& d, uint32_t i, uint32_t f)
 }
 
 SGP_DEV uint32_t cache_find(const DV& d, uint64_t key);
+// Colours a body's contacts may not take: a vehicle's rows are solved in the same launch as the first contact colour of every pass (they come first
+// in the pass: non-contact constraints before contacts, as in PhysicsSystem's solve), so no contact of its chassis may sit in colour 0.
+SGP_DEV uint64_t chassis_colours(uint32_t f) { return (f & BF_CHASSIS) ? 1ull : 0ull; }
 #define MAN_PREV_LOOKUP 0xFFFFFFFFu
 // Every lane that calls this (the lanes active at the call) gets its own index from *counter: one atomic per wave instead of one per lane
 // (hundreds of thousands of atomics on ONE address serialise in L2: that, not the collision arithmetic, bounded the narrow phase).
@@ -1020,6 +1023,7 @@ __global__ void __launch_bounds__(TPB) k_colour_inherit(DV d)
 		const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
 		const bool ma = fa & BF_MOVABLE_CUR, mb = fb & BF_MOVABLE_CUR;
 		if ((ma && !(fa & BF_MOVABLE_PREV)) || (mb && !(fb & BF_MOVABLE_PREV))) continue;
+		if (pc == 0 && ((ma && (fa & BF_CHASSIS)) || (mb && (fb & BF_CHASSIS)))) continue;      // (the body became a chassis since: colour 0 is the vehicle's)
 		d.man_colour[m] = pc;
 		if (ma) atomicOr((unsigned long long*)&d.colour_mask[ab.x], 1ull << pc);
 		if (mb) atomicOr((unsigned long long*)&d.colour_mask[ab.y], 1ull << pc);
@@ -1067,10 +1071,11 @@ __global__ void __launch_bounds__(TPB) k_colour_commit(DV d, uint32_t round)
 			if (!(round == 0 && d.man_colour[m] != -1)) {
 				const uint2 ab = d.man_ab[m];
 				const uint64_t pr = d.man_prio[m];
-				const bool ma = f_movable(d.flags[ab.x]), mb = f_movable(d.flags[ab.y]);
+				const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
+				const bool ma = f_movable(fa), mb = f_movable(fb);
 				const bool win = (!ma || claim[ab.x] == pr) && (!mb || claim[ab.y] == pr);
 				if (win) {
-					const uint64_t used = (ma ? d.colour_mask[ab.x] : 0ull) | (mb ? d.colour_mask[ab.y] : 0ull);
+					const uint64_t used = (ma ? d.colour_mask[ab.x] | chassis_colours(fa) : 0ull) | (mb ? d.colour_mask[ab.y] | chassis_colours(fb) : 0ull);
 					int col = __ffsll((long long)~used) - 1;
 					if (col < 0 || col > SGP_OVERFLOW_COLOUR) col = SGP_OVERFLOW_COLOUR;
 					d.man_colour[m] = col;
@@ -1158,10 +1163,11 @@ __global__ void __launch_bounds__(1024) k_colour_finish(DV d, uint32_t first_rou
 			const uint32_t m = list[idx];
 			const uint2 ab = d.man_ab[m];
 			const uint64_t pr = d.man_prio[m];
-			const bool ma = f_movable(d.flags[ab.x]), mb = f_movable(d.flags[ab.y]);
+			const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
+			const bool ma = f_movable(fa), mb = f_movable(fb);
 			const bool win = (!ma || claim[ab.x] == pr) && (!mb || claim[ab.y] == pr);
 			if (win) {
-				const uint64_t used = (ma ? d.colour_mask[ab.x] : 0ull) | (mb ? d.colour_mask[ab.y] : 0ull);
+				const uint64_t used = (ma ? d.colour_mask[ab.x] | chassis_colours(fa) : 0ull) | (mb ? d.colour_mask[ab.y] | chassis_colours(fb) : 0ull);
 				int col = __ffsll((long long)~used) - 1;
 				if (col < 0 || col > SGP_OVERFLOW_COLOUR) col = SGP_OVERFLOW_COLOUR;
 				d.man_colour[m] = col;
@@ -2937,6 +2943,7 @@ __global__ void __launch_bounds__(TPB) k_apply_cmds(DV d, const BodyCmd* cmds, c
 		}
 		if (c.ops & CMD_REMOVE) { f = 0; continue; }
 		if (!(f & BF_ALIVE)) continue;
+		if (c.ops & CMD_SET_CHASSIS) { f = (f & ~BF_CHASSIS) | (c.flags & BF_CHASSIS); continue; }
 		if (c.ops & CMD_SET_LAYER) f = (f & ~BF_LAYER_MASK) | ((c.flags & 0x3u) << BF_LAYER_SHIFT);
 		if (c.ops & CMD_MOVE_KINEMATIC) {
 			// MotionProperties::MoveKinematic: velocities that reach the target in dt
@@ -3431,11 +3438,13 @@ __global__ void __launch_bounds__(64) k_vehicle_cast(DV d)
 	veh_stage_out(gv, &sv);
 }
 
+SGP_DEV void veh_export(const DV& d, uint32_t k, const sgd_vehicle& v);
+#define VEH_HEAD_F4 5
 __global__ void __launch_bounds__(64) k_vehicle_controller(DV d)
 {
 	__shared__ sgd_vehicle sv;
 	sgd_vehicle* gv = &d.vehicles[blockIdx.x];
-	if (!gv->alive || !gv->active) return;
+	if (!gv->alive || !gv->active) { if (threadIdx.x == 0) d.veh_head[(size_t)blockIdx.x * VEH_HEAD_F4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); return; }      // (no rows this step)
 	veh_stage_in(&sv, gv);
 	if (threadIdx.x == 0) {
 		const uint32_t b = sv.body;
@@ -3444,36 +3453,268 @@ __global__ void __launch_bounds__(64) k_vehicle_controller(DV d)
 		const float4 lv = d.vel[2 * (size_t)b], av = d.vel[2 * (size_t)b + 1];
 		d.vel[2 * (size_t)b] = F4(c.v, lv.w); d.vel[2 * (size_t)b + 1] = F4(c.w, av.w);
 	}
+	__syncthreads();
+	veh_export(d, blockIdx.x, sv);          // the rows of this step, lane-major, for the solver passes
 	veh_stage_out(gv, &sv);
 }
 
-// MODE 0 warm start, 1 velocity iteration (velocities live in the per-step solver records), 2 position iteration (poses)
-template <int MODE> __global__ void __launch_bounds__(64) k_vehicle_solve(DV d)
+// ---- the vehicle rows inside the solver passes: four lanes per vehicle -------------------------------------------------------
+// A solver pass visits a vehicle's rows in a fixed order (VehicleConstraint::SolveVelocityConstraint, then the controller's
+// longitudinal and lateral rows: suspension + upper stop of wheel 0..3, longitudinal 0..3, lateral 0..3, the motorcycle's lean
+// spring), every row reading the chassis velocity the previous one left: a chain, not a reduction.  What the lanes buy is the
+// memory side: lane i of a quad holds wheel i's rows in registers -- sixteen 16-byte chunks per wheel that k_vehicle_controller
+// exported in a lane-major layout (DV::veh_rows: chunk c of wheel i of vehicle k at [c][4 k + i], so one load instruction of a
+// wave fetches 1 KB contiguous) --, all four lanes carry a copy of the chassis state, the lane whose turn it is advances it and a
+// DPP quad broadcast (a register move modifier, no LDS round trip) hands it to the other three.  No LDS, no workgroup barrier:
+// the quads of sixteen vehicles share a wave, and the same code runs as the first workgroups of a contact-colour launch
+// (k_solve_colour_veh below).  Row impulses and wheel spin also go back to the vehicle record, which stays the one the host
+// reads and the next step's cast / controller kernels start from.
+#define VEH_CHUNK_NORMAL 0      // contact normal | bits: 1 has contact, 2 suspension row, 4 upper-stop row, 8 longitudinal row, 16 lateral row
+#define VEH_CHUNK_LONG 1        // longitudinal direction | combined longitudinal friction
+#define VEH_CHUNK_LAT 2         // lateral direction | combined lateral friction
+#define VEH_CHUNK_GVEL 3        // velocity of the ground at the contact point | brake impulse
+#define VEH_CHUNK_CPOS 4        // contact position | wheel angular velocity (state)
+#define VEH_CHUNK_MISC 5        // radius, inertia, suspension softness, suspension bias
+#define VEH_CHUNK_ROW 6         // + 2 r: r1 x axis | effective mass;  + 2 r + 1: I^-1 (r1 x axis) | accumulated impulse (state); r = 0 suspension, 1 upper stop, 2 longitudinal, 3 lateral
+#define VEH_CHUNK_WPOS 14       // wheel position (chassis space) | minimum suspension length
+#define VEH_CHUNK_SDIR 15       // suspension direction (chassis space) | axle plane constant
+// VEH_HEAD_F4 = 5 float4 per vehicle: (body, bits: 1 active 2 lean spring on, wheels, integrated lean error), forward | K, up | D, target lean | Ki, (decay, applied lean impulse, -, -)
+
+template <int I> SGP_DEV float quad_bcast(float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), I * 0x55, 0xF, 0xF, true)); }      // quad_perm [I, I, I, I]
+template <int I> SGP_DEV v3 quad_bcast(v3 a) { return V3(quad_bcast<I>(a.x), quad_bcast<I>(a.y), quad_bcast<I>(a.z)); }
+SGP_DEV size_t veh_chunk_at(const DV& d, uint32_t k, int i, int c) { return (size_t)c * (4u * (size_t)d.veh_cap) + 4u * (size_t)k + (size_t)i; }
+
+// the chunk (c) of wheel (i) of the vehicle record in LDS: what k_vehicle_controller's 64 lanes write out, one chunk each
+SGP_DEV float4 veh_export_chunk(const sgd_vehicle& v, int i, int c)
 {
-	__shared__ sgd_vehicle sv;
-	sgd_vehicle* gv = &d.vehicles[blockIdx.x];
-	if (!gv->alive || !gv->active) return;
-	veh_stage_in(&sv, gv);
-	if (threadIdx.x == 0) {
-		const uint32_t b = sv.body;
-		sgd_chassis c;
-		const float4 p = d.pose[2 * (size_t)b];
-		c.pos = V3(p); c.rot = Q4(d.pose[2 * (size_t)b + 1]); c.inv_inertia_local = V3(d.prop[2 * (size_t)b]);
-		if (MODE == 2) {
-			// the position iterations correct the pose record in place
-			c.im = p.w; c.v = V3(0.0f, 0.0f, 0.0f); c.w = c.v; c.I = sym33_zero();
-			sgd_vehicle_solve_position(&sv, &c, d.st.baumgarte);
-			d.pose[2 * (size_t)b] = F4(c.pos, p.w);
-			d.pose[2 * (size_t)b + 1] = make_float4(c.rot.x, c.rot.y, c.rot.z, c.rot.w);
+	const sgd_wheel& w = v.wheels[i];
+	const sgd_axis_part* part[4] = { &w.suspension, &w.max_up, &w.longitudinal, &w.lateral };
+	if (i >= v.num_wheels) return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	if (c == VEH_CHUNK_NORMAL) return F4(w.contact_normal, __uint_as_float((w.has_contact ? 1u : 0u) | (w.suspension.active ? 2u : 0u) | (w.max_up.active ? 4u : 0u) | (w.longitudinal.active ? 8u : 0u) | (w.lateral.active ? 16u : 0u)));
+	if (c == VEH_CHUNK_LONG) return F4(w.contact_long, w.comb_long_fric);
+	if (c == VEH_CHUNK_LAT) return F4(w.contact_lat, w.comb_lat_fric);
+	if (c == VEH_CHUNK_GVEL) return F4(w.contact_point_vel, w.brake_impulse);
+	if (c == VEH_CHUNK_CPOS) return F4(w.contact_pos, w.angular_velocity);
+	if (c == VEH_CHUNK_MISC) return make_float4(w.radius, w.inertia, w.suspension.softness, w.suspension.bias);
+	if (c == VEH_CHUNK_WPOS) return F4(w.position, w.sus_min);
+	if (c == VEH_CHUNK_SDIR) return F4(w.suspension_dir, w.axle_plane_constant);
+	const sgd_axis_part& p = *part[(c - VEH_CHUNK_ROW) >> 1];
+	return ((c - VEH_CHUNK_ROW) & 1) ? F4(p.iI_r1xa, p.lambda) : F4(p.r1xa, p.eff);
+}
+SGP_DEV void veh_export(const DV& d, uint32_t k, const sgd_vehicle& v)
+{
+	const int i = (int)(threadIdx.x & 3u), c = (int)(threadIdx.x >> 2);
+	d.veh_rows[veh_chunk_at(d, k, i, c)] = veh_export_chunk(v, i, c);
+	if (threadIdx.x < VEH_HEAD_F4) {
+		const uint32_t bits = (v.active ? 1u : 0u) | ((v.is_motorcycle && v.lean_enabled) ? 2u : 0u);
+		float4 h;
+		if (threadIdx.x == 0) h = make_float4(__uint_as_float(v.body), __uint_as_float(bits), __uint_as_float((uint32_t)v.num_wheels), v.lean_integrated_delta);
+		else if (threadIdx.x == 1) h = F4(v.forward, v.lean_spring_constant);
+		else if (threadIdx.x == 2) h = F4(v.up, v.lean_spring_damping);
+		else if (threadIdx.x == 3) h = F4(v.target_lean, v.lean_integration_coefficient);
+		else h = make_float4(v.lean_integration_decay, v.lean_applied_impulse, 0.0f, 0.0f);
+		d.veh_head[(size_t)k * VEH_HEAD_F4 + threadIdx.x] = h;
+	}
+}
+
+// the chassis as the rows see it, one copy per lane of the quad
+struct VehBody { v3 v, w; float im; sym33 I; };
+// one row against the (kinematic) ground: AxisConstraintPart::SolveVelocityConstraint with the spring's softness and bias
+SGP_DEV void veh_row_solve(VehBody& c, float4 ra, float4& ri, float softness, float bias, v3 ground_vel, v3 axis, float lo, float hi)
+{
+	const v3 r1xa = V3(ra), iI = V3(ri);
+	const float jv = v3_dot(axis, v3_sub(c.v, ground_vel)) + v3_dot(r1xa, c.w);
+	const float lambda = ra.w * (jv - (softness * ri.w + bias));
+	const float nl = clampf(ri.w + lambda, lo, hi);
+	const float dl = nl - ri.w;
+	c.v = v3_sub(c.v, v3_scale(axis, dl * c.im));
+	c.w = v3_sub(c.w, v3_scale(iI, dl));
+	ri.w = nl;
+}
+SGP_DEV void veh_row_apply(VehBody& c, float4 ri, v3 axis)
+{
+	c.v = v3_sub(c.v, v3_scale(axis, ri.w * c.im));
+	c.w = v3_sub(c.w, v3_scale(V3(ri), ri.w));
+}
+// after lane I's turn: its chassis velocity becomes everybody's
+#define VEH_TURN(WI, ...) { if (L == WI) { __VA_ARGS__ } c.v = quad_bcast<WI>(c.v); c.w = quad_bcast<WI>(c.w); }
+#define VEH_TURNS(...) VEH_TURN(0, __VA_ARGS__) VEH_TURN(1, __VA_ARGS__) VEH_TURN(2, __VA_ARGS__) VEH_TURN(3, __VA_ARGS__)
+
+// q = index of the quad among the launch's quads = vehicle slot; every lane of a quad takes the same branches up to the turns
+template <int MODE> SGP_DEV void veh_quad_solve(const DV& d, uint32_t k, int L)
+{
+	if (k >= d.n_vehicles) return;
+	const float4 h0 = d.veh_head[(size_t)k * VEH_HEAD_F4];
+	const uint32_t hbits = __float_as_uint(h0.y);
+	if (!(hbits & 1u)) return;                       // not alive, or the chassis was asleep when this step's pre-step ran
+	const uint32_t b = __float_as_uint(h0.x);
+	const int nw = (int)__float_as_uint(h0.z);
+	sgd_vehicle* gv = &d.vehicles[k];
+	sgd_wheel* gw = &gv->wheels[L];
+	const float4 cn = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_NORMAL)];
+	const uint32_t wbits = L < nw ? __float_as_uint(cn.w) : 0u;
+	const bool contact = wbits & 1u;
+	const v3 neg_n = v3_neg(V3(cn));
+	if (MODE == 2) {
+		// VehicleConstraint::SolvePositionConstraint: the axle at minimum suspension length stays on the outer side of the plane through the
+		// axle position at cast time; wheel after wheel on the pose the previous one left
+		const float4 cp = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_CPOS)], wp = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_WPOS)], sd = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_SDIR)];
+		const float4 p4 = d.pose[2 * (size_t)b], q4 = d.pose[2 * (size_t)b + 1];
+		const v3 iil = V3(d.prop[2 * (size_t)b]);
+		v3 pos = V3(p4); quat rot = Q4(q4);
+		const float im = p4.w, baumgarte = d.st.baumgarte;
+#define VEH_POS_TURN(WI) { \
+		if (L == WI && contact) { \
+			const m33 R = quat_to_m33(rot); \
+			const v3 ws_dir = m33_mul(R, V3(sd)); \
+			const v3 ws_pos = v3_add(pos, m33_mul(R, V3(wp))); \
+			const v3 min_pos = v3_add(ws_pos, v3_scale(ws_dir, wp.w)); \
+			const float err = v3_dot(V3(cn), min_pos) - sd.w; \
+			if (err < 0.0f) { \
+				const v3 r1 = v3_sub(V3(cp), pos); \
+				const sym33 I = world_inv_inertia(R, iil); \
+				const v3 r1xa = v3_cross(r1, neg_n); \
+				const v3 iI = sym33_mul(I, r1xa); \
+				const float inv_eff = im + v3_dot(r1xa, iI); \
+				if (inv_eff > 0.0f) { \
+					const float lambda = -(1.0f / inv_eff) * baumgarte * err; \
+					pos = v3_sub(pos, v3_scale(neg_n, lambda * im)); \
+					rot = quat_add_rotation_step(rot, v3_scale(iI, -lambda)); \
+				} \
+			} \
+		} \
+		pos = quad_bcast<WI>(pos); rot.x = quad_bcast<WI>(rot.x); rot.y = quad_bcast<WI>(rot.y); rot.z = quad_bcast<WI>(rot.z); rot.w = quad_bcast<WI>(rot.w); }
+		VEH_POS_TURN(0) VEH_POS_TURN(1) VEH_POS_TURN(2) VEH_POS_TURN(3)
+#undef VEH_POS_TURN
+		if (L == 0) { d.pose[2 * (size_t)b] = F4(pos, p4.w); d.pose[2 * (size_t)b + 1] = make_float4(rot.x, rot.y, rot.z, rot.w); }
+		return;
+	}
+	// the rows of this lane's wheel
+	float4 ra[4], ri[4];
+#pragma unroll
+	for (int r = 0; r < 4; ++r) { ra[r] = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_ROW + 2 * r)]; ri[r] = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_ROW + 2 * r + 1)]; }
+	const float4 s0 = d.vel[2 * (size_t)b], s1 = d.vel[2 * (size_t)b + 1];
+	VehBody c;
+	c.v = V3(s0); c.im = s0.w; c.w = V3(s1);                  // (s0.w: the effective inverse mass of this step, k_pre_solve)
+	const quat crot = Q4(d.pose[2 * (size_t)b + 1]);
+	c.I = c.im > 0.0f ? world_inv_inertia(quat_to_m33(crot), V3(d.prop[2 * (size_t)b])) : sym33_zero();
+	if (MODE == 0) {
+		// VehicleConstraint::WarmStartVelocityConstraint: suspension, upper stop, lateral (the longitudinal row starts every step from zero)
+		const v3 neg_lat = v3_neg(V3(d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_LAT)]));
+		VEH_TURNS(if (contact) { if (wbits & 2u) veh_row_apply(c, ri[0], neg_n); if (wbits & 4u) veh_row_apply(c, ri[1], neg_n); if (wbits & 16u) veh_row_apply(c, ri[3], neg_lat); })
+		if (L == 0) { d.vel[2 * (size_t)b] = F4(c.v, s0.w); d.vel[2 * (size_t)b + 1] = F4(c.w, s1.w); }
+		return;
+	}
+	const float4 cl = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_LONG)], ct = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_LAT)], cg = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_GVEL)];
+	float4 cp = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_CPOS)];
+	const float4 cm = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_MISC)];
+	const v3 cpos = V3(d.pose[2 * (size_t)b]);
+	const v3 gvel = V3(cg);
+	// 1. suspension spring and upper stop: push, never pull
+	VEH_TURNS(if (contact) { if (wbits & 2u) veh_row_solve(c, ra[0], ri[0], cm.z, cm.w, gvel, neg_n, 0.0f, 3.0e38f); if (wbits & 4u) veh_row_solve(c, ra[1], ri[1], 0.0f, 0.0f, gvel, neg_n, 0.0f, 3.0e38f); })
+	// 2. longitudinal: the brake within the friction limit, or the impulse that brings the contact patch to the wheel's rolling speed in this step
+	const float sus_lambda = ri[0].w + ri[1].w;
+	const float max_long = cl.w * sus_lambda, max_lat = contact ? ct.w * sus_lambda : 0.0f;
+	VEH_TURNS(if (contact && (wbits & 8u)) {
+		const v3 rel = v3_sub(v3_add(c.v, v3_cross(c.w, v3_sub(V3(cp), cpos))), gvel);
+		const float rel_long = v3_dot(rel, V3(cl));
+		if (cg.w != 0.0f) {
+			const float bi = fminf(cg.w, max_long);
+			float lo, hi;
+			if (rel_long >= 0.0f) { lo = -bi; hi = 0.0f; } else { lo = 0.0f; hi = bi; }
+			veh_row_solve(c, ra[2], ri[2], 0.0f, 0.0f, gvel, v3_neg(V3(cl)), lo, hi);
 		} else {
-			const float4 s0 = d.vel[2 * (size_t)b], s1 = d.vel[2 * (size_t)b + 1];
-			c.v = V3(s0); c.im = s0.w; c.w = V3(s1);                  // (s0.w: the effective inverse mass of this step, k_pre_solve)
-			c.I = c.im > 0.0f ? world_inv_inertia(quat_to_m33(c.rot), c.inv_inertia_local) : sym33_zero();
-			if (MODE == 0) sgd_vehicle_warm_start(&sv, &c); else sgd_vehicle_solve_velocity(&sv, &c, d.sp->dt);
-			d.vel[2 * (size_t)b] = F4(c.v, s0.w); d.vel[2 * (size_t)b + 1] = F4(c.w, s1.w);
+			const float desired_w = rel_long / cm.x;
+			const float lin_imp = (cp.w - desired_w) * cm.y / cm.x;
+			const float prev = ri[2].w;
+			const float lim = clampf(prev + lin_imp, -max_long, max_long);
+			veh_row_solve(c, ra[2], ri[2], 0.0f, 0.0f, gvel, v3_neg(V3(cl)), lim, lim);
+			cp.w = cp.w - (ri[2].w - prev) * cm.x / cm.y;
+		}
+	})
+	// 3. lateral
+	VEH_TURNS(if (contact && (wbits & 16u)) veh_row_solve(c, ra[3], ri[3], 0.0f, 0.0f, gvel, v3_neg(V3(ct)), -max_lat, max_lat);)
+	// 4. MotorcycleController: the lean spring (a PID on the angle to the target lean), only with every wheel loaded; the matching linear impulse keeps
+	//    the contact patches from being swept sideways.  Every lane of the quad computes it (the sums run over the wheels in order 0..3).
+	float lean_integrated = h0.w, lean_applied = 0.0f;
+	if (hbits & 2u) {
+		const float4 h1 = d.veh_head[(size_t)k * VEH_HEAD_F4 + 1], h2 = d.veh_head[(size_t)k * VEH_HEAD_F4 + 2], h3 = d.veh_head[(size_t)k * VEH_HEAD_F4 + 3], h4 = d.veh_head[(size_t)k * VEH_HEAD_F4 + 4];
+		lean_applied = h4.y;
+		const float lam = ri[0].w + ri[1].w;
+		const v3 arm = v3_sub(V3(cp), cpos);
+		const float lam_w[4] = { quad_bcast<0>(lam), quad_bcast<1>(lam), quad_bcast<2>(lam), quad_bcast<3>(lam) };
+		const v3 arm_w[4] = { quad_bcast<0>(arm), quad_bcast<1>(arm), quad_bcast<2>(arm), quad_bcast<3>(arm) };
+		const uint32_t con = contact ? 1u : 0u;
+		const uint32_t con_w[4] = { (uint32_t)__builtin_amdgcn_mov_dpp((int)con, 0x00, 0xF, 0xF, true), (uint32_t)__builtin_amdgcn_mov_dpp((int)con, 0x55, 0xF, 0xF, true), (uint32_t)__builtin_amdgcn_mov_dpp((int)con, 0xAA, 0xF, 0xF, true), (uint32_t)__builtin_amdgcn_mov_dpp((int)con, 0xFF, 0xF, 0xF, true) };
+		bool all_in_contact = true;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) if (i < nw && (!con_w[i] || !(lam_w[i] > 0.0f))) all_in_contact = false;
+		const float dt = d.sp->dt;
+		if (all_in_contact) {
+			const m33 R = quat_to_m33(crot);
+			const v3 forward = m33_mul(R, V3(h1)), up = m33_mul(R, V3(h2));
+			const v3 target = V3(h3);
+			const float d_angle = -sgd_signf(v3_dot(v3_cross(target, up), forward)) * sgd_acos11(clampf(v3_dot(target, up), -1.0f, 1.0f));
+			const float ddt_angle = v3_dot(c.w, forward);
+			// (the fixed point of Jolt's per-iteration re-evaluation, solved for directly: DESIGN.md 4b)
+			const v3 If = sym33_mul(c.I, forward);
+			const float iff = v3_dot(forward, If);
+			const float wf0 = ddt_angle - iff * lean_applied;
+			const float total = (h1.w * d_angle - h2.w * wf0 + h3.w * lean_integrated) * dt / (1.0f + h2.w * dt * iff);
+			const v3 old_w = c.w;
+			c.w = v3_add(c.w, v3_scale(If, total - lean_applied));
+			lean_applied = total;
+			const v3 dw = v3_sub(c.w, old_w);
+			v3 lin_acc = V3(0.0f, 0.0f, 0.0f); float total_lambda = 0.0f;
+#pragma unroll
+			for (int i = 0; i < 4; ++i) if (i < nw) { total_lambda = total_lambda + lam_w[i]; lin_acc = v3_add(lin_acc, v3_scale(v3_cross(dw, arm_w[i]), lam_w[i])); }
+			c.v = v3_sub(c.v, v3_scale(lin_acc, 1.0f / total_lambda));
+		} else lean_integrated = lean_integrated * fmaxf(0.0f, 1.0f - h4.x * dt);
+	}
+	// state back: the row chunks (next pass), the vehicle record (host reads, next step's pre-step), the chassis velocity
+	if (L < nw) {
+#pragma unroll
+		for (int r = 0; r < 4; ++r) d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_ROW + 2 * r + 1)] = ri[r];
+		d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_CPOS)] = cp;
+		gw->suspension.lambda = ri[0].w; gw->max_up.lambda = ri[1].w; gw->longitudinal.lambda = ri[2].w; gw->lateral.lambda = ri[3].w;
+		gw->angular_velocity = cp.w;
+	}
+	if (L == 0) {
+		d.vel[2 * (size_t)b] = F4(c.v, s0.w); d.vel[2 * (size_t)b + 1] = F4(c.w, s1.w);
+		if (hbits & 2u) {
+			d.veh_head[(size_t)k * VEH_HEAD_F4] = make_float4(h0.x, h0.y, h0.z, lean_integrated);
+			float4* h4p = &d.veh_head[(size_t)k * VEH_HEAD_F4 + 4];
+			*h4p = make_float4(h4p->x, lean_applied, 0.0f, 0.0f);
+			gv->lean_integrated_delta = lean_integrated; gv->lean_applied_impulse = lean_applied;
 		}
 	}
-	if (MODE == 1) veh_stage_out(gv, &sv);        // only the velocity iteration changes the record (row impulses, wheel spin)
+}
+#undef VEH_TURNS
+#undef VEH_TURN
+
+#define VEH_SOLVE_TPB SOLVE_VEL_TPB      // 64 vehicles per workgroup
+// MODE 0 warm start, 1 velocity iteration, 2 position iteration (the chassis pose)
+template <int MODE> __global__ void __launch_bounds__(VEH_SOLVE_TPB) k_vehicle_solve(DV d)
+{
+	const uint32_t t = blockIdx.x * VEH_SOLVE_TPB + threadIdx.x;
+	veh_quad_solve<MODE>(d, t >> 2, (int)(t & 3u));
+}
+
+// The first contact colour of a velocity / position pass with the vehicles' rows in the same launch: no contact of a chassis sits in colour 0
+// (chassis_colours), so the two touch disjoint bodies and the pass order "vehicles, then the contact colours" holds without a launch of
+// its own.  The vehicle workgroups come first in the grid: they are the longer chains.
+template <int MODE> __global__ void __launch_bounds__(SOLVE_VEL_TPB) k_solve_colour_veh(DV d, int colour, uint32_t veh_blocks)
+{
+	if (blockIdx.x < veh_blocks) {
+		const uint32_t t = blockIdx.x * SOLVE_VEL_TPB + threadIdx.x;
+		veh_quad_solve<MODE>(d, t >> 2, (int)(t & 3u));
+		return;
+	}
+	const uint32_t first = d.cstarts[colour], end = d.cstarts[colour + 1];
+	const int side = (int)(threadIdx.x & 1u);
+	for (uint32_t k = first + (((blockIdx.x - veh_blocks) * SOLVE_VEL_TPB + threadIdx.x) >> 1); k < end; k += (gridDim.x - veh_blocks) * (SOLVE_VEL_TPB / 2)) {
+		if (MODE == 1) solve_velocity_pair_t<2>(d, k, side, d.vel); else solve_position_pair(d, k, side);
+	}
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -4208,6 +4449,14 @@ void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStr
 	else if (mode == 1) hipLaunchKernelGGL(k_solve_colour<1>, dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour);
 	else hipLaunchKernelGGL(k_solve_colour<2>, dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour);
 }
+void launch_solve_colour_veh(const DV& d, int colour, uint32_t est, int mode, hipStream_t s)
+{
+	uint32_t blocks = (est + est / 8 + 64 + SOLVE_VEL_TPB / 2 - 1) / (SOLVE_VEL_TPB / 2);
+	if (blocks > 8192) blocks = 8192;
+	const uint32_t vb = (d.n_vehicles * 4u + SOLVE_VEL_TPB - 1) / SOLVE_VEL_TPB;
+	if (mode == 1) hipLaunchKernelGGL(k_solve_colour_veh<1>, dim3(vb + blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour, vb);
+	else hipLaunchKernelGGL(k_solve_colour_veh<2>, dim3(vb + blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour, vb);
+}
 void launch_warm_bodies(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_warm_bodies, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_solve_tail(const DV& d, int first_colour, int mode, hipStream_t s)
 {
@@ -4270,8 +4519,7 @@ void launch_vehicle_pre(const DV& d, hipStream_t s)
 }
 void launch_vehicle_solve(const DV& d, int mode, hipStream_t s)
 {
-	if (!d.n_vehicles) return;
-	const dim3 g(d.n_vehicles), b(64);                     // one wave per vehicle
+	const dim3 g((d.n_vehicles * 4u + VEH_SOLVE_TPB - 1) / VEH_SOLVE_TPB), b(VEH_SOLVE_TPB);
 	if (mode == 0) hipLaunchKernelGGL(k_vehicle_solve<0>, g, b, 0, s, d);
 	else if (mode == 1) hipLaunchKernelGGL(k_vehicle_solve<1>, g, b, 0, s, d);
 	else hipLaunchKernelGGL(k_vehicle_solve<2>, g, b, 0, s, d);

@@ -118,6 +118,8 @@ struct sgp_world {
 	std::vector<sgd_hull> hulls; sgd_hull* d_hulls = nullptr;
 	// wheeled vehicles: device records (AoS) + host mirror of what the ABI needs without a read-back
 	sgd_vehicle* d_vehicles = nullptr; sgp_vehicle_input* d_veh_inputs = nullptr; uint32_t cap_vehicles = 0, n_vehicles = 0;
+	float4* d_veh_rows = nullptr; float4* d_veh_head = nullptr;      // the step's rows in the solver's lane-major layout (DV::veh_rows)
+	bool fuse_vehicle_solve = true;                                  // SGP_VEHICLE_FUSED=0: the vehicles' rows in launches of their own
 	std::vector<uint8_t> veh_alive; std::vector<uint32_t> veh_body; std::vector<sgp_vehicle_input> veh_inputs; bool veh_inputs_dirty = false;
 	// events collected on the host until drained
 	std::vector<sgp_body_event> ev_act, ev_deact, ev_water;
@@ -355,6 +357,7 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	{ const char* e = getenv("SGP_NO_SMALL_WORLD"); if (e && e[0] == '1') w->use_small_world = false; }
 	{ const char* e = getenv("SGP_DEBUG_FLAGS"); w->dv.dbg_flags = e ? (uint32_t)atoi(e) : 0u; }
 	{ const char* e = getenv("SGP_TILE_SOLVER"); if (e) w->use_tile_solver = atoi(e); }
+	{ const char* e = getenv("SGP_VEHICLE_FUSED"); if (e) w->fuse_vehicle_solve = atoi(e) != 0; }
 	{ const char* e = getenv("SGP_COMPACT_ROWS_MIN"); if (e && atoll(e) >= 0) w->compact_rows_min = (uint32_t)atoll(e); }
 	{ const char* e = getenv("SGP_TS_MIN_CONSTRAINTS"); if (e && atoi(e) >= 0) w->ts_min_constraints = (uint32_t)atoi(e); }
 	{ const char* e = getenv("SGP_HC_BUDGET"); if (e) { const int v = atoi(e); if (v <= 0) w->use_components = false; else w->hc_budget = (uint32_t)v; } }
@@ -383,6 +386,7 @@ SGP_API int sgp_world_destroy(sgp_world* w)
 	if (w->d_mesh_nodes) hipFree(w->d_mesh_nodes);
 	if (w->d_vehicles) hipFree(w->d_vehicles);
 	if (w->d_veh_inputs) hipFree(w->d_veh_inputs);
+	hipFree(w->d_veh_rows); hipFree(w->d_veh_head);
 	if (w->stage_host) hipHostFree(w->stage_host);
 	if (w->view_host) hipHostFree(w->view_host);
 	if (w->h_ctr) hipHostFree(w->h_ctr);
@@ -1110,8 +1114,10 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 	STAGE_MARK(4);
 	// -- 5. warm start + velocity iterations: one launch per planned colour, everything else in the single-workgroup tail
 	auto solve_pass = [&](int mode, int kc) {
-		if (p.n_vehicles) { KScope k(w, KC_VEHICLE); launch_vehicle_solve(d, mode, s); }      // non-contact constraints first
-		for (int c = 0; c < p.tail_first; ++c) { KScope k(w, kc); launch_solve_colour(d, c, p.colour_est[c], mode, s); }
+		// non-contact constraints first: the vehicles' rows ride in the launch of contact colour 0 (no chassis contact is in that colour) when the plan has one
+		const bool veh_fused = p.n_vehicles && p.tail_first > 0 && mode != 0 && w->fuse_vehicle_solve;
+		if (p.n_vehicles && !veh_fused) { KScope k(w, KC_VEHICLE); launch_vehicle_solve(d, mode, s); }
+		for (int c = 0; c < p.tail_first; ++c) { KScope k(w, kc); if (c == 0 && veh_fused) launch_solve_colour_veh(d, c, p.colour_est[c], mode, s); else launch_solve_colour(d, c, p.colour_est[c], mode, s); }
 		if (p.hc_first >= 0) { KScope k(w, kc); launch_solve_hc(d, p.hc_first, p.hc_est, mode, s); }      // colours >= tail_first by component + overflow colour
 		else { KScope k(w, kc); launch_solve_tail(d, p.tail_first, mode, s); }
 	};
@@ -1766,9 +1772,18 @@ SGP_API int sgp_vehicle_create(sgp_world* w, const sgp_vehicle_desc* d, uint32_t
 			HIP_TRY(hipMemsetAsync(ni, 0, sizeof(sgp_vehicle_input) * nc, w->stream));
 			if (w->n_vehicles) HIP_TRY(hipMemcpyAsync(nv, w->d_vehicles, sizeof(sgd_vehicle) * w->n_vehicles, hipMemcpyDeviceToDevice, w->stream));
 			HIP_TRY(hipStreamSynchronize(w->stream));
-			if (w->d_vehicles) { hipFree(w->d_vehicles); hipFree(w->d_veh_inputs); w->device_bytes -= (sizeof(sgd_vehicle) + sizeof(sgp_vehicle_input)) * w->cap_vehicles; }
-			w->d_vehicles = nv; w->d_veh_inputs = ni; w->cap_vehicles = nc;
-			w->device_bytes += (sizeof(sgd_vehicle) + sizeof(sgp_vehicle_input)) * nc;
+			// (the row export of the solver passes is rebuilt by every step's controller kernel: nothing to carry over)
+			const size_t row_bytes = sizeof(float4) * 16u * 4u * nc, head_bytes = sizeof(float4) * 5u * nc;
+			float4* nr = nullptr; float4* nh = nullptr;
+			HIP_TRY(hipMalloc((void**)&nr, row_bytes));
+			HIP_TRY(hipMalloc((void**)&nh, head_bytes));
+			HIP_TRY(hipMemsetAsync(nr, 0, row_bytes, w->stream));
+			HIP_TRY(hipMemsetAsync(nh, 0, head_bytes, w->stream));
+			HIP_TRY(hipStreamSynchronize(w->stream));
+			const size_t per_vehicle = sizeof(sgd_vehicle) + sizeof(sgp_vehicle_input) + sizeof(float4) * (16u * 4u + 5u);
+			if (w->d_vehicles) { hipFree(w->d_vehicles); hipFree(w->d_veh_inputs); hipFree(w->d_veh_rows); hipFree(w->d_veh_head); w->device_bytes -= per_vehicle * w->cap_vehicles; }
+			w->d_vehicles = nv; w->d_veh_inputs = ni; w->d_veh_rows = nr; w->d_veh_head = nh; w->cap_vehicles = nc;
+			w->device_bytes += per_vehicle * nc;
 			w->veh_inputs_dirty = true;
 		}
 		w->n_vehicles++;
@@ -1781,6 +1796,8 @@ SGP_API int sgp_vehicle_create(sgp_world* w, const sgp_vehicle_desc* d, uint32_t
 	HIP_TRY(hipStreamSynchronize(w->stream));                  // `rec` lives on this stack frame
 	w->veh_alive[id] = 1; w->veh_body[id] = d->body; w->veh_inputs[id] = sgp_vehicle_input{ 0.0f, 0.0f, 0.0f, 0.0f }; w->veh_inputs_dirty = true;
 	w->dv.vehicles = w->d_vehicles; w->dv.vehicle_inputs = w->d_veh_inputs; w->dv.n_vehicles = w->n_vehicles;
+	w->dv.veh_rows = w->d_veh_rows; w->dv.veh_head = w->d_veh_head; w->dv.veh_cap = w->cap_vehicles;
+	{ BodyCmd c = blank_cmd(d->body, CMD_SET_CHASSIS); c.flags = BF_CHASSIS; w->cmds.push_back(c); w->hb[d->body].flags |= BF_CHASSIS; }
 	invalidate_graphs(w);
 	w->dirty_since_step = true;
 	*id_out = id;
@@ -1795,6 +1812,12 @@ SGP_API int sgp_vehicle_destroy(sgp_world* w, uint32_t id)
 	HIP_TRY(hipMemcpyAsync((char*)&w->d_vehicles[id] + offsetof(sgd_vehicle, alive), &zero, sizeof(int), hipMemcpyHostToDevice, w->stream));
 	HIP_TRY(hipStreamSynchronize(w->stream));
 	w->veh_alive[id] = 0;
+	// the chassis gets colour 0 back once no live vehicle sits on it
+	const uint32_t body = w->veh_body[id];
+	bool other = false;
+	for (uint32_t k = 0; k < w->n_vehicles; ++k) if (w->veh_alive[k] && w->veh_body[k] == body) other = true;
+	if (!other && live(w, body)) { BodyCmd c = blank_cmd(body, CMD_SET_CHASSIS); c.flags = 0; w->cmds.push_back(c); w->hb[body].flags &= ~BF_CHASSIS; }
+	w->dirty_since_step = true;
 	return SGP_OK;
 }
 
