@@ -306,15 +306,15 @@ void launch_colour_count_ts(const DV& d, uint32_t n_man, hipStream_t s);
 void launch_setup_ts(const DV& d, uint32_t n_man, hipStream_t s);
 void launch_ts_solve(const DV& d, int passes, int colour_end, hipStream_t s);      // colours < colour_end, `passes` times
 // mode: 0 warm start, 1 velocity iteration, 2 position iteration.  est = expected constraints of that colour (grid sizing only)
-void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStream_t s);
+void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStream_t s, int compact_rows);      // compact_rows: StepParams::compact_rows of the step (selects the kernel)
 void launch_solve_probe(const DV& d, int variant, int colour, uint32_t est, hipStream_t s);
 void launch_warm_bodies(const DV& d, uint32_t nb, hipStream_t s);
-void launch_solve_tail(const DV& d, int first_colour, int mode, hipStream_t s);
+void launch_solve_tail(const DV& d, int first_colour, int mode, hipStream_t s, int compact_rows = 0);
 // small worlds: warm start + all velocity iterations in one single-workgroup launch (needs n_slots <= SGP_SMALL_WORLD_BODIES)
 #define SGP_SMALL_WORLD_BODIES 2048
 void launch_hc_build(const DV& d, int first_colour, uint32_t est, hipStream_t s);      // components of the colours >= first_colour (after launch_setup)
 void launch_hc_probe(const DV& d, int probe_colour, uint32_t probe_est, hipStream_t s);      // before launch_hc_build: component sizes if the components started at probe_colour
-void launch_solve_hc(const DV& d, int first_colour, uint32_t est, int mode, hipStream_t s);   // one pass over them + the overflow colour
+void launch_solve_hc(const DV& d, int first_colour, uint32_t est, int mode, hipStream_t s, int compact_rows);   // one pass over them + the overflow colour
 void launch_solve_small(const DV& d, int warm_start, int iterations, int lane_pairs, hipStream_t s);      // lane_pairs: two lanes per constraint (<= 384 constraints stay in registers), else one (<= 512)
 void launch_integrate_pose(const DV& d, uint32_t nb, hipStream_t s);
 void launch_finalize(const DV& d, uint32_t nb, hipStream_t s);
@@ -333,7 +333,7 @@ void launch_gather_active_poses(const DV& d, uint32_t nb, void* out, uint32_t ca
 void launch_dump_constraints(const DV& d, uint32_t which, uint32_t n_con, void* out, uint32_t cap, hipStream_t s);
 void launch_vehicle_pre(const DV& d, hipStream_t s);
 void launch_vehicle_solve(const DV& d, int mode, hipStream_t s);
-void launch_solve_colour_veh(const DV& d, int colour, uint32_t est, int mode, hipStream_t s);      // a contact colour whose first workgroups solve the vehicles' rows (mode 1, 2)      // mode as launch_solve_colour
+void launch_solve_colour_veh(const DV& d, int colour, uint32_t est, int mode, hipStream_t s, int compact_rows);      // a contact colour whose first workgroups solve the vehicles' rows (mode 1, 2)      // mode as launch_solve_colour
 void launch_raycast(const DV& d, const sgp_ray* rays, uint32_t n, sgp_hit* hits, hipStream_t s);
 void launch_collide_capsules(const DV& d, const sgp_capsule_query* q, uint32_t n, sgp_query_contact* out, uint32_t cap, uint32_t* count, hipStream_t s);
 void launch_spherecast(const DV& d, const sgp_ray* rays, const float* radii, uint32_t n, sgp_hit* hits, hipStream_t s);

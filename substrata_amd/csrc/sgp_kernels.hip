@@ -1584,11 +1584,13 @@ struct ConHalf {
 	v3     lam[4];          // accumulated impulses n, t1, t2
 };
 
-SGP_DEV void half_load_rows(const DV& d, uint32_t slot, int side, ConHalf& h)
+// ROWS: the row layout as a compile-time fact (0 full, 1 compact) where the launch knows it -- the colour launches: with both layouts behind a run-time
+// branch the velocity kernel spilled ten registers --, -1 = read StepParams::compact_rows
+template <int ROWS = -1> SGP_DEV void half_load_rows(const DV& d, uint32_t slot, int side, ConHalf& h)
 {
 	const int np = h.np_col & 0xFF;
 	const size_t st = d.cap_manifolds;
-	if (d.sp->compact_rows) {
+	if (ROWS < 0 ? d.sp->compact_rows != 0u : ROWS != 0) {
 		// compact rows: r x axis only; this lane rebuilds I (r x axis) from its body's pose and inertia records -- the same function of the same
 		// operands k_setup evaluates for the full rows, hence the same bits
 		const sym33 I = body_world_inv_inertia(d, h.body);
@@ -1635,17 +1637,17 @@ SGP_DEV void half_load_rows(const DV& d, uint32_t slot, int side, ConHalf& h)
 	}
 }
 
-SGP_DEV void half_load_known(const DV& d, uint32_t slot, int side, int np_col, uint32_t body, ConHalf& h)      // (header already known: nothing here waits for it)
+template <int ROWS = -1> SGP_DEV void half_load_known(const DV& d, uint32_t slot, int side, int np_col, uint32_t body, ConHalf& h)      // (header already known: nothing here waits for it)
 {
 	h.body = body;
 	h.nf = CUR(d).n_fric[slot];
 	h.np_col = np_col;
-	half_load_rows(d, slot, side, h);
+	half_load_rows<ROWS>(d, slot, side, h);
 }
-SGP_DEV void half_load(const DV& d, uint32_t slot, int side, ConHalf& h)
+template <int ROWS = -1> SGP_DEV void half_load(const DV& d, uint32_t slot, int side, ConHalf& h)
 {
 	const uint2 ab = CUR(d).ab[slot];
-	half_load_known(d, slot, side, CUR(d).np_col[slot], side ? ab.y : ab.x, h);
+	half_load_known<ROWS>(d, slot, side, CUR(d).np_col[slot], side ? ab.y : ab.x, h);
 }
 
 SGP_DEV void half_store(const DV& d, uint32_t slot, int side, const ConHalf& h)
@@ -1718,10 +1720,10 @@ template <int VS> SGP_DEV void half_solve(ConHalf& h, int side, float4* vel, uin
 }
 
 // load + one iteration + store: what a colour launch does per constraint (lanes 2k and 2k + 1 of a wave call it with the same slot)
-template <int VS> SGP_DEV void solve_velocity_pair_t(const DV& d, uint32_t slot, int side, float4* vel)
+template <int VS, int ROWS = -1> SGP_DEV void solve_velocity_pair_t(const DV& d, uint32_t slot, int side, float4* vel)
 {
 	ConHalf h;
-	half_load(d, slot, side, h);
+	half_load<ROWS>(d, slot, side, h);
 	half_solve<VS>(h, side, vel, d.dbg_flags);
 	half_store(d, slot, side, h);
 }
@@ -1854,14 +1856,14 @@ SGP_DEV void solve_position_pair_at(const DV& d, uint32_t slot, int side, float4
 // one-wave workgroups dispatch ~1 us longer per launch than two-wave ones, two-wave ones another 0.15 us longer than four-wave ones; eight
 // waves are as fast for the velocity launches and slower for the position launches)
 #define SOLVE_VEL_TPB 256
-template <int MODE> __global__ void __launch_bounds__(MODE != 0 ? SOLVE_VEL_TPB : SOLVE_TPB) k_solve_colour(DV d, int colour)
+template <int MODE, int ROWS = -1> __global__ void __launch_bounds__(MODE != 0 ? SOLVE_VEL_TPB : SOLVE_TPB) k_solve_colour(DV d, int colour)
 {
 	const uint32_t first = d.cstarts[colour], end = d.cstarts[colour + 1];
 	if (MODE != 0) {
 		// velocity and position iterations: two neighbouring lanes per constraint
 		const int side = (int)(threadIdx.x & 1u);
 		for (uint32_t k = first + ((blockIdx.x * SOLVE_VEL_TPB + threadIdx.x) >> 1); k < end; k += gridDim.x * (SOLVE_VEL_TPB / 2)) {
-			if (MODE == 1) solve_velocity_pair_t<2>(d, k, side, d.vel); else solve_position_pair(d, k, side);
+			if (MODE == 1) solve_velocity_pair_t<2, ROWS>(d, k, side, d.vel); else solve_position_pair(d, k, side);
 		}
 		return;
 	}
@@ -1952,7 +1954,7 @@ __global__ void __launch_bounds__(512) k_solve_tail(DV d, int first_colour, int 
 }
 
 #define TAIL_VEL_TPB 768    // 384 constraints per phase; 3 waves per SIMD (a constraint half needs ~150 registers)
-__global__ void __launch_bounds__(TAIL_VEL_TPB) k_solve_tail_vel(DV d, int first_colour)
+template <int ROWS> __global__ void __launch_bounds__(TAIL_VEL_TPB) k_solve_tail_vel(DV d, int first_colour)
 {
 	__shared__ uint32_t cs[SGP_MAX_COLOURS + 1];
 	if (threadIdx.x <= SGP_MAX_COLOURS) cs[threadIdx.x] = d.cstarts[threadIdx.x];
@@ -1967,7 +1969,7 @@ __global__ void __launch_bounds__(TAIL_VEL_TPB) k_solve_tail_vel(DV d, int first
 		const uint32_t slot = cs[first_colour] + pair;
 		const bool mine = pair < tail_n;
 		ConHalf h; int my_col = -1;
-		if (mine) { half_load(d, slot, side, h); my_col = (h.np_col >> 8) & 0xFF; }
+		if (mine) { half_load<ROWS>(d, slot, side, h); my_col = (h.np_col >> 8) & 0xFF; }
 		for (int c = first_colour; c < SGP_OVERFLOW_COLOUR; ++c) {
 			if (cs[c] == cs[c + 1]) continue;
 			if (my_col == c) half_solve<2>(h, side, d.vel, d.dbg_flags);
@@ -1978,7 +1980,7 @@ __global__ void __launch_bounds__(TAIL_VEL_TPB) k_solve_tail_vel(DV d, int first
 	for (int c = first_colour; c < SGP_OVERFLOW_COLOUR; ++c) {
 		const uint32_t b = cs[c], e = cs[c + 1];
 		if (b == e) continue;
-		for (uint32_t k = b + pair; k < e; k += TAIL_VEL_TPB / 2) solve_velocity_pair_t<2>(d, k, side, d.vel);
+		for (uint32_t k = b + pair; k < e; k += TAIL_VEL_TPB / 2) solve_velocity_pair_t<2, ROWS>(d, k, side, d.vel);
 		__syncthreads();
 	}
 	const uint32_t first = cs[SGP_OVERFLOW_COLOUR], count = cs[SGP_OVERFLOW_COLOUR + 1] - first;
@@ -1986,7 +1988,7 @@ __global__ void __launch_bounds__(TAIL_VEL_TPB) k_solve_tail_vel(DV d, int first
 	uint64_t last = 0; bool have_last = false;
 	for (uint32_t it = 0; it < count; ++it) {
 		const uint32_t bslot = overflow_next(d, first, count, last, have_last);
-		solve_velocity_pair_t<2>(d, bslot, side, d.vel);
+		solve_velocity_pair_t<2, ROWS>(d, bslot, side, d.vel);
 	}
 }
 
@@ -2155,7 +2157,7 @@ __global__ void __launch_bounds__(HC_WG_PAIRS) k_hc_sort(DV d)
 // A workgroup's components own their movable bodies, so their solver records live in LDS for the whole pass (read once, written once; a
 // colour phase is an LDS gather, the arithmetic and an LDS scatter): HC_TABLE hash slots keyed by body id, filled by the lanes themselves.
 #define HC_TABLE 1024                 // >= 2 x the bodies a workgroup can meet (one per lane)
-template <int MODE> __global__ void __launch_bounds__(HC_TPB) k_solve_hc(DV d, int first_colour)
+template <int MODE, int ROWS = -1> __global__ void __launch_bounds__(HC_TPB) k_solve_hc(DV d, int first_colour)
 {
 	constexpr int RS = MODE == 1 ? 2 : 3;      // float4 per body: velocity half (lin + inverse mass, ang) / pose half (pos + inverse mass, rot, inertia)
 	__shared__ float4 s_rec[HC_TABLE * RS];
@@ -2179,7 +2181,7 @@ template <int MODE> __global__ void __launch_bounds__(HC_TPB) k_solve_hc(DV d, i
 		if (mine) {
 			my_col = ((int)entry.y >> 8) & 0xFF;
 			body = side ? entry.w : entry.z;
-			if (MODE == 1) half_load_known(d, slot, side, (int)entry.y, body, h); else pos_half_load(d, slot, side, (int)entry.y, ph);
+			if (MODE == 1) half_load_known<ROWS>(d, slot, side, (int)entry.y, body, h); else pos_half_load(d, slot, side, (int)entry.y, ph);
 			if (side == 0) atomicOr(&s_present, 1ull << my_col);
 			// this body's LDS slot; the lane that claims it brings the record in
 			at = uf_prio(body) & (HC_TABLE - 1);
@@ -2223,7 +2225,7 @@ template <int MODE> __global__ void __launch_bounds__(HC_TPB) k_solve_hc(DV d, i
 		const uint32_t cb = d.cstarts[c], ce = d.cstarts[c + 1];
 		for (uint32_t k = cb + pair; k < ce; k += HC_WG_PAIRS) {
 			if (!(CUR(d).np_col[k] & NPCOL_CATCH_ALL)) continue;
-			if (MODE == 1) solve_velocity_pair_t<2>(d, k, side, d.vel); else solve_position_pair(d, k, side);
+			if (MODE == 1) solve_velocity_pair_t<2, ROWS>(d, k, side, d.vel); else solve_position_pair(d, k, side);
 		}
 		__syncthreads();
 	}
@@ -2231,7 +2233,7 @@ template <int MODE> __global__ void __launch_bounds__(HC_TPB) k_solve_hc(DV d, i
 	uint64_t last = 0; bool have_last = false;
 	for (uint32_t it = 0; it < ocount; ++it) {
 		const uint32_t bslot = overflow_next(d, ofirst, ocount, last, have_last);
-		if (MODE == 1) solve_velocity_pair_t<2>(d, bslot, side, d.vel); else solve_position_pair(d, bslot, side);
+		if (MODE == 1) solve_velocity_pair_t<2, ROWS>(d, bslot, side, d.vel); else solve_position_pair(d, bslot, side);
 	}
 }
 
@@ -2268,7 +2270,7 @@ __global__ void __launch_bounds__(SMALL_TPB) k_solve_small(DV d, int warm_start,
 			}
 		}
 		ConHalf h; int my_col = -1;
-		if (mine) { half_load(d, slot, side, h); my_col = (h.np_col >> 8) & 0xFF; }
+		if (mine) { half_load<0>(d, slot, side, h); my_col = (h.np_col >> 8) & 0xFF; }
 		for (int pass = 0; pass < iterations; ++pass) {
 			for (int c = 0; c < SGP_OVERFLOW_COLOUR; ++c) {
 				if (cs[c] == cs[c + 1]) continue;
@@ -2284,7 +2286,7 @@ __global__ void __launch_bounds__(SMALL_TPB) k_solve_small(DV d, int warm_start,
 				const uint32_t b = cs[c], e = cs[c + 1];
 				if (b == e) continue;
 				if (pass < 0) { for (uint32_t k = b + threadIdx.x; k < e; k += SMALL_TPB) warm_start_one_t<2>(d, k, sv); }
-				else { for (uint32_t k = b + pair; k < e; k += SMALL_TPB / 2) solve_velocity_pair_t<2>(d, k, side, sv); }
+				else { for (uint32_t k = b + pair; k < e; k += SMALL_TPB / 2) solve_velocity_pair_t<2, 0>(d, k, side, sv); }
 				__syncthreads();
 			}
 			const uint32_t first = cs[SGP_OVERFLOW_COLOUR], count = cs[SGP_OVERFLOW_COLOUR + 1] - first;
@@ -2293,7 +2295,7 @@ __global__ void __launch_bounds__(SMALL_TPB) k_solve_small(DV d, int warm_start,
 					uint64_t last = 0; bool have_last = false;
 					for (uint32_t it = 0; it < count; ++it) {
 						const uint32_t bslot = overflow_next(d, first, count, last, have_last);
-						if (pass < 0) { if (side == 0) warm_start_one_t<2>(d, bslot, sv); } else solve_velocity_pair_t<2>(d, bslot, side, sv);
+						if (pass < 0) { if (side == 0) warm_start_one_t<2>(d, bslot, sv); } else solve_velocity_pair_t<2, 0>(d, bslot, side, sv);
 					}
 				}
 				__syncthreads();
@@ -3703,7 +3705,7 @@ template <int MODE> __global__ void __launch_bounds__(VEH_SOLVE_TPB) k_vehicle_s
 // The first contact colour of a velocity / position pass with the vehicles' rows in the same launch: no contact of a chassis sits in colour 0
 // (chassis_colours), so the two touch disjoint bodies and the pass order "vehicles, then the contact colours" holds without a launch of
 // its own.  The vehicle workgroups come first in the grid: they are the longer chains.
-template <int MODE> __global__ void __launch_bounds__(SOLVE_VEL_TPB) k_solve_colour_veh(DV d, int colour, uint32_t veh_blocks)
+template <int MODE, int ROWS = -1> __global__ void __launch_bounds__(SOLVE_VEL_TPB) k_solve_colour_veh(DV d, int colour, uint32_t veh_blocks)
 {
 	if (blockIdx.x < veh_blocks) {
 		const uint32_t t = blockIdx.x * SOLVE_VEL_TPB + threadIdx.x;
@@ -3713,7 +3715,7 @@ template <int MODE> __global__ void __launch_bounds__(SOLVE_VEL_TPB) k_solve_col
 	const uint32_t first = d.cstarts[colour], end = d.cstarts[colour + 1];
 	const int side = (int)(threadIdx.x & 1u);
 	for (uint32_t k = first + (((blockIdx.x - veh_blocks) * SOLVE_VEL_TPB + threadIdx.x) >> 1); k < end; k += (gridDim.x - veh_blocks) * (SOLVE_VEL_TPB / 2)) {
-		if (MODE == 1) solve_velocity_pair_t<2>(d, k, side, d.vel); else solve_position_pair(d, k, side);
+		if (MODE == 1) solve_velocity_pair_t<2, ROWS>(d, k, side, d.vel); else solve_position_pair(d, k, side);
 	}
 }
 
@@ -4295,7 +4297,7 @@ __global__ void __launch_bounds__(TS_TPB) k_ts_solve(DV d, int passes, int colou
 				bool mine;
 				if (serial) { mine = threadIdx.x < 2; if (mine) slot = overflow_next(d, base, cnt, last, have_last); }
 				else { mine = turn * TS_PAIRS + pair < cnt; slot = base + turn * TS_PAIRS + pair; }
-				if (mine) { half_load(d, slot, side, h); at = d.ts_at[2 * (size_t)slot + side]; }
+				if (mine) { half_load<0>(d, slot, side, h); at = d.ts_at[2 * (size_t)slot + side]; }
 				if (turn == 0 && ((waitmask >> c) & 1ull)) {
 					if (threadIdx.x < 64) {
 						bool ready = poll_mask == 0u; int spins = 0, ok = 1;
@@ -4440,27 +4442,27 @@ void launch_setup(const DV& d, uint32_t n_man, hipStream_t s)
 	hipLaunchKernelGGL(k_setup_slots, dim3(std::max(64u, std::min(4096u, (n_man + TPB * SLOTS_PER_THREAD - 1) / (TPB * SLOTS_PER_THREAD)))), dim3(TPB), 0, s, d);
 	hipLaunchKernelGGL(k_setup, dim3(stride_grid(n_man)), dim3(TPB), 0, s, d);
 }
-void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStream_t s)
+void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStream_t s, int compact_rows)
 {
 	uint32_t blocks = (est + est / 8 + 64 + SOLVE_TPB - 1) / SOLVE_TPB;      // warm start: one thread per constraint, one wave per workgroup
 	if (mode != 0) blocks = (est + est / 8 + 64 + SOLVE_VEL_TPB / 2 - 1) / (SOLVE_VEL_TPB / 2);
 	if (blocks > 8192) blocks = 8192;
 	if (mode == 0) hipLaunchKernelGGL(k_solve_colour<0>, dim3(blocks), dim3(SOLVE_TPB), 0, s, d, colour);
-	else if (mode == 1) hipLaunchKernelGGL(k_solve_colour<1>, dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour);
+	else if (mode == 1) { if (compact_rows) hipLaunchKernelGGL((k_solve_colour<1, 1>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour); else hipLaunchKernelGGL((k_solve_colour<1, 0>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour); }
 	else hipLaunchKernelGGL(k_solve_colour<2>, dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour);
 }
-void launch_solve_colour_veh(const DV& d, int colour, uint32_t est, int mode, hipStream_t s)
+void launch_solve_colour_veh(const DV& d, int colour, uint32_t est, int mode, hipStream_t s, int compact_rows)
 {
 	uint32_t blocks = (est + est / 8 + 64 + SOLVE_VEL_TPB / 2 - 1) / (SOLVE_VEL_TPB / 2);
 	if (blocks > 8192) blocks = 8192;
 	const uint32_t vb = (d.n_vehicles * 4u + SOLVE_VEL_TPB - 1) / SOLVE_VEL_TPB;
-	if (mode == 1) hipLaunchKernelGGL(k_solve_colour_veh<1>, dim3(vb + blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour, vb);
-	else hipLaunchKernelGGL(k_solve_colour_veh<2>, dim3(vb + blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour, vb);
+	if (mode == 1) { if (compact_rows) hipLaunchKernelGGL((k_solve_colour_veh<1, 1>), dim3(vb + blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour, vb); else hipLaunchKernelGGL((k_solve_colour_veh<1, 0>), dim3(vb + blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour, vb); }
+	else hipLaunchKernelGGL((k_solve_colour_veh<2, -1>), dim3(vb + blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour, vb);
 }
 void launch_warm_bodies(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_warm_bodies, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
-void launch_solve_tail(const DV& d, int first_colour, int mode, hipStream_t s)
+void launch_solve_tail(const DV& d, int first_colour, int mode, hipStream_t s, int compact_rows)
 {
-	if (mode == 1) hipLaunchKernelGGL(k_solve_tail_vel, dim3(1), dim3(TAIL_VEL_TPB), 0, s, d, first_colour);      // (position passes of the tail: one thread per constraint measured faster, 30 against 37 us)
+	if (mode == 1) { if (compact_rows) hipLaunchKernelGGL(k_solve_tail_vel<1>, dim3(1), dim3(TAIL_VEL_TPB), 0, s, d, first_colour); else hipLaunchKernelGGL(k_solve_tail_vel<0>, dim3(1), dim3(TAIL_VEL_TPB), 0, s, d, first_colour); }      // (position passes of the tail: one thread per constraint measured faster, 30 against 37 us)
 	else hipLaunchKernelGGL(k_solve_tail, dim3(1), dim3(512), 0, s, d, first_colour, mode);
 }
 void launch_hc_build(const DV& d, int first_colour, uint32_t est, hipStream_t s)
@@ -4480,12 +4482,12 @@ void launch_hc_probe(const DV& d, int probe_colour, uint32_t probe_est, hipStrea
 	hipLaunchKernelGGL(k_hc_probe, dim3(pb), dim3(TPB), 0, s, d, probe_colour);
 	hipLaunchKernelGGL(k_hc_init, dim3(pb), dim3(TPB), 0, s, d, probe_colour);      // (every body the probe touched, i.e. also every body of the real build)
 }
-void launch_solve_hc(const DV& d, int first_colour, uint32_t est, int mode, hipStream_t s)
+void launch_solve_hc(const DV& d, int first_colour, uint32_t est, int mode, hipStream_t s, int compact_rows)
 {
 	// list entries: a component of n constraints takes the next power of two (< 2 n), plus the padding of the classes
 	const uint32_t blocks = std::max(1u, std::min(2048u, (2u * est + HC_CLASSES * HC_WG_PAIRS) / HC_WG_PAIRS));
-	if (mode == 1) hipLaunchKernelGGL(k_solve_hc<1>, dim3(blocks), dim3(HC_TPB), 0, s, d, first_colour);
-	else hipLaunchKernelGGL(k_solve_hc<2>, dim3(blocks), dim3(HC_TPB), 0, s, d, first_colour);
+	if (mode == 1) { if (compact_rows) hipLaunchKernelGGL((k_solve_hc<1, 1>), dim3(blocks), dim3(HC_TPB), 0, s, d, first_colour); else hipLaunchKernelGGL((k_solve_hc<1, 0>), dim3(blocks), dim3(HC_TPB), 0, s, d, first_colour); }
+	else hipLaunchKernelGGL((k_solve_hc<2, -1>), dim3(blocks), dim3(HC_TPB), 0, s, d, first_colour);
 }
 void launch_solve_small(const DV& d, int warm_start, int iterations, int lane_pairs, hipStream_t s)
 {

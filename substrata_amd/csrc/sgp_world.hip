@@ -1061,7 +1061,7 @@ static void make_plan(const sgp_world* w, StepPlan& p)
 	// (the table takes what fits and leaves the rest in global memory, so the bound is about speed, not correctness), no vehicle rows between
 	// the passes, and enough body slots for k_ts_label's grid to clear the (colour, tile) histogram
 	p.tile_solver = (w->use_tile_solver && w->dv.ts_nt && !p.small_world && w->n_vehicles == 0 && p.vel_iters > 0 && w->n_con >= w->ts_min_constraints &&
-	                 w->high >= SGP_MAX_COLOURS * w->dv.ts_nt && w->last_active <= w->dv.ts_nt * 1536u) ? w->use_tile_solver : 0;      // (2: debugging aid -- the tile order of the slots, solved by the colour launches)
+	                 w->high >= SGP_MAX_COLOURS * w->dv.ts_nt && w->last_active <= w->dv.ts_nt * 1536u && !w->h_sp->compact_rows) ? w->use_tile_solver : 0;      // (2: debugging aid -- the tile order of the slots, solved by the colour launches)
 	p.sp = *w->h_sp;
 }
 
@@ -1117,9 +1117,9 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 		// non-contact constraints first: the vehicles' rows ride in the launch of contact colour 0 (no chassis contact is in that colour) when the plan has one
 		const bool veh_fused = p.n_vehicles && p.tail_first > 0 && mode != 0 && w->fuse_vehicle_solve;
 		if (p.n_vehicles && !veh_fused) { KScope k(w, KC_VEHICLE); launch_vehicle_solve(d, mode, s); }
-		for (int c = 0; c < p.tail_first; ++c) { KScope k(w, kc); if (c == 0 && veh_fused) launch_solve_colour_veh(d, c, p.colour_est[c], mode, s); else launch_solve_colour(d, c, p.colour_est[c], mode, s); }
-		if (p.hc_first >= 0) { KScope k(w, kc); launch_solve_hc(d, p.hc_first, p.hc_est, mode, s); }      // colours >= tail_first by component + overflow colour
-		else { KScope k(w, kc); launch_solve_tail(d, p.tail_first, mode, s); }
+		for (int c = 0; c < p.tail_first; ++c) { KScope k(w, kc); if (c == 0 && veh_fused) launch_solve_colour_veh(d, c, p.colour_est[c], mode, s, (int)p.sp.compact_rows); else launch_solve_colour(d, c, p.colour_est[c], mode, s, (int)p.sp.compact_rows); }
+		if (p.hc_first >= 0) { KScope k(w, kc); launch_solve_hc(d, p.hc_first, p.hc_est, mode, s, (int)p.sp.compact_rows); }      // colours >= tail_first by component + overflow colour
+		else { KScope k(w, kc); launch_solve_tail(d, p.tail_first, mode, s, (int)p.sp.compact_rows); }
 	};
 	if (p.small_world) { KScope k(w, KC_SOLVE_VELOCITY); launch_solve_small(d, p.warm_start, p.vel_iters, p.small_pairs, s); }
 	else {
@@ -1134,7 +1134,7 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 			// the big colours of a pass in the resident tile launch, the sparse high colours by connected component (one launch each per pass)
 			for (int it = 0; it < p.vel_iters; ++it) {
 				{ KScope k(w, KC_SOLVE_VELOCITY); launch_ts_solve(d, 1, p.tail_first, s); }
-				{ KScope k(w, KC_SOLVE_VELOCITY); launch_solve_hc(d, p.hc_first, p.hc_est, 1, s); }
+				{ KScope k(w, KC_SOLVE_VELOCITY); launch_solve_hc(d, p.hc_first, p.hc_est, 1, s, (int)p.sp.compact_rows); }
 			}
 		}
 		else for (int it = 0; it < p.vel_iters; ++it) solve_pass(1, KC_SOLVE_VELOCITY);
