@@ -275,66 +275,58 @@ SGP_DEV static void sgd_part_setup(sgd_axis_part* p, const sgd_chassis* c, v3 r1
 	p->active = 1;
 }
 
-SGP_DEV static void sgd_part_apply(const sgd_axis_part* p, sgd_chassis* c, v3 axis, float lambda)
-{
-	c->v = v3_sub(c->v, v3_scale(axis, lambda * c->im));
-	c->w = v3_sub(c->w, v3_scale(p->iI_r1xa, lambda));
-}
+// ---- pre-step, before the casts: lean controller, steering angle and the cast request of every wheel (VehicleConstraint::OnStep, first half) ------
 
-SGP_DEV static void sgd_part_solve(sgd_axis_part* p, sgd_chassis* c, v3 ground_vel, v3 axis, float lo, float hi)
+// By the lanes of the vehicle's wave: the lean controller is one chain (lane 0), the steering angle and the cast request of wheel i are lane i's.
+SGP_DEV static void sgd_vehicle_precast_lanes(sgd_vehicle* v, const sgd_chassis* c, float dt, int lane)
 {
-	const float jv = v3_dot(axis, v3_sub(c->v, ground_vel)) + v3_dot(p->r1xa, c->w);
-	const float lambda = p->eff * (jv - (p->softness * p->lambda + p->bias));
-	const float nl = clampf(p->lambda + lambda, lo, hi);
-	sgd_part_apply(p, c, axis, nl - p->lambda);
-	p->lambda = nl;
-}
-
-// ---- pre-step, part A: steering angle and the cast request of every wheel (VehicleConstraint::OnStep, first half) ------
-
-SGP_DEV static void sgd_vehicle_pre_a(sgd_vehicle* v, const sgd_chassis* c, float dt)
-{
+	__shared__ float lean_limit[2];          // what the steering limit of every wheel needs from the lean controller: WheelBase tan(MaxLean) g, v^2
 	const m33 R = quat_to_m33(c->rot);
-	float lean_max_steer_factor = 0.0f, velocity_sq = 0.0f;
-	if (v->is_motorcycle) {
-		// MotorcycleController::PreCollide: the wheels still hold the contacts and impulses of the previous step here
-		const v3 forward = m33_mul(R, v->forward);
-		const v3 world_up = V3(0.0f, 0.0f, 1.0f);
-		if (v->lean_enabled) {
-			v3 tl = V3(0, 0, 0);
+	if (lane == 0) {
+		float lean_max_steer_factor = 0.0f, velocity_sq = 0.0f;
+		if (v->is_motorcycle) {
+			// MotorcycleController::PreCollide: the wheels still hold the contacts and impulses of the previous step here
+			const v3 forward = m33_mul(R, v->forward);
+			const v3 world_up = V3(0.0f, 0.0f, 1.0f);
+			if (v->lean_enabled) {
+				v3 tl = V3(0, 0, 0);
+				for (int i = 0; i < v->num_wheels; ++i) {
+					const sgd_wheel* w = &v->wheels[i];
+					if (w->has_contact) tl = v3_add(tl, v3_add(v3_scale(w->contact_normal, w->suspension.lambda + w->max_up.lambda), v3_scale(w->contact_lat, w->lateral.lambda)));
+				}
+				tl = sgd_normalized_or(tl, world_up);
+				v->target_lean = v3_add(v3_scale(v->target_lean, v->lean_smoothing), v3_scale(tl, 1.0f - v->lean_smoothing));
+				v->target_lean = v3_sub(v->target_lean, v3_scale(forward, v3_dot(v->target_lean, forward)));       // lean sideways only
+				v->target_lean = sgd_normalized_or(v->target_lean, world_up);
+				v3 adj_up = v3_sub(world_up, v3_scale(forward, v3_dot(world_up, forward)));
+				adj_up = sgd_normalized_or(adj_up, world_up);
+				const float w_angle = -sgd_signf(v3_dot(v3_cross(v->target_lean, adj_up), forward)) * sgd_acos11(clampf(v3_dot(v->target_lean, adj_up), -1.0f, 1.0f));
+				if (fabsf(w_angle) > v->max_lean_angle) v->target_lean = sgd_rotate_about(forward, sgd_signf(w_angle) * v->max_lean_angle, adj_up);
+				const v3 up = m33_mul(R, v->up);
+				const float d_angle = -sgd_signf(v3_dot(v3_cross(v->target_lean, up), forward)) * sgd_acos11(clampf(v3_dot(v->target_lean, up), -1.0f, 1.0f));
+				v->lean_integrated_delta = v->lean_integrated_delta + d_angle * dt;
+			} else {
+				v->target_lean = world_up;
+				v->lean_integrated_delta = 0.0f;
+			}
+			// steering limit: SteerAngle <= asin(WheelBase tan(MaxLean) g / (v^2 cos(caster)))
+			float lo = 3.0e38f, hi = -3.0e38f;
 			for (int i = 0; i < v->num_wheels; ++i) {
 				const sgd_wheel* w = &v->wheels[i];
-				if (w->has_contact) tl = v3_add(tl, v3_add(v3_scale(w->contact_normal, w->suspension.lambda + w->max_up.lambda), v3_scale(w->contact_lat, w->lateral.lambda)));
+				const float val = v3_dot(v3_add(w->position, v3_scale(w->suspension_dir, w->sus_max)), v->forward);
+				lo = fminf(lo, val); hi = fmaxf(hi, val);
 			}
-			tl = sgd_normalized_or(tl, world_up);
-			v->target_lean = v3_add(v3_scale(v->target_lean, v->lean_smoothing), v3_scale(tl, 1.0f - v->lean_smoothing));
-			v->target_lean = v3_sub(v->target_lean, v3_scale(forward, v3_dot(v->target_lean, forward)));       // lean sideways only
-			v->target_lean = sgd_normalized_or(v->target_lean, world_up);
-			v3 adj_up = v3_sub(world_up, v3_scale(forward, v3_dot(world_up, forward)));
-			adj_up = sgd_normalized_or(adj_up, world_up);
-			const float w_angle = -sgd_signf(v3_dot(v3_cross(v->target_lean, adj_up), forward)) * sgd_acos11(clampf(v3_dot(v->target_lean, adj_up), -1.0f, 1.0f));
-			if (fabsf(w_angle) > v->max_lean_angle) v->target_lean = sgd_rotate_about(forward, sgd_signf(w_angle) * v->max_lean_angle, adj_up);
-			const v3 up = m33_mul(R, v->up);
-			const float d_angle = -sgd_signf(v3_dot(v3_cross(v->target_lean, up), forward)) * sgd_acos11(clampf(v3_dot(v->target_lean, up), -1.0f, 1.0f));
-			v->lean_integrated_delta = v->lean_integrated_delta + d_angle * dt;
-		} else {
-			v->target_lean = world_up;
-			v->lean_integrated_delta = 0.0f;
+			lean_max_steer_factor = (hi - lo) * v->tan_max_lean * v->gravity_len;
+			const float vel = v3_dot(c->v, forward);
+			velocity_sq = vel * vel;
+			v->lean_applied_impulse = 0.0f;
 		}
-		// steering limit: SteerAngle <= asin(WheelBase tan(MaxLean) g / (v^2 cos(caster)))
-		float lo = 3.0e38f, hi = -3.0e38f;
-		for (int i = 0; i < v->num_wheels; ++i) {
-			const sgd_wheel* w = &v->wheels[i];
-			const float val = v3_dot(v3_add(w->position, v3_scale(w->suspension_dir, w->sus_max)), v->forward);
-			lo = fminf(lo, val); hi = fmaxf(hi, val);
-		}
-		lean_max_steer_factor = (hi - lo) * v->tan_max_lean * v->gravity_len;
-		const float vel = v3_dot(c->v, forward);
-		velocity_sq = vel * vel;
-		v->lean_applied_impulse = 0.0f;
+		lean_limit[0] = lean_max_steer_factor; lean_limit[1] = velocity_sq;
 	}
-	for (int i = 0; i < v->num_wheels; ++i) {
-		sgd_wheel* w = &v->wheels[i];
+	__syncthreads();
+	if (lane < v->num_wheels) {
+		const float lean_max_steer_factor = lean_limit[0], velocity_sq = lean_limit[1];
+		sgd_wheel* w = &v->wheels[lane];
 		w->steer_angle = -v->in_right * w->max_steer;                       // WheeledVehicleController::PreCollide
 		if (v->is_motorcycle && w->max_steer != 0.0f) {
 			const float cos_caster = v3_dot(w->steering_axis, v->up);
@@ -415,46 +407,56 @@ SGP_DEV static void sgd_differential_split(const sgd_differential* d, float wl, 
 	}
 }
 
-// Returns 1 when the chassis' sleep timer must be reset (wheels still spinning).
-SGP_DEV static int sgd_vehicle_pre_b(sgd_vehicle* v, sgd_chassis* c, float dt)
+// The controller step of one vehicle by the lanes of its wave (VehicleConstraint::OnStep after the casts, WheeledVehicleController::PostCollide,
+// VehicleConstraint::SetupVelocityConstraint).  `v` is the record in LDS, `c` this lane's copy of the chassis state, `lane` 0..63.
+// What belongs to one wheel -- its contact frame, tyre slip and friction, brake, the four axis rows -- is the work of lane i = wheel i; what
+// couples the wheels (anti-roll bars, engine / clutch / differentials / gearbox) is short and sequential: the anti-roll impulses are applied by
+// every lane to its own copy of the chassis (the same operands in the same order: the same bits, and no broadcast), the drivetrain runs on
+// lane 0 between two barriers.  A wheel's arithmetic is that of the sequential statement wheel after wheel: nothing a wheel computes in one
+// phase reads what another wheel computes in the same phase.  Returns (to every lane) whether the chassis' sleep timer must be reset.
+SGP_DEV static int sgd_vehicle_controller_lanes(sgd_vehicle* v, sgd_chassis* c, float dt, int lane)
 {
 	const m33 R = quat_to_m33(c->rot);
 	const int nw = v->num_wheels;
-	// contact frames
-	for (int i = 0; i < nw; ++i) {
-		sgd_wheel* w = &v->wheels[i];
-		if (!w->has_contact) { w->suspension_length = w->sus_max; continue; }
-		w->axle_plane_constant = v3_dot(w->contact_normal, v3_add(w->cast_origin, v3_scale(w->cast_dir, w->suspension_length)));
-		const v3 steering_axis = m33_mul(R, w->steering_axis);
-		const v3 forward = sgd_rotate_about(steering_axis, w->steer_angle, m33_mul(R, w->wheel_forward));
-		v3 lat = v3_cross(forward, w->contact_normal);
-		const float ll = v3_len(lat);
-		lat = ll > 1.0e-12f ? v3_scale(lat, 1.0f / ll) : V3(0, 0, 0);
-		w->contact_lat = lat;
-		w->contact_long = v3_cross(w->contact_normal, lat);
+	const bool mine = lane < nw;
+	sgd_wheel* w = &v->wheels[mine ? lane : 0];
+	// 1. contact frame of the own wheel
+	if (mine) {
+		if (!w->has_contact) w->suspension_length = w->sus_max;
+		else {
+			w->axle_plane_constant = v3_dot(w->contact_normal, v3_add(w->cast_origin, v3_scale(w->cast_dir, w->suspension_length)));
+			const v3 steering_axis = m33_mul(R, w->steering_axis);
+			const v3 forward = sgd_rotate_about(steering_axis, w->steer_angle, m33_mul(R, w->wheel_forward));
+			v3 lat = v3_cross(forward, w->contact_normal);
+			const float ll = v3_len(lat);
+			lat = ll > 1.0e-12f ? v3_scale(lat, 1.0f / ll) : V3(0, 0, 0);
+			w->contact_lat = lat;
+			w->contact_long = v3_cross(w->contact_normal, lat);
+		}
+		w->anti_roll_impulse = 0.0f;
 	}
-	// anti-roll bars: impulse from the suspension length difference, applied to the chassis at the two contact points
-	for (int i = 0; i < nw; ++i) v->wheels[i].anti_roll_impulse = 0.0f;
-	for (int k = 0; k < v->num_anti_roll_bars; ++k) {
-		sgd_wheel* lw = &v->wheels[v->anti_roll_bars[k].left]; sgd_wheel* rw = &v->wheels[v->anti_roll_bars[k].right];
-		if (lw->has_contact && rw->has_contact) {
-			const float impulse = (rw->suspension_length - lw->suspension_length) * v->anti_roll_bars[k].stiffness * dt;
-			lw->anti_roll_impulse = -impulse; rw->anti_roll_impulse = impulse;
+	__syncthreads();
+	// 2. anti-roll bars: impulse from the difference of the suspension lengths, on the chassis at the two contact points (wheel order)
+	if (lane == 0) {
+		for (int k = 0; k < v->num_anti_roll_bars; ++k) {
+			sgd_wheel* lw = &v->wheels[v->anti_roll_bars[k].left]; sgd_wheel* rw = &v->wheels[v->anti_roll_bars[k].right];
+			if (lw->has_contact && rw->has_contact) {
+				const float impulse = (rw->suspension_length - lw->suspension_length) * v->anti_roll_bars[k].stiffness * dt;
+				lw->anti_roll_impulse = -impulse; rw->anti_roll_impulse = impulse;
+			}
 		}
 	}
+	__syncthreads();
 	for (int i = 0; i < nw; ++i) {
-		sgd_wheel* w = &v->wheels[i];
-		if (!w->has_contact || w->anti_roll_impulse == 0.0f) continue;
-		const v3 J = v3_scale(w->contact_normal, w->anti_roll_impulse);
+		const sgd_wheel* o = &v->wheels[i];
+		if (!o->has_contact || o->anti_roll_impulse == 0.0f) continue;
+		const v3 J = v3_scale(o->contact_normal, o->anti_roll_impulse);
 		c->v = v3_add(c->v, v3_scale(J, c->im));
-		c->w = v3_add(c->w, sym33_mul(c->I, v3_cross(v3_sub(w->contact_pos, c->pos), J)));
+		c->w = v3_add(c->w, sym33_mul(c->I, v3_cross(v3_sub(o->contact_pos, c->pos), J)));
 	}
-
-	// ---- WheeledVehicleController::PostCollide ----
+	// 3. WheelWV::Update of the own wheel: spin damping, rotation angle, slip -> tyre friction
 	const float old_rpm = v->engine_rpm;
-	// WheelWV::Update: spin damping, rotation angle, slip -> tyre friction
-	for (int i = 0; i < nw; ++i) {
-		sgd_wheel* w = &v->wheels[i];
+	if (mine) {
 		w->angular_velocity = w->angular_velocity * fmaxf(0.0f, 1.0f - w->ang_damping * dt);
 		w->angle = w->angle + w->angular_velocity * dt;
 		if (w->angle > 2.0f * SGD_VEH_PI) w->angle = w->angle - 2.0f * SGD_VEH_PI;
@@ -475,84 +477,86 @@ SGP_DEV static int sgd_vehicle_pre_b(sgd_vehicle* v, sgd_chassis* c, float dt)
 			w->long_slip = 0.0f; w->lat_slip = 0.0f; w->comb_long_fric = 0.0f; w->comb_lat_fric = 0.0f;
 		}
 	}
-	float forward_input = fabsf(v->in_forward) * v->clutch_friction;                 // auto transmission: no throttle while switching
-	v->engine_rpm = v->engine_rpm * fmaxf(0.0f, 1.0f - v->engine_ang_damping * dt); // VehicleEngine::ApplyDamping
-	const float engine_torque = forward_input * v->engine_max_torque * sgd_curve3(v->engine_curve, v->engine_rpm / v->engine_max_rpm);
-
-	// driven differentials and their share of the clutch torque (limited slip between differentials)
-	float dd_omega[2], dd_ratio[2]; int dd_idx[2]; int ndd = 0;
-	float omin = 3.0e38f, omax = 0.0f;
-	for (int k = 0; k < v->num_differentials; ++k) {
-		const sgd_differential* d = &v->differentials[k];
-		float avg = 0.0f; int cnt = 0;
-		if (d->left >= 0) { avg = avg + v->wheels[d->left].angular_velocity; ++cnt; }
-		if (d->right >= 0) { avg = avg + v->wheels[d->right].angular_velocity; ++cnt; }
-		if (cnt > 0) {
-			avg = fabsf(avg * d->ratio / (float)cnt);
-			dd_omega[ndd] = avg; dd_ratio[ndd] = d->engine_torque_ratio; dd_idx[ndd] = k; ++ndd;
-			omin = fminf(omin, avg); omax = fmaxf(omax, avg);
-		}
-	}
-	if (v->differential_limited_slip_ratio < 3.0e38f && omax > omin) {
-		float tf[2]; float sum = 0.0f;
-		for (int k = 0; k < ndd; ++k) { tf[k] = (omax - dd_omega[k]) / (omax - omin); sum = sum + tf[k]; }
-		for (int k = 0; k < ndd; ++k) tf[k] = tf[k] / sum;
-		const float lo = fmaxf(1.0e-3f, omin), hi = fmaxf(1.0e-3f, omax);
-		const float alpha = fminf((hi / lo - 1.0f) / (v->differential_limited_slip_ratio - 1.0f), 1.0f);
-		for (int k = 0; k < ndd; ++k) dd_ratio[k] = (1.0f - alpha) * dd_ratio[k] + alpha * tf[k];
-	}
-	// driven wheels: engine->wheel speed ratio and torque fraction
-	const float trans_ratio = sgd_gear_ratio(v);
-	int dw[4]; float dw_ratio[4], dw_frac[4]; int ndw = 0;
-	for (int k = 0; k < ndd; ++k) {
-		const sgd_differential* d = &v->differentials[dd_idx[k]];
-		const float ratio = trans_ratio * d->ratio;
-		if (d->left >= 0 && d->right >= 0) {
-			float fl, fr;
-			sgd_differential_split(d, v->wheels[d->left].angular_velocity, v->wheels[d->right].angular_velocity, &fl, &fr);
-			dw[ndw] = d->left; dw_ratio[ndw] = ratio; dw_frac[ndw] = dd_ratio[k] * fl; ++ndw;
-			dw[ndw] = d->right; dw_ratio[ndw] = ratio; dw_frac[ndw] = dd_ratio[k] * fr; ++ndw;
-		} else if (d->left >= 0) { dw[ndw] = d->left; dw_ratio[ndw] = ratio; dw_frac[ndw] = dd_ratio[k]; ++ndw; }
-		else if (d->right >= 0) { dw[ndw] = d->right; dw_ratio[ndw] = ratio; dw_frac[ndw] = dd_ratio[k]; ++ndw; }
-	}
-	// implicit clutch:  tc = tcs (we' - mean_j R_j ww_j'),  we' = we + dt (te - tc)/Ie,  ww_i' = ww_i + dt R_i F_i tc / Iw_i
-	const float rpm_to_w = 2.0f * SGD_VEH_PI / 60.0f, w_to_rpm = 60.0f / (2.0f * SGD_VEH_PI);
-	int solved = 0;
-	if (ndw > 0) {
-		const float tcs = trans_ratio != 0.0f ? v->clutch_friction * v->clutch_strength : 0.0f;
-		if (tcs > 0.0f) {
-			const float we = v->engine_rpm * rpm_to_w;
-			float s0 = 0.0f, bsum = 0.0f;
-			for (int k = 0; k < ndw; ++k) {
-				const sgd_wheel* w = &v->wheels[dw[k]];
-				s0 = s0 + dw_ratio[k] * w->angular_velocity;
-				bsum = bsum + dw_ratio[k] * dw_ratio[k] * dw_frac[k] / w->inertia;
+	__syncthreads();
+	// 4. the drivetrain couples the driven wheels: one lane
+	if (lane == 0) {
+		float forward_input = fabsf(v->in_forward) * v->clutch_friction;                 // auto transmission: no throttle while switching
+		v->engine_rpm = v->engine_rpm * fmaxf(0.0f, 1.0f - v->engine_ang_damping * dt); // VehicleEngine::ApplyDamping
+		const float engine_torque = forward_input * v->engine_max_torque * sgd_curve3(v->engine_curve, v->engine_rpm / v->engine_max_rpm);
+		// driven differentials and their share of the clutch torque (limited slip between differentials)
+		float dd_omega[2], dd_ratio[2]; int dd_idx[2]; int ndd = 0;
+		float omin = 3.0e38f, omax = 0.0f;
+		for (int k = 0; k < v->num_differentials; ++k) {
+			const sgd_differential* d = &v->differentials[k];
+			float avg = 0.0f; int cnt = 0;
+			if (d->left >= 0) { avg = avg + v->wheels[d->left].angular_velocity; ++cnt; }
+			if (d->right >= 0) { avg = avg + v->wheels[d->right].angular_velocity; ++cnt; }
+			if (cnt > 0) {
+				avg = fabsf(avg * d->ratio / (float)cnt);
+				dd_omega[ndd] = avg; dd_ratio[ndd] = d->engine_torque_ratio; dd_idx[ndd] = k; ++ndd;
+				omin = fminf(omin, avg); omax = fmaxf(omax, avg);
 			}
-			const float inv_m = 1.0f / (float)ndw;
-			s0 = s0 * inv_m;
-			const float A = dt / v->engine_inertia, B = dt * bsum * inv_m;
-			const float tc = tcs * (we + A * engine_torque - s0) / (1.0f + tcs * (A + B));
-			v->engine_rpm = (we + A * (engine_torque - tc)) * w_to_rpm;
-			for (int k = 0; k < ndw; ++k) {
-				sgd_wheel* w = &v->wheels[dw[k]];
-				w->angular_velocity = w->angular_velocity + dt * dw_ratio[k] * dw_frac[k] * tc / w->inertia;
-			}
-			solved = 1;
 		}
+		if (v->differential_limited_slip_ratio < 3.0e38f && omax > omin) {
+			float tf[2]; float sum = 0.0f;
+			for (int k = 0; k < ndd; ++k) { tf[k] = (omax - dd_omega[k]) / (omax - omin); sum = sum + tf[k]; }
+			for (int k = 0; k < ndd; ++k) tf[k] = tf[k] / sum;
+			const float lo = fmaxf(1.0e-3f, omin), hi = fmaxf(1.0e-3f, omax);
+			const float alpha = fminf((hi / lo - 1.0f) / (v->differential_limited_slip_ratio - 1.0f), 1.0f);
+			for (int k = 0; k < ndd; ++k) dd_ratio[k] = (1.0f - alpha) * dd_ratio[k] + alpha * tf[k];
+		}
+		// driven wheels: engine->wheel speed ratio and torque fraction
+		const float trans_ratio = sgd_gear_ratio(v);
+		int dw[4]; float dw_ratio[4], dw_frac[4]; int ndw = 0;
+		for (int k = 0; k < ndd; ++k) {
+			const sgd_differential* d = &v->differentials[dd_idx[k]];
+			const float ratio = trans_ratio * d->ratio;
+			if (d->left >= 0 && d->right >= 0) {
+				float fl, fr;
+				sgd_differential_split(d, v->wheels[d->left].angular_velocity, v->wheels[d->right].angular_velocity, &fl, &fr);
+				dw[ndw] = d->left; dw_ratio[ndw] = ratio; dw_frac[ndw] = dd_ratio[k] * fl; ++ndw;
+				dw[ndw] = d->right; dw_ratio[ndw] = ratio; dw_frac[ndw] = dd_ratio[k] * fr; ++ndw;
+			} else if (d->left >= 0) { dw[ndw] = d->left; dw_ratio[ndw] = ratio; dw_frac[ndw] = dd_ratio[k]; ++ndw; }
+			else if (d->right >= 0) { dw[ndw] = d->right; dw_ratio[ndw] = ratio; dw_frac[ndw] = dd_ratio[k]; ++ndw; }
+		}
+		// implicit clutch:  tc = tcs (we' - mean_j R_j ww_j'),  we' = we + dt (te - tc)/Ie,  ww_i' = ww_i + dt R_i F_i tc / Iw_i
+		const float rpm_to_w = 2.0f * SGD_VEH_PI / 60.0f, w_to_rpm = 60.0f / (2.0f * SGD_VEH_PI);
+		int solved = 0;
+		if (ndw > 0) {
+			const float tcs = trans_ratio != 0.0f ? v->clutch_friction * v->clutch_strength : 0.0f;
+			if (tcs > 0.0f) {
+				const float we = v->engine_rpm * rpm_to_w;
+				float s0 = 0.0f, bsum = 0.0f;
+				for (int k = 0; k < ndw; ++k) {
+					const sgd_wheel* o = &v->wheels[dw[k]];
+					s0 = s0 + dw_ratio[k] * o->angular_velocity;
+					bsum = bsum + dw_ratio[k] * dw_ratio[k] * dw_frac[k] / o->inertia;
+				}
+				const float inv_m = 1.0f / (float)ndw;
+				s0 = s0 * inv_m;
+				const float A = dt / v->engine_inertia, B = dt * bsum * inv_m;
+				const float tc = tcs * (we + A * engine_torque - s0) / (1.0f + tcs * (A + B));
+				v->engine_rpm = (we + A * (engine_torque - tc)) * w_to_rpm;
+				for (int k = 0; k < ndw; ++k) {
+					sgd_wheel* o = &v->wheels[dw[k]];
+					o->angular_velocity = o->angular_velocity + dt * dw_ratio[k] * dw_frac[k] * tc / o->inertia;
+				}
+				solved = 1;
+			}
+		}
+		if (!solved) v->engine_rpm = v->engine_rpm + w_to_rpm * engine_torque * dt / v->engine_inertia;   // VehicleEngine::ApplyTorque
+		v->engine_rpm = clampf(v->engine_rpm, v->engine_min_rpm, v->engine_max_rpm);
+		int slipping = 0;
+		for (int k = 0; k < ndw; ++k) {
+			const sgd_wheel* o = &v->wheels[dw[k]];
+			if (dw_frac[k] > 0.0f && (!o->has_contact || o->long_slip > 0.1f)) slipping = 1;
+		}
+		sgd_transmission_update(v, dt, v->engine_rpm, v->in_forward, !slipping && v->engine_rpm >= old_rpm);
 	}
-	if (!solved) v->engine_rpm = v->engine_rpm + w_to_rpm * engine_torque * dt / v->engine_inertia;   // VehicleEngine::ApplyTorque
-	v->engine_rpm = clampf(v->engine_rpm, v->engine_min_rpm, v->engine_max_rpm);
-
-	int slipping = 0;
-	for (int k = 0; k < ndw; ++k) {
-		const sgd_wheel* w = &v->wheels[dw[k]];
-		if (dw_frac[k] > 0.0f && (!w->has_contact || w->long_slip > 0.1f)) slipping = 1;
-	}
-	sgd_transmission_update(v, dt, v->engine_rpm, v->in_forward, !slipping && v->engine_rpm >= old_rpm);
-
-	// brakes
-	for (int i = 0; i < nw; ++i) {
-		sgd_wheel* w = &v->wheels[i];
+	__syncthreads();
+	// 5. the own wheel again: brake, then the four rows (VehicleConstraint::SetupVelocityConstraint)
+	int spinning = 0;
+	if (mine) {
 		const float brake_torque = v->in_brake * w->max_brake_torque + v->in_handbrake * w->max_handbrake_torque;
 		w->brake_impulse = 0.0f;
 		if (brake_torque > 0.0f) {
@@ -564,165 +568,41 @@ SGP_DEV static int sgd_vehicle_pre_b(sgd_vehicle* v, sgd_chassis* c, float dt)
 				w->angular_velocity = w->angular_velocity + (w->angular_velocity < 0.0f ? 1.0f : -1.0f) * brake_torque * dt / w->inertia;
 			}
 		}
-	}
-
-	// ---- VehicleConstraint::SetupVelocityConstraint ----
-	for (int i = 0; i < nw; ++i) {
-		sgd_wheel* w = &v->wheels[i];
 		if (!w->has_contact) {
 			sgd_part_deactivate(&w->suspension); sgd_part_deactivate(&w->max_up); sgd_part_deactivate(&w->longitudinal); sgd_part_deactivate(&w->lateral);
-			continue;
-		}
-		const v3 r1 = v3_sub(w->contact_pos, c->pos);
-		const v3 neg_n = v3_neg(w->contact_normal);
-		float lam;
-		if (w->sus_max > w->sus_min) {
-			// spring stiffness from frequency / damping ratio and the effective mass at the average suspension point
-			const v3 fp = v3_add(w->position, v3_scale(w->suspension_dir, 0.5f * (w->sus_min + w->sus_max)));
-			const v3 fxu = v3_cross(fp, v3_neg(v->up));
-			const v3 il = c->inv_inertia_local;
-			const float eff_mass = 1.0f / (c->im + (fxu.x * il.x * fxu.x + fxu.y * il.y * fxu.y + fxu.z * il.z * fxu.z));
-			const float omega = 2.0f * SGD_VEH_PI * w->spring_freq;
-			const float stiffness = eff_mass * (omega * omega);
-			const float damping = 2.0f * eff_mass * w->spring_damp * omega;
-			const float Cc = w->suspension_length - w->sus_max - w->sus_preload;
-			lam = w->suspension.lambda;
-			sgd_part_setup(&w->suspension, c, r1, neg_n, dt, Cc, stiffness, damping);
-			if (w->suspension.active) w->suspension.lambda = lam;
-		} else sgd_part_deactivate(&w->suspension);
-		if (w->suspension_length < w->sus_min) {
-			lam = w->max_up.lambda;
-			sgd_part_setup(&w->max_up, c, r1, neg_n, dt, 0.0f, 0.0f, 0.0f);
-			if (w->max_up.active) w->max_up.lambda = lam;
-			w->suspension_length = w->sus_min;
-		} else sgd_part_deactivate(&w->max_up);
-		// the longitudinal row (engine / brake force) is never warm started: its impulse starts from zero every step
-		sgd_part_setup(&w->longitudinal, c, r1, v3_neg(w->contact_long), dt, 0.0f, 0.0f, 0.0f);
-		w->longitudinal.lambda = 0.0f;
-		lam = w->lateral.lambda;
-		sgd_part_setup(&w->lateral, c, r1, v3_neg(w->contact_lat), dt, 0.0f, 0.0f, 0.0f);
-		if (w->lateral.active) w->lateral.lambda = lam;
-	}
-	int spinning = 0;
-	for (int i = 0; i < nw; ++i) if (fabsf(v->wheels[i].angular_velocity) > 10.0f * SGD_VEH_PI / 180.0f) spinning = 1;
-	return spinning;
-}
-
-// VehicleConstraint::WarmStartVelocityConstraint
-SGP_DEV static void sgd_vehicle_warm_start(sgd_vehicle* v, sgd_chassis* c)
-{
-	for (int i = 0; i < v->num_wheels; ++i) {
-		sgd_wheel* w = &v->wheels[i];
-		if (!w->has_contact) continue;
-		if (w->suspension.active) sgd_part_apply(&w->suspension, c, v3_neg(w->contact_normal), w->suspension.lambda);
-		if (w->max_up.active) sgd_part_apply(&w->max_up, c, v3_neg(w->contact_normal), w->max_up.lambda);
-		if (w->lateral.active) sgd_part_apply(&w->lateral, c, v3_neg(w->contact_lat), w->lateral.lambda);
-	}
-}
-
-// VehicleConstraint::SolveVelocityConstraint + WheeledVehicleController::SolveLongitudinalAndLateralConstraints
-SGP_DEV static void sgd_vehicle_solve_velocity(sgd_vehicle* v, sgd_chassis* c, float dt)
-{
-	const int nw = v->num_wheels;
-	for (int i = 0; i < nw; ++i) {
-		sgd_wheel* w = &v->wheels[i];
-		if (!w->has_contact) continue;
-		const v3 neg_n = v3_neg(w->contact_normal);
-		if (w->suspension.active) sgd_part_solve(&w->suspension, c, w->contact_point_vel, neg_n, 0.0f, 3.0e38f);   // pushes, never pulls
-		if (w->max_up.active) sgd_part_solve(&w->max_up, c, w->contact_point_vel, neg_n, 0.0f, 3.0e38f);
-	}
-	float max_lat[SGD_MAX_WHEELS];
-	for (int i = 0; i < nw; ++i) {
-		sgd_wheel* w = &v->wheels[i];
-		max_lat[i] = 0.0f;
-		if (!w->has_contact) continue;
-		const float sus_lambda = w->suspension.lambda + w->max_up.lambda;
-		const float max_long = w->comb_long_fric * sus_lambda;
-		max_lat[i] = w->comb_lat_fric * sus_lambda;
-		if (!w->longitudinal.active) continue;
-		const v3 rel = v3_sub(sgd_chassis_point_vel(c, w->contact_pos), w->contact_point_vel);
-		const float rel_long = v3_dot(rel, w->contact_long);
-		if (w->brake_impulse != 0.0f) {
-			const float bi = fminf(w->brake_impulse, max_long);
-			float lo, hi;
-			if (rel_long >= 0.0f) { lo = -bi; hi = 0.0f; } else { lo = 0.0f; hi = bi; }
-			sgd_part_solve(&w->longitudinal, c, w->contact_point_vel, v3_neg(w->contact_long), lo, hi);
 		} else {
-			// impulse that brings the contact patch speed to the rolling speed of the wheel within this step
-			const float desired_w = rel_long / w->radius;
-			const float lin_imp = (w->angular_velocity - desired_w) * w->inertia / w->radius;
-			const float prev = w->longitudinal.lambda;
-			const float lim = clampf(prev + lin_imp, -max_long, max_long);
-			sgd_part_solve(&w->longitudinal, c, w->contact_point_vel, v3_neg(w->contact_long), lim, lim);
-			w->angular_velocity = w->angular_velocity - (w->longitudinal.lambda - prev) * w->radius / w->inertia;
-		}
-	}
-	for (int i = 0; i < nw; ++i) {
-		sgd_wheel* w = &v->wheels[i];
-		if (!w->has_contact || !w->lateral.active) continue;
-		sgd_part_solve(&w->lateral, c, w->contact_point_vel, v3_neg(w->contact_lat), -max_lat[i], max_lat[i]);
-	}
-	if (v->is_motorcycle && v->lean_enabled) {
-		/* MotorcycleController::SolveLongitudinalAndLateralConstraints: lean spring (PID on the angle to the target lean), only
-		   with every wheel loaded; the matching linear impulse keeps the contact patches from being swept sideways */
-		int all_in_contact = 1;
-		for (int i = 0; i < nw; ++i) if (!v->wheels[i].has_contact || !(v->wheels[i].suspension.lambda + v->wheels[i].max_up.lambda > 0.0f)) all_in_contact = 0;
-		if (all_in_contact) {
-			const m33 R = quat_to_m33(c->rot);
-			const v3 forward = m33_mul(R, v->forward), up = m33_mul(R, v->up);
-			const float d_angle = -sgd_signf(v3_dot(v3_cross(v->target_lean, up), forward)) * sgd_acos11(clampf(v3_dot(v->target_lean, up), -1.0f, 1.0f));
-			const float ddt_angle = v3_dot(c->w, forward);
-			/* Jolt re-evaluates  total = (K d - D w.f + Ki integral) dt  with the current angular velocity every iteration and applies
-			   the difference to what it applied before: a fixed-point iteration that only converges while D dt (f.I^-1 f) < 1.  Here the
-			   same fixed point is solved for directly (w.f without the lean impulse = ddt_angle - (f.I^-1 f) applied), which is its
-			   limit when it converges and stays stable when it would not. */
-			const v3 If = sym33_mul(c->I, forward);
-			const float iff = v3_dot(forward, If);
-			const float wf0 = ddt_angle - iff * v->lean_applied_impulse;
-			const float total = (v->lean_spring_constant * d_angle - v->lean_spring_damping * wf0 + v->lean_integration_coefficient * v->lean_integrated_delta) * dt
-			                    / (1.0f + v->lean_spring_damping * dt * iff);
-			const v3 old_w = c->w;
-			c->w = v3_add(c->w, v3_scale(If, total - v->lean_applied_impulse));
-			v->lean_applied_impulse = total;
-			const v3 dw = v3_sub(c->w, old_w);
-			v3 lin_acc = V3(0, 0, 0); float total_lambda = 0.0f;
-			for (int i = 0; i < nw; ++i) {
-				const sgd_wheel* w = &v->wheels[i];
-				const float lam = w->suspension.lambda + w->max_up.lambda;
-				total_lambda = total_lambda + lam;
-				lin_acc = v3_add(lin_acc, v3_scale(v3_cross(dw, v3_sub(w->contact_pos, c->pos)), lam));
-			}
-			c->v = v3_sub(c->v, v3_scale(lin_acc, 1.0f / total_lambda));      // impulse -acc / (lambda im), times im
-		} else {
-			v->lean_integrated_delta = v->lean_integrated_delta * fmaxf(0.0f, 1.0f - v->lean_integration_decay * dt);
-		}
-	}
-}
-
-/* VehicleConstraint::SolvePositionConstraint: the axle at minimum suspension length must stay on the outer side of the plane
-   through the axle position at cast time.  Works on the chassis pose (c->pos, c->rot); c->I is recomputed from the pose. */
-SGP_DEV static void sgd_vehicle_solve_position(sgd_vehicle* v, sgd_chassis* c, float baumgarte)
-{
-	for (int i = 0; i < v->num_wheels; ++i) {
-		sgd_wheel* w = &v->wheels[i];
-		if (!w->has_contact) continue;
-		const m33 R = quat_to_m33(c->rot);
-		const v3 ws_dir = m33_mul(R, w->suspension_dir);
-		const v3 ws_pos = v3_add(c->pos, m33_mul(R, w->position));
-		const v3 min_pos = v3_add(ws_pos, v3_scale(ws_dir, w->sus_min));
-		const float err = v3_dot(w->contact_normal, min_pos) - w->axle_plane_constant;
-		if (err < 0.0f) {
-			const v3 axis = v3_neg(w->contact_normal);
 			const v3 r1 = v3_sub(w->contact_pos, c->pos);
-			const sym33 I = world_inv_inertia(R, c->inv_inertia_local);
-			const v3 r1xa = v3_cross(r1, axis);
-			const v3 iI = sym33_mul(I, r1xa);
-			const float inv_eff = c->im + v3_dot(r1xa, iI);
-			if (!(inv_eff > 0.0f)) continue;
-			const float lambda = -(1.0f / inv_eff) * baumgarte * err;
-			c->pos = v3_sub(c->pos, v3_scale(axis, lambda * c->im));
-			c->rot = quat_add_rotation_step(c->rot, v3_scale(iI, -lambda));
+			const v3 neg_n = v3_neg(w->contact_normal);
+			float lam;
+			if (w->sus_max > w->sus_min) {
+				// spring stiffness from frequency / damping ratio and the effective mass at the average suspension point
+				const v3 fp = v3_add(w->position, v3_scale(w->suspension_dir, 0.5f * (w->sus_min + w->sus_max)));
+				const v3 fxu = v3_cross(fp, v3_neg(v->up));
+				const v3 il = c->inv_inertia_local;
+				const float eff_mass = 1.0f / (c->im + (fxu.x * il.x * fxu.x + fxu.y * il.y * fxu.y + fxu.z * il.z * fxu.z));
+				const float omega = 2.0f * SGD_VEH_PI * w->spring_freq;
+				const float stiffness = eff_mass * (omega * omega);
+				const float damping = 2.0f * eff_mass * w->spring_damp * omega;
+				const float Cc = w->suspension_length - w->sus_max - w->sus_preload;
+				lam = w->suspension.lambda;
+				sgd_part_setup(&w->suspension, c, r1, neg_n, dt, Cc, stiffness, damping);
+				if (w->suspension.active) w->suspension.lambda = lam;
+			} else sgd_part_deactivate(&w->suspension);
+			if (w->suspension_length < w->sus_min) {
+				lam = w->max_up.lambda;
+				sgd_part_setup(&w->max_up, c, r1, neg_n, dt, 0.0f, 0.0f, 0.0f);
+				if (w->max_up.active) w->max_up.lambda = lam;
+				w->suspension_length = w->sus_min;
+			} else sgd_part_deactivate(&w->max_up);
+			// the longitudinal row (engine / brake force) is never warm started: its impulse starts from zero every step
+			sgd_part_setup(&w->longitudinal, c, r1, v3_neg(w->contact_long), dt, 0.0f, 0.0f, 0.0f);
+			w->longitudinal.lambda = 0.0f;
+			lam = w->lateral.lambda;
+			sgd_part_setup(&w->lateral, c, r1, v3_neg(w->contact_lat), dt, 0.0f, 0.0f, 0.0f);
+			if (w->lateral.active) w->lateral.lambda = lam;
 		}
+		if (fabsf(w->angular_velocity) > 10.0f * SGD_VEH_PI / 180.0f) spinning = 1;
 	}
+	return __any(spinning);
 }
 

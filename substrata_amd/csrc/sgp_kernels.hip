@@ -799,29 +799,125 @@ SGP_DEV int collide_with_mesh(const DV& d, uint32_t mbody, const sgd_shape& X, v
 	return sgd_mesh_finish(&mc, out);
 }
 
-// pairs with a static mesh: one thread per pair (sequential walk in triangle-index order, as the reference)
+// Pairs with a static mesh: EIGHT LANES PER PAIR, eight pairs per wave.  The sequential statement walks a pair's candidate triangles in
+// index order, tests each against the body and merges the triangle's manifold into <= 3 groups by normal -- the tests are independent and
+// are the cost (a thin-hull SAT with clipping for a box or hull), the merge depends on the order and is cheap.  So: lane 0 of the group
+// walks the mesh's tree and drops the candidates into LDS, the eight lanes order them by triangle index (rank sort: keys are unique), then
+// round after round each lane tests one of the next eight candidates and the hits are merged one lane at a time, in candidate order, into
+// the group table in LDS -- the sequence of sgd_mesh_add calls of the sequential walk.  The <= 3 groups are reduced and emitted by three lanes.
+// (Eight, not 64: a body on a terrain or floor mesh touches a handful of triangles -- a wave per pair would idle 56 lanes -- and a chassis
+// across 150 triangles of a detailed mesh still gets them tested eight at a time.)
+#define MESH_GROUP 8
+#define MESH_PAIRS_PER_WAVE (64 / MESH_GROUP)
+struct MeshPairLds { uint32_t found[MESH_CAND_CAP]; uint32_t key[MESH_CAND_CAP]; uint32_t cand[MESH_CAND_CAP]; sgd_mesh_contacts mc; };
+
+// every triangle whose leaf box overlaps [llo, lhi] (mesh frame): positions in the tree-ordered triangle array and the triangles' indices in the
+// caller's order, as found (unsorted)
+SGP_DEV int mesh_candidates_found(const DV& d, const MeshHeader& mh, v3 llo, v3 lhi, uint32_t* found, uint32_t* key, bool* overflow)
+{
+	int n = 0; *overflow = false;
+	uint32_t stack[48]; int sp = 0;
+	stack[sp++] = 0;
+	while (sp > 0) {
+		const MeshNode nd = d.mesh_nodes[mh.node_off + stack[--sp]];
+		if (nd.mxx < llo.x || nd.mnx > lhi.x || nd.mxy < llo.y || nd.mny > lhi.y || nd.mxz < llo.z || nd.mnz > lhi.z) continue;
+		if (nd.count == 0) { if (sp + 2 <= 48) { stack[sp++] = nd.left; stack[sp++] = nd.right; } else *overflow = true; continue; }
+		for (uint32_t k = 0; k < nd.count; ++k) {
+			if (n == MESH_CAND_CAP) { *overflow = true; break; }
+			found[n] = nd.left + k; key[n] = d.mesh_tris[mh.tri_off + nd.left + k].w; ++n;
+		}
+	}
+	return n;
+}
+
 __global__ void __launch_bounds__(64) k_narrowphase_mesh(DV d)
 {
+	__shared__ MeshPairLds lds[MESH_PAIRS_PER_WAVE];
+	const int grp = (int)(threadIdx.x / MESH_GROUP), sub = (int)(threadIdx.x % MESH_GROUP);
+	MeshPairLds& L = lds[grp];
 	const uint32_t n = min(d.ctr->n_mesh_pairs, d.cap_mesh_pairs);
-	for (uint32_t p = blockIdx.x * 64 + threadIdx.x; p < n; p += gridDim.x * 64) {
-		const uint2 ab = d.mesh_pairs[p];
-		const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
-		const bool mesh_a = f_shape(fa) == SGP_SHAPE_MESH, mesh_b = f_shape(fb) == SGP_SHAPE_MESH;
-		if (mesh_a && mesh_b) continue;
-		const uint32_t mid = mesh_a ? ab.x : ab.y, xid = mesh_a ? ab.y : ab.x;
-		const uint32_t fx = mesh_a ? fb : fa;
-		const sgd_shape sx = load_shape(d, xid, fx);
-		sgd_manifold mm[SGD_MESH_MAX_GROUPS]; bool dropped = false;
-		const int ng = collide_with_mesh(d, mid, sx, V3(d.aabb_min[xid]), V3(d.aabb_max[xid]), d.st.speculative_contact_distance, mm, &dropped);
-		if (dropped) atomicAdd(&d.ctr->manifolds_dropped, 1u);
-		for (int g = 0; g < ng; ++g) {
-			// the manifold runs mesh -> body; the constraint runs lower id -> higher id, with the mesh's g-th slot
-			const uint32_t alias = mid + (uint32_t)g;
-			sgd_manifold m = mm[g];
-			uint2 key;
-			if (alias < xid) key = make_uint2(alias, xid); else { key = make_uint2(xid, alias); sgd_flip_manifold(&m); }
-			emit_manifold(d, key, d.flags[key.x], d.flags[key.y], m);
+	const float max_sep = d.st.speculative_contact_distance;
+	for (uint32_t p0 = blockIdx.x * MESH_PAIRS_PER_WAVE; p0 < n; p0 += gridDim.x * MESH_PAIRS_PER_WAVE) {
+		const uint32_t p = p0 + (uint32_t)grp;
+		bool valid = p < n;
+		uint32_t mid = 0, xid = 0, fx = 0;
+		if (valid) {
+			const uint2 ab = d.mesh_pairs[p];
+			const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
+			const bool mesh_a = f_shape(fa) == SGP_SHAPE_MESH, mesh_b = f_shape(fb) == SGP_SHAPE_MESH;
+			if (mesh_a && mesh_b) valid = false;
+			mid = mesh_a ? ab.x : ab.y; xid = mesh_a ? ab.y : ab.x; fx = mesh_a ? fb : fa;
 		}
+		// the pair as every lane of its group needs it: the body's shape, the mesh's pose, the query box in the world and in the mesh frame
+		sgd_shape X; MeshHeader mh; v3 mpos = V3(0.0f, 0.0f, 0.0f), qlo = mpos, qhi = mpos; m33 R = quat_to_m33(Q4(make_float4(0.0f, 0.0f, 0.0f, 1.0f)));
+		int nc = 0; bool dropped = false;
+		if (valid) {
+			X = load_shape(d, xid, fx);
+			mh = d.meshes[(uint32_t)d.prop[2 * (size_t)mid + 1].x];
+			mpos = V3(d.pose[2 * (size_t)mid]); R = quat_to_m33(Q4(d.pose[2 * (size_t)mid + 1]));
+			const v3 e = V3(max_sep, max_sep, max_sep);
+			qlo = v3_sub(V3(d.aabb_min[xid]), e); qhi = v3_add(V3(d.aabb_max[xid]), e);
+			if (sub == 0) {
+				v3 llo = V3(3.4e38f, 3.4e38f, 3.4e38f), lhi = V3(-3.4e38f, -3.4e38f, -3.4e38f);      // bounds of the box's 8 corners in the mesh frame, a little generous
+				for (int k = 0; k < 8; ++k) {
+					const v3 c = V3((k & 1) ? qhi.x : qlo.x, (k & 2) ? qhi.y : qlo.y, (k & 4) ? qhi.z : qlo.z);
+					const v3 l = m33_tmul(R, v3_sub(c, mpos));
+					llo = V3(fminf(llo.x, l.x), fminf(llo.y, l.y), fminf(llo.z, l.z)); lhi = V3(fmaxf(lhi.x, l.x), fmaxf(lhi.y, l.y), fmaxf(lhi.z, l.z));
+				}
+				const float pad = 1.0e-4f * (1.0f + fabsf(llo.x) + fabsf(llo.y) + fabsf(llo.z) + fabsf(lhi.x) + fabsf(lhi.y) + fabsf(lhi.z));
+				llo = v3_sub(llo, V3(pad, pad, pad)); lhi = v3_add(lhi, V3(pad, pad, pad));
+				nc = mesh_candidates_found(d, mh, llo, lhi, L.found, L.key, &dropped);
+				L.mc.ng = 0;
+			}
+		}
+		nc = __shfl(nc, grp * MESH_GROUP, 64);
+		__syncthreads();
+		// candidates in the order of the caller's triangle indices: the rank of a key is the number of smaller keys
+		for (int i = sub; i < nc; i += MESH_GROUP) {
+			const uint32_t ki = L.key[i];
+			int rank = 0;
+			for (int j = 0; j < nc; ++j) rank += L.key[j] < ki ? 1 : 0;
+			L.cand[rank] = L.found[i];
+		}
+		__syncthreads();
+		int rounds = (nc + MESH_GROUP - 1) / MESH_GROUP;
+#pragma unroll
+		for (int off = 32; off >= 1; off >>= 1) rounds = max(rounds, __shfl_xor(rounds, off, 64));
+		for (int rd = 0; rd < rounds; ++rd) {
+			const int k = rd * MESH_GROUP + sub;
+			bool hit = false; sgd_manifold m;
+			if (valid && k < nc) {
+				const uint4 tri = d.mesh_tris[mh.tri_off + L.cand[k]];
+				const v3 a = V3(d.mesh_verts[mh.vert_off + tri.x]), b = V3(d.mesh_verts[mh.vert_off + tri.y]), c = V3(d.mesh_verts[mh.vert_off + tri.z]);
+				const v3 wa = v3_add(mpos, m33_mul(R, a)), wb = v3_add(mpos, m33_mul(R, b)), wc = v3_add(mpos, m33_mul(R, c));
+				const v3 tmin = V3(fminf(fminf(wa.x, wb.x), wc.x), fminf(fminf(wa.y, wb.y), wc.y), fminf(fminf(wa.z, wb.z), wc.z));
+				const v3 tmax = V3(fmaxf(fmaxf(wa.x, wb.x), wc.x), fmaxf(fmaxf(wa.y, wb.y), wc.y), fmaxf(fmaxf(wa.z, wb.z), wc.z));
+				if (!(tmax.x < qlo.x || tmin.x > qhi.x || tmax.y < qlo.y || tmin.y > qhi.y || tmax.z < qlo.z || tmin.z > qhi.z)) {
+					sgd_hull th; v3 cen, nrm;
+					sgd_tri_hull(a, b, c, &th, &cen, &nrm);
+					sgd_hview T; T.pos = v3_add(mpos, m33_mul(R, cen)); T.R = R; T.scale = V3(1.0f, 1.0f, 1.0f); T.h = &th;
+					hit = sgd_collide_tri(&X, &T, m33_mul(R, nrm), max_sep, &m) != 0;
+				}
+			}
+			// the hits of this round into the pair's groups, in candidate order
+			for (int t = 0; t < MESH_GROUP; ++t) {
+				if (hit && sub == t) sgd_mesh_add(&L.mc, &m);
+				__syncthreads();
+			}
+		}
+		// the groups as manifolds (mesh -> body), each pruned to <= 4 points; the constraint runs lower id -> higher id, with the mesh's g-th slot
+		const int ng = valid ? L.mc.ng : 0;
+		if (sub < ng) {
+			const sgd_mesh_group& g = L.mc.g[sub];
+			sgd_manifold mm;
+			sgd_hull_reduce(g.n, g.p_mesh, g.p_body, g.np, &mm);
+			const uint32_t alias = mid + (uint32_t)sub;
+			uint2 key;
+			if (alias < xid) key = make_uint2(alias, xid); else { key = make_uint2(xid, alias); sgd_flip_manifold(&mm); }
+			emit_manifold(d, key, d.flags[key.x], d.flags[key.y], mm);
+		}
+		if (valid && sub == 0 && dropped) atomicAdd(&d.ctr->manifolds_dropped, 1u);
+		__syncthreads();          // (the tables are reused by the next eight pairs)
 	}
 }
 
@@ -3394,10 +3490,11 @@ __global__ void __launch_bounds__(64) k_vehicle_cast(DV d)
 		sv.in_forward = in.forward; sv.in_right = in.right; sv.in_brake = in.brake; sv.in_handbrake = in.hand_brake;
 		const uint32_t b = sv.body;
 		sv.active = (b < d.sp->n_slots && f_movable(d.flags[b])) ? 1 : 0;
-		if (sv.active) { const sgd_chassis c = veh_chassis_pose_vel(d, b); sgd_vehicle_pre_a(&sv, &c, d.sp->dt); }
 	}
 	__syncthreads();
 	if (sv.active) {
+		{ const sgd_chassis c = veh_chassis_pose_vel(d, sv.body); sgd_vehicle_precast_lanes(&sv, &c, d.sp->dt, (int)threadIdx.x); }
+		__syncthreads();
 		const int wi = (int)(threadIdx.x >> 4); const uint32_t sub = threadIdx.x & 15u;
 		float best = 0.0f; uint32_t bid = SGP_INVALID_ID; v3 bn = V3(0.0f, 0.0f, 0.0f), bp = bn;
 		if (wi < sv.num_wheels) {
@@ -3448,12 +3545,16 @@ __global__ void __launch_bounds__(64) k_vehicle_controller(DV d)
 	sgd_vehicle* gv = &d.vehicles[blockIdx.x];
 	if (!gv->alive || !gv->active) { if (threadIdx.x == 0) d.veh_head[(size_t)blockIdx.x * VEH_HEAD_F4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); return; }      // (no rows this step)
 	veh_stage_in(&sv, gv);
-	if (threadIdx.x == 0) {
+	{
+		// every lane holds the chassis state (one broadcast load); lane i works on wheel i, lane 0 on what couples the wheels
 		const uint32_t b = sv.body;
 		sgd_chassis c = veh_chassis_pose_vel(d, b);
-		if (sgd_vehicle_pre_b(&sv, &c, d.sp->dt)) d.sleep_timer[b] = 0.0f;
-		const float4 lv = d.vel[2 * (size_t)b], av = d.vel[2 * (size_t)b + 1];
-		d.vel[2 * (size_t)b] = F4(c.v, lv.w); d.vel[2 * (size_t)b + 1] = F4(c.w, av.w);
+		const float lvw = d.vel[2 * (size_t)b].w, avw = d.vel[2 * (size_t)b + 1].w;
+		const int spinning = sgd_vehicle_controller_lanes(&sv, &c, d.sp->dt, (int)threadIdx.x);
+		if (threadIdx.x == 0) {
+			if (spinning) d.sleep_timer[b] = 0.0f;
+			d.vel[2 * (size_t)b] = F4(c.v, lvw); d.vel[2 * (size_t)b + 1] = F4(c.w, avw);      // (the anti-roll impulses)
+		}
 	}
 	__syncthreads();
 	veh_export(d, blockIdx.x, sv);          // the rows of this step, lane-major, for the solver passes
@@ -4404,7 +4505,7 @@ void launch_narrowphase_hull(const DV& d, hipStream_t s)
 	hipLaunchKernelGGL(k_narrowphase_hull, dim3(4096), dim3(64), 0, s, d);
 	hipLaunchKernelGGL(k_narrowphase_hull_manifold, dim3(1024), dim3(64), 0, s, d);
 }
-void launch_narrowphase_mesh(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_narrowphase_mesh, dim3(1024), dim3(64), 0, s, d); }
+void launch_narrowphase_mesh(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_narrowphase_mesh, dim3(2048), dim3(64), 0, s, d); }
 void launch_colour_inherit(const DV& d, uint32_t est, hipStream_t s) { hipLaunchKernelGGL(k_colour_inherit, dim3(stride_grid(est)), dim3(TPB), 0, s, d); }
 void launch_colour_claim(const DV& d, uint32_t est, uint32_t round, hipStream_t s)
 {
