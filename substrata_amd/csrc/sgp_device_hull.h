@@ -28,25 +28,27 @@ struct sgd_hull_s {
 typedef struct sgd_hull_s sgd_hull;
 
 // a hull (or the cube template scaled to a box) placed in the world
-struct sgd_hview { v3 pos; m33 R; v3 scale; const sgd_hull* h; };
+// (H: the full record, or the thin three-vertex hull of a mesh triangle -- sgd_tri_hull_t, sgp_device_mesh.h --, small enough to stay out of scratch memory)
+template <class H> struct sgd_hview_t { v3 pos; m33 R; v3 scale; const H* h; };
+typedef sgd_hview_t<sgd_hull> sgd_hview;
 
-SGP_DEV static v3 sgd_hv_local(const sgd_hview* v, int i) { const v3 p = v->h->verts[i]; return V3(p.x * v->scale.x, p.y * v->scale.y, p.z * v->scale.z); }
-SGP_DEV static v3 sgd_hv_world(const sgd_hview* v, int i) { return v3_add(v->pos, m33_mul(v->R, sgd_hv_local(v, i))); }
-SGP_DEV static v3 sgd_hv_normal(const sgd_hview* v, int f) { return m33_mul(v->R, v->h->normals[f]); }
-SGP_DEV static float sgd_hv_plane_d(const sgd_hview* v, int f)
+template <class HV> SGP_DEV static v3 sgd_hv_local(const HV* v, int i) { const v3 p = v->h->verts[i]; return V3(p.x * v->scale.x, p.y * v->scale.y, p.z * v->scale.z); }
+template <class HV> SGP_DEV static v3 sgd_hv_world(const HV* v, int i) { return v3_add(v->pos, m33_mul(v->R, sgd_hv_local(v, i))); }
+template <class HV> SGP_DEV static v3 sgd_hv_normal(const HV* v, int f) { return m33_mul(v->R, v->h->normals[f]); }
+template <class HV> SGP_DEV static float sgd_hv_plane_d(const HV* v, int f)
 {
 	if (v->h->is_box_template) { const v3 n = v->h->normals[f]; return fabsf(n.x) * v->scale.x + fabsf(n.y) * v->scale.y + fabsf(n.z) * v->scale.z; }
 	return v->h->plane_d[f];
 }
 // min / max over the vertices of w . x (world direction w)
-SGP_DEV static float sgd_hv_proj_min(const sgd_hview* v, v3 w)
+template <class HV> SGP_DEV static float sgd_hv_proj_min(const HV* v, v3 w)
 {
 	const v3 l = m33_tmul(v->R, w);
 	float best = 3.4e38f;
 	for (int i = 0; i < v->h->nv; ++i) { const float d = v3_dot(l, sgd_hv_local(v, i)); if (d < best) best = d; }
 	return v3_dot(w, v->pos) + best;
 }
-SGP_DEV static float sgd_hv_proj_max(const sgd_hview* v, v3 w)
+template <class HV> SGP_DEV static float sgd_hv_proj_max(const HV* v, v3 w)
 {
 	const v3 l = m33_tmul(v->R, w);
 	float best = -3.4e38f;
@@ -119,7 +121,7 @@ SGP_DEV static void sgd_seg_seg_closest(v3 a0, v3 a1, v3 b0, v3 b1, v3* pa, v3* 
 struct sgd_hull_sat { float sA, sB, sE; int fA, fB, eA, eB; v3 nE; };
 
 // separation of B in front of face f of X (X, Y in either role)
-SGP_DEV static float sgd_hull_axis_face(const sgd_hview* X, const sgd_hview* Y, int f)
+template <class HA, class HB> SGP_DEV static float sgd_hull_axis_face(const HA* X, const HB* Y, int f)
 {
 	const v3 n = sgd_hv_normal(X, f);
 	return sgd_hv_proj_min(Y, n) - (v3_dot(n, X->pos) + sgd_hv_plane_d(X, f));
@@ -128,7 +130,7 @@ SGP_DEV static float sgd_hull_axis_face(const sgd_hview* X, const sgd_hview* Y, 
 /* edge pair (i of A, j of B): returns 0 when the edges are (nearly) parallel, else 1 with the axis (oriented A -> B), the
    separation along it and whether this pair really supports the two hulls along it (parallel edges give the same axis: only the
    supporting pair is the contact) */
-SGP_DEV static int sgd_hull_axis_edge(const sgd_hview* A, const sgd_hview* B, int i, int j, v3 T, v3* ax_out, float* s_out, int* supporting)
+template <class HA, class HB> SGP_DEV static int sgd_hull_axis_edge(const HA* A, const HB* B, int i, int j, v3 T, v3* ax_out, float* s_out, int* supporting)
 {
 	const v3 da = m33_mul(A->R, v3_sub(sgd_hv_local(A, A->h->edge_b[i]), sgd_hv_local(A, A->h->edge_a[i])));
 	const v3 db = m33_mul(B->R, v3_sub(sgd_hv_local(B, B->h->edge_b[j]), sgd_hv_local(B, B->h->edge_a[j])));
@@ -145,7 +147,7 @@ SGP_DEV static int sgd_hull_axis_edge(const sgd_hview* A, const sgd_hview* B, in
 }
 
 // Sequential search (first maximum wins).  Returns 0 when some axis separates the hulls by more than max_sep.
-SGP_DEV static int sgd_hull_sat_search(const sgd_hview* A, const sgd_hview* B, float max_sep, sgd_hull_sat* r)
+template <class HA, class HB> SGP_DEV static int sgd_hull_sat_search(const HA* A, const HB* B, float max_sep, sgd_hull_sat* r)
 {
 	r->sA = -3.4e38f; r->sB = -3.4e38f; r->sE = -3.4e38f; r->fA = 0; r->fB = 0; r->eA = -1; r->eB = -1; r->nE = V3(0, 0, 0);
 	for (int f = 0; f < A->h->nf; ++f) {
@@ -170,22 +172,11 @@ SGP_DEV static int sgd_hull_sat_search(const sgd_hview* A, const sgd_hview* B, f
 	return 1;
 }
 
-// Manifold from the result of the search.  Normal from A to B.
-SGP_DEV static int sgd_hull_manifold(const sgd_hview* A, const sgd_hview* B, float max_sep, const sgd_hull_sat* r, sgd_manifold* m)
+// Face contact: reference hull X owns the axis (its face fX), the most anti-parallel face of Y is clipped against X's face.  x_is_a: X is the
+// pair's first hull (the manifold's normal runs from the first to the second).
+template <class HX, class HY> SGP_DEV static int sgd_hull_face_contact(const HX* X, const HY* Y, int fX, int x_is_a, float max_sep, sgd_manifold* m)
 {
-	const float sA = r->sA, sB = r->sB, sE = r->sE; const int fA = r->fA, fB = r->fB, eA = r->eA, eB = r->eB; const v3 nE = r->nE;
-	const float sF = fmaxf(sA, sB);
-	if (eA >= 0 && sE > sF + 1.0e-3f) {
-		v3 pa, pb;
-		sgd_seg_seg_closest(sgd_hv_world(A, A->h->edge_a[eA]), sgd_hv_world(A, A->h->edge_b[eA]),
-		                    sgd_hv_world(B, B->h->edge_a[eB]), sgd_hv_world(B, B->h->edge_b[eB]), &pa, &pb);
-		m->n = nE; m->np = 1; m->p1[0] = pa; m->p2[0] = pb;
-		return 1;
-	}
-	// face contact: reference hull X owns the axis, the most anti-parallel face of Y is clipped against X's face
-	const int refA = !(sB > sA + 1.0e-4f);
-	const sgd_hview* X = refA ? A : B; const sgd_hview* Y = refA ? B : A;
-	const int fX = refA ? fA : fB;
+	const int refA = x_is_a;
 	const v3 nref = sgd_hv_normal(X, fX);
 	int fY = 0; float bestd = 3.4e38f;
 	for (int f = 0; f < Y->h->nf; ++f) { const float d = v3_dot(nref, sgd_hv_normal(Y, f)); if (d < bestd) { bestd = d; fY = f; } }
@@ -226,8 +217,24 @@ SGP_DEV static int sgd_hull_manifold(const sgd_hview* A, const sgd_hview* B, flo
 	return 1;
 }
 
+// Manifold from the result of the search.  Normal from A to B.
+template <class HA, class HB> SGP_DEV static int sgd_hull_manifold(const HA* A, const HB* B, float max_sep, const sgd_hull_sat* r, sgd_manifold* m)
+{
+	const float sA = r->sA, sB = r->sB, sE = r->sE; const int fA = r->fA, fB = r->fB, eA = r->eA, eB = r->eB; const v3 nE = r->nE;
+	const float sF = fmaxf(sA, sB);
+	if (eA >= 0 && sE > sF + 1.0e-3f) {
+		v3 pa, pb;
+		sgd_seg_seg_closest(sgd_hv_world(A, A->h->edge_a[eA]), sgd_hv_world(A, A->h->edge_b[eA]),
+		                    sgd_hv_world(B, B->h->edge_a[eB]), sgd_hv_world(B, B->h->edge_b[eB]), &pa, &pb);
+		m->n = nE; m->np = 1; m->p1[0] = pa; m->p2[0] = pb;
+		return 1;
+	}
+	const int refA = !(sB > sA + 1.0e-4f);
+	return refA ? sgd_hull_face_contact(A, B, fA, 1, max_sep, m) : sgd_hull_face_contact(B, A, fB, 0, max_sep, m);
+}
+
 // A, B = hull views (either may be the scaled cube template): SAT + clipping.  Normal from A to B.
-SGP_DEV static int sgd_hull_hull(const sgd_hview* A, const sgd_hview* B, float max_sep, sgd_manifold* m)
+template <class HA, class HB> SGP_DEV static int sgd_hull_hull(const HA* A, const HB* B, float max_sep, sgd_manifold* m)
 {
 	sgd_hull_sat r;
 	if (!sgd_hull_sat_search(A, B, max_sep, &r)) return 0;
@@ -236,7 +243,7 @@ SGP_DEV static int sgd_hull_hull(const sgd_hview* A, const sgd_hview* B, float m
 
 /* Closest point on the hull surface to the hull-local point l (scale 1 hulls only).  Returns the signed distance (negative
    inside), the closest point q and the outward direction n at q (unit). */
-SGP_DEV static float sgd_hull_closest(const sgd_hull* h, v3 l, v3* q_out, v3* n_out)
+template <class H> SGP_DEV static float sgd_hull_closest(const H* h, v3 l, v3* q_out, v3* n_out)
 {
 	float smax = -3.4e38f; int fmax = 0;
 	for (int f = 0; f < h->nf; ++f) { const float s = v3_dot(h->normals[f], l) - h->plane_d[f]; if (s > smax) { smax = s; fmax = f; } }
@@ -279,7 +286,7 @@ SGP_DEV static float sgd_hull_closest(const sgd_hull* h, v3 l, v3* q_out, v3* n_
 }
 
 // hull H (scale 1) vs sphere: normal from the hull to the sphere
-SGP_DEV static int sgd_hull_sphere(const sgd_hview* H, v3 c, float r, float max_sep, sgd_manifold* m)
+template <class HV> SGP_DEV static int sgd_hull_sphere(const HV* H, v3 c, float r, float max_sep, sgd_manifold* m)
 {
 	const v3 l = m33_tmul(H->R, v3_sub(c, H->pos));
 	v3 q, n;
@@ -293,7 +300,7 @@ SGP_DEV static int sgd_hull_sphere(const sgd_hview* H, v3 c, float r, float max_
 }
 
 // hull H (scale 1) vs capsule (end points e0, e1 of the axis, radius r): normal from the hull to the capsule
-SGP_DEV static int sgd_hull_capsule(const sgd_hview* H, v3 e0, v3 e1, float r, float max_sep, sgd_manifold* m)
+template <class HV> SGP_DEV static int sgd_hull_capsule(const HV* H, v3 e0, v3 e1, float r, float max_sep, sgd_manifold* m)
 {
 	const v3 s0 = m33_tmul(H->R, v3_sub(e0, H->pos)), s1 = m33_tmul(H->R, v3_sub(e1, H->pos));
 	const v3 d = v3_sub(s1, s0);
@@ -354,7 +361,7 @@ SGP_DEV static int sgd_hull_capsule(const sgd_hview* H, v3 e0, v3 e1, float r, f
 /* ray against a hull (scale 1) grown by `grow` along every face normal, hull-local: clip against every face plane.  Returns t
    or -1; normal of the entry face (-dl when the origin is inside).  grow > 0 serves the sphere cast of the wheel tester: the
    planes-only offset is the Minkowski sum with a ball except near edges and corners, where it is slightly larger. */
-SGP_DEV static float sgd_ray_hull(const sgd_hull* h, v3 ol, v3 dl, float max_t, float grow, v3* n_out)
+template <class H> SGP_DEV static float sgd_ray_hull(const H* h, v3 ol, v3 dl, float max_t, float grow, v3* n_out)
 {
 	float t0 = 0.0f, t1 = max_t; int fin = -1;
 	for (int f = 0; f < h->nf; ++f) {

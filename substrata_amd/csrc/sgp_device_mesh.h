@@ -10,8 +10,15 @@
 #define SGD_MESH_MAX_GROUPS 3
 #define SGD_MESH_GROUP_COS 0.95f
 
-// the thin hull of one triangle; vertices relative to the centroid (mesh frame)
-SGP_DEV static void sgd_tri_hull(v3 a, v3 b, v3 c, sgd_hull* h, v3* centroid_out, v3* normal_out)
+// the thin hull of one triangle; vertices relative to the centroid (mesh frame).  The record has the members of sgd_hull the collision
+// functions read, with room for exactly one triangle: 100 bytes a lane can keep near, where the full record is 2.2 KB of scratch memory
+struct sgd_tri_hull_t {
+	int nv, nf, ne, is_box_template;
+	v3 verts[3]; v3 normals[2]; float plane_d[2];
+	unsigned char face_start[3], face_idx[6], edge_a[3], edge_b[3];
+};
+typedef sgd_hview_t<sgd_tri_hull_t> sgd_tri_view;
+SGP_DEV static void sgd_tri_hull(v3 a, v3 b, v3 c, sgd_tri_hull_t* h, v3* centroid_out, v3* normal_out)
 {
 	const v3 cen = v3_scale(v3_add(v3_add(a, b), c), 1.0f / 3.0f);
 	v3 n = v3_cross(v3_sub(b, a), v3_sub(c, a));
@@ -53,7 +60,7 @@ SGP_DEV static void sgd_mesh_add(sgd_mesh_contacts* mc, const sgd_manifold* m)
 }
 
 // X against one triangle (world-space view T of its thin hull, world normal nt).  Normal of the result: triangle -> X.
-SGP_DEV static int sgd_collide_tri(const sgd_shape* X, const sgd_hview* T, v3 nt, float max_sep, sgd_manifold* m)
+SGP_DEV static int sgd_collide_tri(const sgd_shape* X, const sgd_tri_view* T, v3 nt, float max_sep, sgd_manifold* m)
 {
 	int hit;
 	if (X->type == SGD_SHAPE_SPHERE) hit = sgd_hull_sphere(T, X->pos, X->p0, max_sep, m);

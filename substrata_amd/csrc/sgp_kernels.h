@@ -77,6 +77,7 @@ struct StepCounters {
 	uint32_t n_read_active;
 	uint32_t n_export;
 	uint32_t n_mesh_pairs;       // pairs with a static mesh, deferred to k_narrowphase_mesh
+	uint32_t n_mesh_big;         // ... of them with more candidate triangles than eight lanes should take (k_narrowphase_mesh<64>)
 	uint32_t hc_class[9];        // high-colour components per size class (k_hc_alloc)
 	uint32_t hc_entries;         // entries of the component list (classes padded to whole workgroups)
 	uint32_t hc_n;               // constraints of the high colours
@@ -268,7 +269,7 @@ struct DV {
 	// static triangle meshes: headers + pooled vertices / triangles / tree nodes (mesh frame = body frame)
 	const struct MeshHeader* meshes; uint32_t n_meshes;
 	const float4* mesh_verts; const uint4* mesh_tris; const uint32_t* mesh_tri_mat; const struct MeshNode* mesh_nodes;     // mesh_tri_mat: user data (material index) per tree-ordered triangle
-	uint2* mesh_pairs; uint32_t cap_mesh_pairs;
+	uint2* mesh_pairs; uint32_t cap_mesh_pairs; uint32_t* mesh_big;      // mesh_big: indices into mesh_pairs
 	// wheeled vehicles (sgp_device_vehicle.h): AoS, one record per vehicle slot
 	struct sgd_vehicle* vehicles; uint32_t n_vehicles; const sgp_vehicle_input* vehicle_inputs;
 	// the rows of the step as the solver passes read them (k_vehicle_controller exports, veh_quad_solve consumes): 16 chunks per wheel, [chunk][4 vehicle + wheel]; 5 float4 per vehicle

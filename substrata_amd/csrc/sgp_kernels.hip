@@ -790,9 +790,9 @@ SGP_DEV int collide_with_mesh(const DV& d, uint32_t mbody, const sgd_shape& X, v
 		const v3 tmin = V3(fminf(fminf(wa.x, wb.x), wc.x), fminf(fminf(wa.y, wb.y), wc.y), fminf(fminf(wa.z, wb.z), wc.z));
 		const v3 tmax = V3(fmaxf(fmaxf(wa.x, wb.x), wc.x), fmaxf(fmaxf(wa.y, wb.y), wc.y), fmaxf(fmaxf(wa.z, wb.z), wc.z));
 		if (tmax.x < qlo.x || tmin.x > qhi.x || tmax.y < qlo.y || tmin.y > qhi.y || tmax.z < qlo.z || tmin.z > qhi.z) continue;
-		sgd_hull th; v3 cen, n;
+		sgd_tri_hull_t th; v3 cen, n;
 		sgd_tri_hull(a, b, c, &th, &cen, &n);
-		sgd_hview T; T.pos = v3_add(mpos, m33_mul(R, cen)); T.R = R; T.scale = V3(1.0f, 1.0f, 1.0f); T.h = &th;
+		sgd_tri_view T; T.pos = v3_add(mpos, m33_mul(R, cen)); T.R = R; T.scale = V3(1.0f, 1.0f, 1.0f); T.h = &th;
 		sgd_manifold m;
 		if (sgd_collide_tri(&X, &T, m33_mul(R, n), max_sep, &m)) sgd_mesh_add(&mc, &m);
 	}
@@ -805,16 +805,23 @@ SGP_DEV int collide_with_mesh(const DV& d, uint32_t mbody, const sgd_shape& X, v
 // walks the mesh's tree and drops the candidates into LDS, the eight lanes order them by triangle index (rank sort: keys are unique), then
 // round after round each lane tests one of the next eight candidates and the hits are merged one lane at a time, in candidate order, into
 // the group table in LDS -- the sequence of sgd_mesh_add calls of the sequential walk.  The <= 3 groups are reduced and emitted by three lanes.
-// (Eight, not 64: a body on a terrain or floor mesh touches a handful of triangles -- a wave per pair would idle 56 lanes -- and a chassis
-// across 150 triangles of a detailed mesh still gets them tested eight at a time.)
-#define MESH_GROUP 8
-#define MESH_PAIRS_PER_WAVE (64 / MESH_GROUP)
-struct MeshPairLds { uint32_t found[MESH_CAND_CAP]; uint32_t key[MESH_CAND_CAP]; uint32_t cand[MESH_CAND_CAP]; sgd_mesh_contacts mc; };
+// (Eight, not 64: a body on a terrain or floor mesh touches a handful of triangles, and a wave per pair would idle 56 lanes.  A chassis across 150
+// triangles of a detailed mesh is another matter -- a box - triangle test is ~40 us of one lane's instructions, 24 rounds of them ~2 ms --: a pair
+// with more than MESH_BIG_MIN candidates is passed on to a second launch of the same kernel with all 64 lanes on one pair.)
+#define MESH_BIG_MIN 32      // pairs with more candidates than this go to the wave-per-pair launch
+// (the tables of a pair in LDS; G = 8: a pair that fills more than MESH_BIG_MIN entries is passed on, so 64 entries do, and no copy of the polytope)
+struct MeshNoHull {};
+template <int G> struct MeshPairLds {
+	static constexpr int CAP = G == 64 ? MESH_CAND_CAP : 64;
+	uint32_t found[CAP]; uint32_t key[CAP]; uint32_t cand[CAP]; uint32_t n_front[2], n_found, redo;
+	sgd_mesh_contacts mc;
+	typename std::conditional<G == 64, sgd_hull, MeshNoHull>::type hull;      // the body's polytope (cube template / convex hull) next to the lanes that walk its vertices once per axis
+};
 
 // every triangle whose leaf box overlaps [llo, lhi] (mesh frame): positions in the tree-ordered triangle array and the triangles' indices in the
 // caller's order, as found (unsorted)
-SGP_DEV int mesh_candidates_found(const DV& d, const MeshHeader& mh, v3 llo, v3 lhi, uint32_t* found, uint32_t* key, bool* overflow)
-{
+SGP_DEV int mesh_candidates_found(const DV& d, const MeshHeader& mh, v3 llo, v3 lhi, uint32_t* found, uint32_t* key, bool* overflow, int stop_after = MESH_CAND_CAP, int cap = MESH_CAND_CAP)
+{      // (stop_after: the caller only wants to know that there are more than this many)
 	int n = 0; *overflow = false;
 	uint32_t stack[48]; int sp = 0;
 	stack[sp++] = 0;
@@ -823,26 +830,29 @@ SGP_DEV int mesh_candidates_found(const DV& d, const MeshHeader& mh, v3 llo, v3 
 		if (nd.mxx < llo.x || nd.mnx > lhi.x || nd.mxy < llo.y || nd.mny > lhi.y || nd.mxz < llo.z || nd.mnz > lhi.z) continue;
 		if (nd.count == 0) { if (sp + 2 <= 48) { stack[sp++] = nd.left; stack[sp++] = nd.right; } else *overflow = true; continue; }
 		for (uint32_t k = 0; k < nd.count; ++k) {
-			if (n == MESH_CAND_CAP) { *overflow = true; break; }
+			if (n == cap) { *overflow = true; break; }
 			found[n] = nd.left + k; key[n] = d.mesh_tris[mh.tri_off + nd.left + k].w; ++n;
 		}
+		if (n > stop_after) return n;
 	}
 	return n;
 }
 
-__global__ void __launch_bounds__(64) k_narrowphase_mesh(DV d)
+template <int MESH_GROUP> __global__ void __launch_bounds__(64) k_narrowphase_mesh(DV d)
 {
-	__shared__ MeshPairLds lds[MESH_PAIRS_PER_WAVE];
+	constexpr int MESH_PAIRS_PER_WAVE = 64 / MESH_GROUP;
+	__shared__ MeshPairLds<MESH_GROUP> lds[MESH_PAIRS_PER_WAVE];
 	const int grp = (int)(threadIdx.x / MESH_GROUP), sub = (int)(threadIdx.x % MESH_GROUP);
-	MeshPairLds& L = lds[grp];
-	const uint32_t n = min(d.ctr->n_mesh_pairs, d.cap_mesh_pairs);
+	MeshPairLds<MESH_GROUP>& L = lds[grp];
+	const uint32_t n = MESH_GROUP == 64 ? min(d.ctr->n_mesh_big, d.cap_mesh_pairs) : min(d.ctr->n_mesh_pairs, d.cap_mesh_pairs);
 	const float max_sep = d.st.speculative_contact_distance;
 	for (uint32_t p0 = blockIdx.x * MESH_PAIRS_PER_WAVE; p0 < n; p0 += gridDim.x * MESH_PAIRS_PER_WAVE) {
 		const uint32_t p = p0 + (uint32_t)grp;
 		bool valid = p < n;
-		uint32_t mid = 0, xid = 0, fx = 0;
+		uint32_t mid = 0, xid = 0, fx = 0, pair = 0;
 		if (valid) {
-			const uint2 ab = d.mesh_pairs[p];
+			pair = MESH_GROUP == 64 ? d.mesh_big[p] : p;
+			const uint2 ab = d.mesh_pairs[pair];
 			const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
 			const bool mesh_a = f_shape(fa) == SGP_SHAPE_MESH, mesh_b = f_shape(fb) == SGP_SHAPE_MESH;
 			if (mesh_a && mesh_b) valid = false;
@@ -853,24 +863,68 @@ __global__ void __launch_bounds__(64) k_narrowphase_mesh(DV d)
 		int nc = 0; bool dropped = false;
 		if (valid) {
 			X = load_shape(d, xid, fx);
+			if (MESH_GROUP == 64 && X.hull) {
+				// a triangle test walks the polytope's vertices twice per candidate axis: out of LDS, not out of a pointer into global memory (worth the copy
+				// where dozens of tests follow: 2.50 -> 2.13 ms on the car-sized boxes, but 0.93 -> 1.09 ms on the small bodies of tools/experiments/mesh_terrain_bench.py)
+				const uint32_t* src = (const uint32_t*)X.hull; uint32_t* dst = (uint32_t*)&L.hull;
+				for (uint32_t i = (uint32_t)sub; i < sizeof(sgd_hull) / 4; i += MESH_GROUP) dst[i] = src[i];
+				X.hull = (const sgd_hull*)(const void*)&L.hull;
+			}
 			mh = d.meshes[(uint32_t)d.prop[2 * (size_t)mid + 1].x];
 			mpos = V3(d.pose[2 * (size_t)mid]); R = quat_to_m33(Q4(d.pose[2 * (size_t)mid + 1]));
 			const v3 e = V3(max_sep, max_sep, max_sep);
 			qlo = v3_sub(V3(d.aabb_min[xid]), e); qhi = v3_add(V3(d.aabb_max[xid]), e);
-			if (sub == 0) {
-				v3 llo = V3(3.4e38f, 3.4e38f, 3.4e38f), lhi = V3(-3.4e38f, -3.4e38f, -3.4e38f);      // bounds of the box's 8 corners in the mesh frame, a little generous
-				for (int k = 0; k < 8; ++k) {
-					const v3 c = V3((k & 1) ? qhi.x : qlo.x, (k & 2) ? qhi.y : qlo.y, (k & 4) ? qhi.z : qlo.z);
-					const v3 l = m33_tmul(R, v3_sub(c, mpos));
-					llo = V3(fminf(llo.x, l.x), fminf(llo.y, l.y), fminf(llo.z, l.z)); lhi = V3(fmaxf(lhi.x, l.x), fmaxf(lhi.y, l.y), fmaxf(lhi.z, l.z));
+		}
+		// the query box in the mesh frame: bounds of the box's 8 corners, a little generous (every lane of the group: the same operands, the same box)
+		v3 llo = V3(3.4e38f, 3.4e38f, 3.4e38f), lhi = V3(-3.4e38f, -3.4e38f, -3.4e38f);
+		if (valid) {
+			for (int k = 0; k < 8; ++k) {
+				const v3 c = V3((k & 1) ? qhi.x : qlo.x, (k & 2) ? qhi.y : qlo.y, (k & 4) ? qhi.z : qlo.z);
+				const v3 l = m33_tmul(R, v3_sub(c, mpos));
+				llo = V3(fminf(llo.x, l.x), fminf(llo.y, l.y), fminf(llo.z, l.z)); lhi = V3(fmaxf(lhi.x, l.x), fmaxf(lhi.y, l.y), fmaxf(lhi.z, l.z));
+			}
+			const float pad = 1.0e-4f * (1.0f + fabsf(llo.x) + fabsf(llo.y) + fabsf(llo.z) + fabsf(lhi.x) + fabsf(lhi.y) + fabsf(lhi.z));
+			llo = v3_sub(llo, V3(pad, pad, pad)); lhi = v3_add(lhi, V3(pad, pad, pad));
+		}
+		// The candidates.  Eight lanes per pair: lane 0 walks the tree depth-first (a few dozen dependent node fetches for a small body) and gives up
+		// once it holds more than MESH_BIG_MIN -- the pair is passed on.  A wave per pair: level by level, the 64 lanes taking the nodes of a level
+		// 64 at a time (depth-first, a car-sized box on a fine mesh is a chain of hundreds of fetches); the two frontiers live in the arrays the
+		// sort uses afterwards.  The SET found is that of the depth-first walk unless a table overflows -- then the answer depends on the order of
+		// the walk, and lane 0 repeats it depth-first.
+		if (sub == 0) { L.n_front[0] = valid ? 1u : 0u; L.n_front[1] = 0u; L.n_found = 0u; L.redo = MESH_GROUP == 64 ? 0u : 1u; L.key[0] = 0u; L.mc.ng = 0; }
+		__syncthreads();
+		if (MESH_GROUP == 64) {
+			for (int level = 0; level < 64; ++level) {
+				uint32_t* cur = (level & 1) ? L.cand : L.key; uint32_t* nxt = (level & 1) ? L.key : L.cand;
+				const uint32_t ncur = L.redo ? 0u : L.n_front[level & 1];      // (a table overflowed: what the frontiers hold no longer matters)
+				if (!__any(ncur != 0u)) break;
+				for (uint32_t i = (uint32_t)sub; i < ncur; i += MESH_GROUP) {
+					const MeshNode nd = d.mesh_nodes[mh.node_off + cur[i]];
+					if (nd.mxx < llo.x || nd.mnx > lhi.x || nd.mxy < llo.y || nd.mny > lhi.y || nd.mxz < llo.z || nd.mnz > lhi.z) continue;
+					if (nd.count == 0) {
+						const uint32_t at = atomicAdd(&L.n_front[(level & 1) ^ 1], 2u);
+						if (at + 2u <= MESH_CAND_CAP) { nxt[at] = nd.left; nxt[at + 1] = nd.right; } else L.redo = 1u;
+					} else {
+						const uint32_t at = atomicAdd(&L.n_found, nd.count);
+						if (at + nd.count <= MESH_CAND_CAP) { for (uint32_t k = 0; k < nd.count; ++k) L.found[at + k] = nd.left + k; } else L.redo = 1u;
+					}
 				}
-				const float pad = 1.0e-4f * (1.0f + fabsf(llo.x) + fabsf(llo.y) + fabsf(llo.z) + fabsf(lhi.x) + fabsf(lhi.y) + fabsf(lhi.z));
-				llo = v3_sub(llo, V3(pad, pad, pad)); lhi = v3_add(lhi, V3(pad, pad, pad));
-				nc = mesh_candidates_found(d, mh, llo, lhi, L.found, L.key, &dropped);
-				L.mc.ng = 0;
+				__syncthreads();
+				if (sub == 0) L.n_front[level & 1] = 0u;
+				__syncthreads();
 			}
 		}
-		nc = __shfl(nc, grp * MESH_GROUP, 64);
+		if (valid && L.redo) {
+			if (sub == 0) L.n_found = (uint32_t)mesh_candidates_found(d, mh, llo, lhi, L.found, L.key, &dropped, MESH_GROUP == 64 ? MESH_CAND_CAP : MESH_BIG_MIN, MeshPairLds<MESH_GROUP>::CAP);
+		}
+		__syncthreads();
+		nc = valid ? (int)min(L.n_found, (uint32_t)MeshPairLds<MESH_GROUP>::CAP) : 0;
+		if (MESH_GROUP != 64 && nc > MESH_BIG_MIN) {
+			// too many triangles for eight lanes: the wave-per-pair launch takes the pair (and finds its candidates again)
+			if (sub == 0) d.mesh_big[atomicAdd(&d.ctr->n_mesh_big, 1u)] = pair;
+			valid = false; nc = 0; dropped = false;
+		}
+		for (int i = sub; i < nc; i += MESH_GROUP) L.key[i] = d.mesh_tris[mh.tri_off + L.found[i]].w;
 		__syncthreads();
 		// candidates in the order of the caller's triangle indices: the rank of a key is the number of smaller keys
 		for (int i = sub; i < nc; i += MESH_GROUP) {
@@ -893,9 +947,9 @@ __global__ void __launch_bounds__(64) k_narrowphase_mesh(DV d)
 				const v3 tmin = V3(fminf(fminf(wa.x, wb.x), wc.x), fminf(fminf(wa.y, wb.y), wc.y), fminf(fminf(wa.z, wb.z), wc.z));
 				const v3 tmax = V3(fmaxf(fmaxf(wa.x, wb.x), wc.x), fmaxf(fmaxf(wa.y, wb.y), wc.y), fmaxf(fmaxf(wa.z, wb.z), wc.z));
 				if (!(tmax.x < qlo.x || tmin.x > qhi.x || tmax.y < qlo.y || tmin.y > qhi.y || tmax.z < qlo.z || tmin.z > qhi.z)) {
-					sgd_hull th; v3 cen, nrm;
+					sgd_tri_hull_t th; v3 cen, nrm;
 					sgd_tri_hull(a, b, c, &th, &cen, &nrm);
-					sgd_hview T; T.pos = v3_add(mpos, m33_mul(R, cen)); T.R = R; T.scale = V3(1.0f, 1.0f, 1.0f); T.h = &th;
+					sgd_tri_view T; T.pos = v3_add(mpos, m33_mul(R, cen)); T.R = R; T.scale = V3(1.0f, 1.0f, 1.0f); T.h = &th;
 					hit = sgd_collide_tri(&X, &T, m33_mul(R, nrm), max_sep, &m) != 0;
 				}
 			}
@@ -4505,7 +4559,11 @@ void launch_narrowphase_hull(const DV& d, hipStream_t s)
 	hipLaunchKernelGGL(k_narrowphase_hull, dim3(4096), dim3(64), 0, s, d);
 	hipLaunchKernelGGL(k_narrowphase_hull_manifold, dim3(1024), dim3(64), 0, s, d);
 }
-void launch_narrowphase_mesh(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_narrowphase_mesh, dim3(2048), dim3(64), 0, s, d); }
+void launch_narrowphase_mesh(const DV& d, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_narrowphase_mesh<8>, dim3(2048), dim3(64), 0, s, d);       // eight lanes per pair; passes the pairs with many candidate triangles on to ...
+	hipLaunchKernelGGL(k_narrowphase_mesh<64>, dim3(2048), dim3(64), 0, s, d);      // ... a wave per pair
+}
 void launch_colour_inherit(const DV& d, uint32_t est, hipStream_t s) { hipLaunchKernelGGL(k_colour_inherit, dim3(stride_grid(est)), dim3(TPB), 0, s, d); }
 void launch_colour_claim(const DV& d, uint32_t est, uint32_t round, hipStream_t s)
 {

@@ -194,3 +194,38 @@ def test_mesh_added_after_a_large_dynamic_body_matches_oracle(oracle):
             assert d["bit_exact"] and d["active_mismatch"] == 0, (s, d)
     assert touched                                          # the big box did come to rest on the mesh
     tw.close()
+
+
+def test_large_boxes_on_a_fine_mesh_match_oracle(oracle):
+    """Bodies that span many triangles: a car-sized slab on 0.4 m triangles has 100+ candidate triangles, which the mesh kernel hands from its
+    eight-lanes-per-pair launch to the wave-per-pair launch (level-by-level tree walk, 64 triangle tests per round, ordered merge).  The result
+    is that of the sequential walk: the oracle's."""
+    rng = np.random.default_rng(8)
+    tw = parity.make_twin(oracle, max_bodies=256)
+    V, T = grid_mesh(81, 16.0, lambda x, y: 0.04 * np.sin(0.9 * x) * np.cos(0.8 * y))
+    ig, ic = tw.mesh_create(V, T)
+    tw.add_batch(mesh_body(ig))
+    n = 9
+    d = scenes.dynamic_bodies(n, mass=800.0)
+    d["shape_type"] = abi.SHAPE_BOX
+    d["shape"][:, 0] = 2.2; d["shape"][:, 1] = 1.0; d["shape"][:, 2] = 0.5
+    d["shape"][6:, :3] = 0.3                                               # three small ones stay with the eight-lane launch
+    gx, gy = np.meshgrid(np.arange(3), np.arange(3))
+    d["pos"] = np.column_stack([(gx.ravel() - 1) * 7.0, (gy.ravel() - 1) * 5.0, rng.uniform(0.9, 1.6, n)])
+    a = rng.uniform(0, np.pi, n); d["rot"] = np.column_stack([0.05 * rng.normal(size=n), 0.05 * rng.normal(size=n), np.sin(a / 2), np.cos(a / 2)])
+    d["rot"] /= np.linalg.norm(d["rot"], axis=1, keepdims=True)
+    tw.add_batch(d)
+    total = 3 + n
+    for s in range(1, 181):
+        tw.step(DT)
+        if s in (1, 20, 60, 120, 180):
+            c = parity.compare(tw, total)
+            assert c["active_mismatch"] == 0, (s, c)
+            assert c["pos"] <= 2e-4 and c["rot"] <= 2e-4 and c["lin_vel"] <= 2e-3 and c["ang_vel"] <= 2e-3, (s, c)
+            sg, sc = tw.stats()
+            assert (sg.num_pairs, sg.num_manifolds, sg.num_contact_points) == (sc.num_pairs, sc.num_manifolds, sc.num_contact_points), s
+            assert sg.manifolds_dropped == sc.manifolds_dropped == 0
+    print("large boxes on a fine mesh, 180 steps: bit exact =", c["bit_exact"])
+    st = tw.gpu.read_states(3, n)
+    assert (st["pos"][:, 2] > 0.2).all() and (st["pos"][:, 2] < 1.0).all()      # resting on the floor
+    tw.close()
