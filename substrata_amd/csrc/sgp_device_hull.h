@@ -4,7 +4,8 @@
 // (/root/reference/gui_client/PhysicsWorld.cpp:735-1166 with is_dynamic, CarPhysics.cpp:66-92, BikePhysics.cpp:76-112): separating
 // axis test over face normals and edge pairs + reference / incident face clipping (<= 4 points) instead of GJK/EPA.
 // A hull is stored in its body frame (origin = centre of mass, axes = principal axes); a box is the +-1 cube template scaled.
-// Included by sgp_device_collide.h after sgd_manifold / sgd_closest_on_segment.  Regenerate with tools/derive_device_vehicle.py.
+// Included by sgp_device_collide.h after sgd_manifold / sgd_closest_on_segment.  The collision functions are templates over the hull record type (the full
+// record, or the three-vertex record of a mesh triangle).
 #pragma once
 #include "sgp_device_math.h"
 

@@ -3,7 +3,7 @@
 //
 // Role of JPH::MeshShape / HeightFieldShape in CollideShape / CastRay for Substrata's static meshes and terrain
 // (/root/reference/gui_client/PhysicsWorld.cpp:735-1166 with is_dynamic = false, :1020-1120; TerrainSystem.cpp:1300).
-// Included after sgp_device_collide.h.  Regenerate with tools/derive_device_vehicle.py.
+// Included after sgp_device_collide.h.
 #pragma once
 #include "sgp_device_vehicle.h"     // sgd_ray_sphere / sgd_ray_capsule_z, sgd_hull through sgp_device_collide.h
 

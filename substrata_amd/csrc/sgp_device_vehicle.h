@@ -5,10 +5,12 @@
 // /root/reference/gui_client/Scripting.cpp:315-346): per wheel one sphere cast along the suspension, tyre slip -> friction,
 // engine / clutch / gearbox / differential, brakes, anti-roll bars, then 4 axis rows per wheel (soft suspension spring, hard
 // max-up stop, longitudinal, lateral) and, for motorcycles, the lean spring.
-// One wave owns one vehicle; vehicles never share a chassis and treat the body under a wheel as kinematic (its contact
-// point velocity is sampled at cast time), so the vehicle phases need no colouring.
-// The arithmetic (expression order included) is the contract checked by tests/test_vehicle_parity_gpu.py against the CPU
-// oracle; no libm call sits on this path (polynomial sin/cos/acos).  Regenerate with tools/derive_device_vehicle.py.
+// Pre-step: one wave per vehicle, the record staged in LDS, wheel i's work on lane i and what couples the wheels on lane 0
+// (sgd_vehicle_precast_lanes, sgd_vehicle_controller_lanes); the casts spread 16 lanes per wheel (k_vehicle_cast).  Solver passes: four lanes
+// per vehicle on the lane-major row export (veh_quad_solve, sgp_kernels.hip), in the launch of contact colour 0.  Vehicles never share a
+// chassis and treat the body under a wheel as kinematic (its contact point velocity is sampled at cast time).
+// The arithmetic of a wheel (expression order included) is the contract checked by tests/test_vehicle_parity_gpu.py against the sequential CPU
+// statement; no libm call sits on this path (polynomial sin/cos/acos).
 #pragma once
 #include "sgp_device_collide.h"     // sgd_hull (wheel casts against hull bodies)
 

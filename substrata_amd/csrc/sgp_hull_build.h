@@ -2,7 +2,7 @@
 //
 // Role of JPH::ConvexHullShapeSettings::Create + MassProperties (+ OffsetCenterOfMassShape) (/root/reference/gui_client/
 // CarPhysics.cpp:66-92, BikePhysics.cpp:76-112): brute-force supporting planes for <= 32 hull vertices, signed-tetrahedra mass
-// properties, Jacobi principal axes; double precision, rounded to float once.  Regenerate with tools/derive_device_vehicle.py.
+// properties, Jacobi principal axes; double precision, rounded to float once.
 #pragma once
 #include <math.h>
 #include <string.h>

@@ -808,11 +808,12 @@ SGP_DEV int collide_with_mesh(const DV& d, uint32_t mbody, const sgd_shape& X, v
 // (Eight, not 64: a body on a terrain or floor mesh touches a handful of triangles, and a wave per pair would idle 56 lanes.  A chassis across 150
 // triangles of a detailed mesh is another matter -- a box - triangle test is ~40 us of one lane's instructions, 24 rounds of them ~2 ms --: a pair
 // with more than MESH_BIG_MIN candidates is passed on to a second launch of the same kernel with all 64 lanes on one pair.)
-#define MESH_BIG_MIN 32      // pairs with more candidates than this go to the wave-per-pair launch
+#define MESH_BIG_MIN 32      // pairs with more candidates than this go to the wave-per-pair launch ...
+#define MESH_BIG_CAP 1024    // ... which holds this many (a body across more triangles than that loses the rest: counted in manifolds_dropped)
 // (the tables of a pair in LDS; G = 8: a pair that fills more than MESH_BIG_MIN entries is passed on, so 64 entries do, and no copy of the polytope)
 struct MeshNoHull {};
 template <int G> struct MeshPairLds {
-	static constexpr int CAP = G == 64 ? MESH_CAND_CAP : 64;
+	static constexpr int CAP = G == 64 ? MESH_BIG_CAP : 64;
 	uint32_t found[CAP]; uint32_t key[CAP]; uint32_t cand[CAP]; uint32_t n_front[2], n_found, redo;
 	sgd_mesh_contacts mc;
 	typename std::conditional<G == 64, sgd_hull, MeshNoHull>::type hull;      // the body's polytope (cube template / convex hull) next to the lanes that walk its vertices once per axis
@@ -903,10 +904,10 @@ template <int MESH_GROUP> __global__ void __launch_bounds__(64) k_narrowphase_me
 					if (nd.mxx < llo.x || nd.mnx > lhi.x || nd.mxy < llo.y || nd.mny > lhi.y || nd.mxz < llo.z || nd.mnz > lhi.z) continue;
 					if (nd.count == 0) {
 						const uint32_t at = atomicAdd(&L.n_front[(level & 1) ^ 1], 2u);
-						if (at + 2u <= MESH_CAND_CAP) { nxt[at] = nd.left; nxt[at + 1] = nd.right; } else L.redo = 1u;
+						if (at + 2u <= (uint32_t)MeshPairLds<MESH_GROUP>::CAP) { nxt[at] = nd.left; nxt[at + 1] = nd.right; } else L.redo = 1u;
 					} else {
 						const uint32_t at = atomicAdd(&L.n_found, nd.count);
-						if (at + nd.count <= MESH_CAND_CAP) { for (uint32_t k = 0; k < nd.count; ++k) L.found[at + k] = nd.left + k; } else L.redo = 1u;
+						if (at + nd.count <= (uint32_t)MeshPairLds<MESH_GROUP>::CAP) { for (uint32_t k = 0; k < nd.count; ++k) L.found[at + k] = nd.left + k; } else L.redo = 1u;
 					}
 				}
 				__syncthreads();
@@ -915,7 +916,7 @@ template <int MESH_GROUP> __global__ void __launch_bounds__(64) k_narrowphase_me
 			}
 		}
 		if (valid && L.redo) {
-			if (sub == 0) L.n_found = (uint32_t)mesh_candidates_found(d, mh, llo, lhi, L.found, L.key, &dropped, MESH_GROUP == 64 ? MESH_CAND_CAP : MESH_BIG_MIN, MeshPairLds<MESH_GROUP>::CAP);
+			if (sub == 0) L.n_found = (uint32_t)mesh_candidates_found(d, mh, llo, lhi, L.found, L.key, &dropped, MESH_GROUP == 64 ? MESH_BIG_CAP : MESH_BIG_MIN, MeshPairLds<MESH_GROUP>::CAP);
 		}
 		__syncthreads();
 		nc = valid ? (int)min(L.n_found, (uint32_t)MeshPairLds<MESH_GROUP>::CAP) : 0;

@@ -197,18 +197,18 @@ def test_mesh_added_after_a_large_dynamic_body_matches_oracle(oracle):
 
 
 def test_large_boxes_on_a_fine_mesh_match_oracle(oracle):
-    """Bodies that span many triangles: a car-sized slab on 0.4 m triangles has 100+ candidate triangles, which the mesh kernel hands from its
+    """Bodies that span many triangles: a car-sized slab on 0.5 m triangles has 100-250 candidate triangles, which the mesh kernel hands from its
     eight-lanes-per-pair launch to the wave-per-pair launch (level-by-level tree walk, 64 triangle tests per round, ordered merge).  The result
     is that of the sequential walk: the oracle's."""
     rng = np.random.default_rng(8)
     tw = parity.make_twin(oracle, max_bodies=256)
-    V, T = grid_mesh(81, 16.0, lambda x, y: 0.04 * np.sin(0.9 * x) * np.cos(0.8 * y))
+    V, T = grid_mesh(65, 16.0, lambda x, y: 0.04 * np.sin(0.9 * x) * np.cos(0.8 * y))       # 0.5 m triangles
     ig, ic = tw.mesh_create(V, T)
     tw.add_batch(mesh_body(ig))
     n = 9
     d = scenes.dynamic_bodies(n, mass=800.0)
     d["shape_type"] = abi.SHAPE_BOX
-    d["shape"][:, 0] = 2.2; d["shape"][:, 1] = 1.0; d["shape"][:, 2] = 0.5
+    d["shape"][:, 0] = 2.2; d["shape"][:, 1] = 1.0; d["shape"][:, 2] = 0.5           # bounds of up to 4.9 m: 200+ candidates for the turned ones (the wave-per-pair launch holds 1024)
     d["shape"][6:, :3] = 0.3                                               # three small ones stay with the eight-lane launch
     gx, gy = np.meshgrid(np.arange(3), np.arange(3))
     d["pos"] = np.column_stack([(gx.ravel() - 1) * 7.0, (gy.ravel() - 1) * 5.0, rng.uniform(0.9, 1.6, n)])
