@@ -366,7 +366,7 @@ SGP_DEV void push_pair(const DV& d, uint32_t i, uint32_t j)
 }
 
 // pair staged in LDS (falls back to the global list when the tile's buffer is full)
-template <int PCAP> SGP_DEV void stage_pair(const DV& d, uint2* spairs, uint32_t* lcount, uint32_t i, uint32_t j);
+template <int PCAP> SGP_DEV void stage_pair(const DV& d, uint2* spairs, uint8_t* scls, uint32_t* lcount, uint32_t i, uint32_t j, uint32_t fi, uint32_t fj);
 
 #define BP_TILE 4
 #define BP_H 2
@@ -384,11 +384,45 @@ template <int PCAP> SGP_DEV void stage_pair(const DV& d, uint2* spairs, uint32_t
 #define BP_PAIR_CAP_LARGE 2048
 #define BP_SPLIT 4
 
-template <int PCAP> SGP_DEV void stage_pair(const DV& d, uint2* spairs, uint32_t* lcount, uint32_t i, uint32_t j)
+// The class of a pair = its two shape types: the staged pairs leave a workgroup sorted by class (flush_pairs), so that the narrow phase -- one thread
+// per pair, one branch per pairing of shapes -- gets waves of one pairing instead of waves that walk through all six branches one after the other.
+SGP_DEV uint32_t pair_class(uint32_t fa, uint32_t fb) { const uint32_t ta = f_shape(fa), tb = f_shape(fb); return (ta < tb ? ta : tb) * 8u + (ta < tb ? tb : ta); }
+template <int PCAP> SGP_DEV void stage_pair(const DV& d, uint2* spairs, uint8_t* scls, uint32_t* lcount, uint32_t i, uint32_t j, uint32_t fi, uint32_t fj)
 {
 	const uint32_t k = atomicAdd(lcount, 1u);
-	if (k < (uint32_t)PCAP) spairs[k] = make_uint2(i < j ? i : j, i < j ? j : i);
+	if (k < (uint32_t)PCAP) { spairs[k] = make_uint2(i < j ? i : j, i < j ? j : i); scls[k] = (uint8_t)pair_class(fi, fj); }
 	else push_pair(d, i, j);
+}
+// the staged pairs to the global list, grouped by class (counting sort over 64 bins; the order inside a class is whatever the atomics gave: the
+// list's order never enters a result).  Whole workgroup.
+template <int PCAP> SGP_DEV void flush_pairs(const DV& d, const uint2* spairs, const uint8_t* scls, uint32_t lcount, uint32_t* gbase, uint32_t* bins)
+{
+	const uint32_t n_out = min(lcount, (uint32_t)PCAP);
+	if (threadIdx.x < 64) bins[threadIdx.x] = 0;
+	if (threadIdx.x == 0 && n_out) *gbase = atomicAdd(&d.ctr->n_pairs, n_out);
+	__syncthreads();
+	uint32_t rank[PCAP / TPB];
+#pragma unroll
+	for (int r = 0; r < PCAP / TPB; ++r) { const uint32_t k = threadIdx.x + (uint32_t)r * TPB; rank[r] = k < n_out ? atomicAdd(&bins[scls[k]], 1u) : 0u; }
+	__syncthreads();
+	if (threadIdx.x < 64) {
+		// exclusive scan of the 64 bins by the first wave
+		const uint32_t v = bins[threadIdx.x];
+		uint32_t x = v;
+#pragma unroll
+		for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off, 64); if ((int)threadIdx.x >= off) x += y; }
+		bins[threadIdx.x] = x - v;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int r = 0; r < PCAP / TPB; ++r) {
+		const uint32_t k = threadIdx.x + (uint32_t)r * TPB;
+		if (k < n_out) {
+			const uint32_t at = *gbase + bins[scls[k]] + rank[r];
+			if (at < d.cap_pairs) d.pairs[at] = spairs[k];
+			else atomicAdd(&d.ctr->pairs_dropped, 1u);
+		}
+	}
 }
 
 // exclusive scan of n <= 2*TPB values held in LDS (in place), result total returned to every thread
@@ -424,6 +458,8 @@ template <int BP_LDS_CAP, int BP_PAIR_CAP> __global__ void __launch_bounds__(TPB
 	__shared__ uint32_t istart[BP_INNER_CELLS + 1];
 	__shared__ uint32_t wave_tot[TPB / 64];
 	__shared__ uint2 spairs[BP_PAIR_CAP];
+	__shared__ uint8_t scls[BP_PAIR_CAP];
+	__shared__ uint32_t pbins[64];
 	__shared__ uint32_t lcount, gbase;
 	const BpGrid g = *d.grid;
 	const int tnx = (g.nx + BP_TILE - 1) / BP_TILE, tny = (g.ny + BP_TILE - 1) / BP_TILE, tnz = (g.nz + BP_TILE - 1) / BP_TILE;
@@ -511,7 +547,7 @@ template <int BP_LDS_CAP, int BP_PAIR_CAP> __global__ void __launch_bounds__(TPB
 						const uint32_t j = __float_as_uint(mxj.w);
 						if (j == i) continue;
 						if (f_active_for_pairs(__float_as_uint(mnj.w)) && j < i) continue;
-						if (rec_pair_passes(spec, mni, mxi, mnj, mxj)) stage_pair<BP_PAIR_CAP>(d, spairs, &lcount, i, j);
+						if (rec_pair_passes(spec, mni, mxi, mnj, mxj)) stage_pair<BP_PAIR_CAP>(d, spairs, scls, &lcount, i, j, fi, __float_as_uint(mnj.w));
 					}
 				} else {
 					for (int c = xl; c <= xh; ++c) {
@@ -521,7 +557,7 @@ template <int BP_LDS_CAP, int BP_PAIR_CAP> __global__ void __launch_bounds__(TPB
 							const uint32_t j = __float_as_uint(mxj.w);
 							if (j == i) continue;
 							if (f_active_for_pairs(__float_as_uint(mnj.w)) && j < i) continue;
-							if (rec_pair_passes(spec, mni, mxi, mnj, mxj)) stage_pair<BP_PAIR_CAP>(d, spairs, &lcount, i, j);
+							if (rec_pair_passes(spec, mni, mxi, mnj, mxj)) stage_pair<BP_PAIR_CAP>(d, spairs, scls, &lcount, i, j, fi, __float_as_uint(mnj.w));
 						}
 					}
 				}
@@ -531,28 +567,14 @@ template <int BP_LDS_CAP, int BP_PAIR_CAP> __global__ void __launch_bounds__(TPB
 		// counter serialise, ~12 ns each), coalesced stores
 		__syncthreads();
 		if (lcount > BP_PAIR_CAP / 2) {
-			const uint32_t n_out = min(lcount, (uint32_t)BP_PAIR_CAP);
-			if (threadIdx.x == 0) gbase = atomicAdd(&d.ctr->n_pairs, n_out);
-			__syncthreads();
-			for (uint32_t k = threadIdx.x; k < n_out; k += TPB) {
-				if (gbase + k < d.cap_pairs) d.pairs[gbase + k] = spairs[k];
-				else atomicAdd(&d.ctr->pairs_dropped, 1u);
-			}
+			flush_pairs<BP_PAIR_CAP>(d, spairs, scls, lcount, &gbase, pbins);
 			__syncthreads();
 			if (threadIdx.x == 0) lcount = 0;
 		}
 	}
 	// what is left after the workgroup's last tile
 	__syncthreads();
-	{
-		const uint32_t n_out = min(lcount, (uint32_t)BP_PAIR_CAP);
-		if (threadIdx.x == 0 && n_out) gbase = atomicAdd(&d.ctr->n_pairs, n_out);
-		__syncthreads();
-		for (uint32_t k = threadIdx.x; k < n_out; k += TPB) {
-			if (gbase + k < d.cap_pairs) d.pairs[gbase + k] = spairs[k];
-			else atomicAdd(&d.ctr->pairs_dropped, 1u);
-		}
-	}
+	flush_pairs<BP_PAIR_CAP>(d, spairs, scls, lcount, &gbase, pbins);
 }
 
 // large bodies (ground quad, PhysicsWorld.cpp:1123) against every body
