@@ -573,6 +573,7 @@ typedef struct sgp_ghost_record {
 #define SGP_GHOST_FLAG_SENSOR       (1u << 2)
 #define SGP_GHOST_FLAG_ALLOW_SLEEP  (1u << 3)
 #define SGP_GHOST_FLAG_ZERO_DRAG    (1u << 4)
+#define SGP_GHOST_FLAG_CHASSIS      (1u << 5)   /* the body carries a live vehicle: it never changes owner (the vehicle record -- engine, gearbox, wheel state -- lives with the tile that created it); its neighbours see it as a ghost like any other body */
 int  sgp_world_export_boundary(sgp_world* w, const float lo[3], const float hi[3], float margin,
                                sgp_ghost_record* out, uint32_t cap, uint32_t* n_out);
 /* Replace this world's ghost set with `n` records (bodies simulated as velocity-driven, infinite mass). */

@@ -2068,6 +2068,7 @@ SGO_API int sgo_world_export_boundary(sgo_world* w, const float lo[3], const flo
 			r->motion_type = (uint32_t)b->motion; r->global_id = i;
 			r->userdata = b->userdata; r->gravity_factor = b->gravity_factor; r->linear_damping = b->lin_damp; r->angular_damping = b->ang_damp;
 			r->flags = ((uint32_t)b->layer & SGP_GHOST_FLAG_LAYER_MASK) | (b->is_sensor ? SGP_GHOST_FLAG_SENSOR : 0u) | (b->allow_sleep ? SGP_GHOST_FLAG_ALLOW_SLEEP : 0u) | (b->zero_lin_drag ? SGP_GHOST_FLAG_ZERO_DRAG : 0u);
+			for (uint32_t v = 0; v < w->n_vehicles; ++v) if (w->vehicles[v].alive && w->vehicles[v].body == i) r->flags |= SGP_GHOST_FLAG_CHASSIS;
 		}
 		++n;
 	}

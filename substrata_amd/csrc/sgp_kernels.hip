@@ -4029,7 +4029,7 @@ SGP_DEV void fill_ghost_desc(const DV& d, uint32_t i, uint32_t f, sgp_ghost_reco
 	r.userdata = d.userdata[i];
 	const float4 dy = d.dyn[i];
 	r.gravity_factor = dy.z; r.linear_damping = dy.x; r.angular_damping = dy.y;
-	r.flags = f_layer(f) | ((f & BF_SENSOR) ? SGP_GHOST_FLAG_SENSOR : 0u) | ((f & BF_ALLOW_SLEEP) ? SGP_GHOST_FLAG_ALLOW_SLEEP : 0u) | ((f & BF_ZERO_LIN_DRAG) ? SGP_GHOST_FLAG_ZERO_DRAG : 0u);
+	r.flags = f_layer(f) | ((f & BF_SENSOR) ? SGP_GHOST_FLAG_SENSOR : 0u) | ((f & BF_ALLOW_SLEEP) ? SGP_GHOST_FLAG_ALLOW_SLEEP : 0u) | ((f & BF_ZERO_LIN_DRAG) ? SGP_GHOST_FLAG_ZERO_DRAG : 0u) | ((f & BF_CHASSIS) ? SGP_GHOST_FLAG_CHASSIS : 0u);
 	r._pad[0] = 0; r._pad[1] = 0;
 }
 
@@ -4099,7 +4099,8 @@ SGP_DEV unsigned long long route_mask(const DV& d, uint32_t i, const TileRoute& 
 	const float4 p = d.pose[2 * (size_t)i];
 	// an owned dynamic body emigrates only when another tile's own (unpadded) region contains its centre: where the caller's boxes leave a gap
 	// nobody would accept the body, so it stays with its current owner instead of vanishing
-	const bool left = t.n_tiles > 1 && f_motion(f) == SGP_MOTION_DYNAMIC && !tile_in_box(p, mylo, myhi, 0.0f);
+	// (a vehicle's chassis stays with the tile that holds the vehicle record: SGP_GHOST_FLAG_CHASSIS)
+	const bool left = t.n_tiles > 1 && f_motion(f) == SGP_MOTION_DYNAMIC && !(f & BF_CHASSIS) && !tile_in_box(p, mylo, myhi, 0.0f);
 	bool taker = false;
 	unsigned long long m = 0ull;
 	for (uint32_t r = 0; r < t.n_tiles; ++r) {

@@ -2404,7 +2404,7 @@ SGP_API int sgp_tiles_route(const sgp_ghost_record* recs, uint32_t n, uint32_t m
 	for (uint32_t k = 0; k < n; ++k) {
 		bool taker = false;      // (same rule as route_mask on the device: without a tile that contains the centre the body stays where it is)
 		for (uint32_t r = 0; r < n_tiles && !taker; ++r) if (r != my_rank) taker = in_box(recs[k].pos, boxes + 6 * (size_t)r, boxes + 6 * (size_t)r + 3, 0.0f);
-		if (n_tiles > 1 && taker && (recs[k].motion_type & 0xFFu) == SGP_MOTION_DYNAMIC && !in_box(recs[k].pos, mylo, myhi, 0.0f)) {
+		if (n_tiles > 1 && taker && (recs[k].motion_type & 0xFFu) == SGP_MOTION_DYNAMIC && !(recs[k].flags & SGP_GHOST_FLAG_CHASSIS) && !in_box(recs[k].pos, mylo, myhi, 0.0f)) {
 			emig[k] = 1;
 			if (ne < emigrant_cap && emigrant_ids) emigrant_ids[ne] = (uint32_t)(recs[k].global_id & 0xFFFFFFFFull);
 			++ne;

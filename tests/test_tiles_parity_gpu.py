@@ -132,6 +132,62 @@ def test_two_tiles_native_exchange_against_oracle(oracle):
         w.close()
 
 
+def test_a_car_crossing_the_border_keeps_its_vehicle(oracle):
+    """A vehicle's chassis never changes owner (SGP_GHOST_FLAG_CHASSIS: the vehicle record -- engine, gearbox, wheel state -- lives with the tile
+    that created it): the car drives out of tile 0 into tile 1, stays tile 0's body, keeps driving, and tile 1 meets it as a ghost that pushes
+    its boxes.  Native exchange on the HIP worlds, the Python statement of the rules on the oracle worlds: same counts, same bits."""
+    from substrata_amd.lib import World
+    from helpers import add_car
+    boxes = []
+    for r in range(2):
+        lo, hi, _ = tiles.tile_bounds(r, 2, TILE_W, TILE_W)
+        boxes.append(np.concatenate([lo, hi]))
+    boxes = np.array(boxes, np.float32)
+    gpu = [World(max_bodies=256) for _ in range(2)]
+    cpu = [oracle.OracleWorld(max_bodies=256) for _ in range(2)]
+    cars = []
+    for ws in (gpu, cpu):
+        for r in range(2):
+            ws[r].add_batch(scenes.ground())
+        # tile 1: a few boxes in the car's way, just behind the border
+        d = scenes.dynamic_bodies(4, mass=20.0)
+        d["shape"][:, :3] = 0.4
+        d["pos"] = [(TILE_W + 2.0 + 0.9 * k, 6.0 + 0.5 * (k % 2), 0.41) for k in range(4)]
+        ws[1].add_batch(d)
+        q = (0.0, 0.0, -np.sin(np.pi / 4), np.cos(np.pi / 4))                      # the car's forward (+y) turned to +x
+        cars.append(add_car(ws[0], pos=(TILE_W - 5.0, 6.0, 0.8), rot=q))
+    assert cars[0] == cars[1]
+    body, veh = cars[0]
+    nt = [tiles.NativeTiles(gpu[r], r, 2, boxes, 1.5) for r in range(2)]
+    for s in range(1, 301):
+        for ws in (gpu, cpu):
+            ws[0].vehicle_set_input(veh, forward=1.0)
+        lc = []
+        tiles.NativeTiles.exchange_group(nt)
+        exchange(cpu, boxes, 1.5, lc)
+        for r in range(2):
+            st = nt[r].stats()
+            exp = [e for e in lc if len(e) == 4 and e[0] == r][0]; imp = [e for e in lc if len(e) == 3 and e[0] == r][0]
+            assert (st.exported, st.emigrated, st.ghosts, st.immigrated) == (exp[2], exp[3], imp[1], imp[2]), (s, r)
+            assert st.emigrated == 0 or r == 1                  # the car never emigrates (tile 1's boxes may, once pushed around)
+        for r in range(2):
+            gpu[r].step(DT); cpu[r].step(DT)
+        if s % 50 == 0:
+            for r in range(2):
+                d = parity.state_diff(gpu[r].read_states(0, 256), cpu[r].read_states(0, 256))
+                assert d["bit_exact"] and d["active_mismatch"] == 0, (s, r, d)
+    car = gpu[0].get_state([body])[0]
+    assert car["pos"][0] > TILE_W + 1.0, car["pos"]                         # it is well inside tile 1's region ...
+    vs_g, vs_c = gpu[0].vehicle_get_state(veh), cpu[0].vehicle_get_state(veh)
+    assert float(vs_g["engine_rpm"]) == float(vs_c["engine_rpm"]) and float(vs_g["engine_rpm"]) > 1000.0     # ... and still a car, in tile 0's world
+    moved = gpu[1].read_states(1, 4)
+    assert np.max(np.abs(moved["pos"][:, 0] - [TILE_W + 2.0 + 0.9 * k for k in range(4)])) > 0.3      # its ghost pushed tile 1's boxes
+    for t in nt:
+        t.close()
+    for w in gpu + cpu:
+        w.close()
+
+
 def sensor_border_scene(rank):
     """Tile 1 holds a box at rest next to the border; tile 0 holds a SENSOR box and a box on the non-collidable moving layer, both overlapping it
     across the border.  If their ghosts were solid (the round-2 behaviour) they would shove the resting box away."""

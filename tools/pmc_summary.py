@@ -40,13 +40,16 @@ def main():
         bodies = int(sys.argv[5])
 
         def per_launch(name):
+            # (the solver kernels carry template arguments after the mode: "void k_solve_colour<1, 0>" -- match by the name up to the first argument)
+            full = [k for k in fetch if k == name or (name.endswith(">") and k.startswith(name[:-1] + ","))]
+            name = full[0] if full else name
             fv = fetch.get(name, [0.0]); wv = write.get(name, [0.0])
             fv = fv[len(fv) // 2:]; wv = wv[len(wv) // 2:]
             return sum(fv) / len(fv) * 1024 * 2 + sum(wv) / len(wv) * 1024
         sweep = sum(per_launch(k) for k in ("k_pre_solve", "k_integrate_pose", "k_finalize"))
         out = {"sweep_bytes_per_body": sweep / bodies, "solve_velocity_bytes_per_launch": per_launch("void k_solve_colour<1>"),
                # the one launch per pass that takes every colour from the plan's hc_first on (0 if the run never used it)
-               "solve_components_bytes_per_launch": per_launch("void k_solve_hc<1>") if "void k_solve_hc<1>" in fetch else 0.0,
+               "solve_components_bytes_per_launch": per_launch("void k_solve_hc<1>") if any(k.startswith("void k_solve_hc<1") for k in fetch) else 0.0,
                "bodies": bodies,
                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, eager launches), tools/collect_pmc.sh + tools/pmc_summary.py: "
                          "FETCH_SIZE KiB x 1024 x 2 (gfx950 correction) + WRITE_SIZE KiB x 1024, mean over the second half of each kernel's launches"}
