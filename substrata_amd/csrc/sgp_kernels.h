@@ -154,7 +154,7 @@ struct StepParams {
 	int      water_enabled; float water_z;
 	int      contact_events;
 	uint32_t parity;           // which of DV::ca[] is the current constraint buffer (the other one is the contact cache)
-	uint32_t compact_rows;     // 1: the velocity rows hold only r x axis (96 B per point); I (r x axis) is recomputed by the lane that needs it (bandwidth-bound worlds)
+	uint32_t compact_rows;     // row layout of the velocity iterations: 0 full (192 B per point), 1 r x axis only (96 B; I (r x axis) rebuilt by the lane that needs it), 2 none (everything rebuilt from the lever arms r1b / r2e and efft): bandwidth-bound worlds
 	uint32_t pad[6];
 };
 

@@ -1404,6 +1404,7 @@ SGP_DEV float4* axis_rows(const DV& d, uint32_t slot, int point, int axis) { ret
 // (w2, w3: spare lanes of the two inverse-inertia rows; point 0 carries the first tangent there, see k_setup)
 SGP_DEV void write_axis_rows(const DV& d, uint32_t slot, int point, int axis, v3 r1, v3 r2, v3 a, const sym33& I1, const sym33& I2, float w0, float w1, float w2 = 0.0f, float w3 = 0.0f)
 {
+	if (d.sp->compact_rows == 2u) return;            // (rows-free layout: the lanes rebuild everything from r1b / r2e / efft, half_load_rows)
 	const v3 c1 = v3_cross(r1, a), c2 = v3_cross(r2, a);
 	float4* p = axis_rows(d, slot, point, axis);
 	const size_t st = d.cap_manifolds;
@@ -1763,6 +1764,31 @@ template <int ROWS = -1> SGP_DEV void half_load_rows(const DV& d, uint32_t slot,
 {
 	const int np = h.np_col & 0xFF;
 	const size_t st = d.cap_manifolds;
+	if (ROWS < 0 ? d.sp->compact_rows == 2u : ROWS == 2) {
+		// no rows at all: the lever arm of this lane's body (r1 | bias, r2 | effective mass of the normal row: what the warm start reads anyway) and the
+		// friction rows' effective masses; r x axis and I (r x axis) are rebuilt here -- the expressions k_setup evaluates for the full rows on the
+		// same operands, hence the same bits.  40 bytes per point and lane where the full rows are 112: for worlds whose passes stream from HBM.
+		const sym33 I = body_world_inv_inertia(d, h.body);
+		const v3 n = V3(h.nf);
+		h.t1 = v3_normalized_perpendicular(n);
+		const v3 t2 = v3_cross(n, h.t1);
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			if (i == 0 || i < np) {
+				const float4 r4 = side ? CUR(d).r2e[i][slot] : CUR(d).r1b[i][slot];
+				const float2 et = CUR(d).efft[i][slot];
+				const v3 r = V3(r4);
+				h.c[i][0] = v3_cross(r, n); h.c[i][1] = v3_cross(r, h.t1); h.c[i][2] = v3_cross(r, t2);
+#pragma unroll
+				for (int a = 0; a < 3; ++a) h.iv[i][a] = sym33_mul(I, h.c[i][a]);
+				const float ow = lane_swap1(r4.w);
+				h.eff[i][0] = side ? r4.w : ow; h.bias[i] = side ? ow : r4.w;
+				h.eff[i][1] = et.x; h.eff[i][2] = et.y;
+				h.lam[i] = V3(CUR(d).lam[i][slot]);
+			}
+		}
+		return;
+	}
 	if (ROWS < 0 ? d.sp->compact_rows != 0u : ROWS != 0) {
 		// compact rows: r x axis only; this lane rebuilds I (r x axis) from its body's pose and inertia records -- the same function of the same
 		// operands k_setup evaluates for the full rows, hence the same bits
@@ -4631,7 +4657,11 @@ void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStr
 	if (mode != 0) blocks = (est + est / 8 + 64 + SOLVE_VEL_TPB / 2 - 1) / (SOLVE_VEL_TPB / 2);
 	if (blocks > 8192) blocks = 8192;
 	if (mode == 0) hipLaunchKernelGGL(k_solve_colour<0>, dim3(blocks), dim3(SOLVE_TPB), 0, s, d, colour);
-	else if (mode == 1) { if (compact_rows) hipLaunchKernelGGL((k_solve_colour<1, 1>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour); else hipLaunchKernelGGL((k_solve_colour<1, 0>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour); }
+	else if (mode == 1) {
+		if (compact_rows == 2) hipLaunchKernelGGL((k_solve_colour<1, 2>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour);
+		else if (compact_rows) hipLaunchKernelGGL((k_solve_colour<1, 1>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour);
+		else hipLaunchKernelGGL((k_solve_colour<1, 0>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour);
+	}
 	else hipLaunchKernelGGL(k_solve_colour<2>, dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour);
 }
 void launch_solve_colour_veh(const DV& d, int colour, uint32_t est, int mode, hipStream_t s, int compact_rows)
@@ -4639,13 +4669,21 @@ void launch_solve_colour_veh(const DV& d, int colour, uint32_t est, int mode, hi
 	uint32_t blocks = (est + est / 8 + 64 + SOLVE_VEL_TPB / 2 - 1) / (SOLVE_VEL_TPB / 2);
 	if (blocks > 8192) blocks = 8192;
 	const uint32_t vb = (d.n_vehicles * 4u + SOLVE_VEL_TPB - 1) / SOLVE_VEL_TPB;
-	if (mode == 1) { if (compact_rows) hipLaunchKernelGGL((k_solve_colour_veh<1, 1>), dim3(vb + blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour, vb); else hipLaunchKernelGGL((k_solve_colour_veh<1, 0>), dim3(vb + blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour, vb); }
+	if (mode == 1) {
+		if (compact_rows == 2) hipLaunchKernelGGL((k_solve_colour_veh<1, 2>), dim3(vb + blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour, vb);
+		else if (compact_rows) hipLaunchKernelGGL((k_solve_colour_veh<1, 1>), dim3(vb + blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour, vb);
+		else hipLaunchKernelGGL((k_solve_colour_veh<1, 0>), dim3(vb + blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour, vb);
+	}
 	else hipLaunchKernelGGL((k_solve_colour_veh<2, -1>), dim3(vb + blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour, vb);
 }
 void launch_warm_bodies(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_warm_bodies, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_solve_tail(const DV& d, int first_colour, int mode, hipStream_t s, int compact_rows)
 {
-	if (mode == 1) { if (compact_rows) hipLaunchKernelGGL(k_solve_tail_vel<1>, dim3(1), dim3(TAIL_VEL_TPB), 0, s, d, first_colour); else hipLaunchKernelGGL(k_solve_tail_vel<0>, dim3(1), dim3(TAIL_VEL_TPB), 0, s, d, first_colour); }      // (position passes of the tail: one thread per constraint measured faster, 30 against 37 us)
+	if (mode == 1) {
+		if (compact_rows == 2) hipLaunchKernelGGL(k_solve_tail_vel<2>, dim3(1), dim3(TAIL_VEL_TPB), 0, s, d, first_colour);
+		else if (compact_rows) hipLaunchKernelGGL(k_solve_tail_vel<1>, dim3(1), dim3(TAIL_VEL_TPB), 0, s, d, first_colour);
+		else hipLaunchKernelGGL(k_solve_tail_vel<0>, dim3(1), dim3(TAIL_VEL_TPB), 0, s, d, first_colour);
+	}      // (position passes of the tail: one thread per constraint measured faster, 30 against 37 us)
 	else hipLaunchKernelGGL(k_solve_tail, dim3(1), dim3(512), 0, s, d, first_colour, mode);
 }
 void launch_hc_build(const DV& d, int first_colour, uint32_t est, hipStream_t s)
@@ -4669,7 +4707,11 @@ void launch_solve_hc(const DV& d, int first_colour, uint32_t est, int mode, hipS
 {
 	// list entries: a component of n constraints takes the next power of two (< 2 n), plus the padding of the classes
 	const uint32_t blocks = std::max(1u, std::min(2048u, (2u * est + HC_CLASSES * HC_WG_PAIRS) / HC_WG_PAIRS));
-	if (mode == 1) { if (compact_rows) hipLaunchKernelGGL((k_solve_hc<1, 1>), dim3(blocks), dim3(HC_TPB), 0, s, d, first_colour); else hipLaunchKernelGGL((k_solve_hc<1, 0>), dim3(blocks), dim3(HC_TPB), 0, s, d, first_colour); }
+	if (mode == 1) {
+		if (compact_rows == 2) hipLaunchKernelGGL((k_solve_hc<1, 2>), dim3(blocks), dim3(HC_TPB), 0, s, d, first_colour);
+		else if (compact_rows) hipLaunchKernelGGL((k_solve_hc<1, 1>), dim3(blocks), dim3(HC_TPB), 0, s, d, first_colour);
+		else hipLaunchKernelGGL((k_solve_hc<1, 0>), dim3(blocks), dim3(HC_TPB), 0, s, d, first_colour);
+	}
 	else hipLaunchKernelGGL((k_solve_hc<2, -1>), dim3(blocks), dim3(HC_TPB), 0, s, d, first_colour);
 }
 void launch_solve_small(const DV& d, int warm_start, int iterations, int lane_pairs, hipStream_t s)

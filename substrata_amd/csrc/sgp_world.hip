@@ -94,6 +94,7 @@ struct sgp_world {
 	std::map<std::string, hipGraphExec_t> graphs;              // replayable launch sequences keyed by launch plan
 	std::string last_plan_key[2]; uint32_t plan_repeats[2] = { 0, 0 };   // per buffer parity: StepParams (by value in the first launch) flips parity every step
 	bool use_graphs = true; bool use_small_world = true; uint32_t tail_threshold = 256;
+	uint32_t rows_mode_large = 2;          // SGP_ROWS_MODE: the layout worlds of at least compact_rows_min constraints use -- 2 no rows (the lanes rebuild them from the lever arms), 1 compact rows (r x axis only)
 	uint32_t compact_rows_min = 1000000;   // SGP_COMPACT_ROWS_MIN: from this many contact constraints on, the velocity rows are stored compact (96 B per point)
 	int use_tile_solver = 0;            // SGP_TILE_SOLVER: 0 off, 1 on where the plan finds it applicable (k_ts_solve)
 	uint32_t ts_min_constraints = 16384;
@@ -359,6 +360,7 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	{ const char* e = getenv("SGP_TILE_SOLVER"); if (e) w->use_tile_solver = atoi(e); }
 	{ const char* e = getenv("SGP_VEHICLE_FUSED"); if (e) w->fuse_vehicle_solve = atoi(e) != 0; }
 	{ const char* e = getenv("SGP_COMPACT_ROWS_MIN"); if (e && atoll(e) >= 0) w->compact_rows_min = (uint32_t)atoll(e); }
+	{ const char* e = getenv("SGP_ROWS_MODE"); if (e && (atoi(e) == 1 || atoi(e) == 2)) w->rows_mode_large = (uint32_t)atoi(e); }
 	{ const char* e = getenv("SGP_TS_MIN_CONSTRAINTS"); if (e && atoi(e) >= 0) w->ts_min_constraints = (uint32_t)atoi(e); }
 	{ const char* e = getenv("SGP_HC_BUDGET"); if (e) { const int v = atoi(e); if (v <= 0) w->use_components = false; else w->hc_budget = (uint32_t)v; } }
 	{ int dev = 0, cus = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) w->n_cus = (uint32_t)cus; }
@@ -1188,7 +1190,7 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	const double tt0 = timing ? now() : 0.0;
 	w->h_sp->dt = dt;
-	w->h_sp->compact_rows = (w->n_con >= w->compact_rows_min && !(w->high <= SGP_SMALL_WORLD_BODIES)) ? 1u : 0u;      // (decided from the previous step's count; part of the plan's key)
+	w->h_sp->compact_rows = (w->n_con >= w->compact_rows_min && !(w->high <= SGP_SMALL_WORLD_BODIES)) ? w->rows_mode_large : 0u;      // (decided from the previous step's count; part of the plan's key)
 	StepPlan plan;
 	make_plan(w, plan);
 	const std::string key((const char*)&plan, sizeof(plan));

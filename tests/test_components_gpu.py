@@ -79,14 +79,15 @@ def test_pile_by_component_matches_oracle(oracle, budget):
 
 
 def test_compact_rows_give_the_same_bits(monkeypatch):
-    """SGP_COMPACT_ROWS_MIN: from that many constraints on the velocity rows hold only r x axis and every lane rebuilds I (r x axis) from its
-    body's records (what a million-body world does to halve the bytes it streams per pass) -- the same function of the same operands, so
-    the same bits as the full rows."""
+    """SGP_COMPACT_ROWS_MIN / SGP_ROWS_MODE: from that many constraints on the velocity iterations read no precomputed rows at all (mode 2: every
+    lane rebuilds r x axis and I (r x axis) from its body's lever arm and records) or only r x axis (mode 1) -- what a million-body world does to
+    cut the bytes it streams per pass.  The same functions of the same operands, so the same bits as the full rows."""
     from substrata_amd.lib import World
     descs = scenes.small_mixed(20, 6, seed=23)          # (more than 2048 body slots: the small-world kernels never use compact rows)
     out = []
-    for thr in ("0", "4000000000"):
+    for thr, mode in (("4000000000", "2"), ("0", "2"), ("0", "1")):
         monkeypatch.setenv("SGP_COMPACT_ROWS_MIN", thr)
+        monkeypatch.setenv("SGP_ROWS_MODE", mode)
         monkeypatch.setenv("SGP_NO_SMALL_WORLD", "1")
         w = World(max_bodies=4096)
         w.add_batch(descs)
@@ -94,4 +95,4 @@ def test_compact_rows_give_the_same_bits(monkeypatch):
             w.step(DT)
         out.append(w.read_states(0, len(descs)))
         w.close()
-    assert parity.state_diff(out[0], out[1])["bit_exact"]
+    assert parity.state_diff(out[0], out[1])["bit_exact"] and parity.state_diff(out[0], out[2])["bit_exact"]
