@@ -861,6 +861,110 @@ SGP_DEV int mesh_candidates_found(const DV& d, const MeshHeader& mh, v3 llo, v3 
 	return n;
 }
 
+// The groups of one (body X, mesh body mid) pair by the lanes of its group (whole workgroup: every lane calls this; lanes of a group pass the same
+// pair): what lies between "here is the pair" and "here are its <= 3 groups in L.mc".  valid: false for a group without a pair, and false on return
+// when the pair was handed to the wave-per-pair launch (pair = its index in mesh_pairs; G = 8 only).  [qlo, qhi]: X's bounds grown by max_sep.
+template <int MESH_GROUP> SGP_DEV void mesh_pair_groups(const DV& d, MeshPairLds<MESH_GROUP>& L, bool& valid, sgd_shape& X, uint32_t mid, v3 qlo, v3 qhi, float max_sep, int grp, int sub, uint32_t pair, bool& dropped)
+{
+	MeshHeader mh; v3 mpos = V3(0.0f, 0.0f, 0.0f); m33 R = quat_to_m33(Q4(make_float4(0.0f, 0.0f, 0.0f, 1.0f)));
+	int nc = 0;
+	if (valid) {
+		if (MESH_GROUP == 64 && X.hull) {
+			// a triangle test walks the polytope's vertices twice per candidate axis: out of LDS, not out of a pointer into global memory (worth the copy
+			// where dozens of tests follow: 2.50 -> 2.13 ms on the car-sized boxes, but 0.93 -> 1.09 ms on the small bodies of tools/experiments/mesh_terrain_bench.py)
+			const uint32_t* src = (const uint32_t*)X.hull; uint32_t* dst = (uint32_t*)&L.hull;
+			for (uint32_t i = (uint32_t)sub; i < sizeof(sgd_hull) / 4; i += MESH_GROUP) dst[i] = src[i];
+			X.hull = (const sgd_hull*)(const void*)&L.hull;
+		}
+		mh = d.meshes[(uint32_t)d.prop[2 * (size_t)mid + 1].x];
+		mpos = V3(d.pose[2 * (size_t)mid]); R = quat_to_m33(Q4(d.pose[2 * (size_t)mid + 1]));
+	}
+	// the query box in the mesh frame: bounds of the box's 8 corners, a little generous (every lane of the group: the same operands, the same box)
+	v3 llo = V3(3.4e38f, 3.4e38f, 3.4e38f), lhi = V3(-3.4e38f, -3.4e38f, -3.4e38f);
+	if (valid) {
+		for (int k = 0; k < 8; ++k) {
+			const v3 c = V3((k & 1) ? qhi.x : qlo.x, (k & 2) ? qhi.y : qlo.y, (k & 4) ? qhi.z : qlo.z);
+			const v3 l = m33_tmul(R, v3_sub(c, mpos));
+			llo = V3(fminf(llo.x, l.x), fminf(llo.y, l.y), fminf(llo.z, l.z)); lhi = V3(fmaxf(lhi.x, l.x), fmaxf(lhi.y, l.y), fmaxf(lhi.z, l.z));
+		}
+		const float pad = 1.0e-4f * (1.0f + fabsf(llo.x) + fabsf(llo.y) + fabsf(llo.z) + fabsf(lhi.x) + fabsf(lhi.y) + fabsf(lhi.z));
+		llo = v3_sub(llo, V3(pad, pad, pad)); lhi = v3_add(lhi, V3(pad, pad, pad));
+	}
+	// The candidates.  Eight lanes per pair: lane 0 walks the tree depth-first (a few dozen dependent node fetches for a small body) and gives up
+	// once it holds more than MESH_BIG_MIN -- the pair is passed on.  A wave per pair: level by level, the 64 lanes taking the nodes of a level
+	// 64 at a time (depth-first, a car-sized box on a fine mesh is a chain of hundreds of fetches); the two frontiers live in the arrays the
+	// sort uses afterwards.  The SET found is that of the depth-first walk unless a table overflows -- then the answer depends on the order of
+	// the walk, and lane 0 repeats it depth-first.
+	if (sub == 0) { L.n_front[0] = valid ? 1u : 0u; L.n_front[1] = 0u; L.n_found = 0u; L.redo = MESH_GROUP == 64 ? 0u : 1u; L.key[0] = 0u; L.mc.ng = 0; }
+	__syncthreads();
+	if (MESH_GROUP == 64) {
+		for (int level = 0; level < 64; ++level) {
+			uint32_t* cur = (level & 1) ? L.cand : L.key; uint32_t* nxt = (level & 1) ? L.key : L.cand;
+			const uint32_t ncur = L.redo ? 0u : L.n_front[level & 1];      // (a table overflowed: what the frontiers hold no longer matters)
+			if (!__any(ncur != 0u)) break;
+			for (uint32_t i = (uint32_t)sub; i < ncur; i += MESH_GROUP) {
+				const MeshNode nd = d.mesh_nodes[mh.node_off + cur[i]];
+				if (nd.mxx < llo.x || nd.mnx > lhi.x || nd.mxy < llo.y || nd.mny > lhi.y || nd.mxz < llo.z || nd.mnz > lhi.z) continue;
+				if (nd.count == 0) {
+					const uint32_t at = atomicAdd(&L.n_front[(level & 1) ^ 1], 2u);
+					if (at + 2u <= (uint32_t)MeshPairLds<MESH_GROUP>::CAP) { nxt[at] = nd.left; nxt[at + 1] = nd.right; } else L.redo = 1u;
+				} else {
+					const uint32_t at = atomicAdd(&L.n_found, nd.count);
+					if (at + nd.count <= (uint32_t)MeshPairLds<MESH_GROUP>::CAP) { for (uint32_t k = 0; k < nd.count; ++k) L.found[at + k] = nd.left + k; } else L.redo = 1u;
+				}
+			}
+			__syncthreads();
+			if (sub == 0) L.n_front[level & 1] = 0u;
+			__syncthreads();
+		}
+	}
+	if (valid && L.redo) {
+		if (sub == 0) L.n_found = (uint32_t)mesh_candidates_found(d, mh, llo, lhi, L.found, L.key, &dropped, MESH_GROUP == 64 ? MESH_BIG_CAP : MESH_BIG_MIN, MeshPairLds<MESH_GROUP>::CAP);
+	}
+	__syncthreads();
+	nc = valid ? (int)min(L.n_found, (uint32_t)MeshPairLds<MESH_GROUP>::CAP) : 0;
+	if (MESH_GROUP != 64 && nc > MESH_BIG_MIN) {
+		// too many triangles for eight lanes: the wave-per-pair launch takes the pair (and finds its candidates again)
+		if (sub == 0) d.mesh_big[atomicAdd(&d.ctr->n_mesh_big, 1u)] = pair;
+		valid = false; nc = 0; dropped = false;
+	}
+	for (int i = sub; i < nc; i += MESH_GROUP) L.key[i] = d.mesh_tris[mh.tri_off + L.found[i]].w;
+	__syncthreads();
+	// candidates in the order of the caller's triangle indices: the rank of a key is the number of smaller keys
+	for (int i = sub; i < nc; i += MESH_GROUP) {
+		const uint32_t ki = L.key[i];
+		int rank = 0;
+		for (int j = 0; j < nc; ++j) rank += L.key[j] < ki ? 1 : 0;
+		L.cand[rank] = L.found[i];
+	}
+	__syncthreads();
+	int rounds = (nc + MESH_GROUP - 1) / MESH_GROUP;
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) rounds = max(rounds, __shfl_xor(rounds, off, 64));
+	for (int rd = 0; rd < rounds; ++rd) {
+		const int k = rd * MESH_GROUP + sub;
+		bool hit = false; sgd_manifold m;
+		if (valid && k < nc) {
+			const uint4 tri = d.mesh_tris[mh.tri_off + L.cand[k]];
+			const v3 a = V3(d.mesh_verts[mh.vert_off + tri.x]), b = V3(d.mesh_verts[mh.vert_off + tri.y]), c = V3(d.mesh_verts[mh.vert_off + tri.z]);
+			const v3 wa = v3_add(mpos, m33_mul(R, a)), wb = v3_add(mpos, m33_mul(R, b)), wc = v3_add(mpos, m33_mul(R, c));
+			const v3 tmin = V3(fminf(fminf(wa.x, wb.x), wc.x), fminf(fminf(wa.y, wb.y), wc.y), fminf(fminf(wa.z, wb.z), wc.z));
+			const v3 tmax = V3(fmaxf(fmaxf(wa.x, wb.x), wc.x), fmaxf(fmaxf(wa.y, wb.y), wc.y), fmaxf(fmaxf(wa.z, wb.z), wc.z));
+			if (!(tmax.x < qlo.x || tmin.x > qhi.x || tmax.y < qlo.y || tmin.y > qhi.y || tmax.z < qlo.z || tmin.z > qhi.z)) {
+				sgd_tri_hull_t th; v3 cen, nrm;
+				sgd_tri_hull(a, b, c, &th, &cen, &nrm);
+				sgd_tri_view T; T.pos = v3_add(mpos, m33_mul(R, cen)); T.R = R; T.scale = V3(1.0f, 1.0f, 1.0f); T.h = &th;
+				hit = sgd_collide_tri(&X, &T, m33_mul(R, nrm), max_sep, &m) != 0;
+			}
+		}
+		// the hits of this round into the pair's groups, in candidate order
+		for (int t = 0; t < MESH_GROUP; ++t) {
+			if (hit && sub == t) sgd_mesh_add(&L.mc, &m);
+			__syncthreads();
+		}
+	}
+}
+
 template <int MESH_GROUP> __global__ void __launch_bounds__(64) k_narrowphase_mesh(DV d)
 {
 	constexpr int MESH_PAIRS_PER_WAVE = 64 / MESH_GROUP;
@@ -881,107 +985,13 @@ template <int MESH_GROUP> __global__ void __launch_bounds__(64) k_narrowphase_me
 			if (mesh_a && mesh_b) valid = false;
 			mid = mesh_a ? ab.x : ab.y; xid = mesh_a ? ab.y : ab.x; fx = mesh_a ? fb : fa;
 		}
-		// the pair as every lane of its group needs it: the body's shape, the mesh's pose, the query box in the world and in the mesh frame
-		sgd_shape X; MeshHeader mh; v3 mpos = V3(0.0f, 0.0f, 0.0f), qlo = mpos, qhi = mpos; m33 R = quat_to_m33(Q4(make_float4(0.0f, 0.0f, 0.0f, 1.0f)));
-		int nc = 0; bool dropped = false;
+		sgd_shape X; v3 qlo = V3(0.0f, 0.0f, 0.0f), qhi = qlo; bool dropped = false;
 		if (valid) {
 			X = load_shape(d, xid, fx);
-			if (MESH_GROUP == 64 && X.hull) {
-				// a triangle test walks the polytope's vertices twice per candidate axis: out of LDS, not out of a pointer into global memory (worth the copy
-				// where dozens of tests follow: 2.50 -> 2.13 ms on the car-sized boxes, but 0.93 -> 1.09 ms on the small bodies of tools/experiments/mesh_terrain_bench.py)
-				const uint32_t* src = (const uint32_t*)X.hull; uint32_t* dst = (uint32_t*)&L.hull;
-				for (uint32_t i = (uint32_t)sub; i < sizeof(sgd_hull) / 4; i += MESH_GROUP) dst[i] = src[i];
-				X.hull = (const sgd_hull*)(const void*)&L.hull;
-			}
-			mh = d.meshes[(uint32_t)d.prop[2 * (size_t)mid + 1].x];
-			mpos = V3(d.pose[2 * (size_t)mid]); R = quat_to_m33(Q4(d.pose[2 * (size_t)mid + 1]));
 			const v3 e = V3(max_sep, max_sep, max_sep);
 			qlo = v3_sub(V3(d.aabb_min[xid]), e); qhi = v3_add(V3(d.aabb_max[xid]), e);
 		}
-		// the query box in the mesh frame: bounds of the box's 8 corners, a little generous (every lane of the group: the same operands, the same box)
-		v3 llo = V3(3.4e38f, 3.4e38f, 3.4e38f), lhi = V3(-3.4e38f, -3.4e38f, -3.4e38f);
-		if (valid) {
-			for (int k = 0; k < 8; ++k) {
-				const v3 c = V3((k & 1) ? qhi.x : qlo.x, (k & 2) ? qhi.y : qlo.y, (k & 4) ? qhi.z : qlo.z);
-				const v3 l = m33_tmul(R, v3_sub(c, mpos));
-				llo = V3(fminf(llo.x, l.x), fminf(llo.y, l.y), fminf(llo.z, l.z)); lhi = V3(fmaxf(lhi.x, l.x), fmaxf(lhi.y, l.y), fmaxf(lhi.z, l.z));
-			}
-			const float pad = 1.0e-4f * (1.0f + fabsf(llo.x) + fabsf(llo.y) + fabsf(llo.z) + fabsf(lhi.x) + fabsf(lhi.y) + fabsf(lhi.z));
-			llo = v3_sub(llo, V3(pad, pad, pad)); lhi = v3_add(lhi, V3(pad, pad, pad));
-		}
-		// The candidates.  Eight lanes per pair: lane 0 walks the tree depth-first (a few dozen dependent node fetches for a small body) and gives up
-		// once it holds more than MESH_BIG_MIN -- the pair is passed on.  A wave per pair: level by level, the 64 lanes taking the nodes of a level
-		// 64 at a time (depth-first, a car-sized box on a fine mesh is a chain of hundreds of fetches); the two frontiers live in the arrays the
-		// sort uses afterwards.  The SET found is that of the depth-first walk unless a table overflows -- then the answer depends on the order of
-		// the walk, and lane 0 repeats it depth-first.
-		if (sub == 0) { L.n_front[0] = valid ? 1u : 0u; L.n_front[1] = 0u; L.n_found = 0u; L.redo = MESH_GROUP == 64 ? 0u : 1u; L.key[0] = 0u; L.mc.ng = 0; }
-		__syncthreads();
-		if (MESH_GROUP == 64) {
-			for (int level = 0; level < 64; ++level) {
-				uint32_t* cur = (level & 1) ? L.cand : L.key; uint32_t* nxt = (level & 1) ? L.key : L.cand;
-				const uint32_t ncur = L.redo ? 0u : L.n_front[level & 1];      // (a table overflowed: what the frontiers hold no longer matters)
-				if (!__any(ncur != 0u)) break;
-				for (uint32_t i = (uint32_t)sub; i < ncur; i += MESH_GROUP) {
-					const MeshNode nd = d.mesh_nodes[mh.node_off + cur[i]];
-					if (nd.mxx < llo.x || nd.mnx > lhi.x || nd.mxy < llo.y || nd.mny > lhi.y || nd.mxz < llo.z || nd.mnz > lhi.z) continue;
-					if (nd.count == 0) {
-						const uint32_t at = atomicAdd(&L.n_front[(level & 1) ^ 1], 2u);
-						if (at + 2u <= (uint32_t)MeshPairLds<MESH_GROUP>::CAP) { nxt[at] = nd.left; nxt[at + 1] = nd.right; } else L.redo = 1u;
-					} else {
-						const uint32_t at = atomicAdd(&L.n_found, nd.count);
-						if (at + nd.count <= (uint32_t)MeshPairLds<MESH_GROUP>::CAP) { for (uint32_t k = 0; k < nd.count; ++k) L.found[at + k] = nd.left + k; } else L.redo = 1u;
-					}
-				}
-				__syncthreads();
-				if (sub == 0) L.n_front[level & 1] = 0u;
-				__syncthreads();
-			}
-		}
-		if (valid && L.redo) {
-			if (sub == 0) L.n_found = (uint32_t)mesh_candidates_found(d, mh, llo, lhi, L.found, L.key, &dropped, MESH_GROUP == 64 ? MESH_BIG_CAP : MESH_BIG_MIN, MeshPairLds<MESH_GROUP>::CAP);
-		}
-		__syncthreads();
-		nc = valid ? (int)min(L.n_found, (uint32_t)MeshPairLds<MESH_GROUP>::CAP) : 0;
-		if (MESH_GROUP != 64 && nc > MESH_BIG_MIN) {
-			// too many triangles for eight lanes: the wave-per-pair launch takes the pair (and finds its candidates again)
-			if (sub == 0) d.mesh_big[atomicAdd(&d.ctr->n_mesh_big, 1u)] = pair;
-			valid = false; nc = 0; dropped = false;
-		}
-		for (int i = sub; i < nc; i += MESH_GROUP) L.key[i] = d.mesh_tris[mh.tri_off + L.found[i]].w;
-		__syncthreads();
-		// candidates in the order of the caller's triangle indices: the rank of a key is the number of smaller keys
-		for (int i = sub; i < nc; i += MESH_GROUP) {
-			const uint32_t ki = L.key[i];
-			int rank = 0;
-			for (int j = 0; j < nc; ++j) rank += L.key[j] < ki ? 1 : 0;
-			L.cand[rank] = L.found[i];
-		}
-		__syncthreads();
-		int rounds = (nc + MESH_GROUP - 1) / MESH_GROUP;
-#pragma unroll
-		for (int off = 32; off >= 1; off >>= 1) rounds = max(rounds, __shfl_xor(rounds, off, 64));
-		for (int rd = 0; rd < rounds; ++rd) {
-			const int k = rd * MESH_GROUP + sub;
-			bool hit = false; sgd_manifold m;
-			if (valid && k < nc) {
-				const uint4 tri = d.mesh_tris[mh.tri_off + L.cand[k]];
-				const v3 a = V3(d.mesh_verts[mh.vert_off + tri.x]), b = V3(d.mesh_verts[mh.vert_off + tri.y]), c = V3(d.mesh_verts[mh.vert_off + tri.z]);
-				const v3 wa = v3_add(mpos, m33_mul(R, a)), wb = v3_add(mpos, m33_mul(R, b)), wc = v3_add(mpos, m33_mul(R, c));
-				const v3 tmin = V3(fminf(fminf(wa.x, wb.x), wc.x), fminf(fminf(wa.y, wb.y), wc.y), fminf(fminf(wa.z, wb.z), wc.z));
-				const v3 tmax = V3(fmaxf(fmaxf(wa.x, wb.x), wc.x), fmaxf(fmaxf(wa.y, wb.y), wc.y), fmaxf(fmaxf(wa.z, wb.z), wc.z));
-				if (!(tmax.x < qlo.x || tmin.x > qhi.x || tmax.y < qlo.y || tmin.y > qhi.y || tmax.z < qlo.z || tmin.z > qhi.z)) {
-					sgd_tri_hull_t th; v3 cen, nrm;
-					sgd_tri_hull(a, b, c, &th, &cen, &nrm);
-					sgd_tri_view T; T.pos = v3_add(mpos, m33_mul(R, cen)); T.R = R; T.scale = V3(1.0f, 1.0f, 1.0f); T.h = &th;
-					hit = sgd_collide_tri(&X, &T, m33_mul(R, nrm), max_sep, &m) != 0;
-				}
-			}
-			// the hits of this round into the pair's groups, in candidate order
-			for (int t = 0; t < MESH_GROUP; ++t) {
-				if (hit && sub == t) sgd_mesh_add(&L.mc, &m);
-				__syncthreads();
-			}
-		}
+		mesh_pair_groups<MESH_GROUP>(d, L, valid, X, mid, qlo, qhi, max_sep, grp, sub, pair, dropped);
 		// the groups as manifolds (mesh -> body), each pruned to <= 4 points; the constraint runs lower id -> higher id, with the mesh's g-th slot
 		const int ng = valid ? L.mc.ng : 0;
 		if (sub < ng) {
@@ -3926,20 +3936,9 @@ template <int MODE, int ROWS = -1> __global__ void __launch_bounds__(SOLVE_VEL_T
 // ---------------------------------------------------------------------------------------------------------------
 // Shape queries of the character controller (JPH::CharacterVirtual: CollideShape with a maximum separation, swept test).
 
-SGP_DEV void capsule_query_body(const DV& d, const sgp_capsule_query& q, uint32_t k, const sgd_shape& sc, v3 lo, v3 hi, uint32_t j, sgp_query_contact* out, uint32_t cap, uint32_t* count)
+// the points of one manifold (normal: body -> capsule) as contacts of query k with body j
+SGP_DEV void capsule_emit(const DV& d, uint32_t k, uint32_t j, uint32_t f, int g, const sgd_manifold& m, sgp_query_contact* out, uint32_t cap, uint32_t* count)
 {
-	if (j == q.ignore_id) return;
-	const uint32_t f = d.flags[j];
-	if (!(f & BF_ALIVE) || (f & BF_ALIAS)) return;
-	const uint32_t layer = f_layer(f);
-	if (q.collidable_only && !(layer == SGP_LAYER_NON_MOVING || layer == SGP_LAYER_MOVING)) return;
-	const float4 mn = d.aabb_min[j], mx = d.aabb_max[j];
-	if (mx.x < lo.x || mn.x > hi.x || mx.y < lo.y || mn.y > hi.y || mx.z < lo.z || mn.z > hi.z) return;
-	const sgd_shape sb = load_shape(d, j, f);
-	sgd_manifold mm[SGD_MESH_MAX_GROUPS]; int ng; bool dropped = false;
-	if (sb.type == SGP_SHAPE_MESH) ng = collide_with_mesh(d, j, sc, lo, hi, q.max_separation, mm, &dropped);
-	else ng = (sb.type == SGP_SHAPE_HULL ? sgd_collide_hull(&sb, &sc, q.max_separation, &mm[0]) : sgd_collide(&sb, &sc, q.max_separation, &mm[0])) ? 1 : 0;   // normal: body -> capsule
-	for (int g = 0; g < ng; ++g) { const sgd_manifold& m = mm[g];
 	for (int i = 0; i < m.np; ++i) {
 		const uint32_t slot = atomicAdd(count, 1u);
 		if (slot >= cap) continue;
@@ -3954,14 +3953,42 @@ SGP_DEV void capsule_query_body(const DV& d, const sgp_capsule_query& q, uint32_
 		c.motion_type = f_motion(f); c.is_sensor = (f & BF_SENSOR) ? 1u : 0u; c.inv_mass = d.pose[2 * (size_t)j].w; c.userdata = 0;
 		out[slot] = c;
 	}
-	}
 }
 
-// one thread per query capsule: large bodies directly, the rest through the broad-phase cells its bounds reach
+// One candidate body of a query, by one lane: the filters, then the collision test -- except for mesh bodies, which go on the wave's list (their
+// triangles are the whole wave's work).
+#define QUERY_MESH_LIST 32
+SGP_DEV void capsule_query_body(const DV& d, const sgp_capsule_query& q, uint32_t k, const sgd_shape& sc, v3 lo, v3 hi, uint32_t j, sgp_query_contact* out, uint32_t cap, uint32_t* count, uint32_t* mesh_list, uint32_t* n_mesh)
+{
+	if (j == q.ignore_id) return;
+	const uint32_t f = d.flags[j];
+	if (!(f & BF_ALIVE) || (f & BF_ALIAS)) return;
+	const uint32_t layer = f_layer(f);
+	if (q.collidable_only && !(layer == SGP_LAYER_NON_MOVING || layer == SGP_LAYER_MOVING)) return;
+	const float4 mn = d.aabb_min[j], mx = d.aabb_max[j];
+	if (mx.x < lo.x || mn.x > hi.x || mx.y < lo.y || mn.y > hi.y || mx.z < lo.z || mn.z > hi.z) return;
+	const sgd_shape sb = load_shape(d, j, f);
+	sgd_manifold mm[SGD_MESH_MAX_GROUPS]; int ng; bool dropped = false;
+	if (sb.type == SGP_SHAPE_MESH) {
+		const uint32_t at = atomicAdd(n_mesh, 1u);
+		if (at < QUERY_MESH_LIST) { mesh_list[at] = j; return; }
+		ng = collide_with_mesh(d, j, sc, lo, hi, q.max_separation, mm, &dropped);      // (more meshes around one capsule than the list holds: this lane walks the rest)
+	}
+	else ng = (sb.type == SGP_SHAPE_HULL ? sgd_collide_hull(&sb, &sc, q.max_separation, &mm[0]) : sgd_collide(&sb, &sc, q.max_separation, &mm[0])) ? 1 : 0;   // normal: body -> capsule
+	for (int g = 0; g < ng; ++g) capsule_emit(d, k, j, f, g, mm[g], out, cap, count);
+}
+
+// ONE WAVE PER QUERY CAPSULE (the character controller asks for one or a few per update, and waits for the answer): the candidate bodies -- the
+// large ones, and those of the broad-phase cells its bounds reach -- dealt to the 64 lanes; the mesh bodies among them (a player stands on one and
+// next to others all the time) are then taken one after the other by the whole wave, 64 candidate triangles per round (mesh_pair_groups).
 __global__ void __launch_bounds__(64) k_collide_capsules(DV d, const sgp_capsule_query* qs, uint32_t n, sgp_query_contact* out, uint32_t cap, uint32_t* count)
 {
-	const uint32_t k = blockIdx.x * 64 + threadIdx.x;
+	__shared__ MeshPairLds<64> L;
+	__shared__ uint32_t mesh_list[QUERY_MESH_LIST];
+	__shared__ uint32_t n_mesh;
+	const uint32_t k = blockIdx.x;
 	if (k >= n) return;
+	const uint32_t lane = threadIdx.x;
 	const sgp_capsule_query q = qs[k];
 	sgd_shape sc;
 	sc.pos = V3(q.pos[0], q.pos[1], q.pos[2]);
@@ -3971,7 +3998,9 @@ __global__ void __launch_bounds__(64) k_collide_capsules(DV d, const sgp_capsule
 	const float e = q.radius + q.max_separation;
 	const v3 ext = V3(fabsf(ax.x) + e, fabsf(ax.y) + e, fabsf(ax.z) + e);
 	const v3 lo = v3_sub(sc.pos, ext), hi = v3_add(sc.pos, ext);
-	for (uint32_t l = 0; l < d.sp->n_large; ++l) capsule_query_body(d, q, k, sc, lo, hi, d.large_ids[l], out, cap, count);
+	if (lane == 0) n_mesh = 0;
+	__syncthreads();
+	for (uint32_t l = lane; l < d.sp->n_large; l += 64) capsule_query_body(d, q, k, sc, lo, hi, d.large_ids[l], out, cap, count, mesh_list, &n_mesh);
 	const BpGrid g = *d.grid;
 	if (g.n_cells > 0 && g.min_x <= g.max_x) {
 		const int x0 = max((int)floorf((lo.x - g.ox) * g.inv_cell) - 1, 0), x1 = min((int)floorf((hi.x - g.ox) * g.inv_cell) + 1, g.nx - 1);
@@ -3980,8 +4009,24 @@ __global__ void __launch_bounds__(64) k_collide_capsules(DV d, const sgp_capsule
 		if (x0 <= x1) for (int z = z0; z <= z1; ++z) for (int y = y0; y <= y1; ++y) {
 			const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
 			const uint32_t c0 = d.cell_start[row + (uint32_t)x0], c1 = d.cell_start[row + (uint32_t)x1 + 1];
-			for (uint32_t c = c0; c < c1; ++c) capsule_query_body(d, q, k, sc, lo, hi, __float_as_uint(d.sorted_max[c].w), out, cap, count);
+			for (uint32_t c = c0 + lane; c < c1; c += 64) capsule_query_body(d, q, k, sc, lo, hi, __float_as_uint(d.sorted_max[c].w), out, cap, count, mesh_list, &n_mesh);
 		}
+	}
+	__syncthreads();
+	const uint32_t nm = min(n_mesh, (uint32_t)QUERY_MESH_LIST);
+	const v3 es = V3(q.max_separation, q.max_separation, q.max_separation);
+	for (uint32_t mi = 0; mi < nm; ++mi) {
+		const uint32_t mid = mesh_list[mi];
+		bool valid = true, dropped = false;
+		sgd_shape X = sc;
+		mesh_pair_groups<64>(d, L, valid, X, mid, v3_sub(lo, es), v3_add(hi, es), q.max_separation, 0, (int)lane, 0u, dropped);
+		if ((int)lane < L.mc.ng) {
+			const sgd_mesh_group& grp = L.mc.g[lane];
+			sgd_manifold mm;
+			sgd_hull_reduce(grp.n, grp.p_mesh, grp.p_body, grp.np, &mm);
+			capsule_emit(d, k, mid, d.flags[mid], (int)lane, mm, out, cap, count);
+		}
+		__syncthreads();
 	}
 }
 
@@ -4752,7 +4797,7 @@ void launch_vehicle_solve(const DV& d, int mode, hipStream_t s)
 	else hipLaunchKernelGGL(k_vehicle_solve<2>, g, b, 0, s, d);
 }
 void launch_raycast(const DV& d, const sgp_ray* rays, uint32_t n, sgp_hit* hits, hipStream_t s) { if (n) hipLaunchKernelGGL(k_raycast, dim3((n + 63) / 64), dim3(64), 0, s, d, rays, n, hits); }
-void launch_collide_capsules(const DV& d, const sgp_capsule_query* q, uint32_t n, sgp_query_contact* out, uint32_t cap, uint32_t* count, hipStream_t s) { if (n) hipLaunchKernelGGL(k_collide_capsules, dim3((n + 63) / 64), dim3(64), 0, s, d, q, n, out, cap, count); }
+void launch_collide_capsules(const DV& d, const sgp_capsule_query* q, uint32_t n, sgp_query_contact* out, uint32_t cap, uint32_t* count, hipStream_t s) { if (n) hipLaunchKernelGGL(k_collide_capsules, dim3(n), dim3(64), 0, s, d, q, n, out, cap, count); }      // a wave per query
 void launch_spherecast(const DV& d, const sgp_ray* rays, const float* radii, uint32_t n, sgp_hit* hits, hipStream_t s) { if (n) hipLaunchKernelGGL(k_spherecast, dim3((n + 63) / 64), dim3(64), 0, s, d, rays, radii, n, hits); }
 void launch_route_export(const DV& d, uint32_t nb, const TileRoute& t, uint32_t* block_counts, uint32_t* block_offsets, RouteHeader* header,
                          sgp_ghost_record* out, uint32_t cap, uint32_t* emigrant_ids, uint32_t emigrant_cap, hipStream_t s)
