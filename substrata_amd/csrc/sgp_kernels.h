@@ -60,6 +60,13 @@ struct MeshHeader { uint32_t vert_off, nv, tri_off, nt, node_off, n_nodes; float
 // [left, left + count) of the mesh's tree-ordered triangle array (uint4.w of a triangle = its index in the caller's order).
 struct MeshNode { float mnx, mny, mnz; uint32_t left; float mxx, mxy, mxz; uint32_t right; uint32_t count; uint32_t pad[3]; };
 
+// Static large bodies (every static mesh, every static body beyond the broad phase's large-body radius: the buildings of a parcel grid) in a uniform
+// grid of their own, built by the host whenever that set changes (rebuild_large_grid): a body sits in every cell its bounds overlap.  What stays
+// on the linear large-body list are the moving large bodies and the static ones that would fill too many cells (the ground quad, a terrain).
+#define SGP_LG_MAX_CELLS 262144
+#define SGP_LG_MAX_SPAN 256        // cells one body may fill
+struct LargeGrid { float ox, oy, oz, cell, inv_cell; int nx, ny, nz; uint32_t n_items; uint32_t pad[3]; };
+
 // Device-side counters of one step (read back once per step).
 struct StepCounters {
 	uint32_t n_pairs;
@@ -269,6 +276,7 @@ struct DV {
 	// static triangle meshes: headers + pooled vertices / triangles / tree nodes (mesh frame = body frame)
 	const struct MeshHeader* meshes; uint32_t n_meshes;
 	const float4* mesh_verts; const uint4* mesh_tris; const uint32_t* mesh_tri_mat; const struct MeshNode* mesh_nodes;     // mesh_tri_mat: user data (material index) per tree-ordered triangle
+	const LargeGrid* lgrid; const uint32_t* lg_start; const uint32_t* lg_items;      // the static large bodies' grid (cell c: items [lg_start[c], lg_start[c + 1]))
 	uint2* mesh_pairs; uint32_t cap_mesh_pairs; uint32_t* mesh_big;      // mesh_big: indices into mesh_pairs
 	// wheeled vehicles (sgp_device_vehicle.h): AoS, one record per vehicle slot
 	struct sgd_vehicle* vehicles; uint32_t n_vehicles; const sgp_vehicle_input* vehicle_inputs;
@@ -328,6 +336,7 @@ void launch_cache_build(const DV& d, uint32_t n_con, hipStream_t s);
 void launch_contact_events(const DV& d, uint32_t n_man, hipStream_t s);
 void launch_ghost_refresh(const DV& d, const GhostRefresh* recs, uint32_t n, hipStream_t s);
 void launch_apply_cmds(const DV& d, const BodyCmd* cmds, const uint32_t* run_start, uint32_t n_runs, hipStream_t s);
+void launch_gather_aabbs(const DV& d, const uint32_t* ids, uint32_t n, float4* out, hipStream_t s);      // out[2 k], out[2 k + 1] = bounds of body ids[k]
 void launch_gather_states(const DV& d, const uint32_t* ids, uint32_t first, uint32_t n, sgp_body_state* out, hipStream_t s);
 void launch_gather_active(const DV& d, uint32_t nb, sgp_body_state* out, uint32_t cap, hipStream_t s);
 void launch_gather_active_poses(const DV& d, uint32_t nb, void* out, uint32_t cap, hipStream_t s);      // sgp_body_pose records (32 B)

@@ -577,6 +577,77 @@ template <int BP_LDS_CAP, int BP_PAIR_CAP> __global__ void __launch_bounds__(TPB
 	flush_pairs<BP_PAIR_CAP>(d, spairs, scls, lcount, &gbase, pbins);
 }
 
+// ---- the static large bodies' grid (LargeGrid) ---------------------------------------------------------------------------------
+// cell coordinate of x, clamped into the grid (the host sorts the bodies into cells with this very expression on the bounds it read back)
+SGP_DEV int lg_cell(float x, float o, float inv, int n) { return min(max((int)floorf((x - o) * inv), 0), n - 1); }
+// fn(body) for every body of the grid whose cells the box [lo, hi] touches -- each body ONCE: a body sits in several cells, and it is reported from
+// the one that holds the lower corner of (box intersected with the body's bounds), a cell both ranges contain whenever the two overlap.
+template <class F> SGP_DEV void large_grid_query(const DV& d, v3 lo, v3 hi, F fn)
+{
+	const LargeGrid g = *d.lgrid;
+	if (!g.n_items) return;
+	const int x0 = lg_cell(lo.x, g.ox, g.inv_cell, g.nx), x1 = lg_cell(hi.x, g.ox, g.inv_cell, g.nx);
+	const int y0 = lg_cell(lo.y, g.oy, g.inv_cell, g.ny), y1 = lg_cell(hi.y, g.oy, g.inv_cell, g.ny);
+	const int z0 = lg_cell(lo.z, g.oz, g.inv_cell, g.nz), z1 = lg_cell(hi.z, g.oz, g.inv_cell, g.nz);
+	for (int z = z0; z <= z1; ++z) for (int y = y0; y <= y1; ++y) for (int x = x0; x <= x1; ++x) {
+		const uint32_t c = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx + (uint32_t)x;
+		const uint32_t q0 = d.lg_start[c], q1 = d.lg_start[c + 1];
+		for (uint32_t q = q0; q < q1; ++q) {
+			const uint32_t b = d.lg_items[q];
+			const float4 mn = d.aabb_min[b];
+			if (lg_cell(fmaxf(lo.x, mn.x), g.ox, g.inv_cell, g.nx) != x || lg_cell(fmaxf(lo.y, mn.y), g.oy, g.inv_cell, g.ny) != y || lg_cell(fmaxf(lo.z, mn.z), g.oz, g.inv_cell, g.nz) != z) continue;
+			fn(b);
+		}
+	}
+}
+// fn(body) for the bodies of the cells a ray (origin o, unit direction dir) crosses up to *max_t (which fn may shorten); a body may come more than once
+template <class F> SGP_DEV void large_grid_ray(const DV& d, v3 o, v3 dir, const float* max_t, F fn)
+{
+	const LargeGrid g = *d.lgrid;
+	if (!g.n_items) return;
+	const float c = g.cell;
+	const float oo[3] = { o.x, o.y, o.z }, dd[3] = { dir.x, dir.y, dir.z };
+	const float bl[3] = { g.ox, g.oy, g.oz }, bh[3] = { g.ox + (float)g.nx * c, g.oy + (float)g.ny * c, g.oz + (float)g.nz * c };
+	float t0 = 0.0f, t1 = *max_t;
+	for (int a = 0; a < 3; ++a) {
+		if (fabsf(dd[a]) < 1.0e-12f) { if (oo[a] < bl[a] - c || oo[a] > bh[a] + c) return; }
+		else {
+			float ta = (bl[a] - c - oo[a]) / dd[a], tb = (bh[a] + c - oo[a]) / dd[a];      // (one cell of slack: bounds outside the grid box sit in its border cells)
+			if (ta > tb) { const float tmp = ta; ta = tb; tb = tmp; }
+			t0 = fmaxf(t0, ta); t1 = fminf(t1, tb);
+			if (t0 > t1) return;
+		}
+	}
+	const v3 p0 = v3_add(o, v3_scale(dir, t0));
+	int cx = (int)floorf((p0.x - g.ox) * g.inv_cell), cy = (int)floorf((p0.y - g.oy) * g.inv_cell), cz = (int)floorf((p0.z - g.oz) * g.inv_cell);
+	cx = min(max(cx, -1), g.nx); cy = min(max(cy, -1), g.ny); cz = min(max(cz, -1), g.nz);
+	const int sx = dir.x > 0.0f ? 1 : -1, sy = dir.y > 0.0f ? 1 : -1, sz = dir.z > 0.0f ? 1 : -1;
+	const float inf = 3.0e38f;
+	const float tdx = fabsf(dir.x) > 1.0e-12f ? c / fabsf(dir.x) : inf, tdy = fabsf(dir.y) > 1.0e-12f ? c / fabsf(dir.y) : inf, tdz = fabsf(dir.z) > 1.0e-12f ? c / fabsf(dir.z) : inf;
+	float tmx = fabsf(dir.x) > 1.0e-12f ? ((g.ox + (float)(cx + (sx > 0 ? 1 : 0)) * c) - o.x) / dir.x : inf;
+	float tmy = fabsf(dir.y) > 1.0e-12f ? ((g.oy + (float)(cy + (sy > 0 ? 1 : 0)) * c) - o.y) / dir.y : inf;
+	float tmz = fabsf(dir.z) > 1.0e-12f ? ((g.oz + (float)(cz + (sz > 0 ? 1 : 0)) * c) - o.z) / dir.z : inf;
+	float t_enter = t0;
+	for (int iter = 0; iter < 100000; ++iter) {
+		if (t_enter - c > *max_t) break;
+		// (the cell and, against rounding at cell faces, nothing else: a body is in every cell its bounds touch; cells one step outside the box are its border cells)
+		const int x = min(max(cx, 0), g.nx - 1), y = min(max(cy, 0), g.ny - 1), z = min(max(cz, 0), g.nz - 1);
+		const uint32_t cell = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx + (uint32_t)x;
+		const uint32_t q0 = d.lg_start[cell], q1 = d.lg_start[cell + 1];
+		for (uint32_t q = q0; q < q1; ++q) fn(d.lg_items[q]);
+		if (tmx <= tmy && tmx <= tmz) { t_enter = tmx; tmx += tdx; cx += sx; if (cx < -1 || cx > g.nx) break; }
+		else if (tmy <= tmz) { t_enter = tmy; tmy += tdy; cy += sy; if (cy < -1 || cy > g.ny) break; }
+		else { t_enter = tmz; tmz += tdz; cz += sz; if (cz < -1 || cz > g.nz) break; }
+		if (t_enter > t1) break;
+	}
+}
+__global__ void __launch_bounds__(TPB) k_gather_aabbs(DV d, const uint32_t* ids, uint32_t n, float4* out)
+{
+	const uint32_t k = blockIdx.x * TPB + threadIdx.x;
+	if (k >= n) return;
+	out[2 * (size_t)k] = d.aabb_min[ids[k]]; out[2 * (size_t)k + 1] = d.aabb_max[ids[k]];
+}
+
 // large bodies (ground quad, PhysicsWorld.cpp:1123) against every body
 SGP_DEV uint32_t block_alloc(uint32_t* counter, bool want);
 __global__ void __launch_bounds__(TPB) k_bp_large(DV d)
@@ -597,6 +668,15 @@ __global__ void __launch_bounds__(TPB) k_bp_large(DV d)
 		// the ground quad alone pairs with every body: one atomic per workgroup on the pair counter, not one per wave
 		const uint32_t k = block_alloc(&d.ctr->n_pairs, pair);
 		if (pair) { if (k < d.cap_pairs) d.pairs[k] = make_uint2(i < j ? i : j, i < j ? j : i); else atomicAdd(&d.ctr->pairs_dropped, 1u); }
+	}
+	// the static large bodies in reach of an awake body: through their grid (a static body pairs with nothing that sleeps)
+	if (live_j && f_active_for_pairs(fj)) {
+		const float s = d.st.speculative_contact_distance;
+		large_grid_query(d, V3(mnj.x - s, mnj.y - s, mnj.z - s), V3(mxj.x + s, mxj.y + s, mxj.z + s), [&](uint32_t i) {
+			if (i == j || !pair_passes(d, fj, mnj, mxj, i)) return;
+			const uint32_t k = atomicAdd(&d.ctr->n_pairs, 1u);
+			if (k < d.cap_pairs) d.pairs[k] = make_uint2(i < j ? i : j, i < j ? j : i); else atomicAdd(&d.ctr->pairs_dropped, 1u);
+		});
 	}
 }
 
@@ -3438,6 +3518,7 @@ __global__ void __launch_bounds__(64) k_raycast(DV d, const sgp_ray* rays, uint3
 	RayBest best; best.t = ry.max_t; best.id = SGP_INVALID_ID; best.n = V3(0.0f, 0.0f, 0.0f);
 	best.sub.tri = SGP_INVALID_ID; best.sub.mat = 0; best.sub.u = best.sub.v = 0.0f;
 	for (uint32_t l = 0; l < d.sp->n_large; ++l) ray_test_body(d, ry, o, dir, d.large_ids[l], best);
+	large_grid_ray(d, o, dir, &best.t, [&](uint32_t i) { ray_test_body(d, ry, o, dir, i, best); });
 	const BpGrid g = *d.grid;
 	if (g.n_cells > 0 && g.min_x <= g.max_x) {
 		// clip the ray to the grid box inflated by one cell (bodies reach one cell beyond their centre cell)
@@ -3616,6 +3697,14 @@ __global__ void __launch_bounds__(64) k_vehicle_cast(DV d)
 			const float rs = sv.cast_radius;
 			best = wh->cast_len;
 			for (uint32_t l = sub; l < d.sp->n_large; l += 16) veh_cast_test(d, &sv, o, dir, rs, wh->cast_len, d.large_ids[l], best, bid, bn, bp);
+			{
+				// static large bodies under the swept sphere's bounds, dealt to the wheel's 16 lanes in the order the grid yields them
+				const v3 e2 = v3_add(o, v3_scale(dir, wh->cast_len));
+				const float m2 = rs + 2.0e-3f;
+				uint32_t seen = 0;
+				large_grid_query(d, V3(fminf(o.x, e2.x) - m2, fminf(o.y, e2.y) - m2, fminf(o.z, e2.z) - m2), V3(fmaxf(o.x, e2.x) + m2, fmaxf(o.y, e2.y) + m2, fmaxf(o.z, e2.z) + m2),
+				                 [&](uint32_t i) { if ((seen++ & 15u) == sub) veh_cast_test(d, &sv, o, dir, rs, wh->cast_len, i, best, bid, bn, bp); });
+			}
 			const BpGrid g = *d.grid;
 			if (g.n_cells > 0 && g.min_x <= g.max_x) {
 				// cells overlapped by the swept sphere's box, one more cell each side (bodies are binned by centre and reach at most one cell beyond it)
@@ -4001,6 +4090,10 @@ __global__ void __launch_bounds__(64) k_collide_capsules(DV d, const sgp_capsule
 	if (lane == 0) n_mesh = 0;
 	__syncthreads();
 	for (uint32_t l = lane; l < d.sp->n_large; l += 64) capsule_query_body(d, q, k, sc, lo, hi, d.large_ids[l], out, cap, count, mesh_list, &n_mesh);
+	{
+		uint32_t seen = 0;      // static large bodies around the capsule, dealt to the lanes in the order the grid yields them
+		large_grid_query(d, lo, hi, [&](uint32_t i) { if ((seen++ & 63u) == lane) capsule_query_body(d, q, k, sc, lo, hi, i, out, cap, count, mesh_list, &n_mesh); });
+	}
 	const BpGrid g = *d.grid;
 	if (g.n_cells > 0 && g.min_x <= g.max_x) {
 		const int x0 = max((int)floorf((lo.x - g.ox) * g.inv_cell) - 1, 0), x1 = min((int)floorf((hi.x - g.ox) * g.inv_cell) + 1, g.nx - 1);
@@ -4058,6 +4151,13 @@ __global__ void __launch_bounds__(64) k_spherecast(DV d, const sgp_ray* rays, co
 	const v3 o = V3(ry.origin[0], ry.origin[1], ry.origin[2]), dir = V3(ry.dir[0], ry.dir[1], ry.dir[2]);
 	RayBest best; best.t = ry.max_t; best.id = SGP_INVALID_ID; best.n = V3(0.0f, 0.0f, 0.0f);
 	for (uint32_t l = 0; l < d.sp->n_large; ++l) spherecast_body(d, ry, rs, o, dir, d.large_ids[l], best);
+	{
+		// the static large bodies under the swept sphere's bounds (casts are short)
+		const v3 e = v3_add(o, v3_scale(dir, ry.max_t));
+		const float m = rs + 2.0e-3f;
+		large_grid_query(d, V3(fminf(o.x, e.x) - m, fminf(o.y, e.y) - m, fminf(o.z, e.z) - m), V3(fmaxf(o.x, e.x) + m, fmaxf(o.y, e.y) + m, fmaxf(o.z, e.z) + m),
+		                 [&](uint32_t i) { spherecast_body(d, ry, rs, o, dir, i, best); });
+	}
 	const BpGrid g = *d.grid;
 	if (g.n_cells > 0 && g.min_x <= g.max_x) {
 		const v3 e = v3_add(o, v3_scale(dir, ry.max_t));
@@ -4779,6 +4879,7 @@ void launch_cache_build(const DV& d, uint32_t n_con, hipStream_t s)
 void launch_contact_events(const DV& d, uint32_t est, hipStream_t s) { hipLaunchKernelGGL(k_contact_events, dim3(stride_grid(est)), dim3(TPB), 0, s, d); }
 void launch_ghost_refresh(const DV& d, const GhostRefresh* recs, uint32_t n, hipStream_t s) { if (n) hipLaunchKernelGGL(k_ghost_refresh, dim3(blocks_for(n)), dim3(TPB), 0, s, d, recs, n); }
 void launch_apply_cmds(const DV& d, const BodyCmd* cmds, const uint32_t* run_start, uint32_t n_runs, hipStream_t s) { if (n_runs) hipLaunchKernelGGL(k_apply_cmds, dim3(blocks_for(n_runs)), dim3(TPB), 0, s, d, cmds, run_start, n_runs); }
+void launch_gather_aabbs(const DV& d, const uint32_t* ids, uint32_t n, float4* out, hipStream_t s) { if (n) hipLaunchKernelGGL(k_gather_aabbs, dim3(blocks_for(n)), dim3(TPB), 0, s, d, ids, n, out); }
 void launch_gather_states(const DV& d, const uint32_t* ids, uint32_t first, uint32_t n, sgp_body_state* out, hipStream_t s) { if (n) hipLaunchKernelGGL(k_gather_states, dim3(blocks_for(n)), dim3(TPB), 0, s, d, ids, first, n, out); }
 void launch_gather_active_poses(const DV& d, uint32_t nb, void* out, uint32_t cap, hipStream_t s) { hipLaunchKernelGGL(k_gather_active_poses, dim3(blocks_for(nb)), dim3(TPB), 0, s, d, (float4*)out, cap); }
 void launch_gather_active(const DV& d, uint32_t nb, sgp_body_state* out, uint32_t cap, hipStream_t s) { hipLaunchKernelGGL(k_gather_active, dim3(blocks_for(nb)), dim3(TPB), 0, s, d, out, cap); }

@@ -71,7 +71,11 @@ struct sgp_world {
 	std::vector<HostBody> hb;
 	std::vector<uint32_t> free_list;
 	uint32_t high = 0, n_alive = 0;
-	std::vector<uint32_t> large_ids; bool large_dirty = false;
+	std::vector<uint32_t> large_ids; bool large_dirty = false;      // every large body (host order)
+	// what the device sees of them: the static ones in a grid of their own (LargeGrid, rebuilt when the set or a pose in it changes), the rest --
+	// moving large bodies, static ones that would fill too many cells -- on the linear list the kernels walk
+	std::vector<uint32_t> large_linear;
+	LargeGrid* d_lgrid = nullptr; uint32_t* d_lg_start = nullptr; uint32_t* d_lg_items = nullptr; uint32_t cap_lg_items = 0; uint32_t lg_static = 0;
 	uint32_t* d_large = nullptr; uint32_t cap_large = 0;
 	float max_small_radius = 0.0f;
 	uint32_t last_export = 0;                              // records the previous sgp_world_export_boundary produced
@@ -300,6 +304,9 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	DEV_ALLOC(d.cell_hash, N);
 	DEV_ALLOC(d.cell_count, d.table_size + 4); DEV_ALLOC(d.cell_start, d.table_size + 4); DEV_ALLOC(d.cell_fill, d.table_size + 4);
 	DEV_ALLOC(w->d_large, N); w->cap_large = N; d.large_ids = w->d_large;
+	DEV_ALLOC(w->d_lgrid, 1); DEV_ALLOC(w->d_lg_start, SGP_LG_MAX_CELLS + 1); w->cap_lg_items = 4096; DEV_ALLOC(w->d_lg_items, w->cap_lg_items);
+	HIP_TRY(hipMemset(w->d_lgrid, 0, sizeof(LargeGrid)));
+	d.lgrid = w->d_lgrid; d.lg_start = w->d_lg_start; d.lg_items = w->d_lg_items;
 	{ void* q = nullptr; w->cap_mesh_table = 256; HIP_TRY(hipMalloc(&q, sizeof(MeshHeader) * w->cap_mesh_table)); HIP_TRY(hipMemsetAsync(q, 0, sizeof(MeshHeader) * w->cap_mesh_table, w->stream)); w->d_meshes = (MeshHeader*)q; w->device_bytes += sizeof(MeshHeader) * w->cap_mesh_table; }
 	d.meshes = w->d_meshes; d.n_meshes = 1; w->meshes.push_back(MeshHeader{}); w->mesh_refs.push_back(0);
 	d.cap_mesh_pairs = P / 4 + 1024; DEV_ALLOC(d.mesh_pairs, d.cap_mesh_pairs); DEV_ALLOC(d.mesh_big, d.cap_mesh_pairs);
@@ -832,24 +839,107 @@ static int upload_sp(sgp_world* w)
 {
 	StepParams& sp = *w->h_sp;
 	sp.n_slots = w->high;
-	sp.n_large = (uint32_t)w->large_ids.size();
+	sp.n_large = (uint32_t)w->large_linear.size();
 	sp.bp_rmax = std::max(0.25f, w->max_small_radius);
 	sp.cell_size = sp.bp_rmax + w->dv.st.speculative_contact_distance;
 	launch_set_params(w->dv, *w->h_sp, w->stream);
 	return SGP_OK;
 }
 
+static void invalidate_graphs(sgp_world* w);
+// The device's view of the large bodies after the pending edits have been applied (their bounds are read back from the device, which computed
+// them): static ones into the grid, the rest on the linear list.  Runs only when the set changed or a static large body moved.
+static int rebuild_large_grid(sgp_world* w)
+{
+	if (!w->large_dirty) return SGP_OK;
+	w->large_dirty = false;
+	DV& d = w->dv;
+	std::vector<uint32_t> stat;
+	w->large_linear.clear();
+	for (uint32_t id : w->large_ids) { if ((w->hb[id].flags & BF_MOTION_MASK) == SGP_MOTION_STATIC) stat.push_back(id); else w->large_linear.push_back(id); }
+	LargeGrid g; memset(&g, 0, sizeof(g)); g.cell = 1.0f; g.inv_cell = 1.0f; g.nx = g.ny = g.nz = 1;
+	std::vector<uint32_t> start, items;
+	if (stat.size() < 32) { w->large_linear.insert(w->large_linear.end(), stat.begin(), stat.end()); stat.clear(); }      // (a handful: the list is as good)
+	if (!stat.empty()) {
+		const uint32_t n = (uint32_t)stat.size();
+		const size_t id_bytes = (sizeof(uint32_t) * n + 15) & ~size_t(15);
+		{ int r = ensure_stage(w, id_bytes + sizeof(float4) * 2 * (size_t)n); if (r != SGP_OK) return r; }
+		memcpy(w->stage_host, stat.data(), sizeof(uint32_t) * n);
+		HIP_TRY(hipMemcpyAsync(w->stage_dev, w->stage_host, sizeof(uint32_t) * n, hipMemcpyHostToDevice, w->stream));
+		launch_gather_aabbs(d, (const uint32_t*)w->stage_dev, n, (float4*)((char*)w->stage_dev + id_bytes), w->stream);
+		HIP_TRY(hipMemcpyAsync((char*)w->stage_host + id_bytes, (char*)w->stage_dev + id_bytes, sizeof(float4) * 2 * (size_t)n, hipMemcpyDeviceToHost, w->stream));
+		HIP_TRY(hipStreamSynchronize(w->stream));
+		const float4* bb = (const float4*)((char*)w->stage_host + id_bytes);
+		// cell edge: twice the median extent, grown until the grid fits its table and an average body fills few cells
+		std::vector<float> ext(n);
+		for (uint32_t k = 0; k < n; ++k) ext[k] = std::max(std::max(bb[2 * k + 1].x - bb[2 * k].x, bb[2 * k + 1].y - bb[2 * k].y), bb[2 * k + 1].z - bb[2 * k].z);
+		std::vector<float> sorted_ext(ext);
+		std::nth_element(sorted_ext.begin(), sorted_ext.begin() + n / 2, sorted_ext.end());
+		float cell = std::max(2.0f * sorted_ext[n / 2], 0.5f);
+		if (!(cell < 1.0e30f)) cell = 1.0e30f;
+		auto cell_of = [](float x, float o, float inv, int nn) { return std::min(std::max((int)floorf((x - o) * inv), 0), nn - 1); };      // = lg_cell on the device
+		bool placed = false;
+		for (int attempt = 0; attempt < 64 && !placed; ++attempt) {
+			const float inv = 1.0f / cell;
+			// bodies that would fill too many cells stay on the list (the ground, a terrain); the box of the others is the grid
+			float lo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, hi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+			std::vector<uint8_t> huge(n, 0);
+			for (uint32_t k = 0; k < n; ++k) {
+				const float4 mn = bb[2 * k], mx = bb[2 * k + 1];
+				const double span = (double)(floorf((mx.x - mn.x) * inv) + 2.0f) * (double)(floorf((mx.y - mn.y) * inv) + 2.0f) * (double)(floorf((mx.z - mn.z) * inv) + 2.0f);
+				if (!(span <= (double)SGP_LG_MAX_SPAN) || !std::isfinite(mn.x + mn.y + mn.z + mx.x + mx.y + mx.z)) { huge[k] = 1; continue; }
+				lo[0] = std::min(lo[0], mn.x); lo[1] = std::min(lo[1], mn.y); lo[2] = std::min(lo[2], mn.z);
+				hi[0] = std::max(hi[0], mx.x); hi[1] = std::max(hi[1], mx.y); hi[2] = std::max(hi[2], mx.z);
+			}
+			if (!(lo[0] <= hi[0])) break;      // all of them huge
+			const double dx = floor((double)(hi[0] - lo[0]) * inv) + 1.0, dy = floor((double)(hi[1] - lo[1]) * inv) + 1.0, dz = floor((double)(hi[2] - lo[2]) * inv) + 1.0;
+			if (dx * dy * dz > (double)SGP_LG_MAX_CELLS) { cell *= 1.5f; continue; }
+			g.ox = lo[0]; g.oy = lo[1]; g.oz = lo[2]; g.cell = cell; g.inv_cell = inv; g.nx = (int)dx; g.ny = (int)dy; g.nz = (int)dz;
+			const size_t ncell = (size_t)g.nx * g.ny * g.nz;
+			start.assign(ncell + 1, 0u);
+			size_t total = 0;
+			auto for_cells = [&](uint32_t k, auto&& fn) {
+				const float4 mn = bb[2 * k], mx = bb[2 * k + 1];
+				const int x0 = cell_of(mn.x, g.ox, inv, g.nx), x1 = cell_of(mx.x, g.ox, inv, g.nx), y0 = cell_of(mn.y, g.oy, inv, g.ny), y1 = cell_of(mx.y, g.oy, inv, g.ny), z0 = cell_of(mn.z, g.oz, inv, g.nz), z1 = cell_of(mx.z, g.oz, inv, g.nz);
+				for (int z = z0; z <= z1; ++z) for (int y = y0; y <= y1; ++y) for (int x = x0; x <= x1; ++x) fn(((size_t)z * g.ny + y) * g.nx + x);
+			};
+			for (uint32_t k = 0; k < n; ++k) if (!huge[k]) for_cells(k, [&](size_t c) { start[c + 1]++; ++total; });
+			for (size_t c = 0; c < ncell; ++c) start[c + 1] += start[c];
+			items.resize(total);
+			std::vector<uint32_t> fill(start.begin(), start.end() - 1);
+			for (uint32_t k = 0; k < n; ++k) { if (huge[k]) w->large_linear.push_back(stat[k]); else for_cells(k, [&](size_t c) { items[fill[c]++] = stat[k]; }); }
+			g.n_items = (uint32_t)total;
+			placed = true;
+		}
+		if (!placed) { w->large_linear.insert(w->large_linear.end(), stat.begin(), stat.end()); g.n_items = 0; }
+	}
+	w->lg_static = g.n_items ? (uint32_t)stat.size() : 0u;
+	if (w->large_linear.size() > w->cap_large) return fail(SGP_ERR_CAPACITY, "large-body list full");
+	if (items.size() > w->cap_lg_items) {
+		// (the captured graphs carry the old pointer)
+		HIP_TRY(hipStreamSynchronize(w->stream));
+		w->cap_lg_items = (uint32_t)(items.size() + items.size() / 2);
+		uint32_t* ni = nullptr;
+		HIP_TRY(hipMalloc((void**)&ni, sizeof(uint32_t) * (size_t)w->cap_lg_items));
+		w->allocs.push_back(ni); w->device_bytes += sizeof(uint32_t) * (size_t)w->cap_lg_items;
+		w->d_lg_items = ni; d.lg_items = ni;
+		invalidate_graphs(w);
+	}
+	if (!w->large_linear.empty()) HIP_TRY(hipMemcpyAsync(w->d_large, w->large_linear.data(), sizeof(uint32_t) * w->large_linear.size(), hipMemcpyHostToDevice, w->stream));
+	if (g.n_items) {
+		HIP_TRY(hipMemcpyAsync(w->d_lg_start, start.data(), sizeof(uint32_t) * start.size(), hipMemcpyHostToDevice, w->stream));
+		HIP_TRY(hipMemcpyAsync(w->d_lg_items, items.data(), sizeof(uint32_t) * items.size(), hipMemcpyHostToDevice, w->stream));
+	}
+	HIP_TRY(hipMemcpyAsync(w->d_lgrid, &g, sizeof(g), hipMemcpyHostToDevice, w->stream));
+	HIP_TRY(hipStreamSynchronize(w->stream));      // (pageable host vectors)
+	w->grid_valid = false;
+	return upload_sp(w);
+}
+
 static int flush_cmds(sgp_world* w)
 {
 	hipSetDevice(w->device);
 	DV& d = w->dv;
-	if (w->large_dirty) {
-		if (!w->large_ids.empty()) {
-			HIP_TRY(hipMemcpyAsync(w->d_large, w->large_ids.data(), sizeof(uint32_t) * w->large_ids.size(), hipMemcpyHostToDevice, w->stream));
-			HIP_TRY(hipStreamSynchronize(w->stream));   // large_ids is pageable host memory that may change
-		}
-		w->large_dirty = false;
-	}
 	{ int r = upload_sp(w); if (r != SGP_OK) return r; }
 	if (!w->ghost_refresh.empty()) {
 		// ghosts never appear in the command queue while their set is unchanged, so the order against the commands below does not matter
@@ -863,7 +953,7 @@ static int flush_cmds(sgp_world* w)
 		w->grid_valid = false;
 		w->dirty_since_step = true;
 	}
-	if (w->cmds.empty()) return SGP_OK;
+	if (w->cmds.empty()) return rebuild_large_grid(w);
 	w->grid_valid = false;
 	w->dirty_since_step = true;
 	const size_t n = w->cmds.size();
@@ -884,13 +974,15 @@ static int flush_cmds(sgp_world* w)
 	for (size_t i = 0; i < n; ++i) {
 		hc[i] = w->cmds[order[i]];
 		if (i == 0 || hc[i].id != hc[i - 1].id) hr[n_runs++] = (uint32_t)i;
+		// a static large body that moves or is rescaled sits in other cells of the large bodies' grid afterwards
+		if ((hc[i].ops & (CMD_SET_POS | CMD_SET_ROT | CMD_SET_SHAPE)) && hc[i].id < w->hb.size() && (w->hb[hc[i].id].flags & BF_LARGE) && (w->hb[hc[i].id].flags & BF_MOTION_MASK) == SGP_MOTION_STATIC) w->large_dirty = true;
 	}
 	hr[n_runs] = (uint32_t)n;
 	HIP_TRY(hipMemcpyAsync(w->stage_dev, w->stage_host, total, hipMemcpyHostToDevice, w->stream));
 	launch_apply_cmds(d, (const BodyCmd*)w->stage_dev, (const uint32_t*)((char*)w->stage_dev + run_off), n_runs, w->stream);
 	HIP_TRY(hipStreamSynchronize(w->stream));   // the staging buffer is reused by the next call
 	w->cmds.clear();
-	return SGP_OK;
+	return rebuild_large_grid(w);
 }
 
 // Pull the device event lists into the host vectors and reset the device counters.

@@ -229,3 +229,67 @@ def test_large_boxes_on_a_fine_mesh_match_oracle(oracle):
     st = tw.gpu.read_states(3, n)
     assert (st["pos"][:, 2] > 0.2).all() and (st["pos"][:, 2] < 1.0).all()      # resting on the floor
     tw.close()
+
+
+def test_many_static_meshes_go_through_their_grid(oracle):
+    """A parcel grid in small: 100 static mesh buildings (beyond the handful at which the static large bodies get a grid of their own: LargeGrid),
+    bodies falling among them, rays, swept spheres and capsule queries through the grid; one building is moved and one removed half way (the grid
+    is rebuilt).  The oracle walks every body for everything: same pairs, same hits, same states."""
+    rng = np.random.default_rng(17)
+    tw = parity.make_twin(oracle, max_bodies=1024)
+    tw.add_batch(scenes.ground())
+    hx = 3.0
+    V = np.array([(-hx, -hx, 0), (hx, -hx, 0), (hx, hx, 0), (-hx, hx, 0), (-hx, -hx, 4), (hx, -hx, 4), (hx, hx, 4), (-hx, hx, 4)], np.float32)
+    T = np.array([(0, 2, 1), (0, 3, 2), (4, 5, 6), (4, 6, 7), (0, 1, 5), (0, 5, 4), (1, 2, 6), (1, 6, 5), (2, 3, 7), (2, 7, 6), (3, 0, 4), (3, 4, 7)], np.uint32)
+    ig, ic = tw.mesh_create(V, T)
+    side = 10
+    d = scenes._blank(side * side)
+    d["shape_type"] = abi.SHAPE_MESH; d["shape"][:] = 0; d["shape"][:, 0] = float(ig.mesh_id)
+    gx, gy = np.meshgrid(np.arange(side), np.arange(side))
+    d["pos"] = np.column_stack([(gx.ravel() - side / 2) * 11.0, (gy.ravel() - side / 2) * 11.0, np.zeros(side * side)])
+    a = rng.uniform(0, np.pi, side * side); d["rot"] = np.column_stack([np.zeros_like(a), np.zeros_like(a), np.sin(a / 2), np.cos(a / 2)])
+    mg, mc = tw.add_batch(d)
+    assert np.array_equal(mg, mc)
+    n_dyn = 300
+    b = scenes.dynamic_bodies(n_dyn)
+    b["shape_type"] = rng.integers(0, 3, n_dyn)
+    b["shape"][:, :3] = 0.4; b["shape"][b["shape_type"] == 2, 0] = 0.25
+    b["pos"] = np.column_stack([rng.uniform(-52, 52, n_dyn), rng.uniform(-52, 52, n_dyn), rng.uniform(5.0, 9.0, n_dyn)])
+    tw.add_batch(b)
+    total = 1 + 3 * side * side + n_dyn
+
+    def queries():
+        rays = np.zeros(512, dtype=abi.ray_dtype)
+        rays["origin"] = np.column_stack([rng.uniform(-55, 55, 512), rng.uniform(-55, 55, 512), rng.uniform(1.0, 12.0, 512)])
+        dd = rng.normal(size=(512, 3)) * (1.0, 1.0, 0.3); rays["dir"] = dd / np.linalg.norm(dd, axis=1, keepdims=True)
+        rays["max_t"] = rng.uniform(5.0, 80.0, 512); rays["ignore_id"] = abi.INVALID_ID
+        rg_, rc_ = tw.raycast(rays)
+        assert np.array_equal(rg_["id"], rc_["id"]) and np.array_equal(rg_["triangle"], rc_["triangle"]) and (rg_["id"] != abi.INVALID_ID).sum() > 100
+        assert np.max(np.abs(rg_["t"] - rc_["t"])) <= 1e-4
+        radii = rng.choice([0.0, 0.1, 0.3], size=512).astype(np.float32)
+        rays["max_t"] = rng.uniform(1.0, 6.0, 512)
+        sg_, sc_ = tw.spherecast(rays, radii)
+        assert np.array_equal(sg_["id"], sc_["id"]) and np.max(np.abs(sg_["t"] - sc_["t"])) <= 1e-4
+        qy = np.zeros(64, dtype=abi.capsule_query_dtype)
+        k = rng.integers(0, side * side, 64); ang = rng.uniform(0, 2 * np.pi, 64)
+        qy["pos"] = np.column_stack([d["pos"][k, 0] + 3.9 * np.cos(ang), d["pos"][k, 1] + 3.9 * np.sin(ang), np.full(64, 0.97)])     # around the buildings' walls
+        qy["rot"] = (0, 0, 0, 1); qy["radius"] = 0.3; qy["half_height"] = 0.65; qy["max_separation"] = 0.12; qy["ignore_id"] = abi.INVALID_ID; qy["collidable_only"] = 1
+        cg, cc = tw.collide_capsules(qy)
+        assert len(cg) == len(cc) and len(cg) >= 64                            # the ground at least
+        assert np.array_equal(cg["query"], cc["query"]) and np.array_equal(cg["body"], cc["body"])
+        assert np.max(np.abs(cg["point"] - cc["point"])) <= 1e-5
+
+    for s in range(1, 241):
+        tw.step(DT)
+        if s == 120:
+            for w in (tw.gpu, tw.cpu):
+                w.set_pose_shape(int(mg[37]), (3.0, -2.0, 0.0), (0, 0, 0, 1), (float(ig.mesh_id), 0, 0, 0))      # a building moves ...
+                w.remove(int(mg[58]))                                                                              # ... and one is torn down
+        if s in (1, 60, 119, 121, 180, 240):
+            c = parity.compare(tw, total)
+            assert c["active_mismatch"] == 0 and c["pos"] <= 2e-4 and c["lin_vel"] <= 2e-3, (s, c)
+            sg, sc = tw.stats()
+            assert (sg.num_pairs, sg.num_manifolds, sg.num_contact_points) == (sc.num_pairs, sc.num_manifolds, sc.num_contact_points), s
+            queries()
+    print("100 static meshes through the large bodies' grid, 240 steps: bit exact =", c["bit_exact"])
+    tw.close()
