@@ -65,7 +65,7 @@ extern "C" {
 #define SGP_SHAPE_SPHERE   0
 #define SGP_SHAPE_BOX      1
 #define SGP_SHAPE_CAPSULE  2
-#define SGP_SHAPE_MESH     4   /* static triangle mesh created with sgp_mesh_create; shape[0] = (float) mesh id; static bodies only.
+#define SGP_SHAPE_MESH     4   /* static triangle mesh created with sgp_mesh_create; shape[0] = (float) mesh id; static and kinematic bodies (JPH::MeshShape has no mass properties; a scripted object is a kinematic mesh body moved with sgp_body_move_kinematic).
                                   A mesh body occupies three consecutive body ids (the id returned + two internal aliases that carry
                                   the second and third contact manifold of a body touching the mesh from several sides)             */
 #define SGP_SHAPE_HULL     3   /* convex hull created with sgp_hull_create; shape[0] = (float) hull id, body frame = the hull's

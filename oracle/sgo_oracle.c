@@ -422,7 +422,7 @@ SGO_API int sgo_body_add(sgo_world* w, const sgp_body_desc* d, uint32_t* id_out)
 	if (d->shape_type == SGP_SHAPE_MESH) {
 		const uint32_t mid = (uint32_t)d->shape[0];
 		if (!(d->shape[0] >= 1.0f) || (float)mid != d->shape[0] || mid >= w->n_meshes || !w->meshes[mid]) return SGP_ERR_INVALID;
-		if (d->motion_type != SGP_MOTION_STATIC) return SGP_ERR_INVALID;       /* JPH::MeshShape: static bodies only */
+		if (d->motion_type == SGP_MOTION_DYNAMIC) return SGP_ERR_INVALID;      /* JPH::MeshShape: static and kinematic bodies (the reference turns a dynamic mesh object into a kinematic one, PhysicsWorld.cpp:1290) */
 		mesh = w->meshes[mid];
 	}
 	if (d->shape_type == SGP_SHAPE_HULL) {
@@ -572,11 +572,12 @@ static void compound_set_pose(sgo_world* w, uint32_t root, const float pos[3], c
 		set_pose_one(w, ids[k], p, q);
 	}
 }
-/* a static mesh body owns the two alias slots behind it (second / third contact manifold of a pair): they share its pose */
+/* a mesh body owns the two alias slots behind it (second / third contact manifold of a pair): they share its pose */
 static void sync_mesh_aliases(sgo_world* w, uint32_t id)
 {
 	if (w->bodies[id].shape_type != SGP_SHAPE_MESH || w->bodies[id].is_alias) return;
-	for (int k = 1; k <= 2; ++k) { w->bodies[id + k].pos = w->bodies[id].pos; w->bodies[id + k].rot = w->bodies[id].rot; }
+	/* (a kinematic mesh body -- a scripted platform -- shares its velocities with them too; they are never awake themselves) */
+	for (int k = 1; k <= 2; ++k) { sgo_body* a = &w->bodies[id + k]; a->pos = w->bodies[id].pos; a->rot = w->bodies[id].rot; a->linv = w->bodies[id].linv; a->angv = w->bodies[id].angv; a->active = 0; }
 }
 
 SGO_API int sgo_body_remove(sgo_world* w, uint32_t id)
@@ -656,6 +657,7 @@ SGO_API int sgo_body_set_vel(sgo_world* w, uint32_t id, const float lv[3], const
 	if (!live(w, id)) return SGP_ERR_BAD_ID;
 	if (w->bodies[id].motion == SGP_MOTION_STATIC) return SGP_OK;
 	w->bodies[id].linv = V3(lv[0], lv[1], lv[2]); w->bodies[id].angv = V3(av[0], av[1], av[2]);
+	sync_mesh_aliases(w, id);
 	return SGP_OK;
 }
 /* MotionProperties::MoveKinematic: velocities that reach the target in dt. Host-side maths (acos), like the product. */
@@ -675,6 +677,7 @@ SGO_API int sgo_body_move_kinematic(sgo_world* w, uint32_t id, const float tp[3]
 		b->angv = v3_scale(V3(dq.x / sl, dq.y / sl, dq.z / sl), angle / dt);
 	} else b->angv = V3(0, 0, 0);
 	body_activate(w, id);
+	sync_mesh_aliases(w, id);
 	return SGP_OK;
 }
 SGO_API int sgo_body_add_force(sgo_world* w, uint32_t id, const float f[3])
@@ -1935,6 +1938,7 @@ SGO_API int sgo_world_step(sgo_world* w, float dt)
 		}
 		b->pos = v3_add(b->pos, v3_scale(b->linv, dt));
 		b->rot = quat_add_rotation_step(b->rot, v3_scale(b->angv, dt));
+		if (b->shape_type == SGP_SHAPE_MESH) sync_mesh_aliases(w, i);      /* (a kinematic mesh body: only its own three slots are touched) */
 	}
 
 	nan_trace(w, "6 integrate");

@@ -2768,6 +2768,10 @@ __global__ void __launch_bounds__(TPB) k_integrate_pose(DV d)
 	const quat q = quat_add_rotation_step(Q4(r4), v3_scale(av, dt));
 	d.pose[2 * (size_t)i] = F4(np, p.w);
 	d.pose[2 * (size_t)i + 1] = make_float4(q.x, q.y, q.z, q.w);
+	if (f_shape(f) == SGP_SHAPE_MESH) {
+		// a kinematic mesh body (a scripted platform): the two alias slots behind it -- second / third contact manifold of a pair -- share its pose
+		for (uint32_t k = 1; k <= 2; ++k) { d.pose[2 * (size_t)(i + k)] = F4(np, p.w); d.pose[2 * (size_t)(i + k) + 1] = make_float4(q.x, q.y, q.z, q.w); }
+	}
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -3251,7 +3255,7 @@ __global__ void __launch_bounds__(TPB) k_apply_cmds(DV d, const BodyCmd* cmds, c
 				if (sl > 1.0e-12f) { const float angle = sgd_quat_angle(sl, dq.w); av = v3_scale(V3(dq.x / sl, dq.y / sl, dq.z / sl), angle / c.dt); }
 				d.vel[2 * (size_t)i] = F4(lv, d.vel[2 * (size_t)i].w);
 				d.vel[2 * (size_t)i + 1] = F4(av, d.vel[2 * (size_t)i + 1].w);
-				f = activate_body(d, i, f);
+				if (!(f & BF_ALIAS)) f = activate_body(d, i, f);      // (a mesh body's alias slots follow its pose and velocities, they are never awake themselves)
 			}
 			continue;
 		}

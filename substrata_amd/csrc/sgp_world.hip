@@ -481,7 +481,7 @@ static int add_one(sgp_world* w, const sgp_body_desc* d, uint32_t* id_out, bool 
 	if (is_mesh) {
 		const uint32_t mid = (uint32_t)d->shape[0];
 		if (!(d->shape[0] >= 1.0f) || (float)mid != d->shape[0] || mid >= w->meshes.size()) return fail(SGP_ERR_INVALID, "sgp_body_add: bad mesh id");
-		if (d->motion_type != SGP_MOTION_STATIC) return fail(SGP_ERR_INVALID, "sgp_body_add: mesh shapes are for static bodies only");
+		if (d->motion_type == SGP_MOTION_DYNAMIC) return fail(SGP_ERR_INVALID, "sgp_body_add: mesh shapes are for static and kinematic bodies (JPH::MeshShape has no mass properties)");
 		if (w->meshes[mid].nt == 0) return fail(SGP_ERR_INVALID, "sgp_body_add: the mesh has been destroyed");
 	}
 	if (d->shape_type == SGP_SHAPE_HULL) {
@@ -631,7 +631,8 @@ static inline bool is_mesh_body(const sgp_world* w, uint32_t id) { return ((w->h
 static void push_pose_cmd_one(sgp_world* w, const BodyCmd& c)
 {
 	w->cmds.push_back(c);
-	if (is_mesh_body(w, c.id)) for (uint32_t k = 1; k <= 2; ++k) { BodyCmd a = c; a.id = c.id + k; a.ops &= (CMD_SET_POS | CMD_SET_ROT); w->cmds.push_back(a); }
+	// (a kinematic mesh body -- a scripted door, a lift -- also shares its velocities with them: a contact on the second group of a pair must see the platform move)
+	if (is_mesh_body(w, c.id)) for (uint32_t k = 1; k <= 2; ++k) { BodyCmd a = c; a.id = c.id + k; a.ops &= (CMD_SET_POS | CMD_SET_ROT | CMD_SET_VEL | CMD_MOVE_KINEMATIC); if (a.ops) w->cmds.push_back(a); }
 }
 // ... and a compound moves all its children: each gets the compound's new pose composed with its own
 static void push_pose_cmd(sgp_world* w, const BodyCmd& c)
@@ -798,7 +799,7 @@ SGP_API int sgp_body_set_vel(sgp_world* w, uint32_t id, const float lv[3], const
 	REQUIRE_FINITE(lv && av && finite3(lv) && finite3(av), "sgp_body_set_vel");
 	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_set_vel: id not live");
 	BodyCmd c = blank_cmd(id, CMD_SET_VEL); memcpy(c.linv, lv, 12); memcpy(c.angv, av, 12);
-	w->cmds.push_back(c);
+	push_pose_cmd_one(w, c);
 	return SGP_OK;
 }
 SGP_API int sgp_body_move_kinematic(sgp_world* w, uint32_t id, const float tp[3], const float tr[4], float dt)
@@ -806,7 +807,7 @@ SGP_API int sgp_body_move_kinematic(sgp_world* w, uint32_t id, const float tp[3]
 	REQUIRE_FINITE(tp && tr && finite3(tp) && finite4(tr) && std::isfinite(dt), "sgp_body_move_kinematic");
 	if (!live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_body_move_kinematic: id not live");
 	BodyCmd c = blank_cmd(id, CMD_MOVE_KINEMATIC); memcpy(c.pos, tp, 12); memcpy(c.rot, tr, 16); c.dt = dt;
-	w->cmds.push_back(c);
+	push_pose_cmd_one(w, c);
 	return SGP_OK;
 }
 SGP_API int sgp_body_add_force(sgp_world* w, uint32_t id, const float f[3])

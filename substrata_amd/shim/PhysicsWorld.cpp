@@ -286,8 +286,9 @@ void PhysicsWorld::addObject(const Reference<PhysicsObject>& object)
 		if (s.kind < 0) return;           // shape.jolt_shape == NULL (:1278-1279)
 		d.shape_type = s.kind;
 		if (s.kind == 4) {
-			// JPH::MeshShape: static (or kinematic) bodies only -- the reference builds a mesh shape exactly when the object is not dynamic
-			if (d.motion_type != SGP_MOTION_STATIC) return;
+			// JPH::MeshShape: static or kinematic bodies -- the reference builds a mesh shape exactly when the object is not dynamic, and "Jolt doesn't
+			// support dynamic bodies with mesh shapes, so change to kinematic" (:1290-1292)
+			if (d.motion_type == SGP_MOTION_DYNAMIC) d.motion_type = SGP_MOTION_KINEMATIC;
 			PhysicsMeshData::Instance* in = s.mesh ? meshInstance(world, s, object->scale) : nullptr;
 			if (!in) return;
 			mesh_in = in;

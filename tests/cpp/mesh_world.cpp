@@ -169,6 +169,31 @@ int main()
 			if (!(moved && gone && bounced && scaled)) printf("moved mesh: moved %d gone %d bounced %d (max x %.3f) scaled %d\n", (int)moved, (int)gone, (int)bounced, max_x, (int)scaled);
 			ok = ok && moved && gone && bounced && scaled;
 		}
+		{
+			// a scripted object: mesh shape + MotionType_kinematic (the reference builds a MeshShape for everything that is not dynamic, :1290, and
+			// moves it with moveKinematicObject, :706-731): a lift -- the roof-only slab of the building mesh -- rises with a box on it
+			std::vector<bool> only_roof(6, false); only_roof[5] = true;
+			Reference<PhysicsObject> lift = new PhysicsObject(true, PhysicsWorld::createJoltShapeForBatchedMesh(building_mesh, false, nullptr, &only_roof), nullptr, 0);
+			lift->motion_type = PhysicsObject::MotionType_kinematic;
+			lift->pos = Vec4f(30.f, -25.f, 0.f, 1);                    // the slab sits at z = pos.z + 6
+			world->addObject(lift);
+			const bool lift_added = !lift->jolt_body_id.IsInvalid();
+			Reference<PhysicsObject> crate = new PhysicsObject(true);
+			crate->is_cube = true; crate->scale = Vec3f(0.8f); crate->mass = 20.f; crate->motion_type = PhysicsObject::MotionType_dynamic; crate->friction = 0.8f;
+			crate->pos = Vec4f(30.f, -25.f, 6.6f, 1);
+			world->addObject(crate); world->activateObject(crate);
+			for (int s = 0; s < 60; ++s) world->think(1.0 / 60.0);     // settles on the slab
+			const float z_before = world->getPosInJolt(crate)[2];
+			for (int s = 0; s < 120; ++s) {
+				const float t = (float)(s + 1) / 60.f;
+				world->moveKinematicObject(*lift, Vec4f(30.f + 0.5f * t, -25.f, 1.0f * t, 1), Quatf::identity(), 1.f / 60.f);
+				world->think(1.0 / 60.0);
+			}
+			const Vec4f cp = world->getPosInJolt(crate);
+			const bool rode = std::fabs(z_before - 6.4f) < 0.05f && std::fabs(cp[2] - 8.4f) < 0.08f && std::fabs(cp[0] - 31.0f) < 0.25f;      // up 2 m and 1 m along x, carried by friction
+			if (!(lift_added && rode)) printf("kinematic mesh lift: added %d, crate z %.3f -> %.3f, x %.3f\n", (int)lift_added, z_before, cp[2], cp[0]);
+			ok = ok && lift_added && rode;
+		}
 		// a decorated unit cube, as GUIClient builds for splat bounds (createScaledAndTranslatedShapeForShape(unit_cube_shape, aabb_min, aabb_span),
 		// GUIClient.cpp:4807): the [0,1]^3 cube mesh mapped onto the box [(-1,-2,0), (1,2,1.5)] of an object floating at (-12, 12, 8)
 		{

@@ -293,3 +293,54 @@ def test_many_static_meshes_go_through_their_grid(oracle):
             queries()
     print("100 static meshes through the large bodies' grid, 240 steps: bit exact =", c["bit_exact"])
     tw.close()
+
+
+def test_kinematic_mesh_platform_carries_bodies(oracle):
+    """A scripted object with a mesh shape is a KINEMATIC mesh body (the reference builds a MeshShape for everything that is not dynamic and
+    moves it with MoveKinematic: PhysicsWorld.cpp:706-731, 1290): a platform mesh that rises and slides carries the boxes on it by friction,
+    a swinging door mesh pushes a ball.  The alias slots behind a mesh body follow its pose and velocities.  GPU == oracle."""
+    rng = np.random.default_rng(4)
+    tw = parity.make_twin(oracle, max_bodies=256)
+    tw.add_batch(scenes.ground())
+    V, T = room_mesh(2.5, 0.6)                              # a tray: floor + low rim
+    ig, ic = tw.mesh_create(V, T)
+    plat = mesh_body(ig, pos=(0.0, 0.0, 0.5))
+    plat["motion_type"] = abi.MOTION_KINEMATIC; plat["layer"] = abi.LAYER_MOVING; plat["activate"] = 1
+    pg, pc = tw.add_batch(plat)
+    Vd = np.array([(-0.1, -1.5, 0), (0.1, -1.5, 0), (0.1, 1.5, 0), (-0.1, 1.5, 0), (-0.1, -1.5, 2.5), (0.1, -1.5, 2.5), (0.1, 1.5, 2.5), (-0.1, 1.5, 2.5)], np.float32)
+    Td = np.array([(0, 2, 1), (0, 3, 2), (4, 5, 6), (4, 6, 7), (0, 1, 5), (0, 5, 4), (1, 2, 6), (1, 6, 5), (2, 3, 7), (2, 7, 6), (3, 0, 4), (3, 4, 7)], np.uint32)
+    dg, dc = tw.mesh_create(Vd, Td)
+    door = mesh_body(dg, pos=(12.0, 0.0, 0.0))
+    door["motion_type"] = abi.MOTION_KINEMATIC; door["layer"] = abi.LAYER_MOVING; door["activate"] = 1
+    dgid, dcid = tw.add_batch(door)
+    assert int(pg[0]) == int(pc[0]) and int(dgid[0]) == int(dcid[0])
+    n = 8
+    b = scenes.dynamic_bodies(n, mass=10.0, friction=0.8)
+    b["shape_type"] = np.arange(n) % 3
+    b["shape"][:, :3] = 0.3; b["shape"][np.arange(n) % 3 == 2, 0] = 0.2
+    b["pos"] = np.column_stack([rng.uniform(-1.5, 1.5, n), rng.uniform(-1.5, 1.5, n), rng.uniform(1.2, 2.0, n)])
+    tw.add_batch(b)
+    ball = scenes.dynamic_bodies(1, mass=5.0); ball["shape_type"] = abi.SHAPE_SPHERE; ball["shape"][0] = (0.4, 0, 0, 0); ball["pos"][0] = (12.9, 0.8, 0.4)
+    tw.add_batch(ball)
+    total = 1 + 3 + 3 + n + 1
+    for s in range(1, 301):
+        t = s * DT
+        ppos = (0.8 * np.sin(0.8 * t), 0.0, 0.5 + 0.5 * min(t, 2.0))                   # rises for two seconds while sliding to and fro
+        a = 0.6 * np.sin(1.2 * t)                                                        # the door swings about z
+        for w in (tw.gpu, tw.cpu):
+            w.move_kinematic(int(pg[0]), ppos, (0, 0, 0, 1), DT)
+            w.move_kinematic(int(dgid[0]), (12.0, 0.0, 0.0), (0, 0, np.sin(a / 2), np.cos(a / 2)), DT)
+        tw.step(DT)
+        if s in (1, 30, 90, 150, 240, 300):
+            c = parity.compare(tw, total)
+            assert c["active_mismatch"] == 0 and c["pos"] <= 2e-4 and c["rot"] <= 2e-4 and c["lin_vel"] <= 2e-3, (s, c)
+            sg, sc = tw.stats()
+            assert (sg.num_pairs, sg.num_manifolds, sg.num_contact_points) == (sc.num_pairs, sc.num_manifolds, sc.num_contact_points), s
+    print("kinematic mesh platform + door, 300 steps: bit exact =", c["bit_exact"])
+    st = tw.gpu.read_states(7, n)
+    plat_now = tw.gpu.get_state([int(pg[0])])[0]
+    assert abs(float(plat_now["pos"][2]) - 1.5) < 1e-3                                   # the platform went where it was told
+    assert (st["pos"][:, 2] > 1.5).all() and (np.abs(st["pos"][:, 0] - plat_now["pos"][0]) < 2.6).all()     # ... and took its load along
+    ballst = tw.gpu.read_states(7 + n, 1)[0]
+    assert np.linalg.norm(ballst["pos"][:2] - np.float32([12.9, 0.8])) > 0.3             # the door pushed the ball
+    tw.close()
