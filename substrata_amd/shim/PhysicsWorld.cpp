@@ -72,6 +72,7 @@ PhysicsWorld::PhysicsWorld(glare::TaskManager* task_manager_, glare::StackAlloca
 {
 	sgp_world_desc d;
 	sgp_default_world_desc(&d);        // cMaxBodies 65536 (:492), gravity (0,0,-9.81) (:520), Jolt default settings
+	d.max_bodies *= 3;                 // ... of OBJECTS: a mesh object takes three body slots here (the body and two manifold aliases), so 65536 of them still fit
 	const int r = sgp_world_create(&d, &world);
 	if (r != SGP_OK) { world = NULL; throw glare::Exception(std::string("PhysicsWorld: ") + sgp_last_error()); }
 	id_to_ob.resize(d.max_bodies, NULL);
