@@ -128,6 +128,23 @@ static inline void sgo_seg_seg_closest(v3 a0, v3 a1, v3 b0, v3 b1, v3* pa, v3* p
 	*pa = v3_add(a0, v3_scale(d1, s));
 	*pb = v3_add(b0, v3_scale(d2, t));
 }
+/* ... and only the parameter of the closest point along the first segment (same arithmetic) */
+static inline float sgo_seg_seg_param(v3 a0, v3 a1, v3 b0, v3 b1)
+{
+	const v3 d1 = v3_sub(a1, a0), d2 = v3_sub(b1, b0), r = v3_sub(a0, b0);
+	const float a = v3_dot(d1, d1), e = v3_dot(d2, d2), f = v3_dot(d2, r);
+	float s = 0.0f, t = 0.0f;
+	if (a > 1.0e-12f && e > 1.0e-12f) {
+		const float c = v3_dot(d1, r), b = v3_dot(d1, d2);
+		const float den = a * e - b * b;
+		if (den > 1.0e-12f) s = clampf((b * f - c * e) / den, 0.0f, 1.0f);
+		t = (b * s + f) / e;
+		if (t < 0.0f) { t = 0.0f; s = clampf(-c / a, 0.0f, 1.0f); }
+		else if (t > 1.0f) { t = 1.0f; s = clampf((b - c) / a, 0.0f, 1.0f); }
+	} else if (a > 1.0e-12f) { s = clampf(-v3_dot(d1, r) / a, 0.0f, 1.0f); }
+	(void)t;
+	return s;
+}
 
 /* Result of the separating-axis search: best face axis of A, of B, best (supporting) edge pair. */
 typedef struct { float sA, sB, sE; int fA, fB, eA, eB; v3 nE; } sgo_hull_sat;
@@ -254,7 +271,9 @@ static inline float sgo_hull_closest(const sgo_hull* h, v3 l, v3* q_out, v3* n_o
 {
 	float smax = -3.4e38f; int fmax = 0;
 	for (int f = 0; f < h->nf; ++f) { const float s = v3_dot(h->normals[f], l) - h->plane_d[f]; if (s > smax) { smax = s; fmax = f; } }
-	if (smax <= 0.0f) {
+	/* (a mesh triangle's thin hull has no side planes: a point exactly in its plane is 'inside' only above the triangle itself -- the loop below decides) */
+	const int thin = h->nf == 2 && h->nv == 3;
+	if (smax <= 0.0f && !thin) {
 		*n_out = h->normals[fmax];
 		*q_out = v3_sub(l, v3_scale(h->normals[fmax], smax));
 		return smax;
@@ -263,7 +282,7 @@ static inline float sgo_hull_closest(const sgo_hull* h, v3 l, v3* q_out, v3* n_o
 	for (int f = 0; f < h->nf; ++f) {
 		const v3 n = h->normals[f];
 		const float s = v3_dot(n, l) - h->plane_d[f];
-		if (s <= 0.0f) continue;
+		if (thin ? s < 0.0f : s <= 0.0f) continue;
 		const v3 p = v3_sub(l, v3_scale(n, s));
 		const int k0 = h->face_start[f], k1 = h->face_start[f + 1];
 		int inside = 1;
@@ -311,16 +330,44 @@ static inline int sgo_hull_capsule(const sgo_hview* H, v3 e0, v3 e1, float r, fl
 {
 	const v3 s0 = m33_tmul(H->R, v3_sub(e0, H->pos)), s1 = m33_tmul(H->R, v3_sub(e1, H->pos));
 	const v3 d = v3_sub(s1, s0);
-	/* the distance to a convex set is convex along the segment: fixed-count ternary search */
-	float lo = 0.0f, hi = 1.0f;
 	v3 q, n;
-	for (int it = 0; it < 40; ++it) {
-		const float t1 = lo + (hi - lo) * (1.0f / 3.0f), t2 = hi - (hi - lo) * (1.0f / 3.0f);
-		const float f1 = sgo_hull_closest(H->h, v3_add(s0, v3_scale(d, t1)), &q, &n);
-		const float f2 = sgo_hull_closest(H->h, v3_add(s0, v3_scale(d, t2)), &q, &n);
-		if (f1 <= f2) hi = t2; else lo = t1;
+	float ts;
+	if (H->h->nv == 3 && H->h->nf == 2) {
+		/* a mesh triangle (thin hull).  The distance to a convex set is C1 outside the set, so along the axis it is least at an end of the axis, at its
+		   closest approach to one of the three edges, or where it pierces the triangle: at most six evaluations, no search (a capsule on a mesh is
+		   the player on the world: this is the character controller's inner loop) */
+		float cand[6]; int ncand = 0;
+		cand[ncand++] = 0.0f; cand[ncand++] = 1.0f;
+		for (int k = 0; k < 3; ++k) cand[ncand++] = sgo_seg_seg_param(s0, s1, H->h->verts[H->h->edge_a[k]], H->h->verts[H->h->edge_b[k]]);
+		const float h0 = v3_dot(H->h->normals[0], s0) - H->h->plane_d[0], h1 = v3_dot(H->h->normals[0], s1) - H->h->plane_d[0];
+		if ((h0 > 0.0f) != (h1 > 0.0f)) {
+			/* (only a crossing INSIDE the triangle counts: a thin hull has no side planes, and a point of its plane beside the triangle would
+			   pass for "inside" in the closest-point function) */
+			const float tp = h0 / (h0 - h1);
+			const v3 P = v3_add(s0, v3_scale(d, tp));
+			int inside = 1;
+			for (int k = H->h->face_start[0]; k < H->h->face_start[1]; ++k) {
+				const v3 a = H->h->verts[H->h->face_idx[k]], b = H->h->verts[H->h->face_idx[k + 1 < H->h->face_start[1] ? k + 1 : H->h->face_start[0]]];
+				if (v3_dot(v3_cross(v3_sub(b, a), H->h->normals[0]), v3_sub(P, a)) > 0.0f) { inside = 0; break; }
+			}
+			if (inside) cand[ncand++] = tp;
+		}
+		float best = 3.4e38f; ts = 0.0f;
+		for (int k = 0; k < ncand; ++k) {
+			const float fk = sgo_hull_closest(H->h, v3_add(s0, v3_scale(d, cand[k])), &q, &n);
+			if (fk < best) { best = fk; ts = cand[k]; }
+		}
+	} else {
+		/* the distance to a convex set is convex along the segment: fixed-count ternary search */
+		float lo = 0.0f, hi = 1.0f;
+		for (int it = 0; it < 40; ++it) {
+			const float t1 = lo + (hi - lo) * (1.0f / 3.0f), t2 = hi - (hi - lo) * (1.0f / 3.0f);
+			const float f1 = sgo_hull_closest(H->h, v3_add(s0, v3_scale(d, t1)), &q, &n);
+			const float f2 = sgo_hull_closest(H->h, v3_add(s0, v3_scale(d, t2)), &q, &n);
+			if (f1 <= f2) hi = t2; else lo = t1;
+		}
+		ts = 0.5f * (lo + hi);
 	}
-	const float ts = 0.5f * (lo + hi);
 	const v3 S = v3_add(s0, v3_scale(d, ts));
 	const float dist = sgo_hull_closest(H->h, S, &q, &n);
 	if (dist - r > max_sep) return 0;

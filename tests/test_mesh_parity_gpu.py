@@ -344,3 +344,42 @@ def test_kinematic_mesh_platform_carries_bodies(oracle):
     ballst = tw.gpu.read_states(7 + n, 1)[0]
     assert np.linalg.norm(ballst["pos"][:2] - np.float32([12.9, 0.8])) > 0.3             # the door pushed the ball
     tw.close()
+
+
+def test_capsules_around_small_meshes_same_constraints(oracle):
+    """Capsule against triangle without a search (closest approach to the three edges, the ends, the piercing point): 200 small box meshes at random
+    orientations with five capsules around each, one step -- the constraint lists of device and oracle are the same, entry for entry (a bogus
+    candidate -- the axis crossing a triangle's plane beside the triangle -- once produced hundreds of contacts half a metre from anything)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__)))
+    import compound_scene as cs_
+    rng = np.random.default_rng(1)
+    tw = parity.make_twin(oracle, max_bodies=4096)
+    NM, PER = 200, 5
+    bv, bt = cs_.box_mesh((-0.6, -0.4, 0.0), (0.6, 0.4, 0.9))
+    ig, ic = tw.mesh_create(bv, bt)
+    d = scenes._blank(NM); d["shape_type"] = abi.SHAPE_MESH; d["shape"][:] = 0; d["shape"][:, 0] = float(ig.mesh_id)
+    cen = np.column_stack([(np.arange(NM) % 15) * 6.0, (np.arange(NM) // 15) * 6.0, np.full(NM, 3.0)])
+    d["pos"] = cen
+    q = rng.normal(size=(NM, 4)); d["rot"] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    tw.add_batch(d)
+    b = scenes.dynamic_bodies(NM * PER)
+    b["shape_type"] = abi.SHAPE_CAPSULE; b["shape"][:, 0] = rng.uniform(0.15, 0.4, NM * PER); b["shape"][:, 1] = rng.uniform(0.2, 0.8, NM * PER)
+    b["pos"] = np.repeat(cen, PER, axis=0) + rng.normal(size=(NM * PER, 3)) * 0.55
+    q = rng.normal(size=(NM * PER, 4)); b["rot"] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    b["gravity_factor"] = 0.0
+    tw.add_batch(b)
+    tw.step(DT)
+    cg, cc = tw.gpu.dump_constraints(), tw.cpu.dump_constraints()
+    og, oc = np.lexsort((cg["b"], cg["a"])), np.lexsort((cc["b"], cc["a"]))
+    assert len(cg) == len(cc) and 300 < len(cg) < 2500
+    for f in ("a", "b", "np", "n", "bias"):
+        assert np.array_equal(np.ascontiguousarray(cg[f][og]).view(np.uint8), np.ascontiguousarray(cc[f][oc]).view(np.uint8)), f
+    # every contact is a contact: the capsule is within reach of its mesh (no constraint between bodies half a metre apart)
+    st = tw.gpu.read_states(0, 3 * NM + NM * PER)
+    for c in cg[:: max(1, len(cg) // 200)]:
+        m, x = int(c["a"]), int(c["b"])
+        if m >= 3 * NM:
+            continue                                        # (two capsules)
+        assert np.linalg.norm(st[x]["pos"] - st[m - m % 3]["pos"]) < 0.9 + 0.8 + 0.4 + 0.75 + 0.1      # box half diagonal + half height + radius + offset of the box centre
+    tw.close()

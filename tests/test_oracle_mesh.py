@@ -203,3 +203,22 @@ def test_streaming_meshes_in_and_out_reuses_slots_and_ids(oracle):
         w.remove(bid); w.hull_destroy(hi.hull_id)
     assert len(hull_ids) == 1
     w.close()
+
+
+def test_capsule_axis_through_a_triangles_plane(oracle):
+    """Capsule against one triangle without a search (sgo_hull_capsule, thin hull): the axis' closest point is an end, its closest approach to an
+    edge, or where it pierces the triangle.  A crossing of the triangle's PLANE beside the triangle is not a contact (a thin hull has no side planes:
+    a point of its plane passes for 'inside' in the closest-point function, so that candidate only counts inside the triangle) -- 0.5 m beside the
+    triangle there is no constraint, through its middle there is one, and next to an edge the contact sits on that edge."""
+    TRI_V = [(0, 0, 0), (2, 0, 0), (0, 2, 0)]
+    for pos, expect in (((3.0, 3.0, 0.1), 0),            # axis crosses z = 0 at (3, 3): 1.4 m from the hypotenuse
+                        ((0.5, 0.5, 0.1), 1),            # ... at (0.5, 0.5): inside
+                        ((-0.25, 1.0, 0.1), 1)):         # ... 0.25 m outside the edge x = 0: the capsule's side (radius 0.3) reaches the edge
+        w = oracle.OracleWorld(max_bodies=16)
+        add_mesh(w, TRI_V, [(0, 1, 2)])
+        c = dyn(w, shape_type=abi.SHAPE_CAPSULE, shape=(0.3, 0.6, 0, 0), pos=pos, rot=quat_axis_angle((1, 0, 0), 0.35), gravity_factor=0.0)
+        w.step(DT)
+        cons = w.dump_constraints()
+        assert len(cons) == expect, (pos, len(cons))
+        if expect and pos[0] < 0:
+            assert cons[0]["n"][0] < -0.5               # pushed away from the triangle, across its edge x = 0

@@ -251,7 +251,12 @@ def run_seed(oracle, seed, steps, verbose=False):
             if len(eg) != len(ec):
                 def brief(e):
                     return [tuple(int(e[n_][k]) for n_ in e.dtype.names if n_ in ("id", "id1", "id2", "body", "a", "b", "kind", "type")) for k in range(min(len(e), 12))]
-                raise AssertionError((seed, s, "event count", ev, len(eg), len(ec), eg.dtype.names, brief(eg), brief(ec), "stream", stream, "compounds", compounds))
+                # which constraints differ (pairs present on one side only, or with another point count), and what the bodies are
+                dg, dc = tw.gpu.dump_constraints(), tw.cpu.dump_constraints()
+                kg = {(int(c["a"]), int(c["b"])): int(c["np"]) for c in dg}; kc = {(int(c["a"]), int(c["b"])): int(c["np"]) for c in dc}
+                odd = sorted(k for k in set(kg) | set(kc) if kg.get(k) != kc.get(k))[:6]
+                kinds = {i: kind_of.get(i) for k in odd for i in k}
+                raise AssertionError((seed, s, "event count", ev, len(eg), len(ec), "constraints that differ (gpu np, oracle np)", [(k, kg.get(k), kc.get(k)) for k in odd], "shape types", kinds, "stream", stream, "compounds", compounds))
             if len(eg):      # the events of THIS step, same payloads (both sides deliver them sorted by body ids)
                 for f in eg.dtype.names:
                     if f.startswith("userdata"):
@@ -330,7 +335,7 @@ def main():
         try:
             run_seed(oracle, seed, args.steps, verbose=True)
         except AssertionError as e:
-            print(f"seed {seed}: MISMATCH {str(e)[:300]}")
+            print(f"seed {seed}: MISMATCH {str(e)[:700]}")
             failed.append(seed)
     print(f"{len(seeds) - len(failed)} of {len(seeds)} seeds bit-exact; failed: {failed}")
     return 1 if failed else 0
