@@ -179,6 +179,44 @@ template <class HA, class HB> SGP_DEV static int sgd_hull_sat_search(const HA* A
 		if (s > r->sB) { r->sB = s; r->fB = f; }
 	}
 	const v3 T = v3_sub(B->pos, A->pos);
+	const int boxA = A->h->is_box_template, boxB = B->h->is_box_template;
+	if ((boxA || A->h->ne <= 3) && (boxB || B->h->ne <= 3) && (boxA || boxB)) {
+		/* A cube's twelve edges have three directions: the axis of an edge pair and the separation along it are those of the pair of DIRECTIONS
+		   (parallel edges running the same way give the same cross product), so they are evaluated once per direction pair -- nine times for a box
+		   against a triangle instead of 36 -- and only whether THIS pair of edges supports the two hulls along
+		   the axis is asked per pair.  The same operands through the same expressions as sgd_hull_axis_edge: the same bits, the same winner. */
+		int state[6][6]; v3 cax[6][6]; float cs[6][6];      // (direction and sense of a cube edge: an edge running the other way is a class of its own, so that nothing rests on how the template orders its edges)
+		for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) state[a][b] = 0;
+		for (int i = 0; i < A->h->ne; ++i) {
+			const v3 ea = v3_sub(A->h->verts[A->h->edge_b[i]], A->h->verts[A->h->edge_a[i]]);
+			const int ca = boxA ? (ea.x != 0.0f ? (ea.x < 0.0f ? 1 : 0) : (ea.y != 0.0f ? (ea.y < 0.0f ? 3 : 2) : (ea.z < 0.0f ? 5 : 4))) : i;
+			for (int j = 0; j < B->h->ne; ++j) {
+				const v3 eb = v3_sub(B->h->verts[B->h->edge_b[j]], B->h->verts[B->h->edge_a[j]]);
+				const int cb = boxB ? (eb.x != 0.0f ? (eb.x < 0.0f ? 1 : 0) : (eb.y != 0.0f ? (eb.y < 0.0f ? 3 : 2) : (eb.z < 0.0f ? 5 : 4))) : j;
+				if (state[ca][cb] == 0) {
+					const v3 da = m33_mul(A->R, v3_sub(sgd_hv_local(A, A->h->edge_b[i]), sgd_hv_local(A, A->h->edge_a[i])));
+					const v3 db = m33_mul(B->R, v3_sub(sgd_hv_local(B, B->h->edge_b[j]), sgd_hv_local(B, B->h->edge_a[j])));
+					v3 ax = v3_cross(da, db);
+					const float l2 = v3_len_sq(ax);
+					if (l2 < 1.0e-6f * v3_len_sq(da) * v3_len_sq(db)) state[ca][cb] = 1;
+					else {
+						ax = v3_scale(ax, 1.0f / sqrtf(l2));
+						if (v3_dot(ax, T) < 0.0f) ax = v3_neg(ax);
+						cax[ca][cb] = ax; cs[ca][cb] = sgd_hv_proj_min(B, ax) - sgd_hv_proj_max(A, ax);
+						state[ca][cb] = 2;
+					}
+				}
+				if (state[ca][cb] == 1) continue;
+				const v3 ax = cax[ca][cb]; const float s = cs[ca][cb];
+				if (s > max_sep) return 0;
+				const v3 a0 = sgd_hv_world(A, A->h->edge_a[i]), b0 = sgd_hv_world(B, B->h->edge_a[j]);
+				const float s_edge = v3_dot(ax, b0) - v3_dot(ax, a0);
+				const int sup = !(s_edge - s > 1.0e-4f);
+				if (s > r->sE && sup) { r->sE = s; r->eA = i; r->eB = j; r->nE = ax; }
+			}
+		}
+		return 1;
+	}
 	for (int i = 0; i < A->h->ne; ++i) {
 		for (int j = 0; j < B->h->ne; ++j) {
 			v3 ax; float s; int sup;
