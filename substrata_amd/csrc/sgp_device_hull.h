@@ -7,6 +7,7 @@
 // Included by sgp_device_collide.h after sgd_manifold / sgd_closest_on_segment.  The collision functions are templates over the hull record type (the full
 // record, or the three-vertex record of a mesh triangle).
 #pragma once
+#include <type_traits>
 #include "sgp_device_math.h"
 
 #define SGD_HULL_MAX_VERTS 32
@@ -32,6 +33,8 @@ typedef struct sgd_hull_s sgd_hull;
 // (H: the full record, or the thin three-vertex hull of a mesh triangle -- sgd_tri_hull_t, sgp_device_mesh.h --, small enough to stay out of scratch memory)
 template <class H> struct sgd_hview_t { v3 pos; m33 R; v3 scale; const H* h; };
 typedef sgd_hview_t<sgd_hull> sgd_hview;
+// (a record type that only ever holds one triangle says so at compile time: the full record then carries none of the triangle-only code)
+template <class H> struct sgd_is_thin { static constexpr bool value = false; };
 
 template <class HV> SGP_DEV static v3 sgd_hv_local(const HV* v, int i) { const v3 p = v->h->verts[i]; return V3(p.x * v->scale.x, p.y * v->scale.y, p.z * v->scale.z); }
 template <class HV> SGP_DEV static v3 sgd_hv_world(const HV* v, int i) { return v3_add(v->pos, m33_mul(v->R, sgd_hv_local(v, i))); }
@@ -286,7 +289,13 @@ template <class HA, class HB> SGP_DEV static int sgd_hull_manifold(const HA* A, 
 		return 1;
 	}
 	const int refA = !(sB > sA + 1.0e-4f);
-	return refA ? sgd_hull_face_contact(A, B, fA, 1, max_sep, m) : sgd_hull_face_contact(B, A, fB, 0, max_sep, m);
+	if constexpr (std::is_same<HA, HB>::value) {
+		// one call for both roles (two would be two copies of the clipping code, and the lanes of a wave that disagree about the reference hull would run both)
+		const HA* X = refA ? A : B; const HA* Y = refA ? B : A;
+		return sgd_hull_face_contact(X, Y, refA ? fA : fB, refA, max_sep, m);
+	} else {
+		return refA ? sgd_hull_face_contact(A, B, fA, 1, max_sep, m) : sgd_hull_face_contact(B, A, fB, 0, max_sep, m);
+	}
 }
 
 // A, B = hull views (either may be the scaled cube template): SAT + clipping.  Normal from A to B.
@@ -304,7 +313,7 @@ template <class H> SGP_DEV static float sgd_hull_closest(const H* h, v3 l, v3* q
 	float smax = -3.4e38f; int fmax = 0;
 	for (int f = 0; f < h->nf; ++f) { const float s = v3_dot(h->normals[f], l) - h->plane_d[f]; if (s > smax) { smax = s; fmax = f; } }
 	/* (a mesh triangle's thin hull has no side planes: a point exactly in its plane is 'inside' only above the triangle itself -- the loop below decides) */
-	const int thin = h->nf == 2 && h->nv == 3;
+	const int thin = sgd_is_thin<H>::value && h->nf == 2 && h->nv == 3;
 	if (smax <= 0.0f && !thin) {
 		*n_out = h->normals[fmax];
 		*q_out = v3_sub(l, v3_scale(h->normals[fmax], smax));
@@ -364,7 +373,7 @@ template <class HV> SGP_DEV static int sgd_hull_capsule(const HV* H, v3 e0, v3 e
 	const v3 d = v3_sub(s1, s0);
 	v3 q, n;
 	float ts;
-	if (H->h->nv == 3 && H->h->nf == 2) {
+	if (sgd_is_thin<typename std::remove_cv<typename std::remove_pointer<decltype(H->h)>::type>::type>::value && H->h->nv == 3 && H->h->nf == 2) {
 		/* a mesh triangle (thin hull).  The distance to a convex set is C1 outside the set, so along the axis it is least at an end of the axis, at its
 		   closest approach to one of the three edges, or where it pierces the triangle: at most six evaluations, no search (a capsule on a mesh is
 		   the player on the world: this is the character controller's inner loop) */

@@ -17,6 +17,7 @@ struct sgd_tri_hull_t {
 	v3 verts[3]; v3 normals[2]; float plane_d[2];
 	unsigned char face_start[3], face_idx[6], edge_a[3], edge_b[3];
 };
+template <> struct sgd_is_thin<sgd_tri_hull_t> { static constexpr bool value = true; };
 typedef sgd_hview_t<sgd_tri_hull_t> sgd_tri_view;
 SGP_DEV static void sgd_tri_hull(v3 a, v3 b, v3 c, sgd_tri_hull_t* h, v3* centroid_out, v3* normal_out)
 {
