@@ -1099,23 +1099,25 @@ SGP_DEV int hull_sat_search_wave(const sgd_hview* A, const sgd_hview* B, float m
 	const v3 T = v3_sub(B->pos, A->pos);
 	float sA = -3.4e38f, sB = -3.4e38f, sE = -3.4e38f; int iA = 0x7FFFFFFF, iB = 0x7FFFFFFF, iE = 0x7FFFFFFF;
 	bool separated = false;
-	for (int t = lane; t < total; t += 64) {
+	// the face axes first: most candidate pairs that do not touch are told apart by one of them, and the edge pairs (nine tenths of the axes) are then never looked at
+	for (int t = lane; t < nfA + nfB; t += 64) {
 		if (t < nfA) {
 			const float s = sgd_hull_axis_face(A, B, t);
 			if (s > max_sep) separated = true;
 			if (s > sA) { sA = s; iA = t; }
-		} else if (t < nfA + nfB) {
+		} else {
 			const int f = t - nfA;
 			const float s = sgd_hull_axis_face(B, A, f);
 			if (s > max_sep) separated = true;
 			if (s > sB) { sB = s; iB = f; }
-		} else {
-			const int e = t - nfA - nfB;
-			v3 ax; float s; int sup;
-			if (sgd_hull_axis_edge(A, B, e / neB, e % neB, T, &ax, &s, &sup)) {
-				if (s > max_sep) separated = true;
-				if (s > sE && sup) { sE = s; iE = e; }
-			}
+		}
+	}
+	if (__any(separated)) return 0;
+	for (int e = lane; e < total - nfA - nfB; e += 64) {
+		v3 ax; float s; int sup;
+		if (sgd_hull_axis_edge(A, B, e / neB, e % neB, T, &ax, &s, &sup)) {
+			if (s > max_sep) separated = true;
+			if (s > sE && sup) { sE = s; iE = e; }
 		}
 	}
 	if (__any(separated)) return 0;
