@@ -14,6 +14,7 @@
 #include <Jolt/Physics/Collision/Shape/CapsuleShape.h>
 #include <Jolt/Physics/Collision/Shape/RotatedTranslatedShape.h>
 #include <cstdio>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 
@@ -99,9 +100,12 @@ int main()
 		player.init(*world, JPH::Vec3(0, 0, 2.0f));
 		const float dt = 1.f / 60.f;
 		int step = 0; JPH::Vec3 p;
+		double update_us = 0.0; int updates = 0;      // host time of the character's update (its shape queries are blocking calls into the library)
 		auto frame = [&](const JPH::Vec3& desired, bool jump = false) {
 			world->moveKinematicObject(*platform, Vec4f(-10, -3 + 1.0f * dt * (float)(step + 1), 0.2f, 1), Quatf::identity(), dt);       // platform drifts +y at 1 m/s
+			const auto t_up0 = std::chrono::steady_clock::now();
 			player.update(*world, desired, jump, dt);
+			update_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_up0).count(); ++updates;
 			world->think(dt);
 			++step; p = player.jolt_character->GetPosition();
 			if (getenv("PLAYER_DBG") && step >= atoi(getenv("PLAYER_DBG")) && step < atoi(getenv("PLAYER_DBG")) + 40) { const JPH::Vec3 v = player.jolt_character->GetLinearVelocity(); printf("  step %d pos %.4f %.4f %.4f vel %.3f %.3f %.3f state %d gn %.3f %.3f %.3f ncontacts %d\n", step, p.x, p.y, p.z, v.x, v.y, v.z, (int)player.jolt_character->GetGroundState(), player.jolt_character->GetGroundNormal().x, player.jolt_character->GetGroundNormal().y, player.jolt_character->GetGroundNormal().z, (int)player.jolt_character->GetActiveContacts().size()); }
@@ -145,6 +149,7 @@ int main()
 		world->readBackActivatedObjectTransforms();
 		const float crate_x = world->getPosInJolt(crate)[0];
 		printf("final pos %.3f %.3f %.3f  crate x %.3f  contacts added %d\n", p.x, p.y, p.z, crate_x, player.contacts_added);
+		printf("character update: %.1f us on average over %d updates\n", update_us / (double)updates, updates);
 		CHECK(crate_x > -5.5f && p.x > -7.0f && p.x < crate_x - 0.5f);
 		CHECK(player.contacts_added >= 5);
 		return 0;
