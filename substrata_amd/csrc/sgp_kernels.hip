@@ -2153,7 +2153,11 @@ template <int MODE, int ROWS = -1> __global__ void __launch_bounds__(MODE != 0 ?
 	if (MODE != 0) {
 		// velocity and position iterations: two neighbouring lanes per constraint
 		const int side = (int)(threadIdx.x & 1u);
-		for (uint32_t k = first + ((blockIdx.x * SOLVE_VEL_TPB + threadIdx.x) >> 1); k < end; k += gridDim.x * (SOLVE_VEL_TPB / 2)) {
+		// Workgroups are dealt to the eight XCDs in turn, each with an L2 of its own: workgroup b takes chunk (b % 8) * (n / 8) + b / 8 of the colour's
+		// slots, so that one XCD works through a CONTIGUOUS eighth of them -- neighbouring slots are neighbouring manifolds, which share bodies'
+		// cache lines, and the same XCD meets the same rows again in the next pass.  (The grid is a multiple of eight: launch_solve_colour.)
+		const uint32_t bx = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+		for (uint32_t k = first + ((bx * SOLVE_VEL_TPB + threadIdx.x) >> 1); k < end; k += gridDim.x * (SOLVE_VEL_TPB / 2)) {
 			if (MODE == 1) solve_velocity_pair_t<2, ROWS>(d, k, side, d.vel); else solve_position_pair(d, k, side);
 		}
 		return;
@@ -4807,6 +4811,7 @@ void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStr
 	uint32_t blocks = (est + est / 8 + 64 + SOLVE_TPB - 1) / SOLVE_TPB;      // warm start: one thread per constraint, one wave per workgroup
 	if (mode != 0) blocks = (est + est / 8 + 64 + SOLVE_VEL_TPB / 2 - 1) / (SOLVE_VEL_TPB / 2);
 	if (blocks > 8192) blocks = 8192;
+	if (mode != 0) blocks = (blocks + 7u) & ~7u;      // (XCD-contiguous chunks: k_solve_colour)
 	if (mode == 0) hipLaunchKernelGGL(k_solve_colour<0>, dim3(blocks), dim3(SOLVE_TPB), 0, s, d, colour);
 	else if (mode == 1) {
 		if (compact_rows == 2) hipLaunchKernelGGL((k_solve_colour<1, 2>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour);
