@@ -28,6 +28,11 @@ SGP_DEV uint32_t f_motion(uint32_t f) { return f & BF_MOTION_MASK; }
 SGP_DEV uint32_t f_layer(uint32_t f) { return (f & BF_LAYER_MASK) >> BF_LAYER_SHIFT; }
 SGP_DEV uint32_t f_shape(uint32_t f) { return (f & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT; }
 SGP_DEV bool f_movable(uint32_t f) { return (f & (BF_ALIVE | BF_ACTIVE)) == (BF_ALIVE | BF_ACTIVE) && f_motion(f) == SGP_MOTION_DYNAMIC; }
+// Workgroups are dealt to the eight XCDs in turn (each with an L2 of its own).  For a kernel that walks a list whose neighbours share data -- pairs in
+// broad-phase tile order, manifolds, a colour's slots -- workgroup b takes chunk xcd_block() instead of b: one XCD then works through a contiguous
+// eighth of the list.  The grid must be a multiple of eight.  (Pays in the colour launches, +2 % on config 3; the streaming kernels k_narrowphase and
+// k_setup got SLOWER with it -- 85 -> 93 us, 157 -> 188 us -- and keep the plain order.)
+SGP_DEV uint32_t xcd_block() { return (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3); }
 SGP_DEV bool f_active_for_pairs(uint32_t f) { return (f & (BF_ALIVE | BF_ACTIVE)) == (BF_ALIVE | BF_ACTIVE) && f_motion(f) != SGP_MOTION_STATIC; }
 
 // MyObjectLayerPairFilter, PhysicsWorld.cpp:160-189
@@ -2147,8 +2152,10 @@ SGP_DEV void solve_position_pair_at(const DV& d, uint32_t slot, int side, float4
 // one-wave workgroups dispatch ~1 us longer per launch than two-wave ones, two-wave ones another 0.15 us longer than four-wave ones; eight
 // waves are as fast for the velocity launches and slower for the position launches)
 #define SOLVE_VEL_TPB 256
-template <int MODE, int ROWS = -1> __global__ void __launch_bounds__(MODE != 0 ? SOLVE_VEL_TPB : SOLVE_TPB) k_solve_colour(DV d, int colour)
+#define SOLVE_XCD_CHUNKS 0x100      // flag in the colour argument: XCD-contiguous chunks (launch_solve_colour sets it for colours that fit the L2s)
+template <int MODE, int ROWS = -1> __global__ void __launch_bounds__(MODE != 0 ? SOLVE_VEL_TPB : SOLVE_TPB) k_solve_colour(DV d, int colour_arg)
 {
+	const int colour = colour_arg & 0xFF;
 	const uint32_t first = d.cstarts[colour], end = d.cstarts[colour + 1];
 	if (MODE != 0) {
 		// velocity and position iterations: two neighbouring lanes per constraint
@@ -2156,7 +2163,7 @@ template <int MODE, int ROWS = -1> __global__ void __launch_bounds__(MODE != 0 ?
 		// Workgroups are dealt to the eight XCDs in turn, each with an L2 of its own: workgroup b takes chunk (b % 8) * (n / 8) + b / 8 of the colour's
 		// slots, so that one XCD works through a CONTIGUOUS eighth of them -- neighbouring slots are neighbouring manifolds, which share bodies'
 		// cache lines, and the same XCD meets the same rows again in the next pass.  (The grid is a multiple of eight: launch_solve_colour.)
-		const uint32_t bx = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+		const uint32_t bx = (colour_arg & SOLVE_XCD_CHUNKS) ? xcd_block() : blockIdx.x;      // (a colour of 200k constraints -- config 4 -- streams from HBM whatever the order, and lost 17 % with the chunks)
 		for (uint32_t k = first + ((bx * SOLVE_VEL_TPB + threadIdx.x) >> 1); k < end; k += gridDim.x * (SOLVE_VEL_TPB / 2)) {
 			if (MODE == 1) solve_velocity_pair_t<2, ROWS>(d, k, side, d.vel); else solve_position_pair(d, k, side);
 		}
@@ -4018,8 +4025,9 @@ template <int MODE> __global__ void __launch_bounds__(VEH_SOLVE_TPB) k_vehicle_s
 // The first contact colour of a velocity / position pass with the vehicles' rows in the same launch: no contact of a chassis sits in colour 0
 // (chassis_colours), so the two touch disjoint bodies and the pass order "vehicles, then the contact colours" holds without a launch of
 // its own.  The vehicle workgroups come first in the grid: they are the longer chains.
-template <int MODE, int ROWS = -1> __global__ void __launch_bounds__(SOLVE_VEL_TPB) k_solve_colour_veh(DV d, int colour, uint32_t veh_blocks)
+template <int MODE, int ROWS = -1> __global__ void __launch_bounds__(SOLVE_VEL_TPB) k_solve_colour_veh(DV d, int colour_arg, uint32_t veh_blocks)
 {
+	const int colour = colour_arg & 0xFF;
 	if (blockIdx.x < veh_blocks) {
 		const uint32_t t = blockIdx.x * SOLVE_VEL_TPB + threadIdx.x;
 		veh_quad_solve<MODE>(d, t >> 2, (int)(t & 3u));
@@ -4027,7 +4035,9 @@ template <int MODE, int ROWS = -1> __global__ void __launch_bounds__(SOLVE_VEL_T
 	}
 	const uint32_t first = d.cstarts[colour], end = d.cstarts[colour + 1];
 	const int side = (int)(threadIdx.x & 1u);
-	for (uint32_t k = first + (((blockIdx.x - veh_blocks) * SOLVE_VEL_TPB + threadIdx.x) >> 1); k < end; k += (gridDim.x - veh_blocks) * (SOLVE_VEL_TPB / 2)) {
+	const uint32_t cb = blockIdx.x - veh_blocks, cg = gridDim.x - veh_blocks;      // (the colour's workgroups: XCD-contiguous chunks as in k_solve_colour; cg is a multiple of eight)
+	const uint32_t bx = (colour_arg & SOLVE_XCD_CHUNKS) ? (cb & 7u) * (cg >> 3) + (cb >> 3) : cb;
+	for (uint32_t k = first + ((bx * SOLVE_VEL_TPB + threadIdx.x) >> 1); k < end; k += cg * (SOLVE_VEL_TPB / 2)) {
 		if (MODE == 1) solve_velocity_pair_t<2, ROWS>(d, k, side, d.vel); else solve_position_pair(d, k, side);
 	}
 }
@@ -4716,7 +4726,7 @@ __global__ void __launch_bounds__(TPB) k_pack_ghost_keys(const sgp_ghost_record*
 // launch wrappers
 
 static inline uint32_t blocks_for(uint32_t n) { return n ? (n + TPB - 1) / TPB : 1; }
-static inline uint32_t stride_grid(uint32_t estimate) { uint32_t b = blocks_for(estimate); if (b < 64) b = 64; if (b > 4096) b = 4096; return b; }
+static inline uint32_t stride_grid(uint32_t estimate) { uint32_t b = blocks_for(estimate); if (b < 64) b = 64; if (b > 4096) b = 4096; return (b + 7u) & ~7u; }      // (a multiple of eight: xcd_block)
 
 void launch_step_begin(const DV& d, const StepParams& sp, uint32_t nb, bool reset_step_scratch, hipStream_t s)
 {
@@ -4812,6 +4822,7 @@ void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStr
 	if (mode != 0) blocks = (est + est / 8 + 64 + SOLVE_VEL_TPB / 2 - 1) / (SOLVE_VEL_TPB / 2);
 	if (blocks > 8192) blocks = 8192;
 	if (mode != 0) blocks = (blocks + 7u) & ~7u;      // (XCD-contiguous chunks: k_solve_colour)
+	if (mode != 0 && est >= 8192u && est <= 65536u) colour |= SOLVE_XCD_CHUNKS;      // (the colour's bodies and rows then fit the eight L2s)
 	if (mode == 0) hipLaunchKernelGGL(k_solve_colour<0>, dim3(blocks), dim3(SOLVE_TPB), 0, s, d, colour);
 	else if (mode == 1) {
 		if (compact_rows == 2) hipLaunchKernelGGL((k_solve_colour<1, 2>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour);
@@ -4824,6 +4835,8 @@ void launch_solve_colour_veh(const DV& d, int colour, uint32_t est, int mode, hi
 {
 	uint32_t blocks = (est + est / 8 + 64 + SOLVE_VEL_TPB / 2 - 1) / (SOLVE_VEL_TPB / 2);
 	if (blocks > 8192) blocks = 8192;
+	blocks = (blocks + 7u) & ~7u;
+	if (est >= 8192u && est <= 65536u) colour |= SOLVE_XCD_CHUNKS;
 	const uint32_t vb = (d.n_vehicles * 4u + SOLVE_VEL_TPB - 1) / SOLVE_VEL_TPB;
 	if (mode == 1) {
 		if (compact_rows == 2) hipLaunchKernelGGL((k_solve_colour_veh<1, 2>), dim3(vb + blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour, vb);
