@@ -361,6 +361,9 @@ const char* sgp_kernel_class_name(int k);
 int  sgp_abi_sizeof(int which);
 /* activated_obs / newly_activated_obs maintenance + listener callbacks (PhysicsWorld.h:194-200). */
 int  sgp_world_drain_events(sgp_world* w, int kind, void* out, uint32_t cap, uint32_t* n_out);
+/* Events waiting per kind (index = SGP_EVENT_*), nothing drained: lets the caller size its buffers to what a step produced instead of to the
+ * world's capacity (the facade's think() runs every frame: PhysicsWorld.cpp:1356-1443; its listeners get one call per event, :1499-1520). */
+int  sgp_world_event_counts(sgp_world* w, uint32_t counts_out[5]);
 /* ---- static compound bodies ---------------------------------------------------
  * Replaces JPH::StaticCompoundShapeSettings::AddShape(position, rotation, shape, user data) x n + Create() as MeshBuilding.cpp:396-407
  * uses it for portals (the arch mesh + a thin box across the opening).  The compound is a STATIC body made of n child shapes, each with

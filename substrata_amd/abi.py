@@ -294,6 +294,7 @@ PROTOTYPES = {
     "kernel_class_name": (C.c_char_p, [C.c_int]),
     "abi_sizeof": (C.c_int, [C.c_int]),
     "world_drain_events": (C.c_int, [vp, C.c_int, vp, u32, P(u32)]),
+    "world_event_counts": (C.c_int, [vp, P(u32)]),
     "world_num_bodies": (C.c_int, [vp, P(u32)]),
     "world_body_counts": (C.c_int, [vp, P(BodyCounts)]),
     "raycast": (C.c_int, [vp, vp, u32, vp]),

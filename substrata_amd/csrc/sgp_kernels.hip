@@ -679,7 +679,8 @@ __global__ void __launch_bounds__(TPB) k_bp_large(DV d)
 		const float s = d.st.speculative_contact_distance;
 		large_grid_query(d, V3(mnj.x - s, mnj.y - s, mnj.z - s), V3(mxj.x + s, mxj.y + s, mxj.z + s), [&](uint32_t i) {
 			if (i == j || !pair_passes(d, fj, mnj, mxj, i)) return;
-			const uint32_t k = wave_alloc(&d.ctr->n_pairs);      // (one atomic for the lanes that found a pair in this turn: a terrain in the grid pairs with every body on it)
+			if ((fj & BF_LARGE) && j < i) return;                // (a moving large body is on the list above: the grid body's own thread paired the two there when its id is the higher one)
+			const uint32_t k = wave_alloc(&d.ctr->n_pairs);     // (one atomic for the lanes that found a pair in this turn: a terrain in the grid pairs with every body on it)
 			if (k < d.cap_pairs) d.pairs[k] = make_uint2(i < j ? i : j, i < j ? j : i); else atomicAdd(&d.ctr->pairs_dropped, 1u);
 		});
 	}

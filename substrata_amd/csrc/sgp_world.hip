@@ -93,6 +93,8 @@ struct sgp_world {
 	void* view_host = nullptr; size_t view_host_bytes = 0;       // pinned buffer of sgp_world_read_active[_poses]_view only
 	StepCounters* h_ctr = nullptr; StepCounters* h_ctr_dev = nullptr; EventCounters* h_evc = nullptr; EventCounters* h_evc_dev = nullptr;
 	bool dirty_since_step = true;                              // an edit was flushed since the last step (or no step yet)
+	bool events_on_device = true;                              // the device event lists may hold something the host vectors do not (a step without read-back, applied edits)
+	StepParams sp_uploaded; bool sp_uploaded_valid = false;    // what d_sp holds (upload_sp skips the launch when nothing changed)
 	uint32_t last_active = 0xFFFFFFFFu;
 	StepParams* h_sp = nullptr; StepParams* d_sp = nullptr;      // pinned host copy / device copy of the per-step scalars
 	std::map<std::string, hipGraphExec_t> graphs;              // replayable launch sequences keyed by launch plan
@@ -843,7 +845,14 @@ static int upload_sp(sgp_world* w)
 	sp.n_large = (uint32_t)w->large_linear.size();
 	sp.bp_rmax = std::max(0.25f, w->max_small_radius);
 	sp.cell_size = sp.bp_rmax + w->dv.st.speculative_contact_distance;
+	if (w->sp_uploaded_valid) {
+		// nothing changed since the device copy was written (several drains / reads in a row; the first call after a step: k_step_begin wrote it)?
+		// dt and the buffer parity are per-step values that only the kernels of a step read, and k_step_begin brings them along by value.
+		StepParams cmp = sp; cmp.dt = w->sp_uploaded.dt; cmp.parity = w->sp_uploaded.parity;
+		if (memcmp(&w->sp_uploaded, &cmp, sizeof(cmp)) == 0) return SGP_OK;
+	}
 	launch_set_params(w->dv, *w->h_sp, w->stream);
+	w->sp_uploaded = sp; w->sp_uploaded_valid = true;
 	return SGP_OK;
 }
 
@@ -957,6 +966,7 @@ static int flush_cmds(sgp_world* w)
 	if (w->cmds.empty()) return rebuild_large_grid(w);
 	w->grid_valid = false;
 	w->dirty_since_step = true;
+	w->events_on_device = true;               // (k_apply_cmds reports activations)
 	const size_t n = w->cmds.size();
 	// commands of one body must be adjacent and in call order (k_apply_cmds walks runs): a stable sort by id -- skipped when the queue is
 	// already ordered, which is what a per-step refresh of thousands of ghosts or snapshots looks like
@@ -991,9 +1001,11 @@ static int collect_events(sgp_world* w, bool counters_fresh = false)
 {
 	DV& d = w->dv;
 	if (!counters_fresh) {
+		if (!w->events_on_device) return SGP_OK;      // nothing ran on the device since the lists were last pulled: no copy, no sync
 		HIP_TRY(hipMemcpyAsync(w->h_evc, d.evc, sizeof(EventCounters), hipMemcpyDeviceToHost, w->stream));
 		HIP_TRY(hipStreamSynchronize(w->stream));
 	}
+	w->events_on_device = false;
 	const EventCounters ec = *w->h_evc;
 	if (!(ec.n_activated | ec.n_deactivated | ec.n_water | ec.n_contact_added | ec.n_contact_persisted)) return SGP_OK;
 	struct L { uint32_t n; uint32_t* dev; std::vector<sgp_body_event>* out; };
@@ -1313,6 +1325,8 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	}
 	w->last_plan_key[w->h_sp->parity & 1u] = key;
 	if (!launched) { const int r = enqueue_step(w, plan); if (r != SGP_OK) return r; w->eager_steps++; }
+	w->sp_uploaded = plan.sp; w->sp_uploaded_valid = true;      // (k_step_begin wrote it)
+	w->events_on_device = true;
 	// -- the ONE host sync of the step: counters, events, and the launch plan for the next step
 	const double tt1 = timing ? now() : 0.0;
 	HIP_TRY(hipStreamSynchronize(w->stream));
@@ -2160,6 +2174,18 @@ SGP_API int sgp_world_drain_events(sgp_world* w, int kind, void* out, uint32_t c
 	return SGP_OK;
 }
 
+SGP_API int sgp_world_event_counts(sgp_world* w, uint32_t counts_out[5])
+{
+	if (!w || !counts_out) return fail(SGP_ERR_INVALID, "sgp_world_event_counts: NULL");
+	hipSetDevice(w->device);
+	{ int r = flush_cmds(w); if (r != SGP_OK) return r; }
+	{ int r = collect_events(w); if (r != SGP_OK) return r; }
+	counts_out[SGP_EVENT_ACTIVATED] = (uint32_t)w->ev_act.size(); counts_out[SGP_EVENT_DEACTIVATED] = (uint32_t)w->ev_deact.size();
+	counts_out[SGP_EVENT_ENTERED_WATER] = (uint32_t)w->ev_water.size();
+	counts_out[SGP_EVENT_CONTACT_ADDED] = (uint32_t)w->ev_added.size(); counts_out[SGP_EVENT_CONTACT_PERSISTED] = (uint32_t)w->ev_pers.size();
+	return SGP_OK;
+}
+
 // Test / debug view of the constraints of the last step (sorted by pair key on the host).
 struct DumpRec { uint32_t a, b; int32_t colour; int32_t np; float n[3]; float lam_n[4]; float lam_t1[4]; float lam_t2[4]; float bias[4]; };
 SGP_API int sgp_world_dump_constraints(sgp_world* w, void* out, uint32_t cap, uint32_t* n_out)
@@ -2192,7 +2218,7 @@ SGP_API int sgp_raycast(sgp_world* w, const sgp_ray* rays, uint32_t n, sgp_hit* 
 	if (!w->grid_valid && w->high) {
 		// poses changed since the grid was built (a step integrates after its broad phase; edits move bodies): re-bin
 		const DV& d = w->dv; hipStream_t s = w->stream; const uint32_t nb = w->high;
-		launch_step_begin(d, *w->h_sp, nb, false, s);
+		launch_step_begin(d, *w->h_sp, nb, false, s); w->sp_uploaded = *w->h_sp; w->sp_uploaded_valid = true;
 		launch_bp_bounds(d, nb, s); launch_bp_cell(d, nb, s); launch_bp_scan(d, s); launch_bp_scatter(d, nb, s);
 		w->grid_valid = true;
 	}
@@ -2225,7 +2251,7 @@ static int ensure_query_grid(sgp_world* w)
 	if (!w->grid_valid && w->high) {
 		// poses changed since the grid was built (a step integrates after its broad phase; edits move bodies): re-bin
 		const DV& d = w->dv; hipStream_t s = w->stream; const uint32_t nb = w->high;
-		launch_step_begin(d, *w->h_sp, nb, false, s);
+		launch_step_begin(d, *w->h_sp, nb, false, s); w->sp_uploaded = *w->h_sp; w->sp_uploaded_valid = true;
 		launch_bp_bounds(d, nb, s); launch_bp_cell(d, nb, s); launch_bp_scan(d, s); launch_bp_scatter(d, nb, s);
 		w->grid_valid = true;
 	}

@@ -224,13 +224,31 @@ namespace JPH
 		bool IsSensor() const { return is_sensor; }
 		Vec3 lin_vel; uint64_t user_data = 0; BodyID id; bool is_sensor = false;
 	};
+	// JPH::StaticArray: fixed capacity, no heap (a ContactManifold is built per contact event, every step)
+	template <class T, unsigned N> class StaticArray
+	{
+	public:
+		typedef T value_type; typedef unsigned size_type;
+		void push_back(const T& v) { if (n < N) new (begin() + n++) T(v); }
+		void clear() { n = 0; }
+		size_type size() const { return n; }
+		bool empty() const { return n == 0; }
+		T& operator[](size_type i) { return begin()[i]; }
+		const T& operator[](size_type i) const { return begin()[i]; }
+		T* begin() { return reinterpret_cast<T*>(buf); } T* end() { return begin() + n; }
+		const T* begin() const { return reinterpret_cast<const T*>(buf); } const T* end() const { return begin() + n; }
+	private:
+		alignas(T) unsigned char buf[N * sizeof(T)];      // (raw storage: nothing is constructed until it is pushed; T is trivially destructible here)
+		size_type n = 0;
+	};
 	class ContactManifold
 	{
 	public:
 		RVec3 mBaseOffset;
 		Vec3 mWorldSpaceNormal;
 		float mPenetrationDepth = 0;
-		std::vector<Vec3> mRelativeContactPointsOn1;
+		typedef StaticArray<Vec3, 64> ContactPoints;      // (Jolt's capacity; a manifold here carries at most 4)
+		ContactPoints mRelativeContactPointsOn1;
 	};
 	class ContactSettings {};
 

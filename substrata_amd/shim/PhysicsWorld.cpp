@@ -81,8 +81,9 @@ PhysicsWorld::PhysicsWorld(glare::TaskManager* task_manager_, glare::StackAlloca
 
 PhysicsWorld::~PhysicsWorld() { delete physics_system; if (world) sgp_world_destroy(world); }
 
-void PhysicsWorld::setWaterBuoyancyEnabled(bool enabled) { water_buoyancy_enabled = enabled; sgp_world_set_water(world, enabled ? 1 : 0, water_z); }
-void PhysicsWorld::setWaterZ(float z) { water_z = z; sgp_world_set_water(world, water_buoyancy_enabled ? 1 : 0, water_z); }
+static void checkSGP(int rc, const char* what);
+void PhysicsWorld::setWaterBuoyancyEnabled(bool enabled) { water_buoyancy_enabled = enabled; checkSGP(sgp_world_set_water(world, enabled ? 1 : 0, water_z), "setWaterBuoyancyEnabled"); }
+void PhysicsWorld::setWaterZ(float z) { water_z = z; checkSGP(sgp_world_set_water(world, water_buoyancy_enabled ? 1 : 0, water_z), "setWaterZ"); }
 
 // PhysicsWorld.cpp:1123-1135
 PhysicsShape PhysicsWorld::createGroundQuadShape(float ground_quad_w)
@@ -381,7 +382,7 @@ void PhysicsWorld::removeObject(const Reference<PhysicsObject>& object)
 	if (!object->jolt_body_id.IsInvalid()) {
 		const uint32_t id = object->jolt_body_id.GetIndex();
 		if (physics_system->GetBodyInterface().IsAdded(object->jolt_body_id)) { physics_system->GetBodyInterface().RemoveBody(object->jolt_body_id); physics_system->GetBodyInterface().DestroyBody(object->jolt_body_id); }
-		else sgp_body_remove(world, id);
+		else checkSGP(sgp_body_remove(world, id), "removeObject");
 		physics_system->GetBodyInterface().clearFrame(object->jolt_body_id);
 		physics_system->registerCompound(object->jolt_body_id, 0);
 		for (auto& release : object->shape_instance_releases) release();
@@ -400,27 +401,36 @@ void PhysicsWorld::removeObject(const Reference<PhysicsObject>& object)
 void PhysicsWorld::activateObject(const Reference<PhysicsObject>& object)
 {
 	if (object->jolt_body_id.IsInvalid()) return;
-	sgp_body_activate(world, object->jolt_body_id.GetIndex());
+	checkSGP(sgp_body_activate(world, object->jolt_body_id.GetIndex()), "activateObject");
 	drainActivationEvents();
 }
 void PhysicsWorld::setObjectLayer(const Reference<PhysicsObject>& object, uint8 new_object_layer)
 {
 	if (object->jolt_body_id.IsInvalid()) return;
-	sgp_body_set_layer(world, object->jolt_body_id.GetIndex(), new_object_layer);
+	checkSGP(sgp_body_set_layer(world, object->jolt_body_id.GetIndex(), new_object_layer), "setObjectLayer");
+}
+
+// A device-side failure behind a facade call that has no error path in the reference (think(), the setters): surfaced the way the reference's
+// shape builders surface theirs (glare::Exception, PhysicsWorld.cpp:762-763) instead of going on with a world that silently stopped moving.
+static void checkSGP(int rc, const char* what)
+{
+	if (rc != SGP_OK) throw glare::Exception(std::string("PhysicsWorld::") + what + ": " + sgp_last_error());
 }
 
 // OnBodyActivated / OnBodyDeactivated (:1448-1486): maintain activated_obs / newly_activated_obs.
+// The buffers are members sized to what is actually waiting (sgp_world_event_counts), never to the world's capacity, and never cleared.
 void PhysicsWorld::drainActivationEvents()
 {
-	std::vector<sgp_body_event> ev(1024);
+	uint32_t counts[5];
+	checkSGP(sgp_world_event_counts(world, counts), "drainActivationEvents");
 	for (int kind = SGP_EVENT_ACTIVATED; kind <= SGP_EVENT_DEACTIVATED; ++kind) {
+		if (!counts[kind]) continue;
+		if (body_event_buf.size() < counts[kind]) body_event_buf.resize(counts[kind] + counts[kind] / 2 + 64);
 		uint32_t n = 0;
-		// the ABI drains the whole list in one call: size the buffer to the world's capacity
-		ev.resize(id_to_ob.size());
-		sgp_world_drain_events(world, kind, ev.data(), (uint32_t)ev.size(), &n);
+		checkSGP(sgp_world_drain_events(world, kind, body_event_buf.data(), (uint32_t)body_event_buf.size(), &n), "drainActivationEvents");
 		Lock lock(activated_obs_mutex);
-		for (uint32_t i = 0; i < n && i < ev.size(); ++i) {
-			PhysicsObject* ob = (PhysicsObject*)ev[i].userdata;
+		for (uint32_t i = 0; i < n && i < body_event_buf.size(); ++i) {
+			PhysicsObject* ob = (PhysicsObject*)body_event_buf[i].userdata;
 			if (!ob) continue;                                  // inBodyUserData != 0 (:1452,1475)
 			if (kind == SGP_EVENT_ACTIVATED) { activated_obs.insert(ob); newly_activated_obs.insert(ob); }
 			else activated_obs.erase(ob);
@@ -431,20 +441,22 @@ void PhysicsWorld::drainActivationEvents()
 // PhysicsWorld.cpp:1356-1443
 void PhysicsWorld::think(double dt)
 {
-	sgp_world_set_contact_events(world, event_listener ? 1 : 0);
-	sgp_world_step(world, (float)dt);                            // physics_system->Update((float)dt, 1, ...) (:1363) + buoyancy sweep (:1367-1442)
+	checkSGP(sgp_world_set_contact_events(world, event_listener ? 1 : 0), "think");
+	checkSGP(sgp_world_step(world, (float)dt), "think");         // physics_system->Update((float)dt, 1, ...) (:1363) + buoyancy sweep (:1367-1442)
 	physics_system->onStep();                                   // cached body / vehicle read-backs are stale now
 	drainActivationEvents();
 
+	uint32_t counts[5];
+	checkSGP(sgp_world_event_counts(world, counts), "think");    // (host-side: the step already pulled the lists)
 	if (event_listener) {
 		// OnContactAdded / OnContactPersisted -> event_listener (:1499-1520), delivered on the calling thread
-		std::vector<sgp_contact_event> ce;
 		for (int kind = SGP_EVENT_CONTACT_ADDED; kind <= SGP_EVENT_CONTACT_PERSISTED; ++kind) {
+			if (!counts[kind]) continue;
+			if (contact_event_buf.size() < counts[kind]) contact_event_buf.resize(counts[kind] + counts[kind] / 2 + 64);
 			uint32_t n = 0;
-			ce.resize(8 * id_to_ob.size() + 1024);
-			sgp_world_drain_events(world, kind, ce.data(), (uint32_t)ce.size(), &n);
-			for (uint32_t i = 0; i < n && i < ce.size(); ++i) {
-				const sgp_contact_event& e = ce[i];
+			checkSGP(sgp_world_drain_events(world, kind, contact_event_buf.data(), (uint32_t)contact_event_buf.size(), &n), "think");
+			for (uint32_t i = 0; i < n && i < contact_event_buf.size(); ++i) {
+				const sgp_contact_event& e = contact_event_buf[i];
 				JPH::Body b1, b2; JPH::ContactManifold m;
 				b1.lin_vel = JPH::Vec3(e.lin_vel1[0], e.lin_vel1[1], e.lin_vel1[2]); b1.user_data = e.userdata1; b1.id = JPH::BodyID(e.id1);
 				b2.lin_vel = JPH::Vec3(e.lin_vel2[0], e.lin_vel2[1], e.lin_vel2[2]); b2.user_data = e.userdata2; b2.id = JPH::BodyID(e.id2);
@@ -459,19 +471,24 @@ void PhysicsWorld::think(double dt)
 
 	if (water_buoyancy_enabled) {
 		// underwater / last_submerged_volume / physicsObjectEnteredWater bookkeeping (:1414-1437)
-		std::vector<sgp_body_event> ev(id_to_ob.size());
-		uint32_t n = 0;
-		sgp_world_drain_events(world, SGP_EVENT_ENTERED_WATER, ev.data(), (uint32_t)ev.size(), &n);
-		for (uint32_t i = 0; i < n && i < ev.size(); ++i) {
-			PhysicsObject* ob = (PhysicsObject*)ev[i].userdata;
-			if (ob && event_listener) event_listener->physicsObjectEnteredWater(*ob);
+		if (counts[SGP_EVENT_ENTERED_WATER]) {
+			const uint32_t want = counts[SGP_EVENT_ENTERED_WATER];
+			if (body_event_buf.size() < want) body_event_buf.resize(want + want / 2 + 64);
+			uint32_t n = 0;
+			checkSGP(sgp_world_drain_events(world, SGP_EVENT_ENTERED_WATER, body_event_buf.data(), (uint32_t)body_event_buf.size(), &n), "think");
+			for (uint32_t i = 0; i < n && i < body_event_buf.size(); ++i) {
+				PhysicsObject* ob = (PhysicsObject*)body_event_buf[i].userdata;
+				if (ob && event_listener) event_listener->physicsObjectEnteredWater(*ob);
+			}
 		}
 		Lock lock(activated_obs_mutex);
-		std::vector<uint32_t> ids; std::vector<PhysicsObject*> obs;
-		for (auto it = activated_obs.begin(); it != activated_obs.end(); ++it) if (!(*it)->jolt_body_id.IsInvalid()) { ids.push_back((*it)->jolt_body_id.GetIndex()); obs.push_back(*it); }
-		std::vector<sgp_body_state> st(ids.size());
-		if (!ids.empty() && sgp_body_get_state(world, ids.data(), (uint32_t)ids.size(), st.data()) == SGP_OK)
-			for (size_t i = 0; i < ids.size(); ++i) { obs[i]->underwater = st[i].underwater != 0; obs[i]->last_submerged_volume = st[i].submerged_volume; }
+		water_ids.clear(); water_obs.clear();
+		for (auto it = activated_obs.begin(); it != activated_obs.end(); ++it) if (!(*it)->jolt_body_id.IsInvalid()) { water_ids.push_back((*it)->jolt_body_id.GetIndex()); water_obs.push_back(*it); }
+		if (water_states.size() < water_ids.size()) water_states.resize(water_ids.size() + water_ids.size() / 2 + 64);
+		if (!water_ids.empty()) {
+			checkSGP(sgp_body_get_state(world, water_ids.data(), (uint32_t)water_ids.size(), water_states.data()), "think");
+			for (size_t i = 0; i < water_ids.size(); ++i) { water_obs[i]->underwater = water_states[i].underwater != 0; water_obs[i]->last_submerged_volume = water_states[i].submerged_volume; }
+		}
 	}
 }
 
@@ -516,7 +533,7 @@ void PhysicsWorld::setNewObToWorldTransform(PhysicsObject& object, const Vec4f& 
 	else { shape[0] = object.shape.p[0] * std::fabs(scale[0]); shape[1] = object.shape.p[1] * std::fabs(scale[2]); }
 	float bp[3], br[4];
 	toBodyPose(object, translation, rot_quat, bp, br);       // (a hull keeps the scale it was added with: its points are pre-scaled)
-	sgp_body_set_pose_shape(world, object.jolt_body_id.GetIndex(), bp, br, shape);   // zero velocity, new scale, ActivateBody (:553-601)
+	checkSGP(sgp_body_set_pose_shape(world, object.jolt_body_id.GetIndex(), bp, br, shape), "setNewObToWorldTransform");   // zero velocity, new scale, ActivateBody (:553-601)
 	physics_system->GetBodyInterface().invalidate();
 	drainActivationEvents();
 }
@@ -529,7 +546,7 @@ void PhysicsWorld::setNewObToWorldTransform(PhysicsObject& object, const Vec4f& 
 	if (object.jolt_body_id.IsInvalid()) return;
 	float bp[3], br[4];
 	toBodyPose(object, pos, rot, bp, br);
-	sgp_body_set_pose_vel(world, object.jolt_body_id.GetIndex(), bp, br, linear_vel.x, angular_vel.x);
+	checkSGP(sgp_body_set_pose_vel(world, object.jolt_body_id.GetIndex(), bp, br, linear_vel.x, angular_vel.x), "setNewObToWorldTransform");
 	physics_system->GetBodyInterface().invalidate();
 }
 
@@ -541,7 +558,7 @@ void PhysicsWorld::setNewPosition(PhysicsObject& object, const Vec4f& pos)
 	if (object.jolt_body_id.IsInvalid()) return;
 	float bp[3], br[4];
 	toBodyPose(object, pos, object.rot, bp, br);
-	sgp_body_set_pos(world, object.jolt_body_id.GetIndex(), bp);
+	checkSGP(sgp_body_set_pos(world, object.jolt_body_id.GetIndex(), bp), "setNewPosition");
 	physics_system->GetBodyInterface().invalidate();
 }
 
@@ -592,7 +609,7 @@ void PhysicsWorld::moveKinematicObject(PhysicsObject& object, const Vec4f& trans
 	if (object.motion_type != PhysicsObject::MotionType_kinematic) return;     // "Tried to move a non-kinematic object" guard (:713-720)
 	float bp[3], br[4];
 	toBodyPose(object, translation, rot, bp, br);
-	sgp_body_move_kinematic(world, object.jolt_body_id.GetIndex(), bp, br, dt);
+	checkSGP(sgp_body_move_kinematic(world, object.jolt_body_id.GetIndex(), bp, br, dt), "moveKinematicObject");
 	physics_system->GetBodyInterface().invalidate();
 }
 

@@ -25,6 +25,7 @@
 
 namespace glare { class TaskManager; class StackAllocator; class Allocator; }
 struct sgp_world;
+struct sgp_body_event; struct sgp_contact_event; struct sgp_body_state;
 typedef unsigned char uint8;
 typedef uint64_t uint64;
 typedef uint32_t uint32;
@@ -239,6 +240,10 @@ private:
 	glare::TaskManager* task_manager;
 	glare::StackAllocator* stack_allocator;
 	std::vector<PhysicsObject*> id_to_ob;
+	// per-step scratch of think(): kept between calls, sized to what the steps really produce (never to the world's capacity, never zero-filled)
+	std::vector<struct sgp_body_event> body_event_buf;
+	std::vector<struct sgp_contact_event> contact_event_buf;
+	std::vector<uint32_t> water_ids; std::vector<PhysicsObject*> water_obs; std::vector<struct sgp_body_state> water_states;
 };
 
 inline void checkRemoveObAndSetRefToNull(PhysicsWorld& physics_world, Reference<PhysicsObject>& physics_object)

@@ -241,6 +241,12 @@ class CWorld:
         self._check(self._fn("world_num_bodies")(self._h, C.byref(n)), "world_num_bodies")
         return n.value
 
+    def event_counts(self):
+        """Events waiting per kind (index = abi.EVENT_*), nothing drained -- product library only."""
+        c = (C.c_uint32 * 5)()
+        self._check(self._fn("world_event_counts")(self._h, c), "world_event_counts")
+        return list(c)
+
     def drain_events(self, kind, cap=1 << 16):
         dt = abi.body_event_dtype if kind <= abi.EVENT_ENTERED_WATER else abi.contact_event_dtype
         n = C.c_uint32(0)

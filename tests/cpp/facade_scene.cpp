@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <chrono>
 
 struct Listener : public PhysicsWorldEventListener
 {
@@ -68,6 +69,27 @@ int main(int argc, char** argv)
 		world->traceRay(Vec4f(0.3f, 0.2f, 50.f, 1.f), Vec4f(0, 0, -1, 0), 100.f, JPH::BodyID(), res);
 		printf("objects %zu newly_activated %zu active %zu contacts_added %d persisted %d ray_hit %d t %.4f\n%s", world->getNumObjects(), newly, n_active,
 			listener.added, listener.persisted, res.hit_object != nullptr, res.hit_object ? res.hit_t : -1.f, world->getDiagnostics().c_str());
+		// What think() costs on the host beyond the device step (the facade used to allocate and zero-fill event buffers sized to
+		// the world's capacity every call): think() with the listener installed and the bare sgp_world_step alternate on the same world.
+		{
+			auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+			for (auto& ob : obs) if (ob->isDynamic()) world->activateObject(ob);       // keep the pile awake for the measurement
+			double t_think = 0, t_step = 0; const int reps = 100;
+			for (int s = 0; s < reps; ++s) {
+				const double a = now(); world->think(1.0 / 60.0);
+				const double b = now(); sgp_world_step(world->world, 1.0f / 60.0f);
+				const double c = now();
+				t_think += b - a; t_step += c - b;
+				for (int kind = SGP_EVENT_ACTIVATED; kind <= SGP_EVENT_CONTACT_PERSISTED; ++kind) { uint32_t n = 0; sgp_world_drain_events(world->world, kind, nullptr, 0, &n); }      // (untimed: the bare step's events are not the next think()'s to deliver)
+			}
+			printf("think_us %.1f step_us %.1f\n", t_think / reps, t_step / reps);
+		}
+		// a device-side failure must not pass silently (the reference's think() has no error path; its shape builders throw glare::Exception)
+		{
+			bool threw = false;
+			try { world->think(-1.0); } catch (glare::Exception& e) { threw = true; printf("think(-1) threw: %s\n", e.what().c_str()); }
+			if (!threw) printf("think(-1) did not throw\n");
+		}
 		for (auto& ob : obs) world->removeObject(ob);
 		printf("after remove: objects %zu\n", world->getNumObjects());
 	} catch (glare::Exception& e) { fprintf(stderr, "glare::Exception: %s\n", e.what().c_str()); return 1; }

@@ -221,6 +221,11 @@ def test_facade_config1_matches_oracle(tmp_path, oracle):
     assert int(kv["active"]) == int(live_active.sum())
     assert int(kv["contacts_added"]) > 100 and int(kv["persisted"]) > 1000 and int(kv["ray_hit"]) == 1
     assert "after remove: objects 0" in r.stdout
+    # the facade's own host cost per think() (listener installed, 256 awake boxes): the device step + at most 30 us
+    tl = [l for l in r.stdout.splitlines() if l.startswith("think_us")][0].split()
+    think_us, step_us = float(tl[1]), float(tl[3])
+    assert think_us <= step_us + 30.0, (think_us, step_us)
+    assert "think(-1) threw" in r.stdout
     w.close()
 
 

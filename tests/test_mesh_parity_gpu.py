@@ -383,3 +383,53 @@ def test_capsules_around_small_meshes_same_constraints(oracle):
             continue                                        # (two capsules)
         assert np.linalg.norm(st[x]["pos"] - st[m - m % 3]["pos"]) < 0.9 + 0.8 + 0.4 + 0.75 + 0.1      # box half diagonal + half height + radius + offset of the box centre
     tw.close()
+
+
+def test_large_dynamic_bodies_on_grid_resident_static_meshes_pair_once(oracle):
+    """Moving bodies beyond the large-body radius stay on the large bodies' linear list, static meshes (>= 32 of them) sit in the LargeGrid: a
+    slab that rests across several buildings meets each of them through BOTH routes of k_bp_large (the building's thread walking the list, the
+    slab's own query of the grid), and the pair must come out once whichever of the two has the lower id (round 3's advisor found it emitted
+    twice when the static body's id was the higher one).  One slab is created before the buildings, one after."""
+    tw = parity.make_twin(oracle, max_bodies=512)
+    tw.add_batch(scenes.ground())
+
+    def slab(x):
+        b = scenes.dynamic_bodies(1, mass=900.0)
+        b["shape_type"] = abi.SHAPE_BOX; b["shape"][0, :3] = (6.0, 4.5, 0.3); b["pos"][0] = (x, 0.0, 5.2); b["restitution"] = 0.0
+        return b
+    s0g, s0c = tw.add_batch(slab(-16.5)); assert np.array_equal(s0g, s0c)
+    hx = 2.0
+    V = np.array([(-hx, -hx, 0), (hx, -hx, 0), (hx, hx, 0), (-hx, hx, 0), (-hx, -hx, 4), (hx, -hx, 4), (hx, hx, 4), (-hx, hx, 4)], np.float32)
+    T = np.array([(0, 2, 1), (0, 3, 2), (4, 5, 6), (4, 6, 7), (0, 1, 5), (0, 5, 4), (1, 2, 6), (1, 6, 5), (2, 3, 7), (2, 7, 6), (3, 0, 4), (3, 4, 7)], np.uint32)
+    ig, ic = tw.mesh_create(V, T)
+    side = 6
+    d = scenes._blank(side * side)
+    d["shape_type"] = abi.SHAPE_MESH; d["shape"][:] = 0; d["shape"][:, 0] = float(ig.mesh_id)
+    gx, gy = np.meshgrid(np.arange(side), np.arange(side))
+    d["pos"] = np.column_stack([(gx.ravel() - side / 2) * 5.5, (gy.ravel() - side / 2) * 5.5, np.zeros(side * side)])
+    mg, mc = tw.add_batch(d); assert np.array_equal(mg, mc)
+    s1g, s1c = tw.add_batch(slab(8.25)); assert np.array_equal(s1g, s1c)
+    assert int(s0g[0]) < int(mg[0]) < int(s1g[0])
+    small = scenes.dynamic_bodies(24)
+    small["pos"] = [(-14.0 + 1.3 * (k % 12), -2.0 + 3.0 * (k // 12), 7.0) for k in range(24)]
+    tw.add_batch(small)
+    total = 1 + 1 + 3 * side * side + 1 + 24
+    on_mesh = set()
+    tw.set_contact_events(1)
+    for s in range(1, 151):
+        tw.step(DT)
+        sg, sc = tw.stats()
+        assert (sg.num_pairs, sg.num_manifolds, sg.num_contact_points) == (sc.num_pairs, sc.num_manifolds, sc.num_contact_points), s
+        for ev in (abi.EVENT_CONTACT_ADDED, abi.EVENT_CONTACT_PERSISTED):
+            eg, ec = tw.drain_events(ev)
+            assert len(eg) == len(ec), (s, ev)
+            for e in eg:
+                a, b = int(e["id1"]), int(e["id2"])
+                for slab_id in (int(s0g[0]), int(s1g[0])):
+                    if slab_id in (a, b): on_mesh.add((slab_id, a + b - slab_id))
+        if s % 30 == 0:
+            c = parity.compare(tw, total)
+            assert c["bit_exact"] and c["active_mismatch"] == 0, (s, c)
+    mesh_ids = set(int(m) for m in mg)
+    assert any(o in mesh_ids for (sl, o) in on_mesh if sl == int(s0g[0])) and any(o in mesh_ids for (sl, o) in on_mesh if sl == int(s1g[0]))
+    tw.close()
