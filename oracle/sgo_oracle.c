@@ -1108,6 +1108,12 @@ static void colour_constraints(sgo_world* w)
 	   as in PhysicsSystem's solve), and the device solves them in the same launch as the first contact colour -- so no contact of a chassis takes
 	   colour 0.  The order a sequential solve visits the rows of any one body in is unchanged by this: vehicle, then contacts by colour. */
 	for (uint32_t k = 0; k < w->n_vehicles; ++k) if (w->vehicles[k].alive && w->vehicles[k].body < w->high) w->bodies[w->vehicles[k].body].chassis = 1;
+	/* ... and so is colour 0 of a dynamic body under a wheel of an active vehicle: the wheel rows act on it (round 4) */
+	for (uint32_t k = 0; k < w->n_vehicles; ++k) {
+		const sgo_vehicle* v = &w->vehicles[k];
+		if (!v->alive || !v->active) continue;
+		for (int i = 0; i < v->num_wheels; ++i) if (v->wheels[i].has_contact && v->wheels[i].ground_dynamic && v->wheels[i].contact_body < w->high) w->bodies[v->wheels[i].contact_body].chassis = 1;
+	}
 	/* Colour inheritance through the contact cache: a persisted manifold keeps last step's colour when both of its movable
 	   bodies were already movable when that colour was chosen (then last step's proper colouring guarantees that no two
 	   inheritors sharing a movable body carry the same colour).  Only the other manifolds go through the rounds below. */
@@ -1298,6 +1304,18 @@ static void update_sleeping(sgo_world* w, float dt)
 		if (!body_movable(&w->bodies[c->a]) || !body_movable(&w->bodies[c->b])) continue;
 		const uint32_t ra = uf_find(w, c->a), rb = uf_find(w, c->b);
 		if (ra < rb) w->bodies[rb].island = (int)ra; else if (rb < ra) w->bodies[ra].island = (int)rb;
+	}
+	/* a vehicle links its chassis with the dynamic bodies under its wheels (VehicleConstraint::BuildIslands) */
+	for (uint32_t k = 0; k < w->n_vehicles; ++k) {
+		const sgo_vehicle* v = &w->vehicles[k];
+		if (!v->alive || !v->active || !live(w, v->body)) continue;
+		for (int i = 0; i < v->num_wheels; ++i) {
+			const sgo_wheel* wh = &v->wheels[i];
+			if (!wh->has_contact || !wh->ground_dynamic || !live(w, wh->contact_body)) continue;
+			if (!body_movable(&w->bodies[v->body]) || !body_movable(&w->bodies[wh->contact_body])) continue;
+			const uint32_t ra = uf_find(w, v->body), rb = uf_find(w, wh->contact_body);
+			if (ra < rb) w->bodies[rb].island = (int)ra; else if (rb < ra) w->bodies[ra].island = (int)rb;
+		}
 	}
 	/* per-body sleep test */
 	for (uint32_t i = 0; i < w->high; ++i) {
@@ -1718,6 +1736,21 @@ static sgo_chassis chassis_load(const sgo_body* b)
 	return c;
 }
 
+/* The dynamic bodies under the wheels of a vehicle as the rows see them: g[i] = NULL unless wheel i stands on a dynamic body that is awake for the
+   solve (the effective inverse mass of a body still asleep is zero: before the wake-up of this step has happened -- the row setup -- the inverse
+   mass of the body is what counts, see the caller); wheels that share a body share its state. */
+static void vehicle_grounds_load(sgo_world* w, const sgo_vehicle* v, sgo_chassis* gs, sgo_chassis** g)
+{
+	for (int i = 0; i < v->num_wheels; ++i) {
+		const sgo_wheel* wh = &v->wheels[i];
+		g[i] = NULL;
+		if (!wh->has_contact || !wh->ground_dynamic || !live(w, wh->contact_body)) continue;
+		for (int j = 0; j < i; ++j) if (g[j] && v->wheels[j].contact_body == wh->contact_body) { g[i] = g[j]; break; }
+		if (!g[i]) { gs[i] = chassis_load(&w->bodies[wh->contact_body]); g[i] = &gs[i]; }
+	}
+	for (int i = v->num_wheels; i < SGO_MAX_WHEELS; ++i) g[i] = NULL;
+}
+
 /* VehicleConstraint::OnStep for every vehicle whose chassis is awake, in two sweeps so that the result does not depend on the
    order of the vehicles: (A) all wheel casts (read-only on the bodies), (B) controller + row setup (writes the own chassis only).
    The cast visits every body (closest accepted hit; on equal distance the lower body id wins) -- the device walks the
@@ -1798,21 +1831,35 @@ static void vehicles_pre_step(sgo_world* w, float dt)
 				const sgo_body* o = &w->bodies[bid];
 				const v3 gv = o->motion == SGP_MOTION_STATIC ? V3(0, 0, 0) : v3_add(o->linv, v3_cross(o->angv, v3_sub(bp, o->pos)));
 				sgo_vehicle_set_hit(v, i, bid, best, bn, bp, gv, o->friction);
+				wh->ground_dynamic = o->motion == SGP_MOTION_DYNAMIC;      /* the rows then act on it too: VehicleConstraint::SetupVelocityConstraint(.., *w->mContactBody, ..) */
 			}
 		}
 	}
 	free(bounds);
+	/* a sleeping dynamic body under a wheel of an active vehicle wakes up (VehicleConstraint::BuildIslands activates the bodies the wheels touch);
+	   like a body touched by an active one it is activated after this step's collision detection (find_contacts), so it gets no gravity this step */
+	for (uint32_t k = 0; k < w->n_vehicles; ++k) {
+		sgo_vehicle* v = &w->vehicles[k];
+		if (!v->alive || !v->active) continue;
+		for (int i = 0; i < v->num_wheels; ++i) {
+			const sgo_wheel* wh = &v->wheels[i];
+			if (wh->has_contact && wh->ground_dynamic && !w->bodies[wh->contact_body].active) w->bodies[wh->contact_body].can_sleep = -1;
+		}
+	}
 	for (uint32_t k = 0; k < w->n_vehicles; ++k) {
 		sgo_vehicle* v = &w->vehicles[k];
 		if (!v->alive || !v->active) continue;
 		sgo_body* b = &w->bodies[v->body];
 		sgo_chassis c = chassis_load(b);
-		if (sgo_vehicle_pre_b(v, &c, dt)) b->sleep_timer = 0.0f;
+		sgo_chassis gs[SGO_MAX_WHEELS]; sgo_chassis* g[SGO_MAX_WHEELS];
+		vehicle_grounds_load(w, v, gs, g);
+		if (sgo_vehicle_pre_b(v, &c, g, dt)) b->sleep_timer = 0.0f;
 		b->linv = c.v; b->angv = c.w;
 	}
 }
 
-/* mode 0 warm start, 1 velocity iteration, 2 position iteration */
+/* mode 0 warm start, 1 velocity iteration, 2 position iteration.  The vehicles in index order (the constraints of an island in their order, in
+   Jolt): two vehicles with a wheel on the same dynamic body, or one standing on the other, see each other's impulses in that order. */
 static void vehicles_solve(sgo_world* w, int mode, float dt)
 {
 	for (uint32_t k = 0; k < w->n_vehicles; ++k) {
@@ -1820,10 +1867,17 @@ static void vehicles_solve(sgo_world* w, int mode, float dt)
 		if (!v->alive || !v->active) continue;
 		sgo_body* b = &w->bodies[v->body];
 		sgo_chassis c = chassis_load(b);
-		if (mode == 0) sgo_vehicle_warm_start(v, &c);
-		else if (mode == 1) sgo_vehicle_solve_velocity(v, &c, dt);
-		else sgo_vehicle_solve_position(v, &c, w->st.baumgarte);
+		sgo_chassis gs[SGO_MAX_WHEELS]; sgo_chassis* g[SGO_MAX_WHEELS];
+		vehicle_grounds_load(w, v, gs, g);
+		if (mode == 0) sgo_vehicle_warm_start(v, &c, g);
+		else if (mode == 1) sgo_vehicle_solve_velocity(v, &c, g, dt);
+		else sgo_vehicle_solve_position(v, &c, g, w->st.baumgarte);
 		if (mode == 2) { b->pos = c.pos; b->rot = c.rot; } else { b->linv = c.v; b->angv = c.w; }
+		for (int i = 0; i < v->num_wheels; ++i) {
+			if (!g[i] || g[i] != &gs[i]) continue;                      /* (a body two wheels share is written once, by the first of them) */
+			sgo_body* o = &w->bodies[v->wheels[i].contact_body];
+			if (mode == 2) { o->pos = gs[i].pos; o->rot = gs[i].rot; } else { o->linv = gs[i].v; o->angv = gs[i].w; }
+		}
 	}
 }
 
@@ -1985,6 +2039,24 @@ SGO_API int sgo_world_step(sgo_world* w, float dt)
 	w->stats.num_colours = (uint32_t)nreg;      /* regular colours only, like the device's colour table; the overflow colour is num_overflow_constraints */
 	w->stats.num_overflow_constraints = novf;
 	{ uint32_t nr = 0; for (uint32_t k = 0; k < w->n_prev; ++k) nr += (uint32_t)w->prev[k].reused; w->stats.num_cached_manifolds = nr; }
+	/* vehicles that share a movable body with a vehicle of lower index (the device defers their rows; here they are simply later in the loop) */
+	if (w->n_vehicles) {
+		uint32_t* first = (uint32_t*)malloc(sizeof(uint32_t) * (w->high ? w->high : 1));
+		for (uint32_t i = 0; i < w->high; ++i) first[i] = 0xFFFFFFFFu;
+		for (int pass = 0; pass < 2; ++pass) for (uint32_t k = 0; k < w->n_vehicles; ++k) {
+			const sgo_vehicle* v = &w->vehicles[k];
+			if (!v->alive || !v->active || v->body >= w->high) continue;
+			int lost = 0;
+			if (pass == 0) { if (k < first[v->body]) first[v->body] = k; } else if (first[v->body] != k) lost = 1;
+			for (int i = 0; i < v->num_wheels; ++i) {
+				const sgo_wheel* wh = &v->wheels[i];
+				if (!wh->has_contact || !wh->ground_dynamic || wh->contact_body >= w->high) continue;
+				if (pass == 0) { if (k < first[wh->contact_body]) first[wh->contact_body] = k; } else if (first[wh->contact_body] != k) lost = 1;
+			}
+			w->stats.num_deferred_vehicles += (uint32_t)lost;
+		}
+		free(first);
+	}
 	/* activation events raised since the end of the previous step (edits between steps included) */
 	w->stats.num_activated = (uint32_t)(w->tot_act - w->rep_act); w->rep_act = w->tot_act;
 	w->stats.num_deactivated = (uint32_t)(w->tot_deact - w->rep_deact); w->rep_deact = w->tot_deact;

@@ -13,9 +13,10 @@
  *   WarmStart / SolveVelocity (per iteration, before the contact constraints) / SolvePosition (max-up stop only)
  *
  * Deliberate simplifications, shared with the device implementation (so they do not affect GPU-vs-oracle parity):
- *   - the body under a wheel is treated as kinematic: its contact point velocity is sampled at cast time and the wheel rows
- *     apply no reaction impulse to it (Jolt applies the reaction; this keeps vehicles independent of each other and of the
- *     contact colouring);
+ *   - (round 4: the wheel rows are two-body constraints like Jolt's -- AxisConstraintPart between the chassis and the body under the
+ *     wheel: a DYNAMIC ground body takes the reaction impulses of the suspension, upper-stop, longitudinal and lateral rows, enters their
+ *     effective masses and is read live; tyre slip and the longitudinal target still use the contact point velocity sampled at cast time,
+ *     as Jolt's WheeledVehicleController does.  Vehicles are solved in index order, like the constraints of one island in Jolt;)
  *   - anti-roll bar impulses are applied to the chassis in the pre-step;
  *   - the (m+1)x(m+1) implicit clutch system is solved in closed form (same linear system);
  *   - acos of the slip angle uses a fixed polynomial, the wheel angle wraps by subtraction (no libm on the step path);
@@ -33,10 +34,13 @@
 #define SGO_MAX_GEARS 8
 #define SGO_VEH_PI 3.14159265358979323846f
 
-/* one row J = [-axis, -(r1 x axis)] against a kinematic second body (Jolt AxisConstraintPart + SpringPart) */
+/* one row J = [-axis, -(r1 x axis), axis, r2 x axis] between the chassis and the body under the wheel (Jolt AxisConstraintPart + SpringPart);
+   the body-2 terms are zero unless that body is dynamic */
 typedef struct {
 	v3 r1xa;            /* r1 x axis */
 	v3 iI_r1xa;         /* I1^-1 (r1 x axis) */
+	v3 r2xa;            /* r2 x axis */
+	v3 iI_r2xa;         /* I2^-1 (r2 x axis) */
 	float eff;          /* effective mass (incl. spring softness) */
 	float softness, bias;
 	float lambda;
@@ -52,6 +56,7 @@ typedef struct {
 	/* state (JPH::Wheel / WheelWV) */
 	float angular_velocity, angle, steer_angle, suspension_length;
 	int has_contact; uint32_t contact_body;
+	int ground_dynamic;                /* the body under the wheel is dynamic: the rows act on it too (VehicleConstraint::SetupVelocityConstraint, body 2) */
 	v3 contact_pos, contact_normal, contact_long, contact_lat, contact_point_vel;
 	float axle_plane_constant;
 	float anti_roll_impulse, brake_impulse;
@@ -274,12 +279,18 @@ static inline float sgo_cast_sphere_body(int type, const float* p, const sgo_hul
 
 static inline void sgo_part_deactivate(sgo_axis_part* p) { p->active = 0; p->lambda = 0.0f; p->eff = 0.0f; p->softness = 0.0f; p->bias = 0.0f; }
 
-/* hard row, or soft row when stiffness > 0 (Jolt SpringPart::CalculateSpringPropertiesWithStiffnessAndDamping) */
-static inline void sgo_part_setup(sgo_axis_part* p, const sgo_chassis* c, v3 r1, v3 axis, float dt, float C, float stiffness, float damping)
+/* hard row, or soft row when stiffness > 0 (Jolt SpringPart::CalculateSpringPropertiesWithStiffnessAndDamping).  g = the body under the wheel when it
+   is dynamic (NULL otherwise): AxisConstraintPart::TemplatedCalculateInverseEffectiveMass adds its share after body 1's. */
+static inline void sgo_part_setup(sgo_axis_part* p, const sgo_chassis* c, v3 r1, const sgo_chassis* g, v3 r2, v3 axis, float dt, float C, float stiffness, float damping)
 {
 	p->r1xa = v3_cross(r1, axis);
 	p->iI_r1xa = sym33_mul(c->I, p->r1xa);
-	const float inv_eff = c->im + v3_dot(p->r1xa, p->iI_r1xa);
+	float inv_eff = c->im + v3_dot(p->r1xa, p->iI_r1xa);
+	if (g) {
+		p->r2xa = v3_cross(r2, axis);
+		p->iI_r2xa = sym33_mul(g->I, p->r2xa);
+		inv_eff = inv_eff + (g->im + v3_dot(p->r2xa, p->iI_r2xa));
+	} else { p->r2xa = V3(0, 0, 0); p->iI_r2xa = V3(0, 0, 0); }
 	if (!(inv_eff > 0.0f)) { sgo_part_deactivate(p); return; }
 	if (stiffness > 0.0f) {
 		p->softness = 1.0f / (dt * (damping + dt * stiffness));
@@ -292,18 +303,24 @@ static inline void sgo_part_setup(sgo_axis_part* p, const sgo_chassis* c, v3 r1,
 	p->active = 1;
 }
 
-static inline void sgo_part_apply(const sgo_axis_part* p, sgo_chassis* c, v3 axis, float lambda)
+static inline void sgo_part_apply(const sgo_axis_part* p, sgo_chassis* c, sgo_chassis* g, v3 axis, float lambda)
 {
 	c->v = v3_sub(c->v, v3_scale(axis, lambda * c->im));
 	c->w = v3_sub(c->w, v3_scale(p->iI_r1xa, lambda));
+	if (g) {
+		g->v = v3_add(g->v, v3_scale(axis, lambda * g->im));
+		g->w = v3_add(g->w, v3_scale(p->iI_r2xa, lambda));
+	}
 }
 
-static inline void sgo_part_solve(sgo_axis_part* p, sgo_chassis* c, v3 ground_vel, v3 axis, float lo, float hi)
+/* ground_vel: the contact point velocity sampled at cast time, what a ground body that is not dynamic contributes */
+static inline void sgo_part_solve(sgo_axis_part* p, sgo_chassis* c, sgo_chassis* g, v3 ground_vel, v3 axis, float lo, float hi)
 {
-	const float jv = v3_dot(axis, v3_sub(c->v, ground_vel)) + v3_dot(p->r1xa, c->w);
+	const float jv = g ? (v3_dot(axis, v3_sub(c->v, g->v)) + v3_dot(p->r1xa, c->w)) - v3_dot(p->r2xa, g->w)
+	                   : v3_dot(axis, v3_sub(c->v, ground_vel)) + v3_dot(p->r1xa, c->w);
 	const float lambda = p->eff * (jv - (p->softness * p->lambda + p->bias));
 	const float nl = clampf(p->lambda + lambda, lo, hi);
-	sgo_part_apply(p, c, axis, nl - p->lambda);
+	sgo_part_apply(p, c, g, axis, nl - p->lambda);
 	p->lambda = nl;
 }
 
@@ -365,7 +382,7 @@ static inline void sgo_vehicle_pre_a(sgo_vehicle* v, const sgo_chassis* c, float
 		w->cast_origin = v3_add(c->pos, m33_mul(R, w->position));
 		w->cast_dir = m33_mul(R, w->suspension_dir);
 		w->cast_len = w->sus_max + w->radius - v->cast_radius;
-		w->has_contact = 0; w->contact_body = 0xFFFFFFFFu;
+		w->has_contact = 0; w->contact_body = 0xFFFFFFFFu; w->ground_dynamic = 0;
 	}
 }
 
@@ -373,7 +390,7 @@ static inline void sgo_vehicle_pre_a(sgo_vehicle* v, const sgo_chassis* c, float
 static inline void sgo_vehicle_set_hit(sgo_vehicle* v, int i, uint32_t body, float t, v3 n, v3 p, v3 ground_point_vel, float ground_friction)
 {
 	sgo_wheel* w = &v->wheels[i];
-	w->has_contact = 1; w->contact_body = body;
+	w->has_contact = 1; w->contact_body = body; w->ground_dynamic = 0;      /* (the world's glue sets ground_dynamic) */
 	w->contact_normal = n; w->contact_pos = p; w->contact_point_vel = ground_point_vel; w->ground_friction = ground_friction;
 	w->suspension_length = fmaxf(0.0f, t + v->cast_radius - w->radius);
 }
@@ -432,8 +449,8 @@ static inline void sgo_differential_split(const sgo_differential* d, float wl, f
 	}
 }
 
-/* Returns 1 when the chassis' sleep timer must be reset (wheels still spinning). */
-static inline int sgo_vehicle_pre_b(sgo_vehicle* v, sgo_chassis* c, float dt)
+/* Returns 1 when the chassis' sleep timer must be reset (wheels still spinning).  g[i] = the body under wheel i when it is dynamic, else NULL. */
+static inline int sgo_vehicle_pre_b(sgo_vehicle* v, sgo_chassis* c, sgo_chassis* const* g, float dt)
 {
 	const m33 R = quat_to_m33(c->rot);
 	const int nw = v->num_wheels;
@@ -591,6 +608,8 @@ static inline int sgo_vehicle_pre_b(sgo_vehicle* v, sgo_chassis* c, float dt)
 			continue;
 		}
 		const v3 r1 = v3_sub(w->contact_pos, c->pos);
+		const sgo_chassis* gb = w->ground_dynamic ? g[i] : NULL;
+		const v3 r2 = gb ? v3_sub(w->contact_pos, gb->pos) : V3(0, 0, 0);
 		const v3 neg_n = v3_neg(w->contact_normal);
 		float lam;
 		if (w->sus_max > w->sus_min) {
@@ -604,20 +623,20 @@ static inline int sgo_vehicle_pre_b(sgo_vehicle* v, sgo_chassis* c, float dt)
 			const float damping = 2.0f * eff_mass * w->spring_damp * omega;
 			const float Cc = w->suspension_length - w->sus_max - w->sus_preload;
 			lam = w->suspension.lambda;
-			sgo_part_setup(&w->suspension, c, r1, neg_n, dt, Cc, stiffness, damping);
+			sgo_part_setup(&w->suspension, c, r1, gb, r2, neg_n, dt, Cc, stiffness, damping);
 			if (w->suspension.active) w->suspension.lambda = lam;
 		} else sgo_part_deactivate(&w->suspension);
 		if (w->suspension_length < w->sus_min) {
 			lam = w->max_up.lambda;
-			sgo_part_setup(&w->max_up, c, r1, neg_n, dt, 0.0f, 0.0f, 0.0f);
+			sgo_part_setup(&w->max_up, c, r1, gb, r2, neg_n, dt, 0.0f, 0.0f, 0.0f);
 			if (w->max_up.active) w->max_up.lambda = lam;
 			w->suspension_length = w->sus_min;
 		} else sgo_part_deactivate(&w->max_up);
 		/* the longitudinal row (engine / brake force) is never warm started: its impulse starts from zero every step */
-		sgo_part_setup(&w->longitudinal, c, r1, v3_neg(w->contact_long), dt, 0.0f, 0.0f, 0.0f);
+		sgo_part_setup(&w->longitudinal, c, r1, gb, r2, v3_neg(w->contact_long), dt, 0.0f, 0.0f, 0.0f);
 		w->longitudinal.lambda = 0.0f;
 		lam = w->lateral.lambda;
-		sgo_part_setup(&w->lateral, c, r1, v3_neg(w->contact_lat), dt, 0.0f, 0.0f, 0.0f);
+		sgo_part_setup(&w->lateral, c, r1, gb, r2, v3_neg(w->contact_lat), dt, 0.0f, 0.0f, 0.0f);
 		if (w->lateral.active) w->lateral.lambda = lam;
 	}
 	int spinning = 0;
@@ -626,27 +645,29 @@ static inline int sgo_vehicle_pre_b(sgo_vehicle* v, sgo_chassis* c, float dt)
 }
 
 /* VehicleConstraint::WarmStartVelocityConstraint */
-static inline void sgo_vehicle_warm_start(sgo_vehicle* v, sgo_chassis* c)
+static inline void sgo_vehicle_warm_start(sgo_vehicle* v, sgo_chassis* c, sgo_chassis* const* g)
 {
 	for (int i = 0; i < v->num_wheels; ++i) {
 		sgo_wheel* w = &v->wheels[i];
 		if (!w->has_contact) continue;
-		if (w->suspension.active) sgo_part_apply(&w->suspension, c, v3_neg(w->contact_normal), w->suspension.lambda);
-		if (w->max_up.active) sgo_part_apply(&w->max_up, c, v3_neg(w->contact_normal), w->max_up.lambda);
-		if (w->lateral.active) sgo_part_apply(&w->lateral, c, v3_neg(w->contact_lat), w->lateral.lambda);
+		sgo_chassis* gb = w->ground_dynamic ? g[i] : NULL;
+		if (w->suspension.active) sgo_part_apply(&w->suspension, c, gb, v3_neg(w->contact_normal), w->suspension.lambda);
+		if (w->max_up.active) sgo_part_apply(&w->max_up, c, gb, v3_neg(w->contact_normal), w->max_up.lambda);
+		if (w->lateral.active) sgo_part_apply(&w->lateral, c, gb, v3_neg(w->contact_lat), w->lateral.lambda);
 	}
 }
 
 /* VehicleConstraint::SolveVelocityConstraint + WheeledVehicleController::SolveLongitudinalAndLateralConstraints */
-static inline void sgo_vehicle_solve_velocity(sgo_vehicle* v, sgo_chassis* c, float dt)
+static inline void sgo_vehicle_solve_velocity(sgo_vehicle* v, sgo_chassis* c, sgo_chassis* const* g, float dt)
 {
 	const int nw = v->num_wheels;
 	for (int i = 0; i < nw; ++i) {
 		sgo_wheel* w = &v->wheels[i];
 		if (!w->has_contact) continue;
 		const v3 neg_n = v3_neg(w->contact_normal);
-		if (w->suspension.active) sgo_part_solve(&w->suspension, c, w->contact_point_vel, neg_n, 0.0f, 3.0e38f);   /* pushes, never pulls */
-		if (w->max_up.active) sgo_part_solve(&w->max_up, c, w->contact_point_vel, neg_n, 0.0f, 3.0e38f);
+		sgo_chassis* gb = w->ground_dynamic ? g[i] : NULL;
+		if (w->suspension.active) sgo_part_solve(&w->suspension, c, gb, w->contact_point_vel, neg_n, 0.0f, 3.0e38f);   /* pushes, never pulls */
+		if (w->max_up.active) sgo_part_solve(&w->max_up, c, gb, w->contact_point_vel, neg_n, 0.0f, 3.0e38f);
 	}
 	float max_lat[SGO_MAX_WHEELS];
 	for (int i = 0; i < nw; ++i) {
@@ -657,27 +678,28 @@ static inline void sgo_vehicle_solve_velocity(sgo_vehicle* v, sgo_chassis* c, fl
 		const float max_long = w->comb_long_fric * sus_lambda;
 		max_lat[i] = w->comb_lat_fric * sus_lambda;
 		if (!w->longitudinal.active) continue;
+		sgo_chassis* gb = w->ground_dynamic ? g[i] : NULL;
 		const v3 rel = v3_sub(sgo_chassis_point_vel(c, w->contact_pos), w->contact_point_vel);
 		const float rel_long = v3_dot(rel, w->contact_long);
 		if (w->brake_impulse != 0.0f) {
 			const float bi = fminf(w->brake_impulse, max_long);
 			float lo, hi;
 			if (rel_long >= 0.0f) { lo = -bi; hi = 0.0f; } else { lo = 0.0f; hi = bi; }
-			sgo_part_solve(&w->longitudinal, c, w->contact_point_vel, v3_neg(w->contact_long), lo, hi);
+			sgo_part_solve(&w->longitudinal, c, gb, w->contact_point_vel, v3_neg(w->contact_long), lo, hi);
 		} else {
 			/* impulse that brings the contact patch speed to the rolling speed of the wheel within this step */
 			const float desired_w = rel_long / w->radius;
 			const float lin_imp = (w->angular_velocity - desired_w) * w->inertia / w->radius;
 			const float prev = w->longitudinal.lambda;
 			const float lim = clampf(prev + lin_imp, -max_long, max_long);
-			sgo_part_solve(&w->longitudinal, c, w->contact_point_vel, v3_neg(w->contact_long), lim, lim);
+			sgo_part_solve(&w->longitudinal, c, gb, w->contact_point_vel, v3_neg(w->contact_long), lim, lim);
 			w->angular_velocity = w->angular_velocity - (w->longitudinal.lambda - prev) * w->radius / w->inertia;
 		}
 	}
 	for (int i = 0; i < nw; ++i) {
 		sgo_wheel* w = &v->wheels[i];
 		if (!w->has_contact || !w->lateral.active) continue;
-		sgo_part_solve(&w->lateral, c, w->contact_point_vel, v3_neg(w->contact_lat), -max_lat[i], max_lat[i]);
+		sgo_part_solve(&w->lateral, c, w->ground_dynamic ? g[i] : NULL, w->contact_point_vel, v3_neg(w->contact_lat), -max_lat[i], max_lat[i]);
 	}
 	if (v->is_motorcycle && v->lean_enabled) {
 		/* MotorcycleController::SolveLongitudinalAndLateralConstraints: lean spring (PID on the angle to the target lean), only
@@ -717,8 +739,9 @@ static inline void sgo_vehicle_solve_velocity(sgo_vehicle* v, sgo_chassis* c, fl
 }
 
 /* VehicleConstraint::SolvePositionConstraint: the axle at minimum suspension length must stay on the outer side of the plane
-   through the axle position at cast time.  Works on the chassis pose (c->pos, c->rot); c->I is recomputed from the pose. */
-static inline void sgo_vehicle_solve_position(sgo_vehicle* v, sgo_chassis* c, float baumgarte)
+   through the axle position at cast time.  Works on the poses (pos, rot) of the chassis and of a dynamic body under the wheel; the
+   world-space inertias are recomputed from the poses. */
+static inline void sgo_vehicle_solve_position(sgo_vehicle* v, sgo_chassis* c, sgo_chassis* const* g, float baumgarte)
 {
 	for (int i = 0; i < v->num_wheels; ++i) {
 		sgo_wheel* w = &v->wheels[i];
@@ -734,11 +757,22 @@ static inline void sgo_vehicle_solve_position(sgo_vehicle* v, sgo_chassis* c, fl
 			const sym33 I = world_inv_inertia(R, c->inv_inertia_local);
 			const v3 r1xa = v3_cross(r1, axis);
 			const v3 iI = sym33_mul(I, r1xa);
-			const float inv_eff = c->im + v3_dot(r1xa, iI);
+			float inv_eff = c->im + v3_dot(r1xa, iI);
+			sgo_chassis* gb = w->ground_dynamic ? g[i] : NULL;
+			v3 iI2 = V3(0, 0, 0);
+			if (gb) {
+				const v3 r2xa = v3_cross(v3_sub(w->contact_pos, gb->pos), axis);
+				iI2 = sym33_mul(world_inv_inertia(quat_to_m33(gb->rot), gb->inv_inertia_local), r2xa);
+				inv_eff = inv_eff + (gb->im + v3_dot(r2xa, iI2));
+			}
 			if (!(inv_eff > 0.0f)) continue;
 			const float lambda = -(1.0f / inv_eff) * baumgarte * err;
 			c->pos = v3_sub(c->pos, v3_scale(axis, lambda * c->im));
 			c->rot = quat_add_rotation_step(c->rot, v3_scale(iI, -lambda));
+			if (gb) {
+				gb->pos = v3_add(gb->pos, v3_scale(axis, lambda * gb->im));
+				gb->rot = quat_add_rotation_step(gb->rot, v3_scale(iI2, lambda));
+			}
 		}
 	}
 }

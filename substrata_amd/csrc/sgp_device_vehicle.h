@@ -7,8 +7,10 @@
 // max-up stop, longitudinal, lateral) and, for motorcycles, the lean spring.
 // Pre-step: one wave per vehicle, the record staged in LDS, wheel i's work on lane i and what couples the wheels on lane 0
 // (sgd_vehicle_precast_lanes, sgd_vehicle_controller_lanes); the casts spread 16 lanes per wheel (k_vehicle_cast).  Solver passes: four lanes
-// per vehicle on the lane-major row export (veh_quad_solve, sgp_kernels.hip), in the launch of contact colour 0.  Vehicles never share a
-// chassis and treat the body under a wheel as kinematic (its contact point velocity is sampled at cast time).
+// per vehicle on the lane-major row export (veh_quad_solve, sgp_kernels.hip), in the launch of contact colour 0.  The rows are two-body
+// constraints (round 4): a dynamic body under a wheel enters the effective masses, is read live and takes the reaction impulses, like body 2 of
+// Jolt's AxisConstraintPart in VehicleConstraint::SetupVelocityConstraint / SolveVelocityConstraint; tyre slip and the longitudinal target keep
+// using the contact point velocity sampled at cast time, as WheeledVehicleController does.
 // The arithmetic of a wheel (expression order included) is the contract checked by tests/test_vehicle_parity_gpu.py against the sequential CPU
 // statement; no libm call sits on this path (polynomial sin/cos/acos).
 #pragma once
@@ -18,7 +20,9 @@
 #define SGD_MAX_GEARS 8
 #define SGD_VEH_PI 3.14159265358979323846f
 
-// one row J = [-axis, -(r1 x axis)] against a kinematic second body (Jolt AxisConstraintPart + SpringPart)
+// one row J = [-axis, -(r1 x axis), axis, r2 x axis] between the chassis and the body under the wheel (Jolt AxisConstraintPart + SpringPart); the
+// body-2 terms exist only when that body is dynamic, and are rebuilt by the solver lanes from its pose (r2 x axis, I2^-1 (r2 x axis)): only the
+// effective mass, which contains them, is kept
 struct sgd_axis_part {
 	v3 r1xa;            // r1 x axis
 	v3 iI_r1xa;         // I1^-1 (r1 x axis)
@@ -37,6 +41,7 @@ struct sgd_wheel {
 	// state (JPH::Wheel / WheelWV)
 	float angular_velocity, angle, steer_angle, suspension_length;
 	int has_contact; uint32_t contact_body;
+	int ground_dynamic;                // the body under the wheel is dynamic: the rows act on it too
 	v3 contact_pos, contact_normal, contact_long, contact_lat, contact_point_vel;
 	float axle_plane_constant;
 	float anti_roll_impulse, brake_impulse;
@@ -80,6 +85,8 @@ struct sgd_vehicle {
 
 // chassis state as the vehicle rows see it
 struct sgd_chassis { v3 pos; quat rot; v3 v, w; float im; v3 inv_inertia_local; sym33 I; };
+// the dynamic body under a wheel as the row set-up sees it (dyn = 0: none, or not dynamic)
+struct sgd_ground { int dyn; v3 pos; float im; sym33 I; };
 
 SGP_DEV static float sgd_curve3(const float c[3][2], float x)
 {
@@ -259,12 +266,18 @@ SGP_DEV static float sgd_cast_sphere_body(int type, const float* p, const sgd_hu
 
 SGP_DEV static void sgd_part_deactivate(sgd_axis_part* p) { p->active = 0; p->lambda = 0.0f; p->eff = 0.0f; p->softness = 0.0f; p->bias = 0.0f; }
 
-// hard row, or soft row when stiffness > 0 (Jolt SpringPart::CalculateSpringPropertiesWithStiffnessAndDamping)
-SGP_DEV static void sgd_part_setup(sgd_axis_part* p, const sgd_chassis* c, v3 r1, v3 axis, float dt, float C, float stiffness, float damping)
+// hard row, or soft row when stiffness > 0 (Jolt SpringPart::CalculateSpringPropertiesWithStiffnessAndDamping); a dynamic body under the wheel adds
+// its share to the inverse effective mass after the chassis' (AxisConstraintPart::TemplatedCalculateInverseEffectiveMass)
+SGP_DEV static void sgd_part_setup(sgd_axis_part* p, const sgd_chassis* c, v3 r1, const sgd_ground* g, v3 r2, v3 axis, float dt, float C, float stiffness, float damping)
 {
 	p->r1xa = v3_cross(r1, axis);
 	p->iI_r1xa = sym33_mul(c->I, p->r1xa);
-	const float inv_eff = c->im + v3_dot(p->r1xa, p->iI_r1xa);
+	float inv_eff = c->im + v3_dot(p->r1xa, p->iI_r1xa);
+	if (g->dyn) {
+		const v3 r2xa = v3_cross(r2, axis);
+		const v3 iI_r2xa = sym33_mul(g->I, r2xa);
+		inv_eff = inv_eff + (g->im + v3_dot(r2xa, iI_r2xa));
+	}
 	if (!(inv_eff > 0.0f)) { sgd_part_deactivate(p); return; }
 	if (stiffness > 0.0f) {
 		p->softness = 1.0f / (dt * (damping + dt * stiffness));
@@ -342,7 +355,7 @@ SGP_DEV static void sgd_vehicle_precast_lanes(sgd_vehicle* v, const sgd_chassis*
 		w->cast_origin = v3_add(c->pos, m33_mul(R, w->position));
 		w->cast_dir = m33_mul(R, w->suspension_dir);
 		w->cast_len = w->sus_max + w->radius - v->cast_radius;
-		w->has_contact = 0; w->contact_body = 0xFFFFFFFFu;
+		w->has_contact = 0; w->contact_body = 0xFFFFFFFFu; w->ground_dynamic = 0;
 	}
 }
 
@@ -350,7 +363,7 @@ SGP_DEV static void sgd_vehicle_precast_lanes(sgd_vehicle* v, const sgd_chassis*
 SGP_DEV static void sgd_vehicle_set_hit(sgd_vehicle* v, int i, uint32_t body, float t, v3 n, v3 p, v3 ground_point_vel, float ground_friction)
 {
 	sgd_wheel* w = &v->wheels[i];
-	w->has_contact = 1; w->contact_body = body;
+	w->has_contact = 1; w->contact_body = body; w->ground_dynamic = 0;      // (k_vehicle_cast sets ground_dynamic)
 	w->contact_normal = n; w->contact_pos = p; w->contact_point_vel = ground_point_vel; w->ground_friction = ground_friction;
 	w->suspension_length = fmaxf(0.0f, t + v->cast_radius - w->radius);
 }
@@ -416,7 +429,8 @@ SGP_DEV static void sgd_differential_split(const sgd_differential* d, float wl, 
 // every lane to its own copy of the chassis (the same operands in the same order: the same bits, and no broadcast), the drivetrain runs on
 // lane 0 between two barriers.  A wheel's arithmetic is that of the sequential statement wheel after wheel: nothing a wheel computes in one
 // phase reads what another wheel computes in the same phase.  Returns (to every lane) whether the chassis' sleep timer must be reset.
-SGP_DEV static int sgd_vehicle_controller_lanes(sgd_vehicle* v, sgd_chassis* c, float dt, int lane)
+// `g`: the dynamic body under this lane's wheel (g->dyn = 0 if there is none).
+SGP_DEV static int sgd_vehicle_controller_lanes(sgd_vehicle* v, sgd_chassis* c, const sgd_ground* g, float dt, int lane)
 {
 	const m33 R = quat_to_m33(c->rot);
 	const int nw = v->num_wheels;
@@ -574,6 +588,7 @@ SGP_DEV static int sgd_vehicle_controller_lanes(sgd_vehicle* v, sgd_chassis* c, 
 			sgd_part_deactivate(&w->suspension); sgd_part_deactivate(&w->max_up); sgd_part_deactivate(&w->longitudinal); sgd_part_deactivate(&w->lateral);
 		} else {
 			const v3 r1 = v3_sub(w->contact_pos, c->pos);
+			const v3 r2 = g->dyn ? v3_sub(w->contact_pos, g->pos) : V3(0.0f, 0.0f, 0.0f);
 			const v3 neg_n = v3_neg(w->contact_normal);
 			float lam;
 			if (w->sus_max > w->sus_min) {
@@ -587,20 +602,20 @@ SGP_DEV static int sgd_vehicle_controller_lanes(sgd_vehicle* v, sgd_chassis* c, 
 				const float damping = 2.0f * eff_mass * w->spring_damp * omega;
 				const float Cc = w->suspension_length - w->sus_max - w->sus_preload;
 				lam = w->suspension.lambda;
-				sgd_part_setup(&w->suspension, c, r1, neg_n, dt, Cc, stiffness, damping);
+				sgd_part_setup(&w->suspension, c, r1, g, r2, neg_n, dt, Cc, stiffness, damping);
 				if (w->suspension.active) w->suspension.lambda = lam;
 			} else sgd_part_deactivate(&w->suspension);
 			if (w->suspension_length < w->sus_min) {
 				lam = w->max_up.lambda;
-				sgd_part_setup(&w->max_up, c, r1, neg_n, dt, 0.0f, 0.0f, 0.0f);
+				sgd_part_setup(&w->max_up, c, r1, g, r2, neg_n, dt, 0.0f, 0.0f, 0.0f);
 				if (w->max_up.active) w->max_up.lambda = lam;
 				w->suspension_length = w->sus_min;
 			} else sgd_part_deactivate(&w->max_up);
 			// the longitudinal row (engine / brake force) is never warm started: its impulse starts from zero every step
-			sgd_part_setup(&w->longitudinal, c, r1, v3_neg(w->contact_long), dt, 0.0f, 0.0f, 0.0f);
+			sgd_part_setup(&w->longitudinal, c, r1, g, r2, v3_neg(w->contact_long), dt, 0.0f, 0.0f, 0.0f);
 			w->longitudinal.lambda = 0.0f;
 			lam = w->lateral.lambda;
-			sgd_part_setup(&w->lateral, c, r1, v3_neg(w->contact_lat), dt, 0.0f, 0.0f, 0.0f);
+			sgd_part_setup(&w->lateral, c, r1, g, r2, v3_neg(w->contact_lat), dt, 0.0f, 0.0f, 0.0f);
 			if (w->lateral.active) w->lateral.lambda = lam;
 		}
 		if (fabsf(w->angular_velocity) > 10.0f * SGD_VEH_PI / 180.0f) spinning = 1;

@@ -92,6 +92,8 @@ struct StepCounters {
 	uint32_t bp_dense;           // some tile's halo held more records than the small instance of k_bp_pairs stages in LDS
 	uint32_t hc_probe_big;       // launch-plan probe: constraints of components too large for a workgroup if one more colour went to the components
 	uint32_t hc_done;            // workgroups of the running solve launch that have finished (the last one runs the catch-all and clears it)
+	uint32_t veh_deferred;       // vehicles that share a movable body (a dynamic body under a wheel, a chassis a wheel stands on) with a vehicle of lower index: solved after the others, in index order
+	uint32_t veh_done;           // workgroups of the running vehicle-row launch that have finished (the last one solves the deferred vehicles and clears it)
 	uint32_t ts_error;           // tile solver: a tile gave up waiting for a neighbour (k_step_end copies ts_flags[0])
 	uint32_t ts_all_adjacent;    // tile solver: some body was touched by more than four tiles
 	uint32_t round_n[32];        // uncoloured manifolds at the start of colouring round r (the host plans the next step's wide rounds from it)
@@ -282,6 +284,10 @@ struct DV {
 	struct sgd_vehicle* vehicles; uint32_t n_vehicles; const sgp_vehicle_input* vehicle_inputs;
 	// the rows of the step as the solver passes read them (k_vehicle_controller exports, veh_quad_solve consumes): 16 chunks per wheel, [chunk][4 vehicle + wheel]; 5 float4 per vehicle
 	float4* veh_rows; float4* veh_head; uint32_t veh_cap;
+	// the movable bodies a vehicle's rows act on this step (its chassis, the dynamic bodies under its wheels): [body] = step epoch << 32 | ~vehicle index, by
+	// atomicMax (k_vehicle_cast) -- the lowest vehicle index of the current step wins, entries of earlier steps lose against any of this step (no clearing);
+	// the contact colouring keeps such a body out of colour 0, a vehicle that lost a claim is deferred (veh_defer_bits, one bit per vehicle slot)
+	uint64_t* veh_claim; uint32_t* veh_epoch; uint32_t* veh_defer_bits;
 	// settings (fixed after world creation)
 	sgp_settings st;
 	float gx, gy, gz;

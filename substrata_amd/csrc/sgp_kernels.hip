@@ -149,6 +149,7 @@ __global__ void __launch_bounds__(TPB) k_step_begin(DV d, StepParams sp, uint32_
 		g.min_x = g.min_y = g.min_z = 0x7FFFFFFF; g.max_x = g.max_y = g.max_z = (int)0x80000000;
 		g.ox = g.oy = g.oz = 0.0f; g.inv_cell = 1.0f; g.cell = 1.0f; g.nx = g.ny = g.nz = 1; g.n_cells = 1;
 		*d.grid = g;
+		*d.veh_epoch = *d.veh_epoch + 1u;      // (device side: the by-value step parameters are part of a captured graph's key and must not change from step to step)
 	}
 	uint32_t* c = (uint32_t*)d.ctr;
 	for (uint32_t i = tid; i < sizeof(StepCounters) / 4; i += stride) c[i] = 0;
@@ -704,7 +705,9 @@ SGP_DEV sgd_shape load_shape(const DV& d, uint32_t i, uint32_t f)
 SGP_DEV uint32_t cache_find(const DV& d, uint64_t key);
 // Colours a body's contacts may not take: a vehicle's rows are solved in the same launch as the first contact colour of every pass (they come first
 // in the pass: non-contact constraints before contacts, as in PhysicsSystem's solve), so no contact of its chassis may sit in colour 0.
-SGP_DEV uint64_t chassis_colours(uint32_t f) { return (f & BF_CHASSIS) ? 1ull : 0ull; }
+// Round 4: the same holds for a dynamic body under a wheel of an active vehicle -- the wheel rows act on it (DV::veh_claim of the current step).
+SGP_DEV bool veh_body_claimed(const DV& d, uint32_t body) { return d.n_vehicles != 0u && (uint32_t)(d.veh_claim[body] >> 32) == *d.veh_epoch; }
+SGP_DEV uint64_t chassis_colours(const DV& d, uint32_t body, uint32_t f) { return ((f & BF_CHASSIS) || veh_body_claimed(d, body)) ? 1ull : 0ull; }
 #define MAN_PREV_LOOKUP 0xFFFFFFFFu
 // Every lane that calls this (the lanes active at the call) gets its own index from *counter: one atomic per wave instead of one per lane
 // (hundreds of thousands of atomics on ONE address serialise in L2: that, not the collision arithmetic, bounded the narrow phase).
@@ -1294,7 +1297,7 @@ __global__ void __launch_bounds__(TPB) k_colour_inherit(DV d)
 		const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
 		const bool ma = fa & BF_MOVABLE_CUR, mb = fb & BF_MOVABLE_CUR;
 		if ((ma && !(fa & BF_MOVABLE_PREV)) || (mb && !(fb & BF_MOVABLE_PREV))) continue;
-		if (pc == 0 && ((ma && (fa & BF_CHASSIS)) || (mb && (fb & BF_CHASSIS)))) continue;      // (the body became a chassis since: colour 0 is the vehicle's)
+		if (pc == 0 && ((ma && chassis_colours(d, ab.x, fa)) || (mb && chassis_colours(d, ab.y, fb)))) continue;      // (the body became a chassis since: colour 0 is the vehicle's)
 		d.man_colour[m] = pc;
 		if (ma) atomicOr((unsigned long long*)&d.colour_mask[ab.x], 1ull << pc);
 		if (mb) atomicOr((unsigned long long*)&d.colour_mask[ab.y], 1ull << pc);
@@ -1346,7 +1349,7 @@ __global__ void __launch_bounds__(TPB) k_colour_commit(DV d, uint32_t round)
 				const bool ma = f_movable(fa), mb = f_movable(fb);
 				const bool win = (!ma || claim[ab.x] == pr) && (!mb || claim[ab.y] == pr);
 				if (win) {
-					const uint64_t used = (ma ? d.colour_mask[ab.x] | chassis_colours(fa) : 0ull) | (mb ? d.colour_mask[ab.y] | chassis_colours(fb) : 0ull);
+					const uint64_t used = (ma ? d.colour_mask[ab.x] | chassis_colours(d, ab.x, fa) : 0ull) | (mb ? d.colour_mask[ab.y] | chassis_colours(d, ab.y, fb) : 0ull);
 					int col = __ffsll((long long)~used) - 1;
 					if (col < 0 || col > SGP_OVERFLOW_COLOUR) col = SGP_OVERFLOW_COLOUR;
 					d.man_colour[m] = col;
@@ -1438,7 +1441,7 @@ __global__ void __launch_bounds__(1024) k_colour_finish(DV d, uint32_t first_rou
 			const bool ma = f_movable(fa), mb = f_movable(fb);
 			const bool win = (!ma || claim[ab.x] == pr) && (!mb || claim[ab.y] == pr);
 			if (win) {
-				const uint64_t used = (ma ? d.colour_mask[ab.x] | chassis_colours(fa) : 0ull) | (mb ? d.colour_mask[ab.y] | chassis_colours(fb) : 0ull);
+				const uint64_t used = (ma ? d.colour_mask[ab.x] | chassis_colours(d, ab.x, fa) : 0ull) | (mb ? d.colour_mask[ab.y] | chassis_colours(d, ab.y, fb) : 0ull);
 				int col = __ffsll((long long)~used) - 1;
 				if (col < 0 || col > SGP_OVERFLOW_COLOUR) col = SGP_OVERFLOW_COLOUR;
 				d.man_colour[m] = col;
@@ -2871,11 +2874,30 @@ SGP_DEV uint32_t uf_find(const uint32_t* parent, uint32_t x)
 // bodies are spread everywhere, that is almost nothing, instead of one giant component of a hundred thousand sleepy bodies; an island
 // that really is about to sleep, or one whose only awake member is many hops away, still goes through the union-find, which
 // yields the same set of sleepers as before.
+// (the vehicles' row export, defined with the vehicle kernels below)
+#define VEH_HEAD_F4 5
+#define VEH_CHUNK_NORMAL 0
+SGP_DEV size_t veh_chunk_at(const DV& d, uint32_t k, int i, int c) { return (size_t)c * (4u * (size_t)d.veh_cap) + 4u * (size_t)k + (size_t)i; }
+// Edge k of the island graph: the contact constraints, then one link per wheel of an active vehicle that stands on a dynamic body (chassis, that
+// body) -- VehicleConstraint::BuildIslands links them, so a car and the loose box under its wheel fall asleep together or not at all.
+SGP_DEV uint32_t island_edges(const DV& d) { return d.ctr->n_constraints + 4u * d.n_vehicles; }
+SGP_DEV bool island_edge(const DV& d, uint32_t k, uint32_t n_con, uint2& ab)
+{
+	if (k < n_con) { ab = CUR(d).ab[k]; return true; }
+	const uint32_t e = k - n_con, v = e >> 2, i = e & 3u;
+	const float4 h0 = d.veh_head[(size_t)v * VEH_HEAD_F4];
+	if (!(__float_as_uint(h0.y) & 1u) || i >= __float_as_uint(h0.z)) return false;
+	const uint32_t wbits = __float_as_uint(d.veh_rows[veh_chunk_at(d, v, (int)i, VEH_CHUNK_NORMAL)].w);
+	if (!(wbits >> 5)) return false;
+	ab = make_uint2(__float_as_uint(h0.x), (wbits >> 5) - 1u);
+	return true;
+}
+
 __global__ void __launch_bounds__(TPB) k_island_mark(DV d)
 {
-	const uint32_t n_con = d.ctr->n_constraints;
-	for (uint32_t k = blockIdx.x * TPB + threadIdx.x; k < n_con; k += gridDim.x * TPB) {
-		const uint2 ab = CUR(d).ab[k];
+	const uint32_t n_con = d.ctr->n_constraints, n_edges = island_edges(d);
+	for (uint32_t k = blockIdx.x * TPB + threadIdx.x; k < n_edges; k += gridDim.x * TPB) {
+		uint2 ab; if (!island_edge(d, k, n_con, ab)) continue;
 		const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
 		if (!f_movable(fa) || !f_movable(fb)) continue;
 		const bool ka = !(fa & BF_CAN_SLEEP) || d.awake_mark[ab.x], kb = !(fb & BF_CAN_SLEEP) || d.awake_mark[ab.y];
@@ -2890,9 +2912,9 @@ __global__ void __launch_bounds__(TPB) k_island_mark(DV d)
 // an active pile (few sleepy bodies) does almost no union work.
 __global__ void __launch_bounds__(TPB) k_island_hook(DV d)
 {
-	const uint32_t n_con = d.ctr->n_constraints;
-	for (uint32_t k = blockIdx.x * TPB + threadIdx.x; k < n_con; k += gridDim.x * TPB) {
-	const uint2 ab = CUR(d).ab[k];
+	const uint32_t n_con = d.ctr->n_constraints, n_edges = island_edges(d);
+	for (uint32_t k = blockIdx.x * TPB + threadIdx.x; k < n_edges; k += gridDim.x * TPB) {
+	uint2 ab; if (!island_edge(d, k, n_con, ab)) continue;
 	const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
 	if (!f_movable(fa) || !f_movable(fb)) continue;
 	if (!(fa & BF_CAN_SLEEP) || !(fb & BF_CAN_SLEEP)) continue;
@@ -2910,9 +2932,9 @@ __global__ void __launch_bounds__(TPB) k_island_hook(DV d)
 
 __global__ void __launch_bounds__(TPB) k_island_flag(DV d)
 {
-	const uint32_t n_con = d.ctr->n_constraints;
-	for (uint32_t k = blockIdx.x * TPB + threadIdx.x; k < n_con; k += gridDim.x * TPB) {
-		const uint2 ab = CUR(d).ab[k];
+	const uint32_t n_con = d.ctr->n_constraints, n_edges = island_edges(d);
+	for (uint32_t k = blockIdx.x * TPB + threadIdx.x; k < n_edges; k += gridDim.x * TPB) {
+		uint2 ab; if (!island_edge(d, k, n_con, ab)) continue;
 		const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
 		if (!f_movable(fa) || !f_movable(fb)) continue;
 		// "undecided" = sleepy and not marked awake by k_island_mark; an undecided body next to a decided-awake one keeps its component up
@@ -3695,6 +3717,7 @@ __global__ void __launch_bounds__(64) k_vehicle_cast(DV d)
 	__shared__ sgd_vehicle sv;
 	const uint32_t k = blockIdx.x;
 	sgd_vehicle* gv = &d.vehicles[k];
+	if ((k & 31u) == 0u && threadIdx.x == 0) d.veh_defer_bits[k >> 5] = 0u;      // (k_vehicle_controller, the next launch, sets the bits of this step)
 	if (!gv->alive) return;
 	veh_stage_in(&sv, gv);
 	if (threadIdx.x == 0) {
@@ -3752,16 +3775,24 @@ __global__ void __launch_bounds__(64) k_vehicle_cast(DV d)
 			v3 gvel = V3(0.0f, 0.0f, 0.0f);
 			if (f_motion(fo) != SGP_MOTION_STATIC) gvel = v3_add(V3(d.vel[2 * (size_t)bid]), v3_cross(V3(d.vel[2 * (size_t)bid + 1]), v3_sub(bp, V3(d.pose[2 * (size_t)bid]))));
 			sgd_vehicle_set_hit(&sv, wi, bid, best, bn, bp, gvel, d.prop[2 * (size_t)bid + 1].w);
+			if (f_motion(fo) == SGP_MOTION_DYNAMIC) {
+				// the rows act on a dynamic body under the wheel (VehicleConstraint::SetupVelocityConstraint, body 2): it wakes up if it sleeps
+				// (VehicleConstraint::BuildIslands; k_pre_solve does it, like for a body an active one touches) and this vehicle claims it
+				sv.wheels[wi].ground_dynamic = 1;
+				if (!(fo & BF_ACTIVE)) atomicOr(&d.flags[bid], BF_WAKE);
+				atomicMax((unsigned long long*)&d.veh_claim[bid], ((unsigned long long)*d.veh_epoch << 32) | (unsigned long long)(0xFFFFFFFFu - k));
+			}
 		}
+		if (threadIdx.x == 0) atomicMax((unsigned long long*)&d.veh_claim[sv.body], ((unsigned long long)*d.veh_epoch << 32) | (unsigned long long)(0xFFFFFFFFu - k));
 	}
 	veh_stage_out(gv, &sv);
 }
 
-SGP_DEV void veh_export(const DV& d, uint32_t k, const sgd_vehicle& v);
-#define VEH_HEAD_F4 5
+SGP_DEV void veh_export(const DV& d, uint32_t k, const sgd_vehicle& v, int deferred);
 __global__ void __launch_bounds__(64) k_vehicle_controller(DV d)
 {
 	__shared__ sgd_vehicle sv;
+	int sv_deferred = 0;          // (uniform over the wave)
 	sgd_vehicle* gv = &d.vehicles[blockIdx.x];
 	if (!gv->alive || !gv->active) { if (threadIdx.x == 0) d.veh_head[(size_t)blockIdx.x * VEH_HEAD_F4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); return; }      // (no rows this step)
 	veh_stage_in(&sv, gv);
@@ -3770,14 +3801,28 @@ __global__ void __launch_bounds__(64) k_vehicle_controller(DV d)
 		const uint32_t b = sv.body;
 		sgd_chassis c = veh_chassis_pose_vel(d, b);
 		const float lvw = d.vel[2 * (size_t)b].w, avw = d.vel[2 * (size_t)b + 1].w;
-		const int spinning = sgd_vehicle_controller_lanes(&sv, &c, d.sp->dt, (int)threadIdx.x);
+		// lane i: the dynamic body under wheel i, as the row set-up needs it (inverse mass of the body, not of the step: a sleeper is woken by this step's k_pre_solve)
+		sgd_ground g; g.dyn = 0; g.pos = V3(0.0f, 0.0f, 0.0f); g.im = 0.0f; g.I = sym33_zero();
+		bool lost = false;
+		const unsigned long long my_claim = ((unsigned long long)*d.veh_epoch << 32) | (unsigned long long)(0xFFFFFFFFu - blockIdx.x);
+		if ((int)threadIdx.x < sv.num_wheels && sv.wheels[threadIdx.x].has_contact && sv.wheels[threadIdx.x].ground_dynamic) {
+			const uint32_t gb = sv.wheels[threadIdx.x].contact_body;
+			const float4 gp = d.pose[2 * (size_t)gb];
+			g.dyn = 1; g.pos = V3(gp); g.im = gp.w;
+			g.I = world_inv_inertia(quat_to_m33(Q4(d.pose[2 * (size_t)gb + 1])), V3(d.prop[2 * (size_t)gb]));
+			lost = d.veh_claim[gb] != my_claim;
+		}
+		if (threadIdx.x == 0 && d.veh_claim[b] != my_claim) lost = true;
+		// a vehicle that shares a movable body with one of lower index waits for it in every pass (veh_block_solve)
+		if (__any(lost)) { sv_deferred = 1; if (threadIdx.x == 0) { atomicOr(&d.veh_defer_bits[blockIdx.x >> 5], 1u << (blockIdx.x & 31u)); atomicAdd(&d.ctr->veh_deferred, 1u); } }
+		const int spinning = sgd_vehicle_controller_lanes(&sv, &c, &g, d.sp->dt, (int)threadIdx.x);
 		if (threadIdx.x == 0) {
 			if (spinning) d.sleep_timer[b] = 0.0f;
 			d.vel[2 * (size_t)b] = F4(c.v, lvw); d.vel[2 * (size_t)b + 1] = F4(c.w, avw);      // (the anti-roll impulses)
 		}
 	}
 	__syncthreads();
-	veh_export(d, blockIdx.x, sv);          // the rows of this step, lane-major, for the solver passes
+	veh_export(d, blockIdx.x, sv, sv_deferred);          // the rows of this step, lane-major, for the solver passes
 	veh_stage_out(gv, &sv);
 }
 
@@ -3792,7 +3837,7 @@ __global__ void __launch_bounds__(64) k_vehicle_controller(DV d)
 // the quads of sixteen vehicles share a wave, and the same code runs as the first workgroups of a contact-colour launch
 // (k_solve_colour_veh below).  Row impulses and wheel spin also go back to the vehicle record, which stays the one the host
 // reads and the next step's cast / controller kernels start from.
-#define VEH_CHUNK_NORMAL 0      // contact normal | bits: 1 has contact, 2 suspension row, 4 upper-stop row, 8 longitudinal row, 16 lateral row
+//      VEH_CHUNK_NORMAL 0      // contact normal | bits: 1 has contact, 2 suspension row, 4 upper-stop row, 8 longitudinal row, 16 lateral row; from bit 5: id + 1 of the DYNAMIC body under the wheel (0: none, the ground does not move under the rows)
 #define VEH_CHUNK_LONG 1        // longitudinal direction | combined longitudinal friction
 #define VEH_CHUNK_LAT 2         // lateral direction | combined lateral friction
 #define VEH_CHUNK_GVEL 3        // velocity of the ground at the contact point | brake impulse
@@ -3801,11 +3846,10 @@ __global__ void __launch_bounds__(64) k_vehicle_controller(DV d)
 #define VEH_CHUNK_ROW 6         // + 2 r: r1 x axis | effective mass;  + 2 r + 1: I^-1 (r1 x axis) | accumulated impulse (state); r = 0 suspension, 1 upper stop, 2 longitudinal, 3 lateral
 #define VEH_CHUNK_WPOS 14       // wheel position (chassis space) | minimum suspension length
 #define VEH_CHUNK_SDIR 15       // suspension direction (chassis space) | axle plane constant
-// VEH_HEAD_F4 = 5 float4 per vehicle: (body, bits: 1 active 2 lean spring on, wheels, integrated lean error), forward | K, up | D, target lean | Ki, (decay, applied lean impulse, -, -)
+// VEH_HEAD_F4 = 5 float4 per vehicle: (body, bits: 1 active 2 lean spring on 4 deferred (solved after the others, in index order), wheels, integrated lean error), forward | K, up | D, target lean | Ki, (decay, applied lean impulse, -, -)
 
 template <int I> SGP_DEV float quad_bcast(float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), I * 0x55, 0xF, 0xF, true)); }      // quad_perm [I, I, I, I]
 template <int I> SGP_DEV v3 quad_bcast(v3 a) { return V3(quad_bcast<I>(a.x), quad_bcast<I>(a.y), quad_bcast<I>(a.z)); }
-SGP_DEV size_t veh_chunk_at(const DV& d, uint32_t k, int i, int c) { return (size_t)c * (4u * (size_t)d.veh_cap) + 4u * (size_t)k + (size_t)i; }
 
 // the chunk (c) of wheel (i) of the vehicle record in LDS: what k_vehicle_controller's 64 lanes write out, one chunk each
 SGP_DEV float4 veh_export_chunk(const sgd_vehicle& v, int i, int c)
@@ -3813,7 +3857,8 @@ SGP_DEV float4 veh_export_chunk(const sgd_vehicle& v, int i, int c)
 	const sgd_wheel& w = v.wheels[i];
 	const sgd_axis_part* part[4] = { &w.suspension, &w.max_up, &w.longitudinal, &w.lateral };
 	if (i >= v.num_wheels) return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-	if (c == VEH_CHUNK_NORMAL) return F4(w.contact_normal, __uint_as_float((w.has_contact ? 1u : 0u) | (w.suspension.active ? 2u : 0u) | (w.max_up.active ? 4u : 0u) | (w.longitudinal.active ? 8u : 0u) | (w.lateral.active ? 16u : 0u)));
+	if (c == VEH_CHUNK_NORMAL) return F4(w.contact_normal, __uint_as_float((w.has_contact ? 1u : 0u) | (w.suspension.active ? 2u : 0u) | (w.max_up.active ? 4u : 0u) | (w.longitudinal.active ? 8u : 0u) | (w.lateral.active ? 16u : 0u)
+	                                                                       | ((w.has_contact && w.ground_dynamic) ? (w.contact_body + 1u) << 5 : 0u)));
 	if (c == VEH_CHUNK_LONG) return F4(w.contact_long, w.comb_long_fric);
 	if (c == VEH_CHUNK_LAT) return F4(w.contact_lat, w.comb_lat_fric);
 	if (c == VEH_CHUNK_GVEL) return F4(w.contact_point_vel, w.brake_impulse);
@@ -3824,12 +3869,12 @@ SGP_DEV float4 veh_export_chunk(const sgd_vehicle& v, int i, int c)
 	const sgd_axis_part& p = *part[(c - VEH_CHUNK_ROW) >> 1];
 	return ((c - VEH_CHUNK_ROW) & 1) ? F4(p.iI_r1xa, p.lambda) : F4(p.r1xa, p.eff);
 }
-SGP_DEV void veh_export(const DV& d, uint32_t k, const sgd_vehicle& v)
+SGP_DEV void veh_export(const DV& d, uint32_t k, const sgd_vehicle& v, int deferred)
 {
 	const int i = (int)(threadIdx.x & 3u), c = (int)(threadIdx.x >> 2);
 	d.veh_rows[veh_chunk_at(d, k, i, c)] = veh_export_chunk(v, i, c);
 	if (threadIdx.x < VEH_HEAD_F4) {
-		const uint32_t bits = (v.active ? 1u : 0u) | ((v.is_motorcycle && v.lean_enabled) ? 2u : 0u);
+		const uint32_t bits = (v.active ? 1u : 0u) | ((v.is_motorcycle && v.lean_enabled) ? 2u : 0u) | (deferred ? 4u : 0u);
 		float4 h;
 		if (threadIdx.x == 0) h = make_float4(__uint_as_float(v.body), __uint_as_float(bits), __uint_as_float((uint32_t)v.num_wheels), v.lean_integrated_delta);
 		else if (threadIdx.x == 1) h = F4(v.forward, v.lean_spring_constant);
@@ -3842,34 +3887,56 @@ SGP_DEV void veh_export(const DV& d, uint32_t k, const sgd_vehicle& v)
 
 // the chassis as the rows see it, one copy per lane of the quad
 struct VehBody { v3 v, w; float im; sym33 I; };
-// one row against the (kinematic) ground: AxisConstraintPart::SolveVelocityConstraint with the spring's softness and bias
-SGP_DEV void veh_row_solve(VehBody& c, float4 ra, float4& ri, float softness, float bias, v3 ground_vel, v3 axis, float lo, float hi)
+// the dynamic body under this lane's wheel (id == SGP_INVALID_ID: none): its velocity is read and written by the rows like the chassis'
+struct VehGround { uint32_t id; v3 v, w; float im; sym33 I; v3 r2; };
+// one row between the chassis and the ground: AxisConstraintPart::SolveVelocityConstraint with the spring's softness and bias.  A ground that is
+// not dynamic contributes the contact point velocity sampled at cast time (gvel); a dynamic one is read live and takes the reaction.
+SGP_DEV void veh_row_solve(VehBody& c, VehGround& g, float4 ra, float4& ri, float softness, float bias, v3 ground_vel, v3 axis, float lo, float hi)
 {
 	const v3 r1xa = V3(ra), iI = V3(ri);
-	const float jv = v3_dot(axis, v3_sub(c.v, ground_vel)) + v3_dot(r1xa, c.w);
+	const bool two = g.id != SGP_INVALID_ID;
+	v3 r2xa = V3(0.0f, 0.0f, 0.0f), iI2 = r2xa;
+	float jv;
+	if (two) {
+		r2xa = v3_cross(g.r2, axis);
+		iI2 = sym33_mul(g.I, r2xa);
+		jv = (v3_dot(axis, v3_sub(c.v, g.v)) + v3_dot(r1xa, c.w)) - v3_dot(r2xa, g.w);
+	} else jv = v3_dot(axis, v3_sub(c.v, ground_vel)) + v3_dot(r1xa, c.w);
 	const float lambda = ra.w * (jv - (softness * ri.w + bias));
 	const float nl = clampf(ri.w + lambda, lo, hi);
 	const float dl = nl - ri.w;
 	c.v = v3_sub(c.v, v3_scale(axis, dl * c.im));
 	c.w = v3_sub(c.w, v3_scale(iI, dl));
+	if (two) {
+		g.v = v3_add(g.v, v3_scale(axis, dl * g.im));
+		g.w = v3_add(g.w, v3_scale(iI2, dl));
+	}
 	ri.w = nl;
 }
-SGP_DEV void veh_row_apply(VehBody& c, float4 ri, v3 axis)
+SGP_DEV void veh_row_apply(VehBody& c, VehGround& g, float4 ri, v3 axis)
 {
 	c.v = v3_sub(c.v, v3_scale(axis, ri.w * c.im));
 	c.w = v3_sub(c.w, v3_scale(V3(ri), ri.w));
+	if (g.id != SGP_INVALID_ID) {
+		g.v = v3_add(g.v, v3_scale(axis, ri.w * g.im));
+		g.w = v3_add(g.w, v3_scale(sym33_mul(g.I, v3_cross(g.r2, axis)), ri.w));
+	}
 }
-// after lane I's turn: its chassis velocity becomes everybody's
-#define VEH_TURN(WI, ...) { if (L == WI) { __VA_ARGS__ } c.v = quad_bcast<WI>(c.v); c.w = quad_bcast<WI>(c.w); }
+template <int I> SGP_DEV uint32_t quad_bcast_u(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, I * 0x55, 0xF, 0xF, true); }
+// after lane I's turn: its chassis velocity becomes everybody's, and its ground's velocity that of every lane whose wheel stands on the same body
+#define VEH_TURN(WI, ...) { if (L == WI) { __VA_ARGS__ } c.v = quad_bcast<WI>(c.v); c.w = quad_bcast<WI>(c.w); \
+	{ const uint32_t og = quad_bcast_u<WI>(g.id); const v3 ov = quad_bcast<WI>(g.v), ow = quad_bcast<WI>(g.w); if (g.id != SGP_INVALID_ID && og == g.id) { g.v = ov; g.w = ow; } } }
 #define VEH_TURNS(...) VEH_TURN(0, __VA_ARGS__) VEH_TURN(1, __VA_ARGS__) VEH_TURN(2, __VA_ARGS__) VEH_TURN(3, __VA_ARGS__)
 
-// q = index of the quad among the launch's quads = vehicle slot; every lane of a quad takes the same branches up to the turns
-template <int MODE> SGP_DEV void veh_quad_solve(const DV& d, uint32_t k, int L)
+// k = vehicle slot, L = lane of its quad; every lane of a quad takes the same branches up to the turns.  DEFERRED: this call is the catch-all's
+// (vehicles that wait for one of lower index); the regular call skips those.
+template <int MODE> SGP_DEV void veh_quad_solve(const DV& d, uint32_t k, int L, bool deferred_pass)
 {
 	if (k >= d.n_vehicles) return;
 	const float4 h0 = d.veh_head[(size_t)k * VEH_HEAD_F4];
 	const uint32_t hbits = __float_as_uint(h0.y);
 	if (!(hbits & 1u)) return;                       // not alive, or the chassis was asleep when this step's pre-step ran
+	if (((hbits & 4u) != 0u) != deferred_pass) return;
 	const uint32_t b = __float_as_uint(h0.x);
 	const int nw = (int)__float_as_uint(h0.z);
 	sgd_vehicle* gv = &d.vehicles[k];
@@ -3877,15 +3944,20 @@ template <int MODE> SGP_DEV void veh_quad_solve(const DV& d, uint32_t k, int L)
 	const float4 cn = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_NORMAL)];
 	const uint32_t wbits = L < nw ? __float_as_uint(cn.w) : 0u;
 	const bool contact = wbits & 1u;
+	const uint32_t gid = (wbits >> 5) ? (wbits >> 5) - 1u : SGP_INVALID_ID;
 	const v3 neg_n = v3_neg(V3(cn));
 	if (MODE == 2) {
 		// VehicleConstraint::SolvePositionConstraint: the axle at minimum suspension length stays on the outer side of the plane through the
-		// axle position at cast time; wheel after wheel on the pose the previous one left
+		// axle position at cast time; wheel after wheel on the poses the previous one left (the chassis', and that of a dynamic body under the wheel)
 		const float4 cp = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_CPOS)], wp = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_WPOS)], sd = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_SDIR)];
 		const float4 p4 = d.pose[2 * (size_t)b], q4 = d.pose[2 * (size_t)b + 1];
 		const v3 iil = V3(d.prop[2 * (size_t)b]);
 		v3 pos = V3(p4); quat rot = Q4(q4);
 		const float im = p4.w, baumgarte = d.st.baumgarte;
+		float4 gp4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), gq4 = make_float4(0.0f, 0.0f, 0.0f, 1.0f); v3 giil = V3(0.0f, 0.0f, 0.0f);
+		if (gid != SGP_INVALID_ID) { gp4 = d.pose[2 * (size_t)gid]; gq4 = d.pose[2 * (size_t)gid + 1]; giil = V3(d.prop[2 * (size_t)gid]); }
+		v3 gpos = V3(gp4); quat grot = Q4(gq4);
+		bool gmoved = false;
 #define VEH_POS_TURN(WI) { \
 		if (L == WI && contact) { \
 			const m33 R = quat_to_m33(rot); \
@@ -3898,18 +3970,32 @@ template <int MODE> SGP_DEV void veh_quad_solve(const DV& d, uint32_t k, int L)
 				const sym33 I = world_inv_inertia(R, iil); \
 				const v3 r1xa = v3_cross(r1, neg_n); \
 				const v3 iI = sym33_mul(I, r1xa); \
-				const float inv_eff = im + v3_dot(r1xa, iI); \
+				float inv_eff = im + v3_dot(r1xa, iI); \
+				v3 iI2 = V3(0.0f, 0.0f, 0.0f); \
+				if (gid != SGP_INVALID_ID) { \
+					const v3 r2xa = v3_cross(v3_sub(V3(cp), gpos), neg_n); \
+					iI2 = sym33_mul(world_inv_inertia(quat_to_m33(grot), giil), r2xa); \
+					inv_eff = inv_eff + (gp4.w + v3_dot(r2xa, iI2)); \
+				} \
 				if (inv_eff > 0.0f) { \
 					const float lambda = -(1.0f / inv_eff) * baumgarte * err; \
 					pos = v3_sub(pos, v3_scale(neg_n, lambda * im)); \
 					rot = quat_add_rotation_step(rot, v3_scale(iI, -lambda)); \
+					if (gid != SGP_INVALID_ID) { \
+						gpos = v3_add(gpos, v3_scale(neg_n, lambda * gp4.w)); \
+						grot = quat_add_rotation_step(grot, v3_scale(iI2, lambda)); \
+						gmoved = true; \
+					} \
 				} \
 			} \
 		} \
-		pos = quad_bcast<WI>(pos); rot.x = quad_bcast<WI>(rot.x); rot.y = quad_bcast<WI>(rot.y); rot.z = quad_bcast<WI>(rot.z); rot.w = quad_bcast<WI>(rot.w); }
+		pos = quad_bcast<WI>(pos); rot.x = quad_bcast<WI>(rot.x); rot.y = quad_bcast<WI>(rot.y); rot.z = quad_bcast<WI>(rot.z); rot.w = quad_bcast<WI>(rot.w); \
+		{ const uint32_t og = quad_bcast_u<WI>(gid); const v3 op = quad_bcast<WI>(gpos); const float ox = quad_bcast<WI>(grot.x), oy = quad_bcast<WI>(grot.y), oz = quad_bcast<WI>(grot.z), ow = quad_bcast<WI>(grot.w); \
+		  if (L != WI && gid != SGP_INVALID_ID && og == gid) { gpos = op; grot.x = ox; grot.y = oy; grot.z = oz; grot.w = ow; } } }
 		VEH_POS_TURN(0) VEH_POS_TURN(1) VEH_POS_TURN(2) VEH_POS_TURN(3)
 #undef VEH_POS_TURN
 		if (L == 0) { d.pose[2 * (size_t)b] = F4(pos, p4.w); d.pose[2 * (size_t)b + 1] = make_float4(rot.x, rot.y, rot.z, rot.w); }
+		if (gmoved) { d.pose[2 * (size_t)gid] = F4(gpos, gp4.w); d.pose[2 * (size_t)gid + 1] = make_float4(grot.x, grot.y, grot.z, grot.w); }      // (the lane that moved it: a later lane on the same body started from this pose)
 		return;
 	}
 	// the rows of this lane's wheel
@@ -3921,21 +4007,33 @@ template <int MODE> SGP_DEV void veh_quad_solve(const DV& d, uint32_t k, int L)
 	c.v = V3(s0); c.im = s0.w; c.w = V3(s1);                  // (s0.w: the effective inverse mass of this step, k_pre_solve)
 	const quat crot = Q4(d.pose[2 * (size_t)b + 1]);
 	c.I = c.im > 0.0f ? world_inv_inertia(quat_to_m33(crot), V3(d.prop[2 * (size_t)b])) : sym33_zero();
+	float4 cp = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_CPOS)];
+	// the dynamic body under the wheel: velocity record (live), inverse mass, world inverse inertia, lever arm
+	VehGround g; g.id = gid; g.v = V3(0.0f, 0.0f, 0.0f); g.w = g.v; g.im = 0.0f; g.I = sym33_zero(); g.r2 = g.v;
+	float4 g0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), g1 = g0;
+	if (gid != SGP_INVALID_ID) {
+		g0 = d.vel[2 * (size_t)gid]; g1 = d.vel[2 * (size_t)gid + 1];
+		const float4 gp4 = d.pose[2 * (size_t)gid];
+		g.v = V3(g0); g.w = V3(g1); g.im = gp4.w;
+		g.I = world_inv_inertia(quat_to_m33(Q4(d.pose[2 * (size_t)gid + 1])), V3(d.prop[2 * (size_t)gid]));
+		g.r2 = v3_sub(V3(cp), V3(gp4));
+	}
 	if (MODE == 0) {
 		// VehicleConstraint::WarmStartVelocityConstraint: suspension, upper stop, lateral (the longitudinal row starts every step from zero)
 		const v3 neg_lat = v3_neg(V3(d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_LAT)]));
-		VEH_TURNS(if (contact) { if (wbits & 2u) veh_row_apply(c, ri[0], neg_n); if (wbits & 4u) veh_row_apply(c, ri[1], neg_n); if (wbits & 16u) veh_row_apply(c, ri[3], neg_lat); })
+		VEH_TURNS(if (contact) { if (wbits & 2u) veh_row_apply(c, g, ri[0], neg_n); if (wbits & 4u) veh_row_apply(c, g, ri[1], neg_n); if (wbits & 16u) veh_row_apply(c, g, ri[3], neg_lat); })
 		if (L == 0) { d.vel[2 * (size_t)b] = F4(c.v, s0.w); d.vel[2 * (size_t)b + 1] = F4(c.w, s1.w); }
+		if (gid != SGP_INVALID_ID) { d.vel[2 * (size_t)gid] = F4(g.v, g0.w); d.vel[2 * (size_t)gid + 1] = F4(g.w, g1.w); }
 		return;
 	}
 	const float4 cl = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_LONG)], ct = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_LAT)], cg = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_GVEL)];
-	float4 cp = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_CPOS)];
 	const float4 cm = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_MISC)];
 	const v3 cpos = V3(d.pose[2 * (size_t)b]);
 	const v3 gvel = V3(cg);
 	// 1. suspension spring and upper stop: push, never pull
-	VEH_TURNS(if (contact) { if (wbits & 2u) veh_row_solve(c, ra[0], ri[0], cm.z, cm.w, gvel, neg_n, 0.0f, 3.0e38f); if (wbits & 4u) veh_row_solve(c, ra[1], ri[1], 0.0f, 0.0f, gvel, neg_n, 0.0f, 3.0e38f); })
+	VEH_TURNS(if (contact) { if (wbits & 2u) veh_row_solve(c, g, ra[0], ri[0], cm.z, cm.w, gvel, neg_n, 0.0f, 3.0e38f); if (wbits & 4u) veh_row_solve(c, g, ra[1], ri[1], 0.0f, 0.0f, gvel, neg_n, 0.0f, 3.0e38f); })
 	// 2. longitudinal: the brake within the friction limit, or the impulse that brings the contact patch to the wheel's rolling speed in this step
+	//    (relative to the contact point velocity sampled at cast time, like WheeledVehicleController::SolveLongitudinalAndLateralConstraints)
 	const float sus_lambda = ri[0].w + ri[1].w;
 	const float max_long = cl.w * sus_lambda, max_lat = contact ? ct.w * sus_lambda : 0.0f;
 	VEH_TURNS(if (contact && (wbits & 8u)) {
@@ -3945,18 +4043,18 @@ template <int MODE> SGP_DEV void veh_quad_solve(const DV& d, uint32_t k, int L)
 			const float bi = fminf(cg.w, max_long);
 			float lo, hi;
 			if (rel_long >= 0.0f) { lo = -bi; hi = 0.0f; } else { lo = 0.0f; hi = bi; }
-			veh_row_solve(c, ra[2], ri[2], 0.0f, 0.0f, gvel, v3_neg(V3(cl)), lo, hi);
+			veh_row_solve(c, g, ra[2], ri[2], 0.0f, 0.0f, gvel, v3_neg(V3(cl)), lo, hi);
 		} else {
 			const float desired_w = rel_long / cm.x;
 			const float lin_imp = (cp.w - desired_w) * cm.y / cm.x;
 			const float prev = ri[2].w;
 			const float lim = clampf(prev + lin_imp, -max_long, max_long);
-			veh_row_solve(c, ra[2], ri[2], 0.0f, 0.0f, gvel, v3_neg(V3(cl)), lim, lim);
+			veh_row_solve(c, g, ra[2], ri[2], 0.0f, 0.0f, gvel, v3_neg(V3(cl)), lim, lim);
 			cp.w = cp.w - (ri[2].w - prev) * cm.x / cm.y;
 		}
 	})
 	// 3. lateral
-	VEH_TURNS(if (contact && (wbits & 16u)) veh_row_solve(c, ra[3], ri[3], 0.0f, 0.0f, gvel, v3_neg(V3(ct)), -max_lat, max_lat);)
+	VEH_TURNS(if (contact && (wbits & 16u)) veh_row_solve(c, g, ra[3], ri[3], 0.0f, 0.0f, gvel, v3_neg(V3(ct)), -max_lat, max_lat);)
 	// 4. MotorcycleController: the lean spring (a PID on the angle to the target lean), only with every wheel loaded; the matching linear impulse keeps
 	//    the contact patches from being swept sideways.  Every lane of the quad computes it (the sums run over the wheels in order 0..3).
 	float lean_integrated = h0.w, lean_applied = 0.0f;
@@ -3968,7 +4066,7 @@ template <int MODE> SGP_DEV void veh_quad_solve(const DV& d, uint32_t k, int L)
 		const float lam_w[4] = { quad_bcast<0>(lam), quad_bcast<1>(lam), quad_bcast<2>(lam), quad_bcast<3>(lam) };
 		const v3 arm_w[4] = { quad_bcast<0>(arm), quad_bcast<1>(arm), quad_bcast<2>(arm), quad_bcast<3>(arm) };
 		const uint32_t con = contact ? 1u : 0u;
-		const uint32_t con_w[4] = { (uint32_t)__builtin_amdgcn_mov_dpp((int)con, 0x00, 0xF, 0xF, true), (uint32_t)__builtin_amdgcn_mov_dpp((int)con, 0x55, 0xF, 0xF, true), (uint32_t)__builtin_amdgcn_mov_dpp((int)con, 0xAA, 0xF, 0xF, true), (uint32_t)__builtin_amdgcn_mov_dpp((int)con, 0xFF, 0xF, 0xF, true) };
+		const uint32_t con_w[4] = { quad_bcast_u<0>(con), quad_bcast_u<1>(con), quad_bcast_u<2>(con), quad_bcast_u<3>(con) };
 		bool all_in_contact = true;
 #pragma unroll
 		for (int i = 0; i < 4; ++i) if (i < nw && (!con_w[i] || !(lam_w[i] > 0.0f))) all_in_contact = false;
@@ -3994,7 +4092,7 @@ template <int MODE> SGP_DEV void veh_quad_solve(const DV& d, uint32_t k, int L)
 			c.v = v3_sub(c.v, v3_scale(lin_acc, 1.0f / total_lambda));
 		} else lean_integrated = lean_integrated * fmaxf(0.0f, 1.0f - h4.x * dt);
 	}
-	// state back: the row chunks (next pass), the vehicle record (host reads, next step's pre-step), the chassis velocity
+	// state back: the row chunks (next pass), the vehicle record (host reads, next step's pre-step), the velocities of the chassis and of the bodies under the wheels
 	if (L < nw) {
 #pragma unroll
 		for (int r = 0; r < 4; ++r) d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_ROW + 2 * r + 1)] = ri[r];
@@ -4002,6 +4100,7 @@ template <int MODE> SGP_DEV void veh_quad_solve(const DV& d, uint32_t k, int L)
 		gw->suspension.lambda = ri[0].w; gw->max_up.lambda = ri[1].w; gw->longitudinal.lambda = ri[2].w; gw->lateral.lambda = ri[3].w;
 		gw->angular_velocity = cp.w;
 	}
+	if (gid != SGP_INVALID_ID) { d.vel[2 * (size_t)gid] = F4(g.v, g0.w); d.vel[2 * (size_t)gid + 1] = F4(g.w, g1.w); }      // (lanes on the same body hold the same values)
 	if (L == 0) {
 		d.vel[2 * (size_t)b] = F4(c.v, s0.w); d.vel[2 * (size_t)b + 1] = F4(c.w, s1.w);
 		if (hbits & 2u) {
@@ -4015,12 +4114,39 @@ template <int MODE> SGP_DEV void veh_quad_solve(const DV& d, uint32_t k, int L)
 #undef VEH_TURNS
 #undef VEH_TURN
 
+// The vehicle rows of one pass by the workgroups [0, n_blocks) of a launch: every vehicle that shares no movable body with one of lower index by
+// its quad; the others (StepCounters::veh_deferred: two cars with a wheel on the same loose box, a car standing on another) afterwards, one after
+// the other in index order, by the first quad of the workgroup that finishes last -- the order a sequential solve visits them in.
+template <int MODE> SGP_DEV void veh_block_solve(const DV& d, uint32_t block, uint32_t n_blocks)
+{
+	__shared__ uint32_t s_veh_ticket;
+	const uint32_t t = block * blockDim.x + threadIdx.x;
+	veh_quad_solve<MODE>(d, t >> 2, (int)(t & 3u), false);
+	if (d.ctr->veh_deferred == 0u) return;
+	__syncthreads();
+	if (threadIdx.x == 0) { __threadfence(); s_veh_ticket = atomicAdd(&d.ctr->veh_done, 1u); }
+	__syncthreads();
+	if (s_veh_ticket != n_blocks - 1u) return;
+	if (threadIdx.x == 0) d.ctr->veh_done = 0u;      // for the next launch
+	__threadfence();          // what the other workgroups wrote (and this compute unit may still hold older copies of)
+	if (threadIdx.x >= 4u) return;
+	const uint32_t n_words = (d.n_vehicles + 31u) >> 5;
+	for (uint32_t wd = 0; wd < n_words; ++wd) {
+		uint32_t bits = d.veh_defer_bits[wd];
+		while (bits) {
+			const uint32_t k = (wd << 5) + (uint32_t)__ffs((int)bits) - 1u;
+			bits &= bits - 1u;
+			veh_quad_solve<MODE>(d, k, (int)threadIdx.x, true);
+			__threadfence_block();      // the next vehicle may read what this one wrote
+		}
+	}
+}
+
 #define VEH_SOLVE_TPB SOLVE_VEL_TPB      // 64 vehicles per workgroup
 // MODE 0 warm start, 1 velocity iteration, 2 position iteration (the chassis pose)
 template <int MODE> __global__ void __launch_bounds__(VEH_SOLVE_TPB) k_vehicle_solve(DV d)
 {
-	const uint32_t t = blockIdx.x * VEH_SOLVE_TPB + threadIdx.x;
-	veh_quad_solve<MODE>(d, t >> 2, (int)(t & 3u));
+	veh_block_solve<MODE>(d, blockIdx.x, gridDim.x);
 }
 
 // The first contact colour of a velocity / position pass with the vehicles' rows in the same launch: no contact of a chassis sits in colour 0
@@ -4030,8 +4156,7 @@ template <int MODE, int ROWS = -1> __global__ void __launch_bounds__(SOLVE_VEL_T
 {
 	const int colour = colour_arg & 0xFF;
 	if (blockIdx.x < veh_blocks) {
-		const uint32_t t = blockIdx.x * SOLVE_VEL_TPB + threadIdx.x;
-		veh_quad_solve<MODE>(d, t >> 2, (int)(t & 3u));
+		veh_block_solve<MODE>(d, blockIdx.x, veh_blocks);
 		return;
 	}
 	const uint32_t first = d.cstarts[colour], end = d.cstarts[colour + 1];

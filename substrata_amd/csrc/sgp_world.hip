@@ -298,6 +298,7 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	for (int k = 0; k < 3; ++k) DEV_ALLOC(d.sleep_s[k], N);
 	DEV_ALLOC(d.sleep_timer, N); DEV_ALLOC(d.submerged, N); DEV_ALLOC(d.userdata, N);
 	DEV_ALLOC(d.colour_mask, N); DEV_ALLOC(d.body_con, (size_t)N * SGP_MAX_COLOURS); DEV_ALLOC(d.claim[0], N); DEV_ALLOC(d.claim[1], N);
+	DEV_ALLOC(d.veh_claim, N); DEV_ALLOC(d.veh_epoch, 1);
 	DEV_ALLOC(d.island, N); DEV_ALLOC(d.island_awake, N); DEV_ALLOC(d.awake_mark, N); DEV_ALLOC(d.export_counts, N / 256 + 2);
 	// cells of the broad-phase grid: room for 16 per body slot (clearing and scanning follow the cells a step's grid really has, not this capacity).  The grid covers the bounds of all small bodies with cells of R_max + margin and coarsens them
 	// (x 1.5) until it fits this table: a pile that has spread out (config 2 after its tower fell: 60 x 60 x 10 m of 1 m cells) then lands in
@@ -1374,6 +1375,7 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	st.num_overflow_constraints = c1.colour_count[SGP_OVERFLOW_COLOUR];
 	st.num_cached_manifolds = c1.n_cached;
 	st.num_component_constraints = c1.hc_n; st.num_catch_all_constraints = c1.hc_n_big;
+	st.num_deferred_vehicles = c1.veh_deferred;
 	st.tile_solver = plan.tile_solver ? (c1.ts_all_adjacent ? 2u : 1u) : 0u;
 	st.pairs_dropped = c1.pairs_dropped; st.manifolds_dropped = c1.manifolds_dropped;
 	st.device_bytes = w->device_bytes;
@@ -1882,7 +1884,7 @@ SGP_API int sgp_vehicle_create(sgp_world* w, const sgp_vehicle_desc* d, uint32_t
 			if (w->n_vehicles) HIP_TRY(hipMemcpyAsync(nv, w->d_vehicles, sizeof(sgd_vehicle) * w->n_vehicles, hipMemcpyDeviceToDevice, w->stream));
 			HIP_TRY(hipStreamSynchronize(w->stream));
 			// (the row export of the solver passes is rebuilt by every step's controller kernel: nothing to carry over)
-			const size_t row_bytes = sizeof(float4) * 16u * 4u * nc, head_bytes = sizeof(float4) * 5u * nc;
+			const size_t row_bytes = sizeof(float4) * 16u * 4u * nc, head_bytes = sizeof(float4) * 5u * nc + sizeof(uint32_t) * (nc / 32u + 4u);      // (+ one bit per slot behind the heads: DV::veh_defer_bits)
 			float4* nr = nullptr; float4* nh = nullptr;
 			HIP_TRY(hipMalloc((void**)&nr, row_bytes));
 			HIP_TRY(hipMalloc((void**)&nh, head_bytes));
@@ -1906,6 +1908,7 @@ SGP_API int sgp_vehicle_create(sgp_world* w, const sgp_vehicle_desc* d, uint32_t
 	w->veh_alive[id] = 1; w->veh_body[id] = d->body; w->veh_inputs[id] = sgp_vehicle_input{ 0.0f, 0.0f, 0.0f, 0.0f }; w->veh_inputs_dirty = true;
 	w->dv.vehicles = w->d_vehicles; w->dv.vehicle_inputs = w->d_veh_inputs; w->dv.n_vehicles = w->n_vehicles;
 	w->dv.veh_rows = w->d_veh_rows; w->dv.veh_head = w->d_veh_head; w->dv.veh_cap = w->cap_vehicles;
+	w->dv.veh_defer_bits = (uint32_t*)(w->d_veh_head + 5u * (size_t)w->cap_vehicles);
 	{ BodyCmd c = blank_cmd(d->body, CMD_SET_CHASSIS); c.flags = BF_CHASSIS; w->cmds.push_back(c); w->hb[d->body].flags |= BF_CHASSIS; }
 	invalidate_graphs(w);
 	w->dirty_since_step = true;

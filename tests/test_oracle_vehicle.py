@@ -257,3 +257,81 @@ def test_motorcycle_lean_controller(oracle):
         w2.vehicle_set_input(v2, forward=0.5 if s > 30 else 0.0)
         w2.step(DT)
     assert abs(roll_deg(w2.get_state([b2])[0]["rot"])) > 60.0               # on its side
+
+
+# ---- round 4: the wheel rows are two-body constraints (JPH::VehicleConstraint solves them between the chassis and the body under the wheel) ----
+
+def _car_on_floating_plate(oracle, plate_mass=600.0):
+    """A car over a free-floating plate (no gravity on the plate, no damping anywhere, no ground): only the wheel rows connect the two."""
+    w = oracle.OracleWorld(max_bodies=16)
+    plate = dyn(w, shape=(3.0, 4.0, 0.2, 0.0), pos=(0, 0, -0.2), mass=plate_mass, gravity_factor=0.0, lin_damp=0.0, ang_damp=0.0, friction=1.0)
+    body = dyn(w, shape=(0.9, 2.0, 0.25, 0.0), pos=(0, 0, 0.75), mass=1200.0, friction=0.5, restitution=0.0, lin_damp=0.0, ang_damp=0.0)
+    vid = w.vehicle_create(w.default_vehicle_desc(body))
+    return w, plate, body, vid
+
+
+def test_wheels_push_back_on_the_body_they_stand_on(oracle):
+    """Every impulse of a wheel row acts on the chassis and, reversed, on a dynamic body under the wheel: the pair's momentum changes by gravity
+    on the car alone.  (Up to round 3 the body under a wheel was kinematic for the rows: the plate would never move.)"""
+    w, plate, body, vid = _car_on_floating_plate(oracle)
+    n = 45
+    settle(w, n)
+    sc, sp = w.get_state([body])[0], w.get_state([plate])[0]
+    assert all(x["has_contact"] == 1 for x in w.vehicle_get_state(vid)["wheels"])
+    pz = 1200.0 * sc["lin_vel"][2] + 600.0 * sp["lin_vel"][2]
+    assert abs(pz - (-1200.0 * G * n * DT)) < 2e-3 * 1200.0 * G * n * DT, (pz, -1200.0 * G * n * DT)
+    assert sp["lin_vel"][2] < -1.0                                        # the suspension pushes the plate down
+    assert sc["lin_vel"][2] > -G * n * DT + 1.0                            # ... and holds the car up against it
+    w.close()
+
+
+def test_tyre_forces_act_on_the_body_under_the_wheels(oracle):
+    """Throttle on a free-floating plate: the longitudinal rows push the plate backwards with what they push the car forwards with."""
+    w, plate, body, vid = _car_on_floating_plate(oracle, plate_mass=2400.0)
+    settle(w, 20)
+    w.vehicle_set_input(vid, forward=1.0)
+    settle(w, 40)
+    sc, sp = w.get_state([body])[0], w.get_state([plate])[0]
+    py = 1200.0 * sc["lin_vel"][1] + 2400.0 * sp["lin_vel"][1]
+    px = 1200.0 * sc["lin_vel"][0] + 2400.0 * sp["lin_vel"][0]
+    assert sc["lin_vel"][1] > 0.5 and sp["lin_vel"][1] < -0.2, (sc["lin_vel"], sp["lin_vel"])
+    assert abs(py) < 2e-3 * 1200.0 * abs(sc["lin_vel"][1]) and abs(px) < 1e-2
+    w.close()
+
+
+def test_a_wheel_wakes_the_sleeping_body_under_it(oracle):
+    """VehicleConstraint::BuildIslands activates the dynamic bodies the wheels touch and links them with the chassis: car and plate fall asleep
+    together, and driver input wakes both in the same step although only the wheels touch the plate."""
+    w = oracle.OracleWorld(max_bodies=16)
+    add_ground(w)
+    plate = dyn(w, shape=(3.0, 4.0, 0.1, 0.0), pos=(0, 0, 0.1), mass=4000.0, friction=0.8)
+    body, vid = add_car(w, pos=(0, 0, 0.95))
+    settle(w, 400)
+    sc, sp = w.get_state([body])[0], w.get_state([plate])[0]
+    assert sc["active"] == 0 and sp["active"] == 0
+    assert abs(sp["pos"][2] - 0.1) < 0.03                                  # the plate carries the car: it rests on the ground, not pushed through it
+    w.vehicle_set_input(vid, forward=0.3)
+    w.step(DT)
+    assert w.get_state([body])[0]["active"] == 1 and w.get_state([plate])[0]["active"] == 1
+    w.close()
+
+
+def test_a_car_on_a_light_box_loads_it(oracle):
+    """a car parked with one wheel on a 50 kg box pushes it into the ground with the wheel's load -- seen as the friction that now
+    holds the box: a sideways shove that would send a free 50 kg box sliding is resisted by mu * (box weight + wheel load)."""
+    def run(with_car):
+        w = oracle.OracleWorld(max_bodies=16)
+        add_ground(w, friction=1.0)
+        box = dyn(w, shape=(0.3, 0.3, 0.1, 0.0), pos=(0.8, 1.3, 0.1), mass=50.0, friction=1.0, allow_sleeping=0)
+        if with_car:
+            add_car(w, pos=(0, 0, 0.95))
+        settle(w, 180)
+        x0 = float(w.get_state([box])[0]["pos"][0])
+        for _ in range(30):
+            w.add_force(box, (900.0, 0.0, 0.0))      # mu m g = 490 N alone; with a quarter of the car on top ~ 3400 N
+            w.step(DT)
+        x1 = float(w.get_state([box])[0]["pos"][0])
+        w.close()
+        return x1 - x0
+    assert run(False) > 0.3
+    assert abs(run(True)) < 0.02

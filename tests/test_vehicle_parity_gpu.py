@@ -116,3 +116,107 @@ def test_vehicle_lifecycle_and_errors():
     w.vehicle_reset_drivetrain(v3, 0.0, 0.0)
     assert w.vehicle_get_state(v3)["engine_rpm"] == 0.0
     w.close()
+
+
+# ---- round 4: two-body wheel rows (the dynamic body under a wheel takes the reaction; VehicleConstraint::SetupVelocityConstraint) ----
+
+def _states_exact(tw, n, what):
+    d = parity.compare(tw, n)
+    assert d["active_mismatch"] == 0 and d["bit_exact"], (what, d)
+    return d
+
+
+def test_wheel_rows_push_back_on_a_floating_plate(oracle):
+    """The KAT of tests/test_oracle_vehicle.py on the device: car + free plate conserve momentum (gravity acts on the car only), and the
+    device agrees with the oracle bit for bit while the plate sinks away under the wheels and is driven backwards by the tyres."""
+    from helpers import dyn
+    tw = parity.make_twin(oracle, max_bodies=64)
+    ids = []
+    for w in (tw.gpu, tw.cpu):
+        p = dyn(w, shape=(3.0, 4.0, 0.2, 0.0), pos=(0, 0, -0.2), mass=600.0, gravity_factor=0.0, lin_damp=0.0, ang_damp=0.0, friction=1.0)
+        b = dyn(w, shape=(0.9, 2.0, 0.25, 0.0), pos=(0, 0, 0.75), mass=1200.0, friction=0.5, restitution=0.0, lin_damp=0.0, ang_damp=0.0)
+        ids.append((p, b, w.vehicle_create(w.default_vehicle_desc(b))))
+    assert ids[0] == ids[1]
+    plate, body, vid = ids[0]
+    n = 45
+    for s in range(n):
+        tw.step(DT)
+    _states_exact(tw, 2, "sinking plate")
+    sc, sp = tw.gpu.get_state([body])[0], tw.gpu.get_state([plate])[0]
+    pz = 1200.0 * sc["lin_vel"][2] + 600.0 * sp["lin_vel"][2]
+    assert abs(pz - (-1200.0 * 9.81 * n * DT)) < 2e-3 * 1200.0 * 9.81 * n * DT
+    assert sp["lin_vel"][2] < -1.0
+    tw.vehicle_set_input(vid, forward=1.0, right=0.3)
+    for s in range(60):
+        tw.step(DT)
+    _states_exact(tw, 2, "driven plate")
+    sg, sc_ = tw.vehicle_get_states(0, 1)
+    assert vehicle_diff(sg, sc_)["bit_exact"]
+    assert tw.gpu.get_state([plate])[0]["lin_vel"][1] < -0.1
+    tw.close()
+
+
+def test_vehicles_sharing_a_body_are_solved_in_index_order(oracle):
+    """Two cars on one dynamic plate and a small car standing on the flat bed of a third: their rows act on a common movable body, so the
+    device solves the later ones after the earlier ones (StepCounters::veh_deferred, veh_block_solve) -- same bits as the oracle's loop."""
+    from helpers import dyn, add_ground
+    tw = parity.make_twin(oracle, max_bodies=128)
+    recs = []
+    for w in (tw.gpu, tw.cpu):
+        add_ground(w)
+        plate = dyn(w, shape=(6.0, 5.0, 0.15, 0.0), pos=(0, 0, 0.15), mass=3000.0, friction=0.9)
+        a, va = add_car(w, pos=(-2.5, 0, 1.05))
+        b, vb = add_car(w, pos=(2.5, 0, 1.05))
+        bed = dyn(w, shape=(1.6, 3.2, 0.2, 0.0), pos=(0, 12.0, 0.8), mass=4000.0, friction=0.8, restitution=0.0)
+        vbed = w.vehicle_create(w.default_vehicle_desc(bed))
+        top = dyn(w, shape=(0.9, 2.0, 0.25, 0.0), pos=(0, 12.0, 1.75), mass=600.0, friction=0.5, restitution=0.0)
+        vtop = w.vehicle_create(w.default_vehicle_desc(top))
+        for k in range(6):
+            dyn(w, pos=(-4.0 + 1.6 * k, 3.0, 0.9), mass=30.0)
+        recs.append((plate, a, va, b, vb, bed, vbed, top, vtop))
+    assert recs[0] == recs[1]
+    plate, a, va, b, vb, bed, vbed, top, vtop = recs[0]
+    nb = 12
+    deferred_seen = 0
+    for s in range(300):
+        if s == 60:
+            tw.vehicle_set_input(va, forward=1.0, right=0.4)
+            tw.vehicle_set_input(vb, forward=-1.0, right=-0.2)
+            tw.vehicle_set_input(vtop, forward=0.6)
+        if s == 150:
+            tw.vehicle_set_input(vbed, forward=1.0)
+            tw.vehicle_set_input(va, brake=1.0)
+        tw.step(DT)
+        stg, stc = tw.gpu.stats(), tw.cpu.stats()
+        assert stg.num_deferred_vehicles == stc.num_deferred_vehicles, (s, stg.num_deferred_vehicles, stc.num_deferred_vehicles)
+        deferred_seen = max(deferred_seen, stg.num_deferred_vehicles)
+        if s in (0, 1, 30, 59, 61, 90, 149, 151, 200, 299):
+            _states_exact(tw, nb + 1, s)
+            sg, sc = tw.vehicle_get_states(0, 4)
+            vd = vehicle_diff(sg, sc)
+            assert vd["bit_exact"], (s, vd)
+    assert deferred_seen >= 2, deferred_seen          # the second car on the plate and the car on the flat bed
+    tw.close()
+
+
+def test_a_wheel_wakes_the_plate_and_they_sleep_together(oracle):
+    from helpers import dyn, add_ground
+    tw = parity.make_twin(oracle, max_bodies=64)
+    recs = []
+    for w in (tw.gpu, tw.cpu):
+        add_ground(w)
+        plate = dyn(w, shape=(3.0, 4.0, 0.1, 0.0), pos=(0, 0, 0.1), mass=4000.0, friction=0.8)
+        body, vid = add_car(w, pos=(0, 0, 0.95))
+        recs.append((plate, body, vid))
+    plate, body, vid = recs[0]
+    for s in range(400):
+        tw.step(DT)
+    d = _states_exact(tw, 3, "asleep")
+    assert tw.gpu.get_state([body])[0]["active"] == 0 and tw.gpu.get_state([plate])[0]["active"] == 0
+    tw.vehicle_set_input(vid, forward=0.3)
+    tw.step(DT)
+    assert tw.gpu.get_state([body])[0]["active"] == 1 and tw.gpu.get_state([plate])[0]["active"] == 1
+    for s in range(120):
+        tw.step(DT)
+    _states_exact(tw, 3, "driving off")
+    tw.close()
