@@ -126,28 +126,66 @@ namespace JPH
 			updateSupportingContact(c, true);
 		}
 
+		// The pieces of ExtendedUpdate under their own names: PlayerPhysics.cpp:357-446 calls them one by one (its own copy of the sequence).
+		Vec3 GetUp() const { return settings.mUp; }
+		// the part of `desired` that does not push into a slope too steep to stand on (only while such a slope is what we are on / against)
+		Vec3 CancelVelocityTowardsSteepSlopes(Vec3Arg desired) const
+		{
+			if (ground_state == EGroundState::OnGround || ground_state == EGroundState::InAir) return desired;
+			Vec3 v = desired;
+			for (const Contact& c : active) {
+				if (c.sensor || !touching(c) || !IsSlopeTooSteep(c.normal)) continue;
+				const Vec3 h = c.normal - settings.mUp * dot(c.normal, settings.mUp);
+				const float towards = dot(h, v), l2 = h.LengthSq();
+				if (towards < 0.0f && l2 > 1.0e-12f) v = v - h * (towards / l2);
+			}
+			return v;
+		}
+		// supported, moving horizontally, and pushing into something too steep to walk up: a step to try
+		bool CanWalkStairs(Vec3Arg velocity) const
+		{
+			if (!IsSupported()) return false;
+			const Vec3 hv = velocity - settings.mUp * dot(velocity, settings.mUp);
+			if (hv.LengthSq() < 1.0e-12f) return false;
+			for (const Contact& c : active) if (!c.sensor && touching(c) && dot(c.normal, hv - c.velocity) < 0.0f && IsSlopeTooSteep(c.normal)) return true;
+			return false;
+		}
+		bool StickToFloor(Vec3Arg step_down, const BroadPhaseLayerFilter&, const ObjectLayerFilter&, const BodyFilter& bf, const ShapeFilter&, TempAllocator&) { return stickToFloor(step_down, bf.ignored()); }
+		bool WalkStairs(float dt, Vec3Arg step_up, Vec3Arg step_forward, Vec3Arg step_forward_test, Vec3Arg step_down_extra, const BroadPhaseLayerFilter&, const ObjectLayerFilter&,
+		                const BodyFilter& bf, const ShapeFilter&, TempAllocator&) { return walkStairs(dt, step_up, step_forward, step_forward_test, step_down_extra, bf.ignored()); }
+
+		// Update + stick to the floor when walking off an edge + climb a step when a steep face stopped the horizontal move (CharacterVirtual::ExtendedUpdate)
 		void ExtendedUpdate(float dt, Vec3Arg gravity, const ExtendedUpdateSettings& ext, const BroadPhaseLayerFilter& bp, const ObjectLayerFilter& ol, const BodyFilter& bf, const ShapeFilter& sf, TempAllocator& ta)
 		{
-			const bool was_on_ground = ground_state == EGroundState::OnGround;
-			const Vec3 old_position = position;
-			const Vec3 desired_horizontal = linear_velocity - settings.mUp * dot(linear_velocity, settings.mUp);
+			const Vec3 up = settings.mUp, wanted = linear_velocity;
+			linear_velocity = CancelVelocityTowardsSteepSlopes(wanted);
+			const Vec3 before = position;
+			bool left_the_ground = IsSupported();
 			Update(dt, gravity, bp, ol, bf, sf, ta);
-			const uint32_t ignore = bf.ignored();
-			// StickToFloor: we were walking and are now in the air without moving up -> follow the floor down
-			if (was_on_ground && ground_state == EGroundState::InAir && ext.mStickToFloorStepDown.LengthSq() > 0 && dot(linear_velocity, settings.mUp) <= 1.0e-6f) stickToFloor(ext.mStickToFloorStepDown, ignore);
-			// WalkStairs: we wanted to go somewhere horizontally, hit something steep and did not get there
-			if (ext.mWalkStairsStepUp.LengthSq() > 0 && (was_on_ground || IsSupported()) && blocked_by_steep && desired_horizontal.LengthSq() > 1.0e-8f) {
-				const Vec3 achieved = position - old_position;
-				const Vec3 achieved_h = achieved - settings.mUp * dot(achieved, settings.mUp);
-				const float want = std::sqrt(desired_horizontal.LengthSq()) * dt;
-				if (dot(achieved_h, desired_horizontal) < 0.95f * want * std::sqrt(desired_horizontal.LengthSq())) walkStairs(dt, desired_horizontal, achieved_h, ext, ignore);
-			}
+			if (IsSupported()) left_the_ground = false;
+			if (left_the_ground && ext.mStickToFloorStepDown.LengthSq() > 0.0f && dot(position - before, up) / dt <= 1.0e-6f) StickToFloor(ext.mStickToFloorStepDown, bp, ol, bf, sf, ta);
+			if (!(ext.mWalkStairsStepUp.LengthSq() > 0.0f)) return;
+			Vec3 want_h = wanted * dt; want_h = want_h - up * dot(want_h, up);
+			const float want_len = std::sqrt(want_h.LengthSq());
+			if (!(want_len > 0.0f)) return;
+			const Vec3 ahead = want_h * (1.0f / want_len);
+			Vec3 got = position - before; got = got - up * dot(got, up);
+			const float got_len = std::max(0.0f, dot(got, ahead));                       // only progress in the wanted direction counts
+			if (!(got_len + 1.0e-4f < want_len) || !CanWalkStairs(wanted)) return;
+			const Vec3 step_forward = ahead * std::max(ext.mWalkStairsMinStepForward, want_len - got_len);
+			// where to look for a floor if the step's nose is what we land on: against the ground normal, unless that points too far off our way
+			Vec3 test = ground_normal * -1.0f; test = test - up * dot(test, up);
+			const float tl = std::sqrt(test.LengthSq());
+			test = tl > 1.0e-6f ? test * (1.0f / tl) : ahead;
+			if (dot(test, ahead) < ext.mWalkStairsCosAngleForwardContact) test = ahead;
+			WalkStairs(dt, ext.mWalkStairsStepUp, step_forward, test * ext.mWalkStairsStepForwardTest, ext.mWalkStairsStepDownExtra, bp, ol, bf, sf, ta);
 		}
 
 	private:
 		static float dot(const Vec3& a, const Vec3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 		static Vec3 cross(const Vec3& a, const Vec3& b) { return Vec3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 		Vec3 capsuleCentre(const Vec3& pos) const { return pos + shape->offset; }
+		bool touching(const Contact& c) const { return c.distance <= settings.mCollisionTolerance + 0.01f; }      // (what updateSupportingContact counts as a contact)
 
 		void getContacts(const Vec3& pos, uint32_t ignore, std::vector<Contact>& out) const
 		{
@@ -330,52 +368,51 @@ namespace JPH
 			return hit.t;
 		}
 
-		void stickToFloor(const Vec3& step_down, uint32_t ignore)
+		bool stickToFloor(const Vec3& step_down, uint32_t ignore)
 		{
 			Vec3 n;
 			const float t = castDown(position, step_down, ignore, &n);
-			if (t < 0.0f || IsSlopeTooSteep(n)) return;
+			if (t < 0.0f || IsSlopeTooSteep(n)) return false;
 			const float len = std::sqrt(step_down.LengthSq());
 			position = position + step_down * (std::max(0.0f, t - settings.mCharacterPadding) / len);
 			std::vector<Contact> c; getContacts(position, ignore, c);
 			updateSupportingContact(c, true);
+			return true;
 		}
 
-		void walkStairs(float dt, const Vec3& desired_horizontal, const Vec3& achieved_h, const ExtendedUpdateSettings& ext, uint32_t ignore)
+		bool walkStairs(float dt, const Vec3& step_up, const Vec3& step_forward, const Vec3& step_forward_test, const Vec3& step_down_extra, uint32_t ignore)
 		{
 			// up as far as there is head room
 			const Vec3 start = position;
-			Vec3 up_pos = position + ext.mWalkStairsStepUp * sweepFraction(position, ext.mWalkStairsStepUp, ignore);
+			Vec3 up_pos = position + step_up * sweepFraction(position, step_up, ignore);
 			const float risen = std::sqrt((up_pos - position).LengthSq());
-			if (risen < 1.0e-3f) return;
-			// forward by what the blocked move still owed
-			const Vec3 remaining = desired_horizontal * dt - achieved_h;
-			if (remaining.LengthSq() < ext.mWalkStairsMinStepForward * ext.mWalkStairsMinStepForward * 0.0f + 1.0e-10f) return;
+			if (risen < 1.0e-3f) return false;
+			// forward by the step the caller asks for (what the blocked move still owed, at least the minimum step)
+			if (step_forward.LengthSq() < 1.0e-10f || !(dt > 0.0f)) return false;
 			Vec3 fwd_pos = up_pos;
 			const Vec3 saved_velocity = last_solved_velocity; const bool saved_blocked = blocked_by_steep;
-			moveShape(fwd_pos, remaining * (1.0f / dt), dt, ignore, false);
+			moveShape(fwd_pos, step_forward * (1.0f / dt), dt, ignore, false);
 			blocked_by_steep = saved_blocked; last_solved_velocity = saved_velocity;
 			const Vec3 moved = fwd_pos - up_pos;
-			if (moved.LengthSq() < ext.mWalkStairsMinStepForward * ext.mWalkStairsMinStepForward) return;
+			if (moved.LengthSq() < 1.0e-8f) return false;                               // the way is blocked up there as well
 			// and down again onto something we can stand on
-			const Vec3 down = settings.mUp * -(risen + 1.0e-3f) + ext.mWalkStairsStepDownExtra;
+			const Vec3 down = settings.mUp * -(risen + 1.0e-3f) + step_down_extra;
 			Vec3 n;
 			const float t = castDown(fwd_pos, down, ignore, &n);
-			if (t < 0.0f) return;                                                        // nothing under the step: stay where we were
+			if (t < 0.0f) return false;                                                  // nothing under the step: stay where we were
 			if (IsSlopeTooSteep(n)) {
-				// we came down on the rounded nose of the step: look mWalkStairsStepForwardTest further ahead for a floor we can stand on
-				const float hl = std::sqrt(desired_horizontal.LengthSq());
-				const Vec3 ahead = fwd_pos + desired_horizontal * (ext.mWalkStairsStepForwardTest / hl);
+				// we came down on the rounded nose of the step: look step_forward_test further ahead for a floor we can stand on
 				Vec3 n2;
-				const float t2 = castDown(ahead, down, ignore, &n2);
-				if (t2 < 0.0f || IsSlopeTooSteep(n2)) return;
+				const float t2 = castDown(fwd_pos + step_forward_test, down, ignore, &n2);
+				if (t2 < 0.0f || IsSlopeTooSteep(n2)) return false;
 			}
 			const float len = std::sqrt(down.LengthSq());
 			const Vec3 new_pos = fwd_pos + down * (std::max(0.0f, t - settings.mCharacterPadding) / len);
-			if (dot(new_pos - start, settings.mUp) < 1.0e-3f && (new_pos - start).LengthSq() < 1.0e-6f) return;
+			if (dot(new_pos - start, settings.mUp) < 1.0e-3f && (new_pos - start).LengthSq() < 1.0e-6f) return false;
 			position = new_pos;
 			std::vector<Contact> c; getContacts(position, ignore, c);
 			updateSupportingContact(c, true);
+			return true;
 		}
 
 		CharacterVirtualSettings settings;

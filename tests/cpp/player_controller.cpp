@@ -15,6 +15,7 @@
 #include <Jolt/Physics/Collision/Shape/RotatedTranslatedShape.h>
 #include <cstdio>
 #include <chrono>
+#include <string>
 #include <cmath>
 #include <cstdlib>
 
@@ -65,9 +66,36 @@ struct Player : public JPH::CharacterContactListener
 		JPH::CharacterVirtual::ExtendedUpdateSettings settings;
 		settings.mStickToFloorStepDown = JPH::Vec3(0, 0, -0.5f);
 		settings.mWalkStairsStepUp = JPH::Vec3(0.0f, 0.0f, 0.4f);
-		jolt_character->ExtendedUpdate(dtime, physics_world.physics_system->GetGravity(), settings, physics_world.physics_system->GetDefaultBroadPhaseLayerFilter(1),
-			physics_world.physics_system->GetDefaultLayerFilter(1), JPH::BodyFilter(), JPH::ShapeFilter(), temp_allocator);
+		const JPH::BroadPhaseLayerFilter& bp = physics_world.physics_system->GetDefaultBroadPhaseLayerFilter(1);
+		const JPH::ObjectLayerFilter& ol = physics_world.physics_system->GetDefaultLayerFilter(1);
+		const JPH::BodyFilter bf; const JPH::ShapeFilter sf;
+		if (!by_pieces) { jolt_character->ExtendedUpdate(dtime, physics_world.physics_system->GetGravity(), settings, bp, ol, bf, sf, temp_allocator); return; }
+		// What PlayerPhysics::update really compiles (:357-446) is its own spelling-out of ExtendedUpdate from the character's public pieces --
+		// GetUp, CancelVelocityTowardsSteepSlopes, Update, StickToFloor, CanWalkStairs, WalkStairs -- so those members have to exist and to
+		// add up to the same motion.  The same sequence, in this test's words:
+		const JPH::Vec3 up = jolt_character->GetUp(), wanted = jolt_character->GetLinearVelocity();
+		jolt_character->SetLinearVelocity(jolt_character->CancelVelocityTowardsSteepSlopes(wanted));
+		const JPH::Vec3 before = jolt_character->GetPosition();
+		bool left_ground = jolt_character->IsSupported();
+		jolt_character->Update(dtime, physics_world.physics_system->GetGravity(), bp, ol, bf, sf, temp_allocator);
+		if (jolt_character->IsSupported()) left_ground = false;
+		if (left_ground && !settings.mStickToFloorStepDown.IsNearZero() && JPH::Vec3(jolt_character->GetPosition() - before).Dot(up) / dtime <= 1.0e-6f)
+			jolt_character->StickToFloor(settings.mStickToFloorStepDown, bp, ol, bf, sf, temp_allocator);
+		if (settings.mWalkStairsStepUp.IsNearZero()) return;
+		JPH::Vec3 want = wanted * dtime; want -= want.Dot(up) * up;
+		const float want_len = want.Length();
+		if (!(want_len > 0.0f)) return;
+		const JPH::Vec3 dir = want / want_len;
+		JPH::Vec3 got = JPH::Vec3(jolt_character->GetPosition() - before); got -= got.Dot(up) * up;
+		const float got_len = std::max(0.0f, got.Dot(dir));
+		if (got_len + 1.0e-4f < want_len && jolt_character->CanWalkStairs(wanted)) {
+			JPH::Vec3 test = -jolt_character->GetGroundNormal(); test -= test.Dot(up) * up; test = test.NormalizedOr(dir);
+			if (test.Dot(dir) < settings.mWalkStairsCosAngleForwardContact) test = dir;
+			jolt_character->WalkStairs(dtime, settings.mWalkStairsStepUp, dir * std::max(settings.mWalkStairsMinStepForward, want_len - got_len), test * settings.mWalkStairsStepForwardTest,
+				settings.mWalkStairsStepDownExtra, bp, ol, bf, sf, temp_allocator);
+		}
 	}
+	bool by_pieces = false;
 };
 
 static Reference<PhysicsObject> addBox(PhysicsWorld& w, const Vec3f& size, const Vec4f& pos, PhysicsObject::MotionType mt, float mass = 100.f, const Quatf& rot = Quatf::identity())
@@ -81,8 +109,9 @@ static Reference<PhysicsObject> addBox(PhysicsWorld& w, const Vec3f& size, const
 
 #define CHECK(cond) do { if (!(cond)) { printf("FAILED at step %d: %s  (pos %.3f %.3f %.3f)\n", step, #cond, p.x, p.y, p.z); return 1; } } while (0)
 
-int main()
+int main(int argc, char** argv)
 {
+	const bool by_pieces = argc > 1 && std::string(argv[1]) == "pieces";      // drive the character through the pieces of ExtendedUpdate, like PlayerPhysics.cpp:357-446
 	try {
 		PhysicsWorld::init();
 		Reference<PhysicsWorld> world = new PhysicsWorld(nullptr, nullptr);
@@ -97,6 +126,7 @@ int main()
 		Reference<PhysicsObject> platform = addBox(*world, Vec3f(3, 3, 0.4f), Vec4f(-10, -3, 0.2f, 1), PhysicsObject::MotionType_kinematic);
 
 		Player player;
+		player.by_pieces = by_pieces;
 		player.init(*world, JPH::Vec3(0, 0, 2.0f));
 		const float dt = 1.f / 60.f;
 		int step = 0; JPH::Vec3 p;

@@ -178,6 +178,11 @@ def test_player_controller_through_character_virtual(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     print(r.stdout)
     assert r.returncode == 0, r.stdout + r.stderr
+    # ... and the same walk with the character driven through the pieces of ExtendedUpdate one by one (GetUp, CancelVelocityTowardsSteepSlopes,
+    # Update, StickToFloor, CanWalkStairs, WalkStairs), which is what PlayerPhysics.cpp:357-446 does: same pass / fail criteria
+    r2 = subprocess.run([exe, "pieces"], capture_output=True, text=True, timeout=300)
+    print(r2.stdout)
+    assert r2.returncode == 0, r2.stdout + r2.stderr
 
 
 @pytest.mark.gpu
