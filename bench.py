@@ -41,6 +41,7 @@ sys.path.insert(0, ROOT)
 
 DT = 1.0 / 60.0
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBS = 6300.0    # what a streaming kernel reaches on this part (same guide)
 SWEEP_BYTES_PER_BODY = 188     # integrate + AABB body-array sweep, 112 B read + 76 B written
 # per contact point per velocity iteration: 12 precomputed row vectors (3 axes x 4 float4) + lambdas read, lambdas written
 SOLVE_BYTES_PER_POINT = 12 * 16 + 16 + 16
@@ -399,6 +400,7 @@ def main():
     w = leg_world()
     prof = profile_leg(w, n_prof)
     vel_iters = w.desc.settings.num_velocity_steps
+    pos_iters = w.desc.settings.num_position_steps
     st_prof = w.stats()
     w.close()
     roof, roof_solver, kernel_ms = rooflines(prof, n_prof, vel_iters, pmc)
@@ -428,6 +430,21 @@ def main():
         },
         "roofline": roof, "roofline_solver": roof_solver, "kernel_ms_per_step": kernel_ms,
     }
+
+    # ---- the whole step against the roofline (SURVEY 8d's B_step with this step's own counts) ------------------------
+    # B_step = 188 N (sweep) + 40 N (cell key + index, sorted read) + 96 P (pair gather 2 x 44 + pair id) + 132 M (manifold) + I_v C 192 + I_p C 104
+    n_, p_, m_, c_ = float(prof["sweep_bodies"]), float(st.num_pairs), float(st.num_manifolds), float(st.num_contact_points)
+    step_bytes = 188.0 * n_ + 40.0 * n_ + 96.0 * p_ + 132.0 * m_ + vel_iters * c_ * 192.0 + pos_iters * c_ * 104.0
+    step_gbs = step_bytes / (ms_per_step * 1e-3) / 1e9
+    out["roofline_step"] = {
+        "bound": "hbm", "kernel": "the whole step (all launches; SURVEY 8d whole-step model B_step)", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": step_gbs / HBM_PEAK_GBS, "frac_of_achievable": step_gbs / HBM_ACHIEVABLE_GBS, "achievable": HBM_ACHIEVABLE_GBS,
+        "algorithmic_bytes_per_step": step_bytes, "ms_per_step": ms_per_step,
+        "counts": {"N_body_slots": int(n_), "P_pairs": int(p_), "M_manifolds": int(m_), "C_contact_points": int(c_), "I_v": int(vel_iters), "I_p": int(pos_iters)},
+        "launches_per_step": float(sum(prof["klaunch"])) / n_prof,
+        "note": "latency-bound at 100k bodies: ~13 us per dependent launch, not bytes, is what a step is made of (DESIGN.md 3, 8)",
+    }
+    out["roofline"]["frac_of_achievable"] = out["roofline"]["achieved"] / HBM_ACHIEVABLE_GBS
 
     # ---- CPU baseline: the oracle (a port of the same step, NOT Jolt) on a bounded sample of the SAME state ------------------
     cpu_constraints = None

@@ -1375,13 +1375,11 @@ static void update_sleeping(sgo_world* w, float dt)
 
 /* Volume and centroid of the part of a convex polyhedron (box) below the plane z = wz, by slicing the 8
    corners: uses the exact tetrahedral decomposition of the clipped box. */
-static void box_submerged(const sgo_body* b, float wz, float* vol_out, v3* centroid_out)
+static void box_submerged_h(v3 h, m33 R, float posz, float wz, float* vol_out, v3* centroid_out)
 {
-	const m33 R = quat_to_m33(b->rot);
-	const v3 h = V3(b->shape[0], b->shape[1], b->shape[2]);
 	/* Work in the box frame: plane n.x = d with n = R^T (0,0,1), d = wz - pos.z ; submerged part: n.x <= d. */
 	const v3 n = m33_tmul(R, V3(0.0f, 0.0f, 1.0f));
-	const float d = wz - b->pos.z;
+	const float d = wz - posz;
 	/* Clip the 6 faces (quads) by the half space and add the cap polygon; accumulate signed tetrahedra from the origin. */
 	float vol = 0.0f; v3 cen = V3(0, 0, 0);
 	v3 cap[24]; int ncap = 0;
@@ -1455,16 +1453,60 @@ static void sphere_cap_submerged(float r, float depth_of_centre /* wz - centre.z
 	*vol_out = vol; *cz_out = cz;
 }
 
+/* ConvexHullShape::GetSubmergedVolume: the exact volume and centre of the part of the polyhedron under the plane.  Every face polygon is clipped
+   to the half space and fanned into tetrahedra whose apex lies IN the plane (the point of the plane closest to the centre of mass), so that the
+   cut surface itself contributes nothing.  Hull frame = body frame, origin = centre of mass. */
+static void hull_submerged(const sgo_hull* hl, m33 R, float posz, float wz, float* vol_out, v3* centroid_out)
+{
+	const v3 n = m33_tmul(R, V3(0.0f, 0.0f, 1.0f));
+	const float d = wz - posz;
+	float lo = 3.4e38f, hi = -3.4e38f;
+	for (int i = 0; i < hl->nv; ++i) { const float t = v3_dot(n, hl->verts[i]); lo = fminf(lo, t); hi = fmaxf(hi, t); }
+	if (lo >= d) { *vol_out = 0.0f; *centroid_out = V3(0, 0, 0); return; }
+	if (hi <= d) { *vol_out = hl->volume; *centroid_out = V3(0, 0, 0); return; }
+	const v3 apex = v3_scale(n, d);
+	float vol = 0.0f; v3 cen = V3(0, 0, 0);
+	for (int f = 0; f < hl->nf; ++f) {
+		const int b0 = hl->face_start[f], cnt = hl->face_start[f + 1] - b0;
+		v3 poly[SGO_HULL_MAX_FACE_VERTS + 2]; int np = 0;
+		for (int k = 0; k < cnt; ++k) {
+			const v3 a = hl->verts[hl->face_idx[b0 + k]], c = hl->verts[hl->face_idx[b0 + (k + 1) % cnt]];
+			const float da = v3_dot(n, a) - d, dc = v3_dot(n, c) - d;
+			if (da <= 0.0f) poly[np++] = v3_sub(a, apex);
+			if ((da <= 0.0f) != (dc <= 0.0f)) { const float t = da / (da - dc); poly[np++] = v3_sub(v3_add(a, v3_scale(v3_sub(c, a), t)), apex); }
+		}
+		for (int k = 1; k + 1 < np; ++k) {
+			const float tv = v3_dot(poly[0], v3_cross(poly[k], poly[k + 1])) / 6.0f;
+			vol += tv;
+			cen = v3_add(cen, v3_scale(v3_add(v3_add(poly[0], poly[k]), poly[k + 1]), tv * 0.25f));
+		}
+	}
+	*vol_out = vol;
+	*centroid_out = vol > 1.0e-12f ? m33_mul(R, v3_add(apex, v3_scale(cen, 1.0f / vol))) : V3(0, 0, 0);
+}
+
+/* Shape::GetSubmergedVolume as Jolt's shapes implement it: box and convex hull exactly (polyhedra), sphere by the cap formula, and every
+   other convex shape -- here the capsule -- through ConvexShape::GetSubmergedVolume, which stands the shape's LOCAL BOUNDING BOX in for it:
+   total volume = that box's, submerged part = the box's part under the plane.  (The caller's buoyancy factor still comes from
+   Shape::GetVolume, PhysicsWorld.cpp:1387, so what matters is the box's submerged FRACTION; the reported volume is the box's, as the
+   reference would get it back.)  UNVERIFIED: upstream. */
 static void submerged_volume(const sgo_body* b, float wz, float* total, float* sub, v3* rel_cob)
 {
 	*total = shape_volume_h(b->shape_type, b->shape, b->hull);
-	if (b->shape_type == SGP_SHAPE_BOX) { box_submerged(b, wz, sub, rel_cob); return; }
+	if (b->shape_type == SGP_SHAPE_BOX) { box_submerged_h(V3(b->shape[0], b->shape[1], b->shape[2]), quat_to_m33(b->rot), b->pos.z, wz, sub, rel_cob); return; }
+	if (b->shape_type == SGP_SHAPE_HULL && b->hull) { hull_submerged(b->hull, quat_to_m33(b->rot), b->pos.z, wz, sub, rel_cob); return; }
+	if (b->shape_type == SGP_SHAPE_CAPSULE) {
+		const v3 h = V3(b->shape[0], b->shape[0], b->shape[1] + b->shape[0]);      /* capsule along z: radius, half height of the cylinder */
+		*total = 8.0f * h.x * h.y * h.z;
+		box_submerged_h(h, quat_to_m33(b->rot), b->pos.z, wz, sub, rel_cob);
+		return;
+	}
 	if (b->shape_type == SGP_SHAPE_SPHERE) {
 		float cz; sphere_cap_submerged(b->shape[0], wz - b->pos.z, sub, &cz);
 		*rel_cob = V3(0.0f, 0.0f, cz);
 		return;
 	}
-	/* capsule: approximated (as Jolt does for non-trivial convex shapes) by the fraction of its AABB height under water */
+	/* anything else (none today): the fraction of its AABB height under water */
 	{
 		const float zmin = b->aabb_min.z, zmax = b->aabb_max.z;
 		const float f = clampf((wz - zmin) / (zmax - zmin), 0.0f, 1.0f);
@@ -1482,7 +1524,7 @@ static void buoyancy_sweep(sgo_world* w, float dt)
 			const float fluid_density = 1020.0f;                                            /* :1381 */
 			float total, sub; v3 rc;
 			submerged_volume(b, w->water_z, &total, &sub, &rc);
-			const float buoyancy = fluid_density * total / b->mass;                         /* :1387 */
+			const float buoyancy = fluid_density * shape_volume_h(b->shape_type, b->shape, b->hull) / b->mass;      /* :1387: Shape::GetVolume, the real one */
 			int applied = 0;
 			if (sub > 0.0f) {
 				/* Body::ApplyBuoyancyImpulse */

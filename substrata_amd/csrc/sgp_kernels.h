@@ -94,6 +94,7 @@ struct StepCounters {
 	uint32_t hc_done;            // workgroups of the running solve launch that have finished (the last one runs the catch-all and clears it)
 	uint32_t veh_deferred;       // vehicles that share a movable body (a dynamic body under a wheel, a chassis a wheel stands on) with a vehicle of lower index: solved after the others, in index order
 	uint32_t veh_done;           // workgroups of the running vehicle-row launch that have finished (the last one solves the deferred vehicles and clears it)
+	uint32_t tickets[4];         // last_block(): workgroups of k_colour_count / k_warm_bodies / k_cache_build that have finished
 	uint32_t ts_error;           // tile solver: a tile gave up waiting for a neighbour (k_step_end copies ts_flags[0])
 	uint32_t ts_all_adjacent;    // tile solver: some body was touched by more than four tiles
 	uint32_t round_n[32];        // uncoloured manifolds at the start of colouring round r (the host plans the next step's wide rounds from it)
@@ -236,6 +237,7 @@ struct DV {
 	float4*   sorted_min;      // cell-sorted copy: aabb min xyz, flags (bits) w
 	float4*   sorted_max;      // cell-sorted copy: aabb max xyz, body id (bits) w
 	struct BpGrid* grid;       // per-step dense grid parameters (device)
+	int*      bounds_acc;      // [6] ordered-int min / max of the small bodies' AABB centres, accumulated by k_step_begin, consumed by k_bp_cell, reset by k_bp_scatter
 	uint32_t* grid_cells_used; // cells of the most recent grid (what the next step has to clear of the cell tables)
 	const uint32_t* large_ids;
 	uint2*    pairs;
@@ -307,6 +309,7 @@ void launch_bp_scan(const DV& d, hipStream_t s);
 void launch_bp_scatter(const DV& d, uint32_t nb, hipStream_t s);
 void launch_bp_pairs(const DV& d, int small_lds, hipStream_t s);      // small_lds: the instance with room for 4 workgroups per compute unit (sparse scenes)
 void launch_bp_large(const DV& d, uint32_t nb, hipStream_t s);
+void launch_bp_scatter_large(const DV& d, uint32_t nb, hipStream_t s);      // both in one launch (the step's path)
 void launch_narrowphase(const DV& d, uint32_t n_pairs_upper, hipStream_t s);
 void launch_narrowphase_hull(const DV& d, hipStream_t s);     // only worlds with hull shapes
 void launch_narrowphase_mesh(const DV& d, hipStream_t s);     // only worlds with mesh shapes
@@ -338,7 +341,7 @@ void launch_island_hook(const DV& d, uint32_t n_con, hipStream_t s);
 void launch_island_flag(const DV& d, uint32_t n_con, hipStream_t s);
 void launch_sleep_apply(const DV& d, uint32_t nb, hipStream_t s);
 void launch_buoyancy(const DV& d, uint32_t nb, hipStream_t s);
-void launch_cache_build(const DV& d, uint32_t n_con, hipStream_t s);
+void launch_cache_build(const DV& d, uint32_t n_con, StepCounters* host_mapped, EventCounters* host_events, hipStream_t s);      // + the step's counters to the host (its last workgroup)
 void launch_contact_events(const DV& d, uint32_t n_man, hipStream_t s);
 void launch_ghost_refresh(const DV& d, const GhostRefresh* recs, uint32_t n, hipStream_t s);
 void launch_apply_cmds(const DV& d, const BodyCmd* cmds, const uint32_t* run_start, uint32_t n_runs, hipStream_t s);

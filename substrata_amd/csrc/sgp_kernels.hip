@@ -138,17 +138,33 @@ SGP_DEV void push_event(uint32_t* list, uint32_t* counter, uint32_t cap, uint32_
 	if (k < cap) list[k] = id;
 }
 
+// "The last workgroup to finish does what needs everybody's results": every thread of the workgroup calls this at the end of the kernel's parallel part;
+// true (for the whole workgroup) in the workgroup that took the last ticket.  The tickets live in StepCounters (zeroed by the step's first launch) and
+// are used once per step each.  A dependent kernel boundary costs ~4.5 us at the launch floor; this costs a fence and an atomic.
+SGP_DEV bool last_block(uint32_t* ticket)
+{
+	__shared__ uint32_t s_last_ticket;
+	__syncthreads();
+	if (threadIdx.x == 0) { __threadfence(); s_last_ticket = atomicAdd(ticket, 1u); }
+	__syncthreads();
+	const bool last = s_last_ticket == gridDim.x - 1u;
+	if (last) __threadfence();          // what the other workgroups wrote (and this compute unit may still hold older copies of)
+	return last;
+}
+
+SGP_DEV int float_to_ordered(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
+SGP_DEV float ordered_to_float(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
+
 // First launch of a step: the per-step scalars arrive BY VALUE (no upload node), the per-step counters, grid bounds and
 // scratch arrays are reset by this one grid-stride kernel (instead of half a dozen runtime memset nodes).
-__global__ void __launch_bounds__(TPB) k_step_begin(DV d, StepParams sp, uint32_t nb, int reset_scratch)
+// Round 4: the same launch also finds the bounds of the small bodies' AABB centres (the broad-phase grid's extent), which was a launch of its own: the first
+// `bounds_blocks` workgroups sweep the bodies and fold their six extrema into DV::bounds_acc (ordered-int atomics; reset by k_bp_scatter, which runs after
+// the grid parameters have been derived from them).
+__global__ void __launch_bounds__(TPB) k_step_begin(DV d, StepParams sp, uint32_t nb, int reset_scratch, uint32_t bounds_blocks)
 {
 	const uint32_t tid = blockIdx.x * TPB + threadIdx.x, stride = gridDim.x * TPB;
 	if (tid == 0) {
 		*d.sp = sp;
-		BpGrid g;
-		g.min_x = g.min_y = g.min_z = 0x7FFFFFFF; g.max_x = g.max_y = g.max_z = (int)0x80000000;
-		g.ox = g.oy = g.oz = 0.0f; g.inv_cell = 1.0f; g.cell = 1.0f; g.nx = g.ny = g.nz = 1; g.n_cells = 1;
-		*d.grid = g;
 		*d.veh_epoch = *d.veh_epoch + 1u;      // (device side: the by-value step parameters are part of a captured graph's key and must not change from step to step)
 	}
 	uint32_t* c = (uint32_t*)d.ctr;
@@ -159,6 +175,32 @@ __global__ void __launch_bounds__(TPB) k_step_begin(DV d, StepParams sp, uint32_
 	if (reset_scratch) {
 		const uint32_t n = min(nb, d.cap_bodies);
 		for (uint32_t i = tid; i < n; i += stride) { d.colour_mask[i] = 0ull; d.claim[0][i] = ~0ull; d.claim[1][i] = ~0ull; }
+	}
+	if (blockIdx.x >= bounds_blocks) return;          // (workgroup-uniform)
+	// (a grid-stride loop over few workgroups: every workgroup ends with six atomics on the same six words, and those serialise)
+	float mnx = 3.0e38f, mny = 3.0e38f, mnz = 3.0e38f, mxx = -3.0e38f, mxy = -3.0e38f, mxz = -3.0e38f;
+	const uint32_t n_slots = sp.n_slots;
+	for (uint32_t i = tid; i < n_slots; i += bounds_blocks * TPB) {
+		const uint32_t f = d.flags[i];
+		if ((f & BF_ALIVE) && !(f & BF_LARGE)) {
+			const float4 mn = d.aabb_min[i], mx = d.aabb_max[i];
+			const float cx = (mn.x + mx.x) * 0.5f, cy = (mn.y + mx.y) * 0.5f, cz = (mn.z + mx.z) * 0.5f;
+			mnx = fminf(mnx, cx); mny = fminf(mny, cy); mnz = fminf(mnz, cz); mxx = fmaxf(mxx, cx); mxy = fmaxf(mxy, cy); mxz = fmaxf(mxz, cz);
+		}
+	}
+	for (int off = 32; off > 0; off >>= 1) {
+		mnx = fminf(mnx, __shfl_down(mnx, off, 64)); mny = fminf(mny, __shfl_down(mny, off, 64)); mnz = fminf(mnz, __shfl_down(mnz, off, 64));
+		mxx = fmaxf(mxx, __shfl_down(mxx, off, 64)); mxy = fmaxf(mxy, __shfl_down(mxy, off, 64)); mxz = fmaxf(mxz, __shfl_down(mxz, off, 64));
+	}
+	__shared__ float red[6][TPB / 64];
+	if ((threadIdx.x & 63) == 0) { const int wv = threadIdx.x >> 6; red[0][wv] = mnx; red[1][wv] = mny; red[2][wv] = mnz; red[3][wv] = mxx; red[4][wv] = mxy; red[5][wv] = mxz; }
+	__syncthreads();
+	if (threadIdx.x < 6) {
+		float v = red[threadIdx.x][0];
+		for (int k = 1; k < TPB / 64; ++k) v = threadIdx.x < 3 ? fminf(v, red[threadIdx.x][k]) : fmaxf(v, red[threadIdx.x][k]);
+		int* dst = d.bounds_acc + threadIdx.x;
+		if (threadIdx.x < 3) { if (v < 2.9e38f) atomicMin(dst, float_to_ordered(v)); }
+		else { if (v > -2.9e38f) atomicMax(dst, float_to_ordered(v)); }
 	}
 }
 
@@ -187,46 +229,15 @@ __global__ void __launch_bounds__(TPB) k_fill_u64(uint64_t* p, uint64_t v, size_
 // into cell order together with a packed 32-byte AABB record; the pair kernel stages a 4x4x4-cell tile plus its halo in
 // LDS and tests every body of the tile against the 27 neighbouring cells out of LDS.
 
-SGP_DEV int float_to_ordered(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
-SGP_DEV float ordered_to_float(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
-
-__global__ void __launch_bounds__(TPB) k_bp_bounds(DV d)
+// The grid of a step from the bounds k_step_begin accumulated: origin / dimensions; the cell edge grows until the dense table fits.  Every workgroup of
+// k_bp_cell derives it for itself (a few dozen flops by one thread; it was a single-thread launch of its own), workgroup 0 also publishes it.
+SGP_DEV BpGrid bp_grid_from_bounds(const DV& d)
 {
-	// (a grid-stride loop over few workgroups: every workgroup ends with six atomics on the same six words, and those serialise)
-	float mnx = 3.0e38f, mny = 3.0e38f, mnz = 3.0e38f, mxx = -3.0e38f, mxy = -3.0e38f, mxz = -3.0e38f;
-	const uint32_t n_slots = d.sp->n_slots;
-	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n_slots; i += gridDim.x * TPB) {
-		const uint32_t f = d.flags[i];
-		if ((f & BF_ALIVE) && !(f & BF_LARGE)) {
-			const float4 mn = d.aabb_min[i], mx = d.aabb_max[i];
-			const float cx = (mn.x + mx.x) * 0.5f, cy = (mn.y + mx.y) * 0.5f, cz = (mn.z + mx.z) * 0.5f;
-			mnx = fminf(mnx, cx); mny = fminf(mny, cy); mnz = fminf(mnz, cz); mxx = fmaxf(mxx, cx); mxy = fmaxf(mxy, cy); mxz = fmaxf(mxz, cz);
-		}
-	}
-	for (int off = 32; off > 0; off >>= 1) {
-		mnx = fminf(mnx, __shfl_down(mnx, off, 64)); mny = fminf(mny, __shfl_down(mny, off, 64)); mnz = fminf(mnz, __shfl_down(mnz, off, 64));
-		mxx = fmaxf(mxx, __shfl_down(mxx, off, 64)); mxy = fmaxf(mxy, __shfl_down(mxy, off, 64)); mxz = fmaxf(mxz, __shfl_down(mxz, off, 64));
-	}
-	__shared__ float red[6][TPB / 64];
-	if ((threadIdx.x & 63) == 0) { const int wv = threadIdx.x >> 6; red[0][wv] = mnx; red[1][wv] = mny; red[2][wv] = mnz; red[3][wv] = mxx; red[4][wv] = mxy; red[5][wv] = mxz; }
-	__syncthreads();
-	if (threadIdx.x < 6) {
-		float v = red[threadIdx.x][0];
-		for (int k = 1; k < TPB / 64; ++k) v = threadIdx.x < 3 ? fminf(v, red[threadIdx.x][k]) : fmaxf(v, red[threadIdx.x][k]);
-		int* dst = &d.grid->min_x + threadIdx.x;
-		if (threadIdx.x < 3) { if (v < 2.9e38f) atomicMin(dst, float_to_ordered(v)); }
-		else { if (v > -2.9e38f) atomicMax(dst, float_to_ordered(v)); }
-	}
-}
-
-// one thread: grid origin / dims; the cell edge grows until the dense table fits
-__global__ void k_bp_grid_params(DV d)
-{
-	if (threadIdx.x != 0 || blockIdx.x != 0) return;
-	BpGrid g = *d.grid;
+	BpGrid g;
+	g.min_x = d.bounds_acc[0]; g.min_y = d.bounds_acc[1]; g.min_z = d.bounds_acc[2]; g.max_x = d.bounds_acc[3]; g.max_y = d.bounds_acc[4]; g.max_z = d.bounds_acc[5];
+	g.ox = g.oy = g.oz = 0.0f; g.nx = g.ny = g.nz = 1;
 	float cell = d.sp->cell_size;
-	if (g.min_x > g.max_x) { g.ox = g.oy = g.oz = 0.0f; g.nx = g.ny = g.nz = 1; }
-	else {
+	if (g.min_x <= g.max_x) {
 		const float x0 = ordered_to_float(g.min_x), y0 = ordered_to_float(g.min_y), z0 = ordered_to_float(g.min_z);
 		const float x1 = ordered_to_float(g.max_x), y1 = ordered_to_float(g.max_y), z1 = ordered_to_float(g.max_z);
 		for (int it = 0; it < 64; ++it) {
@@ -240,19 +251,24 @@ __global__ void k_bp_grid_params(DV d)
 	}
 	g.cell = cell; g.inv_cell = 1.0f / cell;
 	g.n_cells = (uint32_t)g.nx * (uint32_t)g.ny * (uint32_t)g.nz;
-	*d.grid = g;
-	*d.grid_cells_used = g.n_cells;
+	return g;
 }
 
 __global__ void __launch_bounds__(TPB) k_bp_cell(DV d)
 {
+	__shared__ BpGrid sg;
+	if (threadIdx.x == 0) {
+		sg = bp_grid_from_bounds(d);
+		if (blockIdx.x == 0) { *d.grid = sg; *d.grid_cells_used = sg.n_cells; }
+	}
+	__syncthreads();
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
 	if (i >= d.sp->n_slots) return;
 	const uint32_t f = d.flags[i];
 	uint32_t h = 0xFFFFFFFFu;
 	if ((f & BF_ALIVE) && !(f & BF_LARGE)) {
 		const float4 mn = d.aabb_min[i], mx = d.aabb_max[i];
-		const BpGrid& g = *d.grid;
+		const BpGrid& g = sg;
 		int cx = (int)floorf(((mn.x + mx.x) * 0.5f - g.ox) * g.inv_cell);
 		int cy = (int)floorf(((mn.y + mx.y) * 0.5f - g.oy) * g.inv_cell);
 		int cz = (int)floorf(((mn.z + mx.z) * 0.5f - g.oz) * g.inv_cell);
@@ -325,9 +341,9 @@ __global__ void __launch_bounds__(TPB) k_scan_add(uint32_t* out, const uint32_t*
 	for (int k = 0; k < 4; ++k) if (base + k < n) out[base + k] += add;
 }
 
-__global__ void __launch_bounds__(TPB) k_bp_scatter(DV d)
+SGP_DEV void bp_scatter_one(const DV& d, uint32_t i)
 {
-	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i < 6u) d.bounds_acc[i] = i < 3u ? 0x7FFFFFFF : (int)0x80000000;      // (the grid has been derived: ready for the next step's -- or re-binning's -- bounds)
 	if (i >= d.sp->n_slots) return;
 	const uint32_t h = d.cell_hash[i];
 	if (h == 0xFFFFFFFFu) return;
@@ -336,6 +352,7 @@ __global__ void __launch_bounds__(TPB) k_bp_scatter(DV d)
 	d.sorted_min[slot] = make_float4(mn.x, mn.y, mn.z, __uint_as_float(d.flags[i]));
 	d.sorted_max[slot] = make_float4(mx.x, mx.y, mx.z, __uint_as_float(i));
 }
+__global__ void __launch_bounds__(TPB) k_bp_scatter(DV d) { bp_scatter_one(d, blockIdx.x * TPB + threadIdx.x); }      // (re-binning for queries between steps)
 
 SGP_DEV bool pair_passes(const DV& d, uint32_t fi, float4 mni, float4 mxi, uint32_t j)
 {
@@ -656,9 +673,8 @@ __global__ void __launch_bounds__(TPB) k_gather_aabbs(DV d, const uint32_t* ids,
 
 // large bodies (ground quad, PhysicsWorld.cpp:1123) against every body
 SGP_DEV uint32_t block_alloc(uint32_t* counter, bool want);
-__global__ void __launch_bounds__(TPB) k_bp_large(DV d)
+SGP_DEV void bp_large_one(const DV& d, uint32_t j)
 {
-	const uint32_t j = blockIdx.x * TPB + threadIdx.x;
 	const uint32_t fj = j < d.sp->n_slots ? d.flags[j] : 0u;
 	const bool live_j = (fj & BF_ALIVE) && !(fj & BF_ALIAS);      // (a mesh body's alias slots only carry manifolds: they never pair)
 	float4 mnj = make_float4(0.0f, 0.0f, 0.0f, 0.0f), mxj = mnj;
@@ -686,6 +702,10 @@ __global__ void __launch_bounds__(TPB) k_bp_large(DV d)
 		});
 	}
 }
+__global__ void __launch_bounds__(TPB) k_bp_large(DV d) { bp_large_one(d, blockIdx.x * TPB + threadIdx.x); }
+// In a step, one launch does both per-body jobs -- the body's record into its cell's run, then its pairs with the large bodies (neither reads what the
+// other writes): a launch less on the step's chain (round 4).
+__global__ void __launch_bounds__(TPB) k_bp_scatter_large(DV d) { const uint32_t i = blockIdx.x * TPB + threadIdx.x; bp_scatter_one(d, i); bp_large_one(d, i); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // K4: narrow phase, one thread per candidate pair
@@ -1373,7 +1393,8 @@ __global__ void __launch_bounds__(TPB) k_colour_commit(DV d, uint32_t round)
 	}
 }
 
-__global__ void __launch_bounds__(TPB) k_colour_count(DV d)
+SGP_DEV void colour_scan_block(const DV& d);
+__global__ void __launch_bounds__(TPB) k_colour_count(DV d, int scan_too)
 {
 	__shared__ uint32_t hist[SGP_MAX_COLOURS + 3];
 	__shared__ uint32_t hist4[SGP_MAX_COLOURS * 4];
@@ -1398,6 +1419,8 @@ __global__ void __launch_bounds__(TPB) k_colour_count(DV d)
 	else if (threadIdx.x == SGP_MAX_COLOURS) { if (hist[SGP_MAX_COLOURS]) atomicAdd(&d.ctr->n_points, hist[SGP_MAX_COLOURS]); }
 	else if (threadIdx.x == SGP_MAX_COLOURS + 1) { if (hist[SGP_MAX_COLOURS + 1]) atomicAdd(&d.ctr->n_constraints, hist[SGP_MAX_COLOURS + 1]); }
 	else if (threadIdx.x == SGP_MAX_COLOURS + 2) { if (hist[SGP_MAX_COLOURS + 2]) atomicAdd(&d.ctr->n_cached, hist[SGP_MAX_COLOURS + 2]); }
+	// the scan of the histogram (first slot of every colour and point-count class) by whoever finishes last: it was a launch of its own
+	if (scan_too && last_block(&d.ctr->tickets[0])) colour_scan_block(d);
 }
 
 // Catch-all: if the planned number of rounds left manifolds uncoloured, ONE workgroup finishes the job with workgroup
@@ -1465,7 +1488,7 @@ __global__ void __launch_bounds__(1024) k_colour_finish(DV d, uint32_t first_rou
 }
 
 // exclusive scan of the colour histogram -> first slot of every colour, on the device (no host round trip)
-__global__ void __launch_bounds__(256) k_colour_scan(DV d)
+SGP_DEV void colour_scan_block(const DV& d)
 {
 	// buckets in (colour, point-count class) order: the start of a colour is the start of its first class
 	__shared__ uint32_t wsum[4];
@@ -1487,6 +1510,7 @@ __global__ void __launch_bounds__(256) k_colour_scan(DV d)
 		if (b == 0) d.ctr->n_colours = used ? 64u - (uint32_t)__clzll(used) : 0u;
 	}
 }
+__global__ void __launch_bounds__(256) k_colour_scan(DV d) { colour_scan_block(d); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // K5: contact constraint setup (Jolt ContactConstraintManager::TemplatedAddContactConstraint): contact-cache match
@@ -1757,9 +1781,8 @@ SGP_DEV void warm_start_one(const DV& d, uint32_t slot) { warm_start_one_t<2>(d,
 // per colour), each contributing friction t1, friction t2, normal per point exactly as warm_start_one_t applies them.  This kernel
 // replays that sequence per body from the (body, colour) table written by k_setup; same operations in the same order, hence the same
 // bits, in one launch.  Constraints of the overflow colour come last in the order and are still applied serially by k_solve_tail.
-__global__ void __launch_bounds__(TPB) k_warm_bodies(DV d)
+SGP_DEV void warm_body_one(const DV& d, uint32_t i)
 {
-	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
 	if (i >= d.sp->n_slots) return;
 	uint64_t mask = d.colour_mask[i] & ~(1ull << SGP_OVERFLOW_COLOUR);
 	if (!mask) return;
@@ -1799,6 +1822,19 @@ __global__ void __launch_bounds__(TPB) k_warm_bodies(DV d)
 	}
 	rec[0] = F4(lv, im);
 	rec[1] = F4(av, 0.0f);
+}
+SGP_DEV void warm_start_one(const DV& d, uint32_t k);
+SGP_DEV uint32_t overflow_next(const DV& d, uint32_t first, uint32_t count, uint64_t& last, bool& have_last);
+__global__ void __launch_bounds__(TPB) k_warm_bodies(DV d)
+{
+	warm_body_one(d, blockIdx.x * TPB + threadIdx.x);
+	// the overflow colour comes last for every body: its constraints one after the other, in priority order, once every workgroup is through
+	// (round 4: it was a launch of its own that found nothing to do in almost every step)
+	const uint32_t first = d.cstarts[SGP_OVERFLOW_COLOUR], count = d.cstarts[SGP_OVERFLOW_COLOUR + 1] - first;
+	if (count == 0u) return;                                    // (uniform over the grid)
+	if (!last_block(&d.ctr->tickets[1]) || threadIdx.x != 0) return;
+	uint64_t last = 0; bool have_last = false;
+	for (uint32_t it = 0; it < count; ++it) warm_start_one(d, overflow_next(d, first, count, last, have_last));
 }
 
 // One contact manifold, one velocity iteration (ContactConstraintManager::SolveVelocityConstraints): friction rows of
@@ -2895,6 +2931,8 @@ SGP_DEV bool island_edge(const DV& d, uint32_t k, uint32_t n_con, uint2& ab)
 
 __global__ void __launch_bounds__(TPB) k_island_mark(DV d)
 {
+	// (measured, round 4: the three rounds inside ONE launch -- agent-scope loads so that marks cross the XCDs' L2s -- cost 52 us against 36 us for three
+	// launches with plain accesses: the kernel boundary is the cheaper way to make the marks of a round visible everywhere)
 	const uint32_t n_con = d.ctr->n_constraints, n_edges = island_edges(d);
 	for (uint32_t k = blockIdx.x * TPB + threadIdx.x; k < n_edges; k += gridDim.x * TPB) {
 		uint2 ab; if (!island_edge(d, k, n_con, ab)) continue;
@@ -3059,6 +3097,43 @@ SGP_DEV void box_submerged(v3 h, m33 R, float posz, float wz, float* vol_out, v3
 	*centroid_out = vol > 1.0e-12f ? m33_mul(R, v3_scale(cen, 1.0f / vol)) : V3(0.0f, 0.0f, 0.0f);
 }
 
+// ConvexHullShape::GetSubmergedVolume: the exact part of the polyhedron under the plane -- every face polygon clipped to the half space and fanned
+// into tetrahedra whose apex lies in the plane, so that the cut surface contributes nothing (hull frame = body frame, origin = centre of mass)
+SGP_DEV void hull_submerged(const sgd_hull* hl, m33 R, float posz, float wz, float* vol_out, v3* centroid_out)
+{
+	const v3 n = m33_tmul(R, V3(0.0f, 0.0f, 1.0f));
+	const float dpl = wz - posz;
+	float lo = 3.4e38f, hi = -3.4e38f;
+	for (int i = 0; i < hl->nv; ++i) { const float t = v3_dot(n, hl->verts[i]); lo = fminf(lo, t); hi = fmaxf(hi, t); }
+	if (lo >= dpl) { *vol_out = 0.0f; *centroid_out = V3(0.0f, 0.0f, 0.0f); return; }
+	if (hi <= dpl) { *vol_out = hl->volume; *centroid_out = V3(0.0f, 0.0f, 0.0f); return; }
+	const v3 apex = v3_scale(n, dpl);
+	float vol = 0.0f; v3 cen = V3(0.0f, 0.0f, 0.0f);
+	for (int f = 0; f < hl->nf; ++f) {
+		const int b0 = hl->face_start[f], cnt = hl->face_start[f + 1] - b0;
+		// (fan from the first kept point: no polygon buffer, the face's points stream by)
+		v3 p0 = V3(0.0f, 0.0f, 0.0f), prev = p0; int np = 0;
+		for (int k = 0; k < cnt; ++k) {
+			const v3 a = hl->verts[hl->face_idx[b0 + k]], c = hl->verts[hl->face_idx[b0 + (k + 1 == cnt ? 0 : k + 1)]];
+			const float da = v3_dot(n, a) - dpl, dc = v3_dot(n, c) - dpl;
+			for (int which = 0; which < 2; ++which) {
+				v3 q;
+				if (which == 0) { if (!(da <= 0.0f)) continue; q = v3_sub(a, apex); }
+				else { if ((da <= 0.0f) == (dc <= 0.0f)) continue; const float t = da / (da - dc); q = v3_sub(v3_add(a, v3_scale(v3_sub(c, a), t)), apex); }
+				if (np == 0) p0 = q;
+				else if (np >= 2) {
+					const float tv = v3_dot(p0, v3_cross(prev, q)) / 6.0f;
+					vol += tv;
+					cen = v3_add(cen, v3_scale(v3_add(v3_add(p0, prev), q), tv * 0.25f));
+				}
+				prev = q; ++np;
+			}
+		}
+	}
+	*vol_out = vol;
+	*centroid_out = vol > 1.0e-12f ? m33_mul(R, v3_add(apex, v3_scale(cen, 1.0f / vol))) : V3(0.0f, 0.0f, 0.0f);
+}
+
 __global__ void __launch_bounds__(TPB) k_buoyancy(DV d)
 {
 	const float dt = d.sp->dt;
@@ -3074,9 +3149,18 @@ __global__ void __launch_bounds__(TPB) k_buoyancy(DV d)
 		const float4 pim = d.pose[2 * (size_t)i];
 		const v3 pos = V3(pim);
 		const m33 R = quat_to_m33(Q4(d.pose[2 * (size_t)i + 1]));
-		const float total = shape_volume(d, type, sh);
+		// Shape::GetSubmergedVolume as Jolt's shapes implement it: box and hull exactly, sphere by the cap formula, the capsule through
+		// ConvexShape's stand-in -- its local bounding box (total = the box's volume, submerged = the box's part under the plane)
+		const float real_volume = shape_volume(d, type, sh);
+		float total = real_volume;
 		float sub; v3 rc;
 		if (type == SGP_SHAPE_BOX) box_submerged(V3(sh.x, sh.y, sh.z), R, pos.z, d.sp->water_z, &sub, &rc);
+		else if (type == SGP_SHAPE_HULL) hull_submerged(body_hull(d, sh), R, pos.z, d.sp->water_z, &sub, &rc);
+		else if (type == SGP_SHAPE_CAPSULE) {
+			const v3 hb = V3(sh.x, sh.x, sh.y + sh.x);
+			total = 8.0f * hb.x * hb.y * hb.z;
+			box_submerged(hb, R, pos.z, d.sp->water_z, &sub, &rc);
+		}
 		else if (type == SGP_SHAPE_SPHERE) {
 			const float r = sh.x;
 			const float h = clampf((d.sp->water_z - pos.z) + r, 0.0f, 2.0f * r);
@@ -3091,7 +3175,7 @@ __global__ void __launch_bounds__(TPB) k_buoyancy(DV d)
 			rc = V3(0.0f, 0.0f, (mn.z + 0.5f * fr * (mx.z - mn.z)) - pos.z);
 		}
 		const float mass = d.torque[i].w;
-		const float buoyancy = fluid_density * total / mass;                         // :1387
+		const float buoyancy = fluid_density * real_volume / mass;                   // :1387 (Shape::GetVolume)
 		bool applied = false;
 		if (sub > 0.0f) {
 			const float inv_mass = pim.w;
@@ -3154,7 +3238,18 @@ __global__ void __launch_bounds__(TPB) k_cache_clear(DV d)
 	if (blockIdx.x == 0 && threadIdx.x == 0) *d.ht_cur = size;
 }
 
-__global__ void __launch_bounds__(TPB) k_cache_build(DV d)
+SGP_DEV void step_end_block(const DV& d, StepCounters* host_mapped, EventCounters* host_events)
+{
+	const uint32_t* src = (const uint32_t*)d.ctr;
+	uint32_t* dst = (uint32_t*)host_mapped;
+	for (uint32_t i = threadIdx.x; i < sizeof(StepCounters) / 4; i += TPB) dst[i] = src[i];
+	__syncthreads();
+	if (threadIdx.x == 0 && d.ts_nt) { host_mapped->ts_error = d.ts_flags[0]; host_mapped->ts_all_adjacent = d.ts_flags[1]; }
+	if (threadIdx.x < sizeof(EventCounters) / 4) ((uint32_t*)host_events)[threadIdx.x] = ((const uint32_t*)d.evc)[threadIdx.x];
+}
+
+// (round 4: the step's counters go to the host from workgroup 0 of this, the step's last, launch: k_step_end was a launch of its own)
+__global__ void __launch_bounds__(TPB) k_cache_build(DV d, StepCounters* host_mapped, EventCounters* host_events)
 {
 	const uint32_t n_con = d.ctr->n_constraints;
 	const uint32_t size = *d.ht_cur;
@@ -3168,6 +3263,9 @@ __global__ void __launch_bounds__(TPB) k_cache_build(DV d)
 			h = (h + 1) & mask;
 		}
 	}
+	// the step's counters are final before this launch starts and nothing here touches them: workgroup 0 sends them to the host, no waiting for the others
+	// (measured: a ticket + fence per workgroup after the hash-table inserts cost 42 us -- the fence writes back every dirty line of the XCD's L2)
+	if (host_mapped && blockIdx.x == 0) step_end_block(d, host_mapped, host_events);
 }
 
 __global__ void __launch_bounds__(TPB) k_contact_events(DV d)
@@ -4859,7 +4957,7 @@ void launch_step_begin(const DV& d, const StepParams& sp, uint32_t nb, bool rese
 	const uint32_t work = std::max(d.table_size + 4, reset_step_scratch ? nb : 0u);
 	uint32_t blocks = (work + TPB * 4 - 1) / (TPB * 4);
 	if (blocks < 1) blocks = 1; if (blocks > 1024) blocks = 1024;
-	hipLaunchKernelGGL(k_step_begin, dim3(blocks), dim3(TPB), 0, s, d, sp, nb, reset_step_scratch ? 1 : 0);
+	hipLaunchKernelGGL(k_step_begin, dim3(blocks), dim3(TPB), 0, s, d, sp, nb, reset_step_scratch ? 1 : 0, std::min(blocks, std::min(blocks_for(nb), 128u)));
 }
 void launch_set_params(const DV& d, const StepParams& sp, hipStream_t s) { hipLaunchKernelGGL(k_set_params, dim3(1), dim3(64), 0, s, d, sp); }
 void launch_step_end(const DV& d, StepCounters* host_mapped, EventCounters* host_events, hipStream_t s) { hipLaunchKernelGGL(k_step_end, dim3(1), dim3(TPB), 0, s, d, host_mapped, host_events); }
@@ -4870,11 +4968,7 @@ void launch_fill_u64(uint64_t* p, uint64_t v, size_t n, hipStream_t s)
 	hipLaunchKernelGGL(k_fill_u64, dim3((uint32_t)blocks), dim3(TPB), 0, s, p, v, n);
 }
 void launch_pre_solve(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_pre_solve, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
-void launch_bp_bounds(const DV& d, uint32_t nb, hipStream_t s)
-{
-	hipLaunchKernelGGL(k_bp_bounds, dim3(std::min(blocks_for(nb), 128u)), dim3(TPB), 0, s, d);
-	hipLaunchKernelGGL(k_bp_grid_params, dim3(1), dim3(64), 0, s, d);
-}
+void launch_bp_bounds(const DV&, uint32_t, hipStream_t) {}      // (round 4: inside launch_step_begin; the grid parameters inside launch_bp_cell)
 void launch_bp_cell(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_bp_cell, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_bp_scan(const DV& d, hipStream_t s)
 {
@@ -4891,6 +4985,7 @@ void launch_bp_pairs(const DV& d, int small_lds, hipStream_t s)
 	else hipLaunchKernelGGL((k_bp_pairs<BP_LDS_CAP_LARGE, BP_PAIR_CAP_LARGE>), dim3(4096), dim3(TPB), 0, s, d);
 }      // (fewer workgroups walking several tiles each were slower: 512 -> 159 us against 132 us, the tiles are uneven)
 void launch_bp_large(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_bp_large, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
+void launch_bp_scatter_large(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_bp_scatter_large, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_narrowphase(const DV& d, uint32_t est, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_narrowphase, dim3(stride_grid(est)), dim3(TPB), 0, s, d);
@@ -4916,13 +5011,12 @@ void launch_colour_count(const DV& d, uint32_t est, hipStream_t s)
 	// (few workgroups, each looping: a workgroup ends with one global atomic per colour it saw, and atomics on one address serialise)
 	// few, looping workgroups: every workgroup ends with one global atomic per colour, and those queue per colour (config 3: 512 workgroups 21 us,
 	// 256: 13 us, 128: 11 us, 64: 15 us); more of them only where there is enough to count (a million bodies)
-	hipLaunchKernelGGL(k_colour_count, dim3(std::min(std::max(stride_grid(est) / 8u, 128u), 512u)), dim3(TPB), 0, s, d);
-	hipLaunchKernelGGL(k_colour_scan, dim3(1), dim3(256), 0, s, d);
+	hipLaunchKernelGGL(k_colour_count, dim3(std::min(std::max(stride_grid(est) / 8u, 128u), 512u)), dim3(TPB), 0, s, d, 1);
 }
 void launch_ts_label(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_ts_label, dim3(blocks_for(std::max(nb, SGP_MAX_COLOURS * d.ts_nt))), dim3(TPB), 0, s, d); }
 void launch_colour_count_ts(const DV& d, uint32_t est, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_colour_count, dim3(std::min(std::max(stride_grid(est) / 8u, 128u), 512u)), dim3(TPB), 0, s, d);
+	hipLaunchKernelGGL(k_colour_count, dim3(std::min(std::max(stride_grid(est) / 8u, 128u), 512u)), dim3(TPB), 0, s, d, 0);
 	hipLaunchKernelGGL(k_ts_count, dim3(stride_grid(est)), dim3(TPB), 0, s, d);
 	hipLaunchKernelGGL(k_ts_scan, dim3(1), dim3(1024), 0, s, d);
 }
@@ -5021,10 +5115,10 @@ void launch_island_hook(const DV& d, uint32_t n_con, hipStream_t s) { hipLaunchK
 void launch_island_flag(const DV& d, uint32_t n_con, hipStream_t s) { hipLaunchKernelGGL(k_island_flag, dim3(stride_grid(n_con)), dim3(TPB), 0, s, d); }
 void launch_sleep_apply(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_sleep_apply, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_buoyancy(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_buoyancy, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
-void launch_cache_build(const DV& d, uint32_t n_con, hipStream_t s)
+void launch_cache_build(const DV& d, uint32_t n_con, StepCounters* host_mapped, EventCounters* host_events, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_cache_clear, dim3(std::max(64u, std::min(1024u, n_con / 256u))), dim3(TPB), 0, s, d);
-	hipLaunchKernelGGL(k_cache_build, dim3(stride_grid(n_con)), dim3(TPB), 0, s, d);
+	hipLaunchKernelGGL(k_cache_build, dim3(stride_grid(n_con)), dim3(TPB), 0, s, d, host_mapped, host_events);
 }
 void launch_contact_events(const DV& d, uint32_t est, hipStream_t s) { hipLaunchKernelGGL(k_contact_events, dim3(stride_grid(est)), dim3(TPB), 0, s, d); }
 void launch_ghost_refresh(const DV& d, const GhostRefresh* recs, uint32_t n, hipStream_t s) { if (n) hipLaunchKernelGGL(k_ghost_refresh, dim3(blocks_for(n)), dim3(TPB), 0, s, d, recs, n); }

@@ -323,7 +323,8 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 		HIP_TRY(hipMemcpyAsync(&w->d_hulls[0], &w->hulls[0], sizeof(sgd_hull), hipMemcpyHostToDevice, w->stream));
 		d.n_hulls = 1;
 	}
-	DEV_ALLOC(d.sorted_min, N); DEV_ALLOC(d.sorted_max, N); DEV_ALLOC(d.grid, 1); DEV_ALLOC(d.grid_cells_used, 1); DEV_ALLOC(d.scan_block_sums, (d.table_size + 1) / 1024 + 2);
+	DEV_ALLOC(d.sorted_min, N); DEV_ALLOC(d.sorted_max, N); DEV_ALLOC(d.grid, 1); DEV_ALLOC(d.grid_cells_used, 1);
+	DEV_ALLOC(d.bounds_acc, 8); { const int init[8] = { 0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000, (int)0x80000000, 0, 0 }; if (hipMemcpyAsync(d.bounds_acc, init, sizeof(init), hipMemcpyHostToDevice, w->stream) != hipSuccess || hipStreamSynchronize(w->stream) != hipSuccess) return fail(SGP_ERR_HIP, "bounds_acc init"); } DEV_ALLOC(d.scan_block_sums, (d.table_size + 1) / 1024 + 2);
 	DEV_ALLOC(d.pairs, P);
 	DEV_ALLOC(d.man_ab, M); DEV_ALLOC(d.man_n, M); DEV_ALLOC(d.man_colour, M); DEV_ALLOC(d.man_prio, M); DEV_ALLOC(d.man_prev, M); DEV_ALLOC(d.man_slot, M);
 	DEV_ALLOC(d.hc_root, N); DEV_ALLOC(d.hc_count, N); DEV_ALLOC(d.hc_base, N); DEV_ALLOC(d.hc_rank, M);
@@ -1185,10 +1186,9 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 	//         (VehicleConstraint::OnStep: wheel casts), then forces, then the pair search
 	{ KScope k(w, KC_BP_CELL); launch_bp_bounds(d, nb, s); launch_bp_cell(d, nb, s); }
 	{ KScope k(w, KC_BP_SCAN); launch_bp_scan(d, s); }
-	{ KScope k(w, KC_BP_SCATTER); launch_bp_scatter(d, nb, s); }
+	{ KScope k(w, KC_BP_SCATTER); launch_bp_scatter_large(d, nb, s); }      // (+ the pairs with the large bodies: k_bp_large's work)
 	if (p.n_vehicles) { KScope k(w, KC_VEHICLE); launch_vehicle_pre(d, s); }
 	{ KScope k(w, KC_BP_PAIRS); launch_bp_pairs(d, p.bp_small, s); }
-	{ KScope k(w, KC_BP_LARGE); launch_bp_large(d, nb, s); }
 	STAGE_MARK(2);
 	// -- 3. narrow phase, wake-ups, per-body solver records (+ contact events, which see the velocities before the solve)
 	{ KScope k(w, KC_NARROWPHASE); launch_narrowphase(d, p.est_pairs, s); if (p.has_hulls) launch_narrowphase_hull(d, s); if (p.has_meshes) launch_narrowphase_mesh(d, s); }
@@ -1235,7 +1235,6 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 			// vehicle rows first, then every contact constraint of the regular colours (one launch, by body), then the overflow colour
 			if (p.n_vehicles) { KScope k(w, KC_VEHICLE); launch_vehicle_solve(d, 0, s); }
 			{ KScope k(w, KC_WARM_START); launch_warm_bodies(d, nb, s); }
-			{ KScope k(w, KC_WARM_START); launch_solve_tail(d, SGP_OVERFLOW_COLOUR, 0, s); }
 		}
 		if (p.tile_solver == 1) { KScope k(w, KC_SOLVE_VELOCITY); launch_ts_solve(d, p.vel_iters, SGP_MAX_COLOURS, s); }
 		else if (p.tile_solver == 3 && p.hc_first >= 0) {
@@ -1263,10 +1262,9 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 	if (p.water) { KScope k(w, KC_BUOYANCY); launch_buoyancy(d, nb, s); }
 	{
 		KScope k(w, KC_CACHE_BUILD);
-		launch_cache_build(d, p.est_man, s);
+		launch_cache_build(d, p.est_man, w->h_ctr_dev, w->h_evc_dev, s);      // (+ the counters to host-mapped memory: the step's last launch)
 	}
 	STAGE_MARK(8);
-	launch_step_end(d, w->h_ctr_dev, w->h_evc_dev, s);
 	return SGP_OK;
 }
 

@@ -143,6 +143,43 @@ def test_buoyancy_half_density_cube_floats_half_submerged(world):
     assert len(ev) == 1 and ev[0]["id"] == i
 
 
+def test_submerged_volume_of_hulls_and_capsules(oracle):
+    """Shape::GetSubmergedVolume as Jolt's shapes do it (PhysicsWorld.cpp:1389-1396 calls it): a convex hull exactly -- a tilted tetrahedron
+    against the closed form, a cube-shaped hull against the box routine --, a capsule through ConvexShape's stand-in, its local bounding box."""
+    w = oracle.OracleWorld(max_bodies=16, gravity=(0.0, 0.0, 0.0))
+    w.set_water(True, 0.0)
+    # (1) cube-shaped hull, tilted, vs the same box: equal submerged volume and equal motion
+    pts = np.array([(sx * 0.5, sy * 0.4, sz * 0.3) for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], np.float32)
+    hi = w.hull_create(pts)
+    rot = quat_axis_angle((1.0, 0.3, 0.0), 0.7)
+    b = dyn(w, shape=(0.5, 0.4, 0.3, 0.0), pos=(0, 0, 0.05), rot=rot, mass=60.0, allow_sleeping=0)
+    h = dyn(w, shape_type=abi.SHAPE_HULL, shape=(float(hi.hull_id), 0, 0, 0), pos=(5, 0, 0.05), rot=rot, mass=60.0, allow_sleeping=0)
+    # (2) regular tetrahedron hull, apex down: the part under a horizontal plane at height t above the apex is a similar tetrahedron
+    a = 1.0
+    tet = np.array([(0, 0, 0), (a, 0, 0), (a / 2, a * np.sqrt(3) / 2, 0), (a / 2, a * np.sqrt(3) / 6, a * np.sqrt(2.0 / 3.0))], np.float32)
+    ti = w.hull_create(tet)
+    height = a * np.sqrt(2.0 / 3.0)
+    vol = a ** 3 / (6 * np.sqrt(2))
+    assert abs(ti.volume - vol) < 1e-5
+    # the hull frame: centre of mass at a quarter of the height above the base; turn the hull upside down (apex down) about x
+    t = dyn(w, shape_type=abi.SHAPE_HULL, shape=(float(ti.hull_id), 0, 0, 0), pos=(10, 0, 0.0), rot=quat_axis_angle((1, 0, 0), np.pi), mass=30.0, allow_sleeping=0)
+    # (3) capsule lying on its side, centre at the surface: half of its bounding box (2r x 2r x 2(hh + r)) is under water
+    c = dyn(w, shape_type=abi.SHAPE_CAPSULE, shape=(0.3, 0.65, 0, 0), pos=(15, 0, 0.0), rot=quat_axis_angle((0, 1, 0), np.pi / 2), mass=40.0, allow_sleeping=0)
+    w.step(DT)
+    sb, sh, st, sc = (w.get_state([i])[0] for i in (b, h, t, c))
+    assert abs(sb["submerged_volume"] - sh["submerged_volume"]) < 2e-6 and 0.1 < sh["submerged_volume"] < 0.4
+    assert np.allclose(sb["lin_vel"], sh["lin_vel"], atol=1e-6) and np.allclose(sb["ang_vel"], sh["ang_vel"], atol=2e-5)
+    # apex-down tetrahedron with its centre of mass at z = 0: the apex is 3/4 height below the surface
+    depth = 0.75 * height
+    assert abs(st["submerged_volume"] - vol * (depth / height) ** 3) < 2e-5, (st["submerged_volume"], vol * (depth / height) ** 3)
+    box = 8 * 0.3 * 0.3 * (0.65 + 0.3)
+    assert abs(sc["submerged_volume"] - 0.5 * box) < 1e-5
+    # buoyancy impulse = 1020 * (real volume) * (submerged fraction of the box) * g dt / m   (drag is zero: the body was at rest)
+    real = np.pi * 0.3 ** 2 * (2 * 0.65 + 4.0 / 3.0 * 0.3)
+    assert abs(sc["lin_vel"][2] - 1020.0 * real * 0.5 * 9.81 * DT / 40.0) < 1e-4
+    w.close()
+
+
 def test_layer_matrix(oracle):
     """(viii) MyObjectLayerPairFilter truth table, PhysicsWorld.cpp:151-189."""
     NM, M, NMNC, MNC = 0, 1, 2, 3

@@ -144,15 +144,26 @@ def test_buoyancy(oracle):
         dyn(w, pos=(0, 0, 0.2), mass=510.0, allow_sleeping=0, rot=quat_axis_angle((1, 1, 0), 0.3))
         dyn(w, abi.SHAPE_SPHERE, (0.5,), pos=(3, 0, 0.1), mass=200.0, allow_sleeping=0)
         dyn(w, abi.SHAPE_CAPSULE, (0.3, 0.65), pos=(6, 0, 0.3), mass=100.0, allow_sleeping=0)
-    for _ in range(240):
+        # round 4: a tumbling capsule (ConvexShape's bounding-box stand-in, oriented) and two convex hulls (exact polyhedron under the plane)
+        dyn(w, abi.SHAPE_CAPSULE, (0.25, 0.5), pos=(9, 0, 0.4), mass=60.0, allow_sleeping=0, rot=quat_axis_angle((1, 0.2, 0), 1.1), ang_vel=(0.5, 1.0, 0.0))
+        rng = np.random.default_rng(5)
+        for k in range(2):
+            hi = w.hull_create((rng.normal(size=(14, 3)) * (0.5, 0.4, 0.3)).astype(np.float32))
+            dyn(w, abi.SHAPE_HULL, (float(hi.hull_id), 0, 0, 0), pos=(12 + 3 * k, 0, 0.3), mass=120.0 + 200.0 * k, allow_sleeping=0, rot=quat_axis_angle((0.3, 1, 0.2), 0.8 * (k + 1)), ang_vel=(0.0, 0.7, 0.3))
+    nb = 6
+    for s_ in range(240):
         tw.step(DT)
-    d = parity.compare(tw, 3)
+        if s_ in (0, 10, 60):
+            d = parity.compare(tw, nb)
+            assert d["bit_exact"], (s_, d)
+    d = parity.compare(tw, nb)
     assert d["pos"] <= POS_TOL and d["lin_vel"] <= VEL_TOL, d
-    sg, sc = tw.gpu.read_states(0, 3), tw.cpu.read_states(0, 3)
+    assert d["bit_exact"], d
+    sg, sc = tw.gpu.read_states(0, nb), tw.cpu.read_states(0, nb)
     assert np.array_equal(sg["underwater"], sc["underwater"]) and sg["underwater"][0] == 1
-    assert np.allclose(sg["submerged_volume"], sc["submerged_volume"], atol=1e-5)
+    assert np.array_equal(sg["submerged_volume"].view(np.uint32), sc["submerged_volume"].view(np.uint32))
     eg, ec = tw.drain_events(abi.EVENT_ENTERED_WATER)
-    assert np.array_equal(eg["id"], ec["id"]) and len(eg) == 3
+    assert np.array_equal(eg["id"], ec["id"]) and set(eg["id"].tolist()) == set(range(nb))      # (the tumbling capsule leaves and re-enters)
     tw.close()
 
 
