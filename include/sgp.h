@@ -627,6 +627,8 @@ typedef struct sgp_tiles_stats {
 	uint32_t exchanges;      /* sgp_tiles_exchange calls so far                                                           */
 	float    comm_init_ms;   /* wall time of ncclCommInitRank                                                             */
 	float    last_exchange_ms, total_exchange_ms;    /* host wall time of sgp_tiles_exchange: the last call, all calls    */
+	uint32_t rebalances;     /* sgp_tiles_rebalance calls that moved this tile's region                                  */
+	uint32_t reserved0;
 } sgp_tiles_stats;
 #define SGP_MIGRATION_OUT 0
 #define SGP_MIGRATION_IN  1
@@ -644,6 +646,16 @@ int  sgp_tiles_destroy(sgp_tiles* t);
 int  sgp_tiles_exchange(sgp_tiles* t);
 int  sgp_tiles_exchange_group(sgp_tiles** tiles, uint32_t n_tiles);
 int  sgp_tiles_get_stats(sgp_tiles* t, sgp_tiles_stats* out);
+/* Re-tiling by body count (collective; round 4).  A static split of a scene that moves leaves tiles without work -- BASELINE config 4 is a tower that
+ * falls out of its upper tiles.  The grid gx x gy x gz (gx gy gz = n_tiles, tile = ix + gx (iy + gy iz), at most 4 per axis) keeps its topology; its
+ * split planes move to the quantiles of where the OWNED dynamic bodies are (x planes from all bodies, the y planes of an x slab from that slab's, the z
+ * planes of an (x, y) column from that column's).  Every tile computes the same planes from the same all-gathered counts; bodies then change owner
+ * through the ordinary migration of the following exchanges.  sgp_tiles_rebalance: one tile per process, over the communicator;
+ * sgp_tiles_rebalance_group: all tiles of one process.  sgp_tiles_get_boxes: the regions now in force (n_tiles x (lo xyz, hi xyz)).
+ * by_contacts != 0: a body counts 1 + the contact constraints it was in during the last step (a tile's work is its constraints more than its bodies). */
+int  sgp_tiles_rebalance(sgp_tiles* t, uint32_t gx, uint32_t gy, uint32_t gz, int by_contacts);
+int  sgp_tiles_rebalance_group(sgp_tiles** tiles, uint32_t n_tiles, uint32_t gx, uint32_t gy, uint32_t gz, int by_contacts);
+int  sgp_tiles_get_boxes(sgp_tiles* t, float* boxes_out);
 /* Ownership changes since the last drain (both directions), oldest first; n_out = how many were pending. */
 int  sgp_tiles_drain_migrations(sgp_tiles* t, sgp_migration* out, uint32_t cap, uint32_t* n_out);
 

@@ -112,7 +112,7 @@ GHOST_FLAG_LAYER_MASK, GHOST_FLAG_SENSOR, GHOST_FLAG_ALLOW_SLEEP, GHOST_FLAG_ZER
 class TilesStats(C.Structure):
     _fields_ = [("exported", u32), ("sent", u32), ("received", u32), ("ghosts", u32), ("emigrated", u32), ("immigrated", u32),
                 ("fast_imports", u32), ("slow_imports", u32), ("route_retries", u32), ("comm_ranks", u32), ("exchanges", u32),
-                ("comm_init_ms", f32), ("last_exchange_ms", f32), ("total_exchange_ms", f32)]
+                ("comm_init_ms", f32), ("last_exchange_ms", f32), ("total_exchange_ms", f32), ("rebalances", u32), ("reserved0", u32)]
 
 
 class BodyCounts(C.Structure):
@@ -310,6 +310,9 @@ PROTOTYPES = {
     "tiles_exchange": (C.c_int, [vp]),
     "tiles_exchange_group": (C.c_int, [vp, u32]),
     "tiles_get_stats": (C.c_int, [vp, P(TilesStats)]),
+    "tiles_rebalance": (C.c_int, [vp, u32, u32, u32, C.c_int]),
+    "tiles_rebalance_group": (C.c_int, [vp, u32, u32, u32, u32, C.c_int]),
+    "tiles_get_boxes": (C.c_int, [vp, vp]),
     "tiles_drain_migrations": (C.c_int, [vp, vp, u32, P(u32)]),
     "world_device_array": (C.c_int, [vp, C.c_int, P(vp), P(u32)]),
     "world_stream": (C.c_int, [vp, P(vp)]),

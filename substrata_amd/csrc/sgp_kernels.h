@@ -365,6 +365,11 @@ struct TileRoute { float boxes[6 * SGP_MAX_TILES]; uint32_t n_tiles, my_rank; fl
 // what the routing kernels leave for the host (and for the counts all-gather): records per destination, where each destination's segment
 // starts in the send buffer, how many owned bodies emigrate
 struct RouteHeader { uint32_t seg_count[SGP_MAX_TILES]; uint32_t seg_start[SGP_MAX_TILES]; uint32_t n_emigrants; uint32_t total; uint32_t pad[2]; };
+// Re-tiling by body count (sgp_tiles_rebalance): the split planes found so far + what the histogram kernel needs
+#define SGP_TILE_HIST_BINS 1024
+struct TilePlanes { uint32_t gx, gy, gz, by_contacts; float glo[3], ghi[3]; float xp[4]; float yp[16]; };      // x planes [gx - 1]; y planes of x slab ix at [4 ix ..]
+// level 0: bounds of the owned dynamic bodies' centres (six ordered ints, atomicMin / Max); level 1 / 2 / 3: histogram of x / y (per x slab) / z (per (x, y) column)
+void launch_tiles_hist(const DV& d, uint32_t nb, const TilePlanes& tp, int level, uint32_t* out, hipStream_t s);
 // block_counts / block_offsets: [block][n_tiles + 1] (last column: emigrants)
 void launch_route_export(const DV& d, uint32_t nb, const TileRoute& t, uint32_t* block_counts, uint32_t* block_offsets, RouteHeader* header,
                          sgp_ghost_record* out, uint32_t cap, uint32_t* emigrant_ids, uint32_t emigrant_cap, hipStream_t s);

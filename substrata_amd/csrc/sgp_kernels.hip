@@ -4528,6 +4528,35 @@ SGP_DEV unsigned long long route_mask(const DV& d, uint32_t i, const TileRoute& 
 	return m;
 }
 
+// Where the owned bodies are, for sgp_tiles_rebalance (a few times a second at most: plain global atomics)
+__global__ void __launch_bounds__(TPB) k_tiles_hist(DV d, TilePlanes tp, int level, uint32_t* out)
+{
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i >= d.sp->n_slots) return;
+	const uint32_t f = d.flags[i];
+	if (!(f & BF_ALIVE) || (f & BF_ALIAS) || f_motion(f) != SGP_MOTION_DYNAMIC) return;      // (ghosts are kinematic here: owned bodies only)
+	const float4 p = d.pose[2 * (size_t)i];
+	if (level == 0) {
+		int* o = (int*)out;
+		atomicMin(&o[0], float_to_ordered(p.x)); atomicMin(&o[1], float_to_ordered(p.y)); atomicMin(&o[2], float_to_ordered(p.z));
+		atomicMax(&o[3], float_to_ordered(p.x)); atomicMax(&o[4], float_to_ordered(p.y)); atomicMax(&o[5], float_to_ordered(p.z));
+		return;
+	}
+	uint32_t ix = 0, iy = 0;
+	for (uint32_t k = 0; k + 1 < tp.gx; ++k) if (p.x >= tp.xp[k]) ix = k + 1;
+	if (level == 3) for (uint32_t k = 0; k + 1 < tp.gy; ++k) if (p.y >= tp.yp[4 * ix + k]) iy = k + 1;
+	const int a = level - 1;
+	const float c = a == 0 ? p.x : (a == 1 ? p.y : p.z);
+	const float w = tp.ghi[a] - tp.glo[a];
+	int bin = w > 0.0f ? (int)floorf((c - tp.glo[a]) / w * (float)SGP_TILE_HIST_BINS) : 0;
+	bin = min(max(bin, 0), SGP_TILE_HIST_BINS - 1);
+	const uint32_t group = level == 1 ? 0u : (level == 2 ? ix : ix + tp.gx * iy);
+	// what a body weighs: 1, or (by_contacts) 1 + the contact constraints it was in last step (the colours in its mask): the work of a tile is its
+	// constraints more than its bodies, and a pile has them at the bottom
+	const uint32_t wgt = tp.by_contacts ? 1u + (uint32_t)__popcll(d.colour_mask[i]) : 1u;
+	atomicAdd(&out[group * SGP_TILE_HIST_BINS + (uint32_t)bin], wgt);
+}
+
 __global__ void __launch_bounds__(TPB) k_route_count(DV d, TileRoute t, uint32_t* block_counts)
 {
 	__shared__ uint32_t cnt[SGP_MAX_TILES + 1];
@@ -5152,6 +5181,7 @@ void launch_route_export(const DV& d, uint32_t nb, const TileRoute& t, uint32_t*
 	hipLaunchKernelGGL(k_route_scan, dim3(1), dim3(1024), 0, s, (const uint32_t*)block_counts, block_offsets, blocks, t.n_tiles, header);
 	hipLaunchKernelGGL(k_route_write, dim3(blocks), dim3(TPB), 0, s, d, t, (const uint32_t*)block_offsets, (const RouteHeader*)header, out, cap, emigrant_ids, emigrant_cap);
 }
+void launch_tiles_hist(const DV& d, uint32_t nb, const TilePlanes& tp, int level, uint32_t* out, hipStream_t s) { hipLaunchKernelGGL(k_tiles_hist, dim3(blocks_for(nb)), dim3(TPB), 0, s, d, tp, level, out); }
 void launch_pack_ghost_keys(const sgp_ghost_record* recs, uint32_t n, void* out, hipStream_t s)
 {
 	if (n) hipLaunchKernelGGL(k_pack_ghost_keys, dim3(blocks_for(n)), dim3(TPB), 0, s, recs, n, (uint4*)out);

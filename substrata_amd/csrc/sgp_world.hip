@@ -1353,6 +1353,9 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 			// (a scene that keeps growing -- a tower coming down -- outruns single steps: the stride doubles while catch-alls follow each other closely)
 			w->hc_bump = (w->hc_since_bump < 32u) ? std::min(2u * w->hc_bump, 8u) : 1u;
 			w->hc_since_bump = 0;
+			// (round 4: a BIG miss -- thousands of constraints in the serial catch-all, 10+ ms in a tile of the collapsing 1M tower -- takes the plan well clear
+			// of where it missed at once: the probes bring it back a colour at a time when the scene has calmed down)
+			if (c1.hc_n_big > 4096u) w->hc_bump = 8u;
 			k = std::min(k + (int)w->hc_bump, (int)SGP_OVERFLOW_COLOUR - 1); w->hc_probe_gap = 64; w->hc_probe_in = 64;
 		}
 		else if (plan.hc_probe >= 0) {
@@ -2708,6 +2711,8 @@ struct sgp_tiles {
 	bool seq_valid = false;
 	sgp_tiles_stats stats;
 	std::vector<sgp_migration> migrations;
+	// re-tiling (sgp_tiles_rebalance): this tile's histogram, everybody's (RCCL all-gather), the pinned host copy
+	uint32_t* d_hist = nullptr; uint32_t* d_hist_all = nullptr; uint32_t* h_hist = nullptr;
 };
 static size_t tiles_matrix_off() { return sizeof(RouteHeader); }
 static size_t tiles_emig_off(uint32_t n_tiles) { return sizeof(RouteHeader) + sizeof(uint32_t) * (size_t)n_tiles * n_tiles; }
@@ -2745,6 +2750,7 @@ SGP_API int sgp_tiles_destroy(sgp_tiles* t)
 	if (t->h_recv) hipHostFree(t->h_recv);
 	if (t->h_keys) hipHostFree(t->h_keys);
 	hipFree(t->d_keys);
+	hipFree(t->d_hist); hipFree(t->d_hist_all); if (t->h_hist) hipHostFree(t->h_hist);
 	delete t;
 	return SGP_OK;
 }
@@ -2996,6 +3002,110 @@ SGP_API int sgp_tiles_exchange_group(sgp_tiles** ts, uint32_t n)
 		t->stats.sent = ((const RouteHeader*)t->h_ctl)->total;
 		{ int r = tiles_import(t, n_recv); if (r != SGP_OK) return r; }
 	}
+	return SGP_OK;
+}
+
+// ---- re-tiling by body count ------------------------------------------------------------------------------------------------------
+// A static split of a scene that moves -- BASELINE config 4 is a tower that falls out of its upper tiles -- leaves tiles without work.  The grid keeps
+// its topology (gx x gy x gz, tile = ix + gx (iy + gy iz)); its planes move to the quantiles of where the OWNED bodies are: the x planes from all
+// bodies, the y planes of every x slab from that slab's bodies, the z planes of every (x, y) column from that column's.  Four small rounds (bounds,
+// then one histogram of SGP_TILE_HIST_BINS bins per axis and group), each a kernel + an all-gather of a few KB + one read-back; every rank derives the
+// same planes from the same gathered counts.  Bodies then change owner through the ordinary migration of the next exchange.
+#define TILE_HIST_MAX_GROUPS 16
+static int tiles_hist_buffers(sgp_tiles* t)
+{
+	const size_t one = sizeof(uint32_t) * TILE_HIST_MAX_GROUPS * SGP_TILE_HIST_BINS;
+	if (!t->d_hist) { HIP_TRY(hipMalloc((void**)&t->d_hist, one)); HIP_TRY(hipMalloc((void**)&t->d_hist_all, one * t->n_tiles)); HIP_TRY(hipHostMalloc((void**)&t->h_hist, one * t->n_tiles, hipHostMallocDefault)); }
+	return SGP_OK;
+}
+// one round on the tiles of this process (one with a communicator, or all of a group): sum[k] = counts over every tile (level 0: min / max as ordered ints)
+static int tiles_hist_round(sgp_tiles** ts, uint32_t n_local, const TilePlanes& tp, int level, uint32_t len, std::vector<uint64_t>& sum, int bounds[6])
+{
+	const uint32_t T = ts[0]->n_tiles;
+	for (uint32_t i = 0; i < n_local; ++i) {
+		sgp_tiles* t = ts[i]; sgp_world* w = t->w;
+		hipSetDevice(w->device);
+		{ int r = tiles_hist_buffers(t); if (r != SGP_OK) return r; }
+		{ int r = flush_cmds(w); if (r != SGP_OK) return r; }
+		if (level == 0) { int* h = (int*)t->h_hist; for (int k = 0; k < 6; ++k) h[k] = k < 3 ? 0x7FFFFFFF : (int)0x80000000; h[6] = h[7] = 0; HIP_TRY(hipMemcpyAsync(t->d_hist, h, 32, hipMemcpyHostToDevice, w->stream)); }
+		else HIP_TRY(hipMemsetAsync(t->d_hist, 0, sizeof(uint32_t) * len, w->stream));
+		if (w->high) launch_tiles_hist(w->dv, w->high, tp, level, t->d_hist, w->stream);
+		if (t->comm) {
+			RCCL_TRY(g_rccl.AllGather(t->d_hist, t->d_hist_all, len, SGP_NCCL_UINT32, t->comm, w->stream), "ncclAllGather (re-tiling)");
+			HIP_TRY(hipMemcpyAsync(t->h_hist, t->d_hist_all, sizeof(uint32_t) * (size_t)len * T, hipMemcpyDeviceToHost, w->stream));
+		} else HIP_TRY(hipMemcpyAsync(t->h_hist, t->d_hist, sizeof(uint32_t) * len, hipMemcpyDeviceToHost, w->stream));
+	}
+	for (uint32_t i = 0; i < n_local; ++i) { hipSetDevice(ts[i]->w->device); HIP_TRY(hipStreamSynchronize(ts[i]->w->stream)); }
+	sum.assign(len, 0);
+	for (int k = 0; k < 6; ++k) bounds[k] = k < 3 ? 0x7FFFFFFF : (int)0x80000000;
+	auto fold = [&](const uint32_t* h) {
+		if (level == 0) { const int* b = (const int*)h; for (int k = 0; k < 3; ++k) { bounds[k] = std::min(bounds[k], b[k]); bounds[3 + k] = std::max(bounds[3 + k], b[3 + k]); } }
+		else for (uint32_t k = 0; k < len; ++k) sum[k] += h[k];
+	};
+	if (ts[0]->comm) for (uint32_t r = 0; r < T; ++r) fold(ts[0]->h_hist + (size_t)r * len);
+	else for (uint32_t i = 0; i < n_local; ++i) fold(ts[i]->h_hist);
+	return SGP_OK;
+}
+static inline float ordered_int_to_float(int i) { const int v = i >= 0 ? i : i ^ 0x7FFFFFFF; float f; memcpy(&f, &v, 4); return f; }
+// the g - 1 planes that cut a histogram into g parts of equal count (linear inside a bin); an empty histogram is cut evenly
+static void quantile_planes(const uint64_t* h, float lo, float hi, uint32_t g, float* planes)
+{
+	uint64_t total = 0; for (uint32_t b = 0; b < SGP_TILE_HIST_BINS; ++b) total += h[b];
+	const double bw = ((double)hi - (double)lo) / SGP_TILE_HIST_BINS;
+	for (uint32_t k = 1; k < g; ++k) {
+		if (!total) { planes[k - 1] = (float)(lo + ((double)hi - lo) * k / g); continue; }
+		const double target = (double)total * k / g;
+		uint64_t cum = 0; uint32_t b = 0;
+		while (b + 1 < SGP_TILE_HIST_BINS && (double)(cum + h[b]) < target) { cum += h[b]; ++b; }
+		const double frac = h[b] ? (target - (double)cum) / (double)h[b] : 0.5;
+		planes[k - 1] = (float)(lo + (b + std::min(1.0, std::max(0.0, frac))) * bw);
+	}
+	for (uint32_t k = 1; k + 1 < g; ++k) if (planes[k] < planes[k - 1]) planes[k] = planes[k - 1];
+}
+static int tiles_rebalance_impl(sgp_tiles** ts, uint32_t n_local, uint32_t gx, uint32_t gy, uint32_t gz, int by_contacts)
+{
+	const uint32_t T = ts[0]->n_tiles;
+	if (!gx || !gy || !gz || gx > 4 || gy > 4 || gz > 4 || gx * gy * gz != T) return fail(SGP_ERR_INVALID, "sgp_tiles_rebalance: the grid must have one cell per tile (at most 4 per axis)");
+	TilePlanes tp; memset(&tp, 0, sizeof(tp)); tp.gx = gx; tp.gy = gy; tp.gz = gz; tp.by_contacts = by_contacts ? 1u : 0u;
+	std::vector<uint64_t> sum; int bounds[6];
+	{ int r = tiles_hist_round(ts, n_local, tp, 0, 8, sum, bounds); if (r != SGP_OK) return r; }
+	if (bounds[0] > bounds[3]) return SGP_OK;                         // nobody owns a dynamic body: nothing to balance
+	for (int a = 0; a < 3; ++a) { tp.glo[a] = ordered_int_to_float(bounds[a]); tp.ghi[a] = ordered_int_to_float(bounds[3 + a]); const float pad = 1.0e-3f * (1.0f + fabsf(tp.ghi[a] - tp.glo[a])); tp.glo[a] -= pad; tp.ghi[a] += pad; }
+	{ int r = tiles_hist_round(ts, n_local, tp, 1, SGP_TILE_HIST_BINS, sum, bounds); if (r != SGP_OK) return r; }
+	quantile_planes(sum.data(), tp.glo[0], tp.ghi[0], gx, tp.xp);
+	{ int r = tiles_hist_round(ts, n_local, tp, 2, gx * SGP_TILE_HIST_BINS, sum, bounds); if (r != SGP_OK) return r; }
+	for (uint32_t ix = 0; ix < gx; ++ix) quantile_planes(sum.data() + (size_t)ix * SGP_TILE_HIST_BINS, tp.glo[1], tp.ghi[1], gy, tp.yp + 4 * ix);
+	{ int r = tiles_hist_round(ts, n_local, tp, 3, gx * gy * SGP_TILE_HIST_BINS, sum, bounds); if (r != SGP_OK) return r; }
+	float zp[16 * 4]; memset(zp, 0, sizeof(zp));
+	for (uint32_t c = 0; c < gx * gy; ++c) quantile_planes(sum.data() + (size_t)c * SGP_TILE_HIST_BINS, tp.glo[2], tp.ghi[2], gz, zp + 4 * c);
+	const float big = 1.0e9f;
+	float boxes[6 * SGP_MAX_TILES];
+	for (uint32_t r = 0; r < T; ++r) {
+		const uint32_t ix = r % gx, iy = (r / gx) % gy, iz = r / (gx * gy);
+		float* lo = boxes + 6 * r; float* hi = lo + 3;
+		lo[0] = ix ? tp.xp[ix - 1] : -big; hi[0] = ix + 1 < gx ? tp.xp[ix] : big;
+		lo[1] = iy ? tp.yp[4 * ix + iy - 1] : -big; hi[1] = iy + 1 < gy ? tp.yp[4 * ix + iy] : big;
+		lo[2] = iz ? zp[4 * (ix + gx * iy) + iz - 1] : -big; hi[2] = iz + 1 < gz ? zp[4 * (ix + gx * iy) + iz] : big;
+	}
+	for (uint32_t i = 0; i < n_local; ++i) { memcpy(ts[i]->route.boxes, boxes, sizeof(float) * 6 * T); ts[i]->stats.rebalances++; }
+	return SGP_OK;
+}
+SGP_API int sgp_tiles_rebalance(sgp_tiles* t, uint32_t gx, uint32_t gy, uint32_t gz, int by_contacts)
+{
+	if (!t || !t->w) return fail(SGP_ERR_INVALID, "sgp_tiles_rebalance: NULL");
+	if (t->n_tiles > 1 && !t->comm) return fail(SGP_ERR_INVALID, "sgp_tiles_rebalance: created without a communicator (use sgp_tiles_rebalance_group for tiles of one process)");
+	return tiles_rebalance_impl(&t, 1, gx, gy, gz, by_contacts);
+}
+SGP_API int sgp_tiles_rebalance_group(sgp_tiles** ts, uint32_t n, uint32_t gx, uint32_t gy, uint32_t gz, int by_contacts)
+{
+	if (!ts || !n) return fail(SGP_ERR_INVALID, "sgp_tiles_rebalance_group: NULL");
+	for (uint32_t i = 0; i < n; ++i) if (!ts[i] || ts[i]->n_tiles != n || ts[i]->rank != i || ts[i]->comm) return fail(SGP_ERR_INVALID, "sgp_tiles_rebalance_group: pass all tiles of the (communicator-less) group, in rank order");
+	return tiles_rebalance_impl(ts, n, gx, gy, gz, by_contacts);
+}
+SGP_API int sgp_tiles_get_boxes(sgp_tiles* t, float* boxes_out)
+{
+	if (!t || !boxes_out) return fail(SGP_ERR_INVALID, "sgp_tiles_get_boxes: NULL");
+	memcpy(boxes_out, t->route.boxes, sizeof(float) * 6 * t->n_tiles);
 	return SGP_OK;
 }
 

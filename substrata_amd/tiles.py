@@ -184,6 +184,25 @@ class NativeTiles:
         if rc != 0:
             raise RuntimeError(f"sgp_tiles_exchange_group failed ({rc}): {lib.sgp_last_error().decode()}")
 
+    def rebalance(self, grid, by_contacts=False):
+        """Collective: move the grid's split planes to the body-count (or body + contact count) quantiles (sgp_tiles_rebalance)."""
+        rc = self._lib.sgp_tiles_rebalance(self._h, int(grid[0]), int(grid[1]), int(grid[2]), int(by_contacts))
+        if rc != 0:
+            raise RuntimeError(f"sgp_tiles_rebalance failed ({rc}): {self._lib.sgp_last_error().decode()}")
+
+    @staticmethod
+    def rebalance_group(tiles_list, grid, by_contacts=False):
+        arr = (C.c_void_p * len(tiles_list))(*[t._h for t in tiles_list])
+        lib = tiles_list[0]._lib
+        rc = lib.sgp_tiles_rebalance_group(arr, len(tiles_list), int(grid[0]), int(grid[1]), int(grid[2]), int(by_contacts))
+        if rc != 0:
+            raise RuntimeError(f"sgp_tiles_rebalance_group failed ({rc}): {lib.sgp_last_error().decode()}")
+
+    def boxes(self):
+        out = np.zeros((self.n, 6), dtype=np.float32)
+        self._lib.sgp_tiles_get_boxes(self._h, out.ctypes.data)
+        return out
+
     def stats(self):
         s = abi.TilesStats()
         self._lib.sgp_tiles_get_stats(self._h, C.byref(s))
