@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-readback-leg", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=8)
+    ap.add_argument("--retile-every", type=int, default=16, help="config4 on N > 1 GPUs: move the tiles' split planes to the quantiles of bodies + contacts every this many steps (0: static split)")
     ap.add_argument("--force-comm", action="store_true", help="N = 1 with --workload config4: build the process group and the RCCL communicator anyway "
                     "(one rank), so that a one-GPU box runs the very code path of N > 1")
     return ap.parse_args()
@@ -246,10 +247,18 @@ def main():
             exchange_kind = "sgp_tiles_exchange: device routing + RCCL all-gather of counts + grouped send/recv inside libsgp.so"
 
 
+        # config 4 over several tiles: the regions follow the bodies (sgp_tiles_rebalance every --retile-every steps; 0 = the static split, whose upper
+        # tiles run empty when the tower has fallen: profiles/r04_config4_tiles_projection.md)
+        retile_grid = tiles.tile_grid(n_gpus) if (workload == "config4" and (n_gpus > 1 or args.force_comm) and args.retile_every > 0) else None
+        step_no = [0]
+
         def one_step():
             if ex is not None:
+                if retile_grid is not None and step_no[0] % args.retile_every == 0:
+                    ex.rebalance(retile_grid, by_contacts=True)
                 ex.exchange()
             w.step(DT)
+            step_no[0] += 1
 
         for _ in range(SETTLE_STEPS_TILED):
             one_step()

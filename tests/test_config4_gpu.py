@@ -136,3 +136,58 @@ def test_config4_scaled_down_2x2x2_tiles_against_oracle(oracle):
         t.close()
     for w in gpu + cpu:
         w.close()
+
+
+def test_config4_scaled_down_tiles_with_rebalancing_against_oracle(oracle):
+    """The same falling tower with the tile regions re-balanced every 12 steps (sgp_tiles_rebalance_group: split planes at the quantiles of the
+    owned bodies, by body count and by bodies + contacts in turn).  The oracle tiles exchange with the regions the device computed; states stay
+    bit-identical, no body is lost, and -- the point of it -- no tile runs empty while the static split's upper tiles lose most of theirs."""
+    from substrata_amd.lib import World
+    n, n_tiles = 8, 8
+    grid = tiles.tile_grid(n_tiles)
+    tile_descs, boxes = [], []
+    for r in range(n_tiles):
+        d, lo, hi = scenes.config4_tile_descs(r, n_tiles, n=n)
+        tile_descs.append(d); boxes.append(np.concatenate([lo, hi]))
+    boxes = np.array(boxes, np.float32)
+    total = n ** 3
+    cap = 2048
+    gpu = [World(max_bodies=cap) for _ in range(n_tiles)]
+    cpu = [oracle.OracleWorld(max_bodies=cap) for _ in range(n_tiles)]
+    for r in range(n_tiles):
+        assert np.array_equal(gpu[r].add_batch(tile_descs[r]), cpu[r].add_batch(tile_descs[r]))
+    margin = 2.0
+    nt = [tiles.NativeTiles(gpu[r], r, n_tiles, boxes, margin) for r in range(n_tiles)]
+    min_share, rebalances = 1.0, 0
+    for s in range(0, 240):
+        if s % 12 == 0:
+            tiles.NativeTiles.rebalance_group(nt, grid, by_contacts=(s // 12) % 2 == 1)
+            rebalances += 1
+            boxes = nt[0].boxes()
+            assert all(np.array_equal(boxes, t.boxes()) for t in nt)
+            # a partition of space: the tiles of a column share their z plane, of a slab their y plane, all of them the x plane
+            b = boxes.reshape(2, 2, 2, 6)                      # [iz][iy][ix]
+            assert np.all(b[:, :, 0, 3] == b[:, :, 1, 0]) and np.all(b[:, 0, :, 4] == b[:, 1, :, 1]) and np.all(b[0, :, :, 5] == b[1, :, :, 2])
+        lc = []
+        tiles.NativeTiles.exchange_group(nt)
+        ghost_exchange.exchange_in_process(cpu, boxes, margin, lc)
+        for r in range(n_tiles):
+            st = nt[r].stats()
+            exp = [e for e in lc if e[0] == "export" and e[1] == r][0]; imp = [e for e in lc if e[0] == "import" and e[1] == r][0]
+            assert (st.exported, st.emigrated, st.ghosts, st.immigrated) == (sum(exp[3]), exp[4], imp[2], imp[3]), (s, r)
+        owned = [gpu[r].num_bodies() - 1 - nt[r].stats().ghosts for r in range(n_tiles)]
+        assert sum(owned) == total, (s, owned)
+        if s >= 13:
+            min_share = min(min_share, min(owned) / total)
+        for r in range(n_tiles):
+            gpu[r].step(DT); cpu[r].step(DT)
+        if s % 30 == 29:
+            for r in range(n_tiles):
+                dd = parity.state_diff(gpu[r].read_states(0, cap), cpu[r].read_states(0, cap))
+                assert dd["bit_exact"] and dd["active_mismatch"] == 0, (s, r, dd)
+    assert nt[0].stats().rebalances == rebalances
+    assert min_share >= 0.06, min_share                        # (a static split leaves the upper tiles far fewer: see the test above)
+    for t in nt:
+        t.close()
+    for w in gpu + cpu:
+        w.close()

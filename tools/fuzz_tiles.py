@@ -84,7 +84,16 @@ def run_seed(oracle, seed, steps, verbose=False):
         total += n
     nt = [tiles.NativeTiles(gpu[r], r, n_tiles, boxes, 1.5) for r in range(n_tiles)] if native else None
     migrated = 0
+    # round 4: re-tiling -- every few steps the native tiles move their split planes to the body-count quantiles (sgp_tiles_rebalance_group) and the
+    # oracle tiles take over the regions: bodies then change owner by the dozen in the next exchange
+    retile_every = int(rng.integers(5, 25)) if (native and rng.random() < 0.6 and not os.environ.get("FUZZ_NO_RETILE")) else 0
+    retile_grid = grid if grid else tiles.tile_grid(n_tiles)
+    retiles = 0
     for s in range(1, steps + 1):
+        if retile_every and s % retile_every == 0:
+            tiles.NativeTiles.rebalance_group(nt, retile_grid, by_contacts=bool(rng.integers(2)))
+            boxes = nt[0].boxes()
+            retiles += 1
         # edits between steps, applied to both worlds of a tile: removal, teleport inside the tile, a kick
         if rng.random() < 0.25:
             r = int(rng.integers(n_tiles))
@@ -135,7 +144,7 @@ def run_seed(oracle, seed, steps, verbose=False):
             owned = sum(gpu[r].num_bodies() - 1 - [e for e in lg if e[0] == "import" and e[1] == r][0][2] for r in range(n_tiles))
             assert owned == total, (seed, s, "owned bodies", owned, total)
     if verbose:
-        print(f"seed {seed}: {n_tiles} tiles{' stacked in z' if grid else ''}, {'native' if native else 'python'} exchange, {total} bodies, {migrated} migrations: ok")
+        print(f"seed {seed}: {n_tiles} tiles{' stacked in z' if grid else ''}, {'native' if native else 'python'} exchange, {total} bodies, {migrated} migrations, {retiles} re-tilings: ok")
     if nt:
         for t in nt:
             t.close()
