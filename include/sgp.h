@@ -444,6 +444,10 @@ typedef struct sgp_mesh_info {
 int  sgp_mesh_create(sgp_world* w, const float* vertices_xyz, uint32_t num_vertices, const uint32_t* indices, uint32_t num_triangles, sgp_mesh_info* info_out);
 /* The last JPH::Ref<JPH::Shape> to the mesh going away: its id and its vertex / triangle / node storage become reusable (Substrata streams
  * static meshes in and out as the camera moves).  SGP_ERR_REJECTED while a body still uses it. */
+/* The active-edge bits of a mesh's triangles in the caller's triangle order: bit k set = edge k (vertex k -> vertex k + 1) collides with its own normal;
+ * a clear bit = an edge shared by two (nearly) coplanar triangles, or a concave one: a contact there takes the triangle's normal (JPH::MeshShape's active
+ * edges with the 5 degree default the reference keeps, PhysicsWorld.cpp:1028-1060).  Diagnostics / tests. */
+int  sgp_mesh_edge_flags(sgp_world* w, uint32_t mesh_id, uint8_t* flags_out, uint32_t cap);
 int  sgp_mesh_destroy(sgp_world* w, uint32_t mesh_id);
 /* The same with one user-data word per triangle (JPH::IndexedTriangle::mMaterialIndex / MeshShape::GetTriangleUserData: the reference
  * stores the batch's material index there, PhysicsWorld.cpp:1032-1060), reported by ray hits.  NULL = all 0. */

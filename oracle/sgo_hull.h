@@ -201,22 +201,10 @@ static inline int sgo_hull_sat_search(const sgo_hview* A, const sgo_hview* B, fl
 	return 1;
 }
 
-/* Manifold from the result of the search.  Normal from A to B. */
-static inline int sgo_hull_manifold(const sgo_hview* A, const sgo_hview* B, float max_sep, const sgo_hull_sat* r, sgo_manifold* m)
+/* Face contact: reference hull X owns the axis (its face fX), the most anti-parallel face of Y is clipped against X's face.  refA: X is the
+   pair's first hull (the manifold's normal runs from the first to the second). */
+static inline int sgo_hull_face_contact(const sgo_hview* X, const sgo_hview* Y, int fX, int refA, float max_sep, sgo_manifold* m)
 {
-	const float sA = r->sA, sB = r->sB, sE = r->sE; const int fA = r->fA, fB = r->fB, eA = r->eA, eB = r->eB; const v3 nE = r->nE;
-	const float sF = fmaxf(sA, sB);
-	if (eA >= 0 && sE > sF + 1.0e-3f) {
-		v3 pa, pb;
-		sgo_seg_seg_closest(sgo_hv_world(A, A->h->edge_a[eA]), sgo_hv_world(A, A->h->edge_b[eA]),
-		                    sgo_hv_world(B, B->h->edge_a[eB]), sgo_hv_world(B, B->h->edge_b[eB]), &pa, &pb);
-		m->n = nE; m->np = 1; m->p1[0] = pa; m->p2[0] = pb;
-		return 1;
-	}
-	/* face contact: reference hull X owns the axis, the most anti-parallel face of Y is clipped against X's face */
-	const int refA = !(sB > sA + 1.0e-4f);
-	const sgo_hview* X = refA ? A : B; const sgo_hview* Y = refA ? B : A;
-	const int fX = refA ? fA : fB;
 	const v3 nref = sgo_hv_normal(X, fX);
 	int fY = 0; float bestd = 3.4e38f;
 	for (int f = 0; f < Y->h->nf; ++f) { const float d = v3_dot(nref, sgo_hv_normal(Y, f)); if (d < bestd) { bestd = d; fY = f; } }
@@ -255,6 +243,23 @@ static inline int sgo_hull_manifold(const sgo_hview* A, const sgo_hview* B, floa
 	}
 	sgo_hull_reduce(refA ? nref : v3_neg(nref), q1, q2, cnt, m);
 	return 1;
+}
+
+/* Manifold from the result of the search.  Normal from A to B. */
+static inline int sgo_hull_manifold(const sgo_hview* A, const sgo_hview* B, float max_sep, const sgo_hull_sat* r, sgo_manifold* m)
+{
+	const float sA = r->sA, sB = r->sB, sE = r->sE; const int fA = r->fA, fB = r->fB, eA = r->eA, eB = r->eB; const v3 nE = r->nE;
+	const float sF = fmaxf(sA, sB);
+	if (eA >= 0 && sE > sF + 1.0e-3f) {
+		v3 pa, pb;
+		sgo_seg_seg_closest(sgo_hv_world(A, A->h->edge_a[eA]), sgo_hv_world(A, A->h->edge_b[eA]),
+		                    sgo_hv_world(B, B->h->edge_a[eB]), sgo_hv_world(B, B->h->edge_b[eB]), &pa, &pb);
+		m->n = nE; m->np = 1; m->p1[0] = pa; m->p2[0] = pb;
+		return 1;
+	}
+	/* face contact: reference hull X owns the axis, the most anti-parallel face of Y is clipped against X's face */
+	const int refA = !(sB > sA + 1.0e-4f);
+	return refA ? sgo_hull_face_contact(A, B, fA, 1, max_sep, m) : sgo_hull_face_contact(B, A, fB, 0, max_sep, m);
 }
 
 /* A, B = hull views (either may be the scaled cube template): SAT + clipping.  Normal from A to B. */

@@ -14,7 +14,13 @@
  *     group's first normal), at most 3 groups per body pair, each group pruned to 4 points -- a body in a corner of the mesh
  *     keeps one constraint per wall.  The groups are carried by the mesh body and its two alias body slots, so that the
  *     (body a, body b) constraint key needs no sub-shape part.
- * Not restated: Jolt's active-edge flags (contacts on edges shared by coplanar triangles keep their edge normal here).
+ *   - active edges (round 4; MeshShapeSettings::mActiveEdgeCosThresholdAngle = cos 5 deg, PhysicsWorld.cpp:1028-1060 leaves the default;
+ *     CollideShapeSettings::mActiveEdgeMode = CollideOnlyWithActive with the bodies' relative velocity as movement hint, as
+ *     PhysicsSystem::ProcessBodyPair sets them): an edge shared by two triangles is INACTIVE when it is concave or its triangles' normals are
+ *     within 5 degrees of each other (sgo_mesh_active_edges, restating MeshShape::sFindActiveEdges + ActiveEdges::IsEdgeActive); a contact whose
+ *     normal is not the triangle's and whose deepest point lies on an inactive edge / vertex takes the triangle's normal instead
+ *     (sgo_active_edge_fix, restating ActiveEdges::FixNormal) -- a body sliding over the seams of a flat triangulated floor meets no bumps.
+ *     UNVERIFIED: upstream.
  */
 #ifndef SGO_MESH_H
 #define SGO_MESH_H
@@ -24,6 +30,88 @@
 
 #define SGO_MESH_MAX_GROUPS 3
 #define SGO_MESH_GROUP_COS 0.95f
+#define SGO_ACTIVE_EDGE_COS 0.99619469809f      /* cos(5 degrees): MeshShapeSettings::mActiveEdgeCosThresholdAngle */
+
+/* ---- which edges of which triangles are active (mesh build time, doubles) ---------------------------------------------------------- */
+typedef struct { uint32_t lo, hi, tri, k; } sgo_edge_rec;
+static int sgo_edge_rec_cmp(const void* x, const void* y)
+{
+	const sgo_edge_rec* a = (const sgo_edge_rec*)x; const sgo_edge_rec* b = (const sgo_edge_rec*)y;
+	if (a->lo != b->lo) return a->lo < b->lo ? -1 : 1;
+	if (a->hi != b->hi) return a->hi < b->hi ? -1 : 1;
+	if (a->tri != b->tri) return a->tri < b->tri ? -1 : 1;
+	return a->k < b->k ? -1 : (a->k > b->k ? 1 : 0);
+}
+static int sgo_tri_normal_d(const float* verts, const uint32_t* t, double n[3])
+{
+	const float* a = verts + 3 * t[0]; const float* b = verts + 3 * t[1]; const float* c = verts + 3 * t[2];
+	const double e1[3] = { (double)b[0] - a[0], (double)b[1] - a[1], (double)b[2] - a[2] }, e2[3] = { (double)c[0] - a[0], (double)c[1] - a[1], (double)c[2] - a[2] };
+	n[0] = e1[1] * e2[2] - e1[2] * e2[1]; n[1] = e1[2] * e2[0] - e1[0] * e2[2]; n[2] = e1[0] * e2[1] - e1[1] * e2[0];
+	const double l = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+	if (!(l > 1.0e-30)) return 0;
+	n[0] /= l; n[1] /= l; n[2] /= l;
+	return 1;
+}
+/* flags[t] bit k set = edge k of triangle t (k = 0: v0-v1, 1: v1-v2, 2: v2-v0) is active.  An edge is keyed by its two vertex INDICES (as Jolt's
+   indexed triangle list): used by one triangle or by more than two -> active; by two -> ActiveEdges::IsEdgeActive of their normals. */
+static void sgo_mesh_active_edges(const float* verts, const uint32_t* idx, uint32_t nt, double cos_threshold, unsigned char* flags)
+{
+	sgo_edge_rec* e = (sgo_edge_rec*)malloc(sizeof(sgo_edge_rec) * 3 * (size_t)nt);
+	for (uint32_t t = 0; t < nt; ++t) for (uint32_t k = 0; k < 3; ++k) {
+		const uint32_t a = idx[3 * t + k], b = idx[3 * t + (k + 1) % 3];
+		sgo_edge_rec r; r.lo = a < b ? a : b; r.hi = a < b ? b : a; r.tri = t; r.k = k;
+		e[3 * (size_t)t + k] = r;
+		flags[t] = 7;
+	}
+	qsort(e, 3 * (size_t)nt, sizeof(sgo_edge_rec), sgo_edge_rec_cmp);
+	for (size_t i = 0; i < 3 * (size_t)nt; ) {
+		size_t j = i + 1;
+		while (j < 3 * (size_t)nt && e[j].lo == e[i].lo && e[j].hi == e[i].hi) ++j;
+		if (j - i == 2 && e[i].lo != e[i].hi) {
+			double n1[3], n2[3];
+			if (sgo_tri_normal_d(verts, idx + 3 * e[i].tri, n1) && sgo_tri_normal_d(verts, idx + 3 * e[i + 1].tri, n2)) {
+				const uint32_t va = idx[3 * e[i].tri + e[i].k], vb = idx[3 * e[i].tri + (e[i].k + 1) % 3];       /* the edge in the first triangle's winding */
+				const double d[3] = { (double)verts[3 * vb] - verts[3 * va], (double)verts[3 * vb + 1] - verts[3 * va + 1], (double)verts[3 * vb + 2] - verts[3 * va + 2] };
+				const double cosn = n1[0] * n2[0] + n1[1] * n2[1] + n1[2] * n2[2];
+				const double cx = n1[1] * n2[2] - n1[2] * n2[1], cy = n1[2] * n2[0] - n1[0] * n2[2], cz = n1[0] * n2[1] - n1[1] * n2[0];
+				int active;
+				if (cosn < -0.999848) active = 1;                                   /* back to back */
+				else if (cx * d[0] + cy * d[1] + cz * d[2] < 0.0) active = 0;       /* concave */
+				else active = cosn < cos_threshold;                                 /* convex: active beyond the threshold angle */
+				if (!active) { flags[e[i].tri] &= (unsigned char)~(1u << e[i].k); flags[e[i + 1].tri] &= (unsigned char)~(1u << e[i + 1].k); }
+			}
+		}
+		i = j;
+	}
+	free(e);
+}
+
+/* ---- ActiveEdges::FixNormal: does the triangle's normal nt replace the contact normal n (both unit, triangle -> body)? ----------------------
+   a, b, c: the triangle (world), edges: its active-edge bits, p: the contact point on the triangle that decides (the deepest one), movement: velocity
+   of the body relative to the mesh.  Jolt's axes point the other way (convex -> triangle): its test m . n_J < m . t_J reads m . n > m . nt here. */
+static inline int sgo_active_edge_fix(v3 a, v3 b, v3 c, v3 nt, unsigned edges, v3 p, v3 n, v3 movement)
+{
+	if (edges == 7u) return 0;
+	if (v3_dot(movement, n) > v3_dot(movement, nt)) return 0;        /* the computed normal opposes the motion less than the triangle's: keep it */
+	if (edges == 0u) return 1;
+	if (v3_dot(nt, n) > 0.999848f) return 0;                          /* within a degree of the triangle's normal anyway */
+	/* barycentric coordinates of p (weights of a, b, c) */
+	const v3 v0 = v3_sub(b, a), v1 = v3_sub(c, a), v2 = v3_sub(p, a);
+	const float d00 = v3_dot(v0, v0), d01 = v3_dot(v0, v1), d11 = v3_dot(v1, v1), d20 = v3_dot(v2, v0), d21 = v3_dot(v2, v1);
+	const float den = d00 * d11 - d01 * d01;
+	if (!(fabsf(den) > 1.0e-20f)) return 0;
+	const float bv = (d11 * d20 - d01 * d21) / den, bw = (d00 * d21 - d01 * d20) / den, bu = (1.0f - bv) - bw;
+	const float eps = 1.0e-4f, one = 1.0f - 1.0e-4f;
+	unsigned colliding;
+	if (bu > one) colliding = 5u;            /* vertex a: edge 0 or 2 */
+	else if (bv > one) colliding = 3u;       /* vertex b: edge 0 or 1 */
+	else if (bw > one) colliding = 6u;       /* vertex c: edge 1 or 2 */
+	else if (bu < eps) colliding = 2u;       /* edge b - c */
+	else if (bv < eps) colliding = 4u;       /* edge c - a */
+	else if (bw < eps) colliding = 1u;       /* edge a - b */
+	else return 0;                           /* interior */
+	return (edges & colliding) ? 0 : 1;
+}
 
 /* the thin hull of one triangle; vertices relative to the centroid (mesh frame) */
 static inline void sgo_tri_hull(v3 a, v3 b, v3 c, sgo_hull* h, v3* centroid_out, v3* normal_out)
@@ -67,8 +155,9 @@ static inline void sgo_mesh_add(sgo_mesh_contacts* mc, const sgo_manifold* m)
 	}
 }
 
-/* X against one triangle (world-space view T of its thin hull, world normal nt).  Normal of the result: triangle -> X. */
-static inline int sgo_collide_tri(const sgo_shape* X, const sgo_hview* T, v3 nt, float max_sep, sgo_manifold* m)
+/* X against one triangle (world-space view T of its thin hull, world normal nt).  Normal of the result: triangle -> X.
+   edges: the triangle's active-edge bits (7: no fixing, e.g. a shape query), movement: X's velocity relative to the mesh. */
+static inline int sgo_collide_tri(const sgo_shape* X, const sgo_hview* T, v3 nt, float max_sep, sgo_manifold* m, unsigned edges, v3 movement)
 {
 	int hit;
 	if (X->type == SGO_SHAPE_SPHERE) hit = sgo_hull_sphere(T, X->pos, X->p[0], max_sep, m);
@@ -83,6 +172,21 @@ static inline int sgo_collide_tri(const sgo_shape* X, const sgo_hview* T, v3 nt,
 	}
 	if (!hit) return 0;
 	if (v3_dot(m->n, nt) < 0.0f) return 0;                   /* reached from the back side */
+	if (edges != 7u && m->np > 0) {
+		/* the point that decides: the deepest one (Jolt has one point at this stage, the deepest) */
+		int bi = 0; float bd = -3.4e38f;
+		for (int i = 0; i < m->np; ++i) { const float dd = v3_dot(v3_sub(m->p1[i], m->p2[i]), m->n); if (dd > bd) { bd = dd; bi = i; } }
+		if (sgo_active_edge_fix(sgo_hv_world(T, 0), sgo_hv_world(T, 1), sgo_hv_world(T, 2), nt, edges, m->p1[bi], m->n, movement)) {
+			if (X->type == SGO_SHAPE_SPHERE || X->type == SGO_SHAPE_CAPSULE) m->n = nt;      /* the points stay, the direction changes */
+			else {
+				/* a polytope: the contact as the triangle's FACE makes it (reference face = the triangle's front, clipped incident face of X) */
+				sgo_hview hx;
+				hx.pos = X->pos; hx.R = X->R; hx.h = X->hull;
+				hx.scale = X->type == SGO_SHAPE_BOX ? V3(X->p[0], X->p[1], X->p[2]) : V3(1.0f, 1.0f, 1.0f);
+				if (!sgo_hull_face_contact(T, &hx, 0, 1, max_sep, m)) return 0;
+			}
+		}
+	}
 	return 1;
 }
 

@@ -65,6 +65,7 @@ typedef struct {
 	int chassis;                       /* chassis of a live vehicle (set by colour_constraints): its contacts do not take colour 0 */
 	int movable_prev, movable_cur;   /* movable (dynamic and awake) when the previous / this step coloured its constraints */
 	int island; int can_sleep;
+	v3 linv_pre;                       /* linear velocity at the start of the step (before the forces): the active-edge movement hint */
 	int cache_invalid;               /* created or reshaped since the last step: its pairs do not reuse cached manifolds (Body::InvalidateContactCache) */
 } sgo_body;
 
@@ -92,7 +93,7 @@ typedef struct {
 
 typedef struct { uint32_t a, b; } sgo_pair;
 
-typedef struct sgo_mesh_s { uint32_t nv, nt; v3* verts; uint32_t* tris; uint32_t* mats; v3 aabb_min, aabb_max; float bound_radius; } sgo_mesh;
+typedef struct sgo_mesh_s { uint32_t nv, nt; v3* verts; uint32_t* tris; uint32_t* mats; unsigned char* edges; v3 aabb_min, aabb_max; float bound_radius; } sgo_mesh;
 
 typedef struct sgo_world {
 	sgp_world_desc desc;
@@ -1007,7 +1008,10 @@ static int setup_constraint(sgo_world* w, uint32_t k, const sgo_manifold* m, flo
 }
 
 /* Narrow phase + constraint setup for every candidate pair. */
-static int collide_with_mesh(const sgo_body* M, const sgo_shape* X, v3 lo, v3 hi, float max_sep, sgo_manifold* out);
+static int collide_with_mesh(const sgo_body* M, const sgo_shape* X, v3 lo, v3 hi, float max_sep, sgo_manifold* out, int active_edges, v3 movement);
+static int g_active_edges = 1;      /* test switch: 0 = every edge collides with its own normal (what rounds 1-3 did), so that a KAT can show the difference */
+SGO_API int sgo_set_active_edges(int on) { const int old = g_active_edges; g_active_edges = on ? 1 : 0; return old; }
+SGO_API int sgo_mesh_edge_flags(sgo_world* w, uint32_t mesh_id, uint8_t* out, uint32_t cap);
 
 static void find_contacts(sgo_world* w, float dt)
 {
@@ -1030,7 +1034,10 @@ static void find_contacts(sgo_world* w, float dt)
 			if (A->shape_type == SGP_SHAPE_MESH && B->shape_type == SGP_SHAPE_MESH) continue;       /* (both static anyway) */
 			const sgo_body* M = A->shape_type == SGP_SHAPE_MESH ? A : B; const sgo_body* X = M == A ? B : A;
 			const sgo_shape sx = body_shape_xf(X);
-			hit[p] = (unsigned char)collide_with_mesh(M, &sx, X->aabb_min, X->aabb_max, w->st.speculative_contact_distance, &mans[3 * p]);
+			/* movement hint of the active-edge rule: X's velocity with this step's gravity, relative to the mesh (PhysicsSystem::ProcessBodyPair:
+			   mActiveEdgeMovementDirection = v1 - v2, after ApplyGravity; the device has not applied the forces yet at this point and adds g dt itself) */
+			const v3 mv = v3_sub(v3_add(X->linv_pre, v3_scale(v3_scale(w->gravity, X->gravity_factor), dt)), M->motion == SGP_MOTION_STATIC ? V3(0, 0, 0) : M->linv);
+			hit[p] = (unsigned char)collide_with_mesh(M, &sx, X->aabb_min, X->aabb_max, w->st.speculative_contact_distance, &mans[3 * p], g_active_edges, mv);
 			continue;
 		}
 		/* the body-pair contact cache: both bodies where they were (relative to each other) when the cached manifold was computed ->
@@ -1967,6 +1974,7 @@ SGO_API int sgo_world_step(sgo_world* w, float dt)
 	#pragma omp parallel for schedule(static, 1024) if (g_threads > 1)
 	for (uint32_t i = 0; i < w->high; ++i) {
 		sgo_body* b = &w->bodies[i];
+		b->linv_pre = b->linv;
 		if (!b->alive || !body_movable(b)) continue;
 		b->linv = v3_add(b->linv, v3_scale(v3_add(v3_scale(w->gravity, b->gravity_factor), v3_scale(b->force, b->inv_mass)), dt));
 		const sym33 Iw = world_inv_inertia(quat_to_m33(b->rot), b->inv_inertia);
@@ -2304,6 +2312,8 @@ SGO_API int sgo_mesh_create_with_materials(sgo_world* w, const float* verts, uin
 	memcpy(m->tris, idx, sizeof(uint32_t) * 3 * nt);
 	m->mats = (uint32_t*)calloc(nt, sizeof(uint32_t));
 	if (mats) memcpy(m->mats, mats, sizeof(uint32_t) * nt);
+	m->edges = (unsigned char*)malloc(nt);
+	sgo_mesh_active_edges(verts, idx, nt, (double)SGO_ACTIVE_EDGE_COS, m->edges);
 	v3 mn = V3(3.4e38f, 3.4e38f, 3.4e38f), mx = V3(-3.4e38f, -3.4e38f, -3.4e38f); float br = 0.0f;
 	for (uint32_t k = 0; k < nv; ++k) { const v3 p = V3(verts[3 * k], verts[3 * k + 1], verts[3 * k + 2]); m->verts[k] = p; mn = v3_min(mn, p); mx = v3_max(mx, p); br = fmaxf(br, v3_len(p)); }
 	m->aabb_min = mn; m->aabb_max = mx; m->bound_radius = br;
@@ -2320,6 +2330,15 @@ SGO_API int sgo_mesh_create_with_materials(sgo_world* w, const float* verts, uin
 	return SGP_OK;
 }
 
+/* the active-edge bits of a mesh's triangles, in the caller's triangle order (bit k: edge k = v[k] - v[k + 1] collides with its own normal) */
+SGO_API int sgo_mesh_edge_flags(sgo_world* w, uint32_t mesh_id, uint8_t* out, uint32_t cap)
+{
+	if (!w || !out || mesh_id < 1 || mesh_id >= w->n_meshes || !w->meshes[mesh_id]) return SGP_ERR_BAD_ID;
+	const sgo_mesh* m = w->meshes[mesh_id];
+	for (uint32_t t = 0; t < m->nt && t < cap; ++t) out[t] = m->edges[t];
+	return SGP_OK;
+}
+
 static int shape_in_use(const sgo_world* w, int type, const void* p)
 {
 	for (uint32_t i = 0; i < w->high; ++i) { const sgo_body* b = &w->bodies[i]; if (b->alive && !b->is_alias && b->shape_type == type && (type == SGP_SHAPE_MESH ? (const void*)b->mesh : (const void*)b->hull) == p) return 1; }
@@ -2329,7 +2348,7 @@ SGO_API int sgo_mesh_destroy(sgo_world* w, uint32_t id)
 {
 	if (!w || id < 1 || id >= w->n_meshes || !w->meshes[id]) return SGP_ERR_BAD_ID;
 	if (shape_in_use(w, SGP_SHAPE_MESH, w->meshes[id])) return SGP_ERR_REJECTED;
-	free(w->meshes[id]->verts); free(w->meshes[id]->tris); free(w->meshes[id]->mats); free(w->meshes[id]); w->meshes[id] = NULL;
+	free(w->meshes[id]->verts); free(w->meshes[id]->tris); free(w->meshes[id]->mats); free(w->meshes[id]->edges); free(w->meshes[id]); w->meshes[id] = NULL;
 	w->free_mesh_ids = (uint32_t*)realloc(w->free_mesh_ids, sizeof(uint32_t) * (w->n_free_mesh_ids + 1));
 	w->free_mesh_ids[w->n_free_mesh_ids++] = id;
 	return SGP_OK;
@@ -2346,7 +2365,7 @@ SGO_API int sgo_hull_destroy(sgo_world* w, uint32_t id)
 
 /* Every triangle of mesh body M whose world bounds come within max_sep of the world bounds [lo,hi]; collides X with each in index
    order and groups the manifolds (sgo_mesh.h).  Returns the number of groups; normals point from the mesh to X. */
-static int collide_with_mesh(const sgo_body* M, const sgo_shape* X, v3 lo, v3 hi, float max_sep, sgo_manifold* out)
+static int collide_with_mesh(const sgo_body* M, const sgo_shape* X, v3 lo, v3 hi, float max_sep, sgo_manifold* out, int active_edges, v3 movement)
 {
 	const m33 R = quat_to_m33(M->rot);
 	sgo_mesh_contacts mc; mc.ng = 0;
@@ -2361,7 +2380,7 @@ static int collide_with_mesh(const sgo_body* M, const sgo_shape* X, v3 lo, v3 hi
 		sgo_tri_hull(a, b, c, &th, &cen, &n);
 		sgo_hview T; T.pos = v3_add(M->pos, m33_mul(R, cen)); T.R = R; T.scale = V3(1.0f, 1.0f, 1.0f); T.h = &th;
 		sgo_manifold m;
-		if (sgo_collide_tri(X, &T, m33_mul(R, n), max_sep, &m)) sgo_mesh_add(&mc, &m);
+		if (sgo_collide_tri(X, &T, m33_mul(R, n), max_sep, &m, active_edges ? (unsigned)M->mesh->edges[t] : 7u, movement)) sgo_mesh_add(&mc, &m);
 	}
 	return sgo_mesh_finish(&mc, out);
 }
@@ -2476,7 +2495,7 @@ SGO_API int sgo_collide_capsules(sgo_world* w, const sgp_capsule_query* qs, uint
 			if (b->aabb_max.x < lo.x || b->aabb_min.x > hi.x || b->aabb_max.y < lo.y || b->aabb_min.y > hi.y || b->aabb_max.z < lo.z || b->aabb_min.z > hi.z) continue;
 			const sgo_shape sb = body_shape_xf(b);
 			sgo_manifold mm[SGO_MESH_MAX_GROUPS]; int ng;
-			if (b->shape_type == SGP_SHAPE_MESH) ng = collide_with_mesh(b, &sc, lo, hi, q->max_separation, mm);
+			if (b->shape_type == SGP_SHAPE_MESH) ng = collide_with_mesh(b, &sc, lo, hi, q->max_separation, mm, 0, V3(0, 0, 0));
 			else ng = sgo_collide(&sb, &sc, q->max_separation, &mm[0]) ? 1 : 0;        /* normal from the body to the capsule */
 			for (int g = 0; g < ng; ++g) { const sgo_manifold m = mm[g];
 			for (int i = 0; i < m.np; ++i) {

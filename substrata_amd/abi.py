@@ -319,6 +319,7 @@ PROTOTYPES = {
     "mesh_create": (C.c_int, [vp, vp, u32, vp, u32, P(MeshInfo)]),
     "mesh_create_with_materials": (C.c_int, [vp, vp, u32, vp, u32, vp, P(MeshInfo)]),
     "mesh_destroy": (C.c_int, [vp, u32]),
+    "mesh_edge_flags": (C.c_int, [vp, u32, vp, u32]),
     "hull_destroy": (C.c_int, [vp, u32]),
     "hull_create": (C.c_int, [vp, vp, u32, P(HullInfo)]),
     "hull_create_com": (C.c_int, [vp, vp, u32, P(f32), P(HullInfo)]),

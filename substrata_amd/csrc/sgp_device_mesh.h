@@ -9,6 +9,36 @@
 
 #define SGD_MESH_MAX_GROUPS 3
 #define SGD_MESH_GROUP_COS 0.95f
+// uint4.w of a mesh triangle: index in the caller's order | active-edge flags << 29 (bit k: edge vertex k -> vertex k + 1 collides with its own normal)
+#define MESH_TRI_INDEX(w) ((w) & 0x1FFFFFFFu)
+#define MESH_TRI_EDGES(w) ((w) >> 29)
+
+// ActiveEdges::FixNormal (round 4): does the triangle's normal nt replace the contact normal n (both unit, triangle -> body)?  a, b, c: the triangle
+// (world), edges: its active-edge bits, p: the contact point on the triangle that decides (the deepest one), movement: velocity of the body relative to
+// the mesh.  Jolt's axes point the other way (convex -> triangle): its test m . n_J < m . t_J reads m . n > m . nt here.
+SGP_DEV static int sgd_active_edge_fix(v3 a, v3 b, v3 c, v3 nt, unsigned edges, v3 p, v3 n, v3 movement)
+{
+	if (edges == 7u) return 0;
+	if (v3_dot(movement, n) > v3_dot(movement, nt)) return 0;        // the computed normal opposes the motion less than the triangle's: keep it
+	if (edges == 0u) return 1;
+	if (v3_dot(nt, n) > 0.999848f) return 0;                          // within a degree of the triangle's normal anyway
+	// barycentric coordinates of p (weights of a, b, c)
+	const v3 v0 = v3_sub(b, a), v1 = v3_sub(c, a), v2 = v3_sub(p, a);
+	const float d00 = v3_dot(v0, v0), d01 = v3_dot(v0, v1), d11 = v3_dot(v1, v1), d20 = v3_dot(v2, v0), d21 = v3_dot(v2, v1);
+	const float den = d00 * d11 - d01 * d01;
+	if (!(fabsf(den) > 1.0e-20f)) return 0;
+	const float bv = (d11 * d20 - d01 * d21) / den, bw = (d00 * d21 - d01 * d20) / den, bu = (1.0f - bv) - bw;
+	const float eps = 1.0e-4f, one = 1.0f - 1.0e-4f;
+	unsigned colliding;
+	if (bu > one) colliding = 5u;            // vertex a: edge 0 or 2
+	else if (bv > one) colliding = 3u;       // vertex b: edge 0 or 1
+	else if (bw > one) colliding = 6u;       // vertex c: edge 1 or 2
+	else if (bu < eps) colliding = 2u;       // edge b - c
+	else if (bv < eps) colliding = 4u;       // edge c - a
+	else if (bw < eps) colliding = 1u;       // edge a - b
+	else return 0;                           // interior
+	return (edges & colliding) ? 0 : 1;
+}
 
 // the thin hull of one triangle; vertices relative to the centroid (mesh frame).  The record has the members of sgd_hull the collision
 // functions read, with room for exactly one triangle: 100 bytes a lane can keep near, where the full record is 2.2 KB of scratch memory
@@ -61,21 +91,43 @@ SGP_DEV static void sgd_mesh_add(sgd_mesh_contacts* mc, const sgd_manifold* m)
 }
 
 // X against one triangle (world-space view T of its thin hull, world normal nt).  Normal of the result: triangle -> X.
-SGP_DEV static int sgd_collide_tri(const sgd_shape* X, const sgd_tri_view* T, v3 nt, float max_sep, sgd_manifold* m)
+// edges: the triangle's active-edge bits (7: no fixing, e.g. a shape query), movement: X's velocity relative to the mesh.
+SGP_DEV static bool sgd_tri_needs_face_normal(const sgd_tri_view* T, v3 nt, unsigned edges, v3 movement, const sgd_manifold* m)
 {
-	int hit;
-	if (X->type == SGD_SHAPE_SPHERE) hit = sgd_hull_sphere(T, X->pos, X->p0, max_sep, m);
-	else if (X->type == SGD_SHAPE_CAPSULE) {
-		const v3 ax = v3_scale(m33_col(X->R, 2), X->p1);
-		hit = sgd_hull_capsule(T, v3_sub(X->pos, ax), v3_add(X->pos, ax), X->p0, max_sep, m);
-	} else {
-		sgd_hview hx;
-		hx.pos = X->pos; hx.R = X->R; hx.h = X->hull;
-		hx.scale = X->type == SGD_SHAPE_BOX ? V3(X->p0, X->p1, X->p2) : V3(1.0f, 1.0f, 1.0f);
-		hit = sgd_hull_hull(T, &hx, max_sep, m);
+	if (edges == 7u || m->np <= 0) return false;
+	// the point that decides: the deepest one (Jolt has one point at this stage, the deepest)
+	int bi = 0; float bd = -3.4e38f;
+	for (int i = 0; i < m->np; ++i) { const float dd = v3_dot(v3_sub(m->p1[i], m->p2[i]), m->n); if (dd > bd) { bd = dd; bi = i; } }
+	return sgd_active_edge_fix(sgd_hv_world(T, 0), sgd_hv_world(T, 1), sgd_hv_world(T, 2), nt, edges, m->p1[bi], m->n, movement) != 0;
+}
+SGP_DEV static int sgd_collide_tri(const sgd_shape* X, const sgd_tri_view* T, v3 nt, float max_sep, sgd_manifold* m, unsigned edges, v3 movement)
+{
+	if (X->type == SGD_SHAPE_SPHERE || X->type == SGD_SHAPE_CAPSULE) {
+		int hit;
+		if (X->type == SGD_SHAPE_SPHERE) hit = sgd_hull_sphere(T, X->pos, X->p0, max_sep, m);
+		else {
+			const v3 ax = v3_scale(m33_col(X->R, 2), X->p1);
+			hit = sgd_hull_capsule(T, v3_sub(X->pos, ax), v3_add(X->pos, ax), X->p0, max_sep, m);
+		}
+		if (!hit) return 0;
+		if (v3_dot(m->n, nt) < 0.0f) return 0;                   // reached from the back side
+		if (sgd_tri_needs_face_normal(T, nt, edges, movement, m)) m->n = nt;      // (active edges: the points stay, the direction changes)
+		return 1;
 	}
-	if (!hit) return 0;
-	if (v3_dot(m->n, nt) < 0.0f) return 0;                   // reached from the back side
+	sgd_hview hx;
+	hx.pos = X->pos; hx.R = X->R; hx.h = X->hull;
+	hx.scale = X->type == SGD_SHAPE_BOX ? V3(X->p0, X->p1, X->p2) : V3(1.0f, 1.0f, 1.0f);
+	sgd_hull_sat r;
+	if (!sgd_hull_sat_search(T, &hx, max_sep, &r)) return 0;
+	// ONE call site for the manifold (its clip polygons are a kilobyte of scratch per inlined copy): the second turn of the loop is the active-edge
+	// rule's -- the contact as the triangle's FACE makes it (reference face = the triangle's front, clipped incident face of X)
+	for (int turn = 0; turn < 2; ++turn) {
+		if (!sgd_hull_manifold(T, &hx, max_sep, &r, m)) return 0;
+		if (turn == 1) break;
+		if (v3_dot(m->n, nt) < 0.0f) return 0;                   // reached from the back side
+		if (!sgd_tri_needs_face_normal(T, nt, edges, movement, m)) break;
+		r.eA = -1; r.eB = -1; r.fA = 0; r.sA = 0.0f; r.sB = -3.4e38f; r.sE = -3.4e38f;
+	}
 	return 1;
 }
 

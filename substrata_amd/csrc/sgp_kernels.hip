@@ -885,9 +885,9 @@ SGP_DEV int mesh_candidates(const DV& d, const MeshHeader& mh, v3 llo, v3 lhi, u
 	}
 	// order by the triangle's index in the caller's order (what the sequential reference walks): insertion sort on (orig, pos)
 	for (int i = 1; i < n; ++i) {
-		const uint32_t pos = cand[i]; const uint32_t key = d.mesh_tris[mh.tri_off + pos].w;
+		const uint32_t pos = cand[i]; const uint32_t key = MESH_TRI_INDEX(d.mesh_tris[mh.tri_off + pos].w);
 		int j = i - 1;
-		while (j >= 0 && d.mesh_tris[mh.tri_off + cand[j]].w > key) { cand[j + 1] = cand[j]; --j; }
+		while (j >= 0 && MESH_TRI_INDEX(d.mesh_tris[mh.tri_off + cand[j]].w) > key) { cand[j + 1] = cand[j]; --j; }
 		cand[j + 1] = pos;
 	}
 	return n;
@@ -925,7 +925,7 @@ SGP_DEV int collide_with_mesh(const DV& d, uint32_t mbody, const sgd_shape& X, v
 		sgd_tri_hull(a, b, c, &th, &cen, &n);
 		sgd_tri_view T; T.pos = v3_add(mpos, m33_mul(R, cen)); T.R = R; T.scale = V3(1.0f, 1.0f, 1.0f); T.h = &th;
 		sgd_manifold m;
-		if (sgd_collide_tri(&X, &T, m33_mul(R, n), max_sep, &m)) sgd_mesh_add(&mc, &m);
+		if (sgd_collide_tri(&X, &T, m33_mul(R, n), max_sep, &m, 7u, V3(0.0f, 0.0f, 0.0f))) sgd_mesh_add(&mc, &m);      // (a shape query: no active-edge fixing)
 	}
 	return sgd_mesh_finish(&mc, out);
 }
@@ -963,7 +963,7 @@ SGP_DEV int mesh_candidates_found(const DV& d, const MeshHeader& mh, v3 llo, v3 
 		if (nd.count == 0) { if (sp + 2 <= 48) { stack[sp++] = nd.left; stack[sp++] = nd.right; } else *overflow = true; continue; }
 		for (uint32_t k = 0; k < nd.count; ++k) {
 			if (n == cap) { *overflow = true; break; }
-			found[n] = nd.left + k; key[n] = d.mesh_tris[mh.tri_off + nd.left + k].w; ++n;
+			found[n] = nd.left + k; key[n] = MESH_TRI_INDEX(d.mesh_tris[mh.tri_off + nd.left + k].w); ++n;
 		}
 		if (n > stop_after) return n;
 	}
@@ -973,7 +973,7 @@ SGP_DEV int mesh_candidates_found(const DV& d, const MeshHeader& mh, v3 llo, v3 
 // The groups of one (body X, mesh body mid) pair by the lanes of its group (whole workgroup: every lane calls this; lanes of a group pass the same
 // pair): what lies between "here is the pair" and "here are its <= 3 groups in L.mc".  valid: false for a group without a pair, and false on return
 // when the pair was handed to the wave-per-pair launch (pair = its index in mesh_pairs; G = 8 only).  [qlo, qhi]: X's bounds grown by max_sep.
-template <int MESH_GROUP> SGP_DEV void mesh_pair_groups(const DV& d, MeshPairLds<MESH_GROUP>& L, bool& valid, sgd_shape& X, uint32_t mid, v3 qlo, v3 qhi, float max_sep, int grp, int sub, uint32_t pair, bool& dropped)
+template <int MESH_GROUP> SGP_DEV void mesh_pair_groups(const DV& d, MeshPairLds<MESH_GROUP>& L, bool& valid, sgd_shape& X, uint32_t mid, v3 qlo, v3 qhi, float max_sep, int grp, int sub, uint32_t pair, bool& dropped, v3 movement, bool active_edges = true)
 {
 	MeshHeader mh; v3 mpos = V3(0.0f, 0.0f, 0.0f); m33 R = quat_to_m33(Q4(make_float4(0.0f, 0.0f, 0.0f, 1.0f)));
 	int nc = 0;
@@ -1037,7 +1037,7 @@ template <int MESH_GROUP> SGP_DEV void mesh_pair_groups(const DV& d, MeshPairLds
 		if (sub == 0) d.mesh_big[atomicAdd(&d.ctr->n_mesh_big, 1u)] = pair;
 		valid = false; nc = 0; dropped = false;
 	}
-	for (int i = sub; i < nc; i += MESH_GROUP) L.key[i] = d.mesh_tris[mh.tri_off + L.found[i]].w;
+	for (int i = sub; i < nc; i += MESH_GROUP) L.key[i] = MESH_TRI_INDEX(d.mesh_tris[mh.tri_off + L.found[i]].w);
 	__syncthreads();
 	// candidates in the order of the caller's triangle indices: the rank of a key is the number of smaller keys
 	for (int i = sub; i < nc; i += MESH_GROUP) {
@@ -1063,7 +1063,7 @@ template <int MESH_GROUP> SGP_DEV void mesh_pair_groups(const DV& d, MeshPairLds
 				sgd_tri_hull_t th; v3 cen, nrm;
 				sgd_tri_hull(a, b, c, &th, &cen, &nrm);
 				sgd_tri_view T; T.pos = v3_add(mpos, m33_mul(R, cen)); T.R = R; T.scale = V3(1.0f, 1.0f, 1.0f); T.h = &th;
-				hit = sgd_collide_tri(&X, &T, m33_mul(R, nrm), max_sep, &m) != 0;
+				hit = sgd_collide_tri(&X, &T, m33_mul(R, nrm), max_sep, &m, active_edges ? MESH_TRI_EDGES(tri.w) : 7u, movement) != 0;
 			}
 		}
 		// the hits of this round into the pair's groups, in candidate order
@@ -1100,7 +1100,14 @@ template <int MESH_GROUP> __global__ void __launch_bounds__(64) k_narrowphase_me
 			const v3 e = V3(max_sep, max_sep, max_sep);
 			qlo = v3_sub(V3(d.aabb_min[xid]), e); qhi = v3_add(V3(d.aabb_max[xid]), e);
 		}
-		mesh_pair_groups<MESH_GROUP>(d, L, valid, X, mid, qlo, qhi, max_sep, grp, sub, pair, dropped);
+		// the movement hint of the active-edge rule (PhysicsSystem::ProcessBodyPair: mActiveEdgeMovementDirection = v1 - v2, after ApplyGravity): the forces
+		// of this step are not applied yet at this point (k_pre_solve follows the narrow phase), so gravity is added here -- the same expression as the CPU statement's
+		v3 movement = V3(0.0f, 0.0f, 0.0f);
+		if (valid) {
+			const v3 vx = v3_add(V3(d.vel[2 * (size_t)xid]), v3_scale(v3_scale(V3(d.gx, d.gy, d.gz), d.dyn[xid].z), d.sp->dt));
+			movement = v3_sub(vx, f_motion(d.flags[mid]) == SGP_MOTION_STATIC ? V3(0.0f, 0.0f, 0.0f) : V3(d.vel[2 * (size_t)mid]));
+		}
+		mesh_pair_groups<MESH_GROUP>(d, L, valid, X, mid, qlo, qhi, max_sep, grp, sub, pair, dropped, movement);
 		// the groups as manifolds (mesh -> body), each pruned to <= 4 points; the constraint runs lower id -> higher id, with the mesh's g-th slot
 		const int ng = valid ? L.mc.ng : 0;
 		if (sub < ng) {
@@ -3532,10 +3539,10 @@ SGP_DEV float ray_body(const DV& d, uint32_t type, float4 sh, v3 pos, quat q, v3
 				const v3 pa = V3(d.mesh_verts[mh.vert_off + tri.x]), pb = V3(d.mesh_verts[mh.vert_off + tri.y]), pc = V3(d.mesh_verts[mh.vert_off + tri.z]);
 				float uv[2];
 				const float tt = sgd_ray_tri_uv(ol, dl, pa, pb, pc, best, uv);
-				if (tt >= 0.0f && (tt < best || best_idx == 0xFFFFFFFFu || (tt == best && tri.w < best_idx))) {
-					best = tt; best_idx = tri.w;
+				if (tt >= 0.0f && (tt < best || best_idx == 0xFFFFFFFFu || (tt == best && MESH_TRI_INDEX(tri.w) < best_idx))) {
+					best = tt; best_idx = MESH_TRI_INDEX(tri.w);
 					const v3 nn = v3_cross(v3_sub(pb, pa), v3_sub(pc, pa)); bn = v3_scale(nn, 1.0f / v3_len(nn));
-					sub->tri = tri.w; sub->mat = d.mesh_tri_mat[mh.tri_off + nd.left + k]; sub->u = uv[0]; sub->v = uv[1];
+					sub->tri = MESH_TRI_INDEX(tri.w); sub->mat = d.mesh_tri_mat[mh.tri_off + nd.left + k]; sub->u = uv[0]; sub->v = uv[1];
 				}
 			}
 		}
@@ -3746,7 +3753,7 @@ SGP_DEV float cast_sphere_mesh(const DV& d, uint32_t j, v3 o, v3 dir, float max_
 			const v3 pa = V3(d.mesh_verts[mh.vert_off + tri.x]), pb = V3(d.mesh_verts[mh.vert_off + tri.y]), pc = V3(d.mesh_verts[mh.vert_off + tri.z]);
 			v3 nn;
 			const float tt = sgd_cast_sphere_tri(ol, dl, pa, pb, pc, best, rs, &nn);
-			if (tt >= 0.0f && (tt < best || best_idx == 0xFFFFFFFFu || (tt == best && tri.w < best_idx))) { best = tt; best_idx = tri.w; bn = nn; }
+			if (tt >= 0.0f && (tt < best || best_idx == 0xFFFFFFFFu || (tt == best && MESH_TRI_INDEX(tri.w) < best_idx))) { best = tt; best_idx = MESH_TRI_INDEX(tri.w); bn = nn; }
 		}
 	}
 	if (best_idx == 0xFFFFFFFFu) return -1.0f;
@@ -4356,7 +4363,7 @@ __global__ void __launch_bounds__(64) k_collide_capsules(DV d, const sgp_capsule
 		const uint32_t mid = mesh_list[mi];
 		bool valid = true, dropped = false;
 		sgd_shape X = sc;
-		mesh_pair_groups<64>(d, L, valid, X, mid, v3_sub(lo, es), v3_add(hi, es), q.max_separation, 0, (int)lane, 0u, dropped);
+		mesh_pair_groups<64>(d, L, valid, X, mid, v3_sub(lo, es), v3_add(hi, es), q.max_separation, 0, (int)lane, 0u, dropped, V3(0.0f, 0.0f, 0.0f), false);      // (a shape query: no active-edge fixing)
 		if ((int)lane < L.mc.ng) {
 			const sgd_mesh_group& grp = L.mc.g[lane];
 			sgd_manifold mm;

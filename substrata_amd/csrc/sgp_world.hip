@@ -1583,6 +1583,49 @@ template <typename T> static int grow_table(sgp_world* w, T*& dev, size_t& cap, 
 	return SGP_OK;
 }
 
+// Which edges of which triangles are ACTIVE (MeshShape::sFindActiveEdges + ActiveEdges::IsEdgeActive with the 5 degree default the reference leaves in
+// place, PhysicsWorld.cpp:1028-1060): flags[t] bit k set = edge k (v[k] - v[k + 1]) of triangle t collides with its own normal.  An edge is keyed by its two
+// vertex indices: used by one triangle or by more than two -> active; by two -> inactive when concave or when their normals are within the threshold.
+// Doubles: the flags must come out the same wherever this runs (tests/test_mesh_parity_gpu.py compares them with the sequential CPU statement's).
+#define SGP_ACTIVE_EDGE_COS 0.99619469809f      // cos(5 degrees) as a float (MeshShapeSettings::mActiveEdgeCosThresholdAngle), widened to double for the test below
+static void mesh_active_edges(const float* verts, const uint32_t* idx, uint32_t nt, std::vector<uint8_t>& flags)
+{
+	struct Rec { uint32_t lo, hi, tri, k; };
+	std::vector<Rec> e(3 * (size_t)nt);
+	flags.assign(nt, 7);
+	for (uint32_t t = 0; t < nt; ++t) for (uint32_t k = 0; k < 3; ++k) { const uint32_t a = idx[3 * t + k], b = idx[3 * t + (k + 1) % 3]; e[3 * (size_t)t + k] = Rec{ std::min(a, b), std::max(a, b), t, k }; }
+	std::sort(e.begin(), e.end(), [](const Rec& x, const Rec& y) { if (x.lo != y.lo) return x.lo < y.lo; if (x.hi != y.hi) return x.hi < y.hi; if (x.tri != y.tri) return x.tri < y.tri; return x.k < y.k; });
+	auto normal = [&](uint32_t t, double n[3]) {
+		const float* a = verts + 3 * idx[3 * t]; const float* b = verts + 3 * idx[3 * t + 1]; const float* c = verts + 3 * idx[3 * t + 2];
+		const double e1[3] = { (double)b[0] - a[0], (double)b[1] - a[1], (double)b[2] - a[2] }, e2[3] = { (double)c[0] - a[0], (double)c[1] - a[1], (double)c[2] - a[2] };
+		n[0] = e1[1] * e2[2] - e1[2] * e2[1]; n[1] = e1[2] * e2[0] - e1[0] * e2[2]; n[2] = e1[0] * e2[1] - e1[1] * e2[0];
+		const double l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+		if (!(l > 1.0e-30)) return false;
+		n[0] /= l; n[1] /= l; n[2] /= l;
+		return true;
+	};
+	const double cos_threshold = (double)SGP_ACTIVE_EDGE_COS;
+	for (size_t i = 0; i < e.size(); ) {
+		size_t j = i + 1;
+		while (j < e.size() && e[j].lo == e[i].lo && e[j].hi == e[i].hi) ++j;
+		if (j - i == 2 && e[i].lo != e[i].hi) {
+			double n1[3], n2[3];
+			if (normal(e[i].tri, n1) && normal(e[i + 1].tri, n2)) {
+				const uint32_t va = idx[3 * e[i].tri + e[i].k], vb = idx[3 * e[i].tri + (e[i].k + 1) % 3];       // the edge in the first triangle's winding
+				const double d[3] = { (double)verts[3 * vb] - verts[3 * va], (double)verts[3 * vb + 1] - verts[3 * va + 1], (double)verts[3 * vb + 2] - verts[3 * va + 2] };
+				const double cosn = n1[0] * n2[0] + n1[1] * n2[1] + n1[2] * n2[2];
+				const double cx = n1[1] * n2[2] - n1[2] * n2[1], cy = n1[2] * n2[0] - n1[0] * n2[2], cz = n1[0] * n2[1] - n1[1] * n2[0];
+				bool active;
+				if (cosn < -0.999848) active = true;                                    // back to back
+				else if (cx * d[0] + cy * d[1] + cz * d[2] < 0.0) active = false;       // concave
+				else active = cosn < cos_threshold;                                     // convex: active beyond the threshold angle
+				if (!active) { flags[e[i].tri] &= (uint8_t)~(1u << e[i].k); flags[e[i + 1].tri] &= (uint8_t)~(1u << e[i + 1].k); }
+			}
+		}
+		i = j;
+	}
+}
+
 SGP_API int sgp_mesh_create_with_materials(sgp_world* w, const float* verts, uint32_t nv, const uint32_t* idx, uint32_t nt, const uint32_t* tri_mats, sgp_mesh_info* info);
 SGP_API int sgp_mesh_create(sgp_world* w, const float* verts, uint32_t nv, const uint32_t* idx, uint32_t nt, sgp_mesh_info* info)
 {
@@ -1623,7 +1666,11 @@ SGP_API int sgp_mesh_create_with_materials(sgp_world* w, const float* verts, uin
 		if (w->mesh_nodes.size() < (size_t)mh.node_off + mh.n_nodes) w->mesh_nodes.resize((size_t)mh.node_off + mh.n_nodes);
 		std::copy(nodes.begin(), nodes.end(), w->mesh_nodes.begin() + mh.node_off);
 	}
-	for (uint32_t k = 0; k < nt; ++k) { const uint32_t t = order[k]; w->mesh_tris[mh.tri_off + k] = make_uint4(idx[3 * t], idx[3 * t + 1], idx[3 * t + 2], t); w->mesh_tri_mat[mh.tri_off + k] = tri_mats ? tri_mats[t] : 0u; }
+	if (nt >= (1u << 29)) return fail(SGP_ERR_CAPACITY, "sgp_mesh_create: more than 2^29 triangles");
+	std::vector<uint8_t> edge_flags;
+	mesh_active_edges(verts, idx, nt, edge_flags);
+	// (uint4.w of a triangle: its index in the caller's order, and in the top three bits its active-edge flags: MESH_TRI_INDEX / MESH_TRI_EDGES)
+	for (uint32_t k = 0; k < nt; ++k) { const uint32_t t = order[k]; w->mesh_tris[mh.tri_off + k] = make_uint4(idx[3 * t], idx[3 * t + 1], idx[3 * t + 2], t | ((uint32_t)edge_flags[t] << 29)); w->mesh_tri_mat[mh.tri_off + k] = tri_mats ? tri_mats[t] : 0u; }
 	// upload (pools may move: captured graphs carry the old pointers)
 	{ int r = grow_pool(w, w->d_mesh_verts, w->cap_mesh_verts, w->mesh_verts.size(), w->cap_mesh_verts); if (r != SGP_OK) return r; }
 	{ int r = grow_pool(w, w->d_mesh_tris, w->cap_mesh_tris, w->mesh_tris.size(), w->cap_mesh_tris); if (r != SGP_OK) return r; }
@@ -1649,6 +1696,15 @@ SGP_API int sgp_mesh_create_with_materials(sgp_world* w, const float* verts, uin
 }
 
 // JPH::Ref<JPH::Shape> going out of scope: the mesh's table slot and pool ranges become reusable.  Refused while a body still uses it.
+// the active-edge bits of a mesh's triangles in the caller's triangle order (tests: compared with the sequential CPU statement's)
+SGP_API int sgp_mesh_edge_flags(sgp_world* w, uint32_t mesh_id, uint8_t* out, uint32_t cap)
+{
+	if (!w || !out || mesh_id < 1 || mesh_id >= w->meshes.size() || w->meshes[mesh_id].nt == 0) return fail(SGP_ERR_BAD_ID, "sgp_mesh_edge_flags: no such mesh");
+	const MeshHeader& mh = w->meshes[mesh_id];
+	for (uint32_t k = 0; k < mh.nt; ++k) { const uint32_t wv = w->mesh_tris[mh.tri_off + k].w; const uint32_t t = wv & 0x1FFFFFFFu; if (t < cap) out[t] = (uint8_t)(wv >> 29); }
+	return SGP_OK;
+}
+
 SGP_API int sgp_mesh_destroy(sgp_world* w, uint32_t id)
 {
 	if (!w || id < 1 || id >= w->meshes.size() || w->meshes[id].nt == 0) return fail(SGP_ERR_BAD_ID, "sgp_mesh_destroy: no such mesh");

@@ -222,3 +222,93 @@ def test_capsule_axis_through_a_triangles_plane(oracle):
         assert len(cons) == expect, (pos, len(cons))
         if expect and pos[0] < 0:
             assert cons[0]["n"][0] < -0.5               # pushed away from the triangle, across its edge x = 0
+
+
+# ---- round 4: active edges (MeshShape::sFindActiveEdges + ActiveEdges::FixNormal; PhysicsWorld.cpp:1028-1060 keeps Jolt's 5 degree default) ----
+
+def _edge_flags(oracle, w, info):
+    import ctypes as C
+    out = (C.c_uint8 * info.num_triangles)()
+    f = oracle.lib().sgo_mesh_edge_flags
+    f.restype = C.c_int; f.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+    assert f(w._h, info.mesh_id, out, info.num_triangles) == 0
+    return np.frombuffer(out, dtype=np.uint8).copy()
+
+
+def _grid(n, size, height):
+    xs = np.linspace(-size / 2, size / 2, n)
+    V = [(x, y, height(x, y)) for y in xs for x in xs]
+    T = []
+    for j in range(n - 1):
+        for i in range(n - 1):
+            a, b, c, d = j * n + i, j * n + i + 1, (j + 1) * n + i, (j + 1) * n + i + 1
+            T += [(a, b, d), (a, d, c)]
+    return V, T
+
+
+def test_which_edges_are_active(oracle):
+    w = oracle.OracleWorld(max_bodies=64)
+    # a flat 4 x 4 grid: every interior edge is shared by two coplanar triangles -> inactive; the rim (one triangle per edge) stays active
+    V, T = _grid(5, 8.0, lambda x, y: 0.0)
+    fl = _edge_flags(oracle, w, w.mesh_create(V, T))
+    edge_count = {}
+    for t, tri in enumerate(T):
+        for k in range(3):
+            edge_count.setdefault(tuple(sorted((tri[k], tri[(k + 1) % 3]))), []).append((t, k))
+    for users in edge_count.values():
+        for t, k in users:
+            assert bool(fl[t] >> k & 1) == (len(users) == 1), (t, k, users)
+    # a ridge and a valley, 30 degrees each side: the ridge (convex) is active, the valley (concave) is not; 2 degrees: neither
+    for ang, ridge_active in ((30.0, True), (2.0, False)):
+        s = np.tan(np.radians(ang))
+        for sign, expect in ((-1.0, ridge_active), (1.0, False)):          # z = -|x| s: ridge along y;  z = +|x| s: valley
+            V2 = [(-2, -2, sign * 2 * s), (0, -2, 0), (2, -2, sign * 2 * s), (-2, 2, sign * 2 * s), (0, 2, 0), (2, 2, sign * 2 * s)]
+            T2 = [(0, 1, 4), (0, 4, 3), (1, 2, 5), (1, 5, 4)]
+            f2 = _edge_flags(oracle, w, w.mesh_create(V2, T2))
+            assert bool(f2[0] >> 1 & 1) == expect and bool(f2[3] >> 2 & 1) == expect, (ang, sign, f2)      # edge 1 - 4 in triangles 0 (its edge 1) and 3 (its edge 2)
+            assert not (f2[0] >> 2 & 1) and not (f2[1] >> 0 & 1)          # the diagonals inside each flat half are inactive
+    w.close()
+
+
+def test_sliding_over_the_seams_of_a_flat_mesh_meets_no_bumps(oracle):
+    """A frictionless sphere and an upright capsule crossing the diagonal of a two-triangle floor at 4 m/s: with active edges the contact on the
+    shared (inactive) edge takes the floor's normal and nothing happens; without them (rounds 1-3: sgo_set_active_edges(0)) the sphere loses speed
+    to the edge's backward-tilted normal and the capsule is tripped up."""
+    def run(shape_kw, z0):
+        w = oracle.OracleWorld(max_bodies=64)
+        add_mesh(w, QUAD_V, QUAD_T, friction=0.0)
+        k = dyn(w, pos=(-6, -5.0, z0), lin_vel=(4, 0, 0), friction=0.0, lin_damp=0.0, ang_damp=0.0, **shape_kw)
+        zs = []
+        for _ in range(150):
+            w.step(DT); zs.append(float(w.get_state([k])[0]["pos"][2]))
+        vx = float(w.get_state([k])[0]["lin_vel"][0])
+        w.close()
+        return vx, min(zs[20:]), max(zs[20:])
+    sphere = dict(shape_type=abi.SHAPE_SPHERE, shape=(0.4, 0, 0, 0)); capsule = dict(shape_type=abi.SHAPE_CAPSULE, shape=(0.3, 0.5, 0, 0))
+    for kw, z0 in ((sphere, 0.4), (capsule, 0.8)):
+        vx, zlo, zhi = run(kw, z0)
+        assert abs(vx - 4.0) < 1e-4 and abs(zlo - z0) < 1e-3 and abs(zhi - z0) < 1e-3, (kw, vx, zlo, zhi)
+    old = oracle.lib().sgo_set_active_edges(0)
+    try:
+        vx, zlo, zhi = run(sphere, 0.4)
+        assert vx < 3.95                                   # the ghost collision the flags are there to remove
+        vx, zlo, zhi = run(capsule, 0.8)
+        assert zlo < 0.6                                   # tripped over the seam
+    finally:
+        oracle.lib().sgo_set_active_edges(old)
+
+
+def test_an_active_edge_keeps_its_own_normal(oracle):
+    """A sphere set down exactly on a 90 degree ridge (convex: active) is held by the edge's normal -- straight up -- and stays; taking a face's normal
+    there would push it off sideways at once."""
+    w = oracle.OracleWorld(max_bodies=64)
+    V = [(-3, -3, -3), (0, -3, 0), (3, -3, -3), (-3, 3, -3), (0, 3, 0), (3, 3, -3)]
+    T = [(0, 1, 4), (0, 4, 3), (1, 2, 5), (1, 5, 4)]
+    _, info = add_mesh(w, V, T, friction=0.0)
+    assert _edge_flags(oracle, w, info)[0] >> 1 & 1
+    s = dyn(w, shape_type=abi.SHAPE_SPHERE, shape=(0.4, 0, 0, 0), pos=(0, 0, 0.4), friction=0.0)
+    for _ in range(90):
+        w.step(DT)
+    st = w.get_state([s])[0]
+    assert abs(st["pos"][0]) < 1e-3 and abs(st["pos"][2] - 0.4) < 0.02, st["pos"]
+    w.close()
