@@ -47,11 +47,19 @@ enum {
 };
 
 // Dense broad-phase grid of the current step (written by k_bp_grid_params).
+// Round 4: the grid is PAGED.  Cells are grouped in 4 x 4 x 4 tiles; a dense page table over the TILES of the bounding box (DV::tile_slot, 1/64 of what a
+// dense cell table over the same box would need) maps a tile to a compact slot -- or to nothing: only tiles that hold a body get one, in the order their
+// first body arrives --, and cell (x, y, z) lives at slot * 64 + ((z & 3) * 4 + (y & 3)) * 4 + (x & 3) of the cell arrays.  Counts, scans, the cell-sorted
+// records and k_bp_pairs' workgroups therefore scale with the OCCUPIED tiles: forty piles cost the same side by side or two kilometres apart (the dense
+// grid had to coarsen its cells to fit its table, and walked the empty tiles in between).
+#define BP_TILE_NONE    0xFFFFFFFFu
+#define BP_TILE_PENDING 0xFFFFFFFEu
 struct BpGrid {
 	int   min_x, min_y, min_z, max_x, max_y, max_z;   // ordered-int encoded float bounds of the small bodies' AABB centres
 	float ox, oy, oz, inv_cell, cell;
-	int   nx, ny, nz;
-	uint32_t n_cells;
+	int   nx, ny, nz;                                 // cells of the bounding box (what coordinates clamp to)
+	uint32_t n_cells;                                 // != 0: a grid exists
+	int   tnx, tny, tnz;                              // tiles of the bounding box = the page table's dimensions
 };
 
 // One static triangle mesh in the pools.
@@ -92,6 +100,7 @@ struct StepCounters {
 	uint32_t bp_dense;           // some tile's halo held more records than the small instance of k_bp_pairs stages in LDS
 	uint32_t hc_probe_big;       // launch-plan probe: constraints of components too large for a workgroup if one more colour went to the components
 	uint32_t hc_done;            // workgroups of the running solve launch that have finished (the last one runs the catch-all and clears it)
+	uint32_t n_tiles_used;       // occupied tiles of this step's grid (slots handed out by k_bp_cell)
 	uint32_t veh_deferred;       // vehicles that share a movable body (a dynamic body under a wheel, a chassis a wheel stands on) with a vehicle of lower index: solved after the others, in index order
 	uint32_t veh_done;           // workgroups of the running vehicle-row launch that have finished (the last one solves the deferred vehicles and clears it)
 	uint32_t tickets[4];         // last_block(): workgroups of k_colour_count / k_warm_bodies / k_cache_build that have finished
@@ -238,7 +247,10 @@ struct DV {
 	float4*   sorted_max;      // cell-sorted copy: aabb max xyz, body id (bits) w
 	struct BpGrid* grid;       // per-step dense grid parameters (device)
 	int*      bounds_acc;      // [6] ordered-int min / max of the small bodies' AABB centres, accumulated by k_step_begin, consumed by k_bp_cell, reset by k_bp_scatter
-	uint32_t* grid_cells_used; // cells of the most recent grid (what the next step has to clear of the cell tables)
+	uint32_t* grid_cells_used; // cells of the most recent grid = 64 x its occupied tiles (what the next step has to clear of the cell tables)
+	uint32_t* tile_slot;       // the page table: [tile of the bounding box] -> slot, BP_TILE_NONE, or BP_TILE_PENDING while its first body fetches a slot
+	uint32_t* tile_of_slot;    // [slot] -> tile (index into tile_slot): the tiles k_bp_pairs walks, and what the next step resets of the page table
+	uint32_t  tile_table_size; // entries of tile_slot
 	const uint32_t* large_ids;
 	uint2*    pairs;
 	// narrow phase output (manifolds, unordered)

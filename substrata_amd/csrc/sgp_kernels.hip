@@ -172,6 +172,8 @@ __global__ void __launch_bounds__(TPB) k_step_begin(DV d, StepParams sp, uint32_
 	// the cell tables: only what the previous grid used (everything above it is still zero; the table has room for far more cells than a step uses)
 	const uint32_t used = min(*d.grid_cells_used, d.table_size) + 4u;
 	for (uint32_t i = tid; i < used; i += stride) { d.cell_count[i] = 0; d.cell_fill[i] = 0; }
+	// ... and of the page table: the entries of the tiles that held a slot (everything else already says "none")
+	for (uint32_t sl = tid; sl < (used - 4u) / 64u; sl += stride) d.tile_slot[d.tile_of_slot[sl]] = BP_TILE_NONE;
 	if (reset_scratch) {
 		const uint32_t n = min(nb, d.cap_bodies);
 		for (uint32_t i = tid; i < n; i += stride) { d.colour_mask[i] = 0ull; d.claim[0][i] = ~0ull; d.claim[1][i] = ~0ull; }
@@ -243,15 +245,36 @@ SGP_DEV BpGrid bp_grid_from_bounds(const DV& d)
 		for (int it = 0; it < 64; ++it) {
 			const float inv = 1.0f / cell;
 			const float fx = floorf((x1 - x0) * inv) + 1.0f, fy = floorf((y1 - y0) * inv) + 1.0f, fz = floorf((z1 - z0) * inv) + 1.0f;
-			if (fx * fy * fz <= (float)d.table_size && fx < 2.0e9f && fy < 2.0e9f && fz < 2.0e9f) { g.nx = (int)fx; g.ny = (int)fy; g.nz = (int)fz; break; }
+			const float tx = floorf((fx + 3.0f) * 0.25f), ty = floorf((fy + 3.0f) * 0.25f), tz = floorf((fz + 3.0f) * 0.25f);      // tiles of 4 x 4 x 4 cells
+			if (tx * ty * tz <= (float)d.tile_table_size && fx < 2.0e9f && fy < 2.0e9f && fz < 2.0e9f) { g.nx = (int)fx; g.ny = (int)fy; g.nz = (int)fz; break; }
 			cell = cell * 1.5f;
 			g.nx = g.ny = g.nz = 1;
 		}
 		g.ox = x0; g.oy = y0; g.oz = z0;
 	}
 	g.cell = cell; g.inv_cell = 1.0f / cell;
-	g.n_cells = (uint32_t)g.nx * (uint32_t)g.ny * (uint32_t)g.nz;
+	g.n_cells = 1u;                                   // (a grid exists; how many cells it really has is 64 x the tiles k_bp_cell hands out)
+	g.tnx = (g.nx + 3) >> 2; g.tny = (g.ny + 3) >> 2; g.tnz = (g.nz + 3) >> 2;
 	return g;
+}
+
+// cell (x, y, z) of the paged grid (coordinates inside the bounding box): index into the cell arrays, or BP_TILE_NONE where the tile holds nobody
+SGP_DEV uint32_t grid_cell(const DV& d, const BpGrid& g, int x, int y, int z)
+{
+	const uint32_t slot = d.tile_slot[((uint32_t)(z >> 2) * (uint32_t)g.tny + (uint32_t)(y >> 2)) * (uint32_t)g.tnx + (uint32_t)(x >> 2)];
+	return slot >= BP_TILE_PENDING ? BP_TILE_NONE : slot * 64u + (uint32_t)((((z & 3) << 2) | (y & 3)) << 2 | (x & 3));
+}
+// fn(q0, q1): the cell-sorted records [q0, q1) of cells xa .. xb of row (y, z), tile by tile (the cells of a tile's row are neighbours in the arrays)
+template <class F> SGP_DEV void grid_row_runs(const DV& d, const BpGrid& g, int xa, int xb, int y, int z, F fn)
+{
+	const uint32_t trow = ((uint32_t)(z >> 2) * (uint32_t)g.tny + (uint32_t)(y >> 2)) * (uint32_t)g.tnx;
+	const uint32_t lrow = (uint32_t)((((z & 3) << 2) | (y & 3)) << 2);
+	for (int x = xa; x <= xb; ) {
+		const int xe = min(xb, x | 3);
+		const uint32_t slot = d.tile_slot[trow + (uint32_t)(x >> 2)];
+		if (slot < BP_TILE_PENDING) { const uint32_t c0 = slot * 64u + lrow + (uint32_t)(x & 3); fn(d.cell_start[c0], d.cell_start[c0 + (uint32_t)(xe - x) + 1u]); }
+		x = xe + 1;
+	}
 }
 
 __global__ void __launch_bounds__(TPB) k_bp_cell(DV d)
@@ -259,33 +282,69 @@ __global__ void __launch_bounds__(TPB) k_bp_cell(DV d)
 	__shared__ BpGrid sg;
 	if (threadIdx.x == 0) {
 		sg = bp_grid_from_bounds(d);
-		if (blockIdx.x == 0) { *d.grid = sg; *d.grid_cells_used = sg.n_cells; }
+		if (blockIdx.x == 0) *d.grid = sg;
 	}
 	__syncthreads();
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-	if (i >= d.sp->n_slots) return;
-	const uint32_t f = d.flags[i];
-	uint32_t h = 0xFFFFFFFFu;
+	const bool in_range = i < d.sp->n_slots;
+	const uint32_t f = in_range ? d.flags[i] : 0u;
+	uint32_t h = 0xFFFFFFFFu, tile = 0, local = 0;
+	bool binned = false;
+	const BpGrid& g = sg;
 	if ((f & BF_ALIVE) && !(f & BF_LARGE)) {
 		const float4 mn = d.aabb_min[i], mx = d.aabb_max[i];
-		const BpGrid& g = sg;
 		int cx = (int)floorf(((mn.x + mx.x) * 0.5f - g.ox) * g.inv_cell);
 		int cy = (int)floorf(((mn.y + mx.y) * 0.5f - g.oy) * g.inv_cell);
 		int cz = (int)floorf(((mn.z + mx.z) * 0.5f - g.oz) * g.inv_cell);
 		cx = min(max(cx, 0), g.nx - 1); cy = min(max(cy, 0), g.ny - 1); cz = min(max(cz, 0), g.nz - 1);
-		h = ((uint32_t)cz * (uint32_t)g.ny + (uint32_t)cy) * (uint32_t)g.nx + (uint32_t)cx;
+		tile = ((uint32_t)(cz >> 2) * (uint32_t)g.tny + (uint32_t)(cy >> 2)) * (uint32_t)g.tnx + (uint32_t)(cx >> 2);
+		local = (uint32_t)((((cz & 3) << 2) | (cy & 3)) << 2 | (cx & 3));
+		binned = true;
+	}
+	// The tile's slot: the first body to arrive fetches one (the order is whatever the atomics give: it decides where a tile's cells sit in the arrays and in
+	// what order pairs come out, neither of which enters a result).  One lane per wave and tile talks to the page table -- neighbouring body ids often
+	// share a tile, and atomics on one address queue (every body for itself: 53 us at 100k bodies) --, the others take its answer.  A lane that asks
+	// may have to wait for another WAVE's lane to publish a slot it has claimed; it never waits for a lane of its own wave (their tiles differ).
+	// (the wave's distinct tiles all at once: a lane leads its tile if no lower lane has the same one -- a row of a lattice spreads a wave's 64 bodies over
+	// ten tiles, and one tile after the other was ten dependent round trips to the page table)
+	const int lane = (int)(threadIdx.x & 63u);
+	int leader = lane;
+	for (int k = 0; k < 64; ++k) {
+		const uint32_t tk = (uint32_t)__shfl((int)tile, k, 64);
+		const int bk = __shfl((int)binned, k, 64);
+		if (bk && binned && tk == tile && k < leader) leader = k;
+	}
+	uint32_t sl = BP_TILE_NONE;
+	if (binned && leader == lane) {
+		uint32_t* entry = &d.tile_slot[tile];
+		sl = __hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (relaxed: the slot NUMBER is all that travels through the entry)
+		for (int tries = 0; tries < (1 << 24) && sl >= BP_TILE_PENDING; ++tries) {
+			const uint32_t old = atomicCAS(entry, BP_TILE_NONE, BP_TILE_PENDING);
+			if (old == BP_TILE_NONE) {
+				sl = atomicAdd(&d.ctr->n_tiles_used, 1u);
+				d.tile_of_slot[sl] = tile;
+				__hip_atomic_store(entry, sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			} else if (old != BP_TILE_PENDING) sl = old;
+			else sl = __hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
+	const uint32_t slot = (uint32_t)__shfl((int)sl, leader, 64);
+	if (binned) {
+		h = slot * 64u + local;
 		atomicAdd(&d.cell_count[h], 1u);
 	}
-	d.cell_hash[i] = h;
+	if (in_range) d.cell_hash[i] = h;
 }
 
 // exclusive scan of cell_count[0..n) -> cell_start, 3 passes, 1024 elements per block
 __global__ void __launch_bounds__(TPB) k_scan_blocks(const uint32_t* in, uint32_t* out, uint32_t* block_sums, uint32_t n_cap, const uint32_t* n_live)
 {
 	__shared__ uint32_t wave_sums[TPB / 64];
-	const uint32_t n = min(n_cap, *n_live + 1u);          // (the cells of this step's grid + the end sentinel; the launch covers the table's capacity)
-	if (blockIdx.x * (TPB * 4u) >= n) { if (threadIdx.x == TPB - 1) block_sums[blockIdx.x] = 0u; return; }
-	const uint32_t base = (blockIdx.x * TPB + threadIdx.x) * 4;
+	const uint32_t n = min(n_cap, *n_live * 64u + 1u);          // (n_live: the occupied tiles of this step's grid, 64 cells each, + the end sentinel)
+	// (a fixed, small grid walking the blocks that hold live cells: the table has room for 64 cells per body, a step uses a fraction of it)
+	for (uint32_t blk = blockIdx.x; blk * (TPB * 4u) < n; blk += gridDim.x) {
+	__syncthreads();
+	const uint32_t base = (blk * TPB + threadIdx.x) * 4;
 	uint32_t v[4];
 #pragma unroll
 	for (int k = 0; k < 4; ++k) v[k] = (base + k < n) ? in[base + k] : 0u;
@@ -303,12 +362,14 @@ __global__ void __launch_bounds__(TPB) k_scan_blocks(const uint32_t* in, uint32_
 	uint32_t excl = wbase + x - tsum;
 #pragma unroll
 	for (int k = 0; k < 4; ++k) { if (base + k < n) out[base + k] = excl; excl += v[k]; }
-	if (threadIdx.x == TPB - 1) block_sums[blockIdx.x] = wbase + x;
+	if (threadIdx.x == TPB - 1) block_sums[blk] = wbase + x;
+	}
 }
 
-__global__ void __launch_bounds__(1024) k_scan_sums(uint32_t* block_sums, uint32_t nb_cap, uint32_t n_cap, const uint32_t* n_live)
+__global__ void __launch_bounds__(1024) k_scan_sums(uint32_t* block_sums, uint32_t nb_cap, uint32_t n_cap, const uint32_t* n_live, uint32_t* cells_used_out)
 {
-	const uint32_t nb = min(nb_cap, (min(n_cap, *n_live + 1u) + TPB * 4u - 1u) / (TPB * 4u));      // (the blocks that hold cells of this step's grid)
+	const uint32_t nb = min(nb_cap, (min(n_cap, *n_live * 64u + 1u) + TPB * 4u - 1u) / (TPB * 4u));      // (the blocks that hold cells of this step's grid)
+	if (threadIdx.x == 0) *cells_used_out = min(n_cap, *n_live * 64u);      // what the next step's first launch resets
 	__shared__ uint32_t wave_sums[16];
 	__shared__ uint32_t carry;
 	if (threadIdx.x == 0) carry = 0;
@@ -333,12 +394,13 @@ __global__ void __launch_bounds__(1024) k_scan_sums(uint32_t* block_sums, uint32
 
 __global__ void __launch_bounds__(TPB) k_scan_add(uint32_t* out, const uint32_t* block_sums, uint32_t n_cap, const uint32_t* n_live)
 {
-	const uint32_t n = min(n_cap, *n_live + 1u);
-	if (blockIdx.x * (TPB * 4u) >= n) return;
-	const uint32_t base = (blockIdx.x * TPB + threadIdx.x) * 4;
-	const uint32_t add = block_sums[blockIdx.x];
+	const uint32_t n = min(n_cap, *n_live * 64u + 1u);
+	for (uint32_t blk = blockIdx.x; blk * (TPB * 4u) < n; blk += gridDim.x) {
+		const uint32_t base = (blk * TPB + threadIdx.x) * 4;
+		const uint32_t add = block_sums[blk];
 #pragma unroll
-	for (int k = 0; k < 4; ++k) if (base + k < n) out[base + k] += add;
+		for (int k = 0; k < 4; ++k) if (base + k < n) out[base + k] += add;
+	}
 }
 
 SGP_DEV void bp_scatter_one(const DV& d, uint32_t i)
@@ -484,26 +546,27 @@ template <int BP_LDS_CAP, int BP_PAIR_CAP> __global__ void __launch_bounds__(TPB
 	__shared__ uint8_t scls[BP_PAIR_CAP];
 	__shared__ uint32_t pbins[64];
 	__shared__ uint32_t lcount, gbase;
+	__shared__ uint32_t nslot[27];
 	const BpGrid g = *d.grid;
-	const int tnx = (g.nx + BP_TILE - 1) / BP_TILE, tny = (g.ny + BP_TILE - 1) / BP_TILE, tnz = (g.nz + BP_TILE - 1) / BP_TILE;
-	const uint32_t n_tiles = (uint32_t)tnx * (uint32_t)tny * (uint32_t)tnz;
+	// (round 4: the workgroups walk the OCCUPIED tiles of the paged grid -- slot by slot --, not every tile of the bounding box)
+	const uint32_t n_tiles = d.ctr->n_tiles_used;
 	const float spec = d.st.speculative_contact_distance;
 	const float reach = d.sp->bp_rmax + spec;
 	if (threadIdx.x == 0) lcount = 0;
-	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-		const int tx = (int)(tile % (uint32_t)tnx), ty = (int)((tile / (uint32_t)tnx) % (uint32_t)tny), tz = (int)(tile / ((uint32_t)tnx * (uint32_t)tny));
+	for (uint32_t slot = blockIdx.x; slot < n_tiles; slot += gridDim.x) {
+		const uint32_t tile = d.tile_of_slot[slot];
+		const int tx = (int)(tile % (uint32_t)g.tnx), ty = (int)((tile / (uint32_t)g.tnx) % (uint32_t)g.tny), tz = (int)(tile / ((uint32_t)g.tnx * (uint32_t)g.tny));
 		const int x0 = tx * BP_TILE - BP_H, y0 = ty * BP_TILE - BP_H, z0 = tz * BP_TILE - BP_H;   // halo origin (cell coords)
 		__syncthreads();
-		// the tile's own cells first: an empty tile is skipped without touching the halo
+		// the tile's own cells first (64 neighbours in the cell arrays, in (z, y, x) order like the threads): a tile whose bodies have all gone is skipped without touching the halo
 		if (threadIdx.x < BP_INNER_CELLS) {
-			const int ix = threadIdx.x % BP_TILE, iy = (threadIdx.x / BP_TILE) % BP_TILE, iz = threadIdx.x / (BP_TILE * BP_TILE);
-			const int x = tx * BP_TILE + ix, y = ty * BP_TILE + iy, z = tz * BP_TILE + iz;
-			uint32_t cnt = 0;
-			if (x < g.nx && y < g.ny && z < g.nz) {
-				const uint32_t lin = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx + (uint32_t)x;
-				cnt = d.cell_start[lin + 1] - d.cell_start[lin];
-			}
-			istart[threadIdx.x] = cnt;
+			const uint32_t lin = slot * 64u + threadIdx.x;
+			istart[threadIdx.x] = d.cell_start[lin + 1] - d.cell_start[lin];
+		} else if (threadIdx.x < BP_INNER_CELLS + 27) {
+			// the slots of the 27 tiles the halo reaches into, requested next to the counts (the halo's 512 cells then find them in LDS, not behind a page-table load each)
+			const int k = (int)threadIdx.x - BP_INNER_CELLS;
+			const int nx_ = tx + k % 3 - 1, ny_ = ty + (k / 3) % 3 - 1, nz_ = tz + k / 9 - 1;
+			nslot[k] = (nx_ >= 0 && nx_ < g.tnx && ny_ >= 0 && ny_ < g.tny && nz_ >= 0 && nz_ < g.tnz) ? d.tile_slot[((uint32_t)nz_ * (uint32_t)g.tny + (uint32_t)ny_) * (uint32_t)g.tnx + (uint32_t)nx_] : BP_TILE_NONE;
 		}
 		__syncthreads();
 		const uint32_t n_inner = block_scan_512(istart, BP_INNER_CELLS, wave_tot);
@@ -515,8 +578,8 @@ template <int BP_LDS_CAP, int BP_PAIR_CAP> __global__ void __launch_bounds__(TPB
 			const int x = x0 + hx, y = y0 + hy, z = z0 + hz;
 			uint32_t b = 0, cnt = 0;
 			if (x >= 0 && x < g.nx && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
-				const uint32_t lin = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx + (uint32_t)x;
-				b = d.cell_start[lin]; cnt = d.cell_start[lin + 1] - b;
+				const uint32_t ns = nslot[(((z >> 2) - tz + 1) * 3 + ((y >> 2) - ty + 1)) * 3 + ((x >> 2) - tx + 1)];
+				if (ns < BP_TILE_PENDING) { const uint32_t lin = ns * 64u + (uint32_t)((((z & 3) << 2) | (y & 3)) << 2 | (x & 3)); b = d.cell_start[lin]; cnt = d.cell_start[lin + 1] - b; }
 			}
 			gstart[c] = b;
 			cstart[c] = cnt;
@@ -3701,9 +3764,7 @@ __global__ void __launch_bounds__(64) k_raycast(DV d, const sgp_ray* rays, uint3
 					if (y < 0 || y >= g.ny || z < 0 || z >= g.nz) continue;
 					const int xa = max(cx - 1, 0), xb = min(cx + 1, g.nx - 1);
 					if (xa > xb) continue;
-					const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
-					const uint32_t q0 = d.cell_start[row + (uint32_t)xa], q1 = d.cell_start[row + (uint32_t)xb + 1];
-					for (uint32_t q = q0; q < q1; ++q) ray_test_body(d, ry, o, dir, __float_as_uint(d.sorted_max[q].w), best);
+					grid_row_runs(d, g, xa, xb, y, z, [&](uint32_t q0, uint32_t q1) { for (uint32_t q = q0; q < q1; ++q) ray_test_body(d, ry, o, dir, __float_as_uint(d.sorted_max[q].w), best); });
 				}
 				// next cell
 				if (tmx <= tmy && tmx <= tmz) { t_enter = tmx; tmx += tdx; cx += sx; if (cx < -1 || cx > g.nx) break; }
@@ -3860,9 +3921,7 @@ __global__ void __launch_bounds__(64) k_vehicle_cast(DV d)
 				const int y0 = max((int)floorf((fminf(o.y, e.y) - m - g.oy) * g.inv_cell) - 1, 0), y1 = min((int)floorf((fmaxf(o.y, e.y) + m - g.oy) * g.inv_cell) + 1, g.ny - 1);
 				const int z0 = max((int)floorf((fminf(o.z, e.z) - m - g.oz) * g.inv_cell) - 1, 0), z1 = min((int)floorf((fmaxf(o.z, e.z) + m - g.oz) * g.inv_cell) + 1, g.nz - 1);
 				if (x0 <= x1) for (int z = z0; z <= z1; ++z) for (int y = y0; y <= y1; ++y) {
-					const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
-					const uint32_t q0 = d.cell_start[row + (uint32_t)x0], q1 = d.cell_start[row + (uint32_t)x1 + 1];
-					for (uint32_t q = q0 + sub; q < q1; q += 16) veh_cast_test(d, &sv, o, dir, rs, wh->cast_len, __float_as_uint(d.sorted_max[q].w), best, bid, bn, bp);
+					grid_row_runs(d, g, x0, x1, y, z, [&](uint32_t q0, uint32_t q1) { for (uint32_t q = q0 + sub; q < q1; q += 16) veh_cast_test(d, &sv, o, dir, rs, wh->cast_len, __float_as_uint(d.sorted_max[q].w), best, bid, bn, bp); });
 				}
 			}
 		}
@@ -4351,9 +4410,7 @@ __global__ void __launch_bounds__(64) k_collide_capsules(DV d, const sgp_capsule
 		const int y0 = max((int)floorf((lo.y - g.oy) * g.inv_cell) - 1, 0), y1 = min((int)floorf((hi.y - g.oy) * g.inv_cell) + 1, g.ny - 1);
 		const int z0 = max((int)floorf((lo.z - g.oz) * g.inv_cell) - 1, 0), z1 = min((int)floorf((hi.z - g.oz) * g.inv_cell) + 1, g.nz - 1);
 		if (x0 <= x1) for (int z = z0; z <= z1; ++z) for (int y = y0; y <= y1; ++y) {
-			const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
-			const uint32_t c0 = d.cell_start[row + (uint32_t)x0], c1 = d.cell_start[row + (uint32_t)x1 + 1];
-			for (uint32_t c = c0 + lane; c < c1; c += 64) capsule_query_body(d, q, k, sc, lo, hi, __float_as_uint(d.sorted_max[c].w), out, cap, count, mesh_list, &n_mesh);
+			grid_row_runs(d, g, x0, x1, y, z, [&](uint32_t c0, uint32_t c1) { for (uint32_t c = c0 + lane; c < c1; c += 64) capsule_query_body(d, q, k, sc, lo, hi, __float_as_uint(d.sorted_max[c].w), out, cap, count, mesh_list, &n_mesh); });
 		}
 	}
 	__syncthreads();
@@ -4417,9 +4474,7 @@ __global__ void __launch_bounds__(64) k_spherecast(DV d, const sgp_ray* rays, co
 		const int y0 = max((int)floorf((fminf(o.y, e.y) - m - g.oy) * g.inv_cell) - 1, 0), y1 = min((int)floorf((fmaxf(o.y, e.y) + m - g.oy) * g.inv_cell) + 1, g.ny - 1);
 		const int z0 = max((int)floorf((fminf(o.z, e.z) - m - g.oz) * g.inv_cell) - 1, 0), z1 = min((int)floorf((fmaxf(o.z, e.z) + m - g.oz) * g.inv_cell) + 1, g.nz - 1);
 		if (x0 <= x1) for (int z = z0; z <= z1; ++z) for (int y = y0; y <= y1; ++y) {
-			const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
-			const uint32_t c0 = d.cell_start[row + (uint32_t)x0], c1 = d.cell_start[row + (uint32_t)x1 + 1];
-			for (uint32_t c = c0; c < c1; ++c) spherecast_body(d, ry, rs, o, dir, __float_as_uint(d.sorted_max[c].w), best);
+			grid_row_runs(d, g, x0, x1, y, z, [&](uint32_t c0, uint32_t c1) { for (uint32_t c = c0; c < c1; ++c) spherecast_body(d, ry, rs, o, dir, __float_as_uint(d.sorted_max[c].w), best); });
 		}
 	}
 	sgp_hit h;
@@ -5010,9 +5065,11 @@ void launch_bp_scan(const DV& d, hipStream_t s)
 {
 	const uint32_t n = d.table_size + 1;
 	const uint32_t nb = (n + 1023) / 1024;
-	hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(TPB), 0, s, d.cell_count, d.cell_start, d.scan_block_sums, n, d.grid_cells_used);
-	hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, d.scan_block_sums, nb, n, d.grid_cells_used);
-	hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(TPB), 0, s, d.cell_start, d.scan_block_sums, n, d.grid_cells_used);
+	const uint32_t* n_tiles = &d.ctr->n_tiles_used;
+	const uint32_t grid = std::min(nb, 1024u);
+	hipLaunchKernelGGL(k_scan_blocks, dim3(grid), dim3(TPB), 0, s, d.cell_count, d.cell_start, d.scan_block_sums, n, n_tiles);
+	hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, d.scan_block_sums, nb, n, n_tiles, d.grid_cells_used);
+	hipLaunchKernelGGL(k_scan_add, dim3(grid), dim3(TPB), 0, s, d.cell_start, d.scan_block_sums, n, n_tiles);
 }
 void launch_bp_scatter(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_bp_scatter, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_bp_pairs(const DV& d, int small_lds, hipStream_t s)

@@ -303,9 +303,14 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	// cells of the broad-phase grid: room for 16 per body slot (clearing and scanning follow the cells a step's grid really has, not this capacity).  The grid covers the bounds of all small bodies with cells of R_max + margin and coarsens them
 	// (x 1.5) until it fits this table: a pile that has spread out (config 2 after its tower fell: 60 x 60 x 10 m of 1 m cells) then lands in
 	// cells with several bodies each and k_bp_pairs scans hundreds of candidates per body (0.23 ms for 10k boxes with 2 cells per slot, 0.02 ms with 8 or more).
-	{ const char* e = getenv("SGP_GRID_CELLS_PER_BODY"); const uint32_t per = e && atoi(e) > 0 ? (uint32_t)atoi(e) : 16u; d.table_size = std::max(e ? 1024u : (1u << 23), next_pow2(per * N)); }      // (at least 8M cells: a world whose piles lie hundreds of metres apart keeps cells of ~1.5 m instead of ~4 m -- 40 piles 400 m apart: k_bp_pairs 1.13 -> 0.38 ms; clears and scans only touch the cells a step's grid really has)
+	// the cell arrays: a slot of 64 cells per OCCUPIED tile of the paged grid (sgp_kernels.h), and there are never more occupied tiles than bodies
+	d.table_size = std::max(4096u, next_pow2(64u * N));
 	DEV_ALLOC(d.cell_hash, N);
 	DEV_ALLOC(d.cell_count, d.table_size + 4); DEV_ALLOC(d.cell_start, d.table_size + 4); DEV_ALLOC(d.cell_fill, d.table_size + 4);
+	// the page table over the tiles of the bounding box: 8M tiles = 512M cells (a 4 km x 4 km x 70 m world at 1.5 m cells; 32 MB) before the cells have to grow
+	{ const char* e = getenv("SGP_GRID_TILE_TABLE"); d.tile_table_size = e && atoi(e) > 0 ? (uint32_t)atoi(e) : (1u << 23); }
+	DEV_ALLOC(d.tile_slot, d.tile_table_size); DEV_ALLOC(d.tile_of_slot, d.table_size / 64u + 4u);
+	if (hipMemsetAsync(d.tile_slot, 0xFF, sizeof(uint32_t) * (size_t)d.tile_table_size, w->stream) != hipSuccess) return fail(SGP_ERR_HIP, "tile table init");
 	DEV_ALLOC(w->d_large, N); w->cap_large = N; d.large_ids = w->d_large;
 	DEV_ALLOC(w->d_lgrid, 1); DEV_ALLOC(w->d_lg_start, SGP_LG_MAX_CELLS + 1); w->cap_lg_items = 4096; DEV_ALLOC(w->d_lg_items, w->cap_lg_items);
 	HIP_TRY(hipMemset(w->d_lgrid, 0, sizeof(LargeGrid)));

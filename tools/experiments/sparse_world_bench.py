@@ -20,5 +20,5 @@ def run(spread, n_clusters=40, per=500):
     prof = w.step_profiled(DT); names = w.kernel_class_names(); km = list(prof.kernel_ms); st = w.stats()
     print(f"clusters {spread:.0f} m apart: {ms:.3f} ms/step, pairs {st.num_pairs}, manifolds {st.num_manifolds}, active {st.num_active}; ", {names[i]: round(km[i], 3) for i in range(len(km)) if km[i] > 0.05}, flush=True)
     w.close()
-for s in (15.0, 100.0, 400.0):
+for s in (15.0, 100.0, 400.0, 2000.0):
     run(s)
