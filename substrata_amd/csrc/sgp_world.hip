@@ -53,6 +53,9 @@ struct HostBody {
 	uint32_t shape_ref = 0;                // the mesh / hull id the body references (0 = none): keeps sgp_mesh_destroy / sgp_hull_destroy honest
 	uint32_t comp_root = SGP_INVALID_ID;   // child of a static compound body: slot of the compound (= its first child), else invalid
 	uint32_t comp_child = 0;               // index among the compound's children
+	uint8_t in_large_ids = 0;              // listed in sgp_world::large_ids (no search needed to know)
+	uint8_t lg_state = 0;                  // the static large bodies' grid: 0 not in it, 1 in the device grid, 2 waiting on the linear list for the next rebuild
+	uint8_t lg_tomb = 0;                   // this id still has a (dead) entry in the device grid: giving the slot to a new body forces the rebuild
 };
 
 // A static compound body (sgp_body_add_compound): the slots of its children and their poses in the compound's frame
@@ -71,7 +74,11 @@ struct sgp_world {
 	std::vector<HostBody> hb;
 	std::vector<uint32_t> free_list;
 	uint32_t high = 0, n_alive = 0;
-	std::vector<uint32_t> large_ids; bool large_dirty = false;      // every large body (host order)
+	std::vector<uint32_t> large_ids; bool large_dirty = false;      // every large body (host order; may hold ids that have gone: rebuild_large_grid compacts it)
+	// round 4: the grid of the static large bodies is rebuilt in full only now and then -- a newcomer waits on the linear list every body walks (lg_pending
+	// of them at most), a removed one stays behind as a dead entry (lg_tombs; a query skips what is not alive): streaming one parcel object in or out is
+	// a 64-entry list upload or nothing at all, not a read-back and re-sort of 65k bounds (advisor r03)
+	uint32_t lg_pending = 0, lg_tombs = 0; bool large_list_dirty = false;
 	// what the device sees of them: the static ones in a grid of their own (LargeGrid, rebuilt when the set or a pose in it changes), the rest --
 	// moving large bodies, static ones that would fill too many cells -- on the linear list the kernels walk
 	std::vector<uint32_t> large_linear;
@@ -466,6 +473,7 @@ static float host_shape_volume(int type, const float* p)
 	return pi * p[0] * p[0] * (2.0f * p[1]) + (4.0f / 3.0f) * pi * p[0] * p[0] * p[0];
 }
 
+#define SGP_LG_MAX_PENDING 64u
 static void note_radius(sgp_world* w, uint32_t id, float r)
 {
 	HostBody& b = w->hb[id];
@@ -474,9 +482,13 @@ static void note_radius(sgp_world* w, uint32_t id, float r)
 	b.bound_radius = r;
 	if (is_large) b.flags |= BF_LARGE; else b.flags &= ~BF_LARGE;
 	if (is_large != was_large || (is_large && (b.flags & BF_ALIVE))) {
-		if (is_large && std::find(w->large_ids.begin(), w->large_ids.end(), id) == w->large_ids.end()) w->large_ids.push_back(id);
-		if (!is_large) w->large_ids.erase(std::remove(w->large_ids.begin(), w->large_ids.end(), id), w->large_ids.end());
-		w->large_dirty = true;
+		if (is_large && !b.in_large_ids) { w->large_ids.push_back(id); b.in_large_ids = 1; }
+		if (!is_large) b.in_large_ids = 0;                      // (its entry in large_ids goes at the next rebuild)
+		const bool is_static = (b.flags & BF_MOTION_MASK) == SGP_MOTION_STATIC;
+		if (is_large && !was_large && is_static && w->lg_static >= 32u && !w->large_dirty && !b.lg_tomb && b.lg_state == 0 && w->lg_pending < SGP_LG_MAX_PENDING) {
+			// a new static large body while a grid stands: onto the linear list until the next rebuild
+			w->large_linear.push_back(id); b.lg_state = 2; w->lg_pending++; w->large_list_dirty = true;
+		} else w->large_dirty = true;
 	}
 	if (!is_large) w->max_small_radius = std::max(w->max_small_radius, r);
 }
@@ -541,6 +553,8 @@ static int add_one(sgp_world* w, const sgp_body_desc* d, uint32_t* id_out, bool 
 	hb.flags = f; hb.userdata = d->userdata; hb.ghost = ghost; hb.comp_root = SGP_INVALID_ID; hb.comp_child = 0;
 	hb.shape_ref = (is_mesh || d->shape_type == SGP_SHAPE_HULL) ? (uint32_t)d->shape[0] : 0u;
 	if (is_mesh) w->mesh_refs[hb.shape_ref]++; else if (hb.shape_ref) w->hull_refs[hb.shape_ref]++;
+	if (hb.lg_tomb) w->large_dirty = true;      // the slot of a static large body that left a dead entry in the device grid: the grid is rebuilt before anything can find the newcomer through it
+	for (uint32_t k = 1; is_mesh && k <= 2; ++k) if (id + k < w->hb.size() && w->hb[id + k].lg_tomb) w->large_dirty = true;
 	note_radius(w, id, is_mesh ? 3.0e38f : (hull ? hull->bound_radius : bounding_radius(d->shape_type, d->shape)));   // (meshes always go through the large-body list)
 	hb.volume = is_mesh ? 0.0f : (hull ? hull->volume : host_shape_volume(d->shape_type, d->shape));
 	c.flags = hb.flags;
@@ -679,7 +693,13 @@ SGP_API int sgp_body_remove(sgp_world* w, uint32_t id)
 		// (falls through: the first child's slot is removed like any body and accounts for the one object)
 	}
 	for (uint32_t v = 0; v < w->n_vehicles; ++v) if (w->veh_alive[v] && w->veh_body[v] == id) sgp_vehicle_destroy(w, v);   // a vehicle does not outlive its chassis
-	if (w->hb[id].flags & BF_LARGE) { w->large_ids.erase(std::remove(w->large_ids.begin(), w->large_ids.end(), id), w->large_ids.end()); w->large_dirty = true; }
+	if (w->hb[id].flags & BF_LARGE) {
+		HostBody& b = w->hb[id];
+		b.in_large_ids = 0;                                    // (large_ids is compacted at the next rebuild)
+		if (b.lg_state == 1 && !w->large_dirty && (w->lg_tombs + 1u) * 4u <= w->lg_static) { b.lg_state = 0; b.lg_tomb = 1; w->lg_tombs++; }      // a dead entry stays in the device grid: nothing to do now
+		else if (b.lg_state == 2 && !w->large_dirty) { w->large_linear.erase(std::remove(w->large_linear.begin(), w->large_linear.end(), id), w->large_linear.end()); b.lg_state = 0; w->lg_pending--; w->large_list_dirty = true; }
+		else w->large_dirty = true;
+	}
 	if (w->hb[id].flags & BF_ALIAS) return fail(SGP_ERR_BAD_ID, "sgp_body_remove: id not live");
 	const bool was_mesh = ((w->hb[id].flags & BF_SHAPE_MASK) >> BF_SHAPE_SHIFT) == SGP_SHAPE_MESH;
 	if (w->hb[id].shape_ref) { if (was_mesh) w->mesh_refs[w->hb[id].shape_ref]--; else w->hull_refs[w->hb[id].shape_ref]--; w->hb[id].shape_ref = 0; }
@@ -868,12 +888,30 @@ static void invalidate_graphs(sgp_world* w);
 // them): static ones into the grid, the rest on the linear list.  Runs only when the set changed or a static large body moved.
 static int rebuild_large_grid(sgp_world* w)
 {
-	if (!w->large_dirty) return SGP_OK;
-	w->large_dirty = false;
+	if (!w->large_dirty) {
+		if (!w->large_list_dirty) return SGP_OK;
+		// only the linear list changed (a static large body waits on it for the next rebuild, or one that waited has gone): the list and its length, no read-back
+		w->large_list_dirty = false;
+		if (w->large_linear.size() > w->cap_large) return fail(SGP_ERR_CAPACITY, "large-body list full");
+		if (!w->large_linear.empty()) HIP_TRY(hipMemcpyAsync(w->d_large, w->large_linear.data(), sizeof(uint32_t) * w->large_linear.size(), hipMemcpyHostToDevice, w->stream));
+		HIP_TRY(hipStreamSynchronize(w->stream));      // (a pageable host vector)
+		w->grid_valid = false;
+		return upload_sp(w);
+	}
+	w->large_dirty = false; w->large_list_dirty = false;
 	DV& d = w->dv;
 	std::vector<uint32_t> stat;
 	w->large_linear.clear();
-	for (uint32_t id : w->large_ids) { if ((w->hb[id].flags & BF_MOTION_MASK) == SGP_MOTION_STATIC) stat.push_back(id); else w->large_linear.push_back(id); }
+	// (large_ids may list ids that have gone, or one twice after a removal and re-use: keep the live large ones, once)
+	{
+		std::vector<uint32_t> keep; keep.reserve(w->large_ids.size());
+		for (uint32_t id : w->large_ids) { HostBody& b = w->hb[id]; if (b.in_large_ids == 1 && (b.flags & BF_ALIVE) && (b.flags & BF_LARGE)) { keep.push_back(id); b.in_large_ids = 2; } }
+		for (uint32_t id : keep) w->hb[id].in_large_ids = 1;
+		w->large_ids.swap(keep);
+	}
+	if (w->lg_tombs) for (HostBody& b : w->hb) b.lg_tomb = 0;
+	w->lg_tombs = 0; w->lg_pending = 0;
+	for (uint32_t id : w->large_ids) { w->hb[id].lg_state = 0; if ((w->hb[id].flags & BF_MOTION_MASK) == SGP_MOTION_STATIC) stat.push_back(id); else w->large_linear.push_back(id); }
 	LargeGrid g; memset(&g, 0, sizeof(g)); g.cell = 1.0f; g.inv_cell = 1.0f; g.nx = g.ny = g.nz = 1;
 	std::vector<uint32_t> start, items;
 	if (stat.size() < 32) { w->large_linear.insert(w->large_linear.end(), stat.begin(), stat.end()); stat.clear(); }      // (a handful: the list is as good)
@@ -924,11 +962,11 @@ static int rebuild_large_grid(sgp_world* w)
 			for (size_t c = 0; c < ncell; ++c) start[c + 1] += start[c];
 			items.resize(total);
 			std::vector<uint32_t> fill(start.begin(), start.end() - 1);
-			for (uint32_t k = 0; k < n; ++k) { if (huge[k]) w->large_linear.push_back(stat[k]); else for_cells(k, [&](size_t c) { items[fill[c]++] = stat[k]; }); }
+			for (uint32_t k = 0; k < n; ++k) { if (huge[k]) w->large_linear.push_back(stat[k]); else { w->hb[stat[k]].lg_state = 1; for_cells(k, [&](size_t c) { items[fill[c]++] = stat[k]; }); } }
 			g.n_items = (uint32_t)total;
 			placed = true;
 		}
-		if (!placed) { w->large_linear.insert(w->large_linear.end(), stat.begin(), stat.end()); g.n_items = 0; }
+		if (!placed) { w->large_linear.insert(w->large_linear.end(), stat.begin(), stat.end()); g.n_items = 0; for (uint32_t id : stat) w->hb[id].lg_state = 0; }
 	}
 	w->lg_static = g.n_items ? (uint32_t)stat.size() : 0u;
 	if (w->large_linear.size() > w->cap_large) return fail(SGP_ERR_CAPACITY, "large-body list full");
