@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsgp.so")
 SOURCES = ["sgp_kernels.hip", "sgp_world.hip"]
-HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "sgp.h")]      # every header: several are generated
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("experiments", f) for f in sorted(os.listdir(os.path.join(CSRC, "experiments")))] + [os.path.join("..", "..", "include", "sgp.h")]      # every header: several are generated
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
 
@@ -47,4 +47,6 @@ def build(force=False, verbose=False, extra=()):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
+    # --experiments: also compile csrc/experiments/* (the resident tile solver of round 3, the solver probe) into the library -- measured negatives and
+    # timing aids that the product does not carry (SGP_TILE_SOLVER, tools/solve_probe.py, tests/test_tile_solver_gpu.py need such a build)
+    build(force="--force" in sys.argv or "--experiments" in sys.argv, verbose=True, extra=("-DSGP_EXPERIMENTS",) if "--experiments" in sys.argv else ())

@@ -2282,46 +2282,11 @@ template <int MODE, int ROWS = -1> __global__ void __launch_bounds__(MODE != 0 ?
 	for (uint32_t k = first + blockIdx.x * SOLVE_TPB + threadIdx.x; k < end; k += gridDim.x * SOLVE_TPB) warm_start_one(d, k);
 }
 
-// Timing probe (not part of the step; sgp_debug_time_solve, tools/solve_probe.py): the velocity-iteration launch of one colour with parts
-// of its body removed, to see where a launch's time goes.  V0 full; V1 every load and store but no row arithmetic; V2 the header and the
-// two body records only; V3 the colour range only.
-template <int V> __global__ void __launch_bounds__(SOLVE_TPB) k_solve_probe(DV d, int colour)
-{
-	const uint32_t first = d.cstarts[colour], end = d.cstarts[colour + 1];
-	if (V == 0) {
-		for (uint32_t k = first + ((blockIdx.x * SOLVE_TPB + threadIdx.x) >> 1); k < end; k += gridDim.x * (SOLVE_TPB / 2)) solve_velocity_pair_t<2>(d, k, (int)(threadIdx.x & 1u), d.vel);
-		return;
-	}
-	for (uint32_t k = first + blockIdx.x * SOLVE_TPB + threadIdx.x; k < end; k += gridDim.x * SOLVE_TPB) {
-		if (V == 1) {
-			PairCtx c;
-			load_pair<2>(d, k, c, d.vel);
-			float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll
-			for (int i = 0; i < 4; ++i) if (i < c.np) {
-				const float4 a = CUR(d).r1b[i][k], b = CUR(d).r2e[i][k], l = CUR(d).lam[i][k]; const float2 e = CUR(d).efft[i][k];
-				acc.x += a.x + b.x + l.x + e.x;
-				CUR(d).lam[i][k] = l;
-			}
-			if (acc.x == 12345.678f) c.A.lv.x += 1.0f;
-			store_pair_vel<2>(c, d.vel);
-		} else if (V == 2) {
-			PairCtx c;
-			load_pair<2>(d, k, c, d.vel);
-			store_pair_vel<2>(c, d.vel);
-		}
-	}
-}
-void launch_solve_probe(const DV& d, int variant, int colour, uint32_t est, hipStream_t s)
-{
-	uint32_t blocks = (est + est / 8 + 64 + SOLVE_TPB - 1) / SOLVE_TPB;
-	if (variant == 0) blocks *= 2;      // two lanes per constraint
-	if (blocks > 8192) blocks = 8192;
-	if (variant == 0) hipLaunchKernelGGL(k_solve_probe<0>, dim3(blocks), dim3(SOLVE_TPB), 0, s, d, colour);
-	else if (variant == 1) hipLaunchKernelGGL(k_solve_probe<1>, dim3(blocks), dim3(SOLVE_TPB), 0, s, d, colour);
-	else if (variant == 2) hipLaunchKernelGGL(k_solve_probe<2>, dim3(blocks), dim3(SOLVE_TPB), 0, s, d, colour);
-	else hipLaunchKernelGGL(k_solve_probe<3>, dim3(blocks), dim3(SOLVE_TPB), 0, s, d, colour);
-}
+#ifdef SGP_EXPERIMENTS
+#include "experiments/sgp_solver_probe.inc"
+#else
+void launch_solve_probe(const DV&, int, int, uint32_t, hipStream_t) {}
+#endif
 
 // Tail colours (few constraints each) share ONE launch: a single workgroup walks colours first_colour..62 in
 // order with a workgroup barrier in between (ordered exactly like separate launches), then solves the overflow
@@ -4738,295 +4703,9 @@ __global__ void __launch_bounds__(TPB) k_ghost_refresh_records(DV d, const sgp_g
 	d.flags[i] = f;
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// THE TILE SOLVER: all velocity iterations of a step in ONE resident launch, without grid-wide synchronisation.
-//
-// A colour launch of a 100k-body pile costs ~10 us whatever it holds (launch + three dependent load levels + a short arithmetic chain,
-// profiles/r02f_solve_probe.md), and a grid barrier costs more than the launch boundary it would replace (profiles/r03_barrier_xcd.md).
-// What the colour order really demands is much weaker than a grid-wide barrier: the constraint (a, b) of colour c must see what the
-// previous constraints of a and of b wrote -- two dependencies per constraint, both to spatial neighbours.  So: every workgroup ("tile")
-// owns the constraints whose first movable body lies in its cell of a coarse grid over the world (k_ts_label), the constraint slots are
-// sorted by (colour, tile) so that a tile's share of a colour is one contiguous run (k_ts_count / k_ts_scan / k_setup_slots_ts), and
-//   * a body all of whose constraints belong to one tile (the great majority: a tile's interior) lives in that tile's LDS for all ten
-//     passes -- read once, written once;
-//   * a body touched by the constraints of several tiles ("shared": the tiles' rims) lives in global memory and is read and written with
-//     agent-scope (sc1, write-through) accesses only;
-//   * a tile that has finished a phase (pass, colour) publishes an epoch; before a phase in which it touches a shared body it waits until
-//     every tile it shares a body with has published the phase before -- one wave polling a handful of words (cdna_hip_programming.md
-//     Guideline 16, recipe R1: write-through payload, every storing wave drains, one flag store; relaxed poll, agent-scope loads).
-// Per body the sequence of operations is exactly the colour order, so every bit of the result is what the colour launches produce.  The
-// next phase's constraint data (header, rows, lambdas) does not depend on any other tile and is requested BEFORE the wait.
-// Everything degrades to "correct but slower": a body in more than four tiles makes all tiles neighbours, a full LDS table sends a body
-// through global memory, the overflow colour (a body with more than 63 contacts) is one tile's serial phase; a tile that waits in vain
-// (a workgroup not resident -- never observed) gives up after a bounded number of polls and raises ts_flags[0], which fails the step.
-#define TS_TPB 512
-#define TS_PAIRS (TS_TPB / 2)
-#define TS_TABLE 2048                 // LDS slots for a tile's private bodies (64 KB of records + 8 KB of keys)
-#define TS_AT_IMMOVABLE 0xFFFFu       // the body cannot move: plain loads of the global record, never written
-#define TS_AT_SHARED    0xFFFEu       // the body lives in global memory behind agent-scope accesses
-#define TS_EPOCH_DONE   0x7FFFFFFFu
-#define TS_SPIN_LIMIT   (1 << 21)
-
-typedef __attribute__((address_space(1))) unsigned long long ts_gu64;
-typedef __attribute__((address_space(1))) unsigned ts_gu32;
-SGP_DEV float4 ts_ld(const float4* p)
-{
-	ts_gu64* q = (ts_gu64*)p;
-	const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	return make_float4(__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b), __uint_as_float((unsigned)(b >> 32)));
-}
-SGP_DEV void ts_st(float4* p, float4 v)
-{
-	ts_gu64* q = (ts_gu64*)p;
-	__hip_atomic_store(q, (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	__hip_atomic_store(q + 1, (unsigned long long)__float_as_uint(v.z) | ((unsigned long long)__float_as_uint(v.w) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// tile of a position: a uniform ts_gx x ts_gy grid over the horizontal bounds of this step's broad-phase grid (what lies outside clamps to the rim)
-SGP_DEV uint32_t ts_tile_of(const DV& d, float4 p)
-{
-	const BpGrid g = *d.grid;
-	const float wx = (float)g.nx * g.cell, wy = (float)g.ny * g.cell;
-	int tx = wx > 0.0f ? (int)((p.x - g.ox) / wx * (float)d.ts_gx) : 0, ty = wy > 0.0f ? (int)((p.y - g.oy) / wy * (float)d.ts_gy) : 0;
-	tx = tx < 0 ? 0 : (tx >= (int)d.ts_gx ? (int)d.ts_gx - 1 : tx); ty = ty < 0 ? 0 : (ty >= (int)d.ts_gy ? (int)d.ts_gy - 1 : ty);
-	return (uint32_t)ty * d.ts_gx + (uint32_t)tx;
-}
-
-__global__ void __launch_bounds__(TPB) k_ts_label(DV d)
-{
-	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-	if (i < SGP_MAX_COLOURS * d.ts_nt) d.ts_count[i] = 0u;
-	if (i < d.ts_nt * 8u) d.ts_adj[i] = 0u;
-	if (i < d.ts_nt) d.ts_wait[i] = 0ull;
-	if (i < 4u) d.ts_flags[i] = 0u;
-	if (i >= d.sp->n_slots) return;
-	d.body_tiles4[i] = ~0ull;
-	const uint32_t f = d.flags[i];
-	if (!(f & BF_ALIVE)) return;
-	d.body_tile[i] = (uint8_t)ts_tile_of(d, d.pose[2 * (size_t)i]);
-}
-
-// the set of (at most four) tiles whose constraints touch a body: 16 bits per tile, 0xFFFF = free (a byte would not do: 256 tiles + "free")
-SGP_DEV void ts_tiles_insert(const DV& d, uint32_t body, uint32_t tile)
-{
-	unsigned long long* p = (unsigned long long*)(d.body_tiles4 + body);
-	unsigned long long old = *(volatile unsigned long long*)p;
-	for (;;) {
-		int free_k = -1;
-		for (int k = 0; k < 4; ++k) { const uint32_t b = (uint32_t)(old >> (16 * k)) & 0xFFFFu; if (b == tile) return; if (b == 0xFFFFu && free_k < 0) free_k = k; }
-		if (free_k < 0) { d.ts_flags[1] = 1u; return; }                // a fifth tile: every tile becomes every tile's neighbour this step
-		const unsigned long long want = (old & ~(0xFFFFull << (16 * free_k))) | ((unsigned long long)tile << (16 * free_k));
-		const unsigned long long got = atomicCAS(p, old, want);
-		if (got == old) return;
-		old = got;
-	}
-}
-
-// per constraint: its tile = the tile of its first movable body (the overflow colour: tile 0, which solves it serially); counts per (colour, tile)
-__global__ void __launch_bounds__(TPB) k_ts_count(DV d)
-{
-	const uint32_t n = min(d.ctr->n_manifolds, d.cap_manifolds);
-	for (uint32_t m = blockIdx.x * TPB + threadIdx.x; m < n; m += gridDim.x * TPB) {
-		const int c = d.man_colour[m];
-		if (c < 0) continue;
-		const uint2 ab = d.man_ab[m];
-		const bool ma = d.vel[2 * (size_t)ab.x].w > 0.0f, mb = d.vel[2 * (size_t)ab.y].w > 0.0f;
-		const uint32_t T = c == SGP_OVERFLOW_COLOUR ? 0u : (uint32_t)d.body_tile[ma ? ab.x : ab.y];
-		d.man_tile[m] = (uint8_t)T;
-		atomicAdd(&d.ts_count[(uint32_t)c * d.ts_nt + T], 1u);
-		if (ma) ts_tiles_insert(d, ab.x, T);
-		if (mb) ts_tiles_insert(d, ab.y, T);
-	}
-}
-
-// exclusive scan of the (colour, tile) histogram, colour-major: the first slot of every (colour, tile) run -- and with it of every colour
-__global__ void __launch_bounds__(1024) k_ts_scan(DV d)
-{
-	__shared__ uint32_t wsum[16];
-	const uint32_t E = SGP_MAX_COLOURS * d.ts_nt, per = (E + 1023u) / 1024u;
-	const uint32_t e0 = threadIdx.x * per;
-	uint32_t local = 0;
-	for (uint32_t k = 0; k < per; ++k) if (e0 + k < E) local += d.ts_count[e0 + k];
-	uint32_t x = local;
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off, 64); if (lane >= off) x += y; }
-	if (lane == 63) wsum[wave] = x;
-	__syncthreads();
-	uint32_t base = x - local;
-	for (int k = 0; k < wave; ++k) base += wsum[k];
-	for (uint32_t k = 0; k < per; ++k) if (e0 + k < E) { d.ts_start[e0 + k] = base; d.ts_fill[e0 + k] = 0u; base += d.ts_count[e0 + k]; }
-	if (threadIdx.x == 1023) d.ts_start[E] = base;
-	__syncthreads();
-	__threadfence_block();
-	if (threadIdx.x < SGP_MAX_COLOURS) d.cstarts[threadIdx.x] = d.ts_start[threadIdx.x * d.ts_nt];
-	if (threadIdx.x == SGP_MAX_COLOURS) d.cstarts[SGP_MAX_COLOURS] = d.ts_start[E];
-	if (threadIdx.x < 64) {
-		const uint32_t v = d.ctr->colour_count[threadIdx.x];
-		const unsigned long long used = __ballot(v != 0 && threadIdx.x < SGP_OVERFLOW_COLOUR);
-		if (threadIdx.x == 0) d.ctr->n_colours = used ? 64u - (uint32_t)__clzll(used) : 0u;
-	}
-}
-
-// constraint slots in (colour, tile) order; per constraint side where its body will live during the solve; which tiles share bodies
-__global__ void __launch_bounds__(TPB) k_setup_slots_ts(DV d)
-{
-	const uint32_t n = min(d.ctr->n_manifolds, d.cap_manifolds);
-	const bool all_adjacent = d.ts_flags[1] != 0u;
-	for (uint32_t m = blockIdx.x * TPB + threadIdx.x; m < n; m += gridDim.x * TPB) {
-		const int c = d.man_colour[m];
-		if (c < 0) continue;
-		const uint32_t T = d.man_tile[m], e = (uint32_t)c * d.ts_nt + T;
-		const uint32_t slot = d.ts_start[e] + atomicAdd(&d.ts_fill[e], 1u);
-		d.man_slot[m] = slot;
-		const uint2 ab = d.man_ab[m];
-		for (int side = 0; side < 2; ++side) {
-			const uint32_t body = side ? ab.y : ab.x;
-			uint8_t code = 0;                                              // immovable
-			if (d.vel[2 * (size_t)body].w > 0.0f) {
-				const uint64_t t4 = d.body_tiles4[body];
-				bool shared = all_adjacent;
-				for (int k = 0; k < 4; ++k) {
-					const uint32_t U = (uint32_t)(t4 >> (16 * k)) & 0xFFFFu;
-					if (U == 0xFFFFu || U == T) continue;
-					shared = true;
-					atomicOr(&d.ts_adj[T * 8u + (U >> 5)], 1u << (U & 31u));
-				}
-				if (shared) atomicOr((unsigned long long*)&d.ts_wait[T], 1ull << c);
-				code = shared ? 2 : 1;
-			}
-			d.ts_side[2 * (size_t)slot + side] = code;
-		}
-	}
-}
-
-__global__ void __launch_bounds__(TS_TPB) k_ts_solve(DV d, int passes, int colour_end)
-{
-	__shared__ float4 s_rec[2 * TS_TABLE];
-	__shared__ uint32_t s_key[TS_TABLE];
-	__shared__ uint32_t s_base[SGP_MAX_COLOURS], s_cnt[SGP_MAX_COLOURS];
-	__shared__ unsigned long long s_present, s_waitmask;
-	__shared__ int s_ok;
-	const uint32_t NT = d.ts_nt, T = blockIdx.x;
-	const int side = (int)(threadIdx.x & 1u);
-	const uint32_t pair = threadIdx.x >> 1;
-	ts_gu32* my_epoch = (ts_gu32*)(d.ts_epoch + 32u * T);
-	for (uint32_t i = threadIdx.x; i < TS_TABLE; i += TS_TPB) s_key[i] = 0xFFFFFFFFu;
-	const bool all_adjacent = d.ts_flags[1] != 0u || (d.dbg_flags & 4u);      // (SGP_DEBUG_FLAGS bit 2: every tile waits for every tile; bit 3: no body in LDS)
-	if (threadIdx.x < SGP_MAX_COLOURS) {
-		const uint32_t e = threadIdx.x * NT + T;
-		const uint32_t b = d.ts_start[e], cnt = d.ts_start[e + 1] - b;
-		s_base[threadIdx.x] = b; s_cnt[threadIdx.x] = cnt;
-		const unsigned long long pres = __ballot(cnt != 0u && (int)threadIdx.x < colour_end);      // (colours >= colour_end are somebody else's: the component launch)
-		if (threadIdx.x == 0) { s_present = pres; s_waitmask = all_adjacent ? ~0ull : d.ts_wait[T]; s_ok = 1; }
-	}
-	__syncthreads();
-	const unsigned long long present = s_present, waitmask = s_waitmask;
-	if (!present) { if (threadIdx.x == 0) __hip_atomic_store(my_epoch, TS_EPOCH_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
-	// the tiles this lane polls (wave 0; lane l looks after the tiles l, l + 64, l + 128, l + 192)
-	uint32_t poll_mask = 0;
-	if (threadIdx.x < 64) {
-		for (uint32_t j = 0; j < 4; ++j) {
-			const uint32_t U = threadIdx.x + 64u * j;
-			if (U < NT && U != T && (all_adjacent || ((d.ts_adj[T * 8u + (U >> 5)] >> (U & 31u)) & 1u))) poll_mask |= 1u << j;
-		}
-	}
-	// EVERY access of this launch to the velocity records is an agent-scope one, also where no other tile is involved (the private bodies on
-	// their way into and out of LDS, the bodies that cannot move): a 128 B line holds four bodies' records, and a line that a plain load or
-	// store of one of them left in this XCD's L2 would answer a later agent-scope load of its neighbour with what it held then, not with what
-	// another XCD has written through to memory since (the L2s of the eight XCDs are not coherent with each other; measured: one body in
-	// 25 000 off by one rounding after a dozen steps).
-	// prologue: every private body of this tile into the LDS table (whoever claims its slot brings the record in); where each constraint side
-	// finds its body is remembered per side for the ten passes
-	for (unsigned long long pm = present; pm; pm &= pm - 1) {
-		const int c = __ffsll((long long)pm) - 1;
-		const uint32_t base = s_base[c], cnt = s_cnt[c];
-		for (uint32_t k = pair; k < cnt; k += TS_PAIRS) {
-			const uint32_t slot = base + k;
-			const uint32_t code = d.ts_side[2 * (size_t)slot + side];
-			uint32_t at = code == 0u ? TS_AT_IMMOVABLE : TS_AT_SHARED;
-			if (code == 1u && !(d.dbg_flags & 8u)) {
-				const uint2 ab = CUR(d).ab[slot];
-				const uint32_t body = side ? ab.y : ab.x;
-				uint32_t h = uf_prio(body) & (TS_TABLE - 1);
-				for (uint32_t probe = 0; probe < TS_TABLE; ++probe) {
-					const uint32_t old = atomicCAS(&s_key[h], 0xFFFFFFFFu, body);
-					if (old == 0xFFFFFFFFu) { s_rec[2 * h] = ts_ld(d.vel + 2 * (size_t)body); s_rec[2 * h + 1] = ts_ld(d.vel + 2 * (size_t)body + 1); at = h; break; }
-					if (old == body) { at = h; break; }
-					h = (h + 1) & (TS_TABLE - 1);
-				}
-				// (table full: the body stays in global memory -- only this tile touches it, the agent-scope path is merely slower)
-			}
-			d.ts_at[2 * (size_t)slot + side] = (uint16_t)at;
-		}
-	}
-	{
-		const int c0 = __ffsll((long long)present) - 1;
-		if (threadIdx.x == 0) __hip_atomic_store(my_epoch, (uint32_t)c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // phases < c0 + 1 of pass 0: nothing to do
-	}
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	__syncthreads();
-	const uint32_t dbg = d.dbg_flags;
-	for (int pass = 0; pass < passes; ++pass) {
-		for (unsigned long long pm = present; pm; pm &= pm - 1) {
-			const int c = __ffsll((long long)pm) - 1;
-			const uint32_t g = (uint32_t)pass * SGP_MAX_COLOURS + (uint32_t)c + 1u;            // this phase; epochs count completed phases
-			const uint32_t base = s_base[c], cnt = s_cnt[c];
-			// One loop serves the ordinary colours (a chunk of TS_PAIRS constraints per turn, usually one turn) and the overflow colour (a body with
-			// more than 63 contacts: its surplus constraints one at a time in ascending priority on lanes 0 and 1; only tile 0 has any).  A turn
-			// requests its constraint data first -- nothing of it depends on another tile -- and only then, in the phase's first turn, waits.
-			const bool serial = c == SGP_OVERFLOW_COLOUR;
-			uint64_t last = 0; bool have_last = false;
-			const uint32_t turns = serial ? cnt : (cnt + TS_PAIRS - 1) / TS_PAIRS;
-			for (uint32_t turn = 0; turn < turns; ++turn) {
-				ConHalf h; uint32_t at = 0, slot = 0;
-				bool mine;
-				if (serial) { mine = threadIdx.x < 2; if (mine) slot = overflow_next(d, base, cnt, last, have_last); }
-				else { mine = turn * TS_PAIRS + pair < cnt; slot = base + turn * TS_PAIRS + pair; }
-				if (mine) { half_load<0>(d, slot, side, h); at = d.ts_at[2 * (size_t)slot + side]; }
-				if (turn == 0 && ((waitmask >> c) & 1ull)) {
-					if (threadIdx.x < 64) {
-						bool ready = poll_mask == 0u; int spins = 0, ok = 1;
-						while (!__all(ready)) {
-							if (!ready) { bool r = true; for (uint32_t j = 0; j < 4; ++j) if ((poll_mask >> j) & 1u) r = r && __hip_atomic_load((ts_gu32*)(d.ts_epoch + 32u * (threadIdx.x + 64u * j)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= g - 1u; ready = r; }
-							if (!__all(ready)) { __builtin_amdgcn_s_sleep(1); if (++spins > TS_SPIN_LIMIT) { ok = 0; break; } }
-						}
-						if (threadIdx.x == 0) s_ok = ok;
-					}
-					__syncthreads();
-					if (!s_ok) { if (threadIdx.x == 0) { d.ts_flags[0] = 1u; __hip_atomic_store(my_epoch, TS_EPOCH_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } return; }
-				}
-				if (mine && (h.np_col & 0xFF) != 0) {
-					float4 v4, w4;
-					if (at < TS_AT_SHARED) { v4 = s_rec[2 * at]; w4 = s_rec[2 * at + 1]; }
-					else { v4 = ts_ld(d.vel + 2 * (size_t)h.body); w4 = ts_ld(d.vel + 2 * (size_t)h.body + 1); }      // (shared, or immovable: see below)
-					if (half_solve_core(h, side, v4, w4, dbg)) {
-						if (at < TS_AT_SHARED) { s_rec[2 * at] = v4; s_rec[2 * at + 1] = w4; }
-						else { ts_st(d.vel + 2 * (size_t)h.body, v4); ts_st(d.vel + 2 * (size_t)h.body + 1, w4); }
-					}
-					half_store(d, slot, side, h);
-				}
-				if (serial) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the next constraint of the sequence may read what this one wrote)
-			}
-			// every wave's write-through stores have landed, then ONE lane publishes: all phases below the tile's next one are complete
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			__syncthreads();
-			if (threadIdx.x == 0) {
-				const unsigned long long rest = c == 63 ? 0ull : (present & ~((2ull << c) - 1ull));
-				uint32_t done;
-				if (rest) done = (uint32_t)pass * SGP_MAX_COLOURS + (uint32_t)(__ffsll((long long)rest) - 1);
-				else if (pass + 1 < passes) done = (uint32_t)(pass + 1) * SGP_MAX_COLOURS + (uint32_t)(__ffsll((long long)present) - 1);
-				else done = TS_EPOCH_DONE;
-				__hip_atomic_store(my_epoch, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			}
-		}
-	}
-	// the private bodies go home
-	for (uint32_t i = threadIdx.x; i < TS_TABLE; i += TS_TPB) {
-		const uint32_t body = s_key[i];
-		if (body != 0xFFFFFFFFu) { ts_st(d.vel + 2 * (size_t)body, s_rec[2 * i]); ts_st(d.vel + 2 * (size_t)body + 1, s_rec[2 * i + 1]); }
-	}
-}
-
+#ifdef SGP_EXPERIMENTS
+#define SGP_TILE_SOLVER_INCLUDED 1
+#endif
 // What the host needs of a received record to decide whether the ghost set changed: its global id and whether it asks for a change of ownership
 // (16 B instead of the 128 B record).
 __global__ void __launch_bounds__(TPB) k_pack_ghost_keys(const sgp_ghost_record* recs, uint32_t n, uint4* out)
@@ -5042,6 +4721,15 @@ __global__ void __launch_bounds__(TPB) k_pack_ghost_keys(const sgp_ghost_record*
 
 static inline uint32_t blocks_for(uint32_t n) { return n ? (n + TPB - 1) / TPB : 1; }
 static inline uint32_t stride_grid(uint32_t estimate) { uint32_t b = blocks_for(estimate); if (b < 64) b = 64; if (b > 4096) b = 4096; return (b + 7u) & ~7u; }      // (a multiple of eight: xcd_block)
+#ifdef SGP_EXPERIMENTS
+#include "experiments/sgp_tile_solver.inc"
+#else
+// (the resident tile solver of round 3 is an experiment: built only with -DSGP_EXPERIMENTS; a plain build never plans it, sgp_world.hip)
+void launch_ts_label(const DV&, uint32_t, hipStream_t) {}
+void launch_colour_count_ts(const DV&, uint32_t, hipStream_t) {}
+void launch_setup_ts(const DV&, uint32_t, hipStream_t) {}
+void launch_ts_solve(const DV&, int, int, hipStream_t) {}
+#endif
 
 void launch_step_begin(const DV& d, const StepParams& sp, uint32_t nb, bool reset_step_scratch, hipStream_t s)
 {
@@ -5105,23 +4793,6 @@ void launch_colour_count(const DV& d, uint32_t est, hipStream_t s)
 	// few, looping workgroups: every workgroup ends with one global atomic per colour, and those queue per colour (config 3: 512 workgroups 21 us,
 	// 256: 13 us, 128: 11 us, 64: 15 us); more of them only where there is enough to count (a million bodies)
 	hipLaunchKernelGGL(k_colour_count, dim3(std::min(std::max(stride_grid(est) / 8u, 128u), 512u)), dim3(TPB), 0, s, d, 1);
-}
-void launch_ts_label(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_ts_label, dim3(blocks_for(std::max(nb, SGP_MAX_COLOURS * d.ts_nt))), dim3(TPB), 0, s, d); }
-void launch_colour_count_ts(const DV& d, uint32_t est, hipStream_t s)
-{
-	hipLaunchKernelGGL(k_colour_count, dim3(std::min(std::max(stride_grid(est) / 8u, 128u), 512u)), dim3(TPB), 0, s, d, 0);
-	hipLaunchKernelGGL(k_ts_count, dim3(stride_grid(est)), dim3(TPB), 0, s, d);
-	hipLaunchKernelGGL(k_ts_scan, dim3(1), dim3(1024), 0, s, d);
-}
-void launch_setup_ts(const DV& d, uint32_t n_man, hipStream_t s)
-{
-	hipLaunchKernelGGL(k_setup_slots_ts, dim3(stride_grid(n_man)), dim3(TPB), 0, s, d);
-	hipLaunchKernelGGL(k_setup, dim3(stride_grid(n_man)), dim3(TPB), 0, s, d);
-}
-void launch_ts_solve(const DV& d, int passes, int colour_end, hipStream_t s)
-{
-	hipMemsetAsync(d.ts_epoch, 0, sizeof(uint32_t) * 32u * d.ts_nt, s);      // (a memset node of the captured graph: every polled word starts from zero in every step)
-	hipLaunchKernelGGL(k_ts_solve, dim3(d.ts_nt), dim3(TS_TPB), 0, s, d, passes, colour_end);
 }
 void launch_colour_finish(const DV& d, uint32_t first_round, int build_list, hipStream_t s) { hipLaunchKernelGGL(k_colour_finish, dim3(1), dim3(1024), 0, s, d, first_round, build_list); }
 void launch_setup(const DV& d, uint32_t n_man, hipStream_t s)

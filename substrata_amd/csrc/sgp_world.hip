@@ -345,7 +345,9 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 		int dev = 0, cus = 0;
 		if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
 		d.ts_nt = 0; d.ts_gx = d.ts_gy = 0;
+#ifdef SGP_EXPERIMENTS      // (the resident tile solver is an experiment: csrc/experiments/sgp_tile_solver.inc; a plain build neither allocates for it nor plans it)
 		if (cus >= 256) { d.ts_nt = 256; d.ts_gx = 16; d.ts_gy = 16; } else if (cus >= 128) { d.ts_nt = 128; d.ts_gx = 16; d.ts_gy = 8; } else if (cus >= 64) { d.ts_nt = 64; d.ts_gx = 8; d.ts_gy = 8; }
+#endif
 		if (d.ts_nt) {
 			const size_t E = (size_t)SGP_MAX_COLOURS * d.ts_nt;
 			DEV_ALLOC(d.body_tile, N); DEV_ALLOC(d.body_tiles4, N); DEV_ALLOC(d.man_tile, M);
@@ -380,7 +382,9 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	{ const char* e = getenv("SGP_NO_GRAPH"); if (e && e[0] == '1') w->use_graphs = false; }
 	{ const char* e = getenv("SGP_NO_SMALL_WORLD"); if (e && e[0] == '1') w->use_small_world = false; }
 	{ const char* e = getenv("SGP_DEBUG_FLAGS"); w->dv.dbg_flags = e ? (uint32_t)atoi(e) : 0u; }
+#ifdef SGP_EXPERIMENTS
 	{ const char* e = getenv("SGP_TILE_SOLVER"); if (e) w->use_tile_solver = atoi(e); }
+#endif
 	{ const char* e = getenv("SGP_VEHICLE_FUSED"); if (e) w->fuse_vehicle_solve = atoi(e) != 0; }
 	{ const char* e = getenv("SGP_COMPACT_ROWS_MIN"); if (e && atoll(e) >= 0) w->compact_rows_min = (uint32_t)atoll(e); }
 	{ const char* e = getenv("SGP_ROWS_MODE"); if (e && (atoi(e) == 1 || atoi(e) == 2)) w->rows_mode_large = (uint32_t)atoi(e); }
@@ -1485,8 +1489,20 @@ SGP_API int sgp_world_step_profiled(sgp_world* w, float dt, sgp_step_profile* ou
 
 // Timing probe (tools/solve_probe.py; not declared in include/sgp.h): average time of `reps` back-to-back launches of the velocity
 // iteration of one colour, full (variant 0) or with parts removed (see k_solve_probe).  Leaves the velocities of the world perturbed.
+// 1 when the library carries csrc/experiments/* (python -m substrata_amd.build --experiments); not declared in include/sgp.h
+SGP_API int sgp_debug_has_experiments(void)
+{
+#ifdef SGP_EXPERIMENTS
+	return 1;
+#else
+	return 0;
+#endif
+}
 SGP_API int sgp_debug_time_solve(sgp_world* w, int variant, int colour, int reps, float* us_out, uint32_t* count_out)
 {
+#ifndef SGP_EXPERIMENTS
+	return fail(SGP_ERR_INVALID, "sgp_debug_time_solve: this library was built without the experiments (python -m substrata_amd.build --experiments)");
+#endif
 	if (!w || !us_out || colour < 0 || colour >= SGP_OVERFLOW_COLOUR) return fail(SGP_ERR_INVALID, "sgp_debug_time_solve");
 	hipSetDevice(w->device);
 	hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));

@@ -14,6 +14,16 @@ import parity
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _needs_the_experiments_build():
+    """The tile solver is a measured negative (profiles/r03_tile_solver.md) and no longer part of the product library: these tests run where
+    libsgp.so was built with `python -m substrata_amd.build --experiments`."""
+    from substrata_amd.lib import load
+    lib = load()
+    if not hasattr(lib, "sgp_debug_has_experiments") or lib.sgp_debug_has_experiments() == 0:
+        pytest.skip("libsgp.so was built without csrc/experiments (python -m substrata_amd.build --experiments)")
+
+
 @pytest.fixture
 def ts_env(monkeypatch):
     monkeypatch.setenv("SGP_TILE_SOLVER", "1")
