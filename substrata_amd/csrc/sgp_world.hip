@@ -980,6 +980,8 @@ static int rebuild_large_grid(sgp_world* w)
 		w->cap_lg_items = (uint32_t)(items.size() + items.size() / 2);
 		uint32_t* ni = nullptr;
 		HIP_TRY(hipMalloc((void**)&ni, sizeof(uint32_t) * (size_t)w->cap_lg_items));
+		// (the previous buffer is freed here, after the synchronisation above: it used to be parked in `allocs` at every growth; advisor r03)
+		if (w->d_lg_items) { auto it = std::find(w->allocs.begin(), w->allocs.end(), (void*)w->d_lg_items); if (it != w->allocs.end()) w->allocs.erase(it); hipFree(w->d_lg_items); }
 		w->allocs.push_back(ni); w->device_bytes += sizeof(uint32_t) * (size_t)w->cap_lg_items;
 		w->d_lg_items = ni; d.lg_items = ni;
 		invalidate_graphs(w);
@@ -3281,6 +3283,7 @@ struct SnapshotRing {
 	Entry slots[SGP_SNAPSHOT_HISTORY];
 	uint32_t next_snapshot_i = 0, next_insertable_snapshot_i = 0;
 	double transmission_time_offset = 0.0;
+	uint32_t idle_expires = 0;      // expire() calls this ring has seen without ever holding a snapshot
 };
 struct sgp_snapshot_queue { std::map<uint64_t, SnapshotRing> rings; };      // ordered: the playback order is ascending uid, deterministic
 
@@ -3341,10 +3344,12 @@ SGP_API int sgp_snapshot_queue_expire(sgp_snapshot_queue* q, double local_time_n
 {
 	if (!q) return fail(SGP_ERR_INVALID, "sgp_snapshot_queue_expire: NULL");
 	for (auto it = q->rings.begin(); it != q->rings.end();) {
-		const SnapshotRing& r = it->second;
+		SnapshotRing& r = it->second;
 		const bool has_any = r.next_snapshot_i > 0;
 		const double last = has_any ? r.slots[(r.next_snapshot_i - 1) % (uint32_t)SGP_SNAPSHOT_HISTORY].local_time : -1.0e300;
-		if (has_any && local_time_now - last > max_age) it = q->rings.erase(it); else ++it;
+		// (a ring that an ownership message created and no transform update ever filled has no time stamp to age by: it goes after 1024 calls -- the caller
+		// expires once per frame -- so that the map cannot grow without bound on a long-running client; advisor r03)
+		if (has_any ? (local_time_now - last > max_age) : (++it->second.idle_expires > 1024u)) it = q->rings.erase(it); else ++it;
 	}
 	if (n_out) *n_out = (uint32_t)q->rings.size();
 	return SGP_OK;

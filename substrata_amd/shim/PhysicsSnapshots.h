@@ -96,15 +96,16 @@ public:
 	// null when it has none).  Returns the number of snapshots inserted.
 	template <class Lookup> size_t insertDue(PhysicsWorld& world, double global_time, Lookup lookup, double padding_delay = 0.1)
 	{
+		// first ask how many objects have a snapshot due (cap 0: nothing is consumed), then take exactly those in one poll: a second poll after a short
+		// buffer would hand out the NEXT snapshot of the objects the first one served -- two states of one object in a frame, where the reference
+		// inserts at most one per object and frame (GUIClient.cpp:7469-7492)
 		uint32_t n = 0;
-		uids.resize(std::max<size_t>(uids.size(), 256)); recs.resize(uids.size());
-		for (;;) {
-			sgp_snapshot_queue_poll(q, global_time, padding_delay, uids.data(), recs.data(), (uint32_t)uids.size(), &n);
-			if (n <= uids.size()) break;
-			// more objects due than the buffers held: the first ones were consumed, take them, then ask again with room for the rest
-			applyBatch(world, uids.size(), lookup);
-			uids.resize(n); recs.resize(n);
-		}
+		sgp_snapshot_queue_poll(q, global_time, padding_delay, nullptr, nullptr, 0, &n);
+		if (n == 0) return 0;
+		if (uids.size() < n) { uids.resize(n); recs.resize(n); }
+		uint32_t due = 0;
+		sgp_snapshot_queue_poll(q, global_time, padding_delay, uids.data(), recs.data(), (uint32_t)uids.size(), &due);
+		n = std::min<uint32_t>(due, (uint32_t)uids.size());
 		applyBatch(world, n, lookup);
 		return n;
 	}
