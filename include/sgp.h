@@ -206,7 +206,7 @@ typedef struct sgp_step_stats {
 	uint32_t num_component_constraints;  /* constraints of the high colours, solved component by component in one launch per pass (device launch plan; 0 on the oracle) */
 	uint32_t num_catch_all_constraints;  /* ... of them in components too large for a workgroup (solved serially; the plan then takes fewer colours) */
 	uint32_t num_deferred_vehicles;      /* vehicles that shared a movable body (a dynamic body under a wheel, a chassis a wheel stands on) with a vehicle of lower index this step: their rows are solved after the others', in index order */
-	uint32_t reserved0;
+	uint32_t num_wake_pairs;             /* in-step activation: pairs of the bodies this step woke with what was not awake when it began (part of num_pairs) */
 	uint32_t tile_solver;                /* 1: this step's velocity iterations ran as the one resident launch of the tile solver; 2: ... and some body made all tiles neighbours */
 	uint64_t device_bytes;
 } sgp_step_stats;

@@ -59,6 +59,7 @@ typedef struct {
 	int alive, active;
 	v3 aabb_min, aabb_max;
 	v3 sleep_c[3]; float sleep_r[3]; float sleep_timer;
+	uint32_t sleep_label;              /* the island this body fell asleep with (the member with the lowest uf_prio; its own id from creation): bodies that share it wake together */
 	int underwater; float submerged;
 	/* per-step scratch */
 	uint64_t colour_mask; uint64_t claim[2];
@@ -122,6 +123,7 @@ typedef struct sgo_world {
 	sgp_contact_event* ev_pers; uint32_t n_pers, cap_pers;
 	/* broad-phase scratch */
 	uint64_t* cell_keys; uint32_t* cell_idx; uint32_t* large; uint32_t n_large;
+	struct keyidx_s* bp_ki; uint32_t bp_n_small; float bp_cell;      /* the step's cell-sorted small bodies (kept until the next broad phase: find_contacts pairs the bodies it wakes) */
 	/* multi-tile ghosts: global id -> local id, kept sorted by global id */
 	uint64_t* ghost_gid; uint32_t* ghost_lid; uint32_t n_ghosts;
 	int* is_ghost;
@@ -400,7 +402,7 @@ SGO_API int sgo_world_destroy(sgo_world* w)
 	free(w->bodies); free(w->free_list); free(w->free_triples); free(w->free_mesh_ids); free(w->free_hull_ids); free(w->pairs); free(w->cons); free(w->prev);
 	free(w->prev_keys_sorted); free(w->prev_idx_sorted); free(w->order);
 	free(w->ev_act); free(w->ev_deact); free(w->ev_water); free(w->ev_added); free(w->ev_pers);
-	free(w->cell_keys); free(w->cell_idx); free(w->large); free(w->is_ghost); free(w->ghost_gid); free(w->ghost_lid);
+	free(w->bp_ki); free(w->cell_keys); free(w->cell_idx); free(w->large); free(w->is_ghost); free(w->ghost_gid); free(w->ghost_lid);
 	free(w->vehicles);
 	for (uint32_t k = 0; k < w->n_hulls; ++k) free(w->hulls[k]);       /* (free(NULL) for destroyed hulls) */
 	free(w->hulls);
@@ -468,6 +470,7 @@ SGO_API int sgo_body_add(sgo_world* w, const sgp_body_desc* d, uint32_t* id_out)
 	else { b->inv_mass = 0.0f; b->inv_inertia = V3(0.0f, 0.0f, 0.0f); }
 	if (b->motion != SGP_MOTION_DYNAMIC) { /* non-dynamic bodies carry no force */ }
 	b->alive = 1; b->active = 0;
+	b->sleep_label = id;
 	b->comp_root = SGP_INVALID_ID;
 	body_update_aabb(b);
 	body_reset_sleep(b);
@@ -754,10 +757,10 @@ static int body_is_active_for_pairs(const sgo_body* b)
 	return 0;
 }
 
-static int pair_passes(const sgo_world* w, uint32_t i, uint32_t j)
+/* everything of the pair test but the "one of them is active" condition */
+static int pair_passes_geom(const sgo_world* w, uint32_t i, uint32_t j)
 {
 	const sgo_body* a = &w->bodies[i]; const sgo_body* b = &w->bodies[j];
-	if (!(body_is_active_for_pairs(a) || body_is_active_for_pairs(b))) return 0;
 	if (a->motion != SGP_MOTION_DYNAMIC && b->motion != SGP_MOTION_DYNAMIC) return 0;
 	if (!(layers_collide(a->layer, b->layer))) return 0;
 	const float d = w->st.speculative_contact_distance;
@@ -767,6 +770,12 @@ static int pair_passes(const sgo_world* w, uint32_t i, uint32_t j)
 	return 1;
 }
 
+static int pair_passes(const sgo_world* w, uint32_t i, uint32_t j)
+{
+	if (!(body_is_active_for_pairs(&w->bodies[i]) || body_is_active_for_pairs(&w->bodies[j]))) return 0;
+	return pair_passes_geom(w, i, j);
+}
+
 static void push_pair(sgo_world* w, uint32_t i, uint32_t j)
 {
 	if (w->n_pairs == w->cap_pairs) { w->cap_pairs = w->cap_pairs ? w->cap_pairs * 2 : 1024; w->pairs = (sgo_pair*)realloc(w->pairs, sizeof(sgo_pair) * w->cap_pairs); }
@@ -774,7 +783,7 @@ static void push_pair(sgo_world* w, uint32_t i, uint32_t j)
 	w->pairs[w->n_pairs++] = p;
 }
 
-typedef struct { uint64_t key; uint32_t idx; } keyidx;
+typedef struct keyidx_s { uint64_t key; uint32_t idx; } keyidx;
 static int cmp_keyidx(const void* a, const void* b)
 {
 	const keyidx* x = (const keyidx*)a; const keyidx* y = (const keyidx*)b;
@@ -800,7 +809,9 @@ static void broad_phase(sgo_world* w)
 	const float large_r = w->desc.large_body_radius;
 	float cell = 0.5f;
 	uint32_t n_small = 0;
+	free(w->bp_ki);
 	keyidx* ki = (keyidx*)malloc(sizeof(keyidx) * (w->high ? w->high : 1));
+	w->bp_ki = ki;
 	for (uint32_t i = 0; i < w->high; ++i) {
 		const sgo_body* b = &w->bodies[i];
 		if (!b->alive || b->is_alias) continue;
@@ -816,6 +827,7 @@ static void broad_phase(sgo_world* w)
 		ki[k].key = cell_key((int64_t)floorf(c.x / cell), (int64_t)floorf(c.y / cell), (int64_t)floorf(c.z / cell));
 	}
 	qsort(ki, n_small, sizeof(keyidx), cmp_keyidx);
+	w->bp_n_small = n_small; w->bp_cell = cell;
 	#pragma omp parallel if (g_threads > 1)
 	{
 		sgo_pair* loc = NULL; uint32_t nloc = 0, caploc = 0;
@@ -853,7 +865,6 @@ static void broad_phase(sgo_world* w)
 			if (pair_passes(w, i, j)) push_pair(w, i, j);
 		}
 	}
-	free(ki);
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -1013,45 +1024,43 @@ static int g_active_edges = 1;      /* test switch: 0 = every edge collides with
 SGO_API int sgo_set_active_edges(int on) { const int old = g_active_edges; g_active_edges = on ? 1 : 0; return old; }
 SGO_API int sgo_mesh_edge_flags(sgo_world* w, uint32_t mesh_id, uint8_t* out, uint32_t cap);
 
-static void find_contacts(sgo_world* w, float dt)
+/* manifolds of pairs [first, first + n): mans[3 (p - first) + g], hit[p - first] = number of manifolds, reused[p - first] */
+static void collide_pairs(sgo_world* w, uint32_t first, uint32_t n, float dt, sgo_manifold* mans, unsigned char* hit, unsigned char* reused)
 {
-	w->n_cons = 0;
-	/* pass 1: manifolds + activation of sleeping bodies touched by an active one.  A pair with a mesh body yields up to three
-	   manifolds (groups of triangle contacts with similar normals), carried by the mesh body and its two alias slots. */
-	if (w->cap_cons < 3 * w->n_pairs + 1) {
-		w->cap_cons = 3 * w->n_pairs + 1024;
-		w->cons = (sgo_constraint*)realloc(w->cons, sizeof(sgo_constraint) * w->cap_cons);
-	}
-	sgo_manifold* mans = (sgo_manifold*)malloc(sizeof(sgo_manifold) * (w->n_pairs ? 3 * w->n_pairs : 1));
-	unsigned char* hit = (unsigned char*)malloc(w->n_pairs ? w->n_pairs : 1);
-	unsigned char* reused = (unsigned char*)calloc(w->n_pairs ? w->n_pairs : 1, 1);
 	#pragma omp parallel for schedule(static, 256) if (g_threads > 1)
-	for (uint32_t p = 0; p < w->n_pairs; ++p) {
+	for (uint32_t q = 0; q < n; ++q) {
+		const uint32_t p = first + q;
 		const uint32_t a = w->pairs[p].a, b = w->pairs[p].b;
 		const sgo_body* A = &w->bodies[a]; const sgo_body* B = &w->bodies[b];
+		reused[q] = 0;
 		if (A->shape_type == SGP_SHAPE_MESH || B->shape_type == SGP_SHAPE_MESH) {
-			hit[p] = 0;
+			hit[q] = 0;
 			if (A->shape_type == SGP_SHAPE_MESH && B->shape_type == SGP_SHAPE_MESH) continue;       /* (both static anyway) */
 			const sgo_body* M = A->shape_type == SGP_SHAPE_MESH ? A : B; const sgo_body* X = M == A ? B : A;
 			const sgo_shape sx = body_shape_xf(X);
 			/* movement hint of the active-edge rule: X's velocity with this step's gravity, relative to the mesh (PhysicsSystem::ProcessBodyPair:
 			   mActiveEdgeMovementDirection = v1 - v2, after ApplyGravity; the device has not applied the forces yet at this point and adds g dt itself) */
 			const v3 mv = v3_sub(v3_add(X->linv_pre, v3_scale(v3_scale(w->gravity, X->gravity_factor), dt)), M->motion == SGP_MOTION_STATIC ? V3(0, 0, 0) : M->linv);
-			hit[p] = (unsigned char)collide_with_mesh(M, &sx, X->aabb_min, X->aabb_max, w->st.speculative_contact_distance, &mans[3 * p], g_active_edges, mv);
+			hit[q] = (unsigned char)collide_with_mesh(M, &sx, X->aabb_min, X->aabb_max, w->st.speculative_contact_distance, &mans[3 * q], g_active_edges, mv);
 			continue;
 		}
 		/* the body-pair contact cache: both bodies where they were (relative to each other) when the cached manifold was computed ->
 		   the manifold is rebuilt from its body-space points instead of running the collision test */
-		reused[p] = 0;
-		if (reuse_cached_manifold(w, a, b, &mans[3 * p])) { hit[p] = 1; reused[p] = 1; continue; }
+		if (reuse_cached_manifold(w, a, b, &mans[3 * q])) { hit[q] = 1; reused[q] = 1; continue; }
 		const sgo_shape sa = body_shape_xf(A), sb = body_shape_xf(B);
-		hit[p] = (unsigned char)sgo_collide(&sa, &sb, w->st.speculative_contact_distance, &mans[3 * p]);
+		hit[q] = (unsigned char)sgo_collide(&sa, &sb, w->st.speculative_contact_distance, &mans[3 * q]);
 	}
-	uint32_t nm = 0;
-	for (uint32_t p = 0; p < w->n_pairs; ++p) {
-		for (int g = 0; g < hit[p]; ++g) {
+}
+
+/* ... appended to the constraint list (from slot *nm on) and, compacted, to out[] */
+static void append_manifolds(sgo_world* w, uint32_t first, uint32_t n, const sgo_manifold* mans, const unsigned char* hit, const unsigned char* reused, sgo_manifold* out, uint32_t* nm_io)
+{
+	uint32_t nm = *nm_io;
+	for (uint32_t q = 0; q < n; ++q) {
+		const uint32_t p = first + q;
+		for (int g = 0; g < hit[q]; ++g) {
 			uint32_t a = w->pairs[p].a, b = w->pairs[p].b;
-			sgo_manifold m = mans[3 * p + g];
+			sgo_manifold m = mans[3 * q + g];
 			if (!(v3_len_sq(m.n) > 0.25f)) continue;          /* safety net: a manifold without a direction (or with a NaN one) is dropped, never solved */
 			const int mesh_a = w->bodies[a].shape_type == SGP_SHAPE_MESH, mesh_b = w->bodies[b].shape_type == SGP_SHAPE_MESH;
 			if (mesh_a || mesh_b) {
@@ -1062,12 +1071,38 @@ static void find_contacts(sgo_world* w, float dt)
 			sgo_constraint* c = &w->cons[nm];
 			memset(c, 0, sizeof(*c));
 			c->a = a; c->b = b; c->key = ((uint64_t)a << 32) | b; c->prio = sgp_mix64(c->key);
-			c->np = m.np; c->n = m.n; c->reused = reused[p];
-			mans[nm++] = m;           /* (nm <= 3 p + g: compaction never overtakes the read position) */
+			c->np = m.np; c->n = m.n; c->reused = reused[q];
+			out[nm++] = m;
 		}
 	}
-	free(hit); free(reused);
-	w->n_cons = nm;
+	*nm_io = nm;
+}
+
+static void cons_reserve(sgo_world* w, uint32_t n)
+{
+	if (w->cap_cons < n) { w->cap_cons = n + 1024; w->cons = (sgo_constraint*)realloc(w->cons, sizeof(sgo_constraint) * w->cap_cons); }
+}
+
+static int g_in_step_activation = 1;      /* test switch: 0 = a woken body meets its other contacts one step later (what rounds 1-3 did) */
+SGO_API int sgo_set_in_step_activation(int on) { const int old = g_in_step_activation; g_in_step_activation = on ? 1 : 0; return old; }
+
+static void find_contacts(sgo_world* w, float dt)
+{
+	w->n_cons = 0;
+	/* pass 1: manifolds + activation of sleeping bodies touched by an active one.  A pair with a mesh body yields up to three
+	   manifolds (groups of triangle contacts with similar normals), carried by the mesh body and its two alias slots. */
+	const uint32_t n0 = w->n_pairs;
+	cons_reserve(w, 3 * n0 + 1);
+	sgo_manifold* mans = (sgo_manifold*)malloc(sizeof(sgo_manifold) * (n0 ? 3 * n0 : 1));
+	uint32_t nm = 0;
+	{
+		sgo_manifold* raw = (sgo_manifold*)malloc(sizeof(sgo_manifold) * (n0 ? 3 * n0 : 1));
+		unsigned char* hit = (unsigned char*)malloc(n0 ? n0 : 1);
+		unsigned char* reused = (unsigned char*)calloc(n0 ? n0 : 1, 1);
+		collide_pairs(w, 0, n0, dt, raw, hit, reused);
+		append_manifolds(w, 0, n0, raw, hit, reused, mans, &nm);
+		free(raw); free(hit); free(reused);
+	}
 	for (uint32_t k = 0; k < nm; ++k) {
 		sgo_body* A = &w->bodies[w->cons[k].a]; sgo_body* B = &w->bodies[w->cons[k].b];
 		if (A->is_sensor || B->is_sensor) continue;
@@ -1075,6 +1110,72 @@ static void find_contacts(sgo_world* w, float dt)
 		if (actA && !actB && B->motion == SGP_MOTION_DYNAMIC) B->can_sleep = -1;   /* mark for wake-up */
 		if (actB && !actA && A->motion == SGP_MOTION_DYNAMIC) A->can_sleep = -1;
 	}
+	/* In-step activation (PhysicsSystem::JobFindCollisions keeps taking bodies from the active list while ProcessBodyPair appends the ones it wakes,
+	   so a woken body collides in the step that woke it and wakes what it touches in turn).  Here in one extra round: the bodies marked so far
+	   (by a contact above or by a wheel, vehicles_pre_step) take along everything that fell asleep in the same island (sleep_label: sleeping
+	   bodies have not moved, so the contacts that made the island are the contacts the cascade would follow), and every woken body is paired
+	   with all that was not awake when the step began -- the pairs with awake bodies exist already.  What THOSE contacts wake in turn (two
+	   islands that went to sleep apart and touch) is woken too, but meets its other contacts in the next step. */
+	if (g_in_step_activation) {
+		unsigned char* lab = NULL; uint32_t n_woken = 0;
+		for (uint32_t i = 0; i < w->high; ++i) {
+			const sgo_body* b = &w->bodies[i];
+			if (!b->alive || b->can_sleep != -1) continue;
+			if (!lab) lab = (unsigned char*)calloc(w->cap ? w->cap : 1, 1);
+			if (b->sleep_label < w->cap) lab[b->sleep_label] = 1;
+		}
+		if (lab) {
+			for (uint32_t i = 0; i < w->high; ++i) {
+				sgo_body* b = &w->bodies[i];
+				if (!b->alive || b->is_alias || b->motion != SGP_MOTION_DYNAMIC || b->active) continue;
+				if (b->sleep_label < w->cap && lab[b->sleep_label]) b->can_sleep = -1;
+				if (b->can_sleep == -1) ++n_woken;
+			}
+			free(lab);
+		}
+		if (n_woken) {
+			const float large_r = w->desc.large_body_radius;
+			const keyidx* ki = w->bp_ki; const uint32_t n_small = w->bp_n_small; const float cell = w->bp_cell;
+			#define WOKEN_CANDIDATE(i_, j_) do { \
+				const uint32_t jj_ = (j_); const sgo_body* o_ = &w->bodies[jj_]; \
+				if (jj_ != (i_) && o_->alive && !o_->is_alias && !body_is_active_for_pairs(o_) && !(o_->can_sleep == -1 && jj_ < (i_)) && pair_passes_geom(w, (i_), jj_)) push_pair(w, (i_), jj_); \
+			} while (0)
+			for (uint32_t i = 0; i < w->high; ++i) {
+				const sgo_body* b = &w->bodies[i];
+				if (!b->alive || b->can_sleep != -1) continue;
+				if (body_bounding_radius(b) > large_r) { for (uint32_t j = 0; j < w->high; ++j) WOKEN_CANDIDATE(i, j); continue; }
+				const v3 c = v3_scale(v3_add(b->aabb_min, b->aabb_max), 0.5f);
+				const int64_t cx = (int64_t)floorf(c.x / cell), cy = (int64_t)floorf(c.y / cell), cz = (int64_t)floorf(c.z / cell);
+				for (int64_t dz = -1; dz <= 1; ++dz) for (int64_t dy = -1; dy <= 1; ++dy) for (int64_t dx = -1; dx <= 1; ++dx) {
+					const uint64_t key = cell_key(cx + dx, cy + dy, cz + dz);
+					for (uint32_t q = lower_bound_key(ki, n_small, key); q < n_small && ki[q].key == key; ++q) WOKEN_CANDIDATE(i, ki[q].idx);
+				}
+				for (uint32_t l = 0; l < w->n_large; ++l) WOKEN_CANDIDATE(i, w->large[l]);
+			}
+			#undef WOKEN_CANDIDATE
+			const uint32_t n1 = w->n_pairs - n0;
+			if (n1) {
+				cons_reserve(w, nm + 3 * n1 + 1);
+				mans = (sgo_manifold*)realloc(mans, sizeof(sgo_manifold) * (nm + 3 * n1 + 1));
+				sgo_manifold* raw = (sgo_manifold*)malloc(sizeof(sgo_manifold) * 3 * n1);
+				unsigned char* hit = (unsigned char*)malloc(n1);
+				unsigned char* reused = (unsigned char*)calloc(n1, 1);
+				collide_pairs(w, n0, n1, dt, raw, hit, reused);
+				const uint32_t nm0 = nm;
+				append_manifolds(w, n0, n1, raw, hit, reused, mans, &nm);
+				free(raw); free(hit); free(reused);
+				/* neither body of such a pair was awake when the step began: a contact wakes whichever of the two is dynamic */
+				for (uint32_t k = nm0; k < nm; ++k) {
+					sgo_body* A = &w->bodies[w->cons[k].a]; sgo_body* B = &w->bodies[w->cons[k].b];
+					if (A->is_sensor || B->is_sensor) continue;
+					if (A->motion == SGP_MOTION_DYNAMIC && !A->active) A->can_sleep = -1;
+					if (B->motion == SGP_MOTION_DYNAMIC && !B->active) B->can_sleep = -1;
+				}
+			}
+		}
+	}
+	w->n_cons = nm;
+	w->stats.num_wake_pairs = w->n_pairs - n0;
 	for (uint32_t i = 0; i < w->high; ++i) if (w->bodies[i].alive && w->bodies[i].can_sleep == -1) { w->bodies[i].can_sleep = 0; body_activate(w, i); }
 
 	/* pass 2: constraint properties (independent per constraint: parallel unless contact events must be emitted in order) */
@@ -1296,6 +1397,8 @@ static void solve_position_constraint(sgo_world* w, sgo_constraint* c)
 /* ------------------------------------------------------------------------------------------------ */
 /* islands (union-find, root = smallest body id) and sleeping (Body::UpdateSleepStateInternal)        */
 
+/* the priority the device's union-find hooks by (a bijection of the id: no ties) */
+static uint32_t uf_prio(uint32_t x) { uint32_t h = x * 0x9E3779B1u; h ^= h >> 15; h *= 0x85EBCA6Bu; h ^= h >> 13; return h; }
 static uint32_t uf_find(sgo_world* w, uint32_t x)
 {
 	while ((uint32_t)w->bodies[x].island != x) { w->bodies[x].island = w->bodies[w->bodies[x].island].island; x = (uint32_t)w->bodies[x].island; }
@@ -1360,14 +1463,28 @@ static void update_sleeping(sgo_world* w, float dt)
 		if (!b->alive || !body_movable(b)) continue;
 		if (!b->can_sleep) w->bodies[uf_find(w, i)].colour_mask = 0;
 	}
+	/* an island that goes to sleep is remembered by its members (sleep_label = the member the device's union-find ends with as the root: the one
+	   with the lowest uf_prio): what wakes one of them later wakes all of them in that step (find_contacts) */
+	uint32_t* best = NULL;
+	for (uint32_t i = 0; i < w->high; ++i) {
+		const sgo_body* b = &w->bodies[i];
+		if (!b->alive || !body_movable(b)) continue;
+		const uint32_t r = uf_find(w, i);
+		if (!w->bodies[r].colour_mask) continue;
+		if (!best) { best = (uint32_t*)malloc(sizeof(uint32_t) * w->high); for (uint32_t k = 0; k < w->high; ++k) best[k] = SGP_INVALID_ID; }
+		if (best[r] == SGP_INVALID_ID || uf_prio(i) < uf_prio(best[r])) best[r] = i;
+	}
 	for (uint32_t i = 0; i < w->high; ++i) {
 		sgo_body* b = &w->bodies[i];
 		if (!b->alive || !body_movable(b)) continue;
-		if (w->bodies[uf_find(w, i)].colour_mask) {
+		const uint32_t r = uf_find(w, i);
+		if (w->bodies[r].colour_mask) {
 			b->active = 0; b->linv = V3(0, 0, 0); b->angv = V3(0, 0, 0);
+			b->sleep_label = best[r];
 			push_body_event(w, SGP_EVENT_DEACTIVATED, i);
 		}
 	}
+	free(best);
 	/* kinematic bodies stay active while they move */
 	for (uint32_t i = 0; i < w->high; ++i) {
 		sgo_body* b = &w->bodies[i];

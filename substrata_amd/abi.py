@@ -87,7 +87,7 @@ class StepStats(C.Structure):
                 ("num_overflow_constraints", u32), ("pairs_dropped", u32), ("manifolds_dropped", u32),
                 ("num_activated", u32), ("num_deactivated", u32), ("layer_counts", u32 * NUM_LAYERS),
                 ("num_cached_manifolds", u32), ("num_component_constraints", u32), ("num_catch_all_constraints", u32),
-                ("num_deferred_vehicles", u32), ("reserved0", u32), ("tile_solver", u32), ("device_bytes", u64)]
+                ("num_deferred_vehicles", u32), ("num_wake_pairs", u32), ("tile_solver", u32), ("device_bytes", u64)]
 
 
 NUM_KERNEL_CLASSES = 32

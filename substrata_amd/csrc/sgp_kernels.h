@@ -103,6 +103,8 @@ struct StepCounters {
 	uint32_t n_tiles_used;       // occupied tiles of this step's grid (slots handed out by k_bp_cell)
 	uint32_t veh_deferred;       // vehicles that share a movable body (a dynamic body under a wheel, a chassis a wheel stands on) with a vehicle of lower index: solved after the others, in index order
 	uint32_t veh_done;           // workgroups of the running vehicle-row launch that have finished (the last one solves the deferred vehicles and clears it)
+	// in-step activation (k_wake_pairs): the pairs of the bodies this step wakes, and where the second narrow-phase round starts in the hull / mesh lists
+	uint32_t n_wake_pairs, n_woken, hull_base, mesh_base, mesh_big_base;
 	uint32_t tickets[4];         // last_block(): workgroups of k_colour_count / k_warm_bodies / k_cache_build that have finished
 	uint32_t ts_error;           // tile solver: a tile gave up waiting for a neighbour (k_step_end copies ts_flags[0])
 	uint32_t ts_all_adjacent;    // tile solver: some body was touched by more than four tiles
@@ -213,6 +215,9 @@ struct DV {
 	float4* aabb_max;
 	float4* sleep_s[3];        // sleep test spheres: centre xyz, radius w
 	float*  sleep_timer;
+	uint32_t* sleep_label;     // the island a body fell asleep with (the root its union-find ended with; its own id from creation): bodies that share it wake together
+	uint32_t* label_wake;      // [label] = the step epoch (*veh_epoch) in which a body with that label was woken
+	uint2*  wake_pairs; uint32_t cap_wake_pairs;      // pairs of the woken bodies with what was not awake when the step began
 	float*  submerged;
 	uint64_t* userdata;        // mUserData of the body (the caller's PhysicsObject*): travels with the body when its ownership migrates to another tile
 	uint64_t* colour_mask;
@@ -323,6 +328,8 @@ void launch_bp_pairs(const DV& d, int small_lds, hipStream_t s);      // small_l
 void launch_bp_large(const DV& d, uint32_t nb, hipStream_t s);
 void launch_bp_scatter_large(const DV& d, uint32_t nb, hipStream_t s);      // both in one launch (the step's path)
 void launch_narrowphase(const DV& d, uint32_t n_pairs_upper, hipStream_t s);
+void launch_cache_wipe(const DV& d, hipStream_t s);
+void launch_wake_round(const DV& d, uint32_t nb, bool has_hulls, bool has_meshes, hipStream_t s);      // in-step activation: k_wake_pairs + the narrow phase of its pairs
 void launch_narrowphase_hull(const DV& d, hipStream_t s);     // only worlds with hull shapes
 void launch_narrowphase_mesh(const DV& d, hipStream_t s);     // only worlds with mesh shapes
 void launch_colour_inherit(const DV& d, uint32_t n_man, hipStream_t s);

@@ -808,6 +808,14 @@ SGP_DEV uint32_t wave_alloc(uint32_t* counter)
 // safety net: a manifold without a direction (or with a NaN one) is dropped, never solved
 SGP_DEV bool manifold_ok(const sgd_manifold& m) { return v3_len_sq(m.n) > 0.25f; }
 
+// A sleeping dynamic body is touched by an awake one (or stands under a wheel): k_pre_solve wakes it, and k_wake_pairs wakes, in the same step, everything
+// that fell asleep in the same island (the label's mark carries this step's epoch)
+SGP_DEV void wake_body(const DV& d, uint32_t id)
+{
+	atomicOr(&d.flags[id], BF_WAKE);
+	d.label_wake[d.sleep_label[id]] = *d.veh_epoch;
+}
+
 // the manifold goes to slot `slot` of the step's manifold list (the caller allocated it)
 SGP_DEV void emit_manifold_at(const DV& d, uint32_t slot, uint2 ab, uint32_t fa, uint32_t fb, const sgd_manifold& m, uint32_t prev)
 {
@@ -823,8 +831,10 @@ SGP_DEV void emit_manifold_at(const DV& d, uint32_t slot, uint2 ab, uint32_t fa,
 	d.man_colour[slot] = -1;
 	if (!sensor) {
 		const bool actA = f_active_for_pairs(fa), actB = f_active_for_pairs(fb);
-		if (actA && !actB && f_motion(fb) == SGP_MOTION_DYNAMIC) atomicOr(&d.flags[ab.y], BF_WAKE);
-		if (actB && !actA && f_motion(fa) == SGP_MOTION_DYNAMIC) atomicOr(&d.flags[ab.x], BF_WAKE);
+		// (a pair's other body is awake -- or, in the in-step activation round, neither was when the step began: one of the two has just been woken and the
+		// contact wakes the other.  The broad phase makes no pair of two bodies that stay asleep, so "not awake and dynamic" says it all.)
+		if (!actB && f_motion(fb) == SGP_MOTION_DYNAMIC) wake_body(d, ab.y);
+		if (!actA && f_motion(fa) == SGP_MOTION_DYNAMIC) wake_body(d, ab.x);
 	}
 }
 // ... with the slot taken here: one atomic per wave (the kernels with few manifolds per wave: hulls, meshes)
@@ -873,11 +883,13 @@ SGP_DEV bool reuse_cached_manifold(const DV& d, uint2 ab, uint32_t fa, uint32_t 
 // workgroup therefore allocates the slots of all its manifolds of an iteration with ONE atomic.
 // (at least four waves per SIMD: the kernel waits for its gathers three cycles in four, and 128 instead of 157 registers per lane -- a few spills to
 // scratch -- buy a third more waves to wait with: 138 -> 116 us at config 3; five waves: 143 us, six: 178 us)
-__global__ void __launch_bounds__(TPB, 4) k_narrowphase(DV d)
+// ROUND 0: the broad phase's pairs; ROUND 1: the pairs of the bodies this step wakes (k_wake_pairs)
+template <int ROUND> SGP_DEV void narrowphase_pairs(const DV& d)
 {
 	__shared__ uint32_t s_wave_cnt[TPB / 64];
 	__shared__ uint32_t s_base;
-	const uint32_t n = min(d.ctr->n_pairs, d.cap_pairs);
+	const uint32_t n = ROUND ? min(d.ctr->n_wake_pairs, d.cap_wake_pairs) : min(d.ctr->n_pairs, d.cap_pairs);
+	const uint2* const pairs = ROUND ? d.wake_pairs : d.pairs;
 	const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
 	for (uint32_t p0 = blockIdx.x * TPB; p0 < n; p0 += gridDim.x * TPB) {
 		const uint32_t p = p0 + threadIdx.x;
@@ -886,7 +898,7 @@ __global__ void __launch_bounds__(TPB, 4) k_narrowphase(DV d)
 		sgd_manifold m;
 		uint32_t prev = MAN_PREV_LOOKUP;
 		if (p < n) {
-			ab = d.pairs[p];
+			ab = pairs[p];
 			fa = d.flags[ab.x]; fb = d.flags[ab.y];
 			if (f_shape(fa) == SGP_SHAPE_MESH || f_shape(fb) == SGP_SHAPE_MESH) {
 				const uint32_t k = wave_alloc(&d.ctr->n_mesh_pairs);
@@ -924,6 +936,55 @@ __global__ void __launch_bounds__(TPB, 4) k_narrowphase(DV d)
 			emit_manifold_at(d, slot, ab, fa, fb, m, prev);
 		}
 		__syncthreads();
+	}
+}
+__global__ void __launch_bounds__(TPB, 4) k_narrowphase(DV d) { narrowphase_pairs<0>(d); }
+__global__ void __launch_bounds__(TPB, 4) k_narrowphase_wake(DV d) { narrowphase_pairs<1>(d); }
+
+// IN-STEP ACTIVATION (PhysicsSystem::JobFindCollisions keeps taking bodies from the active list while ProcessBodyPair appends the ones it wakes: a woken
+// body collides in the step that woke it, and wakes what it touches in turn).  One extra round: a body the narrow phase or a wheel marked takes along
+// everything that fell asleep in the same island (sleep_label / label_wake: sleeping bodies have not moved, so the contacts that made the island are the
+// ones the cascade would follow), and every woken body is paired here with all that was not awake when the step began -- its pairs with awake
+// bodies exist already.  The narrow-phase kernels then run once more over these pairs (the hull and mesh kernels from hull_base / mesh_base on).
+// What those contacts wake in turn -- two islands that went to sleep apart and touch -- is woken too but meets its other contacts next step.
+SGP_DEV bool body_woken(const DV& d, uint32_t j, uint32_t fj, uint32_t epoch)
+{
+	return (fj & (BF_ALIVE | BF_ACTIVE | BF_ALIAS)) == BF_ALIVE && f_motion(fj) == SGP_MOTION_DYNAMIC && d.label_wake[d.sleep_label[j]] == epoch;
+}
+__global__ void __launch_bounds__(TPB) k_wake_pairs(DV d)
+{
+	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+	if (i == 0) {
+		d.ctr->hull_base = min(d.ctr->n_hull_pairs, d.cap_hull_pairs);
+		d.ctr->mesh_base = min(d.ctr->n_mesh_pairs, d.cap_mesh_pairs);
+		d.ctr->mesh_big_base = min(d.ctr->n_mesh_big, d.cap_mesh_pairs);
+	}
+	if (i >= d.sp->n_slots) return;
+	const uint32_t fi = d.flags[i], epoch = *d.veh_epoch;
+	if (!body_woken(d, i, fi, epoch)) return;
+	if (!(fi & BF_WAKE)) d.flags[i] = fi | BF_WAKE;      // (nobody else writes this word during this launch; the bits others read of it do not change)
+	atomicAdd(&d.ctr->n_woken, 1u);
+	const float4 mni = d.aabb_min[i], mxi = d.aabb_max[i];
+	auto candidate = [&](uint32_t j) {
+		if (j == i) return;
+		const uint32_t fj = d.flags[j];
+		if (!(fj & BF_ALIVE) || (fj & BF_ALIAS) || f_active_for_pairs(fj)) return;
+		if (j < i && body_woken(d, j, fj, epoch)) return;           // two woken bodies: the lower id makes the pair
+		if (!pair_passes(d, fi, mni, mxi, j)) return;
+		const uint32_t k = wave_alloc(&d.ctr->n_wake_pairs);
+		if (k < d.cap_wake_pairs) d.wake_pairs[k] = make_uint2(i < j ? i : j, i < j ? j : i); else atomicAdd(&d.ctr->pairs_dropped, 1u);
+	};
+	const float sp = d.st.speculative_contact_distance;
+	for (uint32_t l = 0; l < d.sp->n_large; ++l) candidate(d.large_ids[l]);
+	large_grid_query(d, V3(mni.x - sp, mni.y - sp, mni.z - sp), V3(mxi.x + sp, mxi.y + sp, mxi.z + sp), candidate);
+	const BpGrid g = *d.grid;
+	if (g.n_cells > 0 && g.min_x <= g.max_x) {
+		// (small bodies are binned by their centres into cells no smaller than the largest of them plus the margin: one cell of slack around the bounds)
+		const int x0 = max((int)floorf((mni.x - g.ox) * g.inv_cell) - 1, 0), x1 = min((int)floorf((mxi.x - g.ox) * g.inv_cell) + 1, g.nx - 1);
+		const int y0 = max((int)floorf((mni.y - g.oy) * g.inv_cell) - 1, 0), y1 = min((int)floorf((mxi.y - g.oy) * g.inv_cell) + 1, g.ny - 1);
+		const int z0 = max((int)floorf((mni.z - g.oz) * g.inv_cell) - 1, 0), z1 = min((int)floorf((mxi.z - g.oz) * g.inv_cell) + 1, g.nz - 1);
+		if (x0 <= x1) for (int z = z0; z <= z1; ++z) for (int y = y0; y <= y1; ++y)
+			grid_row_runs(d, g, x0, x1, y, z, [&](uint32_t q0, uint32_t q1) { for (uint32_t q = q0; q < q1; ++q) candidate(__float_as_uint(d.sorted_max[q].w)); });
 	}
 }
 
@@ -1145,7 +1206,8 @@ template <int MESH_GROUP> __global__ void __launch_bounds__(64) k_narrowphase_me
 	MeshPairLds<MESH_GROUP>& L = lds[grp];
 	const uint32_t n = MESH_GROUP == 64 ? min(d.ctr->n_mesh_big, d.cap_mesh_pairs) : min(d.ctr->n_mesh_pairs, d.cap_mesh_pairs);
 	const float max_sep = d.st.speculative_contact_distance;
-	for (uint32_t p0 = blockIdx.x * MESH_PAIRS_PER_WAVE; p0 < n; p0 += gridDim.x * MESH_PAIRS_PER_WAVE) {
+	const uint32_t base = MESH_GROUP == 64 ? d.ctr->mesh_big_base : d.ctr->mesh_base;      // (0, or where the in-step activation round's pairs begin)
+	for (uint32_t p0 = base + blockIdx.x * MESH_PAIRS_PER_WAVE; p0 < n; p0 += gridDim.x * MESH_PAIRS_PER_WAVE) {
 		const uint32_t p = p0 + (uint32_t)grp;
 		bool valid = p < n;
 		uint32_t mid = 0, xid = 0, fx = 0, pair = 0;
@@ -1250,7 +1312,7 @@ struct HullWork { uint2 ab; sgd_hull_sat r; uint32_t round_other; };
 __global__ void __launch_bounds__(64, 3) k_narrowphase_hull(DV d)
 {
 	const uint32_t n = min(d.ctr->n_hull_pairs, d.cap_hull_pairs);
-	for (uint32_t p = blockIdx.x; p < n; p += gridDim.x) {
+	for (uint32_t p = d.ctr->hull_base + blockIdx.x; p < n; p += gridDim.x) {      // (hull_base: 0, or where the in-step activation round's pairs begin)
 		const uint2 ab = d.hull_pairs[p];
 		const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
 		const sgd_shape sa = load_shape(d, ab.x, fa), sb = load_shape(d, ab.y, fb);
@@ -1274,7 +1336,7 @@ __global__ void __launch_bounds__(64, 3) k_narrowphase_hull(DV d)
 __global__ void __launch_bounds__(64, 3) k_narrowphase_hull_manifold(DV d)
 {
 	const uint32_t n = min(d.ctr->n_hull_pairs, d.cap_hull_pairs);
-	for (uint32_t k = blockIdx.x * 64 + threadIdx.x; k < n; k += gridDim.x * 64) {
+	for (uint32_t k = d.ctr->hull_base + blockIdx.x * 64 + threadIdx.x; k < n; k += gridDim.x * 64) {
 		const HullWork wk = d.hull_work[k];
 		if (wk.round_other == 2u) continue;            // separated: nothing to do
 		const uint2 ab = wk.ab;
@@ -3050,9 +3112,11 @@ SGP_DEV void sleep_apply_one(const DV& d, uint32_t i, bool& active)
 	uint32_t f = d.flags[i];
 	if (!(f & BF_ALIVE)) return;
 	if (f_movable(f)) {
-		if ((f & BF_CAN_SLEEP) && !d.awake_mark[i] && d.island_awake[uf_find(d.island, i)] == 0) {
+		uint32_t root = i;
+		if ((f & BF_CAN_SLEEP) && !d.awake_mark[i] && d.island_awake[root = uf_find(d.island, i)] == 0) {
 			f &= ~(BF_ACTIVE | BF_CAN_SLEEP);
 			d.flags[i] = f;
+			d.sleep_label[i] = root;        // the island goes to sleep as a whole and is remembered by its root: what wakes a member wakes them all (k_wake_pairs)
 			// (the record of a body that is not awake reads (0, 0, 0 | effective inverse mass 0): k_pre_solve then has nothing to write for it)
 			d.vel[2 * (size_t)i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 			d.vel[2 * (size_t)i + 1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -3401,6 +3465,7 @@ __global__ void __launch_bounds__(TPB) k_apply_cmds(DV d, const BodyCmd* cmds, c
 			d.prop[2 * (size_t)i + 1] = make_float4(c.shape[0], c.shape[1], c.shape[2], c.friction);
 			d.submerged[i] = 0.0f;
 			d.userdata[i] = c.userdata;
+			d.sleep_label[i] = i;
 			refresh_aabb(d, i, f);
 			reset_sleep(d, i, f_shape(f), d.prop[2 * (size_t)i + 1], V3(d.pose[2 * (size_t)i]), Q4(d.pose[2 * (size_t)i + 1]));
 			continue;
@@ -3908,7 +3973,7 @@ __global__ void __launch_bounds__(64) k_vehicle_cast(DV d)
 				// the rows act on a dynamic body under the wheel (VehicleConstraint::SetupVelocityConstraint, body 2): it wakes up if it sleeps
 				// (VehicleConstraint::BuildIslands; k_pre_solve does it, like for a body an active one touches) and this vehicle claims it
 				sv.wheels[wi].ground_dynamic = 1;
-				if (!(fo & BF_ACTIVE)) atomicOr(&d.flags[bid], BF_WAKE);
+				if (!(fo & BF_ACTIVE)) wake_body(d, bid);
 				atomicMax((unsigned long long*)&d.veh_claim[bid], ((unsigned long long)*d.veh_epoch << 32) | (unsigned long long)(0xFFFFFFFFu - k));
 			}
 		}
@@ -4771,6 +4836,19 @@ void launch_narrowphase(const DV& d, uint32_t est, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_narrowphase, dim3(stride_grid(est)), dim3(TPB), 0, s, d);
 }
+void launch_wake_round(const DV& d, uint32_t nb, bool has_hulls, bool has_meshes, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_wake_pairs, dim3(blocks_for(nb)), dim3(TPB), 0, s, d);
+	hipLaunchKernelGGL(k_narrowphase_wake, dim3(256), dim3(TPB), 0, s, d);
+	if (has_hulls) {
+		hipLaunchKernelGGL(k_narrowphase_hull, dim3(1024), dim3(64), 0, s, d);
+		hipLaunchKernelGGL(k_narrowphase_hull_manifold, dim3(256), dim3(64), 0, s, d);
+	}
+	if (has_meshes) {
+		hipLaunchKernelGGL(k_narrowphase_mesh<8>, dim3(512), dim3(64), 0, s, d);
+		hipLaunchKernelGGL(k_narrowphase_mesh<64>, dim3(512), dim3(64), 0, s, d);
+	}
+}
 void launch_narrowphase_hull(const DV& d, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_narrowphase_hull, dim3(4096), dim3(64), 0, s, d);
@@ -4884,6 +4962,8 @@ void launch_cache_build(const DV& d, uint32_t n_con, StepCounters* host_mapped, 
 	hipLaunchKernelGGL(k_cache_clear, dim3(std::max(64u, std::min(1024u, n_con / 256u))), dim3(TPB), 0, s, d);
 	hipLaunchKernelGGL(k_cache_build, dim3(stride_grid(n_con)), dim3(TPB), 0, s, d, host_mapped, host_events);
 }
+// forget the previous step's contacts (the world has gone to sleep as a whole: the CPU statement's steps without an awake body leave no constraints behind either)
+void launch_cache_wipe(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_cache_clear, dim3(64), dim3(TPB), 0, s, d); }
 void launch_contact_events(const DV& d, uint32_t est, hipStream_t s) { hipLaunchKernelGGL(k_contact_events, dim3(stride_grid(est)), dim3(TPB), 0, s, d); }
 void launch_ghost_refresh(const DV& d, const GhostRefresh* recs, uint32_t n, hipStream_t s) { if (n) hipLaunchKernelGGL(k_ghost_refresh, dim3(blocks_for(n)), dim3(TPB), 0, s, d, recs, n); }
 void launch_apply_cmds(const DV& d, const BodyCmd* cmds, const uint32_t* run_start, uint32_t n_runs, hipStream_t s) { if (n_runs) hipLaunchKernelGGL(k_apply_cmds, dim3(blocks_for(n_runs)), dim3(TPB), 0, s, d, cmds, run_start, n_runs); }

@@ -99,6 +99,7 @@ struct sgp_world {
 	void* stage_host = nullptr; size_t stage_host_bytes = 0;
 	void* view_host = nullptr; size_t view_host_bytes = 0;       // pinned buffer of sgp_world_read_active[_poses]_view only
 	StepCounters* h_ctr = nullptr; StepCounters* h_ctr_dev = nullptr; EventCounters* h_evc = nullptr; EventCounters* h_evc_dev = nullptr;
+	bool cache_wiped = false;                                  // the contact cache was emptied by an idle step (step_impl)
 	bool dirty_since_step = true;                              // an edit was flushed since the last step (or no step yet)
 	bool events_on_device = true;                              // the device event lists may hold something the host vectors do not (a step without read-back, applied edits)
 	StepParams sp_uploaded; bool sp_uploaded_valid = false;    // what d_sp holds (upload_sp skips the launch when nothing changed)
@@ -106,7 +107,7 @@ struct sgp_world {
 	StepParams* h_sp = nullptr; StepParams* d_sp = nullptr;      // pinned host copy / device copy of the per-step scalars
 	std::map<std::string, hipGraphExec_t> graphs;              // replayable launch sequences keyed by launch plan
 	std::string last_plan_key[2]; uint32_t plan_repeats[2] = { 0, 0 };   // per buffer parity: StepParams (by value in the first launch) flips parity every step
-	bool use_graphs = true; bool use_small_world = true; uint32_t tail_threshold = 256;
+	bool use_graphs = true; bool use_small_world = true; bool use_wake_round = true; uint32_t tail_threshold = 256;
 	uint32_t rows_mode_large = 2;          // SGP_ROWS_MODE: the layout worlds of at least compact_rows_min constraints use -- 2 no rows (the lanes rebuild them from the lever arms), 1 compact rows (r x axis only)
 	uint32_t compact_rows_min = 1000000;   // SGP_COMPACT_ROWS_MIN: from this many contact constraints on, the velocity rows are stored compact (96 B per point)
 	int use_tile_solver = 0;            // SGP_TILE_SOLVER: 0 off, 1 on where the plan finds it applicable (k_ts_solve)
@@ -338,6 +339,9 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	DEV_ALLOC(d.sorted_min, N); DEV_ALLOC(d.sorted_max, N); DEV_ALLOC(d.grid, 1); DEV_ALLOC(d.grid_cells_used, 1);
 	DEV_ALLOC(d.bounds_acc, 8); { const int init[8] = { 0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000, (int)0x80000000, 0, 0 }; if (hipMemcpyAsync(d.bounds_acc, init, sizeof(init), hipMemcpyHostToDevice, w->stream) != hipSuccess || hipStreamSynchronize(w->stream) != hipSuccess) return fail(SGP_ERR_HIP, "bounds_acc init"); } DEV_ALLOC(d.scan_block_sums, (d.table_size + 1) / 1024 + 2);
 	DEV_ALLOC(d.pairs, P);
+	d.cap_wake_pairs = P / 4 + 1024; DEV_ALLOC(d.wake_pairs, d.cap_wake_pairs);
+	DEV_ALLOC(d.sleep_label, N); DEV_ALLOC(d.label_wake, N);
+	HIP_TRY(hipMemsetAsync(d.label_wake, 0, sizeof(uint32_t) * N, w->stream));
 	DEV_ALLOC(d.man_ab, M); DEV_ALLOC(d.man_n, M); DEV_ALLOC(d.man_colour, M); DEV_ALLOC(d.man_prio, M); DEV_ALLOC(d.man_prev, M); DEV_ALLOC(d.man_slot, M);
 	DEV_ALLOC(d.hc_root, N); DEV_ALLOC(d.hc_count, N); DEV_ALLOC(d.hc_base, N); DEV_ALLOC(d.hc_rank, M);
 	// tile solver: one workgroup per compute unit must be resident, so the tile grid follows the device (256 CUs: 16 x 16)
@@ -381,6 +385,7 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	d.sp = w->d_sp;
 	{ const char* e = getenv("SGP_NO_GRAPH"); if (e && e[0] == '1') w->use_graphs = false; }
 	{ const char* e = getenv("SGP_NO_SMALL_WORLD"); if (e && e[0] == '1') w->use_small_world = false; }
+	{ const char* e = getenv("SGP_NO_WAKE_ROUND"); if (e && e[0] == '1') w->use_wake_round = false; }      // (measurements only: the CPU statement has its own switch)
 	{ const char* e = getenv("SGP_DEBUG_FLAGS"); w->dv.dbg_flags = e ? (uint32_t)atoi(e) : 0u; }
 #ifdef SGP_EXPERIMENTS
 	{ const char* e = getenv("SGP_TILE_SOLVER"); if (e) w->use_tile_solver = atoi(e); }
@@ -1139,6 +1144,7 @@ struct StepPlan {
 	uint32_t n_vehicles;
 	int      has_meshes;         // some body may be a static triangle mesh: run the mesh-pair narrow phase
 	int      has_hulls;          // some body may be a convex hull: run the hull-pair narrow phase
+	int      wake_round;         // in-step activation: pair and collide the bodies this step wakes (k_wake_pairs + a second narrow-phase round)
 	int      small_colouring;    // the whole colouring in one single-workgroup launch (k_colour_finish builds its own worklist)
 	int      small_world;        // warm start + velocity iterations as ONE single-workgroup launch (k_solve_small)
 	int      bp_small;           // k_bp_pairs instance with the small LDS footprint (the previous step met no dense halo)
@@ -1179,6 +1185,7 @@ static void make_plan(const sgp_world* w, StepPlan& p)
 	p.n_vehicles = w->n_vehicles;
 	p.has_hulls = w->hulls.size() > 1 ? 1 : 0;
 	p.has_meshes = w->meshes.size() > 1 ? 1 : 0;
+	p.wake_round = w->use_wake_round ? 1 : 0;
 	p.small_colouring = (w->last_manifolds <= SGP_SMALL_COLOURING_MANIFOLDS && w->high <= SGP_SMALL_WORLD_BODIES) ? 1 : 0;
 	p.small_world = (tf == 0 && w->high <= SGP_SMALL_WORLD_BODIES && w->n_vehicles == 0 && w->use_small_world) ? 1 : 0;
 	p.small_pairs = (w->n_con <= 384u || w->n_con > 512u) ? 1 : 0;
@@ -1241,6 +1248,8 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 	STAGE_MARK(2);
 	// -- 3. narrow phase, wake-ups, per-body solver records (+ contact events, which see the velocities before the solve)
 	{ KScope k(w, KC_NARROWPHASE); launch_narrowphase(d, p.est_pairs, s); if (p.has_hulls) launch_narrowphase_hull(d, s); if (p.has_meshes) launch_narrowphase_mesh(d, s); }
+	// in-step activation: what the contacts above (or a wheel) woke takes its sleeping island along and collides in this step
+	if (p.wake_round) { KScope k(w, KC_NARROWPHASE); launch_wake_round(d, nb, p.has_hulls, p.has_meshes, s); }
 	{ KScope k(w, KC_APPLY_FORCES); launch_pre_solve(d, nb, s); }      // sweep 1/3: wake-ups, forces, per-step solver records
 	STAGE_MARK(3);
 	// -- 4. colouring + constraint setup (k_colour_inherit also resolves every manifold's slot in the previous step's constraints, which the
@@ -1332,8 +1341,12 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 		memset(&st, 0, sizeof(st));
 		st.num_bodies = nb_; memcpy(st.layer_counts, lc, sizeof(lc)); st.device_bytes = w->device_bytes;
 		w->idle_steps++;
+		// the first skipped step takes the contact cache with it: a step without an awake body has no contacts, and what wakes up later (in-step
+		// activation pairs bodies that were asleep) must not find the constraints of the last step that had some
+		if (!w->cache_wiped) { launch_cache_wipe(d, w->stream); w->cache_wiped = true; }
 		return SGP_OK;
 	}
+	w->cache_wiped = false;
 	if (w->veh_inputs_dirty && w->n_vehicles) {
 		HIP_TRY(hipMemcpyAsync(w->d_veh_inputs, w->veh_inputs.data(), sizeof(sgp_vehicle_input) * w->n_vehicles, hipMemcpyHostToDevice, w->stream));
 		w->veh_inputs_dirty = false;
@@ -1417,7 +1430,8 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	sgp_step_stats& st = w->stats;
 	memset(&st, 0, sizeof(st));
 	st.num_bodies = w->n_alive;
-	st.num_pairs = std::min(c1.n_pairs, d.cap_pairs);
+	st.num_wake_pairs = std::min(c1.n_wake_pairs, d.cap_wake_pairs);
+	st.num_pairs = std::min(c1.n_pairs, d.cap_pairs) + st.num_wake_pairs;
 	st.num_manifolds = n_con;
 	st.num_contact_points = c1.n_points;
 	st.num_colours = c1.n_colours;

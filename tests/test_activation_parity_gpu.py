@@ -1,0 +1,118 @@
+"""In-step activation on the device against the CPU statement, bit for bit: what a contact (or a wheel) wakes takes its sleeping island along and
+collides in the step that woke it (PhysicsSystem::JobFindCollisions; oracle/sgo_oracle.c find_contacts, k_wake_pairs on the device).
+The analytic side -- what the behaviour must be -- is pinned on the oracle in tests/test_oracle_kat.py."""
+import numpy as np
+import pytest
+
+from substrata_amd import abi, scenes
+from helpers import DT, add_ground, dyn, add_car
+import parity
+from test_mesh_parity_gpu import grid_mesh, mesh_body
+
+pytestmark = pytest.mark.gpu
+
+
+def _exact(tw, n, what):
+    d = parity.compare(tw, n)
+    assert d["active_mismatch"] == 0 and d["bit_exact"], (what, d)
+
+
+def _both(tw, fn):
+    out = [fn(w) for w in (tw.gpu, tw.cpu)]
+    assert out[0] == out[1]
+    return out[0]
+
+
+def test_ball_on_a_sleeping_stack_wakes_all_of_it_at_once(oracle):
+    tw = parity.make_twin(oracle, max_bodies=64)
+    n = 5
+    ids = _both(tw, lambda w: (add_ground(w), [dyn(w, pos=(0.02 * k, 0, 0.5 + 1.0 * k)) for k in range(n)])[1])
+    for s in range(400):
+        tw.step(DT)
+    _exact(tw, n + 1, "settled")
+    assert not any(s["active"] for s in tw.gpu.get_state(ids))
+    ball = _both(tw, lambda w: dyn(w, abi.SHAPE_SPHERE, (0.25,), pos=(0.1, 0.05, n + 2.0), mass=5.0))
+    touched = None
+    for s in range(120):
+        tw.step(DT)
+        sg, sc = tw.gpu.stats(), tw.cpu.stats()
+        assert (sg.num_pairs, sg.num_wake_pairs, sg.num_manifolds) == (sc.num_pairs, sc.num_wake_pairs, sc.num_manifolds), s
+        _exact(tw, n + 2, f"step {s}")
+        if touched is None and tw.gpu.get_state([ids[-1]])[0]["active"]:
+            touched = s
+            assert all(x["active"] for x in tw.gpu.get_state(ids))       # the whole island, in the step of the first touch
+            assert sg.num_wake_pairs >= n and sg.num_manifolds == n + 1          # ball - box, four box - box, box - ground
+    assert touched is not None
+    tw.close()
+
+
+def test_sleeping_pile_on_a_mesh_with_hulls_is_woken_by_a_thrown_box(oracle):
+    """the second narrow-phase round through all three kernels: primitive pairs, hull pairs and (body, mesh) pairs of the woken bodies"""
+    rng = np.random.default_rng(5)
+    tw = parity.make_twin(oracle, max_bodies=512)
+    V, T = grid_mesh(17, 12.0, lambda x, y: 0.05 * np.sin(0.7 * x) * np.cos(0.6 * y))
+    ig, ic = tw.mesh_create(V, T)
+    tw.add_batch(mesh_body(ig))
+    hg, hc = tw.hull_create(rng.normal(size=(14, 3)) * 0.45)
+    n = 60
+    d = scenes.dynamic_bodies(n)
+    d["pos"] = np.column_stack([rng.uniform(-2.0, 2.0, n), rng.uniform(-2.0, 2.0, n), 0.6 + 0.9 * np.arange(n) / 3.0]).astype(np.float32)
+    d["shape_type"] = np.arange(n) % 4
+    d["shape"][:, :3] = (0.35, 0.4, 0.3)
+    hull = d["shape_type"] == abi.SHAPE_HULL
+    d["shape"][hull, 0] = float(hg.hull_id); d["shape"][hull, 1:3] = 0.0
+    d["friction"] = 0.8
+    d["angular_damping"] = 0.6
+    ids_g, ids_c = tw.add_batch(d)
+    assert np.array_equal(ids_g, ids_c)
+    nb = int(ids_g.max()) + 1
+    asleep = False
+    for s in range(1200):
+        tw.step(DT)
+        if s % 50 == 49 and tw.gpu.stats().num_active <= 6:       # (a sphere or two keep rolling in the terrain's hollows)
+            asleep = True
+            break
+    _exact(tw, nb, "settled")
+    assert asleep, "the pile never went to sleep"
+    thrown = _both(tw, lambda w: dyn(w, pos=(-9.0, 0.0, 1.2), mass=200.0))
+    tw.set_vel(thrown, (14.0, 0.0, 1.0), (0, 0, 0))
+    woke_many = 0
+    for s in range(90):
+        tw.step(DT)
+        sg, sc = tw.gpu.stats(), tw.cpu.stats()
+        assert (sg.num_pairs, sg.num_wake_pairs, sg.num_manifolds, sg.num_active) == (sc.num_pairs, sc.num_wake_pairs, sc.num_manifolds, sc.num_active), s
+        assert sg.pairs_dropped == 0 and sg.manifolds_dropped == 0
+        _exact(tw, nb + 1, f"step {s}")
+        woke_many = max(woke_many, sg.num_wake_pairs)
+    assert woke_many > 20, woke_many
+    tw.close()
+
+
+def test_a_wheel_wakes_the_island_under_it(oracle):
+    """a car rolls onto a sleeping plate that carries sleeping boxes: the wheel wakes the plate (VehicleConstraint::BuildIslands), the plate's island follows in the same step"""
+    tw = parity.make_twin(oracle, max_bodies=64)
+    recs = []
+    for w in (tw.gpu, tw.cpu):
+        add_ground(w)
+        plate = dyn(w, shape=(3.0, 6.0, 0.1, 0.0), pos=(0, 4.0, 0.1), mass=4000.0, friction=0.8)
+        boxes = [dyn(w, shape=(0.3, 0.3, 0.3, 0.0), pos=(1.5, 6.0 + 0.8 * k, 0.5), mass=20.0) for k in range(3)]
+        body, vid = add_car(w, pos=(0, -6.0, 0.95))
+        recs.append((plate, boxes, body, vid))
+    assert recs[0] == recs[1]
+    plate, boxes, body, vid = recs[0]
+    nb = body + 1
+    for s in range(500):
+        tw.step(DT)
+    _exact(tw, nb, "asleep")
+    assert tw.gpu.stats().num_active == 0
+    tw.vehicle_set_input(vid, forward=1.0)
+    woke = None
+    for s in range(420):
+        tw.step(DT)
+        _exact(tw, nb, f"step {s}")
+        if woke is None and tw.gpu.get_state([plate])[0]["active"]:
+            woke = s
+            assert all(x["active"] for x in tw.gpu.get_state(boxes)), "the boxes on the plate sleep on while the plate is awake"
+            assert tw.gpu.stats().num_wake_pairs == tw.cpu.stats().num_wake_pairs > 0
+    assert woke is not None, "the car never reached the plate"
+    tw.close()

@@ -239,3 +239,73 @@ def test_sleeping_body_woken_by_impact(world):
     assert woke
     ev = world.drain_events(abi.EVENT_ACTIVATED)
     assert a in set(ev["id"].tolist())
+
+
+def _sleeping_stack(world, n):
+    add_ground(world)
+    ids = [dyn(world, pos=(0, 0, 0.5 + 1.0 * k)) for k in range(n)]
+    for _ in range(400):
+        world.step(DT)
+        if not any(s["active"] for s in world.get_state(ids)):
+            break
+    assert not any(s["active"] for s in world.get_state(ids))
+    return ids
+
+
+def _drop_until_touch(world, ids, z0):
+    """a ball over the stack; steps until the top box is awake; returns the world's stats of that step"""
+    ball = dyn(world, abi.SHAPE_SPHERE, (0.25,), pos=(0.1, 0.05, z0), mass=5.0)
+    for _ in range(120):
+        world.step(DT)
+        if world.get_state([ids[-1]])[0]["active"]:
+            return ball, world.stats()
+    raise AssertionError("the ball never reached the stack")
+
+
+def test_in_step_activation_wakes_the_island_and_gives_it_its_contacts(oracle):
+    """PhysicsSystem::JobFindCollisions: a body woken by a contact is appended to the active list and collides in the same step, waking what it touches
+    in turn.  A ball lands on a sleeping stack of four boxes: in the step of the first touch ALL four are awake and the step solves ball - box,
+    three box - box and the box - ground contact.  With the switch off (rounds 1-3) only the top box wakes and the step holds one constraint."""
+    n = 4
+    w = oracle.OracleWorld(max_bodies=64)
+    ids = _sleeping_stack(w, n)
+    _, st = _drop_until_touch(w, ids, 0.5 + n + 1.5)
+    assert all(s["active"] for s in w.get_state(ids))
+    assert st.num_manifolds == n + 1
+    w.close()
+
+    old = oracle.lib().sgo_set_in_step_activation(0)
+    try:
+        w = oracle.OracleWorld(max_bodies=64)
+        ids = _sleeping_stack(w, n)
+        _, st = _drop_until_touch(w, ids, 0.5 + n + 1.5)
+        assert [int(s["active"]) for s in w.get_state(ids)] == [0] * (n - 1) + [1]
+        assert st.num_manifolds == 1
+    finally:
+        oracle.lib().sgo_set_in_step_activation(old)
+        w.close()
+
+
+def test_woken_body_is_held_by_the_ground_in_the_step_that_wakes_it(oracle):
+    """a heavy ball lands on a sleeping box that rests on the ground: the box's ground contact is part of the very step that wakes it, so it is not
+    driven into the ground (rounds 1-3: the contact came a step later and the box left that step moving downwards at a good fraction of the ball's speed)"""
+    def run():
+        w = oracle.OracleWorld(max_bodies=16)
+        ids = _sleeping_stack(w, 1)
+        z_rest = w.get_state(ids)[0]["pos"][2]
+        ball = dyn(w, abi.SHAPE_SPHERE, (0.25,), pos=(0, 0, 4.0), mass=50.0)
+        for _ in range(120):
+            w.step(DT)
+            if w.get_state(ids)[0]["active"]:
+                break
+        s = w.get_state(ids)[0]
+        w.close()
+        return float(s["lin_vel"][2]), float(s["pos"][2] - z_rest)
+    vz, dz = run()
+    assert vz > -0.05 and dz > -1.0e-3
+    old = oracle.lib().sgo_set_in_step_activation(0)
+    try:
+        vz_old, dz_old = run()
+    finally:
+        oracle.lib().sgo_set_in_step_activation(old)
+    assert vz_old < -1.0 and dz_old < -0.01

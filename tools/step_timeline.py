@@ -30,8 +30,9 @@ def main():
     for k in range(a.steps):
         lo, hi = sel[k], sel[k + 1]
         step = rows[lo:hi]
-        # the step ends with k_step_end; what follows (host sync, next step's enqueue) is not part of it
-        end_i = max(i for i, r in enumerate(step) if r[2].startswith("k_step_end"))
+        # the step ends with k_cache_build, whose first workgroup copies the counters out (k_step_end until round 3); what follows (host sync, next step's enqueue) is not part of it
+        ends = [i for i, r in enumerate(step) if r[2].startswith("k_step_end")] or [i for i, r in enumerate(step) if r[2].startswith("k_cache_build")]
+        end_i = max(ends)
         step = step[:end_i + 1]
         span += step[-1][1] - step[0][0]
         for i, (s, e, n) in enumerate(step):
