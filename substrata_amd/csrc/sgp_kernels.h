@@ -105,6 +105,7 @@ struct StepCounters {
 	uint32_t veh_done;           // workgroups of the running vehicle-row launch that have finished (the last one solves the deferred vehicles and clears it)
 	// in-step activation (k_wake_pairs): the pairs of the bodies this step wakes, and where the second narrow-phase round starts in the hull / mesh lists
 	uint32_t n_wake_pairs, n_woken, hull_base, mesh_base, mesh_big_base;
+	uint32_t wake_any;           // some sleeping body was marked for wake-up this step (plain store of 1: k_wake_pairs has nothing to do otherwise)
 	uint32_t tickets[4];         // last_block(): workgroups of k_colour_count / k_warm_bodies / k_cache_build that have finished
 	uint32_t ts_error;           // tile solver: a tile gave up waiting for a neighbour (k_step_end copies ts_flags[0])
 	uint32_t ts_all_adjacent;    // tile solver: some body was touched by more than four tiles

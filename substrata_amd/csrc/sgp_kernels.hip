@@ -814,6 +814,7 @@ SGP_DEV void wake_body(const DV& d, uint32_t id)
 {
 	atomicOr(&d.flags[id], BF_WAKE);
 	d.label_wake[d.sleep_label[id]] = *d.veh_epoch;
+	d.ctr->wake_any = 1u;
 }
 
 // the manifold goes to slot `slot` of the step's manifold list (the caller allocated it)
@@ -955,36 +956,51 @@ __global__ void __launch_bounds__(TPB) k_wake_pairs(DV d)
 {
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
 	if (i == 0) {
+		// (the narrow-phase launches that follow start behind the first round's pairs -- also in the usual step, in which nothing was woken)
 		d.ctr->hull_base = min(d.ctr->n_hull_pairs, d.cap_hull_pairs);
 		d.ctr->mesh_base = min(d.ctr->n_mesh_pairs, d.cap_mesh_pairs);
 		d.ctr->mesh_big_base = min(d.ctr->n_mesh_big, d.cap_mesh_pairs);
 	}
-	if (i >= d.sp->n_slots) return;
-	const uint32_t fi = d.flags[i], epoch = *d.veh_epoch;
-	if (!body_woken(d, i, fi, epoch)) return;
-	if (!(fi & BF_WAKE)) d.flags[i] = fi | BF_WAKE;      // (nobody else writes this word during this launch; the bits others read of it do not change)
-	atomicAdd(&d.ctr->n_woken, 1u);
-	const float4 mni = d.aabb_min[i], mxi = d.aabb_max[i];
-	auto candidate = [&](uint32_t j) {
-		if (j == i) return;
-		const uint32_t fj = d.flags[j];
-		if (!(fj & BF_ALIVE) || (fj & BF_ALIAS) || f_active_for_pairs(fj)) return;
-		if (j < i && body_woken(d, j, fj, epoch)) return;           // two woken bodies: the lower id makes the pair
-		if (!pair_passes(d, fi, mni, mxi, j)) return;
-		const uint32_t k = wave_alloc(&d.ctr->n_wake_pairs);
-		if (k < d.cap_wake_pairs) d.wake_pairs[k] = make_uint2(i < j ? i : j, i < j ? j : i); else atomicAdd(&d.ctr->pairs_dropped, 1u);
-	};
+	if (!d.ctr->wake_any) return;                      // (uniform)
+	const uint32_t epoch = *d.veh_epoch;
+	const int lane = (int)(threadIdx.x & 63u);
+	const uint32_t fi_own = i < d.sp->n_slots ? d.flags[i] : 0u;
+	const bool woken = i < d.sp->n_slots && body_woken(d, i, fi_own, epoch);
+	if (woken && !(fi_own & BF_WAKE)) d.flags[i] = fi_own | BF_WAKE;      // (nobody else writes this word during this launch; the bits others read of it do not change)
+	// the woken bodies of a wave one after the other, each with all 64 lanes on its candidates (woken bodies are few among many: a lane
+	// walking its body's cells alone would leave 63 idle)
+	unsigned long long todo = __ballot(woken);
+	if (lane == 0 && todo) atomicAdd(&d.ctr->n_woken, (uint32_t)__popcll(todo));
 	const float sp = d.st.speculative_contact_distance;
-	for (uint32_t l = 0; l < d.sp->n_large; ++l) candidate(d.large_ids[l]);
-	large_grid_query(d, V3(mni.x - sp, mni.y - sp, mni.z - sp), V3(mxi.x + sp, mxi.y + sp, mxi.z + sp), candidate);
 	const BpGrid g = *d.grid;
-	if (g.n_cells > 0 && g.min_x <= g.max_x) {
-		// (small bodies are binned by their centres into cells no smaller than the largest of them plus the margin: one cell of slack around the bounds)
-		const int x0 = max((int)floorf((mni.x - g.ox) * g.inv_cell) - 1, 0), x1 = min((int)floorf((mxi.x - g.ox) * g.inv_cell) + 1, g.nx - 1);
-		const int y0 = max((int)floorf((mni.y - g.oy) * g.inv_cell) - 1, 0), y1 = min((int)floorf((mxi.y - g.oy) * g.inv_cell) + 1, g.ny - 1);
-		const int z0 = max((int)floorf((mni.z - g.oz) * g.inv_cell) - 1, 0), z1 = min((int)floorf((mxi.z - g.oz) * g.inv_cell) + 1, g.nz - 1);
-		if (x0 <= x1) for (int z = z0; z <= z1; ++z) for (int y = y0; y <= y1; ++y)
-			grid_row_runs(d, g, x0, x1, y, z, [&](uint32_t q0, uint32_t q1) { for (uint32_t q = q0; q < q1; ++q) candidate(__float_as_uint(d.sorted_max[q].w)); });
+	while (todo) {
+		const int src = __ffsll((long long)todo) - 1;
+		todo &= todo - 1ull;
+		const uint32_t b = (i - (uint32_t)lane) + (uint32_t)src;
+		const uint32_t fb = d.flags[b];
+		const float4 mnb = d.aabb_min[b], mxb = d.aabb_max[b];
+		auto candidate = [&](uint32_t j) {
+			if (j == b) return;
+			const uint32_t fj = d.flags[j];
+			if (!(fj & BF_ALIVE) || (fj & BF_ALIAS) || f_active_for_pairs(fj)) return;
+			if (j < b && body_woken(d, j, fj, epoch)) return;           // two woken bodies: the lower id makes the pair
+			if (!pair_passes(d, fb, mnb, mxb, j)) return;
+			const uint32_t k = wave_alloc(&d.ctr->n_wake_pairs);
+			if (k < d.cap_wake_pairs) d.wake_pairs[k] = make_uint2(b < j ? b : j, b < j ? j : b); else atomicAdd(&d.ctr->pairs_dropped, 1u);
+		};
+		for (uint32_t l = (uint32_t)lane; l < d.sp->n_large; l += 64u) candidate(d.large_ids[l]);
+		{
+			uint32_t seen = 0;      // static large bodies around the body, dealt to the lanes in the order their grid yields them
+			large_grid_query(d, V3(mnb.x - sp, mnb.y - sp, mnb.z - sp), V3(mxb.x + sp, mxb.y + sp, mxb.z + sp), [&](uint32_t j) { if ((int)(seen++ & 63u) == lane) candidate(j); });
+		}
+		if (g.n_cells > 0 && g.min_x <= g.max_x) {
+			// (small bodies are binned by their centres into cells no smaller than the largest of them plus the margin: one cell of slack around the bounds)
+			const int x0 = max((int)floorf((mnb.x - g.ox) * g.inv_cell) - 1, 0), x1 = min((int)floorf((mxb.x - g.ox) * g.inv_cell) + 1, g.nx - 1);
+			const int y0 = max((int)floorf((mnb.y - g.oy) * g.inv_cell) - 1, 0), y1 = min((int)floorf((mxb.y - g.oy) * g.inv_cell) + 1, g.ny - 1);
+			const int z0 = max((int)floorf((mnb.z - g.oz) * g.inv_cell) - 1, 0), z1 = min((int)floorf((mxb.z - g.oz) * g.inv_cell) + 1, g.nz - 1);
+			if (x0 <= x1) for (int z = z0; z <= z1; ++z) for (int y = y0; y <= y1; ++y)
+				grid_row_runs(d, g, x0, x1, y, z, [&](uint32_t q0, uint32_t q1) { for (uint32_t q = q0 + (uint32_t)lane; q < q1; q += 64u) candidate(__float_as_uint(d.sorted_max[q].w)); });
+		}
 	}
 }
 
@@ -4841,12 +4857,12 @@ void launch_wake_round(const DV& d, uint32_t nb, bool has_hulls, bool has_meshes
 	hipLaunchKernelGGL(k_wake_pairs, dim3(blocks_for(nb)), dim3(TPB), 0, s, d);
 	hipLaunchKernelGGL(k_narrowphase_wake, dim3(256), dim3(TPB), 0, s, d);
 	if (has_hulls) {
-		hipLaunchKernelGGL(k_narrowphase_hull, dim3(1024), dim3(64), 0, s, d);
-		hipLaunchKernelGGL(k_narrowphase_hull_manifold, dim3(256), dim3(64), 0, s, d);
+		hipLaunchKernelGGL(k_narrowphase_hull, dim3(512), dim3(64), 0, s, d);
+		hipLaunchKernelGGL(k_narrowphase_hull_manifold, dim3(128), dim3(64), 0, s, d);
 	}
 	if (has_meshes) {
-		hipLaunchKernelGGL(k_narrowphase_mesh<8>, dim3(512), dim3(64), 0, s, d);
-		hipLaunchKernelGGL(k_narrowphase_mesh<64>, dim3(512), dim3(64), 0, s, d);
+		hipLaunchKernelGGL(k_narrowphase_mesh<8>, dim3(256), dim3(64), 0, s, d);
+		hipLaunchKernelGGL(k_narrowphase_mesh<64>, dim3(256), dim3(64), 0, s, d);
 	}
 }
 void launch_narrowphase_hull(const DV& d, hipStream_t s)

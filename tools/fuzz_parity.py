@@ -198,6 +198,7 @@ def run_seed(oracle, seed, steps, verbose=False):
     tw.set_contact_events(int(rng.random() < 0.5))
     water = False
     max_deferred = 0
+    wake_pairs = 0
     for s in range(1, steps + 1):
         r = rng.random()
         if r < 0.04 and live:                                   # teleport with velocities
@@ -271,6 +272,9 @@ def run_seed(oracle, seed, steps, verbose=False):
             dg_, dc_ = tw.gpu.stats().num_deferred_vehicles, tw.cpu.stats().num_deferred_vehicles
             assert dg_ == dc_, (seed, s, "deferred vehicles", dg_, dc_)
             max_deferred = max(max_deferred, dg_)
+        wg_, wc_ = tw.gpu.stats().num_wake_pairs, tw.cpu.stats().num_wake_pairs
+        assert wg_ == wc_, (seed, s, "pairs of the in-step activation round", wg_, wc_)
+        wake_pairs += wg_
         for ev in (abi.EVENT_CONTACT_ADDED, abi.EVENT_CONTACT_PERSISTED, abi.EVENT_ACTIVATED, abi.EVENT_DEACTIVATED, abi.EVENT_ENTERED_WATER):
             eg, ec = tw.drain_events(ev)
             if len(eg) != len(ec):
@@ -342,7 +346,7 @@ def run_seed(oracle, seed, steps, verbose=False):
                     raise AssertionError((seed, s, "vehicle state", v, diffs[:6]))
     st = tw.gpu.stats()
     if verbose:
-        print(f"seed {seed}: mesh {use_mesh} car {use_car} hulls {len(hulls)} bodies {tw.gpu.num_bodies()} manifolds {st.num_manifolds} colours {st.num_colours} vehicles {len(vids)} (deferred <= {max_deferred}): ok")
+        print(f"seed {seed}: mesh {use_mesh} car {use_car} hulls {len(hulls)} bodies {tw.gpu.num_bodies()} manifolds {st.num_manifolds} colours {st.num_colours} vehicles {len(vids)} (deferred <= {max_deferred}, {wake_pairs} pairs of woken bodies): ok")
     tw.close()
 
 
