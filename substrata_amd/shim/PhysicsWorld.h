@@ -22,6 +22,9 @@
 #include <string>
 #include <vector>
 #include <cstdint>
+#include <algorithm>
+#include <type_traits>
+#include <utility>
 
 namespace glare { class TaskManager; class StackAllocator; class Allocator; }
 struct sgp_world;
@@ -107,8 +110,9 @@ public:
 	//   Indigo::Mesh:  vert_positions[i].{x,y,z}; triangles[i].{vertex_indices[3], tri_mat_index}; quads[i].{vertex_indices[4], mat_index}
 	//   BatchedMesh:   vertexSize(), numVerts(), numIndices(), findAttribute(VertAttribute_Position) -> {component_type, offset_B}, vertex_data,
 	//                  aabb_os.{min_, span()} (uint16 positions are dequantised over it), index_data, index_type, batches[b].{indices_start,
-	//                  num_indices, material_index}.  Skinned meshes (joints + weights + animation_data.joint_nodes) are built in their bind
-	//                  pose here; the reference applies the joint matrices first (PhysicsWorld.cpp:885-947).
+	//                  num_indices, material_index}.  A skinned mesh (Joints + Weights attributes and animation_data.{nodes, sorted_nodes,
+	//                  joint_nodes}) is built in the pose its animation nodes hold, like the reference (PhysicsWorld.cpp:885-947, 814-866):
+	//                  round 4 -- a mesh type without an animation_data member is taken as it is.
 	template <class IndigoMeshT>
 	static PhysicsShape createJoltShapeForIndigoMesh(const IndigoMeshT& mesh, bool build_dynamic_physics_ob, glare::Allocator* mem_allocator = nullptr)
 	{
@@ -130,6 +134,64 @@ public:
 		}
 		return createMeshShape(verts, tris, &mats);
 	}
+	// Skinning of a BatchedMesh before its shape is built (PhysicsWorld.cpp:885-947: "if mesh has joints and weights, take the skinning transform into
+	// account"): node -> object matrices down the hierarchy (T R S per node, parents first: sorted_nodes), joint matrix = node matrix x inverse bind
+	// matrix, vertex = sum over its four influences of weight x (joint matrix x position); weights are uint8 / uint16 (normalised) or float.
+	template <class M, class = void> struct HasAnimationData : std::false_type {};
+	template <class M> struct HasAnimationData<M, std::void_t<decltype(std::declval<const M&>().animation_data.joint_nodes)>> : std::true_type {};
+	template <class BatchedMeshT>
+	static void applySkinTransforms(const BatchedMeshT& mesh, std::vector<Vec3f>& verts)
+	{
+		if constexpr (HasAnimationData<BatchedMeshT>::value) {
+			const auto* joints_attr = mesh.findAttribute(BatchedMeshT::VertAttribute_Joints);
+			const auto* weights_attr = mesh.findAttribute(BatchedMeshT::VertAttribute_Weights);
+			const auto& anim = mesh.animation_data;
+			if (!joints_attr || !weights_attr || anim.joint_nodes.empty()) return;
+			const int num_nodes = (int)anim.nodes.size();
+			std::vector<Matrix4f> node_to_ob((size_t)num_nodes, Matrix4f::identity());
+			for (size_t k = 0; k < anim.sorted_nodes.size(); ++k) {
+				const int n = (int)anim.sorted_nodes[k];
+				if (n < 0 || n >= num_nodes) throw glare::Exception("createJoltShapeForBatchedMesh: animation node index out of range.");
+				const auto& node = anim.nodes[(size_t)n];
+				Matrix4f local = node.rot.toMatrix();
+				for (int c = 0; c < 3; ++c) { const Vec4f col = local.getColumn(c); local.setColumn(c, Vec4f(col[0] * node.scale[c], col[1] * node.scale[c], col[2] * node.scale[c], 0.f)); }
+				local.setColumn(3, Vec4f(node.trans[0], node.trans[1], node.trans[2], 1.f));
+				const int parent = (int)node.parent_index;
+				if (parent < -1 || parent >= num_nodes) throw glare::Exception("createJoltShapeForBatchedMesh: animation node parent out of range.");
+				node_to_ob[(size_t)n] = parent < 0 ? local : node_to_ob[(size_t)parent] * local;
+			}
+			std::vector<Matrix4f> joint_to_ob(anim.joint_nodes.size());
+			for (size_t j = 0; j < joint_to_ob.size(); ++j) {
+				const int n = (int)anim.joint_nodes[j];
+				if (n < 0 || n >= num_nodes) throw glare::Exception("createJoltShapeForBatchedMesh: joint node index out of range.");
+				joint_to_ob[j] = node_to_ob[(size_t)n] * anim.nodes[(size_t)n].inverse_bind_matrix;
+			}
+			const bool joints_u8 = joints_attr->component_type == BatchedMeshT::ComponentType_UInt8, joints_u16 = joints_attr->component_type == BatchedMeshT::ComponentType_UInt16;
+			const bool w_u8 = weights_attr->component_type == BatchedMeshT::ComponentType_UInt8, w_u16 = weights_attr->component_type == BatchedMeshT::ComponentType_UInt16;
+			const bool w_f = weights_attr->component_type == BatchedMeshT::ComponentType_Float;
+			if (!(joints_u8 || joints_u16) || !(w_u8 || w_u16 || w_f)) throw glare::Exception("createJoltShapeForBatchedMesh: unsupported joint / weight component type.");
+			const size_t stride = mesh.vertexSize();
+			const unsigned char* data = (const unsigned char*)mesh.vertex_data.data();
+			if (!verts.empty() && (verts.size() - 1) * stride + std::max(joints_attr->offset_B + (joints_u8 ? 4u : 8u), weights_attr->offset_B + (w_u8 ? 4u : (w_u16 ? 8u : 16u))) > mesh.vertex_data.size())
+				throw glare::Exception("createJoltShapeForBatchedMesh: joint / weight attributes run past the vertex data.");
+			for (size_t i = 0; i < verts.size(); ++i) {
+				uint32 joint[4]; float weight[4];
+				const unsigned char* pj = data + i * stride + joints_attr->offset_B;
+				const unsigned char* pw = data + i * stride + weights_attr->offset_B;
+				for (int z = 0; z < 4; ++z) {
+					if (joints_u8) joint[z] = pj[z]; else { uint16_t t; memcpy(&t, pj + 2 * z, 2); joint[z] = t; }
+					if (w_u8) weight[z] = (float)pw[z] * (1.0f / 255.f);
+					else if (w_u16) { uint16_t t; memcpy(&t, pw + 2 * z, 2); weight[z] = (float)t * (1.0f / 65535.f); }
+					else memcpy(&weight[z], pw + 4 * z, 4);
+					if (joint[z] >= joint_to_ob.size()) throw glare::Exception("createJoltShapeForBatchedMesh: vertex joint index out of range.");
+				}
+				const Vec4f p(verts[i][0], verts[i][1], verts[i][2], 1.f);
+				Vec4f acc(0.f, 0.f, 0.f, 0.f);
+				for (int z = 0; z < 4; ++z) { const Vec4f q = joint_to_ob[joint[z]] * p; for (int c = 0; c < 4; ++c) acc[c] += q[c] * weight[z]; }
+				verts[i] = Vec3f(acc[0], acc[1], acc[2]);
+			}
+		} else { (void)mesh; (void)verts; }
+	}
 	template <class BatchedMeshT, class BoolVectorT = std::vector<bool>>
 	static PhysicsShape createJoltShapeForBatchedMesh(const BatchedMeshT& mesh, bool build_dynamic_physics_ob, glare::Allocator* mem_allocator = nullptr,
 		const BoolVectorT* create_tris_for_mat = nullptr)
@@ -149,6 +211,7 @@ public:
 			if (pos_is_float) { float f[3]; memcpy(f, p, 12); verts[i] = Vec3f(f[0], f[1], f[2]); }
 			else { uint16_t q[3]; memcpy(q, p, 6); verts[i] = Vec3f(lo[0] + span[0] / 65535.f * (float)q[0], lo[1] + span[1] / 65535.f * (float)q[1], lo[2] + span[2] / 65535.f * (float)q[2]); }
 		}
+		applySkinTransforms(mesh, verts);
 		if (build_dynamic_physics_ob) return createConvexHullShape(verts);
 		std::vector<uint32> tris, mats;
 		const unsigned char* idx = (const unsigned char*)mesh.index_data.data();

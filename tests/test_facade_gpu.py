@@ -35,6 +35,7 @@ def test_facade_compiles_without_gpu(tmp_path):
     assert os.path.exists(build_facade_exe(tmp_path, "mesh_world.cpp"))
     assert os.path.exists(build_facade_exe(tmp_path, "boat_controller.cpp"))
     assert os.path.exists(build_facade_exe(tmp_path, "snapshot_stream.cpp"))
+    assert os.path.exists(build_facade_exe(tmp_path, "skinned_mesh.cpp"))
 
 
 # What the reference's callers include from Jolt and from the facade (grep '#include' of the files named; gui_client/ of the reference).
@@ -190,6 +191,16 @@ def test_mesh_world_through_the_facade(tmp_path):
     """Height-field terrain + static mesh building built through the facade's shape builders; objects rest on them, rays hit their
     front faces only, the player follows the terrain and stops at the building's wall."""
     exe = build_facade_exe(tmp_path, "mesh_world.cpp")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_skinned_mesh_is_built_in_its_animated_pose(tmp_path):
+    """createJoltShapeForBatchedMesh applies the joint matrices before it builds the shape (PhysicsWorld.cpp:885-947): a bar whose upper half is
+    bound to a bent joint collides (rays) as the bent bar, as a static triangle shape and as a dynamic convex hull; uint8 and float weights."""
+    exe = build_facade_exe(tmp_path, "skinned_mesh.cpp")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     print(r.stdout)
     assert r.returncode == 0, r.stdout + r.stderr
