@@ -913,8 +913,15 @@ template <int ROUND> SGP_DEV void narrowphase_pairs(const DV& d)
 				else if (f_shape(fa) == SGP_SHAPE_HULL || f_shape(fb) == SGP_SHAPE_HULL) {
 					// the polytope paths (clip buffers in scratch, long loops) live in their own kernel so that they do not cost the
 					// sphere / box / capsule pairs registers or scratch
-					const uint32_t k = wave_alloc(&d.ctr->n_hull_pairs);
-					if (k < d.cap_hull_pairs) d.hull_pairs[k] = ab; else atomicAdd(&d.ctr->pairs_dropped, 1u);
+					if constexpr (ROUND == 0) {
+						const uint32_t k = wave_alloc(&d.ctr->n_hull_pairs);
+						if (k < d.cap_hull_pairs) d.hull_pairs[k] = ab; else atomicAdd(&d.ctr->pairs_dropped, 1u);
+					} else {
+						// the in-step activation round has few pairs and is two launches shorter with the sequential form of the same search here
+						// (every axis through the same device function, first maximum wins: the same manifold as the wave-parallel kernels')
+						const sgd_shape sa = load_shape(d, ab.x, fa), sb = load_shape(d, ab.y, fb);
+						have = sgd_collide_hull(&sa, &sb, d.st.speculative_contact_distance, &m) != 0;
+					}
 				} else {
 					const sgd_shape sa = load_shape(d, ab.x, fa), sb = load_shape(d, ab.y, fb);
 					have = sgd_collide(&sa, &sb, d.st.speculative_contact_distance, &m) != 0;
@@ -4856,10 +4863,7 @@ void launch_wake_round(const DV& d, uint32_t nb, bool has_hulls, bool has_meshes
 {
 	hipLaunchKernelGGL(k_wake_pairs, dim3(blocks_for(nb)), dim3(TPB), 0, s, d);
 	hipLaunchKernelGGL(k_narrowphase_wake, dim3(256), dim3(TPB), 0, s, d);
-	if (has_hulls) {
-		hipLaunchKernelGGL(k_narrowphase_hull, dim3(512), dim3(64), 0, s, d);
-		hipLaunchKernelGGL(k_narrowphase_hull_manifold, dim3(128), dim3(64), 0, s, d);
-	}
+	(void)has_hulls;      // (hull pairs of this round are collided by k_narrowphase_wake itself)
 	if (has_meshes) {
 		hipLaunchKernelGGL(k_narrowphase_mesh<8>, dim3(256), dim3(64), 0, s, d);
 		hipLaunchKernelGGL(k_narrowphase_mesh<64>, dim3(256), dim3(64), 0, s, d);
