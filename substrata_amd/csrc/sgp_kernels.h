@@ -356,7 +356,7 @@ void launch_solve_hc(const DV& d, int first_colour, uint32_t est, int mode, hipS
 void launch_solve_small(const DV& d, int warm_start, int iterations, int lane_pairs, hipStream_t s);      // lane_pairs: two lanes per constraint (<= 384 constraints stay in registers), else one (<= 512)
 void launch_integrate_pose(const DV& d, uint32_t nb, hipStream_t s);
 void launch_finalize(const DV& d, uint32_t nb, hipStream_t s);
-void launch_island_mark(const DV& d, uint32_t n_con, hipStream_t s);
+void launch_island_mark(const DV& d, uint32_t n_con, int clear_cache, hipStream_t s);      // clear_cache: the launch also empties the contact-cache table (first round)
 void launch_island_hook(const DV& d, uint32_t n_con, hipStream_t s);
 void launch_island_flag(const DV& d, uint32_t n_con, hipStream_t s);
 void launch_sleep_apply(const DV& d, uint32_t nb, hipStream_t s);

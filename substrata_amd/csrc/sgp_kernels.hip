@@ -3049,8 +3049,16 @@ SGP_DEV bool island_edge(const DV& d, uint32_t k, uint32_t n_con, uint2& ab)
 	return true;
 }
 
-__global__ void __launch_bounds__(TPB) k_island_mark(DV d)
+SGP_DEV uint32_t cache_table_size(const DV& d);
+__global__ void __launch_bounds__(TPB) k_island_mark(DV d, int clear_cache)
 {
+	// The first of the marking launches also empties the contact-cache table for this step's rebuild (nothing reads the old table after the set-up;
+	// the stores ride along with a launch that waits for its gathers: k_cache_clear was a launch of its own, 6 us on the step's chain)
+	if (clear_cache) {
+		const uint32_t size = cache_table_size(d);
+		for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < size; i += gridDim.x * TPB) d.ht_keys[i] = ~0ull;
+		if (blockIdx.x == 0 && threadIdx.x == 0) *d.ht_cur = size;
+	}
 	// (measured, round 4: the three rounds inside ONE launch -- agent-scope loads so that marks cross the XCDs' L2s -- cost 52 us against 36 us for three
 	// launches with plain accesses: the kernel boundary is the cheaper way to make the marks of a round visible everywhere)
 	const uint32_t n_con = d.ctr->n_constraints, n_edges = island_edges(d);
@@ -4972,14 +4980,14 @@ void launch_solve_small(const DV& d, int warm_start, int iterations, int lane_pa
 }
 void launch_integrate_pose(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_integrate_pose, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_finalize(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_finalize, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
-void launch_island_mark(const DV& d, uint32_t n_con, hipStream_t s) { hipLaunchKernelGGL(k_island_mark, dim3(stride_grid(n_con)), dim3(TPB), 0, s, d); }
+void launch_island_mark(const DV& d, uint32_t n_con, int clear_cache, hipStream_t s) { hipLaunchKernelGGL(k_island_mark, dim3(stride_grid(n_con)), dim3(TPB), 0, s, d, clear_cache); }
 void launch_island_hook(const DV& d, uint32_t n_con, hipStream_t s) { hipLaunchKernelGGL(k_island_hook, dim3(stride_grid(n_con)), dim3(TPB), 0, s, d); }
 void launch_island_flag(const DV& d, uint32_t n_con, hipStream_t s) { hipLaunchKernelGGL(k_island_flag, dim3(stride_grid(n_con)), dim3(TPB), 0, s, d); }
 void launch_sleep_apply(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_sleep_apply, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_buoyancy(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_buoyancy, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_cache_build(const DV& d, uint32_t n_con, StepCounters* host_mapped, EventCounters* host_events, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_cache_clear, dim3(std::max(64u, std::min(1024u, n_con / 256u))), dim3(TPB), 0, s, d);
+	// (the table was emptied by the first k_island_mark launch of the step)
 	hipLaunchKernelGGL(k_cache_build, dim3(stride_grid(n_con)), dim3(TPB), 0, s, d, host_mapped, host_events);
 }
 // forget the previous step's contacts (the world has gone to sleep as a whole: the CPU statement's steps without an awake body leave no constraints behind either)

@@ -1313,7 +1313,7 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 	STAGE_MARK(7);
 	// -- 8. bounds, sleeping, buoyancy, contact cache
 	{ KScope k(w, KC_FINALIZE); launch_finalize(d, nb, s); }
-	for (int r = 0; r < SGP_ISLAND_MARK_ROUNDS; ++r) { KScope k(w, KC_ISLAND_HOOK); launch_island_mark(d, p.est_man, s); }
+	for (int r = 0; r < SGP_ISLAND_MARK_ROUNDS; ++r) { KScope k(w, KC_ISLAND_HOOK); launch_island_mark(d, p.est_man, r == 0 ? 1 : 0, s); }
 	{ KScope k(w, KC_ISLAND_HOOK); launch_island_hook(d, p.est_man, s); }
 	{ KScope k(w, KC_ISLAND_FLAG); launch_island_flag(d, p.est_man, s); }
 	{ KScope k(w, KC_SLEEP_APPLY); launch_sleep_apply(d, nb, s); }
