@@ -278,6 +278,7 @@ struct DV {
 	uint32_t* hc_list;         // constraint slot per lane pair of the solve launch (k_hc_scatter) ...
 	uint4*    hc_entry;        // ... ordered by colour within a workgroup's share, with the constraint's np_col and bodies (k_hc_sort): what k_solve_hc reads
 	uint32_t  cap_hc_list;
+	uint32_t* hc_big_list;     // constraints of components too large for a workgroup (k_hc_scatter; up to HC_BIG_LIST = 1024 of them)
 	// constraints
 	uint32_t dbg_flags;        // SGP_DEBUG_FLAGS (developer switches): bit 0 = tail kernel without its register-resident path
 	float4* rows;              // velocity-iteration rows, [point 0..3][axis n,t1,t2][4][cap_manifolds] (k_setup): r1 x axis (w: bias for n),

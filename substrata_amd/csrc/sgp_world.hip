@@ -360,7 +360,7 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 			DEV_ALLOC(d.ts_at, 2 * (size_t)M); DEV_ALLOC(d.ts_side, 2 * (size_t)M);
 		}
 	}
-	d.cap_hc_list = 2u * M + 4096u; DEV_ALLOC(d.hc_list, d.cap_hc_list); DEV_ALLOC(d.hc_entry, d.cap_hc_list);
+	d.cap_hc_list = 2u * M + 4096u; DEV_ALLOC(d.hc_list, d.cap_hc_list); DEV_ALLOC(d.hc_entry, d.cap_hc_list); DEV_ALLOC(d.hc_big_list, 1024);
 	DEV_ALLOC(d.ulist[0], M); DEV_ALLOC(d.ulist[1], M);
 	for (int k = 0; k < 4; ++k) { DEV_ALLOC(d.man_p1[k], M); DEV_ALLOC(d.man_p2[k], M); }
 	DEV_ALLOC(d.rows, (size_t)48 * M);
@@ -383,6 +383,8 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	memset(w->h_sp, 0, sizeof(StepParams));
 	DEV_ALLOC(w->d_sp, 1);
 	d.sp = w->d_sp;
+	// (the device's copy holds the parity of the LAST step -- k_step_begin flips it -- i.e. the opposite of h_sp's, which is the next step's)
+	{ StepParams init = *w->h_sp; init.parity = w->h_sp->parity ^ 1u; HIP_TRY(hipMemcpyAsync(w->d_sp, &init, sizeof(init), hipMemcpyHostToDevice, w->stream)); HIP_TRY(hipStreamSynchronize(w->stream)); }
 	{ const char* e = getenv("SGP_NO_GRAPH"); if (e && e[0] == '1') w->use_graphs = false; }
 	{ const char* e = getenv("SGP_NO_SMALL_WORLD"); if (e && e[0] == '1') w->use_small_world = false; }
 	{ const char* e = getenv("SGP_NO_WAKE_ROUND"); if (e && e[0] == '1') w->use_wake_round = false; }      // (measurements only: the CPU statement has its own switch)
@@ -887,7 +889,7 @@ static int upload_sp(sgp_world* w)
 		StepParams cmp = sp; cmp.dt = w->sp_uploaded.dt; cmp.parity = w->sp_uploaded.parity;
 		if (memcmp(&w->sp_uploaded, &cmp, sizeof(cmp)) == 0) return SGP_OK;
 	}
-	launch_set_params(w->dv, *w->h_sp, w->stream);
+	{ StepParams up = sp; up.parity = sp.parity ^ 1u; launch_set_params(w->dv, up, w->stream); }      // (device convention: the parity of the last step)
 	w->sp_uploaded = sp; w->sp_uploaded_valid = true;
 	return SGP_OK;
 }
@@ -1228,6 +1230,7 @@ static void make_plan(const sgp_world* w, StepPlan& p)
 	p.tile_solver = (w->use_tile_solver && w->dv.ts_nt && !p.small_world && w->n_vehicles == 0 && p.vel_iters > 0 && w->n_con >= w->ts_min_constraints &&
 	                 w->high >= SGP_MAX_COLOURS * w->dv.ts_nt && w->last_active <= w->dv.ts_nt * 1536u && !w->h_sp->compact_rows) ? w->use_tile_solver : 0;      // (2: debugging aid -- the tile order of the slots, solved by the colour launches)
 	p.sp = *w->h_sp;
+	p.sp.parity = 0u;        // (not part of a plan: the device flips its own)
 }
 
 static int enqueue_step(sgp_world* w, const StepPlan& p)
@@ -1236,7 +1239,7 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 	hipStream_t s = w->stream;
 	const uint32_t nb = p.nb;
 	STAGE_MARK(0);
-	{ KScope k(w, KC_MISC); launch_step_begin(d, *w->h_sp, nb, true, s); }
+	{ KScope k(w, KC_MISC); launch_step_begin(d, p.sp, nb, true, s); }
 	STAGE_MARK(1);
 	// -- 1/2. broad-phase grid of the current poses (forces do not move bodies), then the step listeners that query it
 	//         (VehicleConstraint::OnStep: wheel casts), then forces, then the pair search
@@ -1364,11 +1367,12 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	if (w->use_graphs && !w->profiling) {
 		auto it = w->graphs.find(key);
 		if (it == w->graphs.end()) {
-			// capture only once the same plan has come up twice in a row for this buffer parity (plans churn while a scene is still
-			// changing; the parity is part of the by-value StepParams, so a plan alternates between two keys)
-			const uint32_t par = w->h_sp->parity & 1u;
+			// capture only once the same plan has come up several times in a row (plans churn while a scene is still changing, and a capture costs
+			// 0.4 ms -- a fifth of a 100k-body step, where replaying a graph is worth under 1 % over issuing the launches; a small world, whose step IS
+			// its launches, captures at the first repeat)
+			const uint32_t par = 0u;
 			w->plan_repeats[par] = (key == w->last_plan_key[par]) ? w->plan_repeats[par] + 1 : 0;
-			if (w->plan_repeats[par] >= 1) {
+			if (w->plan_repeats[par] >= (plan.nb <= 2048u ? 1u : 3u)) {
 				if (w->graphs.size() >= 16) { for (auto& kv : w->graphs) hipGraphExecDestroy(kv.second); w->graphs.clear(); }
 				hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
 				HIP_TRY(hipStreamBeginCapture(w->stream, hipStreamCaptureModeThreadLocal));
@@ -1384,7 +1388,7 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 		}
 		if (it != w->graphs.end()) { HIP_TRY(hipGraphLaunch(it->second, w->stream)); launched = true; w->graph_launches++; }
 	}
-	w->last_plan_key[w->h_sp->parity & 1u] = key;
+	w->last_plan_key[0] = key;
 	if (!launched) { const int r = enqueue_step(w, plan); if (r != SGP_OK) return r; w->eager_steps++; }
 	w->sp_uploaded = plan.sp; w->sp_uploaded_valid = true;      // (k_step_begin wrote it)
 	w->events_on_device = true;
