@@ -67,6 +67,7 @@ struct sgp_world {
 	sgp_world_desc desc;
 	int device = 0;
 	hipStream_t stream = nullptr;
+	hipStream_t capture_stream = nullptr;      // launch plans are captured here while the step they belong to already runs, issued eagerly, on `stream`
 	DV dv;
 	std::vector<void*> allocs;
 	uint64_t device_bytes = 0;
@@ -296,6 +297,8 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	if (e != hipSuccess) { delete w; return fail(SGP_ERR_HIP, "hipSetDevice", e); }
 	e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking);
 	if (e != hipSuccess) { delete w; return fail(SGP_ERR_HIP, "hipStreamCreate", e); }
+	e = hipStreamCreateWithFlags(&w->capture_stream, hipStreamNonBlocking);
+	if (e != hipSuccess) { delete w; return fail(SGP_ERR_HIP, "hipStreamCreate", e); }
 	*out = w;   // so that DEV_ALLOC failures can be cleaned by the caller via destroy
 	DV& d = w->dv;
 	const uint32_t N = desc->max_bodies, P = w->desc.max_body_pairs, M = w->desc.max_manifolds;
@@ -431,6 +434,7 @@ SGP_API int sgp_world_destroy(sgp_world* w)
 	for (auto& kv : w->graphs) hipGraphExecDestroy(kv.second);
 	for (hipEvent_t ev : w->event_pool) hipEventDestroy(ev);
 	if (w->stage_ev_ok) for (int i = 0; i <= SGP_NUM_STAGES; ++i) hipEventDestroy(w->stage_ev[i]);
+	if (w->capture_stream) hipStreamDestroy(w->capture_stream);
 	if (w->stream) hipStreamDestroy(w->stream);
 	delete w;
 	return SGP_OK;
@@ -1373,20 +1377,25 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 			const uint32_t par = 0u;
 			w->plan_repeats[par] = (key == w->last_plan_key[par]) ? w->plan_repeats[par] + 1 : 0;
 			if (w->plan_repeats[par] >= (plan.nb <= 2048u ? 1u : 3u)) {
+				// THIS step is issued eagerly first; its plan is then captured on a second stream (capturing executes nothing) and instantiated while
+				// the device is already at work on the step -- the 0.4-0.6 ms a capture costs the host no longer show in any step
+				{ const int r0 = enqueue_step(w, plan); if (r0 != SGP_OK) return r0; w->eager_steps++; launched = true; }
 				if (w->graphs.size() >= 16) { for (auto& kv : w->graphs) hipGraphExecDestroy(kv.second); w->graphs.clear(); }
 				hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
-				HIP_TRY(hipStreamBeginCapture(w->stream, hipStreamCaptureModeThreadLocal));
+				HIP_TRY(hipStreamBeginCapture(w->capture_stream, hipStreamCaptureModeThreadLocal));
+				hipStream_t run_stream = w->stream; w->stream = w->capture_stream;
 				const int r = enqueue_step(w, plan);
-				const hipError_t e = hipStreamEndCapture(w->stream, &g);
+				w->stream = run_stream;
+				const hipError_t e = hipStreamEndCapture(w->capture_stream, &g);
 				if (r != SGP_OK) { if (g) hipGraphDestroy(g); return r; }
 				if (e != hipSuccess) return fail(SGP_ERR_HIP, "hipStreamEndCapture", e);
 				const hipError_t e2 = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
 				hipGraphDestroy(g);
 				if (e2 != hipSuccess) return fail(SGP_ERR_HIP, "hipGraphInstantiate", e2);
-				it = w->graphs.emplace(key, ge).first;
+				w->graphs.emplace(key, ge);
 			}
 		}
-		if (it != w->graphs.end()) { HIP_TRY(hipGraphLaunch(it->second, w->stream)); launched = true; w->graph_launches++; }
+		else { HIP_TRY(hipGraphLaunch(it->second, w->stream)); launched = true; w->graph_launches++; }
 	}
 	w->last_plan_key[0] = key;
 	if (!launched) { const int r = enqueue_step(w, plan); if (r != SGP_OK) return r; w->eager_steps++; }
