@@ -1009,8 +1009,13 @@ __global__ void __launch_bounds__(TPB) k_wake_pairs(DV d)
 			const int x0 = max((int)floorf((mnb.x - g.ox) * g.inv_cell) - 1, 0), x1 = min((int)floorf((mxb.x - g.ox) * g.inv_cell) + 1, g.nx - 1);
 			const int y0 = max((int)floorf((mnb.y - g.oy) * g.inv_cell) - 1, 0), y1 = min((int)floorf((mxb.y - g.oy) * g.inv_cell) + 1, g.ny - 1);
 			const int z0 = max((int)floorf((mnb.z - g.oz) * g.inv_cell) - 1, 0), z1 = min((int)floorf((mxb.z - g.oz) * g.inv_cell) + 1, g.nz - 1);
-			if (x0 <= x1) for (int z = z0; z <= z1; ++z) for (int y = y0; y <= y1; ++y)
-				grid_row_runs(d, g, x0, x1, y, z, [&](uint32_t q0, uint32_t q1) { for (uint32_t q = q0 + (uint32_t)lane; q < q1; q += 64u) candidate(__float_as_uint(d.sorted_max[q].w)); });
+			// the (y, z) rows of cells side by side, four lanes to a row: a row is a chain of dependent loads (page table, cell range, record, the
+			// candidate's flags and bounds), and a small body has up to sixteen of them
+			const int ny = y1 - y0 + 1, nrows = x0 <= x1 ? (z1 - z0 + 1) * ny : 0;
+			for (int r = lane >> 2; r < nrows; r += 16) {
+				const int z = z0 + r / ny, y = y0 + r % ny;
+				grid_row_runs(d, g, x0, x1, y, z, [&](uint32_t q0, uint32_t q1) { for (uint32_t q = q0 + (uint32_t)(lane & 3); q < q1; q += 4u) candidate(__float_as_uint(d.sorted_max[q].w)); });
+			}
 		}
 	}
 }
