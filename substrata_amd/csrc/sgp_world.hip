@@ -319,7 +319,12 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	DEV_ALLOC(d.cell_hash, N);
 	DEV_ALLOC(d.cell_count, d.table_size + 4); DEV_ALLOC(d.cell_start, d.table_size + 4); DEV_ALLOC(d.cell_fill, d.table_size + 4);
 	// the page table over the tiles of the bounding box: 8M tiles = 512M cells (a 4 km x 4 km x 70 m world at 1.5 m cells; 32 MB) before the cells have to grow
-	{ const char* e = getenv("SGP_GRID_TILE_TABLE"); d.tile_table_size = e && atoi(e) > 0 ? (uint32_t)atoi(e) : (1u << 23); }
+	// (scaled with the world's capacity, advisor r03: a world of a few hundred bodies pays 256 KB - 1 MB for it, not 32; where a small world is spread
+	// so wide that its tiles do not fit, its cells grow -- with few bodies to a cell either way)
+	{
+		uint32_t dflt = 1u << 16; while (dflt < (1u << 23) && (uint64_t)dflt < 1024ull * (uint64_t)N) dflt <<= 1;
+		const char* e = getenv("SGP_GRID_TILE_TABLE"); d.tile_table_size = e && atoi(e) > 0 ? (uint32_t)atoi(e) : dflt;
+	}
 	DEV_ALLOC(d.tile_slot, d.tile_table_size); DEV_ALLOC(d.tile_of_slot, d.table_size / 64u + 4u);
 	if (hipMemsetAsync(d.tile_slot, 0xFF, sizeof(uint32_t) * (size_t)d.tile_table_size, w->stream) != hipSuccess) return fail(SGP_ERR_HIP, "tile table init");
 	DEV_ALLOC(w->d_large, N); w->cap_large = N; d.large_ids = w->d_large;
