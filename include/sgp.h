@@ -345,7 +345,10 @@ int  sgp_world_set_water(sgp_world* w, int enabled, float water_z);
 /* Enable capture of contact added/persisted events (only needed when an event_listener is set). */
 int  sgp_world_set_contact_events(sgp_world* w, int enabled);
 /* think(dt) (PhysicsWorld.cpp:1356-1443): one PhysicsSystem::Update with 1 collision step + buoyancy sweep.
- * Blocks until the step has finished on the device. */
+ * Blocks until the step has finished on the device.  A sleeping body that an awake one touches (or a wheel stands on) wakes up IN this
+ * step, together with the island it fell asleep with, and collides in it (PhysicsSystem::JobFindCollisions appends what it wakes to the
+ * active list); sgp_step_stats::num_wake_pairs counts the pairs that brings.  A step in which nothing is awake and nothing was edited
+ * costs nothing (and forgets the previous step's contacts). */
 int  sgp_world_step(sgp_world* w, float dt);
 /* Same, n steps back to back with a single host sync at the end (GUIClient's sub-step loop, GUIClient.cpp:6382). */
 int  sgp_world_step_n(sgp_world* w, float dt, uint32_t n);
