@@ -547,6 +547,9 @@ typedef struct sgp_capsule_query {
 	float    max_separation;    /* report surfaces closer than this (predictive contact distance + character padding) */
 	uint32_t ignore_id;         /* JPH::IgnoreSingleBodyFilter (PlayerPhysics.cpp:477)                             */
 	uint32_t collidable_only;   /* PlayerPhysicsObjectLayerFilter (PlayerPhysics.cpp:240-249)                      */
+	float    movement[3];       /* CollideShapeSettings::mActiveEdgeMovementDirection (CharacterVirtual passes the direction it moves in); only its direction matters */
+	uint32_t active_edges;      /* 1: EActiveEdgeMode::CollideOnlyWithActive -- a hit on an inactive edge of a mesh takes the triangle's normal unless the
+	                               movement runs against the triangle more steeply along the found one (what CharacterVirtual asks for); 0: every edge collides with its own normal */
 } sgp_capsule_query;
 typedef struct sgp_query_contact {
 	uint32_t query;             /* index of the query                                                              */

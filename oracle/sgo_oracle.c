@@ -2612,7 +2612,10 @@ SGO_API int sgo_collide_capsules(sgo_world* w, const sgp_capsule_query* qs, uint
 			if (b->aabb_max.x < lo.x || b->aabb_min.x > hi.x || b->aabb_max.y < lo.y || b->aabb_min.y > hi.y || b->aabb_max.z < lo.z || b->aabb_min.z > hi.z) continue;
 			const sgo_shape sb = body_shape_xf(b);
 			sgo_manifold mm[SGO_MESH_MAX_GROUPS]; int ng;
-			if (b->shape_type == SGP_SHAPE_MESH) ng = collide_with_mesh(b, &sc, lo, hi, q->max_separation, mm, 0, V3(0, 0, 0));
+			if (b->shape_type == SGP_SHAPE_MESH) {
+				/* CharacterVirtual::GetContactsAtPosition: mActiveEdgeMode = CollideOnlyWithActive, mActiveEdgeMovementDirection = the direction of travel */
+				ng = collide_with_mesh(b, &sc, lo, hi, q->max_separation, mm, q->active_edges != 0 && g_active_edges, V3(q->movement[0], q->movement[1], q->movement[2]));
+			}
 			else ng = sgo_collide(&sb, &sc, q->max_separation, &mm[0]) ? 1 : 0;        /* normal from the body to the capsule */
 			for (int g = 0; g < ng; ++g) { const sgo_manifold m = mm[g];
 			for (int i = 0; i < m.np; ++i) {

@@ -196,7 +196,7 @@ class MeshInfo(C.Structure):
 
 class CapsuleQuery(C.Structure):
     _fields_ = [("pos", f32 * 3), ("rot", f32 * 4), ("radius", f32), ("half_height", f32), ("max_separation", f32),
-                ("ignore_id", u32), ("collidable_only", u32)]
+                ("ignore_id", u32), ("collidable_only", u32), ("movement", f32 * 3), ("active_edges", u32)]
 
 
 class CompoundChild(C.Structure):

@@ -4507,7 +4507,7 @@ __global__ void __launch_bounds__(64) k_collide_capsules(DV d, const sgp_capsule
 		const uint32_t mid = mesh_list[mi];
 		bool valid = true, dropped = false;
 		sgd_shape X = sc;
-		mesh_pair_groups<64>(d, L, valid, X, mid, v3_sub(lo, es), v3_add(hi, es), q.max_separation, 0, (int)lane, 0u, dropped, V3(0.0f, 0.0f, 0.0f), false);      // (a shape query: no active-edge fixing)
+		mesh_pair_groups<64>(d, L, valid, X, mid, v3_sub(lo, es), v3_add(hi, es), q.max_separation, 0, (int)lane, 0u, dropped, V3(q.movement[0], q.movement[1], q.movement[2]), q.active_edges != 0u);      // (CharacterVirtual::GetContactsAtPosition: CollideOnlyWithActive + its direction of travel; 0: every edge with its own normal)
 		if ((int)lane < L.mc.ng) {
 			const sgd_mesh_group& grp = L.mc.g[lane];
 			sgd_manifold mm;

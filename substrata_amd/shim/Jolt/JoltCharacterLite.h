@@ -187,9 +187,15 @@ namespace JPH
 		Vec3 capsuleCentre(const Vec3& pos) const { return pos + shape->offset; }
 		bool touching(const Contact& c) const { return c.distance <= settings.mCollisionTolerance + 0.01f; }      // (what updateSupportingContact counts as a contact)
 
-		void getContacts(const Vec3& pos, uint32_t ignore, std::vector<Contact>& out) const
+		// CharacterVirtual::GetContactsAtPosition(position, movement direction, ...): CollideShape with mActiveEdgeMode = CollideOnlyWithActive and
+		// mActiveEdgeMovementDirection = the direction the character travels in, so that the seams of a triangulated floor do not stop it
+		void getContacts(const Vec3& pos, uint32_t ignore, std::vector<Contact>& out) const { getContacts(pos, ignore, out, linear_velocity); }
+		void getContacts(const Vec3& pos, uint32_t ignore, std::vector<Contact>& out, const Vec3& movement) const
 		{
 			sgp_capsule_query q;
+			const float ml = std::sqrt(movement.LengthSq());
+			q.movement[0] = ml > 0.0f ? movement.x / ml : 0.0f; q.movement[1] = ml > 0.0f ? movement.y / ml : 0.0f; q.movement[2] = ml > 0.0f ? movement.z / ml : 0.0f;
+			q.active_edges = 1;
 			const Vec3 c = capsuleCentre(pos);
 			q.pos[0] = c.x; q.pos[1] = c.y; q.pos[2] = c.z; q.rot[0] = q.rot[1] = q.rot[2] = 0; q.rot[3] = 1;
 			q.radius = shape->radius; q.half_height = shape->half_height;
@@ -301,7 +307,7 @@ namespace JPH
 			float time_remaining = dt;
 			std::vector<Contact> contacts; std::vector<Constraint> cs;
 			for (uint it = 0; it < settings.mMaxCollisionIterations && time_remaining >= settings.mMinTimeRemaining; ++it) {
-				getContacts(pos, ignore, contacts);
+				getContacts(pos, ignore, contacts, velocity);
 				cs.clear();
 				for (const Contact& c : contacts) {
 					if (notify && listener && std::find(seen_bodies.begin(), seen_bodies.end(), c.key()) == seen_bodies.end()) {

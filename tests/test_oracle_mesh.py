@@ -312,3 +312,28 @@ def test_an_active_edge_keeps_its_own_normal(oracle):
     st = w.get_state([s])[0]
     assert abs(st["pos"][0]) < 1e-3 and abs(st["pos"][2] - 0.4) < 0.02, st["pos"]
     w.close()
+
+
+def test_capsule_query_with_active_edges_sees_a_flat_floor_at_its_seam(oracle):
+    """CharacterVirtual::GetContactsAtPosition asks with mActiveEdgeMode = CollideOnlyWithActive and its direction of travel: an upright capsule standing 15 cm
+    beside the diagonal of a two-triangle floor touches the far triangle at that (inactive) edge.  With the flag the contact carries the floor's normal; without
+    it (what the query did until round 4) the normal leans back across the seam -- a slope that is not there, against which a character moving towards
+    the seam is slowed."""
+    w = oracle.OracleWorld(max_bodies=16)
+    add_mesh(w, QUAD_V, QUAD_T)
+    q = np.zeros(1, dtype=abi.capsule_query_dtype)
+    # the diagonal runs from (-10, -10) to (10, 10): the point (1.0, 1.0 - 0.2121) lies 15 cm beside it, over triangle (0, 1, 2); the other triangle's
+    # edge is 0.326 m from the centre of the capsule's lower cap (0.29 m up, 0.15 m across): inside the query's reach, 27 degrees off the vertical
+    q["pos"] = (1.0, 1.0 - 0.2121, 0.3 + 0.65 - 0.01); q["rot"] = (0, 0, 0, 1)
+    q["radius"] = 0.3; q["half_height"] = 0.65; q["max_separation"] = 0.05; q["ignore_id"] = abi.INVALID_ID
+    plain = w.collide_capsules(q)
+    assert len(plain) >= 2 and plain["normal"][:, 2].min() < 0.99                 # one of the two triangles answers with its edge's leaning normal
+    q["active_edges"] = 1; q["movement"] = (-0.7071, 0.7071, 0.0)                  # walking across the seam
+    fixed = w.collide_capsules(q)
+    assert len(fixed) == len(plain)
+    assert np.allclose(fixed["normal"], (0, 0, 1), atol=1e-6)
+    # ... and an ACTIVE edge keeps its own normal: the rim of the floor (an open edge), approached from outside
+    q["pos"] = (10.2, 0.0, 0.3 + 0.65 - 0.2); q["movement"] = (-1.0, 0.0, 0.0)
+    rim = w.collide_capsules(q)
+    assert len(rim) >= 1 and rim["normal"][:, 2].min() < 0.99
+    w.close()

@@ -54,3 +54,49 @@ def test_capsule_contacts_and_sphere_casts_match_oracle(oracle):
     both = (h0["id"] != abi.INVALID_ID) & (h3["id"] != abi.INVALID_ID)
     assert (h3["t"][both] <= h0["t"][both] + 1e-4).all()
     tw.close()
+
+
+def test_capsule_queries_on_a_mesh_with_active_edges_match_oracle(oracle):
+    """what CharacterVirtual::GetContactsAtPosition asks (CollideOnlyWithActive + the direction of travel), on a terrain mesh: the same contacts on both sides,
+    and a query standing beside a seam of a flat stretch gets the flat normal with the flag and a leaning one without"""
+    from test_mesh_parity_gpu import grid_mesh, mesh_body
+    rng = np.random.default_rng(4)
+    tw = parity.make_twin(oracle, max_bodies=64)
+    V, T = grid_mesh(25, 12.0, lambda x, y: 0.0 if abs(x) < 4 and abs(y) < 4 else 0.35 * np.sin(0.9 * x) * np.cos(0.8 * y))
+    ig, ic = tw.mesh_create(V, T)
+    tw.add_batch(mesh_body(ig))
+    n = 512
+    q = np.zeros(n, dtype=abi.capsule_query_dtype)
+    xy = rng.uniform(-10, 10, size=(n, 2))
+    h = np.where((np.abs(xy[:, 0]) < 4) & (np.abs(xy[:, 1]) < 4), 0.0, 0.35 * np.sin(0.9 * xy[:, 0]) * np.cos(0.8 * xy[:, 1]))
+    q["pos"] = np.column_stack([xy, h + 0.3 + 0.65 + rng.uniform(-0.05, 0.04, n)])
+    q["rot"] = (0, 0, 0, 1)
+    q["radius"] = 0.3; q["half_height"] = 0.65; q["max_separation"] = 0.08; q["ignore_id"] = abi.INVALID_ID; q["collidable_only"] = 1
+    mv = rng.normal(size=(n, 3)) * (1, 1, 0.2); mv /= np.linalg.norm(mv, axis=1, keepdims=True)
+    q["movement"] = mv; q["active_edges"] = 1
+    q["active_edges"][::5] = 0
+    cg, cc = tw.collide_capsules(q)
+    assert len(cg) == len(cc) and len(cg) > 300
+    assert np.array_equal(cg["query"], cc["query"]) and np.array_equal(cg["body"], cc["body"])
+    for f in ("point", "normal", "distance"):
+        assert np.array_equal(cg[f].view(np.uint32), cc[f].view(np.uint32)), f
+    # on the flat middle (vertices at whole metres: the triangles between 3 and 4 m already slope): without the flag some queries beside a seam see a
+    # leaning normal -- a slope that is not there; walking INTO that slope with the flag set, the contact carries the floor's normal
+    flat = (np.abs(q["pos"][cg["query"], 0]) < 2.5) & (np.abs(q["pos"][cg["query"], 1]) < 2.5)
+    q2 = q.copy(); q2["active_edges"] = 0
+    pg, pc = tw.collide_capsules(q2)
+    flat2 = (np.abs(q2["pos"][pg["query"], 0]) < 2.5) & (np.abs(q2["pos"][pg["query"], 1]) < 2.5)
+    leaning = flat2 & (pg["normal"][:, 2] < 0.99)
+    assert flat.sum() > 30 and leaning.sum() >= 5
+    q3 = q2[pg["query"][leaning]].copy()
+    nxy = pg["normal"][leaning].copy(); nxy[:, 2] = 0; nxy /= np.linalg.norm(nxy, axis=1, keepdims=True)
+    q3["movement"] = -nxy; q3["active_edges"] = 1
+    fg, fc = tw.collide_capsules(q3)
+    assert np.array_equal(fg["normal"].view(np.uint32), fc["normal"].view(np.uint32))
+    # (other seams around the same capsule may still answer with their own normals when the walk does not run into them: what must be gone is every normal
+    # that leans AGAINST the direction of travel -- the floor is flat)
+    against = np.einsum("ij,ij->i", fg["normal"][:, :2], q3["movement"][fg["query"], :2])
+    assert (against > -1e-4).all(), against.min()
+    before = np.einsum("ij,ij->i", pg["normal"][leaning][:, :2], -nxy[:, :2])
+    assert (before < -0.1).all()
+    tw.close()
