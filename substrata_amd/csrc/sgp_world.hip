@@ -3034,7 +3034,7 @@ static int tiles_import(sgp_tiles* t, uint32_t n)
 	if (plain) {
 		// ghosts only: the poses stay on the device -- the host compares global ids (and creates / removes the few bodies that entered or left
 		// the set), one kernel refreshes every ghost from the received records
-		bool unchanged = n == seq_before && n > 0;
+		bool unchanged = n == seq_before;            // (no ghosts before, none now: nothing for the host to do either)
 		for (uint32_t k = 0; k < n && unchanged; ++k) unchanged = t->h_recv[k].global_id == w->ghost_seq[k].first;
 		GhostDeviceSource dev = { t->d_recv, &t->d_seq_ids, &t->cap_seq, &t->ids_version };
 		{ int rc = import_ghosts_impl(w, t->h_recv, n, &dev); if (rc != SGP_OK) return rc; }
