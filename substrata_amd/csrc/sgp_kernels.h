@@ -91,7 +91,8 @@ struct StepCounters {
 	uint32_t n_active;
 	uint32_t n_read_active;
 	uint32_t n_export;
-	uint32_t n_mesh_pairs;       // pairs with a static mesh, deferred to k_narrowphase_mesh
+	uint32_t n_mesh_pairs[4];    // pairs with a static mesh, deferred to k_narrowphase_mesh: one list per shape of the other body (sphere / box / capsule / hull), so that the
+	                             // eight pairs a wave takes at a time run the same code (a sphere is tested in closed form, a box by a separating-axis search with clipping)
 	uint32_t n_mesh_big;         // ... of them with more candidate triangles than eight lanes should take (k_narrowphase_mesh<64>)
 	uint32_t hc_class[9];        // high-colour components per size class (k_hc_alloc)
 	uint32_t hc_entries;         // entries of the component list (classes padded to whole workgroups)
@@ -104,7 +105,7 @@ struct StepCounters {
 	uint32_t veh_deferred;       // vehicles that share a movable body (a dynamic body under a wheel, a chassis a wheel stands on) with a vehicle of lower index: solved after the others, in index order
 	uint32_t veh_done;           // workgroups of the running vehicle-row launch that have finished (the last one solves the deferred vehicles and clears it)
 	// in-step activation (k_wake_pairs): the pairs of the bodies this step wakes, and where the second narrow-phase round starts in the hull / mesh lists
-	uint32_t n_wake_pairs, n_woken, hull_base, mesh_base, mesh_big_base;
+	uint32_t n_wake_pairs, n_woken, hull_base, mesh_base[4], mesh_big_base;
 	uint32_t wake_any;           // some sleeping body was marked for wake-up this step (plain store of 1: k_wake_pairs has nothing to do otherwise)
 	uint32_t tickets[4];         // last_block(): workgroups of k_colour_count / k_warm_bodies / k_cache_build that have finished
 	uint32_t ts_error;           // tile solver: a tile gave up waiting for a neighbour (k_step_end copies ts_flags[0])
@@ -300,7 +301,7 @@ struct DV {
 	const struct MeshHeader* meshes; uint32_t n_meshes;
 	const float4* mesh_verts; const uint4* mesh_tris; const uint32_t* mesh_tri_mat; const struct MeshNode* mesh_nodes;     // mesh_tri_mat: user data (material index) per tree-ordered triangle
 	const LargeGrid* lgrid; const uint32_t* lg_start; const uint32_t* lg_items;      // the static large bodies' grid (cell c: items [lg_start[c], lg_start[c + 1]))
-	uint2* mesh_pairs; uint32_t cap_mesh_pairs; uint32_t* mesh_big;      // mesh_big: indices into mesh_pairs
+	uint2* mesh_pairs; uint32_t cap_mesh_pairs; uint32_t* mesh_big;      // mesh_pairs: four lists of cap_mesh_pairs each (by the other body's shape); mesh_big: indices into mesh_pairs
 	// wheeled vehicles (sgp_device_vehicle.h): AoS, one record per vehicle slot
 	struct sgd_vehicle* vehicles; uint32_t n_vehicles; const sgp_vehicle_input* vehicle_inputs;
 	// the rows of the step as the solver passes read them (k_vehicle_controller exports, veh_quad_solve consumes): 16 chunks per wheel, [chunk][4 vehicle + wheel]; 5 float4 per vehicle

@@ -906,8 +906,14 @@ template <int ROUND> SGP_DEV void narrowphase_pairs(const DV& d)
 			ab = pairs[p];
 			fa = d.flags[ab.x]; fb = d.flags[ab.y];
 			if (f_shape(fa) == SGP_SHAPE_MESH || f_shape(fb) == SGP_SHAPE_MESH) {
-				const uint32_t k = wave_alloc(&d.ctr->n_mesh_pairs);
-				if (k < d.cap_mesh_pairs) d.mesh_pairs[k] = ab; else atomicAdd(&d.ctr->pairs_dropped, 1u);
+				// (two meshes never collide: both are static or kinematic)
+				const bool mesh_a = f_shape(fa) == SGP_SHAPE_MESH, mesh_b = f_shape(fb) == SGP_SHAPE_MESH;
+				const uint32_t other = mesh_a ? f_shape(fb) : f_shape(fa);
+#pragma unroll
+				for (uint32_t t = 0; t < 4u; ++t) if (!(mesh_a && mesh_b) && other == t) {
+					const uint32_t k = wave_alloc(&d.ctr->n_mesh_pairs[t]);
+					if (k < d.cap_mesh_pairs) d.mesh_pairs[(size_t)t * d.cap_mesh_pairs + k] = ab; else atomicAdd(&d.ctr->pairs_dropped, 1u);
+				}
 			} else {
 				// the contact cache is consulted for polytope pairs only (box / hull against box / hull): their separating-axis test and clipping
 				// cost more than the gather of a cached manifold, and they are the pairs whose resting contacts a frozen manifold keeps from
@@ -969,7 +975,7 @@ __global__ void __launch_bounds__(TPB) k_wake_pairs(DV d)
 	if (i == 0) {
 		// (the narrow-phase launches that follow start behind the first round's pairs -- also in the usual step, in which nothing was woken)
 		d.ctr->hull_base = min(d.ctr->n_hull_pairs, d.cap_hull_pairs);
-		d.ctr->mesh_base = min(d.ctr->n_mesh_pairs, d.cap_mesh_pairs);
+		for (int t = 0; t < 4; ++t) d.ctr->mesh_base[t] = min(d.ctr->n_mesh_pairs[t], d.cap_mesh_pairs);
 		d.ctr->mesh_big_base = min(d.ctr->n_mesh_big, d.cap_mesh_pairs);
 	}
 	if (!d.ctr->wake_any) return;                      // (uniform)
@@ -1236,9 +1242,12 @@ template <int MESH_GROUP> __global__ void __launch_bounds__(64) k_narrowphase_me
 	__shared__ MeshPairLds<MESH_GROUP> lds[MESH_PAIRS_PER_WAVE];
 	const int grp = (int)(threadIdx.x / MESH_GROUP), sub = (int)(threadIdx.x % MESH_GROUP);
 	MeshPairLds<MESH_GROUP>& L = lds[grp];
-	const uint32_t n = MESH_GROUP == 64 ? min(d.ctr->n_mesh_big, d.cap_mesh_pairs) : min(d.ctr->n_mesh_pairs, d.cap_mesh_pairs);
 	const float max_sep = d.st.speculative_contact_distance;
-	const uint32_t base = MESH_GROUP == 64 ? d.ctr->mesh_big_base : d.ctr->mesh_base;      // (0, or where the in-step activation round's pairs begin)
+	// G = 8: the four lists one after the other (a wave's eight pairs then hold the same kind of body); G = 64: the list of the big pairs
+	for (uint32_t seg = 0; seg < (MESH_GROUP == 64 ? 1u : 4u); ++seg) {
+	const uint32_t seg0 = MESH_GROUP == 64 ? 0u : seg * d.cap_mesh_pairs;
+	const uint32_t n = seg0 + (MESH_GROUP == 64 ? min(d.ctr->n_mesh_big, d.cap_mesh_pairs) : min(d.ctr->n_mesh_pairs[seg], d.cap_mesh_pairs));
+	const uint32_t base = seg0 + (MESH_GROUP == 64 ? d.ctr->mesh_big_base : d.ctr->mesh_base[seg]);      // (0, or where the in-step activation round's pairs begin)
 	for (uint32_t p0 = base + blockIdx.x * MESH_PAIRS_PER_WAVE; p0 < n; p0 += gridDim.x * MESH_PAIRS_PER_WAVE) {
 		const uint32_t p = p0 + (uint32_t)grp;
 		bool valid = p < n;
@@ -1278,6 +1287,7 @@ template <int MESH_GROUP> __global__ void __launch_bounds__(64) k_narrowphase_me
 		}
 		if (valid && sub == 0 && dropped) atomicAdd(&d.ctr->manifolds_dropped, 1u);
 		__syncthreads();          // (the tables are reused by the next eight pairs)
+	}
 	}
 }
 

@@ -333,7 +333,7 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	d.lgrid = w->d_lgrid; d.lg_start = w->d_lg_start; d.lg_items = w->d_lg_items;
 	{ void* q = nullptr; w->cap_mesh_table = 256; HIP_TRY(hipMalloc(&q, sizeof(MeshHeader) * w->cap_mesh_table)); HIP_TRY(hipMemsetAsync(q, 0, sizeof(MeshHeader) * w->cap_mesh_table, w->stream)); w->d_meshes = (MeshHeader*)q; w->device_bytes += sizeof(MeshHeader) * w->cap_mesh_table; }
 	d.meshes = w->d_meshes; d.n_meshes = 1; w->meshes.push_back(MeshHeader{}); w->mesh_refs.push_back(0);
-	d.cap_mesh_pairs = P / 4 + 1024; DEV_ALLOC(d.mesh_pairs, d.cap_mesh_pairs); DEV_ALLOC(d.mesh_big, d.cap_mesh_pairs);
+	d.cap_mesh_pairs = P / 4 + 1024; DEV_ALLOC(d.mesh_pairs, 4 * (size_t)d.cap_mesh_pairs); DEV_ALLOC(d.mesh_big, d.cap_mesh_pairs);      // (four lists: one per shape of the other body)
 	{ void* q = nullptr; w->cap_hull_table = 64; HIP_TRY(hipMalloc(&q, sizeof(sgd_hull) * w->cap_hull_table)); HIP_TRY(hipMemsetAsync(q, 0, sizeof(sgd_hull) * w->cap_hull_table, w->stream)); w->d_hulls = (sgd_hull*)q; w->device_bytes += sizeof(sgd_hull) * w->cap_hull_table; }
 	d.hulls = w->d_hulls;
 	d.cap_hull_pairs = P / 4 + 1024; DEV_ALLOC(d.hull_pairs, d.cap_hull_pairs);

@@ -47,6 +47,8 @@ def small_bodies_on_terrain(n):
     w.add_batch(mesh_body(info.mesh_id))
     d = scenes.dynamic_bodies(n)
     kinds = rng.integers(0, 3, size=n)
+    import os
+    if os.environ.get("MESH_BENCH_KIND"): kinds[:] = int(os.environ["MESH_BENCH_KIND"])      # all spheres (0) / boxes (1) / capsules (2): what each kind costs
     d["shape_type"] = kinds
     d["shape"][:, :3] = 0.4
     d["shape"][kinds == 2, 1] = 0.5; d["shape"][kinds == 2, 0] = 0.25
