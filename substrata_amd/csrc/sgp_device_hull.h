@@ -61,16 +61,18 @@ template <class HV> SGP_DEV static float sgd_hv_proj_max(const HV* v, v3 w)
 }
 
 // Clip a world-space polygon against the half space (p - a) . side <= 0.
-SGP_DEV static int sgd_hull_clip(const v3* in, int n, v3 a, v3 side, v3* out)
+// (CAP: room in `out` -- SGD_HULL_CLIP_CAP in general; 8 where one of the two faces is a triangle and the other a triangle or a quad: a clip plane adds at
+// most one vertex, so 3 + 4 or 4 + 3 never reach 8 and the smaller buffers hold the very same polygons)
+template <int CAP = SGD_HULL_CLIP_CAP> SGP_DEV static int sgd_hull_clip(const v3* in, int n, v3 a, v3 side, v3* out)
 {
 	int m = 0;
 	for (int i = 0; i < n; ++i) {
 		const v3 p = in[i], q = in[(i + 1) % n];
 		const float dp = v3_dot(v3_sub(p, a), side), dq = v3_dot(v3_sub(q, a), side);
-		if (dp <= 0.0f) { if (m < SGD_HULL_CLIP_CAP) out[m++] = p; }
+		if (dp <= 0.0f) { if (m < CAP) out[m++] = p; }
 		if ((dp <= 0.0f) != (dq <= 0.0f)) {
 			const float t = dp / (dp - dq);
-			if (m < SGD_HULL_CLIP_CAP) out[m++] = v3_add(p, v3_scale(v3_sub(q, p), t));
+			if (m < CAP) out[m++] = v3_add(p, v3_scale(v3_sub(q, p), t));
 		}
 	}
 	return m;
@@ -168,7 +170,9 @@ template <class HA, class HB> SGP_DEV static int sgd_hull_axis_edge(const HA* A,
 }
 
 // Sequential search (first maximum wins).  Returns 0 when some axis separates the hulls by more than max_sep.
-template <class HA, class HB> SGP_DEV static int sgd_hull_sat_search(const HA* A, const HB* B, float max_sep, sgd_hull_sat* r)
+// (DIRCACHE = false: the caller knows that neither hull is the cube template -- a mesh triangle against a convex hull -- and the instance carries neither
+// the branch below nor its 720 bytes of tables)
+template <bool DIRCACHE = true, class HA, class HB> SGP_DEV static int sgd_hull_sat_search(const HA* A, const HB* B, float max_sep, sgd_hull_sat* r)
 {
 	r->sA = -3.4e38f; r->sB = -3.4e38f; r->sE = -3.4e38f; r->fA = 0; r->fB = 0; r->eA = -1; r->eB = -1; r->nE = V3(0, 0, 0);
 	for (int f = 0; f < A->h->nf; ++f) {
@@ -183,7 +187,7 @@ template <class HA, class HB> SGP_DEV static int sgd_hull_sat_search(const HA* A
 	}
 	const v3 T = v3_sub(B->pos, A->pos);
 	const int boxA = A->h->is_box_template, boxB = B->h->is_box_template;
-	if ((boxA || A->h->ne <= 3) && (boxB || B->h->ne <= 3) && (boxA || boxB)) {
+	if (DIRCACHE && (boxA || A->h->ne <= 3) && (boxB || B->h->ne <= 3) && (boxA || boxB)) {
 		/* A cube's twelve edges have three directions: the axis of an edge pair and the separation along it are those of the pair of DIRECTIONS
 		   (parallel edges running the same way give the same cross product), so they are evaluated once per direction pair -- nine times for a box
 		   against a triangle instead of 36 -- and only whether THIS pair of edges supports the two hulls along
@@ -233,13 +237,13 @@ template <class HA, class HB> SGP_DEV static int sgd_hull_sat_search(const HA* A
 
 // Face contact: reference hull X owns the axis (its face fX), the most anti-parallel face of Y is clipped against X's face.  x_is_a: X is the
 // pair's first hull (the manifold's normal runs from the first to the second).
-template <class HX, class HY> SGP_DEV static int sgd_hull_face_contact(const HX* X, const HY* Y, int fX, int x_is_a, float max_sep, sgd_manifold* m)
+template <int CAP = SGD_HULL_CLIP_CAP, class HX, class HY> SGP_DEV static int sgd_hull_face_contact(const HX* X, const HY* Y, int fX, int x_is_a, float max_sep, sgd_manifold* m)
 {
 	const int refA = x_is_a;
 	const v3 nref = sgd_hv_normal(X, fX);
 	int fY = 0; float bestd = 3.4e38f;
 	for (int f = 0; f < Y->h->nf; ++f) { const float d = v3_dot(nref, sgd_hv_normal(Y, f)); if (d < bestd) { bestd = d; fY = f; } }
-	v3 poly[SGD_HULL_CLIP_CAP], tmp[SGD_HULL_CLIP_CAP];
+	v3 poly[CAP], tmp[CAP];
 	int np = 0;
 	for (int k = Y->h->face_start[fY]; k < Y->h->face_start[fY + 1]; ++k) poly[np++] = sgd_hv_world(Y, Y->h->face_idx[k]);
 	const int x0 = X->h->face_start[fX], x1 = X->h->face_start[fX + 1];
@@ -247,11 +251,11 @@ template <class HX, class HY> SGP_DEV static int sgd_hull_face_contact(const HX*
 		const v3 a = sgd_hv_world(X, X->h->face_idx[k]);
 		const v3 b = sgd_hv_world(X, X->h->face_idx[k + 1 < x1 ? k + 1 : x0]);
 		const v3 side = v3_cross(v3_sub(b, a), nref);
-		np = sgd_hull_clip(poly, np, a, side, tmp);
+		np = sgd_hull_clip<CAP>(poly, np, a, side, tmp);
 		for (int i = 0; i < np; ++i) poly[i] = tmp[i];
 	}
 	const float off = v3_dot(nref, X->pos) + sgd_hv_plane_d(X, fX);
-	v3 q1[SGD_HULL_CLIP_CAP], q2[SGD_HULL_CLIP_CAP];
+	v3 q1[CAP], q2[CAP];
 	int cnt = 0;
 	for (int i = 0; i < np; ++i) {
 		const float sep = v3_dot(nref, poly[i]) - off;
@@ -277,7 +281,7 @@ template <class HX, class HY> SGP_DEV static int sgd_hull_face_contact(const HX*
 }
 
 // Manifold from the result of the search.  Normal from A to B.
-template <class HA, class HB> SGP_DEV static int sgd_hull_manifold(const HA* A, const HB* B, float max_sep, const sgd_hull_sat* r, sgd_manifold* m)
+template <int CAP = SGD_HULL_CLIP_CAP, class HA, class HB> SGP_DEV static int sgd_hull_manifold(const HA* A, const HB* B, float max_sep, const sgd_hull_sat* r, sgd_manifold* m)
 {
 	const float sA = r->sA, sB = r->sB, sE = r->sE; const int fA = r->fA, fB = r->fB, eA = r->eA, eB = r->eB; const v3 nE = r->nE;
 	const float sF = fmaxf(sA, sB);
@@ -292,9 +296,9 @@ template <class HA, class HB> SGP_DEV static int sgd_hull_manifold(const HA* A, 
 	if constexpr (std::is_same<HA, HB>::value) {
 		// one call for both roles (two would be two copies of the clipping code, and the lanes of a wave that disagree about the reference hull would run both)
 		const HA* X = refA ? A : B; const HA* Y = refA ? B : A;
-		return sgd_hull_face_contact(X, Y, refA ? fA : fB, refA, max_sep, m);
+		return sgd_hull_face_contact<CAP>(X, Y, refA ? fA : fB, refA, max_sep, m);
 	} else {
-		return refA ? sgd_hull_face_contact(A, B, fA, 1, max_sep, m) : sgd_hull_face_contact(B, A, fB, 0, max_sep, m);
+		return refA ? sgd_hull_face_contact<CAP>(A, B, fA, 1, max_sep, m) : sgd_hull_face_contact<CAP>(B, A, fB, 0, max_sep, m);
 	}
 }
 

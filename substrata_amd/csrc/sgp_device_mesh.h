@@ -90,8 +90,7 @@ SGP_DEV static void sgd_mesh_add(sgd_mesh_contacts* mc, const sgd_manifold* m)
 	}
 }
 
-// X against one triangle (world-space view T of its thin hull, world normal nt).  Normal of the result: triangle -> X.
-// edges: the triangle's active-edge bits (7: no fixing, e.g. a shape query), movement: X's velocity relative to the mesh.
+// does the active-edge rule replace the normal of manifold m (X against triangle T, world normal nt) by the triangle's?
 SGP_DEV static bool sgd_tri_needs_face_normal(const sgd_tri_view* T, v3 nt, unsigned edges, v3 movement, const sgd_manifold* m)
 {
 	if (edges == 7u || m->np <= 0) return false;
@@ -100,11 +99,147 @@ SGP_DEV static bool sgd_tri_needs_face_normal(const sgd_tri_view* T, v3 nt, unsi
 	for (int i = 0; i < m->np; ++i) { const float dd = v3_dot(v3_sub(m->p1[i], m->p2[i]), m->n); if (dd > bd) { bd = dd; bi = i; } }
 	return sgd_active_edge_fix(sgd_hv_world(T, 0), sgd_hv_world(T, 1), sgd_hv_world(T, 2), nt, edges, m->p1[bi], m->n, movement) != 0;
 }
-SGP_DEV static int sgd_collide_tri(const sgd_shape* X, const sgd_tri_view* T, v3 nt, float max_sep, sgd_manifold* m, unsigned edges, v3 movement)
+// ---- a mesh triangle against a BOX: the separating-axis search of sgd_hull_sat_search(T, box) in closed form ----------------------------
+// The general search walks the cube template like any hull: eight corners per projection, tables of direction pairs indexed at run time (720 B of
+// scratch memory per lane), twelve edges.  For the +-1 cube scaled by the half extents every one of those sums has a closed form with THE SAME BITS:
+//   min over the corners of  l . (+-sx, +-sy, +-sz)  =  -((|l.x sx| + |l.y sy|) + |l.z sz|)
+// (a product with a negated factor is the negated product, a sum of negated terms the negated sum, and rounding is monotonic -- so the all-negative corner
+// is the minimum of the eight rounded sums, whichever corner the loop met first), and an edge pair's axis depends only on the DIRECTION of the cube edge:
+// the twelve edges are 3 directions x 2 senses, the sense only decides which of +-axis survives the "points from the triangle to the box" flip -- the same
+// axis either way unless axis . T is exactly zero, which is kept apart below.  What remains per edge pair is the supporting test and "first maximum wins"
+// in the template's edge order, which is read from the template (sgd_box_code_of), not assumed.
+struct sgd_box_code { uint64_t bits; };      // per cube edge j five bits: direction k 0..2 | sense << 2 | (corner a negative along the two other axes (k + 1) % 3, (k + 2) % 3) << 3
+SGP_DEV static sgd_box_code sgd_box_code_of(const sgd_hull* t)
 {
-	if (X->type == SGD_SHAPE_SPHERE || X->type == SGD_SHAPE_CAPSULE) {
+	sgd_box_code c; c.bits = 0ull;
+#pragma unroll
+	for (int j = 0; j < 12; ++j) {
+		const v3 va = t->verts[t->edge_a[j]], vb = t->verts[t->edge_b[j]];
+		const v3 e = v3_sub(vb, va);
+		const uint32_t cb = e.x != 0.0f ? (e.x < 0.0f ? 1u : 0u) : (e.y != 0.0f ? (e.y < 0.0f ? 3u : 2u) : (e.z < 0.0f ? 5u : 4u));      // (the classes of sgd_hull_sat_search)
+		const uint32_t k = cb >> 1;
+		// (along k itself the edge starts at -1 when it runs the positive way and at +1 otherwise: the sense says it)
+		const float u = k == 0u ? va.y : (k == 1u ? va.z : va.x), v = k == 0u ? va.z : (k == 1u ? va.x : va.y);
+		const uint64_t five = k | ((cb & 1u) << 2) | ((u < 0.0f ? 1u : 0u) << 3) | ((v < 0.0f ? 1u : 0u) << 4);
+		c.bits |= five << (5 * j);
+	}
+	return c;
+}
+// sgd_hv_proj_min / max of the scaled cube along the world direction w
+SGP_DEV static float sgd_box_proj_min(const sgd_hview* B, v3 w)
+{
+	const v3 l = m33_tmul(B->R, w);
+	return v3_dot(w, B->pos) + -((fabsf(l.x * B->scale.x) + fabsf(l.y * B->scale.y)) + fabsf(l.z * B->scale.z));
+}
+// ... and of the triangle (its three corners relative to the centroid, mesh frame: the thin hull's vertices, held in registers)
+struct sgd_tri_corners { v3 v0, v1, v2; };
+SGP_DEV static float sgd_tri_proj_min(const sgd_tri_view* T, const sgd_tri_corners& c, v3 w)
+{
+	const v3 l = m33_tmul(T->R, w);
+	float best = 3.4e38f;
+	{ const float d = v3_dot(l, c.v0); if (d < best) best = d; }
+	{ const float d = v3_dot(l, c.v1); if (d < best) best = d; }
+	{ const float d = v3_dot(l, c.v2); if (d < best) best = d; }
+	return v3_dot(w, T->pos) + best;
+}
+SGP_DEV static float sgd_tri_proj_max(const sgd_tri_view* T, const sgd_tri_corners& c, v3 w)
+{
+	const v3 l = m33_tmul(T->R, w);
+	float best = -3.4e38f;
+	{ const float d = v3_dot(l, c.v0); if (d > best) best = d; }
+	{ const float d = v3_dot(l, c.v1); if (d > best) best = d; }
+	{ const float d = v3_dot(l, c.v2); if (d > best) best = d; }
+	return v3_dot(w, T->pos) + best;
+}
+// = sgd_hull_sat_search(T, B, max_sep, r) for B = the cube template scaled (B->h->is_box_template)
+SGP_DEV static int sgd_tri_box_sat(const sgd_tri_view* T, const sgd_hview* B, const sgd_box_code& code, float max_sep, sgd_hull_sat* r)
+{
+	r->sA = -3.4e38f; r->sB = -3.4e38f; r->sE = -3.4e38f; r->fA = 0; r->fB = 0; r->eA = -1; r->eB = -1; r->nE = V3(0, 0, 0);
+	sgd_tri_corners tc; tc.v0 = T->h->verts[0]; tc.v1 = T->h->verts[1]; tc.v2 = T->h->verts[2];
+	// the triangle's two faces (n, -n)
+#pragma unroll
+	for (int f = 0; f < 2; ++f) {
+		const v3 n = m33_mul(T->R, T->h->normals[f]);
+		const float s = sgd_box_proj_min(B, n) - (v3_dot(n, T->pos) + T->h->plane_d[f]);
+		if (s > max_sep) return 0;
+		if (s > r->sA) { r->sA = s; r->fA = f; }
+	}
+	// the cube's six faces, in the template's order
+	for (int f = 0; f < 6; ++f) {
+		const v3 nl = B->h->normals[f];
+		const v3 n = m33_mul(B->R, nl);
+		const float pd = fabsf(nl.x) * B->scale.x + fabsf(nl.y) * B->scale.y + fabsf(nl.z) * B->scale.z;
+		const float s = sgd_tri_proj_min(T, tc, n) - (v3_dot(n, B->pos) + pd);
+		if (s > max_sep) return 0;
+		if (s > r->sB) { r->sB = s; r->fB = f; }
+	}
+	const v3 Tv = v3_sub(B->pos, T->pos);
+	// the triangle's corners in the world (sgd_hv_world with scale 1) -- edge i starts at corner (0, 1, 0)[i] and ends at (1, 2, 2)[i] (sgd_tri_hull)
+	const v3 w0 = v3_add(T->pos, m33_mul(T->R, tc.v0)), w1 = v3_add(T->pos, m33_mul(T->R, tc.v1));
+#pragma unroll 1
+	for (int i = 0; i < 3; ++i) {
+		const v3 la = i == 1 ? tc.v1 : tc.v0, lb = i == 0 ? tc.v1 : tc.v2;
+		const v3 da = m33_mul(T->R, v3_sub(lb, la));
+		const v3 a0 = i == 1 ? w1 : w0;
+		const float da2 = v3_len_sq(da);
+		// per direction k of the cube: parallel?, the axis and the separation for an edge running the positive way (sense 0) and the negative way (sense 1)
+		bool par[3]; v3 axp[3], axn[3]; float sp[3], sn[3];
+#pragma unroll
+		for (int k = 0; k < 3; ++k) {
+			// the edge vector of a cube edge of direction k as sgd_hv_local(b) - sgd_hv_local(a) gives it: (+s) - (-s) along k for the positive sense, (-s) - (+s)
+			// for the negative one, s - s = +0 elsewhere; each sense goes through the general expressions on its own (the results are each other's negation
+			// wherever they are not zero, and the flip below makes them the same vector -- but a zero component keeps the sign its own sums give it)
+			const float sk = k == 0 ? B->scale.x : (k == 1 ? B->scale.y : B->scale.z);
+			const float ep = 1.0f * sk - -1.0f * sk, en = -1.0f * sk - 1.0f * sk;
+			const v3 dbp = m33_mul(B->R, V3(k == 0 ? ep : 0.0f, k == 1 ? ep : 0.0f, k == 2 ? ep : 0.0f));
+			const v3 dbn = m33_mul(B->R, V3(k == 0 ? en : 0.0f, k == 1 ? en : 0.0f, k == 2 ? en : 0.0f));
+			v3 ap = v3_cross(da, dbp), an = v3_cross(da, dbn);
+			const float l2 = v3_len_sq(ap);
+			par[k] = l2 < 1.0e-6f * da2 * v3_len_sq(dbp);
+			ap = v3_scale(ap, 1.0f / sqrtf(l2)); an = v3_scale(an, 1.0f / sqrtf(v3_len_sq(an)));
+			const float t0 = v3_dot(ap, Tv);
+			axp[k] = t0 < 0.0f ? v3_neg(ap) : ap;
+			axn[k] = v3_dot(an, Tv) < 0.0f ? v3_neg(an) : an;
+			sp[k] = 0.0f; sn[k] = 0.0f;
+			if (!par[k]) {
+				sp[k] = sgd_box_proj_min(B, axp[k]) - sgd_tri_proj_max(T, tc, axp[k]);
+				// (t0 != 0: both senses end at the same vector, zero signs apart, and the separation along it is the same number; t0 = +-0: neither is turned, the
+				// two axes are opposite and each has its own separation)
+				sn[k] = (t0 < 0.0f || t0 > 0.0f) ? sp[k] : sgd_box_proj_min(B, axn[k]) - sgd_tri_proj_max(T, tc, axn[k]);
+			}
+		}
+#pragma unroll 1
+		for (int j = 0; j < 12; ++j) {
+			const uint32_t five = (uint32_t)(code.bits >> (5 * j)) & 31u;
+			const uint32_t k = five & 3u; const bool neg = (five & 4u) != 0u;
+			const bool pk = k == 0u ? par[0] : (k == 1u ? par[1] : par[2]);
+			if (pk) continue;
+			const v3 ax = neg ? (k == 0u ? axn[0] : (k == 1u ? axn[1] : axn[2])) : (k == 0u ? axp[0] : (k == 1u ? axp[1] : axp[2]));
+			const float s = neg ? (k == 0u ? sn[0] : (k == 1u ? sn[1] : sn[2])) : (k == 0u ? sp[0] : (k == 1u ? sp[1] : sp[2]));
+			if (s > max_sep) return 0;
+			// the cube corner the edge starts at (sgd_hv_world: the template's +-1 times the half extents)
+			const float ck = neg ? 1.0f : -1.0f, cu = (five & 8u) ? -1.0f : 1.0f, cv = (five & 16u) ? -1.0f : 1.0f;
+			const v3 cs = k == 0u ? V3(ck, cu, cv) : (k == 1u ? V3(cv, ck, cu) : V3(cu, cv, ck));
+			const v3 lc = V3(cs.x * B->scale.x, cs.y * B->scale.y, cs.z * B->scale.z);
+			const v3 b0 = v3_add(B->pos, m33_mul(B->R, lc));
+			const float s_edge = v3_dot(ax, b0) - v3_dot(ax, a0);
+			const int sup = !(s_edge - s > 1.0e-4f);
+			if (s > r->sE && sup) { r->sE = s; r->eA = i; r->eB = j; r->nE = ax; }
+		}
+	}
+	return 1;
+}
+
+// X against one triangle (world-space view T of its thin hull, world normal nt).  Normal of the result: triangle -> X.
+// edges: the triangle's active-edge bits (7: no fixing, e.g. a shape query), movement: X's velocity relative to the mesh.
+// KINDS: the shapes X can be (bit SGD_SHAPE_*): an instance for spheres, boxes and capsules carries nothing of the general hull search.
+#define SGD_KINDS_ALL 15
+#define SGD_KINDS_PRIMITIVES 7      // sphere | box | capsule
+template <int KINDS = SGD_KINDS_ALL> SGP_DEV static int sgd_collide_tri(const sgd_shape* X, const sgd_tri_view* T, v3 nt, float max_sep, sgd_manifold* m, unsigned edges, v3 movement, const sgd_box_code* code = nullptr)
+{
+	if ((KINDS & 5) && (X->type == SGD_SHAPE_SPHERE || X->type == SGD_SHAPE_CAPSULE)) {
 		int hit;
-		if (X->type == SGD_SHAPE_SPHERE) hit = sgd_hull_sphere(T, X->pos, X->p0, max_sep, m);
+		if ((KINDS & 1) && (!(KINDS & 4) || X->type == SGD_SHAPE_SPHERE)) hit = sgd_hull_sphere(T, X->pos, X->p0, max_sep, m);
 		else {
 			const v3 ax = v3_scale(m33_col(X->R, 2), X->p1);
 			hit = sgd_hull_capsule(T, v3_sub(X->pos, ax), v3_add(X->pos, ax), X->p0, max_sep, m);
@@ -114,15 +249,20 @@ SGP_DEV static int sgd_collide_tri(const sgd_shape* X, const sgd_tri_view* T, v3
 		if (sgd_tri_needs_face_normal(T, nt, edges, movement, m)) m->n = nt;      // (active edges: the points stay, the direction changes)
 		return 1;
 	}
+	if (!(KINDS & 10)) return 0;
 	sgd_hview hx;
 	hx.pos = X->pos; hx.R = X->R; hx.h = X->hull;
 	hx.scale = X->type == SGD_SHAPE_BOX ? V3(X->p0, X->p1, X->p2) : V3(1.0f, 1.0f, 1.0f);
 	sgd_hull_sat r;
-	if (!sgd_hull_sat_search(T, &hx, max_sep, &r)) return 0;
+	if constexpr ((KINDS & 2) && !(KINDS & 8)) { if (!sgd_tri_box_sat(T, &hx, *code, max_sep, &r)) return 0; }      // a box, and the caller brought the template's edge code
+	else if constexpr (!(KINDS & 2)) { if (!sgd_hull_sat_search<false>(T, &hx, max_sep, &r)) return 0; }      // a convex hull, never the cube template
+	else if (X->type == SGD_SHAPE_BOX && code) { if (!sgd_tri_box_sat(T, &hx, *code, max_sep, &r)) return 0; }
+	else if (!sgd_hull_sat_search(T, &hx, max_sep, &r)) return 0;
 	// ONE call site for the manifold (its clip polygons are a kilobyte of scratch per inlined copy): the second turn of the loop is the active-edge
 	// rule's -- the contact as the triangle's FACE makes it (reference face = the triangle's front, clipped incident face of X)
 	for (int turn = 0; turn < 2; ++turn) {
-		if (!sgd_hull_manifold(T, &hx, max_sep, &r, m)) return 0;
+		if (KINDS & 8) { if (!sgd_hull_manifold(T, &hx, max_sep, &r, m)) return 0; }
+		else { if (!sgd_hull_manifold<8>(T, &hx, max_sep, &r, m)) return 0; }      // (a triangle and a quad: no polygon beyond seven corners)
 		if (turn == 1) break;
 		if (v3_dot(m->n, nt) < 0.0f) return 0;                   // reached from the back side
 		if (!sgd_tri_needs_face_normal(T, nt, edges, movement, m)) break;

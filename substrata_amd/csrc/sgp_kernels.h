@@ -334,7 +334,7 @@ void launch_narrowphase(const DV& d, uint32_t n_pairs_upper, hipStream_t s);
 void launch_cache_wipe(const DV& d, hipStream_t s);
 void launch_wake_round(const DV& d, uint32_t nb, bool has_hulls, bool has_meshes, hipStream_t s);      // in-step activation: k_wake_pairs + the narrow phase of its pairs
 void launch_narrowphase_hull(const DV& d, hipStream_t s);     // only worlds with hull shapes
-void launch_narrowphase_mesh(const DV& d, hipStream_t s);     // only worlds with mesh shapes
+void launch_narrowphase_mesh(const DV& d, bool has_hulls, hipStream_t s);     // only worlds with mesh shapes; has_hulls: also the instances for hull bodies
 void launch_colour_inherit(const DV& d, uint32_t n_man, hipStream_t s);
 void launch_colour_claim(const DV& d, uint32_t n_man, uint32_t round, hipStream_t s);
 void launch_colour_commit(const DV& d, uint32_t n_man, uint32_t round, hipStream_t s);

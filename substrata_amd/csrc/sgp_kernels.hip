@@ -1057,7 +1057,7 @@ SGP_DEV int mesh_candidates(const DV& d, const MeshHeader& mh, v3 llo, v3 lhi, u
 
 // X against mesh body M: every triangle whose world bounds come within max_sep of [lo, hi], in index order, manifolds grouped by normal.
 // Returns the number of groups (manifolds mesh -> X).  Sequential (one thread).
-SGP_DEV int collide_with_mesh(const DV& d, uint32_t mbody, const sgd_shape& X, v3 lo, v3 hi, float max_sep, sgd_manifold* out, bool* dropped)
+SGP_DEV int collide_with_mesh(const DV& d, uint32_t mbody, const sgd_shape& X, v3 lo, v3 hi, float max_sep, sgd_manifold* out, bool* dropped)      // (X: a capsule)
 {
 	const float4 msh = d.prop[2 * (size_t)mbody + 1];
 	const MeshHeader mh = d.meshes[(uint32_t)msh.x];
@@ -1087,7 +1087,7 @@ SGP_DEV int collide_with_mesh(const DV& d, uint32_t mbody, const sgd_shape& X, v
 		sgd_tri_hull(a, b, c, &th, &cen, &n);
 		sgd_tri_view T; T.pos = v3_add(mpos, m33_mul(R, cen)); T.R = R; T.scale = V3(1.0f, 1.0f, 1.0f); T.h = &th;
 		sgd_manifold m;
-		if (sgd_collide_tri(&X, &T, m33_mul(R, n), max_sep, &m, 7u, V3(0.0f, 0.0f, 0.0f))) sgd_mesh_add(&mc, &m);      // (a shape query: no active-edge fixing)
+		if (sgd_collide_tri<4>(&X, &T, m33_mul(R, n), max_sep, &m, 7u, V3(0.0f, 0.0f, 0.0f))) sgd_mesh_add(&mc, &m);      // (a shape query: no active-edge fixing; X is the character's capsule)
 	}
 	return sgd_mesh_finish(&mc, out);
 }
@@ -1135,7 +1135,8 @@ SGP_DEV int mesh_candidates_found(const DV& d, const MeshHeader& mh, v3 llo, v3 
 // The groups of one (body X, mesh body mid) pair by the lanes of its group (whole workgroup: every lane calls this; lanes of a group pass the same
 // pair): what lies between "here is the pair" and "here are its <= 3 groups in L.mc".  valid: false for a group without a pair, and false on return
 // when the pair was handed to the wave-per-pair launch (pair = its index in mesh_pairs; G = 8 only).  [qlo, qhi]: X's bounds grown by max_sep.
-template <int MESH_GROUP> SGP_DEV void mesh_pair_groups(const DV& d, MeshPairLds<MESH_GROUP>& L, bool& valid, sgd_shape& X, uint32_t mid, v3 qlo, v3 qhi, float max_sep, int grp, int sub, uint32_t pair, bool& dropped, v3 movement, bool active_edges = true)
+// KINDS: what X can be (bits of SGD_SHAPE_*, sgd_collide_tri): an instance for the primitives carries nothing of the general hull search, one for hulls nothing of the box's.
+template <int MESH_GROUP, int KINDS = SGD_KINDS_ALL> SGP_DEV void mesh_pair_groups(const DV& d, MeshPairLds<MESH_GROUP>& L, bool& valid, sgd_shape& X, uint32_t mid, v3 qlo, v3 qhi, float max_sep, int grp, int sub, uint32_t pair, bool& dropped, v3 movement, bool active_edges = true)
 {
 	MeshHeader mh; v3 mpos = V3(0.0f, 0.0f, 0.0f); m33 R = quat_to_m33(Q4(make_float4(0.0f, 0.0f, 0.0f, 1.0f)));
 	int nc = 0;
@@ -1209,34 +1210,70 @@ template <int MESH_GROUP> SGP_DEV void mesh_pair_groups(const DV& d, MeshPairLds
 		L.cand[rank] = L.found[i];
 	}
 	__syncthreads();
+	// A round lasts as long as its slowest lane, and a lane whose triangle's own bounds miss the body's is done at once while its neighbour clips polygons: the
+	// candidates of a tree leaf are mostly such misses (a 0.4 m box on a terrain: 8 - 32 candidates, 2 - 6 of them near it -- four rounds of which three held one
+	// real test among their 64 lanes).  So the cheap bounds test runs first, over all candidates, and the survivors are packed (order kept: the merge below
+	// depends on it, the set of hits does not) -- the rounds then hold real tests only.  L.key is free after the sort and takes the packed list.
+	{
+		int pre = (nc + MESH_GROUP - 1) / MESH_GROUP;
+#pragma unroll
+		for (int off = 32; off >= 1; off >>= 1) pre = max(pre, __shfl_xor(pre, off, 64));
+		int kept = 0;
+		for (int rd = 0; rd < pre; ++rd) {
+			const int k = rd * MESH_GROUP + sub;
+			bool keep = false; uint32_t cand_k = 0u;
+			if (valid && k < nc) {
+				cand_k = L.cand[k];
+				const uint4 tri = d.mesh_tris[mh.tri_off + cand_k];
+				const v3 a = V3(d.mesh_verts[mh.vert_off + tri.x]), b = V3(d.mesh_verts[mh.vert_off + tri.y]), c = V3(d.mesh_verts[mh.vert_off + tri.z]);
+				const v3 wa = v3_add(mpos, m33_mul(R, a)), wb = v3_add(mpos, m33_mul(R, b)), wc = v3_add(mpos, m33_mul(R, c));
+				const v3 tmin = V3(fminf(fminf(wa.x, wb.x), wc.x), fminf(fminf(wa.y, wb.y), wc.y), fminf(fminf(wa.z, wb.z), wc.z));
+				const v3 tmax = V3(fmaxf(fmaxf(wa.x, wb.x), wc.x), fmaxf(fmaxf(wa.y, wb.y), wc.y), fmaxf(fmaxf(wa.z, wb.z), wc.z));
+				keep = !(tmax.x < qlo.x || tmin.x > qhi.x || tmax.y < qlo.y || tmin.y > qhi.y || tmax.z < qlo.z || tmin.z > qhi.z);
+			}
+			const unsigned long long all = __ballot(keep);
+			const unsigned long long mine_m = MESH_GROUP == 64 ? all : ((all >> (grp * MESH_GROUP)) & ((1ull << (MESH_GROUP & 63)) - 1ull));
+			if (keep) L.key[kept + __popcll(mine_m & ((1ull << sub) - 1ull))] = cand_k;
+			kept += __popcll(mine_m);
+		}
+		__syncthreads();
+		nc = valid ? kept : 0;
+	}
 	int rounds = (nc + MESH_GROUP - 1) / MESH_GROUP;
 #pragma unroll
 	for (int off = 32; off >= 1; off >>= 1) rounds = max(rounds, __shfl_xor(rounds, off, 64));
+	// a box: the order and corners of the cube template's edges, read once (the closed-form separating-axis search of sgd_tri_box_sat)
+	sgd_box_code box_code; box_code.bits = 0ull;
+	if ((KINDS & 2) && valid && X.type == SGD_SHAPE_BOX) box_code = sgd_box_code_of(&d.hulls[0]);
 	for (int rd = 0; rd < rounds; ++rd) {
 		const int k = rd * MESH_GROUP + sub;
 		bool hit = false; sgd_manifold m;
 		if (valid && k < nc) {
-			const uint4 tri = d.mesh_tris[mh.tri_off + L.cand[k]];
+			const uint4 tri = d.mesh_tris[mh.tri_off + L.key[k]];      // (the packed list: every entry passed the bounds test)
 			const v3 a = V3(d.mesh_verts[mh.vert_off + tri.x]), b = V3(d.mesh_verts[mh.vert_off + tri.y]), c = V3(d.mesh_verts[mh.vert_off + tri.z]);
-			const v3 wa = v3_add(mpos, m33_mul(R, a)), wb = v3_add(mpos, m33_mul(R, b)), wc = v3_add(mpos, m33_mul(R, c));
-			const v3 tmin = V3(fminf(fminf(wa.x, wb.x), wc.x), fminf(fminf(wa.y, wb.y), wc.y), fminf(fminf(wa.z, wb.z), wc.z));
-			const v3 tmax = V3(fmaxf(fmaxf(wa.x, wb.x), wc.x), fmaxf(fmaxf(wa.y, wb.y), wc.y), fmaxf(fmaxf(wa.z, wb.z), wc.z));
-			if (!(tmax.x < qlo.x || tmin.x > qhi.x || tmax.y < qlo.y || tmin.y > qhi.y || tmax.z < qlo.z || tmin.z > qhi.z)) {
+			{
 				sgd_tri_hull_t th; v3 cen, nrm;
 				sgd_tri_hull(a, b, c, &th, &cen, &nrm);
 				sgd_tri_view T; T.pos = v3_add(mpos, m33_mul(R, cen)); T.R = R; T.scale = V3(1.0f, 1.0f, 1.0f); T.h = &th;
-				hit = sgd_collide_tri(&X, &T, m33_mul(R, nrm), max_sep, &m, active_edges ? MESH_TRI_EDGES(tri.w) : 7u, movement) != 0;
+				hit = sgd_collide_tri<KINDS>(&X, &T, m33_mul(R, nrm), max_sep, &m, active_edges ? MESH_TRI_EDGES(tri.w) : 7u, movement, (KINDS & 2) ? &box_code : nullptr) != 0;
 			}
 		}
-		// the hits of this round into the pair's groups, in candidate order
-		for (int t = 0; t < MESH_GROUP; ++t) {
+		// the hits of this round into the pair's groups, in candidate order: one turn per lane position that holds a hit in some group of the wave
+		unsigned long long turns = __ballot(hit);
+		if (MESH_GROUP == 8) { turns |= turns >> 32; turns |= turns >> 16; turns |= turns >> 8; turns &= 0xFFull; }
+		while (turns) {
+			const int t = __ffsll((long long)turns) - 1;
+			turns &= turns - 1ull;
 			if (hit && sub == t) sgd_mesh_add(&L.mc, &m);
 			__syncthreads();
 		}
 	}
 }
 
-template <int MESH_GROUP> __global__ void __launch_bounds__(64) k_narrowphase_mesh(DV d)
+// KINDS: the shapes of the other body this instance serves (bits of SGD_SHAPE_*).  Two instances per group size: the primitives (spheres, boxes with the
+// closed-form separating-axis search, capsules -- no general hull code, a fraction of the registers and scratch) and the convex hulls; the second one is
+// launched only in worlds that have hulls.  G = 8 takes the lists of its kinds; G = 64 walks the one list of big pairs and skips the other instance's.
+template <int MESH_GROUP, int KINDS> __global__ void __launch_bounds__(64, (KINDS & 8) ? 1 : 2) k_narrowphase_mesh(DV d)
 {
 	constexpr int MESH_PAIRS_PER_WAVE = 64 / MESH_GROUP;
 	__shared__ MeshPairLds<MESH_GROUP> lds[MESH_PAIRS_PER_WAVE];
@@ -1245,6 +1282,7 @@ template <int MESH_GROUP> __global__ void __launch_bounds__(64) k_narrowphase_me
 	const float max_sep = d.st.speculative_contact_distance;
 	// G = 8: the four lists one after the other (a wave's eight pairs then hold the same kind of body); G = 64: the list of the big pairs
 	for (uint32_t seg = 0; seg < (MESH_GROUP == 64 ? 1u : 4u); ++seg) {
+	if (MESH_GROUP != 64 && !((KINDS >> seg) & 1)) continue;
 	const uint32_t seg0 = MESH_GROUP == 64 ? 0u : seg * d.cap_mesh_pairs;
 	const uint32_t n = seg0 + (MESH_GROUP == 64 ? min(d.ctr->n_mesh_big, d.cap_mesh_pairs) : min(d.ctr->n_mesh_pairs[seg], d.cap_mesh_pairs));
 	const uint32_t base = seg0 + (MESH_GROUP == 64 ? d.ctr->mesh_big_base : d.ctr->mesh_base[seg]);      // (0, or where the in-step activation round's pairs begin)
@@ -1259,6 +1297,7 @@ template <int MESH_GROUP> __global__ void __launch_bounds__(64) k_narrowphase_me
 			const bool mesh_a = f_shape(fa) == SGP_SHAPE_MESH, mesh_b = f_shape(fb) == SGP_SHAPE_MESH;
 			if (mesh_a && mesh_b) valid = false;
 			mid = mesh_a ? ab.x : ab.y; xid = mesh_a ? ab.y : ab.x; fx = mesh_a ? fb : fa;
+			if (!((KINDS >> f_shape(fx)) & 1)) valid = false;      // (the other instance's pair: only the list of big pairs mixes the kinds)
 		}
 		sgd_shape X; v3 qlo = V3(0.0f, 0.0f, 0.0f), qhi = qlo; bool dropped = false;
 		if (valid) {
@@ -1273,7 +1312,7 @@ template <int MESH_GROUP> __global__ void __launch_bounds__(64) k_narrowphase_me
 			const v3 vx = v3_add(V3(d.vel[2 * (size_t)xid]), v3_scale(v3_scale(V3(d.gx, d.gy, d.gz), d.dyn[xid].z), d.sp->dt));
 			movement = v3_sub(vx, f_motion(d.flags[mid]) == SGP_MOTION_STATIC ? V3(0.0f, 0.0f, 0.0f) : V3(d.vel[2 * (size_t)mid]));
 		}
-		mesh_pair_groups<MESH_GROUP>(d, L, valid, X, mid, qlo, qhi, max_sep, grp, sub, pair, dropped, movement);
+		mesh_pair_groups<MESH_GROUP, KINDS>(d, L, valid, X, mid, qlo, qhi, max_sep, grp, sub, pair, dropped, movement);
 		// the groups as manifolds (mesh -> body), each pruned to <= 4 points; the constraint runs lower id -> higher id, with the mesh's g-th slot
 		const int ng = valid ? L.mc.ng : 0;
 		if (sub < ng) {
@@ -4517,7 +4556,7 @@ __global__ void __launch_bounds__(64) k_collide_capsules(DV d, const sgp_capsule
 		const uint32_t mid = mesh_list[mi];
 		bool valid = true, dropped = false;
 		sgd_shape X = sc;
-		mesh_pair_groups<64>(d, L, valid, X, mid, v3_sub(lo, es), v3_add(hi, es), q.max_separation, 0, (int)lane, 0u, dropped, V3(q.movement[0], q.movement[1], q.movement[2]), q.active_edges != 0u);      // (CharacterVirtual::GetContactsAtPosition: CollideOnlyWithActive + its direction of travel; 0: every edge with its own normal)
+		mesh_pair_groups<64, 4>(d, L, valid, X, mid, v3_sub(lo, es), v3_add(hi, es), q.max_separation, 0, (int)lane, 0u, dropped, V3(q.movement[0], q.movement[1], q.movement[2]), q.active_edges != 0u);      // (CharacterVirtual::GetContactsAtPosition: CollideOnlyWithActive + its direction of travel; 0: every edge with its own normal)
 		if ((int)lane < L.mc.ng) {
 			const sgd_mesh_group& grp = L.mc.g[lane];
 			sgd_manifold mm;
@@ -4907,10 +4946,12 @@ void launch_wake_round(const DV& d, uint32_t nb, bool has_hulls, bool has_meshes
 {
 	hipLaunchKernelGGL(k_wake_pairs, dim3(blocks_for(nb)), dim3(TPB), 0, s, d);
 	hipLaunchKernelGGL(k_narrowphase_wake, dim3(32), dim3(TPB), 0, s, d);      // (few pairs, 1.7 KB of scratch per lane: a small grid starts faster)
-	(void)has_hulls;      // (hull pairs of this round are collided by k_narrowphase_wake itself)
+	// (hull pairs of this round are collided by k_narrowphase_wake itself; hull - mesh pairs by the hull instances of the mesh kernels)
 	if (has_meshes) {
-		hipLaunchKernelGGL(k_narrowphase_mesh<8>, dim3(256), dim3(64), 0, s, d);
-		hipLaunchKernelGGL(k_narrowphase_mesh<64>, dim3(256), dim3(64), 0, s, d);
+		hipLaunchKernelGGL((k_narrowphase_mesh<8, SGD_KINDS_PRIMITIVES>), dim3(256), dim3(64), 0, s, d);
+		if (has_hulls) hipLaunchKernelGGL((k_narrowphase_mesh<8, 8>), dim3(256), dim3(64), 0, s, d);
+		hipLaunchKernelGGL((k_narrowphase_mesh<64, SGD_KINDS_PRIMITIVES>), dim3(256), dim3(64), 0, s, d);
+		if (has_hulls) hipLaunchKernelGGL((k_narrowphase_mesh<64, 8>), dim3(256), dim3(64), 0, s, d);
 	}
 }
 void launch_narrowphase_hull(const DV& d, hipStream_t s)
@@ -4918,10 +4959,14 @@ void launch_narrowphase_hull(const DV& d, hipStream_t s)
 	hipLaunchKernelGGL(k_narrowphase_hull, dim3(4096), dim3(64), 0, s, d);
 	hipLaunchKernelGGL(k_narrowphase_hull_manifold, dim3(1024), dim3(64), 0, s, d);
 }
-void launch_narrowphase_mesh(const DV& d, hipStream_t s)
+void launch_narrowphase_mesh(const DV& d, bool has_hulls, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_narrowphase_mesh<8>, dim3(2048), dim3(64), 0, s, d);       // eight lanes per pair; passes the pairs with many candidate triangles on to ...
-	hipLaunchKernelGGL(k_narrowphase_mesh<64>, dim3(2048), dim3(64), 0, s, d);      // ... a wave per pair
+	// eight lanes per pair: the primitives, then (worlds with hulls) the hulls; both pass the pairs with many candidate triangles on to ...
+	hipLaunchKernelGGL((k_narrowphase_mesh<8, SGD_KINDS_PRIMITIVES>), dim3(2048), dim3(64), 0, s, d);
+	if (has_hulls) hipLaunchKernelGGL((k_narrowphase_mesh<8, 8>), dim3(2048), dim3(64), 0, s, d);
+	// ... a wave per pair
+	hipLaunchKernelGGL((k_narrowphase_mesh<64, SGD_KINDS_PRIMITIVES>), dim3(2048), dim3(64), 0, s, d);
+	if (has_hulls) hipLaunchKernelGGL((k_narrowphase_mesh<64, 8>), dim3(2048), dim3(64), 0, s, d);
 }
 void launch_colour_inherit(const DV& d, uint32_t est, hipStream_t s) { hipLaunchKernelGGL(k_colour_inherit, dim3(stride_grid(est)), dim3(TPB), 0, s, d); }
 void launch_colour_claim(const DV& d, uint32_t est, uint32_t round, hipStream_t s)
