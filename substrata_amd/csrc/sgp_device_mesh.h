@@ -80,7 +80,9 @@ SGP_DEV static void sgd_mesh_add(sgd_mesh_contacts* mc, const sgd_manifold* m)
 		mc->g[gi].n = m->n; mc->g[gi].np = 0;
 	}
 	sgd_mesh_group* g = &mc->g[gi];
-	for (int i = 0; i < m->np; ++i) {
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {      // (a triangle's manifold: at most four points)
+		if (i >= m->np) break;
 		if (g->np == SGD_HULL_CLIP_CAP) break;
 		// the same point reached through two triangles that share it (an edge or a vertex of the mesh) counts once
 		int dup = 0;
@@ -95,9 +97,12 @@ SGP_DEV static bool sgd_tri_needs_face_normal(const sgd_tri_view* T, v3 nt, unsi
 {
 	if (edges == 7u || m->np <= 0) return false;
 	// the point that decides: the deepest one (Jolt has one point at this stage, the deepest)
+	// (a triangle's manifold has at most four points by now -- sgd_hull_reduce --: loops over the four slots with the count as a predicate keep it in registers)
 	int bi = 0; float bd = -3.4e38f;
-	for (int i = 0; i < m->np; ++i) { const float dd = v3_dot(v3_sub(m->p1[i], m->p2[i]), m->n); if (dd > bd) { bd = dd; bi = i; } }
-	return sgd_active_edge_fix(sgd_hv_world(T, 0), sgd_hv_world(T, 1), sgd_hv_world(T, 2), nt, edges, m->p1[bi], m->n, movement) != 0;
+#pragma unroll
+	for (int i = 0; i < 4; ++i) if (i < m->np) { const float dd = v3_dot(v3_sub(m->p1[i], m->p2[i]), m->n); if (dd > bd) { bd = dd; bi = i; } }
+	const v3 pb = bi == 0 ? m->p1[0] : (bi == 1 ? m->p1[1] : (bi == 2 ? m->p1[2] : m->p1[3]));
+	return sgd_active_edge_fix(sgd_hv_world(T, 0), sgd_hv_world(T, 1), sgd_hv_world(T, 2), nt, edges, pb, m->n, movement) != 0;
 }
 // ---- a mesh triangle against a BOX: the separating-axis search of sgd_hull_sat_search(T, box) in closed form ----------------------------
 // The general search walks the cube template like any hull: eight corners per projection, tables of direction pairs indexed at run time (720 B of
@@ -230,6 +235,172 @@ SGP_DEV static int sgd_tri_box_sat(const sgd_tri_view* T, const sgd_hview* B, co
 	return 1;
 }
 
+// ---- ... and its manifold, sgd_hull_manifold(T, box), with every polygon in registers ------------------------------------------------------
+// The general routine keeps its clip polygons, the candidate points and the triangle's little hull record in arrays indexed at run time: scratch memory,
+// a round trip per access, and one lane of a wave-per-SIMD kernel has nothing to hide it behind -- a box against ONE triangle took ~100 us, most of it
+// waiting.  Here a polygon is eight registers-triples with a count; loops run over the eight slots with the count as a predicate and a vertex is appended by
+// a chain of selects, so that the compiler never sees a run-time index.  A triangle and a quad never make a polygon of more than seven corners (sgd_hull_clip).
+// The arithmetic -- every expression, the order of the corners, the order of the clip planes, "first minimum wins" -- is the general routine's: same bits.
+struct sgd_poly8 { v3 p[8]; int n; };
+SGP_DEV static void sgd_poly8_push(sgd_poly8& o, v3 v)
+{
+#pragma unroll
+	for (int k = 0; k < 8; ++k) if (o.n == k) o.p[k] = v;
+	o.n += o.n < 8 ? 1 : 0;
+}
+SGP_DEV static v3 sgd_poly8_get(const sgd_poly8& o, int i)
+{
+	v3 r = o.p[0];
+#pragma unroll
+	for (int k = 1; k < 8; ++k) if (i == k) r = o.p[k];
+	return r;
+}
+// = sgd_hull_clip: the half space (p - a) . side <= 0
+SGP_DEV static void sgd_poly8_clip(const sgd_poly8& in, v3 a, v3 side, sgd_poly8& out)
+{
+	out.n = 0;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		if (i < in.n) {
+			const v3 p = in.p[i];
+			const v3 q = (i + 1 < in.n) ? in.p[i + 1 < 8 ? i + 1 : 0] : in.p[0];
+			const float dp = v3_dot(v3_sub(p, a), side), dq = v3_dot(v3_sub(q, a), side);
+			if (dp <= 0.0f) sgd_poly8_push(out, p);
+			if ((dp <= 0.0f) != (dq <= 0.0f)) {
+				const float t = dp / (dp - dq);
+				sgd_poly8_push(out, v3_add(p, v3_scale(v3_sub(q, p), t)));
+			}
+		}
+	}
+}
+// = sgd_hull_reduce for <= 8 candidate points held in registers; writes m->n, m->np, m->p1 / p2 [0 .. 3]
+SGP_DEV static void sgd_poly8_reduce(v3 n, const sgd_poly8& P1, const sgd_poly8& P2, int np, sgd_manifold* m)
+{
+	m->n = n;
+	if (np <= 4) {
+#pragma unroll
+		for (int i = 0; i < 4; ++i) if (i < np) { m->p1[i] = P1.p[i]; m->p2[i] = P2.p[i]; }
+		m->np = np; return;
+	}
+	int i0 = 0; float best = -3.4e38f;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) if (i < np) { const float pen = v3_dot(v3_sub(P1.p[i], P2.p[i]), n); if (pen > best) { best = pen; i0 = i; } }
+	const v3 p0 = sgd_poly8_get(P1, i0);
+	int i1 = i0; best = -1.0f;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) if (i < np) { const float d2 = v3_len_sq(v3_sub(P1.p[i], p0)); if (d2 > best) { best = d2; i1 = i; } }
+	const v3 e = v3_sub(sgd_poly8_get(P1, i1), p0);
+	int i2 = -1, i3 = -1; float amax = 0.0f, amin = 0.0f;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) if (i < np && i != i0 && i != i1) {
+		const float area = v3_dot(v3_cross(e, v3_sub(P1.p[i], p0)), n);
+		if (area > amax) { amax = area; i2 = i; }
+		if (area < amin) { amin = area; i3 = i; }
+	}
+	// the survivors in the order i0, i1 (unless it is i0), i2, i3 (those that exist)
+	const int pick[4] = { i0, i1 != i0 ? i1 : -1, i2, i3 };
+	int k = 0;
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		if (pick[j] >= 0) {
+			const v3 a = sgd_poly8_get(P1, pick[j]), b = sgd_poly8_get(P2, pick[j]);
+#pragma unroll
+			for (int o = 0; o < 4; ++o) if (k == o) { m->p1[o] = a; m->p2[o] = b; }
+			++k;
+		}
+	}
+	m->np = k;
+}
+// the triangle of a thin hull view, in registers: corners relative to the centroid (mesh frame), unit normal, plane offset of the front face
+struct sgd_tri_regs { v3 pos; m33 R; v3 v0, v1, v2; v3 n; float d0; };
+SGP_DEV static v3 sgd_trr_corner(const sgd_tri_regs& t, int j) { return v3_add(t.pos, m33_mul(t.R, j == 0 ? t.v0 : (j == 1 ? t.v1 : t.v2))); }      // (sgd_hv_world with scale 1)
+// = sgd_hull_manifold(T, B, max_sep, r, m) for B = the cube template scaled.  Normal from the triangle to the box.
+SGP_DEV static int sgd_tri_box_manifold(const sgd_tri_view* T, const sgd_hview* B, float max_sep, const sgd_hull_sat* r, sgd_manifold* m)
+{
+	sgd_tri_regs tr;
+	tr.pos = T->pos; tr.R = T->R; tr.v0 = T->h->verts[0]; tr.v1 = T->h->verts[1]; tr.v2 = T->h->verts[2]; tr.n = T->h->normals[0]; tr.d0 = T->h->plane_d[0];
+	const float sA = r->sA, sB = r->sB, sE = r->sE; const int fA = r->fA, fB = r->fB, eA = r->eA, eB = r->eB;
+	const float sF = fmaxf(sA, sB);
+	if (eA >= 0 && sE > sF + 1.0e-3f) {
+		v3 pa, pb;      // (edge i of the triangle: corners (0, 1, 0)[i] -> (1, 2, 2)[i])
+		sgd_seg_seg_closest(sgd_trr_corner(tr, eA == 1 ? 1 : 0), sgd_trr_corner(tr, eA == 0 ? 1 : 2),
+		                    sgd_hv_world(B, B->h->edge_a[eB]), sgd_hv_world(B, B->h->edge_b[eB]), &pa, &pb);
+		m->n = r->nE; m->np = 1; m->p1[0] = pa; m->p2[0] = pb;
+		return 1;
+	}
+	const int refA = !(sB > sA + 1.0e-4f);
+	sgd_poly8 P, Q;
+	v3 nref; float off;
+	if (refA) {
+		// reference face = face fA of the triangle (0: front, corners 0 1 2; 1: back, corners 0 2 1), incident face = the cube's most anti-parallel one
+		nref = m33_mul(tr.R, fA == 0 ? tr.n : v3_neg(tr.n));
+		int fY = 0; float bestd = 3.4e38f;
+		for (int f = 0; f < B->h->nf; ++f) { const float dd = v3_dot(nref, sgd_hv_normal(B, f)); if (dd < bestd) { bestd = dd; fY = f; } }
+		P.n = 0;
+		for (int k = B->h->face_start[fY]; k < B->h->face_start[fY + 1]; ++k) sgd_poly8_push(P, sgd_hv_world(B, B->h->face_idx[k]));
+#pragma unroll
+		for (int k = 0; k < 3; ++k) {
+			if (P.n > 0) {
+				const int ia = fA == 0 ? k : (k == 0 ? 0 : 3 - k), ib = fA == 0 ? (k + 1) % 3 : (k == 0 ? 2 : (k == 1 ? 1 : 0));
+				const v3 a = sgd_trr_corner(tr, ia), b = sgd_trr_corner(tr, ib);
+				sgd_poly8_clip(P, a, v3_cross(v3_sub(b, a), nref), Q);
+				P = Q;
+			}
+		}
+		off = v3_dot(nref, tr.pos) + (fA == 0 ? tr.d0 : -tr.d0);
+	} else {
+		// reference face = face fB of the cube, incident face = the side of the triangle that looks at it
+		nref = sgd_hv_normal(B, fB);
+		int fY = 0; float bestd = 3.4e38f;
+		{ const float dd = v3_dot(nref, m33_mul(tr.R, tr.n)); if (dd < bestd) { bestd = dd; fY = 0; } }
+		{ const float dd = v3_dot(nref, m33_mul(tr.R, v3_neg(tr.n))); if (dd < bestd) { bestd = dd; fY = 1; } }
+		P.n = 3;
+		P.p[0] = sgd_trr_corner(tr, 0); P.p[1] = sgd_trr_corner(tr, fY == 0 ? 1 : 2); P.p[2] = sgd_trr_corner(tr, fY == 0 ? 2 : 1);
+		const int x0 = B->h->face_start[fB], x1 = B->h->face_start[fB + 1];
+		for (int k = x0; k < x1 && P.n > 0; ++k) {
+			const v3 a = sgd_hv_world(B, B->h->face_idx[k]);
+			const v3 b = sgd_hv_world(B, B->h->face_idx[k + 1 < x1 ? k + 1 : x0]);
+			sgd_poly8_clip(P, a, v3_cross(v3_sub(b, a), nref), Q);
+			P = Q;
+		}
+		off = v3_dot(nref, B->pos) + sgd_hv_plane_d(B, fB);
+	}
+	// the corners of the clipped incident face within reach of the reference plane, each with its foot point on that plane
+	sgd_poly8 Q1, Q2; Q1.n = 0; Q2.n = 0;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		if (i < P.n) {
+			const float sep = v3_dot(nref, P.p[i]) - off;
+			if (sep <= max_sep) {
+				const v3 pr = v3_sub(P.p[i], v3_scale(nref, sep));
+				if (refA) { sgd_poly8_push(Q1, pr); sgd_poly8_push(Q2, P.p[i]); } else { sgd_poly8_push(Q1, P.p[i]); sgd_poly8_push(Q2, pr); }
+			}
+		}
+	}
+	int cnt = Q1.n;
+	if (cnt == 0) {
+		// nothing of the incident face lies over the reference face: the support vertex of the incident hull along the axis
+		v3 py; float bp = 3.4e38f;
+		if (refA) {
+			int bi = 0;
+			for (int i = 0; i < B->h->nv; ++i) { const float pr = v3_dot(nref, sgd_hv_world(B, i)); if (pr < bp) { bp = pr; bi = i; } }
+			py = sgd_hv_world(B, bi);
+		} else {
+			int bi = 0;
+#pragma unroll
+			for (int i = 0; i < 3; ++i) { const float pr = v3_dot(nref, sgd_trr_corner(tr, i)); if (pr < bp) { bp = pr; bi = i; } }
+			py = sgd_trr_corner(tr, bi);
+		}
+		const float sep = bp - off;
+		if (sep > max_sep) return 0;
+		const v3 px = v3_sub(py, v3_scale(nref, sep));
+		if (refA) { Q1.p[0] = px; Q2.p[0] = py; } else { Q1.p[0] = py; Q2.p[0] = px; }
+		cnt = 1;
+	}
+	sgd_poly8_reduce(refA ? nref : v3_neg(nref), Q1, Q2, cnt, m);
+	return 1;
+}
+
 // X against one triangle (world-space view T of its thin hull, world normal nt).  Normal of the result: triangle -> X.
 // edges: the triangle's active-edge bits (7: no fixing, e.g. a shape query), movement: X's velocity relative to the mesh.
 // KINDS: the shapes X can be (bit SGD_SHAPE_*): an instance for spheres, boxes and capsules carries nothing of the general hull search.
@@ -261,8 +432,8 @@ template <int KINDS = SGD_KINDS_ALL> SGP_DEV static int sgd_collide_tri(const sg
 	// ONE call site for the manifold (its clip polygons are a kilobyte of scratch per inlined copy): the second turn of the loop is the active-edge
 	// rule's -- the contact as the triangle's FACE makes it (reference face = the triangle's front, clipped incident face of X)
 	for (int turn = 0; turn < 2; ++turn) {
-		if (KINDS & 8) { if (!sgd_hull_manifold(T, &hx, max_sep, &r, m)) return 0; }
-		else { if (!sgd_hull_manifold<8>(T, &hx, max_sep, &r, m)) return 0; }      // (a triangle and a quad: no polygon beyond seven corners)
+		if constexpr ((KINDS & 2) && !(KINDS & 8)) { if (!sgd_tri_box_manifold(T, &hx, max_sep, &r, m)) return 0; }      // (a box: polygons in registers)
+		else { if (!sgd_hull_manifold(T, &hx, max_sep, &r, m)) return 0; }
 		if (turn == 1) break;
 		if (v3_dot(m->n, nt) < 0.0f) return 0;                   // reached from the back side
 		if (!sgd_tri_needs_face_normal(T, nt, edges, movement, m)) break;

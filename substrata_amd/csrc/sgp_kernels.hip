@@ -1273,20 +1273,36 @@ template <int MESH_GROUP, int KINDS = SGD_KINDS_ALL> SGP_DEV void mesh_pair_grou
 // KINDS: the shapes of the other body this instance serves (bits of SGD_SHAPE_*).  Two instances per group size: the primitives (spheres, boxes with the
 // closed-form separating-axis search, capsules -- no general hull code, a fraction of the registers and scratch) and the convex hulls; the second one is
 // launched only in worlds that have hulls.  G = 8 takes the lists of its kinds; G = 64 walks the one list of big pairs and skips the other instance's.
-template <int MESH_GROUP, int KINDS> __global__ void __launch_bounds__(64, (KINDS & 8) ? 1 : 2) k_narrowphase_mesh(DV d)
+template <int MESH_GROUP, int KINDS> __global__ void __launch_bounds__(64) k_narrowphase_mesh(DV d)
 {
 	constexpr int MESH_PAIRS_PER_WAVE = 64 / MESH_GROUP;
 	__shared__ MeshPairLds<MESH_GROUP> lds[MESH_PAIRS_PER_WAVE];
 	const int grp = (int)(threadIdx.x / MESH_GROUP), sub = (int)(threadIdx.x % MESH_GROUP);
 	MeshPairLds<MESH_GROUP>& L = lds[grp];
 	const float max_sep = d.st.speculative_contact_distance;
-	// G = 8: the four lists one after the other (a wave's eight pairs then hold the same kind of body); G = 64: the list of the big pairs
-	for (uint32_t seg = 0; seg < (MESH_GROUP == 64 ? 1u : 4u); ++seg) {
-	if (MESH_GROUP != 64 && !((KINDS >> seg) & 1)) continue;
-	const uint32_t seg0 = MESH_GROUP == 64 ? 0u : seg * d.cap_mesh_pairs;
-	const uint32_t n = seg0 + (MESH_GROUP == 64 ? min(d.ctr->n_mesh_big, d.cap_mesh_pairs) : min(d.ctr->n_mesh_pairs[seg], d.cap_mesh_pairs));
-	const uint32_t base = seg0 + (MESH_GROUP == 64 ? d.ctr->mesh_big_base : d.ctr->mesh_base[seg]);      // (0, or where the in-step activation round's pairs begin)
-	for (uint32_t p0 = base + blockIdx.x * MESH_PAIRS_PER_WAVE; p0 < n; p0 += gridDim.x * MESH_PAIRS_PER_WAVE) {
+	// G = 8: a wave's eight pairs hold the same kind of body (one list per kind); G = 64: the list of the big pairs.  The lists of this instance's kinds are
+	// ONE sequence of work items (an item = the next eight pairs of a list) dealt to the workgroups: with the lists taken one after the other by
+	// "workgroup b takes pairs 8 b .. of every list" the first few hundred workgroups walked through a chain of spheres, THEN one of boxes, THEN one of capsules
+	// while the others had nothing to do -- the launch lasted the sum of the three chains instead of the longest.
+	uint32_t it_first[5], seg_base[4], seg_end[4];
+	it_first[0] = 0u;
+#pragma unroll
+	for (uint32_t seg = 0; seg < 4u; ++seg) {
+		uint32_t items = 0u; seg_base[seg] = 0u; seg_end[seg] = 0u;
+		if (MESH_GROUP == 64 ? seg == 0u : ((KINDS >> seg) & 1) != 0) {
+			const uint32_t seg0 = MESH_GROUP == 64 ? 0u : seg * d.cap_mesh_pairs;
+			seg_end[seg] = seg0 + (MESH_GROUP == 64 ? min(d.ctr->n_mesh_big, d.cap_mesh_pairs) : min(d.ctr->n_mesh_pairs[seg], d.cap_mesh_pairs));
+			seg_base[seg] = seg0 + (MESH_GROUP == 64 ? d.ctr->mesh_big_base : d.ctr->mesh_base[seg]);      // (0, or where the in-step activation round's pairs begin)
+			if (seg_end[seg] > seg_base[seg]) items = (seg_end[seg] - seg_base[seg] + (uint32_t)MESH_PAIRS_PER_WAVE - 1u) / (uint32_t)MESH_PAIRS_PER_WAVE;
+		}
+		it_first[seg + 1] = it_first[seg] + items;
+	}
+	{
+	for (uint32_t it = blockIdx.x; it < it_first[4]; it += gridDim.x) {
+		const uint32_t seg = it >= it_first[3] ? 3u : (it >= it_first[2] ? 2u : (it >= it_first[1] ? 1u : 0u));
+		const uint32_t s_first = seg == 3u ? it_first[3] : (seg == 2u ? it_first[2] : (seg == 1u ? it_first[1] : it_first[0]));
+		const uint32_t n = seg == 3u ? seg_end[3] : (seg == 2u ? seg_end[2] : (seg == 1u ? seg_end[1] : seg_end[0]));
+		const uint32_t p0 = (seg == 3u ? seg_base[3] : (seg == 2u ? seg_base[2] : (seg == 1u ? seg_base[1] : seg_base[0]))) + (it - s_first) * (uint32_t)MESH_PAIRS_PER_WAVE;
 		const uint32_t p = p0 + (uint32_t)grp;
 		bool valid = p < n;
 		uint32_t mid = 0, xid = 0, fx = 0, pair = 0;
