@@ -1162,14 +1162,14 @@ template <int MESH_GROUP, int KINDS = SGD_KINDS_ALL> SGP_DEV void mesh_pair_grou
 		const float pad = 1.0e-4f * (1.0f + fabsf(llo.x) + fabsf(llo.y) + fabsf(llo.z) + fabsf(lhi.x) + fabsf(lhi.y) + fabsf(lhi.z));
 		llo = v3_sub(llo, V3(pad, pad, pad)); lhi = v3_add(lhi, V3(pad, pad, pad));
 	}
-	// The candidates.  Eight lanes per pair: lane 0 walks the tree depth-first (a few dozen dependent node fetches for a small body) and gives up
-	// once it holds more than MESH_BIG_MIN -- the pair is passed on.  A wave per pair: level by level, the 64 lanes taking the nodes of a level
-	// 64 at a time (depth-first, a car-sized box on a fine mesh is a chain of hundreds of fetches); the two frontiers live in the arrays the
-	// sort uses afterwards.  The SET found is that of the depth-first walk unless a table overflows -- then the answer depends on the order of
-	// the walk, and lane 0 repeats it depth-first.
-	if (sub == 0) { L.n_front[0] = valid ? 1u : 0u; L.n_front[1] = 0u; L.n_found = 0u; L.redo = MESH_GROUP == 64 ? 0u : 1u; L.key[0] = 0u; L.mc.ng = 0; }
+	// The candidates: the tree level by level, the lanes of the group taking the nodes of a level MESH_GROUP at a time -- a level is one fetch deep whatever
+	// it holds, where the depth-first walk of one lane is a chain of every node it visits (a small body: ~70 dependent fetches, 45 us; a car-sized box on a
+	// fine mesh: hundreds); the two frontiers live in the arrays the sort uses afterwards.  The SET found is that of the depth-first walk unless a table
+	// overflows -- then the answer depends on the order of the walk, and lane 0 repeats it depth-first (eight lanes per pair: it then gives up once it holds
+	// more than MESH_BIG_MIN -- the pair is passed on to the wave-per-pair launch; a table of 64 that overflowed says as much).
+	if (sub == 0) { L.n_front[0] = valid ? 1u : 0u; L.n_front[1] = 0u; L.n_found = 0u; L.redo = 0u; L.key[0] = 0u; L.mc.ng = 0; }
 	__syncthreads();
-	if (MESH_GROUP == 64) {
+	{
 		for (int level = 0; level < 64; ++level) {
 			uint32_t* cur = (level & 1) ? L.cand : L.key; uint32_t* nxt = (level & 1) ? L.key : L.cand;
 			const uint32_t ncur = L.redo ? 0u : L.n_front[level & 1];      // (a table overflowed: what the frontiers hold no longer matters)
