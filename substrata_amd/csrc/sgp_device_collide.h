@@ -390,6 +390,9 @@ SGP_DEV static int sgd_box_box(const sgd_shape* A, const sgd_shape* B, float max
 	const int u = (j + 1) % 3, v = (j + 2) % 3;
 	const v3 yu = v3_scale(m33_col(Y->R, u), v3_get(hY, u)), yv = v3_scale(m33_col(Y->R, v), v3_get(hY, v));
 	const v3 fc = v3_add(Y->pos, v3_scale(m33_col(Y->R, j), sj * v3_get(hY, j)));
+	// (arrays indexed at run time: 560 B of scratch per lane of k_narrowphase.  The same clip with its polygons in registers -- eight slots and a count, corners
+	// appended by select chains, no run-time index -- was measured here and is SLOWER: k_narrowphase runs four waves per SIMD on 128 registers, the four
+	// polygons spill as much as the arrays held, and the select chains are instructions the scratch accesses were not: config 3 108 -> 124 us.)
 	v3 poly[8], tmp[8];
 	const v3 w0 = v3_add(v3_add(fc, yu), yv), w1 = v3_add(v3_sub(fc, yu), yv);
 	const v3 w2 = v3_sub(v3_sub(fc, yu), yv), w3 = v3_sub(v3_add(fc, yu), yv);

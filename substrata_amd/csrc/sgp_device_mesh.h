@@ -235,87 +235,68 @@ SGP_DEV static int sgd_tri_box_sat(const sgd_tri_view* T, const sgd_hview* B, co
 	return 1;
 }
 
-// ---- ... and its manifold, sgd_hull_manifold(T, box), with every polygon in registers ------------------------------------------------------
-// The general routine keeps its clip polygons, the candidate points and the triangle's little hull record in arrays indexed at run time: scratch memory,
-// a round trip per access, and one lane of a wave-per-SIMD kernel has nothing to hide it behind -- a box against ONE triangle took ~100 us, most of it
-// waiting.  Here a polygon is eight registers-triples with a count; loops run over the eight slots with the count as a predicate and a vertex is appended by
-// a chain of selects, so that the compiler never sees a run-time index.  A triangle and a quad never make a polygon of more than seven corners (sgd_hull_clip).
+// ---- ... and its manifold, sgd_hull_manifold(T, box), with every polygon in LDS -------------------------------------------------------------
+// The general routine keeps its clip polygons and the candidate points in arrays indexed at run time: scratch memory, a round trip per access, and one lane
+// of a wave-per-SIMD kernel has nothing to hide it behind -- a box against ONE triangle took ~100 us, most of it waiting.  Two things were tried in their
+// place.  Polygons in REGISTERS (eight slots and a count, loops over the slots with the count as a predicate, corners appended by select chains): no scratch,
+// but 100 KB of straight-line code per kernel that every wave runs once, cold -- the test then waits for its own instructions (66 us).  Polygons in LDS, one
+// column per lane (corner i, component c of lane l at [(3 i + c) * 64 + l]: no bank conflicts), indexed at run time by plain loops: a few hundred
+// instructions.  A triangle and a quad never make a polygon of more than seven corners (sgd_hull_clip), so eight slots do.
 // The arithmetic -- every expression, the order of the corners, the order of the clip planes, "first minimum wins" -- is the general routine's: same bits.
-struct sgd_poly8 { v3 p[8]; int n; };
-SGP_DEV static void sgd_poly8_push(sgd_poly8& o, v3 v)
+#define SGD_LPOLY_FLOATS (8 * 3 * 64)      // one polygon column set for the 64 lanes of a wave
+struct sgd_lpoly { float* b; };             // b = the wave's buffer + lane
+SGP_DEV static v3 sgd_lp_get(sgd_lpoly a, int i) { return V3(a.b[(3 * i) * 64], a.b[(3 * i + 1) * 64], a.b[(3 * i + 2) * 64]); }
+SGP_DEV static void sgd_lp_set(sgd_lpoly a, int i, v3 v) { a.b[(3 * i) * 64] = v.x; a.b[(3 * i + 1) * 64] = v.y; a.b[(3 * i + 2) * 64] = v.z; }
+// = sgd_hull_clip<8>: the half space (p - a) . side <= 0
+SGP_DEV static int sgd_lp_clip(sgd_lpoly in, int n, v3 a, v3 side, sgd_lpoly out)
 {
-#pragma unroll
-	for (int k = 0; k < 8; ++k) if (o.n == k) o.p[k] = v;
-	o.n += o.n < 8 ? 1 : 0;
-}
-SGP_DEV static v3 sgd_poly8_get(const sgd_poly8& o, int i)
-{
-	v3 r = o.p[0];
-#pragma unroll
-	for (int k = 1; k < 8; ++k) if (i == k) r = o.p[k];
-	return r;
-}
-// = sgd_hull_clip: the half space (p - a) . side <= 0
-SGP_DEV static void sgd_poly8_clip(const sgd_poly8& in, v3 a, v3 side, sgd_poly8& out)
-{
-	out.n = 0;
-#pragma unroll
-	for (int i = 0; i < 8; ++i) {
-		if (i < in.n) {
-			const v3 p = in.p[i];
-			const v3 q = (i + 1 < in.n) ? in.p[i + 1 < 8 ? i + 1 : 0] : in.p[0];
-			const float dp = v3_dot(v3_sub(p, a), side), dq = v3_dot(v3_sub(q, a), side);
-			if (dp <= 0.0f) sgd_poly8_push(out, p);
-			if ((dp <= 0.0f) != (dq <= 0.0f)) {
-				const float t = dp / (dp - dq);
-				sgd_poly8_push(out, v3_add(p, v3_scale(v3_sub(q, p), t)));
-			}
+	int m = 0;
+	for (int i = 0; i < n; ++i) {
+		const v3 p = sgd_lp_get(in, i), q = sgd_lp_get(in, i + 1 < n ? i + 1 : 0);
+		const float dp = v3_dot(v3_sub(p, a), side), dq = v3_dot(v3_sub(q, a), side);
+		if (dp <= 0.0f) { if (m < 8) sgd_lp_set(out, m++, p); }
+		if ((dp <= 0.0f) != (dq <= 0.0f)) {
+			const float t = dp / (dp - dq);
+			if (m < 8) sgd_lp_set(out, m++, v3_add(p, v3_scale(v3_sub(q, p), t)));
 		}
 	}
+	return m;
 }
-// = sgd_hull_reduce for <= 8 candidate points held in registers; writes m->n, m->np, m->p1 / p2 [0 .. 3]
-SGP_DEV static void sgd_poly8_reduce(v3 n, const sgd_poly8& P1, const sgd_poly8& P2, int np, sgd_manifold* m)
+// = sgd_hull_reduce for <= 8 candidate points in LDS; writes m->n, m->np, m->p1 / p2 [0 .. 3] (static slots: the manifold stays in registers)
+SGP_DEV static void sgd_lp_reduce(v3 n, sgd_lpoly P1, sgd_lpoly P2, int np, sgd_manifold* m)
 {
 	m->n = n;
-	if (np <= 4) {
-#pragma unroll
-		for (int i = 0; i < 4; ++i) if (i < np) { m->p1[i] = P1.p[i]; m->p2[i] = P2.p[i]; }
-		m->np = np; return;
-	}
-	int i0 = 0; float best = -3.4e38f;
-#pragma unroll
-	for (int i = 0; i < 8; ++i) if (i < np) { const float pen = v3_dot(v3_sub(P1.p[i], P2.p[i]), n); if (pen > best) { best = pen; i0 = i; } }
-	const v3 p0 = sgd_poly8_get(P1, i0);
-	int i1 = i0; best = -1.0f;
-#pragma unroll
-	for (int i = 0; i < 8; ++i) if (i < np) { const float d2 = v3_len_sq(v3_sub(P1.p[i], p0)); if (d2 > best) { best = d2; i1 = i; } }
-	const v3 e = v3_sub(sgd_poly8_get(P1, i1), p0);
-	int i2 = -1, i3 = -1; float amax = 0.0f, amin = 0.0f;
-#pragma unroll
-	for (int i = 0; i < 8; ++i) if (i < np && i != i0 && i != i1) {
-		const float area = v3_dot(v3_cross(e, v3_sub(P1.p[i], p0)), n);
-		if (area > amax) { amax = area; i2 = i; }
-		if (area < amin) { amin = area; i3 = i; }
-	}
-	// the survivors in the order i0, i1 (unless it is i0), i2, i3 (those that exist)
-	const int pick[4] = { i0, i1 != i0 ? i1 : -1, i2, i3 };
-	int k = 0;
-#pragma unroll
-	for (int j = 0; j < 4; ++j) {
-		if (pick[j] >= 0) {
-			const v3 a = sgd_poly8_get(P1, pick[j]), b = sgd_poly8_get(P2, pick[j]);
-#pragma unroll
-			for (int o = 0; o < 4; ++o) if (k == o) { m->p1[o] = a; m->p2[o] = b; }
-			++k;
+	int pick[4] = { 0, 1, 2, 3 }; int k = np;
+	if (np > 4) {
+		int i0 = 0; float best = -3.4e38f;
+		for (int i = 0; i < np; ++i) { const float pen = v3_dot(v3_sub(sgd_lp_get(P1, i), sgd_lp_get(P2, i)), n); if (pen > best) { best = pen; i0 = i; } }
+		const v3 p0 = sgd_lp_get(P1, i0);
+		int i1 = i0; best = -1.0f;
+		for (int i = 0; i < np; ++i) { const float d2 = v3_len_sq(v3_sub(sgd_lp_get(P1, i), p0)); if (d2 > best) { best = d2; i1 = i; } }
+		const v3 e = v3_sub(sgd_lp_get(P1, i1), p0);
+		int i2 = -1, i3 = -1; float amax = 0.0f, amin = 0.0f;
+		for (int i = 0; i < np; ++i) {
+			if (i == i0 || i == i1) continue;
+			const float area = v3_dot(v3_cross(e, v3_sub(sgd_lp_get(P1, i), p0)), n);
+			if (area > amax) { amax = area; i2 = i; }
+			if (area < amin) { amin = area; i3 = i; }
 		}
+		// the survivors in the order i0, i1 (unless it is i0), i2, i3 (those that exist)
+		k = 0;
+		pick[0] = i0; k = 1;
+		if (i1 != i0) { pick[1] = i1; k = 2; }
+		if (i2 >= 0) { if (k == 1) pick[1] = i2; else pick[2] = i2; ++k; }
+		if (i3 >= 0) { if (k == 1) pick[1] = i3; else if (k == 2) pick[2] = i3; else pick[3] = i3; ++k; }
 	}
+#pragma unroll
+	for (int j = 0; j < 4; ++j) if (j < k) { m->p1[j] = sgd_lp_get(P1, pick[j]); m->p2[j] = sgd_lp_get(P2, pick[j]); }
 	m->np = k;
 }
 // the triangle of a thin hull view, in registers: corners relative to the centroid (mesh frame), unit normal, plane offset of the front face
 struct sgd_tri_regs { v3 pos; m33 R; v3 v0, v1, v2; v3 n; float d0; };
 SGP_DEV static v3 sgd_trr_corner(const sgd_tri_regs& t, int j) { return v3_add(t.pos, m33_mul(t.R, j == 0 ? t.v0 : (j == 1 ? t.v1 : t.v2))); }      // (sgd_hv_world with scale 1)
-// = sgd_hull_manifold(T, B, max_sep, r, m) for B = the cube template scaled.  Normal from the triangle to the box.
-SGP_DEV static int sgd_tri_box_manifold(const sgd_tri_view* T, const sgd_hview* B, float max_sep, const sgd_hull_sat* r, sgd_manifold* m)
+// = sgd_hull_manifold(T, B, max_sep, r, m) for B = the cube template scaled.  Normal from the triangle to the box.  lds: 3 x SGD_LPOLY_FLOATS of the wave + lane.
+SGP_DEV static int sgd_tri_box_manifold(const sgd_tri_view* T, const sgd_hview* B, float max_sep, const sgd_hull_sat* r, sgd_manifold* m, float* lds)
 {
 	sgd_tri_regs tr;
 	tr.pos = T->pos; tr.R = T->R; tr.v0 = T->h->verts[0]; tr.v1 = T->h->verts[1]; tr.v2 = T->h->verts[2]; tr.n = T->h->normals[0]; tr.d0 = T->h->plane_d[0];
@@ -329,23 +310,21 @@ SGP_DEV static int sgd_tri_box_manifold(const sgd_tri_view* T, const sgd_hview* 
 		return 1;
 	}
 	const int refA = !(sB > sA + 1.0e-4f);
-	sgd_poly8 P, Q;
+	sgd_lpoly P, Q, S; P.b = lds; Q.b = lds + SGD_LPOLY_FLOATS; S.b = lds + 2 * SGD_LPOLY_FLOATS;
+	int np = 0;
 	v3 nref; float off;
 	if (refA) {
 		// reference face = face fA of the triangle (0: front, corners 0 1 2; 1: back, corners 0 2 1), incident face = the cube's most anti-parallel one
 		nref = m33_mul(tr.R, fA == 0 ? tr.n : v3_neg(tr.n));
 		int fY = 0; float bestd = 3.4e38f;
 		for (int f = 0; f < B->h->nf; ++f) { const float dd = v3_dot(nref, sgd_hv_normal(B, f)); if (dd < bestd) { bestd = dd; fY = f; } }
-		P.n = 0;
-		for (int k = B->h->face_start[fY]; k < B->h->face_start[fY + 1]; ++k) sgd_poly8_push(P, sgd_hv_world(B, B->h->face_idx[k]));
-#pragma unroll
-		for (int k = 0; k < 3; ++k) {
-			if (P.n > 0) {
-				const int ia = fA == 0 ? k : (k == 0 ? 0 : 3 - k), ib = fA == 0 ? (k + 1) % 3 : (k == 0 ? 2 : (k == 1 ? 1 : 0));
-				const v3 a = sgd_trr_corner(tr, ia), b = sgd_trr_corner(tr, ib);
-				sgd_poly8_clip(P, a, v3_cross(v3_sub(b, a), nref), Q);
-				P = Q;
-			}
+		for (int k = B->h->face_start[fY]; k < B->h->face_start[fY + 1]; ++k) { if (np < 8) sgd_lp_set(P, np++, sgd_hv_world(B, B->h->face_idx[k])); }
+#pragma unroll 1
+		for (int k = 0; k < 3 && np > 0; ++k) {
+			const int ia = fA == 0 ? k : (k == 0 ? 0 : 3 - k), ib = fA == 0 ? (k == 2 ? 0 : k + 1) : (k == 0 ? 2 : (k == 1 ? 1 : 0));
+			const v3 a = sgd_trr_corner(tr, ia), b = sgd_trr_corner(tr, ib);
+			np = sgd_lp_clip(P, np, a, v3_cross(v3_sub(b, a), nref), Q);
+			const sgd_lpoly t = P; P = Q; Q = t;
 		}
 		off = v3_dot(nref, tr.pos) + (fA == 0 ? tr.d0 : -tr.d0);
 	} else {
@@ -354,30 +333,29 @@ SGP_DEV static int sgd_tri_box_manifold(const sgd_tri_view* T, const sgd_hview* 
 		int fY = 0; float bestd = 3.4e38f;
 		{ const float dd = v3_dot(nref, m33_mul(tr.R, tr.n)); if (dd < bestd) { bestd = dd; fY = 0; } }
 		{ const float dd = v3_dot(nref, m33_mul(tr.R, v3_neg(tr.n))); if (dd < bestd) { bestd = dd; fY = 1; } }
-		P.n = 3;
-		P.p[0] = sgd_trr_corner(tr, 0); P.p[1] = sgd_trr_corner(tr, fY == 0 ? 1 : 2); P.p[2] = sgd_trr_corner(tr, fY == 0 ? 2 : 1);
+		np = 3;
+		sgd_lp_set(P, 0, sgd_trr_corner(tr, 0)); sgd_lp_set(P, 1, sgd_trr_corner(tr, fY == 0 ? 1 : 2)); sgd_lp_set(P, 2, sgd_trr_corner(tr, fY == 0 ? 2 : 1));
 		const int x0 = B->h->face_start[fB], x1 = B->h->face_start[fB + 1];
-		for (int k = x0; k < x1 && P.n > 0; ++k) {
+#pragma unroll 1
+		for (int k = x0; k < x1 && np > 0; ++k) {
 			const v3 a = sgd_hv_world(B, B->h->face_idx[k]);
 			const v3 b = sgd_hv_world(B, B->h->face_idx[k + 1 < x1 ? k + 1 : x0]);
-			sgd_poly8_clip(P, a, v3_cross(v3_sub(b, a), nref), Q);
-			P = Q;
+			np = sgd_lp_clip(P, np, a, v3_cross(v3_sub(b, a), nref), Q);
+			const sgd_lpoly t = P; P = Q; Q = t;
 		}
 		off = v3_dot(nref, B->pos) + sgd_hv_plane_d(B, fB);
 	}
-	// the corners of the clipped incident face within reach of the reference plane, each with its foot point on that plane
-	sgd_poly8 Q1, Q2; Q1.n = 0; Q2.n = 0;
-#pragma unroll
-	for (int i = 0; i < 8; ++i) {
-		if (i < P.n) {
-			const float sep = v3_dot(nref, P.p[i]) - off;
-			if (sep <= max_sep) {
-				const v3 pr = v3_sub(P.p[i], v3_scale(nref, sep));
-				if (refA) { sgd_poly8_push(Q1, pr); sgd_poly8_push(Q2, P.p[i]); } else { sgd_poly8_push(Q1, P.p[i]); sgd_poly8_push(Q2, pr); }
-			}
+	// the corners of the clipped incident face within reach of the reference plane, each with its foot point on that plane (Q, S: the two free columns)
+	int cnt = 0;
+	for (int i = 0; i < np; ++i) {
+		const v3 pi = sgd_lp_get(P, i);
+		const float sep = v3_dot(nref, pi) - off;
+		if (sep <= max_sep) {
+			const v3 pr = v3_sub(pi, v3_scale(nref, sep));
+			if (refA) { sgd_lp_set(Q, cnt, pr); sgd_lp_set(S, cnt, pi); } else { sgd_lp_set(Q, cnt, pi); sgd_lp_set(S, cnt, pr); }
+			++cnt;
 		}
 	}
-	int cnt = Q1.n;
 	if (cnt == 0) {
 		// nothing of the incident face lies over the reference face: the support vertex of the incident hull along the axis
 		v3 py; float bp = 3.4e38f;
@@ -387,17 +365,17 @@ SGP_DEV static int sgd_tri_box_manifold(const sgd_tri_view* T, const sgd_hview* 
 			py = sgd_hv_world(B, bi);
 		} else {
 			int bi = 0;
-#pragma unroll
+#pragma unroll 1
 			for (int i = 0; i < 3; ++i) { const float pr = v3_dot(nref, sgd_trr_corner(tr, i)); if (pr < bp) { bp = pr; bi = i; } }
 			py = sgd_trr_corner(tr, bi);
 		}
 		const float sep = bp - off;
 		if (sep > max_sep) return 0;
 		const v3 px = v3_sub(py, v3_scale(nref, sep));
-		if (refA) { Q1.p[0] = px; Q2.p[0] = py; } else { Q1.p[0] = py; Q2.p[0] = px; }
+		if (refA) { sgd_lp_set(Q, 0, px); sgd_lp_set(S, 0, py); } else { sgd_lp_set(Q, 0, py); sgd_lp_set(S, 0, px); }
 		cnt = 1;
 	}
-	sgd_poly8_reduce(refA ? nref : v3_neg(nref), Q1, Q2, cnt, m);
+	sgd_lp_reduce(refA ? nref : v3_neg(nref), Q, S, cnt, m);
 	return 1;
 }
 
@@ -406,7 +384,8 @@ SGP_DEV static int sgd_tri_box_manifold(const sgd_tri_view* T, const sgd_hview* 
 // KINDS: the shapes X can be (bit SGD_SHAPE_*): an instance for spheres, boxes and capsules carries nothing of the general hull search.
 #define SGD_KINDS_ALL 15
 #define SGD_KINDS_PRIMITIVES 7      // sphere | box | capsule
-template <int KINDS = SGD_KINDS_ALL> SGP_DEV static int sgd_collide_tri(const sgd_shape* X, const sgd_tri_view* T, v3 nt, float max_sep, sgd_manifold* m, unsigned edges, v3 movement, const sgd_box_code* code = nullptr)
+// code, lpoly: what a box needs (the cube template's edge code, sgd_box_code_of; three polygon columns of the wave in LDS + lane, sgd_tri_box_manifold)
+template <int KINDS = SGD_KINDS_ALL> SGP_DEV static int sgd_collide_tri(const sgd_shape* X, const sgd_tri_view* T, v3 nt, float max_sep, sgd_manifold* m, unsigned edges, v3 movement, const sgd_box_code* code = nullptr, float* lpoly = nullptr)
 {
 	if ((KINDS & 5) && (X->type == SGD_SHAPE_SPHERE || X->type == SGD_SHAPE_CAPSULE)) {
 		int hit;
@@ -432,7 +411,7 @@ template <int KINDS = SGD_KINDS_ALL> SGP_DEV static int sgd_collide_tri(const sg
 	// ONE call site for the manifold (its clip polygons are a kilobyte of scratch per inlined copy): the second turn of the loop is the active-edge
 	// rule's -- the contact as the triangle's FACE makes it (reference face = the triangle's front, clipped incident face of X)
 	for (int turn = 0; turn < 2; ++turn) {
-		if constexpr ((KINDS & 2) && !(KINDS & 8)) { if (!sgd_tri_box_manifold(T, &hx, max_sep, &r, m)) return 0; }      // (a box: polygons in registers)
+		if constexpr ((KINDS & 2) && !(KINDS & 8)) { if (!sgd_tri_box_manifold(T, &hx, max_sep, &r, m, lpoly)) return 0; }      // (a box: polygons in LDS)
 		else { if (!sgd_hull_manifold(T, &hx, max_sep, &r, m)) return 0; }
 		if (turn == 1) break;
 		if (v3_dot(m->n, nt) < 0.0f) return 0;                   // reached from the back side

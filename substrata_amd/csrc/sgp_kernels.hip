@@ -1136,7 +1136,7 @@ SGP_DEV int mesh_candidates_found(const DV& d, const MeshHeader& mh, v3 llo, v3 
 // pair): what lies between "here is the pair" and "here are its <= 3 groups in L.mc".  valid: false for a group without a pair, and false on return
 // when the pair was handed to the wave-per-pair launch (pair = its index in mesh_pairs; G = 8 only).  [qlo, qhi]: X's bounds grown by max_sep.
 // KINDS: what X can be (bits of SGD_SHAPE_*, sgd_collide_tri): an instance for the primitives carries nothing of the general hull search, one for hulls nothing of the box's.
-template <int MESH_GROUP, int KINDS = SGD_KINDS_ALL> SGP_DEV void mesh_pair_groups(const DV& d, MeshPairLds<MESH_GROUP>& L, bool& valid, sgd_shape& X, uint32_t mid, v3 qlo, v3 qhi, float max_sep, int grp, int sub, uint32_t pair, bool& dropped, v3 movement, bool active_edges = true)
+template <int MESH_GROUP, int KINDS = SGD_KINDS_ALL> SGP_DEV void mesh_pair_groups(const DV& d, MeshPairLds<MESH_GROUP>& L, bool& valid, sgd_shape& X, uint32_t mid, v3 qlo, v3 qhi, float max_sep, int grp, int sub, uint32_t pair, bool& dropped, v3 movement, bool active_edges = true, float* lpoly = nullptr)
 {
 	MeshHeader mh; v3 mpos = V3(0.0f, 0.0f, 0.0f); m33 R = quat_to_m33(Q4(make_float4(0.0f, 0.0f, 0.0f, 1.0f)));
 	int nc = 0;
@@ -1172,7 +1172,8 @@ template <int MESH_GROUP, int KINDS = SGD_KINDS_ALL> SGP_DEV void mesh_pair_grou
 	{
 		for (int level = 0; level < 64; ++level) {
 			uint32_t* cur = (level & 1) ? L.cand : L.key; uint32_t* nxt = (level & 1) ? L.key : L.cand;
-			const uint32_t ncur = L.redo ? 0u : L.n_front[level & 1];      // (a table overflowed: what the frontiers hold no longer matters)
+			// (a table overflowed: what the frontiers hold no longer matters; eight lanes that hold more than they will keep: the pair is passed on as soon as that is known)
+			const uint32_t ncur = (L.redo || (MESH_GROUP != 64 && L.n_found > (uint32_t)MESH_BIG_MIN)) ? 0u : L.n_front[level & 1];
 			if (!__any(ncur != 0u)) break;
 			for (uint32_t i = (uint32_t)sub; i < ncur; i += MESH_GROUP) {
 				const MeshNode nd = d.mesh_nodes[mh.node_off + cur[i]];
@@ -1190,7 +1191,7 @@ template <int MESH_GROUP, int KINDS = SGD_KINDS_ALL> SGP_DEV void mesh_pair_grou
 			__syncthreads();
 		}
 	}
-	if (valid && L.redo) {
+	if (valid && L.redo && !(MESH_GROUP != 64 && L.n_found > (uint32_t)MESH_BIG_MIN)) {
 		if (sub == 0) L.n_found = (uint32_t)mesh_candidates_found(d, mh, llo, lhi, L.found, L.key, &dropped, MESH_GROUP == 64 ? MESH_BIG_CAP : MESH_BIG_MIN, MeshPairLds<MESH_GROUP>::CAP);
 	}
 	__syncthreads();
@@ -1255,16 +1256,19 @@ template <int MESH_GROUP, int KINDS = SGD_KINDS_ALL> SGP_DEV void mesh_pair_grou
 				sgd_tri_hull_t th; v3 cen, nrm;
 				sgd_tri_hull(a, b, c, &th, &cen, &nrm);
 				sgd_tri_view T; T.pos = v3_add(mpos, m33_mul(R, cen)); T.R = R; T.scale = V3(1.0f, 1.0f, 1.0f); T.h = &th;
-				hit = sgd_collide_tri<KINDS>(&X, &T, m33_mul(R, nrm), max_sep, &m, active_edges ? MESH_TRI_EDGES(tri.w) : 7u, movement, (KINDS & 2) ? &box_code : nullptr) != 0;
+				hit = sgd_collide_tri<KINDS>(&X, &T, m33_mul(R, nrm), max_sep, &m, active_edges ? MESH_TRI_EDGES(tri.w) : 7u, movement, (KINDS & 2) ? &box_code : nullptr, lpoly) != 0;
 			}
 		}
-		// the hits of this round into the pair's groups, in candidate order: one turn per lane position that holds a hit in some group of the wave
-		unsigned long long turns = __ballot(hit);
-		if (MESH_GROUP == 8) { turns |= turns >> 32; turns |= turns >> 16; turns |= turns >> 8; turns &= 0xFFull; }
-		while (turns) {
-			const int t = __ffsll((long long)turns) - 1;
-			turns &= turns - 1ull;
-			if (hit && sub == t) sgd_mesh_add(&L.mc, &m);
+		// the hits of this round into the pair's groups, in candidate order: in turn r every group of the wave merges its r-th hit (as many turns as the group
+		// with the most hits has hits -- one turn per lane POSITION with a hit somewhere in the wave was up to eight turns for two or three hits per group)
+		const unsigned long long hits = __ballot(hit);
+		const unsigned long long mine_h = MESH_GROUP == 64 ? hits : ((hits >> (grp * MESH_GROUP)) & ((1ull << (MESH_GROUP & 63)) - 1ull));
+		const int my_rank = __popcll(mine_h & ((1ull << sub) - 1ull));
+		int n_turns = __popcll(mine_h);
+#pragma unroll
+		for (int off = 32; off >= 1; off >>= 1) n_turns = max(n_turns, __shfl_xor(n_turns, off, 64));
+		for (int t = 0; t < n_turns; ++t) {
+			if (hit && my_rank == t) sgd_mesh_add(&L.mc, &m);
 			__syncthreads();
 		}
 	}
@@ -1277,6 +1281,7 @@ template <int MESH_GROUP, int KINDS> __global__ void __launch_bounds__(64) k_nar
 {
 	constexpr int MESH_PAIRS_PER_WAVE = 64 / MESH_GROUP;
 	__shared__ MeshPairLds<MESH_GROUP> lds[MESH_PAIRS_PER_WAVE];
+	__shared__ float s_lpoly[((KINDS & 2) && !(KINDS & 8)) ? 3 * SGD_LPOLY_FLOATS : 1];      // a box's clip polygons, a column per lane (sgd_tri_box_manifold)
 	const int grp = (int)(threadIdx.x / MESH_GROUP), sub = (int)(threadIdx.x % MESH_GROUP);
 	MeshPairLds<MESH_GROUP>& L = lds[grp];
 	const float max_sep = d.st.speculative_contact_distance;
@@ -1328,7 +1333,7 @@ template <int MESH_GROUP, int KINDS> __global__ void __launch_bounds__(64) k_nar
 			const v3 vx = v3_add(V3(d.vel[2 * (size_t)xid]), v3_scale(v3_scale(V3(d.gx, d.gy, d.gz), d.dyn[xid].z), d.sp->dt));
 			movement = v3_sub(vx, f_motion(d.flags[mid]) == SGP_MOTION_STATIC ? V3(0.0f, 0.0f, 0.0f) : V3(d.vel[2 * (size_t)mid]));
 		}
-		mesh_pair_groups<MESH_GROUP, KINDS>(d, L, valid, X, mid, qlo, qhi, max_sep, grp, sub, pair, dropped, movement);
+		mesh_pair_groups<MESH_GROUP, KINDS>(d, L, valid, X, mid, qlo, qhi, max_sep, grp, sub, pair, dropped, movement, true, s_lpoly + threadIdx.x);
 		// the groups as manifolds (mesh -> body), each pruned to <= 4 points; the constraint runs lower id -> higher id, with the mesh's g-th slot
 		const int ng = valid ? L.mc.ng : 0;
 		if (sub < ng) {
