@@ -312,8 +312,51 @@ template <class HA, class HB> SGP_DEV static int sgd_hull_hull(const HA* A, cons
 
 /* Closest point on the hull surface to the hull-local point l (scale 1 hulls only).  Returns the signed distance (negative
    inside), the closest point q and the outward direction n at q (unit). */
+// (corner k of face f of a mesh triangle's thin hull: the front face runs 0 1 2, the back face 0 2 1 -- sgd_tri_hull)
+SGP_DEV static int sgd_thin_face_corner(int f, int k) { return k == 0 ? 0 : (f == 0 ? k : 3 - k); }
 template <class H> SGP_DEV static float sgd_hull_closest(const H* h, v3 l, v3* q_out, v3* n_out)
 {
+	if constexpr (sgd_is_thin<H>::value) {
+		// A mesh triangle: two faces, three corners, everything at fixed places in the record -- the loops below with their counts and index tables written
+		// out, so that the compiler never meets a run-time index into the record (which then stays in registers instead of scratch memory).  Same expressions in
+		// the same order: same bits.
+		const v3 n0 = h->normals[0], n1 = h->normals[1];
+		const float s0 = v3_dot(n0, l) - h->plane_d[0], s1 = v3_dot(n1, l) - h->plane_d[1];
+		float smax = -3.4e38f; int fmax = 0;
+		if (s0 > smax) { smax = s0; fmax = 0; }
+		if (s1 > smax) { smax = s1; fmax = 1; }
+		float best = 3.4e38f; v3 bq = l; int on_face = -1;
+#pragma unroll
+		for (int f = 0; f < 2; ++f) {
+			const v3 n = f == 0 ? n0 : n1;
+			const float s = f == 0 ? s0 : s1;
+			if (s < 0.0f) continue;
+			const v3 p = v3_sub(l, v3_scale(n, s));
+			bool inside = true;
+#pragma unroll
+			for (int k = 0; k < 3; ++k) {
+				const v3 a = h->verts[sgd_thin_face_corner(f, k)], b = h->verts[sgd_thin_face_corner(f, k == 2 ? 0 : k + 1)];
+				if (inside && v3_dot(v3_cross(v3_sub(b, a), n), v3_sub(p, a)) > 0.0f) inside = false;
+			}
+			if (inside) { const float d2 = s * s; if (d2 < best) { best = d2; bq = p; on_face = f; } continue; }
+#pragma unroll
+			for (int k = 0; k < 3; ++k) {
+				const v3 a = h->verts[sgd_thin_face_corner(f, k)], b = h->verts[sgd_thin_face_corner(f, k == 2 ? 0 : k + 1)];
+				const v3 c = sgd_closest_on_segment(a, b, l);
+				const float d2 = v3_len_sq(v3_sub(l, c));
+				if (d2 < best) { best = d2; bq = c; on_face = -1; }
+			}
+		}
+		const float dist = sqrtf(best);
+		*q_out = bq;
+		if (on_face >= 0) *n_out = on_face == 0 ? n0 : n1;
+		else {
+			const v3 v = v3_sub(l, bq);
+			const float len = v3_len(v);
+			*n_out = len > 1.0e-12f ? v3_scale(v, 1.0f / len) : (fmax == 0 ? n0 : n1);
+		}
+		return dist;
+	}
 	float smax = -3.4e38f; int fmax = 0;
 	for (int f = 0; f < h->nf; ++f) { const float s = v3_dot(h->normals[f], l) - h->plane_d[f]; if (s > smax) { smax = s; fmax = f; } }
 	/* (a mesh triangle's thin hull has no side planes: a point exactly in its plane is 'inside' only above the triangle itself -- the loop below decides) */
@@ -381,26 +424,34 @@ template <class HV> SGP_DEV static int sgd_hull_capsule(const HV* H, v3 e0, v3 e
 		/* a mesh triangle (thin hull).  The distance to a convex set is C1 outside the set, so along the axis it is least at an end of the axis, at its
 		   closest approach to one of the three edges, or where it pierces the triangle: at most six evaluations, no search (a capsule on a mesh is
 		   the player on the world: this is the character controller's inner loop) */
-		float cand[6]; int ncand = 0;
-		cand[ncand++] = 0.0f; cand[ncand++] = 1.0f;
-		for (int k = 0; k < 3; ++k) cand[ncand++] = sgd_seg_seg_param(s0, s1, H->h->verts[H->h->edge_a[k]], H->h->verts[H->h->edge_b[k]]);
+		/* (the three edges run 0 - 1, 1 - 2, 0 - 2 and the front face 0 1 2 -- sgd_tri_hull --: written out, so that no index into the record is data) */
+		float cand[6]; bool have6 = false;
+		cand[0] = 0.0f; cand[1] = 1.0f;
+		cand[2] = sgd_seg_seg_param(s0, s1, H->h->verts[0], H->h->verts[1]);
+		cand[3] = sgd_seg_seg_param(s0, s1, H->h->verts[1], H->h->verts[2]);
+		cand[4] = sgd_seg_seg_param(s0, s1, H->h->verts[0], H->h->verts[2]);
+		cand[5] = 0.0f;
 		const float h0 = v3_dot(H->h->normals[0], s0) - H->h->plane_d[0], h1 = v3_dot(H->h->normals[0], s1) - H->h->plane_d[0];
 		if ((h0 > 0.0f) != (h1 > 0.0f)) {
 			/* (only a crossing INSIDE the triangle counts: a thin hull has no side planes, and a point of its plane beside the triangle would
 			   pass for "inside" in the closest-point function) */
 			const float tp = h0 / (h0 - h1);
 			const v3 P = v3_add(s0, v3_scale(d, tp));
-			int inside = 1;
-			for (int k = H->h->face_start[0]; k < H->h->face_start[1]; ++k) {
-				const v3 a = H->h->verts[H->h->face_idx[k]], b = H->h->verts[H->h->face_idx[k + 1 < H->h->face_start[1] ? k + 1 : H->h->face_start[0]]];
-				if (v3_dot(v3_cross(v3_sub(b, a), H->h->normals[0]), v3_sub(P, a)) > 0.0f) { inside = 0; break; }
+			bool inside = true;
+#pragma unroll
+			for (int k = 0; k < 3; ++k) {
+				const v3 a = H->h->verts[k], b = H->h->verts[k == 2 ? 0 : k + 1];
+				if (inside && v3_dot(v3_cross(v3_sub(b, a), H->h->normals[0]), v3_sub(P, a)) > 0.0f) inside = false;
 			}
-			if (inside) cand[ncand++] = tp;
+			if (inside) { cand[5] = tp; have6 = true; }
 		}
 		float best = 3.4e38f; ts = 0.0f;
-		for (int k = 0; k < ncand; ++k) {
-			const float fk = sgd_hull_closest(H->h, v3_add(s0, v3_scale(d, cand[k])), &q, &n);
-			if (fk < best) { best = fk; ts = cand[k]; }
+		const int ncand = have6 ? 6 : 5;
+#pragma unroll 1
+		for (int k = 0; k < ncand; ++k) {      // (one copy of the closest-point function, the parameter picked by selects)
+			const float ck = k == 0 ? cand[0] : (k == 1 ? cand[1] : (k == 2 ? cand[2] : (k == 3 ? cand[3] : (k == 4 ? cand[4] : cand[5]))));
+			const float fk = sgd_hull_closest(H->h, v3_add(s0, v3_scale(d, ck)), &q, &n);
+			if (fk < best) { best = fk; ts = ck; }
 		}
 	} else {
 		/* the distance to a convex set is convex along the segment: fixed-count ternary search */
@@ -422,34 +473,48 @@ template <class HV> SGP_DEV static int sgd_hull_capsule(const HV* H, v3 e0, v3 e
 	// axis (nearly) parallel to the supporting face: both ends of the overlap between the axis and that face
 	const float dl = v3_len(d);
 	if (dl > 1.0e-6f && dist > 0.0f && fabsf(v3_dot(n, d)) < SGD_CAPSULE_SLOP * dl) {
+		constexpr bool thin = sgd_is_thin<typename std::remove_cv<typename std::remove_pointer<decltype(H->h)>::type>::type>::value;      // (a mesh triangle: two faces of three corners at fixed places, no index into the record is data)
 		int fb = 0; float bd = -3.4e38f;
-		for (int f = 0; f < H->h->nf; ++f) { const float dd = v3_dot(H->h->normals[f], n); if (dd > bd) { bd = dd; fb = f; } }
+		if constexpr (thin) {
+			{ const float dd = v3_dot(H->h->normals[0], n); if (dd > bd) { bd = dd; fb = 0; } }
+			{ const float dd = v3_dot(H->h->normals[1], n); if (dd > bd) { bd = dd; fb = 1; } }
+		} else {
+			for (int f = 0; f < H->h->nf; ++f) { const float dd = v3_dot(H->h->normals[f], n); if (dd > bd) { bd = dd; fb = f; } }
+		}
 		if (bd > 0.95f) {
-			const v3 nf = H->h->normals[fb];
+			v3 nf; float pdf;
+			if constexpr (thin) { nf = fb == 0 ? H->h->normals[0] : H->h->normals[1]; pdf = fb == 0 ? H->h->plane_d[0] : H->h->plane_d[1]; }
+			else { nf = H->h->normals[fb]; pdf = H->h->plane_d[fb]; }
 			float t0 = 0.0f, t1 = 1.0f; int ok = 1;
-			const int k0 = H->h->face_start[fb], k1 = H->h->face_start[fb + 1];
-			for (int k = k0; k < k1 && ok; ++k) {
-				const v3 a = H->h->verts[H->h->face_idx[k]], b = H->h->verts[H->h->face_idx[k + 1 < k1 ? k + 1 : k0]];
+			auto side_plane = [&](v3 a, v3 b) {
 				const v3 side = v3_cross(v3_sub(b, a), nf);
 				const float g0 = v3_dot(side, v3_sub(s0, a)), gd = v3_dot(side, d);
 				if (fabsf(gd) < 1.0e-12f) { if (g0 > 0.0f) ok = 0; }
 				else { const float tk = -g0 / gd; if (gd > 0.0f) { if (tk < t1) t1 = tk; } else { if (tk > t0) t0 = tk; } if (t0 > t1) ok = 0; }
-			}
-			if (ok && (t1 - t0) * dl > 1.0e-4f) {
-				const float tt[2] = { t0, t1 };
-				v3 a1[2], a2[2]; int np = 0;
-				for (int i = 0; i < 2; ++i) {
-					const v3 P = v3_add(s0, v3_scale(d, tt[i]));
-					const float sep = v3_dot(nf, P) - H->h->plane_d[fb] - r;
-					if (sep <= max_sep) {
-						a1[np] = v3_sub(P, v3_scale(nf, v3_dot(nf, P) - H->h->plane_d[fb]));
-						a2[np] = v3_sub(P, v3_scale(n, r));
-						++np;
+			};
+			if constexpr (thin) {
+#pragma unroll
+				for (int k = 0; k < 3; ++k) {
+					if (ok) {
+						const v3 a = fb == 0 ? H->h->verts[sgd_thin_face_corner(0, k)] : H->h->verts[sgd_thin_face_corner(1, k)];
+						const v3 b = fb == 0 ? H->h->verts[sgd_thin_face_corner(0, k == 2 ? 0 : k + 1)] : H->h->verts[sgd_thin_face_corner(1, k == 2 ? 0 : k + 1)];
+						side_plane(a, b);
 					}
 				}
-				if (np == 2) {
+			} else {
+				const int k0 = H->h->face_start[fb], k1 = H->h->face_start[fb + 1];
+				for (int k = k0; k < k1 && ok; ++k) side_plane(H->h->verts[H->h->face_idx[k]], H->h->verts[H->h->face_idx[k + 1 < k1 ? k + 1 : k0]]);
+			}
+			if (ok && (t1 - t0) * dl > 1.0e-4f) {
+				// both ends of the overlap, or nothing (two points are reported only when both are within reach)
+				const v3 P0 = v3_add(s0, v3_scale(d, t0)), P1 = v3_add(s0, v3_scale(d, t1));
+				const float sep0 = v3_dot(nf, P0) - pdf - r, sep1 = v3_dot(nf, P1) - pdf - r;
+				if (sep0 <= max_sep && sep1 <= max_sep) {
+					const v3 a10 = v3_sub(P0, v3_scale(nf, v3_dot(nf, P0) - pdf)), a20 = v3_sub(P0, v3_scale(n, r));
+					const v3 a11 = v3_sub(P1, v3_scale(nf, v3_dot(nf, P1) - pdf)), a21 = v3_sub(P1, v3_scale(n, r));
 					m->np = 2;
-					for (int i = 0; i < 2; ++i) { m->p1[i] = v3_add(H->pos, m33_mul(H->R, a1[i])); m->p2[i] = v3_add(H->pos, m33_mul(H->R, a2[i])); }
+					m->p1[0] = v3_add(H->pos, m33_mul(H->R, a10)); m->p2[0] = v3_add(H->pos, m33_mul(H->R, a20));
+					m->p1[1] = v3_add(H->pos, m33_mul(H->R, a11)); m->p2[1] = v3_add(H->pos, m33_mul(H->R, a21));
 				}
 			}
 		}
