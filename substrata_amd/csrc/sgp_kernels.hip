@@ -1132,6 +1132,44 @@ SGP_DEV int mesh_candidates_found(const DV& d, const MeshHeader& mh, v3 llo, v3 
 	return n;
 }
 
+// sgd_mesh_add by the lanes of a pair together (whole wave: every lane calls this; `mine`: this lane's manifold m is the one its pair merges in this turn -- at
+// most one lane per pair).  The sequential function compares every point of the manifold with every point its group already holds, one lane at work while the
+// others wait: ~4 us per manifold, and a wave-per-pair round merges dozens of them.  Here the manifold is handed to all lanes of the pair, which look for its
+// group (the same reads, the same answer) and share the comparisons; lane 0 of the pair appends.  The same decisions in the same order: the same groups.
+template <int G> SGP_DEV void mesh_add_coop(sgd_mesh_contacts& mc, bool mine, const sgd_manifold& m, int grp, int sub)
+{
+	const unsigned long long gmask = G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull);
+	const unsigned long long who = (__ballot(mine) >> (G == 64 ? 0 : grp * G)) & gmask;
+	const bool any = who != 0ull;
+	const int src = (any ? __ffsll((long long)who) - 1 : 0) + (G == 64 ? 0 : grp * G);
+	const v3 n = V3(__shfl(m.n.x, src, 64), __shfl(m.n.y, src, 64), __shfl(m.n.z, src, 64));
+	const int np = any ? __shfl(m.np, src, 64) : 0;
+	int gi = -1; bool open_new = false;
+	if (any) {
+		const int ng = mc.ng;
+		for (int k = 0; k < ng; ++k) if (v3_dot(mc.g[k].n, n) >= SGD_MESH_GROUP_COS) { gi = k; break; }
+		if (gi < 0 && ng < SGD_MESH_MAX_GROUPS) { gi = ng; open_new = true; }
+	}
+	__syncthreads();
+	if (open_new && sub == 0) { mc.g[gi].n = n; mc.g[gi].np = 0; mc.ng = gi + 1; }
+	__syncthreads();
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {      // (a triangle's manifold: at most four points)
+		const v3 p1 = V3(__shfl(m.p1[i].x, src, 64), __shfl(m.p1[i].y, src, 64), __shfl(m.p1[i].z, src, 64));
+		const v3 p2 = V3(__shfl(m.p2[i].x, src, 64), __shfl(m.p2[i].y, src, 64), __shfl(m.p2[i].z, src, 64));
+		const bool act = any && gi >= 0 && i < np;
+		bool dup = false; int gnp = 0;
+		if (act) {
+			gnp = mc.g[gi].np;
+			// the same point reached through two triangles that share it (an edge or a vertex of the mesh) counts once
+			for (int j = sub; j < gnp; j += G) if (v3_len_sq(v3_sub(mc.g[gi].p_body[j], p2)) < 1.0e-8f) dup = true;
+		}
+		const bool pair_dup = ((__ballot(dup) >> (G == 64 ? 0 : grp * G)) & gmask) != 0ull;
+		if (act && sub == 0 && gnp < SGD_HULL_CLIP_CAP && !pair_dup) { mc.g[gi].p_mesh[gnp] = p1; mc.g[gi].p_body[gnp] = p2; mc.g[gi].np = gnp + 1; }
+		__syncthreads();
+	}
+}
+
 // The groups of one (body X, mesh body mid) pair by the lanes of its group (whole workgroup: every lane calls this; lanes of a group pass the same
 // pair): what lies between "here is the pair" and "here are its <= 3 groups in L.mc".  valid: false for a group without a pair, and false on return
 // when the pair was handed to the wave-per-pair launch (pair = its index in mesh_pairs; G = 8 only).  [qlo, qhi]: X's bounds grown by max_sep.
@@ -1248,7 +1286,7 @@ template <int MESH_GROUP, int KINDS = SGD_KINDS_ALL> SGP_DEV void mesh_pair_grou
 	if ((KINDS & 2) && valid && X.type == SGD_SHAPE_BOX) box_code = sgd_box_code_of(&d.hulls[0]);
 	for (int rd = 0; rd < rounds; ++rd) {
 		const int k = rd * MESH_GROUP + sub;
-		bool hit = false; sgd_manifold m;
+		bool hit = false; sgd_manifold m; m.np = 0;
 		if (valid && k < nc) {
 			const uint4 tri = d.mesh_tris[mh.tri_off + L.key[k]];      // (the packed list: every entry passed the bounds test)
 			const v3 a = V3(d.mesh_verts[mh.vert_off + tri.x]), b = V3(d.mesh_verts[mh.vert_off + tri.y]), c = V3(d.mesh_verts[mh.vert_off + tri.z]);
@@ -1267,9 +1305,11 @@ template <int MESH_GROUP, int KINDS = SGD_KINDS_ALL> SGP_DEV void mesh_pair_grou
 		int n_turns = __popcll(mine_h);
 #pragma unroll
 		for (int off = 32; off >= 1; off >>= 1) n_turns = max(n_turns, __shfl_xor(n_turns, off, 64));
+		// (eight lanes per pair: the lanes share a merge's comparisons; a wave per pair: dozens of turns per round, and a turn of the shared form -- thirty
+		// lane-to-lane moves of the manifold and six barriers -- measured longer than one lane's walk through the group: 0.35 -> 0.40 ms on the car-sized boxes)
 		for (int t = 0; t < n_turns; ++t) {
-			if (hit && my_rank == t) sgd_mesh_add(&L.mc, &m);
-			__syncthreads();
+			if (MESH_GROUP == 8) mesh_add_coop<MESH_GROUP>(L.mc, hit && my_rank == t, m, grp, sub);
+			else { if (hit && my_rank == t) sgd_mesh_add(&L.mc, &m); __syncthreads(); }
 		}
 	}
 }
