@@ -889,7 +889,9 @@ SGP_DEV bool reuse_cached_manifold(const DV& d, uint2 ab, uint32_t fa, uint32_t 
 // (at least four waves per SIMD: the kernel waits for its gathers three cycles in four, and 128 instead of 157 registers per lane -- a few spills to
 // scratch -- buy a third more waves to wait with: 138 -> 116 us at config 3; five waves: 143 us, six: 178 us)
 // ROUND 0: the broad phase's pairs; ROUND 1: the pairs of the bodies this step wakes (k_wake_pairs)
-template <int ROUND> SGP_DEV void narrowphase_pairs(const DV& d)
+// (HULLS = false: the world holds no convex hull -- the plan knows -- and the activation round's instance carries nothing of the sequential hull search: a launch of a
+// handful of pairs lasts as long as its cold code takes to arrive)
+template <int ROUND, bool HULLS = true> SGP_DEV void narrowphase_pairs(const DV& d)
 {
 	__shared__ uint32_t s_wave_cnt[TPB / 64];
 	__shared__ uint32_t s_base;
@@ -920,7 +922,7 @@ template <int ROUND> SGP_DEV void narrowphase_pairs(const DV& d)
 				// jittering; a sphere or capsule contact is recomputed (a few dozen instructions, the same answer every step)
 				const bool polytopes = (f_shape(fa) == SGP_SHAPE_BOX || f_shape(fa) == SGP_SHAPE_HULL) && (f_shape(fb) == SGP_SHAPE_BOX || f_shape(fb) == SGP_SHAPE_HULL);
 				if (polytopes && reuse_cached_manifold(d, ab, fa, fb, &m, &prev)) have = true;
-				else if (f_shape(fa) == SGP_SHAPE_HULL || f_shape(fb) == SGP_SHAPE_HULL) {
+				else if ((HULLS || ROUND == 0) && (f_shape(fa) == SGP_SHAPE_HULL || f_shape(fb) == SGP_SHAPE_HULL)) {
 					// the polytope paths (clip buffers in scratch, long loops) live in their own kernel so that they do not cost the
 					// sphere / box / capsule pairs registers or scratch
 					if constexpr (ROUND == 0) {
@@ -957,7 +959,7 @@ template <int ROUND> SGP_DEV void narrowphase_pairs(const DV& d)
 	}
 }
 __global__ void __launch_bounds__(TPB, 4) k_narrowphase(DV d) { narrowphase_pairs<0>(d); }
-__global__ void __launch_bounds__(TPB, 4) k_narrowphase_wake(DV d) { narrowphase_pairs<1>(d); }
+template <bool HULLS> __global__ void __launch_bounds__(TPB, 4) k_narrowphase_wake(DV d) { narrowphase_pairs<1, HULLS>(d); }
 
 // IN-STEP ACTIVATION (PhysicsSystem::JobFindCollisions keeps taking bodies from the active list while ProcessBodyPair appends the ones it wakes: a woken
 // body collides in the step that woke it, and wakes what it touches in turn).  One extra round: a body the narrow phase or a wheel marked takes along
@@ -5006,7 +5008,8 @@ void launch_narrowphase(const DV& d, uint32_t est, hipStream_t s)
 void launch_wake_round(const DV& d, uint32_t nb, bool has_hulls, bool has_meshes, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_wake_pairs, dim3(blocks_for(nb)), dim3(TPB), 0, s, d);
-	hipLaunchKernelGGL(k_narrowphase_wake, dim3(32), dim3(TPB), 0, s, d);      // (few pairs, 1.7 KB of scratch per lane: a small grid starts faster)
+	if (has_hulls) hipLaunchKernelGGL(k_narrowphase_wake<true>, dim3(32), dim3(TPB), 0, s, d);      // (few pairs, 1.7 KB of scratch per lane: a small grid starts faster)
+	else hipLaunchKernelGGL(k_narrowphase_wake<false>, dim3(32), dim3(TPB), 0, s, d);
 	// (hull pairs of this round are collided by k_narrowphase_wake itself; hull - mesh pairs by the hull instances of the mesh kernels)
 	if (has_meshes) {
 		hipLaunchKernelGGL((k_narrowphase_mesh<8, SGD_KINDS_PRIMITIVES>), dim3(256), dim3(64), 0, s, d);
