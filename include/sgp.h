@@ -631,7 +631,7 @@ typedef struct sgp_tiles_stats {
 	uint32_t received;       /* records that arrived                                                                     */
 	uint32_t ghosts;         /* ... of which ghosts                                                                      */
 	uint32_t emigrated, immigrated;
-	uint32_t fast_imports, slow_imports;     /* exchanges whose import ran on the device / went through the host (cumulative) */
+	uint32_t fast_imports, slow_imports;     /* cumulative: exchanges that found the ghost set unchanged (the host saw 16 bytes per record) / in which the host created or removed bodies (the set changed, bodies immigrated); the ghosts' POSES go from the received records to the bodies on the device either way */
 	uint32_t route_retries;  /* exchanges that had to grow this tile's send / emigrant buffers and route again (local, no extra collective) */
 	uint32_t comm_ranks;     /* ranks ncclCommCount reports for this tile's communicator (0: no communicator, e.g. tiles of one process) */
 	uint32_t exchanges;      /* sgp_tiles_exchange calls so far                                                           */

@@ -4923,6 +4923,7 @@ __global__ void __launch_bounds__(TPB) k_ghost_refresh_records(DV d, const sgp_g
 	const uint32_t k = blockIdx.x * TPB + threadIdx.x;
 	if (k >= n) return;
 	const uint32_t i = ids[k];
+	if (i == SGP_INVALID_ID) return;      // (a record that is no ghost here: an immigrant of the same exchange, a rejected one)
 	uint32_t f = d.flags[i];
 	if (!(f & BF_ALIVE)) return;
 	const sgp_ghost_record& c = recs[k];

@@ -2508,18 +2508,20 @@ SGP_API int sgp_world_export_boundary(sgp_world* w, const float lo[3], const flo
 // device array for the local body id of every record (grown here); surviving ghosts are then refreshed by ONE kernel, not by commands.
 struct GhostDeviceSource { const sgp_ghost_record* d_recs; uint32_t** d_ids; uint32_t* cap_ids; uint64_t* ids_version; };
 
-static int upload_ghost_ids(sgp_world* w, const GhostDeviceSource* dev)
+// (skip: per RECORD, 1 = not a ghost here (an immigrant of the same exchange); the id array stays aligned with the records, such entries hold "no body")
+static int upload_ghost_ids(sgp_world* w, const GhostDeviceSource* dev, const uint8_t* skip = nullptr, uint32_t n_records = 0)
 {
-	const uint32_t n = (uint32_t)w->ghost_seq.size();
+	const uint32_t n = skip ? n_records : (uint32_t)w->ghost_seq.size();
 	std::vector<uint32_t> ids(n);
-	for (uint32_t k = 0; k < n; ++k) ids[k] = w->ghost_seq[k].second;
+	if (skip) { size_t g = 0; for (uint32_t k = 0; k < n; ++k) ids[k] = skip[k] ? SGP_INVALID_ID : w->ghost_seq[g++].second; }
+	else for (uint32_t k = 0; k < n; ++k) ids[k] = w->ghost_seq[k].second;
 	if (n > *dev->cap_ids) {
 		if (*dev->d_ids) { HIP_TRY(hipStreamSynchronize(w->stream)); hipFree(*dev->d_ids); }
 		*dev->cap_ids = n + n / 2 + 1024;
 		HIP_TRY(hipMalloc((void**)dev->d_ids, sizeof(uint32_t) * (size_t)*dev->cap_ids));
 	}
 	if (n) { HIP_TRY(hipMemcpyAsync(*dev->d_ids, ids.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, w->stream)); HIP_TRY(hipStreamSynchronize(w->stream)); }      // (`ids` is pageable memory going out of scope)
-	*dev->ids_version = w->ghost_seq_version;
+	*dev->ids_version = skip ? ~0ull : w->ghost_seq_version;      // (an array with holes serves this import only: the next one that finds the set unchanged uploads the plain list)
 	return SGP_OK;
 }
 
@@ -2540,7 +2542,23 @@ static int make_ghost(sgp_world* w, const sgp_ghost_record& r, uint32_t* id_out)
 	return add_one(w, &d, id_out, true);
 }
 
-static int import_ghosts_impl(sgp_world* w, const sgp_ghost_record* in, uint32_t n, const GhostDeviceSource* dev)
+static int import_ghosts_impl(sgp_world* w, const sgp_ghost_record* in_all, uint32_t n_all, const GhostDeviceSource* dev, const uint8_t* skip = nullptr);
+// (skip[k] = 1: record k is no ghost -- an immigrant riding in the same exchange -- and is left out; with a device source the records stay where they are and
+// the id array has a hole there)
+struct GhostView {      // the ghost records of an import: all of them, or those a mask lets through (by index: nothing is copied)
+	const sgp_ghost_record* base; const uint32_t* idx; uint32_t n;
+	const sgp_ghost_record& operator[](uint32_t k) const { return idx ? base[idx[k]] : base[k]; }
+};
+static int import_ghosts_view(sgp_world* w, const GhostView& in, uint32_t n, const GhostDeviceSource* dev, const uint8_t* skip, uint32_t n_all);
+static int import_ghosts_impl(sgp_world* w, const sgp_ghost_record* in_all, uint32_t n_all, const GhostDeviceSource* dev, const uint8_t* skip)
+{
+	if (!skip) { GhostView v = { in_all, nullptr, n_all }; return import_ghosts_view(w, v, n_all, dev, nullptr, n_all); }
+	std::vector<uint32_t> idx; idx.reserve(n_all);
+	for (uint32_t k = 0; k < n_all; ++k) if (!skip[k]) idx.push_back(k);
+	GhostView v = { in_all, idx.data(), (uint32_t)idx.size() };
+	return import_ghosts_view(w, v, v.n, dev, skip, n_all);
+}
+static int import_ghosts_view(sgp_world* w, const GhostView& in, uint32_t n, const GhostDeviceSource* dev, const uint8_t* skip, uint32_t n_all)
 {
 	// ghosts keep their local id while they stay in the set, so the contact cache (keyed by body ids) keeps warm-starting.
 	// ghost_seq: (global id, local id) of the previous import, in its order
@@ -2551,8 +2569,8 @@ static int import_ghosts_impl(sgp_world* w, const sgp_ghost_record* in, uint32_t
 		if (same) {
 			if (dev) {
 				{ int r = flush_cmds(w); if (r != SGP_OK) return r; }
-				if (*dev->ids_version != w->ghost_seq_version) { int r = upload_ghost_ids(w, dev); if (r != SGP_OK) return r; }      // (the set was last changed by an import that did not come through here)
-				launch_ghost_refresh_records(w->dv, dev->d_recs, *dev->d_ids, n, w->stream);
+				if (skip || *dev->ids_version != w->ghost_seq_version) { int r = upload_ghost_ids(w, dev, skip, n_all); if (r != SGP_OK) return r; }      // (the set was last changed by an import that did not come through here; or the records hold immigrants between the ghosts)
+				launch_ghost_refresh_records(w->dv, dev->d_recs, *dev->d_ids, n_all, w->stream);
 				w->grid_valid = false; w->dirty_since_step = true;
 				return SGP_OK;
 			}
@@ -2635,18 +2653,11 @@ static int import_ghosts_impl(sgp_world* w, const sgp_ghost_record* in, uint32_t
 	w->ghost_seq.swap(seq);
 	w->ghost_seq_version++;
 	if (dev && n) {
-		// new ghosts and removals reach the device first, then ONE kernel gives every ghost of the set its pose from the received records
-		std::vector<uint32_t> ids(n);
-		bool all = true;
-		for (uint32_t k = 0; k < n; ++k) { ids[k] = w->ghost_seq[k].second; if (ids[k] == SGP_INVALID_ID) all = false; }
+		// new ghosts and removals reach the device first, then ONE kernel gives every ghost of the set its pose from the received records (a rejected
+		// record -- non-finite pose ... -- has "no body" in the id array, like an immigrant's: the kernel passes over it)
 		{ int r = flush_cmds(w); if (r != SGP_OK) return r; }
-		if (!all) {          // a rejected record (non-finite pose ...): its slot in the id array points at the ground-truth "no body" -> refresh the rest by commands
-			for (uint32_t k = 0; k < n; ++k) if (ids[k] != SGP_INVALID_ID) { BodyCmd c = blank_cmd(ids[k], CMD_SET_POS | CMD_SET_ROT | CMD_SET_VEL | CMD_ACTIVATE);
-				memcpy(c.pos, in[k].pos, 12); memcpy(c.rot, in[k].rot, 16); memcpy(c.linv, in[k].lin_vel, 12); memcpy(c.angv, in[k].ang_vel, 12); w->cmds.push_back(c); }
-			return SGP_OK;
-		}
-		{ int r = upload_ghost_ids(w, dev); if (r != SGP_OK) return r; }
-		launch_ghost_refresh_records(w->dv, dev->d_recs, *dev->d_ids, n, w->stream);
+		{ int r = upload_ghost_ids(w, dev, skip, n_all); if (r != SGP_OK) return r; }
+		launch_ghost_refresh_records(w->dv, dev->d_recs, *dev->d_ids, n_all, w->stream);
 		w->grid_valid = false; w->dirty_since_step = true;
 	}
 	return SGP_OK;
@@ -3042,14 +3053,22 @@ static int tiles_import(sgp_tiles* t, uint32_t n)
 		if (unchanged) t->stats.fast_imports++; else t->stats.slow_imports++;
 		return SGP_OK;
 	}
-	std::vector<sgp_ghost_record> ghosts; ghosts.reserve(n);
+	// bodies immigrate with this exchange: their records sit between the ghosts'.  The ghosts still take the device path (by index: no record is copied, no
+	// refresh command is made -- a tile of the collapsing tower holds 25 000 ghosts and receives immigrants in EVERY step: 3.5 MB of records copied and
+	// 25 000 commands built, uploaded and applied per step was most of the exchange's 1.2 ms, profiles/r04_tiles_import.md)
+	std::vector<uint8_t> skip(n, 0);
 	std::vector<const sgp_ghost_record*> immigrants;
+	uint32_t n_ghosts = 0;
 	for (uint32_t k = 0; k < n; ++k) {
 		const sgp_ghost_record& r = t->h_recv[k];
-		if (!(r.motion_type & SGP_GHOST_TAKE_OWNERSHIP)) ghosts.push_back(r);
-		else if (in_box(r.pos, lo, hi, 0.0f)) immigrants.push_back(&r);
+		if (!(r.motion_type & SGP_GHOST_TAKE_OWNERSHIP)) { ++n_ghosts; continue; }
+		skip[k] = 1;
+		if (in_box(r.pos, lo, hi, 0.0f)) immigrants.push_back(&r);
 	}
-	{ int rc = import_ghosts_impl(w, ghosts.data(), (uint32_t)ghosts.size(), nullptr); if (rc != SGP_OK) return rc; }
+	{
+		GhostDeviceSource dev = { t->d_recv, &t->d_seq_ids, &t->cap_seq, &t->ids_version };
+		int rc = import_ghosts_impl(w, t->h_recv, n, &dev, skip.data()); if (rc != SGP_OK) return rc;
+	}
 	uint32_t n_imm = 0;
 	for (const sgp_ghost_record* pr : immigrants) {
 		const sgp_ghost_record& r = *pr;
@@ -3070,7 +3089,7 @@ static int tiles_import(sgp_tiles* t, uint32_t n)
 		t->migrations.push_back(m);
 		++n_imm;
 	}
-	t->stats.immigrated = n_imm; t->stats.ghosts = (uint32_t)ghosts.size(); t->stats.slow_imports++;
+	t->stats.immigrated = n_imm; t->stats.ghosts = n_ghosts; t->stats.slow_imports++;
 	return SGP_OK;
 }
 
