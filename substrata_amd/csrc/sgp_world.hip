@@ -1041,7 +1041,14 @@ static int flush_cmds(sgp_world* w)
 	for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
 	bool ordered = true;
 	for (size_t i = 1; i < n && ordered; ++i) ordered = w->cmds[i - 1].id <= w->cmds[i].id;
-	if (!ordered) std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return w->cmds[a].id < w->cmds[b].id; });
+	if (!ordered) {
+		// (body id, position in the queue) as one 64-bit key: a plain sort of the keys IS the stable sort by id, without a comparison that walks
+		// through the command records (thousands of ghost creations and removals per exchange of a tile: the sort was a third of the flush)
+		std::vector<uint64_t> keys(n);
+		for (size_t i = 0; i < n; ++i) keys[i] = ((uint64_t)w->cmds[i].id << 32) | (uint64_t)i;
+		std::sort(keys.begin(), keys.end());
+		for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)(keys[i] & 0xFFFFFFFFull);
+	}
 	const size_t cmd_bytes = n * sizeof(BodyCmd);
 	const size_t run_off = (cmd_bytes + 15) & ~size_t(15);
 	const size_t total = run_off + (n + 1) * sizeof(uint32_t);
@@ -2542,20 +2549,22 @@ static int make_ghost(sgp_world* w, const sgp_ghost_record& r, uint32_t* id_out)
 	return add_one(w, &d, id_out, true);
 }
 
-static int import_ghosts_impl(sgp_world* w, const sgp_ghost_record* in_all, uint32_t n_all, const GhostDeviceSource* dev, const uint8_t* skip = nullptr);
+static int import_ghosts_impl(sgp_world* w, const sgp_ghost_record* in_all, uint32_t n_all, const GhostDeviceSource* dev, const uint8_t* skip = nullptr, const uint64_t* gids = nullptr, uint32_t gid_stride = 0);
 // (skip[k] = 1: record k is no ghost -- an immigrant riding in the same exchange -- and is left out; with a device source the records stay where they are and
 // the id array has a hole there)
 struct GhostView {      // the ghost records of an import: all of them, or those a mask lets through (by index: nothing is copied)
 	const sgp_ghost_record* base; const uint32_t* idx; uint32_t n;
+	const uint64_t* gids; uint32_t gid_stride;      // the records' global ids packed (16-byte keys of the exchange), or NULL: the diff then walks 16 bytes per record, not 128
 	const sgp_ghost_record& operator[](uint32_t k) const { return idx ? base[idx[k]] : base[k]; }
+	uint64_t gid(uint32_t k) const { const uint32_t r = idx ? idx[k] : k; return gids ? gids[(size_t)r * gid_stride] : base[r].global_id; }
 };
 static int import_ghosts_view(sgp_world* w, const GhostView& in, uint32_t n, const GhostDeviceSource* dev, const uint8_t* skip, uint32_t n_all);
-static int import_ghosts_impl(sgp_world* w, const sgp_ghost_record* in_all, uint32_t n_all, const GhostDeviceSource* dev, const uint8_t* skip)
+static int import_ghosts_impl(sgp_world* w, const sgp_ghost_record* in_all, uint32_t n_all, const GhostDeviceSource* dev, const uint8_t* skip, const uint64_t* gids, uint32_t gid_stride)
 {
-	if (!skip) { GhostView v = { in_all, nullptr, n_all }; return import_ghosts_view(w, v, n_all, dev, nullptr, n_all); }
+	if (!skip) { GhostView v = { in_all, nullptr, n_all, gids, gid_stride }; return import_ghosts_view(w, v, n_all, dev, nullptr, n_all); }
 	std::vector<uint32_t> idx; idx.reserve(n_all);
 	for (uint32_t k = 0; k < n_all; ++k) if (!skip[k]) idx.push_back(k);
-	GhostView v = { in_all, idx.data(), (uint32_t)idx.size() };
+	GhostView v = { in_all, idx.data(), (uint32_t)idx.size(), gids, gid_stride };
 	return import_ghosts_view(w, v, v.n, dev, skip, n_all);
 }
 static int import_ghosts_view(sgp_world* w, const GhostView& in, uint32_t n, const GhostDeviceSource* dev, const uint8_t* skip, uint32_t n_all)
@@ -2565,7 +2574,7 @@ static int import_ghosts_view(sgp_world* w, const GhostView& in, uint32_t n, con
 	// 1. the usual case: the same ghosts as in the previous import, in the same order -- no bookkeeping, just refresh their poses
 	if (n == w->ghost_seq.size() && n > 0) {
 		bool same = true;
-		for (uint32_t k = 0; k < n && same; ++k) same = in[k].global_id == w->ghost_seq[k].first && live(w, w->ghost_seq[k].second);
+		for (uint32_t k = 0; k < n && same; ++k) same = in.gid(k) == w->ghost_seq[k].first && live(w, w->ghost_seq[k].second);
 		if (same) {
 			if (dev) {
 				{ int r = flush_cmds(w); if (r != SGP_OK) return r; }
@@ -2598,24 +2607,24 @@ static int import_ghosts_view(sgp_world* w, const GhostView& in, uint32_t n, con
 	//    id): a two-pointer diff finds who stayed, who is new and who left, without hashing.  New ghosts take their slots in record order,
 	//    leavers are removed afterwards in ascending id order -- the same allocation order as the general path below.
 	bool ascending = true;
-	for (uint32_t k = 1; k < n && ascending; ++k) ascending = in[k - 1].global_id < in[k].global_id;
+	for (uint32_t k = 1; k < n && ascending; ++k) ascending = in.gid(k - 1) < in.gid(k);
 	for (size_t k = 1; k < w->ghost_seq.size() && ascending; ++k) ascending = w->ghost_seq[k - 1].first < w->ghost_seq[k].first;
 	if (ascending) {
 		const std::vector<std::pair<uint64_t, uint32_t>>& old = w->ghost_seq;
 		size_t i = 0, j = 0;
 		while (i < n || j < old.size()) {
-			if (j == old.size() || (i < n && in[i].global_id < old[j].first)) {
+			if (j == old.size() || (i < n && in.gid(i) < old[j].first)) {
 				uint32_t id; const int r = make_ghost(w, in[i], &id);
 				if (r != SGP_OK && r != SGP_ERR_REJECTED) return r;
-				seq[i] = std::make_pair(in[i].global_id, r == SGP_OK ? id : SGP_INVALID_ID); ++i;
-			} else if (i == n || old[j].first < in[i].global_id) {
+				seq[i] = std::make_pair(in.gid(i), r == SGP_OK ? id : SGP_INVALID_ID); ++i;
+			} else if (i == n || old[j].first < in.gid(i)) {
 				if (old[j].second != SGP_INVALID_ID && live(w, old[j].second)) gone.push_back(old[j].second);
 				++j;
 			} else {
 				uint32_t id = old[j].second;
 				if (id != SGP_INVALID_ID && live(w, id)) refresh_cmd(id, in[i]);
 				else { const int r = make_ghost(w, in[i], &id); if (r != SGP_OK && r != SGP_ERR_REJECTED) return r; if (r != SGP_OK) id = SGP_INVALID_ID; }
-				seq[i] = std::make_pair(in[i].global_id, id); ++i; ++j;
+				seq[i] = std::make_pair(in.gid(i), id); ++i; ++j;
 			}
 		}
 		w->ghost_map_stale = true;
@@ -2628,8 +2637,8 @@ static int import_ghosts_view(sgp_world* w, const GhostView& in, uint32_t n, con
 		}
 		const uint32_t gen = ++w->ghost_gen;
 		for (uint32_t k = 0; k < n; ++k) {
-			seq[k].first = in[k].global_id;
-			auto it = w->ghost_map.find(in[k].global_id);
+			seq[k].first = in.gid(k);
+			auto it = w->ghost_map.find(in.gid(k));
 			if (it != w->ghost_map.end() && live(w, (uint32_t)it->second)) {
 				const uint32_t id = (uint32_t)it->second;
 				refresh_cmd(id, in[k]);
@@ -2638,7 +2647,7 @@ static int import_ghosts_view(sgp_world* w, const GhostView& in, uint32_t n, con
 				continue;
 			}
 			uint32_t id; const int r = make_ghost(w, in[k], &id);
-			if (r == SGP_OK) { w->ghost_map[in[k].global_id] = ((uint64_t)gen << 32) | id; seq[k].second = id; }
+			if (r == SGP_OK) { w->ghost_map[in.gid(k)] = ((uint64_t)gen << 32) | id; seq[k].second = id; }
 			else if (r != SGP_ERR_REJECTED) return r;
 		}
 		// whatever was not refreshed by this import left the ghost set
@@ -3039,16 +3048,17 @@ static int tiles_import(sgp_tiles* t, uint32_t n)
 	}
 	// who is a ghost, who immigrates (flagged records addressed to another tile are dropped)
 	const float* lo = t->route.boxes + 6 * t->rank; const float* hi = lo + 3;
+	const GhostKey* keys = (const GhostKey*)t->h_keys;      // (n > 0: packed above; the scans below read 16 bytes per record instead of 128)
 	bool plain = true;
-	for (uint32_t k = 0; k < n && plain; ++k) plain = !(t->h_recv[k].motion_type & SGP_GHOST_TAKE_OWNERSHIP);
+	for (uint32_t k = 0; k < n && plain; ++k) plain = !(keys[k].motion_type & SGP_GHOST_TAKE_OWNERSHIP);
 	const size_t seq_before = w->ghost_seq.size();
 	if (plain) {
 		// ghosts only: the poses stay on the device -- the host compares global ids (and creates / removes the few bodies that entered or left
 		// the set), one kernel refreshes every ghost from the received records
 		bool unchanged = n == seq_before;            // (no ghosts before, none now: nothing for the host to do either)
-		for (uint32_t k = 0; k < n && unchanged; ++k) unchanged = t->h_recv[k].global_id == w->ghost_seq[k].first;
+		for (uint32_t k = 0; k < n && unchanged; ++k) unchanged = keys[k].global_id == w->ghost_seq[k].first;
 		GhostDeviceSource dev = { t->d_recv, &t->d_seq_ids, &t->cap_seq, &t->ids_version };
-		{ int rc = import_ghosts_impl(w, t->h_recv, n, &dev); if (rc != SGP_OK) return rc; }
+		{ int rc = import_ghosts_impl(w, t->h_recv, n, &dev, nullptr, (const uint64_t*)t->h_keys, 2); if (rc != SGP_OK) return rc; }
 		t->stats.ghosts = n; t->stats.immigrated = 0;
 		if (unchanged) t->stats.fast_imports++; else t->stats.slow_imports++;
 		return SGP_OK;
@@ -3060,14 +3070,14 @@ static int tiles_import(sgp_tiles* t, uint32_t n)
 	std::vector<const sgp_ghost_record*> immigrants;
 	uint32_t n_ghosts = 0;
 	for (uint32_t k = 0; k < n; ++k) {
+		if (!(keys[k].motion_type & SGP_GHOST_TAKE_OWNERSHIP)) { ++n_ghosts; continue; }
 		const sgp_ghost_record& r = t->h_recv[k];
-		if (!(r.motion_type & SGP_GHOST_TAKE_OWNERSHIP)) { ++n_ghosts; continue; }
 		skip[k] = 1;
 		if (in_box(r.pos, lo, hi, 0.0f)) immigrants.push_back(&r);
 	}
 	{
 		GhostDeviceSource dev = { t->d_recv, &t->d_seq_ids, &t->cap_seq, &t->ids_version };
-		int rc = import_ghosts_impl(w, t->h_recv, n, &dev, skip.data()); if (rc != SGP_OK) return rc;
+		int rc = import_ghosts_impl(w, t->h_recv, n, &dev, skip.data(), (const uint64_t*)t->h_keys, 2); if (rc != SGP_OK) return rc;
 	}
 	uint32_t n_imm = 0;
 	for (const sgp_ghost_record* pr : immigrants) {
