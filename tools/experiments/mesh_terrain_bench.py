@@ -48,10 +48,18 @@ def small_bodies_on_terrain(n):
     d = scenes.dynamic_bodies(n)
     kinds = rng.integers(0, 3, size=n)
     import os
-    if os.environ.get("MESH_BENCH_KIND"): kinds[:] = int(os.environ["MESH_BENCH_KIND"])      # all spheres (0) / boxes (1) / capsules (2): what each kind costs
+    if os.environ.get("MESH_BENCH_KIND"): kinds[:] = int(os.environ["MESH_BENCH_KIND"])      # all spheres (0) / boxes (1) / capsules (2) / convex hulls (3): what each kind costs
     d["shape_type"] = kinds
     d["shape"][:, :3] = 0.4
     d["shape"][kinds == 2, 1] = 0.5; d["shape"][kinds == 2, 0] = 0.25
+    if (kinds == 3).any():                                    # convex hulls: eight different 14-point clouds of the boxes' size
+        hull_ids = []
+        for k in range(8):
+            pts = rng.normal(size=(14, 3)); pts = (pts / np.linalg.norm(pts, axis=1, keepdims=True) * rng.uniform(0.3, 0.45, (14, 1))).astype(np.float32)
+            hull_ids.append(w.hull_create(pts).hull_id)
+        sel = np.flatnonzero(kinds == 3)
+        d["shape"][sel] = 0
+        d["shape"][sel, 0] = np.array(hull_ids, np.float32)[np.arange(len(sel)) % 8]
     side = int(np.ceil(np.sqrt(n)))
     gx, gy = np.meshgrid(np.arange(side), np.arange(side))
     xy = (np.column_stack([gx.ravel(), gy.ravel()])[:n] - side / 2) * (300.0 / side)
