@@ -1107,12 +1107,15 @@ SGP_DEV int collide_with_mesh(const DV& d, uint32_t mbody, const sgd_shape& X, v
 #define MESH_BIG_CAP 1024    // ... which holds this many (a body across more triangles than that loses the rest: counted in manifolds_dropped)
 // (the tables of a pair in LDS; G = 8: a pair that fills more than MESH_BIG_MIN entries is passed on, so 64 entries do, and no copy of the polytope)
 struct MeshNoHull {};
-template <int G> struct MeshPairLds {
+// (HULL: room for a copy of the body's polytope -- a wave per pair, and the eight-lane instance for convex hulls: a hull against a triangle walks the hull's
+// corners twice per axis, ~130 axes per triangle)
+template <int G, bool HULL = (G == 64)> struct MeshPairLds {
 	static constexpr int CAP = G == 64 ? MESH_BIG_CAP : 64;
 	uint32_t found[CAP]; uint32_t key[CAP]; uint32_t cand[CAP]; uint32_t n_front[2], n_found, redo;
 	sgd_mesh_contacts mc;
-	typename std::conditional<G == 64, sgd_hull, MeshNoHull>::type hull;      // the body's polytope (cube template / convex hull) next to the lanes that walk its vertices once per axis
+	typename std::conditional<HULL, sgd_hull, MeshNoHull>::type hull;      // the body's polytope (cube template / convex hull) next to the lanes that walk its vertices once per axis
 };
+#define MESH_LDS_T(G, KINDS) MeshPairLds<G, (G) == 64 || (KINDS) == 8>
 
 // every triangle whose leaf box overlaps [llo, lhi] (mesh frame): positions in the tree-ordered triangle array and the triangles' indices in the
 // caller's order, as found (unsorted)
@@ -1176,14 +1179,15 @@ template <int G> SGP_DEV void mesh_add_coop(sgd_mesh_contacts& mc, bool mine, co
 // pair): what lies between "here is the pair" and "here are its <= 3 groups in L.mc".  valid: false for a group without a pair, and false on return
 // when the pair was handed to the wave-per-pair launch (pair = its index in mesh_pairs; G = 8 only).  [qlo, qhi]: X's bounds grown by max_sep.
 // KINDS: what X can be (bits of SGD_SHAPE_*, sgd_collide_tri): an instance for the primitives carries nothing of the general hull search, one for hulls nothing of the box's.
-template <int MESH_GROUP, int KINDS = SGD_KINDS_ALL> SGP_DEV void mesh_pair_groups(const DV& d, MeshPairLds<MESH_GROUP>& L, bool& valid, sgd_shape& X, uint32_t mid, v3 qlo, v3 qhi, float max_sep, int grp, int sub, uint32_t pair, bool& dropped, v3 movement, bool active_edges = true, float* lpoly = nullptr)
+template <int MESH_GROUP, int KINDS = SGD_KINDS_ALL> SGP_DEV void mesh_pair_groups(const DV& d, MESH_LDS_T(MESH_GROUP, KINDS)& L, bool& valid, sgd_shape& X, uint32_t mid, v3 qlo, v3 qhi, float max_sep, int grp, int sub, uint32_t pair, bool& dropped, v3 movement, bool active_edges = true, float* lpoly = nullptr)
 {
 	MeshHeader mh; v3 mpos = V3(0.0f, 0.0f, 0.0f); m33 R = quat_to_m33(Q4(make_float4(0.0f, 0.0f, 0.0f, 1.0f)));
 	int nc = 0;
 	if (valid) {
-		if (MESH_GROUP == 64 && X.hull) {
+		if ((MESH_GROUP == 64 || KINDS == 8) && X.hull) {
 			// a triangle test walks the polytope's vertices twice per candidate axis: out of LDS, not out of a pointer into global memory (worth the copy
-			// where dozens of tests follow: 2.50 -> 2.13 ms on the car-sized boxes, but 0.93 -> 1.09 ms on the small bodies of tools/experiments/mesh_terrain_bench.py)
+			// where dozens of tests follow: 2.50 -> 2.13 ms on the car-sized boxes, but 0.93 -> 1.09 ms on the small bodies of tools/experiments/mesh_terrain_bench.py when
+			// every eight-lane pair did it; the eight-lane instance for convex hulls does -- ~130 axes per triangle, each a walk over the hull's corners: 0.80 -> 0.78 ms for 3.5k hulls)
 			const uint32_t* src = (const uint32_t*)X.hull; uint32_t* dst = (uint32_t*)&L.hull;
 			for (uint32_t i = (uint32_t)sub; i < sizeof(sgd_hull) / 4; i += MESH_GROUP) dst[i] = src[i];
 			X.hull = (const sgd_hull*)(const void*)&L.hull;
@@ -1220,10 +1224,10 @@ template <int MESH_GROUP, int KINDS = SGD_KINDS_ALL> SGP_DEV void mesh_pair_grou
 				if (nd.mxx < llo.x || nd.mnx > lhi.x || nd.mxy < llo.y || nd.mny > lhi.y || nd.mxz < llo.z || nd.mnz > lhi.z) continue;
 				if (nd.count == 0) {
 					const uint32_t at = atomicAdd(&L.n_front[(level & 1) ^ 1], 2u);
-					if (at + 2u <= (uint32_t)MeshPairLds<MESH_GROUP>::CAP) { nxt[at] = nd.left; nxt[at + 1] = nd.right; } else L.redo = 1u;
+					if (at + 2u <= (uint32_t)MESH_LDS_T(MESH_GROUP, KINDS)::CAP) { nxt[at] = nd.left; nxt[at + 1] = nd.right; } else L.redo = 1u;
 				} else {
 					const uint32_t at = atomicAdd(&L.n_found, nd.count);
-					if (at + nd.count <= (uint32_t)MeshPairLds<MESH_GROUP>::CAP) { for (uint32_t k = 0; k < nd.count; ++k) L.found[at + k] = nd.left + k; } else L.redo = 1u;
+					if (at + nd.count <= (uint32_t)MESH_LDS_T(MESH_GROUP, KINDS)::CAP) { for (uint32_t k = 0; k < nd.count; ++k) L.found[at + k] = nd.left + k; } else L.redo = 1u;
 				}
 			}
 			__syncthreads();
@@ -1232,10 +1236,10 @@ template <int MESH_GROUP, int KINDS = SGD_KINDS_ALL> SGP_DEV void mesh_pair_grou
 		}
 	}
 	if (valid && L.redo && !(MESH_GROUP != 64 && L.n_found > (uint32_t)MESH_BIG_MIN)) {
-		if (sub == 0) L.n_found = (uint32_t)mesh_candidates_found(d, mh, llo, lhi, L.found, L.key, &dropped, MESH_GROUP == 64 ? MESH_BIG_CAP : MESH_BIG_MIN, MeshPairLds<MESH_GROUP>::CAP);
+		if (sub == 0) L.n_found = (uint32_t)mesh_candidates_found(d, mh, llo, lhi, L.found, L.key, &dropped, MESH_GROUP == 64 ? MESH_BIG_CAP : MESH_BIG_MIN, MESH_LDS_T(MESH_GROUP, KINDS)::CAP);
 	}
 	__syncthreads();
-	nc = valid ? (int)min(L.n_found, (uint32_t)MeshPairLds<MESH_GROUP>::CAP) : 0;
+	nc = valid ? (int)min(L.n_found, (uint32_t)MESH_LDS_T(MESH_GROUP, KINDS)::CAP) : 0;
 	if (MESH_GROUP != 64 && nc > MESH_BIG_MIN) {
 		// too many triangles for eight lanes: the wave-per-pair launch takes the pair (and finds its candidates again)
 		if (sub == 0) d.mesh_big[atomicAdd(&d.ctr->n_mesh_big, 1u)] = pair;
@@ -1322,10 +1326,10 @@ template <int MESH_GROUP, int KINDS = SGD_KINDS_ALL> SGP_DEV void mesh_pair_grou
 template <int MESH_GROUP, int KINDS> __global__ void __launch_bounds__(64) k_narrowphase_mesh(DV d)
 {
 	constexpr int MESH_PAIRS_PER_WAVE = 64 / MESH_GROUP;
-	__shared__ MeshPairLds<MESH_GROUP> lds[MESH_PAIRS_PER_WAVE];
+	__shared__ MESH_LDS_T(MESH_GROUP, KINDS) lds[MESH_PAIRS_PER_WAVE];
 	__shared__ float s_lpoly[((KINDS & 2) && !(KINDS & 8)) ? 3 * SGD_LPOLY_FLOATS : 1];      // a box's clip polygons, a column per lane (sgd_tri_box_manifold)
 	const int grp = (int)(threadIdx.x / MESH_GROUP), sub = (int)(threadIdx.x % MESH_GROUP);
-	MeshPairLds<MESH_GROUP>& L = lds[grp];
+	MESH_LDS_T(MESH_GROUP, KINDS)& L = lds[grp];
 	const float max_sep = d.st.speculative_contact_distance;
 	// G = 8: a wave's eight pairs hold the same kind of body (one list per kind); G = 64: the list of the big pairs.  The lists of this instance's kinds are
 	// ONE sequence of work items (an item = the next eight pairs of a list) dealt to the workgroups: with the lists taken one after the other by
