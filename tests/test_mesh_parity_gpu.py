@@ -541,3 +541,45 @@ def test_static_meshes_streaming_in_and_out_keep_the_grid_exact(oracle):
             assert np.array_equal(sg_["id"], sc_["id"])
     assert added >= 90 and removed >= 70
     tw.close()
+
+
+def test_axis_aligned_boxes_on_axis_aligned_triangles_bit_exact(oracle):
+    """The degenerate corners of the closed-form box - triangle search (sgd_tri_box_sat): boxes whose edges run exactly along the triangles' edges (cross
+    products that are exactly zero: the parallel test), box centres exactly above a triangle's edge or centroid (an axis exactly perpendicular to the
+    centre offset: neither sense of a cube edge is turned, the two senses are opposite axes), identity / half-turn rotations (matrix entries that are
+    exactly 0 and +-1: zero components whose sign the sums decide).  Flat floors of axis-aligned and of diagonal triangles, a ramp.  Bit for bit."""
+    tw = parity.make_twin(oracle, max_bodies=512)
+    V, T = grid_mesh(9, 8.0, lambda x, y: 0.0)                      # 2 m squares cut along one diagonal: edges along x, along y and along (1, 1)
+    ig, ic = tw.mesh_create(V, T)
+    tw.add_batch(mesh_body(ig))
+    Vr = np.array([(20, -4, 0), (28, -4, 0), (28, 4, 2), (20, 4, 2)], np.float32)      # a ramp of two triangles, rising along y
+    ir, _ = tw.mesh_create(Vr, np.array([(0, 1, 2), (0, 2, 3)], np.uint32))
+    tw.add_batch(mesh_body(ir))
+    rots = [(0, 0, 0, 1), (0, 0, 1, 0), (1, 0, 0, 0), (0, 1, 0, 0), (0, 0, np.sqrt(0.5), np.sqrt(0.5))]
+    pos = []
+    for ix in range(-3, 4):
+        for iy in range(-3, 4):
+            pos.append((ix * 2.0, iy * 2.0, 0.5 + 0.01 * ((ix + iy) % 3)))          # centres on the grid's vertices (where six triangles meet) ...
+    for ix in range(-3, 3):
+        pos.append((ix * 2.0 + 1.0, ix * 2.0 + 1.0, 0.75))                      # ... and on the diagonals' midpoints
+    for k in range(6):
+        pos.append((21.0 + k, -3.0 + k, 1.6 + 0.25 * k))                        # over the ramp
+    n = len(pos)
+    d = scenes.dynamic_bodies(n)
+    d["shape_type"] = abi.SHAPE_BOX
+    d["shape"][:, 0] = 0.5; d["shape"][:, 1] = 0.25; d["shape"][:, 2] = 0.5
+    d["shape"][::3, :3] = 0.5
+    d["pos"] = np.array(pos, np.float32)
+    d["rot"] = np.array([rots[k % len(rots)] for k in range(n)], np.float32)
+    tw.add_batch(d)
+    total = 6 + n
+    for s in range(1, 241):
+        tw.step(DT)
+        if s in (1, 2, 5, 30, 120, 240):
+            c = parity.compare(tw, total)
+            assert c["bit_exact"], (s, c)
+            sg, sc = tw.stats()
+            assert (sg.num_pairs, sg.num_manifolds, sg.num_contact_points) == (sc.num_pairs, sc.num_manifolds, sc.num_contact_points), s
+    st = tw.gpu.read_states(6, n)
+    assert (st["pos"][:49, 2] > 0.2).all() and (st["pos"][:49, 2] < 0.8).all()      # the boxes over the floor rest on it
+    tw.close()
