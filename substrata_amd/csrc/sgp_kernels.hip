@@ -334,8 +334,8 @@ __global__ void __launch_bounds__(TPB) k_bp_cell(DV d)
 	}
 	const uint32_t slot = (uint32_t)__shfl((int)sl, leader, 64);
 	if (binned) {
-		h = slot * 64u + local;
-		atomicAdd(&d.cell_count[h], 1u);
+		if (slot >= BP_TILE_PENDING) { h = 0xFFFFFFFFu; if (lane == leader) atomicAdd(&d.ctr->pairs_dropped, 1u); }      // (the bounded wait above ran out: not binned this step and counted, never an index)
+		else { h = slot * 64u + local; atomicAdd(&d.cell_count[h], 1u); }
 	}
 	if (in_range) d.cell_hash[i] = h;
 }
@@ -1242,7 +1242,7 @@ template <int MESH_GROUP, int KINDS = SGD_KINDS_ALL> SGP_DEV void mesh_pair_grou
 	nc = valid ? (int)min(L.n_found, (uint32_t)MESH_LDS_T(MESH_GROUP, KINDS)::CAP) : 0;
 	if (MESH_GROUP != 64 && nc > MESH_BIG_MIN) {
 		// too many triangles for eight lanes: the wave-per-pair launch takes the pair (and finds its candidates again)
-		if (sub == 0) d.mesh_big[atomicAdd(&d.ctr->n_mesh_big, 1u)] = pair;
+		if (sub == 0) { const uint32_t kb = atomicAdd(&d.ctr->n_mesh_big, 1u); if (kb < d.cap_mesh_pairs) d.mesh_big[kb] = pair; else atomicAdd(&d.ctr->pairs_dropped, 1u); }      // (four lists feed this one: bounded like them, the excess is counted)
 		valid = false; nc = 0; dropped = false;
 	}
 	for (int i = sub; i < nc; i += MESH_GROUP) L.key[i] = MESH_TRI_INDEX(d.mesh_tris[mh.tri_off + L.found[i]].w);
