@@ -7,7 +7,7 @@
 // max-up stop, longitudinal, lateral) and, for motorcycles, the lean spring.
 // Pre-step: one wave per vehicle, the record staged in LDS, wheel i's work on lane i and what couples the wheels on lane 0
 // (sgd_vehicle_precast_lanes, sgd_vehicle_controller_lanes); the casts spread 16 lanes per wheel (k_vehicle_cast).  Solver passes: four lanes
-// per vehicle on the lane-major row export (veh_quad_solve, sgp_kernels.hip), in the launch of contact colour 0.  The rows are two-body
+// per vehicle on the lane-major row export (veh_quad_solve, sgp_k_vehicle.hip), in the launch of contact colour 0.  The rows are two-body
 // constraints (round 4): a dynamic body under a wheel enters the effective masses, is read live and takes the reaction impulses, like body 2 of
 // Jolt's AxisConstraintPart in VehicleConstraint::SetupVelocityConstraint / SolveVelocityConstraint; tyre slip and the longitudinal target keep
 // using the contact point velocity sampled at cast time, as WheeledVehicleController does.

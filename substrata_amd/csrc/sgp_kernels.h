@@ -2,6 +2,20 @@
 //
 // One sgp_world owns one set of SoA arrays in HBM (struct DeviceArrays).  Everything a kernel needs is passed as a
 // by-value view (struct DV) so launches carry plain pointers only.
+//
+// Stage map of the step behind PhysicsWorld::think (/root/reference/gui_client/PhysicsWorld.cpp:1356-1443) and where each stage lives:
+//   sgp_k_broadphase.hip   K2/K3  k_step_begin (bounds), k_bp_cell (paged cell grid), k_scan_*, k_bp_scatter_large, k_bp_pairs + layer filter (PhysicsWorld.cpp:160-189)
+//   sgp_k_narrowphase.hip  K4     k_narrowphase (sphere / box / capsule manifolds, sgp_device_collide.h), k_wake_pairs (in-step activation), k_narrowphase_hull*
+//   sgp_k_mesh.hip         K4     k_narrowphase_mesh<8|64, kinds>: (body, static mesh) pairs by lanes
+//   sgp_k_constraints.hip  K5/K6  k_colour_* (deterministic colouring), k_setup (contact-cache match, constraint rows), k_cache_build, k_contact_events
+//   sgp_k_solve.hip        K7     k_warm_bodies, k_solve_colour<0|1|2>, k_hc_* + k_solve_hc (high colours by connected component), k_solve_tail*, k_solve_small*
+//   sgp_k_sweep.hip        K8/K1/K9/A3  the body-array sweep k_pre_solve + k_integrate_pose + k_finalize, k_island_*, k_sleep_apply, k_buoyancy (PhysicsWorld.cpp:1367-1442)
+//   sgp_k_vehicle.hip      (f)1   k_vehicle_cast / controller, the vehicle rows inside the solver passes (k_solve_colour_veh)
+//   sgp_k_queries.hip      A7     k_raycast, k_collide_capsules, k_spherecast
+//   sgp_k_edits.hip        A5/A6  k_apply_cmds, k_ghost_refresh, read-back
+//   sgp_k_tiles.hip        (e)    tile export / routing, re-tiling histograms
+//   sgp_dev_*.h            device-inline functions shared between stage files (sgp_dev_all.h includes them in dependency order)
+// All body state is SoA float4 / 32-byte records in HBM; every per-body kernel is a coalesced 16 B/lane sweep.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -315,7 +329,7 @@ struct DV {
 	float gx, gy, gz;
 };
 
-// ---- launch wrappers (defined in sgp_kernels.hip) ---------------------------------------------------------------
+// ---- launch wrappers (each defined at the end of the stage file that holds its kernels) ---------------------------------------------------------------
 // `nb` = number of body slots the per-body grids must cover (a bucketed upper bound of StepParams::n_slots)
 // first / last launch of a step: per-step scalars in by value + scratch reset; counters out to host-mapped memory
 void launch_step_begin(const DV& d, const StepParams& sp, uint32_t nb, bool reset_step_scratch, hipStream_t s);
@@ -334,7 +348,8 @@ void launch_narrowphase(const DV& d, uint32_t n_pairs_upper, hipStream_t s);
 void launch_cache_wipe(const DV& d, hipStream_t s);
 void launch_wake_round(const DV& d, uint32_t nb, bool has_hulls, bool has_meshes, hipStream_t s);      // in-step activation: k_wake_pairs + the narrow phase of its pairs
 void launch_narrowphase_hull(const DV& d, hipStream_t s);     // only worlds with hull shapes
-void launch_narrowphase_mesh(const DV& d, bool has_hulls, hipStream_t s);     // only worlds with mesh shapes; has_hulls: also the instances for hull bodies
+void launch_narrowphase_mesh(const DV& d, bool has_hulls, hipStream_t s);
+void launch_narrowphase_mesh_blocks(const DV& d, bool has_hulls, uint32_t blocks, hipStream_t s);      // (the same four launches with a grid of `blocks` workgroups)     // only worlds with mesh shapes; has_hulls: also the instances for hull bodies
 void launch_colour_inherit(const DV& d, uint32_t n_man, hipStream_t s);
 void launch_colour_claim(const DV& d, uint32_t n_man, uint32_t round, hipStream_t s);
 void launch_colour_commit(const DV& d, uint32_t n_man, uint32_t round, hipStream_t s);
