@@ -13,6 +13,8 @@ for wl in config3 config5; do
 	{ echo "# rocprofv3 --kernel-trace --stats -- python bench.py --workload $wl --steps 60 --warmup 120 --cpu-steps 0 (from /tmp, TMPDIR=/tmp)"; echo;
 	  echo "Summarised from the rocpd database with tools/rocpd_summary.py (all steps of the run: warm-up, timed, read-back and profiled steps)."; echo;
 	  python "$REPO/tools/rocpd_summary.py" "$db"; } > "$OUT/${TAG}_kernel_stats_$wl.md"
+	# the average kernel durations as bench.py reads them (roofline.frac_kernel_time): copy gpurun_out/kernel_time.json to profiles/ with the summary it belongs to
+	if [ $wl = config3 ]; then python "$REPO/tools/rocpd_summary.py" "$db" --json "$OUT/kernel_time.json" --source "profiles/${TAG}_kernel_stats_config3.md (rocprofv3 --kernel-trace --stats -- python bench.py --workload config3 --steps 60 --warmup 120 --cpu-steps 0; tools/rocpd_summary.py --json)" > /dev/null; fi
 	rm -rf "$OUT/prof_$wl"
 done
 cd "$REPO"

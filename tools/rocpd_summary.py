@@ -1,5 +1,6 @@
 """Summarise a rocprofv3 rocpd sqlite (.db) kernel trace into a per-kernel stats table (markdown/CSV-ish text).
-Usage: python tools/rocpd_summary.py <results.db> [out.txt]"""
+Usage: python tools/rocpd_summary.py <results.db> [out.txt] [--json kernel_time.json --source "text"]
+(--json: the average duration per kernel as bench.py reads it for roofline.frac_kernel_time, profiles/kernel_time.json)"""
 import sqlite3
 import sys
 
@@ -21,8 +22,19 @@ def main():
         m = sorted(med[n])[len(med[n]) // 2]
         lines.append(f"| {short} | {c} | {s / 1e6:.3f} | {a / 1e3:.2f} | {m / 1e3:.2f} | {mn / 1e3:.2f} | {mx / 1e3:.2f} | {100.0 * s / total:.1f} |")
     txt = "\n".join(lines)
-    if len(sys.argv) > 2:
-        open(sys.argv[2], "w").write(txt + "\n")
+    args = sys.argv[2:]
+    if "--json" in args:
+        import json
+        jpath = args[args.index("--json") + 1]
+        source = args[args.index("--source") + 1] if "--source" in args else "rocprofv3 --kernel-trace"
+        avg = {}
+        for n, c, s, a, mn, mx in rows:
+            short = n.split("(")[0].replace("void ", "").strip()
+            avg[short] = round(a / 1e3, 3)
+        json.dump({"source": source, "avg_us": avg}, open(jpath, "w"), indent=1, sort_keys=True)
+        args = [x for i, x in enumerate(args) if x not in ("--json", "--source") and (i == 0 or args[i - 1] not in ("--json", "--source"))]
+    if args:
+        open(args[0], "w").write(txt + "\n")
     print(txt)
 
 
