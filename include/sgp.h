@@ -42,6 +42,7 @@ extern "C" {
 #define SGP_ERR_HIP           -4   /* a HIP runtime call failed; see sgp_last_error()               */
 #define SGP_ERR_BAD_ID        -5   /* body id is not live                                           */
 #define SGP_ERR_REJECTED      -6   /* addObject's silent rejections (PhysicsWorld.cpp:1178-1189)    */
+#define SGP_ERR_PEER          -7   /* sgp_tiles_exchange: ANOTHER rank reported a failure in this exchange; every rank returns (nobody is left waiting) */
 
 /* ---- enums (values are ABI) ------------------------------------------------------------------ */
 /* Motion type: JPH::EMotionType as chosen at PhysicsWorld.cpp:1209-1217. */
@@ -632,7 +633,7 @@ typedef struct sgp_tiles_stats {
 	uint32_t ghosts;         /* ... of which ghosts                                                                      */
 	uint32_t emigrated, immigrated;
 	uint32_t fast_imports, slow_imports;     /* cumulative: exchanges that found the ghost set unchanged (the host saw 16 bytes per record) / in which the host created or removed bodies (the set changed, bodies immigrated); the ghosts' POSES go from the received records to the bodies on the device either way */
-	uint32_t route_retries;  /* exchanges that had to grow this tile's send / emigrant buffers and route again (local, no extra collective) */
+	uint32_t route_retries;  /* exchanges in which some rank had to grow a send / emigrant / receive buffer: every rank routes again and the counts are gathered once more */
 	uint32_t comm_ranks;     /* ranks ncclCommCount reports for this tile's communicator (0: no communicator, e.g. tiles of one process) */
 	uint32_t exchanges;      /* sgp_tiles_exchange calls so far                                                           */
 	float    comm_init_ms;   /* wall time of ncclCommInitRank                                                             */

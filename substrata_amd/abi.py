@@ -8,7 +8,7 @@ import numpy as np
 
 ABI_VERSION = 1
 
-OK, ERR_INVALID, ERR_NO_DEVICE, ERR_CAPACITY, ERR_HIP, ERR_BAD_ID, ERR_REJECTED = 0, -1, -2, -3, -4, -5, -6
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_CAPACITY, ERR_HIP, ERR_BAD_ID, ERR_REJECTED, ERR_PEER = 0, -1, -2, -3, -4, -5, -6, -7
 
 MOTION_STATIC, MOTION_KINEMATIC, MOTION_DYNAMIC = 0, 1, 2
 LAYER_NON_MOVING, LAYER_MOVING, LAYER_NON_MOVING_NON_COLLIDABLE, LAYER_MOVING_NON_COLLIDABLE = 0, 1, 2, 3

@@ -151,7 +151,8 @@ __global__ void __launch_bounds__(TPB) k_route_count(DV d, TileRoute t, uint32_t
 }
 
 // one workgroup: per column (destination, or emigrants) the exclusive scan of the block counts; then the segment starts
-__global__ void __launch_bounds__(1024) k_route_scan(const uint32_t* block_counts, uint32_t* block_offsets, uint32_t n_blocks, uint32_t n_tiles, RouteHeader* header)
+__global__ void __launch_bounds__(1024) k_route_scan(const uint32_t* block_counts, uint32_t* block_offsets, uint32_t n_blocks, uint32_t n_tiles, RouteHeader* header,
+                                                      uint32_t cap, uint32_t emigrant_cap, uint32_t* gather_row, uint32_t cap_recv, uint32_t host_status)
 {
 	__shared__ uint32_t wave_sums[16];
 	__shared__ uint32_t carry;
@@ -182,6 +183,10 @@ __global__ void __launch_bounds__(1024) k_route_scan(const uint32_t* block_count
 		uint32_t acc = 0;
 		for (uint32_t r = 0; r < SGP_MAX_TILES; ++r) { const uint32_t n = r < n_tiles ? totals[r] : 0u; header->seg_count[r] = n; header->seg_start[r] = acc; acc += n; }
 		header->total = acc; header->n_emigrants = totals[n_tiles]; header->pad[0] = header->pad[1] = 0;
+		// this rank's row of the exchange's all-gather: counts per destination, whether it has to route again (or has failed), how many records it can receive
+		for (uint32_t r = 0; r < n_tiles; ++r) gather_row[r] = totals[r];
+		gather_row[n_tiles] = host_status != ROUTE_OK ? host_status : ((acc > cap || totals[n_tiles] > emigrant_cap) ? ROUTE_REDO : ROUTE_OK);
+		gather_row[n_tiles + 1] = cap_recv;
 	}
 }
 
@@ -266,11 +271,11 @@ __global__ void __launch_bounds__(TPB) k_pack_ghost_keys(const sgp_ghost_record*
 	out[k] = make_uint4((uint32_t)g, (uint32_t)(g >> 32), recs[k].motion_type, 0u);
 }
 void launch_route_export(const DV& d, uint32_t nb, const TileRoute& t, uint32_t* block_counts, uint32_t* block_offsets, RouteHeader* header,
-                         sgp_ghost_record* out, uint32_t cap, uint32_t* emigrant_ids, uint32_t emigrant_cap, hipStream_t s)
+                         sgp_ghost_record* out, uint32_t cap, uint32_t* emigrant_ids, uint32_t emigrant_cap, uint32_t* gather_row, uint32_t cap_recv, uint32_t host_status, hipStream_t s)
 {
 	const uint32_t blocks = blocks_for(nb);
 	hipLaunchKernelGGL(k_route_count, dim3(blocks), dim3(TPB), 0, s, d, t, block_counts);
-	hipLaunchKernelGGL(k_route_scan, dim3(1), dim3(1024), 0, s, (const uint32_t*)block_counts, block_offsets, blocks, t.n_tiles, header);
+	hipLaunchKernelGGL(k_route_scan, dim3(1), dim3(1024), 0, s, (const uint32_t*)block_counts, block_offsets, blocks, t.n_tiles, header, cap, emigrant_cap, gather_row, cap_recv, host_status);
 	hipLaunchKernelGGL(k_route_write, dim3(blocks), dim3(TPB), 0, s, d, t, (const uint32_t*)block_offsets, (const RouteHeader*)header, out, cap, emigrant_ids, emigrant_cap);
 }
 void launch_tiles_hist(const DV& d, uint32_t nb, const TilePlanes& tp, int level, uint32_t* out, hipStream_t s) { hipLaunchKernelGGL(k_tiles_hist, dim3(blocks_for(nb)), dim3(TPB), 0, s, d, tp, level, out); }

@@ -408,8 +408,13 @@ struct TilePlanes { uint32_t gx, gy, gz, by_contacts; float glo[3], ghi[3]; floa
 // level 0: bounds of the owned dynamic bodies' centres (six ordered ints, atomicMin / Max); level 1 / 2 / 3: histogram of x / y (per x slab) / z (per (x, y) column)
 void launch_tiles_hist(const DV& d, uint32_t nb, const TilePlanes& tp, int level, uint32_t* out, hipStream_t s);
 // block_counts / block_offsets: [block][n_tiles + 1] (last column: emigrants)
+// gather_row: what this rank contributes to the exchange's all-gather, [seg_count[0 .. n_tiles), status, cap_recv]: status = host_status if that is
+// not ROUTE_OK, else ROUTE_REDO when the records or emigrants do not fit cap / emigrant_cap (decided on the device: no host round trip before the collective)
+#define ROUTE_OK 0u
+#define ROUTE_REDO 1u       // this rank must grow a buffer and route again
+#define ROUTE_FAILED 2u     // this rank cannot take part any more (a growth failed): every rank returns an error from this exchange
 void launch_route_export(const DV& d, uint32_t nb, const TileRoute& t, uint32_t* block_counts, uint32_t* block_offsets, RouteHeader* header,
-                         sgp_ghost_record* out, uint32_t cap, uint32_t* emigrant_ids, uint32_t emigrant_cap, hipStream_t s);
+                         sgp_ghost_record* out, uint32_t cap, uint32_t* emigrant_ids, uint32_t emigrant_cap, uint32_t* gather_row, uint32_t cap_recv, uint32_t host_status, hipStream_t s);
 // ghost pose refresh straight from received records: record k refreshes body ids[k] (the unchanged-ghost-set fast path, no host copy of the poses)
 void launch_pack_ghost_keys(const sgp_ghost_record* recs, uint32_t n, void* out_uint4, hipStream_t s);
 void launch_ghost_refresh_records(const DV& d, const sgp_ghost_record* recs, const uint32_t* ids, uint32_t n, hipStream_t s);

@@ -355,8 +355,11 @@ bool rccl_load()
 	if (g_rccl.tried) return g_rccl.lib != nullptr;
 	g_rccl.tried = true;
 	// the copy this process already has (PyTorch brings its own), else the system's
+	// SGP_RCCL_LIBRARY: bind this build of the collective library instead (a site's own RCCL; the test-only stand-in of tests/rccl_standin, which
+	// lets several processes on ONE GPU run sgp_tiles_exchange itself)
+	if (const char* explicit_lib = getenv("SGP_RCCL_LIBRARY")) { if (*explicit_lib) g_rccl.lib = dlopen(explicit_lib, RTLD_NOW | RTLD_GLOBAL); if (*explicit_lib && !g_rccl.lib) return false; }
 	const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so" };
-	for (const char* n : names) { g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); if (g_rccl.lib) break; }
+	if (!g_rccl.lib) for (const char* n : names) { g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); if (g_rccl.lib) break; }
 	if (!g_rccl.lib) for (const char* n : names) { g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (g_rccl.lib) break; }
 	if (!g_rccl.lib) return false;
 	bool ok = true;
@@ -391,7 +394,9 @@ struct sgp_tiles {
 	sgp_nccl_comm comm = nullptr;
 	// device
 	uint32_t* d_block_counts = nullptr; uint32_t* d_block_offsets = nullptr; uint32_t cap_blocks = 0;
-	char* d_ctl = nullptr;                 // [RouteHeader][counts matrix n_tiles x SGP_MAX_TILES... see ctl_bytes][emigrant ids]
+	char* d_ctl = nullptr;                 // control block, see tiles_ctl_bytes
+	uint32_t host_status = ROUTE_OK;       // ROUTE_FAILED once a growth of this rank's buffers failed: told to every rank by the next all-gather
+	int test_fail_growth = 0;              // SGP_TILES_TEST_FAIL_RANK names this rank: its next buffer growth fails (tests of the failure path)
 	sgp_ghost_record* d_send = nullptr; uint32_t cap_send = 0;
 	sgp_ghost_record* d_recv = nullptr; uint32_t cap_recv = 0;
 	uint32_t* d_emig = nullptr; uint32_t cap_emig = 0;
@@ -408,8 +413,12 @@ struct sgp_tiles {
 	// re-tiling (sgp_tiles_rebalance): this tile's histogram, everybody's (RCCL all-gather), the pinned host copy
 	uint32_t* d_hist = nullptr; uint32_t* d_hist_all = nullptr; uint32_t* h_hist = nullptr;
 };
+// control block (device + pinned host copy): [RouteHeader][matrix: n_tiles rows of n_tiles + 2 words, the all-gathered rows][this rank's row][emigrant ids]
+// a row = [records for destination 0 .. n_tiles), status (ROUTE_*), records this rank can receive]
+static size_t tiles_row_words(uint32_t n_tiles) { return (size_t)n_tiles + 2; }
 static size_t tiles_matrix_off() { return sizeof(RouteHeader); }
-static size_t tiles_emig_off(uint32_t n_tiles) { return sizeof(RouteHeader) + sizeof(uint32_t) * (size_t)n_tiles * n_tiles; }
+static size_t tiles_row_off(uint32_t n_tiles) { return tiles_matrix_off() + sizeof(uint32_t) * (size_t)n_tiles * tiles_row_words(n_tiles); }
+static size_t tiles_emig_off(uint32_t n_tiles) { return tiles_row_off(n_tiles) + sizeof(uint32_t) * tiles_row_words(n_tiles); }
 static size_t tiles_ctl_bytes(uint32_t n_tiles) { return tiles_emig_off(n_tiles) + sizeof(uint32_t) * SGP_TILES_EMIG_INLINE; }
 
 SGP_API int sgp_tiles_unique_id(uint8_t out[SGP_TILES_UNIQUE_ID_BYTES])
@@ -460,6 +469,7 @@ SGP_API int sgp_tiles_create(sgp_world* w, uint32_t rank, uint32_t n_tiles, cons
 	memcpy(t->route.boxes, boxes, sizeof(float) * 6 * n_tiles);
 	t->route.n_tiles = n_tiles; t->route.my_rank = rank; t->route.margin = margin; t->route.pad = margin + radius_pad;
 	memset(&t->stats, 0, sizeof(t->stats));
+	if (const char* fr = getenv("SGP_TILES_TEST_FAIL_RANK")) t->test_fail_growth = (*fr && (uint32_t)atoi(fr) == rank) ? 1 : 0;      // (debugging aid: DESIGN.md 6)
 	const size_t cb = tiles_ctl_bytes(n_tiles);
 	if (hipMalloc((void**)&t->d_ctl, cb) != hipSuccess || hipHostMalloc((void**)&t->h_ctl, cb, hipHostMallocDefault) != hipSuccess) { sgp_tiles_destroy(t); return fail(SGP_ERR_HIP, "sgp_tiles_create: allocation"); }
 	hipMemset(t->d_ctl, 0, cb); memset(t->h_ctl, 0, cb);
@@ -494,24 +504,37 @@ static int tiles_launch_route(sgp_tiles* t)
 	}
 	if (!t->cap_send) { int r = tiles_grow(w, t->d_send, t->cap_send, 16384u); if (r != SGP_OK) return r; }
 	if (!t->cap_emig) { int r = tiles_grow(w, t->d_emig, t->cap_emig, 4096u); if (r != SGP_OK) return r; }
-	launch_route_export(w->dv, w->high, t->route, t->d_block_counts, t->d_block_offsets, (RouteHeader*)t->d_ctl, t->d_send, t->cap_send, t->d_emig, t->cap_emig, w->stream);
+	if (!t->cap_recv) { int r = tiles_grow(w, t->d_recv, t->cap_recv, 16384u); if (r != SGP_OK) return r; }
+	launch_route_export(w->dv, w->high, t->route, t->d_block_counts, t->d_block_offsets, (RouteHeader*)t->d_ctl, t->d_send, t->cap_send, t->d_emig, t->cap_emig,
+	                    (uint32_t*)(t->d_ctl + tiles_row_off(t->n_tiles)), t->cap_recv, t->host_status, w->stream);
 	// the first emigrant ids ride along with the header copy
 	HIP_TRY(hipMemcpyAsync(t->d_ctl + tiles_emig_off(t->n_tiles), t->d_emig, sizeof(uint32_t) * std::min<uint32_t>(SGP_TILES_EMIG_INLINE, t->cap_emig), hipMemcpyDeviceToDevice, w->stream));
 	return SGP_OK;
 }
 
-// phase 2 (after the control block is on the host): capacity check, emigrants leave this world
-static int tiles_after_header(sgp_tiles* t, bool* redo)
+// phase 2 (after the control block is on the host): does this rank have to grow a buffer and route again?
+static bool tiles_needs_redo(const sgp_tiles* t)
+{
+	const RouteHeader* h = (const RouteHeader*)t->h_ctl;
+	return h->total > t->cap_send || h->n_emigrants > t->cap_emig;
+}
+// grows what the last routing found too small; a failure is remembered (host_status) instead of returned: the caller still has a collective to finish
+static void tiles_grow_for_redo(sgp_tiles* t, uint32_t need_recv)
 {
 	sgp_world* w = t->w;
-	*redo = false;
 	const RouteHeader* h = (const RouteHeader*)t->h_ctl;
-	if (h->total > t->cap_send || h->n_emigrants > t->cap_emig) {       // more boundary bodies than the buffers hold: grow, route again
-		if (h->total > t->cap_send) { int r = tiles_grow(w, t->d_send, t->cap_send, h->total); if (r != SGP_OK) return r; }
-		if (h->n_emigrants > t->cap_emig) { int r = tiles_grow(w, t->d_emig, t->cap_emig, h->n_emigrants); if (r != SGP_OK) return r; }
-		*redo = true;
-		return SGP_OK;
-	}
+	int r = SGP_OK;
+	if (t->test_fail_growth) { t->test_fail_growth = 0; r = fail(SGP_ERR_HIP, "sgp_tiles_exchange: buffer growth failed (forced by SGP_TILES_TEST_FAIL_RANK)"); }
+	if (r == SGP_OK && h->total > t->cap_send) r = tiles_grow(w, t->d_send, t->cap_send, h->total);
+	if (r == SGP_OK && h->n_emigrants > t->cap_emig) r = tiles_grow(w, t->d_emig, t->cap_emig, h->n_emigrants);
+	if (r == SGP_OK && need_recv > t->cap_recv) r = tiles_grow(w, t->d_recv, t->cap_recv, need_recv);
+	if (r != SGP_OK) t->host_status = ROUTE_FAILED;
+}
+// phase 3b (after the records have left): the emigrants leave this world
+static int tiles_remove_emigrants(sgp_tiles* t)
+{
+	sgp_world* w = t->w;
+	const RouteHeader* h = (const RouteHeader*)t->h_ctl;
 	t->stats.exported = h->total; t->stats.emigrated = h->n_emigrants;
 	if (h->n_emigrants) {
 		std::vector<uint32_t> ids(h->n_emigrants);
@@ -635,29 +658,57 @@ SGP_API int sgp_tiles_exchange(sgp_tiles* t)
 	hipSetDevice(w->device);
 	const uint32_t T = t->n_tiles;
 	const auto t_begin = std::chrono::steady_clock::now();
-	struct Stamp { sgp_tiles* t; std::chrono::steady_clock::time_point t0; ~Stamp() { t->stats.last_exchange_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); t->stats.exchanges++; t->stats.total_exchange_ms += t->stats.last_exchange_ms; } } stamp = { t, t_begin };
+	struct Stamp { sgp_tiles* t; std::chrono::steady_clock::time_point t0; ~Stamp() { t->stats.last_exchange_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); t->stats.exchanges++; t->stats.total_exchange_ms += t->stats.last_exchange_ms; } } stamp{ t, t_begin };
 	if (T > 1 && !t->comm) return fail(SGP_ERR_INVALID, "sgp_tiles_exchange: created without a communicator (use sgp_tiles_exchange_group for tiles of one process)");
 	uint32_t* d_matrix = (uint32_t*)(t->d_ctl + tiles_matrix_off());
-	// Routing is local and its COUNTS do not depend on the buffer sizes, so the all-gather runs exactly once per exchange; a rank whose
-	// send / emigrant buffers were too small grows them and re-runs only its own routing kernels -- the other ranks never notice, and no rank
-	// can return between the all-gather and the matching send / recv (which would leave its peers waiting in ncclRecv for ever).
-	for (int attempt = 0; attempt < 3; ++attempt) {
-		{ int r = tiles_launch_route(t); if (r != SGP_OK) return r; }
-		// every rank's per-destination counts: one small all-gather on device buffers
-		if (t->comm && attempt == 0) RCCL_TRY(g_rccl.AllGather(t->d_ctl /* RouteHeader::seg_count comes first */, d_matrix, T, SGP_NCCL_UINT32, t->comm, w->stream), "ncclAllGather");
+	uint32_t* d_row = (uint32_t*)(t->d_ctl + tiles_row_off(T));
+	const size_t RW = tiles_row_words(T);
+	const uint32_t* matrix = (const uint32_t*)(t->h_ctl + tiles_matrix_off());          // [source][destination .. , status, receive capacity]
+	// NO RANK MAY LEAVE ITS PEERS WAITING.  Every collective of an exchange is entered by every rank the same number of times, because every decision
+	// that shapes the sequence is taken from the all-gathered rows, which are the same everywhere: a row carries, besides the per-destination counts,
+	// the rank's status (decided on the device: do its records fit its send buffers?) and how many records it can receive.  If any rank has to grow a
+	// buffer, all ranks route again and gather again (local growth in between; the steady state never gets here: one gather, one host round trip).  A
+	// rank whose growth fails does not return: it reports ROUTE_FAILED in the next gather, and then EVERY rank returns an error (SGP_ERR_PEER on the
+	// others) without having posted a send or a receive.  Between the last gather and ncclGroupEnd nothing can fail but the collective library itself.
+	uint32_t n_recv = 0;
+	bool settled = false;
+	for (int attempt = 0; attempt < 4 && !settled; ++attempt) {
+		if (t->test_fail_growth && t->host_status == ROUTE_OK) t->host_status = ROUTE_REDO;      // (test hook: ask for a round of growth, which then fails)
+		{ int r = tiles_launch_route(t);
+		  if (r != SGP_OK) {      // (could not even route: with a communicator the peers are told through the gather, like a failed growth)
+			if (!t->comm) return r;
+			t->host_status = ROUTE_FAILED;
+			std::vector<uint32_t> row(RW, 0u); row[T] = ROUTE_FAILED;
+			HIP_TRY(hipMemcpyAsync(d_row, row.data(), sizeof(uint32_t) * RW, hipMemcpyHostToDevice, w->stream));
+		  } }
+		if (t->comm) RCCL_TRY(g_rccl.AllGather(d_row, d_matrix, RW, SGP_NCCL_UINT32, t->comm, w->stream), "ncclAllGather");
+		else HIP_TRY(hipMemcpyAsync(d_matrix, d_row, sizeof(uint32_t) * RW, hipMemcpyDeviceToDevice, w->stream));      // (one tile: its own row)
 		HIP_TRY(hipMemcpyAsync(t->h_ctl, t->d_ctl, tiles_ctl_bytes(T), hipMemcpyDeviceToHost, w->stream));
 		HIP_TRY(hipStreamSynchronize(w->stream));
-		bool redo = false;
-		{ int r = tiles_after_header(t, &redo); if (r != SGP_OK) return r; }
-		if (!redo) break;
+		if (t->host_status == ROUTE_REDO) t->host_status = ROUTE_OK;
+		bool any_failed = false, any_redo = false;
+		uint32_t my_incoming = 0;
+		for (uint32_t r = 0; r < T; ++r) {
+			const uint32_t* row = matrix + (size_t)r * RW;
+			any_failed = any_failed || row[T] == ROUTE_FAILED;
+			any_redo = any_redo || row[T] == ROUTE_REDO;
+			uint32_t incoming = 0;
+			for (uint32_t src = 0; src < T; ++src) if (src != r) incoming += matrix[(size_t)src * RW + r];
+			any_redo = any_redo || incoming > row[T + 1];
+			if (r == t->rank) my_incoming = incoming;
+		}
+		if (any_failed) {
+			if (t->host_status == ROUTE_FAILED) { t->host_status = ROUTE_OK; return SGP_ERR_HIP; }      // (sgp_last_error holds what failed here)
+			return fail(SGP_ERR_PEER, "sgp_tiles_exchange: another rank could not take part in this exchange (its buffers could not grow); nothing was sent");
+		}
+		if (!any_redo) { settled = true; n_recv = my_incoming; break; }
+		if (attempt == 3) break;
+		tiles_grow_for_redo(t, my_incoming);      // (local; a failure travels with the next gather)
 		t->stats.route_retries++;
-		if (attempt == 2) return fail(SGP_ERR_CAPACITY, "sgp_tiles_exchange: send buffer");      // (unreachable: the second attempt has the sizes the first one reported)
 	}
+	if (!settled) return fail(SGP_ERR_CAPACITY, "sgp_tiles_exchange: the buffers did not settle in four rounds");      // (every rank gets here together: same rows)
 	const RouteHeader* h = (const RouteHeader*)t->h_ctl;
-	const uint32_t* matrix = (const uint32_t*)(t->h_ctl + tiles_matrix_off());          // [source][destination]
-	uint32_t n_recv = 0;
-	for (uint32_t r = 0; r < T; ++r) { t->recv_counts[r] = (T > 1 && r != t->rank) ? matrix[(size_t)r * T + t->rank] : 0u; t->recv_offsets[r] = n_recv; n_recv += t->recv_counts[r]; }
-	{ int r = tiles_grow(w, t->d_recv, t->cap_recv, std::max(n_recv, 1u)); if (r != SGP_OK) return r; }
+	for (uint32_t r = 0, at = 0; r < T; ++r) { t->recv_counts[r] = (r != t->rank) ? matrix[(size_t)r * RW + t->rank] : 0u; t->recv_offsets[r] = at; at += t->recv_counts[r]; }
 	if (T > 1) {
 		RCCL_TRY(g_rccl.GroupStart(), "ncclGroupStart");
 		for (uint32_t r = 0; r < T; ++r) {
@@ -667,6 +718,7 @@ SGP_API int sgp_tiles_exchange(sgp_tiles* t)
 		}
 		RCCL_TRY(g_rccl.GroupEnd(), "ncclGroupEnd");
 	}
+	{ int r = tiles_remove_emigrants(t); if (r != SGP_OK) return r; }      // (their records are on their way: the new owner creates them in its import)
 	t->stats.sent = h->total;
 	return tiles_import(t, n_recv);
 }
@@ -690,7 +742,7 @@ SGP_API int sgp_tiles_exchange_group(sgp_tiles** ts, uint32_t n)
 		}
 		break;
 	}
-	for (uint32_t i = 0; i < n; ++i) { bool redo = false; hipSetDevice(ts[i]->w->device); int r = tiles_after_header(ts[i], &redo); if (r != SGP_OK) return r; }
+	for (uint32_t i = 0; i < n; ++i) { hipSetDevice(ts[i]->w->device); int r = tiles_remove_emigrants(ts[i]); if (r != SGP_OK) return r; }
 	for (uint32_t dst = 0; dst < n; ++dst) {
 		sgp_tiles* t = ts[dst];
 		hipSetDevice(t->w->device);
