@@ -1967,7 +1967,14 @@ static void vehicles_pre_step(sgo_world* w, float dt)
 		sgo_vehicle* v = &w->vehicles[k];
 		if (!v->alive) continue;
 		v->active = live(w, v->body) && body_movable(&w->bodies[v->body]);
-		if (!v->active) continue;
+		/* A vehicle whose chassis sleeps still casts its wheels (VehicleConstraint::OnStep runs every step): the constraint is active when the chassis
+		   OR a body a wheel touches is active, and an active vehicle constraint activates its chassis when the islands are built
+		   (VehicleConstraint::BuildIslands -- UNVERIFIED: upstream).  So a ball rolling under a wheel of a parked car wakes the car although it never
+		   touches the chassis.  The sleeping vehicle casts on a copy of its record: it stays frozen unless this step wakes it. */
+		const int dormant = !v->active && live(w, v->body) && w->bodies[v->body].motion == SGP_MOTION_DYNAMIC && !w->bodies[v->body].active;
+		if (!v->active && !dormant) continue;
+		sgo_vehicle saved; if (dormant) saved = *v;
+		int touched_active = 0;
 		const sgo_chassis c = chassis_load(&w->bodies[v->body]);
 		sgo_vehicle_pre_a(v, &c, dt);
 		for (int i = 0; i < v->num_wheels; ++i) {
@@ -1998,7 +2005,12 @@ static void vehicles_pre_step(sgo_world* w, float dt)
 				const v3 gv = o->motion == SGP_MOTION_STATIC ? V3(0, 0, 0) : v3_add(o->linv, v3_cross(o->angv, v3_sub(bp, o->pos)));
 				sgo_vehicle_set_hit(v, i, bid, best, bn, bp, gv, o->friction);
 				wh->ground_dynamic = o->motion == SGP_MOTION_DYNAMIC;      /* the rows then act on it too: VehicleConstraint::SetupVelocityConstraint(.., *w->mContactBody, ..) */
+				if (o->motion != SGP_MOTION_STATIC && o->active) touched_active = 1;
 			}
+		}
+		if (dormant) {
+			if (touched_active) { v->active = 1; w->bodies[v->body].can_sleep = -1; }      /* woken like a body an active one touches: after this step's collision detection */
+			else *v = saved;
 		}
 	}
 	free(bounds);

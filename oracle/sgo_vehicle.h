@@ -17,7 +17,7 @@
  *     wheel: a DYNAMIC ground body takes the reaction impulses of the suspension, upper-stop, longitudinal and lateral rows, enters their
  *     effective masses and is read live; tyre slip and the longitudinal target still use the contact point velocity sampled at cast time,
  *     as Jolt's WheeledVehicleController does.  Vehicles are solved in index order, like the constraints of one island in Jolt;)
- *   - anti-roll bar impulses are applied to the chassis in the pre-step;
+ *   - (round 5: the anti-roll bar term is the bias of the wheel's suspension row, as upstream hands it over;)
  *   - the (m+1)x(m+1) implicit clutch system is solved in closed form (same linear system);
  *   - acos of the slip angle uses a fixed polynomial, the wheel angle wraps by subtraction (no libm on the step path);
  *   - no pitch/roll limit (CarPhysics / BikePhysics leave mMaxPitchRollAngle at its default pi = off);
@@ -281,7 +281,7 @@ static inline void sgo_part_deactivate(sgo_axis_part* p) { p->active = 0; p->lam
 
 /* hard row, or soft row when stiffness > 0 (Jolt SpringPart::CalculateSpringPropertiesWithStiffnessAndDamping).  g = the body under the wheel when it
    is dynamic (NULL otherwise): AxisConstraintPart::TemplatedCalculateInverseEffectiveMass adds its share after body 1's. */
-static inline void sgo_part_setup(sgo_axis_part* p, const sgo_chassis* c, v3 r1, const sgo_chassis* g, v3 r2, v3 axis, float dt, float C, float stiffness, float damping)
+static inline void sgo_part_setup(sgo_axis_part* p, const sgo_chassis* c, v3 r1, const sgo_chassis* g, v3 r2, v3 axis, float dt, float C, float stiffness, float damping, float bias_in)
 {
 	p->r1xa = v3_cross(r1, axis);
 	p->iI_r1xa = sym33_mul(c->I, p->r1xa);
@@ -294,10 +294,10 @@ static inline void sgo_part_setup(sgo_axis_part* p, const sgo_chassis* c, v3 r1,
 	if (!(inv_eff > 0.0f)) { sgo_part_deactivate(p); return; }
 	if (stiffness > 0.0f) {
 		p->softness = 1.0f / (dt * (damping + dt * stiffness));
-		p->bias = dt * stiffness * p->softness * C;
+		p->bias = bias_in + dt * stiffness * p->softness * C;      /* SpringPart: mBias = inBias + dt k softness C */
 		p->eff = 1.0f / (inv_eff + p->softness);
 	} else {
-		p->softness = 0.0f; p->bias = 0.0f;
+		p->softness = 0.0f; p->bias = bias_in;
 		p->eff = 1.0f / inv_eff;
 	}
 	p->active = 1;
@@ -467,7 +467,9 @@ static inline int sgo_vehicle_pre_b(sgo_vehicle* v, sgo_chassis* c, sgo_chassis*
 		w->contact_lat = lat;
 		w->contact_long = v3_cross(w->contact_normal, lat);
 	}
-	/* anti-roll bars: impulse from the suspension length difference, applied to the chassis at the two contact points */
+	/* anti-roll bars: the "impulse" from the suspension length difference enters the suspension row of the wheel as its bias
+	   (VehicleConstraint::OnStep sets Wheel::mAntiRollBarImpulse, SetupVelocityConstraint hands it to
+	   AxisConstraintPart::CalculateConstraintPropertiesWithStiffnessAndDamping as inBias -- UNVERIFIED: upstream) */
 	for (int i = 0; i < nw; ++i) v->wheels[i].anti_roll_impulse = 0.0f;
 	for (int k = 0; k < v->num_anti_roll_bars; ++k) {
 		sgo_wheel* lw = &v->wheels[v->anti_roll_bars[k].left]; sgo_wheel* rw = &v->wheels[v->anti_roll_bars[k].right];
@@ -475,13 +477,6 @@ static inline int sgo_vehicle_pre_b(sgo_vehicle* v, sgo_chassis* c, sgo_chassis*
 			const float impulse = (rw->suspension_length - lw->suspension_length) * v->anti_roll_bars[k].stiffness * dt;
 			lw->anti_roll_impulse = -impulse; rw->anti_roll_impulse = impulse;
 		}
-	}
-	for (int i = 0; i < nw; ++i) {
-		sgo_wheel* w = &v->wheels[i];
-		if (!w->has_contact || w->anti_roll_impulse == 0.0f) continue;
-		const v3 J = v3_scale(w->contact_normal, w->anti_roll_impulse);
-		c->v = v3_add(c->v, v3_scale(J, c->im));
-		c->w = v3_add(c->w, sym33_mul(c->I, v3_cross(v3_sub(w->contact_pos, c->pos), J)));
 	}
 
 	/* ---- WheeledVehicleController::PostCollide ---- */
@@ -623,20 +618,20 @@ static inline int sgo_vehicle_pre_b(sgo_vehicle* v, sgo_chassis* c, sgo_chassis*
 			const float damping = 2.0f * eff_mass * w->spring_damp * omega;
 			const float Cc = w->suspension_length - w->sus_max - w->sus_preload;
 			lam = w->suspension.lambda;
-			sgo_part_setup(&w->suspension, c, r1, gb, r2, neg_n, dt, Cc, stiffness, damping);
+			sgo_part_setup(&w->suspension, c, r1, gb, r2, neg_n, dt, Cc, stiffness, damping, w->anti_roll_impulse);
 			if (w->suspension.active) w->suspension.lambda = lam;
 		} else sgo_part_deactivate(&w->suspension);
 		if (w->suspension_length < w->sus_min) {
 			lam = w->max_up.lambda;
-			sgo_part_setup(&w->max_up, c, r1, gb, r2, neg_n, dt, 0.0f, 0.0f, 0.0f);
+			sgo_part_setup(&w->max_up, c, r1, gb, r2, neg_n, dt, 0.0f, 0.0f, 0.0f, 0.0f);
 			if (w->max_up.active) w->max_up.lambda = lam;
 			w->suspension_length = w->sus_min;
 		} else sgo_part_deactivate(&w->max_up);
 		/* the longitudinal row (engine / brake force) is never warm started: its impulse starts from zero every step */
-		sgo_part_setup(&w->longitudinal, c, r1, gb, r2, v3_neg(w->contact_long), dt, 0.0f, 0.0f, 0.0f);
+		sgo_part_setup(&w->longitudinal, c, r1, gb, r2, v3_neg(w->contact_long), dt, 0.0f, 0.0f, 0.0f, 0.0f);
 		w->longitudinal.lambda = 0.0f;
 		lam = w->lateral.lambda;
-		sgo_part_setup(&w->lateral, c, r1, gb, r2, v3_neg(w->contact_lat), dt, 0.0f, 0.0f, 0.0f);
+		sgo_part_setup(&w->lateral, c, r1, gb, r2, v3_neg(w->contact_lat), dt, 0.0f, 0.0f, 0.0f, 0.0f);
 		if (w->lateral.active) w->lateral.lambda = lam;
 	}
 	int spinning = 0;

@@ -268,7 +268,7 @@ SGP_DEV static void sgd_part_deactivate(sgd_axis_part* p) { p->active = 0; p->la
 
 // hard row, or soft row when stiffness > 0 (Jolt SpringPart::CalculateSpringPropertiesWithStiffnessAndDamping); a dynamic body under the wheel adds
 // its share to the inverse effective mass after the chassis' (AxisConstraintPart::TemplatedCalculateInverseEffectiveMass)
-SGP_DEV static void sgd_part_setup(sgd_axis_part* p, const sgd_chassis* c, v3 r1, const sgd_ground* g, v3 r2, v3 axis, float dt, float C, float stiffness, float damping)
+SGP_DEV static void sgd_part_setup(sgd_axis_part* p, const sgd_chassis* c, v3 r1, const sgd_ground* g, v3 r2, v3 axis, float dt, float C, float stiffness, float damping, float bias_in)
 {
 	p->r1xa = v3_cross(r1, axis);
 	p->iI_r1xa = sym33_mul(c->I, p->r1xa);
@@ -281,10 +281,10 @@ SGP_DEV static void sgd_part_setup(sgd_axis_part* p, const sgd_chassis* c, v3 r1
 	if (!(inv_eff > 0.0f)) { sgd_part_deactivate(p); return; }
 	if (stiffness > 0.0f) {
 		p->softness = 1.0f / (dt * (damping + dt * stiffness));
-		p->bias = dt * stiffness * p->softness * C;
+		p->bias = bias_in + dt * stiffness * p->softness * C;      /* SpringPart: mBias = inBias + dt k softness C */
 		p->eff = 1.0f / (inv_eff + p->softness);
 	} else {
-		p->softness = 0.0f; p->bias = 0.0f;
+		p->softness = 0.0f; p->bias = bias_in;
 		p->eff = 1.0f / inv_eff;
 	}
 	p->active = 1;
@@ -425,8 +425,8 @@ SGP_DEV static void sgd_differential_split(const sgd_differential* d, float wl, 
 // The controller step of one vehicle by the lanes of its wave (VehicleConstraint::OnStep after the casts, WheeledVehicleController::PostCollide,
 // VehicleConstraint::SetupVelocityConstraint).  `v` is the record in LDS, `c` this lane's copy of the chassis state, `lane` 0..63.
 // What belongs to one wheel -- its contact frame, tyre slip and friction, brake, the four axis rows -- is the work of lane i = wheel i; what
-// couples the wheels (anti-roll bars, engine / clutch / differentials / gearbox) is short and sequential: the anti-roll impulses are applied by
-// every lane to its own copy of the chassis (the same operands in the same order: the same bits, and no broadcast), the drivetrain runs on
+// couples the wheels (anti-roll bars, engine / clutch / differentials / gearbox) is short and sequential: the anti-roll terms are set by lane 0
+// (they become the bias of each wheel's suspension row), the drivetrain runs on
 // lane 0 between two barriers.  A wheel's arithmetic is that of the sequential statement wheel after wheel: nothing a wheel computes in one
 // phase reads what another wheel computes in the same phase.  Returns (to every lane) whether the chassis' sleep timer must be reset.
 // `g`: the dynamic body under this lane's wheel (g->dyn = 0 if there is none).
@@ -452,7 +452,7 @@ SGP_DEV static int sgd_vehicle_controller_lanes(sgd_vehicle* v, sgd_chassis* c, 
 		w->anti_roll_impulse = 0.0f;
 	}
 	__syncthreads();
-	// 2. anti-roll bars: impulse from the difference of the suspension lengths, on the chassis at the two contact points (wheel order)
+	// 2. anti-roll bars: the term from the difference of the suspension lengths becomes the bias of each wheel's suspension row (step 6)
 	if (lane == 0) {
 		for (int k = 0; k < v->num_anti_roll_bars; ++k) {
 			sgd_wheel* lw = &v->wheels[v->anti_roll_bars[k].left]; sgd_wheel* rw = &v->wheels[v->anti_roll_bars[k].right];
@@ -463,13 +463,6 @@ SGP_DEV static int sgd_vehicle_controller_lanes(sgd_vehicle* v, sgd_chassis* c, 
 		}
 	}
 	__syncthreads();
-	for (int i = 0; i < nw; ++i) {
-		const sgd_wheel* o = &v->wheels[i];
-		if (!o->has_contact || o->anti_roll_impulse == 0.0f) continue;
-		const v3 J = v3_scale(o->contact_normal, o->anti_roll_impulse);
-		c->v = v3_add(c->v, v3_scale(J, c->im));
-		c->w = v3_add(c->w, sym33_mul(c->I, v3_cross(v3_sub(o->contact_pos, c->pos), J)));
-	}
 	// 3. WheelWV::Update of the own wheel: spin damping, rotation angle, slip -> tyre friction
 	const float old_rpm = v->engine_rpm;
 	if (mine) {
@@ -602,20 +595,20 @@ SGP_DEV static int sgd_vehicle_controller_lanes(sgd_vehicle* v, sgd_chassis* c, 
 				const float damping = 2.0f * eff_mass * w->spring_damp * omega;
 				const float Cc = w->suspension_length - w->sus_max - w->sus_preload;
 				lam = w->suspension.lambda;
-				sgd_part_setup(&w->suspension, c, r1, g, r2, neg_n, dt, Cc, stiffness, damping);
+				sgd_part_setup(&w->suspension, c, r1, g, r2, neg_n, dt, Cc, stiffness, damping, w->anti_roll_impulse);
 				if (w->suspension.active) w->suspension.lambda = lam;
 			} else sgd_part_deactivate(&w->suspension);
 			if (w->suspension_length < w->sus_min) {
 				lam = w->max_up.lambda;
-				sgd_part_setup(&w->max_up, c, r1, g, r2, neg_n, dt, 0.0f, 0.0f, 0.0f);
+				sgd_part_setup(&w->max_up, c, r1, g, r2, neg_n, dt, 0.0f, 0.0f, 0.0f, 0.0f);
 				if (w->max_up.active) w->max_up.lambda = lam;
 				w->suspension_length = w->sus_min;
 			} else sgd_part_deactivate(&w->max_up);
 			// the longitudinal row (engine / brake force) is never warm started: its impulse starts from zero every step
-			sgd_part_setup(&w->longitudinal, c, r1, g, r2, v3_neg(w->contact_long), dt, 0.0f, 0.0f, 0.0f);
+			sgd_part_setup(&w->longitudinal, c, r1, g, r2, v3_neg(w->contact_long), dt, 0.0f, 0.0f, 0.0f, 0.0f);
 			w->longitudinal.lambda = 0.0f;
 			lam = w->lateral.lambda;
-			sgd_part_setup(&w->lateral, c, r1, g, r2, v3_neg(w->contact_lat), dt, 0.0f, 0.0f, 0.0f);
+			sgd_part_setup(&w->lateral, c, r1, g, r2, v3_neg(w->contact_lat), dt, 0.0f, 0.0f, 0.0f, 0.0f);
 			if (w->lateral.active) w->lateral.lambda = lam;
 		}
 		if (fabsf(w->angular_velocity) > 10.0f * SGD_VEH_PI / 180.0f) spinning = 1;

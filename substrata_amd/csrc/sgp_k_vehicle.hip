@@ -59,6 +59,7 @@ SGP_DEV void veh_stage_out(sgd_vehicle* gv, const sgd_vehicle* sv)
 __global__ void __launch_bounds__(64) k_vehicle_cast(DV d)
 {
 	__shared__ sgd_vehicle sv;
+	__shared__ int s_dormant;
 	const uint32_t k = blockIdx.x;
 	sgd_vehicle* gv = &d.vehicles[k];
 	if ((k & 31u) == 0u && threadIdx.x == 0) d.veh_defer_bits[k >> 5] = 0u;      // (k_vehicle_controller, the next launch, sets the bits of this step)
@@ -68,10 +69,16 @@ __global__ void __launch_bounds__(64) k_vehicle_cast(DV d)
 		const sgp_vehicle_input in = d.vehicle_inputs[k];
 		sv.in_forward = in.forward; sv.in_right = in.right; sv.in_brake = in.brake; sv.in_handbrake = in.hand_brake;
 		const uint32_t b = sv.body;
-		sv.active = (b < d.sp->n_slots && f_movable(d.flags[b])) ? 1 : 0;
+		const uint32_t fb = b < d.sp->n_slots ? d.flags[b] : 0u;
+		sv.active = f_movable(fb) ? 1 : 0;
+		// a vehicle whose chassis sleeps casts too (VehicleConstraint::OnStep runs every step; the constraint is active when the chassis OR a body under
+		// a wheel is active, and VehicleConstraint::BuildIslands then activates the chassis): on the staged copy only -- its record stays as it is unless
+		// this step wakes it
+		s_dormant = (!sv.active && (fb & BF_ALIVE) && !(fb & BF_ACTIVE) && f_motion(fb) == SGP_MOTION_DYNAMIC) ? 1 : 0;
 	}
 	__syncthreads();
-	if (sv.active) {
+	const bool dormant = s_dormant != 0;
+	if (sv.active || dormant) {
 		{ const sgd_chassis c = veh_chassis_pose_vel(d, sv.body); sgd_vehicle_precast_lanes(&sv, &c, d.sp->dt, (int)threadIdx.x); }
 		__syncthreads();
 		const int wi = (int)(threadIdx.x >> 4); const uint32_t sub = threadIdx.x & 15u;
@@ -111,6 +118,13 @@ __global__ void __launch_bounds__(64) k_vehicle_cast(DV d)
 			const float opx = __shfl_xor(bp.x, off, 16), opy = __shfl_xor(bp.y, off, 16), opz = __shfl_xor(bp.z, off, 16);
 			const bool take = oid != SGP_INVALID_ID && (bid == SGP_INVALID_ID || ot < best || (ot == best && oid < bid));
 			if (take) { best = ot; bid = oid; bn = V3(onx, ony, onz); bp = V3(opx, opy, opz); }
+		}
+		if (dormant) {
+			// does a wheel touch something that is awake?  (one wave per vehicle: the vote is the workgroup's)
+			const bool hit = wi < sv.num_wheels && sub == 0 && bid != SGP_INVALID_ID;
+			const uint32_t fh = hit ? d.flags[bid] : 0u;
+			if (__ballot(hit && (fh & BF_ACTIVE) && f_motion(fh) != SGP_MOTION_STATIC) == 0ull) return;      // nothing: the vehicle sleeps on, its record untouched
+			if (threadIdx.x == 0) { sv.active = 1; wake_body(d, sv.body); }      // woken like a body an active one touches: by this step's k_pre_solve, before the solve
 		}
 		if (wi < sv.num_wheels && sub == 0 && bid != SGP_INVALID_ID) {
 			const uint32_t fo = d.flags[bid];

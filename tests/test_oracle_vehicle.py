@@ -335,3 +335,76 @@ def test_a_car_on_a_light_box_loads_it(oracle):
         return x1 - x0
     assert run(False) > 0.3
     assert abs(run(True)) < 0.02
+
+
+def _spring_constants(m=1200.0):
+    """k, c of the default car's suspension rows (frequency 2 Hz, damping ratio 0.5) as test_suspension_static_equilibrium derives them."""
+    hx, hy, hz = 0.9, 2.0, 0.25
+    inv_i = np.array([12.0 / (m * ((2 * hy) ** 2 + (2 * hz) ** 2)), 12.0 / (m * ((2 * hx) ** 2 + (2 * hz) ** 2)), 12.0 / (m * ((2 * hx) ** 2 + (2 * hy) ** 2))])
+    p = np.array([0.8, 1.3, 0.15]) + 0.5 * (0.2 + 0.5) * np.array([0, 0, -1.0])
+    pxu = np.cross(p, [0, 0, -1.0])
+    m_eff = 1.0 / (1.0 / m + pxu @ (inv_i * pxu))
+    om = 2 * np.pi * 2.0
+    return m_eff * om * om, 2.0 * m_eff * 0.5 * om
+
+
+def test_anti_roll_bar_is_the_bias_of_the_suspension_row(oracle):
+    """Round 5 (DESIGN 8 'Vehicles'): the anti-roll term a_i = -/+ (len_R - len_L) K dt of a wheel is the velocity bias of its suspension row
+    (SpringPart: bias = a + dt k s C with softness s = 1 / (dt (c + dt k))), not an impulse on the chassis.  At rest (J v = 0) a soft row settles at
+    lambda = -bias / s, i.e. per wheel   lambda_i = -a_i dt (c + dt k) - dt k C_i   with C_i = len_i - max - preload:
+    the bar acts like a spring of K dt (c + dt k) ~ 63 K between the two suspension lengths, far stiffer than the suspension springs themselves.
+    A car parked with its left wheels on a 6 cm plate leans off it; the lower side's springs carry more and are shorter by 4 mm without bars, by
+    a quarter of that with CarPhysics' bars (K = 1000).  The old statement (impulse a_i on the chassis in the pre-step, K dt
+    per metre of difference) left the bars all but inert: K = 1000 gave the picture of K = 0."""
+    k, c = _spring_constants()
+
+    def run(K):
+        w = oracle.OracleWorld(max_bodies=16)
+        add_ground(w)
+        dyn(w, shape=(0.5, 3.0, 0.03, 0.0), pos=(-0.8, 0.0, 0.03), motion=abi.MOTION_STATIC, layer=abi.LAYER_NON_MOVING)      # under the two left wheels (x = -0.8)
+
+        def bars(vd):
+            for b in range(2):
+                vd.anti_roll_bars[b].stiffness = K
+        body, vid = add_car(w, pos=(0, 0, 0.85), desc_edit=bars)
+        settle(w, 500)
+        vs = w.vehicle_get_state(vid)
+        lens = np.array([x["suspension_length"] for x in vs["wheels"]], np.float64)
+        lam = np.array([x["suspension_lambda"] for x in vs["wheels"]], np.float64)
+        assert all(x["has_contact"] == 1 for x in vs["wheels"])
+        w.close()
+        return lens, lam
+    lens0, lam0 = run(0.0)
+    lens1, lam1 = run(1000.0)
+    for l_i, r_i in ((0, 1), (2, 3)):                                     # default layout: wheels 0 / 2 left, 1 / 3 right
+        d0, d1 = lens0[l_i] - lens0[r_i], lens1[l_i] - lens1[r_i]
+        assert d0 > 0.003, lens0                                           # no bars: the chassis leans off the plate, the low side carries more (4 mm of spring)
+        assert 0.0 < d1 < 0.4 * d0, (lens0, lens1)                         # bars: most of that difference is gone (the old, inert bars left it where it was)
+        for lens, lam, K in ((lens0, lam0, 0.0), (lens1, lam1, 1000.0)):
+            a = (lens[r_i] - lens[l_i]) * K * DT
+            for i, a_i in ((l_i, -a), (r_i, a)):
+                expect = -a_i * DT * (c + DT * k) - DT * k * (lens[i] - 0.5)
+                assert abs(lam[i] - expect) < 0.03 * abs(expect) + 0.2, (K, i, lam[i], expect)
+
+
+def test_an_active_body_under_a_wheel_wakes_the_sleeping_car(oracle):
+    """Round 5 (DESIGN 8 'Vehicles'): a vehicle constraint is active when its chassis OR a body a wheel touches is active, and building the islands
+    then activates the chassis (VehicleConstraint::OnStep / BuildIslands).  A ball rolled through the cast of a wheel of a parked, sleeping car --
+    it passes under the chassis without touching it -- wakes the car; the same ball rolling past out of reach of every wheel does not."""
+    def run(ball_y):
+        w = oracle.OracleWorld(max_bodies=16)
+        add_ground(w)
+        body, vid = add_car(w)
+        settle(w, 420)
+        assert w.get_state([body])[0]["active"] == 0
+        z_chassis_bottom = w.get_state([body])[0]["pos"][2] - 0.25
+        ball = dyn(w, shape_type=abi.SHAPE_SPHERE, shape=(0.1, 0, 0, 0), pos=(2.2, ball_y, 0.1), mass=1.0, friction=0.5, lin_vel=(-3.0, 0.0, 0.0))
+        assert z_chassis_bottom > 0.25                                        # the ball (top at 0.2) cannot touch the chassis
+        woke = False
+        for _ in range(90):
+            w.step(DT)
+            woke = woke or w.get_state([body])[0]["active"] == 1
+        w.close()
+        return woke
+    assert run(1.3 + 0.12)                 # 12 cm beside the front wheels' suspension line (cast radius 0.08 + ball radius 0.1): swept by the cast
+    assert not run(0.0)                    # between the axles: no wheel reaches it, and it never touches the chassis

@@ -220,3 +220,43 @@ def test_a_wheel_wakes_the_plate_and_they_sleep_together(oracle):
         tw.step(DT)
     _states_exact(tw, 3, "driving off")
     tw.close()
+
+
+def test_anti_roll_bias_and_the_sleeping_car_woken_through_a_wheel_match_oracle(oracle):
+    """Round 5: (1) a car parked with its left wheels on a plate -- the anti-roll terms are the biases of the suspension rows -- and (2) a parked,
+    sleeping car with a ball rolling through the cast of a front wheel (it never touches the chassis): the car must wake in the same step on the device
+    as in the oracle, and everything stays bit for bit the same."""
+    from helpers import dyn, add_ground
+    tw = parity.make_twin(oracle, max_bodies=64)
+    for w in (tw.gpu, tw.cpu):
+        add_ground(w)
+        dyn(w, shape=(0.5, 3.0, 0.03, 0.0), pos=(-0.8, 0.0, 0.03), motion=abi.MOTION_STATIC, layer=abi.LAYER_NON_MOVING)
+        add_car(w, pos=(0, 0, 0.85))                                   # car 0: left wheels on the plate
+        add_car(w, pos=(20.0, 0, 0.75))                                # car 1: parked on the flat, will be woken through a wheel
+    n = 64
+    for s in range(420):
+        tw.step(DT)
+        if s in (0, 5, 60, 419):
+            d = parity.compare(tw, n)
+            assert d["bit_exact"] and d["active_mismatch"] == 0, (s, d)
+            sg, sc = tw.vehicle_get_states(0, 2)
+            assert vehicle_diff(sg, sc)["bit_exact"], (s, vehicle_diff(sg, sc))
+    sg, sc = tw.vehicle_get_states(0, 2)
+    assert sg["active"][1] == 0 and sc["active"][1] == 0               # car 1 sleeps
+    lens = sg["wheels"][0]["suspension_length"]
+    assert lens[0] != lens[1]                                          # car 0's bars have something to do
+    for w in (tw.gpu, tw.cpu):
+        dyn(w, shape_type=abi.SHAPE_SPHERE, shape=(0.1, 0, 0, 0), pos=(22.2, 1.42, 0.1), mass=1.0, friction=0.5, lin_vel=(-3.0, 0.0, 0.0))
+    woke_at = None
+    for s in range(90):
+        tw.step(DT)
+        ag = int(tw.gpu.read_states(0, n)["active"][3]); ac = int(tw.cpu.read_states(0, n)["active"][3])     # body 3 = car 1's chassis
+        assert ag == ac, s
+        if woke_at is None and ag:
+            woke_at = s
+        d = parity.compare(tw, n)
+        assert d["bit_exact"] and d["active_mismatch"] == 0, (s, d)
+    assert woke_at is not None and woke_at > 3                         # woken when the ball reached the wheel, not by its creation
+    sg, sc = tw.vehicle_get_states(0, 2)
+    assert vehicle_diff(sg, sc)["bit_exact"]
+    tw.close()
