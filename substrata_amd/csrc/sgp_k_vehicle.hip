@@ -123,7 +123,10 @@ __global__ void __launch_bounds__(64) k_vehicle_cast(DV d)
 			// does a wheel touch something that is awake?  (one wave per vehicle: the vote is the workgroup's)
 			const bool hit = wi < sv.num_wheels && sub == 0 && bid != SGP_INVALID_ID;
 			const uint32_t fh = hit ? d.flags[bid] : 0u;
-			if (__ballot(hit && (fh & BF_ACTIVE) && f_motion(fh) != SGP_MOTION_STATIC) == 0ull) return;      // nothing: the vehicle sleeps on, its record untouched
+			if (__ballot(hit && (fh & BF_ACTIVE) && f_motion(fh) != SGP_MOTION_STATIC) == 0ull) {      // nothing: the vehicle sleeps on, its record untouched ...
+				if (threadIdx.x == 0) gv->active = 0;      // ... but for the flag the controller launch reads (it was awake in the step before it fell asleep)
+				return;
+			}
 			if (threadIdx.x == 0) { sv.active = 1; wake_body(d, sv.body); }      // woken like a body an active one touches: by this step's k_pre_solve, before the solve
 		}
 		if (wi < sv.num_wheels && sub == 0 && bid != SGP_INVALID_ID) {

@@ -741,13 +741,13 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 		uint32_t lc[SGP_NUM_LAYERS]; memcpy(lc, st.layer_counts, sizeof(lc));
 		memset(&st, 0, sizeof(st));
 		st.num_bodies = nb_; memcpy(st.layer_counts, lc, sizeof(lc)); st.device_bytes = w->device_bytes;
-		w->idle_steps++;
+		w->idle_steps++; w->last_step_idle = true;
 		// the first skipped step takes the contact cache with it: a step without an awake body has no contacts, and what wakes up later (in-step
 		// activation pairs bodies that were asleep) must not find the constraints of the last step that had some
 		if (!w->cache_wiped) { launch_cache_wipe(d, w->stream); w->cache_wiped = true; }
 		return SGP_OK;
 	}
-	w->cache_wiped = false;
+	w->cache_wiped = false; w->last_step_idle = false;
 	if (w->veh_inputs_dirty && w->n_vehicles) {
 		HIP_TRY(hipMemcpyAsync(w->d_veh_inputs, w->veh_inputs.data(), sizeof(sgp_vehicle_input) * w->n_vehicles, hipMemcpyHostToDevice, w->stream));
 		w->veh_inputs_dirty = false;

@@ -121,6 +121,7 @@ struct sgp_world {
 	bool bp_dense_last = false;     // the previous step's broad phase met a halo too large for the small instance of k_bp_pairs
 	bool plan_seen = false;         // a step has run: plan_colour_count etc. describe the previous step
 	uint32_t graph_launches = 0, eager_steps = 0, idle_steps = 0;
+	bool last_step_idle = false;       // the last step was skipped (every body asleep, nothing edited): no vehicle took part in it, whatever its record says
 	bool grid_valid = false;                                   // the broad-phase grid matches the current poses (ray queries reuse it)
 	// static triangle meshes: host-side headers + pools mirrored on the device (grown on demand)
 	std::vector<MeshHeader> meshes; std::vector<float4> mesh_verts; std::vector<uint4> mesh_tris; std::vector<uint32_t> mesh_tri_mat; std::vector<MeshNode> mesh_nodes;

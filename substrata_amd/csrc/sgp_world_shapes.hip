@@ -523,7 +523,7 @@ SGP_API int sgp_vehicle_get_states(sgp_world* w, uint32_t first, uint32_t n, sgp
 			ws->suspension_lambda = wh->suspension.lambda + wh->max_up.lambda; ws->longitudinal_lambda = wh->longitudinal.lambda; ws->lateral_lambda = wh->lateral.lambda;
 			ws->longitudinal_slip = wh->long_slip; ws->lateral_slip = wh->lat_slip;
 		}
-		s->engine_rpm = v->engine_rpm; s->current_gear = v->current_gear; s->clutch_friction = v->clutch_friction; s->active = v->active;
+		s->engine_rpm = v->engine_rpm; s->current_gear = v->current_gear; s->clutch_friction = v->clutch_friction; s->active = w->last_step_idle ? 0 : v->active;      // (a skipped step ran no vehicle kernel: the record still says what the last real step saw)
 	}
 	return SGP_OK;
 }
