@@ -134,11 +134,9 @@ SGP_DEV void ray_test_body(const DV& d, const sgp_ray& ry, v3 o, v3 dir, uint32_
 // traceRay (PhysicsWorld.cpp:1668-1725), batched: one thread per ray.  Large bodies (ground quad ...) are tested directly;
 // small bodies through a 3D-DDA walk of the broad-phase cell grid (bodies are binned by centre and reach at most one cell
 // beyond it, so every visited cell also looks at its 26 neighbours), stopping once the cell entry distance passes the best hit.
-__global__ void __launch_bounds__(64) k_raycast(DV d, const sgp_ray* rays, uint32_t n, sgp_hit* hits)
+// one ray against the world: large bodies, the static large bodies' grid, then a DDA walk of the cell grid
+SGP_DEV sgp_hit raycast_one(const DV& d, const sgp_ray& ry)
 {
-	const uint32_t k = blockIdx.x * 64 + threadIdx.x;
-	if (k >= n) return;
-	const sgp_ray ry = rays[k];
 	const v3 o = V3(ry.origin[0], ry.origin[1], ry.origin[2]), dir = V3(ry.dir[0], ry.dir[1], ry.dir[2]);
 	RayBest best; best.t = ry.max_t; best.id = SGP_INVALID_ID; best.n = V3(0.0f, 0.0f, 0.0f);
 	best.sub.tri = SGP_INVALID_ID; best.sub.mat = 0; best.sub.u = best.sub.v = 0.0f;
@@ -196,7 +194,139 @@ __global__ void __launch_bounds__(64) k_raycast(DV d, const sgp_ray* rays, uint3
 	h.normal[0] = best.n.x; h.normal[1] = best.n.y; h.normal[2] = best.n.z;
 	h.triangle = best.sub.tri; h.material = best.sub.mat; h.bary[0] = best.sub.u; h.bary[1] = best.sub.v; h.sub_shape = 0;
 	h.userdata = 0;
-	hits[k] = h;
+	return h;
+}
+__global__ void __launch_bounds__(64) k_raycast(DV d, const sgp_ray* rays, uint32_t n, sgp_hit* hits)
+{
+	const uint32_t k = blockIdx.x * 64 + threadIdx.x;
+	if (k >= n) return;
+	hits[k] = raycast_one(d, rays[k]);
+}
+
+// The same ray by all 64 lanes of a wave together (the resident server's form of raycast_one): the candidates are dealt to the lanes -- the large bodies
+// by index, the bodies of the static large bodies' grid in the order it yields them, the nine neighbour rows of a visited cell one row per lane -- and
+// every lane keeps its own closest hit.  The answer is the lexicographic minimum of (t, body id) over the lanes: ray_test_body breaks ties by body id
+// precisely so that the result does not depend on the order of the tests, so this is raycast_one's answer bit for bit.  `tmin` (the wave's closest t so
+// far, refreshed after every cell) bounds the walk for all lanes alike, which keeps the control flow -- and the dealing -- uniform.
+SGP_DEV float wave_min_f(float x) { for (int off = 32; off >= 1; off >>= 1) x = fminf(x, __shfl_xor(x, off, 64)); return x; }
+SGP_DEV void ray_share_bound(RayBest& best, float& tmin)
+{
+	tmin = wave_min_f(best.t);
+	if (best.t > tmin) { best.t = tmin; best.id = SGP_INVALID_ID; }      // (somebody is closer: this lane's hit cannot win; it keeps pruning with the wave's bound)
+}
+SGP_DEV sgp_hit raycast_wave(const DV& d, const sgp_ray& ry)
+{
+	const int lane = (int)(threadIdx.x & 63u);
+	const v3 o = V3(ry.origin[0], ry.origin[1], ry.origin[2]), dir = V3(ry.dir[0], ry.dir[1], ry.dir[2]);
+	RayBest best; best.t = ry.max_t; best.id = SGP_INVALID_ID; best.n = V3(0.0f, 0.0f, 0.0f);
+	best.sub.tri = SGP_INVALID_ID; best.sub.mat = 0; best.sub.u = best.sub.v = 0.0f;
+	float tmin = ry.max_t;
+	for (uint32_t l = (uint32_t)lane; l < d.sp->n_large; l += 64u) ray_test_body(d, ry, o, dir, d.large_ids[l], best);
+	ray_share_bound(best, tmin);
+	{
+		uint32_t dealt = 0;
+		const float bound = tmin;      // (fixed for the walk: every lane walks the same cells and counts the same candidates)
+		large_grid_ray(d, o, dir, &bound, [&](uint32_t i) { if ((int)(dealt++ & 63u) == lane) ray_test_body(d, ry, o, dir, i, best); });
+		ray_share_bound(best, tmin);
+	}
+	const BpGrid g = *d.grid;
+	if (g.n_cells > 0 && g.min_x <= g.max_x) {
+		const float c = g.cell;
+		const v3 lo = V3(g.ox - c, g.oy - c, g.oz - c);
+		const v3 hi = V3(g.ox + ((float)g.nx + 1.0f) * c, g.oy + ((float)g.ny + 1.0f) * c, g.oz + ((float)g.nz + 1.0f) * c);
+		float t0 = 0.0f, t1 = tmin; bool miss = false;
+		const float oo[3] = { o.x, o.y, o.z }, dd[3] = { dir.x, dir.y, dir.z };
+		const float bl[3] = { lo.x, lo.y, lo.z }, bh[3] = { hi.x, hi.y, hi.z };
+		for (int a = 0; a < 3 && !miss; ++a) {
+			if (fabsf(dd[a]) < 1.0e-12f) { if (oo[a] < bl[a] || oo[a] > bh[a]) miss = true; }
+			else {
+				float ta = (bl[a] - oo[a]) / dd[a], tb = (bh[a] - oo[a]) / dd[a];
+				if (ta > tb) { const float tmp = ta; ta = tb; tb = tmp; }
+				t0 = fmaxf(t0, ta); t1 = fminf(t1, tb);
+				if (t0 > t1) miss = true;
+			}
+		}
+		if (!miss) {
+			const v3 p0 = v3_add(o, v3_scale(dir, t0));
+			int cx = (int)floorf((p0.x - g.ox) * g.inv_cell), cy = (int)floorf((p0.y - g.oy) * g.inv_cell), cz = (int)floorf((p0.z - g.oz) * g.inv_cell);
+			cx = min(max(cx, -1), g.nx); cy = min(max(cy, -1), g.ny); cz = min(max(cz, -1), g.nz);
+			const int sx = dir.x > 0.0f ? 1 : -1, sy = dir.y > 0.0f ? 1 : -1, sz = dir.z > 0.0f ? 1 : -1;
+			const float inf = 3.0e38f;
+			const float tdx = fabsf(dir.x) > 1.0e-12f ? c / fabsf(dir.x) : inf, tdy = fabsf(dir.y) > 1.0e-12f ? c / fabsf(dir.y) : inf, tdz = fabsf(dir.z) > 1.0e-12f ? c / fabsf(dir.z) : inf;
+			float tmx = fabsf(dir.x) > 1.0e-12f ? ((g.ox + (float)(cx + (sx > 0 ? 1 : 0)) * c) - o.x) / dir.x : inf;
+			float tmy = fabsf(dir.y) > 1.0e-12f ? ((g.oy + (float)(cy + (sy > 0 ? 1 : 0)) * c) - o.y) / dir.y : inf;
+			float tmz = fabsf(dir.z) > 1.0e-12f ? ((g.oz + (float)(cz + (sz > 0 ? 1 : 0)) * c) - o.z) / dir.z : inf;
+			float t_enter = t0;
+			const int dy = lane % 3 - 1, dz = (lane / 3) % 3 - 1;      // lanes 0..8: one neighbour row each
+			for (int iter = 0; iter < 100000; ++iter) {
+				if (t_enter - 2.0f * c > tmin) break;
+				if (lane < 9) {
+					const int y = cy + dy, z = cz + dz;
+					const int xa = max(cx - 1, 0), xb = min(cx + 1, g.nx - 1);
+					if (y >= 0 && y < g.ny && z >= 0 && z < g.nz && xa <= xb)
+						grid_row_runs(d, g, xa, xb, y, z, [&](uint32_t q0, uint32_t q1) { for (uint32_t q = q0; q < q1; ++q) ray_test_body(d, ry, o, dir, __float_as_uint(d.sorted_max[q].w), best); });
+				}
+				ray_share_bound(best, tmin);
+				if (tmx <= tmy && tmx <= tmz) { t_enter = tmx; tmx += tdx; cx += sx; if (cx < -1 || cx > g.nx) break; }
+				else if (tmy <= tmz) { t_enter = tmy; tmy += tdy; cy += sy; if (cy < -1 || cy > g.ny) break; }
+				else { t_enter = tmz; tmz += tdz; cz += sz; if (cz < -1 || cz > g.nz) break; }
+				if (t_enter > t1) break;
+			}
+		}
+	}
+	// the wave's answer: lowest (t, id) among the lanes that hold a hit
+	float wt = best.id != SGP_INVALID_ID ? best.t : 3.0e38f; uint32_t wid = best.id;
+	for (int off = 32; off >= 1; off >>= 1) {
+		const float ot = __shfl_xor(wt, off, 64); const uint32_t oid = (uint32_t)__shfl_xor((int)wid, off, 64);
+		if (oid != SGP_INVALID_ID && (wid == SGP_INVALID_ID || ot < wt || (ot == wt && oid < wid))) { wt = ot; wid = oid; }
+	}
+	sgp_hit h;
+	h.id = wid; h.t = 0.0f; h.normal[0] = h.normal[1] = h.normal[2] = 0.0f; h.triangle = SGP_INVALID_ID; h.material = 0; h.bary[0] = h.bary[1] = 0.0f; h.sub_shape = 0; h.userdata = 0;
+	if (wid != SGP_INVALID_ID) {
+		const unsigned long long owners = __ballot(best.id == wid && best.t == wt);
+		const int src = __ffsll((long long)owners) - 1;
+		h.t = wt;
+		h.normal[0] = __shfl(best.n.x, src, 64); h.normal[1] = __shfl(best.n.y, src, 64); h.normal[2] = __shfl(best.n.z, src, 64);
+		h.triangle = (uint32_t)__shfl((int)best.sub.tri, src, 64); h.material = (uint32_t)__shfl((int)best.sub.mat, src, 64);
+		h.bary[0] = __shfl(best.sub.u, src, 64); h.bary[1] = __shfl(best.sub.v, src, 64);
+	}
+	return h;
+}
+
+// The resident ray server (RayMailbox, sgp_kernels.h): one wave.  Its 64 lanes trace the ray together (raycast_wave); the mailbox lines are read and written by lanes 0..15, one word each, as single 64-byte transactions over the host link.
+__global__ void __launch_bounds__(64) k_ray_server(DV d, RayMailbox* mb, uint32_t first_seq, uint64_t idle_ticks, uint64_t max_ticks)
+{
+	const int lane = (int)threadIdx.x;
+	uint32_t* req_line = (uint32_t*)mb;
+	uint32_t* res_line = req_line + 16;
+	uint32_t seen = first_seq;
+	const uint64_t t_start = wall_clock64();
+	uint64_t t_last = t_start;
+	if (lane == 1) __hip_atomic_store(&res_line[1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);      // alive
+	for (uint32_t poll = 0;; ++poll) {
+		const uint32_t wv = lane < 16 ? __hip_atomic_load(&req_line[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+		const uint32_t req = (uint32_t)__shfl((int)wv, 0, 64), stop = (uint32_t)__shfl((int)wv, 1, 64);
+		if (req != seen) {
+			sgp_ray ry;
+			uint32_t* dst = (uint32_t*)&ry;
+#pragma unroll
+			for (int i = 0; i < (int)(sizeof(sgp_ray) / 4); ++i) dst[i] = (uint32_t)__shfl((int)wv, 2 + i, 64);
+			const sgp_hit h = raycast_wave(d, ry);
+			const uint32_t* hs = (const uint32_t*)&h;
+			uint32_t out = 0u;
+			if (lane == 0 || lane == 15) out = req; else if (lane == 1) out = 1u;
+#pragma unroll
+			for (int i = 0; i < (int)(sizeof(sgp_hit) / 4); ++i) if (lane == 2 + i) out = hs[i];
+			if (lane < 16) __hip_atomic_store(&res_line[lane], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			seen = req;
+			t_last = wall_clock64();
+			continue;
+		}
+		if (stop != 0u) break;
+		if ((poll & 15u) == 15u) { const uint64_t now = wall_clock64(); if (now - t_last > idle_ticks || now - t_start > max_ticks) break; }
+	}
+	// a request that arrived while this wave was deciding to leave is answered by the next server: the host sees alive == 0 with its request open
+	if (lane == 1) __hip_atomic_store(&res_line[1], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -351,6 +481,7 @@ __global__ void __launch_bounds__(64) k_spherecast(DV d, const sgp_ray* rays, co
 	h.userdata = 0;
 	hits[k] = h;
 }
+void launch_ray_server(const DV& d, RayMailbox* mb, uint32_t first_seq, uint64_t idle_ticks, uint64_t max_ticks, hipStream_t s) { hipLaunchKernelGGL(k_ray_server, dim3(1), dim3(64), 0, s, d, mb, first_seq, idle_ticks, max_ticks); }
 void launch_raycast(const DV& d, const sgp_ray* rays, uint32_t n, sgp_hit* hits, hipStream_t s) { if (n) hipLaunchKernelGGL(k_raycast, dim3((n + 63) / 64), dim3(64), 0, s, d, rays, n, hits); }
 void launch_collide_capsules(const DV& d, const sgp_capsule_query* q, uint32_t n, sgp_query_contact* out, uint32_t cap, uint32_t* count, hipStream_t s) { if (n) hipLaunchKernelGGL(k_collide_capsules, dim3(n), dim3(64), 0, s, d, q, n, out, cap, count); }      // a wave per query
 void launch_spherecast(const DV& d, const sgp_ray* rays, const float* radii, uint32_t n, sgp_hit* hits, hipStream_t s) { if (n) hipLaunchKernelGGL(k_spherecast, dim3((n + 63) / 64), dim3(64), 0, s, d, rays, radii, n, hits); }

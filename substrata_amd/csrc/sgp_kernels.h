@@ -390,6 +390,20 @@ void launch_dump_constraints(const DV& d, uint32_t which, uint32_t n_con, void* 
 void launch_vehicle_pre(const DV& d, hipStream_t s);
 void launch_vehicle_solve(const DV& d, int mode, hipStream_t s);
 void launch_solve_colour_veh(const DV& d, int colour, uint32_t est, int mode, hipStream_t s, int compact_rows);      // a contact colour whose first workgroups solve the vehicles' rows (mode 1, 2)      // mode as launch_solve_colour
+// Single-query mailbox (round 5): PhysicsWorld::traceRay is called one ray at a time by unchanged callers (ParticleManager.cpp:164: up to 2048 per frame;
+// HoverCarPhysics.cpp:348), and a launch + a host sync per ray is ~23 us.  While such a caller is at it, ONE resident wave (k_ray_server) answers rays
+// handed over through this block of host-mapped, coherent memory: the host writes the ray and bumps `req_seq`, the wave (polling with system-scope
+// loads) traces it with the very function k_raycast runs per thread and publishes the hit + `done_seq`.  The wave leaves when told to (`stop`, set by
+// whatever next touches the world's stream) or after `idle_ticks` without a request, so nothing ever waits for it longer than that.
+struct RayMailbox {
+	// line 0 (64 B), host -> device: the wave reads it with ONE 64-byte load (lane l < 16 takes word l), so a new `req_seq` comes with its ray (the host
+	// writes the ray first; a cache line is read as a whole)
+	uint32_t req_seq, stop; sgp_ray ray; uint32_t pad0[16 - 2 - sizeof(sgp_ray) / 4];
+	// line 1 (64 B), device -> host: written with ONE 64-byte store, the sequence number at both ends (the host takes the hit when both match)
+	uint32_t done_seq, alive; sgp_hit hit; uint32_t pad1[16 - 2 - sizeof(sgp_hit) / 4 - 1]; uint32_t done_seq2;
+};
+static_assert(sizeof(RayMailbox) == 128 && sizeof(sgp_ray) == 36 && sizeof(sgp_hit) == 48, "RayMailbox: two 64-byte lines");
+void launch_ray_server(const DV& d, RayMailbox* mb, uint32_t first_seq, uint64_t idle_ticks, uint64_t max_ticks, hipStream_t s);
 void launch_raycast(const DV& d, const sgp_ray* rays, uint32_t n, sgp_hit* hits, hipStream_t s);
 void launch_collide_capsules(const DV& d, const sgp_capsule_query* q, uint32_t n, sgp_query_contact* out, uint32_t cap, uint32_t* count, hipStream_t s);
 void launch_spherecast(const DV& d, const sgp_ray* rays, const float* radii, uint32_t n, sgp_hit* hits, hipStream_t s);

@@ -217,6 +217,7 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	{ StepParams init = *w->h_sp; init.parity = w->h_sp->parity ^ 1u; HIP_TRY(hipMemcpyAsync(w->d_sp, &init, sizeof(init), hipMemcpyHostToDevice, w->stream)); HIP_TRY(hipStreamSynchronize(w->stream)); }
 	{ const char* e = getenv("SGP_NO_GRAPH"); if (e && e[0] == '1') w->use_graphs = false; }
 	{ const char* e = getenv("SGP_NO_SMALL_WORLD"); if (e && e[0] == '1') w->use_small_world = false; }
+	{ const char* e = getenv("SGP_NO_RAY_SERVER"); if (e && e[0] == '1') w->ray_server_enabled = false; }      // (single rays then cost a launch + a sync each)
 	{ const char* e = getenv("SGP_NO_WAKE_ROUND"); if (e && e[0] == '1') w->use_wake_round = false; }      // (measurements only: the CPU statement has its own switch)
 	{ const char* e = getenv("SGP_DEBUG_FLAGS"); w->dv.dbg_flags = e ? (uint32_t)atoi(e) : 0u; }
 #ifdef SGP_EXPERIMENTS
@@ -241,7 +242,9 @@ SGP_API int sgp_world_destroy(sgp_world* w)
 {
 	if (!w) return fail(SGP_ERR_INVALID, "sgp_world_destroy: NULL");
 	hipSetDevice(w->device);
+	ray_server_stop(w);
 	if (w->stream) hipStreamSynchronize(w->stream);
+	if (w->ray_mb) hipHostFree(w->ray_mb);
 	for (void* p : w->allocs) hipFree(p);
 	if (w->stage_dev) hipFree(w->stage_dev);
 	if (w->d_meshes) hipFree(w->d_meshes);
@@ -395,8 +398,16 @@ static int rebuild_large_grid(sgp_world* w)
 	return upload_sp(w);
 }
 
+void ray_server_stop(sgp_world* w)
+{
+	if (!w->ray_server_on) return;
+	__atomic_store_n(&w->ray_mb->stop, 1u, __ATOMIC_RELEASE);
+	w->ray_server_on = false;
+}
+
 int flush_cmds(sgp_world* w)
 {
+	ray_server_stop(w);      // (every entry point that launches on the world's stream comes through here first)
 	hipSetDevice(w->device);
 	DV& d = w->dv;
 	{ int r = upload_sp(w); if (r != SGP_OK) return r; }

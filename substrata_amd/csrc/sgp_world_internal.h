@@ -121,6 +121,9 @@ struct sgp_world {
 	bool bp_dense_last = false;     // the previous step's broad phase met a halo too large for the small instance of k_bp_pairs
 	bool plan_seen = false;         // a step has run: plan_colour_count etc. describe the previous step
 	uint32_t graph_launches = 0, eager_steps = 0, idle_steps = 0;
+	// single-query mailbox (sgp_raycast with n = 1): host-mapped block + whether a server wave is (believed to be) resident on the stream
+	RayMailbox* ray_mb = nullptr; bool ray_server_on = false; bool ray_server_enabled = true; uint32_t ray_seq = 0;
+	uint32_t ray_server_launches = 0, ray_server_rays = 0;
 	bool last_step_idle = false;       // the last step was skipped (every body asleep, nothing edited): no vehicle took part in it, whatever its record says
 	bool grid_valid = false;                                   // the broad-phase grid matches the current poses (ray queries reuse it)
 	// static triangle meshes: host-side headers + pools mirrored on the device (grown on demand)
@@ -211,6 +214,7 @@ static inline uint32_t compound_id_of(const sgp_world* w, uint32_t id, uint32_t*
 }
 
 // defined in sgp_world.hip
+void ray_server_stop(sgp_world* w);      // tells a resident ray server to leave (no wait: what is launched next runs after it); called by flush_cmds
 void invalidate_graphs(sgp_world* w);
 int flush_cmds(sgp_world* w);
 int collect_events(sgp_world* w, bool counters_fresh = false);

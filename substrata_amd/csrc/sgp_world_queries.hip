@@ -4,10 +4,65 @@
 // ---------------------------------------------------------------------------------------------------------------
 // ray queries, PhysicsWorld.cpp:1668-1725
 
+static void finish_hit(sgp_world* w, sgp_hit* h)
+{
+	h->userdata = h->id != SGP_INVALID_ID ? w->hb[h->id].userdata : 0;
+	h->sub_shape = 0;
+	if (h->id != SGP_INVALID_ID) h->id = compound_id_of(w, h->id, &h->sub_shape);
+}
+
+// One ray through the resident server (RayMailbox, sgp_kernels.h).  Returns 1 when the ray was answered, 0 when the caller should take the launch path
+// (server disabled or it could not be reached), < 0 on error.
+#define SGP_RAY_SERVER_IDLE_TICKS 30000ull          // 300 us at the 100 MHz wall clock: a caller tracing rays one after the other never lets it idle that long
+#define SGP_RAY_SERVER_MAX_TICKS 20000000ull        // 200 ms: a server older than that leaves and is started again (nothing lives on the stream for ever)
+static int ray_through_server(sgp_world* w, const sgp_ray* ray, sgp_hit* hit)
+{
+	if (!w->ray_server_enabled) return 0;
+	if (!w->ray_mb) {
+		if (hipHostMalloc((void**)&w->ray_mb, sizeof(RayMailbox), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { w->ray_server_enabled = false; (void)hipGetLastError(); return 0; }
+		memset(w->ray_mb, 0, sizeof(RayMailbox));
+	}
+	RayMailbox* mb = w->ray_mb;
+	for (int attempt = 0; attempt < 3; ++attempt) {
+		if (!w->ray_server_on) {
+			// (the previous server, if any, was told to stop or left on its own; the new one queues behind it on the stream)
+			__atomic_store_n(&mb->stop, 0u, __ATOMIC_RELAXED);
+			__atomic_store_n(&mb->alive, 2u, __ATOMIC_RELEASE);      // 2 = launched, not yet running (the wave writes 1, then 0 when it leaves)
+			RayMailbox* dmb = nullptr;
+			if (hipHostGetDevicePointer((void**)&dmb, mb, 0) != hipSuccess) { w->ray_server_enabled = false; (void)hipGetLastError(); return 0; }
+			launch_ray_server(w->dv, dmb, w->ray_seq, SGP_RAY_SERVER_IDLE_TICKS, SGP_RAY_SERVER_MAX_TICKS, w->stream);
+			w->ray_server_on = true; w->ray_server_launches++;
+		}
+		mb->ray = *ray;
+		const uint32_t seq = ++w->ray_seq;
+		__atomic_store_n(&mb->req_seq, seq, __ATOMIC_RELEASE);
+		const auto t0 = std::chrono::steady_clock::now();
+		for (uint32_t spin = 0;; ++spin) {
+			if (__atomic_load_n(&mb->done_seq, __ATOMIC_ACQUIRE) == seq && __atomic_load_n(&mb->done_seq2, __ATOMIC_ACQUIRE) == seq) { *hit = mb->hit; w->ray_server_rays++; return 1; }
+			if ((spin & 1023u) == 1023u) {
+				if (__atomic_load_n(&mb->alive, __ATOMIC_ACQUIRE) == 0u) break;      // it left (idle / age) before it saw this request: start another
+				if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) {      // (never observed: the launch path still answers)
+					ray_server_stop(w); HIP_TRY(hipStreamSynchronize(w->stream)); w->ray_server_enabled = false; return 0;
+				}
+			}
+		}
+		// the wave is gone; it may still have answered just before leaving
+		if (__atomic_load_n(&mb->done_seq, __ATOMIC_ACQUIRE) == seq && __atomic_load_n(&mb->done_seq2, __ATOMIC_ACQUIRE) == seq) { *hit = mb->hit; w->ray_server_on = false; w->ray_server_rays++; return 1; }
+		w->ray_server_on = false;
+	}
+	return 0;
+}
+
 SGP_API int sgp_raycast(sgp_world* w, const sgp_ray* rays, uint32_t n, sgp_hit* hits)
 {
 	if (!w || (!rays && n) || (!hits && n)) return fail(SGP_ERR_INVALID, "sgp_raycast: NULL");
 	hipSetDevice(w->device);
+	if (n == 1 && w->ray_server_on && w->cmds.empty() && w->ghost_refresh.empty() && !w->large_dirty && !w->large_list_dirty && w->grid_valid) {
+		// the caller is tracing rays one by one (PhysicsWorld::traceRay in a loop) and nothing touched the world since the last one: hand it to the resident wave
+		const int r = ray_through_server(w, rays, hits);
+		if (r < 0) return r;
+		if (r == 1) { finish_hit(w, hits); return SGP_OK; }
+	}
 	{ int r = flush_cmds(w); if (r != SGP_OK) return r; }
 	if (!n) return SGP_OK;
 	if (!w->grid_valid && w->high) {
@@ -16,6 +71,12 @@ SGP_API int sgp_raycast(sgp_world* w, const sgp_ray* rays, uint32_t n, sgp_hit* 
 		launch_step_begin(d, *w->h_sp, nb, false, s); w->sp_uploaded = *w->h_sp; w->sp_uploaded_valid = true;
 		launch_bp_bounds(d, nb, s); launch_bp_cell(d, nb, s); launch_bp_scan(d, s); launch_bp_scatter(d, nb, s);
 		w->grid_valid = true;
+	}
+	if (n == 1 && w->high) {
+		// a single ray: start (or reach) the resident server behind the grid kernels just queued; the next single rays find it running
+		const int r = ray_through_server(w, rays, hits);
+		if (r < 0) return r;
+		if (r == 1) { finish_hit(w, hits); return SGP_OK; }
 	}
 	const size_t rb = (sizeof(sgp_ray) * n + 15) & ~size_t(15);
 	{ int r = ensure_stage(w, rb + sizeof(sgp_hit) * n); if (r != SGP_OK) return r; }
@@ -33,11 +94,7 @@ SGP_API int sgp_raycast(sgp_world* w, const sgp_ray* rays, uint32_t n, sgp_hit* 
 		HIP_TRY(hipStreamSynchronize(w->stream));
 	}
 	memcpy(hits, (char*)w->stage_host + rb, sizeof(sgp_hit) * n);
-	for (uint32_t k = 0; k < n; ++k) {
-		hits[k].userdata = hits[k].id != SGP_INVALID_ID ? w->hb[hits[k].id].userdata : 0;
-		hits[k].sub_shape = 0;
-		if (hits[k].id != SGP_INVALID_ID) hits[k].id = compound_id_of(w, hits[k].id, &hits[k].sub_shape);
-	}
+	for (uint32_t k = 0; k < n; ++k) finish_hit(w, &hits[k]);
 	return SGP_OK;
 }
 

@@ -100,3 +100,54 @@ def test_capsule_queries_on_a_mesh_with_active_edges_match_oracle(oracle):
     before = np.einsum("ij,ij->i", pg["normal"][leaning][:, :2], -nxy[:, :2])
     assert (before < -0.1).all()
     tw.close()
+
+
+def test_single_rays_through_the_resident_server_equal_the_batched_answers():
+    """PhysicsWorld::traceRay is called one ray at a time by unchanged callers (ParticleManager.cpp:164, HoverCarPhysics.cpp:348): such rays go to a
+    resident wave through a host-mapped mailbox (round 5) that traces each with all 64 lanes.  The answers must be those of the batched kernel, bit for
+    bit, on a pile with hulls over a terrain mesh -- also when the world is edited or stepped between two rays (the server is told to leave, the next
+    ray starts another)."""
+    from substrata_amd.lib import World
+    rng = np.random.default_rng(21)
+    w = World(max_bodies=2048)
+    descs = scenes.small_mixed(8, 3, seed=5)
+    w.add_batch(descs)
+    # a bumpy terrain under and around the pile (rays that miss the bodies hit its triangles: triangle index, material, barycentrics travel too)
+    gx = np.linspace(-12, 12, 25); gy = np.linspace(-12, 12, 25)
+    vx, vy = np.meshgrid(gx, gy, indexing="ij")
+    verts = np.stack([vx.ravel(), vy.ravel(), 0.25 + 0.15 * np.sin(vx.ravel()) * np.cos(0.7 * vy.ravel())], axis=1).astype(np.float32)
+    tris = []
+    for i in range(24):
+        for j in range(24):
+            a = i * 25 + j; tris += [(a, a + 25, a + 1), (a + 1, a + 25, a + 26)]
+    mi = w.mesh_create(verts, np.array(tris, np.uint32), materials=np.arange(len(tris)) % 7)
+    md = scenes.dynamic_bodies(1); md["motion_type"] = abi.MOTION_STATIC; md["layer"] = abi.LAYER_NON_MOVING
+    md["shape_type"] = abi.SHAPE_MESH; md["shape"][0] = (float(mi.mesh_id), 0, 0, 0); md["pos"][0] = (0, 0, 0)
+    w.add_batch(md)
+    hi = w.hull_create(rng.normal(size=(16, 3)) * 0.5)
+    hd = scenes.dynamic_bodies(24)
+    hd["shape_type"] = abi.SHAPE_HULL; hd["shape"][:, 0] = float(hi.hull_id); hd["shape"][:, 1:] = 0
+    hd["pos"] = rng.uniform([-4, -4, 1], [4, 4, 5], size=(24, 3))
+    w.add_batch(hd)
+    for _ in range(120):
+        w.step(DT)
+    n = 600
+    rays = np.zeros(n, dtype=abi.ray_dtype)
+    rays["origin"] = rng.uniform([-6, -6, 0.2], [6, 6, 6.0], size=(n, 3))
+    d = rng.normal(size=(n, 3)) + (0, 0, -0.8); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays["dir"] = d; rays["max_t"] = rng.uniform(0.05, 9.0, size=n); rays["ignore_id"] = abi.INVALID_ID; rays["ignore_id"][::9] = 7
+    rays["collidable_only"] = rng.integers(0, 2, size=n)
+    batched = w.raycast(rays)
+    assert (batched["id"] != abi.INVALID_ID).sum() > 200 and (batched["triangle"] != abi.INVALID_ID).sum() > 20
+    single = np.concatenate([w.raycast(rays[k:k + 1]) for k in range(n)])
+    assert single.tobytes() == batched.tobytes()
+    # edits and a step between single rays: each answer equals the batched answer in the state it was asked in
+    for k in range(0, 120, 3):
+        if k % 2 == 0:
+            w.set_pos(1 + (k % 40), (float(rng.uniform(-3, 3)), float(rng.uniform(-3, 3)), 2.5))
+        else:
+            w.step(DT)
+        one = w.raycast(rays[k:k + 1]); two = w.raycast(rays[k + 1:k + 2])
+        ref = w.raycast(rays[k:k + 2])
+        assert one.tobytes() == ref[:1].tobytes() and two.tobytes() == ref[1:].tobytes(), k
+    w.close()
