@@ -107,6 +107,7 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	if (g_device_count < 0) sgp_init();
 	if (g_device_count <= 0) return fail(SGP_ERR_NO_DEVICE, "sgp_world_create: no HIP device available (there is no CPU fallback)");
 	if (desc->device < 0 || desc->device >= g_device_count) return fail(SGP_ERR_INVALID, "sgp_world_create: bad device ordinal");
+	if (desc->max_bodies >= (1u << 25)) return fail(SGP_ERR_CAPACITY, "sgp_world_create: max_bodies must be below 2^25 (the cell arrays hold 64 cells per body slot in 32-bit indices)");      // (64 N and its power of two overflowed silently)
 	sgp_world* w = new sgp_world();
 	w->desc = *desc;
 	w->device = desc->device;
