@@ -201,88 +201,6 @@ template <int VS> SGP_DEV void half_solve(ConHalf& h, int side, float4* vel, uin
 	if (half_solve_core(h, side, v4, w4, dbg)) { vel[VS * (size_t)h.body] = v4; vel[VS * (size_t)h.body + 1] = w4; }
 }
 
-// A constraint half WITHOUT the inverse-inertia images of its rows (round 5): 36 registers fewer per lane, so that 1024 threads -- 512 lane pairs, four
-// waves per SIMD at 128 registers -- can keep a small world of 385 .. 512 constraints in registers (k_solve_small_t<1024, true>).  I (r x axis) is
-// rebuilt where a row is applied, from the body's world inverse inertia: the expression k_setup evaluated for the stored rows on the same operands
-// (sym33_mul(I, r x axis) with I = world_inv_inertia of the same pose and property records), hence the same bits.
-struct ConHalfL {
-	uint32_t body;
-	float4 nf; int np_col;
-	v3     c[4][3];
-	float  eff[4][3];
-	float  bias[4];
-	v3     lam[4];
-	sym33  I;               // world inverse inertia of this lane's body
-};
-SGP_DEV void half_load_lite(const DV& d, uint32_t slot, int side, ConHalfL& h)
-{
-	const uint2 ab = CUR(d).ab[slot];
-	h.body = side ? ab.y : ab.x;
-	h.nf = CUR(d).n_fric[slot];
-	h.np_col = CUR(d).np_col[slot];
-	h.I = body_world_inv_inertia(d, h.body);
-	const int np = h.np_col & 0xFF;
-	const size_t st = d.cap_manifolds;
-#pragma unroll
-	for (int i = 0; i < 4; ++i) {
-		if (i == 0 || i < np) {
-#pragma unroll
-			for (int a = 0; a < 3; ++a) {
-				const float4 c4 = axis_rows(d, slot, i, a)[(size_t)side * st];      // lane 0: r1 x axis (w: bias of the normal row); lane 1: r2 x axis (w: effective mass)
-				h.c[i][a] = V3(c4);
-				const float ow = lane_swap1(c4.w);
-				h.eff[i][a] = side ? c4.w : ow;
-				if (a == 0) h.bias[i] = side ? ow : c4.w;
-			}
-			h.lam[i] = V3(CUR(d).lam[i][slot]);
-		}
-	}
-}
-SGP_DEV void half_store_lite(const DV& d, uint32_t slot, int side, const ConHalfL& h)
-{
-	if (side) return;
-	const int np = h.np_col & 0xFF;
-#pragma unroll
-	for (int i = 0; i < 4; ++i) { if (i < np) CUR(d).lam[i][slot] = F4(h.lam[i], 0.0f); }
-}
-// half_solve_core on a ConHalfL: the same rows in the same order, I (r x axis) computed at the point of use
-template <int VS> SGP_DEV void half_solve_lite(ConHalfL& h, int side, float4* vel)
-{
-	const int np = h.np_col & 0xFF;
-	if (np == 0) return;
-	float4 v4 = vel[VS * (size_t)h.body], w4 = vel[VS * (size_t)h.body + 1];
-	const float im = v4.w, friction = h.nf.w;
-	v3 lv = V3(v4), av = V3(w4);
-	const v3 n = V3(h.nf);
-	const v3 t1 = v3_normalized_perpendicular(n);          // (what k_setup stores next to the rows: same function, same input)
-	const v3 t2 = v3_cross(n, t1);
-	if (friction > 0.0f) {
-#pragma unroll
-		for (int i = 0; i < 4; ++i) {
-			if (i < np && !(h.eff[i][1] <= 0.0f && h.eff[i][2] <= 0.0f)) {
-				float l1 = h.lam[i].y + h.eff[i][1] * half_jv(lv, av, t1, h.c[i][1], side);
-				float l2 = h.lam[i].z + h.eff[i][2] * half_jv(lv, av, t2, h.c[i][2], side);
-				const float max_f = friction * h.lam[i].x;
-				const float tot_sq = l1 * l1 + l2 * l2;
-				if (tot_sq > max_f * max_f) { const float sc = max_f / sqrtf(tot_sq); l1 = l1 * sc; l2 = l2 * sc; }
-				half_apply(lv, av, im, t1, sym33_mul(h.I, h.c[i][1]), l1 - h.lam[i].y, side); h.lam[i].y = l1;
-				half_apply(lv, av, im, t2, sym33_mul(h.I, h.c[i][2]), l2 - h.lam[i].z, side); h.lam[i].z = l2;
-			}
-		}
-	}
-#pragma unroll
-	for (int i = 0; i < 4; ++i) {
-		if (i < np && h.eff[i][0] > 0.0f) {
-			const float jv = half_jv(lv, av, n, h.c[i][0], side);
-			const float lambda = h.eff[i][0] * (jv - h.bias[i]);
-			const float nl = max0f(h.lam[i].x + lambda);
-			half_apply(lv, av, im, n, sym33_mul(h.I, h.c[i][0]), nl - h.lam[i].x, side);
-			h.lam[i].x = nl;
-		}
-	}
-	if (im > 0.0f) { vel[VS * (size_t)h.body] = F4(lv, im); vel[VS * (size_t)h.body + 1] = F4(av, 0.0f); }
-}
-
 // load + one iteration + store: what a colour launch does per constraint (lanes 2k and 2k + 1 of a wave call it with the same slot)
 template <int VS, int ROWS = -1> SGP_DEV void solve_velocity_pair_t(const DV& d, uint32_t slot, int side, float4* vel)
 {

@@ -1,7 +1,6 @@
 // sgp_k_solve.hip -- K7 -- warm start, velocity and position iterations: a launch per colour, the high colours by connected component, the tail, small worlds.
 // One of the stage files of the step kernels (stage map: sgp_kernels.h).  Kernels first, their launch wrappers at the end.
 #include "sgp_dev_all.h"
-#include <type_traits>
 
 // ---------------------------------------------------------------------------------------------------------------
 // K7: sequential impulses.  One launch per colour: constraints of a colour share no movable body.
@@ -567,19 +566,18 @@ template <int MODE, int ROWS = -1> __global__ void __launch_bounds__(HC_TPB) k_s
 // colour serially by priority), so the result is bit-identical.
 #define SMALL_LDS_BODIES 2048
 #define SMALL_TPB 768       // velocity iterations take two lanes per constraint: 384 constraints per phase (12 waves: 3 per SIMD leaves a constraint half its ~150 registers)
-// (TPB_ = 768, LITE = false: <= 384 constraints in registers; TPB_ = 1024, LITE = true: <= 512, on constraint halves that rebuild I (r x axis), ConHalfL)
-template <int TPB_, bool LITE> __global__ void __launch_bounds__(TPB_) k_solve_small_t(DV d, int warm_start, int iterations)
+__global__ void __launch_bounds__(SMALL_TPB) k_solve_small(DV d, int warm_start, int iterations)
 {
 	__shared__ float4 sv[2 * SMALL_LDS_BODIES];        // 64 KB: [lin vel, effective inverse mass][ang vel, -] per body slot
 	__shared__ uint32_t cs[SGP_MAX_COLOURS + 1];
 	const uint32_t n = min(d.sp->n_slots, (uint32_t)SMALL_LDS_BODIES);
 	if (threadIdx.x <= SGP_MAX_COLOURS) cs[threadIdx.x] = d.cstarts[threadIdx.x];
-	for (uint32_t i = threadIdx.x; i < 2 * n; i += TPB_) sv[i] = d.vel[i];
+	for (uint32_t i = threadIdx.x; i < 2 * n; i += SMALL_TPB) sv[i] = d.vel[i];
 	__syncthreads();
 	const int side = (int)(threadIdx.x & 1u);
 	const uint32_t pair = threadIdx.x >> 1;
 	const uint32_t all_n = cs[SGP_OVERFLOW_COLOUR];
-	if (all_n != 0 && all_n <= TPB_ / 2 && cs[SGP_OVERFLOW_COLOUR] == cs[SGP_MAX_COLOURS]) {
+	if (all_n != 0 && all_n <= SMALL_TPB / 2 && cs[SGP_OVERFLOW_COLOUR] == cs[SGP_MAX_COLOURS]) {
 		// at most one constraint per lane pair and no overflow colour: the constraint lives in registers for the whole solve (read once,
 		// lambdas written once), the velocities in LDS; a phase is an LDS gather, the arithmetic and an LDS scatter.  Same phases in
 		// the same order as the general path below.
@@ -593,24 +591,24 @@ template <int TPB_, bool LITE> __global__ void __launch_bounds__(TPB_) k_solve_s
 				__syncthreads();
 			}
 		}
-		typename std::conditional<LITE, ConHalfL, ConHalf>::type h; int my_col = -1;
-		if (mine) { if constexpr (LITE) half_load_lite(d, slot, side, h); else half_load<0>(d, slot, side, h); my_col = (h.np_col >> 8) & 0xFF; }
+		ConHalf h; int my_col = -1;
+		if (mine) { half_load<0>(d, slot, side, h); my_col = (h.np_col >> 8) & 0xFF; }
 		for (int pass = 0; pass < iterations; ++pass) {
 			for (int c = 0; c < SGP_OVERFLOW_COLOUR; ++c) {
 				if (cs[c] == cs[c + 1]) continue;
-				if (my_col == c) { if constexpr (LITE) half_solve_lite<2>(h, side, sv); else half_solve<2>(h, side, sv, d.dbg_flags); }
+				if (my_col == c) half_solve<2>(h, side, sv, d.dbg_flags);
 				__syncthreads();
 			}
 		}
-		if (mine) { if constexpr (LITE) half_store_lite(d, slot, side, h); else half_store(d, slot, side, h); }
+		if (mine) half_store(d, slot, side, h);
 	} else
 	if (cs[0] != cs[SGP_MAX_COLOURS]) {
 		for (int pass = warm_start ? -1 : 0; pass < iterations; ++pass) {
 			for (int c = 0; c < SGP_OVERFLOW_COLOUR; ++c) {
 				const uint32_t b = cs[c], e = cs[c + 1];
 				if (b == e) continue;
-				if (pass < 0) { for (uint32_t k = b + threadIdx.x; k < e; k += TPB_) warm_start_one_t<2>(d, k, sv); }
-				else { for (uint32_t k = b + pair; k < e; k += TPB_ / 2) { if constexpr (LITE) { ConHalfL hl; half_load_lite(d, k, side, hl); half_solve_lite<2>(hl, side, sv); half_store_lite(d, k, side, hl); } else solve_velocity_pair_t<2, 0>(d, k, side, sv); } }
+				if (pass < 0) { for (uint32_t k = b + threadIdx.x; k < e; k += SMALL_TPB) warm_start_one_t<2>(d, k, sv); }
+				else { for (uint32_t k = b + pair; k < e; k += SMALL_TPB / 2) solve_velocity_pair_t<2, 0>(d, k, side, sv); }
 				__syncthreads();
 			}
 			const uint32_t first = cs[SGP_OVERFLOW_COLOUR], count = cs[SGP_OVERFLOW_COLOUR + 1] - first;
@@ -619,14 +617,14 @@ template <int TPB_, bool LITE> __global__ void __launch_bounds__(TPB_) k_solve_s
 					uint64_t last = 0; bool have_last = false;
 					for (uint32_t it = 0; it < count; ++it) {
 						const uint32_t bslot = overflow_next(d, first, count, last, have_last);
-						if (pass < 0) { if (side == 0) warm_start_one_t<2>(d, bslot, sv); } else if constexpr (LITE) { ConHalfL hl; half_load_lite(d, bslot, side, hl); half_solve_lite<2>(hl, side, sv); half_store_lite(d, bslot, side, hl); } else solve_velocity_pair_t<2, 0>(d, bslot, side, sv);
+						if (pass < 0) { if (side == 0) warm_start_one_t<2>(d, bslot, sv); } else solve_velocity_pair_t<2, 0>(d, bslot, side, sv);
 					}
 				}
 				__syncthreads();
 			}
 		}
 	}
-	for (uint32_t i = threadIdx.x; i < 2 * n; i += TPB_) d.vel[i] = sv[i];
+	for (uint32_t i = threadIdx.x; i < 2 * n; i += SMALL_TPB) d.vel[i] = sv[i];
 }
 
 // The small-world solve with ONE THREAD PER CONSTRAINT (512 threads, the constraint's ~240 registers in one lane): for worlds of 385..512
@@ -836,7 +834,6 @@ void launch_solve_hc(const DV& d, int first_colour, uint32_t est, int mode, hipS
 }
 void launch_solve_small(const DV& d, int warm_start, int iterations, int lane_pairs, hipStream_t s)
 {
-	if (lane_pairs == 1) hipLaunchKernelGGL((k_solve_small_t<SMALL_TPB, false>), dim3(1), dim3(SMALL_TPB), 0, s, d, warm_start, iterations);
-	else if (lane_pairs == 2) hipLaunchKernelGGL((k_solve_small_t<1024, true>), dim3(1), dim3(1024), 0, s, d, warm_start, iterations);      // 385 .. 512 constraints: 512 lane pairs
+	if (lane_pairs) hipLaunchKernelGGL(k_solve_small, dim3(1), dim3(SMALL_TPB), 0, s, d, warm_start, iterations);
 	else hipLaunchKernelGGL(k_solve_small_single, dim3(1), dim3(512), 0, s, d, warm_start, iterations);
 }

@@ -218,7 +218,6 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	{ StepParams init = *w->h_sp; init.parity = w->h_sp->parity ^ 1u; HIP_TRY(hipMemcpyAsync(w->d_sp, &init, sizeof(init), hipMemcpyHostToDevice, w->stream)); HIP_TRY(hipStreamSynchronize(w->stream)); }
 	{ const char* e = getenv("SGP_NO_GRAPH"); if (e && e[0] == '1') w->use_graphs = false; }
 	{ const char* e = getenv("SGP_NO_SMALL_WORLD"); if (e && e[0] == '1') w->use_small_world = false; }
-	{ const char* e = getenv("SGP_SMALL_WIDE"); if (e && e[0] == '0') w->small_wide = false; }
 	{ const char* e = getenv("SGP_NO_RAY_SERVER"); if (e && e[0] == '1') w->ray_server_enabled = false; }      // (single rays then cost a launch + a sync each)
 	{ const char* e = getenv("SGP_NO_WAKE_ROUND"); if (e && e[0] == '1') w->use_wake_round = false; }      // (measurements only: the CPU statement has its own switch)
 	{ const char* e = getenv("SGP_DEBUG_FLAGS"); w->dv.dbg_flags = e ? (uint32_t)atoi(e) : 0u; }
@@ -601,7 +600,7 @@ static void make_plan(const sgp_world* w, StepPlan& p)
 	p.wake_round = w->use_wake_round ? 1 : 0;
 	p.small_colouring = (w->last_manifolds <= SGP_SMALL_COLOURING_MANIFOLDS && w->high <= SGP_SMALL_WORLD_BODIES) ? 1 : 0;
 	p.small_world = (tf == 0 && w->high <= SGP_SMALL_WORLD_BODIES && w->n_vehicles == 0 && w->use_small_world) ? 1 : 0;
-	p.small_pairs = (w->n_con <= 384u || w->n_con > 512u) ? 1 : (w->small_wide ? 2 : 0);      // 1: 384 lane pairs; 2: 512 lane pairs on lighter constraint halves (385 .. 512 constraints); 0: a thread per constraint (SGP_SMALL_WIDE=0)
+	p.small_pairs = (w->n_con <= 384u || w->n_con > 512u) ? 1 : 0;
 	p.bp_small = w->bp_dense_last ? 0 : 1;
 	p.hc_first = -1;
 	if (!p.small_world && w->use_components && w->n_con != 0) {      // (no histogram yet: the tail kernel takes whatever the first step brings)

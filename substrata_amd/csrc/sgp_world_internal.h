@@ -124,7 +124,6 @@ struct sgp_world {
 	// single-query mailbox (sgp_raycast with n = 1): host-mapped block + whether a server wave is (believed to be) resident on the stream
 	RayMailbox* ray_mb = nullptr; bool ray_server_on = false; bool ray_server_enabled = true; uint32_t ray_seq = 0;
 	uint32_t ray_server_launches = 0, ray_server_rays = 0;
-	bool small_wide = true;            // small worlds of 385 .. 512 constraints: 512 lane pairs (k_solve_small_t<1024, true>) instead of a thread per constraint
 	bool last_step_idle = false;       // the last step was skipped (every body asleep, nothing edited): no vehicle took part in it, whatever its record says
 	bool grid_valid = false;                                   // the broad-phase grid matches the current poses (ray queries reuse it)
 	// static triangle meshes: host-side headers + pools mirrored on the device (grown on demand)
