@@ -8,6 +8,13 @@ SGP_DEV sym33 body_world_inv_inertia(const DV& d, uint32_t body)
 {
 	return world_inv_inertia(quat_to_m33(Q4(d.pose[2 * (size_t)body + 1])), V3(d.prop[2 * (size_t)body]));
 }
+// the same matrix from the record k_pre_solve wrote for this step (compact rows only; bodies that cannot move have none and need none: their rows are never applied)
+SGP_DEV sym33 body_world_inv_inertia_rec(const DV& d, uint32_t body)
+{
+	const float4 a = d.iw[2 * (size_t)body], b = d.iw[2 * (size_t)body + 1];
+	sym33 s; s.xx = a.x; s.xy = a.y; s.xz = a.z; s.yy = a.w; s.yz = b.x; s.zz = b.y;
+	return s;
+}
 
 // One contact manifold, one velocity iteration (ContactConstraintManager::SolveVelocityConstraints): friction rows of
 // every point first (they use the normal impulse of the previous iteration), then the non-penetration rows.
@@ -51,7 +58,7 @@ template <int ROWS = -1> SGP_DEV void half_load_rows(const DV& d, uint32_t slot,
 		// no rows at all: the lever arm of this lane's body (r1 | bias, r2 | effective mass of the normal row: what the warm start reads anyway) and the
 		// friction rows' effective masses; r x axis and I (r x axis) are rebuilt here -- the expressions k_setup evaluates for the full rows on the
 		// same operands, hence the same bits.  40 bytes per point and lane where the full rows are 112: for worlds whose passes stream from HBM.
-		const sym33 I = body_world_inv_inertia(d, h.body);
+		const sym33 I = body_world_inv_inertia_rec(d, h.body);
 		const v3 n = V3(h.nf);
 		h.t1 = v3_normalized_perpendicular(n);
 		const v3 t2 = v3_cross(n, h.t1);
@@ -75,7 +82,7 @@ template <int ROWS = -1> SGP_DEV void half_load_rows(const DV& d, uint32_t slot,
 	if (ROWS < 0 ? d.sp->compact_rows != 0u : ROWS != 0) {
 		// compact rows: r x axis only; this lane rebuilds I (r x axis) from its body's pose and inertia records -- the same function of the same
 		// operands k_setup evaluates for the full rows, hence the same bits
-		const sym33 I = body_world_inv_inertia(d, h.body);
+		const sym33 I = body_world_inv_inertia_rec(d, h.body);
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
 			if (i == 0 || i < np) {

@@ -59,6 +59,13 @@ __global__ void __launch_bounds__(TPB) k_pre_solve(DV d)
 		}
 		d.vel[2 * (size_t)i] = F4(lv, im);
 		d.vel[2 * (size_t)i + 1] = F4(av, 0.0f);
+		if (im > 0.0f && d.sp->compact_rows != 0u) {
+			// compact rows: the lanes of the velocity iterations rebuild I (r x axis) -- from this record (the expression k_setup evaluates on the same
+			// pose and property records, hence the same bits), one 32-byte gather instead of 48 bytes and a rotation matrix per lane and launch
+			const sym33 I = world_inv_inertia(quat_to_m33(Q4(d.pose[2 * (size_t)i + 1])), V3(d.prop[2 * (size_t)i]));
+			d.iw[2 * (size_t)i] = make_float4(I.xx, I.xy, I.xz, I.yy);
+			d.iw[2 * (size_t)i + 1] = make_float4(I.yz, I.zz, 0.0f, 0.0f);
+		}
 	}
 	d.hc_root[i] = i; d.hc_count[i] = 0u;      // every body a component of its own (k_hc_hook joins them along the high-colour constraints)
 	// remember whether the body was movable when the previous step coloured its constraints (colour inheritance)

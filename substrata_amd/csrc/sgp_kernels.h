@@ -297,6 +297,8 @@ struct DV {
 	// constraints
 	uint32_t dbg_flags;        // SGP_DEBUG_FLAGS (developer switches): bit 0 = tail kernel without its register-resident path
 	float4* rows;              // velocity-iteration rows, [point 0..3][axis n,t1,t2][4][cap_manifolds] (k_setup): r1 x axis (w: bias for n),
+	float4* iw;                // world inverse inertia of every body that can move this step, [2 i] = (xx, xy, xz, yy), [2 i + 1] = (yz, zz, -, -): written by k_pre_solve when the step's
+	                           // rows are compact (StepParams::compact_rows != 0), so that a lane rebuilding I (r x axis) gathers ONE record instead of the pose and property records + a rotation matrix
 	                           //   r2 x axis (w: effective mass of the axis), I1 (r1 x axis), I2 (r2 x axis)
 	ConstraintArrays ca[2];    // [sp->parity] = this step's constraints, the other = previous step's (contact cache)
 	uint64_t* ht_keys; uint32_t* ht_vals; uint32_t ht_size;   // contact cache: pair key -> prev slot (ht_size: allocated entries, a power of two)

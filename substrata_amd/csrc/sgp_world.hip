@@ -194,7 +194,7 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	d.cap_hc_list = 2u * M + 4096u; DEV_ALLOC(d.hc_list, d.cap_hc_list); DEV_ALLOC(d.hc_entry, d.cap_hc_list); DEV_ALLOC(d.hc_big_list, 1024);
 	DEV_ALLOC(d.ulist[0], M); DEV_ALLOC(d.ulist[1], M);
 	for (int k = 0; k < 4; ++k) { DEV_ALLOC(d.man_p1[k], M); DEV_ALLOC(d.man_p2[k], M); }
-	DEV_ALLOC(d.rows, (size_t)48 * M);
+	DEV_ALLOC(d.rows, (size_t)48 * M); DEV_ALLOC(d.iw, (size_t)2 * N);
 	{ int r = alloc_constraints(w, d.ca[0], M); if (r != SGP_OK) return r; }
 	{ int r = alloc_constraints(w, d.ca[1], M); if (r != SGP_OK) return r; }
 	w->ht_alloc = next_pow2(2u * M);
@@ -227,6 +227,7 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	{ const char* e = getenv("SGP_VEHICLE_FUSED"); if (e) w->fuse_vehicle_solve = atoi(e) != 0; }
 	{ const char* e = getenv("SGP_COMPACT_ROWS_MIN"); if (e && atoll(e) >= 0) w->compact_rows_min = (uint32_t)atoll(e); }
 	{ const char* e = getenv("SGP_ROWS_MODE"); if (e && (atoi(e) == 1 || atoi(e) == 2)) w->rows_mode_large = (uint32_t)atoi(e); }
+	{ const char* e = getenv("SGP_ROWS_MODE_DEFAULT"); if (e && atoi(e) >= 0 && atoi(e) <= 2) w->rows_mode_default = (uint32_t)atoi(e); }
 	{ const char* e = getenv("SGP_TS_MIN_CONSTRAINTS"); if (e && atoi(e) >= 0) w->ts_min_constraints = (uint32_t)atoi(e); }
 	{ const char* e = getenv("SGP_HC_BUDGET"); if (e) { const int v = atoi(e); if (v <= 0) w->use_components = false; else w->hc_budget = (uint32_t)v; } }
 	{ int dev = 0, cus = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) w->n_cus = (uint32_t)cus; }
@@ -769,7 +770,7 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	const double tt0 = timing ? now() : 0.0;
 	w->h_sp->dt = dt;
-	w->h_sp->compact_rows = (w->n_con >= w->compact_rows_min && !(w->high <= SGP_SMALL_WORLD_BODIES)) ? w->rows_mode_large : 0u;      // (decided from the previous step's count; part of the plan's key)
+	w->h_sp->compact_rows = (w->high <= SGP_SMALL_WORLD_BODIES) ? 0u : (w->n_con >= w->compact_rows_min ? w->rows_mode_large : w->rows_mode_default);      // (decided from the previous step's count; part of the plan's key)
 	StepPlan plan;
 	make_plan(w, plan);
 	const std::string key((const char*)&plan, sizeof(plan));
