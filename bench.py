@@ -43,9 +43,10 @@ DT = 1.0 / 60.0
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HBM_ACHIEVABLE_GBS = 6300.0    # what a streaming kernel reaches on this part (same guide)
 SWEEP_BYTES_PER_BODY = 188     # integrate + AABB body-array sweep, 112 B read + 76 B written
-# per contact point per velocity iteration: 12 precomputed row vectors (3 axes x 4 float4) + lambdas read, lambdas written
-SOLVE_BYTES_PER_POINT = 12 * 16 + 16 + 16
-SOLVE_BYTES_PER_MANIFOLD = 28 + 2 * 32 + 2 * 32  # ab 8 + normal/friction 16 + np 4; the velocity halves of two solver-body records read and written
+# per contact point per velocity iteration (compact rows, the default since round 5): 6 row vectors r x axis (3 axes x 2 bodies, float4) + lambdas read, lambdas written
+SOLVE_BYTES_PER_POINT = 6 * 16 + 16 + 16
+# per manifold: ab 8 + normal/friction 16 + np 4; the velocity records of two bodies read and written; their world-inverse-inertia records (DV::iw) read
+SOLVE_BYTES_PER_MANIFOLD = 28 + 2 * 32 + 2 * 32 + 2 * 32
 SETTLE_STEPS = 240             # lattice -> settled pile, untimed, independent of the command line
 SETTLE_STEPS_TILED = 120       # N > 1 (config 4): untimed steps before the warm-up
 PRIME_STEPS = 24               # after a world is rebuilt from the snapshot: contact cache + launch plan + graph capture
@@ -496,7 +497,7 @@ def main():
     # ---- the whole step against the roofline (SURVEY 8d's B_step with this step's own counts) ------------------------
     # B_step = 188 N (sweep) + 40 N (cell key + index, sorted read) + 96 P (pair gather 2 x 44 + pair id) + 132 M (manifold) + I_v C 192 + I_p C 104
     n_, p_, m_, c_ = float(prof["sweep_bodies"]), float(st.num_pairs), float(st.num_manifolds), float(st.num_contact_points)
-    step_bytes = 188.0 * n_ + 40.0 * n_ + 96.0 * p_ + 132.0 * m_ + vel_iters * c_ * 192.0 + pos_iters * c_ * 104.0
+    step_bytes = 188.0 * n_ + 40.0 * n_ + 96.0 * p_ + 132.0 * m_ + vel_iters * c_ * 192.0 + pos_iters * c_ * 104.0      # (SURVEY's model, kept as it is for comparability across rounds: 192 B per point and velocity iteration)
     step_gbs = step_bytes / (ms_per_step * 1e-3) / 1e9
     out["roofline_step"] = {
         "bound": "hbm", "kernel": "the whole step (all launches; SURVEY 8d whole-step model B_step)", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
