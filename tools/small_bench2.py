@@ -25,3 +25,18 @@ for graphs in ("0", "1"):
     print(f"SGP_NO_GRAPH={graphs}: {1000 * el / n:.3f} ms/step wall; active {st.num_active} manifolds {st.num_manifolds} colours {st.num_colours}; launches {nl}; GPU span of a profiled step {p.total_ms:.3f} ms")
     print("   ", {names[k]: (round(p.kernel_ms[k], 3), p.kernel_launches[k]) for k in range(len(names)) if p.kernel_launches[k]})
     w.close()
+# the CPU port (oracle, NOT Jolt) on the same awake scene, one thread (more threads lose at this size): B2 beside the awake config 1
+if "--no-cpu" not in sys.argv:
+    from oracle import oracle
+    oracle.set_threads(1)
+    c = oracle.OracleWorld(max_bodies=len(descs) + 64)
+    c.add_batch(descs)
+    for _ in range(200):
+        c.step(1 / 60)
+    t = time.perf_counter(); n = 300
+    for _ in range(n):
+        c.step(1 / 60)
+    el = time.perf_counter() - t
+    cst = c.stats()
+    print(f"cpu port (oracle, not Jolt), 1 thread: {1000 * el / n:.3f} ms/step; active {cst.num_active} manifolds {cst.num_manifolds} colours {cst.num_colours}")
+    c.close()
