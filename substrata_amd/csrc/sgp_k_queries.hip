@@ -294,7 +294,7 @@ SGP_DEV sgp_hit raycast_wave(const DV& d, const sgp_ray& ry)
 }
 
 // The resident ray server (RayMailbox, sgp_kernels.h): one wave.  Its 64 lanes trace the ray together (raycast_wave); the mailbox lines are read and written by lanes 0..15, one word each, as single 64-byte transactions over the host link.
-__global__ void __launch_bounds__(64) k_ray_server(DV d, RayMailbox* mb, uint32_t first_seq, uint64_t idle_ticks, uint64_t max_ticks)
+__global__ void __launch_bounds__(64) k_ray_server(DV d, RayMailbox* mb, uint32_t first_seq, uint32_t generation, uint64_t idle_ticks, uint64_t max_ticks)
 {
 	const int lane = (int)threadIdx.x;
 	uint32_t* req_line = (uint32_t*)mb;
@@ -302,10 +302,12 @@ __global__ void __launch_bounds__(64) k_ray_server(DV d, RayMailbox* mb, uint32_
 	uint32_t seen = first_seq;
 	const uint64_t t_start = wall_clock64();
 	uint64_t t_last = t_start;
-	if (lane == 1) __hip_atomic_store(&res_line[1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);      // alive
 	for (uint32_t poll = 0;; ++poll) {
 		const uint32_t wv = lane < 16 ? __hip_atomic_load(&req_line[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
-		const uint32_t req = (uint32_t)__shfl((int)wv, 0, 64), stop = (uint32_t)__shfl((int)wv, 1, 64);
+		const uint32_t req = (uint32_t)__shfl((int)wv, 0, 64), stop_gen = (uint32_t)__shfl((int)wv, 1, 64);
+		// told to leave (the host writes that BEFORE anything it does to the world and before any later request; the line is read as a whole, so a request
+		// seen here without the order to leave was made while this server's view of the world was current)
+		if ((int32_t)(stop_gen - generation) >= 0) break;
 		if (req != seen) {
 			sgp_ray ry;
 			uint32_t* dst = (uint32_t*)&ry;
@@ -314,7 +316,7 @@ __global__ void __launch_bounds__(64) k_ray_server(DV d, RayMailbox* mb, uint32_
 			const sgp_hit h = raycast_wave(d, ry);
 			const uint32_t* hs = (const uint32_t*)&h;
 			uint32_t out = 0u;
-			if (lane == 0 || lane == 15) out = req; else if (lane == 1) out = 1u;
+			if (lane == 0 || lane == 15) out = req; else if (lane == 1) out = generation - 1u;      // (exited_gen: not this one)
 #pragma unroll
 			for (int i = 0; i < (int)(sizeof(sgp_hit) / 4); ++i) if (lane == 2 + i) out = hs[i];
 			if (lane < 16) __hip_atomic_store(&res_line[lane], out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -322,11 +324,10 @@ __global__ void __launch_bounds__(64) k_ray_server(DV d, RayMailbox* mb, uint32_
 			t_last = wall_clock64();
 			continue;
 		}
-		if (stop != 0u) break;
 		if ((poll & 15u) == 15u) { const uint64_t now = wall_clock64(); if (now - t_last > idle_ticks || now - t_start > max_ticks) break; }
 	}
-	// a request that arrived while this wave was deciding to leave is answered by the next server: the host sees alive == 0 with its request open
-	if (lane == 1) __hip_atomic_store(&res_line[1], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	// a request that arrived while this wave was deciding to leave is answered by the next server: the host sees exited_gen == this generation with its request open
+	if (lane == 1) __hip_atomic_store(&res_line[1], generation, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);      // exited_gen
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -481,7 +482,7 @@ __global__ void __launch_bounds__(64) k_spherecast(DV d, const sgp_ray* rays, co
 	h.userdata = 0;
 	hits[k] = h;
 }
-void launch_ray_server(const DV& d, RayMailbox* mb, uint32_t first_seq, uint64_t idle_ticks, uint64_t max_ticks, hipStream_t s) { hipLaunchKernelGGL(k_ray_server, dim3(1), dim3(64), 0, s, d, mb, first_seq, idle_ticks, max_ticks); }
+void launch_ray_server(const DV& d, RayMailbox* mb, uint32_t first_seq, uint32_t generation, uint64_t idle_ticks, uint64_t max_ticks, hipStream_t s) { hipLaunchKernelGGL(k_ray_server, dim3(1), dim3(64), 0, s, d, mb, first_seq, generation, idle_ticks, max_ticks); }
 void launch_raycast(const DV& d, const sgp_ray* rays, uint32_t n, sgp_hit* hits, hipStream_t s) { if (n) hipLaunchKernelGGL(k_raycast, dim3((n + 63) / 64), dim3(64), 0, s, d, rays, n, hits); }
 void launch_collide_capsules(const DV& d, const sgp_capsule_query* q, uint32_t n, sgp_query_contact* out, uint32_t cap, uint32_t* count, hipStream_t s) { if (n) hipLaunchKernelGGL(k_collide_capsules, dim3(n), dim3(64), 0, s, d, q, n, out, cap, count); }      // a wave per query
 void launch_spherecast(const DV& d, const sgp_ray* rays, const float* radii, uint32_t n, sgp_hit* hits, hipStream_t s) { if (n) hipLaunchKernelGGL(k_spherecast, dim3((n + 63) / 64), dim3(64), 0, s, d, rays, radii, n, hits); }

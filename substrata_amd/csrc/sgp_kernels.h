@@ -400,12 +400,12 @@ void launch_solve_colour_veh(const DV& d, int colour, uint32_t est, int mode, hi
 struct RayMailbox {
 	// line 0 (64 B), host -> device: the wave reads it with ONE 64-byte load (lane l < 16 takes word l), so a new `req_seq` comes with its ray (the host
 	// writes the ray first; a cache line is read as a whole)
-	uint32_t req_seq, stop; sgp_ray ray; uint32_t pad0[16 - 2 - sizeof(sgp_ray) / 4];
+	uint32_t req_seq, stop_gen; sgp_ray ray; uint32_t pad0[16 - 2 - sizeof(sgp_ray) / 4];      // stop_gen: every server of this generation or older must leave (never reset: a new server has a newer generation)
 	// line 1 (64 B), device -> host: written with ONE 64-byte store, the sequence number at both ends (the host takes the hit when both match)
-	uint32_t done_seq, alive; sgp_hit hit; uint32_t pad1[16 - 2 - sizeof(sgp_hit) / 4 - 1]; uint32_t done_seq2;
+	uint32_t done_seq, exited_gen; sgp_hit hit; uint32_t pad1[16 - 2 - sizeof(sgp_hit) / 4 - 1]; uint32_t done_seq2;      // exited_gen: generation of the last server that left
 };
 static_assert(sizeof(RayMailbox) == 128 && sizeof(sgp_ray) == 36 && sizeof(sgp_hit) == 48, "RayMailbox: two 64-byte lines");
-void launch_ray_server(const DV& d, RayMailbox* mb, uint32_t first_seq, uint64_t idle_ticks, uint64_t max_ticks, hipStream_t s);
+void launch_ray_server(const DV& d, RayMailbox* mb, uint32_t first_seq, uint32_t generation, uint64_t idle_ticks, uint64_t max_ticks, hipStream_t s);
 void launch_raycast(const DV& d, const sgp_ray* rays, uint32_t n, sgp_hit* hits, hipStream_t s);
 void launch_collide_capsules(const DV& d, const sgp_capsule_query* q, uint32_t n, sgp_query_contact* out, uint32_t cap, uint32_t* count, hipStream_t s);
 void launch_spherecast(const DV& d, const sgp_ray* rays, const float* radii, uint32_t n, sgp_hit* hits, hipStream_t s);

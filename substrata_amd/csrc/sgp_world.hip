@@ -403,7 +403,7 @@ static int rebuild_large_grid(sgp_world* w)
 void ray_server_stop(sgp_world* w)
 {
 	if (!w->ray_server_on) return;
-	__atomic_store_n(&w->ray_mb->stop, 1u, __ATOMIC_RELEASE);
+	__atomic_store_n(&w->ray_mb->stop_gen, w->ray_gen, __ATOMIC_RELEASE);      // (never taken back: the next server is a newer generation)
 	w->ray_server_on = false;
 }
 

@@ -124,7 +124,7 @@ struct sgp_world {
 	bool plan_seen = false;         // a step has run: plan_colour_count etc. describe the previous step
 	uint32_t graph_launches = 0, eager_steps = 0, idle_steps = 0;
 	// single-query mailbox (sgp_raycast with n = 1): host-mapped block + whether a server wave is (believed to be) resident on the stream
-	RayMailbox* ray_mb = nullptr; bool ray_server_on = false; bool ray_server_enabled = true; uint32_t ray_seq = 0;
+	RayMailbox* ray_mb = nullptr; bool ray_server_on = false; bool ray_server_enabled = true; uint32_t ray_seq = 0, ray_gen = 0;
 	uint32_t ray_server_launches = 0, ray_server_rays = 0;
 	bool last_step_idle = false;       // the last step was skipped (every body asleep, nothing edited): no vehicle took part in it, whatever its record says
 	bool grid_valid = false;                                   // the broad-phase grid matches the current poses (ray queries reuse it)

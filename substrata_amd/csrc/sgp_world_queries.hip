@@ -20,17 +20,16 @@ static int ray_through_server(sgp_world* w, const sgp_ray* ray, sgp_hit* hit)
 	if (!w->ray_server_enabled) return 0;
 	if (!w->ray_mb) {
 		if (hipHostMalloc((void**)&w->ray_mb, sizeof(RayMailbox), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { w->ray_server_enabled = false; (void)hipGetLastError(); return 0; }
-		memset(w->ray_mb, 0, sizeof(RayMailbox));
+		memset(w->ray_mb, 0, sizeof(RayMailbox));      // (generation 0 = nobody: the first server is generation 1)
 	}
 	RayMailbox* mb = w->ray_mb;
 	for (int attempt = 0; attempt < 3; ++attempt) {
 		if (!w->ray_server_on) {
 			// (the previous server, if any, was told to stop or left on its own; the new one queues behind it on the stream)
-			__atomic_store_n(&mb->stop, 0u, __ATOMIC_RELAXED);
-			__atomic_store_n(&mb->alive, 2u, __ATOMIC_RELEASE);      // 2 = launched, not yet running (the wave writes 1, then 0 when it leaves)
+			++w->ray_gen;      // (servers of older generations have been told to leave, or have left; what they still write names their generation, not this one)
 			RayMailbox* dmb = nullptr;
 			if (hipHostGetDevicePointer((void**)&dmb, mb, 0) != hipSuccess) { w->ray_server_enabled = false; (void)hipGetLastError(); return 0; }
-			launch_ray_server(w->dv, dmb, w->ray_seq, SGP_RAY_SERVER_IDLE_TICKS, SGP_RAY_SERVER_MAX_TICKS, w->stream);
+			launch_ray_server(w->dv, dmb, w->ray_seq, w->ray_gen, SGP_RAY_SERVER_IDLE_TICKS, SGP_RAY_SERVER_MAX_TICKS, w->stream);
 			w->ray_server_on = true; w->ray_server_launches++;
 		}
 		mb->ray = *ray;
@@ -40,7 +39,7 @@ static int ray_through_server(sgp_world* w, const sgp_ray* ray, sgp_hit* hit)
 		for (uint32_t spin = 0;; ++spin) {
 			if (__atomic_load_n(&mb->done_seq, __ATOMIC_ACQUIRE) == seq && __atomic_load_n(&mb->done_seq2, __ATOMIC_ACQUIRE) == seq) { *hit = mb->hit; w->ray_server_rays++; return 1; }
 			if ((spin & 1023u) == 1023u) {
-				if (__atomic_load_n(&mb->alive, __ATOMIC_ACQUIRE) == 0u) break;      // it left (idle / age) before it saw this request: start another
+				if (__atomic_load_n(&mb->exited_gen, __ATOMIC_ACQUIRE) == w->ray_gen) break;      // this generation's server left (idle / age) before it saw the request: start another
 				if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) {      // (never observed: the launch path still answers)
 					ray_server_stop(w); HIP_TRY(hipStreamSynchronize(w->stream)); w->ray_server_enabled = false; return 0;
 				}
