@@ -20,21 +20,25 @@
 #define SGO_HULL_H
 
 #include "sgo_math.h"
+#include <stdlib.h>
 /* (included from sgo_collide.h after sgo_manifold, SGO_CAPSULE_SLOP and sgo_closest_on_segment are defined) */
 
-#define SGO_HULL_MAX_VERTS 32
-#define SGO_HULL_MAX_FACES 60
-#define SGO_HULL_MAX_EDGES 90
-#define SGO_HULL_MAX_FACE_IDX 180
+#define SGO_HULL_MAX_VERTS 256         /* JPH::ConvexHullShape::cMaxPointsInHull (round 5; rounds 1-4 kept 32) */
+#define SGO_HULL_MAX_FACES 512         /* <= 2 V - 4 triangles, fewer once coplanar ones are merged; faces of more than 16 corners are split */
+#define SGO_HULL_MAX_EDGES 768         /* <= 3 V - 6 (+ the diagonals of split faces) */
+#define SGO_HULL_MAX_FACE_IDX 1792     /* sum of the face loops = 2 E */
 #define SGO_HULL_MAX_FACE_VERTS 16
+#define SGO_HULL_GAUSS_MIN_PAIRS 8192   /* more edge pairs than two 32-vertex hulls can have (90 x 90): the Gauss-map test selects the pairs worth an axis */
+#define SGO_HULL_SMALL_VERTS 32        /* up to here the builder and the separating-axis search are those of rounds 1-4, bit for bit */
 #define SGO_HULL_CLIP_CAP 24
 
 struct sgo_hull_s {
 	int nv, nf, ne, is_box_template;
 	v3 verts[SGO_HULL_MAX_VERTS];
 	v3 normals[SGO_HULL_MAX_FACES]; float plane_d[SGO_HULL_MAX_FACES];       /* inside: n.x <= d */
-	unsigned char face_start[SGO_HULL_MAX_FACES + 1]; unsigned char face_idx[SGO_HULL_MAX_FACE_IDX];   /* CCW seen from outside */
+	unsigned short face_start[SGO_HULL_MAX_FACES + 1]; unsigned char face_idx[SGO_HULL_MAX_FACE_IDX];   /* CCW seen from outside */
 	unsigned char edge_a[SGO_HULL_MAX_EDGES], edge_b[SGO_HULL_MAX_EDGES];
+	unsigned short edge_f0[SGO_HULL_MAX_EDGES], edge_f1[SGO_HULL_MAX_EDGES];   /* the two faces an edge lies between: f0 has it as a -> b, f1 as b -> a (Gauss-map test of edge pairs) */
 	v3 aabb_min, aabb_max;
 	float bound_radius, volume;
 	v3 unit_inertia;                   /* principal moments for density 1 */
@@ -190,6 +194,33 @@ static inline int sgo_hull_sat_search(const sgo_hview* A, const sgo_hview* B, fl
 		if (s > r->sB) { r->sB = s; r->fB = f; }
 	}
 	const v3 T = v3_sub(B->pos, A->pos);
+	if (A->h->ne * B->h->ne > SGO_HULL_GAUSS_MIN_PAIRS) {
+		/* Many edge pairs (a hull beyond 32 vertices is involved; round 5): only the pairs whose cross product can be a face of the Minkowski difference are
+		   evaluated -- the arcs between the normals of the faces either side of edge i of A and of (minus) those either side of edge j of B cross on the unit
+		   sphere (the Gauss-map test; 4 dot products per pair instead of a projection of every vertex of both hulls).  The minimum-penetration axis is a face
+		   normal of A, of B, or such a pair, so the answer is that of the full search wherever the full search is decided by more than rounding. */
+		v3* na = (v3*)malloc(sizeof(v3) * (size_t)(A->h->nf + B->h->nf + A->h->ne + B->h->ne));
+		v3* nb = na + A->h->nf; v3* ea = nb + B->h->nf; v3* eb = ea + A->h->ne;
+		for (int f = 0; f < A->h->nf; ++f) na[f] = sgo_hv_normal(A, f);
+		for (int f = 0; f < B->h->nf; ++f) nb[f] = v3_neg(sgo_hv_normal(B, f));
+		for (int i = 0; i < A->h->ne; ++i) ea[i] = v3_cross(na[A->h->edge_f1[i]], na[A->h->edge_f0[i]]);
+		for (int j = 0; j < B->h->ne; ++j) eb[j] = v3_cross(nb[B->h->edge_f1[j]], nb[B->h->edge_f0[j]]);
+		int separated = 0;
+		for (int i = 0; i < A->h->ne && !separated; ++i) {
+			const v3 a = na[A->h->edge_f0[i]], bb = na[A->h->edge_f1[i]], bxa = ea[i];
+			for (int j = 0; j < B->h->ne; ++j) {
+				const v3 c = nb[B->h->edge_f0[j]], dd = nb[B->h->edge_f1[j]], dxc = eb[j];
+				const float cba = v3_dot(c, bxa), dba = v3_dot(dd, bxa), adc = v3_dot(a, dxc), bdc = v3_dot(bb, dxc);
+				if (!(cba * dba < 0.0f && adc * bdc < 0.0f && cba * bdc > 0.0f)) continue;
+				v3 ax; float s; int sup;
+				if (!sgo_hull_axis_edge(A, B, i, j, T, &ax, &s, &sup)) continue;
+				if (s > max_sep) { separated = 1; break; }
+				if (s > r->sE && sup) { r->sE = s; r->eA = i; r->eB = j; r->nE = ax; }
+			}
+		}
+		free(na);
+		return !separated;
+	}
 	for (int i = 0; i < A->h->ne; ++i) {
 		for (int j = 0; j < B->h->ne; ++j) {
 			v3 ax; float s; int sup;

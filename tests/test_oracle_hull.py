@@ -63,11 +63,22 @@ def test_builder_topology_and_mass_properties(oracle):
         w.hull_create([(0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0)])          # flat
     with pytest.raises(SgpError):
         w.hull_create([(0, 0, 0), (1, 0, 0), (2, 0, 0)])
-    # many points: reduced to <= 32 extreme points, still a closed polytope close to the sphere they came from
+    # many points: up to 256 are kept (JPH::ConvexHullShape::cMaxPointsInHull; rounds 1-4 kept 32 and lost a quarter of the sphere's volume), a closed polytope
     S = rng.normal(size=(500, 3)); S /= np.linalg.norm(S, axis=1, keepdims=True)
     s = w.hull_create(S)
-    assert s.num_vertices <= 32 and s.num_vertices - s.num_edges + s.num_faces == 2
-    assert 0.6 * 4.19 < s.volume < 4.19
+    assert 200 <= s.num_vertices <= 256 and s.num_vertices - s.num_edges + s.num_faces == 2
+    assert 0.96 * 4.18879 < s.volume < 4.18879
+    # 200 points on a sphere: every one of them is a vertex of the hull, and stays one
+    S2 = S[:200]
+    s2 = w.hull_create(S2)
+    assert s2.num_vertices == 200 and s2.num_faces == 396 and s2.num_edges == 594          # a triangulated sphere: F = 2 V - 4, E = 3 V - 6
+    from scipy.spatial import ConvexHull
+    assert abs(s2.volume - ConvexHull(S2.astype(np.float32).astype(np.float64)).volume) < 1e-4
+    # a finely tessellated cube (17 x 17 points per side): its coplanar triangles merge into the six quads, only the corners stay
+    g = np.linspace(-1, 1, 7)
+    C = np.array([(x, y, z) for x in g for y in g for z in g if max(abs(x), abs(y), abs(z)) == 1.0])
+    c6 = w.hull_create(C)
+    assert (c6.num_vertices, c6.num_faces, c6.num_edges) == (8, 6, 12) and abs(c6.volume - 8.0) < 1e-5
 
 
 def test_hull_cube_behaves_like_the_native_box(oracle):
@@ -167,7 +178,7 @@ def test_large_point_cloud_uses_every_vertex(oracle):
     pts = np.concatenate([near, far])
     w = oracle.OracleWorld(max_bodies=8)
     info = w.hull_create(pts)
-    assert info.num_vertices >= 8 and info.num_vertices <= 32
+    assert info.num_vertices == 8                                                      # nothing but the corners is on the hull
     ext = np.array(info.aabb_max[:]) - np.array(info.aabb_min[:])
     assert np.allclose(np.sort(ext), [1.0, 2.0, 4.0], atol=1e-3)
     assert abs(info.volume - 8.0) < 1e-2                                               # the clump is inside the box
