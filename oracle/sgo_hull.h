@@ -241,11 +241,13 @@ static inline int sgo_hull_face_contact(const sgo_hview* X, const sgo_hview* Y, 
 	for (int f = 0; f < Y->h->nf; ++f) { const float d = v3_dot(nref, sgo_hv_normal(Y, f)); if (d < bestd) { bestd = d; fY = f; } }
 	v3 poly[SGO_HULL_CLIP_CAP], tmp[SGO_HULL_CLIP_CAP];
 	int np = 0;
-	for (int k = Y->h->face_start[fY]; k < Y->h->face_start[fY + 1]; ++k) poly[np++] = sgo_hv_world(Y, Y->h->face_idx[k]);
-	const int x0 = X->h->face_start[fX], x1 = X->h->face_start[fX + 1];
-	for (int k = x0; k < x1 && np > 0; ++k) {
+	/* (a face of more than SGO_HULL_MAX_FACE_VERTS corners takes part with every step-th of them: the polygon inscribed in it) */
+	const int y0 = Y->h->face_start[fY], y1 = Y->h->face_start[fY + 1], ystep = (y1 - y0 + SGO_HULL_MAX_FACE_VERTS - 1) / SGO_HULL_MAX_FACE_VERTS;
+	for (int k = y0; k < y1; k += ystep) poly[np++] = sgo_hv_world(Y, Y->h->face_idx[k]);
+	const int x0 = X->h->face_start[fX], x1 = X->h->face_start[fX + 1], xstep = (x1 - x0 + SGO_HULL_MAX_FACE_VERTS - 1) / SGO_HULL_MAX_FACE_VERTS;
+	for (int k = x0; k < x1 && np > 0; k += xstep) {
 		const v3 a = sgo_hv_world(X, X->h->face_idx[k]);
-		const v3 b = sgo_hv_world(X, X->h->face_idx[k + 1 < x1 ? k + 1 : x0]);
+		const v3 b = sgo_hv_world(X, X->h->face_idx[k + xstep < x1 ? k + xstep : x0]);
 		const v3 side = v3_cross(v3_sub(b, a), nref);
 		np = sgo_hull_clip(poly, np, a, side, tmp);
 		for (int i = 0; i < np; ++i) poly[i] = tmp[i];

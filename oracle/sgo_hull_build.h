@@ -239,7 +239,7 @@ static inline int sgo_hull_build(const float* pts_in, int n_in, const float* com
 			int known = 0;
 			for (int f = 0; f < nf; ++f) if (masks[f] == mask) { known = 1; break; }
 			if (known) continue;
-			if (nf == 60 || cnt > SGO_HULL_MAX_FACE_VERTS) SGO_HB_FAIL(-2);      /* (the limits of rounds 1-4) */
+			if (nf == 60) SGO_HB_FAIL(-2);      /* (the limit of rounds 1-4 on this path; a face may hold every point since round 5) */
 			masks[nf] = mask; fn[nf] = nn; fd[nf] = dd; fmem_start[nf] = (unsigned short)nm;
 			for (int q = 0; q < n; ++q) if (mask & (1u << q)) fmem[nm++] = (unsigned char)q;
 			++nf;
@@ -251,8 +251,9 @@ static inline int sgo_hull_build(const float* pts_in, int n_in, const float* com
 	}
 	if (nf < 4) SGO_HB_FAIL(-1);                             /* flat or degenerate cloud */
 	{
-	/* 3. drop interior points, order each face counter-clockwise seen from outside; a face of more than 16 corners is split into fans of 16 around its
-	      first corner (coplanar pieces: the clipping buffers of the contact manifold hold 16) */
+	/* 3. drop interior points, order each face counter-clockwise seen from outside.  A face keeps all its corners (a 64-gon cap is ONE face, one SAT axis,
+	      one supporting face); the contact manifold clips against every (cnt + 15) / 16-th of them, sgo_hull_face_contact -- as ConvexHullShape::GetSupportingFace
+	      thins a face that would overflow its caller's buffer.  UNVERIFIED: upstream. */
 	unsigned char usedv[256]; memset(usedv, 0, sizeof(usedv));
 	for (int k = 0; k < fmem_start[nf]; ++k) usedv[fmem[k]] = 1;
 	int remap[256]; int nv = 0;
@@ -271,13 +272,9 @@ static inline int sgo_hull_build(const float* pts_in, int n_in, const float* com
 		const sgo_d3 w = sgo_d3_cross(fn[f], u);
 		for (int k = 0; k < cnt; ++k) { const sgo_d3 r = sgo_d3_sub(hv[ids[k]], c); ang[k] = atan2(sgo_d3_dot(r, w), sgo_d3_dot(r, u)); }
 		for (int a = 1; a < cnt; ++a) { const int id = ids[a]; const double av = ang[a]; int b = a - 1; while (b >= 0 && ang[b] > av) { ids[b + 1] = ids[b]; ang[b + 1] = ang[b]; --b; } ids[b + 1] = id; ang[b + 1] = av; }
-		for (int first = 1; first < cnt - 1; first += SGO_HULL_MAX_FACE_VERTS - 2) {
-			const int last = first + SGO_HULL_MAX_FACE_VERTS - 2 < cnt - 1 ? first + SGO_HULL_MAX_FACE_VERTS - 2 : cnt - 1;      /* corners ids[0], ids[first .. last] */
-			if (nf2 == SGO_HULL_MAX_FACES || nidx + (last - first + 2) > SGO_HULL_MAX_FACE_IDX) { rc = -2; break; }
-			fstart_[nf2] = nidx; fn2[nf2] = fn[f]; fd2[nf2] = fd[f]; ++nf2;
-			fidx_[nidx++] = ids[0];
-			for (int k = first; k <= last; ++k) fidx_[nidx++] = ids[k];
-		}
+		if (nf2 == SGO_HULL_MAX_FACES || nidx + cnt > SGO_HULL_MAX_FACE_IDX) { rc = -2; break; }
+		fstart_[nf2] = nidx; fn2[nf2] = fn[f]; fd2[nf2] = fd[f]; ++nf2;
+		for (int k = 0; k < cnt; ++k) fidx_[nidx++] = ids[k];
 	}
 	fstart_[nf2] = nidx;
 	if (rc == 0) {

@@ -89,7 +89,7 @@ template <int G, bool HULL = (G == 64)> struct MeshPairLds {
 	sgd_mesh_contacts mc;
 	typename std::conditional<HULL, sgd_hull, MeshNoHull>::type hull;      // the body's polytope (cube template / convex hull) next to the lanes that walk its vertices once per axis
 };
-#define MESH_LDS_T(G, KINDS) MeshPairLds<G, (G) == 64 || (KINDS) == 8>
+#define MESH_LDS_T(G, KINDS) MeshPairLds<G, (G) == 64>      // (round 5: a hull record holds up to 256 vertices, 19 KB: only the wave-per-pair launch, one pair per workgroup, stages it)
 
 // every triangle whose leaf box overlaps [llo, lhi] (mesh frame): positions in the tree-ordered triangle array and the triangles' indices in the
 // caller's order, as found (unsorted)
@@ -158,12 +158,19 @@ template <int MESH_GROUP, int KINDS = SGD_KINDS_ALL> SGP_DEV void mesh_pair_grou
 	MeshHeader mh; v3 mpos = V3(0.0f, 0.0f, 0.0f); m33 R = quat_to_m33(Q4(make_float4(0.0f, 0.0f, 0.0f, 1.0f)));
 	int nc = 0;
 	if (valid) {
-		if ((MESH_GROUP == 64 || KINDS == 8) && X.hull) {
+		if constexpr (MESH_GROUP == 64) if (X.hull) {
 			// a triangle test walks the polytope's vertices twice per candidate axis: out of LDS, not out of a pointer into global memory (worth the copy
 			// where dozens of tests follow: 2.50 -> 2.13 ms on the car-sized boxes, but 0.93 -> 1.09 ms on the small bodies of tools/experiments/mesh_terrain_bench.py when
 			// every eight-lane pair did it; the eight-lane instance for convex hulls does -- ~130 axes per triangle, each a walk over the hull's corners: 0.80 -> 0.78 ms for 3.5k hulls)
-			const uint32_t* src = (const uint32_t*)X.hull; uint32_t* dst = (uint32_t*)&L.hull;
-			for (uint32_t i = (uint32_t)sub; i < sizeof(sgd_hull) / 4; i += MESH_GROUP) dst[i] = src[i];
+			// (the live part of every array, not the record's 19 KB: a box's cube template is 8 corners)
+			const sgd_hull* hs = X.hull; sgd_hull* hd = &L.hull;
+			if (sub == 0) { hd->nv = hs->nv; hd->nf = hs->nf; hd->ne = hs->ne; hd->is_box_template = hs->is_box_template; hd->aabb_min = hs->aabb_min; hd->aabb_max = hs->aabb_max; hd->bound_radius = hs->bound_radius; hd->volume = hs->volume; hd->unit_inertia = hs->unit_inertia; }
+			const int nv_ = hs->nv, nf_ = hs->nf, ne_ = hs->ne, ni_ = hs->face_start[hs->nf];
+			for (int i = sub; i < nv_; i += MESH_GROUP) hd->verts[i] = hs->verts[i];
+			for (int i = sub; i < nf_; i += MESH_GROUP) { hd->normals[i] = hs->normals[i]; hd->plane_d[i] = hs->plane_d[i]; }
+			for (int i = sub; i <= nf_; i += MESH_GROUP) hd->face_start[i] = hs->face_start[i];
+			for (int i = sub; i < ni_; i += MESH_GROUP) hd->face_idx[i] = hs->face_idx[i];
+			for (int i = sub; i < ne_; i += MESH_GROUP) { hd->edge_a[i] = hs->edge_a[i]; hd->edge_b[i] = hs->edge_b[i]; hd->edge_f0[i] = hs->edge_f0[i]; hd->edge_f1[i] = hs->edge_f1[i]; }
 			X.hull = (const sgd_hull*)(const void*)&L.hull;
 		}
 		mh = d.meshes[(uint32_t)d.prop[2 * (size_t)mid + 1].x];
@@ -319,6 +326,21 @@ SGP_DEV int hull_sat_search_wave(const sgd_hview* A, const sgd_hview* B, float m
 		}
 	}
 	if (__any(separated)) return 0;
+	if (neA * neB > SGD_HULL_GAUSS_MIN_PAIRS) {
+		// a hull beyond 32 vertices: the edge pairs worth an axis are picked by the Gauss-map test (sgd_hull_sat_search has the words); edge i of A by all lanes,
+		// B's edges dealt to the lanes -- the pair's index i neB + j orders the ties as the sequential search meets them
+		for (int i = 0; i < neA; ++i) {
+			const v3 a = sgd_hv_normal(A, A->h->edge_f0[i]), bb = sgd_hv_normal(A, A->h->edge_f1[i]), bxa = v3_cross(bb, a);
+			for (int j = lane; j < neB; j += 64) {
+				if (!sgd_hull_gauss_pair(B, j, a, bb, bxa)) continue;
+				v3 ax; float s; int sup;
+				if (sgd_hull_axis_edge(A, B, i, j, T, &ax, &s, &sup)) {
+					if (s > max_sep) separated = true;
+					if (s > sE && sup) { sE = s; iE = i * neB + j; }
+				}
+			}
+		}
+	} else
 	for (int e = lane; e < total - nfA - nfB; e += 64) {
 		v3 ax; float s; int sup;
 		if (sgd_hull_axis_edge(A, B, e / neB, e % neB, T, &ax, &s, &sup)) {

@@ -1,0 +1,108 @@
+"""GPU-vs-oracle parity with convex hulls of 33 .. 256 vertices (ConvexHullShapeSettings takes a dynamic mesh's whole vertex
+set, /root/reference/gui_client/PhysicsWorld.cpp:1062-1080 -- rounds 1-4 reduced anything beyond 32 corners): the builder's output record by
+record, piles of such hulls with every other shape kind on the ground plane and on a triangulated terrain, rays through them.  Bit exact."""
+import numpy as np
+import pytest
+
+from substrata_amd import abi, scenes
+from helpers import DT
+from test_hull_parity_gpu import hull_descs
+from test_mesh_parity_gpu import grid_mesh, mesh_body
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+def big_clouds(rng):
+    """Point clouds whose hulls keep 40 .. 256 vertices: ellipsoids, a 64-gon prism (128 corners, two faces of 64 corners each -- the manifold
+    clips against every fourth), a tessellated box with noise inside, a capped cone."""
+    out = []
+    for n in (40, 96, 180, 256):
+        p = rng.normal(size=(n, 3)); p /= np.linalg.norm(p, axis=1, keepdims=True)
+        out.append(p * rng.uniform(0.35, 0.8, size=3))
+    a = np.linspace(0, 2 * np.pi, 64, endpoint=False)
+    out.append(np.array([(0.6 * np.cos(t), 0.6 * np.sin(t), z) for z in (-0.3, 0.3) for t in a]))
+    g = np.linspace(-0.5, 0.5, 6)
+    out.append(np.array([(x, y, z) for x in g for y in g for z in g]) * (1.0, 0.7, 0.5))       # 216 points, 8 of them corners
+    out.append(np.array([(0.5 * np.cos(t), 0.5 * np.sin(t), -0.4) for t in a[::2]] + [(0.2 * np.cos(t), 0.2 * np.sin(t), 0.4) for t in a[::2]]))
+    return [np.asarray(p, np.float32) for p in out]
+
+
+def create_all(tw, oracle, clouds):
+    infos = []
+    for pts in clouds:
+        ig, ic = tw.hull_create(pts)
+        assert (ig.hull_id, ig.num_vertices, ig.num_faces, ig.num_edges) == (ic.hull_id, ic.num_vertices, ic.num_faces, ic.num_edges)
+        assert np.array_equal(np.array(ig.com[:]), np.array(ic.com[:])) and np.array_equal(np.array(ig.rot[:]), np.array(ic.rot[:]))
+        assert ig.volume == ic.volume and list(ig.unit_inertia) == list(ic.unit_inertia)
+        assert list(ig.aabb_min) == list(ic.aabb_min) and list(ig.aabb_max) == list(ic.aabb_max)
+        infos.append(ig)
+    return infos
+
+
+def test_big_hull_builder_matches_oracle(oracle):
+    rng = np.random.default_rng(5)
+    tw = parity.make_twin(oracle, max_bodies=64)
+    infos = create_all(tw, oracle, big_clouds(rng))
+    nv = [i.num_vertices for i in infos]
+    assert nv[:4] == [40, 96, 180, 256] and nv[4] == 128 and nv[5] == 8 and nv[6] == 64, nv
+    assert (infos[4].num_faces, infos[4].num_edges) == (66, 192)            # a 64-corner cap is one face
+    tw.close()
+
+
+def test_big_hull_piles_match_oracle(oracle):
+    rng = np.random.default_rng(78)
+    tw = parity.make_twin(oracle, max_bodies=1024)
+    tw.add_batch(scenes.ground())
+    infos = create_all(tw, oracle, big_clouds(rng))
+    n_per = 10
+    total = 1
+    for k, info in enumerate(infos):
+        pos = rng.uniform([-3, -3, 1.0], [3, 3, 12.0], size=(n_per, 3)).astype(np.float32)
+        tw.add_batch(hull_descs(info, pos, rng, mass=60.0))
+        total += n_per
+    mixed = scenes.small_mixed(4, 2, seed=6)[1:]
+    mixed["pos"][:, 2] += 5.0
+    tw.add_batch(mixed)
+    total += len(mixed)
+    for s in range(1, 361):
+        tw.step(DT)
+        if s in (1, 20, 60, 120, 240, 360):
+            d = parity.compare(tw, total)
+            assert d["active_mismatch"] == 0 and d["bit_exact"], (s, d)
+            sg, sc = tw.stats()
+            assert (sg.num_pairs, sg.num_manifolds, sg.num_contact_points) == (sc.num_pairs, sc.num_manifolds, sc.num_contact_points), s
+    st = tw.gpu.read_states(0, total)
+    assert (st["pos"][1:, 2] > 0.05).all() and np.isfinite(st["pos"]).all()
+    sg, _ = tw.stats()
+    assert sg.num_manifolds > 60
+    rays = np.zeros(512, dtype=abi.ray_dtype)
+    rays["origin"] = rng.uniform([-4, -4, 6], [4, 4, 8], size=(512, 3)); rays["dir"] = (0, 0, -1); rays["max_t"] = 20.0; rays["ignore_id"] = abi.INVALID_ID
+    hg, hc = tw.raycast(rays)
+    assert np.array_equal(hg["id"], hc["id"]) and np.array_equal(hg["t"], hc["t"]) and np.array_equal(hg["normal"], hc["normal"])
+    assert (hg["id"] > 0).sum() > 50
+    tw.close()
+
+
+def test_big_hulls_on_a_triangulated_terrain_match_oracle(oracle):
+    rng = np.random.default_rng(79)
+    tw = parity.make_twin(oracle, max_bodies=512)
+    V, T = grid_mesh(25, 8.0, lambda x, y: 0.5 * np.sin(0.6 * x) * np.cos(0.5 * y) + 0.02 * (x * x + y * y))
+    ig, ic = tw.mesh_create(V, T)
+    tw.add_batch(mesh_body(ig))
+    infos = create_all(tw, oracle, big_clouds(rng))
+    total = 3                                                                          # the mesh body and its alias slots
+    for info in infos:
+        pos = rng.uniform([-3, -3, 2.0], [3, 3, 8.0], size=(6, 3)).astype(np.float32)
+        tw.add_batch(hull_descs(info, pos, rng, mass=60.0))
+        total += 6
+    for s in range(1, 301):
+        tw.step(DT)
+        if s in (1, 30, 90, 180, 300):
+            d = parity.compare(tw, total)
+            assert d["active_mismatch"] == 0 and d["bit_exact"], (s, d)
+            sg, sc = tw.stats()
+            assert (sg.num_pairs, sg.num_manifolds, sg.num_contact_points) == (sc.num_pairs, sc.num_manifolds, sc.num_contact_points), s
+    st = tw.gpu.read_states(0, total)
+    assert np.isfinite(st["pos"]).all() and (st["pos"][3:, 2] > -1.0).all()            # nothing fell through the terrain
+    tw.close()
