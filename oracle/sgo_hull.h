@@ -179,6 +179,22 @@ static inline int sgo_hull_axis_edge(const sgo_hview* A, const sgo_hview* B, int
 	return 1;
 }
 
+/* The same for an edge pair the Gauss-map test has picked (a, bb: world normals of the faces either side of A's edge): the two edges ARE what supports the
+   hulls along +-(da x db), so the separation is that of the edges themselves -- no walk over the vertices -- and the axis points the way A's two faces do. */
+static inline int sgo_hull_axis_edge_picked(const sgo_hview* A, const sgo_hview* B, int i, int j, v3 a, v3 bb, v3* ax_out, float* s_out)
+{
+	const v3 da = m33_mul(A->R, v3_sub(sgo_hv_local(A, A->h->edge_b[i]), sgo_hv_local(A, A->h->edge_a[i])));
+	const v3 db = m33_mul(B->R, v3_sub(sgo_hv_local(B, B->h->edge_b[j]), sgo_hv_local(B, B->h->edge_a[j])));
+	v3 ax = v3_cross(da, db);
+	const float l2 = v3_len_sq(ax);
+	if (l2 < 1.0e-6f * v3_len_sq(da) * v3_len_sq(db)) return 0;
+	ax = v3_scale(ax, 1.0f / sqrtf(l2));
+	if (v3_dot(ax, v3_add(a, bb)) < 0.0f) ax = v3_neg(ax);
+	const v3 a0 = sgo_hv_world(A, A->h->edge_a[i]), b0 = sgo_hv_world(B, B->h->edge_a[j]);
+	*ax_out = ax; *s_out = v3_dot(ax, b0) - v3_dot(ax, a0);
+	return 1;
+}
+
 /* Sequential search (first maximum wins).  Returns 0 when some axis separates the hulls by more than max_sep. */
 static inline int sgo_hull_sat_search(const sgo_hview* A, const sgo_hview* B, float max_sep, sgo_hull_sat* r)
 {
@@ -197,25 +213,34 @@ static inline int sgo_hull_sat_search(const sgo_hview* A, const sgo_hview* B, fl
 	if (A->h->ne * B->h->ne > SGO_HULL_GAUSS_MIN_PAIRS) {
 		/* Many edge pairs (a hull beyond 32 vertices is involved; round 5): only the pairs whose cross product can be a face of the Minkowski difference are
 		   evaluated -- the arcs between the normals of the faces either side of edge i of A and of (minus) those either side of edge j of B cross on the unit
-		   sphere (the Gauss-map test; 4 dot products per pair instead of a projection of every vertex of both hulls).  The minimum-penetration axis is a face
+		   sphere (the Gauss-map test; 4 dot products per pair instead of a projection of every vertex of both hulls), and a picked pair's separation is that of
+		   its two edges (sgo_hull_axis_edge_picked).  The minimum-penetration axis is a face
 		   normal of A, of B, or such a pair, so the answer is that of the full search wherever the full search is decided by more than rounding. */
 		v3* na = (v3*)malloc(sizeof(v3) * (size_t)(A->h->nf + B->h->nf + A->h->ne + B->h->ne));
 		v3* nb = na + A->h->nf; v3* ea = nb + B->h->nf; v3* eb = ea + A->h->ne;
 		for (int f = 0; f < A->h->nf; ++f) na[f] = sgo_hv_normal(A, f);
 		for (int f = 0; f < B->h->nf; ++f) nb[f] = v3_neg(sgo_hv_normal(B, f));
-		for (int i = 0; i < A->h->ne; ++i) ea[i] = v3_cross(na[A->h->edge_f1[i]], na[A->h->edge_f0[i]]);
-		for (int j = 0; j < B->h->ne; ++j) eb[j] = v3_cross(nb[B->h->edge_f1[j]], nb[B->h->edge_f0[j]]);
+		for (int i = 0; i < A->h->ne; ++i) ea[i] = A->h->edge_f0[i] == 0xFFFF ? V3(0, 0, 0) : v3_cross(na[A->h->edge_f1[i]], na[A->h->edge_f0[i]]);
+		for (int j = 0; j < B->h->ne; ++j) eb[j] = B->h->edge_f0[j] == 0xFFFF ? V3(0, 0, 0) : v3_cross(nb[B->h->edge_f1[j]], nb[B->h->edge_f0[j]]);
 		int separated = 0;
 		for (int i = 0; i < A->h->ne && !separated; ++i) {
-			const v3 a = na[A->h->edge_f0[i]], bb = na[A->h->edge_f1[i]], bxa = ea[i];
+			const int open_a = A->h->edge_f0[i] == 0xFFFF;      /* (an edge without its two faces, sgo_hull_build.h: its pairs in full) */
+			const v3 a = open_a ? V3(0, 0, 0) : na[A->h->edge_f0[i]], bb = open_a ? V3(0, 0, 0) : na[A->h->edge_f1[i]], bxa = ea[i];
 			for (int j = 0; j < B->h->ne; ++j) {
+				if (open_a || B->h->edge_f0[j] == 0xFFFF) {
+					v3 ax; float s; int sup;
+					if (!sgo_hull_axis_edge(A, B, i, j, T, &ax, &s, &sup)) continue;
+					if (s > max_sep) { separated = 1; break; }
+					if (s > r->sE && sup) { r->sE = s; r->eA = i; r->eB = j; r->nE = ax; }
+					continue;
+				}
 				const v3 c = nb[B->h->edge_f0[j]], dd = nb[B->h->edge_f1[j]], dxc = eb[j];
 				const float cba = v3_dot(c, bxa), dba = v3_dot(dd, bxa), adc = v3_dot(a, dxc), bdc = v3_dot(bb, dxc);
 				if (!(cba * dba < 0.0f && adc * bdc < 0.0f && cba * bdc > 0.0f)) continue;
-				v3 ax; float s; int sup;
-				if (!sgo_hull_axis_edge(A, B, i, j, T, &ax, &s, &sup)) continue;
+				v3 ax; float s;
+				if (!sgo_hull_axis_edge_picked(A, B, i, j, a, bb, &ax, &s)) continue;
 				if (s > max_sep) { separated = 1; break; }
-				if (s > r->sE && sup) { r->sE = s; r->eA = i; r->eB = j; r->nE = ax; }
+				if (s > r->sE) { r->sE = s; r->eA = i; r->eB = j; r->nE = ax; }
 			}
 		}
 		free(na);

@@ -330,13 +330,22 @@ SGP_DEV int hull_sat_search_wave(const sgd_hview* A, const sgd_hview* B, float m
 		// a hull beyond 32 vertices: the edge pairs worth an axis are picked by the Gauss-map test (sgd_hull_sat_search has the words); edge i of A by all lanes,
 		// B's edges dealt to the lanes -- the pair's index i neB + j orders the ties as the sequential search meets them
 		for (int i = 0; i < neA; ++i) {
-			const v3 a = sgd_hv_normal(A, A->h->edge_f0[i]), bb = sgd_hv_normal(A, A->h->edge_f1[i]), bxa = v3_cross(bb, a);
+			const bool open_a = A->h->edge_f0[i] == 0xFFFF;      // (an edge without its two faces, sgp_hull_build.h: its pairs in full)
+			const v3 a = open_a ? V3(0.0f, 0.0f, 0.0f) : sgd_hv_normal(A, A->h->edge_f0[i]), bb = open_a ? V3(0.0f, 0.0f, 0.0f) : sgd_hv_normal(A, A->h->edge_f1[i]), bxa = v3_cross(bb, a);
 			for (int j = lane; j < neB; j += 64) {
+				if (open_a || B->h->edge_f0[j] == 0xFFFF) {
+					v3 ax; float s; int sup;
+					if (sgd_hull_axis_edge(A, B, i, j, T, &ax, &s, &sup)) {
+						if (s > max_sep) separated = true;
+						if (s > sE && sup) { sE = s; iE = i * neB + j; }
+					}
+					continue;
+				}
 				if (!sgd_hull_gauss_pair(B, j, a, bb, bxa)) continue;
-				v3 ax; float s; int sup;
-				if (sgd_hull_axis_edge(A, B, i, j, T, &ax, &s, &sup)) {
+				v3 ax; float s;
+				if (sgd_hull_axis_edge_picked(A, B, i, j, a, bb, &ax, &s)) {
 					if (s > max_sep) separated = true;
-					if (s > sE && sup) { sE = s; iE = i * neB + j; }
+					if (s > sE) { sE = s; iE = i * neB + j; }
 				}
 			}
 		}
@@ -362,8 +371,146 @@ SGP_DEV int hull_sat_search_wave(const sgd_hview* A, const sgd_hview* B, float m
 	r->sE = sE; r->eA = -1; r->eB = -1; r->nE = V3(0.0f, 0.0f, 0.0f);
 	if (iE != 0x7FFFFFFF) {
 		r->eA = iE / neB; r->eB = iE % neB;
+		float s; int sup;      // the axis of the winning pair (same arithmetic as above)
+		if (neA * neB > SGD_HULL_GAUSS_MIN_PAIRS && A->h->edge_f0[r->eA] != 0xFFFF && B->h->edge_f0[r->eB] != 0xFFFF) sgd_hull_axis_edge_picked(A, B, r->eA, r->eB, sgd_hv_normal(A, A->h->edge_f0[r->eA]), sgd_hv_normal(A, A->h->edge_f1[r->eA]), &r->nE, &s);
+		else sgd_hull_axis_edge(A, B, r->eA, r->eB, T, &r->nE, &s, &sup);
+	}
+	return 1;
+}
+
+// A pair with more than SGD_HULL_GAUSS_MIN_PAIRS edge pairs (a hull beyond 32 vertices is involved) by a WORKGROUP of 256 threads (round 5).  The wave search
+// above walks such a pair with two dependent gathers out of the 17 KB hull records per edge pair -- 9 000 iterations a lane for two 256-vertex hulls, each waiting
+// on L2 -- and evaluates a picked pair where it finds it, 63 lanes idle.  Here the world normals of both hulls' faces and A's edges (as the two faces each lies
+// between) are staged in LDS once; a thread keeps one edge of B in registers and walks A's edges against it out of LDS (the Gauss-map test: 4 dot products);
+// the pairs it picks go to a list in LDS and are evaluated afterwards, a thread each.  Same axes, same arithmetic per axis, (largest separation, lowest pair
+// index) as the order of the reduction: the result of sgd_hull_sat_search bit for bit.
+#define HULL_BIG_TPB 256
+#define HULL_BIG_CAND_CAP 2048
+struct HullBigLds {
+	v3 nA[SGD_HULL_MAX_FACES], nB[SGD_HULL_MAX_FACES];      // world normals of A's faces, MINUS those of B's
+	uint32_t eA[SGD_HULL_MAX_EDGES], eB[SGD_HULL_MAX_EDGES]; // edge i: face f0 | face f1 << 16 (0xFFFF: an open edge, sgp_hull_build.h)
+	uint32_t cand[HULL_BIG_CAND_CAP]; uint32_t n_cand;
+	float red_s[3][HULL_BIG_TPB / 64]; int red_i[3][HULL_BIG_TPB / 64]; int separated;
+};
+SGP_DEV bool hull_pair_is_big(const sgd_shape& sa, const sgd_shape& sb)
+{
+	const bool pa = sa.type == SGP_SHAPE_BOX || sa.type == SGP_SHAPE_HULL, pb = sb.type == SGP_SHAPE_BOX || sb.type == SGP_SHAPE_HULL;
+	if (!pa || !pb) return false;
+	const int ea = sa.type == SGP_SHAPE_BOX ? 12 : sa.hull->ne, eb = sb.type == SGP_SHAPE_BOX ? 12 : sb.hull->ne;
+	return ea * eb > SGD_HULL_GAUSS_MIN_PAIRS;
+}
+SGP_DEV int hull_sat_search_block(const sgd_hview* A, const sgd_hview* B, float max_sep, sgd_hull_sat* r, HullBigLds& L)
+{
+	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int nfA = A->h->nf, nfB = B->h->nf, neA = A->h->ne, neB = B->h->ne;
+	const v3 T = v3_sub(B->pos, A->pos);
+	__syncthreads();      // (the previous pair's last readers)
+	for (int f = tid; f < nfA; f += HULL_BIG_TPB) L.nA[f] = sgd_hv_normal(A, f);
+	for (int f = tid; f < nfB; f += HULL_BIG_TPB) L.nB[f] = v3_neg(sgd_hv_normal(B, f));
+	for (int i = tid; i < neA; i += HULL_BIG_TPB) L.eA[i] = (uint32_t)A->h->edge_f0[i] | ((uint32_t)A->h->edge_f1[i] << 16);
+	for (int j = tid; j < neB; j += HULL_BIG_TPB) L.eB[j] = (uint32_t)B->h->edge_f0[j] | ((uint32_t)B->h->edge_f1[j] << 16);
+	if (tid == 0) { L.n_cand = 0u; L.separated = 0; }
+	float sA = -3.4e38f, sB = -3.4e38f, sE = -3.4e38f; int iA = 0x7FFFFFFF, iB = 0x7FFFFFFF, iE = 0x7FFFFFFF;
+	bool separated = false;
+	for (int t = tid; t < nfA + nfB; t += HULL_BIG_TPB) {
+		if (t < nfA) {
+			const float s = sgd_hull_axis_face(A, B, t);
+			if (s > max_sep) separated = true;
+			if (s > sA) { sA = s; iA = t; }
+		} else {
+			const int f = t - nfA;
+			const float s = sgd_hull_axis_face(B, A, f);
+			if (s > max_sep) separated = true;
+			if (s > sB) { sB = s; iB = f; }
+		}
+	}
+	if (__syncthreads_or(separated ? 1 : 0)) return 0;
+	// the edge pairs: B's edge j stays with its thread, A's edges stream by out of LDS
+	for (int j = tid; j < neB; j += HULL_BIG_TPB) {
+		const uint32_t pkb = L.eB[j];
+		if ((pkb & 0xFFFFu) == 0xFFFFu) continue;      // (an open edge: below)
+		const v3 c = L.nB[pkb & 0xFFFFu], dd = L.nB[pkb >> 16];
+		const v3 dxc = v3_cross(dd, c);
+		for (int i = 0; i < neA; ++i) {
+			const uint32_t pk = L.eA[i];
+			if ((pk & 0xFFFFu) == 0xFFFFu) continue;
+			const v3 a = L.nA[pk & 0xFFFFu], bb = L.nA[pk >> 16];
+			const v3 bxa = v3_cross(bb, a);
+			const float cba = v3_dot(c, bxa), dba = v3_dot(dd, bxa), adc = v3_dot(a, dxc), bdc = v3_dot(bb, dxc);
+			if (!(cba * dba < 0.0f && adc * bdc < 0.0f && cba * bdc > 0.0f)) continue;
+			const uint32_t k = atomicAdd(&L.n_cand, 1u);
+			if (k < HULL_BIG_CAND_CAP) L.cand[k] = (uint32_t)(i * neB + j);
+			else {      // (the list is full: this one where it stands)
+				v3 ax; float s;
+				if (sgd_hull_axis_edge_picked(A, B, i, j, a, bb, &ax, &s)) {
+					if (s > max_sep) separated = true;
+					if (s > sE || (s == sE && i * neB + j < iE)) { sE = s; iE = i * neB + j; }
+				}
+			}
+		}
+	}
+	// the pairs of an edge without its two faces (the builder could not tell which faces it lies between: the Gauss-map test does not apply): in full, the
+	// other hull's edges dealt to the threads
+	for (int j = 0; j < neB; ++j) {
+		if ((L.eB[j] & 0xFFFFu) != 0xFFFFu) continue;
+		for (int i = tid; i < neA; i += HULL_BIG_TPB) {
+			v3 ax; float s; int sup;
+			if (sgd_hull_axis_edge(A, B, i, j, T, &ax, &s, &sup)) {
+				if (s > max_sep) separated = true;
+				if (sup && (s > sE || (s == sE && i * neB + j < iE))) { sE = s; iE = i * neB + j; }
+			}
+		}
+	}
+	for (int i = 0; i < neA; ++i) {
+		if ((L.eA[i] & 0xFFFFu) != 0xFFFFu) continue;
+		for (int j = tid; j < neB; j += HULL_BIG_TPB) {
+			if ((L.eB[j] & 0xFFFFu) == 0xFFFFu) continue;      // (done above)
+			v3 ax; float s; int sup;
+			if (sgd_hull_axis_edge(A, B, i, j, T, &ax, &s, &sup)) {
+				if (s > max_sep) separated = true;
+				if (sup && (s > sE || (s == sE && i * neB + j < iE))) { sE = s; iE = i * neB + j; }
+			}
+		}
+	}
+	__syncthreads();
+	const int nc = (int)min(L.n_cand, (uint32_t)HULL_BIG_CAND_CAP);
+	for (int k = tid; k < nc; k += HULL_BIG_TPB) {
+		const int key = (int)L.cand[k], i = key / neB, j = key % neB;
+		const uint32_t pk = L.eA[i];
+		v3 ax; float s;
+		if (sgd_hull_axis_edge_picked(A, B, i, j, L.nA[pk & 0xFFFFu], L.nA[pk >> 16], &ax, &s)) {
+			if (s > max_sep) separated = true;
+			if (s > sE || (s == sE && key < iE)) { sE = s; iE = key; }      // (the list is in no order: the lowest index among equals, as the walk in order keeps it)
+		}
+	}
+	if (__syncthreads_or(separated ? 1 : 0)) return 0;
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) {
+		float os = __shfl_xor(sA, off); int oi = __shfl_xor(iA, off);
+		if (os > sA || (os == sA && oi < iA)) { sA = os; iA = oi; }
+		os = __shfl_xor(sB, off); oi = __shfl_xor(iB, off);
+		if (os > sB || (os == sB && oi < iB)) { sB = os; iB = oi; }
+		os = __shfl_xor(sE, off); oi = __shfl_xor(iE, off);
+		if (os > sE || (os == sE && oi < iE)) { sE = os; iE = oi; }
+	}
+	if (lane == 0) { L.red_s[0][wave] = sA; L.red_i[0][wave] = iA; L.red_s[1][wave] = sB; L.red_i[1][wave] = iB; L.red_s[2][wave] = sE; L.red_i[2][wave] = iE; }
+	__syncthreads();
+	for (int w = 0; w < HULL_BIG_TPB / 64; ++w) {
+		float os = L.red_s[0][w]; int oi = L.red_i[0][w];
+		if (os > sA || (os == sA && oi < iA)) { sA = os; iA = oi; }
+		os = L.red_s[1][w]; oi = L.red_i[1][w];
+		if (os > sB || (os == sB && oi < iB)) { sB = os; iB = oi; }
+		os = L.red_s[2][w]; oi = L.red_i[2][w];
+		if (os > sE || (os == sE && oi < iE)) { sE = os; iE = oi; }
+	}
+	r->sA = sA; r->fA = iA == 0x7FFFFFFF ? 0 : iA; r->sB = sB; r->fB = iB == 0x7FFFFFFF ? 0 : iB;
+	r->sE = sE; r->eA = -1; r->eB = -1; r->nE = V3(0.0f, 0.0f, 0.0f);
+	if (iE != 0x7FFFFFFF) {
+		r->eA = iE / neB; r->eB = iE % neB;
 		float s; int sup;
-		sgd_hull_axis_edge(A, B, r->eA, r->eB, T, &r->nE, &s, &sup);      // the axis of the winning pair (same arithmetic as above)
+		const uint32_t pk = L.eA[r->eA];
+		if ((pk & 0xFFFFu) != 0xFFFFu && (L.eB[r->eB] & 0xFFFFu) != 0xFFFFu) sgd_hull_axis_edge_picked(A, B, r->eA, r->eB, L.nA[pk & 0xFFFFu], L.nA[pk >> 16], &r->nE, &s);
+		else sgd_hull_axis_edge(A, B, r->eA, r->eB, T, &r->nE, &s, &sup);
 	}
 	return 1;
 }

@@ -172,6 +172,22 @@ template <class HA, class HB> SGP_DEV static int sgd_hull_axis_edge(const HA* A,
 	return 1;
 }
 
+// The same for an edge pair the Gauss-map test has picked (a, bb: world normals of the faces either side of A's edge): the two edges ARE what supports the
+// hulls along +-(da x db), so the separation is that of the edges themselves -- no walk over the vertices -- and the axis points the way A's two faces do.
+template <class HA, class HB> SGP_DEV static int sgd_hull_axis_edge_picked(const HA* A, const HB* B, int i, int j, v3 a, v3 bb, v3* ax_out, float* s_out)
+{
+	const v3 da = m33_mul(A->R, v3_sub(sgd_hv_local(A, A->h->edge_b[i]), sgd_hv_local(A, A->h->edge_a[i])));
+	const v3 db = m33_mul(B->R, v3_sub(sgd_hv_local(B, B->h->edge_b[j]), sgd_hv_local(B, B->h->edge_a[j])));
+	v3 ax = v3_cross(da, db);
+	const float l2 = v3_len_sq(ax);
+	if (l2 < 1.0e-6f * v3_len_sq(da) * v3_len_sq(db)) return 0;
+	ax = v3_scale(ax, 1.0f / sqrtf(l2));
+	if (v3_dot(ax, v3_add(a, bb)) < 0.0f) ax = v3_neg(ax);
+	const v3 a0 = sgd_hv_world(A, A->h->edge_a[i]), b0 = sgd_hv_world(B, B->h->edge_a[j]);
+	*ax_out = ax; *s_out = v3_dot(ax, b0) - v3_dot(ax, a0);
+	return 1;
+}
+
 // Gauss-map test of an edge pair: (a, bb) the world normals of the faces either side of A's edge, bxa = bb x a; B's edge j with its (negated) normals.
 template <class HB> SGP_DEV static bool sgd_hull_gauss_pair(const HB* B, int j, v3 a, v3 bb, v3 bxa)
 {
@@ -242,13 +258,21 @@ template <bool DIRCACHE = true, class HA, class HB> SGP_DEV static int sgd_hull_
 			// evaluated -- the arcs between the normals of the faces either side of edge i of A and of (minus) those either side of edge j of B cross on the unit
 			// sphere (the Gauss-map test; 4 dot products per pair instead of a projection of every vertex of both hulls).
 			for (int i = 0; i < A->h->ne; ++i) {
-				const v3 a = sgd_hv_normal(A, A->h->edge_f0[i]), bb = sgd_hv_normal(A, A->h->edge_f1[i]), bxa = v3_cross(bb, a);
+				const bool open_a = A->h->edge_f0[i] == 0xFFFF;      // (an edge without its two faces, sgp_hull_build.h: its pairs in full)
+				const v3 a = open_a ? V3(0.0f, 0.0f, 0.0f) : sgd_hv_normal(A, A->h->edge_f0[i]), bb = open_a ? V3(0.0f, 0.0f, 0.0f) : sgd_hv_normal(A, A->h->edge_f1[i]), bxa = v3_cross(bb, a);
 				for (int j = 0; j < B->h->ne; ++j) {
+					if (open_a || B->h->edge_f0[j] == 0xFFFF) {
+						v3 ax; float s; int sup;
+						if (!sgd_hull_axis_edge(A, B, i, j, T, &ax, &s, &sup)) continue;
+						if (s > max_sep) return 0;
+						if (s > r->sE && sup) { r->sE = s; r->eA = i; r->eB = j; r->nE = ax; }
+						continue;
+					}
 					if (!sgd_hull_gauss_pair(B, j, a, bb, bxa)) continue;
-					v3 ax; float s; int sup;
-					if (!sgd_hull_axis_edge(A, B, i, j, T, &ax, &s, &sup)) continue;
+					v3 ax; float s;
+					if (!sgd_hull_axis_edge_picked(A, B, i, j, a, bb, &ax, &s)) continue;
 					if (s > max_sep) return 0;
-					if (s > r->sE && sup) { r->sE = s; r->eA = i; r->eB = j; r->nE = ax; }
+					if (s > r->sE) { r->sE = s; r->eA = i; r->eB = j; r->nE = ax; }
 				}
 			}
 			return 1;
