@@ -28,8 +28,7 @@
 #define SGO_HULL_MAX_EDGES 768         /* <= 3 V - 6 (+ the diagonals of split faces) */
 #define SGO_HULL_MAX_FACE_IDX 1792     /* sum of the face loops = 2 E */
 #define SGO_HULL_MAX_FACE_VERTS 16
-#define SGO_HULL_GAUSS_MIN_PAIRS 8192   /* more edge pairs than two 32-vertex hulls can have (90 x 90): the Gauss-map test selects the pairs worth an axis */
-#define SGO_HULL_SMALL_VERTS 32        /* up to here the builder and the separating-axis search are those of rounds 1-4, bit for bit */
+#define SGO_HULL_SMALL_VERTS 32        /* up to here the builder and the separating-axis search are those of rounds 1-4, bit for bit; a pair with a larger hull: the Gauss-map test selects the edge pairs worth an axis */
 #define SGO_HULL_CLIP_CAP 24
 
 struct sgo_hull_s {
@@ -210,8 +209,8 @@ static inline int sgo_hull_sat_search(const sgo_hview* A, const sgo_hview* B, fl
 		if (s > r->sB) { r->sB = s; r->fB = f; }
 	}
 	const v3 T = v3_sub(B->pos, A->pos);
-	if (A->h->ne * B->h->ne > SGO_HULL_GAUSS_MIN_PAIRS) {
-		/* Many edge pairs (a hull beyond 32 vertices is involved; round 5): only the pairs whose cross product can be a face of the Minkowski difference are
+	if ((A->h->nv > SGO_HULL_SMALL_VERTS || B->h->nv > SGO_HULL_SMALL_VERTS) && A->h->nv > 3 && B->h->nv > 3) {      /* (not against a mesh triangle's thin hull: its two faces span no arc) */
+		/* A hull beyond 32 vertices is involved (round 5; up to 768 x 768 edge pairs): only the pairs whose cross product can be a face of the Minkowski difference are
 		   evaluated -- the arcs between the normals of the faces either side of edge i of A and of (minus) those either side of edge j of B cross on the unit
 		   sphere (the Gauss-map test; 4 dot products per pair instead of a projection of every vertex of both hulls), and a picked pair's separation is that of
 		   its two edges (sgo_hull_axis_edge_picked).  The minimum-penetration axis is a face

@@ -326,30 +326,7 @@ SGP_DEV int hull_sat_search_wave(const sgd_hview* A, const sgd_hview* B, float m
 		}
 	}
 	if (__any(separated)) return 0;
-	if (neA * neB > SGD_HULL_GAUSS_MIN_PAIRS) {
-		// a hull beyond 32 vertices: the edge pairs worth an axis are picked by the Gauss-map test (sgd_hull_sat_search has the words); edge i of A by all lanes,
-		// B's edges dealt to the lanes -- the pair's index i neB + j orders the ties as the sequential search meets them
-		for (int i = 0; i < neA; ++i) {
-			const bool open_a = A->h->edge_f0[i] == 0xFFFF;      // (an edge without its two faces, sgp_hull_build.h: its pairs in full)
-			const v3 a = open_a ? V3(0.0f, 0.0f, 0.0f) : sgd_hv_normal(A, A->h->edge_f0[i]), bb = open_a ? V3(0.0f, 0.0f, 0.0f) : sgd_hv_normal(A, A->h->edge_f1[i]), bxa = v3_cross(bb, a);
-			for (int j = lane; j < neB; j += 64) {
-				if (open_a || B->h->edge_f0[j] == 0xFFFF) {
-					v3 ax; float s; int sup;
-					if (sgd_hull_axis_edge(A, B, i, j, T, &ax, &s, &sup)) {
-						if (s > max_sep) separated = true;
-						if (s > sE && sup) { sE = s; iE = i * neB + j; }
-					}
-					continue;
-				}
-				if (!sgd_hull_gauss_pair(B, j, a, bb, bxa)) continue;
-				v3 ax; float s;
-				if (sgd_hull_axis_edge_picked(A, B, i, j, a, bb, &ax, &s)) {
-					if (s > max_sep) separated = true;
-					if (s > sE) { sE = s; iE = i * neB + j; }
-				}
-			}
-		}
-	} else
+	// (a pair with a hull beyond 32 vertices never comes here: hull_sat_search_block)
 	for (int e = lane; e < total - nfA - nfB; e += 64) {
 		v3 ax; float s; int sup;
 		if (sgd_hull_axis_edge(A, B, e / neB, e % neB, T, &ax, &s, &sup)) {
@@ -371,14 +348,13 @@ SGP_DEV int hull_sat_search_wave(const sgd_hview* A, const sgd_hview* B, float m
 	r->sE = sE; r->eA = -1; r->eB = -1; r->nE = V3(0.0f, 0.0f, 0.0f);
 	if (iE != 0x7FFFFFFF) {
 		r->eA = iE / neB; r->eB = iE % neB;
-		float s; int sup;      // the axis of the winning pair (same arithmetic as above)
-		if (neA * neB > SGD_HULL_GAUSS_MIN_PAIRS && A->h->edge_f0[r->eA] != 0xFFFF && B->h->edge_f0[r->eB] != 0xFFFF) sgd_hull_axis_edge_picked(A, B, r->eA, r->eB, sgd_hv_normal(A, A->h->edge_f0[r->eA]), sgd_hv_normal(A, A->h->edge_f1[r->eA]), &r->nE, &s);
-		else sgd_hull_axis_edge(A, B, r->eA, r->eB, T, &r->nE, &s, &sup);
+		float s; int sup;
+		sgd_hull_axis_edge(A, B, r->eA, r->eB, T, &r->nE, &s, &sup);      // the axis of the winning pair (same arithmetic as above)
 	}
 	return 1;
 }
 
-// A pair with more than SGD_HULL_GAUSS_MIN_PAIRS edge pairs (a hull beyond 32 vertices is involved) by a WORKGROUP of 256 threads (round 5).  The wave search
+// A pair with a hull beyond 32 vertices (up to 768 x 768 edge pairs; the Gauss-map test picks the ones worth an axis, sgd_hull_sat_search) by a WORKGROUP of 256 threads (round 5).  The wave search
 // above walks such a pair with two dependent gathers out of the 17 KB hull records per edge pair -- 9 000 iterations a lane for two 256-vertex hulls, each waiting
 // on L2 -- and evaluates a picked pair where it finds it, 63 lanes idle.  Here the world normals of both hulls' faces and A's edges (as the two faces each lies
 // between) are staged in LDS once; a thread keeps one edge of B in registers and walks A's edges against it out of LDS (the Gauss-map test: 4 dot products);
@@ -396,8 +372,7 @@ SGP_DEV bool hull_pair_is_big(const sgd_shape& sa, const sgd_shape& sb)
 {
 	const bool pa = sa.type == SGP_SHAPE_BOX || sa.type == SGP_SHAPE_HULL, pb = sb.type == SGP_SHAPE_BOX || sb.type == SGP_SHAPE_HULL;
 	if (!pa || !pb) return false;
-	const int ea = sa.type == SGP_SHAPE_BOX ? 12 : sa.hull->ne, eb = sb.type == SGP_SHAPE_BOX ? 12 : sb.hull->ne;
-	return ea * eb > SGD_HULL_GAUSS_MIN_PAIRS;
+	return (sa.type == SGP_SHAPE_HULL && sa.hull->nv > SGD_HULL_SMALL_VERTS) || (sb.type == SGP_SHAPE_HULL && sb.hull->nv > SGD_HULL_SMALL_VERTS);
 }
 SGP_DEV int hull_sat_search_block(const sgd_hview* A, const sgd_hview* B, float max_sep, sgd_hull_sat* r, HullBigLds& L)
 {

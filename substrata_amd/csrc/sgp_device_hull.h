@@ -15,7 +15,6 @@
 #define SGD_HULL_MAX_EDGES 768         // <= 3 V - 6 (+ the diagonals of split faces)
 #define SGD_HULL_MAX_FACE_IDX 1792     // sum of the face loops = 2 E
 #define SGD_HULL_MAX_FACE_VERTS 16
-#define SGD_HULL_GAUSS_MIN_PAIRS 8192  // more edge pairs than two 32-vertex hulls can have (90 x 90): the Gauss-map test selects the pairs worth an axis
 #define SGD_HULL_SMALL_VERTS 32        // up to here the builder and the separating-axis search are those of rounds 1-4, bit for bit
 #define SGD_HULL_CLIP_CAP 24
 
@@ -253,7 +252,7 @@ template <bool DIRCACHE = true, class HA, class HB> SGP_DEV static int sgd_hull_
 		return 1;
 	}
 	if constexpr (std::is_same<HA, sgd_hview>::value && std::is_same<HB, sgd_hview>::value) {
-		if (A->h->ne * B->h->ne > SGD_HULL_GAUSS_MIN_PAIRS) {
+		if (A->h->nv > SGD_HULL_SMALL_VERTS || B->h->nv > SGD_HULL_SMALL_VERTS) {
 			// Many edge pairs (a hull beyond 32 vertices is involved; round 5): only the pairs whose cross product can be a face of the Minkowski difference are
 			// evaluated -- the arcs between the normals of the faces either side of edge i of A and of (minus) those either side of edge j of B cross on the unit
 			// sphere (the Gauss-map test; 4 dot products per pair instead of a projection of every vertex of both hulls).

@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(64, 3) k_narrowphase_hull(DV d)
 	}
 }
 
-// The pairs k_narrowphase_hull leaves out: more than SGD_HULL_GAUSS_MIN_PAIRS edge pairs (a hull of more than 32 vertices against a hull or a box), a workgroup
+// The pairs k_narrowphase_hull leaves out: a hull of more than 32 vertices against a hull or a box, a workgroup
 // per pair (hull_sat_search_block).  Launched only in worlds that hold such a hull; in the in-step activation round the list holds nothing else.
 __global__ void __launch_bounds__(HULL_BIG_TPB) k_narrowphase_hull_big(DV d)
 {

@@ -131,3 +131,43 @@ def test_edges_without_their_two_faces_are_searched_in_full(oracle, monkeypatch)
             sg, sc = tw.stats()
             assert (sg.num_pairs, sg.num_manifolds, sg.num_contact_points) == (sc.num_pairs, sc.num_manifolds, sc.num_contact_points), s
     tw.close()
+
+
+def test_sleeping_big_hulls_are_woken_and_collide_in_the_same_step(oracle):
+    """The in-step activation round with pairs of big hulls: k_narrowphase_wake hands them to the list, k_narrowphase_hull_big and the manifold kernel run once
+    more.  A stack of three 200-vertex hulls (a squashed ellipsoid: it stacks) sleeps; a ball dropped on it wakes all of it in the step of the touch."""
+    from helpers import add_ground, dyn
+    rng = np.random.default_rng(81)
+    tw = parity.make_twin(oracle, max_bodies=64)
+    p = rng.normal(size=(200, 3)); p /= np.linalg.norm(p, axis=1, keepdims=True)
+    ig, ic = tw.hull_create((p * (0.8, 0.7, 0.25)).astype(np.float32))
+    assert ig.num_vertices == ic.num_vertices == 200
+    for w in (tw.gpu, tw.cpu):
+        add_ground(w)
+    d = scenes.dynamic_bodies(3, mass=60.0)
+    d["shape_type"] = abi.SHAPE_HULL; d["shape"][:] = 0; d["shape"][:, 0] = float(ig.hull_id)
+    R = np.array(ig.rot[:]); d["rot"][:] = (-R[0], -R[1], -R[2], R[3])                 # (the hull's frame turned back: flat side down)
+    d["pos"] = [(0.0, 0.0, 0.3), (0.03, 0.02, 0.85), (-0.02, 0.03, 1.4)]
+    ids_g, ids_c = tw.add_batch(d)
+    assert np.array_equal(ids_g, ids_c)
+    for s in range(500):
+        tw.step(DT)
+    n = 4
+    dd = parity.compare(tw, n)
+    assert dd["bit_exact"] and dd["active_mismatch"] == 0
+    assert not any(x["active"] for x in tw.gpu.get_state(list(ids_g))), "the stack should be asleep"
+    ball = [dyn(w, abi.SHAPE_SPHERE, (0.25,), pos=(0.05, 0.0, 3.0), mass=20.0) for w in (tw.gpu, tw.cpu)]
+    assert ball[0] == ball[1]
+    touched = None
+    for s in range(90):
+        tw.step(DT)
+        sg, sc = tw.gpu.stats(), tw.cpu.stats()
+        assert (sg.num_pairs, sg.num_wake_pairs, sg.num_manifolds, sg.num_contact_points) == (sc.num_pairs, sc.num_wake_pairs, sc.num_manifolds, sc.num_contact_points), s
+        dd = parity.compare(tw, n + 1)
+        assert dd["bit_exact"] and dd["active_mismatch"] == 0, (s, dd)
+        if touched is None and tw.gpu.get_state([int(ids_g[-1])])[0]["active"]:
+            touched = s
+            assert all(x["active"] for x in tw.gpu.get_state(list(ids_g)))
+            assert sg.num_wake_pairs >= 3 and sg.num_manifolds >= 4                 # ball - hull, two hull - hull, hull - ground: the sleeping ones through the second round
+    assert touched is not None
+    tw.close()
