@@ -209,6 +209,51 @@ static inline int sgo_hull_sat_search(const sgo_hview* A, const sgo_hview* B, fl
 		if (s > r->sB) { r->sB = s; r->fB = f; }
 	}
 	const v3 T = v3_sub(B->pos, A->pos);
+	if (A->h->nv == 3 && A->h->nf == 2 && B->h->nv > SGO_HULL_SMALL_VERTS && !getenv("SGO_HULL_TRIANGLE_FULL_SEARCH")) {      /* (the variable: tests/test_oracle_hull.py compares with the full search) */
+		/* A mesh triangle against a hull beyond 32 vertices (round 5): 3 x up to 768 edge pairs, each a walk over every vertex in the full search.  The Gauss-map
+		   test for a triangle: edge k supports the triangle along the directions of the half circle about it through its outward in-plane normal m_k (from the
+		   triangle's normal to its opposite); edge j of the hull supports the hull along minus the arc between its two faces' normals.  The two meet -- the pair
+		   is a face of the Minkowski difference -- when the arc crosses the plane perpendicular to edge k on m_k's side.  In the hull's frame (its normals as
+		   stored); a picked pair's axis and separation from its two edges.  Hull edge outermost: its normals are fetched once for the three triangle edges. */
+		const v3 nT = sgo_hv_normal(A, 0);
+		v3 da[3], dal[3], ml[3];
+		for (int k = 0; k < 3; ++k) {
+			const int ia = A->h->edge_a[k], ib = A->h->edge_b[k], io = 3 - ia - ib;
+			da[k] = m33_mul(A->R, v3_sub(sgo_hv_local(A, ib), sgo_hv_local(A, ia)));
+			v3 m = v3_cross(da[k], nT);
+			if (v3_dot(m, v3_sub(sgo_hv_world(A, ia), sgo_hv_world(A, io))) < 0.0f) m = v3_neg(m);
+			dal[k] = m33_tmul(B->R, da[k]); ml[k] = m33_tmul(B->R, m);
+		}
+		for (int j = 0; j < B->h->ne; ++j) {
+			if (B->h->edge_f0[j] == 0xFFFF) {      /* (an edge without its two faces: its three pairs in full) */
+				for (int k = 0; k < 3; ++k) {
+					v3 ax; float s; int sup;
+					if (!sgo_hull_axis_edge(A, B, k, j, T, &ax, &s, &sup)) continue;
+					if (s > max_sep) return 0;
+					if (s > r->sE && sup) { r->sE = s; r->eA = k; r->eB = j; r->nE = ax; }
+				}
+				continue;
+			}
+			const v3 c = v3_neg(B->h->normals[B->h->edge_f0[j]]), dd = v3_neg(B->h->normals[B->h->edge_f1[j]]);
+			for (int k = 0; k < 3; ++k) {
+				const float cd = v3_dot(c, dal[k]), ddd = v3_dot(dd, dal[k]);
+				if (!(cd * ddd < 0.0f)) continue;
+				const v3 x = v3_add(v3_scale(c, fabsf(ddd)), v3_scale(dd, fabsf(cd)));      /* (where the arc crosses the plane: the Minkowski face's normal, hull frame) */
+				if (!(v3_dot(x, ml[k]) > 0.0f)) continue;
+				const v3 db = m33_mul(B->R, v3_sub(sgo_hv_local(B, B->h->edge_b[j]), sgo_hv_local(B, B->h->edge_a[j])));
+				v3 ax = v3_cross(da[k], db);
+				const float l2 = v3_len_sq(ax);
+				if (l2 < 1.0e-6f * v3_len_sq(da[k]) * v3_len_sq(db)) continue;
+				ax = v3_scale(ax, 1.0f / sqrtf(l2));
+				if (v3_dot(m33_tmul(B->R, ax), x) < 0.0f) ax = v3_neg(ax);
+				const v3 a0 = sgo_hv_world(A, A->h->edge_a[k]), b0 = sgo_hv_world(B, B->h->edge_a[j]);
+				const float s = v3_dot(ax, b0) - v3_dot(ax, a0);
+				if (s > max_sep) return 0;
+				if (s > r->sE) { r->sE = s; r->eA = k; r->eB = j; r->nE = ax; }
+			}
+		}
+		return 1;
+	}
 	if ((A->h->nv > SGO_HULL_SMALL_VERTS || B->h->nv > SGO_HULL_SMALL_VERTS) && A->h->nv > 3 && B->h->nv > 3) {      /* (not against a mesh triangle's thin hull: its two faces span no arc) */
 		/* A hull beyond 32 vertices is involved (round 5; up to 768 x 768 edge pairs): only the pairs whose cross product can be a face of the Minkowski difference are
 		   evaluated -- the arcs between the normals of the faces either side of edge i of A and of (minus) those either side of edge j of B cross on the unit

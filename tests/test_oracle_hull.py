@@ -186,3 +186,52 @@ def test_large_point_cloud_uses_every_vertex(oracle):
     info2 = w.hull_create(pts[rng.permutation(len(pts))])
     assert abs(info2.volume - info.volume) < 1e-4
     w.close()
+
+
+def test_triangle_against_a_big_hull_picks_the_axes_of_the_full_search(oracle, monkeypatch):
+    """A mesh triangle against a hull beyond 32 vertices: the Gauss-map selection of edge pairs (sgo_hull_sat_search, thin A) against the full search over
+    all 3 x E pairs (SGO_HULL_TRIANGLE_FULL_SEARCH) -- one step from the same state, for hulls thrown at the edges and corners of a coarse, folded mesh, must
+    leave the same contact counts and the same velocities to rounding."""
+    from test_mesh_parity_gpu import grid_mesh, mesh_body
+    from test_hull_parity_gpu import hull_descs
+    rng = np.random.default_rng(12)
+    V, T = grid_mesh(13, 9.0, lambda x, y: 0.8 * np.abs(np.sin(1.3 * x)) + 0.5 * np.abs(np.cos(1.1 * y)))      # 1.5 m triangles, ridges and valleys: edge and corner contacts
+    clouds = []
+    for n in (60, 150, 256):
+        p = rng.normal(size=(n, 3)); p /= np.linalg.norm(p, axis=1, keepdims=True)
+        clouds.append((p * rng.uniform(0.3, 0.7, size=3)).astype(np.float32))
+    a = np.linspace(0, 2 * np.pi, 40, endpoint=False)
+    clouds.append(np.array([(0.5 * np.cos(t), 0.5 * np.sin(t), z) for z in (-0.25, 0.25) for t in a], np.float32))
+    checked = 0
+    for trial in range(10):
+        res = []
+        for full in (False, True):
+            if full:
+                monkeypatch.setenv("SGO_HULL_TRIANGLE_FULL_SEARCH", "1")
+            else:
+                monkeypatch.delenv("SGO_HULL_TRIANGLE_FULL_SEARCH", raising=False)
+            r2 = np.random.default_rng(100 + trial)
+            w = oracle.OracleWorld(max_bodies=64)
+            w.add_batch(mesh_body(w.mesh_create(V, T)))
+            n_b = 0
+            for pts in clouds:
+                info = w.hull_create(pts)
+                k0 = n_b                                                      # (a place of its own for every body: the contacts are with the mesh)
+                pos = np.array([((k0 + q) % 4 * 4.0 - 6.0 + r2.uniform(-1, 1), (k0 + q) // 4 * 4.0 - 4.0 + r2.uniform(-1, 1), r2.uniform(2.0, 2.6)) for q in range(3)], np.float32)
+                d = hull_descs(info, pos, r2, mass=40.0)
+                d["lin_vel"][:, 2] = -3.0
+                w.add_batch(d); n_b += 3
+            hist = []
+            for s in range(40):
+                w.step(1 / 60)
+                st = w.stats()
+                hist.append((st.num_manifolds, st.num_contact_points))
+                if st.num_manifolds >= 8:
+                    break
+            res.append((hist, w.read_states(0, 3 + n_b)))
+            w.close()
+        (h0, s0), (h1, s1) = res
+        assert h0 == h1, (trial, h0, h1)
+        assert np.max(np.abs(s0["lin_vel"] - s1["lin_vel"])) < 2e-3 and np.max(np.abs(s0["pos"] - s1["pos"])) < 2e-4, trial
+        checked += h0[-1][0] >= 1
+    assert checked >= 6
