@@ -221,8 +221,10 @@ template <int MESH_GROUP, int KINDS = SGD_KINDS_ALL> SGP_DEV void mesh_pair_grou
 	}
 	__syncthreads();
 	nc = valid ? (int)min(L.n_found, (uint32_t)MESH_LDS_T(MESH_GROUP, KINDS)::CAP) : 0;
-	if (MESH_GROUP != 64 && nc > MESH_BIG_MIN) {
-		// too many triangles for eight lanes: the wave-per-pair launch takes the pair (and finds its candidates again)
+	if (MESH_GROUP != 64 && (nc > MESH_BIG_MIN || (nc > 0 && X.hull && X.hull->nv > SGD_HULL_SMALL_VERTS))) {
+		// too many triangles for eight lanes: the wave-per-pair launch takes the pair (and finds its candidates again).  So does a hull beyond 32 vertices whatever
+		// the count (round 5): one triangle against it is a walk over up to 768 edges, and a lane per triangle with the hull's record in LDS ends after one
+		// such walk where eight lanes take turns (24 hulls of 256 vertices on a terrain: narrow phase 2.8 ms -> see docs/KERNELS.md)
 		if (sub == 0) { const uint32_t kb = atomicAdd(&d.ctr->n_mesh_big, 1u); if (kb < d.cap_mesh_pairs) d.mesh_big[kb] = pair; else atomicAdd(&d.ctr->pairs_dropped, 1u); }      // (four lists feed this one: bounded like them, the excess is counted)
 		valid = false; nc = 0; dropped = false;
 	}
