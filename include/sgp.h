@@ -416,7 +416,7 @@ int  sgp_raycast(sgp_world* w, const sgp_ray* rays, uint32_t n, sgp_hit* hits_ou
 /* ---- convex hull shapes ---------------------------------------------------------
  * Replaces JPH::ConvexHullShapeSettings(points).Create() (+ OffsetCenterOfMassShape / the principal-axes decomposition Jolt does
  * inside MassProperties) for dynamic meshes and vehicle bodies (gui_client/PhysicsWorld.cpp:735-1166 with is_dynamic,
- * CarPhysics.cpp:66-92, BikePhysics.cpp:76-112).  Up to 32 hull vertices / 60 faces / 16 vertices per face; larger clouds are
+ * CarPhysics.cpp:66-92, BikePhysics.cpp:76-112).  Up to 256 hull vertices / 512 faces / 768 edges (JPH::ConvexHullShape::cMaxPointsInHull; 32 / 60 before round 5); larger clouds are
  * reduced to their extreme points (every input point takes part, up to 100000).  Points must already carry the object's scale (ScaledShape is baked in).
  * The hull is stored in its BODY frame (origin = centre of mass, axes = principal axes of inertia).  `com` / `rot` give that
  * frame in the frame of the input points:  input point = com + rot * body point.  A caller that thinks in the points' frame

@@ -79,8 +79,8 @@ def world_collide_pair(world, a, b, max_sep=0.02):
 
 def hull_dump(world, hull_id):
     """The hull as stored (body frame): (verts[nv,3], planes[nf,4])."""
-    v = np.zeros((32, 3), np.float32)
-    pl = np.zeros((60, 4), np.float32)
+    v = np.zeros((256, 3), np.float32)
+    pl = np.zeros((512, 4), np.float32)
     f = lib().sgo_hull_dump
     f.restype = C.c_int
     f.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]

@@ -20,21 +20,24 @@
 #define SGO_HULL_H
 
 #include "sgo_math.h"
+#include <stdlib.h>
 /* (included from sgo_collide.h after sgo_manifold, SGO_CAPSULE_SLOP and sgo_closest_on_segment are defined) */
 
-#define SGO_HULL_MAX_VERTS 32
-#define SGO_HULL_MAX_FACES 60
-#define SGO_HULL_MAX_EDGES 90
-#define SGO_HULL_MAX_FACE_IDX 180
+#define SGO_HULL_MAX_VERTS 256         /* JPH::ConvexHullShape::cMaxPointsInHull (round 5; rounds 1-4 kept 32) */
+#define SGO_HULL_MAX_FACES 512         /* <= 2 V - 4 triangles, fewer once coplanar ones are merged; faces of more than 16 corners are split */
+#define SGO_HULL_MAX_EDGES 768         /* <= 3 V - 6 (+ the diagonals of split faces) */
+#define SGO_HULL_MAX_FACE_IDX 1792     /* sum of the face loops = 2 E */
 #define SGO_HULL_MAX_FACE_VERTS 16
+#define SGO_HULL_SMALL_VERTS 32        /* up to here the builder and the separating-axis search are those of rounds 1-4, bit for bit; a pair with a larger hull: the Gauss-map test selects the edge pairs worth an axis */
 #define SGO_HULL_CLIP_CAP 24
 
 struct sgo_hull_s {
 	int nv, nf, ne, is_box_template;
 	v3 verts[SGO_HULL_MAX_VERTS];
 	v3 normals[SGO_HULL_MAX_FACES]; float plane_d[SGO_HULL_MAX_FACES];       /* inside: n.x <= d */
-	unsigned char face_start[SGO_HULL_MAX_FACES + 1]; unsigned char face_idx[SGO_HULL_MAX_FACE_IDX];   /* CCW seen from outside */
+	unsigned short face_start[SGO_HULL_MAX_FACES + 1]; unsigned char face_idx[SGO_HULL_MAX_FACE_IDX];   /* CCW seen from outside */
 	unsigned char edge_a[SGO_HULL_MAX_EDGES], edge_b[SGO_HULL_MAX_EDGES];
+	unsigned short edge_f0[SGO_HULL_MAX_EDGES], edge_f1[SGO_HULL_MAX_EDGES];   /* the two faces an edge lies between: f0 has it as a -> b, f1 as b -> a (Gauss-map test of edge pairs) */
 	v3 aabb_min, aabb_max;
 	float bound_radius, volume;
 	v3 unit_inertia;                   /* principal moments for density 1 */
@@ -175,6 +178,22 @@ static inline int sgo_hull_axis_edge(const sgo_hview* A, const sgo_hview* B, int
 	return 1;
 }
 
+/* The same for an edge pair the Gauss-map test has picked (a, bb: world normals of the faces either side of A's edge): the two edges ARE what supports the
+   hulls along +-(da x db), so the separation is that of the edges themselves -- no walk over the vertices -- and the axis points the way A's two faces do. */
+static inline int sgo_hull_axis_edge_picked(const sgo_hview* A, const sgo_hview* B, int i, int j, v3 a, v3 bb, v3* ax_out, float* s_out)
+{
+	const v3 da = m33_mul(A->R, v3_sub(sgo_hv_local(A, A->h->edge_b[i]), sgo_hv_local(A, A->h->edge_a[i])));
+	const v3 db = m33_mul(B->R, v3_sub(sgo_hv_local(B, B->h->edge_b[j]), sgo_hv_local(B, B->h->edge_a[j])));
+	v3 ax = v3_cross(da, db);
+	const float l2 = v3_len_sq(ax);
+	if (l2 < 1.0e-6f * v3_len_sq(da) * v3_len_sq(db)) return 0;
+	ax = v3_scale(ax, 1.0f / sqrtf(l2));
+	if (v3_dot(ax, v3_add(a, bb)) < 0.0f) ax = v3_neg(ax);
+	const v3 a0 = sgo_hv_world(A, A->h->edge_a[i]), b0 = sgo_hv_world(B, B->h->edge_a[j]);
+	*ax_out = ax; *s_out = v3_dot(ax, b0) - v3_dot(ax, a0);
+	return 1;
+}
+
 /* Sequential search (first maximum wins).  Returns 0 when some axis separates the hulls by more than max_sep. */
 static inline int sgo_hull_sat_search(const sgo_hview* A, const sgo_hview* B, float max_sep, sgo_hull_sat* r)
 {
@@ -190,6 +209,87 @@ static inline int sgo_hull_sat_search(const sgo_hview* A, const sgo_hview* B, fl
 		if (s > r->sB) { r->sB = s; r->fB = f; }
 	}
 	const v3 T = v3_sub(B->pos, A->pos);
+	if (A->h->nv == 3 && A->h->nf == 2 && B->h->nv > SGO_HULL_SMALL_VERTS && !getenv("SGO_HULL_TRIANGLE_FULL_SEARCH")) {      /* (the variable: tests/test_oracle_hull.py compares with the full search) */
+		/* A mesh triangle against a hull beyond 32 vertices (round 5): 3 x up to 768 edge pairs, each a walk over every vertex in the full search.  The Gauss-map
+		   test for a triangle: edge k supports the triangle along the directions of the half circle about it through its outward in-plane normal m_k (from the
+		   triangle's normal to its opposite); edge j of the hull supports the hull along minus the arc between its two faces' normals.  The two meet -- the pair
+		   is a face of the Minkowski difference -- when the arc crosses the plane perpendicular to edge k on m_k's side.  In the hull's frame (its normals as
+		   stored); a picked pair's axis and separation from its two edges.  Hull edge outermost: its normals are fetched once for the three triangle edges. */
+		const v3 nT = sgo_hv_normal(A, 0);
+		v3 da[3], dal[3], ml[3];
+		for (int k = 0; k < 3; ++k) {
+			const int ia = A->h->edge_a[k], ib = A->h->edge_b[k], io = 3 - ia - ib;
+			da[k] = m33_mul(A->R, v3_sub(sgo_hv_local(A, ib), sgo_hv_local(A, ia)));
+			v3 m = v3_cross(da[k], nT);
+			if (v3_dot(m, v3_sub(sgo_hv_world(A, ia), sgo_hv_world(A, io))) < 0.0f) m = v3_neg(m);
+			dal[k] = m33_tmul(B->R, da[k]); ml[k] = m33_tmul(B->R, m);
+		}
+		for (int j = 0; j < B->h->ne; ++j) {
+			if (B->h->edge_f0[j] == 0xFFFF) {      /* (an edge without its two faces: its three pairs in full) */
+				for (int k = 0; k < 3; ++k) {
+					v3 ax; float s; int sup;
+					if (!sgo_hull_axis_edge(A, B, k, j, T, &ax, &s, &sup)) continue;
+					if (s > max_sep) return 0;
+					if (s > r->sE && sup) { r->sE = s; r->eA = k; r->eB = j; r->nE = ax; }
+				}
+				continue;
+			}
+			const v3 c = v3_neg(B->h->normals[B->h->edge_f0[j]]), dd = v3_neg(B->h->normals[B->h->edge_f1[j]]);
+			for (int k = 0; k < 3; ++k) {
+				const float cd = v3_dot(c, dal[k]), ddd = v3_dot(dd, dal[k]);
+				if (!(cd * ddd < 0.0f)) continue;
+				const v3 x = v3_add(v3_scale(c, fabsf(ddd)), v3_scale(dd, fabsf(cd)));      /* (where the arc crosses the plane: the Minkowski face's normal, hull frame) */
+				if (!(v3_dot(x, ml[k]) > 0.0f)) continue;
+				const v3 db = m33_mul(B->R, v3_sub(sgo_hv_local(B, B->h->edge_b[j]), sgo_hv_local(B, B->h->edge_a[j])));
+				v3 ax = v3_cross(da[k], db);
+				const float l2 = v3_len_sq(ax);
+				if (l2 < 1.0e-6f * v3_len_sq(da[k]) * v3_len_sq(db)) continue;
+				ax = v3_scale(ax, 1.0f / sqrtf(l2));
+				if (v3_dot(m33_tmul(B->R, ax), x) < 0.0f) ax = v3_neg(ax);
+				const v3 a0 = sgo_hv_world(A, A->h->edge_a[k]), b0 = sgo_hv_world(B, B->h->edge_a[j]);
+				const float s = v3_dot(ax, b0) - v3_dot(ax, a0);
+				if (s > max_sep) return 0;
+				if (s > r->sE) { r->sE = s; r->eA = k; r->eB = j; r->nE = ax; }
+			}
+		}
+		return 1;
+	}
+	if ((A->h->nv > SGO_HULL_SMALL_VERTS || B->h->nv > SGO_HULL_SMALL_VERTS) && A->h->nv > 3 && B->h->nv > 3) {      /* (not against a mesh triangle's thin hull: its two faces span no arc) */
+		/* A hull beyond 32 vertices is involved (round 5; up to 768 x 768 edge pairs): only the pairs whose cross product can be a face of the Minkowski difference are
+		   evaluated -- the arcs between the normals of the faces either side of edge i of A and of (minus) those either side of edge j of B cross on the unit
+		   sphere (the Gauss-map test; 4 dot products per pair instead of a projection of every vertex of both hulls), and a picked pair's separation is that of
+		   its two edges (sgo_hull_axis_edge_picked).  The minimum-penetration axis is a face
+		   normal of A, of B, or such a pair, so the answer is that of the full search wherever the full search is decided by more than rounding. */
+		v3* na = (v3*)malloc(sizeof(v3) * (size_t)(A->h->nf + B->h->nf + A->h->ne + B->h->ne));
+		v3* nb = na + A->h->nf; v3* ea = nb + B->h->nf; v3* eb = ea + A->h->ne;
+		for (int f = 0; f < A->h->nf; ++f) na[f] = sgo_hv_normal(A, f);
+		for (int f = 0; f < B->h->nf; ++f) nb[f] = v3_neg(sgo_hv_normal(B, f));
+		for (int i = 0; i < A->h->ne; ++i) ea[i] = A->h->edge_f0[i] == 0xFFFF ? V3(0, 0, 0) : v3_cross(na[A->h->edge_f1[i]], na[A->h->edge_f0[i]]);
+		for (int j = 0; j < B->h->ne; ++j) eb[j] = B->h->edge_f0[j] == 0xFFFF ? V3(0, 0, 0) : v3_cross(nb[B->h->edge_f1[j]], nb[B->h->edge_f0[j]]);
+		int separated = 0;
+		for (int i = 0; i < A->h->ne && !separated; ++i) {
+			const int open_a = A->h->edge_f0[i] == 0xFFFF;      /* (an edge without its two faces, sgo_hull_build.h: its pairs in full) */
+			const v3 a = open_a ? V3(0, 0, 0) : na[A->h->edge_f0[i]], bb = open_a ? V3(0, 0, 0) : na[A->h->edge_f1[i]], bxa = ea[i];
+			for (int j = 0; j < B->h->ne; ++j) {
+				if (open_a || B->h->edge_f0[j] == 0xFFFF) {
+					v3 ax; float s; int sup;
+					if (!sgo_hull_axis_edge(A, B, i, j, T, &ax, &s, &sup)) continue;
+					if (s > max_sep) { separated = 1; break; }
+					if (s > r->sE && sup) { r->sE = s; r->eA = i; r->eB = j; r->nE = ax; }
+					continue;
+				}
+				const v3 c = nb[B->h->edge_f0[j]], dd = nb[B->h->edge_f1[j]], dxc = eb[j];
+				const float cba = v3_dot(c, bxa), dba = v3_dot(dd, bxa), adc = v3_dot(a, dxc), bdc = v3_dot(bb, dxc);
+				if (!(cba * dba < 0.0f && adc * bdc < 0.0f && cba * bdc > 0.0f)) continue;
+				v3 ax; float s;
+				if (!sgo_hull_axis_edge_picked(A, B, i, j, a, bb, &ax, &s)) continue;
+				if (s > max_sep) { separated = 1; break; }
+				if (s > r->sE) { r->sE = s; r->eA = i; r->eB = j; r->nE = ax; }
+			}
+		}
+		free(na);
+		return !separated;
+	}
 	for (int i = 0; i < A->h->ne; ++i) {
 		for (int j = 0; j < B->h->ne; ++j) {
 			v3 ax; float s; int sup;
@@ -210,11 +310,13 @@ static inline int sgo_hull_face_contact(const sgo_hview* X, const sgo_hview* Y, 
 	for (int f = 0; f < Y->h->nf; ++f) { const float d = v3_dot(nref, sgo_hv_normal(Y, f)); if (d < bestd) { bestd = d; fY = f; } }
 	v3 poly[SGO_HULL_CLIP_CAP], tmp[SGO_HULL_CLIP_CAP];
 	int np = 0;
-	for (int k = Y->h->face_start[fY]; k < Y->h->face_start[fY + 1]; ++k) poly[np++] = sgo_hv_world(Y, Y->h->face_idx[k]);
-	const int x0 = X->h->face_start[fX], x1 = X->h->face_start[fX + 1];
-	for (int k = x0; k < x1 && np > 0; ++k) {
+	/* (a face of more than SGO_HULL_MAX_FACE_VERTS corners takes part with every step-th of them: the polygon inscribed in it) */
+	const int y0 = Y->h->face_start[fY], y1 = Y->h->face_start[fY + 1], ystep = (y1 - y0 + SGO_HULL_MAX_FACE_VERTS - 1) / SGO_HULL_MAX_FACE_VERTS;
+	for (int k = y0; k < y1; k += ystep) poly[np++] = sgo_hv_world(Y, Y->h->face_idx[k]);
+	const int x0 = X->h->face_start[fX], x1 = X->h->face_start[fX + 1], xstep = (x1 - x0 + SGO_HULL_MAX_FACE_VERTS - 1) / SGO_HULL_MAX_FACE_VERTS;
+	for (int k = x0; k < x1 && np > 0; k += xstep) {
 		const v3 a = sgo_hv_world(X, X->h->face_idx[k]);
-		const v3 b = sgo_hv_world(X, X->h->face_idx[k + 1 < x1 ? k + 1 : x0]);
+		const v3 b = sgo_hv_world(X, X->h->face_idx[k + xstep < x1 ? k + xstep : x0]);
 		const v3 side = v3_cross(v3_sub(b, a), nref);
 		np = sgo_hull_clip(poly, np, a, side, tmp);
 		for (int i = 0; i < np; ++i) poly[i] = tmp[i];

@@ -1592,17 +1592,23 @@ static void hull_submerged(const sgo_hull* hl, m33 R, float posz, float wz, floa
 	float vol = 0.0f; v3 cen = V3(0, 0, 0);
 	for (int f = 0; f < hl->nf; ++f) {
 		const int b0 = hl->face_start[f], cnt = hl->face_start[f + 1] - b0;
-		v3 poly[SGO_HULL_MAX_FACE_VERTS + 2]; int np = 0;
+		/* (the clipped polygon is fanned as its corners come: first corner, previous corner, this corner -- a face holds up to 256 of them) */
+		v3 p0 = V3(0, 0, 0), pp = V3(0, 0, 0); int np = 0;
 		for (int k = 0; k < cnt; ++k) {
 			const v3 a = hl->verts[hl->face_idx[b0 + k]], c = hl->verts[hl->face_idx[b0 + (k + 1) % cnt]];
 			const float da = v3_dot(n, a) - d, dc = v3_dot(n, c) - d;
-			if (da <= 0.0f) poly[np++] = v3_sub(a, apex);
-			if ((da <= 0.0f) != (dc <= 0.0f)) { const float t = da / (da - dc); poly[np++] = v3_sub(v3_add(a, v3_scale(v3_sub(c, a), t)), apex); }
-		}
-		for (int k = 1; k + 1 < np; ++k) {
-			const float tv = v3_dot(poly[0], v3_cross(poly[k], poly[k + 1])) / 6.0f;
-			vol += tv;
-			cen = v3_add(cen, v3_scale(v3_add(v3_add(poly[0], poly[k]), poly[k + 1]), tv * 0.25f));
+			v3 q[2]; int nq = 0;
+			if (da <= 0.0f) q[nq++] = v3_sub(a, apex);
+			if ((da <= 0.0f) != (dc <= 0.0f)) { const float t = da / (da - dc); q[nq++] = v3_sub(v3_add(a, v3_scale(v3_sub(c, a), t)), apex); }
+			for (int i = 0; i < nq; ++i) {
+				if (np == 0) p0 = q[i];
+				else if (np >= 2) {
+					const float tv = v3_dot(p0, v3_cross(pp, q[i])) / 6.0f;
+					vol += tv;
+					cen = v3_add(cen, v3_scale(v3_add(v3_add(p0, pp), q[i]), tv * 0.25f));
+				}
+				pp = q[i]; ++np;
+			}
 		}
 	}
 	*vol_out = vol;

@@ -89,7 +89,7 @@ template <int G, bool HULL = (G == 64)> struct MeshPairLds {
 	sgd_mesh_contacts mc;
 	typename std::conditional<HULL, sgd_hull, MeshNoHull>::type hull;      // the body's polytope (cube template / convex hull) next to the lanes that walk its vertices once per axis
 };
-#define MESH_LDS_T(G, KINDS) MeshPairLds<G, (G) == 64 || (KINDS) == 8>
+#define MESH_LDS_T(G, KINDS) MeshPairLds<G, (G) == 64>      // (round 5: a hull record holds up to 256 vertices, 19 KB: only the wave-per-pair launch, one pair per workgroup, stages it)
 
 // every triangle whose leaf box overlaps [llo, lhi] (mesh frame): positions in the tree-ordered triangle array and the triangles' indices in the
 // caller's order, as found (unsorted)
@@ -158,12 +158,19 @@ template <int MESH_GROUP, int KINDS = SGD_KINDS_ALL> SGP_DEV void mesh_pair_grou
 	MeshHeader mh; v3 mpos = V3(0.0f, 0.0f, 0.0f); m33 R = quat_to_m33(Q4(make_float4(0.0f, 0.0f, 0.0f, 1.0f)));
 	int nc = 0;
 	if (valid) {
-		if ((MESH_GROUP == 64 || KINDS == 8) && X.hull) {
+		if constexpr (MESH_GROUP == 64) if (X.hull) {
 			// a triangle test walks the polytope's vertices twice per candidate axis: out of LDS, not out of a pointer into global memory (worth the copy
 			// where dozens of tests follow: 2.50 -> 2.13 ms on the car-sized boxes, but 0.93 -> 1.09 ms on the small bodies of tools/experiments/mesh_terrain_bench.py when
 			// every eight-lane pair did it; the eight-lane instance for convex hulls does -- ~130 axes per triangle, each a walk over the hull's corners: 0.80 -> 0.78 ms for 3.5k hulls)
-			const uint32_t* src = (const uint32_t*)X.hull; uint32_t* dst = (uint32_t*)&L.hull;
-			for (uint32_t i = (uint32_t)sub; i < sizeof(sgd_hull) / 4; i += MESH_GROUP) dst[i] = src[i];
+			// (the live part of every array, not the record's 19 KB: a box's cube template is 8 corners)
+			const sgd_hull* hs = X.hull; sgd_hull* hd = &L.hull;
+			if (sub == 0) { hd->nv = hs->nv; hd->nf = hs->nf; hd->ne = hs->ne; hd->is_box_template = hs->is_box_template; hd->aabb_min = hs->aabb_min; hd->aabb_max = hs->aabb_max; hd->bound_radius = hs->bound_radius; hd->volume = hs->volume; hd->unit_inertia = hs->unit_inertia; }
+			const int nv_ = hs->nv, nf_ = hs->nf, ne_ = hs->ne, ni_ = hs->face_start[hs->nf];
+			for (int i = sub; i < nv_; i += MESH_GROUP) hd->verts[i] = hs->verts[i];
+			for (int i = sub; i < nf_; i += MESH_GROUP) { hd->normals[i] = hs->normals[i]; hd->plane_d[i] = hs->plane_d[i]; }
+			for (int i = sub; i <= nf_; i += MESH_GROUP) hd->face_start[i] = hs->face_start[i];
+			for (int i = sub; i < ni_; i += MESH_GROUP) hd->face_idx[i] = hs->face_idx[i];
+			for (int i = sub; i < ne_; i += MESH_GROUP) { hd->edge_a[i] = hs->edge_a[i]; hd->edge_b[i] = hs->edge_b[i]; hd->edge_f0[i] = hs->edge_f0[i]; hd->edge_f1[i] = hs->edge_f1[i]; }
 			X.hull = (const sgd_hull*)(const void*)&L.hull;
 		}
 		mh = d.meshes[(uint32_t)d.prop[2 * (size_t)mid + 1].x];
@@ -214,8 +221,10 @@ template <int MESH_GROUP, int KINDS = SGD_KINDS_ALL> SGP_DEV void mesh_pair_grou
 	}
 	__syncthreads();
 	nc = valid ? (int)min(L.n_found, (uint32_t)MESH_LDS_T(MESH_GROUP, KINDS)::CAP) : 0;
-	if (MESH_GROUP != 64 && nc > MESH_BIG_MIN) {
-		// too many triangles for eight lanes: the wave-per-pair launch takes the pair (and finds its candidates again)
+	if (MESH_GROUP != 64 && (nc > MESH_BIG_MIN || (nc > 0 && X.hull && X.hull->nv > SGD_HULL_SMALL_VERTS))) {
+		// too many triangles for eight lanes: the wave-per-pair launch takes the pair (and finds its candidates again).  So does a hull beyond 32 vertices whatever
+		// the count (round 5): one triangle against it is a walk over up to 768 edges, and a lane per triangle with the hull's record in LDS ends after one
+		// such walk where eight lanes take turns (24 hulls of 256 vertices on a terrain: narrow phase 2.8 ms -> see docs/KERNELS.md)
 		if (sub == 0) { const uint32_t kb = atomicAdd(&d.ctr->n_mesh_big, 1u); if (kb < d.cap_mesh_pairs) d.mesh_big[kb] = pair; else atomicAdd(&d.ctr->pairs_dropped, 1u); }      // (four lists feed this one: bounded like them, the excess is counted)
 		valid = false; nc = 0; dropped = false;
 	}
@@ -319,6 +328,7 @@ SGP_DEV int hull_sat_search_wave(const sgd_hview* A, const sgd_hview* B, float m
 		}
 	}
 	if (__any(separated)) return 0;
+	// (a pair with a hull beyond 32 vertices never comes here: hull_sat_search_block)
 	for (int e = lane; e < total - nfA - nfB; e += 64) {
 		v3 ax; float s; int sup;
 		if (sgd_hull_axis_edge(A, B, e / neB, e % neB, T, &ax, &s, &sup)) {
@@ -342,6 +352,142 @@ SGP_DEV int hull_sat_search_wave(const sgd_hview* A, const sgd_hview* B, float m
 		r->eA = iE / neB; r->eB = iE % neB;
 		float s; int sup;
 		sgd_hull_axis_edge(A, B, r->eA, r->eB, T, &r->nE, &s, &sup);      // the axis of the winning pair (same arithmetic as above)
+	}
+	return 1;
+}
+
+// A pair with a hull beyond 32 vertices (up to 768 x 768 edge pairs; the Gauss-map test picks the ones worth an axis, sgd_hull_sat_search) by a WORKGROUP of 256 threads (round 5).  The wave search
+// above walks such a pair with two dependent gathers out of the 17 KB hull records per edge pair -- 9 000 iterations a lane for two 256-vertex hulls, each waiting
+// on L2 -- and evaluates a picked pair where it finds it, 63 lanes idle.  Here the world normals of both hulls' faces and A's edges (as the two faces each lies
+// between) are staged in LDS once; a thread keeps one edge of B in registers and walks A's edges against it out of LDS (the Gauss-map test: 4 dot products);
+// the pairs it picks go to a list in LDS and are evaluated afterwards, a thread each.  Same axes, same arithmetic per axis, (largest separation, lowest pair
+// index) as the order of the reduction: the result of sgd_hull_sat_search bit for bit.
+#define HULL_BIG_TPB 256
+#define HULL_BIG_CAND_CAP 2048
+struct HullBigLds {
+	v3 nA[SGD_HULL_MAX_FACES], nB[SGD_HULL_MAX_FACES];      // world normals of A's faces, MINUS those of B's
+	uint32_t eA[SGD_HULL_MAX_EDGES], eB[SGD_HULL_MAX_EDGES]; // edge i: face f0 | face f1 << 16 (0xFFFF: an open edge, sgp_hull_build.h)
+	uint32_t cand[HULL_BIG_CAND_CAP]; uint32_t n_cand;
+	float red_s[3][HULL_BIG_TPB / 64]; int red_i[3][HULL_BIG_TPB / 64]; int separated;
+};
+SGP_DEV bool hull_pair_is_big(const sgd_shape& sa, const sgd_shape& sb)
+{
+	const bool pa = sa.type == SGP_SHAPE_BOX || sa.type == SGP_SHAPE_HULL, pb = sb.type == SGP_SHAPE_BOX || sb.type == SGP_SHAPE_HULL;
+	if (!pa || !pb) return false;
+	return (sa.type == SGP_SHAPE_HULL && sa.hull->nv > SGD_HULL_SMALL_VERTS) || (sb.type == SGP_SHAPE_HULL && sb.hull->nv > SGD_HULL_SMALL_VERTS);
+}
+SGP_DEV int hull_sat_search_block(const sgd_hview* A, const sgd_hview* B, float max_sep, sgd_hull_sat* r, HullBigLds& L)
+{
+	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int nfA = A->h->nf, nfB = B->h->nf, neA = A->h->ne, neB = B->h->ne;
+	const v3 T = v3_sub(B->pos, A->pos);
+	__syncthreads();      // (the previous pair's last readers)
+	for (int f = tid; f < nfA; f += HULL_BIG_TPB) L.nA[f] = sgd_hv_normal(A, f);
+	for (int f = tid; f < nfB; f += HULL_BIG_TPB) L.nB[f] = v3_neg(sgd_hv_normal(B, f));
+	for (int i = tid; i < neA; i += HULL_BIG_TPB) L.eA[i] = (uint32_t)A->h->edge_f0[i] | ((uint32_t)A->h->edge_f1[i] << 16);
+	for (int j = tid; j < neB; j += HULL_BIG_TPB) L.eB[j] = (uint32_t)B->h->edge_f0[j] | ((uint32_t)B->h->edge_f1[j] << 16);
+	if (tid == 0) { L.n_cand = 0u; L.separated = 0; }
+	float sA = -3.4e38f, sB = -3.4e38f, sE = -3.4e38f; int iA = 0x7FFFFFFF, iB = 0x7FFFFFFF, iE = 0x7FFFFFFF;
+	bool separated = false;
+	for (int t = tid; t < nfA + nfB; t += HULL_BIG_TPB) {
+		if (t < nfA) {
+			const float s = sgd_hull_axis_face(A, B, t);
+			if (s > max_sep) separated = true;
+			if (s > sA) { sA = s; iA = t; }
+		} else {
+			const int f = t - nfA;
+			const float s = sgd_hull_axis_face(B, A, f);
+			if (s > max_sep) separated = true;
+			if (s > sB) { sB = s; iB = f; }
+		}
+	}
+	if (__syncthreads_or(separated ? 1 : 0)) return 0;
+	// the edge pairs: B's edge j stays with its thread, A's edges stream by out of LDS
+	for (int j = tid; j < neB; j += HULL_BIG_TPB) {
+		const uint32_t pkb = L.eB[j];
+		if ((pkb & 0xFFFFu) == 0xFFFFu) continue;      // (an open edge: below)
+		const v3 c = L.nB[pkb & 0xFFFFu], dd = L.nB[pkb >> 16];
+		const v3 dxc = v3_cross(dd, c);
+		for (int i = 0; i < neA; ++i) {
+			const uint32_t pk = L.eA[i];
+			if ((pk & 0xFFFFu) == 0xFFFFu) continue;
+			const v3 a = L.nA[pk & 0xFFFFu], bb = L.nA[pk >> 16];
+			const v3 bxa = v3_cross(bb, a);
+			const float cba = v3_dot(c, bxa), dba = v3_dot(dd, bxa), adc = v3_dot(a, dxc), bdc = v3_dot(bb, dxc);
+			if (!(cba * dba < 0.0f && adc * bdc < 0.0f && cba * bdc > 0.0f)) continue;
+			const uint32_t k = atomicAdd(&L.n_cand, 1u);
+			if (k < HULL_BIG_CAND_CAP) L.cand[k] = (uint32_t)(i * neB + j);
+			else {      // (the list is full: this one where it stands)
+				v3 ax; float s;
+				if (sgd_hull_axis_edge_picked(A, B, i, j, a, bb, &ax, &s)) {
+					if (s > max_sep) separated = true;
+					if (s > sE || (s == sE && i * neB + j < iE)) { sE = s; iE = i * neB + j; }
+				}
+			}
+		}
+	}
+	// the pairs of an edge without its two faces (the builder could not tell which faces it lies between: the Gauss-map test does not apply): in full, the
+	// other hull's edges dealt to the threads
+	for (int j = 0; j < neB; ++j) {
+		if ((L.eB[j] & 0xFFFFu) != 0xFFFFu) continue;
+		for (int i = tid; i < neA; i += HULL_BIG_TPB) {
+			v3 ax; float s; int sup;
+			if (sgd_hull_axis_edge(A, B, i, j, T, &ax, &s, &sup)) {
+				if (s > max_sep) separated = true;
+				if (sup && (s > sE || (s == sE && i * neB + j < iE))) { sE = s; iE = i * neB + j; }
+			}
+		}
+	}
+	for (int i = 0; i < neA; ++i) {
+		if ((L.eA[i] & 0xFFFFu) != 0xFFFFu) continue;
+		for (int j = tid; j < neB; j += HULL_BIG_TPB) {
+			if ((L.eB[j] & 0xFFFFu) == 0xFFFFu) continue;      // (done above)
+			v3 ax; float s; int sup;
+			if (sgd_hull_axis_edge(A, B, i, j, T, &ax, &s, &sup)) {
+				if (s > max_sep) separated = true;
+				if (sup && (s > sE || (s == sE && i * neB + j < iE))) { sE = s; iE = i * neB + j; }
+			}
+		}
+	}
+	__syncthreads();
+	const int nc = (int)min(L.n_cand, (uint32_t)HULL_BIG_CAND_CAP);
+	for (int k = tid; k < nc; k += HULL_BIG_TPB) {
+		const int key = (int)L.cand[k], i = key / neB, j = key % neB;
+		const uint32_t pk = L.eA[i];
+		v3 ax; float s;
+		if (sgd_hull_axis_edge_picked(A, B, i, j, L.nA[pk & 0xFFFFu], L.nA[pk >> 16], &ax, &s)) {
+			if (s > max_sep) separated = true;
+			if (s > sE || (s == sE && key < iE)) { sE = s; iE = key; }      // (the list is in no order: the lowest index among equals, as the walk in order keeps it)
+		}
+	}
+	if (__syncthreads_or(separated ? 1 : 0)) return 0;
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) {
+		float os = __shfl_xor(sA, off); int oi = __shfl_xor(iA, off);
+		if (os > sA || (os == sA && oi < iA)) { sA = os; iA = oi; }
+		os = __shfl_xor(sB, off); oi = __shfl_xor(iB, off);
+		if (os > sB || (os == sB && oi < iB)) { sB = os; iB = oi; }
+		os = __shfl_xor(sE, off); oi = __shfl_xor(iE, off);
+		if (os > sE || (os == sE && oi < iE)) { sE = os; iE = oi; }
+	}
+	if (lane == 0) { L.red_s[0][wave] = sA; L.red_i[0][wave] = iA; L.red_s[1][wave] = sB; L.red_i[1][wave] = iB; L.red_s[2][wave] = sE; L.red_i[2][wave] = iE; }
+	__syncthreads();
+	for (int w = 0; w < HULL_BIG_TPB / 64; ++w) {
+		float os = L.red_s[0][w]; int oi = L.red_i[0][w];
+		if (os > sA || (os == sA && oi < iA)) { sA = os; iA = oi; }
+		os = L.red_s[1][w]; oi = L.red_i[1][w];
+		if (os > sB || (os == sB && oi < iB)) { sB = os; iB = oi; }
+		os = L.red_s[2][w]; oi = L.red_i[2][w];
+		if (os > sE || (os == sE && oi < iE)) { sE = os; iE = oi; }
+	}
+	r->sA = sA; r->fA = iA == 0x7FFFFFFF ? 0 : iA; r->sB = sB; r->fB = iB == 0x7FFFFFFF ? 0 : iB;
+	r->sE = sE; r->eA = -1; r->eB = -1; r->nE = V3(0.0f, 0.0f, 0.0f);
+	if (iE != 0x7FFFFFFF) {
+		r->eA = iE / neB; r->eB = iE % neB;
+		float s; int sup;
+		const uint32_t pk = L.eA[r->eA];
+		if ((pk & 0xFFFFu) != 0xFFFFu && (L.eB[r->eB] & 0xFFFFu) != 0xFFFFu) sgd_hull_axis_edge_picked(A, B, r->eA, r->eB, L.nA[pk & 0xFFFFu], L.nA[pk >> 16], &r->nE, &s);
+		else sgd_hull_axis_edge(A, B, r->eA, r->eB, T, &r->nE, &s, &sup);
 	}
 	return 1;
 }

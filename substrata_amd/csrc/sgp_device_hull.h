@@ -10,19 +10,21 @@
 #include <type_traits>
 #include "sgp_device_math.h"
 
-#define SGD_HULL_MAX_VERTS 32
-#define SGD_HULL_MAX_FACES 60
-#define SGD_HULL_MAX_EDGES 90
-#define SGD_HULL_MAX_FACE_IDX 180
+#define SGD_HULL_MAX_VERTS 256         // JPH::ConvexHullShape::cMaxPointsInHull (round 5; rounds 1-4 kept 32)
+#define SGD_HULL_MAX_FACES 512         // <= 2 V - 4 triangles, fewer once coplanar ones are merged; faces of more than 16 corners are split
+#define SGD_HULL_MAX_EDGES 768         // <= 3 V - 6 (+ the diagonals of split faces)
+#define SGD_HULL_MAX_FACE_IDX 1792     // sum of the face loops = 2 E
 #define SGD_HULL_MAX_FACE_VERTS 16
+#define SGD_HULL_SMALL_VERTS 32        // up to here the builder and the separating-axis search are those of rounds 1-4, bit for bit
 #define SGD_HULL_CLIP_CAP 24
 
 struct sgd_hull_s {
 	int nv, nf, ne, is_box_template;
 	v3 verts[SGD_HULL_MAX_VERTS];
 	v3 normals[SGD_HULL_MAX_FACES]; float plane_d[SGD_HULL_MAX_FACES];       // inside: n.x <= d
-	unsigned char face_start[SGD_HULL_MAX_FACES + 1]; unsigned char face_idx[SGD_HULL_MAX_FACE_IDX];   // CCW seen from outside
+	unsigned short face_start[SGD_HULL_MAX_FACES + 1]; unsigned char face_idx[SGD_HULL_MAX_FACE_IDX];   // CCW seen from outside
 	unsigned char edge_a[SGD_HULL_MAX_EDGES], edge_b[SGD_HULL_MAX_EDGES];
+	unsigned short edge_f0[SGD_HULL_MAX_EDGES], edge_f1[SGD_HULL_MAX_EDGES];   // the two faces an edge lies between: f0 has it as a -> b, f1 as b -> a (Gauss-map test of edge pairs)
 	v3 aabb_min, aabb_max;
 	float bound_radius, volume;
 	v3 unit_inertia;                   // principal moments for density 1
@@ -169,6 +171,31 @@ template <class HA, class HB> SGP_DEV static int sgd_hull_axis_edge(const HA* A,
 	return 1;
 }
 
+// The same for an edge pair the Gauss-map test has picked (a, bb: world normals of the faces either side of A's edge): the two edges ARE what supports the
+// hulls along +-(da x db), so the separation is that of the edges themselves -- no walk over the vertices -- and the axis points the way A's two faces do.
+template <class HA, class HB> SGP_DEV static int sgd_hull_axis_edge_picked(const HA* A, const HB* B, int i, int j, v3 a, v3 bb, v3* ax_out, float* s_out)
+{
+	const v3 da = m33_mul(A->R, v3_sub(sgd_hv_local(A, A->h->edge_b[i]), sgd_hv_local(A, A->h->edge_a[i])));
+	const v3 db = m33_mul(B->R, v3_sub(sgd_hv_local(B, B->h->edge_b[j]), sgd_hv_local(B, B->h->edge_a[j])));
+	v3 ax = v3_cross(da, db);
+	const float l2 = v3_len_sq(ax);
+	if (l2 < 1.0e-6f * v3_len_sq(da) * v3_len_sq(db)) return 0;
+	ax = v3_scale(ax, 1.0f / sqrtf(l2));
+	if (v3_dot(ax, v3_add(a, bb)) < 0.0f) ax = v3_neg(ax);
+	const v3 a0 = sgd_hv_world(A, A->h->edge_a[i]), b0 = sgd_hv_world(B, B->h->edge_a[j]);
+	*ax_out = ax; *s_out = v3_dot(ax, b0) - v3_dot(ax, a0);
+	return 1;
+}
+
+// Gauss-map test of an edge pair: (a, bb) the world normals of the faces either side of A's edge, bxa = bb x a; B's edge j with its (negated) normals.
+template <class HB> SGP_DEV static bool sgd_hull_gauss_pair(const HB* B, int j, v3 a, v3 bb, v3 bxa)
+{
+	const v3 c = v3_neg(sgd_hv_normal(B, B->h->edge_f0[j])), dd = v3_neg(sgd_hv_normal(B, B->h->edge_f1[j]));
+	const v3 dxc = v3_cross(dd, c);
+	const float cba = v3_dot(c, bxa), dba = v3_dot(dd, bxa), adc = v3_dot(a, dxc), bdc = v3_dot(bb, dxc);
+	return cba * dba < 0.0f && adc * bdc < 0.0f && cba * bdc > 0.0f;
+}
+
 // Sequential search (first maximum wins).  Returns 0 when some axis separates the hulls by more than max_sep.
 // (DIRCACHE = false: the caller knows that neither hull is the cube template -- a mesh triangle against a convex hull -- and the instance carries neither
 // the branch below nor its 720 bytes of tables)
@@ -186,6 +213,53 @@ template <bool DIRCACHE = true, class HA, class HB> SGP_DEV static int sgd_hull_
 		if (s > r->sB) { r->sB = s; r->fB = f; }
 	}
 	const v3 T = v3_sub(B->pos, A->pos);
+	if constexpr (sgd_is_thin<typename std::remove_cv<typename std::remove_pointer<decltype(A->h)>::type>::type>::value && std::is_same<HB, sgd_hview>::value) {
+	if (B->h->nv > SGD_HULL_SMALL_VERTS) {
+		// A mesh triangle against a hull beyond 32 vertices (round 5): 3 x up to 768 edge pairs, each a walk over every vertex in the full search.  The Gauss-map
+		// test for a triangle: edge k supports the triangle along the directions of the half circle about it through its outward in-plane normal m_k (from the
+		// triangle's normal to its opposite); edge j of the hull supports the hull along minus the arc between its two faces' normals.  The two meet -- the pair
+		// is a face of the Minkowski difference -- when the arc crosses the plane perpendicular to edge k on m_k's side.  In the hull's frame (its normals as
+		// stored); a picked pair's axis and separation from its two edges.  Hull edge outermost: its normals are fetched once for the three triangle edges.
+		const v3 nT = sgd_hv_normal(A, 0);
+		v3 da[3], dal[3], ml[3];
+		for (int k = 0; k < 3; ++k) {
+			const int ia = A->h->edge_a[k], ib = A->h->edge_b[k], io = 3 - ia - ib;
+			da[k] = m33_mul(A->R, v3_sub(sgd_hv_local(A, ib), sgd_hv_local(A, ia)));
+			v3 m = v3_cross(da[k], nT);
+			if (v3_dot(m, v3_sub(sgd_hv_world(A, ia), sgd_hv_world(A, io))) < 0.0f) m = v3_neg(m);
+			dal[k] = m33_tmul(B->R, da[k]); ml[k] = m33_tmul(B->R, m);
+		}
+		for (int j = 0; j < B->h->ne; ++j) {
+			if (B->h->edge_f0[j] == 0xFFFF) {      // (an edge without its two faces: its three pairs in full)
+				for (int k = 0; k < 3; ++k) {
+					v3 ax; float s; int sup;
+					if (!sgd_hull_axis_edge(A, B, k, j, T, &ax, &s, &sup)) continue;
+					if (s > max_sep) return 0;
+					if (s > r->sE && sup) { r->sE = s; r->eA = k; r->eB = j; r->nE = ax; }
+				}
+				continue;
+			}
+			const v3 c = v3_neg(B->h->normals[B->h->edge_f0[j]]), dd = v3_neg(B->h->normals[B->h->edge_f1[j]]);
+			for (int k = 0; k < 3; ++k) {
+				const float cd = v3_dot(c, dal[k]), ddd = v3_dot(dd, dal[k]);
+				if (!(cd * ddd < 0.0f)) continue;
+				const v3 x = v3_add(v3_scale(c, fabsf(ddd)), v3_scale(dd, fabsf(cd)));      // (where the arc crosses the plane: the Minkowski face's normal, hull frame)
+				if (!(v3_dot(x, ml[k]) > 0.0f)) continue;
+				const v3 db = m33_mul(B->R, v3_sub(sgd_hv_local(B, B->h->edge_b[j]), sgd_hv_local(B, B->h->edge_a[j])));
+				v3 ax = v3_cross(da[k], db);
+				const float l2 = v3_len_sq(ax);
+				if (l2 < 1.0e-6f * v3_len_sq(da[k]) * v3_len_sq(db)) continue;
+				ax = v3_scale(ax, 1.0f / sqrtf(l2));
+				if (v3_dot(m33_tmul(B->R, ax), x) < 0.0f) ax = v3_neg(ax);
+				const v3 a0 = sgd_hv_world(A, A->h->edge_a[k]), b0 = sgd_hv_world(B, B->h->edge_a[j]);
+				const float s = v3_dot(ax, b0) - v3_dot(ax, a0);
+				if (s > max_sep) return 0;
+				if (s > r->sE) { r->sE = s; r->eA = k; r->eB = j; r->nE = ax; }
+			}
+		}
+		return 1;
+	}
+	}
 	const int boxA = A->h->is_box_template, boxB = B->h->is_box_template;
 	if (DIRCACHE && (boxA || A->h->ne <= 3) && (boxB || B->h->ne <= 3) && (boxA || boxB)) {
 		/* A cube's twelve edges have three directions: the axis of an edge pair and the separation along it are those of the pair of DIRECTIONS
@@ -224,6 +298,32 @@ template <bool DIRCACHE = true, class HA, class HB> SGP_DEV static int sgd_hull_
 		}
 		return 1;
 	}
+	if constexpr (std::is_same<HA, sgd_hview>::value && std::is_same<HB, sgd_hview>::value) {
+		if (A->h->nv > SGD_HULL_SMALL_VERTS || B->h->nv > SGD_HULL_SMALL_VERTS) {
+			// Many edge pairs (a hull beyond 32 vertices is involved; round 5): only the pairs whose cross product can be a face of the Minkowski difference are
+			// evaluated -- the arcs between the normals of the faces either side of edge i of A and of (minus) those either side of edge j of B cross on the unit
+			// sphere (the Gauss-map test; 4 dot products per pair instead of a projection of every vertex of both hulls).
+			for (int i = 0; i < A->h->ne; ++i) {
+				const bool open_a = A->h->edge_f0[i] == 0xFFFF;      // (an edge without its two faces, sgp_hull_build.h: its pairs in full)
+				const v3 a = open_a ? V3(0.0f, 0.0f, 0.0f) : sgd_hv_normal(A, A->h->edge_f0[i]), bb = open_a ? V3(0.0f, 0.0f, 0.0f) : sgd_hv_normal(A, A->h->edge_f1[i]), bxa = v3_cross(bb, a);
+				for (int j = 0; j < B->h->ne; ++j) {
+					if (open_a || B->h->edge_f0[j] == 0xFFFF) {
+						v3 ax; float s; int sup;
+						if (!sgd_hull_axis_edge(A, B, i, j, T, &ax, &s, &sup)) continue;
+						if (s > max_sep) return 0;
+						if (s > r->sE && sup) { r->sE = s; r->eA = i; r->eB = j; r->nE = ax; }
+						continue;
+					}
+					if (!sgd_hull_gauss_pair(B, j, a, bb, bxa)) continue;
+					v3 ax; float s;
+					if (!sgd_hull_axis_edge_picked(A, B, i, j, a, bb, &ax, &s)) continue;
+					if (s > max_sep) return 0;
+					if (s > r->sE) { r->sE = s; r->eA = i; r->eB = j; r->nE = ax; }
+				}
+			}
+			return 1;
+		}
+	}
 	for (int i = 0; i < A->h->ne; ++i) {
 		for (int j = 0; j < B->h->ne; ++j) {
 			v3 ax; float s; int sup;
@@ -245,11 +345,13 @@ template <int CAP = SGD_HULL_CLIP_CAP, class HX, class HY> SGP_DEV static int sg
 	for (int f = 0; f < Y->h->nf; ++f) { const float d = v3_dot(nref, sgd_hv_normal(Y, f)); if (d < bestd) { bestd = d; fY = f; } }
 	v3 poly[CAP], tmp[CAP];
 	int np = 0;
-	for (int k = Y->h->face_start[fY]; k < Y->h->face_start[fY + 1]; ++k) poly[np++] = sgd_hv_world(Y, Y->h->face_idx[k]);
-	const int x0 = X->h->face_start[fX], x1 = X->h->face_start[fX + 1];
-	for (int k = x0; k < x1 && np > 0; ++k) {
+	// (a face of more than SGD_HULL_MAX_FACE_VERTS corners takes part with every step-th of them: the polygon inscribed in it)
+	const int y0 = Y->h->face_start[fY], y1 = Y->h->face_start[fY + 1], ystep = (y1 - y0 + SGD_HULL_MAX_FACE_VERTS - 1) / SGD_HULL_MAX_FACE_VERTS;
+	for (int k = y0; k < y1; k += ystep) poly[np++] = sgd_hv_world(Y, Y->h->face_idx[k]);
+	const int x0 = X->h->face_start[fX], x1 = X->h->face_start[fX + 1], xstep = (x1 - x0 + SGD_HULL_MAX_FACE_VERTS - 1) / SGD_HULL_MAX_FACE_VERTS;
+	for (int k = x0; k < x1 && np > 0; k += xstep) {
 		const v3 a = sgd_hv_world(X, X->h->face_idx[k]);
-		const v3 b = sgd_hv_world(X, X->h->face_idx[k + 1 < x1 ? k + 1 : x0]);
+		const v3 b = sgd_hv_world(X, X->h->face_idx[k + xstep < x1 ? k + xstep : x0]);
 		const v3 side = v3_cross(v3_sub(b, a), nref);
 		np = sgd_hull_clip<CAP>(poly, np, a, side, tmp);
 		for (int i = 0; i < np; ++i) poly[i] = tmp[i];

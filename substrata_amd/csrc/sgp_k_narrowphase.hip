@@ -77,6 +77,10 @@ template <int ROUND, bool HULLS = true> SGP_DEV void narrowphase_pairs(const DV&
 						// the in-step activation round has few pairs and is two launches shorter with the sequential form of the same search here
 						// (every axis through the same device function, first maximum wins: the same manifold as the wave-parallel kernels')
 						const sgd_shape sa = load_shape(d, ab.x, fa), sb = load_shape(d, ab.y, fb);
+						if (hull_pair_is_big(sa, sb)) {      // (round 5: hundreds of thousands of edge pairs are not one thread's work -- to the list, k_narrowphase_hull_big after this launch)
+							const uint32_t k = wave_alloc(&d.ctr->n_hull_pairs);
+							if (k < d.cap_hull_pairs) d.hull_pairs[k] = ab; else atomicAdd(&d.ctr->pairs_dropped, 1u);
+						} else
 						have = sgd_collide_hull(&sa, &sb, d.st.speculative_contact_distance, &m) != 0;
 					}
 				} else {
@@ -183,6 +187,7 @@ __global__ void __launch_bounds__(64, 3) k_narrowphase_hull(DV d)
 		const float max_sep = d.st.speculative_contact_distance;
 		HullWork wk; wk.ab = ab;
 		wk.round_other = (sa.type == SGP_SHAPE_SPHERE || sa.type == SGP_SHAPE_CAPSULE || sb.type == SGP_SHAPE_SPHERE || sb.type == SGP_SHAPE_CAPSULE) ? 1u : 0u;
+		if (hull_pair_is_big(sa, sb)) continue;      // (a hull beyond 32 vertices: k_narrowphase_hull_big writes this pair's work item)
 		int hit = 1;
 		if (!wk.round_other) {
 			// canonical order (box < hull; hull - hull keeps its order), as sgd_collide_hull
@@ -193,6 +198,26 @@ __global__ void __launch_bounds__(64, 3) k_narrowphase_hull(DV d)
 		} else memset(&wk.r, 0, sizeof(wk.r));
 		// work item p (no list to append to: one counter shared by ten thousand waves would cost more than the search)
 		if (!hit) wk.round_other = 2u;
+		if (threadIdx.x == 0) d.hull_work[p] = wk;
+	}
+}
+
+// The pairs k_narrowphase_hull leaves out: a hull of more than 32 vertices against a hull or a box, a workgroup
+// per pair (hull_sat_search_block).  Launched only in worlds that hold such a hull; in the in-step activation round the list holds nothing else.
+__global__ void __launch_bounds__(HULL_BIG_TPB) k_narrowphase_hull_big(DV d)
+{
+	__shared__ HullBigLds L;
+	const uint32_t n = min(d.ctr->n_hull_pairs, d.cap_hull_pairs);
+	for (uint32_t p = d.ctr->hull_base + blockIdx.x; p < n; p += gridDim.x) {
+		const uint2 ab = d.hull_pairs[p];
+		const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
+		const sgd_shape sa = load_shape(d, ab.x, fa), sb = load_shape(d, ab.y, fb);
+		if (!hull_pair_is_big(sa, sb)) continue;
+		HullWork wk; wk.ab = ab; wk.round_other = 0u;
+		const bool flip = sa.type > sb.type;
+		const sgd_shape* x = flip ? &sb : &sa; const sgd_shape* y = flip ? &sa : &sb;
+		const sgd_hview hx = sgd_hull_view(x), hy = sgd_hull_view(y);
+		if (!hull_sat_search_block(&hx, &hy, d.st.speculative_contact_distance, &wk.r, L)) { wk.round_other = 2u; memset(&wk.r, 0, sizeof(wk.r)); }
 		if (threadIdx.x == 0) d.hull_work[p] = wk;
 	}
 }
@@ -224,16 +249,21 @@ void launch_narrowphase(const DV& d, uint32_t est, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_narrowphase, dim3(stride_grid(est)), dim3(TPB), 0, s, d);
 }
-void launch_wake_round(const DV& d, uint32_t nb, bool has_hulls, bool has_meshes, hipStream_t s)
+void launch_wake_round(const DV& d, uint32_t nb, int has_hulls, bool has_meshes, hipStream_t s)      // has_hulls: 0 none, 1 some, 2 some of more than 32 vertices
 {
 	hipLaunchKernelGGL(k_wake_pairs, dim3(blocks_for(nb)), dim3(TPB), 0, s, d);
 	if (has_hulls) hipLaunchKernelGGL(k_narrowphase_wake<true>, dim3(32), dim3(TPB), 0, s, d);      // (few pairs, 1.7 KB of scratch per lane: a small grid starts faster)
 	else hipLaunchKernelGGL(k_narrowphase_wake<false>, dim3(32), dim3(TPB), 0, s, d);
 	// (hull pairs of this round are collided by k_narrowphase_wake itself; hull - mesh pairs by the hull instances of the mesh kernels)
-	if (has_meshes) launch_narrowphase_mesh_blocks(d, has_hulls, 256, s);
+	if (has_hulls == 2) {      // (the big pairs k_narrowphase_wake put on the list: their search by workgroups, their manifolds)
+		hipLaunchKernelGGL(k_narrowphase_hull_big, dim3(256), dim3(HULL_BIG_TPB), 0, s, d);
+		hipLaunchKernelGGL(k_narrowphase_hull_manifold, dim3(64), dim3(64), 0, s, d);
+	}
+	if (has_meshes) launch_narrowphase_mesh_blocks(d, has_hulls != 0, 256, s);
 }
-void launch_narrowphase_hull(const DV& d, hipStream_t s)
+void launch_narrowphase_hull(const DV& d, bool big_hulls, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_narrowphase_hull, dim3(4096), dim3(64), 0, s, d);
+	if (big_hulls) hipLaunchKernelGGL(k_narrowphase_hull_big, dim3(2048), dim3(HULL_BIG_TPB), 0, s, d);
 	hipLaunchKernelGGL(k_narrowphase_hull_manifold, dim3(1024), dim3(64), 0, s, d);
 }

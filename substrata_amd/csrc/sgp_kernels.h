@@ -348,8 +348,8 @@ void launch_bp_large(const DV& d, uint32_t nb, hipStream_t s);
 void launch_bp_scatter_large(const DV& d, uint32_t nb, hipStream_t s);      // both in one launch (the step's path)
 void launch_narrowphase(const DV& d, uint32_t n_pairs_upper, hipStream_t s);
 void launch_cache_wipe(const DV& d, hipStream_t s);
-void launch_wake_round(const DV& d, uint32_t nb, bool has_hulls, bool has_meshes, hipStream_t s);      // in-step activation: k_wake_pairs + the narrow phase of its pairs
-void launch_narrowphase_hull(const DV& d, hipStream_t s);     // only worlds with hull shapes
+void launch_wake_round(const DV& d, uint32_t nb, int has_hulls, bool has_meshes, hipStream_t s);      // in-step activation: k_wake_pairs + the narrow phase of its pairs
+void launch_narrowphase_hull(const DV& d, bool big_hulls, hipStream_t s);     // only worlds with hull shapes; big_hulls: some hull has more than 32 vertices (k_narrowphase_hull_big)
 void launch_narrowphase_mesh(const DV& d, bool has_hulls, hipStream_t s);
 void launch_narrowphase_mesh_blocks(const DV& d, bool has_hulls, uint32_t blocks, hipStream_t s);      // (the same four launches with a grid of `blocks` workgroups)     // only worlds with mesh shapes; has_hulls: also the instances for hull bodies
 void launch_colour_inherit(const DV& d, uint32_t n_man, hipStream_t s);

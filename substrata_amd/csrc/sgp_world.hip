@@ -556,7 +556,7 @@ struct StepPlan {
 	int      water, contact_events, warm_start, vel_iters, pos_iters;
 	uint32_t n_vehicles;
 	int      has_meshes;         // some body may be a static triangle mesh: run the mesh-pair narrow phase
-	int      has_hulls;          // some body may be a convex hull: run the hull-pair narrow phase
+	int      has_hulls;          // some body may be a convex hull: run the hull-pair narrow phase (2: a hull of more than 32 vertices exists -- k_narrowphase_hull_big too)
 	int      wake_round;         // in-step activation: pair and collide the bodies this step wakes (k_wake_pairs + a second narrow-phase round)
 	int      small_colouring;    // the whole colouring in one single-workgroup launch (k_colour_finish builds its own worklist)
 	int      small_world;        // warm start + velocity iterations as ONE single-workgroup launch (k_solve_small)
@@ -596,7 +596,7 @@ static void make_plan(const sgp_world* w, StepPlan& p)
 	p.water = w->h_sp->water_enabled; p.contact_events = w->h_sp->contact_events;
 	p.warm_start = w->dv.st.warm_start; p.vel_iters = w->dv.st.num_velocity_steps; p.pos_iters = w->dv.st.num_position_steps;
 	p.n_vehicles = w->n_vehicles;
-	p.has_hulls = w->hulls.size() > 1 ? 1 : 0;
+	p.has_hulls = w->hulls.size() > 1 ? (w->n_big_hulls ? 2 : 1) : 0;
 	p.has_meshes = w->meshes.size() > 1 ? 1 : 0;
 	p.wake_round = w->use_wake_round ? 1 : 0;
 	p.small_colouring = (w->last_manifolds <= SGP_SMALL_COLOURING_MANIFOLDS && w->high <= SGP_SMALL_WORLD_BODIES) ? 1 : 0;
@@ -661,7 +661,7 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 	{ KScope k(w, KC_BP_PAIRS); launch_bp_pairs(d, p.bp_small, s); }
 	STAGE_MARK(2);
 	// -- 3. narrow phase, wake-ups, per-body solver records (+ contact events, which see the velocities before the solve)
-	{ KScope k(w, KC_NARROWPHASE); launch_narrowphase(d, p.est_pairs, s); if (p.has_hulls) launch_narrowphase_hull(d, s); if (p.has_meshes) launch_narrowphase_mesh(d, p.has_hulls != 0, s); }
+	{ KScope k(w, KC_NARROWPHASE); launch_narrowphase(d, p.est_pairs, s); if (p.has_hulls) launch_narrowphase_hull(d, p.has_hulls == 2, s); if (p.has_meshes) launch_narrowphase_mesh(d, p.has_hulls != 0, s); }
 	// in-step activation: what the contacts above (or a wheel) woke takes its sleeping island along and collides in this step
 	if (p.wake_round) { KScope k(w, KC_NARROWPHASE); launch_wake_round(d, nb, p.has_hulls, p.has_meshes, s); }
 	{ KScope k(w, KC_APPLY_FORCES); launch_pre_solve(d, nb, s); }      // sweep 1/3: wake-ups, forces, per-step solver records

@@ -134,6 +134,7 @@ struct sgp_world {
 	size_t cap_mesh_verts = 0, cap_mesh_tris = 0, cap_mesh_tri_mat = 0, cap_mesh_nodes = 0;
 	// shape lifecycle: bodies referencing each mesh / hull, ids and pool ranges of destroyed shapes waiting for reuse, table capacities (grown on demand)
 	std::vector<uint32_t> mesh_refs, hull_refs, free_mesh_ids, free_hull_ids;
+	uint32_t n_big_hulls = 0;      // live hulls of more than SGD_HULL_SMALL_VERTS vertices: their pairs go through k_narrowphase_hull_big (part of the step plan)
 	std::vector<std::pair<uint32_t, uint32_t>> free_vert_ranges, free_tri_ranges, free_node_ranges;      // (offset, length)
 	size_t cap_mesh_table = 0, cap_hull_table = 0;
 	std::vector<uint32_t> free_triples;                   // first slot of freed (mesh body + 2 alias) slot triples

@@ -230,6 +230,7 @@ SGP_API int sgp_hull_create_com(sgp_world* w, const float* pts, uint32_t n, cons
 	HIP_TRY(hipMemcpyAsync(&w->d_hulls[id], &w->hulls[id], sizeof(sgd_hull), hipMemcpyHostToDevice, w->stream));
 	HIP_TRY(hipStreamSynchronize(w->stream));
 	w->dv.n_hulls = (uint32_t)w->hulls.size();
+	if (h.nv > SGD_HULL_SMALL_VERTS) ++w->n_big_hulls;
 	invalidate_graphs(w);                        // DV travels by value in the captured launches
 	memset(info, 0, sizeof(*info));
 	info->hull_id = id; info->num_vertices = (uint32_t)h.nv; info->num_faces = (uint32_t)h.nf; info->num_edges = (uint32_t)h.ne;
@@ -247,6 +248,7 @@ SGP_API int sgp_hull_destroy(sgp_world* w, uint32_t id)
 	if (!w || id < 1 || id >= w->hulls.size() || w->hulls[id].nv == 0) return fail(SGP_ERR_BAD_ID, "sgp_hull_destroy: no such hull");
 	if (w->hull_refs[id] != 0) return fail(SGP_ERR_REJECTED, "sgp_hull_destroy: a body still uses the hull");
 	hipSetDevice(w->device);
+	if (w->hulls[id].nv > SGD_HULL_SMALL_VERTS) --w->n_big_hulls;
 	memset(&w->hulls[id], 0, sizeof(sgd_hull));
 	HIP_TRY(hipMemcpyAsync(&w->d_hulls[id], &w->hulls[id], sizeof(sgd_hull), hipMemcpyHostToDevice, w->stream));
 	HIP_TRY(hipStreamSynchronize(w->stream));

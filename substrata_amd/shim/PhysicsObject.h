@@ -28,7 +28,7 @@ class RayTraceResult;
 struct sgp_world;
 struct PhysicsHullData
 {
-	struct Instance { sgp_world* world; float scale[3]; uint32_t hull_id; float com[3]; float rot[4]; float aabb_min[3], aabb_max[3]; uint32_t users; };
+	struct Instance { sgp_world* world; float scale[3]; uint32_t hull_id; float com[3]; float rot[4]; float aabb_min[3], aabb_max[3]; uint32_t users; uint32_t num_vertices; };      // num_vertices: corners the device hull kept (<= 256, JPH::ConvexHullShape::cMaxPointsInHull)
 	std::vector<float> points;          // xyz, object space, unscaled
 	float com_offset[3] = { 0, 0, 0 };  // OffsetCenterOfMassShape: moves the centre of mass away from the hull's own (object space, unscaled)
 	std::vector<Instance> instances;

@@ -219,7 +219,7 @@ static PhysicsHullData::Instance* hullInstance(sgp_world* world, const PhysicsSh
 	if (sgp_hull_create_com(world, pts.data(), (uint32_t)(pts.size() / 3), off, &info) != SGP_OK) { reportShapeFailure("convex hull"); return nullptr; }
 	PhysicsHullData::Instance in;
 	in.users = 0;
-	in.world = world; in.scale[0] = scale.x; in.scale[1] = scale.y; in.scale[2] = scale.z; in.hull_id = info.hull_id;
+	in.world = world; in.scale[0] = scale.x; in.scale[1] = scale.y; in.scale[2] = scale.z; in.hull_id = info.hull_id; in.num_vertices = info.num_vertices;
 	memcpy(in.com, info.com, sizeof(in.com)); memcpy(in.rot, info.rot, sizeof(in.rot));
 	memcpy(in.aabb_min, info.aabb_min, sizeof(in.aabb_min)); memcpy(in.aabb_max, info.aabb_max, sizeof(in.aabb_max));
 	h.instances.push_back(in);

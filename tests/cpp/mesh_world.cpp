@@ -216,6 +216,27 @@ int main()
 				if (!fell) printf("dynamic hull of the cube mesh did not fall\n");
 				ok = ok && fell;
 			}
+			// A finely tessellated DYNAMIC mesh: 200 vertices on an ellipsoid, every one a corner of its hull.  ConvexHullShapeSettings takes them all
+			// (PhysicsWorld.cpp:745-768, :979; Jolt keeps up to 256 points) -- rounds 1-4 kept 32.  The object rolls on the terrain and comes to rest above it.
+			{
+				TestIndigoMesh blob;
+				for (int i = 0; i < 200; ++i) {      // a Fibonacci spiral: no two points alike, none inside the hull of the others
+					const float z = 1.f - 2.f * ((float)i + 0.5f) / 200.f, r = std::sqrt(1.f - z * z), a = 2.399963f * (float)i;
+					blob.vert_positions.push_back({ 0.9f * r * std::cos(a), 0.6f * r * std::sin(a), 0.5f * z });
+				}
+				for (uint32 i = 0; i + 2 < 200; ++i) { TestIndigoMesh::Triangle t = {}; t.vertex_indices[0] = i; t.vertex_indices[1] = i + 1; t.vertex_indices[2] = i + 2; blob.triangles.push_back(t); }
+				Reference<PhysicsObject> ob = new PhysicsObject(true, PhysicsWorld::createJoltShapeForIndigoMesh(blob, /*build_dynamic_physics_ob=*/true), nullptr, 0);
+				ob->motion_type = PhysicsObject::MotionType_dynamic; ob->mass = 40.f; ob->pos = Vec4f(6.f, -6.f, terrainHeight(6.f, -6.f) + 3.f, 1);
+				world->addObject(ob); world->activateObject(ob);
+				const bool all_corners = ob->shape.hull && ob->shape.hull->instances.size() == 1 && ob->shape.hull->instances[0].num_vertices == 200;
+				if (!all_corners) printf("dynamic hull of a 200-vertex mesh kept %u vertices\n", ob->shape.hull && !ob->shape.hull->instances.empty() ? ob->shape.hull->instances[0].num_vertices : 0u);
+				for (int k = 0; k < 240; ++k) world->think(1.0 / 60.0);
+				const Vec4f p = world->getPosInJolt(ob);
+				const float above = p[2] - terrainHeight(p[0], p[1]);
+				const bool rests = above > 0.3f && above < 1.2f;
+				if (!rests) printf("200-vertex hull: %.3f above the terrain at (%.2f, %.2f)\n", above, p[0], p[1]);
+				ok = ok && all_corners && rests;
+			}
 			Reference<PhysicsObject> bounds = new PhysicsObject(true, PhysicsWorld::createScaledAndTranslatedShapeForShape(unit_cube, Vec3f(-1.f, -2.f, 0.f), Vec3f(2.f, 4.f, 1.5f)), nullptr, 0);
 			bounds->pos = Vec4f(-12.f, 12.f, 8.f, 1);
 			world->addObject(bounds);

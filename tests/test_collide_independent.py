@@ -198,3 +198,76 @@ def test_manifold_against_brute_force_support_functions(oracle, ka, kb):
         assert abs(float(overlap(b, a, hit2[0].astype(float))) - along_n) < 1e-4
         checked += 1
     assert checked >= 25
+
+
+def rand_big_hull(rng, oracle, prisms=True):
+    """A convex polytope of 60 .. 250 vertices (points on an ellipsoid: every one is a vertex of the hull) -- beyond the 32 that rounds 1-4 kept."""
+    w = hull_world(oracle)
+    kind = int(rng.integers(0, 4))
+    if kind == 0 and prisms:
+        # a prism / a truncated cone over a 24 .. 64-gon: two faces of that many corners (the manifold clips against at most 16 of them)
+        m = int(rng.integers(24, 65)); a = np.linspace(0, 2 * np.pi, m, endpoint=False)
+        r0, r1, hh = rng.uniform(0.3, 0.7), rng.uniform(0.3, 0.7), rng.uniform(0.2, 0.5)
+        pts = np.array([(r0 * np.cos(t), r0 * np.sin(t), -hh) for t in a] + [(r1 * np.cos(t), r1 * np.sin(t), hh) for t in a])
+        n = 2 * m
+    else:
+        n = int(rng.integers(60, 251))
+        pts = rng.normal(size=(n, 3)); pts /= np.linalg.norm(pts, axis=1, keepdims=True)
+        pts *= rng.uniform(0.35, 0.8, size=3)
+    info = w.hull_create(pts)
+    assert info.num_vertices == n
+    v, pl = oracle.hull_dump(w, info.hull_id)
+    return (info.hull_id, v, pl)
+
+
+@pytest.mark.parametrize("kb", KINDS + ["big"], ids=[NAMES[k] for k in KINDS] + ["bighull"])
+def test_big_hull_manifolds_against_brute_force_support_functions(oracle, kb):
+    """Round 5: hulls of up to 256 vertices (JPH::ConvexHullShape::cMaxPointsInHull).  The same independent reference -- brute-force support functions,
+    no formula shared with the oracle -- for a 60 .. 250-vertex hull against a sphere, a box, a capsule, a small hull and another big hull (the pairing
+    whose edge pairs go through the Gauss-map test)."""
+    rng = np.random.default_rng(900 + (7 if kb == "big" else kb))
+    checked = 0
+    for trial in range(24):
+        # (a capsule lying along a prism's narrow side face keeps the two ends of its overlap with THAT face, as ManifoldBetweenTwoFaces does -- the deepest
+        #  point may lie over the neighbouring face, a few degrees away; the depth check below is not made for that pairing)
+        a = Shape(abi.SHAPE_HULL, (0, 0, 0), rng.uniform(-3, 3, size=3), rand_quat(rng), hull=rand_big_hull(rng, oracle, prisms=kb != abi.SHAPE_CAPSULE))
+        target = rng.choice([-0.015, -0.005, 0.0, 0.005, 0.02, 0.05, 0.1])
+        if kb == "big":
+            u = rng.normal(size=3); u /= np.linalg.norm(u)
+            b = Shape(abi.SHAPE_HULL, (0, 0, 0), a.pos, rand_quat(rng), hull=rand_big_hull(rng, oracle))
+            lo, hi = 0.0, 4.0
+            for _ in range(40):
+                mid = 0.5 * (lo + hi); b.pos = a.pos + u * mid
+                if overlap(a, b, _DIRS).min() > target:
+                    lo = mid
+                else:
+                    hi = mid
+            b.pos = a.pos + u * hi
+        else:
+            b = place_near_contact(rng, a, kb, target, oracle)
+        hit = collide(oracle, a, b, MAX_SEP)
+        ref, dref = min_overlap(a, b, seeds=() if hit is None else (hit[0],))
+        if ref < -MAX_SEP - 2e-3:
+            assert hit is None, (trial, ref)
+            continue
+        if ref < -MAX_SEP + 2e-3:
+            continue
+        assert hit is not None, (trial, ref)
+        n, p1, p2 = hit
+        n = n.astype(float)
+        assert abs(np.linalg.norm(n) - 1) < 1e-5
+        along_n = float(overlap(a, b, n))
+        assert along_n <= ref + 1e-3, (trial, along_n, ref, n, dref)
+        pens = pen(n, p1.astype(float), p2.astype(float))
+        # (deep penetrations of a rounded shape are located by a fixed-count search along its axis: a few per cent of the depth on top of the 3 mm of face clipping)
+        assert abs(pens.max() - along_n) < 3e-3 + 0.06 * max(along_n, 0.0) and pens.max() <= along_n + 2e-4, (trial, pens, along_n)
+        assert (pens > -MAX_SEP - 1e-4).all()
+        tol3 = 2e-2 if along_n < 0.0 else 3e-3 + 0.06 * along_n
+        for q1, q2 in zip(p1, p2):
+            assert abs(a.signed_dist(q1)) < 2e-3 + tol3 + max(0.0, along_n), (trial, a.signed_dist(q1))
+            assert abs(b.signed_dist(q2)) < 2e-3 + tol3 + max(0.0, along_n), (trial, b.signed_dist(q2))
+        hit2 = collide(oracle, b, a, MAX_SEP)
+        assert hit2 is not None and len(hit2[1]) == len(p1)
+        assert abs(float(overlap(b, a, hit2[0].astype(float))) - along_n) < 1e-4
+        checked += 1
+    assert checked >= 14

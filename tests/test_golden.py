@@ -28,13 +28,13 @@ def check(name, make_world):
     assert seen == len(gs.CHECKPOINTS)
 
 
-@pytest.mark.parametrize("name", ["config1", "mixed", "car", "hulls_on_terrain", "config2"])
+@pytest.mark.parametrize("name", ["config1", "mixed", "car", "hulls_on_terrain", "big_hulls", "config2"])
 def test_oracle_reproduces_golden(oracle, name):
     check(name, lambda **kw: oracle.OracleWorld(**kw))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["config1", "mixed", "car", "hulls_on_terrain", "config2"])
+@pytest.mark.parametrize("name", ["config1", "mixed", "car", "hulls_on_terrain", "big_hulls", "config2"])
 def test_hip_path_reproduces_golden(name):
     from substrata_amd.lib import World
     check(name, lambda **kw: World(**kw))

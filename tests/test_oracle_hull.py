@@ -63,11 +63,22 @@ def test_builder_topology_and_mass_properties(oracle):
         w.hull_create([(0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0)])          # flat
     with pytest.raises(SgpError):
         w.hull_create([(0, 0, 0), (1, 0, 0), (2, 0, 0)])
-    # many points: reduced to <= 32 extreme points, still a closed polytope close to the sphere they came from
+    # many points: up to 256 are kept (JPH::ConvexHullShape::cMaxPointsInHull; rounds 1-4 kept 32 and lost a quarter of the sphere's volume), a closed polytope
     S = rng.normal(size=(500, 3)); S /= np.linalg.norm(S, axis=1, keepdims=True)
     s = w.hull_create(S)
-    assert s.num_vertices <= 32 and s.num_vertices - s.num_edges + s.num_faces == 2
-    assert 0.6 * 4.19 < s.volume < 4.19
+    assert 200 <= s.num_vertices <= 256 and s.num_vertices - s.num_edges + s.num_faces == 2
+    assert 0.96 * 4.18879 < s.volume < 4.18879
+    # 200 points on a sphere: every one of them is a vertex of the hull, and stays one
+    S2 = S[:200]
+    s2 = w.hull_create(S2)
+    assert s2.num_vertices == 200 and s2.num_faces == 396 and s2.num_edges == 594          # a triangulated sphere: F = 2 V - 4, E = 3 V - 6
+    from scipy.spatial import ConvexHull
+    assert abs(s2.volume - ConvexHull(S2.astype(np.float32).astype(np.float64)).volume) < 1e-4
+    # a finely tessellated cube (17 x 17 points per side): its coplanar triangles merge into the six quads, only the corners stay
+    g = np.linspace(-1, 1, 7)
+    C = np.array([(x, y, z) for x in g for y in g for z in g if max(abs(x), abs(y), abs(z)) == 1.0])
+    c6 = w.hull_create(C)
+    assert (c6.num_vertices, c6.num_faces, c6.num_edges) == (8, 6, 12) and abs(c6.volume - 8.0) < 1e-5
 
 
 def test_hull_cube_behaves_like_the_native_box(oracle):
@@ -167,7 +178,7 @@ def test_large_point_cloud_uses_every_vertex(oracle):
     pts = np.concatenate([near, far])
     w = oracle.OracleWorld(max_bodies=8)
     info = w.hull_create(pts)
-    assert info.num_vertices >= 8 and info.num_vertices <= 32
+    assert info.num_vertices == 8                                                      # nothing but the corners is on the hull
     ext = np.array(info.aabb_max[:]) - np.array(info.aabb_min[:])
     assert np.allclose(np.sort(ext), [1.0, 2.0, 4.0], atol=1e-3)
     assert abs(info.volume - 8.0) < 1e-2                                               # the clump is inside the box
@@ -175,3 +186,52 @@ def test_large_point_cloud_uses_every_vertex(oracle):
     info2 = w.hull_create(pts[rng.permutation(len(pts))])
     assert abs(info2.volume - info.volume) < 1e-4
     w.close()
+
+
+def test_triangle_against_a_big_hull_picks_the_axes_of_the_full_search(oracle, monkeypatch):
+    """A mesh triangle against a hull beyond 32 vertices: the Gauss-map selection of edge pairs (sgo_hull_sat_search, thin A) against the full search over
+    all 3 x E pairs (SGO_HULL_TRIANGLE_FULL_SEARCH) -- one step from the same state, for hulls thrown at the edges and corners of a coarse, folded mesh, must
+    leave the same contact counts and the same velocities to rounding."""
+    from test_mesh_parity_gpu import grid_mesh, mesh_body
+    from test_hull_parity_gpu import hull_descs
+    rng = np.random.default_rng(12)
+    V, T = grid_mesh(13, 9.0, lambda x, y: 0.8 * np.abs(np.sin(1.3 * x)) + 0.5 * np.abs(np.cos(1.1 * y)))      # 1.5 m triangles, ridges and valleys: edge and corner contacts
+    clouds = []
+    for n in (60, 150, 256):
+        p = rng.normal(size=(n, 3)); p /= np.linalg.norm(p, axis=1, keepdims=True)
+        clouds.append((p * rng.uniform(0.3, 0.7, size=3)).astype(np.float32))
+    a = np.linspace(0, 2 * np.pi, 40, endpoint=False)
+    clouds.append(np.array([(0.5 * np.cos(t), 0.5 * np.sin(t), z) for z in (-0.25, 0.25) for t in a], np.float32))
+    checked = 0
+    for trial in range(10):
+        res = []
+        for full in (False, True):
+            if full:
+                monkeypatch.setenv("SGO_HULL_TRIANGLE_FULL_SEARCH", "1")
+            else:
+                monkeypatch.delenv("SGO_HULL_TRIANGLE_FULL_SEARCH", raising=False)
+            r2 = np.random.default_rng(100 + trial)
+            w = oracle.OracleWorld(max_bodies=64)
+            w.add_batch(mesh_body(w.mesh_create(V, T)))
+            n_b = 0
+            for pts in clouds:
+                info = w.hull_create(pts)
+                k0 = n_b                                                      # (a place of its own for every body: the contacts are with the mesh)
+                pos = np.array([((k0 + q) % 4 * 4.0 - 6.0 + r2.uniform(-1, 1), (k0 + q) // 4 * 4.0 - 4.0 + r2.uniform(-1, 1), r2.uniform(2.0, 2.6)) for q in range(3)], np.float32)
+                d = hull_descs(info, pos, r2, mass=40.0)
+                d["lin_vel"][:, 2] = -3.0
+                w.add_batch(d); n_b += 3
+            hist = []
+            for s in range(40):
+                w.step(1 / 60)
+                st = w.stats()
+                hist.append((st.num_manifolds, st.num_contact_points))
+                if st.num_manifolds >= 8:
+                    break
+            res.append((hist, w.read_states(0, 3 + n_b)))
+            w.close()
+        (h0, s0), (h1, s1) = res
+        assert h0 == h1, (trial, h0, h1)
+        assert np.max(np.abs(s0["lin_vel"] - s1["lin_vel"])) < 2e-3 and np.max(np.abs(s0["pos"] - s1["pos"])) < 2e-4, trial
+        checked += h0[-1][0] >= 1
+    assert checked >= 6

@@ -36,6 +36,15 @@ def terrain(rng, n=14, size=36.0):
 
 
 def random_hull_points(rng):
+    kind = rng.random()
+    if kind < 0.25:      # (round 5) a hull beyond 32 vertices: points on an ellipsoid -- every one a corner -- or a prism / truncated cone over a many-sided polygon
+        if rng.random() < 0.6:
+            n = int(rng.integers(33, 257))
+            p = rng.normal(size=(n, 3)); p /= np.linalg.norm(p, axis=1, keepdims=True)
+            return (p * rng.uniform(0.25, 0.6, 3)).astype(np.float32)
+        m = int(rng.integers(17, 100)); a = np.linspace(0, 2 * np.pi, m, endpoint=False)
+        r0, r1, hh = rng.uniform(0.25, 0.6), rng.uniform(0.25, 0.6), rng.uniform(0.15, 0.5)
+        return np.array([(r0 * np.cos(t), r0 * np.sin(t), -hh) for t in a] + [(r1 * np.cos(t), r1 * np.sin(t), hh) for t in a], np.float32)
     n = int(rng.integers(6, 20))
     p = rng.normal(size=(n, 3)) * rng.uniform(0.25, 0.6, 3)
     return p.astype(np.float32)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Regenerates tests/golden/*.npz from the ORACLE (oracle/sgo_oracle.c).  Run from the repository root:
 
-    python tools/make_golden.py
+    python tools/make_golden.py [scenario ...]
 
 "full" fixtures hold every body's pose / velocity / active flag at steps 1, 10, 60, 240; "digest" fixtures (10k bodies) hold the
 SHA-256 of the same arrays, the first 64 bodies verbatim and three aggregates.  See tests/golden_scenes.py for the scenarios and
@@ -24,7 +24,10 @@ def main():
     oracle.build()
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
+    only = set(sys.argv[1:])                         # (names given: those fixtures only, the others stay as committed)
     for name, (fn, kind) in gs.SCENARIOS.items():
+        if only and name not in only:
+            continue
         arrays = {}
         for step, st in fn(lambda **kw: oracle.OracleWorld(**kw)):
             tag = f"s{step}_"
