@@ -126,7 +126,7 @@ def profile_leg(w, n_prof, exchange=None):
                 total_ms=total_ms / n_prof)
 
 
-def rooflines(prof, n_prof, vel_iters, pmc):
+def rooflines(prof, n_prof, vel_iters, pmc, same_workload_as_profiles=True):
     names, ksum, klaunch = prof["names"], prof["ksum"], prof["klaunch"]
     k = {nm: i for i, nm in enumerate(names)}
     sweep_classes = [c for c in ("apply_forces", "integrate_pose", "finalize", "sweep") if c in k]
@@ -155,7 +155,12 @@ def rooflines(prof, n_prof, vel_iters, pmc):
     # the same fraction by KERNEL time: HIP events around a launch also contain the dispatch gap in front of it (3 launches x ~1.5 us here); the
     # committed rocprofv3 --kernel-trace summary of the same command holds the kernels' own durations (profiles/kernel_time.json, written by
     # tools/rocpd_summary.py --json from the run that produced profiles/*kernel_stats_config3.md), so this figure reproduces from profiles/.
-    kt = load_kernel_times()
+    # (both committed files were measured on the default workload, config 3 on one GPU: another workload gets the per-body sweep traffic only, marked as such)
+    kt = load_kernel_times() if same_workload_as_profiles else None
+    if not same_workload_as_profiles:
+        solve_traffic = None
+        if roof["traffic"] is not None:
+            roof["traffic_source"] = "per-body figure measured at config 3 (100k bodies), scaled by this workload's body slots: " + roof["traffic_source"]
     if kt and prof["sweep_bodies"]:
         us = sum(kt["avg_us"].get(kn, 0.0) for kn in ("k_pre_solve", "k_integrate_pose", "k_finalize"))
         if us > 0:
@@ -308,7 +313,7 @@ def main():
         st = w.stats()
         n_prof = max(1, args.profile_steps)
         prof = profile_leg(w, n_prof, exchange=(ex.exchange if ex is not None else None))
-        roof, roof_solver, kernel_ms = rooflines(prof, n_prof, w.desc.settings.num_velocity_steps, pmc)
+        roof, roof_solver, kernel_ms = rooflines(prof, n_prof, w.desc.settings.num_velocity_steps, pmc, same_workload_as_profiles=False)
         ex_ms = ((ex_after.total_exchange_ms - ex_before.total_exchange_ms) / max(1, ex_after.exchanges - ex_before.exchanges)) if ex is not None else 0.0
         local = np.array([w.num_bodies() - 1 - (ex.last_imported if ex else 0), st.num_manifolds, st.num_active,
                           ex.last_exported if ex else 0, ex.last_imported if ex else 0, st.pairs_dropped + st.manifolds_dropped,
@@ -466,7 +471,7 @@ def main():
     pos_iters = w.desc.settings.num_position_steps
     st_prof = w.stats()
     w.close()
-    roof, roof_solver, kernel_ms = rooflines(prof, n_prof, vel_iters, pmc)
+    roof, roof_solver, kernel_ms = rooflines(prof, n_prof, vel_iters, pmc, same_workload_as_profiles=(workload == "config3" and args.bodies == 100000))
 
     steps_per_s = args.steps / elapsed
     ms_per_step = 1000.0 * elapsed / args.steps
