@@ -87,6 +87,18 @@ def single_gpu_reference(workload, lattice):
         return None
 
 
+def emit_line(out):
+    """Rank 0's ONE JSON line, as the last line of stdout: RCCL writes its version banner through C stdio, which (stdout being a pipe or a file) sits in
+    libc's buffer until exit and would land AFTER a Python print -- so libc's buffers are flushed first."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
+
+
 def load_pmc():
     try:
         with open(PMC_FILE) as f:
@@ -349,6 +361,14 @@ def main():
                                   f"oracle/sgo_oracle.c with {threads} OpenMP threads; this repo's CPU restatement, not JoltPhysics",
                         "contact_constraints": int(cst.num_manifolds), "host_cpus": os.cpu_count()}
             cw.close(); oracle.set_threads(1)
+        # (every rank empties libc's stdout buffer -- RCCL's version banner -- before rank 0 writes the line, so that nothing follows it at exit)
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        barrier()
         if rank == 0:
             steps_per_s = args.steps / elapsed
             out = {
@@ -373,7 +393,7 @@ def main():
                 },
                 "roofline": roof, "roofline_solver": roof_solver, "kernel_ms_per_step": kernel_ms, "cpu_baseline": cpu_base,
             }
-            print(json.dumps(out), flush=True)
+            emit_line(out)
         w.close()
         if dist is not None:
             dist.destroy_process_group()
@@ -627,7 +647,7 @@ def main():
         "bench_state_bit_exact_vs_oracle": (bench_parity["bit_exact"] if bench_parity else None),
         "bench_state_parity": bench_parity,
     }
-    print(json.dumps(out), flush=True)
+    emit_line(out)
 
 
 if __name__ == "__main__":
