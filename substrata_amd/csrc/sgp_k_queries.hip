@@ -117,6 +117,19 @@ SGP_DEV float ray_body(const DV& d, uint32_t type, float4 sh, v3 pos, quat q, v3
 
 struct RayBest { float t; uint32_t id; v3 n; RaySub sub; };
 
+// body i with its records already at hand (the same tests in the same order as ray_test_body below)
+SGP_DEV void ray_test_loaded(const DV& d, const sgp_ray& ry, v3 o, v3 dir, uint32_t i, uint32_t f, float4 amin, float4 amax, float4 prop1, float4 pose0, float4 pose1, RayBest& best)
+{
+	if (i == ry.ignore_id) return;
+	if (!(f & BF_ALIVE) || (f & BF_ALIAS)) return;
+	const uint32_t layer = f_layer(f);
+	if (ry.collidable_only && !(layer == SGP_LAYER_NON_MOVING || layer == SGP_LAYER_MOVING)) return;
+	if (!ray_aabb(o, dir, amin, amax, best.t)) return;
+	v3 nn; RaySub sub;
+	const float t = ray_body(d, f_shape(f), prop1, V3(pose0), Q4(pose1), o, dir, best.t, &nn, &sub);
+	// closest hit; ties go to the lower body id so the result does not depend on the traversal order
+	if (t >= 0.0f && t <= best.t && (t < best.t || best.id == SGP_INVALID_ID || i < best.id)) { best.t = t; best.id = i; best.n = nn; best.sub = sub; }
+}
 SGP_DEV void ray_test_body(const DV& d, const sgp_ray& ry, v3 o, v3 dir, uint32_t i, RayBest& best)
 {
 	if (i == ry.ignore_id) return;
@@ -129,6 +142,14 @@ SGP_DEV void ray_test_body(const DV& d, const sgp_ray& ry, v3 o, v3 dir, uint32_
 	const float t = ray_body(d, f_shape(f), d.prop[2 * (size_t)i + 1], V3(d.pose[2 * (size_t)i]), Q4(d.pose[2 * (size_t)i + 1]), o, dir, best.t, &nn, &sub);
 	// closest hit; ties go to the lower body id so the result does not depend on the traversal order
 	if (t >= 0.0f && t <= best.t && (t < best.t || best.id == SGP_INVALID_ID || i < best.id)) { best.t = t; best.id = i; best.n = nn; best.sub = sub; }
+}
+// ... with all of the body's records fetched at once (the resident server: a lone wave waits for every dependent fetch in full -- flags, then bounds, then
+// pose and shape is three round trips to memory where this is one; the batched kernel, bound by throughput, keeps the tests between the fetches)
+SGP_DEV void ray_test_body_eager(const DV& d, const sgp_ray& ry, v3 o, v3 dir, uint32_t i, RayBest& best)
+{
+	const uint32_t f = d.flags[i];
+	const float4 amin = d.aabb_min[i], amax = d.aabb_max[i], prop1 = d.prop[2 * (size_t)i + 1], pose0 = d.pose[2 * (size_t)i], pose1 = d.pose[2 * (size_t)i + 1];
+	ray_test_loaded(d, ry, o, dir, i, f, amin, amax, prop1, pose0, pose1, best);
 }
 
 // traceRay (PhysicsWorld.cpp:1668-1725), batched: one thread per ray.  Large bodies (ground quad ...) are tested directly;
@@ -214,22 +235,43 @@ SGP_DEV void ray_share_bound(RayBest& best, float& tmin)
 	tmin = wave_min_f(best.t);
 	if (best.t > tmin) { best.t = tmin; best.id = SGP_INVALID_ID; }      // (somebody is closer: this lane's hit cannot win; it keeps pruning with the wave's bound)
 }
-SGP_DEV sgp_hit raycast_wave(const DV& d, const sgp_ray& ry)
+// What the resident server keeps of the world between rays (LDS): the server is told to leave before anything touches the world (RayMailbox::stop_gen), so the
+// grid headers and the large bodies' records it read when it started are those of every ray it answers.
+#define RAY_CACHE_LARGE 16
+struct RayServerCache {
+	BpGrid g; LargeGrid lg; uint32_t n_large;
+	uint32_t id[RAY_CACHE_LARGE], f[RAY_CACHE_LARGE]; float4 amin[RAY_CACHE_LARGE], amax[RAY_CACHE_LARGE], prop1[RAY_CACHE_LARGE], pose0[RAY_CACHE_LARGE], pose1[RAY_CACHE_LARGE];
+};
+SGP_DEV void ray_cache_fill(const DV& d, RayServerCache& C)
+{
+	const int lane = (int)(threadIdx.x & 63u);
+	if (lane == 0) { C.g = *d.grid; C.lg = *d.lgrid; C.n_large = d.sp->n_large; }
+	__syncthreads();
+	if (lane < RAY_CACHE_LARGE && (uint32_t)lane < C.n_large) {
+		const uint32_t i = d.large_ids[lane];
+		C.id[lane] = i; C.f[lane] = d.flags[i]; C.amin[lane] = d.aabb_min[i]; C.amax[lane] = d.aabb_max[i];
+		C.prop1[lane] = d.prop[2 * (size_t)i + 1]; C.pose0[lane] = d.pose[2 * (size_t)i]; C.pose1[lane] = d.pose[2 * (size_t)i + 1];
+	}
+	__syncthreads();
+}
+#define RAY_WAVE_AHEAD 7      // cells of the walk looked at together: 7 x 9 neighbour rows = 63 lanes
+SGP_DEV sgp_hit raycast_wave(const DV& d, const sgp_ray& ry, const RayServerCache& C)
 {
 	const int lane = (int)(threadIdx.x & 63u);
 	const v3 o = V3(ry.origin[0], ry.origin[1], ry.origin[2]), dir = V3(ry.dir[0], ry.dir[1], ry.dir[2]);
 	RayBest best; best.t = ry.max_t; best.id = SGP_INVALID_ID; best.n = V3(0.0f, 0.0f, 0.0f);
 	best.sub.tri = SGP_INVALID_ID; best.sub.mat = 0; best.sub.u = best.sub.v = 0.0f;
 	float tmin = ry.max_t;
-	for (uint32_t l = (uint32_t)lane; l < d.sp->n_large; l += 64u) ray_test_body(d, ry, o, dir, d.large_ids[l], best);
+	if (C.n_large <= RAY_CACHE_LARGE) { if ((uint32_t)lane < C.n_large) ray_test_loaded(d, ry, o, dir, C.id[lane], C.f[lane], C.amin[lane], C.amax[lane], C.prop1[lane], C.pose0[lane], C.pose1[lane], best); }
+	else for (uint32_t l = (uint32_t)lane; l < C.n_large; l += 64u) ray_test_body(d, ry, o, dir, d.large_ids[l], best);
 	ray_share_bound(best, tmin);
-	{
+	if (C.lg.n_items) {
 		uint32_t dealt = 0;
 		const float bound = tmin;      // (fixed for the walk: every lane walks the same cells and counts the same candidates)
-		large_grid_ray(d, o, dir, &bound, [&](uint32_t i) { if ((int)(dealt++ & 63u) == lane) ray_test_body(d, ry, o, dir, i, best); });
+		large_grid_ray(d, o, dir, &bound, [&](uint32_t i) { if ((int)(dealt++ & 63u) == lane) ray_test_body_eager(d, ry, o, dir, i, best); });
 		ray_share_bound(best, tmin);
 	}
-	const BpGrid g = *d.grid;
+	const BpGrid g = C.g;
 	if (g.n_cells > 0 && g.min_x <= g.max_x) {
 		const float c = g.cell;
 		const v3 lo = V3(g.ox - c, g.oy - c, g.oz - c);
@@ -257,20 +299,32 @@ SGP_DEV sgp_hit raycast_wave(const DV& d, const sgp_ray& ry)
 			float tmy = fabsf(dir.y) > 1.0e-12f ? ((g.oy + (float)(cy + (sy > 0 ? 1 : 0)) * c) - o.y) / dir.y : inf;
 			float tmz = fabsf(dir.z) > 1.0e-12f ? ((g.oz + (float)(cz + (sz > 0 ? 1 : 0)) * c) - o.z) / dir.z : inf;
 			float t_enter = t0;
-			const int dy = lane % 3 - 1, dz = (lane / 3) % 3 - 1;      // lanes 0..8: one neighbour row each
-			for (int iter = 0; iter < 100000; ++iter) {
+			// The walk, RAY_WAVE_AHEAD cells at a time: the cells of the walk follow from arithmetic alone, so the wave works out the next seven, lane l takes
+			// neighbour row l % 9 of cell l / 9 of them, and the fetches of seven cells (page table -> cell table -> body records) are in flight together where the
+			// cell-by-cell walk paid them one after the other (a 20 m ray: 23 -> see profiles/NOTES_r05.md section 2).  A cell beyond the one where raycast_one stops
+			// can only hold bodies farther than the hit that stopped it (that is what stops it), so looking at it changes nothing.
+			const int my_step = lane / 9, row = lane % 9, dy = row % 3 - 1, dz = row / 3 - 1;
+			bool done = false;
+			for (int iter = 0; iter < 100000 && !done; ++iter) {
 				if (t_enter - 2.0f * c > tmin) break;
-				if (lane < 9) {
-					const int y = cy + dy, z = cz + dz;
-					const int xa = max(cx - 1, 0), xb = min(cx + 1, g.nx - 1);
+				int mx = 0, my = 0, mz = 0; bool mine = false;
+#pragma unroll
+				for (int k = 0; k < RAY_WAVE_AHEAD; ++k) {
+					if (!done) {
+						if (k == my_step && !(t_enter - 2.0f * c > tmin)) { mx = cx; my = cy; mz = cz; mine = true; }
+						if (tmx <= tmy && tmx <= tmz) { t_enter = tmx; tmx += tdx; cx += sx; if (cx < -1 || cx > g.nx) done = true; }
+						else if (tmy <= tmz) { t_enter = tmy; tmy += tdy; cy += sy; if (cy < -1 || cy > g.ny) done = true; }
+						else { t_enter = tmz; tmz += tdz; cz += sz; if (cz < -1 || cz > g.nz) done = true; }
+						if (t_enter > t1) done = true;
+					}
+				}
+				if (mine && lane < 9 * RAY_WAVE_AHEAD) {
+					const int y = my + dy, z = mz + dz;
+					const int xa = max(mx - 1, 0), xb = min(mx + 1, g.nx - 1);
 					if (y >= 0 && y < g.ny && z >= 0 && z < g.nz && xa <= xb)
-						grid_row_runs(d, g, xa, xb, y, z, [&](uint32_t q0, uint32_t q1) { for (uint32_t q = q0; q < q1; ++q) ray_test_body(d, ry, o, dir, __float_as_uint(d.sorted_max[q].w), best); });
+						grid_row_runs(d, g, xa, xb, y, z, [&](uint32_t q0, uint32_t q1) { for (uint32_t q = q0; q < q1; ++q) ray_test_body_eager(d, ry, o, dir, __float_as_uint(d.sorted_max[q].w), best); });
 				}
 				ray_share_bound(best, tmin);
-				if (tmx <= tmy && tmx <= tmz) { t_enter = tmx; tmx += tdx; cx += sx; if (cx < -1 || cx > g.nx) break; }
-				else if (tmy <= tmz) { t_enter = tmy; tmy += tdy; cy += sy; if (cy < -1 || cy > g.ny) break; }
-				else { t_enter = tmz; tmz += tdz; cz += sz; if (cz < -1 || cz > g.nz) break; }
-				if (t_enter > t1) break;
 			}
 		}
 	}
@@ -297,6 +351,8 @@ SGP_DEV sgp_hit raycast_wave(const DV& d, const sgp_ray& ry)
 __global__ void __launch_bounds__(64) k_ray_server(DV d, RayMailbox* mb, uint32_t first_seq, uint32_t generation, uint64_t idle_ticks, uint64_t max_ticks)
 {
 	const int lane = (int)threadIdx.x;
+	__shared__ RayServerCache cache;
+	ray_cache_fill(d, cache);
 	uint32_t* req_line = (uint32_t*)mb;
 	uint32_t* res_line = req_line + 16;
 	uint32_t seen = first_seq;
@@ -313,7 +369,7 @@ __global__ void __launch_bounds__(64) k_ray_server(DV d, RayMailbox* mb, uint32_
 			uint32_t* dst = (uint32_t*)&ry;
 #pragma unroll
 			for (int i = 0; i < (int)(sizeof(sgp_ray) / 4); ++i) dst[i] = (uint32_t)__shfl((int)wv, 2 + i, 64);
-			const sgp_hit h = raycast_wave(d, ry);
+			const sgp_hit h = raycast_wave(d, ry, cache);
 			const uint32_t* hs = (const uint32_t*)&h;
 			uint32_t out = 0u;
 			if (lane == 0 || lane == 15) out = req; else if (lane == 1) out = generation - 1u;      // (exited_gen: not this one)
