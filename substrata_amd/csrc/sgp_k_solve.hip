@@ -210,7 +210,9 @@ SGP_DEV void solve_position_one(const DV& d, uint32_t slot)
 // One launch = one colour of one pass.  The slot range comes from the device-side colour table, so the host never has
 // to know the counts of the current step; the grid is sized from the previous step and the loop strides over the rest.
 #define SOLVE_TPB 64      // one wave per workgroup: a colour of ~17k constraints then spreads over all 256 CUs instead of 67 of them
-template <int MODE, int ROWS = -1> __global__ void __launch_bounds__(MODE != 0 ? SOLVE_VEL_TPB : SOLVE_TPB) k_solve_colour(DV d, int colour_arg)
+// OCC: waves per SIMD the kernel is built for.  A colour of config 3 (~27k constraints) is less than one wave per SIMD and wants the registers; a colour of config 4
+// (300k+ constraints: nine waves per SIMD) runs in rounds, each a chain of dependent gathers, and wants the rounds to be few -- launch_solve_colour picks by size.
+template <int MODE, int ROWS = -1, int OCC = 1> __global__ void __launch_bounds__(MODE != 0 ? SOLVE_VEL_TPB : SOLVE_TPB, OCC) k_solve_colour(DV d, int colour_arg)
 {
 	const int colour = colour_arg & 0xFF;
 	const uint32_t first = d.cstarts[colour], end = d.cstarts[colour + 1];
@@ -779,6 +781,10 @@ void launch_colour_count_ts(const DV&, uint32_t, hipStream_t) {}
 void launch_setup_ts(const DV&, uint32_t, hipStream_t) {}
 void launch_ts_solve(const DV&, int, int, hipStream_t) {}
 #endif
+#define SOLVE_MANY_MIN 131072u      // constraints in a colour from which the launch runs in rounds (256 CUs x 4 SIMDs x 2-3 waves x 32 constraints = 65k-98k in flight)
+#ifndef SOLVE_MANY_OCC
+#define SOLVE_MANY_OCC 3
+#endif
 void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStream_t s, int compact_rows)
 {
 	uint32_t blocks = (est + est / 8 + 64 + SOLVE_TPB - 1) / SOLVE_TPB;      // warm start: one thread per constraint, one wave per workgroup
@@ -788,10 +794,12 @@ void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStr
 	if (mode != 0 && est >= 8192u && est <= 65536u) colour |= SOLVE_XCD_CHUNKS;      // (the colour's bodies and rows then fit the eight L2s)
 	if (mode == 0) hipLaunchKernelGGL(k_solve_colour<0>, dim3(blocks), dim3(SOLVE_TPB), 0, s, d, colour);
 	else if (mode == 1) {
-		if (compact_rows == 2) hipLaunchKernelGGL((k_solve_colour<1, 2>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour);
-		else if (compact_rows) hipLaunchKernelGGL((k_solve_colour<1, 1>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour);
+		const bool many = est > SOLVE_MANY_MIN;
+		if (compact_rows == 2) { if (many) hipLaunchKernelGGL((k_solve_colour<1, 2, SOLVE_MANY_OCC>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour); else hipLaunchKernelGGL((k_solve_colour<1, 2>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour); }
+		else if (compact_rows) { if (many) hipLaunchKernelGGL((k_solve_colour<1, 1, SOLVE_MANY_OCC>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour); else hipLaunchKernelGGL((k_solve_colour<1, 1>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour); }
 		else hipLaunchKernelGGL((k_solve_colour<1, 0>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour);
 	}
+	else if (est > SOLVE_MANY_MIN) hipLaunchKernelGGL((k_solve_colour<2, -1, SOLVE_MANY_OCC>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour);
 	else hipLaunchKernelGGL(k_solve_colour<2>, dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour);
 }
 void launch_warm_bodies(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_warm_bodies, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
