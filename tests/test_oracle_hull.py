@@ -235,3 +235,81 @@ def test_triangle_against_a_big_hull_picks_the_axes_of_the_full_search(oracle, m
         assert np.max(np.abs(s0["lin_vel"] - s1["lin_vel"])) < 2e-3 and np.max(np.abs(s0["pos"] - s1["pos"])) < 2e-4, trial
         checked += h0[-1][0] >= 1
     assert checked >= 6
+
+
+# ---- round 5: hulls beyond 32 vertices, analytic known answers ------------------------------------------------------
+
+def _fibonacci_sphere(n, r):
+    i = np.arange(n) + 0.5
+    z = 1.0 - 2.0 * i / n; rho = np.sqrt(1.0 - z * z); a = 2.399963229728653 * i
+    return (np.column_stack([rho * np.cos(a), rho * np.sin(a), z]) * r).astype(np.float32)
+
+
+def test_big_hull_mass_properties_approach_the_sphere(oracle):
+    """256 points spread evenly over a sphere of radius R: every one a corner; volume and inertia of the polytope approach 4/3 pi R^3 and 2/5 m R^2 from below
+    (an inscribed polytope of 508 triangles: ~2 % short in volume), isotropic to 1e-3, centre of mass at the centre."""
+    R = 0.5
+    w = oracle.OracleWorld(max_bodies=4)
+    info = w.hull_create(_fibonacci_sphere(256, R))
+    assert (info.num_vertices, info.num_faces, info.num_edges) == (256, 508, 762)                  # all triangles: F = 2V - 4, E = 3V - 6
+    vs = 4.0 / 3.0 * np.pi * R ** 3
+    assert 0.965 * vs < info.volume < vs
+    I = np.array(info.unit_inertia[:]); Is = 0.4 * vs * R * R
+    assert np.all(I < Is) and np.all(I > 0.93 * Is) and (I.max() - I.min()) / I.mean() < 2e-3
+    assert np.linalg.norm(info.com[:]) < 1e-3 * R
+    w.close()
+
+
+def test_many_sided_prism_rests_on_its_cap_and_stacks(oracle):
+    """A 64-gon prism (two caps of 64 corners: ONE face each; the manifold clips against every fourth corner) dropped flat comes to rest with its centre half its
+    height above the ground and falls asleep; a second one on top of it rests a full height higher, and neither drifts sideways -- the contact patch of
+    two large faces holds a stack."""
+    a = np.linspace(0, 2 * np.pi, 64, endpoint=False); r, hh = 0.6, 0.25
+    pts = np.array([(r * np.cos(t), r * np.sin(t), z) for z in (-hh, hh) for t in a], np.float32)
+    w = oracle.OracleWorld(max_bodies=8)
+    add_ground(w)
+    info = w.hull_create(pts)
+    assert (info.num_vertices, info.num_faces, info.num_edges) == (128, 66, 192)
+    lo = hull_body(w, info, pos_obj=(0, 0, hh + 0.05), mass=50.0, restitution=0.0)
+    hi = hull_body(w, info, pos_obj=(0.05, 0.03, 3 * hh + 0.15), rot_obj=quat_axis_angle((0, 0, 1), 0.4), mass=50.0, restitution=0.0)
+    for _ in range(480):
+        w.step(DT)
+    s_lo, s_hi = w.get_state([lo])[0], w.get_state([hi])[0]
+    assert abs(s_lo["pos"][2] - hh) < 0.025 and abs(s_hi["pos"][2] - 3 * hh) < 0.04                 # (within the penetration slop of the two contacts)
+    assert np.hypot(*s_lo["pos"][:2]) < 0.02 and np.hypot(s_hi["pos"][0] - 0.05, s_hi["pos"][1] - 0.03) < 0.03
+    assert s_lo["active"] == 0 and s_hi["active"] == 0
+    w.close()
+
+
+def test_many_sided_prism_slides_down_an_incline_by_coulomb_friction(oracle):
+    """The 64-gon prism flat on a 30 degree incline (a tilted static box).  Friction sqrt(0.3 x 0.3) = 0.3 < tan(30 deg): it slides with a = g (sin - mu cos);
+    friction 0.8: it stays where it is.  (A many-cornered BALL is no such test: rolling over its facets with restitution 0 it loses energy at every edge, as a
+    real polyhedron does -- 0.82 m/s^2 against the sphere's 1.22 on a 10 degree incline.)"""
+    th = np.radians(30.0); g = 9.81
+    a64 = np.linspace(0, 2 * np.pi, 64, endpoint=False); r, hh = 0.6, 0.25
+    pts = np.array([(r * np.cos(t), r * np.sin(t), z) for z in (-hh, hh) for t in a64], np.float32)
+    q = quat_axis_angle((0, 1, 0), th)                                   # +x is downhill
+    Rm = quat_to_mat(q); n = Rm @ np.array([0, 0, 1.0]); down = Rm @ np.array([1.0, 0, 0])
+    for mu, slides in ((0.3, True), (0.8, False)):
+        w = oracle.OracleWorld(max_bodies=8)
+        info = w.hull_create(pts)
+        ramp = scenes._blank(1)
+        ramp["shape_type"] = abi.SHAPE_BOX; ramp["shape"][0, :3] = (40.0, 4.0, 0.5); ramp["friction"] = mu
+        ramp["rot"][0] = q; ramp["pos"][0] = -0.5 * n
+        w.add_batch(ramp)
+        b = hull_body(w, info, pos_obj=tuple(n * (hh + 0.001) - down * 15.0), rot_obj=q, mass=30.0, friction=mu, restitution=0.0, lin_damp=0.0, ang_damp=0.0, allow_sleeping=0)
+        for _ in range(20):
+            w.step(DT)
+        v0 = float(np.dot(w.get_state([b])[0]["lin_vel"], down))
+        for _ in range(60):
+            w.step(DT)
+        s1 = w.get_state([b])[0]
+        v1 = float(np.dot(s1["lin_vel"], down))
+        if slides:
+            a_exp = g * (np.sin(th) - mu * np.cos(th))
+            assert abs((v1 - v0) - a_exp) < 0.03 * a_exp, (v1 - v0, a_exp)
+            assert np.linalg.norm(s1["ang_vel"]) < 0.05                                 # sliding on its cap, not tumbling
+        else:
+            assert abs(v1) < 1e-3 and abs(v0) < 1e-2
+        assert abs(np.dot(s1["pos"] - (n * hh), n)) < 0.03                              # still flat on the ramp (centre half a height above it)
+        w.close()
