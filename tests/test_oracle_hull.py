@@ -313,3 +313,25 @@ def test_many_sided_prism_slides_down_an_incline_by_coulomb_friction(oracle):
             assert abs(v1) < 1e-3 and abs(v0) < 1e-2
         assert abs(np.dot(s1["pos"] - (n * hh), n)) < 0.03                              # still flat on the ramp (centre half a height above it)
         w.close()
+
+
+def test_big_hulls_rest_on_a_flat_mesh_at_their_own_height(oracle):
+    """Mesh triangles against hulls beyond 32 vertices (the Gauss-map selection of the triangle's edge pairs): on a flat, finely triangulated floor the 64-gon prism
+    rests half its height above it and the 256-corner ball one radius (minus the sag of its flat facet: R (1 - cos(half a facet)) < 1 %), on the seams of the
+    triangles as anywhere else, and both fall asleep."""
+    from test_mesh_parity_gpu import grid_mesh, mesh_body
+    w = oracle.OracleWorld(max_bodies=16)
+    V, T = grid_mesh(21, 4.0, lambda x, y: 0.0)
+    w.add_batch(mesh_body(w.mesh_create(V, T)))
+    a64 = np.linspace(0, 2 * np.pi, 64, endpoint=False); r, hh, R = 0.6, 0.25, 0.5
+    prism = w.hull_create(np.array([(r * np.cos(t), r * np.sin(t), z) for z in (-hh, hh) for t in a64], np.float32))
+    ball = w.hull_create(_fibonacci_sphere(256, R))
+    bp = hull_body(w, prism, pos_obj=(0.37, -0.21, hh + 0.1), rot_obj=quat_axis_angle((0, 0, 1), 0.3), mass=40.0, restitution=0.0)
+    bb = hull_body(w, ball, pos_obj=(-2.03, 1.41, R + 0.1), mass=40.0, restitution=0.0)
+    for _ in range(600):
+        w.step(DT)
+    sp, sb = w.get_state([bp])[0], w.get_state([bb])[0]
+    assert abs(sp["pos"][2] - hh) < 0.025 and sp["active"] == 0
+    assert R * 0.985 - 0.02 < sb["pos"][2] < R + 0.005 and sb["active"] == 0
+    assert np.hypot(sp["pos"][0] - 0.37, sp["pos"][1] + 0.21) < 0.02
+    w.close()
