@@ -43,8 +43,9 @@ DT = 1.0 / 60.0
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HBM_ACHIEVABLE_GBS = 6300.0    # what a streaming kernel reaches on this part (same guide)
 SWEEP_BYTES_PER_BODY = 188     # integrate + AABB body-array sweep, 112 B read + 76 B written
-# per contact point per velocity iteration (compact rows, the default since round 5): 6 row vectors r x axis (3 axes x 2 bodies, float4) + lambdas read, lambdas written
-SOLVE_BYTES_PER_POINT = 6 * 16 + 16 + 16
+# per contact point per velocity iteration (no rows, the default from 65k constraints on since the end of round 5: the lanes rebuild r x axis and I (r x axis) from
+# the lever arms): two lever-arm records (float4: r1 | bias, r2 | effective mass of the normal row), the friction rows' effective masses (float2), lambdas read, lambdas written
+SOLVE_BYTES_PER_POINT = 2 * 16 + 8 + 16 + 16
 # per manifold: ab 8 + normal/friction 16 + np 4; the velocity records of two bodies read and written; their world-inverse-inertia records (DV::iw) read
 SOLVE_BYTES_PER_MANIFOLD = 28 + 2 * 32 + 2 * 32 + 2 * 32
 SETTLE_STEPS = 240             # lattice -> settled pile, untimed, independent of the command line

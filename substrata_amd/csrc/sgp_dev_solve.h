@@ -217,6 +217,67 @@ template <int VS, int ROWS = -1> SGP_DEV void solve_velocity_pair_t(const DV& d,
 	half_store(d, slot, side, h);
 }
 
+// The same for the layout without rows (ROWS = 2: worlds of a million constraints and more), written so that nothing is kept that is used once: a colour launch
+// loads a constraint, iterates it ONCE and stores it, so r x axis and I (r x axis) -- 72 registers of a ConHalf -- are built where the row is applied instead of
+// where the constraint is loaded.  The same expressions on the same operands in the same order as half_load_rows<2> + half_solve_core (each value is computed once
+// either way): the same bits.  What it buys is registers: the launch fits four waves per SIMD, and a colour of 300k constraints is nine waves per SIMD.
+template <int VS> SGP_DEV void solve_velocity_pair_norows(const DV& d, uint32_t slot, int side, float4* vel)
+{
+	const uint2 ab = CUR(d).ab[slot];
+	const int np = CUR(d).np_col[slot] & 0xFF;
+	const uint32_t body = side ? ab.y : ab.x;
+	const float4 nf = CUR(d).n_fric[slot];
+	float4 r4[4]; float2 et[4]; v3 lam[4];
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		if (i == 0 || i < np) { r4[i] = side ? CUR(d).r2e[i][slot] : CUR(d).r1b[i][slot]; et[i] = CUR(d).efft[i][slot]; lam[i] = V3(CUR(d).lam[i][slot]); }
+		else { r4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); et[i] = make_float2(0.0f, 0.0f); lam[i] = V3(0.0f, 0.0f, 0.0f); }
+	}
+	if (np == 0) return;                                    // a sensor pair: kept in the contact list, nothing to solve
+	const sym33 I = body_world_inv_inertia_rec(d, body);
+	float4 v4 = vel[VS * (size_t)body], w4 = vel[VS * (size_t)body + 1];
+	const float im = v4.w, friction = nf.w;
+	v3 lv = V3(v4), av = V3(w4);
+	const v3 n = V3(nf);
+	const v3 t1 = v3_normalized_perpendicular(n);
+	const v3 t2 = v3_cross(n, t1);
+	float eff0[4], bias[4];
+#pragma unroll
+	for (int i = 0; i < 4; ++i) { const float ow = lane_swap1(r4[i].w); eff0[i] = side ? r4[i].w : ow; bias[i] = side ? ow : r4[i].w; }
+	if (friction > 0.0f) {
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			if (i < np && !(et[i].x <= 0.0f && et[i].y <= 0.0f)) {
+				const v3 r = V3(r4[i]);
+				const v3 c1 = v3_cross(r, t1), c2 = v3_cross(r, t2);
+				float l1 = lam[i].y + et[i].x * half_jv(lv, av, t1, c1, side);
+				float l2 = lam[i].z + et[i].y * half_jv(lv, av, t2, c2, side);
+				const float max_f = friction * lam[i].x;
+				const float tot_sq = l1 * l1 + l2 * l2;
+				if (tot_sq > max_f * max_f) { const float sc = max_f / sqrtf(tot_sq); l1 = l1 * sc; l2 = l2 * sc; }
+				half_apply(lv, av, im, t1, sym33_mul(I, c1), l1 - lam[i].y, side); lam[i].y = l1;
+				half_apply(lv, av, im, t2, sym33_mul(I, c2), l2 - lam[i].z, side); lam[i].z = l2;
+			}
+		}
+	}
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		if (i < np && eff0[i] > 0.0f) {
+			const v3 c0 = v3_cross(V3(r4[i]), n);
+			const float jv = half_jv(lv, av, n, c0, side);
+			const float lambda = eff0[i] * (jv - bias[i]);
+			const float nl = max0f(lam[i].x + lambda);
+			half_apply(lv, av, im, n, sym33_mul(I, c0), nl - lam[i].x, side);
+			lam[i].x = nl;
+		}
+	}
+	if (im > 0.0f) { vel[VS * (size_t)body] = F4(lv, im); vel[VS * (size_t)body + 1] = F4(av, 0.0f); }
+	if (!side) {
+#pragma unroll
+		for (int i = 0; i < 4; ++i) { if (i < np) CUR(d).lam[i][slot] = F4(lam[i], 0.0f); }
+	}
+}
+
 // The position iteration of one manifold on TWO LANES (side 0 / 1 = body 1 / body 2, neighbouring lanes, both must call it): each lane carries
 // its own body's pose, computes its own contact point and its own share of the effective mass, swaps them with its neighbour, and corrects
 // its own body.  Same operands, same operations as solve_position_one (the effective mass is share of body 1 + share of body 2 there too),

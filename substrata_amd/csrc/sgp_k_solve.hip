@@ -224,7 +224,8 @@ template <int MODE, int ROWS = -1, int OCC = 1> __global__ void __launch_bounds_
 		// cache lines, and the same XCD meets the same rows again in the next pass.  (The grid is a multiple of eight: launch_solve_colour.)
 		const uint32_t bx = (colour_arg & SOLVE_XCD_CHUNKS) ? xcd_block() : blockIdx.x;      // (a colour of 200k constraints -- config 4 -- streams from HBM whatever the order, and lost 17 % with the chunks)
 		for (uint32_t k = first + ((bx * SOLVE_VEL_TPB + threadIdx.x) >> 1); k < end; k += gridDim.x * (SOLVE_VEL_TPB / 2)) {
-			if (MODE == 1) solve_velocity_pair_t<2, ROWS>(d, k, side, d.vel); else solve_position_pair(d, k, side);
+			if (MODE == 1) { if constexpr (ROWS == 2) solve_velocity_pair_norows<2>(d, k, side, d.vel); else solve_velocity_pair_t<2, ROWS>(d, k, side, d.vel); }
+			else solve_position_pair(d, k, side);
 		}
 		return;
 	}
@@ -795,7 +796,7 @@ void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStr
 	if (mode == 0) hipLaunchKernelGGL(k_solve_colour<0>, dim3(blocks), dim3(SOLVE_TPB), 0, s, d, colour);
 	else if (mode == 1) {
 		const bool many = est > SOLVE_MANY_MIN;
-		if (compact_rows == 2) { if (many) hipLaunchKernelGGL((k_solve_colour<1, 2, SOLVE_MANY_OCC>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour); else hipLaunchKernelGGL((k_solve_colour<1, 2>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour); }
+		if (compact_rows == 2) hipLaunchKernelGGL((k_solve_colour<1, 2>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour);      // (108 VGPRs: four waves per SIMD as it is, solve_velocity_pair_norows; five spill and lose)
 		else if (compact_rows) { if (many) hipLaunchKernelGGL((k_solve_colour<1, 1, SOLVE_MANY_OCC>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour); else hipLaunchKernelGGL((k_solve_colour<1, 1>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour); }
 		else hipLaunchKernelGGL((k_solve_colour<1, 0>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour);
 	}

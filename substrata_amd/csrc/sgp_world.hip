@@ -770,7 +770,7 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	const double tt0 = timing ? now() : 0.0;
 	w->h_sp->dt = dt;
-	w->h_sp->compact_rows = (w->high <= SGP_SMALL_WORLD_BODIES || w->n_con == 0u) ? 0u : (w->n_con >= w->compact_rows_min ? w->rows_mode_large : w->rows_mode_default);      // (decided from the previous step's count, part of the plan's key; no constraints: full rows cost nothing and k_pre_solve need not write the inertia records)
+	w->h_sp->compact_rows = (w->high <= SGP_SMALL_WORLD_BODIES || w->n_con == 0u) ? 0u : (w->n_con >= w->compact_rows_min ? w->rows_mode_large : (w->rows_mode_default == 2u && w->n_con < w->rows_mode2_min ? 1u : w->rows_mode_default));      // (decided from the previous step's count, part of the plan's key; no constraints: full rows cost nothing and k_pre_solve need not write the inertia records)
 	StepPlan plan;
 	make_plan(w, plan);
 	const std::string key((const char*)&plan, sizeof(plan));
