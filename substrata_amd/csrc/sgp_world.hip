@@ -227,6 +227,9 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	{ const char* e = getenv("SGP_VEHICLE_FUSED"); if (e) w->fuse_vehicle_solve = atoi(e) != 0; }
 	{ const char* e = getenv("SGP_COMPACT_ROWS_MIN"); if (e && atoll(e) >= 0) w->compact_rows_min = (uint32_t)atoll(e); }
 	{ const char* e = getenv("SGP_ROWS_MODE"); if (e && (atoi(e) == 1 || atoi(e) == 2)) w->rows_mode_large = (uint32_t)atoi(e); }
+	// (differential testing: a world of a few hundred bodies with the row layouts of the large ones -- only without the small-world kernel, which reads full rows)
+	{ const char* e = getenv("SGP_ROWS_IN_SMALL_WORLDS"); if (e && e[0] == '1' && !w->use_small_world) w->rows_in_small_worlds = true; }
+	{ const char* e = getenv("SGP_ROWS_MODE2_MIN"); if (e && atoll(e) >= 0) w->rows_mode2_min = (uint32_t)atoll(e); }
 	{ const char* e = getenv("SGP_ROWS_MODE_DEFAULT"); if (e && atoi(e) >= 0 && atoi(e) <= 2) w->rows_mode_default = (uint32_t)atoi(e); }
 	{ const char* e = getenv("SGP_TS_MIN_CONSTRAINTS"); if (e && atoi(e) >= 0) w->ts_min_constraints = (uint32_t)atoi(e); }
 	{ const char* e = getenv("SGP_HC_BUDGET"); if (e) { const int v = atoi(e); if (v <= 0) w->use_components = false; else w->hc_budget = (uint32_t)v; } }
@@ -770,7 +773,7 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	const double tt0 = timing ? now() : 0.0;
 	w->h_sp->dt = dt;
-	w->h_sp->compact_rows = (w->high <= SGP_SMALL_WORLD_BODIES || w->n_con == 0u) ? 0u : (w->n_con >= w->compact_rows_min ? w->rows_mode_large : (w->rows_mode_default == 2u && w->n_con < w->rows_mode2_min ? 1u : w->rows_mode_default));      // (decided from the previous step's count, part of the plan's key; no constraints: full rows cost nothing and k_pre_solve need not write the inertia records)
+	w->h_sp->compact_rows = ((w->high <= SGP_SMALL_WORLD_BODIES && !w->rows_in_small_worlds) || w->n_con == 0u) ? 0u : (w->n_con >= w->compact_rows_min ? w->rows_mode_large : (w->rows_mode_default == 2u && w->n_con < w->rows_mode2_min ? 1u : w->rows_mode_default));      // (decided from the previous step's count, part of the plan's key; no constraints: full rows cost nothing and k_pre_solve need not write the inertia records)
 	StepPlan plan;
 	make_plan(w, plan);
 	const std::string key((const char*)&plan, sizeof(plan));

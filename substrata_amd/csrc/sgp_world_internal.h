@@ -112,6 +112,7 @@ struct sgp_world {
 	bool use_graphs = true; bool use_small_world = true; bool use_wake_round = true; uint32_t tail_threshold = 256;
 	uint32_t rows_mode_default = 2;        // SGP_ROWS_MODE_DEFAULT: the layout below compact_rows_min constraints -- 1 compact rows: r x axis stored (96 B per point), I (r x axis) rebuilt by the lane from the
 	                                       // step's world-inverse-inertia record (DV::iw, round 5): config 3 496 -> 509, config 5 626 -> 652, config 2 915 -> 939 steps/s against 0 = full rows (192 B per point)
+	bool rows_in_small_worlds = false;     // SGP_ROWS_IN_SMALL_WORLDS=1 with SGP_NO_SMALL_WORLD=1 (tools/fuzz_parity.py): worlds of up to 2048 bodies, which otherwise keep full rows, take the layouts below
 	uint32_t rows_mode2_min = 65536;       // ... and below this many constraints compact rows (1) where the default says none (2): a world of 20k constraints spends its passes in the component and tail kernels, which keep a constraint for ten iterations and have the rows' use ten times (config 2: 942 against 934 steps/s)
 	uint32_t rows_mode_large = 2;          // SGP_ROWS_MODE: the layout worlds of at least compact_rows_min constraints use -- 2 no rows (the lanes rebuild them from the lever arms), 1 compact rows (r x axis only)
 	uint32_t compact_rows_min = 1000000;   // SGP_COMPACT_ROWS_MIN: from this many contact constraints on, the velocity rows are stored compact (96 B per point)

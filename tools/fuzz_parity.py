@@ -55,6 +55,8 @@ def run_seed(oracle, seed, steps, verbose=False):
     # both launch plans of small worlds get their share (the product reads the switch when the world is created)
     os.environ["SGP_NO_SMALL_WORLD"] = "1" if rng.random() < 0.4 else "0"
     # ... and of the large ones: colours with launches of their own (threshold), the rest by connected component (budget in per mille; 0 = tail kernel)
+    os.environ["SGP_ROWS_IN_SMALL_WORLDS"] = "1"      # (takes effect in the seeds that run without the small-world kernel: compact rows, or with the next line none)
+    os.environ["SGP_ROWS_MODE2_MIN"] = str(int(rng.choice([0, 65536])))      # (0: the no-rows layout, the default of worlds with 65k+ constraints, in a world of a few hundred)
     os.environ["SGP_TAIL_THRESHOLD"] = str(int(rng.choice([2, 8, 256])))
     os.environ["SGP_HC_BUDGET"] = str(int(rng.choice([0, 160, 400, 1000])))
     os.environ["SGP_HC_MIN_COLOURS"] = str(int(rng.choice([0, 0, 4])))      # (0: the component launch even where it replaces a single colour)
