@@ -21,7 +21,7 @@ UNITY = "sgp_kernels_experiments.hip"      # every stage file + csrc/experiments
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "sgp.h")]      # every header: several are generated
 EXPERIMENT_FILES = [os.path.join("experiments", f) for f in sorted(os.listdir(os.path.join(CSRC, "experiments")))]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
-         "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
+         "-fvisibility=hidden", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
 
 
 def hipcc():

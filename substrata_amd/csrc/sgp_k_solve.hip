@@ -212,10 +212,14 @@ SGP_DEV void solve_position_one(const DV& d, uint32_t slot)
 #define SOLVE_TPB 64      // one wave per workgroup: a colour of ~17k constraints then spreads over all 256 CUs instead of 67 of them
 // OCC: waves per SIMD the kernel is built for.  A colour of config 3 (~27k constraints) is less than one wave per SIMD and wants the registers; a colour of config 4
 // (300k+ constraints: nine waves per SIMD) runs in rounds, each a chain of dependent gathers, and wants the rounds to be few -- launch_solve_colour picks by size.
-template <int MODE, int ROWS = -1, int OCC = 1> __global__ void __launch_bounds__(MODE != 0 ? SOLVE_VEL_TPB : SOLVE_TPB, OCC) k_solve_colour(DV d, int colour_arg)
+// (the two leading pointer arguments repeat d.cstarts and d.sp: leading scalar arguments are PRELOADED into registers when the wave starts (kernarg preload,
+// -amdgpu-kernarg-preload-count), so the colour table and the buffer parity are requested at once, beside the fetch of the rest of the arguments instead of after it --
+// one dependent scalar fetch less on the chain of each of the ~110 colour launches of a step)
+template <int MODE, int ROWS = -1, int OCC = 1> __global__ void __launch_bounds__(MODE != 0 ? SOLVE_VEL_TPB : SOLVE_TPB, OCC) k_solve_colour(const uint32_t* cstarts_pre, StepParams* sp_pre, DV d_arg, int colour_arg)
 {
+	DV d = d_arg; d.sp = sp_pre;
 	const int colour = colour_arg & 0xFF;
-	const uint32_t first = d.cstarts[colour], end = d.cstarts[colour + 1];
+	const uint32_t first = cstarts_pre[colour], end = cstarts_pre[colour + 1];
 	if (MODE != 0) {
 		// velocity and position iterations: two neighbouring lanes per constraint
 		const int side = (int)(threadIdx.x & 1u);
@@ -470,7 +474,7 @@ __global__ void __launch_bounds__(HC_WG_PAIRS) k_hc_sort(DV d)
 // A workgroup's components own their movable bodies, so their solver records live in LDS for the whole pass (read once, written once; a
 // colour phase is an LDS gather, the arithmetic and an LDS scatter): HC_TABLE hash slots keyed by body id, filled by the lanes themselves.
 #define HC_TABLE 1024                 // >= 2 x the bodies a workgroup can meet (one per lane)
-template <int MODE, int ROWS = -1> __global__ void __launch_bounds__(HC_TPB) k_solve_hc(DV d, int first_colour)
+template <int MODE, int ROWS = -1> __global__ void __launch_bounds__(HC_TPB) k_solve_hc(const StepCounters* ctr_pre, const uint4* hc_entry_pre, DV d, int first_colour)      // (leading pointers: preloaded with the wave, k_solve_colour; `d` itself stays as passed -- the catch-all below takes it by reference, and a modified copy would live in scratch)
 {
 	constexpr int RS = MODE == 1 ? 2 : 3;      // float4 per body: velocity half (lin + inverse mass, ang) / pose half (pos + inverse mass, rot, inertia)
 	__shared__ float4 s_rec[HC_TABLE * RS];
@@ -479,14 +483,14 @@ template <int MODE, int ROWS = -1> __global__ void __launch_bounds__(HC_TPB) k_s
 	__shared__ uint32_t s_ticket;
 	const int side = (int)(threadIdx.x & 1u);
 	const uint32_t pair = threadIdx.x >> 1;
-	const uint32_t entries = d.ctr->hc_entries;
-	const int n_colours = (int)d.ctr->n_colours;
+	const uint32_t entries = ctr_pre->hc_entries;
+	const int n_colours = (int)ctr_pre->n_colours;
 	for (uint32_t e0 = blockIdx.x * HC_WG_PAIRS; e0 < entries; e0 += gridDim.x * HC_WG_PAIRS) {
 		__syncthreads();      // (everyone is done with the previous round's table and mask)
 		for (uint32_t i = threadIdx.x; i < HC_TABLE; i += HC_TPB) s_key[i] = HC_NONE;
 		if (threadIdx.x == 0) s_present = 0ull;
 		__syncthreads();
-		const uint4 entry = d.hc_entry[e0 + pair];
+		const uint4 entry = hc_entry_pre[e0 + pair];
 		const uint32_t slot = entry.x;
 		const bool mine = slot != HC_NONE;
 		ConHalf h; PosHalf ph; int my_col = -1;
@@ -793,15 +797,15 @@ void launch_solve_colour(const DV& d, int colour, uint32_t est, int mode, hipStr
 	if (blocks > 8192) blocks = 8192;
 	if (mode != 0) blocks = (blocks + 7u) & ~7u;      // (XCD-contiguous chunks: k_solve_colour)
 	if (mode != 0 && est >= 8192u && est <= 65536u) colour |= SOLVE_XCD_CHUNKS;      // (the colour's bodies and rows then fit the eight L2s)
-	if (mode == 0) hipLaunchKernelGGL(k_solve_colour<0>, dim3(blocks), dim3(SOLVE_TPB), 0, s, d, colour);
+	if (mode == 0) hipLaunchKernelGGL(k_solve_colour<0>, dim3(blocks), dim3(SOLVE_TPB), 0, s, (const uint32_t*)d.cstarts, d.sp, d, colour);
 	else if (mode == 1) {
 		const bool many = est > SOLVE_MANY_MIN;
-		if (compact_rows == 2) hipLaunchKernelGGL((k_solve_colour<1, 2>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour);      // (108 VGPRs: four waves per SIMD as it is, solve_velocity_pair_norows; five spill and lose)
-		else if (compact_rows) { if (many) hipLaunchKernelGGL((k_solve_colour<1, 1, SOLVE_MANY_OCC>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour); else hipLaunchKernelGGL((k_solve_colour<1, 1>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour); }
-		else hipLaunchKernelGGL((k_solve_colour<1, 0>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour);
+		if (compact_rows == 2) hipLaunchKernelGGL((k_solve_colour<1, 2>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, (const uint32_t*)d.cstarts, d.sp, d, colour);      // (108 VGPRs: four waves per SIMD as it is, solve_velocity_pair_norows; five spill and lose)
+		else if (compact_rows) { if (many) hipLaunchKernelGGL((k_solve_colour<1, 1, SOLVE_MANY_OCC>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, (const uint32_t*)d.cstarts, d.sp, d, colour); else hipLaunchKernelGGL((k_solve_colour<1, 1>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, (const uint32_t*)d.cstarts, d.sp, d, colour); }
+		else hipLaunchKernelGGL((k_solve_colour<1, 0>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, (const uint32_t*)d.cstarts, d.sp, d, colour);
 	}
-	else if (est > SOLVE_MANY_MIN) hipLaunchKernelGGL((k_solve_colour<2, -1, SOLVE_MANY_OCC>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour);
-	else hipLaunchKernelGGL(k_solve_colour<2>, dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour);
+	else if (est > SOLVE_MANY_MIN) hipLaunchKernelGGL((k_solve_colour<2, -1, SOLVE_MANY_OCC>), dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, (const uint32_t*)d.cstarts, d.sp, d, colour);
+	else hipLaunchKernelGGL(k_solve_colour<2>, dim3(blocks), dim3(SOLVE_VEL_TPB), 0, s, (const uint32_t*)d.cstarts, d.sp, d, colour);
 }
 void launch_warm_bodies(const DV& d, uint32_t nb, hipStream_t s) { hipLaunchKernelGGL(k_warm_bodies, dim3(blocks_for(nb)), dim3(TPB), 0, s, d); }
 void launch_solve_tail(const DV& d, int first_colour, int mode, hipStream_t s, int compact_rows)
@@ -835,11 +839,11 @@ void launch_solve_hc(const DV& d, int first_colour, uint32_t est, int mode, hipS
 	// list entries: a component of n constraints takes the next power of two (< 2 n), plus the padding of the classes
 	const uint32_t blocks = std::max(1u, std::min(2048u, (2u * est + HC_CLASSES * HC_WG_PAIRS) / HC_WG_PAIRS));
 	if (mode == 1) {
-		if (compact_rows == 2) hipLaunchKernelGGL((k_solve_hc<1, 2>), dim3(blocks), dim3(HC_TPB), 0, s, d, first_colour);
-		else if (compact_rows) hipLaunchKernelGGL((k_solve_hc<1, 1>), dim3(blocks), dim3(HC_TPB), 0, s, d, first_colour);
-		else hipLaunchKernelGGL((k_solve_hc<1, 0>), dim3(blocks), dim3(HC_TPB), 0, s, d, first_colour);
+		if (compact_rows == 2) hipLaunchKernelGGL((k_solve_hc<1, 2>), dim3(blocks), dim3(HC_TPB), 0, s, (const StepCounters*)d.ctr, (const uint4*)d.hc_entry, d, first_colour);
+		else if (compact_rows) hipLaunchKernelGGL((k_solve_hc<1, 1>), dim3(blocks), dim3(HC_TPB), 0, s, (const StepCounters*)d.ctr, (const uint4*)d.hc_entry, d, first_colour);
+		else hipLaunchKernelGGL((k_solve_hc<1, 0>), dim3(blocks), dim3(HC_TPB), 0, s, (const StepCounters*)d.ctr, (const uint4*)d.hc_entry, d, first_colour);
 	}
-	else hipLaunchKernelGGL((k_solve_hc<2, -1>), dim3(blocks), dim3(HC_TPB), 0, s, d, first_colour);
+	else hipLaunchKernelGGL((k_solve_hc<2, -1>), dim3(blocks), dim3(HC_TPB), 0, s, (const StepCounters*)d.ctr, (const uint4*)d.hc_entry, d, first_colour);
 }
 void launch_solve_small(const DV& d, int warm_start, int iterations, int lane_pairs, hipStream_t s)
 {
