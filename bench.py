@@ -4,6 +4,11 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+Called directly with --gpus N > 1 (no WORLD_SIZE in the environment) it launches itself through torch.distributed.run with N ranks on 127.0.0.1
+and hands the ranks' output through, rank 0's JSON line last.  SGP_BENCH_SHARE_GPU=1 (a test switch, tests/test_bench_selflaunch_gpu.py) puts every
+rank on cuda:0 with gloo between the processes and the test-only collective library behind SGP_RCCL_LIBRARY: the line then says
+"transport": "test stand-in" and is never a scaling number.
+
 A "step" is one PhysicsWorld::think(1/60) (/root/reference/gui_client/PhysicsWorld.cpp:1356-1443).  All state is resident in HBM
 before the timed region; every step blocks until the device has finished it, like think().
 
@@ -57,7 +62,7 @@ PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # per-launch HBM
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--steps", type=int, default=600)      # >= 600 timed steps after 120 warm-up steps
     ap.add_argument("--warmup", type=int, default=120)
     ap.add_argument("--bodies", type=int, default=100000, help="config3: bodies per tile (BASELINE: 100k)")
     ap.add_argument("--workload", default="auto", choices=["auto", "config3", "config4", "config5"],
@@ -191,8 +196,36 @@ def rooflines(prof, n_prof, vel_iters, pmc, same_workload_as_profiles=True):
     return roof, roof_solver, kernel_ms
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` as the driver calls it, N > 1 and no launcher around it: run the same command line through torch.distributed.run
+    (one rank per GPU, rendezvous on 127.0.0.1 at a free port) and hand its output through -- rank 0's JSON line last, whatever the launcher or
+    a library's exit handlers printed after it."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL / tensor sharing across processes on this driver)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = r.stdout.splitlines()
+    result = [l for l in lines if l.startswith('{"metric"')]
+    for l in lines:
+        if not result or l is not result[-1]:
+            print(l)
+    sys.stdout.flush()
+    if result:
+        print(result[-1], flush=True)
+    raise SystemExit(r.returncode if r.returncode or result else 1)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     import torch
     from substrata_amd import abi, scenes, tiles
     from substrata_amd.lib import World, init
@@ -201,26 +234,36 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     n_gpus = args.gpus
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     dist = None
+    # test switch: every rank on cuda:0, gloo between the processes, the exchange's collectives through the library SGP_RCCL_LIBRARY names (the test-only
+    # stand-in: real RCCL wants one GPU per rank).  Proves the launch path on a one-GPU box; its numbers are labelled and mean nothing.
+    share_gpu = os.environ.get("SGP_BENCH_SHARE_GPU", "0") == "1"
+    if share_gpu and world_size > 1:
+        if not os.environ.get("SGP_RCCL_LIBRARY"):
+            raise SystemExit("SGP_BENCH_SHARE_GPU=1 needs SGP_RCCL_LIBRARY (tests/rccl_standin/librccl_standin.so): RCCL itself refuses two ranks on one GPU")
+        local_rank = 0
     if world_size > 1 or args.force_comm:
         import torch.distributed as dist
         if args.force_comm and world_size == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))      # "nccl" IS RCCL on ROCm
+        if share_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))      # "nccl" IS RCCL on ROCm
         assert world_size == n_gpus, "launch with --nproc-per-node equal to --gpus"
     elif n_gpus != 1:
-        raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run with N ranks")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+        raise SystemExit("--gpus N > 1 needs N ranks (WORLD_SIZE is set but 1?)")
     init()
     workload = args.workload
     if workload == "auto":
         workload = "config3" if n_gpus == 1 else "config4"
     if workload == "config5" and n_gpus != 1:
         raise SystemExit("--workload config5 is a single-GPU measurement")
-    xdev = torch.device("cuda", local_rank)
+    xdev = torch.device("cpu") if (share_gpu and world_size > 1) else torch.device("cuda", local_rank)      # where the tensors of the torch.distributed calls live
     pmc = load_pmc()
 
     def barrier():
@@ -286,6 +329,8 @@ def main():
                 print(f"[bench rank {rank}] native tile exchange (sgp_tiles_create over RCCL) failed: {err or 'on another rank'}", file=sys.stderr, flush=True)
                 raise SystemExit(f"bench.py --gpus {n_gpus}: the sgp_tiles_* exchange could not be set up on every rank; there is no fallback transport")
             exchange_kind = "sgp_tiles_exchange: device routing + RCCL all-gather of counts + grouped send/recv inside libsgp.so"
+            if os.environ.get("SGP_RCCL_LIBRARY"):
+                exchange_kind += f" -- collective library overridden by SGP_RCCL_LIBRARY={os.environ['SGP_RCCL_LIBRARY']}"
 
 
         # config 4 over several tiles: the regions follow the bodies (sgp_tiles_rebalance every --retile-every steps; 0 = the static split, whose upper
@@ -394,6 +439,9 @@ def main():
                 },
                 "roofline": roof, "roofline_solver": roof_solver, "kernel_ms_per_step": kernel_ms, "cpu_baseline": cpu_base,
             }
+            if share_gpu and world_size > 1:
+                out["transport"] = "test stand-in"
+                out["note"] = "SGP_BENCH_SHARE_GPU=1: every rank ran on cuda:0 behind a test-only collective library -- a launch-path check, NOT a scaling number"
             emit_line(out)
         w.close()
         if dist is not None:
@@ -501,7 +549,9 @@ def main():
     out = {
         "metric": "physics steps/sec at fixed dt, 100k bodies" if workload == "config3" else "physics steps/sec at fixed dt, 1k cars + 50k debris",
         "value": steps_per_s, "unit": "steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "ms_per_step": ms_per_step, "higher_is_better": True,
+        # one GPU: nothing is scaled on this line.  `--gpus N` > 1 runs BASELINE config 4 (1M boxes) STRONG-scaled over N tiles and says "strong" on its own line.
+        "scaling": None, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": (f"BASELINE config 3: {n_bodies} mixed box/sphere/capsule bodies, 100x100x{max(1, args.bodies // 10000)} lattice spacing 1.5 m, seed 3, "
                          "ground quad 2000 m, dt 1/60, Jolt default settings (10 velocity / 2 position iterations), sleeping enabled")

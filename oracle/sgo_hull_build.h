@@ -41,14 +41,118 @@ static inline void sgo_jacobi3(double a[3][3], double v[3][3])
 	}
 }
 
+/* A candidate for a face's plane: three points and twice the area of their triangle. */
+typedef struct { double len; unsigned char a, b, c; } sgo_cand;
+static inline int sgo_cand_cmp(const void* x, const void* y)
+{
+	const sgo_cand* p = (const sgo_cand*)x; const sgo_cand* q = (const sgo_cand*)y;
+	if (p->len != q->len) return p->len > q->len ? -1 : 1;      /* largest first */
+	if (p->a != q->a) return (int)p->a - (int)q->a;
+	if (p->b != q->b) return (int)p->b - (int)q->b;
+	return (int)p->c - (int)q->c;
+}
+
+/* Faces from candidate triangles (round 6): one face per supporting plane = ALL points of the cloud within eps of it, reduced to the corners of
+   their polygon.  The candidates are walked from the largest triangle down, so a face takes its plane from a well-conditioned triangle -- on a cap whose points
+   are coplanar only to float rounding the first triangle met can be a sliver with a garbage normal (round 5 took that one) --, a candidate whose corners already
+   lie in an accepted face is that face again, and a candidate whose plane has points on both sides (a triangle of a hull that went wrong) is no face.
+   Returns the number of faces (planes fn / fd, corners per face in fmem / fmem_start, ascending point index), < 0 when the tables overflow. */
+static inline int sgo_faces_from_candidates(const sgo_d3* pts, int n, double eps, double ext, sgo_cand* cand, int ncand, sgo_d3* fn, double* fd, unsigned short* fmem_start, unsigned char* fmem, int fmem_cap)
+{
+	int nf = 0, nm = 0;
+	qsort(cand, (size_t)ncand, sizeof(sgo_cand), sgo_cand_cmp);
+	for (int ci = 0; ci < ncand; ++ci) {
+		if (!(cand[ci].len > 1.0e-9 * ext * ext)) break;           /* (sorted: the rest is degenerate) */
+		const sgo_d3 pa = pts[cand[ci].a], pb = pts[cand[ci].b], pc = pts[cand[ci].c];
+		int known = 0;
+		for (int f = 0; f < nf && !known; ++f)
+			if (fabs(sgo_d3_dot(fn[f], pa) - fd[f]) <= eps && fabs(sgo_d3_dot(fn[f], pb) - fd[f]) <= eps && fabs(sgo_d3_dot(fn[f], pc) - fd[f]) <= eps) known = 1;
+		if (known) continue;
+		sgo_d3 nn = sgo_d3_cross(sgo_d3_sub(pb, pa), sgo_d3_sub(pc, pa));
+		const double len = sqrt(sgo_d3_dot(nn, nn));
+		if (!(len > 0.0)) continue;
+		nn.x /= len; nn.y /= len; nn.z /= len;
+		const double d0 = sgo_d3_dot(nn, pa);
+		double mx = 0.0, mn = 0.0;
+		for (int q = 0; q < n; ++q) { const double sd = sgo_d3_dot(nn, pts[q]) - d0; if (sd > mx) mx = sd; if (sd < mn) mn = sd; }
+		if (mx > eps && mn < -eps) continue;                       /* points on both sides: not a supporting plane */
+		if (mx > eps) { nn.x = -nn.x; nn.y = -nn.y; nn.z = -nn.z; }
+		const double dd = sgo_d3_dot(nn, pa);
+		if (nf == SGO_HULL_MAX_FACES) return -2;
+		fn[nf] = nn; fd[nf] = dd; fmem_start[nf] = (unsigned short)nm;
+		int cnt = 0;
+		for (int q = 0; q < n; ++q) if (fabs(sgo_d3_dot(nn, pts[q]) - dd) <= eps) { if (nm == fmem_cap) return -2; fmem[nm++] = (unsigned char)q; ++cnt; }
+		/* only the corners of the face's polygon stay: points inside a face or along one of its sides (a tessellated flat side) are not vertices of the
+		   solid.  Convex hull of the members in the face's plane (monotone chain). */
+		{
+			const int m0 = fmem_start[nf];
+			sgo_d3 u = sgo_d3_sub(pts[fmem[m0 + 1]], pts[fmem[m0]]);
+			for (int k = m0 + 2; k < nm; ++k) { const sgo_d3 u2 = sgo_d3_sub(pts[fmem[k]], pts[fmem[m0]]); if (sgo_d3_dot(u2, u2) > sgo_d3_dot(u, u)) u = u2; }
+			const double ul = sqrt(sgo_d3_dot(u, u)); u.x /= ul; u.y /= ul; u.z /= ul;
+			const sgo_d3 w = sgo_d3_cross(nn, u);
+			double px[256], py[256]; int ord[256];
+			for (int k = 0; k < cnt; ++k) { const sgo_d3 r = sgo_d3_sub(pts[fmem[m0 + k]], pts[fmem[m0]]); px[k] = sgo_d3_dot(r, u); py[k] = sgo_d3_dot(r, w); ord[k] = k; }
+			for (int a = 1; a < cnt; ++a) { const int o = ord[a]; int bb = a - 1; while (bb >= 0 && (px[ord[bb]] > px[o] || (px[ord[bb]] == px[o] && py[ord[bb]] > py[o]))) { ord[bb + 1] = ord[bb]; --bb; } ord[bb + 1] = o; }
+			int hullk[512]; int hk = 0;
+			const double tol = eps * ul;                       /* (twice the area of a triangle as thin as eps over the face's extent) */
+			for (int pass = 0; pass < 2; ++pass) {
+				const int base = hk;
+				for (int ii = 0; ii < cnt; ++ii) {
+					const int o = pass == 0 ? ord[ii] : ord[cnt - 1 - ii];
+					while (hk - base >= 2) {
+						const int o1 = hullk[hk - 1], o0 = hullk[hk - 2];
+						const double cr = (px[o1] - px[o0]) * (py[o] - py[o0]) - (py[o1] - py[o0]) * (px[o] - px[o0]);
+						if (cr <= tol) --hk; else break;
+					}
+					hullk[hk++] = o;
+				}
+				--hk;                                          /* (the last point of a chain is the first of the next) */
+			}
+			unsigned char keepm[256]; memset(keepm, 0, sizeof(keepm));
+			for (int k = 0; k < hk; ++k) keepm[hullk[k]] = 1;
+			int m1 = m0;
+			for (int k = 0; k < cnt; ++k) if (keepm[k]) fmem[m1++] = fmem[m0 + k];
+			nm = m1; cnt = m1 - m0;
+		}
+		if (cnt < 3) { nm = fmem_start[nf]; continue; }
+		++nf;
+	}
+	fmem_start[nf] = (unsigned short)nm;
+	/* A face whose corners all belong to another face is that face seen from a plane a hair off.  It goes.  Two passes: which faces are covered is
+	   decided against the untouched arrays, then the arrays are compacted. */
+	{
+		unsigned char covered[SGO_HULL_MAX_FACES + 1]; memset(covered, 0, sizeof(covered));
+		for (int f = 0; f < nf; ++f) {
+			const int f0 = fmem_start[f], cf = fmem_start[f + 1] - f0;
+			for (int g = 0; g < nf && !covered[f]; ++g) {
+				if (g == f) continue;
+				const int g0 = fmem_start[g], cg = fmem_start[g + 1] - g0;
+				if (cg < cf || (cg == cf && g > f)) continue;
+				int all = 1;
+				for (int k = 0; k < cf && all; ++k) { int found = 0; for (int m = 0; m < cg; ++m) if (fmem[g0 + m] == fmem[f0 + k]) { found = 1; break; } all = found; }
+				covered[f] = (unsigned char)all;
+			}
+		}
+		int nf2 = 0, nm2 = 0;
+		for (int f = 0; f < nf; ++f) {
+			if (covered[f]) continue;
+			const int f0 = fmem_start[f], f1 = fmem_start[f + 1];      /* (read before entry nf2 <= f is overwritten; entry f + 1 is still the old one) */
+			fn[nf2] = fn[f]; fd[nf2] = fd[f];
+			for (int k = f0; k < f1; ++k) fmem[nm2 + (k - f0)] = fmem[k];      /* (nm2 <= f0: moving down, never over unread members) */
+			fmem_start[nf2] = (unsigned short)nm2; nm2 += f1 - f0; ++nf2;
+		}
+		fmem_start[nf2] = (unsigned short)nm2; nf = nf2;
+	}
+	return nf;
+}
+
 /* Faces of a cloud of 33 .. 256 points (round 5): incremental hull over the points in index order (initial tetrahedron from the extreme points, then every
-   point outside the hull so far replaces the triangles it sees by a fan from their horizon), the triangles' supporting planes, one face per plane = all hull
-   vertices on it.  Deterministic: ties go to the lower index everywhere.  Returns the number of faces (planes fn / fd, members per face in fmem / fmem_start,
-   ascending point index), < 0 on a degenerate cloud. */
+   point outside the hull so far replaces the triangles it sees by a fan from their horizon); its triangles are the candidates sgo_faces_from_candidates
+   assembles the faces from (round 6).  Deterministic: ties go to the lower index everywhere.  Returns the number of faces, < 0 on a degenerate cloud. */
 static inline int sgo_hull_faces_large(const sgo_d3* pts, int n, double eps, double ext, sgo_d3* fn, double* fd, unsigned short* fmem_start, unsigned char* fmem, int fmem_cap)
 {
 	enum { TCAP = 8192 };
-	typedef struct { int a, b, c, alive; sgo_d3 n; double d; } tri_t;
+	typedef struct { int a, b, c, alive; sgo_d3 n; double d, len; } tri_t;      /* len: twice the area */
 	tri_t* T = (tri_t*)malloc(sizeof(tri_t) * TCAP);
 	short* etri = (short*)malloc(sizeof(short) * 256 * 256);      /* triangle holding the directed edge a -> b */
 	int nt = 0, result = -1;
@@ -75,7 +179,7 @@ static inline int sgo_hull_faces_large(const sgo_d3* pts, int n, double eps, dou
 			sgo_d3 nn = sgo_d3_cross(sgo_d3_sub(pts[tr.b], pts[tr.a]), sgo_d3_sub(pts[tr.c], pts[tr.a]));
 			double len = sqrt(sgo_d3_dot(nn, nn)); nn.x /= len; nn.y /= len; nn.z /= len;
 			if (sgo_d3_dot(nn, cen) - sgo_d3_dot(nn, pts[tr.a]) > 0.0) { const int tmp = tr.b; tr.b = tr.c; tr.c = tmp; nn.x = -nn.x; nn.y = -nn.y; nn.z = -nn.z; }
-			tr.n = nn; tr.d = sgo_d3_dot(nn, pts[tr.a]);
+			tr.n = nn; tr.d = sgo_d3_dot(nn, pts[tr.a]); tr.len = len;
 			T[nt++] = tr;
 		}
 		used[p0] = used[p1] = used[p2] = used[p3] = 1;
@@ -101,147 +205,54 @@ static inline int sgo_hull_faces_large(const sgo_d3* pts, int n, double eps, dou
 					const double len = sqrt(sgo_d3_dot(nn, nn));
 					if (!(len > 0.0)) goto done;
 					nn.x /= len; nn.y /= len; nn.z /= len;
-					tr.n = nn; tr.d = sgo_d3_dot(nn, pts[tr.a]);
+					tr.n = nn; tr.d = sgo_d3_dot(nn, pts[tr.a]); tr.len = len;
 					T[nt++] = tr;
 				}
 			}
 			for (int t = 0; t < nt0; ++t) if (T[t].alive == 2) T[t].alive = 0;
 			used[q] = 1;
 		}
-		/* hull vertices: the corners of what is left */
-		unsigned char on[256]; memset(on, 0, sizeof(on));
-		for (int t = 0; t < nt; ++t) if (T[t].alive) { on[T[t].a] = on[T[t].b] = on[T[t].c] = 1; }
-		/* one face per supporting plane: all hull vertices on it */
-		int nf = 0, nm = 0;
-		for (int t = 0; t < nt; ++t) {
-			if (!T[t].alive) continue;
-			int known = 0;
-			for (int f = 0; f < nf && !known; ++f) {
-				if (sgo_d3_dot(fn[f], T[t].n) < 0.999999) continue;
-				if (fabs(sgo_d3_dot(fn[f], pts[T[t].a]) - fd[f]) <= eps && fabs(sgo_d3_dot(fn[f], pts[T[t].b]) - fd[f]) <= eps && fabs(sgo_d3_dot(fn[f], pts[T[t].c]) - fd[f]) <= eps) known = 1;
-			}
-			if (known) continue;
-			if (nf == SGO_HULL_MAX_FACES) { result = -2; goto done; }
-			fn[nf] = T[t].n; fd[nf] = T[t].d; fmem_start[nf] = (unsigned short)nm;
-			int cnt = 0;
-			for (int q = 0; q < n; ++q) if (on[q] && fabs(sgo_d3_dot(T[t].n, pts[q]) - T[t].d) <= eps) { if (nm == fmem_cap) { result = -2; goto done; } fmem[nm++] = (unsigned char)q; ++cnt; }
-			/* only the corners of the face's polygon stay: points inside a face or along one of its sides (a tessellated flat side: an earlier,
-			   smaller hull had them as corners) are not vertices of the solid.  Convex hull of the members in the face's plane (monotone chain). */
-			{
-				const int m0 = fmem_start[nf];
-				sgo_d3 u = sgo_d3_sub(pts[fmem[m0 + 1]], pts[fmem[m0]]);
-				for (int k = m0 + 2; k < nm; ++k) { const sgo_d3 u2 = sgo_d3_sub(pts[fmem[k]], pts[fmem[m0]]); if (sgo_d3_dot(u2, u2) > sgo_d3_dot(u, u)) u = u2; }
-				const double ul = sqrt(sgo_d3_dot(u, u)); u.x /= ul; u.y /= ul; u.z /= ul;
-				const sgo_d3 w = sgo_d3_cross(T[t].n, u);
-				double px[256], py[256]; int ord[256];
-				for (int k = 0; k < cnt; ++k) { const sgo_d3 r = sgo_d3_sub(pts[fmem[m0 + k]], pts[fmem[m0]]); px[k] = sgo_d3_dot(r, u); py[k] = sgo_d3_dot(r, w); ord[k] = k; }
-				for (int a = 1; a < cnt; ++a) { const int o = ord[a]; int bb = a - 1; while (bb >= 0 && (px[ord[bb]] > px[o] || (px[ord[bb]] == px[o] && py[ord[bb]] > py[o]))) { ord[bb + 1] = ord[bb]; --bb; } ord[bb + 1] = o; }
-				int hullk[512]; int hk = 0;
-				const double tol = eps * ul;                       /* (twice the area of a triangle as thin as eps over the face's extent) */
-				for (int pass = 0; pass < 2; ++pass) {
-					const int base = hk;
-					for (int ii = 0; ii < cnt; ++ii) {
-						const int o = pass == 0 ? ord[ii] : ord[cnt - 1 - ii];
-						while (hk - base >= 2) {
-							const int o1 = hullk[hk - 1], o0 = hullk[hk - 2];
-							const double cr = (px[o1] - px[o0]) * (py[o] - py[o0]) - (py[o1] - py[o0]) * (px[o] - px[o0]);
-							if (cr <= tol) --hk; else break;
-						}
-						hullk[hk++] = o;
-					}
-					--hk;                                          /* (the last point of a chain is the first of the next) */
-				}
-				unsigned char keepm[256]; memset(keepm, 0, sizeof(keepm));
-				for (int k = 0; k < hk; ++k) keepm[hullk[k]] = 1;
-				int m1 = m0;
-				for (int k = 0; k < cnt; ++k) if (keepm[k]) fmem[m1++] = fmem[m0 + k];
-				nm = m1; cnt = m1 - m0;
-			}
-			if (cnt < 3) { nm = fmem_start[nf]; continue; }
-			++nf;
-		}
-		fmem_start[nf] = (unsigned short)nm;
-		/* A face whose corners all belong to another face is that face seen from a triangle whose plane, a hair off, missed one of its points: the triangle came */
-		/* first, the full face later.  It goes (its plane is the other's within eps; left in, its diagonal would be an edge that only one face runs along). */
+		/* the triangles that are left are the candidates for the faces' planes */
 		{
-			int nf2 = 0, nm2 = 0;
-			for (int f = 0; f < nf; ++f) {
-				int covered = 0;
-				const int f0 = fmem_start[f], cf = fmem_start[f + 1] - f0;
-				for (int g = 0; g < nf && !covered; ++g) {
-					if (g == f) continue;
-					const int g0 = fmem_start[g], cg = fmem_start[g + 1] - g0;
-					if (cg < cf || (cg == cf && g > f)) continue;
-					int all = 1;
-					for (int k = 0; k < cf && all; ++k) { int found = 0; for (int m = 0; m < cg; ++m) if (fmem[g0 + m] == fmem[f0 + k]) { found = 1; break; } all = found; }
-					covered = all;
-				}
-				if (covered) continue;
-				fn[nf2] = fn[f]; fd[nf2] = fd[f];
-				for (int k = 0; k < cf; ++k) fmem[nm2 + k] = fmem[f0 + k];      /* (nm2 <= f0: moving down, never over unread members) */
-				fmem_start[nf2] = (unsigned short)nm2; nm2 += cf; ++nf2;
-			}
-			fmem_start[nf2] = (unsigned short)nm2; nf = nf2; nm = nm2;
+			sgo_cand* cand = (sgo_cand*)malloc(sizeof(sgo_cand) * (size_t)(nt + 1));
+			if (!cand) goto done;
+			int nc = 0;
+			for (int t = 0; t < nt; ++t) if (T[t].alive) { cand[nc].len = T[t].len; cand[nc].a = (unsigned char)T[t].a; cand[nc].b = (unsigned char)T[t].b; cand[nc].c = (unsigned char)T[t].c; ++nc; }
+			result = sgo_faces_from_candidates(pts, n, eps, ext, cand, nc, fn, fd, fmem_start, fmem, fmem_cap);
+			free(cand);
 		}
-		result = nf;
 	}
 done:
 	free(T); free(etri);
 	return result;
 }
 
-/* Returns 0 on success.  com_out / rot_out (quaternion xyzw): body frame expressed in the input frame, i.e.
-   input point = com + rot * body point.  com_offset (may be NULL): JPH::OffsetCenterOfMassShape -- the body's centre of mass is
-   moved by this vector (input frame) away from the hull's own; the inertia is taken about the moved point. */
-static inline int sgo_hull_build(const float* pts_in, int n_in, const float* com_offset, sgo_hull* h, float com_out[3], float rot_out[4])
+/* Steps 2 - 7 of the builder on the unique points.  mode 0: <= 32 points by the brute-force supporting-plane search of rounds 1-4 (bit-identical for every cloud
+   whose coplanar points are coplanar exactly: boxes, the car hull, every fixture), more through the incremental hull; mode 1 (<= 32 points): every point
+   triple is a candidate for sgo_faces_from_candidates.  Returns 0, or < 0: -3 = the result failed the checks a hull must pass (round 6) -- every
+   face plane supports the cloud, every edge runs between exactly two faces, V - E + F = 2.  With vertices from the cloud these three make the result THE hull,
+   whatever path the faces came by. */
+static inline int sgo_hull_build_pts(const sgo_d3* pts, int n, double eps, double ext, int mode, const float* com_offset, sgo_hull* h, float com_out[3], float rot_out[4])
 {
 	memset(h, 0, sizeof(*h));
-	if (n_in < 4) return -1;
-	/* 1. unique points */
-	sgo_d3 pts[256]; int n = 0;
-	double ext = 0.0;
-	for (int i = 0; i < n_in; ++i) for (int k = 0; k < 3; ++k) { if (!isfinite(pts_in[3 * i + k])) return -1; ext = fmax(ext, fabs((double)pts_in[3 * i + k])); }
-	if (!(ext > 0.0)) return -1;
-	const double eps = 1.0e-5 * ext;
-	if (n_in > 256) {
-		/* a larger cloud (a dynamic mesh with thousands of vertices): the extreme points of ALL input points along a fixed set of directions
-		   (Fibonacci sphere) plus the six axis directions -- every vertex takes part, wherever it sits in the array; at most 256 of them
-		   (JPH::ConvexHullShape::cMaxPointsInHull) */
-		int cand[2 * SGO_HULL_MAX_VERTS + 6]; int nc = 0;
-		for (int kk = 0; kk < 2 * SGO_HULL_MAX_VERTS + 6 && nc < SGO_HULL_MAX_VERTS; ++kk) {
-			sgo_d3 dir;
-			if (kk < 6) { dir.x = dir.y = dir.z = 0.0; const double sg = (kk & 1) ? -1.0 : 1.0; if (kk / 2 == 0) dir.x = sg; else if (kk / 2 == 1) dir.y = sg; else dir.z = sg; }
-			else {
-				const int k = ((kk - 6) * 37) % (2 * SGO_HULL_MAX_VERTS);
-				const double z = 1.0 - (2.0 * k + 1.0) / (2.0 * SGO_HULL_MAX_VERTS), rr = sqrt(1.0 - z * z), ph = k * 2.399963229728653;
-				dir.x = rr * cos(ph); dir.y = rr * sin(ph); dir.z = z;
-			}
-			int bi = 0; double bd = -1.0e300;
-			for (int i = 0; i < n_in; ++i) { const double d = dir.x * pts_in[3 * i] + dir.y * pts_in[3 * i + 1] + dir.z * pts_in[3 * i + 2]; if (d > bd) { bd = d; bi = i; } }
-			int seen = 0;
-			for (int j = 0; j < nc; ++j) {
-				const sgo_d3 a = { pts_in[3 * bi], pts_in[3 * bi + 1], pts_in[3 * bi + 2] }, b = { pts_in[3 * cand[j]], pts_in[3 * cand[j] + 1], pts_in[3 * cand[j] + 2] };
-				const sgo_d3 d = sgo_d3_sub(a, b);
-				if (cand[j] == bi || sgo_d3_dot(d, d) < eps * eps) { seen = 1; break; }
-			}
-			if (!seen) cand[nc++] = bi;
-		}
-		for (int j = 0; j < nc; ++j) { const sgo_d3 p = { pts_in[3 * cand[j]], pts_in[3 * cand[j] + 1], pts_in[3 * cand[j] + 2] }; pts[n++] = p; }
-	} else
-	for (int i = 0; i < n_in && n < 256; ++i) {
-		const sgo_d3 p = { pts_in[3 * i], pts_in[3 * i + 1], pts_in[3 * i + 2] };
-		int dup = 0;
-		for (int j = 0; j < n; ++j) { const sgo_d3 d = sgo_d3_sub(p, pts[j]); if (sgo_d3_dot(d, d) < eps * eps) { dup = 1; break; } }
-		if (!dup) pts[n++] = p;
-	}
-	if (n < 4) return -1;
 	/* 2. faces: planes fn / fd, and per face the points on it (ascending index) */
 	static const int FCAP = SGO_HULL_MAX_FACES + 64;
 	sgo_d3* fn = (sgo_d3*)malloc(sizeof(sgo_d3) * FCAP); double* fd = (double*)malloc(sizeof(double) * FCAP);
 	unsigned short* fmem_start = (unsigned short*)malloc(sizeof(unsigned short) * (FCAP + 1)); unsigned char* fmem = (unsigned char*)malloc(8192);
 	int nf = 0, rc = 0;
 #define SGO_HB_FAIL(code) do { rc = (code); goto cleanup; } while (0)
-	if (n <= SGO_HULL_SMALL_VERTS) {
+	if (n <= SGO_HULL_SMALL_VERTS && mode == 1) {
+		sgo_cand* cand = (sgo_cand*)malloc(sizeof(sgo_cand) * 4960);      /* 32 choose 3 */
+		if (!cand) SGO_HB_FAIL(-1);
+		int nc = 0;
+		for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) for (int k = j + 1; k < n; ++k) {
+			const sgo_d3 cr = sgo_d3_cross(sgo_d3_sub(pts[j], pts[i]), sgo_d3_sub(pts[k], pts[i]));
+			cand[nc].len = sqrt(sgo_d3_dot(cr, cr)); cand[nc].a = (unsigned char)i; cand[nc].b = (unsigned char)j; cand[nc].c = (unsigned char)k; ++nc;
+		}
+		nf = sgo_faces_from_candidates(pts, n, eps, ext, cand, nc, fn, fd, fmem_start, fmem, 8192);
+		free(cand);
+		if (nf < 0) SGO_HB_FAIL(nf);
+	} else if (n <= SGO_HULL_SMALL_VERTS) {
 		/* up to 32 points (rounds 1-4, unchanged): every supporting plane through three points; face = all points on that plane */
 		unsigned int masks[64]; int nm = 0;
 		for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) for (int k = j + 1; k < n; ++k) {
@@ -272,6 +283,8 @@ static inline int sgo_hull_build(const float* pts_in, int n_in, const float* com
 		if (nf < 0) SGO_HB_FAIL(nf);
 	}
 	if (nf < 4) SGO_HB_FAIL(-1);                             /* flat or degenerate cloud */
+	/* check 1 of 3: every face plane supports the cloud (no point beyond it) */
+	for (int f = 0; f < nf; ++f) for (int q = 0; q < n; ++q) if (sgo_d3_dot(fn[f], pts[q]) - fd[f] > 2.0 * eps) SGO_HB_FAIL(-3);
 	{
 	/* 3. drop interior points, order each face counter-clockwise seen from outside.  A face keeps all its corners (a 64-gon cap is ONE face, one SAT axis,
 	      one supporting face); the contact manifold clips against every (cnt + 15) / 16-th of them, sgo_hull_face_contact -- as ConvexHullShape::GetSupportingFace
@@ -398,6 +411,12 @@ static inline int sgo_hull_build(const float* pts_in, int n_in, const float* com
 	for (int e = 0; e < ne; ++e) if (h->edge_f0[e] == 0xFFFF || h->edge_f1[e] == 0xFFFF) { h->edge_f0[e] = 0xFFFF; h->edge_f1[e] = 0xFFFF; }
 	/* (test hook, tests/test_big_hull_parity_gpu.py: every 50th edge of a large hull declared open, so that the searches' path for such edges is exercised -- the */
 	/*  builder itself has not produced one since covered faces are dropped) */
+	/* checks 2 and 3 of 3: a closed surface (every edge between two faces) of the topology of a sphere */
+	{
+		int open_edges = 0;
+		for (int e = 0; e < ne; ++e) if (h->edge_f0[e] == 0xFFFF) ++open_edges;
+		if (open_edges || nv - ne + nf != 2) { rc = -3; goto finish; }
+	}
 	if (ne > 90 && getenv("SGP_HULL_TEST_OPEN_EDGES")) for (int e = 7; e < ne; e += 50) { h->edge_f0[e] = 0xFFFF; h->edge_f1[e] = 0xFFFF; }
 	}
 finish:
@@ -406,6 +425,86 @@ finish:
 cleanup:
 	free(fn); free(fd); free(fmem_start); free(fmem);
 #undef SGO_HB_FAIL
+	return rc;
+}
+
+/* Returns 0 on success.  com_out / rot_out (quaternion xyzw): body frame expressed in the input frame, i.e.
+   input point = com + rot * body point.  com_offset (may be NULL): JPH::OffsetCenterOfMassShape -- the body's centre of mass is
+   moved by this vector (input frame) away from the hull's own; the inertia is taken about the moved point. */
+static inline int sgo_hull_build(const float* pts_in, int n_in, const float* com_offset, sgo_hull* h, float com_out[3], float rot_out[4])
+{
+	memset(h, 0, sizeof(*h));
+	if (n_in < 4) return -1;
+	/* 1. unique points */
+	sgo_d3 pts[256]; int n = 0;
+	double ext = 0.0;
+	for (int i = 0; i < n_in; ++i) for (int k = 0; k < 3; ++k) { if (!isfinite(pts_in[3 * i + k])) return -1; ext = fmax(ext, fabs((double)pts_in[3 * i + k])); }
+	if (!(ext > 0.0)) return -1;
+	const double eps = 1.0e-5 * ext;
+	if (n_in > 256) {
+		/* a larger cloud (a dynamic mesh with thousands of vertices): the extreme points of ALL input points along a fixed set of directions
+		   (Fibonacci sphere) plus the six axis directions -- every vertex takes part, wherever it sits in the array; at most 256 of them
+		   (JPH::ConvexHullShape::cMaxPointsInHull) */
+		int cand[2 * SGO_HULL_MAX_VERTS + 6]; int nc = 0;
+		for (int kk = 0; kk < 2 * SGO_HULL_MAX_VERTS + 6 && nc < SGO_HULL_MAX_VERTS; ++kk) {
+			sgo_d3 dir;
+			if (kk < 6) { dir.x = dir.y = dir.z = 0.0; const double sg = (kk & 1) ? -1.0 : 1.0; if (kk / 2 == 0) dir.x = sg; else if (kk / 2 == 1) dir.y = sg; else dir.z = sg; }
+			else {
+				const int k = ((kk - 6) * 37) % (2 * SGO_HULL_MAX_VERTS);
+				const double z = 1.0 - (2.0 * k + 1.0) / (2.0 * SGO_HULL_MAX_VERTS), rr = sqrt(1.0 - z * z), ph = k * 2.399963229728653;
+				dir.x = rr * cos(ph); dir.y = rr * sin(ph); dir.z = z;
+			}
+			int bi = 0; double bd = -1.0e300;
+			for (int i = 0; i < n_in; ++i) { const double d = dir.x * pts_in[3 * i] + dir.y * pts_in[3 * i + 1] + dir.z * pts_in[3 * i + 2]; if (d > bd) { bd = d; bi = i; } }
+			int seen = 0;
+			for (int j = 0; j < nc; ++j) {
+				const sgo_d3 a = { pts_in[3 * bi], pts_in[3 * bi + 1], pts_in[3 * bi + 2] }, b = { pts_in[3 * cand[j]], pts_in[3 * cand[j] + 1], pts_in[3 * cand[j] + 2] };
+				const sgo_d3 d = sgo_d3_sub(a, b);
+				if (cand[j] == bi || sgo_d3_dot(d, d) < eps * eps) { seen = 1; break; }
+			}
+			if (!seen) cand[nc++] = bi;
+		}
+		for (int j = 0; j < nc; ++j) { const sgo_d3 p = { pts_in[3 * cand[j]], pts_in[3 * cand[j] + 1], pts_in[3 * cand[j] + 2] }; pts[n++] = p; }
+	} else
+	for (int i = 0; i < n_in && n < 256; ++i) {
+		const sgo_d3 p = { pts_in[3 * i], pts_in[3 * i + 1], pts_in[3 * i + 2] };
+		int dup = 0;
+		for (int j = 0; j < n; ++j) { const sgo_d3 d = sgo_d3_sub(p, pts[j]); if (sgo_d3_dot(d, d) < eps * eps) { dup = 1; break; } }
+		if (!dup) pts[n++] = p;
+	}
+	if (n < 4) return -1;
+	/* 2 .. 7 on the unique points.  A cloud whose result fails the builder's checks (points coplanar only to rounding, or scattered about a plane by about the
+	   tolerance, can defeat either path) is tried again: <= 32 points with every triple as a candidate plane, largest first; then with the tolerance four times
+	   as wide, up to 2.6e-3 of the extent (JPH::ConvexHullShapeSettings::mHullTolerance is 1e-3 m: points that close to a face belong to it); a larger cloud that
+	   fails at every tolerance is reduced to its 32 extreme points, as every larger cloud was in rounds 1-4, and goes through the same ladder. */
+	int rc = -1;
+	for (int pass = 0; pass < 2; ++pass) {
+		double e = eps;
+		for (int k = 0; k < 5; ++k, e *= 4.0) {
+			rc = sgo_hull_build_pts(pts, n, e, ext, 0, com_offset, h, com_out, rot_out);
+			if (rc == 0) return 0;
+			if (n <= SGO_HULL_SMALL_VERTS) { rc = sgo_hull_build_pts(pts, n, e, ext, 1, com_offset, h, com_out, rot_out); if (rc == 0) return 0; }
+		}
+		if (pass == 1 || n <= SGO_HULL_SMALL_VERTS) break;
+		sgo_d3 red[SGO_HULL_SMALL_VERTS]; int nr = 0;
+		for (int kk = 0; kk < 2 * SGO_HULL_SMALL_VERTS + 6 && nr < SGO_HULL_SMALL_VERTS; ++kk) {
+			sgo_d3 dir;
+			if (kk < 6) { dir.x = dir.y = dir.z = 0.0; const double sg = (kk & 1) ? -1.0 : 1.0; if (kk / 2 == 0) dir.x = sg; else if (kk / 2 == 1) dir.y = sg; else dir.z = sg; }
+			else {
+				const int k = ((kk - 6) * 37) % (2 * SGO_HULL_SMALL_VERTS);
+				const double z = 1.0 - (2.0 * k + 1.0) / (2.0 * SGO_HULL_SMALL_VERTS), rr = sqrt(1.0 - z * z), ph = k * 2.399963229728653;
+				dir.x = rr * cos(ph); dir.y = rr * sin(ph); dir.z = z;
+			}
+			int bi = 0; double bd = -1.0e300;
+			for (int i = 0; i < n; ++i) { const double dd = sgo_d3_dot(dir, pts[i]); if (dd > bd) { bd = dd; bi = i; } }
+			int seen = 0;
+			for (int j = 0; j < nr; ++j) if (red[j].x == pts[bi].x && red[j].y == pts[bi].y && red[j].z == pts[bi].z) { seen = 1; break; }
+			if (!seen) red[nr++] = pts[bi];
+		}
+		if (nr < 4) break;
+		for (int i = 0; i < nr; ++i) pts[i] = red[i];
+		n = nr;
+	}
 	return rc;
 }
 

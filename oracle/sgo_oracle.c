@@ -1313,6 +1313,12 @@ static float axis_jv(const sgo_body* A, const sgo_body* B, v3 r1, v3 r2, v3 axis
 	return (v3_dot(axis, A->linv) + v3_dot(v3_cross(r1, axis), A->angv)) - (v3_dot(axis, B->linv) + v3_dot(v3_cross(r2, axis), B->angv));
 }
 
+/* Warm start (ContactConstraintManager::WarmStartVelocityConstraints): the cached impulses of a manifold applied to its two bodies.
+   Round 6 contract: the impulses of a manifold are SUMMED first -- per point n lam_n (+ t1 lam_t1 + t2 lam_t2 with friction), then over the points the
+   linear impulse P and the angular impulses about either centre of mass A1 = sum r1 x j, A2 = sum r2 x j -- and each body receives ONE velocity change,
+   v -+ P / m, w -+ I^-1 A.  Jolt applies the parts one after the other (AxisConstraintPart::WarmStart per axis and point); the sum is the same impulse up to
+   rounding, and what a body receives from a manifold becomes one 32-byte record (the device's k_setup writes it, its warm start adds a body's records in
+   colour order: docs/CONTRACT.md, warm start).  UNVERIFIED: upstream applies the parts sequentially. */
 static void warm_start_constraint(sgo_world* w, sgo_constraint* c)
 {
 	sgo_body* A = &w->bodies[c->a]; sgo_body* B = &w->bodies[c->b];
@@ -1320,14 +1326,17 @@ static void warm_start_constraint(sgo_world* w, sgo_constraint* c)
 	sym33 I1, I2; memset(&I1, 0, sizeof(I1)); memset(&I2, 0, sizeof(I2));
 	if (im1 > 0.0f) I1 = world_inv_inertia(quat_to_m33(A->rot), A->inv_inertia);
 	if (im2 > 0.0f) I2 = world_inv_inertia(quat_to_m33(B->rot), B->inv_inertia);
+	v3 P = V3(0.0f, 0.0f, 0.0f), A1 = V3(0.0f, 0.0f, 0.0f), A2 = V3(0.0f, 0.0f, 0.0f);
 	for (int i = 0; i < c->np; ++i) {
-		sgo_point* p = &c->pt[i];
-		if (c->friction > 0.0f) {
-			apply_impulse(A, B, im1, I1, im2, I2, p->r1, p->r2, c->t1, p->lam_t1);
-			apply_impulse(A, B, im1, I1, im2, I2, p->r1, p->r2, c->t2, p->lam_t2);
-		}
-		apply_impulse(A, B, im1, I1, im2, I2, p->r1, p->r2, c->n, p->lam_n);
+		const sgo_point* p = &c->pt[i];
+		v3 j = v3_scale(c->n, p->lam_n);
+		if (c->friction > 0.0f) { j = v3_add(j, v3_scale(c->t1, p->lam_t1)); j = v3_add(j, v3_scale(c->t2, p->lam_t2)); }
+		P = v3_add(P, j);
+		A1 = v3_add(A1, v3_cross(p->r1, j));
+		A2 = v3_add(A2, v3_cross(p->r2, j));
 	}
+	if (im1 > 0.0f) { A->linv = v3_sub(A->linv, v3_scale(P, im1)); A->angv = v3_sub(A->angv, sym33_mul(I1, A1)); }
+	if (im2 > 0.0f) { B->linv = v3_add(B->linv, v3_scale(P, im2)); B->angv = v3_add(B->angv, sym33_mul(I2, A2)); }
 }
 
 static void solve_velocity_constraint(sgo_world* w, sgo_constraint* c)

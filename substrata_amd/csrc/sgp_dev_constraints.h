@@ -7,7 +7,7 @@
 // claims its movable bodies with atomicMin; the manifold that holds both claims takes the lowest colour free on
 // both bodies.  The result depends only on the SET of manifolds (spec: DESIGN.md "Colouring").
 
-SGP_DEV uint32_t cache_find(const DV& d, uint64_t key);
+SGP_DEV uint32_t cache_find(const DV& d, uint64_t key, int* np_col_prev);
 
 // ---------------------------------------------------------------------------------------------------------------
 // K5: contact constraint setup (Jolt ContactConstraintManager::TemplatedAddContactConstraint): contact-cache match
@@ -26,19 +26,24 @@ SGP_DEV float4* axis_rows(const DV& d, uint32_t slot, int point, int axis) { ret
 
 SGP_DEV uint32_t ht_hash(uint64_t key, uint32_t mask) { return (uint32_t)(sgp_mix64(key) >> 20) & mask; }
 
-SGP_DEV uint32_t cache_find(const DV& d, uint64_t key)
+// -> the pair's slot in the previous step's constraints (0xFFFFFFFF: it had none) and that constraint's np_col: ONE 16-byte entry per probe
+SGP_DEV uint32_t cache_find(const DV& d, uint64_t key, int* np_col_prev)
 {
 	const uint32_t size = *d.ht_cur;          // (the part of the table the last rebuild used: k_cache_clear)
 	const uint32_t mask = size - 1;
 	uint32_t h = ht_hash(key, mask);
 	for (uint32_t probe = 0; probe < size; ++probe) {
-		const uint64_t k = d.ht_keys[h];
-		if (k == key) return d.ht_vals[h];
+		const uint4 e = d.ht[h];
+		const uint64_t k = ((uint64_t)e.y << 32) | e.x;
+		if (k == key) { *np_col_prev = (int)e.w; return e.z; }
 		if (k == ~0ull) return 0xFFFFFFFFu;
 		h = (h + 1) & mask;
 	}
 	return 0xFFFFFFFFu;
 }
+// man_colour of a manifold between the narrow phase and k_colour_inherit: -1, or -(3 + c) when the narrow phase's own probe of the contact cache found the
+// pair's previous constraint in colour c (k_colour_inherit then needs neither a probe nor the previous constraint's header)
+SGP_DEV int man_colour_candidate(int np_col_prev) { return -(3 + ((np_col_prev >> 8) & 0xFF)); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // contact cache (pair key -> constraint slot) for the next step's warm start; contact events

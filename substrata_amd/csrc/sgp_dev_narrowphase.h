@@ -17,7 +17,8 @@ SGP_DEV sgd_shape load_shape(const DV& d, uint32_t i, uint32_t f)
 	return s;
 }
 
-SGP_DEV uint32_t cache_find(const DV& d, uint64_t key);
+SGP_DEV uint32_t cache_find(const DV& d, uint64_t key, int* np_col_prev);
+SGP_DEV int man_colour_candidate(int np_col_prev);
 // Colours a body's contacts may not take: a vehicle's rows are solved in the same launch as the first contact colour of every pass (they come first
 // in the pass: non-contact constraints before contacts, as in PhysicsSystem's solve), so no contact of its chassis may sit in colour 0.
 // Round 4: the same holds for a dynamic body under a wheel of an active vehicle -- the wheel rows act on it (DV::veh_claim of the current step).
@@ -50,18 +51,27 @@ SGP_DEV void wake_body(const DV& d, uint32_t id)
 }
 
 // the manifold goes to slot `slot` of the step's manifold list (the caller allocated it)
-SGP_DEV void emit_manifold_at(const DV& d, uint32_t slot, uint2 ab, uint32_t fa, uint32_t fb, const sgd_manifold& m, uint32_t prev)
+// bit 9 of a manifold's point-count word: a polytope pair (box / hull against box / hull), the pairs the body-pair contact cache serves -- k_setup keeps the second
+// sector of the cache record for them only
+#define MAN_NP_SENSOR   0x100
+#define MAN_NP_POLYTOPE 0x200
+SGP_DEV bool pair_is_polytopes(uint32_t fa, uint32_t fb)
+{
+	return (f_shape(fa) == SGP_SHAPE_BOX || f_shape(fa) == SGP_SHAPE_HULL) && (f_shape(fb) == SGP_SHAPE_BOX || f_shape(fb) == SGP_SHAPE_HULL);
+}
+// colour_candidate: -1, or man_colour_candidate() of the previous constraint the caller's probe found
+SGP_DEV void emit_manifold_at(const DV& d, uint32_t slot, uint2 ab, uint32_t fa, uint32_t fb, const sgd_manifold& m, uint32_t prev, int colour_candidate = -1)
 {
 	if (slot >= d.cap_manifolds) { atomicAdd(&d.ctr->manifolds_dropped, 1u); return; }
 	d.man_ab[slot] = ab;
 	const bool sensor = (fa | fb) & BF_SENSOR;
 	// bit 8 = sensor pair (mIsSensor, PhysicsWorld.cpp:1235): reported in the contact events, kept in the contact list
 	// (so that it is 'persisted' next step) but with zero points for the solver
-	d.man_n[slot] = make_float4(m.n.x, m.n.y, m.n.z, __int_as_float(m.np | (sensor ? 0x100 : 0)));
+	d.man_n[slot] = make_float4(m.n.x, m.n.y, m.n.z, __int_as_float(m.np | (sensor ? MAN_NP_SENSOR : 0) | (pair_is_polytopes(fa, fb) ? MAN_NP_POLYTOPE : 0)));
 	for (int k = 0; k < 4; ++k) if (k < m.np) { d.man_p1[k][slot] = F4(m.p1[k], 0.0f); d.man_p2[k][slot] = F4(m.p2[k], 0.0f); }
 	d.man_prio[slot] = sgp_mix64(((uint64_t)ab.x << 32) | ab.y);
 	d.man_prev[slot] = prev;          // (MAN_PREV_LOOKUP: k_colour_inherit -- a light kernel that hides the hash probe's latency -- resolves it)
-	d.man_colour[slot] = -1;
+	d.man_colour[slot] = colour_candidate;
 	if (!sensor) {
 		const bool actA = f_active_for_pairs(fa), actB = f_active_for_pairs(fb);
 		// (a pair's other body is awake -- or, in the in-step activation round, neither was when the step began: one of the two has just been woken and the

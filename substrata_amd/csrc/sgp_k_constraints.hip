@@ -10,21 +10,29 @@ __global__ void __launch_bounds__(TPB) k_colour_inherit(DV d)
 	const uint32_t n = min(d.ctr->n_manifolds, d.cap_manifolds);
 	for (uint32_t m = blockIdx.x * TPB + threadIdx.x; m < n; m += gridDim.x * TPB) {
 		const uint2 ab = d.man_ab[m];
-		// the one hash probe per manifold (unless the narrow phase already made it for a contact-cache attempt): every later kernel reads man_prev
+		// the one hash probe per manifold (unless the narrow phase already made it for a contact-cache attempt): every later kernel reads man_prev.
+		// The probe's 16-byte entry also holds the previous constraint's colour; a manifold the narrow phase probed carries it in man_colour (-(3 + colour))
 		uint32_t mp = d.man_prev[m];
-		if (mp == MAN_PREV_LOOKUP) { const uint32_t f = cache_find(d, ((uint64_t)ab.x << 32) | ab.y); mp = f == 0xFFFFFFFFu ? MAN_PREV_NONE : f; d.man_prev[m] = mp; }
-		if (d.man_colour[m] != -1) continue;      // (debug bit 2: no colour inheritance -- every manifold goes through the rounds)
-		const uint32_t ps = mp & ~MAN_PREV_REUSED;
-		if (ps == MAN_PREV_NONE) continue;
-		const int pc = (PRV(d).np_col[ps] >> 8) & 0xFF;
-		if (pc >= SGP_OVERFLOW_COLOUR) continue;
-		const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
-		const bool ma = fa & BF_MOVABLE_CUR, mb = fb & BF_MOVABLE_CUR;
-		if ((ma && !(fa & BF_MOVABLE_PREV)) || (mb && !(fb & BF_MOVABLE_PREV))) continue;
-		if (pc == 0 && ((ma && chassis_colours(d, ab.x, fa)) || (mb && chassis_colours(d, ab.y, fb)))) continue;      // (the body became a chassis since: colour 0 is the vehicle's)
-		d.man_colour[m] = pc;
-		if (ma) atomicOr((unsigned long long*)&d.colour_mask[ab.x], 1ull << pc);
-		if (mb) atomicOr((unsigned long long*)&d.colour_mask[ab.y], 1ull << pc);
+		const int mc = d.man_colour[m];
+		int pc = mc <= -3 ? -3 - mc : -1;
+		if (mp == MAN_PREV_LOOKUP) {
+			int pnc = 0;
+			const uint32_t f = cache_find(d, ((uint64_t)ab.x << 32) | ab.y, &pnc);
+			mp = f == 0xFFFFFFFFu ? MAN_PREV_NONE : f; d.man_prev[m] = mp;
+			if (f != 0xFFFFFFFFu) pc = (pnc >> 8) & 0xFF;
+		}
+		int col = -1;
+		if (pc >= 0 && pc < SGP_OVERFLOW_COLOUR && (mp & ~MAN_PREV_REUSED) != MAN_PREV_NONE) {
+			const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
+			const bool ma = fa & BF_MOVABLE_CUR, mb = fb & BF_MOVABLE_CUR;
+			if (!((ma && !(fa & BF_MOVABLE_PREV)) || (mb && !(fb & BF_MOVABLE_PREV))) &&
+			    !(pc == 0 && ((ma && chassis_colours(d, ab.x, fa)) || (mb && chassis_colours(d, ab.y, fb))))) {      // (the body became a chassis since: colour 0 is the vehicle's)
+				col = pc;
+				if (ma) atomicOr((unsigned long long*)&d.colour_mask[ab.x], 1ull << pc);
+				if (mb) atomicOr((unsigned long long*)&d.colour_mask[ab.y], 1ull << pc);
+			}
+		}
+		if (col != mc) d.man_colour[m] = col;      // (-1: through the colouring rounds)
 	}
 }
 
@@ -275,11 +283,22 @@ __global__ void __launch_bounds__(TPB) k_setup(DV d)
 		if (col < 0) continue;
 		const uint32_t slot = d.man_slot[m];
 		const uint2 ab = d.man_ab[m];
-		const uint64_t key = ((uint64_t)ab.x << 32) | ab.y;
 		const float4 n4 = d.man_n[m];
 		const int npb = __float_as_int(n4.w);
-		const int np = (npb & 0x100) ? 0 : (npb & 0xFF);          // sensor pairs carry no points
+		const int np = (npb & MAN_NP_SENSOR) ? 0 : (npb & 0xFF);          // sensor pairs carry no points
 		const v3 nrm = V3(n4);
+		const uint32_t mprev = d.man_prev[m];
+		const bool reused = mprev & MAN_PREV_REUSED;                 // the manifold came from the body-pair contact cache
+		const uint32_t fslot = (mprev & ~MAN_PREV_REUSED) == MAN_PREV_NONE ? 0xFFFFFFFFu : (mprev & ~MAN_PREV_REUSED);
+		const uint32_t pslot = d.st.warm_start ? fslot : 0xFFFFFFFFu;
+		// the previous constraint of the pair: its cache record (ONE 128-byte line: point count, its first two points in body space, and for polytope
+		// pairs the relative pose it was computed at), requested together with the bodies' records
+		float4 pr0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pr1 = pr0, pr2 = pr0, pr3 = pr0, pr4 = pr0, pr5 = pr0, pr6 = pr0;
+		if (fslot != 0xFFFFFFFFu) {
+			const float4* rec = PRV(d).crec0 + (size_t)fslot * CREC0_F4;
+			pr0 = rec[0]; pr1 = rec[1]; pr2 = rec[2]; pr3 = rec[3];
+			if (reused) { pr4 = rec[4]; pr5 = rec[5]; pr6 = rec[6]; }
+		}
 		// per body: pose record, velocity record (velocities after gravity + the effective inverse mass: k_pre_solve), property record
 		const float4 pa4 = d.pose[2 * (size_t)ab.x], qa4 = d.pose[2 * (size_t)ab.x + 1], pb4 = d.pose[2 * (size_t)ab.y], qb4 = d.pose[2 * (size_t)ab.y + 1];
 		const float4 va4 = d.vel[2 * (size_t)ab.x], wa4 = d.vel[2 * (size_t)ab.x + 1], vb4 = d.vel[2 * (size_t)ab.y], wb4 = d.vel[2 * (size_t)ab.y + 1];
@@ -294,46 +313,41 @@ __global__ void __launch_bounds__(TPB) k_setup(DV d)
 		const v3 t1 = v3_normalized_perpendicular(nrm);
 		const v3 t2 = v3_cross(nrm, t1);
 		const v3 lvA = V3(va4), avA = V3(wa4), lvB = V3(vb4), avB = V3(wb4);
-		const uint32_t mprev = d.man_prev[m];
-		const bool reused = mprev & MAN_PREV_REUSED;                 // the manifold came from the body-pair contact cache
-		const uint32_t fslot = (mprev & ~MAN_PREV_REUSED) == MAN_PREV_NONE ? 0xFFFFFFFFu : (mprev & ~MAN_PREV_REUSED);
-		const uint32_t pslot = d.st.warm_start ? fslot : 0xFFFFFFFFu;
-		int pnp = 0;
-		if (pslot != 0xFFFFFFFFu) pnp = PRV(d).np_col[pslot] & 0xFF;
+		const int pnp_all = fslot != 0xFFFFFFFFu ? (__float_as_int(pr0.x) & 0xFF) : 0;      // points of the previous constraint
+		const int pnp = pslot != 0xFFFFFFFFu ? pnp_all : 0;                                   // ... whose impulses may be taken over
+		// its points (body space): the first two came with the record, the third and fourth (rare) are a second gather
+		v3 pl1[4], pl2[4];
+		pl1[0] = V3(pr0.y, pr0.z, pr0.w); pl2[0] = V3(pr1); pl1[1] = V3(pr2); pl2[1] = V3(pr3);
+		pl1[2] = pl1[3] = pl2[2] = pl2[3] = V3(0.0f, 0.0f, 0.0f);
+		if (pnp_all > 2) {
+			const float4* r1 = PRV(d).crec1 + (size_t)fslot * CREC1_F4;
+			pl1[2] = V3(r1[0]); pl2[2] = V3(r1[1]);
+			if (pnp_all > 3) { pl1[3] = V3(r1[2]); pl2[3] = V3(r1[3]); }
+		}
 		const v3 g = V3(d.gx, d.gy, d.gz);
 		CUR(d).ab[slot] = ab;
-		// (body, colour) -> constraint: a proper colouring gives every movable body at most one constraint per colour, so this
-		// table needs no clearing -- its valid entries are exactly the bits of colour_mask[body] (read by k_warm_bodies)
-		if (col < SGP_OVERFLOW_COLOUR) {
-			if (im1 > 0.0f) d.body_con[(size_t)ab.x * SGP_MAX_COLOURS + col] = slot * 2u;
-			if (im2 > 0.0f) d.body_con[(size_t)ab.y * SGP_MAX_COLOURS + col] = slot * 2u + 1u;
-		}
 		CUR(d).n_fric[slot] = F4(nrm, friction);
-		CUR(d).key[slot] = key;
-		CUR(d).np_col[slot] = np | (col << 8) | ((fslot != 0xFFFFFFFFu ? 1 : 0) << 16);
-		// body-pair contact cache: a fresh manifold records where the bodies are relative to each other now; a reused one keeps the record of
-		// the step its points were computed in (slow drift then ends the reuse)
-		if (reused) { CUR(d).cdp[slot] = PRV(d).cdp[fslot]; CUR(d).cdr[slot] = PRV(d).cdr[fslot]; CUR(d).cnl[slot] = PRV(d).cnl[fslot]; }
-		else {
-			v3 dpos; quat drot;
-			pair_relative_pose(posA, Q4(qa4), posB, Q4(qb4), &dpos, &drot);
-			const v3 nl = m33_tmul(RB, nrm);
-			CUR(d).cdp[slot] = make_float4(dpos.x, dpos.y, dpos.z, nl.x);
-			CUR(d).cdr[slot] = make_float4(drot.x, drot.y, drot.z, drot.w);
-			CUR(d).cnl[slot] = make_float2(nl.y, nl.z);
-		}
+		const int np_col = np | (col << 8) | ((fslot != 0xFFFFFFFFu ? 1 : 0) << 16);
+		CUR(d).np_col[slot] = np_col;
+		v3 loc1[4], loc2[4];
+		loc1[0] = loc1[1] = loc1[2] = loc1[3] = loc2[0] = loc2[1] = loc2[2] = loc2[3] = V3(0.0f, 0.0f, 0.0f);
+		// warm start (docs/CONTRACT.md): the cached impulses of the manifold summed -- linear P, angular about either centre of mass A1, A2 --, one velocity
+		// change per body, written as the body's record of this colour (k_warm_bodies adds a body's records in colour order)
+		v3 wP = V3(0.0f, 0.0f, 0.0f), wA1 = V3(0.0f, 0.0f, 0.0f), wA2 = V3(0.0f, 0.0f, 0.0f);
+#pragma unroll
 		for (int i = 0; i < 4; ++i) {
 			if (i >= np) break;
 			const v3 p1 = V3(d.man_p1[i][m]), p2 = V3(d.man_p2[i][m]);
 			v3 local1 = m33_tmul(RA, v3_sub(p1, posA));
 			v3 local2 = m33_tmul(RB, v3_sub(p2, posB));
-			if (reused) { local1 = V3(PRV(d).loc1[i][fslot]); local2 = V3(PRV(d).loc2[i][fslot]); }      // the cached body-space points themselves: no drift from re-deriving them
+			if (reused) { local1 = pl1[i]; local2 = pl2[i]; }      // the cached body-space points themselves: no drift from re-deriving them
+			loc1[i] = local1; loc2[i] = local2;
 			float lam_n = 0.0f, lam_t1 = 0.0f, lam_t2 = 0.0f;
+#pragma unroll
 			for (int j = 0; j < 4; ++j) {
 				if (j >= pnp) break;
-				const v3 c1 = V3(PRV(d).loc1[j][pslot]), c2 = V3(PRV(d).loc2[j][pslot]);
-				if (v3_len_sq(v3_sub(local1, c1)) < d.st.contact_point_preserve_lambda_max_dist_sq &&
-				    v3_len_sq(v3_sub(local2, c2)) < d.st.contact_point_preserve_lambda_max_dist_sq) {
+				if (v3_len_sq(v3_sub(local1, pl1[j])) < d.st.contact_point_preserve_lambda_max_dist_sq &&
+				    v3_len_sq(v3_sub(local2, pl2[j])) < d.st.contact_point_preserve_lambda_max_dist_sq) {
 					const float4 pl = PRV(d).lam[j][pslot];
 					lam_n = pl.x; lam_t1 = pl.y; lam_t2 = pl.z;
 					break;
@@ -371,13 +385,54 @@ __global__ void __launch_bounds__(TPB) k_setup(DV d)
 			CUR(d).efft[i][slot] = make_float2(eff_t1, eff_t2);
 			CUR(d).loc1[i][slot] = F4(local1, 0.0f);
 			CUR(d).loc2[i][slot] = F4(local2, 0.0f);
+			v3 wj = v3_scale(nrm, lam_n);
+			if (friction > 0.0f) { wj = v3_add(wj, v3_scale(t1, lam_t1)); wj = v3_add(wj, v3_scale(t2, lam_t2)); }
+			wP = v3_add(wP, wj);
+			wA1 = v3_add(wA1, v3_cross(r1, wj));
+			wA2 = v3_add(wA2, v3_cross(r2, wj));
+		}
+		// the cache record of this constraint (what the next step gathers of it): first sector for every constraint, second for polytope pairs -- a fresh
+		// manifold records where the bodies are relative to each other now; a reused one keeps the record of the step its points were computed in (slow
+		// drift then ends the reuse)
+		{
+			float4* rec = CUR(d).crec0 + (size_t)slot * CREC0_F4;
+			rec[0] = make_float4(__int_as_float(np_col), loc1[0].x, loc1[0].y, loc1[0].z);
+			rec[1] = F4(loc2[0], 0.0f); rec[2] = F4(loc1[1], 0.0f); rec[3] = F4(loc2[1], 0.0f);
+			if (npb & MAN_NP_POLYTOPE) {
+				if (reused) { rec[4] = pr4; rec[5] = pr5; rec[6] = pr6; }
+				else {
+					v3 dpos; quat drot;
+					pair_relative_pose(posA, Q4(qa4), posB, Q4(qb4), &dpos, &drot);
+					const v3 nl = m33_tmul(RB, nrm);
+					rec[4] = make_float4(drot.x, drot.y, drot.z, drot.w);
+					rec[5] = make_float4(dpos.x, dpos.y, dpos.z, nl.x);
+					rec[6] = make_float4(nl.y, nl.z, 0.0f, 0.0f);
+				}
+				rec[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);      // (the whole line: no partial sector goes to memory)
+			}
+			if (np > 2) {
+				float4* r1 = CUR(d).crec1 + (size_t)slot * CREC1_F4;
+				r1[0] = F4(loc1[2], 0.0f); r1[1] = F4(loc2[2], 0.0f); r1[2] = F4(loc1[3], 0.0f); r1[3] = F4(loc2[3], 0.0f);
+			}
+		}
+		// (body, colour) -> warm-start record: a proper colouring gives every movable body at most one constraint per colour, so this table needs no
+		// clearing -- its valid entries are exactly the bits of colour_mask[body] (read by k_warm_bodies).  Body 1 loses what body 2 gains.
+		if (col < SGP_OVERFLOW_COLOUR) {
+			if (im1 > 0.0f) {
+				float4* wr = d.warm + ((size_t)ab.x * SGP_MAX_COLOURS + col) * 2;
+				wr[0] = F4(v3_neg(v3_scale(wP, im1)), 0.0f); wr[1] = F4(v3_neg(sym33_mul(I1, wA1)), 0.0f);
+			}
+			if (im2 > 0.0f) {
+				float4* wr = d.warm + ((size_t)ab.y * SGP_MAX_COLOURS + col) * 2;
+				wr[0] = F4(v3_scale(wP, im2), 0.0f); wr[1] = F4(sym33_mul(I2, wA2), 0.0f);
+			}
 		}
 	}
 }
 __global__ void __launch_bounds__(TPB) k_cache_clear(DV d)
 {
 	const uint32_t size = cache_table_size(d);
-	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < size; i += gridDim.x * TPB) d.ht_keys[i] = ~0ull;
+	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < size; i += gridDim.x * TPB) d.ht[i] = make_uint4(~0u, ~0u, 0u, 0u);
 	if (blockIdx.x == 0 && threadIdx.x == 0) *d.ht_cur = size;
 }
 
@@ -398,11 +453,15 @@ __global__ void __launch_bounds__(TPB) k_cache_build(DV d, StepCounters* host_ma
 	const uint32_t size = *d.ht_cur;
 	const uint32_t mask = size - 1;
 	for (uint32_t k = blockIdx.x * TPB + threadIdx.x; k < n_con; k += gridDim.x * TPB) {
-		const uint64_t key = CUR(d).key[k];
+		const uint2 ab = CUR(d).ab[k];
+		const uint32_t nc = (uint32_t)CUR(d).np_col[k];
+		const uint64_t key = ((uint64_t)ab.x << 32) | ab.y;
 		uint32_t h = ht_hash(key, mask);
 		for (uint32_t probe = 0; probe < size; ++probe) {
-			const unsigned long long old = atomicCAS((unsigned long long*)&d.ht_keys[h], ~0ull, (unsigned long long)key);
-			if (old == ~0ull || old == key) { d.ht_vals[h] = k; break; }
+			// (an entry is 16 bytes: the key's two words claimed with one 64-bit compare-and-swap, slot and np_col stored behind it -- nothing reads the
+			// table before the next step)
+			const unsigned long long old = atomicCAS((unsigned long long*)&d.ht[h], ~0ull, (unsigned long long)key);
+			if (old == ~0ull || old == key) { ((uint2*)&d.ht[h])[1] = make_uint2(k, nc); break; }
 			h = (h + 1) & mask;
 		}
 	}

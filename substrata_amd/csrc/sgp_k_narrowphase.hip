@@ -6,24 +6,34 @@
 // manifold carried to the bodies' current poses -- the two bodies sit, relative to each other, where they sat when it was computed (within
 // 1 mm and 2 degrees), so the collision test is skipped.  *prev: the pair's slot in last step's constraints (MAN_PREV_NONE if it had none),
 // found with the one hash look-up every later kernel shares.
-SGP_DEV bool reuse_cached_manifold(const DV& d, uint2 ab, uint32_t fa, uint32_t fb, sgd_manifold* m, uint32_t* prev)
+SGP_DEV bool reuse_cached_manifold(const DV& d, uint2 ab, uint32_t fa, uint32_t fb, sgd_manifold* m, uint32_t* prev, int* colour_candidate)
 {
-	const uint32_t ps = cache_find(d, ((uint64_t)ab.x << 32) | ab.y);
+	int pnc = 0;
+	const uint32_t ps = cache_find(d, ((uint64_t)ab.x << 32) | ab.y, &pnc);
 	*prev = ps == 0xFFFFFFFFu ? MAN_PREV_NONE : ps;
-	if (ps == 0xFFFFFFFFu || !d.st.use_body_pair_contact_cache || ((fa | fb) & (BF_CACHE_INVALID | BF_SENSOR))) return false;
+	if (ps == 0xFFFFFFFFu) return false;
+	*colour_candidate = man_colour_candidate(pnc);      // (k_colour_inherit needs no probe of its own for this pair)
+	if (!d.st.use_body_pair_contact_cache || ((fa | fb) & (BF_CACHE_INVALID | BF_SENSOR))) return false;
+	// the previous constraint's cache record: ONE 128-byte line holds the relative pose it was computed at and its first two points
+	const float4* rec = PRV(d).crec0 + (size_t)ps * CREC0_F4;
+	const float4 c0 = rec[0], c1 = rec[1], c2 = rec[2], c3 = rec[3], cdr = rec[4], cdp = rec[5], cnl = rec[6];
 	const v3 posA = V3(d.pose[2 * (size_t)ab.x]), posB = V3(d.pose[2 * (size_t)ab.y]);
 	const quat qA = Q4(d.pose[2 * (size_t)ab.x + 1]), qB = Q4(d.pose[2 * (size_t)ab.y + 1]);
 	v3 dpos; quat drot;
 	pair_relative_pose(posA, qA, posB, qB, &dpos, &drot);
-	const float4 cdp = PRV(d).cdp[ps], cdr = PRV(d).cdr[ps];
 	if (!(v3_len_sq(v3_sub(dpos, V3(cdp))) <= d.st.body_pair_cache_max_delta_position_sq)) return false;
 	const float dq = drot.x * cdr.x + drot.y * cdr.y + drot.z * cdr.z + drot.w * cdr.w;
 	if (!(fabsf(dq) >= d.st.body_pair_cache_cos_max_delta_rotation_div2)) return false;
 	const m33 RA = quat_to_m33(qA), RB = quat_to_m33(qB);
-	const float2 cnl = PRV(d).cnl[ps];
-	m->np = PRV(d).np_col[ps] & 0xFF;
+	m->np = pnc & 0xFF;
 	m->n = m33_mul(RB, V3(cdp.w, cnl.x, cnl.y));
-	for (int i = 0; i < 4; ++i) if (i < m->np) { m->p1[i] = v3_add(posA, m33_mul(RA, V3(PRV(d).loc1[i][ps]))); m->p2[i] = v3_add(posB, m33_mul(RB, V3(PRV(d).loc2[i][ps]))); }
+	if (m->np > 0) { m->p1[0] = v3_add(posA, m33_mul(RA, V3(c0.y, c0.z, c0.w))); m->p2[0] = v3_add(posB, m33_mul(RB, V3(c1))); }
+	if (m->np > 1) { m->p1[1] = v3_add(posA, m33_mul(RA, V3(c2))); m->p2[1] = v3_add(posB, m33_mul(RB, V3(c3))); }
+	if (m->np > 2) {
+		const float4* r1 = PRV(d).crec1 + (size_t)ps * CREC1_F4;
+		m->p1[2] = v3_add(posA, m33_mul(RA, V3(r1[0]))); m->p2[2] = v3_add(posB, m33_mul(RB, V3(r1[1])));
+		if (m->np > 3) { m->p1[3] = v3_add(posA, m33_mul(RA, V3(r1[2]))); m->p2[3] = v3_add(posB, m33_mul(RB, V3(r1[3]))); }
+	}
 	*prev = ps | MAN_PREV_REUSED;
 	return true;
 }
@@ -49,6 +59,7 @@ template <int ROUND, bool HULLS = true> SGP_DEV void narrowphase_pairs(const DV&
 		uint2 ab = make_uint2(0u, 0u); uint32_t fa = 0, fb = 0;
 		sgd_manifold m;
 		uint32_t prev = MAN_PREV_LOOKUP;
+		int colour_candidate = -1;
 		if (p < n) {
 			ab = pairs[p];
 			fa = d.flags[ab.x]; fb = d.flags[ab.y];
@@ -65,8 +76,8 @@ template <int ROUND, bool HULLS = true> SGP_DEV void narrowphase_pairs(const DV&
 				// the contact cache is consulted for polytope pairs only (box / hull against box / hull): their separating-axis test and clipping
 				// cost more than the gather of a cached manifold, and they are the pairs whose resting contacts a frozen manifold keeps from
 				// jittering; a sphere or capsule contact is recomputed (a few dozen instructions, the same answer every step)
-				const bool polytopes = (f_shape(fa) == SGP_SHAPE_BOX || f_shape(fa) == SGP_SHAPE_HULL) && (f_shape(fb) == SGP_SHAPE_BOX || f_shape(fb) == SGP_SHAPE_HULL);
-				if (polytopes && reuse_cached_manifold(d, ab, fa, fb, &m, &prev)) have = true;
+				const bool polytopes = pair_is_polytopes(fa, fb);
+				if (polytopes && reuse_cached_manifold(d, ab, fa, fb, &m, &prev, &colour_candidate)) have = true;
 				else if ((HULLS || ROUND == 0) && (f_shape(fa) == SGP_SHAPE_HULL || f_shape(fb) == SGP_SHAPE_HULL)) {
 					// the polytope paths (clip buffers in scratch, long loops) live in their own kernel so that they do not cost the
 					// sphere / box / capsule pairs registers or scratch
@@ -102,7 +113,7 @@ template <int ROUND, bool HULLS = true> SGP_DEV void narrowphase_pairs(const DV&
 		if (have) {
 			uint32_t slot = s_base + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
 			for (int k = 0; k < wave; ++k) slot += s_wave_cnt[k];
-			emit_manifold_at(d, slot, ab, fa, fb, m, prev);
+			emit_manifold_at(d, slot, ab, fa, fb, m, prev, colour_candidate);
 		}
 		__syncthreads();
 	}

@@ -46,34 +46,41 @@ template <int VS> SGP_DEV void store_pair_vel(const PairCtx& c, float4* vel)
 	if (c.im2 > 0.0f) { vel[VS * (size_t)c.ab.y] = F4(c.B.lv, c.im2); vel[VS * (size_t)c.ab.y + 1] = F4(c.B.av, 0.0f); }
 }
 
+// Warm start of ONE constraint (docs/CONTRACT.md, warm start; oracle: warm_start_constraint): the cached impulses of the manifold are summed first -- per point
+// n lam_n (+ t1 lam_t1 + t2 lam_t2 with friction), over the points the linear impulse P and the angular impulses A1 = sum r1 x j, A2 = sum r2 x j -- and each
+// body receives one velocity change, v -+ P / m, w -+ I^-1 A.  k_setup evaluates the same expressions on the same operands for the (body, colour) records
+// k_warm_bodies adds up, so this form (small worlds, the tail, the overflow colour) and that one give the same bits.
 template <int VS> SGP_DEV void warm_start_one_t(const DV& d, uint32_t slot, float4* vel)
 {
 	PairCtx c;
 	load_pair<VS>(d, slot, c, vel);
 	c.t1 = v3_normalized_perpendicular(c.n);
 	c.t2 = v3_cross(c.n, c.t1);
+	v3 P = V3(0.0f, 0.0f, 0.0f), A1 = V3(0.0f, 0.0f, 0.0f), A2 = V3(0.0f, 0.0f, 0.0f);
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
 		if (i < c.np) {
 			const v3 r1 = V3(CUR(d).r1b[i][slot]), r2 = V3(CUR(d).r2e[i][slot]);
 			const float4 l = CUR(d).lam[i][slot];
-			if (c.friction > 0.0f) {
-				apply_impulse(c.A, c.B, c.im1, c.I1, c.im2, c.I2, r1, r2, c.t1, l.y);
-				apply_impulse(c.A, c.B, c.im1, c.I1, c.im2, c.I2, r1, r2, c.t2, l.z);
-			}
-			apply_impulse(c.A, c.B, c.im1, c.I1, c.im2, c.I2, r1, r2, c.n, l.x);
+			v3 j = v3_scale(c.n, l.x);
+			if (c.friction > 0.0f) { j = v3_add(j, v3_scale(c.t1, l.y)); j = v3_add(j, v3_scale(c.t2, l.z)); }
+			P = v3_add(P, j);
+			A1 = v3_add(A1, v3_cross(r1, j));
+			A2 = v3_add(A2, v3_cross(r2, j));
 		}
 	}
+	if (c.im1 > 0.0f) { c.A.lv = v3_add(c.A.lv, v3_neg(v3_scale(P, c.im1))); c.A.av = v3_add(c.A.av, v3_neg(sym33_mul(c.I1, A1))); }
+	if (c.im2 > 0.0f) { c.B.lv = v3_add(c.B.lv, v3_scale(P, c.im2)); c.B.av = v3_add(c.B.av, sym33_mul(c.I2, A2)); }
 	store_pair_vel<VS>(c, vel);
 }
 SGP_DEV void warm_start_one(const DV& d, uint32_t slot) { warm_start_one_t<2>(d, slot, d.vel); }
 
-// Warm start, one thread per BODY instead of one launch per colour.  A warm-start impulse depends only on its own constraint (cached
-// lambdas, axes, lever arms) and on the inverse mass / inertia of the body it is applied to -- not on any velocity -- so what the
-// colour-by-colour order does to one body is a fixed sequence of additions: its constraints in ascending colour (a body has at most one
-// per colour), each contributing friction t1, friction t2, normal per point exactly as warm_start_one_t applies them.  This kernel
-// replays that sequence per body from the (body, colour) table written by k_setup; same operations in the same order, hence the same
-// bits, in one launch.  Constraints of the overflow colour come last in the order and are still applied serially by k_solve_tail.
+// Warm start, one thread per BODY instead of one launch per colour.  What a constraint's warm start does to one of its bodies depends only on the constraint
+// (cached impulses, axes, lever arms) and on that body's inverse mass / inertia -- not on any velocity --, so what the colour-by-colour order does to one body
+// is a fixed sequence of additions: the velocity changes of its constraints in ascending colour (a body has at most one per colour).  k_setup writes each
+// change as a 32-byte record at [body][colour]; this kernel adds a body's records in colour order.  A body's colours are its lowest ones (the colouring takes
+// the lowest free colour), so its records are a few consecutive 128-byte lines.  Constraints of the overflow colour come last in the order and are applied
+// serially by the last workgroup.
 SGP_DEV void warm_body_one(const DV& d, uint32_t i)
 {
 	if (i >= d.sp->n_slots) return;
@@ -83,35 +90,19 @@ SGP_DEV void warm_body_one(const DV& d, uint32_t i)
 	const float4 v4 = rec[0], w4 = rec[1];
 	const float im = v4.w;
 	if (!(im > 0.0f)) return;
-	const sym33 I = body_world_inv_inertia(d, i);
+	const float4* wr = d.warm + (size_t)i * SGP_MAX_COLOURS * 2;
 	v3 lv = V3(v4), av = V3(w4);
+	// four records requested at a time (independent loads), added in colour order
 	while (mask) {
-		const int col = __ffsll((long long)mask) - 1;
-		mask &= mask - 1;
-		const uint32_t e = d.body_con[(size_t)i * SGP_MAX_COLOURS + col];
-		const uint32_t slot = e >> 1;
-		const bool second = e & 1u;
-		const float4 nf = CUR(d).n_fric[slot];
-		const int np = CUR(d).np_col[slot] & 0xFF;
-		const v3 n = V3(nf);
-		const v3 t1 = v3_normalized_perpendicular(n);
-		const v3 t2 = v3_cross(n, t1);
+		int col[4]; float4 a[4], b[4];
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
-			if (k < np) {
-				const v3 r = second ? V3(CUR(d).r2e[k][slot]) : V3(CUR(d).r1b[k][slot]);
-				const float4 l = CUR(d).lam[k][slot];
-				// apply_impulse, one side: body 1 subtracts, body 2 adds
-				if (nf.w > 0.0f) {
-					if (second) { lv = v3_add(lv, v3_scale(t1, l.y * im)); av = v3_add(av, v3_scale(sym33_mul(I, v3_cross(r, t1)), l.y)); }
-					else        { lv = v3_sub(lv, v3_scale(t1, l.y * im)); av = v3_sub(av, v3_scale(sym33_mul(I, v3_cross(r, t1)), l.y)); }
-					if (second) { lv = v3_add(lv, v3_scale(t2, l.z * im)); av = v3_add(av, v3_scale(sym33_mul(I, v3_cross(r, t2)), l.z)); }
-					else        { lv = v3_sub(lv, v3_scale(t2, l.z * im)); av = v3_sub(av, v3_scale(sym33_mul(I, v3_cross(r, t2)), l.z)); }
-				}
-				if (second) { lv = v3_add(lv, v3_scale(n, l.x * im)); av = v3_add(av, v3_scale(sym33_mul(I, v3_cross(r, n)), l.x)); }
-				else        { lv = v3_sub(lv, v3_scale(n, l.x * im)); av = v3_sub(av, v3_scale(sym33_mul(I, v3_cross(r, n)), l.x)); }
-			}
+			col[k] = mask ? __ffsll((long long)mask) - 1 : -1;
+			if (mask) mask &= mask - 1;
+			if (col[k] >= 0) { a[k] = wr[2 * col[k]]; b[k] = wr[2 * col[k] + 1]; }
 		}
+#pragma unroll
+		for (int k = 0; k < 4; ++k) if (col[k] >= 0) { lv = v3_add(lv, V3(a[k])); av = v3_add(av, V3(b[k])); }
 	}
 	rec[0] = F4(lv, im);
 	rec[1] = F4(av, 0.0f);
@@ -248,7 +239,7 @@ SGP_DEV uint32_t overflow_next(const DV& d, uint32_t first, uint32_t count, uint
 	// the overflow constraint with the lowest priority above `last` (selection by scanning: the overflow colour is rare and short)
 	uint64_t best = ~0ull; uint32_t bslot = first;
 	for (uint32_t k = 0; k < count; ++k) {
-		const uint64_t pr = sgp_mix64(CUR(d).key[first + k]);
+		const uint2 okab = CUR(d).ab[first + k]; const uint64_t pr = sgp_mix64(((uint64_t)okab.x << 32) | okab.y);
 		if ((!have_last || pr > last) && pr <= best) { best = pr; bslot = first + k; }
 	}
 	last = best; have_last = true;
@@ -764,7 +755,7 @@ __global__ void __launch_bounds__(512) k_solve_small_single(DV d, int warm_start
 					for (uint32_t it = 0; it < count; ++it) {
 						uint64_t best = ~0ull; uint32_t bslot = first;
 						for (uint32_t k = 0; k < count; ++k) {
-							const uint64_t pr = sgp_mix64(CUR(d).key[first + k]);
+							const uint2 okab = CUR(d).ab[first + k]; const uint64_t pr = sgp_mix64(((uint64_t)okab.x << 32) | okab.y);
 							if ((!have_last || pr > last) && pr <= best) { best = pr; bslot = first + k; }
 						}
 						last = best; have_last = true;

@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(TPB) k_island_mark(DV d, int clear_cache)
 	// the stores ride along with a launch that waits for its gathers: k_cache_clear was a launch of its own, 6 us on the step's chain)
 	if (clear_cache) {
 		const uint32_t size = cache_table_size(d);
-		for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < size; i += gridDim.x * TPB) d.ht_keys[i] = ~0ull;
+		for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < size; i += gridDim.x * TPB) d.ht[i] = make_uint4(~0u, ~0u, 0u, 0u);
 		if (blockIdx.x == 0 && threadIdx.x == 0) *d.ht_cur = size;
 	}
 	// (measured, round 4: the three rounds inside ONE launch -- agent-scope loads so that marks cross the XCDs' L2s -- cost 52 us against 36 us for three

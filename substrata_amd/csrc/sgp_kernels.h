@@ -196,21 +196,27 @@ struct StepParams {
 };
 
 // Constraint (contact manifold) SoA, double buffered (current step / previous step = contact cache).
+// What the NEXT step gathers of a constraint -- the body-space contact points it matches its own against, and for polytope pairs the relative pose the
+// body-pair contact cache compares -- is kept a second time as ONE record per slot (crec0, a 128-byte line; crec1 for the rare third and fourth point):
+// a gather moves a whole 128-byte line whatever it asks for (profiles/r06_pmc_calibration.md: a scattered 16-byte read costs what a full line costs),
+// and the SoA arrays cost one line per array and point (round 5: 4.6 lines per manifold in k_setup, 6 and more per polytope pair in k_narrowphase).
+#define CREC0_F4 8      // float4 per slot of crec0:
+                        //   [0] = (np_col bits, loc1[0].xyz)  [1] = (loc2[0].xyz, -)  [2] = (loc1[1].xyz, -)  [3] = (loc2[1].xyz, -)       <- first 64-byte sector: every constraint
+                        //   [4] = relative rotation conj(q1) q2   [5] = (relative position in body 1's frame xyz, normal in body 2's frame x)  [6] = (normal-in-2 y, z, -, -)  [7] = -
+                        //         <- second sector: polytope pairs only (the pose of body 2 relative to body 1 and the normal WHEN THE MANIFOLD WAS COMPUTED)
+#define CREC1_F4 4      // float4 per slot of crec1: loc1[2], loc2[2], loc1[3], loc2[3] (manifolds of three and four points)
 struct ConstraintArrays {
-	uint2*    ab;          // body ids, a < b
+	uint2*    ab;          // body ids, a < b (the pair key is a << 32 | b)
 	float4*   n_fric;      // normal xyz, combined friction w
-	uint64_t* key;         // a << 32 | b
 	int32_t*  np_col;      // np | colour << 8 | persisted << 16
 	float4*   r1b[4];      // r1 xyz, bias w
 	float4*   r2e[4];      // r2 xyz, eff_n w
 	float4*   lam[4];      // lam_n, lam_t1, lam_t2, -
 	float2*   efft[4];     // eff_t1, eff_t2
-	float4*   loc1[4];     // contact point in body-1 frame
+	float4*   loc1[4];     // contact point in body-1 frame (what the position iterations stream)
 	float4*   loc2[4];     // contact point in body-2 frame
-	// body-pair contact cache: pose of body 2 relative to body 1 and the normal in body 2's frame WHEN THE MANIFOLD WAS COMPUTED
-	float4*   cdp;         // relative position (in body 1's frame) xyz, normal-in-2 x
-	float4*   cdr;         // relative rotation conj(q1) * q2
-	float2*   cnl;         // normal-in-2 y, z
+	float4*   crec0;       // the cache record (above), CREC0_F4 per slot
+	float4*   crec1;       // CREC1_F4 per slot
 };
 
 struct DV {
@@ -237,7 +243,9 @@ struct DV {
 	float*  submerged;
 	uint64_t* userdata;        // mUserData of the body (the caller's PhysicsObject*): travels with the body when its ownership migrates to another tile
 	uint64_t* colour_mask;
-	uint32_t* body_con;        // [body][colour] -> 2 * constraint slot + side, valid where colour_mask[body] has the bit (k_setup)
+	float4* warm;              // [body][colour][2]: what the warm start of the body's constraint of that colour adds to its velocity record (linear, angular), valid where
+	                           //   colour_mask[body] has the bit (k_setup writes it, k_warm_bodies adds a body's records in colour order: a body's colours are its lowest ones, so
+	                           //   its records are a few consecutive 128-byte lines -- round 5: ~19 scattered lines per body through a (body, colour) -> slot table)
 	uint64_t* claim[2];
 	uint32_t* island;
 	uint32_t* island_awake;
@@ -301,7 +309,8 @@ struct DV {
 	                           // rows are compact (StepParams::compact_rows != 0), so that a lane rebuilding I (r x axis) gathers ONE record instead of the pose and property records + a rotation matrix
 	                           //   r2 x axis (w: effective mass of the axis), I1 (r1 x axis), I2 (r2 x axis)
 	ConstraintArrays ca[2];    // [sp->parity] = this step's constraints, the other = previous step's (contact cache)
-	uint64_t* ht_keys; uint32_t* ht_vals; uint32_t ht_size;   // contact cache: pair key -> prev slot (ht_size: allocated entries, a power of two)
+	uint4* ht; uint32_t ht_size;   // contact cache: 16-byte entries (pair key low, high, slot in the previous step's constraints, its np_col) -- one line per probe, and the
+	                           //   colour a manifold may inherit comes with the probe (ht_size: allocated entries, a power of two); key ~0 = empty
 	uint32_t* ht_cur;          // entries the last rebuild used (device scalar, a power of two <= ht_size): what look-ups mask with
 	uint32_t* cstarts;         // [SGP_MAX_COLOURS + 1] first constraint slot of every colour (device-side exclusive scan)
 	// counters / events

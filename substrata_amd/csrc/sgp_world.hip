@@ -89,8 +89,8 @@ SGP_API int sgp_init(void)
 
 static int alloc_constraints(sgp_world* w, ConstraintArrays& c, uint32_t cap)
 {
-	DEV_ALLOC(c.ab, cap); DEV_ALLOC(c.n_fric, cap); DEV_ALLOC(c.key, cap); DEV_ALLOC(c.np_col, cap);
-	DEV_ALLOC(c.cdp, cap); DEV_ALLOC(c.cdr, cap); DEV_ALLOC(c.cnl, cap);
+	DEV_ALLOC(c.ab, cap); DEV_ALLOC(c.n_fric, cap); DEV_ALLOC(c.np_col, cap);
+	DEV_ALLOC(c.crec0, (size_t)cap * CREC0_F4); DEV_ALLOC(c.crec1, (size_t)cap * CREC1_F4);      // the cache records: a 128-byte line per slot (+ 64 bytes for a third and fourth point)
 	for (int k = 0; k < 4; ++k) {
 		DEV_ALLOC(c.r1b[k], cap); DEV_ALLOC(c.r2e[k], cap); DEV_ALLOC(c.lam[k], cap); DEV_ALLOC(c.efft[k], cap);
 		DEV_ALLOC(c.loc1[k], cap); DEV_ALLOC(c.loc2[k], cap);
@@ -131,7 +131,7 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	DEV_ALLOC(d.flags, N); DEV_ALLOC(d.aabb_min, N); DEV_ALLOC(d.aabb_max, N);
 	for (int k = 0; k < 3; ++k) DEV_ALLOC(d.sleep_s[k], N);
 	DEV_ALLOC(d.sleep_timer, N); DEV_ALLOC(d.submerged, N); DEV_ALLOC(d.userdata, N);
-	DEV_ALLOC(d.colour_mask, N); DEV_ALLOC(d.body_con, (size_t)N * SGP_MAX_COLOURS); DEV_ALLOC(d.claim[0], N); DEV_ALLOC(d.claim[1], N);
+	DEV_ALLOC(d.colour_mask, N); DEV_ALLOC(d.warm, (size_t)N * SGP_MAX_COLOURS * 2); DEV_ALLOC(d.claim[0], N); DEV_ALLOC(d.claim[1], N);
 	DEV_ALLOC(d.veh_claim, N); DEV_ALLOC(d.veh_epoch, 1);
 	DEV_ALLOC(d.island, N); DEV_ALLOC(d.island_awake, N); DEV_ALLOC(d.awake_mark, N); DEV_ALLOC(d.export_counts, N / 256 + 2);
 	// cells of the broad-phase grid: room for 16 per body slot (clearing and scanning follow the cells a step's grid really has, not this capacity).  The grid covers the bounds of all small bodies with cells of R_max + margin and coarsens them
@@ -198,8 +198,8 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	{ int r = alloc_constraints(w, d.ca[0], M); if (r != SGP_OK) return r; }
 	{ int r = alloc_constraints(w, d.ca[1], M); if (r != SGP_OK) return r; }
 	w->ht_alloc = next_pow2(2u * M);
-	DEV_ALLOC(d.ht_keys, w->ht_alloc); DEV_ALLOC(d.ht_vals, w->ht_alloc);
-	HIP_TRY(hipMemsetAsync(d.ht_keys, 0xFF, sizeof(uint64_t) * w->ht_alloc, w->stream));      // empty contact cache
+	DEV_ALLOC(d.ht, w->ht_alloc);
+	HIP_TRY(hipMemsetAsync(d.ht, 0xFF, sizeof(uint4) * w->ht_alloc, w->stream));      // empty contact cache (key ~0)
 	d.ht_size = w->ht_alloc;
 	DEV_ALLOC(d.ht_cur, 1);
 	{ static const uint32_t first = 1024u; HIP_TRY(hipMemcpyAsync(d.ht_cur, &first, sizeof(first), hipMemcpyHostToDevice, w->stream)); }      // (an empty table: any size will do)

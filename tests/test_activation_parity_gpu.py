@@ -67,9 +67,9 @@ def test_sleeping_pile_on_a_mesh_with_hulls_is_woken_by_a_thrown_box(oracle):
     assert np.array_equal(ids_g, ids_c)
     nb = int(ids_g.max()) + 1
     asleep = False
-    for s in range(1200):
+    for s in range(2400):      # (round 6: the summed warm start changes the pile's chaotic path; it is down to the bodies that rolled off the terrain by step ~1300)
         tw.step(DT)
-        if s % 50 == 49 and tw.gpu.stats().num_active <= 6:       # (a sphere or two keep rolling in the terrain's hollows)
+        if s % 50 == 49 and tw.gpu.stats().num_active <= 6:       # (a sphere or two keep rolling in the terrain's hollows, three fall for ever beside the terrain)
             asleep = True
             break
     _exact(tw, nb, "settled")
