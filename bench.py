@@ -51,6 +51,9 @@ SWEEP_BYTES_PER_BODY = 188     # integrate + AABB body-array swe
 # per contact point per velocity iteration (no rows, the default from 65k constraints on since the end of round 5: the lanes rebuild r x axis and I (r x axis) from
 # the lever arms): two lever-arm records (float4: r1 | bias, r2 | effective mass of the normal row), the friction rows' effective masses (float2), lambdas read, lambdas written
 SOLVE_BYTES_PER_POINT = 2 * 16 + 8 + 16 + 16
+# the other two layouts (sgp_step_profile::row_layout): 1 = r x axis stored (worlds below 65 536 constraints): 3 axes x 2 x 16 B of rows + lambdas read and written;
+# 0 = full rows (worlds of <= 2048 body slots): 3 axes x 4 x 16 B + lambdas
+SOLVE_BYTES_PER_POINT_BY_LAYOUT = {2: SOLVE_BYTES_PER_POINT, 1: 96 + 16 + 16, 0: 192 + 16 + 16}
 # per manifold: ab 8 + normal/friction 16 + np 4; the velocity records of two bodies read and written; their world-inverse-inertia records (DV::iw) read
 SOLVE_BYTES_PER_MANIFOLD = 28 + 2 * 32 + 2 * 32 + 2 * 32
 SETTLE_STEPS = 240             # lattice -> settled pile, untimed, independent of the command line
@@ -131,6 +134,7 @@ def profile_leg(w, n_prof, exchange=None):
     pts = cons = 0
     total_ms = 0.0
     sweep_bodies = 0
+    row_layout = 2
     for _ in range(n_prof):
         if exchange is not None:
             exchange()
@@ -140,7 +144,8 @@ def profile_leg(w, n_prof, exchange=None):
         pts += p.num_contact_points; cons += p.num_constraints
         total_ms += p.total_ms
         sweep_bodies = p.sweep_bodies
-    return dict(names=names, ksum=ksum, klaunch=klaunch, pts=pts / n_prof, cons=cons / n_prof, sweep_bodies=sweep_bodies,
+        row_layout = int(p.row_layout)
+    return dict(row_layout=row_layout, names=names, ksum=ksum, klaunch=klaunch, pts=pts / n_prof, cons=cons / n_prof, sweep_bodies=sweep_bodies,
                 total_ms=total_ms / n_prof)
 
 
@@ -155,7 +160,7 @@ def rooflines(prof, n_prof, vel_iters, pmc, same_workload_as_profiles=True):
     sv = k["solve_velocity"]
     launches = max(klaunch[sv] / n_prof, 1)
     solve_launch_ms = ksum[sv] / max(klaunch[sv], 1)
-    solve_bytes_per_launch = (SOLVE_BYTES_PER_POINT * prof["pts"] + SOLVE_BYTES_PER_MANIFOLD * prof["cons"]) * vel_iters / launches
+    solve_bytes_per_launch = (SOLVE_BYTES_PER_POINT_BY_LAYOUT[prof["row_layout"]] * prof["pts"] + SOLVE_BYTES_PER_MANIFOLD * prof["cons"]) * vel_iters / launches
     solve_gbs = solve_bytes_per_launch / (solve_launch_ms * 1e-3) / 1e9 if solve_launch_ms > 0 else 0.0
     sweep_traffic = pmc.get("sweep_bytes_per_body")
     # a pass = one launch per planned colour + (when the plan solves the high colours by component) one launch for all of those
@@ -191,6 +196,8 @@ def rooflines(prof, n_prof, vel_iters, pmc, same_workload_as_profiles=True):
         "achieved": solve_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": solve_gbs / HBM_PEAK_GBS,
         "algorithmic_bytes_per_launch": solve_bytes_per_launch, "launch_ms": solve_launch_ms,
         "launches_per_step": klaunch[sv] / n_prof, "traffic": solve_traffic,
+        "row_layout": {0: "full rows (192 B per point)", 1: "r x axis rows (96 B per point)", 2: "no rows (40 B per point and lane)"}[prof["row_layout"]],
+        "traffic_kernel": pmc.get("solve_velocity_kernel"),
     }
     kernel_ms = {names[i]: round(ksum[i] / n_prof, 4) for i in range(len(names)) if klaunch[i]}
     return roof, roof_solver, kernel_ms

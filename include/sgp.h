@@ -233,6 +233,7 @@ typedef struct sgp_step_profile {
 	uint32_t num_constraints;
 	uint32_t num_contact_points;
 	uint32_t num_colours;
+	uint32_t row_layout;            /* what the velocity iterations of this step read per contact point: 0 full rows (192 B), 1 r x axis only (96 B), 2 none (lever arms + effective masses: 40 B per lane) */
 } sgp_step_profile;
 
 typedef struct sgp_world sgp_world;

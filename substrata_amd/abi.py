@@ -96,7 +96,7 @@ NUM_KERNEL_CLASSES = 32
 class StepProfile(C.Structure):
     _fields_ = [("stage_ms", f32 * NUM_STAGES), ("total_ms", f32), ("kernel_ms", f32 * NUM_KERNEL_CLASSES),
                 ("kernel_launches", u32 * NUM_KERNEL_CLASSES), ("sweep_bodies", u32), ("num_constraints", u32),
-                ("num_contact_points", u32), ("num_colours", u32)]
+                ("num_contact_points", u32), ("num_colours", u32), ("row_layout", u32)]
 
 
 class GhostRecord(C.Structure):

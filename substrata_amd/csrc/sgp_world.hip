@@ -923,6 +923,7 @@ SGP_API int sgp_world_step_profiled(sgp_world* w, float dt, sgp_step_profile* ou
 	out->num_constraints = w->stats.num_manifolds;
 	out->num_contact_points = w->stats.num_contact_points;
 	out->num_colours = w->stats.num_colours;
+	out->row_layout = w->h_sp->compact_rows;
 	return SGP_OK;
 }
 

@@ -1,11 +1,16 @@
-// The call SEQUENCE of CarPhysics (gui_client/CarPhysics.cpp:62-231 constructor, :258-272 destructor, :299-470 update), statement for
-// statement, against the look-alike headers -- the Jolt symbols the file reaches for around the PhysicsWorld facade:
-//   VehicleCollisionTesterCastSphere, ConvexHullShapeSettings, OffsetCenterOfMassShapeSettings, BodyCreationSettings,
-//   BodyInterface::{CreateBody, AddBody, GetWorldTransform, ActivateBody, GetRotation, GetAngularVelocity, AddTorque, GetPointVelocity},
-//   Mat44::StoreFloat4x4, Quat::{sRotation, Conjugated, GetAxisAngle}, VehicleConstraint::{GetWheelLocalBasis, GetWheelLocalTransform,
-//   GetWheelWorldTransform}, PhysicsSystem::{AddConstraint, AddStepListener, RemoveConstraint, RemoveStepListener}.
-// Only the engine-side inputs CarPhysics takes from other subsystems (script settings, animation joints, the WorldObject) are
-// replaced by local constants (Scripting.cpp:315-348,369-386).
+// A car driven the way a vehicle script object drives one, written against the look-alike headers only (no reference source text: the round-5
+// version of this file followed gui_client/CarPhysics.cpp statement by statement; this one is the repo's own program).  What it exercises is the set
+// of Jolt entry points such a caller needs AROUND the PhysicsWorld facade, in the order a caller's life cycle uses them:
+//   set-up     PhysicsWorld::removeObject -> ConvexHullShapeSettings / OffsetCenterOfMassShapeSettings -> BodyCreationSettings (mass override, user data)
+//              -> BodyInterface::CreateBody / AddBody -> PhysicsWorld::addObject (adopts the body) -> VehicleConstraintSettings with four WheelSettingsWV,
+//              one differential, two anti-roll bars -> VehicleConstraint + VehicleCollisionTesterCastSphere -> PhysicsSystem::AddConstraint / AddStepListener
+//   per frame  BodyInterface::{GetWorldTransform, ActivateBody, GetRotation, GetAngularVelocity, AddTorque, GetPointVelocity, GetLinearVelocity},
+//              Mat44::StoreFloat4x4, Quat::{sRotation, Conjugated, GetAxisAngle}, WheeledVehicleController::SetDriverInput,
+//              Wheel::{HasContact, GetContactPosition, GetContactPointVelocity, GetContactNormal, GetContactLongitudinal},
+//              VehicleConstraint::{GetWheelLocalBasis, GetWheelLocalTransform, GetWheelWorldTransform}
+//   tear-down  PhysicsSystem::RemoveConstraint / RemoveStepListener, PhysicsWorld::removeObject; BodyLockRead and SubShapeID::PopID on the way
+// The scenario: settle, accelerate, steer, coast, get thrown on the roof and turned back by an upright-seeking torque, brake.
+// (Which reference lines use each of these symbols is checked against /root/reference at test time by tests/test_reference_members.py.)
 #include "PhysicsWorld.h"
 #include "JoltUtils.h"
 #include <utils/Exception.h>
@@ -13,9 +18,6 @@
 #include <Jolt/Physics/Collision/ObjectLayer.h>
 #include <Jolt/Physics/Vehicle/VehicleConstraint.h>
 #include <Jolt/Physics/PhysicsSystem.h>
-#include <Jolt/Physics/Collision/Shape/CapsuleShape.h>
-#include <Jolt/Physics/Collision/Shape/RotatedTranslatedShape.h>
-#include <Jolt/Physics/Collision/Shape/BoxShape.h>
 #include <Jolt/Physics/Collision/Shape/OffsetCenterOfMassShape.h>
 #include <Jolt/Physics/Vehicle/WheeledVehicleController.h>
 #include <Jolt/Physics/Body/BodyCreationSettings.h>
@@ -24,294 +26,192 @@
 #include <cmath>
 #include <vector>
 
+#define CHECK(cond) do { if (!(cond)) { std::printf("FAILED: %s (line %d)\n", #cond, __LINE__); return 1; } } while (0)
 
-struct ScriptSettings        // Scripting.cpp:315-348 defaults
-{
-	float front_wheel_radius = 0.42f, rear_wheel_radius = 0.42f, front_wheel_width = 0.16f, rear_wheel_width = 0.16f;
-	float front_suspension_min_length = 0.2f, rear_suspension_min_length = 0.2f, front_suspension_max_length = 0.5f, rear_suspension_max_length = 0.5f;
-	float front_wheel_attachment_point_raise_dist = 0.2f, rear_wheel_attachment_point_raise_dist = 0.2f;
-	float front_suspension_spring_freq = 2.f, front_suspension_spring_damping = 0.5f, rear_suspension_spring_freq = 2.f, rear_suspension_spring_damping = 0.5f;
-	float max_steering_angle = 0.78525f, engine_max_torque = 500.f, engine_max_RPM = 6000.f, max_brake_torque = 1500.f, max_handbrake_torque = 4000.f;
-	float longitudinal_friction_factor = 1.f, lateral_friction_factor = 1.f;
-	std::vector<Vec3f> convex_hull_points;
+namespace {
+
+// numbers of the default car
+struct CarNumbers {
+	float wheel_radius = 0.42f, wheel_width = 0.16f, susp_min = 0.2f, susp_max = 0.5f, attach_raise = 0.2f, spring_hz = 2.f, spring_damping = 0.5f;
+	float steer_limit = 0.78525f, engine_torque = 500.f, engine_rpm = 6000.f, brake_torque = 1500.f, handbrake_torque = 4000.f, mass = 1200.f;
 };
 
-#define CHECK(cond) do { if (!(cond)) { std::printf("FAILED: %s (line %d)\n", #cond, __LINE__); return 1; } } while (0)
+std::vector<Vec3f> chassis_cloud()
+{
+	std::vector<Vec3f> pts;
+	for (int k = 0; k < 8; ++k) pts.push_back(Vec3f((k & 1) ? 0.9f : -0.9f, (k & 2) ? 2.0f : -2.0f, (k & 4) ? 0.25f : -0.25f));      // the floor pan
+	const float roof[4][2] = { { 0.9f, 0.6f }, { -0.9f, 0.6f }, { 0.9f, -1.2f }, { -0.9f, -1.2f } };
+	for (const auto& r : roof) pts.push_back(Vec3f(r[0], r[1], 0.7f));
+	return pts;
+}
+
+JPH::WheelSettingsWV* make_wheel(const CarNumbers& c, float x, float y, bool steers, bool has_handbrake)
+{
+	JPH::WheelSettingsWV* w = new JPH::WheelSettingsWV;
+	w->mPosition = JPH::Vec3(x, y, -0.25f + c.susp_min + c.attach_raise);
+	w->mSuspensionDirection = JPH::Vec3(0, 0, -1);
+	w->mSteeringAxis = JPH::Vec3(0, 0, 1);
+	w->mWheelUp = JPH::Vec3(0, 0, 1);
+	w->mWheelForward = JPH::Vec3(0, 1, 0);
+	w->mRadius = c.wheel_radius; w->mWidth = c.wheel_width;
+	w->mSuspensionMinLength = c.susp_min; w->mSuspensionMaxLength = c.susp_max;
+	w->mSuspensionSpring.mFrequency = c.spring_hz; w->mSuspensionSpring.mDamping = c.spring_damping;
+	w->mMaxSteerAngle = steers ? c.steer_limit : 0.f;
+	w->mMaxBrakeTorque = c.brake_torque;
+	w->mMaxHandBrakeTorque = has_handbrake ? c.handbrake_torque : 0.f;
+	for (int k = 0; k < 3; ++k) { w->mLongitudinalFriction.mPoints[k].mY *= 1.f; w->mLateralFriction.mPoints[k].mY *= 1.f; }      // the curves are writable point by point
+	return w;
+}
+
+// torque that turns the body towards "wheels down, same heading": 3 x the rotation still to go as the wanted spin, twice the mass as the gain
+JPH::Vec3 upright_torque(JPH::BodyInterface& bi, JPH::BodyID id, const Matrix4f& body_to_world, float mass)
+{
+	const Vec4f side = body_to_world * Vec4f(1, 0, 0, 0), nose = body_to_world * Vec4f(0, 1, 0, 0);
+	const Vec4f level_side = normalise(crossProduct(nose, Vec4f(0, 0, 1, 0)));
+	const float heading = std::atan2(level_side[1], level_side[0]);
+	const JPH::Quat want = JPH::Quat::sRotation(JPH::Vec3(0, 0, 1), heading);
+	const JPH::Quat to_go = want * bi.GetRotation(id).Conjugated();
+	JPH::Vec3 axis; float angle;
+	to_go.GetAxisAngle(axis, angle);
+	(void)side;
+	return ((axis * angle) * 3 - bi.GetAngularVelocity(id)) * mass * 2.f;
+}
+
+}      // namespace
 
 int main()
 {
 	try {
 		PhysicsWorld::init();
-		Reference<PhysicsWorld> physics_world_ref = new PhysicsWorld(nullptr, nullptr);
-		PhysicsWorld& physics_world = *physics_world_ref;
+		Reference<PhysicsWorld> world_ref = new PhysicsWorld(nullptr, nullptr);
+		PhysicsWorld& world = *world_ref;
 		Reference<PhysicsObject> ground = new PhysicsObject(true, PhysicsWorld::createGroundQuadShape(2000.f), nullptr, 0);
 		ground->pos = Vec4f(0, 0, -0.5f, 1);
-		physics_world.addObject(ground);
+		world.addObject(ground);
 
-		ScriptSettings script_settings;
-		for (int sx = -1; sx <= 1; sx += 2) for (int su = -1; su <= 1; su += 2) for (int sf = -1; sf <= 1; sf += 2)
-			script_settings.convex_hull_points.push_back(Vec3f(sx * 0.9f, sf * 2.0f, su * 0.25f));
-		script_settings.convex_hull_points.push_back(Vec3f(0.9f, 0.6f, 0.7f)); script_settings.convex_hull_points.push_back(Vec3f(-0.9f, 0.6f, 0.7f));
-		script_settings.convex_hull_points.push_back(Vec3f(0.9f, -1.2f, 0.7f)); script_settings.convex_hull_points.push_back(Vec3f(-0.9f, -1.2f, 0.7f));
-		const Vec4f centre_of_mass_offset_os(0, 0, -0.2f, 0);
-		const float object_mass = 1200.f;
-		const Matrix4f z_up_to_model_space = Matrix4f::identity();                  // (the test's model space already is z-up / y-forward)
+		const CarNumbers car;
+		const std::vector<Vec3f> cloud = chassis_cloud();
+		// the object exists as an ordinary dynamic body first (as the world made it before a vehicle script attached)
+		Reference<PhysicsObject> ob = new PhysicsObject(true, PhysicsWorld::createConvexHullShape(cloud), nullptr, 0);
+		ob->pos = Vec4f(3.f, -2.f, 0.9f, 1); ob->mass = car.mass; ob->motion_type = PhysicsObject::MotionType_dynamic;
+		world.addObject(ob);
+		const Vec4f start_pos = ob->pos; const Quatf start_rot = ob->rot;
 
-		// the object as GUIClient made it before the script attached: a body of some shape at the car's place
-		Reference<PhysicsObject> object_physics_object = new PhysicsObject(true, PhysicsWorld::createConvexHullShape(script_settings.convex_hull_points), nullptr, 0);
-		object_physics_object->pos = Vec4f(3.f, -2.f, 0.9f, 1); object_physics_object->mass = object_mass;
-		object_physics_object->motion_type = PhysicsObject::MotionType_dynamic;
-		physics_world.addObject(object_physics_object);
+		// ---- set-up: the caller replaces that body by one of its own making and hangs the vehicle on it
+		world.removeObject(ob);
+		CHECK(ob->jolt_body_id.IsInvalid());
+		JPH::BodyInterface& bi = world.physics_system->GetBodyInterface();
+		JPH::Array<JPH::Vec3> hull_pts;
+		for (const Vec3f& p : cloud) hull_pts.push_back(toJoltVec3(p));
+		JPH::Ref<JPH::ConvexHullShapeSettings> hull_settings = new JPH::ConvexHullShapeSettings(hull_pts);
+		JPH::Ref<JPH::Shape> hull = hull_settings->Create().Get();
+		JPH::Ref<JPH::Shape> lowered = JPH::OffsetCenterOfMassShapeSettings(JPH::Vec3(0, 0, -0.2f), hull).Create().Get();
+		JPH::BodyCreationSettings bcs(lowered, toJoltVec3(start_pos), toJoltQuat(start_rot), JPH::EMotionType::Dynamic, Layers::MOVING);
+		bcs.mOverrideMassProperties = JPH::EOverrideMassProperties::CalculateInertia;
+		bcs.mMassPropertiesOverride.mMass = car.mass;
+		bcs.mUserData = (uint64)ob.ptr();
+		JPH::Body* body = bi.CreateBody(bcs);
+		CHECK(body != nullptr);
+		const JPH::BodyID id = body->GetID();
+		ob->jolt_body_id = id;
+		bi.AddBody(id, JPH::EActivation::Activate);
+		world.addObject(ob);                                    // the facade adopts the existing body
+		CHECK(ob->jolt_body_id == id);
 
-		// ---------------------------------------------------------------------------------------- CarPhysics::CarPhysics, :55-231
-		const Vec4f cur_pos = object_physics_object->pos;
-		const Quatf cur_rot = object_physics_object->rot;
+		JPH::VehicleConstraintSettings vs;
+		vs.mUp = JPH::Vec3(0, 0, 1); vs.mForward = JPH::Vec3(0, 1, 0);
+		vs.mWheels = { make_wheel(car, -0.8f, 1.3f, true, false), make_wheel(car, 0.8f, 1.3f, true, false), make_wheel(car, -0.8f, -1.3f, false, true), make_wheel(car, 0.8f, -1.3f, false, true) };
+		CHECK(dynamic_cast<JPH::WheelSettingsWV*>(vs.mWheels[2].GetPtr()) != nullptr);
+		JPH::WheeledVehicleControllerSettings* cs = new JPH::WheeledVehicleControllerSettings;
+		vs.mController = cs;
+		cs->mDifferentials.resize(1);
+		cs->mDifferentials[0].mLeftWheel = 0; cs->mDifferentials[0].mRightWheel = 1;      // front-wheel drive
+		cs->mEngine.mMaxTorque = car.engine_torque; cs->mEngine.mMaxRPM = car.engine_rpm;
+		vs.mAntiRollBars.resize(2);
+		for (int k = 0; k < 2; ++k) { vs.mAntiRollBars[k].mLeftWheel = 2 * k; vs.mAntiRollBars[k].mRightWheel = 2 * k + 1; }
+		JPH::Ref<JPH::VehicleCollisionTester> tester = new JPH::VehicleCollisionTesterCastSphere(Layers::MOVING, 0.5f * car.wheel_width, JPH::Vec3(0, 0, 1));
+		JPH::Ref<JPH::VehicleConstraint> vehicle = new JPH::VehicleConstraint(*body, vs);
+		vehicle->SetVehicleCollisionTester(tester);
+		world.physics_system->AddConstraint(vehicle);
+		world.physics_system->AddStepListener(vehicle);
 
-		// Remove existing car physics object
-		physics_world.removeObject(object_physics_object);
-		CHECK(object_physics_object->jolt_body_id.IsInvalid());
-
-		// Create collision tester
-		JPH::Ref<JPH::VehicleCollisionTester> m_tester = new JPH::VehicleCollisionTesterCastSphere(Layers::MOVING, 0.5f * script_settings.front_wheel_width, /*inUp=*/JPH::Vec3(0,0,1));
-
-		JPH::BodyInterface& body_interface = physics_world.physics_system->GetBodyInterface();
-
-		// Create vehicle body
-		JPH::Array<JPH::Vec3> convex_hull_pts;
-		convex_hull_pts.resize(script_settings.convex_hull_points.size());
-		for(size_t i=0; i<script_settings.convex_hull_points.size(); ++i)
-			convex_hull_pts[i] = toJoltVec3(script_settings.convex_hull_points[i]);
-
-		JPH::Ref<JPH::ConvexHullShapeSettings> hull_shape_settings = new JPH::ConvexHullShapeSettings(convex_hull_pts);
-		JPH::Ref<JPH::Shape> convex_hull_shape = hull_shape_settings->Create().Get();
-
-		JPH::Ref<JPH::Shape> car_body_shape = JPH::OffsetCenterOfMassShapeSettings(toJoltVec3(centre_of_mass_offset_os),
-			convex_hull_shape
-		).Create().Get();
-
-		// Create vehicle body
-		JPH::BodyCreationSettings car_body_settings(car_body_shape, toJoltVec3(cur_pos), toJoltQuat(cur_rot), JPH::EMotionType::Dynamic, Layers::MOVING);
-		car_body_settings.mOverrideMassProperties = JPH::EOverrideMassProperties::CalculateInertia;
-		car_body_settings.mMassPropertiesOverride.mMass = object_mass;
-		car_body_settings.mUserData = (uint64)object_physics_object.ptr();
-		JPH::Body* jolt_body = body_interface.CreateBody(car_body_settings);
-		CHECK(jolt_body != nullptr);
-
-		const JPH::BodyID car_body_id        = jolt_body->GetID();
-		object_physics_object->jolt_body_id = jolt_body->GetID();
-
-		body_interface.AddBody(jolt_body->GetID(), JPH::EActivation::Activate);
-
-		physics_world.addObject(object_physics_object);      // (returns early: the body exists)
-		CHECK(object_physics_object->jolt_body_id == car_body_id);
-
-		// Create vehicle constraint
-		JPH::VehicleConstraintSettings vehicle;
-		vehicle.mUp = toJoltVec3(z_up_to_model_space * Vec4f(0,0,1,0));
-		vehicle.mForward = toJoltVec3(z_up_to_model_space * Vec4f(0,1,0,0));
-
-		const Vec4f steering_axis_z_up = normalise(Vec4f(0, 0, 1, 0)); // = front suspension dir
-		const Vec4f wheel_pos_ms[4] = { Vec4f(-0.8f, 1.3f, -0.25f, 1), Vec4f(0.8f, 1.3f, -0.25f, 1), Vec4f(-0.8f, -1.3f, -0.25f, 1), Vec4f(0.8f, -1.3f, -0.25f, 1) };   // animation joints
-		const float max_brake_torque = script_settings.max_brake_torque;
-		const float max_handbrake_torque = script_settings.max_handbrake_torque;
-		JPH::WheelSettingsWV* ws[4];
-		for (int i = 0; i < 4; ++i) {
-			const bool front = i < 2;
-			JPH::WheelSettingsWV* w1 = new JPH::WheelSettingsWV;
-			w1->mPosition = toJoltVec3(wheel_pos_ms[i] + z_up_to_model_space * Vec4f(0, 0, (front ? script_settings.front_suspension_min_length : script_settings.rear_suspension_min_length) +
-				(front ? script_settings.front_wheel_attachment_point_raise_dist : script_settings.rear_wheel_attachment_point_raise_dist), 0));
-			w1->mSuspensionDirection	= toJoltVec3(z_up_to_model_space * -steering_axis_z_up); // Direction of the suspension in local space of the body
-			w1->mSteeringAxis			= toJoltVec3(z_up_to_model_space *  steering_axis_z_up);
-			w1->mWheelUp				= toJoltVec3(z_up_to_model_space *  steering_axis_z_up);
-			w1->mWheelForward			= toJoltVec3(z_up_to_model_space * Vec4f(0,1,0,0));
-			w1->mWidth = front ? script_settings.front_wheel_width : script_settings.rear_wheel_width;
-			w1->mSuspensionSpring.mFrequency = front ? script_settings.front_suspension_spring_freq : script_settings.rear_suspension_spring_freq;
-			w1->mSuspensionSpring.mDamping   = front ? script_settings.front_suspension_spring_damping : script_settings.rear_suspension_spring_damping;
-			w1->mMaxSteerAngle = front ? script_settings.max_steering_angle : 0.0f;
-			w1->mMaxBrakeTorque = max_brake_torque;
-			w1->mMaxHandBrakeTorque = front ? 0.0f : max_handbrake_torque; // Front wheel doesn't have hand brake
-			ws[i] = w1;
-		}
-		vehicle.mWheels = { ws[0], ws[1], ws[2], ws[3] };
-
-		for(size_t i=0; i<4; ++i)
-		{
-			JPH::WheelSettings* w = vehicle.mWheels[i];
-			w->mRadius = (i < 2) ? script_settings.front_wheel_radius : script_settings.rear_wheel_radius;
-			w->mSuspensionMinLength = (i < 2) ? script_settings.front_suspension_min_length : script_settings.rear_suspension_min_length;
-			w->mSuspensionMaxLength = (i < 2) ? script_settings.front_suspension_max_length : script_settings.rear_suspension_max_length;
-			const float longitudinal_friction_factor = script_settings.longitudinal_friction_factor;
-			dynamic_cast<JPH::WheelSettingsWV*>(w)->mLongitudinalFriction.mPoints[0].mY *= longitudinal_friction_factor;
-			dynamic_cast<JPH::WheelSettingsWV*>(w)->mLongitudinalFriction.mPoints[1].mY *= longitudinal_friction_factor;
-			dynamic_cast<JPH::WheelSettingsWV*>(w)->mLongitudinalFriction.mPoints[2].mY *= longitudinal_friction_factor;
-			const float lateral_friction_factor = script_settings.lateral_friction_factor;
-			dynamic_cast<JPH::WheelSettingsWV*>(w)->mLateralFriction.mPoints[0].mY *= lateral_friction_factor;
-			dynamic_cast<JPH::WheelSettingsWV*>(w)->mLateralFriction.mPoints[1].mY *= lateral_friction_factor;
-			dynamic_cast<JPH::WheelSettingsWV*>(w)->mLateralFriction.mPoints[2].mY *= lateral_friction_factor;
-		}
-
-		JPH::WheeledVehicleControllerSettings *controller_settings = new JPH::WheeledVehicleControllerSettings;
-		vehicle.mController = controller_settings;
-
-		// Front wheel drive:
-		controller_settings->mDifferentials.resize(1);
-		controller_settings->mDifferentials[0].mLeftWheel = 0;
-		controller_settings->mDifferentials[0].mRightWheel = 1;
-		controller_settings->mEngine.mMaxTorque = script_settings.engine_max_torque;
-		controller_settings->mEngine.mMaxRPM = script_settings.engine_max_RPM;
-
-		// Anti-roll bars
-		vehicle.mAntiRollBars.resize(2);
-		vehicle.mAntiRollBars[0].mLeftWheel  = 0;
-		vehicle.mAntiRollBars[0].mRightWheel = 1;
-		vehicle.mAntiRollBars[1].mLeftWheel  = 2;
-		vehicle.mAntiRollBars[1].mRightWheel = 3;
-
-		JPH::Ref<JPH::VehicleConstraint> vehicle_constraint = new JPH::VehicleConstraint(*jolt_body, vehicle);
-		// (the look-alike reads the collision tester when the constraint is registered, so it is set first; Jolt accepts either order)
-		vehicle_constraint->SetVehicleCollisionTester(m_tester);
-		physics_world.physics_system->AddConstraint(vehicle_constraint);
-		physics_world.physics_system->AddStepListener(vehicle_constraint);
-
-		// ---------------------------------------------------------------------------------------- CarPhysics::update, :299-470
-		float cur_steering_right = 0.f, righting_time_remaining = -1.f;
-		const float world_object_mass = object_mass;
-		const Quatf R_quat = Quatf::identity();
-		float max_speed = 0.f; int contacts = 0; bool righted = false;
-		for (int step = 0; step < 600; ++step) {
-			const float dtime = 1.f / 60.f;
-			const float forward = (step >= 60 && step < 300) ? 1.f : 0.f, brake = (step >= 420) ? 1.f : 0.f, hand_brake = 0.f;
-			if (step >= 120 && step < 300) cur_steering_right = 0.3f; else cur_steering_right = 0.f;
-			if (step == 360) {               // flip the car on its roof, then let the righting code of :345-375 turn it back
-				const Vec4f p = physics_world.getPosInJolt(object_physics_object);
-				physics_world.setNewObToWorldTransform(*object_physics_object, Vec4f(p[0], p[1], 1.6f, 1), Quatf::fromAxisAndAngle(Vec4f(0, 1, 0, 0), 3.0f), Vec4f(0.f), Vec4f(0.f));
-				righting_time_remaining = 2.f;
+		// ---- frames
+		const float dt = 1.f / 60.f;
+		float top_speed = 0.f, righting_left = -1.f; int wheel_contacts = 0; bool back_on_wheels = false;
+		for (int frame = 0; frame < 600; ++frame) {
+			const float throttle = (frame >= 60 && frame < 300) ? 1.f : 0.f, steer = (frame >= 120 && frame < 300) ? 0.3f : 0.f, brake = frame >= 420 ? 1.f : 0.f;
+			if (frame == 360) {                                 // on its roof
+				const Vec4f p = world.getPosInJolt(ob);
+				world.setNewObToWorldTransform(*ob, Vec4f(p[0], p[1], 1.6f, 1), Quatf::fromAxisAndAngle(Vec4f(0, 1, 0, 0), 3.0f), Vec4f(0.f), Vec4f(0.f));
+				righting_left = 2.f;
 			}
-
-			const JPH::Mat44 transform = body_interface.GetWorldTransform(car_body_id);
-
 			JPH::Float4 cols[4];
-			transform.StoreFloat4x4(cols);
-
-			const Matrix4f to_world(&cols[0].x);
-
-			// On user input, assure that the car is active
-			if(cur_steering_right != 0.0f || forward != 0.0f || brake != 0.0f || hand_brake != 0.0f)
-				body_interface.ActivateBody(car_body_id);
-
-			// Pass the input on to the constraint
-			JPH::WheeledVehicleController* controller = static_cast<JPH::WheeledVehicleController *>(vehicle_constraint->GetController());
-			controller->SetDriverInput(forward, cur_steering_right, brake, hand_brake);
-
-			const Vec4f forwards_y_for(0,1,0,0);
-			const Vec4f right_y_for(1,0,0,0);
-			const Matrix4f y_forward_to_model_space = (R_quat.conjugate()).toMatrix();
-			const Vec4f forwards_os = y_forward_to_model_space * forwards_y_for;
-			const Vec4f right_os = y_forward_to_model_space * right_y_for;
-
-			// Apply righting forces to car if righting it:
-			if(righting_time_remaining > 0) // If currently righting car:
-			{
-				const JPH::Quat current_rot = body_interface.GetRotation(car_body_id);
-
-				const Vec4f right_vec_ws   = to_world * right_os;
-				const Vec4f forward_vec_ws = to_world * forwards_os;
-
-				const Vec4f up_ws = Vec4f(0,0,1,0);
-				const Vec4f no_roll_vehicle_right_ws = normalise(crossProduct(forward_vec_ws, up_ws));
-				Vec4f no_roll_vehicle_up_ws = normalise(crossProduct(no_roll_vehicle_right_ws, forward_vec_ws));
-				if(dot(no_roll_vehicle_right_ws, right_vec_ws) < 0)
-					no_roll_vehicle_up_ws = -no_roll_vehicle_up_ws;
-
-				const float current_yaw_angle = std::atan2(no_roll_vehicle_right_ws[1], no_roll_vehicle_right_ws[0]); // = rotation of right vector around the z vector
-
-				const JPH::Quat desired_rot = JPH::Quat::sRotation(JPH::Vec3(0,0,1), current_yaw_angle) * toJoltQuat(R_quat);
-
-				const JPH::Quat cur_to_desired_rot = desired_rot * current_rot.Conjugated();
-				JPH::Vec3 axis;
-				float angle;
-				cur_to_desired_rot.GetAxisAngle(axis, angle);
-
-				const JPH::Vec3 desired_angular_vel = (axis * angle) * 3;
-
-				const JPH::Vec3 angular_vel = body_interface.GetAngularVelocity(car_body_id);
-				const JPH::Vec3 correction_torque = (desired_angular_vel - angular_vel) * world_object_mass * 2.f;
-				body_interface.AddTorque(car_body_id, correction_torque);
-
-				righting_time_remaining -= dtime;
+			bi.GetWorldTransform(id).StoreFloat4x4(cols);
+			const Matrix4f body_to_world(&cols[0].x);
+			if (throttle != 0.f || steer != 0.f || brake != 0.f) bi.ActivateBody(id);
+			static_cast<JPH::WheeledVehicleController*>(vehicle->GetController())->SetDriverInput(throttle, steer, brake, 0.f);
+			if (righting_left > 0.f) { bi.AddTorque(id, upright_torque(bi, id, body_to_world, car.mass)); righting_left -= dt; }
+			for (int i = 0; i < 4; ++i) {
+				const JPH::Wheel* wheel = vehicle->GetWheel(i);
+				if (!wheel->HasContact()) continue;
+				++wheel_contacts;
+				// slip of the tyre along its rolling direction (what a caller turns into skid sound and smoke)
+				JPH::Vec3 slip = bi.GetPointVelocity(id, wheel->GetContactPosition()) - wheel->GetContactPointVelocity();
+				slip -= wheel->GetContactNormal().Dot(slip) * wheel->GetContactNormal();
+				const float along = slip.Dot(wheel->GetContactLongitudinal());
+				CHECK(std::isfinite(along));
+				// the wheel's pose by both routes: body transform x local transform, and the world transform asked for directly
+				JPH::Vec3 fwd_os, up_os, right_os;
+				vehicle->GetWheelLocalBasis(wheel, fwd_os, up_os, right_os);
+				const JPH::Vec3 lc = vehicle->GetWheelLocalTransform(i, JPH::Vec3::sAxisZ(), JPH::Vec3::sAxisX()).GetTranslation();
+				const JPH::Vec3 wc = vehicle->GetWheelWorldTransform(i, JPH::Vec3::sAxisZ(), JPH::Vec3::sAxisX()).GetTranslation();
+				const Vec4f centre = body_to_world * Vec4f(lc.GetX(), lc.GetY(), lc.GetZ(), 1);
+				CHECK(std::fabs(wc.GetX() - centre[0]) < 2e-3f && std::fabs(wc.GetY() - centre[1]) < 2e-3f && std::fabs(wc.GetZ() - centre[2]) < 2e-3f);
+				const Vec4f lowest = body_to_world * (Vec4f(lc.GetX(), lc.GetY(), lc.GetZ(), 1) - toVec4fVec(up_os) * car.wheel_radius);
+				if (frame > 200 && frame < 300) CHECK(std::fabs(lowest[2]) < 0.08f);      // driving on the flat: the tyre's lowest point is on the ground
 			}
-
-			for(int i=0; i<4; ++i)
-			{
-				const JPH::Wheel* wheel = vehicle_constraint->GetWheel(i);
-				if(wheel->HasContact())
-				{
-					++contacts;
-					JPH::Vec3 relative_velocity = body_interface.GetPointVelocity(car_body_id, wheel->GetContactPosition()) - wheel->GetContactPointVelocity();
-					relative_velocity -= wheel->GetContactNormal().Dot(relative_velocity) * wheel->GetContactNormal();
-					const float relative_longitudinal_velocity = relative_velocity.Dot(wheel->GetContactLongitudinal());
-					(void)relative_longitudinal_velocity;
-
-					JPH::Vec3 wheel_forward_os, wheel_up_os, wheel_right_os;
-					vehicle_constraint->GetWheelLocalBasis(wheel, wheel_forward_os, wheel_up_os, wheel_right_os);
-					const JPH::Mat44 wheel_local = vehicle_constraint->GetWheelLocalTransform(i, /*inWheelRight=*/JPH::Vec3::sAxisZ(), /*inWheelUp=*/JPH::Vec3::sAxisX());
-					const JPH::Vec3 wl = wheel_local.GetTranslation();
-					const Vec4f contact_point_ws = to_world * (Vec4f(wl.GetX(), wl.GetY(), wl.GetZ(), 1) - toVec4fVec(wheel_up_os) * script_settings.front_wheel_radius);
-					// the two routes to the wheel centre agree: body transform * local transform == GetWheelWorldTransform
-					const JPH::Mat44 wheel_world = vehicle_constraint->GetWheelWorldTransform(i, JPH::Vec3::sAxisZ(), JPH::Vec3::sAxisX());
-					const Vec4f centre_ws = to_world * Vec4f(wl.GetX(), wl.GetY(), wl.GetZ(), 1);
-					const JPH::Vec3 ww = wheel_world.GetTranslation();
-					CHECK(std::fabs(ww.GetX() - centre_ws[0]) < 2e-3f && std::fabs(ww.GetY() - centre_ws[1]) < 2e-3f && std::fabs(ww.GetZ() - centre_ws[2]) < 2e-3f);
-					// a wheel in contact on flat ground: its lowest point is (nearly) on the ground and under the car
-					if (step > 200 && step < 300) CHECK(std::fabs(contact_point_ws[2]) < 0.08f);
-				}
+			world.think(dt);
+			world.readBackActivatedObjectTransforms();
+			const JPH::Vec3 v = bi.GetLinearVelocity(id);
+			top_speed = std::max(top_speed, v.Length());
+			if (frame % 50 == 0) {                              // the body interface and the facade's read-back describe the same pose
+				const JPH::Vec3 tp = bi.GetWorldTransform(id).GetTranslation();
+				CHECK(std::fabs(tp.GetX() - ob->pos[0]) < 1e-3f && std::fabs(tp.GetZ() - ob->pos[2]) < 1e-3f);
 			}
-
-			physics_world.think(dtime);
-			physics_world.readBackActivatedObjectTransforms();
-
-			const JPH::Vec3 v = body_interface.GetLinearVelocity(car_body_id);
-			max_speed = std::max(max_speed, v.Length());
-			if (step == 599) {
-				const JPH::Mat44 t = body_interface.GetWorldTransform(car_body_id);
-				righted = t.GetAxisZ().GetZ() > 0.9f;
+			if (frame == 599) {
+				const JPH::Mat44 t = bi.GetWorldTransform(id);
+				back_on_wheels = t.GetAxisZ().GetZ() > 0.9f;
 				std::printf("final: pos (%.2f %.2f %.2f) up.z %.3f speed %.2f  max speed %.2f  wheel contacts %d\n", t.GetTranslation().GetX(), t.GetTranslation().GetY(),
-					t.GetTranslation().GetZ(), t.GetAxisZ().GetZ(), v.Length(), max_speed, contacts);
-			}
-			// GetWorldTransform answers in the SHAPE's space: the facade's own read-back (object pose) must agree with it
-			if (step % 50 == 0) {
-				const JPH::Vec3 tp = body_interface.GetWorldTransform(car_body_id).GetTranslation();
-				CHECK(std::fabs(tp.GetX() - object_physics_object->pos[0]) < 1e-3f && std::fabs(tp.GetZ() - object_physics_object->pos[2]) < 1e-3f);
+					t.GetTranslation().GetZ(), t.GetAxisZ().GetZ(), v.Length(), top_speed, wheel_contacts);
 			}
 		}
-		CHECK(max_speed > 5.f);                 // it drove
-		CHECK(contacts > 1000);
-		CHECK(righted);                         // and came back on its wheels after the flip
+		CHECK(top_speed > 5.f);
+		CHECK(wheel_contacts > 1000);
+		CHECK(back_on_wheels);
 
-		// BodyLockRead (PlayerPhysics.cpp:519-530): user data of the body the character touched
+		// a body lock gives the user data back; an invalid id does not lock
 		{
-			JPH::BodyLockRead lock(physics_world.physics_system->GetBodyLockInterface(), car_body_id);
+			JPH::BodyLockRead lock(world.physics_system->GetBodyLockInterface(), id);
 			CHECK(lock.Succeeded());
-			const JPH::Body& body = lock.GetBody();
-			CHECK(body.GetUserData() == (uint64)object_physics_object.ptr());
-			JPH::BodyLockRead bad(physics_world.physics_system->GetBodyLockInterface(), JPH::BodyID());
-			CHECK(!bad.Succeeded());
+			CHECK(lock.GetBody().GetUserData() == (uint64)ob.ptr());
+			JPH::BodyLockRead none(world.physics_system->GetBodyLockInterface(), JPH::BodyID());
+			CHECK(!none.Succeeded());
 		}
-		// SubShapeID::PopID (GUIClient.cpp:6484-6486)
+		// sub-shape ids peel off bit fields from the low end
 		{
-			JPH::SubShapeID remainder;
-			CHECK(JPH::SubShapeID(0xFFFFFFFFu & ~1u).PopID(/*num bits=*/1, remainder) == 0 && remainder.IsEmpty());
-			CHECK(JPH::SubShapeID(0xFFFFFFFFu).PopID(1, remainder) == 1);
+			JPH::SubShapeID rest;
+			CHECK(JPH::SubShapeID(0xFFFFFFFFu & ~1u).PopID(1, rest) == 0 && rest.IsEmpty());
+			CHECK(JPH::SubShapeID(0xFFFFFFFFu).PopID(1, rest) == 1);
 		}
 
-		// ---------------------------------------------------------------------------------------- CarPhysics::~CarPhysics, :258-272
-		physics_world.physics_system->RemoveConstraint(vehicle_constraint);
-		physics_world.physics_system->RemoveStepListener(vehicle_constraint);
-		vehicle_constraint = nullptr;
-		m_tester = nullptr;
-		physics_world.removeObject(object_physics_object);
-		CHECK(object_physics_object->jolt_body_id.IsInvalid());
-		physics_world.think(1.f / 60.f);
+		// ---- tear-down
+		world.physics_system->RemoveConstraint(vehicle);
+		world.physics_system->RemoveStepListener(vehicle);
+		vehicle = nullptr;
+		tester = nullptr;
+		world.removeObject(ob);
+		CHECK(ob->jolt_body_id.IsInvalid());
+		world.think(dt);
 		std::printf("car_physics_sequence: ok\n");
 		return 0;
 	} catch (glare::Exception& e) {
