@@ -14,6 +14,10 @@
 
 SGP_DEV const ConstraintArrays& CUR(const DV& d) { return d.ca[d.sp->parity & 1]; }
 SGP_DEV const ConstraintArrays& PRV(const DV& d) { return d.ca[(d.sp->parity & 1) ^ 1]; }
+// a constraint's header: the two body ids (8 bytes), np_col, or all of it in one 16-byte load
+SGP_DEV uint2 con_ab(const ConstraintArrays& c, size_t k) { return *(const uint2*)(c.hdr + k); }
+SGP_DEV int& con_npc(const ConstraintArrays& c, size_t k) { return ((int*)(c.hdr + k))[2]; }
+SGP_DEV uint4 con_hdr(const ConstraintArrays& c, size_t k) { return c.hdr[k]; }
 
 SGP_DEV uint32_t f_motion(uint32_t f) { return f & BF_MOTION_MASK; }
 SGP_DEV uint32_t f_layer(uint32_t f) { return (f & BF_LAYER_MASK) >> BF_LAYER_SHIFT; }

@@ -135,8 +135,8 @@ template <int ROWS = -1> SGP_DEV void half_load_known(const DV& d, uint32_t slot
 }
 template <int ROWS = -1> SGP_DEV void half_load(const DV& d, uint32_t slot, int side, ConHalf& h)
 {
-	const uint2 ab = CUR(d).ab[slot];
-	half_load_known<ROWS>(d, slot, side, CUR(d).np_col[slot], side ? ab.y : ab.x, h);
+	const uint4 hd = con_hdr(CUR(d), slot);      // ids + np_col: one 16-byte load
+	half_load_known<ROWS>(d, slot, side, (int)hd.z, side ? hd.y : hd.x, h);
 }
 
 SGP_DEV void half_store(const DV& d, uint32_t slot, int side, const ConHalf& h)
@@ -223,9 +223,9 @@ template <int VS, int ROWS = -1> SGP_DEV void solve_velocity_pair_t(const DV& d,
 // either way): the same bits.  What it buys is registers: the launch fits four waves per SIMD, and a colour of 300k constraints is nine waves per SIMD.
 template <int VS> SGP_DEV void solve_velocity_pair_norows(const DV& d, uint32_t slot, int side, float4* vel)
 {
-	const uint2 ab = CUR(d).ab[slot];
-	const int np = CUR(d).np_col[slot] & 0xFF;
-	const uint32_t body = side ? ab.y : ab.x;
+	const uint4 hd = con_hdr(CUR(d), slot);      // ids + np_col: one 16-byte load
+	const int np = (int)hd.z & 0xFF;
+	const uint32_t body = side ? hd.y : hd.x;
 	const float4 nf = CUR(d).n_fric[slot];
 	float4 r4[4]; float2 et[4]; v3 lam[4];
 #pragma unroll
@@ -282,13 +282,6 @@ template <int VS> SGP_DEV void solve_velocity_pair_norows(const DV& d, uint32_t 
 // its own body's pose, computes its own contact point and its own share of the effective mass, swaps them with its neighbour, and corrects
 // its own body.  Same operands, same operations as solve_position_one (the effective mass is share of body 1 + share of body 2 there too),
 // hence the same bits -- at about half the instructions per lane, which is what a position launch is made of (4700 of them per manifold).
-SGP_DEV void solve_position_pair_at(const DV& d, uint32_t slot, int side, float4* rec, v3 ii);
-SGP_DEV void solve_position_pair(const DV& d, uint32_t slot, int side)
-{
-	const uint2 ab = CUR(d).ab[slot];
-	const uint32_t body = side ? ab.y : ab.x;
-	solve_position_pair_at(d, slot, side, d.pose + 2 * (size_t)body, V3(d.prop[2 * (size_t)body]));      // this lane's body's pose record + its local inverse inertia
-}
 // What a position iteration reads of the constraint itself (this lane's side): loaded once, iterated any number of times.
 struct PosHalf { float4 nf; int np; v3 loc[4]; };
 SGP_DEV void pos_half_load(const DV& d, uint32_t slot, int side, int np_col, PosHalf& ph)
@@ -341,10 +334,18 @@ SGP_DEV void pos_half_solve(const DV& d, const PosHalf& ph, int side, float4* re
 	}
 	if (moved && im > 0.0f) { rec[0] = F4(pos, im); rec[1] = make_float4(q.x, q.y, q.z, q.w); }
 }
+SGP_DEV void solve_position_pair(const DV& d, uint32_t slot, int side)
+{
+	const uint4 hd = con_hdr(CUR(d), slot);      // ids + np_col: one 16-byte load
+	const uint32_t body = side ? hd.y : hd.x;
+	PosHalf ph;
+	pos_half_load(d, slot, side, (int)hd.z, ph);
+	pos_half_solve(d, ph, side, d.pose + 2 * (size_t)body, V3(d.prop[2 * (size_t)body]));      // this lane's body's pose record + its local inverse inertia
+}
 SGP_DEV void solve_position_pair_at(const DV& d, uint32_t slot, int side, float4* rec, v3 ii)
 {
 	PosHalf ph;
-	pos_half_load(d, slot, side, CUR(d).np_col[slot], ph);
+	pos_half_load(d, slot, side, con_npc(CUR(d), slot), ph);
 	pos_half_solve(d, ph, side, rec, ii);
 }
 // (velocity and position iterations: two neighbouring lanes per constraint; workgroups of four waves = 128 constraints.  Measured on config 3:

@@ -290,7 +290,9 @@ template <int PCAP> SGP_DEV void stage_pair(const DV& d, uint2* spairs, uint8_t*
 #define BP_PAIR_CAP_SMALL 1024
 #define BP_LDS_CAP_LARGE 1536
 #define BP_PAIR_CAP_LARGE 2048
+#ifndef BP_SPLIT
 #define BP_SPLIT 4
+#endif
 
 // The class of a pair = its two shape types: the staged pairs leave a workgroup sorted by class (flush_pairs), so that the narrow phase -- one thread
 // per pair, one branch per pairing of shapes -- gets waves of one pairing instead of waves that walk through all six branches one after the other.

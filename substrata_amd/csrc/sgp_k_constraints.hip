@@ -18,11 +18,11 @@ __global__ void __launch_bounds__(TPB) k_colour_inherit(DV d)
 		if (mp == MAN_PREV_LOOKUP) {
 			int pnc = 0;
 			const uint32_t f = cache_find(d, ((uint64_t)ab.x << 32) | ab.y, &pnc);
-			mp = f == 0xFFFFFFFFu ? MAN_PREV_NONE : f; d.man_prev[m] = mp;
+			mp = f == 0xFFFFFFFFu ? MAN_PREV_NONE : (f | ((uint32_t)(pnc & 0xFF) << MAN_PREV_PNP_SHIFT)); d.man_prev[m] = mp;
 			if (f != 0xFFFFFFFFu) pc = (pnc >> 8) & 0xFF;
 		}
 		int col = -1;
-		if (pc >= 0 && pc < SGP_OVERFLOW_COLOUR && (mp & ~MAN_PREV_REUSED) != MAN_PREV_NONE) {
+		if (pc >= 0 && pc < SGP_OVERFLOW_COLOUR && (mp & MAN_PREV_SLOT_MASK) != MAN_PREV_NONE) {
 			const uint32_t fa = d.flags[ab.x], fb = d.flags[ab.y];
 			const bool ma = fa & BF_MOVABLE_CUR, mb = fb & BF_MOVABLE_CUR;
 			if (!((ma && !(fa & BF_MOVABLE_PREV)) || (mb && !(fb & BF_MOVABLE_PREV))) &&
@@ -289,16 +289,20 @@ __global__ void __launch_bounds__(TPB) k_setup(DV d)
 		const v3 nrm = V3(n4);
 		const uint32_t mprev = d.man_prev[m];
 		const bool reused = mprev & MAN_PREV_REUSED;                 // the manifold came from the body-pair contact cache
-		const uint32_t fslot = (mprev & ~MAN_PREV_REUSED) == MAN_PREV_NONE ? 0xFFFFFFFFu : (mprev & ~MAN_PREV_REUSED);
+		const uint32_t fslot = (mprev & MAN_PREV_SLOT_MASK) == MAN_PREV_NONE ? 0xFFFFFFFFu : (mprev & MAN_PREV_SLOT_MASK);
 		const uint32_t pslot = d.st.warm_start ? fslot : 0xFFFFFFFFu;
-		// the previous constraint of the pair: its cache record (ONE 128-byte line: point count, its first two points in body space, and for polytope
-		// pairs the relative pose it was computed at), requested together with the bodies' records
-		float4 pr0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pr1 = pr0, pr2 = pr0, pr3 = pr0, pr4 = pr0, pr5 = pr0, pr6 = pr0;
-		if (fslot != 0xFFFFFFFFu) {
-			const float4* rec = PRV(d).crec0 + (size_t)fslot * CREC0_F4;
-			pr0 = rec[0]; pr1 = rec[1]; pr2 = rec[2]; pr3 = rec[3];
-			if (reused) { pr4 = rec[4]; pr5 = rec[5]; pr6 = rec[6]; }
+		const int pnp_all = fslot != 0xFFFFFFFFu ? (int)((mprev >> MAN_PREV_PNP_SHIFT) & 7u) : 0;      // points of the previous constraint (came with the hash probe: no gather)
+		const int pnp = pslot != 0xFFFFFFFFu ? pnp_all : 0;                                           // ... whose impulses may be taken over
+		// the previous constraint's points in body space (requested together with the bodies' records) and, for a manifold taken from the body-pair contact
+		// cache, the record of the relative pose it was computed at
+		v3 pl1[4], pl2[4];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			pl1[j] = pl2[j] = V3(0.0f, 0.0f, 0.0f);
+			if (j < pnp_all) { pl1[j] = V3(PRV(d).loc1[j][fslot]); pl2[j] = V3(PRV(d).loc2[j][fslot]); }
 		}
+		float4 pr0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pr1 = pr0, pr2 = pr0;
+		if (reused) { const float4* rec = PRV(d).prec + (size_t)fslot * PREC_F4; pr0 = rec[0]; pr1 = rec[1]; pr2 = rec[2]; }
 		// per body: pose record, velocity record (velocities after gravity + the effective inverse mass: k_pre_solve), property record
 		const float4 pa4 = d.pose[2 * (size_t)ab.x], qa4 = d.pose[2 * (size_t)ab.x + 1], pb4 = d.pose[2 * (size_t)ab.y], qb4 = d.pose[2 * (size_t)ab.y + 1];
 		const float4 va4 = d.vel[2 * (size_t)ab.x], wa4 = d.vel[2 * (size_t)ab.x + 1], vb4 = d.vel[2 * (size_t)ab.y], wb4 = d.vel[2 * (size_t)ab.y + 1];
@@ -313,24 +317,9 @@ __global__ void __launch_bounds__(TPB) k_setup(DV d)
 		const v3 t1 = v3_normalized_perpendicular(nrm);
 		const v3 t2 = v3_cross(nrm, t1);
 		const v3 lvA = V3(va4), avA = V3(wa4), lvB = V3(vb4), avB = V3(wb4);
-		const int pnp_all = fslot != 0xFFFFFFFFu ? (__float_as_int(pr0.x) & 0xFF) : 0;      // points of the previous constraint
-		const int pnp = pslot != 0xFFFFFFFFu ? pnp_all : 0;                                   // ... whose impulses may be taken over
-		// its points (body space): the first two came with the record, the third and fourth (rare) are a second gather
-		v3 pl1[4], pl2[4];
-		pl1[0] = V3(pr0.y, pr0.z, pr0.w); pl2[0] = V3(pr1); pl1[1] = V3(pr2); pl2[1] = V3(pr3);
-		pl1[2] = pl1[3] = pl2[2] = pl2[3] = V3(0.0f, 0.0f, 0.0f);
-		if (pnp_all > 2) {
-			const float4* r1 = PRV(d).crec1 + (size_t)fslot * CREC1_F4;
-			pl1[2] = V3(r1[0]); pl2[2] = V3(r1[1]);
-			if (pnp_all > 3) { pl1[3] = V3(r1[2]); pl2[3] = V3(r1[3]); }
-		}
 		const v3 g = V3(d.gx, d.gy, d.gz);
-		CUR(d).ab[slot] = ab;
+		CUR(d).hdr[slot] = make_uint4(ab.x, ab.y, (uint32_t)(np | (col << 8) | ((fslot != 0xFFFFFFFFu ? 1 : 0) << 16)), 0u);      // one 16-byte store: ids + np_col
 		CUR(d).n_fric[slot] = F4(nrm, friction);
-		const int np_col = np | (col << 8) | ((fslot != 0xFFFFFFFFu ? 1 : 0) << 16);
-		CUR(d).np_col[slot] = np_col;
-		v3 loc1[4], loc2[4];
-		loc1[0] = loc1[1] = loc1[2] = loc1[3] = loc2[0] = loc2[1] = loc2[2] = loc2[3] = V3(0.0f, 0.0f, 0.0f);
 		// warm start (docs/CONTRACT.md): the cached impulses of the manifold summed -- linear P, angular about either centre of mass A1, A2 --, one velocity
 		// change per body, written as the body's record of this colour (k_warm_bodies adds a body's records in colour order)
 		v3 wP = V3(0.0f, 0.0f, 0.0f), wA1 = V3(0.0f, 0.0f, 0.0f), wA2 = V3(0.0f, 0.0f, 0.0f);
@@ -341,7 +330,6 @@ __global__ void __launch_bounds__(TPB) k_setup(DV d)
 			v3 local1 = m33_tmul(RA, v3_sub(p1, posA));
 			v3 local2 = m33_tmul(RB, v3_sub(p2, posB));
 			if (reused) { local1 = pl1[i]; local2 = pl2[i]; }      // the cached body-space points themselves: no drift from re-deriving them
-			loc1[i] = local1; loc2[i] = local2;
 			float lam_n = 0.0f, lam_t1 = 0.0f, lam_t2 = 0.0f;
 #pragma unroll
 			for (int j = 0; j < 4; ++j) {
@@ -391,28 +379,18 @@ __global__ void __launch_bounds__(TPB) k_setup(DV d)
 			wA1 = v3_add(wA1, v3_cross(r1, wj));
 			wA2 = v3_add(wA2, v3_cross(r2, wj));
 		}
-		// the cache record of this constraint (what the next step gathers of it): first sector for every constraint, second for polytope pairs -- a fresh
-		// manifold records where the bodies are relative to each other now; a reused one keeps the record of the step its points were computed in (slow
-		// drift then ends the reuse)
-		{
-			float4* rec = CUR(d).crec0 + (size_t)slot * CREC0_F4;
-			rec[0] = make_float4(__int_as_float(np_col), loc1[0].x, loc1[0].y, loc1[0].z);
-			rec[1] = F4(loc2[0], 0.0f); rec[2] = F4(loc1[1], 0.0f); rec[3] = F4(loc2[1], 0.0f);
-			if (npb & MAN_NP_POLYTOPE) {
-				if (reused) { rec[4] = pr4; rec[5] = pr5; rec[6] = pr6; }
-				else {
-					v3 dpos; quat drot;
-					pair_relative_pose(posA, Q4(qa4), posB, Q4(qb4), &dpos, &drot);
-					const v3 nl = m33_tmul(RB, nrm);
-					rec[4] = make_float4(drot.x, drot.y, drot.z, drot.w);
-					rec[5] = make_float4(dpos.x, dpos.y, dpos.z, nl.x);
-					rec[6] = make_float4(nl.y, nl.z, 0.0f, 0.0f);
-				}
-				rec[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);      // (the whole line: no partial sector goes to memory)
-			}
-			if (np > 2) {
-				float4* r1 = CUR(d).crec1 + (size_t)slot * CREC1_F4;
-				r1[0] = F4(loc1[2], 0.0f); r1[1] = F4(loc2[2], 0.0f); r1[2] = F4(loc1[3], 0.0f); r1[3] = F4(loc2[3], 0.0f);
+		// body-pair contact cache (polytope pairs): a fresh manifold records where the bodies are relative to each other now; a reused one keeps the record of
+		// the step its points were computed in (slow drift then ends the reuse)
+		if (npb & MAN_NP_POLYTOPE) {
+			float4* rec = CUR(d).prec + (size_t)slot * PREC_F4;
+			if (reused) { rec[0] = pr0; rec[1] = pr1; rec[2] = pr2; }
+			else {
+				v3 dpos; quat drot;
+				pair_relative_pose(posA, Q4(qa4), posB, Q4(qb4), &dpos, &drot);
+				const v3 nl = m33_tmul(RB, nrm);
+				rec[0] = make_float4(drot.x, drot.y, drot.z, drot.w);
+				rec[1] = make_float4(dpos.x, dpos.y, dpos.z, nl.x);
+				rec[2] = make_float4(nl.y, nl.z, 0.0f, 0.0f);
 			}
 		}
 		// (body, colour) -> warm-start record: a proper colouring gives every movable body at most one constraint per colour, so this table needs no
@@ -453,8 +431,9 @@ __global__ void __launch_bounds__(TPB) k_cache_build(DV d, StepCounters* host_ma
 	const uint32_t size = *d.ht_cur;
 	const uint32_t mask = size - 1;
 	for (uint32_t k = blockIdx.x * TPB + threadIdx.x; k < n_con; k += gridDim.x * TPB) {
-		const uint2 ab = CUR(d).ab[k];
-		const uint32_t nc = (uint32_t)CUR(d).np_col[k];
+		const uint4 hd = con_hdr(CUR(d), k);
+		const uint2 ab = make_uint2(hd.x, hd.y);
+		const uint32_t nc = hd.z;
 		const uint64_t key = ((uint64_t)ab.x << 32) | ab.y;
 		uint32_t h = ht_hash(key, mask);
 		for (uint32_t probe = 0; probe < size; ++probe) {
@@ -475,7 +454,7 @@ __global__ void __launch_bounds__(TPB) k_contact_events(DV d)
 	const uint32_t n = min(d.ctr->n_manifolds, d.cap_manifolds);
 	for (uint32_t m = blockIdx.x * TPB + threadIdx.x; m < n; m += gridDim.x * TPB) {
 		const uint2 ab = d.man_ab[m];
-		const bool persisted = (d.man_prev[m] & ~MAN_PREV_REUSED) != MAN_PREV_NONE;
+		const bool persisted = (d.man_prev[m] & MAN_PREV_SLOT_MASK) != MAN_PREV_NONE;
 		// one atomic per wave and list (the lanes here are the loop's active lanes; wave_alloc serves those that call it together)
 		uint32_t k;
 		if (persisted) k = wave_alloc(&d.evc->n_contact_persisted); else k = wave_alloc(&d.evc->n_contact_added);

@@ -165,8 +165,8 @@ __global__ void __launch_bounds__(TPB) k_dump_constraints(DV d, uint32_t which, 
 	if (k >= n_con || k >= cap) return;
 	const ConstraintArrays& ca = d.ca[which & 1];
 	ConstraintDumpRec r;
-	const uint2 ab = ca.ab[k];
-	const int nc = ca.np_col[k];
+	const uint2 ab = con_ab(ca, k);
+	const int nc = con_npc(ca, k);
 	const float4 nf = ca.n_fric[k];
 	r.a = ab.x; r.b = ab.y; r.colour = (nc >> 8) & 0xFF; r.np = nc & 0xFF;
 	r.n[0] = nf.x; r.n[1] = nf.y; r.n[2] = nf.z;

@@ -10,13 +10,12 @@ SGP_DEV bool reuse_cached_manifold(const DV& d, uint2 ab, uint32_t fa, uint32_t 
 {
 	int pnc = 0;
 	const uint32_t ps = cache_find(d, ((uint64_t)ab.x << 32) | ab.y, &pnc);
-	*prev = ps == 0xFFFFFFFFu ? MAN_PREV_NONE : ps;
-	if (ps == 0xFFFFFFFFu) return false;
+	if (ps == 0xFFFFFFFFu) { *prev = MAN_PREV_NONE; return false; }
+	*prev = ps | ((uint32_t)(pnc & 0xFF) << MAN_PREV_PNP_SHIFT);
 	*colour_candidate = man_colour_candidate(pnc);      // (k_colour_inherit needs no probe of its own for this pair)
 	if (!d.st.use_body_pair_contact_cache || ((fa | fb) & (BF_CACHE_INVALID | BF_SENSOR))) return false;
-	// the previous constraint's cache record: ONE 128-byte line holds the relative pose it was computed at and its first two points
-	const float4* rec = PRV(d).crec0 + (size_t)ps * CREC0_F4;
-	const float4 c0 = rec[0], c1 = rec[1], c2 = rec[2], c3 = rec[3], cdr = rec[4], cdp = rec[5], cnl = rec[6];
+	const float4* rec = PRV(d).prec + (size_t)ps * PREC_F4;      // the relative pose the previous manifold was computed at: one 64-byte record
+	const float4 cdr = rec[0], cdp = rec[1], cnl = rec[2];
 	const v3 posA = V3(d.pose[2 * (size_t)ab.x]), posB = V3(d.pose[2 * (size_t)ab.y]);
 	const quat qA = Q4(d.pose[2 * (size_t)ab.x + 1]), qB = Q4(d.pose[2 * (size_t)ab.y + 1]);
 	v3 dpos; quat drot;
@@ -27,14 +26,8 @@ SGP_DEV bool reuse_cached_manifold(const DV& d, uint2 ab, uint32_t fa, uint32_t 
 	const m33 RA = quat_to_m33(qA), RB = quat_to_m33(qB);
 	m->np = pnc & 0xFF;
 	m->n = m33_mul(RB, V3(cdp.w, cnl.x, cnl.y));
-	if (m->np > 0) { m->p1[0] = v3_add(posA, m33_mul(RA, V3(c0.y, c0.z, c0.w))); m->p2[0] = v3_add(posB, m33_mul(RB, V3(c1))); }
-	if (m->np > 1) { m->p1[1] = v3_add(posA, m33_mul(RA, V3(c2))); m->p2[1] = v3_add(posB, m33_mul(RB, V3(c3))); }
-	if (m->np > 2) {
-		const float4* r1 = PRV(d).crec1 + (size_t)ps * CREC1_F4;
-		m->p1[2] = v3_add(posA, m33_mul(RA, V3(r1[0]))); m->p2[2] = v3_add(posB, m33_mul(RB, V3(r1[1])));
-		if (m->np > 3) { m->p1[3] = v3_add(posA, m33_mul(RA, V3(r1[2]))); m->p2[3] = v3_add(posB, m33_mul(RB, V3(r1[3]))); }
-	}
-	*prev = ps | MAN_PREV_REUSED;
+	for (int i = 0; i < 4; ++i) if (i < m->np) { m->p1[i] = v3_add(posA, m33_mul(RA, V3(PRV(d).loc1[i][ps]))); m->p2[i] = v3_add(posB, m33_mul(RB, V3(PRV(d).loc2[i][ps]))); }
+	*prev |= MAN_PREV_REUSED;
 	return true;
 }
 

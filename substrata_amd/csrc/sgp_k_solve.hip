@@ -27,10 +27,11 @@ SGP_DEV float axis_jv(const BodyVel& A, const BodyVel& B, v3 r1, v3 r2, v3 axis)
 struct PairCtx { uint2 ab; float im1, im2; sym33 I1, I2; BodyVel A, B; v3 n, t1, t2; float friction; int np; };
 template <int VS> SGP_DEV void load_pair(const DV& d, uint32_t slot, PairCtx& c, const float4* vel)
 {
-	c.ab = CUR(d).ab[slot];
+	const uint4 hd = con_hdr(CUR(d), slot);
+	c.ab = make_uint2(hd.x, hd.y);
 	const float4 nf = CUR(d).n_fric[slot];
 	c.n = V3(nf); c.friction = nf.w;
-	c.np = CUR(d).np_col[slot] & 0xFF;
+	c.np = (int)hd.z & 0xFF;
 	const float4 va = vel[VS * (size_t)c.ab.x], wa = vel[VS * (size_t)c.ab.x + 1];
 	const float4 vb = vel[VS * (size_t)c.ab.y], wb = vel[VS * (size_t)c.ab.y + 1];
 	c.im1 = va.w; c.im2 = vb.w;
@@ -149,10 +150,11 @@ SGP_DEV void rows_apply(BodyVel& A, BodyVel& B, float im1, float im2, v3 axis, c
 
 SGP_DEV void solve_position_one(const DV& d, uint32_t slot)
 {
-	const uint2 ab = CUR(d).ab[slot];
+	const uint4 hd = con_hdr(CUR(d), slot);
+	const uint2 ab = make_uint2(hd.x, hd.y);
 	const float4 nf = CUR(d).n_fric[slot];
 	const v3 nrm = V3(nf);
-	const int np = CUR(d).np_col[slot] & 0xFF;
+	const int np = (int)hd.z & 0xFF;
 	// the pose records themselves (k_integrate_pose advanced them; the corrections are made in place) + the local inverse inertia
 	float4* ra = d.pose + 2 * (size_t)ab.x;
 	float4* rb = d.pose + 2 * (size_t)ab.y;
@@ -239,7 +241,7 @@ SGP_DEV uint32_t overflow_next(const DV& d, uint32_t first, uint32_t count, uint
 	// the overflow constraint with the lowest priority above `last` (selection by scanning: the overflow colour is rare and short)
 	uint64_t best = ~0ull; uint32_t bslot = first;
 	for (uint32_t k = 0; k < count; ++k) {
-		const uint2 okab = CUR(d).ab[first + k]; const uint64_t pr = sgp_mix64(((uint64_t)okab.x << 32) | okab.y);
+		const uint2 okab = con_ab(CUR(d), first + k); const uint64_t pr = sgp_mix64(((uint64_t)okab.x << 32) | okab.y);
 		if ((!have_last || pr > last) && pr <= best) { best = pr; bslot = first + k; }
 	}
 	last = best; have_last = true;
@@ -327,7 +329,7 @@ __global__ void __launch_bounds__(TPB) k_hc_hook(DV d, int first_colour)
 	const uint32_t lim = min(2u * (e - b) + HC_CLASSES * HC_WG_PAIRS, d.cap_hc_list);
 	for (uint32_t i = tid; i < lim; i += stride) d.hc_list[i] = HC_NONE;
 	for (uint32_t k = b + tid; k < e; k += stride) {
-		const uint2 ab = CUR(d).ab[k];
+		const uint2 ab = con_ab(CUR(d), k);
 		if (!hc_can_move(d, ab.x) || !hc_can_move(d, ab.y)) continue;
 		uint32_t ra = uf_find(d.hc_root, ab.x), rb = uf_find(d.hc_root, ab.y);
 		while (ra != rb) {
@@ -349,7 +351,7 @@ __global__ void __launch_bounds__(TPB) k_hc_count(DV d, int first_colour)
 {
 	const uint32_t b = d.cstarts[first_colour], e = d.cstarts[SGP_OVERFLOW_COLOUR];
 	for (uint32_t k = b + blockIdx.x * TPB + threadIdx.x; k < e; k += gridDim.x * TPB) {
-		const uint32_t r = hc_root_of(d, CUR(d).ab[k]);
+		const uint32_t r = hc_root_of(d, con_ab(CUR(d), k));
 		d.hc_rank[k] = r == HC_NONE ? 0u : atomicAdd(&d.hc_count[r], 1u);
 	}
 }
@@ -361,7 +363,7 @@ __global__ void __launch_bounds__(TPB) k_hc_alloc(DV d, int first_colour)
 	for (uint32_t k0 = b + blockIdx.x * TPB; k0 < e; k0 += gridDim.x * TPB) {          // (uniform per workgroup: the ballots below need whole waves)
 		const uint32_t k = k0 + threadIdx.x;
 		uint32_t r = HC_NONE, size = 0;
-		if (k < e && d.hc_rank[k] == 0u) { r = hc_root_of(d, CUR(d).ab[k]); if (r != HC_NONE) size = d.hc_count[r]; }
+		if (k < e && d.hc_rank[k] == 0u) { r = hc_root_of(d, con_ab(CUR(d), k)); if (r != HC_NONE) size = d.hc_count[r]; }
 		const bool lead = r != HC_NONE;
 		int cls = -1;
 		if (lead) {
@@ -392,7 +394,7 @@ __global__ void __launch_bounds__(TPB) k_hc_scatter(DV d, int first_colour)
 	const uint32_t b = d.cstarts[first_colour], e = d.cstarts[SGP_OVERFLOW_COLOUR];
 	if (blockIdx.x == 0 && threadIdx.x == 0) { d.ctr->hc_entries = hc_class_first(d, HC_CLASSES); d.ctr->hc_n = e - b; }
 	for (uint32_t k = b + blockIdx.x * TPB + threadIdx.x; k < e; k += gridDim.x * TPB) {
-		const uint32_t r = hc_root_of(d, CUR(d).ab[k]);
+		const uint32_t r = hc_root_of(d, con_ab(CUR(d), k));
 		const uint32_t place = r == HC_NONE ? HC_BIG : d.hc_base[r];
 		uint32_t at = HC_NONE;
 		if (place != HC_BIG) {
@@ -401,7 +403,7 @@ __global__ void __launch_bounds__(TPB) k_hc_scatter(DV d, int first_colour)
 		}
 		if (at < d.cap_hc_list) d.hc_list[at] = k;          // (the list has room for every constraint rounded up to its class: at is always inside)
 		else {
-			CUR(d).np_col[k] |= NPCOL_CATCH_ALL;
+			con_npc(CUR(d), k) |= NPCOL_CATCH_ALL;
 			const uint32_t bi = wave_alloc(&d.ctr->hc_n_big);
 			if (bi < HC_BIG_LIST) d.hc_big_list[bi] = k;          // (the catch-all walks this list instead of searching the colours for the flag)
 		}
@@ -415,7 +417,7 @@ __global__ void __launch_bounds__(TPB) k_hc_init(DV d, int first_colour)
 {
 	const uint32_t b = d.cstarts[first_colour], e = d.cstarts[SGP_OVERFLOW_COLOUR];
 	for (uint32_t k = b + blockIdx.x * TPB + threadIdx.x; k < e; k += gridDim.x * TPB) {
-		const uint2 ab = CUR(d).ab[k];
+		const uint2 ab = con_ab(CUR(d), k);
 		if (hc_can_move(d, ab.x)) { d.hc_root[ab.x] = ab.x; d.hc_count[ab.x] = 0u; }
 		if (hc_can_move(d, ab.y)) { d.hc_root[ab.y] = ab.y; d.hc_count[ab.y] = 0u; }
 	}
@@ -425,7 +427,7 @@ __global__ void __launch_bounds__(TPB) k_hc_probe(DV d, int first_colour)
 	const uint32_t b = d.cstarts[first_colour], e = d.cstarts[SGP_OVERFLOW_COLOUR];
 	for (uint32_t k = b + blockIdx.x * TPB + threadIdx.x; k < e; k += gridDim.x * TPB) {
 		if (d.hc_rank[k] != 0u) continue;
-		const uint32_t r = hc_root_of(d, CUR(d).ab[k]);
+		const uint32_t r = hc_root_of(d, con_ab(CUR(d), k));
 		if (r == HC_NONE) continue;
 		const uint32_t size = d.hc_count[r];
 		if (size > (uint32_t)HC_WG_PAIRS) atomicAdd(&d.ctr->hc_probe_big, size);
@@ -443,8 +445,9 @@ __global__ void __launch_bounds__(HC_WG_PAIRS) k_hc_sort(DV d)
 		if (threadIdx.x < SGP_MAX_COLOURS) s_cnt[threadIdx.x] = 0u;
 		__syncthreads();
 		const uint32_t slot = d.hc_list[e0 + threadIdx.x];
-		const int npc = slot != HC_NONE ? CUR(d).np_col[slot] : 0;
-		const uint2 ab = slot != HC_NONE ? CUR(d).ab[slot] : make_uint2(0u, 0u);
+		const uint4 hd = slot != HC_NONE ? con_hdr(CUR(d), slot) : make_uint4(0u, 0u, 0u, 0u);
+		const int npc = (int)hd.z;
+		const uint2 ab = make_uint2(hd.x, hd.y);
 		const int col = slot != HC_NONE ? ((npc >> 8) & 0xFF) : SGP_MAX_COLOURS - 1;      // (unused lane pairs last)
 		const uint32_t rank = atomicAdd(&s_cnt[col], 1u);
 		__syncthreads();
@@ -534,7 +537,7 @@ template <int MODE, int ROWS = -1> __global__ void __launch_bounds__(HC_TPB) k_s
 		// movable body: any order).  Searching every colour's whole range for the flag instead cost 140 us per pass for 288 constraints -- a step of
 		// 3.7 instead of 2.0 ms whenever one component of the pile outgrew a workgroup.
 		uint32_t mine[4]; int mcol[4]; int cnt = 0;
-		for (uint32_t e = pair; e < n_big; e += HC_WG_PAIRS) { const uint32_t k = d.hc_big_list[e]; mine[cnt] = k; mcol[cnt] = (int)((CUR(d).np_col[k] >> 8) & 0xFF); ++cnt; }
+		for (uint32_t e = pair; e < n_big; e += HC_WG_PAIRS) { const uint32_t k = d.hc_big_list[e]; mine[cnt] = k; mcol[cnt] = (int)((con_npc(CUR(d), k) >> 8) & 0xFF); ++cnt; }
 		for (int c = first_colour; c < n_colours; ++c) {
 #pragma unroll
 			for (int j = 0; j < 4; ++j) if (j < cnt && mcol[j] == c) { if (MODE == 1) solve_velocity_pair_t<2, ROWS>(d, mine[j], side, d.vel); else solve_position_pair(d, mine[j], side); }
@@ -544,7 +547,7 @@ template <int MODE, int ROWS = -1> __global__ void __launch_bounds__(HC_TPB) k_s
 	for (int c = first_colour; c < n_colours && n_big != 0u; ++c) {
 		const uint32_t cb = d.cstarts[c], ce = d.cstarts[c + 1];
 		for (uint32_t k = cb + pair; k < ce; k += HC_WG_PAIRS) {
-			if (!(CUR(d).np_col[k] & NPCOL_CATCH_ALL)) continue;
+			if (!(con_npc(CUR(d), k) & NPCOL_CATCH_ALL)) continue;
 			if (MODE == 1) solve_velocity_pair_t<2, ROWS>(d, k, side, d.vel); else solve_position_pair(d, k, side);
 		}
 		__syncthreads();
@@ -636,9 +639,10 @@ struct ConReg { uint2 ab; float4 nf; int np_col; AxisRows rn[4], rt1[4], rt2[4];
 
 SGP_DEV void con_load(const DV& d, uint32_t slot, ConReg& r)
 {
-	r.ab = CUR(d).ab[slot];
+	const uint4 hd = con_hdr(CUR(d), slot);
+	r.ab = make_uint2(hd.x, hd.y);
 	r.nf = CUR(d).n_fric[slot];
-	r.np_col = CUR(d).np_col[slot];
+	r.np_col = (int)hd.z;
 	const int np = r.np_col & 0xFF;
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
@@ -755,7 +759,7 @@ __global__ void __launch_bounds__(512) k_solve_small_single(DV d, int warm_start
 					for (uint32_t it = 0; it < count; ++it) {
 						uint64_t best = ~0ull; uint32_t bslot = first;
 						for (uint32_t k = 0; k < count; ++k) {
-							const uint2 okab = CUR(d).ab[first + k]; const uint64_t pr = sgp_mix64(((uint64_t)okab.x << 32) | okab.y);
+							const uint2 okab = con_ab(CUR(d), first + k); const uint64_t pr = sgp_mix64(((uint64_t)okab.x << 32) | okab.y);
 							if ((!have_last || pr > last) && pr <= best) { best = pr; bslot = first + k; }
 						}
 						last = best; have_last = true;

@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(TPB) k_finalize(DV d)
 SGP_DEV uint32_t island_edges(const DV& d) { return d.ctr->n_constraints + 4u * d.n_vehicles; }
 SGP_DEV bool island_edge(const DV& d, uint32_t k, uint32_t n_con, uint2& ab)
 {
-	if (k < n_con) { ab = CUR(d).ab[k]; return true; }
+	if (k < n_con) { ab = con_ab(CUR(d), k); return true; }
 	const uint32_t e = k - n_con, v = e >> 2, i = e & 3u;
 	const float4 h0 = d.veh_head[(size_t)v * VEH_HEAD_F4];
 	if (!(__float_as_uint(h0.y) & 1u) || i >= __float_as_uint(h0.z)) return false;

@@ -48,8 +48,12 @@
 #define SGP_ISLAND_MARK_ROUNDS 3   // marking rounds before the island union-find (k_island_mark)
 #define SGP_MAX_COLOURS      64
 #define SGP_OVERFLOW_COLOUR  63
-#define MAN_PREV_NONE   0x7FFFFFFFu
-#define MAN_PREV_REUSED 0x80000000u
+// DV::man_prev of a manifold: slot of the pair's constraint in the previous step's buffer (28 bits; MAN_PREV_NONE: it had none) | that constraint's point count
+// << 28 (what the set-up needs of its header: no gather for it) | MAN_PREV_REUSED: the manifold itself was taken from the body-pair contact cache
+#define MAN_PREV_SLOT_MASK 0x0FFFFFFFu
+#define MAN_PREV_NONE      0x0FFFFFFFu
+#define MAN_PREV_PNP_SHIFT 28
+#define MAN_PREV_REUSED    0x80000000u
 #define SGP_COLOUR_WIDE_MIN  2048u   // a colouring round with fewer uncoloured manifolds than this runs inside k_colour_finish (one workgroup)
 
 // kernel classes for the per-kernel profile
@@ -196,27 +200,23 @@ struct StepParams {
 };
 
 // Constraint (contact manifold) SoA, double buffered (current step / previous step = contact cache).
-// What the NEXT step gathers of a constraint -- the body-space contact points it matches its own against, and for polytope pairs the relative pose the
-// body-pair contact cache compares -- is kept a second time as ONE record per slot (crec0, a 128-byte line; crec1 for the rare third and fourth point):
-// a gather moves a whole 128-byte line whatever it asks for (profiles/r06_pmc_calibration.md: a scattered 16-byte read costs what a full line costs),
-// and the SoA arrays cost one line per array and point (round 5: 4.6 lines per manifold in k_setup, 6 and more per polytope pair in k_narrowphase).
-#define CREC0_F4 8      // float4 per slot of crec0:
-                        //   [0] = (np_col bits, loc1[0].xyz)  [1] = (loc2[0].xyz, -)  [2] = (loc1[1].xyz, -)  [3] = (loc2[1].xyz, -)       <- first 64-byte sector: every constraint
-                        //   [4] = relative rotation conj(q1) q2   [5] = (relative position in body 1's frame xyz, normal in body 2's frame x)  [6] = (normal-in-2 y, z, -, -)  [7] = -
-                        //         <- second sector: polytope pairs only (the pose of body 2 relative to body 1 and the normal WHEN THE MANIFOLD WAS COMPUTED)
-#define CREC1_F4 4      // float4 per slot of crec1: loc1[2], loc2[2], loc1[3], loc2[3] (manifolds of three and four points)
+// Round 6 measured what these kernels are bound by (profiles/r06_pmc_calibration.md, profiles/r06d_sq_counters.md): a gather moves a whole 128-byte line
+// whatever it asks for, and a kernel with a thread per manifold is paced by the NUMBER of per-lane 16-byte accesses its waves issue (every scattered
+// access is a tag look-up of its own), not by the lines behind them.  So: nothing is stored twice, the point count of the previous constraint travels in
+// DV::man_prev (no header gather), body ids and np_col are one 16-byte header (one load in the solver, one store in the set-up), and what only the
+// body-pair contact cache reads is one 64-byte record per slot (three accesses, one line).
+#define PREC_F4 4       // float4 per slot of ConstraintArrays::prec: [0] relative rotation conj(q1) q2, [1] (relative position in body 1's frame xyz, normal in body 2's frame x),
+                        // [2] (normal-in-2 y, z, -, -), [3] -: the pose of body 2 relative to body 1 and the normal WHEN THE MANIFOLD WAS COMPUTED (polytope pairs only)
 struct ConstraintArrays {
-	uint2*    ab;          // body ids, a < b (the pair key is a << 32 | b)
+	uint4*    hdr;         // body ids a < b (the pair key is a << 32 | b), np_col = np | colour << 8 | persisted << 16 (| NPCOL_CATCH_ALL), -
 	float4*   n_fric;      // normal xyz, combined friction w
-	int32_t*  np_col;      // np | colour << 8 | persisted << 16
 	float4*   r1b[4];      // r1 xyz, bias w
 	float4*   r2e[4];      // r2 xyz, eff_n w
 	float4*   lam[4];      // lam_n, lam_t1, lam_t2, -
 	float2*   efft[4];     // eff_t1, eff_t2
-	float4*   loc1[4];     // contact point in body-1 frame (what the position iterations stream)
+	float4*   loc1[4];     // contact point in body-1 frame
 	float4*   loc2[4];     // contact point in body-2 frame
-	float4*   crec0;       // the cache record (above), CREC0_F4 per slot
-	float4*   crec1;       // CREC1_F4 per slot
+	float4*   prec;        // the body-pair contact cache's record (above), PREC_F4 per slot
 };
 
 struct DV {

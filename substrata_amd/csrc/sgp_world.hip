@@ -89,8 +89,8 @@ SGP_API int sgp_init(void)
 
 static int alloc_constraints(sgp_world* w, ConstraintArrays& c, uint32_t cap)
 {
-	DEV_ALLOC(c.ab, cap); DEV_ALLOC(c.n_fric, cap); DEV_ALLOC(c.np_col, cap);
-	DEV_ALLOC(c.crec0, (size_t)cap * CREC0_F4); DEV_ALLOC(c.crec1, (size_t)cap * CREC1_F4);      // the cache records: a 128-byte line per slot (+ 64 bytes for a third and fourth point)
+	DEV_ALLOC(c.hdr, cap); DEV_ALLOC(c.n_fric, cap);
+	DEV_ALLOC(c.prec, (size_t)cap * PREC_F4);      // the body-pair contact cache's records: 64 bytes per slot
 	for (int k = 0; k < 4; ++k) {
 		DEV_ALLOC(c.r1b[k], cap); DEV_ALLOC(c.r2e[k], cap); DEV_ALLOC(c.lam[k], cap); DEV_ALLOC(c.efft[k], cap);
 		DEV_ALLOC(c.loc1[k], cap); DEV_ALLOC(c.loc2[k], cap);
@@ -113,7 +113,8 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	w->device = desc->device;
 	if (w->desc.large_body_radius <= 0.0f) w->desc.large_body_radius = 4.0f;
 	if (w->desc.max_body_pairs == 0) w->desc.max_body_pairs = 16u * desc->max_bodies + 1024u;
-	if (w->desc.max_manifolds == 0) w->desc.max_manifolds = 8u * desc->max_bodies + 1024u;
+	if (w->desc.max_manifolds == 0) w->desc.max_manifolds = std::min(8u * desc->max_bodies + 1024u, MAN_PREV_NONE - 1u);
+	if (w->desc.max_manifolds >= MAN_PREV_NONE) { delete w; return fail(SGP_ERR_CAPACITY, "sgp_world_create: max_manifolds must be below 2^28 (a manifold's reference to its previous constraint keeps 28 bits for the slot)"); }
 	memset(&w->dv, 0, sizeof(w->dv));
 	memset(&w->stats, 0, sizeof(w->stats));
 	hipError_t e = hipSetDevice(w->device);
