@@ -633,14 +633,14 @@ typedef struct sgp_tiles_stats {
 	uint32_t received;       /* records that arrived                                                                     */
 	uint32_t ghosts;         /* ... of which ghosts                                                                      */
 	uint32_t emigrated, immigrated;
-	uint32_t fast_imports, slow_imports;     /* cumulative: exchanges that found the ghost set unchanged (the host saw 16 bytes per record) / in which the host created or removed bodies (the set changed, bodies immigrated); the ghosts' POSES go from the received records to the bodies on the device either way */
+	uint32_t fast_imports, slow_imports;     /* cumulative: exchanges that found the ghost set unchanged (the host saw 16 bytes per record) / whose 128-byte records had to come to the host (round 6: only sets with hull or mesh records; a changed set of primitives costs the host 32 bytes per record, and the newcomers are created on the device from the records: device_creates); the ghosts' POSES go from the received records to the bodies on the device either way */
 	uint32_t route_retries;  /* exchanges in which some rank had to grow a send / emigrant / receive buffer: every rank routes again and the counts are gathered once more */
 	uint32_t comm_ranks;     /* ranks ncclCommCount reports for this tile's communicator (0: no communicator, e.g. tiles of one process) */
 	uint32_t exchanges;      /* sgp_tiles_exchange calls so far                                                           */
 	float    comm_init_ms;   /* wall time of ncclCommInitRank                                                             */
 	float    last_exchange_ms, total_exchange_ms;    /* host wall time of sgp_tiles_exchange: the last call, all calls    */
 	uint32_t rebalances;     /* sgp_tiles_rebalance calls that moved this tile's region                                  */
-	uint32_t reserved0;
+	uint32_t device_creates; /* cumulative: ghosts and immigrants created on the device straight from the received records (no record to the host, no create command back) */
 } sgp_tiles_stats;
 #define SGP_MIGRATION_OUT 0
 #define SGP_MIGRATION_IN  1

@@ -112,7 +112,7 @@ GHOST_FLAG_LAYER_MASK, GHOST_FLAG_SENSOR, GHOST_FLAG_ALLOW_SLEEP, GHOST_FLAG_ZER
 class TilesStats(C.Structure):
     _fields_ = [("exported", u32), ("sent", u32), ("received", u32), ("ghosts", u32), ("emigrated", u32), ("immigrated", u32),
                 ("fast_imports", u32), ("slow_imports", u32), ("route_retries", u32), ("comm_ranks", u32), ("exchanges", u32),
-                ("comm_init_ms", f32), ("last_exchange_ms", f32), ("total_exchange_ms", f32), ("rebalances", u32), ("reserved0", u32)]
+                ("comm_init_ms", f32), ("last_exchange_ms", f32), ("total_exchange_ms", f32), ("rebalances", u32), ("device_creates", u32)]
 
 
 class BodyCounts(C.Structure):

@@ -261,14 +261,84 @@ __global__ void __launch_bounds__(TPB) k_ghost_refresh_records(DV d, const sgp_g
 	d.flags[i] = f;
 }
 
-// What the host needs of a received record to decide whether the ghost set changed: its global id and whether it asks for a change of ownership
-// (16 B instead of the 128 B record).
-__global__ void __launch_bounds__(TPB) k_pack_ghost_keys(const sgp_ghost_record* recs, uint32_t n, uint4* out)
+// What the host needs of a received record: 16 bytes to decide whether the ghost set changed (global id, ownership flag), and -- round 6 -- everything its
+// bookkeeping needs to give a NEWCOMER a body slot without seeing the 128-byte record: the `info` word of the key (is the record valid, does it name a
+// primitive shape, its layer / sensor / sleeping / drag bits, does a record that changes owner lie in this tile's region) and 16 more bytes (user data, bounding
+// radius, volume) that only come to the host when the set changed.  The body itself is then created ON THE DEVICE from the record (k_create_from_records).
+__global__ void __launch_bounds__(TPB) k_pack_ghost_keys(const sgp_ghost_record* recs, uint32_t n, uint4* out, uint4* aux, float3 lo, float3 hi)
 {
 	const uint32_t k = blockIdx.x * TPB + threadIdx.x;
 	if (k >= n) return;
-	const uint64_t g = recs[k].global_id;
-	out[k] = make_uint4((uint32_t)g, (uint32_t)(g >> 32), recs[k].motion_type, 0u);
+	const sgp_ghost_record& r = recs[k];
+	const uint64_t g = r.global_id;
+	const int type = r.shape_type;
+	bool valid = isfinite(r.pos[0]) && isfinite(r.pos[1]) && isfinite(r.pos[2]) && fabsf(r.pos[0]) <= 1.0e9f && fabsf(r.pos[1]) <= 1.0e9f && fabsf(r.pos[2]) <= 1.0e9f;
+	valid = valid && type >= 0 && type <= SGP_SHAPE_MESH;
+	const int nparam = type == SGP_SHAPE_BOX ? 3 : (type == SGP_SHAPE_SPHERE ? 1 : ((type == SGP_SHAPE_HULL || type == SGP_SHAPE_MESH) ? 0 : 2));
+	for (int i = 0; i < 3; ++i) if (i < nparam) { const float lim = (type == SGP_SHAPE_CAPSULE && i == 1) ? 0.0f : 0.5e-7f; if (!isfinite(r.shape[i]) || r.shape[i] < lim) valid = false; }
+	uint32_t info = (valid ? GKEY_VALID : 0u) | (((uint32_t)type & 7u) << GKEY_SHAPE_SHIFT) | ((r.flags & 0x3Fu) << GKEY_FLAGS_SHIFT);
+	if (r.pos[0] >= lo.x && r.pos[0] < hi.x && r.pos[1] >= lo.y && r.pos[1] < hi.y && r.pos[2] >= lo.z && r.pos[2] < hi.z) info |= GKEY_IN_REGION;
+	out[k] = make_uint4((uint32_t)g, (uint32_t)(g >> 32), r.motion_type, info);
+	// bounding radius and volume as the host computes them for a primitive (sgp_world_bodies.hip: bounding_radius, host_shape_volume -- the same expressions)
+	float rad = 0.0f, vol = 0.0f;
+	const float pi = 3.14159265358979323846f;
+	if (type == SGP_SHAPE_SPHERE) { rad = r.shape[0]; vol = (4.0f / 3.0f) * pi * r.shape[0] * r.shape[0] * r.shape[0]; }
+	else if (type == SGP_SHAPE_BOX) { rad = sqrtf(r.shape[0] * r.shape[0] + r.shape[1] * r.shape[1] + r.shape[2] * r.shape[2]); vol = 8.0f * r.shape[0] * r.shape[1] * r.shape[2]; }
+	else if (type == SGP_SHAPE_CAPSULE) { rad = r.shape[0] + r.shape[1]; vol = pi * r.shape[0] * r.shape[0] * (2.0f * r.shape[1]) + (4.0f / 3.0f) * pi * r.shape[0] * r.shape[0] * r.shape[0]; }
+	aux[k] = make_uint4((uint32_t)r.userdata, (uint32_t)(r.userdata >> 32), __float_as_uint(rad), __float_as_uint(vol));
+}
+
+// Bodies created straight from received records (round 6): the host chose the slots (in the order the CPU statement chooses them: parity) and mirrored the flags;
+// entry = (record index, body slot, flags, 0).  A ghost is a kinematic copy (what make_ghost + CMD_CREATE + CMD_ACTIVATE did through a 160-byte command), a body
+// that changes owner arrives as the dynamic body it was, with the mass properties add_one computes for a primitive (the same expressions: mass_properties).
+struct CreateDefaults { float gravity_factor, lin_damp, ang_damp, pad; };
+__global__ void __launch_bounds__(TPB) k_create_from_records(DV d, const sgp_ghost_record* recs, const uint4* list, uint32_t n, CreateDefaults def)
+{
+	const uint32_t e = blockIdx.x * TPB + threadIdx.x;
+	if (e >= n) return;
+	const uint4 en = list[e];
+	const sgp_ghost_record& r = recs[en.x];
+	const uint32_t i = en.y;
+	uint32_t f = en.z | BF_CACHE_INVALID;
+	const bool ghost = f & BF_GHOST;
+	const float mass = fmaxf(0.001f, r.mass);
+	float inv_mass = 0.0f, ii0 = 0.0f, ii1 = 0.0f, ii2 = 0.0f;
+	if (f_motion(f) == SGP_MOTION_DYNAMIC) {
+		const float* p = r.shape;
+		float ix, iy, iz;
+		if (r.shape_type == SGP_SHAPE_SPHERE) { const float q = 0.4f * mass * p[0] * p[0]; ix = iy = iz = q; }
+		else if (r.shape_type == SGP_SHAPE_BOX) {
+			const float sx = 2.0f * p[0], sy = 2.0f * p[1], sz = 2.0f * p[2];
+			const float k = mass / 12.0f;
+			ix = k * (sy * sy + sz * sz); iy = k * (sx * sx + sz * sz); iz = k * (sx * sx + sy * sy);
+		} else {
+			const float rr = p[0], H = 2.0f * p[1];
+			const float vc = 3.14159265358979323846f * rr * rr * H;
+			const float vs = (4.0f / 3.0f) * 3.14159265358979323846f * rr * rr * rr;
+			const float mc = mass * vc / (vc + vs), ms = mass * vs / (vc + vs);
+			iz = 0.5f * mc * rr * rr + 0.4f * ms * rr * rr;
+			ix = mc * (3.0f * rr * rr + H * H) / 12.0f + ms * (0.4f * rr * rr + 0.25f * H * H + 0.375f * H * rr);
+			iy = ix;
+		}
+		inv_mass = 1.0f / mass; ii0 = 1.0f / ix; ii1 = 1.0f / iy; ii2 = 1.0f / iz;
+	}
+	const float friction = r.friction < 0.0f ? 0.0f : (r.friction > 1.0f ? 1.0f : r.friction), restitution = r.restitution < 0.0f ? 0.0f : (r.restitution > 1.0f ? 1.0f : r.restitution);      // (clamp01 of add_one)
+	d.pose[2 * (size_t)i] = make_float4(r.pos[0], r.pos[1], r.pos[2], inv_mass);
+	d.pose[2 * (size_t)i + 1] = make_float4(r.rot[0], r.rot[1], r.rot[2], r.rot[3]);
+	d.vel[2 * (size_t)i] = make_float4(r.lin_vel[0], r.lin_vel[1], r.lin_vel[2], 0.0f);
+	d.vel[2 * (size_t)i + 1] = make_float4(r.ang_vel[0], r.ang_vel[1], r.ang_vel[2], 0.0f);
+	d.dyn[i] = ghost ? make_float4(def.lin_damp, def.ang_damp, def.gravity_factor, inv_mass) : make_float4(r.linear_damping, r.angular_damping, r.gravity_factor, inv_mass);
+	d.force[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	d.torque[i] = make_float4(0.0f, 0.0f, 0.0f, mass);
+	d.prop[2 * (size_t)i] = make_float4(ii0, ii1, ii2, restitution);
+	d.prop[2 * (size_t)i + 1] = make_float4(r.shape[0], r.shape[1], r.shape[2], friction);
+	d.submerged[i] = 0.0f;
+	d.userdata[i] = r.userdata;
+	d.sleep_label[i] = i;
+	refresh_aabb(d, i, f);
+	reset_sleep(d, i, f_shape(f), d.prop[2 * (size_t)i + 1], V3(d.pose[2 * (size_t)i]), Q4(d.pose[2 * (size_t)i + 1]));
+	f = activate_body(d, i, f);      // (both kinds arrive awake: d.activate = 1 in make_ghost and in the take-over)
+	d.flags[i] = f;
 }
 void launch_route_export(const DV& d, uint32_t nb, const TileRoute& t, uint32_t* block_counts, uint32_t* block_offsets, RouteHeader* header,
                          sgp_ghost_record* out, uint32_t cap, uint32_t* emigrant_ids, uint32_t emigrant_cap, uint32_t* gather_row, uint32_t cap_recv, uint32_t host_status, hipStream_t s)
@@ -279,9 +349,14 @@ void launch_route_export(const DV& d, uint32_t nb, const TileRoute& t, uint32_t*
 	hipLaunchKernelGGL(k_route_write, dim3(blocks), dim3(TPB), 0, s, d, t, (const uint32_t*)block_offsets, (const RouteHeader*)header, out, cap, emigrant_ids, emigrant_cap);
 }
 void launch_tiles_hist(const DV& d, uint32_t nb, const TilePlanes& tp, int level, uint32_t* out, hipStream_t s) { hipLaunchKernelGGL(k_tiles_hist, dim3(blocks_for(nb)), dim3(TPB), 0, s, d, tp, level, out); }
-void launch_pack_ghost_keys(const sgp_ghost_record* recs, uint32_t n, void* out, hipStream_t s)
+void launch_pack_ghost_keys(const sgp_ghost_record* recs, uint32_t n, void* out, void* aux, const float* lo, const float* hi, hipStream_t s)
 {
-	if (n) hipLaunchKernelGGL(k_pack_ghost_keys, dim3(blocks_for(n)), dim3(TPB), 0, s, recs, n, (uint4*)out);
+	if (n) hipLaunchKernelGGL(k_pack_ghost_keys, dim3(blocks_for(n)), dim3(TPB), 0, s, recs, n, (uint4*)out, (uint4*)aux, make_float3(lo[0], lo[1], lo[2]), make_float3(hi[0], hi[1], hi[2]));
+}
+void launch_create_from_records(const DV& d, const sgp_ghost_record* recs, const void* list, uint32_t n, float gravity_factor, float lin_damp, float ang_damp, hipStream_t s)
+{
+	CreateDefaults def = { gravity_factor, lin_damp, ang_damp, 0.0f };
+	if (n) hipLaunchKernelGGL(k_create_from_records, dim3(blocks_for(n)), dim3(TPB), 0, s, d, recs, (const uint4*)list, n, def);
 }
 void launch_ghost_refresh_records(const DV& d, const sgp_ghost_record* recs, const uint32_t* ids, uint32_t n, hipStream_t s)
 {

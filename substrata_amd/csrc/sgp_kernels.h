@@ -441,5 +441,11 @@ void launch_tiles_hist(const DV& d, uint32_t nb, const TilePlanes& tp, int level
 void launch_route_export(const DV& d, uint32_t nb, const TileRoute& t, uint32_t* block_counts, uint32_t* block_offsets, RouteHeader* header,
                          sgp_ghost_record* out, uint32_t cap, uint32_t* emigrant_ids, uint32_t emigrant_cap, uint32_t* gather_row, uint32_t cap_recv, uint32_t host_status, hipStream_t s);
 // ghost pose refresh straight from received records: record k refreshes body ids[k] (the unchanged-ghost-set fast path, no host copy of the poses)
-void launch_pack_ghost_keys(const sgp_ghost_record* recs, uint32_t n, void* out_uint4, hipStream_t s);
+void launch_pack_ghost_keys(const sgp_ghost_record* recs, uint32_t n, void* out_uint4, void* aux_uint4, const float* region_lo, const float* region_hi, hipStream_t s);
+// bodies created on the device from received records: list = uint4 (record index, body slot, flags, -) per newcomer (the host chose the slots)
+void launch_create_from_records(const DV& d, const sgp_ghost_record* recs, const void* list_uint4, uint32_t n, float gravity_factor, float lin_damp, float ang_damp, hipStream_t s);
+#define GKEY_VALID      (1u << 0)
+#define GKEY_SHAPE_SHIFT 1
+#define GKEY_FLAGS_SHIFT 4
+#define GKEY_IN_REGION  (1u << 10)
 void launch_ghost_refresh_records(const DV& d, const sgp_ghost_record* recs, const uint32_t* ids, uint32_t n, hipStream_t s);

@@ -142,6 +142,25 @@ int add_one(sgp_world* w, const sgp_body_desc* d, uint32_t* id_out, bool ghost)
 	return SGP_OK;
 }
 
+// The host's share of add_one for a body the DEVICE creates from a received record (k_create_from_records; primitive shapes only): the slot, the mirror of the
+// flags, radius and volume -- in the order add_one does it, so that slots are handed out exactly as before.  *flags_io: in = the flags add_one would compose from
+// the description, out = with BF_LARGE as note_radius decided (what the device must store).
+int book_record_body(sgp_world* w, uint32_t* flags_io, uint64_t userdata, float radius, float volume, bool ghost, uint32_t* id_out)
+{
+	uint32_t id;
+	if (!w->free_list.empty()) { id = w->free_list.back(); w->free_list.pop_back(); }
+	else { if (w->high >= w->dv.cap_bodies) return fail(SGP_ERR_CAPACITY, "sgp_body_add: max_bodies exceeded"); id = w->high++; }
+	HostBody& hb = w->hb[id];
+	hb.flags = *flags_io; hb.userdata = userdata; hb.ghost = ghost; hb.comp_root = SGP_INVALID_ID; hb.comp_child = 0; hb.shape_ref = 0u;
+	if (hb.lg_tomb) w->large_dirty = true;
+	note_radius(w, id, radius);
+	hb.volume = volume;
+	*flags_io = hb.flags;
+	w->n_alive++;
+	*id_out = id;
+	return SGP_OK;
+}
+
 SGP_API int sgp_body_add(sgp_world* w, const sgp_body_desc* d, uint32_t* id_out)
 {
 	if (!w || !d) return fail(SGP_ERR_INVALID, "sgp_body_add: NULL");

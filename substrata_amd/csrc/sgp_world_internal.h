@@ -89,6 +89,7 @@ struct sgp_world {
 	float max_small_radius = 0.0f;
 	uint32_t last_export = 0;                              // records the previous sgp_world_export_boundary produced
 	std::unordered_map<uint64_t, uint64_t> ghost_map;      // global id of a ghost -> generation << 32 | local body id (stable across steps)
+	std::vector<uint4> rec_creates;      // bodies the device is to create from received records: (record index, body slot, flags, -), launched by the import that queued them
 	uint32_t ghost_gen = 0; bool ghost_map_stale = false; uint64_t ghost_seq_version = 1;      // version: bumped whenever ghost_seq changes (a device copy of the ids knows whether it is current)
 	//      // ghost_map is rebuilt from ghost_seq when the general import path needs it
 	std::vector<GhostRefresh> ghost_refresh;               // pose refreshes of existing ghosts queued by the last import (uploaded by flush_cmds)
@@ -226,3 +227,4 @@ int collect_events(sgp_world* w, bool counters_fresh = false);
 int read_counters(sgp_world* w);
 // defined in sgp_world_bodies.hip
 int add_one(sgp_world* w, const sgp_body_desc* d, uint32_t* id_out, bool ghost);
+int book_record_body(sgp_world* w, uint32_t* flags_io, uint64_t userdata, float radius, float volume, bool ghost, uint32_t* id_out);      // (the host's share of add_one for a body created on the device from a record)

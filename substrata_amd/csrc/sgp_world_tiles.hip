@@ -74,22 +74,49 @@ static int make_ghost(sgp_world* w, const sgp_ghost_record& r, uint32_t* id_out)
 	return add_one(w, &d, id_out, true);
 }
 
-static int import_ghosts_impl(sgp_world* w, const sgp_ghost_record* in_all, uint32_t n_all, const GhostDeviceSource* dev, const uint8_t* skip = nullptr, const uint64_t* gids = nullptr, uint32_t gid_stride = 0);
+static int import_ghosts_impl(sgp_world* w, const sgp_ghost_record* in_all, uint32_t n_all, const GhostDeviceSource* dev, const uint8_t* skip = nullptr, const uint64_t* gids = nullptr, uint32_t gid_stride = 0, const uint4* keys = nullptr, const uint4* aux = nullptr);
 // (skip[k] = 1: record k is no ghost -- an immigrant riding in the same exchange -- and is left out; with a device source the records stay where they are and
 // the id array has a hole there)
 struct GhostView {      // the ghost records of an import: all of them, or those a mask lets through (by index: nothing is copied)
 	const sgp_ghost_record* base; const uint32_t* idx; uint32_t n;
 	const uint64_t* gids; uint32_t gid_stride;      // the records' global ids packed (16-byte keys of the exchange), or NULL: the diff then walks 16 bytes per record, not 128
+	const uint4* keys; const uint4* aux;            // round 6: the packed keys + user data / radius / volume of every record, or NULL.  With them a newcomer gets its slot from
+	                                                // the key alone and the device creates the body from the record (base may then be NULL: no record came to the host)
+	uint32_t rec(uint32_t k) const { return idx ? idx[k] : k; }
 	const sgp_ghost_record& operator[](uint32_t k) const { return idx ? base[idx[k]] : base[k]; }
 	uint64_t gid(uint32_t k) const { const uint32_t r = idx ? idx[k] : k; return gids ? gids[(size_t)r * gid_stride] : base[r].global_id; }
 };
 static int import_ghosts_view(sgp_world* w, const GhostView& in, uint32_t n, const GhostDeviceSource* dev, const uint8_t* skip, uint32_t n_all);
-static int import_ghosts_impl(sgp_world* w, const sgp_ghost_record* in_all, uint32_t n_all, const GhostDeviceSource* dev, const uint8_t* skip, const uint64_t* gids, uint32_t gid_stride)
+// A newcomer to the ghost set: through a create command built from its record, or -- when only its key came to the host -- a slot from the key and the body
+// created on the device (w->rec_creates; the caller launches k_create_from_records once the import's commands are flushed)
+static int make_ghost_at(sgp_world* w, const GhostView& in, uint32_t i, uint32_t* id_out)
 {
-	if (!skip) { GhostView v = { in_all, nullptr, n_all, gids, gid_stride }; return import_ghosts_view(w, v, n_all, dev, nullptr, n_all); }
+	if (!in.keys) return make_ghost(w, in[i], id_out);
+	*id_out = SGP_INVALID_ID;
+	const uint32_t r = in.rec(i);
+	const uint4 key = in.keys[r], aux = in.aux[r];
+	if (!(key.w & GKEY_VALID)) return SGP_ERR_REJECTED;
+	const uint32_t rflags = (key.w >> GKEY_FLAGS_SHIFT) & 0x3Fu, type = (key.w >> GKEY_SHAPE_SHIFT) & 7u;
+	uint32_t layer = rflags & SGP_GHOST_FLAG_LAYER_MASK;      // (as make_ghost: a kinematic ghost lives on a moving layer)
+	if (layer == SGP_LAYER_NON_MOVING) layer = SGP_LAYER_MOVING;
+	if (layer == SGP_LAYER_NON_MOVING_NON_COLLIDABLE) layer = SGP_LAYER_MOVING_NON_COLLIDABLE;
+	uint32_t f = BF_ALIVE | SGP_MOTION_KINEMATIC | (layer << BF_LAYER_SHIFT) | (type << BF_SHAPE_SHIFT) | BF_ALLOW_SLEEP | BF_GHOST;      // (allow_sleeping: the default description's)
+	if (rflags & SGP_GHOST_FLAG_SENSOR) f |= BF_SENSOR;
+	float rad, vol; memcpy(&rad, &aux.z, 4); memcpy(&vol, &aux.w, 4);
+	uint32_t id;
+	const int rc = book_record_body(w, &f, (uint64_t)aux.x | ((uint64_t)aux.y << 32), rad, vol, true, &id);
+	if (rc != SGP_OK) return rc;
+	w->rec_creates.push_back(make_uint4(r, id, f, 0u));
+	*id_out = id;
+	return SGP_OK;
+}
+
+static int import_ghosts_impl(sgp_world* w, const sgp_ghost_record* in_all, uint32_t n_all, const GhostDeviceSource* dev, const uint8_t* skip, const uint64_t* gids, uint32_t gid_stride, const uint4* keys, const uint4* aux)
+{
+	if (!skip) { GhostView v = { in_all, nullptr, n_all, gids, gid_stride, keys, aux }; return import_ghosts_view(w, v, n_all, dev, nullptr, n_all); }
 	std::vector<uint32_t> idx; idx.reserve(n_all);
 	for (uint32_t k = 0; k < n_all; ++k) if (!skip[k]) idx.push_back(k);
-	GhostView v = { in_all, idx.data(), (uint32_t)idx.size(), gids, gid_stride };
+	GhostView v = { in_all, idx.data(), (uint32_t)idx.size(), gids, gid_stride, keys, aux };
 	return import_ghosts_view(w, v, v.n, dev, skip, n_all);
 }
 static int import_ghosts_view(sgp_world* w, const GhostView& in, uint32_t n, const GhostDeviceSource* dev, const uint8_t* skip, uint32_t n_all)
@@ -122,8 +149,9 @@ static int import_ghosts_view(sgp_world* w, const GhostView& in, uint32_t n, con
 	w->cmds.reserve(w->cmds.size() + n);
 	std::vector<std::pair<uint64_t, uint32_t>> seq(n, std::pair<uint64_t, uint32_t>(0, SGP_INVALID_ID));
 	std::vector<uint32_t> gone;
-	auto refresh_cmd = [&](uint32_t id, const sgp_ghost_record& r) {
+	auto refresh_cmd = [&](uint32_t id, uint32_t rec_k) {
 		if (dev) return;                       // refreshed from the device copy of the records below
+		const sgp_ghost_record& r = in[rec_k];
 		BodyCmd c = blank_cmd(id, CMD_SET_POS | CMD_SET_ROT | CMD_SET_VEL | CMD_ACTIVATE);
 		memcpy(c.pos, r.pos, 12); memcpy(c.rot, r.rot, 16); memcpy(c.linv, r.lin_vel, 12); memcpy(c.angv, r.ang_vel, 12);
 		w->cmds.push_back(c);
@@ -139,7 +167,7 @@ static int import_ghosts_view(sgp_world* w, const GhostView& in, uint32_t n, con
 		size_t i = 0, j = 0;
 		while (i < n || j < old.size()) {
 			if (j == old.size() || (i < n && in.gid(i) < old[j].first)) {
-				uint32_t id; const int r = make_ghost(w, in[i], &id);
+				uint32_t id; const int r = make_ghost_at(w, in, (uint32_t)i, &id);
 				if (r != SGP_OK && r != SGP_ERR_REJECTED) return r;
 				seq[i] = std::make_pair(in.gid(i), r == SGP_OK ? id : SGP_INVALID_ID); ++i;
 			} else if (i == n || old[j].first < in.gid(i)) {
@@ -147,8 +175,8 @@ static int import_ghosts_view(sgp_world* w, const GhostView& in, uint32_t n, con
 				++j;
 			} else {
 				uint32_t id = old[j].second;
-				if (id != SGP_INVALID_ID && live(w, id)) refresh_cmd(id, in[i]);
-				else { const int r = make_ghost(w, in[i], &id); if (r != SGP_OK && r != SGP_ERR_REJECTED) return r; if (r != SGP_OK) id = SGP_INVALID_ID; }
+				if (id != SGP_INVALID_ID && live(w, id)) refresh_cmd(id, (uint32_t)i);
+				else { const int r = make_ghost_at(w, in, (uint32_t)i, &id); if (r != SGP_OK && r != SGP_ERR_REJECTED) return r; if (r != SGP_OK) id = SGP_INVALID_ID; }
 				seq[i] = std::make_pair(in.gid(i), id); ++i; ++j;
 			}
 		}
@@ -166,12 +194,12 @@ static int import_ghosts_view(sgp_world* w, const GhostView& in, uint32_t n, con
 			auto it = w->ghost_map.find(in.gid(k));
 			if (it != w->ghost_map.end() && live(w, (uint32_t)it->second)) {
 				const uint32_t id = (uint32_t)it->second;
-				refresh_cmd(id, in[k]);
+				refresh_cmd(id, k);
 				it->second = ((uint64_t)gen << 32) | id;
 				seq[k].second = id;
 				continue;
 			}
-			uint32_t id; const int r = make_ghost(w, in[k], &id);
+			uint32_t id; const int r = make_ghost_at(w, in, k, &id);
 			if (r == SGP_OK) { w->ghost_map[in.gid(k)] = ((uint64_t)gen << 32) | id; seq[k].second = id; }
 			else if (r != SGP_ERR_REJECTED) return r;
 		}
@@ -403,7 +431,10 @@ struct sgp_tiles {
 	uint32_t* d_seq_ids = nullptr; uint32_t cap_seq = 0; uint64_t ids_version = 0;      // local body id of ghost k of the current ghost set (device copy, for the refresh kernel)
 	// host (pinned)
 	char* h_ctl = nullptr; sgp_ghost_record* h_recv = nullptr; uint32_t cap_h_recv = 0;
-	uint4* d_keys = nullptr; uint32_t cap_keys = 0; void* h_keys = nullptr; uint32_t cap_h_keys = 0;      // (global id, ownership flag) of the received records
+	uint4* d_keys = nullptr; uint32_t cap_keys = 0; void* h_keys = nullptr; uint32_t cap_h_keys = 0;      // (global id, ownership flag, kind of record) of the received records
+	uint4* d_aux = nullptr; uint32_t cap_aux = 0; void* h_aux = nullptr;                                  // (user data, bounding radius, volume): to the host only when the set changed
+	uint4* d_create = nullptr; uint32_t cap_create = 0; uint4* h_create = nullptr; uint32_t cap_h_create = 0;      // bodies to create on the device from received records
+	bool host_records_only = false;        // SGP_TILES_HOST_RECORDS=1: every changed set takes the records to the host (the round-5 path; A/B and tests)
 	// last exchange
 	std::vector<uint32_t> recv_counts, recv_offsets;
 	std::vector<uint64_t> seq_gids;        // global ids of the ghosts of the previous import, in order
@@ -452,7 +483,9 @@ SGP_API int sgp_tiles_destroy(sgp_tiles* t)
 	if (t->h_ctl) hipHostFree(t->h_ctl);
 	if (t->h_recv) hipHostFree(t->h_recv);
 	if (t->h_keys) hipHostFree(t->h_keys);
-	hipFree(t->d_keys);
+	if (t->h_aux) hipHostFree(t->h_aux);
+	if (t->h_create) hipHostFree(t->h_create);
+	hipFree(t->d_keys); hipFree(t->d_aux); hipFree(t->d_create);
 	hipFree(t->d_hist); hipFree(t->d_hist_all); if (t->h_hist) hipHostFree(t->h_hist);
 	delete t;
 	return SGP_OK;
@@ -469,6 +502,7 @@ SGP_API int sgp_tiles_create(sgp_world* w, uint32_t rank, uint32_t n_tiles, cons
 	memcpy(t->route.boxes, boxes, sizeof(float) * 6 * n_tiles);
 	t->route.n_tiles = n_tiles; t->route.my_rank = rank; t->route.margin = margin; t->route.pad = margin + radius_pad;
 	memset(&t->stats, 0, sizeof(t->stats));
+	if (const char* hr = getenv("SGP_TILES_HOST_RECORDS")) t->host_records_only = *hr && atoi(hr) != 0;
 	if (const char* fr = getenv("SGP_TILES_TEST_FAIL_RANK")) t->test_fail_growth = (*fr && (uint32_t)atoi(fr) == rank) ? 1 : 0;      // (debugging aid: DESIGN.md 6)
 	const size_t cb = tiles_ctl_bytes(n_tiles);
 	if (hipMalloc((void**)&t->d_ctl, cb) != hipSuccess || hipHostMalloc((void**)&t->h_ctl, cb, hipHostMallocDefault) != hipSuccess) { sgp_tiles_destroy(t); return fail(SGP_ERR_HIP, "sgp_tiles_create: allocation"); }
@@ -554,21 +588,49 @@ static int tiles_remove_emigrants(sgp_tiles* t)
 }
 
 // phase 4: what arrived (n records in d_recv, by source rank) becomes this world's ghost set (+ immigrants)
+// the bodies the last import queued for creation on the device (w->rec_creates): list up, one kernel over the received records
+static int tiles_launch_creates(sgp_tiles* t)
+{
+	sgp_world* w = t->w;
+	const uint32_t n = (uint32_t)w->rec_creates.size();
+	if (!n) return SGP_OK;
+	{ int r = tiles_grow(w, t->d_create, t->cap_create, n); if (r != SGP_OK) return r; }
+	if (n > t->cap_h_create) {
+		if (t->h_create) { HIP_TRY(hipStreamSynchronize(w->stream)); hipHostFree(t->h_create); }
+		t->cap_h_create = n + n / 2 + 256;
+		HIP_TRY(hipHostMalloc((void**)&t->h_create, sizeof(uint4) * (size_t)t->cap_h_create, hipHostMallocDefault));
+	}
+	HIP_TRY(hipStreamSynchronize(w->stream));      // (the pinned list of the previous import has been read)
+	memcpy(t->h_create, w->rec_creates.data(), sizeof(uint4) * n);
+	HIP_TRY(hipMemcpyAsync(t->d_create, t->h_create, sizeof(uint4) * n, hipMemcpyHostToDevice, w->stream));
+	sgp_body_desc def; sgp_default_body_desc(&def);
+	launch_create_from_records(w->dv, t->d_recv, t->d_create, n, def.gravity_factor, def.linear_damping, def.angular_damping, w->stream);
+	t->stats.device_creates += n;
+	w->rec_creates.clear();
+	w->grid_valid = false; w->dirty_since_step = true;
+	return SGP_OK;
+}
+
 static int tiles_import(sgp_tiles* t, uint32_t n)
 {
 	sgp_world* w = t->w;
 	t->stats.received = n;
+	w->rec_creates.clear();
 	// steady state: the same ghosts as last step in the same order, nobody immigrating -> poses go from the received records to the bodies
-	// on the device; the host only sees 16 bytes per record (global id + ownership flag, packed by a kernel), not the 128-byte records
-	struct GhostKey { uint64_t global_id; uint32_t motion_type, pad; };
+	// on the device; the host only sees 16 bytes per record (global id + ownership flag + what kind of record it is, packed by a kernel), not the 128-byte records
+	struct GhostKey { uint64_t global_id; uint32_t motion_type, info; };
+	const float* lo = t->route.boxes + 6 * t->rank; const float* hi = lo + 3;
 	if (n) {
 		{ int r = tiles_grow(w, t->d_keys, t->cap_keys, n); if (r != SGP_OK) return r; }
+		{ int r = tiles_grow(w, t->d_aux, t->cap_aux, n); if (r != SGP_OK) return r; }
 		if (n > t->cap_h_keys) {
 			if (t->h_keys) hipHostFree(t->h_keys);
+			if (t->h_aux) hipHostFree(t->h_aux);
 			t->cap_h_keys = n + n / 2 + 1024;
 			HIP_TRY(hipHostMalloc((void**)&t->h_keys, 16 * (size_t)t->cap_h_keys, hipHostMallocDefault));
+			HIP_TRY(hipHostMalloc((void**)&t->h_aux, 16 * (size_t)t->cap_h_keys, hipHostMallocDefault));
 		}
-		launch_pack_ghost_keys(t->d_recv, n, t->d_keys, w->stream);
+		launch_pack_ghost_keys(t->d_recv, n, t->d_keys, t->d_aux, lo, hi, w->stream);
 		HIP_TRY(hipMemcpyAsync(t->h_keys, t->d_keys, 16 * (size_t)n, hipMemcpyDeviceToHost, w->stream));
 		HIP_TRY(hipStreamSynchronize(w->stream));
 		const GhostKey* keys = (const GhostKey*)t->h_keys;
@@ -584,70 +646,101 @@ static int tiles_import(sgp_tiles* t, uint32_t n)
 			return SGP_OK;
 		}
 	}
-	// the set changed (or bodies immigrate): the records themselves come to the host, which owns the body slots
-	if (n > t->cap_h_recv) {
-		if (t->h_recv) hipHostFree(t->h_recv);
-		t->cap_h_recv = n + n / 2 + 1024;
-		HIP_TRY(hipHostMalloc((void**)&t->h_recv, sizeof(sgp_ghost_record) * (size_t)t->cap_h_recv, hipHostMallocDefault));
+	// The set changed (or bodies immigrate).  Round 6: the host still owns the body slots -- it hands them out in the order the CPU statement does, from the
+	// 16-byte keys --, but the bodies are created on the device straight from the received records: no 128-byte record comes to the host, no 160-byte create
+	// command goes back.  Only records that name a hull or a mesh (the host keeps reference counts and mass properties for those shapes) take the old road.
+	const GhostKey* keys = (const GhostKey*)t->h_keys;      // (n > 0: packed above)
+	bool by_key = !t->host_records_only;
+	for (uint32_t k = 0; k < n && by_key; ++k) { const uint32_t type = (keys[k].info >> GKEY_SHAPE_SHIFT) & 7u; by_key = type == SGP_SHAPE_SPHERE || type == SGP_SHAPE_BOX || type == SGP_SHAPE_CAPSULE; }
+	if (by_key) {
+		if (n) { HIP_TRY(hipMemcpyAsync(t->h_aux, t->d_aux, 16 * (size_t)n, hipMemcpyDeviceToHost, w->stream)); HIP_TRY(hipStreamSynchronize(w->stream)); }
+	} else {
+		if (n > t->cap_h_recv) {
+			if (t->h_recv) hipHostFree(t->h_recv);
+			t->cap_h_recv = n + n / 2 + 1024;
+			HIP_TRY(hipHostMalloc((void**)&t->h_recv, sizeof(sgp_ghost_record) * (size_t)t->cap_h_recv, hipHostMallocDefault));
+		}
+		if (n) {
+			HIP_TRY(hipMemcpyAsync(t->h_recv, t->d_recv, sizeof(sgp_ghost_record) * (size_t)n, hipMemcpyDeviceToHost, w->stream));
+			HIP_TRY(hipStreamSynchronize(w->stream));
+		}
+		t->stats.slow_imports++;      // (= imports whose records came to the host)
 	}
-	if (n) {
-		HIP_TRY(hipMemcpyAsync(t->h_recv, t->d_recv, sizeof(sgp_ghost_record) * (size_t)n, hipMemcpyDeviceToHost, w->stream));
-		HIP_TRY(hipStreamSynchronize(w->stream));
-	}
+	const sgp_ghost_record* recs = by_key ? nullptr : t->h_recv;
+	const uint4* k4 = by_key ? (const uint4*)t->h_keys : nullptr; const uint4* a4 = by_key ? (const uint4*)t->h_aux : nullptr;
 	// who is a ghost, who immigrates (flagged records addressed to another tile are dropped)
-	const float* lo = t->route.boxes + 6 * t->rank; const float* hi = lo + 3;
-	const GhostKey* keys = (const GhostKey*)t->h_keys;      // (n > 0: packed above; the scans below read 16 bytes per record instead of 128)
 	bool plain = true;
 	for (uint32_t k = 0; k < n && plain; ++k) plain = !(keys[k].motion_type & SGP_GHOST_TAKE_OWNERSHIP);
 	const size_t seq_before = w->ghost_seq.size();
 	if (plain) {
-		// ghosts only: the poses stay on the device -- the host compares global ids (and creates / removes the few bodies that entered or left
-		// the set), one kernel refreshes every ghost from the received records
+		// ghosts only: the poses stay on the device -- the host compares global ids (and gives the few bodies that entered the set a slot, removes those that
+		// left), one kernel refreshes every ghost from the received records
 		bool unchanged = n == seq_before;            // (no ghosts before, none now: nothing for the host to do either)
 		for (uint32_t k = 0; k < n && unchanged; ++k) unchanged = keys[k].global_id == w->ghost_seq[k].first;
 		GhostDeviceSource dev = { t->d_recv, &t->d_seq_ids, &t->cap_seq, &t->ids_version };
-		{ int rc = import_ghosts_impl(w, t->h_recv, n, &dev, nullptr, (const uint64_t*)t->h_keys, 2); if (rc != SGP_OK) return rc; }
+		{ int rc = import_ghosts_impl(w, recs, n, &dev, nullptr, (const uint64_t*)t->h_keys, 2, k4, a4); if (rc != SGP_OK) return rc; }
+		{ int rc = tiles_launch_creates(t); if (rc != SGP_OK) return rc; }
 		t->stats.ghosts = n; t->stats.immigrated = 0;
-		if (unchanged) t->stats.fast_imports++; else t->stats.slow_imports++;
+		if (unchanged) t->stats.fast_imports++;
 		return SGP_OK;
 	}
 	// bodies immigrate with this exchange: their records sit between the ghosts'.  The ghosts still take the device path (by index: no record is copied, no
 	// refresh command is made -- a tile of the collapsing tower holds 25 000 ghosts and receives immigrants in EVERY step: 3.5 MB of records copied and
 	// 25 000 commands built, uploaded and applied per step was most of the exchange's 1.2 ms, profiles/r04_tiles_import.md)
 	std::vector<uint8_t> skip(n, 0);
-	std::vector<const sgp_ghost_record*> immigrants;
+	std::vector<uint32_t> immigrants;
 	uint32_t n_ghosts = 0;
 	for (uint32_t k = 0; k < n; ++k) {
 		if (!(keys[k].motion_type & SGP_GHOST_TAKE_OWNERSHIP)) { ++n_ghosts; continue; }
-		const sgp_ghost_record& r = t->h_recv[k];
 		skip[k] = 1;
-		if (in_box(r.pos, lo, hi, 0.0f)) immigrants.push_back(&r);
+		if (by_key ? (keys[k].info & GKEY_IN_REGION) != 0u : in_box(t->h_recv[k].pos, lo, hi, 0.0f)) immigrants.push_back(k);
 	}
 	{
 		GhostDeviceSource dev = { t->d_recv, &t->d_seq_ids, &t->cap_seq, &t->ids_version };
-		int rc = import_ghosts_impl(w, t->h_recv, n, &dev, skip.data(), (const uint64_t*)t->h_keys, 2); if (rc != SGP_OK) return rc;
+		int rc = import_ghosts_impl(w, recs, n, &dev, skip.data(), (const uint64_t*)t->h_keys, 2, k4, a4); if (rc != SGP_OK) return rc;
 	}
 	uint32_t n_imm = 0;
-	for (const sgp_ghost_record* pr : immigrants) {
-		const sgp_ghost_record& r = *pr;
-		sgp_body_desc d; sgp_default_body_desc(&d);
-		memcpy(d.pos, r.pos, 12); memcpy(d.rot, r.rot, 16); memcpy(d.lin_vel, r.lin_vel, 12); memcpy(d.ang_vel, r.ang_vel, 12);
-		d.shape_type = r.shape_type; memcpy(d.shape, r.shape, 16);
-		d.motion_type = SGP_MOTION_DYNAMIC;
-		d.layer = (int32_t)(r.flags & SGP_GHOST_FLAG_LAYER_MASK);
-		d.is_sensor = (r.flags & SGP_GHOST_FLAG_SENSOR) ? 1 : 0; d.allow_sleeping = (r.flags & SGP_GHOST_FLAG_ALLOW_SLEEP) ? 1 : 0; d.use_zero_linear_drag = (r.flags & SGP_GHOST_FLAG_ZERO_DRAG) ? 1 : 0;
-		d.mass = r.mass; d.friction = r.friction; d.restitution = r.restitution;
-		d.gravity_factor = r.gravity_factor; d.linear_damping = r.linear_damping; d.angular_damping = r.angular_damping;
-		d.userdata = r.userdata; d.activate = 1;
+	for (uint32_t k : immigrants) {
 		uint32_t id = SGP_INVALID_ID;
-		const int rc = add_one(w, &d, &id, false);
+		int rc;
+		uint64_t userdata, gid = keys[k].global_id;
+		if (by_key) {
+			// the body as it was: dynamic, its own layer and flags; slot from the key, created on the device from the record (mass properties there too)
+			const uint4 aux = a4[k];
+			userdata = (uint64_t)aux.x | ((uint64_t)aux.y << 32);
+			if (!(keys[k].info & GKEY_VALID)) rc = SGP_ERR_REJECTED;
+			else {
+				const uint32_t rflags = (keys[k].info >> GKEY_FLAGS_SHIFT) & 0x3Fu, type = (keys[k].info >> GKEY_SHAPE_SHIFT) & 7u;
+				uint32_t f = BF_ALIVE | SGP_MOTION_DYNAMIC | ((rflags & SGP_GHOST_FLAG_LAYER_MASK) << BF_LAYER_SHIFT) | (type << BF_SHAPE_SHIFT);
+				if (rflags & SGP_GHOST_FLAG_SENSOR) f |= BF_SENSOR;
+				if (rflags & SGP_GHOST_FLAG_ALLOW_SLEEP) f |= BF_ALLOW_SLEEP;
+				if (rflags & SGP_GHOST_FLAG_ZERO_DRAG) f |= BF_ZERO_LIN_DRAG;
+				float rad, vol; memcpy(&rad, &aux.z, 4); memcpy(&vol, &aux.w, 4);
+				rc = book_record_body(w, &f, userdata, rad, vol, false, &id);
+				if (rc == SGP_OK) w->rec_creates.push_back(make_uint4(k, id, f, 0u));
+			}
+		} else {
+			const sgp_ghost_record& r = t->h_recv[k];
+			userdata = r.userdata;
+			sgp_body_desc d; sgp_default_body_desc(&d);
+			memcpy(d.pos, r.pos, 12); memcpy(d.rot, r.rot, 16); memcpy(d.lin_vel, r.lin_vel, 12); memcpy(d.ang_vel, r.ang_vel, 12);
+			d.shape_type = r.shape_type; memcpy(d.shape, r.shape, 16);
+			d.motion_type = SGP_MOTION_DYNAMIC;
+			d.layer = (int32_t)(r.flags & SGP_GHOST_FLAG_LAYER_MASK);
+			d.is_sensor = (r.flags & SGP_GHOST_FLAG_SENSOR) ? 1 : 0; d.allow_sleeping = (r.flags & SGP_GHOST_FLAG_ALLOW_SLEEP) ? 1 : 0; d.use_zero_linear_drag = (r.flags & SGP_GHOST_FLAG_ZERO_DRAG) ? 1 : 0;
+			d.mass = r.mass; d.friction = r.friction; d.restitution = r.restitution;
+			d.gravity_factor = r.gravity_factor; d.linear_damping = r.linear_damping; d.angular_damping = r.angular_damping;
+			d.userdata = r.userdata; d.activate = 1;
+			rc = add_one(w, &d, &id, false);
+		}
 		// the previous owner has already let go of the body: failing to take it over must not pass silently
 		if (rc != SGP_OK) return fail(rc == SGP_ERR_REJECTED ? SGP_ERR_INVALID : rc, "sgp_tiles_exchange: could not take over a migrating body (raise max_bodies; hull / mesh ids must mean the same shape on every tile)");
-		sgp_migration m; memset(&m, 0, sizeof(m)); m.userdata = r.userdata; m.old_id = (uint32_t)(r.global_id & 0xFFFFFFFFull); m.new_id = id; m.direction = SGP_MIGRATION_IN; m.peer = (uint32_t)(r.global_id >> 40);
+		sgp_migration m; memset(&m, 0, sizeof(m)); m.userdata = userdata; m.old_id = (uint32_t)(gid & 0xFFFFFFFFull); m.new_id = id; m.direction = SGP_MIGRATION_IN; m.peer = (uint32_t)(gid >> 40);
 		t->migrations.push_back(m);
 		++n_imm;
 	}
-	t->stats.immigrated = n_imm; t->stats.ghosts = n_ghosts; t->stats.slow_imports++;
+	{ int rc = tiles_launch_creates(t); if (rc != SGP_OK) return rc; }
+	t->stats.immigrated = n_imm; t->stats.ghosts = n_ghosts;
 	return SGP_OK;
 }
 

@@ -101,7 +101,7 @@ def parity_worker(rank, world_size, port, steps, out_dir):
                 ok = False; why = why or f"step {s}: {dd}"
     st = nt.stats()
     owned = g.num_bodies() - 1 - st.ghosts
-    np.save(os.path.join(out_dir, f"mr{rank}.npy"), np.array([int(ok), migrated_in, migrated_out, max_ghosts, owned, st.comm_ranks, st.rebalances, rebalances, st.fast_imports, st.slow_imports]))
+    np.save(os.path.join(out_dir, f"mr{rank}.npy"), np.array([int(ok), migrated_in, migrated_out, max_ghosts, owned, st.comm_ranks, st.rebalances, rebalances, st.fast_imports, st.slow_imports, st.device_creates]))
     if why:
         open(os.path.join(out_dir, f"mr{rank}.txt"), "w").write(why)
     dist.barrier()
@@ -127,6 +127,7 @@ def test_native_exchange_across_processes_against_oracle_tiles(tmp_path, oracle,
         assert v[5] == world_size                          # the communicator really had one rank per tile
         assert v[6] == v[7] > 0                            # every re-tiling went through the collective
     assert sum(int(v[4]) for v in res) == 8 ** 3           # no body lost or duplicated across the processes
+    assert all(int(v[9]) == 0 and int(v[10]) > 0 for v in res)      # round 6: no import brought records to the host; newcomers were created on the device
     assert all(v[3] > 0 for v in res)                      # ghosts flowed to every tile
     assert sum(int(v[1]) for v in res) == sum(int(v[2]) for v in res) >= 1       # bodies changed owner, and every emigrant arrived somewhere
 

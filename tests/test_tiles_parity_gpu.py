@@ -80,11 +80,16 @@ def test_two_tiles_hip_against_oracle(oracle):
         w.close()
 
 
-def test_two_tiles_native_exchange_against_oracle(oracle):
-    """The same scene with the HIP worlds exchanged by the native path (sgp_tiles_exchange_group: routing kernels, device-to-device
+@pytest.mark.parametrize("host_records", [0, 1])
+def test_two_tiles_native_exchange_against_oracle(oracle, host_records, monkeypatch):
+    """host_records = 0 (round 6, the default): newcomers to the ghost set and bodies that change owner are created ON THE DEVICE from the received
+    records, the host hands out the slots from 16 + 16-byte keys; 1 (SGP_TILES_HOST_RECORDS=1): the round-5 road, records to the host and create
+    commands back.  Both must equal the oracle bit for bit.
+    The same scene with the HIP worlds exchanged by the native path (sgp_tiles_exchange_group: routing kernels, device-to-device
     copies, device-side ghost refresh while the set is unchanged) and the oracle worlds by the Python statement of the rules: identical
     counts every step, identical bits every 30 steps, ownership migrations reported with the body's user data."""
     from substrata_amd.lib import World
+    monkeypatch.setenv("SGP_TILES_HOST_RECORDS", str(host_records))
     scenes_, boxes = [], []
     for r in range(2):
         d, lo, hi = tile_scene(r)
@@ -118,6 +123,13 @@ def test_two_tiles_native_exchange_against_oracle(oracle):
     assert all(int(m["new_id"]) != abi.INVALID_ID and int(m["peer"]) in (0, 1) for m in inn)
     # the steady state ran on the device: most imports never touched the host
     assert nt[0].stats().fast_imports > nt[0].stats().slow_imports
+    # ... and a changed set (primitives only here) did not bring the records to the host either: the device created the newcomers from them
+    for t_ in nt:
+        st_ = t_.stats()
+        if host_records:
+            assert st_.device_creates == 0 and st_.slow_imports > 0
+        else:
+            assert st_.slow_imports == 0 and st_.device_creates > 0
     # a ray in the new owner's world finds the migrated ball under its original user data
     ball_ud = int(scenes_[0]["userdata"][-1])
     assert ball_ud in [int(m["userdata"]) for m in inn]
