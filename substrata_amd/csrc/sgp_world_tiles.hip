@@ -594,6 +594,9 @@ static int tiles_launch_creates(sgp_tiles* t)
 	sgp_world* w = t->w;
 	const uint32_t n = (uint32_t)w->rec_creates.size();
 	if (!n) return SGP_OK;
+	// what is still queued comes first: a newcomer may have been given the slot of a body whose removal (an emigrant, a ghost that left) has not reached the
+	// device yet -- as a command its creation would have queued up behind that removal
+	{ int r = flush_cmds(w); if (r != SGP_OK) return r; }
 	{ int r = tiles_grow(w, t->d_create, t->cap_create, n); if (r != SGP_OK) return r; }
 	if (n > t->cap_h_create) {
 		if (t->h_create) { HIP_TRY(hipStreamSynchronize(w->stream)); hipHostFree(t->h_create); }

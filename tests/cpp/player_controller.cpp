@@ -46,16 +46,28 @@ struct Player : public JPH::CharacterContactListener
 		// anti-sliding rule of PlayerPhysics::OnContactSolve (:535-545)
 		if (!allow_sliding && contact_velocity.LengthSq() < 1.0e-12f && !ch->IsSlopeTooSteep(n)) new_velocity = JPH::Vec3(0, 0, 0);
 	}
-	// PlayerPhysics::update (:253-353) without swimming / flying
+	// How deep the character stands in the water: 0 dry ... 1 when the water is an eye height above the feet (the rule of PlayerPhysics.cpp:179-195, through the
+	// facade's water getters).  From 0.3 on the caller treats the character as swimming.
+	static constexpr float EYE_HEIGHT = 1.67f;
+	static float submerged_fraction(PhysicsWorld& physics_world, const JPH::Vec3& feet)
+	{
+		if (!physics_world.getWaterBuoyancyEnabled()) return 0.f;
+		return std::fmin(1.f, std::fmax(0.f, (physics_world.getWaterZ() - feet.z) / EYE_HEIGHT));
+	}
+	// PlayerPhysics::update (:253-353) without flying; the swimming branch (:266-294): a swimmer keeps the vertical part of what it wants, floats up with
+	// 1.1 g per submerged fraction and loses up to 20 % of its velocity per frame to the water
 	void update(PhysicsWorld& physics_world, const JPH::Vec3& move_desired_vel, bool jump, float dtime)
 	{
 		allow_sliding = move_desired_vel.LengthSq() != 0.f;
 		JPH::Vec3 vel = jolt_character->GetLinearVelocity();
-		JPH::Vec3 parallel_vel = move_desired_vel; parallel_vel.z = 0;
+		const float wet = submerged_fraction(physics_world, jolt_character->GetPosition());
+		JPH::Vec3 parallel_vel = move_desired_vel; if (wet < 0.3f) parallel_vel.z = 0;
 		jolt_character->UpdateGroundVelocity();
 		if (jolt_character->IsSupported() && (vel.z - jolt_character->GetGroundVelocity().GetZ()) < 0.1f) vel = parallel_vel + jolt_character->GetGroundVelocity();
 		else vel = vel + parallel_vel * dtime;
 		vel = vel + JPH::Vec3(0, 0, -9.81f) * dtime;
+		vel = vel + JPH::Vec3(0, 0, 9.81f * 1.1f * wet) * dtime;
+		vel = vel * (1.f - std::fmin(0.2f, 2.0f * wet * dtime));
 		if (vel.z < -100) vel.z = -100;
 		if (jump && jolt_character->IsSupported()) {
 			const JPH::Vec3 gn = jolt_character->GetGroundNormal();
@@ -178,6 +190,25 @@ int main(int argc, char** argv)
 		for (int i = 0; i < 180; ++i) frame(JPH::Vec3(2, 0, 0));
 		world->readBackActivatedObjectTransforms();
 		const float crate_x = world->getPosInJolt(crate)[0];
+		// 9. swimming (PlayerPhysics.cpp:182-205,266-294): the water rises to z = 3 over a pit far from everything else.  Dropped in, the character comes up and floats
+		//    where buoyancy (1.1 g x submerged fraction) balances gravity -- the water 1 / 1.1 of an eye height above its feet --, a swimmer's wish to go up or down is
+		//    honoured (on dry ground it is dropped), and with the water switched off again the character falls to the floor.
+		{
+			world->setWaterBuoyancyEnabled(true); world->setWaterZ(3.0f);
+			CHECK(world->getWaterBuoyancyEnabled() && world->getWaterZ() == 3.0f);
+			player.jolt_character->SetPosition(JPH::Vec3(40, 40, 2.6f)); player.jolt_character->SetLinearVelocity(JPH::Vec3(0, 0, 0));
+			for (int i = 0; i < 600; ++i) frame(JPH::Vec3(0, 0, 0));
+			const float float_z = 3.0f - Player::EYE_HEIGHT / 1.1f;
+			CHECK(!player.jolt_character->IsSupported() && std::fabs(p.z - float_z) < 0.05f && std::fabs(player.jolt_character->GetLinearVelocity().z) < 0.05f);
+			for (int i = 0; i < 90; ++i) frame(JPH::Vec3(0, 0, -1.5f));      // dive
+			CHECK(p.z < float_z - 0.4f && p.z > 0.05f);
+			const float dived_z = p.z;
+			for (int i = 0; i < 240; ++i) frame(JPH::Vec3(1, 0, 0));          // swim along: comes back up while it moves
+			CHECK(p.z > dived_z + 0.2f && p.x > 41.0f);
+			world->setWaterBuoyancyEnabled(false);
+			for (int i = 0; i < 120; ++i) frame(JPH::Vec3(0, 0, 1.5f));       // no water: the wish to go up means nothing, the character falls and stands
+			CHECK(player.jolt_character->IsSupported() && std::fabs(p.z) < 0.05f);
+		}
 		printf("final pos %.3f %.3f %.3f  crate x %.3f  contacts added %d\n", p.x, p.y, p.z, crate_x, player.contacts_added);
 		printf("character update: %.1f us on average over %d updates\n", update_us / (double)updates, updates);
 		CHECK(crate_x > -5.5f && p.x > -7.0f && p.x < crate_x - 0.5f);
