@@ -59,7 +59,8 @@ typedef struct {
 	int alive, active;
 	v3 aabb_min, aabb_max;
 	v3 sleep_c[3]; float sleep_r[3]; float sleep_timer;
-	uint32_t sleep_label;              /* the island this body fell asleep with (the member with the lowest uf_prio; its own id from creation): bodies that share it wake together */
+	uint32_t slot_gen;                 /* how often this SLOT has been given to a new body (7 bits are used): part of every label made from its id */
+	uint32_t sleep_label;              /* SGO_LABEL(id, generation of that slot when the label was made): the island this body fell asleep with (the member with the lowest uf_prio; its own id from creation): bodies that share it wake together */
 	int underwater; float submerged;
 	/* per-step scratch */
 	uint64_t colour_mask; uint64_t claim[2];
@@ -96,6 +97,10 @@ typedef struct { uint32_t a, b; } sgo_pair;
 
 typedef struct sgo_mesh_s { uint32_t nv, nt; v3* verts; uint32_t* tris; uint32_t* mats; unsigned char* edges; v3 aabb_min, aabb_max; float bound_radius; } sgo_mesh;
 
+#define SGO_LABEL(id, gen) ((uint32_t)(id) | ((uint32_t)(gen) << 25))
+#define SGO_LABEL_SLOT(l) ((l) & 0x1FFFFFFu)
+/* a label is current while the slot it names still holds the body (generation) it was made from */
+#define SGO_LABEL_CURRENT(w, l) (SGO_LABEL_SLOT(l) < (w)->cap && ((l) >> 25) == ((w)->bodies[SGO_LABEL_SLOT(l)].slot_gen & 0x7Fu))
 typedef struct sgo_world {
 	sgp_world_desc desc;
 	sgp_settings st;
@@ -447,7 +452,7 @@ SGO_API int sgo_body_add(sgo_world* w, const sgp_body_desc* d, uint32_t* id_out)
 	else if (w->n_free) id = w->free_list[--w->n_free];
 	else { if (w->high >= w->cap) return SGP_ERR_CAPACITY; id = w->high++; }
 	sgo_body* b = &w->bodies[id];
-	memset(b, 0, sizeof(*b));
+	{ const uint32_t gen_ = b->slot_gen; memset(b, 0, sizeof(*b)); b->slot_gen = gen_; }      /* (the slot's generation outlives its bodies) */
 	b->pos = V3(d->pos[0], d->pos[1], d->pos[2]);
 	quat q = { d->rot[0], d->rot[1], d->rot[2], d->rot[3] };
 	b->rot = q;
@@ -470,12 +475,15 @@ SGO_API int sgo_body_add(sgo_world* w, const sgp_body_desc* d, uint32_t* id_out)
 	else { b->inv_mass = 0.0f; b->inv_inertia = V3(0.0f, 0.0f, 0.0f); }
 	if (b->motion != SGP_MOTION_DYNAMIC) { /* non-dynamic bodies carry no force */ }
 	b->alive = 1; b->active = 0;
-	b->sleep_label = id;
+	/* a label names a slot AND the generation of the body in it: a body created in the slot a removed island root left must not share the wake label of that
+	   island's sleepers (round 6) */
+	b->slot_gen = (b->slot_gen + 1u) & 0x7Fu;
+	b->sleep_label = SGO_LABEL(id, b->slot_gen);
 	b->comp_root = SGP_INVALID_ID;
 	body_update_aabb(b);
 	body_reset_sleep(b);
 	w->n_alive++;
-	if (mesh) for (uint32_t k = 1; k <= 2; ++k) { w->bodies[id + k] = *b; w->bodies[id + k].is_alias = 1; }
+	if (mesh) for (uint32_t k = 1; k <= 2; ++k) { const uint32_t ag = (w->bodies[id + k].slot_gen + 1u) & 0x7Fu; w->bodies[id + k] = *b; w->bodies[id + k].is_alias = 1; w->bodies[id + k].slot_gen = ag; w->bodies[id + k].sleep_label = SGO_LABEL(id + k, ag); }
 	if (d->activate) body_activate(w, id);
 	if (id_out) *id_out = id;
 	return SGP_OK;
@@ -1122,13 +1130,13 @@ static void find_contacts(sgo_world* w, float dt)
 			const sgo_body* b = &w->bodies[i];
 			if (!b->alive || b->can_sleep != -1) continue;
 			if (!lab) lab = (unsigned char*)calloc(w->cap ? w->cap : 1, 1);
-			if (b->sleep_label < w->cap) lab[b->sleep_label] = 1;
+			if (SGO_LABEL_CURRENT(w, b->sleep_label)) lab[SGO_LABEL_SLOT(b->sleep_label)] = 1;
 		}
 		if (lab) {
 			for (uint32_t i = 0; i < w->high; ++i) {
 				sgo_body* b = &w->bodies[i];
 				if (!b->alive || b->is_alias || b->motion != SGP_MOTION_DYNAMIC || b->active) continue;
-				if (b->sleep_label < w->cap && lab[b->sleep_label]) b->can_sleep = -1;
+				if (SGO_LABEL_CURRENT(w, b->sleep_label) && lab[SGO_LABEL_SLOT(b->sleep_label)]) b->can_sleep = -1;
 				if (b->can_sleep == -1) ++n_woken;
 			}
 			free(lab);
@@ -1489,7 +1497,7 @@ static void update_sleeping(sgo_world* w, float dt)
 		const uint32_t r = uf_find(w, i);
 		if (w->bodies[r].colour_mask) {
 			b->active = 0; b->linv = V3(0, 0, 0); b->angv = V3(0, 0, 0);
-			b->sleep_label = best[r];
+			b->sleep_label = SGO_LABEL(best[r], w->bodies[best[r]].slot_gen & 0x7Fu);
 			push_body_event(w, SGP_EVENT_DEACTIVATED, i);
 		}
 	}

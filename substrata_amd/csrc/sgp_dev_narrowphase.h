@@ -41,12 +41,17 @@ SGP_DEV uint32_t wave_alloc(uint32_t* counter)
 // safety net: a manifold without a direction (or with a NaN one) is dropped, never solved
 SGP_DEV bool manifold_ok(const sgd_manifold& m) { return v3_len_sq(m.n) > 0.25f; }
 
+// a label is current while the slot it names still holds the body (generation) it was made from
+SGP_DEV bool label_current(const DV& d, uint32_t lbl) { return (lbl >> 25) == (d.slot_gen[SGP_LABEL_SLOT(lbl)] & 0x7Fu); }
+// a new body in slot i: the slot's next generation, and the body's own label
+SGP_DEV void label_new_body(const DV& d, uint32_t i) { const uint32_t g = (d.slot_gen[i] + 1u) & 0x7Fu; d.slot_gen[i] = g; d.sleep_label[i] = SGP_LABEL(i, g); }
 // A sleeping dynamic body is touched by an awake one (or stands under a wheel): k_pre_solve wakes it, and k_wake_pairs wakes, in the same step, everything
 // that fell asleep in the same island (the label's mark carries this step's epoch)
 SGP_DEV void wake_body(const DV& d, uint32_t id)
 {
 	atomicOr(&d.flags[id], BF_WAKE);
-	d.label_wake[d.sleep_label[id]] = *d.veh_epoch;
+	const uint32_t lbl = d.sleep_label[id];
+	if (label_current(d, lbl)) d.label_wake[SGP_LABEL_SLOT(lbl)] = *d.veh_epoch;      // (a label whose slot has since been given to another body names nobody: the body wakes alone)
 	d.ctr->wake_any = 1u;
 }
 

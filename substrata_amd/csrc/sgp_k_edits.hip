@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(TPB) k_apply_cmds(DV d, const BodyCmd* cmds, c
 			d.prop[2 * (size_t)i + 1] = make_float4(c.shape[0], c.shape[1], c.shape[2], c.friction);
 			d.submerged[i] = 0.0f;
 			d.userdata[i] = c.userdata;
-			d.sleep_label[i] = i;
+			label_new_body(d, i);
 			refresh_aabb(d, i, f);
 			reset_sleep(d, i, f_shape(f), d.prop[2 * (size_t)i + 1], V3(d.pose[2 * (size_t)i]), Q4(d.pose[2 * (size_t)i + 1]));
 			continue;

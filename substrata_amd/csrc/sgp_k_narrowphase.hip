@@ -122,7 +122,7 @@ template <bool HULLS> __global__ void __launch_bounds__(TPB, 4) k_narrowphase_wa
 // What those contacts wake in turn -- two islands that went to sleep apart and touch -- is woken too but meets its other contacts next step.
 SGP_DEV bool body_woken(const DV& d, uint32_t j, uint32_t fj, uint32_t epoch)
 {
-	return (fj & (BF_ALIVE | BF_ACTIVE | BF_ALIAS)) == BF_ALIVE && f_motion(fj) == SGP_MOTION_DYNAMIC && d.label_wake[d.sleep_label[j]] == epoch;
+	return (fj & (BF_ALIVE | BF_ACTIVE | BF_ALIAS)) == BF_ALIVE && f_motion(fj) == SGP_MOTION_DYNAMIC && label_current(d, d.sleep_label[j]) && d.label_wake[SGP_LABEL_SLOT(d.sleep_label[j])] == epoch;
 }
 __global__ void __launch_bounds__(TPB) k_wake_pairs(DV d)
 {

@@ -268,7 +268,7 @@ SGP_DEV void sleep_apply_one(const DV& d, uint32_t i, bool& active)
 		if ((f & BF_CAN_SLEEP) && !d.awake_mark[i] && d.island_awake[root = uf_find(d.island, i)] == 0) {
 			f &= ~(BF_ACTIVE | BF_CAN_SLEEP);
 			d.flags[i] = f;
-			d.sleep_label[i] = root;        // the island goes to sleep as a whole and is remembered by its root: what wakes a member wakes them all (k_wake_pairs)
+			d.sleep_label[i] = SGP_LABEL(root, d.slot_gen[root] & 0x7Fu);        // the island goes to sleep as a whole and is remembered by its root: what wakes a member wakes them all (k_wake_pairs)
 			// (the record of a body that is not awake reads (0, 0, 0 | effective inverse mass 0): k_pre_solve then has nothing to write for it)
 			d.vel[2 * (size_t)i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 			d.vel[2 * (size_t)i + 1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);

@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(TPB) k_create_from_records(DV d, const sgp_gho
 	d.prop[2 * (size_t)i + 1] = make_float4(r.shape[0], r.shape[1], r.shape[2], friction);
 	d.submerged[i] = 0.0f;
 	d.userdata[i] = r.userdata;
-	d.sleep_label[i] = i;
+	label_new_body(d, i);
 	refresh_aabb(d, i, f);
 	reset_sleep(d, i, f_shape(f), d.prop[2 * (size_t)i + 1], V3(d.pose[2 * (size_t)i]), Q4(d.pose[2 * (size_t)i + 1]));
 	f = activate_body(d, i, f);      // (both kinds arrive awake: d.activate = 1 in make_ghost and in the take-over)

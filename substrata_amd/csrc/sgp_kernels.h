@@ -44,6 +44,8 @@
 #define BF_MOVABLE_PREV  (1u << 16)  // movable (dynamic and awake) when the PREVIOUS step coloured its constraints
 #define BF_MOVABLE_CUR   (1u << 17)  // same, this step
 
+#define SGP_LABEL(slot, gen) ((uint32_t)(slot) | ((uint32_t)(gen) << 25))      // (max_bodies < 2^25)
+#define SGP_LABEL_SLOT(l) ((l) & 0x1FFFFFFu)
 #define SGP_SMALL_COLOURING_MANIFOLDS 4096   // at most this many manifolds last step: colouring rounds run inside one workgroup
 #define SGP_ISLAND_MARK_ROUNDS 3   // marking rounds before the island union-find (k_island_mark)
 #define SGP_MAX_COLOURS      64
@@ -237,7 +239,9 @@ struct DV {
 	float4* aabb_max;
 	float4* sleep_s[3];        // sleep test spheres: centre xyz, radius w
 	float*  sleep_timer;
-	uint32_t* sleep_label;     // the island a body fell asleep with (the root its union-find ended with; its own id from creation): bodies that share it wake together
+	uint32_t* sleep_label;     // LABEL(slot, generation): the island a body fell asleep with (the root its union-find ended with; itself from creation): bodies that share it wake together
+	uint32_t* slot_gen;        // [slot] how often the slot has been given to a new body (7 bits used): a label made from a slot is current only while that body lives in it --
+	                           //   a body created in the slot a removed island root left must not share the wake label of that island's sleepers (round 6)
 	uint32_t* label_wake;      // [label] = the step epoch (*veh_epoch) in which a body with that label was woken
 	uint2*  wake_pairs; uint32_t cap_wake_pairs;      // pairs of the woken bodies with what was not awake when the step began
 	float*  submerged;

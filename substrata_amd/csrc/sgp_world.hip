@@ -172,8 +172,9 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	DEV_ALLOC(d.bounds_acc, 8); { const int init[8] = { 0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000, (int)0x80000000, 0, 0 }; if (hipMemcpyAsync(d.bounds_acc, init, sizeof(init), hipMemcpyHostToDevice, w->stream) != hipSuccess || hipStreamSynchronize(w->stream) != hipSuccess) return fail(SGP_ERR_HIP, "bounds_acc init"); } DEV_ALLOC(d.scan_block_sums, (d.table_size + 1) / 1024 + 2);
 	DEV_ALLOC(d.pairs, P);
 	d.cap_wake_pairs = P / 4 + 1024; DEV_ALLOC(d.wake_pairs, d.cap_wake_pairs);
-	DEV_ALLOC(d.sleep_label, N); DEV_ALLOC(d.label_wake, N);
+	DEV_ALLOC(d.sleep_label, N); DEV_ALLOC(d.label_wake, N); DEV_ALLOC(d.slot_gen, N);
 	HIP_TRY(hipMemsetAsync(d.label_wake, 0, sizeof(uint32_t) * N, w->stream));
+	HIP_TRY(hipMemsetAsync(d.slot_gen, 0, sizeof(uint32_t) * N, w->stream));
 	DEV_ALLOC(d.man_ab, M); DEV_ALLOC(d.man_n, M); DEV_ALLOC(d.man_colour, M); DEV_ALLOC(d.man_prio, M); DEV_ALLOC(d.man_prev, M); DEV_ALLOC(d.man_slot, M);
 	DEV_ALLOC(d.hc_root, N); DEV_ALLOC(d.hc_count, N); DEV_ALLOC(d.hc_base, N); DEV_ALLOC(d.hc_rank, M);
 	// tile solver: one workgroup per compute unit must be resident, so the tile grid follows the device (256 CUs: 16 x 16)

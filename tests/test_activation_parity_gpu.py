@@ -116,3 +116,18 @@ def test_a_wheel_wakes_the_island_under_it(oracle):
             assert tw.gpu.stats().num_wake_pairs == tw.cpu.stats().num_wake_pairs > 0
     assert woke is not None, "the car never reached the plate"
     tw.close()
+
+
+def test_stale_label_after_slot_reuse_matches_the_oracle(oracle):
+    """the label generations of round 6 on the device: the scene of tests/test_oracle_kat2.py (a body created in the slot of a removed island root), bit for bit"""
+    from test_oracle_kat2 import stale_label_scene
+    tw = parity.make_twin(oracle, max_bodies=64)
+    out = [stale_label_scene(w) for w in (tw.gpu, tw.cpu)]
+    assert out[0] == out[1]
+    rest, new = out[0]
+    _both(tw, lambda w: dyn(w, abi.SHAPE_SPHERE, (0.2,), pos=(20.0, 0.0, 1.6), mass=5.0))
+    for s in range(90):
+        tw.step(DT)
+        _exact(tw, 8, f"step {s}")
+        assert not any(x["active"] for x in tw.gpu.get_state(rest))
+    tw.close()

@@ -159,3 +159,57 @@ def test_body_pair_contact_cache_reuses_resting_box_manifolds(oracle):
         w.step(DT)
     assert w.stats().num_cached_manifolds == 0 and w.stats().num_manifolds == 3
     w.close()
+
+
+def _uf_prio(x):
+    h = (x * 0x9E3779B1) & 0xFFFFFFFF; h ^= h >> 15; h = (h * 0x85EBCA6B) & 0xFFFFFFFF; h ^= h >> 13
+    return h
+
+
+def stale_label_scene(w):
+    """Three boxes stacked, asleep; the member the island is remembered by (lowest uf_prio: the label) sits on TOP and is removed, a new box is created in its
+    slot somewhere else and falls asleep there.  Returns (the two boxes left of the stack, the new box)."""
+    from helpers import add_ground, dyn
+    add_ground(w)
+    ids = [dyn(w, pos=(0, 0, 10.0 + k)) for k in range(3)]                     # (parked high up; placed below)
+    order = sorted(ids, key=_uf_prio)                                           # order[0] = the island's label
+    for z, i in zip((2.5, 1.5, 0.5), order):
+        w.set_pose_vel(i, (0.0, 0.0, z), (0, 0, 0, 1))
+    for _ in range(300):
+        w.step(DT)
+    assert not any(s["active"] for s in w.get_state(ids))
+    w.remove(order[0])
+    new = dyn(w, pos=(20.0, 0.0, 0.5))
+    assert new == order[0]                                                      # the freed slot is handed out again
+    for _ in range(200):
+        w.step(DT)
+    st = w.get_state(order[1:] + [new])
+    assert not any(s["active"] for s in st)
+    return order[1:], new
+
+
+def test_a_body_created_in_a_removed_island_roots_slot_does_not_wake_that_island(oracle):
+    """sleep labels were bare slot ids, so a body created in the slot of a removed island root shared the wake label of the island's
+    sleepers -- poking the newcomer woke a stack twenty metres away.  Labels now carry the slot's generation."""
+    from helpers import dyn
+    from substrata_amd import abi
+    w = oracle.OracleWorld(max_bodies=64)
+    rest, new = stale_label_scene(w)
+    dyn(w, abi.SHAPE_SPHERE, (0.2,), pos=(20.0, 0.0, 1.6), mass=5.0)            # a ball drops on the newcomer
+    woke_new = False
+    for _ in range(90):
+        w.step(DT)
+        woke_new = woke_new or bool(w.get_state([new])[0]["active"])
+        assert not any(s["active"] for s in w.get_state(rest))                  # the old stack sleeps on
+    assert woke_new
+    # ... and the cascade itself still works: a ball on the old stack wakes both of its boxes in the step of the touch
+    dyn(w, abi.SHAPE_SPHERE, (0.2,), pos=(0.0, 0.0, 2.4), mass=5.0)
+    first = None
+    for s_ in range(60):
+        w.step(DT)
+        act = [bool(s["active"]) for s in w.get_state(rest)]
+        if first is None and any(act):
+            first = s_
+            assert all(act)
+    assert first is not None
+    w.close()
