@@ -286,8 +286,12 @@ template <int PCAP> SGP_DEV void stage_pair(const DV& d, uint2* spairs, uint8_t*
 // launch: 70 KB of LDS = 2 workgroups per CU, 37 KB = 4 (config 3: 130 -> 83 us; its halos hold 500-640 records).  The small instance serves scenes whose halos hold at most
 // BP_LDS_CAP_SMALL records (k_bp_pairs reports a larger one in StepCounters::bp_dense, the next step's plan then takes the large instance);
 // a halo above the instance's capacity is read from global memory either way.
+#ifndef BP_LDS_CAP_SMALL
 #define BP_LDS_CAP_SMALL 768
+#endif
+#ifndef BP_PAIR_CAP_SMALL
 #define BP_PAIR_CAP_SMALL 1024
+#endif
 #define BP_LDS_CAP_LARGE 1536
 #define BP_PAIR_CAP_LARGE 2048
 #ifndef BP_SPLIT

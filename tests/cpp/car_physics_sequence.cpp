@@ -10,7 +10,8 @@
 //              VehicleConstraint::{GetWheelLocalBasis, GetWheelLocalTransform, GetWheelWorldTransform}
 //   tear-down  PhysicsSystem::RemoveConstraint / RemoveStepListener, PhysicsWorld::removeObject; BodyLockRead and SubShapeID::PopID on the way
 // The scenario: settle, accelerate, steer, coast, get thrown on the roof and turned back by an upright-seeking torque, brake.
-// (Which reference lines use each of these symbols is checked against /root/reference at test time by tests/test_reference_members.py.)
+// (Which reference lines use each of these symbols is checked against /root/reference at test time by tests/test_reference_members.py; the Jolt include
+// paths below are the caller's own list, which tests/test_facade_gpu.py holds this file to.)
 #include "PhysicsWorld.h"
 #include "JoltUtils.h"
 #include <utils/Exception.h>
@@ -18,6 +19,9 @@
 #include <Jolt/Physics/Collision/ObjectLayer.h>
 #include <Jolt/Physics/Vehicle/VehicleConstraint.h>
 #include <Jolt/Physics/PhysicsSystem.h>
+#include <Jolt/Physics/Collision/Shape/CapsuleShape.h>
+#include <Jolt/Physics/Collision/Shape/RotatedTranslatedShape.h>
+#include <Jolt/Physics/Collision/Shape/BoxShape.h>
 #include <Jolt/Physics/Collision/Shape/OffsetCenterOfMassShape.h>
 #include <Jolt/Physics/Vehicle/WheeledVehicleController.h>
 #include <Jolt/Physics/Body/BodyCreationSettings.h>
