@@ -125,6 +125,7 @@ SGP_API int sgp_mesh_create(sgp_world* w, const float* verts, uint32_t nv, const
 }
 SGP_API int sgp_mesh_create_with_materials(sgp_world* w, const float* verts, uint32_t nv, const uint32_t* idx, uint32_t nt, const uint32_t* tri_mats, sgp_mesh_info* info)
 {
+	if (w) ray_server_stop(w);      // (a resident ray server must not keep this call's stream work waiting: ADVICE r05)
 	if (!w || !verts || !idx || !info || nv < 3 || nt < 1) return fail(SGP_ERR_INVALID, "sgp_mesh_create: bad arguments");
 	for (uint32_t k = 0; k < 3 * nt; ++k) if (idx[k] >= nv) return fail(SGP_ERR_INVALID, "sgp_mesh_create: vertex index out of range");
 	for (uint32_t k = 0; k < 3 * nv; ++k) if (!std::isfinite(verts[k])) return fail(SGP_ERR_INVALID, "sgp_mesh_create: non-finite vertex");
@@ -199,6 +200,7 @@ SGP_API int sgp_mesh_edge_flags(sgp_world* w, uint32_t mesh_id, uint8_t* out, ui
 
 SGP_API int sgp_mesh_destroy(sgp_world* w, uint32_t id)
 {
+	if (w) ray_server_stop(w);      // (a resident ray server must not keep this call's stream work waiting: ADVICE r05)
 	if (!w || id < 1 || id >= w->meshes.size() || w->meshes[id].nt == 0) return fail(SGP_ERR_BAD_ID, "sgp_mesh_destroy: no such mesh");
 	if (w->mesh_refs[id] != 0) return fail(SGP_ERR_REJECTED, "sgp_mesh_destroy: a body still uses the mesh");
 	hipSetDevice(w->device);
@@ -217,6 +219,7 @@ SGP_API int sgp_mesh_destroy(sgp_world* w, uint32_t id)
 
 SGP_API int sgp_hull_create_com(sgp_world* w, const float* pts, uint32_t n, const float* com_offset, sgp_hull_info* info)
 {
+	if (w) ray_server_stop(w);      // (a resident ray server must not keep this call's stream work waiting: ADVICE r05)
 	if (!w || !pts || !info || n < 4 || n > 100000) return fail(SGP_ERR_INVALID, "sgp_hull_create: bad arguments");
 	hipSetDevice(w->device);
 	sgd_hull h;
@@ -245,6 +248,7 @@ SGP_API int sgp_hull_create_com(sgp_world* w, const float* pts, uint32_t n, cons
 SGP_API int sgp_hull_create(sgp_world* w, const float* pts, uint32_t n, sgp_hull_info* info) { return sgp_hull_create_com(w, pts, n, nullptr, info); }
 SGP_API int sgp_hull_destroy(sgp_world* w, uint32_t id)
 {
+	if (w) ray_server_stop(w);      // (a resident ray server must not keep this call's stream work waiting: ADVICE r05)
 	if (!w || id < 1 || id >= w->hulls.size() || w->hulls[id].nv == 0) return fail(SGP_ERR_BAD_ID, "sgp_hull_destroy: no such hull");
 	if (w->hull_refs[id] != 0) return fail(SGP_ERR_REJECTED, "sgp_hull_destroy: a body still uses the hull");
 	hipSetDevice(w->device);
@@ -416,6 +420,7 @@ static inline bool vehicle_live(const sgp_world* w, uint32_t id) { return w && i
 
 SGP_API int sgp_vehicle_create(sgp_world* w, const sgp_vehicle_desc* d, uint32_t* id_out)
 {
+	if (w) ray_server_stop(w);      // (a resident ray server must not keep this call's stream work waiting: ADVICE r05)
 	if (!w || !d || !id_out) return fail(SGP_ERR_INVALID, "sgp_vehicle_create: NULL");
 	if (!live(w, d->body) || (w->hb[d->body].flags & BF_MOTION_MASK) != SGP_MOTION_DYNAMIC) return fail(SGP_ERR_BAD_ID, "sgp_vehicle_create: the chassis must be a live dynamic body");
 	if (!vehicle_desc_valid(d)) return fail(SGP_ERR_INVALID, "sgp_vehicle_create: bad vehicle description");
@@ -468,6 +473,7 @@ SGP_API int sgp_vehicle_create(sgp_world* w, const sgp_vehicle_desc* d, uint32_t
 
 SGP_API int sgp_vehicle_destroy(sgp_world* w, uint32_t id)
 {
+	if (w) ray_server_stop(w);      // (a resident ray server must not keep this call's stream work waiting: ADVICE r05)
 	if (!vehicle_live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_vehicle_destroy: id not live");
 	hipSetDevice(w->device);
 	const int zero = 0;
@@ -503,6 +509,7 @@ static void hvec_out(float* o, v3 v) { o[0] = v.x; o[1] = v.y; o[2] = v.z; }
 
 SGP_API int sgp_vehicle_get_states(sgp_world* w, uint32_t first, uint32_t n, sgp_vehicle_state* out)
 {
+	if (w) ray_server_stop(w);      // (a resident ray server must not keep this call's stream work waiting: ADVICE r05)
 	if (!w || (!out && n)) return fail(SGP_ERR_INVALID, "sgp_vehicle_get_states: NULL");
 	for (uint32_t k = 0; k < n; ++k) if (!vehicle_live(w, first + k)) return fail(SGP_ERR_BAD_ID, "sgp_vehicle_get_states: id not live");
 	if (!n) return SGP_OK;
@@ -533,6 +540,7 @@ SGP_API int sgp_vehicle_get_state(sgp_world* w, uint32_t id, sgp_vehicle_state* 
 
 SGP_API int sgp_vehicle_enable_lean_controller(sgp_world* w, uint32_t id, int enabled)
 {
+	if (w) ray_server_stop(w);      // (a resident ray server must not keep this call's stream work waiting: ADVICE r05)
 	if (!vehicle_live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_vehicle_enable_lean_controller: id not live");
 	hipSetDevice(w->device);
 	sgd_vehicle rec;
@@ -548,6 +556,7 @@ SGP_API int sgp_vehicle_enable_lean_controller(sgp_world* w, uint32_t id, int en
 
 SGP_API int sgp_vehicle_reset_drivetrain(sgp_world* w, uint32_t id, float rpm, float wheel_w)
 {
+	if (w) ray_server_stop(w);      // (a resident ray server must not keep this call's stream work waiting: ADVICE r05)
 	if (!vehicle_live(w, id)) return fail(SGP_ERR_BAD_ID, "sgp_vehicle_reset_drivetrain: id not live");
 	hipSetDevice(w->device);
 	sgd_vehicle rec;

@@ -306,6 +306,7 @@ SGP_API int sgp_world_device_array(sgp_world* w, int which, void** dev_ptr_out, 
 SGP_API int sgp_world_stream(sgp_world* w, void** stream_out)
 {
 	if (!w || !stream_out) return fail(SGP_ERR_INVALID, "sgp_world_stream: NULL");
+	ray_server_stop(w);      // (whoever asks for the stream is about to put work on it)
 	*stream_out = (void*)w->stream;
 	return SGP_OK;
 }

@@ -25,6 +25,7 @@ def main():
     last = len(begins) - 1 - a.skip_last
     sel = begins[last - a.steps:last + 1]
     dur = OrderedDict(); gap = OrderedDict(); cnt = OrderedDict()
+    by_pass = {}      # velocity pass (1 .. 10) -> [sum of the colour launches' durations, launches]: is the first pass, which meets the constraint rows cold, slower?
     span = kern = gaps = 0.0
     n_launch = 0
     for k in range(a.steps):
@@ -35,7 +36,10 @@ def main():
         end_i = max(ends)
         step = step[:end_i + 1]
         span += step[-1][1] - step[0][0]
+        vpass = 1
         for i, (s, e, n) in enumerate(step):
+            if n.startswith("void k_solve_colour<1"): bp = by_pass.setdefault(vpass, [0.0, 0]); bp[0] += e - s; bp[1] += 1
+            if n.startswith("void k_solve_hc<1") or n.startswith("void k_solve_tail_vel"): vpass += 1
             dur[n] = dur.get(n, 0.0) + (e - s); cnt[n] = cnt.get(n, 0) + 1
             kern += e - s
             if i:
@@ -50,6 +54,8 @@ def main():
     for n in sorted(dur, key=lambda x: -(dur[x] + gap.get(x, 0.0))):
         c = cnt[n]
         print(f"| {n} | {c / S:.1f} | {dur[n] / S / 1e3:.1f} | {dur[n] / c / 1e3:.2f} | {gap.get(n, 0.0) / S / 1e3:.1f} | {gap.get(n, 0.0) / c / 1e3:.2f} |")
+    if by_pass:
+        print("\nvelocity colour launches by pass (mean duration us): " + ", ".join(f"{k}: {v[0] / max(v[1], 1) / 1e3:.2f}" for k, v in sorted(by_pass.items())))
 
 
 if __name__ == "__main__":
