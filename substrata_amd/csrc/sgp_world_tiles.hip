@@ -767,6 +767,8 @@ SGP_API int sgp_tiles_exchange(sgp_tiles* t)
 	// buffer, all ranks route again and gather again (local growth in between; the steady state never gets here: one gather, one host round trip).  A
 	// rank whose growth fails does not return: it reports ROUTE_FAILED in the next gather, and then EVERY rank returns an error (SGP_ERR_PEER on the
 	// others) without having posted a send or a receive.  Between the last gather and ncclGroupEnd nothing can fail but the collective library itself.
+	// (What this cannot cover: a HIP runtime failure of the copies and the synchronisation inside the loop -- a rank whose device stops answering cannot tell
+	// anybody, with or without this protocol.)
 	uint32_t n_recv = 0;
 	bool settled = false;
 	for (int attempt = 0; attempt < 4 && !settled; ++attempt) {
@@ -838,6 +840,13 @@ SGP_API int sgp_tiles_exchange_group(sgp_tiles** ts, uint32_t n)
 			continue;
 		}
 		break;
+	}
+	// the receive buffers grow BEFORE any body is let go of (a growth that failed after the emigrants had been removed lost them)
+	for (uint32_t dst = 0; dst < n; ++dst) {
+		uint32_t need = 0;
+		for (uint32_t src = 0; src < n; ++src) if (src != dst) need += ((const RouteHeader*)ts[src]->h_ctl)->seg_count[dst];
+		hipSetDevice(ts[dst]->w->device);
+		{ int r = tiles_grow(ts[dst]->w, ts[dst]->d_recv, ts[dst]->cap_recv, std::max(need, 1u)); if (r != SGP_OK) return r; }
 	}
 	for (uint32_t i = 0; i < n; ++i) { hipSetDevice(ts[i]->w->device); int r = tiles_remove_emigrants(ts[i]); if (r != SGP_OK) return r; }
 	for (uint32_t dst = 0; dst < n; ++dst) {
