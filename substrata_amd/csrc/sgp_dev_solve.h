@@ -2,7 +2,7 @@
 // Device-inline functions only (no kernels), shared between stage files; included through sgp_dev_all.h, whose order is the dependency order.
 #pragma once
 
-// `vel` / VS: where the velocity records live -- the global array (vel = d.vel) or a workgroup's copy in LDS; VS = float4 per record (2).
+// `vel` / VS: where the velocity records live -- the global array (vel = d.vel) or a workgroup's copy in LDS; VS = float4 per record (VEL_F4 in the global array, 2 in LDS).
 // The world-space inverse inertia is derived here from the pose and property records (read-only during the solve).
 SGP_DEV sym33 body_world_inv_inertia(const DV& d, uint32_t body)
 {
@@ -11,7 +11,7 @@ SGP_DEV sym33 body_world_inv_inertia(const DV& d, uint32_t body)
 // the same matrix from the record k_pre_solve wrote for this step (compact rows only; bodies that cannot move have none and need none: their rows are never applied)
 SGP_DEV sym33 body_world_inv_inertia_rec(const DV& d, uint32_t body)
 {
-	const float4 a = d.iw[2 * (size_t)body], b = d.iw[2 * (size_t)body + 1];
+	const float4 a = d.vel[VEL_F4 * (size_t)body + 2], b = d.vel[VEL_F4 * (size_t)body + 3];
 	sym33 s; s.xx = a.x; s.xy = a.y; s.xz = a.z; s.yy = a.w; s.yz = b.x; s.zz = b.y;
 	return s;
 }
@@ -163,7 +163,7 @@ SGP_DEV void half_apply(v3& lv, v3& av, float im, v3 axis, v3 iv, float lambda, 
 
 // One contact manifold, one velocity iteration (ContactConstraintManager::SolveVelocityConstraints): friction rows of every point first (they
 // use the normal impulse of the previous iteration), then the non-penetration rows.  Both lanes of the constraint must call this together.
-// `vel` / VS: where the velocity records live (the global array d.vel or an LDS copy; VS = 2 float4 per record).
+// `vel` / VS: where the velocity records live (the global array d.vel or an LDS copy; VS float4 per record).
 // The arithmetic of half_solve on values: this lane's body's velocity record in (v4: linear velocity + effective inverse mass, w4: angular
 // velocity), the updated record out.  Returns whether the body can move (whether the record changed).
 SGP_DEV bool half_solve_core(ConHalf& h, int side, float4& v4, float4& w4, uint32_t dbg)

@@ -132,6 +132,7 @@ SGP_DEV static int sgd_capsule_capsule(const sgd_shape* a, const sgd_shape* b, f
 		const float lo = fmaxf(-ha, fminf(u0, u1)), hi = fminf(ha, fmaxf(u0, u1));
 		if (hi - lo > 1.0e-4f) {
 			const float us[2] = { lo, hi };
+#pragma unroll
 			for (int i = 0; i < 2; ++i) {
 				const v3 pa = v3_add(a->pos, v3_scale(axa, us[i]));
 				const float tb = clampf(v3_dot(v3_sub(pa, b->pos), axb), -hb, hb);
@@ -222,13 +223,14 @@ SGP_DEV static int sgd_box_capsule(const sgd_shape* b, const sgd_shape* c, float
 				if (ok && (t1 - t0) * (2.0f * hh) > 1.0e-4f) {
 					const float ts[2] = { t0, t1 };
 					int np = 0;
+#pragma unroll
 					for (int i = 0; i < 2; ++i) {
 						const v3 P = v3_add(s0, v3_scale(d, ts[i]));
 						const float sep = sg * v3_get(P, k) - v3_get(h, k) - r;
 						if (sep <= max_sep) {
 							v3 pb = P; v3_set(pb, k, sg * v3_get(h, k));
-							m->p1[np] = v3_add(b->pos, m33_mul(b->R, pb));
-							m->p2[np] = v3_add(b->pos, m33_mul(b->R, v3_sub(P, v3_scale(nl, r))));
+							const v3 x1 = v3_add(b->pos, m33_mul(b->R, pb)), x2 = v3_add(b->pos, m33_mul(b->R, v3_sub(P, v3_scale(nl, r))));
+							if (np == 0) { m->p1[0] = x1; m->p2[0] = x2; } else { m->p1[1] = x1; m->p2[1] = x2; }      // (static slots: the manifold stays in registers)
 							++np;
 						}
 					}
@@ -314,8 +316,62 @@ SGP_DEV static void sgd_reduce_manifold(sgd_manifold* m)
 	m->np = k;
 }
 
+// ---- polygons in LDS, one column per lane (corner i, component c of lane l at [(3 i + c) * 64 + l]: no bank conflicts), indexed at run time by plain loops ----
+// (first used by the triangle - box manifold of the mesh kernels, sgp_device_mesh.h, which tells why; round 6: the box - box clip of k_narrowphase)
+#define SGD_LPOLY_FLOATS (8 * 3 * 64)      // one polygon column set for the 64 lanes of a wave
+struct sgd_lpoly { float* b; };             // b = the wave's buffer + lane
+SGP_DEV static v3 sgd_lp_get(sgd_lpoly a, int i) { return V3(a.b[(3 * i) * 64], a.b[(3 * i + 1) * 64], a.b[(3 * i + 2) * 64]); }
+SGP_DEV static void sgd_lp_set(sgd_lpoly a, int i, v3 v) { a.b[(3 * i) * 64] = v.x; a.b[(3 * i + 1) * 64] = v.y; a.b[(3 * i + 2) * 64] = v.z; }
+// = sgd_hull_reduce / sgd_reduce_manifold for <= 8 candidate points in LDS; writes m->n, m->np, m->p1 / p2 [0 .. 3] (static slots: the manifold stays in registers)
+SGP_DEV static void sgd_lp_reduce(v3 n, sgd_lpoly P1, sgd_lpoly P2, int np, sgd_manifold* m)
+{
+	m->n = n;
+	int pick[4] = { 0, 1, 2, 3 }; int k = np;
+	if (np > 4) {
+		int i0 = 0; float best = -3.4e38f;
+		for (int i = 0; i < np; ++i) { const float pen = v3_dot(v3_sub(sgd_lp_get(P1, i), sgd_lp_get(P2, i)), n); if (pen > best) { best = pen; i0 = i; } }
+		const v3 p0 = sgd_lp_get(P1, i0);
+		int i1 = i0; best = -1.0f;
+		for (int i = 0; i < np; ++i) { const float d2 = v3_len_sq(v3_sub(sgd_lp_get(P1, i), p0)); if (d2 > best) { best = d2; i1 = i; } }
+		const v3 e = v3_sub(sgd_lp_get(P1, i1), p0);
+		int i2 = -1, i3 = -1; float amax = 0.0f, amin = 0.0f;
+		for (int i = 0; i < np; ++i) {
+			if (i == i0 || i == i1) continue;
+			const float area = v3_dot(v3_cross(e, v3_sub(sgd_lp_get(P1, i), p0)), n);
+			if (area > amax) { amax = area; i2 = i; }
+			if (area < amin) { amin = area; i3 = i; }
+		}
+		// the survivors in the order i0, i1 (unless it is i0), i2, i3 (those that exist)
+		k = 0;
+		pick[0] = i0; k = 1;
+		if (i1 != i0) { pick[1] = i1; k = 2; }
+		if (i2 >= 0) { if (k == 1) pick[1] = i2; else pick[2] = i2; ++k; }
+		if (i3 >= 0) { if (k == 1) pick[1] = i3; else if (k == 2) pick[2] = i3; else pick[3] = i3; ++k; }
+	}
+#pragma unroll
+	for (int j = 0; j < 4; ++j) if (j < k) { m->p1[j] = sgd_lp_get(P1, pick[j]); m->p2[j] = sgd_lp_get(P2, pick[j]); }
+	m->np = k;
+}
+
 /* A = box, B = box: 15-axis SAT, then reference-face / incident-face clipping or an edge-edge point. */
-SGP_DEV static int sgd_box_box(const sgd_shape* A, const sgd_shape* B, float max_sep, sgd_manifold* m)
+// LDS = true: the clip polygons and the (up to eight) candidate points live in two LDS polygon columns of the lane (lds = the wave's 2 x SGD_LPOLY_FLOATS + lane)
+// instead of arrays indexed at run time, i.e. scratch: at 1 M bodies k_narrowphase moved 8 GB of scratch per launch for 0.9 GB of pairs, bodies and manifolds
+// (profiles/NOTES_r06.md 7).  Same expressions, same order of corners and planes: the same bits.
+SGP_DEV static int sgd_clip_poly_lds(sgd_lpoly in, int n, int axis, float sgn, float lim, sgd_lpoly out)
+{
+	int m = 0;
+	for (int i = 0; i < n; ++i) {
+		const v3 a = sgd_lp_get(in, i), b = sgd_lp_get(in, i + 1 < n ? i + 1 : 0);
+		const float da = sgn * v3_get(a, axis) - lim, db = sgn * v3_get(b, axis) - lim;
+		if (da <= 0.0f) { if (m < 8) sgd_lp_set(out, m++, a); }
+		if ((da <= 0.0f) != (db <= 0.0f)) {
+			const float t = da / (da - db);
+			if (m < 8) sgd_lp_set(out, m++, v3_add(a, v3_scale(v3_sub(b, a), t)));
+		}
+	}
+	return m;
+}
+template <bool LDS = false> SGP_DEV static int sgd_box_box(const sgd_shape* A, const sgd_shape* B, float max_sep, sgd_manifold* m, float* lds = nullptr)
 {
 	const v3 hA = V3(A->p0, A->p1, A->p2), hB = V3(B->p0, B->p1, B->p2);
 	const v3 T = v3_sub(B->pos, A->pos);
@@ -390,16 +446,42 @@ SGP_DEV static int sgd_box_box(const sgd_shape* A, const sgd_shape* B, float max
 	const int u = (j + 1) % 3, v = (j + 2) % 3;
 	const v3 yu = v3_scale(m33_col(Y->R, u), v3_get(hY, u)), yv = v3_scale(m33_col(Y->R, v), v3_get(hY, v));
 	const v3 fc = v3_add(Y->pos, v3_scale(m33_col(Y->R, j), sj * v3_get(hY, j)));
-	// (arrays indexed at run time: 560 B of scratch per lane of k_narrowphase.  The same clip with its polygons in registers -- eight slots and a count, corners
-	// appended by select chains, no run-time index -- was measured here and is SLOWER: k_narrowphase runs four waves per SIMD on 128 registers, the four
-	// polygons spill as much as the arrays held, and the select chains are instructions the scratch accesses were not: config 3 108 -> 124 us.)
-	v3 poly[8], tmp[8];
 	const v3 w0 = v3_add(v3_add(fc, yu), yv), w1 = v3_add(v3_sub(fc, yu), yv);
 	const v3 w2 = v3_sub(v3_sub(fc, yu), yv), w3 = v3_sub(v3_add(fc, yu), yv);
+	const int a1 = (k + 1) % 3, a2 = (k + 2) % 3;
+	if constexpr (LDS) {
+		sgd_lpoly P, Q; P.b = lds; Q.b = lds + SGD_LPOLY_FLOATS;
+		sgd_lp_set(P, 0, m33_tmul(X->R, v3_sub(w0, X->pos))); sgd_lp_set(P, 1, m33_tmul(X->R, v3_sub(w1, X->pos)));
+		sgd_lp_set(P, 2, m33_tmul(X->R, v3_sub(w2, X->pos))); sgd_lp_set(P, 3, m33_tmul(X->R, v3_sub(w3, X->pos)));
+		int np = 4;
+		np = sgd_clip_poly_lds(P, np, a1, 1.0f, v3_get(hX, a1), Q);
+		np = sgd_clip_poly_lds(Q, np, a1, -1.0f, v3_get(hX, a1), P);
+		np = sgd_clip_poly_lds(P, np, a2, 1.0f, v3_get(hX, a2), Q);
+		np = sgd_clip_poly_lds(Q, np, a2, -1.0f, v3_get(hX, a2), P);
+		// the candidates over the polygon they come from: slot cnt <= i is written after corner i was read (P: points on body 1, Q: on body 2)
+		int cnt = 0;
+		for (int i = 0; i < np; ++i) {
+			const v3 pi = sgd_lp_get(P, i);
+			const float sep = sg * v3_get(pi, k) - v3_get(hX, k);
+			if (sep <= max_sep) {
+				v3 pr = pi; v3_set(pr, k, sg * v3_get(hX, k));
+				const v3 wi = v3_add(X->pos, m33_mul(X->R, pi));   /* on Y */
+				const v3 wr = v3_add(X->pos, m33_mul(X->R, pr));   /* on X */
+				sgd_lp_set(P, cnt, refA ? wr : wi); sgd_lp_set(Q, cnt, refA ? wi : wr);
+				++cnt;
+			}
+		}
+		if (cnt == 0) return 0;
+		sgd_lp_reduce(refA ? nref : v3_neg(nref), P, Q, cnt, m);
+		return 1;
+	} else {
+	// (arrays indexed at run time: scratch.  The same clip with its polygons in registers -- eight slots and a count, corners appended by select chains, no
+	// run-time index -- was measured here and is SLOWER: k_narrowphase runs four waves per SIMD on 128 registers, the four polygons spill as much as the
+	// arrays held, and the select chains are instructions the scratch accesses were not: config 3 108 -> 124 us.  k_narrowphase itself takes the LDS branch above.)
+	v3 poly[8], tmp[8];
 	poly[0] = m33_tmul(X->R, v3_sub(w0, X->pos)); poly[1] = m33_tmul(X->R, v3_sub(w1, X->pos));
 	poly[2] = m33_tmul(X->R, v3_sub(w2, X->pos)); poly[3] = m33_tmul(X->R, v3_sub(w3, X->pos));
 	int np = 4;
-	const int a1 = (k + 1) % 3, a2 = (k + 2) % 3;
 	np = sgd_clip_poly(poly, np, a1, 1.0f, v3_get(hX, a1), tmp);
 	np = sgd_clip_poly(tmp, np, a1, -1.0f, v3_get(hX, a1), poly);
 	np = sgd_clip_poly(poly, np, a2, 1.0f, v3_get(hX, a2), tmp);
@@ -420,12 +502,14 @@ SGP_DEV static int sgd_box_box(const sgd_shape* A, const sgd_shape* B, float max
 	m->np = cnt;
 	sgd_reduce_manifold(m);
 	return 1;
+	}
 }
 
 SGP_DEV static void sgd_flip_manifold(sgd_manifold* m)
 {
 	m->n = v3_neg(m->n);
-	for (int i = 0; i < m->np; ++i) { const v3 t = m->p1[i]; m->p1[i] = m->p2[i]; m->p2[i] = t; }
+#pragma unroll
+	for (int i = 0; i < 4; ++i) if (i < m->np) { const v3 t = m->p1[i]; m->p1[i] = m->p2[i]; m->p2[i] = t; }      // (a finished manifold: at most four points; static slots)
 }
 
 /* Dispatch on the (type_a, type_b) pair; canonical order sphere < box < capsule. */
@@ -455,7 +539,7 @@ SGP_DEV static int sgd_collide_hull(const sgd_shape* a, const sgd_shape* b, floa
 	return hit;
 }
 
-SGP_DEV static int sgd_collide(const sgd_shape* a, const sgd_shape* b, float max_sep, sgd_manifold* m)
+template <bool LDS = false> SGP_DEV static int sgd_collide(const sgd_shape* a, const sgd_shape* b, float max_sep, sgd_manifold* m, float* lds = nullptr)
 {
 	int hit, flip = 0;
 	const sgd_shape* x = a; const sgd_shape* y = b;
@@ -465,7 +549,7 @@ SGP_DEV static int sgd_collide(const sgd_shape* a, const sgd_shape* b, float max
 		else if (y->type == SGD_SHAPE_BOX) hit = sgd_sphere_box(x, y, max_sep, m);
 		else hit = sgd_sphere_capsule(x, y, max_sep, m);
 	} else if (x->type == SGD_SHAPE_BOX) {
-		if (y->type == SGD_SHAPE_BOX) hit = sgd_box_box(x, y, max_sep, m);
+		if (y->type == SGD_SHAPE_BOX) hit = sgd_box_box<LDS>(x, y, max_sep, m, lds);
 		else hit = sgd_box_capsule(x, y, max_sep, m);
 	} else hit = sgd_capsule_capsule(x, y, max_sep, m);
 	if (hit && flip) sgd_flip_manifold(m);

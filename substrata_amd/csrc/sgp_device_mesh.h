@@ -243,10 +243,7 @@ SGP_DEV static int sgd_tri_box_sat(const sgd_tri_view* T, const sgd_hview* B, co
 // column per lane (corner i, component c of lane l at [(3 i + c) * 64 + l]: no bank conflicts), indexed at run time by plain loops: a few hundred
 // instructions.  A triangle and a quad never make a polygon of more than seven corners (sgd_hull_clip), so eight slots do.
 // The arithmetic -- every expression, the order of the corners, the order of the clip planes, "first minimum wins" -- is the general routine's: same bits.
-#define SGD_LPOLY_FLOATS (8 * 3 * 64)      // one polygon column set for the 64 lanes of a wave
-struct sgd_lpoly { float* b; };             // b = the wave's buffer + lane
-SGP_DEV static v3 sgd_lp_get(sgd_lpoly a, int i) { return V3(a.b[(3 * i) * 64], a.b[(3 * i + 1) * 64], a.b[(3 * i + 2) * 64]); }
-SGP_DEV static void sgd_lp_set(sgd_lpoly a, int i, v3 v) { a.b[(3 * i) * 64] = v.x; a.b[(3 * i + 1) * 64] = v.y; a.b[(3 * i + 2) * 64] = v.z; }
+// (SGD_LPOLY_FLOATS, sgd_lpoly, sgd_lp_get / sgd_lp_set / sgd_lp_reduce: sgp_device_collide.h -- the box - box clip of k_narrowphase uses them too)
 // = sgd_hull_clip<8>: the half space (p - a) . side <= 0
 SGP_DEV static int sgd_lp_clip(sgd_lpoly in, int n, v3 a, v3 side, sgd_lpoly out)
 {
@@ -261,36 +258,6 @@ SGP_DEV static int sgd_lp_clip(sgd_lpoly in, int n, v3 a, v3 side, sgd_lpoly out
 		}
 	}
 	return m;
-}
-// = sgd_hull_reduce for <= 8 candidate points in LDS; writes m->n, m->np, m->p1 / p2 [0 .. 3] (static slots: the manifold stays in registers)
-SGP_DEV static void sgd_lp_reduce(v3 n, sgd_lpoly P1, sgd_lpoly P2, int np, sgd_manifold* m)
-{
-	m->n = n;
-	int pick[4] = { 0, 1, 2, 3 }; int k = np;
-	if (np > 4) {
-		int i0 = 0; float best = -3.4e38f;
-		for (int i = 0; i < np; ++i) { const float pen = v3_dot(v3_sub(sgd_lp_get(P1, i), sgd_lp_get(P2, i)), n); if (pen > best) { best = pen; i0 = i; } }
-		const v3 p0 = sgd_lp_get(P1, i0);
-		int i1 = i0; best = -1.0f;
-		for (int i = 0; i < np; ++i) { const float d2 = v3_len_sq(v3_sub(sgd_lp_get(P1, i), p0)); if (d2 > best) { best = d2; i1 = i; } }
-		const v3 e = v3_sub(sgd_lp_get(P1, i1), p0);
-		int i2 = -1, i3 = -1; float amax = 0.0f, amin = 0.0f;
-		for (int i = 0; i < np; ++i) {
-			if (i == i0 || i == i1) continue;
-			const float area = v3_dot(v3_cross(e, v3_sub(sgd_lp_get(P1, i), p0)), n);
-			if (area > amax) { amax = area; i2 = i; }
-			if (area < amin) { amin = area; i3 = i; }
-		}
-		// the survivors in the order i0, i1 (unless it is i0), i2, i3 (those that exist)
-		k = 0;
-		pick[0] = i0; k = 1;
-		if (i1 != i0) { pick[1] = i1; k = 2; }
-		if (i2 >= 0) { if (k == 1) pick[1] = i2; else pick[2] = i2; ++k; }
-		if (i3 >= 0) { if (k == 1) pick[1] = i3; else if (k == 2) pick[2] = i3; else pick[3] = i3; ++k; }
-	}
-#pragma unroll
-	for (int j = 0; j < 4; ++j) if (j < k) { m->p1[j] = sgd_lp_get(P1, pick[j]); m->p2[j] = sgd_lp_get(P2, pick[j]); }
-	m->np = k;
 }
 // the triangle of a thin hull view, in registers: corners relative to the centroid (mesh frame), unit normal, plane offset of the front face
 struct sgd_tri_regs { v3 pos; m33 R; v3 v0, v1, v2; v3 n; float d0; };

@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(TPB) k_setup(DV d)
 		if (reused) { const float4* rec = PRV(d).prec + (size_t)fslot * PREC_F4; pr0 = rec[0]; pr1 = rec[1]; pr2 = rec[2]; }
 		// per body: pose record, velocity record (velocities after gravity + the effective inverse mass: k_pre_solve), property record
 		const float4 pa4 = d.pose[2 * (size_t)ab.x], qa4 = d.pose[2 * (size_t)ab.x + 1], pb4 = d.pose[2 * (size_t)ab.y], qb4 = d.pose[2 * (size_t)ab.y + 1];
-		const float4 va4 = d.vel[2 * (size_t)ab.x], wa4 = d.vel[2 * (size_t)ab.x + 1], vb4 = d.vel[2 * (size_t)ab.y], wb4 = d.vel[2 * (size_t)ab.y + 1];
+		const float4 va4 = d.vel[VEL_F4 * (size_t)ab.x], wa4 = d.vel[VEL_F4 * (size_t)ab.x + 1], vb4 = d.vel[VEL_F4 * (size_t)ab.y], wb4 = d.vel[VEL_F4 * (size_t)ab.y + 1];
 		const float4 ia4 = d.prop[2 * (size_t)ab.x], sa4 = d.prop[2 * (size_t)ab.x + 1], ib4 = d.prop[2 * (size_t)ab.y], sb4 = d.prop[2 * (size_t)ab.y + 1];
 		const v3 posA = V3(pa4), posB = V3(pb4);
 		const m33 RA = quat_to_m33(Q4(qa4)), RB = quat_to_m33(Q4(qb4));
@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(TPB) k_contact_events(DV d)
 		if (k >= d.cap_contact_events) continue;
 		sgp_contact_event e;
 		e.id1 = ab.x; e.id2 = ab.y; e.userdata1 = 0; e.userdata2 = 0;
-		const float4 la = d.vel[2 * (size_t)ab.x], lb = d.vel[2 * (size_t)ab.y];      // velocities after gravity, before the solve (k_pre_solve)
+		const float4 la = d.vel[VEL_F4 * (size_t)ab.x], lb = d.vel[VEL_F4 * (size_t)ab.y];      // velocities after gravity, before the solve (k_pre_solve)
 		e.lin_vel1[0] = la.x; e.lin_vel1[1] = la.y; e.lin_vel1[2] = la.z;
 		e.lin_vel2[0] = lb.x; e.lin_vel2[1] = lb.y; e.lin_vel2[2] = lb.z;
 		const float4 n4 = d.man_n[m];

@@ -15,8 +15,8 @@ __global__ void __launch_bounds__(TPB) k_ghost_refresh(DV d, const GhostRefresh*
 	d.pose[2 * (size_t)i] = make_float4(c.pos[0], c.pos[1], c.pos[2], d.pose[2 * (size_t)i].w);
 	d.pose[2 * (size_t)i + 1] = make_float4(c.rot[0], c.rot[1], c.rot[2], c.rot[3]);
 	if (f_motion(f) != SGP_MOTION_STATIC) {
-		d.vel[2 * (size_t)i] = make_float4(c.linv[0], c.linv[1], c.linv[2], d.vel[2 * (size_t)i].w);
-		d.vel[2 * (size_t)i + 1] = make_float4(c.angv[0], c.angv[1], c.angv[2], d.vel[2 * (size_t)i + 1].w);
+		d.vel[VEL_F4 * (size_t)i] = make_float4(c.linv[0], c.linv[1], c.linv[2], d.vel[VEL_F4 * (size_t)i].w);
+		d.vel[VEL_F4 * (size_t)i + 1] = make_float4(c.angv[0], c.angv[1], c.angv[2], d.vel[VEL_F4 * (size_t)i + 1].w);
 	}
 	refresh_aabb(d, i, f);
 	f = activate_body(d, i, f);
@@ -36,8 +36,8 @@ __global__ void __launch_bounds__(TPB) k_apply_cmds(DV d, const BodyCmd* cmds, c
 			f = c.flags | BF_CACHE_INVALID;
 			d.pose[2 * (size_t)i] = make_float4(c.pos[0], c.pos[1], c.pos[2], c.inv_mass);
 			d.pose[2 * (size_t)i + 1] = make_float4(c.rot[0], c.rot[1], c.rot[2], c.rot[3]);
-			d.vel[2 * (size_t)i] = make_float4(c.linv[0], c.linv[1], c.linv[2], 0.0f);        // (effective inverse mass: set by k_pre_solve once the body is awake)
-			d.vel[2 * (size_t)i + 1] = make_float4(c.angv[0], c.angv[1], c.angv[2], 0.0f);
+			d.vel[VEL_F4 * (size_t)i] = make_float4(c.linv[0], c.linv[1], c.linv[2], 0.0f);        // (effective inverse mass: set by k_pre_solve once the body is awake)
+			d.vel[VEL_F4 * (size_t)i + 1] = make_float4(c.angv[0], c.angv[1], c.angv[2], 0.0f);
 			d.dyn[i] = make_float4(c.lin_damp, c.ang_damp, c.gravity_factor, c.inv_mass);
 			d.force[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 			d.torque[i] = make_float4(0.0f, 0.0f, 0.0f, c.mass);
@@ -67,8 +67,8 @@ __global__ void __launch_bounds__(TPB) k_apply_cmds(DV d, const BodyCmd* cmds, c
 				const float sl = sqrtf(dq.x * dq.x + dq.y * dq.y + dq.z * dq.z);
 				v3 av = V3(0.0f, 0.0f, 0.0f);
 				if (sl > 1.0e-12f) { const float angle = sgd_quat_angle(sl, dq.w); av = v3_scale(V3(dq.x / sl, dq.y / sl, dq.z / sl), angle / c.dt); }
-				d.vel[2 * (size_t)i] = F4(lv, d.vel[2 * (size_t)i].w);
-				d.vel[2 * (size_t)i + 1] = F4(av, d.vel[2 * (size_t)i + 1].w);
+				d.vel[VEL_F4 * (size_t)i] = F4(lv, d.vel[VEL_F4 * (size_t)i].w);
+				d.vel[VEL_F4 * (size_t)i + 1] = F4(av, d.vel[VEL_F4 * (size_t)i + 1].w);
 				if (!(f & BF_ALIAS)) f = activate_body(d, i, f);      // (a mesh body's alias slots follow its pose and velocities, they are never awake themselves)
 			}
 			continue;
@@ -81,8 +81,8 @@ __global__ void __launch_bounds__(TPB) k_apply_cmds(DV d, const BodyCmd* cmds, c
 			f = ((f & ~BF_LARGE) | (c.flags & BF_LARGE)) | BF_CACHE_INVALID;      // a new scale can move the body across the broad phase's large-body radius (host: note_radius)
 		}
 		if ((c.ops & CMD_SET_VEL) && f_motion(f) != SGP_MOTION_STATIC) {
-			d.vel[2 * (size_t)i] = make_float4(c.linv[0], c.linv[1], c.linv[2], d.vel[2 * (size_t)i].w);
-			d.vel[2 * (size_t)i + 1] = make_float4(c.angv[0], c.angv[1], c.angv[2], d.vel[2 * (size_t)i + 1].w);
+			d.vel[VEL_F4 * (size_t)i] = make_float4(c.linv[0], c.linv[1], c.linv[2], d.vel[VEL_F4 * (size_t)i].w);
+			d.vel[VEL_F4 * (size_t)i + 1] = make_float4(c.angv[0], c.angv[1], c.angv[2], d.vel[VEL_F4 * (size_t)i + 1].w);
 		}
 		if (pose) refresh_aabb(d, i, f);
 		if (f_motion(f) == SGP_MOTION_DYNAMIC) {
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(TPB) k_apply_cmds(DV d, const BodyCmd* cmds, c
 
 SGP_DEV void fill_state(const DV& d, uint32_t i, sgp_body_state* s)
 {
-	const float4 p = d.pose[2 * (size_t)i], q = d.pose[2 * (size_t)i + 1], lv = d.vel[2 * (size_t)i], av = d.vel[2 * (size_t)i + 1];
+	const float4 p = d.pose[2 * (size_t)i], q = d.pose[2 * (size_t)i + 1], lv = d.vel[VEL_F4 * (size_t)i], av = d.vel[VEL_F4 * (size_t)i + 1];
 	const uint32_t f = d.flags[i];
 	s->pos[0] = p.x; s->pos[1] = p.y; s->pos[2] = p.z;
 	s->rot[0] = q.x; s->rot[1] = q.y; s->rot[2] = q.z; s->rot[3] = q.w;

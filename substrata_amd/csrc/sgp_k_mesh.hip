@@ -58,8 +58,8 @@ template <int MESH_GROUP, int KINDS> __global__ void __launch_bounds__(64) k_nar
 		// of this step are not applied yet at this point (k_pre_solve follows the narrow phase), so gravity is added here -- the same expression as the CPU statement's
 		v3 movement = V3(0.0f, 0.0f, 0.0f);
 		if (valid) {
-			const v3 vx = v3_add(V3(d.vel[2 * (size_t)xid]), v3_scale(v3_scale(V3(d.gx, d.gy, d.gz), d.dyn[xid].z), d.sp->dt));
-			movement = v3_sub(vx, f_motion(d.flags[mid]) == SGP_MOTION_STATIC ? V3(0.0f, 0.0f, 0.0f) : V3(d.vel[2 * (size_t)mid]));
+			const v3 vx = v3_add(V3(d.vel[VEL_F4 * (size_t)xid]), v3_scale(v3_scale(V3(d.gx, d.gy, d.gz), d.dyn[xid].z), d.sp->dt));
+			movement = v3_sub(vx, f_motion(d.flags[mid]) == SGP_MOTION_STATIC ? V3(0.0f, 0.0f, 0.0f) : V3(d.vel[VEL_F4 * (size_t)mid]));
 		}
 		mesh_pair_groups<MESH_GROUP, KINDS>(d, L, valid, X, mid, qlo, qhi, max_sep, grp, sub, pair, dropped, movement, true, s_lpoly + threadIdx.x);
 		// the groups as manifolds (mesh -> body), each pruned to <= 4 points; the constraint runs lower id -> higher id, with the mesh's g-th slot

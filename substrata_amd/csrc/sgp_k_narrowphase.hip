@@ -1,6 +1,9 @@
 // sgp_k_narrowphase.hip -- K4 -- one thread per candidate pair (sphere / box / capsule), in-step activation (k_wake_pairs), convex hull pairs (a wave per pair).
 // One of the stage files of the step kernels (stage map: sgp_kernels.h).  Kernels first, their launch wrappers at the end.
 #include "sgp_dev_all.h"
+#ifndef NP_CLIP_LDS
+#define NP_CLIP_LDS 1      // the box - box clip polygons of k_narrowphase in LDS (0: private arrays, i.e. scratch -- kept for A/B measurements)
+#endif
 
 // The body-pair contact cache (ContactConstraintManager::GetContactsFromCache) for one pair of non-mesh bodies: true = *m is last step's
 // manifold carried to the bodies' current poses -- the two bodies sit, relative to each other, where they sat when it was computed (within
@@ -43,6 +46,8 @@ template <int ROUND, bool HULLS = true> SGP_DEV void narrowphase_pairs(const DV&
 {
 	__shared__ uint32_t s_wave_cnt[TPB / 64];
 	__shared__ uint32_t s_base;
+	// the box - box clip's two polygons per lane (sgd_box_box<true>): 12 KB per wave; the activation round's few pairs keep the private arrays
+	__shared__ float s_clip[ROUND == 0 && NP_CLIP_LDS ? TPB / 64 : 1][ROUND == 0 && NP_CLIP_LDS ? 2 * SGD_LPOLY_FLOATS : 1];
 	const uint32_t n = ROUND ? min(d.ctr->n_wake_pairs, d.cap_wake_pairs) : min(d.ctr->n_pairs, d.cap_pairs);
 	const uint2* const pairs = ROUND ? d.wake_pairs : d.pairs;
 	const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
@@ -89,7 +94,8 @@ template <int ROUND, bool HULLS = true> SGP_DEV void narrowphase_pairs(const DV&
 					}
 				} else {
 					const sgd_shape sa = load_shape(d, ab.x, fa), sb = load_shape(d, ab.y, fb);
-					have = sgd_collide(&sa, &sb, d.st.speculative_contact_distance, &m) != 0;
+					if constexpr (ROUND == 0 && NP_CLIP_LDS) have = sgd_collide<true>(&sa, &sb, d.st.speculative_contact_distance, &m, &s_clip[wave][lane]) != 0;
+					else have = sgd_collide(&sa, &sb, d.st.speculative_contact_distance, &m) != 0;
 				}
 				have = have && manifold_ok(m);
 			}
@@ -111,7 +117,10 @@ template <int ROUND, bool HULLS = true> SGP_DEV void narrowphase_pairs(const DV&
 		__syncthreads();
 	}
 }
-__global__ void __launch_bounds__(TPB, 4) k_narrowphase(DV d) { narrowphase_pairs<0>(d); }
+#ifndef NP_WAVES
+#define NP_WAVES 3      // waves per SIMD of k_narrowphase: its 48 KB of clip polygons allow three workgroups per CU
+#endif
+__global__ void __launch_bounds__(TPB, NP_WAVES) k_narrowphase(DV d) { narrowphase_pairs<0>(d); }
 template <bool HULLS> __global__ void __launch_bounds__(TPB, 4) k_narrowphase_wake(DV d) { narrowphase_pairs<1, HULLS>(d); }
 
 // IN-STEP ACTIVATION (PhysicsSystem::JobFindCollisions keeps taking bodies from the active list while ProcessBodyPair appends the ones it wakes: a woken

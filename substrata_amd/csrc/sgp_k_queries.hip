@@ -401,7 +401,7 @@ SGP_DEV void capsule_emit(const DV& d, uint32_t k, uint32_t j, uint32_t f, int g
 		c.normal[0] = m.n.x; c.normal[1] = m.n.y; c.normal[2] = m.n.z;
 		c.distance = v3_dot(v3_sub(m.p2[i], m.p1[i]), m.n);
 		v3 pv = V3(0.0f, 0.0f, 0.0f);
-		if (f_motion(f) != SGP_MOTION_STATIC) pv = v3_add(V3(d.vel[2 * (size_t)j]), v3_cross(V3(d.vel[2 * (size_t)j + 1]), v3_sub(m.p1[i], V3(d.pose[2 * (size_t)j]))));
+		if (f_motion(f) != SGP_MOTION_STATIC) pv = v3_add(V3(d.vel[VEL_F4 * (size_t)j]), v3_cross(V3(d.vel[VEL_F4 * (size_t)j + 1]), v3_sub(m.p1[i], V3(d.pose[2 * (size_t)j]))));
 		c.point_velocity[0] = pv.x; c.point_velocity[1] = pv.y; c.point_velocity[2] = pv.z;
 		c.motion_type = f_motion(f); c.is_sensor = (f & BF_SENSOR) ? 1u : 0u; c.inv_mass = d.pose[2 * (size_t)j].w; c.userdata = 0;
 		out[slot] = c;

@@ -74,7 +74,7 @@ template <int VS> SGP_DEV void warm_start_one_t(const DV& d, uint32_t slot, floa
 	if (c.im2 > 0.0f) { c.B.lv = v3_add(c.B.lv, v3_scale(P, c.im2)); c.B.av = v3_add(c.B.av, sym33_mul(c.I2, A2)); }
 	store_pair_vel<VS>(c, vel);
 }
-SGP_DEV void warm_start_one(const DV& d, uint32_t slot) { warm_start_one_t<2>(d, slot, d.vel); }
+SGP_DEV void warm_start_one(const DV& d, uint32_t slot) { warm_start_one_t<VEL_F4>(d, slot, d.vel); }
 
 // Warm start, one thread per BODY instead of one launch per colour.  What a constraint's warm start does to one of its bodies depends only on the constraint
 // (cached impulses, axes, lever arms) and on that body's inverse mass / inertia -- not on any velocity --, so what the colour-by-colour order does to one body
@@ -87,7 +87,7 @@ SGP_DEV void warm_body_one(const DV& d, uint32_t i)
 	if (i >= d.sp->n_slots) return;
 	uint64_t mask = d.colour_mask[i] & ~(1ull << SGP_OVERFLOW_COLOUR);
 	if (!mask) return;
-	float4* rec = d.vel + 2 * (size_t)i;
+	float4* rec = d.vel + VEL_F4 * (size_t)i;
 	const float4 v4 = rec[0], w4 = rec[1];
 	const float im = v4.w;
 	if (!(im > 0.0f)) return;
@@ -221,7 +221,7 @@ template <int MODE, int ROWS = -1, int OCC = 1> __global__ void __launch_bounds_
 		// cache lines, and the same XCD meets the same rows again in the next pass.  (The grid is a multiple of eight: launch_solve_colour.)
 		const uint32_t bx = (colour_arg & SOLVE_XCD_CHUNKS) ? xcd_block() : blockIdx.x;      // (a colour of 200k constraints -- config 4 -- streams from HBM whatever the order, and lost 17 % with the chunks)
 		for (uint32_t k = first + ((bx * SOLVE_VEL_TPB + threadIdx.x) >> 1); k < end; k += gridDim.x * (SOLVE_VEL_TPB / 2)) {
-			if (MODE == 1) { if constexpr (ROWS == 2) solve_velocity_pair_norows<2>(d, k, side, d.vel); else solve_velocity_pair_t<2, ROWS>(d, k, side, d.vel); }
+			if (MODE == 1) { if constexpr (ROWS == 2) solve_velocity_pair_norows<VEL_F4>(d, k, side, d.vel); else solve_velocity_pair_t<VEL_F4, ROWS>(d, k, side, d.vel); }
 			else solve_position_pair(d, k, side);
 		}
 		return;
@@ -291,7 +291,7 @@ template <int ROWS> __global__ void __launch_bounds__(TAIL_VEL_TPB) k_solve_tail
 		if (mine) { half_load<ROWS>(d, slot, side, h); my_col = (h.np_col >> 8) & 0xFF; }
 		for (int c = first_colour; c < SGP_OVERFLOW_COLOUR; ++c) {
 			if (cs[c] == cs[c + 1]) continue;
-			if (my_col == c) half_solve<2>(h, side, d.vel, d.dbg_flags);
+			if (my_col == c) half_solve<VEL_F4>(h, side, d.vel, d.dbg_flags);
 			__syncthreads();
 		}
 		if (mine) half_store(d, slot, side, h);
@@ -299,7 +299,7 @@ template <int ROWS> __global__ void __launch_bounds__(TAIL_VEL_TPB) k_solve_tail
 	for (int c = first_colour; c < SGP_OVERFLOW_COLOUR; ++c) {
 		const uint32_t b = cs[c], e = cs[c + 1];
 		if (b == e) continue;
-		for (uint32_t k = b + pair; k < e; k += TAIL_VEL_TPB / 2) solve_velocity_pair_t<2, ROWS>(d, k, side, d.vel);
+		for (uint32_t k = b + pair; k < e; k += TAIL_VEL_TPB / 2) solve_velocity_pair_t<VEL_F4, ROWS>(d, k, side, d.vel);
 		__syncthreads();
 	}
 	const uint32_t first = cs[SGP_OVERFLOW_COLOUR], count = cs[SGP_OVERFLOW_COLOUR + 1] - first;
@@ -307,7 +307,7 @@ template <int ROWS> __global__ void __launch_bounds__(TAIL_VEL_TPB) k_solve_tail
 	uint64_t last = 0; bool have_last = false;
 	for (uint32_t it = 0; it < count; ++it) {
 		const uint32_t bslot = overflow_next(d, first, count, last, have_last);
-		solve_velocity_pair_t<2, ROWS>(d, bslot, side, d.vel);
+		solve_velocity_pair_t<VEL_F4, ROWS>(d, bslot, side, d.vel);
 	}
 }
 #define HC_CLASSES 9                  // component size classes: 1 << class constraints
@@ -318,7 +318,7 @@ template <int ROWS> __global__ void __launch_bounds__(TAIL_VEL_TPB) k_solve_tail
 #define NPCOL_CATCH_ALL (1 << 17)     // np_col: the constraint's component is too large for a workgroup
 #define HC_BIG_LIST (4 * HC_WG_PAIRS)  // the catch-all's own list of such constraints (up to four per lane pair; more: it searches the colours for the flag)
 
-SGP_DEV bool hc_can_move(const DV& d, uint32_t body) { return d.vel[2 * (size_t)body].w > 0.0f; }      // effective inverse mass of the step (k_pre_solve)
+SGP_DEV bool hc_can_move(const DV& d, uint32_t body) { return d.vel[VEL_F4 * (size_t)body].w > 0.0f; }      // effective inverse mass of the step (k_pre_solve)
 
 // (1) a constraint between two bodies that can move joins their components (k_pre_solve made every body a component of its own);
 //     the slot list is cleared to "no constraint"
@@ -503,7 +503,7 @@ template <int MODE, int ROWS = -1> __global__ void __launch_bounds__(HC_TPB) k_s
 				at = (at + 1) & (HC_TABLE - 1);
 			}
 			if (owner) {
-				const float4* g = (MODE == 1 ? d.vel : d.pose) + 2 * (size_t)body;
+				const float4* g = (MODE == 1 ? d.vel + VEL_F4 * (size_t)body : d.pose + 2 * (size_t)body);
 				s_rec[RS * at] = g[0]; s_rec[RS * at + 1] = g[1];
 				if (MODE != 1) s_rec[RS * at + 2] = d.prop[2 * (size_t)body];
 			}
@@ -518,7 +518,7 @@ template <int MODE, int ROWS = -1> __global__ void __launch_bounds__(HC_TPB) k_s
 		}
 		if (MODE == 1 && mine) half_store(d, slot, side, h);
 		if (owner && s_rec[RS * at].w > 0.0f) {
-			float4* g = (MODE == 1 ? d.vel : d.pose) + 2 * (size_t)body;
+			float4* g = (MODE == 1 ? d.vel + VEL_F4 * (size_t)body : d.pose + 2 * (size_t)body);
 			g[0] = s_rec[RS * at]; g[1] = s_rec[RS * at + 1];
 		}
 	}
@@ -540,7 +540,7 @@ template <int MODE, int ROWS = -1> __global__ void __launch_bounds__(HC_TPB) k_s
 		for (uint32_t e = pair; e < n_big; e += HC_WG_PAIRS) { const uint32_t k = d.hc_big_list[e]; mine[cnt] = k; mcol[cnt] = (int)((con_npc(CUR(d), k) >> 8) & 0xFF); ++cnt; }
 		for (int c = first_colour; c < n_colours; ++c) {
 #pragma unroll
-			for (int j = 0; j < 4; ++j) if (j < cnt && mcol[j] == c) { if (MODE == 1) solve_velocity_pair_t<2, ROWS>(d, mine[j], side, d.vel); else solve_position_pair(d, mine[j], side); }
+			for (int j = 0; j < 4; ++j) if (j < cnt && mcol[j] == c) { if (MODE == 1) solve_velocity_pair_t<VEL_F4, ROWS>(d, mine[j], side, d.vel); else solve_position_pair(d, mine[j], side); }
 			__syncthreads();
 		}
 	} else
@@ -548,7 +548,7 @@ template <int MODE, int ROWS = -1> __global__ void __launch_bounds__(HC_TPB) k_s
 		const uint32_t cb = d.cstarts[c], ce = d.cstarts[c + 1];
 		for (uint32_t k = cb + pair; k < ce; k += HC_WG_PAIRS) {
 			if (!(con_npc(CUR(d), k) & NPCOL_CATCH_ALL)) continue;
-			if (MODE == 1) solve_velocity_pair_t<2, ROWS>(d, k, side, d.vel); else solve_position_pair(d, k, side);
+			if (MODE == 1) solve_velocity_pair_t<VEL_F4, ROWS>(d, k, side, d.vel); else solve_position_pair(d, k, side);
 		}
 		__syncthreads();
 	}
@@ -556,7 +556,7 @@ template <int MODE, int ROWS = -1> __global__ void __launch_bounds__(HC_TPB) k_s
 	uint64_t last = 0; bool have_last = false;
 	for (uint32_t it = 0; it < ocount; ++it) {
 		const uint32_t bslot = overflow_next(d, ofirst, ocount, last, have_last);
-		if (MODE == 1) solve_velocity_pair_t<2, ROWS>(d, bslot, side, d.vel); else solve_position_pair(d, bslot, side);
+		if (MODE == 1) solve_velocity_pair_t<VEL_F4, ROWS>(d, bslot, side, d.vel); else solve_position_pair(d, bslot, side);
 	}
 }
 
@@ -573,7 +573,7 @@ __global__ void __launch_bounds__(SMALL_TPB) k_solve_small(DV d, int warm_start,
 	__shared__ uint32_t cs[SGP_MAX_COLOURS + 1];
 	const uint32_t n = min(d.sp->n_slots, (uint32_t)SMALL_LDS_BODIES);
 	if (threadIdx.x <= SGP_MAX_COLOURS) cs[threadIdx.x] = d.cstarts[threadIdx.x];
-	for (uint32_t i = threadIdx.x; i < 2 * n; i += SMALL_TPB) sv[i] = d.vel[i];
+	for (uint32_t i = threadIdx.x; i < 2 * n; i += SMALL_TPB) sv[i] = d.vel[VEL_F4 * (size_t)(i >> 1) + (i & 1u)];
 	__syncthreads();
 	const int side = (int)(threadIdx.x & 1u);
 	const uint32_t pair = threadIdx.x >> 1;
@@ -625,7 +625,7 @@ __global__ void __launch_bounds__(SMALL_TPB) k_solve_small(DV d, int warm_start,
 			}
 		}
 	}
-	for (uint32_t i = threadIdx.x; i < 2 * n; i += SMALL_TPB) d.vel[i] = sv[i];
+	for (uint32_t i = threadIdx.x; i < 2 * n; i += SMALL_TPB) d.vel[VEL_F4 * (size_t)(i >> 1) + (i & 1u)] = sv[i];
 }
 
 // The small-world solve with ONE THREAD PER CONSTRAINT (512 threads, the constraint's ~240 registers in one lane): for worlds of 385..512
@@ -714,7 +714,7 @@ __global__ void __launch_bounds__(512) k_solve_small_single(DV d, int warm_start
 	__shared__ uint32_t cs[SGP_MAX_COLOURS + 1];
 	const uint32_t n = min(d.sp->n_slots, (uint32_t)SMALL_LDS_BODIES);
 	if (threadIdx.x <= SGP_MAX_COLOURS) cs[threadIdx.x] = d.cstarts[threadIdx.x];
-	for (uint32_t i = threadIdx.x; i < 2 * n; i += 512) sv[i] = d.vel[i];
+	for (uint32_t i = threadIdx.x; i < 2 * n; i += 512) sv[i] = d.vel[VEL_F4 * (size_t)(i >> 1) + (i & 1u)];
 	__syncthreads();
 	const uint32_t all_n = cs[SGP_OVERFLOW_COLOUR];
 	if (all_n != 0 && all_n <= 512u && cs[SGP_OVERFLOW_COLOUR] == cs[SGP_MAX_COLOURS]) {
@@ -770,7 +770,7 @@ __global__ void __launch_bounds__(512) k_solve_small_single(DV d, int warm_start
 			}
 		}
 	}
-	for (uint32_t i = threadIdx.x; i < 2 * n; i += 512) d.vel[i] = sv[i];
+	for (uint32_t i = threadIdx.x; i < 2 * n; i += 512) d.vel[VEL_F4 * (size_t)(i >> 1) + (i & 1u)] = sv[i];
 }
 #ifndef SGP_EXPERIMENTS
 // (the solver probe and the resident tile solver of round 3 are experiments: built only with -DSGP_EXPERIMENTS, as the unity file sgp_kernels_experiments.hip;

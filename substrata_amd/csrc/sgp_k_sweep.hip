@@ -16,7 +16,7 @@ __global__ void __launch_bounds__(TPB) k_pre_solve(DV d)
 	if (i >= d.cap_bodies) return;
 	// everything an awake body needs is requested at once, next to the flags that say whether it is needed (one memory round trip instead of two)
 	const uint32_t f0 = d.flags[i];
-	const float4 lv4 = d.vel[2 * (size_t)i], av4 = d.vel[2 * (size_t)i + 1];
+	const float4 lv4 = d.vel[VEL_F4 * (size_t)i], av4 = d.vel[VEL_F4 * (size_t)i + 1];
 	const float4 dy = d.dyn[i];                                        // linear damping, angular damping, gravity factor, inverse mass
 	const float dt = d.sp->dt;
 	if (i >= d.sp->n_slots) return;
@@ -57,14 +57,14 @@ __global__ void __launch_bounds__(TPB) k_pre_solve(DV d)
 				if (a2 > ma * ma) av = v3_scale(av, ma / sqrtf(a2));
 			}
 		}
-		d.vel[2 * (size_t)i] = F4(lv, im);
-		d.vel[2 * (size_t)i + 1] = F4(av, 0.0f);
+		d.vel[VEL_F4 * (size_t)i] = F4(lv, im);
+		d.vel[VEL_F4 * (size_t)i + 1] = F4(av, 0.0f);
 		if (im > 0.0f && d.sp->compact_rows != 0u) {
 			// compact rows: the lanes of the velocity iterations rebuild I (r x axis) -- from this record (the expression k_setup evaluates on the same
 			// pose and property records, hence the same bits), one 32-byte gather instead of 48 bytes and a rotation matrix per lane and launch
 			const sym33 I = world_inv_inertia(quat_to_m33(Q4(d.pose[2 * (size_t)i + 1])), V3(d.prop[2 * (size_t)i]));
-			d.iw[2 * (size_t)i] = make_float4(I.xx, I.xy, I.xz, I.yy);
-			d.iw[2 * (size_t)i + 1] = make_float4(I.yz, I.zz, 0.0f, 0.0f);
+			d.vel[VEL_F4 * (size_t)i + 2] = make_float4(I.xx, I.xy, I.xz, I.yy);
+			d.vel[VEL_F4 * (size_t)i + 3] = make_float4(I.yz, I.zz, 0.0f, 0.0f);
 		}
 	}
 	d.hc_root[i] = i; d.hc_count[i] = 0u;      // every body a component of its own (k_hc_hook joins them along the high-colour constraints)
@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(TPB) k_integrate_pose(DV d)
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
 	if (i >= d.cap_bodies) return;
 	const uint32_t f = d.flags[i];                                      // (flags and records requested together: one memory round trip)
-	const float4 v4 = d.vel[2 * (size_t)i], w4 = d.vel[2 * (size_t)i + 1];
+	const float4 v4 = d.vel[VEL_F4 * (size_t)i], w4 = d.vel[VEL_F4 * (size_t)i + 1];
 	float4 p = d.pose[2 * (size_t)i], r4 = d.pose[2 * (size_t)i + 1];
 	const float dt = d.sp->dt;
 	if (i >= d.sp->n_slots) return;
@@ -98,8 +98,8 @@ __global__ void __launch_bounds__(TPB) k_integrate_pose(DV d)
 		const bool cl = l2 > ml * ml, ca = a2 > ma * ma;
 		if (cl) lv = v3_scale(lv, ml / sqrtf(l2));
 		if (ca) av = v3_scale(av, ma / sqrtf(a2));
-		if (cl) d.vel[2 * (size_t)i] = F4(lv, v4.w);                       // (only a clamped velocity changes)
-		if (ca) d.vel[2 * (size_t)i + 1] = F4(av, w4.w);
+		if (cl) d.vel[VEL_F4 * (size_t)i] = F4(lv, v4.w);                       // (only a clamped velocity changes)
+		if (ca) d.vel[VEL_F4 * (size_t)i + 1] = F4(av, w4.w);
 	}
 	const v3 np = v3_add(V3(p), v3_scale(lv, dt));
 	const quat q = quat_add_rotation_step(Q4(r4), v3_scale(av, dt));
@@ -270,12 +270,12 @@ SGP_DEV void sleep_apply_one(const DV& d, uint32_t i, bool& active)
 			d.flags[i] = f;
 			d.sleep_label[i] = SGP_LABEL(root, d.slot_gen[root] & 0x7Fu);        // the island goes to sleep as a whole and is remembered by its root: what wakes a member wakes them all (k_wake_pairs)
 			// (the record of a body that is not awake reads (0, 0, 0 | effective inverse mass 0): k_pre_solve then has nothing to write for it)
-			d.vel[2 * (size_t)i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-			d.vel[2 * (size_t)i + 1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			d.vel[VEL_F4 * (size_t)i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			d.vel[VEL_F4 * (size_t)i + 1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 			push_event(d.ev_deactivated, &d.evc->n_deactivated, d.cap_bodies, i);
 		}
 	} else if (f_motion(f) == SGP_MOTION_KINEMATIC && (f & BF_ACTIVE)) {
-		const v3 lv = V3(d.vel[2 * (size_t)i]), av = V3(d.vel[2 * (size_t)i + 1]);
+		const v3 lv = V3(d.vel[VEL_F4 * (size_t)i]), av = V3(d.vel[VEL_F4 * (size_t)i + 1]);
 		if (v3_len_sq(lv) == 0.0f && v3_len_sq(av) == 0.0f) {
 			f &= ~BF_ACTIVE;
 			d.flags[i] = f;
@@ -434,7 +434,7 @@ __global__ void __launch_bounds__(TPB) k_buoyancy(DV d)
 			const v3 g = V3(0.0f, 0.0f, -9.81f);                                      // :1407
 			const float gf = d.dyn[i].z;
 			const v3 buoy_imp = v3_scale(g, -rho * sub * gf * dt);
-			float4 lv4 = d.vel[2 * (size_t)i], av4 = d.vel[2 * (size_t)i + 1];
+			float4 lv4 = d.vel[VEL_F4 * (size_t)i], av4 = d.vel[VEL_F4 * (size_t)i + 1];
 			const v3 lv = V3(lv4), av = V3(av4);
 			const v3 cob_vel = v3_add(lv, v3_cross(av, rc));
 			const v3 rel = v3_neg(cob_vel);
@@ -459,8 +459,8 @@ __global__ void __launch_bounds__(TPB) k_buoyancy(DV d)
 			v3 ddrag = sym33_mul(Iw, drag_ang_imp);
 			if (v3_len_sq(ddrag) > v3_len_sq(av)) ddrag = v3_neg(av);
 			const v3 dang = v3_add(ddrag, sym33_mul(Iw, v3_cross(rc, v3_add(buoy_imp, drag_imp))));
-			d.vel[2 * (size_t)i] = F4(v3_add(lv, dlin), lv4.w);
-			d.vel[2 * (size_t)i + 1] = F4(v3_add(av, dang), av4.w);
+			d.vel[VEL_F4 * (size_t)i] = F4(v3_add(lv, dlin), lv4.w);
+			d.vel[VEL_F4 * (size_t)i + 1] = F4(v3_add(av, dang), av4.w);
 			applied = true;
 		}
 		if (applied) {

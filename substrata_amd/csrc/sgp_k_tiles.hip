@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(TPB) k_export_boundary(DV d, float3 lo, float3
 	const uint32_t k = base + wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 	if (k >= cap) return;
 	sgp_ghost_record r;
-	const float4 p = d.pose[2 * (size_t)i], qq = d.pose[2 * (size_t)i + 1], lv = d.vel[2 * (size_t)i], av = d.vel[2 * (size_t)i + 1], sh = d.prop[2 * (size_t)i + 1];
+	const float4 p = d.pose[2 * (size_t)i], qq = d.pose[2 * (size_t)i + 1], lv = d.vel[VEL_F4 * (size_t)i], av = d.vel[VEL_F4 * (size_t)i + 1], sh = d.prop[2 * (size_t)i + 1];
 	r.pos[0] = p.x; r.pos[1] = p.y; r.pos[2] = p.z;
 	r.rot[0] = qq.x; r.rot[1] = qq.y; r.rot[2] = qq.z; r.rot[3] = qq.w;
 	r.lin_vel[0] = lv.x; r.lin_vel[1] = lv.y; r.lin_vel[2] = lv.z;
@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(TPB) k_route_write(DV d, TileRoute t, const ui
 		const uint32_t k = header->seg_start[dst] + block_offsets[(size_t)blockIdx.x * cols + dst] + wbase + (uint32_t)__popcll(b & below);
 		if (k >= cap) continue;
 		if (!built) {
-			const float4 p = d.pose[2 * (size_t)i], qq = d.pose[2 * (size_t)i + 1], lv = d.vel[2 * (size_t)i], av = d.vel[2 * (size_t)i + 1], sh = d.prop[2 * (size_t)i + 1];
+			const float4 p = d.pose[2 * (size_t)i], qq = d.pose[2 * (size_t)i + 1], lv = d.vel[VEL_F4 * (size_t)i], av = d.vel[VEL_F4 * (size_t)i + 1], sh = d.prop[2 * (size_t)i + 1];
 			r.pos[0] = p.x; r.pos[1] = p.y; r.pos[2] = p.z;
 			r.rot[0] = qq.x; r.rot[1] = qq.y; r.rot[2] = qq.z; r.rot[3] = qq.w;
 			r.lin_vel[0] = lv.x; r.lin_vel[1] = lv.y; r.lin_vel[2] = lv.z;
@@ -253,8 +253,8 @@ __global__ void __launch_bounds__(TPB) k_ghost_refresh_records(DV d, const sgp_g
 	d.pose[2 * (size_t)i] = make_float4(c.pos[0], c.pos[1], c.pos[2], d.pose[2 * (size_t)i].w);
 	d.pose[2 * (size_t)i + 1] = make_float4(c.rot[0], c.rot[1], c.rot[2], c.rot[3]);
 	if (f_motion(f) != SGP_MOTION_STATIC) {
-		d.vel[2 * (size_t)i] = make_float4(c.lin_vel[0], c.lin_vel[1], c.lin_vel[2], d.vel[2 * (size_t)i].w);
-		d.vel[2 * (size_t)i + 1] = make_float4(c.ang_vel[0], c.ang_vel[1], c.ang_vel[2], d.vel[2 * (size_t)i + 1].w);
+		d.vel[VEL_F4 * (size_t)i] = make_float4(c.lin_vel[0], c.lin_vel[1], c.lin_vel[2], d.vel[VEL_F4 * (size_t)i].w);
+		d.vel[VEL_F4 * (size_t)i + 1] = make_float4(c.ang_vel[0], c.ang_vel[1], c.ang_vel[2], d.vel[VEL_F4 * (size_t)i + 1].w);
 	}
 	refresh_aabb(d, i, f);
 	f = activate_body(d, i, f);
@@ -325,8 +325,8 @@ __global__ void __launch_bounds__(TPB) k_create_from_records(DV d, const sgp_gho
 	const float friction = r.friction < 0.0f ? 0.0f : (r.friction > 1.0f ? 1.0f : r.friction), restitution = r.restitution < 0.0f ? 0.0f : (r.restitution > 1.0f ? 1.0f : r.restitution);      // (clamp01 of add_one)
 	d.pose[2 * (size_t)i] = make_float4(r.pos[0], r.pos[1], r.pos[2], inv_mass);
 	d.pose[2 * (size_t)i + 1] = make_float4(r.rot[0], r.rot[1], r.rot[2], r.rot[3]);
-	d.vel[2 * (size_t)i] = make_float4(r.lin_vel[0], r.lin_vel[1], r.lin_vel[2], 0.0f);
-	d.vel[2 * (size_t)i + 1] = make_float4(r.ang_vel[0], r.ang_vel[1], r.ang_vel[2], 0.0f);
+	d.vel[VEL_F4 * (size_t)i] = make_float4(r.lin_vel[0], r.lin_vel[1], r.lin_vel[2], 0.0f);
+	d.vel[VEL_F4 * (size_t)i + 1] = make_float4(r.ang_vel[0], r.ang_vel[1], r.ang_vel[2], 0.0f);
 	d.dyn[i] = ghost ? make_float4(def.lin_damp, def.ang_damp, def.gravity_factor, inv_mass) : make_float4(r.linear_damping, r.angular_damping, r.gravity_factor, inv_mass);
 	d.force[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	d.torque[i] = make_float4(0.0f, 0.0f, 0.0f, mass);

@@ -28,7 +28,7 @@ SGP_DEV sgd_chassis veh_chassis_pose_vel(const DV& d, uint32_t b)
 {
 	sgd_chassis c;
 	const float4 p = d.pose[2 * (size_t)b];
-	c.pos = V3(p); c.rot = Q4(d.pose[2 * (size_t)b + 1]); c.v = V3(d.vel[2 * (size_t)b]); c.w = V3(d.vel[2 * (size_t)b + 1]);
+	c.pos = V3(p); c.rot = Q4(d.pose[2 * (size_t)b + 1]); c.v = V3(d.vel[VEL_F4 * (size_t)b]); c.w = V3(d.vel[VEL_F4 * (size_t)b + 1]);
 	c.im = p.w; c.inv_inertia_local = V3(d.prop[2 * (size_t)b]);
 	c.I = world_inv_inertia(quat_to_m33(c.rot), c.inv_inertia_local);
 	return c;
@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(64) k_vehicle_cast(DV d)
 		if (wi < sv.num_wheels && sub == 0 && bid != SGP_INVALID_ID) {
 			const uint32_t fo = d.flags[bid];
 			v3 gvel = V3(0.0f, 0.0f, 0.0f);
-			if (f_motion(fo) != SGP_MOTION_STATIC) gvel = v3_add(V3(d.vel[2 * (size_t)bid]), v3_cross(V3(d.vel[2 * (size_t)bid + 1]), v3_sub(bp, V3(d.pose[2 * (size_t)bid]))));
+			if (f_motion(fo) != SGP_MOTION_STATIC) gvel = v3_add(V3(d.vel[VEL_F4 * (size_t)bid]), v3_cross(V3(d.vel[VEL_F4 * (size_t)bid + 1]), v3_sub(bp, V3(d.pose[2 * (size_t)bid]))));
 			sgd_vehicle_set_hit(&sv, wi, bid, best, bn, bp, gvel, d.prop[2 * (size_t)bid + 1].w);
 			if (f_motion(fo) == SGP_MOTION_DYNAMIC) {
 				// the rows act on a dynamic body under the wheel (VehicleConstraint::SetupVelocityConstraint, body 2): it wakes up if it sleeps
@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(64) k_vehicle_controller(DV d)
 		// every lane holds the chassis state (one broadcast load); lane i works on wheel i, lane 0 on what couples the wheels
 		const uint32_t b = sv.body;
 		sgd_chassis c = veh_chassis_pose_vel(d, b);
-		const float lvw = d.vel[2 * (size_t)b].w, avw = d.vel[2 * (size_t)b + 1].w;
+		const float lvw = d.vel[VEL_F4 * (size_t)b].w, avw = d.vel[VEL_F4 * (size_t)b + 1].w;
 		// lane i: the dynamic body under wheel i, as the row set-up needs it (inverse mass of the body, not of the step: a sleeper is woken by this step's k_pre_solve)
 		sgd_ground g; g.dyn = 0; g.pos = V3(0.0f, 0.0f, 0.0f); g.im = 0.0f; g.I = sym33_zero();
 		bool lost = false;
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(64) k_vehicle_controller(DV d)
 		const int spinning = sgd_vehicle_controller_lanes(&sv, &c, &g, d.sp->dt, (int)threadIdx.x);
 		if (threadIdx.x == 0) {
 			if (spinning) d.sleep_timer[b] = 0.0f;
-			d.vel[2 * (size_t)b] = F4(c.v, lvw); d.vel[2 * (size_t)b + 1] = F4(c.w, avw);      // (the anti-roll impulses)
+			d.vel[VEL_F4 * (size_t)b] = F4(c.v, lvw); d.vel[VEL_F4 * (size_t)b + 1] = F4(c.w, avw);      // (the anti-roll impulses)
 		}
 	}
 	__syncthreads();
@@ -361,7 +361,7 @@ template <int MODE> SGP_DEV void veh_quad_solve(const DV& d, uint32_t k, int L, 
 	float4 ra[4], ri[4];
 #pragma unroll
 	for (int r = 0; r < 4; ++r) { ra[r] = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_ROW + 2 * r)]; ri[r] = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_ROW + 2 * r + 1)]; }
-	const float4 s0 = d.vel[2 * (size_t)b], s1 = d.vel[2 * (size_t)b + 1];
+	const float4 s0 = d.vel[VEL_F4 * (size_t)b], s1 = d.vel[VEL_F4 * (size_t)b + 1];
 	VehBody c;
 	c.v = V3(s0); c.im = s0.w; c.w = V3(s1);                  // (s0.w: the effective inverse mass of this step, k_pre_solve)
 	const quat crot = Q4(d.pose[2 * (size_t)b + 1]);
@@ -371,7 +371,7 @@ template <int MODE> SGP_DEV void veh_quad_solve(const DV& d, uint32_t k, int L, 
 	VehGround g; g.id = gid; g.v = V3(0.0f, 0.0f, 0.0f); g.w = g.v; g.im = 0.0f; g.I = sym33_zero(); g.r2 = g.v;
 	float4 g0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), g1 = g0;
 	if (gid != SGP_INVALID_ID) {
-		g0 = d.vel[2 * (size_t)gid]; g1 = d.vel[2 * (size_t)gid + 1];
+		g0 = d.vel[VEL_F4 * (size_t)gid]; g1 = d.vel[VEL_F4 * (size_t)gid + 1];
 		const float4 gp4 = d.pose[2 * (size_t)gid];
 		g.v = V3(g0); g.w = V3(g1); g.im = gp4.w;
 		g.I = world_inv_inertia(quat_to_m33(Q4(d.pose[2 * (size_t)gid + 1])), V3(d.prop[2 * (size_t)gid]));
@@ -381,8 +381,8 @@ template <int MODE> SGP_DEV void veh_quad_solve(const DV& d, uint32_t k, int L, 
 		// VehicleConstraint::WarmStartVelocityConstraint: suspension, upper stop, lateral (the longitudinal row starts every step from zero)
 		const v3 neg_lat = v3_neg(V3(d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_LAT)]));
 		VEH_TURNS(if (contact) { if (wbits & 2u) veh_row_apply(c, g, ri[0], neg_n); if (wbits & 4u) veh_row_apply(c, g, ri[1], neg_n); if (wbits & 16u) veh_row_apply(c, g, ri[3], neg_lat); })
-		if (L == 0) { d.vel[2 * (size_t)b] = F4(c.v, s0.w); d.vel[2 * (size_t)b + 1] = F4(c.w, s1.w); }
-		if (gid != SGP_INVALID_ID) { d.vel[2 * (size_t)gid] = F4(g.v, g0.w); d.vel[2 * (size_t)gid + 1] = F4(g.w, g1.w); }
+		if (L == 0) { d.vel[VEL_F4 * (size_t)b] = F4(c.v, s0.w); d.vel[VEL_F4 * (size_t)b + 1] = F4(c.w, s1.w); }
+		if (gid != SGP_INVALID_ID) { d.vel[VEL_F4 * (size_t)gid] = F4(g.v, g0.w); d.vel[VEL_F4 * (size_t)gid + 1] = F4(g.w, g1.w); }
 		return;
 	}
 	const float4 cl = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_LONG)], ct = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_LAT)], cg = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_GVEL)];
@@ -459,9 +459,9 @@ template <int MODE> SGP_DEV void veh_quad_solve(const DV& d, uint32_t k, int L, 
 		gw->suspension.lambda = ri[0].w; gw->max_up.lambda = ri[1].w; gw->longitudinal.lambda = ri[2].w; gw->lateral.lambda = ri[3].w;
 		gw->angular_velocity = cp.w;
 	}
-	if (gid != SGP_INVALID_ID) { d.vel[2 * (size_t)gid] = F4(g.v, g0.w); d.vel[2 * (size_t)gid + 1] = F4(g.w, g1.w); }      // (lanes on the same body hold the same values)
+	if (gid != SGP_INVALID_ID) { d.vel[VEL_F4 * (size_t)gid] = F4(g.v, g0.w); d.vel[VEL_F4 * (size_t)gid + 1] = F4(g.w, g1.w); }      // (lanes on the same body hold the same values)
 	if (L == 0) {
-		d.vel[2 * (size_t)b] = F4(c.v, s0.w); d.vel[2 * (size_t)b + 1] = F4(c.w, s1.w);
+		d.vel[VEL_F4 * (size_t)b] = F4(c.v, s0.w); d.vel[VEL_F4 * (size_t)b + 1] = F4(c.w, s1.w);
 		if (hbits & 2u) {
 			d.veh_head[(size_t)k * VEH_HEAD_F4] = make_float4(h0.x, h0.y, h0.z, lean_integrated);
 			float4* h4p = &d.veh_head[(size_t)k * VEH_HEAD_F4 + 4];
@@ -523,7 +523,7 @@ template <int MODE, int ROWS = -1> __global__ void __launch_bounds__(SOLVE_VEL_T
 	const uint32_t cb = blockIdx.x - veh_blocks, cg = gridDim.x - veh_blocks;      // (the colour's workgroups: XCD-contiguous chunks as in k_solve_colour; cg is a multiple of eight)
 	const uint32_t bx = (colour_arg & SOLVE_XCD_CHUNKS) ? (cb & 7u) * (cg >> 3) + (cb >> 3) : cb;
 	for (uint32_t k = first + ((bx * SOLVE_VEL_TPB + threadIdx.x) >> 1); k < end; k += cg * (SOLVE_VEL_TPB / 2)) {
-		if (MODE == 1) solve_velocity_pair_t<2, ROWS>(d, k, side, d.vel); else solve_position_pair(d, k, side);
+		if (MODE == 1) solve_velocity_pair_t<VEL_F4, ROWS>(d, k, side, d.vel); else solve_position_pair(d, k, side);
 	}
 }
 void launch_solve_colour_veh(const DV& d, int colour, uint32_t est, int mode, hipStream_t s, int compact_rows)

@@ -221,6 +221,7 @@ struct ConstraintArrays {
 	float4*   prec;        // the body-pair contact cache's record (above), PREC_F4 per slot
 };
 
+#define VEL_F4 4u             // float4 per body in DV::vel (velocity record + the step's world inverse inertia)
 struct DV {
 	StepParams* sp;
 	uint32_t cap_bodies, cap_pairs, cap_manifolds;
@@ -228,8 +229,11 @@ struct DV {
 	// Per-body state as 32-byte records (two float4 each, record i at [2 i], [2 i + 1]): a sweep kernel streams exactly the records it needs and a
 	// constraint gathers one 32 B record per body and purpose, instead of one float4 from each of several arrays.
 	float4* pose;              // [position xyz, inverse mass (0 unless dynamic)] [rotation quaternion]; the position iterations correct it in place
-	float4* vel;               // [linear velocity xyz, EFFECTIVE inverse mass of the step (0 unless dynamic and awake; k_pre_solve)] [angular velocity xyz, -]:
-	                           //   THE velocity storage, and the record the velocity iterations gather and scatter
+	float4* vel;               // 64-byte records (VEL_F4 float4 per body, record i at [VEL_F4 i]): [linear velocity xyz, EFFECTIVE inverse mass of the step (0 unless
+	                           //   dynamic and awake; k_pre_solve)] [angular velocity xyz, -]: THE velocity storage, what the velocity iterations gather and scatter; then the
+	                           //   world inverse inertia of the step, [+2] = (xx, xy, xz, yy), [+3] = (yz, zz, -, -), written by k_pre_solve when the step's rows are compact
+	                           //   (StepParams::compact_rows != 0) for bodies that can move: a lane rebuilding I (r x axis) finds it in the SAME 128-byte line as the velocities it
+	                           //   gathers anyway (round 6: at 1 M bodies a velocity launch moved 784 B per constraint for 340 algorithmic -- four gathered lines, two now)
 	float4* prop;              // [local inverse inertia diagonal xyz, restitution] [shape parameters xyz, friction]
 	float4* dyn;               // one float4 per body: linear damping, angular damping, gravity factor, inverse mass (again; k_pre_solve reads nothing else of the pose)
 	float4* force;             // accumulated force xyz, - (read only for bodies flagged BF_HAS_FORCE)
@@ -309,8 +313,6 @@ struct DV {
 	// constraints
 	uint32_t dbg_flags;        // SGP_DEBUG_FLAGS (developer switches): bit 0 = tail kernel without its register-resident path
 	float4* rows;              // velocity-iteration rows, [point 0..3][axis n,t1,t2][4][cap_manifolds] (k_setup): r1 x axis (w: bias for n),
-	float4* iw;                // world inverse inertia of every body that can move this step, [2 i] = (xx, xy, xz, yy), [2 i + 1] = (yz, zz, -, -): written by k_pre_solve when the step's
-	                           // rows are compact (StepParams::compact_rows != 0), so that a lane rebuilding I (r x axis) gathers ONE record instead of the pose and property records + a rotation matrix
 	                           //   r2 x axis (w: effective mass of the axis), I1 (r1 x axis), I2 (r2 x axis)
 	ConstraintArrays ca[2];    // [sp->parity] = this step's constraints, the other = previous step's (contact cache)
 	uint4* ht; uint32_t ht_size;   // contact cache: 16-byte entries (pair key low, high, slot in the previous step's constraints, its np_col) -- one line per probe, and the

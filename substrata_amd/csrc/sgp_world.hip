@@ -127,7 +127,7 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	DV& d = w->dv;
 	const uint32_t N = desc->max_bodies, P = w->desc.max_body_pairs, M = w->desc.max_manifolds;
 	d.cap_bodies = N; d.cap_pairs = P; d.cap_manifolds = M;
-	DEV_ALLOC(d.pose, 2 * (size_t)N); DEV_ALLOC(d.vel, 2 * (size_t)N); DEV_ALLOC(d.prop, 2 * (size_t)N); DEV_ALLOC(d.dyn, N);
+	DEV_ALLOC(d.pose, 2 * (size_t)N); DEV_ALLOC(d.vel, VEL_F4 * (size_t)N); DEV_ALLOC(d.prop, 2 * (size_t)N); DEV_ALLOC(d.dyn, N);
 	DEV_ALLOC(d.force, N); DEV_ALLOC(d.torque, N);
 	DEV_ALLOC(d.flags, N); DEV_ALLOC(d.aabb_min, N); DEV_ALLOC(d.aabb_max, N);
 	for (int k = 0; k < 3; ++k) DEV_ALLOC(d.sleep_s[k], N);
@@ -196,7 +196,7 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	d.cap_hc_list = 2u * M + 4096u; DEV_ALLOC(d.hc_list, d.cap_hc_list); DEV_ALLOC(d.hc_entry, d.cap_hc_list); DEV_ALLOC(d.hc_big_list, 1024);
 	DEV_ALLOC(d.ulist[0], M); DEV_ALLOC(d.ulist[1], M);
 	for (int k = 0; k < 4; ++k) { DEV_ALLOC(d.man_p1[k], M); DEV_ALLOC(d.man_p2[k], M); }
-	DEV_ALLOC(d.rows, (size_t)48 * M); DEV_ALLOC(d.iw, (size_t)2 * N);
+	DEV_ALLOC(d.rows, (size_t)48 * M);
 	{ int r = alloc_constraints(w, d.ca[0], M); if (r != SGP_OK) return r; }
 	{ int r = alloc_constraints(w, d.ca[1], M); if (r != SGP_OK) return r; }
 	w->ht_alloc = next_pow2(2u * M);
