@@ -672,9 +672,9 @@ int  sgp_tiles_get_boxes(sgp_tiles* t, float* boxes_out);
 int  sgp_tiles_drain_migrations(sgp_tiles* t, sgp_migration* out, uint32_t cap, uint32_t* n_out);
 
 /* ---- device-resident bulk access (bench / torch plumbing; pointers are HIP device pointers) ---- */
-/* Raw views of the body records, valid until the world is destroyed.  which = 0 pose, record i = two float4 at [2 i], [2 i + 1]:
- * (position xyz, inverse mass) (rotation quaternion xyzw); 1 velocity, record i = FOUR float4 (64 bytes) at [4 i] .. [4 i + 3]:
- * (linear velocity xyz, -) (angular velocity xyz, -) and two float4 that belong to the solver (the step's world-space inverse inertia). */
+/* Raw views of the body records, valid until the world is destroyed; record i = FOUR float4 (64 bytes) at [4 i] .. [4 i + 3], of which the first two are
+ * the caller's: which = 0 pose: (position xyz, inverse mass) (rotation quaternion xyzw), then two float4 of body properties; 1 velocity: (linear velocity
+ * xyz, -) (angular velocity xyz, -), then two float4 that belong to the solver (the step's world-space inverse inertia). */
 int  sgp_world_device_array(sgp_world* w, int which, void** dev_ptr_out, uint32_t* count_out);
 /* hipStream_t the world launches on (as void*). */
 int  sgp_world_stream(sgp_world* w, void** stream_out);

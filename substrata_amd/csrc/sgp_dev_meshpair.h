@@ -35,9 +35,9 @@ SGP_DEV int mesh_candidates(const DV& d, const MeshHeader& mh, v3 llo, v3 lhi, u
 // Returns the number of groups (manifolds mesh -> X).  Sequential (one thread).
 SGP_DEV int collide_with_mesh(const DV& d, uint32_t mbody, const sgd_shape& X, v3 lo, v3 hi, float max_sep, sgd_manifold* out, bool* dropped)      // (X: a capsule)
 {
-	const float4 msh = d.prop[2 * (size_t)mbody + 1];
+	const float4 msh = d.pose[POSE_F4 * (size_t)mbody + 3];
 	const MeshHeader mh = d.meshes[(uint32_t)msh.x];
-	const v3 mpos = V3(d.pose[2 * (size_t)mbody]); const m33 R = quat_to_m33(Q4(d.pose[2 * (size_t)mbody + 1]));
+	const v3 mpos = V3(d.pose[POSE_F4 * (size_t)mbody]); const m33 R = quat_to_m33(Q4(d.pose[POSE_F4 * (size_t)mbody + 1]));
 	const v3 e = V3(max_sep, max_sep, max_sep);
 	const v3 qlo = v3_sub(lo, e), qhi = v3_add(hi, e);
 	// the query box in the mesh frame (bounds of its 8 corners), a little generous
@@ -173,8 +173,8 @@ template <int MESH_GROUP, int KINDS = SGD_KINDS_ALL> SGP_DEV void mesh_pair_grou
 			for (int i = sub; i < ne_; i += MESH_GROUP) { hd->edge_a[i] = hs->edge_a[i]; hd->edge_b[i] = hs->edge_b[i]; hd->edge_f0[i] = hs->edge_f0[i]; hd->edge_f1[i] = hs->edge_f1[i]; }
 			X.hull = (const sgd_hull*)(const void*)&L.hull;
 		}
-		mh = d.meshes[(uint32_t)d.prop[2 * (size_t)mid + 1].x];
-		mpos = V3(d.pose[2 * (size_t)mid]); R = quat_to_m33(Q4(d.pose[2 * (size_t)mid + 1]));
+		mh = d.meshes[(uint32_t)d.pose[POSE_F4 * (size_t)mid + 3].x];
+		mpos = V3(d.pose[POSE_F4 * (size_t)mid]); R = quat_to_m33(Q4(d.pose[POSE_F4 * (size_t)mid + 1]));
 	}
 	// the query box in the mesh frame: bounds of the box's 8 corners, a little generous (every lane of the group: the same operands, the same box)
 	v3 llo = V3(3.4e38f, 3.4e38f, 3.4e38f), lhi = V3(-3.4e38f, -3.4e38f, -3.4e38f);

@@ -8,10 +8,10 @@
 SGP_DEV sgd_shape load_shape(const DV& d, uint32_t i, uint32_t f)
 {
 	sgd_shape s;
-	s.pos = V3(d.pose[2 * (size_t)i]);
-	s.R = quat_to_m33(Q4(d.pose[2 * (size_t)i + 1]));
+	s.pos = V3(d.pose[POSE_F4 * (size_t)i]);
+	s.R = quat_to_m33(Q4(d.pose[POSE_F4 * (size_t)i + 1]));
 	s.type = (int)f_shape(f);
-	const float4 sh = d.prop[2 * (size_t)i + 1];
+	const float4 sh = d.pose[POSE_F4 * (size_t)i + 3];
 	s.p0 = sh.x; s.p1 = sh.y; s.p2 = sh.z;
 	s.hull = s.type == SGP_SHAPE_HULL ? body_hull(d, sh) : (s.type == SGP_SHAPE_BOX ? &d.hulls[0] : nullptr);
 	return s;

@@ -6,7 +6,7 @@
 // The world-space inverse inertia is derived here from the pose and property records (read-only during the solve).
 SGP_DEV sym33 body_world_inv_inertia(const DV& d, uint32_t body)
 {
-	return world_inv_inertia(quat_to_m33(Q4(d.pose[2 * (size_t)body + 1])), V3(d.prop[2 * (size_t)body]));
+	return world_inv_inertia(quat_to_m33(Q4(d.pose[POSE_F4 * (size_t)body + 1])), V3(d.pose[POSE_F4 * (size_t)body + 2]));
 }
 // the same matrix from the record k_pre_solve wrote for this step (compact rows only; bodies that cannot move have none and need none: their rows are never applied)
 SGP_DEV sym33 body_world_inv_inertia_rec(const DV& d, uint32_t body)
@@ -340,7 +340,7 @@ SGP_DEV void solve_position_pair(const DV& d, uint32_t slot, int side)
 	const uint32_t body = side ? hd.y : hd.x;
 	PosHalf ph;
 	pos_half_load(d, slot, side, (int)hd.z, ph);
-	pos_half_solve(d, ph, side, d.pose + 2 * (size_t)body, V3(d.prop[2 * (size_t)body]));      // this lane's body's pose record + its local inverse inertia
+	pos_half_solve(d, ph, side, d.pose + POSE_F4 * (size_t)body, V3(d.pose[POSE_F4 * (size_t)body + 2]));      // this lane's body's pose record + its local inverse inertia
 }
 SGP_DEV void solve_position_pair_at(const DV& d, uint32_t slot, int side, float4* rec, v3 ii)
 {

@@ -10,8 +10,8 @@
 // swept sphere against mesh body j: closest front-side touch; on equal distance the lower triangle index (caller's order) wins
 SGP_DEV float cast_sphere_mesh(const DV& d, uint32_t j, v3 o, v3 dir, float max_t, float rs, v3* n_out, v3* p_out)
 {
-	const MeshHeader mh = d.meshes[(uint32_t)d.prop[2 * (size_t)j + 1].x];
-	const v3 mpos = V3(d.pose[2 * (size_t)j]); const m33 R = quat_to_m33(Q4(d.pose[2 * (size_t)j + 1]));
+	const MeshHeader mh = d.meshes[(uint32_t)d.pose[POSE_F4 * (size_t)j + 3].x];
+	const v3 mpos = V3(d.pose[POSE_F4 * (size_t)j]); const m33 R = quat_to_m33(Q4(d.pose[POSE_F4 * (size_t)j + 1]));
 	const v3 ol = m33_tmul(R, v3_sub(o, mpos)), dl = m33_tmul(R, dir);
 	float best = max_t; uint32_t best_idx = 0xFFFFFFFFu; v3 bn = V3(0.0f, 0.0f, 0.0f);
 	uint32_t stack[48]; int sp = 0;

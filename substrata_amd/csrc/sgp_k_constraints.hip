@@ -304,9 +304,9 @@ __global__ void __launch_bounds__(TPB) k_setup(DV d)
 		float4 pr0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pr1 = pr0, pr2 = pr0;
 		if (reused) { const float4* rec = PRV(d).prec + (size_t)fslot * PREC_F4; pr0 = rec[0]; pr1 = rec[1]; pr2 = rec[2]; }
 		// per body: pose record, velocity record (velocities after gravity + the effective inverse mass: k_pre_solve), property record
-		const float4 pa4 = d.pose[2 * (size_t)ab.x], qa4 = d.pose[2 * (size_t)ab.x + 1], pb4 = d.pose[2 * (size_t)ab.y], qb4 = d.pose[2 * (size_t)ab.y + 1];
+		const float4 pa4 = d.pose[POSE_F4 * (size_t)ab.x], qa4 = d.pose[POSE_F4 * (size_t)ab.x + 1], pb4 = d.pose[POSE_F4 * (size_t)ab.y], qb4 = d.pose[POSE_F4 * (size_t)ab.y + 1];
 		const float4 va4 = d.vel[VEL_F4 * (size_t)ab.x], wa4 = d.vel[VEL_F4 * (size_t)ab.x + 1], vb4 = d.vel[VEL_F4 * (size_t)ab.y], wb4 = d.vel[VEL_F4 * (size_t)ab.y + 1];
-		const float4 ia4 = d.prop[2 * (size_t)ab.x], sa4 = d.prop[2 * (size_t)ab.x + 1], ib4 = d.prop[2 * (size_t)ab.y], sb4 = d.prop[2 * (size_t)ab.y + 1];
+		const float4 ia4 = d.pose[POSE_F4 * (size_t)ab.x + 2], sa4 = d.pose[POSE_F4 * (size_t)ab.x + 3], ib4 = d.pose[POSE_F4 * (size_t)ab.y + 2], sb4 = d.pose[POSE_F4 * (size_t)ab.y + 3];
 		const v3 posA = V3(pa4), posB = V3(pb4);
 		const m33 RA = quat_to_m33(Q4(qa4)), RB = quat_to_m33(Q4(qb4));
 		const float im1 = va4.w, im2 = vb4.w;

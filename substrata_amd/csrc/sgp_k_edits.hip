@@ -12,8 +12,8 @@ __global__ void __launch_bounds__(TPB) k_ghost_refresh(DV d, const GhostRefresh*
 	const uint32_t i = c.id;
 	uint32_t f = d.flags[i];
 	if (!(f & BF_ALIVE)) return;
-	d.pose[2 * (size_t)i] = make_float4(c.pos[0], c.pos[1], c.pos[2], d.pose[2 * (size_t)i].w);
-	d.pose[2 * (size_t)i + 1] = make_float4(c.rot[0], c.rot[1], c.rot[2], c.rot[3]);
+	d.pose[POSE_F4 * (size_t)i] = make_float4(c.pos[0], c.pos[1], c.pos[2], d.pose[POSE_F4 * (size_t)i].w);
+	d.pose[POSE_F4 * (size_t)i + 1] = make_float4(c.rot[0], c.rot[1], c.rot[2], c.rot[3]);
 	if (f_motion(f) != SGP_MOTION_STATIC) {
 		d.vel[VEL_F4 * (size_t)i] = make_float4(c.linv[0], c.linv[1], c.linv[2], d.vel[VEL_F4 * (size_t)i].w);
 		d.vel[VEL_F4 * (size_t)i + 1] = make_float4(c.angv[0], c.angv[1], c.angv[2], d.vel[VEL_F4 * (size_t)i + 1].w);
@@ -34,20 +34,20 @@ __global__ void __launch_bounds__(TPB) k_apply_cmds(DV d, const BodyCmd* cmds, c
 		const BodyCmd& c = cmds[k];
 		if (c.ops & CMD_CREATE) {
 			f = c.flags | BF_CACHE_INVALID;
-			d.pose[2 * (size_t)i] = make_float4(c.pos[0], c.pos[1], c.pos[2], c.inv_mass);
-			d.pose[2 * (size_t)i + 1] = make_float4(c.rot[0], c.rot[1], c.rot[2], c.rot[3]);
+			d.pose[POSE_F4 * (size_t)i] = make_float4(c.pos[0], c.pos[1], c.pos[2], c.inv_mass);
+			d.pose[POSE_F4 * (size_t)i + 1] = make_float4(c.rot[0], c.rot[1], c.rot[2], c.rot[3]);
 			d.vel[VEL_F4 * (size_t)i] = make_float4(c.linv[0], c.linv[1], c.linv[2], 0.0f);        // (effective inverse mass: set by k_pre_solve once the body is awake)
 			d.vel[VEL_F4 * (size_t)i + 1] = make_float4(c.angv[0], c.angv[1], c.angv[2], 0.0f);
 			d.dyn[i] = make_float4(c.lin_damp, c.ang_damp, c.gravity_factor, c.inv_mass);
 			d.force[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 			d.torque[i] = make_float4(0.0f, 0.0f, 0.0f, c.mass);
-			d.prop[2 * (size_t)i] = make_float4(c.inv_inertia[0], c.inv_inertia[1], c.inv_inertia[2], c.restitution);
-			d.prop[2 * (size_t)i + 1] = make_float4(c.shape[0], c.shape[1], c.shape[2], c.friction);
+			d.pose[POSE_F4 * (size_t)i + 2] = make_float4(c.inv_inertia[0], c.inv_inertia[1], c.inv_inertia[2], c.restitution);
+			d.pose[POSE_F4 * (size_t)i + 3] = make_float4(c.shape[0], c.shape[1], c.shape[2], c.friction);
 			d.submerged[i] = 0.0f;
 			d.userdata[i] = c.userdata;
 			label_new_body(d, i);
 			refresh_aabb(d, i, f);
-			reset_sleep(d, i, f_shape(f), d.prop[2 * (size_t)i + 1], V3(d.pose[2 * (size_t)i]), Q4(d.pose[2 * (size_t)i + 1]));
+			reset_sleep(d, i, f_shape(f), d.pose[POSE_F4 * (size_t)i + 3], V3(d.pose[POSE_F4 * (size_t)i]), Q4(d.pose[POSE_F4 * (size_t)i + 1]));
 			continue;
 		}
 		if (c.ops & CMD_REMOVE) { f = 0; continue; }
@@ -57,8 +57,8 @@ __global__ void __launch_bounds__(TPB) k_apply_cmds(DV d, const BodyCmd* cmds, c
 		if (c.ops & CMD_MOVE_KINEMATIC) {
 			// MotionProperties::MoveKinematic: velocities that reach the target in dt
 			if (f_motion(f) == SGP_MOTION_KINEMATIC && c.dt > 0.0f) {
-				const v3 pos = V3(d.pose[2 * (size_t)i]);
-				const quat q = Q4(d.pose[2 * (size_t)i + 1]);
+				const v3 pos = V3(d.pose[POSE_F4 * (size_t)i]);
+				const quat q = Q4(d.pose[POSE_F4 * (size_t)i + 1]);
 				const v3 lv = v3_scale(v3_sub(V3(c.pos[0], c.pos[1], c.pos[2]), pos), 1.0f / c.dt);
 				quat t; t.x = c.rot[0]; t.y = c.rot[1]; t.z = c.rot[2]; t.w = c.rot[3];
 				quat cj; cj.x = -q.x; cj.y = -q.y; cj.z = -q.z; cj.w = q.w;
@@ -74,10 +74,10 @@ __global__ void __launch_bounds__(TPB) k_apply_cmds(DV d, const BodyCmd* cmds, c
 			continue;
 		}
 		bool pose = false;
-		if (c.ops & CMD_SET_POS) { d.pose[2 * (size_t)i] = make_float4(c.pos[0], c.pos[1], c.pos[2], d.pose[2 * (size_t)i].w); pose = true; }
-		if (c.ops & CMD_SET_ROT) { d.pose[2 * (size_t)i + 1] = make_float4(c.rot[0], c.rot[1], c.rot[2], c.rot[3]); pose = true; }
+		if (c.ops & CMD_SET_POS) { d.pose[POSE_F4 * (size_t)i] = make_float4(c.pos[0], c.pos[1], c.pos[2], d.pose[POSE_F4 * (size_t)i].w); pose = true; }
+		if (c.ops & CMD_SET_ROT) { d.pose[POSE_F4 * (size_t)i + 1] = make_float4(c.rot[0], c.rot[1], c.rot[2], c.rot[3]); pose = true; }
 		if (c.ops & CMD_SET_SHAPE) {
-			d.prop[2 * (size_t)i + 1] = make_float4(c.shape[0], c.shape[1], c.shape[2], d.prop[2 * (size_t)i + 1].w); pose = true;
+			d.pose[POSE_F4 * (size_t)i + 3] = make_float4(c.shape[0], c.shape[1], c.shape[2], d.pose[POSE_F4 * (size_t)i + 3].w); pose = true;
 			f = ((f & ~BF_LARGE) | (c.flags & BF_LARGE)) | BF_CACHE_INVALID;      // a new scale can move the body across the broad phase's large-body radius (host: note_radius)
 		}
 		if ((c.ops & CMD_SET_VEL) && f_motion(f) != SGP_MOTION_STATIC) {
@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(TPB) k_apply_cmds(DV d, const BodyCmd* cmds, c
 				const v3 Fv = V3(c.linv[0], c.linv[1], c.linv[2]);
 				const float4 F = d.force[i], T = d.torque[i];
 				d.force[i] = F4(v3_add(V3(F), Fv), F.w);
-				d.torque[i] = F4(v3_add(V3(T), v3_cross(v3_sub(V3(c.pos[0], c.pos[1], c.pos[2]), V3(d.pose[2 * (size_t)i])), Fv)), T.w);
+				d.torque[i] = F4(v3_add(V3(T), v3_cross(v3_sub(V3(c.pos[0], c.pos[1], c.pos[2]), V3(d.pose[POSE_F4 * (size_t)i])), Fv)), T.w);
 				f = activate_body(d, i, f) | BF_HAS_FORCE;
 			}
 		}
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(TPB) k_apply_cmds(DV d, const BodyCmd* cmds, c
 
 SGP_DEV void fill_state(const DV& d, uint32_t i, sgp_body_state* s)
 {
-	const float4 p = d.pose[2 * (size_t)i], q = d.pose[2 * (size_t)i + 1], lv = d.vel[VEL_F4 * (size_t)i], av = d.vel[VEL_F4 * (size_t)i + 1];
+	const float4 p = d.pose[POSE_F4 * (size_t)i], q = d.pose[POSE_F4 * (size_t)i + 1], lv = d.vel[VEL_F4 * (size_t)i], av = d.vel[VEL_F4 * (size_t)i + 1];
 	const uint32_t f = d.flags[i];
 	s->pos[0] = p.x; s->pos[1] = p.y; s->pos[2] = p.z;
 	s->rot[0] = q.x; s->rot[1] = q.y; s->rot[2] = q.z; s->rot[3] = q.w;
@@ -151,9 +151,9 @@ __global__ void __launch_bounds__(TPB) k_gather_active_poses(DV d, float4* out, 
 	const bool want = (f & (BF_ALIVE | BF_ACTIVE)) == (BF_ALIVE | BF_ACTIVE);
 	const uint32_t k = block_alloc(&d.ctr->n_read_active, want);      // one atomic per workgroup
 	if (want && k < cap) {
-		const float4 p = d.pose[2 * (size_t)i];
+		const float4 p = d.pose[POSE_F4 * (size_t)i];
 		out[2 * (size_t)k] = make_float4(p.x, p.y, p.z, __uint_as_float(i));
-		out[2 * (size_t)k + 1] = d.pose[2 * (size_t)i + 1];
+		out[2 * (size_t)k + 1] = d.pose[POSE_F4 * (size_t)i + 1];
 	}
 }
 

@@ -19,8 +19,8 @@ SGP_DEV bool reuse_cached_manifold(const DV& d, uint2 ab, uint32_t fa, uint32_t 
 	if (!d.st.use_body_pair_contact_cache || ((fa | fb) & (BF_CACHE_INVALID | BF_SENSOR))) return false;
 	const float4* rec = PRV(d).prec + (size_t)ps * PREC_F4;      // the relative pose the previous manifold was computed at: one 64-byte record
 	const float4 cdr = rec[0], cdp = rec[1], cnl = rec[2];
-	const v3 posA = V3(d.pose[2 * (size_t)ab.x]), posB = V3(d.pose[2 * (size_t)ab.y]);
-	const quat qA = Q4(d.pose[2 * (size_t)ab.x + 1]), qB = Q4(d.pose[2 * (size_t)ab.y + 1]);
+	const v3 posA = V3(d.pose[POSE_F4 * (size_t)ab.x]), posB = V3(d.pose[POSE_F4 * (size_t)ab.y]);
+	const quat qA = Q4(d.pose[POSE_F4 * (size_t)ab.x + 1]), qB = Q4(d.pose[POSE_F4 * (size_t)ab.y + 1]);
 	v3 dpos; quat drot;
 	pair_relative_pose(posA, qA, posB, qB, &dpos, &drot);
 	if (!(v3_len_sq(v3_sub(dpos, V3(cdp))) <= d.st.body_pair_cache_max_delta_position_sq)) return false;

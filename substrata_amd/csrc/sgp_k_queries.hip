@@ -139,7 +139,7 @@ SGP_DEV void ray_test_body(const DV& d, const sgp_ray& ry, v3 o, v3 dir, uint32_
 	if (ry.collidable_only && !(layer == SGP_LAYER_NON_MOVING || layer == SGP_LAYER_MOVING)) return;
 	if (!ray_aabb(o, dir, d.aabb_min[i], d.aabb_max[i], best.t)) return;
 	v3 nn; RaySub sub;
-	const float t = ray_body(d, f_shape(f), d.prop[2 * (size_t)i + 1], V3(d.pose[2 * (size_t)i]), Q4(d.pose[2 * (size_t)i + 1]), o, dir, best.t, &nn, &sub);
+	const float t = ray_body(d, f_shape(f), d.pose[POSE_F4 * (size_t)i + 3], V3(d.pose[POSE_F4 * (size_t)i]), Q4(d.pose[POSE_F4 * (size_t)i + 1]), o, dir, best.t, &nn, &sub);
 	// closest hit; ties go to the lower body id so the result does not depend on the traversal order
 	if (t >= 0.0f && t <= best.t && (t < best.t || best.id == SGP_INVALID_ID || i < best.id)) { best.t = t; best.id = i; best.n = nn; best.sub = sub; }
 }
@@ -148,7 +148,7 @@ SGP_DEV void ray_test_body(const DV& d, const sgp_ray& ry, v3 o, v3 dir, uint32_
 SGP_DEV void ray_test_body_eager(const DV& d, const sgp_ray& ry, v3 o, v3 dir, uint32_t i, RayBest& best)
 {
 	const uint32_t f = d.flags[i];
-	const float4 amin = d.aabb_min[i], amax = d.aabb_max[i], prop1 = d.prop[2 * (size_t)i + 1], pose0 = d.pose[2 * (size_t)i], pose1 = d.pose[2 * (size_t)i + 1];
+	const float4 amin = d.aabb_min[i], amax = d.aabb_max[i], prop1 = d.pose[POSE_F4 * (size_t)i + 3], pose0 = d.pose[POSE_F4 * (size_t)i], pose1 = d.pose[POSE_F4 * (size_t)i + 1];
 	ray_test_loaded(d, ry, o, dir, i, f, amin, amax, prop1, pose0, pose1, best);
 }
 
@@ -250,7 +250,7 @@ SGP_DEV void ray_cache_fill(const DV& d, RayServerCache& C)
 	if (lane < RAY_CACHE_LARGE && (uint32_t)lane < C.n_large) {
 		const uint32_t i = d.large_ids[lane];
 		C.id[lane] = i; C.f[lane] = d.flags[i]; C.amin[lane] = d.aabb_min[i]; C.amax[lane] = d.aabb_max[i];
-		C.prop1[lane] = d.prop[2 * (size_t)i + 1]; C.pose0[lane] = d.pose[2 * (size_t)i]; C.pose1[lane] = d.pose[2 * (size_t)i + 1];
+		C.prop1[lane] = d.pose[POSE_F4 * (size_t)i + 3]; C.pose0[lane] = d.pose[POSE_F4 * (size_t)i]; C.pose1[lane] = d.pose[POSE_F4 * (size_t)i + 1];
 	}
 	__syncthreads();
 }
@@ -401,9 +401,9 @@ SGP_DEV void capsule_emit(const DV& d, uint32_t k, uint32_t j, uint32_t f, int g
 		c.normal[0] = m.n.x; c.normal[1] = m.n.y; c.normal[2] = m.n.z;
 		c.distance = v3_dot(v3_sub(m.p2[i], m.p1[i]), m.n);
 		v3 pv = V3(0.0f, 0.0f, 0.0f);
-		if (f_motion(f) != SGP_MOTION_STATIC) pv = v3_add(V3(d.vel[VEL_F4 * (size_t)j]), v3_cross(V3(d.vel[VEL_F4 * (size_t)j + 1]), v3_sub(m.p1[i], V3(d.pose[2 * (size_t)j]))));
+		if (f_motion(f) != SGP_MOTION_STATIC) pv = v3_add(V3(d.vel[VEL_F4 * (size_t)j]), v3_cross(V3(d.vel[VEL_F4 * (size_t)j + 1]), v3_sub(m.p1[i], V3(d.pose[POSE_F4 * (size_t)j]))));
 		c.point_velocity[0] = pv.x; c.point_velocity[1] = pv.y; c.point_velocity[2] = pv.z;
-		c.motion_type = f_motion(f); c.is_sensor = (f & BF_SENSOR) ? 1u : 0u; c.inv_mass = d.pose[2 * (size_t)j].w; c.userdata = 0;
+		c.motion_type = f_motion(f); c.is_sensor = (f & BF_SENSOR) ? 1u : 0u; c.inv_mass = d.pose[POSE_F4 * (size_t)j].w; c.userdata = 0;
 		out[slot] = c;
 	}
 }
@@ -495,11 +495,11 @@ SGP_DEV void spherecast_body(const DV& d, const sgp_ray& ry, float rs, v3 o, v3 
 	const float4 mn = d.aabb_min[j], mx = d.aabb_max[j];
 	const float e = rs + 1.0e-3f;
 	if (!ray_aabb(o, dir, make_float4(mn.x - e, mn.y - e, mn.z - e, 0.0f), make_float4(mx.x + e, mx.y + e, mx.z + e, 0.0f), ry.max_t)) return;      // full length: see veh_cast_test
-	const float4 sh = d.prop[2 * (size_t)j + 1];
+	const float4 sh = d.pose[POSE_F4 * (size_t)j + 3];
 	const float prm[3] = { sh.x, sh.y, sh.z };
 	v3 n, p;
 	const float t = f_shape(f) == SGP_SHAPE_MESH ? cast_sphere_mesh(d, j, o, dir, best.t, rs, &n, &p)
-	              : sgd_cast_sphere_body((int)f_shape(f), prm, f_shape(f) == SGP_SHAPE_HULL ? body_hull(d, sh) : nullptr, V3(d.pose[2 * (size_t)j]), quat_to_m33(Q4(d.pose[2 * (size_t)j + 1])), o, dir, best.t, rs, &n, &p);
+	              : sgd_cast_sphere_body((int)f_shape(f), prm, f_shape(f) == SGP_SHAPE_HULL ? body_hull(d, sh) : nullptr, V3(d.pose[POSE_F4 * (size_t)j]), quat_to_m33(Q4(d.pose[POSE_F4 * (size_t)j + 1])), o, dir, best.t, rs, &n, &p);
 	if (t >= 0.0f && t <= best.t && (t < best.t || best.id == SGP_INVALID_ID || j < best.id)) { best.t = t; best.id = j; best.n = n; }
 }
 

@@ -156,12 +156,12 @@ SGP_DEV void solve_position_one(const DV& d, uint32_t slot)
 	const v3 nrm = V3(nf);
 	const int np = (int)hd.z & 0xFF;
 	// the pose records themselves (k_integrate_pose advanced them; the corrections are made in place) + the local inverse inertia
-	float4* ra = d.pose + 2 * (size_t)ab.x;
-	float4* rb = d.pose + 2 * (size_t)ab.y;
+	float4* ra = d.pose + POSE_F4 * (size_t)ab.x;
+	float4* rb = d.pose + POSE_F4 * (size_t)ab.y;
 	const float4 pa = ra[0], pb = rb[0];
 	const float im1 = pa.w, im2 = pb.w;                 // 0 unless dynamic (and a dynamic body in a constraint is awake: touched sleepers are woken by k_pre_solve)
 	quat qa = Q4(ra[1]), qb = Q4(rb[1]);
-	const v3 iiA = V3(d.prop[2 * (size_t)ab.x]), iiB = V3(d.prop[2 * (size_t)ab.y]);
+	const v3 iiA = V3(d.pose[POSE_F4 * (size_t)ab.x + 2]), iiB = V3(d.pose[POSE_F4 * (size_t)ab.y + 2]);
 	v3 posA = V3(pa), posB = V3(pb);
 	bool moved = false;
 	m33 RA = quat_to_m33(qa), RB = quat_to_m33(qb);          // recomputed below only after a correction turned a body (same values as computing them per point)
@@ -503,9 +503,9 @@ template <int MODE, int ROWS = -1> __global__ void __launch_bounds__(HC_TPB) k_s
 				at = (at + 1) & (HC_TABLE - 1);
 			}
 			if (owner) {
-				const float4* g = (MODE == 1 ? d.vel + VEL_F4 * (size_t)body : d.pose + 2 * (size_t)body);
+				const float4* g = (MODE == 1 ? d.vel + VEL_F4 * (size_t)body : d.pose + POSE_F4 * (size_t)body);
 				s_rec[RS * at] = g[0]; s_rec[RS * at + 1] = g[1];
-				if (MODE != 1) s_rec[RS * at + 2] = d.prop[2 * (size_t)body];
+				if (MODE != 1) s_rec[RS * at + 2] = d.pose[POSE_F4 * (size_t)body + 2];
 			}
 			if (MODE == 1) h.body = at;
 		}
@@ -518,7 +518,7 @@ template <int MODE, int ROWS = -1> __global__ void __launch_bounds__(HC_TPB) k_s
 		}
 		if (MODE == 1 && mine) half_store(d, slot, side, h);
 		if (owner && s_rec[RS * at].w > 0.0f) {
-			float4* g = (MODE == 1 ? d.vel + VEL_F4 * (size_t)body : d.pose + 2 * (size_t)body);
+			float4* g = (MODE == 1 ? d.vel + VEL_F4 * (size_t)body : d.pose + POSE_F4 * (size_t)body);
 			g[0] = s_rec[RS * at]; g[1] = s_rec[RS * at + 1];
 		}
 	}

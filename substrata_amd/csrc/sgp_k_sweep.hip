@@ -27,7 +27,7 @@ __global__ void __launch_bounds__(TPB) k_pre_solve(DV d)
 	if (f & BF_WAKE) {
 		f &= ~BF_WAKE;
 		if (!(f & BF_ACTIVE)) { f |= BF_ACTIVE; push_event(d.ev_activated, &d.evc->n_activated, d.cap_bodies, i); }
-		reset_sleep(d, i, f_shape(f), d.prop[2 * (size_t)i + 1], V3(d.pose[2 * (size_t)i]), Q4(d.pose[2 * (size_t)i + 1]));
+		reset_sleep(d, i, f_shape(f), d.pose[POSE_F4 * (size_t)i + 3], V3(d.pose[POSE_F4 * (size_t)i]), Q4(d.pose[POSE_F4 * (size_t)i + 1]));
 	}
 	if ((f & BF_ACTIVE) && f_motion(f) != SGP_MOTION_STATIC) {
 		v3 lv = V3(lv4), av = V3(av4);
@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(TPB) k_pre_solve(DV d)
 				if (f & BF_HAS_FORCE) {                                      // the accumulators hold something: read them, clear them
 					const float4 F4v = d.force[i], T4 = d.torque[i];
 					F = V3(F4v); T = V3(T4);
-					Iw = world_inv_inertia(quat_to_m33(Q4(d.pose[2 * (size_t)i + 1])), V3(d.prop[2 * (size_t)i]));
+					Iw = world_inv_inertia(quat_to_m33(Q4(d.pose[POSE_F4 * (size_t)i + 1])), V3(d.pose[POSE_F4 * (size_t)i + 2]));
 					d.force[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 					d.torque[i] = make_float4(0.0f, 0.0f, 0.0f, T4.w);
 					f &= ~BF_HAS_FORCE;
@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(TPB) k_pre_solve(DV d)
 		if (im > 0.0f && d.sp->compact_rows != 0u) {
 			// compact rows: the lanes of the velocity iterations rebuild I (r x axis) -- from this record (the expression k_setup evaluates on the same
 			// pose and property records, hence the same bits), one 32-byte gather instead of 48 bytes and a rotation matrix per lane and launch
-			const sym33 I = world_inv_inertia(quat_to_m33(Q4(d.pose[2 * (size_t)i + 1])), V3(d.prop[2 * (size_t)i]));
+			const sym33 I = world_inv_inertia(quat_to_m33(Q4(d.pose[POSE_F4 * (size_t)i + 1])), V3(d.pose[POSE_F4 * (size_t)i + 2]));
 			d.vel[VEL_F4 * (size_t)i + 2] = make_float4(I.xx, I.xy, I.xz, I.yy);
 			d.vel[VEL_F4 * (size_t)i + 3] = make_float4(I.yz, I.zz, 0.0f, 0.0f);
 		}
@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(TPB) k_integrate_pose(DV d)
 	if (i >= d.cap_bodies) return;
 	const uint32_t f = d.flags[i];                                      // (flags and records requested together: one memory round trip)
 	const float4 v4 = d.vel[VEL_F4 * (size_t)i], w4 = d.vel[VEL_F4 * (size_t)i + 1];
-	float4 p = d.pose[2 * (size_t)i], r4 = d.pose[2 * (size_t)i + 1];
+	float4 p = d.pose[POSE_F4 * (size_t)i], r4 = d.pose[POSE_F4 * (size_t)i + 1];
 	const float dt = d.sp->dt;
 	if (i >= d.sp->n_slots) return;
 	if ((f & (BF_ALIVE | BF_ACTIVE)) != (BF_ALIVE | BF_ACTIVE) || f_motion(f) == SGP_MOTION_STATIC) return;
@@ -103,11 +103,11 @@ __global__ void __launch_bounds__(TPB) k_integrate_pose(DV d)
 	}
 	const v3 np = v3_add(V3(p), v3_scale(lv, dt));
 	const quat q = quat_add_rotation_step(Q4(r4), v3_scale(av, dt));
-	d.pose[2 * (size_t)i] = F4(np, p.w);
-	d.pose[2 * (size_t)i + 1] = make_float4(q.x, q.y, q.z, q.w);
+	d.pose[POSE_F4 * (size_t)i] = F4(np, p.w);
+	d.pose[POSE_F4 * (size_t)i + 1] = make_float4(q.x, q.y, q.z, q.w);
 	if (f_shape(f) == SGP_SHAPE_MESH) {
 		// a kinematic mesh body (a scripted platform): the two alias slots behind it -- second / third contact manifold of a pair -- share its pose
-		for (uint32_t k = 1; k <= 2; ++k) { d.pose[2 * (size_t)(i + k)] = F4(np, p.w); d.pose[2 * (size_t)(i + k) + 1] = make_float4(q.x, q.y, q.z, q.w); }
+		for (uint32_t k = 1; k <= 2; ++k) { d.pose[POSE_F4 * (size_t)(i + k)] = F4(np, p.w); d.pose[POSE_F4 * (size_t)(i + k) + 1] = make_float4(q.x, q.y, q.z, q.w); }
 	}
 }
 
@@ -122,8 +122,8 @@ __global__ void __launch_bounds__(TPB) k_finalize(DV d)
 	const uint32_t i = blockIdx.x * TPB + threadIdx.x;
 	if (i >= d.cap_bodies) return;
 	uint32_t f = d.flags[i];                                            // (flags and records requested together: one memory round trip)
-	const float4 sh = d.prop[2 * (size_t)i + 1];
-	const float4 p4 = d.pose[2 * (size_t)i], r4 = d.pose[2 * (size_t)i + 1];      // (the position iterations corrected the pose records in place)
+	const float4 sh = d.pose[POSE_F4 * (size_t)i + 3];
+	const float4 p4 = d.pose[POSE_F4 * (size_t)i], r4 = d.pose[POSE_F4 * (size_t)i + 1];      // (the position iterations corrected the pose records in place)
 	float4 s[3];
 	for (int k = 0; k < 3; ++k) s[k] = d.sleep_s[k][i];
 	const float timer = d.sleep_timer[i];
@@ -396,10 +396,10 @@ __global__ void __launch_bounds__(TPB) k_buoyancy(DV d)
 	if (mn.z < d.sp->water_z) {                                                          // :1379
 		const float fluid_density = 1020.0f;                                         // :1381
 		const uint32_t type = f_shape(f);
-		const float4 sh = d.prop[2 * (size_t)i + 1];
-		const float4 pim = d.pose[2 * (size_t)i];
+		const float4 sh = d.pose[POSE_F4 * (size_t)i + 3];
+		const float4 pim = d.pose[POSE_F4 * (size_t)i];
 		const v3 pos = V3(pim);
-		const m33 R = quat_to_m33(Q4(d.pose[2 * (size_t)i + 1]));
+		const m33 R = quat_to_m33(Q4(d.pose[POSE_F4 * (size_t)i + 1]));
 		// Shape::GetSubmergedVolume as Jolt's shapes implement it: box and hull exactly, sphere by the cap formula, the capsule through
 		// ConvexShape's stand-in -- its local bounding box (total = the box's volume, submerged = the box's part under the plane)
 		const float real_volume = shape_volume(d, type, sh);
@@ -455,7 +455,7 @@ __global__ void __launch_bounds__(TPB) k_buoyancy(DV d)
 			const float l = (size.x + size.y + size.z) / 3.0f;
 			const float ang_drag = 3.0f;                                             // :1405
 			const v3 drag_ang_imp = v3_scale(av, -ang_drag * sub / total * dt * (l * l) / inv_mass);
-			const sym33 Iw = world_inv_inertia(R, V3(d.prop[2 * (size_t)i]));
+			const sym33 Iw = world_inv_inertia(R, V3(d.pose[POSE_F4 * (size_t)i + 2]));
 			v3 ddrag = sym33_mul(Iw, drag_ang_imp);
 			if (v3_len_sq(ddrag) > v3_len_sq(av)) ddrag = v3_neg(av);
 			const v3 dang = v3_add(ddrag, sym33_mul(Iw, v3_cross(rc, v3_add(buoy_imp, drag_imp))));

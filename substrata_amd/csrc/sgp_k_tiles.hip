@@ -63,14 +63,14 @@ __global__ void __launch_bounds__(TPB) k_export_boundary(DV d, float3 lo, float3
 	const uint32_t k = base + wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 	if (k >= cap) return;
 	sgp_ghost_record r;
-	const float4 p = d.pose[2 * (size_t)i], qq = d.pose[2 * (size_t)i + 1], lv = d.vel[VEL_F4 * (size_t)i], av = d.vel[VEL_F4 * (size_t)i + 1], sh = d.prop[2 * (size_t)i + 1];
+	const float4 p = d.pose[POSE_F4 * (size_t)i], qq = d.pose[POSE_F4 * (size_t)i + 1], lv = d.vel[VEL_F4 * (size_t)i], av = d.vel[VEL_F4 * (size_t)i + 1], sh = d.pose[POSE_F4 * (size_t)i + 3];
 	r.pos[0] = p.x; r.pos[1] = p.y; r.pos[2] = p.z;
 	r.rot[0] = qq.x; r.rot[1] = qq.y; r.rot[2] = qq.z; r.rot[3] = qq.w;
 	r.lin_vel[0] = lv.x; r.lin_vel[1] = lv.y; r.lin_vel[2] = lv.z;
 	r.ang_vel[0] = av.x; r.ang_vel[1] = av.y; r.ang_vel[2] = av.z;
 	r.shape_type = (int32_t)f_shape(f);
 	r.shape[0] = sh.x; r.shape[1] = sh.y; r.shape[2] = sh.z; r.shape[3] = 0.0f;
-	r.mass = d.torque[i].w; r.friction = sh.w; r.restitution = d.prop[2 * (size_t)i].w;
+	r.mass = d.torque[i].w; r.friction = sh.w; r.restitution = d.pose[POSE_F4 * (size_t)i + 2].w;
 	r.motion_type = f_motion(f);
 	r.global_id = i;
 	fill_ghost_desc(d, i, f, r);
@@ -90,7 +90,7 @@ SGP_DEV unsigned long long route_mask(const DV& d, uint32_t i, const TileRoute& 
 	emigrates = false;
 	const float* mylo = t.boxes + 6 * t.my_rank; const float* myhi = mylo + 3;
 	if (!export_qualifies(d, i, make_float3(mylo[0], mylo[1], mylo[2]), make_float3(myhi[0], myhi[1], myhi[2]), t.margin, f)) return 0ull;
-	const float4 p = d.pose[2 * (size_t)i];
+	const float4 p = d.pose[POSE_F4 * (size_t)i];
 	// an owned dynamic body emigrates only when another tile's own (unpadded) region contains its centre: where the caller's boxes leave a gap
 	// nobody would accept the body, so it stays with its current owner instead of vanishing
 	// (a vehicle's chassis stays with the tile that holds the vehicle record: SGP_GHOST_FLAG_CHASSIS)
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(TPB) k_tiles_hist(DV d, TilePlanes tp, int lev
 	if (i >= d.sp->n_slots) return;
 	const uint32_t f = d.flags[i];
 	if (!(f & BF_ALIVE) || (f & BF_ALIAS) || f_motion(f) != SGP_MOTION_DYNAMIC) return;      // (ghosts are kinematic here: owned bodies only)
-	const float4 p = d.pose[2 * (size_t)i];
+	const float4 p = d.pose[POSE_F4 * (size_t)i];
 	if (level == 0) {
 		int* o = (int*)out;
 		atomicMin(&o[0], float_to_ordered(p.x)); atomicMin(&o[1], float_to_ordered(p.y)); atomicMin(&o[2], float_to_ordered(p.z));
@@ -217,14 +217,14 @@ __global__ void __launch_bounds__(TPB) k_route_write(DV d, TileRoute t, const ui
 		const uint32_t k = header->seg_start[dst] + block_offsets[(size_t)blockIdx.x * cols + dst] + wbase + (uint32_t)__popcll(b & below);
 		if (k >= cap) continue;
 		if (!built) {
-			const float4 p = d.pose[2 * (size_t)i], qq = d.pose[2 * (size_t)i + 1], lv = d.vel[VEL_F4 * (size_t)i], av = d.vel[VEL_F4 * (size_t)i + 1], sh = d.prop[2 * (size_t)i + 1];
+			const float4 p = d.pose[POSE_F4 * (size_t)i], qq = d.pose[POSE_F4 * (size_t)i + 1], lv = d.vel[VEL_F4 * (size_t)i], av = d.vel[VEL_F4 * (size_t)i + 1], sh = d.pose[POSE_F4 * (size_t)i + 3];
 			r.pos[0] = p.x; r.pos[1] = p.y; r.pos[2] = p.z;
 			r.rot[0] = qq.x; r.rot[1] = qq.y; r.rot[2] = qq.z; r.rot[3] = qq.w;
 			r.lin_vel[0] = lv.x; r.lin_vel[1] = lv.y; r.lin_vel[2] = lv.z;
 			r.ang_vel[0] = av.x; r.ang_vel[1] = av.y; r.ang_vel[2] = av.z;
 			r.shape_type = (int32_t)f_shape(f);
 			r.shape[0] = sh.x; r.shape[1] = sh.y; r.shape[2] = sh.z; r.shape[3] = 0.0f;
-			r.mass = d.torque[i].w; r.friction = sh.w; r.restitution = d.prop[2 * (size_t)i].w;
+			r.mass = d.torque[i].w; r.friction = sh.w; r.restitution = d.pose[POSE_F4 * (size_t)i + 2].w;
 			r.motion_type = emig ? (SGP_MOTION_DYNAMIC | SGP_GHOST_TAKE_OWNERSHIP) : f_motion(f);
 			r.global_id = (uint64_t)i | ((uint64_t)t.my_rank << 40);
 			fill_ghost_desc(d, i, f, r);
@@ -250,8 +250,8 @@ __global__ void __launch_bounds__(TPB) k_ghost_refresh_records(DV d, const sgp_g
 	uint32_t f = d.flags[i];
 	if (!(f & BF_ALIVE)) return;
 	const sgp_ghost_record& c = recs[k];
-	d.pose[2 * (size_t)i] = make_float4(c.pos[0], c.pos[1], c.pos[2], d.pose[2 * (size_t)i].w);
-	d.pose[2 * (size_t)i + 1] = make_float4(c.rot[0], c.rot[1], c.rot[2], c.rot[3]);
+	d.pose[POSE_F4 * (size_t)i] = make_float4(c.pos[0], c.pos[1], c.pos[2], d.pose[POSE_F4 * (size_t)i].w);
+	d.pose[POSE_F4 * (size_t)i + 1] = make_float4(c.rot[0], c.rot[1], c.rot[2], c.rot[3]);
 	if (f_motion(f) != SGP_MOTION_STATIC) {
 		d.vel[VEL_F4 * (size_t)i] = make_float4(c.lin_vel[0], c.lin_vel[1], c.lin_vel[2], d.vel[VEL_F4 * (size_t)i].w);
 		d.vel[VEL_F4 * (size_t)i + 1] = make_float4(c.ang_vel[0], c.ang_vel[1], c.ang_vel[2], d.vel[VEL_F4 * (size_t)i + 1].w);
@@ -323,20 +323,20 @@ __global__ void __launch_bounds__(TPB) k_create_from_records(DV d, const sgp_gho
 		inv_mass = 1.0f / mass; ii0 = 1.0f / ix; ii1 = 1.0f / iy; ii2 = 1.0f / iz;
 	}
 	const float friction = r.friction < 0.0f ? 0.0f : (r.friction > 1.0f ? 1.0f : r.friction), restitution = r.restitution < 0.0f ? 0.0f : (r.restitution > 1.0f ? 1.0f : r.restitution);      // (clamp01 of add_one)
-	d.pose[2 * (size_t)i] = make_float4(r.pos[0], r.pos[1], r.pos[2], inv_mass);
-	d.pose[2 * (size_t)i + 1] = make_float4(r.rot[0], r.rot[1], r.rot[2], r.rot[3]);
+	d.pose[POSE_F4 * (size_t)i] = make_float4(r.pos[0], r.pos[1], r.pos[2], inv_mass);
+	d.pose[POSE_F4 * (size_t)i + 1] = make_float4(r.rot[0], r.rot[1], r.rot[2], r.rot[3]);
 	d.vel[VEL_F4 * (size_t)i] = make_float4(r.lin_vel[0], r.lin_vel[1], r.lin_vel[2], 0.0f);
 	d.vel[VEL_F4 * (size_t)i + 1] = make_float4(r.ang_vel[0], r.ang_vel[1], r.ang_vel[2], 0.0f);
 	d.dyn[i] = ghost ? make_float4(def.lin_damp, def.ang_damp, def.gravity_factor, inv_mass) : make_float4(r.linear_damping, r.angular_damping, r.gravity_factor, inv_mass);
 	d.force[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	d.torque[i] = make_float4(0.0f, 0.0f, 0.0f, mass);
-	d.prop[2 * (size_t)i] = make_float4(ii0, ii1, ii2, restitution);
-	d.prop[2 * (size_t)i + 1] = make_float4(r.shape[0], r.shape[1], r.shape[2], friction);
+	d.pose[POSE_F4 * (size_t)i + 2] = make_float4(ii0, ii1, ii2, restitution);
+	d.pose[POSE_F4 * (size_t)i + 3] = make_float4(r.shape[0], r.shape[1], r.shape[2], friction);
 	d.submerged[i] = 0.0f;
 	d.userdata[i] = r.userdata;
 	label_new_body(d, i);
 	refresh_aabb(d, i, f);
-	reset_sleep(d, i, f_shape(f), d.prop[2 * (size_t)i + 1], V3(d.pose[2 * (size_t)i]), Q4(d.pose[2 * (size_t)i + 1]));
+	reset_sleep(d, i, f_shape(f), d.pose[POSE_F4 * (size_t)i + 3], V3(d.pose[POSE_F4 * (size_t)i]), Q4(d.pose[POSE_F4 * (size_t)i + 1]));
 	f = activate_body(d, i, f);      // (both kinds arrive awake: d.activate = 1 in make_ghost and in the take-over)
 	d.flags[i] = f;
 }

@@ -14,11 +14,11 @@ SGP_DEV void veh_cast_test(const DV& d, const sgd_vehicle* v, v3 o, v3 dir, floa
 	// the bounds filter uses the full cast length, not the best hit so far: the planes-only swept-sphere test of boxes and hulls can report a
 	// touch just outside the inflated bounds (it is generous at corners), and the answer must not depend on the order of the candidates
 	if (!ray_aabb(o, dir, make_float4(mn.x - e, mn.y - e, mn.z - e, 0.0f), make_float4(mx.x + e, mx.y + e, mx.z + e, 0.0f), cast_len)) return;
-	const float4 sh = d.prop[2 * (size_t)j + 1];
+	const float4 sh = d.pose[POSE_F4 * (size_t)j + 3];
 	const float prm[3] = { sh.x, sh.y, sh.z };
 	v3 n, p;
 	const float t = f_shape(f) == SGP_SHAPE_MESH ? cast_sphere_mesh(d, j, o, dir, best, rs, &n, &p)
-	              : sgd_cast_sphere_body((int)f_shape(f), prm, f_shape(f) == SGP_SHAPE_HULL ? body_hull(d, sh) : nullptr, V3(d.pose[2 * (size_t)j]), quat_to_m33(Q4(d.pose[2 * (size_t)j + 1])), o, dir, best, rs, &n, &p);
+	              : sgd_cast_sphere_body((int)f_shape(f), prm, f_shape(f) == SGP_SHAPE_HULL ? body_hull(d, sh) : nullptr, V3(d.pose[POSE_F4 * (size_t)j]), quat_to_m33(Q4(d.pose[POSE_F4 * (size_t)j + 1])), o, dir, best, rs, &n, &p);
 	if (t < 0.0f || n.z < v->cos_max_slope) return;
 	// closest accepted hit; on equal distance the lower body id wins (the oracle visits ids in ascending order)
 	if (t < best || bid == SGP_INVALID_ID || (t == best && j < bid)) { best = t; bid = j; bn = n; bp = p; }
@@ -27,9 +27,9 @@ SGP_DEV void veh_cast_test(const DV& d, const sgd_vehicle* v, v3 o, v3 dir, floa
 SGP_DEV sgd_chassis veh_chassis_pose_vel(const DV& d, uint32_t b)
 {
 	sgd_chassis c;
-	const float4 p = d.pose[2 * (size_t)b];
-	c.pos = V3(p); c.rot = Q4(d.pose[2 * (size_t)b + 1]); c.v = V3(d.vel[VEL_F4 * (size_t)b]); c.w = V3(d.vel[VEL_F4 * (size_t)b + 1]);
-	c.im = p.w; c.inv_inertia_local = V3(d.prop[2 * (size_t)b]);
+	const float4 p = d.pose[POSE_F4 * (size_t)b];
+	c.pos = V3(p); c.rot = Q4(d.pose[POSE_F4 * (size_t)b + 1]); c.v = V3(d.vel[VEL_F4 * (size_t)b]); c.w = V3(d.vel[VEL_F4 * (size_t)b + 1]);
+	c.im = p.w; c.inv_inertia_local = V3(d.pose[POSE_F4 * (size_t)b + 2]);
 	c.I = world_inv_inertia(quat_to_m33(c.rot), c.inv_inertia_local);
 	return c;
 }
@@ -132,8 +132,8 @@ __global__ void __launch_bounds__(64) k_vehicle_cast(DV d)
 		if (wi < sv.num_wheels && sub == 0 && bid != SGP_INVALID_ID) {
 			const uint32_t fo = d.flags[bid];
 			v3 gvel = V3(0.0f, 0.0f, 0.0f);
-			if (f_motion(fo) != SGP_MOTION_STATIC) gvel = v3_add(V3(d.vel[VEL_F4 * (size_t)bid]), v3_cross(V3(d.vel[VEL_F4 * (size_t)bid + 1]), v3_sub(bp, V3(d.pose[2 * (size_t)bid]))));
-			sgd_vehicle_set_hit(&sv, wi, bid, best, bn, bp, gvel, d.prop[2 * (size_t)bid + 1].w);
+			if (f_motion(fo) != SGP_MOTION_STATIC) gvel = v3_add(V3(d.vel[VEL_F4 * (size_t)bid]), v3_cross(V3(d.vel[VEL_F4 * (size_t)bid + 1]), v3_sub(bp, V3(d.pose[POSE_F4 * (size_t)bid]))));
+			sgd_vehicle_set_hit(&sv, wi, bid, best, bn, bp, gvel, d.pose[POSE_F4 * (size_t)bid + 3].w);
 			if (f_motion(fo) == SGP_MOTION_DYNAMIC) {
 				// the rows act on a dynamic body under the wheel (VehicleConstraint::SetupVelocityConstraint, body 2): it wakes up if it sleeps
 				// (VehicleConstraint::BuildIslands; k_pre_solve does it, like for a body an active one touches) and this vehicle claims it
@@ -166,9 +166,9 @@ __global__ void __launch_bounds__(64) k_vehicle_controller(DV d)
 		const unsigned long long my_claim = ((unsigned long long)*d.veh_epoch << 32) | (unsigned long long)(0xFFFFFFFFu - blockIdx.x);
 		if ((int)threadIdx.x < sv.num_wheels && sv.wheels[threadIdx.x].has_contact && sv.wheels[threadIdx.x].ground_dynamic) {
 			const uint32_t gb = sv.wheels[threadIdx.x].contact_body;
-			const float4 gp = d.pose[2 * (size_t)gb];
+			const float4 gp = d.pose[POSE_F4 * (size_t)gb];
 			g.dyn = 1; g.pos = V3(gp); g.im = gp.w;
-			g.I = world_inv_inertia(quat_to_m33(Q4(d.pose[2 * (size_t)gb + 1])), V3(d.prop[2 * (size_t)gb]));
+			g.I = world_inv_inertia(quat_to_m33(Q4(d.pose[POSE_F4 * (size_t)gb + 1])), V3(d.pose[POSE_F4 * (size_t)gb + 2]));
 			lost = d.veh_claim[gb] != my_claim;
 		}
 		if (threadIdx.x == 0 && d.veh_claim[b] != my_claim) lost = true;
@@ -309,12 +309,12 @@ template <int MODE> SGP_DEV void veh_quad_solve(const DV& d, uint32_t k, int L, 
 		// VehicleConstraint::SolvePositionConstraint: the axle at minimum suspension length stays on the outer side of the plane through the
 		// axle position at cast time; wheel after wheel on the poses the previous one left (the chassis', and that of a dynamic body under the wheel)
 		const float4 cp = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_CPOS)], wp = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_WPOS)], sd = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_SDIR)];
-		const float4 p4 = d.pose[2 * (size_t)b], q4 = d.pose[2 * (size_t)b + 1];
-		const v3 iil = V3(d.prop[2 * (size_t)b]);
+		const float4 p4 = d.pose[POSE_F4 * (size_t)b], q4 = d.pose[POSE_F4 * (size_t)b + 1];
+		const v3 iil = V3(d.pose[POSE_F4 * (size_t)b + 2]);
 		v3 pos = V3(p4); quat rot = Q4(q4);
 		const float im = p4.w, baumgarte = d.st.baumgarte;
 		float4 gp4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), gq4 = make_float4(0.0f, 0.0f, 0.0f, 1.0f); v3 giil = V3(0.0f, 0.0f, 0.0f);
-		if (gid != SGP_INVALID_ID) { gp4 = d.pose[2 * (size_t)gid]; gq4 = d.pose[2 * (size_t)gid + 1]; giil = V3(d.prop[2 * (size_t)gid]); }
+		if (gid != SGP_INVALID_ID) { gp4 = d.pose[POSE_F4 * (size_t)gid]; gq4 = d.pose[POSE_F4 * (size_t)gid + 1]; giil = V3(d.pose[POSE_F4 * (size_t)gid + 2]); }
 		v3 gpos = V3(gp4); quat grot = Q4(gq4);
 		bool gmoved = false;
 #define VEH_POS_TURN(WI) { \
@@ -353,8 +353,8 @@ template <int MODE> SGP_DEV void veh_quad_solve(const DV& d, uint32_t k, int L, 
 		  if (L != WI && gid != SGP_INVALID_ID && og == gid) { gpos = op; grot.x = ox; grot.y = oy; grot.z = oz; grot.w = ow; } } }
 		VEH_POS_TURN(0) VEH_POS_TURN(1) VEH_POS_TURN(2) VEH_POS_TURN(3)
 #undef VEH_POS_TURN
-		if (L == 0) { d.pose[2 * (size_t)b] = F4(pos, p4.w); d.pose[2 * (size_t)b + 1] = make_float4(rot.x, rot.y, rot.z, rot.w); }
-		if (gmoved) { d.pose[2 * (size_t)gid] = F4(gpos, gp4.w); d.pose[2 * (size_t)gid + 1] = make_float4(grot.x, grot.y, grot.z, grot.w); }      // (the lane that moved it: a later lane on the same body started from this pose)
+		if (L == 0) { d.pose[POSE_F4 * (size_t)b] = F4(pos, p4.w); d.pose[POSE_F4 * (size_t)b + 1] = make_float4(rot.x, rot.y, rot.z, rot.w); }
+		if (gmoved) { d.pose[POSE_F4 * (size_t)gid] = F4(gpos, gp4.w); d.pose[POSE_F4 * (size_t)gid + 1] = make_float4(grot.x, grot.y, grot.z, grot.w); }      // (the lane that moved it: a later lane on the same body started from this pose)
 		return;
 	}
 	// the rows of this lane's wheel
@@ -364,17 +364,17 @@ template <int MODE> SGP_DEV void veh_quad_solve(const DV& d, uint32_t k, int L, 
 	const float4 s0 = d.vel[VEL_F4 * (size_t)b], s1 = d.vel[VEL_F4 * (size_t)b + 1];
 	VehBody c;
 	c.v = V3(s0); c.im = s0.w; c.w = V3(s1);                  // (s0.w: the effective inverse mass of this step, k_pre_solve)
-	const quat crot = Q4(d.pose[2 * (size_t)b + 1]);
-	c.I = c.im > 0.0f ? world_inv_inertia(quat_to_m33(crot), V3(d.prop[2 * (size_t)b])) : sym33_zero();
+	const quat crot = Q4(d.pose[POSE_F4 * (size_t)b + 1]);
+	c.I = c.im > 0.0f ? world_inv_inertia(quat_to_m33(crot), V3(d.pose[POSE_F4 * (size_t)b + 2])) : sym33_zero();
 	float4 cp = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_CPOS)];
 	// the dynamic body under the wheel: velocity record (live), inverse mass, world inverse inertia, lever arm
 	VehGround g; g.id = gid; g.v = V3(0.0f, 0.0f, 0.0f); g.w = g.v; g.im = 0.0f; g.I = sym33_zero(); g.r2 = g.v;
 	float4 g0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), g1 = g0;
 	if (gid != SGP_INVALID_ID) {
 		g0 = d.vel[VEL_F4 * (size_t)gid]; g1 = d.vel[VEL_F4 * (size_t)gid + 1];
-		const float4 gp4 = d.pose[2 * (size_t)gid];
+		const float4 gp4 = d.pose[POSE_F4 * (size_t)gid];
 		g.v = V3(g0); g.w = V3(g1); g.im = gp4.w;
-		g.I = world_inv_inertia(quat_to_m33(Q4(d.pose[2 * (size_t)gid + 1])), V3(d.prop[2 * (size_t)gid]));
+		g.I = world_inv_inertia(quat_to_m33(Q4(d.pose[POSE_F4 * (size_t)gid + 1])), V3(d.pose[POSE_F4 * (size_t)gid + 2]));
 		g.r2 = v3_sub(V3(cp), V3(gp4));
 	}
 	if (MODE == 0) {
@@ -387,7 +387,7 @@ template <int MODE> SGP_DEV void veh_quad_solve(const DV& d, uint32_t k, int L, 
 	}
 	const float4 cl = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_LONG)], ct = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_LAT)], cg = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_GVEL)];
 	const float4 cm = d.veh_rows[veh_chunk_at(d, k, L, VEH_CHUNK_MISC)];
-	const v3 cpos = V3(d.pose[2 * (size_t)b]);
+	const v3 cpos = V3(d.pose[POSE_F4 * (size_t)b]);
 	const v3 gvel = V3(cg);
 	// 1. suspension spring and upper stop: push, never pull
 	VEH_TURNS(if (contact) { if (wbits & 2u) veh_row_solve(c, g, ra[0], ri[0], cm.z, cm.w, gvel, neg_n, 0.0f, 3.0e38f); if (wbits & 4u) veh_row_solve(c, g, ra[1], ri[1], 0.0f, 0.0f, gvel, neg_n, 0.0f, 3.0e38f); })

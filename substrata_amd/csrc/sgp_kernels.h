@@ -221,20 +221,22 @@ struct ConstraintArrays {
 	float4*   prec;        // the body-pair contact cache's record (above), PREC_F4 per slot
 };
 
+#define POSE_F4 4u            // float4 per body in DV::pose (pose record + property record)
 #define VEL_F4 4u             // float4 per body in DV::vel (velocity record + the step's world inverse inertia)
 struct DV {
 	StepParams* sp;
 	uint32_t cap_bodies, cap_pairs, cap_manifolds;
 	// bodies
-	// Per-body state as 32-byte records (two float4 each, record i at [2 i], [2 i + 1]): a sweep kernel streams exactly the records it needs and a
-	// constraint gathers one 32 B record per body and purpose, instead of one float4 from each of several arrays.
-	float4* pose;              // [position xyz, inverse mass (0 unless dynamic)] [rotation quaternion]; the position iterations correct it in place
+	// Per-body state as 64-byte records (four float4 each, record i at [4 i] .. [4 i + 3]), one array per purpose: a constraint gathers ONE 128-byte line per
+	// body and purpose (a gather moves a whole line whatever it asks for: profiles/r06_pmc_calibration.md), a sweep kernel streams the records it needs.
+	float4* pose;              // POSE_F4 float4 per body: [position xyz, inverse mass (0 unless dynamic)] [rotation quaternion] -- the position iterations correct these two in
+	                           //   place -- then the properties, [+2] = [local inverse inertia diagonal xyz, restitution], [+3] = [shape parameters xyz, friction]: the narrow phase,
+	                           //   k_setup and the position iterations read pose and properties together (round 6: one gathered line per body instead of two)
 	float4* vel;               // 64-byte records (VEL_F4 float4 per body, record i at [VEL_F4 i]): [linear velocity xyz, EFFECTIVE inverse mass of the step (0 unless
 	                           //   dynamic and awake; k_pre_solve)] [angular velocity xyz, -]: THE velocity storage, what the velocity iterations gather and scatter; then the
 	                           //   world inverse inertia of the step, [+2] = (xx, xy, xz, yy), [+3] = (yz, zz, -, -), written by k_pre_solve when the step's rows are compact
 	                           //   (StepParams::compact_rows != 0) for bodies that can move: a lane rebuilding I (r x axis) finds it in the SAME 128-byte line as the velocities it
 	                           //   gathers anyway (round 6: at 1 M bodies a velocity launch moved 784 B per constraint for 340 algorithmic -- four gathered lines, two now)
-	float4* prop;              // [local inverse inertia diagonal xyz, restitution] [shape parameters xyz, friction]
 	float4* dyn;               // one float4 per body: linear damping, angular damping, gravity factor, inverse mass (again; k_pre_solve reads nothing else of the pose)
 	float4* force;             // accumulated force xyz, - (read only for bodies flagged BF_HAS_FORCE)
 	float4* torque;            // accumulated torque xyz, mass w

@@ -127,7 +127,7 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	DV& d = w->dv;
 	const uint32_t N = desc->max_bodies, P = w->desc.max_body_pairs, M = w->desc.max_manifolds;
 	d.cap_bodies = N; d.cap_pairs = P; d.cap_manifolds = M;
-	DEV_ALLOC(d.pose, 2 * (size_t)N); DEV_ALLOC(d.vel, VEL_F4 * (size_t)N); DEV_ALLOC(d.prop, 2 * (size_t)N); DEV_ALLOC(d.dyn, N);
+	DEV_ALLOC(d.pose, POSE_F4 * (size_t)N); DEV_ALLOC(d.vel, VEL_F4 * (size_t)N); DEV_ALLOC(d.dyn, N);
 	DEV_ALLOC(d.force, N); DEV_ALLOC(d.torque, N);
 	DEV_ALLOC(d.flags, N); DEV_ALLOC(d.aabb_min, N); DEV_ALLOC(d.aabb_max, N);
 	for (int k = 0; k < 3; ++k) DEV_ALLOC(d.sleep_s[k], N);
