@@ -49,6 +49,10 @@ def exchange(worlds, boxes, margin, log, moved=None):
         log.append(("import", r, len(ghosts), len(immigrants)))
 
 
+CHECK_EVERY = int(os.environ.get("FUZZ_TILES_CHECK_EVERY", "30"))
+TRACE_FROM = int(os.environ.get("FUZZ_TILES_TRACE_FROM", "0"))
+
+
 def run_seed(oracle, seed, steps, verbose=False):
     from substrata_amd.lib import World
     rng = np.random.default_rng(seed)
@@ -100,6 +104,7 @@ def run_seed(oracle, seed, steps, verbose=False):
             if len(own[r]) > 5:
                 i = int(rng.choice(sorted(own[r])))
                 what = rng.random()
+                if TRACE_FROM and s >= TRACE_FROM: print(f"   [trace] step {s}: edit on tile {r} body {i}: {'remove' if what < 0.3 else ('teleport' if what < 0.6 else 'kick')}", flush=True)
                 if what < 0.3:
                     gpu[r].remove(i); cpu[r].remove(i); own[r].discard(i); total -= 1
                 elif what < 0.6:
@@ -133,12 +138,38 @@ def run_seed(oracle, seed, steps, verbose=False):
         assert lg == lc, (seed, s, "exchange logs differ", [a for a, b in zip(lg, lc) if a != b][:3], [b for a, b in zip(lg, lc) if a != b][:3])
         for r in range(n_tiles):
             own[r] -= set(moved[r][0]); own[r] |= set(moved[r][1])
+            if TRACE_FROM and s >= TRACE_FROM and (moved[r][0] or moved[r][1]): print(f"   [trace] step {s}: tile {r} emigrants {sorted(moved[r][0])} immigrants {sorted(moved[r][1])}", flush=True)
+        if TRACE_FROM and s >= TRACE_FROM:
+            for r in range(n_tiles):
+                ag_, ac_ = gpu[r].read_states(0, 2048)["active"], cpu[r].read_states(0, 2048)["active"]
+                print(f"   [trace] step {s} before stepping: tile {r} awake gpu {int(ag_.sum())} cpu {int(ac_.sum())} alive {gpu[r].num_bodies()}", flush=True)
         migrated += sum(e[4] for e in lg if e[0] == "export")
         for r in range(n_tiles):
             gpu[r].step(DT); cpu[r].step(DT)
-        if s % 30 == 0 or s == steps:
+        if TRACE_FROM and s >= TRACE_FROM and os.environ.get("FUZZ_TILES_TRACE_BODY"):
+            tb_ = int(os.environ["FUZZ_TILES_TRACE_BODY"]); tr_ = int(os.environ.get("FUZZ_TILES_TRACE_TILE", "0"))
+            for nm_, w_ in (("gpu", gpu[tr_]), ("cpu", cpu[tr_])):
+                st_ = w_.stats(); cs_ = [c for c in w_.dump_constraints() if tb_ in (int(c["a"]), int(c["b"]))]
+                print(f"   [trace] after step {s} {nm_}: body {tb_} active {int(w_.read_states(0, 2048)['active'][tb_])} constraints {[(int(c['a']), int(c['b']), int(c['colour']), int(c['np'])) for c in cs_]} cached {st_.num_cached_manifolds} wake pairs {st_.num_wake_pairs} activated {st_.num_activated} deactivated {st_.num_deactivated} rounds {st_.num_colour_rounds}", flush=True)
+        if s % CHECK_EVERY == 0 or s == steps:
             for r in range(n_tiles):
-                dd = parity.state_diff(gpu[r].read_states(0, 2048), cpu[r].read_states(0, 2048))
+                sg_, sc_ = gpu[r].read_states(0, 2048), cpu[r].read_states(0, 2048)
+                dd = parity.state_diff(sg_, sc_)
+                if not (dd["bit_exact"] and dd["active_mismatch"] == 0) and os.environ.get("FUZZ_TILES_DETAIL"):
+                    # which bodies differ (debugging aid: FUZZ_TILES_CHECK_EVERY=1 FUZZ_TILES_DETAIL=1)
+                    bad = [int(i) for i in range(2048) if any(not np.array_equal(sg_[f][i], sc_[f][i]) for f in ("pos", "rot", "lin_vel", "ang_vel"))]
+                    print(f"seed {seed} step {s} tile {r}: bodies that differ {bad[:12]}; owned here {sorted(own[r])[:0]}", flush=True)
+                    cg_, cc_ = gpu[r].dump_constraints(), cpu[r].dump_constraints()
+                    kg = {(int(c["a"]), int(c["b"])): c for c in cg_}; kc = {(int(c["a"]), int(c["b"])): c for c in cc_}
+                    print("   constraints gpu/cpu:", len(kg), len(kc), "only gpu", sorted(set(kg) - set(kc))[:6], "only cpu", sorted(set(kc) - set(kg))[:6], flush=True)
+                    for k_ in sorted(set(kg) & set(kc)):
+                        a_, b_ = kg[k_], kc[k_]
+                        if any(not np.array_equal(a_[f], b_[f]) for f in a_.dtype.names):
+                            print("   constraint", k_, "gpu", {f: a_[f].tolist() for f in a_.dtype.names if not np.array_equal(a_[f], b_[f])}, "cpu", {f: b_[f].tolist() for f in a_.dtype.names if not np.array_equal(a_[f], b_[f])}, flush=True)
+                    sa, sb = gpu[r].stats(), cpu[r].stats()
+                    print("   stats gpu/cpu:", {f[0]: (getattr(sa, f[0]), getattr(sb, f[0])) for f in sa._fields_ if isinstance(getattr(sa, f[0]), int) and getattr(sa, f[0]) != getattr(sb, f[0])}, flush=True)
+                    for i in bad[:4]:
+                        print("   body", i, "owned" if i in own[r] else "ghost/other", "gpu", sg_["pos"][i], sg_["lin_vel"][i], "cpu", sc_["pos"][i], sc_["lin_vel"][i], "active", sg_["active"][i], sc_["active"][i], flush=True)
                 assert dd["bit_exact"] and dd["active_mismatch"] == 0, (seed, s, r, dd)
             # nothing lost or duplicated: owned dynamic bodies over all tiles
             owned = sum(gpu[r].num_bodies() - 1 - [e for e in lg if e[0] == "import" and e[1] == r][0][2] for r in range(n_tiles))
