@@ -461,6 +461,7 @@ int  sgp_mesh_create_with_materials(sgp_world* w, const float* vertices_xyz, uin
 
 /* ---- wheeled vehicles --------------------------------------------------------
  * Replaces JPH::VehicleConstraint + JPH::WheeledVehicleController + JPH::VehicleCollisionTesterCastSphere as CarPhysics
+ * (and JPH::MotorcycleController + JPH::VehicleCollisionTesterCastCylinder as BikePhysics, gui_client/BikePhysics.cpp:97-230)
  * sets them up (gui_client/CarPhysics.cpp:62,94-231; script defaults gui_client/Scripting.cpp:315-346).  A vehicle is
  * attached to an existing dynamic body (the chassis; body origin = centre of mass).  Each step, before the forces:
  * one sphere cast per wheel, tyre slip -> friction, engine / clutch / gearbox / differential, brakes, anti-roll bars;
@@ -471,6 +472,10 @@ int  sgp_mesh_create_with_materials(sgp_world* w, const float* vertices_xyz, uin
 #define SGP_MAX_GEARS  8
 #define SGP_VEHICLE_CONTROLLER_WHEELED     0   /* JPH::WheeledVehicleController (CarPhysics)                        */
 #define SGP_VEHICLE_CONTROLLER_MOTORCYCLE  1   /* JPH::MotorcycleController (BikePhysics): + lean spring, lean steering limit */
+#define SGP_VEHICLE_TESTER_SPHERE    0   /* JPH::VehicleCollisionTesterCastSphere of cast_radius (CarPhysics.cpp:62); radius 0: VehicleCollisionTesterRay */
+#define SGP_VEHICLE_TESTER_CYLINDER  1   /* JPH::VehicleCollisionTesterCastCylinder(layer, inConvexRadiusFraction = 1) as BikePhysics.cpp:229 makes it: the wheel
+                                          * itself is cast -- radius `radius`, width `width`, rounded by half its width -- from the attachment point over
+                                          * suspension_max_length; no slope filter.  (Other fractions are not offered.) */
 typedef struct sgp_wheel_desc {
 	float position[3];            /* mPosition: suspension attachment point, chassis frame                       */
 	float suspension_dir[3];      /* mSuspensionDirection (default (0,0,-1))                                      */
@@ -511,6 +516,7 @@ typedef struct sgp_vehicle_desc {
 	float lean_spring_integration_coefficient, lean_spring_integration_decay;   /* 0, 4                              */
 	float lean_smoothing_factor;             /* 0.8                                                                */
 	uint32_t lean_steering_limit;            /* mEnableLeanSteeringLimit (1)                                       */
+	uint32_t collision_tester;               /* SGP_VEHICLE_TESTER_* (0: the sphere / ray of cast_radius)          */
 } sgp_vehicle_desc;
 /* WheeledVehicleController::SetDriverInput(forward, right, brake, hand brake) (CarPhysics.cpp:366-367) */
 typedef struct sgp_vehicle_input { float forward, right, brake, hand_brake; } sgp_vehicle_input;

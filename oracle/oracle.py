@@ -103,6 +103,19 @@ def cast_sphere(body, origin, direction, max_t, radius):
     return None if t < 0 else (float(t), n, p)
 
 
+def cast_disc(body, origin, direction, across, leading, disc_r, rho, max_t):
+    """The wheel cast of the oracle (VehicleCollisionTesterCastCylinder: a disc of radius disc_r in the plane spanned by `across` and `leading`, rounded by rho)
+    against one body desc.  Returns (t, normal, point) or None."""
+    a = [np.ascontiguousarray(x, np.float32) for x in (origin, direction, across, leading)]
+    n = np.zeros(3, np.float32)
+    p = np.zeros(3, np.float32)
+    f = lib().sgo_cast_disc_hook
+    f.restype = C.c_float
+    f.argtypes = [C.c_void_p] * 5 + [C.c_float] * 3 + [C.c_void_p] * 2
+    t = f(C.addressof(body), a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data, float(disc_r), float(rho), float(max_t), n.ctypes.data, p.ctypes.data)
+    return None if t < 0 else (float(t), n, p)
+
+
 def set_threads(n):
     """OpenMP threads for the order-independent loops of the oracle (cpu_baseline timing only; tests use 1)."""
     return int(lib().sgo_set_threads(int(n)))

@@ -1807,6 +1807,7 @@ static void vehicle_from_desc(sgo_vehicle* v, const sgp_vehicle_desc* d)
 	}
 	v->up = v3_from(d->up); v->forward = v3_from(d->forward);
 	v->cast_radius = d->cast_radius;
+	v->tester = d->collision_tester == SGP_VEHICLE_TESTER_CYLINDER ? SGP_VEHICLE_TESTER_CYLINDER : SGP_VEHICLE_TESTER_SPHERE;
 	{ float sn, cs; sgp_sincos_poly(d->max_slope_angle, &sn, &cs); v->cos_max_slope = cs; }
 	v->engine_max_torque = d->engine_max_torque; v->engine_min_rpm = d->engine_min_rpm; v->engine_max_rpm = d->engine_max_rpm;
 	v->engine_inertia = d->engine_inertia; v->engine_ang_damping = d->engine_angular_damping;
@@ -1945,6 +1946,7 @@ static void vehicle_grounds_load(sgo_world* w, const sgo_vehicle* v, sgo_chassis
    The cast visits every body (closest accepted hit; on equal distance the lower body id wins) -- the device walks the
    broad-phase grid instead and must find the same hit. */
 static float cast_sphere_mesh(const sgo_body* M, v3 o, v3 d, float max_t, float rs, v3* n_out, v3* p_out);
+static float cast_disc_mesh(const sgo_body* M, v3 o, v3 d, v3 e, v3 din, float disc_r, float rho, float max_t, v3* n_out, v3* p_out);
 
 /* Slab test of a ray against a box, the broad-phase filter in front of every swept-sphere test (same arithmetic as the device's
  * ray_aabb; it is part of the result because the planes-only swept-sphere test of hulls and boxes is generous at their corners). */
@@ -2006,7 +2008,9 @@ static void vehicles_pre_step(sgo_world* w, float dt)
 			const v3 e = v3_add(wh->cast_origin, v3_scale(wh->cast_dir, wh->cast_len));
 			/* cheap reject only; it must never be stricter than the slab test below (which allows 1e-4 of slack and is the filter the device
 			   applies), so it gets a wider margin -- a wheel 8e-5 m beside a hull's bounds once made the two disagree (tools/fuzz_parity.py) */
-			const float m = v->cast_radius + 2.0e-3f;
+			const int cyl = v->tester == SGP_VEHICLE_TESTER_CYLINDER;
+			const float reach = cyl ? wh->radius : v->cast_radius;      /* what the moving shape reaches around the path of its centre */
+			const float m = reach + 2.0e-3f;
 			const v3 lo = v3_sub(v3_min(wh->cast_origin, e), V3(m, m, m)), hi = v3_add(v3_max(wh->cast_origin, e), V3(m, m, m));
 			for (uint32_t j = 0; j < w->high; ++j) {
 				const float* bb = &bounds[6 * j];
@@ -2015,12 +2019,19 @@ static void vehicles_pre_step(sgo_world* w, float dt)
 				if (j == v->body) continue;
 				const sgo_body* o = &w->bodies[j];
 				if (dbg_wheel >= 0 && i == dbg_wheel) fprintf(stderr, "[sgo wheel trace] step %d body %u: in segment box; reaches bounds %d; origin %g %g %g dir %g %g %g len %g aabb %g %g %g .. %g %g %g\n", dbg_step_now, j, cast_reaches_bounds(o, wh->cast_origin, wh->cast_dir, v->cast_radius, wh->cast_len), wh->cast_origin.x, wh->cast_origin.y, wh->cast_origin.z, wh->cast_dir.x, wh->cast_dir.y, wh->cast_dir.z, wh->cast_len, o->aabb_min.x, o->aabb_min.y, o->aabb_min.z, o->aabb_max.x, o->aabb_max.y, o->aabb_max.z);
-				if (!cast_reaches_bounds(o, wh->cast_origin, wh->cast_dir, v->cast_radius, wh->cast_len)) continue;      /* full length, not `best`: the answer must not depend on the visiting order */
+				if (!cast_reaches_bounds(o, wh->cast_origin, wh->cast_dir, reach, wh->cast_len)) continue;      /* full length, not `best`: the answer must not depend on the visiting order */
 				v3 n, p;
-				const float t = o->shape_type == SGP_SHAPE_MESH ? cast_sphere_mesh(o, wh->cast_origin, wh->cast_dir, best, v->cast_radius, &n, &p)
-				                                                : sgo_cast_sphere_body(o->shape_type, o->shape, o->hull, o->pos, quat_to_m33(o->rot), wh->cast_origin, wh->cast_dir, best, v->cast_radius, &n, &p);
+				float t;
+				if (cyl) {
+					/* the wheel itself (sgo_cast_disc): always over the whole travel; a hit behind the best one so far loses below */
+					t = o->shape_type == SGP_SHAPE_MESH ? cast_disc_mesh(o, wh->cast_origin, wh->cast_dir, wh->cast_e, wh->cast_din, wh->disc_r, wh->cast_rho, wh->cast_len, &n, &p)
+					                                    : sgo_cast_disc_body(o->shape_type, o->shape, o->hull, o->pos, quat_to_m33(o->rot), wh->cast_origin, wh->cast_dir, wh->cast_e, wh->cast_din, wh->disc_r, wh->cast_rho, wh->cast_len, &n, &p);
+					if (t > best) t = -1.0f;
+				} else
+				t = o->shape_type == SGP_SHAPE_MESH ? cast_sphere_mesh(o, wh->cast_origin, wh->cast_dir, best, v->cast_radius, &n, &p)
+				                                    : sgo_cast_sphere_body(o->shape_type, o->shape, o->hull, o->pos, quat_to_m33(o->rot), wh->cast_origin, wh->cast_dir, best, v->cast_radius, &n, &p);
 				if (dbg_wheel >= 0 && i == dbg_wheel) fprintf(stderr, "[sgo wheel trace]   body %u: t %g n %g %g %g (best so far %g)\n", j, t, n.x, n.y, n.z, best);
-				if (t < 0.0f || n.z < v->cos_max_slope) continue;
+				if (t < 0.0f || (!cyl && n.z < v->cos_max_slope)) continue;      /* (VehicleCollisionTesterCastCylinder has no slope limit -- UNVERIFIED: upstream) */
 				if (t < best || bid == SGP_INVALID_ID) { best = t; bid = j; bn = n; bp = p; }
 			}
 			if (bid != SGP_INVALID_ID) {
@@ -2556,6 +2567,39 @@ static float cast_sphere_mesh(const sgo_body* M, v3 o, v3 d, float max_t, float 
 	return best;
 }
 
+/* the wheel itself (sgo_cast_disc) against mesh body M: the search per triangle whose bounds the swept wheel can reach; closest touch, on equal distance the lower
+   triangle index wins */
+typedef struct { v3 d; v3 a, b, c; float max_t, rho; } disc_tri_ctx;
+static float disc_probe_tri(const void* ctx, v3 start, v3* n_out, v3* p_out)
+{
+	const disc_tri_ctx* c = (const disc_tri_ctx*)ctx;
+	const float t = sgo_cast_sphere_tri(start, c->d, c->a, c->b, c->c, c->max_t, c->rho, n_out);
+	if (t >= 0.0f) *p_out = v3_sub(v3_add(start, v3_scale(c->d, t)), v3_scale(*n_out, c->rho));
+	return t;
+}
+static float cast_disc_mesh(const sgo_body* M, v3 o, v3 d, v3 e, v3 din, float disc_r, float rho, float max_t, v3* n_out, v3* p_out)
+{
+	const m33 R = quat_to_m33(M->rot);
+	const v3 ol = m33_tmul(R, v3_sub(o, M->pos)), dl = m33_tmul(R, d), el = m33_tmul(R, e), dinl = m33_tmul(R, din);
+	const v3 end = v3_add(ol, v3_scale(dl, max_t));
+	const float m = disc_r + rho + 2.0e-3f;
+	const v3 lo = v3_sub(v3_min(ol, end), V3(m, m, m)), hi = v3_add(v3_max(ol, end), V3(m, m, m));
+	float best = 0.0f; int hit = 0; v3 bn = V3(0, 0, 0), bp = V3(0, 0, 0);
+	disc_tri_ctx c; c.d = dl; c.max_t = max_t; c.rho = rho;
+	for (uint32_t t = 0; t < M->mesh->nt; ++t) {
+		c.a = M->mesh->verts[M->mesh->tris[3 * t]]; c.b = M->mesh->verts[M->mesh->tris[3 * t + 1]]; c.c = M->mesh->verts[M->mesh->tris[3 * t + 2]];
+		const v3 tlo = v3_min(v3_min(c.a, c.b), c.c), thi = v3_max(v3_max(c.a, c.b), c.c);
+		if (thi.x < lo.x || tlo.x > hi.x || thi.y < lo.y || tlo.y > hi.y || thi.z < lo.z || tlo.z > hi.z) continue;
+		v3 nn, pp;
+		const float tt = sgo_cast_disc(disc_probe_tri, &c, ol, el, dinl, disc_r, &nn, &pp);
+		if (tt >= 0.0f && (!hit || tt < best)) { best = tt; hit = 1; bn = nn; bp = pp; }
+	}
+	if (!hit) return -1.0f;
+	*n_out = m33_mul(R, bn);
+	*p_out = v3_add(M->pos, m33_mul(R, bp));
+	return best;
+}
+
 /* ConvexHullShapeSettings::Create */
 SGO_API int sgo_hull_create_com(sgo_world* w, const float* pts, uint32_t n, const float* com_offset, sgp_hull_info* info)
 {
@@ -2590,6 +2634,17 @@ SGO_API int sgo_hull_dump(sgo_world* w, uint32_t id, float* verts, float* planes
 	for (int i = 0; i < h->nv; ++i) { verts[3 * i] = h->verts[i].x; verts[3 * i + 1] = h->verts[i].y; verts[3 * i + 2] = h->verts[i].z; }
 	for (int f = 0; f < h->nf; ++f) { planes[4 * f] = h->normals[f].x; planes[4 * f + 1] = h->normals[f].y; planes[4 * f + 2] = h->normals[f].z; planes[4 * f + 3] = h->plane_d[f]; }
 	return h->nv | (h->nf << 16);
+}
+
+/* The wheel cast against one body desc (test hook for sgo_cast_disc_body): disc of radius disc_r in the plane spanned by e and din, rounded by rho. */
+SGO_API float sgo_cast_disc_hook(const sgp_body_desc* b, const float o[3], const float d[3], const float e[3], const float din[3], float disc_r, float rho, float max_t, float* n_out, float* p_out)
+{
+	const quat q = { b->rot[0], b->rot[1], b->rot[2], b->rot[3] };
+	v3 n = V3(0, 0, 0), p = V3(0, 0, 0);
+	const float t = sgo_cast_disc_body(b->shape_type, b->shape, NULL, V3(b->pos[0], b->pos[1], b->pos[2]), quat_to_m33(q), V3(o[0], o[1], o[2]), V3(d[0], d[1], d[2]), V3(e[0], e[1], e[2]), V3(din[0], din[1], din[2]), disc_r, rho, max_t, &n, &p);
+	if (n_out) { n_out[0] = n.x; n_out[1] = n.y; n_out[2] = n.z; }
+	if (p_out) { p_out[0] = p.x; p_out[1] = p.y; p_out[2] = p.z; }
+	return t;
 }
 
 /* Sphere cast against one body desc (test hook for sgo_cast_sphere_body). Returns t or -1. */

@@ -65,6 +65,9 @@ typedef struct {
 	sgo_axis_part suspension, max_up, longitudinal, lateral;
 	/* cast request of this step (filled by pre_a, consumed by the world's cast loop) */
 	v3 cast_origin, cast_dir; float cast_len;
+	/* ... when the tester casts the wheel itself (SGP_VEHICLE_TESTER_CYLINDER): the rounded disc's frame -- cast_din = the cast direction within the wheel plane,
+	   cast_e = the in-plane direction across it, disc_r = radius of the flat disc, cast_rho = its rounding (sgo_cast_disc) */
+	v3 cast_e, cast_din; float disc_r, cast_rho;
 } sgo_wheel;
 
 typedef struct { int left, right; float ratio, left_right_split, limited_slip_ratio, engine_torque_ratio; } sgo_differential;
@@ -77,6 +80,7 @@ typedef struct {
 	sgo_wheel wheels[SGO_MAX_WHEELS];
 	v3 up, forward;                    /* chassis frame */
 	float cast_radius, cos_max_slope;
+	int tester;                        /* SGP_VEHICLE_TESTER_*: cast a sphere of cast_radius (0: a ray), or the wheel itself */
 	/* engine (JPH::VehicleEngineSettings) */
 	float engine_max_torque, engine_min_rpm, engine_max_rpm, engine_inertia, engine_ang_damping;
 	float engine_curve[3][2];
@@ -275,6 +279,71 @@ static inline float sgo_cast_sphere_body(int type, const float* p, const sgo_hul
 	return t;
 }
 
+/* ---- the wheel itself as the cast shape (VehicleCollisionTesterCastCylinder, BikePhysics.cpp:229) -----------------------------------------------------
+   BikePhysics makes the tester with inConvexRadiusFraction = 1: Jolt's CylinderShape(half width, radius, convex radius = half width) is then, cast with
+   mUseShrunkenShapeAndConvexRadius, a flat DISC of radius disc_r = radius - half width, in the wheel plane, rounded by rho = half width -- the union of the spheres
+   of radius rho centred on the disc.  Its first touch is therefore the earliest first touch among those spheres, and the sphere casts (KAT'd against a marching
+   reference) are the building block: no general convex cast.  The cast direction lies in the wheel plane (suspension and steering axis do, for a bike), so of every
+   chord of the disc along the direction only the LEADING end can touch first: the minimum is over the leading half of the rim, p(u) = u e + sqrt(disc_r^2 - u^2) din,
+   u in [-disc_r, disc_r], and t(p(u)) is convex in u against a convex body (time-to-enter of a convex set along a fixed direction is convex in the start point, and
+   -sqrt(disc_r^2 - u^2) is convex): 17 samples bracket the minimum, 20 golden-section steps refine it to ~1e-5 disc_r.  Every evaluation is a full sphere cast over
+   the whole travel (never shortened by what another body already returned: the path of the search must not depend on the order of the candidates); the best
+   evaluation is the answer.  A cast direction with a component along the axle is treated through its in-plane part (the rim's leading half); nothing but fraction 1
+   of the convex radius is offered.  Against a mesh the search runs per triangle (the minimum over several convex pieces is not convex).
+   f(ctx, start, &n, &p) = travel of a sphere of radius rho from start along d to its first touch with the piece, or -1. */
+typedef float (*sgo_disc_probe_fn)(const void* ctx, v3 start, v3* n_out, v3* p_out);
+#define SGO_DISC_SAMPLES 17
+#define SGO_DISC_REFINE  20
+static inline v3 sgo_disc_start(v3 o, v3 e, v3 din, float disc_r, float u)
+{
+	const float s = sqrtf(fmaxf(disc_r * disc_r - u * u, 0.0f));
+	return v3_add(v3_add(o, v3_scale(e, u)), v3_scale(din, s));
+}
+static inline float sgo_cast_disc(sgo_disc_probe_fn f, const void* ctx, v3 o, v3 e, v3 din, float disc_r, v3* n_out, v3* p_out)
+{
+	if (!(disc_r > 0.0f)) return f(ctx, o, n_out, p_out);
+	float best = -1.0f; int bk = -1; v3 bn = V3(0, 0, 0), bp = V3(0, 0, 0);
+	for (int k = 0; k < SGO_DISC_SAMPLES; ++k) {
+		const float u = disc_r * ((float)k * (2.0f / (float)(SGO_DISC_SAMPLES - 1)) - 1.0f);
+		v3 n, p;
+		const float t = f(ctx, sgo_disc_start(o, e, din, disc_r, u), &n, &p);
+		if (t >= 0.0f && (bk < 0 || t < best)) { best = t; bk = k; bn = n; bp = p; }
+	}
+	if (bk < 0) return -1.0f;
+	if (best > 0.0f) {
+		const int k0 = bk > 0 ? bk - 1 : 0, k1 = bk < SGO_DISC_SAMPLES - 1 ? bk + 1 : SGO_DISC_SAMPLES - 1;
+		float lo = disc_r * ((float)k0 * (2.0f / (float)(SGO_DISC_SAMPLES - 1)) - 1.0f), hi = disc_r * ((float)k1 * (2.0f / (float)(SGO_DISC_SAMPLES - 1)) - 1.0f);
+		const float g = 0.61803398875f, miss = 3.0e38f;
+		float x1 = hi - g * (hi - lo), x2 = lo + g * (hi - lo);
+		v3 n, p;
+		float t = f(ctx, sgo_disc_start(o, e, din, disc_r, x1), &n, &p);
+		float f1 = t >= 0.0f ? t : miss;
+		if (t >= 0.0f && t < best) { best = t; bn = n; bp = p; }
+		t = f(ctx, sgo_disc_start(o, e, din, disc_r, x2), &n, &p);
+		float f2 = t >= 0.0f ? t : miss;
+		if (t >= 0.0f && t < best) { best = t; bn = n; bp = p; }
+		for (int it = 0; it < SGO_DISC_REFINE; ++it) {
+			if (f1 <= f2) { hi = x2; x2 = x1; f2 = f1; x1 = hi - g * (hi - lo); t = f(ctx, sgo_disc_start(o, e, din, disc_r, x1), &n, &p); f1 = t >= 0.0f ? t : miss; }
+			else { lo = x1; x1 = x2; f1 = f2; x2 = lo + g * (hi - lo); t = f(ctx, sgo_disc_start(o, e, din, disc_r, x2), &n, &p); f2 = t >= 0.0f ? t : miss; }
+			if (t >= 0.0f && t < best) { best = t; bn = n; bp = p; }
+		}
+	}
+	*n_out = bn; *p_out = bp;
+	return best;
+}
+/* ... against one body that is not a mesh */
+typedef struct { int type; const float* p; const sgo_hull* hull; v3 pos; m33 R; v3 d; float max_t, rho; } sgo_disc_body_ctx;
+static inline float sgo_disc_probe_body(const void* ctx, v3 start, v3* n_out, v3* p_out)
+{
+	const sgo_disc_body_ctx* c = (const sgo_disc_body_ctx*)ctx;
+	return sgo_cast_sphere_body(c->type, c->p, c->hull, c->pos, c->R, start, c->d, c->max_t, c->rho, n_out, p_out);
+}
+static inline float sgo_cast_disc_body(int type, const float* p, const sgo_hull* hull, v3 pos, m33 R, v3 o, v3 d, v3 e, v3 din, float disc_r, float rho, float max_t, v3* n_out, v3* p_out)
+{
+	sgo_disc_body_ctx c; c.type = type; c.p = p; c.hull = hull; c.pos = pos; c.R = R; c.d = d; c.max_t = max_t; c.rho = rho;
+	return sgo_cast_disc(sgo_disc_probe_body, &c, o, e, din, disc_r, n_out, p_out);
+}
+
 /* ---- axis rows ------------------------------------------------------------------------------------------------------------------ */
 
 static inline void sgo_part_deactivate(sgo_axis_part* p) { p->active = 0; p->lambda = 0.0f; p->eff = 0.0f; p->softness = 0.0f; p->bias = 0.0f; }
@@ -382,6 +451,19 @@ static inline void sgo_vehicle_pre_a(sgo_vehicle* v, const sgo_chassis* c, float
 		w->cast_origin = v3_add(c->pos, m33_mul(R, w->position));
 		w->cast_dir = m33_mul(R, w->suspension_dir);
 		w->cast_len = w->sus_max + w->radius - v->cast_radius;
+		if (v->tester == SGP_VEHICLE_TESTER_CYLINDER) {
+			/* VehicleCollisionTesterCastCylinder::Collide: the wheel's cylinder, oriented as the steered wheel, starts at the attachment point and travels
+			   mSuspensionMaxLength along the suspension; the suspension length is the distance travelled (UNVERIFIED: upstream) */
+			const v3 steering_axis = m33_mul(R, w->steering_axis);
+			const v3 fwd = sgo_rotate_about(steering_axis, w->steer_angle, m33_mul(R, w->wheel_forward));
+			const v3 upw = sgo_rotate_about(steering_axis, w->steer_angle, m33_mul(R, w->wheel_up));
+			const v3 axle = sgo_normalized_or(v3_cross(upw, fwd), V3(1.0f, 0.0f, 0.0f));
+			w->cast_din = sgo_normalized_or(v3_sub(w->cast_dir, v3_scale(axle, v3_dot(w->cast_dir, axle))), w->cast_dir);
+			w->cast_e = v3_cross(axle, w->cast_din);
+			w->cast_rho = fminf(0.5f * w->width, w->radius);
+			w->disc_r = w->radius - w->cast_rho;
+			w->cast_len = w->sus_max;
+		}
 		w->has_contact = 0; w->contact_body = 0xFFFFFFFFu; w->ground_dynamic = 0;
 	}
 }
@@ -392,7 +474,7 @@ static inline void sgo_vehicle_set_hit(sgo_vehicle* v, int i, uint32_t body, flo
 	sgo_wheel* w = &v->wheels[i];
 	w->has_contact = 1; w->contact_body = body; w->ground_dynamic = 0;      /* (the world's glue sets ground_dynamic) */
 	w->contact_normal = n; w->contact_pos = p; w->contact_point_vel = ground_point_vel; w->ground_friction = ground_friction;
-	w->suspension_length = fmaxf(0.0f, t + v->cast_radius - w->radius);
+	w->suspension_length = v->tester == SGP_VEHICLE_TESTER_CYLINDER ? t : fmaxf(0.0f, t + v->cast_radius - w->radius);
 }
 
 /* ---- pre-step, part B: everything after the casts --------------------------------------------------------------------------- */

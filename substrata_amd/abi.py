@@ -133,6 +133,7 @@ class ConstraintDump(C.Structure):
 
 MAX_WHEELS, MAX_GEARS = 4, 8
 VEHICLE_CONTROLLER_WHEELED, VEHICLE_CONTROLLER_MOTORCYCLE = 0, 1
+VEHICLE_TESTER_SPHERE, VEHICLE_TESTER_CYLINDER = 0, 1
 
 
 class WheelDesc(C.Structure):
@@ -165,7 +166,7 @@ class VehicleDesc(C.Structure):
                 ("num_anti_roll_bars", u32), ("anti_roll_bars", AntiRollBarDesc * 2), ("controller_type", u32),
                 ("max_lean_angle", f32), ("lean_spring_constant", f32), ("lean_spring_damping", f32),
                 ("lean_spring_integration_coefficient", f32), ("lean_spring_integration_decay", f32),
-                ("lean_smoothing_factor", f32), ("lean_steering_limit", u32)]
+                ("lean_smoothing_factor", f32), ("lean_steering_limit", u32), ("collision_tester", u32)]
 
 
 class VehicleInput(C.Structure):

@@ -21,6 +21,8 @@ SGP_DEV v3 v3_add(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
 SGP_DEV v3 v3_sub(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
 SGP_DEV v3 v3_scale(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
 SGP_DEV v3 v3_neg(v3 a) { return V3(-a.x, -a.y, -a.z); }
+SGP_DEV v3 v3_min(v3 a, v3 b) { return V3(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)); }
+SGP_DEV v3 v3_max(v3 a, v3 b) { return V3(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)); }
 SGP_DEV float v3_dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 SGP_DEV v3 v3_cross(v3 a, v3 b) { return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 SGP_DEV float v3_len_sq(v3 a) { return v3_dot(a, a); }

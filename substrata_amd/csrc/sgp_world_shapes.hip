@@ -383,6 +383,7 @@ static void vehicle_record_from_desc(sgd_vehicle* v, const sgp_vehicle_desc* d)
 	}
 	v->up = hv3(d->up); v->forward = hv3(d->forward);
 	v->cast_radius = d->cast_radius;
+	v->tester = d->collision_tester == SGP_VEHICLE_TESTER_CYLINDER ? SGP_VEHICLE_TESTER_CYLINDER : SGP_VEHICLE_TESTER_SPHERE;
 	v->cos_max_slope = host_cos_poly(d->max_slope_angle);
 	v->engine_max_torque = d->engine_max_torque; v->engine_min_rpm = d->engine_min_rpm; v->engine_max_rpm = d->engine_max_rpm;
 	v->engine_inertia = d->engine_inertia; v->engine_ang_damping = d->engine_angular_damping;

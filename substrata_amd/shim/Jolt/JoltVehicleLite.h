@@ -4,7 +4,7 @@
 //   PhysicsSystem::AddConstraint(VehicleConstraint*)                                  -> sgp_vehicle_create
 //   WheeledVehicleController::SetDriverInput                                          -> sgp_vehicle_set_input
 //   Wheel getters, VehicleEngine::GetCurrentRPM                                       -> sgp_vehicle_get_state (one read-back per step)
-// Differences a maintainer must know: VehicleCollisionTesterCastCylinder is served by the sphere cast.
+// Differences a maintainer must know: VehicleCollisionTesterCastCylinder casts the wheel as Jolt does for inConvexRadiusFraction = 1 (BikePhysics' value) whatever fraction is passed.
 #pragma once
 #include "JoltLite.h"
 #include "../../../include/sgp.h"
@@ -99,7 +99,7 @@ namespace JPH
 		Ref<VehicleControllerSettings> mController;
 	};
 
-	class VehicleCollisionTester : public RefTargetBase { public: virtual float castRadius(float /*wheel_width*/) const { return 0.0f; } };
+	class VehicleCollisionTester : public RefTargetBase { public: virtual float castRadius(float /*wheel_width*/) const { return 0.0f; } virtual uint32_t testerKind() const { return SGP_VEHICLE_TESTER_SPHERE; } };
 	class VehicleCollisionTesterRay : public VehicleCollisionTester
 	{
 	public:
@@ -113,13 +113,14 @@ namespace JPH
 		float castRadius(float) const override { return mRadius; }
 		float mRadius, mMaxSlopeAngle;
 	};
-	// BikePhysics.cpp:227.  Served by the sphere cast with the half wheel width as radius (exact on flat ground; a kerb is met by the
-	// tyre's centre line rather than by its full radius).
+	// BikePhysics.cpp:229.  The wheel itself is cast (SGP_VEHICLE_TESTER_CYLINDER): a disc of the wheel's radius less half its width, rounded by half its width --
+	// what Jolt's cylinder is with inConvexRadiusFraction = 1, the value BikePhysics passes.  Other fractions get the same shape.
 	class VehicleCollisionTesterCastCylinder : public VehicleCollisionTester
 	{
 	public:
 		VehicleCollisionTesterCastCylinder(ObjectLayer, float convex_radius_fraction = 0.1f) : mConvexRadiusFraction(convex_radius_fraction) {}
 		float castRadius(float wheel_width) const override { return 0.5f * wheel_width; }
+		uint32_t testerKind() const override { return SGP_VEHICLE_TESTER_CYLINDER; }
 		float mConvexRadiusFraction;
 	};
 
@@ -193,7 +194,7 @@ namespace JPH
 			for (size_t i = 0; i < wheels.size(); ++i) { wheels[i].owner = this; wheels[i].index = (int)i; wheels[i].settings = settings.mWheels[i].GetPtr(); }
 			controller.owner = this; controller.engine.owner = this;
 		}
-		void SetVehicleCollisionTester(const VehicleCollisionTester* t) { cast_radius = t ? t->castRadius(settings.mWheels.empty() ? 0.0f : settings.mWheels[0]->mWidth) : 0.0f; }
+		void SetVehicleCollisionTester(const VehicleCollisionTester* t) { cast_radius = t ? t->castRadius(settings.mWheels.empty() ? 0.0f : settings.mWheels[0]->mWidth) : 0.0f; tester_kind = t ? t->testerKind() : (uint32_t)SGP_VEHICLE_TESTER_SPHERE; }
 		VehicleController* GetController() { return &controller; }
 		const VehicleController* GetController() const { return &controller; }
 		Wheel* GetWheel(uint i) { return &wheels[i]; }
@@ -251,6 +252,7 @@ namespace JPH
 			}
 			put(d.up, frame_rot.Conjugated() * settings.mUp); put(d.forward, frame_rot.Conjugated() * settings.mForward);
 			d.cast_radius = cast_radius;
+			d.collision_tester = tester_kind;
 			const WheeledVehicleControllerSettings* c = dynamic_cast<const WheeledVehicleControllerSettings*>(settings.mController.GetPtr());
 			d.engine_max_torque = c->mEngine.mMaxTorque; d.engine_min_rpm = c->mEngine.mMinRPM; d.engine_max_rpm = c->mEngine.mMaxRPM;
 			d.engine_inertia = c->mEngine.mInertia; d.engine_angular_damping = c->mEngine.mAngularDamping;
@@ -289,7 +291,7 @@ namespace JPH
 		sgp_world* world = nullptr;
 	private:
 		static void put(float* o, const Vec3& v) { o[0] = v.x; o[1] = v.y; o[2] = v.z; }
-		BodyID body_id; VehicleConstraintSettings settings; Vec3 frame_com; Quat frame_rot; float cast_radius = 0.0f;
+		BodyID body_id; VehicleConstraintSettings settings; Vec3 frame_com; Quat frame_rot; float cast_radius = 0.0f; uint32_t tester_kind = SGP_VEHICLE_TESTER_SPHERE;
 		std::vector<Wheel> wheels; MotorcycleController controller;    // (a WheeledVehicleController for cars; the lean part is inert then)
 		uint32_t vehicle_id = 0xFFFFFFFFu; const uint64_t* step_serial = nullptr;
 		mutable uint64_t cached_serial = ~0ull; mutable sgp_vehicle_state cached = {};

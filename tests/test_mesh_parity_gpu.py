@@ -159,6 +159,40 @@ def test_car_on_mesh_terrain_matches_oracle(oracle):
     tw.close()
 
 
+def test_car_with_cylinder_tester_on_mesh_terrain_matches_oracle(oracle):
+    """The wheel itself as the cast shape (SGP_VEHICLE_TESTER_CYLINDER) against triangles: the search runs per triangle the swept wheel can reach."""
+    from helpers import add_car
+
+    def cyl(vd):
+        vd.collision_tester = abi.VEHICLE_TESTER_CYLINDER
+    tw = parity.make_twin(oracle, max_bodies=256)
+    V, T = grid_mesh(41, 40.0, lambda x, y: 0.4 * np.sin(0.3 * x) * np.sin(0.25 * y) + 0.15 * np.sin(1.7 * y))
+    ig, ic = tw.mesh_create(V, T)
+    tw.add_batch(mesh_body(ig))
+    ids = []
+    for w in (tw.gpu, tw.cpu):
+        ids.append(add_car(w, pos=(0.0, -20.0, 1.5), desc_edit=cyl))
+    assert ids[0] == ids[1]
+    body, vid = ids[0]
+    for s in range(1, 301):
+        if s == 60:
+            tw.vehicle_set_input(vid, 1.0, 0.0, 0.0, 0.0)
+        if s == 200:
+            tw.vehicle_set_input(vid, 1.0, 0.4, 0.0, 0.0)
+        tw.step(DT)
+        if s % 30 == 0:
+            d = parity.compare(tw, body + 1)
+            assert d["active_mismatch"] == 0 and d["bit_exact"], (s, d)
+            vg, vc = tw.vehicle_get_states(vid, 1)
+            for f in ("contact_body", "angular_velocity", "suspension_length", "contact_normal", "contact_position"):
+                assert np.array_equal(vg["wheels"][f], vc["wheels"][f]), (s, f)
+    st = tw.gpu.get_state([body])[0]
+    vs = tw.gpu.vehicle_get_state(vid)
+    print("car with cast wheels on terrain: pos", np.round(st["pos"], 2))
+    assert st["pos"][1] > -15.0 and 0.2 < st["pos"][2] < 2.5 and (vs["wheels"]["contact_body"][:4] == 0).sum() >= 2
+    tw.close()
+
+
 def test_mesh_added_after_a_large_dynamic_body_matches_oracle(oracle):
     """A static mesh body streamed in AFTER (so: with a higher id than) a dynamic body that is itself beyond the large-body radius, the big box
     lying across it.  Both go through the large-body pair kernel; the mesh body's two alias slots must not pair with the box (found by the

