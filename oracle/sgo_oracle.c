@@ -2154,6 +2154,10 @@ SGO_API int sgo_world_step(sgo_world* w, float dt)
 	/* 2-3. broad phase, narrow phase, contact constraints */
 	broad_phase(w);
 	find_contacts(w, dt);
+	/* is anybody awake in this step (kinematic bodies count; what the contacts above woke is awake by now)?  A step nobody is awake in is the identity -- and
+	   leaves the contact cache as it is (step 10) */
+	int any_awake = 0;
+	for (uint32_t i = 0; i < w->high && !any_awake; ++i) if (w->bodies[i].alive && !w->bodies[i].is_alias && body_is_active_for_pairs(&w->bodies[i])) any_awake = 1;
 
 	nan_trace(w, "1-3 forces, collision");
 	/* 4. colouring and solve order */
@@ -2225,8 +2229,13 @@ SGO_API int sgo_world_step(sgo_world* w, float dt)
 	if (w->water_enabled) buoyancy_sweep(w, dt);
 
 	nan_trace(w, "9 buoyancy");
-	/* 10. contact cache for the next step */
-	{
+	/* 10. contact cache for the next step.  A step without an awake body keeps the cache it found: the contacts of a pile that fell asleep as a whole are
+	   there when it wakes (warm start, colours, the body-pair cache's manifolds) -- ContactConstraintManager keeps the cached contacts of sleeping bodies
+	   (UNVERIFIED: upstream).  Only the whole-world case: a pair that sleeps while others are awake loses its entry with the next step (docs/GAPS.md). */
+	const uint32_t n_cons_step = w->n_cons;
+	uint32_t n_reused_step = 0;
+	for (uint32_t k = 0; k < w->n_cons; ++k) n_reused_step += (uint32_t)w->cons[k].reused;
+	if (any_awake) {
 		sgo_constraint* t = w->prev; w->prev = w->cons; w->cons = t;
 		const uint32_t tc = w->cap_prev; w->cap_prev = w->cap_cons; w->cap_cons = tc;
 		w->n_prev = w->n_cons;
@@ -2248,10 +2257,10 @@ SGO_API int sgo_world_step(sgo_world* w, float dt)
 		if (b->layer >= 0 && b->layer < SGP_NUM_LAYERS) w->stats.layer_counts[b->layer]++;
 	}
 	w->stats.num_pairs = w->n_pairs;
-	w->stats.num_manifolds = w->n_prev;
+	w->stats.num_manifolds = n_cons_step;
 	w->stats.num_colours = (uint32_t)nreg;      /* regular colours only, like the device's colour table; the overflow colour is num_overflow_constraints */
 	w->stats.num_overflow_constraints = novf;
-	{ uint32_t nr = 0; for (uint32_t k = 0; k < w->n_prev; ++k) nr += (uint32_t)w->prev[k].reused; w->stats.num_cached_manifolds = nr; }
+	w->stats.num_cached_manifolds = n_reused_step;
 	/* vehicles that share a movable body with a vehicle of lower index (the device defers their rows; here they are simply later in the loop) */
 	if (w->n_vehicles) {
 		uint32_t* first = (uint32_t*)malloc(sizeof(uint32_t) * (w->high ? w->high : 1));

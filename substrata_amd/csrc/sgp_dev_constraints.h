@@ -29,7 +29,7 @@ SGP_DEV uint32_t ht_hash(uint64_t key, uint32_t mask) { return (uint32_t)(sgp_mi
 // -> the pair's slot in the previous step's constraints (0xFFFFFFFF: it had none) and that constraint's np_col: ONE 16-byte entry per probe
 SGP_DEV uint32_t cache_find(const DV& d, uint64_t key, int* np_col_prev)
 {
-	const uint32_t size = *d.ht_cur;          // (the part of the table the last rebuild used: k_cache_clear)
+	const uint32_t size = *d.ht_cur;          // (the part of the table the last rebuild used: k_island_mark empties it)
 	const uint32_t mask = size - 1;
 	uint32_t h = ht_hash(key, mask);
 	for (uint32_t probe = 0; probe < size; ++probe) {

@@ -153,6 +153,8 @@ static inline int sgh_hull_faces_large(const sgh_d3* pts, int n, double eps, dou
 	int nt = 0, result = -1;
 	unsigned char used[256]; memset(used, 0, sizeof(used));
 	if (!T || !etri) goto done;
+	memset(etri, 0xFF, sizeof(short) * 256 * 256);      // -1: no triangle has held this directed edge (round 6: the table was read uninitialised where a visible
+	                                                       // triangle's edge had no twin -- a hull gone non-manifold within eps -- and indexed T with whatever malloc left)
 	{
 		// initial tetrahedron
 		int p0 = 0, p1 = -1, p2 = -1, p3 = -1; double best;
@@ -193,7 +195,7 @@ static inline int sgh_hull_faces_large(const sgh_d3* pts, int n, double eps, dou
 				const int e[3][2] = { { T[t].a, T[t].b }, { T[t].b, T[t].c }, { T[t].c, T[t].a } };
 				for (int k = 0; k < 3; ++k) {
 					const int tw = etri[e[k][1] * 256 + e[k][0]];
-					if (T[tw].alive == 2) continue;
+					if (tw >= 0 && T[tw].alive == 2) continue;      // (no twin, or a dead one: the edge is on the horizon)
 					if (nt == TCAP) goto done;
 					tri_t tr; tr.a = e[k][0]; tr.b = e[k][1]; tr.c = q; tr.alive = 1;
 					sgh_d3 nn = sgh_d3_cross(sgh_d3_sub(pts[tr.b], pts[tr.a]), sgh_d3_sub(pts[tr.c], pts[tr.a]));

@@ -407,13 +407,6 @@ __global__ void __launch_bounds__(TPB) k_setup(DV d)
 		}
 	}
 }
-__global__ void __launch_bounds__(TPB) k_cache_clear(DV d)
-{
-	const uint32_t size = cache_table_size(d);
-	for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < size; i += gridDim.x * TPB) d.ht[i] = make_uint4(~0u, ~0u, 0u, 0u);
-	if (blockIdx.x == 0 && threadIdx.x == 0) *d.ht_cur = size;
-}
-
 SGP_DEV void step_end_block(const DV& d, StepCounters* host_mapped, EventCounters* host_events)
 {
 	const uint32_t* src = (const uint32_t*)d.ctr;
@@ -427,9 +420,13 @@ SGP_DEV void step_end_block(const DV& d, StepCounters* host_mapped, EventCounter
 // (round 4: the step's counters go to the host from workgroup 0 of this, the step's last, launch: k_step_end was a launch of its own)
 __global__ void __launch_bounds__(TPB) k_cache_build(DV d, StepCounters* host_mapped, EventCounters* host_events)
 {
-	const uint32_t n_con = d.ctr->n_constraints;
+	// nobody was awake in this step (StepCounters::any_awake): it made no constraint, the table was not emptied, and the buffer parity goes back to what it was --
+	// the next step finds the cache this one found
+	const bool kept = !d.ctr->any_awake;
+	const uint32_t n_con = kept ? 0u : d.ctr->n_constraints;
 	const uint32_t size = *d.ht_cur;
 	const uint32_t mask = size - 1;
+	if (kept && blockIdx.x == 0 && threadIdx.x == 0) d.sp->parity = d.sp->parity ^ 1u;
 	for (uint32_t k = blockIdx.x * TPB + threadIdx.x; k < n_con; k += gridDim.x * TPB) {
 		const uint4 hd = con_hdr(CUR(d), k);
 		const uint2 ab = make_uint2(hd.x, hd.y);
@@ -509,6 +506,4 @@ void launch_cache_build(const DV& d, uint32_t n_con, StepCounters* host_mapped, 
 	// (the table was emptied by the first k_island_mark launch of the step)
 	hipLaunchKernelGGL(k_cache_build, dim3(stride_grid(n_con)), dim3(TPB), 0, s, d, host_mapped, host_events);
 }
-// forget the previous step's contacts (the world has gone to sleep as a whole: the CPU statement's steps without an awake body leave no constraints behind either)
-void launch_cache_wipe(const DV& d, hipStream_t s) { hipLaunchKernelGGL(k_cache_clear, dim3(64), dim3(TPB), 0, s, d); }
 void launch_contact_events(const DV& d, uint32_t est, hipStream_t s) { hipLaunchKernelGGL(k_contact_events, dim3(stride_grid(est)), dim3(TPB), 0, s, d); }

@@ -30,6 +30,7 @@ __global__ void __launch_bounds__(TPB) k_pre_solve(DV d)
 		reset_sleep(d, i, f_shape(f), d.pose[POSE_F4 * (size_t)i + 3], V3(d.pose[POSE_F4 * (size_t)i]), Q4(d.pose[POSE_F4 * (size_t)i + 1]));
 	}
 	if ((f & BF_ACTIVE) && f_motion(f) != SGP_MOTION_STATIC) {
+		if (!(f & BF_ALIAS)) d.ctr->any_awake = 1u;      // (every awake lane stores the same word: no atomic)
 		v3 lv = V3(lv4), av = V3(av4);
 		float im = 0.0f;
 		if (f_movable(f)) {
@@ -192,8 +193,8 @@ SGP_DEV bool island_edge(const DV& d, uint32_t k, uint32_t n_con, uint2& ab)
 __global__ void __launch_bounds__(TPB) k_island_mark(DV d, int clear_cache)
 {
 	// The first of the marking launches also empties the contact-cache table for this step's rebuild (nothing reads the old table after the set-up;
-	// the stores ride along with a launch that waits for its gathers: k_cache_clear was a launch of its own, 6 us on the step's chain)
-	if (clear_cache) {
+	// the stores ride along with a launch that waits for its gathers: a launch of its own was 6 us on the step's chain)
+	if (clear_cache && d.ctr->any_awake) {      // (nobody awake: the step leaves the contact cache as it found it, StepCounters::any_awake)
 		const uint32_t size = cache_table_size(d);
 		for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < size; i += gridDim.x * TPB) d.ht[i] = make_uint4(~0u, ~0u, 0u, 0u);
 		if (blockIdx.x == 0 && threadIdx.x == 0) *d.ht_cur = size;

@@ -126,6 +126,9 @@ struct StepCounters {
 	uint32_t veh_done;           // workgroups of the running vehicle-row launch that have finished (the last one solves the deferred vehicles and clears it)
 	// in-step activation (k_wake_pairs): the pairs of the bodies this step wakes, and where the second narrow-phase round starts in the hull / mesh lists
 	uint32_t n_wake_pairs, n_woken, hull_base, mesh_base[4], mesh_big_base;
+	uint32_t any_awake;          // somebody (dynamic or kinematic) is awake in this step (plain store of 1 by k_pre_solve).  A step nobody is awake in is the identity and leaves the
+	                             //   contact cache as it found it: no table wipe (k_island_mark), no rebuild, and the buffer parity goes back (k_cache_build) -- a pile that fell
+	                             //   asleep as a whole finds its contacts when it wakes (round 6; VERDICT r05 'a pile that wakes later starts cold')
 	uint32_t wake_any;           // some sleeping body was marked for wake-up this step (plain store of 1: k_wake_pairs has nothing to do otherwise)
 	uint32_t tickets[4];         // last_block(): workgroups of k_colour_count / k_warm_bodies / k_cache_build that have finished
 	uint32_t ts_error;           // tile solver: a tile gave up waiting for a neighbour (k_step_end copies ts_flags[0])
@@ -364,7 +367,6 @@ void launch_bp_pairs(const DV& d, int small_lds, hipStream_t s);      // small_l
 void launch_bp_large(const DV& d, uint32_t nb, hipStream_t s);
 void launch_bp_scatter_large(const DV& d, uint32_t nb, hipStream_t s);      // both in one launch (the step's path)
 void launch_narrowphase(const DV& d, uint32_t n_pairs_upper, hipStream_t s);
-void launch_cache_wipe(const DV& d, hipStream_t s);
 void launch_wake_round(const DV& d, uint32_t nb, int has_hulls, bool has_meshes, hipStream_t s);      // in-step activation: k_wake_pairs + the narrow phase of its pairs
 void launch_narrowphase_hull(const DV& d, bool big_hulls, hipStream_t s);     // only worlds with hull shapes; big_hulls: some hull has more than 32 vertices (k_narrowphase_hull_big)
 void launch_narrowphase_mesh(const DV& d, bool has_hulls, hipStream_t s);

@@ -760,12 +760,10 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 		memset(&st, 0, sizeof(st));
 		st.num_bodies = nb_; memcpy(st.layer_counts, lc, sizeof(lc)); st.device_bytes = w->device_bytes;
 		w->idle_steps++; w->last_step_idle = true;
-		// the first skipped step takes the contact cache with it: a step without an awake body has no contacts, and what wakes up later (in-step
-		// activation pairs bodies that were asleep) must not find the constraints of the last step that had some
-		if (!w->cache_wiped) { launch_cache_wipe(d, w->stream); w->cache_wiped = true; }
+		// (the contact cache stays as the last step with somebody awake left it: what wakes up later finds the contacts it fell asleep with)
 		return SGP_OK;
 	}
-	w->cache_wiped = false; w->last_step_idle = false;
+	w->last_step_idle = false;
 	if (w->veh_inputs_dirty && w->n_vehicles) {
 		HIP_TRY(hipMemcpyAsync(w->d_veh_inputs, w->veh_inputs.data(), sizeof(sgp_vehicle_input) * w->n_vehicles, hipMemcpyHostToDevice, w->stream));
 		w->veh_inputs_dirty = false;
@@ -817,7 +815,7 @@ static int step_impl(sgp_world* w, float dt, bool final_readback)
 	const double tt1 = timing ? now() : 0.0;
 	HIP_TRY(hipStreamSynchronize(w->stream));
 	const double tt2 = timing ? now() : 0.0;
-	w->h_sp->parity ^= 1u;                    // the buffer just solved becomes the contact cache of the next step
+	if (w->h_ctr->any_awake) w->h_sp->parity ^= 1u;  // the buffer just solved becomes the contact cache of the next step (a step nobody was awake in keeps the one it found: k_cache_build)
 	w->grid_valid = false;                    // bodies moved after the broad phase of this step
 	w->dirty_since_step = false;
 	w->last_active = w->h_ctr->n_active;

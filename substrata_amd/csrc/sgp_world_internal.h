@@ -102,7 +102,6 @@ struct sgp_world {
 	void* stage_host = nullptr; size_t stage_host_bytes = 0;
 	void* view_host = nullptr; size_t view_host_bytes = 0;       // pinned buffer of sgp_world_read_active[_poses]_view only
 	StepCounters* h_ctr = nullptr; StepCounters* h_ctr_dev = nullptr; EventCounters* h_evc = nullptr; EventCounters* h_evc_dev = nullptr;
-	bool cache_wiped = false;                                  // the contact cache was emptied by an idle step (step_impl)
 	bool dirty_since_step = true;                              // an edit was flushed since the last step (or no step yet)
 	bool events_on_device = true;                              // the device event lists may hold something the host vectors do not (a step without read-back, applied edits)
 	StepParams sp_uploaded; bool sp_uploaded_valid = false;    // what d_sp holds (upload_sp skips the launch when nothing changed)

@@ -142,3 +142,41 @@ def test_stale_label_after_slot_reuse_matches_the_oracle(oracle):
         cg, cc = parity.constraint_sets(tw)
         assert sorted((int(c["a"]), int(c["b"])) for c in cg) == sorted((int(c["a"]), int(c["b"])) for c in cc), f"second ball, step {s}: constraint pairs differ"
     tw.close()
+
+
+def test_a_pile_that_fell_asleep_as_a_whole_wakes_with_its_contacts(oracle):
+    """A step nobody is awake in leaves the contact cache as it found it (StepCounters::any_awake: no table wipe, no rebuild, the buffer parity goes back; host: the
+    skipped steps): the scene of tests/test_oracle_kat2.py on the device, bit for bit -- counts, events, states -- through the nudge and 60 steps after it; then the
+    same again after edits that wake nobody (real steps with nobody awake: the device's path, not the host's skip)."""
+    from test_oracle_kat2 import sleeping_pile_scene
+    tw = parity.make_twin(oracle, max_bodies=16)
+    _both(tw, lambda w: w.set_contact_events(True))
+    out = [sleeping_pile_scene(w) for w in (tw.gpu, tw.cpu)]
+    assert out[0] == out[1]
+    ids = out[0]
+    for rnd in range(2):
+        for w in (tw.gpu, tw.cpu):
+            for k in (abi.EVENT_CONTACT_ADDED, abi.EVENT_CONTACT_PERSISTED):
+                w.drain_events(k)
+        _both(tw, lambda w: (w.set_vel(ids[2], (0.02, 0.0, 0.0), (0.0, 0.0, 0.0)), w.activate(ids[2])))
+        tw.step(DT)
+        _exact(tw, 8, f"round {rnd}: the step that wakes the pile")
+        sg, sc = tw.gpu.stats(), tw.cpu.stats()
+        assert (sg.num_manifolds, sg.num_cached_manifolds) == (sc.num_manifolds, sc.num_cached_manifolds) == (3, 3), (rnd, sg.num_manifolds, sg.num_cached_manifolds, sc.num_manifolds, sc.num_cached_manifolds)
+        for k, n in ((abi.EVENT_CONTACT_ADDED, 0), (abi.EVENT_CONTACT_PERSISTED, 3)):
+            assert len(tw.gpu.drain_events(k)) == len(tw.cpu.drain_events(k)) == n, (rnd, k)
+        for s in range(400):
+            tw.step(DT)
+            _exact(tw, 8, f"round {rnd}, step {s} after the nudge")
+        assert not any(x["active"] for x in tw.gpu.get_state(ids))
+        if rnd == 0:
+            # edits that wake nobody (a static box far away, then its removal): real steps, not the host's skipped ones, with nobody awake
+            far = [dyn(w, pos=(50.0, 50.0, 5.0), motion=abi.MOTION_STATIC, layer=abi.LAYER_NON_MOVING, activate=0) for w in (tw.gpu, tw.cpu)]
+            assert far[0] == far[1]
+            for s in range(3):
+                tw.step(DT)
+            _both(tw, lambda w: w.remove(far[0]))
+            for s in range(5):
+                tw.step(DT)
+    tw.close()
+

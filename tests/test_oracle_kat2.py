@@ -213,3 +213,40 @@ def test_a_body_created_in_a_removed_island_roots_slot_does_not_wake_that_island
             assert all(act)
     assert first is not None
     w.close()
+
+
+def sleeping_pile_scene(w):
+    """Three boxes stacked on the ground, nothing else in the world: the pile falls asleep as a whole and the world idles for a while.  Returns the box ids, bottom first."""
+    from helpers import add_ground, dyn
+    add_ground(w)
+    ids = [dyn(w, pos=(0.0, 0.0, 0.5 + k)) for k in range(3)]
+    for _ in range(400):
+        w.step(DT)
+    assert not any(s["active"] for s in w.get_state(ids))
+    for _ in range(40):
+        w.step(DT)                                                              # steps nobody is awake in
+    return ids
+
+
+def test_a_pile_that_fell_asleep_as_a_whole_wakes_with_its_contacts(oracle):
+    """'the first idle step wipes the whole contact cache, so a pile that wakes later starts cold'.  A step nobody is awake in now leaves the cache as it
+    found it: when the top box is nudged, the step that wakes the pile (in-step activation: all three collide in it) finds last contacts of every pair -- the body-pair
+    cache hands back their manifolds, the events say 'persisted', and the impulses start from what held the pile up."""
+    w = oracle.OracleWorld(max_bodies=16)
+    w.set_contact_events(True)
+    ids = sleeping_pile_scene(w)
+    for k in (abi.EVENT_CONTACT_ADDED, abi.EVENT_CONTACT_PERSISTED):
+        w.drain_events(k)
+    z0 = [float(s["pos"][2]) for s in w.get_state(ids)]
+    w.set_vel(ids[2], (0.02, 0.0, 0.0), (0.0, 0.0, 0.0))
+    w.activate(ids[2])
+    w.step(DT)
+    st = w.stats()
+    assert all(s["active"] for s in w.get_state(ids))                           # the nudge woke the box, the box its island, in the same step
+    assert st.num_manifolds == 3 and st.num_cached_manifolds == 3, (st.num_manifolds, st.num_cached_manifolds)
+    added, persisted = w.drain_events(abi.EVENT_CONTACT_ADDED), w.drain_events(abi.EVENT_CONTACT_PERSISTED)
+    assert len(added) == 0 and len(persisted) == 3
+    s1 = w.get_state(ids)
+    assert max(abs(float(s["pos"][2]) - z) for s, z in zip(s1, z0)) < 2e-4
+    w.close()
+
