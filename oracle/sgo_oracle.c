@@ -68,6 +68,8 @@ typedef struct {
 	int movable_prev, movable_cur;   /* movable (dynamic and awake) when the previous / this step coloured its constraints */
 	int island; int can_sleep;
 	v3 linv_pre;                       /* linear velocity at the start of the step (before the forces): the active-edge movement hint */
+	int awake_step;                  /* awake (active and not static) in the step being taken, once its collision detection has woken what it wakes */
+	int fresh;                       /* was cache_invalid when the step being taken began */
 	int cache_invalid;               /* created or reshaped since the last step: its pairs do not reuse cached manifolds (Body::InvalidateContactCache) */
 } sgo_body;
 
@@ -90,6 +92,7 @@ typedef struct {
 	/* body-pair contact cache (ContactConstraintManager::GetContactsFromCache): pose of body 2 relative to body 1 and the normal in body 2's
 	   frame WHEN THE MANIFOLD WAS COMPUTED; a reused manifold keeps them, so slow drift ends the reuse */
 	v3 dpos; quat drot; v3 nloc2; int reused;
+	int carried;         /* not of the last step: the contact of a pair both of whose bodies have been asleep (or static) since -- kept in the cache, never solved */
 	sgo_point pt[4];
 } sgo_constraint;
 
@@ -2157,7 +2160,11 @@ SGO_API int sgo_world_step(sgo_world* w, float dt)
 	/* is anybody awake in this step (kinematic bodies count; what the contacts above woke is awake by now)?  A step nobody is awake in is the identity -- and
 	   leaves the contact cache as it is (step 10) */
 	int any_awake = 0;
-	for (uint32_t i = 0; i < w->high && !any_awake; ++i) if (w->bodies[i].alive && !w->bodies[i].is_alias && body_is_active_for_pairs(&w->bodies[i])) any_awake = 1;
+	for (uint32_t i = 0; i < w->high; ++i) {
+		sgo_body* b = &w->bodies[i];
+		b->awake_step = b->alive && !b->is_alias && body_is_active_for_pairs(b);
+		if (b->awake_step) any_awake = 1;
+	}
 
 	nan_trace(w, "1-3 forces, collision");
 	/* 4. colouring and solve order */
@@ -2222,7 +2229,7 @@ SGO_API int sgo_world_step(sgo_world* w, float dt)
 	for (uint32_t i = 0; i < w->high; ++i) { sgo_body* b = &w->bodies[i]; if (b->alive && b->active) body_update_aabb(b); }
 	update_sleeping(w, dt);
 
-	for (uint32_t i = 0; i < w->high; ++i) w->bodies[i].cache_invalid = 0;      /* every live body has now been through a step with its present shape */
+	for (uint32_t i = 0; i < w->high; ++i) { w->bodies[i].fresh = w->bodies[i].cache_invalid; w->bodies[i].cache_invalid = 0; }      /* every live body has now been through a step with its present shape */
 
 	nan_trace(w, "8 bounds, sleeping");
 	/* 9. buoyancy (Substrata's own sweep after Update) */
@@ -2236,6 +2243,18 @@ SGO_API int sgo_world_step(sgo_world* w, float dt)
 	uint32_t n_reused_step = 0;
 	for (uint32_t k = 0; k < w->n_cons; ++k) n_reused_step += (uint32_t)w->cons[k].reused;
 	if (any_awake) {
+		/* the contacts of sleeping pairs stay in the cache (ContactConstraintManager keeps the cached contacts of bodies that are not active -- UNVERIFIED:
+		   upstream): an entry of the cache this step found is carried over when neither of its bodies was awake in this step (such a pair made no
+		   constraint of its own: no duplicate) and neither was created or reshaped since the last step; it is looked up like any other when the pair
+		   wakes -- warm start, the body-pair cache's manifold, 'persisted' -- and is never solved, counted or reported */
+		for (uint32_t k = 0; k < w->n_prev; ++k) {
+			const sgo_constraint* e = &w->prev[k];
+			const sgo_body* A = &w->bodies[e->a]; const sgo_body* B = &w->bodies[e->b];
+			if (!A->alive || !B->alive || A->awake_step || B->awake_step || A->fresh || B->fresh) continue;
+			if (w->n_cons == w->cap_cons) { w->cap_cons = w->cap_cons + w->cap_cons / 2 + 1024; w->cons = (sgo_constraint*)realloc(w->cons, sizeof(sgo_constraint) * w->cap_cons); }
+			w->cons[w->n_cons] = *e; w->cons[w->n_cons].carried = 1;
+			w->n_cons++;
+		}
 		sgo_constraint* t = w->prev; w->prev = w->cons; w->cons = t;
 		const uint32_t tc = w->cap_prev; w->cap_prev = w->cap_cons; w->cap_cons = tc;
 		w->n_prev = w->n_cons;
@@ -2670,15 +2689,18 @@ SGO_API float sgo_cast_sphere(const sgp_body_desc* b, const float o[3], const fl
 typedef struct { uint32_t a, b; int32_t colour; int32_t np; float n[3]; float lam_n[4]; float lam_t1[4]; float lam_t2[4]; float bias[4]; } sgo_constraint_dump;
 SGO_API int sgo_world_dump_constraints(sgo_world* w, sgo_constraint_dump* out, uint32_t cap, uint32_t* n_out)
 {
-	*n_out = w->n_prev;
-	for (uint32_t k = 0; k < w->n_prev && k < cap; ++k) {
+	uint32_t n = 0;
+	for (uint32_t k = 0; k < w->n_prev; ++k) {
 		const sgo_constraint* c = &w->prev[w->prev_idx_sorted[k]];
-		sgo_constraint_dump* d = &out[k];
+		if (c->carried) continue;      /* (kept for a sleeping pair: not a constraint of the step) */
+		if (n >= cap) { ++n; continue; }
+		sgo_constraint_dump* d = &out[n++];
 		memset(d, 0, sizeof(*d));
 		d->a = c->a; d->b = c->b; d->colour = c->colour; d->np = c->np;
 		d->n[0] = c->n.x; d->n[1] = c->n.y; d->n[2] = c->n.z;
 		for (int i = 0; i < c->np; ++i) { d->lam_n[i] = c->pt[i].lam_n; d->lam_t1[i] = c->pt[i].lam_t1; d->lam_t2[i] = c->pt[i].lam_t2; d->bias[i] = c->pt[i].bias; }
 	}
+	*n_out = n;
 	return SGP_OK;
 }
 

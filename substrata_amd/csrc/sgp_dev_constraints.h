@@ -52,7 +52,9 @@ SGP_DEV int man_colour_candidate(int np_col_prev) { return -(3 + ((np_col_prev >
 // constraints: 8 MB instead of 33 MB per step at config 3, and a table that stays in the caches between the rebuild and the next step's probes.
 SGP_DEV uint32_t cache_table_size(const DV& d)
 {
-	const uint32_t want = 4u * max(d.ctr->n_constraints, 256u);
+	// (room for the step's constraints and for every entry of the previous cache -- all of them may be carried over, k_cache_build: half full at the very worst, a
+	// quarter when few pairs sleep; called by k_island_mark, where the parity is this step's)
+	const uint32_t want = 2u * max(d.ctr->n_constraints + min(d.cache_total[d.sp->parity ^ 1u], d.cap_manifolds), 512u);
 	uint32_t size = 1024u;
 	while (size < want && size < d.ht_size) size <<= 1;
 	return min(size, d.ht_size);

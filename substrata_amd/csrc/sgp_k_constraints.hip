@@ -441,6 +441,38 @@ __global__ void __launch_bounds__(TPB) k_cache_build(DV d, StepCounters* host_ma
 			h = (h + 1) & mask;
 		}
 	}
+	// The contacts of sleeping pairs stay in the cache: an entry of the cache this step found is carried over -- copied behind this step's constraints, entered in the
+	// table -- when neither of its bodies was awake in this step (such a pair made no constraint of its own: no duplicate) and neither was created or reshaped since
+	// the last step.  It is found like any other when the pair wakes (warm start, the body-pair cache's manifold, 'persisted') and is never solved, counted or reported.
+	if (!kept) {
+		const uint32_t par = d.sp->parity;
+		const uint32_t prev_total = min(d.cache_total[par ^ 1u], d.cap_manifolds);
+		const ConstraintArrays& P = PRV(d); const ConstraintArrays& Cn = CUR(d);
+		for (uint32_t k0 = blockIdx.x * TPB; k0 < prev_total; k0 += gridDim.x * TPB) {
+			const uint32_t k = k0 + threadIdx.x;
+			bool carry = false; uint4 hd = make_uint4(0u, 0u, 0u, 0u);
+			if (k < prev_total) {
+				hd = con_hdr(P, k);
+				const uint32_t fa = d.flags[hd.x], fb = d.flags[hd.y];
+				carry = (fa & BF_ALIVE) && (fb & BF_ALIVE) && !((fa | fb) & (BF_AWAKE_STEP | BF_FRESH));
+			}
+			if (!carry) continue;
+			const uint32_t slot = wave_alloc(&d.cache_total[par]);
+			if (slot >= d.cap_manifolds) continue;
+			Cn.hdr[slot] = hd;
+			const int np = (int)(hd.z & 0xFFu);
+#pragma unroll
+			for (int j = 0; j < 4; ++j) if (j < np) { Cn.loc1[j][slot] = P.loc1[j][k]; Cn.loc2[j][slot] = P.loc2[j][k]; Cn.lam[j][slot] = P.lam[j][k]; }
+			{ const float4* src = P.prec + (size_t)k * PREC_F4; float4* dst = Cn.prec + (size_t)slot * PREC_F4; dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; }
+			const uint64_t key = ((uint64_t)hd.x << 32) | hd.y;
+			uint32_t h = ht_hash(key, mask);
+			for (uint32_t probe = 0; probe < size; ++probe) {
+				const unsigned long long old = atomicCAS((unsigned long long*)&d.ht[h], ~0ull, (unsigned long long)key);
+				if (old == ~0ull || old == key) { ((uint2*)&d.ht[h])[1] = make_uint2(slot, hd.z); break; }
+				h = (h + 1) & mask;
+			}
+		}
+	}
 	// the step's counters are final before this launch starts and nothing here touches them: workgroup 0 sends them to the host, no waiting for the others
 	// (measured: a ticket + fence per workgroup after the hash-table inserts cost 42 us -- the fence writes back every dirty line of the XCD's L2)
 	if (host_mapped && blockIdx.x == 0) step_end_block(d, host_mapped, host_events);

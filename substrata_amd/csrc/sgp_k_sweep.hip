@@ -70,7 +70,9 @@ __global__ void __launch_bounds__(TPB) k_pre_solve(DV d)
 	}
 	d.hc_root[i] = i; d.hc_count[i] = 0u;      // every body a component of its own (k_hc_hook joins them along the high-colour constraints)
 	// remember whether the body was movable when the previous step coloured its constraints (colour inheritance)
-	uint32_t nf = f & ~(BF_MOVABLE_PREV | BF_MOVABLE_CUR | BF_CACHE_INVALID);      // (the narrow phase of this step has seen the flag)
+	uint32_t nf = f & ~(BF_MOVABLE_PREV | BF_MOVABLE_CUR | BF_CACHE_INVALID | BF_AWAKE_STEP | BF_FRESH);      // (the narrow phase of this step has seen the flag)
+	if ((f & BF_ACTIVE) && f_motion(f) != SGP_MOTION_STATIC && !(f & BF_ALIAS)) nf |= BF_AWAKE_STEP;      // (what k_cache_build asks of the bodies of a cached contact)
+	if (f & BF_CACHE_INVALID) nf |= BF_FRESH;
 	if (f & BF_MOVABLE_CUR) nf |= BF_MOVABLE_PREV;
 	if (f_movable(f)) nf |= BF_MOVABLE_CUR;
 	if (nf != f0) d.flags[i] = nf;
@@ -197,7 +199,7 @@ __global__ void __launch_bounds__(TPB) k_island_mark(DV d, int clear_cache)
 	if (clear_cache && d.ctr->any_awake) {      // (nobody awake: the step leaves the contact cache as it found it, StepCounters::any_awake)
 		const uint32_t size = cache_table_size(d);
 		for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < size; i += gridDim.x * TPB) d.ht[i] = make_uint4(~0u, ~0u, 0u, 0u);
-		if (blockIdx.x == 0 && threadIdx.x == 0) *d.ht_cur = size;
+		if (blockIdx.x == 0 && threadIdx.x == 0) { *d.ht_cur = size; d.cache_total[d.sp->parity] = d.ctr->n_constraints; }      // (k_cache_build appends the carried entries)
 	}
 	// (measured, round 4: the three rounds inside ONE launch -- agent-scope loads so that marks cross the XCDs' L2s -- cost 52 us against 36 us for three
 	// launches with plain accesses: the kernel boundary is the cheaper way to make the marks of a round visible everywhere)

@@ -43,6 +43,8 @@
 #define BF_CAN_SLEEP     (1u << 15)  // scratch: sleep test result
 #define BF_MOVABLE_PREV  (1u << 16)  // movable (dynamic and awake) when the PREVIOUS step coloured its constraints
 #define BF_MOVABLE_CUR   (1u << 17)  // same, this step
+#define BF_AWAKE_STEP    (1u << 23)  // awake (active, not static) in the step being taken, once its collision detection has woken what it wakes (k_pre_solve); until the next k_pre_solve
+#define BF_FRESH         (1u << 24)  // was BF_CACHE_INVALID when the step being taken began (k_pre_solve): no cache entry of this slot's pairs is carried over (k_cache_build)
 
 #define SGP_LABEL(slot, gen) ((uint32_t)(slot) | ((uint32_t)(gen) << 25))      // (max_bodies < 2^25)
 #define SGP_LABEL_SLOT(l) ((l) & 0x1FFFFFFu)
@@ -322,6 +324,8 @@ struct DV {
 	ConstraintArrays ca[2];    // [sp->parity] = this step's constraints, the other = previous step's (contact cache)
 	uint4* ht; uint32_t ht_size;   // contact cache: 16-byte entries (pair key low, high, slot in the previous step's constraints, its np_col) -- one line per probe, and the
 	                           //   colour a manifold may inherit comes with the probe (ht_size: allocated entries, a power of two); key ~0 = empty
+	uint32_t* cache_total;     // [2] per constraint buffer (parity): entries the contact cache holds in it -- the step's constraints [0, n_constraints) and behind them the contacts of
+	                           //   sleeping pairs carried over from step to step (k_cache_build; never solved, counted or reported): set to n_constraints by k_island_mark, grown by the carry
 	uint32_t* ht_cur;          // entries the last rebuild used (device scalar, a power of two <= ht_size): what look-ups mask with
 	uint32_t* cstarts;         // [SGP_MAX_COLOURS + 1] first constraint slot of every colour (device-side exclusive scan)
 	// counters / events

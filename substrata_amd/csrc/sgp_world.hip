@@ -204,6 +204,7 @@ SGP_API int sgp_world_create(const sgp_world_desc* desc, sgp_world** out)
 	HIP_TRY(hipMemsetAsync(d.ht, 0xFF, sizeof(uint4) * w->ht_alloc, w->stream));      // empty contact cache (key ~0)
 	d.ht_size = w->ht_alloc;
 	DEV_ALLOC(d.ht_cur, 1);
+	DEV_ALLOC(d.cache_total, 2); HIP_TRY(hipMemsetAsync(d.cache_total, 0, sizeof(uint32_t) * 2, w->stream));
 	{ static const uint32_t first = 1024u; HIP_TRY(hipMemcpyAsync(d.ht_cur, &first, sizeof(first), hipMemcpyHostToDevice, w->stream)); }      // (an empty table: any size will do)
 	DEV_ALLOC(d.cstarts, SGP_MAX_COLOURS + 2);
 	DEV_ALLOC(d.ctr, 1); DEV_ALLOC(d.evc, 1);

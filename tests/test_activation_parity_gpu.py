@@ -144,14 +144,16 @@ def test_stale_label_after_slot_reuse_matches_the_oracle(oracle):
     tw.close()
 
 
-def test_a_pile_that_fell_asleep_as_a_whole_wakes_with_its_contacts(oracle):
+@pytest.mark.parametrize("somebody_awake", [False, True])
+def test_a_pile_that_fell_asleep_as_a_whole_wakes_with_its_contacts(oracle, somebody_awake):
     """A step nobody is awake in leaves the contact cache as it found it (StepCounters::any_awake: no table wipe, no rebuild, the buffer parity goes back; host: the
     skipped steps): the scene of tests/test_oracle_kat2.py on the device, bit for bit -- counts, events, states -- through the nudge and 60 steps after it; then the
-    same again after edits that wake nobody (real steps with nobody awake: the device's path, not the host's skip)."""
+    same again after edits that wake nobody (real steps with nobody awake: the device's path, not the host's skip).
+    somebody_awake: a kinematic body keeps the world awake all along -- the pile's contacts are carried over from step to step (k_cache_build)."""
     from test_oracle_kat2 import sleeping_pile_scene
     tw = parity.make_twin(oracle, max_bodies=16)
     _both(tw, lambda w: w.set_contact_events(True))
-    out = [sleeping_pile_scene(w) for w in (tw.gpu, tw.cpu)]
+    out = [sleeping_pile_scene(w, somebody_awake) for w in (tw.gpu, tw.cpu)]
     assert out[0] == out[1]
     ids = out[0]
     for rnd in range(2):
@@ -169,6 +171,7 @@ def test_a_pile_that_fell_asleep_as_a_whole_wakes_with_its_contacts(oracle):
             tw.step(DT)
             _exact(tw, 8, f"round {rnd}, step {s} after the nudge")
         assert not any(x["active"] for x in tw.gpu.get_state(ids))
+        assert tw.gpu.stats().num_manifolds == tw.cpu.stats().num_manifolds == 0
         if rnd == 0:
             # edits that wake nobody (a static box far away, then its removal): real steps, not the host's skipped ones, with nobody awake
             far = [dyn(w, pos=(50.0, 50.0, 5.0), motion=abi.MOTION_STATIC, layer=abi.LAYER_NON_MOVING, activate=0) for w in (tw.gpu, tw.cpu)]
