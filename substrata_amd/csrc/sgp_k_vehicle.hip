@@ -3,7 +3,8 @@
 #include "sgp_dev_all.h"
 
 // rs: what the moving shape reaches around the path of its centre -- the cast sphere's radius, or (wh != nullptr: the wheel itself is cast, sgd_cast_disc) the wheel's
-SGP_DEV void veh_cast_test(const DV& d, const sgd_vehicle* v, v3 o, v3 dir, float rs, float cast_len, uint32_t j, float& best, uint32_t& bid, v3& bn, v3& bp, const sgd_wheel* wh = nullptr)
+// CYL: the instance that can cast the wheel itself (a world without such a vehicle runs the one without: half the registers)
+template <bool CYL> SGP_DEV void veh_cast_test(const DV& d, const sgd_vehicle* v, v3 o, v3 dir, float rs, float cast_len, uint32_t j, float& best, uint32_t& bid, v3& bn, v3& bp, const sgd_wheel* wh = nullptr)
 {
 	if (j == v->body) return;
 	const uint32_t f = d.flags[j];
@@ -19,7 +20,7 @@ SGP_DEV void veh_cast_test(const DV& d, const sgd_vehicle* v, v3 o, v3 dir, floa
 	const float prm[3] = { sh.x, sh.y, sh.z };
 	v3 n, p;
 	float t;
-	if (wh) {
+	if (CYL && wh) {
 		// the wheel itself: always over the whole travel (the search's path must not depend on what another candidate returned); a hit behind the best so far loses
 		t = f_shape(f) == SGP_SHAPE_MESH ? cast_disc_mesh(d, j, o, dir, wh->cast_e, wh->cast_din, wh->disc_r, wh->cast_rho, cast_len, &n, &p)
 		  : sgd_cast_disc_body((int)f_shape(f), prm, f_shape(f) == SGP_SHAPE_HULL ? body_hull(d, sh) : nullptr, V3(d.pose[POSE_F4 * (size_t)j]), quat_to_m33(Q4(d.pose[POSE_F4 * (size_t)j + 1])), o, dir, wh->cast_e, wh->cast_din, wh->disc_r, wh->cast_rho, cast_len, &n, &p);
@@ -27,7 +28,7 @@ SGP_DEV void veh_cast_test(const DV& d, const sgd_vehicle* v, v3 o, v3 dir, floa
 	} else
 	t = f_shape(f) == SGP_SHAPE_MESH ? cast_sphere_mesh(d, j, o, dir, best, rs, &n, &p)
 	  : sgd_cast_sphere_body((int)f_shape(f), prm, f_shape(f) == SGP_SHAPE_HULL ? body_hull(d, sh) : nullptr, V3(d.pose[POSE_F4 * (size_t)j]), quat_to_m33(Q4(d.pose[POSE_F4 * (size_t)j + 1])), o, dir, best, rs, &n, &p);
-	if (t < 0.0f || (!wh && n.z < v->cos_max_slope)) return;      // (VehicleCollisionTesterCastCylinder has no slope limit)
+	if (t < 0.0f || (!(CYL && wh) && n.z < v->cos_max_slope)) return;      // (VehicleCollisionTesterCastCylinder has no slope limit)
 	// closest accepted hit; on equal distance the lower body id wins (the oracle visits ids in ascending order)
 	if (t < best || bid == SGP_INVALID_ID || (t == best && j < bid)) { best = t; bid = j; bn = n; bp = p; }
 }
@@ -64,7 +65,7 @@ SGP_DEV void veh_stage_out(sgd_vehicle* gv, const sgd_vehicle* sv)
 // Cast: 16 lanes per wheel share the candidate list (large bodies + the grid cells under the swept sphere); each lane keeps its
 // closest accepted hit and a butterfly reduction takes the lexicographic (distance, body id) minimum, which does not depend
 // on how the candidates were dealt to the lanes.
-__global__ void __launch_bounds__(64) k_vehicle_cast(DV d)
+template <bool CYL> __global__ void __launch_bounds__(64) k_vehicle_cast(DV d)
 {
 	__shared__ sgd_vehicle sv;
 	__shared__ int s_dormant;
@@ -94,18 +95,18 @@ __global__ void __launch_bounds__(64) k_vehicle_cast(DV d)
 		if (wi < sv.num_wheels) {
 			const sgd_wheel* wh = &sv.wheels[wi];
 			const v3 o = wh->cast_origin, dir = wh->cast_dir;
-			const bool cyl = sv.tester == SGP_VEHICLE_TESTER_CYLINDER;
+			const bool cyl = CYL && sv.tester == SGP_VEHICLE_TESTER_CYLINDER;
 			const float rs = cyl ? wh->radius : sv.cast_radius;
 			const sgd_wheel* const whc = cyl ? wh : nullptr;
 			best = wh->cast_len;
-			for (uint32_t l = sub; l < d.sp->n_large; l += 16) veh_cast_test(d, &sv, o, dir, rs, wh->cast_len, d.large_ids[l], best, bid, bn, bp, whc);
+			for (uint32_t l = sub; l < d.sp->n_large; l += 16) veh_cast_test<CYL>(d, &sv, o, dir, rs, wh->cast_len, d.large_ids[l], best, bid, bn, bp, whc);
 			{
 				// static large bodies under the swept sphere's bounds, dealt to the wheel's 16 lanes in the order the grid yields them
 				const v3 e2 = v3_add(o, v3_scale(dir, wh->cast_len));
 				const float m2 = rs + 2.0e-3f;
 				uint32_t seen = 0;
 				large_grid_query(d, V3(fminf(o.x, e2.x) - m2, fminf(o.y, e2.y) - m2, fminf(o.z, e2.z) - m2), V3(fmaxf(o.x, e2.x) + m2, fmaxf(o.y, e2.y) + m2, fmaxf(o.z, e2.z) + m2),
-				                 [&](uint32_t i) { if ((seen++ & 15u) == sub) veh_cast_test(d, &sv, o, dir, rs, wh->cast_len, i, best, bid, bn, bp, whc); });
+				                 [&](uint32_t i) { if ((seen++ & 15u) == sub) veh_cast_test<CYL>(d, &sv, o, dir, rs, wh->cast_len, i, best, bid, bn, bp, whc); });
 			}
 			const BpGrid g = *d.grid;
 			if (g.n_cells > 0 && g.min_x <= g.max_x) {
@@ -116,7 +117,7 @@ __global__ void __launch_bounds__(64) k_vehicle_cast(DV d)
 				const int y0 = max((int)floorf((fminf(o.y, e.y) - m - g.oy) * g.inv_cell) - 1, 0), y1 = min((int)floorf((fmaxf(o.y, e.y) + m - g.oy) * g.inv_cell) + 1, g.ny - 1);
 				const int z0 = max((int)floorf((fminf(o.z, e.z) - m - g.oz) * g.inv_cell) - 1, 0), z1 = min((int)floorf((fmaxf(o.z, e.z) + m - g.oz) * g.inv_cell) + 1, g.nz - 1);
 				if (x0 <= x1) for (int z = z0; z <= z1; ++z) for (int y = y0; y <= y1; ++y) {
-					grid_row_runs(d, g, x0, x1, y, z, [&](uint32_t q0, uint32_t q1) { for (uint32_t q = q0 + sub; q < q1; q += 16) veh_cast_test(d, &sv, o, dir, rs, wh->cast_len, __float_as_uint(d.sorted_max[q].w), best, bid, bn, bp, whc); });
+					grid_row_runs(d, g, x0, x1, y, z, [&](uint32_t q0, uint32_t q1) { for (uint32_t q = q0 + sub; q < q1; q += 16) veh_cast_test<CYL>(d, &sv, o, dir, rs, wh->cast_len, __float_as_uint(d.sorted_max[q].w), best, bid, bn, bp, whc); });
 				}
 			}
 		}
@@ -550,10 +551,11 @@ void launch_solve_colour_veh(const DV& d, int colour, uint32_t est, int mode, hi
 	}
 	else hipLaunchKernelGGL((k_solve_colour_veh<2, -1>), dim3(vb + blocks), dim3(SOLVE_VEL_TPB), 0, s, d, colour, vb);
 }
-void launch_vehicle_pre(const DV& d, hipStream_t s)
+void launch_vehicle_pre(const DV& d, bool cylinder_testers, hipStream_t s)
 {
 	if (!d.n_vehicles) return;
-	hipLaunchKernelGGL(k_vehicle_cast, dim3(d.n_vehicles), dim3(64), 0, s, d);
+	if (cylinder_testers) hipLaunchKernelGGL(k_vehicle_cast<true>, dim3(d.n_vehicles), dim3(64), 0, s, d);
+	else hipLaunchKernelGGL(k_vehicle_cast<false>, dim3(d.n_vehicles), dim3(64), 0, s, d);
 	hipLaunchKernelGGL(k_vehicle_controller, dim3(d.n_vehicles), dim3(64), 0, s, d);
 }
 void launch_vehicle_solve(const DV& d, int mode, hipStream_t s)

@@ -412,7 +412,7 @@ void launch_gather_states(const DV& d, const uint32_t* ids, uint32_t first, uint
 void launch_gather_active(const DV& d, uint32_t nb, sgp_body_state* out, uint32_t cap, hipStream_t s);
 void launch_gather_active_poses(const DV& d, uint32_t nb, void* out, uint32_t cap, hipStream_t s);      // sgp_body_pose records (32 B)
 void launch_dump_constraints(const DV& d, uint32_t which, uint32_t n_con, void* out, uint32_t cap, hipStream_t s);
-void launch_vehicle_pre(const DV& d, hipStream_t s);
+void launch_vehicle_pre(const DV& d, bool cylinder_testers, hipStream_t s);
 void launch_vehicle_solve(const DV& d, int mode, hipStream_t s);
 void launch_solve_colour_veh(const DV& d, int colour, uint32_t est, int mode, hipStream_t s, int compact_rows);      // a contact colour whose first workgroups solve the vehicles' rows (mode 1, 2)      // mode as launch_solve_colour
 // Single-query mailbox (round 5): PhysicsWorld::traceRay is called one ray at a time by unchanged callers (ParticleManager.cpp:164: up to 2048 per frame;

@@ -561,6 +561,7 @@ struct StepPlan {
 	uint32_t colour_est[SGP_MAX_COLOURS];
 	int      water, contact_events, warm_start, vel_iters, pos_iters;
 	uint32_t n_vehicles;
+	int      veh_cylinder;       // some vehicle casts its wheels as cylinders: the cast kernel's instance that holds that search (twice the registers)
 	int      has_meshes;         // some body may be a static triangle mesh: run the mesh-pair narrow phase
 	int      has_hulls;          // some body may be a convex hull: run the hull-pair narrow phase (2: a hull of more than 32 vertices exists -- k_narrowphase_hull_big too)
 	int      wake_round;         // in-step activation: pair and collide the bodies this step wakes (k_wake_pairs + a second narrow-phase round)
@@ -602,6 +603,7 @@ static void make_plan(const sgp_world* w, StepPlan& p)
 	p.water = w->h_sp->water_enabled; p.contact_events = w->h_sp->contact_events;
 	p.warm_start = w->dv.st.warm_start; p.vel_iters = w->dv.st.num_velocity_steps; p.pos_iters = w->dv.st.num_position_steps;
 	p.n_vehicles = w->n_vehicles;
+	p.veh_cylinder = w->veh_cylinder_seen ? 1 : 0;
 	p.has_hulls = w->hulls.size() > 1 ? (w->n_big_hulls ? 2 : 1) : 0;
 	p.has_meshes = w->meshes.size() > 1 ? 1 : 0;
 	p.wake_round = w->use_wake_round ? 1 : 0;
@@ -663,7 +665,7 @@ static int enqueue_step(sgp_world* w, const StepPlan& p)
 	{ KScope k(w, KC_BP_CELL); launch_bp_bounds(d, nb, s); launch_bp_cell(d, nb, s); }
 	{ KScope k(w, KC_BP_SCAN); launch_bp_scan(d, s); }
 	{ KScope k(w, KC_BP_SCATTER); launch_bp_scatter_large(d, nb, s); }      // (+ the pairs with the large bodies: k_bp_large's work)
-	if (p.n_vehicles) { KScope k(w, KC_VEHICLE); launch_vehicle_pre(d, s); }
+	if (p.n_vehicles) { KScope k(w, KC_VEHICLE); launch_vehicle_pre(d, p.veh_cylinder != 0, s); }
 	{ KScope k(w, KC_BP_PAIRS); launch_bp_pairs(d, p.bp_small, s); }
 	STAGE_MARK(2);
 	// -- 3. narrow phase, wake-ups, per-body solver records (+ contact events, which see the velocities before the solve)

@@ -147,6 +147,7 @@ struct sgp_world {
 	float4* d_veh_rows = nullptr; float4* d_veh_head = nullptr;      // the step's rows in the solver's lane-major layout (DV::veh_rows)
 	bool fuse_vehicle_solve = true;                                  // SGP_VEHICLE_FUSED=0: the vehicles' rows in launches of their own
 	std::vector<uint8_t> veh_alive; std::vector<uint32_t> veh_body; std::vector<sgp_vehicle_input> veh_inputs; bool veh_inputs_dirty = false;
+	bool veh_cylinder_seen = false;                            // some vehicle casts its wheels as cylinders (SGP_VEHICLE_TESTER_CYLINDER): k_vehicle_cast's instance with that search in it
 	// events collected on the host until drained
 	std::vector<sgp_body_event> ev_act, ev_deact, ev_water;
 	std::vector<sgp_contact_event> ev_added, ev_pers;
