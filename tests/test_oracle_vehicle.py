@@ -424,7 +424,7 @@ def test_wheel_cast_against_brute_force(oracle):
     rng = np.random.default_rng(11)
     checked = 0
     ang = np.linspace(0, 2 * np.pi, 720, endpoint=False)
-    for trial in range(90):
+    for trial in range(60):
         kind = [abi.SHAPE_SPHERE, abi.SHAPE_BOX, abi.SHAPE_CAPSULE][trial % 3]
         q = rng.normal(size=4); q /= np.linalg.norm(q)
         p = (rng.uniform(0.2, 0.8), rng.uniform(0.2, 0.8), rng.uniform(0.2, 0.8))
@@ -446,7 +446,7 @@ def test_wheel_cast_against_brute_force(oracle):
         hit = oracle.cast_disc(sh.desc(), o, d, e, d, disc_r, rho, max_t)
         if dist(0.0) <= 0:
             continue
-        ts = np.linspace(0, max_t, 1501)
+        ts = np.linspace(0, max_t, 1001)
         dd = np.array([dist(t) for t in ts])
         inside = np.nonzero(dd <= 0)[0]
         if len(inside) == 0:
@@ -464,7 +464,7 @@ def test_wheel_cast_against_brute_force(oracle):
         c = pt + n * rho - (o + d * t)                                                        # the touching sphere's centre, relative to the disc's centre
         assert abs(c @ axle) < 3e-4 and np.linalg.norm(c) < disc_r + 3e-4                     # ... lies on the disc
         checked += 1
-    assert checked > 50
+    assert checked > 30
 
 
 def _cylinder(vd):
