@@ -87,6 +87,9 @@ def bike_vehicle_desc(w, body):
     return vd
 
 
-def add_bike(w, pos=(0, 0, 0.7), rot=(0, 0, 0, 1), mass=200.0):
+def add_bike(w, pos=(0, 0, 0.7), rot=(0, 0, 0, 1), mass=200.0, desc_edit=None):
     body = dyn(w, shape=(1.7 / 2 * 0.18, 9.0 / 2 * 0.18, 3.2 / 2 * 0.18, 0.0), pos=pos, rot=rot, mass=mass, friction=0.5, restitution=0.0)
-    return body, w.vehicle_create(bike_vehicle_desc(w, body))
+    vd = bike_vehicle_desc(w, body)
+    if desc_edit is not None:
+        desc_edit(vd)
+    return body, w.vehicle_create(vd)
