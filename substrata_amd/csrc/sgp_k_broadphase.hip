@@ -154,19 +154,32 @@ __global__ void __launch_bounds__(TPB) k_bp_cell(DV d)
 		if (bk && binned && tk == tile && k < leader) leader = k;
 	}
 	uint32_t sl = BP_TILE_NONE;
-	if (binned && leader == lane) {
-		uint32_t* entry = &d.tile_slot[tile];
-		sl = __hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (relaxed: the slot NUMBER is all that travels through the entry)
-		for (int tries = 0; tries < (1 << 24) && sl >= BP_TILE_PENDING; ++tries) {
-			const uint32_t old = atomicCAS(entry, BP_TILE_NONE, BP_TILE_PENDING);
-			if (old == BP_TILE_NONE) {
-				sl = atomicAdd(&d.ctr->n_tiles_used, 1u);
+	const bool leads = binned && leader == lane;
+	uint32_t* const entry = &d.tile_slot[leads ? tile : 0u];
+	if (leads) sl = __hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (relaxed: the slot NUMBER is all that travels through the entry)
+	// a tile nobody has asked for yet: whoever turns its entry from NONE to PENDING gives it a slot.  The wave's winners take their slots with ONE atomic on the counter
+	// (round 6: every new tile for itself was 12 k atomics on one address at config 5 -- scattered debris, a wave's 64 bodies in 64 tiles -- and most of the kernel's 48 us)
+	bool won = false;
+	if (leads && sl >= BP_TILE_PENDING) {
+		const uint32_t old = atomicCAS(entry, BP_TILE_NONE, BP_TILE_PENDING);
+		if (old == BP_TILE_NONE) won = true; else sl = old;      // (a slot, or PENDING: somebody else is about to publish one)
+	}
+	{
+		const unsigned long long wm = __ballot(won);
+		if (wm) {
+			uint32_t base = 0;
+			const int first = __ffsll((long long)wm) - 1;
+			if (lane == first) base = atomicAdd(&d.ctr->n_tiles_used, (uint32_t)__popcll(wm));
+			base = (uint32_t)__shfl((int)base, first, 64);
+			if (won) {
+				sl = base + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull));
 				d.tile_of_slot[sl] = tile;
 				__hip_atomic_store(entry, sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			} else if (old != BP_TILE_PENDING) sl = old;
-			else sl = __hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
 		}
 	}
+	// (a lane that waits, waits for a lane of ANOTHER wave: the tiles of this wave's leaders differ, and its winners have published above)
+	if (leads) for (int tries = 0; tries < (1 << 24) && sl >= BP_TILE_PENDING; ++tries) sl = __hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	const uint32_t slot = (uint32_t)__shfl((int)sl, leader, 64);
 	if (binned) {
 		if (slot >= BP_TILE_PENDING) { h = 0xFFFFFFFFu; if (lane == leader) atomicAdd(&d.ctr->pairs_dropped, 1u); }      // (the bounded wait above ran out: not binned this step and counted, never an index)
