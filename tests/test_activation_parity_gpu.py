@@ -183,3 +183,35 @@ def test_a_pile_that_fell_asleep_as_a_whole_wakes_with_its_contacts(oracle, some
                 tw.step(DT)
     tw.close()
 
+
+@pytest.mark.parametrize("somebody_awake", [False, True])
+def test_kept_contacts_of_a_removed_body_do_not_outlive_it(oracle, somebody_awake):
+    """The cache's kept entries are keyed by body slots: the middle box of the sleeping pile is removed and another body is created in its slot, asleep, elsewhere --
+    the entries of the old occupant must go (not alive / created since), on both sides alike; then the rest of the pile is woken and everything is compared bit for bit,
+    events included."""
+    from test_oracle_kat2 import sleeping_pile_scene
+    tw = parity.make_twin(oracle, max_bodies=16)
+    _both(tw, lambda w: w.set_contact_events(True))
+    out = [sleeping_pile_scene(w, somebody_awake) for w in (tw.gpu, tw.cpu)]
+    assert out[0] == out[1]
+    ids = out[0]
+    _both(tw, lambda w: w.remove(ids[1]))
+    new = [dyn(w, pos=(6.0, 0.0, 0.5), activate=0) for w in (tw.gpu, tw.cpu)]
+    assert new[0] == new[1] == ids[1]                                            # the freed slot is handed out again
+    for s in range(3):
+        tw.step(DT)
+        _exact(tw, 8, f"after the swap, step {s}")
+    for w in (tw.gpu, tw.cpu):
+        for k in (abi.EVENT_CONTACT_ADDED, abi.EVENT_CONTACT_PERSISTED):
+            w.drain_events(k)
+    _both(tw, lambda w: (w.activate(ids[2]), w.activate(new[0])))                # the top box falls onto the bottom one; the newcomer wakes where it lies
+    for s in range(240):
+        tw.step(DT)
+        _exact(tw, 8, f"woken, step {s}")
+        for k in (abi.EVENT_CONTACT_ADDED, abi.EVENT_CONTACT_PERSISTED):
+            eg, ec = tw.gpu.drain_events(k), tw.cpu.drain_events(k)
+            assert sorted((int(e["id1"]), int(e["id2"])) for e in eg) == sorted((int(e["id1"]), int(e["id2"])) for e in ec), (s, k)
+        sg, sc = tw.gpu.stats(), tw.cpu.stats()
+        assert (sg.num_manifolds, sg.num_cached_manifolds) == (sc.num_manifolds, sc.num_cached_manifolds), (s, sg.num_manifolds, sc.num_manifolds, sg.num_cached_manifolds, sc.num_cached_manifolds)
+    tw.close()
+
